@@ -1,0 +1,245 @@
+/*
+ * pinot_gpu.h -- C ABI of the MI355X segment scan-filter-aggregate engine.
+ *
+ * This is the drop-in boundary: the entry points a JNI shim inside Pinot's
+ * `PlanMaker.makeSegmentPlanNode` replacement binds to.
+ * Plain C, plain pointers and sizes, no C++/torch types.
+ *
+ * Reference interfaces each entry point replaces (paths under /root/reference,
+ *   core/ = pinot-core/src/main/java/org/apache/pinot/core/,
+ *   segl/ = pinot-segment-local/src/main/java/org/apache/pinot/segment/local/,
+ *   sspi/ = pinot-segment-spi/src/main/java/org/apache/pinot/segment/spi/):
+ *
+ *   pg_init / pg_shutdown      PlanMaker.init(PinotConfiguration)            core/plan/maker/PlanMaker.java:42
+ *   pg_segment_open            ImmutableSegment load: DataSource per column   sspi/datasource/DataSource.java:46-132
+ *                              (ForwardIndexReader + Dictionary + InvertedIndexReader buffers handed over once)
+ *   pg_segment_close           IndexSegment.destroy()                         sspi/IndexSegment.java:142
+ *   pg_execute                 PlanNode.run().nextBlock() of AggregationPlanNode / GroupByPlanNode:
+ *                              core/plan/AggregationPlanNode.java:71-121, core/plan/GroupByPlanNode.java:49-74,
+ *                              core/operator/query/AggregationOperator.java:64-93, GroupByOperator.java:101-140
+ *   pg_filter_bitmap           BaseFilterOperator.nextBlock().getBlockDocIdSet() materialised as a docId bitmap
+ *                              core/operator/filter/BaseFilterOperator.java, core/common/BlockDocIdSet.java:61-67
+ *   pg_read_dict_ids           ForwardIndexReader.readDictIds(int[] docIds, int length, int[] dictIdBuffer, ctx)
+ *                              sspi/index/reader/ForwardIndexReader.java, segl/.../FixedBitSVForwardIndexReaderV2.java:65-99
+ *   pg_read_int_values /       DataFetcher.fetchIntValues / fetchDoubleValues (BlockValSet.getIntValuesSV /
+ *   pg_read_double_values      getDoubleValuesSV)  core/common/DataFetcher.java:111-113,335-386, core/common/BlockValSet.java:65-93
+ *   pg_last_error              exception message carried into BaseCombineOperator.wrapOperatorException
+ *                              core/operator/combine/BaseCombineOperator.java:185-199
+ *
+ * Ownership: the caller owns every pointer inside pg_segment_desc / pg_query; pg_segment_open copies
+ * the index buffers into HBM and never dereferences the host pointers afterwards.  Results are
+ * engine-owned POD, released by pg_result_free.  All functions return a status code and never
+ * throw or abort; pg_last_error() returns the thread-local message of the last failure.
+ * pg_execute is re-entrant per segment handle (concurrent queries on one segment), pg_segment_open /
+ * pg_segment_close must be serialised per segment by the caller (the combine Phaser already does,
+ * core/operator/combine/BaseCombineOperator.java:86-92).
+ */
+#ifndef PINOT_GPU_H
+#define PINOT_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_ABI_VERSION 1
+
+typedef enum pg_status {
+  PG_OK = 0,
+  PG_ERR_INVALID_ARGUMENT = 1,
+  PG_ERR_UNSUPPORTED = 2,      /* query shape not offloadable: caller keeps the CPU plan (decided at plan time) */
+  PG_ERR_DEVICE = 3,           /* HIP runtime error */
+  PG_ERR_OUT_OF_MEMORY = 4,
+  PG_ERR_NOT_INITIALIZED = 5,
+  PG_ERR_INTERNAL = 6
+} pg_status;
+
+/* FieldSpec.DataType stored types supported for fixed-width single-value columns
+ * (pinot-spi/src/main/java/org/apache/pinot/spi/data/FieldSpec.java DataType.getStoredType()). */
+typedef enum pg_data_type {
+  PG_TYPE_INT = 0,
+  PG_TYPE_LONG = 1,
+  PG_TYPE_FLOAT = 2,
+  PG_TYPE_DOUBLE = 3
+} pg_data_type;
+
+/* Forward-index encodings (segl/segment/index/forward/ForwardIndexReaderFactory.java:75-117). */
+typedef enum pg_fwd_encoding {
+  PG_FWD_FIXED_BIT_DICT = 0,   /* FixedBitSVForwardIndexReaderV2: big-endian MSB-first bit-packed dictIds, no header */
+  PG_FWD_RAW_FIXED_BYTE = 1    /* FixedByteChunkSVForwardIndexReader, PASS_THROUGH: chunk header + big-endian values */
+} pg_fwd_encoding;
+
+typedef struct pg_config {
+  int32_t abi_version;         /* must be PG_ABI_VERSION */
+  int32_t device_id;           /* default HIP device for segments whose desc says device_id = -1 */
+  int32_t blocks_per_cu;       /* 0 = engine default; launch geometry knob for tuning */
+  int32_t flags;               /* PG_CFG_* */
+} pg_config;
+
+#define PG_CFG_TIME_KERNELS 1  /* bracket kernels with HIP events on the launch stream; report pg_result.device_ms */
+
+typedef struct pg_column_desc {
+  const char* name;
+  int32_t stored_type;         /* pg_data_type of the column values (dictionary values or raw values) */
+  int32_t fwd_encoding;        /* pg_fwd_encoding */
+  int32_t bits_per_value;      /* FIXED_BIT_DICT: PinotDataBitSet.getNumBitsPerValue(cardinality - 1) */
+  int32_t cardinality;         /* dictionary length (0 for raw columns) */
+  const void* fwd_data;        /* whole forward-index buffer exactly as on disk */
+  uint64_t fwd_size;
+  const void* dict_data;       /* sorted dictionary, big-endian fixed-width values, no header (NULL for raw) */
+  uint64_t dict_size;
+  const void* inv_data;        /* optional bitmap inverted index (BitmapInvertedIndexWriter layout) or NULL */
+  uint64_t inv_size;
+} pg_column_desc;
+
+typedef struct pg_segment_desc {
+  const char* name;
+  uint64_t crc;
+  int32_t num_docs;
+  int32_t num_columns;
+  const pg_column_desc* columns;
+  int32_t device_id;           /* -1 = pg_config.device_id */
+  int32_t reserved;
+} pg_segment_desc;
+
+typedef struct pg_segment pg_segment;   /* opaque, HBM-resident segment */
+
+/* ---- query description: the filter is already lowered the way the reference's PredicateEvaluators
+ * lower it (dictionary binary search happens on the caller side or in the host mirror). ---- */
+
+typedef enum pg_predicate_kind {
+  PG_PRED_MATCH_ALL = 0,       /* predicateEvaluator.isAlwaysTrue()  -> MatchAllFilterOperator */
+  PG_PRED_MATCH_NONE = 1,      /* predicateEvaluator.isAlwaysFalse() -> EmptyFilterOperator */
+  PG_PRED_DICT_RANGE = 2,      /* SortedDictionaryBasedRangePredicateEvaluator.applySV: lo <= dictId < hi; EQ is [d, d+1) */
+  PG_PRED_DICT_SET = 3,        /* DictionaryBasedInPredicateEvaluator.applySV: bit dictId of set_words is set */
+  PG_PRED_RAW_RANGE = 4        /* IntRawValueBasedRangePredicateEvaluator.applySV: lo <= value <= hi (both inclusive) */
+} pg_predicate_kind;
+
+typedef enum pg_leaf_eval {
+  PG_EVAL_SCAN = 0,            /* ScanBasedFilterOperator */
+  PG_EVAL_INVERTED = 1         /* InvertedIndexFilterOperator: OR of the postings of the matching dictIds */
+} pg_leaf_eval;
+
+typedef struct pg_predicate {
+  int32_t kind;                /* pg_predicate_kind */
+  int32_t column;              /* index into pg_segment_desc.columns */
+  int32_t eval;                /* pg_leaf_eval */
+  int32_t exclusive;           /* 1 = NOT_EQ / NOT_IN: matches when the inner predicate does not */
+  int64_t lo;                  /* DICT_RANGE: startDictId ; RAW_RANGE: inclusive lower bound */
+  int64_t hi;                  /* DICT_RANGE: endDictId (exclusive) ; RAW_RANGE: inclusive upper bound */
+  const uint32_t* set_words;   /* DICT_SET: bitset over dictIds, bit d = (set_words[d >> 5] >> (d & 31)) & 1 */
+  int32_t num_set_words;
+  int32_t reserved;
+} pg_predicate;
+
+typedef enum pg_filter_op {
+  PG_FILTER_LEAF = 0,
+  PG_FILTER_AND = 1,
+  PG_FILTER_OR = 2,
+  PG_FILTER_NOT = 3
+} pg_filter_op;
+
+/* Filter tree flattened in postfix order (children before parent). */
+typedef struct pg_filter_node {
+  int32_t op;                  /* pg_filter_op */
+  int32_t predicate;           /* LEAF: index into pg_query.predicates */
+  int32_t num_children;        /* AND / OR: operand count (>= 2); NOT: 1 */
+  int32_t reserved;
+} pg_filter_node;
+
+typedef enum pg_agg_function {
+  PG_AGG_COUNT = 0,            /* core/query/aggregation/function/CountAggregationFunction.java */
+  PG_AGG_SUM = 1,              /* SumAggregationFunction.java */
+  PG_AGG_MIN = 2,              /* MinAggregationFunction.java */
+  PG_AGG_MAX = 3,              /* MaxAggregationFunction.java */
+  PG_AGG_AVG = 4               /* AvgAggregationFunction.java (AvgPair = sum, count) */
+} pg_agg_function;
+
+typedef struct pg_aggregation {
+  int32_t function;            /* pg_agg_function */
+  int32_t column;              /* -1 for COUNT(*) */
+} pg_aggregation;
+
+typedef struct pg_query {
+  const pg_filter_node* filter;      /* NULL / 0 nodes = match all */
+  int32_t num_filter_nodes;
+  int32_t num_predicates;
+  const pg_predicate* predicates;
+  const pg_aggregation* aggregations;
+  int32_t num_aggregations;
+  int32_t num_group_by;              /* 0 = aggregation only */
+  const int32_t* group_by_columns;   /* dictionary-encoded columns; group id = sum dictId_j * prod_{k<j} card_k */
+  int32_t num_groups_limit;          /* InstancePlanMakerImplV2 numGroupsLimit (default 100000); 0 = default */
+  int32_t flags;                     /* PG_QUERY_* */
+} pg_query;
+
+#define PG_QUERY_DEFAULT 0
+
+/* Intermediate result of one aggregation function, in the reference's holder types:
+ * SUM/MIN/MAX -> Double, COUNT -> Long, AVG -> AvgPair(sum, count). */
+typedef struct pg_agg_value {
+  int64_t count;               /* COUNT result / AVG count / number of aggregated docs */
+  double sum;                  /* SUM / AVG sum as the reference's double holder value */
+  int64_t sum_i64;             /* exact integer sum for INT/LONG sources (valid when sum_exact != 0) */
+  int32_t sum_exact;
+  int32_t reserved;
+  double min;                  /* +inf when no doc matched (MinAggregationFunction.DEFAULT_VALUE) */
+  double max;                  /* -inf when no doc matched */
+} pg_agg_value;
+
+/* ExecutionStatistics (core/operator/ExecutionStatistics.java:25-64). */
+typedef struct pg_stats {
+  int64_t num_docs_scanned;
+  int64_t num_entries_scanned_in_filter;
+  int64_t num_entries_scanned_post_filter;
+  int64_t num_total_docs;
+} pg_stats;
+
+typedef struct pg_result {
+  pg_stats stats;
+  int32_t num_aggregations;
+  int32_t num_groups;              /* group-by: number of groups present (ArrayBasedHolder flags set) */
+  pg_agg_value* aggregations;      /* [num_aggregations], aggregation-only queries */
+  int32_t* group_ids;              /* [num_groups] ascending raw group ids (DictionaryBasedGroupKeyGenerator.java:306-324) */
+  pg_agg_value* group_aggregations;/* [num_groups * num_aggregations], row-major by group */
+  int32_t group_id_upper_bound;    /* product of group-by cardinalities */
+  int32_t reserved;
+  double device_ms;                /* HIP-event time of this query's kernels (PG_CFG_TIME_KERNELS), else 0 */
+  double dominant_kernel_ms;       /* HIP-event time of the scan kernel alone */
+  void* internal;
+} pg_result;
+
+pg_status pg_init(const pg_config* config);
+pg_status pg_shutdown(void);
+const char* pg_last_error(void);
+const char* pg_version(void);
+/* Fills name (e.g. "gfx950"), CU count, HBM bytes of the configured device. */
+pg_status pg_device_info(int32_t device_id, char* arch_name, int32_t arch_name_len, int32_t* num_cus,
+                         uint64_t* hbm_bytes);
+
+pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment);
+pg_status pg_segment_close(pg_segment* segment);
+pg_status pg_segment_num_docs(const pg_segment* segment, int32_t* out_num_docs);
+pg_status pg_segment_device_bytes(const pg_segment* segment, uint64_t* out_bytes);
+
+pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_result);
+void pg_result_free(pg_result* result);
+
+/* Evaluates only the filter and returns the matching docIds as a dense bitmap:
+ * bit (docId & 63) of out_words[docId >> 6]; num_words >= ceil(num_docs / 64).  out_cardinality may be NULL. */
+pg_status pg_filter_bitmap(pg_segment* segment, const pg_query* query, uint64_t* out_words, int64_t num_words,
+                           int64_t* out_cardinality);
+
+/* BlockValSet-level SPI (ProjectionOperatorUtils hook): arbitrary ascending docIds, length <= any. */
+pg_status pg_read_dict_ids(pg_segment* segment, int32_t column, const int32_t* doc_ids, int32_t length,
+                           int32_t* out_dict_ids);
+pg_status pg_read_int_values(pg_segment* segment, int32_t column, const int32_t* doc_ids, int32_t length,
+                             int32_t* out_values);
+pg_status pg_read_double_values(pg_segment* segment, int32_t column, const int32_t* doc_ids, int32_t length,
+                                double* out_values);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINOT_GPU_H */

@@ -1,0 +1,174 @@
+"""ctypes binding of oracle/_build/libpinot_oracle.so (the CPU restatement of the reference path).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+It consumes the same `pg_segment_desc` / `pg_query` PODs as the engine so one query description drives both.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pinot_amd import _abi
+from pinot_amd.query import Result
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_DIR, "_build", "libpinot_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_DIR, "pinot_oracle.c")
+    hdr = os.path.join(_DIR, "..", "include", "pinot_gpu.h")
+    stale = (not os.path.exists(_LIB)) or os.path.getmtime(_LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _DIR, "-s"])
+    return _LIB
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    lib = C.CDLL(_LIB)
+    P = C.POINTER
+    u8p, i32p = P(C.c_uint8), P(C.c_int32)
+    sigs = {
+        "po_last_error": (C.c_char_p, []),
+        "po_num_bits_per_value": (C.c_int, [C.c_int32]),
+        "po_bitset_read_int": (C.c_int32, [u8p, C.c_int64, C.c_int]),
+        "po_bitset_write_int": (None, [u8p, C.c_int64, C.c_int, C.c_int32]),
+        "po_fixedbit_file_size": (C.c_int64, [C.c_int64, C.c_int]),
+        "po_fixedbit_write": (None, [u8p, i32p, C.c_int64, C.c_int]),
+        "po_fixedbit_read_dict_ids": (None, [u8p, C.c_int, C.c_int32, i32p, C.c_int32, i32p]),
+        "po_raw_file_size_v2": (C.c_int64, [C.c_int32, C.c_int32]),
+        "po_raw_write_int_v2": (None, [u8p, i32p, C.c_int32, C.c_int32]),
+        "po_dict_get_int": (C.c_int32, [u8p, C.c_int32]),
+        "po_dict_insertion_index_of_int": (C.c_int32, [u8p, C.c_int32, C.c_int32]),
+        "po_dict_index_of_int": (C.c_int32, [u8p, C.c_int32, C.c_int32]),
+        "po_dict_write_int": (None, [u8p, i32p, C.c_int32]),
+        "po_lower_range_int": (None, [u8p, C.c_int32, C.c_int, C.c_int32, C.c_int, C.c_int, C.c_int32, C.c_int, i32p, i32p]),
+        "po_roaring_or_into": (C.c_int64, [u8p, C.c_uint64, P(C.c_uint64), C.c_int64]),
+        "po_roaring_serialize": (C.c_int64, [i32p, C.c_int64, C.c_int, u8p]),
+        "po_inverted_build": (C.c_int64, [i32p, C.c_int32, C.c_int32, C.c_int, u8p]),
+        "po_execute": (C.c_int, [P(_abi.pg_segment_desc), P(_abi.pg_query), P(_abi.pg_result)]),
+        "po_result_free": (None, [P(_abi.pg_result)]),
+        "po_filter_bitmap": (C.c_int, [P(_abi.pg_segment_desc), P(_abi.pg_query), P(C.c_uint64), C.c_int64, P(C.c_int64)]),
+        "po_read_int_values": (C.c_int, [P(_abi.pg_segment_desc), C.c_int32, i32p, C.c_int32, i32p]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _u8p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _i32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise OracleError("oracle rc=%d: %s" % (rc, (load().po_last_error() or b"").decode()))
+
+
+def execute(segment_data, spec):
+    lib = load()
+    res = _abi.pg_result()
+    _check(lib.po_execute(C.byref(segment_data.desc), C.byref(spec.c), C.byref(res)))
+    try:
+        return Result(res, spec)
+    finally:
+        lib.po_result_free(C.byref(res))
+
+
+def execute_raw(segment_data, spec, res):
+    return load().po_execute(C.byref(segment_data.desc), C.byref(spec.c), C.byref(res))
+
+
+def filter_bitmap(segment_data, spec):
+    lib = load()
+    words = np.zeros((segment_data.num_docs + 63) // 64, dtype=np.uint64)
+    card = C.c_int64()
+    _check(lib.po_filter_bitmap(C.byref(segment_data.desc), C.byref(spec.c), words.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                int(words.shape[0]), C.byref(card)))
+    return words, int(card.value)
+
+
+def read_int_values(segment_data, column, doc_ids):
+    doc_ids = np.ascontiguousarray(doc_ids, dtype=np.int32)
+    out = np.zeros(doc_ids.shape[0], dtype=np.int32)
+    _check(load().po_read_int_values(C.byref(segment_data.desc), column, _i32p(doc_ids), int(doc_ids.shape[0]), _i32p(out)))
+    return out
+
+
+def read_dict_ids(fwd, bits, num_docs, doc_ids):
+    doc_ids = np.ascontiguousarray(doc_ids, dtype=np.int32)
+    out = np.zeros(doc_ids.shape[0], dtype=np.int32)
+    # the reference's readUnchecked may read up to 7 bytes past a value that is not one of the last two: pad
+    padded = np.concatenate([fwd, np.zeros(8, dtype=np.uint8)])
+    load().po_fixedbit_read_dict_ids(_u8p(padded), bits, num_docs, _i32p(doc_ids), int(doc_ids.shape[0]), _i32p(out))
+    return out
+
+
+def fixedbit_write(dict_ids, bits):
+    lib = load()
+    dict_ids = np.ascontiguousarray(dict_ids, dtype=np.int32)
+    out = np.zeros(int(lib.po_fixedbit_file_size(int(dict_ids.shape[0]), bits)), dtype=np.uint8)
+    lib.po_fixedbit_write(_u8p(out), _i32p(dict_ids), int(dict_ids.shape[0]), bits)
+    return out
+
+
+def dict_write(sorted_values):
+    v = np.ascontiguousarray(sorted_values, dtype=np.int32)
+    out = np.zeros(v.shape[0] * 4, dtype=np.uint8)
+    load().po_dict_write_int(_u8p(out), _i32p(v), int(v.shape[0]))
+    return out
+
+
+def raw_write(values, docs_per_chunk=1000):
+    lib = load()
+    v = np.ascontiguousarray(values, dtype=np.int32)
+    out = np.zeros(int(lib.po_raw_file_size_v2(int(v.shape[0]), docs_per_chunk)), dtype=np.uint8)
+    lib.po_raw_write_int_v2(_u8p(out), _i32p(v), int(v.shape[0]), docs_per_chunk)
+    return out
+
+
+def inverted_build(dict_ids, cardinality, run_optimize=True):
+    lib = load()
+    d = np.ascontiguousarray(dict_ids, dtype=np.int32)
+    size = int(lib.po_inverted_build(_i32p(d), int(d.shape[0]), cardinality, int(run_optimize), None))
+    out = np.zeros(size, dtype=np.uint8)
+    lib.po_inverted_build(_i32p(d), int(d.shape[0]), cardinality, int(run_optimize), _u8p(out))
+    return out
+
+
+def lower_range(dictionary_bytes, cardinality, lower=None, upper=None, lower_inclusive=True, upper_inclusive=True):
+    """SortedDictionaryBasedRangePredicateEvaluator bounds -> (startDictId, endDictId)."""
+    s, e = C.c_int32(), C.c_int32()
+    load().po_lower_range_int(_u8p(dictionary_bytes), cardinality, int(lower is not None), int(lower or 0), int(lower_inclusive),
+                              int(upper is not None), int(upper or 0), int(upper_inclusive), C.byref(s), C.byref(e))
+    return int(s.value), int(e.value)
+
+
+def index_of(dictionary_bytes, cardinality, value):
+    return int(load().po_dict_index_of_int(_u8p(dictionary_bytes), cardinality, int(value)))
+
+
+def roaring_to_words(data, num_words):
+    words = np.zeros(num_words, dtype=np.uint64)
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    card = load().po_roaring_or_into(_u8p(data), int(data.shape[0]), words.ctypes.data_as(C.POINTER(C.c_uint64)), num_words)
+    if card < 0:
+        raise OracleError((load().po_last_error() or b"").decode())
+    return words, int(card)

@@ -1,0 +1,973 @@
+/*
+ * pinot_oracle.c -- CPU restatement of the reference's per-segment scan -> filter -> aggregate path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under pinot_amd/ may include, link, load or call this file; it is
+ * used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker / CPU baseline.
+ *
+ * The reference (y-scope/pinot, Java) cannot be compiled in this environment (no JDK), so this file
+ * restates the algorithms, function by function, each citing the reference file:line it follows.
+ * Paths are under /root/reference with
+ *   segl/ = pinot-segment-local/src/main/java/org/apache/pinot/segment/local/
+ *   core/ = pinot-core/src/main/java/org/apache/pinot/core/
+ *   sspi/ = pinot-segment-spi/src/main/java/org/apache/pinot/segment/spi/
+ *
+ * Parity pins: query-level results are pinned by the reference's own golden vectors over
+ * test_data-sv.avro (tests/golden/, InnerSegmentAggregationSingleValueQueriesTest.java:44-112) and the raw
+ * chunk layout by fixedByteRaw-style headers; the fixed-bit byte layout is pinned by the writer source only
+ * (the reference's tests are unseeded round trips), with known-answer bytes derived from
+ * PinotDataBitSet.writeInt in tests/test_oracle_layouts.py.  RoaringBitmap (third-party
+ * org.roaringbitmap:RoaringBitmap:1.3.0, not under /root/reference) follows the public RoaringFormatSpec:
+ * serialized-byte parity is "unpinned", set semantics are pinned through the golden queries.
+ *
+ * The structure deliberately mirrors the JVM path so that timing it is a fair "port" CPU baseline:
+ * 256-doc scan batches (BlockDocIdIterator.OPTIMAL_ITERATOR_BATCH_SIZE), 10 000-doc projection blocks
+ * (DocIdSetPlanNode.MAX_DOC_PER_CALL), double result holders, one segment per thread.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/pinot_gpu.h"
+
+#define PO_SCAN_BATCH 256      /* core/common/BlockDocIdIterator.java:49 */
+#define PO_MAX_DOC_PER_CALL 10000 /* core/plan/DocIdSetPlanNode.java:29 */
+#define PO_EOF (-1)            /* segl Constants.EOF is Integer.MIN_VALUE in the reference; any negative works here */
+
+static __thread char po_error[512];
+const char* po_last_error(void) { return po_error; }
+#define PO_FAIL(code, ...) do { snprintf(po_error, sizeof(po_error), __VA_ARGS__); return (code); } while (0)
+
+/* ------------------------------------------------------------------------------------------------
+ * PinotDataBuffer big-endian accessors (sspi/memory/PinotDataBuffer.java:375-444; files are BIG_ENDIAN,
+ * segl/io/writer/impl/FixedBitSVForwardIndexWriter.java:43-44)
+ * ---------------------------------------------------------------------------------------------- */
+static inline int32_t be_get_int(const uint8_t* p) {
+  return (int32_t)(((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]);
+}
+static inline int64_t be_get_long(const uint8_t* p) {
+  return (int64_t)(((uint64_t)(uint32_t)be_get_int(p) << 32) | (uint64_t)(uint32_t)be_get_int(p + 4));
+}
+static inline void be_put_int(uint8_t* p, int32_t v) {
+  p[0] = (uint8_t)((uint32_t)v >> 24); p[1] = (uint8_t)((uint32_t)v >> 16); p[2] = (uint8_t)((uint32_t)v >> 8); p[3] = (uint8_t)v;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * PinotDataBitSet (segl/io/util/PinotDataBitSet.java)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* getNumBitsPerValue, PinotDataBitSet.java:61-72 (FIRST_BIT_SET[v] = index from the MSB of the first set bit). */
+int po_num_bits_per_value(int32_t max_value) {
+  if (max_value <= 1) return 1;
+  int num_bits = 8;
+  uint32_t v = (uint32_t)max_value;
+  while (v > 0xFF) { v >>= 8; num_bits += 8; }
+  int first_bit_set = 0;
+  while (!(v & (0x80u >> first_bit_set))) first_bit_set++;
+  return num_bits - first_bit_set;
+}
+
+/* readInt(index, numBitsPerValue), PinotDataBitSet.java:80-104 -- byte-exact, never reads past the value. */
+int32_t po_bitset_read_int(const uint8_t* buf, int64_t index, int num_bits) {
+  int64_t bit_offset = index * num_bits;
+  int64_t byte_offset = bit_offset / 8;
+  int bit_offset_in_first_byte = (int)(bit_offset % 8);
+  int32_t current = buf[byte_offset] & (0xFF >> bit_offset_in_first_byte);
+  int num_bits_left = num_bits - (8 - bit_offset_in_first_byte);
+  if (num_bits_left <= 0) {
+    return (int32_t)((uint32_t)current >> -num_bits_left);
+  }
+  while (num_bits_left > 8) {
+    byte_offset++;
+    current = (int32_t)(((uint32_t)current << 8) | buf[byte_offset]);
+    num_bits_left -= 8;
+  }
+  return (int32_t)(((uint32_t)current << num_bits_left) | ((uint32_t)buf[byte_offset + 1] >> (8 - num_bits_left)));
+}
+
+/* writeInt(index, numBitsPerValue, value), PinotDataBitSet.java:143-170 -- the layout authority. */
+void po_bitset_write_int(uint8_t* buf, int64_t index, int num_bits, int32_t value) {
+  int64_t bit_offset = index * num_bits;
+  int64_t byte_offset = bit_offset / 8;
+  int bit_offset_in_first_byte = (int)(bit_offset % 8);
+  int first_byte = buf[byte_offset];
+  int first_byte_mask = 0xFF >> bit_offset_in_first_byte;
+  int num_bits_left = num_bits - (8 - bit_offset_in_first_byte);
+  if (num_bits_left <= 0) {
+    first_byte_mask &= 0xFF << -num_bits_left;
+    buf[byte_offset] = (uint8_t)((first_byte & ~first_byte_mask) | (value << -num_bits_left));
+  } else {
+    buf[byte_offset] = (uint8_t)((first_byte & ~first_byte_mask) | (((uint32_t)value >> num_bits_left) & first_byte_mask));
+    while (num_bits_left > 8) {
+      num_bits_left -= 8;
+      byte_offset++;
+      buf[byte_offset] = (uint8_t)(value >> num_bits_left);
+    }
+    byte_offset++;
+    int last_byte = buf[byte_offset];
+    buf[byte_offset] = (uint8_t)((last_byte & (0xFF >> num_bits_left)) | (value << (8 - num_bits_left)));
+  }
+}
+
+/* FixedBitSVForwardIndexWriter (segl/io/writer/impl/FixedBitSVForwardIndexWriter.java:39-50): file length
+ * ceil(numDocs * bits / 8), values written one by one through writeInt.  buf must be zero-initialised. */
+int64_t po_fixedbit_file_size(int64_t num_docs, int num_bits) { return (num_docs * num_bits + 7) / 8; }
+void po_fixedbit_write(uint8_t* buf, const int32_t* dict_ids, int64_t num_docs, int num_bits) {
+  for (int64_t i = 0; i < num_docs; i++) po_bitset_write_int(buf, i, num_bits, dict_ids[i]);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * FixedBitIntReader (segl/io/reader/impl/FixedBitIntReader.java): the reference hand-unrolls 31 classes;
+ * all of them compute the closed form below (checked against Bit17Reader
+ * :1268-1337).  read() is the bounded variant (byte-exact); readUnchecked() does one wide big-endian
+ * load at floor(i*b/8) and may touch up to 7 bytes past the value; read32() decodes 32 values from b ints.
+ * ---------------------------------------------------------------------------------------------- */
+static inline int32_t fixedbit_read(const uint8_t* buf, int64_t index, int num_bits) {
+  return po_bitset_read_int(buf, index, num_bits);
+}
+static inline int32_t fixedbit_read_unchecked(const uint8_t* buf, int64_t index, int num_bits) {
+  int64_t bit_offset = index * num_bits;
+  const uint8_t* p = buf + (bit_offset >> 3);
+  int bit_off = (int)(bit_offset & 7);
+  uint32_t mask = (num_bits == 32) ? 0xFFFFFFFFu : ((1u << num_bits) - 1u);
+  if (bit_off + num_bits <= 32) {
+    /* e.g. Bit17Reader.readUnchecked :1278-1283: (getInt(off) >>> (15 - bitOff)) & 0x1ffff */
+    return (int32_t)(((uint32_t)be_get_int(p) >> (32 - bit_off - num_bits)) & mask);
+  }
+  /* wider than an int window: the reference switches to getLong (e.g. Bit31Reader) */
+  return (int32_t)(((uint64_t)be_get_long(p) >> (64 - bit_off - num_bits)) & mask);
+}
+static void fixedbit_read32(const uint8_t* buf, int64_t index, int num_bits, int32_t* out) {
+  /* read32(index,...): offset = (index >>> 3) * b, loads b big-endian ints, emits 32 values
+   * (FixedBitIntReader.java:1285-1337 for b = 17). */
+  const uint8_t* p = buf + (index >> 3) * num_bits;
+  uint32_t w[32];
+  for (int j = 0; j < num_bits; j++) w[j] = (uint32_t)be_get_int(p + 4 * j);
+  uint32_t mask = (1u << num_bits) - 1u;
+  for (int k = 0; k < 32; k++) {
+    int bit = k * num_bits;
+    int j = bit >> 5, s = bit & 31;
+    if (s + num_bits <= 32) {
+      out[k] = (int32_t)((w[j] >> (32 - s - num_bits)) & mask);
+    } else {
+      int lo_bits = s + num_bits - 32;
+      out[k] = (int32_t)(((w[j] << lo_bits) | (w[j + 1] >> (32 - lo_bits))) & mask);
+    }
+  }
+}
+
+/* FixedBitSVForwardIndexReaderV2.readDictIds (segl/segment/index/readers/forward/FixedBitSVForwardIndexReaderV2.java:65-99) */
+void po_fixedbit_read_dict_ids(const uint8_t* buf, int num_bits, int32_t num_docs, const int32_t* doc_ids,
+                               int32_t length, int32_t* dict_id_buffer) {
+  if (length <= 0) return;
+  int32_t first_doc_id = doc_ids[0];
+  int32_t last_doc_id = doc_ids[length - 1];
+  int32_t index = 0;
+  /* Use bulk read if the doc ids are sequential */
+  if (last_doc_id - first_doc_id + 1 == length && length >= 64) {
+    int32_t bulk_start = (first_doc_id + 31) & (int32_t)0xffffffe0;
+    int32_t bulk_end = last_doc_id & (int32_t)0xffffffe0;
+    for (int32_t i = first_doc_id; i < bulk_start; i++) dict_id_buffer[index++] = fixedbit_read_unchecked(buf, i, num_bits);
+    for (int32_t i = bulk_start; i < bulk_end; i += 32) {
+      fixedbit_read32(buf, i, num_bits, dict_id_buffer + index);
+      index += 32;
+    }
+  }
+  /* Process the remaining docs */
+  if (last_doc_id < num_docs - 2) {
+    for (int32_t i = index; i < length; i++) dict_id_buffer[i] = fixedbit_read_unchecked(buf, doc_ids[i], num_bits);
+  } else {
+    dict_id_buffer[length - 1] = fixedbit_read(buf, last_doc_id, num_bits);
+    int32_t unchecked_end = length - 2;
+    if (unchecked_end >= index) {
+      dict_id_buffer[unchecked_end] = fixedbit_read(buf, doc_ids[unchecked_end], num_bits);
+      for (int32_t i = index; i < unchecked_end; i++) dict_id_buffer[i] = fixedbit_read_unchecked(buf, doc_ids[i], num_bits);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Raw fixed-byte chunk forward index, PASS_THROUGH (segl/segment/index/readers/forward/
+ * BaseChunkForwardIndexReader.java:61-111, FixedByteChunkSVForwardIndexReader.java:53-61; writer
+ * segl/io/writer/impl/BaseChunkForwardIndexWriter.java:130-163).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct po_raw_reader {
+  int32_t version, num_chunks, num_docs_per_chunk, length_of_longest_entry, total_docs, compression_type;
+  int32_t data_header_start, raw_data_start;
+  const uint8_t* raw_data;
+} po_raw_reader;
+
+int po_raw_open(const uint8_t* buf, uint64_t size, po_raw_reader* r) {
+  if (size < 16) PO_FAIL(1, "raw forward index too small");
+  int off = 0;
+  r->version = be_get_int(buf + off); off += 4;
+  r->num_chunks = be_get_int(buf + off); off += 4;
+  r->num_docs_per_chunk = be_get_int(buf + off); off += 4;
+  r->length_of_longest_entry = be_get_int(buf + off); off += 4;
+  int data_header_start = off;
+  r->total_docs = -1;
+  r->compression_type = 2; /* SNAPPY for version 1 */
+  if (r->version > 1) {
+    r->total_docs = be_get_int(buf + off); off += 4;
+    r->compression_type = be_get_int(buf + off); off += 4;
+    data_header_start = be_get_int(buf + off);
+  }
+  int entry = r->version <= 2 ? 4 : 8;
+  r->data_header_start = data_header_start;
+  r->raw_data_start = data_header_start + r->num_chunks * entry;
+  r->raw_data = buf + r->raw_data_start;
+  if (r->compression_type != 0) PO_FAIL(2, "only PASS_THROUGH raw chunks are in scope (compressionType=%d)", r->compression_type);
+  return 0;
+}
+static inline int32_t raw_get_int(const po_raw_reader* r, int32_t doc_id) { return be_get_int(r->raw_data + (int64_t)doc_id * 4); }
+
+/* Writer restatement: version 2 header, 4-byte chunk offsets, PASS_THROUGH (value 0). Returns total size. */
+int64_t po_raw_file_size_v2(int32_t num_docs, int32_t num_docs_per_chunk) {
+  int64_t num_chunks = ((int64_t)num_docs + num_docs_per_chunk - 1) / num_docs_per_chunk;
+  return 7 * 4 + num_chunks * 4 + (int64_t)num_docs * 4;
+}
+void po_raw_write_int_v2(uint8_t* buf, const int32_t* values, int32_t num_docs, int32_t num_docs_per_chunk) {
+  int32_t num_chunks = (int32_t)(((int64_t)num_docs + num_docs_per_chunk - 1) / num_docs_per_chunk);
+  int32_t header_size = 7 * 4 + num_chunks * 4;
+  be_put_int(buf + 0, 2);
+  be_put_int(buf + 4, num_chunks);
+  be_put_int(buf + 8, num_docs_per_chunk);
+  be_put_int(buf + 12, 4);
+  be_put_int(buf + 16, num_docs);
+  be_put_int(buf + 20, 0);   /* PASS_THROUGH */
+  be_put_int(buf + 24, 28);  /* dataHeaderStart */
+  for (int32_t c = 0; c < num_chunks; c++) be_put_int(buf + 28 + 4 * c, header_size + c * num_docs_per_chunk * 4);
+  for (int32_t i = 0; i < num_docs; i++) be_put_int(buf + header_size + (int64_t)i * 4, values[i]);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * IntDictionary / BaseImmutableDictionary (segl/segment/index/readers/IntDictionary.java:38-70,
+ * BaseImmutableDictionary.java:124-140; value access FixedByteValueReaderWriter.java:37-38)
+ * ---------------------------------------------------------------------------------------------- */
+static inline int32_t dict_get_int(const uint8_t* dict, int32_t dict_id) { return be_get_int(dict + (int64_t)dict_id * 4); }
+int32_t po_dict_get_int(const uint8_t* dict, int32_t dict_id) { return dict_get_int(dict, dict_id); }
+
+/* binarySearch(int value): returns index, or -(insertionPoint + 1) when absent. */
+int32_t po_dict_insertion_index_of_int(const uint8_t* dict, int32_t length, int32_t value) {
+  int32_t low = 0, high = length - 1;
+  while (low <= high) {
+    int32_t mid = (int32_t)(((uint32_t)low + (uint32_t)high) >> 1);
+    int32_t mid_value = dict_get_int(dict, mid);
+    if (mid_value < value) low = mid + 1;
+    else if (mid_value > value) high = mid - 1;
+    else return mid;
+  }
+  return -(low + 1);
+}
+/* indexOf -> normalizeIndex, BaseImmutableDictionary.java:73-80 */
+int32_t po_dict_index_of_int(const uint8_t* dict, int32_t length, int32_t value) {
+  int32_t idx = po_dict_insertion_index_of_int(dict, length, value);
+  return idx >= 0 ? idx : -1;
+}
+void po_dict_write_int(uint8_t* buf, const int32_t* sorted_values, int32_t length) {
+  /* SegmentDictionaryCreator.java:109-125: C x big-endian int32, ascending, no header */
+  for (int32_t i = 0; i < length; i++) be_put_int(buf + (int64_t)i * 4, sorted_values[i]);
+}
+
+/* SortedDictionaryBasedRangePredicateEvaluator ctor (core/operator/filter/predicate/
+ * RangePredicateEvaluatorFactory.java:126-169): bounds -> [startDictId, endDictId). */
+void po_lower_range_int(const uint8_t* dict, int32_t length, int has_lower, int32_t lower, int lower_inclusive,
+                        int has_upper, int32_t upper, int upper_inclusive, int32_t* out_start, int32_t* out_end) {
+  int32_t start, end;
+  if (!has_lower) {
+    start = 0;
+  } else {
+    int32_t ins = po_dict_insertion_index_of_int(dict, length, lower);
+    if (ins < 0) start = -(ins + 1);
+    else start = lower_inclusive ? ins : ins + 1;
+  }
+  if (!has_upper) {
+    end = length;
+  } else {
+    int32_t ins = po_dict_insertion_index_of_int(dict, length, upper);
+    if (ins < 0) end = -(ins + 1);
+    else end = upper_inclusive ? ins + 1 : ins;
+  }
+  *out_start = start;
+  *out_end = end;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * RoaringBitmap portable serialization (third-party; public RoaringFormatSpec).  Call sites in the
+ * reference: BitmapInvertedIndexReader.java:57 (deserialize view), BitmapInvertedIndexWriter.java:90-96.
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static inline uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static inline void put_le16(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+static inline void put_le32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+
+#define ROARING_COOKIE_NO_RUN 12346u
+#define ROARING_COOKIE_RUN 12347u
+#define ROARING_NO_OFFSET_THRESHOLD 4
+
+/* ORs the serialized bitmap into a dense bitmap (bit d&63 of words[d>>6]); returns cardinality or -1. */
+int64_t po_roaring_or_into(const uint8_t* data, uint64_t size, uint64_t* words, int64_t num_words) {
+  if (size < 8) { snprintf(po_error, sizeof(po_error), "roaring: truncated"); return -1; }
+  uint32_t cookie = le32(data);
+  uint32_t n;
+  const uint8_t* run_flags = NULL;
+  uint64_t pos;
+  int has_run = 0;
+  if ((cookie & 0xFFFF) == ROARING_COOKIE_RUN) {
+    has_run = 1;
+    n = (cookie >> 16) + 1;
+    run_flags = data + 4;
+    pos = 4 + (n + 7) / 8;
+  } else if (cookie == ROARING_COOKIE_NO_RUN) {
+    n = le32(data + 4);
+    pos = 8;
+  } else { snprintf(po_error, sizeof(po_error), "roaring: bad cookie %u", cookie); return -1; }
+  const uint8_t* desc = data + pos;
+  pos += (uint64_t)n * 4;
+  if (!has_run || n >= ROARING_NO_OFFSET_THRESHOLD) pos += (uint64_t)n * 4; /* offset header (not needed: containers are sequential) */
+  int64_t total = 0;
+  for (uint32_t c = 0; c < n; c++) {
+    uint32_t key = le16(desc + 4 * c);
+    uint32_t card = (uint32_t)le16(desc + 4 * c + 2) + 1;
+    int64_t base_word = (int64_t)key * 1024;
+    int is_run = has_run && ((run_flags[c >> 3] >> (c & 7)) & 1);
+    if (is_run) {
+      uint32_t num_runs = le16(data + pos); pos += 2;
+      for (uint32_t r = 0; r < num_runs; r++) {
+        uint32_t start = le16(data + pos), len = le16(data + pos + 2); pos += 4;
+        for (uint32_t v = start; v <= start + len; v++) {
+          int64_t w = base_word + (v >> 6);
+          if (w >= num_words) { snprintf(po_error, sizeof(po_error), "roaring: value out of range"); return -1; }
+          words[w] |= 1ull << (v & 63);
+        }
+      }
+    } else if (card > 4096) {
+      for (int j = 0; j < 1024; j++) {
+        uint64_t v = (uint64_t)le32(data + pos) | ((uint64_t)le32(data + pos + 4) << 32); pos += 8;
+        if (v) {
+          if (base_word + j >= num_words) { snprintf(po_error, sizeof(po_error), "roaring: value out of range"); return -1; }
+          words[base_word + j] |= v;
+        }
+      }
+    } else {
+      for (uint32_t i = 0; i < card; i++) {
+        uint32_t v = le16(data + pos); pos += 2;
+        int64_t w = base_word + (v >> 6);
+        if (w >= num_words) { snprintf(po_error, sizeof(po_error), "roaring: value out of range"); return -1; }
+        words[w] |= 1ull << (v & 63);
+      }
+    }
+    total += card;
+    if (pos > size) { snprintf(po_error, sizeof(po_error), "roaring: truncated container"); return -1; }
+  }
+  return total;
+}
+
+/* Serializer used to build synthetic postings: sorted distinct docIds -> portable format.  Container choice
+ * follows the library: array when card <= 4096 else bitset, then runOptimize() (what
+ * RoaringBitmapWriter.writer().get() does on flush; OffHeapBitmapInvertedIndexCreator.java:235-249):
+ * convert to a run container when its serialized size 2 + 4*numRuns is smaller.
+ * Returns the size; writes when out != NULL. */
+int64_t po_roaring_serialize(const int32_t* doc_ids, int64_t n, int run_optimize, uint8_t* out) {
+  /* pass 1: container boundaries */
+  int64_t num_containers = 0;
+  for (int64_t i = 0; i < n;) {
+    uint32_t key = (uint32_t)doc_ids[i] >> 16;
+    while (i < n && ((uint32_t)doc_ids[i] >> 16) == key) i++;
+    num_containers++;
+  }
+  uint32_t* keys = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(num_containers + 1));
+  int64_t* starts = (int64_t*)malloc(sizeof(int64_t) * (size_t)(num_containers + 1));
+  uint8_t* kinds = (uint8_t*)malloc((size_t)num_containers + 1); /* 0 array, 1 bitset, 2 run */
+  uint32_t* num_runs = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(num_containers + 1));
+  int64_t c = 0;
+  int any_run = 0;
+  for (int64_t i = 0; i < n;) {
+    uint32_t key = (uint32_t)doc_ids[i] >> 16;
+    keys[c] = key; starts[c] = i;
+    uint32_t runs = 0; int64_t j = i;
+    while (j < n && ((uint32_t)doc_ids[j] >> 16) == key) {
+      if (j == i || doc_ids[j] != doc_ids[j - 1] + 1) runs++;
+      j++;
+    }
+    int64_t card = j - i;
+    int64_t plain_size = card > 4096 ? 8192 : 2 * card;
+    kinds[c] = card > 4096 ? 1 : 0;
+    num_runs[c] = runs;
+    if (run_optimize && 2 + 4 * (int64_t)runs < plain_size) { kinds[c] = 2; any_run = 1; }
+    i = j; c++;
+  }
+  starts[num_containers] = n;
+  /* header */
+  int64_t pos = 0;
+  if (any_run) {
+    if (out) { put_le32(out, ROARING_COOKIE_RUN | ((uint32_t)(num_containers - 1) << 16)); memset(out + 4, 0, (size_t)((num_containers + 7) / 8)); }
+    pos = 4 + (num_containers + 7) / 8;
+    if (out) for (int64_t k = 0; k < num_containers; k++) if (kinds[k] == 2) out[4 + (k >> 3)] |= (uint8_t)(1u << (k & 7));
+  } else {
+    if (out) { put_le32(out, ROARING_COOKIE_NO_RUN); put_le32(out + 4, (uint32_t)num_containers); }
+    pos = 8;
+  }
+  for (int64_t k = 0; k < num_containers; k++) {
+    if (out) { put_le16(out + pos, keys[k]); put_le16(out + pos + 2, (uint32_t)(starts[k + 1] - starts[k] - 1)); }
+    pos += 4;
+  }
+  int64_t offset_header_pos = -1;
+  if (!any_run || num_containers >= ROARING_NO_OFFSET_THRESHOLD) { offset_header_pos = pos; pos += 4 * num_containers; }
+  for (int64_t k = 0; k < num_containers; k++) {
+    if (offset_header_pos >= 0 && out) put_le32(out + offset_header_pos + 4 * k, (uint32_t)pos);
+    int64_t s = starts[k], e = starts[k + 1];
+    if (kinds[k] == 0) {
+      if (out) for (int64_t i = s; i < e; i++) put_le16(out + pos + 2 * (i - s), (uint32_t)doc_ids[i] & 0xFFFF);
+      pos += 2 * (e - s);
+    } else if (kinds[k] == 1) {
+      if (out) {
+        memset(out + pos, 0, 8192);
+        for (int64_t i = s; i < e; i++) { uint32_t v = (uint32_t)doc_ids[i] & 0xFFFF; out[pos + (v >> 3)] |= (uint8_t)(1u << (v & 7)); }
+      }
+      pos += 8192;
+    } else {
+      if (out) put_le16(out + pos, num_runs[k]);
+      pos += 2;
+      int64_t i = s;
+      while (i < e) {
+        int64_t j = i;
+        while (j + 1 < e && doc_ids[j + 1] == doc_ids[j] + 1) j++;
+        if (out) { put_le16(out + pos, (uint32_t)doc_ids[i] & 0xFFFF); put_le16(out + pos + 2, (uint32_t)(j - i)); }
+        pos += 4;
+        i = j + 1;
+      }
+    }
+  }
+  free(keys); free(starts); free(kinds); free(num_runs);
+  return pos;
+}
+
+/* BitmapInvertedIndexReader (segl/segment/index/readers/BitmapInvertedIndexReader.java:45-62):
+ * (numBitmaps + 1) big-endian uint32 offsets, then the serialized bitmaps; offsets are relative to the
+ * first offset (the reader subtracts _firstOffset). */
+int po_inverted_get(const uint8_t* inv, uint64_t inv_size, int32_t num_bitmaps, int32_t dict_id,
+                    const uint8_t** out_data, uint64_t* out_len) {
+  if (dict_id < 0 || dict_id >= num_bitmaps) PO_FAIL(1, "inverted index: dictId %d out of range", dict_id);
+  uint64_t offset_buffer_end = ((uint64_t)num_bitmaps + 1) * 4;
+  uint64_t first_offset = (uint32_t)be_get_int(inv);
+  uint64_t offset = (uint32_t)be_get_int(inv + (uint64_t)dict_id * 4);
+  uint64_t length = (uint32_t)be_get_int(inv + ((uint64_t)dict_id + 1) * 4) - offset;
+  *out_data = inv + offset_buffer_end + (offset - first_offset);
+  *out_len = length;
+  if (offset_buffer_end + (offset - first_offset) + length > inv_size) PO_FAIL(1, "inverted index: bitmap past end of buffer");
+  return 0;
+}
+
+/* BitmapInvertedIndexWriter layout (segl/segment/creator/impl/inv/BitmapInvertedIndexWriter.java:35-50,90-97):
+ * offsets are absolute positions in the file (first offset = (numBitmaps + 1) * 4). */
+int64_t po_inverted_build(const int32_t* dict_ids, int32_t num_docs, int32_t cardinality, int run_optimize, uint8_t* out) {
+  /* counting sort of docIds by dictId (postings are ascending docIds) */
+  int64_t* starts = (int64_t*)calloc((size_t)cardinality + 1, sizeof(int64_t));
+  for (int32_t i = 0; i < num_docs; i++) starts[dict_ids[i] + 1]++;
+  for (int32_t d = 0; d < cardinality; d++) starts[d + 1] += starts[d];
+  int32_t* postings = (int32_t*)malloc(sizeof(int32_t) * (size_t)(num_docs > 0 ? num_docs : 1));
+  int64_t* fill = (int64_t*)malloc(sizeof(int64_t) * (size_t)(cardinality + 1));
+  memcpy(fill, starts, sizeof(int64_t) * (size_t)(cardinality + 1));
+  for (int32_t i = 0; i < num_docs; i++) postings[fill[dict_ids[i]]++] = i;
+  int64_t pos = ((int64_t)cardinality + 1) * 4;
+  for (int32_t d = 0; d < cardinality; d++) {
+    if (out) be_put_int(out + (int64_t)d * 4, (int32_t)(uint32_t)pos);
+    pos += po_roaring_serialize(postings + starts[d], starts[d + 1] - starts[d], run_optimize, out ? out + pos : NULL);
+  }
+  if (out) be_put_int(out + (int64_t)cardinality * 4, (int32_t)(uint32_t)pos);
+  free(starts); free(postings); free(fill);
+  return pos;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Query execution: FilterPlanNode -> DocIdSetOperator -> ProjectionOperator -> AggregationOperator /
+ * GroupByOperator, one thread, pull model.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct po_column {
+  const pg_column_desc* desc;
+  po_raw_reader raw;           /* valid for RAW_FIXED_BYTE */
+} po_column;
+
+/* PredicateEvaluator.applySV on one dictId / raw value (RangePredicateEvaluatorFactory.java:220-222,
+ * 364-366; EqualsPredicateEvaluatorFactory.java:122-124; InPredicateEvaluatorFactory.java:186-188;
+ * NOT_EQ / NOT_IN evaluators are the negations). */
+static inline int pred_apply(const pg_predicate* p, int32_t v) {
+  int m;
+  switch (p->kind) {
+    case PG_PRED_MATCH_ALL: m = 1; break;
+    case PG_PRED_MATCH_NONE: m = 0; break;
+    case PG_PRED_DICT_RANGE: m = (p->lo <= v && p->hi > v); break;
+    case PG_PRED_DICT_SET: m = (v >= 0 && (v >> 5) < p->num_set_words) ? (int)((p->set_words[v >> 5] >> (v & 31)) & 1u) : 0; break;
+    case PG_PRED_RAW_RANGE: m = (v >= p->lo && v <= p->hi); break;
+    default: m = 0;
+  }
+  return p->exclusive ? !m : m;
+}
+
+/* SVScanDocIdIterator (core/operator/dociditerators/SVScanDocIdIterator.java:76-98, 213-243):
+ * fills 256 sequential docIds, reads their dictIds / values, compacts the matches in place. */
+typedef struct po_scan_iter {
+  const po_column* col;
+  const pg_predicate* pred;
+  int32_t num_docs;
+  int32_t next_doc_id;
+  int32_t batch[PO_SCAN_BATCH];
+  int32_t buffer[PO_SCAN_BATCH];
+  int32_t first_mismatch, cursor;
+  int64_t num_entries_scanned;
+} po_scan_iter;
+
+static void scan_iter_init(po_scan_iter* it, const po_column* col, const pg_predicate* pred, int32_t num_docs) {
+  memset(it, 0, sizeof(*it));
+  it->col = col; it->pred = pred; it->num_docs = num_docs;
+}
+
+/* ValueMatcher.matchValues: readDictIds / readValuesSV then predicateEvaluator.applySV(limit, docIds, values) */
+static int32_t scan_match_values(po_scan_iter* it, int32_t limit, int32_t* doc_ids) {
+  const pg_column_desc* d = it->col->desc;
+  if (d->fwd_encoding == PG_FWD_FIXED_BIT_DICT) {
+    po_fixedbit_read_dict_ids((const uint8_t*)d->fwd_data, d->bits_per_value, it->num_docs, doc_ids, limit, it->buffer);
+  } else {
+    for (int32_t i = 0; i < limit; i++) it->buffer[i] = raw_get_int(&it->col->raw, doc_ids[i]);
+  }
+  int32_t matches = 0;
+  for (int32_t i = 0; i < limit; i++) {
+    if (pred_apply(it->pred, it->buffer[i])) doc_ids[matches++] = doc_ids[i];
+  }
+  return matches;
+}
+
+static int32_t scan_iter_next(po_scan_iter* it) {
+  if (it->cursor >= it->first_mismatch) {
+    int32_t limit, batch_size = 0;
+    do {
+      limit = it->num_docs - it->next_doc_id;
+      if (limit > PO_SCAN_BATCH) limit = PO_SCAN_BATCH;
+      if (limit > 0) {
+        for (int32_t i = 0; i < limit; i++) it->batch[i] = it->next_doc_id + i;
+        batch_size = scan_match_values(it, limit, it->batch);
+        it->next_doc_id += limit;
+        it->num_entries_scanned += limit;
+      }
+    } while ((limit > 0) & (batch_size == 0));
+    it->first_mismatch = batch_size;
+    it->cursor = 0;
+    if (it->first_mismatch == 0) return PO_EOF;
+  }
+  return it->batch[it->cursor++];
+}
+
+/* Dense docId bitmap helpers (stand in for MutableRoaringBitmap: same set semantics). */
+static inline int64_t bitmap_words(int32_t num_docs) { return ((int64_t)num_docs + 63) / 64; }
+static void bitmap_clear_tail(uint64_t* w, int32_t num_docs) {
+  int r = num_docs & 63;
+  if (r) w[num_docs >> 6] &= (1ull << r) - 1ull;
+}
+
+/* Evaluate one leaf into a dense bitmap.
+ *  - scan leaf: the full-column scan of SVScanDocIdIterator.next() (256-doc batches)
+ *  - inverted leaf: InvertedIndexFilterOperator.getTrues (core/operator/filter/InvertedIndexFilterOperator.java:60-96):
+ *    OR of the postings of the matching dictIds; exclusive predicates flip over [0, numDocs). */
+static int leaf_to_bitmap(const po_column* cols, const pg_segment_desc* seg, const pg_predicate* p, uint64_t* words,
+                          int64_t* entries_scanned) {
+  int32_t num_docs = seg->num_docs;
+  int64_t nw = bitmap_words(num_docs);
+  memset(words, 0, (size_t)nw * 8);
+  if (p->kind == PG_PRED_MATCH_ALL || p->kind == PG_PRED_MATCH_NONE) {
+    int all = (p->kind == PG_PRED_MATCH_ALL) != (p->exclusive != 0);
+    if (all) { memset(words, 0xFF, (size_t)nw * 8); bitmap_clear_tail(words, num_docs); }
+    return 0;
+  }
+  const po_column* col = &cols[p->column];
+  if (p->eval == PG_EVAL_INVERTED) {
+    const pg_column_desc* d = col->desc;
+    if (!d->inv_data) PO_FAIL(1, "column %s has no inverted index", d->name);
+    for (int32_t dict_id = 0; dict_id < d->cardinality; dict_id++) {
+      pg_predicate inner = *p; inner.exclusive = 0;
+      if (!pred_apply(&inner, dict_id)) continue;
+      const uint8_t* data; uint64_t len;
+      if (po_inverted_get((const uint8_t*)d->inv_data, d->inv_size, d->cardinality, dict_id, &data, &len)) return 1;
+      if (po_roaring_or_into(data, len, words, nw) < 0) return 1;
+    }
+    if (p->exclusive) { for (int64_t i = 0; i < nw; i++) words[i] = ~words[i]; bitmap_clear_tail(words, num_docs); }
+    return 0;
+  }
+  po_scan_iter it;
+  scan_iter_init(&it, col, p, num_docs);
+  int32_t doc;
+  while ((doc = scan_iter_next(&it)) != PO_EOF) words[doc >> 6] |= 1ull << (doc & 63);
+  *entries_scanned += it.num_entries_scanned;
+  return 0;
+}
+
+/* AND / OR / NOT over docId sets (AndDocIdSet.java:110-172 intersects; OrDocIdSet unions; NotDocIdSet
+ * complements over [0, numDocs)).  Postfix evaluation of the flattened tree. */
+static int filter_to_bitmap(const po_column* cols, const pg_segment_desc* seg, const pg_query* q, uint64_t** out_words,
+                            int64_t* entries_scanned) {
+  int32_t num_docs = seg->num_docs;
+  int64_t nw = bitmap_words(num_docs);
+  if (q->num_filter_nodes == 0) {
+    uint64_t* w = (uint64_t*)malloc((size_t)(nw ? nw : 1) * 8);
+    memset(w, 0xFF, (size_t)nw * 8); bitmap_clear_tail(w, num_docs);
+    *out_words = w;
+    return 0;
+  }
+  uint64_t** stack = (uint64_t**)calloc((size_t)q->num_filter_nodes, sizeof(uint64_t*));
+  int sp = 0, rc = 0;
+  for (int32_t n = 0; n < q->num_filter_nodes && !rc; n++) {
+    const pg_filter_node* node = &q->filter[n];
+    if (node->op == PG_FILTER_LEAF) {
+      uint64_t* w = (uint64_t*)malloc((size_t)(nw ? nw : 1) * 8);
+      rc = leaf_to_bitmap(cols, seg, &q->predicates[node->predicate], w, entries_scanned);
+      stack[sp++] = w;
+    } else if (node->op == PG_FILTER_NOT) {
+      if (sp < 1) { rc = 1; snprintf(po_error, sizeof(po_error), "filter stack underflow"); break; }
+      uint64_t* w = stack[sp - 1];
+      for (int64_t i = 0; i < nw; i++) w[i] = ~w[i];
+      bitmap_clear_tail(w, num_docs);
+    } else {
+      int k = node->num_children;
+      if (sp < k || k < 1) { rc = 1; snprintf(po_error, sizeof(po_error), "filter stack underflow"); break; }
+      uint64_t* acc = stack[sp - k];
+      for (int c = 1; c < k; c++) {
+        uint64_t* w = stack[sp - k + c];
+        if (node->op == PG_FILTER_AND) for (int64_t i = 0; i < nw; i++) acc[i] &= w[i];
+        else for (int64_t i = 0; i < nw; i++) acc[i] |= w[i];
+        free(w);
+      }
+      sp -= k - 1;
+    }
+  }
+  if (!rc && sp != 1) { rc = 1; snprintf(po_error, sizeof(po_error), "malformed filter tree"); }
+  if (rc) { for (int i = 0; i < sp; i++) free(stack[i]); free(stack); return 1; }
+  *out_words = stack[0];
+  free(stack);
+  return 0;
+}
+
+/* BlockDocIdIterator over either one streaming scan leaf (the C2 shape: ScanBasedFilterOperator directly
+ * under DocIdSetOperator) or a materialised bitmap (BitmapDocIdIterator), or match-all. */
+typedef struct po_doc_iter {
+  int kind;                    /* 0 match-all, 1 scan, 2 bitmap */
+  int32_t num_docs, next;
+  po_scan_iter scan;
+  uint64_t* words; int64_t word_idx; uint64_t cur;
+} po_doc_iter;
+
+static inline int32_t doc_iter_next(po_doc_iter* it) {
+  switch (it->kind) {
+    case 0: return it->next < it->num_docs ? it->next++ : PO_EOF;
+    case 1: return scan_iter_next(&it->scan);
+    default: {
+      int64_t nw = bitmap_words(it->num_docs);
+      while (it->cur == 0) {
+        it->word_idx++;
+        if (it->word_idx >= nw) return PO_EOF;
+        it->cur = it->words[it->word_idx];
+      }
+      int b = __builtin_ctzll(it->cur);
+      it->cur &= it->cur - 1;
+      return (int32_t)(it->word_idx * 64 + b);
+    }
+  }
+}
+
+/* DataFetcher.ColumnValueReader (core/common/DataFetcher.java:335-386) */
+static void fetch_dict_ids(const po_column* col, int32_t num_docs, const int32_t* doc_ids, int32_t len, int32_t* out) {
+  po_fixedbit_read_dict_ids((const uint8_t*)col->desc->fwd_data, col->desc->bits_per_value, num_docs, doc_ids, len, out);
+}
+static void fetch_int_values(const po_column* col, int32_t num_docs, const int32_t* doc_ids, int32_t len,
+                             int32_t* dict_id_scratch, int32_t* out) {
+  if (col->desc->fwd_encoding == PG_FWD_FIXED_BIT_DICT) {
+    fetch_dict_ids(col, num_docs, doc_ids, len, dict_id_scratch);
+    const uint8_t* dict = (const uint8_t*)col->desc->dict_data;
+    /* Dictionary.readIntValues, sspi/index/reader/Dictionary.java:207-211 */
+    for (int32_t i = 0; i < len; i++) out[i] = dict_get_int(dict, dict_id_scratch[i]);
+  } else {
+    /* ForwardIndexReader.readValuesSV default impl, sspi/index/reader/ForwardIndexReader.java:156-162 */
+    for (int32_t i = 0; i < len; i++) out[i] = raw_get_int(&col->raw, doc_ids[i]);
+  }
+}
+
+typedef struct po_holder {          /* DoubleAggregationResultHolder / AvgPair + exact side channel */
+  double value;                     /* COUNT, SUM, MIN, MAX holder */
+  double avg_sum; int64_t avg_count;
+  int64_t exact_sum; int64_t n;
+} po_holder;
+
+static void holder_init(po_holder* h, int func) {
+  memset(h, 0, sizeof(*h));
+  if (func == PG_AGG_MIN) h->value = INFINITY;
+  if (func == PG_AGG_MAX) h->value = -INFINITY;
+}
+
+int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
+  memset(res, 0, sizeof(*res));
+  if (seg->num_docs < 0) PO_FAIL(1, "negative num_docs");
+  int32_t num_docs = seg->num_docs;
+  po_column* cols = (po_column*)calloc((size_t)(seg->num_columns > 0 ? seg->num_columns : 1), sizeof(po_column));
+  for (int32_t c = 0; c < seg->num_columns; c++) {
+    cols[c].desc = &seg->columns[c];
+    if (seg->columns[c].stored_type != PG_TYPE_INT) { free(cols); PO_FAIL(2, "oracle: only INT stored type is restated"); }
+    if (seg->columns[c].fwd_encoding == PG_FWD_RAW_FIXED_BYTE) {
+      if (po_raw_open((const uint8_t*)seg->columns[c].fwd_data, seg->columns[c].fwd_size, &cols[c].raw)) { free(cols); return 1; }
+    }
+  }
+  int rc = 0;
+  int64_t entries_in_filter = 0;
+  po_doc_iter* it = (po_doc_iter*)calloc(1, sizeof(po_doc_iter));
+  it->num_docs = num_docs;
+  uint64_t* filter_words = NULL;
+  /* FilterPlanNode: a single scan leaf streams; anything else is materialised (same docId set). */
+  if (q->num_filter_nodes == 0) {
+    it->kind = 0;
+  } else if (q->num_filter_nodes == 1 && q->filter[0].op == PG_FILTER_LEAF &&
+             q->predicates[q->filter[0].predicate].eval == PG_EVAL_SCAN &&
+             q->predicates[q->filter[0].predicate].kind >= PG_PRED_DICT_RANGE) {
+    it->kind = 1;
+    const pg_predicate* p = &q->predicates[q->filter[0].predicate];
+    scan_iter_init(&it->scan, &cols[p->column], p, num_docs);
+  } else {
+    if (filter_to_bitmap(cols, seg, q, &filter_words, &entries_in_filter)) { free(cols); free(it); return 1; }
+    it->kind = 2; it->words = filter_words; it->word_idx = 0; it->cur = bitmap_words(num_docs) ? filter_words[0] : 0;
+    if (bitmap_words(num_docs) == 0) it->word_idx = 0;
+  }
+
+  int na = q->num_aggregations;
+  int ng = q->num_group_by;
+  int64_t group_upper = 1;
+  int32_t cards[8];
+  if (ng > 8) { rc = 2; snprintf(po_error, sizeof(po_error), "too many group-by columns"); goto done; }
+  for (int g = 0; g < ng; g++) {
+    const pg_column_desc* d = &seg->columns[q->group_by_columns[g]];
+    if (d->fwd_encoding != PG_FWD_FIXED_BIT_DICT) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by on raw column"); goto done; }
+    cards[g] = d->cardinality;
+    group_upper *= d->cardinality;
+    /* DictionaryBasedGroupKeyGenerator.java:175-183: array-based holder only when the product fits */
+    if (group_upper > 10000) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by cardinality product > arrayBasedThreshold"); goto done; }
+  }
+
+  po_holder* holders = NULL;       /* aggregation only */
+  double* gholders = NULL;         /* group-by: [na][G] DoubleGroupByResultHolder */
+  double* gavg_sum = NULL; int64_t* gavg_cnt = NULL; int64_t* gexact = NULL; int64_t* gcount = NULL;
+  uint8_t* flags = NULL;
+  if (ng == 0) {
+    holders = (po_holder*)calloc((size_t)(na > 0 ? na : 1), sizeof(po_holder));
+    for (int a = 0; a < na; a++) holder_init(&holders[a], q->aggregations[a].function);
+  } else {
+    size_t G = (size_t)group_upper;
+    gholders = (double*)malloc(sizeof(double) * G * (size_t)(na > 0 ? na : 1));
+    gavg_sum = (double*)calloc(G * (size_t)(na > 0 ? na : 1), sizeof(double));
+    gavg_cnt = (int64_t*)calloc(G * (size_t)(na > 0 ? na : 1), sizeof(int64_t));
+    gexact = (int64_t*)calloc(G * (size_t)(na > 0 ? na : 1), sizeof(int64_t));
+    gcount = (int64_t*)calloc(G, sizeof(int64_t));
+    flags = (uint8_t*)calloc(G, 1);
+    for (int a = 0; a < na; a++) {
+      double init = q->aggregations[a].function == PG_AGG_MIN ? INFINITY : (q->aggregations[a].function == PG_AGG_MAX ? -INFINITY : 0.0);
+      for (size_t g = 0; g < G; g++) gholders[(size_t)a * G + g] = init;
+    }
+  }
+
+  /* thread-local scratch of the reference: DocIdSetOperator.java:42-43, DataFetcher.java:50-51 */
+  int32_t* doc_ids = (int32_t*)malloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  int32_t* dict_scratch = (int32_t*)malloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  int32_t* int_values = (int32_t*)malloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  double* dbl_values = (double*)malloc(sizeof(double) * PO_MAX_DOC_PER_CALL);
+  int32_t* group_ids = (int32_t*)malloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  int64_t num_docs_scanned = 0;
+
+  for (;;) {
+    /* DocIdSetOperator.getNextBlock, core/operator/DocIdSetOperator.java:72-85 */
+    int32_t pos = 0;
+    for (int32_t i = 0; i < PO_MAX_DOC_PER_CALL; i++) {
+      int32_t d = doc_iter_next(it);
+      if (d == PO_EOF) break;
+      doc_ids[pos++] = d;
+    }
+    if (pos == 0) break;
+    num_docs_scanned += pos;
+
+    if (ng > 0) {
+      /* DictionaryBasedGroupKeyGenerator.ArrayBasedHolder.processSingleValue, :298-338 */
+      for (int32_t i = 0; i < pos; i++) group_ids[i] = 0;
+      for (int g = ng - 1; g >= 0; g--) {
+        fetch_dict_ids(&cols[q->group_by_columns[g]], num_docs, doc_ids, pos, dict_scratch);
+        for (int32_t i = 0; i < pos; i++) group_ids[i] = group_ids[i] * cards[g] + dict_scratch[i];
+      }
+      for (int32_t i = 0; i < pos; i++) { flags[group_ids[i]] = 1; gcount[group_ids[i]]++; }
+    }
+
+    for (int a = 0; a < na; a++) {
+      int func = q->aggregations[a].function;
+      int colidx = q->aggregations[a].column;
+      size_t G = (size_t)group_upper;
+      if (func == PG_AGG_COUNT) {
+        if (ng == 0) {
+          /* CountAggregationFunction.aggregate :84-88 */
+          holders[a].value = holders[a].value + pos;
+        } else {
+          /* aggregateGroupBySV :110-116 */
+          for (int32_t i = 0; i < pos; i++) gholders[(size_t)a * G + group_ids[i]] = gholders[(size_t)a * G + group_ids[i]] + 1;
+        }
+        continue;
+      }
+      if (colidx < 0 || colidx >= seg->num_columns) { rc = 1; snprintf(po_error, sizeof(po_error), "bad aggregation column"); goto cleanup; }
+      fetch_int_values(&cols[colidx], num_docs, doc_ids, pos, dict_scratch, int_values);
+      if (ng == 0) {
+        po_holder* h = &holders[a];
+        switch (func) {
+          case PG_AGG_SUM: {
+            /* SumAggregationFunction.aggregate INT case :75-86, updateAggregationResultHolder :147-157 */
+            double inner_sum = 0;
+            for (int32_t i = 0; i < pos; i++) { inner_sum += int_values[i]; h->exact_sum += int_values[i]; }
+            h->value = inner_sum + h->value;
+            break;
+          }
+          case PG_AGG_MAX: {
+            /* MaxAggregationFunction.aggregate INT case :74-86, :150-160 */
+            int32_t inner = int_values[0];
+            for (int32_t i = 0; i < pos; i++) inner = int_values[i] > inner ? int_values[i] : inner;
+            h->value = fmax((double)inner, h->value);
+            break;
+          }
+          case PG_AGG_MIN: {
+            int32_t inner = int_values[0];
+            for (int32_t i = 0; i < pos; i++) inner = int_values[i] < inner ? int_values[i] : inner;
+            h->value = fmin((double)inner, h->value);
+            break;
+          }
+          case PG_AGG_AVG: {
+            /* AvgAggregationFunction.aggregate :63-79: getDoubleValuesSV, avgPair.apply(v, 1) per doc,
+             * then updateAggregationResult -> holder pair.apply(sum, count) :95-102 */
+            double s = 0; int64_t c = 0;
+            for (int32_t i = 0; i < pos; i++) { s += (double)int_values[i]; c += 1; h->exact_sum += int_values[i]; }
+            h->avg_sum += s; h->avg_count += c;
+            break;
+          }
+          default: rc = 2; snprintf(po_error, sizeof(po_error), "unsupported aggregation %d", func); goto cleanup;
+        }
+        h->n += pos;
+      } else {
+        /* group-by functions all read getDoubleValuesSV (dictionary.readDoubleValues: (double) int) */
+        for (int32_t i = 0; i < pos; i++) dbl_values[i] = (double)int_values[i];
+        double* hold = gholders + (size_t)a * G;
+        switch (func) {
+          case PG_AGG_SUM: /* SumAggregationFunction.aggregateGroupBySV :173-178 */
+            for (int32_t i = 0; i < pos; i++) { hold[group_ids[i]] = hold[group_ids[i]] + dbl_values[i]; gexact[(size_t)a * G + group_ids[i]] += int_values[i]; }
+            break;
+          case PG_AGG_MAX: /* MaxAggregationFunction.aggregateGroupBySV :180-187 */
+            for (int32_t i = 0; i < pos; i++) if (dbl_values[i] > hold[group_ids[i]]) hold[group_ids[i]] = dbl_values[i];
+            break;
+          case PG_AGG_MIN:
+            for (int32_t i = 0; i < pos; i++) if (dbl_values[i] < hold[group_ids[i]]) hold[group_ids[i]] = dbl_values[i];
+            break;
+          case PG_AGG_AVG:
+            for (int32_t i = 0; i < pos; i++) {
+              gavg_sum[(size_t)a * G + group_ids[i]] += dbl_values[i]; gavg_cnt[(size_t)a * G + group_ids[i]] += 1;
+              gexact[(size_t)a * G + group_ids[i]] += int_values[i];
+            }
+            break;
+          default: rc = 2; snprintf(po_error, sizeof(po_error), "unsupported aggregation %d", func); goto cleanup;
+        }
+      }
+    }
+  }
+
+  /* results */
+  res->num_aggregations = na;
+  if (ng == 0) {
+    res->aggregations = (pg_agg_value*)calloc((size_t)(na > 0 ? na : 1), sizeof(pg_agg_value));
+    for (int a = 0; a < na; a++) {
+      pg_agg_value* v = &res->aggregations[a];
+      int func = q->aggregations[a].function;
+      v->min = INFINITY; v->max = -INFINITY;
+      v->count = func == PG_AGG_COUNT ? (int64_t)holders[a].value : (func == PG_AGG_AVG ? holders[a].avg_count : holders[a].n);
+      if (func == PG_AGG_SUM) { v->sum = holders[a].value; v->sum_i64 = holders[a].exact_sum; v->sum_exact = 1; }
+      if (func == PG_AGG_AVG) { v->sum = holders[a].avg_sum; v->sum_i64 = holders[a].exact_sum; v->sum_exact = 1; }
+      if (func == PG_AGG_MIN) v->min = holders[a].value;
+      if (func == PG_AGG_MAX) v->max = holders[a].value;
+    }
+  } else {
+    size_t G = (size_t)group_upper;
+    int32_t num_groups = 0;
+    for (size_t g = 0; g < G; g++) num_groups += flags[g];
+    res->num_groups = num_groups;
+    res->group_id_upper_bound = (int32_t)group_upper;
+    res->group_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)(num_groups > 0 ? num_groups : 1));
+    res->group_aggregations = (pg_agg_value*)calloc((size_t)(num_groups > 0 ? num_groups : 1) * (size_t)(na > 0 ? na : 1), sizeof(pg_agg_value));
+    int32_t k = 0;
+    for (size_t g = 0; g < G; g++) {
+      if (!flags[g]) continue;
+      res->group_ids[k] = (int32_t)g;
+      for (int a = 0; a < na; a++) {
+        pg_agg_value* v = &res->group_aggregations[(size_t)k * (size_t)na + (size_t)a];
+        int func = q->aggregations[a].function;
+        v->min = INFINITY; v->max = -INFINITY;
+        v->count = func == PG_AGG_COUNT ? (int64_t)gholders[(size_t)a * G + g] : (func == PG_AGG_AVG ? gavg_cnt[(size_t)a * G + g] : gcount[g]);
+        if (func == PG_AGG_SUM) { v->sum = gholders[(size_t)a * G + g]; v->sum_i64 = gexact[(size_t)a * G + g]; v->sum_exact = 1; }
+        if (func == PG_AGG_AVG) { v->sum = gavg_sum[(size_t)a * G + g]; v->sum_i64 = gexact[(size_t)a * G + g]; v->sum_exact = 1; }
+        if (func == PG_AGG_MIN) v->min = gholders[(size_t)a * G + g];
+        if (func == PG_AGG_MAX) v->max = gholders[(size_t)a * G + g];
+      }
+      k++;
+    }
+  }
+  /* ExecutionStatistics: AggregationOperator.java:88-93 (numDocsScanned, inFilter, numDocsScanned * numProjectedColumns, totalDocs) */
+  {
+    int proj[64]; int nproj = 0;
+    for (int g = 0; g < ng; g++) { int c = q->group_by_columns[g], seen = 0; for (int j = 0; j < nproj; j++) seen |= proj[j] == c; if (!seen && nproj < 64) proj[nproj++] = c; }
+    for (int a = 0; a < na; a++) { int c = q->aggregations[a].column; if (c < 0) continue; int seen = 0; for (int j = 0; j < nproj; j++) seen |= proj[j] == c; if (!seen && nproj < 64) proj[nproj++] = c; }
+    if (it->kind == 1) entries_in_filter = it->scan.num_entries_scanned;
+    res->stats.num_docs_scanned = num_docs_scanned;
+    res->stats.num_entries_scanned_in_filter = entries_in_filter;
+    res->stats.num_entries_scanned_post_filter = num_docs_scanned * nproj;
+    res->stats.num_total_docs = num_docs;
+  }
+
+cleanup:
+  free(doc_ids); free(dict_scratch); free(int_values); free(dbl_values); free(group_ids);
+  free(holders); free(gholders); free(gavg_sum); free(gavg_cnt); free(gexact); free(gcount); free(flags);
+done:
+  free(filter_words); free(it); free(cols);
+  return rc;
+}
+
+void po_result_free(pg_result* res) {
+  if (!res) return;
+  free(res->aggregations); free(res->group_ids); free(res->group_aggregations);
+  memset(res, 0, sizeof(*res));
+}
+
+/* Filter only -> dense bitmap (used to check pg_filter_bitmap). */
+int po_filter_bitmap(const pg_segment_desc* seg, const pg_query* q, uint64_t* out_words, int64_t num_words, int64_t* out_cardinality) {
+  po_column* cols = (po_column*)calloc((size_t)(seg->num_columns > 0 ? seg->num_columns : 1), sizeof(po_column));
+  for (int32_t c = 0; c < seg->num_columns; c++) {
+    cols[c].desc = &seg->columns[c];
+    if (seg->columns[c].fwd_encoding == PG_FWD_RAW_FIXED_BYTE &&
+        po_raw_open((const uint8_t*)seg->columns[c].fwd_data, seg->columns[c].fwd_size, &cols[c].raw)) { free(cols); return 1; }
+  }
+  uint64_t* words = NULL; int64_t entries = 0;
+  int rc = filter_to_bitmap(cols, seg, q, &words, &entries);
+  free(cols);
+  if (rc) return rc;
+  int64_t nw = bitmap_words(seg->num_docs);
+  if (num_words < nw) { free(words); PO_FAIL(1, "bitmap buffer too small"); }
+  int64_t card = 0;
+  for (int64_t i = 0; i < nw; i++) { out_words[i] = words[i]; card += __builtin_popcountll(words[i]); }
+  if (out_cardinality) *out_cardinality = card;
+  free(words);
+  return 0;
+}
+
+/* BlockValSet-level readers for SPI parity tests. */
+int po_read_int_values(const pg_segment_desc* seg, int32_t column, const int32_t* doc_ids, int32_t length, int32_t* out) {
+  po_column col; memset(&col, 0, sizeof(col));
+  col.desc = &seg->columns[column];
+  if (col.desc->fwd_encoding == PG_FWD_RAW_FIXED_BYTE && po_raw_open((const uint8_t*)col.desc->fwd_data, col.desc->fwd_size, &col.raw)) return 1;
+  int32_t* scratch = (int32_t*)malloc(sizeof(int32_t) * (size_t)(length > 0 ? length : 1));
+  fetch_int_values(&col, seg->num_docs, doc_ids, length, scratch, out);
+  free(scratch);
+  return 0;
+}

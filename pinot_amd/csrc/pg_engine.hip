@@ -1,0 +1,920 @@
+// pg_engine.hip -- host side of the C ABI declared in include/pinot_gpu.h: HBM-resident segments,
+// query lowering to kernel parameter blocks, launches on per-query HIP streams, partial-result readback.
+// Everything that computes runs in the kernels of pg_kernels.h; there is no CPU fallback in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pinot_gpu.h"
+#include "pg_device.h"
+#include "pg_kernels.h"
+
+namespace {
+
+using namespace pg;
+
+thread_local std::string g_error;
+
+pg_status fail(pg_status st, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return st;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      return fail(_e == hipErrorOutOfMemory ? PG_ERR_OUT_OF_MEMORY : PG_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, \
+                  hipGetErrorString(_e), __FILE__, __LINE__);                                          \
+  } while (0)
+
+struct Engine {
+  bool initialized = false;
+  int device = 0;
+  int blocks_per_cu = 0;
+  int flags = 0;
+  bool use_dma = true;
+  std::mutex mu;
+};
+Engine g_engine;
+
+inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
+inline uint32_t le16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+inline uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+struct ColumnDev {
+  std::string name;
+  int stored_type = 0, encoding = 0, bits = 0, cardinality = 0;
+  uint8_t* d_fwd_alloc = nullptr;
+  uint8_t* d_fwd = nullptr;      // first value byte
+  size_t fwd_alloc_bytes = 0;
+  int32_t* d_dict = nullptr;
+  std::vector<int32_t> h_dict;   // host-order values (min/max lookups, group keys)
+  uint8_t* d_inv = nullptr;
+  uint64_t inv_size = 0;
+  DevContainer* d_dir = nullptr;
+  std::vector<DevContainer> h_dir;
+  std::vector<int64_t> posting_first;   // [cardinality + 1] index into the container directory
+};
+
+// Per-query execution context: a stream plus reusable device scratch.  Pooled per segment so that
+// concurrent pg_execute calls on one handle never share mutable state.
+struct ExecCtx {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  BlockPartial* d_partials = nullptr;
+  int partial_capacity = 0;
+  BlockPartial* h_partial = nullptr;            // pinned
+  std::vector<unsigned long long*> d_bitmaps;   // each num_tiles*32 words
+  std::vector<uint32_t*> d_sets;
+  std::vector<size_t> set_capacity;
+  unsigned long long* d_table = nullptr;
+  size_t table_capacity = 0;                    // in 8-byte words
+  unsigned long long* h_table = nullptr;        // pinned
+  size_t h_table_capacity = 0;
+  int32_t* d_gather_in = nullptr;
+  uint8_t* d_gather_out = nullptr;
+  size_t gather_capacity = 0;
+};
+
+}  // namespace
+
+struct pg_segment {
+  int device = 0;
+  int num_docs = 0;
+  int num_tiles = 0;
+  int num_cus = 256;
+  uint64_t device_bytes = 0;
+  std::string name;
+  std::vector<ColumnDev> cols;
+  std::mutex ctx_mu;
+  std::vector<ExecCtx*> free_ctx;
+  std::vector<ExecCtx*> all_ctx;
+};
+
+namespace {
+
+void destroy_ctx(ExecCtx* c) {
+  if (!c) return;
+  if (c->d_partials) (void)hipFree(c->d_partials);
+  if (c->h_partial) (void)hipHostFree(c->h_partial);
+  for (auto* b : c->d_bitmaps) (void)hipFree(b);
+  for (auto* s : c->d_sets) (void)hipFree(s);
+  if (c->d_table) (void)hipFree(c->d_table);
+  if (c->h_table) (void)hipHostFree(c->h_table);
+  if (c->d_gather_in) (void)hipFree(c->d_gather_in);
+  if (c->d_gather_out) (void)hipFree(c->d_gather_out);
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+pg_status acquire_ctx(pg_segment* seg, ExecCtx** out) {
+  {
+    std::lock_guard<std::mutex> lk(seg->ctx_mu);
+    if (!seg->free_ctx.empty()) {
+      *out = seg->free_ctx.back();
+      seg->free_ctx.pop_back();
+      return PG_OK;
+    }
+  }
+  ExecCtx* c = new ExecCtx();
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) for (auto& ev : c->ev) { e = hipEventCreate(&ev); if (e != hipSuccess) break; }
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_partial, sizeof(BlockPartial), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    destroy_ctx(c);
+    return fail(PG_ERR_DEVICE, "creating execution context failed: %s", hipGetErrorString(e));
+  }
+  {
+    std::lock_guard<std::mutex> lk(seg->ctx_mu);
+    seg->all_ctx.push_back(c);
+  }
+  *out = c;
+  return PG_OK;
+}
+
+void release_ctx(pg_segment* seg, ExecCtx* c) {
+  std::lock_guard<std::mutex> lk(seg->ctx_mu);
+  seg->free_ctx.push_back(c);
+}
+
+struct CtxGuard {
+  pg_segment* seg;
+  ExecCtx* ctx;
+  ~CtxGuard() { if (ctx) release_ctx(seg, ctx); }
+};
+
+pg_status ensure_partials(ExecCtx* c, int blocks) {
+  if (c->partial_capacity >= blocks + 1) return PG_OK;
+  if (c->d_partials) (void)hipFree(c->d_partials);
+  c->d_partials = nullptr;
+  HIP_TRY(hipMalloc((void**)&c->d_partials, sizeof(BlockPartial) * (size_t)(blocks + 1)));
+  c->partial_capacity = blocks + 1;
+  return PG_OK;
+}
+
+pg_status ensure_bitmap(pg_segment* seg, ExecCtx* c, size_t index) {
+  while (c->d_bitmaps.size() <= index) {
+    unsigned long long* p = nullptr;
+    size_t words = (size_t)std::max(seg->num_tiles, 1) * kTileSteps;
+    HIP_TRY(hipMalloc((void**)&p, words * 8));
+    c->d_bitmaps.push_back(p);
+  }
+  return PG_OK;
+}
+
+pg_status ensure_set(ExecCtx* c, size_t index, size_t bytes) {
+  while (c->d_sets.size() <= index) { c->d_sets.push_back(nullptr); c->set_capacity.push_back(0); }
+  if (c->set_capacity[index] < bytes) {
+    if (c->d_sets[index]) (void)hipFree(c->d_sets[index]);
+    c->d_sets[index] = nullptr;
+    size_t cap = std::max<size_t>(bytes, 4096);
+    HIP_TRY(hipMalloc((void**)&c->d_sets[index], cap));
+    c->set_capacity[index] = cap;
+  }
+  return PG_OK;
+}
+
+pg_status ensure_table(ExecCtx* c, size_t words) {
+  if (c->table_capacity < words) {
+    if (c->d_table) (void)hipFree(c->d_table);
+    c->d_table = nullptr;
+    HIP_TRY(hipMalloc((void**)&c->d_table, words * 8));
+    c->table_capacity = words;
+  }
+  if (c->h_table_capacity < words) {
+    if (c->h_table) (void)hipHostFree(c->h_table);
+    c->h_table = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&c->h_table, words * 8, hipHostMallocDefault));
+    c->h_table_capacity = words;
+  }
+  return PG_OK;
+}
+
+// Parse one serialized RoaringBitmap (public RoaringFormatSpec) into container descriptors whose
+// offsets are relative to the start of the column's inverted-index buffer.
+pg_status parse_roaring(const uint8_t* base, uint64_t start, uint64_t len, std::vector<DevContainer>* out) {
+  if (len == 0) return PG_OK;
+  if (len < 8) return fail(PG_ERR_INVALID_ARGUMENT, "inverted index: truncated bitmap");
+  const uint8_t* data = base + start;
+  uint32_t cookie = le32(data);
+  uint32_t n;
+  const uint8_t* run_flags = nullptr;
+  uint64_t pos;
+  bool has_run = false;
+  if ((cookie & 0xFFFF) == 12347u) {
+    has_run = true;
+    n = (cookie >> 16) + 1;
+    run_flags = data + 4;
+    pos = 4 + (n + 7) / 8;
+  } else if (cookie == 12346u) {
+    n = le32(data + 4);
+    pos = 8;
+  } else {
+    return fail(PG_ERR_INVALID_ARGUMENT, "inverted index: bad roaring cookie %u", cookie);
+  }
+  const uint8_t* desc = data + pos;
+  pos += (uint64_t)n * 4;
+  if (!has_run || n >= 4) pos += (uint64_t)n * 4;
+  if (pos > len) return fail(PG_ERR_INVALID_ARGUMENT, "inverted index: truncated roaring header");
+  for (uint32_t c = 0; c < n; ++c) {
+    DevContainer dc;
+    dc.key = le16(desc + 4 * c);
+    dc.cardinality = le16(desc + 4 * c + 2) + 1;
+    dc.num_runs = 0;
+    dc.offset = start + pos;
+    bool is_run = has_run && ((run_flags[c >> 3] >> (c & 7)) & 1);
+    if (is_run) {
+      if (pos + 2 > len) return fail(PG_ERR_INVALID_ARGUMENT, "inverted index: truncated run container");
+      dc.type = 2;
+      dc.num_runs = le16(data + pos);
+      pos += 2 + 4ull * dc.num_runs;
+    } else if (dc.cardinality > 4096) {
+      dc.type = 1;
+      pos += 8192;
+    } else {
+      dc.type = 0;
+      pos += 2ull * dc.cardinality;
+    }
+    if (pos > len) return fail(PG_ERR_INVALID_ARGUMENT, "inverted index: truncated container");
+    out->push_back(dc);
+  }
+  return PG_OK;
+}
+
+void free_segment(pg_segment* seg) {
+  if (!seg) return;
+  for (auto* c : seg->all_ctx) destroy_ctx(c);
+  for (auto& col : seg->cols) {
+    if (col.d_fwd_alloc) (void)hipFree(col.d_fwd_alloc);
+    if (col.d_dict) (void)hipFree(col.d_dict);
+    if (col.d_inv) (void)hipFree(col.d_inv);
+    if (col.d_dir) (void)hipFree(col.d_dir);
+  }
+  delete seg;
+}
+
+template <typename K>
+void set_dynamic_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// ---- query lowering ----
+struct Lowered {
+  ScanParams sp;
+  std::vector<int> col_of_slot;       // segment column index per slot
+  int num_scan_leaves = 0;
+  int max_bits = 1;
+};
+
+int slot_for(Lowered* lw, const pg_segment* seg, int column) {
+  for (size_t i = 0; i < lw->col_of_slot.size(); ++i) if (lw->col_of_slot[i] == column) return (int)i;
+  if ((int)lw->col_of_slot.size() >= kMaxCols) return -1;
+  const ColumnDev& c = seg->cols[column];
+  DevColumn& d = lw->sp.cols[lw->col_of_slot.size()];
+  d.fwd = c.d_fwd;
+  d.dict = c.d_dict;
+  d.bits = c.encoding == PG_FWD_RAW_FIXED_BYTE ? 32 : c.bits;
+  d.is_raw = c.encoding == PG_FWD_RAW_FIXED_BYTE;
+  d.cardinality = c.cardinality;
+  d.dict_bytes = c.cardinality * 4;
+  d.in_filter = 0;
+  d.in_agg = 0;
+  if (!d.is_raw) lw->max_bits = std::max(lw->max_bits, c.bits);
+  lw->col_of_slot.push_back(column);
+  lw->sp.num_cols = (int)lw->col_of_slot.size();
+  return lw->sp.num_cols - 1;
+}
+
+pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered* lw) {
+  ScanParams& sp = lw->sp;
+  if (q->num_filter_nodes < 0 || q->num_filter_nodes > kMaxNodes) return fail(PG_ERR_UNSUPPORTED, "filter tree has %d nodes (max %d)", q->num_filter_nodes, kMaxNodes);
+  if (q->num_filter_nodes > 0 && (!q->filter || !q->predicates)) return fail(PG_ERR_INVALID_ARGUMENT, "filter nodes without predicates");
+  int depth = 0, max_depth = 0;
+  size_t bitmap_idx = 1;   // bitmap 0 is reserved for pg_filter_bitmap output
+  size_t set_idx = 0;
+  for (int n = 0; n < q->num_filter_nodes; ++n) {
+    const pg_filter_node& fn = q->filter[n];
+    DevNode& dn = sp.nodes[n];
+    dn.op = fn.op;
+    dn.leaf = -1;
+    dn.num_children = fn.num_children;
+    dn.pad = 0;
+    if (fn.op == PG_FILTER_LEAF) {
+      if (fn.predicate < 0 || fn.predicate >= q->num_predicates) return fail(PG_ERR_INVALID_ARGUMENT, "filter node %d: bad predicate index", n);
+      if (sp.num_leaves >= kMaxLeaves) return fail(PG_ERR_UNSUPPORTED, "more than %d filter leaves", kMaxLeaves);
+      const pg_predicate& pr = q->predicates[fn.predicate];
+      DevLeaf& L = sp.leaves[sp.num_leaves];
+      memset(&L, 0, sizeof(L));
+      dn.leaf = sp.num_leaves++;
+      L.exclusive = pr.exclusive ? 1 : 0;
+      L.col = 0;
+      if (pr.kind == PG_PRED_MATCH_ALL) { L.kind = kLeafMatchAll; }
+      else if (pr.kind == PG_PRED_MATCH_NONE) { L.kind = kLeafMatchNone; }
+      else {
+        if (pr.column < 0 || pr.column >= (int)seg->cols.size()) return fail(PG_ERR_INVALID_ARGUMENT, "predicate column %d out of range", pr.column);
+        const ColumnDev& col = seg->cols[pr.column];
+        const bool is_dict = col.encoding == PG_FWD_FIXED_BIT_DICT;
+        if ((pr.kind == PG_PRED_DICT_RANGE || pr.kind == PG_PRED_DICT_SET) && !is_dict)
+          return fail(PG_ERR_INVALID_ARGUMENT, "dictionary predicate on raw column %s", col.name.c_str());
+        if (pr.kind == PG_PRED_RAW_RANGE && is_dict) return fail(PG_ERR_INVALID_ARGUMENT, "raw predicate on dictionary column %s", col.name.c_str());
+        if (pr.eval == PG_EVAL_INVERTED) {
+          if (!col.d_inv) return fail(PG_ERR_INVALID_ARGUMENT, "column %s has no inverted index", col.name.c_str());
+          if (pr.kind != PG_PRED_DICT_RANGE && pr.kind != PG_PRED_DICT_SET) return fail(PG_ERR_INVALID_ARGUMENT, "inverted-index leaf needs a dictionary predicate");
+          // InvertedIndexFilterOperator.getTrues: OR of the postings of every matching dictId.
+          pg_status st = ensure_bitmap(seg, ctx, bitmap_idx);
+          if (st != PG_OK) return st;
+          unsigned long long* bm = ctx->d_bitmaps[bitmap_idx++];
+          const long long words = (long long)seg->num_tiles * kTileSteps;
+          fill_words_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(bm, words, 0ull);
+          for (int d = 0; d < col.cardinality; ++d) {
+            bool in;
+            if (pr.kind == PG_PRED_DICT_RANGE) in = d >= pr.lo && d < pr.hi;
+            else in = (d >> 5) < pr.num_set_words && ((pr.set_words[d >> 5] >> (d & 31)) & 1u);
+            if (!in) continue;
+            const int64_t first = col.posting_first[d], cnt = col.posting_first[d + 1] - first;
+            if (cnt > 0)
+              roaring_expand_kernel<<<dim3((unsigned)cnt), dim3(kBlockThreads), 0, ctx->stream>>>(col.d_inv, col.d_dir, (int)first, bm, words);
+          }
+          L.kind = kLeafBitmap;
+          L.bitmap = bm;
+        } else if (pr.kind == PG_PRED_DICT_RANGE) {
+          int64_t lo = std::max<int64_t>(pr.lo, 0), hi = std::min<int64_t>(pr.hi, col.cardinality);
+          if (lo >= hi) { L.kind = kLeafMatchNone; }
+          else {
+            int s = slot_for(lw, seg, pr.column);
+            if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
+            sp.cols[s].in_filter = 1;
+            L.kind = kLeafDictRange; L.col = s; L.lo = (int32_t)lo; L.span = (uint32_t)(hi - lo);
+            lw->num_scan_leaves++;
+          }
+        } else if (pr.kind == PG_PRED_DICT_SET) {
+          if (pr.num_set_words < 0 || (pr.num_set_words > 0 && !pr.set_words)) return fail(PG_ERR_INVALID_ARGUMENT, "bad dictId set");
+          int s = slot_for(lw, seg, pr.column);
+          if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
+          sp.cols[s].in_filter = 1;
+          size_t bytes = (size_t)pr.num_set_words * 4;
+          pg_status st = ensure_set(ctx, set_idx, bytes);
+          if (st != PG_OK) return st;
+          if (bytes) HIP_TRY(hipMemcpyAsync(ctx->d_sets[set_idx], pr.set_words, bytes, hipMemcpyHostToDevice, ctx->stream));
+          // the host words may go out of scope as soon as pg_execute returns; the copy is ordered before the kernel
+          // on the same stream and the caller's buffer is read synchronously for pageable memory.
+          L.kind = kLeafDictSet; L.col = s; L.set_words = ctx->d_sets[set_idx]; L.set_bytes = (int32_t)bytes;
+          set_idx++;
+          lw->num_scan_leaves++;
+        } else if (pr.kind == PG_PRED_RAW_RANGE) {
+          int64_t lo = std::max<int64_t>(pr.lo, std::numeric_limits<int32_t>::min());
+          int64_t hi = std::min<int64_t>(pr.hi, std::numeric_limits<int32_t>::max());
+          if (lo > hi) { L.kind = kLeafMatchNone; }
+          else {
+            int s = slot_for(lw, seg, pr.column);
+            if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
+            sp.cols[s].in_filter = 1;
+            L.kind = kLeafRawRange; L.col = s; L.lo = (int32_t)lo; L.span = (uint32_t)(hi - lo);
+            lw->num_scan_leaves++;
+          }
+        } else {
+          return fail(PG_ERR_INVALID_ARGUMENT, "unknown predicate kind %d", pr.kind);
+        }
+      }
+      depth++;
+    } else if (fn.op == PG_FILTER_NOT) {
+      if (depth < 1) return fail(PG_ERR_INVALID_ARGUMENT, "malformed filter tree (NOT without operand)");
+    } else if (fn.op == PG_FILTER_AND || fn.op == PG_FILTER_OR) {
+      if (fn.num_children < 1 || depth < fn.num_children) return fail(PG_ERR_INVALID_ARGUMENT, "malformed filter tree (node %d)", n);
+      depth -= fn.num_children - 1;
+    } else {
+      return fail(PG_ERR_INVALID_ARGUMENT, "unknown filter op %d", fn.op);
+    }
+    max_depth = std::max(max_depth, depth);
+  }
+  if (q->num_filter_nodes > 0 && depth != 1) return fail(PG_ERR_INVALID_ARGUMENT, "malformed filter tree (%d roots)", depth);
+  if (max_depth > kStackDepth) return fail(PG_ERR_UNSUPPORTED, "filter tree deeper than %d", kStackDepth);
+  sp.num_nodes = q->num_filter_nodes;
+  return PG_OK;
+}
+
+int default_blocks_per_cu(size_t lds_per_block) {
+  int by_lds = lds_per_block ? (int)((160 * 1024) / lds_per_block) : 8;
+  return std::max(1, std::min(8, by_lds));
+}
+
+void finish_geometry(const pg_segment* seg, Lowered* lw, size_t extra_lds, int* blocks, size_t* lds_bytes) {
+  ScanParams& sp = lw->sp;
+  sp.num_docs = seg->num_docs;
+  sp.num_tiles = seg->num_tiles;
+  sp.slot_bytes = ((256 * lw->max_bits + 16) + 15) & ~15;
+  sp.wave_lds_bytes = std::max(sp.num_cols, 1) * sp.slot_bytes;
+  const int waves_per_block = kBlockThreads / 64;
+  size_t lds = (size_t)waves_per_block * sp.wave_lds_bytes + extra_lds;
+  lds = std::max(lds, sizeof(BlockPartial) * waves_per_block);
+  int bpc = g_engine.blocks_per_cu > 0 ? g_engine.blocks_per_cu : default_blocks_per_cu(lds);
+  long long want = ((long long)sp.num_tiles + waves_per_block - 1) / waves_per_block;
+  long long cap = (long long)seg->num_cus * bpc;
+  *blocks = (int)std::max<long long>(1, std::min(want, cap));
+  *lds_bytes = lds;
+}
+
+double agg_value_double(const ColumnDev& col, int32_t key) {
+  if (col.encoding == PG_FWD_RAW_FIXED_BYTE) return (double)key;
+  return (double)col.h_dict[key];
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* pg_last_error(void) { return g_error.c_str(); }
+const char* pg_version(void) { return "pinot_amd 0.1 (gfx950)"; }
+
+pg_status pg_init(const pg_config* config) {
+  std::lock_guard<std::mutex> lk(g_engine.mu);
+  if (config && config->abi_version != PG_ABI_VERSION) return fail(PG_ERR_INVALID_ARGUMENT, "ABI version mismatch: got %d, built %d", config->abi_version, PG_ABI_VERSION);
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) return fail(PG_ERR_DEVICE, "no HIP device available: %s", hipGetErrorString(e));
+  int dev = config ? config->device_id : 0;
+  if (dev < 0 || dev >= count) return fail(PG_ERR_INVALID_ARGUMENT, "device %d out of range (have %d)", dev, count);
+  g_engine.device = dev;
+  g_engine.blocks_per_cu = config ? config->blocks_per_cu : 0;
+  g_engine.flags = config ? config->flags : 0;
+  const char* nodma = getenv("PINOT_GPU_NO_DMA");
+  g_engine.use_dma = !(nodma && nodma[0] == '1');
+  const char* bpc = getenv("PINOT_GPU_BLOCKS_PER_CU");
+  if (bpc && atoi(bpc) > 0) g_engine.blocks_per_cu = atoi(bpc);
+  g_engine.initialized = true;
+  return PG_OK;
+}
+
+pg_status pg_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_engine.mu);
+  g_engine.initialized = false;
+  return PG_OK;
+}
+
+pg_status pg_device_info(int32_t device_id, char* arch_name, int32_t arch_name_len, int32_t* num_cus, uint64_t* hbm_bytes) {
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  if (arch_name && arch_name_len > 0) { strncpy(arch_name, prop.gcnArchName, (size_t)arch_name_len - 1); arch_name[arch_name_len - 1] = 0; }
+  if (num_cus) *num_cus = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  return PG_OK;
+}
+
+pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment) {
+  if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");
+  if (!desc || !out_segment) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
+  if (desc->num_docs < 0 || desc->num_columns < 0 || (desc->num_columns > 0 && !desc->columns)) return fail(PG_ERR_INVALID_ARGUMENT, "bad segment descriptor");
+  pg_segment* seg = new pg_segment();
+  seg->device = desc->device_id >= 0 ? desc->device_id : g_engine.device;
+  seg->num_docs = desc->num_docs;
+  seg->num_tiles = (int)(((long long)desc->num_docs + kTileDocs - 1) / kTileDocs);
+  seg->name = desc->name ? desc->name : "";
+  pg_status st = PG_OK;
+  auto bail = [&](pg_status s) { free_segment(seg); return s; };
+  {
+    hipError_t e = hipSetDevice(seg->device);
+    if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "hipSetDevice(%d): %s", seg->device, hipGetErrorString(e)));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, seg->device);
+    if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e)));
+    seg->num_cus = prop.multiProcessorCount;
+  }
+  seg->cols.resize((size_t)desc->num_columns);
+  for (int i = 0; i < desc->num_columns; ++i) {
+    const pg_column_desc& cd = desc->columns[i];
+    ColumnDev& col = seg->cols[(size_t)i];
+    col.name = cd.name ? cd.name : "";
+    col.stored_type = cd.stored_type;
+    col.encoding = cd.fwd_encoding;
+    col.bits = cd.bits_per_value;
+    col.cardinality = cd.cardinality;
+    if (cd.stored_type != PG_TYPE_INT) return bail(fail(PG_ERR_UNSUPPORTED, "column %s: only INT stored type is offloaded", col.name.c_str()));
+    if (!cd.fwd_data && desc->num_docs > 0) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: missing forward index", col.name.c_str()));
+    const uint8_t* fwd = (const uint8_t*)cd.fwd_data;
+    if (cd.fwd_encoding == PG_FWD_FIXED_BIT_DICT) {
+      if (cd.bits_per_value < 1 || cd.bits_per_value > 31) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: bits_per_value %d", col.name.c_str(), cd.bits_per_value));
+      // FixedBitIntReaderWriter precondition (segl/io/util/FixedBitIntReaderWriter.java:30-33), in 64-bit
+      const uint64_t expect = ((uint64_t)desc->num_docs * (uint64_t)cd.bits_per_value + 7) / 8;
+      if (cd.fwd_size != expect) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: forward index is %llu bytes, expected %llu", col.name.c_str(), (unsigned long long)cd.fwd_size, (unsigned long long)expect));
+      // BaseImmutableDictionary precondition (BaseImmutableDictionary.java:51-53)
+      if (cd.cardinality < 1 || !cd.dict_data || cd.dict_size != (uint64_t)cd.cardinality * 4) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: dictionary buffer size mismatch", col.name.c_str()));
+      col.fwd_alloc_bytes = (size_t)std::max(seg->num_tiles, 1) * 256 * (size_t)cd.bits_per_value + 64;
+      hipError_t e = hipMalloc((void**)&col.d_fwd_alloc, col.fwd_alloc_bytes);
+      if (e != hipSuccess) return bail(fail(PG_ERR_OUT_OF_MEMORY, "column %s: hipMalloc(%zu): %s", col.name.c_str(), col.fwd_alloc_bytes, hipGetErrorString(e)));
+      col.d_fwd = col.d_fwd_alloc;
+      // zero the padding past the file bytes so tail tiles decode deterministic (masked) values
+      size_t tail = col.fwd_alloc_bytes - (size_t)cd.fwd_size;
+      e = hipMemset(col.d_fwd_alloc + cd.fwd_size, 0, tail);
+      if (e == hipSuccess && cd.fwd_size) e = hipMemcpy(col.d_fwd_alloc, fwd, (size_t)cd.fwd_size, hipMemcpyHostToDevice);
+      if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "column %s: H2D copy: %s", col.name.c_str(), hipGetErrorString(e)));
+      col.h_dict.resize((size_t)cd.cardinality);
+      const uint8_t* dp = (const uint8_t*)cd.dict_data;
+      for (int d = 0; d < cd.cardinality; ++d) col.h_dict[(size_t)d] = (int32_t)be32(dp + 4 * (size_t)d);
+      e = hipMalloc((void**)&col.d_dict, (size_t)cd.cardinality * 4);
+      if (e == hipSuccess) e = hipMemcpy(col.d_dict, col.h_dict.data(), (size_t)cd.cardinality * 4, hipMemcpyHostToDevice);
+      if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "column %s: dictionary upload: %s", col.name.c_str(), hipGetErrorString(e)));
+      seg->device_bytes += col.fwd_alloc_bytes + (size_t)cd.cardinality * 4;
+    } else if (cd.fwd_encoding == PG_FWD_RAW_FIXED_BYTE) {
+      // BaseChunkForwardIndexReader header (BaseChunkForwardIndexReader.java:61-111)
+      if (cd.fwd_size < 16) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: raw forward index too small", col.name.c_str()));
+      int off = 0;
+      const int version = (int)be32(fwd + off); off += 4;
+      const int num_chunks = (int)be32(fwd + off); off += 4;
+      off += 4;  // numDocsPerChunk
+      const int entry_size = (int)be32(fwd + off); off += 4;
+      int data_header_start = off;
+      int compression = 2;
+      if (version > 1) {
+        if (cd.fwd_size < 28) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: raw forward index header truncated", col.name.c_str()));
+        off += 4;  // totalDocs
+        compression = (int)be32(fwd + off); off += 4;
+        data_header_start = (int)be32(fwd + off);
+      }
+      if (compression != 0) return bail(fail(PG_ERR_UNSUPPORTED, "column %s: only PASS_THROUGH raw chunks are offloaded (compressionType=%d)", col.name.c_str(), compression));
+      if (entry_size != 4) return bail(fail(PG_ERR_UNSUPPORTED, "column %s: raw entry size %d", col.name.c_str(), entry_size));
+      const uint64_t raw_start = (uint64_t)data_header_start + (uint64_t)num_chunks * (version <= 2 ? 4 : 8);
+      if (raw_start + (uint64_t)desc->num_docs * 4 > cd.fwd_size) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: raw forward index shorter than numDocs", col.name.c_str()));
+      col.fwd_alloc_bytes = (size_t)cd.fwd_size + 64;
+      hipError_t e = hipMalloc((void**)&col.d_fwd_alloc, col.fwd_alloc_bytes);
+      if (e != hipSuccess) return bail(fail(PG_ERR_OUT_OF_MEMORY, "column %s: hipMalloc(%zu): %s", col.name.c_str(), col.fwd_alloc_bytes, hipGetErrorString(e)));
+      e = hipMemset(col.d_fwd_alloc + cd.fwd_size, 0, 64);
+      if (e == hipSuccess) e = hipMemcpy(col.d_fwd_alloc, fwd, (size_t)cd.fwd_size, hipMemcpyHostToDevice);
+      if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "column %s: H2D copy: %s", col.name.c_str(), hipGetErrorString(e)));
+      col.d_fwd = col.d_fwd_alloc + raw_start;
+      col.bits = 32;
+      col.cardinality = 0;
+      seg->device_bytes += col.fwd_alloc_bytes;
+    } else {
+      return bail(fail(PG_ERR_UNSUPPORTED, "column %s: unknown forward-index encoding %d", col.name.c_str(), cd.fwd_encoding));
+    }
+    if (cd.inv_data && cd.inv_size && cd.fwd_encoding == PG_FWD_FIXED_BIT_DICT) {
+      // BitmapInvertedIndexReader (BitmapInvertedIndexReader.java:45-62)
+      const uint8_t* inv = (const uint8_t*)cd.inv_data;
+      const uint64_t offsets_end = ((uint64_t)cd.cardinality + 1) * 4;
+      if (cd.inv_size < offsets_end) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: inverted index too small", col.name.c_str()));
+      const uint64_t first_offset = be32(inv);
+      col.posting_first.assign((size_t)cd.cardinality + 1, 0);
+      for (int d = 0; d < cd.cardinality; ++d) {
+        col.posting_first[(size_t)d] = (int64_t)col.h_dir.size();
+        const uint64_t o0 = be32(inv + 4 * (size_t)d), o1 = be32(inv + 4 * (size_t)(d + 1));
+        if (o1 < o0 || offsets_end + (o1 - first_offset) > cd.inv_size) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: inverted index offsets out of range", col.name.c_str()));
+        st = parse_roaring(inv, offsets_end + (o0 - first_offset), o1 - o0, &col.h_dir);
+        if (st != PG_OK) return bail(st);
+      }
+      col.posting_first[(size_t)cd.cardinality] = (int64_t)col.h_dir.size();
+      hipError_t e = hipMalloc((void**)&col.d_inv, (size_t)cd.inv_size + 16);
+      if (e == hipSuccess) e = hipMemcpy(col.d_inv, inv, (size_t)cd.inv_size, hipMemcpyHostToDevice);
+      if (e == hipSuccess && !col.h_dir.empty()) {
+        e = hipMalloc((void**)&col.d_dir, col.h_dir.size() * sizeof(DevContainer));
+        if (e == hipSuccess) e = hipMemcpy(col.d_dir, col.h_dir.data(), col.h_dir.size() * sizeof(DevContainer), hipMemcpyHostToDevice);
+      }
+      if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "column %s: inverted index upload: %s", col.name.c_str(), hipGetErrorString(e)));
+      col.inv_size = cd.inv_size;
+      seg->device_bytes += cd.inv_size + col.h_dir.size() * sizeof(DevContainer);
+    }
+  }
+  *out_segment = seg;
+  return PG_OK;
+}
+
+pg_status pg_segment_close(pg_segment* segment) {
+  if (!segment) return fail(PG_ERR_INVALID_ARGUMENT, "null segment");
+  (void)hipSetDevice(segment->device);
+  free_segment(segment);
+  return PG_OK;
+}
+
+pg_status pg_segment_num_docs(const pg_segment* segment, int32_t* out_num_docs) {
+  if (!segment || !out_num_docs) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
+  *out_num_docs = segment->num_docs;
+  return PG_OK;
+}
+
+pg_status pg_segment_device_bytes(const pg_segment* segment, uint64_t* out_bytes) {
+  if (!segment || !out_bytes) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
+  *out_bytes = segment->device_bytes;
+  return PG_OK;
+}
+
+void pg_result_free(pg_result* r) {
+  if (!r) return;
+  free(r->aggregations);
+  free(r->group_ids);
+  free(r->group_aggregations);
+  memset(r, 0, sizeof(*r));
+}
+
+static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out, unsigned long long* d_out_bitmap_request,
+                              uint64_t* host_bitmap, int64_t host_bitmap_words, int64_t* out_cardinality) {
+  if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");
+  if (!seg || !q) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
+  (void)d_out_bitmap_request;
+  HIP_TRY(hipSetDevice(seg->device));
+  ExecCtx* ctx = nullptr;
+  pg_status st = acquire_ctx(seg, &ctx);
+  if (st != PG_OK) return st;
+  CtxGuard guard{seg, ctx};
+
+  const bool want_bitmap = host_bitmap != nullptr;
+  const int na = want_bitmap ? 0 : q->num_aggregations;
+  const int ng = want_bitmap ? 0 : q->num_group_by;
+  if (na < 0 || ng < 0 || (na > 0 && !q->aggregations) || (ng > 0 && !q->group_by_columns)) return fail(PG_ERR_INVALID_ARGUMENT, "bad aggregation / group-by lists");
+  if (ng > kMaxGroupCols) return fail(PG_ERR_UNSUPPORTED, "more than %d group-by columns", kMaxGroupCols);
+  const bool timed = (g_engine.flags & PG_CFG_TIME_KERNELS) != 0;
+
+  Lowered lw;
+  memset(&lw.sp, 0, sizeof(lw.sp));
+  if (timed) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+  st = lower_filter(seg, ctx, q, &lw);
+  if (st != PG_OK) return st;
+  ScanParams& sp = lw.sp;
+  const int num_cols_total = (int)seg->cols.size();
+
+  // distinct projected columns (ExecutionStatistics numEntriesScannedPostFilter = numDocsScanned * numProjectedColumns)
+  std::vector<int> projected;
+  auto add_projected = [&](int c) { if (std::find(projected.begin(), projected.end(), c) == projected.end()) projected.push_back(c); };
+
+  if (out) memset(out, 0, sizeof(*out));
+
+  if (ng == 0) {
+    // ---------------- aggregation only ----------------
+    std::vector<int> agg_slot_of((size_t)std::max(na, 1), -1);
+    for (int a = 0; a < na; ++a) {
+      const pg_aggregation& ag = q->aggregations[a];
+      if (ag.function == PG_AGG_COUNT) continue;
+      if (ag.function < PG_AGG_COUNT || ag.function > PG_AGG_AVG) return fail(PG_ERR_UNSUPPORTED, "aggregation function %d", ag.function);
+      if (ag.column < 0 || ag.column >= num_cols_total) return fail(PG_ERR_INVALID_ARGUMENT, "aggregation column %d out of range", ag.column);
+      add_projected(ag.column);
+      int s = slot_for(&lw, seg, ag.column);
+      if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
+      sp.cols[s].in_agg = 1;
+      int ac = -1;
+      for (int i = 0; i < sp.num_agg_cols; ++i) if (sp.agg_cols[i].col == s) ac = i;
+      if (ac < 0) {
+        if (sp.num_agg_cols >= kMaxAggCols) return fail(PG_ERR_UNSUPPORTED, "more than %d aggregated columns", kMaxAggCols);
+        ac = sp.num_agg_cols++;
+        sp.agg_cols[ac] = DevAggCol{s, 0, 0, 0};
+      }
+      if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) sp.agg_cols[ac].need_sum = 1;
+      if (ag.function == PG_AGG_MIN || ag.function == PG_AGG_MAX) sp.agg_cols[ac].need_minmax = 1;
+      agg_slot_of[(size_t)a] = ac;
+    }
+    int blocks = 1;
+    size_t lds = 0;
+    finish_geometry(seg, &lw, 0, &blocks, &lds);
+    sp.speculate = 1;
+    st = ensure_partials(ctx, blocks);
+    if (st != PG_OK) return st;
+    sp.partials = ctx->d_partials;
+    sp.out_bitmap = nullptr;
+    if (want_bitmap) {
+      st = ensure_bitmap(seg, ctx, 0);
+      if (st != PG_OK) return st;
+      sp.out_bitmap = ctx->d_bitmaps[0];
+    }
+    if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (g_engine.use_dma) {
+      set_dynamic_lds(scan_agg_kernel<true>, lds);
+      scan_agg_kernel<true><<<dim3((unsigned)blocks), dim3(kBlockThreads), lds, ctx->stream>>>(sp);
+    } else {
+      set_dynamic_lds(scan_agg_kernel<false>, lds);
+      scan_agg_kernel<false><<<dim3((unsigned)blocks), dim3(kBlockThreads), lds, ctx->stream>>>(sp);
+    }
+    HIP_TRY(hipGetLastError());
+    if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    finalize_partials_kernel<<<dim3(1), dim3(kBlockThreads), 0, ctx->stream>>>(ctx->d_partials, blocks);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ctx->h_partial, ctx->d_partials + blocks, sizeof(BlockPartial), hipMemcpyDeviceToHost, ctx->stream));
+    if (want_bitmap) {
+      const int64_t need = ((int64_t)seg->num_docs + 63) / 64;
+      if (host_bitmap_words < need) return fail(PG_ERR_INVALID_ARGUMENT, "bitmap buffer has %lld words, need %lld", (long long)host_bitmap_words, (long long)need);
+      if (need) HIP_TRY(hipMemcpyAsync(host_bitmap, ctx->d_bitmaps[0], (size_t)need * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (timed) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const BlockPartial& fp = *ctx->h_partial;
+    if (out_cardinality) *out_cardinality = (int64_t)fp.count;
+    if (out) {
+      out->num_aggregations = na;
+      out->aggregations = (pg_agg_value*)calloc((size_t)std::max(na, 1), sizeof(pg_agg_value));
+      for (int a = 0; a < na; ++a) {
+        const pg_aggregation& ag = q->aggregations[a];
+        pg_agg_value& v = out->aggregations[a];
+        v.count = (int64_t)fp.count;
+        v.min = std::numeric_limits<double>::infinity();
+        v.max = -std::numeric_limits<double>::infinity();
+        if (ag.function == PG_AGG_COUNT) continue;
+        const int ac = agg_slot_of[(size_t)a];
+        const ColumnDev& col = seg->cols[(size_t)ag.column];
+        if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) {
+          v.sum_i64 = fp.sum[ac];
+          v.sum_exact = 1;
+          v.sum = (double)fp.sum[ac];
+        } else if (fp.count > 0) {
+          if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, fp.kmin[ac]);
+          if (ag.function == PG_AGG_MAX) v.max = agg_value_double(col, fp.kmax[ac]);
+        }
+      }
+      out->stats.num_docs_scanned = (int64_t)fp.count;
+      out->stats.num_entries_scanned_in_filter = (int64_t)lw.num_scan_leaves * seg->num_docs;
+      out->stats.num_entries_scanned_post_filter = (int64_t)fp.count * (int64_t)projected.size();
+      out->stats.num_total_docs = seg->num_docs;
+    }
+  } else {
+    // ---------------- group-by (ArrayBasedHolder) ----------------
+    GroupParams gp;
+    memset(&gp, 0, sizeof(gp));
+    long long product = 1;
+    std::vector<int> cards;
+    for (int g = 0; g < ng; ++g) {
+      const int c = q->group_by_columns[g];
+      if (c < 0 || c >= num_cols_total) return fail(PG_ERR_INVALID_ARGUMENT, "group-by column %d out of range", c);
+      const ColumnDev& col = seg->cols[(size_t)c];
+      if (col.encoding != PG_FWD_FIXED_BIT_DICT) return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s", col.name.c_str());
+      add_projected(c);
+      int s = slot_for(&lw, seg, c);
+      if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
+      sp.cols[s].in_agg = 1;
+      gp.group_cols[g] = s;
+      gp.group_mult[g] = (int32_t)product;
+      product *= col.cardinality;
+      cards.push_back(col.cardinality);
+      // DictionaryBasedGroupKeyGenerator.java:175-183: array-based holder only up to arrayBasedThreshold (10 000)
+      if (product > 10000) return fail(PG_ERR_UNSUPPORTED, "group-by cardinality product exceeds the array-based threshold (10000)");
+    }
+    gp.num_group_cols = ng;
+    gp.num_groups = (int32_t)product;
+    std::vector<int> dev_agg_of((size_t)std::max(na, 1), -1);
+    for (int a = 0; a < na; ++a) {
+      const pg_aggregation& ag = q->aggregations[a];
+      if (ag.function == PG_AGG_COUNT) continue;
+      if (ag.function < PG_AGG_COUNT || ag.function > PG_AGG_AVG) return fail(PG_ERR_UNSUPPORTED, "aggregation function %d", ag.function);
+      if (ag.column < 0 || ag.column >= num_cols_total) return fail(PG_ERR_INVALID_ARGUMENT, "aggregation column %d out of range", ag.column);
+      add_projected(ag.column);
+      int s = slot_for(&lw, seg, ag.column);
+      if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
+      sp.cols[s].in_agg = 1;
+      const int kind = (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) ? kGroupSum : (ag.function == PG_AGG_MIN ? kGroupMin : kGroupMax);
+      int da = -1;
+      for (int i = 0; i < gp.num_group_aggs; ++i) if (gp.group_aggs[i].col == s && gp.group_aggs[i].kind == kind) da = i;
+      if (da < 0) {
+        if (gp.num_group_aggs >= kMaxAggCols) return fail(PG_ERR_UNSUPPORTED, "more than %d distinct group-by aggregations", kMaxAggCols);
+        da = gp.num_group_aggs++;
+        gp.group_aggs[da] = DevGroupAgg{s, kind};
+      }
+      dev_agg_of[(size_t)a] = da;
+    }
+    const size_t table_words = (size_t)gp.num_groups * (size_t)(1 + gp.num_group_aggs);
+    st = ensure_table(ctx, table_words);
+    if (st != PG_OK) return st;
+    gp.table_count = ctx->d_table;
+    gp.table_acc = reinterpret_cast<long long*>(ctx->d_table + gp.num_groups);
+    const size_t table_bytes = table_words * 8;
+    gp.use_lds_table = table_bytes <= 96 * 1024 ? 1 : 0;
+    int blocks = 1;
+    size_t lds = 0;
+    finish_geometry(seg, &lw, gp.use_lds_table ? table_bytes : 0, &blocks, &lds);
+    gp.scan = sp;
+    gp.scan.partials = nullptr;
+    gp.scan.out_bitmap = nullptr;
+    init_group_table_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(gp);
+    HIP_TRY(hipGetLastError());
+    if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (gp.use_lds_table) {
+      if (g_engine.use_dma) { set_dynamic_lds(scan_group_kernel<true, true>, lds); scan_group_kernel<true, true><<<dim3((unsigned)blocks), dim3(kBlockThreads), lds, ctx->stream>>>(gp); }
+      else { set_dynamic_lds(scan_group_kernel<false, true>, lds); scan_group_kernel<false, true><<<dim3((unsigned)blocks), dim3(kBlockThreads), lds, ctx->stream>>>(gp); }
+    } else {
+      if (g_engine.use_dma) { set_dynamic_lds(scan_group_kernel<true, false>, lds); scan_group_kernel<true, false><<<dim3((unsigned)blocks), dim3(kBlockThreads), lds, ctx->stream>>>(gp); }
+      else { set_dynamic_lds(scan_group_kernel<false, false>, lds); scan_group_kernel<false, false><<<dim3((unsigned)blocks), dim3(kBlockThreads), lds, ctx->stream>>>(gp); }
+    }
+    HIP_TRY(hipGetLastError());
+    if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_table, ctx->d_table, table_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (timed) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const unsigned long long* hc = ctx->h_table;
+    const long long* ha = reinterpret_cast<const long long*>(ctx->h_table + gp.num_groups);
+    int num_present = 0;
+    long long docs = 0;
+    for (int g = 0; g < gp.num_groups; ++g) if (hc[g]) { num_present++; docs += (long long)hc[g]; }
+    out->num_aggregations = na;
+    out->num_groups = num_present;
+    out->group_id_upper_bound = gp.num_groups;
+    out->group_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)std::max(num_present, 1));
+    out->group_aggregations = (pg_agg_value*)calloc((size_t)std::max(num_present, 1) * (size_t)std::max(na, 1), sizeof(pg_agg_value));
+    int k = 0;
+    for (int g = 0; g < gp.num_groups; ++g) {
+      if (!hc[g]) continue;
+      out->group_ids[k] = g;
+      for (int a = 0; a < na; ++a) {
+        const pg_aggregation& ag = q->aggregations[a];
+        pg_agg_value& v = out->group_aggregations[(size_t)k * (size_t)na + (size_t)a];
+        v.count = (int64_t)hc[g];
+        v.min = std::numeric_limits<double>::infinity();
+        v.max = -std::numeric_limits<double>::infinity();
+        if (ag.function == PG_AGG_COUNT) continue;
+        const long long acc = ha[(size_t)dev_agg_of[(size_t)a] * (size_t)gp.num_groups + (size_t)g];
+        const ColumnDev& col = seg->cols[(size_t)ag.column];
+        if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) { v.sum_i64 = acc; v.sum_exact = 1; v.sum = (double)acc; }
+        else if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, (int32_t)acc);
+        else v.max = agg_value_double(col, (int32_t)acc);
+      }
+      k++;
+    }
+    out->stats.num_docs_scanned = docs;
+    out->stats.num_entries_scanned_in_filter = (int64_t)lw.num_scan_leaves * seg->num_docs;
+    out->stats.num_entries_scanned_post_filter = docs * (int64_t)projected.size();
+    out->stats.num_total_docs = seg->num_docs;
+  }
+  if (timed && out) {
+    float ms_all = 0.f, ms_scan = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms_all, ctx->ev[0], ctx->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&ms_scan, ctx->ev[1], ctx->ev[2]));
+    out->device_ms = ms_all;
+    out->dominant_kernel_ms = ms_scan;
+  }
+  return PG_OK;
+}
+
+pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_result) {
+  if (!out_result) return fail(PG_ERR_INVALID_ARGUMENT, "null result");
+  pg_status st = execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr);
+  if (st != PG_OK) pg_result_free(out_result);
+  return st;
+}
+
+pg_status pg_filter_bitmap(pg_segment* segment, const pg_query* query, uint64_t* out_words, int64_t num_words, int64_t* out_cardinality) {
+  if (!out_words) return fail(PG_ERR_INVALID_ARGUMENT, "null bitmap buffer");
+  return execute_impl(segment, query, nullptr, nullptr, out_words, num_words, out_cardinality);
+}
+
+static pg_status gather_impl(pg_segment* seg, int32_t column, const int32_t* doc_ids, int32_t length, int32_t* out_dict, int32_t* out_int, double* out_double) {
+  if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");
+  if (!seg || (length > 0 && !doc_ids)) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
+  if (column < 0 || column >= (int)seg->cols.size()) return fail(PG_ERR_INVALID_ARGUMENT, "column %d out of range", column);
+  if (length <= 0) return PG_OK;
+  for (int32_t i = 0; i < length; ++i) if (doc_ids[i] < 0 || doc_ids[i] >= seg->num_docs) return fail(PG_ERR_INVALID_ARGUMENT, "docId %d out of range", doc_ids[i]);
+  const ColumnDev& col = seg->cols[(size_t)column];
+  if (out_dict && col.encoding != PG_FWD_FIXED_BIT_DICT) return fail(PG_ERR_INVALID_ARGUMENT, "column %s is not dictionary encoded", col.name.c_str());
+  HIP_TRY(hipSetDevice(seg->device));
+  ExecCtx* ctx = nullptr;
+  pg_status st = acquire_ctx(seg, &ctx);
+  if (st != PG_OK) return st;
+  CtxGuard guard{seg, ctx};
+  if (ctx->gather_capacity < (size_t)length) {
+    if (ctx->d_gather_in) (void)hipFree(ctx->d_gather_in);
+    if (ctx->d_gather_out) (void)hipFree(ctx->d_gather_out);
+    ctx->d_gather_in = nullptr; ctx->d_gather_out = nullptr; ctx->gather_capacity = 0;
+    size_t cap = std::max<size_t>((size_t)length, 16384);
+    HIP_TRY(hipMalloc((void**)&ctx->d_gather_in, cap * 4));
+    HIP_TRY(hipMalloc((void**)&ctx->d_gather_out, cap * 8));
+    ctx->gather_capacity = cap;
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->d_gather_in, doc_ids, (size_t)length * 4, hipMemcpyHostToDevice, ctx->stream));
+  DevColumn dc;
+  dc.fwd = col.d_fwd; dc.dict = col.d_dict; dc.bits = col.bits; dc.is_raw = col.encoding == PG_FWD_RAW_FIXED_BYTE;
+  dc.cardinality = col.cardinality; dc.dict_bytes = col.cardinality * 4; dc.in_filter = 0; dc.in_agg = 0;
+  const unsigned blocks = (unsigned)((length + 255) / 256);
+  gather_values_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(dc, ctx->d_gather_in, length,
+      out_dict ? (int32_t*)ctx->d_gather_out : nullptr, out_int ? (int32_t*)ctx->d_gather_out : nullptr,
+      out_double ? (double*)ctx->d_gather_out : nullptr);
+  HIP_TRY(hipGetLastError());
+  void* host_out = out_dict ? (void*)out_dict : (out_int ? (void*)out_int : (void*)out_double);
+  HIP_TRY(hipMemcpyAsync(host_out, ctx->d_gather_out, (size_t)length * (out_double ? 8 : 4), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return PG_OK;
+}
+
+pg_status pg_read_dict_ids(pg_segment* segment, int32_t column, const int32_t* doc_ids, int32_t length, int32_t* out_dict_ids) {
+  if (!out_dict_ids && length > 0) return fail(PG_ERR_INVALID_ARGUMENT, "null output");
+  return gather_impl(segment, column, doc_ids, length, out_dict_ids, nullptr, nullptr);
+}
+pg_status pg_read_int_values(pg_segment* segment, int32_t column, const int32_t* doc_ids, int32_t length, int32_t* out_values) {
+  if (!out_values && length > 0) return fail(PG_ERR_INVALID_ARGUMENT, "null output");
+  return gather_impl(segment, column, doc_ids, length, nullptr, out_values, nullptr);
+}
+pg_status pg_read_double_values(pg_segment* segment, int32_t column, const int32_t* doc_ids, int32_t length, double* out_values) {
+  if (!out_values && length > 0) return fail(PG_ERR_INVALID_ARGUMENT, "null output");
+  return gather_impl(segment, column, doc_ids, length, nullptr, nullptr, out_values);
+}
+
+}  // extern "C"

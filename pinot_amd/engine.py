@@ -1,0 +1,86 @@
+"""Thin Python handle over the C ABI (`libpinot_gpu.so`): what the JNI shim does, for tests and bench.py."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from .query import Result
+
+
+class Engine:
+    def __init__(self, device_id=0, time_kernels=False, blocks_per_cu=0, lib_path=None):
+        self.lib = _abi.load_gpu_library(lib_path)
+        cfg = _abi.pg_config(_abi.PG_ABI_VERSION, device_id, blocks_per_cu, _abi.PG_CFG_TIME_KERNELS if time_kernels else 0)
+        _abi.check(self.lib, self.lib.pg_init(C.byref(cfg)))
+        self.device_id = device_id
+
+    def device_info(self):
+        name = C.create_string_buffer(64)
+        cus = C.c_int32()
+        hbm = C.c_uint64()
+        _abi.check(self.lib, self.lib.pg_device_info(self.device_id, name, 64, C.byref(cus), C.byref(hbm)))
+        return name.value.decode(), int(cus.value), int(hbm.value)
+
+    def open(self, segment_data):
+        handle = C.c_void_p()
+        _abi.check(self.lib, self.lib.pg_segment_open(C.byref(segment_data.desc), C.byref(handle)))
+        return GpuSegment(self, handle, segment_data.num_docs)
+
+
+class GpuSegment:
+    def __init__(self, engine, handle, num_docs):
+        self.engine = engine
+        self.lib = engine.lib
+        self.handle = handle
+        self.num_docs = num_docs
+
+    def close(self):
+        if self.handle:
+            _abi.check(self.lib, self.lib.pg_segment_close(self.handle))
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def device_bytes(self):
+        out = C.c_uint64()
+        _abi.check(self.lib, self.lib.pg_segment_device_bytes(self.handle, C.byref(out)))
+        return int(out.value)
+
+    def execute(self, spec):
+        res = _abi.pg_result()
+        _abi.check(self.lib, self.lib.pg_execute(self.handle, C.byref(spec.c), C.byref(res)))
+        try:
+            return Result(res, spec)
+        finally:
+            self.lib.pg_result_free(C.byref(res))
+
+    def execute_raw(self, spec, res):
+        """Hot-loop variant for bench.py: no Python-side result conversion; caller frees `res`."""
+        return self.lib.pg_execute(self.handle, C.byref(spec.c), C.byref(res))
+
+    def filter_bitmap(self, spec):
+        words = np.zeros((self.num_docs + 63) // 64, dtype=np.uint64)
+        card = C.c_int64()
+        _abi.check(self.lib, self.lib.pg_filter_bitmap(self.handle, C.byref(spec.c), words.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                       int(words.shape[0]), C.byref(card)))
+        return words, int(card.value)
+
+    def _read(self, fn, column, doc_ids, dtype, ctype):
+        doc_ids = np.ascontiguousarray(doc_ids, dtype=np.int32)
+        out = np.zeros(doc_ids.shape[0], dtype=dtype)
+        _abi.check(self.lib, fn(self.handle, column, doc_ids.ctypes.data_as(C.POINTER(C.c_int32)), int(doc_ids.shape[0]),
+                                out.ctypes.data_as(C.POINTER(ctype))))
+        return out
+
+    def read_dict_ids(self, column, doc_ids):
+        return self._read(self.lib.pg_read_dict_ids, column, doc_ids, np.int32, C.c_int32)
+
+    def read_int_values(self, column, doc_ids):
+        return self._read(self.lib.pg_read_int_values, column, doc_ids, np.int32, C.c_int32)
+
+    def read_double_values(self, column, doc_ids):
+        return self._read(self.lib.pg_read_double_values, column, doc_ids, np.float64, C.c_double)

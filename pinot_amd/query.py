@@ -1,0 +1,175 @@
+"""Lowered query description (Python view of `pg_query`).
+
+The filter is expressed the way the reference's PredicateEvaluators leave it after dictionary lookup:
+dictId ranges / dictId sets on dictionary-encoded columns, inclusive value ranges on raw columns.  Lowering
+SQL-level predicates (values) to this form is done by the C++ host mirror (libpinot_host.so); tests may also
+build it directly.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+class Pred:
+    def __init__(self, kind, column=0, lo=0, hi=0, dict_ids=None, cardinality=0, exclusive=False, inverted=False):
+        self.kind = kind
+        self.column = column
+        self.lo = int(lo)
+        self.hi = int(hi)
+        self.exclusive = bool(exclusive)
+        self.inverted = bool(inverted)
+        self.set_words = None
+        if kind == _abi.PG_PRED_DICT_SET:
+            words = np.zeros((max(cardinality, 1) + 31) // 32, dtype=np.uint32)
+            for d in dict_ids or []:
+                words[d >> 5] |= np.uint32(1 << (d & 31))
+            self.set_words = words
+
+    @staticmethod
+    def match_all():
+        return Pred(_abi.PG_PRED_MATCH_ALL)
+
+    @staticmethod
+    def match_none():
+        return Pred(_abi.PG_PRED_MATCH_NONE)
+
+    @staticmethod
+    def dict_range(column, start, end, exclusive=False, inverted=False):
+        """startDictId <= dictId < endDictId (SortedDictionaryBasedRangePredicateEvaluator); EQ is [d, d + 1)."""
+        return Pred(_abi.PG_PRED_DICT_RANGE, column, start, end, exclusive=exclusive, inverted=inverted)
+
+    @staticmethod
+    def dict_set(column, dict_ids, cardinality, exclusive=False, inverted=False):
+        return Pred(_abi.PG_PRED_DICT_SET, column, dict_ids=list(dict_ids), cardinality=cardinality, exclusive=exclusive, inverted=inverted)
+
+    @staticmethod
+    def raw_range(column, lo, hi, exclusive=False):
+        """lo <= value <= hi, both inclusive (IntRawValueBasedRangePredicateEvaluator)."""
+        return Pred(_abi.PG_PRED_RAW_RANGE, column, lo, hi, exclusive=exclusive)
+
+
+class Node:
+    def __init__(self, op, children=(), pred=None):
+        self.op = op
+        self.children = list(children)
+        self.pred = pred
+
+
+def leaf(pred):
+    return Node(_abi.PG_FILTER_LEAF, pred=pred)
+
+
+def and_(*children):
+    return Node(_abi.PG_FILTER_AND, children)
+
+
+def or_(*children):
+    return Node(_abi.PG_FILTER_OR, children)
+
+
+def not_(child):
+    return Node(_abi.PG_FILTER_NOT, [child])
+
+
+COUNT, SUM, MIN, MAX, AVG = _abi.PG_AGG_COUNT, _abi.PG_AGG_SUM, _abi.PG_AGG_MIN, _abi.PG_AGG_MAX, _abi.PG_AGG_AVG
+
+
+class QuerySpec:
+    def __init__(self, aggregations, filter=None, group_by=()):
+        """aggregations: list of (function, column_index) with column_index -1 for COUNT(*)."""
+        self.aggregations = [(int(f), int(c)) for f, c in aggregations]
+        self.filter = filter
+        self.group_by = [int(c) for c in group_by]
+        self._build()
+
+    def _build(self):
+        nodes, preds = [], []
+
+        def walk(n):
+            if n.op == _abi.PG_FILTER_LEAF:
+                preds.append(n.pred)
+                nodes.append((n.op, len(preds) - 1, 0))
+            else:
+                for ch in n.children:
+                    walk(ch)
+                nodes.append((n.op, -1, len(n.children)))
+
+        if self.filter is not None:
+            walk(self.filter)
+        self._nodes = (_abi.pg_filter_node * max(len(nodes), 1))()
+        for i, (op, p, k) in enumerate(nodes):
+            self._nodes[i].op, self._nodes[i].predicate, self._nodes[i].num_children = op, p, k
+        self._preds = (_abi.pg_predicate * max(len(preds), 1))()
+        self._keep = []
+        for i, p in enumerate(preds):
+            cp = self._preds[i]
+            cp.kind, cp.column = p.kind, p.column
+            cp.eval = _abi.PG_EVAL_INVERTED if p.inverted else _abi.PG_EVAL_SCAN
+            cp.exclusive = 1 if p.exclusive else 0
+            cp.lo, cp.hi = p.lo, p.hi
+            if p.set_words is not None:
+                self._keep.append(p.set_words)
+                cp.set_words = p.set_words.ctypes.data_as(C.POINTER(C.c_uint32))
+                cp.num_set_words = int(p.set_words.shape[0])
+        self._aggs = (_abi.pg_aggregation * max(len(self.aggregations), 1))()
+        for i, (f, c) in enumerate(self.aggregations):
+            self._aggs[i].function, self._aggs[i].column = f, c
+        self._groups = (C.c_int32 * max(len(self.group_by), 1))(*self.group_by)
+        q = _abi.pg_query()
+        q.filter = self._nodes
+        q.num_filter_nodes = len(nodes)
+        q.num_predicates = len(preds)
+        q.predicates = self._preds
+        q.aggregations = self._aggs
+        q.num_aggregations = len(self.aggregations)
+        q.num_group_by = len(self.group_by)
+        q.group_by_columns = self._groups
+        q.num_groups_limit = 0
+        q.flags = 0
+        self.c = q
+
+
+class AggValue:
+    __slots__ = ("count", "sum", "sum_i64", "sum_exact", "min", "max")
+
+    def __init__(self, v):
+        self.count, self.sum, self.sum_i64, self.sum_exact, self.min, self.max = (
+            int(v.count), float(v.sum), int(v.sum_i64), bool(v.sum_exact), float(v.min), float(v.max))
+
+    def intermediate(self, function):
+        """The reference's intermediate result type: COUNT -> Long, SUM/MIN/MAX -> Double, AVG -> (sum, count)."""
+        if function == COUNT:
+            return self.count
+        if function == SUM:
+            return self.sum
+        if function == MIN:
+            return self.min
+        if function == MAX:
+            return self.max
+        return (self.sum, self.count)
+
+    def __repr__(self):
+        return "AggValue(count=%d sum=%r sum_i64=%d min=%r max=%r)" % (self.count, self.sum, self.sum_i64, self.min, self.max)
+
+
+class Result:
+    """Python copy of a `pg_result` (the C result is freed by the caller right after conversion)."""
+
+    def __init__(self, res, spec):
+        self.functions = [f for f, _ in spec.aggregations]
+        self.stats = (int(res.stats.num_docs_scanned), int(res.stats.num_entries_scanned_in_filter),
+                      int(res.stats.num_entries_scanned_post_filter), int(res.stats.num_total_docs))
+        self.device_ms = float(res.device_ms)
+        self.dominant_kernel_ms = float(res.dominant_kernel_ms)
+        na = int(res.num_aggregations)
+        self.aggregations = [AggValue(res.aggregations[a]) for a in range(na)] if res.aggregations else []
+        self.groups = {}
+        self.group_id_upper_bound = int(res.group_id_upper_bound)
+        for g in range(int(res.num_groups)):
+            gid = int(res.group_ids[g])
+            self.groups[gid] = [AggValue(res.group_aggregations[g * na + a]) for a in range(na)]
+
+    def intermediates(self):
+        return [v.intermediate(f) for v, f in zip(self.aggregations, self.functions)]

@@ -1,0 +1,176 @@
+"""Host-side segment construction for tests and benchmarks (Python plumbing over libpinot_host.so).
+
+Column buffers are produced by the product's C++ writers (pinot_amd/csrc/host/segment_writer.cpp) in the
+reference's on-disk layouts and handed to the engine through `pg_segment_desc`, exactly what a JNI shim
+would do with the `PinotDataBuffer`s of an `ImmutableSegment`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+_host_lib = None
+
+
+def load_host_library():
+    global _host_lib
+    if _host_lib is not None:
+        return _host_lib
+    if not os.path.exists(_abi.HOST_LIB_PATH):
+        raise ImportError("%s has not been built (make -C pinot_amd/csrc)" % _abi.HOST_LIB_PATH)
+    lib = C.CDLL(_abi.HOST_LIB_PATH)
+    i32p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    lib.ph_num_bits_per_value.restype = C.c_int32
+    lib.ph_num_bits_per_value.argtypes = [C.c_int32]
+    lib.ph_fixedbit_size.restype = C.c_int64
+    lib.ph_fixedbit_size.argtypes = [C.c_int64, C.c_int32]
+    lib.ph_fixedbit_pack.restype = None
+    lib.ph_fixedbit_pack.argtypes = [i32p, C.c_int64, C.c_int32, u8p, C.c_int32]
+    lib.ph_generate_packed_uniform.restype = None
+    lib.ph_generate_packed_uniform.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.c_int32, u8p, C.c_int32]
+    lib.ph_generate_uniform.restype = None
+    lib.ph_generate_uniform.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, i32p]
+    lib.ph_dict_write_int.restype = None
+    lib.ph_dict_write_int.argtypes = [i32p, C.c_int32, u8p]
+    lib.ph_raw_size_v2.restype = C.c_int64
+    lib.ph_raw_size_v2.argtypes = [C.c_int32, C.c_int32]
+    lib.ph_raw_write_int_v2.restype = None
+    lib.ph_raw_write_int_v2.argtypes = [i32p, C.c_int32, C.c_int32, u8p]
+    lib.ph_roaring_serialize.restype = C.c_int64
+    lib.ph_roaring_serialize.argtypes = [i32p, C.c_int64, C.c_int32, u8p]
+    lib.ph_inverted_build.restype = C.c_int64
+    lib.ph_inverted_build.argtypes = [i32p, C.c_int32, C.c_int32, C.c_int32, u8p]
+    _host_lib = lib
+    return lib
+
+
+def _i32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _u8p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def host_threads():
+    return max(1, min(32, os.cpu_count() or 1))
+
+
+class Column:
+    """One single-value INT column: forward index (+ dictionary, + optional inverted index) as raw bytes."""
+
+    def __init__(self, name, encoding, bits, cardinality, fwd, dictionary=None, inverted=None, dict_values=None):
+        self.name = name
+        self.encoding = encoding
+        self.bits = bits
+        self.cardinality = cardinality
+        self.fwd = fwd                  # np.uint8
+        self.dictionary = dictionary    # np.uint8 big-endian int32s
+        self.inverted = inverted        # np.uint8 or None
+        self.dict_values = dict_values  # np.int32 sorted values (host convenience, not handed to the engine)
+
+    @staticmethod
+    def dict_encoded(name, values, with_inverted=False, run_optimize=True):
+        """Dictionary-encode `values` the way SegmentDictionaryCreator + FixedBitSVForwardIndexWriter do."""
+        lib = load_host_library()
+        values = np.ascontiguousarray(values, dtype=np.int32)
+        dict_values, dict_ids = np.unique(values, return_inverse=True)
+        dict_ids = np.ascontiguousarray(dict_ids, dtype=np.int32)
+        return Column.from_dict_ids(name, dict_values.astype(np.int32), dict_ids, with_inverted, run_optimize)
+
+    @staticmethod
+    def from_dict_ids(name, dict_values, dict_ids, with_inverted=False, run_optimize=True):
+        lib = load_host_library()
+        dict_values = np.ascontiguousarray(dict_values, dtype=np.int32)
+        dict_ids = np.ascontiguousarray(dict_ids, dtype=np.int32)
+        card = int(dict_values.shape[0])
+        n = int(dict_ids.shape[0])
+        bits = int(lib.ph_num_bits_per_value(card - 1))
+        fwd = np.zeros(int(lib.ph_fixedbit_size(n, bits)), dtype=np.uint8)
+        if n:
+            lib.ph_fixedbit_pack(_i32p(dict_ids), n, bits, _u8p(fwd), host_threads())
+        dictionary = np.zeros(card * 4, dtype=np.uint8)
+        lib.ph_dict_write_int(_i32p(dict_values), card, _u8p(dictionary))
+        inverted = None
+        if with_inverted:
+            size = int(lib.ph_inverted_build(_i32p(dict_ids), n, card, int(run_optimize), None))
+            inverted = np.zeros(size, dtype=np.uint8)
+            lib.ph_inverted_build(_i32p(dict_ids), n, card, int(run_optimize), _u8p(inverted))
+        return Column(name, _abi.PG_FWD_FIXED_BIT_DICT, bits, card, fwd, dictionary, inverted, dict_values)
+
+    @staticmethod
+    def synthetic_uniform(name, num_docs, dict_values, seed):
+        """dictId_i = splitmix64-based uniform over the dictionary, generated and packed by the C++ writer."""
+        lib = load_host_library()
+        dict_values = np.ascontiguousarray(dict_values, dtype=np.int32)
+        card = int(dict_values.shape[0])
+        bits = int(lib.ph_num_bits_per_value(card - 1))
+        fwd = np.zeros(int(lib.ph_fixedbit_size(num_docs, bits)), dtype=np.uint8)
+        lib.ph_generate_packed_uniform(seed, num_docs, card, bits, _u8p(fwd), host_threads())
+        dictionary = np.zeros(card * 4, dtype=np.uint8)
+        lib.ph_dict_write_int(_i32p(dict_values), card, _u8p(dictionary))
+        return Column(name, _abi.PG_FWD_FIXED_BIT_DICT, bits, card, fwd, dictionary, None, dict_values)
+
+    @staticmethod
+    def raw(name, values, docs_per_chunk=1000):
+        lib = load_host_library()
+        values = np.ascontiguousarray(values, dtype=np.int32)
+        n = int(values.shape[0])
+        fwd = np.zeros(int(lib.ph_raw_size_v2(n, docs_per_chunk)), dtype=np.uint8)
+        lib.ph_raw_write_int_v2(_i32p(values), n, docs_per_chunk, _u8p(fwd))
+        return Column(name, _abi.PG_FWD_RAW_FIXED_BYTE, 32, 0, fwd)
+
+    def value_of(self, dict_id):
+        return int(self.dict_values[dict_id])
+
+
+def synthetic_dict_ids(seed, start, count, cardinality):
+    lib = load_host_library()
+    out = np.zeros(count, dtype=np.int32)
+    lib.ph_generate_uniform(seed, start, count, cardinality, _i32p(out))
+    return out
+
+
+class SegmentData:
+    """Host buffers of one segment + the `pg_segment_desc` that points at them."""
+
+    def __init__(self, name, num_docs, columns, device_id=-1):
+        self.name = name
+        self.num_docs = int(num_docs)
+        self.columns = list(columns)
+        self._name_b = name.encode()
+        self._col_names = [c.name.encode() for c in self.columns]
+        self._descs = (_abi.pg_column_desc * max(len(self.columns), 1))()
+        for i, c in enumerate(self.columns):
+            d = self._descs[i]
+            d.name = self._col_names[i]
+            d.stored_type = _abi.PG_TYPE_INT
+            d.fwd_encoding = c.encoding
+            d.bits_per_value = c.bits
+            d.cardinality = c.cardinality
+            d.fwd_data = c.fwd.ctypes.data
+            d.fwd_size = c.fwd.nbytes
+            if c.dictionary is not None:
+                d.dict_data = c.dictionary.ctypes.data
+                d.dict_size = c.dictionary.nbytes
+            if c.inverted is not None:
+                d.inv_data = c.inverted.ctypes.data
+                d.inv_size = c.inverted.nbytes
+        self.desc = _abi.pg_segment_desc()
+        self.desc.name = self._name_b
+        self.desc.crc = 0
+        self.desc.num_docs = self.num_docs
+        self.desc.num_columns = len(self.columns)
+        self.desc.columns = self._descs
+        self.desc.device_id = device_id
+
+    def column_index(self, name):
+        for i, c in enumerate(self.columns):
+            if c.name == name:
+                return i
+        raise KeyError(name)
+
+    def column(self, name):
+        return self.columns[self.column_index(name)]

@@ -1,0 +1,85 @@
+"""CPU tests: pin the oracle against the reference's own golden vectors (test_data-sv.avro fixture)."""
+import numpy as np
+
+from oracle import oracle
+from pinot_amd import query as Q
+import helpers as H
+
+
+def _check_inner(res, want):
+    count, s1, mx3, mn6, avg7 = res.aggregations
+    assert count.intermediate(Q.COUNT) == want["count"]
+    assert s1.intermediate(Q.SUM) == float(want["sum_column1"]) and s1.sum_i64 == want["sum_column1"]
+    assert mx3.intermediate(Q.MAX) == float(want["max_column3"])
+    assert mn6.intermediate(Q.MIN) == float(want["min_column6"])
+    assert avg7.intermediate(Q.AVG) == (float(want["avg_column7"][0]), want["avg_column7"][1])
+    docs, in_filter, post_filter, total = want["stats"]
+    assert res.stats[0] == docs and res.stats[2] == post_filter and res.stats[3] == total
+
+
+def test_inner_segment_aggregation_goldens():
+    # InnerSegmentAggregationSingleValueQueriesTest.testAggregationOnly :44-61
+    g = H.load_golden_queries()["inner_segment"]
+    seg = H.golden_segment()
+    _check_inner(oracle.execute(seg, Q.QuerySpec(H.golden_aggregations(seg))), g["unfiltered"])
+    for inverted in (False, True):
+        res = oracle.execute(seg, Q.QuerySpec(H.golden_aggregations(seg), filter=H.golden_filter(seg, inverted)))
+        _check_inner(res, g["filtered"])
+
+
+def test_inner_segment_group_by_goldens():
+    # testSmallAggregationGroupBy :96-112 (GROUP BY column9, ARRAY_BASED holder)
+    g = H.load_golden_queries()["inner_segment_group_by_column9"]
+    seg = H.golden_segment()
+    c9 = seg.column("column9")
+    for key, flt in (("unfiltered", None), ("filtered", H.golden_filter(seg))):
+        res = oracle.execute(seg, Q.QuerySpec(H.golden_aggregations(seg), filter=flt, group_by=[seg.column_index("column9")]))
+        want = g[key]
+        gid = int(np.searchsorted(c9.dict_values, want["key"]))
+        assert c9.value_of(gid) == want["key"]
+        count, s1, mx3, mn6, avg7 = res.groups[gid]
+        assert count.intermediate(Q.COUNT) == want["count"]
+        assert s1.intermediate(Q.SUM) == float(want["sum_column1"])
+        assert mx3.intermediate(Q.MAX) == float(want["max_column3"])
+        assert mn6.intermediate(Q.MIN) == float(want["min_column6"])
+        assert avg7.intermediate(Q.AVG) == (float(want["avg_column7"][0]), want["avg_column7"][1])
+        assert res.stats[0] == want["stats"][0] and res.stats[2] == want["stats"][2] and res.stats[3] == want["stats"][3]
+
+
+def test_inter_segment_goldens_by_merging_four_copies():
+    # InterSegmentAggregationSingleValueQueriesTest: 4 identical segments through combine + reduce;
+    # merge rule = AggregationFunction.merge (SUM '+', COUNT '+'), AggregationResultsBlockMerger.java:34-44
+    g = H.load_golden_queries()["inter_segment_x4"]
+    seg = H.golden_segment()
+    ci = seg.column_index
+    aggs = [(Q.COUNT, -1), (Q.SUM, ci("column1")), (Q.SUM, ci("column3"))]
+    for key, flt in (("unfiltered", None), ("filtered", H.golden_filter(seg))):
+        r = oracle.execute(seg, Q.QuerySpec(aggs, filter=flt))
+        count = sum(r.aggregations[0].intermediate(Q.COUNT) for _ in range(4))
+        s1 = 0.0
+        s3 = 0.0
+        for _ in range(4):
+            s1 = s1 + r.aggregations[1].intermediate(Q.SUM)
+            s3 = s3 + r.aggregations[2].intermediate(Q.SUM)
+        assert count == g["count"][key]
+        assert s1 == g["sum_column1"][key] and s3 == g["sum_column3"][key]
+    # GROUP BY column9 ORDER BY COUNT(*) DESC LIMIT 1 -> 64420 / 17080 (InterSegment...testCount :60-67)
+    for want, flt in ((64420, None), (17080, H.golden_filter(seg))):
+        r = oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1)], filter=flt, group_by=[ci("column9")]))
+        assert 4 * max(v[0].count for v in r.groups.values()) == want
+
+
+def test_oracle_matches_numpy_on_fixture_filters():
+    d = H.load_golden_columns()
+    seg = H.golden_segment()
+    c1 = d["column1"].astype(np.int64)
+    m = (d["column17"] == d["column17"][0]) & (d["column18"] > np.median(d["column18"]))
+    flt = Q.and_(Q.leaf(H.eq_pred(seg, "column17", int(d["column17"][0]), inverted=True)),
+                 Q.leaf(H.range_pred(seg, "column18", lower=int(np.median(d["column18"])), lower_inclusive=False)))
+    r = oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, seg.column_index("column1"))], filter=flt))
+    assert r.aggregations[0].count == int(m.sum())
+    assert r.aggregations[1].sum_i64 == int(c1[m].sum())
+    words, card = oracle.filter_bitmap(seg, Q.QuerySpec([], filter=flt))
+    assert card == int(m.sum())
+    bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:30000].astype(bool)
+    assert (bits == m).all()

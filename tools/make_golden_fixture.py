@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/test_data_sv.npz from the reference's own test fixture.
+
+Source: /root/reference/pinot-core/src/test/resources/data/test_data-sv.avro (30 000 rows, null codec, no
+nulls), the Avro file behind BaseSingleValueQueriesTest (pinot-core/src/test/java/org/apache/pinot/queries/
+BaseSingleValueQueriesTest.java:53-106).  /root/reference does not exist on the GPU box, so the columns the
+golden queries touch are re-encoded here as a compressed .npz that travels with the repo:
+  int columns      -> int32 arrays
+  string columns   -> sorted unique values (the dictionary Pinot would build) + int32 dictIds
+The expected results live in tests/golden/golden_queries.json, copied by hand from
+InnerSegmentAggregationSingleValueQueriesTest.java:44-112 and InterSegmentAggregationSingleValueQueriesTest.java.
+
+Run in the build container only:  python tools/make_golden_fixture.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+SRC = "/root/reference/pinot-core/src/test/resources/data/test_data-sv.avro"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "test_data_sv.npz")
+
+# columns of BaseSingleValueQueriesTest.SCHEMA
+INT_COLUMNS = ["column1", "column3", "column6", "column7", "column9", "column17", "column18", "daysSinceEpoch"]
+STRING_COLUMNS = ["column5", "column11", "column12"]
+
+
+class AvroReader:
+    """Minimal Avro object-container reader: null codec, records of ["null", T] unions, T in {int, string}."""
+
+    def __init__(self, data):
+        self.b = data
+        self.pos = 0
+
+    def read_long(self):
+        shift = 0
+        n = 0
+        while True:
+            c = self.b[self.pos]
+            self.pos += 1
+            n |= (c & 0x7F) << shift
+            if not c & 0x80:
+                break
+            shift += 7
+        return (n >> 1) ^ -(n & 1)
+
+    def read_bytes(self):
+        n = self.read_long()
+        v = self.b[self.pos:self.pos + n]
+        self.pos += n
+        return v
+
+
+def read_avro(path):
+    r = AvroReader(open(path, "rb").read())
+    assert r.b[:4] == b"Obj\x01"
+    r.pos = 4
+    meta = {}
+    while True:
+        cnt = r.read_long()
+        if cnt == 0:
+            break
+        if cnt < 0:
+            r.read_long()
+            cnt = -cnt
+        for _ in range(cnt):
+            k = r.read_bytes()
+            meta[k] = r.read_bytes()
+    assert meta.get(b"avro.codec", b"null") == b"null"
+    schema = json.loads(meta[b"avro.schema"])
+    fields = [(f["name"], [t for t in f["type"] if t != "null"][0], f["type"].index("null")) for f in schema["fields"]]
+    sync = r.b[r.pos:r.pos + 16]
+    r.pos += 16
+    rows = {name: [] for name, _, _ in fields}
+    while r.pos < len(r.b):
+        nrec = r.read_long()
+        r.read_long()  # block byte size
+        for _ in range(nrec):
+            for name, typ, null_idx in fields:
+                branch = r.read_long()
+                if branch == null_idx:
+                    raise ValueError("unexpected null in fixture")
+                rows[name].append(r.read_long() if typ == "int" else r.read_bytes().decode("utf-8"))
+        assert r.b[r.pos:r.pos + 16] == sync
+        r.pos += 16
+    return rows
+
+
+def main():
+    if not os.path.exists(SRC):
+        sys.exit("reference fixture not found (this script only runs in the build container)")
+    rows = read_avro(SRC)
+    n = len(rows["column1"])
+    assert n == 30000
+    out = {}
+    for c in INT_COLUMNS:
+        out[c] = np.asarray(rows[c], dtype=np.int32)
+    for c in STRING_COLUMNS:
+        values = sorted(set(rows[c]))  # Pinot sorts string dictionaries by UTF-8 bytes; ASCII here so str order matches
+        index = {v: i for i, v in enumerate(values)}
+        out[c + "__dict"] = np.asarray(values, dtype="U")
+        out[c + "__ids"] = np.asarray([index[v] for v in rows[c]], dtype=np.int32)
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    # sanity: the unfiltered goldens of InnerSegmentAggregationSingleValueQueriesTest.java:50
+    assert int(out["column1"].astype(np.int64).sum()) == 32317185437847
+    assert int(out["column3"].max()) == 2147419555
+    assert int(out["column6"].min()) == 1689277
+    assert int(out["column7"].astype(np.int64).sum()) == 28175373944314
+    print("unfiltered goldens reproduce")
+
+
+if __name__ == "__main__":
+    main()
