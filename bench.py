@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- filtered SUM over 1 B-row dictionary-encoded segments, one segment per GPU (BASELINE.json configs[1]/[3]).
+
+Workload C2b: SELECT SUM(v) FROM t WHERE f < 100
+  v: INT, dictionary {7k+3 : k < 100000} -> 17-bit fixed-bit forward index (2.125 GB), dictIds uniform, seed 2r+1
+  f: INT, dictionary {0..999}            -> 10-bit fixed-bit forward index (1.25 GB),  dictIds uniform, seed 2r+2
+  predicate lowered to dictId range [0, 100) (10 % selectivity); r = rank (segment r lives on GPU r).
+A step = one pg_execute over the whole resident segment (fused scan -> filter -> dictionary gather -> SUM kernel +
+a one-block partial reduction + 72-byte readback).  Columns are generated on the host by the product's C++ writer
+in Pinot's on-disk layout and copied to HBM by pg_segment_open before the timed region.
+
+Launch:  python bench.py --gpus 1 --steps 20 --warmup 3
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s float4-copy ceiling)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=int(os.environ.get("PINOT_BENCH_ROWS", 1_000_000_000)))
+    ap.add_argument("--threshold", type=int, default=100, help="f < threshold (dictIds [0, threshold) of 1000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra", action="store_true", help="also time the other BASELINE.md query shapes (stderr)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from pinot_amd import _abi
+    from pinot_amd import query as Q
+    from pinot_amd import segment as S
+    from pinot_amd.engine import Engine
+
+    n = args.rows
+    t0 = time.time()
+    v = S.Column.synthetic_uniform("v", n, (np.arange(100000, dtype=np.int64) * 7 + 3).astype(np.int32), seed=2 * rank + 1)
+    f = S.Column.synthetic_uniform("f", n, np.arange(1000, dtype=np.int32), seed=2 * rank + 2)
+    seg = S.SegmentData("c2b_%d" % rank, n, [v, f])
+    gen_s = time.time() - t0
+    spec = Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, args.threshold)))
+    algorithmic_bytes = v.fwd.nbytes + f.fwd.nbytes   # B(f) + B(v) = 3.375 B/row
+
+    engine = Engine(device_id=local_rank, time_kernels=True)
+    t0 = time.time()
+    gseg = engine.open(seg)
+    h2d_s = time.time() - t0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = _abi.pg_result()
+    lib = engine.lib
+
+    def step():
+        st = gseg.execute_raw(spec, res)
+        if st != _abi.PG_OK:
+            raise RuntimeError(lib.pg_last_error().decode())
+        out = (res.aggregations[0].sum_i64, res.aggregations[0].count, res.dominant_kernel_ms, res.device_ms)
+        lib.pg_result_free(C.byref(res))
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    device_ms = []
+    last = None
+    for _ in range(args.steps):
+        last = step()
+        kernel_ms.append(last[2])
+        device_ms.append(last[3])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # host-side merge of the per-segment partials (SumAggregationFunction.merge is '+'): gather, then add on rank 0
+        part = torch.tensor([last[0], last[1]], dtype=torch.int64, device="cuda")
+        parts = [torch.zeros_like(part) for _ in range(world)]
+        dist.all_gather(parts, part)
+        merged_sum = float(0.0)
+        merged_count = 0
+        for p in parts:
+            merged_sum = merged_sum + float(int(p[0].item()))
+            merged_count += int(p[1].item())
+    else:
+        merged_sum, merged_count = float(last[0]), last[1]
+
+    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    result = None
+    if rank == 0:
+        rows_per_s = world * n * args.steps / elapsed
+        achieved = algorithmic_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        result = {
+            "metric": "scanned rows/sec + achieved HBM GB/s, filtered SUM on 1B-row segment",
+            "value": rows_per_s,
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "config": {"workload": "C2b: SELECT SUM(v) WHERE f < t, %d rows/segment, v 17-bit dict (C=100000), f 10-bit dict (C=1000), "
+                                   "selectivity %.0f%%, one segment per GPU, host-side merge" % (n, args.threshold / 10.0),
+                       "rows_per_segment": n, "segments": world, "algorithmic_bytes_per_row": algorithmic_bytes / n},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "kernel": "scan_agg_kernel", "kernel_ms": avg_kernel_ms,
+                         "algorithmic_bytes_per_launch": algorithmic_bytes},
+            "hbm_GBps_whole_step": world * algorithmic_bytes * args.steps / elapsed / 1e9,
+            "result": {"sum": merged_sum, "count": merged_count},
+            "setup": {"host_generate_s": gen_s, "segment_open_h2d_s": h2d_s, "device_bytes": gseg.device_bytes(),
+                      "h2d_GBps": gseg.device_bytes() / h2d_s / 1e9, "host_threads": S.host_threads()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle
+            ores = _abi.pg_result()
+            t0 = time.perf_counter()
+            rc = oracle.execute_raw(seg, spec, ores)
+            cpu_s = time.perf_counter() - t0
+            assert rc == 0
+            osum, ocount = ores.aggregations[0].sum_i64, ores.aggregations[0].count
+            oracle.load().po_result_free(C.byref(ores))
+            result["cpu_baseline"] = {"value": n / cpu_s, "unit": "rows/s", "cores": 1, "kind": "port",
+                                      "sample": "the full workload (%d rows, same segment, same query) through the C oracle on one host core "
+                                                "(one segment = one thread, as in BaseCombineOperator); %.1f s" % (n, cpu_s),
+                                      "host_cores_available": os.cpu_count()}
+            result["parity"] = {"bit_exact_vs_oracle": bool(osum == last[0] and ocount == last[1]), "oracle_sum": osum, "gpu_sum": last[0]}
+    if args.extra and rank == 0 and world == 1:
+        run_extra(gseg, seg, n, lib, Q, _abi, C)
+    gseg.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def run_extra(gseg, seg, n, lib, Q, _abi, C):
+    """Other BASELINE.md shapes on the same resident segment (diagnostics on stderr, not the bench line)."""
+    shapes = {
+        "C2a SUM(v) WHERE v in 10% range": (Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, 45000, 55000))), seg.columns[0].fwd.nbytes),
+        "C2a 50%": (Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, 25000, 75000))), seg.columns[0].fwd.nbytes),
+        "C2a 90%": (Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, 5000, 95000))), seg.columns[0].fwd.nbytes),
+        "C2b 1%": (Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 10))), seg.columns[0].fwd.nbytes + seg.columns[1].fwd.nbytes),
+        "C2b 50%": (Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 500))), seg.columns[0].fwd.nbytes + seg.columns[1].fwd.nbytes),
+        "COUNT WHERE f<100": (Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), seg.columns[1].fwd.nbytes),
+        "MAX(v) WHERE f<100": (Q.QuerySpec([(Q.MAX, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), seg.columns[0].fwd.nbytes + seg.columns[1].fwd.nbytes),
+        "SUM(v),COUNT GROUP BY f": (Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1)], group_by=[1]), seg.columns[0].fwd.nbytes + seg.columns[1].fwd.nbytes),
+        "MAX(v) GROUP BY f": (Q.QuerySpec([(Q.MAX, 0)], group_by=[1]), seg.columns[0].fwd.nbytes + seg.columns[1].fwd.nbytes),
+    }
+    res = _abi.pg_result()
+    for name, (spec, nbytes) in shapes.items():
+        ms = []
+        for i in range(6):
+            st = gseg.execute_raw(spec, res)
+            if st != _abi.PG_OK:
+                print("extra %s failed: %s" % (name, lib.pg_last_error().decode()), file=sys.stderr)
+                break
+            if i:
+                ms.append(res.dominant_kernel_ms)
+            lib.pg_result_free(C.byref(res))
+        if ms:
+            k = sum(ms) / len(ms)
+            print(json.dumps({"extra": name, "kernel_ms": k, "rows_per_s": n / k * 1e3, "GBps": nbytes / k / 1e6}), file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

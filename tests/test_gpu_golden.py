@@ -1,0 +1,62 @@
+"""GPU tests against the reference's own golden vectors (test_data-sv.avro fixture) through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from pinot_amd import query as Q
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_inner(vals, want):
+    count, s1, mx3, mn6, avg7 = vals
+    assert count.intermediate(Q.COUNT) == want["count"]
+    assert s1.intermediate(Q.SUM) == float(want["sum_column1"]) and s1.sum_i64 == want["sum_column1"]
+    assert mx3.intermediate(Q.MAX) == float(want["max_column3"])
+    assert mn6.intermediate(Q.MIN) == float(want["min_column6"])
+    assert avg7.intermediate(Q.AVG) == (float(want["avg_column7"][0]), want["avg_column7"][1])
+
+
+def test_inner_segment_goldens(engine):
+    g = H.load_golden_queries()
+    seg = H.golden_segment()
+    c9 = seg.column("column9")
+    with engine.open(seg) as gseg:
+        for key, inverted in (("unfiltered", False), ("filtered", False), ("filtered", True)):
+            flt = None if key == "unfiltered" else H.golden_filter(seg, inverted)
+            spec = Q.QuerySpec(H.golden_aggregations(seg), filter=flt)
+            res = gseg.execute(spec)
+            want = g["inner_segment"][key]
+            _check_inner(res.aggregations, want)
+            assert (res.stats[0], res.stats[2], res.stats[3]) == (want["stats"][0], want["stats"][2], want["stats"][3])
+            H.assert_results_equal(res, oracle.execute(seg, spec))
+            gspec = Q.QuerySpec(H.golden_aggregations(seg), filter=flt, group_by=[seg.column_index("column9")])
+            gres = gseg.execute(gspec)
+            gw = g["inner_segment_group_by_column9"][key]
+            gid = int(np.searchsorted(c9.dict_values, gw["key"]))
+            _check_inner(gres.groups[gid], gw)
+            assert (gres.stats[0], gres.stats[2], gres.stats[3]) == (gw["stats"][0], gw["stats"][2], gw["stats"][3])
+            H.assert_results_equal(gres, oracle.execute(seg, gspec))
+
+
+def test_inter_segment_goldens(engine):
+    g = H.load_golden_queries()["inter_segment_x4"]
+    seg = H.golden_segment()
+    ci = seg.column_index
+    aggs = [(Q.COUNT, -1), (Q.SUM, ci("column1")), (Q.SUM, ci("column3"))]
+    segments = [engine.open(seg) for _ in range(4)]
+    try:
+        for key in ("unfiltered", "filtered"):
+            flt = None if key == "unfiltered" else H.golden_filter(seg)
+            parts = [s.execute(Q.QuerySpec(aggs, filter=flt)) for s in segments]
+            count = sum(p.aggregations[0].intermediate(Q.COUNT) for p in parts)
+            s1 = s3 = 0.0
+            for p in parts:   # SumAggregationFunction.merge: double '+'
+                s1 = s1 + p.aggregations[1].intermediate(Q.SUM)
+                s3 = s3 + p.aggregations[2].intermediate(Q.SUM)
+            assert count == g["count"][key]
+            assert s1 == g["sum_column1"][key] and s3 == g["sum_column3"][key]
+    finally:
+        for s in segments:
+            s.close()

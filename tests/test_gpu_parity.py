@@ -1,0 +1,295 @@
+"""GPU parity tests: the HIP path behind the C ABI against the CPU oracle on the same seeded inputs (bit exact)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from pinot_amd import _abi
+from pinot_amd import query as Q
+from pinot_amd import segment as S
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+ALL_AGGS = lambda c: [(Q.COUNT, -1), (Q.SUM, c), (Q.MIN, c), (Q.MAX, c), (Q.AVG, c)]
+
+
+def run_both(engine, seg, spec, check_stats=True):
+    with engine.open(seg) as gseg:
+        got = gseg.execute(spec)
+    want = oracle.execute(seg, spec)
+    H.assert_results_equal(got, want, check_stats)
+    return got, want
+
+
+def test_library_is_the_hip_build(engine):
+    name, cus, hbm = engine.device_info()
+    assert name.startswith("gfx950"), name
+    assert cus >= 200 and hbm > 200 * 2 ** 30
+
+
+@pytest.mark.parametrize("bits", list(range(1, 23)))
+def test_every_bit_width_filter_and_aggregate(engine, bits):
+    """FixedBitIntReaderTest.java:52-84 runs all 31 widths; widths whose dictionary fits comfortably use
+    full-range dictIds here (cardinality = 2^bits or one less)."""
+    rng = np.random.default_rng(100 + bits)
+    card = 2 ** bits - (bits % 2) if bits > 1 else 2
+    n = 4099 + 13 * bits
+    col, ids, dv = H.random_dict_column(rng, "v", n, card, value_stride=5)
+    seg = S.SegmentData("w%d" % bits, n, [col])
+    lo, hi = card // 4, max(card // 4 + 1, (3 * card) // 4)
+    spec = Q.QuerySpec(ALL_AGGS(0), filter=Q.leaf(Q.Pred.dict_range(0, lo, hi)))
+    got, _ = run_both(engine, seg, spec)
+    m = (ids >= lo) & (ids < hi)
+    assert got.aggregations[0].count == int(m.sum())
+    assert got.aggregations[1].sum_i64 == int(dv[ids[m]].astype(np.int64).sum())
+    run_both(engine, seg, Q.QuerySpec(ALL_AGGS(0)))
+
+
+@pytest.mark.parametrize("bits", [23, 25, 26, 29, 31])
+def test_wide_bit_widths_with_forced_width(engine, bits):
+    """Widths whose real dictionary would be GBs: the stream is packed at `bits` bits with a small dictionary, so
+    the kernel's wide decode path (26..31 bits) is exercised on values whose low bits vary."""
+    rng = np.random.default_rng(bits)
+    card, n = 50000, 10007
+    dict_values = (np.arange(card, dtype=np.int64) * 11 - 70000).astype(np.int32)
+    ids = rng.integers(0, card, n).astype(np.int32)
+    col = S.Column.from_dict_ids("v", dict_values, ids)
+    host = S.load_host_library()
+    col.bits = bits
+    col.fwd = np.zeros(int(host.ph_fixedbit_size(n, bits)), dtype=np.uint8)
+    host.ph_fixedbit_pack(S._i32p(ids), n, bits, S._u8p(col.fwd), 2)
+    seg = S.SegmentData("wide%d" % bits, n, [col])
+    run_both(engine, seg, Q.QuerySpec(ALL_AGGS(0), filter=Q.leaf(Q.Pred.dict_range(0, 1000, 40000))))
+
+
+def test_full_range_26_bit_dictionary(engine):
+    """A real 2^26-entry dictionary (256 MB) so that dictIds use all 26 bits (kWide path, 5-byte spans)."""
+    rng = np.random.default_rng(26)
+    bits, n = 26, 300000
+    card = 2 ** bits
+    dict_values = np.arange(card, dtype=np.int32) - 2 ** 25
+    ids = rng.integers(0, card, n).astype(np.int32)
+    ids[:4] = [card - 1, 0, card - 1, 1]
+    col = S.Column.from_dict_ids("v", dict_values, ids)
+    assert col.bits == 26
+    seg = S.SegmentData("full26", n, [col])
+    got, _ = run_both(engine, seg, Q.QuerySpec(ALL_AGGS(0), filter=Q.leaf(Q.Pred.dict_range(0, card // 3, card))))
+    m = ids >= card // 3
+    assert got.aggregations[1].sum_i64 == int(dict_values[ids[m]].astype(np.int64).sum())
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 2047, 2048, 2049, 4096, 10000])
+def test_ragged_sizes(engine, n):
+    rng = np.random.default_rng(n)
+    card = 37
+    dict_values = np.arange(card, dtype=np.int32) * 3 + 1
+    ids = rng.integers(0, card, n).astype(np.int32)
+    seg = S.SegmentData("n%d" % n, n, [S.Column.from_dict_ids("v", dict_values, ids), S.Column.raw("r", (ids * 2 - 5).astype(np.int32))])
+    run_both(engine, seg, Q.QuerySpec(ALL_AGGS(0) + [(Q.SUM, 1), (Q.MAX, 1)], filter=Q.leaf(Q.Pred.dict_range(0, 5, 30))))
+    run_both(engine, seg, Q.QuerySpec(ALL_AGGS(0)))
+    run_both(engine, seg, Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, 5, 30)), group_by=[0]))
+
+
+def _three_column_segment(rng, n, with_inverted=False):
+    a, ida, dva = H.random_dict_column(rng, "a", n, 1000, with_inverted=with_inverted)
+    b, idb, dvb = H.random_dict_column(rng, "b", n, 13, with_inverted=with_inverted)
+    c, idc, dvc = H.random_dict_column(rng, "c", n, 70000, value_stride=3)
+    raw_vals = rng.integers(-1000, 1000, n).astype(np.int32)
+    seg = S.SegmentData("three", n, [a, b, c, S.Column.raw("r", raw_vals)])
+    return seg, (ida, idb, idc, raw_vals)
+
+
+def test_filter_trees_and_predicate_kinds(engine):
+    rng = np.random.default_rng(7)
+    n = 50021
+    seg, (ida, idb, idc, raw) = _three_column_segment(rng, n)
+    P = Q.Pred
+    filters = {
+        "and": Q.and_(Q.leaf(P.dict_range(0, 100, 900)), Q.leaf(P.dict_range(1, 2, 9))),
+        "or": Q.or_(Q.leaf(P.dict_range(0, 0, 10)), Q.leaf(P.dict_range(2, 60000, 70000))),
+        "not": Q.not_(Q.leaf(P.dict_range(1, 3, 4))),
+        "neq": Q.leaf(P.dict_range(1, 3, 4, exclusive=True)),
+        "in": Q.leaf(P.dict_set(0, [1, 5, 33, 64, 999], 1000)),
+        "not_in": Q.leaf(P.dict_set(1, [0, 12], 13, exclusive=True)),
+        "raw": Q.leaf(P.raw_range(3, -10, 500)),
+        "raw_and_dict": Q.and_(Q.leaf(P.raw_range(3, 0, 2 ** 31 - 1)), Q.leaf(P.dict_set(2, list(range(0, 70000, 3)), 70000))),
+        "nested": Q.and_(Q.leaf(P.dict_range(0, 50, 950)),
+                         Q.or_(Q.leaf(P.dict_range(1, 0, 3)), Q.not_(Q.leaf(P.dict_set(2, list(range(100, 30000)), 70000)))),
+                         Q.leaf(P.match_all()), Q.not_(Q.leaf(P.match_none()))),
+        "none": Q.and_(Q.leaf(P.dict_range(0, 0, 1000)), Q.leaf(P.match_none())),
+        "empty_range": Q.leaf(P.dict_range(0, 10, 10)),
+        "all": Q.leaf(P.match_all()),
+        "five_leaves": Q.or_(Q.and_(Q.leaf(P.dict_range(0, 0, 500)), Q.leaf(P.dict_range(1, 0, 6)), Q.leaf(P.dict_range(2, 0, 35000))),
+                             Q.and_(Q.leaf(P.dict_range(0, 500, 1000)), Q.leaf(P.raw_range(3, -5, 5)))),
+    }
+    aggs = [(Q.COUNT, -1), (Q.SUM, 2), (Q.MIN, 0), (Q.MAX, 3), (Q.AVG, 1), (Q.SUM, 3), (Q.MAX, 2)]
+    with engine.open(seg) as gseg:
+        for name, flt in filters.items():
+            spec = Q.QuerySpec(aggs, filter=flt)
+            H.assert_results_equal(gseg.execute(spec), oracle.execute(seg, spec))
+            gw, gc = gseg.filter_bitmap(Q.QuerySpec([], filter=flt))
+            ow, oc = oracle.filter_bitmap(seg, Q.QuerySpec([], filter=flt))
+            assert gc == oc, name
+            assert (gw == ow).all(), name
+
+
+def test_same_column_filter_and_sum_like_c2a(engine):
+    rng = np.random.default_rng(11)
+    n = 300007
+    v, ids, dv = H.random_dict_column(rng, "v", n, 100000, value_stride=7)
+    assert v.bits == 17
+    seg = S.SegmentData("c2a", n, [v])
+    for lo, hi in ((45000, 55000), (25000, 75000), (5000, 95000)):
+        got, _ = run_both(engine, seg, Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(0, lo, hi))))
+        m = (ids >= lo) & (ids < hi)
+        assert got.aggregations[0].sum_i64 == int(dv[ids[m]].astype(np.int64).sum())
+
+
+def test_two_column_filtered_sum_like_c2b(engine):
+    n = 1000003
+    v = S.Column.synthetic_uniform("v", n, (np.arange(100000, dtype=np.int64) * 7 + 3).astype(np.int32), seed=1)
+    f = S.Column.synthetic_uniform("f", n, np.arange(1000, dtype=np.int32), seed=2)
+    assert (v.bits, f.bits) == (17, 10)
+    seg = S.SegmentData("c2b", n, [v, f])
+    for t in (10, 100, 500):
+        run_both(engine, seg, Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, t))))
+
+
+def test_group_by_lds_table(engine):
+    rng = np.random.default_rng(3)
+    n = 200003
+    k, idk, _ = H.random_dict_column(rng, "k", n, 1000)
+    a, ida, dva = H.random_dict_column(rng, "a", n, 100000, value_stride=7)
+    b, idb, dvb = H.random_dict_column(rng, "b", n, 65536, value_stride=2)
+    f, idf, _ = H.random_dict_column(rng, "f", n, 1000)
+    seg = S.SegmentData("c3", n, [k, a, b, f, S.Column.raw("r", rng.integers(-50, 50, n).astype(np.int32))])
+    aggs = [(Q.SUM, 1), (Q.MAX, 2), (Q.COUNT, -1), (Q.MIN, 2), (Q.AVG, 1), (Q.SUM, 4), (Q.MIN, 4)]
+    got, _ = run_both(engine, seg, Q.QuerySpec(aggs, group_by=[0]))
+    assert len(got.groups) == 1000
+    g7 = ida[idk == 7]
+    assert got.groups[7][0].sum_i64 == int(dva[g7].astype(np.int64).sum())
+    run_both(engine, seg, Q.QuerySpec(aggs, filter=Q.leaf(Q.Pred.dict_range(3, 0, 100)), group_by=[0]))
+    run_both(engine, seg, Q.QuerySpec(aggs, filter=Q.leaf(Q.Pred.dict_range(3, 0, 1)), group_by=[0]))
+    run_both(engine, seg, Q.QuerySpec(aggs, filter=Q.leaf(Q.Pred.match_none()), group_by=[0]))
+
+
+def test_group_by_multiple_keys_and_global_table(engine):
+    rng = np.random.default_rng(4)
+    n = 120001
+    k1, id1, _ = H.random_dict_column(rng, "k1", n, 90)
+    k2, id2, _ = H.random_dict_column(rng, "k2", n, 11)
+    k3, id3, _ = H.random_dict_column(rng, "k3", n, 10)
+    v, idv, dvv = H.random_dict_column(rng, "v", n, 5000)
+    seg = S.SegmentData("mk", n, [k1, k2, k3, v])
+    aggs = [(Q.COUNT, -1), (Q.SUM, 3), (Q.MAX, 3), (Q.MIN, 3)]
+    got, _ = run_both(engine, seg, Q.QuerySpec(aggs, group_by=[0, 1]))              # 990 groups, LDS table
+    gid = 5 + 3 * 90   # dictIds (5, 3): k2 * card(k1) + k1  (DictionaryBasedGroupKeyGenerator.java:312-317)
+    m = (id1 == 5) & (id2 == 3)
+    assert got.groups[gid][0].count == int(m.sum())
+    got, _ = run_both(engine, seg, Q.QuerySpec(aggs, group_by=[0, 1, 2]))           # 9900 groups x 4 words: global-memory table
+    assert got.group_id_upper_bound == 9900
+    gid = 5 + 3 * 90 + 7 * 990
+    m = (id1 == 5) & (id2 == 3) & (id3 == 7)
+    assert (gid in got.groups) == bool(m.any())
+    run_both(engine, seg, Q.QuerySpec(aggs, filter=Q.leaf(Q.Pred.dict_range(3, 100, 2000)), group_by=[2, 0]))
+    with engine.open(seg) as gseg:
+        with pytest.raises(_abi.PinotGpuError) as e:
+            gseg.execute(Q.QuerySpec(aggs, group_by=[0, 1, 3]))   # 90 * 11 * 5000 > arrayBasedThreshold
+        assert e.value.status == _abi.PG_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("run_optimize", [False, True])
+def test_inverted_index_leaves(engine, run_optimize):
+    """InvertedIndexFilterOperator + AndDocIdSet: postings (array / bitset / run containers) expanded on device,
+    ANDed with each other and with scan leaves.  Config 5's shape at CI size."""
+    rng = np.random.default_rng(9)
+    n = 400009
+    p, idp, _ = H.random_dict_column(rng, "p", n, 2, with_inverted=True, run_optimize=run_optimize)        # bitset containers
+    q, idq, _ = H.random_dict_column(rng, "q", n, 64, with_inverted=True, run_optimize=run_optimize)       # array containers
+    r, idr, _ = H.random_dict_column(rng, "r", n, 40, with_inverted=True, run_optimize=run_optimize, sorted_runs=True)  # runs
+    v, idv, dv = H.random_dict_column(rng, "v", n, 100000, value_stride=7)
+    seg = S.SegmentData("c5", n, [p, q, r, v])
+    P = Q.Pred
+    inv = lambda c, d: Q.leaf(P.dict_range(c, d, d + 1, inverted=True))
+    filters = [
+        Q.and_(inv(0, 1), inv(1, 5), inv(2, 7)),
+        Q.and_(inv(0, 0), inv(1, 63)),
+        inv(2, 39),
+        Q.and_(inv(0, 1), Q.leaf(P.dict_range(3, 0, 50000))),                                   # bitmap AND scan (applyAnd)
+        Q.or_(inv(1, 1), inv(1, 2), Q.leaf(P.dict_set(1, [7, 9, 30], 64, inverted=True))),      # IN over postings
+        Q.leaf(P.dict_range(1, 3, 4, exclusive=True, inverted=True)),                           # NOT_EQ flips over [0, numDocs)
+        Q.and_(Q.leaf(P.dict_range(2, 3, 20, inverted=True)), inv(0, 1)),                       # range served by postings
+    ]
+    aggs = [(Q.COUNT, -1), (Q.SUM, 3), (Q.MAX, 3)]
+    with engine.open(seg) as gseg:
+        for i, flt in enumerate(filters):
+            spec = Q.QuerySpec(aggs, filter=flt)
+            H.assert_results_equal(gseg.execute(spec), oracle.execute(seg, spec), check_stats=False)
+            gw, gc = gseg.filter_bitmap(Q.QuerySpec([], filter=flt))
+            ow, oc = oracle.filter_bitmap(seg, Q.QuerySpec([], filter=flt))
+            assert gc == oc and (gw == ow).all(), i
+    m = (idp == 1) & (idq == 5) & (idr == 7)
+    with engine.open(seg) as gseg:
+        got = gseg.execute(Q.QuerySpec(aggs, filter=filters[0]))
+    assert got.aggregations[0].count == int(m.sum())
+    assert got.aggregations[1].sum_i64 == int(dv[idv[m]].astype(np.int64).sum())
+
+
+def test_block_val_set_readers(engine):
+    """ForwardIndexReader.readDictIds / Dictionary.readIntValues / readDoubleValues for arbitrary docIds
+    (FixedBitSVForwardIndexReaderV2Test.java:76-110: sequential, sparse and tail docIds)."""
+    rng = np.random.default_rng(5)
+    n = 99999
+    v, ids, dv = H.random_dict_column(rng, "v", n, 30000)
+    raw_vals = rng.integers(-2 ** 31, 2 ** 31 - 1, n, dtype=np.int64).astype(np.int32)
+    seg = S.SegmentData("spi", n, [v, S.Column.raw("r", raw_vals)])
+    with engine.open(seg) as gseg:
+        for doc_ids in (np.arange(n), np.arange(17, 17 + 10000), np.sort(rng.choice(n, 5000, replace=False)),
+                        np.array([n - 2, n - 1]), np.array([0]), np.array([], dtype=np.int64)):
+            doc_ids = doc_ids.astype(np.int32)
+            assert (gseg.read_dict_ids(0, doc_ids) == ids[doc_ids]).all()
+            assert (gseg.read_dict_ids(0, doc_ids) == oracle.read_dict_ids(v.fwd, v.bits, n, doc_ids)).all() if len(doc_ids) else True
+            assert (gseg.read_int_values(0, doc_ids) == oracle.read_int_values(seg, 0, doc_ids)).all()
+            assert (gseg.read_double_values(0, doc_ids) == dv[ids[doc_ids]].astype(np.float64)).all()
+            assert (gseg.read_int_values(1, doc_ids) == raw_vals[doc_ids]).all()
+        with pytest.raises(_abi.PinotGpuError):
+            gseg.read_int_values(0, np.array([n], dtype=np.int32))
+
+
+def test_error_reporting(engine):
+    rng = np.random.default_rng(1)
+    v, _, _ = H.random_dict_column(rng, "v", 1000, 10)
+    seg = S.SegmentData("err", 1000, [v])
+    with engine.open(seg) as gseg:
+        with pytest.raises(_abi.PinotGpuError) as e:
+            gseg.execute(Q.QuerySpec([(Q.SUM, 3)]))
+        assert e.value.status == _abi.PG_ERR_INVALID_ARGUMENT and "column" in str(e.value)
+        with pytest.raises(_abi.PinotGpuError):
+            gseg.execute(Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.raw_range(0, 0, 5))))
+    bad = S.SegmentData("bad", 1001, [v])   # forward index size does not match numDocs
+    with pytest.raises(_abi.PinotGpuError) as e:
+        engine.open(bad)
+    assert "expected" in str(e.value)
+
+
+def test_concurrent_queries_on_one_segment(engine):
+    """pg_execute is re-entrant per handle: combine worker threads run different queries on the same segment."""
+    import threading
+    rng = np.random.default_rng(8)
+    n = 500000
+    v, ids, dv = H.random_dict_column(rng, "v", n, 5000)
+    seg = S.SegmentData("conc", n, [v])
+    specs = [Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(0, lo, lo + 1000))) for lo in range(0, 4000, 500)]
+    want = [oracle.execute(seg, s) for s in specs]
+    errors = []
+    with engine.open(seg) as gseg:
+        def worker(i):
+            try:
+                for _ in range(5):
+                    H.assert_results_equal(gseg.execute(specs[i]), want[i])
+            except Exception as ex:  # noqa: BLE001
+                errors.append(ex)
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(specs))]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+    assert not errors, errors

@@ -1,0 +1,183 @@
+// microbench.hip -- MI355X measurements that drive the kernel design (DESIGN.md section "measured constants"):
+// streaming-read ceiling, L2-resident dictionary gather rate (dense / sparse), LDS gather and LDS atomic rates.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/microbench.hip -o tools/microbench ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+// 1. streaming read-reduce, 16 B per lane per load
+__global__ __launch_bounds__(256) void stream_read(const uint4* __restrict__ src, size_t n16, unsigned long long* out) {
+  unsigned long long acc = 0;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+    uint4 v = src[i];
+    acc += v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x1234567ull) out[0] = acc;
+}
+
+// 1b. streaming through LDS-DMA: each wave pulls 4 KiB chunks into LDS and reads them back
+__global__ __launch_bounds__(256) void stream_read_dma(const uint8_t* __restrict__ src, size_t nbytes, unsigned long long* out) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 4096];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t* slot = lds + wave * 4096;
+  unsigned long long acc = 0;
+  size_t nchunks = nbytes / 4096;
+  size_t total_waves = (size_t)gridDim.x * 4;
+  for (size_t c = (size_t)blockIdx.x * 4 + wave; c < nchunks; c += total_waves) {
+    const uint8_t* p = src + c * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(p + j * 1024 + lane * 16), (lds_void_t*)(slot + j * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4 v = *reinterpret_cast<const uint4*>(slot + j * 1024 + lane * 16);
+      acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+  }
+  if (acc == 0x1234567ull) out[0] = acc;
+}
+
+// 2. gather from a table in global memory (L2 resident): `active_pct` percent of lanes do a real gather,
+// the others present an out-of-range buffer offset (returns 0, no memory access).
+__global__ __launch_bounds__(256) void gather_global(const int32_t* __restrict__ table, int table_entries, int iters, int active_pct, unsigned long long* out) {
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, table_entries * 4, 0x00020000);
+  uint32_t x = mix32(blockIdx.x * 256u + threadIdx.x + 1u);
+  long long acc = 0;
+  for (int it = 0; it < iters; it += 8) {
+    int v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      x = mix32(x + 0x9e3779b9u);
+      const uint32_t idx = (uint32_t)(((unsigned long long)x * (unsigned)table_entries) >> 32);
+      const bool active = (mix32(x ^ 0x55555555u) % 100u) < (unsigned)active_pct;
+      v[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, active ? idx * 4u : 0xFFFFFFFFu, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j];
+  }
+  if (acc == 0x1234567ll) out[0] = acc;
+}
+
+// 3. gather from a table staged in LDS
+__global__ __launch_bounds__(256) void gather_lds(const int32_t* __restrict__ table, int table_entries, int iters, unsigned long long* out) {
+  extern __shared__ int32_t ltab[];
+  for (int i = threadIdx.x; i < table_entries; i += blockDim.x) ltab[i] = table[i];
+  __syncthreads();
+  uint32_t x = mix32(blockIdx.x * 256u + threadIdx.x + 1u);
+  long long acc = 0;
+  for (int it = 0; it < iters; it += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      x = mix32(x + 0x9e3779b9u);
+      const uint32_t idx = (uint32_t)(((unsigned long long)x * (unsigned)table_entries) >> 32);
+      acc += ltab[idx];
+    }
+  }
+  if (acc == 0x1234567ll) out[0] = acc;
+}
+
+// 4. LDS atomics on a group table: 64-bit add + 64-bit max + 64-bit count (what group-by does per row)
+template <int kOps>
+__global__ __launch_bounds__(256) void lds_atomics(int groups, int iters, unsigned long long* out) {
+  extern __shared__ unsigned long long tab[];
+  for (int i = threadIdx.x; i < groups * 3; i += blockDim.x) tab[i] = 0;
+  __syncthreads();
+  uint32_t x = mix32(blockIdx.x * 256u + threadIdx.x + 1u);
+  for (int it = 0; it < iters; ++it) {
+    x = mix32(x + 0x9e3779b9u);
+    const uint32_t g = (uint32_t)(((unsigned long long)x * (unsigned)groups) >> 32);
+    __hip_atomic_fetch_add(&tab[g], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (kOps >= 2) __hip_atomic_fetch_add(&tab[groups + g], (unsigned long long)(x & 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (kOps >= 3) __hip_atomic_fetch_max((long long*)&tab[2 * groups + g], (long long)(x >> 12), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  if (tab[threadIdx.x % (groups * 3)] == 0x1234567ull) out[0] = 1;
+}
+
+template <typename F>
+double time_ms(F launch, int reps) {
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a));
+  CHECK(hipEventCreate(&b));
+  launch();
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  for (int i = 0; i < reps; ++i) launch();
+  CHECK(hipEventRecord(b));
+  CHECK(hipEventSynchronize(b));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, a, b));
+  CHECK(hipGetLastError());
+  return ms / reps;
+}
+
+int main() {
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, \"hbm_gb\": %.1f, \"lds_per_block\": %zu}\n", prop.gcnArchName,
+         prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1e9, prop.sharedMemPerBlock);
+  const int cus = prop.multiProcessorCount;
+  unsigned long long* d_out;
+  CHECK(hipMalloc((void**)&d_out, 64));
+
+  // streaming
+  const size_t bytes = 4ull << 30;
+  uint8_t* d_buf;
+  CHECK(hipMalloc((void**)&d_buf, bytes));
+  CHECK(hipMemset(d_buf, 0x5a, bytes));
+  for (int bpc : {2, 4, 8}) {
+    double ms = time_ms([&] { stream_read<<<cus * bpc, 256>>>((const uint4*)d_buf, bytes / 16, d_out); }, 5);
+    printf("{\"bench\": \"stream_read_dwordx4\", \"blocks_per_cu\": %d, \"GBps\": %.1f}\n", bpc, bytes / ms / 1e6);
+  }
+  for (int bpc : {2, 4, 8}) {
+    double ms = time_ms([&] { stream_read_dma<<<cus * bpc, 256>>>(d_buf, bytes, d_out); }, 5);
+    printf("{\"bench\": \"stream_read_lds_dma\", \"blocks_per_cu\": %d, \"GBps\": %.1f}\n", bpc, bytes / ms / 1e6);
+  }
+
+  // gathers
+  for (int entries : {4096, 32768, 100000, 1000000}) {
+    std::vector<int32_t> h(entries);
+    for (int i = 0; i < entries; ++i) h[i] = i * 7 + 3;
+    int32_t* d_tab;
+    CHECK(hipMalloc((void**)&d_tab, entries * 4));
+    CHECK(hipMemcpy(d_tab, h.data(), entries * 4, hipMemcpyHostToDevice));
+    for (int pct : {100, 50, 10, 1}) {
+      const int iters = 2048, blocks = cus * 8;
+      double ms = time_ms([&] { gather_global<<<blocks, 256>>>(d_tab, entries, iters, pct, d_out); }, 3);
+      const double lanes = (double)blocks * 256 * iters;
+      printf("{\"bench\": \"gather_global\", \"table_entries\": %d, \"active_pct\": %d, \"lane_slots_per_s\": %.3e, \"gathers_per_s\": %.3e}\n", entries, pct,
+             lanes / ms * 1e3, lanes * pct / 100.0 / ms * 1e3);
+    }
+    if (entries * 4 <= 128 * 1024) {
+      const int iters = 4096, blocks = cus * (entries * 4 <= 64 * 1024 ? 2 : 1);
+      CHECK(hipFuncSetAttribute((const void*)gather_lds, hipFuncAttributeMaxDynamicSharedMemorySize, entries * 4));
+      double ms = time_ms([&] { gather_lds<<<blocks, 256, entries * 4>>>(d_tab, entries, iters, d_out); }, 3);
+      printf("{\"bench\": \"gather_lds\", \"table_entries\": %d, \"blocks\": %d, \"gathers_per_s\": %.3e}\n", entries, blocks, (double)blocks * 256 * iters / ms * 1e3);
+    }
+    CHECK(hipFree(d_tab));
+  }
+
+  // LDS atomics
+  for (int groups : {16, 1000, 4000}) {
+    const int iters = 4096, blocks = cus * 4;
+    double m1 = time_ms([&] { lds_atomics<1><<<blocks, 256, groups * 24>>>(groups, iters, d_out); }, 3);
+    double m2 = time_ms([&] { lds_atomics<2><<<blocks, 256, groups * 24>>>(groups, iters, d_out); }, 3);
+    double m3 = time_ms([&] { lds_atomics<3><<<blocks, 256, groups * 24>>>(groups, iters, d_out); }, 3);
+    const double rows = (double)blocks * 256 * iters;
+    printf("{\"bench\": \"lds_atomics_u64\", \"groups\": %d, \"rows_per_s_1op\": %.3e, \"rows_per_s_2op\": %.3e, \"rows_per_s_3op\": %.3e}\n", groups,
+           rows / m1 * 1e3, rows / m2 * 1e3, rows / m3 * 1e3);
+  }
+  return 0;
+}
