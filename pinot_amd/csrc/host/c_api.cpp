@@ -1,0 +1,207 @@
+// c_api.cpp -- flat C facade over the C++ host mirror so that Python tests can drive
+// GpuPlanMaker.makeSegmentPlanNode(...).run().nextBlock() and the combine step the way the reference's
+// BaseQueriesTest.getOperator(sql) / getBrokerResponse(sql, planMaker) do (BaseQueriesTest.java:100-105,154-156).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+#include "pinot_host.h"
+
+using namespace pinot;
+
+namespace {
+thread_local std::string g_hostError;
+GpuPlanMaker g_planMaker;
+
+std::string jsonEscape(const std::string& s) {
+  std::string o;
+  for (char c : s) {
+    if (c == '"' || c == '\\') { o += '\\'; o += c; }
+    else if ((unsigned char)c < 0x20) { char b[8]; snprintf(b, sizeof(b), "\\u%04x", c); o += b; }
+    else o += c;
+  }
+  return o;
+}
+
+std::string num(double v) {
+  if (std::isinf(v)) return v > 0 ? "\"Infinity\"" : "\"-Infinity\"";
+  char b[64];
+  snprintf(b, sizeof(b), "%.17g", v);
+  return b;
+}
+
+std::string intermediateJson(const IntermediateResult& r) {
+  if (std::holds_alternative<int64_t>(r)) return std::to_string(std::get<int64_t>(r));
+  if (std::holds_alternative<double>(r)) return num(std::get<double>(r));
+  const AvgPair& p = std::get<AvgPair>(r);
+  return "[" + num(p.sum) + ", " + std::to_string(p.count) + "]";
+}
+
+std::string blockJson(const ResultsBlock& b) {
+  std::ostringstream o;
+  o << "{\"isGroupBy\": " << (b.isGroupBy ? "true" : "false");
+  const auto& functions = b.isGroupBy ? b.groupBy.functions : b.aggregation.functions;
+  o << ", \"columns\": [";
+  for (size_t i = 0; i < functions.size(); ++i) o << (i ? ", " : "") << "\"" << jsonEscape(functions[i].getResultColumnName()) << "\"";
+  o << "]";
+  if (!b.isGroupBy) {
+    o << ", \"intermediate\": [";
+    for (size_t i = 0; i < functions.size(); ++i) o << (i ? ", " : "") << intermediateJson(b.aggregation.results[i]);
+    o << "], \"final\": [";
+    for (size_t i = 0; i < functions.size(); ++i) o << (i ? ", " : "") << num(functions[i].extractFinalResult(b.aggregation.results[i]));
+    o << "]";
+  } else {
+    o << ", \"groupByColumns\": [";
+    for (size_t i = 0; i < b.groupBy.groupByColumns.size(); ++i) o << (i ? ", " : "") << "\"" << jsonEscape(b.groupBy.groupByColumns[i]) << "\"";
+    o << "], \"groups\": [";
+    for (size_t g = 0; g < b.groupBy.groupKeys.size(); ++g) {
+      o << (g ? ", " : "") << "{\"key\": [";
+      const auto& keys = b.groupBy.groupKeys[g].keys;
+      for (size_t k = 0; k < keys.size(); ++k) {
+        o << (k ? ", " : "");
+        if (std::holds_alternative<int64_t>(keys[k])) o << std::get<int64_t>(keys[k]);
+        else o << "\"" << jsonEscape(std::get<std::string>(keys[k])) << "\"";
+      }
+      o << "], \"intermediate\": [";
+      for (size_t i = 0; i < functions.size(); ++i) o << (i ? ", " : "") << intermediateJson(b.groupBy.results[g][i]);
+      o << "], \"final\": [";
+      for (size_t i = 0; i < functions.size(); ++i) o << (i ? ", " : "") << num(functions[i].extractFinalResult(b.groupBy.results[g][i]));
+      o << "]}";
+    }
+    o << "]";
+  }
+  o << ", \"stats\": {\"numDocsScanned\": " << b.stats.numDocsScanned << ", \"numEntriesScannedInFilter\": " << b.stats.numEntriesScannedInFilter
+    << ", \"numEntriesScannedPostFilter\": " << b.stats.numEntriesScannedPostFilter << ", \"numTotalDocs\": " << b.stats.numTotalDocs << "}";
+  o << ", \"deviceMs\": " << num(b.deviceMs) << ", \"kernelMs\": " << num(b.kernelMs) << "}";
+  return o.str();
+}
+
+template <typename F>
+int guarded(F f) {
+  try { f(); return 0; }
+  catch (const QueryException& e) { g_hostError = e.what(); return 1; }
+  catch (const UnsupportedOperationException& e) { g_hostError = e.what(); return 2; }
+  catch (const std::exception& e) { g_hostError = e.what(); return 3; }
+}
+}  // namespace
+
+extern "C" {
+
+const char* ph_last_error(void) { return g_hostError.c_str(); }
+void ph_free(char* p) { free(p); }
+
+void* ph_segment_create(const char* name, int32_t num_docs) { return new ImmutableSegment(name ? name : "", num_docs); }
+
+int32_t ph_segment_add_int_column(void* seg, const char* name, int32_t has_dictionary, int32_t bits, int32_t cardinality, const void* fwd,
+                                  uint64_t fwd_size, const void* dict, uint64_t dict_size, const void* inv, uint64_t inv_size) {
+  return guarded([&] {
+    DataSource ds;
+    ds.name = name;
+    ds.dataType = DataType::INT;
+    ds.hasDictionary = has_dictionary != 0;
+    ds.bitsPerElement = bits;
+    ds.cardinality = cardinality;
+    ds.forwardIndex = (const uint8_t*)fwd; ds.forwardIndexSize = fwd_size;
+    ds.dictionaryBuffer = (const uint8_t*)dict; ds.dictionaryBufferSize = dict_size;
+    if (ds.hasDictionary) ds.dictionary = std::make_shared<IntDictionary>((const uint8_t*)dict, cardinality);
+    ds.hasInvertedIndex = inv != nullptr && inv_size > 0;
+    ds.invertedIndex = (const uint8_t*)inv; ds.invertedIndexSize = inv_size;
+    ((ImmutableSegment*)seg)->addDataSource(std::move(ds));
+  });
+}
+
+// values: `cardinality` NUL-terminated strings back to back, sorted ascending.
+int32_t ph_segment_add_string_column(void* seg, const char* name, int32_t bits, int32_t cardinality, const void* fwd, uint64_t fwd_size,
+                                     const char* values, const void* inv, uint64_t inv_size) {
+  return guarded([&] {
+    std::vector<std::string> vals;
+    const char* p = values;
+    for (int i = 0; i < cardinality; ++i) { vals.emplace_back(p); p += vals.back().size() + 1; }
+    DataSource ds;
+    ds.name = name;
+    ds.dataType = DataType::STRING;
+    ds.hasDictionary = true;
+    ds.bitsPerElement = bits;
+    ds.cardinality = cardinality;
+    ds.forwardIndex = (const uint8_t*)fwd; ds.forwardIndexSize = fwd_size;
+    ds.dictionary = std::make_shared<StringDictionary>(std::move(vals));
+    ds.hasInvertedIndex = inv != nullptr && inv_size > 0;
+    ds.invertedIndex = (const uint8_t*)inv; ds.invertedIndexSize = inv_size;
+    ((ImmutableSegment*)seg)->addDataSource(std::move(ds));
+  });
+}
+
+int32_t ph_segment_load(void* seg, int32_t device) { return guarded([&] { ((ImmutableSegment*)seg)->load(device); }); }
+void ph_segment_destroy(void* seg) { delete (ImmutableSegment*)seg; }
+
+int32_t ph_plan_maker_init(int32_t device, int32_t time_kernels) {
+  return guarded([&] {
+    std::map<std::string, std::string> cfg;
+    cfg[GpuPlanMaker::kConfigDevice] = std::to_string(device);
+    cfg[GpuPlanMaker::kConfigTimeKernels] = time_kernels ? "true" : "false";
+    g_planMaker.init(cfg);
+  });
+}
+
+// Parse only (no device): returns a JSON description of the QueryContext; used by the CPU-side tests.
+char* ph_parse_sql(const char* sql, int32_t* status) {
+  std::string out;
+  *status = guarded([&] {
+    const QueryContext q = getQueryContext(sql);
+    std::ostringstream o;
+    o << "{\"table\": \"" << jsonEscape(q.tableName) << "\", \"aggregations\": [";
+    for (size_t i = 0; i < q.aggregations.size(); ++i)
+      o << (i ? ", " : "") << "\"" << jsonEscape(AggregationFunction(q.aggregations[i].function, q.aggregations[i].column).getResultColumnName()) << "\"";
+    o << "], \"groupBy\": [";
+    for (size_t i = 0; i < q.groupByExpressions.size(); ++i) o << (i ? ", " : "") << "\"" << jsonEscape(q.groupByExpressions[i]) << "\"";
+    o << "], \"hasFilter\": " << (q.hasFilter ? "true" : "false") << "}";
+    out = o.str();
+  });
+  return *status == 0 ? strdup(out.c_str()) : nullptr;
+}
+
+// Lower one predicate against a dictionary buffer (no device): "[alwaysTrue, alwaysFalse, exclusive, isRange, start, end, n]"
+char* ph_lower_predicate(const char* sql_predicate, const void* dict, int32_t cardinality, int32_t* status) {
+  std::string out;
+  *status = guarded([&] {
+    const QueryContext q = getQueryContext(std::string("SELECT COUNT(*) FROM t WHERE ") + sql_predicate);
+    if (q.filter.type != FilterContext::Type::PREDICATE) throw QueryException("expected a single predicate");
+    DataSource ds;
+    ds.name = q.filter.predicate.column;
+    ds.cardinality = cardinality;
+    ds.dictionary = std::make_shared<IntDictionary>((const uint8_t*)dict, cardinality);
+    const PredicateEvaluator ev = getPredicateEvaluator(q.filter.predicate, ds);
+    std::ostringstream o;
+    o << "{\"alwaysTrue\": " << (ev.alwaysTrue ? "true" : "false") << ", \"alwaysFalse\": " << (ev.alwaysFalse ? "true" : "false")
+      << ", \"exclusive\": " << (ev.exclusive ? "true" : "false") << ", \"isRange\": " << (ev.isRange ? "true" : "false")
+      << ", \"start\": " << ev.startDictId << ", \"end\": " << ev.endDictId << ", \"dictIds\": [";
+    for (size_t i = 0; i < ev.matchingDictIds.size(); ++i) o << (i ? ", " : "") << ev.matchingDictIds[i];
+    o << "]}";
+    out = o.str();
+  });
+  return *status == 0 ? strdup(out.c_str()) : nullptr;
+}
+
+// getOperator(sql).nextBlock() per segment + the combined block: {"segments": [...], "combined": {...}}
+char* ph_execute_sql(void** segments, int32_t num_segments, const char* sql, int32_t max_execution_threads, int32_t* status) {
+  std::string out;
+  *status = guarded([&] {
+    const QueryContext q = getQueryContext(sql);
+    std::vector<SegmentContext> ctxs;
+    for (int i = 0; i < num_segments; ++i) ctxs.push_back(SegmentContext{(ImmutableSegment*)segments[i]});
+    std::ostringstream o;
+    o << "{\"segments\": [";
+    for (int i = 0; i < num_segments; ++i) {
+      auto op = g_planMaker.makeSegmentPlanNode(ctxs[(size_t)i], q)->run();
+      const ResultsBlock b = op->nextBlock();
+      o << (i ? ", " : "") << blockJson(b);
+    }
+    o << "], \"combined\": " << blockJson(g_planMaker.executeCombined(ctxs, q, max_execution_threads)) << "}";
+    out = o.str();
+  });
+  return *status == 0 ? strdup(out.c_str()) : nullptr;
+}
+
+}  // extern "C"

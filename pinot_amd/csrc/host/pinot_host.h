@@ -1,0 +1,275 @@
+// pinot_host.h -- C++ host mirror of the reference's per-segment operator interface, sitting ABOVE the C ABI.
+//
+// The reference is Java and no JDK exists in the build environment, so the host side that a Pinot server would
+// run in the JVM is mirrored here in C++ with the reference's names, argument meaning and error behaviour.  Every
+// class cites the Java type it mirrors (paths under /root/reference/pinot-core/src/main/java/org/apache/pinot/core/
+// unless noted).  The only way this layer computes anything is by calling the pg_* C ABI (include/pinot_gpu.h),
+// resolved with dlopen from libpinot_gpu.so: there is no CPU execution path here.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <variant>
+#include <vector>
+
+#include "../../../include/pinot_gpu.h"
+
+namespace pinot {
+
+// ---- errors -------------------------------------------------------------------------------------------------
+struct QueryException : std::runtime_error { using std::runtime_error::runtime_error; };          // BadQueryRequestException
+struct UnsupportedOperationException : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// ---- pinot-spi FieldSpec.DataType (stored types on this path) -------------------------------------------------
+enum class DataType { INT, STRING };
+
+// ---- sspi/index/reader/Dictionary.java:37-301; segl/segment/index/readers/BaseImmutableDictionary.java ----------
+class Dictionary {
+ public:
+  virtual ~Dictionary() = default;
+  virtual DataType getValueType() const = 0;
+  virtual int length() const = 0;
+  bool isSorted() const { return true; }
+  // Returns the dictId of the value, or -(insertionIndex + 1) when absent (BaseImmutableDictionary.java:124-140).
+  virtual int insertionIndexOf(const std::string& stringValue) const = 0;
+  int indexOf(const std::string& stringValue) const { int i = insertionIndexOf(stringValue); return i >= 0 ? i : -1; }
+  virtual int32_t getIntValue(int dictId) const = 0;
+  virtual double getDoubleValue(int dictId) const = 0;
+  virtual std::string getStringValue(int dictId) const = 0;
+};
+
+// segl/segment/index/readers/IntDictionary.java:38-70 over a big-endian buffer.
+class IntDictionary : public Dictionary {
+ public:
+  IntDictionary(const uint8_t* buffer, int length) : _buffer(buffer), _length(length) {}
+  DataType getValueType() const override { return DataType::INT; }
+  int length() const override { return _length; }
+  int insertionIndexOf(const std::string& stringValue) const override;
+  int binarySearch(int32_t value) const;
+  int32_t getIntValue(int dictId) const override;
+  double getDoubleValue(int dictId) const override { return (double)getIntValue(dictId); }
+  std::string getStringValue(int dictId) const override { return std::to_string(getIntValue(dictId)); }
+ private:
+  const uint8_t* _buffer;
+  int _length;
+};
+
+// StringDictionary values never reach the device: predicates are lowered to dictIds on the host and group keys are
+// mapped back here (segl/segment/index/readers/StringDictionary.java).
+class StringDictionary : public Dictionary {
+ public:
+  explicit StringDictionary(std::vector<std::string> sortedValues) : _values(std::move(sortedValues)) {}
+  DataType getValueType() const override { return DataType::STRING; }
+  int length() const override { return (int)_values.size(); }
+  int insertionIndexOf(const std::string& stringValue) const override;
+  int32_t getIntValue(int) const override { throw UnsupportedOperationException("getIntValue on STRING dictionary"); }
+  double getDoubleValue(int) const override { throw UnsupportedOperationException("getDoubleValue on STRING dictionary"); }
+  std::string getStringValue(int dictId) const override { return _values.at((size_t)dictId); }
+ private:
+  std::vector<std::string> _values;
+};
+
+// ---- sspi/datasource/DataSource.java:46-132 + DataSourceMetadata ------------------------------------------------
+struct DataSource {
+  std::string name;
+  DataType dataType = DataType::INT;
+  bool hasDictionary = true;
+  bool hasInvertedIndex = false;
+  int cardinality = 0;
+  int bitsPerElement = 0;
+  std::shared_ptr<Dictionary> dictionary;     // null for raw columns
+  const uint8_t* forwardIndex = nullptr; uint64_t forwardIndexSize = 0;
+  const uint8_t* dictionaryBuffer = nullptr; uint64_t dictionaryBufferSize = 0;   // INT dictionaries only
+  const uint8_t* invertedIndex = nullptr; uint64_t invertedIndexSize = 0;
+  std::vector<uint8_t> placeholderDictionary;  // STRING columns hand the device a 0..C-1 int dictionary
+};
+
+// ---- sspi/IndexSegment.java / ImmutableSegment: the buffers stay caller-owned, the HBM copy is made by load() ----
+class ImmutableSegment {
+ public:
+  ImmutableSegment(std::string name, int totalDocs) : _name(std::move(name)), _totalDocs(totalDocs) {}
+  ~ImmutableSegment();
+  const std::string& getSegmentName() const { return _name; }
+  int getTotalDocs() const { return _totalDocs; }
+  void addDataSource(DataSource ds) { _columns.push_back(std::move(ds)); }
+  const DataSource& getDataSource(const std::string& column) const;      // throws QueryException for unknown columns
+  int getColumnIndex(const std::string& column) const;
+  const std::vector<DataSource>& getDataSources() const { return _columns; }
+  void load(int deviceId);       // pg_segment_open
+  void destroy();                // IndexSegment.destroy() -> pg_segment_close
+  pg_segment* handle() const { return _handle; }
+  int deviceId() const { return _deviceId; }
+ private:
+  std::string _name;
+  int _totalDocs;
+  std::vector<DataSource> _columns;
+  pg_segment* _handle = nullptr;
+  int _deviceId = -1;
+};
+
+// ---- common/request/context: ExpressionContext (identifiers only on this path), predicates, FilterContext -------
+struct Predicate {                                   // common/request/context/predicate/Predicate.java
+  enum class Type { EQ, NOT_EQ, IN, NOT_IN, RANGE };
+  Type type = Type::EQ;
+  std::string column;
+  std::vector<std::string> values;                  // EQ / NOT_EQ: 1 value; IN / NOT_IN: n values
+  // RangePredicate: "*" = UNBOUNDED (RangePredicate.java)
+  std::string lowerBound = "*", upperBound = "*";
+  bool lowerInclusive = false, upperInclusive = false;
+};
+
+struct FilterContext {                               // common/request/context/FilterContext.java
+  enum class Type { AND, OR, NOT, PREDICATE };
+  Type type = Type::PREDICATE;
+  std::vector<FilterContext> children;
+  Predicate predicate;
+};
+
+enum class AggregationFunctionType { COUNT, SUM, MIN, MAX, AVG };   // sspi/AggregationFunctionType.java
+
+struct AggregationExpression {
+  AggregationFunctionType function;
+  std::string column;                                // "*" for COUNT(*)
+};
+
+// query/request/context/QueryContext.java (the slice this path needs)
+struct QueryContext {
+  std::string tableName;
+  std::vector<AggregationExpression> aggregations;
+  std::vector<std::string> groupByExpressions;
+  bool hasFilter = false;
+  FilterContext filter;
+  int maxInitialResultHolderCapacity = 10000;        // InstancePlanMakerImplV2.java:69-91 defaults
+  int numGroupsLimit = 100000;
+};
+
+// QueryContextConverterUtils.getQueryContext(sql) for the SQL subset of this path:
+//   SELECT agg(col|*) [, ...] FROM t [WHERE <AND/OR/NOT tree of =, !=, <>, <, <=, >, >=, BETWEEN, IN, NOT IN>] [GROUP BY c [, ...]]
+QueryContext getQueryContext(const std::string& sql);
+
+// ---- operator/filter/predicate: PredicateEvaluator lowering -----------------------------------------------------
+struct PredicateEvaluator {                          // operator/filter/predicate/PredicateEvaluator.java
+  Predicate::Type predicateType = Predicate::Type::EQ;
+  bool alwaysTrue = false, alwaysFalse = false;      // BaseDictionaryBasedPredicateEvaluator.java:69-89
+  bool exclusive = false;                            // NOT_EQ / NOT_IN
+  bool isRange = false;                              // dictId range [startDictId, endDictId)
+  int startDictId = 0, endDictId = 0;
+  std::vector<int> matchingDictIds;                  // sorted (IN / NOT_IN inner set)
+  bool rawRange = false; int64_t rawLower = 0, rawUpper = 0;   // raw INT columns: inclusive bounds
+  int getNumMatchingItems() const;
+};
+// PredicateEvaluatorProvider.getPredicateEvaluator (operator/filter/predicate/PredicateEvaluatorProvider.java)
+PredicateEvaluator getPredicateEvaluator(const Predicate& predicate, const DataSource& dataSource);
+
+// ---- query/aggregation/function ----------------------------------------------------------------------------------
+struct AvgPair { double sum = 0.0; int64_t count = 0; };                  // segl/customobject/AvgPair.java:26-45
+using IntermediateResult = std::variant<int64_t, double, AvgPair>;        // Long / Double / AvgPair
+
+class AggregationFunction {                         // query/aggregation/function/AggregationFunction.java:42-145
+ public:
+  AggregationFunction(AggregationFunctionType type, std::string column) : _type(type), _column(std::move(column)) {}
+  AggregationFunctionType getType() const { return _type; }
+  const std::string& getColumn() const { return _column; }
+  std::string getResultColumnName() const;
+  IntermediateResult fromDevice(const pg_agg_value& v) const;            // extractAggregationResult / extractGroupByResult
+  IntermediateResult merge(const IntermediateResult& a, const IntermediateResult& b) const;
+  double extractFinalResult(const IntermediateResult& r) const;          // COUNT returns the long as a double-exact value
+ private:
+  AggregationFunctionType _type;
+  std::string _column;
+};
+
+// ---- operator/ExecutionStatistics.java:25-64 ---------------------------------------------------------------------
+struct ExecutionStatistics {
+  int64_t numDocsScanned = 0, numEntriesScannedInFilter = 0, numEntriesScannedPostFilter = 0, numTotalDocs = 0;
+  void merge(const ExecutionStatistics& o) {
+    numDocsScanned += o.numDocsScanned; numEntriesScannedInFilter += o.numEntriesScannedInFilter;
+    numEntriesScannedPostFilter += o.numEntriesScannedPostFilter; numTotalDocs += o.numTotalDocs;
+  }
+};
+
+// ---- operator/blocks/results --------------------------------------------------------------------------------------
+using GroupKeyValue = std::variant<int64_t, std::string>;
+struct GroupKey { int groupId; std::vector<GroupKeyValue> keys; };        // groupby/GroupKeyGenerator.GroupKey
+
+struct AggregationResultsBlock {                    // operator/blocks/results/AggregationResultsBlock.java:54-59
+  std::vector<AggregationFunction> functions;
+  std::vector<IntermediateResult> results;
+};
+
+struct GroupByResultsBlock {                        // GroupByResultsBlock.java:68-76 + AggregationGroupByResult.java:31-56
+  std::vector<std::string> groupByColumns;
+  std::vector<AggregationFunction> functions;
+  std::vector<GroupKey> groupKeys;                                       // ascending raw group id (ArrayBasedHolder iterator)
+  std::vector<std::vector<IntermediateResult>> results;                   // [group][function]
+};
+
+struct ResultsBlock {
+  bool isGroupBy = false;
+  AggregationResultsBlock aggregation;
+  GroupByResultsBlock groupBy;
+  ExecutionStatistics stats;
+  double deviceMs = 0.0, kernelMs = 0.0;
+};
+
+// ---- common/Operator.java:35-122, operator/BaseOperator.java:39-50 -------------------------------------------------
+class Operator {
+ public:
+  virtual ~Operator() = default;
+  virtual ResultsBlock nextBlock() = 0;              // called exactly once
+  virtual std::string toExplainString() const = 0;
+  virtual ExecutionStatistics getExecutionStatistics() const = 0;
+  virtual const ImmutableSegment* getIndexSegment() const = 0;
+};
+
+class PlanNode {                                     // plan/PlanNode.java
+ public:
+  virtual ~PlanNode() = default;
+  virtual std::unique_ptr<Operator> run() = 0;
+};
+
+struct SegmentContext { ImmutableSegment* indexSegment; };   // sspi/SegmentContext.java
+
+// ---- plan/maker/PlanMaker.java:37-67 ------------------------------------------------------------------------------
+class PlanMaker {
+ public:
+  virtual ~PlanMaker() = default;
+  virtual void init(const std::map<std::string, std::string>& queryExecutorConfig) = 0;
+  virtual std::unique_ptr<PlanNode> makeSegmentPlanNode(const SegmentContext& segmentContext, const QueryContext& queryContext) = 0;
+};
+
+// The drop-in: what `pinot.server.query.executor.plan.maker.class` would name.  Mirrors a subclass of
+// InstancePlanMakerImplV2 that overrides makeSegmentPlanNode (plan/maker/InstancePlanMakerImplV2.java:270-289):
+// eligible aggregation / group-by queries get a device plan node; anything else throws
+// UnsupportedOperationException at PLAN time so the caller keeps the stock CPU plan.
+class GpuPlanMaker : public PlanMaker {
+ public:
+  void init(const std::map<std::string, std::string>& queryExecutorConfig) override;
+  std::unique_ptr<PlanNode> makeSegmentPlanNode(const SegmentContext& segmentContext, const QueryContext& queryContext) override;
+  // makeInstancePlan + CombinePlanNode: one worker per segment, results merged like
+  // AggregationResultsBlockMerger.java:34-44 / GroupByCombineOperator.java:132-147 (keys are VALUES, not dictIds).
+  ResultsBlock executeCombined(const std::vector<SegmentContext>& segments, const QueryContext& queryContext, int maxExecutionThreads);
+  static constexpr const char* kConfigDevice = "pinot.server.query.executor.gpu.device";
+  static constexpr const char* kConfigTimeKernels = "pinot.server.query.executor.gpu.time.kernels";
+ private:
+  int _device = 0;
+};
+
+// Merge helpers (operator/combine/merger/AggregationResultsBlockMerger.java, combine/GroupByCombineOperator.java)
+void mergeResultsBlocks(ResultsBlock* merged, const ResultsBlock& toMerge);
+
+// ---- the C ABI, resolved at run time from libpinot_gpu.so ---------------------------------------------------------
+struct GpuAbi {
+  decltype(&pg_init) init;
+  decltype(&pg_last_error) last_error;
+  decltype(&pg_segment_open) segment_open;
+  decltype(&pg_segment_close) segment_close;
+  decltype(&pg_execute) execute;
+  decltype(&pg_result_free) result_free;
+  decltype(&pg_filter_bitmap) filter_bitmap;
+};
+const GpuAbi& gpuAbi();   // throws std::runtime_error when libpinot_gpu.so cannot be loaded (no fallback)
+
+}  // namespace pinot

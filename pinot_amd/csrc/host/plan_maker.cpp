@@ -1,0 +1,426 @@
+// plan_maker.cpp -- GpuPlanMaker, plan nodes, operators, results blocks and the combine step, above the C ABI.
+// Mirrors (paths under /root/reference/pinot-core/src/main/java/org/apache/pinot/core/):
+//   plan/maker/InstancePlanMakerImplV2.java:166-193,270-289   makeInstancePlan / makeSegmentPlanNode
+//   plan/AggregationPlanNode.java:71-121, plan/GroupByPlanNode.java:49-74, plan/FilterPlanNode.java:88-106,195-320
+//   operator/filter/FilterOperatorUtils.java:74-159 (leaf operator choice: inverted index before scan for non-range)
+//   operator/query/AggregationOperator.java:64-93, operator/query/GroupByOperator.java:101-140
+//   operator/combine/BaseCombineOperator.java:85-142, merger/AggregationResultsBlockMerger.java:34-44,
+//   operator/combine/GroupByCombineOperator.java:132-147
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "pinot_host.h"
+
+namespace pinot {
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI loader: libpinot_gpu.so sits next to this library.  No fallback: a missing library is a hard error.
+// ---------------------------------------------------------------------------------------------------------------
+const GpuAbi& gpuAbi() {
+  static GpuAbi abi;
+  static std::once_flag once;
+  static std::string error;
+  std::call_once(once, [] {
+    Dl_info info;
+    std::string dir = ".";
+    if (dladdr((void*)&gpuAbi, &info) && info.dli_fname) {
+      std::string p = info.dli_fname;
+      size_t slash = p.rfind('/');
+      if (slash != std::string::npos) dir = p.substr(0, slash);
+    }
+    const std::string path = dir + "/libpinot_gpu.so";
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { error = std::string("cannot load ") + path + ": " + dlerror(); return; }
+    auto sym = [&](const char* name) { void* s = dlsym(h, name); if (!s && error.empty()) error = std::string("missing symbol ") + name; return s; };
+    abi.init = (decltype(abi.init))sym("pg_init");
+    abi.last_error = (decltype(abi.last_error))sym("pg_last_error");
+    abi.segment_open = (decltype(abi.segment_open))sym("pg_segment_open");
+    abi.segment_close = (decltype(abi.segment_close))sym("pg_segment_close");
+    abi.execute = (decltype(abi.execute))sym("pg_execute");
+    abi.result_free = (decltype(abi.result_free))sym("pg_result_free");
+    abi.filter_bitmap = (decltype(abi.filter_bitmap))sym("pg_filter_bitmap");
+  });
+  if (!error.empty()) throw std::runtime_error("pinot GPU engine unavailable (no CPU fallback in this library): " + error);
+  return abi;
+}
+
+static void checkStatus(pg_status st, const char* what) {
+  if (st == PG_OK) return;
+  const std::string msg = std::string(what) + ": " + gpuAbi().last_error();
+  if (st == PG_ERR_UNSUPPORTED) throw UnsupportedOperationException(msg);
+  if (st == PG_ERR_INVALID_ARGUMENT) throw QueryException(msg);
+  throw std::runtime_error(msg);   // BaseCombineOperator.wrapOperatorException attaches the segment name (:185-199)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ImmutableSegment
+// ---------------------------------------------------------------------------------------------------------------
+ImmutableSegment::~ImmutableSegment() {
+  if (_handle) { try { gpuAbi().segment_close(_handle); } catch (...) {} }
+}
+
+const DataSource& ImmutableSegment::getDataSource(const std::string& column) const {
+  for (const auto& c : _columns) if (c.name == column) return c;
+  throw QueryException("Cannot find data source for column: " + column);   // same text as the reference's segment impl
+}
+
+int ImmutableSegment::getColumnIndex(const std::string& column) const {
+  for (size_t i = 0; i < _columns.size(); ++i) if (_columns[i].name == column) return (int)i;
+  throw QueryException("Cannot find data source for column: " + column);
+}
+
+void ImmutableSegment::load(int deviceId) {
+  if (_handle) return;
+  std::vector<pg_column_desc> descs(_columns.size());
+  for (size_t i = 0; i < _columns.size(); ++i) {
+    DataSource& ds = _columns[i];
+    pg_column_desc& d = descs[i];
+    memset(&d, 0, sizeof(d));
+    d.name = ds.name.c_str();
+    d.stored_type = PG_TYPE_INT;
+    d.fwd_encoding = ds.hasDictionary ? PG_FWD_FIXED_BIT_DICT : PG_FWD_RAW_FIXED_BYTE;
+    d.bits_per_value = ds.bitsPerElement;
+    d.cardinality = ds.hasDictionary ? ds.cardinality : 0;
+    d.fwd_data = ds.forwardIndex;
+    d.fwd_size = ds.forwardIndexSize;
+    if (ds.hasDictionary) {
+      if (ds.dataType == DataType::STRING) {
+        // the device only ever sees dictIds of STRING columns; give it a 0..C-1 big-endian placeholder dictionary
+        ds.placeholderDictionary.resize((size_t)ds.cardinality * 4);
+        for (int k = 0; k < ds.cardinality; ++k) {
+          uint8_t* p = ds.placeholderDictionary.data() + (size_t)k * 4;
+          p[0] = (uint8_t)(k >> 24); p[1] = (uint8_t)(k >> 16); p[2] = (uint8_t)(k >> 8); p[3] = (uint8_t)k;
+        }
+        d.dict_data = ds.placeholderDictionary.data();
+        d.dict_size = ds.placeholderDictionary.size();
+      } else {
+        d.dict_data = ds.dictionaryBuffer;
+        d.dict_size = ds.dictionaryBufferSize;
+      }
+    }
+    if (ds.hasInvertedIndex) { d.inv_data = ds.invertedIndex; d.inv_size = ds.invertedIndexSize; }
+  }
+  pg_segment_desc sd;
+  memset(&sd, 0, sizeof(sd));
+  sd.name = _name.c_str();
+  sd.num_docs = _totalDocs;
+  sd.num_columns = (int32_t)descs.size();
+  sd.columns = descs.data();
+  sd.device_id = deviceId;
+  checkStatus(gpuAbi().segment_open(&sd, &_handle), ("loading segment " + _name).c_str());
+  _deviceId = deviceId;
+}
+
+void ImmutableSegment::destroy() {
+  if (_handle) { gpuAbi().segment_close(_handle); _handle = nullptr; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// AggregationFunction
+// ---------------------------------------------------------------------------------------------------------------
+std::string AggregationFunction::getResultColumnName() const {
+  static const char* names[] = {"count", "sum", "min", "max", "avg"};
+  return std::string(names[(int)_type]) + "(" + _column + ")";
+}
+
+IntermediateResult AggregationFunction::fromDevice(const pg_agg_value& v) const {
+  switch (_type) {
+    case AggregationFunctionType::COUNT: return (int64_t)v.count;          // CountAggregationFunction.extractAggregationResult -> Long
+    case AggregationFunctionType::SUM: return v.sum;                       // Double
+    case AggregationFunctionType::MIN: return v.min;                       // Double, +inf when nothing matched
+    case AggregationFunctionType::MAX: return v.max;                       // Double, -inf when nothing matched
+    case AggregationFunctionType::AVG: return AvgPair{v.sum, v.count};     // AvgPair(sum, count)
+  }
+  return 0.0;
+}
+
+IntermediateResult AggregationFunction::merge(const IntermediateResult& a, const IntermediateResult& b) const {
+  switch (_type) {
+    case AggregationFunctionType::COUNT: return std::get<int64_t>(a) + std::get<int64_t>(b);   // CountAggregationFunction.merge
+    case AggregationFunctionType::SUM: return std::get<double>(a) + std::get<double>(b);        // SumAggregationFunction.merge :223-233
+    case AggregationFunctionType::MIN: return std::fmin(std::get<double>(a), std::get<double>(b));
+    case AggregationFunctionType::MAX: return std::fmax(std::get<double>(a), std::get<double>(b));
+    case AggregationFunctionType::AVG: {                                                       // AvgAggregationFunction.merge -> AvgPair.apply
+      AvgPair r = std::get<AvgPair>(a);
+      const AvgPair& o = std::get<AvgPair>(b);
+      r.sum += o.sum; r.count += o.count;
+      return r;
+    }
+  }
+  return a;
+}
+
+double AggregationFunction::extractFinalResult(const IntermediateResult& r) const {
+  switch (_type) {
+    case AggregationFunctionType::COUNT: return (double)std::get<int64_t>(r);
+    case AggregationFunctionType::AVG: {                                    // AvgAggregationFunction.extractFinalResult :209-218
+      const AvgPair& p = std::get<AvgPair>(r);
+      return p.count == 0 ? -INFINITY : p.sum / (double)p.count;            // DEFAULT_FINAL_RESULT = Double.NEGATIVE_INFINITY
+    }
+    default: return std::get<double>(r);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Filter lowering: FilterPlanNode.constructPhysicalOperator + FilterOperatorUtils.getLeafFilterOperator
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct LoweredQuery {
+  std::vector<pg_filter_node> nodes;
+  std::vector<pg_predicate> predicates;
+  std::vector<std::vector<uint32_t>> setWords;   // owns DICT_SET bitsets
+  std::vector<pg_aggregation> aggregations;
+  std::vector<int32_t> groupBy;
+  pg_query query;
+};
+
+void lowerFilter(const FilterContext& f, const ImmutableSegment& seg, LoweredQuery* out) {
+  switch (f.type) {
+    case FilterContext::Type::AND:
+    case FilterContext::Type::OR: {
+      for (const auto& c : f.children) lowerFilter(c, seg, out);
+      pg_filter_node n{f.type == FilterContext::Type::AND ? PG_FILTER_AND : PG_FILTER_OR, -1, (int32_t)f.children.size(), 0};
+      out->nodes.push_back(n);
+      return;
+    }
+    case FilterContext::Type::NOT: {
+      lowerFilter(f.children.at(0), seg, out);
+      out->nodes.push_back(pg_filter_node{PG_FILTER_NOT, -1, 1, 0});
+      return;
+    }
+    case FilterContext::Type::PREDICATE: {
+      const DataSource& ds = seg.getDataSource(f.predicate.column);
+      const PredicateEvaluator ev = getPredicateEvaluator(f.predicate, ds);
+      pg_predicate p;
+      memset(&p, 0, sizeof(p));
+      p.column = seg.getColumnIndex(f.predicate.column);
+      if (ev.alwaysTrue) p.kind = PG_PRED_MATCH_ALL;          // MatchAllFilterOperator (FilterOperatorUtils.java:79-92)
+      else if (ev.alwaysFalse) p.kind = PG_PRED_MATCH_NONE;   // EmptyFilterOperator
+      else if (ev.rawRange) {
+        p.kind = PG_PRED_RAW_RANGE; p.lo = ev.rawLower; p.hi = ev.rawUpper; p.exclusive = ev.exclusive;
+      } else {
+        p.exclusive = ev.exclusive;
+        // FilterOperatorUtils.java:96-133: RANGE predicates scan (no sorted / range index on this path); every other
+        // predicate type prefers the inverted index when the column has one.
+        p.eval = (f.predicate.type != Predicate::Type::RANGE && ds.hasInvertedIndex) ? PG_EVAL_INVERTED : PG_EVAL_SCAN;
+        if (ev.isRange) { p.kind = PG_PRED_DICT_RANGE; p.lo = ev.startDictId; p.hi = ev.endDictId; }
+        else {
+          p.kind = PG_PRED_DICT_SET;
+          std::vector<uint32_t> words(((size_t)ds.cardinality + 31) / 32, 0u);
+          for (int d : ev.matchingDictIds) words[(size_t)d >> 5] |= 1u << (d & 31);
+          out->setWords.push_back(std::move(words));
+          p.set_words = out->setWords.back().data();
+          p.num_set_words = (int32_t)out->setWords.back().size();
+        }
+      }
+      out->predicates.push_back(p);
+      out->nodes.push_back(pg_filter_node{PG_FILTER_LEAF, (int32_t)out->predicates.size() - 1, 0, 0});
+      return;
+    }
+  }
+}
+
+std::unique_ptr<LoweredQuery> lowerQuery(const ImmutableSegment& seg, const QueryContext& qc) {
+  auto lq = std::make_unique<LoweredQuery>();
+  // reserve so that set_words pointers taken during lowering stay valid
+  lq->setWords.reserve(64);
+  if (qc.hasFilter) lowerFilter(qc.filter, seg, lq.get());
+  for (const auto& a : qc.aggregations) {
+    pg_aggregation pa;
+    pa.function = (int32_t)a.function;
+    pa.column = a.column == "*" ? -1 : seg.getColumnIndex(a.column);
+    if (pa.column >= 0) {
+      const DataSource& ds = seg.getDataSource(a.column);
+      if (ds.dataType != DataType::INT && a.function != AggregationFunctionType::COUNT)
+        throw QueryException("Cannot compute " + AggregationFunction(a.function, a.column).getResultColumnName() + " for non-numeric type: STRING");
+      if (a.function == AggregationFunctionType::COUNT) pa.column = -1;   // COUNT(col) == COUNT(*) with null handling off
+    }
+    lq->aggregations.push_back(pa);
+  }
+  long long product = 1;
+  for (const auto& g : qc.groupByExpressions) {
+    const DataSource& ds = seg.getDataSource(g);
+    if (!ds.hasDictionary) throw UnsupportedOperationException("group-by on a raw column uses the no-dictionary key generator (CPU plan)");
+    product *= ds.cardinality;
+    // DictionaryBasedGroupKeyGenerator.java:164-184: above arrayBasedThreshold the map-based holders take over (CPU plan)
+    if (product > qc.maxInitialResultHolderCapacity) throw UnsupportedOperationException("group-by cardinality product exceeds the array-based threshold");
+    lq->groupBy.push_back(seg.getColumnIndex(g));
+  }
+  pg_query& q = lq->query;
+  memset(&q, 0, sizeof(q));
+  q.filter = lq->nodes.data();
+  q.num_filter_nodes = (int32_t)lq->nodes.size();
+  q.predicates = lq->predicates.data();
+  q.num_predicates = (int32_t)lq->predicates.size();
+  q.aggregations = lq->aggregations.data();
+  q.num_aggregations = (int32_t)lq->aggregations.size();
+  q.group_by_columns = lq->groupBy.data();
+  q.num_group_by = (int32_t)lq->groupBy.size();
+  q.num_groups_limit = qc.numGroupsLimit;
+  return lq;
+}
+
+// One operator class serves both AggregationOperator and GroupByOperator roles: the device does the whole
+// filter -> project -> aggregate pull loop in one fused launch, nextBlock() is called exactly once (Operator.java:35-44).
+class GpuAggregationOperator : public Operator {
+ public:
+  GpuAggregationOperator(const ImmutableSegment* seg, QueryContext qc, std::unique_ptr<LoweredQuery> lq)
+      : _segment(seg), _queryContext(std::move(qc)), _lowered(std::move(lq)) {}
+
+  ResultsBlock nextBlock() override {
+    pg_result res;
+    checkStatus(gpuAbi().execute(_segment->handle(), &_lowered->query, &res), ("executing on segment " + _segment->getSegmentName()).c_str());
+    ResultsBlock block;
+    std::vector<AggregationFunction> functions;
+    for (const auto& a : _queryContext.aggregations) functions.emplace_back(a.function, a.column);
+    block.stats.numDocsScanned = res.stats.num_docs_scanned;
+    block.stats.numEntriesScannedInFilter = res.stats.num_entries_scanned_in_filter;
+    block.stats.numEntriesScannedPostFilter = res.stats.num_entries_scanned_post_filter;
+    block.stats.numTotalDocs = res.stats.num_total_docs;
+    block.deviceMs = res.device_ms;
+    block.kernelMs = res.dominant_kernel_ms;
+    const int na = (int)functions.size();
+    if (_queryContext.groupByExpressions.empty()) {
+      block.isGroupBy = false;
+      block.aggregation.functions = functions;
+      for (int a = 0; a < na; ++a) block.aggregation.results.push_back(functions[(size_t)a].fromDevice(res.aggregations[a]));
+    } else {
+      block.isGroupBy = true;
+      GroupByResultsBlock& g = block.groupBy;
+      g.groupByColumns = _queryContext.groupByExpressions;
+      g.functions = functions;
+      std::vector<const DataSource*> keyCols;
+      for (const auto& c : g.groupByColumns) keyCols.push_back(&_segment->getDataSource(c));
+      for (int i = 0; i < res.num_groups; ++i) {
+        GroupKey key;
+        key.groupId = res.group_ids[i];
+        // DictionaryBasedGroupKeyGenerator.getKeys: groupId -> dictIds (mixed radix) -> dictionary VALUES
+        int rem = key.groupId;
+        for (const DataSource* ds : keyCols) {
+          const int d = rem % ds->cardinality;
+          rem /= ds->cardinality;
+          if (ds->dataType == DataType::STRING) key.keys.emplace_back(ds->dictionary->getStringValue(d));
+          else key.keys.emplace_back((int64_t)ds->dictionary->getIntValue(d));
+        }
+        g.groupKeys.push_back(std::move(key));
+        std::vector<IntermediateResult> row;
+        for (int a = 0; a < na; ++a) row.push_back(functions[(size_t)a].fromDevice(res.group_aggregations[(size_t)i * (size_t)na + (size_t)a]));
+        g.results.push_back(std::move(row));
+      }
+    }
+    gpuAbi().result_free(&res);
+    _stats = block.stats;
+    return block;
+  }
+
+  std::string toExplainString() const override { return _queryContext.groupByExpressions.empty() ? "GPU_AGGREGATE" : "GPU_GROUP_BY"; }
+  ExecutionStatistics getExecutionStatistics() const override { return _stats; }
+  const ImmutableSegment* getIndexSegment() const override { return _segment; }
+
+ private:
+  const ImmutableSegment* _segment;
+  QueryContext _queryContext;
+  std::unique_ptr<LoweredQuery> _lowered;
+  ExecutionStatistics _stats;
+};
+
+class GpuAggregationPlanNode : public PlanNode {
+ public:
+  GpuAggregationPlanNode(const ImmutableSegment* seg, QueryContext qc, std::unique_ptr<LoweredQuery> lq)
+      : _segment(seg), _queryContext(std::move(qc)), _lowered(std::move(lq)) {}
+  std::unique_ptr<Operator> run() override { return std::make_unique<GpuAggregationOperator>(_segment, _queryContext, std::move(_lowered)); }
+ private:
+  const ImmutableSegment* _segment;
+  QueryContext _queryContext;
+  std::unique_ptr<LoweredQuery> _lowered;
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// GpuPlanMaker
+// ---------------------------------------------------------------------------------------------------------------
+void GpuPlanMaker::init(const std::map<std::string, std::string>& cfg) {
+  pg_config c;
+  memset(&c, 0, sizeof(c));
+  c.abi_version = PG_ABI_VERSION;
+  auto it = cfg.find(kConfigDevice);
+  _device = it == cfg.end() ? 0 : atoi(it->second.c_str());
+  c.device_id = _device;
+  it = cfg.find(kConfigTimeKernels);
+  if (it != cfg.end() && it->second == "true") c.flags |= PG_CFG_TIME_KERNELS;
+  checkStatus(gpuAbi().init(&c), "initialising the GPU plan maker");
+}
+
+std::unique_ptr<PlanNode> GpuPlanMaker::makeSegmentPlanNode(const SegmentContext& sc, const QueryContext& qc) {
+  const ImmutableSegment* seg = sc.indexSegment;
+  if (!seg || !seg->handle()) throw std::runtime_error("segment is not loaded on a device");
+  if (qc.aggregations.empty()) throw UnsupportedOperationException("only aggregation / group-by queries are offloaded (selection stays on the CPU plan)");
+  // Anything the device cannot run is rejected HERE, at plan time, never at run time.
+  return std::make_unique<GpuAggregationPlanNode>(seg, qc, lowerQuery(*seg, qc));
+}
+
+// AggregationResultsBlockMerger.mergeResultsBlocks (:34-44) and GroupByCombineOperator (:132-147, keyed by VALUES).
+void mergeResultsBlocks(ResultsBlock* merged, const ResultsBlock& other) {
+  merged->stats.merge(other.stats);
+  merged->deviceMs = std::max(merged->deviceMs, other.deviceMs);
+  merged->kernelMs = std::max(merged->kernelMs, other.kernelMs);
+  if (!merged->isGroupBy) {
+    auto& m = merged->aggregation;
+    for (size_t a = 0; a < m.functions.size(); ++a) m.results[a] = m.functions[a].merge(m.results[a], other.aggregation.results[a]);
+    return;
+  }
+  auto& m = merged->groupBy;
+  std::map<std::vector<GroupKeyValue>, size_t> index;
+  for (size_t i = 0; i < m.groupKeys.size(); ++i) index[m.groupKeys[i].keys] = i;
+  for (size_t i = 0; i < other.groupBy.groupKeys.size(); ++i) {
+    const auto& keys = other.groupBy.groupKeys[i].keys;
+    auto it = index.find(keys);
+    if (it == index.end()) {
+      index[keys] = m.groupKeys.size();
+      GroupKey k = other.groupBy.groupKeys[i];
+      k.groupId = (int)m.groupKeys.size();           // group ids are segment-local; after the merge they are just ordinals
+      m.groupKeys.push_back(std::move(k));
+      m.results.push_back(other.groupBy.results[i]);
+    } else {
+      for (size_t a = 0; a < m.functions.size(); ++a) m.results[it->second][a] = m.functions[a].merge(m.results[it->second][a], other.groupBy.results[i][a]);
+    }
+  }
+}
+
+ResultsBlock GpuPlanMaker::executeCombined(const std::vector<SegmentContext>& segments, const QueryContext& qc, int maxExecutionThreads) {
+  if (segments.empty()) throw QueryException("no segments");
+  // CombinePlanNode: plan every segment first (plan-time rejection), then BaseCombineOperator: one task per segment,
+  // numTasks = min(numSegments, maxExecutionThreads) (QueryMultiThreadingUtils.java:46-65).
+  std::vector<std::unique_ptr<Operator>> operators;
+  for (const auto& sc : segments) operators.push_back(makeSegmentPlanNode(sc, qc)->run());
+  std::vector<ResultsBlock> blocks(operators.size());
+  std::vector<std::string> errors(operators.size());
+  const int numTasks = std::max(1, std::min((int)operators.size(), maxExecutionThreads > 0 ? maxExecutionThreads : (int)operators.size()));
+  std::vector<std::thread> workers;
+  for (int t = 0; t < numTasks; ++t) {
+    workers.emplace_back([&, t] {
+      for (size_t i = (size_t)t; i < operators.size(); i += (size_t)numTasks) {
+        try { blocks[i] = operators[i]->nextBlock(); }
+        catch (const std::exception& e) {   // wrapOperatorException: attach the segment name
+          errors[i] = std::string("Caught exception while doing operator: ") + operators[i]->toExplainString() + " on segment " +
+                      operators[i]->getIndexSegment()->getSegmentName() + ": " + e.what();
+        }
+      }
+    });
+  }
+  for (auto& w : workers) w.join();
+  for (const auto& e : errors) if (!e.empty()) throw std::runtime_error(e);
+  // deterministic merge order (segment order); for integer sums below 2^53 any order gives the same doubles
+  ResultsBlock merged = blocks[0];
+  for (size_t i = 1; i < blocks.size(); ++i) mergeResultsBlocks(&merged, blocks[i]);
+  return merged;
+}
+
+}  // namespace pinot

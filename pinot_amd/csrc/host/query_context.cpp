@@ -1,0 +1,344 @@
+// query_context.cpp -- SQL subset -> QueryContext, dictionaries, predicate evaluators.
+// Mirrors (paths under /root/reference/):
+//   pinot-core/.../query/request/context/utils/QueryContextConverterUtils.java (getQueryContext)
+//   pinot-common/.../request/context/RequestContextUtils.java (filter tree, BETWEEN -> RANGE, <,<=,>,>= -> RANGE)
+//   pinot-core/.../operator/filter/predicate/{Equals,NotEquals,In,NotIn,Range}PredicateEvaluatorFactory.java
+#include <algorithm>
+#include <cctype>
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+
+#include "pinot_host.h"
+
+namespace pinot {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Dictionaries
+// ---------------------------------------------------------------------------------------------------------------
+static inline int32_t be_int(const uint8_t* p) {
+  return (int32_t)(((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]);
+}
+
+int32_t IntDictionary::getIntValue(int dictId) const { return be_int(_buffer + (size_t)dictId * 4); }
+
+// BaseImmutableDictionary.binarySearch(int), BaseImmutableDictionary.java:124-140
+int IntDictionary::binarySearch(int32_t value) const {
+  int low = 0, high = _length - 1;
+  while (low <= high) {
+    const int mid = (int)(((unsigned)low + (unsigned)high) >> 1);
+    const int32_t midValue = getIntValue(mid);
+    if (midValue < value) low = mid + 1;
+    else if (midValue > value) high = mid - 1;
+    else return mid;
+  }
+  return -(low + 1);
+}
+
+static bool parseInt32(const std::string& s, int32_t* out) {
+  if (s.empty()) return false;
+  char* end = nullptr;
+  errno = 0;
+  const long long v = strtoll(s.c_str(), &end, 10);
+  if (errno != 0 || *end != 0 || v < INT_MIN || v > INT_MAX) return false;
+  *out = (int32_t)v;
+  return true;
+}
+
+// IntDictionary.insertionIndexOf(String) = binarySearch(Integer.parseInt(stringValue)), IntDictionary.java:38-46.
+// The reference converts the literal with PredicateUtils.getStoredValue; a non-integer literal on an INT column is a
+// BadQueryRequestException there, a QueryException here.
+int IntDictionary::insertionIndexOf(const std::string& stringValue) const {
+  int32_t v;
+  if (!parseInt32(stringValue, &v)) throw QueryException("Cannot convert value: '" + stringValue + "' to INT");
+  return binarySearch(v);
+}
+
+int StringDictionary::insertionIndexOf(const std::string& stringValue) const {
+  auto it = std::lower_bound(_values.begin(), _values.end(), stringValue);
+  if (it != _values.end() && *it == stringValue) return (int)(it - _values.begin());
+  return -((int)(it - _values.begin()) + 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SQL subset parser
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Token {
+  enum Kind { END, IDENT, NUMBER, STRING, SYMBOL } kind = END;
+  std::string text;
+};
+
+class Lexer {
+ public:
+  explicit Lexer(const std::string& s) : _s(s) { advance(); }
+  const Token& peek() const { return _tok; }
+  Token next() { Token t = _tok; advance(); return t; }
+  bool isKeyword(const char* kw) const {
+    if (_tok.kind != Token::IDENT) return false;
+    std::string u = _tok.text;
+    for (auto& c : u) c = (char)toupper((unsigned char)c);
+    return u == kw;
+  }
+  bool acceptKeyword(const char* kw) { if (isKeyword(kw)) { advance(); return true; } return false; }
+  bool acceptSymbol(const char* sym) { if (_tok.kind == Token::SYMBOL && _tok.text == sym) { advance(); return true; } return false; }
+  void expectSymbol(const char* sym) { if (!acceptSymbol(sym)) throw QueryException(std::string("expected '") + sym + "' near '" + _tok.text + "'"); }
+  void expectKeyword(const char* kw) { if (!acceptKeyword(kw)) throw QueryException(std::string("expected ") + kw + " near '" + _tok.text + "'"); }
+
+ private:
+  void advance() {
+    while (_pos < _s.size() && isspace((unsigned char)_s[_pos])) _pos++;
+    _tok = Token();
+    if (_pos >= _s.size()) return;
+    const char c = _s[_pos];
+    if (isalpha((unsigned char)c) || c == '_' || c == '"') {
+      if (c == '"') {
+        size_t e = _s.find('"', _pos + 1);
+        if (e == std::string::npos) throw QueryException("unterminated quoted identifier");
+        _tok.kind = Token::IDENT; _tok.text = _s.substr(_pos + 1, e - _pos - 1); _pos = e + 1;
+        return;
+      }
+      size_t e = _pos;
+      while (e < _s.size() && (isalnum((unsigned char)_s[e]) || _s[e] == '_' || _s[e] == '.')) e++;
+      _tok.kind = Token::IDENT; _tok.text = _s.substr(_pos, e - _pos); _pos = e;
+    } else if (isdigit((unsigned char)c) || (c == '-' && _pos + 1 < _s.size() && isdigit((unsigned char)_s[_pos + 1]))) {
+      size_t e = _pos + 1;
+      while (e < _s.size() && isdigit((unsigned char)_s[e])) e++;
+      _tok.kind = Token::NUMBER; _tok.text = _s.substr(_pos, e - _pos); _pos = e;
+    } else if (c == '\'') {
+      std::string out;
+      size_t e = _pos + 1;
+      for (;;) {
+        if (e >= _s.size()) throw QueryException("unterminated string literal");
+        if (_s[e] == '\'') { if (e + 1 < _s.size() && _s[e + 1] == '\'') { out += '\''; e += 2; continue; } break; }
+        out += _s[e++];
+      }
+      _tok.kind = Token::STRING; _tok.text = out; _pos = e + 1;
+    } else {
+      static const char* two[] = {"<=", ">=", "<>", "!="};
+      for (const char* t : two) if (_s.compare(_pos, 2, t) == 0) { _tok.kind = Token::SYMBOL; _tok.text = t; _pos += 2; return; }
+      _tok.kind = Token::SYMBOL; _tok.text = std::string(1, c); _pos++;
+    }
+  }
+  const std::string& _s;
+  size_t _pos = 0;
+  Token _tok;
+};
+
+std::string literal(Lexer& lx) {
+  const Token t = lx.next();
+  if (t.kind != Token::NUMBER && t.kind != Token::STRING) throw QueryException("expected a literal near '" + t.text + "'");
+  return t.text;
+}
+
+FilterContext parseOr(Lexer& lx);
+
+FilterContext parsePredicate(Lexer& lx) {
+  if (lx.acceptSymbol("(")) {
+    FilterContext f = parseOr(lx);
+    lx.expectSymbol(")");
+    return f;
+  }
+  const Token col = lx.next();
+  if (col.kind != Token::IDENT) throw QueryException("expected a column name near '" + col.text + "'");
+  FilterContext f;
+  f.type = FilterContext::Type::PREDICATE;
+  Predicate& p = f.predicate;
+  p.column = col.text;
+  if (lx.acceptKeyword("BETWEEN")) {
+    // RequestContextUtils: BETWEEN a AND b -> RANGE [a, b]
+    p.type = Predicate::Type::RANGE;
+    p.lowerBound = literal(lx); p.lowerInclusive = true;
+    lx.expectKeyword("AND");
+    p.upperBound = literal(lx); p.upperInclusive = true;
+    return f;
+  }
+  bool negated = lx.acceptKeyword("NOT");
+  if (lx.acceptKeyword("IN")) {
+    p.type = negated ? Predicate::Type::NOT_IN : Predicate::Type::IN;
+    lx.expectSymbol("(");
+    do { p.values.push_back(literal(lx)); } while (lx.acceptSymbol(","));
+    lx.expectSymbol(")");
+    return f;
+  }
+  if (negated) throw QueryException("expected IN after NOT");
+  const Token op = lx.next();
+  if (op.kind != Token::SYMBOL) throw QueryException("expected a comparison operator near '" + op.text + "'");
+  const std::string v = literal(lx);
+  if (op.text == "=") { p.type = Predicate::Type::EQ; p.values = {v}; }
+  else if (op.text == "!=" || op.text == "<>") { p.type = Predicate::Type::NOT_EQ; p.values = {v}; }
+  else if (op.text == ">") { p.type = Predicate::Type::RANGE; p.lowerBound = v; p.lowerInclusive = false; }
+  else if (op.text == ">=") { p.type = Predicate::Type::RANGE; p.lowerBound = v; p.lowerInclusive = true; }
+  else if (op.text == "<") { p.type = Predicate::Type::RANGE; p.upperBound = v; p.upperInclusive = false; }
+  else if (op.text == "<=") { p.type = Predicate::Type::RANGE; p.upperBound = v; p.upperInclusive = true; }
+  else throw QueryException("unsupported operator '" + op.text + "'");
+  return f;
+}
+
+FilterContext parseNot(Lexer& lx) {
+  if (lx.acceptKeyword("NOT")) {
+    FilterContext f;
+    f.type = FilterContext::Type::NOT;
+    f.children.push_back(parseNot(lx));
+    return f;
+  }
+  return parsePredicate(lx);
+}
+
+FilterContext parseAnd(Lexer& lx) {
+  FilterContext first = parseNot(lx);
+  if (!lx.isKeyword("AND")) return first;
+  FilterContext f;
+  f.type = FilterContext::Type::AND;
+  f.children.push_back(std::move(first));
+  while (lx.acceptKeyword("AND")) f.children.push_back(parseNot(lx));
+  return f;
+}
+
+FilterContext parseOr(Lexer& lx) {
+  FilterContext first = parseAnd(lx);
+  if (!lx.isKeyword("OR")) return first;
+  FilterContext f;
+  f.type = FilterContext::Type::OR;
+  f.children.push_back(std::move(first));
+  while (lx.acceptKeyword("OR")) f.children.push_back(parseAnd(lx));
+  return f;
+}
+
+}  // namespace
+
+QueryContext getQueryContext(const std::string& sql) {
+  Lexer lx(sql);
+  QueryContext q;
+  lx.expectKeyword("SELECT");
+  do {
+    const Token fn = lx.next();
+    if (fn.kind != Token::IDENT) throw QueryException("expected an aggregation function near '" + fn.text + "'");
+    std::string u = fn.text;
+    for (auto& c : u) c = (char)toupper((unsigned char)c);
+    AggregationExpression e;
+    if (u == "COUNT") e.function = AggregationFunctionType::COUNT;
+    else if (u == "SUM") e.function = AggregationFunctionType::SUM;
+    else if (u == "MIN") e.function = AggregationFunctionType::MIN;
+    else if (u == "MAX") e.function = AggregationFunctionType::MAX;
+    else if (u == "AVG") e.function = AggregationFunctionType::AVG;
+    else throw UnsupportedOperationException("only COUNT/SUM/MIN/MAX/AVG are offloaded, got " + fn.text);
+    lx.expectSymbol("(");
+    if (lx.acceptSymbol("*")) e.column = "*";
+    else {
+      const Token c = lx.next();
+      if (c.kind != Token::IDENT) throw UnsupportedOperationException("only identifier arguments are offloaded (ProjectPlanNode.java:85-86)");
+      e.column = c.text;
+      if (!(lx.peek().kind == Token::SYMBOL && lx.peek().text == ")"))
+        throw UnsupportedOperationException("only identifier arguments are offloaded (transform expressions keep the CPU plan, ProjectPlanNode.java:85-86)");
+    }
+    lx.expectSymbol(")");
+    if (e.function != AggregationFunctionType::COUNT && e.column == "*") throw QueryException("'*' is only valid in COUNT(*)");
+    q.aggregations.push_back(e);
+    if (lx.acceptKeyword("AS")) lx.next();
+  } while (lx.acceptSymbol(","));
+  lx.expectKeyword("FROM");
+  const Token t = lx.next();
+  if (t.kind != Token::IDENT) throw QueryException("expected a table name");
+  q.tableName = t.text;
+  if (lx.acceptKeyword("WHERE")) {
+    q.hasFilter = true;
+    q.filter = parseOr(lx);
+  }
+  if (lx.acceptKeyword("GROUP")) {
+    lx.expectKeyword("BY");
+    do {
+      const Token c = lx.next();
+      if (c.kind != Token::IDENT) throw QueryException("expected a group-by column");
+      q.groupByExpressions.push_back(c.text);
+    } while (lx.acceptSymbol(","));
+  }
+  if (lx.peek().kind != Token::END) throw UnsupportedOperationException("unsupported clause near '" + lx.peek().text + "'");
+  return q;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Predicate evaluators
+// ---------------------------------------------------------------------------------------------------------------
+int PredicateEvaluator::getNumMatchingItems() const {
+  if (isRange) return std::max(endDictId - startDictId, 0);
+  return (int)matchingDictIds.size();
+}
+
+PredicateEvaluator getPredicateEvaluator(const Predicate& predicate, const DataSource& ds) {
+  PredicateEvaluator ev;
+  ev.predicateType = predicate.type;
+  if (!ds.hasDictionary) {
+    // raw INT column: IntRawValueBasedRangePredicateEvaluator (RangePredicateEvaluatorFactory.java:68-81,331-366);
+    // EQ is the degenerate range, the other raw evaluators are not offloaded.
+    auto toInt = [](const std::string& s) { int32_t v; if (!parseInt32(s, &v)) throw QueryException("Cannot convert value: '" + s + "' to INT"); return (int64_t)v; };
+    ev.rawRange = true;
+    if (predicate.type == Predicate::Type::RANGE) {
+      const bool lowerUnbounded = predicate.lowerBound == "*", upperUnbounded = predicate.upperBound == "*";
+      ev.rawLower = lowerUnbounded ? INT_MIN : toInt(predicate.lowerBound);
+      ev.rawUpper = upperUnbounded ? INT_MAX : toInt(predicate.upperBound);
+      if (!lowerUnbounded && !predicate.lowerInclusive) ev.rawLower += 1;
+      if (!upperUnbounded && !predicate.upperInclusive) ev.rawUpper -= 1;
+    } else if (predicate.type == Predicate::Type::EQ || predicate.type == Predicate::Type::NOT_EQ) {
+      ev.rawLower = ev.rawUpper = toInt(predicate.values.at(0));
+      ev.exclusive = predicate.type == Predicate::Type::NOT_EQ;
+    } else {
+      throw UnsupportedOperationException("IN / NOT IN on a raw column is not offloaded");
+    }
+    if (ev.rawLower > ev.rawUpper) { if (ev.exclusive) ev.alwaysTrue = true; else ev.alwaysFalse = true; }
+    return ev;
+  }
+  const Dictionary& dict = *ds.dictionary;
+  switch (predicate.type) {
+    case Predicate::Type::EQ:
+    case Predicate::Type::NOT_EQ: {
+      // EqualsPredicateEvaluatorFactory.java:92-124 / NotEqualsPredicateEvaluatorFactory
+      const int d = dict.indexOf(predicate.values.at(0));
+      ev.exclusive = predicate.type == Predicate::Type::NOT_EQ;
+      ev.isRange = true;
+      if (d >= 0) {
+        ev.startDictId = d; ev.endDictId = d + 1;
+        if (dict.length() == 1) { if (ev.exclusive) ev.alwaysFalse = true; else ev.alwaysTrue = true; }
+      } else {
+        if (ev.exclusive) ev.alwaysTrue = true; else ev.alwaysFalse = true;
+      }
+      break;
+    }
+    case Predicate::Type::IN:
+    case Predicate::Type::NOT_IN: {
+      // InPredicateEvaluatorFactory.java:161-188 (PredicateUtils.getDictIdSet drops values absent from the dictionary)
+      ev.exclusive = predicate.type == Predicate::Type::NOT_IN;
+      for (const auto& v : predicate.values) { const int d = dict.indexOf(v); if (d >= 0) ev.matchingDictIds.push_back(d); }
+      std::sort(ev.matchingDictIds.begin(), ev.matchingDictIds.end());
+      ev.matchingDictIds.erase(std::unique(ev.matchingDictIds.begin(), ev.matchingDictIds.end()), ev.matchingDictIds.end());
+      const int n = (int)ev.matchingDictIds.size();
+      if (n == 0) { if (ev.exclusive) ev.alwaysTrue = true; else ev.alwaysFalse = true; }
+      else if (n == dict.length()) { if (ev.exclusive) ev.alwaysFalse = true; else ev.alwaysTrue = true; }
+      break;
+    }
+    case Predicate::Type::RANGE: {
+      // SortedDictionaryBasedRangePredicateEvaluator, RangePredicateEvaluatorFactory.java:126-169
+      ev.isRange = true;
+      if (predicate.lowerBound == "*") ev.startDictId = 0;
+      else {
+        const int ins = dict.insertionIndexOf(predicate.lowerBound);
+        if (ins < 0) ev.startDictId = -(ins + 1);
+        else ev.startDictId = predicate.lowerInclusive ? ins : ins + 1;
+      }
+      if (predicate.upperBound == "*") ev.endDictId = dict.length();
+      else {
+        const int ins = dict.insertionIndexOf(predicate.upperBound);
+        if (ins < 0) ev.endDictId = -(ins + 1);
+        else ev.endDictId = predicate.upperInclusive ? ins + 1 : ins;
+      }
+      const int n = std::max(ev.endDictId - ev.startDictId, 0);
+      if (n == 0) ev.alwaysFalse = true;
+      else if (n == dict.length()) ev.alwaysTrue = true;
+      break;
+    }
+  }
+  return ev;
+}
+
+}  // namespace pinot

@@ -17,8 +17,9 @@ constexpr int kMaxLeaves = 8;
 constexpr int kMaxNodes = 24;
 constexpr int kMaxAggCols = 4;                  // distinct aggregated columns
 constexpr int kMaxGroupCols = 3;                // ArrayBasedHolder fast paths cover 1..3 keys
+constexpr int kMaxGroupAggs = 8;                // distinct (column, SUM|MIN|MAX) pairs of a group-by query
 constexpr int kStackDepth = 8;
-constexpr int kBlockThreads = 256;
+constexpr int kBlockThreads = 256;           // maximum; launches may use 64 / 128 when LDS is tight
 
 enum LeafKind : int32_t {
   kLeafMatchAll = 0,
@@ -38,6 +39,8 @@ struct DevColumn {
   int32_t dict_bytes;      // cardinality * 4 (buffer-descriptor num_records for the gather)
   int32_t in_filter;       // referenced by a scan leaf
   int32_t in_agg;          // referenced by an aggregation or a group-by key
+  int32_t slot_off;        // byte offset of this column's staging slot inside the wave's LDS region
+  int32_t is_plane;        // fwd points at the column's VALUE PLANE: bit-packed (value - plane base), same stream format
 };
 
 struct DevLeaf {
@@ -80,10 +83,12 @@ struct ScanParams {
   int32_t num_leaves;
   int32_t num_nodes;
   int32_t num_agg_cols;
-  int32_t slot_bytes;          // LDS bytes of one staging slot (256 * max bits + 16, rounded to 16)
-  int32_t wave_lds_bytes;      // slots per wave * slot_bytes
+  int32_t queue_off;           // byte offset of the wave's gather queue inside its LDS region
+  int32_t wave_lds_bytes;      // staging slots (256 * bits + 16 each) + gather queue
   int32_t speculate;           // 1: issue aggregation-column loads together with the filter loads when the last tile matched
-  int32_t pad;
+  int32_t queue_cap;           // gather-queue capacity in entries (multiple of 64, >= 128)
+  int32_t stage_bytes;         // bytes of ONE staging buffer set (all column slots); the wave owns two (double buffering)
+  int32_t double_buffer;       // 1: prefetch the wave's next tile into the second staging buffer set
   DevColumn cols[kMaxCols];
   DevLeaf leaves[kMaxLeaves];
   DevNode nodes[kMaxNodes];
@@ -111,7 +116,7 @@ struct GroupParams {
   int32_t use_lds_table;
   int32_t group_cols[kMaxGroupCols];
   int32_t group_mult[kMaxGroupCols];
-  DevGroupAgg group_aggs[kMaxAggCols];
+  DevGroupAgg group_aggs[kMaxGroupAggs];
   unsigned long long* table_count; // [num_groups]
   long long* table_acc;            // [num_group_aggs * num_groups]
 };

@@ -48,6 +48,8 @@ struct Engine {
   int blocks_per_cu = 0;
   int flags = 0;
   bool use_dma = true;
+  int value_plane = -1;      // -1 auto, 0 never, 1 always (PINOT_GPU_VALUE_PLANE)
+  bool double_buffer = false;
   std::mutex mu;
 };
 Engine g_engine;
@@ -69,6 +71,11 @@ struct ColumnDev {
   DevContainer* d_dir = nullptr;
   std::vector<DevContainer> h_dir;
   std::vector<int64_t> posting_first;   // [cardinality + 1] index into the container directory
+  // value plane (built lazily on the device the first time the column is summed)
+  uint8_t* d_plane = nullptr;
+  int plane_bits = 0;                   // 1..31 packed, 32 = big-endian int32 values
+  int64_t plane_base = 0;               // value = plane_base + decoded field (0 for plane_bits == 32)
+  bool plane_ready = false;
 };
 
 // Per-query execution context: a stream plus reusable device scratch.  Pooled per segment so that
@@ -102,6 +109,7 @@ struct pg_segment {
   std::string name;
   std::vector<ColumnDev> cols;
   std::mutex ctx_mu;
+  std::mutex plane_mu;
   std::vector<ExecCtx*> free_ctx;
   std::vector<ExecCtx*> all_ctx;
 };
@@ -265,6 +273,7 @@ void free_segment(pg_segment* seg) {
     if (col.d_dict) (void)hipFree(col.d_dict);
     if (col.d_inv) (void)hipFree(col.d_inv);
     if (col.d_dir) (void)hipFree(col.d_dir);
+    if (col.d_plane) (void)hipFree(col.d_plane);
   }
   delete seg;
 }
@@ -274,29 +283,84 @@ void set_dynamic_lds(K kernel, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// ---- value planes ----
+// Policy: summing a dictionary column through its dictionary costs one L2 gather per matching row; a gather costs the
+// L2 as much as streaming ~22 bytes, so unless the dictionary is tiny (L1-resident) or the plane would be much wider
+// than the dictId stream, the plane wins as soon as a few percent of the rows match.
+bool want_value_plane(const ColumnDev& col) {
+  if (col.encoding != PG_FWD_FIXED_BIT_DICT || col.cardinality < 1) return false;
+  if (g_engine.value_plane == 0) return false;
+  if (g_engine.value_plane == 1) return true;
+  const int64_t range = (int64_t)col.h_dict.back() - (int64_t)col.h_dict.front();
+  int w = 1;
+  while (w < 32 && (range >> w) != 0) ++w;
+  return col.cardinality > 8192 || w - col.bits <= 8;
+}
+
+pg_status ensure_plane(pg_segment* seg, int column, ExecCtx* ctx) {
+  ColumnDev& col = seg->cols[(size_t)column];
+  std::lock_guard<std::mutex> lk(seg->plane_mu);
+  if (col.plane_ready) return PG_OK;
+  const int64_t lo = col.h_dict.front(), hi = col.h_dict.back();
+  const int64_t range = hi - lo;
+  int w = 1;
+  while (w < 32 && (range >> w) != 0) ++w;
+  col.plane_bits = w;
+  col.plane_base = w == 32 ? 0 : lo;
+  const size_t bytes = (size_t)std::max(seg->num_tiles, 1) * 256 * (size_t)w + 64;
+  HIP_TRY(hipMalloc((void**)&col.d_plane, bytes));
+  HIP_TRY(hipMemsetAsync(col.d_plane, 0, bytes, ctx->stream));
+  DevColumn dc;
+  memset(&dc, 0, sizeof(dc));
+  dc.fwd = col.d_fwd; dc.dict = col.d_dict; dc.bits = col.bits; dc.cardinality = col.cardinality; dc.dict_bytes = col.cardinality * 4;
+  const int in_slot = ((256 * col.bits + 16) + 15) & ~15;
+  const int waves = 4;
+  const size_t lds = (size_t)waves * (size_t)(in_slot + 64 * w * 4 + 16);
+  const int blocks = (int)std::max<long long>(1, std::min<long long>(((long long)seg->num_tiles + waves - 1) / waves, (long long)seg->num_cus * 2));
+  set_dynamic_lds(materialize_plane_kernel, lds);
+  materialize_plane_kernel<<<dim3((unsigned)blocks), dim3(waves * 64), lds, ctx->stream>>>(dc, col.d_plane, w, (int32_t)col.plane_base, seg->num_docs,
+                                                                                            seg->num_tiles, in_slot);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  seg->device_bytes += bytes;
+  col.plane_ready = true;
+  return PG_OK;
+}
+
 // ---- query lowering ----
 struct Lowered {
   ScanParams sp;
-  std::vector<int> col_of_slot;       // segment column index per slot
+  std::vector<int> col_of_slot;       // segment column index * 2 + (1 if the slot streams the value plane)
+  std::vector<char> plane_cols;       // per segment column: aggregations read it through its value plane
   int num_scan_leaves = 0;
   int max_bits = 1;
 };
 
-int slot_for(Lowered* lw, const pg_segment* seg, int column) {
-  for (size_t i = 0; i < lw->col_of_slot.size(); ++i) if (lw->col_of_slot[i] == column) return (int)i;
+int slot_for(Lowered* lw, const pg_segment* seg, int column, bool plane = false) {
+  const int id = column * 2 + (plane ? 1 : 0);
+  for (size_t i = 0; i < lw->col_of_slot.size(); ++i) if (lw->col_of_slot[i] == id) return (int)i;
   if ((int)lw->col_of_slot.size() >= kMaxCols) return -1;
   const ColumnDev& c = seg->cols[column];
   DevColumn& d = lw->sp.cols[lw->col_of_slot.size()];
-  d.fwd = c.d_fwd;
-  d.dict = c.d_dict;
-  d.bits = c.encoding == PG_FWD_RAW_FIXED_BYTE ? 32 : c.bits;
-  d.is_raw = c.encoding == PG_FWD_RAW_FIXED_BYTE;
-  d.cardinality = c.cardinality;
-  d.dict_bytes = c.cardinality * 4;
-  d.in_filter = 0;
-  d.in_agg = 0;
-  if (!d.is_raw) lw->max_bits = std::max(lw->max_bits, c.bits);
-  lw->col_of_slot.push_back(column);
+  memset(&d, 0, sizeof(d));
+  if (plane) {
+    d.fwd = c.d_plane;
+    d.dict = nullptr;
+    d.bits = c.plane_bits;
+    d.is_raw = c.plane_bits == 32;     // 32-bit planes are big-endian int32 values: the raw-column path
+    d.is_plane = c.plane_bits == 32 ? 0 : 1;
+    d.cardinality = 0;
+    d.dict_bytes = 0;
+  } else {
+    d.fwd = c.d_fwd;
+    d.dict = c.d_dict;
+    d.bits = c.encoding == PG_FWD_RAW_FIXED_BYTE ? 32 : c.bits;
+    d.is_raw = c.encoding == PG_FWD_RAW_FIXED_BYTE;
+    d.cardinality = c.cardinality;
+    d.dict_bytes = c.cardinality * 4;
+  }
+  if (!d.is_raw) lw->max_bits = std::max(lw->max_bits, d.bits);
+  lw->col_of_slot.push_back(id);
   lw->sp.num_cols = (int)lw->col_of_slot.size();
   return lw->sp.num_cols - 1;
 }
@@ -356,7 +420,18 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
         } else if (pr.kind == PG_PRED_DICT_RANGE) {
           int64_t lo = std::max<int64_t>(pr.lo, 0), hi = std::min<int64_t>(pr.hi, col.cardinality);
           if (lo >= hi) { L.kind = kLeafMatchNone; }
-          else {
+          else if (!lw->plane_cols.empty() && lw->plane_cols[(size_t)pr.column]) {
+            // The column is also summed through its value plane: evaluate the range on the plane so only one
+            // stream is read.  The dictionary is sorted, so dictIds [lo, hi) <=> values [dict[lo], dict[hi-1]].
+            int s = slot_for(lw, seg, pr.column, true);
+            if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
+            sp.cols[s].in_filter = 1;
+            const int64_t vlo = col.h_dict[(size_t)lo], vhi = col.h_dict[(size_t)hi - 1];
+            if (sp.cols[s].is_raw) { L.kind = kLeafRawRange; L.lo = (int32_t)vlo; L.span = (uint32_t)(vhi - vlo); }
+            else { L.kind = kLeafDictRange; L.lo = (int32_t)(vlo - col.plane_base); L.span = (uint32_t)(vhi - vlo + 1); }
+            L.col = s;
+            lw->num_scan_leaves++;
+          } else {
             int s = slot_for(lw, seg, pr.column);
             if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
             sp.cols[s].in_filter = 1;
@@ -409,29 +484,58 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
   return PG_OK;
 }
 
-int default_blocks_per_cu(size_t lds_per_block) {
-  int by_lds = lds_per_block ? (int)((160 * 1024) / lds_per_block) : 8;
-  return std::max(1, std::min(8, by_lds));
-}
+struct Geometry {
+  int blocks = 1;
+  int threads = kBlockThreads;
+  size_t lds = 0;
+  bool table_in_lds = false;
+};
 
-void finish_geometry(const pg_segment* seg, Lowered* lw, size_t extra_lds, int* blocks, size_t* lds_bytes) {
+constexpr size_t kLdsBudget = 156 * 1024;     // of the 160 KiB per CU; leaves room for the runtime's own use
+constexpr int kMaxWavesPerCu = 24;            // these kernels use ~80 VGPRs / ~100 SGPRs: 6 waves per SIMD are admitted
+
+// Lays out the per-wave LDS region (one staging slot per dictionary column + the gather queue), picks the
+// workgroup size that fits the LDS budget and sizes the grid to what is co-resident (a persistent grid: a
+// grid larger than residency runs in rounds and leaves the chip half empty during the last one).
+void finish_geometry(const pg_segment* seg, Lowered* lw, size_t table_bytes, bool need_queue, Geometry* g) {
   ScanParams& sp = lw->sp;
   sp.num_docs = seg->num_docs;
   sp.num_tiles = seg->num_tiles;
-  sp.slot_bytes = ((256 * lw->max_bits + 16) + 15) & ~15;
-  sp.wave_lds_bytes = std::max(sp.num_cols, 1) * sp.slot_bytes;
-  const int waves_per_block = kBlockThreads / 64;
-  size_t lds = (size_t)waves_per_block * sp.wave_lds_bytes + extra_lds;
-  lds = std::max(lds, sizeof(BlockPartial) * waves_per_block);
-  int bpc = g_engine.blocks_per_cu > 0 ? g_engine.blocks_per_cu : default_blocks_per_cu(lds);
-  long long want = ((long long)sp.num_tiles + waves_per_block - 1) / waves_per_block;
-  long long cap = (long long)seg->num_cus * bpc;
-  *blocks = (int)std::max<long long>(1, std::min(want, cap));
-  *lds_bytes = lds;
+  int off = 0;
+  for (int c = 0; c < sp.num_cols; ++c) {
+    sp.cols[c].slot_off = off;
+    if (!sp.cols[c].is_raw) off += ((256 * sp.cols[c].bits + 16) + 15) & ~15;
+  }
+  sp.stage_bytes = std::max(off, 16);
+  sp.double_buffer = g_engine.double_buffer ? 1 : 0;
+  off = (sp.double_buffer ? 2 : 1) * sp.stage_bytes;
+  sp.queue_off = off;
+  sp.queue_cap = 256;
+  if (need_queue) off += sp.queue_cap * 4;
+  sp.wave_lds_bytes = std::max(off, 128);
+  // choose the workgroup size (1, 2 or 4 wavefronts) that keeps the most wavefronts resident per CU within the LDS budget
+  g->table_in_lds = table_bytes > 0 && table_bytes <= 96 * 1024 && (size_t)sp.wave_lds_bytes + table_bytes <= kLdsBudget;
+  const size_t fixed = g->table_in_lds ? table_bytes : 0;
+  int waves = 1, best_resident = 0;
+  for (int w = kBlockThreads / 64; w >= 1; w >>= 1) {
+    const size_t lds_w = (size_t)w * sp.wave_lds_bytes + fixed;
+    if (lds_w > kLdsBudget) continue;
+    const int resident = std::min(kMaxWavesPerCu, (int)(kLdsBudget / lds_w) * w);
+    if (resident > best_resident) { best_resident = resident; waves = w; }
+  }
+  g->threads = waves * 64;
+  g->lds = (size_t)waves * sp.wave_lds_bytes + fixed;
+  g->lds = std::max(g->lds, sizeof(BlockPartial) * (size_t)waves);
+  int bpc = std::max(1, std::min(kMaxWavesPerCu / waves, (int)(kLdsBudget / g->lds)));
+  if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
+  const long long want = ((long long)sp.num_tiles + waves - 1) / waves;
+  const long long cap = (long long)seg->num_cus * bpc;
+  g->blocks = (int)std::max<long long>(1, std::min(want, cap));
 }
 
-double agg_value_double(const ColumnDev& col, int32_t key) {
+double agg_value_double(const ColumnDev& col, int32_t key, bool plane) {
   if (col.encoding == PG_FWD_RAW_FIXED_BYTE) return (double)key;
+  if (plane) return (double)(col.plane_base + (int64_t)key);   // 32-bit planes have base 0 and key = value
   return (double)col.h_dict[key];
 }
 
@@ -458,6 +562,10 @@ pg_status pg_init(const pg_config* config) {
   g_engine.flags = config ? config->flags : 0;
   const char* nodma = getenv("PINOT_GPU_NO_DMA");
   g_engine.use_dma = !(nodma && nodma[0] == '1');
+  const char* vp = getenv("PINOT_GPU_VALUE_PLANE");
+  g_engine.value_plane = vp ? atoi(vp) : -1;
+  const char* db = getenv("PINOT_GPU_DOUBLE_BUFFER");
+  g_engine.double_buffer = db && db[0] == '1';
   const char* bpc = getenv("PINOT_GPU_BLOCKS_PER_CU");
   if (bpc && atoi(bpc) > 0) g_engine.blocks_per_cu = atoi(bpc);
   g_engine.initialized = true;
@@ -643,11 +751,23 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
 
   Lowered lw;
   memset(&lw.sp, 0, sizeof(lw.sp));
+  const int num_cols_total = (int)seg->cols.size();
+  // Columns that are summed are read through their value plane (built on first use); decided before the filter is
+  // lowered so that a range predicate on the same column can be evaluated on the plane too.
+  lw.plane_cols.assign((size_t)std::max(num_cols_total, 1), 0);
+  for (int a = 0; a < na; ++a) {
+    const pg_aggregation& ag = q->aggregations[a];
+    if ((ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) && ag.column >= 0 && ag.column < num_cols_total &&
+        want_value_plane(seg->cols[(size_t)ag.column])) {
+      st = ensure_plane(seg, ag.column, ctx);
+      if (st != PG_OK) return st;
+      lw.plane_cols[(size_t)ag.column] = 1;
+    }
+  }
   if (timed) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
   st = lower_filter(seg, ctx, q, &lw);
   if (st != PG_OK) return st;
   ScanParams& sp = lw.sp;
-  const int num_cols_total = (int)seg->cols.size();
 
   // distinct projected columns (ExecutionStatistics numEntriesScannedPostFilter = numDocsScanned * numProjectedColumns)
   std::vector<int> projected;
@@ -664,7 +784,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if (ag.function < PG_AGG_COUNT || ag.function > PG_AGG_AVG) return fail(PG_ERR_UNSUPPORTED, "aggregation function %d", ag.function);
       if (ag.column < 0 || ag.column >= num_cols_total) return fail(PG_ERR_INVALID_ARGUMENT, "aggregation column %d out of range", ag.column);
       add_projected(ag.column);
-      int s = slot_for(&lw, seg, ag.column);
+      int s = slot_for(&lw, seg, ag.column, lw.plane_cols[(size_t)ag.column] != 0);
       if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
       sp.cols[s].in_agg = 1;
       int ac = -1;
@@ -678,9 +798,13 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if (ag.function == PG_AGG_MIN || ag.function == PG_AGG_MAX) sp.agg_cols[ac].need_minmax = 1;
       agg_slot_of[(size_t)a] = ac;
     }
-    int blocks = 1;
-    size_t lds = 0;
-    finish_geometry(seg, &lw, 0, &blocks, &lds);
+    bool need_queue = false;
+    for (int i = 0; i < sp.num_agg_cols; ++i) need_queue |= sp.agg_cols[i].need_sum && !sp.cols[sp.agg_cols[i].col].is_raw && !sp.cols[sp.agg_cols[i].col].is_plane;
+    Geometry geo;
+    finish_geometry(seg, &lw, 0, need_queue, &geo);
+    const int blocks = geo.blocks;
+    const size_t lds = geo.lds;
+    if ((size_t)sp.wave_lds_bytes > kLdsBudget) return fail(PG_ERR_UNSUPPORTED, "query needs %d bytes of LDS per wavefront", sp.wave_lds_bytes);
     sp.speculate = 1;
     st = ensure_partials(ctx, blocks);
     if (st != PG_OK) return st;
@@ -694,10 +818,10 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (g_engine.use_dma) {
       set_dynamic_lds(scan_agg_kernel<true>, lds);
-      scan_agg_kernel<true><<<dim3((unsigned)blocks), dim3(kBlockThreads), lds, ctx->stream>>>(sp);
+      scan_agg_kernel<true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp);
     } else {
       set_dynamic_lds(scan_agg_kernel<false>, lds);
-      scan_agg_kernel<false><<<dim3((unsigned)blocks), dim3(kBlockThreads), lds, ctx->stream>>>(sp);
+      scan_agg_kernel<false><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp);
     }
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -725,13 +849,15 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         if (ag.function == PG_AGG_COUNT) continue;
         const int ac = agg_slot_of[(size_t)a];
         const ColumnDev& col = seg->cols[(size_t)ag.column];
+        const bool plane = lw.plane_cols[(size_t)ag.column] != 0;
         if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) {
-          v.sum_i64 = fp.sum[ac];
+          // value plane: sum(value) = count * base + sum(value - base)
+          v.sum_i64 = fp.sum[ac] + (plane ? (long long)fp.count * (long long)col.plane_base : 0ll);
           v.sum_exact = 1;
-          v.sum = (double)fp.sum[ac];
+          v.sum = (double)v.sum_i64;
         } else if (fp.count > 0) {
-          if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, fp.kmin[ac]);
-          if (ag.function == PG_AGG_MAX) v.max = agg_value_double(col, fp.kmax[ac]);
+          if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, fp.kmin[ac], plane);
+          if (ag.function == PG_AGG_MAX) v.max = agg_value_double(col, fp.kmax[ac], plane);
         }
       }
       out->stats.num_docs_scanned = (int64_t)fp.count;
@@ -770,14 +896,14 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if (ag.function < PG_AGG_COUNT || ag.function > PG_AGG_AVG) return fail(PG_ERR_UNSUPPORTED, "aggregation function %d", ag.function);
       if (ag.column < 0 || ag.column >= num_cols_total) return fail(PG_ERR_INVALID_ARGUMENT, "aggregation column %d out of range", ag.column);
       add_projected(ag.column);
-      int s = slot_for(&lw, seg, ag.column);
+      int s = slot_for(&lw, seg, ag.column, lw.plane_cols[(size_t)ag.column] != 0);
       if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
       sp.cols[s].in_agg = 1;
       const int kind = (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) ? kGroupSum : (ag.function == PG_AGG_MIN ? kGroupMin : kGroupMax);
       int da = -1;
       for (int i = 0; i < gp.num_group_aggs; ++i) if (gp.group_aggs[i].col == s && gp.group_aggs[i].kind == kind) da = i;
       if (da < 0) {
-        if (gp.num_group_aggs >= kMaxAggCols) return fail(PG_ERR_UNSUPPORTED, "more than %d distinct group-by aggregations", kMaxAggCols);
+        if (gp.num_group_aggs >= kMaxGroupAggs) return fail(PG_ERR_UNSUPPORTED, "more than %d distinct group-by aggregations", kMaxGroupAggs);
         da = gp.num_group_aggs++;
         gp.group_aggs[da] = DevGroupAgg{s, kind};
       }
@@ -789,10 +915,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     gp.table_count = ctx->d_table;
     gp.table_acc = reinterpret_cast<long long*>(ctx->d_table + gp.num_groups);
     const size_t table_bytes = table_words * 8;
-    gp.use_lds_table = table_bytes <= 96 * 1024 ? 1 : 0;
-    int blocks = 1;
-    size_t lds = 0;
-    finish_geometry(seg, &lw, gp.use_lds_table ? table_bytes : 0, &blocks, &lds);
+    Geometry geo;
+    finish_geometry(seg, &lw, table_bytes, false, &geo);
+    if ((size_t)sp.wave_lds_bytes > kLdsBudget) return fail(PG_ERR_UNSUPPORTED, "query needs %d bytes of LDS per wavefront", sp.wave_lds_bytes);
+    gp.use_lds_table = geo.table_in_lds ? 1 : 0;
+    const int blocks = geo.blocks;
+    const size_t lds = geo.lds;
     gp.scan = sp;
     gp.scan.partials = nullptr;
     gp.scan.out_bitmap = nullptr;
@@ -800,11 +928,11 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (gp.use_lds_table) {
-      if (g_engine.use_dma) { set_dynamic_lds(scan_group_kernel<true, true>, lds); scan_group_kernel<true, true><<<dim3((unsigned)blocks), dim3(kBlockThreads), lds, ctx->stream>>>(gp); }
-      else { set_dynamic_lds(scan_group_kernel<false, true>, lds); scan_group_kernel<false, true><<<dim3((unsigned)blocks), dim3(kBlockThreads), lds, ctx->stream>>>(gp); }
+      if (g_engine.use_dma) { set_dynamic_lds(scan_group_kernel<true, true>, lds); scan_group_kernel<true, true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(gp); }
+      else { set_dynamic_lds(scan_group_kernel<false, true>, lds); scan_group_kernel<false, true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(gp); }
     } else {
-      if (g_engine.use_dma) { set_dynamic_lds(scan_group_kernel<true, false>, lds); scan_group_kernel<true, false><<<dim3((unsigned)blocks), dim3(kBlockThreads), lds, ctx->stream>>>(gp); }
-      else { set_dynamic_lds(scan_group_kernel<false, false>, lds); scan_group_kernel<false, false><<<dim3((unsigned)blocks), dim3(kBlockThreads), lds, ctx->stream>>>(gp); }
+      if (g_engine.use_dma) { set_dynamic_lds(scan_group_kernel<true, false>, lds); scan_group_kernel<true, false><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(gp); }
+      else { set_dynamic_lds(scan_group_kernel<false, false>, lds); scan_group_kernel<false, false><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(gp); }
     }
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -834,9 +962,14 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         if (ag.function == PG_AGG_COUNT) continue;
         const long long acc = ha[(size_t)dev_agg_of[(size_t)a] * (size_t)gp.num_groups + (size_t)g];
         const ColumnDev& col = seg->cols[(size_t)ag.column];
-        if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) { v.sum_i64 = acc; v.sum_exact = 1; v.sum = (double)acc; }
-        else if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, (int32_t)acc);
-        else v.max = agg_value_double(col, (int32_t)acc);
+        const bool plane = lw.plane_cols[(size_t)ag.column] != 0;
+        if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) {
+          v.sum_i64 = acc + (plane ? (long long)hc[g] * (long long)col.plane_base : 0ll);
+          v.sum_exact = 1;
+          v.sum = (double)v.sum_i64;
+        }
+        else if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, (int32_t)acc, plane);
+        else v.max = agg_value_double(col, (int32_t)acc, plane);
       }
       k++;
     }

@@ -147,7 +147,7 @@ __device__ uint32_t eval_leaf(const ScanParams& p, const DevLeaf& L, int tile, u
     case kLeafDictSet: {
       const DevColumn& c = p.cols[L.col];
       const int b = c.bits;
-      const uint8_t* slot = wave_lds + L.col * p.slot_bytes;   // staged by the caller
+      const uint8_t* slot = wave_lds + c.slot_off;   // wave_lds = current staging buffer, staged by the caller
       const LaneDec dec = make_lane_dec(b, lane);
       m = b <= 25 ? eval_dict_leaf_loop<false>(L, slot, dec, b) : eval_dict_leaf_loop<true>(L, slot, dec, b);
       break;
@@ -220,7 +220,7 @@ __device__ __forceinline__ void stage_columns(const ScanParams& p, int tile, uin
     const bool is_filter = col.in_filter != 0;
     if ((is_filter && filter_cols) || (!is_filter && agg_only_cols)) {
       const int tile_bytes = 256 * col.bits;
-      stage_tile<kDma>(col.fwd + (long long)tile * tile_bytes, wave_lds + c * p.slot_bytes, tile_bytes, lane);
+      stage_tile<kDma>(col.fwd + (long long)tile * tile_bytes, wave_lds + col.slot_off, tile_bytes, lane);
     }
   }
 }
@@ -252,47 +252,65 @@ __device__ __forceinline__ void store_tile_bitmap(unsigned long long* out, int t
   if (lane < kTileSteps) out[(long long)tile * kTileSteps + lane] = mine;
 }
 
-// Per-column aggregation of the matching docs of one staged tile.
+// Wave-private queue of matching dictIds waiting for their dictionary gather.  Matches are compacted into it
+// (ballot + mbcnt prefix), and it is drained 256 entries at a time with four back-to-back dense buffer loads and
+// ONE wait, so the number of gather instructions is (matches / 64) instead of (rows / 64) and the L2 round trip is
+// paid once per 256 matches instead of once per 8 steps.  `count` is wave-uniform.
+struct GatherQueue {
+  uint32_t* q;
+  int cap;
+  int count;
+};
+
+__device__ __forceinline__ void drain_queue(GatherQueue& gq, const __amdgpu_buffer_rsrc_t rsrc, int lane, long long& sum, int keep) {
+  // gathers entries [0, n) where n = count - keep rounded down to what is there; `keep` = 0 drains everything.
+  const int n = gq.count - keep;
+  __builtin_amdgcn_wave_barrier();
+  for (int base = 0; base < n; base += 256) {
+    int32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = base + j * 64 + lane;
+      const uint32_t d = gq.q[idx < n ? idx : 0];
+      // Dictionary.readIntValues gather; out-of-range offset => the buffer load returns 0 and touches no memory.
+      v[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, idx < n ? d * 4u : 0xFFFFFFFFu, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += (long long)v[j];
+  }
+  __builtin_amdgcn_wave_barrier();
+  gq.count = 0;
+}
+
+// Per-column aggregation of the matching docs of one staged tile: every lane walks the set bits of its mask.
 template <bool kWide>
 __device__ __forceinline__ void agg_dict_column(const DevColumn& col, const DevAggCol& ac, const uint8_t* slot, uint32_t m,
-                                                int lane, long long& sum, int32_t& kmin, int32_t& kmax) {
+                                                int lane, long long& sum, int32_t& kmin, int32_t& kmax, GatherQueue& gq) {
   const int b = col.bits;
   const LaneDec dec = make_lane_dec(b, lane);
-  if (ac.need_sum) {
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)col.dict, 0, col.dict_bytes, 0x00020000);
-    for (int kb = 0; kb < kTileSteps; kb += 8) {
-      if (__builtin_amdgcn_ballot_w64(((m >> kb) & 0xFFu) != 0u) == 0ull) continue;   // nothing to do in these 8 steps
-      uint32_t d[8];
-      int32_t v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        d[j] = decode_step<kWide>(slot, dec, kb + j, b);
-        const bool match = ((m >> (kb + j)) & 1u) != 0u;
-        // Dictionary.readIntValues gather: out-of-range offset => the buffer load returns 0 and touches no memory.
-        v[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, match ? d[j] * 4u : 0xFFFFFFFFu, 0, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        sum += (long long)v[j];
-        if (ac.need_minmax) {
-          const bool match = ((m >> (kb + j)) & 1u) != 0u;
-          const int32_t key = (int32_t)d[j];
-          kmin = (match && key < kmin) ? key : kmin;
-          kmax = (match && key > kmax) ? key : kmax;
-        }
-      }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)col.dict, 0, col.dict_bytes, 0x00020000);
+  uint32_t rem = m;
+  for (;;) {
+    const bool active = rem != 0u;
+    const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);
+    if (amask == 0ull) break;
+    const int k = active ? __builtin_ctz(rem) : 0;
+    rem &= rem - 1u;
+    const uint32_t d = decode_step<kWide>(slot, dec, k, b);
+    if (ac.need_minmax) {
+      // sorted dictionary => min/max of the value is min/max of the dictId; the lookup happens once on the host
+      const int32_t key = (int32_t)d;
+      kmin = (active && key < kmin) ? key : kmin;
+      kmax = (active && key > kmax) ? key : kmax;
     }
-  } else {
-    // MIN / MAX only: the dictionary is sorted, so min/max of the value is min/max of the dictId; no gather.
-    for (int kb = 0; kb < kTileSteps; kb += 8) {
-      if (__builtin_amdgcn_ballot_w64(((m >> kb) & 0xFFu) != 0u) == 0ull) continue;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int32_t key = (int32_t)decode_step<kWide>(slot, dec, kb + j, b);
-        const bool match = ((m >> (kb + j)) & 1u) != 0u;
-        kmin = (match && key < kmin) ? key : kmin;
-        kmax = (match && key > kmax) ? key : kmax;
-      }
+    if (col.is_plane) {
+      // value plane: the decoded field IS (value - base); no dictionary, no gather
+      if (ac.need_sum) sum += active ? (long long)d : 0ll;
+    } else if (ac.need_sum) {
+      const uint32_t pos = (uint32_t)gq.count + __builtin_amdgcn_mbcnt_hi((uint32_t)(amask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)amask, 0u));
+      if (active) gq.q[pos] = d;
+      gq.count += __builtin_popcountll(amask);
+      if (gq.count > gq.cap - 64) drain_queue(gq, rsrc, lane, sum, 0);
     }
   }
 }
@@ -332,20 +350,38 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
 #pragma unroll
   for (int a = 0; a < kMaxAggCols; ++a) { sum[a] = 0; kmin[a] = 0x7FFFFFFF; kmax[a] = (int32_t)0x80000000; }
 
-  bool hot = false;   // did the previous tile of this wave match anything? (drives speculative value-column loads)
-  for (int tile = blockIdx.x * waves_per_block + wave_in_block; tile < p.num_tiles; tile += total_waves) {
-    const bool spec = hot && p.speculate != 0;
-    stage_columns<kDma>(p, tile, wave_lds, lane, true, spec);
-    if constexpr (kDma) wait_vmem();
-    uint32_t m = eval_filter<kDma>(p, tile, wave_lds, lane);
+  GatherQueue gq;
+  gq.q = reinterpret_cast<uint32_t*>(wave_lds + p.queue_off);
+  gq.cap = p.queue_cap;
+  gq.count = 0;
+  // the queue may stay filled across tiles only when exactly one column is summed (its entries are all that column's)
+  int num_sum_cols = 0;
+#pragma unroll
+  for (int a = 0; a < kMaxAggCols; ++a)
+    num_sum_cols += (a < p.num_agg_cols && p.agg_cols[a].need_sum && !p.cols[p.agg_cols[a].col].is_raw && !p.cols[p.agg_cols[a].col].is_plane) ? 1 : 0;
+
+  // Double-buffered tile pipeline: while tile t is decoded from staging buffer `buf`, the LDS-DMA loads of this
+  // wave's next tile are already in flight into the other buffer, so the memory pipe never idles behind VALU work.
+  bool hot = false;        // did the last processed tile match anything? (drives speculative value-column loads)
+  bool cur_has_agg = false;
+  int buf = 0;
+  int tile = blockIdx.x * waves_per_block + wave_in_block;
+  if (tile < p.num_tiles) stage_columns<kDma>(p, tile, wave_lds, lane, true, false);
+  for (; tile < p.num_tiles; tile += total_waves) {
+    uint8_t* cur = wave_lds + buf * p.stage_bytes;
+    if constexpr (kDma) wait_vmem();                       // the current tile has landed
+    const int next = tile + total_waves;
+    const bool next_has_agg = hot && p.speculate != 0;
+    if (p.double_buffer && next < p.num_tiles) stage_columns<kDma>(p, next, wave_lds + (buf ^ 1) * p.stage_bytes, lane, true, next_has_agg);
+    uint32_t m = eval_filter<kDma>(p, tile, cur, lane);
     m &= valid_lane_mask(p.num_docs, tile, lane);
     if (p.out_bitmap) store_tile_bitmap(p.out_bitmap, tile, m, lane);
     count += (unsigned)__builtin_popcount(m);
     const bool any = __builtin_amdgcn_ballot_w64(m != 0u) != 0ull;
     hot = any;
     if (any && p.num_agg_cols > 0) {
-      if (!spec) {
-        stage_columns<kDma>(p, tile, wave_lds, lane, false, true);
+      if (!cur_has_agg) {
+        stage_columns<kDma>(p, tile, cur, lane, false, true);
         if constexpr (kDma) wait_vmem();
       }
 #pragma unroll
@@ -355,12 +391,35 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
           const DevColumn& col = p.cols[ac.col];
           if (col.is_raw) {
             agg_raw_column(col, ac, p.num_docs, tile, m, lane, sum[a], kmin[a], kmax[a]);
-          } else if (col.bits <= 25) {
-            agg_dict_column<false>(col, ac, wave_lds + ac.col * p.slot_bytes, m, lane, sum[a], kmin[a], kmax[a]);
           } else {
-            agg_dict_column<true>(col, ac, wave_lds + ac.col * p.slot_bytes, m, lane, sum[a], kmin[a], kmax[a]);
+            if (col.bits <= 25) agg_dict_column<false>(col, ac, cur + col.slot_off, m, lane, sum[a], kmin[a], kmax[a], gq);
+            else agg_dict_column<true>(col, ac, cur + col.slot_off, m, lane, sum[a], kmin[a], kmax[a], gq);
+            if (num_sum_cols > 1 && ac.need_sum && !col.is_plane && gq.count > 0) {
+              const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)col.dict, 0, col.dict_bytes, 0x00020000);
+              drain_queue(gq, rsrc, lane, sum[a], 0);
+            }
           }
         }
+      }
+    }
+    if (p.double_buffer) {
+      cur_has_agg = next_has_agg;
+      buf ^= 1;
+    } else if (next < p.num_tiles) {
+      // single buffer: the next tile is staged only now that this one is fully consumed
+      stage_columns<kDma>(p, next, wave_lds, lane, true, next_has_agg);
+      cur_has_agg = next_has_agg;
+    }
+  }
+
+  // final drain of the carried queue (single summed column)
+  if (num_sum_cols == 1 && gq.count > 0) {
+#pragma unroll
+    for (int a = 0; a < kMaxAggCols; ++a) {
+      if (a < p.num_agg_cols && p.agg_cols[a].need_sum && !p.cols[p.agg_cols[a].col].is_raw && !p.cols[p.agg_cols[a].col].is_plane) {
+        const DevColumn& col = p.cols[p.agg_cols[a].col];
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)col.dict, 0, col.dict_bytes, 0x00020000);
+        drain_queue(gq, rsrc, lane, sum[a], 0);
       }
     }
   }
@@ -465,7 +524,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_group_kernel(const GroupPa
   unsigned long long* t_cnt;
   long long* t_acc;
   if constexpr (kLdsTable) {
-    t_cnt = reinterpret_cast<unsigned long long*>(smem + waves_per_block * p.wave_lds_bytes);
+    t_cnt = reinterpret_cast<unsigned long long*>(smem + waves_per_block * p.wave_lds_bytes);   // after every wave's staging buffers
     t_acc = reinterpret_cast<long long*>(t_cnt + G);
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
       t_cnt[g] = 0ull;
@@ -480,12 +539,21 @@ __global__ __launch_bounds__(kBlockThreads) void scan_group_kernel(const GroupPa
     t_acc = gp.table_acc;
   }
 
-  for (int tile = blockIdx.x * waves_per_block + wave_in_block; tile < p.num_tiles; tile += total_waves) {
-    stage_columns<kDma>(p, tile, wave_lds, lane, true, true);   // group-by touches every column of (nearly) every tile
+  int buf = 0;
+  int tile = blockIdx.x * waves_per_block + wave_in_block;
+  if (tile < p.num_tiles) stage_columns<kDma>(p, tile, wave_lds, lane, true, true);   // group-by touches every column of (nearly) every tile
+  for (; tile < p.num_tiles; tile += total_waves) {
+    uint8_t* cur = wave_lds + buf * p.stage_bytes;
     if constexpr (kDma) wait_vmem();
-    uint32_t m = eval_filter<kDma>(p, tile, wave_lds, lane);
+    const int next = tile + total_waves;
+    if (p.double_buffer) {
+      if (next < p.num_tiles) stage_columns<kDma>(p, next, wave_lds + (buf ^ 1) * p.stage_bytes, lane, true, true);
+      buf ^= 1;
+    }
+    uint32_t m = eval_filter<kDma>(p, tile, cur, lane);
     m &= valid_lane_mask(p.num_docs, tile, lane);
-    if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
+    const bool any = __builtin_amdgcn_ballot_w64(m != 0u) != 0ull;
+    if (any)
 
     for (int kb = 0; kb < kTileSteps; kb += 8) {
       if (__builtin_amdgcn_ballot_w64(((m >> kb) & 0xFFu) != 0u) == 0ull) continue;
@@ -497,7 +565,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_group_kernel(const GroupPa
         const DevColumn& col = p.cols[gp.group_cols[c]];
         const int b = col.bits;
         const LaneDec dec = make_lane_dec(b, lane);
-        const uint8_t* slot = wave_lds + gp.group_cols[c] * p.slot_bytes;
+        const uint8_t* slot = cur + col.slot_off;
         const uint32_t mult = (uint32_t)gp.group_mult[c];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -525,17 +593,18 @@ __global__ __launch_bounds__(kBlockThreads) void scan_group_kernel(const GroupPa
         } else {
           const int b = col.bits;
           const LaneDec dec = make_lane_dec(b, lane);
-          const uint8_t* slot = wave_lds + ga.col * p.slot_bytes;
-          if (ga.kind == kGroupSum) {
+          const uint8_t* slot = cur + col.slot_off;
+          if (ga.kind == kGroupSum && !col.is_plane) {
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)col.dict, 0, col.dict_bytes, 0x00020000);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const uint32_t d = b <= 25 ? decode_step<false>(slot, dec, kb + j, b) : decode_step<true>(slot, dec, kb + j, b);
               const bool match = ((m >> (kb + j)) & 1u) != 0u;
-              v[j] = (long long)__builtin_amdgcn_raw_buffer_load_b32(rsrc, match ? d * 4u : 0xFFFFFFFFu, 0, 0);
+              v[j] = (long long)(int32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, match ? d * 4u : 0xFFFFFFFFu, 0, 0);
             }
           } else {
-            // MIN / MAX on a sorted dictionary: aggregate the dictId, look the value up on the host at the end.
+            // value plane: the decoded field is (value - base).  MIN / MAX on a sorted dictionary: aggregate the
+            // dictId (monotone in the value), look the value up on the host at the end.
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               v[j] = (long long)(b <= 25 ? decode_step<false>(slot, dec, kb + j, b) : decode_step<true>(slot, dec, kb + j, b));
@@ -548,6 +617,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_group_kernel(const GroupPa
         }
       }
     }
+    if (!p.double_buffer && next < p.num_tiles) stage_columns<kDma>(p, next, wave_lds, lane, true, true);
   }
 
   if constexpr (kLdsTable) {
@@ -616,6 +686,58 @@ __global__ __launch_bounds__(kBlockThreads) void roaring_expand_kernel(const uin
   for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
     const unsigned long long v = w[j];
     if (v != 0ull && base + j < num_words) bitmap[base + j] |= v;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Value-plane materialisation (one-time, per summed column): plane[doc] = dictionary[dictId[doc]] - base, bit-packed
+// with `w` bits in the SAME big-endian MSB-first stream format as the forward index, so the scan kernels decode it
+// with the same code.  It trades HBM capacity (288 GB) for the per-row dictionary gather, which on MI355X costs as
+// much L2 capacity as streaming ~22 bytes (profiles/r1_microbench.jsonl).  w == 32 stores big-endian int32 values.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockThreads) void materialize_plane_kernel(const DevColumn col, uint8_t* __restrict__ out, int w, int32_t base,
+                                                                          int num_docs, int num_tiles, int in_slot_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  const int out_words = 64 * w;                                   // 2048 values * w bits
+  uint8_t* wave_lds = smem + wave_in_block * (in_slot_bytes + out_words * 4 + 16);
+  uint32_t* W = reinterpret_cast<uint32_t*>(wave_lds + in_slot_bytes);
+  const int total_waves = gridDim.x * waves_per_block;
+  const int b = col.bits;
+  const LaneDec dec = make_lane_dec(b, lane);
+  for (int tile = blockIdx.x * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
+    stage_tile<false>(col.fwd + (long long)tile * 256 * b, wave_lds, 256 * b, lane);
+    if (w < 32) for (int i = lane; i <= out_words; i += 64) W[i] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < kTileSteps; ++k) {
+      const uint32_t d = b <= 25 ? decode_step<false>(wave_lds, dec, k, b) : decode_step<true>(wave_lds, dec, k, b);
+      const long long doc = (long long)tile * kTileDocs + k * 64 + lane;
+      const bool valid = doc < num_docs;
+      const int32_t v = valid ? col.dict[d < (uint32_t)col.cardinality ? d : 0u] : base;
+      if (w == 32) {
+        if (valid) *reinterpret_cast<uint32_t*>(out + doc * 4) = __builtin_bswap32((uint32_t)v);
+      } else {
+        const uint32_t x = (uint32_t)v - (uint32_t)base;
+        const uint32_t pos = (uint32_t)(k * 64 + lane) * (uint32_t)w;
+        const uint32_t j = pos >> 5, s = pos & 31u;
+        if (s + (uint32_t)w <= 32u) {
+          atomicOr(&W[j], x << (32u - s - (uint32_t)w));
+        } else {
+          const uint32_t lo_bits = s + (uint32_t)w - 32u;
+          atomicOr(&W[j], x >> lo_bits);
+          atomicOr(&W[j + 1], x << (32u - lo_bits));
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (w < 32) {
+      uint32_t* dst = reinterpret_cast<uint32_t*>(out + (long long)tile * 256 * w);
+      for (int i = lane; i < out_words; i += 64) dst[i] = __builtin_bswap32(W[i]);   // host-order BE word -> stream bytes
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

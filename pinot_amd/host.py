@@ -1,0 +1,114 @@
+"""Python handle over the C++ host mirror (libpinot_host.so): SQL in, results blocks out.
+
+Plays the role of the reference's test harness `BaseQueriesTest.getOperator(sql)` / `getBrokerResponse(sql, planMaker)`
+(pinot-core/src/test/java/org/apache/pinot/queries/BaseQueriesTest.java:100-105,154-156): the query is parsed, lowered
+with dictionary binary searches and planned by the C++ `GpuPlanMaker`, executed through the C ABI on the device, and the
+per-segment blocks are merged by the C++ combine step.
+"""
+import ctypes as C
+import json
+
+from . import _abi
+from .segment import load_host_library
+
+
+class HostError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status   # 1 bad query, 2 not offloadable (keep the CPU plan), 3 runtime
+
+
+def _lib():
+    lib = load_host_library()
+    if getattr(lib, "_host_bound", False):
+        return lib
+    vp = C.c_void_p
+    lib.ph_last_error.restype = C.c_char_p
+    lib.ph_free.argtypes = [vp]
+    lib.ph_segment_create.restype = vp
+    lib.ph_segment_create.argtypes = [C.c_char_p, C.c_int32]
+    lib.ph_segment_add_int_column.restype = C.c_int32
+    lib.ph_segment_add_int_column.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64]
+    lib.ph_segment_add_string_column.restype = C.c_int32
+    lib.ph_segment_add_string_column.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, vp, C.c_uint64, C.c_char_p, vp, C.c_uint64]
+    lib.ph_segment_load.restype = C.c_int32
+    lib.ph_segment_load.argtypes = [vp, C.c_int32]
+    lib.ph_segment_destroy.argtypes = [vp]
+    lib.ph_plan_maker_init.restype = C.c_int32
+    lib.ph_plan_maker_init.argtypes = [C.c_int32, C.c_int32]
+    for name in ("ph_parse_sql", "ph_lower_predicate", "ph_execute_sql"):
+        getattr(lib, name).restype = vp
+    lib.ph_parse_sql.argtypes = [C.c_char_p, C.POINTER(C.c_int32)]
+    lib.ph_lower_predicate.argtypes = [C.c_char_p, vp, C.c_int32, C.POINTER(C.c_int32)]
+    lib.ph_execute_sql.argtypes = [C.POINTER(vp), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
+    lib._host_bound = True
+    return lib
+
+
+def _take_json(lib, ptr, status):
+    if status.value != 0 or not ptr:
+        raise HostError(status.value, (lib.ph_last_error() or b"").decode("utf-8", "replace"))
+    try:
+        return json.loads(C.string_at(ptr).decode("utf-8"))
+    finally:
+        lib.ph_free(ptr)
+
+
+def parse_sql(sql):
+    lib = _lib()
+    st = C.c_int32()
+    return _take_json(lib, lib.ph_parse_sql(sql.encode(), C.byref(st)), st)
+
+
+def lower_predicate(predicate_sql, dictionary_bytes, cardinality):
+    lib = _lib()
+    st = C.c_int32()
+    return _take_json(lib, lib.ph_lower_predicate(predicate_sql.encode(), dictionary_bytes.ctypes.data, cardinality, C.byref(st)), st)
+
+
+def init_plan_maker(device=0, time_kernels=True):
+    lib = _lib()
+    st = lib.ph_plan_maker_init(device, int(time_kernels))
+    if st != 0:
+        raise HostError(st, (lib.ph_last_error() or b"").decode())
+
+
+class HostSegment:
+    """ImmutableSegment of the C++ host mirror built from a `SegmentData` (buffers stay owned by the SegmentData)."""
+
+    def __init__(self, segment_data, string_dicts=None, device=0):
+        lib = _lib()
+        self.lib = lib
+        self.data = segment_data
+        self.handle = C.c_void_p(lib.ph_segment_create(segment_data.name.encode(), segment_data.num_docs))
+        string_dicts = string_dicts or {}
+        for c in segment_data.columns:
+            inv_ptr = c.inverted.ctypes.data if c.inverted is not None else None
+            inv_size = c.inverted.nbytes if c.inverted is not None else 0
+            if c.name in string_dicts:
+                values = b"".join(s.encode("utf-8") + b"\0" for s in string_dicts[c.name])
+                st = lib.ph_segment_add_string_column(self.handle, c.name.encode(), c.bits, c.cardinality, c.fwd.ctypes.data, c.fwd.nbytes,
+                                                      values, inv_ptr, inv_size)
+            else:
+                has_dict = c.encoding == _abi.PG_FWD_FIXED_BIT_DICT
+                st = lib.ph_segment_add_int_column(self.handle, c.name.encode(), int(has_dict), c.bits, c.cardinality, c.fwd.ctypes.data,
+                                                   c.fwd.nbytes, c.dictionary.ctypes.data if has_dict else None,
+                                                   c.dictionary.nbytes if has_dict else 0, inv_ptr, inv_size)
+            if st != 0:
+                raise HostError(st, (lib.ph_last_error() or b"").decode())
+        st = lib.ph_segment_load(self.handle, device)
+        if st != 0:
+            raise HostError(st, (lib.ph_last_error() or b"").decode())
+
+    def destroy(self):
+        if self.handle:
+            self.lib.ph_segment_destroy(self.handle)
+            self.handle = None
+
+
+def execute_sql(segments, sql, max_execution_threads=0):
+    """Returns {"segments": [per-segment block...], "combined": block}."""
+    lib = _lib()
+    arr = (C.c_void_p * len(segments))(*[s.handle for s in segments])
+    st = C.c_int32()
+    return _take_json(lib, lib.ph_execute_sql(arr, len(segments), sql.encode(), max_execution_threads, C.byref(st)), st)

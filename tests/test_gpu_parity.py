@@ -163,7 +163,7 @@ def test_group_by_lds_table(engine):
     b, idb, dvb = H.random_dict_column(rng, "b", n, 65536, value_stride=2)
     f, idf, _ = H.random_dict_column(rng, "f", n, 1000)
     seg = S.SegmentData("c3", n, [k, a, b, f, S.Column.raw("r", rng.integers(-50, 50, n).astype(np.int32))])
-    aggs = [(Q.SUM, 1), (Q.MAX, 2), (Q.COUNT, -1), (Q.MIN, 2), (Q.AVG, 1), (Q.SUM, 4), (Q.MIN, 4)]
+    aggs = [(Q.SUM, 1), (Q.MAX, 2), (Q.COUNT, -1), (Q.MIN, 2), (Q.AVG, 1), (Q.SUM, 4), (Q.MIN, 4)]  # 5 distinct device accumulators
     got, _ = run_both(engine, seg, Q.QuerySpec(aggs, group_by=[0]))
     assert len(got.groups) == 1000
     g7 = ida[idk == 7]
@@ -293,3 +293,41 @@ def test_concurrent_queries_on_one_segment(engine):
         [t.start() for t in threads]
         [t.join() for t in threads]
     assert not errors, errors
+
+
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_value_plane_and_dictionary_gather_paths_agree(mode, monkeypatch):
+    """SUM through the device-built value plane (PINOT_GPU_VALUE_PLANE=1) and through per-row dictionary gathers (=0)
+    must both equal the oracle, for narrow, wide (31-bit range) and negative-valued dictionaries, same-column filters
+    (the range is evaluated on the plane) and group-by."""
+    import torch  # noqa: F401
+    from pinot_amd.engine import Engine
+    monkeypatch.setenv("PINOT_GPU_VALUE_PLANE", mode)
+    eng = Engine(device_id=0, time_kernels=True)   # pg_init re-reads the environment
+    try:
+        rng = np.random.default_rng(12)
+        n = 150001
+        narrow, ids_n, dv_n = H.random_dict_column(rng, "narrow", n, 70000, value_stride=3)
+        wide_values = np.sort(rng.choice(np.arange(-2 ** 31, 2 ** 31 - 1, 65537, dtype=np.int64), 5000, replace=False)).astype(np.int32)
+        ids_w = rng.integers(0, 5000, n).astype(np.int32)
+        wide = S.Column.from_dict_ids("wide", wide_values, ids_w)
+        single = S.Column.from_dict_ids("single", np.array([-17], dtype=np.int32), np.zeros(n, dtype=np.int32))
+        k, idk, _ = H.random_dict_column(rng, "k", n, 300)
+        seg = S.SegmentData("planes", n, [narrow, wide, single, k])
+        aggs = [(Q.SUM, 0), (Q.AVG, 1), (Q.SUM, 2), (Q.MIN, 0), (Q.MAX, 1), (Q.COUNT, -1), (Q.MIN, 1), (Q.MAX, 0)]
+        filters = [None, Q.leaf(Q.Pred.dict_range(0, 20000, 50000)), Q.leaf(Q.Pred.dict_range(1, 100, 4000)),
+                   Q.and_(Q.leaf(Q.Pred.dict_range(0, 1000, 69000)), Q.leaf(Q.Pred.dict_set(1, list(range(0, 5000, 3)), 5000))),
+                   Q.leaf(Q.Pred.dict_range(3, 0, 3))]
+        with eng.open(seg) as gseg:
+            for flt in filters:
+                spec = Q.QuerySpec(aggs, filter=flt)
+                H.assert_results_equal(gseg.execute(spec), oracle.execute(seg, spec))
+                gspec = Q.QuerySpec(aggs, filter=flt, group_by=[3])
+                H.assert_results_equal(gseg.execute(gspec), oracle.execute(seg, gspec))
+        got = None
+        with eng.open(seg) as gseg:
+            got = gseg.execute(Q.QuerySpec([(Q.SUM, 1)]))
+        assert got.aggregations[0].sum_i64 == int(wide_values[ids_w].astype(np.int64).sum())
+    finally:
+        monkeypatch.delenv("PINOT_GPU_VALUE_PLANE")
+        Engine(device_id=0, time_kernels=True)

@@ -1,0 +1,44 @@
+#!/bin/bash
+# GPU session driver: tools/gpu_run.sh <mode>...   (modes: smoke micro test testall bench benchvar sweep prof pmc)
+set -u
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+short() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('kernel_ms=%.4f achieved=%.0f GB/s frac=%.3f rows/s=%.3e parity=%s' % (d['roofline']['kernel_ms'], d['roofline']['achieved'], d['roofline']['frac'], d['value'], d.get('parity',{}).get('bit_exact_vs_oracle')))"; }
+for mode in "$@"; do
+case $mode in
+smoke)
+  echo "== smoke =="; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ;;
+micro)
+  echo "== microbench =="; timeout 300 ./tools/microbench > $OUT/microbench.jsonl 2>&1; tail -60 $OUT/microbench.jsonl ;;
+test)
+  echo "== pytest gpu =="; timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 ;;
+testall)
+  echo "== pytest gpu (no -x) =="; timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -40 ;;
+bench)
+  echo "== bench 1B =="; timeout 900 python bench.py --steps 20 --warmup 3 --extra > $OUT/bench_1B.json 2> $OUT/bench_1B.err; cat $OUT/bench_1B.json; grep extra $OUT/bench_1B.err ;;
+benchvar)
+  for v in "PINOT_GPU_VALUE_PLANE=0" "PINOT_GPU_DOUBLE_BUFFER=1" "PINOT_GPU_VALUE_PLANE=0 PINOT_GPU_DOUBLE_BUFFER=1" "PINOT_GPU_NO_DMA=1"; do
+    echo "== bench $v =="; env $v timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --extra 2> $OUT/tmp.err | short; grep extra $OUT/tmp.err | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('   %-34s %.3f ms %6.0f GB/s' % (d['extra'], d['kernel_ms'], d['GBps']))"
+  done ;;
+sweep)
+  for bpc in 2 3 4 5 6 8 10 12; do echo "== bench bpc=$bpc =="; PINOT_GPU_BLOCKS_PER_CU=$bpc timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | short; done ;;
+prof)
+  echo "== rocprof =="; cd /tmp && export TMPDIR=/tmp
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/rocprof.log 2>&1
+  tail -2 $OUT/rocprof.log; find $OUT/prof -name "*kernel_stats*.csv" -exec cat {} \; | head -12
+  find $OUT/prof -name "*kernel_trace*.csv" -size +8M -delete
+  cd $GRAFT_REPO_ROOT ;;
+pmc)
+  echo "== rocprof pmc =="; cd /tmp && export TMPDIR=/tmp
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+  tail -2 $OUT/pmc_fetch.log
+  for f in $(find $OUT/pmc_fetch -name "*counter_collection*.csv"); do head -1 $f; grep scan_agg $f | head -4; done
+  timeout 900 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_tcc.log 2>&1
+  for f in $(find $OUT/pmc_tcc -name "*counter_collection*.csv"); do head -1 $f; grep scan_agg $f | head -4; done
+  cd $GRAFT_REPO_ROOT ;;
+esac
+done

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void stream_read_dma(const uint8_t* __restrict
 
 // 2. gather from a table in global memory (L2 resident): `active_pct` percent of lanes do a real gather,
 // the others present an out-of-range buffer offset (returns 0, no memory access).
+template <int kAux>
 __global__ __launch_bounds__(256) void gather_global(const int32_t* __restrict__ table, int table_entries, int iters, int active_pct, unsigned long long* out) {
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, table_entries * 4, 0x00020000);
   uint32_t x = mix32(blockIdx.x * 256u + threadIdx.x + 1u);
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void gather_global(const int32_t* __restrict__
       x = mix32(x + 0x9e3779b9u);
       const uint32_t idx = (uint32_t)(((unsigned long long)x * (unsigned)table_entries) >> 32);
       const bool active = (mix32(x ^ 0x55555555u) % 100u) < (unsigned)active_pct;
-      v[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, active ? idx * 4u : 0xFFFFFFFFu, 0, 0);
+      v[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, active ? idx * 4u : 0xFFFFFFFFu, 0, kAux);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc += v[j];
@@ -86,6 +87,52 @@ __global__ __launch_bounds__(256) void gather_lds(const int32_t* __restrict__ ta
     }
   }
   if (acc == 0x1234567ll) out[0] = acc;
+}
+
+
+// 5. mixed: every wave streams 4 KiB through LDS-DMA and issues `gathers_per_chunk` dense 64-lane gathers from a
+// 400 KB table per chunk (C2b at 10 % selectivity = ~120 gathers per 4 KiB = ~2 instructions), no decode work.
+template <int kAux>
+__global__ __launch_bounds__(256) void stream_plus_gather(const uint8_t* __restrict__ src, size_t nbytes, const int32_t* __restrict__ table, int table_entries,
+                                                          int gather_instrs, unsigned long long* out) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 2 * 4096];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t* slot = lds + wave * 8192;
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, table_entries * 4, 0x00020000);
+  unsigned long long acc = 0;
+  uint32_t x = mix32(blockIdx.x * 256u + threadIdx.x + 1u);
+  const size_t nchunks = nbytes / 4096, total_waves = (size_t)gridDim.x * 4;
+  size_t c = (size_t)blockIdx.x * 4 + wave;
+  int buf = 0;
+  if (c < nchunks) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + c * 4096 + j * 1024 + lane * 16), (lds_void_t*)(slot + j * 1024), 16, 0, 0);
+  }
+  for (; c < nchunks; c += total_waves, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const size_t n = c + total_waves;
+    if (n < nchunks) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + n * 4096 + j * 1024 + lane * 16), (lds_void_t*)(slot + (buf ^ 1) * 4096 + j * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4 v = *reinterpret_cast<const uint4*>(slot + buf * 4096 + j * 1024 + lane * 16);
+      acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+    for (int g = 0; g < gather_instrs; g += 2) {
+      int v[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        x = mix32(x + 0x9e3779b9u);
+        const uint32_t idx = (uint32_t)(((unsigned long long)x * (unsigned)table_entries) >> 32);
+        v[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (g + j < gather_instrs) ? idx * 4u : 0xFFFFFFFFu, 0, kAux);
+      }
+      acc += (unsigned)(v[0] + v[1]);
+    }
+  }
+  if (acc == 0x1234567ull) out[0] = acc;
 }
 
 // 4. LDS atomics on a group table: 64-bit add + 64-bit max + 64-bit count (what group-by does per row)
@@ -155,7 +202,7 @@ int main() {
     CHECK(hipMemcpy(d_tab, h.data(), entries * 4, hipMemcpyHostToDevice));
     for (int pct : {100, 50, 10, 1}) {
       const int iters = 2048, blocks = cus * 8;
-      double ms = time_ms([&] { gather_global<<<blocks, 256>>>(d_tab, entries, iters, pct, d_out); }, 3);
+      double ms = time_ms([&] { gather_global<0><<<blocks, 256>>>(d_tab, entries, iters, pct, d_out); }, 3);
       const double lanes = (double)blocks * 256 * iters;
       printf("{\"bench\": \"gather_global\", \"table_entries\": %d, \"active_pct\": %d, \"lane_slots_per_s\": %.3e, \"gathers_per_s\": %.3e}\n", entries, pct,
              lanes / ms * 1e3, lanes * pct / 100.0 / ms * 1e3);
@@ -165,6 +212,35 @@ int main() {
       CHECK(hipFuncSetAttribute((const void*)gather_lds, hipFuncAttributeMaxDynamicSharedMemorySize, entries * 4));
       double ms = time_ms([&] { gather_lds<<<blocks, 256, entries * 4>>>(d_tab, entries, iters, d_out); }, 3);
       printf("{\"bench\": \"gather_lds\", \"table_entries\": %d, \"blocks\": %d, \"gathers_per_s\": %.3e}\n", entries, blocks, (double)blocks * 256 * iters / ms * 1e3);
+    }
+    CHECK(hipFree(d_tab));
+  }
+
+
+  // gather cache-policy variants (100000-entry table, dense)
+  {
+    const int entries = 100000;
+    std::vector<int32_t> h(entries);
+    for (int i = 0; i < entries; ++i) h[i] = i * 7 + 3;
+    int32_t* d_tab;
+    CHECK(hipMalloc((void**)&d_tab, entries * 4));
+    CHECK(hipMemcpy(d_tab, h.data(), entries * 4, hipMemcpyHostToDevice));
+    const int iters = 2048, blocks = cus * 8;
+    const double lanes = (double)blocks * 256 * iters;
+#define AUXRUN(A) { double ms = time_ms([&] { gather_global<A><<<blocks, 256>>>(d_tab, entries, iters, 100, d_out); }, 3); \
+    printf("{\"bench\": \"gather_global_aux\", \"aux\": %d, \"gathers_per_s\": %.3e}\n", A, lanes / ms * 1e3); }
+    AUXRUN(0) AUXRUN(1) AUXRUN(2) AUXRUN(3) AUXRUN(16) AUXRUN(17) AUXRUN(18) AUXRUN(19)
+    // mixed stream + gather
+    for (int bpc : {2, 4}) for (int gi : {0, 1, 2, 4, 8}) {
+      double ms = time_ms([&] { stream_plus_gather<0><<<cus * bpc, 256>>>(d_buf, bytes, d_tab, entries, gi, d_out); }, 3);
+      printf("{\"bench\": \"stream_plus_gather\", \"blocks_per_cu\": %d, \"gather_instrs_per_4KiB\": %d, \"GBps\": %.1f, \"gathers_per_s\": %.3e}\n", bpc, gi,
+             bytes / ms / 1e6, (double)(bytes / 4096) * gi * 64 / ms * 1e3);
+    }
+    for (int gi : {2, 4}) {
+      double ms = time_ms([&] { stream_plus_gather<2><<<cus * 4, 256>>>(d_buf, bytes, d_tab, entries, gi, d_out); }, 3);
+      printf("{\"bench\": \"stream_plus_gather_nt\", \"gather_instrs_per_4KiB\": %d, \"GBps\": %.1f}\n", gi, bytes / ms / 1e6);
+      ms = time_ms([&] { stream_plus_gather<17><<<cus * 4, 256>>>(d_buf, bytes, d_tab, entries, gi, d_out); }, 3);
+      printf("{\"bench\": \"stream_plus_gather_sc0sc1\", \"gather_instrs_per_4KiB\": %d, \"GBps\": %.1f}\n", gi, bytes / ms / 1e6);
     }
     CHECK(hipFree(d_tab));
   }
