@@ -36,6 +36,7 @@ def parse_args():
     ap.add_argument("--threshold", type=int, default=100, help="f < threshold (dictIds [0, threshold) of 1000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra", action="store_true", help="also time the other BASELINE.md query shapes (stderr)")
+    ap.add_argument("--profile-waves", action="store_true", help="diagnostic: per-wave phase cycle counters (perturbs timing slightly)")
     return ap.parse_args()
 
 
@@ -69,7 +70,7 @@ def main():
     spec = Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, args.threshold)))
     algorithmic_bytes = v.fwd.nbytes + f.fwd.nbytes   # B(f) + B(v) = 3.375 B/row
 
-    engine = Engine(device_id=local_rank, time_kernels=True)
+    engine = Engine(device_id=local_rank, time_kernels=True, profile_waves=args.profile_waves)
     t0 = time.time()
     gseg = engine.open(seg)
     h2d_s = time.time() - t0
@@ -88,6 +89,8 @@ def main():
         if st != _abi.PG_OK:
             raise RuntimeError(lib.pg_last_error().decode())
         out = (res.aggregations[0].sum_i64, res.aggregations[0].count, res.dominant_kernel_ms, res.device_ms)
+        if args.profile_waves:
+            step.cycles = [int(c) for c in res.profile_cycles] + [int(res.profile_waves)]
         lib.pg_result_free(C.byref(res))
         return out
 
@@ -104,21 +107,10 @@ def main():
         device_ms.append(last[3])
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # host-side merge of the per-segment partials (SumAggregationFunction.merge is '+'): gather, then add on rank 0
-        part = torch.tensor([last[0], last[1]], dtype=torch.int64, device="cuda")
-        parts = [torch.zeros_like(part) for _ in range(world)]
-        dist.all_gather(parts, part)
-        merged_sum = float(0.0)
-        merged_count = 0
-        for p in parts:
-            merged_sum = merged_sum + float(int(p[0].item()))
-            merged_count += int(p[1].item())
-    else:
-        merged_sum, merged_count = float(last[0]), last[1]
+    from pinot_amd import distributed as D
+    elapsed = D.max_over_ranks(elapsed, "cuda")
+    # host-side merge of the per-segment partials (no data-path collective: 16 bytes per rank travel)
+    merged_sum, merged_count = D.merge_sum_count(D.gather_partials([last[0], last[1]], "cuda"))
 
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
     result = None
@@ -145,6 +137,9 @@ def main():
                          "traffic": None, "kernel": "scan_agg_kernel", "kernel_ms": avg_kernel_ms,
                          "algorithmic_bytes_per_launch": algorithmic_bytes},
             "hbm_GBps_whole_step": world * algorithmic_bytes * args.steps / elapsed / 1e9,
+            "wave_profile": ({"waves": step.cycles[4], "cycles_per_wave": {"memory_wait": step.cycles[0] / step.cycles[4], "filter": step.cycles[1] / step.cycles[4],
+                                                                          "aggregate": step.cycles[2] / step.cycles[4], "loop_total": step.cycles[3] / step.cycles[4]}}
+                             if args.profile_waves else None),
             "result": {"sum": merged_sum, "count": merged_count},
             "setup": {"host_generate_s": gen_s, "segment_open_h2d_s": h2d_s, "device_bytes": gseg.device_bytes(),
                       "h2d_GBps": gseg.device_bytes() / h2d_s / 1e9, "host_threads": S.host_threads()},

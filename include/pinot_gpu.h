@@ -78,6 +78,7 @@ typedef struct pg_config {
 } pg_config;
 
 #define PG_CFG_TIME_KERNELS 1  /* bracket kernels with HIP events on the launch stream; report pg_result.device_ms */
+#define PG_CFG_PROFILE_WAVES 2 /* diagnostic: per-wave s_memtime phase counters in pg_result.profile_cycles */
 
 typedef struct pg_column_desc {
   const char* name;
@@ -207,6 +208,9 @@ typedef struct pg_result {
   int32_t reserved;
   double device_ms;                /* HIP-event time of this query's kernels (PG_CFG_TIME_KERNELS), else 0 */
   double dominant_kernel_ms;       /* HIP-event time of the scan kernel alone */
+  uint64_t profile_cycles[4];      /* PG_CFG_PROFILE_WAVES: shader cycles summed over wavefronts: memory wait, filter, aggregate, total */
+  int32_t profile_waves;           /* number of wavefronts the sums cover */
+  int32_t reserved2;
   void* internal;
 } pg_result;
 

@@ -22,6 +22,7 @@ PG_FILTER_LEAF, PG_FILTER_AND, PG_FILTER_OR, PG_FILTER_NOT = range(4)
 # pg_agg_function
 PG_AGG_COUNT, PG_AGG_SUM, PG_AGG_MIN, PG_AGG_MAX, PG_AGG_AVG = range(5)
 PG_CFG_TIME_KERNELS = 1
+PG_CFG_PROFILE_WAVES = 2
 
 
 class pg_config(C.Structure):
@@ -77,6 +78,7 @@ class pg_result(C.Structure):
                 ("aggregations", C.POINTER(pg_agg_value)), ("group_ids", C.POINTER(C.c_int32)),
                 ("group_aggregations", C.POINTER(pg_agg_value)), ("group_id_upper_bound", C.c_int32),
                 ("reserved", C.c_int32), ("device_ms", C.c_double), ("dominant_kernel_ms", C.c_double),
+                ("profile_cycles", C.c_uint64 * 4), ("profile_waves", C.c_int32), ("reserved2", C.c_int32),
                 ("internal", C.c_void_p)]
 
 

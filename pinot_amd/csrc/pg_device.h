@@ -74,6 +74,7 @@ struct BlockPartial {
   long long sum[kMaxAggCols];
   int32_t kmin[kMaxAggCols];   // min dictId (dictionary columns: sorted dictionary => monotone) or min raw value
   int32_t kmax[kMaxAggCols];
+  unsigned long long cyc[4];   // PG_CFG_PROFILE_WAVES: shader cycles per wave summed: memory wait, filter, aggregate, whole loop
 };
 
 struct ScanParams {
@@ -89,6 +90,8 @@ struct ScanParams {
   int32_t queue_cap;           // gather-queue capacity in entries (multiple of 64, >= 128)
   int32_t stage_bytes;         // bytes of ONE staging buffer set (all column slots); the wave owns two (double buffering)
   int32_t double_buffer;       // 1: prefetch the wave's next tile into the second staging buffer set
+  int32_t profile;             // 1: accumulate s_memtime phase counters into BlockPartial.cyc
+  int32_t pad3;
   DevColumn cols[kMaxCols];
   DevLeaf leaves[kMaxLeaves];
   DevNode nodes[kMaxNodes];

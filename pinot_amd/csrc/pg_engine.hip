@@ -806,6 +806,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const size_t lds = geo.lds;
     if ((size_t)sp.wave_lds_bytes > kLdsBudget) return fail(PG_ERR_UNSUPPORTED, "query needs %d bytes of LDS per wavefront", sp.wave_lds_bytes);
     sp.speculate = 1;
+    sp.profile = (g_engine.flags & PG_CFG_PROFILE_WAVES) ? 1 : 0;
     st = ensure_partials(ctx, blocks);
     if (st != PG_OK) return st;
     sp.partials = ctx->d_partials;
@@ -860,6 +861,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
           if (ag.function == PG_AGG_MAX) v.max = agg_value_double(col, fp.kmax[ac], plane);
         }
       }
+      for (int c = 0; c < 4; ++c) out->profile_cycles[c] = fp.cyc[c];
+      out->profile_waves = blocks * (geo.threads / 64);
       out->stats.num_docs_scanned = (int64_t)fp.count;
       out->stats.num_entries_scanned_in_filter = (int64_t)lw.num_scan_leaves * seg->num_docs;
       out->stats.num_entries_scanned_post_filter = (int64_t)fp.count * (int64_t)projected.size();

@@ -120,7 +120,7 @@ __device__ __forceinline__ uint32_t eval_dict_leaf_loop(const DevLeaf& L, const 
   uint32_t m = 0;
   if (L.kind == kLeafDictRange) {
     const uint32_t lo = (uint32_t)L.lo, span = L.span;
-#pragma unroll 8
+#pragma unroll 16
     for (int k = 0; k < kTileSteps; ++k) {
       const uint32_t d = decode_step<kWide>(slot, dec, k, b);
       m = (m << 1) | ((d - lo) < span ? 1u : 0u);
@@ -282,7 +282,9 @@ __device__ __forceinline__ void drain_queue(GatherQueue& gq, const __amdgpu_buff
   gq.count = 0;
 }
 
-// Per-column aggregation of the matching docs of one staged tile: every lane walks the set bits of its mask.
+// Per-column aggregation of the matching docs of one staged tile: every lane walks the set bits of its mask, four at
+// a time so that four LDS reads are in flight (a separate straight 32-step path for dense tiles cost 30 VGPRs and
+// one wavefront per SIMD of occupancy, which lost more than it gained).
 template <bool kWide>
 __device__ __forceinline__ void agg_dict_column(const DevColumn& col, const DevAggCol& ac, const uint8_t* slot, uint32_t m,
                                                 int lane, long long& sum, int32_t& kmin, int32_t& kmax, GatherQueue& gq) {
@@ -291,26 +293,36 @@ __device__ __forceinline__ void agg_dict_column(const DevColumn& col, const DevA
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)col.dict, 0, col.dict_bytes, 0x00020000);
   uint32_t rem = m;
   for (;;) {
-    const bool active = rem != 0u;
-    const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);
-    if (amask == 0ull) break;
-    const int k = active ? __builtin_ctz(rem) : 0;
-    rem &= rem - 1u;
-    const uint32_t d = decode_step<kWide>(slot, dec, k, b);
-    if (ac.need_minmax) {
-      // sorted dictionary => min/max of the value is min/max of the dictId; the lookup happens once on the host
-      const int32_t key = (int32_t)d;
-      kmin = (active && key < kmin) ? key : kmin;
-      kmax = (active && key > kmax) ? key : kmax;
+    if (__builtin_amdgcn_ballot_w64(rem != 0u) == 0ull) break;
+    bool active[4];
+    int k[4];
+    uint32_t d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      active[j] = rem != 0u;
+      k[j] = active[j] ? __builtin_ctz(rem) : 0;
+      rem &= rem - 1u;
     }
-    if (col.is_plane) {
-      // value plane: the decoded field IS (value - base); no dictionary, no gather
-      if (ac.need_sum) sum += active ? (long long)d : 0ll;
-    } else if (ac.need_sum) {
-      const uint32_t pos = (uint32_t)gq.count + __builtin_amdgcn_mbcnt_hi((uint32_t)(amask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)amask, 0u));
-      if (active) gq.q[pos] = d;
-      gq.count += __builtin_popcountll(amask);
-      if (gq.count > gq.cap - 64) drain_queue(gq, rsrc, lane, sum, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = decode_step<kWide>(slot, dec, k[j], b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (ac.need_minmax) {
+        // sorted dictionary => min/max of the value is min/max of the dictId; the lookup happens once on the host
+        const int32_t key = (int32_t)d[j];
+        kmin = (active[j] && key < kmin) ? key : kmin;
+        kmax = (active[j] && key > kmax) ? key : kmax;
+      }
+      if (col.is_plane) {
+        // value plane: the decoded field IS (value - base); no dictionary, no gather
+        if (ac.need_sum) sum += active[j] ? (long long)d[j] : 0ll;
+      } else if (ac.need_sum) {
+        const unsigned long long amask = __builtin_amdgcn_ballot_w64(active[j]);
+        const uint32_t pos = (uint32_t)gq.count + __builtin_amdgcn_mbcnt_hi((uint32_t)(amask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)amask, 0u));
+        if (active[j]) gq.q[pos] = d[j];
+        gq.count += __builtin_popcountll(amask);
+        if (gq.count > gq.cap - 64) drain_queue(gq, rsrc, lane, sum, 0);
+      }
     }
   }
 }
@@ -362,6 +374,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
 
   // Double-buffered tile pipeline: while tile t is decoded from staging buffer `buf`, the LDS-DMA loads of this
   // wave's next tile are already in flight into the other buffer, so the memory pipe never idles behind VALU work.
+  unsigned long long cyc_wait = 0, cyc_filter = 0, cyc_agg = 0;
+  const unsigned long long cyc_start = p.profile ? __builtin_amdgcn_s_memtime() : 0ull;
   bool hot = false;        // did the last processed tile match anything? (drives speculative value-column loads)
   bool cur_has_agg = false;
   int buf = 0;
@@ -369,7 +383,10 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
   if (tile < p.num_tiles) stage_columns<kDma>(p, tile, wave_lds, lane, true, false);
   for (; tile < p.num_tiles; tile += total_waves) {
     uint8_t* cur = wave_lds + buf * p.stage_bytes;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    if (p.profile) t0 = __builtin_amdgcn_s_memtime();
     if constexpr (kDma) wait_vmem();                       // the current tile has landed
+    if (p.profile) t1 = __builtin_amdgcn_s_memtime();
     const int next = tile + total_waves;
     const bool next_has_agg = hot && p.speculate != 0;
     if (p.double_buffer && next < p.num_tiles) stage_columns<kDma>(p, next, wave_lds + (buf ^ 1) * p.stage_bytes, lane, true, next_has_agg);
@@ -379,6 +396,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
     count += (unsigned)__builtin_popcount(m);
     const bool any = __builtin_amdgcn_ballot_w64(m != 0u) != 0ull;
     hot = any;
+    if (p.profile) t2 = __builtin_amdgcn_s_memtime();
     if (any && p.num_agg_cols > 0) {
       if (!cur_has_agg) {
         stage_columns<kDma>(p, tile, cur, lane, false, true);
@@ -401,6 +419,10 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
           }
         }
       }
+    }
+    if (p.profile) {
+      const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+      cyc_wait += t1 - t0; cyc_filter += t2 - t1; cyc_agg += t3 - t2;
     }
     if (p.double_buffer) {
       cur_has_agg = next_has_agg;
@@ -435,12 +457,16 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
     mine.kmin[a] = wave_min_i32(kmin[a]);
     mine.kmax[a] = wave_max_i32(kmax[a]);
   }
+  mine.cyc[0] = cyc_wait; mine.cyc[1] = cyc_filter; mine.cyc[2] = cyc_agg;
+  mine.cyc[3] = p.profile ? __builtin_amdgcn_s_memtime() - cyc_start : 0ull;
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
   if (threadIdx.x == 0) {
     BlockPartial acc = red[0];
     for (int w = 1; w < waves_per_block; ++w) {
       acc.count += red[w].count;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc.cyc[c] += red[w].cyc[c];
 #pragma unroll
       for (int a = 0; a < kMaxAggCols; ++a) {
         acc.sum[a] += red[w].sum[a];
@@ -458,10 +484,14 @@ __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockP
   BlockPartial acc;
   acc.count = 0;
 #pragma unroll
+  for (int c = 0; c < 4; ++c) acc.cyc[c] = 0;
+#pragma unroll
   for (int a = 0; a < kMaxAggCols; ++a) { acc.sum[a] = 0; acc.kmin[a] = 0x7FFFFFFF; acc.kmax[a] = (int32_t)0x80000000; }
   for (int i = threadIdx.x; i < num_blocks; i += blockDim.x) {
     const BlockPartial b = partials[i];
     acc.count += b.count;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc.cyc[c] += b.cyc[c];
 #pragma unroll
     for (int a = 0; a < kMaxAggCols; ++a) {
       acc.sum[a] += b.sum[a];
@@ -470,6 +500,8 @@ __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockP
     }
   }
   acc.count = (unsigned long long)wave_sum_i64((long long)acc.count);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc.cyc[c] = (unsigned long long)wave_sum_i64((long long)acc.cyc[c]);
 #pragma unroll
   for (int a = 0; a < kMaxAggCols; ++a) {
     acc.sum[a] = wave_sum_i64(acc.sum[a]);
@@ -483,6 +515,8 @@ __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockP
     BlockPartial t = red[0];
     for (int i = 1; i < (int)(blockDim.x >> 6); ++i) {
       t.count += red[i].count;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t.cyc[c] += red[i].cyc[c];
 #pragma unroll
       for (int a = 0; a < kMaxAggCols; ++a) {
         t.sum[a] += red[i].sum[a];

@@ -8,9 +8,10 @@ from .query import Result
 
 
 class Engine:
-    def __init__(self, device_id=0, time_kernels=False, blocks_per_cu=0, lib_path=None):
+    def __init__(self, device_id=0, time_kernels=False, blocks_per_cu=0, lib_path=None, profile_waves=False):
         self.lib = _abi.load_gpu_library(lib_path)
-        cfg = _abi.pg_config(_abi.PG_ABI_VERSION, device_id, blocks_per_cu, _abi.PG_CFG_TIME_KERNELS if time_kernels else 0)
+        flags = (_abi.PG_CFG_TIME_KERNELS if time_kernels else 0) | (_abi.PG_CFG_PROFILE_WAVES if profile_waves else 0)
+        cfg = _abi.pg_config(_abi.PG_ABI_VERSION, device_id, blocks_per_cu, flags)
         _abi.check(self.lib, self.lib.pg_init(C.byref(cfg)))
         self.device_id = device_id
 

@@ -24,6 +24,8 @@ import sys,json
 for l in sys.stdin:
     d=json.loads(l); print('   %-34s %.3f ms %6.0f GB/s' % (d['extra'], d['kernel_ms'], d['GBps']))"
   done ;;
+profile)
+  echo "== wave profile =="; timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --profile-waves 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d[\"roofline\"][\"kernel_ms\"], json.dumps(d[\"wave_profile\"]))" ;;
 sweep)
   for bpc in 2 3 4 5 6 8 10 12; do echo "== bench bpc=$bpc =="; PINOT_GPU_BLOCKS_PER_CU=$bpc timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | short; done ;;
 prof)
