@@ -728,7 +728,7 @@ __global__ __launch_bounds__(kBlockThreads) void roaring_expand_kernel(const uin
 // Value-plane materialisation (one-time, per summed column): plane[doc] = dictionary[dictId[doc]] - base, bit-packed
 // with `w` bits in the SAME big-endian MSB-first stream format as the forward index, so the scan kernels decode it
 // with the same code.  It trades HBM capacity (288 GB) for the per-row dictionary gather, which on MI355X costs as
-// much L2 capacity as streaming ~22 bytes (profiles/r1_microbench.jsonl).  w == 32 stores big-endian int32 values.
+// much L2 capacity as streaming ~22 bytes (profiles/r1/microbench.jsonl).  w == 32 stores big-endian int32 values.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlockThreads) void materialize_plane_kernel(const DevColumn col, uint8_t* __restrict__ out, int w, int32_t base,
                                                                           int num_docs, int num_tiles, int in_slot_bytes) {

@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Times every BASELINE.md configuration (C1, C2a, C2b, C3, C5) on one GPU and checks each result against the oracle.
+
+Not the driver's bench (that is bench.py, C2b only): this fills the per-config table of DESIGN.md / profiles/.
+Usage: python tools/bench_configs.py [--rows N] [--rows-c5 N] [--out profiles/xxx.jsonl]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402,F401
+
+from oracle import oracle  # noqa: E402
+from pinot_amd import _abi  # noqa: E402
+from pinot_amd import query as Q  # noqa: E402
+from pinot_amd import segment as S  # noqa: E402
+from pinot_amd.engine import Engine  # noqa: E402
+
+
+def timed(gseg, spec, reps=8):
+    res = _abi.pg_result()
+    ms = []
+    for i in range(reps + 2):
+        st = gseg.execute_raw(spec, res)
+        if st != _abi.PG_OK:
+            raise RuntimeError(gseg.lib.pg_last_error().decode())
+        if i >= 2:
+            ms.append(res.dominant_kernel_ms)
+        gseg.lib.pg_result_free(C.byref(res))
+    return sum(ms) / len(ms), min(ms)
+
+
+def report(out, name, n, nbytes, gseg, seg, spec, check=True):
+    avg, best = timed(gseg, spec)
+    got = gseg.execute(spec)
+    ok = None
+    if check:
+        t0 = time.time()
+        want = oracle.execute(seg, spec)
+        cpu_s = time.time() - t0
+        ok = (got.stats[0] == want.stats[0] and
+              all(a.sum_i64 == b.sum_i64 and a.count == b.count and a.min == b.min and a.max == b.max for a, b in zip(got.aggregations, want.aggregations)) and
+              sorted(got.groups) == sorted(want.groups) and
+              all(all(x.sum_i64 == y.sum_i64 and x.count == y.count and x.min == y.min and x.max == y.max for x, y in zip(got.groups[g], want.groups[g])) for g in want.groups))
+    else:
+        cpu_s = None
+    rec = {"config": name, "rows": n, "kernel_ms": avg, "kernel_ms_min": best, "rows_per_s": n / avg * 1e3, "algorithmic_GB": nbytes / 1e9,
+           "GBps": nbytes / avg / 1e6, "frac_of_8TBps": nbytes / avg / 1e6 / 8000.0, "docs_matched": got.stats[0],
+           "bit_exact_vs_oracle": ok, "oracle_rows_per_s_1core": (n / cpu_s if cpu_s else None)}
+    print(json.dumps(rec), flush=True)
+    out.append(rec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1_000_000_000)
+    ap.add_argument("--rows-c5", type=int, default=250_000_000)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+    engine = Engine(device_id=0, time_kernels=True)
+    out = []
+    check = not args.no_check
+    B = lambda col: col.fwd.nbytes
+
+    # ---- C1: 10 M rows, raw int32 forward index ----
+    n1 = 10_000_000
+    vals = S.synthetic_dict_ids(42, 0, n1, 1_000_000)
+    raw = S.Column.raw("raw_i32", vals)
+    seg1 = S.SegmentData("c1", n1, [raw])
+    with engine.open(seg1) as g:
+        report(out, "C1 COUNT(*) WHERE raw_i32 BETWEEN 1 AND 10 (10M rows, raw)", n1, 4 * n1, g, seg1, Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.raw_range(0, 1, 10))), check)
+        report(out, "C1 SUM(raw_i32) (10M rows, raw)", n1, 4 * n1, g, seg1, Q.QuerySpec([(Q.SUM, 0)]), check)
+        report(out, "C1 COUNT(*) no filter (10M rows; O(1) in the reference, a24)", n1, 0, g, seg1, Q.QuerySpec([(Q.COUNT, -1)]), check)
+    del seg1, raw, vals
+
+    # ---- C2 / C3 share one segment: v (C=100000), f (C=1000), k (C=1000), b (C=65536) ----
+    n = args.rows
+    t0 = time.time()
+    v = S.Column.synthetic_uniform("v", n, (np.arange(100000, dtype=np.int64) * 7 + 3).astype(np.int32), seed=1)
+    f = S.Column.synthetic_uniform("f", n, np.arange(1000, dtype=np.int32), seed=2)
+    k = S.Column.synthetic_uniform("k", n, np.arange(1000, dtype=np.int32) * 3, seed=3)
+    a = S.Column.synthetic_uniform("a", n, (np.arange(100000, dtype=np.int64) * 5 + 1).astype(np.int32), seed=4)
+    b = S.Column.synthetic_uniform("b", n, np.arange(65536, dtype=np.int32) * 2, seed=5)
+    seg = S.SegmentData("c23", n, [v, f, k, a, b])
+    print(json.dumps({"setup": "C2/C3 segment", "rows": n, "generate_s": time.time() - t0}), flush=True)
+    with engine.open(seg) as g:
+        for pct, lo, hi in ((10, 45000, 55000), (50, 25000, 75000), (90, 5000, 95000)):
+            report(out, "C2a SUM(v) WHERE v BETWEEN (%d%%)" % pct, n, B(v), g, seg, Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, lo, hi))), check)
+        for pct, t in ((1, 10), (10, 100), (50, 500)):
+            report(out, "C2b SUM(v) WHERE f < t (%d%%)" % pct, n, B(v) + B(f), g, seg, Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, t))), check)
+        report(out, "C3 SUM(a), MAX(b) GROUP BY k", n, B(k) + B(a) + B(b), g, seg, Q.QuerySpec([(Q.SUM, 3), (Q.MAX, 4)], group_by=[2]), check)
+        report(out, "C3 SUM(a), MAX(b) WHERE f < 100 GROUP BY k", n, B(k) + B(a) + B(b) + B(f), g, seg,
+               Q.QuerySpec([(Q.SUM, 3), (Q.MAX, 4)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100)), group_by=[2]), check)
+        report(out, "COUNT(*) WHERE f < 100", n, B(f), g, seg, Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), check)
+        report(out, "MIN(v), MAX(v), AVG(v) WHERE f < 100", n, B(v) + B(f), g, seg,
+               Q.QuerySpec([(Q.MIN, 0), (Q.MAX, 0), (Q.AVG, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), check)
+    del seg, f, k, a, b
+
+    # ---- C5: inverted-index AND of 3 postings -> docIds -> gather + SUM ----
+    n5 = args.rows_c5
+    t0 = time.time()
+    cols = []
+    for name, card, seed in (("p", 16, 11), ("q", 64, 12), ("r", 256, 13)):
+        ids = S.synthetic_dict_ids(seed, 0, n5, card)
+        cols.append(S.Column.from_dict_ids(name, np.arange(card, dtype=np.int32), ids, with_inverted=True))
+    v5 = S.Column.synthetic_uniform("v", n5, (np.arange(100000, dtype=np.int64) * 7 + 3).astype(np.int32), seed=1)
+    seg5 = S.SegmentData("c5", n5, cols + [v5])
+    print(json.dumps({"setup": "C5 segment", "rows": n5, "generate_s": time.time() - t0,
+                      "posting_bytes": [int(c.inverted.nbytes) for c in cols]}), flush=True)
+    inv = lambda c, d: Q.leaf(Q.Pred.dict_range(c, d, d + 1, inverted=True))
+    with engine.open(seg5) as g:
+        # bytes: the three postings that are read (1/card of each index) + one docId bitmap written and read per posting
+        post = sum(c.inverted.nbytes / c.cardinality for c in cols)
+        bitmaps = 3 * 2 * ((n5 + 7) // 8)
+        report(out, "C5 SUM(v) WHERE p=3 AND q=5 AND r=7 (inverted, sparse)", n5, post + bitmaps, g, seg5,
+               Q.QuerySpec([(Q.SUM, 3)], filter=Q.and_(inv(0, 3), inv(1, 5), inv(2, 7))), check)
+        report(out, "C5 COUNT(*) WHERE p=3 AND q=5 (inverted)", n5, post + bitmaps, g, seg5,
+               Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(inv(0, 3), inv(1, 5))), check)
+        report(out, "C5 same filter evaluated by scanning p,q,r", n5, sum(B(c) for c in cols), g, seg5,
+               Q.QuerySpec([(Q.SUM, 3)], filter=Q.and_(Q.leaf(Q.Pred.dict_range(0, 3, 4)), Q.leaf(Q.Pred.dict_range(1, 5, 6)), Q.leaf(Q.Pred.dict_range(2, 7, 8)))), check)
+    if args.out:
+        with open(args.out, "w") as fh:
+            for rec in out:
+                fh.write(json.dumps(rec) + "\n")
+
+
+if __name__ == "__main__":
+    main()

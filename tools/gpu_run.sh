@@ -26,6 +26,8 @@ for l in sys.stdin:
   done ;;
 profile)
   echo "== wave profile =="; timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --profile-waves 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d[\"roofline\"][\"kernel_ms\"], json.dumps(d[\"wave_profile\"]))" ;;
+configs)
+  echo "== all configs =="; timeout 1500 python tools/bench_configs.py --out $OUT/configs.jsonl 2>&1 | tail -30 ;;
 sweep)
   for bpc in 2 3 4 5 6 8 10 12; do echo "== bench bpc=$bpc =="; PINOT_GPU_BLOCKS_PER_CU=$bpc timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | short; done ;;
 prof)
@@ -33,6 +35,14 @@ prof)
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/rocprof.log 2>&1
   tail -2 $OUT/rocprof.log; find $OUT/prof -name "*kernel_stats*.csv" -exec cat {} \; | head -12
   find $OUT/prof -name "*kernel_trace*.csv" -size +8M -delete
+  cd $GRAFT_REPO_ROOT ;;
+sq)
+  echo "== rocprof SQ counters =="; cd /tmp && export TMPDIR=/tmp
+  timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
+  tail -2 $OUT/pmc_sq.log
+  for f in $(find $OUT/pmc_sq -name "*counter_collection*.csv"); do head -1 $f; grep scan_agg $f | head -16; done
+  timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc_sq2 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq2.log 2>&1
+  for f in $(find $OUT/pmc_sq2 -name "*counter_collection*.csv"); do head -1 $f; grep scan_agg $f | head -16; done
   cd $GRAFT_REPO_ROOT ;;
 pmc)
   echo "== rocprof pmc =="; cd /tmp && export TMPDIR=/tmp
