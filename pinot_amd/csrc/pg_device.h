@@ -1,30 +1,31 @@
 // pg_device.h -- device-side parameter blocks shared by the kernels and the host engine.
 //
-// Vocabulary: a *tile* is 2048 consecutive docIds handled by one wavefront in one
-// pass; inside a tile, *step* k (0..31) covers docs [64k, 64k+64) and lane i owns doc 64k+i of every
-// step, so a per-lane 32-bit register holds the match bits of the lane's 32 docs ("lane mask") and a
-// wave ballot of bit k is exactly the 64-bit word k of the tile's docId bitmap.
+// Vocabulary: a *tile* is 64 * steps consecutive docIds (steps = 32 or 16, chosen per query)
+// handled by one wavefront in one pass; inside a tile, *step* k covers docs [64k, 64k+64) and lane i owns doc 64k+i
+// of every step, so a per-lane 32-bit register holds the match bits of the lane's docs ("lane mask") and a wave
+// ballot of bit k is exactly the 64-bit word k of the tile's docId bitmap.
 #pragma once
 #include <stdint.h>
 
 namespace pg {
 
 constexpr int kWave = 64;
-constexpr int kTileSteps = 32;
-constexpr int kTileDocs = kWave * kTileSteps;   // 2048 docs per tile
-constexpr int kMaxCols = 8;                     // distinct columns referenced by one query
+constexpr int kMaxTileSteps = 32;
+constexpr int kMaxTileDocs = kWave * kMaxTileSteps;   // 2048: device buffers are padded to whole 2048-doc tiles
+constexpr int kMaxCols = 8;                     // distinct column streams referenced by one query
 constexpr int kMaxLeaves = 8;
 constexpr int kMaxNodes = 24;
 constexpr int kMaxAggCols = 4;                  // distinct aggregated columns
 constexpr int kMaxGroupCols = 3;                // ArrayBasedHolder fast paths cover 1..3 keys
 constexpr int kMaxGroupAggs = 8;                // distinct (column, SUM|MIN|MAX) pairs of a group-by query
 constexpr int kStackDepth = 8;
-constexpr int kBlockThreads = 256;           // maximum; launches may use 64 / 128 when LDS is tight
+constexpr int kBlockThreads = 256;              // scan_agg_kernel: at most 4 wavefronts per workgroup
+constexpr int kGroupBlockThreads = 1024;        // scan_group_kernel: up to 16 wavefronts share one LDS group table
 
 enum LeafKind : int32_t {
   kLeafMatchAll = 0,
   kLeafMatchNone = 1,
-  kLeafDictRange = 2,   // (uint32)(dictId - lo) < span
+  kLeafDictRange = 2,   // (uint32)(field - lo) < span   (field = dictId, or value-plane offset)
   kLeafDictSet = 3,     // bit dictId of set_words
   kLeafRawRange = 4,    // (uint32)(value - lo) <= span  (signed inclusive range)
   kLeafBitmap = 5       // precomputed docId bitmap (inverted-index postings expanded on device)
@@ -32,14 +33,14 @@ enum LeafKind : int32_t {
 
 struct DevColumn {
   const uint8_t* fwd;      // dict: first byte of the packed bit stream; raw: first value byte (after chunk header)
-  const int32_t* dict;     // host-order int32 dictionary values (NULL for raw)
-  int32_t bits;            // 1..31 for dictionary columns, 32 for raw
+  const int32_t* dict;     // host-order int32 dictionary values (NULL for raw / plane)
+  int32_t bits;            // 1..31 for packed streams, 32 for raw
   int32_t is_raw;
   int32_t cardinality;
   int32_t dict_bytes;      // cardinality * 4 (buffer-descriptor num_records for the gather)
   int32_t in_filter;       // referenced by a scan leaf
   int32_t in_agg;          // referenced by an aggregation or a group-by key
-  int32_t slot_off;        // byte offset of this column's staging slot inside the wave's LDS region
+  int32_t slot_off;        // byte offset of this column's staging slot inside one staging buffer
   int32_t is_plane;        // fwd points at the column's VALUE PLANE: bit-packed (value - plane base), same stream format
 };
 
@@ -52,60 +53,144 @@ struct DevLeaf {
   int32_t set_bytes;
   const uint32_t* set_words;
   const unsigned long long* bitmap;  // kLeafBitmap: doc-order words
+  int32_t lds_off;         // kLeafBitmap: byte offset of its 256-byte slot inside one bitmap staging buffer
+  int32_t pad;
 };
 
-struct DevNode {
+constexpr int32_t kNodeExitIfZero = 1;   // root AND chain: the tile is finished (mask 0) if the running result is wave-zero
+
+// Host-side plan node (DevColumn / DevLeaf / PlanNode are what the engine reasons with).
+struct PlanNode {
   int32_t op;              // pg_filter_op
   int32_t leaf;
   int32_t num_children;
+  int32_t flags;
+};
+
+// What the kernels read.  The kernel-argument block lives in memory and is read through the scalar cache; with ~100
+// SGPRs live the compiler cannot keep it in registers, so every dynamically indexed field access is a dependent
+// scalar load (node -> leaf -> column cost three round trips per leaf per tile).  Each filter node is therefore ONE
+// self-contained 64-byte record (a single s_load_dwordx16), and staging / aggregation descriptors are only ever
+// indexed with compile-time constants.
+struct DevNode {
+  int32_t op;              // pg_filter_op
+  int32_t flags;
+  int32_t num_children;
+  int32_t kind;            // LeafKind (LEAF nodes)
+  int32_t exclusive;
+  int32_t lo;
+  uint32_t span;
+  int32_t bits;            // packed width of the leaf's column
+  int32_t slot_off;        // column staging slot (scan leaves)
+  int32_t lds_off;         // bitmap staging slot (bitmap leaves)
+  int32_t set_bytes;
+  int32_t pad;
+  const uint8_t* fwd;      // raw-range leaves: first value byte
+  const uint32_t* set_words;
+};
+static_assert(sizeof(DevNode) == 64, "one scalar load per filter node");
+
+struct DevStage {          // one packed column stream to stage per tile
+  const uint8_t* fwd;
+  int32_t bits;
+  int32_t slot_off;
+  int32_t in_filter;
   int32_t pad;
 };
 
-struct DevAggCol {
-  int32_t col;             // index into ScanParams.cols
+struct PlanAggCol {
+  int32_t col;             // index into the plan's cols
   int32_t need_sum;
   int32_t need_minmax;
   int32_t pad;
+};
+
+struct DevAggCol {         // self-contained: no second lookup into a column table
+  int32_t need_sum;
+  int32_t need_minmax;
+  int32_t bits;
+  int32_t slot_off;
+  int32_t is_raw;
+  int32_t is_plane;
+  int32_t dict_bytes;
+  int32_t pad;
+  const uint8_t* fwd;
+  const int32_t* dict;
 };
 
 // One record per workgroup, reduced by finalize_partials.
 struct BlockPartial {
   unsigned long long count;
   long long sum[kMaxAggCols];
-  int32_t kmin[kMaxAggCols];   // min dictId (dictionary columns: sorted dictionary => monotone) or min raw value
+  int32_t kmin[kMaxAggCols];   // min dictId (dictionary columns: sorted dictionary => monotone), plane offset or raw value
   int32_t kmax[kMaxAggCols];
   unsigned long long cyc[4];   // PG_CFG_PROFILE_WAVES: shader cycles per wave summed: memory wait, filter, aggregate, whole loop
 };
 
 struct ScanParams {
   int32_t num_docs;
-  int32_t num_tiles;
+  int32_t num_tiles;           // ceil(num_docs / (64 * tile_steps))
+  int32_t tile_steps;          // 32 or 16
   int32_t num_cols;
   int32_t num_leaves;
   int32_t num_nodes;
   int32_t num_agg_cols;
+  int32_t num_bitmap_leaves;
+  int32_t stage_bytes;         // bytes of ONE column staging buffer (all column slots)
   int32_t queue_off;           // byte offset of the wave's gather queue inside its LDS region
-  int32_t wave_lds_bytes;      // staging slots (256 * bits + 16 each) + gather queue
-  int32_t speculate;           // 1: issue aggregation-column loads together with the filter loads when the last tile matched
   int32_t queue_cap;           // gather-queue capacity in entries (multiple of 64, >= 128)
-  int32_t stage_bytes;         // bytes of ONE staging buffer set (all column slots); the wave owns two (double buffering)
+  int32_t wave_lds_bytes;      // (1 or 2) * stage_bytes + gather queue
+  int32_t speculate;           // 1: stage aggregation columns together with the filter columns when the last tile matched
   int32_t double_buffer;       // 1: prefetch the wave's next tile into the second staging buffer set
+  int32_t lazy_columns;        // 1: index-driven filter: stage the scan columns only if the bitmap prefix left something
+  int32_t lazy_node;           // node index after which the scan columns are staged when lazy_columns
   int32_t profile;             // 1: accumulate s_memtime phase counters into BlockPartial.cyc
-  int32_t pad3;
-  DevColumn cols[kMaxCols];
-  DevLeaf leaves[kMaxLeaves];
+  int32_t bitmap_off;          // byte offset of the two (always double-buffered) bitmap staging buffers in the wave's LDS region
+  int32_t bitmap_bytes;        // bytes of one bitmap staging buffer (256 per bitmap leaf)
+  int32_t num_stage;           // packed column streams to stage
+  DevStage stage[kMaxCols];
   DevNode nodes[kMaxNodes];
   DevAggCol agg_cols[kMaxAggCols];
-  unsigned long long* out_bitmap;  // optional doc-order bitmap output (num_tiles * 32 words)
+  const unsigned long long* bitmaps[kMaxLeaves];   // bitmap leaves, in leaf order
+  int32_t bitmap_lds_off[kMaxLeaves];
+  unsigned long long* out_bitmap;  // optional doc-order bitmap output (num_tiles * tile_steps words)
   BlockPartial* partials;          // [gridDim.x]
+};
+
+// Host-side plan (what lower_filter / execute build before it is flattened into ScanParams).
+struct PlanParams {
+  int32_t num_cols = 0, num_leaves = 0, num_nodes = 0, num_agg_cols = 0, num_bitmap_leaves = 0;
+  int32_t lazy_columns = 0, lazy_node = -1;
+  DevColumn cols[kMaxCols];
+  DevLeaf leaves[kMaxLeaves];
+  PlanNode nodes[kMaxNodes];
+  PlanAggCol agg_cols[kMaxAggCols];
 };
 
 // ---- group-by ----
 enum GroupAggKind : int32_t { kGroupSum = 1, kGroupMin = 2, kGroupMax = 3 };
 
-struct DevGroupAgg {
-  int32_t col;             // index into cols
+struct PlanGroupAgg {
+  int32_t col;             // index into the plan's cols
   int32_t kind;            // GroupAggKind
+};
+
+struct DevGroupAgg {       // self-contained
+  int32_t kind;            // GroupAggKind
+  int32_t bits;
+  int32_t slot_off;
+  int32_t is_raw;
+  int32_t is_plane;
+  int32_t dict_bytes;
+  const uint8_t* fwd;
+  const int32_t* dict;
+};
+
+struct DevGroupKey {
+  int32_t bits;
+  int32_t slot_off;
+  int32_t mult;
+  int32_t pad;
 };
 
 // Global (and LDS) group table layout, struct-of-arrays per group id g in [0, num_groups):
@@ -117,8 +202,7 @@ struct GroupParams {
   int32_t num_group_aggs;
   int32_t num_groups;              // product of cardinalities (<= arrayBasedThreshold)
   int32_t use_lds_table;
-  int32_t group_cols[kMaxGroupCols];
-  int32_t group_mult[kMaxGroupCols];
+  DevGroupKey group_keys[kMaxGroupCols];
   DevGroupAgg group_aggs[kMaxGroupAggs];
   unsigned long long* table_count; // [num_groups]
   long long* table_acc;            // [num_group_aggs * num_groups]

@@ -49,6 +49,7 @@ struct Engine {
   int flags = 0;
   bool use_dma = true;
   int value_plane = -1;      // -1 auto, 0 never, 1 always (PINOT_GPU_VALUE_PLANE)
+  int tile_steps = 0;        // 0 auto, 16 or 32 forced (PINOT_GPU_TILE_STEPS)
   bool double_buffer = false;
   std::mutex mu;
 };
@@ -179,7 +180,7 @@ pg_status ensure_partials(ExecCtx* c, int blocks) {
 pg_status ensure_bitmap(pg_segment* seg, ExecCtx* c, size_t index) {
   while (c->d_bitmaps.size() <= index) {
     unsigned long long* p = nullptr;
-    size_t words = (size_t)std::max(seg->num_tiles, 1) * kTileSteps;
+    size_t words = (size_t)std::max(seg->num_tiles, 1) * kMaxTileSteps;
     HIP_TRY(hipMalloc((void**)&p, words * 8));
     c->d_bitmaps.push_back(p);
   }
@@ -329,7 +330,8 @@ pg_status ensure_plane(pg_segment* seg, int column, ExecCtx* ctx) {
 
 // ---- query lowering ----
 struct Lowered {
-  ScanParams sp;
+  PlanParams plan;                    // host-side plan (columns, leaves, nodes) ...
+  ScanParams sp;                      // ... flattened into the kernel parameter block by flatten_plan()
   std::vector<int> col_of_slot;       // segment column index * 2 + (1 if the slot streams the value plane)
   std::vector<char> plane_cols;       // per segment column: aggregations read it through its value plane
   int num_scan_leaves = 0;
@@ -341,7 +343,7 @@ int slot_for(Lowered* lw, const pg_segment* seg, int column, bool plane = false)
   for (size_t i = 0; i < lw->col_of_slot.size(); ++i) if (lw->col_of_slot[i] == id) return (int)i;
   if ((int)lw->col_of_slot.size() >= kMaxCols) return -1;
   const ColumnDev& c = seg->cols[column];
-  DevColumn& d = lw->sp.cols[lw->col_of_slot.size()];
+  DevColumn& d = lw->plan.cols[lw->col_of_slot.size()];
   memset(&d, 0, sizeof(d));
   if (plane) {
     d.fwd = c.d_plane;
@@ -361,24 +363,88 @@ int slot_for(Lowered* lw, const pg_segment* seg, int column, bool plane = false)
   }
   if (!d.is_raw) lw->max_bits = std::max(lw->max_bits, d.bits);
   lw->col_of_slot.push_back(id);
-  lw->sp.num_cols = (int)lw->col_of_slot.size();
-  return lw->sp.num_cols - 1;
+  lw->plan.num_cols = (int)lw->col_of_slot.size();
+  return lw->plan.num_cols - 1;
+}
+
+struct SeqNode { int src; int op; int num_children; int flags; };
+
+// Re-orders the children of a root AND so that inverted-index (bitmap) leaves come first, rewrites that AND as a chain
+// of binary ANDs flagged kNodeExitIfZero (AND is commutative and associative: same docId set), and reports where the
+// bitmap prefix ends.  Everything else keeps its postfix order.
+void build_sequence(const pg_query* q, std::vector<SeqNode>* seq, int* lazy_node, int* num_bitmap_prefix) {
+  const int n = q->num_filter_nodes;
+  *lazy_node = -1;
+  *num_bitmap_prefix = 0;
+  seq->clear();
+  if (n == 0) return;
+  std::vector<int> start((size_t)n, 0);
+  for (int i = 0; i < n; ++i) {
+    const pg_filter_node& fn = q->filter[i];
+    if (fn.op == PG_FILTER_LEAF) start[(size_t)i] = i;
+    else {
+      int k = fn.op == PG_FILTER_NOT ? 1 : fn.num_children;
+      int idx = i - 1;
+      for (int c = 0; c < k && idx >= 0; ++c) idx = start[(size_t)idx] - 1;
+      start[(size_t)i] = idx + 1;
+    }
+  }
+  const pg_filter_node& root = q->filter[n - 1];
+  auto identity = [&](int from, int to) { for (int i = from; i <= to; ++i) seq->push_back(SeqNode{i, q->filter[i].op, q->filter[i].num_children, 0}); };
+  if (root.op != PG_FILTER_AND || root.num_children < 2 || start[(size_t)n - 1] != 0) {
+    identity(0, n - 1);
+    if (root.op == PG_FILTER_LEAF) seq->back().flags |= kNodeExitIfZero;
+    return;
+  }
+  // children of the root, in query order
+  std::vector<std::pair<int, int>> children;   // [first, last] node index of each child subtree
+  int idx = n - 2;
+  for (int c = 0; c < root.num_children; ++c) { children.push_back({start[(size_t)idx], idx}); idx = start[(size_t)idx] - 1; }
+  std::reverse(children.begin(), children.end());
+  auto is_bitmap_leaf = [&](const std::pair<int, int>& ch) {
+    if (ch.first != ch.second || q->filter[ch.first].op != PG_FILTER_LEAF) return false;
+    const int pi = q->filter[ch.first].predicate;
+    if (pi < 0 || pi >= q->num_predicates) return false;
+    const pg_predicate& pr = q->predicates[pi];
+    return pr.eval == PG_EVAL_INVERTED && (pr.kind == PG_PRED_DICT_RANGE || pr.kind == PG_PRED_DICT_SET);
+  };
+  std::stable_partition(children.begin(), children.end(), is_bitmap_leaf);
+  for (const auto& ch : children) *num_bitmap_prefix += is_bitmap_leaf(ch) ? 1 : 0;
+  for (size_t c = 0; c < children.size(); ++c) {
+    identity(children[c].first, children[c].second);
+    if (c == 0) seq->back().flags |= kNodeExitIfZero;
+    else seq->push_back(SeqNode{-1, PG_FILTER_AND, 2, kNodeExitIfZero});
+    if ((int)c + 1 == *num_bitmap_prefix) *lazy_node = (int)seq->size() - 1;
+  }
 }
 
 pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered* lw) {
-  ScanParams& sp = lw->sp;
+  PlanParams& sp = lw->plan;
   if (q->num_filter_nodes < 0 || q->num_filter_nodes > kMaxNodes) return fail(PG_ERR_UNSUPPORTED, "filter tree has %d nodes (max %d)", q->num_filter_nodes, kMaxNodes);
   if (q->num_filter_nodes > 0 && (!q->filter || !q->predicates)) return fail(PG_ERR_INVALID_ARGUMENT, "filter nodes without predicates");
+  for (int n = 0; n < q->num_filter_nodes; ++n) {
+    const int op = q->filter[n].op;
+    if (op < PG_FILTER_LEAF || op > PG_FILTER_NOT) return fail(PG_ERR_INVALID_ARGUMENT, "unknown filter op %d", op);
+    if ((op == PG_FILTER_AND || op == PG_FILTER_OR) && q->filter[n].num_children < 1) return fail(PG_ERR_INVALID_ARGUMENT, "malformed filter tree (node %d)", n);
+  }
+  std::vector<SeqNode> seq;
+  int lazy_node = -1, num_bitmap_prefix = 0;
+  build_sequence(q, &seq, &lazy_node, &num_bitmap_prefix);
+  if ((int)seq.size() > kMaxNodes) return fail(PG_ERR_UNSUPPORTED, "filter tree has %d nodes (max %d)", (int)seq.size(), kMaxNodes);
   int depth = 0, max_depth = 0;
   size_t bitmap_idx = 1;   // bitmap 0 is reserved for pg_filter_bitmap output
   size_t set_idx = 0;
-  for (int n = 0; n < q->num_filter_nodes; ++n) {
-    const pg_filter_node& fn = q->filter[n];
-    DevNode& dn = sp.nodes[n];
+  for (int n = 0; n < (int)seq.size(); ++n) {
+    pg_filter_node fn;
+    memset(&fn, 0, sizeof(fn));
+    if (seq[(size_t)n].src >= 0) fn = q->filter[seq[(size_t)n].src];
+    fn.op = seq[(size_t)n].op;
+    fn.num_children = seq[(size_t)n].num_children;
+    PlanNode& dn = sp.nodes[n];
     dn.op = fn.op;
     dn.leaf = -1;
     dn.num_children = fn.num_children;
-    dn.pad = 0;
+    dn.flags = seq[(size_t)n].flags;
     if (fn.op == PG_FILTER_LEAF) {
       if (fn.predicate < 0 || fn.predicate >= q->num_predicates) return fail(PG_ERR_INVALID_ARGUMENT, "filter node %d: bad predicate index", n);
       if (sp.num_leaves >= kMaxLeaves) return fail(PG_ERR_UNSUPPORTED, "more than %d filter leaves", kMaxLeaves);
@@ -404,19 +470,25 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
           pg_status st = ensure_bitmap(seg, ctx, bitmap_idx);
           if (st != PG_OK) return st;
           unsigned long long* bm = ctx->d_bitmaps[bitmap_idx++];
-          const long long words = (long long)seg->num_tiles * kTileSteps;
-          fill_words_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(bm, words, 0ull);
+          const long long words = (long long)seg->num_tiles * kMaxTileSteps;
+          const unsigned num_windows = (unsigned)((words + 1023) / 1024);
+          bool first_posting = true;
           for (int d = 0; d < col.cardinality; ++d) {
             bool in;
             if (pr.kind == PG_PRED_DICT_RANGE) in = d >= pr.lo && d < pr.hi;
             else in = (d >> 5) < pr.num_set_words && ((pr.set_words[d >> 5] >> (d & 31)) & 1u);
             if (!in) continue;
             const int64_t first = col.posting_first[d], cnt = col.posting_first[d + 1] - first;
-            if (cnt > 0)
-              roaring_expand_kernel<<<dim3((unsigned)cnt), dim3(kBlockThreads), 0, ctx->stream>>>(col.d_inv, col.d_dir, (int)first, bm, words);
+            if (cnt <= 0 && !first_posting) continue;
+            // the first posting stores every window (zeros where it has no container); later ones OR
+            roaring_expand_kernel<<<dim3(num_windows), dim3(kBlockThreads), 0, ctx->stream>>>(col.d_inv, col.d_dir, (int)first, (int)cnt, bm, words,
+                                                                                              first_posting ? 0 : 1);
+            first_posting = false;
           }
+          if (first_posting) fill_words_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(bm, words, 0ull);   // no dictId matched
           L.kind = kLeafBitmap;
           L.bitmap = bm;
+          sp.num_bitmap_leaves++;
         } else if (pr.kind == PG_PRED_DICT_RANGE) {
           int64_t lo = std::max<int64_t>(pr.lo, 0), hi = std::min<int64_t>(pr.hi, col.cardinality);
           if (lo >= hi) { L.kind = kLeafMatchNone; }
@@ -478,9 +550,12 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
     }
     max_depth = std::max(max_depth, depth);
   }
-  if (q->num_filter_nodes > 0 && depth != 1) return fail(PG_ERR_INVALID_ARGUMENT, "malformed filter tree (%d roots)", depth);
+  if (!seq.empty() && depth != 1) return fail(PG_ERR_INVALID_ARGUMENT, "malformed filter tree (%d roots)", depth);
   if (max_depth > kStackDepth) return fail(PG_ERR_UNSUPPORTED, "filter tree deeper than %d", kStackDepth);
-  sp.num_nodes = q->num_filter_nodes;
+  sp.num_nodes = (int)seq.size();
+  // index-driven query: postings first, the scan columns only for tiles the postings did not eliminate
+  sp.lazy_columns = (num_bitmap_prefix > 0 && lw->num_scan_leaves > 0 && lazy_node >= 0) ? 1 : 0;
+  sp.lazy_node = lazy_node;
   return PG_OK;
 }
 
@@ -492,45 +567,125 @@ struct Geometry {
 };
 
 constexpr size_t kLdsBudget = 156 * 1024;     // of the 160 KiB per CU; leaves room for the runtime's own use
-constexpr int kMaxWavesPerCu = 24;            // these kernels use ~80 VGPRs / ~100 SGPRs: 6 waves per SIMD are admitted
 
-// Lays out the per-wave LDS region (one staging slot per dictionary column + the gather queue), picks the
-// workgroup size that fits the LDS budget and sizes the grid to what is co-resident (a persistent grid: a
-// grid larger than residency runs in rounds and leaves the chip half empty during the last one).
-void finish_geometry(const pg_segment* seg, Lowered* lw, size_t table_bytes, bool need_queue, Geometry* g) {
+// Wavefronts per CU the register file admits for a kernel: 512 VGPRs per SIMD lane in 8-register granules, at most 6
+// because these kernels use ~100 SGPRs (MI355X_MICROARCH.md: 256-thread blocks admitted = floor(800 / (sgpr granule + 16))).
+template <typename K>
+int max_waves_per_cu(K kernel) {
+  hipFuncAttributes attr;
+  if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) != hipSuccess || attr.numRegs <= 0) return 16;
+  const int alloc = ((attr.numRegs + 7) / 8) * 8;
+  return std::max(1, std::min(6, 512 / alloc)) * 4;
+}
+
+// Lays out the per-wave LDS region (one staging slot per packed column, 256 bytes per bitmap leaf, the gather queue),
+// then picks tile size (32 or 16 steps) and workgroup size so that the most wavefronts stay resident per CU within the
+// LDS budget, and sizes the grid to exactly what is co-resident (a persistent grid: a grid larger than residency runs
+// in rounds and leaves the chip partly empty during the last one).
+// Plan -> kernel parameter block: self-contained node records, statically indexed staging / aggregation descriptors.
+void flatten_plan(Lowered* lw) {
+  const PlanParams& pl = lw->plan;
   ScanParams& sp = lw->sp;
+  sp.num_cols = pl.num_cols;
+  sp.num_leaves = pl.num_leaves;
+  sp.num_nodes = pl.num_nodes;
+  sp.num_agg_cols = pl.num_agg_cols;
+  sp.num_bitmap_leaves = 0;
+  sp.lazy_columns = pl.lazy_columns;
+  sp.lazy_node = pl.lazy_node;
+  sp.num_stage = 0;
+  for (int c = 0; c < pl.num_cols; ++c) {
+    if (pl.cols[c].is_raw) continue;
+    DevStage& st = sp.stage[sp.num_stage++];
+    st.fwd = pl.cols[c].fwd; st.bits = pl.cols[c].bits; st.slot_off = pl.cols[c].slot_off; st.in_filter = pl.cols[c].in_filter; st.pad = 0;
+  }
+  for (int n = 0; n < pl.num_nodes; ++n) {
+    DevNode& dn = sp.nodes[n];
+    memset(&dn, 0, sizeof(dn));
+    dn.op = pl.nodes[n].op; dn.flags = pl.nodes[n].flags; dn.num_children = pl.nodes[n].num_children;
+    if (pl.nodes[n].op != PG_FILTER_LEAF) continue;
+    const DevLeaf& L = pl.leaves[pl.nodes[n].leaf];
+    dn.kind = L.kind; dn.exclusive = L.exclusive; dn.lo = L.lo; dn.span = L.span; dn.set_bytes = L.set_bytes; dn.set_words = L.set_words;
+    dn.lds_off = L.lds_off;
+    if (L.kind == kLeafDictRange || L.kind == kLeafDictSet || L.kind == kLeafRawRange) {
+      const DevColumn& c = pl.cols[L.col];
+      dn.bits = c.bits; dn.slot_off = c.slot_off; dn.fwd = c.fwd;
+    }
+  }
+  for (int l = 0; l < pl.num_leaves; ++l) {
+    if (pl.leaves[l].kind != kLeafBitmap) continue;
+    sp.bitmaps[sp.num_bitmap_leaves] = pl.leaves[l].bitmap;
+    sp.bitmap_lds_off[sp.num_bitmap_leaves] = pl.leaves[l].lds_off;
+    sp.num_bitmap_leaves++;
+  }
+  for (int a = 0; a < pl.num_agg_cols; ++a) {
+    const DevColumn& c = pl.cols[pl.agg_cols[a].col];
+    DevAggCol& ac = sp.agg_cols[a];
+    ac.need_sum = pl.agg_cols[a].need_sum; ac.need_minmax = pl.agg_cols[a].need_minmax;
+    ac.bits = c.bits; ac.slot_off = c.slot_off; ac.is_raw = c.is_raw; ac.is_plane = c.is_plane; ac.dict_bytes = c.dict_bytes; ac.pad = 0;
+    ac.fwd = c.fwd; ac.dict = c.dict;
+  }
+}
+
+void finish_geometry(const pg_segment* seg, Lowered* lw, size_t table_bytes, bool need_queue, int max_block_waves, int wave_cap, Geometry* g) {
+  ScanParams& sp = lw->sp;
+  PlanParams& pl = lw->plan;
   sp.num_docs = seg->num_docs;
-  sp.num_tiles = seg->num_tiles;
+  sp.double_buffer = g_engine.double_buffer ? 1 : 0;
+  sp.queue_cap = 256;
+  const bool table_fits_lds = table_bytes > 0 && table_bytes <= 96 * 1024;
+  int best_steps = 32, best_waves = 1, best_resident = -1;
+  bool best_table = false;
+  for (int steps : {32, 16}) {
+    if (g_engine.tile_steps != 0 && steps != g_engine.tile_steps) continue;
+    int stage = 0;
+    for (int c = 0; c < pl.num_cols; ++c) if (!pl.cols[c].is_raw) stage += ((8 * pl.cols[c].bits * steps + 16) + 15) & ~15;
+    stage = std::max(stage, 16);
+    const size_t wave_lds = std::max<size_t>((size_t)(sp.double_buffer ? 2 : 1) * stage + 512 * pl.num_bitmap_leaves + (need_queue ? sp.queue_cap * 4 : 0), 128);
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool in_lds = pass == 0 ? table_fits_lds : false;
+      if (pass == 1 && table_fits_lds && best_table) break;     // an LDS-table configuration exists: keep it
+      const size_t fixed = in_lds ? table_bytes : 0;
+      for (int w = max_block_waves; w >= 1; w >>= 1) {
+        const size_t lds_w = (size_t)w * wave_lds + fixed;
+        if (lds_w > kLdsBudget) continue;
+        const int resident = std::min(wave_cap, (int)(kLdsBudget / lds_w) * w);
+        // prefer more resident wavefronts; on ties the larger tile, then the larger workgroup (fewer table copies)
+        if (resident > best_resident) { best_resident = resident; best_steps = steps; best_waves = w; best_table = in_lds; }
+      }
+      if (!table_fits_lds) break;
+    }
+  }
+  if (best_resident < 0) { best_steps = 16; best_waves = 1; best_table = false; }
+  // final layout for the chosen tile size
+  const int steps = best_steps;
+  sp.tile_steps = steps;
+  sp.num_tiles = (int)(((long long)seg->num_docs + 64 * steps - 1) / (64 * steps));
   int off = 0;
-  for (int c = 0; c < sp.num_cols; ++c) {
-    sp.cols[c].slot_off = off;
-    if (!sp.cols[c].is_raw) off += ((256 * sp.cols[c].bits + 16) + 15) & ~15;
+  for (int c = 0; c < pl.num_cols; ++c) {
+    pl.cols[c].slot_off = off;
+    if (!pl.cols[c].is_raw) off += ((8 * pl.cols[c].bits * steps + 16) + 15) & ~15;
   }
   sp.stage_bytes = std::max(off, 16);
-  sp.double_buffer = g_engine.double_buffer ? 1 : 0;
   off = (sp.double_buffer ? 2 : 1) * sp.stage_bytes;
+  sp.bitmap_off = off;
+  int boff = 0;
+  for (int l = 0; l < pl.num_leaves; ++l) if (pl.leaves[l].kind == kLeafBitmap) { pl.leaves[l].lds_off = boff; boff += 256; }
+  sp.bitmap_bytes = boff;
+  off += 2 * boff;                            // the posting words of the next tile are always prefetched
   sp.queue_off = off;
-  sp.queue_cap = 256;
   if (need_queue) off += sp.queue_cap * 4;
   sp.wave_lds_bytes = std::max(off, 128);
-  // choose the workgroup size (1, 2 or 4 wavefronts) that keeps the most wavefronts resident per CU within the LDS budget
-  g->table_in_lds = table_bytes > 0 && table_bytes <= 96 * 1024 && (size_t)sp.wave_lds_bytes + table_bytes <= kLdsBudget;
-  const size_t fixed = g->table_in_lds ? table_bytes : 0;
-  int waves = 1, best_resident = 0;
-  for (int w = kBlockThreads / 64; w >= 1; w >>= 1) {
-    const size_t lds_w = (size_t)w * sp.wave_lds_bytes + fixed;
-    if (lds_w > kLdsBudget) continue;
-    const int resident = std::min(kMaxWavesPerCu, (int)(kLdsBudget / lds_w) * w);
-    if (resident > best_resident) { best_resident = resident; waves = w; }
-  }
-  g->threads = waves * 64;
-  g->lds = (size_t)waves * sp.wave_lds_bytes + fixed;
-  g->lds = std::max(g->lds, sizeof(BlockPartial) * (size_t)waves);
-  int bpc = std::max(1, std::min(kMaxWavesPerCu / waves, (int)(kLdsBudget / g->lds)));
+  g->table_in_lds = best_table;
+  g->threads = best_waves * 64;
+  g->lds = (size_t)best_waves * sp.wave_lds_bytes + (best_table ? table_bytes : 0);
+  g->lds = std::max(g->lds, sizeof(BlockPartial) * (size_t)best_waves);
+  int bpc = std::max(1, std::min(wave_cap / best_waves, (int)(kLdsBudget / g->lds)));
   if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
-  const long long want = ((long long)sp.num_tiles + waves - 1) / waves;
+  const long long want = ((long long)sp.num_tiles + best_waves - 1) / best_waves;
   const long long cap = (long long)seg->num_cus * bpc;
   g->blocks = (int)std::max<long long>(1, std::min(want, cap));
+  flatten_plan(lw);
 }
 
 double agg_value_double(const ColumnDev& col, int32_t key, bool plane) {
@@ -566,6 +721,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.value_plane = vp ? atoi(vp) : -1;
   const char* db = getenv("PINOT_GPU_DOUBLE_BUFFER");
   g_engine.double_buffer = db && db[0] == '1';
+  const char* ts = getenv("PINOT_GPU_TILE_STEPS");
+  g_engine.tile_steps = (ts && (atoi(ts) == 16 || atoi(ts) == 32)) ? atoi(ts) : 0;
   const char* bpc = getenv("PINOT_GPU_BLOCKS_PER_CU");
   if (bpc && atoi(bpc) > 0) g_engine.blocks_per_cu = atoi(bpc);
   g_engine.initialized = true;
@@ -594,7 +751,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
   pg_segment* seg = new pg_segment();
   seg->device = desc->device_id >= 0 ? desc->device_id : g_engine.device;
   seg->num_docs = desc->num_docs;
-  seg->num_tiles = (int)(((long long)desc->num_docs + kTileDocs - 1) / kTileDocs);
+  seg->num_tiles = (int)(((long long)desc->num_docs + kMaxTileDocs - 1) / kMaxTileDocs);   // 2048-doc tiles (buffer padding unit)
   seg->name = desc->name ? desc->name : "";
   pg_status st = PG_OK;
   auto bail = [&](pg_status s) { free_segment(seg); return s; };
@@ -751,6 +908,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
 
   Lowered lw;
   memset(&lw.sp, 0, sizeof(lw.sp));
+  memset(&lw.plan, 0, sizeof(lw.plan));
+  lw.plan.lazy_node = -1;
   const int num_cols_total = (int)seg->cols.size();
   // Columns that are summed are read through their value plane (built on first use); decided before the filter is
   // lowered so that a range predicate on the same column can be evaluated on the plane too.
@@ -768,6 +927,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   st = lower_filter(seg, ctx, q, &lw);
   if (st != PG_OK) return st;
   ScanParams& sp = lw.sp;
+  PlanParams& pl = lw.plan;
 
   // distinct projected columns (ExecutionStatistics numEntriesScannedPostFilter = numDocsScanned * numProjectedColumns)
   std::vector<int> projected;
@@ -786,22 +946,25 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       add_projected(ag.column);
       int s = slot_for(&lw, seg, ag.column, lw.plane_cols[(size_t)ag.column] != 0);
       if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
-      sp.cols[s].in_agg = 1;
+      pl.cols[s].in_agg = 1;
       int ac = -1;
-      for (int i = 0; i < sp.num_agg_cols; ++i) if (sp.agg_cols[i].col == s) ac = i;
+      for (int i = 0; i < pl.num_agg_cols; ++i) if (pl.agg_cols[i].col == s) ac = i;
       if (ac < 0) {
-        if (sp.num_agg_cols >= kMaxAggCols) return fail(PG_ERR_UNSUPPORTED, "more than %d aggregated columns", kMaxAggCols);
-        ac = sp.num_agg_cols++;
-        sp.agg_cols[ac] = DevAggCol{s, 0, 0, 0};
+        if (pl.num_agg_cols >= kMaxAggCols) return fail(PG_ERR_UNSUPPORTED, "more than %d aggregated columns", kMaxAggCols);
+        ac = pl.num_agg_cols++;
+        pl.agg_cols[ac] = PlanAggCol{s, 0, 0, 0};
       }
-      if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) sp.agg_cols[ac].need_sum = 1;
-      if (ag.function == PG_AGG_MIN || ag.function == PG_AGG_MAX) sp.agg_cols[ac].need_minmax = 1;
+      if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) pl.agg_cols[ac].need_sum = 1;
+      if (ag.function == PG_AGG_MIN || ag.function == PG_AGG_MAX) pl.agg_cols[ac].need_minmax = 1;
       agg_slot_of[(size_t)a] = ac;
     }
     bool need_queue = false;
-    for (int i = 0; i < sp.num_agg_cols; ++i) need_queue |= sp.agg_cols[i].need_sum && !sp.cols[sp.agg_cols[i].col].is_raw && !sp.cols[sp.agg_cols[i].col].is_plane;
+    for (int i = 0; i < pl.num_agg_cols; ++i) need_queue |= pl.agg_cols[i].need_sum && !pl.cols[pl.agg_cols[i].col].is_raw && !pl.cols[pl.agg_cols[i].col].is_plane;
     Geometry geo;
-    finish_geometry(seg, &lw, 0, need_queue, &geo);
+    static const int agg_wave_cap1 = max_waves_per_cu(scan_agg_kernel<true, 1>);
+    static const int agg_wave_cap4 = max_waves_per_cu(scan_agg_kernel<true, kMaxAggCols>);
+    const int agg_wave_cap = pl.num_agg_cols <= 1 ? agg_wave_cap1 : agg_wave_cap4;
+    finish_geometry(seg, &lw, 0, need_queue, kBlockThreads / 64, agg_wave_cap, &geo);
     const int blocks = geo.blocks;
     const size_t lds = geo.lds;
     if ((size_t)sp.wave_lds_bytes > kLdsBudget) return fail(PG_ERR_UNSUPPORTED, "query needs %d bytes of LDS per wavefront", sp.wave_lds_bytes);
@@ -817,12 +980,14 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       sp.out_bitmap = ctx->d_bitmaps[0];
     }
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
+    const bool one = pl.num_agg_cols <= 1;
     if (g_engine.use_dma) {
-      set_dynamic_lds(scan_agg_kernel<true>, lds);
-      scan_agg_kernel<true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp);
+      if (one) { set_dynamic_lds(scan_agg_kernel<true, 1>, lds); scan_agg_kernel<true, 1><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
+      else { set_dynamic_lds(scan_agg_kernel<true, kMaxAggCols>, lds); scan_agg_kernel<true, kMaxAggCols><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
     } else {
-      set_dynamic_lds(scan_agg_kernel<false>, lds);
-      scan_agg_kernel<false><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp);
+      if (one) { set_dynamic_lds(scan_agg_kernel<false, 1>, lds); scan_agg_kernel<false, 1><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
+      else { set_dynamic_lds(scan_agg_kernel<false, kMaxAggCols>, lds); scan_agg_kernel<false, kMaxAggCols><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
     }
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -872,6 +1037,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // ---------------- group-by (ArrayBasedHolder) ----------------
     GroupParams gp;
     memset(&gp, 0, sizeof(gp));
+    int group_slot[kMaxGroupCols] = {0, 0, 0}, group_mult[kMaxGroupCols] = {0, 0, 0};
+    PlanGroupAgg plan_aggs[kMaxGroupAggs];
     long long product = 1;
     std::vector<int> cards;
     for (int g = 0; g < ng; ++g) {
@@ -882,9 +1049,9 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       add_projected(c);
       int s = slot_for(&lw, seg, c);
       if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
-      sp.cols[s].in_agg = 1;
-      gp.group_cols[g] = s;
-      gp.group_mult[g] = (int32_t)product;
+      pl.cols[s].in_agg = 1;
+      group_slot[g] = s;
+      group_mult[g] = (int32_t)product;
       product *= col.cardinality;
       cards.push_back(col.cardinality);
       // DictionaryBasedGroupKeyGenerator.java:175-183: array-based holder only up to arrayBasedThreshold (10 000)
@@ -901,14 +1068,14 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       add_projected(ag.column);
       int s = slot_for(&lw, seg, ag.column, lw.plane_cols[(size_t)ag.column] != 0);
       if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
-      sp.cols[s].in_agg = 1;
+      pl.cols[s].in_agg = 1;
       const int kind = (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) ? kGroupSum : (ag.function == PG_AGG_MIN ? kGroupMin : kGroupMax);
       int da = -1;
-      for (int i = 0; i < gp.num_group_aggs; ++i) if (gp.group_aggs[i].col == s && gp.group_aggs[i].kind == kind) da = i;
+      for (int i = 0; i < gp.num_group_aggs; ++i) if (plan_aggs[i].col == s && plan_aggs[i].kind == kind) da = i;
       if (da < 0) {
         if (gp.num_group_aggs >= kMaxGroupAggs) return fail(PG_ERR_UNSUPPORTED, "more than %d distinct group-by aggregations", kMaxGroupAggs);
         da = gp.num_group_aggs++;
-        gp.group_aggs[da] = DevGroupAgg{s, kind};
+        plan_aggs[da] = PlanGroupAgg{s, kind};
       }
       dev_agg_of[(size_t)a] = da;
     }
@@ -919,11 +1086,23 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     gp.table_acc = reinterpret_cast<long long*>(ctx->d_table + gp.num_groups);
     const size_t table_bytes = table_words * 8;
     Geometry geo;
-    finish_geometry(seg, &lw, table_bytes, false, &geo);
+    static const int group_wave_cap = max_waves_per_cu(scan_group_kernel<true, true>);
+    finish_geometry(seg, &lw, table_bytes, false, kGroupBlockThreads / 64, group_wave_cap, &geo);
     if ((size_t)sp.wave_lds_bytes > kLdsBudget) return fail(PG_ERR_UNSUPPORTED, "query needs %d bytes of LDS per wavefront", sp.wave_lds_bytes);
     gp.use_lds_table = geo.table_in_lds ? 1 : 0;
     const int blocks = geo.blocks;
     const size_t lds = geo.lds;
+    sp.speculate = 1;
+    for (int g = 0; g < ng; ++g) {
+      const DevColumn& c = pl.cols[group_slot[g]];
+      gp.group_keys[g] = DevGroupKey{c.bits, c.slot_off, group_mult[g], 0};
+    }
+    for (int a = 0; a < gp.num_group_aggs; ++a) {
+      const DevColumn& c = pl.cols[plan_aggs[a].col];
+      DevGroupAgg& ga = gp.group_aggs[a];
+      ga.kind = plan_aggs[a].kind; ga.bits = c.bits; ga.slot_off = c.slot_off; ga.is_raw = c.is_raw; ga.is_plane = c.is_plane;
+      ga.dict_bytes = c.dict_bytes; ga.fwd = c.fwd; ga.dict = c.dict;
+    }
     gp.scan = sp;
     gp.scan.partials = nullptr;
     gp.scan.out_bitmap = nullptr;

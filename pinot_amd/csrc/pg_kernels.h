@@ -11,7 +11,7 @@
 //   gather_*_kernel     ForwardIndexReader.readDictIds / Dictionary.read{Int,Double}Values for arbitrary docIds
 //
 // Data layout: columns stay in HBM byte-for-byte as Pinot writes them (big-endian, MSB-first bit stream,
-// PinotDataBitSet.java:143-170).  A wavefront owns a tile of 2048 docs = 256*b bytes of a b-bit column; it
+// PinotDataBitSet.java:143-170).  A wavefront owns a tile of 64*steps docs (steps = 32: 256*b bytes of a b-bit column); it
 // pulls the tile with coalesced 16 B/lane LDS-DMA loads (global_load_lds_dwordx4) into its private LDS slot,
 // then every lane extracts doc 64k+lane of step k with one ds_read2_b32 + v_perm_b32 (big-endian byte
 // gather) + v_bfe_u32 -- the per-lane byte selector and bit offset are loop invariant because 64*b bits is a
@@ -35,16 +35,23 @@ __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" 
 // tile_bytes is a multiple of 256; tile_src is 256-byte aligned.
 template <bool kDma>
 __device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ tile_src, uint8_t* slot, int tile_bytes, int lane) {
-  for (int base = 0; base < tile_bytes; base += 1024) {
-    const int off = base + lane * 16;
-    if (off < tile_bytes) {
-      if constexpr (kDma) {
-        // LDS destination = M0 base (wave-uniform) + lane * 16; global source is per lane.
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(tile_src + off), (lds_void_t*)(slot + base), 16, 0, 0);
-      } else {
-        const uint4 v = *reinterpret_cast<const uint4*>(tile_src + off);
-        *reinterpret_cast<uint4*>(slot + off) = v;
-      }
+  const int lane_off = lane * 16;
+  const int full = tile_bytes & ~1023;
+  for (int base = 0; base < full; base += 1024) {        // whole 1 KiB chunks: no per-lane guard
+    if constexpr (kDma) {
+      // LDS destination = M0 base (wave-uniform) + lane * 16; global source is per lane.
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(tile_src + base + lane_off), (lds_void_t*)(slot + base), 16, 0, 0);
+    } else {
+      const uint4 v = *reinterpret_cast<const uint4*>(tile_src + base + lane_off);
+      *reinterpret_cast<uint4*>(slot + base + lane_off) = v;
+    }
+  }
+  if (full < tile_bytes && full + lane_off < tile_bytes) {   // tail chunk (tile_bytes is a multiple of 128)
+    if constexpr (kDma) {
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(tile_src + full + lane_off), (lds_void_t*)(slot + full), 16, 0, 0);
+    } else {
+      const uint4 v = *reinterpret_cast<const uint4*>(tile_src + full + lane_off);
+      *reinterpret_cast<uint4*>(slot + full + lane_off) = v;
     }
   }
 }
@@ -105,124 +112,223 @@ struct MaskStack {
   }
 };
 
-__device__ __forceinline__ uint32_t valid_lane_mask(int num_docs, int tile, int lane) {
-  const long long rem = (long long)num_docs - (long long)tile * kTileDocs;  // docs remaining from the tile start
-  if (rem >= kTileDocs) return 0xFFFFFFFFu;
-  long long nk = (rem - lane + 63) >> 6;                                     // steps k with 64k + lane < rem
+
+__device__ __forceinline__ uint32_t full_mask(int steps) { return steps >= 32 ? 0xFFFFFFFFu : ((1u << steps) - 1u); }
+
+__device__ __forceinline__ uint32_t valid_lane_mask(int num_docs, int tile, int lane, int steps) {
+  const long long rem = (long long)num_docs - (long long)tile * 64 * steps;  // docs remaining from the tile start
+  if (rem >= 64 * steps) return full_mask(steps);
+  long long nk = (rem - lane + 63) >> 6;                                      // steps k with 64k + lane < rem
   if (nk <= 0) return 0u;
-  if (nk >= 32) return 0xFFFFFFFFu;
+  if (nk >= steps) return full_mask(steps);
   return (1u << (int)nk) - 1u;
 }
 
-// Evaluate one scan leaf over the staged tile -> lane mask (bit k = doc 64k+lane matches).
+__device__ __forceinline__ uint32_t decode_auto(const uint8_t* slot, const LaneDec& L, int k, int b) {
+  return b <= 25 ? decode_step<false>(slot, L, k, b) : decode_step<true>(slot, L, k, b);
+}
+
+// Shift a compare result into the lane mask with two VALU ops: v_cmp writes VCC, v_addc computes m = 2*m + carry.
+// (The portable form -- compare, select, shift, or -- costs 3.5 ops per value; integer VALU ops issue at 4 cycles per
+// wave64 instruction on gfx950, and this loop is what bounds the kernel: profiles/r1/microbench.jsonl "valu_rate".)
+__device__ __forceinline__ void shift_in_lt(uint32_t& m, uint32_t x, uint32_t limit) {
+  asm("v_cmp_gt_u32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x), "s"(limit) : "vcc");
+}
+__device__ __forceinline__ void shift_in_le(uint32_t& m, uint32_t x, uint32_t limit) {
+  asm("v_cmp_ge_u32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x), "s"(limit) : "vcc");
+}
+
+// DICT_RANGE leaf with the bit width known at compile time: the LDS offsets of the 32 steps become instruction
+// immediates (no per-step address add) and the field width / selector math folds away.
+template <int B, bool kLoZero>
+__device__ __forceinline__ uint32_t range_leaf_loop(const uint8_t* slot, int lane, uint32_t lo, uint32_t span, int steps) {
+  // The lane constants of all 25 widths are loop invariant, so LLVM would hoist every one of them out of the tile
+  // loop and keep ~150 VGPRs live; the empty asm makes `lane` opaque here so they are recomputed (8 ops per tile).
+  asm volatile("" : "+v"(lane));
+  const LaneDec dec = make_lane_dec(B, lane);
+  const uint8_t* base = slot + dec.off;
+  const uint32_t limit = __builtin_amdgcn_readfirstlane(span);
+  uint32_t m = 0;
+  for (int kb = 0; kb < steps; kb += 16) {     // steps is 16 or 32: no remainder loop
+    uint32_t w0[16], w1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {              // 16 LDS reads in flight, offsets are immediates
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(base + (kb + j) * 8 * B);
+      w0[j] = p[0];
+      w1[j] = p[1];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t win = __builtin_amdgcn_perm(w1[j], w0[j], dec.sel);
+      const uint32_t d = __builtin_amdgcn_ubfe(win, dec.shift, (uint32_t)B);
+      shift_in_lt(m, kLoZero ? d : d - lo, limit);
+    }
+  }
+  return __builtin_bitreverse32(m) >> (32 - steps);   // step k was shifted in first; restore bit k
+}
+
+template <bool kLoZero>
+__device__ __forceinline__ uint32_t range_leaf_dispatch(int b, const uint8_t* slot, int lane, uint32_t lo, uint32_t span, int steps) {
+  switch (b) {
+#define PG_CASE(B) case B: return range_leaf_loop<B, kLoZero>(slot, lane, lo, span, steps);
+    PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10)
+    PG_CASE(11) PG_CASE(12) PG_CASE(13) PG_CASE(14) PG_CASE(15) PG_CASE(16) PG_CASE(17) PG_CASE(18) PG_CASE(19) PG_CASE(20)
+    PG_CASE(21) PG_CASE(22) PG_CASE(23) PG_CASE(24) PG_CASE(25)
+#undef PG_CASE
+    default: return 0u;
+  }
+}
+
+// Generic leaf loops (wide 26..31-bit streams, dictId sets).
 template <bool kWide>
-__device__ __forceinline__ uint32_t eval_dict_leaf_loop(const DevLeaf& L, const uint8_t* slot, const LaneDec& dec, int b) {
+__device__ __forceinline__ uint32_t eval_dict_leaf_loop(const DevNode& L, const uint8_t* slot, const LaneDec& dec, int b, int steps) {
   uint32_t m = 0;
   if (L.kind == kLeafDictRange) {
-    const uint32_t lo = (uint32_t)L.lo, span = L.span;
-#pragma unroll 16
-    for (int k = 0; k < kTileSteps; ++k) {
+    const uint32_t lo = (uint32_t)L.lo, limit = __builtin_amdgcn_readfirstlane(L.span);
+#pragma unroll 8
+    for (int k = 0; k < steps; ++k) {
       const uint32_t d = decode_step<kWide>(slot, dec, k, b);
-      m = (m << 1) | ((d - lo) < span ? 1u : 0u);
+      shift_in_lt(m, d - lo, limit);
     }
   } else {  // kLeafDictSet
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)L.set_words, 0, L.set_bytes, 0x00020000);
 #pragma unroll 8
-    for (int k = 0; k < kTileSteps; ++k) {
+    for (int k = 0; k < steps; ++k) {
       const uint32_t d = decode_step<kWide>(slot, dec, k, b);
       const uint32_t w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (d >> 5) * 4u, 0, 0);  // OOB -> 0
       m = (m << 1) | ((w >> (d & 31u)) & 1u);
     }
   }
-  return __builtin_bitreverse32(m);   // step k was shifted in first -> bit 31-k; restore bit k
+  return __builtin_bitreverse32(m) >> (32 - steps);   // step k was shifted in first; restore bit k
 }
 
-template <bool kDma>
-__device__ uint32_t eval_leaf(const ScanParams& p, const DevLeaf& L, int tile, uint8_t* wave_lds, int lane) {
+// `stage` is the wave's current column staging buffer, `bstage` its current bitmap staging buffer (already filled).
+// The node record carries everything the leaf needs (one scalar load).
+__device__ uint32_t eval_leaf(const ScanParams& p, const DevNode& L, int tile, const uint8_t* stage, const uint8_t* bstage, int lane) {
+  const int steps = p.tile_steps;
   uint32_t m;
   switch (L.kind) {
     case kLeafMatchAll: m = 0xFFFFFFFFu; break;
     case kLeafMatchNone: m = 0u; break;
     case kLeafDictRange:
     case kLeafDictSet: {
-      const DevColumn& c = p.cols[L.col];
-      const int b = c.bits;
-      const uint8_t* slot = wave_lds + c.slot_off;   // wave_lds = current staging buffer, staged by the caller
-      const LaneDec dec = make_lane_dec(b, lane);
-      m = b <= 25 ? eval_dict_leaf_loop<false>(L, slot, dec, b) : eval_dict_leaf_loop<true>(L, slot, dec, b);
+      const int b = L.bits;
+      const uint8_t* slot = stage + L.slot_off;
+      if (L.kind == kLeafDictRange && b <= 25) {
+        m = L.lo == 0 ? range_leaf_dispatch<true>(b, slot, lane, 0u, L.span, steps)
+                      : range_leaf_dispatch<false>(b, slot, lane, (uint32_t)L.lo, L.span, steps);
+      } else {
+        const LaneDec dec = make_lane_dec(b, lane);
+        m = b <= 25 ? eval_dict_leaf_loop<false>(L, slot, dec, b, steps) : eval_dict_leaf_loop<true>(L, slot, dec, b, steps);
+      }
       break;
     }
     case kLeafRawRange: {
-      const DevColumn& c = p.cols[L.col];
-      const long long base_doc = (long long)tile * kTileDocs;
+      const long long base_doc = (long long)tile * 64 * steps;
       const long long last = (long long)p.num_docs - 1;
       const uint32_t lo = (uint32_t)L.lo, span = L.span;
       m = 0;
 #pragma unroll 8
-      for (int k = 0; k < kTileSteps; ++k) {
+      for (int k = 0; k < steps; ++k) {
         long long doc = base_doc + k * 64 + lane;
         doc = doc > last ? last : doc;
-        const uint32_t v = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(c.fwd + doc * 4));
-        m = (m << 1) | ((v - lo) <= span ? 1u : 0u);
+        const uint32_t v = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(L.fwd + doc * 4));
+        shift_in_le(m, v - lo, __builtin_amdgcn_readfirstlane(span));
       }
-      m = __builtin_bitreverse32(m);
+      m = __builtin_bitreverse32(m) >> (32 - steps);
       break;
     }
-    default: {  // kLeafBitmap: doc-order 64-bit words; word k of the tile covers docs 64k..64k+63
-      const unsigned long long w = L.bitmap[(long long)tile * kTileSteps + (lane & 31)];
-      const uint32_t wlo = (uint32_t)w, whi = (uint32_t)(w >> 32);
-      m = 0;
-#pragma unroll
-      for (int k = 0; k < kTileSteps; ++k) {
-        const uint32_t klo = __builtin_amdgcn_readlane(wlo, k);
-        const uint32_t khi = __builtin_amdgcn_readlane(whi, k);
-        const uint32_t half = lane < 32 ? klo : khi;
-        m |= ((half >> (lane & 31)) & 1u) << k;
+    default: {  // kLeafBitmap: doc-order 64-bit words staged in LDS; word k of the tile covers docs 64k..64k+63
+      // Lanes 0..31 take the low dwords of words 0..31, lanes 32..63 the high dwords; a 32x32 bit-matrix transpose
+      // inside each half-wave (5 ds_swizzle butterfly stages) then leaves in lane i the mask "bit k = bit i of word k".
+      const uint32_t* words = reinterpret_cast<const uint32_t*>(bstage + L.lds_off);
+      const int row = lane & 31;
+      uint32_t x = row < steps ? words[2 * row + (lane >> 5)] : 0u;
+#define PG_TRANSPOSE_STAGE(J, M)                                                              \
+      {                                                                                         \
+        const uint32_t pr = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, ((J) << 10) | 0x1F);  \
+        const bool lo_role = (lane & (J)) == 0;                                                 \
+        const uint32_t a = lo_role ? x : pr;                                                    \
+        const uint32_t bsrc = lo_role ? pr : x;                                                 \
+        const uint32_t t = ((a >> (J)) ^ bsrc) & (M);                                           \
+        x ^= lo_role ? (t << (J)) : t;                                                          \
       }
+      PG_TRANSPOSE_STAGE(16, 0x0000FFFFu)
+      PG_TRANSPOSE_STAGE(8, 0x00FF00FFu)
+      PG_TRANSPOSE_STAGE(4, 0x0F0F0F0Fu)
+      PG_TRANSPOSE_STAGE(2, 0x33333333u)
+      PG_TRANSPOSE_STAGE(1, 0x55555555u)
+#undef PG_TRANSPOSE_STAGE
+      m = x;
       break;
     }
   }
   return L.exclusive ? ~m : m;
 }
 
-// Filter program (postfix) -> lane mask of the tile.  Scan-leaf columns must already be staged.
+// Stage every packed column stream of the tile that satisfies the (filter / aggregation-only) selection.
 template <bool kDma>
-__device__ __forceinline__ uint32_t eval_filter(const ScanParams& p, int tile, uint8_t* wave_lds, int lane) {
+__device__ __forceinline__ void stage_columns(const ScanParams& p, int tile, uint8_t* stage, int lane, bool filter_cols, bool agg_only_cols) {
+  for (int c = 0; c < p.num_stage; ++c) {
+    const DevStage& st = p.stage[c];
+    const bool is_filter = st.in_filter != 0;
+    if ((is_filter && filter_cols) || (!is_filter && agg_only_cols)) {
+      const int tile_bytes = 8 * st.bits * p.tile_steps;
+      stage_tile<kDma>(st.fwd + (long long)tile * tile_bytes, stage + st.slot_off, tile_bytes, lane);
+    }
+  }
+}
+
+// Stage the tile's words of every bitmap leaf (8 bytes per step, one dword per lane).
+template <bool kDma>
+__device__ __forceinline__ void stage_bitmaps(const ScanParams& p, int tile, uint8_t* bstage, int lane) {
+  if (p.num_bitmap_leaves == 0) return;
+  const int bytes = 8 * p.tile_steps;
+  for (int l = 0; l < p.num_bitmap_leaves; ++l) {
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(p.bitmaps[l]) + (long long)tile * bytes;
+    if (lane * 4 < bytes) {
+      if constexpr (kDma) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + lane * 4), (lds_void_t*)(bstage + p.bitmap_lds_off[l]), 4, 0, 0);
+      } else {
+        *reinterpret_cast<uint32_t*>(bstage + p.bitmap_lds_off[l] + lane * 4) = *reinterpret_cast<const uint32_t*>(src + lane * 4);
+      }
+    }
+  }
+}
+
+// Filter program (postfix) -> lane mask of the tile.  Nodes flagged kNodeExitIfZero sit on the root AND chain: when
+// the running result is zero for the whole wavefront the tile is finished.  With lazy_columns the scan columns are
+// staged only after the bitmap prefix (node lazy_node) left something (index-driven queries touch few tiles).
+template <bool kDma>
+__device__ __forceinline__ uint32_t eval_filter(const ScanParams& p, int tile, uint8_t* stage, const uint8_t* bstage, int lane, bool stage_agg_too) {
   if (p.num_nodes == 0) return 0xFFFFFFFFu;
+  if (p.num_nodes == 1) return eval_leaf(p, p.nodes[0], tile, stage, bstage, lane);   // no mask stack for the common single-leaf filter
   MaskStack st;
 #pragma unroll
   for (int i = 0; i < kStackDepth; ++i) st.v[i] = 0;
   st.sp = 0;
   for (int n = 0; n < p.num_nodes; ++n) {
-    const DevNode& nd = p.nodes[n];
+    const DevNode& nd = p.nodes[n];     // self-contained 64-byte record: independent scalar loads off one base
+    uint32_t top;
     if (nd.op == PG_FILTER_LEAF) {
-      st.push(eval_leaf<kDma>(p, p.leaves[nd.leaf], tile, wave_lds, lane));
+      top = eval_leaf(p, nd, tile, stage, bstage, lane);
     } else if (nd.op == PG_FILTER_NOT) {
-      st.push(~st.pop());
+      top = ~st.pop();
     } else {
-      uint32_t acc = st.pop();
+      top = st.pop();
       for (int c = 1; c < nd.num_children; ++c) {
         const uint32_t o = st.pop();
-        acc = nd.op == PG_FILTER_AND ? (acc & o) : (acc | o);
+        top = nd.op == PG_FILTER_AND ? (top & o) : (top | o);
       }
-      st.push(acc);
+    }
+    if ((nd.flags & kNodeExitIfZero) && __builtin_amdgcn_ballot_w64((top & full_mask(p.tile_steps)) != 0u) == 0ull) return 0u;
+    st.push(top);
+    if (p.lazy_columns && n == p.lazy_node) {
+      stage_columns<kDma>(p, tile, stage, lane, true, stage_agg_too);
+      if constexpr (kDma) wait_vmem();
     }
   }
   return st.pop();
-}
-
-// Stage every dictionary column of the tile that satisfies (in_filter / in_agg-only) selection.
-template <bool kDma>
-__device__ __forceinline__ void stage_columns(const ScanParams& p, int tile, uint8_t* wave_lds, int lane, bool filter_cols, bool agg_only_cols) {
-  for (int c = 0; c < p.num_cols; ++c) {
-    const DevColumn& col = p.cols[c];
-    if (col.is_raw) continue;
-    const bool is_filter = col.in_filter != 0;
-    if ((is_filter && filter_cols) || (!is_filter && agg_only_cols)) {
-      const int tile_bytes = 256 * col.bits;
-      stage_tile<kDma>(col.fwd + (long long)tile * tile_bytes, wave_lds + col.slot_off, tile_bytes, lane);
-    }
-  }
 }
 
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
@@ -241,15 +347,15 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
   return v;
 }
 
-// Write the tile's docId bitmap (32 doc-order 64-bit words) from the lane masks.
-__device__ __forceinline__ void store_tile_bitmap(unsigned long long* out, int tile, uint32_t m, int lane) {
+// Write the tile's docId bitmap (one doc-order 64-bit word per step) from the lane masks.
+__device__ __forceinline__ void store_tile_bitmap(unsigned long long* out, int tile, uint32_t m, int lane, int steps) {
   unsigned long long mine = 0;
-#pragma unroll
-  for (int k = 0; k < kTileSteps; ++k) {
+#pragma unroll 16
+  for (int k = 0; k < steps; ++k) {
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(((m >> k) & 1u) != 0u);
     mine = (lane == k) ? bal : mine;
   }
-  if (lane < kTileSteps) out[(long long)tile * kTileSteps + lane] = mine;
+  if (lane < steps) out[(long long)tile * steps + lane] = mine;
 }
 
 // Wave-private queue of matching dictIds waiting for their dictionary gather.  Matches are compacted into it
@@ -262,9 +368,8 @@ struct GatherQueue {
   int count;
 };
 
-__device__ __forceinline__ void drain_queue(GatherQueue& gq, const __amdgpu_buffer_rsrc_t rsrc, int lane, long long& sum, int keep) {
-  // gathers entries [0, n) where n = count - keep rounded down to what is there; `keep` = 0 drains everything.
-  const int n = gq.count - keep;
+__device__ __forceinline__ void drain_queue(GatherQueue& gq, const __amdgpu_buffer_rsrc_t rsrc, int lane, long long& sum) {
+  const int n = gq.count;
   __builtin_amdgcn_wave_barrier();
   for (int base = 0; base < n; base += 256) {
     int32_t v[4];
@@ -286,11 +391,13 @@ __device__ __forceinline__ void drain_queue(GatherQueue& gq, const __amdgpu_buff
 // a time so that four LDS reads are in flight (a separate straight 32-step path for dense tiles cost 30 VGPRs and
 // one wavefront per SIMD of occupancy, which lost more than it gained).
 template <bool kWide>
-__device__ __forceinline__ void agg_dict_column(const DevColumn& col, const DevAggCol& ac, const uint8_t* slot, uint32_t m,
+__device__ __forceinline__ void agg_dict_column(const DevAggCol& ac, const uint8_t* slot, uint32_t m,
                                                 int lane, long long& sum, int32_t& kmin, int32_t& kmax, GatherQueue& gq) {
-  const int b = col.bits;
+  const int b = ac.bits;
   const LaneDec dec = make_lane_dec(b, lane);
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)col.dict, 0, col.dict_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ac.dict, 0, ac.dict_bytes, 0x00020000);
+  const bool narrow_plane = ac.is_plane && ac.need_sum && b <= 27;
+  uint32_t psum = 0;
   uint32_t rem = m;
   for (;;) {
     if (__builtin_amdgcn_ballot_w64(rem != 0u) == 0ull) break;
@@ -313,26 +420,28 @@ __device__ __forceinline__ void agg_dict_column(const DevColumn& col, const DevA
         kmin = (active[j] && key < kmin) ? key : kmin;
         kmax = (active[j] && key > kmax) ? key : kmax;
       }
-      if (col.is_plane) {
+      if (ac.is_plane) {
         // value plane: the decoded field IS (value - base); no dictionary, no gather
-        if (ac.need_sum) sum += active[j] ? (long long)d[j] : 0ll;
+        if (narrow_plane) psum += active[j] ? d[j] : 0u;
+        else if (ac.need_sum) sum += active[j] ? (long long)d[j] : 0ll;
       } else if (ac.need_sum) {
         const unsigned long long amask = __builtin_amdgcn_ballot_w64(active[j]);
         const uint32_t pos = (uint32_t)gq.count + __builtin_amdgcn_mbcnt_hi((uint32_t)(amask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)amask, 0u));
         if (active[j]) gq.q[pos] = d[j];
         gq.count += __builtin_popcountll(amask);
-        if (gq.count > gq.cap - 64) drain_queue(gq, rsrc, lane, sum, 0);
+        if (gq.count > gq.cap - 64) drain_queue(gq, rsrc, lane, sum);
       }
     }
   }
+  sum += (long long)psum;
 }
 
-__device__ __forceinline__ void agg_raw_column(const DevColumn& col, const DevAggCol& ac, int num_docs, int tile, uint32_t m,
+__device__ __forceinline__ void agg_raw_column(const DevAggCol& col, int num_docs, int tile, int steps, uint32_t m,
                                                int lane, long long& sum, int32_t& kmin, int32_t& kmax) {
-  const long long base_doc = (long long)tile * kTileDocs;
+  const long long base_doc = (long long)tile * 64 * steps;
   const long long last = (long long)num_docs - 1;
 #pragma unroll 8
-  for (int k = 0; k < kTileSteps; ++k) {
+  for (int k = 0; k < steps; ++k) {
     long long doc = base_doc + k * 64 + lane;
     doc = doc > last ? last : doc;
     const int32_t v = (int32_t)__builtin_bswap32(*reinterpret_cast<const uint32_t*>(col.fwd + doc * 4));
@@ -341,13 +450,12 @@ __device__ __forceinline__ void agg_raw_column(const DevColumn& col, const DevAg
     kmin = (match && v < kmin) ? v : kmin;
     kmax = (match && v > kmax) ? v : kmax;
   }
-  (void)ac;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused scan -> filter -> aggregate.  One wavefront per tile, grid-stride over tiles.
+// Fused scan -> filter -> aggregate.  One wavefront per tile, tiles dealt round-robin over a persistent grid.
 // ------------------------------------------------------------------------------------------------
-template <bool kDma>
+template <bool kDma, int kAggSlots>
 __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63;
@@ -355,93 +463,102 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
   const int waves_per_block = blockDim.x >> 6;
   uint8_t* wave_lds = smem + wave_in_block * p.wave_lds_bytes;
   const int total_waves = gridDim.x * waves_per_block;
+  const int steps = p.tile_steps;
 
   unsigned long long count = 0;
-  long long sum[kMaxAggCols];
-  int32_t kmin[kMaxAggCols], kmax[kMaxAggCols];
+  long long sum[kAggSlots];
+  int32_t kmin[kAggSlots], kmax[kAggSlots];
 #pragma unroll
-  for (int a = 0; a < kMaxAggCols; ++a) { sum[a] = 0; kmin[a] = 0x7FFFFFFF; kmax[a] = (int32_t)0x80000000; }
+  for (int a = 0; a < kAggSlots; ++a) { sum[a] = 0; kmin[a] = 0x7FFFFFFF; kmax[a] = (int32_t)0x80000000; }
 
   GatherQueue gq;
   gq.q = reinterpret_cast<uint32_t*>(wave_lds + p.queue_off);
   gq.cap = p.queue_cap;
   gq.count = 0;
-  // the queue may stay filled across tiles only when exactly one column is summed (its entries are all that column's)
+  // the queue may stay filled across tiles only when exactly one column is summed through its dictionary
   int num_sum_cols = 0;
 #pragma unroll
-  for (int a = 0; a < kMaxAggCols; ++a)
-    num_sum_cols += (a < p.num_agg_cols && p.agg_cols[a].need_sum && !p.cols[p.agg_cols[a].col].is_raw && !p.cols[p.agg_cols[a].col].is_plane) ? 1 : 0;
+  for (int a = 0; a < kAggSlots; ++a)
+    num_sum_cols += (a < p.num_agg_cols && p.agg_cols[a].need_sum && !p.agg_cols[a].is_raw && !p.agg_cols[a].is_plane) ? 1 : 0;
 
-  // Double-buffered tile pipeline: while tile t is decoded from staging buffer `buf`, the LDS-DMA loads of this
-  // wave's next tile are already in flight into the other buffer, so the memory pipe never idles behind VALU work.
   unsigned long long cyc_wait = 0, cyc_filter = 0, cyc_agg = 0;
   const unsigned long long cyc_start = p.profile ? __builtin_amdgcn_s_memtime() : 0ull;
-  bool hot = false;        // did the last processed tile match anything? (drives speculative value-column loads)
+  const bool eager = p.lazy_columns == 0;   // stage the scan columns together with the bitmap words
+  uint8_t* bitmap_lds = wave_lds + p.bitmap_off;   // two tiny buffers: the next tile's posting words are always prefetched
+  bool hot = false;
   bool cur_has_agg = false;
-  int buf = 0;
+  int buf = 0, bbuf = 0;
   int tile = blockIdx.x * waves_per_block + wave_in_block;
-  if (tile < p.num_tiles) stage_columns<kDma>(p, tile, wave_lds, lane, true, false);
+  if (tile < p.num_tiles) {
+    stage_bitmaps<kDma>(p, tile, bitmap_lds, lane);
+    if (eager) stage_columns<kDma>(p, tile, wave_lds, lane, true, false);
+  }
   for (; tile < p.num_tiles; tile += total_waves) {
-    uint8_t* cur = wave_lds + buf * p.stage_bytes;
+    const ScanParams& q = p;
+    uint8_t* cur = wave_lds + buf * q.stage_bytes;
+    const uint8_t* bcur = bitmap_lds + bbuf * q.bitmap_bytes;
     unsigned long long t0 = 0, t1 = 0, t2 = 0;
-    if (p.profile) t0 = __builtin_amdgcn_s_memtime();
+    if (q.profile) t0 = __builtin_amdgcn_s_memtime();
     if constexpr (kDma) wait_vmem();                       // the current tile has landed
-    if (p.profile) t1 = __builtin_amdgcn_s_memtime();
+    if (q.profile) t1 = __builtin_amdgcn_s_memtime();
     const int next = tile + total_waves;
-    const bool next_has_agg = hot && p.speculate != 0;
-    if (p.double_buffer && next < p.num_tiles) stage_columns<kDma>(p, next, wave_lds + (buf ^ 1) * p.stage_bytes, lane, true, next_has_agg);
-    uint32_t m = eval_filter<kDma>(p, tile, cur, lane);
-    m &= valid_lane_mask(p.num_docs, tile, lane);
-    if (p.out_bitmap) store_tile_bitmap(p.out_bitmap, tile, m, lane);
+    const bool next_has_agg = eager && hot && q.speculate != 0;
+    if (next < q.num_tiles) {
+      stage_bitmaps<kDma>(q, next, bitmap_lds + (bbuf ^ 1) * q.bitmap_bytes, lane);
+      if (q.double_buffer && eager) stage_columns<kDma>(q, next, wave_lds + (buf ^ 1) * q.stage_bytes, lane, true, next_has_agg);
+    }
+    uint32_t m = eval_filter<kDma>(q, tile, cur, bcur, lane, false);
+    m &= valid_lane_mask(q.num_docs, tile, lane, steps);
+    if (q.out_bitmap) store_tile_bitmap(q.out_bitmap, tile, m, lane, steps);
     count += (unsigned)__builtin_popcount(m);
     const bool any = __builtin_amdgcn_ballot_w64(m != 0u) != 0ull;
     hot = any;
-    if (p.profile) t2 = __builtin_amdgcn_s_memtime();
-    if (any && p.num_agg_cols > 0) {
+    if (q.profile) t2 = __builtin_amdgcn_s_memtime();
+    if (any && q.num_agg_cols > 0) {
       if (!cur_has_agg) {
-        stage_columns<kDma>(p, tile, cur, lane, false, true);
+        stage_columns<kDma>(q, tile, cur, lane, false, true);
         if constexpr (kDma) wait_vmem();
       }
 #pragma unroll
-      for (int a = 0; a < kMaxAggCols; ++a) {
-        if (a < p.num_agg_cols) {
-          const DevAggCol& ac = p.agg_cols[a];
-          const DevColumn& col = p.cols[ac.col];
-          if (col.is_raw) {
-            agg_raw_column(col, ac, p.num_docs, tile, m, lane, sum[a], kmin[a], kmax[a]);
+      for (int a = 0; a < kAggSlots; ++a) {
+        if (a < q.num_agg_cols) {
+          const DevAggCol& ac = q.agg_cols[a];
+          if (ac.is_raw) {
+            agg_raw_column(ac, q.num_docs, tile, steps, m, lane, sum[a], kmin[a], kmax[a]);
           } else {
-            if (col.bits <= 25) agg_dict_column<false>(col, ac, cur + col.slot_off, m, lane, sum[a], kmin[a], kmax[a], gq);
-            else agg_dict_column<true>(col, ac, cur + col.slot_off, m, lane, sum[a], kmin[a], kmax[a], gq);
-            if (num_sum_cols > 1 && ac.need_sum && !col.is_plane && gq.count > 0) {
-              const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)col.dict, 0, col.dict_bytes, 0x00020000);
-              drain_queue(gq, rsrc, lane, sum[a], 0);
+            if (ac.bits <= 25) agg_dict_column<false>(ac, cur + ac.slot_off, m, lane, sum[a], kmin[a], kmax[a], gq);
+            else agg_dict_column<true>(ac, cur + ac.slot_off, m, lane, sum[a], kmin[a], kmax[a], gq);
+            if (num_sum_cols > 1 && ac.need_sum && !ac.is_plane && gq.count > 0) {
+              const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ac.dict, 0, ac.dict_bytes, 0x00020000);
+              drain_queue(gq, rsrc, lane, sum[a]);
             }
           }
         }
       }
     }
-    if (p.profile) {
+    if (q.profile) {
       const unsigned long long t3 = __builtin_amdgcn_s_memtime();
       cyc_wait += t1 - t0; cyc_filter += t2 - t1; cyc_agg += t3 - t2;
     }
-    if (p.double_buffer) {
+    bbuf ^= 1;
+    if (q.double_buffer) {
       cur_has_agg = next_has_agg;
       buf ^= 1;
-    } else if (next < p.num_tiles) {
-      // single buffer: the next tile is staged only now that this one is fully consumed
-      stage_columns<kDma>(p, next, wave_lds, lane, true, next_has_agg);
+    } else {
+      // single column buffer: the next tile's columns are staged only now that this one is fully consumed
+      if (eager && next < q.num_tiles) stage_columns<kDma>(q, next, wave_lds, lane, true, next_has_agg);
       cur_has_agg = next_has_agg;
     }
   }
 
-  // final drain of the carried queue (single summed column)
+  // final drain of the carried queue (single dictionary-summed column)
   if (num_sum_cols == 1 && gq.count > 0) {
 #pragma unroll
-    for (int a = 0; a < kMaxAggCols; ++a) {
-      if (a < p.num_agg_cols && p.agg_cols[a].need_sum && !p.cols[p.agg_cols[a].col].is_raw && !p.cols[p.agg_cols[a].col].is_plane) {
-        const DevColumn& col = p.cols[p.agg_cols[a].col];
+    for (int a = 0; a < kAggSlots; ++a) {
+      if (a < p.num_agg_cols && p.agg_cols[a].need_sum && !p.agg_cols[a].is_raw && !p.agg_cols[a].is_plane) {
+        const DevAggCol& col = p.agg_cols[a];
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)col.dict, 0, col.dict_bytes, 0x00020000);
-        drain_queue(gq, rsrc, lane, sum[a], 0);
+        drain_queue(gq, rsrc, lane, sum[a]);
       }
     }
   }
@@ -453,9 +570,13 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
   mine.count = (unsigned long long)wave_sum_i64((long long)count);
 #pragma unroll
   for (int a = 0; a < kMaxAggCols; ++a) {
-    mine.sum[a] = wave_sum_i64(sum[a]);
-    mine.kmin[a] = wave_min_i32(kmin[a]);
-    mine.kmax[a] = wave_max_i32(kmax[a]);
+    if (a < kAggSlots) {
+      mine.sum[a] = wave_sum_i64(sum[a < kAggSlots ? a : 0]);
+      mine.kmin[a] = wave_min_i32(kmin[a < kAggSlots ? a : 0]);
+      mine.kmax[a] = wave_max_i32(kmax[a < kAggSlots ? a : 0]);
+    } else {
+      mine.sum[a] = 0; mine.kmin[a] = 0x7FFFFFFF; mine.kmax[a] = (int32_t)0x80000000;
+    }
   }
   mine.cyc[0] = cyc_wait; mine.cyc[1] = cyc_filter; mine.cyc[2] = cyc_agg;
   mine.cyc[3] = p.profile ? __builtin_amdgcn_s_memtime() - cyc_start : 0ull;
@@ -531,19 +652,118 @@ __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockP
 // ------------------------------------------------------------------------------------------------
 // Fused scan -> filter -> group-by aggregate with a direct-indexed group table
 // (DictionaryBasedGroupKeyGenerator.ArrayBasedHolder: groupId = sum dictId_j * prod_{k<j} card_k).
-// Per-workgroup LDS partial table with LDS atomics, flushed with global atomics.
+// Up to 16 wavefronts of a workgroup share one LDS partial table (LDS atomics), flushed with global atomics.
 // ------------------------------------------------------------------------------------------------
-template <int kScope>
-__device__ __forceinline__ void table_update(long long* acc, int num_groups, int a, int kind, uint32_t g, long long v) {
-  long long* slot = acc + (long long)a * num_groups + g;
-  if (kind == kGroupSum) __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, kScope);
-  else if (kind == kGroupMin) __hip_atomic_fetch_min(slot, v, __ATOMIC_RELAXED, kScope);
-  else __hip_atomic_fetch_max(slot, v, __ATOMIC_RELAXED, kScope);
+// Group table (LDS copy and global copy share the layout): count[G] (u64) then acc[a][G] (i64).
+// The LDS copy uses 32-bit atomics where the per-workgroup value provably fits: a workgroup sees fewer than 2^31 docs,
+// and MIN/MAX keys are int32 (dictIds, plane offsets or raw values); only SUM needs 64 bits.  The low dword of each
+// 64-bit slot is used and the flush widens it.
+template <bool kLds>
+__device__ __forceinline__ void group_count(unsigned long long* cnt, uint32_t g) {
+  if constexpr (kLds) __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(cnt + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_fetch_add(cnt + g, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool kLds>
+__device__ __forceinline__ void group_sum(long long* slot, long long v) {
+  __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, kLds ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool kLds>
+__device__ __forceinline__ void group_min(long long* slot, int32_t v) {
+  if constexpr (kLds) __hip_atomic_fetch_min(reinterpret_cast<int32_t*>(slot), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_fetch_min(slot, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool kLds>
+__device__ __forceinline__ void group_max(long long* slot, int32_t v) {
+  if constexpr (kLds) __hip_atomic_fetch_max(reinterpret_cast<int32_t*>(slot), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_fetch_max(slot, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Aggregate four docs per lane (steps k[0..3]) into the group table.  kAllActive: every lane owns four real matching
+// docs (no exec masking around the atomics).
+template <bool kLds, bool kAllActive>
+__device__ __forceinline__ void group_process4(const GroupParams& gp, const uint8_t* stage, int tile, int lane, const int (&k)[4], const bool (&active)[4],
+                                               unsigned long long* t_cnt, long long* t_acc) {
+  const ScanParams& p = gp.scan;
+  const int G = gp.num_groups;
+  uint32_t g[4] = {0u, 0u, 0u, 0u};
+  for (int c = 0; c < gp.num_group_cols; ++c) {
+    const DevGroupKey& key = gp.group_keys[c];
+    const int b = key.bits;
+    const LaneDec dec = make_lane_dec(b, lane);
+    const uint8_t* slot = stage + key.slot_off;
+    const uint32_t mult = (uint32_t)key.mult;
+    if (b <= 25) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] += decode_step<false>(slot, dec, k[j], b) * mult;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] += decode_step<true>(slot, dec, k[j], b) * mult;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (kAllActive || active[j]) group_count<kLds>(t_cnt, g[j]);
+  }
+  for (int a = 0; a < gp.num_group_aggs; ++a) {
+    const DevGroupAgg& ga = gp.group_aggs[a];     // self-contained record
+    const DevGroupAgg& col = ga;
+    long long* acc = t_acc + (long long)a * G;
+    int32_t v[4];
+    if (col.is_raw) {
+      const long long base_doc = (long long)tile * 64 * p.tile_steps;
+      const long long last = (long long)p.num_docs - 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        long long doc = base_doc + k[j] * 64 + lane;
+        doc = doc > last ? last : doc;
+        v[j] = (int32_t)__builtin_bswap32(*reinterpret_cast<const uint32_t*>(col.fwd + doc * 4));
+      }
+    } else {
+      const int b = col.bits;
+      const LaneDec dec = make_lane_dec(b, lane);
+      const uint8_t* slot = stage + ga.slot_off;
+      uint32_t d[4];
+      if (b <= 25) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = decode_step<false>(slot, dec, k[j], b);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = decode_step<true>(slot, dec, k[j], b);
+      }
+      if (ga.kind == kGroupSum && !col.is_plane) {
+        // dictionary gather (small dictionaries / PINOT_GPU_VALUE_PLANE=0); inactive lanes use an out-of-range offset
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)col.dict, 0, col.dict_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (kAllActive || active[j]) ? d[j] * 4u : 0xFFFFFFFFu, 0, 0);
+      } else {
+        // value plane: the field is (value - base).  MIN / MAX on a sorted dictionary: the dictId is monotone in the value.
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (int32_t)d[j];
+      }
+    }
+    if (ga.kind == kGroupSum) {
+      // plane offsets are unsigned fields; gathered / raw values are signed
+      const bool is_unsigned = !col.is_raw && col.is_plane;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kAllActive || active[j]) group_sum<kLds>(acc + g[j], is_unsigned ? (long long)(uint32_t)v[j] : (long long)v[j]);
+      }
+    } else if (ga.kind == kGroupMin) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kAllActive || active[j]) group_min<kLds>(acc + g[j], v[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kAllActive || active[j]) group_max<kLds>(acc + g[j], v[j]);
+      }
+    }
+  }
 }
 
 template <bool kDma, bool kLdsTable>
-__global__ __launch_bounds__(kBlockThreads) void scan_group_kernel(const GroupParams gp) {
-  constexpr int kScope = kLdsTable ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT;
+__global__ __launch_bounds__(kGroupBlockThreads) void scan_group_kernel(const GroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const ScanParams& p = gp.scan;
   const int lane = threadIdx.x & 63;
@@ -552,19 +772,21 @@ __global__ __launch_bounds__(kBlockThreads) void scan_group_kernel(const GroupPa
   const int total_waves = gridDim.x * waves_per_block;
   const int G = gp.num_groups;
   const int NA = gp.num_group_aggs;
+  const int steps = p.tile_steps;
 
-  // LDS: [staging slots of all waves][group table]
+  // LDS: [staging buffers of all waves][group table]
   uint8_t* wave_lds = smem + wave_in_block * p.wave_lds_bytes;
   unsigned long long* t_cnt;
   long long* t_acc;
   if constexpr (kLdsTable) {
-    t_cnt = reinterpret_cast<unsigned long long*>(smem + waves_per_block * p.wave_lds_bytes);   // after every wave's staging buffers
+    t_cnt = reinterpret_cast<unsigned long long*>(smem + waves_per_block * p.wave_lds_bytes);
     t_acc = reinterpret_cast<long long*>(t_cnt + G);
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
       t_cnt[g] = 0ull;
       for (int a = 0; a < NA; ++a) {
         const int kind = gp.group_aggs[a].kind;
-        t_acc[(long long)a * G + g] = kind == kGroupSum ? 0ll : (kind == kGroupMin ? 0x7FFFFFFFFFFFFFFFll : (long long)0x8000000000000000ull);
+        // MIN / MAX slots hold an int32 in their low dword
+        t_acc[(long long)a * G + g] = kind == kGroupSum ? 0ll : (kind == kGroupMin ? 0x7FFFFFFFll : (long long)(uint32_t)0x80000000u);
       }
     }
     __syncthreads();
@@ -573,95 +795,73 @@ __global__ __launch_bounds__(kBlockThreads) void scan_group_kernel(const GroupPa
     t_acc = gp.table_acc;
   }
 
-  int buf = 0;
+  const bool eager = p.lazy_columns == 0;
+  const uint32_t fullm = full_mask(steps);
+  uint8_t* bitmap_lds = wave_lds + p.bitmap_off;
+  bool hot = false, cur_has_agg = false;
+  int bbuf = 0;
   int tile = blockIdx.x * waves_per_block + wave_in_block;
-  if (tile < p.num_tiles) stage_columns<kDma>(p, tile, wave_lds, lane, true, true);   // group-by touches every column of (nearly) every tile
+  if (tile < p.num_tiles) {
+    stage_bitmaps<kDma>(p, tile, bitmap_lds, lane);
+    // without a filter every tile needs every column: stage them all up front
+    if (eager) { stage_columns<kDma>(p, tile, wave_lds, lane, true, p.num_nodes == 0); cur_has_agg = p.num_nodes == 0; }
+  }
   for (; tile < p.num_tiles; tile += total_waves) {
-    uint8_t* cur = wave_lds + buf * p.stage_bytes;
     if constexpr (kDma) wait_vmem();
     const int next = tile + total_waves;
-    if (p.double_buffer) {
-      if (next < p.num_tiles) stage_columns<kDma>(p, next, wave_lds + (buf ^ 1) * p.stage_bytes, lane, true, true);
-      buf ^= 1;
-    }
-    uint32_t m = eval_filter<kDma>(p, tile, cur, lane);
-    m &= valid_lane_mask(p.num_docs, tile, lane);
+    if (next < p.num_tiles) stage_bitmaps<kDma>(p, next, bitmap_lds + (bbuf ^ 1) * p.bitmap_bytes, lane);
+    uint32_t m = eval_filter<kDma>(p, tile, wave_lds, bitmap_lds + bbuf * p.bitmap_bytes, lane, false);
+    m &= valid_lane_mask(p.num_docs, tile, lane, steps);
     const bool any = __builtin_amdgcn_ballot_w64(m != 0u) != 0ull;
-    if (any)
-
-    for (int kb = 0; kb < kTileSteps; kb += 8) {
-      if (__builtin_amdgcn_ballot_w64(((m >> kb) & 0xFFu) != 0u) == 0ull) continue;
-      uint32_t g[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) g[j] = 0;
-      // group id
-      for (int c = 0; c < gp.num_group_cols; ++c) {
-        const DevColumn& col = p.cols[gp.group_cols[c]];
-        const int b = col.bits;
-        const LaneDec dec = make_lane_dec(b, lane);
-        const uint8_t* slot = cur + col.slot_off;
-        const uint32_t mult = (uint32_t)gp.group_mult[c];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const uint32_t d = b <= 25 ? decode_step<false>(slot, dec, kb + j, b) : decode_step<true>(slot, dec, kb + j, b);
-          g[j] += d * mult;
-        }
+    hot = any;
+    if (any) {
+      if (!cur_has_agg) {
+        stage_columns<kDma>(p, tile, wave_lds, lane, false, true);
+        if constexpr (kDma) wait_vmem();
       }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if ((m >> (kb + j)) & 1u) __hip_atomic_fetch_add(&t_cnt[g[j]], 1ull, __ATOMIC_RELAXED, kScope);
-      }
-      for (int a = 0; a < NA; ++a) {
-        const DevGroupAgg ga = gp.group_aggs[a];
-        const DevColumn& col = p.cols[ga.col];
-        long long v[8];
-        if (col.is_raw) {
-          const long long base_doc = (long long)tile * kTileDocs;
-          const long long last = (long long)p.num_docs - 1;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            long long doc = base_doc + (kb + j) * 64 + lane;
-            doc = doc > last ? last : doc;
-            v[j] = (long long)(int32_t)__builtin_bswap32(*reinterpret_cast<const uint32_t*>(col.fwd + doc * 4));
-          }
-        } else {
-          const int b = col.bits;
-          const LaneDec dec = make_lane_dec(b, lane);
-          const uint8_t* slot = cur + col.slot_off;
-          if (ga.kind == kGroupSum && !col.is_plane) {
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)col.dict, 0, col.dict_bytes, 0x00020000);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const uint32_t d = b <= 25 ? decode_step<false>(slot, dec, kb + j, b) : decode_step<true>(slot, dec, kb + j, b);
-              const bool match = ((m >> (kb + j)) & 1u) != 0u;
-              v[j] = (long long)(int32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, match ? d * 4u : 0xFFFFFFFFu, 0, 0);
-            }
-          } else {
-            // value plane: the decoded field is (value - base).  MIN / MAX on a sorted dictionary: aggregate the
-            // dictId (monotone in the value), look the value up on the host at the end.
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              v[j] = (long long)(b <= 25 ? decode_step<false>(slot, dec, kb + j, b) : decode_step<true>(slot, dec, kb + j, b));
-            }
-          }
+      if (__builtin_amdgcn_ballot_w64(m != fullm) == 0ull) {
+        // every doc of the tile matches: walk the steps in order, no per-lane bookkeeping, no exec masking
+        const bool all[4] = {true, true, true, true};
+        for (int kb = 0; kb < steps; kb += 4) {
+          const int k[4] = {kb, kb + 1, kb + 2, kb + 3};
+          group_process4<kLdsTable, true>(gp, wave_lds, tile, lane, k, all, t_cnt, t_acc);
         }
+      } else {
+        uint32_t rem = m;
+        for (;;) {
+          if (__builtin_amdgcn_ballot_w64(rem != 0u) == 0ull) break;
+          bool active[4];
+          int k[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if ((m >> (kb + j)) & 1u) table_update<kScope>(t_acc, G, a, ga.kind, g[j], v[j]);
+          for (int j = 0; j < 4; ++j) {
+            active[j] = rem != 0u;
+            k[j] = active[j] ? __builtin_ctz(rem) : 0;
+            rem &= rem - 1u;
+          }
+          group_process4<kLdsTable, false>(gp, wave_lds, tile, lane, k, active, t_cnt, t_acc);
         }
       }
     }
-    if (!p.double_buffer && next < p.num_tiles) stage_columns<kDma>(p, next, wave_lds, lane, true, true);
+    bbuf ^= 1;
+    const bool next_has_agg = eager && (p.num_nodes == 0 || (hot && p.speculate != 0));
+    if (eager && next < p.num_tiles) stage_columns<kDma>(p, next, wave_lds, lane, true, next_has_agg);
+    cur_has_agg = next_has_agg;
   }
 
   if constexpr (kLdsTable) {
     __syncthreads();
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
-      const unsigned long long c = t_cnt[g];
+      const unsigned long long c = (unsigned long long)(uint32_t)t_cnt[g];
       if (c == 0ull) continue;
       __hip_atomic_fetch_add(&gp.table_count[g], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int a = 0; a < NA; ++a)
-        table_update<__HIP_MEMORY_SCOPE_AGENT>(gp.table_acc, G, a, gp.group_aggs[a].kind, (uint32_t)g, t_acc[(long long)a * G + g]);
+      for (int a = 0; a < NA; ++a) {
+        const int kind = gp.group_aggs[a].kind;
+        long long* slot = gp.table_acc + (long long)a * G + g;
+        const long long v = t_acc[(long long)a * G + g];
+        if (kind == kGroupSum) __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (kind == kGroupMin) __hip_atomic_fetch_min(slot, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_max(slot, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
@@ -684,13 +884,32 @@ __global__ void init_group_table_kernel(GroupParams gp) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t load_u16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 
+// One workgroup per 64 Ki-doc window (key = blockIdx.x): it looks its container up in the posting's sorted directory
+// slice, builds the 8 KiB window in LDS and either STORES it (first posting of a leaf: no separate zero-fill pass,
+// windows without a container become zeros) or ORs it into the bitmap (further postings of an IN / range leaf).
 __global__ __launch_bounds__(kBlockThreads) void roaring_expand_kernel(const uint8_t* __restrict__ inv, const DevContainer* __restrict__ dir,
-                                                                       int first, unsigned long long* bitmap, long long num_words) {
+                                                                       int first, int count, unsigned long long* bitmap, long long num_words, int or_mode) {
   __shared__ unsigned long long w[1024];
-  const DevContainer c = dir[first + blockIdx.x];
-  const uint8_t* payload = inv + c.offset;
+  __shared__ int found;
+  const uint32_t key = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int lo = first, hi = first + count - 1, f = -1;
+    while (lo <= hi) {                       // containers of one posting are sorted by key
+      const int mid = (lo + hi) >> 1;
+      const uint32_t k = dir[mid].key;
+      if (k < key) lo = mid + 1; else if (k > key) hi = mid - 1; else { f = mid; break; }
+    }
+    found = f;
+  }
   for (int j = threadIdx.x; j < 1024; j += blockDim.x) w[j] = 0ull;
   __syncthreads();
+  const long long base = (long long)key * 1024;
+  if (found < 0) {
+    if (!or_mode) for (int j = threadIdx.x; j < 1024; j += blockDim.x) if (base + j < num_words) bitmap[base + j] = 0ull;
+    return;
+  }
+  const DevContainer c = dir[found];
+  const uint8_t* payload = inv + c.offset;
   if (c.type == 0) {
     for (uint32_t i = threadIdx.x; i < c.cardinality; i += blockDim.x) {
       const uint32_t v = load_u16(payload + 2 * i);
@@ -716,13 +935,13 @@ __global__ __launch_bounds__(kBlockThreads) void roaring_expand_kernel(const uin
     }
   }
   __syncthreads();
-  const long long base = (long long)c.key * 1024;
   for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
+    if (base + j >= num_words) continue;
     const unsigned long long v = w[j];
-    if (v != 0ull && base + j < num_words) bitmap[base + j] |= v;
+    if (or_mode) { if (v != 0ull) bitmap[base + j] |= v; }
+    else bitmap[base + j] = v;
   }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // Value-plane materialisation (one-time, per summed column): plane[doc] = dictionary[dictId[doc]] - base, bit-packed
@@ -746,9 +965,9 @@ __global__ __launch_bounds__(kBlockThreads) void materialize_plane_kernel(const 
     stage_tile<false>(col.fwd + (long long)tile * 256 * b, wave_lds, 256 * b, lane);
     if (w < 32) for (int i = lane; i <= out_words; i += 64) W[i] = 0u;
     __builtin_amdgcn_wave_barrier();
-    for (int k = 0; k < kTileSteps; ++k) {
+    for (int k = 0; k < kMaxTileSteps; ++k) {
       const uint32_t d = b <= 25 ? decode_step<false>(wave_lds, dec, k, b) : decode_step<true>(wave_lds, dec, k, b);
-      const long long doc = (long long)tile * kTileDocs + k * 64 + lane;
+      const long long doc = (long long)tile * kMaxTileDocs + k * 64 + lane;
       const bool valid = doc < num_docs;
       const int32_t v = valid ? col.dict[d < (uint32_t)col.cardinality ? d : 0u] : base;
       if (w == 32) {

@@ -26,19 +26,21 @@ from pinot_amd.engine import Engine  # noqa: E402
 
 def timed(gseg, spec, reps=8):
     res = _abi.pg_result()
-    ms = []
+    ms, dev = [], []
     for i in range(reps + 2):
         st = gseg.execute_raw(spec, res)
         if st != _abi.PG_OK:
             raise RuntimeError(gseg.lib.pg_last_error().decode())
         if i >= 2:
             ms.append(res.dominant_kernel_ms)
+            dev.append(res.device_ms)
+            timed.cycles = [int(c) for c in res.profile_cycles] + [int(res.profile_waves)]
         gseg.lib.pg_result_free(C.byref(res))
-    return sum(ms) / len(ms), min(ms)
+    return sum(ms) / len(ms), min(ms), sum(dev) / len(dev)
 
 
 def report(out, name, n, nbytes, gseg, seg, spec, check=True):
-    avg, best = timed(gseg, spec)
+    avg, best, dev = timed(gseg, spec)
     got = gseg.execute(spec)
     ok = None
     if check:
@@ -51,9 +53,12 @@ def report(out, name, n, nbytes, gseg, seg, spec, check=True):
               all(all(x.sum_i64 == y.sum_i64 and x.count == y.count and x.min == y.min and x.max == y.max for x, y in zip(got.groups[g], want.groups[g])) for g in want.groups))
     else:
         cpu_s = None
-    rec = {"config": name, "rows": n, "kernel_ms": avg, "kernel_ms_min": best, "rows_per_s": n / avg * 1e3, "algorithmic_GB": nbytes / 1e9,
+    rec = {"config": name, "rows": n, "kernel_ms": avg, "kernel_ms_min": best, "device_ms_all_kernels": dev, "rows_per_s": n / avg * 1e3, "algorithmic_GB": nbytes / 1e9,
            "GBps": nbytes / avg / 1e6, "frac_of_8TBps": nbytes / avg / 1e6 / 8000.0, "docs_matched": got.stats[0],
            "bit_exact_vs_oracle": ok, "oracle_rows_per_s_1core": (n / cpu_s if cpu_s else None)}
+    cyc = getattr(timed, "cycles", None)
+    if cyc and cyc[4] and cyc[3]:
+        rec["wave_cycles"] = {"waves": cyc[4], "wait": cyc[0] // cyc[4], "filter": cyc[1] // cyc[4], "aggregate": cyc[2] // cyc[4], "loop": cyc[3] // cyc[4]}
     print(json.dumps(rec), flush=True)
     out.append(rec)
 
@@ -64,12 +69,15 @@ def main():
     ap.add_argument("--rows-c5", type=int, default=250_000_000)
     ap.add_argument("--out", default=None)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--profile-waves", action="store_true")
+    ap.add_argument("--only", default="")
     args = ap.parse_args()
-    engine = Engine(device_id=0, time_kernels=True)
+    engine = Engine(device_id=0, time_kernels=True, profile_waves=args.profile_waves)
     out = []
     check = not args.no_check
     B = lambda col: col.fwd.nbytes
 
+    only = args.only
     # ---- C1: 10 M rows, raw int32 forward index ----
     n1 = 10_000_000
     vals = S.synthetic_dict_ids(42, 0, n1, 1_000_000)
@@ -82,7 +90,7 @@ def main():
     del seg1, raw, vals
 
     # ---- C2 / C3 share one segment: v (C=100000), f (C=1000), k (C=1000), b (C=65536) ----
-    n = args.rows
+    n = args.rows if only in ('', 'c23') else 1_000_000
     t0 = time.time()
     v = S.Column.synthetic_uniform("v", n, (np.arange(100000, dtype=np.int64) * 7 + 3).astype(np.int32), seed=1)
     f = S.Column.synthetic_uniform("f", n, np.arange(1000, dtype=np.int32), seed=2)

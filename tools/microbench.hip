@@ -153,6 +153,34 @@ __global__ __launch_bounds__(256) void lds_atomics(int groups, int iters, unsign
   if (tab[threadIdx.x % (groups * 3)] == 0x1234567ull) out[0] = 1;
 }
 
+
+// 6. VALU issue rate of the integer ops the decode loop is made of (is a wave64 op 2 or 4 cycles on a SIMD?)
+template <int kOp>
+__global__ __launch_bounds__(256) void valu_rate(int iters, unsigned long long* out) {
+  uint32_t a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = threadIdx.x * 2654435761u + j * 40503u + blockIdx.x;
+  const uint32_t sel = 0x00010203u + (threadIdx.x & 3) * 0x01010101u, sh = threadIdx.x & 7, y = blockIdx.x | 1u;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (kOp == 0) a[j] = __builtin_amdgcn_perm(a[j], a[(j + 1) & 7], sel);
+        else if (kOp == 1) a[j] = __builtin_amdgcn_ubfe(a[j], sh, 17) + 0u * y;
+        else if (kOp == 2) a[j] = a[j] + y;
+        else if (kOp == 3) a[j] = (a[j] - y) < 1000u ? a[(j + 1) & 7] : y;
+        else if (kOp == 4) a[j] = (a[j] << 1) | ((a[(j + 1) & 7] - y) < 1000u ? 1u : 0u);
+        asm volatile("" : "+v"(a[j]));
+      }
+    }
+  }
+  uint32_t x = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x ^= a[j];
+  if (x == 0x12345u) out[0] = x;
+}
+
 template <typename F>
 double time_ms(F launch, int reps) {
   hipEvent_t a, b;
@@ -243,6 +271,27 @@ int main() {
       printf("{\"bench\": \"stream_plus_gather_sc0sc1\", \"gather_instrs_per_4KiB\": %d, \"GBps\": %.1f}\n", gi, bytes / ms / 1e6);
     }
     CHECK(hipFree(d_tab));
+  }
+
+
+  // VALU issue rate
+  {
+    const int iters = 2000;
+    const char* names[] = {"v_perm_b32", "v_bfe_u32", "v_add_u32", "sub+cmp+cndmask", "sub+cmp+cndmask+lshl_or"};
+    for (int wpe : {1, 2, 4, 8}) {
+      const int blocks = cus * wpe;   // one 256-thread block = 1 wave per SIMD
+      double ms[5];
+      ms[0] = time_ms([&] { valu_rate<0><<<blocks, 256>>>(iters, d_out); }, 2);
+      ms[1] = time_ms([&] { valu_rate<1><<<blocks, 256>>>(iters, d_out); }, 2);
+      ms[2] = time_ms([&] { valu_rate<2><<<blocks, 256>>>(iters, d_out); }, 2);
+      ms[3] = time_ms([&] { valu_rate<3><<<blocks, 256>>>(iters, d_out); }, 2);
+      ms[4] = time_ms([&] { valu_rate<4><<<blocks, 256>>>(iters, d_out); }, 2);
+      for (int o = 0; o < 5; ++o) {
+        const double stmts = (double)iters * 64 * wpe;          // source statements per SIMD
+        printf("{\"bench\": \"valu_rate\", \"op\": \"%s\", \"waves_per_simd\": %d, \"ns_per_statement_per_simd\": %.3f, \"cycles_at_2.4GHz\": %.2f}\n",
+               names[o], wpe, ms[o] * 1e6 / stmts, ms[o] * 1e6 / stmts * 2.4);
+      }
+    }
   }
 
   // LDS atomics
