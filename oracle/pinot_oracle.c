@@ -12,10 +12,11 @@
  *   sspi/ = pinot-segment-spi/src/main/java/org/apache/pinot/segment/spi/
  *
  * Parity pins: query-level results are pinned by the reference's own golden vectors over
- * test_data-sv.avro (tests/golden/, InnerSegmentAggregationSingleValueQueriesTest.java:44-112) and the raw
- * chunk layout by fixedByteRaw-style headers; the fixed-bit byte layout is pinned by the writer source only
- * (the reference's tests are unseeded round trips), with known-answer bytes derived from
- * PinotDataBitSet.writeInt in tests/test_oracle_layouts.py.  RoaringBitmap (third-party
+ * test_data-sv.avro (tests/golden/, InnerSegmentAggregationSingleValueQueriesTest.java:44-112); the fixed-bit
+ * forward-index and dictionary BYTE layouts are pinned by files the reference's own Java writers produced
+ * (pinot-core/src/test/resources/data/paddingOld.tar.gz -> tests/golden/pinot_v1_segment_paddingOld.json: the
+ * writer restatement reproduces them byte for byte) plus known-answer bytes derived from
+ * PinotDataBitSet.writeInt; the raw chunk layout by its header fields.  RoaringBitmap (third-party
  * org.roaringbitmap:RoaringBitmap:1.3.0, not under /root/reference) follows the public RoaringFormatSpec:
  * serialized-byte parity is "unpinned", set semantics are pinned through the golden queries.
  *

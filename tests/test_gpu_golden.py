@@ -60,3 +60,28 @@ def test_inter_segment_goldens(engine):
     finally:
         for s in segments:
             s.close()
+
+
+def test_segment_written_by_the_reference_java_writers(engine):
+    """The `age` column of pinot-core/src/test/resources/data/paddingOld.tar.gz (bytes produced by the reference's Java
+    writers, stored in tests/golden/pinot_v1_segment_paddingOld.json) opened as-is through the C ABI."""
+    import json
+    import os
+    from pinot_amd import _abi
+    from pinot_amd import segment as S
+    g = json.load(open(os.path.join(H.GOLDEN_DIR, "pinot_v1_segment_paddingOld.json")))
+    age = g["columns"]["age"]
+    col = S.Column("age", _abi.PG_FWD_FIXED_BIT_DICT, age["bitsPerElement"], age["cardinality"],
+                   np.frombuffer(bytes.fromhex(age["fwd_hex"]), dtype=np.uint8).copy(),
+                   np.frombuffer(bytes.fromhex(age["dict_hex"]), dtype=np.uint8).copy())
+    seg = S.SegmentData("paddingOld", g["total_docs"], [col])
+    ages = [1228, 837, 1209, 617, 824]     # dictIds [4, 2, 3, 0, 1] over the dictionary [617, 824, 837, 1209, 1228]
+    with engine.open(seg) as gseg:
+        assert gseg.read_int_values(0, np.arange(5, dtype=np.int32)).tolist() == ages
+        assert gseg.read_dict_ids(0, np.arange(5, dtype=np.int32)).tolist() == [4, 2, 3, 0, 1]
+        r = gseg.execute(Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0), (Q.MIN, 0), (Q.MAX, 0), (Q.AVG, 0)]))
+        assert r.intermediates() == [5, float(sum(ages)), 617.0, 1228.0, (float(sum(ages)), 5)]
+        s, e = oracle.lower_range(col.dictionary, 5, lower=800, lower_inclusive=False)      # age > 800
+        r = gseg.execute(Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, s, e))))
+        assert r.intermediates() == [4, float(1228 + 837 + 1209 + 824)]
+        H.assert_results_equal(r, oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, s, e)))))

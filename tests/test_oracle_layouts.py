@@ -183,3 +183,36 @@ def test_synthetic_generator_is_counter_based():
     assert a.min() >= 0 and a.max() < 1000 and len(np.unique(a)) > 990
     col = S.Column.synthetic_uniform("v", 10000, np.arange(1000, dtype=np.int32), 7)
     assert (numpy_unpack(col.fwd, col.bits, 10000) == a).all()
+
+
+def test_bytes_written_by_the_reference_java_writers():
+    """tests/golden/pinot_v1_segment_paddingOld.json holds the forward-index and dictionary files of a 5-doc segment that
+    the reference's own Java writers produced (pinot-core/src/test/resources/data/paddingOld.tar.gz).  Every column has
+    cardinality == totalDocs, so the decoded dictIds must be a permutation of 0..4 -- and re-encoding them with the
+    oracle's and the product's writers must reproduce the reference's bytes exactly."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pinot_v1_segment_paddingOld.json")))
+    n = g["total_docs"]
+    assert n == 5
+    host = S.load_host_library()
+    expect = {"age": [4, 2, 3, 0, 1], "percent": [0, 2, 4, 3, 1], "outgoingName1": [4, 3, 1, 0, 2], "name": [1, 0, 0, 0, 1]}
+    for name, col in g["columns"].items():
+        fwd = np.frombuffer(bytes.fromhex(col["fwd_hex"]), dtype=np.uint8)
+        bits, card = col["bitsPerElement"], col["cardinality"]
+        assert oracle.load().po_num_bits_per_value(card - 1) == bits == host.ph_num_bits_per_value(card - 1)
+        assert fwd.shape[0] == (n * bits + 7) // 8
+        ids = oracle.read_dict_ids(fwd, bits, n, np.arange(n, dtype=np.int32))
+        assert ids.tolist() == expect[name]
+        if card == n:
+            assert sorted(ids.tolist()) == list(range(n))
+        assert bytes(oracle.fixedbit_write(ids, bits)) == bytes(fwd)            # oracle writer == Java writer
+        out = np.zeros(fwd.shape[0], dtype=np.uint8)
+        host.ph_fixedbit_pack(S._i32p(ids), n, bits, S._u8p(out), 1)
+        assert bytes(out) == bytes(fwd)                                          # product writer == Java writer
+    age = g["columns"]["age"]
+    d = np.frombuffer(bytes.fromhex(age["dict_hex"]), dtype=np.uint8)
+    values = [oracle.load().po_dict_get_int(oracle._u8p(d), i) for i in range(5)]
+    assert values == [617, 824, 837, 1209, 1228] and values == sorted(values)
+    assert bytes(oracle.dict_write(np.array(values, dtype=np.int32))) == bytes(d)   # dictionary writer == Java writer
+    assert oracle.index_of(d, 5, 1209) == 3

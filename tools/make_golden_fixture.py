@@ -112,5 +112,33 @@ def main():
     print("unfiltered goldens reproduce")
 
 
+def export_prebuilt_segment():
+    """pinot-core/src/test/resources/data/paddingOld.tar.gz is a 5-doc v1-format segment that was written by the
+    reference's own Java writers (FixedBitSVForwardIndexWriter, SegmentDictionaryCreator): real golden BYTES for the
+    fixed-bit forward index and the dictionary layouts.  The few bytes are stored as hex next to the metadata keys."""
+    import io
+    import tarfile
+    src = "/root/reference/pinot-core/src/test/resources/data/paddingOld.tar.gz"
+    out = {"_source": src, "columns": {}}
+    with tarfile.open(src) as tar:
+        files = {m.name.split("/", 1)[1]: tar.extractfile(m).read() for m in tar.getmembers() if m.isfile()}
+    meta = {}
+    for line in files["metadata.properties"].decode().splitlines():
+        if "=" in line and not line.startswith("#"):
+            k, v = line.split("=", 1)
+            meta[k.strip()] = v.strip()
+    out["total_docs"] = int(meta["segment.total.docs"])
+    for col in ("age", "percent", "outgoingName1", "name"):
+        out["columns"][col] = {
+            "dataType": meta["column.%s.dataType" % col], "cardinality": int(meta["column.%s.cardinality" % col]),
+            "bitsPerElement": int(meta["column.%s.bitsPerElement" % col]), "isSorted": meta["column.%s.isSorted" % col],
+            "dict_hex": files[col + ".dict"].hex(), "fwd_hex": files[col + ".sv.unsorted.fwd"].hex()}
+    path = os.path.join(os.path.dirname(OUT), "pinot_v1_segment_paddingOld.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
     main()
+    export_prebuilt_segment()

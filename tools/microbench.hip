@@ -181,6 +181,25 @@ __global__ __launch_bounds__(256) void valu_rate(int iters, unsigned long long* 
   if (x == 0x12345u) out[0] = x;
 }
 
+
+// 7. cross-lane 32x32 bit-matrix transpose (bitmap leaf): ds_swizzle butterfly vs ds_bpermute (__shfl_xor)
+template <int kMode>
+__global__ __launch_bounds__(256) void transpose_rate(int iters, unsigned long long* out) {
+  const int lane = threadIdx.x & 63;
+  uint32_t x = threadIdx.x * 2654435761u + blockIdx.x;
+  uint32_t acc = 0;
+  for (int it = 0; it < iters; ++it) {
+#define STAGE(J, M) { uint32_t pr; if (kMode == 0) pr = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, ((J) << 10) | 0x1F); else pr = (uint32_t)__shfl_xor((int)x, J, 64); \
+      const bool lo_role = (lane & (J)) == 0; const uint32_t a = lo_role ? x : pr; const uint32_t b = lo_role ? pr : x; \
+      const uint32_t t = ((a >> (J)) ^ b) & (M); x ^= lo_role ? (t << (J)) : t; }
+    STAGE(16, 0x0000FFFFu) STAGE(8, 0x00FF00FFu) STAGE(4, 0x0F0F0F0Fu) STAGE(2, 0x33333333u) STAGE(1, 0x55555555u)
+#undef STAGE
+    acc += x;
+    x += it;
+  }
+  if (acc == 0x12345u) out[0] = acc;
+}
+
 template <typename F>
 double time_ms(F launch, int reps) {
   hipEvent_t a, b;
@@ -292,6 +311,16 @@ int main() {
                names[o], wpe, ms[o] * 1e6 / stmts, ms[o] * 1e6 / stmts * 2.4);
       }
     }
+  }
+
+
+  // bitmap-leaf transpose rate
+  for (int wpe : {1, 4}) {
+    const int iters = 4000, blocks = cus * wpe;
+    double m0 = time_ms([&] { transpose_rate<0><<<blocks, 256>>>(iters, d_out); }, 2);
+    double m1 = time_ms([&] { transpose_rate<1><<<blocks, 256>>>(iters, d_out); }, 2);
+    printf("{\"bench\": \"bit_transpose_32x32\", \"waves_per_simd\": %d, \"ns_per_transpose_per_wave_swizzle\": %.1f, \"ns_per_transpose_per_wave_bpermute\": %.1f}\n",
+           wpe, m0 * 1e6 / iters, m1 * 1e6 / iters);
   }
 
   // LDS atomics
