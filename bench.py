@@ -5,8 +5,8 @@ Workload C2b: SELECT SUM(v) FROM t WHERE f < 100
   v: INT, dictionary {7k+3 : k < 100000} -> 17-bit fixed-bit forward index (2.125 GB), dictIds uniform, seed 2r+1
   f: INT, dictionary {0..999}            -> 10-bit fixed-bit forward index (1.25 GB),  dictIds uniform, seed 2r+2
   predicate lowered to dictId range [0, 100) (10 % selectivity); r = rank (segment r lives on GPU r).
-A step = one pg_execute over the whole resident segment (fused scan -> filter -> dictionary gather -> SUM kernel +
-a one-block partial reduction + 72-byte readback).  Columns are generated on the host by the product's C++ writer
+A step = one pg_execute over the whole resident segment (fused scan -> filter -> SUM kernel reading f's dictIds and
+v's device-built value plane + a one-block partial reduction + 104-byte readback + stream sync).  Columns are generated on the host by the product's C++ writer
 in Pinot's on-disk layout and copied to HBM by pg_segment_open before the timed region.
 
 Launch:  python bench.py --gpus 1 --steps 20 --warmup 3

@@ -128,7 +128,10 @@ typedef struct pg_predicate {
   int32_t eval;                /* pg_leaf_eval */
   int32_t exclusive;           /* 1 = NOT_EQ / NOT_IN: matches when the inner predicate does not */
   int64_t lo;                  /* DICT_RANGE: startDictId ; RAW_RANGE: inclusive lower bound */
-  int64_t hi;                  /* DICT_RANGE: endDictId (exclusive) ; RAW_RANGE: inclusive upper bound */
+  int64_t hi;                  /* DICT_RANGE: endDictId (exclusive) ; RAW_RANGE: inclusive upper bound.
+                                * RAW_RANGE on a raw FLOAT / DOUBLE column: lo / hi carry the IEEE-754 bit pattern of the inclusive
+                                * bounds as doubles (Float / DoubleRawValueBasedRangePredicateEvaluator after Math.nextUp / nextDown
+                                * made exclusive bounds inclusive; FLOAT bounds widened exactly). */
   const uint32_t* set_words;   /* DICT_SET: bitset over dictIds, bit d = (set_words[d >> 5] >> (d & 31)) & 1 */
   int32_t num_set_words;
   int32_t reserved;
@@ -242,6 +245,10 @@ pg_status pg_read_int_values(pg_segment* segment, int32_t column, const int32_t*
                              int32_t* out_values);
 pg_status pg_read_double_values(pg_segment* segment, int32_t column, const int32_t* doc_ids, int32_t length,
                                 double* out_values);
+/* BlockValSet.getLongValuesSV (DataFetcher.fetchLongValues, core/common/DataFetcher.java:121-123): INT / LONG columns return
+ * the value, FLOAT / DOUBLE the Java (long) cast.  pg_read_int_values is defined for INT columns only. */
+pg_status pg_read_long_values(pg_segment* segment, int32_t column, const int32_t* doc_ids, int32_t length,
+                              int64_t* out_values);
 
 #ifdef __cplusplus
 }

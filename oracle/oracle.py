@@ -49,6 +49,15 @@ def load():
         "po_dict_index_of_int": (C.c_int32, [u8p, C.c_int32, C.c_int32]),
         "po_dict_write_int": (None, [u8p, i32p, C.c_int32]),
         "po_lower_range_int": (None, [u8p, C.c_int32, C.c_int, C.c_int32, C.c_int, C.c_int, C.c_int32, C.c_int, i32p, i32p]),
+        "po_dict_write_long": (None, [u8p, P(C.c_int64), C.c_int32]),
+        "po_dict_write_float": (None, [u8p, P(C.c_float), C.c_int32]),
+        "po_dict_write_double": (None, [u8p, P(C.c_double), C.c_int32]),
+        "po_dict_insertion_index_of": (C.c_int32, [u8p, C.c_int32, C.c_int, C.c_int64, C.c_double]),
+        "po_lower_range_typed": (None, [u8p, C.c_int32, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_int, i32p, i32p]),
+        "po_raw_file_size_typed_v2": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+        "po_raw_write_typed_v2": (None, [u8p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+        "po_raw_header": (C.c_int, [u8p, C.c_uint64, i32p]),
+        "po_read_double_values": (C.c_int, [P(_abi.pg_segment_desc), C.c_int32, i32p, C.c_int32, P(C.c_double), P(C.c_int64)]),
         "po_roaring_or_into": (C.c_int64, [u8p, C.c_uint64, P(C.c_uint64), C.c_int64]),
         "po_roaring_serialize": (C.c_int64, [i32p, C.c_int64, C.c_int, u8p]),
         "po_inverted_build": (C.c_int64, [i32p, C.c_int32, C.c_int32, C.c_int, u8p]),
@@ -110,6 +119,59 @@ def read_int_values(segment_data, column, doc_ids):
     out = np.zeros(doc_ids.shape[0], dtype=np.int32)
     _check(load().po_read_int_values(C.byref(segment_data.desc), column, _i32p(doc_ids), int(doc_ids.shape[0]), _i32p(out)))
     return out
+
+
+def read_double_values(segment_data, column, doc_ids):
+    """(getDoubleValuesSV, getLongValuesSV) of any numeric column."""
+    doc_ids = np.ascontiguousarray(doc_ids, dtype=np.int32)
+    out = np.zeros(doc_ids.shape[0], dtype=np.float64)
+    out_long = np.zeros(doc_ids.shape[0], dtype=np.int64)
+    _check(load().po_read_double_values(C.byref(segment_data.desc), column, _i32p(doc_ids), int(doc_ids.shape[0]),
+                                        out.ctypes.data_as(C.POINTER(C.c_double)), out_long.ctypes.data_as(C.POINTER(C.c_int64))))
+    return out, out_long
+
+
+def raw_header(buf):
+    """(version, numChunks, numDocsPerChunk, sizeOfEntry, totalDocs, compressionType, dataHeaderStart, rawDataStart)"""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    out = np.zeros(8, dtype=np.int32)
+    _check(load().po_raw_header(_u8p(buf), buf.nbytes, _i32p(out)))
+    return tuple(int(x) for x in out)
+
+
+def dict_write_typed(sorted_values):
+    lib = load()
+    v = np.ascontiguousarray(sorted_values)
+    out = np.zeros(v.nbytes, dtype=np.uint8)
+    if v.dtype == np.int32:
+        lib.po_dict_write_int(_u8p(out), _i32p(v), int(v.shape[0]))
+    elif v.dtype == np.int64:
+        lib.po_dict_write_long(_u8p(out), v.ctypes.data_as(C.POINTER(C.c_int64)), int(v.shape[0]))
+    elif v.dtype == np.float32:
+        lib.po_dict_write_float(_u8p(out), v.ctypes.data_as(C.POINTER(C.c_float)), int(v.shape[0]))
+    else:
+        lib.po_dict_write_double(_u8p(out), v.ctypes.data_as(C.POINTER(C.c_double)), int(v.shape[0]))
+    return out
+
+
+def raw_write_typed(values, docs_per_chunk=1000):
+    lib = load()
+    v = np.ascontiguousarray(values)
+    out = np.zeros(int(lib.po_raw_file_size_typed_v2(int(v.shape[0]), docs_per_chunk, v.dtype.itemsize)), dtype=np.uint8)
+    lib.po_raw_write_typed_v2(_u8p(out), v.ctypes.data, int(v.shape[0]), docs_per_chunk, v.dtype.itemsize)
+    return out
+
+
+def lower_range_typed(column, lower=None, lower_inclusive=True, upper=None, upper_inclusive=True):
+    """[startDictId, endDictId) of a range predicate on a dictionary column of any numeric stored type (bounds are numbers
+    as Long.parseLong / Float.parseFloat / Double.parseDouble would return them)."""
+    s, e = C.c_int32(), C.c_int32()
+    integral = column.stored_type in (_abi.PG_TYPE_INT, _abi.PG_TYPE_LONG)
+    lo_i, lo_d = (int(lower), 0.0) if (lower is not None and integral) else (0, float(lower or 0.0))
+    hi_i, hi_d = (int(upper), 0.0) if (upper is not None and integral) else (0, float(upper or 0.0))
+    load().po_lower_range_typed(_u8p(column.dictionary), column.cardinality, column.stored_type, int(lower is not None), lo_i, lo_d,
+                                int(lower_inclusive), int(upper is not None), hi_i, hi_d, int(upper_inclusive), C.byref(s), C.byref(e))
+    return int(s.value), int(e.value)
 
 
 def read_dict_ids(fwd, bits, num_docs, doc_ids):

@@ -50,9 +50,13 @@ static inline int32_t be_get_int(const uint8_t* p) {
 static inline int64_t be_get_long(const uint8_t* p) {
   return (int64_t)(((uint64_t)(uint32_t)be_get_int(p) << 32) | (uint64_t)(uint32_t)be_get_int(p + 4));
 }
+static inline float be_get_float(const uint8_t* p) { int32_t i = be_get_int(p); float f; memcpy(&f, &i, 4); return f; }
+static inline double be_get_double(const uint8_t* p) { int64_t i = be_get_long(p); double d; memcpy(&d, &i, 8); return d; }
 static inline void be_put_int(uint8_t* p, int32_t v) {
   p[0] = (uint8_t)((uint32_t)v >> 24); p[1] = (uint8_t)((uint32_t)v >> 16); p[2] = (uint8_t)((uint32_t)v >> 8); p[3] = (uint8_t)v;
 }
+
+static inline void be_put_long(uint8_t* p, int64_t v) { be_put_int(p, (int32_t)((uint64_t)v >> 32)); be_put_int(p + 4, (int32_t)(uint64_t)v); }
 
 /* ------------------------------------------------------------------------------------------------
  * PinotDataBitSet (segl/io/util/PinotDataBitSet.java)
@@ -222,6 +226,18 @@ int po_raw_open(const uint8_t* buf, uint64_t size, po_raw_reader* r) {
   return 0;
 }
 static inline int32_t raw_get_int(const po_raw_reader* r, int32_t doc_id) { return be_get_int(r->raw_data + (int64_t)doc_id * 4); }
+/* FixedByteChunkSVForwardIndexReader.getLong/getFloat/getDouble :63-93: same addressing with the entry size of the type */
+static inline int64_t raw_get_long(const po_raw_reader* r, int32_t doc_id) { return be_get_long(r->raw_data + (int64_t)doc_id * 8); }
+static inline float raw_get_float(const po_raw_reader* r, int32_t doc_id) { return be_get_float(r->raw_data + (int64_t)doc_id * 4); }
+static inline double raw_get_double(const po_raw_reader* r, int32_t doc_id) { return be_get_double(r->raw_data + (int64_t)doc_id * 8); }
+/* header fields for tests (the reference's own fixedByteRaw.v2 fixture pins them) */
+int po_raw_header(const uint8_t* buf, uint64_t size, int32_t* out8) {
+  po_raw_reader r;
+  if (po_raw_open(buf, size, &r)) return 1;
+  out8[0] = r.version; out8[1] = r.num_chunks; out8[2] = r.num_docs_per_chunk; out8[3] = r.length_of_longest_entry;
+  out8[4] = r.total_docs; out8[5] = r.compression_type; out8[6] = r.data_header_start; out8[7] = r.raw_data_start;
+  return 0;
+}
 
 /* Writer restatement: version 2 header, 4-byte chunk offsets, PASS_THROUGH (value 0). Returns total size. */
 int64_t po_raw_file_size_v2(int32_t num_docs, int32_t num_docs_per_chunk) {
@@ -240,6 +256,28 @@ void po_raw_write_int_v2(uint8_t* buf, const int32_t* values, int32_t num_docs, 
   be_put_int(buf + 24, 28);  /* dataHeaderStart */
   for (int32_t c = 0; c < num_chunks; c++) be_put_int(buf + 28 + 4 * c, header_size + c * num_docs_per_chunk * 4);
   for (int32_t i = 0; i < num_docs; i++) be_put_int(buf + header_size + (int64_t)i * 4, values[i]);
+}
+
+/* Same writer for any fixed-width type: `values` is a host-order array of `entry_size`-byte elements (4 or 8). */
+int64_t po_raw_file_size_typed_v2(int32_t num_docs, int32_t num_docs_per_chunk, int32_t entry_size) {
+  int64_t num_chunks = ((int64_t)num_docs + num_docs_per_chunk - 1) / num_docs_per_chunk;
+  return 7 * 4 + num_chunks * 4 + (int64_t)num_docs * entry_size;
+}
+void po_raw_write_typed_v2(uint8_t* buf, const void* values, int32_t num_docs, int32_t num_docs_per_chunk, int32_t entry_size) {
+  int32_t num_chunks = (int32_t)(((int64_t)num_docs + num_docs_per_chunk - 1) / num_docs_per_chunk);
+  int32_t header_size = 7 * 4 + num_chunks * 4;
+  be_put_int(buf + 0, 2);
+  be_put_int(buf + 4, num_chunks);
+  be_put_int(buf + 8, num_docs_per_chunk);
+  be_put_int(buf + 12, entry_size);
+  be_put_int(buf + 16, num_docs);
+  be_put_int(buf + 20, 0);
+  be_put_int(buf + 24, 28);
+  for (int32_t c = 0; c < num_chunks; c++) be_put_int(buf + 28 + 4 * c, header_size + c * num_docs_per_chunk * entry_size);
+  for (int32_t i = 0; i < num_docs; i++) {
+    if (entry_size == 4) { int32_t v; memcpy(&v, (const uint8_t*)values + (int64_t)i * 4, 4); be_put_int(buf + header_size + (int64_t)i * 4, v); }
+    else { int64_t v; memcpy(&v, (const uint8_t*)values + (int64_t)i * 8, 8); be_put_long(buf + header_size + (int64_t)i * 8, v); }
+  }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -269,6 +307,64 @@ int32_t po_dict_index_of_int(const uint8_t* dict, int32_t length, int32_t value)
 void po_dict_write_int(uint8_t* buf, const int32_t* sorted_values, int32_t length) {
   /* SegmentDictionaryCreator.java:109-125: C x big-endian int32, ascending, no header */
   for (int32_t i = 0; i < length; i++) be_put_int(buf + (int64_t)i * 4, sorted_values[i]);
+}
+
+/* LongDictionary / FloatDictionary / DoubleDictionary (segl/segment/index/readers/{Long,Float,Double}Dictionary.java;
+ * BaseImmutableDictionary.binarySearch(long|float|double) :142-195; FixedByteValueReaderWriter.getLong/getFloat/getDouble
+ * :42-54): C x big-endian fixed-width values, ascending.  `value` arrives as the Java-parsed number widened to double for
+ * FLOAT (Float.parseFloat) / DOUBLE and as int64 for LONG. */
+static inline int64_t dict_get_long(const uint8_t* dict, int32_t dict_id) { return be_get_long(dict + (int64_t)dict_id * 8); }
+static inline float dict_get_float(const uint8_t* dict, int32_t dict_id) { return be_get_float(dict + (int64_t)dict_id * 4); }
+static inline double dict_get_double(const uint8_t* dict, int32_t dict_id) { return be_get_double(dict + (int64_t)dict_id * 8); }
+#define PO_BSEARCH(NAME, T, GET)                                                                 \
+  int32_t NAME(const uint8_t* dict, int32_t length, T value) {                                    \
+    int32_t low = 0, high = length - 1;                                                           \
+    while (low <= high) {                                                                         \
+      int32_t mid = (int32_t)(((uint32_t)low + (uint32_t)high) >> 1);                              \
+      T mid_value = GET(dict, mid);                                                               \
+      if (mid_value < value) low = mid + 1;                                                       \
+      else if (mid_value > value) high = mid - 1;                                                 \
+      else return mid;                                                                            \
+    }                                                                                             \
+    return -(low + 1);                                                                            \
+  }
+PO_BSEARCH(po_dict_insertion_index_of_long, int64_t, dict_get_long)
+PO_BSEARCH(po_dict_insertion_index_of_float, float, dict_get_float)
+PO_BSEARCH(po_dict_insertion_index_of_double, double, dict_get_double)
+void po_dict_write_long(uint8_t* buf, const int64_t* sorted_values, int32_t length) {
+  for (int32_t i = 0; i < length; i++) be_put_long(buf + (int64_t)i * 8, sorted_values[i]);
+}
+void po_dict_write_float(uint8_t* buf, const float* sorted_values, int32_t length) {
+  for (int32_t i = 0; i < length; i++) { int32_t b; memcpy(&b, &sorted_values[i], 4); be_put_int(buf + (int64_t)i * 4, b); }
+}
+void po_dict_write_double(uint8_t* buf, const double* sorted_values, int32_t length) {
+  for (int32_t i = 0; i < length; i++) { int64_t b; memcpy(&b, &sorted_values[i], 8); be_put_long(buf + (int64_t)i * 8, b); }
+}
+/* insertionIndexOf for any stored type; the bound is given as int64 (INT / LONG) or double (FLOAT / DOUBLE) */
+int32_t po_dict_insertion_index_of(const uint8_t* dict, int32_t length, int stored_type, int64_t ivalue, double dvalue) {
+  switch (stored_type) {
+    case PG_TYPE_INT: return po_dict_insertion_index_of_int(dict, length, (int32_t)ivalue);
+    case PG_TYPE_LONG: return po_dict_insertion_index_of_long(dict, length, ivalue);
+    case PG_TYPE_FLOAT: return po_dict_insertion_index_of_float(dict, length, (float)dvalue);
+    default: return po_dict_insertion_index_of_double(dict, length, dvalue);
+  }
+}
+/* the same bound rules as po_lower_range_int for any stored type */
+void po_lower_range_typed(const uint8_t* dict, int32_t length, int stored_type, int has_lower, int64_t ilower, double dlower, int lower_inclusive,
+                          int has_upper, int64_t iupper, double dupper, int upper_inclusive, int32_t* out_start, int32_t* out_end) {
+  int32_t start, end;
+  if (!has_lower) start = 0;
+  else {
+    int32_t ins = po_dict_insertion_index_of(dict, length, stored_type, ilower, dlower);
+    start = ins < 0 ? -(ins + 1) : (lower_inclusive ? ins : ins + 1);
+  }
+  if (!has_upper) end = length;
+  else {
+    int32_t ins = po_dict_insertion_index_of(dict, length, stored_type, iupper, dupper);
+    end = ins < 0 ? -(ins + 1) : (upper_inclusive ? ins + 1 : ins);
+  }
+  *out_start = start;
+  *out_end = end;
 }
 
 /* SortedDictionaryBasedRangePredicateEvaluator ctor (core/operator/filter/predicate/
@@ -494,7 +590,7 @@ typedef struct po_column {
 /* PredicateEvaluator.applySV on one dictId / raw value (RangePredicateEvaluatorFactory.java:220-222,
  * 364-366; EqualsPredicateEvaluatorFactory.java:122-124; InPredicateEvaluatorFactory.java:186-188;
  * NOT_EQ / NOT_IN evaluators are the negations). */
-static inline int pred_apply(const pg_predicate* p, int32_t v) {
+static inline int pred_apply(const pg_predicate* p, int64_t v) {
   int m;
   switch (p->kind) {
     case PG_PRED_MATCH_ALL: m = 1; break;
@@ -530,6 +626,25 @@ static int32_t scan_match_values(po_scan_iter* it, int32_t limit, int32_t* doc_i
   const pg_column_desc* d = it->col->desc;
   if (d->fwd_encoding == PG_FWD_FIXED_BIT_DICT) {
     po_fixedbit_read_dict_ids((const uint8_t*)d->fwd_data, d->bits_per_value, it->num_docs, doc_ids, limit, it->buffer);
+  } else if (d->stored_type == PG_TYPE_FLOAT || d->stored_type == PG_TYPE_DOUBLE) {
+    /* Float / DoubleRawValueBasedRangePredicateEvaluator.applySV, RangePredicateEvaluatorFactory.java:448-560:
+     * value >= inclusiveLowerBound && value <= inclusiveUpperBound on primitives (NaN never matches, -0.0 == 0.0) */
+    double lo, hi;
+    memcpy(&lo, &it->pred->lo, 8); memcpy(&hi, &it->pred->hi, 8);
+    int32_t matches = 0;
+    for (int32_t i = 0; i < limit; i++) {
+      double v = d->stored_type == PG_TYPE_FLOAT ? (double)raw_get_float(&it->col->raw, doc_ids[i]) : raw_get_double(&it->col->raw, doc_ids[i]);
+      int m = (it->pred->kind == PG_PRED_RAW_RANGE) ? (v >= lo && v <= hi) : (it->pred->kind == PG_PRED_MATCH_ALL);
+      if (it->pred->exclusive ? !m : m) doc_ids[matches++] = doc_ids[i];
+    }
+    return matches;
+  } else if (d->stored_type == PG_TYPE_LONG) {
+    /* LongRawValueBasedRangePredicateEvaluator.applySV(long), RangePredicateEvaluatorFactory.java:411-446 */
+    int32_t matches = 0;
+    for (int32_t i = 0; i < limit; i++) {
+      if (pred_apply(it->pred, raw_get_long(&it->col->raw, doc_ids[i]))) doc_ids[matches++] = doc_ids[i];
+    }
+    return matches;
   } else {
     for (int32_t i = 0; i < limit; i++) it->buffer[i] = raw_get_int(&it->col->raw, doc_ids[i]);
   }
@@ -692,11 +807,55 @@ static void fetch_int_values(const po_column* col, int32_t num_docs, const int32
   }
 }
 
+/* typed value arrays of one block (BlockValSet.getIntValuesSV / getLongValuesSV / getFloatValuesSV / getDoubleValuesSV) */
+typedef struct po_values { int32_t* i; int64_t* l; float* f; double* d; } po_values;
+
+/* DataFetcher.ColumnValueReader.read{Int,Long,Float,Double}Values (core/common/DataFetcher.java:335-470): dictionary
+ * columns readDictIds then Dictionary.read*Values (typed get per dictId); raw columns ForwardIndexReader.readValuesSV
+ * (sspi/index/reader/ForwardIndexReader.java:156-300, typed get per docId).  Fills the array of the stored type. */
+static void fetch_stored_values(const po_column* col, int32_t num_docs, const int32_t* doc_ids, int32_t len,
+                                int32_t* dict_id_scratch, po_values* out) {
+  const pg_column_desc* d = col->desc;
+  if (d->stored_type == PG_TYPE_INT) { fetch_int_values(col, num_docs, doc_ids, len, dict_id_scratch, out->i); return; }
+  if (d->fwd_encoding == PG_FWD_FIXED_BIT_DICT) {
+    fetch_dict_ids(col, num_docs, doc_ids, len, dict_id_scratch);
+    const uint8_t* dict = (const uint8_t*)d->dict_data;
+    if (d->stored_type == PG_TYPE_LONG) for (int32_t i = 0; i < len; i++) out->l[i] = dict_get_long(dict, dict_id_scratch[i]);
+    else if (d->stored_type == PG_TYPE_FLOAT) for (int32_t i = 0; i < len; i++) out->f[i] = dict_get_float(dict, dict_id_scratch[i]);
+    else for (int32_t i = 0; i < len; i++) out->d[i] = dict_get_double(dict, dict_id_scratch[i]);
+  } else {
+    if (d->stored_type == PG_TYPE_LONG) for (int32_t i = 0; i < len; i++) out->l[i] = raw_get_long(&col->raw, doc_ids[i]);
+    else if (d->stored_type == PG_TYPE_FLOAT) for (int32_t i = 0; i < len; i++) out->f[i] = raw_get_float(&col->raw, doc_ids[i]);
+    else for (int32_t i = 0; i < len; i++) out->d[i] = raw_get_double(&col->raw, doc_ids[i]);
+  }
+}
+/* getDoubleValuesSV on any numeric stored type: Dictionary.readDoubleValues / readValuesSV(double[]) widen per value */
+static void widen_to_double(int stored_type, const po_values* v, int32_t len, double* out) {
+  switch (stored_type) {
+    case PG_TYPE_INT: for (int32_t i = 0; i < len; i++) out[i] = (double)v->i[i]; break;
+    case PG_TYPE_LONG: for (int32_t i = 0; i < len; i++) out[i] = (double)v->l[i]; break;
+    case PG_TYPE_FLOAT: for (int32_t i = 0; i < len; i++) out[i] = (double)v->f[i]; break;
+    default: for (int32_t i = 0; i < len; i++) out[i] = v->d[i]; break;
+  }
+}
+/* java.lang.Math.max / min on floating point: NaN wins, -0.0 < +0.0 */
+static inline double java_max(double a, double b) { if (a != a) return a; if (b != b) return b; if (a == 0.0 && b == 0.0) return signbit(a) ? b : a; return a > b ? a : b; }
+static inline double java_min(double a, double b) { if (a != a) return a; if (b != b) return b; if (a == 0.0 && b == 0.0) return signbit(a) ? a : b; return a < b ? a : b; }
+static inline float java_maxf(float a, float b) { return (float)java_max((double)a, (double)b); }
+static inline float java_minf(float a, float b) { return (float)java_min((double)a, (double)b); }
+
 typedef struct po_holder {          /* DoubleAggregationResultHolder / AvgPair + exact side channel */
   double value;                     /* COUNT, SUM, MIN, MAX holder */
   double avg_sum; int64_t avg_count;
   int64_t exact_sum; int64_t n;
+  int overflow;                     /* the int64 side channel wrapped: sum_exact = 0 */
 } po_holder;
+/* exact integer side channel: wrapping add that remembers whether it ever wrapped */
+static inline void exact_add(int64_t* acc, int64_t v, int* overflow) {
+  int64_t r;
+  if (__builtin_add_overflow(*acc, v, &r)) *overflow = 1;
+  *acc = r;
+}
 
 static void holder_init(po_holder* h, int func) {
   memset(h, 0, sizeof(*h));
@@ -711,7 +870,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   po_column* cols = (po_column*)calloc((size_t)(seg->num_columns > 0 ? seg->num_columns : 1), sizeof(po_column));
   for (int32_t c = 0; c < seg->num_columns; c++) {
     cols[c].desc = &seg->columns[c];
-    if (seg->columns[c].stored_type != PG_TYPE_INT) { free(cols); PO_FAIL(2, "oracle: only INT stored type is restated"); }
+    if (seg->columns[c].stored_type < PG_TYPE_INT || seg->columns[c].stored_type > PG_TYPE_DOUBLE) { free(cols); PO_FAIL(2, "oracle: stored type %d is not restated", seg->columns[c].stored_type); }
     if (seg->columns[c].fwd_encoding == PG_FWD_RAW_FIXED_BYTE) {
       if (po_raw_open((const uint8_t*)seg->columns[c].fwd_data, seg->columns[c].fwd_size, &cols[c].raw)) { free(cols); return 1; }
     }
@@ -752,7 +911,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
 
   po_holder* holders = NULL;       /* aggregation only */
   double* gholders = NULL;         /* group-by: [na][G] DoubleGroupByResultHolder */
-  double* gavg_sum = NULL; int64_t* gavg_cnt = NULL; int64_t* gexact = NULL; int64_t* gcount = NULL;
+  double* gavg_sum = NULL; int64_t* gavg_cnt = NULL; int64_t* gexact = NULL; int64_t* gcount = NULL; int* gover = NULL;
   uint8_t* flags = NULL;
   if (ng == 0) {
     holders = (po_holder*)calloc((size_t)(na > 0 ? na : 1), sizeof(po_holder));
@@ -763,6 +922,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
     gavg_sum = (double*)calloc(G * (size_t)(na > 0 ? na : 1), sizeof(double));
     gavg_cnt = (int64_t*)calloc(G * (size_t)(na > 0 ? na : 1), sizeof(int64_t));
     gexact = (int64_t*)calloc(G * (size_t)(na > 0 ? na : 1), sizeof(int64_t));
+    gover = (int*)calloc(G * (size_t)(na > 0 ? na : 1), sizeof(int));
     gcount = (int64_t*)calloc(G, sizeof(int64_t));
     flags = (uint8_t*)calloc(G, 1);
     for (int a = 0; a < na; a++) {
@@ -774,7 +934,11 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   /* thread-local scratch of the reference: DocIdSetOperator.java:42-43, DataFetcher.java:50-51 */
   int32_t* doc_ids = (int32_t*)malloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
   int32_t* dict_scratch = (int32_t*)malloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
-  int32_t* int_values = (int32_t*)malloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  po_values vals;
+  vals.i = (int32_t*)malloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  vals.l = (int64_t*)malloc(sizeof(int64_t) * PO_MAX_DOC_PER_CALL);
+  vals.f = (float*)malloc(sizeof(float) * PO_MAX_DOC_PER_CALL);
+  vals.d = (double*)malloc(sizeof(double) * PO_MAX_DOC_PER_CALL);
   double* dbl_values = (double*)malloc(sizeof(double) * PO_MAX_DOC_PER_CALL);
   int32_t* group_ids = (int32_t*)malloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
   int64_t num_docs_scanned = 0;
@@ -815,35 +979,48 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
         continue;
       }
       if (colidx < 0 || colidx >= seg->num_columns) { rc = 1; snprintf(po_error, sizeof(po_error), "bad aggregation column"); goto cleanup; }
-      fetch_int_values(&cols[colidx], num_docs, doc_ids, pos, dict_scratch, int_values);
+      const int st = cols[colidx].desc->stored_type;
+      fetch_stored_values(&cols[colidx], num_docs, doc_ids, pos, dict_scratch, &vals);
       if (ng == 0) {
         po_holder* h = &holders[a];
         switch (func) {
           case PG_AGG_SUM: {
-            /* SumAggregationFunction.aggregate INT case :75-86, updateAggregationResultHolder :147-157 */
+            /* SumAggregationFunction.aggregate :69-129 (one case per stored type, double innerSum), updateAggregationResultHolder :147-157 */
             double inner_sum = 0;
-            for (int32_t i = 0; i < pos; i++) { inner_sum += int_values[i]; h->exact_sum += int_values[i]; }
+            if (st == PG_TYPE_INT) for (int32_t i = 0; i < pos; i++) { inner_sum += vals.i[i]; exact_add(&h->exact_sum, vals.i[i], &h->overflow); }
+            else if (st == PG_TYPE_LONG) for (int32_t i = 0; i < pos; i++) { inner_sum += (double)vals.l[i]; exact_add(&h->exact_sum, vals.l[i], &h->overflow); }
+            else if (st == PG_TYPE_FLOAT) for (int32_t i = 0; i < pos; i++) inner_sum += (double)vals.f[i];
+            else for (int32_t i = 0; i < pos; i++) inner_sum += vals.d[i];
             h->value = inner_sum + h->value;
             break;
           }
           case PG_AGG_MAX: {
-            /* MaxAggregationFunction.aggregate INT case :74-86, :150-160 */
-            int32_t inner = int_values[0];
-            for (int32_t i = 0; i < pos; i++) inner = int_values[i] > inner ? int_values[i] : inner;
-            h->value = fmax((double)inner, h->value);
+            /* MaxAggregationFunction.aggregate :69-149 (typed inner max, Math.max), :150-160 */
+            double inner;
+            if (st == PG_TYPE_INT) { int32_t m = vals.i[0]; for (int32_t i = 0; i < pos; i++) m = vals.i[i] > m ? vals.i[i] : m; inner = (double)m; }
+            else if (st == PG_TYPE_LONG) { int64_t m = vals.l[0]; for (int32_t i = 0; i < pos; i++) m = vals.l[i] > m ? vals.l[i] : m; inner = (double)m; }
+            else if (st == PG_TYPE_FLOAT) { float m = vals.f[0]; for (int32_t i = 0; i < pos; i++) m = java_maxf(m, vals.f[i]); inner = (double)m; }
+            else { double m = vals.d[0]; for (int32_t i = 0; i < pos; i++) m = java_max(m, vals.d[i]); inner = m; }
+            h->value = java_max(inner, h->value);
             break;
           }
           case PG_AGG_MIN: {
-            int32_t inner = int_values[0];
-            for (int32_t i = 0; i < pos; i++) inner = int_values[i] < inner ? int_values[i] : inner;
-            h->value = fmin((double)inner, h->value);
+            double inner;
+            if (st == PG_TYPE_INT) { int32_t m = vals.i[0]; for (int32_t i = 0; i < pos; i++) m = vals.i[i] < m ? vals.i[i] : m; inner = (double)m; }
+            else if (st == PG_TYPE_LONG) { int64_t m = vals.l[0]; for (int32_t i = 0; i < pos; i++) m = vals.l[i] < m ? vals.l[i] : m; inner = (double)m; }
+            else if (st == PG_TYPE_FLOAT) { float m = vals.f[0]; for (int32_t i = 0; i < pos; i++) m = java_minf(m, vals.f[i]); inner = (double)m; }
+            else { double m = vals.d[0]; for (int32_t i = 0; i < pos; i++) m = java_min(m, vals.d[i]); inner = m; }
+            h->value = java_min(inner, h->value);
             break;
           }
           case PG_AGG_AVG: {
             /* AvgAggregationFunction.aggregate :63-79: getDoubleValuesSV, avgPair.apply(v, 1) per doc,
              * then updateAggregationResult -> holder pair.apply(sum, count) :95-102 */
+            widen_to_double(st, &vals, pos, dbl_values);
             double s = 0; int64_t c = 0;
-            for (int32_t i = 0; i < pos; i++) { s += (double)int_values[i]; c += 1; h->exact_sum += int_values[i]; }
+            for (int32_t i = 0; i < pos; i++) { s += dbl_values[i]; c += 1; }
+            if (st == PG_TYPE_INT) for (int32_t i = 0; i < pos; i++) exact_add(&h->exact_sum, vals.i[i], &h->overflow);
+            if (st == PG_TYPE_LONG) for (int32_t i = 0; i < pos; i++) exact_add(&h->exact_sum, vals.l[i], &h->overflow);
             h->avg_sum += s; h->avg_count += c;
             break;
           }
@@ -851,12 +1028,17 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
         }
         h->n += pos;
       } else {
-        /* group-by functions all read getDoubleValuesSV (dictionary.readDoubleValues: (double) int) */
-        for (int32_t i = 0; i < pos; i++) dbl_values[i] = (double)int_values[i];
+        /* group-by functions all read getDoubleValuesSV (Dictionary.readDoubleValues / readValuesSV(double[])) */
+        widen_to_double(st, &vals, pos, dbl_values);
         double* hold = gholders + (size_t)a * G;
+        int64_t* ex = gexact + (size_t)a * G;
+        if (func == PG_AGG_SUM || func == PG_AGG_AVG) {
+          if (st == PG_TYPE_INT) for (int32_t i = 0; i < pos; i++) exact_add(&ex[group_ids[i]], vals.i[i], &gover[(size_t)a * G + group_ids[i]]);
+          if (st == PG_TYPE_LONG) for (int32_t i = 0; i < pos; i++) exact_add(&ex[group_ids[i]], vals.l[i], &gover[(size_t)a * G + group_ids[i]]);
+        }
         switch (func) {
           case PG_AGG_SUM: /* SumAggregationFunction.aggregateGroupBySV :173-178 */
-            for (int32_t i = 0; i < pos; i++) { hold[group_ids[i]] = hold[group_ids[i]] + dbl_values[i]; gexact[(size_t)a * G + group_ids[i]] += int_values[i]; }
+            for (int32_t i = 0; i < pos; i++) hold[group_ids[i]] = hold[group_ids[i]] + dbl_values[i];
             break;
           case PG_AGG_MAX: /* MaxAggregationFunction.aggregateGroupBySV :180-187 */
             for (int32_t i = 0; i < pos; i++) if (dbl_values[i] > hold[group_ids[i]]) hold[group_ids[i]] = dbl_values[i];
@@ -865,10 +1047,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
             for (int32_t i = 0; i < pos; i++) if (dbl_values[i] < hold[group_ids[i]]) hold[group_ids[i]] = dbl_values[i];
             break;
           case PG_AGG_AVG:
-            for (int32_t i = 0; i < pos; i++) {
-              gavg_sum[(size_t)a * G + group_ids[i]] += dbl_values[i]; gavg_cnt[(size_t)a * G + group_ids[i]] += 1;
-              gexact[(size_t)a * G + group_ids[i]] += int_values[i];
-            }
+            for (int32_t i = 0; i < pos; i++) { gavg_sum[(size_t)a * G + group_ids[i]] += dbl_values[i]; gavg_cnt[(size_t)a * G + group_ids[i]] += 1; }
             break;
           default: rc = 2; snprintf(po_error, sizeof(po_error), "unsupported aggregation %d", func); goto cleanup;
         }
@@ -885,8 +1064,9 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       int func = q->aggregations[a].function;
       v->min = INFINITY; v->max = -INFINITY;
       v->count = func == PG_AGG_COUNT ? (int64_t)holders[a].value : (func == PG_AGG_AVG ? holders[a].avg_count : holders[a].n);
-      if (func == PG_AGG_SUM) { v->sum = holders[a].value; v->sum_i64 = holders[a].exact_sum; v->sum_exact = 1; }
-      if (func == PG_AGG_AVG) { v->sum = holders[a].avg_sum; v->sum_i64 = holders[a].exact_sum; v->sum_exact = 1; }
+      const int integral = func != PG_AGG_COUNT && seg->columns[q->aggregations[a].column].stored_type <= PG_TYPE_LONG && !holders[a].overflow;
+      if (func == PG_AGG_SUM) { v->sum = holders[a].value; v->sum_i64 = holders[a].exact_sum; v->sum_exact = integral; }
+      if (func == PG_AGG_AVG) { v->sum = holders[a].avg_sum; v->sum_i64 = holders[a].exact_sum; v->sum_exact = integral; }
       if (func == PG_AGG_MIN) v->min = holders[a].value;
       if (func == PG_AGG_MAX) v->max = holders[a].value;
     }
@@ -907,8 +1087,9 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
         int func = q->aggregations[a].function;
         v->min = INFINITY; v->max = -INFINITY;
         v->count = func == PG_AGG_COUNT ? (int64_t)gholders[(size_t)a * G + g] : (func == PG_AGG_AVG ? gavg_cnt[(size_t)a * G + g] : gcount[g]);
-        if (func == PG_AGG_SUM) { v->sum = gholders[(size_t)a * G + g]; v->sum_i64 = gexact[(size_t)a * G + g]; v->sum_exact = 1; }
-        if (func == PG_AGG_AVG) { v->sum = gavg_sum[(size_t)a * G + g]; v->sum_i64 = gexact[(size_t)a * G + g]; v->sum_exact = 1; }
+        const int integral = func != PG_AGG_COUNT && seg->columns[q->aggregations[a].column].stored_type <= PG_TYPE_LONG && !gover[(size_t)a * G + g];
+        if (func == PG_AGG_SUM) { v->sum = gholders[(size_t)a * G + g]; v->sum_i64 = gexact[(size_t)a * G + g]; v->sum_exact = integral; }
+        if (func == PG_AGG_AVG) { v->sum = gavg_sum[(size_t)a * G + g]; v->sum_i64 = gexact[(size_t)a * G + g]; v->sum_exact = integral; }
         if (func == PG_AGG_MIN) v->min = gholders[(size_t)a * G + g];
         if (func == PG_AGG_MAX) v->max = gholders[(size_t)a * G + g];
       }
@@ -928,8 +1109,8 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   }
 
 cleanup:
-  free(doc_ids); free(dict_scratch); free(int_values); free(dbl_values); free(group_ids);
-  free(holders); free(gholders); free(gavg_sum); free(gavg_cnt); free(gexact); free(gcount); free(flags);
+  free(doc_ids); free(dict_scratch); free(vals.i); free(vals.l); free(vals.f); free(vals.d); free(dbl_values); free(group_ids);
+  free(holders); free(gholders); free(gavg_sum); free(gavg_cnt); free(gexact); free(gover); free(gcount); free(flags);
 done:
   free(filter_words); free(it); free(cols);
   return rc;
@@ -962,10 +1143,31 @@ int po_filter_bitmap(const pg_segment_desc* seg, const pg_query* q, uint64_t* ou
   return 0;
 }
 
+/* BlockValSet.getDoubleValuesSV on any numeric stored type (and getLongValuesSV for INT / LONG). */
+int po_read_double_values(const pg_segment_desc* seg, int32_t column, const int32_t* doc_ids, int32_t length, double* out, int64_t* out_long) {
+  po_column col; memset(&col, 0, sizeof(col));
+  col.desc = &seg->columns[column];
+  if (col.desc->fwd_encoding == PG_FWD_RAW_FIXED_BYTE && po_raw_open((const uint8_t*)col.desc->fwd_data, col.desc->fwd_size, &col.raw)) return 1;
+  size_t n = (size_t)(length > 0 ? length : 1);
+  int32_t* scratch = (int32_t*)malloc(sizeof(int32_t) * n);
+  po_values v;
+  v.i = (int32_t*)malloc(4 * n); v.l = (int64_t*)malloc(8 * n); v.f = (float*)malloc(4 * n); v.d = (double*)malloc(8 * n);
+  fetch_stored_values(&col, seg->num_docs, doc_ids, length, scratch, &v);
+  widen_to_double(col.desc->stored_type, &v, length, out);
+  if (out_long) {
+    if (col.desc->stored_type == PG_TYPE_INT) for (int32_t i = 0; i < length; i++) out_long[i] = v.i[i];
+    else if (col.desc->stored_type == PG_TYPE_LONG) for (int32_t i = 0; i < length; i++) out_long[i] = v.l[i];
+    else for (int32_t i = 0; i < length; i++) out_long[i] = (int64_t)out[i];
+  }
+  free(scratch); free(v.i); free(v.l); free(v.f); free(v.d);
+  return 0;
+}
+
 /* BlockValSet-level readers for SPI parity tests. */
 int po_read_int_values(const pg_segment_desc* seg, int32_t column, const int32_t* doc_ids, int32_t length, int32_t* out) {
   po_column col; memset(&col, 0, sizeof(col));
   col.desc = &seg->columns[column];
+  if (col.desc->stored_type != PG_TYPE_INT) PO_FAIL(2, "po_read_int_values: column is not INT");
   if (col.desc->fwd_encoding == PG_FWD_RAW_FIXED_BYTE && po_raw_open((const uint8_t*)col.desc->fwd_data, col.desc->fwd_size, &col.raw)) return 1;
   int32_t* scratch = (int32_t*)malloc(sizeof(int32_t) * (size_t)(length > 0 ? length : 1));
   fetch_int_values(&col, seg->num_docs, doc_ids, length, scratch, out);

@@ -100,6 +100,7 @@ ABI_SYMBOLS = [
     ("pg_read_dict_ids", C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), C.c_int32, _P(C.c_int32)]),
     ("pg_read_int_values", C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), C.c_int32, _P(C.c_int32)]),
     ("pg_read_double_values", C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), C.c_int32, _P(C.c_double)]),
+    ("pg_read_long_values", C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), C.c_int32, _P(C.c_int64)]),
 ]
 
 CSRC_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
@@ -121,7 +122,7 @@ def load_gpu_library(path=None):
     global _gpu_lib
     if _gpu_lib is not None and path is None:
         return _gpu_lib
-    path = path or GPU_LIB_PATH
+    path = path or os.environ.get("PINOT_GPU_LIB") or GPU_LIB_PATH      # PINOT_GPU_LIB: A/B builds of the same ABI (tools/)
     if not os.path.exists(path):
         raise ImportError("HIP extension %s has not been built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(make -C pinot_amd/csrc).  The engine has no CPU fallback." % path)
@@ -130,7 +131,7 @@ def load_gpu_library(path=None):
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
-    if path == GPU_LIB_PATH:
+    if path == (os.environ.get("PINOT_GPU_LIB") or GPU_LIB_PATH):
         _gpu_lib = lib
     return lib
 

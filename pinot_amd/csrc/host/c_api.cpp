@@ -62,6 +62,7 @@ std::string blockJson(const ResultsBlock& b) {
       for (size_t k = 0; k < keys.size(); ++k) {
         o << (k ? ", " : "");
         if (std::holds_alternative<int64_t>(keys[k])) o << std::get<int64_t>(keys[k]);
+        else if (std::holds_alternative<double>(keys[k])) o << num(std::get<double>(keys[k]));
         else o << "\"" << jsonEscape(std::get<std::string>(keys[k])) << "\"";
       }
       o << "], \"intermediate\": [";
@@ -112,6 +113,36 @@ int32_t ph_segment_add_int_column(void* seg, const char* name, int32_t has_dicti
   });
 }
 
+// data_type: 0 INT, 1 LONG, 2 FLOAT, 3 DOUBLE (pg_data_type).  Dictionary columns pass the big-endian fixed-width dictionary
+// buffer; raw columns the PASS_THROUGH chunk file.
+int32_t ph_segment_add_numeric_column(void* seg, const char* name, int32_t data_type, int32_t has_dictionary, int32_t bits, int32_t cardinality,
+                                      const void* fwd, uint64_t fwd_size, const void* dict, uint64_t dict_size, const void* inv, uint64_t inv_size) {
+  return guarded([&] {
+    if (data_type < 0 || data_type > 3) throw QueryException("unknown data type");
+    static const DataType kTypes[] = {DataType::INT, DataType::LONG, DataType::FLOAT, DataType::DOUBLE};
+    DataSource ds;
+    ds.name = name;
+    ds.dataType = kTypes[data_type];
+    ds.hasDictionary = has_dictionary != 0;
+    ds.bitsPerElement = bits;
+    ds.cardinality = cardinality;
+    ds.forwardIndex = (const uint8_t*)fwd; ds.forwardIndexSize = fwd_size;
+    ds.dictionaryBuffer = (const uint8_t*)dict; ds.dictionaryBufferSize = dict_size;
+    if (ds.hasDictionary) {
+      const uint8_t* d = (const uint8_t*)dict;
+      switch (ds.dataType) {
+        case DataType::INT: ds.dictionary = std::make_shared<IntDictionary>(d, cardinality); break;
+        case DataType::LONG: ds.dictionary = std::make_shared<LongDictionary>(d, cardinality); break;
+        case DataType::FLOAT: ds.dictionary = std::make_shared<FloatDictionary>(d, cardinality); break;
+        default: ds.dictionary = std::make_shared<DoubleDictionary>(d, cardinality); break;
+      }
+    }
+    ds.hasInvertedIndex = inv != nullptr && inv_size > 0;
+    ds.invertedIndex = (const uint8_t*)inv; ds.invertedIndexSize = inv_size;
+    ((ImmutableSegment*)seg)->addDataSource(std::move(ds));
+  });
+}
+
 // values: `cardinality` NUL-terminated strings back to back, sorted ascending.
 int32_t ph_segment_add_string_column(void* seg, const char* name, int32_t bits, int32_t cardinality, const void* fwd, uint64_t fwd_size,
                                      const char* values, const void* inv, uint64_t inv_size) {
@@ -131,6 +162,44 @@ int32_t ph_segment_add_string_column(void* seg, const char* name, int32_t bits, 
     ds.invertedIndex = (const uint8_t*)inv; ds.invertedIndexSize = inv_size;
     ((ImmutableSegment*)seg)->addDataSource(std::move(ds));
   });
+}
+
+// ImmutableSegmentLoader.load(indexDir): opens a v1 / v3 segment directory and makes it HBM resident.  NULL + status on error.
+void* ph_segment_load_directory(const char* index_dir, int32_t device, int32_t* status) {
+  ImmutableSegment* out = nullptr;
+  *status = guarded([&] {
+    std::vector<std::string> skipped;
+    std::unique_ptr<ImmutableSegment> seg = loadSegmentDirectory(index_dir ? index_dir : "", &skipped);
+    seg->notOffloaded = std::move(skipped);
+    if (device >= 0) seg->load(device);      // device < 0: host-side open only (metadata, dictionaries, buffers)
+    out = seg.release();
+  });
+  return out;
+}
+
+// JSON description of a segment of the host mirror (columns as DataSourceMetadata sees them).
+char* ph_segment_describe(void* segment, int32_t* status) {
+  std::string out;
+  *status = guarded([&] {
+    const ImmutableSegment* seg = (const ImmutableSegment*)segment;
+    std::ostringstream o;
+    o << "{\"name\": \"" << jsonEscape(seg->getSegmentName()) << "\", \"totalDocs\": " << seg->getTotalDocs() << ", \"columns\": [";
+    bool first = true;
+    for (const DataSource& ds : seg->getDataSources()) {
+      o << (first ? "" : ", ") << "{\"name\": \"" << jsonEscape(ds.name) << "\", \"dataType\": \"" << dataTypeName(ds.dataType) << "\", \"hasDictionary\": "
+        << (ds.hasDictionary ? "true" : "false") << ", \"cardinality\": " << ds.cardinality << ", \"bitsPerElement\": " << ds.bitsPerElement
+        << ", \"hasInvertedIndex\": " << (ds.hasInvertedIndex ? "true" : "false");
+      if (ds.dictionary && ds.cardinality > 0)
+        o << ", \"minValue\": \"" << jsonEscape(ds.dictionary->getStringValue(0)) << "\", \"maxValue\": \"" << jsonEscape(ds.dictionary->getStringValue(ds.cardinality - 1)) << "\"";
+      o << "}";
+      first = false;
+    }
+    o << "], \"notOffloaded\": [";
+    for (size_t i = 0; i < seg->notOffloaded.size(); ++i) o << (i ? ", " : "") << "\"" << jsonEscape(seg->notOffloaded[i]) << "\"";
+    o << "]}";
+    out = o.str();
+  });
+  return *status == 0 ? strdup(out.c_str()) : nullptr;
 }
 
 int32_t ph_segment_load(void* seg, int32_t device) { return guarded([&] { ((ImmutableSegment*)seg)->load(device); }); }

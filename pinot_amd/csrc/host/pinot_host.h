@@ -23,7 +23,9 @@ struct QueryException : std::runtime_error { using std::runtime_error::runtime_e
 struct UnsupportedOperationException : std::runtime_error { using std::runtime_error::runtime_error; };
 
 // ---- pinot-spi FieldSpec.DataType (stored types on this path) -------------------------------------------------
-enum class DataType { INT, STRING };
+enum class DataType { INT, LONG, FLOAT, DOUBLE, STRING };
+inline bool isNumeric(DataType t) { return t != DataType::STRING; }
+const char* dataTypeName(DataType t);
 
 // ---- sspi/index/reader/Dictionary.java:37-301; segl/segment/index/readers/BaseImmutableDictionary.java ----------
 class Dictionary {
@@ -36,6 +38,7 @@ class Dictionary {
   virtual int insertionIndexOf(const std::string& stringValue) const = 0;
   int indexOf(const std::string& stringValue) const { int i = insertionIndexOf(stringValue); return i >= 0 ? i : -1; }
   virtual int32_t getIntValue(int dictId) const = 0;
+  virtual int64_t getLongValue(int dictId) const { return (int64_t)getIntValue(dictId); }
   virtual double getDoubleValue(int dictId) const = 0;
   virtual std::string getStringValue(int dictId) const = 0;
 };
@@ -51,6 +54,52 @@ class IntDictionary : public Dictionary {
   int32_t getIntValue(int dictId) const override;
   double getDoubleValue(int dictId) const override { return (double)getIntValue(dictId); }
   std::string getStringValue(int dictId) const override { return std::to_string(getIntValue(dictId)); }
+ private:
+  const uint8_t* _buffer;
+  int _length;
+};
+
+// segl/segment/index/readers/{Long,Float,Double}Dictionary.java over a big-endian fixed-width buffer;
+// insertionIndexOf(String) = binarySearch(Long.parseLong / Float.parseFloat / Double.parseDouble), BaseImmutableDictionary.java:142-195.
+class LongDictionary : public Dictionary {
+ public:
+  LongDictionary(const uint8_t* buffer, int length) : _buffer(buffer), _length(length) {}
+  DataType getValueType() const override { return DataType::LONG; }
+  int length() const override { return _length; }
+  int insertionIndexOf(const std::string& stringValue) const override;
+  int32_t getIntValue(int dictId) const override { return (int32_t)getLongValue(dictId); }
+  int64_t getLongValue(int dictId) const override;
+  double getDoubleValue(int dictId) const override { return (double)getLongValue(dictId); }
+  std::string getStringValue(int dictId) const override { return std::to_string(getLongValue(dictId)); }
+ private:
+  const uint8_t* _buffer;
+  int _length;
+};
+class FloatDictionary : public Dictionary {
+ public:
+  FloatDictionary(const uint8_t* buffer, int length) : _buffer(buffer), _length(length) {}
+  DataType getValueType() const override { return DataType::FLOAT; }
+  int length() const override { return _length; }
+  int insertionIndexOf(const std::string& stringValue) const override;
+  float getFloatValue(int dictId) const;
+  int32_t getIntValue(int dictId) const override { return (int32_t)getFloatValue(dictId); }
+  int64_t getLongValue(int dictId) const override { return (int64_t)getFloatValue(dictId); }
+  double getDoubleValue(int dictId) const override { return (double)getFloatValue(dictId); }
+  std::string getStringValue(int dictId) const override;
+ private:
+  const uint8_t* _buffer;
+  int _length;
+};
+class DoubleDictionary : public Dictionary {
+ public:
+  DoubleDictionary(const uint8_t* buffer, int length) : _buffer(buffer), _length(length) {}
+  DataType getValueType() const override { return DataType::DOUBLE; }
+  int length() const override { return _length; }
+  int insertionIndexOf(const std::string& stringValue) const override;
+  int32_t getIntValue(int dictId) const override { return (int32_t)getDoubleValue(dictId); }
+  int64_t getLongValue(int dictId) const override { return (int64_t)getDoubleValue(dictId); }
+  double getDoubleValue(int dictId) const override;
+  std::string getStringValue(int dictId) const override;
  private:
   const uint8_t* _buffer;
   int _length;
@@ -101,13 +150,21 @@ class ImmutableSegment {
   void destroy();                // IndexSegment.destroy() -> pg_segment_close
   pg_segment* handle() const { return _handle; }
   int deviceId() const { return _deviceId; }
+  void keepAlive(std::shared_ptr<std::vector<uint8_t>> buffer) { _owned.push_back(std::move(buffer)); }   // loader-owned index buffers
+  std::vector<std::string> notOffloaded;      // "<column>: <reason>" for columns of a loaded directory that stay on the CPU plan
  private:
   std::string _name;
   int _totalDocs;
   std::vector<DataSource> _columns;
+  std::vector<std::shared_ptr<std::vector<uint8_t>>> _owned;
   pg_segment* _handle = nullptr;
   int _deviceId = -1;
 };
+
+// ImmutableSegmentLoader.load(indexDir, ReadMode) for the single-value numeric / string columns of a v1 or v3 segment directory
+// (segment_loader.cpp).  Columns that are not offloaded are reported by name and reason.
+std::unique_ptr<ImmutableSegment> loadSegmentDirectory(const std::string& indexDir, std::vector<std::string>* notOffloaded);
+extern "C" int32_t ph_num_bits_per_value(int32_t max_value);
 
 // ---- common/request/context: ExpressionContext (identifiers only on this path), predicates, FilterContext -------
 struct Predicate {                                   // common/request/context/predicate/Predicate.java
@@ -191,7 +248,7 @@ struct ExecutionStatistics {
 };
 
 // ---- operator/blocks/results --------------------------------------------------------------------------------------
-using GroupKeyValue = std::variant<int64_t, std::string>;
+using GroupKeyValue = std::variant<int64_t, std::string, double>;   // INT / LONG keys, STRING keys, FLOAT / DOUBLE keys
 struct GroupKey { int groupId; std::vector<GroupKeyValue> keys; };        // groupby/GroupKeyGenerator.GroupKey
 
 struct AggregationResultsBlock {                    // operator/blocks/results/AggregationResultsBlock.java:54-59

@@ -82,7 +82,7 @@ void ImmutableSegment::load(int deviceId) {
     pg_column_desc& d = descs[i];
     memset(&d, 0, sizeof(d));
     d.name = ds.name.c_str();
-    d.stored_type = PG_TYPE_INT;
+    d.stored_type = ds.dataType == DataType::LONG ? PG_TYPE_LONG : (ds.dataType == DataType::FLOAT ? PG_TYPE_FLOAT : (ds.dataType == DataType::DOUBLE ? PG_TYPE_DOUBLE : PG_TYPE_INT));
     d.fwd_encoding = ds.hasDictionary ? PG_FWD_FIXED_BIT_DICT : PG_FWD_RAW_FIXED_BYTE;
     d.bits_per_value = ds.bitsPerElement;
     d.cardinality = ds.hasDictionary ? ds.cardinality : 0;
@@ -237,7 +237,7 @@ std::unique_ptr<LoweredQuery> lowerQuery(const ImmutableSegment& seg, const Quer
     pa.column = a.column == "*" ? -1 : seg.getColumnIndex(a.column);
     if (pa.column >= 0) {
       const DataSource& ds = seg.getDataSource(a.column);
-      if (ds.dataType != DataType::INT && a.function != AggregationFunctionType::COUNT)
+      if (!isNumeric(ds.dataType) && a.function != AggregationFunctionType::COUNT)
         throw QueryException("Cannot compute " + AggregationFunction(a.function, a.column).getResultColumnName() + " for non-numeric type: STRING");
       if (a.function == AggregationFunctionType::COUNT) pa.column = -1;   // COUNT(col) == COUNT(*) with null handling off
     }
@@ -306,7 +306,8 @@ class GpuAggregationOperator : public Operator {
           const int d = rem % ds->cardinality;
           rem /= ds->cardinality;
           if (ds->dataType == DataType::STRING) key.keys.emplace_back(ds->dictionary->getStringValue(d));
-          else key.keys.emplace_back((int64_t)ds->dictionary->getIntValue(d));
+          else if (ds->dataType == DataType::FLOAT || ds->dataType == DataType::DOUBLE) key.keys.emplace_back(ds->dictionary->getDoubleValue(d));
+          else key.keys.emplace_back(ds->dictionary->getLongValue(d));
         }
         g.groupKeys.push_back(std::move(key));
         std::vector<IntermediateResult> row;

@@ -54,6 +54,65 @@ int IntDictionary::insertionIndexOf(const std::string& stringValue) const {
   return binarySearch(v);
 }
 
+const char* dataTypeName(DataType t) {
+  switch (t) { case DataType::INT: return "INT"; case DataType::LONG: return "LONG"; case DataType::FLOAT: return "FLOAT";
+               case DataType::DOUBLE: return "DOUBLE"; default: return "STRING"; }
+}
+
+static inline int64_t be_long(const uint8_t* p) { return (int64_t)(((uint64_t)(uint32_t)be_int(p) << 32) | (uint64_t)(uint32_t)be_int(p + 4)); }
+int64_t LongDictionary::getLongValue(int dictId) const { return be_long(_buffer + (size_t)dictId * 8); }
+float FloatDictionary::getFloatValue(int dictId) const { const int32_t b = be_int(_buffer + (size_t)dictId * 4); float f; memcpy(&f, &b, 4); return f; }
+double DoubleDictionary::getDoubleValue(int dictId) const { const int64_t b = be_long(_buffer + (size_t)dictId * 8); double d; memcpy(&d, &b, 8); return d; }
+std::string FloatDictionary::getStringValue(int dictId) const { char buf[64]; snprintf(buf, sizeof(buf), "%.9g", (double)getFloatValue(dictId)); return buf; }
+std::string DoubleDictionary::getStringValue(int dictId) const { char buf[64]; snprintf(buf, sizeof(buf), "%.17g", getDoubleValue(dictId)); return buf; }
+
+// BaseImmutableDictionary.binarySearch(long | float | double), BaseImmutableDictionary.java:142-195
+template <typename T, typename Get>
+static int binarySearchTyped(int length, T value, Get get) {
+  int low = 0, high = length - 1;
+  while (low <= high) {
+    const int mid = (int)(((unsigned)low + (unsigned)high) >> 1);
+    const T midValue = get(mid);
+    if (midValue < value) low = mid + 1;
+    else if (midValue > value) high = mid - 1;
+    else return mid;
+  }
+  return -(low + 1);
+}
+bool parseInt64(const std::string& s, int64_t* out) {
+  if (s.empty()) return false;
+  char* end = nullptr;
+  errno = 0;
+  const long long v = strtoll(s.c_str(), &end, 10);
+  if (errno != 0 || *end != 0) return false;
+  *out = (int64_t)v;
+  return true;
+}
+bool parseFloating(const std::string& s, double* out) {
+  if (s.empty()) return false;
+  char* end = nullptr;
+  errno = 0;
+  const double v = strtod(s.c_str(), &end);
+  if (*end != 0) return false;
+  *out = v;
+  return true;
+}
+int LongDictionary::insertionIndexOf(const std::string& stringValue) const {
+  int64_t v;
+  if (!parseInt64(stringValue, &v)) throw QueryException("Cannot convert value: '" + stringValue + "' to LONG");
+  return binarySearchTyped<int64_t>(_length, v, [this](int d) { return getLongValue(d); });
+}
+int FloatDictionary::insertionIndexOf(const std::string& stringValue) const {
+  double v;
+  if (!parseFloating(stringValue, &v)) throw QueryException("Cannot convert value: '" + stringValue + "' to FLOAT");
+  return binarySearchTyped<float>(_length, (float)v, [this](int d) { return getFloatValue(d); });     // Float.parseFloat rounds to float
+}
+int DoubleDictionary::insertionIndexOf(const std::string& stringValue) const {
+  double v;
+  if (!parseFloating(stringValue, &v)) throw QueryException("Cannot convert value: '" + stringValue + "' to DOUBLE");
+  return binarySearchTyped<double>(_length, v, [this](int d) { return getDoubleValue(d); });
+}
+
 int StringDictionary::insertionIndexOf(const std::string& stringValue) const {
   auto it = std::lower_bound(_values.begin(), _values.end(), stringValue);
   if (it != _values.end() && *it == stringValue) return (int)(it - _values.begin());
@@ -103,8 +162,15 @@ class Lexer {
       while (e < _s.size() && (isalnum((unsigned char)_s[e]) || _s[e] == '_' || _s[e] == '.')) e++;
       _tok.kind = Token::IDENT; _tok.text = _s.substr(_pos, e - _pos); _pos = e;
     } else if (isdigit((unsigned char)c) || (c == '-' && _pos + 1 < _s.size() && isdigit((unsigned char)_s[_pos + 1]))) {
+      // integer or decimal literal with an optional exponent (what Calcite hands the reference as a numeric literal)
       size_t e = _pos + 1;
       while (e < _s.size() && isdigit((unsigned char)_s[e])) e++;
+      if (e + 1 < _s.size() && _s[e] == '.' && isdigit((unsigned char)_s[e + 1])) { e++; while (e < _s.size() && isdigit((unsigned char)_s[e])) e++; }
+      if (e < _s.size() && (_s[e] == 'e' || _s[e] == 'E')) {
+        size_t x = e + 1;
+        if (x < _s.size() && (_s[x] == '+' || _s[x] == '-')) x++;
+        if (x < _s.size() && isdigit((unsigned char)_s[x])) { while (x < _s.size() && isdigit((unsigned char)_s[x])) x++; e = x; }
+      }
       _tok.kind = Token::NUMBER; _tok.text = _s.substr(_pos, e - _pos); _pos = e;
     } else if (c == '\'') {
       std::string out;
@@ -270,14 +336,23 @@ PredicateEvaluator getPredicateEvaluator(const Predicate& predicate, const DataS
   PredicateEvaluator ev;
   ev.predicateType = predicate.type;
   if (!ds.hasDictionary) {
-    // raw INT column: IntRawValueBasedRangePredicateEvaluator (RangePredicateEvaluatorFactory.java:68-81,331-366);
+    // raw INT / LONG column: Int / LongRawValueBasedRangePredicateEvaluator (RangePredicateEvaluatorFactory.java:68-81,331-446);
     // EQ is the degenerate range, the other raw evaluators are not offloaded.
-    auto toInt = [](const std::string& s) { int32_t v; if (!parseInt32(s, &v)) throw QueryException("Cannot convert value: '" + s + "' to INT"); return (int64_t)v; };
+    if (ds.dataType != DataType::INT && ds.dataType != DataType::LONG)
+      throw UnsupportedOperationException(std::string("predicates on a raw ") + dataTypeName(ds.dataType) + " column are not offloaded");
+    const bool isLong = ds.dataType == DataType::LONG;
+    auto toInt = [isLong](const std::string& s) {
+      if (isLong) { int64_t v; if (!parseInt64(s, &v)) throw QueryException("Cannot convert value: '" + s + "' to LONG"); return v; }
+      int32_t v; if (!parseInt32(s, &v)) throw QueryException("Cannot convert value: '" + s + "' to INT"); return (int64_t)v; };
+    const int64_t typeMin = isLong ? INT64_MIN : (int64_t)INT_MIN, typeMax = isLong ? INT64_MAX : (int64_t)INT_MAX;
     ev.rawRange = true;
     if (predicate.type == Predicate::Type::RANGE) {
       const bool lowerUnbounded = predicate.lowerBound == "*", upperUnbounded = predicate.upperBound == "*";
-      ev.rawLower = lowerUnbounded ? INT_MIN : toInt(predicate.lowerBound);
-      ev.rawUpper = upperUnbounded ? INT_MAX : toInt(predicate.upperBound);
+      ev.rawLower = lowerUnbounded ? typeMin : toInt(predicate.lowerBound);
+      ev.rawUpper = upperUnbounded ? typeMax : toInt(predicate.upperBound);
+      // an exclusive bound at the type's extreme is "Invalid range" in the reference (Preconditions.checkArgument)
+      if ((!lowerUnbounded && !predicate.lowerInclusive && ev.rawLower == typeMax) || (!upperUnbounded && !predicate.upperInclusive && ev.rawUpper == typeMin))
+        throw QueryException("Invalid range");
       if (!lowerUnbounded && !predicate.lowerInclusive) ev.rawLower += 1;
       if (!upperUnbounded && !predicate.upperInclusive) ev.rawUpper -= 1;
     } else if (predicate.type == Predicate::Type::EQ || predicate.type == Predicate::Type::NOT_EQ) {

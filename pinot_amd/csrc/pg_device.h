@@ -28,7 +28,19 @@ enum LeafKind : int32_t {
   kLeafDictRange = 2,   // (uint32)(field - lo) < span   (field = dictId, or value-plane offset)
   kLeafDictSet = 3,     // bit dictId of set_words
   kLeafRawRange = 4,    // (uint32)(value - lo) <= span  (signed inclusive range)
-  kLeafBitmap = 5       // precomputed docId bitmap (inverted-index postings expanded on device)
+  kLeafBitmap = 5,      // precomputed docId bitmap (inverted-index postings expanded on device)
+  kLeafRawRange64 = 6,  // raw LONG column: (uint64)(value - lo64) <= span64
+  kLeafRawRangeF64 = 7, // raw DOUBLE column: the same compare on the order-preserving integer image of the value
+  kLeafRawRangeF32 = 8  // raw FLOAT column (widened to double first)
+};
+
+// How an aggregated column's VALUES are represented on the device.
+enum ValueKind : int32_t {
+  kValI32 = 0,   // 32-bit integer domain: INT, or a LONG dictionary whose value range fits 31 bits ("offset dictionary":
+                 // entries are value - min, the host adds count * min back) -- dictionary gather, value plane, raw INT
+  kValI64 = 1,   // 8-byte integers: LONG dictionary with a wide range (64-bit gather), raw LONG
+  kValF64 = 2,   // doubles: FLOAT / DOUBLE dictionaries (FLOAT widened at open: 64-bit gather), raw DOUBLE
+  kValF32 = 3    // raw FLOAT (big-endian float32 per doc, widened on load)
 };
 
 struct DevColumn {
@@ -42,6 +54,8 @@ struct DevColumn {
   int32_t in_agg;          // referenced by an aggregation or a group-by key
   int32_t slot_off;        // byte offset of this column's staging slot inside one staging buffer
   int32_t is_plane;        // fwd points at the column's VALUE PLANE: bit-packed (value - plane base), same stream format
+  int32_t vkind;           // ValueKind of the values behind `dict` / the raw stream
+  int32_t pad;
 };
 
 struct DevLeaf {
@@ -51,6 +65,8 @@ struct DevLeaf {
   int32_t lo;
   uint32_t span;
   int32_t set_bytes;
+  int32_t lo_hi;           // kLeafRawRange64: high dwords of the 64-bit bound / span
+  uint32_t span_hi;
   const uint32_t* set_words;
   const unsigned long long* bitmap;  // kLeafBitmap: doc-order words
   int32_t lds_off;         // kLeafBitmap: byte offset of its 256-byte slot inside one bitmap staging buffer
@@ -83,8 +99,8 @@ struct DevNode {
   int32_t bits;            // packed width of the leaf's column
   int32_t slot_off;        // column staging slot (scan leaves)
   int32_t lds_off;         // bitmap staging slot (bitmap leaves)
-  int32_t set_bytes;
-  int32_t pad;
+  int32_t set_bytes;       // kLeafDictSet: bytes of set_words ; kLeafRawRange64: high dword of the span
+  int32_t lo_hi;           // kLeafRawRange64: high dword of lo
   const uint8_t* fwd;      // raw-range leaves: first value byte
   const uint32_t* set_words;
 };
@@ -113,9 +129,9 @@ struct DevAggCol {         // self-contained: no second lookup into a column tab
   int32_t is_raw;
   int32_t is_plane;
   int32_t dict_bytes;
-  int32_t pad;
+  int32_t vkind;           // ValueKind
   const uint8_t* fwd;
-  const int32_t* dict;
+  const int32_t* dict;     // kValI32: int32 entries ; kValI64 / kValF64: 8-byte entries
 };
 
 // One record per workgroup, reduced by finalize_partials.
@@ -125,6 +141,11 @@ struct BlockPartial {
   int32_t kmin[kMaxAggCols];   // min dictId (dictionary columns: sorted dictionary => monotone), plane offset or raw value
   int32_t kmax[kMaxAggCols];
   unsigned long long cyc[4];   // PG_CFG_PROFILE_WAVES: shader cycles per wave summed: memory wait, filter, aggregate, whole loop
+  // typed columns only (scan_agg_kernel<.., kTyped = true>): double sums, and 64-bit min / max keys (raw LONG value, or the
+  // order-preserving integer image of a raw FLOAT / DOUBLE value)
+  double fsum[kMaxAggCols];
+  long long kmin64[kMaxAggCols];
+  long long kmax64[kMaxAggCols];
 };
 
 struct ScanParams {
@@ -182,6 +203,8 @@ struct DevGroupAgg {       // self-contained
   int32_t is_raw;
   int32_t is_plane;
   int32_t dict_bytes;
+  int32_t vkind;           // ValueKind (kValI64 / kValF64: 64-bit dictionary gather, 64-bit integer / double atomic add)
+  int32_t pad;
   const uint8_t* fwd;
   const int32_t* dict;
 };
@@ -202,6 +225,10 @@ struct GroupParams {
   int32_t num_group_aggs;
   int32_t num_groups;              // product of cardinalities (<= arrayBasedThreshold)
   int32_t use_lds_table;
+  int32_t packed_agg;              // >= 0: that SUM slot of the LDS table also carries the group's doc count in its high bits
+  int32_t packed_shift;            //       (count << packed_shift) | sum ; no separate count atomic
+  int32_t dense_ok;                // 1: every aggregation is in the 32-bit value domain (the dense 16-step path applies)
+  int32_t pad;
   DevGroupKey group_keys[kMaxGroupCols];
   DevGroupAgg group_aggs[kMaxGroupAggs];
   unsigned long long* table_count; // [num_groups]

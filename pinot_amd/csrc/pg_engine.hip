@@ -51,6 +51,8 @@ struct Engine {
   int value_plane = -1;      // -1 auto, 0 never, 1 always (PINOT_GPU_VALUE_PLANE)
   int tile_steps = 0;        // 0 auto, 16 or 32 forced (PINOT_GPU_TILE_STEPS)
   bool double_buffer = false;
+  bool group_pack = true;    // PINOT_GPU_GROUP_PACK=0: separate count atomic in the group-by LDS table
+  int group_waves = 0;       // PINOT_GPU_GROUP_WAVES: cap on wavefronts per group-by workgroup (default 16)
   std::mutex mu;
 };
 Engine g_engine;
@@ -66,7 +68,18 @@ struct ColumnDev {
   uint8_t* d_fwd = nullptr;      // first value byte
   size_t fwd_alloc_bytes = 0;
   int32_t* d_dict = nullptr;
-  std::vector<int32_t> h_dict;   // host-order values (min/max lookups, group keys)
+  std::vector<int32_t> h_dict;   // host-order 32-bit values in the kernels' domain: INT values, or (LONG value - value_base)
+  // Stored types other than INT.  vkind says how the kernels see the VALUES of the column:
+  //   kValI32  INT; or a LONG dictionary whose range fits 31 bits: h_dict / d_dict hold value - value_base ("offset
+  //            dictionary"), every 32-bit path (gather, value plane, plane-evaluated ranges) works unchanged and the host adds
+  //            count * value_base to the sums;
+  //   kValI64  LONG dictionary with a wider range (d_dict64: int64 entries), raw LONG;
+  //   kValF64  FLOAT / DOUBLE dictionary (d_dict64: doubles, FLOAT widened exactly), raw DOUBLE;   kValF32  raw FLOAT.
+  int vkind = kValI32;
+  int64_t value_base = 0;
+  std::vector<double> h_dict_f64;       // every dictionary: (double) of the true value (MIN / MAX / group keys / SPI readers)
+  std::vector<int64_t> h_dict_i64;      // INT / LONG dictionaries: the true value
+  unsigned long long* d_dict64 = nullptr;
   uint8_t* d_inv = nullptr;
   uint64_t inv_size = 0;
   DevContainer* d_dir = nullptr;
@@ -272,6 +285,7 @@ void free_segment(pg_segment* seg) {
   for (auto& col : seg->cols) {
     if (col.d_fwd_alloc) (void)hipFree(col.d_fwd_alloc);
     if (col.d_dict) (void)hipFree(col.d_dict);
+    if (col.d_dict64) (void)hipFree(col.d_dict64);
     if (col.d_inv) (void)hipFree(col.d_inv);
     if (col.d_dir) (void)hipFree(col.d_dir);
     if (col.d_plane) (void)hipFree(col.d_plane);
@@ -289,7 +303,7 @@ void set_dynamic_lds(K kernel, size_t bytes) {
 // L2 as much as streaming ~22 bytes, so unless the dictionary is tiny (L1-resident) or the plane would be much wider
 // than the dictId stream, the plane wins as soon as a few percent of the rows match.
 bool want_value_plane(const ColumnDev& col) {
-  if (col.encoding != PG_FWD_FIXED_BIT_DICT || col.cardinality < 1) return false;
+  if (col.encoding != PG_FWD_FIXED_BIT_DICT || col.cardinality < 1 || col.vkind != kValI32) return false;
   if (g_engine.value_plane == 0) return false;
   if (g_engine.value_plane == 1) return true;
   const int64_t range = (int64_t)col.h_dict.back() - (int64_t)col.h_dict.front();
@@ -355,11 +369,12 @@ int slot_for(Lowered* lw, const pg_segment* seg, int column, bool plane = false)
     d.dict_bytes = 0;
   } else {
     d.fwd = c.d_fwd;
-    d.dict = c.d_dict;
+    d.dict = c.vkind == kValI32 ? c.d_dict : reinterpret_cast<const int32_t*>(c.d_dict64);
     d.bits = c.encoding == PG_FWD_RAW_FIXED_BYTE ? 32 : c.bits;
     d.is_raw = c.encoding == PG_FWD_RAW_FIXED_BYTE;
     d.cardinality = c.cardinality;
-    d.dict_bytes = c.cardinality * 4;
+    d.dict_bytes = c.cardinality * (c.vkind == kValI32 ? 4 : 8);
+    d.vkind = c.vkind;
   }
   if (!d.is_raw) lw->max_bits = std::max(lw->max_bits, d.bits);
   lw->col_of_slot.push_back(id);
@@ -524,6 +539,41 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
           L.kind = kLeafDictSet; L.col = s; L.set_words = ctx->d_sets[set_idx]; L.set_bytes = (int32_t)bytes;
           set_idx++;
           lw->num_scan_leaves++;
+        } else if (pr.kind == PG_PRED_RAW_RANGE && col.stored_type == PG_TYPE_LONG) {
+          // LongRawValueBasedRangePredicateEvaluator (RangePredicateEvaluatorFactory.java:411-446): inclusive int64 bounds
+          if (pr.lo > pr.hi) { L.kind = kLeafMatchNone; }
+          else {
+            int s = slot_for(lw, seg, pr.column);
+            if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
+            sp.cols[s].in_filter = 1;
+            const uint64_t span = (uint64_t)pr.hi - (uint64_t)pr.lo;
+            L.kind = kLeafRawRange64; L.col = s;
+            L.lo = (int32_t)(uint32_t)(uint64_t)pr.lo; L.lo_hi = (int32_t)(uint32_t)((uint64_t)pr.lo >> 32);
+            L.span = (uint32_t)span; L.span_hi = (uint32_t)(span >> 32);
+            lw->num_scan_leaves++;
+          }
+        } else if (pr.kind == PG_PRED_RAW_RANGE && col.stored_type != PG_TYPE_INT) {
+          // Float / DoubleRawValueBasedRangePredicateEvaluator: lo / hi are the bit patterns of the inclusive double bounds.
+          // value >= lo && value <= hi  <=>  key(value) in [key(lo'), key(hi')] with a zero lower bound taken as -0.0 and a zero
+          // upper bound as +0.0 (primitive compares treat the zeros as equal; NaN values match nothing because their keys lie
+          // outside [key(-inf), key(+inf)]).
+          double dlo, dhi;
+          memcpy(&dlo, &pr.lo, 8); memcpy(&dhi, &pr.hi, 8);
+          if (!(dlo <= dhi)) { L.kind = kLeafMatchNone; }
+          else {
+            int s = slot_for(lw, seg, pr.column);
+            if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
+            sp.cols[s].in_filter = 1;
+            if (dlo == 0.0) dlo = -0.0;
+            if (dhi == 0.0) dhi = 0.0;
+            auto key = [](double v) { long long bb; memcpy(&bb, &v, 8); return bb ^ ((bb >> 63) & 0x7FFFFFFFFFFFFFFFll); };
+            const long long klo = key(dlo), khi = key(dhi);
+            const uint64_t span = (uint64_t)khi - (uint64_t)klo;
+            L.kind = col.stored_type == PG_TYPE_FLOAT ? kLeafRawRangeF32 : kLeafRawRangeF64; L.col = s;
+            L.lo = (int32_t)(uint32_t)(uint64_t)klo; L.lo_hi = (int32_t)(uint32_t)((uint64_t)klo >> 32);
+            L.span = (uint32_t)span; L.span_hi = (uint32_t)(span >> 32);
+            lw->num_scan_leaves++;
+          }
         } else if (pr.kind == PG_PRED_RAW_RANGE) {
           int64_t lo = std::max<int64_t>(pr.lo, std::numeric_limits<int32_t>::min());
           int64_t hi = std::min<int64_t>(pr.hi, std::numeric_limits<int32_t>::max());
@@ -607,10 +657,11 @@ void flatten_plan(Lowered* lw) {
     const DevLeaf& L = pl.leaves[pl.nodes[n].leaf];
     dn.kind = L.kind; dn.exclusive = L.exclusive; dn.lo = L.lo; dn.span = L.span; dn.set_bytes = L.set_bytes; dn.set_words = L.set_words;
     dn.lds_off = L.lds_off;
-    if (L.kind == kLeafDictRange || L.kind == kLeafDictSet || L.kind == kLeafRawRange) {
+    if (L.kind == kLeafDictRange || L.kind == kLeafDictSet || L.kind == kLeafRawRange || L.kind >= kLeafRawRange64) {
       const DevColumn& c = pl.cols[L.col];
       dn.bits = c.bits; dn.slot_off = c.slot_off; dn.fwd = c.fwd;
     }
+    if (L.kind >= kLeafRawRange64) { dn.lo_hi = L.lo_hi; dn.set_bytes = (int32_t)L.span_hi; }
   }
   for (int l = 0; l < pl.num_leaves; ++l) {
     if (pl.leaves[l].kind != kLeafBitmap) continue;
@@ -622,7 +673,7 @@ void flatten_plan(Lowered* lw) {
     const DevColumn& c = pl.cols[pl.agg_cols[a].col];
     DevAggCol& ac = sp.agg_cols[a];
     ac.need_sum = pl.agg_cols[a].need_sum; ac.need_minmax = pl.agg_cols[a].need_minmax;
-    ac.bits = c.bits; ac.slot_off = c.slot_off; ac.is_raw = c.is_raw; ac.is_plane = c.is_plane; ac.dict_bytes = c.dict_bytes; ac.pad = 0;
+    ac.bits = c.bits; ac.slot_off = c.slot_off; ac.is_raw = c.is_raw; ac.is_plane = c.is_plane; ac.dict_bytes = c.dict_bytes; ac.vkind = c.vkind;
     ac.fwd = c.fwd; ac.dict = c.dict;
   }
 }
@@ -688,10 +739,29 @@ void finish_geometry(const pg_segment* seg, Lowered* lw, size_t table_bytes, boo
   flatten_plan(lw);
 }
 
+// MIN / MAX key of a column in the 32-bit domain or of any dictionary column (dictId) -> the value as the reference's
+// holder sees it ((double) of the typed minimum / maximum).
 double agg_value_double(const ColumnDev& col, int32_t key, bool plane) {
   if (col.encoding == PG_FWD_RAW_FIXED_BYTE) return (double)key;
-  if (plane) return (double)(col.plane_base + (int64_t)key);   // 32-bit planes have base 0 and key = value
-  return (double)col.h_dict[key];
+  if (plane) return (double)(col.value_base + col.plane_base + (int64_t)key);   // 32-bit planes have base 0 and key = value
+  return col.h_dict_f64[(size_t)key];
+}
+// An integer sum known exactly (128 bits): sum_i64 is it modulo 2^64, `sum` its correctly rounded double; exact while it
+// fits int64 (the reference's double accumulation agrees bit for bit below 2^53 and to rounding above).
+void set_integer_sum(pg_agg_value* v, __int128 t) {
+  v->sum_i64 = (int64_t)(unsigned long long)(unsigned __int128)t;
+  v->sum_exact = ((__int128)v->sum_i64 == t) ? 1 : 0;
+  v->sum = (double)t;
+}
+// what count * base adds back to a sum accumulated in the 32-bit domain
+int64_t sum_base(const ColumnDev& col, bool plane) { return col.value_base + (plane ? col.plane_base : 0); }
+// 64-bit MIN / MAX key of a raw LONG / FLOAT / DOUBLE column (f64_order_key is its own inverse)
+double key64_to_double(const ColumnDev& col, long long key) {
+  if (col.vkind == kValI64) return (double)key;
+  const long long b = key ^ ((key >> 63) & 0x7FFFFFFFFFFFFFFFll);
+  double v;
+  memcpy(&v, &b, 8);
+  return v;
 }
 
 }  // namespace
@@ -721,6 +791,10 @@ pg_status pg_init(const pg_config* config) {
   g_engine.value_plane = vp ? atoi(vp) : -1;
   const char* db = getenv("PINOT_GPU_DOUBLE_BUFFER");
   g_engine.double_buffer = db && db[0] == '1';
+  const char* gpk = getenv("PINOT_GPU_GROUP_PACK");
+  g_engine.group_pack = !(gpk && gpk[0] == '0');
+  const char* gw = getenv("PINOT_GPU_GROUP_WAVES");
+  g_engine.group_waves = (gw && atoi(gw) > 0) ? atoi(gw) : 0;
   const char* ts = getenv("PINOT_GPU_TILE_STEPS");
   g_engine.tile_steps = (ts && (atoi(ts) == 16 || atoi(ts) == 32)) ? atoi(ts) : 0;
   const char* bpc = getenv("PINOT_GPU_BLOCKS_PER_CU");
@@ -772,7 +846,8 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
     col.encoding = cd.fwd_encoding;
     col.bits = cd.bits_per_value;
     col.cardinality = cd.cardinality;
-    if (cd.stored_type != PG_TYPE_INT) return bail(fail(PG_ERR_UNSUPPORTED, "column %s: only INT stored type is offloaded", col.name.c_str()));
+    if (cd.stored_type < PG_TYPE_INT || cd.stored_type > PG_TYPE_DOUBLE) return bail(fail(PG_ERR_UNSUPPORTED, "column %s: stored type %d is not offloaded", col.name.c_str(), cd.stored_type));
+    const int value_bytes = (cd.stored_type == PG_TYPE_INT || cd.stored_type == PG_TYPE_FLOAT) ? 4 : 8;
     if (!cd.fwd_data && desc->num_docs > 0) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: missing forward index", col.name.c_str()));
     const uint8_t* fwd = (const uint8_t*)cd.fwd_data;
     if (cd.fwd_encoding == PG_FWD_FIXED_BIT_DICT) {
@@ -781,7 +856,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       const uint64_t expect = ((uint64_t)desc->num_docs * (uint64_t)cd.bits_per_value + 7) / 8;
       if (cd.fwd_size != expect) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: forward index is %llu bytes, expected %llu", col.name.c_str(), (unsigned long long)cd.fwd_size, (unsigned long long)expect));
       // BaseImmutableDictionary precondition (BaseImmutableDictionary.java:51-53)
-      if (cd.cardinality < 1 || !cd.dict_data || cd.dict_size != (uint64_t)cd.cardinality * 4) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: dictionary buffer size mismatch", col.name.c_str()));
+      if (cd.cardinality < 1 || !cd.dict_data || cd.dict_size != (uint64_t)cd.cardinality * (uint64_t)value_bytes) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: dictionary buffer size mismatch", col.name.c_str()));
       col.fwd_alloc_bytes = (size_t)std::max(seg->num_tiles, 1) * 256 * (size_t)cd.bits_per_value + 64;
       hipError_t e = hipMalloc((void**)&col.d_fwd_alloc, col.fwd_alloc_bytes);
       if (e != hipSuccess) return bail(fail(PG_ERR_OUT_OF_MEMORY, "column %s: hipMalloc(%zu): %s", col.name.c_str(), col.fwd_alloc_bytes, hipGetErrorString(e)));
@@ -791,13 +866,52 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       e = hipMemset(col.d_fwd_alloc + cd.fwd_size, 0, tail);
       if (e == hipSuccess && cd.fwd_size) e = hipMemcpy(col.d_fwd_alloc, fwd, (size_t)cd.fwd_size, hipMemcpyHostToDevice);
       if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "column %s: H2D copy: %s", col.name.c_str(), hipGetErrorString(e)));
-      col.h_dict.resize((size_t)cd.cardinality);
+      // Dictionary values -> host order (IntDictionary / LongDictionary / FloatDictionary / DoubleDictionary: C big-endian
+      // fixed-width values, ascending; FixedByteValueReaderWriter.getInt/getLong/getFloat/getDouble)
+      const size_t C = (size_t)cd.cardinality;
       const uint8_t* dp = (const uint8_t*)cd.dict_data;
-      for (int d = 0; d < cd.cardinality; ++d) col.h_dict[(size_t)d] = (int32_t)be32(dp + 4 * (size_t)d);
-      e = hipMalloc((void**)&col.d_dict, (size_t)cd.cardinality * 4);
-      if (e == hipSuccess) e = hipMemcpy(col.d_dict, col.h_dict.data(), (size_t)cd.cardinality * 4, hipMemcpyHostToDevice);
+      col.h_dict_f64.resize(C);
+      std::vector<unsigned long long> wide;
+      if (cd.stored_type == PG_TYPE_INT) {
+        col.h_dict.resize(C); col.h_dict_i64.resize(C);
+        for (size_t d = 0; d < C; ++d) { col.h_dict[d] = (int32_t)be32(dp + 4 * d); col.h_dict_i64[d] = col.h_dict[d]; col.h_dict_f64[d] = (double)col.h_dict[d]; }
+      } else if (cd.stored_type == PG_TYPE_LONG) {
+        col.h_dict_i64.resize(C);
+        for (size_t d = 0; d < C; ++d) {
+          col.h_dict_i64[d] = (int64_t)(((uint64_t)be32(dp + 8 * d) << 32) | (uint64_t)be32(dp + 8 * d + 4));
+          col.h_dict_f64[d] = (double)col.h_dict_i64[d];
+        }
+        const uint64_t range = (uint64_t)col.h_dict_i64[C - 1] - (uint64_t)col.h_dict_i64[0];
+        if (col.h_dict_i64[C - 1] >= col.h_dict_i64[0] && range < (1ull << 31)) {
+          // offset dictionary: the whole 32-bit machinery applies to (value - min)
+          col.value_base = col.h_dict_i64[0];
+          col.h_dict.resize(C);
+          for (size_t d = 0; d < C; ++d) col.h_dict[d] = (int32_t)(col.h_dict_i64[d] - col.value_base);
+        } else {
+          col.vkind = kValI64;
+          wide.resize(C);
+          for (size_t d = 0; d < C; ++d) wide[d] = (unsigned long long)col.h_dict_i64[d];
+        }
+      } else {
+        col.vkind = kValF64;
+        wide.resize(C);
+        for (size_t d = 0; d < C; ++d) {
+          double v;
+          if (cd.stored_type == PG_TYPE_FLOAT) { const uint32_t b = be32(dp + 4 * d); float f; memcpy(&f, &b, 4); v = (double)f; }
+          else { const uint64_t b = ((uint64_t)be32(dp + 8 * d) << 32) | (uint64_t)be32(dp + 8 * d + 4); memcpy(&v, &b, 8); }
+          col.h_dict_f64[d] = v;
+          memcpy(&wide[d], &v, 8);
+        }
+      }
+      if (col.vkind == kValI32) {
+        e = hipMalloc((void**)&col.d_dict, C * 4);
+        if (e == hipSuccess) e = hipMemcpy(col.d_dict, col.h_dict.data(), C * 4, hipMemcpyHostToDevice);
+      } else {
+        e = hipMalloc((void**)&col.d_dict64, C * 8);
+        if (e == hipSuccess) e = hipMemcpy(col.d_dict64, wide.data(), C * 8, hipMemcpyHostToDevice);
+      }
       if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "column %s: dictionary upload: %s", col.name.c_str(), hipGetErrorString(e)));
-      seg->device_bytes += col.fwd_alloc_bytes + (size_t)cd.cardinality * 4;
+      seg->device_bytes += col.fwd_alloc_bytes + C * (col.vkind == kValI32 ? 4 : 8);
     } else if (cd.fwd_encoding == PG_FWD_RAW_FIXED_BYTE) {
       // BaseChunkForwardIndexReader header (BaseChunkForwardIndexReader.java:61-111)
       if (cd.fwd_size < 16) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: raw forward index too small", col.name.c_str()));
@@ -815,9 +929,10 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
         data_header_start = (int)be32(fwd + off);
       }
       if (compression != 0) return bail(fail(PG_ERR_UNSUPPORTED, "column %s: only PASS_THROUGH raw chunks are offloaded (compressionType=%d)", col.name.c_str(), compression));
-      if (entry_size != 4) return bail(fail(PG_ERR_UNSUPPORTED, "column %s: raw entry size %d", col.name.c_str(), entry_size));
+      if (entry_size != value_bytes) return bail(fail(PG_ERR_UNSUPPORTED, "column %s: raw entry size %d for stored type %d", col.name.c_str(), entry_size, cd.stored_type));
+      col.vkind = cd.stored_type == PG_TYPE_INT ? kValI32 : (cd.stored_type == PG_TYPE_LONG ? kValI64 : (cd.stored_type == PG_TYPE_FLOAT ? kValF32 : kValF64));
       const uint64_t raw_start = (uint64_t)data_header_start + (uint64_t)num_chunks * (version <= 2 ? 4 : 8);
-      if (raw_start + (uint64_t)desc->num_docs * 4 > cd.fwd_size) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: raw forward index shorter than numDocs", col.name.c_str()));
+      if (raw_start + (uint64_t)desc->num_docs * (uint64_t)value_bytes > cd.fwd_size) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: raw forward index shorter than numDocs", col.name.c_str()));
       col.fwd_alloc_bytes = (size_t)cd.fwd_size + 64;
       hipError_t e = hipMalloc((void**)&col.d_fwd_alloc, col.fwd_alloc_bytes);
       if (e != hipSuccess) return bail(fail(PG_ERR_OUT_OF_MEMORY, "column %s: hipMalloc(%zu): %s", col.name.c_str(), col.fwd_alloc_bytes, hipGetErrorString(e)));
@@ -958,12 +1073,17 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if (ag.function == PG_AGG_MIN || ag.function == PG_AGG_MAX) pl.agg_cols[ac].need_minmax = 1;
       agg_slot_of[(size_t)a] = ac;
     }
-    bool need_queue = false;
-    for (int i = 0; i < pl.num_agg_cols; ++i) need_queue |= pl.agg_cols[i].need_sum && !pl.cols[pl.agg_cols[i].col].is_raw && !pl.cols[pl.agg_cols[i].col].is_plane;
+    bool need_queue = false, typed = false;
+    for (int i = 0; i < pl.num_agg_cols; ++i) {
+      const DevColumn& c = pl.cols[pl.agg_cols[i].col];
+      need_queue |= pl.agg_cols[i].need_sum && !c.is_raw && !c.is_plane && c.vkind == kValI32;
+      typed |= c.vkind != kValI32 && (pl.agg_cols[i].need_sum || c.is_raw);     // 8-byte / floating-point values are read
+    }
     Geometry geo;
     static const int agg_wave_cap1 = max_waves_per_cu(scan_agg_kernel<true, 1>);
     static const int agg_wave_cap4 = max_waves_per_cu(scan_agg_kernel<true, kMaxAggCols>);
-    const int agg_wave_cap = pl.num_agg_cols <= 1 ? agg_wave_cap1 : agg_wave_cap4;
+    static const int agg_wave_cap_typed = max_waves_per_cu(scan_agg_kernel<true, kMaxAggCols, true>);
+    const int agg_wave_cap = typed ? agg_wave_cap_typed : (pl.num_agg_cols <= 1 ? agg_wave_cap1 : agg_wave_cap4);
     finish_geometry(seg, &lw, 0, need_queue, kBlockThreads / 64, agg_wave_cap, &geo);
     const int blocks = geo.blocks;
     const size_t lds = geo.lds;
@@ -982,7 +1102,10 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
-    if (g_engine.use_dma) {
+    if (typed) {
+      if (g_engine.use_dma) { set_dynamic_lds(scan_agg_kernel<true, kMaxAggCols, true>, lds); scan_agg_kernel<true, kMaxAggCols, true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
+      else { set_dynamic_lds(scan_agg_kernel<false, kMaxAggCols, true>, lds); scan_agg_kernel<false, kMaxAggCols, true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
+    } else if (g_engine.use_dma) {
       if (one) { set_dynamic_lds(scan_agg_kernel<true, 1>, lds); scan_agg_kernel<true, 1><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
       else { set_dynamic_lds(scan_agg_kernel<true, kMaxAggCols>, lds); scan_agg_kernel<true, kMaxAggCols><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
     } else {
@@ -1016,14 +1139,35 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         const int ac = agg_slot_of[(size_t)a];
         const ColumnDev& col = seg->cols[(size_t)ag.column];
         const bool plane = lw.plane_cols[(size_t)ag.column] != 0;
+        const bool raw = col.encoding == PG_FWD_RAW_FIXED_BYTE;
         if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) {
-          // value plane: sum(value) = count * base + sum(value - base)
-          v.sum_i64 = fp.sum[ac] + (plane ? (long long)fp.count * (long long)col.plane_base : 0ll);
-          v.sum_exact = 1;
-          v.sum = (double)v.sum_i64;
+          if (col.vkind == kValF64 || col.vkind == kValF32) {
+            // SumAggregationFunction on FLOAT / DOUBLE: a double sum; the addition order differs from the reference's
+            // doc order, so the last bits may (tests/test_gpu_typed.py states the tolerance)
+            v.sum = fp.fsum[ac];
+            v.sum_i64 = 0;
+            v.sum_exact = 0;
+          } else if (col.vkind == kValI64) {
+            // LONG values: the int64 sum is exact unless it wrapped, which the double image of the same sum reveals (a wrap moves
+            // it by a multiple of 2^64).  Wrapped: report the double sum, like the reference's double accumulation, inexact.
+            v.sum_i64 = fp.sum[ac];
+            const bool wrapped = std::fabs(fp.fsum[ac] - (double)fp.sum[ac]) > 4.6e18;
+            v.sum_exact = wrapped ? 0 : 1;
+            v.sum = wrapped ? fp.fsum[ac] : (double)v.sum_i64;
+          } else {
+            // value plane: sum(value) = count * base + sum(value - base); offset dictionaries add count * value_base
+            set_integer_sum(&v, (__int128)fp.sum[ac] + (__int128)fp.count * (__int128)sum_base(col, plane));
+          }
         } else if (fp.count > 0) {
-          if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, fp.kmin[ac], plane);
-          if (ag.function == PG_AGG_MAX) v.max = agg_value_double(col, fp.kmax[ac], plane);
+          if (raw && col.vkind != kValI32) {
+            double mn = key64_to_double(col, fp.kmin64[ac]), mx = key64_to_double(col, fp.kmax64[ac]);
+            if (mx != mx) mn = mx;      // Math.min / Math.max propagate NaN
+            if (ag.function == PG_AGG_MIN) v.min = mn;
+            if (ag.function == PG_AGG_MAX) v.max = mx;
+          } else {
+            if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, fp.kmin[ac], plane);
+            if (ag.function == PG_AGG_MAX) v.max = agg_value_double(col, fp.kmax[ac], plane);
+          }
         }
       }
       for (int c = 0; c < 4; ++c) out->profile_cycles[c] = fp.cyc[c];
@@ -1059,6 +1203,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
     gp.num_group_cols = ng;
     gp.num_groups = (int32_t)product;
+    gp.dense_ok = 1;
     std::vector<int> dev_agg_of((size_t)std::max(na, 1), -1);
     for (int a = 0; a < na; ++a) {
       const pg_aggregation& ag = q->aggregations[a];
@@ -1087,7 +1232,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const size_t table_bytes = table_words * 8;
     Geometry geo;
     static const int group_wave_cap = max_waves_per_cu(scan_group_kernel<true, true>);
-    finish_geometry(seg, &lw, table_bytes, false, kGroupBlockThreads / 64, group_wave_cap, &geo);
+    finish_geometry(seg, &lw, table_bytes, false, g_engine.group_waves > 0 ? std::min(g_engine.group_waves, kGroupBlockThreads / 64) : kGroupBlockThreads / 64, group_wave_cap, &geo);
     if ((size_t)sp.wave_lds_bytes > kLdsBudget) return fail(PG_ERR_UNSUPPORTED, "query needs %d bytes of LDS per wavefront", sp.wave_lds_bytes);
     gp.use_lds_table = geo.table_in_lds ? 1 : 0;
     const int blocks = geo.blocks;
@@ -1102,6 +1247,32 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       DevGroupAgg& ga = gp.group_aggs[a];
       ga.kind = plan_aggs[a].kind; ga.bits = c.bits; ga.slot_off = c.slot_off; ga.is_raw = c.is_raw; ga.is_plane = c.is_plane;
       ga.dict_bytes = c.dict_bytes; ga.fwd = c.fwd; ga.dict = c.dict;
+      // MIN / MAX run on dictIds whatever the value type; only a SUM reads 8-byte / floating-point dictionary entries
+      ga.vkind = (ga.kind == kGroupSum) ? c.vkind : kValI32;
+      if (c.is_raw && c.vkind != kValI32) return fail(PG_ERR_UNSUPPORTED, "group-by aggregation of a raw LONG / FLOAT / DOUBLE column (plan-time fallback)");
+      if (ga.vkind != kValI32) gp.dense_ok = 0;
+      if (ga.vkind == kValI64) {
+        // the table slot is one wrapping int64: refuse (plan-time fallback) when numDocs * max|value| could overflow it
+        const ColumnDev& sc = seg->cols[(size_t)(lw.col_of_slot[(size_t)plan_aggs[a].col] / 2)];
+        const double max_abs = std::max(std::fabs((double)sc.h_dict_i64.front()), std::fabs((double)sc.h_dict_i64.back()));
+        if ((double)seg->num_docs * max_abs >= 9.2e18) return fail(PG_ERR_UNSUPPORTED, "group-by SUM of LONG column %s could overflow int64", sc.name.c_str());
+      }
+    }
+    // Count packing: when the first summed value plane is narrow enough, its 64-bit LDS slot carries (count << shift) | sum
+    // and the separate count atomic disappears.  Safe while a workgroup sees fewer than 2^cbits docs:
+    // sum < 2^cbits * 2^w = 2^shift and count < 2^cbits, so cbits + shift <= 64 never carries into or out of the count.
+    gp.packed_agg = -1;
+    gp.packed_shift = 0;
+    if (gp.use_lds_table && g_engine.group_pack) {
+      const long long waves_total = (long long)blocks * (geo.threads / 64);
+      const long long tiles_per_wave = (sp.num_tiles + waves_total - 1) / waves_total;
+      const long long docs_per_block = tiles_per_wave * (geo.threads / 64) * 64 * sp.tile_steps;
+      int cbits = 1;
+      while ((1ll << cbits) <= docs_per_block) ++cbits;
+      for (int a = 0; a < gp.num_group_aggs; ++a) {
+        const DevGroupAgg& ga = gp.group_aggs[a];
+        if (ga.kind == kGroupSum && ga.is_plane && !ga.is_raw && 2 * cbits + ga.bits <= 64) { gp.packed_agg = a; gp.packed_shift = std::max(32, cbits + ga.bits); break; }
+      }
     }
     gp.scan = sp;
     gp.scan.partials = nullptr;
@@ -1146,9 +1317,13 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         const ColumnDev& col = seg->cols[(size_t)ag.column];
         const bool plane = lw.plane_cols[(size_t)ag.column] != 0;
         if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) {
-          v.sum_i64 = acc + (plane ? (long long)hc[g] * (long long)col.plane_base : 0ll);
-          v.sum_exact = 1;
-          v.sum = (double)v.sum_i64;
+          if (col.vkind == kValF64) {
+            memcpy(&v.sum, &acc, 8);          // the slot accumulated doubles (ds_add_f64 / global_atomic_add_f64)
+            v.sum_i64 = 0;
+            v.sum_exact = 0;
+          } else {
+            set_integer_sum(&v, (__int128)acc + (__int128)hc[g] * (__int128)sum_base(col, plane));
+          }
         }
         else if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, (int32_t)acc, plane);
         else v.max = agg_value_double(col, (int32_t)acc, plane);
@@ -1182,7 +1357,8 @@ pg_status pg_filter_bitmap(pg_segment* segment, const pg_query* query, uint64_t*
   return execute_impl(segment, query, nullptr, nullptr, out_words, num_words, out_cardinality);
 }
 
-static pg_status gather_impl(pg_segment* seg, int32_t column, const int32_t* doc_ids, int32_t length, int32_t* out_dict, int32_t* out_int, double* out_double) {
+static pg_status gather_impl(pg_segment* seg, int32_t column, const int32_t* doc_ids, int32_t length, int32_t* out_dict, int32_t* out_int, double* out_double,
+                             int64_t* out_long = nullptr) {
   if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");
   if (!seg || (length > 0 && !doc_ids)) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
   if (column < 0 || column >= (int)seg->cols.size()) return fail(PG_ERR_INVALID_ARGUMENT, "column %d out of range", column);
@@ -1190,6 +1366,7 @@ static pg_status gather_impl(pg_segment* seg, int32_t column, const int32_t* doc
   for (int32_t i = 0; i < length; ++i) if (doc_ids[i] < 0 || doc_ids[i] >= seg->num_docs) return fail(PG_ERR_INVALID_ARGUMENT, "docId %d out of range", doc_ids[i]);
   const ColumnDev& col = seg->cols[(size_t)column];
   if (out_dict && col.encoding != PG_FWD_FIXED_BIT_DICT) return fail(PG_ERR_INVALID_ARGUMENT, "column %s is not dictionary encoded", col.name.c_str());
+  if (out_int && col.stored_type != PG_TYPE_INT) return fail(PG_ERR_INVALID_ARGUMENT, "column %s is not INT: use pg_read_long_values / pg_read_double_values", col.name.c_str());
   HIP_TRY(hipSetDevice(seg->device));
   ExecCtx* ctx = nullptr;
   pg_status st = acquire_ctx(seg, &ctx);
@@ -1206,15 +1383,18 @@ static pg_status gather_impl(pg_segment* seg, int32_t column, const int32_t* doc
   }
   HIP_TRY(hipMemcpyAsync(ctx->d_gather_in, doc_ids, (size_t)length * 4, hipMemcpyHostToDevice, ctx->stream));
   DevColumn dc;
-  dc.fwd = col.d_fwd; dc.dict = col.d_dict; dc.bits = col.bits; dc.is_raw = col.encoding == PG_FWD_RAW_FIXED_BYTE;
-  dc.cardinality = col.cardinality; dc.dict_bytes = col.cardinality * 4; dc.in_filter = 0; dc.in_agg = 0;
+  memset(&dc, 0, sizeof(dc));
+  dc.fwd = col.d_fwd; dc.bits = col.bits; dc.is_raw = col.encoding == PG_FWD_RAW_FIXED_BYTE;
+  dc.vkind = col.vkind;
+  dc.dict = col.vkind == kValI32 ? col.d_dict : reinterpret_cast<const int32_t*>(col.d_dict64);
+  dc.cardinality = col.cardinality; dc.dict_bytes = col.cardinality * (col.vkind == kValI32 ? 4 : 8);
   const unsigned blocks = (unsigned)((length + 255) / 256);
-  gather_values_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(dc, ctx->d_gather_in, length,
+  gather_values_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(dc, (long long)col.value_base, ctx->d_gather_in, length,
       out_dict ? (int32_t*)ctx->d_gather_out : nullptr, out_int ? (int32_t*)ctx->d_gather_out : nullptr,
-      out_double ? (double*)ctx->d_gather_out : nullptr);
+      out_long ? (long long*)ctx->d_gather_out : nullptr, out_double ? (double*)ctx->d_gather_out : nullptr);
   HIP_TRY(hipGetLastError());
-  void* host_out = out_dict ? (void*)out_dict : (out_int ? (void*)out_int : (void*)out_double);
-  HIP_TRY(hipMemcpyAsync(host_out, ctx->d_gather_out, (size_t)length * (out_double ? 8 : 4), hipMemcpyDeviceToHost, ctx->stream));
+  void* host_out = out_dict ? (void*)out_dict : (out_int ? (void*)out_int : (out_long ? (void*)out_long : (void*)out_double));
+  HIP_TRY(hipMemcpyAsync(host_out, ctx->d_gather_out, (size_t)length * ((out_double || out_long) ? 8 : 4), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return PG_OK;
 }
@@ -1226,6 +1406,10 @@ pg_status pg_read_dict_ids(pg_segment* segment, int32_t column, const int32_t* d
 pg_status pg_read_int_values(pg_segment* segment, int32_t column, const int32_t* doc_ids, int32_t length, int32_t* out_values) {
   if (!out_values && length > 0) return fail(PG_ERR_INVALID_ARGUMENT, "null output");
   return gather_impl(segment, column, doc_ids, length, nullptr, out_values, nullptr);
+}
+pg_status pg_read_long_values(pg_segment* segment, int32_t column, const int32_t* doc_ids, int32_t length, int64_t* out_values) {
+  if (!out_values && length > 0) return fail(PG_ERR_INVALID_ARGUMENT, "null output");
+  return gather_impl(segment, column, doc_ids, length, nullptr, nullptr, nullptr, out_values);
 }
 pg_status pg_read_double_values(pg_segment* segment, int32_t column, const int32_t* doc_ids, int32_t length, double* out_values) {
   if (!out_values && length > 0) return fail(PG_ERR_INVALID_ARGUMENT, "null output");

@@ -94,6 +94,32 @@ __device__ __forceinline__ uint32_t decode_step(const uint8_t* slot, const LaneD
   }
 }
 
+// Eight consecutive steps k0..k0+7 of one column: all eight LDS reads are issued before the first result is used (written
+// out as two phases on purpose -- left to itself the scheduler serialises read -> wait -> extract under register pressure and
+// the loop becomes LDS-latency bound).
+__device__ __forceinline__ void decode_steps8(const uint8_t* slot, const LaneDec& L, int k0, int b, uint32_t (&out)[8]) {
+  const uint8_t* base = slot + L.off + (uint32_t)k0 * 8u * (uint32_t)b;
+  uint32_t w0[8], w1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(base + (uint32_t)j * 8u * (uint32_t)b);
+    w0[j] = p[0];
+    w1[j] = p[1];
+  }
+  if (b <= 25) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = __builtin_amdgcn_ubfe(__builtin_amdgcn_perm(w1[j], w0[j], L.sel), L.shift, (uint32_t)b);
+  } else {
+    const uint32_t end = L.s + (uint32_t)b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t hi = __builtin_bswap32(w0[j]), lo = __builtin_bswap32(w1[j]);
+      const uint32_t v = end <= 32u ? (hi >> (32u - end)) : __builtin_amdgcn_alignbit(hi, lo, 64u - end);
+      out[j] = v & ((1u << b) - 1u);
+    }
+  }
+}
+
 // Register stack with a wave-uniform stack pointer (no scratch: every index is a compile-time constant).
 struct MaskStack {
   uint32_t v[kStackDepth];
@@ -202,9 +228,19 @@ __device__ __forceinline__ uint32_t eval_dict_leaf_loop(const DevNode& L, const 
   return __builtin_bitreverse32(m) >> (32 - steps);   // step k was shifted in first; restore bit k
 }
 
+// Order-preserving integer image of a double (signed compare of the keys == Double.compare of the values: -0.0 < +0.0,
+// NaN above +Infinity).  Every NaN is mapped to the canonical one so that MAX sees it; the host turns a NaN maximum into
+// a NaN minimum as well (java.lang.Math.min / max propagate NaN).  The map is its own inverse.
+__device__ __forceinline__ long long f64_order_key(double v) {
+  long long b = __double_as_longlong(v);
+  b = (v != v) ? 0x7FF8000000000000ll : b;
+  return b ^ ((b >> 63) & 0x7FFFFFFFFFFFFFFFll);
+}
+
 // `stage` is the wave's current column staging buffer, `bstage` its current bitmap staging buffer (already filled).
 // The node record carries everything the leaf needs (one scalar load).
-__device__ uint32_t eval_leaf(const ScanParams& p, const DevNode& L, int tile, const uint8_t* stage, const uint8_t* bstage, int lane) {
+// (must inline: a call would force the kernel-argument block into scratch memory to take its address)
+__device__ __forceinline__ uint32_t eval_leaf(const ScanParams& p, const DevNode& L, int tile, const uint8_t* stage, const uint8_t* bstage, int lane) {
   const int steps = p.tile_steps;
   uint32_t m;
   switch (L.kind) {
@@ -236,6 +272,30 @@ __device__ uint32_t eval_leaf(const ScanParams& p, const DevNode& L, int tile, c
         shift_in_le(m, v - lo, __builtin_amdgcn_readfirstlane(span));
       }
       m = __builtin_bitreverse32(m) >> (32 - steps);
+      break;
+    }
+    case kLeafRawRange64:
+    case kLeafRawRangeF64:
+    case kLeafRawRangeF32: {
+      // raw LONG / DOUBLE / FLOAT column (Long / Double / FloatRawValueBasedRangePredicateEvaluator): coalesced loads straight
+      // from HBM; floating-point values are compared through f64_order_key (the host adjusts zero bounds so that -0.0 == 0.0)
+      const long long base_doc = (long long)tile * 64 * steps;
+      const long long last = (long long)p.num_docs - 1;
+      const unsigned long long lo = ((unsigned long long)(uint32_t)L.lo_hi << 32) | (uint32_t)L.lo;
+      const unsigned long long span = ((unsigned long long)(uint32_t)L.set_bytes << 32) | L.span;
+      m = 0;
+#pragma unroll 8
+      for (int k = 0; k < steps; ++k) {
+        long long doc = base_doc + k * 64 + lane;
+        doc = doc > last ? last : doc;
+        unsigned long long v;
+        if (L.kind == kLeafRawRangeF32) v = (unsigned long long)f64_order_key((double)__uint_as_float(__builtin_bswap32(*reinterpret_cast<const uint32_t*>(L.fwd + doc * 4))));
+        else {
+          v = __builtin_bswap64(*reinterpret_cast<const unsigned long long*>(L.fwd + doc * 8));
+          if (L.kind == kLeafRawRangeF64) v = (unsigned long long)f64_order_key(__longlong_as_double((long long)v));
+        }
+        m |= ((v - lo) <= span ? 1u : 0u) << k;
+      }
       break;
     }
     default: {  // kLeafBitmap: doc-order 64-bit words staged in LDS; word k of the tile covers docs 64k..64k+63
@@ -495,10 +555,98 @@ __device__ __forceinline__ void agg_raw_column(const DevAggCol& col, int num_doc
   }
 }
 
+// ---- typed values (LONG / FLOAT / DOUBLE stored types) ----
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ long long wave_min_i64(long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+  return v;
+}
+__device__ __forceinline__ long long wave_max_i64(long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  return v;
+}
+// SUM of a dictionary column whose values are 8-byte entries (LONG with a wide range, FLOAT / DOUBLE): set-bit walk, four
+// decodes then four 64-bit dictionary gathers in flight.  (MIN / MAX never come here: they run on dictIds.)
+template <bool kWide>
+__device__ __forceinline__ void agg_dict_column_wide(const DevAggCol& ac, const uint8_t* slot, uint32_t m, int lane,
+                                                     long long& isum, double& fsum, int32_t& kmin, int32_t& kmax) {
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  const int b = ac.bits;
+  const LaneDec dec = make_lane_dec(b, lane);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ac.dict, 0, ac.dict_bytes, 0x00020000);
+  uint32_t rem = m;
+  for (;;) {
+    if (__builtin_amdgcn_ballot_w64(rem != 0u) == 0ull) break;
+    bool active[4];
+    uint32_t d[4];
+    u32x2 w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      active[j] = rem != 0u;
+      const int k = active[j] ? __builtin_ctz(rem) : 0;
+      rem &= rem - 1u;
+      d[j] = decode_step<kWide>(slot, dec, k, b);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, active[j] ? d[j] * 8u : 0xFFFFFFFFu, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long bits = (long long)(((unsigned long long)w[j].y << 32) | (unsigned long long)w[j].x);   // 0 when inactive
+      if (ac.need_sum) {
+        // LONG: exact wrapping int64 sum, plus a double image the host falls back to when the int64 sum can overflow
+        if (ac.vkind == kValI64) { isum += bits; fsum += (double)bits; }
+        else fsum += __longlong_as_double(bits);     // +0.0 when inactive
+      }
+      if (ac.need_minmax) {
+        const int32_t key = (int32_t)d[j];
+        kmin = (active[j] && key < kmin) ? key : kmin;
+        kmax = (active[j] && key > kmax) ? key : kmax;
+      }
+    }
+  }
+}
+
+// Raw LONG / FLOAT / DOUBLE column: one coalesced load per step straight from HBM (FixedByteChunkSVForwardIndexReader
+// .getLong / getFloat / getDouble: big-endian value at rawDataStart + entrySize * docId).
+__device__ __forceinline__ void agg_raw_column_typed(const DevAggCol& ac, int num_docs, int tile, int steps, uint32_t m, int lane,
+                                                     long long& isum, double& fsum, long long& kmin, long long& kmax) {
+  const long long base_doc = (long long)tile * 64 * steps;
+  const long long last = (long long)num_docs - 1;
+#pragma unroll 4
+  for (int k = 0; k < steps; ++k) {
+    long long doc = base_doc + k * 64 + lane;
+    doc = doc > last ? last : doc;
+    const bool match = ((m >> k) & 1u) != 0u;
+    long long key;
+    if (ac.vkind == kValI64) {
+      const long long v = (long long)__builtin_bswap64(*reinterpret_cast<const unsigned long long*>(ac.fwd + doc * 8));
+      isum += match ? v : 0ll;
+      fsum += match ? (double)v : 0.0;
+      key = v;
+    } else {
+      double v;
+      if (ac.vkind == kValF32) v = (double)__uint_as_float(__builtin_bswap32(*reinterpret_cast<const uint32_t*>(ac.fwd + doc * 4)));
+      else v = __longlong_as_double((long long)__builtin_bswap64(*reinterpret_cast<const unsigned long long*>(ac.fwd + doc * 8)));
+      fsum += match ? v : 0.0;
+      key = f64_order_key(v);
+    }
+    kmin = (match && key < kmin) ? key : kmin;
+    kmax = (match && key > kmax) ? key : kmax;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused scan -> filter -> aggregate.  One wavefront per tile, tiles dealt round-robin over a persistent grid.
 // ------------------------------------------------------------------------------------------------
-template <bool kDma, int kAggSlots>
+// kTyped: some aggregated column has 8-byte / floating-point values (ValueKind != kValI32); adds double sums and 64-bit
+// min / max keys per slot.  The all-INT instantiations carry none of that.
+template <bool kDma, int kAggSlots, bool kTyped = false>
 __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63;
@@ -513,6 +661,10 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
   int32_t kmin[kAggSlots], kmax[kAggSlots];
 #pragma unroll
   for (int a = 0; a < kAggSlots; ++a) { sum[a] = 0; kmin[a] = 0x7FFFFFFF; kmax[a] = (int32_t)0x80000000; }
+  double fsum[kTyped ? kAggSlots : 1];
+  long long kmin64[kTyped ? kAggSlots : 1], kmax64[kTyped ? kAggSlots : 1];
+#pragma unroll
+  for (int a = 0; a < (kTyped ? kAggSlots : 1); ++a) { fsum[a] = 0.0; kmin64[a] = 0x7FFFFFFFFFFFFFFFll; kmax64[a] = (long long)0x8000000000000000ull; }
 
   GatherQueue gq;
   gq.q = reinterpret_cast<uint32_t*>(wave_lds + p.queue_off);
@@ -522,7 +674,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
   int num_sum_cols = 0;
 #pragma unroll
   for (int a = 0; a < kAggSlots; ++a)
-    num_sum_cols += (a < p.num_agg_cols && p.agg_cols[a].need_sum && !p.agg_cols[a].is_raw && !p.agg_cols[a].is_plane) ? 1 : 0;
+    num_sum_cols += (a < p.num_agg_cols && p.agg_cols[a].need_sum && !p.agg_cols[a].is_raw && !p.agg_cols[a].is_plane && p.agg_cols[a].vkind == kValI32) ? 1 : 0;
 
   unsigned long long cyc_wait = 0, cyc_filter = 0, cyc_agg = 0;
   const unsigned long long cyc_start = p.profile ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -566,7 +718,11 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
       for (int a = 0; a < kAggSlots; ++a) {
         if (a < q.num_agg_cols) {
           const DevAggCol& ac = q.agg_cols[a];
-          if (ac.is_raw) {
+          if (kTyped && ac.vkind != kValI32) {
+            if (ac.is_raw) agg_raw_column_typed(ac, q.num_docs, tile, steps, m, lane, sum[a], fsum[kTyped ? a : 0], kmin64[kTyped ? a : 0], kmax64[kTyped ? a : 0]);
+            else if (ac.bits <= 25) agg_dict_column_wide<false>(ac, cur + ac.slot_off, m, lane, sum[a], fsum[kTyped ? a : 0], kmin[a], kmax[a]);
+            else agg_dict_column_wide<true>(ac, cur + ac.slot_off, m, lane, sum[a], fsum[kTyped ? a : 0], kmin[a], kmax[a]);
+          } else if (ac.is_raw) {
             agg_raw_column(ac, q.num_docs, tile, steps, m, lane, sum[a], kmin[a], kmax[a]);
           } else {
             if (ac.bits <= 25) agg_dict_column<false>(ac, cur + ac.slot_off, m, lane, sum[a], kmin[a], kmax[a], gq);
@@ -598,7 +754,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
   if (num_sum_cols == 1 && gq.count > 0) {
 #pragma unroll
     for (int a = 0; a < kAggSlots; ++a) {
-      if (a < p.num_agg_cols && p.agg_cols[a].need_sum && !p.agg_cols[a].is_raw && !p.agg_cols[a].is_plane) {
+      if (a < p.num_agg_cols && p.agg_cols[a].need_sum && !p.agg_cols[a].is_raw && !p.agg_cols[a].is_plane && p.agg_cols[a].vkind == kValI32) {
         const DevAggCol& col = p.agg_cols[a];
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)col.dict, 0, col.dict_bytes, 0x00020000);
         drain_queue(gq, rsrc, lane, sum[a]);
@@ -620,6 +776,13 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
     } else {
       mine.sum[a] = 0; mine.kmin[a] = 0x7FFFFFFF; mine.kmax[a] = (int32_t)0x80000000;
     }
+    if (kTyped && a < kAggSlots) {
+      mine.fsum[a] = wave_sum_f64(fsum[(kTyped && a < kAggSlots) ? a : 0]);
+      mine.kmin64[a] = wave_min_i64(kmin64[(kTyped && a < kAggSlots) ? a : 0]);
+      mine.kmax64[a] = wave_max_i64(kmax64[(kTyped && a < kAggSlots) ? a : 0]);
+    } else {
+      mine.fsum[a] = 0.0; mine.kmin64[a] = 0x7FFFFFFFFFFFFFFFll; mine.kmax64[a] = (long long)0x8000000000000000ull;
+    }
   }
   mine.cyc[0] = cyc_wait; mine.cyc[1] = cyc_filter; mine.cyc[2] = cyc_agg;
   mine.cyc[3] = p.profile ? __builtin_amdgcn_s_memtime() - cyc_start : 0ull;
@@ -636,33 +799,49 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
         acc.sum[a] += red[w].sum[a];
         acc.kmin[a] = red[w].kmin[a] < acc.kmin[a] ? red[w].kmin[a] : acc.kmin[a];
         acc.kmax[a] = red[w].kmax[a] > acc.kmax[a] ? red[w].kmax[a] : acc.kmax[a];
+        if (kTyped) {
+          acc.fsum[a] += red[w].fsum[a];
+          acc.kmin64[a] = red[w].kmin64[a] < acc.kmin64[a] ? red[w].kmin64[a] : acc.kmin64[a];
+          acc.kmax64[a] = red[w].kmax64[a] > acc.kmax64[a] ? red[w].kmax64[a] : acc.kmax64[a];
+        }
       }
     }
     p.partials[blockIdx.x] = acc;
   }
 }
 
-// Reduce the per-workgroup partials into partials[num_blocks] (one record).
-__global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockPartial* partials, int num_blocks) {
-  __shared__ BlockPartial red[kBlockThreads / 64];
-  BlockPartial acc;
+// Reduce the per-workgroup partials into partials[num_blocks] (one record).  The order of the double additions is fixed by
+// the grid size, so a given launch geometry always returns the same floating-point sum.
+__device__ __forceinline__ void partial_identity(BlockPartial& acc) {
   acc.count = 0;
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc.cyc[c] = 0;
 #pragma unroll
-  for (int a = 0; a < kMaxAggCols; ++a) { acc.sum[a] = 0; acc.kmin[a] = 0x7FFFFFFF; acc.kmax[a] = (int32_t)0x80000000; }
-  for (int i = threadIdx.x; i < num_blocks; i += blockDim.x) {
-    const BlockPartial b = partials[i];
-    acc.count += b.count;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc.cyc[c] += b.cyc[c];
-#pragma unroll
-    for (int a = 0; a < kMaxAggCols; ++a) {
-      acc.sum[a] += b.sum[a];
-      acc.kmin[a] = b.kmin[a] < acc.kmin[a] ? b.kmin[a] : acc.kmin[a];
-      acc.kmax[a] = b.kmax[a] > acc.kmax[a] ? b.kmax[a] : acc.kmax[a];
-    }
+  for (int a = 0; a < kMaxAggCols; ++a) {
+    acc.sum[a] = 0; acc.kmin[a] = 0x7FFFFFFF; acc.kmax[a] = (int32_t)0x80000000;
+    acc.fsum[a] = 0.0; acc.kmin64[a] = 0x7FFFFFFFFFFFFFFFll; acc.kmax64[a] = (long long)0x8000000000000000ull;
   }
+}
+__device__ __forceinline__ void partial_merge(BlockPartial& acc, const BlockPartial& b) {
+  acc.count += b.count;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc.cyc[c] += b.cyc[c];
+#pragma unroll
+  for (int a = 0; a < kMaxAggCols; ++a) {
+    acc.sum[a] += b.sum[a];
+    acc.kmin[a] = b.kmin[a] < acc.kmin[a] ? b.kmin[a] : acc.kmin[a];
+    acc.kmax[a] = b.kmax[a] > acc.kmax[a] ? b.kmax[a] : acc.kmax[a];
+    acc.fsum[a] += b.fsum[a];
+    acc.kmin64[a] = b.kmin64[a] < acc.kmin64[a] ? b.kmin64[a] : acc.kmin64[a];
+    acc.kmax64[a] = b.kmax64[a] > acc.kmax64[a] ? b.kmax64[a] : acc.kmax64[a];
+  }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockPartial* partials, int num_blocks) {
+  __shared__ BlockPartial red[kBlockThreads / 64];
+  BlockPartial acc;
+  partial_identity(acc);
+  for (int i = threadIdx.x; i < num_blocks; i += blockDim.x) partial_merge(acc, partials[i]);
   acc.count = (unsigned long long)wave_sum_i64((long long)acc.count);
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc.cyc[c] = (unsigned long long)wave_sum_i64((long long)acc.cyc[c]);
@@ -671,23 +850,16 @@ __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockP
     acc.sum[a] = wave_sum_i64(acc.sum[a]);
     acc.kmin[a] = wave_min_i32(acc.kmin[a]);
     acc.kmax[a] = wave_max_i32(acc.kmax[a]);
+    acc.fsum[a] = wave_sum_f64(acc.fsum[a]);
+    acc.kmin64[a] = wave_min_i64(acc.kmin64[a]);
+    acc.kmax64[a] = wave_max_i64(acc.kmax64[a]);
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) red[w] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     BlockPartial t = red[0];
-    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) {
-      t.count += red[i].count;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) t.cyc[c] += red[i].cyc[c];
-#pragma unroll
-      for (int a = 0; a < kMaxAggCols; ++a) {
-        t.sum[a] += red[i].sum[a];
-        t.kmin[a] = red[i].kmin[a] < t.kmin[a] ? red[i].kmin[a] : t.kmin[a];
-        t.kmax[a] = red[i].kmax[a] > t.kmax[a] ? red[i].kmax[a] : t.kmax[a];
-      }
-    }
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) partial_merge(t, red[i]);
     partials[num_blocks] = t;
   }
 }
@@ -737,21 +909,48 @@ __device__ __forceinline__ void group_process4(const GroupParams& gp, const uint
     const uint32_t mult = (uint32_t)key.mult;
     if (b <= 25) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] += decode_step<false>(slot, dec, k[j], b) * mult;
+      for (int j = 0; j < 4; ++j) g[j] += __umul24(decode_step<false>(slot, dec, k[j], b), mult);   // both < 2^24
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] += decode_step<true>(slot, dec, k[j], b) * mult;
+      for (int j = 0; j < 4; ++j) g[j] += __umul24(decode_step<true>(slot, dec, k[j], b), mult);
     }
   }
+  const bool packed = kLds && gp.packed_agg >= 0;
+  if (!packed) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (kAllActive || active[j]) group_count<kLds>(t_cnt, g[j]);
+    for (int j = 0; j < 4; ++j) {
+      if (kAllActive || active[j]) group_count<kLds>(t_cnt, g[j]);
+    }
   }
   for (int a = 0; a < gp.num_group_aggs; ++a) {
     const DevGroupAgg& ga = gp.group_aggs[a];     // self-contained record
     const DevGroupAgg& col = ga;
     long long* acc = t_acc + (long long)a * G;
     int32_t v[4];
+    if (ga.vkind != kValI32) {
+      // SUM over a dictionary with 8-byte entries (LONG with a wide range: exact int64 add; FLOAT / DOUBLE: double add)
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      const int b = col.bits;
+      const LaneDec dec = make_lane_dec(b, lane);
+      const uint8_t* slot = stage + ga.slot_off;
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)col.dict, 0, col.dict_bytes, 0x00020000);
+      u32x2 w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t d = b <= 25 ? decode_step<false>(slot, dec, k[j], b) : decode_step<true>(slot, dec, k[j], b);
+        w[j] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (kAllActive || active[j]) ? d * 8u : 0xFFFFFFFFu, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kAllActive || active[j]) {
+          const long long bits = (long long)(((unsigned long long)w[j].y << 32) | (unsigned long long)w[j].x);
+          if (ga.vkind == kValI64) group_sum<kLds>(acc + g[j], bits);
+          else __hip_atomic_fetch_add(reinterpret_cast<double*>(acc + g[j]), __longlong_as_double(bits), __ATOMIC_RELAXED,
+                                      kLds ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      continue;
+    }
     if (col.is_raw) {
       const long long base_doc = (long long)tile * 64 * p.tile_steps;
       const long long last = (long long)p.num_docs - 1;
@@ -787,9 +986,10 @@ __device__ __forceinline__ void group_process4(const GroupParams& gp, const uint
     if (ga.kind == kGroupSum) {
       // plane offsets are unsigned fields; gathered / raw values are signed
       const bool is_unsigned = !col.is_raw && col.is_plane;
+      const long long one = (packed && a == gp.packed_agg) ? (1ll << gp.packed_shift) : 0ll;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (kAllActive || active[j]) group_sum<kLds>(acc + g[j], is_unsigned ? (long long)(uint32_t)v[j] : (long long)v[j]);
+        if (kAllActive || active[j]) group_sum<kLds>(acc + g[j], (is_unsigned ? (long long)(uint32_t)v[j] : (long long)v[j]) + one);
       }
     } else if (ga.kind == kGroupMin) {
 #pragma unroll
@@ -801,6 +1001,86 @@ __device__ __forceinline__ void group_process4(const GroupParams& gp, const uint
       for (int j = 0; j < 4; ++j) {
         if (kAllActive || active[j]) group_max<kLds>(acc + g[j], v[j]);
       }
+    }
+  }
+}
+
+// Sixteen consecutive steps of a tile whose docs all match: the group ids of the lane's sixteen docs stay in registers, the
+// column descriptors are read once per sixteen steps, and each column is decoded in one straight unrolled run (sixteen
+// LDS reads in flight, 3 VALU per decode) followed by its sixteen atomics.
+template <bool kLds>
+__device__ __forceinline__ void group_dense16(const GroupParams& gp, const uint8_t* stage, int tile, int lane, int k0,
+                                              unsigned long long* t_cnt, long long* t_acc) {
+  const ScanParams& p = gp.scan;
+  const int G = gp.num_groups;
+  uint32_t g[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) g[j] = 0u;
+  for (int c = 0; c < gp.num_group_cols; ++c) {
+    const DevGroupKey& key = gp.group_keys[c];
+    const int b = key.bits;
+    const LaneDec dec = make_lane_dec(b, lane);
+    const uint8_t* slot = stage + key.slot_off;
+    const uint32_t mult = (uint32_t)key.mult;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint32_t d[8];
+      decode_steps8(slot, dec, k0 + 8 * h, b, d);
+      // dictIds and multipliers are below 2^24 (the product of the cardinalities is at most 10 000): full-rate 24-bit multiply
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[8 * h + j] = c == 0 ? d[j] : __umul24(d[j], mult) + g[8 * h + j];
+    }
+  }
+  const bool packed = kLds && gp.packed_agg >= 0;
+  if (!packed) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) group_count<kLds>(t_cnt, g[j]);
+  }
+  for (int a = 0; a < gp.num_group_aggs; ++a) {
+    const DevGroupAgg& ga = gp.group_aggs[a];
+    long long* acc = t_acc + (long long)a * G;
+    int32_t v[16];
+    if (ga.is_raw) {
+      const long long base_doc = (long long)tile * 64 * p.tile_steps;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const long long doc = base_doc + (k0 + j) * 64 + lane;     // a full tile: every doc exists
+        v[j] = (int32_t)__builtin_bswap32(*reinterpret_cast<const uint32_t*>(ga.fwd + doc * 4));
+      }
+    } else {
+      const int b = ga.bits;
+      const LaneDec dec = make_lane_dec(b, lane);
+      const uint8_t* slot = stage + ga.slot_off;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t d[8];
+        decode_steps8(slot, dec, k0 + 8 * h, b, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[8 * h + j] = (int32_t)d[j];
+      }
+      if (ga.kind == kGroupSum && !ga.is_plane) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ga.dict, 0, ga.dict_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (uint32_t)v[j] * 4u, 0, 0);
+      }
+    }
+    if (ga.kind == kGroupSum) {
+      const bool is_unsigned = !ga.is_raw && ga.is_plane;
+      if (is_unsigned) {
+        // the packed count lives entirely in the high dword (packed_shift >= 32): the operand is the pair {field, 1 << (shift-32)}
+        const uint32_t one_hi = (packed && a == gp.packed_agg) ? (1u << (gp.packed_shift - 32)) : 0u;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) group_sum<kLds>(acc + g[j], (long long)(((unsigned long long)one_hi << 32) | (unsigned long long)(uint32_t)v[j]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) group_sum<kLds>(acc + g[j], (long long)v[j]);
+      }
+    } else if (ga.kind == kGroupMin) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) group_min<kLds>(acc + g[j], v[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) group_max<kLds>(acc + g[j], v[j]);
     }
   }
 }
@@ -862,13 +1142,9 @@ __global__ __launch_bounds__(kGroupBlockThreads) void scan_group_kernel(const Gr
         stage_columns<kDma>(p, tile, wave_lds, lane, false, true);
         if constexpr (kDma) wait_vmem();
       }
-      if (__builtin_amdgcn_ballot_w64(m != fullm) == 0ull) {
+      if (gp.dense_ok && __builtin_amdgcn_ballot_w64(m != fullm) == 0ull) {
         // every doc of the tile matches: walk the steps in order, no per-lane bookkeeping, no exec masking
-        const bool all[4] = {true, true, true, true};
-        for (int kb = 0; kb < steps; kb += 4) {
-          const int k[4] = {kb, kb + 1, kb + 2, kb + 3};
-          group_process4<kLdsTable, true>(gp, wave_lds, tile, lane, k, all, t_cnt, t_acc);
-        }
+        for (int kb = 0; kb < steps; kb += 16) group_dense16<kLdsTable>(gp, wave_lds, tile, lane, kb, t_cnt, t_acc);
       } else {
         uint32_t rem = m;
         for (;;) {
@@ -894,14 +1170,18 @@ __global__ __launch_bounds__(kGroupBlockThreads) void scan_group_kernel(const Gr
   if constexpr (kLdsTable) {
     __syncthreads();
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
-      const unsigned long long c = (unsigned long long)(uint32_t)t_cnt[g];
+      const bool packed = gp.packed_agg >= 0;
+      const unsigned long long pk = packed ? (unsigned long long)t_acc[(long long)gp.packed_agg * G + g] : 0ull;
+      const unsigned long long c = packed ? (pk >> gp.packed_shift) : (unsigned long long)(uint32_t)t_cnt[g];
       if (c == 0ull) continue;
       __hip_atomic_fetch_add(&gp.table_count[g], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int a = 0; a < NA; ++a) {
         const int kind = gp.group_aggs[a].kind;
         long long* slot = gp.table_acc + (long long)a * G + g;
-        const long long v = t_acc[(long long)a * G + g];
-        if (kind == kGroupSum) __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long v = t_acc[(long long)a * G + g];
+        if (packed && a == gp.packed_agg) v = (long long)(pk & ((1ull << gp.packed_shift) - 1ull));
+        if (kind == kGroupSum && gp.group_aggs[a].vkind == kValF64) __hip_atomic_fetch_add(reinterpret_cast<double*>(slot), __longlong_as_double(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (kind == kGroupSum) __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else if (kind == kGroupMin) __hip_atomic_fetch_min(slot, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else __hip_atomic_fetch_max(slot, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1055,22 +1335,38 @@ __device__ __forceinline__ uint32_t read_packed(const uint8_t* fwd, long long do
   return (uint32_t)((win >> (64 - s - b)) & ((1ull << b) - 1ull));
 }
 
-__global__ void gather_values_kernel(DevColumn col, const int32_t* __restrict__ doc_ids, int n, int32_t* out_dict_ids,
-                                     int32_t* out_ints, double* out_doubles) {
+__global__ void gather_values_kernel(DevColumn col, long long value_base, const int32_t* __restrict__ doc_ids, int n, int32_t* out_dict_ids,
+                                     int32_t* out_ints, long long* out_longs, double* out_doubles) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const long long doc = doc_ids[i];
-  int32_t v;
+  long long lv = 0;
+  double dv = 0.0;
+  const bool integral = col.vkind == kValI32 || col.vkind == kValI64;
+  const bool want_value = out_ints || out_longs || out_doubles;
   if (col.is_raw) {
-    v = (int32_t)__builtin_bswap32(*reinterpret_cast<const uint32_t*>(col.fwd + doc * 4));
     if (out_dict_ids) out_dict_ids[i] = -1;
+    if (col.vkind == kValI32) lv = (int32_t)__builtin_bswap32(*reinterpret_cast<const uint32_t*>(col.fwd + doc * 4));
+    else if (col.vkind == kValI64) lv = (long long)__builtin_bswap64(*reinterpret_cast<const unsigned long long*>(col.fwd + doc * 8));
+    else if (col.vkind == kValF32) dv = (double)__uint_as_float(__builtin_bswap32(*reinterpret_cast<const uint32_t*>(col.fwd + doc * 4)));
+    else dv = __longlong_as_double((long long)__builtin_bswap64(*reinterpret_cast<const unsigned long long*>(col.fwd + doc * 8)));
   } else {
     const uint32_t d = read_packed(col.fwd, doc, col.bits);
     if (out_dict_ids) out_dict_ids[i] = (int32_t)d;
-    v = (out_ints || out_doubles) ? col.dict[d] : 0;
+    if (want_value) {
+      if (col.vkind == kValI32) lv = value_base + (long long)col.dict[d];
+      else if (col.vkind == kValI64) lv = reinterpret_cast<const long long*>(col.dict)[d];
+      else dv = reinterpret_cast<const double*>(col.dict)[d];
+    }
   }
-  if (out_ints) out_ints[i] = v;
-  if (out_doubles) out_doubles[i] = (double)v;
+  if (integral) dv = (double)lv;
+  else {
+    // Java (long) double: NaN -> 0, saturating
+    lv = (dv != dv) ? 0ll : (dv >= 9.2233720368547758e18 ? 0x7FFFFFFFFFFFFFFFll : (dv <= -9.2233720368547758e18 ? (long long)0x8000000000000000ull : (long long)dv));
+  }
+  if (out_ints) out_ints[i] = (int32_t)lv;
+  if (out_longs) out_longs[i] = lv;
+  if (out_doubles) out_doubles[i] = dv;
 }
 
 }  // namespace pg

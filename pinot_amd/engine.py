@@ -83,5 +83,8 @@ class GpuSegment:
     def read_int_values(self, column, doc_ids):
         return self._read(self.lib.pg_read_int_values, column, doc_ids, np.int32, C.c_int32)
 
+    def read_long_values(self, column, doc_ids):
+        return self._read(self.lib.pg_read_long_values, column, doc_ids, np.int64, C.c_int64)
+
     def read_double_values(self, column, doc_ids):
         return self._read(self.lib.pg_read_double_values, column, doc_ids, np.float64, C.c_double)

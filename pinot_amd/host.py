@@ -29,6 +29,8 @@ def _lib():
     lib.ph_segment_create.argtypes = [C.c_char_p, C.c_int32]
     lib.ph_segment_add_int_column.restype = C.c_int32
     lib.ph_segment_add_int_column.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64]
+    lib.ph_segment_add_numeric_column.restype = C.c_int32
+    lib.ph_segment_add_numeric_column.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64]
     lib.ph_segment_add_string_column.restype = C.c_int32
     lib.ph_segment_add_string_column.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, vp, C.c_uint64, C.c_char_p, vp, C.c_uint64]
     lib.ph_segment_load.restype = C.c_int32
@@ -36,7 +38,10 @@ def _lib():
     lib.ph_segment_destroy.argtypes = [vp]
     lib.ph_plan_maker_init.restype = C.c_int32
     lib.ph_plan_maker_init.argtypes = [C.c_int32, C.c_int32]
-    for name in ("ph_parse_sql", "ph_lower_predicate", "ph_execute_sql"):
+    lib.ph_segment_load_directory.restype = vp
+    lib.ph_segment_load_directory.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
+    lib.ph_segment_describe.argtypes = [vp, C.POINTER(C.c_int32)]
+    for name in ("ph_parse_sql", "ph_lower_predicate", "ph_execute_sql", "ph_segment_describe"):
         getattr(lib, name).restype = vp
     lib.ph_parse_sql.argtypes = [C.c_char_p, C.POINTER(C.c_int32)]
     lib.ph_lower_predicate.argtypes = [C.c_char_p, vp, C.c_int32, C.POINTER(C.c_int32)]
@@ -91,14 +96,36 @@ class HostSegment:
                                                       values, inv_ptr, inv_size)
             else:
                 has_dict = c.encoding == _abi.PG_FWD_FIXED_BIT_DICT
-                st = lib.ph_segment_add_int_column(self.handle, c.name.encode(), int(has_dict), c.bits, c.cardinality, c.fwd.ctypes.data,
-                                                   c.fwd.nbytes, c.dictionary.ctypes.data if has_dict else None,
-                                                   c.dictionary.nbytes if has_dict else 0, inv_ptr, inv_size)
+                st = lib.ph_segment_add_numeric_column(self.handle, c.name.encode(), c.stored_type, int(has_dict), c.bits, c.cardinality,
+                                                       c.fwd.ctypes.data, c.fwd.nbytes, c.dictionary.ctypes.data if has_dict else None,
+                                                       c.dictionary.nbytes if has_dict else 0, inv_ptr, inv_size)
             if st != 0:
                 raise HostError(st, (lib.ph_last_error() or b"").decode())
         st = lib.ph_segment_load(self.handle, device)
         if st != 0:
             raise HostError(st, (lib.ph_last_error() or b"").decode())
+
+    def destroy(self):
+        if self.handle:
+            self.lib.ph_segment_destroy(self.handle)
+            self.handle = None
+
+
+class DirectorySegment:
+    """A v1 / v3 Pinot segment directory opened by the native loader (ImmutableSegmentLoader.load) and made HBM resident."""
+
+    def __init__(self, index_dir, device=0):
+        lib = _lib()
+        self.lib = lib
+        st = C.c_int32()
+        self.handle = C.c_void_p(lib.ph_segment_load_directory(str(index_dir).encode(), device, C.byref(st)))
+        if st.value != 0 or not self.handle:
+            self.handle = None
+            raise HostError(st.value, (lib.ph_last_error() or b"").decode("utf-8", "replace"))
+
+    def describe(self):
+        st = C.c_int32()
+        return _take_json(self.lib, self.lib.ph_segment_describe(self.handle, C.byref(st)), st)
 
     def destroy(self):
         if self.handle:

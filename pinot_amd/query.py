@@ -49,6 +49,17 @@ class Pred:
         """lo <= value <= hi, both inclusive (IntRawValueBasedRangePredicateEvaluator)."""
         return Pred(_abi.PG_PRED_RAW_RANGE, column, lo, hi, exclusive=exclusive)
 
+    @staticmethod
+    def raw_range_f64(column, lo, hi, exclusive=False):
+        """lo <= value <= hi on a raw FLOAT / DOUBLE column (Float / DoubleRawValueBasedRangePredicateEvaluator)."""
+        return Pred(_abi.PG_PRED_RAW_RANGE, column, f64_bits(lo), f64_bits(hi), exclusive=exclusive)
+
+
+def f64_bits(x):
+    """IEEE-754 bit pattern of a double as a signed 64-bit integer (how RAW_RANGE bounds of FLOAT / DOUBLE columns travel)."""
+    import struct
+    return struct.unpack("<q", struct.pack("<d", float(x)))[0]
+
 
 class Node:
     def __init__(self, op, children=(), pred=None):

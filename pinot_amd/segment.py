@@ -38,6 +38,12 @@ def load_host_library():
     lib.ph_raw_size_v2.argtypes = [C.c_int32, C.c_int32]
     lib.ph_raw_write_int_v2.restype = None
     lib.ph_raw_write_int_v2.argtypes = [i32p, C.c_int32, C.c_int32, u8p]
+    lib.ph_dict_write_fixed.restype = None
+    lib.ph_dict_write_fixed.argtypes = [C.c_void_p, C.c_int32, C.c_int32, u8p]
+    lib.ph_raw_size_fixed_v2.restype = C.c_int64
+    lib.ph_raw_size_fixed_v2.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.ph_raw_write_fixed_v2.restype = None
+    lib.ph_raw_write_fixed_v2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, u8p]
     lib.ph_roaring_serialize.restype = C.c_int64
     lib.ph_roaring_serialize.argtypes = [i32p, C.c_int64, C.c_int32, u8p]
     lib.ph_inverted_build.restype = C.c_int64
@@ -58,10 +64,24 @@ def host_threads():
     return max(1, min(32, os.cpu_count() or 1))
 
 
-class Column:
-    """One single-value INT column: forward index (+ dictionary, + optional inverted index) as raw bytes."""
+# stored type -> numpy host dtype of the values
+TYPE_DTYPES = {_abi.PG_TYPE_INT: np.int32, _abi.PG_TYPE_LONG: np.int64, _abi.PG_TYPE_FLOAT: np.float32, _abi.PG_TYPE_DOUBLE: np.float64}
 
-    def __init__(self, name, encoding, bits, cardinality, fwd, dictionary=None, inverted=None, dict_values=None):
+
+def stored_type_of(dtype):
+    dtype = np.dtype(dtype)
+    for t, d in TYPE_DTYPES.items():
+        if np.dtype(d) == dtype:
+            return t
+    raise TypeError("no Pinot stored type for %s" % dtype)
+
+
+class Column:
+    """One single-value numeric column: forward index (+ dictionary, + optional inverted index) as raw bytes."""
+
+    def __init__(self, name, encoding, bits, cardinality, fwd, dictionary=None, inverted=None, dict_values=None,
+                 stored_type=_abi.PG_TYPE_INT):
+        self.stored_type = stored_type
         self.name = name
         self.encoding = encoding
         self.bits = bits
@@ -101,6 +121,42 @@ class Column:
         return Column(name, _abi.PG_FWD_FIXED_BIT_DICT, bits, card, fwd, dictionary, inverted, dict_values)
 
     @staticmethod
+    def dict_encoded_typed(name, values, with_inverted=False):
+        """LONG / FLOAT / DOUBLE (or INT) dictionary column; the stored type follows the numpy dtype of `values`."""
+        lib = load_host_library()
+        values = np.ascontiguousarray(values)
+        st = stored_type_of(values.dtype)
+        if st == _abi.PG_TYPE_INT:
+            return Column.dict_encoded(name, values, with_inverted)
+        dict_values, dict_ids = np.unique(values, return_inverse=True)     # ascending, like SegmentDictionaryCreator
+        dict_values = np.ascontiguousarray(dict_values, dtype=values.dtype)
+        dict_ids = np.ascontiguousarray(dict_ids, dtype=np.int32)
+        card, n = int(dict_values.shape[0]), int(dict_ids.shape[0])
+        bits = int(lib.ph_num_bits_per_value(card - 1))
+        fwd = np.zeros(int(lib.ph_fixedbit_size(n, bits)), dtype=np.uint8)
+        if n:
+            lib.ph_fixedbit_pack(_i32p(dict_ids), n, bits, _u8p(fwd), host_threads())
+        dictionary = np.zeros(card * values.dtype.itemsize, dtype=np.uint8)
+        lib.ph_dict_write_fixed(dict_values.ctypes.data, card, values.dtype.itemsize, _u8p(dictionary))
+        inverted = None
+        if with_inverted:
+            size = int(lib.ph_inverted_build(_i32p(dict_ids), n, card, 1, None))
+            inverted = np.zeros(size, dtype=np.uint8)
+            lib.ph_inverted_build(_i32p(dict_ids), n, card, 1, _u8p(inverted))
+        return Column(name, _abi.PG_FWD_FIXED_BIT_DICT, bits, card, fwd, dictionary, inverted, dict_values, stored_type=st)
+
+    @staticmethod
+    def raw_typed(name, values, docs_per_chunk=1000):
+        """Raw PASS_THROUGH v2 chunks of INT / LONG / FLOAT / DOUBLE values."""
+        lib = load_host_library()
+        values = np.ascontiguousarray(values)
+        st = stored_type_of(values.dtype)
+        n, es = int(values.shape[0]), values.dtype.itemsize
+        fwd = np.zeros(int(lib.ph_raw_size_fixed_v2(n, docs_per_chunk, es)), dtype=np.uint8)
+        lib.ph_raw_write_fixed_v2(values.ctypes.data, n, docs_per_chunk, es, _u8p(fwd))
+        return Column(name, _abi.PG_FWD_RAW_FIXED_BYTE, 8 * es, 0, fwd, stored_type=st)
+
+    @staticmethod
     def synthetic_uniform(name, num_docs, dict_values, seed):
         """dictId_i = splitmix64-based uniform over the dictionary, generated and packed by the C++ writer."""
         lib = load_host_library()
@@ -123,7 +179,8 @@ class Column:
         return Column(name, _abi.PG_FWD_RAW_FIXED_BYTE, 32, 0, fwd)
 
     def value_of(self, dict_id):
-        return int(self.dict_values[dict_id])
+        v = self.dict_values[dict_id]
+        return int(v) if self.stored_type in (_abi.PG_TYPE_INT, _abi.PG_TYPE_LONG) else float(v)
 
 
 def synthetic_dict_ids(seed, start, count, cardinality):
@@ -146,7 +203,7 @@ class SegmentData:
         for i, c in enumerate(self.columns):
             d = self._descs[i]
             d.name = self._col_names[i]
-            d.stored_type = _abi.PG_TYPE_INT
+            d.stored_type = c.stored_type
             d.fwd_encoding = c.encoding
             d.bits_per_value = c.bits
             d.cardinality = c.cardinality

@@ -113,18 +113,28 @@ def golden_aggregations(seg):
     return [(Q.COUNT, -1), (Q.SUM, ci("column1")), (Q.MAX, ci("column3")), (Q.MIN, ci("column6")), (Q.AVG, ci("column7"))]
 
 
+# SUM / AVG over FLOAT / DOUBLE values: |device - reference| <= 1e-11 * |reference| (+1e-9 absolute); everything else is bit exact
+FP_SUM_RTOL = 1e-11
+FP_SUM_ATOL = 1e-9
+
+
 def assert_agg_equal(a, b, function, where=""):
     """Bit-exact comparison of two AggValue for the fields `function` defines."""
     assert a.count == b.count, "%s count %d != %d" % (where, a.count, b.count)
-    if function in (Q.SUM, Q.AVG):
+    if function in (Q.SUM, Q.AVG) and not b.sum_exact:
+        # FLOAT / DOUBLE columns: the reference adds doubles in doc order, the device in tile order; tolerance 1e-11 relative
+        assert not a.sum_exact, "%s: a floating-point sum must not be flagged exact" % where
+        assert (math.isnan(a.sum) and math.isnan(b.sum)) or math.isclose(a.sum, b.sum, rel_tol=FP_SUM_RTOL, abs_tol=FP_SUM_ATOL), \
+            "%s double sum %r != %r" % (where, a.sum, b.sum)
+    elif function in (Q.SUM, Q.AVG):
         assert a.sum_i64 == b.sum_i64, "%s exact sum %d != %d" % (where, a.sum_i64, b.sum_i64)
         assert a.sum == b.sum or abs(a.sum - b.sum) <= 1e-6 * abs(b.sum), "%s sum %r != %r" % (where, a.sum, b.sum)
         if abs(b.sum_i64) < 2 ** 53:
             assert a.sum == b.sum, "%s double sum %r != %r (below 2^53 must be bit exact)" % (where, a.sum, b.sum)
     if function == Q.MIN:
-        assert a.min == b.min or (math.isinf(a.min) and math.isinf(b.min)), "%s min %r != %r" % (where, a.min, b.min)
+        assert a.min == b.min or (math.isnan(a.min) and math.isnan(b.min)), "%s min %r != %r" % (where, a.min, b.min)
     if function == Q.MAX:
-        assert a.max == b.max or (math.isinf(a.max) and math.isinf(b.max)), "%s max %r != %r" % (where, a.max, b.max)
+        assert a.max == b.max or (math.isnan(a.max) and math.isnan(b.max)), "%s max %r != %r" % (where, a.max, b.max)
 
 
 def assert_results_equal(got, want, check_stats=True):

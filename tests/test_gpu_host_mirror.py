@@ -78,3 +78,53 @@ def test_plan_time_rejection_and_errors(golden_segments):
         with pytest.raises(host.HostError) as e:
             host.execute_sql(segs[:1], sql)
         assert e.value.status == status, sql
+
+
+def test_sql_over_the_segment_written_by_the_reference():
+    """paddingOld (pinot-core/src/test/resources/data/paddingOld.tar.gz): INT `age`, FLOAT `percent`, LONG `outgoingName1`,
+    STRING `name` -- the bytes the reference's Java writers produced, queried with SQL through the C++ plan maker."""
+    import json
+    import os
+    from pinot_amd import _abi
+    from pinot_amd import segment as S
+    import torch  # noqa: F401
+    host.init_plan_maker(device=0, time_kernels=False)
+    p = json.load(open(os.path.join(H.GOLDEN_DIR, "pinot_v1_segment_paddingOld.json")))
+    types = {"age": _abi.PG_TYPE_INT, "percent": _abi.PG_TYPE_FLOAT, "outgoingName1": _abi.PG_TYPE_LONG, "name": _abi.PG_TYPE_INT}
+    cols, raw = [], {}
+    for name, st in types.items():
+        c = p["columns"][name]
+        raw[name] = bytes.fromhex(c["dict_hex"])
+        dict_bytes = np.frombuffer(raw[name], dtype=np.uint8).copy()
+        if name == "name":      # STRING dictionary: fixed-length padded entries; the device only sees dictIds
+            dict_bytes = np.arange(c["cardinality"], dtype=">i4").view(np.uint8).copy()
+        cols.append(S.Column(name, _abi.PG_FWD_FIXED_BIT_DICT, c["bitsPerElement"], c["cardinality"],
+                             np.frombuffer(bytes.fromhex(c["fwd_hex"]), dtype=np.uint8).copy(), dict_bytes, stored_type=st))
+    width = len(raw["name"]) // p["columns"]["name"]["cardinality"]
+    names = [raw["name"][i * width:(i + 1) * width].decode().rstrip("%\0") for i in range(p["columns"]["name"]["cardinality"])]
+    data = S.SegmentData("paddingOld", p["total_docs"], cols)
+    seg = host.HostSegment(data, string_dicts={"name": names})
+    try:
+        ages = np.frombuffer(raw["age"], dtype=">i4").astype(np.int64)
+        longs = np.frombuffer(raw["outgoingName1"], dtype=">i8").astype(np.int64)
+        floats = np.frombuffer(raw["percent"], dtype=">f4").astype(np.float32)
+        b = host.execute_sql([seg], "SELECT COUNT(*), SUM(age), SUM(outgoingName1), MAX(outgoingName1), MIN(percent), SUM(percent) FROM t")["segments"][0]
+        got = b["intermediate"]
+        assert got[:5] == [5, float(ages.sum()), float(longs.sum()), float(longs.max()), float(floats.min())]
+        assert abs(got[5] - float(floats.astype(np.float64).sum())) <= 1e-11 * abs(got[5])
+        # predicates on the LONG and FLOAT dictionaries (LongDictionary / FloatDictionary.insertionIndexOf)
+        thr = int(longs[2])
+        b = host.execute_sql([seg], "SELECT COUNT(*), SUM(outgoingName1) FROM t WHERE outgoingName1 >= %d" % thr)["segments"][0]
+        assert b["intermediate"] == [int((longs >= thr).sum()), float(longs[longs >= thr].sum())]
+        fthr = float(floats[1])
+        b = host.execute_sql([seg], "SELECT COUNT(*) FROM t WHERE percent > %r" % fthr)["segments"][0]
+        assert b["intermediate"] == [int((floats > np.float32(fthr)).sum())]
+        # group by the STRING column: keys come back as dictionary values
+        g = host.execute_sql([seg], "SELECT COUNT(*), SUM(outgoingName1) FROM t GROUP BY name")["segments"][0]
+        assert sorted(r["key"][0] for r in g["groups"]) == sorted(names)
+        assert sum(r["intermediate"][0] for r in g["groups"]) == 5 and sum(r["intermediate"][1] for r in g["groups"]) == float(longs.sum())
+        # group by the LONG column
+        g = host.execute_sql([seg], "SELECT COUNT(*) FROM t GROUP BY outgoingName1")["segments"][0]
+        assert sorted(r["key"][0] for r in g["groups"]) == sorted(int(x) for x in longs)
+    finally:
+        seg.destroy()

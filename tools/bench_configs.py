@@ -39,7 +39,12 @@ def timed(gseg, spec, reps=8):
     return sum(ms) / len(ms), min(ms), sum(dev) / len(dev)
 
 
+MATCH = None
+
+
 def report(out, name, n, nbytes, gseg, seg, spec, check=True):
+    if MATCH is not None and not MATCH.search(name):
+        return
     avg, best, dev = timed(gseg, spec)
     got = gseg.execute(spec)
     ok = None
@@ -71,7 +76,12 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--profile-waves", action="store_true")
     ap.add_argument("--only", default="")
+    ap.add_argument("--match", default="", help="regexp: run only the queries whose label matches (segments nobody needs are skipped)")
     args = ap.parse_args()
+    import re
+    global MATCH
+    MATCH = re.compile(args.match) if args.match else None
+    want = lambda prefix: MATCH is None or prefix in args.match
     engine = Engine(device_id=0, time_kernels=True, profile_waves=args.profile_waves)
     out = []
     check = not args.no_check
@@ -79,7 +89,7 @@ def main():
 
     only = args.only
     # ---- C1: 10 M rows, raw int32 forward index ----
-    n1 = 10_000_000
+    n1 = 10_000_000 if want("C1") else 1000
     vals = S.synthetic_dict_ids(42, 0, n1, 1_000_000)
     raw = S.Column.raw("raw_i32", vals)
     seg1 = S.SegmentData("c1", n1, [raw])
@@ -113,7 +123,7 @@ def main():
     del seg, f, k, a, b
 
     # ---- C5: inverted-index AND of 3 postings -> docIds -> gather + SUM ----
-    n5 = args.rows_c5
+    n5 = args.rows_c5 if want("C5") else 100_000
     t0 = time.time()
     cols = []
     for name, card, seed in (("p", 16, 11), ("q", 64, 12), ("r", 256, 13)):

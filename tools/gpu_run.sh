@@ -11,6 +11,38 @@ smoke)
   echo "== smoke =="; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ;;
 micro)
   echo "== microbench =="; timeout 300 ./tools/microbench > $OUT/microbench.jsonl 2>&1; tail -60 $OUT/microbench.jsonl ;;
+atomics)
+  echo "== lds atomic mixes =="; timeout 300 ./tools/microbench atomics 2>&1 | tee $OUT/microbench_atomics.jsonl ;;
+c3)
+  echo "== group-by tests + C3 =="; timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "group" 2>&1 | tail -5
+  for v in ${C3_VARIANTS:-"PINOT_GPU_GROUP_PACK=1" "PINOT_GPU_GROUP_PACK=0" "PINOT_GPU_GROUP_WAVES=8" "PINOT_GPU_TILE_STEPS=32"}; do
+    echo "-- $v"; NC=--no-check; [ "$v" = "PINOT_GPU_GROUP_PACK=1" ] && NC=""; env $v timeout 900 python tools/bench_configs.py --match "C3|GROUP" --only c23 $NC 2>&1 | grep -E "C3|GROUP|Error|error" | python -c "
+import sys,json
+for l in sys.stdin:
+    try: d=json.loads(l); print('   %-52s %.3f ms %6.0f GB/s exact=%s' % (d['config'], d['kernel_ms'], d['GBps'], d['bit_exact_vs_oracle']))
+    except Exception: print(l.rstrip())"
+  done ;;
+c3sq)
+  echo "== rocprof SQ counters, C3 =="; cd /tmp && export TMPDIR=/tmp
+  for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_WAVES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS"; do
+    rm -rf $OUT/pmc_c3; timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_c3 -o c3 -- python $GRAFT_REPO_ROOT/tools/bench_configs.py --match "C3 SUM\(a\), MAX\(b\) GROUP" --only c23 --no-check > $OUT/pmc_c3.log 2>&1
+    tail -1 $OUT/pmc_c3.log
+    for f in $(find $OUT/pmc_c3 -name "*counter_collection*.csv"); do python - "$f" <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    if 'scan_group' in r['Kernel_Name']:
+        agg[r['Counter_Name']][r['Dispatch_Id']].append(float(r['Counter_Value']))
+for c, d in agg.items():
+    vals = [sum(v) for v in d.values()]
+    print('   %-24s per-dispatch mean %.4g (n=%d)' % (c, sum(vals) / len(vals), len(vals)))
+PY
+    done
+  done
+  cd $GRAFT_REPO_ROOT ;;
+golden)
+  echo "== pytest gpu golden =="; timeout 900 python -m pytest tests/test_gpu_golden.py -m gpu -x -q 2>&1 | tail -8 ;;
 test)
   echo "== pytest gpu =="; timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 ;;
 testall)

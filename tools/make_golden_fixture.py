@@ -139,6 +139,43 @@ def export_prebuilt_segment():
     print("wrote", path)
 
 
+def export_segment_directories():
+    """The three complete v1 segment directories under pinot-core/src/test/resources/data/ (paddingOld / paddingPercent /
+    paddingNull: 5 docs, INT + FLOAT + LONG + STRING columns, written by the reference's Java segment creator with the three
+    string-padding conventions).  Every file is stored as hex so a test can lay the directory out again and open it with the
+    native segment loader."""
+    import tarfile
+    out = {}
+    for name in ("paddingOld", "paddingPercent", "paddingNull"):
+        src = "/root/reference/pinot-core/src/test/resources/data/%s.tar.gz" % name
+        with tarfile.open(src) as tar:
+            out[name] = {"_source": src, "files": {m.name.split("/", 1)[1]: tar.extractfile(m).read().hex() for m in tar.getmembers() if m.isfile()}}
+    # a real index_map (keys only need to pin the syntax): the star-tree test segment's
+    lines = [l for l in open("/root/reference/pinot-segment-local/src/test/resources/data/startree/segment/index_map").read().splitlines()
+             if l and not l.startswith("#")]
+    out["_index_map_sample"] = {"_source": "pinot-segment-local/src/test/resources/data/startree/segment/index_map", "lines": lines[:12]}
+    path = os.path.join(os.path.dirname(OUT), "pinot_v1_segment_directories.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def export_raw_chunk_fixture():
+    """pinot-segment-local/src/test/resources/data/fixedByteRaw.v2: a PASS_THROUGH version-2 fixed-byte chunk file written by
+    the reference (2000 doubles, value i = i + 100.2356 -- FixedByteChunkSVForwardIndexTest.java:352-375
+    testBackwardCompatibilityV2).  Pins the chunk header / offset table layout and the big-endian value bytes."""
+    import base64
+    src = "/root/reference/pinot-segment-local/src/test/resources/data/fixedByteRaw.v2"
+    data = open(src, "rb").read()
+    path = os.path.join(os.path.dirname(OUT), "fixedByteRaw_v2.json")
+    with open(path, "w") as f:
+        json.dump({"_source": src, "num_docs": 2000, "start_value": 100.2356, "stored_type": "DOUBLE",
+                   "file_base64": base64.b64encode(data).decode()}, f)
+    print("wrote", path, len(data), "bytes")
+
+
 if __name__ == "__main__":
     main()
     export_prebuilt_segment()
+    export_raw_chunk_fixture()
+    export_segment_directories()

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <cstring>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -153,6 +154,30 @@ __global__ __launch_bounds__(256) void lds_atomics(int groups, int iters, unsign
   if (tab[threadIdx.x % (groups * 3)] == 0x1234567ull) out[0] = 1;
 }
 
+// 4b. the group-by update mixes: which LDS atomic widths / counts does a row cost?  Cheap LCG keys so the atomics dominate.
+//   0: u32 add            1: u64 add           2: u32 add + u64 add + i32 max (count, sum, max)
+//   3: u64 add + i32 max (count packed into the sum word)      4: u32 add + i32 max      5: two u32 adds + i32 max
+template <int kMode>
+__global__ __launch_bounds__(1024) void lds_atomic_mix(int groups, int iters, unsigned long long* out) {
+  extern __shared__ unsigned long long tab[];
+  for (int i = threadIdx.x; i < groups * 3; i += blockDim.x) tab[i] = 0;
+  __syncthreads();
+  uint32_t x = blockIdx.x * 1024u + threadIdx.x + 1u;
+  uint32_t* t32 = reinterpret_cast<uint32_t*>(tab);
+  for (int it = 0; it < iters; ++it) {
+    x = x * 1664525u + 1013904223u;
+    const uint32_t g = __umulhi(x, (uint32_t)groups);
+    const uint32_t v = x & 0xFFFFFu;
+    if (kMode == 0 || kMode == 2 || kMode == 4 || kMode == 5) __hip_atomic_fetch_add(&t32[2 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (kMode == 1 || kMode == 2) __hip_atomic_fetch_add(&tab[groups + g], (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (kMode == 3) __hip_atomic_fetch_add(&tab[groups + g], (1ull << 42) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (kMode == 5) __hip_atomic_fetch_add(&t32[2 * (groups + g)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (kMode >= 2) __hip_atomic_fetch_max((int32_t*)&t32[2 * (2 * groups + g)], (int32_t)(x >> 12), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  if (tab[threadIdx.x % (groups * 3)] == 0x1234567ull) out[0] = 1;
+}
+
 
 // 6. VALU issue rate of the integer ops the decode loop is made of (is a wave64 op 2 or 4 cycles on a SIMD?)
 template <int kOp>
@@ -217,7 +242,8 @@ double time_ms(F launch, int reps) {
   return ms / reps;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool only_atomics = argc > 1 && !strcmp(argv[1], "atomics");
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, \"hbm_gb\": %.1f, \"lds_per_block\": %zu}\n", prop.gcnArchName,
@@ -225,6 +251,26 @@ int main() {
   const int cus = prop.multiProcessorCount;
   unsigned long long* d_out;
   CHECK(hipMalloc((void**)&d_out, 64));
+
+  if (only_atomics) {
+    for (int groups : {1000}) {
+      for (int threads : {256, 1024}) {
+        const int iters = 4096, blocks = cus * (1024 / threads);
+        double m[6];
+        m[0] = time_ms([&] { lds_atomic_mix<0><<<blocks, threads, groups * 24>>>(groups, iters, d_out); }, 3);
+        m[1] = time_ms([&] { lds_atomic_mix<1><<<blocks, threads, groups * 24>>>(groups, iters, d_out); }, 3);
+        m[2] = time_ms([&] { lds_atomic_mix<2><<<blocks, threads, groups * 24>>>(groups, iters, d_out); }, 3);
+        m[3] = time_ms([&] { lds_atomic_mix<3><<<blocks, threads, groups * 24>>>(groups, iters, d_out); }, 3);
+        m[4] = time_ms([&] { lds_atomic_mix<4><<<blocks, threads, groups * 24>>>(groups, iters, d_out); }, 3);
+        m[5] = time_ms([&] { lds_atomic_mix<5><<<blocks, threads, groups * 24>>>(groups, iters, d_out); }, 3);
+        const double rows = (double)blocks * threads * iters;
+        printf("{\"bench\": \"lds_atomic_mix\", \"groups\": %d, \"threads\": %d, \"rows_per_s\": {\"u32\": %.3e, \"u64\": %.3e, \"u32+u64+max32\": %.3e, "
+               "\"u64packed+max32\": %.3e, \"u32+max32\": %.3e, \"u32+u32+max32\": %.3e}}\n", groups, threads,
+               rows / m[0] * 1e3, rows / m[1] * 1e3, rows / m[2] * 1e3, rows / m[3] * 1e3, rows / m[4] * 1e3, rows / m[5] * 1e3);
+      }
+    }
+    return 0;
+  }
 
   // streaming
   const size_t bytes = 4ull << 30;
