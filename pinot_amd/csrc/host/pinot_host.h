@@ -6,6 +6,7 @@
 // unless noted).  The only way this layer computes anything is by calling the pg_* C ABI (include/pinot_gpu.h),
 // resolved with dlopen from libpinot_gpu.so: there is no CPU execution path here.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -33,7 +34,7 @@ class Dictionary {
   virtual ~Dictionary() = default;
   virtual DataType getValueType() const = 0;
   virtual int length() const = 0;
-  bool isSorted() const { return true; }
+  virtual bool isSorted() const { return true; }
   // Returns the dictId of the value, or -(insertionIndex + 1) when absent (BaseImmutableDictionary.java:124-140).
   virtual int insertionIndexOf(const std::string& stringValue) const = 0;
   int indexOf(const std::string& stringValue) const { int i = insertionIndexOf(stringValue); return i >= 0 ? i : -1; }
@@ -109,7 +110,10 @@ class DoubleDictionary : public Dictionary {
 // mapped back here (segl/segment/index/readers/StringDictionary.java).
 class StringDictionary : public Dictionary {
  public:
-  explicit StringDictionary(std::vector<std::string> sortedValues) : _values(std::move(sortedValues)) {}
+  // Values in dictId order.  Legacy segments pad strings with '%', and the padded order (what the file is sorted by) can differ
+  // from the order of the un-padded values ("lynda 2.0" < "lynda%%%%"): then lookups are linear and range predicates are not offloaded.
+  explicit StringDictionary(std::vector<std::string> values) : _values(std::move(values)), _sorted(std::is_sorted(_values.begin(), _values.end())) {}
+  bool isSorted() const override { return _sorted; }
   DataType getValueType() const override { return DataType::STRING; }
   int length() const override { return (int)_values.size(); }
   int insertionIndexOf(const std::string& stringValue) const override;
@@ -118,6 +122,7 @@ class StringDictionary : public Dictionary {
   std::string getStringValue(int dictId) const override { return _values.at((size_t)dictId); }
  private:
   std::vector<std::string> _values;
+  bool _sorted;
 };
 
 // ---- sspi/datasource/DataSource.java:46-132 + DataSourceMetadata ------------------------------------------------

@@ -114,6 +114,10 @@ int DoubleDictionary::insertionIndexOf(const std::string& stringValue) const {
 }
 
 int StringDictionary::insertionIndexOf(const std::string& stringValue) const {
+  if (!_sorted) {
+    for (size_t i = 0; i < _values.size(); ++i) if (_values[i] == stringValue) return (int)i;
+    return -1;     // absent; the insertion point is meaningless here and RANGE predicates are rejected before they ask for it
+  }
   auto it = std::lower_bound(_values.begin(), _values.end(), stringValue);
   if (it != _values.end() && *it == stringValue) return (int)(it - _values.begin());
   return -((int)(it - _values.begin()) + 1);
@@ -394,6 +398,7 @@ PredicateEvaluator getPredicateEvaluator(const Predicate& predicate, const DataS
     }
     case Predicate::Type::RANGE: {
       // SortedDictionaryBasedRangePredicateEvaluator, RangePredicateEvaluatorFactory.java:126-169
+      if (!dict.isSorted()) throw UnsupportedOperationException("range predicate on a dictionary whose un-padded values are not sorted");
       ev.isRange = true;
       if (predicate.lowerBound == "*") ev.startDictId = 0;
       else {

@@ -214,6 +214,7 @@ struct DevGroupKey {
   int32_t slot_off;
   int32_t mult;
   int32_t pad;
+  const uint8_t* fwd;      // the key column's packed dictId stream (group_private_kernel reads it straight from HBM)
 };
 
 // Global (and LDS) group table layout, struct-of-arrays per group id g in [0, num_groups):

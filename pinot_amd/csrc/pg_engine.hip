@@ -51,6 +51,7 @@ struct Engine {
   int value_plane = -1;      // -1 auto, 0 never, 1 always (PINOT_GPU_VALUE_PLANE)
   int tile_steps = 0;        // 0 auto, 16 or 32 forced (PINOT_GPU_TILE_STEPS)
   bool double_buffer = false;
+  bool group_private = true; // PINOT_GPU_GROUP_PRIVATE=0: unfiltered group-by through the LDS-staged kernel
   bool group_pack = true;    // PINOT_GPU_GROUP_PACK=0: separate count atomic in the group-by LDS table
   int group_waves = 0;       // PINOT_GPU_GROUP_WAVES: cap on wavefronts per group-by workgroup (default 16)
   std::mutex mu;
@@ -791,6 +792,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.value_plane = vp ? atoi(vp) : -1;
   const char* db = getenv("PINOT_GPU_DOUBLE_BUFFER");
   g_engine.double_buffer = db && db[0] == '1';
+  const char* gpv = getenv("PINOT_GPU_GROUP_PRIVATE");
+  g_engine.group_private = !(gpv && gpv[0] == '0');
   const char* gpk = getenv("PINOT_GPU_GROUP_PACK");
   g_engine.group_pack = !(gpk && gpk[0] == '0');
   const char* gw = getenv("PINOT_GPU_GROUP_WAVES");
@@ -1240,7 +1243,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     sp.speculate = 1;
     for (int g = 0; g < ng; ++g) {
       const DevColumn& c = pl.cols[group_slot[g]];
-      gp.group_keys[g] = DevGroupKey{c.bits, c.slot_off, group_mult[g], 0};
+      gp.group_keys[g] = DevGroupKey{c.bits, c.slot_off, group_mult[g], 0, c.fwd};
     }
     for (int a = 0; a < gp.num_group_aggs; ++a) {
       const DevColumn& c = pl.cols[plan_aggs[a].col];
@@ -1258,15 +1261,36 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         if ((double)seg->num_docs * max_abs >= 9.2e18) return fail(PG_ERR_UNSUPPORTED, "group-by SUM of LONG column %s could overflow int64", sc.name.c_str());
       }
     }
+    // Without a filter every tile is aggregated in full: the lane-private kernel decodes straight from HBM and needs LDS only
+    // for the table (group_private_kernel).
+    const bool use_private = g_engine.group_private && pl.num_nodes == 0 && gp.dense_ok && !want_bitmap;
+    int pblocks = blocks, pthreads = geo.threads;
+    size_t plds = lds;
+    if (use_private) {
+      static const int private_wave_cap = max_waves_per_cu(group_private_kernel<true>);
+      const bool in_lds = table_bytes <= 96 * 1024;
+      gp.use_lds_table = in_lds ? 1 : 0;
+      int waves = in_lds ? kGroupBlockThreads / 64 : kBlockThreads / 64;
+      if (g_engine.group_waves > 0) waves = std::min(waves, g_engine.group_waves);
+      while (waves > private_wave_cap) waves >>= 1;
+      pthreads = waves * 64;
+      plds = in_lds ? table_bytes : 0;
+      int bpc = std::max(1, private_wave_cap / waves);
+      if (in_lds) bpc = std::max(1, std::min(bpc, (int)(kLdsBudget / std::max<size_t>(plds, 1))));
+      if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
+      const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
+      pblocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + waves - 1) / waves, (long long)seg->num_cus * bpc));
+    }
     // Count packing: when the first summed value plane is narrow enough, its 64-bit LDS slot carries (count << shift) | sum
     // and the separate count atomic disappears.  Safe while a workgroup sees fewer than 2^cbits docs:
     // sum < 2^cbits * 2^w = 2^shift and count < 2^cbits, so cbits + shift <= 64 never carries into or out of the count.
     gp.packed_agg = -1;
     gp.packed_shift = 0;
     if (gp.use_lds_table && g_engine.group_pack) {
-      const long long waves_total = (long long)blocks * (geo.threads / 64);
-      const long long tiles_per_wave = (sp.num_tiles + waves_total - 1) / waves_total;
-      const long long docs_per_block = tiles_per_wave * (geo.threads / 64) * 64 * sp.tile_steps;
+      const long long waves_total = use_private ? (long long)pblocks * (pthreads / 64) : (long long)blocks * (geo.threads / 64);
+      const long long tiles_total = use_private ? ((long long)seg->num_docs + 2047) / 2048 : (long long)sp.num_tiles;
+      const long long tiles_per_wave = (tiles_total + waves_total - 1) / waves_total;
+      const long long docs_per_block = use_private ? tiles_per_wave * (pthreads / 64) * 2048 : tiles_per_wave * (geo.threads / 64) * 64 * sp.tile_steps;
       int cbits = 1;
       while ((1ll << cbits) <= docs_per_block) ++cbits;
       for (int a = 0; a < gp.num_group_aggs; ++a) {
@@ -1280,7 +1304,10 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     init_group_table_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(gp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
-    if (gp.use_lds_table) {
+    if (use_private) {
+      if (gp.use_lds_table) { set_dynamic_lds(group_private_kernel<true>, plds); group_private_kernel<true><<<dim3((unsigned)pblocks), dim3((unsigned)pthreads), plds, ctx->stream>>>(gp); }
+      else group_private_kernel<false><<<dim3((unsigned)pblocks), dim3((unsigned)pthreads), 0, ctx->stream>>>(gp);
+    } else if (gp.use_lds_table) {
       if (g_engine.use_dma) { set_dynamic_lds(scan_group_kernel<true, true>, lds); scan_group_kernel<true, true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(gp); }
       else { set_dynamic_lds(scan_group_kernel<false, true>, lds); scan_group_kernel<false, true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(gp); }
     } else {

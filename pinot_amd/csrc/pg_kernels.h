@@ -1189,6 +1189,173 @@ __global__ __launch_bounds__(kGroupBlockThreads) void scan_group_kernel(const Gr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Group-by without a filter: lane-private decode straight from HBM, no LDS staging at all.
+//
+// Lane i of the wave that owns a 2048-doc tile owns the 32 CONSECUTIVE docs 32*i .. 32*i+31, i.e. the B consecutive dwords
+// i*B .. i*B+B-1 of the tile's 256*B-byte image of a B-bit column.  It loads them with plain global loads (every byte is used;
+// the L1 keeps the lines between the wave's dwordx4 instructions: `lane_contiguous_read` in tools/microbench.hip streams at the
+// same 6.2-6.5 TB/s as fully coalesced loads for every width) and extracts its 32 values from registers with shifts whose
+// positions are compile-time constants: one v_bfe_u32, or v_alignbit_b32 + v_and_b32 when a value straddles two dwords, plus one
+// byte swap per dword.  The LDS pipe, which bounds the staged kernel (three 8-byte reads per doc + the DMA writes + the atomics),
+// is left with the group-table atomics only.
+// ------------------------------------------------------------------------------------------------
+// Values 16*H .. 16*H+15 of the lane's 32 (H = 0, 1).  `lane_words` = first dword of the lane's B-dword chunk.
+template <int B, int H>
+__device__ __forceinline__ void decode16_private(const uint32_t* __restrict__ lane_words, uint32_t (&v)[16]) {
+  constexpr int first_bit = 16 * B * H;
+  constexpr int w0 = first_bit >> 5;
+  constexpr int w1 = (16 * B * (H + 1) - 1) >> 5;
+  constexpr int NW = w1 - w0 + 1;
+  uint32_t d[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) d[i] = __builtin_bswap32(lane_words[w0 + i]);     // big-endian bit stream
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int bit = first_bit + j * B - w0 * 32;
+    const int i = bit >> 5, o = bit & 31;
+    if (o + B <= 32) v[j] = __builtin_amdgcn_ubfe(d[i], 32 - o - B, B);
+    else v[j] = __builtin_amdgcn_alignbit(d[i], d[(i + 1) < NW ? (i + 1) : i], 64 - o - B) & ((1u << B) - 1u);
+  }
+}
+
+template <int H>
+__device__ __forceinline__ void decode16_private_dispatch(int b, const uint32_t* lane_words, uint32_t (&v)[16]) {
+  switch (b) {
+#define PG_CASE(B) case B: decode16_private<B, H>(lane_words, v); break;
+    PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10)
+    PG_CASE(11) PG_CASE(12) PG_CASE(13) PG_CASE(14) PG_CASE(15) PG_CASE(16) PG_CASE(17) PG_CASE(18) PG_CASE(19) PG_CASE(20)
+    PG_CASE(21) PG_CASE(22) PG_CASE(23) PG_CASE(24) PG_CASE(25) PG_CASE(26) PG_CASE(27) PG_CASE(28) PG_CASE(29) PG_CASE(30)
+    PG_CASE(31)
+#undef PG_CASE
+    default:
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = 0u;
+  }
+}
+
+// One 2048-doc tile.  kTail: the last, partial tile -- docs past numDocs are masked out of every atomic.
+template <bool kLds, bool kTail>
+__device__ __forceinline__ void group_private_tile(const GroupParams& gp, long long tile, int lane, unsigned long long* t_cnt, long long* t_acc) {
+  const int G = gp.num_groups;
+  const long long first_doc = tile * 2048 + lane * 32;
+  const int valid = kTail ? (int)((long long)gp.scan.num_docs - first_doc) : 32;      // docs of this lane that exist
+  uint32_t g[32];
+  for (int c = 0; c < gp.num_group_cols; ++c) {
+    const DevGroupKey& key = gp.group_keys[c];
+    const int b = key.bits;
+    const uint32_t mult = (uint32_t)key.mult;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(key.fwd + tile * (256ll * b)) + lane * b;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint32_t d[16];
+      if (h == 0) decode16_private_dispatch<0>(b, words, d); else decode16_private_dispatch<1>(b, words, d);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : __umul24(d[j], mult) + g[16 * h + j];
+    }
+  }
+  const bool packed = kLds && gp.packed_agg >= 0;
+  if (!packed) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) if (!kTail || j < valid) group_count<kLds>(t_cnt, g[j]);
+  }
+  for (int a = 0; a < gp.num_group_aggs; ++a) {
+    const DevGroupAgg& ga = gp.group_aggs[a];
+    long long* acc = t_acc + (long long)a * G;
+    const int b = ga.bits;
+    const uint32_t* words = ga.is_raw ? reinterpret_cast<const uint32_t*>(ga.fwd) + first_doc
+                                      : reinterpret_cast<const uint32_t*>(ga.fwd + tile * (256ll * b)) + lane * b;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ga.dict, 0, ga.dict_bytes, 0x00020000);
+    const bool is_unsigned = !ga.is_raw && ga.is_plane;
+    const uint32_t one_hi = (packed && a == gp.packed_agg) ? (1u << (gp.packed_shift - 32)) : 0u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint32_t d[16];
+      if (ga.is_raw) {
+        // raw INT column: the lane's 32 docs are 128 contiguous bytes
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d[j] = (!kTail || 16 * h + j < valid) ? __builtin_bswap32(words[16 * h + j]) : 0u;
+      } else {
+        if (h == 0) decode16_private_dispatch<0>(b, words, d); else decode16_private_dispatch<1>(b, words, d);
+        if (ga.kind == kGroupSum && !ga.is_plane) {
+          // dictionary gather (small dictionaries / PINOT_GPU_VALUE_PLANE=0)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) d[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, d[j] * 4u, 0, 0);
+        }
+      }
+      if (ga.kind == kGroupSum && is_unsigned) {
+        // plane field; the packed count lives entirely in the high dword: the operand is the register pair {field, one_hi}
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (!kTail || 16 * h + j < valid) group_sum<kLds>(acc + g[16 * h + j], (long long)(((unsigned long long)one_hi << 32) | (unsigned long long)d[j]));
+      } else if (ga.kind == kGroupSum) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (!kTail || 16 * h + j < valid) group_sum<kLds>(acc + g[16 * h + j], (long long)(int32_t)d[j]);
+      } else if (ga.kind == kGroupMin) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (!kTail || 16 * h + j < valid) group_min<kLds>(acc + g[16 * h + j], (int32_t)d[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (!kTail || 16 * h + j < valid) group_max<kLds>(acc + g[16 * h + j], (int32_t)d[j]);
+      }
+    }
+  }
+}
+
+template <bool kLdsTable>
+__global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const GroupParams gp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  const long long total_waves = (long long)gridDim.x * waves_per_block;
+  const int G = gp.num_groups;
+  const int NA = gp.num_group_aggs;
+  unsigned long long* t_cnt;
+  long long* t_acc;
+  if constexpr (kLdsTable) {
+    t_cnt = reinterpret_cast<unsigned long long*>(smem);
+    t_acc = reinterpret_cast<long long*>(t_cnt + G);
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+      t_cnt[g] = 0ull;
+      for (int a = 0; a < NA; ++a) {
+        const int kind = gp.group_aggs[a].kind;
+        t_acc[(long long)a * G + g] = kind == kGroupSum ? 0ll : (kind == kGroupMin ? 0x7FFFFFFFll : (long long)(uint32_t)0x80000000u);
+      }
+    }
+    __syncthreads();
+  } else {
+    t_cnt = gp.table_count;
+    t_acc = gp.table_acc;
+  }
+  const long long full_tiles = (long long)gp.scan.num_docs / 2048;
+  const long long wave = (long long)blockIdx.x * waves_per_block + wave_in_block;
+  for (long long tile = wave; tile < full_tiles; tile += total_waves) group_private_tile<kLdsTable, false>(gp, tile, lane, t_cnt, t_acc);
+  // the partial last tile goes to the wave that would have been next in the round-robin
+  if ((gp.scan.num_docs & 2047) != 0 && wave == full_tiles % total_waves) group_private_tile<kLdsTable, true>(gp, full_tiles, lane, t_cnt, t_acc);
+
+  if constexpr (kLdsTable) {
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+      const bool packed = gp.packed_agg >= 0;
+      const unsigned long long pk = packed ? (unsigned long long)t_acc[(long long)gp.packed_agg * G + g] : 0ull;
+      const unsigned long long c = packed ? (pk >> gp.packed_shift) : (unsigned long long)(uint32_t)t_cnt[g];
+      if (c == 0ull) continue;
+      __hip_atomic_fetch_add(&gp.table_count[g], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int a = 0; a < NA; ++a) {
+        const int kind = gp.group_aggs[a].kind;
+        long long* slot = gp.table_acc + (long long)a * G + g;
+        long long v = t_acc[(long long)a * G + g];
+        if (packed && a == gp.packed_agg) v = (long long)(pk & ((1ull << gp.packed_shift) - 1ull));
+        if (kind == kGroupSum) __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (kind == kGroupMin) __hip_atomic_fetch_min(slot, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_max(slot, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
 __global__ void init_group_table_kernel(GroupParams gp) {
   const int G = gp.num_groups;
   for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x) {

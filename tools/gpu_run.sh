@@ -11,12 +11,14 @@ smoke)
   echo "== smoke =="; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ;;
 micro)
   echo "== microbench =="; timeout 300 ./tools/microbench > $OUT/microbench.jsonl 2>&1; tail -60 $OUT/microbench.jsonl ;;
+lane)
+  echo "== lane-contiguous direct loads =="; timeout 300 ./tools/microbench lane 2>&1 | tee $OUT/microbench_lane.jsonl ;;
 atomics)
   echo "== lds atomic mixes =="; timeout 300 ./tools/microbench atomics 2>&1 | tee $OUT/microbench_atomics.jsonl ;;
 c3)
-  echo "== group-by tests + C3 =="; timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "group" 2>&1 | tail -5
-  for v in ${C3_VARIANTS:-"PINOT_GPU_GROUP_PACK=1" "PINOT_GPU_GROUP_PACK=0" "PINOT_GPU_GROUP_WAVES=8" "PINOT_GPU_TILE_STEPS=32"}; do
-    echo "-- $v"; NC=--no-check; [ "$v" = "PINOT_GPU_GROUP_PACK=1" ] && NC=""; env $v timeout 900 python tools/bench_configs.py --match "C3|GROUP" --only c23 $NC 2>&1 | grep -E "C3|GROUP|Error|error" | python -c "
+  echo "== group-by tests + C3 =="; timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_typed.py tests/test_gpu_golden.py -m gpu -x -q -k "group or golden" 2>&1 | tail -5
+  for v in ${C3_VARIANTS:-"PINOT_GPU_GROUP_PRIVATE=1" "PINOT_GPU_GROUP_PRIVATE=0" "PINOT_GPU_GROUP_PACK=0" "PINOT_GPU_GROUP_WAVES=8" "PINOT_GPU_BLOCKS_PER_CU=2"}; do
+    echo "-- $v"; NC=--no-check; [ "$v" = "PINOT_GPU_GROUP_PRIVATE=1" ] && NC=""; env $v timeout 900 python tools/bench_configs.py --match "C3|GROUP" --only c23 $NC 2>&1 | grep -E "C3|GROUP|Error|error" | python -c "
 import sys,json
 for l in sys.stdin:
     try: d=json.loads(l); print('   %-52s %.3f ms %6.0f GB/s exact=%s' % (d['config'], d['kernel_ms'], d['GBps'], d['bit_exact_vs_oracle']))

@@ -178,6 +178,26 @@ __global__ __launch_bounds__(1024) void lds_atomic_mix(int groups, int iters, un
   if (tab[threadIdx.x % (groups * 3)] == 0x1234567ull) out[0] = 1;
 }
 
+// 7. Lane-contiguous direct loads: lane i of a wave reads kDw consecutive dwords at byte offset i*4*kDw of a 256*kDw-byte tile
+// (what a "lane owns 32 consecutive docs of a kDw-bit column" decode would issue), dwordx4 at a time.  Every byte is used, but
+// each wave-level instruction touches 64 separate 16-byte pieces spread over kDw/32 KiB: does the TCP keep the lines until the
+// next instruction of the same wave comes for their other bytes?
+template <int kDw>
+__global__ __launch_bounds__(256) void lane_contiguous_read(const uint8_t* __restrict__ src, size_t num_tiles, unsigned long long* out) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), waves = (size_t)gridDim.x * 4;
+  uint32_t acc = 0;
+  for (size_t t = wave; t < num_tiles; t += waves) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(src + t * (256 * kDw) + (size_t)lane * 4 * kDw);
+    uint32_t d[kDw];
+#pragma unroll
+    for (int i = 0; i < kDw; ++i) d[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < kDw; ++i) acc ^= d[i];
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
 
 // 6. VALU issue rate of the integer ops the decode loop is made of (is a wave64 op 2 or 4 cycles on a SIMD?)
 template <int kOp>
@@ -244,6 +264,7 @@ double time_ms(F launch, int reps) {
 
 int main(int argc, char** argv) {
   const bool only_atomics = argc > 1 && !strcmp(argv[1], "atomics");
+  const bool only_lane = argc > 1 && !strcmp(argv[1], "lane");
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, \"hbm_gb\": %.1f, \"lds_per_block\": %zu}\n", prop.gcnArchName,
@@ -251,6 +272,23 @@ int main(int argc, char** argv) {
   const int cus = prop.multiProcessorCount;
   unsigned long long* d_out;
   CHECK(hipMalloc((void**)&d_out, 64));
+
+  if (only_lane) {
+    const size_t bytes = 4ull << 30;
+    uint8_t* d_buf;
+    CHECK(hipMalloc((void**)&d_buf, bytes));
+    CHECK(hipMemset(d_buf, 0x5a, bytes));
+    for (int bpc : {2, 4, 8}) {
+      double m10 = time_ms([&] { lane_contiguous_read<10><<<cus * bpc, 256>>>(d_buf, bytes / (256 * 10), d_out); }, 3);
+      double m16 = time_ms([&] { lane_contiguous_read<16><<<cus * bpc, 256>>>(d_buf, bytes / (256 * 16), d_out); }, 3);
+      double m17 = time_ms([&] { lane_contiguous_read<17><<<cus * bpc, 256>>>(d_buf, bytes / (256 * 17), d_out); }, 3);
+      double m20 = time_ms([&] { lane_contiguous_read<20><<<cus * bpc, 256>>>(d_buf, bytes / (256 * 20), d_out); }, 3);
+      double m4 = time_ms([&] { lane_contiguous_read<4><<<cus * bpc, 256>>>(d_buf, bytes / (256 * 4), d_out); }, 3);
+      printf("{\"bench\": \"lane_contiguous_read\", \"blocks_per_cu\": %d, \"GBps\": {\"4dw\": %.0f, \"10dw\": %.0f, \"16dw\": %.0f, \"17dw\": %.0f, \"20dw\": %.0f}}\n", bpc,
+             bytes / m4 / 1e6, bytes / m10 / 1e6, bytes / m16 / 1e6, bytes / m17 / 1e6, bytes / m20 / 1e6);
+    }
+    return 0;
+  }
 
   if (only_atomics) {
     for (int groups : {1000}) {
