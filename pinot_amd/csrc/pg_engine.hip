@@ -51,6 +51,7 @@ struct Engine {
   int value_plane = -1;      // -1 auto, 0 never, 1 always (PINOT_GPU_VALUE_PLANE)
   int tile_steps = 0;        // 0 auto, 16 or 32 forced (PINOT_GPU_TILE_STEPS)
   bool double_buffer = false;
+  bool scan_private = true;  // PINOT_GPU_SCAN_PRIVATE=0: always the LDS-staged scan kernel
   bool group_private = true; // PINOT_GPU_GROUP_PRIVATE=0: unfiltered group-by through the LDS-staged kernel
   bool group_pack = true;    // PINOT_GPU_GROUP_PACK=0: separate count atomic in the group-by LDS table
   int group_waves = 0;       // PINOT_GPU_GROUP_WAVES: cap on wavefronts per group-by workgroup (default 16)
@@ -658,6 +659,7 @@ void flatten_plan(Lowered* lw) {
     const DevLeaf& L = pl.leaves[pl.nodes[n].leaf];
     dn.kind = L.kind; dn.exclusive = L.exclusive; dn.lo = L.lo; dn.span = L.span; dn.set_bytes = L.set_bytes; dn.set_words = L.set_words;
     dn.lds_off = L.lds_off;
+    if (L.kind == kLeafBitmap) dn.set_words = reinterpret_cast<const uint32_t*>(L.bitmap);   // scan_private_kernel reads the bitmap as dwords
     if (L.kind == kLeafDictRange || L.kind == kLeafDictSet || L.kind == kLeafRawRange || L.kind >= kLeafRawRange64) {
       const DevColumn& c = pl.cols[L.col];
       dn.bits = c.bits; dn.slot_off = c.slot_off; dn.fwd = c.fwd;
@@ -792,6 +794,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.value_plane = vp ? atoi(vp) : -1;
   const char* db = getenv("PINOT_GPU_DOUBLE_BUFFER");
   g_engine.double_buffer = db && db[0] == '1';
+  const char* spv = getenv("PINOT_GPU_SCAN_PRIVATE");
+  g_engine.scan_private = !(spv && spv[0] == '0');
   const char* gpv = getenv("PINOT_GPU_GROUP_PRIVATE");
   g_engine.group_private = !(gpv && gpv[0] == '0');
   const char* gpk = getenv("PINOT_GPU_GROUP_PACK");
@@ -1082,15 +1086,32 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       need_queue |= pl.agg_cols[i].need_sum && !c.is_raw && !c.is_plane && c.vkind == kValI32;
       typed |= c.vkind != kValI32 && (pl.agg_cols[i].need_sum || c.is_raw);     // 8-byte / floating-point values are read
     }
+    // The lane-private kernel (no LDS, plain global loads) takes every query whose leaves and aggregations it implements:
+    // scan / set / bitmap leaves and raw INT ranges; COUNT, and SUM through a value plane / MIN / MAX on dictionary columns.
+    bool use_private = g_engine.scan_private && !typed;
+    for (int l = 0; l < pl.num_leaves && use_private; ++l) use_private = pl.leaves[l].kind <= kLeafBitmap;
+    for (int i = 0; i < pl.num_agg_cols && use_private; ++i) {
+      const DevColumn& c = pl.cols[pl.agg_cols[i].col];
+      use_private = !c.is_raw && c.vkind == kValI32 && c.bits <= 31 && (!pl.agg_cols[i].need_sum || c.is_plane);
+    }
     Geometry geo;
     static const int agg_wave_cap1 = max_waves_per_cu(scan_agg_kernel<true, 1>);
     static const int agg_wave_cap4 = max_waves_per_cu(scan_agg_kernel<true, kMaxAggCols>);
     static const int agg_wave_cap_typed = max_waves_per_cu(scan_agg_kernel<true, kMaxAggCols, true>);
     const int agg_wave_cap = typed ? agg_wave_cap_typed : (pl.num_agg_cols <= 1 ? agg_wave_cap1 : agg_wave_cap4);
     finish_geometry(seg, &lw, 0, need_queue, kBlockThreads / 64, agg_wave_cap, &geo);
-    const int blocks = geo.blocks;
+    int blocks = geo.blocks;
     const size_t lds = geo.lds;
-    if ((size_t)sp.wave_lds_bytes > kLdsBudget) return fail(PG_ERR_UNSUPPORTED, "query needs %d bytes of LDS per wavefront", sp.wave_lds_bytes);
+    if (use_private) {
+      static const int private_cap1 = max_waves_per_cu(scan_private_kernel<1>);
+      static const int private_cap4 = max_waves_per_cu(scan_private_kernel<kMaxAggCols>);
+      const int cap = pl.num_agg_cols <= 1 ? private_cap1 : private_cap4;
+      int bpc = std::max(1, cap / (kBlockThreads / 64));
+      if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
+      const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
+      blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + 3) / 4, (long long)seg->num_cus * bpc));
+      geo.threads = kBlockThreads;
+    } else if ((size_t)sp.wave_lds_bytes > kLdsBudget) return fail(PG_ERR_UNSUPPORTED, "query needs %d bytes of LDS per wavefront", sp.wave_lds_bytes);
     sp.speculate = 1;
     sp.profile = (g_engine.flags & PG_CFG_PROFILE_WAVES) ? 1 : 0;
     st = ensure_partials(ctx, blocks);
@@ -1105,7 +1126,10 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
-    if (typed) {
+    if (use_private) {
+      if (one) scan_private_kernel<1><<<dim3((unsigned)blocks), dim3(kBlockThreads), 0, ctx->stream>>>(sp);
+      else scan_private_kernel<kMaxAggCols><<<dim3((unsigned)blocks), dim3(kBlockThreads), 0, ctx->stream>>>(sp);
+    } else if (typed) {
       if (g_engine.use_dma) { set_dynamic_lds(scan_agg_kernel<true, kMaxAggCols, true>, lds); scan_agg_kernel<true, kMaxAggCols, true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
       else { set_dynamic_lds(scan_agg_kernel<false, kMaxAggCols, true>, lds); scan_agg_kernel<false, kMaxAggCols, true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
     } else if (g_engine.use_dma) {

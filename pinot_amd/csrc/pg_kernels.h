@@ -1234,6 +1234,216 @@ __device__ __forceinline__ void decode16_private_dispatch(int b, const uint32_t*
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// scan_private_kernel: fused scan -> filter -> aggregate in the lane-private layout.
+//
+// Same ownership as the group-by kernel above: lane i holds the 32 consecutive docs 32*i .. 32*i+31 of the wave's 2048-doc tile,
+// so its 32-bit mask IS dword (64*tile + i) of the doc-order docId bitmap -- posting bitmaps are read and filter bitmaps written
+// with one coalesced dword per lane, no ballots and no bit transposes.  Columns are read with plain global loads (no LDS, no
+// DMA, nothing to size per query) and decoded from registers at compile-time bit positions:
+//     range leaf      bswap per dword + (v_bfe | v_alignbit+v_and) + v_cmp + v_addc per value   (~3.3-3.7 VALU per doc)
+//     plane SUM       bswap per dword + extract + v_bfe (the match bit) + v_mad_u32_u24          (~3.6 VALU per doc, any selectivity)
+// against ~4.5 and ~4-12 in the LDS-staged kernel, whose decode needs a per-lane byte gather (v_perm) on top of the extract.
+// ------------------------------------------------------------------------------------------------
+// Sixteen values (half H) of the lane's chunk of a B-bit column: mask bits of ((value - lo) < span), most recent value in bit 0.
+template <int B, int H, bool kLoZero>
+__device__ __forceinline__ void range16_private(const uint32_t* __restrict__ lane_words, uint32_t lo, uint32_t span, uint32_t& m) {
+  uint32_t v[16];
+  decode16_private<B, H>(lane_words, v);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) shift_in_lt(m, kLoZero ? v[j] : v[j] - lo, span);
+}
+
+template <bool kLoZero>
+__device__ __forceinline__ uint32_t range_private_dispatch(int b, const uint32_t* lane_words, uint32_t lo, uint32_t span) {
+  uint32_t m = 0;
+  switch (b) {
+#define PG_CASE(B) case B: range16_private<B, 0, kLoZero>(lane_words, lo, span, m); range16_private<B, 1, kLoZero>(lane_words, lo, span, m); break;
+    PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10)
+    PG_CASE(11) PG_CASE(12) PG_CASE(13) PG_CASE(14) PG_CASE(15) PG_CASE(16) PG_CASE(17) PG_CASE(18) PG_CASE(19) PG_CASE(20)
+    PG_CASE(21) PG_CASE(22) PG_CASE(23) PG_CASE(24) PG_CASE(25) PG_CASE(26) PG_CASE(27) PG_CASE(28) PG_CASE(29) PG_CASE(30)
+    PG_CASE(31)
+#undef PG_CASE
+    default: break;
+  }
+  return __builtin_bitreverse32(m);      // value j -> bit j
+}
+
+__device__ __forceinline__ uint32_t eval_leaf_private(const ScanParams& p, const DevNode& L, long long tile, int lane) {
+  uint32_t m;
+  switch (L.kind) {
+    case kLeafMatchAll: m = 0xFFFFFFFFu; break;
+    case kLeafMatchNone: m = 0u; break;
+    case kLeafDictRange: {
+      const uint32_t* words = reinterpret_cast<const uint32_t*>(L.fwd + tile * (256ll * L.bits)) + lane * L.bits;
+      m = L.lo == 0 ? range_private_dispatch<true>(L.bits, words, 0u, L.span) : range_private_dispatch<false>(L.bits, words, (uint32_t)L.lo, L.span);
+      break;
+    }
+    case kLeafDictSet: {
+      // InPredicateEvaluator: bit dictId of the set (the words stay L1-resident)
+      const uint32_t* words = reinterpret_cast<const uint32_t*>(L.fwd + tile * (256ll * L.bits)) + lane * L.bits;
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)L.set_words, 0, L.set_bytes, 0x00020000);
+      m = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t d[16], w[16];
+        if (h == 0) decode16_private_dispatch<0>(L.bits, words, d); else decode16_private_dispatch<1>(L.bits, words, d);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (d[j] >> 5) * 4u, 0, 0);   // out of range -> 0
+#pragma unroll
+        for (int j = 0; j < 16; ++j) m |= ((w[j] >> (d[j] & 31u)) & 1u) << (16 * h + j);
+      }
+      break;
+    }
+    case kLeafRawRange: {
+      // raw INT column: the lane's 32 docs are 128 contiguous bytes
+      const long long first = tile * 2048 + lane * 32;
+      const long long last = (long long)p.num_docs - 1;
+      const uint32_t* vals = reinterpret_cast<const uint32_t*>(L.fwd);
+      const uint32_t lo = (uint32_t)L.lo, span = L.span;
+      m = 0;
+#pragma unroll 16
+      for (int j = 0; j < 32; ++j) {
+        const long long doc = first + j > last ? last : first + j;
+        shift_in_le(m, __builtin_bswap32(vals[doc]) - lo, span);
+      }
+      m = __builtin_bitreverse32(m);
+      break;
+    }
+    default: {  // kLeafBitmap: the lane's mask is one dword of the doc-order bitmap
+      m = L.set_words[tile * 64 + lane];
+      break;
+    }
+  }
+  return L.exclusive ? ~m : m;
+}
+
+__device__ __forceinline__ uint32_t eval_filter_private(const ScanParams& p, long long tile, int lane) {
+  if (p.num_nodes == 0) return 0xFFFFFFFFu;
+  if (p.num_nodes == 1) return eval_leaf_private(p, p.nodes[0], tile, lane);
+  MaskStack st;
+#pragma unroll
+  for (int i = 0; i < kStackDepth; ++i) st.v[i] = 0;
+  st.sp = 0;
+  for (int n = 0; n < p.num_nodes; ++n) {
+    const DevNode& nd = p.nodes[n];
+    uint32_t top;
+    if (nd.op == PG_FILTER_LEAF) {
+      top = eval_leaf_private(p, nd, tile, lane);
+    } else if (nd.op == PG_FILTER_NOT) {
+      top = ~st.pop();
+    } else {
+      top = st.pop();
+      for (int c = 1; c < nd.num_children; ++c) {
+        const uint32_t o = st.pop();
+        top = nd.op == PG_FILTER_AND ? (top & o) : (top | o);
+      }
+    }
+    // root AND chain: nothing left in the whole tile -> the remaining leaves' columns are never read
+    if ((nd.flags & kNodeExitIfZero) && __builtin_amdgcn_ballot_w64(top != 0u) == 0ull) return 0u;
+    st.push(top);
+  }
+  return st.pop();
+}
+
+// Masked aggregation of one half (16 values) of a column chunk.  Keys (dictIds / plane fields) are below 2^31.
+template <int B, int H>
+__device__ __forceinline__ void agg16_private(const uint32_t* __restrict__ lane_words, uint32_t m, bool need_sum, bool need_minmax,
+                                              uint32_t& psum, unsigned long long& wsum, uint32_t& umin, uint32_t& umax) {
+  uint32_t v[16];
+  decode16_private<B, H>(lane_words, v);
+  if (need_sum) {
+    if (B <= 24) {
+      // match bit as 0 / 1, one full-rate 24-bit multiply-add per value; 32 fields of <= 24 bits fit the 32-bit partial sum
+#pragma unroll
+      for (int j = 0; j < 16; ++j) psum = __umul24(v[j], __builtin_amdgcn_ubfe(m, 16 * H + j, 1)) + psum;
+    } else if (B <= 27) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) psum += v[j] & (uint32_t)__builtin_amdgcn_sbfe((int)m, 16 * H + j, 1);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) wsum += (unsigned long long)(v[j] & (uint32_t)__builtin_amdgcn_sbfe((int)m, 16 * H + j, 1));
+    }
+  }
+  if (need_minmax) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t all = (uint32_t)__builtin_amdgcn_sbfe((int)m, 16 * H + j, 1);     // ~0 when the doc matches
+      const uint32_t hi = v[j] & all, lo = v[j] | ~all;
+      umax = hi > umax ? hi : umax;
+      umin = lo < umin ? lo : umin;
+    }
+  }
+}
+
+__device__ __forceinline__ void agg_private_dispatch(int b, const uint32_t* lane_words, uint32_t m, bool need_sum, bool need_minmax,
+                                                     uint32_t& psum, unsigned long long& wsum, uint32_t& umin, uint32_t& umax) {
+  switch (b) {
+#define PG_CASE(B) case B: agg16_private<B, 0>(lane_words, m, need_sum, need_minmax, psum, wsum, umin, umax); \
+                           agg16_private<B, 1>(lane_words, m, need_sum, need_minmax, psum, wsum, umin, umax); break;
+    PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10)
+    PG_CASE(11) PG_CASE(12) PG_CASE(13) PG_CASE(14) PG_CASE(15) PG_CASE(16) PG_CASE(17) PG_CASE(18) PG_CASE(19) PG_CASE(20)
+    PG_CASE(21) PG_CASE(22) PG_CASE(23) PG_CASE(24) PG_CASE(25) PG_CASE(26) PG_CASE(27) PG_CASE(28) PG_CASE(29) PG_CASE(30)
+    PG_CASE(31)
+#undef PG_CASE
+    default: break;
+  }
+}
+
+template <int kAggSlots>
+__global__ __launch_bounds__(kBlockThreads) void scan_private_kernel(const ScanParams p) {
+  __shared__ BlockPartial red[kBlockThreads / 64];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  const long long total_waves = (long long)gridDim.x * waves_per_block;
+  const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
+
+  unsigned long long count = 0;
+  unsigned long long sum[kAggSlots];
+  uint32_t umin[kAggSlots], umax[kAggSlots];
+#pragma unroll
+  for (int a = 0; a < kAggSlots; ++a) { sum[a] = 0; umin[a] = 0xFFFFFFFFu; umax[a] = 0u; }
+
+  for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
+    uint32_t m = eval_filter_private(p, tile, lane);
+    // docs past numDocs (last tile only)
+    const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
+    m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
+    if (p.out_bitmap) reinterpret_cast<uint32_t*>(p.out_bitmap)[tile * 64 + lane] = m;
+    count += (unsigned)__builtin_popcount(m);
+    if (p.num_agg_cols == 0 || __builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
+#pragma unroll
+    for (int a = 0; a < kAggSlots; ++a) {
+      if (a < p.num_agg_cols) {
+        const DevAggCol& ac = p.agg_cols[a];
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(ac.fwd + tile * (256ll * ac.bits)) + lane * ac.bits;
+        uint32_t psum = 0;
+        agg_private_dispatch(ac.bits, words, m, ac.need_sum != 0, ac.need_minmax != 0, psum, sum[a], umin[a], umax[a]);
+        sum[a] += psum;
+      }
+    }
+  }
+
+  BlockPartial mine;
+  partial_identity(mine);
+  mine.count = (unsigned long long)wave_sum_i64((long long)count);
+#pragma unroll
+  for (int a = 0; a < kAggSlots; ++a) {
+    mine.sum[a] = wave_sum_i64((long long)sum[a]);
+    // unsigned keys below 2^31 -> the int32 keys of BlockPartial; lanes that matched nothing keep the identities
+    mine.kmin[a] = wave_min_i32(umin[a] == 0xFFFFFFFFu ? 0x7FFFFFFF : (int32_t)umin[a]);
+    mine.kmax[a] = wave_max_i32(count == 0ull ? (int32_t)0x80000000 : (int32_t)umax[a]);
+  }
+  if (lane == 0) red[wave_in_block] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    BlockPartial acc = red[0];
+    for (int w = 1; w < waves_per_block; ++w) partial_merge(acc, red[w]);
+    p.partials[blockIdx.x] = acc;
+  }
+}
+
 // One 2048-doc tile.  kTail: the last, partial tile -- docs past numDocs are masked out of every atomic.
 template <bool kLds, bool kTail>
 __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long long tile, int lane, unsigned long long* t_cnt, long long* t_acc) {
