@@ -6,7 +6,8 @@ Workload C2b: SELECT SUM(v) FROM t WHERE f < 100
   f: INT, dictionary {0..999}            -> 10-bit fixed-bit forward index (1.25 GB),  dictIds uniform, seed 2r+2
   predicate lowered to dictId range [0, 100) (10 % selectivity); r = rank (segment r lives on GPU r).
 A step = one pg_execute over the whole resident segment (fused scan -> filter -> SUM kernel reading f's dictIds and
-v's device-built value plane + a one-block partial reduction + 104-byte readback + stream sync).  Columns are generated on the host by the product's C++ writer
+v's device-built value plane (`roofline.kernel` names the kernel that ran) + a one-block partial reduction +
+200-byte readback + stream sync).  Columns are generated on the host by the product's C++ writer
 in Pinot's on-disk layout and copied to HBM by pg_segment_open before the timed region.
 
 Launch:  python bench.py --gpus 1 --steps 20 --warmup 3
@@ -88,7 +89,7 @@ def main():
         st = gseg.execute_raw(spec, res)
         if st != _abi.PG_OK:
             raise RuntimeError(lib.pg_last_error().decode())
-        out = (res.aggregations[0].sum_i64, res.aggregations[0].count, res.dominant_kernel_ms, res.device_ms)
+        out = (res.aggregations[0].sum_i64, res.aggregations[0].count, res.dominant_kernel_ms, res.device_ms, int(res.dominant_kernel))
         if args.profile_waves:
             step.cycles = [int(c) for c in res.profile_cycles] + [int(res.profile_waves)]
         lib.pg_result_free(C.byref(res))
@@ -118,7 +119,7 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and os.environ.get("PINOT_GPU_VALUE_PLANE", "-1") != "0":
-        t = json.load(open(tpath)).get("scan_agg_kernel", {})
+        t = json.load(open(tpath)).get(_abi.KERNEL_NAMES[last[4]], {})
         if t.get("workload_rows") == n and args.threshold == 100:
             traffic = t.get("bytes_per_launch")
     result = None
@@ -142,7 +143,7 @@ def main():
                                    "selectivity %.0f%%, one segment per GPU, host-side merge" % (n, args.threshold / 10.0),
                        "rows_per_segment": n, "segments": world, "algorithmic_bytes_per_row": algorithmic_bytes / n},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": "scan_agg_kernel", "kernel_ms": avg_kernel_ms,
+                         "traffic": traffic, "kernel": _abi.KERNEL_NAMES[last[4]], "kernel_ms": avg_kernel_ms,
                          "algorithmic_bytes_per_launch": algorithmic_bytes},
             "hbm_GBps_whole_step": world * algorithmic_bytes * args.steps / elapsed / 1e9,
             "wave_profile": ({"waves": step.cycles[4], "cycles_per_wave": {"memory_wait": step.cycles[0] / step.cycles[4], "filter": step.cycles[1] / step.cycles[4],

@@ -193,6 +193,14 @@ typedef struct pg_agg_value {
 } pg_agg_value;
 
 /* ExecutionStatistics (core/operator/ExecutionStatistics.java:25-64). */
+/* Which kernel executed the scan (pg_result.dominant_kernel); names as rocprofv3 prints them. */
+typedef enum pg_kernel_id {
+  PG_KERNEL_SCAN_AGG = 0,          /* scan_agg_kernel: LDS-staged scan -> filter -> aggregate */
+  PG_KERNEL_SCAN_PRIVATE = 1,      /* scan_private_kernel: lane-private decode straight from HBM */
+  PG_KERNEL_SCAN_GROUP = 2,        /* scan_group_kernel: LDS-staged group-by */
+  PG_KERNEL_GROUP_PRIVATE = 3      /* group_private_kernel: lane-private group-by (no filter) */
+} pg_kernel_id;
+
 typedef struct pg_stats {
   int64_t num_docs_scanned;
   int64_t num_entries_scanned_in_filter;
@@ -213,7 +221,7 @@ typedef struct pg_result {
   double dominant_kernel_ms;       /* HIP-event time of the scan kernel alone */
   uint64_t profile_cycles[4];      /* PG_CFG_PROFILE_WAVES: shader cycles summed over wavefronts: memory wait, filter, aggregate, total */
   int32_t profile_waves;           /* number of wavefronts the sums cover */
-  int32_t reserved2;
+  int32_t dominant_kernel;         /* pg_kernel_id of the kernel dominant_kernel_ms refers to */
   void* internal;
 } pg_result;
 

@@ -51,6 +51,7 @@ struct Engine {
   int value_plane = -1;      // -1 auto, 0 never, 1 always (PINOT_GPU_VALUE_PLANE)
   int tile_steps = 0;        // 0 auto, 16 or 32 forced (PINOT_GPU_TILE_STEPS)
   bool double_buffer = false;
+  bool plane_gcd = true;     // PINOT_GPU_PLANE_GCD=0: planes hold value - min unscaled, never alias the dictId stream
   bool scan_private = true;  // PINOT_GPU_SCAN_PRIVATE=0: always the LDS-staged scan kernel
   bool group_private = true; // PINOT_GPU_GROUP_PRIVATE=0: unfiltered group-by through the LDS-staged kernel
   bool group_pack = true;    // PINOT_GPU_GROUP_PACK=0: separate count atomic in the group-by LDS table
@@ -90,7 +91,9 @@ struct ColumnDev {
   // value plane (built lazily on the device the first time the column is summed)
   uint8_t* d_plane = nullptr;
   int plane_bits = 0;                   // 1..31 packed, 32 = big-endian int32 values
-  int64_t plane_base = 0;               // value = plane_base + decoded field (0 for plane_bits == 32)
+  int64_t plane_base = 0;               // value = plane_base + plane_scale * decoded field (0 / 1 for plane_bits == 32)
+  int64_t plane_scale = 1;              // gcd of (value - min): frame of reference + GCD scaling
+  bool plane_is_fwd = false;            // arithmetic-progression dictionary: the dictId stream itself is the plane (d_plane == d_fwd)
   bool plane_ready = false;
 };
 
@@ -290,7 +293,7 @@ void free_segment(pg_segment* seg) {
     if (col.d_dict64) (void)hipFree(col.d_dict64);
     if (col.d_inv) (void)hipFree(col.d_inv);
     if (col.d_dir) (void)hipFree(col.d_dir);
-    if (col.d_plane) (void)hipFree(col.d_plane);
+    if (col.d_plane && !col.plane_is_fwd) (void)hipFree(col.d_plane);
   }
   delete seg;
 }
@@ -304,41 +307,80 @@ void set_dynamic_lds(K kernel, size_t bytes) {
 // Policy: summing a dictionary column through its dictionary costs one L2 gather per matching row; a gather costs the
 // L2 as much as streaming ~22 bytes, so unless the dictionary is tiny (L1-resident) or the plane would be much wider
 // than the dictId stream, the plane wins as soon as a few percent of the rows match.
+// Frame of reference + GCD: field = (value - min) / g with g = gcd of all (value - min); w = bits of the largest field.
+// When the dictionary is an arithmetic progression (field[d] == d: dense ids, fixed-step values) the dictId stream already IS
+// the plane and nothing is materialised.  PINOT_GPU_PLANE_GCD=0 keeps g = 1.
+struct PlaneShape { int64_t base; int64_t scale; int bits; bool is_fwd; };
+PlaneShape plane_shape(const ColumnDev& col) {
+  PlaneShape ps;
+  const int64_t lo = col.h_dict.front(), hi = col.h_dict.back();
+  int64_t g = 0;
+  if (g_engine.plane_gcd) {
+    for (size_t d = 1; d < col.h_dict.size() && g != 1; ++d) {
+      int64_t a = (int64_t)col.h_dict[d] - lo, b = g;
+      while (b) { const int64_t t = a % b; a = b; b = t; }
+      g = a;
+    }
+  }
+  if (g <= 0) g = 1;
+  const int64_t top = (hi - lo) / g;
+  int w = 1;
+  while (w < 32 && (top >> w) != 0) ++w;
+  ps.base = w == 32 ? 0 : lo;
+  ps.scale = w == 32 ? 1 : g;
+  ps.bits = w;
+  ps.is_fwd = g_engine.plane_gcd && w < 32 && top == (int64_t)col.h_dict.size() - 1;     // sorted distinct multiples: field[d] == d
+  if (ps.is_fwd) ps.bits = col.bits;
+  return ps;
+}
+
 bool want_value_plane(const ColumnDev& col) {
   if (col.encoding != PG_FWD_FIXED_BIT_DICT || col.cardinality < 1 || col.vkind != kValI32) return false;
   if (g_engine.value_plane == 0) return false;
   if (g_engine.value_plane == 1) return true;
-  const int64_t range = (int64_t)col.h_dict.back() - (int64_t)col.h_dict.front();
-  int w = 1;
-  while (w < 32 && (range >> w) != 0) ++w;
-  return col.cardinality > 8192 || w - col.bits <= 8;
+  const PlaneShape ps = plane_shape(col);
+  return ps.is_fwd || col.cardinality > 8192 || ps.bits - col.bits <= 8;
 }
 
 pg_status ensure_plane(pg_segment* seg, int column, ExecCtx* ctx) {
   ColumnDev& col = seg->cols[(size_t)column];
   std::lock_guard<std::mutex> lk(seg->plane_mu);
   if (col.plane_ready) return PG_OK;
-  const int64_t lo = col.h_dict.front(), hi = col.h_dict.back();
-  const int64_t range = hi - lo;
-  int w = 1;
-  while (w < 32 && (range >> w) != 0) ++w;
+  const PlaneShape ps = plane_shape(col);
+  const int w = ps.bits;
   col.plane_bits = w;
-  col.plane_base = w == 32 ? 0 : lo;
+  col.plane_base = ps.base;
+  col.plane_scale = ps.scale;
+  if (ps.is_fwd) {
+    col.plane_is_fwd = true;
+    col.d_plane = col.d_fwd;
+    col.plane_ready = true;
+    return PG_OK;
+  }
   const size_t bytes = (size_t)std::max(seg->num_tiles, 1) * 256 * (size_t)w + 64;
   HIP_TRY(hipMalloc((void**)&col.d_plane, bytes));
   HIP_TRY(hipMemsetAsync(col.d_plane, 0, bytes, ctx->stream));
+  // the kernel writes dict'[dictId] where dict' = the scaled fields (for scale 1: value - base through the base argument)
+  int32_t* d_fields = nullptr;
+  if (ps.scale != 1) {
+    std::vector<int32_t> fields(col.h_dict.size());
+    for (size_t d = 0; d < fields.size(); ++d) fields[d] = (int32_t)(((int64_t)col.h_dict[d] - ps.base) / ps.scale);
+    HIP_TRY(hipMalloc((void**)&d_fields, fields.size() * 4));
+    HIP_TRY(hipMemcpy(d_fields, fields.data(), fields.size() * 4, hipMemcpyHostToDevice));
+  }
   DevColumn dc;
   memset(&dc, 0, sizeof(dc));
-  dc.fwd = col.d_fwd; dc.dict = col.d_dict; dc.bits = col.bits; dc.cardinality = col.cardinality; dc.dict_bytes = col.cardinality * 4;
+  dc.fwd = col.d_fwd; dc.dict = d_fields ? d_fields : col.d_dict; dc.bits = col.bits; dc.cardinality = col.cardinality; dc.dict_bytes = col.cardinality * 4;
   const int in_slot = ((256 * col.bits + 16) + 15) & ~15;
   const int waves = 4;
   const size_t lds = (size_t)waves * (size_t)(in_slot + 64 * w * 4 + 16);
   const int blocks = (int)std::max<long long>(1, std::min<long long>(((long long)seg->num_tiles + waves - 1) / waves, (long long)seg->num_cus * 2));
   set_dynamic_lds(materialize_plane_kernel, lds);
-  materialize_plane_kernel<<<dim3((unsigned)blocks), dim3(waves * 64), lds, ctx->stream>>>(dc, col.d_plane, w, (int32_t)col.plane_base, seg->num_docs,
+  materialize_plane_kernel<<<dim3((unsigned)blocks), dim3(waves * 64), lds, ctx->stream>>>(dc, col.d_plane, w, d_fields ? 0 : (int32_t)col.plane_base, seg->num_docs,
                                                                                             seg->num_tiles, in_slot);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (d_fields) (void)hipFree(d_fields);
   seg->device_bytes += bytes;
   col.plane_ready = true;
   return PG_OK;
@@ -517,7 +559,7 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
             sp.cols[s].in_filter = 1;
             const int64_t vlo = col.h_dict[(size_t)lo], vhi = col.h_dict[(size_t)hi - 1];
             if (sp.cols[s].is_raw) { L.kind = kLeafRawRange; L.lo = (int32_t)vlo; L.span = (uint32_t)(vhi - vlo); }
-            else { L.kind = kLeafDictRange; L.lo = (int32_t)(vlo - col.plane_base); L.span = (uint32_t)(vhi - vlo + 1); }
+            else { L.kind = kLeafDictRange; L.lo = (int32_t)((vlo - col.plane_base) / col.plane_scale); L.span = (uint32_t)((vhi - vlo) / col.plane_scale + 1); }
             L.col = s;
             lw->num_scan_leaves++;
           } else {
@@ -746,7 +788,7 @@ void finish_geometry(const pg_segment* seg, Lowered* lw, size_t table_bytes, boo
 // holder sees it ((double) of the typed minimum / maximum).
 double agg_value_double(const ColumnDev& col, int32_t key, bool plane) {
   if (col.encoding == PG_FWD_RAW_FIXED_BYTE) return (double)key;
-  if (plane) return (double)(col.value_base + col.plane_base + (int64_t)key);   // 32-bit planes have base 0 and key = value
+  if (plane) return (double)(col.value_base + col.plane_base + col.plane_scale * (int64_t)key);   // 32-bit planes: base 0, scale 1, key = value
   return col.h_dict_f64[(size_t)key];
 }
 // An integer sum known exactly (128 bits): sum_i64 is it modulo 2^64, `sum` its correctly rounded double; exact while it
@@ -758,6 +800,7 @@ void set_integer_sum(pg_agg_value* v, __int128 t) {
 }
 // what count * base adds back to a sum accumulated in the 32-bit domain
 int64_t sum_base(const ColumnDev& col, bool plane) { return col.value_base + (plane ? col.plane_base : 0); }
+int64_t sum_scale(const ColumnDev& col, bool plane) { return plane ? col.plane_scale : 1; }
 // 64-bit MIN / MAX key of a raw LONG / FLOAT / DOUBLE column (f64_order_key is its own inverse)
 double key64_to_double(const ColumnDev& col, long long key) {
   if (col.vkind == kValI64) return (double)key;
@@ -794,6 +837,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.value_plane = vp ? atoi(vp) : -1;
   const char* db = getenv("PINOT_GPU_DOUBLE_BUFFER");
   g_engine.double_buffer = db && db[0] == '1';
+  const char* pgv = getenv("PINOT_GPU_PLANE_GCD");
+  g_engine.plane_gcd = !(pgv && pgv[0] == '0');
   const char* spv = getenv("PINOT_GPU_SCAN_PRIVATE");
   g_engine.scan_private = !(spv && spv[0] == '0');
   const char* gpv = getenv("PINOT_GPU_GROUP_PRIVATE");
@@ -940,10 +985,11 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       col.vkind = cd.stored_type == PG_TYPE_INT ? kValI32 : (cd.stored_type == PG_TYPE_LONG ? kValI64 : (cd.stored_type == PG_TYPE_FLOAT ? kValF32 : kValF64));
       const uint64_t raw_start = (uint64_t)data_header_start + (uint64_t)num_chunks * (version <= 2 ? 4 : 8);
       if (raw_start + (uint64_t)desc->num_docs * (uint64_t)value_bytes > cd.fwd_size) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: raw forward index shorter than numDocs", col.name.c_str()));
-      col.fwd_alloc_bytes = (size_t)cd.fwd_size + 64;
+      // padded so that whole 2048-doc tiles can be read past numDocs (the lane-private kernels never clamp docIds)
+      col.fwd_alloc_bytes = std::max<size_t>((size_t)cd.fwd_size, (size_t)raw_start + (size_t)std::max(seg->num_tiles, 1) * 2048 * (size_t)value_bytes) + 64;
       hipError_t e = hipMalloc((void**)&col.d_fwd_alloc, col.fwd_alloc_bytes);
       if (e != hipSuccess) return bail(fail(PG_ERR_OUT_OF_MEMORY, "column %s: hipMalloc(%zu): %s", col.name.c_str(), col.fwd_alloc_bytes, hipGetErrorString(e)));
-      e = hipMemset(col.d_fwd_alloc + cd.fwd_size, 0, 64);
+      e = hipMemset(col.d_fwd_alloc + cd.fwd_size, 0, col.fwd_alloc_bytes - (size_t)cd.fwd_size);
       if (e == hipSuccess) e = hipMemcpy(col.d_fwd_alloc, fwd, (size_t)cd.fwd_size, hipMemcpyHostToDevice);
       if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "column %s: H2D copy: %s", col.name.c_str(), hipGetErrorString(e)));
       col.d_fwd = col.d_fwd_alloc + raw_start;
@@ -1183,7 +1229,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
             v.sum = wrapped ? fp.fsum[ac] : (double)v.sum_i64;
           } else {
             // value plane: sum(value) = count * base + sum(value - base); offset dictionaries add count * value_base
-            set_integer_sum(&v, (__int128)fp.sum[ac] + (__int128)fp.count * (__int128)sum_base(col, plane));
+            set_integer_sum(&v, (__int128)fp.sum[ac] * (__int128)sum_scale(col, plane) + (__int128)fp.count * (__int128)sum_base(col, plane));
           }
         } else if (fp.count > 0) {
           if (raw && col.vkind != kValI32) {
@@ -1197,6 +1243,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
           }
         }
       }
+      out->dominant_kernel = use_private ? PG_KERNEL_SCAN_PRIVATE : PG_KERNEL_SCAN_AGG;
       for (int c = 0; c < 4; ++c) out->profile_cycles[c] = fp.cyc[c];
       out->profile_waves = blocks * (geo.threads / 64);
       out->stats.num_docs_scanned = (int64_t)fp.count;
@@ -1349,6 +1396,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     long long docs = 0;
     for (int g = 0; g < gp.num_groups; ++g) if (hc[g]) { num_present++; docs += (long long)hc[g]; }
     out->num_aggregations = na;
+    out->dominant_kernel = use_private ? PG_KERNEL_GROUP_PRIVATE : PG_KERNEL_SCAN_GROUP;
     out->num_groups = num_present;
     out->group_id_upper_bound = gp.num_groups;
     out->group_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)std::max(num_present, 1));
@@ -1373,7 +1421,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
             v.sum_i64 = 0;
             v.sum_exact = 0;
           } else {
-            set_integer_sum(&v, (__int128)acc + (__int128)hc[g] * (__int128)sum_base(col, plane));
+            set_integer_sum(&v, (__int128)acc * (__int128)sum_scale(col, plane) + (__int128)hc[g] * (__int128)sum_base(col, plane));
           }
         }
         else if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, (int32_t)acc, plane);

@@ -1296,16 +1296,18 @@ __device__ __forceinline__ uint32_t eval_leaf_private(const ScanParams& p, const
       break;
     }
     case kLeafRawRange: {
-      // raw INT column: the lane's 32 docs are 128 contiguous bytes
-      const long long first = tile * 2048 + lane * 32;
-      const long long last = (long long)p.num_docs - 1;
-      const uint32_t* vals = reinterpret_cast<const uint32_t*>(L.fwd);
+      // raw INT column: the lane's 32 docs are 128 contiguous bytes (pg_segment_open pads raw buffers to whole 2048-doc tiles, so
+      // the last tile needs no clamping; its surplus docs are masked by the caller)
+      const uint32_t* vals = reinterpret_cast<const uint32_t*>(L.fwd) + tile * 2048 + lane * 32;
       const uint32_t lo = (uint32_t)L.lo, span = L.span;
       m = 0;
-#pragma unroll 16
-      for (int j = 0; j < 32; ++j) {
-        const long long doc = first + j > last ? last : first + j;
-        shift_in_le(m, __builtin_bswap32(vals[doc]) - lo, span);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = vals[16 * h + j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) shift_in_le(m, __builtin_bswap32(v[j]) - lo, span);
       }
       m = __builtin_bitreverse32(m);
       break;
@@ -1390,8 +1392,11 @@ __device__ __forceinline__ void agg_private_dispatch(int b, const uint32_t* lane
   }
 }
 
+#ifndef PG_PRIVATE_WAVES
+#define PG_PRIVATE_WAVES 4      // wavefronts per SIMD the register allocation must allow; 5 and 6 spill in the hot path (measured)
+#endif
 template <int kAggSlots>
-__global__ __launch_bounds__(kBlockThreads) void scan_private_kernel(const ScanParams p) {
+__global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_kernel(const ScanParams p) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
@@ -1405,6 +1410,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_private_kernel(const ScanP
 #pragma unroll
   for (int a = 0; a < kAggSlots; ++a) { sum[a] = 0; umin[a] = 0xFFFFFFFFu; umax[a] = 0u; }
 
+  // (Early "touch" loads of the next column chunks were tried and lost 30 %: vmcnt retires in order, so a wave's own L2 hits
+  // queue behind its prefetches that are still on their way from HBM.  Latency is hidden by the other resident waves instead.)
   for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
     uint32_t m = eval_filter_private(p, tile, lane);
     // docs past numDocs (last tile only)
@@ -1413,14 +1420,22 @@ __global__ __launch_bounds__(kBlockThreads) void scan_private_kernel(const ScanP
     if (p.out_bitmap) reinterpret_cast<uint32_t*>(p.out_bitmap)[tile * 64 + lane] = m;
     count += (unsigned)__builtin_popcount(m);
     if (p.num_agg_cols == 0 || __builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
+    // one instance of the width dispatch for all slots (a runtime loop: unrolling it four times quadruples the code and keeps
+    // ~190 VGPRs live); the per-slot accumulators are selected with wave-uniform predicates
+    for (int a = 0; a < p.num_agg_cols; ++a) {
+      const DevAggCol& ac = p.agg_cols[a];
+      const uint32_t* words = reinterpret_cast<const uint32_t*>(ac.fwd + tile * (256ll * ac.bits)) + lane * ac.bits;
+      uint32_t psum = 0, tmin = 0xFFFFFFFFu, tmax = 0u;
+      unsigned long long wsum = 0;
+      agg_private_dispatch(ac.bits, words, m, ac.need_sum != 0, ac.need_minmax != 0, psum, wsum, tmin, tmax);
+      wsum += psum;
 #pragma unroll
-    for (int a = 0; a < kAggSlots; ++a) {
-      if (a < p.num_agg_cols) {
-        const DevAggCol& ac = p.agg_cols[a];
-        const uint32_t* words = reinterpret_cast<const uint32_t*>(ac.fwd + tile * (256ll * ac.bits)) + lane * ac.bits;
-        uint32_t psum = 0;
-        agg_private_dispatch(ac.bits, words, m, ac.need_sum != 0, ac.need_minmax != 0, psum, sum[a], umin[a], umax[a]);
-        sum[a] += psum;
+      for (int s = 0; s < kAggSlots; ++s) {
+        if (s == a) {
+          sum[s] += wsum;
+          umin[s] = tmin < umin[s] ? tmin : umin[s];
+          umax[s] = tmax > umax[s] ? tmax : umax[s];
+        }
       }
     }
   }

@@ -52,7 +52,7 @@ testall)
 bench)
   echo "== bench 1B =="; timeout 900 python bench.py --steps 20 --warmup 3 --extra > $OUT/bench_1B.json 2> $OUT/bench_1B.err; cat $OUT/bench_1B.json; grep extra $OUT/bench_1B.err ;;
 benchvar)
-  for v in "PINOT_GPU_VALUE_PLANE=0" "PINOT_GPU_DOUBLE_BUFFER=1" "PINOT_GPU_VALUE_PLANE=0 PINOT_GPU_DOUBLE_BUFFER=1" "PINOT_GPU_NO_DMA=1"; do
+  for v in ${BENCH_VARIANTS:-"PINOT_GPU_PREFETCH=1" "PINOT_GPU_PREFETCH=0" "PINOT_GPU_SCAN_PRIVATE=0" "PINOT_GPU_BLOCKS_PER_CU=8" "PINOT_GPU_BLOCKS_PER_CU=3"}; do
     echo "== bench $v =="; env $v timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --extra 2> $OUT/tmp.err | short; grep extra $OUT/tmp.err | python -c "
 import sys,json
 for l in sys.stdin:
@@ -74,17 +74,17 @@ sq)
   echo "== rocprof SQ counters =="; cd /tmp && export TMPDIR=/tmp
   timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
   tail -2 $OUT/pmc_sq.log
-  for f in $(find $OUT/pmc_sq -name "*counter_collection*.csv"); do head -1 $f; grep scan_agg $f | head -16; done
+  for f in $(find $OUT/pmc_sq -name "*counter_collection*.csv"); do head -1 $f; grep -E "scan_agg|scan_private" $f | head -16; done
   timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc_sq2 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq2.log 2>&1
-  for f in $(find $OUT/pmc_sq2 -name "*counter_collection*.csv"); do head -1 $f; grep scan_agg $f | head -16; done
+  for f in $(find $OUT/pmc_sq2 -name "*counter_collection*.csv"); do head -1 $f; grep -E "scan_agg|scan_private" $f | head -16; done
   cd $GRAFT_REPO_ROOT ;;
 pmc)
   echo "== rocprof pmc =="; cd /tmp && export TMPDIR=/tmp
   timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
   tail -2 $OUT/pmc_fetch.log
-  for f in $(find $OUT/pmc_fetch -name "*counter_collection*.csv"); do head -1 $f; grep scan_agg $f | head -4; done
+  for f in $(find $OUT/pmc_fetch -name "*counter_collection*.csv"); do head -1 $f; grep -E "scan_agg|scan_private" $f | head -4; done
   timeout 900 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_tcc.log 2>&1
-  for f in $(find $OUT/pmc_tcc -name "*counter_collection*.csv"); do head -1 $f; grep scan_agg $f | head -4; done
+  for f in $(find $OUT/pmc_tcc -name "*counter_collection*.csv"); do head -1 $f; grep -E "scan_agg|scan_private" $f | head -4; done
   cd $GRAFT_REPO_ROOT ;;
 esac
 done
