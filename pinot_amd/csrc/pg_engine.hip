@@ -94,6 +94,10 @@ struct ColumnDev {
   int64_t plane_base = 0;               // value = plane_base + plane_scale * decoded field (0 / 1 for plane_bits == 32)
   int64_t plane_scale = 1;              // gcd of (value - min): frame of reference + GCD scaling
   bool plane_is_fwd = false;            // arithmetic-progression dictionary: the dictId stream itself is the plane (d_plane == d_fwd)
+  // what the plane of this column would look like (computed once at open: the gcd walks the whole dictionary)
+  int64_t shape_base = 0, shape_scale = 1;
+  int shape_bits = 0;
+  bool shape_is_fwd = false;
   bool plane_ready = false;
 };
 
@@ -311,7 +315,8 @@ void set_dynamic_lds(K kernel, size_t bytes) {
 // When the dictionary is an arithmetic progression (field[d] == d: dense ids, fixed-step values) the dictId stream already IS
 // the plane and nothing is materialised.  PINOT_GPU_PLANE_GCD=0 keeps g = 1.
 struct PlaneShape { int64_t base; int64_t scale; int bits; bool is_fwd; };
-PlaneShape plane_shape(const ColumnDev& col) {
+PlaneShape plane_shape(const ColumnDev& col) { return PlaneShape{col.shape_base, col.shape_scale, col.shape_bits, col.shape_is_fwd}; }
+PlaneShape compute_plane_shape(const ColumnDev& col) {
   PlaneShape ps;
   const int64_t lo = col.h_dict.front(), hi = col.h_dict.back();
   int64_t g = 0;
@@ -956,6 +961,8 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
         }
       }
       if (col.vkind == kValI32) {
+        const PlaneShape ps = compute_plane_shape(col);
+        col.shape_base = ps.base; col.shape_scale = ps.scale; col.shape_bits = ps.bits; col.shape_is_fwd = ps.is_fwd;
         e = hipMalloc((void**)&col.d_dict, C * 4);
         if (e == hipSuccess) e = hipMemcpy(col.d_dict, col.h_dict.data(), C * 4, hipMemcpyHostToDevice);
       } else {

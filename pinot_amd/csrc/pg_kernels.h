@@ -1412,6 +1412,11 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
 
   // (Early "touch" loads of the next column chunks were tried and lost 30 %: vmcnt retires in order, so a wave's own L2 hits
   // queue behind its prefetches that are still on their way from HBM.  Latency is hidden by the other resident waves instead.)
+  // Per wave the chain load -> decode -> load -> decode is what is left between this kernel and the HBM ceiling (C2a reads one
+  // column twice and still takes as long as C2b).  Two ways of overlapping a wave's own loads with its own compute were tried
+  // and dropped: early "touch" loads through the LDS-DMA path (-30 %: vmcnt retires in order, a wave's L2 hits queue behind
+  // its prefetches still coming from HBM), and holding whole column chunks in 31-register arrays loaded one phase ahead (the
+  // arrays cross the width switch, are not promoted to registers and go to scratch: 15-40x slower).
   for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
     uint32_t m = eval_filter_private(p, tile, lane);
     // docs past numDocs (last tile only)

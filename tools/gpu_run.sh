@@ -49,6 +49,8 @@ test)
   echo "== pytest gpu =="; timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 ;;
 testall)
   echo "== pytest gpu (no -x) =="; timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -40 ;;
+benchgcd0)
+  echo "== bench 1B, PINOT_GPU_PLANE_GCD=0 (plain value - min plane) =="; PINOT_GPU_PLANE_GCD=0 timeout 900 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_1B_plane_gcd0.json 2>/dev/null; cat $OUT/bench_1B_plane_gcd0.json | short ;;
 bench)
   echo "== bench 1B =="; timeout 900 python bench.py --steps 20 --warmup 3 --extra > $OUT/bench_1B.json 2> $OUT/bench_1B.err; cat $OUT/bench_1B.json; grep extra $OUT/bench_1B.err ;;
 benchvar)
