@@ -114,7 +114,10 @@ typedef enum pg_predicate_kind {
   PG_PRED_MATCH_NONE = 1,      /* predicateEvaluator.isAlwaysFalse() -> EmptyFilterOperator */
   PG_PRED_DICT_RANGE = 2,      /* SortedDictionaryBasedRangePredicateEvaluator.applySV: lo <= dictId < hi; EQ is [d, d+1) */
   PG_PRED_DICT_SET = 3,        /* DictionaryBasedInPredicateEvaluator.applySV: bit dictId of set_words is set */
-  PG_PRED_RAW_RANGE = 4        /* IntRawValueBasedRangePredicateEvaluator.applySV: lo <= value <= hi (both inclusive) */
+  PG_PRED_RAW_RANGE = 4,       /* IntRawValueBasedRangePredicateEvaluator.applySV: lo <= value <= hi (both inclusive) */
+  PG_PRED_DOC_RANGE = 5        /* SortedIndexBasedFilterOperator (core/operator/filter/SortedIndexBasedFilterOperator.java:60-85): the docId
+                                * range [lo, hi] (both inclusive) that SortedIndexReader.getDocIds gives for the predicate's dictIds on a sorted
+                                * column; `exclusive` inverts it over [0, numDocs).  No column is read.  `column` is ignored. */
 } pg_predicate_kind;
 
 typedef enum pg_leaf_eval {

@@ -696,6 +696,14 @@ static int leaf_to_bitmap(const po_column* cols, const pg_segment_desc* seg, con
     if (all) { memset(words, 0xFF, (size_t)nw * 8); bitmap_clear_tail(words, num_docs); }
     return 0;
   }
+  if (p->kind == PG_PRED_DOC_RANGE) {
+    /* SortedIndexBasedFilterOperator.getTrues -> SortedDocIdSet of one inclusive [start, end] pair (:60-85); exclusive
+     * predicates take the complement over [0, numDocs) (:72-84).  No entries are scanned. */
+    int64_t lo = p->lo < 0 ? 0 : p->lo, hi = p->hi >= num_docs ? (int64_t)num_docs - 1 : p->hi;
+    for (int64_t d = lo; d <= hi; d++) words[d >> 6] |= 1ull << (d & 63);
+    if (p->exclusive) { for (int64_t i = 0; i < nw; i++) words[i] = ~words[i]; bitmap_clear_tail(words, num_docs); }
+    return 0;
+  }
   const po_column* col = &cols[p->column];
   if (p->eval == PG_EVAL_INVERTED) {
     const pg_column_desc* d = col->desc;
@@ -885,7 +893,8 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
     it->kind = 0;
   } else if (q->num_filter_nodes == 1 && q->filter[0].op == PG_FILTER_LEAF &&
              q->predicates[q->filter[0].predicate].eval == PG_EVAL_SCAN &&
-             q->predicates[q->filter[0].predicate].kind >= PG_PRED_DICT_RANGE) {
+             q->predicates[q->filter[0].predicate].kind >= PG_PRED_DICT_RANGE &&
+             q->predicates[q->filter[0].predicate].kind <= PG_PRED_RAW_RANGE) {
     it->kind = 1;
     const pg_predicate* p = &q->predicates[q->filter[0].predicate];
     scan_iter_init(&it->scan, &cols[p->column], p, num_docs);

@@ -188,7 +188,7 @@ char* ph_segment_describe(void* segment, int32_t* status) {
     for (const DataSource& ds : seg->getDataSources()) {
       o << (first ? "" : ", ") << "{\"name\": \"" << jsonEscape(ds.name) << "\", \"dataType\": \"" << dataTypeName(ds.dataType) << "\", \"hasDictionary\": "
         << (ds.hasDictionary ? "true" : "false") << ", \"cardinality\": " << ds.cardinality << ", \"bitsPerElement\": " << ds.bitsPerElement
-        << ", \"hasInvertedIndex\": " << (ds.hasInvertedIndex ? "true" : "false");
+        << ", \"hasInvertedIndex\": " << (ds.hasInvertedIndex ? "true" : "false") << ", \"isSorted\": " << (ds.isSorted ? "true" : "false");
       if (ds.dictionary && ds.cardinality > 0)
         o << ", \"minValue\": \"" << jsonEscape(ds.dictionary->getStringValue(0)) << "\", \"maxValue\": \"" << jsonEscape(ds.dictionary->getStringValue(ds.cardinality - 1)) << "\"";
       o << "}";

@@ -138,6 +138,9 @@ struct DataSource {
   const uint8_t* dictionaryBuffer = nullptr; uint64_t dictionaryBufferSize = 0;   // INT dictionaries only
   const uint8_t* invertedIndex = nullptr; uint64_t invertedIndexSize = 0;
   std::vector<uint8_t> placeholderDictionary;  // STRING columns hand the device a 0..C-1 int dictionary
+  // sorted column: SortedIndexReaderImpl's [startDocId, endDocId] per dictId (2 * cardinality ints); predicates become docId ranges
+  bool isSorted = false;
+  std::vector<int32_t> sortedDocIdRanges;
 };
 
 // ---- sspi/IndexSegment.java / ImmutableSegment: the buffers stay caller-owned, the HBM copy is made by load() ----

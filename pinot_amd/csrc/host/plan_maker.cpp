@@ -204,6 +204,13 @@ void lowerFilter(const FilterContext& f, const ImmutableSegment& seg, LoweredQue
       else if (ev.alwaysFalse) p.kind = PG_PRED_MATCH_NONE;   // EmptyFilterOperator
       else if (ev.rawRange) {
         p.kind = PG_PRED_RAW_RANGE; p.lo = ev.rawLower; p.hi = ev.rawUpper; p.exclusive = ev.exclusive;
+      } else if (ds.isSorted && ev.isRange && (int)ds.sortedDocIdRanges.size() == 2 * ds.cardinality && ev.endDictId > ev.startDictId) {
+        // SortedIndexBasedFilterOperator (priority 0, FilterOperatorUtils.java:96-104): RANGE / EQ / NOT_EQ on a sorted column are the docId
+        // range [start of startDictId, end of endDictId - 1] (SortedIndexBasedFilterOperator.java:60-85); nothing is scanned
+        p.kind = PG_PRED_DOC_RANGE;
+        p.lo = ds.sortedDocIdRanges[2 * (size_t)ev.startDictId];
+        p.hi = ds.sortedDocIdRanges[2 * (size_t)(ev.endDictId - 1) + 1];
+        p.exclusive = ev.exclusive;
       } else {
         p.exclusive = ev.exclusive;
         // FilterOperatorUtils.java:96-133: RANGE predicates scan (no sorted / range index on this path); every other

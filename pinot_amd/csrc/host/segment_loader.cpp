@@ -230,9 +230,12 @@ std::unique_ptr<ImmutableSegment> loadSegmentDirectory(const std::string& indexD
       if (sorted && fwd.size == 2ull * 4ull * (uint64_t)ds.cardinality && !(fwd.size == packedSize && !v3)) {
         // SortedIndexReaderImpl: [startDocId, endDocId] per dictId -> the dictId of every doc, packed like an unsorted column
         std::vector<int32_t> ids((size_t)totalDocs, 0);
+        ds.isSorted = true;
         for (int d = 0; d < ds.cardinality; ++d) {
           const int32_t s = beInt(fwd.data + 8 * (size_t)d), e = beInt(fwd.data + 8 * (size_t)d + 4);
           if (s < 0 || e >= totalDocs || s > e + 1) throw QueryException("column " + col + ": corrupt sorted forward index");
+          ds.sortedDocIdRanges.push_back(s);
+          ds.sortedDocIdRanges.push_back(e);
           for (int32_t doc = s; doc <= e; ++doc) ids[(size_t)doc] = d;
         }
         auto packed = std::make_shared<std::vector<uint8_t>>((size_t)packedSize, 0);

@@ -31,7 +31,8 @@ enum LeafKind : int32_t {
   kLeafBitmap = 5,      // precomputed docId bitmap (inverted-index postings expanded on device)
   kLeafRawRange64 = 6,  // raw LONG column: (uint64)(value - lo64) <= span64
   kLeafRawRangeF64 = 7, // raw DOUBLE column: the same compare on the order-preserving integer image of the value
-  kLeafRawRangeF32 = 8  // raw FLOAT column (widened to double first)
+  kLeafRawRangeF32 = 8, // raw FLOAT column (widened to double first)
+  kLeafDocRange = 9     // (uint32)(docId - lo) <= span: sorted-column predicates resolved to a docId range, no column read
 };
 
 // How an aggregated column's VALUES are represented on the device.

@@ -470,7 +470,8 @@ void build_sequence(const pg_query* q, std::vector<SeqNode>* seq, int* lazy_node
     const int pi = q->filter[ch.first].predicate;
     if (pi < 0 || pi >= q->num_predicates) return false;
     const pg_predicate& pr = q->predicates[pi];
-    return pr.eval == PG_EVAL_INVERTED && (pr.kind == PG_PRED_DICT_RANGE || pr.kind == PG_PRED_DICT_SET);
+    // index-driven leaves go first, like the reference's priorities (sorted 0 < bitmap 100 < scan 500, FilterOperatorUtils.java:205-251)
+    return pr.kind == PG_PRED_DOC_RANGE || (pr.eval == PG_EVAL_INVERTED && (pr.kind == PG_PRED_DICT_RANGE || pr.kind == PG_PRED_DICT_SET));
   };
   std::stable_partition(children.begin(), children.end(), is_bitmap_leaf);
   for (const auto& ch : children) *num_bitmap_prefix += is_bitmap_leaf(ch) ? 1 : 0;
@@ -520,6 +521,12 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
       L.col = 0;
       if (pr.kind == PG_PRED_MATCH_ALL) { L.kind = kLeafMatchAll; }
       else if (pr.kind == PG_PRED_MATCH_NONE) { L.kind = kLeafMatchNone; }
+      else if (pr.kind == PG_PRED_DOC_RANGE) {
+        // SortedIndexBasedFilterOperator: one inclusive docId range; nothing is scanned
+        const int64_t lo = std::max<int64_t>(pr.lo, 0), hi = std::min<int64_t>(pr.hi, (int64_t)seg->num_docs - 1);
+        if (lo > hi) L.kind = kLeafMatchNone;
+        else { L.kind = kLeafDocRange; L.lo = (int32_t)lo; L.span = (uint32_t)(hi - lo); }
+      }
       else {
         if (pr.column < 0 || pr.column >= (int)seg->cols.size()) return fail(PG_ERR_INVALID_ARGUMENT, "predicate column %d out of range", pr.column);
         const ColumnDev& col = seg->cols[pr.column];
@@ -1142,7 +1149,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // The lane-private kernel (no LDS, plain global loads) takes every query whose leaves and aggregations it implements:
     // scan / set / bitmap leaves and raw INT ranges; COUNT, and SUM through a value plane / MIN / MAX on dictionary columns.
     bool use_private = g_engine.scan_private && !typed;
-    for (int l = 0; l < pl.num_leaves && use_private; ++l) use_private = pl.leaves[l].kind <= kLeafBitmap;
+    for (int l = 0; l < pl.num_leaves && use_private; ++l) use_private = pl.leaves[l].kind <= kLeafBitmap || pl.leaves[l].kind == kLeafDocRange;
     for (int i = 0; i < pl.num_agg_cols && use_private; ++i) {
       const DevColumn& c = pl.cols[pl.agg_cols[i].col];
       use_private = !c.is_raw && c.vkind == kValI32 && c.bits <= 31 && (!pl.agg_cols[i].need_sum || c.is_plane);

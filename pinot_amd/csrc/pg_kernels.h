@@ -298,6 +298,14 @@ __device__ __forceinline__ uint32_t eval_leaf(const ScanParams& p, const DevNode
       }
       break;
     }
+    case kLeafDocRange: {
+      const uint32_t first = (uint32_t)tile * 64u * (uint32_t)steps + (uint32_t)lane;     // doc of step 0
+      const uint32_t lo = (uint32_t)L.lo, span = L.span;
+      m = 0;
+#pragma unroll 8
+      for (int k = 0; k < steps; ++k) m |= ((first + 64u * (uint32_t)k - lo) <= span ? 1u : 0u) << k;
+      break;
+    }
     default: {  // kLeafBitmap: doc-order 64-bit words staged in LDS; word k of the tile covers docs 64k..64k+63
       // Lanes 0..31 take the low dwords of words 0..31, lanes 32..63 the high dwords; a 32x32 bit-matrix transpose
       // inside each half-wave (5 ds_swizzle butterfly stages) then leaves in lane i the mask "bit k = bit i of word k".
@@ -1310,6 +1318,17 @@ __device__ __forceinline__ uint32_t eval_leaf_private(const ScanParams& p, const
         for (int j = 0; j < 16; ++j) shift_in_le(m, __builtin_bswap32(v[j]) - lo, span);
       }
       m = __builtin_bitreverse32(m);
+      break;
+    }
+    case kLeafDocRange: {
+      // docs first .. first+31 against [lo, lo+span]: bits [a, b) with a, b clamped to 0..32
+      const long long first = tile * 2048 + lane * 32;
+      const long long lo = (long long)(uint32_t)L.lo, hi = lo + (long long)L.span;
+      const long long a = lo - first < 0 ? 0 : (lo - first > 32 ? 32 : lo - first);
+      const long long b = hi + 1 - first < 0 ? 0 : (hi + 1 - first > 32 ? 32 : hi + 1 - first);
+      const uint32_t below_b = b >= 32 ? 0xFFFFFFFFu : ((1u << (int)b) - 1u);
+      const uint32_t below_a = a >= 32 ? 0xFFFFFFFFu : ((1u << (int)a) - 1u);
+      m = below_b & ~below_a;
       break;
     }
     default: {  // kLeafBitmap: the lane's mask is one dword of the doc-order bitmap

@@ -50,6 +50,11 @@ class Pred:
         return Pred(_abi.PG_PRED_RAW_RANGE, column, lo, hi, exclusive=exclusive)
 
     @staticmethod
+    def doc_range(first_doc, last_doc, exclusive=False):
+        """first_doc <= docId <= last_doc: what SortedIndexBasedFilterOperator derives from a sorted column's [start, end] pairs."""
+        return Pred(_abi.PG_PRED_DOC_RANGE, 0, first_doc, last_doc, exclusive=exclusive)
+
+    @staticmethod
     def raw_range_f64(column, lo, hi, exclusive=False):
         """lo <= value <= hi on a raw FLOAT / DOUBLE column (Float / DoubleRawValueBasedRangePredicateEvaluator)."""
         return Pred(_abi.PG_PRED_RAW_RANGE, column, f64_bits(lo), f64_bits(hi), exclusive=exclusive)

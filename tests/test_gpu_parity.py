@@ -331,3 +331,28 @@ def test_value_plane_and_dictionary_gather_paths_agree(mode, monkeypatch):
     finally:
         monkeypatch.delenv("PINOT_GPU_VALUE_PLANE")
         Engine(device_id=0, time_kernels=True)
+
+
+def test_doc_range_leaves(engine):
+    """Sorted-column predicates arrive as docId ranges (PG_PRED_DOC_RANGE): no column is read for them.  Exercised in the
+    lane-private kernel (plane / dictId aggregations) and in the LDS-staged one (a raw aggregation column forces it)."""
+    rng = np.random.default_rng(23)
+    n = 70_001
+    v = rng.integers(0, 50_000, n).astype(np.int32)
+    f = rng.integers(0, 100, n).astype(np.int32)
+    seg = S.SegmentData("docrange", n, [S.Column.dict_encoded("v", v), S.Column.dict_encoded("f", f), S.Column.raw("r", v)])
+    flt = H.range_pred(seg, "f", upper=30, upper_inclusive=False)
+    with engine.open(seg) as g:
+        for lo, hi, excl in ((0, n - 1, False), (100, 100, False), (2047, 2049, False), (1024, 4095, False), (5000, 60_000, False),
+                             (5000, 60_000, True), (0, 0, True), (n - 5, n + 100, False), (-7, 3, False), (10, 9, False), (2048, 2048 + 31, False)):
+            dr = Q.leaf(Q.Pred.doc_range(lo, hi, exclusive=excl))
+            for filt in (dr, Q.and_(Q.leaf(flt), dr), Q.or_(dr, Q.leaf(flt)), Q.not_(dr)):
+                for aggs in ([(Q.COUNT, -1), (Q.SUM, 0), (Q.MAX, 0)], [(Q.COUNT, -1), (Q.SUM, 2), (Q.MIN, 2)]):
+                    spec = Q.QuerySpec(aggs, filter=filt)
+                    H.assert_results_equal(g.execute(spec), oracle.execute(seg, spec), check_stats=False)
+            spec = Q.QuerySpec([(Q.COUNT, -1)], filter=dr)
+            words, card = g.filter_bitmap(spec)
+            owords, ocard = oracle.filter_bitmap(seg, spec)
+            assert card == ocard and np.array_equal(words, owords)
+        spec = Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0)], filter=Q.leaf(Q.Pred.doc_range(5000, 60_000)), group_by=[1])
+        H.assert_results_equal(g.execute(spec), oracle.execute(seg, spec), check_stats=False)

@@ -55,6 +55,14 @@ def test_sql_over_v3_and_sorted_v1(tmp_path):
             g = host.execute_sql([seg], "SELECT COUNT(*), SUM(v) FROM t WHERE r > 0 GROUP BY k")["segments"][0]
             want = {int(key): (int(((k == key) & (rr > 0)).sum()), float(vv[(k == key) & (rr > 0)].sum())) for key in np.unique(k[rr > 0])}
             assert {r["key"][0]: (r["intermediate"][0], r["intermediate"][1]) for r in g["groups"]} == want
+        # the sorted v1 column answers range / equality predicates with docId ranges (SortedIndexBasedFilterOperator): nothing is scanned
+        assert segs[1].describe()["columns"][1]["isSorted"] or any(c["isSorted"] for c in segs[1].describe()["columns"])
+        st_sorted = host.execute_sql([segs[1]], "SELECT COUNT(*) FROM t WHERE k >= 51 AND k < 101")["segments"][0]
+        st_scan = host.execute_sql([segs[0]], "SELECT COUNT(*) FROM t WHERE k >= 51 AND k < 101")["segments"][0]
+        assert st_sorted["intermediate"] == st_scan["intermediate"] == [int(((k >= 51) & (k < 101)).sum())]
+        assert st_sorted["stats"]["numEntriesScannedInFilter"] == 0 and st_scan["stats"]["numEntriesScannedInFilter"] == 2 * n   # two scan leaves
+        ne = host.execute_sql([segs[1]], "SELECT COUNT(*) FROM t WHERE k != 51")["segments"][0]
+        assert ne["intermediate"] == [int((k != 51).sum())]
         combined = host.execute_sql(segs, "SELECT COUNT(*), SUM(v) FROM t WHERE v IN (1, 2, 3, 5000)")["combined"]
         assert combined["final"][0] == 2.0 * float(np.isin(vv, [1, 2, 3, 5000]).sum())
     finally:

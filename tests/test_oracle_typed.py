@@ -183,3 +183,20 @@ def test_raw_long_and_floating_point_range_predicates():
             assert r.aggregations[0].count == int(((dv >= dlo) & (dv <= dhi)).sum()), (dlo, dhi)
     r = oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.raw_range_f64(2, 10.125, 100.0))))
     assert r.aggregations[0].count == int(((fv >= np.float32(10.125)) & (fv <= np.float32(100.0))).sum())
+
+
+def test_doc_range_predicate_of_sorted_columns():
+    """PG_PRED_DOC_RANGE: the docId range SortedIndexBasedFilterOperator derives from a sorted column's [start, end] pairs."""
+    rng = np.random.default_rng(17)
+    n = 30_000
+    v = rng.integers(0, 1000, n).astype(np.int32)
+    seg = S.SegmentData("sorted", n, [S.Column.dict_encoded("v", v)])
+    docs = np.arange(n)
+    for lo, hi, excl in ((0, n - 1, False), (100, 100, False), (2047, 2049, False), (5000, 20_000, False), (5000, 20_000, True), (0, 0, True),
+                         (n - 5, n + 100, False), (-7, 3, False), (10, 9, False)):
+        r = oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0)], filter=Q.leaf(Q.Pred.doc_range(lo, hi, exclusive=excl))))
+        sel = (docs >= lo) & (docs <= hi)
+        if excl:
+            sel = ~sel
+        assert r.aggregations[0].count == int(sel.sum()) and r.aggregations[1].sum_i64 == int(v[sel].astype(np.int64).sum())
+        assert r.stats[1] == 0      # numEntriesScannedInFilter: a sorted index scans nothing
