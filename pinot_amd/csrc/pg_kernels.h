@@ -1262,6 +1262,40 @@ __device__ __forceinline__ void range16_private(const uint32_t* __restrict__ lan
   for (int j = 0; j < 16; ++j) shift_in_lt(m, kLoZero ? v[j] : v[j] - lo, span);
 }
 
+// C2a shape -- SUM(col) WHERE col in range, one leaf and one summed column reading the SAME stream: decode once, and use the
+// compare's VCC twice (select the value for the sum, then shift the match into the mask).  One load phase per tile instead of two.
+template <int B, int H, bool kLoZero>
+__device__ __forceinline__ void range_sum16_private(const uint32_t* __restrict__ lane_words, uint32_t lo, uint32_t span, uint32_t& m, uint32_t& psum,
+                                                    unsigned long long& wsum) {
+  uint32_t v[16];
+  decode16_private<B, H>(lane_words, v);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t x = kLoZero ? v[j] : v[j] - lo;
+    uint32_t picked;
+    asm("v_cmp_gt_u32 vcc, %3, %2\n\tv_cndmask_b32 %1, 0, %4, vcc\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+        : "+v"(m), "=&v"(picked) : "v"(x), "s"(span), "v"(v[j]) : "vcc");
+    if (B <= 27) psum += picked;          // 32 fields of <= 27 bits fit the 32-bit partial sum
+    else wsum += picked;
+  }
+}
+
+template <bool kLoZero>
+__device__ __forceinline__ uint32_t range_sum_private_dispatch(int b, const uint32_t* lane_words, uint32_t lo, uint32_t span, unsigned long long& wsum) {
+  uint32_t m = 0, psum = 0;
+  switch (b) {
+#define PG_CASE(B) case B: range_sum16_private<B, 0, kLoZero>(lane_words, lo, span, m, psum, wsum); range_sum16_private<B, 1, kLoZero>(lane_words, lo, span, m, psum, wsum); break;
+    PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10)
+    PG_CASE(11) PG_CASE(12) PG_CASE(13) PG_CASE(14) PG_CASE(15) PG_CASE(16) PG_CASE(17) PG_CASE(18) PG_CASE(19) PG_CASE(20)
+    PG_CASE(21) PG_CASE(22) PG_CASE(23) PG_CASE(24) PG_CASE(25) PG_CASE(26) PG_CASE(27) PG_CASE(28) PG_CASE(29) PG_CASE(30)
+    PG_CASE(31)
+#undef PG_CASE
+    default: break;
+  }
+  wsum += psum;
+  return __builtin_bitreverse32(m);
+}
+
 template <bool kLoZero>
 __device__ __forceinline__ uint32_t range_private_dispatch(int b, const uint32_t* lane_words, uint32_t lo, uint32_t span) {
   uint32_t m = 0;
@@ -1436,7 +1470,23 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
   // and dropped: early "touch" loads through the LDS-DMA path (-30 %: vmcnt retires in order, a wave's L2 hits queue behind
   // its prefetches still coming from HBM), and holding whole column chunks in 31-register arrays loaded one phase ahead (the
   // arrays cross the width switch, are not promoted to registers and go to scratch: 15-40x slower).
+  // one inclusive-range leaf and one SUM over the same stream (not exclusive, no MIN / MAX): fused decode
+  const bool fused = p.num_nodes == 1 && p.num_agg_cols == 1 && p.nodes[0].kind == kLeafDictRange && p.nodes[0].exclusive == 0 &&
+                     p.nodes[0].fwd == p.agg_cols[0].fwd && p.nodes[0].bits == p.agg_cols[0].bits && p.agg_cols[0].need_sum != 0 &&
+                     p.agg_cols[0].need_minmax == 0 && p.out_bitmap == nullptr;
   for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
+    if (fused) {
+      const DevNode& L = p.nodes[0];
+      const uint32_t* words = reinterpret_cast<const uint32_t*>(L.fwd + tile * (256ll * L.bits)) + lane * L.bits;
+      unsigned long long wsum = 0;
+      uint32_t fm = L.lo == 0 ? range_sum_private_dispatch<true>(L.bits, words, 0u, L.span, wsum) : range_sum_private_dispatch<false>(L.bits, words, (uint32_t)L.lo, L.span, wsum);
+      // the padding past numDocs decodes to field 0: it can only match when lo == 0, and then it adds 0 to the sum
+      const long long frem = (long long)p.num_docs - (tile * 2048 + lane * 32);
+      fm &= frem >= 32 ? 0xFFFFFFFFu : (frem <= 0 ? 0u : ((1u << (int)frem) - 1u));
+      count += (unsigned)__builtin_popcount(fm);
+      sum[0] += wsum;
+      continue;
+    }
     uint32_t m = eval_filter_private(p, tile, lane);
     // docs past numDocs (last tile only)
     const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
