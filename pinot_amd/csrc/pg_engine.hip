@@ -17,6 +17,7 @@
 #include "../../include/pinot_gpu.h"
 #include "pg_device.h"
 #include "pg_kernels.h"
+#include "pg_launch.h"
 
 namespace {
 
@@ -300,11 +301,6 @@ void free_segment(pg_segment* seg) {
     if (col.d_plane && !col.plane_is_fwd) (void)hipFree(col.d_plane);
   }
   delete seg;
-}
-
-template <typename K>
-void set_dynamic_lds(K kernel, size_t bytes) {
-  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 // ---- value planes ----
@@ -673,16 +669,6 @@ struct Geometry {
 };
 
 constexpr size_t kLdsBudget = 156 * 1024;     // of the 160 KiB per CU; leaves room for the runtime's own use
-
-// Wavefronts per CU the register file admits for a kernel: 512 VGPRs per SIMD lane in 8-register granules, at most 6
-// because these kernels use ~100 SGPRs (MI355X_MICROARCH.md: 256-thread blocks admitted = floor(800 / (sgpr granule + 16))).
-template <typename K>
-int max_waves_per_cu(K kernel) {
-  hipFuncAttributes attr;
-  if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) != hipSuccess || attr.numRegs <= 0) return 16;
-  const int alloc = ((attr.numRegs + 7) / 8) * 8;
-  return std::max(1, std::min(6, 512 / alloc)) * 4;
-}
 
 // Lays out the per-wave LDS region (one staging slot per packed column, 256 bytes per bitmap leaf, the gather queue),
 // then picks tile size (32 or 16 steps) and workgroup size so that the most wavefronts stay resident per CU within the
@@ -1155,17 +1141,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       use_private = !c.is_raw && c.vkind == kValI32 && c.bits <= 31 && (!pl.agg_cols[i].need_sum || c.is_plane);
     }
     Geometry geo;
-    static const int agg_wave_cap1 = max_waves_per_cu(scan_agg_kernel<true, 1>);
-    static const int agg_wave_cap4 = max_waves_per_cu(scan_agg_kernel<true, kMaxAggCols>);
-    static const int agg_wave_cap_typed = max_waves_per_cu(scan_agg_kernel<true, kMaxAggCols, true>);
-    const int agg_wave_cap = typed ? agg_wave_cap_typed : (pl.num_agg_cols <= 1 ? agg_wave_cap1 : agg_wave_cap4);
+    const int agg_wave_cap = waves_scan_agg(pl.num_agg_cols <= 1, typed);
     finish_geometry(seg, &lw, 0, need_queue, kBlockThreads / 64, agg_wave_cap, &geo);
     int blocks = geo.blocks;
     const size_t lds = geo.lds;
     if (use_private) {
-      static const int private_cap1 = max_waves_per_cu(scan_private_kernel<1>);
-      static const int private_cap4 = max_waves_per_cu(scan_private_kernel<kMaxAggCols>);
-      const int cap = pl.num_agg_cols <= 1 ? private_cap1 : private_cap4;
+      const int cap = waves_scan_private(pl.num_agg_cols <= 1);
       int bpc = std::max(1, cap / (kBlockThreads / 64));
       if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
       const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
@@ -1186,19 +1167,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
-    if (use_private) {
-      if (one) scan_private_kernel<1><<<dim3((unsigned)blocks), dim3(kBlockThreads), 0, ctx->stream>>>(sp);
-      else scan_private_kernel<kMaxAggCols><<<dim3((unsigned)blocks), dim3(kBlockThreads), 0, ctx->stream>>>(sp);
-    } else if (typed) {
-      if (g_engine.use_dma) { set_dynamic_lds(scan_agg_kernel<true, kMaxAggCols, true>, lds); scan_agg_kernel<true, kMaxAggCols, true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
-      else { set_dynamic_lds(scan_agg_kernel<false, kMaxAggCols, true>, lds); scan_agg_kernel<false, kMaxAggCols, true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
-    } else if (g_engine.use_dma) {
-      if (one) { set_dynamic_lds(scan_agg_kernel<true, 1>, lds); scan_agg_kernel<true, 1><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
-      else { set_dynamic_lds(scan_agg_kernel<true, kMaxAggCols>, lds); scan_agg_kernel<true, kMaxAggCols><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
-    } else {
-      if (one) { set_dynamic_lds(scan_agg_kernel<false, 1>, lds); scan_agg_kernel<false, 1><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
-      else { set_dynamic_lds(scan_agg_kernel<false, kMaxAggCols>, lds); scan_agg_kernel<false, kMaxAggCols><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(sp); }
-    }
+    if (use_private) launch_scan_private(one, blocks, ctx->stream, sp);
+    else launch_scan_agg(g_engine.use_dma, one, typed, blocks, geo.threads, lds, ctx->stream, sp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     finalize_partials_kernel<<<dim3(1), dim3(kBlockThreads), 0, ctx->stream>>>(ctx->d_partials, blocks);
@@ -1319,7 +1289,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     gp.table_acc = reinterpret_cast<long long*>(ctx->d_table + gp.num_groups);
     const size_t table_bytes = table_words * 8;
     Geometry geo;
-    static const int group_wave_cap = max_waves_per_cu(scan_group_kernel<true, true>);
+    const int group_wave_cap = waves_scan_group();
     finish_geometry(seg, &lw, table_bytes, false, g_engine.group_waves > 0 ? std::min(g_engine.group_waves, kGroupBlockThreads / 64) : kGroupBlockThreads / 64, group_wave_cap, &geo);
     if ((size_t)sp.wave_lds_bytes > kLdsBudget) return fail(PG_ERR_UNSUPPORTED, "query needs %d bytes of LDS per wavefront", sp.wave_lds_bytes);
     gp.use_lds_table = geo.table_in_lds ? 1 : 0;
@@ -1352,7 +1322,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     int pblocks = blocks, pthreads = geo.threads;
     size_t plds = lds;
     if (use_private) {
-      static const int private_wave_cap = max_waves_per_cu(group_private_kernel<true>);
+      const int private_wave_cap = waves_group_private();
       const bool in_lds = table_bytes <= 96 * 1024;
       gp.use_lds_table = in_lds ? 1 : 0;
       int waves = in_lds ? kGroupBlockThreads / 64 : kBlockThreads / 64;
@@ -1389,16 +1359,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     init_group_table_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(gp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
-    if (use_private) {
-      if (gp.use_lds_table) { set_dynamic_lds(group_private_kernel<true>, plds); group_private_kernel<true><<<dim3((unsigned)pblocks), dim3((unsigned)pthreads), plds, ctx->stream>>>(gp); }
-      else group_private_kernel<false><<<dim3((unsigned)pblocks), dim3((unsigned)pthreads), 0, ctx->stream>>>(gp);
-    } else if (gp.use_lds_table) {
-      if (g_engine.use_dma) { set_dynamic_lds(scan_group_kernel<true, true>, lds); scan_group_kernel<true, true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(gp); }
-      else { set_dynamic_lds(scan_group_kernel<false, true>, lds); scan_group_kernel<false, true><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(gp); }
-    } else {
-      if (g_engine.use_dma) { set_dynamic_lds(scan_group_kernel<true, false>, lds); scan_group_kernel<true, false><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(gp); }
-      else { set_dynamic_lds(scan_group_kernel<false, false>, lds); scan_group_kernel<false, false><<<dim3((unsigned)blocks), dim3((unsigned)geo.threads), lds, ctx->stream>>>(gp); }
-    }
+    if (use_private) launch_group_private(gp.use_lds_table != 0, pblocks, pthreads, plds, ctx->stream, gp);
+    else launch_scan_group(g_engine.use_dma, gp.use_lds_table != 0, blocks, geo.threads, lds, ctx->stream, gp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->h_table, ctx->d_table, table_bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -845,7 +845,7 @@ __device__ __forceinline__ void partial_merge(BlockPartial& acc, const BlockPart
   }
 }
 
-__global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockPartial* partials, int num_blocks) {
+static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockPartial* partials, int num_blocks) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   BlockPartial acc;
   partial_identity(acc);
@@ -1655,7 +1655,7 @@ __global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const
   }
 }
 
-__global__ void init_group_table_kernel(GroupParams gp) {
+static __global__ void init_group_table_kernel(GroupParams gp) {
   const int G = gp.num_groups;
   for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x) {
     gp.table_count[g] = 0ull;
@@ -1676,7 +1676,7 @@ __device__ __forceinline__ uint32_t load_u16(const uint8_t* p) { return (uint32_
 // One workgroup per 64 Ki-doc window (key = blockIdx.x): it looks its container up in the posting's sorted directory
 // slice, builds the 8 KiB window in LDS and either STORES it (first posting of a leaf: no separate zero-fill pass,
 // windows without a container become zeros) or ORs it into the bitmap (further postings of an IN / range leaf).
-__global__ __launch_bounds__(kBlockThreads) void roaring_expand_kernel(const uint8_t* __restrict__ inv, const DevContainer* __restrict__ dir,
+static __global__ __launch_bounds__(kBlockThreads) void roaring_expand_kernel(const uint8_t* __restrict__ inv, const DevContainer* __restrict__ dir,
                                                                        int first, int count, unsigned long long* bitmap, long long num_words, int or_mode) {
   __shared__ unsigned long long w[1024];
   __shared__ int found;
@@ -1738,7 +1738,7 @@ __global__ __launch_bounds__(kBlockThreads) void roaring_expand_kernel(const uin
 // with the same code.  It trades HBM capacity (288 GB) for the per-row dictionary gather, which on MI355X costs as
 // much L2 capacity as streaming ~22 bytes (profiles/r1/microbench.jsonl).  w == 32 stores big-endian int32 values.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlockThreads) void materialize_plane_kernel(const DevColumn col, uint8_t* __restrict__ out, int w, int32_t base,
+static __global__ __launch_bounds__(kBlockThreads) void materialize_plane_kernel(const DevColumn col, uint8_t* __restrict__ out, int w, int32_t base,
                                                                           int num_docs, int num_tiles, int in_slot_bytes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63;
@@ -1783,7 +1783,7 @@ __global__ __launch_bounds__(kBlockThreads) void materialize_plane_kernel(const 
   }
 }
 
-__global__ void fill_words_kernel(unsigned long long* words, long long n, unsigned long long value) {
+static __global__ void fill_words_kernel(unsigned long long* words, long long n, unsigned long long value) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) words[i] = value;
 }
 
@@ -1801,7 +1801,7 @@ __device__ __forceinline__ uint32_t read_packed(const uint8_t* fwd, long long do
   return (uint32_t)((win >> (64 - s - b)) & ((1ull << b) - 1ull));
 }
 
-__global__ void gather_values_kernel(DevColumn col, long long value_base, const int32_t* __restrict__ doc_ids, int n, int32_t* out_dict_ids,
+static __global__ void gather_values_kernel(DevColumn col, long long value_base, const int32_t* __restrict__ doc_ids, int n, int32_t* out_dict_ids,
                                      int32_t* out_ints, long long* out_longs, double* out_doubles) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -1,0 +1,41 @@
+// pg_launch.h -- host-callable launchers of the big kernel templates.  Each family is instantiated in its own translation unit
+// (pg_unit_*.hip) so that the four of them compile in parallel; pg_engine.hip only sees these declarations.
+#ifndef PG_LAUNCH_H
+#define PG_LAUNCH_H
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "pg_device.h"
+
+namespace pg {
+
+// Wavefronts per CU the register file admits for a kernel: 512 VGPRs per SIMD lane in 8-register granules, at most 6
+// because these kernels use ~100 SGPRs (MI355X_MICROARCH.md: 256-thread blocks admitted = floor(800 / (sgpr granule + 16))).
+template <typename K>
+int max_waves_per_cu(K kernel) {
+  hipFuncAttributes attr;
+  if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) != hipSuccess || attr.numRegs <= 0) return 16;
+  const int alloc = ((attr.numRegs + 7) / 8) * 8;
+  return std::max(1, std::min(6, 512 / alloc)) * 4;
+}
+template <typename K>
+void set_dynamic_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// scan_agg_kernel<kDma, slots (1 | kMaxAggCols), typed>: the LDS-staged scan -> filter -> aggregate kernel
+void launch_scan_agg(bool dma, bool one_slot, bool typed, int blocks, int threads, size_t lds, hipStream_t stream, const ScanParams& p);
+int waves_scan_agg(bool one_slot, bool typed);
+// scan_private_kernel<slots>: the lane-private scan -> filter -> aggregate kernel
+void launch_scan_private(bool one_slot, int blocks, hipStream_t stream, const ScanParams& p);
+int waves_scan_private(bool one_slot);
+// scan_group_kernel<kDma, kLdsTable>: LDS-staged group-by
+void launch_scan_group(bool dma, bool lds_table, int blocks, int threads, size_t lds, hipStream_t stream, const GroupParams& gp);
+int waves_scan_group();
+// group_private_kernel<kLdsTable>: lane-private group-by (no filter)
+void launch_group_private(bool lds_table, int blocks, int threads, size_t lds, hipStream_t stream, const GroupParams& gp);
+int waves_group_private();
+
+}  // namespace pg
+#endif

@@ -1,0 +1,18 @@
+// Instantiates group_private_kernel (the lane-private group-by kernel) -- see pg_launch.h.
+#include "pg_kernels.h"
+#include "pg_launch.h"
+
+namespace pg {
+
+void launch_group_private(bool lds_table, int blocks, int threads, size_t lds, hipStream_t stream, const GroupParams& gp) {
+  const dim3 grid((unsigned)blocks), block((unsigned)threads);
+  if (lds_table) { set_dynamic_lds(group_private_kernel<true>, lds); group_private_kernel<true><<<grid, block, lds, stream>>>(gp); }
+  else group_private_kernel<false><<<grid, block, 0, stream>>>(gp);
+}
+
+int waves_group_private() {
+  static const int cap = max_waves_per_cu(group_private_kernel<true>);
+  return cap;
+}
+
+}  // namespace pg
