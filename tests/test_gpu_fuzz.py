@@ -1,0 +1,101 @@
+"""Randomised parity: random segments (every packed width 1..31, affine and irregular dictionaries, ragged sizes), random filter
+trees (range / set / docId-range / inverted leaves, AND / OR / NOT, exclusive predicates) and random aggregation lists and
+group-bys, HIP path vs. oracle, bit exact.  Seeds are fixed: a failure reproduces."""
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import oracle
+from pinot_amd import _abi
+from pinot_amd import query as Q
+from pinot_amd import segment as S
+
+pytestmark = pytest.mark.gpu
+
+
+def forced_width_column(rng, name, n, card, bits, affine, with_inverted=False):
+    """A `card`-entry dictionary packed at `bits` bits per dictId (bits >= the natural width)."""
+    if affine:
+        values = (np.arange(card, dtype=np.int64) * int(rng.integers(1, 9)) + int(rng.integers(-1000, 1000))).astype(np.int32)
+    else:
+        values = np.sort(rng.choice(np.arange(-2 ** 20, 2 ** 20, dtype=np.int64), card, replace=False)).astype(np.int32)
+    ids = rng.integers(0, card, n).astype(np.int32)
+    col = S.Column.from_dict_ids(name, values, ids, with_inverted=with_inverted)
+    if bits > col.bits:
+        host = S.load_host_library()
+        col.bits = bits
+        col.fwd = np.zeros(int(host.ph_fixedbit_size(n, bits)), dtype=np.uint8)
+        if n:
+            host.ph_fixedbit_pack(S._i32p(ids), n, bits, S._u8p(col.fwd), 2)
+    return col
+
+
+def random_leaf(rng, seg, n):
+    kind = rng.integers(0, 5)
+    ci = int(rng.integers(0, len(seg.columns)))
+    col = seg.columns[ci]
+    card = col.cardinality
+    excl = bool(rng.integers(0, 4) == 0)
+    if kind == 0 or card < 3:
+        lo = int(rng.integers(0, card))
+        hi = int(rng.integers(lo, card + 1))
+        if hi == lo:
+            hi = min(card, lo + 1)
+        return Q.leaf(Q.Pred.dict_range(ci, lo, hi, exclusive=excl))
+    if kind == 1:
+        ids = sorted(set(int(x) for x in rng.integers(0, card, int(rng.integers(1, 6)))))
+        return Q.leaf(Q.Pred.dict_set(ci, ids, card, exclusive=excl))
+    if kind == 2:
+        lo = int(rng.integers(-5, n + 5))
+        return Q.leaf(Q.Pred.doc_range(lo, lo + int(rng.integers(0, n + 1)), exclusive=excl))
+    if kind == 3 and col.inverted is not None:
+        d = int(rng.integers(0, card))
+        return Q.leaf(Q.Pred.dict_range(ci, d, min(card, d + int(rng.integers(1, 4))), exclusive=excl, inverted=True))
+    return Q.leaf(Q.Pred.dict_range(ci, 0, max(1, card // 2), exclusive=excl))
+
+
+def random_tree(rng, seg, n, depth):
+    if depth == 0 or rng.integers(0, 3) == 0:
+        return random_leaf(rng, seg, n)
+    op = rng.integers(0, 3)
+    if op == 2:
+        return Q.not_(random_tree(rng, seg, n, depth - 1))
+    kids = [random_tree(rng, seg, n, depth - 1) for _ in range(int(rng.integers(2, 4)))]
+    return Q.and_(*kids) if op == 0 else Q.or_(*kids)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_segments_and_queries(engine, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 31, 32, 33, 2047, 2048, 2049, 4097, 9001, 20_011]))
+    cols = []
+    for c in range(3):
+        card = int(rng.choice([2, 3, 7, 64, 1000, 5000]))
+        natural = max(1, int(np.ceil(np.log2(card))))
+        bits = int(rng.integers(natural, 32)) if rng.integers(0, 2) else natural
+        cols.append(forced_width_column(rng, "c%d" % c, n, card, bits, affine=bool(rng.integers(0, 2)), with_inverted=(c == 0)))
+    seg = S.SegmentData("fuzz%d" % seed, n, cols)
+    funcs = [Q.COUNT, Q.SUM, Q.MIN, Q.MAX, Q.AVG]
+    with engine.open(seg) as g:
+        for q in range(12):
+            aggs = [(int(f), -1 if f == Q.COUNT else int(rng.integers(0, 3))) for f in rng.choice(funcs, int(rng.integers(1, 5)))]
+            flt = random_tree(rng, seg, n, 2) if rng.integers(0, 5) else None
+            group_by = []
+            if rng.integers(0, 3) == 0:
+                group_by = [int(x) for x in rng.choice(3, int(rng.integers(1, 3)), replace=False)]
+                if np.prod([seg.columns[x].cardinality for x in group_by]) > 10_000:
+                    group_by = group_by[:1]
+            try:
+                spec = Q.QuerySpec(aggs, filter=flt, group_by=group_by)
+            except Exception:
+                continue
+            try:
+                got = g.execute(spec)
+            except _abi.PinotGpuError as e:
+                assert e.status == _abi.PG_ERR_UNSUPPORTED, e      # e.g. more than 8 leaves: a plan-time fallback, not a wrong answer
+                continue
+            H.assert_results_equal(got, oracle.execute(seg, spec), check_stats=False)
+            if flt is not None and not group_by:
+                words, card = g.filter_bitmap(spec)
+                owords, ocard = oracle.filter_bitmap(seg, spec)
+                assert card == ocard and np.array_equal(words, owords)
