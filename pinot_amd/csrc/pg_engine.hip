@@ -1318,7 +1318,10 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
     // Without a filter every tile is aggregated in full: the lane-private kernel decodes straight from HBM and needs LDS only
     // for the table (group_private_kernel).
-    const bool use_private = g_engine.group_private && pl.num_nodes == 0 && gp.dense_ok && !want_bitmap;
+    // every leaf kind the lane-private filter implements (scan / set / bitmap / docId-range leaves, raw INT ranges)
+    bool private_leaves = true;
+    for (int l = 0; l < pl.num_leaves; ++l) private_leaves &= pl.leaves[l].kind <= kLeafBitmap || pl.leaves[l].kind == kLeafDocRange;
+    const bool use_private = g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap;
     int pblocks = blocks, pthreads = geo.threads;
     size_t plds = lds;
     if (use_private) {

@@ -1533,12 +1533,12 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
   }
 }
 
-// One 2048-doc tile.  kTail: the last, partial tile -- docs past numDocs are masked out of every atomic.
-template <bool kLds, bool kTail>
-__device__ __forceinline__ void group_private_tile(const GroupParams& gp, long long tile, int lane, unsigned long long* t_cnt, long long* t_acc) {
+// One 2048-doc tile.  kMasked: only the docs whose bit is set in the lane's mask `m` reach the table (a filter's result, and /
+// or the docs that exist in the last, partial tile); otherwise every doc of the tile does, with no exec masking around the atomics.
+template <bool kLds, bool kMasked>
+__device__ __forceinline__ void group_private_tile(const GroupParams& gp, long long tile, int lane, uint32_t m, unsigned long long* t_cnt, long long* t_acc) {
   const int G = gp.num_groups;
   const long long first_doc = tile * 2048 + lane * 32;
-  const int valid = kTail ? (int)((long long)gp.scan.num_docs - first_doc) : 32;      // docs of this lane that exist
   uint32_t g[32];
   for (int c = 0; c < gp.num_group_cols; ++c) {
     const DevGroupKey& key = gp.group_keys[c];
@@ -1556,7 +1556,7 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
   const bool packed = kLds && gp.packed_agg >= 0;
   if (!packed) {
 #pragma unroll
-    for (int j = 0; j < 32; ++j) if (!kTail || j < valid) group_count<kLds>(t_cnt, g[j]);
+    for (int j = 0; j < 32; ++j) if (!kMasked || ((m >> j) & 1u)) group_count<kLds>(t_cnt, g[j]);
   }
   for (int a = 0; a < gp.num_group_aggs; ++a) {
     const DevGroupAgg& ga = gp.group_aggs[a];
@@ -1573,7 +1573,7 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
       if (ga.is_raw) {
         // raw INT column: the lane's 32 docs are 128 contiguous bytes
 #pragma unroll
-        for (int j = 0; j < 16; ++j) d[j] = (!kTail || 16 * h + j < valid) ? __builtin_bswap32(words[16 * h + j]) : 0u;
+        for (int j = 0; j < 16; ++j) d[j] = __builtin_bswap32(words[16 * h + j]);      // raw buffers are padded to whole tiles
       } else {
         if (h == 0) decode16_private_dispatch<0>(b, words, d); else decode16_private_dispatch<1>(b, words, d);
         if (ga.kind == kGroupSum && !ga.is_plane) {
@@ -1586,17 +1586,17 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
         // plane field; the packed count lives entirely in the high dword: the operand is the register pair {field, one_hi}
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-          if (!kTail || 16 * h + j < valid) group_sum<kLds>(acc + g[16 * h + j], (long long)(((unsigned long long)one_hi << 32) | (unsigned long long)d[j]));
+          if (!kMasked || ((m >> (16 * h + j)) & 1u)) group_sum<kLds>(acc + g[16 * h + j], (long long)(((unsigned long long)one_hi << 32) | (unsigned long long)d[j]));
       } else if (ga.kind == kGroupSum) {
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-          if (!kTail || 16 * h + j < valid) group_sum<kLds>(acc + g[16 * h + j], (long long)(int32_t)d[j]);
+          if (!kMasked || ((m >> (16 * h + j)) & 1u)) group_sum<kLds>(acc + g[16 * h + j], (long long)(int32_t)d[j]);
       } else if (ga.kind == kGroupMin) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) if (!kTail || 16 * h + j < valid) group_min<kLds>(acc + g[16 * h + j], (int32_t)d[j]);
+        for (int j = 0; j < 16; ++j) if (!kMasked || ((m >> (16 * h + j)) & 1u)) group_min<kLds>(acc + g[16 * h + j], (int32_t)d[j]);
       } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) if (!kTail || 16 * h + j < valid) group_max<kLds>(acc + g[16 * h + j], (int32_t)d[j]);
+        for (int j = 0; j < 16; ++j) if (!kMasked || ((m >> (16 * h + j)) & 1u)) group_max<kLds>(acc + g[16 * h + j], (int32_t)d[j]);
       }
     }
   }
@@ -1628,11 +1628,17 @@ __global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const
     t_cnt = gp.table_count;
     t_acc = gp.table_acc;
   }
-  const long long full_tiles = (long long)gp.scan.num_docs / 2048;
+  const long long num_tiles = ((long long)gp.scan.num_docs + 2047) / 2048;
   const long long wave = (long long)blockIdx.x * waves_per_block + wave_in_block;
-  for (long long tile = wave; tile < full_tiles; tile += total_waves) group_private_tile<kLdsTable, false>(gp, tile, lane, t_cnt, t_acc);
-  // the partial last tile goes to the wave that would have been next in the round-robin
-  if ((gp.scan.num_docs & 2047) != 0 && wave == full_tiles % total_waves) group_private_tile<kLdsTable, true>(gp, full_tiles, lane, t_cnt, t_acc);
+  for (long long tile = wave; tile < num_tiles; tile += total_waves) {
+    // the filter (if any) in the same lane-private layout: bit j of the lane's mask = doc 32*lane + j of the tile
+    uint32_t m = eval_filter_private(gp.scan, tile, lane);
+    const long long rem = (long long)gp.scan.num_docs - (tile * 2048 + lane * 32);
+    m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
+    if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
+    if (__builtin_amdgcn_ballot_w64(m != 0xFFFFFFFFu) == 0ull) group_private_tile<kLdsTable, false>(gp, tile, lane, m, t_cnt, t_acc);
+    else group_private_tile<kLdsTable, true>(gp, tile, lane, m, t_cnt, t_acc);
+  }
 
   if constexpr (kLdsTable) {
     __syncthreads();

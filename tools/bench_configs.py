@@ -24,14 +24,17 @@ from pinot_amd import segment as S  # noqa: E402
 from pinot_amd.engine import Engine  # noqa: E402
 
 
+SETTLE = 40     # untimed launches that step through the GPU clock transient; --no-settle sets 2
+
+
 def timed(gseg, spec, reps=8):
     res = _abi.pg_result()
     ms, dev = [], []
-    for i in range(reps + 2):
+    for i in range(reps + SETTLE):
         st = gseg.execute_raw(spec, res)
         if st != _abi.PG_OK:
             raise RuntimeError(gseg.lib.pg_last_error().decode())
-        if i >= 2:
+        if i >= SETTLE:
             ms.append(res.dominant_kernel_ms)
             dev.append(res.device_ms)
             timed.cycles = [int(c) for c in res.profile_cycles] + [int(res.profile_waves)]
@@ -74,12 +77,15 @@ def main():
     ap.add_argument("--rows-c5", type=int, default=250_000_000)
     ap.add_argument("--out", default=None)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-settle", action="store_true")
     ap.add_argument("--profile-waves", action="store_true")
     ap.add_argument("--only", default="")
     ap.add_argument("--match", default="", help="regexp: run only the queries whose label matches (segments nobody needs are skipped)")
     args = ap.parse_args()
     import re
-    global MATCH
+    global MATCH, SETTLE
+    if args.no_settle:
+        SETTLE = 2
     MATCH = re.compile(args.match) if args.match else None
     want = lambda prefix: MATCH is None or prefix in args.match
     engine = Engine(device_id=0, time_kernels=True, profile_waves=args.profile_waves)
