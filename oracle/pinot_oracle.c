@@ -883,6 +883,45 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       if (po_raw_open((const uint8_t*)seg->columns[c].fwd_data, seg->columns[c].fwd_size, &cols[c].raw)) { free(cols); return 1; }
     }
   }
+  /* AggregationPlanNode.buildNonFilteredAggOperator (core/plan/AggregationPlanNode.java:98-115): when the filter matches all docs
+   * and every function is COUNT or a dictionary-based MIN / MAX (isFitForNonScanBasedPlan :159-190), NonScanBasedAggregationOperator
+   * answers from the metadata and the dictionary ends (NonScanBasedAggregationOperator.java:83-105) with statistics
+   * (totalDocs, 0, 0, totalDocs). */
+  if (q->num_group_by == 0 && q->num_aggregations > 0) {
+    int match_all = q->num_filter_nodes == 0;
+    if (q->num_filter_nodes == 1 && q->filter[0].op == PG_FILTER_LEAF) {
+      const pg_predicate* p = &q->predicates[q->filter[0].predicate];
+      match_all = (p->kind == PG_PRED_MATCH_ALL && !p->exclusive) || (p->kind == PG_PRED_MATCH_NONE && p->exclusive);
+    }
+    int fit = match_all;
+    for (int a = 0; a < q->num_aggregations && fit; a++) {
+      int func = q->aggregations[a].function, c = q->aggregations[a].column;
+      if (func == PG_AGG_COUNT) continue;
+      fit = (func == PG_AGG_MIN || func == PG_AGG_MAX) && c >= 0 && c < seg->num_columns && seg->columns[c].fwd_encoding == PG_FWD_FIXED_BIT_DICT;
+    }
+    if (fit) {
+      int na0 = q->num_aggregations;
+      res->num_aggregations = na0;
+      res->aggregations = (pg_agg_value*)calloc((size_t)na0, sizeof(pg_agg_value));
+      for (int a = 0; a < na0; a++) {
+        pg_agg_value* v = &res->aggregations[a];
+        int func = q->aggregations[a].function;
+        v->count = num_docs; v->min = INFINITY; v->max = -INFINITY;
+        if (func == PG_AGG_MIN || func == PG_AGG_MAX) {
+          const pg_column_desc* d = &seg->columns[q->aggregations[a].column];
+          const uint8_t* dict = (const uint8_t*)d->dict_data;
+          int32_t id = func == PG_AGG_MIN ? 0 : d->cardinality - 1;       /* dictionary.getMinVal() / getMaxVal() */
+          double val = d->stored_type == PG_TYPE_INT ? (double)dict_get_int(dict, id) : d->stored_type == PG_TYPE_LONG ? (double)dict_get_long(dict, id)
+                     : d->stored_type == PG_TYPE_FLOAT ? (double)dict_get_float(dict, id) : dict_get_double(dict, id);
+          if (func == PG_AGG_MIN) v->min = val; else v->max = val;
+        }
+      }
+      res->stats.num_docs_scanned = num_docs;
+      res->stats.num_total_docs = num_docs;
+      free(cols);
+      return 0;
+    }
+  }
   int rc = 0;
   int64_t entries_in_filter = 0;
   po_doc_iter* it = (po_doc_iter*)calloc(1, sizeof(po_doc_iter));

@@ -1074,6 +1074,45 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   if (ng > kMaxGroupCols) return fail(PG_ERR_UNSUPPORTED, "more than %d group-by columns", kMaxGroupCols);
   const bool timed = (g_engine.flags & PG_CFG_TIME_KERNELS) != 0;
 
+  // NonScanBasedAggregationOperator (core/plan/AggregationPlanNode.java:98-115,159-190; core/operator/query/
+  // NonScanBasedAggregationOperator.java:83-105): the filter matches everything and every function is COUNT, or MIN / MAX of a
+  // dictionary column -> the answer comes from the segment metadata and the dictionary ends; nothing is scanned.
+  if (ng == 0 && !want_bitmap && out && na > 0) {
+    bool match_all = q->num_filter_nodes == 0;
+    if (q->num_filter_nodes == 1 && q->filter && q->predicates && q->filter[0].op == PG_FILTER_LEAF && q->filter[0].predicate >= 0 &&
+        q->filter[0].predicate < q->num_predicates) {
+      const pg_predicate& pr = q->predicates[q->filter[0].predicate];
+      match_all = (pr.kind == PG_PRED_MATCH_ALL && !pr.exclusive) || (pr.kind == PG_PRED_MATCH_NONE && pr.exclusive);
+    }
+    bool fit = match_all;
+    for (int a = 0; a < na && fit; ++a) {
+      const pg_aggregation& ag = q->aggregations[a];
+      if (ag.function == PG_AGG_COUNT) continue;
+      fit = (ag.function == PG_AGG_MIN || ag.function == PG_AGG_MAX) && ag.column >= 0 && ag.column < (int)seg->cols.size() &&
+            seg->cols[(size_t)ag.column].encoding == PG_FWD_FIXED_BIT_DICT;
+    }
+    if (fit) {
+      memset(out, 0, sizeof(*out));
+      out->num_aggregations = na;
+      out->aggregations = (pg_agg_value*)calloc((size_t)na, sizeof(pg_agg_value));
+      for (int a = 0; a < na; ++a) {
+        const pg_aggregation& ag = q->aggregations[a];
+        pg_agg_value& v = out->aggregations[a];
+        v.count = seg->num_docs;
+        v.min = std::numeric_limits<double>::infinity();
+        v.max = -std::numeric_limits<double>::infinity();
+        if (ag.function == PG_AGG_MIN) v.min = seg->cols[(size_t)ag.column].h_dict_f64.front();
+        if (ag.function == PG_AGG_MAX) v.max = seg->cols[(size_t)ag.column].h_dict_f64.back();
+      }
+      out->stats.num_docs_scanned = seg->num_docs;          // NonScanBasedAggregationOperator.getExecutionStatistics: (totalDocs, 0, 0, totalDocs)
+      out->stats.num_entries_scanned_in_filter = 0;
+      out->stats.num_entries_scanned_post_filter = 0;
+      out->stats.num_total_docs = seg->num_docs;
+      if (out_cardinality) *out_cardinality = seg->num_docs;
+      return PG_OK;
+    }
+  }
+
   Lowered lw;
   memset(&lw.sp, 0, sizeof(lw.sp));
   memset(&lw.plan, 0, sizeof(lw.plan));

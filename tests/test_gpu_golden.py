@@ -85,3 +85,17 @@ def test_segment_written_by_the_reference_java_writers(engine):
         r = gseg.execute(Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, s, e))))
         assert r.intermediates() == [4, float(1228 + 837 + 1209 + 824)]
         H.assert_results_equal(r, oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, s, e)))))
+
+
+def test_non_scan_based_aggregation_plan(engine):
+    """COUNT / dictionary-based MIN, MAX without a filter are answered from the metadata (NonScanBasedAggregationOperator): same
+    values and the reference's statistics (totalDocs, 0, 0, totalDocs), no kernel launch."""
+    seg = H.golden_segment(use_inverted=False)
+    ci = seg.column_index
+    with engine.open(seg) as g:
+        spec = Q.QuerySpec([(Q.COUNT, -1), (Q.MAX, ci("column3")), (Q.MIN, ci("column6"))])
+        r = g.execute(spec)
+        assert r.intermediates() == [30000, 2147419555.0, 1689277.0] and r.stats == (30000, 0, 0, 30000)
+        H.assert_results_equal(r, oracle.execute(seg, spec))
+        spec = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.match_all()))
+        assert g.execute(spec).stats == (30000, 0, 0, 30000)

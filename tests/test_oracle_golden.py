@@ -83,3 +83,15 @@ def test_oracle_matches_numpy_on_fixture_filters():
     assert card == int(m.sum())
     bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:30000].astype(bool)
     assert (bits == m).all()
+
+
+def test_non_scan_based_aggregation_plan():
+    """AggregationPlanNode.java:98-115: no filter + COUNT / dictionary-based MIN, MAX -> NonScanBasedAggregationOperator: the answer
+    comes from the metadata and the dictionary ends, statistics (totalDocs, 0, 0, totalDocs); one SUM in the list and the scan is back."""
+    seg = H.golden_segment(use_inverted=False)
+    ci = seg.column_index
+    r = oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1), (Q.MAX, ci("column3")), (Q.MIN, ci("column6"))]))
+    assert r.intermediates() == [30000, 2147419555.0, 1689277.0]
+    assert r.stats == (30000, 0, 0, 30000)
+    r = oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1), (Q.MAX, ci("column3")), (Q.SUM, ci("column1"))]))
+    assert r.stats == (30000, 0, 60000, 30000)

@@ -61,8 +61,9 @@ def report(out, name, n, nbytes, gseg, seg, spec, check=True):
               all(all(x.sum_i64 == y.sum_i64 and x.count == y.count and x.min == y.min and x.max == y.max for x, y in zip(got.groups[g], want.groups[g])) for g in want.groups))
     else:
         cpu_s = None
-    rec = {"config": name, "rows": n, "kernel_ms": avg, "kernel_ms_min": best, "device_ms_all_kernels": dev, "rows_per_s": n / avg * 1e3, "algorithmic_GB": nbytes / 1e9,
-           "GBps": nbytes / avg / 1e6, "frac_of_8TBps": nbytes / avg / 1e6 / 8000.0, "docs_matched": got.stats[0],
+    safe = avg if avg > 0 else float("inf")      # metadata-only answers launch no kernel
+    rec = {"config": name, "rows": n, "kernel_ms": avg, "kernel_ms_min": best, "device_ms_all_kernels": dev, "rows_per_s": n / safe * 1e3, "algorithmic_GB": nbytes / 1e9,
+           "GBps": nbytes / safe / 1e6, "frac_of_8TBps": nbytes / safe / 1e6 / 8000.0, "docs_matched": got.stats[0],
            "bit_exact_vs_oracle": ok, "oracle_rows_per_s_1core": (n / cpu_s if cpu_s else None)}
     cyc = getattr(timed, "cycles", None)
     if cyc and cyc[4] and cyc[3]:
