@@ -52,6 +52,7 @@ struct Engine {
   int value_plane = -1;      // -1 auto, 0 never, 1 always (PINOT_GPU_VALUE_PLANE)
   int tile_steps = 0;        // 0 auto, 16 or 32 forced (PINOT_GPU_TILE_STEPS)
   bool double_buffer = false;
+  bool direct_result = true; // PINOT_GPU_DIRECT_RESULT=0: the folded partial is copied device -> host with a copy command
   bool plane_gcd = true;     // PINOT_GPU_PLANE_GCD=0: planes hold value - min unscaled, never alias the dictId stream
   bool scan_private = true;  // PINOT_GPU_SCAN_PRIVATE=0: always the LDS-staged scan kernel
   bool group_private = true; // PINOT_GPU_GROUP_PRIVATE=0: unfiltered group-by through the LDS-staged kernel
@@ -109,7 +110,8 @@ struct ExecCtx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   BlockPartial* d_partials = nullptr;
   int partial_capacity = 0;
-  BlockPartial* h_partial = nullptr;            // pinned
+  BlockPartial* h_partial = nullptr;            // pinned and device-mapped: finalize_partials_kernel writes the result into it
+  BlockPartial* h_partial_dev = nullptr;        // its device-side address
   std::vector<unsigned long long*> d_bitmaps;   // each num_tiles*32 words
   std::vector<uint32_t*> d_sets;
   std::vector<size_t> set_capacity;
@@ -167,7 +169,8 @@ pg_status acquire_ctx(pg_segment* seg, ExecCtx** out) {
   ExecCtx* c = new ExecCtx();
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) for (auto& ev : c->ev) { e = hipEventCreate(&ev); if (e != hipSuccess) break; }
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_partial, sizeof(BlockPartial), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_partial, sizeof(BlockPartial), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->h_partial_dev, c->h_partial, 0);
   if (e != hipSuccess) {
     destroy_ctx(c);
     return fail(PG_ERR_DEVICE, "creating execution context failed: %s", hipGetErrorString(e));
@@ -835,6 +838,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.value_plane = vp ? atoi(vp) : -1;
   const char* db = getenv("PINOT_GPU_DOUBLE_BUFFER");
   g_engine.double_buffer = db && db[0] == '1';
+  const char* drv = getenv("PINOT_GPU_DIRECT_RESULT");
+  g_engine.direct_result = !(drv && drv[0] == '0');
   const char* pgv = getenv("PINOT_GPU_PLANE_GCD");
   g_engine.plane_gcd = !(pgv && pgv[0] == '0');
   const char* spv = getenv("PINOT_GPU_SCAN_PRIVATE");
@@ -1210,9 +1215,9 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     else launch_scan_agg(g_engine.use_dma, one, typed, blocks, geo.threads, lds, ctx->stream, sp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-    finalize_partials_kernel<<<dim3(1), dim3(kBlockThreads), 0, ctx->stream>>>(ctx->d_partials, blocks);
+    finalize_partials_kernel<<<dim3(1), dim3(kBlockThreads), 0, ctx->stream>>>(ctx->d_partials, blocks, g_engine.direct_result ? ctx->h_partial_dev : nullptr);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(ctx->h_partial, ctx->d_partials + blocks, sizeof(BlockPartial), hipMemcpyDeviceToHost, ctx->stream));
+    if (!g_engine.direct_result) HIP_TRY(hipMemcpyAsync(ctx->h_partial, ctx->d_partials + blocks, sizeof(BlockPartial), hipMemcpyDeviceToHost, ctx->stream));
     if (want_bitmap) {
       const int64_t need = ((int64_t)seg->num_docs + 63) / 64;
       if (host_bitmap_words < need) return fail(PG_ERR_INVALID_ARGUMENT, "bitmap buffer has %lld words, need %lld", (long long)host_bitmap_words, (long long)need);

@@ -845,7 +845,8 @@ __device__ __forceinline__ void partial_merge(BlockPartial& acc, const BlockPart
   }
 }
 
-static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockPartial* partials, int num_blocks) {
+// `host_out`: pinned, device-mapped host memory -- the folded record goes straight to the host, no copy command follows.
+static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockPartial* partials, int num_blocks, BlockPartial* host_out) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   BlockPartial acc;
   partial_identity(acc);
@@ -868,7 +869,8 @@ static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel
   if (threadIdx.x == 0) {
     BlockPartial t = red[0];
     for (int i = 1; i < (int)(blockDim.x >> 6); ++i) partial_merge(t, red[i]);
-    partials[num_blocks] = t;
+    if (host_out) { *host_out = t; __threadfence_system(); }
+    else partials[num_blocks] = t;
   }
 }
 
