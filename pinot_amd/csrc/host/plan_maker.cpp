@@ -211,6 +211,26 @@ void lowerFilter(const FilterContext& f, const ImmutableSegment& seg, LoweredQue
         p.lo = ds.sortedDocIdRanges[2 * (size_t)ev.startDictId];
         p.hi = ds.sortedDocIdRanges[2 * (size_t)(ev.endDictId - 1) + 1];
         p.exclusive = ev.exclusive;
+      } else if (ds.isSorted && !ev.isRange && (int)ds.sortedDocIdRanges.size() == 2 * ds.cardinality && !ev.matchingDictIds.empty() &&
+                 ev.matchingDictIds.size() <= 6) {
+        // IN / NOT IN on a sorted column: the docId ranges of the matching dictIds, adjacent ones merged
+        // (SortedIndexBasedFilterOperator.java:86-125) -> OR of docId-range leaves; NOT IN is the NOT of that union
+        std::vector<std::pair<int32_t, int32_t>> ranges;
+        for (int d : ev.matchingDictIds) {      // ascending dictIds
+          const int32_t s0 = ds.sortedDocIdRanges[2 * (size_t)d], e0 = ds.sortedDocIdRanges[2 * (size_t)d + 1];
+          if (!ranges.empty() && s0 == ranges.back().second + 1) ranges.back().second = e0;
+          else ranges.push_back({s0, e0});
+        }
+        for (const auto& r : ranges) {
+          pg_predicate dr;
+          memset(&dr, 0, sizeof(dr));
+          dr.kind = PG_PRED_DOC_RANGE; dr.lo = r.first; dr.hi = r.second;
+          out->predicates.push_back(dr);
+          out->nodes.push_back(pg_filter_node{PG_FILTER_LEAF, (int32_t)out->predicates.size() - 1, 0, 0});
+        }
+        if (ranges.size() > 1) out->nodes.push_back(pg_filter_node{PG_FILTER_OR, -1, (int32_t)ranges.size(), 0});
+        if (ev.exclusive) out->nodes.push_back(pg_filter_node{PG_FILTER_NOT, -1, 1, 0});
+        return;
       } else {
         p.exclusive = ev.exclusive;
         // FilterOperatorUtils.java:96-133: RANGE predicates scan (no sorted / range index on this path); every other

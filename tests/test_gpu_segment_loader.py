@@ -63,6 +63,11 @@ def test_sql_over_v3_and_sorted_v1(tmp_path):
         assert st_sorted["stats"]["numEntriesScannedInFilter"] == 0 and st_scan["stats"]["numEntriesScannedInFilter"] == 2 * n   # two scan leaves
         ne = host.execute_sql([segs[1]], "SELECT COUNT(*) FROM t WHERE k != 51")["segments"][0]
         assert ne["intermediate"] == [int((k != 51).sum())]
+        inq = host.execute_sql([segs[1]], "SELECT COUNT(*), SUM(v) FROM t WHERE k IN (6, 11, 16, 101) AND v < 9000")["segments"][0]
+        sel_in = np.isin(k, [6, 11, 16, 101]) & (vv < 9000)
+        assert inq["intermediate"] == [int(sel_in.sum()), float(vv[sel_in].sum())] and inq["stats"]["numEntriesScannedInFilter"] == n   # only v is scanned
+        nin = host.execute_sql([segs[1]], "SELECT COUNT(*) FROM t WHERE k NOT IN (6, 101)")["segments"][0]
+        assert nin["intermediate"] == [int((~np.isin(k, [6, 101])).sum())] and nin["stats"]["numEntriesScannedInFilter"] == 0
         combined = host.execute_sql(segs, "SELECT COUNT(*), SUM(v) FROM t WHERE v IN (1, 2, 3, 5000)")["combined"]
         assert combined["final"][0] == 2.0 * float(np.isin(vv, [1, 2, 3, 5000]).sum())
     finally:
