@@ -1471,7 +1471,9 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
   // column twice and still takes as long as C2b).  Two ways of overlapping a wave's own loads with its own compute were tried
   // and dropped: early "touch" loads through the LDS-DMA path (-30 %: vmcnt retires in order, a wave's L2 hits queue behind
   // its prefetches still coming from HBM), and holding whole column chunks in 31-register arrays loaded one phase ahead (the
-  // arrays cross the width switch, are not promoted to registers and go to scratch: 15-40x slower).
+  // arrays cross the width switch, are not promoted to registers and go to scratch: 15-40x slower).  A third variant, two tiles per
+  // iteration with both chunks loaded inside one width-specialised function, does put two requests in flight (+5 % on C2b within
+  // the same build) but the extra code costs the other shapes about as much, and two more minutes of compile time: not kept.
   // one inclusive-range leaf and one SUM over the same stream (not exclusive, no MIN / MAX): fused decode
   const bool fused = p.num_nodes == 1 && p.num_agg_cols == 1 && p.nodes[0].kind == kLeafDictRange && p.nodes[0].exclusive == 0 &&
                      p.nodes[0].fwd == p.agg_cols[0].fwd && p.nodes[0].bits == p.agg_cols[0].bits && p.agg_cols[0].need_sum != 0 &&
