@@ -99,3 +99,12 @@ def test_non_scan_based_aggregation_plan(engine):
         H.assert_results_equal(r, oracle.execute(seg, spec))
         spec = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.match_all()))
         assert g.execute(spec).stats == (30000, 0, 0, 30000)
+
+
+def test_inter_segment_max_min_avg_goldens(engine):
+    """InterSegmentAggregationSingleValueQueriesTest.testMax / testMin / testSum / testAvg through the C ABI (values and the
+    statistics that show the non-scan plan for the unfiltered MAX / MIN)."""
+    from test_oracle_golden import check_inter_segment_max_min_avg
+    seg = H.golden_segment()
+    with engine.open(seg) as g:
+        check_inter_segment_max_min_avg(g.execute, seg)

@@ -95,3 +95,53 @@ def test_non_scan_based_aggregation_plan():
     assert r.stats == (30000, 0, 0, 30000)
     r = oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1), (Q.MAX, ci("column3")), (Q.SUM, ci("column1"))]))
     assert r.stats == (30000, 0, 60000, 30000)
+
+
+def _merged_stats(r):
+    """Four identical segments: every ExecutionStatistics field is summed by the combine operator."""
+    return [4 * r.stats[0], 4 * r.stats[1], 4 * r.stats[2], 4 * r.stats[3]]
+
+
+def check_inter_segment_max_min_avg(execute, seg):
+    """InterSegmentAggregationSingleValueQueriesTest.testMax / testMin / testSum / testAvg (:91-203) with `execute(spec) -> Result`
+    for one segment; the x4 merge (MAX max, MIN min, SUM +, AVG pairwise) and ORDER BY ... LIMIT 1 are done here."""
+    g = H.load_golden_queries()["inter_segment_x4"]
+    ci = seg.column_index
+    c1, c3, c9 = ci("column1"), ci("column3"), ci("column9")
+    flt = H.golden_filter(seg)
+    for func, key, pick in ((Q.MAX, "max_column1_column3", "max"), (Q.MIN, "min_column1_column3", "min")):
+        gg = g[key]
+        for name, f in (("unfiltered", None), ("filtered", flt)):
+            r = execute(Q.QuerySpec([(func, c1), (func, c3)], filter=f))
+            assert [getattr(r.aggregations[0], pick), getattr(r.aggregations[1], pick)] == gg[name]["values"]
+            st, want = _merged_stats(r), gg[name]["stats"]
+            # numEntriesScannedInFilter (index 1) is the documented deviation; the unfiltered case must show the non-scan plan: 0 entries
+            assert (st[0], st[2], st[3]) == (want[0], want[2], want[3]), (name, st, want)
+            if f is None:
+                assert st[1] == 0
+        desc = func == Q.MAX
+        for name, f in (("group_by_top_desc" if desc else "group_by_top_asc", None), ("filtered_group_by_top_desc" if desc else "filtered_group_by_top_asc", flt)):
+            r = execute(Q.QuerySpec([(func, c1), (func, c3)], filter=f, group_by=[c9]))
+            rows = sorted(([getattr(v[0], pick), getattr(v[1], pick)] for v in r.groups.values()), reverse=desc)
+            assert rows[0] == gg[name]["values"]
+            st, want = _merged_stats(r), gg[name]["stats"]
+            assert (st[0], st[2], st[3]) == (want[0], want[2], want[3])
+    for name, f in (("unfiltered", None), ("filtered", flt)):
+        r = execute(Q.QuerySpec([(Q.SUM, c1), (Q.SUM, c3)], filter=f, group_by=[c9]))
+        rows = sorted(([4 * v[0].sum, 4 * v[1].sum] for v in r.groups.values()), reverse=True)
+        assert rows[0] == g["sum_group_by_top_desc"][name]
+        ga = g["avg_column1_column3"][name]
+        r = execute(Q.QuerySpec([(Q.AVG, c1), (Q.AVG, c3)], filter=f))
+        for i in range(2):
+            avg = (4 * r.aggregations[i].sum) / (4 * r.aggregations[i].count)
+            assert abs(avg - ga["values"][i]) <= ga["tolerance"] * max(1.0, abs(ga["values"][i])) or abs(avg - ga["values"][i]) < 1e-3
+        st = _merged_stats(r)
+        assert (st[0], st[2], st[3]) == (ga["stats"][0], ga["stats"][2], ga["stats"][3])
+    r = execute(Q.QuerySpec([(Q.AVG, c1), (Q.AVG, c3)], group_by=[c9]))
+    rows = sorted(([v[0].sum / v[0].count, v[1].sum / v[1].count] for v in r.groups.values()), reverse=True)
+    assert rows[0] == g["avg_column1_column3"]["group_by_top_desc"]["values"]
+
+
+def test_inter_segment_max_min_avg_goldens():
+    seg = H.golden_segment()
+    check_inter_segment_max_min_avg(lambda spec: oracle.execute(seg, spec), seg)
