@@ -108,3 +108,10 @@ def test_inter_segment_max_min_avg_goldens(engine):
     seg = H.golden_segment()
     with engine.open(seg) as g:
         check_inter_segment_max_min_avg(g.execute, seg)
+
+
+def test_string_key_group_by_goldens(engine):
+    from test_oracle_golden import check_string_key_group_by
+    seg = H.golden_segment()
+    with engine.open(seg) as g:
+        check_string_key_group_by(g.execute, seg)

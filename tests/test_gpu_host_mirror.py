@@ -128,3 +128,13 @@ def test_sql_over_the_segment_written_by_the_reference():
         assert sorted(r["key"][0] for r in g["groups"]) == sorted(int(x) for x in longs)
     finally:
         seg.destroy()
+
+
+def test_string_key_group_by_goldens_through_sql(golden_segments):
+    """InterSegmentGroupBySingleValueQueriesTest.java:66-107 through SQL -> plan maker -> device -> value-keyed combine of 4 segments."""
+    _, segs = golden_segments
+    g = H.load_golden_queries()["inter_segment_group_by_x4"]
+    combined = host.execute_sql(segs, "SELECT SUM(column1) FROM testTable GROUP BY column11", max_execution_threads=4)["combined"]
+    assert sorted([r["key"][0], r["final"][0]] for r in combined["groups"]) == g["sum_column1_by_column11"]
+    combined = host.execute_sql(segs, "SELECT SUM(column1) FROM testTable GROUP BY column11, column12", max_execution_threads=2)["combined"]
+    assert sorted([r["key"][0], r["key"][1], r["final"][0]] for r in combined["groups"])[:15] == g["sum_column1_by_column11_column12_first15"]

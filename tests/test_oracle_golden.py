@@ -145,3 +145,26 @@ def check_inter_segment_max_min_avg(execute, seg):
 def test_inter_segment_max_min_avg_goldens():
     seg = H.golden_segment()
     check_inter_segment_max_min_avg(lambda spec: oracle.execute(seg, spec), seg)
+
+
+def check_string_key_group_by(execute, seg):
+    """InterSegmentGroupBySingleValueQueriesTest.java:66-107: GROUP BY on STRING dictionary columns (one and two keys); group ids are
+    turned back into dictionary values (mixed radix, first key fastest) and the four identical segments are merged by '+'."""
+    g = H.load_golden_queries()["inter_segment_group_by_x4"]
+    ci = seg.column_index
+    c1, c11, c12 = ci("column1"), ci("column11"), ci("column12")
+    d11, d12 = seg.string_dicts["column11"], seg.string_dicts["column12"]
+    r = execute(Q.QuerySpec([(Q.SUM, c1)], group_by=[c11]))
+    rows = sorted([d11[gid], 4 * v[0].sum] for gid, v in r.groups.items())
+    assert rows == g["sum_column1_by_column11"]
+    assert 4 * r.stats[2] == g["numEntriesScannedPostFilter"][0]
+    r = execute(Q.QuerySpec([(Q.SUM, c1)], group_by=[c11, c12]))
+    card11 = len(d11)
+    rows = sorted([d11[gid % card11], d12[gid // card11], 4 * v[0].sum] for gid, v in r.groups.items())
+    assert rows[:15] == g["sum_column1_by_column11_column12_first15"]
+    assert 4 * r.stats[2] == g["numEntriesScannedPostFilter"][1]
+
+
+def test_string_key_group_by_goldens():
+    seg = H.golden_segment()
+    check_string_key_group_by(lambda spec: oracle.execute(seg, spec), seg)
