@@ -21,8 +21,13 @@
  *                              core/operator/filter/BaseFilterOperator.java, core/common/BlockDocIdSet.java:61-67
  *   pg_read_dict_ids           ForwardIndexReader.readDictIds(int[] docIds, int length, int[] dictIdBuffer, ctx)
  *                              sspi/index/reader/ForwardIndexReader.java, segl/.../FixedBitSVForwardIndexReaderV2.java:65-99
- *   pg_read_int_values /       DataFetcher.fetchIntValues / fetchDoubleValues (BlockValSet.getIntValuesSV /
- *   pg_read_double_values      getDoubleValuesSV)  core/common/DataFetcher.java:111-113,335-386, core/common/BlockValSet.java:65-93
+ *   pg_read_int_values /       DataFetcher.fetchIntValues / fetchLongValues / fetchDoubleValues (BlockValSet.getIntValuesSV /
+ *   pg_read_long_values /      getLongValuesSV / getDoubleValuesSV)
+ *   pg_read_double_values      core/common/DataFetcher.java:111-123,335-470, core/common/BlockValSet.java:65-93
+ *
+ * Inside pg_execute the plan rules of the reference are applied to the lowered query: a filter that matches everything plus
+ * COUNT / dictionary-based MIN, MAX is answered from metadata (AggregationPlanNode.java:98-115, NonScanBasedAggregationOperator);
+ * PG_PRED_DOC_RANGE leaves stand for SortedIndexBasedFilterOperator, PG_EVAL_INVERTED leaves for InvertedIndexFilterOperator.
  *   pg_last_error              exception message carried into BaseCombineOperator.wrapOperatorException
  *                              core/operator/combine/BaseCombineOperator.java:185-199
  *

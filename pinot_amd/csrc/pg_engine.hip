@@ -1178,7 +1178,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
     // The lane-private kernel (no LDS, plain global loads) takes every query whose leaves and aggregations it implements:
     // scan / set / bitmap leaves and raw INT ranges; COUNT, and SUM through a value plane / MIN / MAX on dictionary columns.
-    bool use_private = g_engine.scan_private && !typed;
+    // (the per-wave phase counters of PG_CFG_PROFILE_WAVES exist in the LDS-staged kernel only)
+    bool use_private = g_engine.scan_private && !typed && !(g_engine.flags & PG_CFG_PROFILE_WAVES);
     for (int l = 0; l < pl.num_leaves && use_private; ++l) use_private = pl.leaves[l].kind <= kLeafBitmap || pl.leaves[l].kind == kLeafDocRange;
     for (int i = 0; i < pl.num_agg_cols && use_private; ++i) {
       const DevColumn& c = pl.cols[pl.agg_cols[i].col];
