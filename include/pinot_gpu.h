@@ -97,6 +97,11 @@ typedef struct pg_column_desc {
   uint64_t dict_size;
   const void* inv_data;        /* optional bitmap inverted index (BitmapInvertedIndexWriter layout) or NULL */
   uint64_t inv_size;
+  const void* null_data;       /* optional null value vector: the `<column>.bitmap.nullvalue` file = ONE serialized RoaringBitmap of the
+                                * null docIds (NullValueVectorCreator.seal, segment/creator/impl/nullvalue/NullValueVectorCreator.java:69-78;
+                                * read by NullValueVectorReaderImpl.getNullBitmap :44-46), or NULL when the column has no null docs (the
+                                * creator writes no file for an empty bitmap).  The forward index holds the default null value there. */
+  uint64_t null_size;
 } pg_column_desc;
 
 typedef struct pg_segment_desc {
@@ -120,9 +125,12 @@ typedef enum pg_predicate_kind {
   PG_PRED_DICT_RANGE = 2,      /* SortedDictionaryBasedRangePredicateEvaluator.applySV: lo <= dictId < hi; EQ is [d, d+1) */
   PG_PRED_DICT_SET = 3,        /* DictionaryBasedInPredicateEvaluator.applySV: bit dictId of set_words is set */
   PG_PRED_RAW_RANGE = 4,       /* IntRawValueBasedRangePredicateEvaluator.applySV: lo <= value <= hi (both inclusive) */
-  PG_PRED_DOC_RANGE = 5        /* SortedIndexBasedFilterOperator (core/operator/filter/SortedIndexBasedFilterOperator.java:60-85): the docId
+  PG_PRED_DOC_RANGE = 5,       /* SortedIndexBasedFilterOperator (core/operator/filter/SortedIndexBasedFilterOperator.java:60-85): the docId
                                 * range [lo, hi] (both inclusive) that SortedIndexReader.getDocIds gives for the predicate's dictIds on a sorted
-                                * column; `exclusive` inverts it over [0, numDocs).  No column is read.  `column` is ignored. */
+                                * column; `exclusive` inverts it over [0, numDocs).  No column is read.  `column` is ignored unless the query
+                                * runs with PG_QUERY_NULL_HANDLING, where it names the sorted column (its null docs are excluded) or is -1. */
+  PG_PRED_IS_NULL = 6          /* FilterPlanNode.java:294-307: BitmapBasedFilterOperator over the column's null bitmap; `exclusive` = IS NOT NULL.
+                                * A column without a null vector matches nothing (IS NULL) / everything (IS NOT NULL).  No entries are scanned. */
 } pg_predicate_kind;
 
 typedef enum pg_leaf_eval {
@@ -170,7 +178,7 @@ typedef enum pg_agg_function {
 
 typedef struct pg_aggregation {
   int32_t function;            /* pg_agg_function */
-  int32_t column;              /* -1 for COUNT(*) */
+  int32_t column;              /* -1 for COUNT(*); COUNT(column) differs from COUNT(*) only under PG_QUERY_NULL_HANDLING */
 } pg_aggregation;
 
 typedef struct pg_query {
@@ -187,6 +195,18 @@ typedef struct pg_query {
 } pg_query;
 
 #define PG_QUERY_DEFAULT 0
+/* Query option enableNullHandling=true (QueryContext.isNullHandlingEnabled), for columns that carry a null vector:
+ *  - a column leaf is true only where the column is not null, and is NULL where it is (BaseColumnFilterOperator.getTrues / getNulls,
+ *    core/operator/filter/BaseColumnFilterOperator.java:45-64); NOT takes the child's FALSE set, i.e. NOT (trues OR nulls)
+ *    (BaseFilterOperator.getFalses :96-113, And/OrFilterOperator.getFalses, NotFilterOperator.getTrues); AND / OR / NOT / IS_NULL /
+ *    MATCH_ALL / MATCH_NONE nodes have no NULL set of their own.  A predicate that is always true on a column WITH nulls must be passed
+ *    as {PG_PRED_IS_NULL, exclusive} the way FilterOperatorUtils.java:78-86 builds it;
+ *  - SUM / MIN / MAX / AVG / COUNT(column) skip the docs where their column is null (NullableSingleInputAggregationFunction.java:72-166);
+ *    pg_agg_value.count is the number of non-null docs aggregated, and count == 0 means the reference's holder stays null;
+ *  - the metadata / dictionary fast path is taken only when no aggregated column has nulls (AggregationPlanNode.java:99-100);
+ *  - GROUP BY is accepted only when neither the keys nor the aggregated columns have null docs (the reference switches to the
+ *    no-dictionary key generators otherwise, DefaultGroupByExecutor.java:106-121) -- PG_ERR_UNSUPPORTED at plan time. */
+#define PG_QUERY_NULL_HANDLING 1
 
 /* Intermediate result of one aggregation function, in the reference's holder types:
  * SUM/MIN/MAX -> Double, COUNT -> Long, AVG -> AvgPair(sum, count). */

@@ -696,6 +696,15 @@ static int leaf_to_bitmap(const po_column* cols, const pg_segment_desc* seg, con
     if (all) { memset(words, 0xFF, (size_t)nw * 8); bitmap_clear_tail(words, num_docs); }
     return 0;
   }
+  if (p->kind == PG_PRED_IS_NULL) {
+    /* FilterPlanNode.java:294-310: BitmapBasedFilterOperator(nullBitmap, exclusive = IS_NOT_NULL); no null vector -> EmptyFilterOperator
+     * (IS_NULL) / MatchAllFilterOperator (IS_NOT_NULL).  BitmapBasedFilterOperator.getTrues :41-47 flips over [0, numDocs). */
+    if (p->column < 0 || p->column >= seg->num_columns) PO_FAIL(1, "IS_NULL column out of range");
+    const pg_column_desc* d = &seg->columns[p->column];
+    if (d->null_data && d->null_size) { if (po_roaring_or_into((const uint8_t*)d->null_data, d->null_size, words, nw) < 0) return 1; bitmap_clear_tail(words, num_docs); }
+    if (p->exclusive) { for (int64_t i = 0; i < nw; i++) words[i] = ~words[i]; bitmap_clear_tail(words, num_docs); }
+    return 0;
+  }
   if (p->kind == PG_PRED_DOC_RANGE) {
     /* SortedIndexBasedFilterOperator.getTrues -> SortedDocIdSet of one inclusive [start, end] pair (:60-85); exclusive
      * predicates take the complement over [0, numDocs) (:72-84).  No entries are scanned. */
@@ -726,12 +735,88 @@ static int leaf_to_bitmap(const po_column* cols, const pg_segment_desc* seg, con
   return 0;
 }
 
+/* The null bitmap of a column as dense words, or NULL when the column has no null docs (NullValueVectorReaderImpl.getNullBitmap). */
+static uint64_t* column_null_words(const pg_segment_desc* seg, int32_t column) {
+  if (column < 0 || column >= seg->num_columns) return NULL;
+  const pg_column_desc* d = &seg->columns[column];
+  if (!d->null_data || !d->null_size) return NULL;
+  int64_t nw = bitmap_words(seg->num_docs);
+  uint64_t* w = (uint64_t*)calloc((size_t)(nw ? nw : 1), 8);
+  int64_t card = po_roaring_or_into((const uint8_t*)d->null_data, d->null_size, w, nw);
+  bitmap_clear_tail(w, seg->num_docs);
+  int64_t in_range = 0;
+  for (int64_t i = 0; i < nw; i++) in_range += __builtin_popcountll(w[i]);
+  if (card < 0 || in_range == 0) { free(w); return NULL; }   /* nullBitmap.isEmpty() */
+  return w;
+}
+
+/* enableNullHandling=true: every filter operator has three docId sets (BaseFilterOperator.java:85-113):
+ *   column leaf   trues = matches AND NOT nulls, nulls = the column's null bitmap (BaseColumnFilterOperator.java:45-64),
+ *                 falses = NOT (trues OR nulls) (BaseFilterOperator.getFalses :96-113)
+ *   IS_NULL / MATCH_ALL / MATCH_NONE leaves: no nulls, falses = NOT trues
+ *   AND  trues = AND trues_i, falses = NOT AND_i (trues_i OR nulls_i) (AndFilterOperator.java:52-90); no nulls of its own
+ *   OR   trues = OR trues_i,  falses = NOT OR_i (trues_i OR nulls_i)  (OrFilterOperator.java:51-89); no nulls of its own
+ *   NOT  trues = child falses, falses = child trues (NotFilterOperator.java:52-63); no nulls of its own
+ * The filter block is getTrues() of the root (BaseFilterOperator.getNextBlock :82-84). */
+typedef struct po_tnf { uint64_t *t, *n, *f; } po_tnf;
+static void tnf_free(po_tnf* e) { free(e->t); free(e->n); free(e->f); }
+static int filter_to_bitmap_nulls(const po_column* cols, const pg_segment_desc* seg, const pg_query* q, uint64_t** out_words,
+                                  int64_t* entries_scanned) {
+  int32_t num_docs = seg->num_docs;
+  int64_t nw = bitmap_words(num_docs);
+  size_t bytes = (size_t)(nw ? nw : 1) * 8;
+  po_tnf* stack = (po_tnf*)calloc((size_t)q->num_filter_nodes, sizeof(po_tnf));
+  int sp = 0, rc = 0;
+  for (int32_t n = 0; n < q->num_filter_nodes && !rc; n++) {
+    const pg_filter_node* node = &q->filter[n];
+    if (node->op == PG_FILTER_LEAF) {
+      const pg_predicate* p = &q->predicates[node->predicate];
+      po_tnf e; e.t = (uint64_t*)malloc(bytes); e.n = (uint64_t*)calloc(1, bytes); e.f = (uint64_t*)malloc(bytes);
+      rc = leaf_to_bitmap(cols, seg, p, e.t, entries_scanned);
+      const int column_leaf = p->kind == PG_PRED_DICT_RANGE || p->kind == PG_PRED_DICT_SET || p->kind == PG_PRED_RAW_RANGE || p->kind == PG_PRED_DOC_RANGE;
+      uint64_t* nulls = (!rc && column_leaf) ? column_null_words(seg, p->column) : NULL;
+      if (nulls) { for (int64_t i = 0; i < nw; i++) { e.n[i] = nulls[i]; e.t[i] &= ~nulls[i]; } free(nulls); }
+      for (int64_t i = 0; i < nw; i++) e.f[i] = ~(e.t[i] | e.n[i]);
+      bitmap_clear_tail(e.f, num_docs);
+      stack[sp++] = e;
+    } else if (node->op == PG_FILTER_NOT) {
+      if (sp < 1) { rc = 1; snprintf(po_error, sizeof(po_error), "filter stack underflow"); break; }
+      po_tnf* e = &stack[sp - 1];
+      uint64_t* t = e->t; e->t = e->f; e->f = t;
+      memset(e->n, 0, bytes);
+    } else {
+      int k = node->num_children;
+      if (sp < k || k < 1) { rc = 1; snprintf(po_error, sizeof(po_error), "filter stack underflow"); break; }
+      po_tnf* acc = &stack[sp - k];
+      /* acc.f is reused as the running AND / OR of (trues_i OR nulls_i) */
+      for (int64_t i = 0; i < nw; i++) acc->f[i] = acc->t[i] | acc->n[i];
+      for (int c = 1; c < k; c++) {
+        po_tnf* w = &stack[sp - k + c];
+        if (node->op == PG_FILTER_AND) for (int64_t i = 0; i < nw; i++) { acc->t[i] &= w->t[i]; acc->f[i] &= (w->t[i] | w->n[i]); }
+        else for (int64_t i = 0; i < nw; i++) { acc->t[i] |= w->t[i]; acc->f[i] |= (w->t[i] | w->n[i]); }
+        tnf_free(w);
+      }
+      for (int64_t i = 0; i < nw; i++) acc->f[i] = ~acc->f[i];
+      bitmap_clear_tail(acc->f, num_docs);
+      memset(acc->n, 0, bytes);
+      sp -= k - 1;
+    }
+  }
+  if (!rc && sp != 1) { rc = 1; snprintf(po_error, sizeof(po_error), "malformed filter tree"); }
+  if (rc) { for (int i = 0; i < sp; i++) tnf_free(&stack[i]); free(stack); return 1; }
+  *out_words = stack[0].t;
+  free(stack[0].n); free(stack[0].f);
+  free(stack);
+  return 0;
+}
+
 /* AND / OR / NOT over docId sets (AndDocIdSet.java:110-172 intersects; OrDocIdSet unions; NotDocIdSet
  * complements over [0, numDocs)).  Postfix evaluation of the flattened tree. */
 static int filter_to_bitmap(const po_column* cols, const pg_segment_desc* seg, const pg_query* q, uint64_t** out_words,
                             int64_t* entries_scanned) {
   int32_t num_docs = seg->num_docs;
   int64_t nw = bitmap_words(num_docs);
+  if ((q->flags & PG_QUERY_NULL_HANDLING) && q->num_filter_nodes > 0) return filter_to_bitmap_nulls(cols, seg, q, out_words, entries_scanned);
   if (q->num_filter_nodes == 0) {
     uint64_t* w = (uint64_t*)malloc((size_t)(nw ? nw : 1) * 8);
     memset(w, 0xFF, (size_t)nw * 8); bitmap_clear_tail(w, num_docs);
@@ -871,6 +956,69 @@ static void holder_init(po_holder* h, int func) {
   if (func == PG_AGG_MAX) h->value = -INFINITY;
 }
 
+/* One aggregate() call of a function over values[from, to) of a block (the reducer body that foldNotNull applies to each non-null range,
+ * NullableSingleInputAggregationFunction.java:118-160; the whole block [0, length) when there are no nulls). */
+static int agg_range(po_holder* h, int func, int st, const po_values* vals, int32_t from, int32_t to, double* dbl_values) {
+  if (to <= from) return 0;
+  switch (func) {
+          case PG_AGG_SUM: {
+            /* SumAggregationFunction.aggregate :69-129 (one case per stored type, double innerSum), updateAggregationResultHolder :147-157 */
+            double inner_sum = 0;
+            if (st == PG_TYPE_INT) for (int32_t i = from; i < to; i++) { inner_sum += vals->i[i]; exact_add(&h->exact_sum, vals->i[i], &h->overflow); }
+            else if (st == PG_TYPE_LONG) for (int32_t i = from; i < to; i++) { inner_sum += (double)vals->l[i]; exact_add(&h->exact_sum, vals->l[i], &h->overflow); }
+            else if (st == PG_TYPE_FLOAT) for (int32_t i = from; i < to; i++) inner_sum += (double)vals->f[i];
+            else for (int32_t i = from; i < to; i++) inner_sum += vals->d[i];
+            h->value = inner_sum + h->value;
+            break;
+          }
+          case PG_AGG_MAX: {
+            /* MaxAggregationFunction.aggregate :69-149 (typed inner max, Math.max), :150-160 */
+            double inner;
+            if (st == PG_TYPE_INT) { int32_t m = vals->i[from]; for (int32_t i = from; i < to; i++) m = vals->i[i] > m ? vals->i[i] : m; inner = (double)m; }
+            else if (st == PG_TYPE_LONG) { int64_t m = vals->l[from]; for (int32_t i = from; i < to; i++) m = vals->l[i] > m ? vals->l[i] : m; inner = (double)m; }
+            else if (st == PG_TYPE_FLOAT) { float m = vals->f[from]; for (int32_t i = from; i < to; i++) m = java_maxf(m, vals->f[i]); inner = (double)m; }
+            else { double m = vals->d[from]; for (int32_t i = from; i < to; i++) m = java_max(m, vals->d[i]); inner = m; }
+            h->value = java_max(inner, h->value);
+            break;
+          }
+          case PG_AGG_MIN: {
+            double inner;
+            if (st == PG_TYPE_INT) { int32_t m = vals->i[from]; for (int32_t i = from; i < to; i++) m = vals->i[i] < m ? vals->i[i] : m; inner = (double)m; }
+            else if (st == PG_TYPE_LONG) { int64_t m = vals->l[from]; for (int32_t i = from; i < to; i++) m = vals->l[i] < m ? vals->l[i] : m; inner = (double)m; }
+            else if (st == PG_TYPE_FLOAT) { float m = vals->f[from]; for (int32_t i = from; i < to; i++) m = java_minf(m, vals->f[i]); inner = (double)m; }
+            else { double m = vals->d[from]; for (int32_t i = from; i < to; i++) m = java_min(m, vals->d[i]); inner = m; }
+            h->value = java_min(inner, h->value);
+            break;
+          }
+          case PG_AGG_AVG: {
+            /* AvgAggregationFunction.aggregate :63-79: getDoubleValuesSV, avgPair.apply(v, 1) per doc,
+             * then updateAggregationResult -> holder pair.apply(sum, count) :95-102 */
+            widen_to_double(st, vals, to, dbl_values);
+            double s = 0; int64_t c = 0;
+            for (int32_t i = from; i < to; i++) { s += dbl_values[i]; c += 1; }
+            if (st == PG_TYPE_INT) for (int32_t i = from; i < to; i++) exact_add(&h->exact_sum, vals->i[i], &h->overflow);
+            if (st == PG_TYPE_LONG) for (int32_t i = from; i < to; i++) exact_add(&h->exact_sum, vals->l[i], &h->overflow);
+            h->avg_sum += s; h->avg_count += c;
+            break;
+          }
+          default: snprintf(po_error, sizeof(po_error), "unsupported aggregation %d", func); return 2;
+        }
+  h->n += to - from;
+  return 0;
+}
+
+/* Folds a per-block holder into the query holder: updateAggregationResultHolder of Sum :147-157 / Min / Max, AvgPair.apply. */
+static void holder_merge(po_holder* h, const po_holder* b, int func) {
+  if (b->n == 0) return;
+  if (func == PG_AGG_SUM) h->value = b->value + h->value;
+  if (func == PG_AGG_MIN) h->value = java_min(b->value, h->value);
+  if (func == PG_AGG_MAX) h->value = java_max(b->value, h->value);
+  if (func == PG_AGG_AVG) { h->avg_sum += b->avg_sum; h->avg_count += b->avg_count; }
+  exact_add(&h->exact_sum, b->exact_sum, &h->overflow);
+  h->overflow |= b->overflow;
+  h->n += b->n;
+}
+
 int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   memset(res, 0, sizeof(*res));
   if (seg->num_docs < 0) PO_FAIL(1, "negative num_docs");
@@ -887,7 +1035,18 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
    * and every function is COUNT or a dictionary-based MIN / MAX (isFitForNonScanBasedPlan :159-190), NonScanBasedAggregationOperator
    * answers from the metadata and the dictionary ends (NonScanBasedAggregationOperator.java:83-105) with statistics
    * (totalDocs, 0, 0, totalDocs). */
-  if (q->num_group_by == 0 && q->num_aggregations > 0) {
+  const int null_handling = (q->flags & PG_QUERY_NULL_HANDLING) != 0;
+  /* per aggregation: the null bitmap of its column when null handling is on and the column has null docs, else NULL */
+  uint64_t** agg_nulls = NULL;
+  int has_null_values = 0;                    /* AggregationPlanNode.hasNullValues :130-152 */
+  if (null_handling && q->num_aggregations > 0) {
+    agg_nulls = (uint64_t**)calloc((size_t)q->num_aggregations, sizeof(uint64_t*));
+    for (int a = 0; a < q->num_aggregations; a++) {
+      agg_nulls[a] = column_null_words(seg, q->aggregations[a].column);
+      has_null_values |= agg_nulls[a] != NULL;
+    }
+  }
+  if (q->num_group_by == 0 && q->num_aggregations > 0 && !has_null_values) {
     int match_all = q->num_filter_nodes == 0;
     if (q->num_filter_nodes == 1 && q->filter[0].op == PG_FILTER_LEAF) {
       const pg_predicate* p = &q->predicates[q->filter[0].predicate];
@@ -918,7 +1077,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       }
       res->stats.num_docs_scanned = num_docs;
       res->stats.num_total_docs = num_docs;
-      free(cols);
+      free(cols); free(agg_nulls);
       return 0;
     }
   }
@@ -930,7 +1089,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   /* FilterPlanNode: a single scan leaf streams; anything else is materialised (same docId set). */
   if (q->num_filter_nodes == 0) {
     it->kind = 0;
-  } else if (q->num_filter_nodes == 1 && q->filter[0].op == PG_FILTER_LEAF &&
+  } else if (!null_handling && q->num_filter_nodes == 1 && q->filter[0].op == PG_FILTER_LEAF &&
              q->predicates[q->filter[0].predicate].eval == PG_EVAL_SCAN &&
              q->predicates[q->filter[0].predicate].kind >= PG_PRED_DICT_RANGE &&
              q->predicates[q->filter[0].predicate].kind <= PG_PRED_RAW_RANGE) {
@@ -938,7 +1097,10 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
     const pg_predicate* p = &q->predicates[q->filter[0].predicate];
     scan_iter_init(&it->scan, &cols[p->column], p, num_docs);
   } else {
-    if (filter_to_bitmap(cols, seg, q, &filter_words, &entries_in_filter)) { free(cols); free(it); return 1; }
+    if (filter_to_bitmap(cols, seg, q, &filter_words, &entries_in_filter)) {
+      if (agg_nulls) for (int a = 0; a < q->num_aggregations; a++) free(agg_nulls[a]);
+      free(agg_nulls); free(cols); free(it); return 1;
+    }
     it->kind = 2; it->words = filter_words; it->word_idx = 0; it->cur = bitmap_words(num_docs) ? filter_words[0] : 0;
     if (bitmap_words(num_docs) == 0) it->word_idx = 0;
   }
@@ -955,6 +1117,12 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
     group_upper *= d->cardinality;
     /* DictionaryBasedGroupKeyGenerator.java:175-183: array-based holder only when the product fits */
     if (group_upper > 10000) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by cardinality product > arrayBasedThreshold"); goto done; }
+    if (null_handling) {
+      /* DefaultGroupByExecutor.java:106-121 leaves the dictionary-based key generator when null handling is on; only the case where it
+       * cannot matter (no nulls in the keys or the aggregated columns) is restated. */
+      uint64_t* w = column_null_words(seg, q->group_by_columns[g]);
+      if (w || has_null_values) { free(w); rc = 2; snprintf(po_error, sizeof(po_error), "group-by over nullable columns with null handling"); goto done; }
+    }
   }
 
   po_holder* holders = NULL;       /* aggregation only */
@@ -1018,8 +1186,10 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       size_t G = (size_t)group_upper;
       if (func == PG_AGG_COUNT) {
         if (ng == 0) {
-          /* CountAggregationFunction.aggregate :84-88 */
-          holders[a].value = holders[a].value + pos;
+          /* CountAggregationFunction.aggregate :84-88; COUNT(column) under null handling counts length - numNulls (:88-97) */
+          int32_t num_nulls = 0;
+          if (agg_nulls && agg_nulls[a]) for (int32_t i = 0; i < pos; i++) num_nulls += (int32_t)((agg_nulls[a][doc_ids[i] >> 6] >> (doc_ids[i] & 63)) & 1);
+          holders[a].value = holders[a].value + (pos - num_nulls);
         } else {
           /* aggregateGroupBySV :110-116 */
           for (int32_t i = 0; i < pos; i++) gholders[(size_t)a * G + group_ids[i]] = gholders[(size_t)a * G + group_ids[i]] + 1;
@@ -1031,50 +1201,21 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       fetch_stored_values(&cols[colidx], num_docs, doc_ids, pos, dict_scratch, &vals);
       if (ng == 0) {
         po_holder* h = &holders[a];
-        switch (func) {
-          case PG_AGG_SUM: {
-            /* SumAggregationFunction.aggregate :69-129 (one case per stored type, double innerSum), updateAggregationResultHolder :147-157 */
-            double inner_sum = 0;
-            if (st == PG_TYPE_INT) for (int32_t i = 0; i < pos; i++) { inner_sum += vals.i[i]; exact_add(&h->exact_sum, vals.i[i], &h->overflow); }
-            else if (st == PG_TYPE_LONG) for (int32_t i = 0; i < pos; i++) { inner_sum += (double)vals.l[i]; exact_add(&h->exact_sum, vals.l[i], &h->overflow); }
-            else if (st == PG_TYPE_FLOAT) for (int32_t i = 0; i < pos; i++) inner_sum += (double)vals.f[i];
-            else for (int32_t i = 0; i < pos; i++) inner_sum += vals.d[i];
-            h->value = inner_sum + h->value;
-            break;
+        if (agg_nulls && agg_nulls[a]) {
+          /* foldNotNull / forEachNotNull (NullableSingleInputAggregationFunction.java:72-160): the reducer runs on every maximal range of
+           * non-null positions of the block, then the block result is folded into the holder (nothing when the block is all null). */
+          po_holder blk; holder_init(&blk, func);
+          int32_t from = 0;
+          for (int32_t i = 0; i <= pos && !rc; i++) {
+            const int is_null = i < pos && ((agg_nulls[a][doc_ids[i] >> 6] >> (doc_ids[i] & 63)) & 1);
+            if (i == pos || is_null) { rc = agg_range(&blk, func, st, &vals, from, i, dbl_values); from = i + 1; }
           }
-          case PG_AGG_MAX: {
-            /* MaxAggregationFunction.aggregate :69-149 (typed inner max, Math.max), :150-160 */
-            double inner;
-            if (st == PG_TYPE_INT) { int32_t m = vals.i[0]; for (int32_t i = 0; i < pos; i++) m = vals.i[i] > m ? vals.i[i] : m; inner = (double)m; }
-            else if (st == PG_TYPE_LONG) { int64_t m = vals.l[0]; for (int32_t i = 0; i < pos; i++) m = vals.l[i] > m ? vals.l[i] : m; inner = (double)m; }
-            else if (st == PG_TYPE_FLOAT) { float m = vals.f[0]; for (int32_t i = 0; i < pos; i++) m = java_maxf(m, vals.f[i]); inner = (double)m; }
-            else { double m = vals.d[0]; for (int32_t i = 0; i < pos; i++) m = java_max(m, vals.d[i]); inner = m; }
-            h->value = java_max(inner, h->value);
-            break;
-          }
-          case PG_AGG_MIN: {
-            double inner;
-            if (st == PG_TYPE_INT) { int32_t m = vals.i[0]; for (int32_t i = 0; i < pos; i++) m = vals.i[i] < m ? vals.i[i] : m; inner = (double)m; }
-            else if (st == PG_TYPE_LONG) { int64_t m = vals.l[0]; for (int32_t i = 0; i < pos; i++) m = vals.l[i] < m ? vals.l[i] : m; inner = (double)m; }
-            else if (st == PG_TYPE_FLOAT) { float m = vals.f[0]; for (int32_t i = 0; i < pos; i++) m = java_minf(m, vals.f[i]); inner = (double)m; }
-            else { double m = vals.d[0]; for (int32_t i = 0; i < pos; i++) m = java_min(m, vals.d[i]); inner = m; }
-            h->value = java_min(inner, h->value);
-            break;
-          }
-          case PG_AGG_AVG: {
-            /* AvgAggregationFunction.aggregate :63-79: getDoubleValuesSV, avgPair.apply(v, 1) per doc,
-             * then updateAggregationResult -> holder pair.apply(sum, count) :95-102 */
-            widen_to_double(st, &vals, pos, dbl_values);
-            double s = 0; int64_t c = 0;
-            for (int32_t i = 0; i < pos; i++) { s += dbl_values[i]; c += 1; }
-            if (st == PG_TYPE_INT) for (int32_t i = 0; i < pos; i++) exact_add(&h->exact_sum, vals.i[i], &h->overflow);
-            if (st == PG_TYPE_LONG) for (int32_t i = 0; i < pos; i++) exact_add(&h->exact_sum, vals.l[i], &h->overflow);
-            h->avg_sum += s; h->avg_count += c;
-            break;
-          }
-          default: rc = 2; snprintf(po_error, sizeof(po_error), "unsupported aggregation %d", func); goto cleanup;
+          if (rc) goto cleanup;
+          holder_merge(h, &blk, func);
+        } else {
+          rc = agg_range(h, func, st, &vals, 0, pos, dbl_values);
+          if (rc) goto cleanup;
         }
-        h->n += pos;
       } else {
         /* group-by functions all read getDoubleValuesSV (Dictionary.readDoubleValues / readValuesSV(double[])) */
         widen_to_double(st, &vals, pos, dbl_values);
@@ -1160,6 +1301,8 @@ cleanup:
   free(doc_ids); free(dict_scratch); free(vals.i); free(vals.l); free(vals.f); free(vals.d); free(dbl_values); free(group_ids);
   free(holders); free(gholders); free(gavg_sum); free(gavg_cnt); free(gexact); free(gover); free(gcount); free(flags);
 done:
+  if (agg_nulls) for (int a = 0; a < q->num_aggregations; a++) free(agg_nulls[a]);
+  free(agg_nulls);
   free(filter_words); free(it); free(cols);
   return rc;
 }

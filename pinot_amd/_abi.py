@@ -16,7 +16,8 @@ KERNEL_NAMES = {0: "scan_agg_kernel", 1: "scan_private_kernel", 2: "scan_group_k
 PG_TYPE_INT, PG_TYPE_LONG, PG_TYPE_FLOAT, PG_TYPE_DOUBLE = range(4)
 PG_FWD_FIXED_BIT_DICT, PG_FWD_RAW_FIXED_BYTE = 0, 1
 # pg_predicate_kind / pg_leaf_eval
-PG_PRED_MATCH_ALL, PG_PRED_MATCH_NONE, PG_PRED_DICT_RANGE, PG_PRED_DICT_SET, PG_PRED_RAW_RANGE, PG_PRED_DOC_RANGE = range(6)
+PG_PRED_MATCH_ALL, PG_PRED_MATCH_NONE, PG_PRED_DICT_RANGE, PG_PRED_DICT_SET, PG_PRED_RAW_RANGE, PG_PRED_DOC_RANGE, PG_PRED_IS_NULL = range(7)
+PG_QUERY_DEFAULT, PG_QUERY_NULL_HANDLING = 0, 1
 PG_EVAL_SCAN, PG_EVAL_INVERTED = 0, 1
 # pg_filter_op
 PG_FILTER_LEAF, PG_FILTER_AND, PG_FILTER_OR, PG_FILTER_NOT = range(4)
@@ -35,7 +36,8 @@ class pg_column_desc(C.Structure):
                 ("bits_per_value", C.c_int32), ("cardinality", C.c_int32),
                 ("fwd_data", C.c_void_p), ("fwd_size", C.c_uint64),
                 ("dict_data", C.c_void_p), ("dict_size", C.c_uint64),
-                ("inv_data", C.c_void_p), ("inv_size", C.c_uint64)]
+                ("inv_data", C.c_void_p), ("inv_size", C.c_uint64),
+                ("null_data", C.c_void_p), ("null_size", C.c_uint64)]
 
 
 class pg_segment_desc(C.Structure):

@@ -33,6 +33,7 @@ std::string num(double v) {
 }
 
 std::string intermediateJson(const IntermediateResult& r) {
+  if (isNullResult(r)) return "null";
   if (std::holds_alternative<int64_t>(r)) return std::to_string(std::get<int64_t>(r));
   if (std::holds_alternative<double>(r)) return num(std::get<double>(r));
   const AvgPair& p = std::get<AvgPair>(r);
@@ -50,7 +51,8 @@ std::string blockJson(const ResultsBlock& b) {
     o << ", \"intermediate\": [";
     for (size_t i = 0; i < functions.size(); ++i) o << (i ? ", " : "") << intermediateJson(b.aggregation.results[i]);
     o << "], \"final\": [";
-    for (size_t i = 0; i < functions.size(); ++i) o << (i ? ", " : "") << num(functions[i].extractFinalResult(b.aggregation.results[i]));
+    for (size_t i = 0; i < functions.size(); ++i)
+      o << (i ? ", " : "") << (isNullResult(b.aggregation.results[i]) ? std::string("null") : num(functions[i].extractFinalResult(b.aggregation.results[i])));
     o << "]";
   } else {
     o << ", \"groupByColumns\": [";
@@ -68,7 +70,8 @@ std::string blockJson(const ResultsBlock& b) {
       o << "], \"intermediate\": [";
       for (size_t i = 0; i < functions.size(); ++i) o << (i ? ", " : "") << intermediateJson(b.groupBy.results[g][i]);
       o << "], \"final\": [";
-      for (size_t i = 0; i < functions.size(); ++i) o << (i ? ", " : "") << num(functions[i].extractFinalResult(b.groupBy.results[g][i]));
+      for (size_t i = 0; i < functions.size(); ++i)
+        o << (i ? ", " : "") << (isNullResult(b.groupBy.results[g][i]) ? std::string("null") : num(functions[i].extractFinalResult(b.groupBy.results[g][i])));
       o << "]}";
     }
     o << "]";
@@ -92,6 +95,16 @@ extern "C" {
 
 const char* ph_last_error(void) { return g_hostError.c_str(); }
 void ph_free(char* p) { free(p); }
+
+// Attaches the null value vector file of a column added earlier (the buffer stays caller-owned like the other index buffers).
+int32_t ph_segment_set_null_vector(void* seg, const char* column, const void* data, uint64_t size) {
+  return guarded([&] {
+    ImmutableSegment* s = static_cast<ImmutableSegment*>(seg);
+    DataSource& ds = s->mutableDataSource(column ? column : "");
+    ds.nullValueVector = (const uint8_t*)data;
+    ds.nullValueVectorSize = size;
+  });
+}
 
 void* ph_segment_create(const char* name, int32_t num_docs) { return new ImmutableSegment(name ? name : "", num_docs); }
 
@@ -188,7 +201,8 @@ char* ph_segment_describe(void* segment, int32_t* status) {
     for (const DataSource& ds : seg->getDataSources()) {
       o << (first ? "" : ", ") << "{\"name\": \"" << jsonEscape(ds.name) << "\", \"dataType\": \"" << dataTypeName(ds.dataType) << "\", \"hasDictionary\": "
         << (ds.hasDictionary ? "true" : "false") << ", \"cardinality\": " << ds.cardinality << ", \"bitsPerElement\": " << ds.bitsPerElement
-        << ", \"hasInvertedIndex\": " << (ds.hasInvertedIndex ? "true" : "false") << ", \"isSorted\": " << (ds.isSorted ? "true" : "false");
+        << ", \"hasInvertedIndex\": " << (ds.hasInvertedIndex ? "true" : "false") << ", \"isSorted\": " << (ds.isSorted ? "true" : "false")
+        << ", \"hasNullValueVector\": " << (ds.nullValueVector && ds.nullValueVectorSize ? "true" : "false");
       if (ds.dictionary && ds.cardinality > 0)
         o << ", \"minValue\": \"" << jsonEscape(ds.dictionary->getStringValue(0)) << "\", \"maxValue\": \"" << jsonEscape(ds.dictionary->getStringValue(ds.cardinality - 1)) << "\"";
       o << "}";
@@ -222,10 +236,13 @@ char* ph_parse_sql(const char* sql, int32_t* status) {
     std::ostringstream o;
     o << "{\"table\": \"" << jsonEscape(q.tableName) << "\", \"aggregations\": [";
     for (size_t i = 0; i < q.aggregations.size(); ++i)
-      o << (i ? ", " : "") << "\"" << jsonEscape(AggregationFunction(q.aggregations[i].function, q.aggregations[i].column).getResultColumnName()) << "\"";
+      o << (i ? ", " : "") << "\"" << jsonEscape(AggregationFunction(q.aggregations[i].function, q.aggregations[i].column).getResultColumnName()
+                                                + (q.aggregations[i].hasFilter ? " FILTER(WHERE " + q.aggregations[i].filterText + ")" : std::string())) << "\"";
     o << "], \"groupBy\": [";
     for (size_t i = 0; i < q.groupByExpressions.size(); ++i) o << (i ? ", " : "") << "\"" << jsonEscape(q.groupByExpressions[i]) << "\"";
-    o << "], \"hasFilter\": " << (q.hasFilter ? "true" : "false") << "}";
+    o << "], \"hasFilter\": " << (q.hasFilter ? "true" : "false");
+    if (q.nullHandlingEnabled) o << ", \"nullHandling\": true";
+    o << "}";
     out = o.str();
   });
   return *status == 0 ? strdup(out.c_str()) : nullptr;

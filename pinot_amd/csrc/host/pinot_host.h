@@ -137,6 +137,8 @@ struct DataSource {
   const uint8_t* forwardIndex = nullptr; uint64_t forwardIndexSize = 0;
   const uint8_t* dictionaryBuffer = nullptr; uint64_t dictionaryBufferSize = 0;   // INT dictionaries only
   const uint8_t* invertedIndex = nullptr; uint64_t invertedIndexSize = 0;
+  // DataSource.getNullValueVector(): the <column>.bitmap.nullvalue file (one RoaringBitmap of null docIds), absent when there are none
+  const uint8_t* nullValueVector = nullptr; uint64_t nullValueVectorSize = 0;
   std::vector<uint8_t> placeholderDictionary;  // STRING columns hand the device a 0..C-1 int dictionary
   // sorted column: SortedIndexReaderImpl's [startDocId, endDocId] per dictId (2 * cardinality ints); predicates become docId ranges
   bool isSorted = false;
@@ -152,6 +154,7 @@ class ImmutableSegment {
   int getTotalDocs() const { return _totalDocs; }
   void addDataSource(DataSource ds) { _columns.push_back(std::move(ds)); }
   const DataSource& getDataSource(const std::string& column) const;      // throws QueryException for unknown columns
+  DataSource& mutableDataSource(const std::string& column) { return _columns.at((size_t)getColumnIndex(column)); }
   int getColumnIndex(const std::string& column) const;
   const std::vector<DataSource>& getDataSources() const { return _columns; }
   void load(int deviceId);       // pg_segment_open
@@ -176,7 +179,7 @@ extern "C" int32_t ph_num_bits_per_value(int32_t max_value);
 
 // ---- common/request/context: ExpressionContext (identifiers only on this path), predicates, FilterContext -------
 struct Predicate {                                   // common/request/context/predicate/Predicate.java
-  enum class Type { EQ, NOT_EQ, IN, NOT_IN, RANGE };
+  enum class Type { EQ, NOT_EQ, IN, NOT_IN, RANGE, IS_NULL, IS_NOT_NULL };
   Type type = Type::EQ;
   std::string column;
   std::vector<std::string> values;                  // EQ / NOT_EQ: 1 value; IN / NOT_IN: n values
@@ -197,6 +200,11 @@ enum class AggregationFunctionType { COUNT, SUM, MIN, MAX, AVG };   // sspi/Aggr
 struct AggregationExpression {
   AggregationFunctionType function;
   std::string column;                                // "*" for COUNT(*)
+  // SUM(x) FILTER (WHERE ...): FilteredAggregationFunction (core/query/aggregation/function/FilterableAggregationFunction / QueryContext
+  // filtered aggregations); evaluated as one "swim lane" per distinct filter like FilteredAggregationOperator
+  bool hasFilter = false;
+  FilterContext filter;
+  std::string filterText;                            // canonical text of `filter`: the lane key
 };
 
 // query/request/context/QueryContext.java (the slice this path needs)
@@ -208,10 +216,12 @@ struct QueryContext {
   FilterContext filter;
   int maxInitialResultHolderCapacity = 10000;        // InstancePlanMakerImplV2.java:69-91 defaults
   int numGroupsLimit = 100000;
+  bool nullHandlingEnabled = false;                  // query option enableNullHandling (QueryContext.isNullHandlingEnabled)
 };
 
 // QueryContextConverterUtils.getQueryContext(sql) for the SQL subset of this path:
-//   SELECT agg(col|*) [, ...] FROM t [WHERE <AND/OR/NOT tree of =, !=, <>, <, <=, >, >=, BETWEEN, IN, NOT IN>] [GROUP BY c [, ...]]
+//   [SET enableNullHandling = true;] SELECT agg(col|*) [FILTER (WHERE ...)] [, ...] FROM t
+//   [WHERE <AND/OR/NOT tree of =, !=, <>, <, <=, >, >=, BETWEEN, IN, NOT IN, IS NULL, IS NOT NULL>] [GROUP BY c [, ...]]
 QueryContext getQueryContext(const std::string& sql);
 
 // ---- operator/filter/predicate: PredicateEvaluator lowering -----------------------------------------------------
@@ -230,11 +240,13 @@ PredicateEvaluator getPredicateEvaluator(const Predicate& predicate, const DataS
 
 // ---- query/aggregation/function ----------------------------------------------------------------------------------
 struct AvgPair { double sum = 0.0; int64_t count = 0; };                  // segl/customobject/AvgPair.java:26-45
-using IntermediateResult = std::variant<int64_t, double, AvgPair>;        // Long / Double / AvgPair
+using IntermediateResult = std::variant<int64_t, double, AvgPair, std::monostate>;   // Long / Double / AvgPair / null (null handling only)
+inline bool isNullResult(const IntermediateResult& r) { return std::holds_alternative<std::monostate>(r); }
 
 class AggregationFunction {                         // query/aggregation/function/AggregationFunction.java:42-145
  public:
-  AggregationFunction(AggregationFunctionType type, std::string column) : _type(type), _column(std::move(column)) {}
+  AggregationFunction(AggregationFunctionType type, std::string column, bool nullHandlingEnabled = false)
+      : _type(type), _column(std::move(column)), _nullHandlingEnabled(nullHandlingEnabled) {}
   AggregationFunctionType getType() const { return _type; }
   const std::string& getColumn() const { return _column; }
   std::string getResultColumnName() const;
@@ -244,6 +256,7 @@ class AggregationFunction {                         // query/aggregation/functio
  private:
   AggregationFunctionType _type;
   std::string _column;
+  bool _nullHandlingEnabled;                          // NullableSingleInputAggregationFunction._nullHandlingEnabled
 };
 
 // ---- operator/ExecutionStatistics.java:25-64 ---------------------------------------------------------------------

@@ -104,6 +104,7 @@ void ImmutableSegment::load(int deviceId) {
       }
     }
     if (ds.hasInvertedIndex) { d.inv_data = ds.invertedIndex; d.inv_size = ds.invertedIndexSize; }
+    if (ds.nullValueVector && ds.nullValueVectorSize) { d.null_data = ds.nullValueVector; d.null_size = ds.nullValueVectorSize; }
   }
   pg_segment_desc sd;
   memset(&sd, 0, sizeof(sd));
@@ -129,6 +130,9 @@ std::string AggregationFunction::getResultColumnName() const {
 }
 
 IntermediateResult AggregationFunction::fromDevice(const pg_agg_value& v) const {
+  // null handling: the holder is an ObjectAggregationResultHolder that stays null until a non-null value arrives
+  // (SumAggregationFunction.java:52-57,147-157; same in Min / Max / Avg); COUNT is never null
+  if (_nullHandlingEnabled && _type != AggregationFunctionType::COUNT && v.count == 0) return std::monostate{};
   switch (_type) {
     case AggregationFunctionType::COUNT: return (int64_t)v.count;          // CountAggregationFunction.extractAggregationResult -> Long
     case AggregationFunctionType::SUM: return v.sum;                       // Double
@@ -140,6 +144,9 @@ IntermediateResult AggregationFunction::fromDevice(const pg_agg_value& v) const 
 }
 
 IntermediateResult AggregationFunction::merge(const IntermediateResult& a, const IntermediateResult& b) const {
+  // SumAggregationFunction.merge :223-233 and friends under null handling: a null side yields the other side
+  if (isNullResult(a)) return b;
+  if (isNullResult(b)) return a;
   switch (_type) {
     case AggregationFunctionType::COUNT: return std::get<int64_t>(a) + std::get<int64_t>(b);   // CountAggregationFunction.merge
     case AggregationFunctionType::SUM: return std::get<double>(a) + std::get<double>(b);        // SumAggregationFunction.merge :223-233
@@ -156,6 +163,7 @@ IntermediateResult AggregationFunction::merge(const IntermediateResult& a, const
 }
 
 double AggregationFunction::extractFinalResult(const IntermediateResult& r) const {
+  if (isNullResult(r)) return std::nan("");           // the final result is null (printed as such by the callers)
   switch (_type) {
     case AggregationFunctionType::COUNT: return (double)std::get<int64_t>(r);
     case AggregationFunctionType::AVG: {                                    // AvgAggregationFunction.extractFinalResult :209-218
@@ -180,27 +188,37 @@ struct LoweredQuery {
   pg_query query;
 };
 
-void lowerFilter(const FilterContext& f, const ImmutableSegment& seg, LoweredQuery* out) {
+void lowerFilter(const FilterContext& f, const ImmutableSegment& seg, bool nullHandling, LoweredQuery* out) {
   switch (f.type) {
     case FilterContext::Type::AND:
     case FilterContext::Type::OR: {
-      for (const auto& c : f.children) lowerFilter(c, seg, out);
+      for (const auto& c : f.children) lowerFilter(c, seg, nullHandling, out);
       pg_filter_node n{f.type == FilterContext::Type::AND ? PG_FILTER_AND : PG_FILTER_OR, -1, (int32_t)f.children.size(), 0};
       out->nodes.push_back(n);
       return;
     }
     case FilterContext::Type::NOT: {
-      lowerFilter(f.children.at(0), seg, out);
+      lowerFilter(f.children.at(0), seg, nullHandling, out);
       out->nodes.push_back(pg_filter_node{PG_FILTER_NOT, -1, 1, 0});
       return;
     }
     case FilterContext::Type::PREDICATE: {
       const DataSource& ds = seg.getDataSource(f.predicate.column);
-      const PredicateEvaluator ev = getPredicateEvaluator(f.predicate, ds);
       pg_predicate p;
       memset(&p, 0, sizeof(p));
       p.column = seg.getColumnIndex(f.predicate.column);
-      if (ev.alwaysTrue) p.kind = PG_PRED_MATCH_ALL;          // MatchAllFilterOperator (FilterOperatorUtils.java:79-92)
+      const bool hasNulls = ds.nullValueVector != nullptr && ds.nullValueVectorSize > 0;
+      if (f.predicate.type == Predicate::Type::IS_NULL || f.predicate.type == Predicate::Type::IS_NOT_NULL) {
+        // FilterPlanNode.java:294-310: the null bitmap as a BitmapBasedFilterOperator, Empty / MatchAll without a null vector
+        p.kind = PG_PRED_IS_NULL;
+        p.exclusive = f.predicate.type == Predicate::Type::IS_NOT_NULL;
+        out->predicates.push_back(p);
+        out->nodes.push_back(pg_filter_node{PG_FILTER_LEAF, (int32_t)out->predicates.size() - 1, 0, 0});
+        return;
+      }
+      const PredicateEvaluator ev = getPredicateEvaluator(f.predicate, ds);
+      if (ev.alwaysTrue && nullHandling && hasNulls) { p.kind = PG_PRED_IS_NULL; p.exclusive = 1; }   // FilterOperatorUtils.java:78-86
+      else if (ev.alwaysTrue) p.kind = PG_PRED_MATCH_ALL;     // MatchAllFilterOperator (FilterOperatorUtils.java:79-92)
       else if (ev.alwaysFalse) p.kind = PG_PRED_MATCH_NONE;   // EmptyFilterOperator
       else if (ev.rawRange) {
         p.kind = PG_PRED_RAW_RANGE; p.lo = ev.rawLower; p.hi = ev.rawUpper; p.exclusive = ev.exclusive;
@@ -224,7 +242,7 @@ void lowerFilter(const FilterContext& f, const ImmutableSegment& seg, LoweredQue
         for (const auto& r : ranges) {
           pg_predicate dr;
           memset(&dr, 0, sizeof(dr));
-          dr.kind = PG_PRED_DOC_RANGE; dr.lo = r.first; dr.hi = r.second;
+          dr.kind = PG_PRED_DOC_RANGE; dr.lo = r.first; dr.hi = r.second; dr.column = p.column;
           out->predicates.push_back(dr);
           out->nodes.push_back(pg_filter_node{PG_FILTER_LEAF, (int32_t)out->predicates.size() - 1, 0, 0});
         }
@@ -257,7 +275,7 @@ std::unique_ptr<LoweredQuery> lowerQuery(const ImmutableSegment& seg, const Quer
   auto lq = std::make_unique<LoweredQuery>();
   // reserve so that set_words pointers taken during lowering stay valid
   lq->setWords.reserve(64);
-  if (qc.hasFilter) lowerFilter(qc.filter, seg, lq.get());
+  if (qc.hasFilter) lowerFilter(qc.filter, seg, qc.nullHandlingEnabled, lq.get());
   for (const auto& a : qc.aggregations) {
     pg_aggregation pa;
     pa.function = (int32_t)a.function;
@@ -266,7 +284,8 @@ std::unique_ptr<LoweredQuery> lowerQuery(const ImmutableSegment& seg, const Quer
       const DataSource& ds = seg.getDataSource(a.column);
       if (!isNumeric(ds.dataType) && a.function != AggregationFunctionType::COUNT)
         throw QueryException("Cannot compute " + AggregationFunction(a.function, a.column).getResultColumnName() + " for non-numeric type: STRING");
-      if (a.function == AggregationFunctionType::COUNT) pa.column = -1;   // COUNT(col) == COUNT(*) with null handling off
+      // COUNT(col) == COUNT(*) unless null handling is on (CountAggregationFunction.java:44-50)
+      if (a.function == AggregationFunctionType::COUNT && !qc.nullHandlingEnabled) pa.column = -1;
     }
     lq->aggregations.push_back(pa);
   }
@@ -290,6 +309,7 @@ std::unique_ptr<LoweredQuery> lowerQuery(const ImmutableSegment& seg, const Quer
   q.group_by_columns = lq->groupBy.data();
   q.num_group_by = (int32_t)lq->groupBy.size();
   q.num_groups_limit = qc.numGroupsLimit;
+  q.flags = qc.nullHandlingEnabled ? PG_QUERY_NULL_HANDLING : PG_QUERY_DEFAULT;
   return lq;
 }
 
@@ -305,7 +325,7 @@ class GpuAggregationOperator : public Operator {
     checkStatus(gpuAbi().execute(_segment->handle(), &_lowered->query, &res), ("executing on segment " + _segment->getSegmentName()).c_str());
     ResultsBlock block;
     std::vector<AggregationFunction> functions;
-    for (const auto& a : _queryContext.aggregations) functions.emplace_back(a.function, a.column);
+    for (const auto& a : _queryContext.aggregations) functions.emplace_back(a.function, a.column, _queryContext.nullHandlingEnabled);
     block.stats.numDocsScanned = res.stats.num_docs_scanned;
     block.stats.numEntriesScannedInFilter = res.stats.num_entries_scanned_in_filter;
     block.stats.numEntriesScannedPostFilter = res.stats.num_entries_scanned_post_filter;
@@ -386,12 +406,103 @@ void GpuPlanMaker::init(const std::map<std::string, std::string>& cfg) {
   checkStatus(gpuAbi().init(&c), "initialising the GPU plan maker");
 }
 
+// FilteredAggregationOperator (core/operator/query/FilteredAggregationOperator.java:68-110; lanes built by
+// AggregationFunctionUtils.buildFilteredAggregationInfos): the aggregations are split into one "swim lane" per distinct FILTER clause
+// (plus one for the unfiltered ones), each lane runs over main-filter AND lane-filter, the results go back to their positions and
+// the execution statistics of the lanes are added up.  Every lane is one pg_execute.
+class GpuFilteredAggregationOperator : public Operator {
+ public:
+  struct Lane { std::unique_ptr<Operator> op; std::vector<int> positions; };
+  GpuFilteredAggregationOperator(const ImmutableSegment* seg, QueryContext qc, std::vector<Lane> lanes)
+      : _segment(seg), _queryContext(std::move(qc)), _lanes(std::move(lanes)) {}
+
+  ResultsBlock nextBlock() override {
+    ResultsBlock block;
+    block.isGroupBy = false;
+    for (const auto& a : _queryContext.aggregations) block.aggregation.functions.emplace_back(a.function, a.column, _queryContext.nullHandlingEnabled);
+    block.aggregation.results.resize(_queryContext.aggregations.size());
+    for (auto& lane : _lanes) {
+      ResultsBlock b = lane.op->nextBlock();
+      for (size_t i = 0; i < lane.positions.size(); ++i) block.aggregation.results[(size_t)lane.positions[i]] = b.aggregation.results[i];
+      block.stats.numDocsScanned += b.stats.numDocsScanned;
+      block.stats.numEntriesScannedInFilter += b.stats.numEntriesScannedInFilter;
+      block.stats.numEntriesScannedPostFilter += b.stats.numEntriesScannedPostFilter;
+      block.stats.numTotalDocs = b.stats.numTotalDocs;
+      block.deviceMs += b.deviceMs;
+      block.kernelMs += b.kernelMs;
+    }
+    _stats = block.stats;
+    return block;
+  }
+  std::string toExplainString() const override { return "GPU_AGGREGATE_FILTERED"; }
+  ExecutionStatistics getExecutionStatistics() const override { return _stats; }
+  const ImmutableSegment* getIndexSegment() const override { return _segment; }
+
+ private:
+  const ImmutableSegment* _segment;
+  QueryContext _queryContext;
+  std::vector<Lane> _lanes;
+  ExecutionStatistics _stats;
+};
+
+class GpuFilteredAggregationPlanNode : public PlanNode {
+ public:
+  GpuFilteredAggregationPlanNode(const ImmutableSegment* seg, QueryContext qc, std::vector<std::unique_ptr<PlanNode>> lanePlans, std::vector<std::vector<int>> positions)
+      : _segment(seg), _queryContext(std::move(qc)), _lanePlans(std::move(lanePlans)), _positions(std::move(positions)) {}
+  std::unique_ptr<Operator> run() override {
+    std::vector<GpuFilteredAggregationOperator::Lane> lanes;
+    for (size_t i = 0; i < _lanePlans.size(); ++i) lanes.push_back({_lanePlans[i]->run(), _positions[i]});
+    return std::make_unique<GpuFilteredAggregationOperator>(_segment, _queryContext, std::move(lanes));
+  }
+ private:
+  const ImmutableSegment* _segment;
+  QueryContext _queryContext;
+  std::vector<std::unique_ptr<PlanNode>> _lanePlans;
+  std::vector<std::vector<int>> _positions;
+};
+
 std::unique_ptr<PlanNode> GpuPlanMaker::makeSegmentPlanNode(const SegmentContext& sc, const QueryContext& qc) {
   const ImmutableSegment* seg = sc.indexSegment;
   if (!seg || !seg->handle()) throw std::runtime_error("segment is not loaded on a device");
   if (qc.aggregations.empty()) throw UnsupportedOperationException("only aggregation / group-by queries are offloaded (selection stays on the CPU plan)");
   // Anything the device cannot run is rejected HERE, at plan time, never at run time.
-  return std::make_unique<GpuAggregationPlanNode>(seg, qc, lowerQuery(*seg, qc));
+  bool anyFiltered = false;
+  for (const auto& a : qc.aggregations) anyFiltered |= a.hasFilter;
+  if (!anyFiltered) return std::make_unique<GpuAggregationPlanNode>(seg, qc, lowerQuery(*seg, qc));
+  if (!qc.groupByExpressions.empty()) throw UnsupportedOperationException("FILTER (WHERE ...) aggregations under GROUP BY keep the CPU plan (FilteredGroupByOperator)");
+  std::vector<std::string> keys;                       // lane order = first appearance, the unfiltered lane keyed ""
+  std::vector<QueryContext> laneQueries;
+  std::vector<std::vector<int>> positions;
+  for (size_t i = 0; i < qc.aggregations.size(); ++i) {
+    const AggregationExpression& a = qc.aggregations[i];
+    const std::string key = a.hasFilter ? a.filterText : std::string();
+    size_t lane = std::find(keys.begin(), keys.end(), key) - keys.begin();
+    if (lane == keys.size()) {
+      keys.push_back(key);
+      QueryContext lq = qc;
+      lq.aggregations.clear();
+      if (a.hasFilter) {
+        if (qc.hasFilter) {
+          FilterContext both;
+          both.type = FilterContext::Type::AND;
+          both.children = {qc.filter, a.filter};
+          lq.filter = both;
+        } else {
+          lq.filter = a.filter;
+        }
+        lq.hasFilter = true;
+      }
+      laneQueries.push_back(std::move(lq));
+      positions.emplace_back();
+    }
+    AggregationExpression plain = a;
+    plain.hasFilter = false;
+    laneQueries[lane].aggregations.push_back(plain);
+    positions[lane].push_back((int)i);
+  }
+  std::vector<std::unique_ptr<PlanNode>> lanePlans;
+  for (const auto& lq : laneQueries) lanePlans.push_back(std::make_unique<GpuAggregationPlanNode>(seg, lq, lowerQuery(*seg, lq)));
+  return std::make_unique<GpuFilteredAggregationPlanNode>(seg, qc, std::move(lanePlans), std::move(positions));
 }
 
 // AggregationResultsBlockMerger.mergeResultsBlocks (:34-44) and GroupByCombineOperator (:132-147, keyed by VALUES).

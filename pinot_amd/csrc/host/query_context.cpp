@@ -224,6 +224,13 @@ FilterContext parsePredicate(Lexer& lx) {
     p.upperBound = literal(lx); p.upperInclusive = true;
     return f;
   }
+  if (lx.acceptKeyword("IS")) {
+    // IS NULL / IS NOT NULL (Predicate.Type.IS_NULL / IS_NOT_NULL)
+    const bool isNot = lx.acceptKeyword("NOT");
+    lx.expectKeyword("NULL");
+    p.type = isNot ? Predicate::Type::IS_NOT_NULL : Predicate::Type::IS_NULL;
+    return f;
+  }
   bool negated = lx.acceptKeyword("NOT");
   if (lx.acceptKeyword("IN")) {
     p.type = negated ? Predicate::Type::NOT_IN : Predicate::Type::IN;
@@ -278,9 +285,42 @@ FilterContext parseOr(Lexer& lx) {
 
 }  // namespace
 
+// canonical text of a filter tree (used to find aggregations that share a FILTER clause)
+static std::string filterToString(const FilterContext& f) {
+  switch (f.type) {
+    case FilterContext::Type::PREDICATE: {
+      const Predicate& p = f.predicate;
+      std::string s = p.column + "#" + std::to_string((int)p.type) + "#" + p.lowerBound + (p.lowerInclusive ? "[" : "(") + p.upperBound + (p.upperInclusive ? "]" : ")");
+      for (const auto& v : p.values) s += "|" + v;
+      return "{" + s + "}";
+    }
+    case FilterContext::Type::NOT: return "NOT(" + filterToString(f.children.at(0)) + ")";
+    default: {
+      std::string s = f.type == FilterContext::Type::AND ? "AND(" : "OR(";
+      for (const auto& c : f.children) s += filterToString(c) + ",";
+      return s + ")";
+    }
+  }
+}
+
 QueryContext getQueryContext(const std::string& sql) {
   Lexer lx(sql);
   QueryContext q;
+  // SET key = value; statements ahead of the query are query options (CalciteSqlParser SET statements -> QueryOptions)
+  while (lx.acceptKeyword("SET")) {
+    const Token key = lx.next();
+    if (key.kind != Token::IDENT) throw QueryException("expected an option name near '" + key.text + "'");
+    lx.expectSymbol("=");
+    const Token value = lx.next();
+    if (value.kind == Token::END) throw QueryException("expected an option value");
+    lx.expectSymbol(";");
+    std::string k = key.text, v = value.text;
+    for (auto& c : k) c = (char)tolower((unsigned char)c);
+    for (auto& c : v) c = (char)tolower((unsigned char)c);
+    if (k == "enablenullhandling") q.nullHandlingEnabled = v == "true";
+    else if (k == "numgroupslimit") q.numGroupsLimit = atoi(v.c_str());
+    else throw UnsupportedOperationException("query option '" + key.text + "' is not handled on this path");
+  }
   lx.expectKeyword("SELECT");
   do {
     const Token fn = lx.next();
@@ -305,6 +345,14 @@ QueryContext getQueryContext(const std::string& sql) {
     }
     lx.expectSymbol(")");
     if (e.function != AggregationFunctionType::COUNT && e.column == "*") throw QueryException("'*' is only valid in COUNT(*)");
+    if (lx.acceptKeyword("FILTER")) {
+      lx.expectSymbol("(");
+      lx.expectKeyword("WHERE");
+      e.filter = parseOr(lx);
+      e.hasFilter = true;
+      e.filterText = filterToString(e.filter);
+      lx.expectSymbol(")");
+    }
     q.aggregations.push_back(e);
     if (lx.acceptKeyword("AS")) lx.next();
   } while (lx.acceptSymbol(","));

@@ -247,6 +247,8 @@ std::unique_ptr<ImmutableSegment> loadSegmentDirectory(const std::string& indexD
         continue;
       }
       ds.forwardIndex = fwd.data; ds.forwardIndexSize = fwd.size;
+      const Slice nulls = index.get(col, ".bitmap.nullvalue", "nullvalue_vector", &keep);   // V1Constants.Indexes.NULLVALUE_VECTOR_FILE_EXTENSION
+      ds.nullValueVector = nulls.data; ds.nullValueVectorSize = nulls.size;
       const Slice inv = index.get(col, ".bitmap.inv", "inverted_index", &keep);
       ds.hasInvertedIndex = inv.data != nullptr && inv.size > 0;
       ds.invertedIndex = inv.data; ds.invertedIndexSize = inv.size;
@@ -257,6 +259,8 @@ std::unique_ptr<ImmutableSegment> loadSegmentDirectory(const std::string& indexD
       if (fwd.size >= 28 && beInt(fwd.data + 20) != 0) { skip("compressed raw forward index"); continue; }   // PASS_THROUGH only
       ds.forwardIndex = fwd.data; ds.forwardIndexSize = fwd.size;
       ds.bitsPerElement = 8 * valueBytes;
+      const Slice nulls = index.get(col, ".bitmap.nullvalue", "nullvalue_vector", &keep);
+      ds.nullValueVector = nulls.data; ds.nullValueVectorSize = nulls.size;
     }
     for (auto& b : keep) seg->keepAlive(b);
     seg->addDataSource(std::move(ds));

@@ -90,6 +90,8 @@ struct ColumnDev {
   DevContainer* d_dir = nullptr;
   std::vector<DevContainer> h_dir;
   std::vector<int64_t> posting_first;   // [cardinality + 1] index into the container directory
+  unsigned long long* d_null_bitmap = nullptr;   // null value vector expanded to a doc-order bitmap (num_tiles * 32 words), or nullptr
+  int64_t num_nulls = 0;
   // value plane (built lazily on the device the first time the column is summed)
   uint8_t* d_plane = nullptr;
   int plane_bits = 0;                   // 1..31 packed, 32 = big-endian int32 values
@@ -301,6 +303,7 @@ void free_segment(pg_segment* seg) {
     if (col.d_dict64) (void)hipFree(col.d_dict64);
     if (col.d_inv) (void)hipFree(col.d_inv);
     if (col.d_dir) (void)hipFree(col.d_dir);
+    if (col.d_null_bitmap) (void)hipFree(col.d_null_bitmap);
     if (col.d_plane && !col.plane_is_fwd) (void)hipFree(col.d_plane);
   }
   delete seg;
@@ -470,7 +473,7 @@ void build_sequence(const pg_query* q, std::vector<SeqNode>* seq, int* lazy_node
     if (pi < 0 || pi >= q->num_predicates) return false;
     const pg_predicate& pr = q->predicates[pi];
     // index-driven leaves go first, like the reference's priorities (sorted 0 < bitmap 100 < scan 500, FilterOperatorUtils.java:205-251)
-    return pr.kind == PG_PRED_DOC_RANGE || (pr.eval == PG_EVAL_INVERTED && (pr.kind == PG_PRED_DICT_RANGE || pr.kind == PG_PRED_DICT_SET));
+    return pr.kind == PG_PRED_DOC_RANGE || pr.kind == PG_PRED_IS_NULL || (pr.eval == PG_EVAL_INVERTED && (pr.kind == PG_PRED_DICT_RANGE || pr.kind == PG_PRED_DICT_SET));
   };
   std::stable_partition(children.begin(), children.end(), is_bitmap_leaf);
   for (const auto& ch : children) *num_bitmap_prefix += is_bitmap_leaf(ch) ? 1 : 0;
@@ -520,6 +523,13 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
       L.col = 0;
       if (pr.kind == PG_PRED_MATCH_ALL) { L.kind = kLeafMatchAll; }
       else if (pr.kind == PG_PRED_MATCH_NONE) { L.kind = kLeafMatchNone; }
+      else if (pr.kind == PG_PRED_IS_NULL) {
+        // FilterPlanNode.java:294-310: the null bitmap as a BitmapBasedFilterOperator; no null vector -> Empty (IS NULL) / MatchAll (IS NOT NULL)
+        if (pr.column < 0 || pr.column >= (int)seg->cols.size()) return fail(PG_ERR_INVALID_ARGUMENT, "predicate column %d out of range", pr.column);
+        const ColumnDev& col = seg->cols[pr.column];
+        if (!col.d_null_bitmap) { L.kind = kLeafMatchNone; }
+        else { L.kind = kLeafBitmap; L.bitmap = col.d_null_bitmap; sp.num_bitmap_leaves++; }
+      }
       else if (pr.kind == PG_PRED_DOC_RANGE) {
         // SortedIndexBasedFilterOperator: one inclusive docId range; nothing is scanned
         const int64_t lo = std::max<int64_t>(pr.lo, 0), hi = std::min<int64_t>(pr.hi, (int64_t)seg->num_docs - 1);
@@ -1029,6 +1039,39 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       col.inv_size = cd.inv_size;
       seg->device_bytes += cd.inv_size + col.h_dir.size() * sizeof(DevContainer);
     }
+    if (cd.null_data && cd.null_size) {
+      // NullValueVectorReaderImpl.getNullBitmap (NullValueVectorReaderImpl.java:44-46): the whole buffer is one RoaringBitmap.  It is
+      // expanded once into a doc-order bitmap that IS_NULL leaves and the null-skipping aggregation lanes read like a posting.
+      std::vector<DevContainer> dir;
+      st = parse_roaring((const uint8_t*)cd.null_data, 0, cd.null_size, &dir);
+      if (st != PG_OK) return bail(st);
+      const long long words = (long long)std::max(seg->num_tiles, 1) * kMaxTileSteps;
+      int64_t nulls = 0;
+      std::vector<DevContainer> kept;
+      for (const DevContainer& dc : dir) {
+        if ((long long)dc.key * 1024 >= words) continue;   // containers beyond numDocs cannot hold a docId of this segment
+        kept.push_back(dc);
+        nulls += dc.cardinality;
+      }
+      if (nulls > 0) {
+        uint8_t* d_bytes = nullptr;
+        DevContainer* d_cont = nullptr;
+        hipError_t e = hipMalloc((void**)&d_bytes, (size_t)cd.null_size + 16);
+        if (e == hipSuccess) e = hipMemcpy(d_bytes, cd.null_data, (size_t)cd.null_size, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_cont, kept.size() * sizeof(DevContainer));
+        if (e == hipSuccess) e = hipMemcpy(d_cont, kept.data(), kept.size() * sizeof(DevContainer), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&col.d_null_bitmap, (size_t)words * 8);
+        if (e == hipSuccess) {
+          roaring_expand_kernel<<<dim3((unsigned)((words + 1023) / 1024)), dim3(kBlockThreads), 0, 0>>>(d_bytes, d_cont, 0, (int)kept.size(), col.d_null_bitmap, words, 0);
+          e = hipDeviceSynchronize();
+        }
+        if (d_bytes) (void)hipFree(d_bytes);
+        if (d_cont) (void)hipFree(d_cont);
+        if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "column %s: null value vector upload: %s", col.name.c_str(), hipGetErrorString(e)));
+        col.num_nulls = nulls;
+        seg->device_bytes += (uint64_t)words * 8;
+      }
+    }
   }
   *out_segment = seg;
   return PG_OK;
@@ -1062,7 +1105,7 @@ void pg_result_free(pg_result* r) {
 }
 
 static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out, unsigned long long* d_out_bitmap_request,
-                              uint64_t* host_bitmap, int64_t host_bitmap_words, int64_t* out_cardinality) {
+                              uint64_t* host_bitmap, int64_t host_bitmap_words, int64_t* out_cardinality, bool allow_metadata_plan = true) {
   if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");
   if (!seg || !q) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
   (void)d_out_bitmap_request;
@@ -1082,7 +1125,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   // NonScanBasedAggregationOperator (core/plan/AggregationPlanNode.java:98-115,159-190; core/operator/query/
   // NonScanBasedAggregationOperator.java:83-105): the filter matches everything and every function is COUNT, or MIN / MAX of a
   // dictionary column -> the answer comes from the segment metadata and the dictionary ends; nothing is scanned.
-  if (ng == 0 && !want_bitmap && out && na > 0) {
+  if (ng == 0 && !want_bitmap && out && na > 0 && allow_metadata_plan) {
     bool match_all = q->num_filter_nodes == 0;
     if (q->num_filter_nodes == 1 && q->filter && q->predicates && q->filter[0].op == PG_FILTER_LEAF && q->filter[0].predicate >= 0 &&
         q->filter[0].predicate < q->num_predicates) {
@@ -1468,15 +1511,202 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   return PG_OK;
 }
 
+// ---- PG_QUERY_NULL_HANDLING (query option enableNullHandling=true) ----
+// The reference gives every filter operator three docId sets -- trues, nulls, falses (BaseFilterOperator.java:85-113) -- and the
+// aggregation functions skip the null docs of their own column (NullableSingleInputAggregationFunction.java:72-166).  Both are
+// lowered HERE, on the host, into plain two-valued work for the kernels: the filter becomes an ordinary tree whose extra leaves
+// read the columns' null bitmaps (IS_NULL postings expanded at open), and the aggregations are split into one lane per nullable
+// column, each lane running the filter AND "column IS NOT NULL".  The kernels do not know about nulls.
+struct FilterExpr {
+  int op = PG_FILTER_LEAF;
+  pg_predicate pred{};
+  std::vector<FilterExpr> kids;
+};
+
+struct NullRewriter {
+  const pg_segment* seg;
+  bool has_nulls(int column) const { return column >= 0 && column < (int)seg->cols.size() && seg->cols[(size_t)column].d_null_bitmap != nullptr; }
+  static bool column_leaf(const pg_predicate& p) {
+    return p.kind == PG_PRED_DICT_RANGE || p.kind == PG_PRED_DICT_SET || p.kind == PG_PRED_RAW_RANGE || p.kind == PG_PRED_DOC_RANGE;
+  }
+  static FilterExpr leaf(const pg_predicate& p) { FilterExpr e; e.pred = p; return e; }
+  static FilterExpr null_leaf(int column, bool is_not_null) {
+    pg_predicate p{};
+    p.kind = PG_PRED_IS_NULL; p.column = column; p.exclusive = is_not_null ? 1 : 0;
+    return leaf(p);
+  }
+  static FilterExpr combine(int op, std::vector<FilterExpr> kids) {
+    if (kids.size() == 1 && op != PG_FILTER_NOT) return std::move(kids[0]);
+    FilterExpr e; e.op = op; e.kids = std::move(kids);
+    return e;
+  }
+  static FilterExpr negate(FilterExpr e) { std::vector<FilterExpr> k; k.push_back(std::move(e)); return combine(PG_FILTER_NOT, std::move(k)); }
+
+  // getTrues(): BaseColumnFilterOperator.java:45-53 (matches AND NOT nulls); And / Or: of the children's trues; Not: the child's falses
+  FilterExpr trues(const FilterExpr& e) const {
+    if (e.op == PG_FILTER_LEAF) {
+      if (column_leaf(e.pred) && has_nulls(e.pred.column)) return combine(PG_FILTER_AND, {leaf(e.pred), null_leaf(e.pred.column, true)});
+      return e;
+    }
+    if (e.op == PG_FILTER_NOT) return falses(e.kids[0]);
+    std::vector<FilterExpr> k;
+    for (const auto& c : e.kids) k.push_back(trues(c));
+    return combine(e.op, std::move(k));
+  }
+  // trues OR nulls of a child, as And / OrFilterOperator.getFalses collect them (AndFilterOperator.java:62-80): only column leaves
+  // have a null set (BaseColumnFilterOperator.getNulls :56-64); (matches AND NOT nulls) OR nulls == matches OR nulls
+  FilterExpr trues_or_nulls(const FilterExpr& e) const {
+    if (e.op == PG_FILTER_LEAF && column_leaf(e.pred) && has_nulls(e.pred.column))
+      return combine(PG_FILTER_OR, {leaf(e.pred), null_leaf(e.pred.column, false)});
+    return trues(e);
+  }
+  // getFalses(): leaf NOT (trues OR nulls) (BaseFilterOperator.java:96-113); And / Or: NOT AND / OR of (trues_i OR nulls_i); Not: child trues
+  FilterExpr falses(const FilterExpr& e) const {
+    if (e.op == PG_FILTER_LEAF) return negate(trues_or_nulls(e));
+    if (e.op == PG_FILTER_NOT) return trues(e.kids[0]);
+    std::vector<FilterExpr> k;
+    for (const auto& c : e.kids) k.push_back(trues_or_nulls(c));
+    return negate(combine(e.op, std::move(k)));
+  }
+};
+
+struct FlatQuery {
+  std::vector<pg_filter_node> nodes;
+  std::vector<pg_predicate> preds;
+  std::vector<pg_aggregation> aggs;
+  pg_query q{};
+  void emit(const FilterExpr& e) {
+    pg_filter_node n{};
+    n.op = e.op;
+    if (e.op == PG_FILTER_LEAF) { n.predicate = (int32_t)preds.size(); preds.push_back(e.pred); }
+    else { for (const auto& c : e.kids) emit(c); n.predicate = -1; n.num_children = (int32_t)e.kids.size(); }
+    nodes.push_back(n);
+  }
+  void finish(const pg_query& base) {
+    q = base;
+    q.flags = base.flags & ~PG_QUERY_NULL_HANDLING;
+    q.filter = nodes.empty() ? nullptr : nodes.data(); q.num_filter_nodes = (int32_t)nodes.size();
+    q.predicates = preds.empty() ? nullptr : preds.data(); q.num_predicates = (int32_t)preds.size();
+  }
+};
+
+static pg_status parse_filter(const pg_query* q, FilterExpr* root, bool* has_filter) {
+  *has_filter = q->num_filter_nodes > 0;
+  if (!*has_filter) return PG_OK;
+  if (!q->filter || !q->predicates) return fail(PG_ERR_INVALID_ARGUMENT, "filter nodes without predicates");
+  std::vector<FilterExpr> stack;
+  for (int n = 0; n < q->num_filter_nodes; ++n) {
+    const pg_filter_node& fn = q->filter[n];
+    FilterExpr e;
+    e.op = fn.op;
+    if (fn.op == PG_FILTER_LEAF) {
+      if (fn.predicate < 0 || fn.predicate >= q->num_predicates) return fail(PG_ERR_INVALID_ARGUMENT, "filter node %d: bad predicate index", n);
+      e.pred = q->predicates[fn.predicate];
+    } else if (fn.op == PG_FILTER_AND || fn.op == PG_FILTER_OR || fn.op == PG_FILTER_NOT) {
+      const int k = fn.op == PG_FILTER_NOT ? 1 : fn.num_children;
+      if (k < 1 || (int)stack.size() < k) return fail(PG_ERR_INVALID_ARGUMENT, "malformed filter tree (node %d)", n);
+      e.kids.assign(std::make_move_iterator(stack.end() - k), std::make_move_iterator(stack.end()));
+      stack.resize(stack.size() - (size_t)k);
+    } else {
+      return fail(PG_ERR_INVALID_ARGUMENT, "unknown filter op %d", fn.op);
+    }
+    stack.push_back(std::move(e));
+  }
+  if (stack.size() != 1) return fail(PG_ERR_INVALID_ARGUMENT, "malformed filter tree (%d roots)", (int)stack.size());
+  *root = std::move(stack[0]);
+  return PG_OK;
+}
+
+static pg_status execute_null_handling(pg_segment* seg, const pg_query* q, pg_result* out, uint64_t* host_bitmap, int64_t host_bitmap_words,
+                                       int64_t* out_cardinality) {
+  if (!seg || !q) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
+  NullRewriter rw{seg};
+  FilterExpr root, filter_trues;
+  bool has_filter = false;
+  pg_status st = parse_filter(q, &root, &has_filter);
+  if (st != PG_OK) return st;
+  if (has_filter) filter_trues = rw.trues(root);
+  FlatQuery base;
+  if (has_filter) base.emit(filter_trues);
+  base.finish(*q);
+  if (host_bitmap) return execute_impl(seg, &base.q, nullptr, nullptr, host_bitmap, host_bitmap_words, out_cardinality);
+  const int na = q->num_aggregations, ng = q->num_group_by;
+  if (na < 0 || ng < 0 || (na > 0 && !q->aggregations) || (ng > 0 && !q->group_by_columns)) return fail(PG_ERR_INVALID_ARGUMENT, "bad aggregation / group-by lists");
+  // lanes: the nullable columns that are aggregated, in first-use order (AggregationPlanNode.hasNullValues :130-152)
+  std::vector<int> lane_cols;
+  for (int a = 0; a < na; ++a) {
+    const int c = q->aggregations[a].column;
+    if (rw.has_nulls(c) && std::find(lane_cols.begin(), lane_cols.end(), c) == lane_cols.end()) lane_cols.push_back(c);
+  }
+  if (ng > 0) {
+    // DefaultGroupByExecutor.java:106-121 drops the dictionary-based key generator under null handling; equal results are only
+    // guaranteed when no key and no aggregated column has nulls.
+    bool nullable = !lane_cols.empty();
+    for (int g = 0; g < ng; ++g) nullable |= rw.has_nulls(q->group_by_columns[g]);
+    if (nullable) return fail(PG_ERR_UNSUPPORTED, "GROUP BY over columns with null docs under null handling keeps the CPU plan");
+    return execute_impl(seg, &base.q, out, nullptr, nullptr, 0, nullptr);
+  }
+  if (lane_cols.empty()) return execute_impl(seg, &base.q, out, nullptr, nullptr, 0, nullptr);
+
+  // Base lane: COUNT(*) and the aggregations of columns without nulls, over the filter itself.  It also yields numDocsScanned; the
+  // metadata-only plan is off because the reference does not take it when any aggregated column has nulls (AggregationPlanNode.java:99-100).
+  std::vector<int> base_pos;
+  for (int a = 0; a < na; ++a) if (!rw.has_nulls(q->aggregations[a].column)) { base.aggs.push_back(q->aggregations[a]); base_pos.push_back(a); }
+  const bool synthetic_count = base.aggs.empty();
+  if (synthetic_count) base.aggs.push_back(pg_aggregation{PG_AGG_COUNT, -1});
+  base.q.aggregations = base.aggs.data(); base.q.num_aggregations = (int32_t)base.aggs.size();
+  pg_result part;
+  memset(&part, 0, sizeof(part));
+  st = execute_impl(seg, &base.q, &part, nullptr, nullptr, 0, nullptr, false);
+  if (st != PG_OK) { pg_result_free(&part); return st; }
+  memset(out, 0, sizeof(*out));
+  out->num_aggregations = na;
+  out->aggregations = (pg_agg_value*)calloc((size_t)std::max(na, 1), sizeof(pg_agg_value));
+  out->stats = part.stats;
+  out->device_ms = part.device_ms; out->dominant_kernel_ms = part.dominant_kernel_ms; out->dominant_kernel = part.dominant_kernel;
+  if (!synthetic_count) for (size_t i = 0; i < base_pos.size(); ++i) out->aggregations[base_pos[i]] = part.aggregations[i];
+  pg_result_free(&part);
+  // numEntriesScannedPostFilter = numDocsScanned * projected columns of the WHOLE query (AggregationOperator.java:88-93)
+  std::vector<int> projected;
+  for (int a = 0; a < na; ++a) {
+    const pg_aggregation& ag = q->aggregations[a];
+    const bool reads = ag.function != PG_AGG_COUNT || rw.has_nulls(ag.column);   // COUNT(col) keeps its input expression under null handling
+    if (reads && ag.column >= 0 && std::find(projected.begin(), projected.end(), ag.column) == projected.end()) projected.push_back(ag.column);
+  }
+  out->stats.num_entries_scanned_post_filter = out->stats.num_docs_scanned * (int64_t)projected.size();
+
+  for (int c : lane_cols) {
+    FlatQuery lane;
+    std::vector<FilterExpr> both;
+    if (has_filter) both.push_back(filter_trues);
+    both.push_back(NullRewriter::null_leaf(c, true));
+    lane.emit(NullRewriter::combine(PG_FILTER_AND, std::move(both)));
+    lane.finish(*q);
+    std::vector<int> pos;
+    for (int a = 0; a < na; ++a) if (q->aggregations[a].column == c) { lane.aggs.push_back(q->aggregations[a]); pos.push_back(a); }
+    lane.q.aggregations = lane.aggs.data(); lane.q.num_aggregations = (int32_t)lane.aggs.size();
+    memset(&part, 0, sizeof(part));
+    st = execute_impl(seg, &lane.q, &part, nullptr, nullptr, 0, nullptr, false);
+    if (st != PG_OK) { pg_result_free(&part); return st; }
+    for (size_t i = 0; i < pos.size(); ++i) out->aggregations[pos[i]] = part.aggregations[i];
+    out->device_ms += part.device_ms;
+    if (part.dominant_kernel_ms > out->dominant_kernel_ms) { out->dominant_kernel_ms = part.dominant_kernel_ms; out->dominant_kernel = part.dominant_kernel; }
+    pg_result_free(&part);
+  }
+  return PG_OK;
+}
+
 pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_result) {
   if (!out_result) return fail(PG_ERR_INVALID_ARGUMENT, "null result");
-  pg_status st = execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr);
+  pg_status st = (query && (query->flags & PG_QUERY_NULL_HANDLING)) ? execute_null_handling(segment, query, out_result, nullptr, 0, nullptr)
+                                                                  : execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr);
   if (st != PG_OK) pg_result_free(out_result);
   return st;
 }
 
 pg_status pg_filter_bitmap(pg_segment* segment, const pg_query* query, uint64_t* out_words, int64_t num_words, int64_t* out_cardinality) {
   if (!out_words) return fail(PG_ERR_INVALID_ARGUMENT, "null bitmap buffer");
+  if (query && (query->flags & PG_QUERY_NULL_HANDLING)) return execute_null_handling(segment, query, nullptr, out_words, num_words, out_cardinality);
   return execute_impl(segment, query, nullptr, nullptr, out_words, num_words, out_cardinality);
 }
 

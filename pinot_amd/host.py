@@ -33,6 +33,8 @@ def _lib():
     lib.ph_segment_add_numeric_column.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64]
     lib.ph_segment_add_string_column.restype = C.c_int32
     lib.ph_segment_add_string_column.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, vp, C.c_uint64, C.c_char_p, vp, C.c_uint64]
+    lib.ph_segment_set_null_vector.restype = C.c_int32
+    lib.ph_segment_set_null_vector.argtypes = [vp, C.c_char_p, vp, C.c_uint64]
     lib.ph_segment_load.restype = C.c_int32
     lib.ph_segment_load.argtypes = [vp, C.c_int32]
     lib.ph_segment_destroy.argtypes = [vp]
@@ -78,6 +80,14 @@ def init_plan_maker(device=0, time_kernels=True):
         raise HostError(st, (lib.ph_last_error() or b"").decode())
 
 
+def _attach_null_vectors(lib, handle, columns):
+    for c in columns:
+        if getattr(c, "null_vector", None) is not None:
+            st = lib.ph_segment_set_null_vector(handle, c.name.encode(), c.null_vector.ctypes.data, c.null_vector.nbytes)
+            if st != 0:
+                raise HostError(st, lib.ph_last_error().decode())
+
+
 class HostSegment:
     """ImmutableSegment of the C++ host mirror built from a `SegmentData` (buffers stay owned by the SegmentData)."""
 
@@ -101,6 +111,7 @@ class HostSegment:
                                                        c.dictionary.nbytes if has_dict else 0, inv_ptr, inv_size)
             if st != 0:
                 raise HostError(st, (lib.ph_last_error() or b"").decode())
+        _attach_null_vectors(lib, self.handle, segment_data.columns)
         st = lib.ph_segment_load(self.handle, device)
         if st != 0:
             raise HostError(st, (lib.ph_last_error() or b"").decode())

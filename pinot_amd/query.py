@@ -50,6 +50,11 @@ class Pred:
         return Pred(_abi.PG_PRED_RAW_RANGE, column, lo, hi, exclusive=exclusive)
 
     @staticmethod
+    def is_null(column, exclusive=False):
+        """column IS NULL (exclusive=True: IS NOT NULL): BitmapBasedFilterOperator over the column's null value vector."""
+        return Pred(_abi.PG_PRED_IS_NULL, column, 0, 0, exclusive=exclusive)
+
+    @staticmethod
     def doc_range(first_doc, last_doc, exclusive=False):
         """first_doc <= docId <= last_doc: what SortedIndexBasedFilterOperator derives from a sorted column's [start, end] pairs."""
         return Pred(_abi.PG_PRED_DOC_RANGE, 0, first_doc, last_doc, exclusive=exclusive)
@@ -93,8 +98,10 @@ COUNT, SUM, MIN, MAX, AVG = _abi.PG_AGG_COUNT, _abi.PG_AGG_SUM, _abi.PG_AGG_MIN,
 
 
 class QuerySpec:
-    def __init__(self, aggregations, filter=None, group_by=()):
-        """aggregations: list of (function, column_index) with column_index -1 for COUNT(*)."""
+    def __init__(self, aggregations, filter=None, group_by=(), null_handling=False):
+        """aggregations: list of (function, column_index) with column_index -1 for COUNT(*).
+        null_handling: the query option enableNullHandling=true (PG_QUERY_NULL_HANDLING)."""
+        self.null_handling = bool(null_handling)
         self.aggregations = [(int(f), int(c)) for f, c in aggregations]
         self.filter = filter
         self.group_by = [int(c) for c in group_by]
@@ -143,7 +150,7 @@ class QuerySpec:
         q.num_group_by = len(self.group_by)
         q.group_by_columns = self._groups
         q.num_groups_limit = 0
-        q.flags = 0
+        q.flags = _abi.PG_QUERY_NULL_HANDLING if self.null_handling else _abi.PG_QUERY_DEFAULT
         self.c = q
 
 

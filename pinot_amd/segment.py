@@ -76,6 +76,19 @@ def stored_type_of(dtype):
     raise TypeError("no Pinot stored type for %s" % dtype)
 
 
+def roaring_serialize(doc_ids, num_docs):
+    """One RoaringBitmap of ascending docIds in the portable serialization, cut out of a two-posting bitmap inverted index
+    (BitmapInvertedIndexWriter layout: (C + 1) big-endian offsets, then the bitmaps) that the host writer builds."""
+    lib = load_host_library()
+    flags = np.zeros(int(num_docs), dtype=np.int32)
+    flags[np.asarray(doc_ids, dtype=np.int64)] = 1
+    size = int(lib.ph_inverted_build(_i32p(flags), int(num_docs), 2, 1, None))
+    inv = np.zeros(size, dtype=np.uint8)
+    lib.ph_inverted_build(_i32p(flags), int(num_docs), 2, 1, _u8p(inv))
+    offsets = np.frombuffer(inv[:12].tobytes(), dtype=">i4").astype(np.int64)
+    return np.ascontiguousarray(inv[offsets[1]:offsets[2]])
+
+
 class Column:
     """One single-value numeric column: forward index (+ dictionary, + optional inverted index) as raw bytes."""
 
@@ -90,6 +103,15 @@ class Column:
         self.dictionary = dictionary    # np.uint8 big-endian int32s
         self.inverted = inverted        # np.uint8 or None
         self.dict_values = dict_values  # np.int32 sorted values (host convenience, not handed to the engine)
+        self.null_vector = None         # np.uint8: the <column>.bitmap.nullvalue file (one serialized RoaringBitmap) or None
+
+    def with_nulls(self, null_mask):
+        """Attach a null value vector (NullValueVectorCreator: a RoaringBitmap of the null docIds; no file when there are none).
+        The caller has already stored the default null value at those docs, like the segment creator does."""
+        null_mask = np.ascontiguousarray(null_mask, dtype=bool)
+        if null_mask.any():
+            self.null_vector = roaring_serialize(np.flatnonzero(null_mask).astype(np.int32), len(null_mask))
+        return self
 
     @staticmethod
     def dict_encoded(name, values, with_inverted=False, run_optimize=True):
@@ -215,6 +237,9 @@ class SegmentData:
             if c.inverted is not None:
                 d.inv_data = c.inverted.ctypes.data
                 d.inv_size = c.inverted.nbytes
+            if c.null_vector is not None:
+                d.null_data = c.null_vector.ctypes.data
+                d.null_size = c.null_vector.nbytes
         self.desc = _abi.pg_segment_desc()
         self.desc.name = self._name_b
         self.desc.crc = 0

@@ -60,6 +60,8 @@ def write_v1(tmp_path, name, num_docs, columns, sorted_fwd=None):
                 c.inverted.tofile(os.path.join(d, c.name + ".bitmap.inv"))
         else:
             c.fwd.tofile(os.path.join(d, c.name + ".sv.raw.fwd"))
+        if c.null_vector is not None:       # NullValueVectorCreator.seal: <column>.bitmap.nullvalue, only when some doc is null
+            c.null_vector.tofile(os.path.join(d, c.name + ".bitmap.nullvalue"))
     with open(os.path.join(d, "metadata.properties"), "w") as f:
         f.write(metadata_text(name, num_docs, columns, sorted_fwd.keys()))
     return d
@@ -83,6 +85,8 @@ def write_v3(tmp_path, name, num_docs, columns):
         add(c.name, "forward_index", c.fwd.tobytes())
         if c.inverted is not None:
             add(c.name, "inverted_index", c.inverted.tobytes())
+        if c.null_vector is not None:
+            add(c.name, "nullvalue_vector", c.null_vector.tobytes())
     with open(os.path.join(d, "columns.psf"), "wb") as f:
         f.write(bytes(psf))
     with open(os.path.join(d, "index_map"), "w") as f:

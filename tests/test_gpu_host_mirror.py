@@ -68,6 +68,34 @@ def test_inter_segment_results_through_combine(golden_segments):
     assert combined["groups"][0]["final"][1] == float(d["column1"][m].max())
 
 
+def test_filtered_aggregations_run_as_swim_lanes(golden_segments):
+    """FILTER (WHERE ...) aggregations (FilteredAggregationOperator.java:68-110; the reference's FilteredAggregationsTest compares a
+    filtered-aggregation query with the equivalent separately filtered queries -- so does this)."""
+    _, segs = golden_segments
+    main = " WHERE column3 BETWEEN 20000000 AND 1000000000"
+    f1 = "column1 > 100000000 AND column11 NOT IN ('t', 'P')"
+    f2 = "column6 < 500000000 OR column5 = 'gFuH'"
+    for where in ("", main):
+        sql = (f"SELECT SUM(column1) FILTER (WHERE {f1}), COUNT(*), MAX(column3) FILTER (WHERE {f2}), "
+               f"AVG(column7) FILTER (WHERE {f1}), MIN(column6) FROM testTable{where}")
+        got = host.execute_sql(segs[:1], sql)["segments"][0]
+        glue = " AND " if where else " WHERE "
+        lane0 = host.execute_sql(segs[:1], "SELECT COUNT(*), MIN(column6) FROM testTable" + where)["segments"][0]
+        lane1 = host.execute_sql(segs[:1], f"SELECT SUM(column1), AVG(column7) FROM testTable{where}{glue}({f1})")["segments"][0]
+        lane2 = host.execute_sql(segs[:1], f"SELECT MAX(column3) FROM testTable{where}{glue}({f2})")["segments"][0]
+        assert got["intermediate"] == [lane1["intermediate"][0], lane0["intermediate"][0], lane2["intermediate"][0],
+                                       lane1["intermediate"][1], lane0["intermediate"][1]]
+        for k in ("numDocsScanned", "numEntriesScannedInFilter", "numEntriesScannedPostFilter"):
+            assert got["stats"][k] == lane0["stats"][k] + lane1["stats"][k] + lane2["stats"][k], k
+        assert got["stats"]["numTotalDocs"] == 30000
+        # and through the combine over 4 copies of the segment
+        combined = host.execute_sql(segs, sql, max_execution_threads=4)["combined"]
+        assert combined["final"][1] == 4.0 * lane0["intermediate"][0] and combined["final"][0] == 4.0 * lane1["intermediate"][0]
+    with pytest.raises(host.HostError) as e:
+        host.execute_sql(segs[:1], f"SELECT SUM(column1) FILTER (WHERE {f1}) FROM testTable GROUP BY column9")
+    assert e.value.status == 2
+
+
 def test_plan_time_rejection_and_errors(golden_segments):
     _, segs = golden_segments
     for sql, status in (("SELECT column1 FROM testTable", 2),

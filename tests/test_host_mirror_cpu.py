@@ -12,7 +12,16 @@ def test_parse_sql_shapes():
                  "groupBy": [], "hasFilter": False}
     q = host.parse_sql("select sum(a) as s from t where a > 1 and (b in (1, 2, -3) or not c between 5 and 9) and d <> 'x''y' group by k1, k2")
     assert q["groupBy"] == ["k1", "k2"] and q["hasFilter"]
-    for bad, status in (("SELECT a FROM t", 2), ("SELECT SUM(a + 1) FROM t", 2), ("SELECT SUM(*) FROM t", 1), ("SELECT SUM(a) FROM", 1),
+    q = host.parse_sql("SELECT SUM(a) FILTER (WHERE b > 3 AND c = 'x'), COUNT(*) FILTER(WHERE b > 3 AND c = 'x'), MAX(a) FROM t WHERE d < 5")
+    assert len(q["aggregations"]) == 3 and q["aggregations"][2] == "max(a)" and q["hasFilter"]
+    assert q["aggregations"][0].startswith("sum(a) FILTER(WHERE AND(") and q["aggregations"][1].startswith("count(*) FILTER(WHERE AND(")
+    assert q["aggregations"][0].split("FILTER")[1] == q["aggregations"][1].split("FILTER")[1]       # same clause -> same swim lane
+    q = host.parse_sql("SET enableNullHandling = true; SELECT COUNT(a), SUM(a) FROM t WHERE a IS NOT NULL AND (b IS NULL OR NOT c > 3)")
+    assert q["nullHandling"] is True and q["hasFilter"] and q["aggregations"] == ["count(a)", "sum(a)"]
+    assert "nullHandling" not in host.parse_sql("SET enableNullHandling = false; SELECT COUNT(*) FROM t")
+    with pytest.raises(host.HostError):
+        host.parse_sql("SELECT COUNT(*) FROM t WHERE a IS 3")
+    for bad, status in (("SELECT a FROM t", 2), ("SET useStarTree = true; SELECT COUNT(*) FROM t", 2), ("SELECT SUM(a) FILTER (b > 3) FROM t", 1), ("SELECT SUM(a) FILTER (WHERE b > 3 FROM t", 1), ("SELECT SUM(a + 1) FROM t", 2), ("SELECT SUM(*) FROM t", 1), ("SELECT SUM(a) FROM", 1),
                         ("SELECT SUM(a) FROM t ORDER BY a", 2), ("SELECT SUM(a) FROM t WHERE a >", 1)):
         with pytest.raises(host.HostError) as e:
             host.parse_sql(bad)
