@@ -189,7 +189,12 @@ typedef struct pg_query {
   const pg_aggregation* aggregations;
   int32_t num_aggregations;
   int32_t num_group_by;              /* 0 = aggregation only */
-  const int32_t* group_by_columns;   /* dictionary-encoded columns; group id = sum dictId_j * prod_{k<j} card_k */
+  const int32_t* group_by_columns;   /* dictionary-encoded columns; group id = raw key = sum dictId_j * prod_{k<j} card_k
+                                      * (DictionaryBasedGroupKeyGenerator.java:298-338,437-445).  Product of cardinalities <= 10 000: the
+                                      * reference's ArrayBasedHolder.  Up to 2^24: its IntMapBasedHolder range -- the same raw keys come back
+                                      * (the reference's insertion-order group ids are internal to its hash map), at most num_groups_limit of
+                                      * them: the groups whose first doc comes earliest, exactly those IntGroupIdMap.getGroupId :1022-1047
+                                      * would have admitted.  Beyond 2^24 (Long / ArrayMap holders): PG_ERR_UNSUPPORTED at plan time. */
   int32_t num_groups_limit;          /* InstancePlanMakerImplV2 numGroupsLimit (default 100000); 0 = default */
   int32_t flags;                     /* PG_QUERY_* */
 } pg_query;
@@ -244,7 +249,7 @@ typedef struct pg_result {
   int32_t* group_ids;              /* [num_groups] ascending raw group ids (DictionaryBasedGroupKeyGenerator.java:306-324) */
   pg_agg_value* group_aggregations;/* [num_groups * num_aggregations], row-major by group */
   int32_t group_id_upper_bound;    /* product of group-by cardinalities */
-  int32_t reserved;
+  int32_t num_groups_limit_reached;/* GroupByOperator.java:114-115: the query created >= numGroupsLimit groups (later keys were dropped) */
   double device_ms;                /* HIP-event time of this query's kernels (PG_CFG_TIME_KERNELS), else 0 */
   double dominant_kernel_ms;       /* HIP-event time of the scan kernel alone */
   uint64_t profile_cycles[4];      /* PG_CFG_PROFILE_WAVES: shader cycles summed over wavefronts: memory wait, filter, aggregate, total */

@@ -958,6 +958,12 @@ static void holder_init(po_holder* h, int func) {
 
 /* One aggregate() call of a function over values[from, to) of a block (the reducer body that foldNotNull applies to each non-null range,
  * NullableSingleInputAggregationFunction.java:118-160; the whole block [0, length) when there are no nulls). */
+static __thread const int32_t* po_sort_keys;
+static int po_cmp_by_key(const void* a, const void* b) {
+  const int32_t ka = po_sort_keys[*(const int32_t*)a], kb = po_sort_keys[*(const int32_t*)b];
+  return ka < kb ? -1 : (ka > kb ? 1 : 0);
+}
+
 static int agg_range(po_holder* h, int func, int st, const po_values* vals, int32_t from, int32_t to, double* dbl_values) {
   if (to <= from) return 0;
   switch (func) {
@@ -1115,14 +1121,31 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
     if (d->fwd_encoding != PG_FWD_FIXED_BIT_DICT) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by on raw column"); goto done; }
     cards[g] = d->cardinality;
     group_upper *= d->cardinality;
-    /* DictionaryBasedGroupKeyGenerator.java:175-183: array-based holder only when the product fits */
-    if (group_upper > 10000) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by cardinality product > arrayBasedThreshold"); goto done; }
+    /* DictionaryBasedGroupKeyGenerator.java:164-184: ArrayBasedHolder up to arrayBasedThreshold, IntMapBasedHolder while the product
+     * fits an int; the Long / ArrayMap holders beyond that are not restated */
+    if (group_upper > 2147483647ll) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by cardinality product > Integer.MAX_VALUE"); goto done; }
     if (null_handling) {
       /* DefaultGroupByExecutor.java:106-121 leaves the dictionary-based key generator when null handling is on; only the case where it
        * cannot matter (no nulls in the keys or the aggregated columns) is restated. */
       uint64_t* w = column_null_words(seg, q->group_by_columns[g]);
       if (w || has_null_values) { free(w); rc = 2; snprintf(po_error, sizeof(po_error), "group-by over nullable columns with null handling"); goto done; }
     }
+  }
+
+  /* IntMapBasedHolder (DictionaryBasedGroupKeyGenerator.java:415-490) + IntGroupIdMap.getGroupId (:1022-1047): raw key -> group id in
+   * order of first appearance; once _size == groupIdUpperBound = min(product, numGroupsLimit) (:176) new keys get INVALID_ID and the
+   * result holders ignore their docs. */
+  const int map_based = ng > 0 && group_upper > 10000;
+  const int64_t raw_key_upper = group_upper;
+  int32_t num_groups_limit = q->num_groups_limit > 0 ? q->num_groups_limit : 100000;
+  int64_t map_capacity = 0; int32_t* map_keys = NULL; int32_t* map_ids = NULL; int32_t* raw_of_gid = NULL; int32_t map_size = 0;
+  if (map_based) {
+    group_upper = group_upper < num_groups_limit ? group_upper : num_groups_limit;     /* _globalGroupIdUpperBound */
+    map_capacity = 16; while (map_capacity < 2 * group_upper + 2) map_capacity <<= 1;
+    map_keys = (int32_t*)malloc(sizeof(int32_t) * (size_t)map_capacity);
+    map_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)map_capacity);
+    raw_of_gid = (int32_t*)malloc(sizeof(int32_t) * (size_t)(group_upper > 0 ? group_upper : 1));
+    for (int64_t i = 0; i < map_capacity; i++) map_keys[i] = -1;
   }
 
   po_holder* holders = NULL;       /* aggregation only */
@@ -1176,6 +1199,30 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       for (int g = ng - 1; g >= 0; g--) {
         fetch_dict_ids(&cols[q->group_by_columns[g]], num_docs, doc_ids, pos, dict_scratch);
         for (int32_t i = 0; i < pos; i++) group_ids[i] = group_ids[i] * cards[g] + dict_scratch[i];
+      }
+      if (map_based) {
+        /* group ids in first-appearance order; docs of keys refused by the full map drop out of every aggregation (the holders
+         * ignore INVALID_ID) but still count as scanned */
+        int32_t kept = 0;
+        for (int32_t i = 0; i < pos; i++) {
+          const int32_t raw = group_ids[i];
+          uint64_t h = ((uint64_t)(uint32_t)raw * 0x9E3779B97F4A7C15ull) >> 20;
+          int64_t slot = (int64_t)(h & (uint64_t)(map_capacity - 1));
+          int32_t gid = -1;
+          for (;;) {
+            if (map_keys[slot] == raw) { gid = map_ids[slot]; break; }
+            if (map_keys[slot] == -1) {
+              if (map_size < group_upper) { map_keys[slot] = raw; map_ids[slot] = map_size; raw_of_gid[map_size] = raw; gid = map_size++; }
+              break;
+            }
+            slot = (slot + 1) & (map_capacity - 1);
+          }
+          if (gid < 0) continue;
+          doc_ids[kept] = doc_ids[i]; group_ids[kept] = gid; kept++;
+        }
+        /* (num_docs_scanned already holds the whole block: GroupByOperator.java:111) */
+        pos = kept;
+        if (pos == 0) continue;
       }
       for (int32_t i = 0; i < pos; i++) { flags[group_ids[i]] = 1; gcount[group_ids[i]]++; }
     }
@@ -1268,9 +1315,19 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
     res->group_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)(num_groups > 0 ? num_groups : 1));
     res->group_aggregations = (pg_agg_value*)calloc((size_t)(num_groups > 0 ? num_groups : 1) * (size_t)(na > 0 ? na : 1), sizeof(pg_agg_value));
     int32_t k = 0;
-    for (size_t g = 0; g < G; g++) {
+    /* result rows in ascending raw-key order (the ABI's order; the reference's own iteration order is the hash map's) */
+    int32_t* order = NULL;
+    if (map_based) {
+      order = (int32_t*)malloc(sizeof(int32_t) * (size_t)(map_size > 0 ? map_size : 1));
+      for (int32_t i = 0; i < map_size; i++) order[i] = i;
+      po_sort_keys = raw_of_gid;
+      qsort(order, (size_t)map_size, sizeof(int32_t), po_cmp_by_key);
+      res->num_groups_limit_reached = map_size >= num_groups_limit;      /* GroupByOperator.java:114-115 */
+    }
+    for (size_t idx = 0; idx < (map_based ? (size_t)map_size : G); idx++) {
+      const size_t g = map_based ? (size_t)order[idx] : idx;
       if (!flags[g]) continue;
-      res->group_ids[k] = (int32_t)g;
+      res->group_ids[k] = map_based ? raw_of_gid[g] : (int32_t)g;
       for (int a = 0; a < na; a++) {
         pg_agg_value* v = &res->group_aggregations[(size_t)k * (size_t)na + (size_t)a];
         int func = q->aggregations[a].function;
@@ -1284,6 +1341,8 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       }
       k++;
     }
+    free(order);
+    res->group_id_upper_bound = (int32_t)raw_key_upper;
   }
   /* ExecutionStatistics: AggregationOperator.java:88-93 (numDocsScanned, inFilter, numDocsScanned * numProjectedColumns, totalDocs) */
   {
@@ -1300,6 +1359,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
 cleanup:
   free(doc_ids); free(dict_scratch); free(vals.i); free(vals.l); free(vals.f); free(vals.d); free(dbl_values); free(group_ids);
   free(holders); free(gholders); free(gavg_sum); free(gavg_cnt); free(gexact); free(gover); free(gcount); free(flags);
+  free(map_keys); free(map_ids); free(raw_of_gid);
 done:
   if (agg_nulls) for (int a = 0; a < q->num_aggregations; a++) free(agg_nulls[a]);
   free(agg_nulls);

@@ -80,7 +80,7 @@ class pg_result(C.Structure):
     _fields_ = [("stats", pg_stats), ("num_aggregations", C.c_int32), ("num_groups", C.c_int32),
                 ("aggregations", C.POINTER(pg_agg_value)), ("group_ids", C.POINTER(C.c_int32)),
                 ("group_aggregations", C.POINTER(pg_agg_value)), ("group_id_upper_bound", C.c_int32),
-                ("reserved", C.c_int32), ("device_ms", C.c_double), ("dominant_kernel_ms", C.c_double),
+                ("num_groups_limit_reached", C.c_int32), ("device_ms", C.c_double), ("dominant_kernel_ms", C.c_double),
                 ("profile_cycles", C.c_uint64 * 4), ("profile_waves", C.c_int32), ("dominant_kernel", C.c_int32),
                 ("internal", C.c_void_p)]
 

@@ -78,6 +78,7 @@ std::string blockJson(const ResultsBlock& b) {
   }
   o << ", \"stats\": {\"numDocsScanned\": " << b.stats.numDocsScanned << ", \"numEntriesScannedInFilter\": " << b.stats.numEntriesScannedInFilter
     << ", \"numEntriesScannedPostFilter\": " << b.stats.numEntriesScannedPostFilter << ", \"numTotalDocs\": " << b.stats.numTotalDocs << "}";
+  if (b.isGroupBy) o << ", \"numGroupsLimitReached\": " << (b.numGroupsLimitReached ? "true" : "false");
   o << ", \"deviceMs\": " << num(b.deviceMs) << ", \"kernelMs\": " << num(b.kernelMs) << "}";
   return o.str();
 }

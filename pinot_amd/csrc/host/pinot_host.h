@@ -289,6 +289,7 @@ struct ResultsBlock {
   AggregationResultsBlock aggregation;
   GroupByResultsBlock groupBy;
   ExecutionStatistics stats;
+  bool numGroupsLimitReached = false;                 // GroupByResultsBlock.setNumGroupsLimitReached (GroupByOperator.java:114-146)
   double deviceMs = 0.0, kernelMs = 0.0;
 };
 

@@ -294,8 +294,9 @@ std::unique_ptr<LoweredQuery> lowerQuery(const ImmutableSegment& seg, const Quer
     const DataSource& ds = seg.getDataSource(g);
     if (!ds.hasDictionary) throw UnsupportedOperationException("group-by on a raw column uses the no-dictionary key generator (CPU plan)");
     product *= ds.cardinality;
-    // DictionaryBasedGroupKeyGenerator.java:164-184: above arrayBasedThreshold the map-based holders take over (CPU plan)
-    if (product > qc.maxInitialResultHolderCapacity) throw UnsupportedOperationException("group-by cardinality product exceeds the array-based threshold");
+    // DictionaryBasedGroupKeyGenerator.java:164-184: ArrayBasedHolder up to arrayBasedThreshold, IntMapBasedHolder above it -- both are
+    // one direct-indexed device table (at most 2^24 slots); the Long / ArrayMap holders beyond that keep the CPU plan
+    if (product > (1ll << 24)) throw UnsupportedOperationException("group-by cardinality product exceeds the device's direct-indexed table (2^24 raw keys)");
     lq->groupBy.push_back(seg.getColumnIndex(g));
   }
   pg_query& q = lq->query;
@@ -330,6 +331,7 @@ class GpuAggregationOperator : public Operator {
     block.stats.numEntriesScannedInFilter = res.stats.num_entries_scanned_in_filter;
     block.stats.numEntriesScannedPostFilter = res.stats.num_entries_scanned_post_filter;
     block.stats.numTotalDocs = res.stats.num_total_docs;
+    block.numGroupsLimitReached = res.num_groups_limit_reached != 0;
     block.deviceMs = res.device_ms;
     block.kernelMs = res.dominant_kernel_ms;
     const int na = (int)functions.size();
@@ -508,6 +510,7 @@ std::unique_ptr<PlanNode> GpuPlanMaker::makeSegmentPlanNode(const SegmentContext
 // AggregationResultsBlockMerger.mergeResultsBlocks (:34-44) and GroupByCombineOperator (:132-147, keyed by VALUES).
 void mergeResultsBlocks(ResultsBlock* merged, const ResultsBlock& other) {
   merged->stats.merge(other.stats);
+  merged->numGroupsLimitReached = merged->numGroupsLimitReached || other.numGroupsLimitReached;   // GroupByCombineOperator: any segment
   merged->deviceMs = std::max(merged->deviceMs, other.deviceMs);
   merged->kernelMs = std::max(merged->kernelMs, other.kernelMs);
   if (!merged->isGroupBy) {

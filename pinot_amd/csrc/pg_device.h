@@ -225,7 +225,7 @@ struct GroupParams {
   ScanParams scan;
   int32_t num_group_cols;
   int32_t num_group_aggs;
-  int32_t num_groups;              // product of cardinalities (<= arrayBasedThreshold)
+  int32_t num_groups;              // product of cardinalities = slots of the direct-indexed table (<= 2^24)
   int32_t use_lds_table;
   int32_t packed_agg;              // >= 0: that SUM slot of the LDS table also carries the group's doc count in its high bits
   int32_t packed_shift;            //       (count << packed_shift) | sum ; no separate count atomic

@@ -227,18 +227,32 @@ pg_status ensure_set(ExecCtx* c, size_t index, size_t bytes) {
   return PG_OK;
 }
 
-pg_status ensure_table(ExecCtx* c, size_t words) {
+constexpr int kMaxGroupSlots = 1 << 24;
+
+// hipMalloc'ed scratch of one query, released when it goes out of scope (rare paths only: the hot paths reuse ExecCtx buffers)
+struct DeviceScratch {
+  std::vector<void*> blocks;
+  void* alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr;
+    blocks.push_back(p);
+    return p;
+  }
+  ~DeviceScratch() { for (void* p : blocks) (void)hipFree(p); }
+};
+
+pg_status ensure_table(ExecCtx* c, size_t words, size_t host_words) {
   if (c->table_capacity < words) {
     if (c->d_table) (void)hipFree(c->d_table);
     c->d_table = nullptr;
     HIP_TRY(hipMalloc((void**)&c->d_table, words * 8));
     c->table_capacity = words;
   }
-  if (c->h_table_capacity < words) {
+  if (c->h_table_capacity < host_words) {
     if (c->h_table) (void)hipHostFree(c->h_table);
     c->h_table = nullptr;
-    HIP_TRY(hipHostMalloc((void**)&c->h_table, words * 8, hipHostMallocDefault));
-    c->h_table_capacity = words;
+    HIP_TRY(hipHostMalloc((void**)&c->h_table, host_words * 8, hipHostMallocDefault));
+    c->h_table_capacity = host_words;
   }
   return PG_OK;
 }
@@ -1344,9 +1358,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       group_mult[g] = (int32_t)product;
       product *= col.cardinality;
       cards.push_back(col.cardinality);
-      // DictionaryBasedGroupKeyGenerator.java:175-183: array-based holder only up to arrayBasedThreshold (10 000)
-      if (product > 10000) return fail(PG_ERR_UNSUPPORTED, "group-by cardinality product exceeds the array-based threshold (10000)");
+      // DictionaryBasedGroupKeyGenerator.java:164-184: up to arrayBasedThreshold (10 000) the raw key IS the group id (ArrayBasedHolder);
+      // above it the reference hashes raw keys (IntMapBasedHolder) -- here the table stays direct-indexed, in HBM, one slot per raw
+      // key, and only the groups that exist come back.  2^24 slots keep the 24-bit key multiplies exact and the table <= 1.2 GB.
+      if (product > kMaxGroupSlots) return fail(PG_ERR_UNSUPPORTED, "group-by cardinality product exceeds %d direct-indexed slots (Long / ArrayMap holders keep the CPU plan)", kMaxGroupSlots);
     }
+    const bool map_based = product > 10000;
     gp.num_group_cols = ng;
     gp.num_groups = (int32_t)product;
     gp.dense_ok = 1;
@@ -1371,7 +1388,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       dev_agg_of[(size_t)a] = da;
     }
     const size_t table_words = (size_t)gp.num_groups * (size_t)(1 + gp.num_group_aggs);
-    st = ensure_table(ctx, table_words);
+    st = ensure_table(ctx, table_words, map_based ? 0 : table_words);
     if (st != PG_OK) return st;
     gp.table_count = ctx->d_table;
     gp.table_acc = reinterpret_cast<long long*>(ctx->d_table + gp.num_groups);
@@ -1454,32 +1471,126 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     else launch_scan_group(g_engine.use_dma, gp.use_lds_table != 0, blocks, geo.threads, lds, ctx->stream, gp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->h_table, ctx->d_table, table_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (timed) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    const unsigned long long* hc = ctx->h_table;
-    const long long* ha = reinterpret_cast<const long long*>(ctx->h_table + gp.num_groups);
+    // The groups that exist, in ascending raw-key order: (raw key, doc count, accumulators[a * num_present + k]).
+    std::vector<int32_t> present_ids;
+    std::vector<unsigned long long> present_counts;
+    std::vector<long long> present_acc;
     int num_present = 0;
     long long docs = 0;
-    for (int g = 0; g < gp.num_groups; ++g) if (hc[g]) { num_present++; docs += (long long)hc[g]; }
+    if (!map_based) {
+      HIP_TRY(hipMemcpyAsync(ctx->h_table, ctx->d_table, table_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      if (timed) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      const unsigned long long* hc = ctx->h_table;
+      const long long* ha = reinterpret_cast<const long long*>(ctx->h_table + gp.num_groups);
+      for (int g = 0; g < gp.num_groups; ++g) if (hc[g]) { num_present++; docs += (long long)hc[g]; }
+      present_ids.reserve((size_t)num_present); present_counts.reserve((size_t)num_present);
+      present_acc.resize((size_t)num_present * (size_t)gp.num_group_aggs);
+      int k = 0;
+      for (int g = 0; g < gp.num_groups; ++g) {
+        if (!hc[g]) continue;
+        present_ids.push_back(g); present_counts.push_back(hc[g]);
+        for (int a = 0; a < gp.num_group_aggs; ++a) present_acc[(size_t)a * (size_t)num_present + (size_t)k] = ha[(size_t)a * (size_t)gp.num_groups + (size_t)g];
+        k++;
+      }
+    } else {
+      // IntMapBasedHolder range: compact the HBM table on the device; honour numGroupsLimit the way the reference does
+      // (_globalGroupIdUpperBound = min(product, numGroupsLimit), DictionaryBasedGroupKeyGenerator.java:176).
+      const int limit = q->num_groups_limit > 0 ? q->num_groups_limit : 100000;
+      const long long bound = std::min<long long>(product, limit);
+      const int num_chunks = (gp.num_groups + kGroupChunk - 1) / kGroupChunk;
+      DeviceScratch scratch;
+      uint32_t* d_chunk_counts = (uint32_t*)scratch.alloc((size_t)num_chunks * 4);
+      uint32_t* d_chunk_offsets = (uint32_t*)scratch.alloc((size_t)(num_chunks + 1) * 4);
+      unsigned long long* d_total_docs = (unsigned long long*)scratch.alloc(8);
+      if (!d_chunk_counts || !d_chunk_offsets || !d_total_docs) return fail(PG_ERR_OUT_OF_MEMORY, "group-by compaction scratch");
+      uint32_t* d_first_doc = nullptr;
+      uint32_t max_first_doc = 0xFFFFFFFFu;
+      auto count_groups = [&](bool with_docs, uint32_t* total) -> pg_status {
+        if (with_docs) HIP_TRY(hipMemsetAsync(d_total_docs, 0, 8, ctx->stream));
+        group_chunk_count_kernel<<<dim3((unsigned)num_chunks), dim3(256), 0, ctx->stream>>>(gp.table_count, d_first_doc, max_first_doc, gp.num_groups, d_chunk_counts,
+                                                                                             with_docs ? d_total_docs : nullptr);
+        group_chunk_scan_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(d_chunk_counts, num_chunks, d_chunk_offsets);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(total, d_chunk_offsets + num_chunks, 4, hipMemcpyDeviceToHost, ctx->stream));
+        return PG_OK;
+      };
+      uint32_t total = 0;
+      unsigned long long total_docs = 0;
+      st = count_groups(true, &total);
+      if (st != PG_OK) return st;
+      HIP_TRY(hipMemcpyAsync(&total_docs, d_total_docs, 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (timed) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      docs = (long long)total_docs;
+      out->num_groups_limit_reached = (long long)total >= (long long)limit ? 1 : 0;      // GroupByOperator.java:114-115
+      if ((long long)total > bound) {
+        // More groups than the reference would have created: it hands out group ids in order of first appearance (docId order)
+        // and drops the docs of later keys, so the survivors are the `bound` groups whose first doc comes earliest.
+        std::vector<uint64_t> filter_words;
+        unsigned long long* d_filter = nullptr;
+        if (q->num_filter_nodes > 0) {
+          filter_words.assign(((size_t)seg->num_docs + 63) / 64 + 1, 0ull);
+          int64_t card = 0;
+          pg_query fq = *q;
+          fq.num_aggregations = 0; fq.num_group_by = 0;
+          st = execute_impl(seg, &fq, nullptr, nullptr, filter_words.data(), (int64_t)filter_words.size(), &card);
+          if (st != PG_OK) return st;
+          d_filter = (unsigned long long*)scratch.alloc(filter_words.size() * 8);
+          if (!d_filter) return fail(PG_ERR_OUT_OF_MEMORY, "group-by first-doc pass: filter bitmap");
+          HIP_TRY(hipMemcpyAsync(d_filter, filter_words.data(), filter_words.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
+        d_first_doc = (uint32_t*)scratch.alloc((size_t)gp.num_groups * 4);
+        uint32_t* d_present_first = (uint32_t*)scratch.alloc((size_t)total * 4);
+        if (!d_first_doc || !d_present_first) return fail(PG_ERR_OUT_OF_MEMORY, "group-by first-doc pass: %d slots", gp.num_groups);
+        HIP_TRY(hipMemsetAsync(d_first_doc, 0xFF, (size_t)gp.num_groups * 4, ctx->stream));
+        group_first_doc_kernel<<<dim3((unsigned)std::min<long long>(((long long)seg->num_docs + 255) / 256, (long long)seg->num_cus * 16)), dim3(256), 0, ctx->stream>>>(gp, d_filter, d_first_doc);
+        group_compact_kernel<<<dim3((unsigned)num_chunks), dim3(256), 0, ctx->stream>>>(gp.table_count, gp.table_acc, 0, gp.num_groups, d_first_doc, 0xFFFFFFFFu, d_chunk_offsets, total,
+                                                                                         nullptr, nullptr, nullptr, d_present_first);
+        HIP_TRY(hipGetLastError());
+        std::vector<uint32_t> firsts((size_t)total);
+        HIP_TRY(hipMemcpyAsync(firsts.data(), d_present_first, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        std::nth_element(firsts.begin(), firsts.begin() + (bound - 1), firsts.end());
+        max_first_doc = firsts[(size_t)bound - 1];      // first docs are distinct (a doc has one key): exactly `bound` groups pass
+        st = count_groups(false, &total);
+        if (st != PG_OK) return st;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+      }
+      num_present = (int)total;
+      present_ids.resize((size_t)num_present); present_counts.resize((size_t)num_present);
+      present_acc.resize((size_t)num_present * (size_t)gp.num_group_aggs);
+      if (num_present > 0) {
+        int32_t* d_ids = (int32_t*)scratch.alloc((size_t)num_present * 4);
+        unsigned long long* d_counts = (unsigned long long*)scratch.alloc((size_t)num_present * 8);
+        long long* d_acc = (long long*)scratch.alloc(std::max<size_t>((size_t)num_present * (size_t)gp.num_group_aggs * 8, 8));
+        if (!d_ids || !d_counts || !d_acc) return fail(PG_ERR_OUT_OF_MEMORY, "group-by result of %d groups", num_present);
+        group_compact_kernel<<<dim3((unsigned)num_chunks), dim3(256), 0, ctx->stream>>>(gp.table_count, gp.table_acc, gp.num_group_aggs, gp.num_groups, d_first_doc, max_first_doc,
+                                                                                         d_chunk_offsets, total, d_ids, d_counts, d_acc, nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(present_ids.data(), d_ids, (size_t)num_present * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(present_counts.data(), d_counts, (size_t)num_present * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (gp.num_group_aggs > 0) HIP_TRY(hipMemcpyAsync(present_acc.data(), d_acc, present_acc.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+      }
+    }
     out->num_aggregations = na;
     out->dominant_kernel = use_private ? PG_KERNEL_GROUP_PRIVATE : PG_KERNEL_SCAN_GROUP;
     out->num_groups = num_present;
     out->group_id_upper_bound = gp.num_groups;
     out->group_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)std::max(num_present, 1));
     out->group_aggregations = (pg_agg_value*)calloc((size_t)std::max(num_present, 1) * (size_t)std::max(na, 1), sizeof(pg_agg_value));
-    int k = 0;
-    for (int g = 0; g < gp.num_groups; ++g) {
-      if (!hc[g]) continue;
-      out->group_ids[k] = g;
+    for (int k = 0; k < num_present; ++k) {
+      const unsigned long long group_docs = present_counts[(size_t)k];
+      out->group_ids[k] = present_ids[(size_t)k];
       for (int a = 0; a < na; ++a) {
         const pg_aggregation& ag = q->aggregations[a];
         pg_agg_value& v = out->group_aggregations[(size_t)k * (size_t)na + (size_t)a];
-        v.count = (int64_t)hc[g];
+        v.count = (int64_t)group_docs;
         v.min = std::numeric_limits<double>::infinity();
         v.max = -std::numeric_limits<double>::infinity();
         if (ag.function == PG_AGG_COUNT) continue;
-        const long long acc = ha[(size_t)dev_agg_of[(size_t)a] * (size_t)gp.num_groups + (size_t)g];
+        const long long acc = present_acc[(size_t)dev_agg_of[(size_t)a] * (size_t)num_present + (size_t)k];
         const ColumnDev& col = seg->cols[(size_t)ag.column];
         const bool plane = lw.plane_cols[(size_t)ag.column] != 0;
         if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) {
@@ -1488,13 +1599,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
             v.sum_i64 = 0;
             v.sum_exact = 0;
           } else {
-            set_integer_sum(&v, (__int128)acc * (__int128)sum_scale(col, plane) + (__int128)hc[g] * (__int128)sum_base(col, plane));
+            set_integer_sum(&v, (__int128)acc * (__int128)sum_scale(col, plane) + (__int128)group_docs * (__int128)sum_base(col, plane));
           }
         }
         else if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, (int32_t)acc, plane);
         else v.max = agg_value_double(col, (int32_t)acc, plane);
       }
-      k++;
     }
     out->stats.num_docs_scanned = docs;
     out->stats.num_entries_scanned_in_filter = (int64_t)lw.num_scan_leaves * seg->num_docs;

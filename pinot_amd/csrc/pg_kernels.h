@@ -1798,6 +1798,117 @@ static __global__ void fill_words_kernel(unsigned long long* words, long long n,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Direct-indexed HBM group table -> dense result (group-by key spaces above the array-based threshold, the reference's
+// IntMapBasedHolder range: DictionaryBasedGroupKeyGenerator.java:164-184,415-490).  The table has one slot per raw key; the
+// result keeps only the groups that exist, in ascending raw-key order, so the host never copies or walks the whole table.
+//   group_chunk_count_kernel   per 2048-slot chunk: how many groups exist (and pass the first-doc cut), and the docs they hold
+//   group_chunk_scan_kernel    exclusive scan of the chunk counts (one workgroup)
+//   group_compact_kernel       order-preserving write of (raw key, count, accumulators[, first doc]) at chunk offset + rank
+//   group_first_doc_kernel     numGroupsLimit reached: first docId of every group, to keep the groups the reference would have
+//                              created first (IntGroupIdMap.getGroupId hands out ids in order of first appearance and refuses new
+//                              keys once _size == groupIdUpperBound, :1022-1047)
+// ------------------------------------------------------------------------------------------------
+constexpr int kGroupChunk = 2048;
+
+__device__ __forceinline__ bool group_kept(const unsigned long long* table_count, const uint32_t* first_doc, uint32_t max_first_doc, long long g, long long G) {
+  if (g >= G || table_count[g] == 0ull) return false;
+  return first_doc == nullptr || first_doc[g] <= max_first_doc;
+}
+
+static __global__ __launch_bounds__(256) void group_chunk_count_kernel(const unsigned long long* __restrict__ table_count, const uint32_t* __restrict__ first_doc,
+                                                                        uint32_t max_first_doc, int G, uint32_t* __restrict__ chunk_counts,
+                                                                        unsigned long long* __restrict__ total_docs) {
+  __shared__ uint32_t s_groups;
+  __shared__ unsigned long long s_docs;
+  if (threadIdx.x == 0) { s_groups = 0u; s_docs = 0ull; }
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * kGroupChunk;
+  uint32_t n = 0;
+  unsigned long long docs = 0;
+  for (int j = threadIdx.x; j < kGroupChunk; j += 256) {
+    const long long g = base + j;
+    if (g < G) docs += table_count[g];                      // numDocsScanned counts the docs of dropped groups too
+    n += group_kept(table_count, first_doc, max_first_doc, g, G) ? 1u : 0u;
+  }
+  atomicAdd(&s_groups, n);
+  atomicAdd(&s_docs, docs);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    chunk_counts[blockIdx.x] = s_groups;
+    if (total_docs && s_docs) atomicAdd(total_docs, s_docs);
+  }
+}
+
+// chunk_offsets[i] = sum of chunk_counts[0..i); chunk_offsets[num_chunks] = total.  One workgroup of 1024 threads.
+static __global__ __launch_bounds__(1024) void group_chunk_scan_kernel(const uint32_t* __restrict__ chunk_counts, int num_chunks, uint32_t* __restrict__ chunk_offsets) {
+  __shared__ uint32_t s[1024];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0u;
+  __syncthreads();
+  for (int base = 0; base < num_chunks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = i < num_chunks ? chunk_counts[i] : 0u;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                    // Hillis-Steele inclusive scan
+      const uint32_t add = threadIdx.x >= (unsigned)d ? s[threadIdx.x - d] : 0u;
+      __syncthreads();
+      s[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < num_chunks) chunk_offsets[i] = carry + s[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += s[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) chunk_offsets[num_chunks] = carry;
+}
+
+static __global__ __launch_bounds__(256) void group_compact_kernel(const unsigned long long* __restrict__ table_count, const long long* __restrict__ table_acc,
+                                                                    int num_aggs, int G, const uint32_t* __restrict__ first_doc, uint32_t max_first_doc,
+                                                                    const uint32_t* __restrict__ chunk_offsets, uint32_t total, int32_t* __restrict__ out_ids,
+                                                                    unsigned long long* __restrict__ out_counts, long long* __restrict__ out_acc,
+                                                                    uint32_t* __restrict__ out_first_doc) {
+  __shared__ uint32_t wave_base[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long base = (long long)blockIdx.x * kGroupChunk;
+  uint32_t running = chunk_offsets[blockIdx.x];
+  for (int round = 0; round < kGroupChunk / 256; ++round) {         // consecutive slots per round keep the output in raw-key order
+    const long long g = base + round * 256 + threadIdx.x;
+    const bool keep = group_kept(table_count, first_doc, max_first_doc, g, G);
+    const unsigned long long ballot = __builtin_amdgcn_ballot_w64(keep);
+    const uint32_t rank_in_wave = (uint32_t)__builtin_popcountll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_base[wave] = (uint32_t)__builtin_popcountll(ballot);
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (int w = 0; w < 4; ++w) { const uint32_t c = wave_base[w]; if (w < wave) before += c; all += c; }
+    if (keep) {
+      const uint32_t k = running + before + rank_in_wave;
+      if (out_ids) out_ids[k] = (int32_t)g;
+      if (out_counts) out_counts[k] = table_count[g];
+      if (out_acc) for (int a = 0; a < num_aggs; ++a) out_acc[(size_t)a * total + k] = table_acc[(long long)a * G + g];
+      if (out_first_doc) out_first_doc[k] = first_doc[g];
+    }
+    running += all;
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ uint32_t read_packed(const uint8_t* fwd, long long doc, int b);
+
+// One thread per doc: atomicMin of the docId into the slot of the doc's raw key.  `bitmap` is the filter result in doc order
+// (nullptr = every doc matches).  Only runs when a query created more groups than numGroupsLimit.
+static __global__ __launch_bounds__(256) void group_first_doc_kernel(const GroupParams gp, const unsigned long long* __restrict__ bitmap, uint32_t* __restrict__ first_doc) {
+  const long long n = gp.scan.num_docs;
+  for (long long doc = (long long)blockIdx.x * blockDim.x + threadIdx.x; doc < n; doc += (long long)gridDim.x * blockDim.x) {
+    if (bitmap && !((bitmap[doc >> 6] >> (doc & 63)) & 1ull)) continue;
+    uint32_t key = 0;
+    for (int c = 0; c < gp.num_group_cols; ++c) key += read_packed(gp.group_keys[c].fwd, doc, gp.group_keys[c].bits) * (uint32_t)gp.group_keys[c].mult;
+    atomicMin(&first_doc[key], (uint32_t)doc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // BlockValSet-level readers for arbitrary docIds (one thread per docId).
 // FixedBitIntReader.readUnchecked restated for a padded device buffer.
 // ------------------------------------------------------------------------------------------------

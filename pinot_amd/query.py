@@ -98,10 +98,11 @@ COUNT, SUM, MIN, MAX, AVG = _abi.PG_AGG_COUNT, _abi.PG_AGG_SUM, _abi.PG_AGG_MIN,
 
 
 class QuerySpec:
-    def __init__(self, aggregations, filter=None, group_by=(), null_handling=False):
+    def __init__(self, aggregations, filter=None, group_by=(), null_handling=False, num_groups_limit=0):
         """aggregations: list of (function, column_index) with column_index -1 for COUNT(*).
         null_handling: the query option enableNullHandling=true (PG_QUERY_NULL_HANDLING)."""
         self.null_handling = bool(null_handling)
+        self.num_groups_limit = int(num_groups_limit)
         self.aggregations = [(int(f), int(c)) for f, c in aggregations]
         self.filter = filter
         self.group_by = [int(c) for c in group_by]
@@ -149,7 +150,7 @@ class QuerySpec:
         q.num_aggregations = len(self.aggregations)
         q.num_group_by = len(self.group_by)
         q.group_by_columns = self._groups
-        q.num_groups_limit = 0
+        q.num_groups_limit = self.num_groups_limit
         q.flags = _abi.PG_QUERY_NULL_HANDLING if self.null_handling else _abi.PG_QUERY_DEFAULT
         self.c = q
 
@@ -190,6 +191,7 @@ class Result:
         self.aggregations = [AggValue(res.aggregations[a]) for a in range(na)] if res.aggregations else []
         self.groups = {}
         self.group_id_upper_bound = int(res.group_id_upper_bound)
+        self.num_groups_limit_reached = bool(res.num_groups_limit_reached)
         for g in range(int(res.num_groups)):
             gid = int(res.group_ids[g])
             self.groups[gid] = [AggValue(res.group_aggregations[g * na + a]) for a in range(na)]

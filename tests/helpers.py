@@ -107,6 +107,20 @@ def golden_filter(seg, inverted=False):
         Q.leaf(eq_pred(seg, "daysSinceEpoch", 126164076)))
 
 
+def golden_medium_group(seg, want):
+    """(group-by column indexes, raw key) of a testMediumAggregationGroupBy golden row: raw key = sum dictId_j * prod_{k<j} cardinality_k
+    (DictionaryBasedGroupKeyGenerator.java:437-445)."""
+    cols, raw, mult = [], 0, 1
+    for name, value in zip(("column9", "column11", "column12"), want["key"]):
+        ci = seg.column_index(name)
+        c = seg.columns[ci]
+        d = seg.string_dicts[name].index(value) if name in seg.string_dicts else int(np.searchsorted(c.dict_values, value))
+        raw += d * mult
+        mult *= c.cardinality
+        cols.append(ci)
+    return cols, raw
+
+
 def golden_aggregations(seg):
     """SELECT COUNT(*), SUM(column1), MAX(column3), MIN(column6), AVG(column7)"""
     ci = seg.column_index

@@ -38,6 +38,15 @@ def test_inner_segment_goldens(engine):
             _check_inner(gres.groups[gid], gw)
             assert (gres.stats[0], gres.stats[2], gres.stats[3]) == (gw["stats"][0], gw["stats"][2], gw["stats"][3])
             H.assert_results_equal(gres, oracle.execute(seg, gspec))
+            # testMediumAggregationGroupBy :114-132: 78 165 raw keys, the reference's INT_MAP_BASED holder -> HBM table + device compaction
+            mw = g["inner_segment_group_by_medium"][key]
+            cols, raw = H.golden_medium_group(seg, mw)
+            mspec = Q.QuerySpec(H.golden_aggregations(seg), filter=flt, group_by=cols)
+            mres = gseg.execute(mspec)
+            _check_inner(mres.groups[raw], mw)
+            assert (mres.stats[0], mres.stats[2], mres.stats[3]) == (mw["stats"][0], mw["stats"][2], mw["stats"][3])
+            assert mres.group_id_upper_bound == 1737 * 5 * 9 and not mres.num_groups_limit_reached
+            H.assert_results_equal(mres, oracle.execute(seg, mspec))
 
 
 def test_inter_segment_goldens(engine):

@@ -1,0 +1,55 @@
+"""GPU parity for group-by key spaces above the array-based threshold: one direct-indexed HBM table slot per raw key, device-side
+compaction, and the reference's numGroupsLimit rule (the first keys in docId order survive)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from pinot_amd import _abi
+from pinot_amd import query as Q
+import helpers as H
+import group_map_cases as GM
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cards,num_docs", [((700, 900), 300000), ((40, 50, 60), 70001), ((4000, 4000), 200000)])
+def test_wide_key_spaces_against_the_oracle(engine, cards, num_docs):
+    rng = np.random.default_rng(len(cards) * 1000 + num_docs)
+    seg, raw, v, d, f = GM.wide_group_segment(rng, num_docs, cards)
+    ci = seg.column_index
+    keys = [ci("k%d" % i) for i in range(len(cards))]
+    agg_lists = [[(Q.COUNT, -1), (Q.SUM, ci("v")), (Q.MAX, ci("v")), (Q.MIN, ci("v")), (Q.AVG, ci("v"))],
+                 [(Q.SUM, ci("d")), (Q.MAX, ci("d")), (Q.COUNT, -1)],
+                 [(Q.COUNT, -1)]]
+    filters = [None, Q.leaf(H.range_pred(seg, "f", upper=100, upper_inclusive=False)),
+               Q.or_(Q.leaf(H.range_pred(seg, "f", lower=990)), Q.not_(Q.leaf(H.range_pred(seg, "v", lower=0))))]
+    with engine.open(seg) as gseg:
+        for aggs in agg_lists:
+            for flt in filters:
+                spec = Q.QuerySpec(aggs, filter=flt, group_by=keys)
+                got, want = gseg.execute(spec), oracle.execute(seg, spec)
+                H.assert_results_equal(got, want)
+                assert got.group_id_upper_bound == int(np.prod(cards)) and got.num_groups_limit_reached == want.num_groups_limit_reached
+                assert list(got.groups) == sorted(got.groups)          # ascending raw keys
+
+
+@pytest.mark.parametrize("limit", [1, 1000, 15000])
+def test_num_groups_limit_keeps_the_first_keys_in_doc_order(engine, limit):
+    rng = np.random.default_rng(limit)
+    seg, raw, v, d, f = GM.wide_group_segment(rng, 150000, cards=(300, 400), skew=True)
+    ci = seg.column_index
+    aggs = [(Q.COUNT, -1), (Q.SUM, ci("v")), (Q.MIN, ci("v"))]
+    with engine.open(seg) as gseg:
+        for flt, mask in ((None, np.ones(len(raw), bool)), (Q.leaf(H.range_pred(seg, "f", upper=500, upper_inclusive=False)), f < 500)):
+            spec = Q.QuerySpec(aggs, filter=flt, group_by=[ci("k0"), ci("k1")], num_groups_limit=limit)
+            got, want = gseg.execute(spec), oracle.execute(seg, spec)
+            H.assert_results_equal(got, want)
+            assert set(got.groups) == GM.admitted_keys(raw, mask, limit) and len(got.groups) == limit
+            assert got.num_groups_limit_reached and want.num_groups_limit_reached
+            assert got.stats[0] == int(mask.sum())               # the docs of refused keys were still scanned
+        # a limit that is exactly the number of groups: nothing is dropped, the flag is still raised (>=)
+        present = len(np.unique(raw))
+        spec = Q.QuerySpec(aggs, group_by=[ci("k0"), ci("k1")], num_groups_limit=present)
+        got = gseg.execute(spec)
+        H.assert_results_equal(got, oracle.execute(seg, spec))
+        assert len(got.groups) == present and got.num_groups_limit_reached

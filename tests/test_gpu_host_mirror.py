@@ -99,7 +99,7 @@ def test_filtered_aggregations_run_as_swim_lanes(golden_segments):
 def test_plan_time_rejection_and_errors(golden_segments):
     _, segs = golden_segments
     for sql, status in (("SELECT column1 FROM testTable", 2),
-                        ("SELECT SUM(column1) FROM testTable GROUP BY column1, column3", 2),     # 6582 * 21910 > array-based threshold
+                        ("SELECT SUM(column1) FROM testTable GROUP BY column1, column3", 2),     # 6582 * 21910 > 2^24 direct-indexed raw keys
                         ("SELECT SUM(nope) FROM testTable", 1),
                         ("SELECT SUM(column11) FROM testTable", 1),
                         ("SELECT SUM(column1) FROM testTable WHERE column1 = 'abc'", 1)):

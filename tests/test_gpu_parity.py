@@ -192,9 +192,11 @@ def test_group_by_multiple_keys_and_global_table(engine):
     m = (id1 == 5) & (id2 == 3) & (id3 == 7)
     assert (gid in got.groups) == bool(m.any())
     run_both(engine, seg, Q.QuerySpec(aggs, filter=Q.leaf(Q.Pred.dict_range(3, 100, 2000)), group_by=[2, 0]))
+    got, _ = run_both(engine, seg, Q.QuerySpec(aggs, group_by=[0, 1, 3]))   # 90 * 11 * 5000 raw keys: the IntMapBasedHolder range, HBM table
+    assert got.group_id_upper_bound == 90 * 11 * 5000 and len(got.groups) > 10000
     with engine.open(seg) as gseg:
         with pytest.raises(_abi.PinotGpuError) as e:
-            gseg.execute(Q.QuerySpec(aggs, group_by=[0, 1, 3]))   # 90 * 11 * 5000 > arrayBasedThreshold
+            gseg.execute(Q.QuerySpec(aggs, group_by=[3, 3]))      # 5000 * 5000 > 2^24 direct-indexed slots
         assert e.value.status == _abi.PG_ERR_UNSUPPORTED
 
 

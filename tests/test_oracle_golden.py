@@ -46,6 +46,25 @@ def test_inner_segment_group_by_goldens():
         assert res.stats[0] == want["stats"][0] and res.stats[2] == want["stats"][2] and res.stats[3] == want["stats"][3]
 
 
+def test_inner_segment_medium_group_by_goldens_int_map_holder():
+    # testMediumAggregationGroupBy :114-132 (GROUP BY column9, column11, column12 -> 78 165 raw keys, INT_MAP_BASED holder)
+    g = H.load_golden_queries()["inner_segment_group_by_medium"]
+    seg = H.golden_segment()
+    for key, flt in (("unfiltered", None), ("filtered", H.golden_filter(seg))):
+        want = g[key]
+        cols, raw = H.golden_medium_group(seg, want)
+        res = oracle.execute(seg, Q.QuerySpec(H.golden_aggregations(seg), filter=flt, group_by=cols))
+        assert res.group_id_upper_bound == 1737 * 5 * 9 and not res.num_groups_limit_reached
+        count, s1, mx3, mn6, avg7 = res.groups[raw]
+        assert count.intermediate(Q.COUNT) == want["count"]
+        assert s1.intermediate(Q.SUM) == float(want["sum_column1"])
+        assert mx3.intermediate(Q.MAX) == float(want["max_column3"])
+        assert mn6.intermediate(Q.MIN) == float(want["min_column6"])
+        assert avg7.intermediate(Q.AVG) == (float(want["avg_column7"][0]), want["avg_column7"][1])
+        assert res.stats[0] == want["stats"][0] and res.stats[2] == want["stats"][2] and res.stats[3] == want["stats"][3]
+        assert sum(v[0].count for v in res.groups.values()) == want["stats"][0]
+
+
 def test_inter_segment_goldens_by_merging_four_copies():
     # InterSegmentAggregationSingleValueQueriesTest: 4 identical segments through combine + reduce;
     # merge rule = AggregationFunction.merge (SUM '+', COUNT '+'), AggregationResultsBlockMerger.java:34-44
