@@ -231,7 +231,8 @@ typedef enum pg_kernel_id {
   PG_KERNEL_SCAN_AGG = 0,          /* scan_agg_kernel: LDS-staged scan -> filter -> aggregate */
   PG_KERNEL_SCAN_PRIVATE = 1,      /* scan_private_kernel: lane-private decode straight from HBM */
   PG_KERNEL_SCAN_GROUP = 2,        /* scan_group_kernel: LDS-staged group-by */
-  PG_KERNEL_GROUP_PRIVATE = 3      /* group_private_kernel: lane-private group-by (no filter) */
+  PG_KERNEL_GROUP_PRIVATE = 3,     /* group_private_kernel: lane-private group-by */
+  PG_KERNEL_GROUP_PARTITION = 4    /* group_partition_scatter_kernel (+ histogram / aggregate): key spaces above the LDS table */
 } pg_kernel_id;
 
 typedef struct pg_stats {

@@ -237,6 +237,30 @@ struct GroupParams {
   long long* table_acc;            // [num_group_aggs * num_groups]
 };
 
+// ---- partitioned group-by (pg_group_partition.h) ----
+constexpr int kMaxPartitions = 512;
+constexpr int kPartitionChunk = 1 << 18;       // records per pass-B workgroup
+constexpr int kMaxPartitionAggs = 3;
+
+struct PartitionWork {
+  int32_t partition;
+  uint32_t start;          // first record of the chunk inside the partition
+  uint32_t len;            // records of the chunk (upper bound; clamped by what pass A really wrote)
+  uint32_t pad;
+};
+
+struct PartitionParams {
+  GroupParams gp;
+  int32_t shift;                    // log2(slots per partition)
+  int32_t num_partitions;
+  uint32_t* upper;                  // [P] pass 0 result: docs per partition ignoring the filter
+  uint32_t* cursor;                 // [P] records appended by pass A
+  const uint32_t* offsets;          // [P + 1] first record of each partition buffer (prefix sum of `upper`)
+  uint32_t* part_key;               // [num_docs] raw keys
+  uint32_t* part_val[kMaxPartitionAggs];   // [num_docs] 32-bit aggregation inputs (dictIds, plane fields or raw values)
+  const PartitionWork* work;        // pass B work list
+};
+
 // ---- roaring expansion ----
 struct DevContainer {
   uint32_t key;            // high 16 bits of the docIds in this container

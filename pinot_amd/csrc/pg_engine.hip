@@ -57,6 +57,8 @@ struct Engine {
   bool scan_private = true;  // PINOT_GPU_SCAN_PRIVATE=0: always the LDS-staged scan kernel
   bool group_private = true; // PINOT_GPU_GROUP_PRIVATE=0: unfiltered group-by through the LDS-staged kernel
   bool group_pack = true;    // PINOT_GPU_GROUP_PACK=0: separate count atomic in the group-by LDS table
+  bool group_partition = true;        // PINOT_GPU_GROUP_PARTITION=0: key spaces above the LDS table always use direct HBM atomics
+  long long partition_min_docs = 1ll << 22;   // ... =force: partition even tiny segments (tests)
   int group_waves = 0;       // PINOT_GPU_GROUP_WAVES: cap on wavefronts per group-by workgroup (default 16)
   std::mutex mu;
 };
@@ -124,6 +126,8 @@ struct ExecCtx {
   int32_t* d_gather_in = nullptr;
   uint8_t* d_gather_out = nullptr;
   size_t gather_capacity = 0;
+  uint8_t* d_partition = nullptr;               // partitioned group-by: counters, work list and the record buffers
+  size_t partition_capacity = 0;
 };
 
 }  // namespace
@@ -154,6 +158,7 @@ void destroy_ctx(ExecCtx* c) {
   if (c->h_table) (void)hipHostFree(c->h_table);
   if (c->d_gather_in) (void)hipFree(c->d_gather_in);
   if (c->d_gather_out) (void)hipFree(c->d_gather_out);
+  if (c->d_partition) (void)hipFree(c->d_partition);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -870,6 +875,9 @@ pg_status pg_init(const pg_config* config) {
   g_engine.scan_private = !(spv && spv[0] == '0');
   const char* gpv = getenv("PINOT_GPU_GROUP_PRIVATE");
   g_engine.group_private = !(gpv && gpv[0] == '0');
+  const char* gpt = getenv("PINOT_GPU_GROUP_PARTITION");
+  g_engine.group_partition = !(gpt && gpt[0] == '0');
+  g_engine.partition_min_docs = (gpt && gpt[0] == 'f') ? 0 : (1ll << 22);
   const char* gpk = getenv("PINOT_GPU_GROUP_PACK");
   g_engine.group_pack = !(gpk && gpk[0] == '0');
   const char* gw = getenv("PINOT_GPU_GROUP_WAVES");
@@ -1467,7 +1475,62 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     init_group_table_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(gp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
-    if (use_private) launch_group_private(gp.use_lds_table != 0, pblocks, pthreads, plds, ctx->stream, gp);
+    // Key spaces above the LDS table: partition the docs by key range first, then aggregate every partition in LDS
+    // (pg_group_partition.h) instead of one global atomic per doc and aggregation.
+    const int partition_entry_bytes = 4 + 8 * gp.num_group_aggs;
+    const int partition_shift = partition_entry_bytes <= 20 ? 12 : 11;
+    const long long num_partitions = (product + (1ll << partition_shift) - 1) >> partition_shift;
+    const bool use_partition = map_based && g_engine.group_partition && g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap &&
+                               gp.num_group_aggs <= kMaxPartitionAggs && num_partitions <= kMaxPartitions && (long long)seg->num_docs >= g_engine.partition_min_docs;
+    if (use_partition) {
+      const int P = (int)num_partitions;
+      const size_t N = (size_t)std::max(seg->num_tiles, 1) * 2048;
+      const size_t max_work = N / kPartitionChunk + (size_t)P + 1;
+      auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+      const size_t off_upper = 0, off_cursor = align(off_upper + (size_t)P * 4), off_offsets = align(off_cursor + (size_t)P * 4);
+      const size_t off_work = align(off_offsets + (size_t)(P + 1) * 4), off_key = align(off_work + max_work * sizeof(PartitionWork));
+      const size_t off_val = align(off_key + N * 4), bytes = off_val + (size_t)gp.num_group_aggs * align(N * 4);
+      if (ctx->partition_capacity < bytes) {
+        if (ctx->d_partition) (void)hipFree(ctx->d_partition);
+        ctx->d_partition = nullptr; ctx->partition_capacity = 0;
+        if (hipMalloc((void**)&ctx->d_partition, bytes) != hipSuccess) return fail(PG_ERR_OUT_OF_MEMORY, "partitioned group-by needs %zu bytes of record buffers", bytes);
+        ctx->partition_capacity = bytes;
+      }
+      PartitionParams pp;
+      memset(&pp, 0, sizeof(pp));
+      pp.gp = gp;
+      pp.shift = partition_shift;
+      pp.num_partitions = P;
+      pp.upper = reinterpret_cast<uint32_t*>(ctx->d_partition + off_upper);
+      pp.cursor = reinterpret_cast<uint32_t*>(ctx->d_partition + off_cursor);
+      pp.offsets = reinterpret_cast<const uint32_t*>(ctx->d_partition + off_offsets);
+      pp.work = reinterpret_cast<const PartitionWork*>(ctx->d_partition + off_work);
+      pp.part_key = reinterpret_cast<uint32_t*>(ctx->d_partition + off_key);
+      for (int a = 0; a < gp.num_group_aggs; ++a) pp.part_val[a] = reinterpret_cast<uint32_t*>(ctx->d_partition + off_val + (size_t)a * align(N * 4));
+      HIP_TRY(hipMemsetAsync(ctx->d_partition, 0, off_offsets, ctx->stream));          // upper and cursor
+      const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
+      const int hist_blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + 3) / 4, (long long)seg->num_cus * 6));
+      launch_group_partition_histogram(hist_blocks, ctx->stream, pp);
+      HIP_TRY(hipGetLastError());
+      std::vector<uint32_t> upper((size_t)P);
+      HIP_TRY(hipMemcpyAsync(upper.data(), pp.upper, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      std::vector<uint32_t> offsets((size_t)P + 1, 0u);
+      std::vector<PartitionWork> work;
+      for (int p = 0; p < P; ++p) {
+        offsets[(size_t)p + 1] = offsets[(size_t)p] + upper[(size_t)p];
+        for (uint32_t s0 = 0; s0 < upper[(size_t)p]; s0 += kPartitionChunk) work.push_back(PartitionWork{p, s0, std::min<uint32_t>(kPartitionChunk, upper[(size_t)p] - s0), 0u});
+      }
+      HIP_TRY(hipMemcpyAsync(ctx->d_partition + off_offsets, offsets.data(), offsets.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+      if (!work.empty()) HIP_TRY(hipMemcpyAsync(ctx->d_partition + off_work, work.data(), work.size() * sizeof(PartitionWork), hipMemcpyHostToDevice, ctx->stream));
+      const int scatter_bpc = std::max(1, waves_group_partition_scatter() / 4);
+      const int scatter_blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + 3) / 4, (long long)seg->num_cus * scatter_bpc));
+      launch_group_partition_scatter(scatter_blocks, ctx->stream, pp);
+      HIP_TRY(hipGetLastError());
+      if (!work.empty()) launch_group_partition_aggregate((int)work.size(), ((size_t)partition_entry_bytes) << partition_shift, ctx->stream, pp);
+      HIP_TRY(hipStreamSynchronize(ctx->stream));      // `offsets` / `work` are pageable host vectors: keep them alive until the copies ran
+    }
+    else if (use_private) launch_group_private(gp.use_lds_table != 0, pblocks, pthreads, plds, ctx->stream, gp);
     else launch_scan_group(g_engine.use_dma, gp.use_lds_table != 0, blocks, geo.threads, lds, ctx->stream, gp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -1575,7 +1638,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       }
     }
     out->num_aggregations = na;
-    out->dominant_kernel = use_private ? PG_KERNEL_GROUP_PRIVATE : PG_KERNEL_SCAN_GROUP;
+    out->dominant_kernel = use_partition ? PG_KERNEL_GROUP_PARTITION : (use_private ? PG_KERNEL_GROUP_PRIVATE : PG_KERNEL_SCAN_GROUP);
     out->num_groups = num_present;
     out->group_id_upper_bound = gp.num_groups;
     out->group_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)std::max(num_present, 1));

@@ -1,0 +1,189 @@
+// Partitioned group-by for key spaces that do not fit an LDS table (the reference's IntMapBasedHolder range,
+// DictionaryBasedGroupKeyGenerator.java:164-184,415-490; aggregateGroupBySV of Sum / Min / Max / Avg / Count).
+//
+// One global atomic per doc and per aggregation is what the direct HBM table costs (measured: 23.7 G atomics/s on MI355X, i.e.
+// 42 ms per atomic stream over 1 B rows, < 1 % of the HBM roofline).  This path pays streaming traffic instead:
+//   pass 0  group_partition_histogram_kernel   docs per partition (partition = raw key >> shift), an upper bound without the filter
+//   pass A  group_partition_scatter_kernel     filter + decode like group_private_kernel, then (raw key, value...) records are
+//                                              appended to their partition's buffer.  A workgroup ranks its 8192 docs with LDS
+//                                              atomics and reserves buffer space with ONE global atomic per (workgroup, partition),
+//                                              so records of a partition leave in runs and global atomics drop by 8192 / P.
+//   pass B  group_partition_aggregate_kernel   a workgroup takes a chunk of one partition: every key of the chunk falls in the
+//                                              same 2^shift-slot window, which fits an LDS table; LDS atomics (~3 T/s) do the
+//                                              aggregation and only the touched slots are flushed to the HBM table.
+// The HBM table, its initialisation and the compaction of the result are shared with the direct path (pg_kernels.h).
+// Traffic per doc: keys twice + values once + 2 x 4 B x (1 + aggregations) of record write / read.
+#pragma once
+#include "pg_kernels.h"
+
+namespace pg {
+
+// raw key of the lane's 32 docs of a tile: sum dictId_c * mult_c (DictionaryBasedGroupKeyGenerator.java:437-445)
+__device__ __forceinline__ void decode_group_keys(const GroupParams& gp, long long tile, int lane, uint32_t (&g)[32]) {
+  for (int c = 0; c < gp.num_group_cols; ++c) {
+    const DevGroupKey& key = gp.group_keys[c];
+    const int b = key.bits;
+    const uint32_t mult = (uint32_t)key.mult;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(key.fwd + tile * (256ll * b)) + lane * b;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint32_t d[16];
+      if (h == 0) decode16_private_dispatch<0>(b, words, d); else decode16_private_dispatch<1>(b, words, d);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : __umul24(d[j], mult) + g[16 * h + j];
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t tail_mask(const GroupParams& gp, long long tile, int lane) {
+  const long long rem = (long long)gp.scan.num_docs - (tile * 2048 + lane * 32);
+  return rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
+}
+
+static __global__ __launch_bounds__(256) void group_partition_histogram_kernel(const PartitionParams pp) {
+  __shared__ uint32_t hist[kMaxPartitions];
+  const GroupParams& gp = pp.gp;
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < pp.num_partitions; i += 256) hist[i] = 0u;
+  __syncthreads();
+  const long long num_tiles = ((long long)gp.scan.num_docs + 2047) / 2048;
+  const long long total_waves = (long long)gridDim.x * 4;
+  for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < num_tiles; tile += total_waves) {
+    const uint32_t m = tail_mask(gp, tile, lane);
+    uint32_t g[32];
+    decode_group_keys(gp, tile, lane, g);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) if ((m >> j) & 1u) __hip_atomic_fetch_add(&hist[g[j] >> pp.shift], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < pp.num_partitions; i += 256) {
+    const uint32_t c = hist[i];
+    if (c) __hip_atomic_fetch_add(&pp.upper[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+static __global__ __launch_bounds__(256) void group_partition_scatter_kernel(const PartitionParams pp) {
+  __shared__ uint32_t hist[kMaxPartitions];
+  __shared__ uint32_t base[kMaxPartitions];
+  const GroupParams& gp = pp.gp;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long long num_tiles = ((long long)gp.scan.num_docs + 2047) / 2048;
+  const long long tiles_per_round = (long long)gridDim.x * 4;
+  const long long rounds = (num_tiles + tiles_per_round - 1) / tiles_per_round;
+  for (long long r = 0; r < rounds; ++r) {
+    // the four wavefronts of the workgroup take four tiles and rank their 8192 docs together
+    const long long tile = (r * gridDim.x + blockIdx.x) * 4 + wave;
+    for (int i = threadIdx.x; i < pp.num_partitions; i += 256) hist[i] = 0u;
+    __syncthreads();
+    uint32_t m = 0u;
+    uint32_t g[32], pos[32];
+    if (tile < num_tiles) {
+      m = eval_filter_private(gp.scan, tile, lane) & tail_mask(gp, tile, lane);
+      if (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+        decode_group_keys(gp, tile, lane, g);
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+          if ((m >> j) & 1u) pos[j] = __hip_atomic_fetch_add(&hist[g[j] >> pp.shift], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < pp.num_partitions; i += 256) {
+      const uint32_t c = hist[i];
+      if (c) base[i] = pp.offsets[i] + __hip_atomic_fetch_add(&pp.cursor[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;      // wave-uniform; nothing below synchronises
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      if ((m >> j) & 1u) {
+        pos[j] += base[g[j] >> pp.shift];
+        pp.part_key[pos[j]] = g[j];
+      }
+    }
+    const long long first_doc = tile * 2048 + lane * 32;
+    for (int a = 0; a < gp.num_group_aggs; ++a) {
+      const DevGroupAgg& ga = gp.group_aggs[a];
+      uint32_t* out = pp.part_val[a];
+      const int b = ga.bits;
+      const uint32_t* words = ga.is_raw ? reinterpret_cast<const uint32_t*>(ga.fwd) + first_doc
+                                        : reinterpret_cast<const uint32_t*>(ga.fwd + tile * (256ll * b)) + lane * b;
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ga.dict, 0, ga.dict_bytes, 0x00020000);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t d[16];
+        if (ga.is_raw) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) d[j] = __builtin_bswap32(words[16 * h + j]);      // raw buffers are padded to whole tiles
+        } else {
+          if (h == 0) decode16_private_dispatch<0>(b, words, d); else decode16_private_dispatch<1>(b, words, d);
+          if (ga.kind == kGroupSum && !ga.is_plane) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, d[j] * 4u, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if ((m >> (16 * h + j)) & 1u) out[pos[16 * h + j]] = d[j];
+      }
+    }
+  }
+}
+
+// LDS: acc[num_aggs][S] (i64) then cnt[S] (u32), S = 1 << shift.
+static __global__ __launch_bounds__(256) void group_partition_aggregate_kernel(const PartitionParams pp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const GroupParams& gp = pp.gp;
+  const int S = 1 << pp.shift;
+  const int NA = gp.num_group_aggs;
+  long long* acc = reinterpret_cast<long long*>(smem);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(acc + (size_t)NA * S);
+  const PartitionWork w = pp.work[blockIdx.x];
+  const uint32_t written = pp.cursor[w.partition];
+  if (w.start >= written) return;                        // workgroup-uniform: the filter left this chunk empty
+  const uint32_t n = min(w.len, written - w.start);
+  for (int s = threadIdx.x; s < S; s += 256) {
+    cnt[s] = 0u;
+    for (int a = 0; a < NA; ++a) {
+      const int kind = gp.group_aggs[a].kind;
+      acc[(size_t)a * S + s] = kind == kGroupSum ? 0ll : (kind == kGroupMin ? 0x7FFFFFFFll : -0x80000000ll);
+    }
+  }
+  __syncthreads();
+  const uint32_t first = pp.offsets[w.partition] + w.start;
+  const uint32_t key_base = (uint32_t)w.partition << pp.shift;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    const uint32_t slot = pp.part_key[first + i] - key_base;
+    __hip_atomic_fetch_add(&cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int a = 0; a < NA; ++a) {
+      const DevGroupAgg& ga = gp.group_aggs[a];
+      const uint32_t v = pp.part_val[a][first + i];
+      long long* slot_acc = acc + (size_t)a * S + slot;
+      if (ga.kind == kGroupSum) {
+        const bool is_unsigned = !ga.is_raw && ga.is_plane;
+        __hip_atomic_fetch_add(slot_acc, is_unsigned ? (long long)v : (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (ga.kind == kGroupMin) {
+        __hip_atomic_fetch_min(slot_acc, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        __hip_atomic_fetch_max(slot_acc, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  __syncthreads();
+  const long long G = gp.num_groups;
+  for (int s = threadIdx.x; s < S; s += 256) {
+    const uint32_t c = cnt[s];
+    if (!c) continue;
+    const long long g = (long long)key_base + s;
+    __hip_atomic_fetch_add(&gp.table_count[g], (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int a = 0; a < NA; ++a) {
+      const int kind = gp.group_aggs[a].kind;
+      long long* slot = gp.table_acc + (long long)a * G + g;
+      const long long v = acc[(size_t)a * S + s];
+      if (kind == kGroupSum) __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (kind == kGroupMin) __hip_atomic_fetch_min(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_fetch_max(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace pg

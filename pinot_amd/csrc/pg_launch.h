@@ -37,5 +37,11 @@ int waves_scan_group();
 void launch_group_private(bool lds_table, int blocks, int threads, size_t lds, hipStream_t stream, const GroupParams& gp);
 int waves_group_private();
 
+// partitioned group-by for key spaces above the LDS table (pg_group_partition.h): histogram, scatter, aggregate
+void launch_group_partition_histogram(int blocks, hipStream_t stream, const PartitionParams& pp);
+void launch_group_partition_scatter(int blocks, hipStream_t stream, const PartitionParams& pp);
+void launch_group_partition_aggregate(int work_items, size_t lds, hipStream_t stream, const PartitionParams& pp);
+int waves_group_partition_scatter();
+
 }  // namespace pg
 #endif

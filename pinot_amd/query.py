@@ -187,6 +187,7 @@ class Result:
                       int(res.stats.num_entries_scanned_post_filter), int(res.stats.num_total_docs))
         self.device_ms = float(res.device_ms)
         self.dominant_kernel_ms = float(res.dominant_kernel_ms)
+        self.dominant_kernel = _abi.KERNEL_NAMES.get(int(getattr(res, "dominant_kernel", -1)), "")
         na = int(res.num_aggregations)
         self.aggregations = [AggValue(res.aggregations[a]) for a in range(na)] if res.aggregations else []
         self.groups = {}

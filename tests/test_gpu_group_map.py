@@ -53,3 +53,34 @@ def test_num_groups_limit_keeps_the_first_keys_in_doc_order(engine, limit):
         got = gseg.execute(spec)
         H.assert_results_equal(got, oracle.execute(seg, spec))
         assert len(got.groups) == present and got.num_groups_limit_reached
+
+
+def test_partitioned_path_on_a_segment_large_enough_to_take_it(engine):
+    """>= 4 Mi docs: the docs are first partitioned by key range and every partition is aggregated in LDS (pg_group_partition.h)."""
+    rng = np.random.default_rng(77)
+    seg, raw, v, d, f = GM.wide_group_segment(rng, 5_000_000, cards=(700, 900), skew=True)
+    ci = seg.column_index
+    keys = [ci("k0"), ci("k1")]
+    agg_lists = [[(Q.COUNT, -1)],
+                 [(Q.SUM, ci("v")), (Q.COUNT, -1)],
+                 [(Q.SUM, ci("v")), (Q.MAX, ci("f")), (Q.AVG, ci("v"))],
+                 [(Q.MIN, ci("v")), (Q.MAX, ci("v")), (Q.SUM, ci("f"))]]          # three accumulators: 2048-slot partitions
+    filters = [None, Q.leaf(H.range_pred(seg, "f", upper=100, upper_inclusive=False)),
+               Q.or_(Q.leaf(H.range_pred(seg, "f", lower=990)), Q.not_(Q.leaf(H.range_pred(seg, "v", lower=0))))]
+    with engine.open(seg) as gseg:
+        for aggs in agg_lists:
+            for flt in filters:
+                spec = Q.QuerySpec(aggs, filter=flt, group_by=keys, num_groups_limit=1_000_000)
+                got, want = gseg.execute(spec), oracle.execute(seg, spec)
+                H.assert_results_equal(got, want)
+                assert got.dominant_kernel == "group_partition_scatter_kernel"
+        # the limit rule on top of the partitioned table
+        spec = Q.QuerySpec([(Q.SUM, ci("v"))], group_by=keys, num_groups_limit=5000)
+        got = gseg.execute(spec)
+        H.assert_results_equal(got, oracle.execute(seg, spec))
+        assert len(got.groups) == 5000 and got.num_groups_limit_reached
+        # a DOUBLE sum is outside the 32-bit record format: the direct HBM-atomic path takes it
+        spec = Q.QuerySpec([(Q.SUM, ci("d"))], group_by=keys, num_groups_limit=1_000_000)
+        got = gseg.execute(spec)
+        H.assert_results_equal(got, oracle.execute(seg, spec))
+        assert got.dominant_kernel != "group_partition_scatter_kernel"

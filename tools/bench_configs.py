@@ -124,6 +124,12 @@ def main():
         report(out, "C3 SUM(a), MAX(b) GROUP BY k", n, B(k) + B(a) + B(b), g, seg, Q.QuerySpec([(Q.SUM, 3), (Q.MAX, 4)], group_by=[2]), check)
         report(out, "C3 SUM(a), MAX(b) WHERE f < 100 GROUP BY k", n, B(k) + B(a) + B(b) + B(f), g, seg,
                Q.QuerySpec([(Q.SUM, 3), (Q.MAX, 4)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100)), group_by=[2]), check)
+        # key spaces above the array-based threshold (the reference's IntMapBasedHolder range): HBM table, global atomics, device compaction
+        report(out, "C6 COUNT(*) GROUP BY k, f (1M raw keys)", n, B(k) + B(f), g, seg, Q.QuerySpec([(Q.COUNT, -1)], group_by=[2, 1], num_groups_limit=2_000_000), check)
+        report(out, "C6 SUM(a) GROUP BY k, f (1M raw keys)", n, B(k) + B(f) + B(a), g, seg, Q.QuerySpec([(Q.SUM, 3)], group_by=[2, 1], num_groups_limit=2_000_000), check)
+        report(out, "C6 SUM(a), MAX(b) WHERE f < 100 GROUP BY k, f (100k of 1M raw keys present)", n, B(k) + B(f) + B(a) + B(b), g, seg,
+               Q.QuerySpec([(Q.SUM, 3), (Q.MAX, 4)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100)), group_by=[2, 1], num_groups_limit=2_000_000), check)
+        report(out, "C6 SUM(a) GROUP BY k, f LIMITED to 100000 groups (first-doc pass)", n, B(k) + B(f) + B(a), g, seg, Q.QuerySpec([(Q.SUM, 3)], group_by=[2, 1]), check)
         report(out, "COUNT(*) WHERE f < 100", n, B(f), g, seg, Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), check)
         report(out, "MIN(v), MAX(v), AVG(v) WHERE f < 100", n, B(v) + B(f), g, seg,
                Q.QuerySpec([(Q.MIN, 0), (Q.MAX, 0), (Q.AVG, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), check)
