@@ -239,7 +239,7 @@ struct GroupParams {
 
 // ---- partitioned group-by (pg_group_partition.h) ----
 constexpr int kMaxPartitions = 512;
-constexpr int kPartitionChunk = 1 << 18;       // records per pass-B workgroup
+constexpr int kPartitionChunk = 1 << 21;       // most records one pass-B workgroup takes
 constexpr int kMaxPartitionAggs = 3;
 
 struct PartitionWork {

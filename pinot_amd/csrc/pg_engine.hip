@@ -1485,7 +1485,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (use_partition) {
       const int P = (int)num_partitions;
       const size_t N = (size_t)std::max(seg->num_tiles, 1) * 2048;
-      const size_t max_work = N / kPartitionChunk + (size_t)P + 1;
+      const size_t max_work = N / (1u << 16) + (size_t)P + 1;
       auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
       const size_t off_upper = 0, off_cursor = align(off_upper + (size_t)P * 4), off_offsets = align(off_cursor + (size_t)P * 4);
       const size_t off_work = align(off_offsets + (size_t)(P + 1) * 4), off_key = align(off_work + max_work * sizeof(PartitionWork));
@@ -1517,9 +1517,15 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       std::vector<uint32_t> offsets((size_t)P + 1, 0u);
       std::vector<PartitionWork> work;
+      // chunk size: about two rounds of resident pass-B workgroups over the whole input, so that the flush of the touched slots
+      // (one global atomic per slot, accumulator and chunk) stays small next to the records a chunk aggregates
+      unsigned long long total_upper = 0;
+      for (int p = 0; p < P; ++p) total_upper += upper[(size_t)p];
+      const unsigned long long want_chunk = (total_upper + (unsigned long long)seg->num_cus * 6 - 1) / ((unsigned long long)seg->num_cus * 6);
+      const uint32_t chunk = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>((want_chunk + 1023) & ~1023ull, 1u << 16), (unsigned long long)kPartitionChunk);
       for (int p = 0; p < P; ++p) {
         offsets[(size_t)p + 1] = offsets[(size_t)p] + upper[(size_t)p];
-        for (uint32_t s0 = 0; s0 < upper[(size_t)p]; s0 += kPartitionChunk) work.push_back(PartitionWork{p, s0, std::min<uint32_t>(kPartitionChunk, upper[(size_t)p] - s0), 0u});
+        for (uint32_t s0 = 0; s0 < upper[(size_t)p]; s0 += chunk) work.push_back(PartitionWork{p, s0, std::min<uint32_t>(chunk, upper[(size_t)p] - s0), 0u});
       }
       HIP_TRY(hipMemcpyAsync(ctx->d_partition + off_offsets, offsets.data(), offsets.size() * 4, hipMemcpyHostToDevice, ctx->stream));
       if (!work.empty()) HIP_TRY(hipMemcpyAsync(ctx->d_partition + off_work, work.data(), work.size() * sizeof(PartitionWork), hipMemcpyHostToDevice, ctx->stream));

@@ -6,8 +6,9 @@
 //   pass 0  group_partition_histogram_kernel   docs per partition (partition = raw key >> shift), an upper bound without the filter
 //   pass A  group_partition_scatter_kernel     filter + decode like group_private_kernel, then (raw key, value...) records are
 //                                              appended to their partition's buffer.  A workgroup ranks its 8192 docs with LDS
-//                                              atomics and reserves buffer space with ONE global atomic per (workgroup, partition),
-//                                              so records of a partition leave in runs and global atomics drop by 8192 / P.
+//                                              atomics, reserves buffer space with ONE global atomic per (workgroup, partition)
+//                                              -- global atomics drop by 8192 / P -- and stages the records in LDS in partition
+//                                              order so that they leave as contiguous runs.
 //   pass B  group_partition_aggregate_kernel   a workgroup takes a chunk of one partition: every key of the chunk falls in the
 //                                              same 2^shift-slot window, which fits an LDS table; LDS atomics (~3 T/s) do the
 //                                              aggregation and only the touched slots are flushed to the HBM table.
@@ -62,10 +63,22 @@ static __global__ __launch_bounds__(256) void group_partition_histogram_kernel(c
   }
 }
 
+// LDS (dynamic): hist[P], lbase[P + 1], gbase[P], then two 8192-dword staging columns (keys, current value column).
+// The records of a round are first laid out in LDS in partition order (slot = partition's LDS base + rank), then copied out
+// linearly: consecutive staging slots of one partition are consecutive in its global buffer, so a wavefront's store covers a
+// few contiguous runs instead of 64 unrelated dwords (the direct scatter was bound by the L2's write-request rate).
+constexpr int kScatterDocsPerRound = 8192;
+inline size_t partition_scatter_lds_bytes() { return (size_t)(3 * kMaxPartitions + 1) * 4 + 2 * (size_t)kScatterDocsPerRound * 4; }
+
 static __global__ __launch_bounds__(256) void group_partition_scatter_kernel(const PartitionParams pp) {
-  __shared__ uint32_t hist[kMaxPartitions];
-  __shared__ uint32_t base[kMaxPartitions];
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* lbase = hist + kMaxPartitions;              // [P + 1] exclusive prefix of hist; lbase[P] = records of the round
+  uint32_t* gbase = lbase + kMaxPartitions + 1;         // [P] first global record slot reserved for the round
+  uint32_t* skey = gbase + kMaxPartitions;
+  uint32_t* sval = skey + kScatterDocsPerRound;
   const GroupParams& gp = pp.gp;
+  const int P = pp.num_partitions;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const long long num_tiles = ((long long)gp.scan.num_docs + 2047) / 2048;
@@ -74,58 +87,93 @@ static __global__ __launch_bounds__(256) void group_partition_scatter_kernel(con
   for (long long r = 0; r < rounds; ++r) {
     // the four wavefronts of the workgroup take four tiles and rank their 8192 docs together
     const long long tile = (r * gridDim.x + blockIdx.x) * 4 + wave;
-    for (int i = threadIdx.x; i < pp.num_partitions; i += 256) hist[i] = 0u;
+    for (int i = threadIdx.x; i < P; i += 256) hist[i] = 0u;
     __syncthreads();
     uint32_t m = 0u;
-    uint32_t g[32], pos[32];
+    uint32_t g[32], slot[32];
     if (tile < num_tiles) {
       m = eval_filter_private(gp.scan, tile, lane) & tail_mask(gp, tile, lane);
       if (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
         decode_group_keys(gp, tile, lane, g);
 #pragma unroll
         for (int j = 0; j < 32; ++j)
-          if ((m >> j) & 1u) pos[j] = __hip_atomic_fetch_add(&hist[g[j] >> pp.shift], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if ((m >> j) & 1u) slot[j] = __hip_atomic_fetch_add(&hist[g[j] >> pp.shift], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < pp.num_partitions; i += 256) {
+    // reserve the global space of every partition (one atomic each) and lay the partitions out back to back in LDS
+    for (int i = threadIdx.x; i < P; i += 256) {
       const uint32_t c = hist[i];
-      if (c) base[i] = pp.offsets[i] + __hip_atomic_fetch_add(&pp.cursor[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (c) gbase[i] = pp.offsets[i] + __hip_atomic_fetch_add(&pp.cursor[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wave == 0) {
+      uint32_t carry = 0u;
+      for (int base_i = 0; base_i < P; base_i += 64) {
+        const int i = base_i + lane;
+        const uint32_t c = i < P ? hist[i] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t up = __shfl_up(incl, d, 64);
+          if (lane >= d) incl += up;
+        }
+        if (i < P) lbase[i] = carry + incl - c;
+        carry += __shfl(incl, 63, 64);
+      }
+      if (lane == 0) lbase[P] = carry;
     }
     __syncthreads();
-    if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;      // wave-uniform; nothing below synchronises
+    const bool any = __builtin_amdgcn_ballot_w64(m != 0u) != 0ull;      // wave-uniform
+    if (any) {
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      if ((m >> j) & 1u) {
-        pos[j] += base[g[j] >> pp.shift];
-        pp.part_key[pos[j]] = g[j];
+      for (int j = 0; j < 32; ++j) {
+        if ((m >> j) & 1u) {
+          slot[j] += lbase[g[j] >> pp.shift];
+          skey[slot[j]] = g[j];
+        }
       }
+    }
+    __syncthreads();
+    const uint32_t round_records = lbase[P];
+    for (uint32_t i = threadIdx.x; i < round_records; i += 256) {
+      const uint32_t key = skey[i];
+      const uint32_t p = key >> pp.shift;
+      pp.part_key[gbase[p] + (i - lbase[p])] = key;
     }
     const long long first_doc = tile * 2048 + lane * 32;
     for (int a = 0; a < gp.num_group_aggs; ++a) {
       const DevGroupAgg& ga = gp.group_aggs[a];
-      uint32_t* out = pp.part_val[a];
-      const int b = ga.bits;
-      const uint32_t* words = ga.is_raw ? reinterpret_cast<const uint32_t*>(ga.fwd) + first_doc
-                                        : reinterpret_cast<const uint32_t*>(ga.fwd + tile * (256ll * b)) + lane * b;
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ga.dict, 0, ga.dict_bytes, 0x00020000);
+      if (any) {
+        const int b = ga.bits;
+        const uint32_t* words = ga.is_raw ? reinterpret_cast<const uint32_t*>(ga.fwd) + first_doc
+                                          : reinterpret_cast<const uint32_t*>(ga.fwd + tile * (256ll * b)) + lane * b;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ga.dict, 0, ga.dict_bytes, 0x00020000);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        uint32_t d[16];
-        if (ga.is_raw) {
+        for (int h = 0; h < 2; ++h) {
+          uint32_t d[16];
+          if (ga.is_raw) {
 #pragma unroll
-          for (int j = 0; j < 16; ++j) d[j] = __builtin_bswap32(words[16 * h + j]);      // raw buffers are padded to whole tiles
-        } else {
-          if (h == 0) decode16_private_dispatch<0>(b, words, d); else decode16_private_dispatch<1>(b, words, d);
-          if (ga.kind == kGroupSum && !ga.is_plane) {
+            for (int j = 0; j < 16; ++j) d[j] = __builtin_bswap32(words[16 * h + j]);      // raw buffers are padded to whole tiles
+          } else {
+            if (h == 0) decode16_private_dispatch<0>(b, words, d); else decode16_private_dispatch<1>(b, words, d);
+            if (ga.kind == kGroupSum && !ga.is_plane) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) d[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, d[j] * 4u, 0, 0);
+              for (int j = 0; j < 16; ++j) d[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, d[j] * 4u, 0, 0);
+            }
           }
-        }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) if ((m >> (16 * h + j)) & 1u) out[pos[16 * h + j]] = d[j];
+          for (int j = 0; j < 16; ++j) if ((m >> (16 * h + j)) & 1u) sval[slot[16 * h + j]] = d[j];
+        }
       }
+      __syncthreads();
+      uint32_t* out = pp.part_val[a];
+      for (uint32_t i = threadIdx.x; i < round_records; i += 256) {
+        const uint32_t p = skey[i] >> pp.shift;
+        out[gbase[p] + (i - lbase[p])] = sval[i];
+      }
+      __syncthreads();      // the next column (or the next round's keys) overwrites the staging area
     }
+    __syncthreads();
   }
 }
 
@@ -151,20 +199,32 @@ static __global__ __launch_bounds__(256) void group_partition_aggregate_kernel(c
   __syncthreads();
   const uint32_t first = pp.offsets[w.partition] + w.start;
   const uint32_t key_base = (uint32_t)w.partition << pp.shift;
-  for (uint32_t i = threadIdx.x; i < n; i += 256) {
-    const uint32_t slot = pp.part_key[first + i] - key_base;
-    __hip_atomic_fetch_add(&cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    for (int a = 0; a < NA; ++a) {
-      const DevGroupAgg& ga = gp.group_aggs[a];
-      const uint32_t v = pp.part_val[a][first + i];
-      long long* slot_acc = acc + (size_t)a * S + slot;
-      if (ga.kind == kGroupSum) {
-        const bool is_unsigned = !ga.is_raw && ga.is_plane;
-        __hip_atomic_fetch_add(slot_acc, is_unsigned ? (long long)v : (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else if (ga.kind == kGroupMin) {
-        __hip_atomic_fetch_min(slot_acc, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else {
-        __hip_atomic_fetch_max(slot_acc, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // four independent record loads per thread and column are in flight before the LDS atomics of the batch start
+  for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 1024) {
+    uint32_t key[4], val[kMaxPartitionAggs][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = i0 + 256u * u;
+      key[u] = i < n ? pp.part_key[first + i] : 0xFFFFFFFFu;
+      for (int a = 0; a < NA; ++a) val[a][u] = i < n ? pp.part_val[a][first + i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (key[u] == 0xFFFFFFFFu) continue;             // raw keys are < 2^24
+      const uint32_t slot = key[u] - key_base;
+      __hip_atomic_fetch_add(&cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int a = 0; a < NA; ++a) {
+        const DevGroupAgg& ga = gp.group_aggs[a];
+        const uint32_t v = val[a][u];
+        long long* slot_acc = acc + (size_t)a * S + slot;
+        if (ga.kind == kGroupSum) {
+          const bool is_unsigned = !ga.is_raw && ga.is_plane;
+          __hip_atomic_fetch_add(slot_acc, is_unsigned ? (long long)v : (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (ga.kind == kGroupMin) {
+          __hip_atomic_fetch_min(slot_acc, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          __hip_atomic_fetch_max(slot_acc, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
     }
   }

@@ -9,7 +9,9 @@ void launch_group_partition_histogram(int blocks, hipStream_t stream, const Part
 }
 
 void launch_group_partition_scatter(int blocks, hipStream_t stream, const PartitionParams& pp) {
-  group_partition_scatter_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(pp);
+  const size_t lds = partition_scatter_lds_bytes();
+  set_dynamic_lds(group_partition_scatter_kernel, lds);
+  group_partition_scatter_kernel<<<dim3((unsigned)blocks), dim3(256), lds, stream>>>(pp);
 }
 
 void launch_group_partition_aggregate(int work_items, size_t lds, hipStream_t stream, const PartitionParams& pp) {
@@ -18,7 +20,8 @@ void launch_group_partition_aggregate(int work_items, size_t lds, hipStream_t st
 }
 
 int waves_group_partition_scatter() {
-  static const int cap = max_waves_per_cu(group_partition_scatter_kernel);
+  // registers and the 70 KB staging area (two workgroups per CU) both bound it
+  static const int cap = std::min(max_waves_per_cu(group_partition_scatter_kernel), 8);
   return cap;
 }
 

@@ -66,6 +66,12 @@ configs)
   echo "== all configs =="; timeout 1500 python tools/bench_configs.py --out $OUT/configs.jsonl 2>&1 | tail -30 ;;
 sweep)
   for bpc in 2 3 4 5 6 8 10 12; do echo "== bench bpc=$bpc =="; PINOT_GPU_BLOCKS_PER_CU=$bpc timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | short; done ;;
+c6prof)
+  echo "== rocprof kernel stats, C6 wide group-by =="; cd /tmp && export TMPDIR=/tmp
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c6 -o c6 -- python $GRAFT_REPO_ROOT/tools/bench_configs.py --match "${C6_MATCH:-C6 SUM\(a\) GROUP BY k, f \(1M}" --only c23 --no-check > $OUT/prof_c6.log 2>&1
+  tail -2 $OUT/prof_c6.log | cut -c1-300; find $OUT/prof_c6 -name "*kernel_stats*.csv" -exec cat {} \; | head -14
+  find $OUT/prof_c6 -name "*kernel_trace*.csv" -size +8M -delete
+  cd $GRAFT_REPO_ROOT ;;
 prof)
   echo "== rocprof =="; cd /tmp && export TMPDIR=/tmp
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/rocprof.log 2>&1
