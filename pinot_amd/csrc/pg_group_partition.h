@@ -177,12 +177,13 @@ static __global__ __launch_bounds__(256) void group_partition_scatter_kernel(con
   }
 }
 
-// LDS: acc[num_aggs][S] (i64) then cnt[S] (u32), S = 1 << shift.
-static __global__ __launch_bounds__(256) void group_partition_aggregate_kernel(const PartitionParams pp) {
+// LDS: acc[NA][S] (i64) then cnt[S] (u32), S = 1 << shift.  NA (accumulators) is a template parameter so that the record loads of
+// a batch are straight-line code: with a run-time column loop and guarded loads the compiler waited for every load separately.
+template <int NA>
+__global__ __launch_bounds__(256) void group_partition_aggregate_kernel(const PartitionParams pp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const GroupParams& gp = pp.gp;
   const int S = 1 << pp.shift;
-  const int NA = gp.num_group_aggs;
   long long* acc = reinterpret_cast<long long*>(smem);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(acc + (size_t)NA * S);
   const PartitionWork w = pp.work[blockIdx.x];
@@ -191,6 +192,7 @@ static __global__ __launch_bounds__(256) void group_partition_aggregate_kernel(c
   const uint32_t n = min(w.len, written - w.start);
   for (int s = threadIdx.x; s < S; s += 256) {
     cnt[s] = 0u;
+#pragma unroll
     for (int a = 0; a < NA; ++a) {
       const int kind = gp.group_aggs[a].kind;
       acc[(size_t)a * S + s] = kind == kGroupSum ? 0ll : (kind == kGroupMin ? 0x7FFFFFFFll : -0x80000000ll);
@@ -199,20 +201,25 @@ static __global__ __launch_bounds__(256) void group_partition_aggregate_kernel(c
   __syncthreads();
   const uint32_t first = pp.offsets[w.partition] + w.start;
   const uint32_t key_base = (uint32_t)w.partition << pp.shift;
-  // four independent record loads per thread and column are in flight before the LDS atomics of the batch start
-  for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 1024) {
-    uint32_t key[4], val[kMaxPartitionAggs][4];
+  const uint32_t* __restrict__ keys = pp.part_key + first;
+  // eight record loads per thread and column are in flight before the LDS atomics of the batch start; indexes past the chunk are
+  // clamped (the loads stay unconditional) and their records skipped
+  constexpr int kUnroll = 8;
+  for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 256 * kUnroll) {
+    uint32_t key[kUnroll], val[NA > 0 ? NA : 1][kUnroll];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t i = i0 + 256u * u;
-      key[u] = i < n ? pp.part_key[first + i] : 0xFFFFFFFFu;
-      for (int a = 0; a < NA; ++a) val[a][u] = i < n ? pp.part_val[a][first + i] : 0u;
+    for (int u = 0; u < kUnroll; ++u) {
+      const uint32_t i = min(i0 + 256u * u, n - 1u);
+      key[u] = keys[i];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) val[a][u] = pp.part_val[a][first + i];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (key[u] == 0xFFFFFFFFu) continue;             // raw keys are < 2^24
+    for (int u = 0; u < kUnroll; ++u) {
+      if (i0 + 256u * u >= n) continue;
       const uint32_t slot = key[u] - key_base;
       __hip_atomic_fetch_add(&cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
       for (int a = 0; a < NA; ++a) {
         const DevGroupAgg& ga = gp.group_aggs[a];
         const uint32_t v = val[a][u];
@@ -235,6 +242,7 @@ static __global__ __launch_bounds__(256) void group_partition_aggregate_kernel(c
     if (!c) continue;
     const long long g = (long long)key_base + s;
     __hip_atomic_fetch_add(&gp.table_count[g], (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
     for (int a = 0; a < NA; ++a) {
       const int kind = gp.group_aggs[a].kind;
       long long* slot = gp.table_acc + (long long)a * G + g;

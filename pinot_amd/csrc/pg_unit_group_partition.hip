@@ -15,8 +15,13 @@ void launch_group_partition_scatter(int blocks, hipStream_t stream, const Partit
 }
 
 void launch_group_partition_aggregate(int work_items, size_t lds, hipStream_t stream, const PartitionParams& pp) {
-  set_dynamic_lds(group_partition_aggregate_kernel, lds);
-  group_partition_aggregate_kernel<<<dim3((unsigned)work_items), dim3(256), lds, stream>>>(pp);
+  const dim3 grid((unsigned)work_items), block(256);
+  switch (pp.gp.num_group_aggs) {
+    case 0: set_dynamic_lds(group_partition_aggregate_kernel<0>, lds); group_partition_aggregate_kernel<0><<<grid, block, lds, stream>>>(pp); break;
+    case 1: set_dynamic_lds(group_partition_aggregate_kernel<1>, lds); group_partition_aggregate_kernel<1><<<grid, block, lds, stream>>>(pp); break;
+    case 2: set_dynamic_lds(group_partition_aggregate_kernel<2>, lds); group_partition_aggregate_kernel<2><<<grid, block, lds, stream>>>(pp); break;
+    default: set_dynamic_lds(group_partition_aggregate_kernel<3>, lds); group_partition_aggregate_kernel<3><<<grid, block, lds, stream>>>(pp); break;
+  }
 }
 
 int waves_group_partition_scatter() {
