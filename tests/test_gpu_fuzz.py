@@ -99,3 +99,68 @@ def test_random_segments_and_queries(engine, seed):
                 words, card = g.filter_bitmap(spec)
                 owords, ocard = oracle.filter_bitmap(seg, spec)
                 assert card == ocard and np.array_equal(words, owords)
+
+
+def random_leaf_with_nulls(rng, seg, n):
+    if rng.integers(0, 4) == 0:
+        return Q.leaf(Q.Pred.is_null(int(rng.integers(0, len(seg.columns))), exclusive=bool(rng.integers(0, 2))))
+    return random_leaf(rng, seg, n)
+
+
+def random_tree_with_nulls(rng, seg, n, depth):
+    if depth == 0 or rng.integers(0, 3) == 0:
+        return random_leaf_with_nulls(rng, seg, n)
+    op = rng.integers(0, 3)
+    if op == 2:
+        return Q.not_(random_tree_with_nulls(rng, seg, n, depth - 1))
+    kids = [random_tree_with_nulls(rng, seg, n, depth - 1) for _ in range(2)]
+    return Q.and_(*kids) if op == 0 else Q.or_(*kids)
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_null_vectors_null_handling_and_wide_group_bys(engine, seed):
+    """Same idea with the later features switched on at random: null value vectors (sparse, dense, runs), IS NULL leaves, the
+    enableNullHandling option, group-by key spaces above the array-based threshold and small numGroupsLimit values."""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([1, 33, 2049, 9001, 70_001, 140_000]))
+    cols = []
+    for c in range(3):
+        card = int(rng.choice([3, 64, 300, 1000, 5000]))
+        col = forced_width_column(rng, "c%d" % c, n, card, max(1, int(np.ceil(np.log2(card)))), affine=bool(rng.integers(0, 2)), with_inverted=(c == 0))
+        style = int(rng.integers(0, 4))
+        if style == 1:
+            col.with_nulls(rng.random(n) < 0.01)
+        elif style == 2:
+            col.with_nulls(rng.random(n) < 0.7)
+        elif style == 3:
+            m = np.zeros(n, bool)
+            m[n // 3: n // 3 + max(1, n // 5)] = True
+            col.with_nulls(m)
+        cols.append(col)
+    seg = S.SegmentData("fuzznull%d" % seed, n, cols)
+    funcs = [Q.COUNT, Q.SUM, Q.MIN, Q.MAX, Q.AVG]
+    ran = 0
+    with engine.open(seg) as g:
+        for q in range(14):
+            aggs = []
+            for f in rng.choice(funcs, int(rng.integers(1, 4))):
+                column = int(rng.integers(0, 3))
+                aggs.append((int(f), (column if rng.integers(0, 2) else -1) if f == Q.COUNT else column))
+            flt = random_tree_with_nulls(rng, seg, n, 2) if rng.integers(0, 5) else None
+            group_by = [int(x) for x in rng.choice(3, int(rng.integers(1, 3)), replace=False)] if rng.integers(0, 3) == 0 else []
+            limit = int(rng.choice([0, 0, 5, 200])) if group_by else 0
+            spec = Q.QuerySpec(aggs, filter=flt, group_by=group_by, null_handling=bool(rng.integers(0, 2)), num_groups_limit=limit)
+            try:
+                got = g.execute(spec)
+            except _abi.PinotGpuError as e:
+                assert e.status == _abi.PG_ERR_UNSUPPORTED, e      # plan-time fallbacks: leaf / node tables, nullable group-by, > 2^24 keys
+                continue
+            want = oracle.execute(seg, spec)
+            H.assert_results_equal(got, want, check_stats=False)
+            assert got.stats[0] == want.stats[0] and got.num_groups_limit_reached == want.num_groups_limit_reached
+            ran += 1
+            if flt is not None and not group_by:
+                words, card = g.filter_bitmap(spec)
+                owords, ocard = oracle.filter_bitmap(seg, spec)
+                assert card == ocard and np.array_equal(words, owords)
+    assert ran >= 5
