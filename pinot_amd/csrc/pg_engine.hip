@@ -57,6 +57,7 @@ struct Engine {
   bool scan_private = true;  // PINOT_GPU_SCAN_PRIVATE=0: always the LDS-staged scan kernel
   bool group_private = true; // PINOT_GPU_GROUP_PRIVATE=0: unfiltered group-by through the LDS-staged kernel
   bool group_pack = true;    // PINOT_GPU_GROUP_PACK=0: separate count atomic in the group-by LDS table
+  bool scan_typed_private = true;     // PINOT_GPU_SCAN_TYPED_PRIVATE=0: raw / 8-byte aggregated columns stay in the LDS-staged kernel
   bool group_partition = true;        // PINOT_GPU_GROUP_PARTITION=0: key spaces above the LDS table always use direct HBM atomics
   long long partition_min_docs = 1ll << 22;   // ... =force: partition even tiny segments (tests)
   int group_waves = 0;       // PINOT_GPU_GROUP_WAVES: cap on wavefronts per group-by workgroup (default 16)
@@ -875,6 +876,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.scan_private = !(spv && spv[0] == '0');
   const char* gpv = getenv("PINOT_GPU_GROUP_PRIVATE");
   g_engine.group_private = !(gpv && gpv[0] == '0');
+  const char* stp = getenv("PINOT_GPU_SCAN_TYPED_PRIVATE");
+  g_engine.scan_typed_private = !(stp && stp[0] == '0');
   const char* gpt = getenv("PINOT_GPU_GROUP_PARTITION");
   g_engine.group_partition = !(gpt && gpt[0] == '0');
   g_engine.partition_min_docs = (gpt && gpt[0] == 'f') ? 0 : (1ll << 22);
@@ -1023,13 +1026,16 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       const uint64_t raw_start = (uint64_t)data_header_start + (uint64_t)num_chunks * (version <= 2 ? 4 : 8);
       if (raw_start + (uint64_t)desc->num_docs * (uint64_t)value_bytes > cd.fwd_size) return bail(fail(PG_ERR_INVALID_ARGUMENT, "column %s: raw forward index shorter than numDocs", col.name.c_str()));
       // padded so that whole 2048-doc tiles can be read past numDocs (the lane-private kernels never clamp docIds)
-      col.fwd_alloc_bytes = std::max<size_t>((size_t)cd.fwd_size, (size_t)raw_start + (size_t)std::max(seg->num_tiles, 1) * 2048 * (size_t)value_bytes) + 64;
+      // The file is placed so that the VALUES (not the header) start on a 256-byte boundary: a lane's 32 docs are then whole,
+      // aligned 16-byte loads and a tile's rows whole cache lines (the header is 28 + 4 * numChunks bytes: any multiple of 4).
+      const size_t lead = (256 - (size_t)(raw_start % 256)) % 256;
+      col.fwd_alloc_bytes = lead + std::max<size_t>((size_t)cd.fwd_size, (size_t)raw_start + (size_t)std::max(seg->num_tiles, 1) * 2048 * (size_t)value_bytes) + 64;
       hipError_t e = hipMalloc((void**)&col.d_fwd_alloc, col.fwd_alloc_bytes);
       if (e != hipSuccess) return bail(fail(PG_ERR_OUT_OF_MEMORY, "column %s: hipMalloc(%zu): %s", col.name.c_str(), col.fwd_alloc_bytes, hipGetErrorString(e)));
-      e = hipMemset(col.d_fwd_alloc + cd.fwd_size, 0, col.fwd_alloc_bytes - (size_t)cd.fwd_size);
-      if (e == hipSuccess) e = hipMemcpy(col.d_fwd_alloc, fwd, (size_t)cd.fwd_size, hipMemcpyHostToDevice);
+      e = hipMemset(col.d_fwd_alloc, 0, col.fwd_alloc_bytes);
+      if (e == hipSuccess) e = hipMemcpy(col.d_fwd_alloc + lead, fwd, (size_t)cd.fwd_size, hipMemcpyHostToDevice);
       if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "column %s: H2D copy: %s", col.name.c_str(), hipGetErrorString(e)));
-      col.d_fwd = col.d_fwd_alloc + raw_start;
+      col.d_fwd = col.d_fwd_alloc + lead + raw_start;
       col.bits = 32;
       col.cardinality = 0;
       seg->device_bytes += col.fwd_alloc_bytes;
@@ -1250,13 +1256,21 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       const DevColumn& c = pl.cols[pl.agg_cols[i].col];
       use_private = !c.is_raw && c.vkind == kValI32 && c.bits <= 31 && (!pl.agg_cols[i].need_sum || c.is_plane);
     }
+    // Raw columns and 8-byte dictionaries: the same lane-private layout, read with 16-byte loads (scan_private_typed_kernel).
+    // PINOT_GPU_SCAN_TYPED_PRIVATE=0 keeps them in the LDS-staged kernel.
+    bool use_private_typed = g_engine.scan_private && g_engine.scan_typed_private && !use_private && pl.num_agg_cols > 0 && !(g_engine.flags & PG_CFG_PROFILE_WAVES);
+    for (int l = 0; l < pl.num_leaves && use_private_typed; ++l) use_private_typed = pl.leaves[l].kind <= kLeafBitmap || pl.leaves[l].kind == kLeafDocRange;
+    for (int i = 0; i < pl.num_agg_cols && use_private_typed; ++i) {
+      const DevColumn& c = pl.cols[pl.agg_cols[i].col];
+      use_private_typed = c.is_raw || (c.vkind != kValI32 && c.bits <= 31);      // every slot raw, or an 8-byte dictionary
+    }
     Geometry geo;
     const int agg_wave_cap = waves_scan_agg(pl.num_agg_cols <= 1, typed);
     finish_geometry(seg, &lw, 0, need_queue, kBlockThreads / 64, agg_wave_cap, &geo);
     int blocks = geo.blocks;
     const size_t lds = geo.lds;
-    if (use_private) {
-      const int cap = waves_scan_private(pl.num_agg_cols <= 1);
+    if (use_private || use_private_typed) {
+      const int cap = use_private_typed ? waves_scan_private_typed() : waves_scan_private(pl.num_agg_cols <= 1);
       int bpc = std::max(1, cap / (kBlockThreads / 64));
       if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
       const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
@@ -1278,6 +1292,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
     if (use_private) launch_scan_private(one, blocks, ctx->stream, sp);
+    else if (use_private_typed) launch_scan_private_typed(blocks, ctx->stream, sp);
     else launch_scan_agg(g_engine.use_dma, one, typed, blocks, geo.threads, lds, ctx->stream, sp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -1337,7 +1352,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
           }
         }
       }
-      out->dominant_kernel = use_private ? PG_KERNEL_SCAN_PRIVATE : PG_KERNEL_SCAN_AGG;
+      out->dominant_kernel = use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
       for (int c = 0; c < 4; ++c) out->profile_cycles[c] = fp.cyc[c];
       out->profile_waves = blocks * (geo.threads / 64);
       out->stats.num_docs_scanned = (int64_t)fp.count;

@@ -37,6 +37,9 @@ int waves_scan_group();
 void launch_group_private(bool lds_table, int blocks, int threads, size_t lds, hipStream_t stream, const GroupParams& gp);
 int waves_group_private();
 
+// scan_private_typed_kernel: lane-private scan for raw / 8-byte aggregated columns (pg_scan_typed.h)
+void launch_scan_private_typed(int blocks, hipStream_t stream, const ScanParams& p);
+int waves_scan_private_typed();
 // partitioned group-by for key spaces above the LDS table (pg_group_partition.h): histogram, scatter, aggregate
 void launch_group_partition_histogram(int blocks, hipStream_t stream, const PartitionParams& pp);
 void launch_group_partition_scatter(int blocks, hipStream_t stream, const PartitionParams& pp);

@@ -157,6 +157,38 @@ def main():
                Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(inv(0, 3), inv(1, 5))), check)
         report(out, "C5 same filter evaluated by scanning p,q,r", n5, sum(B(c) for c in cols), g, seg5,
                Q.QuerySpec([(Q.SUM, 3)], filter=Q.and_(Q.leaf(Q.Pred.dict_range(0, 3, 4)), Q.leaf(Q.Pred.dict_range(1, 5, 6)), Q.leaf(Q.Pred.dict_range(2, 7, 8)))), check)
+    # ---- C7: LONG / DOUBLE metric columns (dictionary-encoded and raw), the typed paths of DESIGN.md section 4.5 ----
+    if want("C7"):
+        n7 = args.rows_c5
+        t0 = time.time()
+        lib = S.load_host_library()
+        f7 = S.Column.synthetic_uniform("f", n7, np.arange(1000, dtype=np.int32), seed=2)
+        base = S.Column.synthetic_uniform("x", n7, np.arange(100000, dtype=np.int32), seed=7)       # dictIds 0..99999, 17 bits
+
+        def typed_dict(name, dict_values):
+            dict_values = np.ascontiguousarray(dict_values)
+            dictionary = np.zeros(dict_values.shape[0] * dict_values.dtype.itemsize, dtype=np.uint8)
+            lib.ph_dict_write_fixed(dict_values.ctypes.data, int(dict_values.shape[0]), dict_values.dtype.itemsize, S._u8p(dictionary))
+            return S.Column(name, _abi.PG_FWD_FIXED_BIT_DICT, base.bits, base.cardinality, base.fwd, dictionary, None, dict_values,
+                            stored_type=S.stored_type_of(dict_values.dtype))
+        d_dict = typed_dict("d_dict", np.sort(np.random.default_rng(1).normal(0, 1e6, 100000)))
+        l_wide = typed_dict("l_wide", (np.arange(100000, dtype=np.int64) * 92233720368547 - 2 ** 62))      # needs the 8-byte dictionary
+        l_narrow = typed_dict("l_narrow", (np.arange(100000, dtype=np.int64) * 1000 + 1_600_000_000_000))   # epoch millis: 31-bit range -> int32 domain
+        rng7 = np.random.default_rng(3)
+        d_raw = S.Column.raw_typed("d_raw", rng7.normal(0, 1e6, n7))
+        l_raw = S.Column.raw_typed("l_raw", rng7.integers(-2 ** 40, 2 ** 40, n7))
+        seg7 = S.SegmentData("c7", n7, [f7, d_dict, l_wide, l_narrow, d_raw, l_raw])
+        print(json.dumps({"setup": "C7 segment", "rows": n7, "generate_s": time.time() - t0}), flush=True)
+        flt = Q.leaf(Q.Pred.dict_range(0, 0, 100))
+        with engine.open(seg7) as g:
+            for ci, label in ((1, "DOUBLE dictionary (8-byte gather)"), (2, "LONG dictionary, wide (8-byte gather)"), (3, "LONG dictionary, 31-bit range (int32 domain)"),
+                              (4, "raw DOUBLE"), (5, "raw LONG")):
+                col = seg7.columns[ci]
+                report(out, "C7 SUM(%s) WHERE f < 100 (10%%): %s" % (col.name, label), n7, B(col) + B(f7), g, seg7, Q.QuerySpec([(Q.SUM, ci)], filter=flt), check)
+                report(out, "C7 SUM(%s) no filter: %s" % (col.name, label), n7, B(col), g, seg7, Q.QuerySpec([(Q.SUM, ci)]), check)
+            report(out, "C7 MIN(d_raw), MAX(d_raw) WHERE f < 100: raw DOUBLE", n7, B(d_raw) + B(f7), g, seg7, Q.QuerySpec([(Q.MIN, 4), (Q.MAX, 4)], filter=flt), check)
+        del seg7
+
     if args.out:
         with open(args.out, "w") as fh:
             for rec in out:
