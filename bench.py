@@ -12,7 +12,9 @@ in Pinot's on-disk layout and copied to HBM by pg_segment_open before the timed 
 
 Launch:  python bench.py --gpus 1 --steps 20 --warmup 3
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  At N=1 the line also carries `cpu_baseline` (the C oracle on one host core over the same full
+workload -- it doubles as the parity check) and `cpu_baseline_all_cores` (the workload split into one segment per host core, the way
+the reference's combine operator runs segments).
 """
 import argparse
 import ctypes as C
@@ -175,6 +177,7 @@ def main():
                                                 "(one segment = one thread, as in BaseCombineOperator); %.1f s" % (n, cpu_s),
                                       "host_cores_available": os.cpu_count()}
             result["parity"] = {"bit_exact_vs_oracle": bool(osum == last[0] and ocount == last[1]), "oracle_sum": osum, "gpu_sum": last[0]}
+            result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(seg, spec, n, osum, ocount)
     if args.extra and rank == 0 and world == 1:
         run_extra(gseg, seg, n, lib, Q, _abi, C)
     gseg.close()
@@ -183,6 +186,43 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def cpu_baseline_all_cores(seg, spec, n, want_sum, want_count):
+    """the reference runs one segment per thread (BaseCombineOperator), so the honest all-core number splits
+    the workload into as many equal segments as the host has cores.  The same packed columns are sliced at multiples of 8 docs
+    (8 docs of a b-bit column are b whole bytes), the C oracle runs on every slice in its own thread, the partials are merged."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    from pinot_amd import _abi
+    from pinot_amd import segment as S
+    cores = os.cpu_count() or 1
+    bounds = [min(n, ((n * i // cores) + 7) // 8 * 8) for i in range(cores)] + [n]
+    slices = []
+    for i in range(cores):
+        lo, hi = bounds[i], bounds[i + 1]
+        if hi <= lo:
+            continue
+        cols = []
+        for c in seg.columns:
+            first = lo * c.bits // 8
+            cols.append(S.Column(c.name, c.encoding, c.bits, c.cardinality, c.fwd[first:first + ((hi - lo) * c.bits + 7) // 8 + 8], c.dictionary, None, c.dict_values,
+                                 stored_type=c.stored_type))
+        slices.append(S.SegmentData("slice%d" % i, hi - lo, cols))
+
+    def run(part):
+        res = _abi.pg_result()
+        rc = oracle.execute_raw(part, spec, res)
+        out = (rc, int(res.aggregations[0].sum_i64), int(res.aggregations[0].count)) if rc == 0 else (rc, 0, 0)
+        oracle.load().po_result_free(C.byref(res))
+        return out
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        parts = list(pool.map(run, slices))
+    cpu_s = time.perf_counter() - t0
+    ok = all(rc == 0 for rc, _, _ in parts) and sum(p[1] for p in parts) == want_sum and sum(p[2] for p in parts) == want_count
+    return {"value": n / cpu_s, "unit": "rows/s", "cores": cores, "kind": "port", "merged_result_matches": bool(ok),
+            "sample": "the full workload split into %d equal segments, one oracle thread per segment, partials merged; %.2f s" % (len(slices), cpu_s)}
 
 
 def run_extra(gseg, seg, n, lib, Q, _abi, C):

@@ -157,6 +157,27 @@ def main():
                Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(inv(0, 3), inv(1, 5))), check)
         report(out, "C5 same filter evaluated by scanning p,q,r", n5, sum(B(c) for c in cols), g, seg5,
                Q.QuerySpec([(Q.SUM, 3)], filter=Q.and_(Q.leaf(Q.Pred.dict_range(0, 3, 4)), Q.leaf(Q.Pred.dict_range(1, 5, 6)), Q.leaf(Q.Pred.dict_range(2, 7, 8)))), check)
+    # ---- C5 dense variant: C = 2 / 4 / 8 (bitmap containers; 1/64 of the docs survive the AND) ----
+    if want("C5d"):
+        n5d = args.rows_c5
+        t0 = time.time()
+        dcols = []
+        for name, card, seed in (("p2", 2, 21), ("q4", 4, 22), ("r8", 8, 23)):
+            ids = S.synthetic_dict_ids(seed, 0, n5d, card)
+            dcols.append(S.Column.from_dict_ids(name, np.arange(card, dtype=np.int32), ids, with_inverted=True))
+            del ids
+        v5d = S.Column.synthetic_uniform("v", n5d, (np.arange(100000, dtype=np.int64) * 7 + 3).astype(np.int32), seed=1)
+        seg5d = S.SegmentData("c5d", n5d, dcols + [v5d])
+        print(json.dumps({"setup": "C5d segment", "rows": n5d, "generate_s": time.time() - t0, "posting_bytes": [int(c.inverted.nbytes) for c in dcols]}), flush=True)
+        with engine.open(seg5d) as g:
+            post = sum(c.inverted.nbytes / c.cardinality for c in dcols)
+            bitmaps = 3 * 2 * ((n5d + 7) // 8)
+            report(out, "C5d SUM(v) WHERE p2=1 AND q4=2 AND r8=5 (inverted, dense: 1/64 survive)", n5d, post + bitmaps + min(B(v5d), (n5d // 64) * 64), g, seg5d,
+                   Q.QuerySpec([(Q.SUM, 3)], filter=Q.and_(inv(0, 1), inv(1, 2), inv(2, 5))), check)
+            report(out, "C5d same filter evaluated by scanning p2,q4,r8", n5d, sum(B(c) for c in dcols) + B(v5d), g, seg5d,
+                   Q.QuerySpec([(Q.SUM, 3)], filter=Q.and_(Q.leaf(Q.Pred.dict_range(0, 1, 2)), Q.leaf(Q.Pred.dict_range(1, 2, 3)), Q.leaf(Q.Pred.dict_range(2, 5, 6)))), check)
+        del seg5d, dcols
+
     # ---- C7: LONG / DOUBLE metric columns (dictionary-encoded and raw), the typed paths of DESIGN.md section 4.5 ----
     if want("C7"):
         n7 = args.rows_c5
