@@ -419,6 +419,7 @@ class GpuFilteredAggregationOperator : public Operator {
       : _segment(seg), _queryContext(std::move(qc)), _lanes(std::move(lanes)) {}
 
   ResultsBlock nextBlock() override {
+    if (!_queryContext.groupByExpressions.empty()) return nextGroupByBlock();
     ResultsBlock block;
     block.isGroupBy = false;
     for (const auto& a : _queryContext.aggregations) block.aggregation.functions.emplace_back(a.function, a.column, _queryContext.nullHandlingEnabled);
@@ -436,7 +437,54 @@ class GpuFilteredAggregationOperator : public Operator {
     _stats = block.stats;
     return block;
   }
-  std::string toExplainString() const override { return "GPU_AGGREGATE_FILTERED"; }
+  // FilteredGroupByOperator (core/operator/query/FilteredGroupByOperator.java:108-150): the lanes share one group key generator, so
+  // the result holds every group some lane saw; a function whose lane never saw a group keeps its holder's default there
+  // (COUNT 0, SUM 0.0, MIN +inf, MAX -inf, AVG (0, 0)).  Raw group ids are the same in every lane: rows are merged on them.
+  ResultsBlock nextGroupByBlock() {
+    ResultsBlock block;
+    block.isGroupBy = true;
+    GroupByResultsBlock& g = block.groupBy;
+    g.groupByColumns = _queryContext.groupByExpressions;
+    for (const auto& a : _queryContext.aggregations) g.functions.emplace_back(a.function, a.column, _queryContext.nullHandlingEnabled);
+    pg_agg_value empty;
+    memset(&empty, 0, sizeof(empty));
+    empty.min = INFINITY; empty.max = -INFINITY;
+    std::vector<IntermediateResult> defaults;
+    for (const auto& f : g.functions) defaults.push_back(AggregationFunction(f.getType(), f.getColumn()).fromDevice(empty));
+    std::map<int, size_t> rowOf;                          // raw group id -> row
+    for (auto& lane : _lanes) {
+      ResultsBlock b = lane.op->nextBlock();
+      for (size_t r = 0; r < b.groupBy.groupKeys.size(); ++r) {
+        const GroupKey& key = b.groupBy.groupKeys[r];
+        auto it = rowOf.find(key.groupId);
+        if (it == rowOf.end()) {
+          it = rowOf.emplace(key.groupId, g.groupKeys.size()).first;
+          g.groupKeys.push_back(key);
+          g.results.push_back(defaults);
+        }
+        for (size_t i = 0; i < lane.positions.size(); ++i) g.results[it->second][(size_t)lane.positions[i]] = b.groupBy.results[r][i];
+      }
+      block.stats.numDocsScanned += b.stats.numDocsScanned;
+      block.stats.numEntriesScannedInFilter += b.stats.numEntriesScannedInFilter;
+      block.stats.numEntriesScannedPostFilter += b.stats.numEntriesScannedPostFilter;
+      block.stats.numTotalDocs = b.stats.numTotalDocs;
+      block.numGroupsLimitReached = block.numGroupsLimitReached || b.numGroupsLimitReached;
+      block.deviceMs += b.deviceMs;
+      block.kernelMs += b.kernelMs;
+    }
+    // ascending raw group id, like every other group-by block of this path
+    std::vector<size_t> order(g.groupKeys.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b2) { return g.groupKeys[a].groupId < g.groupKeys[b2].groupId; });
+    std::vector<GroupKey> keys;
+    std::vector<std::vector<IntermediateResult>> rows;
+    for (size_t i : order) { keys.push_back(std::move(g.groupKeys[i])); rows.push_back(std::move(g.results[i])); }
+    g.groupKeys = std::move(keys);
+    g.results = std::move(rows);
+    _stats = block.stats;
+    return block;
+  }
+  std::string toExplainString() const override { return _queryContext.groupByExpressions.empty() ? "GPU_AGGREGATE_FILTERED" : "GPU_GROUP_BY_FILTERED"; }
   ExecutionStatistics getExecutionStatistics() const override { return _stats; }
   const ImmutableSegment* getIndexSegment() const override { return _segment; }
 
@@ -471,7 +519,6 @@ std::unique_ptr<PlanNode> GpuPlanMaker::makeSegmentPlanNode(const SegmentContext
   bool anyFiltered = false;
   for (const auto& a : qc.aggregations) anyFiltered |= a.hasFilter;
   if (!anyFiltered) return std::make_unique<GpuAggregationPlanNode>(seg, qc, lowerQuery(*seg, qc));
-  if (!qc.groupByExpressions.empty()) throw UnsupportedOperationException("FILTER (WHERE ...) aggregations under GROUP BY keep the CPU plan (FilteredGroupByOperator)");
   std::vector<std::string> keys;                       // lane order = first appearance, the unfiltered lane keyed ""
   std::vector<QueryContext> laneQueries;
   std::vector<std::vector<int>> positions;

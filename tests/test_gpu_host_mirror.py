@@ -91,9 +91,18 @@ def test_filtered_aggregations_run_as_swim_lanes(golden_segments):
         # and through the combine over 4 copies of the segment
         combined = host.execute_sql(segs, sql, max_execution_threads=4)["combined"]
         assert combined["final"][1] == 4.0 * lane0["intermediate"][0] and combined["final"][0] == 4.0 * lane1["intermediate"][0]
-    with pytest.raises(host.HostError) as e:
-        host.execute_sql(segs[:1], f"SELECT SUM(column1) FILTER (WHERE {f1}) FROM testTable GROUP BY column9")
-    assert e.value.status == 2
+    # under GROUP BY (FilteredGroupByOperator): the union of the lanes' groups; a function whose lane never saw a group keeps its default
+    sql = f"SELECT SUM(column1) FILTER (WHERE {f1}), COUNT(*), MAX(column3) FILTER (WHERE {f2}), AVG(column7) FILTER (WHERE {f1}) FROM testTable{main} GROUP BY column9"
+    got = host.execute_sql(segs[:1], sql)["segments"][0]
+    lane0 = {tuple(r["key"]): r["intermediate"] for r in host.execute_sql(segs[:1], f"SELECT COUNT(*) FROM testTable{main} GROUP BY column9")["segments"][0]["groups"]}
+    lane1 = {tuple(r["key"]): r["intermediate"] for r in host.execute_sql(segs[:1], f"SELECT SUM(column1), AVG(column7) FROM testTable{main} AND ({f1}) GROUP BY column9")["segments"][0]["groups"]}
+    lane2 = {tuple(r["key"]): r["intermediate"] for r in host.execute_sql(segs[:1], f"SELECT MAX(column3) FROM testTable{main} AND ({f2}) GROUP BY column9")["segments"][0]["groups"]}
+    rows = {tuple(r["key"]): r["intermediate"] for r in got["groups"]}
+    assert set(rows) == set(lane0) | set(lane1) | set(lane2) and len(lane1) < len(lane0)
+    for key, row in rows.items():
+        s1, a7 = lane1.get(key, [0.0, [0.0, 0]])
+        assert row == [s1, lane0.get(key, [0])[0], lane2.get(key, ["-Infinity"])[0], a7], key
+    assert [r["key"] for r in got["groups"]] == sorted(r["key"] for r in got["groups"])
 
 
 def test_plan_time_rejection_and_errors(golden_segments):
