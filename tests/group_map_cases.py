@@ -16,7 +16,7 @@ def wide_group_segment(rng, num_docs, cards=(700, 900), skew=False):
         cols.append(col)
         ids.append(kid.astype(np.int64))
     v = rng.integers(-1000, 100000, num_docs).astype(np.int32)
-    d = rng.normal(0.0, 1e6, num_docs)
+    d = rng.normal(0.0, 1e4, num_docs)      # |values| well under helpers.FP_VALUE_SCALE: the atomics add in any order
     f = rng.integers(0, 1000, num_docs).astype(np.int32)
     cols += [S.Column.dict_encoded("v", v), S.Column.dict_encoded_typed("d", d), S.Column.dict_encoded("f", f)]
     raw = np.zeros(num_docs, dtype=np.int64)

@@ -1,5 +1,7 @@
 """GPU parity for group-by key spaces above the array-based threshold: one direct-indexed HBM table slot per raw key, device-side
 compaction, and the reference's numGroupsLimit rule (the first keys in docId order survive)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -57,6 +59,8 @@ def test_num_groups_limit_keeps_the_first_keys_in_doc_order(engine, limit):
 
 def test_partitioned_path_on_a_segment_large_enough_to_take_it(engine):
     """>= 4 Mi docs: the docs are first partitioned by key range and every partition is aggregated in LDS (pg_group_partition.h)."""
+    # the environment switches that route group-bys elsewhere (used to test the fallbacks) turn the kernel-name checks off
+    default_routing = not any(os.environ.get(k) for k in ("PINOT_GPU_GROUP_PARTITION", "PINOT_GPU_GROUP_PRIVATE", "PINOT_GPU_SCAN_PRIVATE"))
     rng = np.random.default_rng(77)
     seg, raw, v, d, f = GM.wide_group_segment(rng, 5_000_000, cards=(700, 900), skew=True)
     ci = seg.column_index
@@ -73,7 +77,7 @@ def test_partitioned_path_on_a_segment_large_enough_to_take_it(engine):
                 spec = Q.QuerySpec(aggs, filter=flt, group_by=keys, num_groups_limit=1_000_000)
                 got, want = gseg.execute(spec), oracle.execute(seg, spec)
                 H.assert_results_equal(got, want)
-                assert got.dominant_kernel == "group_partition_scatter_kernel"
+                assert got.dominant_kernel == "group_partition_scatter_kernel" or not default_routing
         # the limit rule on top of the partitioned table
         spec = Q.QuerySpec([(Q.SUM, ci("v"))], group_by=keys, num_groups_limit=5000)
         got = gseg.execute(spec)
