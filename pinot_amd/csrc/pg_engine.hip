@@ -1136,14 +1136,15 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
                               uint64_t* host_bitmap, int64_t host_bitmap_words, int64_t* out_cardinality, bool allow_metadata_plan = true) {
   if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");
   if (!seg || !q) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
-  (void)d_out_bitmap_request;
+  // d_out_bitmap_request: like host_bitmap, but the filter's doc-order bitmap is copied device to device into the caller's
+  // buffer ((num_docs + 63) / 64 words, any stream-ordered device memory) and never visits the host.
   HIP_TRY(hipSetDevice(seg->device));
   ExecCtx* ctx = nullptr;
   pg_status st = acquire_ctx(seg, &ctx);
   if (st != PG_OK) return st;
   CtxGuard guard{seg, ctx};
 
-  const bool want_bitmap = host_bitmap != nullptr;
+  const bool want_bitmap = host_bitmap != nullptr || d_out_bitmap_request != nullptr;
   const int na = want_bitmap ? 0 : q->num_aggregations;
   const int ng = want_bitmap ? 0 : q->num_group_by;
   if (na < 0 || ng < 0 || (na > 0 && !q->aggregations) || (ng > 0 && !q->group_by_columns)) return fail(PG_ERR_INVALID_ARGUMENT, "bad aggregation / group-by lists");
@@ -1301,8 +1302,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (!g_engine.direct_result) HIP_TRY(hipMemcpyAsync(ctx->h_partial, ctx->d_partials + blocks, sizeof(BlockPartial), hipMemcpyDeviceToHost, ctx->stream));
     if (want_bitmap) {
       const int64_t need = ((int64_t)seg->num_docs + 63) / 64;
-      if (host_bitmap_words < need) return fail(PG_ERR_INVALID_ARGUMENT, "bitmap buffer has %lld words, need %lld", (long long)host_bitmap_words, (long long)need);
-      if (need) HIP_TRY(hipMemcpyAsync(host_bitmap, ctx->d_bitmaps[0], (size_t)need * 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (d_out_bitmap_request) {
+        if (need) HIP_TRY(hipMemcpyAsync(d_out_bitmap_request, ctx->d_bitmaps[0], (size_t)need * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      } else {
+        if (host_bitmap_words < need) return fail(PG_ERR_INVALID_ARGUMENT, "bitmap buffer has %lld words, need %lld", (long long)host_bitmap_words, (long long)need);
+        if (need) HIP_TRY(hipMemcpyAsync(host_bitmap, ctx->d_bitmaps[0], (size_t)need * 8, hipMemcpyDeviceToHost, ctx->stream));
+      }
     }
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1611,29 +1616,43 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if ((long long)total > bound) {
         // More groups than the reference would have created: it hands out group ids in order of first appearance (docId order)
         // and drops the docs of later keys, so the survivors are the `bound` groups whose first doc comes earliest.
-        std::vector<uint64_t> filter_words;
         unsigned long long* d_filter = nullptr;
         if (q->num_filter_nodes > 0) {
-          filter_words.assign(((size_t)seg->num_docs + 63) / 64 + 1, 0ull);
-          int64_t card = 0;
+          d_filter = (unsigned long long*)scratch.alloc((((size_t)seg->num_docs + 63) / 64 + 1) * 8);
+          if (!d_filter) return fail(PG_ERR_OUT_OF_MEMORY, "group-by first-doc pass: filter bitmap");
           pg_query fq = *q;
           fq.num_aggregations = 0; fq.num_group_by = 0;
-          st = execute_impl(seg, &fq, nullptr, nullptr, filter_words.data(), (int64_t)filter_words.size(), &card);
+          st = execute_impl(seg, &fq, nullptr, d_filter, nullptr, 0, nullptr);      // stays on the device
           if (st != PG_OK) return st;
-          d_filter = (unsigned long long*)scratch.alloc(filter_words.size() * 8);
-          if (!d_filter) return fail(PG_ERR_OUT_OF_MEMORY, "group-by first-doc pass: filter bitmap");
-          HIP_TRY(hipMemcpyAsync(d_filter, filter_words.data(), filter_words.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         }
         d_first_doc = (uint32_t*)scratch.alloc((size_t)gp.num_groups * 4);
-        uint32_t* d_present_first = (uint32_t*)scratch.alloc((size_t)total * 4);
-        if (!d_first_doc || !d_present_first) return fail(PG_ERR_OUT_OF_MEMORY, "group-by first-doc pass: %d slots", gp.num_groups);
+        if (!d_first_doc) return fail(PG_ERR_OUT_OF_MEMORY, "group-by first-doc pass: %d slots", gp.num_groups);
         HIP_TRY(hipMemsetAsync(d_first_doc, 0xFF, (size_t)gp.num_groups * 4, ctx->stream));
-        group_first_doc_kernel<<<dim3((unsigned)std::min<long long>(((long long)seg->num_docs + 255) / 256, (long long)seg->num_cus * 16)), dim3(256), 0, ctx->stream>>>(gp, d_filter, d_first_doc);
-        group_compact_kernel<<<dim3((unsigned)num_chunks), dim3(256), 0, ctx->stream>>>(gp.table_count, gp.table_acc, 0, gp.num_groups, d_first_doc, 0xFFFFFFFFu, d_chunk_offsets, total,
+        // The survivors are the distinct keys of a PREFIX of the matching docs -- the reference stops admitting keys at the doc
+        // where the bound-th one appears.  With far more groups than the limit that prefix is short, so the docs are visited in
+        // growing prefixes until `bound` keys have a first doc, not all of them.
+        uint32_t seen = 0;
+        long long done_docs = 0;
+        long long step_docs = std::max<long long>(1 << 16, 4 * bound);
+        while (done_docs < (long long)seg->num_docs && (long long)seen < bound) {
+          const long long hi = std::min<long long>((long long)seg->num_docs, done_docs + step_docs);
+          const long long span = hi - done_docs;
+          group_first_doc_kernel<<<dim3((unsigned)std::min<long long>((span + 255) / 256, (long long)seg->num_cus * 16)), dim3(256), 0, ctx->stream>>>(gp, d_filter, d_first_doc, done_docs, hi);
+          HIP_TRY(hipGetLastError());
+          done_docs = hi;
+          step_docs *= 2;
+          max_first_doc = 0xFFFFFFFEu;            // "has a first doc"
+          st = count_groups(false, &seen);
+          if (st != PG_OK) return st;
+          HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        uint32_t* d_present_first = (uint32_t*)scratch.alloc((size_t)std::max<uint32_t>(seen, 1) * 4);
+        if (!d_present_first) return fail(PG_ERR_OUT_OF_MEMORY, "group-by first-doc pass: %u groups", seen);
+        group_compact_kernel<<<dim3((unsigned)num_chunks), dim3(256), 0, ctx->stream>>>(gp.table_count, gp.table_acc, 0, gp.num_groups, d_first_doc, 0xFFFFFFFEu, d_chunk_offsets, seen,
                                                                                          nullptr, nullptr, nullptr, d_present_first);
         HIP_TRY(hipGetLastError());
-        std::vector<uint32_t> firsts((size_t)total);
-        HIP_TRY(hipMemcpyAsync(firsts.data(), d_present_first, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<uint32_t> firsts((size_t)seen);
+        HIP_TRY(hipMemcpyAsync(firsts.data(), d_present_first, (size_t)seen * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         std::nth_element(firsts.begin(), firsts.begin() + (bound - 1), firsts.end());
         max_first_doc = firsts[(size_t)bound - 1];      // first docs are distinct (a doc has one key): exactly `bound` groups pass

@@ -1898,9 +1898,9 @@ __device__ __forceinline__ uint32_t read_packed(const uint8_t* fwd, long long do
 
 // One thread per doc: atomicMin of the docId into the slot of the doc's raw key.  `bitmap` is the filter result in doc order
 // (nullptr = every doc matches).  Only runs when a query created more groups than numGroupsLimit.
-static __global__ __launch_bounds__(256) void group_first_doc_kernel(const GroupParams gp, const unsigned long long* __restrict__ bitmap, uint32_t* __restrict__ first_doc) {
-  const long long n = gp.scan.num_docs;
-  for (long long doc = (long long)blockIdx.x * blockDim.x + threadIdx.x; doc < n; doc += (long long)gridDim.x * blockDim.x) {
+static __global__ __launch_bounds__(256) void group_first_doc_kernel(const GroupParams gp, const unsigned long long* __restrict__ bitmap, uint32_t* __restrict__ first_doc,
+                                                                      long long doc_lo, long long doc_hi) {
+  for (long long doc = doc_lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; doc < doc_hi; doc += (long long)gridDim.x * blockDim.x) {
     if (bitmap && !((bitmap[doc >> 6] >> (doc & 63)) & 1ull)) continue;
     uint32_t key = 0;
     for (int c = 0; c < gp.num_group_cols; ++c) key += read_packed(gp.group_keys[c].fwd, doc, gp.group_keys[c].bits) * (uint32_t)gp.group_keys[c].mult;
