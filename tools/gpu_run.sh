@@ -66,6 +66,25 @@ configs)
   echo "== all configs =="; timeout 1500 python tools/bench_configs.py --out $OUT/configs.jsonl 2>&1 | tail -30 ;;
 sweep)
   for bpc in 2 3 4 5 6 8 10 12; do echo "== bench bpc=$bpc =="; PINOT_GPU_BLOCKS_PER_CU=$bpc timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | short; done ;;
+c6pmc)
+  echo "== rocprof pmc FETCH_SIZE / WRITE_SIZE, C6 wide group-by =="; cd /tmp && export TMPDIR=/tmp
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $OUT/pmc_c6_$ctr
+    timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_c6_$ctr -o c6 -- python $GRAFT_REPO_ROOT/tools/bench_configs.py --match "C6 SUM\(a\) GROUP BY k, f \(1M" --only c23 --no-check --no-settle > $OUT/pmc_c6_$ctr.log 2>&1
+    for f in $(find $OUT/pmc_c6_$ctr -name "*counter_collection*.csv"); do python - "$f" "$ctr" <<'PY'
+import csv, sys, collections
+per = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in csv.DictReader(open(sys.argv[1])):
+    if "group_partition" in r["Kernel_Name"] and r["Counter_Name"] == sys.argv[2]:
+        per[r["Kernel_Name"].split("(")[0]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+for k, d in per.items():
+    v = sum(d.values()) / len(d)
+    print("%-60s %s mean per launch = %.1f KiB raw  (x2 on gfx950 for FETCH_SIZE streaming reads: %.3f GB; as is: %.3f GB)" % (k, sys.argv[2], v, 2 * v * 1024 / 1e9, v * 1024 / 1e9))
+PY
+    done
+    find $OUT/pmc_c6_$ctr -name "*.csv" -size +8M -delete
+  done
+  cd $GRAFT_REPO_ROOT ;;
 c6prof)
   echo "== rocprof kernel stats, C6 wide group-by =="; cd /tmp && export TMPDIR=/tmp
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c6 -o c6 -- python $GRAFT_REPO_ROOT/tools/bench_configs.py --match "${C6_MATCH:-C6 SUM\(a\) GROUP BY k, f \(1M}" --only c23 --no-check > $OUT/prof_c6.log 2>&1
