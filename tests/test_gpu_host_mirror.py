@@ -105,6 +105,30 @@ def test_filtered_aggregations_run_as_swim_lanes(golden_segments):
     assert [r["key"] for r in got["groups"]] == sorted(r["key"] for r in got["groups"])
 
 
+def test_medium_group_by_golden_and_num_groups_limit_through_sql(golden_segments):
+    """InnerSegmentAggregationSingleValueQueriesTest.testMediumAggregationGroupBy :114-132 (78 165 raw keys: the reference's INT_MAP_BASED
+    holder) as SQL, and the numGroupsLimit option."""
+    _, segs = golden_segments
+    g = H.load_golden_queries()["inner_segment_group_by_medium"]
+    for sql, want in ((QUERY + " GROUP BY column9, column11, column12", g["unfiltered"]), (QUERY + FILTER + " GROUP BY column9, column11, column12", g["filtered"])):
+        block = host.execute_sql(segs[:1], sql)["segments"][0]
+        row = [r for r in block["groups"] if r["key"] == want["key"]]
+        assert len(row) == 1 and not block["numGroupsLimitReached"]
+        assert row[0]["intermediate"] == [want["count"], float(want["sum_column1"]), float(want["max_column3"]),
+                                          float(want["min_column6"]), [float(want["avg_column7"][0]), want["avg_column7"][1]]]
+        st = block["stats"]
+        assert (st["numDocsScanned"], st["numEntriesScannedPostFilter"], st["numTotalDocs"]) == (want["stats"][0], want["stats"][2], want["stats"][3])
+    d = H.load_golden_columns()
+    all_groups = host.execute_sql(segs[:1], "SELECT COUNT(*) FROM testTable GROUP BY column9, column11, column12")["segments"][0]
+    limited = host.execute_sql(segs[:1], "SET numGroupsLimit = 50; SELECT COUNT(*) FROM testTable GROUP BY column9, column11, column12")["segments"][0]
+    assert len(all_groups["groups"]) > 50 and len(limited["groups"]) == 50 and limited["numGroupsLimitReached"]
+    # the survivors are the first 50 distinct keys in docId order (IntGroupIdMap admits keys in order of first appearance)
+    keys = list(zip(d["column9"].tolist(), d["column11__dict"][d["column11__ids"]].tolist(), d["column12__dict"][d["column12__ids"]].tolist()))
+    first50 = list(dict.fromkeys(keys))[:50]
+    assert sorted(tuple(r["key"]) for r in limited["groups"]) == sorted(first50)
+    assert limited["stats"]["numDocsScanned"] == 30000
+
+
 def test_plan_time_rejection_and_errors(golden_segments):
     _, segs = golden_segments
     for sql, status in (("SELECT column1 FROM testTable", 2),
