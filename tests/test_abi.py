@@ -25,6 +25,22 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.pg_version()
 
 
+def test_host_library_exports_every_symbol_its_header_declares():
+    """include/pinot_host_c.h: the C entry points of the C++ host mirror (libpinot_host.so)."""
+    import ctypes as C
+    text = open(os.path.join(ROOT, "include", "pinot_host_c.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(ph_[a-z_0-9]+)\s*\(", text))
+    assert len(declared) >= 25
+    lib = C.CDLL(_abi.HOST_LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    # and nothing the library exports is missing from the header
+    import subprocess
+    exported = set(re.findall(r" T (ph_[a-z_0-9]+)", subprocess.check_output(["nm", "-D", "--defined-only", _abi.HOST_LIB_PATH]).decode()))
+    assert exported == declared, exported ^ declared
+
+
 def test_library_embeds_gfx950_code_object():
     data = open(_abi.GPU_LIB_PATH, "rb").read()
     assert b"gfx950" in data and b"scan_agg_kernel" in data
