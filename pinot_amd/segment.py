@@ -76,17 +76,16 @@ def stored_type_of(dtype):
     raise TypeError("no Pinot stored type for %s" % dtype)
 
 
-def roaring_serialize(doc_ids, num_docs):
-    """One RoaringBitmap of ascending docIds in the portable serialization, cut out of a two-posting bitmap inverted index
-    (BitmapInvertedIndexWriter layout: (C + 1) big-endian offsets, then the bitmaps) that the host writer builds."""
+def roaring_serialize(doc_ids, num_docs=None, run_optimize=True):
+    """One RoaringBitmap of ascending docIds in the portable serialization (what RoaringBitmap.serialize writes)."""
     lib = load_host_library()
-    flags = np.zeros(int(num_docs), dtype=np.int32)
-    flags[np.asarray(doc_ids, dtype=np.int64)] = 1
-    size = int(lib.ph_inverted_build(_i32p(flags), int(num_docs), 2, 1, None))
-    inv = np.zeros(size, dtype=np.uint8)
-    lib.ph_inverted_build(_i32p(flags), int(num_docs), 2, 1, _u8p(inv))
-    offsets = np.frombuffer(inv[:12].tobytes(), dtype=">i4").astype(np.int64)
-    return np.ascontiguousarray(inv[offsets[1]:offsets[2]])
+    ids = np.ascontiguousarray(doc_ids, dtype=np.int32)
+    lib.ph_roaring_serialize.restype = C.c_int64
+    lib.ph_roaring_serialize.argtypes = [C.POINTER(C.c_int32), C.c_int64, C.c_int32, C.POINTER(C.c_uint8)]
+    size = int(lib.ph_roaring_serialize(_i32p(ids), int(ids.shape[0]), int(run_optimize), None))
+    out = np.zeros(size, dtype=np.uint8)
+    lib.ph_roaring_serialize(_i32p(ids), int(ids.shape[0]), int(run_optimize), _u8p(out))
+    return out
 
 
 class Column:
