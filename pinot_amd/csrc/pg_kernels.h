@@ -9,9 +9,14 @@
 //   roaring_expand_kernel  ImmutableRoaringBitmap postings -> docId bitmap (BitmapInvertedIndexReader.getDocIds,
 //                       InvertedIndexFilterOperator.getTrues OR of postings)
 //   gather_*_kernel     ForwardIndexReader.readDictIds / Dictionary.read{Int,Double}Values for arbitrary docIds
+//   scan_private_kernel / group_private_kernel   the same roles in the lane-private layout (the kernels that normally run)
+//   group_chunk_* / group_compact_kernel / group_first_doc_kernel   IntMapBasedHolder-range results and numGroupsLimit
+//   (pg_scan_typed.h: raw and 8-byte aggregated columns; pg_group_partition.h: partitioned fill of the HBM group table)
 //
 // Data layout: columns stay in HBM byte-for-byte as Pinot writes them (big-endian, MSB-first bit stream,
-// PinotDataBitSet.java:143-170).  A wavefront owns a tile of 64*steps docs (steps = 32: 256*b bytes of a b-bit column); it
+// PinotDataBitSet.java:143-170).  Two ways of dealing a 2048-doc tile to the 64 lanes of a wavefront:
+// lane-private (lane i owns docs 32i..32i+31 = b consecutive dwords, decoded at compile-time bit positions straight from global
+// loads) and strided / LDS-staged, described next.  In the staged kernels a wavefront owns a tile of 64*steps docs (steps = 32: 256*b bytes of a b-bit column); it
 // pulls the tile with coalesced 16 B/lane LDS-DMA loads (global_load_lds_dwordx4) into its private LDS slot,
 // then every lane extracts doc 64k+lane of step k with one ds_read2_b32 + v_perm_b32 (big-endian byte
 // gather) + v_bfe_u32 -- the per-lane byte selector and bit offset are loop invariant because 64*b bits is a
