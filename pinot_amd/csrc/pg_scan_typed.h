@@ -187,12 +187,15 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void scan_private_typed_ke
   mine.count = (unsigned long long)wave_sum_i64((long long)count);
 #pragma unroll
   for (int a = 0; a < kMaxAggCols; ++a) {
-    mine.sum[a] = wave_sum_i64(acc[a].isum);
-    mine.fsum[a] = wave_sum_f64(acc[a].fsum);
-    mine.kmin[a] = wave_min_i32(acc[a].kmin);
-    mine.kmax[a] = wave_max_i32(acc[a].kmax);
-    mine.kmin64[a] = wave_min_i64(acc[a].kmin64);
-    mine.kmax64[a] = wave_max_i64(acc[a].kmax64);
+    if (a >= p.num_agg_cols) continue;             // unused slots keep the identities: six wave reductions less each
+    const DevAggCol& ac = p.agg_cols[a];
+    const bool wide_keys = ac.is_raw && ac.vkind != kValI32;
+    if (ac.need_sum) {
+      mine.sum[a] = wave_sum_i64(acc[a].isum);
+      if (ac.vkind != kValI32) mine.fsum[a] = wave_sum_f64(acc[a].fsum);
+    }
+    if (ac.need_minmax && !wide_keys) { mine.kmin[a] = wave_min_i32(acc[a].kmin); mine.kmax[a] = wave_max_i32(acc[a].kmax); }
+    if (ac.need_minmax && wide_keys) { mine.kmin64[a] = wave_min_i64(acc[a].kmin64); mine.kmax64[a] = wave_max_i64(acc[a].kmax64); }
   }
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
