@@ -12,6 +12,7 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pinot_gpu.h"
@@ -1683,7 +1684,10 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     out->group_id_upper_bound = gp.num_groups;
     out->group_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)std::max(num_present, 1));
     out->group_aggregations = (pg_agg_value*)calloc((size_t)std::max(num_present, 1) * (size_t)std::max(na, 1), sizeof(pg_agg_value));
-    for (int k = 0; k < num_present; ++k) {
+    // Turning accumulators into the reference's holder values is independent per group: large results (the IntMapBasedHolder range
+    // returns up to numGroupsLimit rows) are converted by a few host threads, each touching its own pages of the result.
+    auto convert_groups = [&](int k_begin, int k_end) {
+    for (int k = k_begin; k < k_end; ++k) {
       const unsigned long long group_docs = present_counts[(size_t)k];
       out->group_ids[k] = present_ids[(size_t)k];
       for (int a = 0; a < na; ++a) {
@@ -1708,6 +1712,18 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         else if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, (int32_t)acc, plane);
         else v.max = agg_value_double(col, (int32_t)acc, plane);
       }
+    }
+    };
+    const int convert_threads = num_present >= (1 << 16) ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (convert_threads <= 1) {
+      convert_groups(0, num_present);
+    } else {
+      std::vector<std::thread> workers;
+      for (int t = 0; t < convert_threads; ++t) {
+        const int k0 = (int)((long long)num_present * t / convert_threads), k1 = (int)((long long)num_present * (t + 1) / convert_threads);
+        workers.emplace_back(convert_groups, k0, k1);
+      }
+      for (auto& w : workers) w.join();
     }
     out->stats.num_docs_scanned = docs;
     out->stats.num_entries_scanned_in_filter = (int64_t)lw.num_scan_leaves * seg->num_docs;
