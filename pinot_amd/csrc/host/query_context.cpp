@@ -387,6 +387,10 @@ int PredicateEvaluator::getNumMatchingItems() const {
 PredicateEvaluator getPredicateEvaluator(const Predicate& predicate, const DataSource& ds) {
   PredicateEvaluator ev;
   ev.predicateType = predicate.type;
+  // IS_NULL / IS_NOT_NULL have no predicate evaluator in the reference either: FilterPlanNode.java:294-310 turns them into bitmap
+  // operators over the null value vector (lowerFilter does the same before it gets here)
+  if (predicate.type == Predicate::Type::IS_NULL || predicate.type == Predicate::Type::IS_NOT_NULL)
+    throw QueryException("IS NULL / IS NOT NULL are evaluated on the null value vector, not through a predicate evaluator");
   if (!ds.hasDictionary) {
     // raw INT / LONG column: Int / LongRawValueBasedRangePredicateEvaluator (RangePredicateEvaluatorFactory.java:68-81,331-446);
     // EQ is the degenerate range, the other raw evaluators are not offloaded.
@@ -444,6 +448,9 @@ PredicateEvaluator getPredicateEvaluator(const Predicate& predicate, const DataS
       else if (n == dict.length()) { if (ev.exclusive) ev.alwaysFalse = true; else ev.alwaysTrue = true; }
       break;
     }
+    case Predicate::Type::IS_NULL:
+    case Predicate::Type::IS_NOT_NULL:
+      break;      // rejected above
     case Predicate::Type::RANGE: {
       // SortedDictionaryBasedRangePredicateEvaluator, RangePredicateEvaluatorFactory.java:126-169
       if (!dict.isSorted()) throw UnsupportedOperationException("range predicate on a dictionary whose un-padded values are not sorted");
