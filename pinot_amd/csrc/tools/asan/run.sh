@@ -1,0 +1,15 @@
+#!/bin/bash
+# AddressSanitizer / UBSan pass over the C++ host mirror without Python (an LD_PRELOADed libasan cannot intercept __cxa_throw there):
+#   tools/asan/run.sh [segment directories...]
+# builds the two drivers against pinot_amd/csrc/host/*.cpp and runs the SQL parser / predicate lowering cases and the
+# segment-directory loader (device -1: nothing is opened on a GPU) over the directories given (tests/segment_dirs.py writes some).
+set -e
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+OUT=${TMPDIR:-/tmp}/pinot_asan
+mkdir -p "$OUT"
+FLAGS="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -pthread"
+g++ $FLAGS -o "$OUT/parser_driver" "$ROOT/tools/asan/parser_driver.cpp" "$ROOT"/pinot_amd/csrc/host/*.cpp -ldl
+g++ $FLAGS -o "$OUT/loader_driver" "$ROOT/tools/asan/loader_driver.cpp" "$ROOT"/pinot_amd/csrc/host/*.cpp -ldl
+ASAN_OPTIONS=detect_leaks=1 "$OUT/parser_driver"
+if [ $# -gt 0 ]; then ASAN_OPTIONS=detect_leaks=1 "$OUT/loader_driver" "$@"; fi
+echo "asan: clean"
