@@ -101,7 +101,7 @@ void po_bitset_write_int(uint8_t* buf, int64_t index, int num_bits, int32_t valu
   int num_bits_left = num_bits - (8 - bit_offset_in_first_byte);
   if (num_bits_left <= 0) {
     first_byte_mask &= 0xFF << -num_bits_left;
-    buf[byte_offset] = (uint8_t)((first_byte & ~first_byte_mask) | (value << -num_bits_left));
+    buf[byte_offset] = (uint8_t)((first_byte & ~first_byte_mask) | ((uint32_t)value << -num_bits_left));
   } else {
     buf[byte_offset] = (uint8_t)((first_byte & ~first_byte_mask) | (((uint32_t)value >> num_bits_left) & first_byte_mask));
     while (num_bits_left > 8) {
@@ -111,7 +111,7 @@ void po_bitset_write_int(uint8_t* buf, int64_t index, int num_bits, int32_t valu
     }
     byte_offset++;
     int last_byte = buf[byte_offset];
-    buf[byte_offset] = (uint8_t)((last_byte & (0xFF >> num_bits_left)) | (value << (8 - num_bits_left)));
+    buf[byte_offset] = (uint8_t)((last_byte & (0xFF >> num_bits_left)) | ((uint32_t)value << (8 - num_bits_left)));   /* Java's int shift wraps */
   }
 }
 
@@ -131,8 +131,12 @@ void po_fixedbit_write(uint8_t* buf, const int32_t* dict_ids, int64_t num_docs, 
 static inline int32_t fixedbit_read(const uint8_t* buf, int64_t index, int num_bits) {
   return po_bitset_read_int(buf, index, num_bits);
 }
-static inline int32_t fixedbit_read_unchecked(const uint8_t* buf, int64_t index, int num_bits) {
+/* `size` = bytes of the file: the reference's readUnchecked may look up to 7 bytes past the value (harmless inside the JVM's
+ * page-granular buffers: the extra bits are masked off); here a window that would leave the file is read byte-exactly instead,
+ * which yields the same value. */
+static inline int32_t fixedbit_read_unchecked(const uint8_t* buf, int64_t size, int64_t index, int num_bits) {
   int64_t bit_offset = index * num_bits;
+  if ((bit_offset >> 3) + 8 > size) return po_bitset_read_int(buf, index, num_bits);
   const uint8_t* p = buf + (bit_offset >> 3);
   int bit_off = (int)(bit_offset & 7);
   uint32_t mask = (num_bits == 32) ? 0xFFFFFFFFu : ((1u << num_bits) - 1u);
@@ -166,6 +170,7 @@ static void fixedbit_read32(const uint8_t* buf, int64_t index, int num_bits, int
 void po_fixedbit_read_dict_ids(const uint8_t* buf, int num_bits, int32_t num_docs, const int32_t* doc_ids,
                                int32_t length, int32_t* dict_id_buffer) {
   if (length <= 0) return;
+  const int64_t size = ((int64_t)num_docs * num_bits + 7) / 8;      /* FixedBitSVForwardIndexWriter.java:41-45: no header, no padding */
   int32_t first_doc_id = doc_ids[0];
   int32_t last_doc_id = doc_ids[length - 1];
   int32_t index = 0;
@@ -173,7 +178,7 @@ void po_fixedbit_read_dict_ids(const uint8_t* buf, int num_bits, int32_t num_doc
   if (last_doc_id - first_doc_id + 1 == length && length >= 64) {
     int32_t bulk_start = (first_doc_id + 31) & (int32_t)0xffffffe0;
     int32_t bulk_end = last_doc_id & (int32_t)0xffffffe0;
-    for (int32_t i = first_doc_id; i < bulk_start; i++) dict_id_buffer[index++] = fixedbit_read_unchecked(buf, i, num_bits);
+    for (int32_t i = first_doc_id; i < bulk_start; i++) dict_id_buffer[index++] = fixedbit_read_unchecked(buf, size, i, num_bits);
     for (int32_t i = bulk_start; i < bulk_end; i += 32) {
       fixedbit_read32(buf, i, num_bits, dict_id_buffer + index);
       index += 32;
@@ -181,13 +186,13 @@ void po_fixedbit_read_dict_ids(const uint8_t* buf, int num_bits, int32_t num_doc
   }
   /* Process the remaining docs */
   if (last_doc_id < num_docs - 2) {
-    for (int32_t i = index; i < length; i++) dict_id_buffer[i] = fixedbit_read_unchecked(buf, doc_ids[i], num_bits);
+    for (int32_t i = index; i < length; i++) dict_id_buffer[i] = fixedbit_read_unchecked(buf, size, doc_ids[i], num_bits);
   } else {
     dict_id_buffer[length - 1] = fixedbit_read(buf, last_doc_id, num_bits);
     int32_t unchecked_end = length - 2;
     if (unchecked_end >= index) {
       dict_id_buffer[unchecked_end] = fixedbit_read(buf, doc_ids[unchecked_end], num_bits);
-      for (int32_t i = index; i < unchecked_end; i++) dict_id_buffer[i] = fixedbit_read_unchecked(buf, doc_ids[i], num_bits);
+      for (int32_t i = index; i < unchecked_end; i++) dict_id_buffer[i] = fixedbit_read_unchecked(buf, size, doc_ids[i], num_bits);
     }
   }
 }

@@ -1,6 +1,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 #include "../../include/pinot_host_c.h"
 int main() {
@@ -28,6 +29,33 @@ int main() {
     char* r = ph_lower_predicate(p, dict.data(), 7, &st);
     printf("%d %s\n", st, r ? r : ph_last_error());
     if (r) ph_free(r);
+  }
+  // writers: every bit width with extreme values, all three RoaringBitmap container kinds, raw chunks
+  for (int bits = 1; bits <= 31; ++bits) {
+    const int n = 1000;
+    std::vector<int32_t> ids(n);
+    const uint32_t max = bits == 31 ? 0x7FFFFFFFu : ((1u << bits) - 1u);
+    for (int i = 0; i < n; ++i) ids[i] = (int32_t)((i % 3 == 0) ? max : ((uint32_t)i * 2654435761u) & max);
+    std::vector<uint8_t> out((size_t)ph_fixedbit_size(n, bits));
+    ph_fixedbit_pack(ids.data(), n, bits, out.data(), 3);
+    std::vector<uint8_t> gen((size_t)ph_fixedbit_size(n, bits));
+    ph_generate_packed_uniform(7, n, (int32_t)std::min<uint32_t>(max, 100000u) + 1, bits, gen.data(), 2);
+  }
+  {
+    const int n = 300000;
+    std::vector<int32_t> ids(n);
+    for (int i = 0; i < n; ++i) ids[i] = i < 100000 ? 0 : (i % 7 == 0 ? 1 : (i % 1000 == 1 ? 2 : 3));
+    const int64_t size = ph_inverted_build(ids.data(), n, 4, 1, nullptr);
+    std::vector<uint8_t> inv((size_t)size);
+    ph_inverted_build(ids.data(), n, 4, 1, inv.data());
+    std::vector<int32_t> docs;
+    for (int i = 0; i < n; i += 3) docs.push_back(i);
+    std::vector<uint8_t> rb((size_t)ph_roaring_serialize(docs.data(), (int64_t)docs.size(), 1, nullptr));
+    ph_roaring_serialize(docs.data(), (int64_t)docs.size(), 1, rb.data());
+    std::vector<int64_t> longs(5003, INT64_MIN);
+    std::vector<uint8_t> raw((size_t)ph_raw_size_fixed_v2((int32_t)longs.size(), 1000, 8));
+    ph_raw_write_fixed_v2(longs.data(), (int32_t)longs.size(), 1000, 8, raw.data());
+    printf("writers ok: inverted %lld bytes, roaring %zu bytes, raw %zu bytes\n", (long long)size, rb.size(), raw.size());
   }
   return 0;
 }

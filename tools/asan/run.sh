@@ -13,3 +13,8 @@ g++ $FLAGS -o "$OUT/loader_driver" "$ROOT/tools/asan/loader_driver.cpp" "$ROOT"/
 ASAN_OPTIONS=detect_leaks=1 "$OUT/parser_driver"
 if [ $# -gt 0 ]; then ASAN_OPTIONS=detect_leaks=1 "$OUT/loader_driver" "$@"; fi
 echo "asan: clean"
+
+# The C oracle under the sanitizers (it is C: an LD_PRELOADed libasan works with Python):
+#   gcc -O1 -g -fsanitize=address,undefined -fPIC -shared -o oracle/_build/libpinot_oracle.so oracle/pinot_oracle.c -lm
+#   LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python tools/asan/run_oracle_tests.py
+#   (cd oracle && make clean && make)      # back to the optimised build
