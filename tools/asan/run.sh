@@ -7,9 +7,17 @@ set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=${TMPDIR:-/tmp}/pinot_asan
 mkdir -p "$OUT"
-FLAGS="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -pthread"
-g++ $FLAGS -o "$OUT/parser_driver" "$ROOT/tools/asan/parser_driver.cpp" "$ROOT"/pinot_amd/csrc/host/*.cpp -ldl
-g++ $FLAGS -o "$OUT/loader_driver" "$ROOT/tools/asan/loader_driver.cpp" "$ROOT"/pinot_amd/csrc/host/*.cpp -ldl
+FLAGS="-O0 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -pthread"
+# the host sources are compiled once, in parallel, and linked into both drivers
+OBJS=""
+for src in "$ROOT"/pinot_amd/csrc/host/*.cpp "$ROOT"/tools/asan/parser_driver.cpp "$ROOT"/tools/asan/loader_driver.cpp; do
+  obj="$OUT/$(basename "$src" .cpp).o"
+  g++ $FLAGS -c -o "$obj" "$src" &
+  case "$src" in *_driver.cpp) ;; *) OBJS="$OBJS $obj" ;; esac
+done
+wait
+g++ $FLAGS -o "$OUT/parser_driver" "$OUT/parser_driver.o" $OBJS -ldl
+g++ $FLAGS -o "$OUT/loader_driver" "$OUT/loader_driver.o" $OBJS -ldl
 ASAN_OPTIONS=detect_leaks=1 "$OUT/parser_driver"
 if [ $# -gt 0 ]; then ASAN_OPTIONS=detect_leaks=1 "$OUT/loader_driver" "$@"; fi
 echo "asan: clean"
