@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=int(os.environ.get("PINOT_BENCH_ROWS", 1_000_000_000)))
     ap.add_argument("--threshold", type=int, default=100, help="f < threshold (dictIds [0, threshold) of 1000)")
+    ap.add_argument("--dictionary", default="affine", choices=["affine", "irregular", "window"],
+                    help="dictionary of v: {7k+3} (BASELINE.md C2), 100000 sorted distinct values from the whole int32 range, or from a 2^20 window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-settle", action="store_true", help="skip the 48 untimed launches that step through the GPU clock transient")
     ap.add_argument("--extra", action="store_true", help="also time the other BASELINE.md query shapes (stderr)")
@@ -67,7 +69,7 @@ def main():
 
     n = args.rows
     t0 = time.time()
-    v = S.Column.synthetic_uniform("v", n, (np.arange(100000, dtype=np.int64) * 7 + 3).astype(np.int32), seed=2 * rank + 1)
+    v = S.Column.synthetic_uniform("v", n, v_dictionary(args.dictionary), seed=2 * rank + 1)
     f = S.Column.synthetic_uniform("f", n, np.arange(1000, dtype=np.int32), seed=2 * rank + 2)
     seg = S.SegmentData("c2b_%d" % rank, n, [v, f])
     gen_s = time.time() - t0
@@ -154,6 +156,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "kernel": _abi.KERNEL_NAMES[last[4]], "kernel_ms": avg_kernel_ms,
                          "algorithmic_bytes_per_launch": algorithmic_bytes},
+            "dictionary": args.dictionary,
             "clock_settle_launches": settle,
             "hbm_GBps_whole_step": world * algorithmic_bytes * args.steps / elapsed / 1e9,
             "wave_profile": ({"waves": step.cycles[4], "cycles_per_wave": {"memory_wait": step.cycles[0] / step.cycles[4], "filter": step.cycles[1] / step.cycles[4],
@@ -186,6 +189,17 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def v_dictionary(kind, cardinality=100000):
+    """The dictionary of the summed column: BASELINE.md's arithmetic progression, or sorted distinct values without structure."""
+    import numpy as np
+    if kind == "affine":
+        return (np.arange(cardinality, dtype=np.int64) * 7 + 3).astype(np.int32)
+    rng = np.random.default_rng(20260921)
+    lo, hi = (-2 ** 31, 2 ** 31 - 1) if kind == "irregular" else (0, 2 ** 20)
+    vals = np.unique(rng.integers(lo, hi, 4 * cardinality, dtype=np.int64))
+    return np.sort(rng.permutation(vals)[:cardinality]).astype(np.int32)
 
 
 def cpu_baseline_all_cores(seg, spec, n, want_sum, want_count):

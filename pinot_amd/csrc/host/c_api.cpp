@@ -27,6 +27,7 @@ std::string jsonEscape(const std::string& s) {
 
 std::string num(double v) {
   if (std::isinf(v)) return v > 0 ? "\"Infinity\"" : "\"-Infinity\"";
+  if (std::isnan(v)) return "\"NaN\"";        // bare nan is not JSON
   char b[64];
   snprintf(b, sizeof(b), "%.17g", v);
   return b;

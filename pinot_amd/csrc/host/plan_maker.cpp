@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -143,6 +144,19 @@ IntermediateResult AggregationFunction::fromDevice(const pg_agg_value& v) const 
   return 0.0;
 }
 
+// java.lang.Math.min / max on doubles (MinAggregationFunction.merge / MaxAggregationFunction.merge): a NaN operand gives NaN, and
+// the zeros are ordered -0.0 < +0.0 -- std::fmin / fmax drop NaNs and leave the zeros' order unspecified.
+static double javaMin(double a, double b) {
+  if (a != a || b != b) return std::numeric_limits<double>::quiet_NaN();
+  if (a == 0.0 && b == 0.0) return std::signbit(a) ? a : b;
+  return a < b ? a : b;
+}
+static double javaMax(double a, double b) {
+  if (a != a || b != b) return std::numeric_limits<double>::quiet_NaN();
+  if (a == 0.0 && b == 0.0) return std::signbit(a) ? b : a;
+  return a > b ? a : b;
+}
+
 IntermediateResult AggregationFunction::merge(const IntermediateResult& a, const IntermediateResult& b) const {
   // SumAggregationFunction.merge :223-233 and friends under null handling: a null side yields the other side
   if (isNullResult(a)) return b;
@@ -150,8 +164,8 @@ IntermediateResult AggregationFunction::merge(const IntermediateResult& a, const
   switch (_type) {
     case AggregationFunctionType::COUNT: return std::get<int64_t>(a) + std::get<int64_t>(b);   // CountAggregationFunction.merge
     case AggregationFunctionType::SUM: return std::get<double>(a) + std::get<double>(b);        // SumAggregationFunction.merge :223-233
-    case AggregationFunctionType::MIN: return std::fmin(std::get<double>(a), std::get<double>(b));
-    case AggregationFunctionType::MAX: return std::fmax(std::get<double>(a), std::get<double>(b));
+    case AggregationFunctionType::MIN: return javaMin(std::get<double>(a), std::get<double>(b));      // Math.min: NaN wins, -0.0 < +0.0
+    case AggregationFunctionType::MAX: return javaMax(std::get<double>(a), std::get<double>(b));
     case AggregationFunctionType::AVG: {                                                       // AvgAggregationFunction.merge -> AvgPair.apply
       AvgPair r = std::get<AvgPair>(a);
       const AvgPair& o = std::get<AvgPair>(b);
@@ -322,7 +336,7 @@ class GpuAggregationOperator : public Operator {
       : _segment(seg), _queryContext(std::move(qc)), _lowered(std::move(lq)) {}
 
   ResultsBlock nextBlock() override {
-    pg_result res;
+    pg_result res{};      // zero-initialised: pg_execute also clears it first thing, whatever path fails
     checkStatus(gpuAbi().execute(_segment->handle(), &_lowered->query, &res), ("executing on segment " + _segment->getSegmentName()).c_str());
     ResultsBlock block;
     std::vector<AggregationFunction> functions;
@@ -450,7 +464,7 @@ class GpuFilteredAggregationOperator : public Operator {
     memset(&empty, 0, sizeof(empty));
     empty.min = INFINITY; empty.max = -INFINITY;
     std::vector<IntermediateResult> defaults;
-    for (const auto& f : g.functions) defaults.push_back(AggregationFunction(f.getType(), f.getColumn()).fromDevice(empty));
+    for (const auto& f : g.functions) defaults.push_back(AggregationFunction(f.getType(), f.getColumn(), _queryContext.nullHandlingEnabled).fromDevice(empty));
     std::map<int, size_t> rowOf;                          // raw group id -> row
     for (auto& lane : _lanes) {
       ResultsBlock b = lane.op->nextBlock();

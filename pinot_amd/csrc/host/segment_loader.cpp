@@ -222,12 +222,24 @@ std::unique_ptr<ImmutableSegment> loadSegmentDirectory(const std::string& indexD
           default: ds.dictionary = std::make_shared<DoubleDictionary>(dict.data, ds.cardinality); break;
         }
       }
+      // Which reader the reference picks is decided by the metadata, not by the file size (ForwardIndexReaderFactory.java:75-91:
+      // dictionary + single-value + isSorted -> SortedIndexReaderImpl over [start, end] pairs).  v1 names the file after the format
+      // (.sv.sorted.fwd / .sv.unsorted.fwd); in v3 the index map has one forward_index entry and isSorted says what it holds.
       Slice fwd = index.get(col, sorted ? ".sv.sorted.fwd" : ".sv.unsorted.fwd", "forward_index", &keep);
-      if (!fwd.data && !v3) fwd = index.get(col, sorted ? ".sv.unsorted.fwd" : ".sv.sorted.fwd", "forward_index", &keep);
+      bool pairFile = sorted && fwd.data != nullptr;
+      bool sniffed = false;
+      if (!fwd.data && !v3) {
+        // the other extension had to be used (metadata and file name disagree): only here the size decides
+        fwd = index.get(col, sorted ? ".sv.unsorted.fwd" : ".sv.sorted.fwd", "forward_index", &keep);
+        sniffed = true;
+      }
       if (!fwd.data && totalDocs > 0) { skip("forward index not found"); continue; }
       if (ds.bitsPerElement < 1) ds.bitsPerElement = ph_num_bits_per_value(ds.cardinality - 1);
       const uint64_t packedSize = (uint64_t)ph_fixedbit_size(totalDocs, ds.bitsPerElement);
-      if (sorted && fwd.size == 2ull * 4ull * (uint64_t)ds.cardinality && !(fwd.size == packedSize && !v3)) {
+      const uint64_t pairSize = 2ull * 4ull * (uint64_t)ds.cardinality;
+      if (sniffed) pairFile = fwd.size == pairSize && fwd.size != packedSize;
+      if (pairFile && fwd.size != pairSize) { skip("sorted forward index size does not match 8 * cardinality"); continue; }
+      if (pairFile) {
         // SortedIndexReaderImpl: [startDocId, endDocId] per dictId -> the dictId of every doc, packed like an unsorted column
         std::vector<int32_t> ids((size_t)totalDocs, 0);
         ds.isSorted = true;

@@ -20,6 +20,8 @@ constexpr int kMaxGroupCols = 3;                // ArrayBasedHolder fast paths c
 constexpr int kMaxGroupAggs = 8;                // distinct (column, SUM|MIN|MAX) pairs of a group-by query
 constexpr int kStackDepth = 8;
 constexpr int kBlockThreads = 256;              // scan_agg_kernel: at most 4 wavefronts per workgroup
+constexpr int kHistBlockThreads = 1024;         // scan_hist_kernel: 16 wavefronts share one LDS histogram
+constexpr unsigned long long kPartialHistAlarm = 1ull;   // BlockPartial.flags
 constexpr int kGroupBlockThreads = 1024;        // scan_group_kernel: up to 16 wavefronts share one LDS group table
 
 enum LeafKind : int32_t {
@@ -142,6 +144,7 @@ struct BlockPartial {
   int32_t kmin[kMaxAggCols];   // min dictId (dictionary columns: sorted dictionary => monotone), plane offset or raw value
   int32_t kmax[kMaxAggCols];
   unsigned long long cyc[4];   // PG_CFG_PROFILE_WAVES: shader cycles per wave summed: memory wait, filter, aggregate, whole loop
+  unsigned long long flags;    // OR over the workgroups: kPartialHistAlarm (pg_scan_hist.h) = a histogram counter may have left its field
   // typed columns only (scan_agg_kernel<.., kTyped = true>): double sums, and 64-bit min / max keys (raw LONG value, or the
   // order-preserving integer image of a raw FLOAT / DOUBLE value)
   double fsum[kMaxAggCols];
@@ -170,6 +173,8 @@ struct ScanParams {
   int32_t bitmap_off;          // byte offset of the two (always double-buffered) bitmap staging buffers in the wave's LDS region
   int32_t bitmap_bytes;        // bytes of one bitmap staging buffer (256 per bitmap leaf)
   int32_t num_stage;           // packed column streams to stage
+  int32_t hist_slot;           // scan_hist_kernel: index into agg_cols of the column summed through the LDS histogram
+  int32_t hist_bins;           //                   its cardinality (counters in the histogram)
   DevStage stage[kMaxCols];
   DevNode nodes[kMaxNodes];
   DevAggCol agg_cols[kMaxAggCols];

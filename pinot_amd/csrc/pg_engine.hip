@@ -61,6 +61,8 @@ struct Engine {
   bool scan_typed_private = true;     // PINOT_GPU_SCAN_TYPED_PRIVATE=0: raw / 8-byte aggregated columns stay in the LDS-staged kernel
   bool group_partition = true;        // PINOT_GPU_GROUP_PARTITION=0: key spaces above the LDS table always use direct HBM atomics
   long long partition_min_docs = 1ll << 22;   // ... =force: partition even tiny segments (tests)
+  int hist = -1;             // PINOT_GPU_HIST: -1 auto, 0 never, 1 also for arithmetic-progression dictionaries (tests)
+  int hist_bits = 0;         // PINOT_GPU_HIST_BITS: 8 / 16 force narrower counters than the cardinality needs (tests of the guard protocol)
   int group_waves = 0;       // PINOT_GPU_GROUP_WAVES: cap on wavefronts per group-by workgroup (default 16)
   std::mutex mu;
 };
@@ -107,6 +109,7 @@ struct ColumnDev {
   int shape_bits = 0;
   bool shape_is_fwd = false;
   bool plane_ready = false;
+  int hist_disabled = 0;                // a histogram counter of this column once ran into its guard: the column is summed through the other paths
 };
 
 // Per-query execution context: a stream plus reusable device scratch.  Pooled per segment so that
@@ -368,6 +371,24 @@ bool want_value_plane(const ColumnDev& col) {
   if (g_engine.value_plane == 1) return true;
   const PlaneShape ps = plane_shape(col);
   return ps.is_fwd || col.cardinality > 8192 || ps.bits - col.bits <= 8;
+}
+
+// ---- histogram SUM (pg_scan_hist.h) ----
+// SUM(col) = sum_d matches[d] * dictionary[d]: the kernel counts the matching docs per dictId in LDS and never reads a value per
+// row.  It reads exactly the dictId stream, so it is preferred over a value plane whenever the histogram fits the CU's LDS --
+// except for arithmetic-progression dictionaries, whose dictId stream already is the plane (same bytes, fewer VALU ops per doc).
+constexpr size_t kHistLdsBytes = 152 * 1024;      // of 160 KiB: the rest holds the workgroup's reduction records
+int hist_counter_bits(const ColumnDev& col) {
+  const size_t C = (size_t)std::max(col.cardinality, 1);
+  int cw = C * 4 <= kHistLdsBytes ? 32 : (C * 2 <= kHistLdsBytes ? 16 : (C <= kHistLdsBytes ? 8 : 0));
+  if (cw > 0 && g_engine.hist_bits > 0) cw = std::min(cw, g_engine.hist_bits);
+  return cw;
+}
+bool want_hist(const ColumnDev& col) {
+  if (col.encoding != PG_FWD_FIXED_BIT_DICT || col.cardinality < 1 || col.vkind != kValI32 || col.bits > 18) return false;
+  if (g_engine.hist == 0 || __atomic_load_n(&col.hist_disabled, __ATOMIC_RELAXED)) return false;
+  if (hist_counter_bits(col) == 0) return false;
+  return g_engine.hist == 1 || !plane_shape(col).is_fwd;
 }
 
 pg_status ensure_plane(pg_segment* seg, int column, ExecCtx* ctx) {
@@ -886,6 +907,10 @@ pg_status pg_init(const pg_config* config) {
   g_engine.group_pack = !(gpk && gpk[0] == '0');
   const char* gw = getenv("PINOT_GPU_GROUP_WAVES");
   g_engine.group_waves = (gw && atoi(gw) > 0) ? atoi(gw) : 0;
+  const char* hs = getenv("PINOT_GPU_HIST");
+  g_engine.hist = hs ? atoi(hs) : -1;
+  const char* hb = getenv("PINOT_GPU_HIST_BITS");
+  g_engine.hist_bits = (hb && (atoi(hb) == 8 || atoi(hb) == 16)) ? atoi(hb) : 0;
   const char* ts = getenv("PINOT_GPU_TILE_STEPS");
   g_engine.tile_steps = (ts && (atoi(ts) == 16 || atoi(ts) == 32)) ? atoi(ts) : 0;
   const char* bpc = getenv("PINOT_GPU_BLOCKS_PER_CU");
@@ -1199,9 +1224,31 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   // Columns that are summed are read through their value plane (built on first use); decided before the filter is
   // lowered so that a range predicate on the same column can be evaluated on the plane too.
   lw.plane_cols.assign((size_t)std::max(num_cols_total, 1), 0);
+  // At most one summed column goes through the LDS histogram instead (scan_hist_kernel); it needs the lane-private kernel, so the
+  // shapes that kernel does not take are ruled out here, before a plane is (not) built.
+  int hist_col = -1;
+  if (ng == 0 && !want_bitmap && g_engine.scan_private && !(g_engine.flags & PG_CFG_PROFILE_WAVES)) {
+    bool shape_ok = true;
+    int only_col = -1;                  // the histogram kernel aggregates ONE column (SUM / AVG / MIN / MAX of it, and COUNT)
+    for (int a = 0; a < na && shape_ok; ++a) {
+      const pg_aggregation& ag = q->aggregations[a];
+      if (ag.function == PG_AGG_COUNT) continue;
+      shape_ok = ag.column >= 0 && ag.column < num_cols_total && seg->cols[(size_t)ag.column].encoding == PG_FWD_FIXED_BIT_DICT &&
+                 seg->cols[(size_t)ag.column].vkind == kValI32 && (only_col < 0 || only_col == ag.column);
+      only_col = ag.column;
+    }
+    for (int i = 0; i < q->num_predicates && shape_ok && q->predicates; ++i) {
+      const pg_predicate& pr = q->predicates[i];
+      if (pr.kind == PG_PRED_RAW_RANGE) shape_ok = pr.column >= 0 && pr.column < num_cols_total && seg->cols[(size_t)pr.column].stored_type == PG_TYPE_INT;
+    }
+    for (int a = 0; a < na && shape_ok && hist_col < 0; ++a) {
+      const pg_aggregation& ag = q->aggregations[a];
+      if ((ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) && want_hist(seg->cols[(size_t)ag.column])) hist_col = ag.column;
+    }
+  }
   for (int a = 0; a < na; ++a) {
     const pg_aggregation& ag = q->aggregations[a];
-    if ((ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) && ag.column >= 0 && ag.column < num_cols_total &&
+    if ((ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) && ag.column >= 0 && ag.column < num_cols_total && ag.column != hist_col &&
         want_value_plane(seg->cols[(size_t)ag.column])) {
       st = ensure_plane(seg, ag.column, ctx);
       if (st != PG_OK) return st;
@@ -1254,10 +1301,15 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // (the per-wave phase counters of PG_CFG_PROFILE_WAVES exist in the LDS-staged kernel only)
     bool use_private = g_engine.scan_private && !typed && !(g_engine.flags & PG_CFG_PROFILE_WAVES);
     for (int l = 0; l < pl.num_leaves && use_private; ++l) use_private = pl.leaves[l].kind <= kLeafBitmap || pl.leaves[l].kind == kLeafDocRange;
+    int hist_slot = -1;
+    for (int i = 0; i < pl.num_agg_cols && hist_col >= 0; ++i) if (lw.col_of_slot[(size_t)pl.agg_cols[i].col] == hist_col * 2) hist_slot = i;
     for (int i = 0; i < pl.num_agg_cols && use_private; ++i) {
       const DevColumn& c = pl.cols[pl.agg_cols[i].col];
-      use_private = !c.is_raw && c.vkind == kValI32 && c.bits <= 31 && (!pl.agg_cols[i].need_sum || c.is_plane);
+      use_private = !c.is_raw && c.vkind == kValI32 && c.bits <= 31 && (!pl.agg_cols[i].need_sum || c.is_plane || i == hist_slot);
     }
+    const bool use_hist = use_private && hist_slot == 0 && pl.num_agg_cols == 1;      // the histogram kernel aggregates one column
+    if (hist_slot >= 0 && !use_hist) use_private = false;                           // (rare: the gather path of the LDS-staged kernel)
+    const int hist_cw = use_hist ? hist_counter_bits(seg->cols[(size_t)hist_col]) : 0;
     // Raw columns and 8-byte dictionaries: the same lane-private layout, read with 16-byte loads (scan_private_typed_kernel).
     // PINOT_GPU_SCAN_TYPED_PRIVATE=0 keeps them in the LDS-staged kernel.
     bool use_private_typed = g_engine.scan_private && g_engine.scan_typed_private && !use_private && pl.num_agg_cols > 0 && !(g_engine.flags & PG_CFG_PROFILE_WAVES);
@@ -1271,7 +1323,22 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     finish_geometry(seg, &lw, 0, need_queue, kBlockThreads / 64, agg_wave_cap, &geo);
     int blocks = geo.blocks;
     const size_t lds = geo.lds;
-    if (use_private || use_private_typed) {
+    size_t hist_lds = 0;
+    if (use_hist) {
+      // one histogram per workgroup of 16 wavefronts; as many workgroups per CU as LDS and registers admit
+      const int per_word = 32 / hist_cw;
+      hist_lds = (((size_t)(seg->cols[(size_t)hist_col].cardinality + per_word - 1) / per_word * 4) + 15) & ~(size_t)15;
+      hist_lds = std::max(hist_lds, sizeof(BlockPartial) * (kHistBlockThreads / 64));      // the reduction records reuse the counters' LDS
+      const size_t per_block = hist_lds + 256;
+      int bpc = std::max(1, std::min(waves_scan_hist(hist_cw) / (kHistBlockThreads / 64), (int)((160 * 1024 - 2048) / per_block)));
+      if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
+      const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
+      const int wpb = kHistBlockThreads / 64;
+      blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + wpb - 1) / wpb, (long long)seg->num_cus * bpc));
+      geo.threads = kHistBlockThreads;
+      sp.hist_slot = hist_slot;
+      sp.hist_bins = seg->cols[(size_t)hist_col].cardinality;
+    } else if (use_private || use_private_typed) {
       const int cap = use_private_typed ? waves_scan_private_typed() : waves_scan_private(pl.num_agg_cols <= 1);
       int bpc = std::max(1, cap / (kBlockThreads / 64));
       if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
@@ -1293,7 +1360,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
-    if (use_private) launch_scan_private(one, blocks, ctx->stream, sp);
+    if (use_hist) launch_scan_hist(hist_cw, blocks, hist_lds, ctx->stream, sp);
+    else if (use_private) launch_scan_private(one, blocks, ctx->stream, sp);
     else if (use_private_typed) launch_scan_private_typed(blocks, ctx->stream, sp);
     else launch_scan_agg(g_engine.use_dma, one, typed, blocks, geo.threads, lds, ctx->stream, sp);
     HIP_TRY(hipGetLastError());
@@ -1313,6 +1381,14 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const BlockPartial& fp = *ctx->h_partial;
+    if (use_hist && (fp.flags & kPartialHistAlarm)) {
+      // A narrow counter came within half its range of leaving its field (heavily skewed dictIds): the histogram's sum is not
+      // trusted.  The column is summed through its value plane / the gather path from now on; this query is answered again.
+      __atomic_store_n(&seg->cols[(size_t)hist_col].hist_disabled, 1, __ATOMIC_RELAXED);
+      release_ctx(seg, ctx);
+      guard.ctx = nullptr;
+      return execute_impl(seg, q, out, d_out_bitmap_request, host_bitmap, host_bitmap_words, out_cardinality, allow_metadata_plan);
+    }
     if (out_cardinality) *out_cardinality = (int64_t)fp.count;
     if (out) {
       out->num_aggregations = na;
@@ -1358,7 +1434,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
           }
         }
       }
-      out->dominant_kernel = use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
+      out->dominant_kernel = use_hist ? PG_KERNEL_SCAN_HIST : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
       for (int c = 0; c < 4; ++c) out->profile_cycles[c] = fp.cyc[c];
       out->profile_waves = blocks * (geo.threads / 64);
       out->stats.num_docs_scanned = (int64_t)fp.count;
@@ -1927,6 +2003,7 @@ static pg_status execute_null_handling(pg_segment* seg, const pg_query* q, pg_re
 
 pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_result) {
   if (!out_result) return fail(PG_ERR_INVALID_ARGUMENT, "null result");
+  memset(out_result, 0, sizeof(*out_result));     // before anything can fail: every error path below ends in pg_result_free(out_result)
   pg_status st = (query && (query->flags & PG_QUERY_NULL_HANDLING)) ? execute_null_handling(segment, query, out_result, nullptr, 0, nullptr)
                                                                   : execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr);
   if (st != PG_OK) pg_result_free(out_result);

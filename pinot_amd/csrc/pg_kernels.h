@@ -779,6 +779,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
   __syncthreads();   // all waves are done with their staging slots; reuse the start of LDS for the reduction
   BlockPartial* red = reinterpret_cast<BlockPartial*>(smem);
   BlockPartial mine;
+  mine.flags = 0ull;
   mine.count = (unsigned long long)wave_sum_i64((long long)count);
 #pragma unroll
   for (int a = 0; a < kMaxAggCols; ++a) {
@@ -827,6 +828,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
 // the grid size, so a given launch geometry always returns the same floating-point sum.
 __device__ __forceinline__ void partial_identity(BlockPartial& acc) {
   acc.count = 0;
+  acc.flags = 0;
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc.cyc[c] = 0;
 #pragma unroll
@@ -837,6 +839,7 @@ __device__ __forceinline__ void partial_identity(BlockPartial& acc) {
 }
 __device__ __forceinline__ void partial_merge(BlockPartial& acc, const BlockPartial& b) {
   acc.count += b.count;
+  acc.flags |= b.flags;
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc.cyc[c] += b.cyc[c];
 #pragma unroll
@@ -857,6 +860,7 @@ static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel
   partial_identity(acc);
   for (int i = threadIdx.x; i < num_blocks; i += blockDim.x) partial_merge(acc, partials[i]);
   acc.count = (unsigned long long)wave_sum_i64((long long)acc.count);
+  acc.flags = __builtin_amdgcn_ballot_w64(acc.flags != 0ull) != 0ull ? 1ull : 0ull;      // single-bit vocabulary (kPartialHistAlarm)
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc.cyc[c] = (unsigned long long)wave_sum_i64((long long)acc.cyc[c]);
 #pragma unroll
@@ -1729,7 +1733,8 @@ static __global__ __launch_bounds__(kBlockThreads) void roaring_expand_kernel(co
   } else {
     for (uint32_t r = threadIdx.x; r < c.num_runs; r += blockDim.x) {
       const uint32_t start = load_u16(payload + 2 + 4 * r);
-      const uint32_t end = start + load_u16(payload + 4 + 4 * r);   // inclusive
+      uint32_t end = start + load_u16(payload + 4 + 4 * r);         // inclusive
+      end = end > 65535u ? 65535u : end;                            // a malformed run must not write past the 1024-word window
       for (uint32_t wi = start >> 6; wi <= (end >> 6); ++wi) {
         const uint32_t lo = wi == (start >> 6) ? (start & 63u) : 0u;
         const uint32_t hi = wi == (end >> 6) ? (end & 63u) : 63u;

@@ -1,0 +1,194 @@
+// scan_hist_kernel: SUM over a dictionary column WITHOUT reading a single dictionary value per row.
+//
+// What it replaces: Dictionary.readIntValues (sspi/index/reader/Dictionary.java:207-211: one dictionary lookup per matching doc)
+// feeding SumAggregationFunction.aggregate (core/query/aggregation/function/SumAggregationFunction.java:69-157).  On MI355X a
+// lookup in a 400 KB dictionary is an L2 gather (2.87e11 /s measured: each one moves a 128-byte line into the L1 for 4 useful
+// bytes), and a value plane of a dictionary whose values span the int range is 32 bits per doc -- twice the dictId stream.
+// Both stay below half the HBM roofline on `SUM(v) WHERE f < t`.  But
+//
+//        SUM(v) over the matching docs  =  sum over dictIds d of  matches[d] * dictionary[d],
+//
+// so the kernel only COUNTS the matching docs per dictId, in a histogram in the CU's LDS (160 KB), and multiplies by the
+// dictionary once per workgroup at the end: HBM traffic is exactly the dictId streams (the algorithmic bytes), nothing extra is
+// resident in HBM, and the values are touched C times per workgroup instead of once per row.
+//
+// Counters.  One workgroup per CU keeps the whole histogram:
+//     CW = 32   C <= 38 912    plain ds_add_u32, cannot overflow (a workgroup sees < 2^31 docs)
+//     CW = 16   C <= 77 824    two counters per dword
+//     CW =  8   C <= 155 648   four counters per dword (C = 100 000, BASELINE's `v`, lives here: 100 KB)
+// Narrow counters use the top bit as a guard: the returned old value of every add is watched; a wave that sees a counter at
+// or above G = 2^(CW-1) sweeps its tile and CLAIMS the guard bit with an atomic AND -- whoever clears it owns G matches of that
+// dictId and adds G * dictionary[d] to a private spill sum.  A counter can only leave its field after G further adds that all
+// return values >= 1.5 G; any such value raises the kernel's alarm flag and the engine answers the query through the gather /
+// value-plane path instead (and remembers the column).  So the result is either exact or not used: never silently wrong.
+// Uniform-ish data never gets near G (BASELINE's C2b: ~4 matches per counter and workgroup).
+//
+// Everything else (lane-private ownership, filter program, decode at compile-time bit positions) is scan_private_kernel's.
+#pragma once
+#include "pg_kernels.h"
+
+namespace pg {
+
+template <int CW> struct HistField;
+template <> struct HistField<32> {
+  static __device__ __forceinline__ uint32_t word(uint32_t d) { return d; }
+  static __device__ __forceinline__ uint32_t shift(uint32_t) { return 0u; }
+};
+template <> struct HistField<16> {
+  static __device__ __forceinline__ uint32_t word(uint32_t d) { return d >> 1; }
+  static __device__ __forceinline__ uint32_t shift(uint32_t d) { return (d & 1u) << 4; }
+};
+template <> struct HistField<8> {
+  static __device__ __forceinline__ uint32_t word(uint32_t d) { return d >> 2; }
+  static __device__ __forceinline__ uint32_t shift(uint32_t d) { return (d & 3u) << 3; }
+};
+
+// Sixteen docs (half H) of the lane's chunk of the summed column: one LDS add of the match bit per doc.
+// mx: running maximum of the counter values the adds returned (CW < 32).
+template <int B, int H, int CW>
+__device__ __forceinline__ void hist16_private(const uint32_t* __restrict__ lane_words, uint32_t m, uint32_t* hist, uint32_t& mx,
+                                               bool need_minmax, uint32_t& umin, uint32_t& umax) {
+  uint32_t v[16];
+  decode16_private<B, H>(lane_words, v);
+  if constexpr (CW == 32) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      __hip_atomic_fetch_add(hist + v[j], __builtin_amdgcn_ubfe(m, 16 * H + j, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    uint32_t old[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      old[j] = __hip_atomic_fetch_add(hist + HistField<CW>::word(v[j]), __builtin_amdgcn_ubfe(m, 16 * H + j, 1) << HistField<CW>::shift(v[j]), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t f = __builtin_amdgcn_ubfe(old[j], HistField<CW>::shift(v[j]), CW);
+      mx = f > mx ? f : mx;
+    }
+  }
+  if (need_minmax) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t all = (uint32_t)__builtin_amdgcn_sbfe((int)m, 16 * H + j, 1);     // ~0 when the doc matches
+      const uint32_t hi = v[j] & all, lo = v[j] | ~all;
+      umax = hi > umax ? hi : umax;
+      umin = lo < umin ? lo : umin;
+    }
+  }
+}
+
+// Histograms hold at most 155 648 counters: 18-bit dictIds.
+template <int CW>
+__device__ __forceinline__ void hist_private_dispatch(int b, const uint32_t* lane_words, uint32_t m, uint32_t* hist, uint32_t& mx, bool need_minmax,
+                                                      uint32_t& umin, uint32_t& umax) {
+  switch (b) {
+#define PG_CASE(B) case B: hist16_private<B, 0, CW>(lane_words, m, hist, mx, need_minmax, umin, umax); \
+                           hist16_private<B, 1, CW>(lane_words, m, hist, mx, need_minmax, umin, umax); break;
+    PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10)
+    PG_CASE(11) PG_CASE(12) PG_CASE(13) PG_CASE(14) PG_CASE(15) PG_CASE(16) PG_CASE(17) PG_CASE(18)
+#undef PG_CASE
+    default: break;
+  }
+}
+
+// Doc j of the lane's chunk, any width, bit position computed at run time (the rare sweep only).
+__device__ __forceinline__ uint32_t decode_private_generic(const uint32_t* lane_words, int b, int j) {
+  const uint32_t bit = (uint32_t)j * (uint32_t)b;
+  const uint32_t w = bit >> 5, o = bit & 31u;
+  const unsigned long long x = ((unsigned long long)__builtin_bswap32(lane_words[w]) << 32) | (unsigned long long)__builtin_bswap32(lane_words[w + 1]);   // w + 1 may be the next lane's (or the padding's) first dword
+  return (uint32_t)(x >> (64u - o - (uint32_t)b)) & ((1u << b) - 1u);
+}
+
+// A wave saw a guarded counter: claim the guard bit of every counter its matching docs of this tile point at.
+template <int CW>
+__device__ __noinline__ void hist_sweep(const uint32_t* lane_words, int b, uint32_t m, uint32_t* hist, const int32_t* __restrict__ dict, long long& spill,
+                                        uint32_t& alarm) {
+  constexpr uint32_t G = 1u << (CW - 1), FM = (CW == 32) ? 0xFFFFFFFFu : ((1u << CW) - 1u);
+#pragma unroll 1
+  for (int j = 0; j < 32; ++j) {
+    if (!((m >> j) & 1u)) continue;
+    const uint32_t d = decode_private_generic(lane_words, b, j);
+    const uint32_t w = HistField<CW>::word(d), s = HistField<CW>::shift(d);
+    const uint32_t cur = (__hip_atomic_load(hist + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> s) & FM;
+    if (cur < G) continue;
+    const uint32_t before = (__hip_atomic_fetch_and(hist + w, ~(G << s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> s) & FM;
+    if (before & G) spill += (long long)G * (long long)dict[d];      // this lane cleared the bit: it owns G matches of dictId d
+    if (before >= G + G / 2) alarm = 1u;
+  }
+}
+
+template <int CW>
+__global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const ScanParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t hist[];      // the only LDS object: counter addresses need no base add
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  const long long total_waves = (long long)gridDim.x * waves_per_block;
+  const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
+  const int C = p.hist_bins;
+  constexpr int kPerWord = 32 / CW;
+  const int hist_words = (C + kPerWord - 1) / kPerWord;
+  for (int w = threadIdx.x; w < hist_words; w += blockDim.x) hist[w] = 0u;
+  __syncthreads();
+
+  unsigned long long count = 0;
+  uint32_t umin = 0xFFFFFFFFu, umax = 0u;
+  long long spill = 0;
+  uint32_t alarm = 0;
+  // the one aggregated column (the engine sends other shapes to scan_private_kernel): summed through the histogram, MIN / MAX on
+  // its dictIds in registers
+  const DevAggCol& ac = p.agg_cols[0];
+
+  for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
+    uint32_t m = eval_filter_private(p, tile, lane);
+    const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
+    m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
+    count += (unsigned)__builtin_popcount(m);
+    if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(ac.fwd + tile * (256ll * ac.bits)) + lane * ac.bits;
+    uint32_t mx = 0;
+    hist_private_dispatch<CW>(ac.bits, words, m, hist, mx, ac.need_minmax != 0, umin, umax);
+    if constexpr (CW < 32) {
+      constexpr uint32_t G = 1u << (CW - 1);
+      alarm |= mx >= G + G / 2 ? 1u : 0u;
+      if (__builtin_amdgcn_ballot_w64(mx >= G) != 0ull) hist_sweep<CW>(words, ac.bits, m, hist, ac.dict, spill, alarm);
+    }
+  }
+
+  // SUM = sum_d matches[d] * dictionary[d]: every thread folds its share of the counters (the guard bit is part of the count)
+  __syncthreads();
+  long long hsum = spill;
+  {
+    const int32_t* __restrict__ dict = ac.dict;
+    constexpr uint32_t FM = (CW == 32) ? 0xFFFFFFFFu : ((1u << CW) - 1u);
+    for (int w = threadIdx.x; w < hist_words; w += blockDim.x) {
+      const uint32_t h = hist[w];
+      if (h == 0u) continue;
+#pragma unroll
+      for (int k = 0; k < kPerWord; ++k) {
+        const int d = w * kPerWord + k;
+        const uint32_t c = (h >> (k * CW)) & FM;
+        if (c != 0u && d < C) hsum += (long long)c * (long long)dict[d];
+      }
+    }
+  }
+
+  BlockPartial mine;
+  partial_identity(mine);
+  mine.count = (unsigned long long)wave_sum_i64((long long)count);
+  mine.flags = __builtin_amdgcn_ballot_w64(alarm != 0u) != 0ull ? kPartialHistAlarm : 0ull;
+  mine.sum[0] = wave_sum_i64(hsum);
+  mine.kmin[0] = wave_min_i32(umin == 0xFFFFFFFFu ? 0x7FFFFFFF : (int32_t)umin);
+  mine.kmax[0] = wave_max_i32(count == 0ull ? (int32_t)0x80000000 : (int32_t)umax);
+  __syncthreads();       // every thread is done with the counters: the start of LDS becomes the reduction scratch
+  BlockPartial* red = reinterpret_cast<BlockPartial*>(hist);
+  if (lane == 0) red[wave_in_block] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    BlockPartial acc = red[0];
+    for (int w = 1; w < waves_per_block; ++w) partial_merge(acc, red[w]);
+    p.partials[blockIdx.x] = acc;
+  }
+}
+
+}  // namespace pg
