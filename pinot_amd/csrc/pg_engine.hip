@@ -62,6 +62,8 @@ struct Engine {
   bool group_partition = true;        // PINOT_GPU_GROUP_PARTITION=0: key spaces above the LDS table always use direct HBM atomics
   long long partition_min_docs = 1ll << 22;   // ... =force: partition even tiny segments (tests)
   int hist = -1;             // PINOT_GPU_HIST: -1 auto, 0 never, 1 also for arithmetic-progression dictionaries (tests)
+  int hist_blocks = 0;       // PINOT_GPU_HIST_BLOCKS: cap on the histogram kernel's workgroups (tests: many docs per counter from a small segment)
+  bool hist_guard = false;   // PINOT_GPU_HIST_GUARD=1: start every column in the guarded tier (tests)
   int hist_bits = 0;         // PINOT_GPU_HIST_BITS: 8 / 16 force narrower counters than the cardinality needs (tests of the guard protocol)
   int group_waves = 0;       // PINOT_GPU_GROUP_WAVES: cap on wavefronts per group-by workgroup (default 16)
   std::mutex mu;
@@ -109,7 +111,8 @@ struct ColumnDev {
   int shape_bits = 0;
   bool shape_is_fwd = false;
   bool plane_ready = false;
-  int hist_disabled = 0;                // a histogram counter of this column once ran into its guard: the column is summed through the other paths
+  int hist_tier = 0;                    // histogram SUM of this column: 0 plain counters + checksum, 1 guarded counters (a counter once wrapped), 2 not
+                                        // used any more (even a guarded counter ran away: the value plane / gather paths serve the column)
 };
 
 // Per-query execution context: a stream plus reusable device scratch.  Pooled per segment so that
@@ -386,7 +389,7 @@ int hist_counter_bits(const ColumnDev& col) {
 }
 bool want_hist(const ColumnDev& col) {
   if (col.encoding != PG_FWD_FIXED_BIT_DICT || col.cardinality < 1 || col.vkind != kValI32 || col.bits > 18) return false;
-  if (g_engine.hist == 0 || __atomic_load_n(&col.hist_disabled, __ATOMIC_RELAXED)) return false;
+  if (g_engine.hist == 0 || __atomic_load_n(&col.hist_tier, __ATOMIC_RELAXED) >= 2) return false;
   if (hist_counter_bits(col) == 0) return false;
   return g_engine.hist == 1 || !plane_shape(col).is_fwd;
 }
@@ -909,6 +912,10 @@ pg_status pg_init(const pg_config* config) {
   g_engine.group_waves = (gw && atoi(gw) > 0) ? atoi(gw) : 0;
   const char* hs = getenv("PINOT_GPU_HIST");
   g_engine.hist = hs ? atoi(hs) : -1;
+  const char* hbl = getenv("PINOT_GPU_HIST_BLOCKS");
+  g_engine.hist_blocks = (hbl && atoi(hbl) > 0) ? atoi(hbl) : 0;
+  const char* hg = getenv("PINOT_GPU_HIST_GUARD");
+  g_engine.hist_guard = hg && hg[0] == '1';
   const char* hb = getenv("PINOT_GPU_HIST_BITS");
   g_engine.hist_bits = (hb && (atoi(hb) == 8 || atoi(hb) == 16)) ? atoi(hb) : 0;
   const char* ts = getenv("PINOT_GPU_TILE_STEPS");
@@ -1310,6 +1317,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const bool use_hist = use_private && hist_slot == 0 && pl.num_agg_cols == 1;      // the histogram kernel aggregates one column
     if (hist_slot >= 0 && !use_hist) use_private = false;                           // (rare: the gather path of the LDS-staged kernel)
     const int hist_cw = use_hist ? hist_counter_bits(seg->cols[(size_t)hist_col]) : 0;
+    const int hist_tier = use_hist ? std::max(__atomic_load_n(&seg->cols[(size_t)hist_col].hist_tier, __ATOMIC_RELAXED), g_engine.hist_guard ? 1 : 0) : 0;
+    const bool hist_guarded = hist_tier >= 1 && hist_cw < 32;
     // Raw columns and 8-byte dictionaries: the same lane-private layout, read with 16-byte loads (scan_private_typed_kernel).
     // PINOT_GPU_SCAN_TYPED_PRIVATE=0 keeps them in the LDS-staged kernel.
     bool use_private_typed = g_engine.scan_private && g_engine.scan_typed_private && !use_private && pl.num_agg_cols > 0 && !(g_engine.flags & PG_CFG_PROFILE_WAVES);
@@ -1330,11 +1339,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       hist_lds = (((size_t)(seg->cols[(size_t)hist_col].cardinality + per_word - 1) / per_word * 4) + 15) & ~(size_t)15;
       hist_lds = std::max(hist_lds, sizeof(BlockPartial) * (kHistBlockThreads / 64));      // the reduction records reuse the counters' LDS
       const size_t per_block = hist_lds + 256;
-      int bpc = std::max(1, std::min(waves_scan_hist(hist_cw) / (kHistBlockThreads / 64), (int)((160 * 1024 - 2048) / per_block)));
+      int bpc = std::max(1, std::min(waves_scan_hist(hist_cw, hist_guarded) / (kHistBlockThreads / 64), (int)((160 * 1024 - 2048) / per_block)));
       if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
       const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
       const int wpb = kHistBlockThreads / 64;
       blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + wpb - 1) / wpb, (long long)seg->num_cus * bpc));
+      if (g_engine.hist_blocks > 0) blocks = std::min(blocks, g_engine.hist_blocks);
       geo.threads = kHistBlockThreads;
       sp.hist_slot = hist_slot;
       sp.hist_bins = seg->cols[(size_t)hist_col].cardinality;
@@ -1360,7 +1370,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
-    if (use_hist) launch_scan_hist(hist_cw, blocks, hist_lds, ctx->stream, sp);
+    if (use_hist) launch_scan_hist(hist_cw, hist_guarded, blocks, hist_lds, ctx->stream, sp);
     else if (use_private) launch_scan_private(one, blocks, ctx->stream, sp);
     else if (use_private_typed) launch_scan_private_typed(blocks, ctx->stream, sp);
     else launch_scan_agg(g_engine.use_dma, one, typed, blocks, geo.threads, lds, ctx->stream, sp);
@@ -1381,10 +1391,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const BlockPartial& fp = *ctx->h_partial;
-    if (use_hist && (fp.flags & kPartialHistAlarm)) {
-      // A narrow counter came within half its range of leaving its field (heavily skewed dictIds): the histogram's sum is not
-      // trusted.  The column is summed through its value plane / the gather path from now on; this query is answered again.
-      __atomic_store_n(&seg->cols[(size_t)hist_col].hist_disabled, 1, __ATOMIC_RELAXED);
+    // plain narrow counters: the counters must add up to the matches (a wrapped counter always leaves the total short)
+    const bool hist_wrapped = use_hist && !hist_guarded && hist_cw < 32 && (unsigned long long)fp.sum[1] != fp.count;
+    if (use_hist && (hist_wrapped || (fp.flags & kPartialHistAlarm))) {
+      // Skewed dictIds: the histogram's sum is not used.  From now on the column runs in the next tier -- guarded counters, which count
+      // hot dictIds exactly through guard-bit claims, then the value plane / gather path -- and this query is answered again.
+      __atomic_store_n(&seg->cols[(size_t)hist_col].hist_tier, hist_wrapped ? 1 : 2, __ATOMIC_RELAXED);
       release_ctx(seg, ctx);
       guard.ctx = nullptr;
       return execute_impl(seg, q, out, d_out_bitmap_request, host_bitmap, host_bitmap_words, out_cardinality, allow_metadata_plan);

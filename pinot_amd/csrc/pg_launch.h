@@ -37,9 +37,9 @@ int waves_scan_group();
 void launch_group_private(bool lds_table, int blocks, int threads, size_t lds, hipStream_t stream, const GroupParams& gp);
 int waves_group_private();
 
-// scan_hist_kernel<8 | 16 | 32>: lane-private scan whose SUM column is counted per dictId in an LDS histogram (pg_scan_hist.h)
-void launch_scan_hist(int counter_bits, int blocks, size_t lds, hipStream_t stream, const ScanParams& p);
-int waves_scan_hist(int counter_bits);
+// scan_hist_kernel<8 | 16 | 32, guarded>: lane-private scan whose SUM column is counted per dictId in an LDS histogram (pg_scan_hist.h)
+void launch_scan_hist(int counter_bits, bool guarded, int blocks, size_t lds, hipStream_t stream, const ScanParams& p);
+int waves_scan_hist(int counter_bits, bool guarded);
 
 // scan_private_typed_kernel: lane-private scan for raw / 8-byte aggregated columns (pg_scan_typed.h)
 void launch_scan_private_typed(int blocks, hipStream_t stream, const ScanParams& p);

@@ -103,33 +103,83 @@ def test_long_dictionary_in_the_int32_domain(engine):
     check(engine, seg, Q.QuerySpec(ALL_AGGS(0), filter=Q.leaf(Q.Pred.dict_range(1, 0, 50))))
 
 
-@pytest.fixture()
-def narrow_counter_engine():
-    """PINOT_GPU_HIST_BITS forces 8-bit counters whatever the cardinality, so that small test segments reach the guard protocol."""
+def _engine_with_env(env):
     import torch  # noqa: F401
     from pinot_amd.engine import Engine
-    os.environ["PINOT_GPU_HIST_BITS"] = "8"
+    os.environ.update(env)
     try:
         yield Engine(device_id=0, time_kernels=True)
     finally:
-        del os.environ["PINOT_GPU_HIST_BITS"]
+        for k in env:
+            del os.environ[k]
         Engine(device_id=0, time_kernels=True)       # pg_init re-reads the environment
 
 
-@pytest.mark.parametrize("hot_fraction", [0.02, 0.3, 1.0])
-def test_guarded_counters_under_skew(narrow_counter_engine, hot_fraction):
-    """A dictId that takes a large share of the docs drives its 8-bit counter through the guard many times: owners claim 128 matches at
-    a time.  Extreme skew trips the alarm and the engine answers through the other path -- either way the result is exact."""
-    n, cardinality = 1_500_000, 5000
+@pytest.fixture()
+def narrow_counter_engine():
+    """PINOT_GPU_HIST_BITS forces 8-bit counters whatever the cardinality, so that small test segments make counters wrap."""
+    yield from _engine_with_env({"PINOT_GPU_HIST_BITS": "8"})
+
+
+@pytest.fixture()
+def guarded_engine():
+    """Every column starts in the guarded tier (returning adds + guard-bit claims), with 8-bit counters."""
+    yield from _engine_with_env({"PINOT_GPU_HIST_BITS": "8", "PINOT_GPU_HIST_GUARD": "1"})
+
+
+def skewed_segment(hot_fraction, n=1_500_000, cardinality=5000):
     rng = np.random.default_rng(int(hot_fraction * 100))
     ids = rng.integers(0, cardinality, n).astype(np.int32)
     hot = rng.random(n) < hot_fraction
     ids[hot] = 4321
-    seg, ids, fids, dv = segment(n, cardinality, 99, ids=ids)
+    return segment(n, cardinality, 99, ids=ids)
+
+
+@pytest.mark.parametrize("hot_fraction", [0.0, 0.02, 0.3, 1.0])
+def test_wrapped_counters_are_detected_and_the_next_tier_answers(narrow_counter_engine, hot_fraction):
+    """8-bit counters over 1.5 M docs and 5000 dictIds wrap (about 300 docs per counter and segment, many more for the hot dictId):
+    the checksum `sum of counters == matches` fails, the column moves to guarded counters (which count the hot dictId in claims of 128)
+    and, under extreme skew, on to the other paths.  Every answer is exact, including the repeats that start in the later tier."""
+    seg, ids, fids, dv = skewed_segment(hot_fraction)
     for spec in (Q.QuerySpec([(Q.SUM, 0)]), Q.QuerySpec(ALL_AGGS(0), filter=Q.leaf(Q.Pred.dict_range(1, 0, 900)))):
         with narrow_counter_engine.open(seg) as g:
             for _ in range(3):
                 got = g.execute(spec)
                 H.assert_results_equal(got, oracle.execute(seg, spec))
-    m = np.ones(n, dtype=bool)
-    assert oracle.execute(seg, Q.QuerySpec([(Q.SUM, 0)])).aggregations[0].sum_i64 == int(dv[ids[m]].astype(np.int64).sum())
+    assert oracle.execute(seg, Q.QuerySpec([(Q.SUM, 0)])).aggregations[0].sum_i64 == int(dv[ids].astype(np.int64).sum())
+
+
+@pytest.fixture()
+def guarded_few_blocks_engine():
+    """Guarded 8-bit counters and only 8 workgroups: a 3 M-doc segment then puts ~190 docs on every counter of a workgroup, one at a
+    time (about one per tile), which is the regime the guard-bit claims are for."""
+    yield from _engine_with_env({"PINOT_GPU_HIST_BITS": "8", "PINOT_GPU_HIST_GUARD": "1", "PINOT_GPU_HIST_BLOCKS": "8"})
+
+
+def test_guard_bit_claims_keep_slowly_filling_counters_exact(guarded_few_blocks_engine):
+    n, cardinality = 3_000_000, 2000
+    seg, ids, fids, dv = segment(n, cardinality, 4242)
+    for spec in (Q.QuerySpec([(Q.SUM, 0)]), Q.QuerySpec(ALL_AGGS(0), filter=Q.leaf(Q.Pred.dict_range(1, 0, 800)))):
+        with guarded_few_blocks_engine.open(seg) as g:
+            got = g.execute(spec)
+        H.assert_results_equal(got, oracle.execute(seg, spec))
+        assert got.dominant_kernel == "scan_hist_kernel"       # every counter passed 128 at least once and none ran away: no fallback
+
+
+@pytest.mark.parametrize("hot_fraction", [0.0, 0.02, 0.3])
+def test_guarded_counters_under_bursts(guarded_engine, hot_fraction):
+    """A dictId hit by sixteen wavefronts at once can outrun the claims: the alarm sends the query to the other paths.  Exact either way."""
+    seg, ids, fids, dv = skewed_segment(hot_fraction, n=400_000)
+    for spec in (Q.QuerySpec([(Q.SUM, 0)]), Q.QuerySpec(ALL_AGGS(0), filter=Q.leaf(Q.Pred.dict_range(1, 0, 500)))):
+        with guarded_engine.open(seg) as g:
+            got = g.execute(spec)
+            H.assert_results_equal(got, oracle.execute(seg, spec))
+            if hot_fraction == 0.0:
+                assert got.dominant_kernel == "scan_hist_kernel"
+
+
+def test_a_small_sparse_filter_keeps_the_plain_tier(narrow_counter_engine):
+    """Few matches per counter: the plain 8-bit counters do not wrap and the checksum passes (no rerun: same kernel, one launch)."""
+    seg, ids, fids, dv = skewed_segment(0.0, n=200_000, cardinality=5000)
+    spec = Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100)))
+    check(narrow_counter_engine, seg, spec)
