@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- filtered SUM over 1 B-row dictionary-encoded segments, one segment per GPU (BASELINE.json configs[1]/[3]).
+"""bench.py -- filtered SUM over 1 B-row dictionary-encoded segments (BASELINE.json configs[1] and configs[3]).
 
-Workload C2b: SELECT SUM(v) FROM t WHERE f < 100
-  v: INT, dictionary {7k+3 : k < 100000} -> 17-bit fixed-bit forward index (2.125 GB), dictIds uniform, seed 2r+1
-  f: INT, dictionary {0..999}            -> 10-bit fixed-bit forward index (1.25 GB),  dictIds uniform, seed 2r+2
-  predicate lowered to dictId range [0, 100) (10 % selectivity); r = rank (segment r lives on GPU r).
-A step = one pg_execute over the whole resident segment (fused scan -> filter -> SUM kernel reading f's dictIds and
-v's device-built value plane (`roofline.kernel` names the kernel that ran) + a one-block partial reduction +
-200-byte readback + stream sync).  Columns are generated on the host by the product's C++ writer
-in Pinot's on-disk layout and copied to HBM by pg_segment_open before the timed region.
+Headline workload, C2b of BASELINE.md section 3:   SELECT SUM(v) FROM t WHERE f < 100
+  v: INT, dictionary {7k+3 : k < 100000} -> 17-bit fixed-bit forward index (2.125 GB), dictIds uniform, seed 2s+1
+  f: INT, dictionary {0..999}            -> 10-bit fixed-bit forward index (1.25 GB),  dictIds uniform, seed 2s+2
+  predicate lowered to the dictId range [0, 100) (10 % selectivity); s = segment number.
+C4: `--segments S` (default 8) segments IN TOTAL at every N; segment s lives on GPU (s mod N), one process
+per GPU, no collective on the data path: the 16-byte partials travel over gloo and are merged on the host (SumAggregationFunction.merge).
+A step = one pg_execute per resident segment of the rank (fused scan -> filter -> SUM kernel + a one-block partial reduction +
+200-byte readback + stream sync).  value = S * rows * steps / time, "scaling": "strong".  Columns are generated on the host by the
+product's C++ writer in Pinot's on-disk layout and copied to HBM by pg_segment_open before the timed region.
 
 Launch:  python bench.py --gpus 1 --steps 20 --warmup 3
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
-Prints ONE JSON line on rank 0.  At N=1 the line also carries `cpu_baseline` (the C oracle on one host core over the same full
-workload -- it doubles as the parity check) and `cpu_baseline_all_cores` (the workload split into one segment per host core, the way
-the reference's combine operator runs segments).
+Prints ONE JSON line on rank 0.  At N=1 the line also carries
+  cpu_baseline            the C oracle ("port") on one host core over segment 0's full workload -- it doubles as a parity check
+  cpu_baseline_all_cores  the same workload split into one segment per host core (how BaseCombineOperator runs segments)
+  parity                  every segment's result against the oracle at full size
+  variants                every other BASELINE.json configuration, driver-timed with the parity check on: C2b over dictionaries without
+                          structure (irregular / 2^20 window), C2a, C3 (config 3) with and without a filter, C5 sparse and dense
+                          (config 5), C1 (config 0's scan pair)
+  roofline.empirical_peak the box's own 16 B/lane streaming-read ceiling, measured in this run
 """
 import argparse
 import ctypes as C
 import json
 import os
+import shutil
 import sys
 import time
 
@@ -35,15 +42,60 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--segments", type=int, default=int(os.environ.get("PINOT_BENCH_SEGMENTS", 8)),
+                    help="segments in total (BASELINE.md C4: 8 at every N); segment s runs on GPU s mod N")
     ap.add_argument("--rows", type=int, default=int(os.environ.get("PINOT_BENCH_ROWS", 1_000_000_000)))
+    ap.add_argument("--rows-c5", type=int, default=int(os.environ.get("PINOT_BENCH_ROWS_C5", 0)), help="rows of the C5 variants (0 = --rows)")
     ap.add_argument("--threshold", type=int, default=100, help="f < threshold (dictIds [0, threshold) of 1000)")
     ap.add_argument("--dictionary", default="affine", choices=["affine", "irregular", "window"],
-                    help="dictionary of v: {7k+3} (BASELINE.md C2), 100000 sorted distinct values from the whole int32 range, or from a 2^20 window")
+                    help="dictionary of v in the headline: {7k+3} (BASELINE.md C2), 100000 sorted distinct values from the whole int32 range, or from a 2^20 window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--variants", default="", help="regexp: only the variants whose id matches")
     ap.add_argument("--no-clock-settle", action="store_true", help="skip the 48 untimed launches that step through the GPU clock transient")
-    ap.add_argument("--extra", action="store_true", help="also time the other BASELINE.md query shapes (stderr)")
-    ap.add_argument("--profile-waves", action="store_true", help="diagnostic: per-wave phase cycle counters (perturbs timing slightly)")
     return ap.parse_args()
+
+
+def v_dictionary(kind, cardinality=100000, seed=20260921):
+    """The dictionary of a summed column: BASELINE.md's arithmetic progression, or sorted distinct values without structure."""
+    import numpy as np
+    if kind == "affine":
+        return (np.arange(cardinality, dtype=np.int64) * 7 + 3).astype(np.int32)
+    rng = np.random.default_rng(seed)
+    lo, hi = (-2 ** 31, 2 ** 31 - 1) if kind == "irregular" else (0, 2 ** 20)
+    vals = np.unique(rng.integers(lo, hi, 4 * cardinality, dtype=np.int64))
+    return np.sort(rng.permutation(vals)[:cardinality]).astype(np.int32)
+
+
+def c2b_segment(S, s, n, dictionary):
+    v = S.Column.synthetic_uniform("v", n, v_dictionary(dictionary), seed=2 * s + 1)
+    f = S.Column.synthetic_uniform("f", n, __import__("numpy").arange(1000, dtype="int32"), seed=2 * s + 2)
+    return S.SegmentData("c2b_%d" % s, n, [v, f])
+
+
+class Timer:
+    """Runs a query `steps` times on a resident segment and averages the HIP-event times the engine reports."""
+
+    def __init__(self, lib, _abi):
+        self.lib, self._abi = lib, _abi
+        self.res = _abi.pg_result()
+
+    def run(self, gseg, spec, steps, warmup):
+        kernel, device, wall, kid = [], [], [], -1
+        for i in range(warmup + steps):
+            t0 = time.perf_counter()
+            st = gseg.execute_raw(spec, self.res)
+            t1 = time.perf_counter()
+            if st != self._abi.PG_OK:
+                raise RuntimeError(self.lib.pg_last_error().decode())
+            if i >= warmup:
+                kernel.append(self.res.dominant_kernel_ms)
+                device.append(self.res.device_ms)
+                wall.append((t1 - t0) * 1e3)
+                kid = int(self.res.dominant_kernel)
+            self.lib.pg_result_free(C.byref(self.res))
+        mean = lambda x: sum(x) / len(x)
+        return {"kernel_ms": mean(kernel), "all_kernels_ms": mean(device), "step_ms_host_clock": mean(wall), "kernel": self._abi.KERNEL_NAMES.get(kid, "")}
 
 
 def main():
@@ -59,27 +111,31 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     if world > 1:
+        # no collective on the data path: gloo carries the barrier, the timing MAX and the 16-byte partials (no RCCL needed)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="gloo")
 
     from pinot_amd import _abi
+    from pinot_amd import distributed as D
     from pinot_amd import query as Q
     from pinot_amd import segment as S
     from pinot_amd.engine import Engine
 
     n = args.rows
+    num_segments = max(args.segments, world)
+    mine = [s for s in range(num_segments) if s % world == rank]          # BASELINE.md C4 / SURVEY.md 8(e): segment s -> device s mod N
     t0 = time.time()
-    v = S.Column.synthetic_uniform("v", n, v_dictionary(args.dictionary), seed=2 * rank + 1)
-    f = S.Column.synthetic_uniform("f", n, np.arange(1000, dtype=np.int32), seed=2 * rank + 2)
-    seg = S.SegmentData("c2b_%d" % rank, n, [v, f])
+    segs = [c2b_segment(S, s, n, args.dictionary) for s in mine]
     gen_s = time.time() - t0
     spec = Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, args.threshold)))
-    algorithmic_bytes = v.fwd.nbytes + f.fwd.nbytes   # B(f) + B(v) = 3.375 B/row
+    algorithmic_bytes = segs[0].columns[0].fwd.nbytes + segs[0].columns[1].fwd.nbytes   # B(f) + B(v) = 3.375 B/row
 
-    engine = Engine(device_id=local_rank, time_kernels=True, profile_waves=args.profile_waves)
+    engine = Engine(device_id=local_rank, time_kernels=True)
+    lib = engine.lib
     t0 = time.time()
-    gseg = engine.open(seg)
+    gsegs = [engine.open(seg) for seg in segs]
     h2d_s = time.time() - t0
+    device_bytes = sum(g.device_bytes() for g in gsegs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -88,54 +144,61 @@ def main():
         torch.cuda.synchronize()
 
     res = _abi.pg_result()
-    lib = engine.lib
+    kernel_ms, partials = [], [None] * len(gsegs)
+    kernel_id = [-1]
 
-    def step():
-        st = gseg.execute_raw(spec, res)
-        if st != _abi.PG_OK:
-            raise RuntimeError(lib.pg_last_error().decode())
-        out = (res.aggregations[0].sum_i64, res.aggregations[0].count, res.dominant_kernel_ms, res.device_ms, int(res.dominant_kernel))
-        if args.profile_waves:
-            step.cycles = [int(c) for c in res.profile_cycles] + [int(res.profile_waves)]
-        lib.pg_result_free(C.byref(res))
-        return out
+    def step(record=False):
+        for i, g in enumerate(gsegs):
+            st = g.execute_raw(spec, res)
+            if st != _abi.PG_OK:
+                raise RuntimeError(lib.pg_last_error().decode())
+            partials[i] = (int(res.aggregations[0].sum_i64), int(res.aggregations[0].count))
+            if record:
+                kernel_ms.append(res.dominant_kernel_ms)
+            kernel_id[0] = int(res.dominant_kernel)
+            lib.pg_result_free(C.byref(res))
 
     # Clock settle: the first ~35 launches after an idle period run through the GPU's power-management transient (0.72 -> 0.58 ->
     # 0.69 -> 0.575 ms for this kernel, tools/steps_probe.py); a resident query engine is never in that state, so it is stepped through
     # before the W warm-up steps.  Reported in the JSON ("clock_settle_launches"); --no-clock-settle turns it off.
     settle = 0 if args.no_clock_settle else 48
-    for _ in range(settle):
+    for _ in range((settle + len(gsegs) - 1) // len(gsegs)):
         step()
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = []
-    device_ms = []
-    last = None
     for _ in range(args.steps):
-        last = step()
-        kernel_ms.append(last[2])
-        device_ms.append(last[3])
+        step(record=True)
     barrier()
-    elapsed = time.perf_counter() - t0
-    from pinot_amd import distributed as D
-    elapsed = D.max_over_ranks(elapsed, "cuda")
-    # host-side merge of the per-segment partials (no data-path collective: 16 bytes per rank travel)
-    merged_sum, merged_count = D.merge_sum_count(D.gather_partials([last[0], last[1]], "cuda"))
-
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, "cpu")
+    # host-side merge of the per-segment partials, in segment order (no data-path collective: 16 bytes per segment travel)
+    flat = []
+    for i in range((num_segments + world - 1) // world):
+        flat += list(partials[i]) if i < len(partials) else [0, 0]
+    gathered = D.gather_partials(flat, "cpu")
+    per_segment = {}
+    for r, vals in enumerate(gathered):
+        owned = [s for s in range(num_segments) if s % world == r]
+        for i, s in enumerate(owned):
+            per_segment[s] = (vals[2 * i], vals[2 * i + 1])
+    merged_sum, merged_count = D.merge_sum_count([per_segment[s] for s in range(num_segments)])
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-    # HBM traffic per launch comes from a separate rocprofv3 --pmc pass (it cannot be collected inside this process);
-    # the committed summary applies to the default workload only.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and os.environ.get("PINOT_GPU_VALUE_PLANE", "-1") != "0":
-        t = json.load(open(tpath)).get(_abi.KERNEL_NAMES[last[4]], {})
-        if t.get("workload_rows") == n and args.threshold == 100:
-            traffic = t.get("bytes_per_launch")
+    kernel_name = _abi.KERNEL_NAMES[kernel_id[0]]
+
     result = None
     if rank == 0:
-        rows_per_s = world * n * args.steps / elapsed
+        # HBM traffic per launch comes from a separate rocprofv3 --pmc pass (counters cannot be collected inside this process):
+        # the committed summary of that pass is replayed here, for the default workload only, and labelled as such.
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and args.dictionary == "affine" and args.threshold == 100:
+            t = json.load(open(tpath)).get(kernel_name, {})
+            if t.get("workload_rows") == n:
+                traffic = t.get("bytes_per_launch")
+                traffic_source = {"replayed": True, "file": "profiles/traffic.json", "from": t.get("source"),
+                                  "note": "FETCH_SIZE x2 (gfx950) of a separate rocprofv3 --pmc run of this command; not measured in this run"}
+        rows_per_s = num_segments * n * args.steps / elapsed
         achieved = algorithmic_bytes / (avg_kernel_ms * 1e-3) / 1e9
         result = {
             "metric": "scanned rows/sec + achieved HBM GB/s, filtered SUM on 1B-row segment",
@@ -146,126 +209,75 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "int64",
             "data": "synthetic",
-            "config": {"workload": "C2b: SELECT SUM(v) WHERE f < t, %d rows/segment, v 17-bit dict (C=100000), f 10-bit dict (C=1000), "
-                                   "selectivity %.0f%%, one segment per GPU, host-side merge" % (n, args.threshold / 10.0),
-                       "rows_per_segment": n, "segments": world, "algorithmic_bytes_per_row": algorithmic_bytes / n},
+            "config": {"workload": "C2b/C4: SELECT SUM(v) WHERE f < t over %d segments x %d rows (segment s on GPU s mod N), v 17-bit dict (C=100000, %s), "
+                                   "f 10-bit dict (C=1000), selectivity %.0f%%, host-side merge; one launch = one whole 1 B-row segment"
+                                   % (num_segments, n, args.dictionary, args.threshold / 10.0),
+                       "rows_per_segment": n, "segments": num_segments, "segments_per_gpu": len(mine), "algorithmic_bytes_per_row": algorithmic_bytes / n,
+                       "dictionary": args.dictionary},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": _abi.KERNEL_NAMES[last[4]], "kernel_ms": avg_kernel_ms,
-                         "algorithmic_bytes_per_launch": algorithmic_bytes},
-            "dictionary": args.dictionary,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms": avg_kernel_ms,
+                         "launches_timed": len(kernel_ms), "algorithmic_bytes_per_launch": algorithmic_bytes},
             "clock_settle_launches": settle,
-            "hbm_GBps_whole_step": world * algorithmic_bytes * args.steps / elapsed / 1e9,
-            "wave_profile": ({"waves": step.cycles[4], "cycles_per_wave": {"memory_wait": step.cycles[0] / step.cycles[4], "filter": step.cycles[1] / step.cycles[4],
-                                                                          "aggregate": step.cycles[2] / step.cycles[4], "loop_total": step.cycles[3] / step.cycles[4]}}
-                             if args.profile_waves else None),
+            "hbm_GBps_whole_step": num_segments * algorithmic_bytes * args.steps / elapsed / 1e9,
             "result": {"sum": merged_sum, "count": merged_count},
-            "setup": {"host_generate_s": gen_s, "segment_open_h2d_s": h2d_s, "device_bytes": gseg.device_bytes(),
-                      "h2d_GBps": gseg.device_bytes() / h2d_s / 1e9, "host_threads": S.host_threads()},
+            "setup": {"host_generate_s": gen_s, "segment_open_h2d_s": h2d_s, "device_bytes": device_bytes,
+                      "h2d_GBps": device_bytes / h2d_s / 1e9, "host_threads": S.host_threads()},
         }
+        if world == 1:
+            peak = C.c_double()
+            if lib.pg_measure_stream_read(local_rank, 4 << 30, 6, C.byref(peak)) == _abi.PG_OK:
+                result["roofline"]["empirical_peak"] = peak.value
+                result["roofline"]["frac_of_empirical_peak"] = achieved / peak.value
+                result["roofline"]["empirical_peak_note"] = "best of 6 launches of a pure 16 B/lane read-reduce kernel over 4 GiB, this run, this box"
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle
             ores = _abi.pg_result()
             t0 = time.perf_counter()
-            rc = oracle.execute_raw(seg, spec, ores)
+            rc = oracle.execute_raw(segs[0], spec, ores)
             cpu_s = time.perf_counter() - t0
             assert rc == 0
-            osum, ocount = ores.aggregations[0].sum_i64, ores.aggregations[0].count
+            osum, ocount = int(ores.aggregations[0].sum_i64), int(ores.aggregations[0].count)
             oracle.load().po_result_free(C.byref(ores))
+            java = shutil.which("java")
             result["cpu_baseline"] = {"value": n / cpu_s, "unit": "rows/s", "cores": 1, "kind": "port",
-                                      "sample": "the full workload (%d rows, same segment, same query) through the C oracle on one host core "
+                                      "sample": "segment 0's full workload (%d rows, same query) through the C oracle on one host core "
                                                 "(one segment = one thread, as in BaseCombineOperator); %.1f s" % (n, cpu_s),
-                                      "host_cores_available": os.cpu_count()}
-            result["parity"] = {"bit_exact_vs_oracle": bool(osum == last[0] and ocount == last[1]), "oracle_sum": osum, "gpu_sum": last[0]}
-            result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(seg, spec, n, osum, ocount)
-    if args.extra and rank == 0 and world == 1:
-        run_extra(gseg, seg, n, lib, Q, _abi, C)
-    gseg.close()
+                                      "host_cores_available": os.cpu_count(),
+                                      "reference_jvm": {"java_on_this_box": java,
+                                                        "note": "no JDK on the measurement box: the reference's JVM path (pinot-perf BenchmarkQueries) cannot be timed here; "
+                                                                "kind stays 'port'" if java is None else "a JVM exists here but the reference's jars do not travel with this repository"}}
+            ok = [osum == per_segment[0][0] and ocount == per_segment[0][1]]
+            t0 = time.perf_counter()
+            all_cores = None
+            for s in range(num_segments):
+                want = oracle.execute_sliced(segs[s], spec)
+                got = per_segment[s]
+                if s == 0:
+                    all_cores = {"value": n / want["seconds"], "unit": "rows/s", "cores": want["threads"], "kind": "port",
+                                 "merged_result_matches": bool(want["aggregations"][0]["sum_i64"] == osum and want["aggregations"][0]["count"] == ocount),
+                                 "sample": "segment 0's full workload split into %d equal segments, one oracle thread per segment, partials merged; %.2f s"
+                                           % (want["slices"], want["seconds"])}
+                ok.append(want["aggregations"][0]["sum_i64"] == got[0] and want["aggregations"][0]["count"] == got[1])
+            result["cpu_baseline_all_cores"] = all_cores
+            result["parity"] = {"bit_exact_vs_oracle": bool(all(ok)), "segments_checked": num_segments, "oracle_sum_segment0": osum, "gpu_sum_segment0": per_segment[0][0],
+                                "check_s": time.perf_counter() - t0}
+    for g in gsegs[1:]:
+        g.close()
+    if rank == 0 and world == 1 and not args.no_variants:
+        import re
+        from tools import bench_variants
+        match = re.compile(args.variants) if args.variants else None
+        result["variants"] = bench_variants.run(engine, gsegs[0], segs[0], n, args.rows_c5 or n, match, check=not args.no_cpu_baseline)
+    gsegs[0].close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
-
-
-def v_dictionary(kind, cardinality=100000):
-    """The dictionary of the summed column: BASELINE.md's arithmetic progression, or sorted distinct values without structure."""
-    import numpy as np
-    if kind == "affine":
-        return (np.arange(cardinality, dtype=np.int64) * 7 + 3).astype(np.int32)
-    rng = np.random.default_rng(20260921)
-    lo, hi = (-2 ** 31, 2 ** 31 - 1) if kind == "irregular" else (0, 2 ** 20)
-    vals = np.unique(rng.integers(lo, hi, 4 * cardinality, dtype=np.int64))
-    return np.sort(rng.permutation(vals)[:cardinality]).astype(np.int32)
-
-
-def cpu_baseline_all_cores(seg, spec, n, want_sum, want_count):
-    """the reference runs one segment per thread (BaseCombineOperator), so the honest all-core number splits
-    the workload into as many equal segments as the host has cores.  The same packed columns are sliced at multiples of 8 docs
-    (8 docs of a b-bit column are b whole bytes), the C oracle runs on every slice in its own thread, the partials are merged."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle
-    from pinot_amd import _abi
-    from pinot_amd import segment as S
-    cores = os.cpu_count() or 1
-    bounds = [min(n, ((n * i // cores) + 7) // 8 * 8) for i in range(cores)] + [n]
-    slices = []
-    for i in range(cores):
-        lo, hi = bounds[i], bounds[i + 1]
-        if hi <= lo:
-            continue
-        cols = []
-        for c in seg.columns:
-            first = lo * c.bits // 8
-            cols.append(S.Column(c.name, c.encoding, c.bits, c.cardinality, c.fwd[first:first + ((hi - lo) * c.bits + 7) // 8 + 8], c.dictionary, None, c.dict_values,
-                                 stored_type=c.stored_type))
-        slices.append(S.SegmentData("slice%d" % i, hi - lo, cols))
-
-    def run(part):
-        res = _abi.pg_result()
-        rc = oracle.execute_raw(part, spec, res)
-        out = (rc, int(res.aggregations[0].sum_i64), int(res.aggregations[0].count)) if rc == 0 else (rc, 0, 0)
-        oracle.load().po_result_free(C.byref(res))
-        return out
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as pool:
-        parts = list(pool.map(run, slices))
-    cpu_s = time.perf_counter() - t0
-    ok = all(rc == 0 for rc, _, _ in parts) and sum(p[1] for p in parts) == want_sum and sum(p[2] for p in parts) == want_count
-    return {"value": n / cpu_s, "unit": "rows/s", "cores": cores, "kind": "port", "merged_result_matches": bool(ok),
-            "sample": "the full workload split into %d equal segments, one oracle thread per segment, partials merged; %.2f s" % (len(slices), cpu_s)}
-
-
-def run_extra(gseg, seg, n, lib, Q, _abi, C):
-    """Other BASELINE.md shapes on the same resident segment (diagnostics on stderr, not the bench line)."""
-    shapes = {
-        "C2a SUM(v) WHERE v in 10% range": (Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, 45000, 55000))), seg.columns[0].fwd.nbytes),
-        "C2a 50%": (Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, 25000, 75000))), seg.columns[0].fwd.nbytes),
-        "C2a 90%": (Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, 5000, 95000))), seg.columns[0].fwd.nbytes),
-        "C2b 1%": (Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 10))), seg.columns[0].fwd.nbytes + seg.columns[1].fwd.nbytes),
-        "C2b 50%": (Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 500))), seg.columns[0].fwd.nbytes + seg.columns[1].fwd.nbytes),
-        "COUNT WHERE f<100": (Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), seg.columns[1].fwd.nbytes),
-        "MAX(v) WHERE f<100": (Q.QuerySpec([(Q.MAX, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), seg.columns[0].fwd.nbytes + seg.columns[1].fwd.nbytes),
-        "SUM(v),COUNT GROUP BY f": (Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1)], group_by=[1]), seg.columns[0].fwd.nbytes + seg.columns[1].fwd.nbytes),
-        "MAX(v) GROUP BY f": (Q.QuerySpec([(Q.MAX, 0)], group_by=[1]), seg.columns[0].fwd.nbytes + seg.columns[1].fwd.nbytes),
-    }
-    res = _abi.pg_result()
-    for name, (spec, nbytes) in shapes.items():
-        ms = []
-        for i in range(6):
-            st = gseg.execute_raw(spec, res)
-            if st != _abi.PG_OK:
-                print("extra %s failed: %s" % (name, lib.pg_last_error().decode()), file=sys.stderr)
-                break
-            if i:
-                ms.append(res.dominant_kernel_ms)
-            lib.pg_result_free(C.byref(res))
-        if ms:
-            k = sum(ms) / len(ms)
-            print(json.dumps({"extra": name, "kernel_ms": k, "rows_per_s": n / k * 1e3, "GBps": nbytes / k / 1e6}), file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -269,6 +269,10 @@ const char* pg_version(void);
 pg_status pg_device_info(int32_t device_id, char* arch_name, int32_t arch_name_len, int32_t* num_cus,
                          uint64_t* hbm_bytes);
 
+/* Diagnostic: the box's empirical HBM read ceiling -- a pure 16 B/lane read-reduce kernel over `bytes` of device memory, best of
+ * `launches` timed launches, in GB/s (BASELINE.md section 2 asks for it next to the 8 TB/s vendor figure).  Not on the query path. */
+pg_status pg_measure_stream_read(int32_t device_id, uint64_t bytes, int32_t launches, double* out_gbps);
+
 pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment);
 pg_status pg_segment_close(pg_segment* segment);
 pg_status pg_segment_num_docs(const pg_segment* segment, int32_t* out_num_docs);

@@ -234,3 +234,82 @@ def roaring_to_words(data, num_words):
     if card < 0:
         raise OracleError((load().po_last_error() or b"").decode())
     return words, int(card)
+
+
+def execute_sliced(segment_data, spec, threads=None):
+    """The oracle on every host core: the reference runs one segment per thread (BaseCombineOperator), so a big segment is cut into
+    equal row ranges that start on multiples of 8 docs (8 docs of a b-bit column are b whole bytes: the slices are views of the same
+    packed buffers and share the dictionaries, so raw group ids coincide), one oracle thread per slice, and the partial results are
+    merged like AggregationFunction.merge does (SUM / COUNT '+', MIN / MAX min / max, AVG pairwise).  Checker plumbing only: used by
+    bench.py to verify 1 B-row results in well under a second.  Dictionary-encoded columns and scan leaves only."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    from pinot_amd import segment as S
+    n = segment_data.num_docs
+    threads = threads or (os.cpu_count() or 1)
+    parts = max(1, min(threads, n // 65536))
+    for c in segment_data.columns:
+        if c.encoding != _abi.PG_FWD_FIXED_BIT_DICT:
+            parts = 1
+    bounds = [min(n, ((n * i // parts) + 7) // 8 * 8) for i in range(parts)] + [n]
+    slices = []
+    for i in range(parts):
+        lo, hi = bounds[i], bounds[i + 1]
+        if hi <= lo:
+            continue
+        if parts == 1:
+            slices.append(segment_data)
+            continue
+        cols = []
+        for c in segment_data.columns:
+            first = lo * c.bits // 8
+            cols.append(S.Column(c.name, c.encoding, c.bits, c.cardinality, c.fwd[first:first + ((hi - lo) * c.bits + 7) // 8], c.dictionary, None, c.dict_values,
+                                 stored_type=c.stored_type))
+        slices.append(S.SegmentData("slice%d" % i, hi - lo, cols))
+
+    def run(part):
+        return execute(part, spec)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=max(1, len(slices))) as pool:
+        results = list(pool.map(run, slices))
+    seconds = time.perf_counter() - t0
+
+    def fold(values):
+        out = {"count": 0, "sum_i64": 0, "sum": 0.0, "min": float("inf"), "max": float("-inf")}
+        for v in values:
+            out["count"] += v.count
+            out["sum_i64"] += v.sum_i64
+            out["sum"] += v.sum
+            out["min"] = min(out["min"], v.min)
+            out["max"] = max(out["max"], v.max)
+        return out
+    na = len(spec.aggregations)
+    merged = {"seconds": seconds, "threads": threads, "slices": len(slices), "docs_scanned": sum(r.stats[0] for r in results),
+              "aggregations": [fold([r.aggregations[a] for r in results]) for a in range(na)] if not spec.group_by else [], "groups": {}}
+    if spec.group_by:
+        keys = set()
+        for r in results:
+            keys.update(r.groups)
+        for g in keys:
+            merged["groups"][g] = [fold([r.groups[g][a] for r in results if g in r.groups]) for a in range(na)]
+    return merged
+
+
+def matches_sliced(got, want, functions):
+    """A pinot_amd.query.Result against execute_sliced's merge: bit exact on what each function defines."""
+    def same(a, w, f):
+        from pinot_amd import query as Q
+        if a.count != w["count"]:
+            return False
+        if f in (Q.SUM, Q.AVG) and a.sum_i64 != w["sum_i64"]:
+            return False
+        if f == Q.MIN and a.min != w["min"]:
+            return False
+        if f == Q.MAX and a.max != w["max"]:
+            return False
+        return True
+    if want["groups"] or got.groups:
+        if sorted(got.groups) != sorted(want["groups"]):
+            return False
+        return all(same(got.groups[g][a], want["groups"][g][a], f) for g in want["groups"] for a, f in enumerate(functions))
+    return all(same(got.aggregations[a], want["aggregations"][a], f) for a, f in enumerate(functions))

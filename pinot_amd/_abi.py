@@ -97,6 +97,7 @@ ABI_SYMBOLS = [
     ("pg_segment_open", C.c_int, [_P(pg_segment_desc), _P(C.c_void_p)]),
     ("pg_segment_close", C.c_int, [C.c_void_p]),
     ("pg_segment_num_docs", C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    ("pg_measure_stream_read", C.c_int, [C.c_int32, C.c_uint64, C.c_int32, _P(C.c_double)]),
     ("pg_segment_device_bytes", C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     ("pg_execute", C.c_int, [C.c_void_p, _P(pg_query), _P(pg_result)]),
     ("pg_result_free", None, [_P(pg_result)]),

@@ -941,6 +941,41 @@ pg_status pg_device_info(int32_t device_id, char* arch_name, int32_t arch_name_l
   return PG_OK;
 }
 
+pg_status pg_measure_stream_read(int32_t device_id, uint64_t bytes, int32_t launches, double* out_gbps) {
+  if (!out_gbps || bytes < (1u << 20) || launches < 1) return fail(PG_ERR_INVALID_ARGUMENT, "bad stream probe arguments");
+  HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  uint8_t* buf = nullptr;
+  unsigned long long* sink = nullptr;
+  HIP_TRY(hipMalloc((void**)&buf, bytes));
+  hipError_t e = hipMalloc((void**)&sink, 8);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (e == hipSuccess) e = hipMemset(buf, 0, bytes);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  float best = 0.f;
+  if (e == hipSuccess) {
+    const unsigned blocks = (unsigned)prop.multiProcessorCount * 8u;        // 2048 threads per CU: a persistent grid, like the scan kernels
+    for (int i = 0; i < launches + 2 && e == hipSuccess; ++i) {
+      (void)hipEventRecord(e0, 0);
+      stream_read_probe_kernel<<<dim3(blocks), dim3(kBlockThreads), 0, 0>>>(reinterpret_cast<const uint4*>(buf), (size_t)(bytes / 16), sink);
+      (void)hipEventRecord(e1, 0);
+      e = hipEventSynchronize(e1);
+      float ms = 0.f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+      if (i >= 2 && ms > 0.f) best = std::max(best, (float)((double)bytes / (ms * 1e-3) / 1e9));
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(buf);
+  if (sink) (void)hipFree(sink);
+  if (e != hipSuccess) return fail(PG_ERR_DEVICE, "stream probe: %s", hipGetErrorString(e));
+  *out_gbps = best;
+  return PG_OK;
+}
+
 pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment) {
   if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");
   if (!desc || !out_segment) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");

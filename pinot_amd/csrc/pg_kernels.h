@@ -1803,6 +1803,17 @@ static __global__ __launch_bounds__(kBlockThreads) void materialize_plane_kernel
   }
 }
 
+// Empirical HBM read ceiling of the box: a pure 16 B/lane read-reduce over a buffer, nothing else.
+static __global__ __launch_bounds__(kBlockThreads) void stream_read_probe_kernel(const uint4* __restrict__ src, size_t n16, unsigned long long* out) {
+  unsigned long long acc = 0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+    const uint4 v = src[i];
+    acc += v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x1234567ull) out[0] = acc;       // never true for the zero-filled probe buffer's checksum: keeps the loads alive
+}
+
 static __global__ void fill_words_kernel(unsigned long long* words, long long n, unsigned long long value) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) words[i] = value;
 }

@@ -37,3 +37,48 @@ def max_over_ranks(seconds, device):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---- group-by across ranks ----
+# DictIds are segment-local (every segment has its own dictionaries), so group-by partials can only be merged on the VALUES of the
+# keys, like GroupByCombineOperator does when it upserts `Key(Object[] values)` records into its indexed table
+# (core/operator/combine/GroupByCombineOperator.java:132-147, core/data/table/Key.java).  Each rank turns its raw group ids into
+# value tuples with its own dictionaries first; only those rows travel (all_gather_object: tens of bytes per group).
+
+def group_rows(result, segment_data, group_by_columns):
+    """[(key values tuple, [(function, AggValue)...])] of one segment's group-by result: raw group id -> per-column dictIds
+    (DictionaryBasedGroupKeyGenerator.java:306-324: id = sum dictId_j * prod_{k<j} cardinality_k) -> dictionary values."""
+    cards = [segment_data.columns[c].cardinality for c in group_by_columns]
+    rows = []
+    for gid, values in result.groups.items():
+        key, rest = [], gid
+        for c, card in zip(group_by_columns, cards):
+            key.append(segment_data.columns[c].value_of(rest % card))
+            rest //= card
+        rows.append((tuple(key), [(f, v.count, v.sum, v.sum_i64, v.min, v.max) for f, v in zip(result.functions, values)]))
+    return rows
+
+
+def merge_group_rows(per_rank_rows):
+    """Value-keyed merge with the reference's merge rules per function (AggregationFunction.merge: SUM '+' on doubles, COUNT '+',
+    MIN / MAX Math.min / max, AVG pairwise sum and count).  Returns {key tuple: [(function, count, sum, sum_i64, min, max)...]}."""
+    table = {}
+    for rows in per_rank_rows:
+        for key, values in rows:
+            if key not in table:
+                table[key] = [tuple(v) for v in values]
+                continue
+            merged = []
+            for (f, c0, s0, i0, mn0, mx0), (_, c1, s1, i1, mn1, mx1) in zip(table[key], values):
+                merged.append((f, c0 + c1, s0 + s1, i0 + i1, min(mn0, mn1), max(mx0, mx1)))
+            table[key] = merged
+    return table
+
+
+def gather_group_rows(rows):
+    """all_gather of the value-keyed rows (python objects over the process group's CPU backend)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [rows]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, rows)
+    return out

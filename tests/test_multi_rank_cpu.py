@@ -72,3 +72,72 @@ def test_two_ranks_shard_segments_and_merge_on_host():
         total_sum += per_rank[r][0]
         total_count += per_rank[r][1]
     assert results[0][2] == (float(total_sum), total_count)
+
+
+def _group_worker(rank, world, port, out_queue):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from oracle import oracle
+    from pinot_amd import distributed as D
+    from pinot_amd import query as Q
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    seg, _, _ = _group_segment(rank)
+    res = oracle.execute(seg, Q.QuerySpec([(Q.SUM, 2), (Q.COUNT, -1), (Q.MIN, 2), (Q.MAX, 2), (Q.AVG, 2)], group_by=[0, 1]))
+    rows = D.group_rows(res, seg, [0, 1])
+    merged = D.merge_group_rows(D.gather_group_rows(rows))
+    dist.barrier()
+    out_queue.put((rank, sorted(res.groups), sorted((k, tuple(v)) for k, v in merged.items())))
+    dist.destroy_process_group()
+
+
+def _group_segment(rank):
+    """Two key columns whose DICTIONARIES differ per rank: the same values sit under different dictIds (rank 1 has extra values in
+    front), and some keys exist on one rank only."""
+    from pinot_amd import segment as S
+    rng = np.random.default_rng(100 + rank)
+    n = 50_021
+    kv = np.array([10, 20, 30, 40, 50], dtype=np.int32) if rank == 0 else np.array([-5, 0, 10, 30, 50, 70], dtype=np.int32)
+    gv = np.array([1, 2, 3], dtype=np.int32) if rank == 0 else np.array([2, 3, 4, 5], dtype=np.int32)
+    k = kv[rng.integers(0, kv.shape[0], n)]
+    g = gv[rng.integers(0, gv.shape[0], n)]
+    m = rng.integers(-1000, 1000, n).astype(np.int32)
+    seg = S.SegmentData("g%d" % rank, n, [S.Column.dict_encoded("k", k), S.Column.dict_encoded("g", g), S.Column.dict_encoded("m", m)])
+    return seg, (k, g), m
+
+
+def test_group_by_partials_merge_on_key_values_not_dictids():
+    """GroupByCombineOperator.java:132-147: the merge key is the tuple of VALUES.  The two ranks' dictionaries differ, so equal raw
+    group ids mean different keys and equal keys have different raw ids: a merge keyed on dictIds / raw ids cannot pass this."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert results[0][2] == results[1][2]                  # every rank ends with the same merged table
+    assert set(results[0][1]) & set(results[1][1])         # raw group ids DO collide across ranks ...
+    # ground truth straight from the values
+    truth = {}
+    for r in range(world):
+        _, (k, g), m = _group_segment(r)
+        for key in set(zip(k.tolist(), g.tolist())):
+            sel = (k == key[0]) & (g == key[1])
+            c, s, mn, mx = int(sel.sum()), int(m[sel].astype(np.int64).sum()), float(m[sel].min()), float(m[sel].max())
+            c0, s0, mn0, mx0 = truth.get(key, (0, 0, float("inf"), float("-inf")))
+            truth[key] = (c0 + c, s0 + s, min(mn0, mn), max(mx0, mx))
+    merged = dict(results[0][2])
+    assert set(merged) == set(truth)
+    only_rank1 = [key for key in truth if key[0] in (-5, 0, 70) or key[1] in (4, 5)]
+    assert only_rank1                                       # ... and some keys exist on one rank only
+    for key, (c, s, mn, mx) in truth.items():
+        rows = merged[key]          # [(SUM), (COUNT), (MIN), (MAX), (AVG)] as (function, count, sum, sum_i64, min, max)
+        assert rows[0][3] == s and rows[0][2] == float(s)
+        assert rows[1][1] == c
+        assert rows[2][4] == mn and rows[3][5] == mx
+        assert rows[4][3] == s and rows[4][1] == c

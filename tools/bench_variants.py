@@ -1,0 +1,145 @@
+"""The `variants` array of bench.py's JSON line: every BASELINE.json configuration besides the headline, timed in the driver's own
+run with the parity check on (rank 0, N = 1).
+
+Each entry: {id, config, query, rows, kernel, kernel_ms (the dominant kernel, HIP events on the launch stream), all_kernels_ms (every
+kernel of the query, e.g. posting expansion), algorithmic_bytes (SURVEY.md 8(d) / BASELINE.md section 3), achieved_GBps and frac of
+8 TB/s on all_kernels_ms, rows_per_s, bit_exact_vs_oracle}.  The oracle runs on all host cores (oracle.execute_sliced) so that a
+1 B-row check takes a fraction of a second; inverted-index leaves are checked against the oracle's SCAN of the same predicate (the
+same docId set by definition; the oracle's own posting reader is pinned in tests/).
+"""
+import time
+
+import numpy as np
+
+HBM_PEAK_GBPS = 8000.0
+
+
+def _shared(S, col, name, dict_values):
+    """A column with the same packed dictIds as `col` (the host buffer is shared) under another dictionary."""
+    lib = S.load_host_library()
+    dict_values = np.ascontiguousarray(dict_values, dtype=np.int32)
+    dictionary = np.zeros(dict_values.shape[0] * 4, dtype=np.uint8)
+    lib.ph_dict_write_int(S._i32p(dict_values), int(dict_values.shape[0]), S._u8p(dictionary))
+    return S.Column(name, col.encoding, col.bits, col.cardinality, col.fwd, dictionary, None, dict_values)
+
+
+def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=3):
+    from bench import Timer, v_dictionary
+    from oracle import oracle
+    from pinot_amd import _abi
+    from pinot_amd import query as Q
+    from pinot_amd import segment as S
+
+    timer = Timer(engine.lib, _abi)
+    out = []
+    want = lambda vid: match is None or match.search(vid) is not None
+
+    def report(vid, config, query, rows, nbytes, gseg, seg, spec, oracle_spec=None, extra=None):
+        t = timer.run(gseg, spec, steps, warmup)
+        rec = {"id": vid, "config": config, "query": query, "rows": rows}
+        rec.update(t)
+        ms = t["all_kernels_ms"] if t["all_kernels_ms"] > 0 else float("inf")      # metadata-only answers launch nothing
+        rec.update({"algorithmic_bytes": int(nbytes), "achieved_GBps": nbytes / ms / 1e6, "frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS,
+                    "frac_dominant_kernel": (nbytes / t["kernel_ms"] / 1e6 / HBM_PEAK_GBPS) if t["kernel_ms"] > 0 else None,
+                    "rows_per_s": rows / ms * 1e3})
+        got = gseg.execute(spec)
+        rec["docs_matched"] = got.stats[0]
+        rec["bit_exact_vs_oracle"] = None
+        if check:
+            t0 = time.perf_counter()
+            wanted = oracle.execute_sliced(seg, oracle_spec or spec)
+            rec["bit_exact_vs_oracle"] = bool(oracle.matches_sliced(got, wanted, [f for f, _ in spec.aggregations]) and got.stats[0] == wanted["docs_scanned"])
+            rec["oracle_check_s"] = time.perf_counter() - t0
+        if extra:
+            rec.update(extra)
+        out.append(rec)
+
+    B = lambda col: col.fwd.nbytes
+    v, f = seg0.columns[0], seg0.columns[1]
+
+    # ---- C2 / C3 on 1 B rows: the headline's v and f, v under two dictionaries without structure, and the C3 columns ----
+    if any(want(x) for x in ("C2b-irregular", "C2b-window", "C2a-affine", "C2a-irregular", "C3", "C3-filter", "C3-irregular", "COUNT-filter", "C2b-1pct", "C2b-50pct")):
+        t0 = time.time()
+        v_irr = _shared(S, v, "v_irr", v_dictionary("irregular"))
+        v_win = _shared(S, v, "v_win", v_dictionary("window"))
+        k = S.Column.synthetic_uniform("k", n, np.arange(1000, dtype=np.int32) * 3, seed=3)
+        a = S.Column.synthetic_uniform("a", n, (np.arange(100000, dtype=np.int64) * 5 + 1).astype(np.int32), seed=4)
+        b = S.Column.synthetic_uniform("b", n, np.arange(65536, dtype=np.int32) * 2, seed=5)
+        a_irr = _shared(S, a, "a_irr", v_dictionary("irregular", seed=77))
+        seg = S.SegmentData("variants", n, [v, f, v_irr, v_win, k, a, b, a_irr])
+        gen_s = time.time() - t0
+        flt = Q.leaf(Q.Pred.dict_range(1, 0, 100))
+        with engine.open(seg) as g:
+            setup = {"host_generate_s": gen_s, "device_bytes": g.device_bytes()}
+            for vid, ci, name in (("C2b-irregular", 2, "100000 sorted distinct values from the whole int32 range"), ("C2b-window", 3, "100000 sorted distinct values from [0, 2^20)")):
+                if want(vid):
+                    report(vid, "BASELINE.json configs[1], dictionary without structure", "SELECT SUM(%s) WHERE f < 100 (10%%); dictionary: %s" % (seg.columns[ci].name, name), n, B(v) + B(f), g, seg,
+                           Q.QuerySpec([(Q.SUM, ci)], filter=flt), extra={"dictionary": "irregular" if ci == 2 else "window", "hbm_resident_bytes_of_the_summed_column": B(v) + 400000})
+            for vid, t in (("C2b-1pct", 10), ("C2b-50pct", 500)):
+                if want(vid):
+                    report(vid, "BASELINE.json configs[1], other selectivities", "SELECT SUM(v) WHERE f < %d" % t, n, B(v) + B(f), g, seg, Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, t))),
+                           extra={"dictionary": "affine"})
+            for vid, ci in (("C2a-affine", 0), ("C2a-irregular", 2)):
+                if want(vid):
+                    report(vid, "BASELINE.md C2a (predicate on the summed column)", "SELECT SUM(%s) WHERE %s BETWEEN dict[45000] AND dict[54999] (10%%)" % (seg.columns[ci].name, seg.columns[ci].name),
+                           n, B(v), g, seg, Q.QuerySpec([(Q.SUM, ci)], filter=Q.leaf(Q.Pred.dict_range(ci, 45000, 55000))), extra={"dictionary": "affine" if ci == 0 else "irregular"})
+            if want("C3"):
+                report("C3", "BASELINE.json configs[2]", "SELECT SUM(a), MAX(b) GROUP BY k (1000 groups)", n, B(k) + B(a) + B(b), g, seg, Q.QuerySpec([(Q.SUM, 5), (Q.MAX, 6)], group_by=[4]))
+            if want("C3-filter"):
+                report("C3-filter", "BASELINE.json configs[2] + filter", "SELECT SUM(a), MAX(b) WHERE f < 100 GROUP BY k", n, B(k) + B(a) + B(b) + B(f), g, seg,
+                       Q.QuerySpec([(Q.SUM, 5), (Q.MAX, 6)], filter=flt, group_by=[4]))
+            if want("C3-irregular"):
+                report("C3-irregular", "BASELINE.json configs[2], summed column with a dictionary without structure", "SELECT SUM(a_irr), MAX(b) GROUP BY k", n, B(k) + B(a) + B(b), g, seg,
+                       Q.QuerySpec([(Q.SUM, 7), (Q.MAX, 6)], group_by=[4]), extra={"dictionary": "irregular"})
+            if want("COUNT-filter"):
+                report("COUNT-filter", "filter only", "SELECT COUNT(*) WHERE f < 100", n, B(f), g, seg, Q.QuerySpec([(Q.COUNT, -1)], filter=flt))
+            if out:
+                out[-1]["setup"] = setup
+        del seg, k, a, b, a_irr, v_irr, v_win
+
+    # ---- C5: inverted-index AND of 3 postings -> docIds -> SUM, sparse (C = 16 / 64 / 256) and dense (C = 2 / 4 / 8) ----
+    for vid, cards, seeds, picks in (("C5-sparse", (16, 64, 256), (11, 12, 13), (3, 5, 7)), ("C5-dense", (2, 4, 8), (21, 22, 23), (1, 2, 5))):
+        if not (want(vid) or want(vid + "-count")):
+            continue
+        t0 = time.time()
+        cols = []
+        for name, card, seed in zip("pqr", cards, seeds):
+            ids = S.synthetic_dict_ids(seed, 0, n_c5, card)
+            cols.append(S.Column.from_dict_ids(name, np.arange(card, dtype=np.int32), ids, with_inverted=True))
+            del ids
+        if n_c5 == n:
+            v5 = v
+        else:
+            v5 = S.Column.synthetic_uniform("v", n_c5, v_dictionary("affine"), seed=1)
+        seg5 = S.SegmentData(vid, n_c5, cols + [v5])
+        gen_s = time.time() - t0
+        inv = lambda c, d: Q.leaf(Q.Pred.dict_range(c, d, d + 1, inverted=True))
+        scan = lambda c, d: Q.leaf(Q.Pred.dict_range(c, d, d + 1))
+        post = [int(c.inverted.nbytes / c.cardinality) for c in cols]
+        with engine.open(seg5) as g:
+            survivors = int(n_c5 / (cards[0] * cards[1] * cards[2]))
+            value_bytes = min(B(v5), survivors * 64)
+            if want(vid):
+                report(vid, "BASELINE.json configs[4]", "SELECT SUM(v) WHERE p=%d AND q=%d AND r=%d via inverted indexes (C = %d / %d / %d)" % (picks + cards), n_c5,
+                       sum(post) + value_bytes, g, seg5, Q.QuerySpec([(Q.SUM, 3)], filter=Q.and_(inv(0, picks[0]), inv(1, picks[1]), inv(2, picks[2]))),
+                       oracle_spec=Q.QuerySpec([(Q.SUM, 3)], filter=Q.and_(scan(0, picks[0]), scan(1, picks[1]), scan(2, picks[2]))),
+                       extra={"posting_bytes_read": post, "value_bytes": value_bytes, "host_generate_s": gen_s,
+                              "algorithmic_bytes_note": "the three serialized postings + min(B(v), survivors x 64 B); dense intermediates are not charged (BASELINE.md C5)"})
+            if want(vid + "-count"):
+                report(vid + "-count", "BASELINE.json configs[4], two postings, COUNT", "SELECT COUNT(*) WHERE p=%d AND q=%d via inverted indexes" % picks[:2], n_c5, post[0] + post[1], g, seg5,
+                       Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(inv(0, picks[0]), inv(1, picks[1]))),
+                       oracle_spec=Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(scan(0, picks[0]), scan(1, picks[1]))))
+        del seg5, cols
+
+    # ---- C1: 10 M rows, raw int32 forward index (BASELINE.json configs[0] is the reference's CPU case; COUNT(*) itself is O(1)) ----
+    if want("C1"):
+        n1 = 10_000_000
+        raw = S.Column.raw("raw_i32", S.synthetic_dict_ids(42, 0, n1, 1_000_000))
+        seg1 = S.SegmentData("c1", n1, [raw])
+        with engine.open(seg1) as g:
+            report("C1-count-range", "BASELINE.json configs[0], scan-forcing companion", "SELECT COUNT(*) WHERE raw_i32 BETWEEN 1 AND 10 (10 M rows, raw)", n1, 4 * n1, g, seg1,
+                   Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.raw_range(0, 1, 10))))
+            report("C1-sum", "BASELINE.json configs[0], scan-forcing companion", "SELECT SUM(raw_i32) (10 M rows, raw)", n1, 4 * n1, g, seg1, Q.QuerySpec([(Q.SUM, 0)]))
+            report("C1-count", "BASELINE.json configs[0] literally: O(1) in the reference (NonScanBasedAggregationOperator) and here", "SELECT COUNT(*) (10 M rows)", n1, 0, g, seg1,
+                   Q.QuerySpec([(Q.COUNT, -1)]))
+    return out
