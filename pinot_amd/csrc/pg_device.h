@@ -180,6 +180,8 @@ struct ScanParams {
   DevAggCol agg_cols[kMaxAggCols];
   const unsigned long long* bitmaps[kMaxLeaves];   // bitmap leaves, in leaf order
   int32_t bitmap_lds_off[kMaxLeaves];
+  const uint32_t* tile_list;       // lane-private kernels: visit only these 2048-doc tiles (index_and_kernel's survivors), or nullptr = all
+  const uint32_t* tile_count;      //                       [1] how many of them
   unsigned long long* out_bitmap;  // optional doc-order bitmap output (num_tiles * tile_steps words)
   BlockPartial* partials;          // [gridDim.x]
 };
@@ -264,6 +266,31 @@ struct PartitionParams {
   uint32_t* part_key;               // [num_docs] raw keys
   uint32_t* part_val[kMaxPartitionAggs];   // [num_docs] 32-bit aggregation inputs (dictIds, plane fields or raw values)
   const PartitionWork* work;        // pass B work list
+};
+
+// ---- index-only AND (index_and_kernel): the inverted-index children of a root AND, intersected window by window ----
+constexpr int kMaxAndChildren = 8;
+constexpr int kMaxAndPostings = 16;      // postings OR-ed into one child (EQ: 1; IN lists and short dictId ranges: up to 16)
+
+struct AndChild {
+  const uint8_t* inv;                    // the column's inverted-index buffer (serialized RoaringBitmaps), or nullptr for a dense child
+  const struct DevContainer* dir;        // the column's parsed container directory
+  const unsigned long long* dense;       // dense child: a doc-order bitmap that already exists (long IN lists expanded by roaring_expand_kernel)
+  int32_t num_postings;
+  int32_t exclusive;                     // NOT_EQ / NOT_IN: the complement over [0, numDocs)
+  int32_t first[kMaxAndPostings];        // directory slice [first, first + count) of every posting
+  int32_t count[kMaxAndPostings];
+};
+
+struct IndexAndParams {
+  int32_t num_children;
+  int32_t num_docs;
+  long long num_words;                   // 64-bit words of the output bitmap (2048-doc tiles * 32)
+  unsigned long long* out;               // doc-order result; every 65 536-doc window is written (zeros included)
+  uint32_t* tile_list;                   // the 2048-doc tiles that hold at least one match, in no particular order
+  uint32_t* tile_count;                  // [1] number of listed tiles (zeroed by the host before the launch)
+  unsigned long long* cardinality;       // [1] matching docs (zeroed by the host before the launch)
+  AndChild child[kMaxAndChildren];
 };
 
 // ---- roaring expansion ----

@@ -136,6 +136,8 @@ struct ExecCtx {
   size_t gather_capacity = 0;
   uint8_t* d_partition = nullptr;               // partitioned group-by: counters, work list and the record buffers
   size_t partition_capacity = 0;
+  uint32_t* d_tile_list = nullptr;              // index_and_kernel: surviving 2048-doc tiles (one entry per tile of the segment)
+  unsigned long long* d_and_counters = nullptr; // [0] cardinality (u64), [1] low dword: number of listed tiles
 };
 
 }  // namespace
@@ -167,6 +169,8 @@ void destroy_ctx(ExecCtx* c) {
   if (c->d_gather_in) (void)hipFree(c->d_gather_in);
   if (c->d_gather_out) (void)hipFree(c->d_gather_out);
   if (c->d_partition) (void)hipFree(c->d_partition);
+  if (c->d_tile_list) (void)hipFree(c->d_tile_list);
+  if (c->d_and_counters) (void)hipFree(c->d_and_counters);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -446,6 +450,11 @@ struct Lowered {
   std::vector<char> plane_cols;       // per segment column: aggregations read it through its value plane
   int num_scan_leaves = 0;
   int max_bits = 1;
+  // index_and_kernel ran for the inverted-index children of the root AND: every match lies in one of the listed tiles
+  const uint32_t* tile_list = nullptr;
+  const uint32_t* tile_count = nullptr;
+  const unsigned long long* d_cardinality = nullptr;
+  bool index_and_is_whole_filter = false;      // the filter is exactly that AND: its cardinality answers COUNT(*)
 };
 
 int slot_for(Lowered* lw, const pg_segment* seg, int column, bool plane = false) {
@@ -483,11 +492,22 @@ struct SeqNode { int src; int op; int num_children; int flags; };
 // Re-orders the children of a root AND so that inverted-index (bitmap) leaves come first, rewrites that AND as a chain
 // of binary ANDs flagged kNodeExitIfZero (AND is commutative and associative: same docId set), and reports where the
 // bitmap prefix ends.  Everything else keeps its postfix order.
-void build_sequence(const pg_query* q, std::vector<SeqNode>* seq, int* lazy_node, int* num_bitmap_prefix) {
+constexpr int kSeqIndexAnd = -2;       // SeqNode.src of the leaf that stands for all inverted-index children of the root AND
+
+bool is_inverted_leaf(const pg_query* q, int node) {
+  if (q->filter[node].op != PG_FILTER_LEAF) return false;
+  const int pi = q->filter[node].predicate;
+  if (pi < 0 || pi >= q->num_predicates) return false;
+  const pg_predicate& pr = q->predicates[pi];
+  return pr.eval == PG_EVAL_INVERTED && (pr.kind == PG_PRED_DICT_RANGE || pr.kind == PG_PRED_DICT_SET);
+}
+
+void build_sequence(const pg_query* q, std::vector<SeqNode>* seq, int* lazy_node, int* num_bitmap_prefix, std::vector<int>* and_members) {
   const int n = q->num_filter_nodes;
   *lazy_node = -1;
   *num_bitmap_prefix = 0;
   seq->clear();
+  and_members->clear();
   if (n == 0) return;
   std::vector<int> start((size_t)n, 0);
   for (int i = 0; i < n; ++i) {
@@ -503,6 +523,12 @@ void build_sequence(const pg_query* q, std::vector<SeqNode>* seq, int* lazy_node
   const pg_filter_node& root = q->filter[n - 1];
   auto identity = [&](int from, int to) { for (int i = from; i <= to; ++i) seq->push_back(SeqNode{i, q->filter[i].op, q->filter[i].num_children, 0}); };
   if (root.op != PG_FILTER_AND || root.num_children < 2 || start[(size_t)n - 1] != 0) {
+    if (n == 1 && is_inverted_leaf(q, 0)) {
+      // a single inverted-index leaf: the same window-by-window kernel expands it and lists the tiles that hold a match
+      and_members->push_back(q->filter[0].predicate);
+      seq->push_back(SeqNode{kSeqIndexAnd, PG_FILTER_LEAF, 0, kNodeExitIfZero});
+      return;
+    }
     identity(0, n - 1);
     if (root.op == PG_FILTER_LEAF) seq->back().flags |= kNodeExitIfZero;
     return;
@@ -521,9 +547,19 @@ void build_sequence(const pg_query* q, std::vector<SeqNode>* seq, int* lazy_node
     return pr.kind == PG_PRED_DOC_RANGE || pr.kind == PG_PRED_IS_NULL || (pr.eval == PG_EVAL_INVERTED && (pr.kind == PG_PRED_DICT_RANGE || pr.kind == PG_PRED_DICT_SET));
   };
   std::stable_partition(children.begin(), children.end(), is_bitmap_leaf);
-  for (const auto& ch : children) *num_bitmap_prefix += is_bitmap_leaf(ch) ? 1 : 0;
-  for (size_t c = 0; c < children.size(); ++c) {
-    identity(children[c].first, children[c].second);
+  // The inverted-index children are and-ed by ONE kernel, container by container (AndDocIdSet.java:127-165 and-s the index-based
+  // children first): they become a single leaf at the head of the chain.
+  std::vector<std::pair<int, int>> rest;
+  for (const auto& ch : children) {
+    if (ch.first == ch.second && is_inverted_leaf(q, ch.first) && (int)and_members->size() < kMaxAndChildren) and_members->push_back(q->filter[ch.first].predicate);
+    else rest.push_back(ch);
+  }
+  const int head = and_members->empty() ? 0 : 1;
+  for (const auto& ch : rest) *num_bitmap_prefix += is_bitmap_leaf(ch) ? 1 : 0;
+  *num_bitmap_prefix += head;
+  for (size_t c = 0; c < rest.size() + (size_t)head; ++c) {
+    if (head && c == 0) seq->push_back(SeqNode{kSeqIndexAnd, PG_FILTER_LEAF, 0, 0});
+    else identity(rest[c - (size_t)head].first, rest[c - (size_t)head].second);
     if (c == 0) seq->back().flags |= kNodeExitIfZero;
     else seq->push_back(SeqNode{-1, PG_FILTER_AND, 2, kNodeExitIfZero});
     if ((int)c + 1 == *num_bitmap_prefix) *lazy_node = (int)seq->size() - 1;
@@ -540,8 +576,31 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
     if ((op == PG_FILTER_AND || op == PG_FILTER_OR) && q->filter[n].num_children < 1) return fail(PG_ERR_INVALID_ARGUMENT, "malformed filter tree (node %d)", n);
   }
   std::vector<SeqNode> seq;
+  std::vector<int> and_members;
   int lazy_node = -1, num_bitmap_prefix = 0;
-  build_sequence(q, &seq, &lazy_node, &num_bitmap_prefix);
+  build_sequence(q, &seq, &lazy_node, &num_bitmap_prefix, &and_members);
+  for (int pi : and_members) if (pi < 0 || pi >= q->num_predicates) return fail(PG_ERR_INVALID_ARGUMENT, "bad predicate index");
+  // InvertedIndexFilterOperator.getTrues as a dense doc-order bitmap: OR of the postings of every matching dictId (the general path:
+  // leaves under OR / NOT, and members of the index AND with more than kMaxAndPostings postings)
+  auto expand_dense = [&](const ColumnDev& col, const pg_predicate& pr, unsigned long long* bm) -> pg_status {
+    const long long words = (long long)seg->num_tiles * kMaxTileSteps;
+    const unsigned num_windows = (unsigned)((words + 1023) / 1024);
+    bool first_posting = true;
+    for (int d = 0; d < col.cardinality; ++d) {
+      bool in;
+      if (pr.kind == PG_PRED_DICT_RANGE) in = d >= pr.lo && d < pr.hi;
+      else in = (d >> 5) < pr.num_set_words && ((pr.set_words[d >> 5] >> (d & 31)) & 1u);
+      if (!in) continue;
+      const int64_t first = col.posting_first[d], cnt = col.posting_first[d + 1] - first;
+      if (cnt <= 0 && !first_posting) continue;
+      // the first posting stores every window (zeros where it has no container); later ones OR
+      roaring_expand_kernel<<<dim3(num_windows), dim3(kBlockThreads), 0, ctx->stream>>>(col.d_inv, col.d_dir, (int)first, (int)cnt, bm, words, first_posting ? 0 : 1);
+      first_posting = false;
+    }
+    if (first_posting) fill_words_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(bm, words, 0ull);   // no dictId matched
+    HIP_TRY(hipGetLastError());
+    return PG_OK;
+  };
   if ((int)seq.size() > kMaxNodes) return fail(PG_ERR_UNSUPPORTED, "filter tree has %d nodes (max %d)", (int)seq.size(), kMaxNodes);
   int depth = 0, max_depth = 0;
   size_t bitmap_idx = 1;   // bitmap 0 is reserved for pg_filter_bitmap output
@@ -557,6 +616,89 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
     dn.leaf = -1;
     dn.num_children = fn.num_children;
     dn.flags = seq[(size_t)n].flags;
+    if (fn.op == PG_FILTER_LEAF && seq[(size_t)n].src == kSeqIndexAnd) {
+      // ---- the inverted-index children of the root AND, intersected container by container (index_and_kernel) ----
+      if (sp.num_leaves >= kMaxLeaves) return fail(PG_ERR_UNSUPPORTED, "more than %d filter leaves", kMaxLeaves);
+      DevLeaf& L = sp.leaves[sp.num_leaves];
+      memset(&L, 0, sizeof(L));
+      dn.leaf = sp.num_leaves++;
+      struct Member { AndChild child; double estimate; };
+      std::vector<Member> members;
+      bool empty = false;
+      std::vector<size_t> dense_bitmaps;
+      for (int pi : and_members) {
+        const pg_predicate& pr = q->predicates[pi];
+        if (pr.column < 0 || pr.column >= (int)seg->cols.size()) return fail(PG_ERR_INVALID_ARGUMENT, "predicate column %d out of range", pr.column);
+        const ColumnDev& col = seg->cols[pr.column];
+        if (col.encoding != PG_FWD_FIXED_BIT_DICT) return fail(PG_ERR_INVALID_ARGUMENT, "dictionary predicate on raw column %s", col.name.c_str());
+        if (!col.d_inv) return fail(PG_ERR_INVALID_ARGUMENT, "column %s has no inverted index", col.name.c_str());
+        if (pr.kind == PG_PRED_DICT_SET && (pr.num_set_words < 0 || (pr.num_set_words > 0 && !pr.set_words))) return fail(PG_ERR_INVALID_ARGUMENT, "bad dictId set");
+        Member mb;
+        memset(&mb.child, 0, sizeof(mb.child));
+        mb.child.inv = col.d_inv; mb.child.dir = col.d_dir; mb.child.exclusive = pr.exclusive ? 1 : 0;
+        double docs = 0;
+        int postings = 0;
+        bool inline_ok = true;
+        for (int d = 0; d < col.cardinality; ++d) {
+          bool in;
+          if (pr.kind == PG_PRED_DICT_RANGE) in = d >= pr.lo && d < pr.hi;
+          else in = (d >> 5) < pr.num_set_words && ((pr.set_words[d >> 5] >> (d & 31)) & 1u);
+          if (!in) continue;
+          const int64_t first = col.posting_first[d], cnt = col.posting_first[d + 1] - first;
+          if (cnt <= 0) continue;
+          for (int64_t k = first; k < first + cnt; ++k) docs += col.h_dir[(size_t)k].cardinality;
+          if (postings < kMaxAndPostings) { mb.child.first[postings] = (int32_t)first; mb.child.count[postings] = (int32_t)cnt; }
+          else inline_ok = false;
+          postings++;
+        }
+        if (postings == 0 && !pr.exclusive) { empty = true; break; }          // nothing matches this child: the AND is empty
+        if (postings == 0 && pr.exclusive) continue;                          // NOT (nothing) = everything: the child drops out
+        mb.estimate = pr.exclusive ? (double)seg->num_docs - docs : docs;
+        if (inline_ok) mb.child.num_postings = postings;
+        else {
+          pg_status st = ensure_bitmap(seg, ctx, bitmap_idx);
+          if (st != PG_OK) return st;
+          unsigned long long* bm = ctx->d_bitmaps[bitmap_idx++];
+          st = expand_dense(col, pr, bm);
+          if (st != PG_OK) return st;
+          mb.child.inv = nullptr; mb.child.dir = nullptr; mb.child.dense = bm; mb.child.num_postings = 0;
+        }
+        members.push_back(mb);
+      }
+      if (empty) { L.kind = kLeafMatchNone; depth++; max_depth = std::max(max_depth, depth); continue; }
+      if (members.empty()) { L.kind = kLeafMatchAll; depth++; max_depth = std::max(max_depth, depth); continue; }
+      // smallest first, like AndDocIdSet sorts its bitmaps: an empty window ends the work for the later children
+      std::stable_sort(members.begin(), members.end(), [](const Member& a, const Member& b) { return a.estimate < b.estimate; });
+      pg_status st = ensure_bitmap(seg, ctx, bitmap_idx);
+      if (st != PG_OK) return st;
+      unsigned long long* bm = ctx->d_bitmaps[bitmap_idx++];
+      if (!ctx->d_tile_list) HIP_TRY(hipMalloc((void**)&ctx->d_tile_list, (size_t)std::max(seg->num_tiles, 1) * 4 + 256));
+      if (!ctx->d_and_counters) HIP_TRY(hipMalloc((void**)&ctx->d_and_counters, 16));
+      HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16, ctx->stream));
+      IndexAndParams ap;
+      memset(&ap, 0, sizeof(ap));
+      ap.num_children = (int32_t)members.size();
+      ap.num_docs = seg->num_docs;
+      ap.num_words = (long long)seg->num_tiles * kMaxTileSteps;
+      ap.out = bm;
+      ap.tile_list = ctx->d_tile_list;
+      ap.cardinality = ctx->d_and_counters;
+      ap.tile_count = reinterpret_cast<uint32_t*>(ctx->d_and_counters + 1);
+      for (size_t c = 0; c < members.size(); ++c) ap.child[c] = members[c].child;
+      const unsigned num_windows = (unsigned)((ap.num_words + 1023) / 1024);
+      if (num_windows) index_and_kernel<<<dim3(num_windows), dim3(kBlockThreads), 0, ctx->stream>>>(ap);
+      HIP_TRY(hipGetLastError());
+      L.kind = kLeafBitmap;
+      L.bitmap = bm;
+      sp.num_bitmap_leaves++;
+      lw->tile_list = ctx->d_tile_list;
+      lw->tile_count = ap.tile_count;
+      lw->d_cardinality = ap.cardinality;
+      lw->index_and_is_whole_filter = seq.size() == 1;
+      depth++;
+      max_depth = std::max(max_depth, depth);
+      continue;
+    }
     if (fn.op == PG_FILTER_LEAF) {
       if (fn.predicate < 0 || fn.predicate >= q->num_predicates) return fail(PG_ERR_INVALID_ARGUMENT, "filter node %d: bad predicate index", n);
       if (sp.num_leaves >= kMaxLeaves) return fail(PG_ERR_UNSUPPORTED, "more than %d filter leaves", kMaxLeaves);
@@ -592,25 +734,12 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
           if (!col.d_inv) return fail(PG_ERR_INVALID_ARGUMENT, "column %s has no inverted index", col.name.c_str());
           if (pr.kind != PG_PRED_DICT_RANGE && pr.kind != PG_PRED_DICT_SET) return fail(PG_ERR_INVALID_ARGUMENT, "inverted-index leaf needs a dictionary predicate");
           // InvertedIndexFilterOperator.getTrues: OR of the postings of every matching dictId.
+          if (pr.kind == PG_PRED_DICT_SET && (pr.num_set_words < 0 || (pr.num_set_words > 0 && !pr.set_words))) return fail(PG_ERR_INVALID_ARGUMENT, "bad dictId set");
           pg_status st = ensure_bitmap(seg, ctx, bitmap_idx);
           if (st != PG_OK) return st;
           unsigned long long* bm = ctx->d_bitmaps[bitmap_idx++];
-          const long long words = (long long)seg->num_tiles * kMaxTileSteps;
-          const unsigned num_windows = (unsigned)((words + 1023) / 1024);
-          bool first_posting = true;
-          for (int d = 0; d < col.cardinality; ++d) {
-            bool in;
-            if (pr.kind == PG_PRED_DICT_RANGE) in = d >= pr.lo && d < pr.hi;
-            else in = (d >> 5) < pr.num_set_words && ((pr.set_words[d >> 5] >> (d & 31)) & 1u);
-            if (!in) continue;
-            const int64_t first = col.posting_first[d], cnt = col.posting_first[d + 1] - first;
-            if (cnt <= 0 && !first_posting) continue;
-            // the first posting stores every window (zeros where it has no container); later ones OR
-            roaring_expand_kernel<<<dim3(num_windows), dim3(kBlockThreads), 0, ctx->stream>>>(col.d_inv, col.d_dir, (int)first, (int)cnt, bm, words,
-                                                                                              first_posting ? 0 : 1);
-            first_posting = false;
-          }
-          if (first_posting) fill_words_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(bm, words, 0ull);   // no dictId matched
+          st = expand_dense(col, pr, bm);
+          if (st != PG_OK) return st;
           L.kind = kLeafBitmap;
           L.bitmap = bm;
           sp.num_bitmap_leaves++;
@@ -1309,6 +1438,39 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
 
   if (out) memset(out, 0, sizeof(*out));
 
+  if (ng == 0 && out && !want_bitmap && lw.index_and_is_whole_filter && na > 0) {
+    // FastFilteredCountOperator (core/plan/AggregationPlanNode.java:98-115, core/operator/query/FastFilteredCountOperator.java:66-72): COUNT(*)
+    // over a filter that the indexes answer alone is the cardinality of the and-ed bitmaps -- index_and_kernel counted it, nothing is scanned.
+    bool only_count = true;
+    for (int a = 0; a < na; ++a) only_count &= q->aggregations[a].function == PG_AGG_COUNT;
+    if (only_count) {
+      unsigned long long* h_card = &ctx->h_partial->count;
+      HIP_TRY(hipMemcpyAsync(h_card, lw.d_cardinality, 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (timed) { HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream)); HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream)); HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      const int64_t card = (int64_t)*h_card;
+      out->num_aggregations = na;
+      out->aggregations = (pg_agg_value*)calloc((size_t)na, sizeof(pg_agg_value));
+      for (int a = 0; a < na; ++a) {
+        out->aggregations[a].count = card;
+        out->aggregations[a].min = std::numeric_limits<double>::infinity();
+        out->aggregations[a].max = -std::numeric_limits<double>::infinity();
+      }
+      out->dominant_kernel = PG_KERNEL_INDEX_AND;
+      out->stats.num_docs_scanned = card;
+      out->stats.num_entries_scanned_in_filter = 0;
+      out->stats.num_entries_scanned_post_filter = 0;
+      out->stats.num_total_docs = seg->num_docs;
+      if (out_cardinality) *out_cardinality = card;
+      if (timed) {
+        float ms_all = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms_all, ctx->ev[0], ctx->ev[3]));
+        out->device_ms = ms_all;
+        out->dominant_kernel_ms = ms_all;        // the index AND is the query
+      }
+      return PG_OK;
+    }
+  }
   if (ng == 0) {
     // ---------------- aggregation only ----------------
     std::vector<int> agg_slot_of((size_t)std::max(na, 1), -1);
@@ -1402,6 +1564,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if (st != PG_OK) return st;
       sp.out_bitmap = ctx->d_bitmaps[0];
     }
+    if (!want_bitmap && (use_hist || use_private || use_private_typed)) { sp.tile_list = lw.tile_list; sp.tile_count = lw.tile_count; }
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
@@ -1616,6 +1779,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     gp.scan = sp;
     gp.scan.partials = nullptr;
     gp.scan.out_bitmap = nullptr;
+    gp.scan.tile_list = lw.tile_list;            // read by group_private_kernel only
+    gp.scan.tile_count = lw.tile_count;
     init_group_table_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(gp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));

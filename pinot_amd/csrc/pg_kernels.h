@@ -1487,7 +1487,11 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
   const bool fused = p.num_nodes == 1 && p.num_agg_cols == 1 && p.nodes[0].kind == kLeafDictRange && p.nodes[0].exclusive == 0 &&
                      p.nodes[0].fwd == p.agg_cols[0].fwd && p.nodes[0].bits == p.agg_cols[0].bits && p.agg_cols[0].need_sum != 0 &&
                      p.agg_cols[0].need_minmax == 0 && p.out_bitmap == nullptr;
-  for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
+  // index-driven filters: only the tiles index_and_kernel listed hold a match (any order)
+  const bool listed = p.tile_list != nullptr;
+  const long long tile_limit = listed ? (long long)*p.tile_count : num_tiles;
+  for (long long tile_it = (long long)blockIdx.x * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
+    const long long tile = listed ? (long long)p.tile_list[tile_it] : tile_it;
     if (fused) {
       const DevNode& L = p.nodes[0];
       const uint32_t* words = reinterpret_cast<const uint32_t*>(L.fwd + tile * (256ll * L.bits)) + lane * L.bits;
@@ -1643,7 +1647,10 @@ __global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const
   }
   const long long num_tiles = ((long long)gp.scan.num_docs + 2047) / 2048;
   const long long wave = (long long)blockIdx.x * waves_per_block + wave_in_block;
-  for (long long tile = wave; tile < num_tiles; tile += total_waves) {
+  const bool listed = gp.scan.tile_list != nullptr;        // index-driven filters: only the tiles index_and_kernel listed hold a match
+  const long long tile_limit = listed ? (long long)*gp.scan.tile_count : num_tiles;
+  for (long long tile_it = wave; tile_it < tile_limit; tile_it += total_waves) {
+    const long long tile = listed ? (long long)gp.scan.tile_list[tile_it] : tile_it;
     // the filter (if any) in the same lane-private layout: bit j of the lane's mask = doc 32*lane + j of the tile
     uint32_t m = eval_filter_private(gp.scan, tile, lane);
     const long long rem = (long long)gp.scan.num_docs - (tile * 2048 + lane * 32);
@@ -1692,6 +1699,36 @@ static __global__ void init_group_table_kernel(GroupParams gp) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t load_u16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 
+// ORs one Roaring container (array / bitset / run) into a 1024-word LDS window; the whole workgroup takes part.
+__device__ __forceinline__ void expand_container_into(const uint8_t* __restrict__ inv, const DevContainer c, unsigned long long* w) {
+  const uint8_t* payload = inv + c.offset;
+  if (c.type == 0) {
+    for (uint32_t i = threadIdx.x; i < c.cardinality; i += blockDim.x) {
+      const uint32_t v = load_u16(payload + 2 * i);
+      atomicOr(&w[v >> 6], 1ull << (v & 63u));
+    }
+  } else if (c.type == 1) {
+    for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
+      const uint8_t* q = payload + 8 * j;
+      const unsigned long long v = (unsigned long long)load_u16(q) | ((unsigned long long)load_u16(q + 2) << 16) |
+                                   ((unsigned long long)load_u16(q + 4) << 32) | ((unsigned long long)load_u16(q + 6) << 48);
+      atomicOr(&w[j], v);
+    }
+  } else {
+    for (uint32_t r = threadIdx.x; r < c.num_runs; r += blockDim.x) {
+      const uint32_t start = load_u16(payload + 2 + 4 * r);
+      uint32_t end = start + load_u16(payload + 4 + 4 * r);         // inclusive
+      end = end > 65535u ? 65535u : end;                            // a malformed run must not write past the 1024-word window
+      for (uint32_t wi = start >> 6; wi <= (end >> 6); ++wi) {
+        const uint32_t lo = wi == (start >> 6) ? (start & 63u) : 0u;
+        const uint32_t hi = wi == (end >> 6) ? (end & 63u) : 63u;
+        const unsigned long long mask = (hi - lo == 63u ? ~0ull : ((1ull << (hi - lo + 1u)) - 1ull)) << lo;
+        atomicOr(&w[wi], mask);
+      }
+    }
+  }
+}
+
 // One workgroup per 64 Ki-doc window (key = blockIdx.x): it looks its container up in the posting's sorted directory
 // slice, builds the 8 KiB window in LDS and either STORES it (first posting of a leaf: no separate zero-fill pass,
 // windows without a container become zeros) or ORs it into the bitmap (further postings of an IN / range leaf).
@@ -1716,25 +1753,74 @@ static __global__ __launch_bounds__(kBlockThreads) void roaring_expand_kernel(co
     if (!or_mode) for (int j = threadIdx.x; j < 1024; j += blockDim.x) if (base + j < num_words) bitmap[base + j] = 0ull;
     return;
   }
-  const DevContainer c = dir[found];
-  const uint8_t* payload = inv + c.offset;
+  expand_container_into(inv, dir[found], w);
+  __syncthreads();
+  for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
+    if (base + j >= num_words) continue;
+    const unsigned long long v = w[j];
+    if (or_mode) { if (v != 0ull) bitmap[base + j] |= v; }
+    else bitmap[base + j] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// index_and_kernel: AND of inverted-index leaves at RoaringBitmap-container granularity -- AndDocIdSet.iterator's index-based
+// branch (core/operator/docidsets/AndDocIdSet.java:127-165: the bitmaps of all index-based children are and-ed, smallest first)
+// and BitmapCollection (core/operator/filter/BitmapCollection.java:58-128) for inverted (NOT_EQ / NOT_IN) members.
+// One workgroup per 65 536-doc window: for every child, the containers of its postings that carry this window's key are OR-ed
+// into an 8 KB LDS window (a child is the OR of the postings of its matching dictIds, InvertedIndexFilterOperator.java:60-145),
+// complemented if the child is exclusive, and-ed into the accumulator; the window is finished as soon as the accumulator is
+// empty, so later children's containers are never read.  Nothing dense is materialised per child: HBM sees the serialized
+// postings once and the 125 MB result.  Besides the doc-order result it leaves the list of 2048-doc tiles that hold a match
+// (the aggregating kernel visits only those) and the cardinality (COUNT(*) over an index-only filter needs nothing else:
+// FastFilteredCountOperator, core/operator/query/FastFilteredCountOperator.java:66-72).
+// ------------------------------------------------------------------------------------------------
+// Container of `key` inside one posting's sorted directory slice.  Postings of frequent values have a container in (nearly) every
+// window, so the slot is guessed by interpolation and confirmed with one load; a binary search over what is left otherwise (each
+// probe is a dependent ~1 us global load: fourteen of them per child and window were most of this kernel's time).
+__device__ __forceinline__ int find_container(const DevContainer* __restrict__ dir, int first, int count, uint32_t key, uint32_t num_windows) {
+  if (count <= 0) return -1;
+  int lo = first, hi = first + count - 1;
+  int g = first + (int)(((unsigned long long)key * (unsigned long long)count) / (num_windows ? num_windows : 1u));
+  g = g > hi ? hi : g;
+  const uint32_t kg = dir[g].key;
+  if (kg == key) return g;
+  if (kg < key) lo = g + 1; else hi = g - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const uint32_t k = dir[mid].key;
+    if (k < key) lo = mid + 1; else if (k > key) hi = mid - 1; else return mid;
+  }
+  return -1;
+}
+
+// ORs one container into the 1024-word LDS window `w`.  The serialized bytes may start at any byte offset (a run-flag bitset of odd
+// length shifts everything behind it), so they are first copied into LDS with aligned dword loads and parsed from there.
+__device__ __forceinline__ void stage_and_expand(const uint8_t* __restrict__ inv, const DevContainer c, uint32_t* stage, unsigned long long* w) {
+  const uint32_t nbytes = c.type == 0 ? 2u * c.cardinality : (c.type == 1 ? 8192u : 2u + 4u * c.num_runs);
+  const uint64_t lead = c.offset & 3ull;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(inv + (c.offset - lead));      // the buffer itself is 256-byte aligned and padded
+  const uint32_t ndw = (uint32_t)((lead + nbytes + 3u) >> 2);
+  for (uint32_t i = threadIdx.x; i < ndw; i += blockDim.x) stage[i] = src[i];
+  __syncthreads();
+  const uint8_t* bytes = reinterpret_cast<const uint8_t*>(stage) + lead;
   if (c.type == 0) {
     for (uint32_t i = threadIdx.x; i < c.cardinality; i += blockDim.x) {
-      const uint32_t v = load_u16(payload + 2 * i);
+      const uint32_t v = load_u16(bytes + 2 * i);
       atomicOr(&w[v >> 6], 1ull << (v & 63u));
     }
   } else if (c.type == 1) {
     for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
-      const uint8_t* q = payload + 8 * j;
+      const uint8_t* q = bytes + 8 * j;
       const unsigned long long v = (unsigned long long)load_u16(q) | ((unsigned long long)load_u16(q + 2) << 16) |
                                    ((unsigned long long)load_u16(q + 4) << 32) | ((unsigned long long)load_u16(q + 6) << 48);
-      w[j] = v;
+      atomicOr(&w[j], v);
     }
   } else {
     for (uint32_t r = threadIdx.x; r < c.num_runs; r += blockDim.x) {
-      const uint32_t start = load_u16(payload + 2 + 4 * r);
-      uint32_t end = start + load_u16(payload + 4 + 4 * r);         // inclusive
-      end = end > 65535u ? 65535u : end;                            // a malformed run must not write past the 1024-word window
+      const uint32_t start = load_u16(bytes + 2 + 4 * r);
+      uint32_t end = start + load_u16(bytes + 4 + 4 * r);           // inclusive
+      end = end > 65535u ? 65535u : end;
       for (uint32_t wi = start >> 6; wi <= (end >> 6); ++wi) {
         const uint32_t lo = wi == (start >> 6) ? (start & 63u) : 0u;
         const uint32_t hi = wi == (end >> 6) ? (end & 63u) : 63u;
@@ -1743,13 +1829,76 @@ static __global__ __launch_bounds__(kBlockThreads) void roaring_expand_kernel(co
       }
     }
   }
-  __syncthreads();
-  for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
-    if (base + j >= num_words) continue;
-    const unsigned long long v = w[j];
-    if (or_mode) { if (v != 0ull) bitmap[base + j] |= v; }
-    else bitmap[base + j] = v;
+  __syncthreads();          // `stage` is free again
+}
+
+static __global__ __launch_bounds__(kBlockThreads) void index_and_kernel(const IndexAndParams ap) {
+  __shared__ unsigned long long acc[1024];
+  __shared__ unsigned long long tmp[1024];
+  __shared__ uint32_t stage[2048 + 4];
+  __shared__ int found[kMaxAndChildren * kMaxAndPostings];
+  __shared__ uint32_t tile_mask;
+  __shared__ uint32_t tile_slot;
+  __shared__ unsigned long long block_card;
+  const uint32_t key = blockIdx.x;
+  const long long base = (long long)key * 1024;
+  if (threadIdx.x == 0) { tile_mask = 0u; block_card = 0ull; }
+  // every (child, posting) directory lookup of the window at once: one round of memory latency instead of one per child
+  for (int t = threadIdx.x; t < ap.num_children * kMaxAndPostings; t += blockDim.x) {
+    const AndChild& ch = ap.child[t / kMaxAndPostings];
+    const int q = t % kMaxAndPostings;
+    found[t] = (ch.dense == nullptr && q < ch.num_postings) ? find_container(ch.dir, ch.first[q], ch.count[q], key, gridDim.x) : -1;
   }
+  __syncthreads();
+  bool alive = true;                       // uniform over the workgroup
+  for (int c = 0; c < ap.num_children && alive; ++c) {
+    const AndChild& ch = ap.child[c];
+    unsigned long long* dst = c == 0 ? acc : tmp;
+    if (ch.dense) {
+      for (int j = threadIdx.x; j < 1024; j += blockDim.x) dst[j] = base + j < ap.num_words ? ch.dense[base + j] : 0ull;
+      __syncthreads();
+    } else {
+      bool any_container = false;
+      for (int q = 0; q < ch.num_postings; ++q) any_container |= found[c * kMaxAndPostings + q] >= 0;
+      if (!any_container && !ch.exclusive) { alive = false; break; }       // this child has nothing in the window: neither has the AND
+      for (int j = threadIdx.x; j < 1024; j += blockDim.x) dst[j] = 0ull;
+      __syncthreads();
+      for (int q = 0; q < ch.num_postings; ++q) {
+        const int f = found[c * kMaxAndPostings + q];
+        if (f >= 0) stage_and_expand(ch.inv, ch.dir[f], stage, dst);
+      }
+    }
+    unsigned long long any = 0ull;
+    for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
+      unsigned long long v = dst[j];
+      if (ch.exclusive) v = ~v;
+      if (c > 0) v &= acc[j];
+      acc[j] = v;
+      any |= v;
+    }
+    alive = __syncthreads_or(any != 0ull ? 1 : 0) != 0;
+  }
+  unsigned long long cnt = 0ull;
+  for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
+    const long long word = base + j;
+    if (word >= ap.num_words) continue;
+    unsigned long long v = alive ? acc[j] : 0ull;
+    const long long first_doc = word * 64;               // docs past numDocs (an exclusive child sets them)
+    if (first_doc + 64 > (long long)ap.num_docs) v &= first_doc >= (long long)ap.num_docs ? 0ull : ((1ull << (int)((long long)ap.num_docs - first_doc)) - 1ull);
+    ap.out[word] = v;
+    if (v != 0ull) { cnt += (unsigned long long)__builtin_popcountll(v); atomicOr(&tile_mask, 1u << (j >> 5)); }
+  }
+  if (!alive) return;
+  cnt = (unsigned long long)wave_sum_i64((long long)cnt);
+  if ((threadIdx.x & 63) == 0 && cnt != 0ull) atomicAdd(&block_card, cnt);
+  __syncthreads();
+  if (threadIdx.x == 0 && tile_mask != 0u) {
+    tile_slot = atomicAdd(ap.tile_count, (uint32_t)__builtin_popcount(tile_mask));
+    atomicAdd(ap.cardinality, block_card);
+  }
+  __syncthreads();
+  if (threadIdx.x < 32 && ((tile_mask >> threadIdx.x) & 1u))
+    ap.tile_list[tile_slot + (uint32_t)__builtin_popcount(tile_mask & ((1u << threadIdx.x) - 1u))] = key * 32u + threadIdx.x;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -84,6 +84,34 @@ __device__ __forceinline__ void hist16_private(const uint32_t* __restrict__ lane
   }
 }
 
+// C2a shape -- SUM(col) WHERE col's dictId in [lo, lo + span): one decode feeds the range compare, the mask and the counter add
+// (the compare's VCC selects 0 / 1 as the value added).  Full tiles only: the caller sends the last, partial tile down the general path.
+template <int B, int H, int CW>
+__device__ __forceinline__ void hist_range16_private(const uint32_t* __restrict__ lane_words, uint32_t lo, uint32_t span, uint32_t& m, uint32_t* hist) {
+  uint32_t v[16];
+  decode16_private<B, H>(lane_words, v);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t x = v[j] - lo;
+    uint32_t bit;
+    asm("v_cmp_gt_u32 vcc, %3, %2\n\tv_cndmask_b32_e64 %1, 0, 1, vcc\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m), "=&v"(bit) : "v"(x), "s"(span) : "vcc");
+    __hip_atomic_fetch_add(hist + HistField<CW>::word(v[j]), bit << HistField<CW>::shift(v[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
+template <int CW>
+__device__ __forceinline__ uint32_t hist_range_dispatch(int b, const uint32_t* lane_words, uint32_t lo, uint32_t span, uint32_t* hist) {
+  uint32_t m = 0;
+  switch (b) {
+#define PG_CASE(B) case B: hist_range16_private<B, 0, CW>(lane_words, lo, span, m, hist); hist_range16_private<B, 1, CW>(lane_words, lo, span, m, hist); break;
+    PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10)
+    PG_CASE(11) PG_CASE(12) PG_CASE(13) PG_CASE(14) PG_CASE(15) PG_CASE(16) PG_CASE(17) PG_CASE(18)
+#undef PG_CASE
+    default: break;
+  }
+  return __builtin_bitreverse32(m);      // value j -> bit j
+}
+
 // Histograms hold at most 155 648 counters: 18-bit dictIds.
 template <int CW, bool kGuard>
 __device__ __forceinline__ void hist_private_dispatch(int b, const uint32_t* lane_words, uint32_t m, uint32_t* hist, uint32_t& mx, bool need_minmax,
@@ -147,7 +175,20 @@ __global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const Scan
   // its dictIds in registers
   const DevAggCol& ac = p.agg_cols[0];
 
-  for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
+  // one inclusive-range leaf on the summed column itself (C2a), plain counters, no MIN / MAX: one decode per tile instead of two
+  const bool fused = !kGuard && p.num_nodes == 1 && p.nodes[0].kind == kLeafDictRange && p.nodes[0].exclusive == 0 && p.nodes[0].fwd == ac.fwd &&
+                     p.nodes[0].bits == ac.bits && ac.need_minmax == 0;
+  const bool listed = p.tile_list != nullptr;              // index-driven filters: only the tiles index_and_kernel listed hold a match
+  const long long tile_limit = listed ? (long long)*p.tile_count : num_tiles;
+  for (long long tile_it = (long long)blockIdx.x * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
+    const long long tile = listed ? (long long)p.tile_list[tile_it] : tile_it;
+    if constexpr (!kGuard) {
+      if (fused && (tile + 1) * 2048 <= (long long)p.num_docs) {
+        const uint32_t* fwords = reinterpret_cast<const uint32_t*>(ac.fwd + tile * (256ll * ac.bits)) + lane * ac.bits;
+        count += (unsigned)__builtin_popcount(hist_range_dispatch<CW>(ac.bits, fwords, (uint32_t)p.nodes[0].lo, p.nodes[0].span, hist));
+        continue;
+      }
+    }
     uint32_t m = eval_filter_private(p, tile, lane);
     const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));

@@ -151,7 +151,10 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void scan_private_typed_ke
 #pragma unroll
   for (int a = 0; a < kMaxAggCols; ++a) typed_acc_identity(acc[a]);
 
-  for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
+  const bool listed = p.tile_list != nullptr;              // index-driven filters: only the tiles index_and_kernel listed hold a match
+  const long long tile_limit = listed ? (long long)*p.tile_count : num_tiles;
+  for (long long tile_it = (long long)blockIdx.x * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
+    const long long tile = listed ? (long long)p.tile_list[tile_it] : tile_it;
     uint32_t m = eval_filter_private(p, tile, lane);
     const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));

@@ -23,13 +23,15 @@ def _shared(S, col, name, dict_values):
     return S.Column(name, col.encoding, col.bits, col.cardinality, col.fwd, dictionary, None, dict_values)
 
 
-def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=3):
+def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
     from bench import Timer, v_dictionary
     from oracle import oracle
     from pinot_amd import _abi
     from pinot_amd import query as Q
     from pinot_amd import segment as S
 
+    # warmup = 40 untimed launches per variant: the GPU idles while the host generates columns and runs the oracle, and the first
+    # launches after an idle period run through the clock transient (same reason as bench.py's clock settle)
     timer = Timer(engine.lib, _abi)
     out = []
     want = lambda vid: match is None or match.search(vid) is not None
