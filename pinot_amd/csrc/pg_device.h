@@ -270,27 +270,32 @@ struct PartitionParams {
 
 // ---- index-only AND (index_and_kernel): the inverted-index children of a root AND, intersected window by window ----
 constexpr int kMaxAndChildren = 8;
-constexpr int kMaxAndPostings = 16;      // postings OR-ed into one child (EQ: 1; IN lists and short dictId ranges: up to 16)
+constexpr int kMaxAndPostings = 64;      // postings of all children together: one directory lookup per lane of the window's wavefront
+constexpr int kMaxChildPostings = 16;    // postings OR-ed into one child before it is expanded densely instead (EQ: 1; IN lists, short ranges)
+
+struct WindowInfo { uint32_t tiles; uint32_t docs; };   // mask of the window's 32 2048-doc tiles that hold a match; matching docs
 
 struct AndChild {
   const uint8_t* inv;                    // the column's inverted-index buffer (serialized RoaringBitmaps), or nullptr for a dense child
   const struct DevContainer* dir;        // the column's parsed container directory
   const unsigned long long* dense;       // dense child: a doc-order bitmap that already exists (long IN lists expanded by roaring_expand_kernel)
-  int32_t num_postings;
+  int32_t posting_begin, posting_end;    // its slice of IndexAndParams.first / count
   int32_t exclusive;                     // NOT_EQ / NOT_IN: the complement over [0, numDocs)
-  int32_t first[kMaxAndPostings];        // directory slice [first, first + count) of every posting
-  int32_t count[kMaxAndPostings];
+  int32_t reserved;
 };
 
 struct IndexAndParams {
   int32_t num_children;
+  int32_t num_postings;
   int32_t num_docs;
+  int32_t sparse_out;                    // store only the 2048-doc tiles that hold a match (see index_and_zero_unlisted_kernel)
   long long num_words;                   // 64-bit words of the output bitmap (2048-doc tiles * 32)
-  unsigned long long* out;               // doc-order result; every 65 536-doc window is written (zeros included)
-  uint32_t* tile_list;                   // the 2048-doc tiles that hold at least one match, in no particular order
-  uint32_t* tile_count;                  // [1] number of listed tiles (zeroed by the host before the launch)
-  unsigned long long* cardinality;       // [1] matching docs (zeroed by the host before the launch)
+  unsigned long long* out;               // doc-order result; nullptr = only the cardinality is wanted
+  struct WindowInfo* window_info;        // [windows]
   AndChild child[kMaxAndChildren];
+  int32_t first[kMaxAndPostings];        // directory slice [first, first + count) of every posting
+  int32_t count[kMaxAndPostings];
+  uint8_t posting_child[kMaxAndPostings];
 };
 
 // ---- roaring expansion ----

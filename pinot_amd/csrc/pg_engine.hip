@@ -138,6 +138,8 @@ struct ExecCtx {
   size_t partition_capacity = 0;
   uint32_t* d_tile_list = nullptr;              // index_and_kernel: surviving 2048-doc tiles (one entry per tile of the segment)
   unsigned long long* d_and_counters = nullptr; // [0] cardinality (u64), [1] low dword: number of listed tiles
+  WindowInfo* d_window_info = nullptr;          // index_and_kernel: {tile mask, matching docs} of every 65 536-doc window
+  size_t tile_list_capacity = 0, window_info_capacity = 0;
 };
 
 }  // namespace
@@ -171,6 +173,7 @@ void destroy_ctx(ExecCtx* c) {
   if (c->d_partition) (void)hipFree(c->d_partition);
   if (c->d_tile_list) (void)hipFree(c->d_tile_list);
   if (c->d_and_counters) (void)hipFree(c->d_and_counters);
+  if (c->d_window_info) (void)hipFree(c->d_window_info);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -455,6 +458,12 @@ struct Lowered {
   const uint32_t* tile_count = nullptr;
   const unsigned long long* d_cardinality = nullptr;
   bool index_and_is_whole_filter = false;      // the filter is exactly that AND: its cardinality answers COUNT(*)
+  // ... and its bitmap is stored sparsely (tiles without a match are not written): a reader that does not go by the tile list calls
+  // complete_index_and_bitmap first
+  unsigned long long* and_bitmap = nullptr;
+  const WindowInfo* and_info = nullptr;
+  long long and_words = 0;
+  bool cardinality_only_hint = false;          // in: the query is COUNT(*) only, so an index-only filter needs neither bitmap nor tile list
 };
 
 int slot_for(Lowered* lw, const pg_segment* seg, int column, bool plane = false) {
@@ -566,6 +575,15 @@ void build_sequence(const pg_query* q, std::vector<SeqNode>* seq, int* lazy_node
   }
 }
 
+// Zeros in every tile index_and_kernel did not store: for the kernels that read the whole bitmap instead of the tile list.
+pg_status complete_index_and_bitmap(Lowered* lw, ExecCtx* ctx) {
+  if (!lw->and_bitmap) return PG_OK;
+  index_and_zero_unlisted_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>(lw->and_info, lw->and_bitmap, lw->and_words);
+  HIP_TRY(hipGetLastError());
+  lw->and_bitmap = nullptr;
+  return PG_OK;
+}
+
 pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered* lw) {
   PlanParams& sp = lw->plan;
   if (q->num_filter_nodes < 0 || q->num_filter_nodes > kMaxNodes) return fail(PG_ERR_UNSUPPORTED, "filter tree has %d nodes (max %d)", q->num_filter_nodes, kMaxNodes);
@@ -622,10 +640,9 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
       DevLeaf& L = sp.leaves[sp.num_leaves];
       memset(&L, 0, sizeof(L));
       dn.leaf = sp.num_leaves++;
-      struct Member { AndChild child; double estimate; };
+      struct Member { AndChild child; double estimate; std::vector<std::pair<int32_t, int32_t>> postings; };
       std::vector<Member> members;
       bool empty = false;
-      std::vector<size_t> dense_bitmaps;
       for (int pi : and_members) {
         const pg_predicate& pr = q->predicates[pi];
         if (pr.column < 0 || pr.column >= (int)seg->cols.size()) return fail(PG_ERR_INVALID_ARGUMENT, "predicate column %d out of range", pr.column);
@@ -638,7 +655,6 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
         mb.child.inv = col.d_inv; mb.child.dir = col.d_dir; mb.child.exclusive = pr.exclusive ? 1 : 0;
         double docs = 0;
         int postings = 0;
-        bool inline_ok = true;
         for (int d = 0; d < col.cardinality; ++d) {
           bool in;
           if (pr.kind == PG_PRED_DICT_RANGE) in = d >= pr.lo && d < pr.hi;
@@ -647,54 +663,88 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
           const int64_t first = col.posting_first[d], cnt = col.posting_first[d + 1] - first;
           if (cnt <= 0) continue;
           for (int64_t k = first; k < first + cnt; ++k) docs += col.h_dir[(size_t)k].cardinality;
-          if (postings < kMaxAndPostings) { mb.child.first[postings] = (int32_t)first; mb.child.count[postings] = (int32_t)cnt; }
-          else inline_ok = false;
+          if (postings < kMaxChildPostings) mb.postings.emplace_back((int32_t)first, (int32_t)cnt);
           postings++;
         }
         if (postings == 0 && !pr.exclusive) { empty = true; break; }          // nothing matches this child: the AND is empty
         if (postings == 0 && pr.exclusive) continue;                          // NOT (nothing) = everything: the child drops out
         mb.estimate = pr.exclusive ? (double)seg->num_docs - docs : docs;
-        if (inline_ok) mb.child.num_postings = postings;
-        else {
+        size_t inline_so_far = 0;
+        for (const Member& m : members) inline_so_far += m.postings.size();
+        if (postings > kMaxChildPostings || inline_so_far + (size_t)postings > (size_t)kMaxAndPostings) {
+          // too many postings for one lookup per lane: this child is expanded densely first
           pg_status st = ensure_bitmap(seg, ctx, bitmap_idx);
           if (st != PG_OK) return st;
           unsigned long long* bm = ctx->d_bitmaps[bitmap_idx++];
           st = expand_dense(col, pr, bm);
           if (st != PG_OK) return st;
-          mb.child.inv = nullptr; mb.child.dir = nullptr; mb.child.dense = bm; mb.child.num_postings = 0;
+          mb.child.inv = nullptr; mb.child.dir = nullptr; mb.child.dense = bm;
+          mb.postings.clear();
         }
-        members.push_back(mb);
+        members.push_back(std::move(mb));
       }
       if (empty) { L.kind = kLeafMatchNone; depth++; max_depth = std::max(max_depth, depth); continue; }
       if (members.empty()) { L.kind = kLeafMatchAll; depth++; max_depth = std::max(max_depth, depth); continue; }
       // smallest first, like AndDocIdSet sorts its bitmaps: an empty window ends the work for the later children
       std::stable_sort(members.begin(), members.end(), [](const Member& a, const Member& b) { return a.estimate < b.estimate; });
-      pg_status st = ensure_bitmap(seg, ctx, bitmap_idx);
-      if (st != PG_OK) return st;
-      unsigned long long* bm = ctx->d_bitmaps[bitmap_idx++];
-      if (!ctx->d_tile_list) HIP_TRY(hipMalloc((void**)&ctx->d_tile_list, (size_t)std::max(seg->num_tiles, 1) * 4 + 256));
+      const bool cardinality_only = lw->cardinality_only_hint && seq.size() == 1;     // FastFilteredCount: neither the bitmap nor the tile list is read
+      unsigned long long* bm = nullptr;
+      if (!cardinality_only) {
+        pg_status st = ensure_bitmap(seg, ctx, bitmap_idx);
+        if (st != PG_OK) return st;
+        bm = ctx->d_bitmaps[bitmap_idx++];
+      }
+      const long long num_words = (long long)seg->num_tiles * kMaxTileSteps;
+      const unsigned num_windows = (unsigned)((num_words + 1023) / 1024);
+      if (ctx->tile_list_capacity < (size_t)seg->num_tiles + 64 || ctx->window_info_capacity < (size_t)num_windows + 1) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_tile_list) (void)hipFree(ctx->d_tile_list);
+        if (ctx->d_window_info) (void)hipFree(ctx->d_window_info);
+        ctx->d_tile_list = nullptr; ctx->d_window_info = nullptr;
+        ctx->tile_list_capacity = (size_t)seg->num_tiles + 64;
+        ctx->window_info_capacity = (size_t)num_windows + 1;
+        HIP_TRY(hipMalloc((void**)&ctx->d_tile_list, ctx->tile_list_capacity * 4));
+        HIP_TRY(hipMalloc((void**)&ctx->d_window_info, ctx->window_info_capacity * sizeof(WindowInfo)));
+      }
       if (!ctx->d_and_counters) HIP_TRY(hipMalloc((void**)&ctx->d_and_counters, 16));
-      HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16, ctx->stream));
       IndexAndParams ap;
       memset(&ap, 0, sizeof(ap));
       ap.num_children = (int32_t)members.size();
       ap.num_docs = seg->num_docs;
-      ap.num_words = (long long)seg->num_tiles * kMaxTileSteps;
+      ap.num_words = num_words;
       ap.out = bm;
-      ap.tile_list = ctx->d_tile_list;
-      ap.cardinality = ctx->d_and_counters;
-      ap.tile_count = reinterpret_cast<uint32_t*>(ctx->d_and_counters + 1);
-      for (size_t c = 0; c < members.size(); ++c) ap.child[c] = members[c].child;
-      const unsigned num_windows = (unsigned)((ap.num_words + 1023) / 1024);
-      if (num_windows) index_and_kernel<<<dim3(num_windows), dim3(kBlockThreads), 0, ctx->stream>>>(ap);
+      ap.sparse_out = 1;
+      ap.window_info = ctx->d_window_info;
+      for (size_t c = 0; c < members.size(); ++c) {
+        ap.child[c] = members[c].child;
+        ap.child[c].posting_begin = ap.num_postings;
+        for (const auto& ps : members[c].postings) {
+          ap.first[ap.num_postings] = ps.first; ap.count[ap.num_postings] = ps.second; ap.posting_child[ap.num_postings] = (uint8_t)c;
+          ap.num_postings++;
+        }
+        ap.child[c].posting_end = ap.num_postings;
+      }
+      unsigned long long* d_cardinality = ctx->d_and_counters;
+      uint32_t* d_tile_count = reinterpret_cast<uint32_t*>(ctx->d_and_counters + 1);
+      if (num_windows) {
+        index_and_kernel<<<dim3(num_windows), dim3(64), 0, ctx->stream>>>(ap);
+        index_and_finalize_kernel<<<dim3((num_windows + 255) / 256), dim3(256), 0, ctx->stream>>>(ctx->d_window_info, (int)num_windows, cardinality_only ? nullptr : ctx->d_tile_list,
+                                                                                                  d_tile_count, d_cardinality);
+      } else {
+        HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16, ctx->stream));
+      }
       HIP_TRY(hipGetLastError());
+      lw->d_cardinality = d_cardinality;
+      lw->index_and_is_whole_filter = seq.size() == 1;
+      if (cardinality_only) { L.kind = kLeafMatchAll; depth++; max_depth = std::max(max_depth, depth); continue; }   // never evaluated: execute_impl answers from the cardinality
       L.kind = kLeafBitmap;
       L.bitmap = bm;
       sp.num_bitmap_leaves++;
       lw->tile_list = ctx->d_tile_list;
-      lw->tile_count = ap.tile_count;
-      lw->d_cardinality = ap.cardinality;
-      lw->index_and_is_whole_filter = seq.size() == 1;
+      lw->tile_count = d_tile_count;
+      lw->and_bitmap = bm;
+      lw->and_info = ctx->d_window_info;
+      lw->and_words = num_words;
       depth++;
       max_depth = std::max(max_depth, depth);
       continue;
@@ -1254,7 +1304,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
         if (st != PG_OK) return bail(st);
       }
       col.posting_first[(size_t)cd.cardinality] = (int64_t)col.h_dir.size();
-      hipError_t e = hipMalloc((void**)&col.d_inv, (size_t)cd.inv_size + 16);
+      hipError_t e = hipMalloc((void**)&col.d_inv, (size_t)cd.inv_size + 64);
       if (e == hipSuccess) e = hipMemcpy(col.d_inv, inv, (size_t)cd.inv_size, hipMemcpyHostToDevice);
       if (e == hipSuccess && !col.h_dir.empty()) {
         e = hipMalloc((void**)&col.d_dir, col.h_dir.size() * sizeof(DevContainer));
@@ -1427,6 +1477,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
   }
   if (timed) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+  lw.cardinality_only_hint = ng == 0 && out && !want_bitmap && na > 0;
+  for (int a = 0; a < na; ++a) lw.cardinality_only_hint = lw.cardinality_only_hint && q->aggregations[a].function == PG_AGG_COUNT;
   st = lower_filter(seg, ctx, q, &lw);
   if (st != PG_OK) return st;
   ScanParams& sp = lw.sp;
@@ -1565,6 +1617,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       sp.out_bitmap = ctx->d_bitmaps[0];
     }
     if (!want_bitmap && (use_hist || use_private || use_private_typed)) { sp.tile_list = lw.tile_list; sp.tile_count = lw.tile_count; }
+    else { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
@@ -1791,6 +1844,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const long long num_partitions = (product + (1ll << partition_shift) - 1) >> partition_shift;
     const bool use_partition = map_based && g_engine.group_partition && g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap &&
                                gp.num_group_aggs <= kMaxPartitionAggs && num_partitions <= kMaxPartitions && (long long)seg->num_docs >= g_engine.partition_min_docs;
+    if (use_partition || !use_private) { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
     if (use_partition) {
       const int P = (int)num_partitions;
       const size_t N = (size_t)std::max(seg->num_tiles, 1) * 2048;

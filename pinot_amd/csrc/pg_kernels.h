@@ -1767,138 +1767,274 @@ static __global__ __launch_bounds__(kBlockThreads) void roaring_expand_kernel(co
 // index_and_kernel: AND of inverted-index leaves at RoaringBitmap-container granularity -- AndDocIdSet.iterator's index-based
 // branch (core/operator/docidsets/AndDocIdSet.java:127-165: the bitmaps of all index-based children are and-ed, smallest first)
 // and BitmapCollection (core/operator/filter/BitmapCollection.java:58-128) for inverted (NOT_EQ / NOT_IN) members.
-// One workgroup per 65 536-doc window: for every child, the containers of its postings that carry this window's key are OR-ed
-// into an 8 KB LDS window (a child is the OR of the postings of its matching dictIds, InvertedIndexFilterOperator.java:60-145),
-// complemented if the child is exclusive, and-ed into the accumulator; the window is finished as soon as the accumulator is
-// empty, so later children's containers are never read.  Nothing dense is materialised per child: HBM sees the serialized
-// postings once and the 125 MB result.  Besides the doc-order result it leaves the list of 2048-doc tiles that hold a match
-// (the aggregating kernel visits only those) and the cardinality (COUNT(*) over an index-only filter needs nothing else:
-// FastFilteredCountOperator, core/operator/query/FastFilteredCountOperator.java:66-72).
+//
+// ONE WAVEFRONT per 65 536-doc window (a workgroup is a single wave: its barriers cost nothing, nothing is shared with other
+// waves, and 8 KB of LDS per wave keeps ~18 windows in flight per CU -- the work per window is a handful of dependent loads, so
+// the kernel lives on how many windows are in flight, not on bandwidth).  The accumulator, 1024 words, stays in REGISTERS: lane l
+// owns the word pairs (2l + 128 i, 2l + 1 + 128 i), i = 0..7, so bitset containers, dense children and the result move as one
+// 16-byte access per lane and never touch LDS.  Array and run containers (and children that OR several postings: a child is the
+// OR of the postings of its matching dictIds, InvertedIndexFilterOperator.java:60-145) are scattered into the wave's 8 KB LDS
+// window with ds_or, read back by the owning lanes and re-zeroed in the same pass.  Serialized containers start at any byte
+// offset (odd array lengths, a run-flag bitset): they are read with aligned dword loads and re-aligned with v_alignbyte.
+// Every directory lookup of the window (one posting per lane, an interpolated guess confirmed by one load) is issued before any
+// container is touched, so a window costs two dependent loads plus one per child.  The window is finished as soon as the
+// accumulator is empty: later children's containers are never read.  Nothing dense is materialised per child.
+//
+// Per window it leaves {mask of its 32 2048-doc tiles that hold a match, cardinality}; index_and_finalize_kernel turns those into
+// the ascending list of matching tiles (the aggregating kernels visit only those) and the cardinality (COUNT(*) over an
+// index-only filter needs nothing else: FastFilteredCountOperator, core/operator/query/FastFilteredCountOperator.java:66-72) --
+// no same-address atomics, and the list order does not depend on scheduling.
 // ------------------------------------------------------------------------------------------------
 // Container of `key` inside one posting's sorted directory slice.  Postings of frequent values have a container in (nearly) every
-// window, so the slot is guessed by interpolation and confirmed with one load; a binary search over what is left otherwise (each
-// probe is a dependent ~1 us global load: fourteen of them per child and window were most of this kernel's time).
-__device__ __forceinline__ int find_container(const DevContainer* __restrict__ dir, int first, int count, uint32_t key, uint32_t num_windows) {
-  if (count <= 0) return -1;
+// window, so the slot is guessed by interpolation and confirmed with one load; a binary search over what is left otherwise.
+__device__ __forceinline__ bool find_container(const DevContainer* __restrict__ dir, int first, int count, uint32_t key, uint32_t num_windows, DevContainer* out) {
+  if (count <= 0) return false;
   int lo = first, hi = first + count - 1;
   int g = first + (int)(((unsigned long long)key * (unsigned long long)count) / (num_windows ? num_windows : 1u));
   g = g > hi ? hi : g;
-  const uint32_t kg = dir[g].key;
-  if (kg == key) return g;
-  if (kg < key) lo = g + 1; else hi = g - 1;
+  const DevContainer guess = dir[g];                    // the whole 24-byte entry: a right guess costs one round trip, not two
+  if (guess.key == key) { *out = guess; return true; }
+  // keys are distinct and ascending, so the slot is no further from the guess than the keys are apart
+  if (guess.key < key) { lo = g + 1; const long long far = (long long)g + (long long)(key - guess.key); hi = far < hi ? (int)far : hi; }
+  else { hi = g - 1; const long long far = (long long)g - (long long)(guess.key - key); lo = far > lo ? (int)far : lo; }
   while (lo <= hi) {
     const int mid = (lo + hi) >> 1;
     const uint32_t k = dir[mid].key;
-    if (k < key) lo = mid + 1; else if (k > key) hi = mid - 1; else return mid;
+    if (k < key) lo = mid + 1; else if (k > key) hi = mid - 1; else { *out = dir[mid]; return true; }
   }
-  return -1;
+  return false;
 }
 
-// ORs one container into the 1024-word LDS window `w`.  The serialized bytes may start at any byte offset (a run-flag bitset of odd
-// length shifts everything behind it), so they are first copied into LDS with aligned dword loads and parsed from there.
-__device__ __forceinline__ void stage_and_expand(const uint8_t* __restrict__ inv, const DevContainer c, uint32_t* stage, unsigned long long* w) {
-  const uint32_t nbytes = c.type == 0 ? 2u * c.cardinality : (c.type == 1 ? 8192u : 2u + 4u * c.num_runs);
-  const uint64_t lead = c.offset & 3ull;
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(inv + (c.offset - lead));      // the buffer itself is 256-byte aligned and padded
-  const uint32_t ndw = (uint32_t)((lead + nbytes + 3u) >> 2);
-  for (uint32_t i = threadIdx.x; i < ndw; i += blockDim.x) stage[i] = src[i];
-  __syncthreads();
-  const uint8_t* bytes = reinterpret_cast<const uint8_t*>(stage) + lead;
-  if (c.type == 0) {
-    for (uint32_t i = threadIdx.x; i < c.cardinality; i += blockDim.x) {
-      const uint32_t v = load_u16(bytes + 2 * i);
-      atomicOr(&w[v >> 6], 1ull << (v & 63u));
-    }
-  } else if (c.type == 1) {
-    for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
-      const uint8_t* q = bytes + 8 * j;
-      const unsigned long long v = (unsigned long long)load_u16(q) | ((unsigned long long)load_u16(q + 2) << 16) |
-                                   ((unsigned long long)load_u16(q + 4) << 32) | ((unsigned long long)load_u16(q + 6) << 48);
-      atomicOr(&w[j], v);
-    }
-  } else {
-    for (uint32_t r = threadIdx.x; r < c.num_runs; r += blockDim.x) {
-      const uint32_t start = load_u16(bytes + 2 + 4 * r);
-      uint32_t end = start + load_u16(bytes + 4 + 4 * r);           // inclusive
-      end = end > 65535u ? 65535u : end;
-      for (uint32_t wi = start >> 6; wi <= (end >> 6); ++wi) {
-        const uint32_t lo = wi == (start >> 6) ? (start & 63u) : 0u;
-        const uint32_t hi = wi == (end >> 6) ? (end & 63u) : 63u;
-        const unsigned long long mask = (hi - lo == 63u ? ~0ull : ((1ull << (hi - lo + 1u)) - 1ull)) << lo;
-        atomicOr(&w[wi], mask);
-      }
-    }
+struct __attribute__((aligned(4))) Dwords4 { uint32_t x, y, z, w; };
+
+// 16 bytes at byte offset 16 * index of a stream that starts `lead` bytes into the 4-byte aligned `origin`.
+__device__ __forceinline__ Dwords4 load16_stream(const uint32_t* __restrict__ origin, uint32_t lead, long long index) {
+  const uint32_t* p = origin + 4 * index;
+  Dwords4 a = *reinterpret_cast<const Dwords4*>(p);
+  if (lead != 0u) {                                       // uniform over the wave
+    const uint32_t e = p[4];                              // the column's buffer is padded: this never leaves it
+    a.x = __builtin_amdgcn_alignbyte(a.y, a.x, lead);
+    a.y = __builtin_amdgcn_alignbyte(a.z, a.y, lead);
+    a.z = __builtin_amdgcn_alignbyte(a.w, a.z, lead);
+    a.w = __builtin_amdgcn_alignbyte(e, a.w, lead);
   }
-  __syncthreads();          // `stage` is free again
+  return a;
 }
 
-static __global__ __launch_bounds__(kBlockThreads) void index_and_kernel(const IndexAndParams ap) {
-  __shared__ unsigned long long acc[1024];
-  __shared__ unsigned long long tmp[1024];
-  __shared__ uint32_t stage[2048 + 4];
-  __shared__ int found[kMaxAndChildren * kMaxAndPostings];
-  __shared__ uint32_t tile_mask;
-  __shared__ uint32_t tile_slot;
-  __shared__ unsigned long long block_card;
+__device__ __forceinline__ void or_doc(uint32_t* w32, uint32_t doc) { atomicOr(&w32[doc >> 5], 1u << (doc & 31u)); }
+
+static __global__ __launch_bounds__(64) void index_and_kernel(const IndexAndParams ap) {
+  __shared__ uint4 window[512];                         // 1024 64-bit words; all zero whenever no child is being expanded
+  uint32_t* w32 = reinterpret_cast<uint32_t*>(window);
+  const int lane = (int)threadIdx.x;
   const uint32_t key = blockIdx.x;
-  const long long base = (long long)key * 1024;
-  if (threadIdx.x == 0) { tile_mask = 0u; block_card = 0ull; }
-  // every (child, posting) directory lookup of the window at once: one round of memory latency instead of one per child
-  for (int t = threadIdx.x; t < ap.num_children * kMaxAndPostings; t += blockDim.x) {
-    const AndChild& ch = ap.child[t / kMaxAndPostings];
-    const int q = t % kMaxAndPostings;
-    found[t] = (ch.dense == nullptr && q < ch.num_postings) ? find_container(ch.dir, ch.first[q], ch.count[q], key, gridDim.x) : -1;
+  const long long base = (long long)key * 1024;         // first word of the window
+  const long long words_here = ap.num_words - base < 1024 ? ap.num_words - base : 1024;   // a multiple of 32
+
+  // ---- every directory lookup of the window at once: lane t looks posting t up ----
+  int c_valid = 0;
+  uint32_t c_card = 0, c_type = 0, c_runs = 0, c_off_lo = 0, c_off_hi = 0;
+  if (lane < ap.num_postings) {
+    const AndChild& ch = ap.child[ap.posting_child[lane]];
+    DevContainer dc;
+    if (find_container(ch.dir, ap.first[lane], ap.count[lane], key, gridDim.x, &dc)) {
+      c_valid = 1; c_card = dc.cardinality; c_type = dc.type; c_runs = dc.num_runs;
+      c_off_lo = (uint32_t)dc.offset; c_off_hi = (uint32_t)(dc.offset >> 32);
+    }
   }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) window[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
-  bool alive = true;                       // uniform over the workgroup
-  for (int c = 0; c < ap.num_children && alive; ++c) {
+
+  uint4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = make_uint4(0u, 0u, 0u, 0u);
+  bool alive = true;                                    // uniform
+  for (int c = 0; c < ap.num_children; ++c) {
     const AndChild& ch = ap.child[c];
-    unsigned long long* dst = c == 0 ? acc : tmp;
-    if (ch.dense) {
-      for (int j = threadIdx.x; j < 1024; j += blockDim.x) dst[j] = base + j < ap.num_words ? ch.dense[base + j] : 0ull;
-      __syncthreads();
+    uint4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (ch.dense != nullptr) {
+      const uint4* src = reinterpret_cast<const uint4*>(ch.dense + base);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (2 * (lane + 64 * i) < words_here) v[i] = src[lane + 64 * i];
     } else {
-      bool any_container = false;
-      for (int q = 0; q < ch.num_postings; ++q) any_container |= found[c * kMaxAndPostings + q] >= 0;
-      if (!any_container && !ch.exclusive) { alive = false; break; }       // this child has nothing in the window: neither has the AND
-      for (int j = threadIdx.x; j < 1024; j += blockDim.x) dst[j] = 0ull;
-      __syncthreads();
-      for (int q = 0; q < ch.num_postings; ++q) {
-        const int f = found[c * kMaxAndPostings + q];
-        if (f >= 0) stage_and_expand(ch.inv, ch.dir[f], stage, dst);
+      int found = 0, last = -1;
+      for (int q = ch.posting_begin; q < ch.posting_end; ++q) if (__builtin_amdgcn_readlane(c_valid, q)) { found++; last = q; }
+      if (found == 0) {
+        if (!ch.exclusive) { alive = false; break; }    // this child has nothing in the window: neither has the AND
+      } else if (found == 1 && __builtin_amdgcn_readlane((int)c_type, last) == 1) {
+        // a single bitset container: straight from HBM into the owning lanes
+        const unsigned long long off = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)c_off_lo, last) |
+                                       ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)c_off_hi, last) << 32);
+        const uint32_t lead = (uint32_t)(off & 3ull);
+        const uint32_t* origin = reinterpret_cast<const uint32_t*>(ch.inv + (off - lead));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const Dwords4 d = load16_stream(origin, lead, lane + 64 * i); v[i] = make_uint4(d.x, d.y, d.z, d.w); }
+      } else {
+        for (int q = ch.posting_begin; q < ch.posting_end; ++q) {
+          if (!__builtin_amdgcn_readlane(c_valid, q)) continue;
+          const uint32_t type = (uint32_t)__builtin_amdgcn_readlane((int)c_type, q);
+          const unsigned long long off = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)c_off_lo, q) |
+                                         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)c_off_hi, q) << 32);
+          if (type == 0u) {
+            // array container: sorted 16-bit docIds, eight per lane and step
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)c_card, q);
+            const uint32_t lead = (uint32_t)(off & 3ull);
+            const uint32_t* origin = reinterpret_cast<const uint32_t*>(ch.inv + (off - lead));
+            for (uint32_t e0 = 8u * (uint32_t)lane; e0 < n; e0 += 512u) {
+              const Dwords4 d = load16_stream(origin, lead, e0 >> 3);
+              const uint32_t left = n - e0;
+              or_doc(w32, d.x & 0xffffu);
+              if (left > 1u) or_doc(w32, d.x >> 16);
+              if (left > 2u) or_doc(w32, d.y & 0xffffu);
+              if (left > 3u) or_doc(w32, d.y >> 16);
+              if (left > 4u) or_doc(w32, d.z & 0xffffu);
+              if (left > 5u) or_doc(w32, d.z >> 16);
+              if (left > 6u) or_doc(w32, d.w & 0xffffu);
+              if (left > 7u) or_doc(w32, d.w >> 16);
+            }
+          } else if (type == 1u) {
+            const uint32_t lead = (uint32_t)(off & 3ull);
+            const uint32_t* origin = reinterpret_cast<const uint32_t*>(ch.inv + (off - lead));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const Dwords4 d = load16_stream(origin, lead, lane + 64 * i);
+              uint4 o = window[lane + 64 * i];           // this lane's own words: no other lane writes them between the two accesses
+              o.x |= d.x; o.y |= d.y; o.z |= d.z; o.w |= d.w;
+              window[lane + 64 * i] = o;
+            }
+          } else {
+            // run container: u16 count, then (start, length - 1) pairs
+            const uint32_t runs = (uint32_t)__builtin_amdgcn_readlane((int)c_runs, q);
+            const unsigned long long first = off + 2ull;
+            const uint32_t lead = (uint32_t)(first & 3ull);
+            const uint32_t* origin = reinterpret_cast<const uint32_t*>(ch.inv + (first - lead));
+            for (uint32_t r = (uint32_t)lane; r < runs; r += 64u) {
+              uint32_t pair = origin[r];
+              if (lead != 0u) pair = __builtin_amdgcn_alignbyte(origin[r + 1], pair, lead);
+              const uint32_t start = pair & 0xffffu;
+              uint32_t end = start + (pair >> 16);                            // inclusive
+              end = end > 65535u ? 65535u : end;                              // a malformed run must not leave the window
+              for (uint32_t wi = start >> 5; wi <= (end >> 5); ++wi) {
+                const uint32_t lo = wi == (start >> 5) ? (start & 31u) : 0u;
+                const uint32_t hi = wi == (end >> 5) ? (end & 31u) : 31u;
+                atomicOr(&w32[wi], (hi - lo == 31u ? ~0u : ((1u << (hi - lo + 1u)) - 1u)) << lo);
+              }
+            }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = window[lane + 64 * i]; window[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u); }
+        __syncthreads();
       }
     }
-    unsigned long long any = 0ull;
-    for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
-      unsigned long long v = dst[j];
-      if (ch.exclusive) v = ~v;
-      if (c > 0) v &= acc[j];
-      acc[j] = v;
-      any |= v;
+    uint32_t any = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint4 x = v[i];
+      if (ch.exclusive) { x.x = ~x.x; x.y = ~x.y; x.z = ~x.z; x.w = ~x.w; }
+      if (c > 0) { x.x &= acc[i].x; x.y &= acc[i].y; x.z &= acc[i].z; x.w &= acc[i].w; }
+      acc[i] = x;
+      any |= x.x | x.y | x.z | x.w;
     }
-    alive = __syncthreads_or(any != 0ull ? 1 : 0) != 0;
+    alive = __builtin_amdgcn_ballot_w64(any != 0u) != 0ull;
+    if (!alive) break;
   }
-  unsigned long long cnt = 0ull;
-  for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
-    const long long word = base + j;
-    if (word >= ap.num_words) continue;
-    unsigned long long v = alive ? acc[j] : 0ull;
-    const long long first_doc = word * 64;               // docs past numDocs (an exclusive child sets them)
-    if (first_doc + 64 > (long long)ap.num_docs) v &= first_doc >= (long long)ap.num_docs ? 0ull : ((1ull << (int)((long long)ap.num_docs - first_doc)) - 1ull);
-    ap.out[word] = v;
-    if (v != 0ull) { cnt += (unsigned long long)__builtin_popcountll(v); atomicOr(&tile_mask, 1u << (j >> 5)); }
+
+  // ---- the window's result: docs past numDocs cleared (an exclusive child sets them), words, tile mask, cardinality ----
+  uint32_t tiles = 0u;
+  uint32_t card = 0u;
+  const long long docs_left = (long long)ap.num_docs - base * 64;      // docs of the segment from this window on
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint4 x = alive ? acc[i] : make_uint4(0u, 0u, 0u, 0u);
+    const long long bit0 = 128ll * (lane + 64 * i);                    // window-relative doc of this pair's first bit
+    if (bit0 + 128 > docs_left) {
+      uint32_t* xs = &x.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long long rem = docs_left - (bit0 + 32 * k);
+        if (rem <= 0) xs[k] = 0u; else if (rem < 32) xs[k] &= (1u << (int)rem) - 1u;
+      }
+    }
+    card += (uint32_t)(__builtin_popcount(x.x) + __builtin_popcount(x.y) + __builtin_popcount(x.z) + __builtin_popcount(x.w));
+    // pair 2 (l + 64 i) lies in tile 4 i + (l >> 4)
+    const unsigned long long nz = __builtin_amdgcn_ballot_w64((x.x | x.y | x.z | x.w) != 0u);
+    // sparse output: only the tiles that hold a match are stored (the list-driven kernels read no others; anybody else calls
+    // index_and_zero_unlisted_kernel first)
+    const bool store = !ap.sparse_out || ((nz >> (16 * (lane >> 4))) & 0xffffull) != 0ull;
+    if (ap.out != nullptr && store && 2 * (lane + 64 * i) < words_here) reinterpret_cast<uint4*>(ap.out + base)[lane + 64 * i] = x;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) if ((nz >> (16 * g)) & 0xffffull) tiles |= 1u << (4 * i + g);
   }
-  if (!alive) return;
-  cnt = (unsigned long long)wave_sum_i64((long long)cnt);
-  if ((threadIdx.x & 63) == 0 && cnt != 0ull) atomicAdd(&block_card, cnt);
+  const uint32_t total = (uint32_t)wave_sum_i64((long long)card);
+  if (lane == 0) ap.window_info[key] = WindowInfo{tiles, total};
+}
+
+// Completes a sparsely stored result (IndexAndParams.sparse_out) for a reader that does not go by the tile list: zeros in every
+// 2048-doc tile without a match.
+static __global__ __launch_bounds__(256) void index_and_zero_unlisted_kernel(const WindowInfo* __restrict__ info, unsigned long long* __restrict__ out, long long num_words) {
+  const long long pairs = num_words / 2;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < pairs; p += (long long)gridDim.x * blockDim.x) {
+    const uint32_t mask = info[p >> 9].tiles;           // 512 pairs per window, 16 per tile
+    if (!((mask >> ((p >> 4) & 31)) & 1u)) reinterpret_cast<uint4*>(out)[p] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+// Turns index_and_kernel's per-window {tile mask, cardinality} into the ascending tile list, its length and the cardinality.
+// Workgroup b owns windows [256 b, 256 b + 256): it sums the tile counts of everything before them (a few thousand 8-byte
+// entries out of L2), scans its own and writes its slice of the list; the last workgroup also stores the totals.
+static __global__ __launch_bounds__(256) void index_and_finalize_kernel(const WindowInfo* __restrict__ info, int num_windows, uint32_t* __restrict__ tile_list,
+                                                                        uint32_t* __restrict__ tile_count, unsigned long long* __restrict__ cardinality) {
+  __shared__ unsigned long long part_card[4];
+  __shared__ uint32_t part_tiles[4];
+  __shared__ uint32_t wave_total[4];
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  const int first = (int)blockIdx.x * 256;
+  const bool last_block = blockIdx.x + 1 == gridDim.x;
+  unsigned long long before_card = 0ull;
+  uint32_t before_tiles = 0u;
+  // (two entries per 16-byte load, four loads in flight per thread: the whole prefix is one or two round trips)
+  const uint4* info2 = reinterpret_cast<const uint4*>(info);
+  for (int w = (int)threadIdx.x; w < first / 2; w += 1024) {
+    uint4 e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = w + 256 * k < first / 2 ? info2[w + 256 * k] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { before_tiles += (uint32_t)(__builtin_popcount(e[k].x) + __builtin_popcount(e[k].z)); before_card += (unsigned long long)e[k].y + e[k].w; }
+  }
+  before_tiles = (uint32_t)wave_sum_i64((long long)before_tiles);
+  before_card = (unsigned long long)wave_sum_i64((long long)before_card);
+  if (lane == 0) { part_tiles[wave] = before_tiles; part_card[wave] = before_card; }
+  const int w = first + (int)threadIdx.x;
+  const WindowInfo mine = w < num_windows ? info[w] : WindowInfo{0u, 0u};
+  const uint32_t my_tiles = (uint32_t)__builtin_popcount(mine.tiles);
+  // inclusive scan inside the wave
+  uint32_t scan = my_tiles;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)scan, d, 64); if (lane >= d) scan += o; }
+  if (lane == 63) wave_total[wave] = scan;
+  const unsigned long long my_card = (unsigned long long)wave_sum_i64((long long)mine.docs);
   __syncthreads();
-  if (threadIdx.x == 0 && tile_mask != 0u) {
-    tile_slot = atomicAdd(ap.tile_count, (uint32_t)__builtin_popcount(tile_mask));
-    atomicAdd(ap.cardinality, block_card);
+  uint32_t pos = part_tiles[0] + part_tiles[1] + part_tiles[2] + part_tiles[3];
+  for (int k = 0; k < wave; ++k) pos += wave_total[k];
+  pos += scan - my_tiles;
+  if (tile_list != nullptr) {
+    uint32_t m = mine.tiles;
+    while (m) { const int t = __builtin_ctz(m); m &= m - 1u; tile_list[pos++] = (uint32_t)w * 32u + (uint32_t)t; }
   }
-  __syncthreads();
-  if (threadIdx.x < 32 && ((tile_mask >> threadIdx.x) & 1u))
-    ap.tile_list[tile_slot + (uint32_t)__builtin_popcount(tile_mask & ((1u << threadIdx.x) - 1u))] = key * 32u + threadIdx.x;
+  if (last_block) {
+    __syncthreads();
+    if (lane == 0) part_card[wave] += my_card;          // each wave's own docs on top of its share of the prefix
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      *cardinality = part_card[0] + part_card[1] + part_card[2] + part_card[3];
+      *tile_count = part_tiles[0] + part_tiles[1] + part_tiles[2] + part_tiles[3] + wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
