@@ -259,6 +259,10 @@ typedef struct pg_result {
   uint64_t profile_cycles[4];      /* PG_CFG_PROFILE_WAVES: shader cycles summed over wavefronts: memory wait, filter, aggregate, total */
   int32_t profile_waves;           /* number of wavefronts the sums cover */
   int32_t dominant_kernel;         /* pg_kernel_id of the kernel dominant_kernel_ms refers to */
+  int32_t filter_entries_exact;    /* stats.num_entries_scanned_in_filter is the reference's count (AndDocIdSet / SVScanDocIdIterator accounting);
+                                    * 0: an upper bound (numDocs per scan leaf) -- filters whose iterators leap-frog, on segments above
+                                    * PINOT_GPU_EXACT_FILTER_STATS_DOCS docs, and enableNullHandling queries */
+  int32_t reserved;
   void* internal;
 } pg_result;
 

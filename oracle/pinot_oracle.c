@@ -861,6 +861,351 @@ static int filter_to_bitmap(const po_column* cols, const pg_segment_desc* seg, c
   return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * numEntriesScannedInFilter, exactly: the reference's BlockDocIdIterator tree restated and driven the way DocIdSetOperator drives
+ * it (next() until EOF, core/operator/DocIdSetOperator.java:66-90).  Every ScanBasedDocIdIterator counts the docs whose value it
+ * looks at (SVScanDocIdIterator._numEntriesScanned); which docs those are depends on how its parents call it:
+ *   SVScanDocIdIterator           next(): 256-doc batches until one holds a match (:76-98); advance(t): doc by doc from t to the
+ *                                 first match (:101-112); applyAnd(bitmap): one entry per doc of the bitmap (:115-145)
+ *   AndDocIdSet.iterator()        docidsets/AndDocIdSet.java:73-172: index-based children (sorted ranges, bitmaps) are merged, every
+ *                                 scan-based child is and-ed into that bitmap with applyAnd in list order, whatever remains (OR / NOT
+ *                                 / nested iterators) leap-frogs with the merged bitmap in an AndDocIdIterator; without an
+ *                                 index-based child all children leap-frog (dociditerators/AndDocIdIterator.java:41-74)
+ *   OrDocIdSet.iterator()         docidsets/OrDocIdSet.java:62-126 -> OrDocIdIterator (dociditerators/OrDocIdIterator.java:52-120)
+ *   NotDocIdSet / NotDocIdIterator  docidsets/NotDocIdSet.java:39-41, dociditerators/NotDocIdIterator.java:36-70
+ *   getTrues / getFalses          filter/AndFilterOperator.java:52-88, OrFilterOperator.java:51-87, NotFilterOperator.java:52-63,
+ *                                 BaseFilterOperator.java:96-113
+ * A scan leaf is represented by its match bitmap (the value matcher's answers): the count depends on nothing else.
+ * (This fork's OrDocIdSet never fills its bitmapBasedDocIdIterators list, :80-82, so bitmap children of an OR always iterate
+ * individually; followed here, it changes no docId set unless two sorted children meet a bitmap child.)
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+enum { IT_EMPTY = 0, IT_MATCH_ALL, IT_SCAN, IT_SORTED, IT_BITMAP, IT_RANGELESS, IT_AND, IT_OR, IT_NOT };
+
+typedef struct po_it {
+  int kind;
+  int32_t num_docs;
+  /* SCAN / SORTED / BITMAP / RANGELESS: the docId set as dense words (owned iff owns_words) */
+  uint64_t* words; int owns_words;
+  int64_t pos;                                   /* bitmap iterators: next candidate docId */
+  /* SCAN */
+  int32_t next_doc_id, first_mismatch, cursor; int32_t batch[PO_SCAN_BATCH]; int64_t* entries;
+  /* AND / OR / NOT */
+  struct po_it** child; int num_children;
+  int32_t next_doc;                              /* AND _nextDocId, NOT _nextDocId, MATCH_ALL _nextDocId */
+  int32_t* next_ids; int num_live; int32_t previous;   /* OR */
+  int32_t next_non_matching;                     /* NOT */
+} po_it;
+
+static int32_t words_next_set(const uint64_t* w, int32_t num_docs, int64_t from) {
+  if (from >= num_docs) return PO_EOF;
+  int64_t nw = bitmap_words(num_docs), i = from >> 6;
+  uint64_t cur = w[i] & (~0ull << (from & 63));
+  while (cur == 0) { if (++i >= nw) return PO_EOF; cur = w[i]; }
+  int64_t d = i * 64 + __builtin_ctzll(cur);
+  return d < num_docs ? (int32_t)d : PO_EOF;
+}
+
+static int32_t it_next(po_it* it);
+static int32_t it_advance(po_it* it, int32_t target);
+
+static int32_t it_next(po_it* it) {
+  switch (it->kind) {
+    case IT_EMPTY: return PO_EOF;
+    case IT_MATCH_ALL: return it->next_doc < it->num_docs ? it->next_doc++ : PO_EOF;
+    case IT_SCAN: {
+      if (it->cursor >= it->first_mismatch) {
+        int32_t limit, batch_size = 0;
+        do {
+          limit = it->num_docs - it->next_doc_id;
+          if (limit > PO_SCAN_BATCH) limit = PO_SCAN_BATCH;
+          if (limit > 0) {
+            batch_size = 0;
+            for (int32_t i = 0; i < limit; i++) { int32_t d = it->next_doc_id + i; if ((it->words[d >> 6] >> (d & 63)) & 1ull) it->batch[batch_size++] = d; }
+            it->next_doc_id += limit;
+            *it->entries += limit;
+          }
+        } while ((limit > 0) & (batch_size == 0));
+        it->first_mismatch = batch_size;
+        it->cursor = 0;
+        if (batch_size == 0) return PO_EOF;
+      }
+      return it->batch[it->cursor++];
+    }
+    case IT_SORTED: case IT_BITMAP: case IT_RANGELESS: {
+      int32_t d = words_next_set(it->words, it->num_docs, it->pos);
+      if (d == PO_EOF) { it->pos = it->num_docs; return PO_EOF; }
+      it->pos = (int64_t)d + 1;
+      return d;
+    }
+    case IT_AND: {
+      int32_t max_doc = it->next_doc; int max_idx = -1, index = 0;
+      while (index < it->num_children) {
+        if (index == max_idx) { index++; continue; }
+        int32_t d = it_advance(it->child[index], max_doc);
+        if (d == PO_EOF) return PO_EOF;
+        if (d == max_doc) index++; else { max_doc = d; max_idx = index; index = 0; }
+      }
+      it->next_doc = max_doc;
+      return it->next_doc++;
+    }
+    case IT_OR: {
+      int32_t next = INT32_MAX; int exhausted = 0;
+      for (int i = 0; i < it->num_live; i++) {
+        int32_t d = it->next_ids[i];
+        if (d == it->previous) {
+          d = it_next(it->child[i]); it->next_ids[i] = d;
+          if (d == PO_EOF) { exhausted = 1; continue; }
+        }
+        if (d < next) next = d;
+      }
+      if (exhausted) { int i = 0; while (i < it->num_live) { if (it->next_ids[i] == PO_EOF) { it->num_live--; po_it* gone = it->child[i]; it->child[i] = it->child[it->num_live]; it->child[it->num_live] = gone; it->next_ids[i] = it->next_ids[it->num_live]; it->next_ids[it->num_live] = PO_EOF; } else i++; } }
+      if (next != INT32_MAX) { it->previous = next; return next; }
+      return PO_EOF;
+    }
+    default: {   /* IT_NOT */
+      if (it->next_doc >= it->num_docs) return PO_EOF;
+      while (it->next_doc == it->next_non_matching) {
+        it->next_doc++;
+        int32_t d = it_next(it->child[0]);
+        it->next_non_matching = d == PO_EOF ? it->num_docs : d;
+      }
+      if (it->next_doc >= it->num_docs) return PO_EOF;
+      return it->next_doc++;
+    }
+  }
+}
+
+static int32_t it_advance(po_it* it, int32_t target) {
+  switch (it->kind) {
+    case IT_EMPTY: return PO_EOF;
+    case IT_MATCH_ALL: it->next_doc = target; return it_next(it);
+    case IT_SCAN: {
+      it->next_doc_id = target; it->first_mismatch = 0;
+      while (it->next_doc_id < it->num_docs) {
+        int32_t d = it->next_doc_id++;
+        (*it->entries)++;
+        if ((it->words[d >> 6] >> (d & 63)) & 1ull) return d;
+      }
+      return PO_EOF;
+    }
+    case IT_SORTED: case IT_BITMAP: case IT_RANGELESS: if (target > it->pos) it->pos = target; return it_next(it);   /* advanceIfNeeded + next */
+    case IT_AND: it->next_doc = target; return it_next(it);
+    case IT_OR: {
+      int32_t next = INT32_MAX; int exhausted = 0;
+      for (int i = 0; i < it->num_live; i++) {
+        int32_t d = it->next_ids[i];
+        if (d < target) {
+          d = it_advance(it->child[i], target); it->next_ids[i] = d;
+          if (d == PO_EOF) { exhausted = 1; continue; }
+        }
+        if (d < next) next = d;
+      }
+      if (exhausted) { int i = 0; while (i < it->num_live) { if (it->next_ids[i] == PO_EOF) { it->num_live--; po_it* gone = it->child[i]; it->child[i] = it->child[it->num_live]; it->child[it->num_live] = gone; it->next_ids[i] = it->next_ids[it->num_live]; it->next_ids[it->num_live] = PO_EOF; } else i++; } }
+      if (next != INT32_MAX) { it->previous = next; return next; }
+      return PO_EOF;
+    }
+    default: {   /* IT_NOT */
+      it->next_doc = target;
+      if (target > it->next_non_matching) {
+        int32_t d = it_advance(it->child[0], target);
+        it->next_non_matching = d == PO_EOF ? it->num_docs : d;
+      }
+      return it_next(it);
+    }
+  }
+}
+
+/* A BlockDocIdSet: what getTrues / getFalses build before anybody asks for an iterator. */
+enum { DS_EMPTY = 0, DS_MATCH_ALL, DS_SCAN, DS_SORTED, DS_BITMAP, DS_AND, DS_OR, DS_NOT };
+typedef struct po_ds { int kind; uint64_t* words; struct po_ds** child; int num_children; } po_ds;
+
+static po_ds* ds_new(int kind, int nchildren) {
+  po_ds* s = (po_ds*)calloc(1, sizeof(po_ds));
+  s->kind = kind;
+  if (nchildren) s->child = (po_ds**)calloc((size_t)nchildren, sizeof(po_ds*));
+  return s;
+}
+static void ds_free(po_ds* s) { if (!s) return; for (int i = 0; i < s->num_children; i++) ds_free(s->child[i]); free(s->child); free(s->words); free(s); }
+static void it_free(po_it* it) {
+  if (!it) return;
+  for (int i = 0; i < it->num_children; i++) it_free(it->child[i]);
+  /* OR swaps exhausted children out of the live prefix but keeps all of them in child[] */
+  free(it->child); free(it->next_ids); if (it->owns_words) free(it->words); free(it);
+}
+static po_it* it_new(int kind, int32_t num_docs) { po_it* it = (po_it*)calloc(1, sizeof(po_it)); it->kind = kind; it->num_docs = num_docs; return it; }
+
+static po_it* ds_iterator(const po_ds* s, int32_t num_docs, int64_t* entries);
+
+/* AndDocIdSet.iterator(), AndDocIdSet.java:73-172 */
+static po_it* and_iterator(const po_ds* s, int32_t num_docs, int64_t* entries) {
+  int n = s->num_children;
+  po_it** all = (po_it**)calloc((size_t)n, sizeof(po_it*));
+  int nsorted = 0, nbitmap = 0, nscan = 0, nrem = 0;
+  for (int i = 0; i < n; i++) {
+    all[i] = ds_iterator(s->child[i], num_docs, entries);
+    int k = all[i]->kind;
+    if (k == IT_SORTED) nsorted++; else if (k == IT_BITMAP || k == IT_RANGELESS) nbitmap++; else if (k == IT_SCAN) nscan++; else nrem++;
+  }
+  int64_t nw = bitmap_words(num_docs);
+  if ((nsorted + nbitmap > 0 && nscan > 0) || nsorted + nbitmap > 1) {
+    uint64_t* docs = (uint64_t*)malloc((size_t)(nw ? nw : 1) * 8);
+    memset(docs, 0xFF, (size_t)nw * 8); bitmap_clear_tail(docs, num_docs);
+    for (int i = 0; i < n; i++) if (all[i]->kind == IT_SORTED || all[i]->kind == IT_BITMAP || all[i]->kind == IT_RANGELESS) for (int64_t w = 0; w < nw; w++) docs[w] &= all[i]->words[w];
+    /* scan-based children in list order (andScanReordering off): ScanBasedDocIdIterator.applyAnd */
+    for (int i = 0; i < n; i++) if (all[i]->kind == IT_SCAN) {
+      int any = 0;
+      for (int64_t w = 0; w < nw; w++) any |= docs[w] != 0;
+      if (!any) continue;                                             /* applyAnd: !docIdIterator.hasNext() -> empty, nothing counted */
+      for (int64_t w = 0; w < nw; w++) { *entries += __builtin_popcountll(docs[w]); docs[w] &= all[i]->words[w]; }
+    }
+    po_it* merged = it_new(IT_RANGELESS, num_docs);
+    merged->words = docs; merged->owns_words = 1;
+    po_it* out = merged;
+    if (nrem > 0) {
+      out = it_new(IT_AND, num_docs);
+      out->child = (po_it**)calloc((size_t)nrem + 1, sizeof(po_it*));
+      out->child[out->num_children++] = merged;
+      for (int i = 0; i < n; i++) { int k = all[i]->kind; if (k != IT_SORTED && k != IT_BITMAP && k != IT_RANGELESS && k != IT_SCAN) { out->child[out->num_children++] = all[i]; all[i] = NULL; } }
+    }
+    for (int i = 0; i < n; i++) it_free(all[i]);
+    free(all);
+    return out;
+  }
+  po_it* out = it_new(IT_AND, num_docs);
+  out->child = all; out->num_children = n;
+  return out;
+}
+
+static po_it* ds_iterator(const po_ds* s, int32_t num_docs, int64_t* entries) {
+  switch (s->kind) {
+    case DS_EMPTY: return it_new(IT_EMPTY, num_docs);
+    case DS_MATCH_ALL: return it_new(IT_MATCH_ALL, num_docs);
+    case DS_SCAN: { po_it* it = it_new(IT_SCAN, num_docs); it->words = s->words; it->entries = entries; return it; }
+    case DS_SORTED: { po_it* it = it_new(IT_SORTED, num_docs); it->words = s->words; return it; }
+    case DS_BITMAP: { po_it* it = it_new(IT_BITMAP, num_docs); it->words = s->words; return it; }
+    case DS_AND: return and_iterator(s, num_docs, entries);
+    case DS_OR: {
+      /* OrDocIdSet.iterator(): two or more SORTED children are merged into one BitmapDocIdIterator that leads the OrDocIdIterator */
+      int n = s->num_children, nsorted = 0;
+      po_it* out = it_new(IT_OR, num_docs);
+      out->child = (po_it**)calloc((size_t)n + 1, sizeof(po_it*));
+      po_it** all = (po_it**)calloc((size_t)n, sizeof(po_it*));
+      for (int i = 0; i < n; i++) { all[i] = ds_iterator(s->child[i], num_docs, entries); nsorted += all[i]->kind == IT_SORTED; }
+      if (nsorted > 1) {
+        int64_t nw = bitmap_words(num_docs);
+        po_it* merged = it_new(IT_BITMAP, num_docs);
+        merged->words = (uint64_t*)calloc((size_t)(nw ? nw : 1), 8); merged->owns_words = 1;
+        for (int i = 0; i < n; i++) if (all[i]->kind == IT_SORTED || all[i]->kind == IT_BITMAP || all[i]->kind == IT_RANGELESS) {
+          for (int64_t w = 0; w < nw; w++) merged->words[w] |= all[i]->words[w];     /* (the bitmap children too: see the note above) */
+          it_free(all[i]); all[i] = NULL;
+        }
+        out->child[out->num_children++] = merged;
+      }
+      for (int i = 0; i < n; i++) if (all[i]) out->child[out->num_children++] = all[i];
+      free(all);
+      if (out->num_children == 1) { po_it* only = out->child[0]; out->num_children = 0; it_free(out); return only; }
+      out->next_ids = (int32_t*)malloc((size_t)out->num_children * 4);
+      for (int i = 0; i < out->num_children; i++) out->next_ids[i] = -1;
+      out->num_live = out->num_children; out->previous = -1;
+      return out;
+    }
+    default: {   /* DS_NOT: NotDocIdIterator's constructor already pulls the child's first docId */
+      po_it* out = it_new(IT_NOT, num_docs);
+      out->child = (po_it**)calloc(1, sizeof(po_it*));
+      out->child[0] = ds_iterator(s->child[0], num_docs, entries); out->num_children = 1;
+      int32_t d = it_next(out->child[0]);
+      out->next_non_matching = d == PO_EOF ? num_docs : d;
+      return out;
+    }
+  }
+}
+
+static po_ds* ds_trues(const po_column* cols, const pg_segment_desc* seg, const pg_query* q, int node, const int* first_child, int* rc);
+static po_ds* ds_falses(const po_column* cols, const pg_segment_desc* seg, const pg_query* q, int node, const int* first_child, int* rc);
+
+/* children of postfix node `node`, left to right: child c ends where child c + 1 starts */
+static void node_children(const pg_query* q, int node, const int* start, int* out) {
+  int k = q->filter[node].op == PG_FILTER_NOT ? 1 : q->filter[node].num_children;
+  int end = node - 1;
+  for (int c = k - 1; c >= 0; c--) { out[c] = end; end = start[end] - 1; }
+}
+
+static po_ds* ds_leaf(const po_column* cols, const pg_segment_desc* seg, const pg_predicate* p, int* rc) {
+  int32_t num_docs = seg->num_docs;
+  if (p->kind == PG_PRED_MATCH_ALL || p->kind == PG_PRED_MATCH_NONE) return ds_new(((p->kind == PG_PRED_MATCH_ALL) != (p->exclusive != 0)) ? DS_MATCH_ALL : DS_EMPTY, 0);
+  int64_t nw = bitmap_words(num_docs), unused = 0;
+  po_ds* s = ds_new(p->kind == PG_PRED_DOC_RANGE ? DS_SORTED : ((p->kind == PG_PRED_IS_NULL || p->eval == PG_EVAL_INVERTED) ? DS_BITMAP : DS_SCAN), 0);
+  s->words = (uint64_t*)malloc((size_t)(nw ? nw : 1) * 8);
+  if (leaf_to_bitmap(cols, seg, p, s->words, &unused)) *rc = 1;
+  return s;
+}
+
+static po_ds* ds_trues(const po_column* cols, const pg_segment_desc* seg, const pg_query* q, int node, const int* start, int* rc) {
+  const pg_filter_node* fn = &q->filter[node];
+  if (fn->op == PG_FILTER_LEAF) return ds_leaf(cols, seg, &q->predicates[fn->predicate], rc);
+  int kids[64];
+  int k = fn->op == PG_FILTER_NOT ? 1 : fn->num_children;
+  if (k > 64) { *rc = 1; return ds_new(DS_EMPTY, 0); }
+  node_children(q, node, start, kids);
+  if (fn->op == PG_FILTER_NOT) return ds_falses(cols, seg, q, kids[0], start, rc);          /* NotFilterOperator.getTrues */
+  po_ds* s = ds_new(fn->op == PG_FILTER_AND ? DS_AND : DS_OR, k);
+  for (int c = 0; c < k; c++) s->child[s->num_children++] = ds_trues(cols, seg, q, kids[c], start, rc);
+  return s;
+}
+
+static po_ds* ds_not(po_ds* inner) { po_ds* s = ds_new(DS_NOT, 1); s->child[0] = inner; s->num_children = 1; return s; }
+
+static po_ds* ds_falses(const po_column* cols, const pg_segment_desc* seg, const pg_query* q, int node, const int* start, int* rc) {
+  const pg_filter_node* fn = &q->filter[node];
+  if (fn->op == PG_FILTER_LEAF) {                                                          /* BaseFilterOperator.getFalses */
+    po_ds* t = ds_leaf(cols, seg, &q->predicates[fn->predicate], rc);
+    if (t->kind == DS_MATCH_ALL) { t->kind = DS_EMPTY; return t; }
+    if (t->kind == DS_EMPTY) { t->kind = DS_MATCH_ALL; return t; }
+    return ds_not(t);
+  }
+  int kids[64];
+  int k = fn->op == PG_FILTER_NOT ? 1 : fn->num_children;
+  if (k > 64) { *rc = 1; return ds_new(DS_EMPTY, 0); }
+  node_children(q, node, start, kids);
+  if (fn->op == PG_FILTER_NOT) return ds_trues(cols, seg, q, kids[0], start, rc);          /* NotFilterOperator.getFalses */
+  const int is_and = fn->op == PG_FILTER_AND;
+  po_ds* inner = ds_new(is_and ? DS_AND : DS_OR, k);
+  for (int c = 0; c < k; c++) {
+    po_ds* t = ds_trues(cols, seg, q, kids[c], start, rc);
+    /* And: an empty child makes the AND empty, NOT of it everything; match-all children drop out.  Or: the mirror image. */
+    if (t->kind == (is_and ? DS_EMPTY : DS_MATCH_ALL)) { ds_free(t); ds_free(inner); return ds_new(is_and ? DS_MATCH_ALL : DS_EMPTY, 0); }
+    if (t->kind == (is_and ? DS_MATCH_ALL : DS_EMPTY)) { ds_free(t); continue; }
+    inner->child[inner->num_children++] = t;
+  }
+  if (inner->num_children == 0) { ds_free(inner); return ds_new(is_and ? DS_EMPTY : DS_MATCH_ALL, 0); }
+  if (inner->num_children == 1) { po_ds* only = inner->child[0]; inner->num_children = 0; ds_free(inner); return ds_not(only); }
+  return ds_not(inner);
+}
+
+/* numEntriesScannedInFilter of the filter as the reference would execute it (enableNullHandling off). */
+static int filter_entries_scanned(const po_column* cols, const pg_segment_desc* seg, const pg_query* q, int64_t* out_entries) {
+  *out_entries = 0;
+  int n = q->num_filter_nodes;
+  if (n == 0) return 0;
+  int* start = (int*)calloc((size_t)n, sizeof(int));
+  for (int i = 0; i < n; i++) {
+    int k = q->filter[i].op == PG_FILTER_LEAF ? 0 : (q->filter[i].op == PG_FILTER_NOT ? 1 : q->filter[i].num_children);
+    int s = i;
+    for (int c = 0; c < k; c++) { if (s - 1 < 0) { free(start); PO_FAIL(1, "malformed filter tree"); } s = start[s - 1]; }
+    start[i] = s;
+  }
+  int rc = 0;
+  po_ds* root = ds_trues(cols, seg, q, n - 1, start, &rc);
+  free(start);
+  if (!rc) {
+    po_it* it = ds_iterator(root, seg->num_docs, out_entries);
+    while (it_next(it) != PO_EOF) {}
+    it_free(it);
+  }
+  ds_free(root);
+  return rc;
+}
+
 /* BlockDocIdIterator over either one streaming scan leaf (the C2 shape: ScanBasedFilterOperator directly
  * under DocIdSetOperator) or a materialised bitmap (BitmapDocIdIterator), or match-all. */
 typedef struct po_doc_iter {
@@ -1112,6 +1457,11 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       if (agg_nulls) for (int a = 0; a < q->num_aggregations; a++) free(agg_nulls[a]);
       free(agg_nulls); free(cols); free(it); return 1;
     }
+    /* the docId set came from the set algebra above; the entries scanned come from the reference's iterators */
+    if (!null_handling && filter_entries_scanned(cols, seg, q, &entries_in_filter)) {
+      if (agg_nulls) for (int a = 0; a < q->num_aggregations; a++) free(agg_nulls[a]);
+      free(agg_nulls); free(cols); free(it); free(filter_words); return 1;
+    }
     it->kind = 2; it->words = filter_words; it->word_idx = 0; it->cur = bitmap_words(num_docs) ? filter_words[0] : 0;
     if (bitmap_words(num_docs) == 0) it->word_idx = 0;
   }
@@ -1357,6 +1707,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
     if (it->kind == 1) entries_in_filter = it->scan.num_entries_scanned;
     res->stats.num_docs_scanned = num_docs_scanned;
     res->stats.num_entries_scanned_in_filter = entries_in_filter;
+    res->filter_entries_exact = null_handling ? 0 : 1;     /* the iterator accounting above; under enableNullHandling: full scans per leaf */
     res->stats.num_entries_scanned_post_filter = num_docs_scanned * nproj;
     res->stats.num_total_docs = num_docs;
   }

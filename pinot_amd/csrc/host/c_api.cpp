@@ -108,6 +108,30 @@ int32_t ph_segment_set_null_vector(void* seg, const char* column, const void* da
   });
 }
 
+// Segments assembled column by column have no metadata.properties: isSorted is derived from the data the way the segment creator's
+// column statistics do (a dictionary column whose dictIds never decrease in docId order, AbstractColumnStatisticsCollector), together
+// with the [start, end] docId pair of every dictId that SortedIndexReaderImpl would hold.  Unsorted columns leave at the first descent.
+static void detectSorted(DataSource* ds, int numDocs) {
+  if (!ds->hasDictionary || ds->forwardIndex == nullptr || ds->bitsPerElement <= 0 || ds->bitsPerElement > 31 || numDocs <= 0 || ds->cardinality <= 0) return;
+  const int b = ds->bitsPerElement;
+  if (ds->forwardIndexSize < ((uint64_t)numDocs * (uint64_t)b + 7) / 8) return;
+  std::vector<int32_t> ranges((size_t)ds->cardinality * 2, -1);
+  int32_t previous = -1;
+  for (int64_t doc = 0; doc < numDocs; ++doc) {
+    const uint64_t bit = (uint64_t)doc * (uint64_t)b;
+    uint64_t window = 0;                                      // the 5 bytes that hold the value, MSB first (PinotDataBitSet layout)
+    for (int k = 0; k < 5; ++k) { const uint64_t at = (bit >> 3) + (uint64_t)k; window = (window << 8) | (at < ds->forwardIndexSize ? ds->forwardIndex[at] : 0u); }
+    const int32_t id = (int32_t)((window >> (40 - (int)(bit & 7) - b)) & ((1ull << b) - 1ull));
+    if (id < previous || id >= ds->cardinality) return;
+    if (id != previous) ranges[2 * (size_t)id] = (int32_t)doc;
+    ranges[2 * (size_t)id + 1] = (int32_t)doc;
+    previous = id;
+  }
+  for (int32_t r : ranges) if (r < 0) return;                 // a dictionary entry no doc uses: not a creator-built segment
+  ds->isSorted = true;
+  ds->sortedDocIdRanges = std::move(ranges);
+}
+
 void* ph_segment_create(const char* name, int32_t num_docs) { return new ImmutableSegment(name ? name : "", num_docs); }
 
 int32_t ph_segment_add_int_column(void* seg, const char* name, int32_t has_dictionary, int32_t bits, int32_t cardinality, const void* fwd,
@@ -124,6 +148,7 @@ int32_t ph_segment_add_int_column(void* seg, const char* name, int32_t has_dicti
     if (ds.hasDictionary) ds.dictionary = std::make_shared<IntDictionary>((const uint8_t*)dict, cardinality);
     ds.hasInvertedIndex = inv != nullptr && inv_size > 0;
     ds.invertedIndex = (const uint8_t*)inv; ds.invertedIndexSize = inv_size;
+    detectSorted(&ds, ((ImmutableSegment*)seg)->getTotalDocs());
     ((ImmutableSegment*)seg)->addDataSource(std::move(ds));
   });
 }
@@ -154,6 +179,7 @@ int32_t ph_segment_add_numeric_column(void* seg, const char* name, int32_t data_
     }
     ds.hasInvertedIndex = inv != nullptr && inv_size > 0;
     ds.invertedIndex = (const uint8_t*)inv; ds.invertedIndexSize = inv_size;
+    detectSorted(&ds, ((ImmutableSegment*)seg)->getTotalDocs());
     ((ImmutableSegment*)seg)->addDataSource(std::move(ds));
   });
 }
@@ -175,6 +201,7 @@ int32_t ph_segment_add_string_column(void* seg, const char* name, int32_t bits, 
     ds.dictionary = std::make_shared<StringDictionary>(std::move(vals));
     ds.hasInvertedIndex = inv != nullptr && inv_size > 0;
     ds.invertedIndex = (const uint8_t*)inv; ds.invertedIndexSize = inv_size;
+    detectSorted(&ds, ((ImmutableSegment*)seg)->getTotalDocs());
     ((ImmutableSegment*)seg)->addDataSource(std::move(ds));
   });
 }

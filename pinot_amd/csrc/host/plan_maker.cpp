@@ -202,86 +202,171 @@ struct LoweredQuery {
   pg_query query;
 };
 
-void lowerFilter(const FilterContext& f, const ImmutableSegment& seg, bool nullHandling, LoweredQuery* out) {
+// The physical filter tree before it is flattened: FilterPlanNode.constructPhysicalOperator builds it bottom-up through
+// FilterOperatorUtils.get{Leaf,And,Or,Not}FilterOperator (core/operator/filter/FilterOperatorUtils.java:68-193), which drop
+// MatchAll / Empty children and re-order the children of an AND by priority (:196-245).  The order is part of the contract:
+// AndDocIdSet.iterator() applies the scan-based children in list order, so numEntriesScannedInFilter depends on it.
+struct PhysNode {
+  enum Kind { MATCH_ALL, EMPTY, LEAF, AND, OR, NOT } kind = LEAF;
+  int predicate = -1;
+  int priority = 10000;                      // PrioritizedFilterOperator.java:32-39
+  std::vector<PhysNode> children;
+};
+
+constexpr int kSortedPriority = 0, kBitmapPriority = 100, kAndPriority = 300, kOrPriority = 400, kScanPriority = 500, kUnknownPriority = 10000;
+
+PhysNode physLeaf(LoweredQuery* out, const pg_predicate& p, int priority) {
+  out->predicates.push_back(p);
+  PhysNode n;
+  n.kind = PhysNode::LEAF; n.predicate = (int)out->predicates.size() - 1; n.priority = priority;
+  return n;
+}
+
+PhysNode physAnd(std::vector<PhysNode> children) {       // FilterOperatorUtils.getAndFilterOperator :136-158
+  std::vector<PhysNode> kept;
+  for (auto& c : children) {
+    if (c.kind == PhysNode::EMPTY) { PhysNode e; e.kind = PhysNode::EMPTY; return e; }
+    if (c.kind != PhysNode::MATCH_ALL) kept.push_back(std::move(c));
+  }
+  if (kept.empty()) { PhysNode m; m.kind = PhysNode::MATCH_ALL; return m; }
+  if (kept.size() == 1) return std::move(kept[0]);
+  std::stable_sort(kept.begin(), kept.end(), [](const PhysNode& a, const PhysNode& b) { return a.priority < b.priority; });   // List.sort is stable
+  PhysNode n;
+  n.kind = PhysNode::AND; n.priority = kAndPriority; n.children = std::move(kept);
+  return n;
+}
+
+PhysNode physOr(std::vector<PhysNode> children) {        // FilterOperatorUtils.getOrFilterOperator :161-183
+  std::vector<PhysNode> kept;
+  for (auto& c : children) {
+    if (c.kind == PhysNode::MATCH_ALL) { PhysNode m; m.kind = PhysNode::MATCH_ALL; return m; }
+    if (c.kind != PhysNode::EMPTY) kept.push_back(std::move(c));
+  }
+  if (kept.empty()) { PhysNode e; e.kind = PhysNode::EMPTY; return e; }
+  if (kept.size() == 1) return std::move(kept[0]);
+  PhysNode n;
+  n.kind = PhysNode::OR; n.priority = kOrPriority; n.children = std::move(kept);
+  return n;
+}
+
+PhysNode physNot(PhysNode child) {                       // FilterOperatorUtils.getNotFilterOperator :186-194
+  PhysNode n;
+  if (child.kind == PhysNode::MATCH_ALL) { n.kind = PhysNode::EMPTY; return n; }
+  if (child.kind == PhysNode::EMPTY) { n.kind = PhysNode::MATCH_ALL; return n; }
+  n.kind = PhysNode::NOT; n.priority = child.priority;  // getPriority(NotFilterOperator) = priority of its child (:228-230)
+  n.children.push_back(std::move(child));
+  return n;
+}
+
+PhysNode lowerFilter(const FilterContext& f, const ImmutableSegment& seg, bool nullHandling, LoweredQuery* out) {
   switch (f.type) {
     case FilterContext::Type::AND:
     case FilterContext::Type::OR: {
-      for (const auto& c : f.children) lowerFilter(c, seg, nullHandling, out);
-      pg_filter_node n{f.type == FilterContext::Type::AND ? PG_FILTER_AND : PG_FILTER_OR, -1, (int32_t)f.children.size(), 0};
-      out->nodes.push_back(n);
-      return;
+      std::vector<PhysNode> children;
+      for (const auto& c : f.children) children.push_back(lowerFilter(c, seg, nullHandling, out));
+      return f.type == FilterContext::Type::AND ? physAnd(std::move(children)) : physOr(std::move(children));
     }
-    case FilterContext::Type::NOT: {
-      lowerFilter(f.children.at(0), seg, nullHandling, out);
-      out->nodes.push_back(pg_filter_node{PG_FILTER_NOT, -1, 1, 0});
-      return;
-    }
+    case FilterContext::Type::NOT: return physNot(lowerFilter(f.children.at(0), seg, nullHandling, out));
     case FilterContext::Type::PREDICATE: {
       const DataSource& ds = seg.getDataSource(f.predicate.column);
       pg_predicate p;
       memset(&p, 0, sizeof(p));
       p.column = seg.getColumnIndex(f.predicate.column);
       const bool hasNulls = ds.nullValueVector != nullptr && ds.nullValueVectorSize > 0;
+      PhysNode constant;
       if (f.predicate.type == Predicate::Type::IS_NULL || f.predicate.type == Predicate::Type::IS_NOT_NULL) {
         // FilterPlanNode.java:294-310: the null bitmap as a BitmapBasedFilterOperator, Empty / MatchAll without a null vector
+        if (!hasNulls) { constant.kind = f.predicate.type == Predicate::Type::IS_NULL ? PhysNode::EMPTY : PhysNode::MATCH_ALL; return constant; }
         p.kind = PG_PRED_IS_NULL;
         p.exclusive = f.predicate.type == Predicate::Type::IS_NOT_NULL;
-        out->predicates.push_back(p);
-        out->nodes.push_back(pg_filter_node{PG_FILTER_LEAF, (int32_t)out->predicates.size() - 1, 0, 0});
-        return;
+        return physLeaf(out, p, kBitmapPriority);
       }
       const PredicateEvaluator ev = getPredicateEvaluator(f.predicate, ds);
-      if (ev.alwaysTrue && nullHandling && hasNulls) { p.kind = PG_PRED_IS_NULL; p.exclusive = 1; }   // FilterOperatorUtils.java:78-86
-      else if (ev.alwaysTrue) p.kind = PG_PRED_MATCH_ALL;     // MatchAllFilterOperator (FilterOperatorUtils.java:79-92)
-      else if (ev.alwaysFalse) p.kind = PG_PRED_MATCH_NONE;   // EmptyFilterOperator
-      else if (ev.rawRange) {
+      if (ev.alwaysTrue && nullHandling && hasNulls) { p.kind = PG_PRED_IS_NULL; p.exclusive = 1; return physLeaf(out, p, kBitmapPriority); }   // FilterOperatorUtils.java:78-86
+      if (ev.alwaysTrue) { constant.kind = PhysNode::MATCH_ALL; return constant; }     // MatchAllFilterOperator (FilterOperatorUtils.java:79-92)
+      if (ev.alwaysFalse) { constant.kind = PhysNode::EMPTY; return constant; }        // EmptyFilterOperator
+      if (ev.rawRange) {
         p.kind = PG_PRED_RAW_RANGE; p.lo = ev.rawLower; p.hi = ev.rawUpper; p.exclusive = ev.exclusive;
-      } else if (ds.isSorted && ev.isRange && (int)ds.sortedDocIdRanges.size() == 2 * ds.cardinality && ev.endDictId > ev.startDictId) {
+        return physLeaf(out, p, kScanPriority);
+      }
+      if (ds.isSorted && ev.isRange && (int)ds.sortedDocIdRanges.size() == 2 * ds.cardinality && ev.endDictId > ev.startDictId) {
         // SortedIndexBasedFilterOperator (priority 0, FilterOperatorUtils.java:96-104): RANGE / EQ / NOT_EQ on a sorted column are the docId
         // range [start of startDictId, end of endDictId - 1] (SortedIndexBasedFilterOperator.java:60-85); nothing is scanned
         p.kind = PG_PRED_DOC_RANGE;
         p.lo = ds.sortedDocIdRanges[2 * (size_t)ev.startDictId];
         p.hi = ds.sortedDocIdRanges[2 * (size_t)(ev.endDictId - 1) + 1];
         p.exclusive = ev.exclusive;
-      } else if (ds.isSorted && !ev.isRange && (int)ds.sortedDocIdRanges.size() == 2 * ds.cardinality && !ev.matchingDictIds.empty() &&
-                 ev.matchingDictIds.size() <= 6) {
-        // IN / NOT IN on a sorted column: the docId ranges of the matching dictIds, adjacent ones merged
-        // (SortedIndexBasedFilterOperator.java:86-125) -> OR of docId-range leaves; NOT IN is the NOT of that union
+        return physLeaf(out, p, kSortedPriority);
+      }
+      if (ds.isSorted && !ev.isRange && (int)ds.sortedDocIdRanges.size() == 2 * ds.cardinality && !ev.matchingDictIds.empty() &&
+          ev.matchingDictIds.size() <= 6) {
+        // IN / NOT IN on a sorted column: ONE SortedIndexBasedFilterOperator whose SortedDocIdSet holds the docId ranges of the
+        // matching dictIds, adjacent ones merged (SortedIndexBasedFilterOperator.java:86-125); NOT IN holds the complementary
+        // ranges.  Here: an OR of docId-range leaves with the sorted operator's priority -- the iterators merge such an OR back
+        // into one index-based docId set (OrDocIdSet.java:94-112).
         std::vector<std::pair<int32_t, int32_t>> ranges;
         for (int d : ev.matchingDictIds) {      // ascending dictIds
           const int32_t s0 = ds.sortedDocIdRanges[2 * (size_t)d], e0 = ds.sortedDocIdRanges[2 * (size_t)d + 1];
           if (!ranges.empty() && s0 == ranges.back().second + 1) ranges.back().second = e0;
           else ranges.push_back({s0, e0});
         }
+        if (ev.exclusive) {
+          std::vector<std::pair<int32_t, int32_t>> rest;
+          int32_t next = 0;
+          for (const auto& r : ranges) { if (r.first > next) rest.push_back({next, r.first - 1}); next = r.second + 1; }
+          if (next < seg.getTotalDocs()) rest.push_back({next, seg.getTotalDocs() - 1});
+          ranges.swap(rest);
+          if (ranges.empty()) { constant.kind = PhysNode::EMPTY; return constant; }
+        }
+        std::vector<PhysNode> leaves;
         for (const auto& r : ranges) {
           pg_predicate dr;
           memset(&dr, 0, sizeof(dr));
           dr.kind = PG_PRED_DOC_RANGE; dr.lo = r.first; dr.hi = r.second; dr.column = p.column;
-          out->predicates.push_back(dr);
-          out->nodes.push_back(pg_filter_node{PG_FILTER_LEAF, (int32_t)out->predicates.size() - 1, 0, 0});
+          leaves.push_back(physLeaf(out, dr, kSortedPriority));
         }
-        if (ranges.size() > 1) out->nodes.push_back(pg_filter_node{PG_FILTER_OR, -1, (int32_t)ranges.size(), 0});
-        if (ev.exclusive) out->nodes.push_back(pg_filter_node{PG_FILTER_NOT, -1, 1, 0});
-        return;
-      } else {
-        p.exclusive = ev.exclusive;
-        // FilterOperatorUtils.java:96-133: RANGE predicates scan (no sorted / range index on this path); every other
-        // predicate type prefers the inverted index when the column has one.
-        p.eval = (f.predicate.type != Predicate::Type::RANGE && ds.hasInvertedIndex) ? PG_EVAL_INVERTED : PG_EVAL_SCAN;
-        if (ev.isRange) { p.kind = PG_PRED_DICT_RANGE; p.lo = ev.startDictId; p.hi = ev.endDictId; }
-        else {
-          p.kind = PG_PRED_DICT_SET;
-          std::vector<uint32_t> words(((size_t)ds.cardinality + 31) / 32, 0u);
-          for (int d : ev.matchingDictIds) words[(size_t)d >> 5] |= 1u << (d & 31);
-          out->setWords.push_back(std::move(words));
-          p.set_words = out->setWords.back().data();
-          p.num_set_words = (int32_t)out->setWords.back().size();
-        }
+        if (leaves.size() == 1) return std::move(leaves[0]);
+        PhysNode n;
+        n.kind = PhysNode::OR; n.priority = kSortedPriority; n.children = std::move(leaves);
+        return n;
       }
+      p.exclusive = ev.exclusive;
+      // FilterOperatorUtils.java:96-133: RANGE predicates scan (no sorted / range index on this path); every other predicate type
+      // prefers the inverted index when the column has one.  InvertedIndexFilterOperator is none of the classes
+      // reorderAndFilterChildOperators knows (:204-243), so it sorts last (UNKNOWN_FILTER_PRIORITY).
+      p.eval = (f.predicate.type != Predicate::Type::RANGE && ds.hasInvertedIndex) ? PG_EVAL_INVERTED : PG_EVAL_SCAN;
+      if (ev.isRange) { p.kind = PG_PRED_DICT_RANGE; p.lo = ev.startDictId; p.hi = ev.endDictId; }
+      else {
+        p.kind = PG_PRED_DICT_SET;
+        std::vector<uint32_t> words(((size_t)ds.cardinality + 31) / 32, 0u);
+        for (int d : ev.matchingDictIds) words[(size_t)d >> 5] |= 1u << (d & 31);
+        out->setWords.push_back(std::move(words));
+        p.set_words = out->setWords.back().data();
+        p.num_set_words = (int32_t)out->setWords.back().size();
+      }
+      return physLeaf(out, p, p.eval == PG_EVAL_INVERTED ? kUnknownPriority : kScanPriority);
+    }
+  }
+  throw std::logic_error("unreachable filter type");
+}
+
+void flattenFilter(const PhysNode& n, LoweredQuery* out) {
+  switch (n.kind) {
+    case PhysNode::MATCH_ALL: case PhysNode::EMPTY: {
+      pg_predicate p;
+      memset(&p, 0, sizeof(p));
+      p.kind = n.kind == PhysNode::MATCH_ALL ? PG_PRED_MATCH_ALL : PG_PRED_MATCH_NONE;
+      p.column = -1;
       out->predicates.push_back(p);
       out->nodes.push_back(pg_filter_node{PG_FILTER_LEAF, (int32_t)out->predicates.size() - 1, 0, 0});
       return;
     }
+    case PhysNode::LEAF: out->nodes.push_back(pg_filter_node{PG_FILTER_LEAF, n.predicate, 0, 0}); return;
+    case PhysNode::NOT: flattenFilter(n.children[0], out); out->nodes.push_back(pg_filter_node{PG_FILTER_NOT, -1, 1, 0}); return;
+    default:
+      for (const auto& c : n.children) flattenFilter(c, out);
+      out->nodes.push_back(pg_filter_node{n.kind == PhysNode::AND ? PG_FILTER_AND : PG_FILTER_OR, -1, (int32_t)n.children.size(), 0});
+      return;
   }
 }
 
@@ -289,7 +374,11 @@ std::unique_ptr<LoweredQuery> lowerQuery(const ImmutableSegment& seg, const Quer
   auto lq = std::make_unique<LoweredQuery>();
   // reserve so that set_words pointers taken during lowering stay valid
   lq->setWords.reserve(64);
-  if (qc.hasFilter) lowerFilter(qc.filter, seg, qc.nullHandlingEnabled, lq.get());
+  lq->predicates.reserve(256);
+  if (qc.hasFilter) {
+    const PhysNode root = lowerFilter(qc.filter, seg, qc.nullHandlingEnabled, lq.get());
+    if (root.kind != PhysNode::MATCH_ALL) flattenFilter(root, lq.get());      // a filter that matches everything is no filter (MatchAllFilterOperator)
+  }
   for (const auto& a : qc.aggregations) {
     pg_aggregation pa;
     pa.function = (int32_t)a.function;

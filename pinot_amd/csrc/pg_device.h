@@ -76,6 +76,7 @@ struct DevLeaf {
   int32_t pad;
 };
 
+constexpr int32_t kNodeCountEntries = 2; // scan leaf on the root AND chain behind an index-based child: ScanBasedDocIdIterator.applyAnd looks at every doc still standing
 constexpr int32_t kNodeExitIfZero = 1;   // root AND chain: the tile is finished (mask 0) if the running result is wave-zero
 
 // Host-side plan node (DevColumn / DevLeaf / PlanNode are what the engine reasons with).
@@ -182,6 +183,7 @@ struct ScanParams {
   int32_t bitmap_lds_off[kMaxLeaves];
   const uint32_t* tile_list;       // lane-private kernels: visit only these 2048-doc tiles (index_and_kernel's survivors), or nullptr = all
   const uint32_t* tile_count;      //                       [1] how many of them
+  unsigned long long* filter_entries;  // [1] numEntriesScannedInFilter of the kNodeCountEntries leaves (lane-private kernels), or nullptr
   unsigned long long* out_bitmap;  // optional doc-order bitmap output (num_tiles * tile_steps words)
   BlockPartial* partials;          // [gridDim.x]
 };

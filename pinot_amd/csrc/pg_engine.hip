@@ -17,6 +17,7 @@
 
 #include "../../include/pinot_gpu.h"
 #include "pg_device.h"
+#include "pg_filter_stats.h"
 #include "pg_kernels.h"
 #include "pg_launch.h"
 
@@ -48,6 +49,7 @@ struct Engine {
   bool initialized = false;
   int device = 0;
   int blocks_per_cu = 0;
+  long long exact_stats_docs = 64ll << 20;   // PINOT_GPU_EXACT_FILTER_STATS_DOCS: largest segment whose leap-frogging filters are replayed for numEntriesScannedInFilter
   int flags = 0;
   bool use_dma = true;
   int value_plane = -1;      // -1 auto, 0 never, 1 always (PINOT_GPU_VALUE_PLANE)
@@ -138,6 +140,8 @@ struct ExecCtx {
   size_t partition_capacity = 0;
   uint32_t* d_tile_list = nullptr;              // index_and_kernel: surviving 2048-doc tiles (one entry per tile of the segment)
   unsigned long long* d_and_counters = nullptr; // [0] cardinality (u64), [1] low dword: number of listed tiles
+  unsigned long long* d_filter_entries = nullptr;   // kNodeCountEntries leaves: numEntriesScannedInFilter counted by the lane-private kernels
+  unsigned long long* h_filter_entries = nullptr;   // pinned copy
   WindowInfo* d_window_info = nullptr;          // index_and_kernel: {tile mask, matching docs} of every 65 536-doc window
   size_t tile_list_capacity = 0, window_info_capacity = 0;
 };
@@ -174,6 +178,8 @@ void destroy_ctx(ExecCtx* c) {
   if (c->d_tile_list) (void)hipFree(c->d_tile_list);
   if (c->d_and_counters) (void)hipFree(c->d_and_counters);
   if (c->d_window_info) (void)hipFree(c->d_window_info);
+  if (c->d_filter_entries) (void)hipFree(c->d_filter_entries);
+  if (c->h_filter_entries) (void)hipHostFree(c->h_filter_entries);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -463,6 +469,10 @@ struct Lowered {
   unsigned long long* and_bitmap = nullptr;
   const WindowInfo* and_info = nullptr;
   long long and_words = 0;
+  // numEntriesScannedInFilter: how this query's count is obtained (pg_filter_stats.h)
+  fstats::Plan stats_plan = fstats::Plan::kZero;
+  int stats_scan_leaves = 0;
+  bool stats_chain_flagged = false;            // the chain's scan leaves carry kNodeCountEntries
   bool cardinality_only_hint = false;          // in: the query is COUNT(*) only, so an index-only filter needs neither bitmap nor tile list
 };
 
@@ -575,6 +585,15 @@ void build_sequence(const pg_query* q, std::vector<SeqNode>* seq, int* lazy_node
   }
 }
 
+// kNodeCountEntries leaves: the device counter the lane-private kernels add their entries to, zeroed in stream order.
+pg_status arm_filter_entries(ExecCtx* ctx, unsigned long long** out_counter) {
+  if (!ctx->d_filter_entries) HIP_TRY(hipMalloc((void**)&ctx->d_filter_entries, 8));
+  if (!ctx->h_filter_entries) HIP_TRY(hipHostMalloc((void**)&ctx->h_filter_entries, 8, hipHostMallocDefault));
+  HIP_TRY(hipMemsetAsync(ctx->d_filter_entries, 0, 8, ctx->stream));
+  *out_counter = ctx->d_filter_entries;
+  return PG_OK;
+}
+
 // Zeros in every tile index_and_kernel did not store: for the kernels that read the whole bitmap instead of the tile list.
 pg_status complete_index_and_bitmap(Lowered* lw, ExecCtx* ctx) {
   if (!lw->and_bitmap) return PG_OK;
@@ -634,6 +653,12 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
     dn.leaf = -1;
     dn.num_children = fn.num_children;
     dn.flags = seq[(size_t)n].flags;
+    if (lw->stats_plan == fstats::Plan::kChain && fn.op == PG_FILTER_LEAF && seq[(size_t)n].src >= 0 && fn.predicate >= 0 && fn.predicate < q->num_predicates &&
+        fstats::classify(q->predicates[fn.predicate]) == fstats::LeafClass::kScan && n > 0) {
+      // a scan-based child of the root AND, behind the index-based ones: ScanBasedDocIdIterator.applyAnd looks at every doc still standing
+      dn.flags |= kNodeCountEntries;
+      lw->stats_chain_flagged = true;
+    }
     if (fn.op == PG_FILTER_LEAF && seq[(size_t)n].src == kSeqIndexAnd) {
       // ---- the inverted-index children of the root AND, intersected container by container (index_and_kernel) ----
       if (sp.num_leaves >= kMaxLeaves) return fail(PG_ERR_UNSUPPORTED, "more than %d filter leaves", kMaxLeaves);
@@ -1099,6 +1124,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.hist_bits = (hb && (atoi(hb) == 8 || atoi(hb) == 16)) ? atoi(hb) : 0;
   const char* ts = getenv("PINOT_GPU_TILE_STEPS");
   g_engine.tile_steps = (ts && (atoi(ts) == 16 || atoi(ts) == 32)) ? atoi(ts) : 0;
+  const char* esd = getenv("PINOT_GPU_EXACT_FILTER_STATS_DOCS");
+  if (esd) g_engine.exact_stats_docs = atoll(esd);
   const char* bpc = getenv("PINOT_GPU_BLOCKS_PER_CU");
   if (bpc && atoi(bpc) > 0) g_engine.blocks_per_cu = atoi(bpc);
   g_engine.initialized = true;
@@ -1379,6 +1406,20 @@ void pg_result_free(pg_result* r) {
   memset(r, 0, sizeof(*r));
 }
 
+// ExecutionStatistics.numEntriesScannedInFilter from the plan pg_filter_stats.h chose; `counted`: the kernel that ran carried the
+// kNodeCountEntries counter (its value has been copied to ctx->h_filter_entries and the stream is idle).
+static void finish_filter_stats(const Lowered& lw, const pg_segment* seg, const ExecCtx* ctx, bool counted, pg_result* out) {
+  const int64_t upper_bound = (int64_t)lw.stats_scan_leaves * seg->num_docs;      // every scan leaf looking at every doc
+  switch (lw.stats_plan) {
+    case fstats::Plan::kZero: out->stats.num_entries_scanned_in_filter = 0; out->filter_entries_exact = 1; break;
+    case fstats::Plan::kPerLeaf: out->stats.num_entries_scanned_in_filter = upper_bound; out->filter_entries_exact = 1; break;
+    case fstats::Plan::kChain:
+      if (counted) { out->stats.num_entries_scanned_in_filter = (int64_t)*ctx->h_filter_entries; out->filter_entries_exact = 1; break; }
+      [[fallthrough]];                                                            // an LDS-staged kernel ran: replayed by pg_execute
+    default: out->stats.num_entries_scanned_in_filter = upper_bound; out->filter_entries_exact = 0; break;
+  }
+}
+
 static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out, unsigned long long* d_out_bitmap_request,
                               uint64_t* host_bitmap, int64_t host_bitmap_words, int64_t* out_cardinality, bool allow_metadata_plan = true) {
   if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");
@@ -1430,6 +1471,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       }
       out->stats.num_docs_scanned = seg->num_docs;          // NonScanBasedAggregationOperator.getExecutionStatistics: (totalDocs, 0, 0, totalDocs)
       out->stats.num_entries_scanned_in_filter = 0;
+      out->filter_entries_exact = 1;
       out->stats.num_entries_scanned_post_filter = 0;
       out->stats.num_total_docs = seg->num_docs;
       if (out_cardinality) *out_cardinality = seg->num_docs;
@@ -1477,6 +1519,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
   }
   if (timed) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+  if (out && !want_bitmap) lw.stats_plan = fstats::choose_plan(q, &lw.stats_scan_leaves);
   lw.cardinality_only_hint = ng == 0 && out && !want_bitmap && na > 0;
   for (int a = 0; a < na; ++a) lw.cardinality_only_hint = lw.cardinality_only_hint && q->aggregations[a].function == PG_AGG_COUNT;
   st = lower_filter(seg, ctx, q, &lw);
@@ -1510,7 +1553,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       }
       out->dominant_kernel = PG_KERNEL_INDEX_AND;
       out->stats.num_docs_scanned = card;
-      out->stats.num_entries_scanned_in_filter = 0;
+      out->stats.num_entries_scanned_in_filter = 0;     // bitmaps only: nothing is scanned
+      out->filter_entries_exact = 1;
       out->stats.num_entries_scanned_post_filter = 0;
       out->stats.num_total_docs = seg->num_docs;
       if (out_cardinality) *out_cardinality = card;
@@ -1618,6 +1662,9 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
     if (!want_bitmap && (use_hist || use_private || use_private_typed)) { sp.tile_list = lw.tile_list; sp.tile_count = lw.tile_count; }
     else { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
+    const bool count_entries = out && lw.stats_chain_flagged && (use_hist || use_private || use_private_typed);
+    sp.filter_entries = nullptr;
+    if (count_entries) { st = arm_filter_entries(ctx, &sp.filter_entries); if (st != PG_OK) return st; }
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
@@ -1630,6 +1677,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     finalize_partials_kernel<<<dim3(1), dim3(kBlockThreads), 0, ctx->stream>>>(ctx->d_partials, blocks, g_engine.direct_result ? ctx->h_partial_dev : nullptr);
     HIP_TRY(hipGetLastError());
     if (!g_engine.direct_result) HIP_TRY(hipMemcpyAsync(ctx->h_partial, ctx->d_partials + blocks, sizeof(BlockPartial), hipMemcpyDeviceToHost, ctx->stream));
+    if (count_entries) HIP_TRY(hipMemcpyAsync(ctx->h_filter_entries, ctx->d_filter_entries, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (want_bitmap) {
       const int64_t need = ((int64_t)seg->num_docs + 63) / 64;
       if (d_out_bitmap_request) {
@@ -1701,7 +1749,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       for (int c = 0; c < 4; ++c) out->profile_cycles[c] = fp.cyc[c];
       out->profile_waves = blocks * (geo.threads / 64);
       out->stats.num_docs_scanned = (int64_t)fp.count;
-      out->stats.num_entries_scanned_in_filter = (int64_t)lw.num_scan_leaves * seg->num_docs;
+      finish_filter_stats(lw, seg, ctx, count_entries, out);
       out->stats.num_entries_scanned_post_filter = (int64_t)fp.count * (int64_t)projected.size();
       out->stats.num_total_docs = seg->num_docs;
     }
@@ -1834,6 +1882,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     gp.scan.out_bitmap = nullptr;
     gp.scan.tile_list = lw.tile_list;            // read by group_private_kernel only
     gp.scan.tile_count = lw.tile_count;
+    gp.scan.filter_entries = nullptr;
     init_group_table_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(gp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -1845,6 +1894,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const bool use_partition = map_based && g_engine.group_partition && g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap &&
                                gp.num_group_aggs <= kMaxPartitionAggs && num_partitions <= kMaxPartitions && (long long)seg->num_docs >= g_engine.partition_min_docs;
     if (use_partition || !use_private) { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
+    const bool count_entries = out && lw.stats_chain_flagged && use_private && !use_partition;
+    if (count_entries) { st = arm_filter_entries(ctx, &gp.scan.filter_entries); if (st != PG_OK) return st; }
     if (use_partition) {
       const int P = (int)num_partitions;
       const size_t N = (size_t)std::max(seg->num_tiles, 1) * 2048;
@@ -1902,6 +1953,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     else if (use_private) launch_group_private(gp.use_lds_table != 0, pblocks, pthreads, plds, ctx->stream, gp);
     else launch_scan_group(g_engine.use_dma, gp.use_lds_table != 0, blocks, geo.threads, lds, ctx->stream, gp);
     HIP_TRY(hipGetLastError());
+    if (count_entries) HIP_TRY(hipMemcpyAsync(ctx->h_filter_entries, ctx->d_filter_entries, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     // The groups that exist, in ascending raw-key order: (raw key, doc count, accumulators[a * num_present + k]).
     std::vector<int32_t> present_ids;
@@ -2068,7 +2120,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       for (auto& w : workers) w.join();
     }
     out->stats.num_docs_scanned = docs;
-    out->stats.num_entries_scanned_in_filter = (int64_t)lw.num_scan_leaves * seg->num_docs;
+    finish_filter_stats(lw, seg, ctx, count_entries, out);
     out->stats.num_entries_scanned_post_filter = docs * (int64_t)projected.size();
     out->stats.num_total_docs = seg->num_docs;
   }
@@ -2267,11 +2319,38 @@ static pg_status execute_null_handling(pg_segment* seg, const pg_query* q, pg_re
   return PG_OK;
 }
 
+// numEntriesScannedInFilter of a filter that leap-frogs (pg_filter_stats.h, Plan::kReplay): every leaf's docId set comes off the device
+// as a bitmap, the reference's iterator tree is replayed over them.  Sequential in the docId space, hence the segment-size limit.
+static pg_status replay_filter_stats(pg_segment* seg, const pg_query* q, pg_result* out) {
+  const size_t words = ((size_t)seg->num_docs + 63) / 64;
+  std::vector<fstats::Words> leaf_words((size_t)q->num_predicates);
+  for (int i = 0; i < q->num_filter_nodes; ++i) {
+    const pg_filter_node& n = q->filter[i];
+    if (n.op != PG_FILTER_LEAF || leaf_words[(size_t)n.predicate]) continue;
+    const fstats::LeafClass c = fstats::classify(q->predicates[n.predicate]);
+    if (c == fstats::LeafClass::kMatchAll || c == fstats::LeafClass::kEmpty) continue;
+    auto w = std::make_shared<std::vector<uint64_t>>(std::max<size_t>(words, 1), 0ull);
+    pg_filter_node leaf = n;
+    pg_query lq;
+    memset(&lq, 0, sizeof(lq));
+    lq.filter = &leaf; lq.num_filter_nodes = 1;
+    lq.predicates = q->predicates; lq.num_predicates = q->num_predicates;
+    pg_status st = execute_impl(seg, &lq, nullptr, nullptr, w->data(), (int64_t)w->size(), nullptr);
+    if (st != PG_OK) return st;
+    leaf_words[(size_t)n.predicate] = std::move(w);
+  }
+  out->stats.num_entries_scanned_in_filter = fstats::replay(q, seg->num_docs, leaf_words);
+  out->filter_entries_exact = 1;
+  return PG_OK;
+}
+
 pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_result) {
   if (!out_result) return fail(PG_ERR_INVALID_ARGUMENT, "null result");
   memset(out_result, 0, sizeof(*out_result));     // before anything can fail: every error path below ends in pg_result_free(out_result)
-  pg_status st = (query && (query->flags & PG_QUERY_NULL_HANDLING)) ? execute_null_handling(segment, query, out_result, nullptr, 0, nullptr)
-                                                                  : execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr);
+  const bool null_handling = query && (query->flags & PG_QUERY_NULL_HANDLING);
+  pg_status st = null_handling ? execute_null_handling(segment, query, out_result, nullptr, 0, nullptr) : execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr);
+  // (enableNullHandling changes the iterator tree -- nulls are or-ed in, NOT takes the falses: the upper bound stands there)
+  if (st == PG_OK && !null_handling && !out_result->filter_entries_exact && (int64_t)segment->num_docs <= g_engine.exact_stats_docs) st = replay_filter_stats(segment, query, out_result);
   if (st != PG_OK) pg_result_free(out_result);
   return st;
 }

@@ -94,7 +94,8 @@ static __global__ __launch_bounds__(256) void group_partition_scatter_kernel(con
     uint32_t m = 0u;
     uint32_t g[32], slot[32];
     if (tile < num_tiles) {
-      m = eval_filter_private(gp.scan, tile, lane) & tail_mask(gp, tile, lane);
+      uint32_t entries_unused = 0u;             // (this kernel is not asked to count: ScanParams.filter_entries stays null)
+      m = eval_filter_private(gp.scan, tile, lane, entries_unused) & tail_mask(gp, tile, lane);
       if (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
         decode_group_keys(gp, tile, lane, g);
 #pragma unroll

@@ -1384,7 +1384,10 @@ __device__ __forceinline__ uint32_t eval_leaf_private(const ScanParams& p, const
   return L.exclusive ? ~m : m;
 }
 
-__device__ __forceinline__ uint32_t eval_filter_private(const ScanParams& p, long long tile, int lane) {
+// `entries`: per-lane share of numEntriesScannedInFilter -- a kNodeCountEntries leaf is a scan-based child of the root AND that the
+// reference and-s into the docIds left by the children before it (ScanBasedDocIdIterator.applyAnd, AndDocIdSet.java:161-163,
+// SVScanDocIdIterator.java:115-145: one entry per doc of that bitmap).  On the AND chain the only mask on the stack is that bitmap.
+__device__ __forceinline__ uint32_t eval_filter_private(const ScanParams& p, long long tile, int lane, uint32_t& entries) {
   if (p.num_nodes == 0) return 0xFFFFFFFFu;
   if (p.num_nodes == 1) return eval_leaf_private(p, p.nodes[0], tile, lane);
   MaskStack st;
@@ -1395,6 +1398,10 @@ __device__ __forceinline__ uint32_t eval_filter_private(const ScanParams& p, lon
     const DevNode& nd = p.nodes[n];
     uint32_t top;
     if (nd.op == PG_FILTER_LEAF) {
+      if (nd.flags & kNodeCountEntries) {
+        const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
+        entries += (uint32_t)__builtin_popcount(st.v[0] & (rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u))));
+      }
       top = eval_leaf_private(p, nd, tile, lane);
     } else if (nd.op == PG_FILTER_NOT) {
       top = ~st.pop();
@@ -1410,6 +1417,12 @@ __device__ __forceinline__ uint32_t eval_filter_private(const ScanParams& p, lon
     st.push(top);
   }
   return st.pop();
+}
+
+__device__ __forceinline__ void flush_filter_entries(const ScanParams& p, uint32_t entries) {
+  if (p.filter_entries == nullptr) return;
+  const unsigned long long total = (unsigned long long)wave_sum_i64((long long)entries);
+  if ((threadIdx.x & 63u) == 0u && total != 0ull) atomicAdd(p.filter_entries, total);
 }
 
 // Masked aggregation of one half (16 values) of a column chunk.  Keys (dictIds / plane fields) are below 2^31.
@@ -1488,6 +1501,7 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
                      p.nodes[0].fwd == p.agg_cols[0].fwd && p.nodes[0].bits == p.agg_cols[0].bits && p.agg_cols[0].need_sum != 0 &&
                      p.agg_cols[0].need_minmax == 0 && p.out_bitmap == nullptr;
   // index-driven filters: only the tiles index_and_kernel listed hold a match (any order)
+  uint32_t entries = 0u;                                   // numEntriesScannedInFilter, this lane's share
   const bool listed = p.tile_list != nullptr;
   const long long tile_limit = listed ? (long long)*p.tile_count : num_tiles;
   for (long long tile_it = (long long)blockIdx.x * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
@@ -1504,7 +1518,7 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
       sum[0] += wsum;
       continue;
     }
-    uint32_t m = eval_filter_private(p, tile, lane);
+    uint32_t m = eval_filter_private(p, tile, lane, entries);
     // docs past numDocs (last tile only)
     const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
@@ -1531,6 +1545,7 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
     }
   }
 
+  flush_filter_entries(p, entries);
   BlockPartial mine;
   partial_identity(mine);
   mine.count = (unsigned long long)wave_sum_i64((long long)count);
@@ -1647,18 +1662,20 @@ __global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const
   }
   const long long num_tiles = ((long long)gp.scan.num_docs + 2047) / 2048;
   const long long wave = (long long)blockIdx.x * waves_per_block + wave_in_block;
+  uint32_t entries = 0u;
   const bool listed = gp.scan.tile_list != nullptr;        // index-driven filters: only the tiles index_and_kernel listed hold a match
   const long long tile_limit = listed ? (long long)*gp.scan.tile_count : num_tiles;
   for (long long tile_it = wave; tile_it < tile_limit; tile_it += total_waves) {
     const long long tile = listed ? (long long)gp.scan.tile_list[tile_it] : tile_it;
     // the filter (if any) in the same lane-private layout: bit j of the lane's mask = doc 32*lane + j of the tile
-    uint32_t m = eval_filter_private(gp.scan, tile, lane);
+    uint32_t m = eval_filter_private(gp.scan, tile, lane, entries);
     const long long rem = (long long)gp.scan.num_docs - (tile * 2048 + lane * 32);
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
     if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
     if (__builtin_amdgcn_ballot_w64(m != 0xFFFFFFFFu) == 0ull) group_private_tile<kLdsTable, false>(gp, tile, lane, m, t_cnt, t_acc);
     else group_private_tile<kLdsTable, true>(gp, tile, lane, m, t_cnt, t_acc);
   }
+  flush_filter_entries(gp.scan, entries);
 
   if constexpr (kLdsTable) {
     __syncthreads();

@@ -178,6 +178,7 @@ __global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const Scan
   // one inclusive-range leaf on the summed column itself (C2a), plain counters, no MIN / MAX: one decode per tile instead of two
   const bool fused = !kGuard && p.num_nodes == 1 && p.nodes[0].kind == kLeafDictRange && p.nodes[0].exclusive == 0 && p.nodes[0].fwd == ac.fwd &&
                      p.nodes[0].bits == ac.bits && ac.need_minmax == 0;
+  uint32_t entries = 0u;
   const bool listed = p.tile_list != nullptr;              // index-driven filters: only the tiles index_and_kernel listed hold a match
   const long long tile_limit = listed ? (long long)*p.tile_count : num_tiles;
   for (long long tile_it = (long long)blockIdx.x * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const Scan
         continue;
       }
     }
-    uint32_t m = eval_filter_private(p, tile, lane);
+    uint32_t m = eval_filter_private(p, tile, lane, entries);
     const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
     count += (unsigned)__builtin_popcount(m);
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const Scan
     }
   }
 
+  flush_filter_entries(p, entries);
   BlockPartial mine;
   partial_identity(mine);
   mine.count = (unsigned long long)wave_sum_i64((long long)count);

@@ -151,11 +151,12 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void scan_private_typed_ke
 #pragma unroll
   for (int a = 0; a < kMaxAggCols; ++a) typed_acc_identity(acc[a]);
 
+  uint32_t entries = 0u;
   const bool listed = p.tile_list != nullptr;              // index-driven filters: only the tiles index_and_kernel listed hold a match
   const long long tile_limit = listed ? (long long)*p.tile_count : num_tiles;
   for (long long tile_it = (long long)blockIdx.x * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
     const long long tile = listed ? (long long)p.tile_list[tile_it] : tile_it;
-    uint32_t m = eval_filter_private(p, tile, lane);
+    uint32_t m = eval_filter_private(p, tile, lane, entries);
     const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
     if (p.out_bitmap) reinterpret_cast<uint32_t*>(p.out_bitmap)[tile * 64 + lane] = m;
@@ -185,6 +186,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void scan_private_typed_ke
     }
   }
 
+  flush_filter_entries(p, entries);
   BlockPartial mine;
   partial_identity(mine);
   mine.count = (unsigned long long)wave_sum_i64((long long)count);

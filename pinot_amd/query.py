@@ -125,6 +125,7 @@ class QuerySpec:
         self._nodes = (_abi.pg_filter_node * max(len(nodes), 1))()
         for i, (op, p, k) in enumerate(nodes):
             self._nodes[i].op, self._nodes[i].predicate, self._nodes[i].num_children = op, p, k
+        self.predicates = preds                  # Pred objects in predicate-index order
         self._preds = (_abi.pg_predicate * max(len(preds), 1))()
         self._keep = []
         for i, p in enumerate(preds):
@@ -188,6 +189,7 @@ class Result:
         self.device_ms = float(res.device_ms)
         self.dominant_kernel_ms = float(res.dominant_kernel_ms)
         self.dominant_kernel = _abi.KERNEL_NAMES.get(int(getattr(res, "dominant_kernel", -1)), "")
+        self.filter_entries_exact = bool(res.filter_entries_exact)      # stats[1] is the reference's count, not an upper bound
         na = int(res.num_aggregations)
         self.aggregations = [AggValue(res.aggregations[a]) for a in range(na)] if res.aggregations else []
         self.groups = {}

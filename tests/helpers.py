@@ -107,6 +107,45 @@ def golden_filter(seg, inverted=False):
         Q.leaf(eq_pred(seg, "daysSinceEpoch", 126164076)))
 
 
+def and_leapfrog_entries(matches):
+    """numEntriesScannedInFilter of an AND whose children are all scan leaves (no index-based child: AndDocIdIterator.java:41-74 leap-frogs
+    SVScanDocIdIterator.advance, one entry per doc a leaf looks at), written as the state machine the loop amounts to: exactly one leaf
+    is scanning at any doc; when it hits a match the others are asked about that doc in order until one of them says no (that one scans
+    on), and when all say yes the doc is a result and the first leaf scans on from the next doc."""
+    n, k = len(matches[0]), len(matches)
+    entries, scanning = 0, 0
+    for d in range(n):
+        entries += 1
+        if not matches[scanning][d]:
+            continue
+        nxt = 0
+        for i in range(k):
+            if i == scanning:
+                continue
+            entries += 1
+            if not matches[i][d]:
+                nxt = i
+                break
+        scanning = nxt
+    return entries
+
+
+def golden_filter_physical(seg, inverted=True):
+    """The operator tree the reference builds for BaseSingleValueQueriesTest.FILTER (FilterPlanNode + FilterOperatorUtils):
+    column5 = 'gFuH' is always true on a one-value dictionary and drops out (getLeafFilterOperator :72-88, getAndFilterOperator :140-144);
+    daysSinceEpoch is sorted -> SortedIndexBasedFilterOperator, i.e. a docId range (priority 0); the OR (priority 400) comes before the
+    scan leaves (500), which keep their order in the query (reorderAndFilterChildOperators :196-245)."""
+    days = load_golden_columns()["daysSinceEpoch"]
+    hit = np.flatnonzero(days == 126164076)
+    assert hit[-1] - hit[0] + 1 == hit.shape[0]            # the column is sorted: one docId range
+    return Q.and_(
+        Q.leaf(Q.Pred.doc_range(int(hit[0]), int(hit[-1]))),
+        Q.or_(Q.leaf(range_pred(seg, "column6", upper=500000000, upper_inclusive=False)),
+              Q.leaf(string_in_pred(seg, "column11", ["t", "P"], exclusive=True, inverted=inverted))),
+        Q.leaf(range_pred(seg, "column1", lower=100000000, lower_inclusive=False)),
+        Q.leaf(range_pred(seg, "column3", lower=20000000, upper=1000000000)))
+
+
 def golden_medium_group(seg, want):
     """(group-by column indexes, raw key) of a testMediumAggregationGroupBy golden row: raw key = sum dictId_j * prod_{k<j} cardinality_k
     (DictionaryBasedGroupKeyGenerator.java:437-445)."""
@@ -165,8 +204,11 @@ def assert_results_equal(got, want, check_stats=True):
         for i, f in enumerate(want.functions):
             assert_agg_equal(got.groups[gid][i], vals[i], f, "group %d agg %d" % (gid, i))
     if check_stats:
-        # numEntriesScannedInFilter deliberately differs (see DESIGN.md "execution statistics")
         assert got.stats[0] == want.stats[0], "numDocsScanned %r != %r" % (got.stats, want.stats)
+        # numEntriesScannedInFilter: the reference's iterator accounting on both sides, unless one of them declares an upper bound
+        # (enableNullHandling; leap-frogging filters on segments above PINOT_GPU_EXACT_FILTER_STATS_DOCS)
+        if getattr(got, "filter_entries_exact", False) and getattr(want, "filter_entries_exact", False):
+            assert got.stats[1] == want.stats[1], "numEntriesScannedInFilter %r != %r" % (got.stats, want.stats)
         assert got.stats[2] == want.stats[2], "numEntriesScannedPostFilter %r != %r" % (got.stats, want.stats)
         assert got.stats[3] == want.stats[3]
 

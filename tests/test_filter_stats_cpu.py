@@ -1,0 +1,107 @@
+"""CPU test of the engine's numEntriesScannedInFilter replay (pinot_amd/csrc/pg_filter_stats.h, host C++): built stand-alone through
+tools/fstats/fstats_driver.cpp and compared with the oracle's restatement of the reference's iterator tree (AndDocIdSet.iterator,
+AndDocIdIterator, OrDocIdIterator, NotDocIdIterator, SVScanDocIdIterator) on the golden filter and on random trees.  Two independent
+implementations of the same accounting: the oracle's is pinned to the reference's 63064 in test_oracle_golden.py."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from pinot_amd import _abi
+from pinot_amd import query as Q
+from pinot_amd import segment as S
+import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PLAN_ZERO, PLAN_PER_LEAF, PLAN_CHAIN, PLAN_REPLAY = 0, 1, 2, 3
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("needs g++")
+    out = str(tmp_path_factory.mktemp("fstats") / "libfstats_driver.so")
+    src = os.path.join(ROOT, "tools", "fstats", "fstats_driver.cpp")
+    base = ["g++", "-std=c++17", "-O1", "-g", "-shared", "-fPIC", "-Wall", "-Werror", "-o", out, src]
+    subprocess.run(base, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    lib = C.CDLL(out)
+    lib.fstats_replay.restype = C.c_int64
+    lib.fstats_replay.argtypes = [C.POINTER(_abi.pg_query), C.c_int32, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    return lib
+
+
+def replay(lib, seg, spec):
+    """(entries, plan, scan leaves): leaf docId sets from the oracle's single-leaf filter bitmaps, the walk from the engine's header."""
+    preds = spec.predicates
+    keep, ptrs = [], (C.POINTER(C.c_uint64) * max(len(preds), 1))()
+    for i, p in enumerate(preds):
+        if p.kind in (_abi.PG_PRED_MATCH_ALL, _abi.PG_PRED_MATCH_NONE):
+            continue
+        words, _ = oracle.filter_bitmap(seg, Q.QuerySpec([], filter=Q.leaf(p)))
+        words = np.ascontiguousarray(np.concatenate([words, np.zeros(1, dtype=np.uint64)]))
+        keep.append(words)
+        ptrs[i] = words.ctypes.data_as(C.POINTER(C.c_uint64))
+    plan, leaves = C.c_int32(), C.c_int32()
+    entries = lib.fstats_replay(C.byref(spec.c), seg.num_docs, ptrs, C.byref(plan), C.byref(leaves))
+    return int(entries), int(plan.value), int(leaves.value)
+
+
+def test_replay_reproduces_the_reference_golden(driver):
+    seg = H.golden_segment()
+    spec = Q.QuerySpec(H.golden_aggregations(seg), filter=H.golden_filter_physical(seg))
+    entries, plan, leaves = replay(driver, seg, spec)
+    assert (entries, plan, leaves) == (63064, PLAN_REPLAY, 3)       # InnerSegmentAggregationSingleValueQueriesTest.java:56
+    assert oracle.execute(seg, spec).stats[1] == 63064
+
+
+def test_replay_matches_the_oracle_on_random_trees(driver):
+    rng = np.random.default_rng(20260921)
+    n = 20_011
+    cols = [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "b", n, 7, with_inverted=True)[0],
+            H.random_dict_column(rng, "c", n, 300, with_inverted=True)[0], H.random_dict_column(rng, "d", n, 3)[0]]
+    seg = S.SegmentData("fs", n, cols)
+
+    def leaf():
+        k = int(rng.integers(0, 7))
+        if k == 0:
+            lo = int(rng.integers(0, 40)); return Q.leaf(Q.Pred.dict_range(0, lo, lo + int(rng.integers(1, 12)), exclusive=bool(rng.integers(0, 2))))
+        if k == 1:
+            return Q.leaf(Q.Pred.dict_range(1, int(rng.integers(0, 6)), 7, inverted=True, exclusive=bool(rng.integers(0, 2))))
+        if k == 2:
+            return Q.leaf(Q.Pred.dict_set(2, sorted(set(int(x) for x in rng.integers(0, 300, size=40))), 300, inverted=bool(rng.integers(0, 2))))
+        if k == 3:
+            lo = int(rng.integers(0, n)); return Q.leaf(Q.Pred.doc_range(lo, min(n - 1, lo + int(rng.integers(0, n))), exclusive=bool(rng.integers(0, 4) == 0)))
+        if k == 4:
+            return Q.leaf(Q.Pred.dict_range(3, int(rng.integers(0, 2)), 3))
+        if k == 5:
+            return Q.leaf(Q.Pred.dict_set(0, sorted(set(int(x) for x in rng.integers(0, 50, size=5))), 50, exclusive=bool(rng.integers(0, 2))))
+        return Q.leaf(Q.Pred.dict_range(2, 0, int(rng.integers(1, 300))))
+
+    def tree(depth):
+        k = int(rng.integers(0, 10))
+        if depth == 0 or k < 3:
+            return leaf()
+        if k < 6:
+            return Q.and_(*[tree(depth - 1) for _ in range(int(rng.integers(2, 4)))])
+        if k < 9:
+            return Q.or_(*[tree(depth - 1) for _ in range(int(rng.integers(2, 4)))])
+        return Q.not_(tree(depth - 1))
+
+    plans = set()
+    for _ in range(300):
+        spec = Q.QuerySpec([(Q.COUNT, -1)], filter=tree(3))
+        if spec.c.num_filter_nodes > 24:
+            continue
+        entries, plan, leaves = replay(driver, seg, spec)
+        want = oracle.execute(seg, spec)
+        plans.add(plan)
+        assert entries == want.stats[1], (plan, entries, want.stats)
+        if plan == PLAN_PER_LEAF:
+            assert entries == leaves * n            # no AND above a scan leaf: every scan leaf looks at every doc
+        if plan == PLAN_ZERO:
+            assert entries == 0
+    assert plans == {PLAN_ZERO, PLAN_PER_LEAF, PLAN_CHAIN, PLAN_REPLAY}

@@ -18,6 +18,40 @@ def _check_inner(vals, want):
     assert avg7.intermediate(Q.AVG) == (float(want["avg_column7"][0]), want["avg_column7"][1])
 
 
+def test_num_entries_scanned_in_filter_goldens(engine):
+    """InnerSegmentAggregationSingleValueQueriesTest :56,108,127,148,169: all four ExecutionStatistics, numEntriesScannedInFilter = 63064
+    included -- the reference's operator tree (sorted docId range, OR of a scan and a posting, two scan leaves) whose OR leap-frogs with
+    the merged bitmap, so the count comes from the iterator replay; plus the shapes the kernels count themselves."""
+    g = H.load_golden_queries()
+    seg = H.golden_segment()
+    flt = H.golden_filter_physical(seg)
+    with engine.open(seg) as gseg:
+        for group_by, key in ((None, "inner_segment"), ([seg.column_index("column9")], "inner_segment_group_by_column9")):
+            spec = Q.QuerySpec(H.golden_aggregations(seg), filter=flt, group_by=group_by or ())
+            res = gseg.execute(spec)
+            assert res.filter_entries_exact and list(res.stats) == g[key]["filtered"]["stats"]
+            H.assert_results_equal(res, oracle.execute(seg, spec))
+        mw = g["inner_segment_group_by_medium"]["filtered"]
+        cols, _ = H.golden_medium_group(seg, mw)
+        mres = gseg.execute(Q.QuerySpec(H.golden_aggregations(seg), filter=flt, group_by=cols))
+        assert list(mres.stats) == mw["stats"]
+        # root AND of plain leaves behind an index-based child: counted by the scan kernel itself (ScanBasedDocIdIterator.applyAnd)
+        c1 = Q.leaf(H.range_pred(seg, "column1", lower=100000000, lower_inclusive=False))
+        c3 = Q.leaf(H.range_pred(seg, "column3", lower=20000000, upper=1000000000))
+        days = Q.leaf(Q.Pred.doc_range(0, 24718))
+        c11 = Q.leaf(H.string_in_pred(seg, "column11", ["t", "P"], exclusive=True, inverted=True))
+        for chain in (Q.and_(days, c1, c3), Q.and_(c1, days, c3), Q.and_(c11, c3, c1), Q.and_(c3, c11, days, c1)):
+            for group_by in (None, [seg.column_index("column9")]):
+                spec = Q.QuerySpec(H.golden_aggregations(seg), filter=chain, group_by=group_by or ())
+                res, want = gseg.execute(spec), oracle.execute(seg, spec)
+                assert res.filter_entries_exact and res.stats == want.stats and 0 < res.stats[1] < 2 * 30000, (res.stats, want.stats)
+        # scan leaves only (AndDocIdIterator leap-frogs them), OR / NOT above scans, nested AND: the replay
+        for other in (Q.and_(c1, c3), Q.or_(c1, c3), Q.not_(c1), Q.and_(c1, Q.or_(c3, c11)), Q.or_(Q.and_(c1, c3), days), Q.not_(Q.and_(c1, Q.not_(c3)))):
+            spec = Q.QuerySpec(H.golden_aggregations(seg), filter=other)
+            res, want = gseg.execute(spec), oracle.execute(seg, spec)
+            assert res.filter_entries_exact and res.stats == want.stats, (res.stats, want.stats)
+
+
 def test_inner_segment_goldens(engine):
     g = H.load_golden_queries()
     seg = H.golden_segment()

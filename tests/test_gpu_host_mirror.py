@@ -32,7 +32,9 @@ def test_inner_segment_aggregation_only(golden_segments):
         assert block["intermediate"] == [want["count"], float(want["sum_column1"]), float(want["max_column3"]),
                                          float(want["min_column6"]), [float(want["avg_column7"][0]), want["avg_column7"][1]]]
         st = block["stats"]
-        assert (st["numDocsScanned"], st["numEntriesScannedPostFilter"], st["numTotalDocs"]) == (want["stats"][0], want["stats"][2], want["stats"][3])
+        # all four, numEntriesScannedInFilter = 63064 included: the host mirror builds the reference's operator tree from the SQL
+        # (FilterOperatorUtils pruning and priorities), the engine accounts for its iterators
+        assert [st["numDocsScanned"], st["numEntriesScannedInFilter"], st["numEntriesScannedPostFilter"], st["numTotalDocs"]] == want["stats"]
 
 
 def test_inner_segment_small_group_by(golden_segments):

@@ -27,6 +27,22 @@ def test_inner_segment_aggregation_goldens():
         _check_inner(res, g["filtered"])
 
 
+def test_num_entries_scanned_in_filter_golden():
+    # InnerSegmentAggregationSingleValueQueriesTest :56,108,127: (6129, 63064, 24516, 30000) -- the iterator accounting of
+    # AndDocIdSet.iterator / SVScanDocIdIterator / OrDocIdIterator on the operator tree FilterOperatorUtils builds
+    g = H.load_golden_queries()
+    seg = H.golden_segment()
+    res = oracle.execute(seg, Q.QuerySpec(H.golden_aggregations(seg), filter=H.golden_filter_physical(seg)))
+    _check_inner(res, g["inner_segment"]["filtered"])
+    assert list(res.stats) == g["inner_segment"]["filtered"]["stats"] and res.filter_entries_exact
+    gres = oracle.execute(seg, Q.QuerySpec(H.golden_aggregations(seg), filter=H.golden_filter_physical(seg), group_by=[seg.column_index("column9")]))
+    assert list(gres.stats) == g["inner_segment_group_by_column9"]["filtered"]["stats"]
+    # unfiltered: nothing scanned; one scan leaf alone: every doc once (SVScanDocIdIterator.next over the whole column)
+    assert oracle.execute(seg, Q.QuerySpec(H.golden_aggregations(seg))).stats[1] == 0
+    one = oracle.execute(seg, Q.QuerySpec(H.golden_aggregations(seg), filter=Q.leaf(H.range_pred(seg, "column1", lower=100000000, lower_inclusive=False))))
+    assert one.stats[1] == 30000
+
+
 def test_inner_segment_group_by_goldens():
     # testSmallAggregationGroupBy :96-112 (GROUP BY column9, ARRAY_BASED holder)
     g = H.load_golden_queries()["inner_segment_group_by_column9"]

@@ -1,0 +1,17 @@
+// CPU test driver for pinot_amd/csrc/pg_filter_stats.h (the engine's numEntriesScannedInFilter replay): the header is plain host C++,
+// so tests/test_filter_stats_cpu.py builds this file with g++ (-fsanitize=address,undefined when available) and compares the replay
+// with the oracle's restatement of the reference's iterators on random filter trees -- no GPU involved.
+#include "../../pinot_amd/csrc/pg_filter_stats.h"
+
+extern "C" int64_t fstats_replay(const pg_query* q, int32_t num_docs, const uint64_t* const* leaf_words, int32_t* out_plan, int32_t* out_scan_leaves) {
+  int scan_leaves = 0;
+  const pg::fstats::Plan plan = pg::fstats::choose_plan(q, &scan_leaves);
+  if (out_plan) *out_plan = (int32_t)plan;
+  if (out_scan_leaves) *out_scan_leaves = scan_leaves;
+  if (q->num_filter_nodes == 0 || pg::fstats::malformed(q)) return 0;
+  const size_t words = ((size_t)num_docs + 63) / 64;
+  std::vector<pg::fstats::Words> leaves((size_t)q->num_predicates);
+  for (int i = 0; i < q->num_predicates; ++i)
+    if (leaf_words[i]) leaves[(size_t)i] = std::make_shared<std::vector<uint64_t>>(leaf_words[i], leaf_words[i] + (words ? words : 1));
+  return pg::fstats::replay(q, num_docs, leaves);
+}
