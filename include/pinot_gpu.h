@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 1
+#define PG_ABI_VERSION 2   /* 2: pg_result.filter_entries_exact, pg_query_check */
 
 typedef enum pg_status {
   PG_OK = 0,
@@ -282,6 +282,14 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
 pg_status pg_segment_close(pg_segment* segment);
 pg_status pg_segment_num_docs(const pg_segment* segment, int32_t* out_num_docs);
 pg_status pg_segment_device_bytes(const pg_segment* segment, uint64_t* out_bytes);
+
+/* Plan-time eligibility: PG_OK when pg_execute would run this query on this segment, PG_ERR_UNSUPPORTED (pg_last_error says why) when
+ * it would decline it -- more filter leaves / nodes / column streams / aggregations than the kernels take, key spaces beyond the
+ * direct-indexed table, raw 8-byte aggregations or nullable columns under GROUP BY ... -- decided from the query and the segment's
+ * metadata alone: nothing is allocated or launched.  pg_execute makes the same call first, so the two never disagree.  This is what
+ * InstancePlanMakerImplV2.makeSegmentPlanNode (core/plan/maker/InstancePlanMakerImplV2.java:270-289) asks before it swaps the
+ * operator: on anything but PG_OK the caller keeps the CPU plan. */
+pg_status pg_query_check(const pg_segment* segment, const pg_query* query);
 
 pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_result);
 void pg_result_free(pg_result* result);

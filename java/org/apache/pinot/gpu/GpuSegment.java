@@ -1,0 +1,227 @@
+/**
+ * One immutable segment resident in HBM: the native handle of pg_segment_open plus the column table the lowering needs.
+ *
+ * <p>Opening reads every supported column's index buffers ONCE: the segment directory is re-opened read-only (the same mmap-ed files the
+ * server already holds; SegmentDirectoryLoaderRegistry, pinot-segment-spi/.../loader/SegmentDirectoryLoaderRegistry.java:88), each
+ * buffer's address is handed to pg_segment_open, which copies it to the device, and the directory is closed again.  Afterwards the JVM
+ * keeps no reference to those buffers on behalf of the device.
+ *
+ * <p>What reaches the device per column (pg_column_desc, include/pinot_gpu.h:88-105): single-value columns of stored type INT / LONG /
+ * FLOAT / DOUBLE with a dictionary (fixed-bit forward index + big-endian dictionary file, + the bitmap inverted index and the null value
+ * vector when they exist) or raw (PASS_THROUGH fixed-byte chunks); STRING columns with a dictionary travel as their dictIds under a
+ * placeholder dictionary {0..cardinality-1} (their values never reach the device: predicates are lowered to dictIds here, group keys
+ * are mapped back through the Java dictionary).  Sorted columns store [start, end] docId pairs instead of a dictId per doc
+ * (SortedIndexReaderImpl): the fixed-bit stream the device scans is packed here from those pairs, in the layout of
+ * FixedBitSVForwardIndexWriter / PinotDataBitSet.  Anything else is left out, and a query that touches it keeps the CPU plan.
+ */
+package org.apache.pinot.gpu;
+
+import java.io.Closeable;
+import java.io.File;
+import java.nio.ByteBuffer;
+import java.nio.ByteOrder;
+import java.util.ArrayList;
+import java.util.HashMap;
+import java.util.List;
+import java.util.Map;
+import org.apache.pinot.segment.spi.IndexSegment;
+import org.apache.pinot.segment.spi.compression.ChunkCompressionType;
+import org.apache.pinot.segment.spi.datasource.DataSource;
+import org.apache.pinot.segment.spi.datasource.DataSourceMetadata;
+import org.apache.pinot.segment.spi.index.StandardIndexes;
+import org.apache.pinot.segment.spi.index.reader.Dictionary;
+import org.apache.pinot.segment.spi.index.reader.ForwardIndexReader;
+import org.apache.pinot.segment.spi.index.reader.SortedIndexReader;
+import org.apache.pinot.segment.spi.loader.SegmentDirectoryLoaderContext;
+import org.apache.pinot.segment.spi.loader.SegmentDirectoryLoaderRegistry;
+import org.apache.pinot.segment.spi.memory.PinotDataBuffer;
+import org.apache.pinot.segment.spi.store.SegmentDirectory;
+import org.apache.pinot.spi.data.FieldSpec.DataType;
+import org.apache.pinot.spi.env.PinotConfiguration;
+import org.apache.pinot.spi.utils.Pairs;
+
+
+final class GpuSegment implements Closeable {
+  // pg_data_type / pg_fwd_encoding
+  private static final int TYPE_INT = 0;
+  private static final int TYPE_LONG = 1;
+  private static final int TYPE_FLOAT = 2;
+  private static final int TYPE_DOUBLE = 3;
+  private static final int FWD_FIXED_BIT_DICT = 0;
+  private static final int FWD_RAW_FIXED_BYTE = 1;
+
+  private final IndexSegment _indexSegment;
+  private final Map<String, Integer> _columnIndex = new HashMap<>();
+  private final List<String> _columnNames = new ArrayList<>();
+  private final List<Boolean> _hasDictionary = new ArrayList<>();
+  private final List<Boolean> _numeric = new ArrayList<>();
+  private final int _numDocs;
+  private volatile long _handle;
+
+  private GpuSegment(IndexSegment indexSegment) {
+    _indexSegment = indexSegment;
+    _numDocs = indexSegment.getSegmentMetadata().getTotalDocs();
+  }
+
+  IndexSegment getIndexSegment() {
+    return _indexSegment;
+  }
+
+  long handle() {
+    return _handle;
+  }
+
+  int numDocs() {
+    return _numDocs;
+  }
+
+  /** Index of a column in the device segment; NotOffloadable when the column did not qualify. */
+  int columnIndex(String column) {
+    Integer index = _columnIndex.get(column);
+    if (index == null) {
+      throw new GpuQueryLowering.NotOffloadable("column " + column + " is not on the device");
+    }
+    return index;
+  }
+
+  String columnName(int index) {
+    return _columnNames.get(index);
+  }
+
+  boolean hasDictionary(int column) {
+    return _hasDictionary.get(column);
+  }
+
+  boolean isNumeric(int column) {
+    return _numeric.get(column);
+  }
+
+  @Override
+  public synchronized void close() {
+    if (_handle != 0) {
+      PinotGpuNative.segmentClose(_handle);
+      _handle = 0;
+    }
+  }
+
+  static GpuSegment open(IndexSegment indexSegment, int device)
+      throws Exception {
+    GpuSegment segment = new GpuSegment(indexSegment);
+    File indexDir = indexSegment.getSegmentMetadata().getIndexDir();
+    SegmentDirectoryLoaderContext context = new SegmentDirectoryLoaderContext.Builder()
+        .setSegmentName(indexSegment.getSegmentName())
+        .setSegmentDirectoryConfigs(new PinotConfiguration(Map.of("readMode", "mmap")))
+        .build();
+    List<Integer> ints = new ArrayList<>();
+    List<Long> buffers = new ArrayList<>();
+    List<ByteBuffer> keepAlive = new ArrayList<>();            // direct buffers made here (placeholder dictionaries, packed sorted columns)
+    try (SegmentDirectory directory = SegmentDirectoryLoaderRegistry.getDefaultSegmentDirectoryLoader().load(indexDir.toURI(), context);
+        SegmentDirectory.Reader reader = directory.createReader()) {
+      for (String column : indexSegment.getPhysicalColumnNames()) {
+        DataSource dataSource = indexSegment.getDataSource(column);
+        DataSourceMetadata metadata = dataSource.getDataSourceMetadata();
+        ForwardIndexReader<?> forwardIndex = dataSource.getForwardIndex();
+        if (forwardIndex == null || !metadata.isSingleValue()) {
+          continue;
+        }
+        DataType storedType = metadata.getDataType().getStoredType();
+        Dictionary dictionary = dataSource.getDictionary();
+        boolean numeric = storedType == DataType.INT || storedType == DataType.LONG || storedType == DataType.FLOAT || storedType == DataType.DOUBLE;
+        if (!numeric && !(storedType == DataType.STRING && dictionary != null)) {
+          continue;
+        }
+        long[] fwd;
+        long[] dict = {0, 0};
+        long[] inverted = {0, 0};
+        long[] nulls = {0, 0};
+        int encoding;
+        int bits = 0;
+        int cardinality = 0;
+        if (dictionary != null) {
+          encoding = FWD_FIXED_BIT_DICT;
+          cardinality = dictionary.length();
+          bits = numBitsPerValue(cardinality - 1);
+          if (metadata.isSorted() && dataSource.getInvertedIndex() instanceof SortedIndexReader) {
+            ByteBuffer packed = packSorted((SortedIndexReader<?>) dataSource.getInvertedIndex(), cardinality, bits, segment._numDocs);
+            keepAlive.add(packed);
+            fwd = new long[]{PinotGpuNative.directBufferAddress(packed), packed.capacity()};
+          } else {
+            fwd = addressOf(reader.getIndexFor(column, StandardIndexes.forward()));
+            if (reader.hasIndexFor(column, StandardIndexes.inverted())) {
+              inverted = addressOf(reader.getIndexFor(column, StandardIndexes.inverted()));
+            }
+          }
+          if (numeric) {
+            // the .dict file is the header-less big-endian value array of Int / Long / Float / DoubleDictionary
+            dict = addressOf(reader.getIndexFor(column, StandardIndexes.dictionary()));
+          } else {
+            ByteBuffer placeholder = ByteBuffer.allocateDirect(4 * cardinality).order(ByteOrder.BIG_ENDIAN);
+            for (int d = 0; d < cardinality; d++) {
+              placeholder.putInt(4 * d, d);
+            }
+            keepAlive.add(placeholder);
+            dict = new long[]{PinotGpuNative.directBufferAddress(placeholder), placeholder.capacity()};
+          }
+        } else {
+          if (forwardIndex.getCompressionType() != ChunkCompressionType.PASS_THROUGH) {
+            continue;                                            // compressed raw chunks are decoded on the CPU plan
+          }
+          encoding = FWD_RAW_FIXED_BYTE;
+          fwd = addressOf(reader.getIndexFor(column, StandardIndexes.forward()));
+        }
+        if (reader.hasIndexFor(column, StandardIndexes.nullValueVector())) {
+          nulls = addressOf(reader.getIndexFor(column, StandardIndexes.nullValueVector()));
+        }
+        int storedCode = storedType == DataType.LONG ? TYPE_LONG : (storedType == DataType.FLOAT ? TYPE_FLOAT : (storedType == DataType.DOUBLE ? TYPE_DOUBLE : TYPE_INT));
+        segment._columnIndex.put(column, segment._columnNames.size());
+        segment._columnNames.add(column);
+        segment._hasDictionary.add(dictionary != null);
+        segment._numeric.add(numeric);
+        for (int v : new int[]{storedCode, encoding, bits, cardinality, dictionary != null ? 1 : 0, 0}) {
+          ints.add(v);
+        }
+        for (long[] pair : new long[][]{fwd, dict, inverted, nulls}) {
+          buffers.add(pair[0]);
+          buffers.add(pair[1]);
+        }
+      }
+      long crc = Long.parseLong(indexSegment.getSegmentMetadata().getCrc());
+      segment._handle = PinotGpuNative.segmentOpen(indexSegment.getSegmentName(), crc, device, segment._numDocs,
+          segment._columnNames.toArray(new String[0]), ints.stream().mapToInt(Integer::intValue).toArray(),
+          buffers.stream().mapToLong(Long::longValue).toArray());
+    }
+    keepAlive.clear();       // pg_segment_open has copied everything to the device
+    return segment;
+  }
+
+  /** {address, size} of a mapped index buffer.  toDirectByteBuffer takes an int size: the base address is all that is needed. */
+  private static long[] addressOf(PinotDataBuffer buffer) {
+    long size = buffer.size();
+    ByteBuffer head = buffer.toDirectByteBuffer(0, (int) Math.min(size, 1 << 20));
+    return new long[]{PinotGpuNative.directBufferAddress(head), size};
+  }
+
+  /** PinotDataBitSet.getNumBitsPerValue (pinot-segment-local/.../io/util/PinotDataBitSet.java:61-72) */
+  static int numBitsPerValue(int maxValue) {
+    return maxValue <= 0 ? 1 : 32 - Integer.numberOfLeadingZeros(maxValue);
+  }
+
+  /** The dictId of every doc of a sorted column as the MSB-first fixed-bit stream of FixedBitSVForwardIndexWriter. */
+  private static ByteBuffer packSorted(SortedIndexReader<?> sortedIndex, int cardinality, int bits, int numDocs) {
+    long totalBits = (long) numDocs * bits;
+    ByteBuffer out = ByteBuffer.allocateDirect((int) ((totalBits + 7) / 8));
+    long bit = 0;
+    for (int dictId = 0; dictId < cardinality; dictId++) {
+      Pairs.IntPair range = sortedIndex.getDocIds(dictId);
+      for (int doc = range.getLeft(); doc <= range.getRight(); doc++) {
+        for (int b = bits - 1; b >= 0; b--, bit++) {
+          if (((dictId >>> b) & 1) != 0) {
+            int at = (int) (bit >>> 3);
+            out.put(at, (byte) (out.get(at) | (0x80 >>> (int) (bit & 7))));
+          }
+        }
+      }
+    }
+    return out;
+  }
+}

@@ -1,0 +1,258 @@
+/* JNI functions of org.apache.pinot.gpu.PinotGpuNative (java/org/apache/pinot/gpu/PinotGpuNative.java) over the C ABI of
+ * include/pinot_gpu.h.  Every function is: pin the Java arrays, hand them to the JNI-free marshalling of pg_marshal.c, call ONE C-ABI
+ * entry point, copy plain arrays back.  No native pointer other than the opaque segment handle (a jlong) escapes into Java, and no
+ * Java object is retained past a call.
+ *
+ * Replaces, on the reference side: nothing that exists -- the reference has no native code.  It is what a maintainer adds next to
+ * org.apache.pinot.gpu.GpuPlanMaker so that InstancePlanMakerImplV2.makeSegmentPlanNode (core/plan/maker/InstancePlanMakerImplV2.java:270-289)
+ * can hand a segment's aggregation to the device.  Build: jni/Makefile (`make jni JAVA_HOME=...`); this environment has no JDK, so the
+ * file is compiled here only against the type-level stand-in jni/stub/jni.h (tests/test_marshal.py), the code under it through ctypes.
+ *
+ * Errors: PG_ERR_UNSUPPORTED -> java.lang.UnsupportedOperationException (the plan maker asked queryCheck first, so this is a bug in the
+ * caller), every other non-OK status -> java.lang.RuntimeException carrying pg_last_error(). */
+#include <jni.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/pinot_gpu.h"
+#include "pg_marshal.h"
+
+static void throw_new(JNIEnv* env, const char* class_name, const char* message) {
+  jclass cls = (*env)->FindClass(env, class_name);
+  if (cls != NULL) (*env)->ThrowNew(env, cls, message ? message : "");
+}
+
+static void throw_status(JNIEnv* env, pg_status status) {
+  throw_new(env, status == PG_ERR_UNSUPPORTED ? "java/lang/UnsupportedOperationException" : "java/lang/RuntimeException", pg_last_error());
+}
+
+JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_init(JNIEnv* env, jclass cls, jint device, jint flags) {
+  (void)cls;
+  pg_config config;
+  memset(&config, 0, sizeof(config));
+  config.abi_version = PG_ABI_VERSION;
+  config.device_id = device;
+  config.flags = (int32_t)flags;
+  const pg_status status = pg_init(&config);
+  if (status != PG_OK) throw_status(env, status);
+}
+
+JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_shutdown(JNIEnv* env, jclass cls) {
+  (void)env; (void)cls;
+  (void)pg_shutdown();
+}
+
+JNIEXPORT jstring JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_version(JNIEnv* env, jclass cls) {
+  (void)cls;
+  return (*env)->NewStringUTF(env, pg_version());
+}
+
+/* The address behind a direct ByteBuffer: how the Java side learns where PinotDataBuffer mapped an index file. */
+JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_directBufferAddress(JNIEnv* env, jclass cls, jobject buffer) {
+  (void)cls;
+  void* address = buffer != NULL ? (*env)->GetDirectBufferAddress(env, buffer) : NULL;
+  if (address == NULL) { throw_new(env, "java/lang/IllegalArgumentException", "not a direct ByteBuffer"); return 0; }
+  return (jlong)(intptr_t)address;
+}
+
+/* columnInts / columnBuffers: the layouts of pgm_segment_build.  The buffer addresses are those of the segment's memory-mapped index
+ * buffers (PinotDataBuffer -> direct ByteBuffer -> GetDirectBufferAddress on the Java side, see PinotGpuNative.addressOf); they are
+ * read once, here, while pg_segment_open copies them to HBM. */
+JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_segmentOpen(JNIEnv* env, jclass cls, jstring name, jlong crc, jint device,
+    jint numDocs, jobjectArray columnNames, jintArray columnInts, jlongArray columnBuffers) {
+  (void)cls;
+  const jsize num_columns = (*env)->GetArrayLength(env, columnNames);
+  if ((*env)->GetArrayLength(env, columnInts) != 6 * num_columns || (*env)->GetArrayLength(env, columnBuffers) != 8 * num_columns) {
+    throw_new(env, "java/lang/IllegalArgumentException", "column arrays do not match the number of columns");
+    return 0;
+  }
+  const char* segment_name = (*env)->GetStringUTFChars(env, name, NULL);
+  const char** names = (const char**)calloc(num_columns ? (size_t)num_columns : 1, sizeof(char*));
+  jstring* name_refs = (jstring*)calloc(num_columns ? (size_t)num_columns : 1, sizeof(jstring));
+  jint* ints = (*env)->GetIntArrayElements(env, columnInts, NULL);
+  jlong* buffers = (*env)->GetLongArrayElements(env, columnBuffers, NULL);
+  jlong handle = 0;
+  int ok = segment_name != NULL && names != NULL && name_refs != NULL && ints != NULL && buffers != NULL;
+  for (jsize c = 0; ok && c < num_columns; c++) {
+    name_refs[c] = (jstring)(*env)->GetObjectArrayElement(env, columnNames, c);
+    names[c] = name_refs[c] ? (*env)->GetStringUTFChars(env, name_refs[c], NULL) : NULL;
+    ok = names[c] != NULL;
+  }
+  if (ok) {
+    pgm_segment* built = pgm_segment_build(segment_name, (int64_t)crc, (int32_t)device, (int32_t)numDocs, (int32_t)num_columns, names,
+                                           (const int32_t*)ints, (const int64_t*)buffers);
+    if (built == NULL) {
+      throw_new(env, "java/lang/IllegalArgumentException", pgm_last_error());
+    } else {
+      pg_segment* segment = NULL;
+      const pg_status status = pg_segment_open(pgm_segment_get(built), &segment);
+      pgm_segment_free(built);                      /* pg_segment_open copied what it keeps */
+      if (status != PG_OK) throw_status(env, status); else handle = (jlong)(intptr_t)segment;
+    }
+  } else if (!(*env)->ExceptionCheck(env)) {
+    throw_new(env, "java/lang/OutOfMemoryError", "pinning the segment description failed");
+  }
+  for (jsize c = 0; c < num_columns; c++) {
+    if (names != NULL && name_refs != NULL && names[c] != NULL) (*env)->ReleaseStringUTFChars(env, name_refs[c], names[c]);
+    if (name_refs != NULL && name_refs[c] != NULL) (*env)->DeleteLocalRef(env, name_refs[c]);
+  }
+  if (buffers != NULL) (*env)->ReleaseLongArrayElements(env, columnBuffers, buffers, JNI_ABORT);
+  if (ints != NULL) (*env)->ReleaseIntArrayElements(env, columnInts, ints, JNI_ABORT);
+  if (segment_name != NULL) (*env)->ReleaseStringUTFChars(env, name, segment_name);
+  free(name_refs);
+  free((void*)names);
+  return handle;
+}
+
+JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_segmentClose(JNIEnv* env, jclass cls, jlong handle) {
+  (void)env; (void)cls;
+  if (handle != 0) (void)pg_segment_close((pg_segment*)(intptr_t)handle);
+}
+
+JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_segmentDeviceBytes(JNIEnv* env, jclass cls, jlong handle) {
+  (void)cls;
+  uint64_t bytes = 0;
+  const pg_status status = pg_segment_device_bytes((const pg_segment*)(intptr_t)handle, &bytes);
+  if (status != PG_OK) { throw_status(env, status); return 0; }
+  return (jlong)bytes;
+}
+
+/* The query arrays of pg_marshal.h, pinned for the duration of one call. */
+typedef struct pinned_query {
+  jint *nodes, *pred_ints, *set_offsets, *set_words, *aggregations, *group_by;
+  jlong* pred_longs;
+  pgm_query* built;
+} pinned_query;
+
+static void release_query(JNIEnv* env, pinned_query* p, jintArray filterNodes, jintArray predInts, jlongArray predLongs, jintArray setOffsets,
+                          jintArray setWords, jintArray aggregations, jintArray groupBy) {
+  pgm_query_free(p->built);
+  if (p->group_by) (*env)->ReleaseIntArrayElements(env, groupBy, p->group_by, JNI_ABORT);
+  if (p->aggregations) (*env)->ReleaseIntArrayElements(env, aggregations, p->aggregations, JNI_ABORT);
+  if (p->set_words) (*env)->ReleaseIntArrayElements(env, setWords, p->set_words, JNI_ABORT);
+  if (p->set_offsets) (*env)->ReleaseIntArrayElements(env, setOffsets, p->set_offsets, JNI_ABORT);
+  if (p->pred_longs) (*env)->ReleaseLongArrayElements(env, predLongs, p->pred_longs, JNI_ABORT);
+  if (p->pred_ints) (*env)->ReleaseIntArrayElements(env, predInts, p->pred_ints, JNI_ABORT);
+  if (p->nodes) (*env)->ReleaseIntArrayElements(env, filterNodes, p->nodes, JNI_ABORT);
+}
+
+/* Returns 0 and leaves a Java exception pending on failure. */
+static int pin_query(JNIEnv* env, pinned_query* p, jintArray filterNodes, jintArray predInts, jlongArray predLongs, jintArray setOffsets,
+                     jintArray setWords, jintArray aggregations, jintArray groupBy, jint numGroupsLimit, jint flags) {
+  memset(p, 0, sizeof(*p));
+  const jsize num_nodes = (*env)->GetArrayLength(env, filterNodes) / 3;
+  const jsize num_preds = (*env)->GetArrayLength(env, predInts) / 4;
+  const jsize num_set_words = (*env)->GetArrayLength(env, setWords);
+  const jsize num_aggs = (*env)->GetArrayLength(env, aggregations) / 2;
+  const jsize num_group_by = (*env)->GetArrayLength(env, groupBy);
+  if ((*env)->GetArrayLength(env, predLongs) != 2 * num_preds || (*env)->GetArrayLength(env, setOffsets) != num_preds + 1) {
+    throw_new(env, "java/lang/IllegalArgumentException", "predicate arrays of different lengths");
+    return 0;
+  }
+  p->nodes = (*env)->GetIntArrayElements(env, filterNodes, NULL);
+  p->pred_ints = (*env)->GetIntArrayElements(env, predInts, NULL);
+  p->pred_longs = (*env)->GetLongArrayElements(env, predLongs, NULL);
+  p->set_offsets = (*env)->GetIntArrayElements(env, setOffsets, NULL);
+  p->set_words = (*env)->GetIntArrayElements(env, setWords, NULL);
+  p->aggregations = (*env)->GetIntArrayElements(env, aggregations, NULL);
+  p->group_by = (*env)->GetIntArrayElements(env, groupBy, NULL);
+  if (!p->nodes || !p->pred_ints || !p->pred_longs || !p->set_offsets || !p->set_words || !p->aggregations || !p->group_by) {
+    release_query(env, p, filterNodes, predInts, predLongs, setOffsets, setWords, aggregations, groupBy);
+    if (!(*env)->ExceptionCheck(env)) throw_new(env, "java/lang/OutOfMemoryError", "pinning the query arrays failed");
+    return 0;
+  }
+  p->built = pgm_query_build((const int32_t*)p->nodes, (int32_t)num_nodes, (const int32_t*)p->pred_ints, (const int64_t*)p->pred_longs,
+                             (int32_t)num_preds, (const int32_t*)p->set_offsets, (const uint32_t*)p->set_words, (int32_t)num_set_words,
+                             (const int32_t*)p->aggregations, (int32_t)num_aggs, (const int32_t*)p->group_by, (int32_t)num_group_by,
+                             (int32_t)numGroupsLimit, (int32_t)flags);
+  if (p->built == NULL) {
+    release_query(env, p, filterNodes, predInts, predLongs, setOffsets, setWords, aggregations, groupBy);
+    throw_new(env, "java/lang/IllegalArgumentException", pgm_last_error());
+    return 0;
+  }
+  return 1;
+}
+
+/* pg_query_check: PG_OK (0) or PG_ERR_UNSUPPORTED (2) come back as the status; anything else is an exception. */
+JNIEXPORT jint JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_queryCheck(JNIEnv* env, jclass cls, jlong handle, jintArray filterNodes,
+    jintArray predInts, jlongArray predLongs, jintArray setOffsets, jintArray setWords, jintArray aggregations, jintArray groupBy,
+    jint numGroupsLimit, jint flags) {
+  (void)cls;
+  pinned_query p;
+  if (!pin_query(env, &p, filterNodes, predInts, predLongs, setOffsets, setWords, aggregations, groupBy, numGroupsLimit, flags)) return PG_ERR_INTERNAL;
+  const pg_status status = pg_query_check((const pg_segment*)(intptr_t)handle, pgm_query_get(p.built));
+  release_query(env, &p, filterNodes, predInts, predLongs, setOffsets, setWords, aggregations, groupBy);
+  if (status != PG_OK && status != PG_ERR_UNSUPPORTED) throw_status(env, status);
+  return (jint)status;
+}
+
+JNIEXPORT jstring JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_lastError(JNIEnv* env, jclass cls) {
+  (void)cls;
+  return (*env)->NewStringUTF(env, pg_last_error());
+}
+
+/* pg_execute.  Returns Object[8]: {long[] header (PGM_H_* layout), int[] groupIds, long[] counts, double[] sums, long[] sumsI64,
+ * int[] sumExact, double[] mins, double[] maxs}, the value arrays row-major [row * numAggregations + a]. */
+JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(JNIEnv* env, jclass cls, jlong handle, jintArray filterNodes,
+    jintArray predInts, jlongArray predLongs, jintArray setOffsets, jintArray setWords, jintArray aggregations, jintArray groupBy,
+    jint numGroupsLimit, jint flags) {
+  (void)cls;
+  pinned_query p;
+  if (!pin_query(env, &p, filterNodes, predInts, predLongs, setOffsets, setWords, aggregations, groupBy, numGroupsLimit, flags)) return NULL;
+  const int32_t is_group_by = pgm_query_get(p.built)->num_group_by > 0;
+  pg_result result;
+  const pg_status status = pg_execute((pg_segment*)(intptr_t)handle, pgm_query_get(p.built), &result);
+  release_query(env, &p, filterNodes, predInts, predLongs, setOffsets, setWords, aggregations, groupBy);
+  if (status != PG_OK) { throw_status(env, status); return NULL; }     /* pg_execute freed the result */
+
+  const jsize rows = (jsize)pgm_result_rows(&result, is_group_by);
+  const jsize cells = rows * (jsize)result.num_aggregations;
+  jobjectArray out = NULL;
+  jclass object_class = (*env)->FindClass(env, "java/lang/Object");
+  jlongArray header = (*env)->NewLongArray(env, PGM_HEADER_LEN);
+  jintArray group_ids = (*env)->NewIntArray(env, is_group_by ? rows : 0);
+  jlongArray counts = (*env)->NewLongArray(env, cells);
+  jdoubleArray sums = (*env)->NewDoubleArray(env, cells);
+  jlongArray sums_i64 = (*env)->NewLongArray(env, cells);
+  jintArray sum_exact = (*env)->NewIntArray(env, cells);
+  jdoubleArray mins = (*env)->NewDoubleArray(env, cells);
+  jdoubleArray maxs = (*env)->NewDoubleArray(env, cells);
+  if (object_class && header && group_ids && counts && sums && sums_i64 && sum_exact && mins && maxs) {
+    int64_t h[PGM_HEADER_LEN];
+    pgm_result_header(&result, is_group_by, h);
+    (*env)->SetLongArrayRegion(env, header, 0, PGM_HEADER_LEN, (const jlong*)h);
+    /* the value arrays are filled in place: GetPrimitiveArrayCritical would forbid the JNI calls in between, plain element access does not */
+    jint* g = (*env)->GetIntArrayElements(env, group_ids, NULL);
+    jlong* c = (*env)->GetLongArrayElements(env, counts, NULL);
+    jdouble* s = (*env)->GetDoubleArrayElements(env, sums, NULL);
+    jlong* si = (*env)->GetLongArrayElements(env, sums_i64, NULL);
+    jint* se = (*env)->GetIntArrayElements(env, sum_exact, NULL);
+    jdouble* mn = (*env)->GetDoubleArrayElements(env, mins, NULL);
+    jdouble* mx = (*env)->GetDoubleArrayElements(env, maxs, NULL);
+    if (g && c && s && si && se && mn && mx) {
+      (void)pgm_result_fill(&result, is_group_by, (int32_t*)g, (int64_t*)c, (double*)s, (int64_t*)si, (int32_t*)se, (double*)mn, (double*)mx);
+      out = (*env)->NewObjectArray(env, 8, object_class, NULL);
+    }
+    if (mx) (*env)->ReleaseDoubleArrayElements(env, maxs, mx, 0);
+    if (mn) (*env)->ReleaseDoubleArrayElements(env, mins, mn, 0);
+    if (se) (*env)->ReleaseIntArrayElements(env, sum_exact, se, 0);
+    if (si) (*env)->ReleaseLongArrayElements(env, sums_i64, si, 0);
+    if (s) (*env)->ReleaseDoubleArrayElements(env, sums, s, 0);
+    if (c) (*env)->ReleaseLongArrayElements(env, counts, c, 0);
+    if (g) (*env)->ReleaseIntArrayElements(env, group_ids, g, 0);
+    if (out != NULL) {
+      (*env)->SetObjectArrayElement(env, out, 0, header);
+      (*env)->SetObjectArrayElement(env, out, 1, group_ids);
+      (*env)->SetObjectArrayElement(env, out, 2, counts);
+      (*env)->SetObjectArrayElement(env, out, 3, sums);
+      (*env)->SetObjectArrayElement(env, out, 4, sums_i64);
+      (*env)->SetObjectArrayElement(env, out, 5, sum_exact);
+      (*env)->SetObjectArrayElement(env, out, 6, mins);
+      (*env)->SetObjectArrayElement(env, out, 7, maxs);
+    }
+  }
+  pg_result_free(&result);
+  if (out == NULL && !(*env)->ExceptionCheck(env)) throw_new(env, "java/lang/OutOfMemoryError", "allocating the result arrays failed");
+  return out;
+}

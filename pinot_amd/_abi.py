@@ -7,7 +7,7 @@ C ABI into the HIP kernels, and loading fails loudly when the library has not be
 import ctypes as C
 import os
 
-PG_ABI_VERSION = 1
+PG_ABI_VERSION = 2
 
 # pg_status
 PG_OK, PG_ERR_INVALID_ARGUMENT, PG_ERR_UNSUPPORTED, PG_ERR_DEVICE, PG_ERR_OUT_OF_MEMORY, PG_ERR_NOT_INITIALIZED, PG_ERR_INTERNAL = range(7)
@@ -99,6 +99,7 @@ ABI_SYMBOLS = [
     ("pg_segment_num_docs", C.c_int, [C.c_void_p, _P(C.c_int32)]),
     ("pg_measure_stream_read", C.c_int, [C.c_int32, C.c_uint64, C.c_int32, _P(C.c_double)]),
     ("pg_segment_device_bytes", C.c_int, [C.c_void_p, _P(C.c_uint64)]),
+    ("pg_query_check", C.c_int, [C.c_void_p, _P(pg_query)]),
     ("pg_execute", C.c_int, [C.c_void_p, _P(pg_query), _P(pg_result)]),
     ("pg_result_free", None, [_P(pg_result)]),
     ("pg_filter_bitmap", C.c_int, [C.c_void_p, _P(pg_query), _P(C.c_uint64), C.c_int64, _P(C.c_int64)]),

@@ -345,6 +345,7 @@ struct GpuAbi {
   decltype(&pg_last_error) last_error;
   decltype(&pg_segment_open) segment_open;
   decltype(&pg_segment_close) segment_close;
+  decltype(&pg_query_check) query_check;
   decltype(&pg_execute) execute;
   decltype(&pg_result_free) result_free;
   decltype(&pg_filter_bitmap) filter_bitmap;

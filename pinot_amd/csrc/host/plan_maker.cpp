@@ -42,6 +42,7 @@ const GpuAbi& gpuAbi() {
     abi.last_error = (decltype(abi.last_error))sym("pg_last_error");
     abi.segment_open = (decltype(abi.segment_open))sym("pg_segment_open");
     abi.segment_close = (decltype(abi.segment_close))sym("pg_segment_close");
+    abi.query_check = (decltype(abi.query_check))sym("pg_query_check");
     abi.execute = (decltype(abi.execute))sym("pg_execute");
     abi.result_free = (decltype(abi.result_free))sym("pg_result_free");
     abi.filter_bitmap = (decltype(abi.filter_bitmap))sym("pg_filter_bitmap");
@@ -485,8 +486,13 @@ class GpuAggregationOperator : public Operator {
 
 class GpuAggregationPlanNode : public PlanNode {
  public:
+  // Plan-time eligibility: pg_query_check takes the decision pg_execute would take (leaf / node / column-stream tables, key spaces,
+  // nullable group-by ...) without launching anything; PG_ERR_UNSUPPORTED becomes the UnsupportedOperationException on which the
+  // caller keeps the CPU plan (InstancePlanMakerImplV2.makeSegmentPlanNode :270-289).  Nothing is rejected at run time.
   GpuAggregationPlanNode(const ImmutableSegment* seg, QueryContext qc, std::unique_ptr<LoweredQuery> lq)
-      : _segment(seg), _queryContext(std::move(qc)), _lowered(std::move(lq)) {}
+      : _segment(seg), _queryContext(std::move(qc)), _lowered(std::move(lq)) {
+    checkStatus(gpuAbi().query_check((const pg_segment*)seg->handle(), &_lowered->query), "planning the segment query");
+  }
   std::unique_ptr<Operator> run() override { return std::make_unique<GpuAggregationOperator>(_segment, _queryContext, std::move(_lowered)); }
  private:
   const ImmutableSegment* _segment;
@@ -694,6 +700,7 @@ ResultsBlock GpuPlanMaker::executeCombined(const std::vector<SegmentContext>& se
   for (const auto& sc : segments) operators.push_back(makeSegmentPlanNode(sc, qc)->run());
   std::vector<ResultsBlock> blocks(operators.size());
   std::vector<std::string> errors(operators.size());
+  std::vector<int> errorKinds(operators.size(), 0);       // 1 UnsupportedOperationException, 2 QueryException, 3 anything else
   const int numTasks = std::max(1, std::min((int)operators.size(), maxExecutionThreads > 0 ? maxExecutionThreads : (int)operators.size()));
   std::vector<std::thread> workers;
   for (int t = 0; t < numTasks; ++t) {
@@ -701,6 +708,7 @@ ResultsBlock GpuPlanMaker::executeCombined(const std::vector<SegmentContext>& se
       for (size_t i = (size_t)t; i < operators.size(); i += (size_t)numTasks) {
         try { blocks[i] = operators[i]->nextBlock(); }
         catch (const std::exception& e) {   // wrapOperatorException: attach the segment name
+          errorKinds[i] = dynamic_cast<const UnsupportedOperationException*>(&e) ? 1 : (dynamic_cast<const QueryException*>(&e) ? 2 : 3);
           errors[i] = std::string("Caught exception while doing operator: ") + operators[i]->toExplainString() + " on segment " +
                       operators[i]->getIndexSegment()->getSegmentName() + ": " + e.what();
         }
@@ -708,7 +716,12 @@ ResultsBlock GpuPlanMaker::executeCombined(const std::vector<SegmentContext>& se
     });
   }
   for (auto& w : workers) w.join();
-  for (const auto& e : errors) if (!e.empty()) throw std::runtime_error(e);
+  for (size_t i = 0; i < errors.size(); ++i) {
+    if (errors[i].empty()) continue;
+    if (errorKinds[i] == 1) throw UnsupportedOperationException(errors[i]);      // the caller's fallback signal keeps its class
+    if (errorKinds[i] == 2) throw QueryException(errors[i]);
+    throw std::runtime_error(errors[i]);
+  }
   // deterministic merge order (segment order); for integer sums below 2^53 any order gives the same doubles
   ResultsBlock merged = blocks[0];
   for (size_t i = 1; i < blocks.size(); ++i) mergeResultsBlocks(&merged, blocks[i]);

@@ -1406,6 +1406,119 @@ void pg_result_free(pg_result* r) {
   memset(r, 0, sizeof(*r));
 }
 
+// ---- plan-time eligibility (pg_query_check) ----
+// Every reason pg_execute can answer PG_ERR_UNSUPPORTED for, decided from the query and the segment's metadata alone: no context, no
+// allocation, no launch.  pg_execute runs it first, so both entry points reject the same queries; the same conditions further down the
+// execution path are safety nets behind it.  Where the exact resource use depends on run-time state (which summed columns read a
+// value plane decides how many column streams a query stages) the check takes the upper bound: it may decline a query whose streams
+// would just have fitted, never the other way round.  InstancePlanMakerImplV2.makeSegmentPlanNode (:270-289) is where the caller asks.
+static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int extra_and_leaves) {
+  const int num_cols_total = (int)seg->cols.size();
+  if (q->num_filter_nodes < 0 || q->num_filter_nodes > kMaxNodes) return fail(PG_ERR_UNSUPPORTED, "filter tree has %d nodes (max %d)", q->num_filter_nodes, kMaxNodes);
+  if (q->num_filter_nodes > 0 && (!q->filter || !q->predicates)) return fail(PG_ERR_INVALID_ARGUMENT, "filter nodes without predicates");
+  std::vector<int> filter_cols;           // columns whose stream a scan leaf stages
+  {
+    int depth = 0;
+    for (int n = 0; n < q->num_filter_nodes; ++n) {
+      const pg_filter_node& fn = q->filter[n];
+      if (fn.op == PG_FILTER_LEAF) {
+        if (fn.predicate < 0 || fn.predicate >= q->num_predicates) return fail(PG_ERR_INVALID_ARGUMENT, "filter node %d: bad predicate index", n);
+        depth++;
+      } else if (fn.op == PG_FILTER_NOT) {
+        if (depth < 1) return fail(PG_ERR_INVALID_ARGUMENT, "malformed filter tree (node %d)", n);
+      } else if (fn.op == PG_FILTER_AND || fn.op == PG_FILTER_OR) {
+        if (fn.num_children < 1 || depth < fn.num_children) return fail(PG_ERR_INVALID_ARGUMENT, "malformed filter tree (node %d)", n);
+        depth -= fn.num_children - 1;
+      } else return fail(PG_ERR_INVALID_ARGUMENT, "unknown filter op %d", fn.op);
+    }
+    if (q->num_filter_nodes > 0 && depth != 1) return fail(PG_ERR_INVALID_ARGUMENT, "malformed filter tree (%d roots)", depth);
+    // the same re-ordering lower_filter applies: the root AND as a chain, its inverted-index children as one leaf
+    std::vector<SeqNode> seq;
+    std::vector<int> and_members;
+    int lazy_node = -1, num_bitmap_prefix = 0;
+    build_sequence(q, &seq, &lazy_node, &num_bitmap_prefix, &and_members);
+    if ((int)seq.size() + 2 * extra_and_leaves > kMaxNodes) return fail(PG_ERR_UNSUPPORTED, "filter tree has %d nodes (max %d)", (int)seq.size() + 2 * extra_and_leaves, kMaxNodes);
+    int leaves = extra_and_leaves, max_depth = extra_and_leaves > 0 ? 2 : 0;
+    depth = 0;
+    for (const SeqNode& sn : seq) {
+      if (sn.op == PG_FILTER_LEAF) { leaves++; depth++; }
+      else if (sn.op != PG_FILTER_NOT) depth -= sn.num_children - 1;
+      max_depth = std::max(max_depth, depth);
+      if (sn.op == PG_FILTER_LEAF && sn.src >= 0) {
+        const pg_predicate& pr = q->predicates[q->filter[sn.src].predicate];
+        const bool stages = pr.kind == PG_PRED_RAW_RANGE || ((pr.kind == PG_PRED_DICT_RANGE || pr.kind == PG_PRED_DICT_SET) && pr.eval != PG_EVAL_INVERTED);
+        if (stages) {
+          if (pr.column < 0 || pr.column >= num_cols_total) return fail(PG_ERR_INVALID_ARGUMENT, "predicate column %d out of range", pr.column);
+          if (std::find(filter_cols.begin(), filter_cols.end(), pr.column) == filter_cols.end()) filter_cols.push_back(pr.column);
+        }
+      }
+    }
+    if (leaves > kMaxLeaves) return fail(PG_ERR_UNSUPPORTED, "more than %d filter leaves", kMaxLeaves);
+    if (max_depth + (extra_and_leaves > 0 ? 1 : 0) > kStackDepth) return fail(PG_ERR_UNSUPPORTED, "filter tree deeper than %d", kStackDepth);
+  }
+  const int na = q->num_aggregations, ng = q->num_group_by;
+  if (na < 0 || ng < 0 || (na > 0 && !q->aggregations) || (ng > 0 && !q->group_by_columns)) return fail(PG_ERR_INVALID_ARGUMENT, "bad aggregation / group-by lists");
+  if (ng > kMaxGroupCols) return fail(PG_ERR_UNSUPPORTED, "more than %d group-by columns", kMaxGroupCols);
+  std::vector<int> key_cols, agg_cols;
+  long long product = 1;
+  for (int g = 0; g < ng; ++g) {
+    const int c = q->group_by_columns[g];
+    if (c < 0 || c >= num_cols_total) return fail(PG_ERR_INVALID_ARGUMENT, "group-by column %d out of range", c);
+    const ColumnDev& col = seg->cols[(size_t)c];
+    if (col.encoding != PG_FWD_FIXED_BIT_DICT) return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s", col.name.c_str());
+    product *= std::max(col.cardinality, 1);
+    if (product > kMaxGroupSlots) return fail(PG_ERR_UNSUPPORTED, "group-by cardinality product exceeds %d direct-indexed slots (Long / ArrayMap holders keep the CPU plan)", kMaxGroupSlots);
+    if (std::find(key_cols.begin(), key_cols.end(), c) == key_cols.end()) key_cols.push_back(c);
+  }
+  std::vector<std::pair<int, int>> group_aggs;     // distinct (column, SUM | MIN | MAX)
+  for (int a = 0; a < na; ++a) {
+    const pg_aggregation& ag = q->aggregations[a];
+    if (ag.function < PG_AGG_COUNT || ag.function > PG_AGG_AVG) return fail(PG_ERR_UNSUPPORTED, "aggregation function %d", ag.function);
+    if (ag.function == PG_AGG_COUNT) continue;
+    if (ag.column < 0 || ag.column >= num_cols_total) return fail(PG_ERR_INVALID_ARGUMENT, "aggregation column %d out of range", ag.column);
+    if (std::find(agg_cols.begin(), agg_cols.end(), ag.column) == agg_cols.end()) agg_cols.push_back(ag.column);
+    if (ng > 0) {
+      const ColumnDev& col = seg->cols[(size_t)ag.column];
+      const int kind = (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) ? 0 : (ag.function == PG_AGG_MIN ? 1 : 2);
+      if (std::find(group_aggs.begin(), group_aggs.end(), std::make_pair(ag.column, kind)) == group_aggs.end()) group_aggs.emplace_back(ag.column, kind);
+      if (col.encoding == PG_FWD_RAW_FIXED_BYTE && col.vkind != kValI32) return fail(PG_ERR_UNSUPPORTED, "group-by aggregation of a raw LONG / FLOAT / DOUBLE column (plan-time fallback)");
+      if (kind == 0 && col.vkind == kValI64 && !col.h_dict_i64.empty()) {
+        const double max_abs = std::max(std::fabs((double)col.h_dict_i64.front()), std::fabs((double)col.h_dict_i64.back()));
+        if ((double)seg->num_docs * max_abs >= 9.2e18) return fail(PG_ERR_UNSUPPORTED, "group-by SUM of LONG column %s could overflow int64", col.name.c_str());
+      }
+    }
+  }
+  if (ng == 0 && (int)agg_cols.size() > kMaxAggCols) return fail(PG_ERR_UNSUPPORTED, "more than %d aggregated columns", kMaxAggCols);
+  if ((int)group_aggs.size() > kMaxGroupAggs) return fail(PG_ERR_UNSUPPORTED, "more than %d distinct group-by aggregations", kMaxGroupAggs);
+  // Column streams, as slot_for hands them out: (column, read through its value plane?).  A column summed through its plane is read
+  // through the plane by everything that can be (its other aggregations, a dictId-range leaf on it); set leaves and group keys read
+  // the dictIds.  Which summed columns have a plane is want_value_plane's decision; the histogram path, which reads the dictIds
+  // instead, is not anticipated here (run-time tiers): at worst one stream too many is counted.
+  std::vector<char> plane((size_t)std::max(num_cols_total, 1), 0);
+  for (int a = 0; a < na; ++a) {
+    const pg_aggregation& ag = q->aggregations[a];
+    if ((ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) && want_value_plane(seg->cols[(size_t)ag.column])) plane[(size_t)ag.column] = 1;
+  }
+  std::vector<int> streams;               // column * 2 + plane
+  auto use = [&](int column, bool through_plane) {
+    const int key = column * 2 + (through_plane ? 1 : 0);
+    if (std::find(streams.begin(), streams.end(), key) == streams.end()) streams.push_back(key);
+  };
+  for (int n = 0; n < q->num_filter_nodes; ++n) {
+    if (q->filter[n].op != PG_FILTER_LEAF) continue;
+    const pg_predicate& pr = q->predicates[q->filter[n].predicate];
+    if (pr.column < 0 || pr.column >= num_cols_total) continue;
+    if (pr.kind == PG_PRED_RAW_RANGE) use(pr.column, false);
+    else if (pr.kind == PG_PRED_DICT_RANGE && pr.eval != PG_EVAL_INVERTED) use(pr.column, plane[(size_t)pr.column] != 0);
+    else if (pr.kind == PG_PRED_DICT_SET && pr.eval != PG_EVAL_INVERTED) use(pr.column, false);
+  }
+  for (int c : key_cols) use(c, false);
+  for (int c : agg_cols) use(c, plane[(size_t)c] != 0);
+  const int bound = (int)streams.size();
+  if (bound > kMaxCols) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
+  return PG_OK;
+}
+
 // ExecutionStatistics.numEntriesScannedInFilter from the plan pg_filter_stats.h chose; `counted`: the kernel that ran carried the
 // kNodeCountEntries counter (its value has been copied to ctx->h_filter_entries and the stream is idle).
 static void finish_filter_stats(const Lowered& lw, const pg_segment* seg, const ExecCtx* ctx, bool counted, pg_result* out) {
@@ -1426,6 +1539,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   if (!seg || !q) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
   // d_out_bitmap_request: like host_bitmap, but the filter's doc-order bitmap is copied device to device into the caller's
   // buffer ((num_docs + 63) / 64 words, any stream-ordered device memory) and never visits the host.
+  {
+    pg_query shape = *q;                      // pg_filter_bitmap evaluates the filter only
+    if (host_bitmap != nullptr || d_out_bitmap_request != nullptr) { shape.num_aggregations = 0; shape.num_group_by = 0; }
+    const pg_status eligible = check_query_plan(seg, &shape, 0);
+    if (eligible != PG_OK) return eligible;
+  }
   HIP_TRY(hipSetDevice(seg->device));
   ExecCtx* ctx = nullptr;
   pg_status st = acquire_ctx(seg, &ctx);
@@ -2353,6 +2472,32 @@ pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_
   if (st == PG_OK && !null_handling && !out_result->filter_entries_exact && (int64_t)segment->num_docs <= g_engine.exact_stats_docs) st = replay_filter_stats(segment, query, out_result);
   if (st != PG_OK) pg_result_free(out_result);
   return st;
+}
+
+pg_status pg_query_check(const pg_segment* segment, const pg_query* query) {
+  if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");
+  if (!segment || !query) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
+  if (!(query->flags & PG_QUERY_NULL_HANDLING)) return check_query_plan(segment, query, 0);
+  // enableNullHandling: the query that runs is the rewritten one (execute_null_handling): the filter's getTrues() over three-valued
+  // leaves, one more IS NOT NULL leaf for every aggregated column that has null docs
+  NullRewriter rw{segment};
+  FilterExpr root;
+  bool has_filter = false;
+  pg_status st = parse_filter(query, &root, &has_filter);
+  if (st != PG_OK) return st;
+  FlatQuery base;
+  if (has_filter) base.emit(rw.trues(root));
+  base.finish(*query);
+  const int na = query->num_aggregations, ng = query->num_group_by;
+  if (na < 0 || ng < 0 || (na > 0 && !query->aggregations) || (ng > 0 && !query->group_by_columns)) return fail(PG_ERR_INVALID_ARGUMENT, "bad aggregation / group-by lists");
+  bool lanes = false;
+  for (int a = 0; a < na; ++a) lanes |= rw.has_nulls(query->aggregations[a].column);
+  if (ng > 0) {
+    bool nullable = lanes;
+    for (int g = 0; g < ng; ++g) nullable |= rw.has_nulls(query->group_by_columns[g]);
+    if (nullable) return fail(PG_ERR_UNSUPPORTED, "GROUP BY over columns with null docs under null handling keeps the CPU plan");
+  }
+  return check_query_plan(segment, &base.q, lanes ? 1 : 0);
 }
 
 pg_status pg_filter_bitmap(pg_segment* segment, const pg_query* query, uint64_t* out_words, int64_t num_words, int64_t* out_cardinality) {

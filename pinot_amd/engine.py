@@ -1,5 +1,6 @@
 """Thin Python handle over the C ABI (`libpinot_gpu.so`): what the JNI shim does, for tests and bench.py."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -53,11 +54,22 @@ class GpuSegment:
 
     def execute(self, spec):
         res = _abi.pg_result()
-        _abi.check(self.lib, self.lib.pg_execute(self.handle, C.byref(spec.c), C.byref(res)))
+        if os.environ.get("PINOT_GPU_ASSERT_QUERY_CHECK"):
+            # the test suite's standing check of pg_query_check: a query it admits is never declined by pg_execute, and vice versa
+            admitted = self.lib.pg_query_check(self.handle, C.byref(spec.c))
+            status = self.lib.pg_execute(self.handle, C.byref(spec.c), C.byref(res))
+            assert (admitted == _abi.PG_ERR_UNSUPPORTED) == (status == _abi.PG_ERR_UNSUPPORTED), "pg_query_check %d, pg_execute %d" % (admitted, status)
+            _abi.check(self.lib, status)
+        else:
+            _abi.check(self.lib, self.lib.pg_execute(self.handle, C.byref(spec.c), C.byref(res)))
         try:
             return Result(res, spec)
         finally:
             self.lib.pg_result_free(C.byref(res))
+
+    def check(self, spec):
+        """pg_query_check: the status pg_execute would return for eligibility reasons (0 = PG_OK, 2 = PG_ERR_UNSUPPORTED), nothing launched."""
+        return int(self.lib.pg_query_check(self.handle, C.byref(spec.c)))
 
     def execute_raw(self, spec, res):
         """Hot-loop variant for bench.py: no Python-side result conversion; caller frees `res`."""

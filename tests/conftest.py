@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # every query the GPU tests run is first put to pg_query_check: the two must agree on what is declined (pinot_amd/engine.py)
+    os.environ.setdefault("PINOT_GPU_ASSERT_QUERY_CHECK", "1")
 
 
 def pytest_sessionstart(session):
