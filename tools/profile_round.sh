@@ -1,0 +1,39 @@
+#!/bin/bash
+# tools/profile_round.sh <round>: the rocprofv3 evidence of a round, left under gpurun_out/<round>/ (copy what is to be judged into profiles/<round>/)
+#   1. kernel trace + stats of the driver's own command line (python bench.py, all variants)
+#   2. HBM traffic of the headline kernel (FETCH_SIZE, TCC) -- separate --pmc passes, as MI355X_MICROARCH.md prescribes
+#   3. SQ / LDS counters of the C3 group-by kernel and HBM traffic of the C5 kernels
+R=${1:-r2}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$R; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+echo "== 1. kernel stats, python bench.py (all variants)"
+timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $GRAFT_REPO_ROOT/bench.py > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+find $OUT/stats -name "*kernel_stats*.csv" -exec cat {} \; | cut -c1-200 | head -24
+find $OUT/stats -name "*kernel_trace*.csv" -size +8M -delete
+pmc() {   # pmc <tag> <kernel regexp> <bench args> <counters...>
+  local tag=$1 kern=$2 args=$3; shift 3
+  rm -rf $OUT/pmc_$tag
+  timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$tag -o p -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/pmc_$tag.log 2>&1
+  for f in $(find $OUT/pmc_$tag -name "*counter_collection*.csv"); do python - "$f" "$kern" "$tag" <<'PY'
+import csv, sys, collections, re, json
+per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+for r in csv.DictReader(open(sys.argv[1])):
+    if re.search(sys.argv[2], r["Kernel_Name"]):
+        per[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+out = {}
+for k, cs in per.items():
+    out[k] = {c: {"mean_per_dispatch": sum(d.values()) / len(d), "dispatches": len(d)} for c, d in cs.items()}
+    print("  %-40s %s" % (k[-40:], "  ".join("%s=%.4g" % (c, v["mean_per_dispatch"]) for c, v in out[k].items())))
+json.dump(out, open(sys.argv[1].rsplit("/", 1)[0] + "/../../pmc_%s_summary.json" % sys.argv[3], "w"), indent=1)
+PY
+  done
+  find $OUT/pmc_$tag -name "*.csv" -size +8M -delete
+}
+echo "== 2. headline HBM traffic"
+pmc head_fetch "scan_private_kernel" "--steps 3 --warmup 1 --segments 1 --no-cpu-baseline --no-variants" FETCH_SIZE
+pmc head_tcc "scan_private_kernel" "--steps 3 --warmup 1 --segments 1 --no-cpu-baseline --no-variants" TCC_HIT_sum TCC_MISS_sum
+echo "== 3. C3 group-by kernel: SQ / LDS counters; C5 kernels: HBM traffic"
+pmc c3_sq "group_private_kernel" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --variants ^C3$" SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+pmc c3_sq2 "group_private_kernel" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --variants ^C3$" SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SALU
+pmc c3_fetch "group_private_kernel" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --variants ^C3$" FETCH_SIZE
+pmc c5_fetch "index_and|scan_private_kernel" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --rows 100000 --rows-c5 1000000000 --variants C5" FETCH_SIZE WRITE_SIZE
