@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 2   /* 2: pg_result.filter_entries_exact, pg_query_check */
+#define PG_ABI_VERSION 2   /* 2: pg_result.filter_entries_exact, pg_query_check, pg_config.plane_budget_bytes */
 
 typedef enum pg_status {
   PG_OK = 0,
@@ -80,6 +80,8 @@ typedef struct pg_config {
   int32_t device_id;           /* default HIP device for segments whose desc says device_id = -1 */
   int32_t blocks_per_cu;       /* 0 = engine default; launch geometry knob for tuning */
   int32_t flags;               /* PG_CFG_* */
+  uint64_t plane_budget_bytes; /* HBM the value planes of ALL open segments may hold together (see pg_segment_plane_bytes); 0 = a quarter
+                                * of the device's memory.  Over budget, the least recently used planes that no query is reading go first. */
 } pg_config;
 
 #define PG_CFG_TIME_KERNELS 1  /* bracket kernels with HIP events on the launch stream; report pg_result.device_ms */
@@ -281,7 +283,13 @@ pg_status pg_measure_stream_read(int32_t device_id, uint64_t bytes, int32_t laun
 pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment);
 pg_status pg_segment_close(pg_segment* segment);
 pg_status pg_segment_num_docs(const pg_segment* segment, int32_t* out_num_docs);
-pg_status pg_segment_device_bytes(const pg_segment* segment, uint64_t* out_bytes);
+pg_status pg_segment_device_bytes(const pg_segment* segment, uint64_t* out_bytes);   /* index buffers + value planes */
+/* The part of pg_segment_device_bytes held by materialised value planes: plane[doc] = dictionary[dictId[doc]] re-packed, built on the
+ * device -- beside the queries, on a stream of its own -- the first time a column with an irregular dictionary is summed, so that
+ * SUM streams values instead of gathering them.  A query never waits for a build (until the plane is there it runs the dictionary
+ * path, same result) and never fails for lack of one.  pg_set_plane_budget changes the process-wide budget at run time. */
+pg_status pg_segment_plane_bytes(const pg_segment* segment, uint64_t* out_bytes);
+pg_status pg_set_plane_budget(uint64_t budget_bytes, uint64_t* out_previous);
 
 /* Plan-time eligibility: PG_OK when pg_execute would run this query on this segment, PG_ERR_UNSUPPORTED (pg_last_error says why) when
  * it would decline it -- more filter leaves / nodes / column streams / aggregations than the kernels take, key spaces beyond the

@@ -29,7 +29,8 @@ PG_CFG_PROFILE_WAVES = 2
 
 
 class pg_config(C.Structure):
-    _fields_ = [("abi_version", C.c_int32), ("device_id", C.c_int32), ("blocks_per_cu", C.c_int32), ("flags", C.c_int32)]
+    _fields_ = [("abi_version", C.c_int32), ("device_id", C.c_int32), ("blocks_per_cu", C.c_int32), ("flags", C.c_int32),
+                ("plane_budget_bytes", C.c_uint64)]
 
 
 class pg_column_desc(C.Structure):
@@ -99,6 +100,8 @@ ABI_SYMBOLS = [
     ("pg_segment_num_docs", C.c_int, [C.c_void_p, _P(C.c_int32)]),
     ("pg_measure_stream_read", C.c_int, [C.c_int32, C.c_uint64, C.c_int32, _P(C.c_double)]),
     ("pg_segment_device_bytes", C.c_int, [C.c_void_p, _P(C.c_uint64)]),
+    ("pg_segment_plane_bytes", C.c_int, [C.c_void_p, _P(C.c_uint64)]),
+    ("pg_set_plane_budget", C.c_int, [C.c_uint64, _P(C.c_uint64)]),
     ("pg_query_check", C.c_int, [C.c_void_p, _P(pg_query)]),
     ("pg_execute", C.c_int, [C.c_void_p, _P(pg_query), _P(pg_result)]),
     ("pg_result_free", None, [_P(pg_result)]),

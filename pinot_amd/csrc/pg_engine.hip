@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -49,6 +50,8 @@ struct Engine {
   bool initialized = false;
   int device = 0;
   int blocks_per_cu = 0;
+  bool plane_async = true;   // PINOT_GPU_PLANE_ASYNC=0: a query that wants a plane waits for its build
+  bool staged_h2d = true;    // PINOT_GPU_STAGED_H2D=0: pg_segment_open copies with plain (pageable) hipMemcpy
   long long exact_stats_docs = 64ll << 20;   // PINOT_GPU_EXACT_FILTER_STATS_DOCS: largest segment whose leap-frogging filters are replayed for numEntriesScannedInFilter
   int flags = 0;
   bool use_dma = true;
@@ -113,6 +116,13 @@ struct ColumnDev {
   int shape_bits = 0;
   bool shape_is_fwd = false;
   bool plane_ready = false;
+  // residency of a materialised plane (g_planes.mu guards all of these): state, queries reading it right now, LRU stamp, bytes
+  int plane_state = 0;                  // 0 none, 1 being built on the segment's plane stream, 2 ready
+  int plane_users = 0;
+  uint64_t plane_last_use = 0;
+  size_t plane_bytes = 0;
+  hipEvent_t plane_event = nullptr;     // recorded behind the build
+  int32_t* d_plane_fields = nullptr;    // scaled dictionary the build kernel reads (freed when the build is seen complete)
   int hist_tier = 0;                    // histogram SUM of this column: 0 plain counters + checksum, 1 guarded counters (a counter once wrapped), 2 not
                                         // used any more (even a guarded counter ran away: the value plane / gather paths serve the column)
 };
@@ -157,7 +167,8 @@ struct pg_segment {
   std::string name;
   std::vector<ColumnDev> cols;
   std::mutex ctx_mu;
-  std::mutex plane_mu;
+  hipStream_t plane_stream = nullptr;   // value planes are built here, beside the queries
+  uint64_t plane_bytes = 0;             // HBM held by materialised value planes (part of device_bytes)
   std::vector<ExecCtx*> free_ctx;
   std::vector<ExecCtx*> all_ctx;
 };
@@ -334,8 +345,77 @@ pg_status parse_roaring(const uint8_t* base, uint64_t start, uint64_t len, std::
   return PG_OK;
 }
 
+// ---- host -> HBM at segment open ----
+// The caller's index buffers are pageable (mmap-ed segment files): a plain hipMemcpy stages them through one internal bounce buffer on
+// one thread (~16-24 GB/s measured on the bench box).  Large buffers instead go through a small pool of pinned bounce buffers, one
+// host thread and one stream per slot: each thread copies a 16 MiB chunk into its pinned buffer while its previous chunk is still on
+// the wire, so the CPU-side copies of several threads and the DMA overlap and the link is the limit.  One upload at a time.
+constexpr size_t kStageChunk = 16u << 20;
+constexpr int kStageSlots = 8;
+struct StageSlot { hipStream_t stream = nullptr; uint8_t* buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; };
+struct StagePool { std::mutex mu; int device = -1; StageSlot slots[kStageSlots]; };
+StagePool g_stage;
+
+void destroy_stage_pool_locked() {
+  for (auto& sl : g_stage.slots) {
+    for (int b = 0; b < 2; ++b) { if (sl.buf[b]) (void)hipHostFree(sl.buf[b]); if (sl.ev[b]) (void)hipEventDestroy(sl.ev[b]); sl.buf[b] = nullptr; sl.ev[b] = nullptr; }
+    if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    sl.stream = nullptr;
+  }
+  g_stage.device = -1;
+}
+
+hipError_t h2d_copy(void* dst, const void* src, size_t bytes, int device) {
+  if (!g_engine.staged_h2d || bytes < 4 * kStageChunk) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+  std::lock_guard<std::mutex> lk(g_stage.mu);
+  if (g_stage.device != device) {
+    destroy_stage_pool_locked();
+    for (auto& sl : g_stage.slots) {
+      hipError_t e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
+      for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        e = hipHostMalloc((void**)&sl.buf[b], kStageChunk, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev[b], hipEventDisableTiming);
+      }
+      if (e != hipSuccess) { destroy_stage_pool_locked(); (void)hipGetLastError(); return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
+    }
+    g_stage.device = device;
+  }
+  const size_t chunks = (bytes + kStageChunk - 1) / kStageChunk;
+  std::atomic<size_t> next{0};
+  std::atomic<int> error{(int)hipSuccess};
+  std::vector<std::thread> workers;
+  const int threads = (int)std::min<size_t>(kStageSlots, chunks);
+  for (int t = 0; t < threads; ++t) {
+    workers.emplace_back([&, t] {
+      StageSlot& sl = g_stage.slots[t];
+      hipError_t e = hipSetDevice(device);
+      int b = 0;
+      while (e == hipSuccess) {
+        const size_t c = next.fetch_add(1);
+        if (c >= chunks) break;
+        const size_t off = c * kStageChunk, n = std::min(kStageChunk, bytes - off);
+        e = hipEventSynchronize(sl.ev[b]);                     // the chunk this buffer carried last has left it (no-op before its first use)
+        if (e != hipSuccess) break;
+        memcpy(sl.buf[b], (const uint8_t*)src + off, n);
+        e = hipMemcpyAsync((uint8_t*)dst + off, sl.buf[b], n, hipMemcpyHostToDevice, sl.stream);
+        if (e == hipSuccess) e = hipEventRecord(sl.ev[b], sl.stream);
+        b ^= 1;
+      }
+      const hipError_t done = hipStreamSynchronize(sl.stream);
+      if (e == hipSuccess) e = done;
+      if (e != hipSuccess) error.store((int)e);
+    });
+  }
+  for (auto& w : workers) w.join();
+  return (hipError_t)error.load();
+}
+
+void drop_planes_of(pg_segment* seg);
+
 void free_segment(pg_segment* seg) {
   if (!seg) return;
+  drop_planes_of(seg);
+  if (seg->plane_stream) (void)hipStreamDestroy(seg->plane_stream);
   for (auto* c : seg->all_ctx) destroy_ctx(c);
   for (auto& col : seg->cols) {
     if (col.d_fwd_alloc) (void)hipFree(col.d_fwd_alloc);
@@ -344,7 +424,7 @@ void free_segment(pg_segment* seg) {
     if (col.d_inv) (void)hipFree(col.d_inv);
     if (col.d_dir) (void)hipFree(col.d_dir);
     if (col.d_null_bitmap) (void)hipFree(col.d_null_bitmap);
-    if (col.d_plane && !col.plane_is_fwd) (void)hipFree(col.d_plane);
+    if (col.plane_event) (void)hipEventDestroy(col.plane_event);
   }
   delete seg;
 }
@@ -407,49 +487,139 @@ bool want_hist(const ColumnDev& col) {
   return g_engine.hist == 1 || !plane_shape(col).is_fwd;
 }
 
-pg_status ensure_plane(pg_segment* seg, int column, ExecCtx* ctx) {
+// ---- value-plane residency ----
+// A materialised plane costs about as much HBM as the column itself, so planes live under a budget (pg_config.plane_budget_bytes,
+// PINOT_GPU_PLANE_BUDGET_BYTES, pg_set_plane_budget) shared by all segments of the process: a plane is built the first time its
+// column is summed, on the segment's own plane stream -- the query that asked does not wait for it, it runs the path that reads the
+// dictionary instead (same result), and so does every query until the build is seen complete -- and when the budget is exceeded the
+// least recently used planes nobody is reading are released first.  PINOT_GPU_PLANE_ASYNC=0 builds in line (the query waits).
+struct PlaneRegistry {
+  std::mutex mu;
+  std::vector<std::pair<pg_segment*, int>> resident;      // planes in state 1 or 2
+  uint64_t total_bytes = 0;
+  uint64_t budget_bytes = ~0ull;
+  uint64_t tick = 0;
+};
+PlaneRegistry g_planes;
+
+// g_planes.mu held.  Frees the plane of (seg, column); it must be ready and unused.
+void drop_plane_locked(pg_segment* seg, int column) {
   ColumnDev& col = seg->cols[(size_t)column];
-  std::lock_guard<std::mutex> lk(seg->plane_mu);
-  if (col.plane_ready) return PG_OK;
-  const PlaneShape ps = plane_shape(col);
-  const int w = ps.bits;
-  col.plane_bits = w;
-  col.plane_base = ps.base;
-  col.plane_scale = ps.scale;
-  if (ps.is_fwd) {
-    col.plane_is_fwd = true;
-    col.d_plane = col.d_fwd;
+  if (col.d_plane && !col.plane_is_fwd) (void)hipFree(col.d_plane);
+  col.d_plane = nullptr;
+  col.plane_ready = false;
+  col.plane_state = 0;
+  g_planes.total_bytes -= col.plane_bytes;
+  seg->plane_bytes -= col.plane_bytes;
+  seg->device_bytes -= col.plane_bytes;
+  col.plane_bytes = 0;
+  auto& r = g_planes.resident;
+  r.erase(std::remove(r.begin(), r.end(), std::make_pair(seg, column)), r.end());
+}
+
+// Every plane of a segment that is going away (no query is running on it any more).
+void drop_planes_of(pg_segment* seg) {
+  std::lock_guard<std::mutex> lk(g_planes.mu);
+  for (int c = 0; c < (int)seg->cols.size(); ++c) {
+    ColumnDev& col = seg->cols[(size_t)c];
+    if (col.plane_state == 0) continue;
+    if (col.plane_event) (void)hipEventSynchronize(col.plane_event);
+    if (col.d_plane_fields) { (void)hipFree(col.d_plane_fields); col.d_plane_fields = nullptr; }
+    drop_plane_locked(seg, c);
+  }
+}
+
+// Asks for the value plane of a column.  *ready: the plane can be read by this query (release_plane when the query is over);
+// otherwise the query runs without it.  Never blocks on a build unless PINOT_GPU_PLANE_ASYNC=0.
+pg_status acquire_plane(pg_segment* seg, int column, bool* ready) {
+  *ready = false;
+  ColumnDev& col = seg->cols[(size_t)column];
+  std::lock_guard<std::mutex> lk(g_planes.mu);
+  if (col.plane_state == 0) {
+    const PlaneShape ps = plane_shape(col);
+    col.plane_bits = ps.bits;
+    col.plane_base = ps.base;
+    col.plane_scale = ps.scale;
+    if (ps.is_fwd) {                       // arithmetic-progression dictionary: the dictId stream is the plane, nothing to build or to budget
+      col.plane_is_fwd = true;
+      col.d_plane = col.d_fwd;
+      col.plane_ready = true;
+      col.plane_state = 2;
+      *ready = true;
+      return PG_OK;
+    }
+    const int w = ps.bits;
+    const size_t bytes = (size_t)std::max(seg->num_tiles, 1) * 256 * (size_t)w + 64;
+    // make room: least recently used first, only planes nobody reads
+    while (g_planes.total_bytes + bytes > g_planes.budget_bytes) {
+      int best = -1;
+      for (int i = 0; i < (int)g_planes.resident.size(); ++i) {
+        const ColumnDev& c = g_planes.resident[(size_t)i].first->cols[(size_t)g_planes.resident[(size_t)i].second];
+        if (c.plane_state != 2 || c.plane_users != 0 || c.plane_is_fwd) continue;
+        if (best < 0 || c.plane_last_use < g_planes.resident[(size_t)best].first->cols[(size_t)g_planes.resident[(size_t)best].second].plane_last_use) best = i;
+      }
+      if (best < 0) return PG_OK;          // nothing can go: this column is served without a plane
+      drop_plane_locked(g_planes.resident[(size_t)best].first, g_planes.resident[(size_t)best].second);
+    }
+    HIP_TRY(hipSetDevice(seg->device));
+    if (!seg->plane_stream) HIP_TRY(hipStreamCreateWithFlags(&seg->plane_stream, hipStreamNonBlocking));
+    if (!col.plane_event) HIP_TRY(hipEventCreateWithFlags(&col.plane_event, hipEventDisableTiming));
+    uint8_t* plane = nullptr;
+    if (hipMalloc((void**)&plane, bytes) != hipSuccess) { (void)hipGetLastError(); return PG_OK; }      // no room on the device either: no plane
+    HIP_TRY(hipMemsetAsync(plane, 0, bytes, seg->plane_stream));
+    // the kernel writes dict'[dictId] where dict' = the scaled fields (for scale 1: value - base through the base argument)
+    if (ps.scale != 1) {
+      std::vector<int32_t> fields(col.h_dict.size());
+      for (size_t d = 0; d < fields.size(); ++d) fields[d] = (int32_t)(((int64_t)col.h_dict[d] - ps.base) / ps.scale);
+      HIP_TRY(hipMalloc((void**)&col.d_plane_fields, fields.size() * 4));
+      HIP_TRY(hipMemcpy(col.d_plane_fields, fields.data(), fields.size() * 4, hipMemcpyHostToDevice));
+    }
+    DevColumn dc;
+    memset(&dc, 0, sizeof(dc));
+    dc.fwd = col.d_fwd; dc.dict = col.d_plane_fields ? col.d_plane_fields : col.d_dict; dc.bits = col.bits; dc.cardinality = col.cardinality; dc.dict_bytes = col.cardinality * 4;
+    const int in_slot = ((256 * col.bits + 16) + 15) & ~15;
+    const int waves = 4;
+    const size_t lds = (size_t)waves * (size_t)(in_slot + 64 * w * 4 + 16);
+    const int blocks = (int)std::max<long long>(1, std::min<long long>(((long long)seg->num_tiles + waves - 1) / waves, (long long)seg->num_cus * 2));
+    set_dynamic_lds(materialize_plane_kernel, lds);
+    materialize_plane_kernel<<<dim3((unsigned)blocks), dim3(waves * 64), lds, seg->plane_stream>>>(dc, plane, w, col.d_plane_fields ? 0 : (int32_t)col.plane_base, seg->num_docs,
+                                                                                                    seg->num_tiles, in_slot);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(col.plane_event, seg->plane_stream));
+    col.d_plane = plane;
+    col.plane_bytes = bytes;
+    col.plane_state = 1;
+    g_planes.total_bytes += bytes;
+    seg->plane_bytes += bytes;
+    seg->device_bytes += bytes;
+    g_planes.resident.emplace_back(seg, column);
+  }
+  if (col.plane_state == 1) {
+    const hipError_t built = g_engine.plane_async ? hipEventQuery(col.plane_event) : hipEventSynchronize(col.plane_event);
+    if (built == hipErrorNotReady) return PG_OK;
+    if (built != hipSuccess) return fail(PG_ERR_DEVICE, "value plane of %s: %s", col.name.c_str(), hipGetErrorString(built));
+    if (col.d_plane_fields) { (void)hipFree(col.d_plane_fields); col.d_plane_fields = nullptr; }
     col.plane_ready = true;
-    return PG_OK;
+    col.plane_state = 2;
   }
-  const size_t bytes = (size_t)std::max(seg->num_tiles, 1) * 256 * (size_t)w + 64;
-  HIP_TRY(hipMalloc((void**)&col.d_plane, bytes));
-  HIP_TRY(hipMemsetAsync(col.d_plane, 0, bytes, ctx->stream));
-  // the kernel writes dict'[dictId] where dict' = the scaled fields (for scale 1: value - base through the base argument)
-  int32_t* d_fields = nullptr;
-  if (ps.scale != 1) {
-    std::vector<int32_t> fields(col.h_dict.size());
-    for (size_t d = 0; d < fields.size(); ++d) fields[d] = (int32_t)(((int64_t)col.h_dict[d] - ps.base) / ps.scale);
-    HIP_TRY(hipMalloc((void**)&d_fields, fields.size() * 4));
-    HIP_TRY(hipMemcpy(d_fields, fields.data(), fields.size() * 4, hipMemcpyHostToDevice));
-  }
-  DevColumn dc;
-  memset(&dc, 0, sizeof(dc));
-  dc.fwd = col.d_fwd; dc.dict = d_fields ? d_fields : col.d_dict; dc.bits = col.bits; dc.cardinality = col.cardinality; dc.dict_bytes = col.cardinality * 4;
-  const int in_slot = ((256 * col.bits + 16) + 15) & ~15;
-  const int waves = 4;
-  const size_t lds = (size_t)waves * (size_t)(in_slot + 64 * w * 4 + 16);
-  const int blocks = (int)std::max<long long>(1, std::min<long long>(((long long)seg->num_tiles + waves - 1) / waves, (long long)seg->num_cus * 2));
-  set_dynamic_lds(materialize_plane_kernel, lds);
-  materialize_plane_kernel<<<dim3((unsigned)blocks), dim3(waves * 64), lds, ctx->stream>>>(dc, col.d_plane, w, d_fields ? 0 : (int32_t)col.plane_base, seg->num_docs,
-                                                                                            seg->num_tiles, in_slot);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (d_fields) (void)hipFree(d_fields);
-  seg->device_bytes += bytes;
-  col.plane_ready = true;
+  col.plane_users++;
+  col.plane_last_use = ++g_planes.tick;
+  *ready = true;
   return PG_OK;
 }
+
+void release_plane(pg_segment* seg, int column) {
+  std::lock_guard<std::mutex> lk(g_planes.mu);
+  ColumnDev& col = seg->cols[(size_t)column];
+  if (col.plane_users > 0) col.plane_users--;
+}
+
+// The planes a query holds, released on every way out of execute_impl.
+struct PlaneHold {
+  pg_segment* seg;
+  std::vector<int> columns;
+  ~PlaneHold() { for (int c : columns) release_plane(seg, c); }
+};
 
 // ---- query lowering ----
 struct Lowered {
@@ -1124,6 +1294,23 @@ pg_status pg_init(const pg_config* config) {
   g_engine.hist_bits = (hb && (atoi(hb) == 8 || atoi(hb) == 16)) ? atoi(hb) : 0;
   const char* ts = getenv("PINOT_GPU_TILE_STEPS");
   g_engine.tile_steps = (ts && (atoi(ts) == 16 || atoi(ts) == 32)) ? atoi(ts) : 0;
+  const char* pas = getenv("PINOT_GPU_PLANE_ASYNC");
+  if (pas) g_engine.plane_async = atoi(pas) != 0;
+  const char* sh2d = getenv("PINOT_GPU_STAGED_H2D");
+  if (sh2d) g_engine.staged_h2d = atoi(sh2d) != 0;
+  {
+    // value-plane budget: pg_config, then the environment; default a quarter of the device's memory
+    uint64_t budget = config ? config->plane_budget_bytes : 0;
+    const char* pb = getenv("PINOT_GPU_PLANE_BUDGET_BYTES");
+    if (pb) budget = strtoull(pb, nullptr, 10);
+    if (budget == 0) {
+      size_t free_bytes = 0, total_bytes = 0;
+      (void)hipSetDevice(dev);
+      if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) budget = total_bytes / 4; else budget = 64ull << 30;
+    }
+    std::lock_guard<std::mutex> lk(g_planes.mu);
+    g_planes.budget_bytes = budget;
+  }
   const char* esd = getenv("PINOT_GPU_EXACT_FILTER_STATS_DOCS");
   if (esd) g_engine.exact_stats_docs = atoll(esd);
   const char* bpc = getenv("PINOT_GPU_BLOCKS_PER_CU");
@@ -1135,6 +1322,7 @@ pg_status pg_init(const pg_config* config) {
 pg_status pg_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_engine.mu);
   g_engine.initialized = false;
+  { std::lock_guard<std::mutex> sl(g_stage.mu); destroy_stage_pool_locked(); }
   return PG_OK;
 }
 
@@ -1228,7 +1416,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       // zero the padding past the file bytes so tail tiles decode deterministic (masked) values
       size_t tail = col.fwd_alloc_bytes - (size_t)cd.fwd_size;
       e = hipMemset(col.d_fwd_alloc + cd.fwd_size, 0, tail);
-      if (e == hipSuccess && cd.fwd_size) e = hipMemcpy(col.d_fwd_alloc, fwd, (size_t)cd.fwd_size, hipMemcpyHostToDevice);
+      if (e == hipSuccess && cd.fwd_size) e = h2d_copy(col.d_fwd_alloc, fwd, (size_t)cd.fwd_size, seg->device);
       if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "column %s: H2D copy: %s", col.name.c_str(), hipGetErrorString(e)));
       // Dictionary values -> host order (IntDictionary / LongDictionary / FloatDictionary / DoubleDictionary: C big-endian
       // fixed-width values, ascending; FixedByteValueReaderWriter.getInt/getLong/getFloat/getDouble)
@@ -1307,7 +1495,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       hipError_t e = hipMalloc((void**)&col.d_fwd_alloc, col.fwd_alloc_bytes);
       if (e != hipSuccess) return bail(fail(PG_ERR_OUT_OF_MEMORY, "column %s: hipMalloc(%zu): %s", col.name.c_str(), col.fwd_alloc_bytes, hipGetErrorString(e)));
       e = hipMemset(col.d_fwd_alloc, 0, col.fwd_alloc_bytes);
-      if (e == hipSuccess) e = hipMemcpy(col.d_fwd_alloc + lead, fwd, (size_t)cd.fwd_size, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = h2d_copy(col.d_fwd_alloc + lead, fwd, (size_t)cd.fwd_size, seg->device);
       if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "column %s: H2D copy: %s", col.name.c_str(), hipGetErrorString(e)));
       col.d_fwd = col.d_fwd_alloc + lead + raw_start;
       col.bits = 32;
@@ -1332,7 +1520,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       }
       col.posting_first[(size_t)cd.cardinality] = (int64_t)col.h_dir.size();
       hipError_t e = hipMalloc((void**)&col.d_inv, (size_t)cd.inv_size + 64);
-      if (e == hipSuccess) e = hipMemcpy(col.d_inv, inv, (size_t)cd.inv_size, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = h2d_copy(col.d_inv, inv, (size_t)cd.inv_size, seg->device);
       if (e == hipSuccess && !col.h_dir.empty()) {
         e = hipMalloc((void**)&col.d_dir, col.h_dir.size() * sizeof(DevContainer));
         if (e == hipSuccess) e = hipMemcpy(col.d_dir, col.h_dir.data(), col.h_dir.size() * sizeof(DevContainer), hipMemcpyHostToDevice);
@@ -1606,6 +1794,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   // Columns that are summed are read through their value plane (built on first use); decided before the filter is
   // lowered so that a range predicate on the same column can be evaluated on the plane too.
   lw.plane_cols.assign((size_t)std::max(num_cols_total, 1), 0);
+  PlaneHold planes{seg, {}};
   // At most one summed column goes through the LDS histogram instead (scan_hist_kernel); it needs the lane-private kernel, so the
   // shapes that kernel does not take are ruled out here, before a plane is (not) built.
   int hist_col = -1;
@@ -1632,9 +1821,11 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const pg_aggregation& ag = q->aggregations[a];
     if ((ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) && ag.column >= 0 && ag.column < num_cols_total && ag.column != hist_col &&
         want_value_plane(seg->cols[(size_t)ag.column])) {
-      st = ensure_plane(seg, ag.column, ctx);
+      if (lw.plane_cols[(size_t)ag.column]) continue;
+      bool ready = false;
+      st = acquire_plane(seg, ag.column, &ready);
       if (st != PG_OK) return st;
-      lw.plane_cols[(size_t)ag.column] = 1;
+      if (ready) { planes.columns.push_back(ag.column); lw.plane_cols[(size_t)ag.column] = 1; }
     }
   }
   if (timed) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
@@ -2472,6 +2663,20 @@ pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_
   if (st == PG_OK && !null_handling && !out_result->filter_entries_exact && (int64_t)segment->num_docs <= g_engine.exact_stats_docs) st = replay_filter_stats(segment, query, out_result);
   if (st != PG_OK) pg_result_free(out_result);
   return st;
+}
+
+pg_status pg_segment_plane_bytes(const pg_segment* segment, uint64_t* out_bytes) {
+  if (!segment || !out_bytes) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> lk(g_planes.mu);
+  *out_bytes = segment->plane_bytes;
+  return PG_OK;
+}
+
+pg_status pg_set_plane_budget(uint64_t budget_bytes, uint64_t* out_previous) {
+  std::lock_guard<std::mutex> lk(g_planes.mu);
+  if (out_previous) *out_previous = g_planes.budget_bytes;
+  g_planes.budget_bytes = budget_bytes;
+  return PG_OK;
 }
 
 pg_status pg_query_check(const pg_segment* segment, const pg_query* query) {

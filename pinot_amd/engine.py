@@ -52,6 +52,11 @@ class GpuSegment:
         _abi.check(self.lib, self.lib.pg_segment_device_bytes(self.handle, C.byref(out)))
         return int(out.value)
 
+    def plane_bytes(self):
+        out = C.c_uint64()
+        _abi.check(self.lib, self.lib.pg_segment_plane_bytes(self.handle, C.byref(out)))
+        return int(out.value)
+
     def execute(self, spec):
         res = _abi.pg_result()
         if os.environ.get("PINOT_GPU_ASSERT_QUERY_CHECK"):
