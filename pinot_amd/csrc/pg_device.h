@@ -262,6 +262,8 @@ struct PartitionParams {
   GroupParams gp;
   int32_t shift;                    // log2(slots per partition)
   int32_t num_partitions;
+  int32_t packed_bits;              // > 0: ONE 32-bit record per doc = (slot within the partition << packed_bits) | value, value < 2^packed_bits
+  int32_t reserved;                 //      (COUNT(*): packed_bits = 1, value 0); part_val is not used
   uint32_t* upper;                  // [P] pass 0 result: docs per partition ignoring the filter
   uint32_t* cursor;                 // [P] records appended by pass A
   const uint32_t* offsets;          // [P + 1] first record of each partition buffer (prefix sum of `upper`)

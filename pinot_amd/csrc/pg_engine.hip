@@ -50,6 +50,8 @@ struct Engine {
   bool initialized = false;
   int device = 0;
   int blocks_per_cu = 0;
+  bool partition_stats_cache = true;   // PINOT_GPU_PARTITION_STATS_CACHE=0: run the partition histogram pass in every query
+  bool partition_packed = true;   // PINOT_GPU_PARTITION_PACKED=0: always separate key / value record columns
   bool plane_async = true;   // PINOT_GPU_PLANE_ASYNC=0: a query that wants a plane waits for its build
   bool staged_h2d = true;    // PINOT_GPU_STAGED_H2D=0: pg_segment_open copies with plain (pageable) hipMemcpy
   long long exact_stats_docs = 64ll << 20;   // PINOT_GPU_EXACT_FILTER_STATS_DOCS: largest segment whose leap-frogging filters are replayed for numEntriesScannedInFilter
@@ -150,6 +152,10 @@ struct ExecCtx {
   size_t partition_capacity = 0;
   uint32_t* d_tile_list = nullptr;              // index_and_kernel: surviving 2048-doc tiles (one entry per tile of the segment)
   unsigned long long* d_and_counters = nullptr; // [0] cardinality (u64), [1] low dword: number of listed tiles
+  uint8_t* d_arena = nullptr;                   // DeviceScratch: per-query device scratch (compaction of group-by results)
+  size_t arena_capacity = 0, arena_wanted = 0;
+  uint8_t* h_groups = nullptr;                  // pinned staging of many-group results
+  size_t h_groups_capacity = 0;
   unsigned long long* d_filter_entries = nullptr;   // kNodeCountEntries leaves: numEntriesScannedInFilter counted by the lane-private kernels
   unsigned long long* h_filter_entries = nullptr;   // pinned copy
   WindowInfo* d_window_info = nullptr;          // index_and_kernel: {tile mask, matching docs} of every 65 536-doc window
@@ -167,6 +173,11 @@ struct pg_segment {
   std::string name;
   std::vector<ColumnDev> cols;
   std::mutex ctx_mu;
+  // Partitioned group-by: docs per partition of a key-column set, ignoring the filter -- a property of the segment, not of the query.
+  // Pass 0 (group_partition_histogram_kernel) computes it the first time a (key columns, shift) combination is grouped by; later
+  // queries size their record buffers from the cached counts and skip the pass and its round trip to the host.
+  std::mutex partition_stats_mu;
+  std::vector<std::pair<std::vector<int>, std::vector<uint32_t>>> partition_stats;      // key = {shift, key columns...}
   hipStream_t plane_stream = nullptr;   // value planes are built here, beside the queries
   uint64_t plane_bytes = 0;             // HBM held by materialised value planes (part of device_bytes)
   std::vector<ExecCtx*> free_ctx;
@@ -189,6 +200,8 @@ void destroy_ctx(ExecCtx* c) {
   if (c->d_tile_list) (void)hipFree(c->d_tile_list);
   if (c->d_and_counters) (void)hipFree(c->d_and_counters);
   if (c->d_window_info) (void)hipFree(c->d_window_info);
+  if (c->d_arena) (void)hipFree(c->d_arena);
+  if (c->h_groups) (void)hipHostFree(c->h_groups);
   if (c->d_filter_entries) (void)hipFree(c->d_filter_entries);
   if (c->h_filter_entries) (void)hipHostFree(c->h_filter_entries);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -267,16 +280,47 @@ pg_status ensure_set(ExecCtx* c, size_t index, size_t bytes) {
 constexpr int kMaxGroupSlots = 1 << 24;
 
 // hipMalloc'ed scratch of one query, released when it goes out of scope (rare paths only: the hot paths reuse ExecCtx buffers)
+// Device scratch of one query, carved out of the context's arena; what does not fit is allocated for the query alone and the arena
+// grows before the context's next query, so a steady stream of queries allocates nothing (hipMalloc / hipFree cost ~100 us each and
+// synchronise the device: they were most of the host time of a many-group result).
 struct DeviceScratch {
-  std::vector<void*> blocks;
+  ExecCtx* ctx;
+  size_t used = 0, wanted = 0;
+  std::vector<void*> overflow;
+  explicit DeviceScratch(ExecCtx* c) : ctx(c) {
+    if (c->arena_wanted > c->arena_capacity) {
+      if (c->d_arena) (void)hipFree(c->d_arena);
+      c->d_arena = nullptr; c->arena_capacity = 0;
+      const size_t bytes = c->arena_wanted + (c->arena_wanted >> 2);
+      if (hipMalloc((void**)&c->d_arena, bytes) == hipSuccess) c->arena_capacity = bytes; else (void)hipGetLastError();
+    }
+  }
   void* alloc(size_t bytes) {
+    const size_t need = (std::max<size_t>(bytes, 8) + 255) & ~(size_t)255;
+    wanted += need;
+    if (used + need <= ctx->arena_capacity) { void* p = ctx->d_arena + used; used += need; return p; }
     void* p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr;
-    blocks.push_back(p);
+    if (hipMalloc(&p, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    overflow.push_back(p);
     return p;
   }
-  ~DeviceScratch() { for (void* p : blocks) (void)hipFree(p); }
+  ~DeviceScratch() {
+    for (void* p : overflow) (void)hipFree(p);
+    ctx->arena_wanted = std::max(ctx->arena_wanted, wanted);
+  }
 };
+
+// Pinned host staging of a many-group result (ids, counts, accumulators): the copies off the device run at link speed and the
+// conversion into pg_agg_value reads them in place.
+pg_status ensure_host_groups(ExecCtx* c, size_t bytes) {
+  if (c->h_groups_capacity >= bytes) return PG_OK;
+  if (c->h_groups) (void)hipHostFree(c->h_groups);
+  c->h_groups = nullptr; c->h_groups_capacity = 0;
+  const size_t want = bytes + (bytes >> 2);
+  HIP_TRY(hipHostMalloc((void**)&c->h_groups, want, hipHostMallocDefault));
+  c->h_groups_capacity = want;
+  return PG_OK;
+}
 
 pg_status ensure_table(ExecCtx* c, size_t words, size_t host_words) {
   if (c->table_capacity < words) {
@@ -1294,6 +1338,10 @@ pg_status pg_init(const pg_config* config) {
   g_engine.hist_bits = (hb && (atoi(hb) == 8 || atoi(hb) == 16)) ? atoi(hb) : 0;
   const char* ts = getenv("PINOT_GPU_TILE_STEPS");
   g_engine.tile_steps = (ts && (atoi(ts) == 16 || atoi(ts) == 32)) ? atoi(ts) : 0;
+  const char* psc = getenv("PINOT_GPU_PARTITION_STATS_CACHE");
+  if (psc) g_engine.partition_stats_cache = atoi(psc) != 0;
+  const char* ppk = getenv("PINOT_GPU_PARTITION_PACKED");
+  if (ppk) g_engine.partition_packed = atoi(ppk) != 0;
   const char* pas = getenv("PINOT_GPU_PLANE_ASYNC");
   if (pas) g_engine.plane_async = atoi(pas) != 0;
   const char* sh2d = getenv("PINOT_GPU_STAGED_H2D");
@@ -2213,7 +2261,17 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
       const size_t off_upper = 0, off_cursor = align(off_upper + (size_t)P * 4), off_offsets = align(off_cursor + (size_t)P * 4);
       const size_t off_work = align(off_offsets + (size_t)(P + 1) * 4), off_key = align(off_work + max_work * sizeof(PartitionWork));
-      const size_t off_val = align(off_key + N * 4), bytes = off_val + (size_t)gp.num_group_aggs * align(N * 4);
+      // one packed dword per doc when the only aggregation input is an unsigned field that fits beside the slot (pg_group_partition.h)
+      int packed_bits = 0;
+      if (g_engine.partition_packed) {
+        if (gp.num_group_aggs == 0) packed_bits = 1;
+        else if (gp.num_group_aggs == 1) {
+          const DevGroupAgg& ga = gp.group_aggs[0];
+          const bool unsigned_field = !ga.is_raw && ga.vkind == kValI32 && (ga.kind != kGroupSum || ga.is_plane);
+          if (unsigned_field && ga.bits + partition_shift <= 32) packed_bits = ga.bits;
+        }
+      }
+      const size_t off_val = align(off_key + N * 4), bytes = off_val + (packed_bits > 0 ? 0 : (size_t)gp.num_group_aggs * align(N * 4));
       if (ctx->partition_capacity < bytes) {
         if (ctx->d_partition) (void)hipFree(ctx->d_partition);
         ctx->d_partition = nullptr; ctx->partition_capacity = 0;
@@ -2225,6 +2283,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       pp.gp = gp;
       pp.shift = partition_shift;
       pp.num_partitions = P;
+      pp.packed_bits = packed_bits;
       pp.upper = reinterpret_cast<uint32_t*>(ctx->d_partition + off_upper);
       pp.cursor = reinterpret_cast<uint32_t*>(ctx->d_partition + off_cursor);
       pp.offsets = reinterpret_cast<const uint32_t*>(ctx->d_partition + off_offsets);
@@ -2234,11 +2293,24 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       HIP_TRY(hipMemsetAsync(ctx->d_partition, 0, off_offsets, ctx->stream));          // upper and cursor
       const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
       const int hist_blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + 3) / 4, (long long)seg->num_cus * 6));
-      launch_group_partition_histogram(hist_blocks, ctx->stream, pp);
-      HIP_TRY(hipGetLastError());
-      std::vector<uint32_t> upper((size_t)P);
-      HIP_TRY(hipMemcpyAsync(upper.data(), pp.upper, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      std::vector<int> stats_key{partition_shift};
+      for (int g = 0; g < ng; ++g) stats_key.push_back(q->group_by_columns[g]);
+      std::vector<uint32_t> upper;
+      if (g_engine.partition_stats_cache) {
+        std::lock_guard<std::mutex> lk(seg->partition_stats_mu);
+        for (const auto& e : seg->partition_stats) if (e.first == stats_key) upper = e.second;
+      }
+      if ((int)upper.size() != P) {
+        upper.assign((size_t)P, 0u);
+        launch_group_partition_histogram(hist_blocks, ctx->stream, pp);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(upper.data(), pp.upper, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (g_engine.partition_stats_cache) {
+          std::lock_guard<std::mutex> lk(seg->partition_stats_mu);
+          if (seg->partition_stats.size() < 64) seg->partition_stats.emplace_back(stats_key, upper);
+        }
+      }
       std::vector<uint32_t> offsets((size_t)P + 1, 0u);
       std::vector<PartitionWork> work;
       // chunk size: about two rounds of resident pass-B workgroups over the whole input, so that the flush of the touched slots
@@ -2253,7 +2325,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       }
       HIP_TRY(hipMemcpyAsync(ctx->d_partition + off_offsets, offsets.data(), offsets.size() * 4, hipMemcpyHostToDevice, ctx->stream));
       if (!work.empty()) HIP_TRY(hipMemcpyAsync(ctx->d_partition + off_work, work.data(), work.size() * sizeof(PartitionWork), hipMemcpyHostToDevice, ctx->stream));
-      const int scatter_bpc = std::max(1, waves_group_partition_scatter() / 4);
+      const int scatter_bpc = packed_bits > 0 ? blocks_per_cu_group_partition_scatter_packed(P) : std::max(1, waves_group_partition_scatter() / 4);
       const int scatter_blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + 3) / 4, (long long)seg->num_cus * scatter_bpc));
       launch_group_partition_scatter(scatter_blocks, ctx->stream, pp);
       HIP_TRY(hipGetLastError());
@@ -2269,6 +2341,9 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     std::vector<int32_t> present_ids;
     std::vector<unsigned long long> present_counts;
     std::vector<long long> present_acc;
+    const int32_t* ids_of = nullptr;                 // [num_present] where the conversion below reads: the vectors, or pinned staging
+    const unsigned long long* counts_of = nullptr;
+    const long long* acc_of = nullptr;
     int num_present = 0;
     long long docs = 0;
     if (!map_based) {
@@ -2293,7 +2368,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       const int limit = q->num_groups_limit > 0 ? q->num_groups_limit : 100000;
       const long long bound = std::min<long long>(product, limit);
       const int num_chunks = (gp.num_groups + kGroupChunk - 1) / kGroupChunk;
-      DeviceScratch scratch;
+      DeviceScratch scratch(ctx);
       uint32_t* d_chunk_counts = (uint32_t*)scratch.alloc((size_t)num_chunks * 4);
       uint32_t* d_chunk_offsets = (uint32_t*)scratch.alloc((size_t)(num_chunks + 1) * 4);
       unsigned long long* d_total_docs = (unsigned long long*)scratch.alloc(8);
@@ -2366,9 +2441,15 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         HIP_TRY(hipStreamSynchronize(ctx->stream));
       }
       num_present = (int)total;
-      present_ids.resize((size_t)num_present); present_counts.resize((size_t)num_present);
-      present_acc.resize((size_t)num_present * (size_t)gp.num_group_aggs);
       if (num_present > 0) {
+        const size_t ids_bytes = ((size_t)num_present * 4 + 255) & ~(size_t)255, counts_bytes = (size_t)num_present * 8;
+        const size_t acc_bytes = (size_t)num_present * (size_t)gp.num_group_aggs * 8;
+        st = ensure_host_groups(ctx, ids_bytes + counts_bytes + acc_bytes + 256);
+        if (st != PG_OK) return st;
+        int32_t* h_ids = reinterpret_cast<int32_t*>(ctx->h_groups);
+        unsigned long long* h_counts = reinterpret_cast<unsigned long long*>(ctx->h_groups + ids_bytes);
+        long long* h_acc = reinterpret_cast<long long*>(ctx->h_groups + ids_bytes + counts_bytes);
+        ids_of = h_ids; counts_of = h_counts; acc_of = h_acc;
         int32_t* d_ids = (int32_t*)scratch.alloc((size_t)num_present * 4);
         unsigned long long* d_counts = (unsigned long long*)scratch.alloc((size_t)num_present * 8);
         long long* d_acc = (long long*)scratch.alloc(std::max<size_t>((size_t)num_present * (size_t)gp.num_group_aggs * 8, 8));
@@ -2376,12 +2457,13 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         group_compact_kernel<<<dim3((unsigned)num_chunks), dim3(256), 0, ctx->stream>>>(gp.table_count, gp.table_acc, gp.num_group_aggs, gp.num_groups, d_first_doc, max_first_doc,
                                                                                          d_chunk_offsets, total, d_ids, d_counts, d_acc, nullptr);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(present_ids.data(), d_ids, (size_t)num_present * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(present_counts.data(), d_counts, (size_t)num_present * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (gp.num_group_aggs > 0) HIP_TRY(hipMemcpyAsync(present_acc.data(), d_acc, present_acc.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_ids, d_ids, (size_t)num_present * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_counts, d_counts, counts_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (gp.num_group_aggs > 0) HIP_TRY(hipMemcpyAsync(h_acc, d_acc, acc_bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
       }
     }
+    if (!ids_of) { ids_of = present_ids.data(); counts_of = present_counts.data(); acc_of = present_acc.data(); }
     out->num_aggregations = na;
     out->dominant_kernel = use_partition ? PG_KERNEL_GROUP_PARTITION : (use_private ? PG_KERNEL_GROUP_PRIVATE : PG_KERNEL_SCAN_GROUP);
     out->num_groups = num_present;
@@ -2392,8 +2474,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // returns up to numGroupsLimit rows) are converted by a few host threads, each touching its own pages of the result.
     auto convert_groups = [&](int k_begin, int k_end) {
     for (int k = k_begin; k < k_end; ++k) {
-      const unsigned long long group_docs = present_counts[(size_t)k];
-      out->group_ids[k] = present_ids[(size_t)k];
+      const unsigned long long group_docs = counts_of[(size_t)k];
+      out->group_ids[k] = ids_of[(size_t)k];
       for (int a = 0; a < na; ++a) {
         const pg_aggregation& ag = q->aggregations[a];
         pg_agg_value& v = out->group_aggregations[(size_t)k * (size_t)na + (size_t)a];
@@ -2401,7 +2483,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         v.min = std::numeric_limits<double>::infinity();
         v.max = -std::numeric_limits<double>::infinity();
         if (ag.function == PG_AGG_COUNT) continue;
-        const long long acc = present_acc[(size_t)dev_agg_of[(size_t)a] * (size_t)num_present + (size_t)k];
+        const long long acc = acc_of[(size_t)dev_agg_of[(size_t)a] * (size_t)num_present + (size_t)k];
         const ColumnDev& col = seg->cols[(size_t)ag.column];
         const bool plane = lw.plane_cols[(size_t)ag.column] != 0;
         if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) {

@@ -49,6 +49,7 @@ void launch_group_partition_histogram(int blocks, hipStream_t stream, const Part
 void launch_group_partition_scatter(int blocks, hipStream_t stream, const PartitionParams& pp);
 void launch_group_partition_aggregate(int work_items, size_t lds, hipStream_t stream, const PartitionParams& pp);
 int waves_group_partition_scatter();
+int blocks_per_cu_group_partition_scatter_packed(int num_partitions);
 
 }  // namespace pg
 #endif

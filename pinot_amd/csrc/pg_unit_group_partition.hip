@@ -9,6 +9,12 @@ void launch_group_partition_histogram(int blocks, hipStream_t stream, const Part
 }
 
 void launch_group_partition_scatter(int blocks, hipStream_t stream, const PartitionParams& pp) {
+  if (pp.packed_bits > 0) {
+    const size_t lds = partition_scatter_packed_lds_bytes(pp.num_partitions);
+    set_dynamic_lds(group_partition_scatter_packed_kernel, lds);
+    group_partition_scatter_packed_kernel<<<dim3((unsigned)blocks), dim3(256), lds, stream>>>(pp);
+    return;
+  }
   const size_t lds = partition_scatter_lds_bytes();
   set_dynamic_lds(group_partition_scatter_kernel, lds);
   group_partition_scatter_kernel<<<dim3((unsigned)blocks), dim3(256), lds, stream>>>(pp);
@@ -16,6 +22,11 @@ void launch_group_partition_scatter(int blocks, hipStream_t stream, const Partit
 
 void launch_group_partition_aggregate(int work_items, size_t lds, hipStream_t stream, const PartitionParams& pp) {
   const dim3 grid((unsigned)work_items), block(256);
+  if (pp.packed_bits > 0) {
+    if (pp.gp.num_group_aggs == 0) { set_dynamic_lds(group_partition_aggregate_kernel<0, true>, lds); group_partition_aggregate_kernel<0, true><<<grid, block, lds, stream>>>(pp); }
+    else { set_dynamic_lds(group_partition_aggregate_kernel<1, true>, lds); group_partition_aggregate_kernel<1, true><<<grid, block, lds, stream>>>(pp); }
+    return;
+  }
   switch (pp.gp.num_group_aggs) {
     case 0: set_dynamic_lds(group_partition_aggregate_kernel<0>, lds); group_partition_aggregate_kernel<0><<<grid, block, lds, stream>>>(pp); break;
     case 1: set_dynamic_lds(group_partition_aggregate_kernel<1>, lds); group_partition_aggregate_kernel<1><<<grid, block, lds, stream>>>(pp); break;
@@ -28,6 +39,13 @@ int waves_group_partition_scatter() {
   // registers and the 70 KB staging area (two workgroups per CU) both bound it
   static const int cap = std::min(max_waves_per_cu(group_partition_scatter_kernel), 8);
   return cap;
+}
+
+int blocks_per_cu_group_partition_scatter_packed(int num_partitions) {
+  // the staging area is 48 KB + 12 B per partition: three workgroups per CU up to ~330 partitions, two beyond
+  const int by_lds = (int)((156 * 1024) / partition_scatter_packed_lds_bytes(num_partitions));
+  static const int by_registers = std::max(1, max_waves_per_cu(group_partition_scatter_packed_kernel) / 4);
+  return std::max(1, std::min(by_lds, by_registers));
 }
 
 }  // namespace pg
