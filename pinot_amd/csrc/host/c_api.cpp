@@ -319,4 +319,89 @@ char* ph_execute_sql(void** segments, int32_t num_segments, const char* sql, int
   return *status == 0 ? strdup(out.c_str()) : nullptr;
 }
 
+// DataTable V4 bytes of a results block given as flat arrays (tests drive the writer without a device through this):
+// function_types: AggregationFunctionType ordinals (COUNT 0, SUM 1, MIN 2, MAX 3, AVG 4); key_types: DataType ordinals (INT 0, LONG 1,
+// FLOAT 2, DOUBLE 3, STRING 4); per row and key the value comes from key_longs (INT / LONG), key_doubles (FLOAT / DOUBLE) or
+// key_strings; per row and function: COUNT counts[], SUM sums[], MIN mins[], MAX maxs[], AVG (sums[], counts[]); is_null marks a null
+// intermediate result (null handling).  stats: numDocsScanned, numEntriesScannedInFilter, numEntriesScannedPostFilter, numTotalDocs.
+uint8_t* ph_datatable_v4_build(int32_t is_group_by, int32_t num_functions, const int32_t* function_types, const char* const* function_columns, int32_t num_keys,
+                               const char* const* key_names, const int32_t* key_types, int64_t num_rows, const int64_t* key_longs, const double* key_doubles,
+                               const char* const* key_strings, const int64_t* counts, const double* sums, const double* mins, const double* maxs,
+                               const uint8_t* is_null, const int64_t* stats, int32_t null_handling, int32_t limit_reached, int32_t segments_processed,
+                               int32_t segments_matched, int64_t* out_size, int32_t* status) {
+  std::vector<uint8_t> bytes;
+  *status = guarded([&] {
+    ResultsBlock block;
+    block.isGroupBy = is_group_by != 0;
+    std::vector<AggregationFunction> functions;
+    for (int f = 0; f < num_functions; ++f) functions.emplace_back((AggregationFunctionType)function_types[f], function_columns[f], null_handling != 0);
+    auto value = [&](int64_t row, int f) -> IntermediateResult {
+      const size_t at = (size_t)row * (size_t)num_functions + (size_t)f;
+      if (is_null && is_null[at]) return std::monostate{};
+      switch (functions[(size_t)f].getType()) {
+        case AggregationFunctionType::COUNT: return counts[at];
+        case AggregationFunctionType::SUM: return sums[at];
+        case AggregationFunctionType::MIN: return mins[at];
+        case AggregationFunctionType::MAX: return maxs[at];
+        default: return AvgPair{sums[at], counts[at]};
+      }
+    };
+    if (!block.isGroupBy) {
+      block.aggregation.functions = functions;
+      for (int f = 0; f < num_functions; ++f) block.aggregation.results.push_back(value(0, f));
+    } else {
+      GroupByResultsBlock& g = block.groupBy;
+      g.functions = functions;
+      for (int k = 0; k < num_keys; ++k) { g.groupByColumns.push_back(key_names[k]); g.groupByTypes.push_back((DataType)key_types[k]); }
+      for (int64_t r = 0; r < num_rows; ++r) {
+        GroupKey key;
+        key.groupId = (int)r;
+        for (int k = 0; k < num_keys; ++k) {
+          const size_t at = (size_t)r * (size_t)num_keys + (size_t)k;
+          const DataType t = (DataType)key_types[k];
+          if (t == DataType::INT || t == DataType::LONG) key.keys.emplace_back(key_longs[at]);
+          else if (t == DataType::STRING) key.keys.emplace_back(std::string(key_strings[at]));
+          else key.keys.emplace_back(key_doubles[at]);
+        }
+        g.groupKeys.push_back(std::move(key));
+        std::vector<IntermediateResult> row;
+        for (int f = 0; f < num_functions; ++f) row.push_back(value(r, f));
+        g.results.push_back(std::move(row));
+      }
+    }
+    block.stats.numDocsScanned = stats[0]; block.stats.numEntriesScannedInFilter = stats[1];
+    block.stats.numEntriesScannedPostFilter = stats[2]; block.stats.numTotalDocs = stats[3];
+    block.numGroupsLimitReached = limit_reached != 0;
+    bytes = toDataTableV4(block, null_handling != 0, segments_processed, segments_matched);
+  });
+  if (*status != 0) return nullptr;
+  uint8_t* out = (uint8_t*)malloc(bytes.size() ? bytes.size() : 1);
+  memcpy(out, bytes.data(), bytes.size());
+  *out_size = (int64_t)bytes.size();
+  return out;
+}
+
+// The DataTable V4 bytes the server would send for `sql` over these segments (combine, then InstanceResponseBlock.toDataTable().toBytes()).
+// Returns a malloc-ed buffer (*out_size bytes, ph_free it) or NULL with *status set.
+uint8_t* ph_execute_sql_datatable(void** segments, int32_t num_segments, const char* sql, int32_t max_execution_threads, int64_t* out_size, int32_t* status) {
+  std::vector<uint8_t> bytes;
+  *status = guarded([&] {
+    const QueryContext q = getQueryContext(sql);
+    std::vector<SegmentContext> ctxs;
+    for (int i = 0; i < num_segments; ++i) ctxs.push_back(SegmentContext{(ImmutableSegment*)segments[i]});
+    // numSegmentsMatched: segments with at least one doc scanned (BaseCombineOperator / InstanceResponseOperator bookkeeping)
+    int matched = 0;
+    for (int i = 0; i < num_segments; ++i) {
+      const ResultsBlock b = g_planMaker.makeSegmentPlanNode(ctxs[(size_t)i], q)->run()->nextBlock();
+      matched += b.stats.numDocsScanned > 0 ? 1 : 0;
+    }
+    bytes = toDataTableV4(g_planMaker.executeCombined(ctxs, q, max_execution_threads), q.nullHandlingEnabled, num_segments, matched);
+  });
+  if (*status != 0) return nullptr;
+  uint8_t* out = (uint8_t*)malloc(bytes.size() ? bytes.size() : 1);
+  memcpy(out, bytes.data(), bytes.size());
+  *out_size = (int64_t)bytes.size();
+  return out;
+}
+
 }  // extern "C"

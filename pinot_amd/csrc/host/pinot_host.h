@@ -279,6 +279,7 @@ struct AggregationResultsBlock {                    // operator/blocks/results/A
 
 struct GroupByResultsBlock {                        // GroupByResultsBlock.java:68-76 + AggregationGroupByResult.java:31-56
   std::vector<std::string> groupByColumns;
+  std::vector<DataType> groupByTypes;                                     // data type of every key column (the DataSchema's key column types)
   std::vector<AggregationFunction> functions;
   std::vector<GroupKey> groupKeys;                                       // ascending raw group id (ArrayBasedHolder iterator)
   std::vector<std::vector<IntermediateResult>> results;                   // [group][function]
@@ -336,6 +337,9 @@ class GpuPlanMaker : public PlanMaker {
   int _device = 0;
 };
 
+// DataTable V4 bytes of a results block (host/datatable_v4.cpp): what InstanceResponseBlock.toDataTable().toBytes() hands the broker.
+std::vector<uint8_t> toDataTableV4(const ResultsBlock& block, bool nullHandlingEnabled, int numSegmentsProcessed, int numSegmentsMatched);
+
 // Merge helpers (operator/combine/merger/AggregationResultsBlockMerger.java, combine/GroupByCombineOperator.java)
 void mergeResultsBlocks(ResultsBlock* merged, const ResultsBlock& toMerge);
 
@@ -353,3 +357,5 @@ struct GpuAbi {
 const GpuAbi& gpuAbi();   // throws std::runtime_error when libpinot_gpu.so cannot be loaded (no fallback)
 
 }  // namespace pinot
+
+extern "C" int64_t ph_roaring_serialize(const int32_t* sorted_doc_ids, int64_t n, int32_t run_optimize, uint8_t* out);

@@ -450,6 +450,7 @@ class GpuAggregationOperator : public Operator {
       g.functions = functions;
       std::vector<const DataSource*> keyCols;
       for (const auto& c : g.groupByColumns) keyCols.push_back(&_segment->getDataSource(c));
+      for (const DataSource* ds : keyCols) g.groupByTypes.push_back(ds->dataType);
       for (int i = 0; i < res.num_groups; ++i) {
         GroupKey key;
         key.groupId = res.group_ids[i];
@@ -554,6 +555,7 @@ class GpuFilteredAggregationOperator : public Operator {
     block.isGroupBy = true;
     GroupByResultsBlock& g = block.groupBy;
     g.groupByColumns = _queryContext.groupByExpressions;
+    for (const auto& c : g.groupByColumns) g.groupByTypes.push_back(_segment->getDataSource(c).dataType);
     for (const auto& a : _queryContext.aggregations) g.functions.emplace_back(a.function, a.column, _queryContext.nullHandlingEnabled);
     pg_agg_value empty;
     memset(&empty, 0, sizeof(empty));

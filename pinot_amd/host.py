@@ -150,3 +150,20 @@ def execute_sql(segments, sql, max_execution_threads=0):
     arr = (C.c_void_p * len(segments))(*[s.handle for s in segments])
     st = C.c_int32()
     return _take_json(lib, lib.ph_execute_sql(arr, len(segments), sql.encode(), max_execution_threads, C.byref(st)), st)
+
+
+def execute_sql_datatable(segments, sql, max_execution_threads=0):
+    """The DataTable V4 bytes a server would send the broker for `sql` over these segments (combine, then
+    InstanceResponseBlock.toDataTable().toBytes(); pinot_amd/csrc/host/datatable_v4.cpp)."""
+    lib = _lib()
+    lib.ph_execute_sql_datatable.restype = C.POINTER(C.c_uint8)
+    lib.ph_execute_sql_datatable.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    handles = (C.c_void_p * len(segments))(*[s.handle for s in segments])
+    size, status = C.c_int64(), C.c_int32()
+    ptr = lib.ph_execute_sql_datatable(handles, len(segments), sql.encode(), max_execution_threads, C.byref(size), C.byref(status))
+    if status.value != 0 or not ptr:
+        raise HostError(status.value, (lib.ph_last_error() or b"").decode("utf-8", "replace"))
+    data = bytes(bytearray(ptr[:size.value]))
+    lib.ph_free.argtypes = [C.c_void_p]
+    lib.ph_free(C.cast(ptr, C.c_void_p))
+    return data

@@ -201,3 +201,30 @@ def test_string_key_group_by_goldens_through_sql(golden_segments):
     assert sorted([r["key"][0], r["final"][0]] for r in combined["groups"]) == g["sum_column1_by_column11"]
     combined = host.execute_sql(segs, "SELECT SUM(column1) FROM testTable GROUP BY column11, column12", max_execution_threads=2)["combined"]
     assert sorted([r["key"][0], r["key"][1], r["final"][0]] for r in combined["groups"])[:15] == g["sum_column1_by_column11_column12_first15"]
+
+
+def test_datatable_v4_of_the_golden_queries(golden_segments):
+    """The bytes the server would send the broker (DataTableImplV4, intermediate results): decoded with the reader of tests/datatable_v4.py
+    and compared with the reference's golden values; and equal to that file's own encoding of the same values."""
+    import datatable_v4 as D
+    _, segs = golden_segments
+    g = H.load_golden_queries()
+    want = g["inner_segment"]["filtered"]
+    data = host.execute_sql_datatable(segs[:1], QUERY + FILTER)
+    back = D.decode(data)
+    assert back["names"] == ["count(*)", "sum(column1)", "max(column3)", "min(column6)", "avg(column7)"] and back["types"] == ["LONG", "DOUBLE", "DOUBLE", "DOUBLE", "OBJECT"]
+    assert back["rows"] == [[want["count"], float(want["sum_column1"]), float(want["max_column3"]), float(want["min_column6"]), (float(want["avg_column7"][0]), want["avg_column7"][1])]]
+    assert [back["metadata"][k] for k in ("numDocsScanned", "numEntriesScannedInFilter", "numEntriesScannedPostFilter", "totalDocs")] == want["stats"]
+    import json, os
+    fixture = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "datatable_v4_golden.json")))
+    assert data.hex() == fixture["inner_segment_filtered_aggregation"]["hex"]
+    # four segments through the combine: the x4 goldens, and a STRING-keyed group-by whose keys travel through the string dictionary
+    x4 = g["inter_segment_x4"]
+    back = D.decode(host.execute_sql_datatable(segs, "SELECT COUNT(*), SUM(column1), SUM(column3) FROM testTable" + FILTER, max_execution_threads=4))
+    assert back["rows"] == [[x4["count"]["filtered"], x4["sum_column1"]["filtered"], x4["sum_column3"]["filtered"]]]
+    assert back["metadata"]["numSegmentsProcessed"] == 4 and back["metadata"]["numSegmentsMatched"] == 4 and back["metadata"]["totalDocs"] == 120000
+    combined = host.execute_sql(segs, "SELECT SUM(column1) FROM testTable GROUP BY column11")["combined"]
+    back = D.decode(host.execute_sql_datatable(segs, "SELECT SUM(column1) FROM testTable GROUP BY column11"))
+    assert back["names"] == ["column11", "sum(column1)"] and back["types"] == ["STRING", "DOUBLE"]
+    assert sorted(back["rows"]) == sorted([r["key"][0], r["intermediate"][0]] for r in combined["groups"])
+    assert sorted(back["rows"]) == sorted(g["inter_segment_group_by_x4"]["sum_column1_by_column11"])
