@@ -42,6 +42,16 @@ char* ph_parse_sql(const char* sql, int32_t* status);               /* QueryCont
 char* ph_lower_predicate(const char* sql_predicate, const void* dict, int32_t cardinality, int32_t* status);   /* PredicateEvaluatorProvider */
 char* ph_execute_sql(void** segments, int32_t num_segments, const char* sql, int32_t max_execution_threads, int32_t* status);
 
+/* ---- DataTable V4 (DataTableImplV4.toBytes of the intermediate results: what the server sends the broker; host/datatable_v4.cpp) ---- */
+/* malloc-ed buffer of *out_size bytes (ph_free), or NULL with *status set */
+uint8_t* ph_execute_sql_datatable(void** segments, int32_t num_segments, const char* sql, int32_t max_execution_threads, int64_t* out_size, int32_t* status);
+/* the writer alone, over a results block given as flat arrays (CPU tests): see host/c_api.cpp for the array layouts */
+uint8_t* ph_datatable_v4_build(int32_t is_group_by, int32_t num_functions, const int32_t* function_types, const char* const* function_columns, int32_t num_keys,
+                               const char* const* key_names, const int32_t* key_types, int64_t num_rows, const int64_t* key_longs, const double* key_doubles,
+                               const char* const* key_strings, const int64_t* counts, const double* sums, const double* mins, const double* maxs,
+                               const uint8_t* is_null, const int64_t* stats, int32_t null_handling, int32_t limit_reached, int32_t segments_processed,
+                               int32_t segments_matched, int64_t* out_size, int32_t* status);
+
 /* ---- writers in the reference's layouts (FixedBitSVForwardIndexWriter, SegmentDictionaryCreator, FixedByteChunkForwardIndexWriter v2,
  *      BitmapInvertedIndexWriter, RoaringBitmap portable serialization) and the synthetic-column generator of the benchmarks ---- */
 int32_t ph_num_bits_per_value(int32_t max_value);
