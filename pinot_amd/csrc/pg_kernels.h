@@ -2245,6 +2245,14 @@ __device__ __forceinline__ uint32_t read_packed(const uint8_t* fwd, long long do
   return (uint32_t)((win >> (64 - s - b)) & ((1ull << b) - 1ull));
 }
 
+// Wide value plane (pg_engine.hip want_wide_plane): out[doc] = the 8-byte dictionary entry of the doc's dictId, big-endian like the
+// value area of a raw LONG / DOUBLE forward index.  One-time build per column: a plain gather.
+static __global__ __launch_bounds__(256) void materialize_wide_plane_kernel(const uint8_t* __restrict__ fwd, int bits, const unsigned long long* __restrict__ dict64,
+                                                                            unsigned long long* __restrict__ out, int num_docs) {
+  for (long long doc = (long long)blockIdx.x * blockDim.x + threadIdx.x; doc < (long long)num_docs; doc += (long long)gridDim.x * blockDim.x)
+    out[doc] = __builtin_bswap64(dict64[read_packed(fwd, doc, bits)]);
+}
+
 static __global__ void gather_values_kernel(DevColumn col, long long value_base, const int32_t* __restrict__ doc_ids, int n, int32_t* out_dict_ids,
                                      int32_t* out_ints, long long* out_longs, double* out_doubles) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -72,3 +72,28 @@ def test_planes_are_built_beside_the_queries_and_evicted_under_a_budget(engine):
                 H.assert_results_equal(g.execute(specs[c]), wants[c])
         finally:
             assert lib.pg_set_plane_budget(previous.value, None) == 0
+
+
+@pytest.mark.parametrize("kind", ["long", "double"])
+def test_wide_plane_streams_an_eight_byte_dictionary_column(engine, kind):
+    """SUM / AVG over a LONG / DOUBLE dictionary without a filter: the values are materialised once (8 bytes per doc, a raw column's image)
+    and streamed by scan_private_typed_kernel instead of gathered per doc; MIN / MAX of the same column keep the dictId path."""
+    rng = np.random.default_rng(5)
+    n = 300_017
+    if kind == "long":
+        values = rng.integers(-2**40, 2**40, 5000).astype(np.int64)[rng.integers(0, 5000, n)]          # a range wider than 31 bits: 8-byte dictionary entries
+    else:
+        values = (rng.normal(size=4000) * 1e6)[rng.integers(0, 4000, n)].astype(np.float64)
+    seg = S.SegmentData("wide", n, [S.Column.dict_encoded_typed("m", values), H.random_dict_column(rng, "f", n, 40)[0]])
+    spec = Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1), (Q.AVG, 0)])
+    want = oracle.execute(seg, spec)
+    with engine.open(seg) as g:
+        answers = wait_for_plane(g, spec, 0)
+        for a in answers:
+            H.assert_results_equal(a, want)
+        assert g.plane_bytes() >= 8 * n and answers[-1].dominant_kernel == "scan_private_typed_kernel"
+        if kind == "long":
+            assert answers[-1].aggregations[0].sum_i64 == int(values.sum()) and answers[-1].aggregations[0].sum_exact
+        # MIN / MAX on the column, or a filter: the plane is not used, the answers stay right
+        for other in (Q.QuerySpec([(Q.SUM, 0), (Q.MAX, 0), (Q.MIN, 0)]), Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 13)))):
+            H.assert_results_equal(g.execute(other), oracle.execute(seg, other))
