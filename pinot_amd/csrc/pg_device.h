@@ -183,6 +183,8 @@ struct ScanParams {
   int32_t bitmap_lds_off[kMaxLeaves];
   const uint32_t* tile_list;       // lane-private kernels: visit only these 2048-doc tiles (index_and_kernel's survivors), or nullptr = all
   const uint32_t* tile_count;      //                       [1] how many of them
+  int32_t raw64_coalesced;         // scan_private_typed_kernel: raw 8-byte columns are read 1 KB per instruction across the wave (pg_scan_typed.h)
+  int32_t reserved0;
   unsigned long long* filter_entries;  // [1] numEntriesScannedInFilter of the kNodeCountEntries leaves (lane-private kernels), or nullptr
   unsigned long long* out_bitmap;  // optional doc-order bitmap output (num_tiles * tile_steps words)
   BlockPartial* partials;          // [gridDim.x]

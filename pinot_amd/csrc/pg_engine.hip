@@ -50,6 +50,7 @@ struct Engine {
   bool initialized = false;
   int device = 0;
   int blocks_per_cu = 0;
+  bool raw64_coalesced = true;   // PINOT_GPU_RAW64_COALESCED=0: raw LONG / DOUBLE columns are read lane-contiguously (256 bytes per lane)
   int wide_plane = -1;       // PINOT_GPU_WIDE_PLANE: -1 unfiltered sums of 8-byte dictionaries stream a materialised value column, 0 never, 1 always
   bool partition_stats_cache = true;   // PINOT_GPU_PARTITION_STATS_CACHE=0: run the partition histogram pass in every query
   bool partition_packed = true;   // PINOT_GPU_PARTITION_PACKED=0: always separate key / value record columns
@@ -1398,6 +1399,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.hist_bits = (hb && (atoi(hb) == 8 || atoi(hb) == 16)) ? atoi(hb) : 0;
   const char* ts = getenv("PINOT_GPU_TILE_STEPS");
   g_engine.tile_steps = (ts && (atoi(ts) == 16 || atoi(ts) == 32)) ? atoi(ts) : 0;
+  const char* r64 = getenv("PINOT_GPU_RAW64_COALESCED");
+  if (r64) g_engine.raw64_coalesced = atoi(r64) != 0;
   const char* wpl = getenv("PINOT_GPU_WIDE_PLANE");
   if (wpl) g_engine.wide_plane = atoi(wpl);
   const char* psc = getenv("PINOT_GPU_PARTITION_STATS_CACHE");
@@ -2084,6 +2087,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     else { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
     const bool count_entries = out && lw.stats_chain_flagged && (use_hist || use_private || use_private_typed);
     sp.filter_entries = nullptr;
+    sp.raw64_coalesced = g_engine.raw64_coalesced ? 1 : 0;
     if (count_entries) { st = arm_filter_entries(ctx, &sp.filter_entries); if (st != PG_OK) return st; }
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)

@@ -65,6 +65,27 @@ __device__ __forceinline__ void agg_raw64_private(const DevAggCol& ac, long long
   }
 }
 
+// The same column read COALESCED: load i of the tile takes 16 bytes per lane at (64 i + lane) * 16 -- one full KB per instruction,
+// eight 128-byte lines instead of the 64 half-used lines of the lane-contiguous pattern -- so the lane holds docs 128 i + 2 lane (+1)
+// of the tile instead of its own 32.  The filter mask stays in the lane-private layout (bit j of lane L = doc 32 L + j); the two mask
+// bits a lane needs per load are lane (4 i + lane / 16)'s bits 2 (lane % 16) (+1): one ds_bpermute per load.
+__device__ __forceinline__ void agg_raw64_coalesced(const DevAggCol& ac, long long tile, int lane, uint32_t m, TypedAcc& t) {
+  const uint4* src = reinterpret_cast<const uint4*>(ac.fwd + tile * 2048 * 8) + lane;
+  const int bit = (2 * lane) & 31;
+#pragma unroll 1
+  for (int c = 0; c < 4; ++c) {
+    uint4 w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = src[(c * 4 + i) * 64];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t mm = (uint32_t)__shfl((int)m, 4 * (c * 4 + i) + (lane >> 4), 64) >> bit;
+      typed_fold64(ac, be64(w[i].x, w[i].y), (mm & 1u) != 0u, t);
+      typed_fold64(ac, be64(w[i].z, w[i].w), (mm & 2u) != 0u, t);
+    }
+  }
+}
+
 // raw INT / FLOAT: 32 docs = 128 contiguous bytes per lane
 __device__ __forceinline__ void agg_raw32_private(const DevAggCol& ac, long long tile, int lane, uint32_t m, TypedAcc& t) {
   const uint4* src = reinterpret_cast<const uint4*>(ac.fwd + (tile * 2048 + (long long)lane * 32) * 4);
@@ -167,7 +188,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void scan_private_typed_ke
       TypedAcc t;
       typed_acc_identity(t);
       if (ac.is_raw) {
-        if (ac.vkind == kValI64 || ac.vkind == kValF64) agg_raw64_private(ac, tile, lane, m, t);
+        if (ac.vkind == kValI64 || ac.vkind == kValF64) { if (p.raw64_coalesced) agg_raw64_coalesced(ac, tile, lane, m, t); else agg_raw64_private(ac, tile, lane, m, t); }
         else agg_raw32_private(ac, tile, lane, m, t);
       } else {
         agg_dict64_private(ac, tile, lane, m, t);          // the host sends 32-bit-domain dictionary columns elsewhere
