@@ -1782,7 +1782,15 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
       const ColumnDev& col = seg->cols[(size_t)ag.column];
       const int kind = (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) ? 0 : (ag.function == PG_AGG_MIN ? 1 : 2);
       if (std::find(group_aggs.begin(), group_aggs.end(), std::make_pair(ag.column, kind)) == group_aggs.end()) group_aggs.emplace_back(ag.column, kind);
-      if (col.encoding == PG_FWD_RAW_FIXED_BYTE && col.vkind != kValI32) return fail(PG_ERR_UNSUPPORTED, "group-by aggregation of a raw LONG / FLOAT / DOUBLE column (plan-time fallback)");
+      if (col.encoding == PG_FWD_RAW_FIXED_BYTE && col.vkind != kValI32) {
+        // group_typed_direct_kernel takes it, with the lane-private filter: a range leaf on a raw 8-byte column is not in that filter
+        for (int n = 0; n < q->num_filter_nodes; ++n) {
+          if (q->filter[n].op != PG_FILTER_LEAF) continue;
+          const pg_predicate& pr = q->predicates[q->filter[n].predicate];
+          if (pr.kind == PG_PRED_RAW_RANGE && pr.column >= 0 && pr.column < num_cols_total && seg->cols[(size_t)pr.column].stored_type != PG_TYPE_INT)
+            return fail(PG_ERR_UNSUPPORTED, "group-by aggregation of a raw 8-byte column under a raw 8-byte range predicate (plan-time fallback)");
+        }
+      }
       if (kind == 0 && col.vkind == kValI64 && !col.h_dict_i64.empty()) {
         const double max_abs = std::max(std::fabs((double)col.h_dict_i64.front()), std::fabs((double)col.h_dict_i64.back()));
         if ((double)seg->num_docs * max_abs >= 9.2e18) return fail(PG_ERR_UNSUPPORTED, "group-by SUM of LONG column %s could overflow int64", col.name.c_str());
@@ -2204,6 +2212,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if (product > kMaxGroupSlots) return fail(PG_ERR_UNSUPPORTED, "group-by cardinality product exceeds %d direct-indexed slots (Long / ArrayMap holders keep the CPU plan)", kMaxGroupSlots);
     }
     const bool map_based = product > 10000;
+    bool typed_direct = false;            // an aggregation input is a raw LONG / FLOAT / DOUBLE column: group_typed_direct_kernel
     gp.num_group_cols = ng;
     gp.num_groups = (int32_t)product;
     gp.dense_ok = 1;
@@ -2252,9 +2261,9 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       ga.dict_bytes = c.dict_bytes; ga.fwd = c.fwd; ga.dict = c.dict;
       // MIN / MAX run on dictIds whatever the value type; only a SUM reads 8-byte / floating-point dictionary entries
       ga.vkind = (ga.kind == kGroupSum) ? c.vkind : kValI32;
-      if (c.is_raw && c.vkind != kValI32) return fail(PG_ERR_UNSUPPORTED, "group-by aggregation of a raw LONG / FLOAT / DOUBLE column (plan-time fallback)");
+      if (c.is_raw && c.vkind != kValI32) { typed_direct = true; ga.vkind = c.vkind; }      // group_typed_direct_kernel: the value type decides the accumulator
       if (ga.vkind != kValI32) gp.dense_ok = 0;
-      if (ga.vkind == kValI64) {
+      if (ga.vkind == kValI64 && !c.is_raw) {
         // the table slot is one wrapping int64: refuse (plan-time fallback) when numDocs * max|value| could overflow it
         const ColumnDev& sc = seg->cols[(size_t)(lw.col_of_slot[(size_t)plan_aggs[a].col] / 2)];
         const double max_abs = std::max(std::fabs((double)sc.h_dict_i64.front()), std::fabs((double)sc.h_dict_i64.back()));
@@ -2266,7 +2275,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // every leaf kind the lane-private filter implements (scan / set / bitmap / docId-range leaves, raw INT ranges)
     bool private_leaves = true;
     for (int l = 0; l < pl.num_leaves; ++l) private_leaves &= pl.leaves[l].kind <= kLeafBitmap || pl.leaves[l].kind == kLeafDocRange;
-    const bool use_private = g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap;
+    if (typed_direct && !private_leaves) return fail(PG_ERR_UNSUPPORTED, "group-by aggregation of a raw 8-byte column under a raw 8-byte range predicate (plan-time fallback)");
+    const bool use_private = g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap && !typed_direct;
     int pblocks = blocks, pthreads = geo.threads;
     size_t plds = lds;
     if (use_private) {
@@ -2315,10 +2325,10 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const int partition_entry_bytes = 4 + 8 * gp.num_group_aggs;
     const int partition_shift = partition_entry_bytes <= 20 ? 12 : 11;
     const long long num_partitions = (product + (1ll << partition_shift) - 1) >> partition_shift;
-    const bool use_partition = map_based && g_engine.group_partition && g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap &&
+    const bool use_partition = !typed_direct && map_based && g_engine.group_partition && g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap &&
                                gp.num_group_aggs <= kMaxPartitionAggs && num_partitions <= kMaxPartitions && (long long)seg->num_docs >= g_engine.partition_min_docs;
-    if (use_partition || !use_private) { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
-    const bool count_entries = out && lw.stats_chain_flagged && use_private && !use_partition;
+    if (use_partition || !(use_private || typed_direct)) { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
+    const bool count_entries = out && lw.stats_chain_flagged && ((use_private && !use_partition) || typed_direct);
     if (count_entries) { st = arm_filter_entries(ctx, &gp.scan.filter_entries); if (st != PG_OK) return st; }
     if (use_partition) {
       const int P = (int)num_partitions;
@@ -2397,6 +2407,10 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       HIP_TRY(hipGetLastError());
       if (!work.empty()) launch_group_partition_aggregate((int)work.size(), ((size_t)partition_entry_bytes) << partition_shift, ctx->stream, pp);
       HIP_TRY(hipStreamSynchronize(ctx->stream));      // `offsets` / `work` are pageable host vectors: keep them alive until the copies ran
+    }
+    else if (typed_direct) {
+      const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
+      launch_group_typed_direct((int)std::max<long long>(1, std::min<long long>((tiles2k + 3) / 4, (long long)seg->num_cus * 8)), ctx->stream, gp);
     }
     else if (use_private) launch_group_private(gp.use_lds_table != 0, pblocks, pthreads, plds, ctx->stream, gp);
     else launch_scan_group(g_engine.use_dma, gp.use_lds_table != 0, blocks, geo.threads, lds, ctx->stream, gp);
@@ -2553,13 +2567,16 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         const ColumnDev& col = seg->cols[(size_t)ag.column];
         const bool plane = lw.plane_cols[(size_t)ag.column] != 0;
         if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) {
-          if (col.vkind == kValF64) {
+          if (col.vkind == kValF64 || col.vkind == kValF32) {
             memcpy(&v.sum, &acc, 8);          // the slot accumulated doubles (ds_add_f64 / global_atomic_add_f64)
             v.sum_i64 = 0;
             v.sum_exact = 0;
           } else {
             set_integer_sum(&v, (__int128)acc * (__int128)sum_scale(col, plane) + (__int128)group_docs * (__int128)sum_base(col, plane));
           }
+        }
+        else if (col.encoding == PG_FWD_RAW_FIXED_BYTE && col.vkind != kValI32) {      // raw LONG value, or the order key of a raw FLOAT / DOUBLE value
+          if (ag.function == PG_AGG_MIN) v.min = key64_to_double(col, acc); else v.max = key64_to_double(col, acc);
         }
         else if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, (int32_t)acc, plane);
         else v.max = agg_value_double(col, (int32_t)acc, plane);

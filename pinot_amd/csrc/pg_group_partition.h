@@ -366,4 +366,72 @@ __global__ __launch_bounds__(256) void group_partition_aggregate_kernel(const Pa
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// group_typed_direct_kernel: group-by whose aggregation inputs include a RAW LONG / FLOAT / DOUBLE column
+// (SumAggregationFunction.aggregateGroupBySV over getDoubleValuesSV / getLongValuesSV of a no-dictionary column,
+// core/query/aggregation/function/SumAggregationFunction.java:160-179; Min / Max / Avg likewise).  Those values have no 32-bit image
+// (no dictId, no plane field), so none of the LDS-table kernels takes them: this kernel keeps the lane-private filter and key decode
+// and aggregates straight into the direct-indexed HBM table, one global atomic per doc and accumulator (23.7 G atomics/s: the price
+// of the general case; the reference runs it at ~25 M rows/s per core).  Every other input kind rides along (dictIds, plane fields,
+// gathered dictionary values of either width), so the query runs in one pass.
+// Table slots: SUM of LONG / INT: int64 add; SUM of FLOAT / DOUBLE: the slot holds a double (global_atomic_add_f64); MIN / MAX of raw LONG:
+// the value; of raw FLOAT / DOUBLE: its order-preserving 64-bit key (f64_order_key); of dictionary columns: the dictId.
+// ------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void group_typed_direct_kernel(const GroupParams gp) {
+  const int lane = threadIdx.x & 63;
+  const long long num_tiles = ((long long)gp.scan.num_docs + 2047) / 2048;
+  const long long total_waves = (long long)gridDim.x * 4;
+  const long long G = gp.num_groups;
+  uint32_t entries = 0u;
+  for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < num_tiles; tile += total_waves) {
+    const uint32_t m = eval_filter_private(gp.scan, tile, lane, entries) & tail_mask(gp, tile, lane);
+    if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
+    uint32_t g[32];
+    decode_group_keys(gp, tile, lane, g);
+    const long long first_doc = tile * 2048 + lane * 32;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) if ((m >> j) & 1u) __hip_atomic_fetch_add(&gp.table_count[g[j]], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int a = 0; a < gp.num_group_aggs; ++a) {
+      const DevGroupAgg& ga = gp.group_aggs[a];
+      long long* acc = gp.table_acc + (long long)a * G;
+      const bool wide_raw = ga.is_raw && (ga.vkind == kValI64 || ga.vkind == kValF64);
+      const bool float_sum = ga.kind == kGroupSum && (ga.vkind == kValF64 || ga.vkind == kValF32);
+      uint32_t d[32];
+      if (!ga.is_raw) {
+        const int b = ga.bits;
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(ga.fwd + tile * (256ll * b)) + lane * b;
+        decode16_private_dispatch<0>(b, words, *reinterpret_cast<uint32_t(*)[16]>(&d[0]));
+        decode16_private_dispatch<1>(b, words, *reinterpret_cast<uint32_t(*)[16]>(&d[16]));
+      }
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        if (!((m >> j) & 1u)) continue;
+        long long bits;                  // the accumulator's operand: an integer, the bits of a double, or a key
+        if (wide_raw) {
+          bits = (long long)__builtin_bswap64(*reinterpret_cast<const unsigned long long*>(ga.fwd + (first_doc + j) * 8));
+        } else if (ga.is_raw) {
+          const uint32_t w = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(ga.fwd + (first_doc + j) * 4));
+          bits = ga.vkind == kValF32 ? __double_as_longlong((double)__uint_as_float(w)) : (long long)(int32_t)w;
+        } else if (ga.kind == kGroupSum && !ga.is_plane) {
+          bits = ga.vkind == kValI32 ? (long long)ga.dict[d[j]] : reinterpret_cast<const long long*>(ga.dict)[d[j]];
+        } else {
+          bits = (long long)d[j];        // dictId (MIN / MAX) or plane field (SUM)
+        }
+        long long* slot = acc + g[j];
+        if (ga.kind == kGroupSum) {
+          if (float_sum) __hip_atomic_fetch_add(reinterpret_cast<double*>(slot), __longlong_as_double(bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else __hip_atomic_fetch_add(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          const bool float_key = ga.is_raw && (ga.vkind == kValF64 || ga.vkind == kValF32);
+          const long long key = float_key ? f64_order_key(__longlong_as_double(bits)) : bits;
+          if (ga.kind == kGroupMin) __hip_atomic_fetch_min(slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else __hip_atomic_fetch_max(slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+  flush_filter_entries(gp.scan, entries);
+}
+
 }  // namespace pg

