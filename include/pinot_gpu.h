@@ -211,8 +211,11 @@ typedef struct pg_query {
  *  - SUM / MIN / MAX / AVG / COUNT(column) skip the docs where their column is null (NullableSingleInputAggregationFunction.java:72-166);
  *    pg_agg_value.count is the number of non-null docs aggregated, and count == 0 means the reference's holder stays null;
  *  - the metadata / dictionary fast path is taken only when no aggregated column has nulls (AggregationPlanNode.java:99-100);
- *  - GROUP BY is accepted only when neither the keys nor the aggregated columns have null docs (the reference switches to the
- *    no-dictionary key generators otherwise, DefaultGroupByExecutor.java:106-121) -- PG_ERR_UNSUPPORTED at plan time. */
+ *  - GROUP BY: NULL is a key value of its own (the reference switches to its no-dictionary key generators, DefaultGroupByExecutor.java:
+ *    106-121).  On the raw group-id scale a key column WITH null docs has cardinality + 1 digit values, the last one meaning NULL:
+ *    raw id = sum digit_j * prod_{k<j} (cardinality_k + hasNulls_k); group_id_upper_bound is that product.  Every function skips the
+ *    null docs of its own column per group (count == 0: the holder stays null).  numGroupsLimit binds at any key-space size, the
+ *    first keys in docId order surviving.  Raw (no-dictionary) key columns: PG_ERR_UNSUPPORTED at plan time. */
 #define PG_QUERY_NULL_HANDLING 1
 
 /* Intermediate result of one aggregation function, in the reference's holder types:

@@ -26,8 +26,10 @@ import org.apache.pinot.core.query.aggregation.groupby.GroupByResultHolder;
 import org.apache.pinot.core.query.aggregation.groupby.ObjectGroupByResultHolder;
 import org.apache.pinot.core.query.request.context.QueryContext;
 import org.apache.pinot.segment.local.customobject.AvgPair;
+import org.apache.pinot.segment.spi.AggregationFunctionType;
 import org.apache.pinot.segment.spi.IndexSegment;
 import org.apache.pinot.segment.spi.index.reader.Dictionary;
+import org.apache.pinot.segment.spi.index.reader.NullValueVectorReader;
 
 
 final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
@@ -79,11 +81,30 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
         case AVG: {
           ObjectGroupByResultHolder holder = new ObjectGroupByResultHolder(Math.max(numGroups, 1), Math.max(numGroups, 1));
           for (int g = 0; g < numGroups; g++) {
-            holder.setValueForKey(g, new AvgPair(sums[g * numFunctions + i], counts[g * numFunctions + i]));
+            if (!nullHandling || counts[g * numFunctions + i] != 0) {
+              holder.setValueForKey(g, new AvgPair(sums[g * numFunctions + i], counts[g * numFunctions + i]));
+            }
           }
           holders[i] = holder;
           break;
         }
+        case SUM:
+        case MIN:
+        case MAX:
+          if (nullHandling) {
+            // NullableSingleInputAggregationFunction keeps these in an ObjectGroupByResultHolder that stays null until a value arrives
+            ObjectGroupByResultHolder nullable = new ObjectGroupByResultHolder(Math.max(numGroups, 1), Math.max(numGroups, 1));
+            for (int g = 0; g < numGroups; g++) {
+              int at = g * numFunctions + i;
+              if (counts[at] != 0) {
+                nullable.setValueForKey(g, (Object) Double.valueOf(_functions[i].getType() == AggregationFunctionType.SUM ? sums[at]
+                    : (_functions[i].getType() == AggregationFunctionType.MIN ? mins[at] : maxs[at])));
+              }
+            }
+            holders[i] = nullable;
+            break;
+          }
+          // fall through
         default: {
           // COUNT / SUM / MIN / MAX read getDoubleResult (CountAggregationFunction.extractGroupByResult casts it back to long)
           DoubleGroupByResultHolder holder = new DoubleGroupByResultHolder(Math.max(numGroups, 1), Math.max(numGroups, 1), 0.0);
@@ -113,12 +134,15 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
     }
     List<ExpressionContext> groupBy = _queryContext.getGroupByExpressions();
     Dictionary[] dictionaries = new Dictionary[groupBy.size()];
+    boolean[] nullableKeys = new boolean[groupBy.size()];
     String[] columnNames = new String[groupBy.size() + numFunctions];
     DataSchema.ColumnDataType[] columnTypes = new DataSchema.ColumnDataType[groupBy.size() + numFunctions];
     IndexSegment indexSegment = _segment.getIndexSegment();
     for (int i = 0; i < groupBy.size(); i++) {
       String column = groupBy.get(i).getIdentifier();
       dictionaries[i] = indexSegment.getDataSource(column).getDictionary();
+      NullValueVectorReader nullVector = indexSegment.getDataSource(column).getNullValueVector();
+      nullableKeys[i] = nullHandling && nullVector != null && nullVector.getNullBitmap() != null && !nullVector.getNullBitmap().isEmpty();
       columnNames[i] = groupBy.get(i).toString();
       columnTypes[i] = DataSchema.ColumnDataType.fromDataTypeSV(indexSegment.getDataSource(column).getDataSourceMetadata().getDataType());
     }
@@ -126,7 +150,7 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
       columnNames[groupBy.size() + i] = _functions[i].getResultColumnName();
       columnTypes[groupBy.size() + i] = _functions[i].getIntermediateResultColumnType();
     }
-    GpuGroupKeyGenerator keys = new GpuGroupKeyGenerator(groupIds, dictionaries, (int) _header[H_GROUP_ID_UPPER_BOUND]);
+    GpuGroupKeyGenerator keys = new GpuGroupKeyGenerator(groupIds, dictionaries, nullableKeys, (int) _header[H_GROUP_ID_UPPER_BOUND]);
     GroupByResultsBlock block = new GroupByResultsBlock(new DataSchema(columnNames, columnTypes), new AggregationGroupByResult(keys, _functions, holders), _queryContext);
     block.setNumGroupsLimitReached(_header[H_NUM_GROUPS_LIMIT_REACHED] != 0);      // GroupByOperator.java:114-115
     return block;

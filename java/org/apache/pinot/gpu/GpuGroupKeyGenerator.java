@@ -16,14 +16,22 @@ final class GpuGroupKeyGenerator implements GroupKeyGenerator {
   private final int[] _rawGroupIds;
   private final Dictionary[] _dictionaries;
   private final int[] _cardinalities;
+  private final int[] _radix;
   private final int _globalUpperBound;
 
-  GpuGroupKeyGenerator(int[] rawGroupIds, Dictionary[] dictionaries, int globalUpperBound) {
+  /**
+   * @param nullableKeys under enableNullHandling, the key columns that have null docs: their digit runs to cardinality INCLUSIVE, the last
+   *                     value meaning NULL (include/pinot_gpu.h, PG_QUERY_NULL_HANDLING: the no-dictionary key generators of
+   *                     DefaultGroupByExecutor.java:106-121 treat NULL as a key value of its own)
+   */
+  GpuGroupKeyGenerator(int[] rawGroupIds, Dictionary[] dictionaries, boolean[] nullableKeys, int globalUpperBound) {
     _rawGroupIds = rawGroupIds;
     _dictionaries = dictionaries;
     _cardinalities = new int[dictionaries.length];
+    _radix = new int[dictionaries.length];
     for (int i = 0; i < dictionaries.length; i++) {
       _cardinalities[i] = dictionaries[i].length();
+      _radix[i] = _cardinalities[i] + (nullableKeys[i] ? 1 : 0);
     }
     _globalUpperBound = globalUpperBound;
   }
@@ -69,8 +77,9 @@ final class GpuGroupKeyGenerator implements GroupKeyGenerator {
         int raw = _rawGroupIds[_next];
         Object[] keys = new Object[_dictionaries.length];
         for (int i = 0; i < _dictionaries.length; i++) {
-          keys[i] = _dictionaries[i].getInternal(raw % _cardinalities[i]);
-          raw /= _cardinalities[i];
+          int digit = raw % _radix[i];
+          keys[i] = digit == _cardinalities[i] ? null : _dictionaries[i].getInternal(digit);
+          raw /= _radix[i];
         }
         _groupKey._groupId = _next++;
         _groupKey._keys = keys;

@@ -1470,6 +1470,8 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   int ng = q->num_group_by;
   int64_t group_upper = 1;
   int32_t cards[8];
+  uint64_t* key_nulls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int nullable_group_by = 0;      /* null handling with nulls in a key or an aggregated column: the no-dictionary generators' semantics */
   if (ng > 8) { rc = 2; snprintf(po_error, sizeof(po_error), "too many group-by columns"); goto done; }
   for (int g = 0; g < ng; g++) {
     const pg_column_desc* d = &seg->columns[q->group_by_columns[g]];
@@ -1480,17 +1482,21 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
      * fits an int; the Long / ArrayMap holders beyond that are not restated */
     if (group_upper > 2147483647ll) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by cardinality product > Integer.MAX_VALUE"); goto done; }
     if (null_handling) {
-      /* DefaultGroupByExecutor.java:106-121 leaves the dictionary-based key generator when null handling is on; only the case where it
-       * cannot matter (no nulls in the keys or the aggregated columns) is restated. */
-      uint64_t* w = column_null_words(seg, q->group_by_columns[g]);
-      if (w || has_null_values) { free(w); rc = 2; snprintf(po_error, sizeof(po_error), "group-by over nullable columns with null handling"); goto done; }
+      /* DefaultGroupByExecutor.java:106-121: under null handling the keys come from the no-dictionary generators
+       * (NoDictionarySingleColumnGroupKeyGenerator / NoDictionaryMultiColumnGroupKeyGenerator with nullHandlingEnabled): a null key value
+       * is a key of its own, group ids are handed out in order of first appearance up to numGroupsLimit.  Restated on the raw-key
+       * scale of the ABI: a nullable key column has one more digit value, `cardinality`, meaning NULL. */
+      key_nulls[g] = column_null_words(seg, q->group_by_columns[g]);
+      if (key_nulls[g]) { cards[g] = d->cardinality + 1; group_upper = group_upper / d->cardinality * cards[g]; nullable_group_by = 1; }
+      if (group_upper > 2147483647ll) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by cardinality product > Integer.MAX_VALUE"); goto done; }
     }
   }
+  if (null_handling && ng > 0 && has_null_values) nullable_group_by = 1;
 
   /* IntMapBasedHolder (DictionaryBasedGroupKeyGenerator.java:415-490) + IntGroupIdMap.getGroupId (:1022-1047): raw key -> group id in
    * order of first appearance; once _size == groupIdUpperBound = min(product, numGroupsLimit) (:176) new keys get INVALID_ID and the
    * result holders ignore their docs. */
-  const int map_based = ng > 0 && group_upper > 10000;
+  const int map_based = ng > 0 && (group_upper > 10000 || nullable_group_by);
   const int64_t raw_key_upper = group_upper;
   int32_t num_groups_limit = q->num_groups_limit > 0 ? q->num_groups_limit : 100000;
   int64_t map_capacity = 0; int32_t* map_keys = NULL; int32_t* map_ids = NULL; int32_t* raw_of_gid = NULL; int32_t map_size = 0;
@@ -1535,6 +1541,8 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   vals.d = (double*)malloc(sizeof(double) * PO_MAX_DOC_PER_CALL);
   double* dbl_values = (double*)malloc(sizeof(double) * PO_MAX_DOC_PER_CALL);
   int32_t* group_ids = (int32_t*)malloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  int32_t* nn_gids = (int32_t*)malloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  int64_t* gnn = ng > 0 ? (int64_t*)calloc((size_t)group_upper * (size_t)(na > 0 ? na : 1), sizeof(int64_t)) : NULL;   /* docs that reached the holder, per group and function */
   int64_t num_docs_scanned = 0;
 
   for (;;) {
@@ -1553,6 +1561,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       for (int32_t i = 0; i < pos; i++) group_ids[i] = 0;
       for (int g = ng - 1; g >= 0; g--) {
         fetch_dict_ids(&cols[q->group_by_columns[g]], num_docs, doc_ids, pos, dict_scratch);
+        if (key_nulls[g]) for (int32_t i = 0; i < pos; i++) if ((key_nulls[g][doc_ids[i] >> 6] >> (doc_ids[i] & 63)) & 1) dict_scratch[i] = cards[g] - 1;   /* NULL */
         for (int32_t i = 0; i < pos; i++) group_ids[i] = group_ids[i] * cards[g] + dict_scratch[i];
       }
       if (map_based) {
@@ -1593,8 +1602,11 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
           if (agg_nulls && agg_nulls[a]) for (int32_t i = 0; i < pos; i++) num_nulls += (int32_t)((agg_nulls[a][doc_ids[i] >> 6] >> (doc_ids[i] & 63)) & 1);
           holders[a].value = holders[a].value + (pos - num_nulls);
         } else {
-          /* aggregateGroupBySV :110-116 */
-          for (int32_t i = 0; i < pos; i++) gholders[(size_t)a * G + group_ids[i]] = gholders[(size_t)a * G + group_ids[i]] + 1;
+          /* aggregateGroupBySV :110-116; COUNT(column) under null handling skips the null docs (:118-131) */
+          for (int32_t i = 0; i < pos; i++) {
+            if (agg_nulls && agg_nulls[a] && ((agg_nulls[a][doc_ids[i] >> 6] >> (doc_ids[i] & 63)) & 1)) continue;
+            gholders[(size_t)a * G + group_ids[i]] = gholders[(size_t)a * G + group_ids[i]] + 1;
+          }
         }
         continue;
       }
@@ -1623,6 +1635,21 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
         widen_to_double(st, &vals, pos, dbl_values);
         double* hold = gholders + (size_t)a * G;
         int64_t* ex = gexact + (size_t)a * G;
+        const int32_t* gids = group_ids;
+        int32_t npos = pos;
+        if (agg_nulls && agg_nulls[a]) {
+          /* NullableSingleInputAggregationFunction.forEachNotNull (:118-160): the null docs of THIS column do not reach its holders */
+          npos = 0;
+          for (int32_t i = 0; i < pos; i++) {
+            if ((agg_nulls[a][doc_ids[i] >> 6] >> (doc_ids[i] & 63)) & 1) continue;
+            nn_gids[npos] = group_ids[i]; dbl_values[npos] = dbl_values[i]; vals.i[npos] = vals.i[i]; vals.l[npos] = vals.l[i];
+            npos++;
+          }
+          gids = nn_gids;
+        }
+        for (int32_t i = 0; i < npos; i++) gnn[(size_t)a * G + gids[i]]++;
+#define group_ids gids
+#define pos npos
         if (func == PG_AGG_SUM || func == PG_AGG_AVG) {
           if (st == PG_TYPE_INT) for (int32_t i = 0; i < pos; i++) exact_add(&ex[group_ids[i]], vals.i[i], &gover[(size_t)a * G + group_ids[i]]);
           if (st == PG_TYPE_LONG) for (int32_t i = 0; i < pos; i++) exact_add(&ex[group_ids[i]], vals.l[i], &gover[(size_t)a * G + group_ids[i]]);
@@ -1642,6 +1669,8 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
             break;
           default: rc = 2; snprintf(po_error, sizeof(po_error), "unsupported aggregation %d", func); goto cleanup;
         }
+#undef group_ids
+#undef pos
       }
     }
   }
@@ -1687,7 +1716,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
         pg_agg_value* v = &res->group_aggregations[(size_t)k * (size_t)na + (size_t)a];
         int func = q->aggregations[a].function;
         v->min = INFINITY; v->max = -INFINITY;
-        v->count = func == PG_AGG_COUNT ? (int64_t)gholders[(size_t)a * G + g] : (func == PG_AGG_AVG ? gavg_cnt[(size_t)a * G + g] : gcount[g]);
+        v->count = func == PG_AGG_COUNT ? (int64_t)gholders[(size_t)a * G + g] : (func == PG_AGG_AVG ? gavg_cnt[(size_t)a * G + g] : gnn[(size_t)a * G + g]);
         const int integral = func != PG_AGG_COUNT && seg->columns[q->aggregations[a].column].stored_type <= PG_TYPE_LONG && !gover[(size_t)a * G + g];
         if (func == PG_AGG_SUM) { v->sum = gholders[(size_t)a * G + g]; v->sum_i64 = gexact[(size_t)a * G + g]; v->sum_exact = integral; }
         if (func == PG_AGG_AVG) { v->sum = gavg_sum[(size_t)a * G + g]; v->sum_i64 = gexact[(size_t)a * G + g]; v->sum_exact = integral; }
@@ -1713,7 +1742,8 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   }
 
 cleanup:
-  free(doc_ids); free(dict_scratch); free(vals.i); free(vals.l); free(vals.f); free(vals.d); free(dbl_values); free(group_ids);
+  free(doc_ids); free(dict_scratch); free(vals.i); free(vals.l); free(vals.f); free(vals.d); free(dbl_values); free(group_ids); free(nn_gids); free(gnn);
+  for (int g = 0; g < 8; g++) free(key_nulls[g]);
   free(holders); free(gholders); free(gavg_sum); free(gavg_cnt); free(gexact); free(gover); free(gcount); free(flags);
   free(map_keys); free(map_ids); free(raw_of_gid);
 done:

@@ -64,7 +64,8 @@ std::string blockJson(const ResultsBlock& b) {
       const auto& keys = b.groupBy.groupKeys[g].keys;
       for (size_t k = 0; k < keys.size(); ++k) {
         o << (k ? ", " : "");
-        if (std::holds_alternative<int64_t>(keys[k])) o << std::get<int64_t>(keys[k]);
+        if (std::holds_alternative<std::monostate>(keys[k])) o << "null";
+        else if (std::holds_alternative<int64_t>(keys[k])) o << std::get<int64_t>(keys[k]);
         else if (std::holds_alternative<double>(keys[k])) o << num(std::get<double>(keys[k]));
         else o << "\"" << jsonEscape(std::get<std::string>(keys[k])) << "\"";
       }

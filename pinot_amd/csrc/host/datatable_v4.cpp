@@ -176,6 +176,17 @@ std::vector<uint8_t> toDataTableV4(const ResultsBlock& block, bool nullHandlingE
       builder.startRow();
       for (size_t k = 0; k < nk; ++k) {
         const GroupKeyValue& v = block.groupBy.groupKeys[r].keys[k];
+        if (std::holds_alternative<std::monostate>(v)) {        // NULL key: the stored type's placeholder + the key column's null bitmap (GroupByResultsBlock.java:208-214)
+          nullRows[k].push_back((int32_t)r);
+          switch (types[k]) {
+            case ColumnType::INT: builder.setInt((int)k, 0); break;
+            case ColumnType::LONG: builder.setLong((int)k, 0); break;
+            case ColumnType::FLOAT: builder.setFloat((int)k, 0.0f); break;
+            case ColumnType::DOUBLE: builder.setDouble((int)k, 0.0); break;
+            default: builder.setString((int)k, ""); break;
+          }
+          continue;
+        }
         switch (types[k]) {
           case ColumnType::INT: builder.setInt((int)k, (int32_t)std::get<int64_t>(v)); break;
           case ColumnType::LONG: builder.setLong((int)k, std::get<int64_t>(v)); break;

@@ -269,7 +269,7 @@ struct ExecutionStatistics {
 };
 
 // ---- operator/blocks/results --------------------------------------------------------------------------------------
-using GroupKeyValue = std::variant<int64_t, std::string, double>;   // INT / LONG keys, STRING keys, FLOAT / DOUBLE keys
+using GroupKeyValue = std::variant<int64_t, std::string, double, std::monostate>;   // INT / LONG keys, STRING keys, FLOAT / DOUBLE keys, NULL (null handling)
 struct GroupKey { int groupId; std::vector<GroupKeyValue> keys; };        // groupby/GroupKeyGenerator.GroupKey
 
 struct AggregationResultsBlock {                    // operator/blocks/results/AggregationResultsBlock.java:54-59

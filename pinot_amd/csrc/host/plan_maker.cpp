@@ -397,7 +397,7 @@ std::unique_ptr<LoweredQuery> lowerQuery(const ImmutableSegment& seg, const Quer
   for (const auto& g : qc.groupByExpressions) {
     const DataSource& ds = seg.getDataSource(g);
     if (!ds.hasDictionary) throw UnsupportedOperationException("group-by on a raw column uses the no-dictionary key generator (CPU plan)");
-    product *= ds.cardinality;
+    product *= ds.cardinality + ((qc.nullHandlingEnabled && ds.nullValueVector != nullptr && ds.nullValueVectorSize > 0) ? 1 : 0);   // NULL is a key value of its own
     // DictionaryBasedGroupKeyGenerator.java:164-184: ArrayBasedHolder up to arrayBasedThreshold, IntMapBasedHolder above it -- both are
     // one direct-indexed device table (at most 2^24 slots); the Long / ArrayMap holders beyond that keep the CPU plan
     if (product > (1ll << 24)) throw UnsupportedOperationException("group-by cardinality product exceeds the device's direct-indexed table (2^24 raw keys)");
@@ -455,11 +455,16 @@ class GpuAggregationOperator : public Operator {
         GroupKey key;
         key.groupId = res.group_ids[i];
         // DictionaryBasedGroupKeyGenerator.getKeys: groupId -> dictIds (mixed radix) -> dictionary VALUES
+        // Under null handling a nullable key column has one more digit value, `cardinality` = NULL (include/pinot_gpu.h, pg_query.flags):
+        // the no-dictionary key generators of DefaultGroupByExecutor.java:106-121 treat NULL as a key value of its own.
         int rem = key.groupId;
         for (const DataSource* ds : keyCols) {
-          const int d = rem % ds->cardinality;
-          rem /= ds->cardinality;
-          if (ds->dataType == DataType::STRING) key.keys.emplace_back(ds->dictionary->getStringValue(d));
+          const bool nullable = _queryContext.nullHandlingEnabled && ds->nullValueVector != nullptr && ds->nullValueVectorSize > 0;
+          const int radix = ds->cardinality + (nullable ? 1 : 0);
+          const int d = rem % radix;
+          rem /= radix;
+          if (d == ds->cardinality) key.keys.emplace_back(std::monostate{});
+          else if (ds->dataType == DataType::STRING) key.keys.emplace_back(ds->dictionary->getStringValue(d));
           else if (ds->dataType == DataType::FLOAT || ds->dataType == DataType::DOUBLE) key.keys.emplace_back(ds->dictionary->getDoubleValue(d));
           else key.keys.emplace_back(ds->dictionary->getLongValue(d));
         }

@@ -108,6 +108,8 @@ struct ColumnDev {
   std::vector<DevContainer> h_dir;
   std::vector<int64_t> posting_first;   // [cardinality + 1] index into the container directory
   unsigned long long* d_null_bitmap = nullptr;   // null value vector expanded to a doc-order bitmap (num_tiles * 32 words), or nullptr
+  int nullkey_column = -1;              // nullable dictionary column: index of its hidden null-key image (dictId = cardinality where the doc is null)
+  bool borrows_dictionary = false;      // hidden image: d_dict / d_dict64 belong to the column it was made from
   int64_t num_nulls = 0;
   // value plane (built lazily on the device the first time the column is summed)
   uint8_t* d_plane = nullptr;
@@ -173,7 +175,8 @@ struct pg_segment {
   int num_cus = 256;
   uint64_t device_bytes = 0;
   std::string name;
-  std::vector<ColumnDev> cols;
+  std::vector<ColumnDev> cols;          // the caller's columns, then hidden null-key images (ColumnDev.nullkey_column)
+  int num_user_cols = 0;
   std::mutex ctx_mu;
   // Partitioned group-by: docs per partition of a key-column set, ignoring the filter -- a property of the segment, not of the query.
   // Pass 0 (group_partition_histogram_kernel) computes it the first time a (key columns, shift) combination is grouped by; later
@@ -465,8 +468,8 @@ void free_segment(pg_segment* seg) {
   for (auto* c : seg->all_ctx) destroy_ctx(c);
   for (auto& col : seg->cols) {
     if (col.d_fwd_alloc) (void)hipFree(col.d_fwd_alloc);
-    if (col.d_dict) (void)hipFree(col.d_dict);
-    if (col.d_dict64) (void)hipFree(col.d_dict64);
+    if (col.d_dict && !col.borrows_dictionary) (void)hipFree(col.d_dict);
+    if (col.d_dict64 && !col.borrows_dictionary) (void)hipFree(col.d_dict64);
     if (col.d_inv) (void)hipFree(col.d_inv);
     if (col.d_dir) (void)hipFree(col.d_dir);
     if (col.d_null_bitmap) (void)hipFree(col.d_null_bitmap);
@@ -1676,6 +1679,39 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       }
     }
   }
+  // GROUP BY under enableNullHandling treats NULL as a key of its own (DefaultGroupByExecutor.java:106-121: the no-dictionary key
+  // generators).  A nullable dictionary column therefore gets a second forward index whose dictId is `cardinality` wherever the doc is
+  // null: the group-by kernels then need no notion of null (execute_null_handling points the key at this image).
+  seg->num_user_cols = (int)seg->cols.size();
+  seg->cols.reserve(seg->cols.size() * 2);
+  for (int i = 0; i < seg->num_user_cols; ++i) {
+    if (!seg->cols[(size_t)i].d_null_bitmap || seg->cols[(size_t)i].encoding != PG_FWD_FIXED_BIT_DICT) continue;
+    int bits_out = 1;
+    while (bits_out < 31 && (1ll << bits_out) <= (long long)seg->cols[(size_t)i].cardinality) ++bits_out;      // PinotDataBitSet.getNumBitsPerValue(cardinality)
+    ColumnDev image;
+    const ColumnDev& col = seg->cols[(size_t)i];
+    image.name = col.name + "$nullkey";
+    image.stored_type = col.stored_type; image.encoding = col.encoding; image.vkind = col.vkind; image.value_base = col.value_base;
+    image.bits = bits_out;
+    image.cardinality = col.cardinality + 1;
+    image.h_dict = col.h_dict; image.h_dict.push_back(0);
+    image.h_dict_f64 = col.h_dict_f64; image.h_dict_f64.push_back(std::numeric_limits<double>::quiet_NaN());
+    image.h_dict_i64 = col.h_dict_i64; if (!image.h_dict_i64.empty()) image.h_dict_i64.push_back(0);
+    image.d_dict = col.d_dict; image.d_dict64 = col.d_dict64; image.borrows_dictionary = true;      // never gathered: the image is only ever a group key
+    image.fwd_alloc_bytes = (size_t)std::max(seg->num_tiles, 1) * 256 * (size_t)bits_out + 64;
+    hipError_t e = hipMalloc((void**)&image.d_fwd_alloc, image.fwd_alloc_bytes);
+    if (e == hipSuccess) e = hipMemset(image.d_fwd_alloc, 0, image.fwd_alloc_bytes);
+    if (e == hipSuccess) {
+      build_nullkey_fwd_kernel<<<dim3((unsigned)std::max(1, std::min(seg->num_tiles / 4 + 1, seg->num_cus * 8))), dim3(256), 0, 0>>>(col.d_fwd, col.bits, col.d_null_bitmap, image.d_fwd_alloc,
+                                                                                                                                     bits_out, (uint32_t)col.cardinality, seg->num_tiles);
+      e = hipDeviceSynchronize();
+    }
+    if (e != hipSuccess) { if (image.d_fwd_alloc) (void)hipFree(image.d_fwd_alloc); return bail(fail(PG_ERR_DEVICE, "column %s: null-key image: %s", col.name.c_str(), hipGetErrorString(e))); }
+    image.d_fwd = image.d_fwd_alloc;
+    seg->device_bytes += image.fwd_alloc_bytes;
+    seg->cols[(size_t)i].nullkey_column = (int)seg->cols.size();
+    seg->cols.push_back(std::move(image));
+  }
   *out_segment = seg;
   return PG_OK;
 }
@@ -1706,6 +1742,8 @@ void pg_result_free(pg_result* r) {
   free(r->group_aggregations);
   memset(r, 0, sizeof(*r));
 }
+
+constexpr int32_t kQueryHashHolder = 1 << 30;      // internal pg_query.flags bit (execute_null_handling -> execute_impl)
 
 // ---- plan-time eligibility (pg_query_check) ----
 // Every reason pg_execute can answer PG_ERR_UNSUPPORTED for, decided from the query and the segment's metadata alone: no context, no
@@ -2211,7 +2249,9 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       // key, and only the groups that exist come back.  2^24 slots keep the 24-bit key multiplies exact and the table <= 1.2 GB.
       if (product > kMaxGroupSlots) return fail(PG_ERR_UNSUPPORTED, "group-by cardinality product exceeds %d direct-indexed slots (Long / ArrayMap holders keep the CPU plan)", kMaxGroupSlots);
     }
-    const bool map_based = product > 10000;
+    // (kQueryHashHolder: the no-dictionary key generators of null handling hand out group ids by first appearance up to numGroupsLimit
+    //  whatever the key space: the compaction path below is the one that honours the limit)
+    const bool map_based = product > 10000 || (q->flags & kQueryHashHolder) != 0;
     bool typed_direct = false;            // an aggregation input is a raw LONG / FLOAT / DOUBLE column: group_typed_direct_kernel
     gp.num_group_cols = ng;
     gp.num_groups = (int32_t)product;
@@ -2737,12 +2777,100 @@ static pg_status execute_null_handling(pg_segment* seg, const pg_query* q, pg_re
     if (rw.has_nulls(c) && std::find(lane_cols.begin(), lane_cols.end(), c) == lane_cols.end()) lane_cols.push_back(c);
   }
   if (ng > 0) {
-    // DefaultGroupByExecutor.java:106-121 drops the dictionary-based key generator under null handling; equal results are only
-    // guaranteed when no key and no aggregated column has nulls.
-    bool nullable = !lane_cols.empty();
-    for (int g = 0; g < ng; ++g) nullable |= rw.has_nulls(q->group_by_columns[g]);
-    if (nullable) return fail(PG_ERR_UNSUPPORTED, "GROUP BY over columns with null docs under null handling keeps the CPU plan");
-    return execute_impl(seg, &base.q, out, nullptr, nullptr, 0, nullptr);
+    // DefaultGroupByExecutor.java:106-121: under null handling the keys come from the no-dictionary generators -- NULL is a key value of
+    // its own -- and every aggregation function skips the null docs of its own column (NullableSingleInputAggregationFunction
+    // .aggregateGroupBySV :118-160).  Here: a nullable key column is read through its null-key image (dictId = cardinality where the doc
+    // is null: one more digit value of the raw group id), and the aggregations are split into lanes like above -- the base lane over the
+    // filter's trues (COUNT(*) and the columns without nulls; it also decides which groups exist), one lane per nullable aggregated
+    // column over trues AND column IS NOT NULL, merged by group id.  A group none of whose docs has a value in a lane comes back with
+    // count 0 for that function: the reference's holder stays null.
+    bool nullable_keys = false;
+    std::vector<int32_t> keys((size_t)ng);
+    for (int g = 0; g < ng; ++g) {
+      const int c = q->group_by_columns[g];
+      keys[(size_t)g] = c;
+      if (!rw.has_nulls(c)) continue;
+      if (seg->cols[(size_t)c].nullkey_column < 0) return fail(PG_ERR_UNSUPPORTED, "GROUP BY over nullable raw column %s keeps the CPU plan", seg->cols[(size_t)c].name.c_str());
+      keys[(size_t)g] = seg->cols[(size_t)c].nullkey_column;
+      nullable_keys = true;
+    }
+    base.q.group_by_columns = keys.data();
+    if (nullable_keys || !lane_cols.empty()) {
+      // numGroupsLimit binds at any key-space size here (NoDictionary*GroupKeyGenerator: _globalGroupIdUpperBound = numGroupsLimit)
+      long long product = 1;
+      for (int g = 0; g < ng; ++g) product *= std::max(seg->cols[(size_t)keys[(size_t)g]].cardinality, 1);
+      const long long limit = q->num_groups_limit > 0 ? q->num_groups_limit : 100000;
+      if (limit < product) base.q.flags |= kQueryHashHolder;
+    }
+    if (lane_cols.empty()) return execute_impl(seg, &base.q, out, nullptr, nullptr, 0, nullptr);
+    std::vector<int> base_pos;
+    for (int a = 0; a < na; ++a) if (!rw.has_nulls(q->aggregations[a].column)) { base.aggs.push_back(q->aggregations[a]); base_pos.push_back(a); }
+    const bool synthetic_count = base.aggs.empty();
+    if (synthetic_count) base.aggs.push_back(pg_aggregation{PG_AGG_COUNT, -1});
+    base.q.aggregations = base.aggs.data(); base.q.num_aggregations = (int32_t)base.aggs.size();
+    pg_result part;
+    memset(&part, 0, sizeof(part));
+    st = execute_impl(seg, &base.q, &part, nullptr, nullptr, 0, nullptr, false);
+    if (st != PG_OK) { pg_result_free(&part); return st; }
+    memset(out, 0, sizeof(*out));
+    const int num_groups = part.num_groups;
+    const int base_na = part.num_aggregations;
+    out->num_aggregations = na;
+    out->num_groups = num_groups;
+    out->group_id_upper_bound = part.group_id_upper_bound;
+    out->num_groups_limit_reached = part.num_groups_limit_reached;
+    out->stats = part.stats;
+    out->filter_entries_exact = 0;
+    out->device_ms = part.device_ms; out->dominant_kernel_ms = part.dominant_kernel_ms; out->dominant_kernel = part.dominant_kernel;
+    out->group_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)std::max(num_groups, 1));
+    out->group_aggregations = (pg_agg_value*)calloc((size_t)std::max(num_groups, 1) * (size_t)std::max(na, 1), sizeof(pg_agg_value));
+    for (int k = 0; k < num_groups; ++k) {
+      out->group_ids[k] = part.group_ids[k];
+      for (int a = 0; a < na; ++a) {                       // until a lane says otherwise: no value reached the holder
+        pg_agg_value& v = out->group_aggregations[(size_t)k * (size_t)na + (size_t)a];
+        v.min = std::numeric_limits<double>::infinity();
+        v.max = -std::numeric_limits<double>::infinity();
+      }
+      if (!synthetic_count) for (size_t i = 0; i < base_pos.size(); ++i) out->group_aggregations[(size_t)k * (size_t)na + (size_t)base_pos[i]] = part.group_aggregations[(size_t)k * (size_t)base_na + i];
+    }
+    pg_result_free(&part);
+    // numEntriesScannedPostFilter = numDocsScanned * projected columns of the WHOLE query (GroupByOperator.java:160-166): keys + inputs
+    std::vector<int> projected;
+    for (int g = 0; g < ng; ++g) if (std::find(projected.begin(), projected.end(), q->group_by_columns[g]) == projected.end()) projected.push_back(q->group_by_columns[g]);
+    for (int a = 0; a < na; ++a) {
+      const pg_aggregation& ag = q->aggregations[a];
+      const bool reads = ag.function != PG_AGG_COUNT || rw.has_nulls(ag.column);
+      if (reads && ag.column >= 0 && std::find(projected.begin(), projected.end(), ag.column) == projected.end()) projected.push_back(ag.column);
+    }
+    out->stats.num_entries_scanned_post_filter = out->stats.num_docs_scanned * (int64_t)projected.size();
+    for (int c : lane_cols) {
+      FlatQuery lane;
+      std::vector<FilterExpr> both;
+      if (has_filter) both.push_back(filter_trues);
+      both.push_back(NullRewriter::null_leaf(c, true));
+      lane.emit(NullRewriter::combine(PG_FILTER_AND, std::move(both)));
+      lane.finish(*q);
+      lane.q.group_by_columns = keys.data();
+      lane.q.num_groups_limit = kMaxGroupSlots;            // which groups exist is the base lane's decision: this lane reports all of its own
+      std::vector<int> pos;
+      for (int a = 0; a < na; ++a) if (q->aggregations[a].column == c) { lane.aggs.push_back(q->aggregations[a]); pos.push_back(a); }
+      lane.q.aggregations = lane.aggs.data(); lane.q.num_aggregations = (int32_t)lane.aggs.size();
+      memset(&part, 0, sizeof(part));
+      st = execute_impl(seg, &lane.q, &part, nullptr, nullptr, 0, nullptr, false);
+      if (st != PG_OK) { pg_result_free(&part); return st; }
+      // both id lists ascend: one merge pass; lane groups the base lane did not admit (numGroupsLimit) are dropped
+      int k = 0;
+      for (int j = 0; j < part.num_groups; ++j) {
+        while (k < num_groups && out->group_ids[k] < part.group_ids[j]) ++k;
+        if (k == num_groups) break;
+        if (out->group_ids[k] != part.group_ids[j]) continue;
+        for (size_t i = 0; i < pos.size(); ++i) out->group_aggregations[(size_t)k * (size_t)na + (size_t)pos[i]] = part.group_aggregations[(size_t)j * (size_t)part.num_aggregations + i];
+      }
+      out->device_ms += part.device_ms;
+      if (part.dominant_kernel_ms > out->dominant_kernel_ms) { out->dominant_kernel_ms = part.dominant_kernel_ms; out->dominant_kernel = part.dominant_kernel; }
+      pg_result_free(&part);
+    }
+    return PG_OK;
   }
   if (lane_cols.empty()) return execute_impl(seg, &base.q, out, nullptr, nullptr, 0, nullptr);
 
@@ -2862,10 +2990,15 @@ pg_status pg_query_check(const pg_segment* segment, const pg_query* query) {
   if (na < 0 || ng < 0 || (na > 0 && !query->aggregations) || (ng > 0 && !query->group_by_columns)) return fail(PG_ERR_INVALID_ARGUMENT, "bad aggregation / group-by lists");
   bool lanes = false;
   for (int a = 0; a < na; ++a) lanes |= rw.has_nulls(query->aggregations[a].column);
+  std::vector<int32_t> keys;
   if (ng > 0) {
-    bool nullable = lanes;
-    for (int g = 0; g < ng; ++g) nullable |= rw.has_nulls(query->group_by_columns[g]);
-    if (nullable) return fail(PG_ERR_UNSUPPORTED, "GROUP BY over columns with null docs under null handling keeps the CPU plan");
+    // nullable keys are read through their null-key images (one more digit value each: the key space grows)
+    for (int g = 0; g < ng; ++g) {
+      const int c = query->group_by_columns[g];
+      if (rw.has_nulls(c) && segment->cols[(size_t)c].nullkey_column < 0) return fail(PG_ERR_UNSUPPORTED, "GROUP BY over nullable raw column keeps the CPU plan");
+      keys.push_back(rw.has_nulls(c) ? segment->cols[(size_t)c].nullkey_column : c);
+    }
+    base.q.group_by_columns = keys.data();
   }
   return check_query_plan(segment, &base.q, lanes ? 1 : 0);
 }

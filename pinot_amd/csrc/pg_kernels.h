@@ -2245,6 +2245,31 @@ __device__ __forceinline__ uint32_t read_packed(const uint8_t* fwd, long long do
   return (uint32_t)((win >> (64 - s - b)) & ((1ull << b) - 1ull));
 }
 
+// Null-key image of a nullable dictionary column (pg_engine.hip, GROUP BY under enableNullHandling): the same fixed-bit stream with
+// dictId = cardinality wherever the doc is null, `bits_out` wide.  Lane-private layout like the scan kernels: a lane owns 32 docs of a
+// 2048-doc tile = bits_in dwords in, bits_out dwords out, written MSB-first like PinotDataBitSet.writeInt.
+static __global__ __launch_bounds__(256) void build_nullkey_fwd_kernel(const uint8_t* __restrict__ fwd, int bits_in, const unsigned long long* __restrict__ nulls,
+                                                                       uint8_t* __restrict__ out, int bits_out, uint32_t null_id, int num_tiles) {
+  const int lane = threadIdx.x & 63;
+  for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < (long long)num_tiles; tile += (long long)gridDim.x * 4) {
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(fwd + tile * (256ll * bits_in)) + lane * bits_in;
+    uint32_t d[32];
+    decode16_private_dispatch<0>(bits_in, words, *reinterpret_cast<uint32_t(*)[16]>(&d[0]));
+    decode16_private_dispatch<1>(bits_in, words, *reinterpret_cast<uint32_t(*)[16]>(&d[16]));
+    const uint32_t null_mask = reinterpret_cast<const uint32_t*>(nulls)[tile * 64 + lane];      // the lane's 32 docs are one dword of the doc-order bitmap
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + tile * (256ll * bits_out)) + lane * bits_out;
+    unsigned long long acc = 0ull;
+    int have = 0, k = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const uint32_t id = ((null_mask >> j) & 1u) ? null_id : d[j];
+      acc = (acc << bits_out) | (unsigned long long)id;
+      have += bits_out;
+      if (have >= 32) { dst[k++] = __builtin_bswap32((uint32_t)(acc >> (have - 32))); have -= 32; }
+    }
+  }
+}
+
 // Wide value plane (pg_engine.hip want_wide_plane): out[doc] = the 8-byte dictionary entry of the doc's dictId, big-endian like the
 // value area of a raw LONG / DOUBLE forward index.  One-time build per column: a plain gather.
 static __global__ __launch_bounds__(256) void materialize_wide_plane_kernel(const uint8_t* __restrict__ fwd, int bits, const unsigned long long* __restrict__ dict64,

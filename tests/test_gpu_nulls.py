@@ -108,13 +108,22 @@ def test_aggregation_lanes_skip_the_nulls_of_their_own_column(engine, num_docs):
         slow = seg.execute(Q.QuerySpec([(Q.COUNT, -1), (Q.MAX, 0)], null_handling=True))
         assert fast.stats[2] == 0 and slow.stats[2] == num_docs and slow.aggregations[1].count == int((~nulls["c1"]).sum())
         H.assert_results_equal(slow, oracle.execute(data, Q.QuerySpec([(Q.COUNT, -1), (Q.MAX, 0)], null_handling=True)))
-        # GROUP BY: accepted without nulls in keys / aggregated columns, rejected at plan time otherwise
-        ok = Q.QuerySpec([(Q.SUM, 2), (Q.COUNT, -1)], filter=NC.tree_for(data, ["NOT", ["GT", "c1", 0]]), group_by=[2], null_handling=True)
-        H.assert_results_equal(seg.execute(ok), oracle.execute(data, ok))
-        for bad in (Q.QuerySpec([(Q.SUM, 2)], group_by=[0], null_handling=True), Q.QuerySpec([(Q.SUM, 0)], group_by=[2], null_handling=True)):
-            with pytest.raises(_abi.PinotGpuError) as e:
-                seg.execute(bad)
-            assert e.value.status == _abi.PG_ERR_UNSUPPORTED
+        # GROUP BY under null handling: NULL is a key of its own (the key column's null-key image), every function skips the nulls of
+        # its own column (one lane per nullable aggregated column, merged by group id); numGroupsLimit binds at any key-space size
+        for keys in ([2], [0], [1, 0], [0, 2, 1], [3]):
+            for tree in (None, ["NOT", ["GT", "c1", 0]], ["OR", ["GT", "c3", 5], ["NOT", ["LT", "c2", 5]]]):
+                for aggs in ([(Q.SUM, 2), (Q.COUNT, -1)], [(Q.COUNT, -1), (Q.SUM, 0), (Q.COUNT, 1), (Q.MIN, 1), (Q.MAX, 0), (Q.AVG, 2), (Q.SUM, 2)], [(Q.SUM, 3), (Q.AVG, 3), (Q.MAX, 0)]):
+                    spec = Q.QuerySpec(aggs, filter=NC.tree_for(data, tree) if tree else None, group_by=keys, null_handling=True)
+                    H.assert_results_equal(seg.execute(spec), oracle.execute(data, spec))
+        for limit in (3, 5, 41):
+            spec = Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0)], group_by=[0], null_handling=True, num_groups_limit=limit)
+            got, want = seg.execute(spec), oracle.execute(data, spec)
+            H.assert_results_equal(got, want)
+            assert got.num_groups_limit_reached == want.num_groups_limit_reached
+        # a raw nullable column cannot be a key on either side (group-by keys are dictionary columns)
+        with pytest.raises(_abi.PinotGpuError) as e:
+            seg.execute(Q.QuerySpec([(Q.COUNT, -1)], group_by=[4], null_handling=True))
+        assert e.value.status in (_abi.PG_ERR_UNSUPPORTED, _abi.PG_ERR_INVALID_ARGUMENT)
     finally:
         seg.close()
 

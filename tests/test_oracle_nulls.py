@@ -113,8 +113,77 @@ def test_aggregations_skip_nulls_per_column_and_count_column():
     # without the option the stored default null values are aggregated like any other value
     plain = oracle.execute(seg, Q.QuerySpec([(Q.MIN, 0), (Q.COUNT, 0)]))
     assert plain.aggregations[0].min == float(-2 ** 31) and plain.aggregations[1].count == seg.num_docs
-    # group-by over nullable columns is not restated (the reference leaves the dictionary-based key generator)
-    with pytest.raises(oracle.OracleError):
-        oracle.execute(seg, Q.QuerySpec([(Q.SUM, 2)], group_by=[0], null_handling=True))
     ok = oracle.execute(seg, Q.QuerySpec([(Q.SUM, 2)], group_by=[2], null_handling=True))
     assert sum(v[0].count for v in ok.groups.values()) == seg.num_docs
+
+
+def brute_force_groups(seg, values, nulls, keys, aggs, flt):
+    """GROUP BY under enableNullHandling, doc by doc: NULL is a key value of its own (digit = cardinality on the ABI's raw-key scale),
+    every function skips the null docs of its own column (DefaultGroupByExecutor.java:106-121, NullableSingleInputAggregationFunction)."""
+    names = [c.name for c in seg.columns]
+    digits, radix = [], []
+    for k in keys:
+        col = seg.columns[k]
+        has_nulls = bool(nulls[names[k]].any())
+        d = np.searchsorted(col.dict_values, values[names[k]]).astype(np.int64)
+        if has_nulls:
+            d[nulls[names[k]]] = col.cardinality
+        digits.append(d)
+        radix.append(col.cardinality + (1 if has_nulls else 0))
+    raw, mult = np.zeros(seg.num_docs, dtype=np.int64), 1
+    for d, r in zip(digits, radix):
+        raw += d * mult
+        mult *= r
+    out = {}
+    for gid in np.unique(raw[flt]):
+        m = flt & (raw == gid)
+        row = []
+        for f, c in aggs:
+            if f == Q.COUNT and c < 0:
+                row.append((int(m.sum()), None))
+                continue
+            mm = m & ~nulls[names[c]]
+            v = values[names[c]][mm].astype(np.int64)
+            row.append((int(mm.sum()), {Q.COUNT: None, Q.SUM: int(v.sum()), Q.AVG: int(v.sum()), Q.MIN: float(v.min()) if len(v) else np.inf,
+                                        Q.MAX: float(v.max()) if len(v) else -np.inf}[f]))
+        out[int(gid)] = row
+    return out
+
+
+def check_groups(res, want, aggs):
+    assert sorted(res.groups) == sorted(want)
+    for gid, row in want.items():
+        for (f, _), (count, value), got in zip(aggs, row, res.groups[gid]):
+            assert got.count == count, (gid, f, got.count, count)
+            if f in (Q.SUM, Q.AVG):
+                assert got.sum_i64 == value
+            if f == Q.MIN:
+                assert got.min == value
+            if f == Q.MAX:
+                assert got.max == value
+
+
+def test_group_by_under_null_handling_against_a_per_doc_restatement():
+    rng = np.random.default_rng(11)
+    seg, values, nulls = random_nullable_segment(rng, 20000)
+    tree = ["OR", ["GT", "c3", 0], ["NOT", ["LT", "c2", 5]]]
+    for flt_tree in (None, tree):
+        flt = NC.reference_trues(flt_tree, values, nulls, seg.num_docs) if flt_tree else np.ones(seg.num_docs, bool)
+        for keys in ([0], [2], [1, 0], [0, 2, 1]):
+            aggs = [(Q.COUNT, -1), (Q.SUM, 0), (Q.COUNT, 1), (Q.MIN, 1), (Q.MAX, 0), (Q.AVG, 2), (Q.SUM, 2)]
+            spec = Q.QuerySpec(aggs, filter=NC.tree_for(seg, flt_tree) if flt_tree else None, group_by=keys, null_handling=True)
+            res = oracle.execute(seg, spec)
+            check_groups(res, brute_force_groups(seg, values, nulls, keys, aggs, flt), aggs)
+            assert res.stats[0] == int(flt.sum())
+    # numGroupsLimit binds at any key-space size (the no-dictionary generators): the first `limit` keys in docId order survive
+    spec = Q.QuerySpec([(Q.COUNT, -1)], group_by=[0], null_handling=True, num_groups_limit=5)
+    res = oracle.execute(seg, spec)
+    d = np.searchsorted(seg.columns[0].dict_values, values["c1"]).astype(np.int64)
+    d[nulls["c1"]] = seg.columns[0].cardinality
+    first = []
+    for x in d:
+        if x not in first:
+            first.append(int(x))
+        if len(first) == 5:
+            break
+    assert sorted(res.groups) == sorted(first) and res.num_groups_limit_reached
