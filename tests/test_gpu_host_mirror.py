@@ -228,3 +228,24 @@ def test_datatable_v4_of_the_golden_queries(golden_segments):
     assert back["names"] == ["column11", "sum(column1)"] and back["types"] == ["STRING", "DOUBLE"]
     assert sorted(back["rows"]) == sorted([r["key"][0], r["intermediate"][0]] for r in combined["groups"])
     assert sorted(back["rows"]) == sorted(g["inter_segment_group_by_x4"]["sum_column1_by_column11"])
+
+
+def test_execute_combined_over_segments_on_different_devices():
+    """CombinePlanNode over segments that live on different GPUs of the node (one segment per device, host-side merge: SURVEY 8(e)).
+    Needs two visible devices: skipped on the single-GPU test boxes, run wherever the node has more."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device")
+    host.init_plan_maker(device=0, time_kernels=True)
+    data = H.golden_segment()
+    segs = [host.HostSegment(data, string_dicts=data.string_dicts, device=d) for d in (0, 1, 0, 1)]
+    try:
+        g = H.load_golden_queries()["inter_segment_x4"]
+        for key, flt in (("unfiltered", ""), ("filtered", FILTER)):
+            combined = host.execute_sql(segs, "SELECT COUNT(*), SUM(column1), SUM(column3) FROM testTable" + flt, max_execution_threads=4)["combined"]
+            assert combined["final"] == [float(g["count"][key]), g["sum_column1"][key], g["sum_column3"][key]]
+        rows = host.execute_sql(segs, "SELECT SUM(column1) FROM testTable GROUP BY column11")["combined"]["groups"]
+        assert sorted([r["key"][0], r["final"][0]] for r in rows) == sorted(H.load_golden_queries()["inter_segment_group_by_x4"]["sum_column1_by_column11"])
+    finally:
+        for s in segs:
+            s.destroy()
