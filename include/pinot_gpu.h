@@ -193,10 +193,12 @@ typedef struct pg_query {
   int32_t num_group_by;              /* 0 = aggregation only */
   const int32_t* group_by_columns;   /* dictionary-encoded columns; group id = raw key = sum dictId_j * prod_{k<j} card_k
                                       * (DictionaryBasedGroupKeyGenerator.java:298-338,437-445).  Product of cardinalities <= 10 000: the
-                                      * reference's ArrayBasedHolder.  Up to 2^24: its IntMapBasedHolder range -- the same raw keys come back
+                                      * reference's ArrayBasedHolder.  Up to Integer.MAX_VALUE: its IntMapBasedHolder range -- the same raw keys come back
                                       * (the reference's insertion-order group ids are internal to its hash map), at most num_groups_limit of
                                       * them: the groups whose first doc comes earliest, exactly those IntGroupIdMap.getGroupId :1022-1047
-                                      * would have admitted.  Beyond 2^24 (Long / ArrayMap holders): PG_ERR_UNSUPPORTED at plan time. */
+                                      * would have admitted.  The table is direct-indexed in HBM, 8 * (1 + distinct aggregations) bytes per raw
+                                      * key, at most PINOT_GPU_GROUP_TABLE_BYTES (default 64 GiB of the 288) per query.  Beyond an int (Long /
+                                      * ArrayMap holders) or beyond that budget: PG_ERR_UNSUPPORTED at plan time. */
   int32_t num_groups_limit;          /* InstancePlanMakerImplV2 numGroupsLimit (default 100000); 0 = default */
   int32_t flags;                     /* PG_QUERY_* */
 } pg_query;

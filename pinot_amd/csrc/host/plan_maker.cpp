@@ -399,8 +399,9 @@ std::unique_ptr<LoweredQuery> lowerQuery(const ImmutableSegment& seg, const Quer
     if (!ds.hasDictionary) throw UnsupportedOperationException("group-by on a raw column uses the no-dictionary key generator (CPU plan)");
     product *= ds.cardinality + ((qc.nullHandlingEnabled && ds.nullValueVector != nullptr && ds.nullValueVectorSize > 0) ? 1 : 0);   // NULL is a key value of its own
     // DictionaryBasedGroupKeyGenerator.java:164-184: ArrayBasedHolder up to arrayBasedThreshold, IntMapBasedHolder above it -- both are
-    // one direct-indexed device table (at most 2^24 slots); the Long / ArrayMap holders beyond that keep the CPU plan
-    if (product > (1ll << 24)) throw UnsupportedOperationException("group-by cardinality product exceeds the device's direct-indexed table (2^24 raw keys)");
+    // one direct-indexed device table while the raw key is an int (pg_query_check also prices the table against the device's budget);
+    // the Long / ArrayMap holders beyond that keep the CPU plan
+    if (product > 0x7FFFFFFFll) throw UnsupportedOperationException("group-by cardinality product exceeds the int raw-key range of the device's direct-indexed table");
     lq->groupBy.push_back(seg.getColumnIndex(g));
   }
   pg_query& q = lq->query;

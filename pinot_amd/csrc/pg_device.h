@@ -236,12 +236,12 @@ struct GroupParams {
   ScanParams scan;
   int32_t num_group_cols;
   int32_t num_group_aggs;
-  int32_t num_groups;              // product of cardinalities = slots of the direct-indexed table (<= 2^24)
+  int32_t num_groups;              // product of cardinalities = slots of the direct-indexed table (an int: the IntMapBasedHolder range)
   int32_t use_lds_table;
   int32_t packed_agg;              // >= 0: that SUM slot of the LDS table also carries the group's doc count in its high bits
   int32_t packed_shift;            //       (count << packed_shift) | sum ; no separate count atomic
   int32_t dense_ok;                // 1: every aggregation is in the 32-bit value domain (the dense 16-step path applies)
-  int32_t pad;
+  int32_t wide_keys;               // 1: num_groups > 2^24, so dictIds / multipliers may not fit the full-rate 24-bit multiply
   DevGroupKey group_keys[kMaxGroupCols];
   DevGroupAgg group_aggs[kMaxGroupAggs];
   unsigned long long* table_count; // [num_groups]

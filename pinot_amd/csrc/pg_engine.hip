@@ -70,6 +70,7 @@ struct Engine {
   bool scan_typed_private = true;     // PINOT_GPU_SCAN_TYPED_PRIVATE=0: raw / 8-byte aggregated columns stay in the LDS-staged kernel
   bool group_partition = true;        // PINOT_GPU_GROUP_PARTITION=0: key spaces above the LDS table always use direct HBM atomics
   long long partition_min_docs = 1ll << 22;   // ... =force: partition even tiny segments (tests)
+  unsigned long long group_table_bytes = 64ull << 30;      // PINOT_GPU_GROUP_TABLE_BYTES: largest direct-indexed group table a query may ask for
   int hist = -1;             // PINOT_GPU_HIST: -1 auto, 0 never, 1 also for arithmetic-progression dictionaries (tests)
   int hist_blocks = 0;       // PINOT_GPU_HIST_BLOCKS: cap on the histogram kernel's workgroups (tests: many docs per counter from a small segment)
   bool hist_guard = false;   // PINOT_GPU_HIST_GUARD=1: start every column in the guarded tier (tests)
@@ -282,7 +283,9 @@ pg_status ensure_set(ExecCtx* c, size_t index, size_t bytes) {
   return PG_OK;
 }
 
-constexpr int kMaxGroupSlots = 1 << 24;
+constexpr int kMaxGroupSlots = 0x7FFFFFFF;        // raw keys are ints: the reference's ArrayBasedHolder + IntMapBasedHolder range (DictionaryBasedGroupKeyGenerator.java:164-184)
+constexpr size_t kGroupTableKeepBytes = 1ull << 31; // a direct-indexed table above this is freed after the query instead of staying with the context
+constexpr size_t kArenaKeepBytes = 1ull << 30;      // same for the scratch arena
 
 // hipMalloc'ed scratch of one query, released when it goes out of scope (rare paths only: the hot paths reuse ExecCtx buffers)
 // Device scratch of one query, carved out of the context's arena; what does not fit is allocated for the query alone and the arena
@@ -311,7 +314,7 @@ struct DeviceScratch {
   }
   ~DeviceScratch() {
     for (void* p : overflow) (void)hipFree(p);
-    ctx->arena_wanted = std::max(ctx->arena_wanted, wanted);
+    ctx->arena_wanted = std::max(ctx->arena_wanted, std::min(wanted, kArenaKeepBytes));      // larger requests stay one-off allocations
   }
 };
 
@@ -330,8 +333,12 @@ pg_status ensure_host_groups(ExecCtx* c, size_t bytes) {
 pg_status ensure_table(ExecCtx* c, size_t words, size_t host_words) {
   if (c->table_capacity < words) {
     if (c->d_table) (void)hipFree(c->d_table);
-    c->d_table = nullptr;
-    HIP_TRY(hipMalloc((void**)&c->d_table, words * 8));
+    c->d_table = nullptr; c->table_capacity = 0;
+    if (hipMalloc((void**)&c->d_table, words * 8) != hipSuccess) {
+      (void)hipGetLastError();
+      c->d_table = nullptr;
+      return fail(PG_ERR_OUT_OF_MEMORY, "group-by table of %zu bytes does not fit the device", words * 8);
+    }
     c->table_capacity = words;
   }
   if (c->h_table_capacity < host_words) {
@@ -1388,6 +1395,8 @@ pg_status pg_init(const pg_config* config) {
   const char* gpt = getenv("PINOT_GPU_GROUP_PARTITION");
   g_engine.group_partition = !(gpt && gpt[0] == '0');
   g_engine.partition_min_docs = (gpt && gpt[0] == 'f') ? 0 : (1ll << 22);
+  const char* gtb = getenv("PINOT_GPU_GROUP_TABLE_BYTES");
+  g_engine.group_table_bytes = (gtb && atoll(gtb) > 0) ? (unsigned long long)atoll(gtb) : (64ull << 30);
   const char* gpk = getenv("PINOT_GPU_GROUP_PACK");
   g_engine.group_pack = !(gpk && gpk[0] == '0');
   const char* gw = getenv("PINOT_GPU_GROUP_WAVES");
@@ -1806,7 +1815,7 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
     const ColumnDev& col = seg->cols[(size_t)c];
     if (col.encoding != PG_FWD_FIXED_BIT_DICT) return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s", col.name.c_str());
     product *= std::max(col.cardinality, 1);
-    if (product > kMaxGroupSlots) return fail(PG_ERR_UNSUPPORTED, "group-by cardinality product exceeds %d direct-indexed slots (Long / ArrayMap holders keep the CPU plan)", kMaxGroupSlots);
+    if (product > kMaxGroupSlots) return fail(PG_ERR_UNSUPPORTED, "group-by cardinality product exceeds the int raw-key range (%d): Long / ArrayMap holders keep the CPU plan", kMaxGroupSlots);
     if (std::find(key_cols.begin(), key_cols.end(), c) == key_cols.end()) key_cols.push_back(c);
   }
   std::vector<std::pair<int, int>> group_aggs;     // distinct (column, SUM | MIN | MAX)
@@ -1837,6 +1846,9 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
   }
   if (ng == 0 && (int)agg_cols.size() > kMaxAggCols) return fail(PG_ERR_UNSUPPORTED, "more than %d aggregated columns", kMaxAggCols);
   if ((int)group_aggs.size() > kMaxGroupAggs) return fail(PG_ERR_UNSUPPORTED, "more than %d distinct group-by aggregations", kMaxGroupAggs);
+  if (ng > 0 && (unsigned long long)product * (1ull + group_aggs.size()) * 8ull > g_engine.group_table_bytes)
+    return fail(PG_ERR_UNSUPPORTED, "group-by table of %lld slots x %zu words exceeds the %llu-byte budget (PINOT_GPU_GROUP_TABLE_BYTES)", product, 1 + group_aggs.size(),
+                (unsigned long long)g_engine.group_table_bytes);
   // Column streams, as slot_for hands them out: (column, read through its value plane?).  A column summed through its plane is read
   // through the plane by everything that can be (its other aggregations, a dictId-range leaf on it); set leaves and group keys read
   // the dictIds.  Which summed columns have a plane is want_value_plane's decision; the histogram path, which reads the dictIds
@@ -2247,7 +2259,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       // DictionaryBasedGroupKeyGenerator.java:164-184: up to arrayBasedThreshold (10 000) the raw key IS the group id (ArrayBasedHolder);
       // above it the reference hashes raw keys (IntMapBasedHolder) -- here the table stays direct-indexed, in HBM, one slot per raw
       // key, and only the groups that exist come back.  2^24 slots keep the 24-bit key multiplies exact and the table <= 1.2 GB.
-      if (product > kMaxGroupSlots) return fail(PG_ERR_UNSUPPORTED, "group-by cardinality product exceeds %d direct-indexed slots (Long / ArrayMap holders keep the CPU plan)", kMaxGroupSlots);
+      if (product > kMaxGroupSlots) return fail(PG_ERR_UNSUPPORTED, "group-by cardinality product exceeds the int raw-key range (%d): Long / ArrayMap holders keep the CPU plan", kMaxGroupSlots);
     }
     // (kQueryHashHolder: the no-dictionary key generators of null handling hand out group ids by first appearance up to numGroupsLimit
     //  whatever the key space: the compaction path below is the one that honours the limit)
@@ -2276,9 +2288,19 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       }
       dev_agg_of[(size_t)a] = da;
     }
+    gp.wide_keys = product > (1ll << 24) ? 1 : 0;
     const size_t table_words = (size_t)gp.num_groups * (size_t)(1 + gp.num_group_aggs);
+    if ((unsigned long long)table_words * 8ull > g_engine.group_table_bytes)
+      return fail(PG_ERR_UNSUPPORTED, "group-by table of %lld slots x %d words exceeds the %llu-byte budget (PINOT_GPU_GROUP_TABLE_BYTES)", product, 1 + gp.num_group_aggs,
+                  (unsigned long long)g_engine.group_table_bytes);
     st = ensure_table(ctx, table_words, map_based ? 0 : table_words);
     if (st != PG_OK) return st;
+    struct TableTrim {            // a table of the upper IntMapBasedHolder range goes back to the allocator with the query
+      ExecCtx* c;
+      ~TableTrim() {
+        if (c->table_capacity * 8 > kGroupTableKeepBytes) { (void)hipFree(c->d_table); c->d_table = nullptr; c->table_capacity = 0; }
+      }
+    } table_trim{ctx};
     gp.table_count = ctx->d_table;
     gp.table_acc = reinterpret_cast<long long*>(ctx->d_table + gp.num_groups);
     const size_t table_bytes = table_words * 8;
@@ -2357,7 +2379,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     gp.scan.tile_list = lw.tile_list;            // read by group_private_kernel only
     gp.scan.tile_count = lw.tile_count;
     gp.scan.filter_entries = nullptr;
-    init_group_table_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(gp);
+    init_group_table_kernel<<<dim3((unsigned)std::max<long long>(64, std::min<long long>(product >> 12, (long long)seg->num_cus * 16))), dim3(256), 0, ctx->stream>>>(gp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // Key spaces above the LDS table: partition the docs by key range first, then aggregate every partition in LDS
@@ -2487,7 +2509,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       // (_globalGroupIdUpperBound = min(product, numGroupsLimit), DictionaryBasedGroupKeyGenerator.java:176).
       const int limit = q->num_groups_limit > 0 ? q->num_groups_limit : 100000;
       const long long bound = std::min<long long>(product, limit);
-      const int num_chunks = (gp.num_groups + kGroupChunk - 1) / kGroupChunk;
+      const int num_chunks = (int)(((long long)gp.num_groups + kGroupChunk - 1) / kGroupChunk);
       DeviceScratch scratch(ctx);
       uint32_t* d_chunk_counts = (uint32_t*)scratch.alloc((size_t)num_chunks * 4);
       uint32_t* d_chunk_offsets = (uint32_t*)scratch.alloc((size_t)(num_chunks + 1) * 4);

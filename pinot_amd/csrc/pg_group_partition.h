@@ -35,7 +35,7 @@ __device__ __forceinline__ void decode_group_keys(const GroupParams& gp, long lo
       uint32_t d[16];
       if (h == 0) decode16_private_dispatch<0>(b, words, d); else decode16_private_dispatch<1>(b, words, d);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : __umul24(d[j], mult) + g[16 * h + j];
+      for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : key_term(d[j], mult, gp.wide_keys != 0) + g[16 * h + j];
     }
   }
 }

@@ -912,6 +912,13 @@ __device__ __forceinline__ void group_max(long long* slot, int32_t v) {
   else __hip_atomic_fetch_max(slot, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// One term of the raw key, dictId * multiplier (DictionaryBasedGroupKeyGenerator.java:437-445).  Up to 2^24 slots both factors
+// fit the full-rate 24-bit multiply; `wide` (uniform: GroupParams::wide_keys) takes the 32-bit one.
+__device__ __forceinline__ uint32_t key_term(uint32_t d, uint32_t mult, bool wide) {
+  if (wide) return d * mult;
+  return __umul24(d, mult);
+}
+
 // Aggregate four docs per lane (steps k[0..3]) into the group table.  kAllActive: every lane owns four real matching
 // docs (no exec masking around the atomics).
 template <bool kLds, bool kAllActive>
@@ -928,10 +935,10 @@ __device__ __forceinline__ void group_process4(const GroupParams& gp, const uint
     const uint32_t mult = (uint32_t)key.mult;
     if (b <= 25) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] += __umul24(decode_step<false>(slot, dec, k[j], b), mult);   // both < 2^24
+      for (int j = 0; j < 4; ++j) g[j] += key_term(decode_step<false>(slot, dec, k[j], b), mult, gp.wide_keys != 0);
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] += __umul24(decode_step<true>(slot, dec, k[j], b), mult);
+      for (int j = 0; j < 4; ++j) g[j] += key_term(decode_step<true>(slot, dec, k[j], b), mult, gp.wide_keys != 0);
     }
   }
   const bool packed = kLds && gp.packed_agg >= 0;
@@ -1045,9 +1052,8 @@ __device__ __forceinline__ void group_dense16(const GroupParams& gp, const uint8
     for (int h = 0; h < 2; ++h) {
       uint32_t d[8];
       decode_steps8(slot, dec, k0 + 8 * h, b, d);
-      // dictIds and multipliers are below 2^24 (the product of the cardinalities is at most 10 000): full-rate 24-bit multiply
 #pragma unroll
-      for (int j = 0; j < 8; ++j) g[8 * h + j] = c == 0 ? d[j] : __umul24(d[j], mult) + g[8 * h + j];
+      for (int j = 0; j < 8; ++j) g[8 * h + j] = c == 0 ? d[j] : key_term(d[j], mult, gp.wide_keys != 0) + g[8 * h + j];
     }
   }
   const bool packed = kLds && gp.packed_agg >= 0;
@@ -1582,7 +1588,7 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
       uint32_t d[16];
       if (h == 0) decode16_private_dispatch<0>(b, words, d); else decode16_private_dispatch<1>(b, words, d);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : __umul24(d[j], mult) + g[16 * h + j];
+      for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : key_term(d[j], mult, gp.wide_keys != 0) + g[16 * h + j];
     }
   }
   const bool packed = kLds && gp.packed_agg >= 0;
@@ -1699,8 +1705,8 @@ __global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const
 }
 
 static __global__ void init_group_table_kernel(GroupParams gp) {
-  const int G = gp.num_groups;
-  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x) {
+  const long long G = gp.num_groups;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += (long long)gridDim.x * blockDim.x) {
     gp.table_count[g] = 0ull;
     for (int a = 0; a < gp.num_group_aggs; ++a) {
       const int kind = gp.group_aggs[a].kind;

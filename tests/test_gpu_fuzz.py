@@ -153,7 +153,7 @@ def test_random_null_vectors_null_handling_and_wide_group_bys(engine, seed):
             try:
                 got = g.execute(spec)
             except _abi.PinotGpuError as e:
-                assert e.status == _abi.PG_ERR_UNSUPPORTED, e      # plan-time fallbacks: leaf / node tables, nullable group-by, > 2^24 keys
+                assert e.status == _abi.PG_ERR_UNSUPPORTED, e      # plan-time fallbacks: leaf / node tables, key spaces beyond an int
                 continue
             want = oracle.execute(seg, spec)
             H.assert_results_equal(got, want, check_stats=False)

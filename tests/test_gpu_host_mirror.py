@@ -131,10 +131,24 @@ def test_medium_group_by_golden_and_num_groups_limit_through_sql(golden_segments
     assert limited["stats"]["numDocsScanned"] == 30000
 
 
+def test_group_by_over_144_million_raw_keys(golden_segments):
+    """GROUP BY column1, column3: 6582 * 21910 raw keys, the upper IntMapBasedHolder range, one direct-indexed table in HBM."""
+    d, segs = golden_segments
+    d = H.load_golden_columns()
+    got = host.execute_sql(segs[:1], "SELECT COUNT(*), SUM(column6) FROM testTable GROUP BY column1, column3")["segments"][0]
+    want = {}
+    for a, b, c in zip(d["column1"].tolist(), d["column3"].tolist(), d["column6"].tolist()):
+        e = want.setdefault((a, b), [0, 0.0])
+        e[0] += 1
+        e[1] += float(c)
+    assert {tuple(r["key"]): r["intermediate"] for r in got["groups"]} == want
+    assert got["stats"]["numDocsScanned"] == 30000 and not got["numGroupsLimitReached"]
+
+
 def test_plan_time_rejection_and_errors(golden_segments):
     _, segs = golden_segments
     for sql, status in (("SELECT column1 FROM testTable", 2),
-                        ("SELECT SUM(column1) FROM testTable GROUP BY column1, column3", 2),     # 6582 * 21910 > 2^24 direct-indexed raw keys
+                        ("SELECT SUM(column1) FROM testTable GROUP BY column1, column3, column6", 2),     # 6582 * 21910 * 608 raw keys are not an int
                         ("SELECT SUM(nope) FROM testTable", 1),
                         ("SELECT SUM(column11) FROM testTable", 1),
                         ("SELECT SUM(column1) FROM testTable WHERE column1 = 'abc'", 1)):

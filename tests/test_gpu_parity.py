@@ -196,8 +196,38 @@ def test_group_by_multiple_keys_and_global_table(engine):
     assert got.group_id_upper_bound == 90 * 11 * 5000 and len(got.groups) > 10000
     with engine.open(seg) as gseg:
         with pytest.raises(_abi.PinotGpuError) as e:
-            gseg.execute(Q.QuerySpec(aggs, group_by=[3, 3]))      # 5000 * 5000 > 2^24 direct-indexed slots
+            gseg.execute(Q.QuerySpec(aggs, group_by=[3, 3, 0]))      # 5000 * 5000 * 90 raw keys are not an int: LongMapBasedHolder, CPU plan
         assert e.value.status == _abi.PG_ERR_UNSUPPORTED
+
+
+def test_group_by_whole_int_map_range(engine):
+    """Cardinality products up to Integer.MAX_VALUE stay one direct-indexed HBM table (IntMapBasedHolder's range,
+    DictionaryBasedGroupKeyGenerator.java:164-184): above 2^24 slots the key multiplies leave the 24-bit form."""
+    rng = np.random.default_rng(41)
+    n = 150001
+    k1, id1, _ = H.random_dict_column(rng, "k1", n, 5000)
+    k2, id2, _ = H.random_dict_column(rng, "k2", n, 11)
+    v, idv, dvv = H.random_dict_column(rng, "v", n, 3000, value_stride=3)
+    rl = S.Column.raw_typed("rl", rng.integers(-10 ** 12, 10 ** 12, n).astype(np.int64))
+    seg = S.SegmentData("wide", n, [k1, k2, v, rl])
+    aggs = [(Q.COUNT, -1), (Q.SUM, 2), (Q.MAX, 2)]
+    got, _ = run_both(engine, seg, Q.QuerySpec(aggs, group_by=[0, 0]))               # 25 M slots, multiplier 5000
+    assert got.group_id_upper_bound == 25_000_000 and set(got.groups) == set((id1.astype(np.int64) * 5001).tolist())
+    got, _ = run_both(engine, seg, Q.QuerySpec(aggs, group_by=[0, 0, 1]))            # 275 M slots, third multiplier 25 M >= 2^24
+    assert got.group_id_upper_bound == 275_000_000
+    keys = id1.astype(np.int64) * 5001 + id2.astype(np.int64) * 25_000_000
+    assert set(got.groups) == set(keys.tolist())
+    big = int(keys.max())
+    m = keys == big
+    assert got.groups[big][0].count == int(m.sum()) and got.groups[big][1].sum_i64 == int(dvv[idv[m]].astype(np.int64).sum())
+    run_both(engine, seg, Q.QuerySpec(aggs, filter=Q.leaf(Q.Pred.dict_range(2, 100, 900)), group_by=[0, 0, 1]))      # masked lane-private path
+    # a raw LONG range leaf is not in the lane-private filter: the LDS-staged kernel aggregates the same key space
+    run_both(engine, seg, Q.QuerySpec(aggs, filter=Q.leaf(Q.Pred.raw_range(3, -10 ** 11, 10 ** 11)), group_by=[0, 0, 1]))
+    # numGroupsLimit below the groups that exist: the first-doc pass walks the 275 M slots
+    got, want = run_both(engine, seg, Q.QuerySpec(aggs, group_by=[0, 0, 1], num_groups_limit=300))
+    assert len(got.groups) == 300 and got.num_groups_limit_reached
+    # a raw 8-byte aggregation input goes through group_typed_direct_kernel
+    run_both(engine, seg, Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 3), (Q.MIN, 3)], group_by=[0, 0, 1]))
 
 
 @pytest.mark.parametrize("run_optimize", [False, True])
