@@ -52,6 +52,15 @@ uint8_t* ph_datatable_v4_build(int32_t is_group_by, int32_t num_functions, const
                                const uint8_t* is_null, const int64_t* stats, int32_t null_handling, int32_t limit_reached, int32_t segments_processed,
                                int32_t segments_matched, int64_t* out_size, int32_t* status);
 
+/* ---- the group-by table behind the combine operator and the broker's reducer (IndexedTable / TableResizer / GroupByUtils; host/indexed_table.cpp) ---- */
+/* GroupByCombineOperator + GroupByDataTableReducer over group-by blocks given as flat arrays (block b = the next block_rows[b] rows); `sql` supplies
+ * aggregations, GROUP BY, ORDER BY, LIMIT and the trim options.  JSON: {"combined": block, "reduced": rows, "table": sizes}; ph_free it. */
+char* ph_group_by_combine(const char* sql, int32_t num_blocks, const int64_t* block_rows, const int32_t* key_types, const int64_t* key_longs,
+                          const double* key_doubles, const char* const* key_strings, const uint8_t* key_is_null, const int64_t* counts, const double* sums,
+                          const double* mins, const double* maxs, const uint8_t* is_null, int32_t* status);
+int32_t ph_group_by_table_capacity(int32_t limit, int32_t min_num_groups);          /* GroupByUtils.getTableCapacity */
+int32_t ph_group_by_trim_threshold(int32_t trim_size, int32_t trim_threshold);      /* GroupByUtils.getIndexedTableTrimThreshold */
+
 /* ---- writers in the reference's layouts (FixedBitSVForwardIndexWriter, SegmentDictionaryCreator, FixedByteChunkForwardIndexWriter v2,
  *      BitmapInvertedIndexWriter, RoaringBitmap portable serialization) and the synthetic-column generator of the benchmarks ---- */
 int32_t ph_num_bits_per_value(int32_t max_value);

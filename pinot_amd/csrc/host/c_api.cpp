@@ -85,6 +85,82 @@ std::string blockJson(const ResultsBlock& b) {
   return o.str();
 }
 
+// the broker's rows (GroupByDataTableReducer): [[key..., final...], ...] in ORDER BY order, at most LIMIT of them
+std::string reducedJson(const std::vector<ReducedRow>& rows) {
+  std::ostringstream o;
+  o << "[";
+  for (size_t r = 0; r < rows.size(); ++r) {
+    o << (r ? ", " : "") << "[";
+    bool first = true;
+    for (const auto& k : rows[r].keys) {
+      o << (first ? "" : ", ");
+      first = false;
+      if (std::holds_alternative<std::monostate>(k)) o << "null";
+      else if (std::holds_alternative<int64_t>(k)) o << std::get<int64_t>(k);
+      else if (std::holds_alternative<double>(k)) o << num(std::get<double>(k));
+      else o << "\"" << jsonEscape(std::get<std::string>(k)) << "\"";
+    }
+    for (const auto& v : rows[r].finals) {
+      o << (first ? "" : ", ");
+      first = false;
+      if (std::holds_alternative<std::monostate>(v)) o << "null";
+      else if (std::holds_alternative<int64_t>(v)) o << std::get<int64_t>(v);
+      else if (std::holds_alternative<double>(v)) o << num(std::get<double>(v));
+      else o << "\"" << jsonEscape(std::get<std::string>(v)) << "\"";
+    }
+    o << "]";
+  }
+  o << "]";
+  return o.str();
+}
+
+// A results block from flat arrays (ph_datatable_v4_build / ph_group_by_combine: tests drive the writers and the combine without a
+// device): rows [row_begin, row_end) of the arrays.
+ResultsBlock blockFromArrays(bool is_group_by, const std::vector<AggregationFunction>& functions, int32_t num_keys, const char* const* key_names,
+                             const int32_t* key_types, int64_t row_begin, int64_t row_end, const int64_t* key_longs, const double* key_doubles,
+                             const char* const* key_strings, const uint8_t* key_is_null, const int64_t* counts, const double* sums, const double* mins,
+                             const double* maxs, const uint8_t* is_null) {
+  ResultsBlock block;
+  block.isGroupBy = is_group_by;
+  const int num_functions = (int)functions.size();
+  auto value = [&](int64_t row, int f) -> IntermediateResult {
+    const size_t at = (size_t)row * (size_t)num_functions + (size_t)f;
+    if (is_null && is_null[at]) return std::monostate{};
+    switch (functions[(size_t)f].getType()) {
+      case AggregationFunctionType::COUNT: return counts[at];
+      case AggregationFunctionType::SUM: return sums[at];
+      case AggregationFunctionType::MIN: return mins[at];
+      case AggregationFunctionType::MAX: return maxs[at];
+      default: return AvgPair{sums[at], counts[at]};
+    }
+  };
+  if (!block.isGroupBy) {
+    block.aggregation.functions = functions;
+    for (int f = 0; f < num_functions; ++f) block.aggregation.results.push_back(value(row_begin, f));
+    return block;
+  }
+  GroupByResultsBlock& g = block.groupBy;
+  g.functions = functions;
+  for (int k = 0; k < num_keys; ++k) { g.groupByColumns.push_back(key_names[k]); g.groupByTypes.push_back((DataType)key_types[k]); }
+  for (int64_t r = row_begin; r < row_end; ++r) {
+    GroupKey key;
+    key.groupId = (int)(r - row_begin);
+    for (int k = 0; k < num_keys; ++k) {
+      const size_t at = (size_t)r * (size_t)num_keys + (size_t)k;
+      const DataType t = (DataType)key_types[k];
+      if (key_is_null && key_is_null[at]) key.keys.emplace_back(std::monostate{});
+      else if (t == DataType::INT || t == DataType::LONG) key.keys.emplace_back(key_longs[at]);
+      else if (t == DataType::STRING) key.keys.emplace_back(std::string(key_strings[at]));
+      else key.keys.emplace_back(key_doubles[at]);
+    }
+    g.groupKeys.push_back(std::move(key));
+    std::vector<IntermediateResult> row;
+    for (int f = 0; f < num_functions; ++f) row.push_back(value(r, f));
+    g.results.push_back(std::move(row));
+  }
+  return block;
+}
+
 template <typename F>
 int guarded(F f) {
   try { f(); return 0; }
@@ -272,6 +348,18 @@ char* ph_parse_sql(const char* sql, int32_t* status) {
     for (size_t i = 0; i < q.groupByExpressions.size(); ++i) o << (i ? ", " : "") << "\"" << jsonEscape(q.groupByExpressions[i]) << "\"";
     o << "], \"hasFilter\": " << (q.hasFilter ? "true" : "false");
     if (q.nullHandlingEnabled) o << ", \"nullHandling\": true";
+    if (q.hasOrderBy()) {
+      o << ", \"orderBy\": [";
+      for (size_t i = 0; i < q.orderByExpressions.size(); ++i) {
+        const OrderByExpressionContext& ob = q.orderByExpressions[i];
+        const std::string text = ob.isAggregation ? AggregationFunction(q.aggregations[(size_t)ob.index].function, q.aggregations[(size_t)ob.index].column).getResultColumnName()
+                                                  : q.groupByExpressions[(size_t)ob.index];
+        o << (i ? ", " : "") << "{\"expression\": \"" << jsonEscape(text) << "\", \"asc\": " << (ob.isAsc ? "true" : "false") << ", \"nullsLast\": "
+          << (ob.isNullsLast() ? "true" : "false") << "}";
+      }
+      o << "]";
+    }
+    if (q.limit >= 0) o << ", \"limit\": " << q.limit;
     o << "}";
     out = o.str();
   });
@@ -314,7 +402,10 @@ char* ph_execute_sql(void** segments, int32_t num_segments, const char* sql, int
       const ResultsBlock b = op->nextBlock();
       o << (i ? ", " : "") << blockJson(b);
     }
-    o << "], \"combined\": " << blockJson(g_planMaker.executeCombined(ctxs, q, max_execution_threads)) << "}";
+    const ResultsBlock combined = g_planMaker.executeCombined(ctxs, q, max_execution_threads);
+    o << "], \"combined\": " << blockJson(combined);
+    if (combined.isGroupBy) o << ", \"reduced\": " << reducedJson(reduceGroupBy(combined, q));      // what the broker would answer
+    o << "}";
     out = o.str();
   });
   return *status == 0 ? strdup(out.c_str()) : nullptr;
@@ -332,44 +423,10 @@ uint8_t* ph_datatable_v4_build(int32_t is_group_by, int32_t num_functions, const
                                int32_t segments_matched, int64_t* out_size, int32_t* status) {
   std::vector<uint8_t> bytes;
   *status = guarded([&] {
-    ResultsBlock block;
-    block.isGroupBy = is_group_by != 0;
     std::vector<AggregationFunction> functions;
     for (int f = 0; f < num_functions; ++f) functions.emplace_back((AggregationFunctionType)function_types[f], function_columns[f], null_handling != 0);
-    auto value = [&](int64_t row, int f) -> IntermediateResult {
-      const size_t at = (size_t)row * (size_t)num_functions + (size_t)f;
-      if (is_null && is_null[at]) return std::monostate{};
-      switch (functions[(size_t)f].getType()) {
-        case AggregationFunctionType::COUNT: return counts[at];
-        case AggregationFunctionType::SUM: return sums[at];
-        case AggregationFunctionType::MIN: return mins[at];
-        case AggregationFunctionType::MAX: return maxs[at];
-        default: return AvgPair{sums[at], counts[at]};
-      }
-    };
-    if (!block.isGroupBy) {
-      block.aggregation.functions = functions;
-      for (int f = 0; f < num_functions; ++f) block.aggregation.results.push_back(value(0, f));
-    } else {
-      GroupByResultsBlock& g = block.groupBy;
-      g.functions = functions;
-      for (int k = 0; k < num_keys; ++k) { g.groupByColumns.push_back(key_names[k]); g.groupByTypes.push_back((DataType)key_types[k]); }
-      for (int64_t r = 0; r < num_rows; ++r) {
-        GroupKey key;
-        key.groupId = (int)r;
-        for (int k = 0; k < num_keys; ++k) {
-          const size_t at = (size_t)r * (size_t)num_keys + (size_t)k;
-          const DataType t = (DataType)key_types[k];
-          if (t == DataType::INT || t == DataType::LONG) key.keys.emplace_back(key_longs[at]);
-          else if (t == DataType::STRING) key.keys.emplace_back(std::string(key_strings[at]));
-          else key.keys.emplace_back(key_doubles[at]);
-        }
-        g.groupKeys.push_back(std::move(key));
-        std::vector<IntermediateResult> row;
-        for (int f = 0; f < num_functions; ++f) row.push_back(value(r, f));
-        g.results.push_back(std::move(row));
-      }
-    }
+    ResultsBlock block = blockFromArrays(is_group_by != 0, functions, num_keys, key_names, key_types, 0, num_rows, key_longs, key_doubles, key_strings, nullptr,
+                                         counts, sums, mins, maxs, is_null);
     block.stats.numDocsScanned = stats[0]; block.stats.numEntriesScannedInFilter = stats[1];
     block.stats.numEntriesScannedPostFilter = stats[2]; block.stats.numTotalDocs = stats[3];
     block.numGroupsLimitReached = limit_reached != 0;
@@ -404,5 +461,48 @@ uint8_t* ph_execute_sql_datatable(void** segments, int32_t num_segments, const c
   *out_size = (int64_t)bytes.size();
   return out;
 }
+
+// GroupByCombineOperator + GroupByDataTableReducer over group-by blocks given as flat arrays (block b holds rows
+// [sum(block_rows[0..b)), +block_rows[b]) of the arrays; same array conventions as ph_datatable_v4_build, key_is_null marks NULL keys).
+// `sql` supplies the query context: aggregations (in the arrays' function order), GROUP BY columns, ORDER BY, LIMIT and the trim
+// options.  Returns {"combined": <block>, "reduced": [[key..., final...], ...], "table": {resultSize, trimSize, trimThreshold, numResizes}}.
+char* ph_group_by_combine(const char* sql, int32_t num_blocks, const int64_t* block_rows, const int32_t* key_types, const int64_t* key_longs,
+                          const double* key_doubles, const char* const* key_strings, const uint8_t* key_is_null, const int64_t* counts, const double* sums,
+                          const double* mins, const double* maxs, const uint8_t* is_null, int32_t* status) {
+  std::string out;
+  *status = guarded([&] {
+    const QueryContext q = getQueryContext(sql);
+    if (q.groupByExpressions.empty()) throw QueryException("ph_group_by_combine needs a GROUP BY query");
+    std::vector<AggregationFunction> functions;
+    for (const auto& a : q.aggregations) functions.emplace_back(a.function, a.column, q.nullHandlingEnabled);
+    std::vector<const char*> key_names;
+    for (const auto& g : q.groupByExpressions) key_names.push_back(g.c_str());
+    std::vector<ResultsBlock> blocks;
+    int64_t row = 0;
+    for (int b = 0; b < num_blocks; ++b) {
+      ResultsBlock block = blockFromArrays(true, functions, (int32_t)key_names.size(), key_names.data(), key_types, row, row + block_rows[b], key_longs, key_doubles,
+                                           key_strings, key_is_null, counts, sums, mins, maxs, is_null);
+      trimSegmentGroupByBlock(&block, q);          // the segment operator's own trim comes first (GroupByOperator.java:119-135)
+      blocks.push_back(std::move(block));
+      row += block_rows[b];
+    }
+    if (blocks.empty()) throw QueryException("no blocks");
+    const IndexedTable sizes = IndexedTable::forCombineOperator(functions, q);
+    // count the resizes the way the combine operator's table does
+    IndexedTable table = IndexedTable::forCombineOperator(functions, q);
+    for (const auto& b : blocks) for (size_t i = 0; i < b.groupBy.groupKeys.size(); ++i) table.upsert(Record{b.groupBy.groupKeys[i].keys, b.groupBy.results[i]});
+    table.finish(false);
+    const ResultsBlock combined = combineGroupByBlocks(blocks, q);
+    std::ostringstream o;
+    o << "{\"combined\": " << blockJson(combined) << ", \"reduced\": " << reducedJson(reduceGroupBy(combined, q)) << ", \"table\": {\"resultSize\": " << sizes.resultSize()
+      << ", \"trimSize\": " << sizes.trimSize() << ", \"trimThreshold\": " << sizes.trimThreshold() << ", \"numResizes\": " << table.getNumResizes() << "}}";
+    out = o.str();
+  });
+  return *status == 0 ? strdup(out.c_str()) : nullptr;
+}
+
+// GroupByUtils.getTableCapacity / getIndexedTableTrimThreshold (core/util/GroupByUtils.java:48-73)
+int32_t ph_group_by_table_capacity(int32_t limit, int32_t min_num_groups) { return GroupByUtils::getTableCapacity(limit, min_num_groups); }
+int32_t ph_group_by_trim_threshold(int32_t trim_size, int32_t trim_threshold) { return GroupByUtils::getIndexedTableTrimThreshold(trim_size, trim_threshold); }
 
 }  // extern "C"

@@ -205,9 +205,20 @@ struct AggregationExpression {
   bool hasFilter = false;
   FilterContext filter;
   std::string filterText;                            // canonical text of `filter`: the lane key
+  std::string alias;                                 // SELECT SUM(x) AS v1: ORDER BY may name it
 };
 
 // query/request/context/QueryContext.java (the slice this path needs)
+// common/request/context/OrderByExpressionContext.java: an ORDER BY item of a group-by query is a group-by column or one of the
+// query's aggregations (post-aggregation expressions are not on this path)
+struct OrderByExpressionContext {
+  bool isAggregation = false;
+  int index = 0;                                     // into groupByExpressions, or into aggregations
+  bool isAsc = true;
+  int nullsLast = -1;                                // -1: not given -> NULLS LAST for ASC, NULLS FIRST for DESC (:54-62)
+  bool isNullsLast() const { return nullsLast < 0 ? isAsc : nullsLast != 0; }
+};
+
 struct QueryContext {
   std::string tableName;
   std::vector<AggregationExpression> aggregations;
@@ -217,6 +228,14 @@ struct QueryContext {
   int maxInitialResultHolderCapacity = 10000;        // InstancePlanMakerImplV2.java:69-91 defaults
   int numGroupsLimit = 100000;
   bool nullHandlingEnabled = false;                  // query option enableNullHandling (QueryContext.isNullHandlingEnabled)
+  std::vector<OrderByExpressionContext> orderByExpressions;   // empty = no ORDER BY (getOrderByExpressions() == null)
+  int limit = -1;                                    // LIMIT n; -1 = no LIMIT clause.  The reference's parser would default to 10; this mirror's SQL is a
+                                                     // test vehicle and keeps every group unless the query says otherwise (getLimit() -> Integer.MAX_VALUE)
+  int minSegmentGroupTrimSize = -1;                  // InstancePlanMakerImplV2.java:82-91 defaults; query options of the same names override
+  int minServerGroupTrimSize = 5000;
+  int groupTrimThreshold = 1000000;
+  bool hasOrderBy() const { return !orderByExpressions.empty(); }
+  int getLimit() const { return limit < 0 ? 0x7FFFFFFF : limit; }
 };
 
 // QueryContextConverterUtils.getQueryContext(sql) for the SQL subset of this path:
@@ -342,6 +361,78 @@ std::vector<uint8_t> toDataTableV4(const ResultsBlock& block, bool nullHandlingE
 
 // Merge helpers (operator/combine/merger/AggregationResultsBlockMerger.java, combine/GroupByCombineOperator.java)
 void mergeResultsBlocks(ResultsBlock* merged, const ResultsBlock& toMerge);
+
+// ---- core/util/GroupByUtils.java:38-73 ----------------------------------------------------------------------------
+struct GroupByUtils {
+  static constexpr int DEFAULT_MIN_NUM_GROUPS = 5000;
+  static constexpr int MAX_TRIM_THRESHOLD = 1000000000;
+  static int getTableCapacity(int limit, int minNumGroups = DEFAULT_MIN_NUM_GROUPS);      // max(limit * 5, minNumGroups), saturating
+  static int getIndexedTableTrimThreshold(int trimSize, int trimThreshold);              // Integer.MAX_VALUE = trim disabled
+};
+
+// ---- core/data/table/{Record,Key,IndexedTable,SimpleIndexedTable,TableResizer}.java --------------------------------
+struct Record {                                       // key columns in front, then one intermediate result per aggregation
+  std::vector<GroupKeyValue> keys;
+  std::vector<IntermediateResult> values;
+};
+
+// An ORDER BY value: what TableResizer's extractors hand the comparators -- a key value, or an aggregation's FINAL result
+// (AggregationFunctionExtractor.extract = extractFinalResult: Long for COUNT, Double for the rest), null under null handling.
+using OrderByValue = std::variant<std::monostate, int64_t, double, std::string>;
+
+class TableResizer {                                  // core/data/table/TableResizer.java:60-330
+ public:
+  TableResizer(const std::vector<AggregationFunction>& functions, const QueryContext& queryContext);
+  std::vector<OrderByValue> orderByValues(const Record& r) const;                       // getIntermediateRecord
+  int compare(const std::vector<OrderByValue>& a, const std::vector<OrderByValue>& b) const;     // _intermediateRecordComparator
+  // the `size` records that sort first (resizeRecordsMap / getTopRecords); sorted when `sort`
+  std::vector<Record> topRecords(std::vector<Record> records, size_t size, bool sort) const;
+ private:
+  std::vector<AggregationFunction> _functions;
+  std::vector<OrderByExpressionContext> _orderBy;
+  bool _nullHandlingEnabled;
+};
+
+// SimpleIndexedTable: the single-threaded table of GroupByCombineOperator / GroupByDataTableReducer.  Records are merged in the order
+// they are upserted (segment order here: deterministic where the reference's concurrent table depends on thread timing).
+class IndexedTable {
+ public:
+  IndexedTable(std::vector<AggregationFunction> functions, const QueryContext& queryContext, int resultSize, int trimSize, int trimThreshold);
+  // GroupByUtils.createIndexedTableForCombineOperator (:95-140): sizes from LIMIT, minServerGroupTrimSize, groupTrimThreshold
+  static IndexedTable forCombineOperator(std::vector<AggregationFunction> functions, const QueryContext& queryContext);
+  // GroupByUtils.createIndexedTableForDataTableReducer (:145-175): the broker's table (resultSize = LIMIT)
+  static IndexedTable forDataTableReducer(std::vector<AggregationFunction> functions, const QueryContext& queryContext);
+  bool upsert(const Record& record);                  // SimpleIndexedTable.upsert :47-62
+  void finish(bool sort);                             // IndexedTable.finish :143-170 (intermediate results are kept; finals are extracted by the caller)
+  size_t size() const { return _finished ? _topRecords.size() : _records.size(); }
+  const std::vector<Record>& records() const { return _finished ? _topRecords : _records; }
+  int getNumResizes() const { return _numResizes; }
+  int resultSize() const { return _resultSize; }
+  int trimSize() const { return _trimSize; }
+  int trimThreshold() const { return _trimThreshold; }
+ private:
+  void resize();
+  std::vector<AggregationFunction> _functions;
+  bool _hasOrderBy;
+  TableResizer _resizer;
+  int _resultSize, _trimSize, _trimThreshold;
+  std::map<std::vector<GroupKeyValue>, size_t> _lookup;      // key -> index into _records
+  std::vector<Record> _records, _topRecords;
+  bool _finished = false;
+  int _numResizes = 0;
+};
+
+// GroupByCombineOperator: the segments' group-by blocks through one IndexedTable (plan_maker.cpp)
+ResultsBlock combineGroupByBlocks(const std::vector<ResultsBlock>& blocks, const QueryContext& queryContext);
+
+// GroupByOperator.java:119-135: ORDER BY + minSegmentGroupTrimSize > 0 + more groups than max(5 * LIMIT, minSegmentGroupTrimSize):
+// keep that many groups, the ones that sort first (TableResizer.trimInSegmentResults)
+void trimSegmentGroupByBlock(ResultsBlock* block, const QueryContext& queryContext);
+
+// GroupByDataTableReducer: the broker's rows for a combined block -- merged into the reducer's table, sorted by ORDER BY, first LIMIT rows,
+// aggregations as final results
+struct ReducedRow { std::vector<GroupKeyValue> keys; std::vector<OrderByValue> finals; };
+std::vector<ReducedRow> reduceGroupBy(const ResultsBlock& combined, const QueryContext& queryContext);
 
 // ---- the C ABI, resolved at run time from libpinot_gpu.so ---------------------------------------------------------
 struct GpuAbi {

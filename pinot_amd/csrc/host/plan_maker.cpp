@@ -477,6 +477,7 @@ class GpuAggregationOperator : public Operator {
     }
     gpuAbi().result_free(&res);
     _stats = block.stats;
+    trimSegmentGroupByBlock(&block, _queryContext);      // GroupByOperator.java:119-135 (ORDER BY + minSegmentGroupTrimSize)
     return block;
   }
 
@@ -599,6 +600,7 @@ class GpuFilteredAggregationOperator : public Operator {
     g.groupKeys = std::move(keys);
     g.results = std::move(rows);
     _stats = block.stats;
+    trimSegmentGroupByBlock(&block, _queryContext);
     return block;
   }
   std::string toExplainString() const override { return _queryContext.groupByExpressions.empty() ? "GPU_AGGREGATE_FILTERED" : "GPU_GROUP_BY_FILTERED"; }
@@ -647,6 +649,7 @@ std::unique_ptr<PlanNode> GpuPlanMaker::makeSegmentPlanNode(const SegmentContext
       keys.push_back(key);
       QueryContext lq = qc;
       lq.aggregations.clear();
+      lq.orderByExpressions.clear();                   // the lanes return every group; the operator above them orders and trims
       if (a.hasFilter) {
         if (qc.hasFilter) {
           FilterContext both;
@@ -731,8 +734,38 @@ ResultsBlock GpuPlanMaker::executeCombined(const std::vector<SegmentContext>& se
     throw std::runtime_error(errors[i]);
   }
   // deterministic merge order (segment order); for integer sums below 2^53 any order gives the same doubles
-  ResultsBlock merged = blocks[0];
-  for (size_t i = 1; i < blocks.size(); ++i) mergeResultsBlocks(&merged, blocks[i]);
+  if (!blocks[0].isGroupBy) {
+    ResultsBlock merged = blocks[0];
+    for (size_t i = 1; i < blocks.size(); ++i) mergeResultsBlocks(&merged, blocks[i]);
+    return merged;
+  }
+  return combineGroupByBlocks(blocks, qc);
+}
+
+// GroupByCombineOperator.processSegments + mergeResults (:102-162,186-222): every segment's groups are upserted into one IndexedTable
+// keyed by the key VALUES; the table decides which groups survive (LIMIT without ORDER BY: the first LIMIT keys; ORDER BY: trims to
+// max(5 * LIMIT, minServerGroupTrimSize) whenever groupTrimThreshold records pile up, and once more at the end).
+ResultsBlock combineGroupByBlocks(const std::vector<ResultsBlock>& blocks, const QueryContext& qc) {
+  if (blocks.empty() || !blocks[0].isGroupBy) throw QueryException("combineGroupByBlocks needs group-by blocks");
+  ResultsBlock merged;
+  merged.isGroupBy = true;
+  GroupByResultsBlock& m = merged.groupBy;
+  m.groupByColumns = blocks[0].groupBy.groupByColumns;
+  m.groupByTypes = blocks[0].groupBy.groupByTypes;
+  m.functions = blocks[0].groupBy.functions;
+  IndexedTable table = IndexedTable::forCombineOperator(m.functions, qc);
+  for (const ResultsBlock& b : blocks) {
+    merged.stats.merge(b.stats);
+    merged.numGroupsLimitReached = merged.numGroupsLimitReached || b.numGroupsLimitReached;      // any segment
+    merged.deviceMs = std::max(merged.deviceMs, b.deviceMs);
+    merged.kernelMs = std::max(merged.kernelMs, b.kernelMs);
+    for (size_t i = 0; i < b.groupBy.groupKeys.size(); ++i) table.upsert(Record{b.groupBy.groupKeys[i].keys, b.groupBy.results[i]});
+  }
+  table.finish(false);
+  for (const Record& r : table.records()) {
+    m.groupKeys.push_back(GroupKey{(int)m.groupKeys.size(), r.keys});      // group ids are segment-local; after the merge they are ordinals
+    m.results.push_back(r.values);
+  }
   return merged;
 }
 

@@ -319,6 +319,10 @@ QueryContext getQueryContext(const std::string& sql) {
     for (auto& c : v) c = (char)tolower((unsigned char)c);
     if (k == "enablenullhandling") q.nullHandlingEnabled = v == "true";
     else if (k == "numgroupslimit") q.numGroupsLimit = atoi(v.c_str());
+    // QueryOptionsUtils: minSegmentGroupTrimSize / minServerGroupTrimSize / groupTrimThreshold override the plan maker's defaults
+    else if (k == "minsegmentgrouptrimsize") q.minSegmentGroupTrimSize = atoi(v.c_str());
+    else if (k == "minservergrouptrimsize") q.minServerGroupTrimSize = atoi(v.c_str());
+    else if (k == "grouptrimthreshold") q.groupTrimThreshold = atoi(v.c_str());
     else throw UnsupportedOperationException("query option '" + key.text + "' is not handled on this path");
   }
   lx.expectKeyword("SELECT");
@@ -353,8 +357,12 @@ QueryContext getQueryContext(const std::string& sql) {
       e.filterText = filterToString(e.filter);
       lx.expectSymbol(")");
     }
+    if (lx.acceptKeyword("AS")) {
+      const Token alias = lx.next();
+      if (alias.kind != Token::IDENT) throw QueryException("expected an alias near '" + alias.text + "'");
+      e.alias = alias.text;
+    }
     q.aggregations.push_back(e);
-    if (lx.acceptKeyword("AS")) lx.next();
   } while (lx.acceptSymbol(","));
   lx.expectKeyword("FROM");
   const Token t = lx.next();
@@ -371,6 +379,62 @@ QueryContext getQueryContext(const std::string& sql) {
       if (c.kind != Token::IDENT) throw QueryException("expected a group-by column");
       q.groupByExpressions.push_back(c.text);
     } while (lx.acceptSymbol(","));
+  }
+  if (lx.acceptKeyword("ORDER")) {
+    // ORDER BY <group-by column | one of the selected aggregations> [ASC | DESC] [NULLS FIRST | NULLS LAST] [, ...]
+    lx.expectKeyword("BY");
+    if (q.groupByExpressions.empty()) throw UnsupportedOperationException("ORDER BY without GROUP BY is a selection query (CPU plan)");
+    do {
+      const Token first = lx.next();
+      if (first.kind != Token::IDENT) throw QueryException("expected an ORDER BY expression near '" + first.text + "'");
+      OrderByExpressionContext ob;
+      if (lx.acceptSymbol("(")) {
+        std::string u = first.text;
+        for (auto& c : u) c = (char)toupper((unsigned char)c);
+        std::string column;
+        if (lx.acceptSymbol("*")) column = "*";
+        else {
+          const Token c = lx.next();
+          if (c.kind != Token::IDENT) throw UnsupportedOperationException("only identifier arguments are offloaded (post-aggregation ORDER BY keeps the CPU plan)");
+          column = c.text;
+        }
+        lx.expectSymbol(")");
+        int found = -1;
+        for (size_t a = 0; a < q.aggregations.size() && found < 0; ++a) {
+          const AggregationExpression& e = q.aggregations[a];
+          static const char* const names[] = {"COUNT", "SUM", "MIN", "MAX", "AVG"};
+          if (!e.hasFilter && u == names[(int)e.function] && (e.column == column || (e.function == AggregationFunctionType::COUNT && (column == "*" || e.column == "*")))) found = (int)a;
+        }
+        // (the reference appends an ORDER BY aggregation that is not selected to the query's functions; here it has to be selected)
+        if (found < 0) throw UnsupportedOperationException("ORDER BY " + first.text + "(" + column + ") is not one of the selected aggregations");
+        ob.isAggregation = true;
+        ob.index = found;
+      } else {
+        int found = -1;
+        for (size_t g = 0; g < q.groupByExpressions.size(); ++g) if (q.groupByExpressions[g] == first.text) found = (int)g;
+        if (found < 0) {
+          // an alias of a selected aggregation (CalciteSqlParser rewrites ORDER BY aliases into the aliased expression)
+          for (size_t a = 0; a < q.aggregations.size() && found < 0; ++a) if (!q.aggregations[a].alias.empty() && q.aggregations[a].alias == first.text) found = (int)a;
+          if (found >= 0 && q.aggregations[(size_t)found].hasFilter) throw UnsupportedOperationException("ORDER BY a filtered aggregation keeps the CPU plan");
+          if (found >= 0) ob.isAggregation = true;
+        }
+        if (found < 0) throw QueryException("Failed to find ORDER-BY expression: " + first.text + " in the GROUP-BY clause");      // TableResizer.java:150-151
+        ob.index = found;
+      }
+      if (lx.acceptKeyword("DESC")) ob.isAsc = false;
+      else (void)lx.acceptKeyword("ASC");
+      if (lx.acceptKeyword("NULLS")) {
+        if (lx.acceptKeyword("LAST")) ob.nullsLast = 1;
+        else { lx.expectKeyword("FIRST"); ob.nullsLast = 0; }
+      }
+      q.orderByExpressions.push_back(ob);
+    } while (lx.acceptSymbol(","));
+  }
+  if (lx.acceptKeyword("LIMIT")) {
+    const Token n = lx.next();
+    int32_t v = 0;
+    if (!parseInt32(n.text, &v) || v < 0) throw QueryException("expected a non-negative LIMIT near '" + n.text + "'");
+    q.limit = v;
   }
   if (lx.peek().kind != Token::END) throw UnsupportedOperationException("unsupported clause near '" + lx.peek().text + "'");
   return q;

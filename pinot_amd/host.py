@@ -152,6 +152,46 @@ def execute_sql(segments, sql, max_execution_threads=0):
     return _take_json(lib, lib.ph_execute_sql(arr, len(segments), sql.encode(), max_execution_threads, C.byref(st)), st)
 
 
+KEY_INT, KEY_LONG, KEY_FLOAT, KEY_DOUBLE, KEY_STRING = range(5)      # DataType ordinals of the key arrays (host/c_api.cpp)
+
+
+def group_by_combine(sql, blocks, key_types):
+    """GroupByCombineOperator + GroupByDataTableReducer over group-by blocks built on the host (no device): the IndexedTable / TableResizer
+    mirror of pinot_amd/csrc/host/indexed_table.cpp.  `blocks`: one list of rows per segment, a row = (key values, cells) with one cell
+    (count, sum, min, max, is_null) per aggregation of `sql`, None as a key value = NULL.  Returns {"combined", "reduced", "table"}."""
+    lib = _lib()
+    P = C.POINTER
+    lib.ph_group_by_combine.restype = C.c_void_p
+    lib.ph_group_by_combine.argtypes = [C.c_char_p, C.c_int32, P(C.c_int64), P(C.c_int32), P(C.c_int64), P(C.c_double), P(C.c_char_p), P(C.c_uint8), P(C.c_int64),
+                                        P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_uint8), P(C.c_int32)]
+    rows = [r for b in blocks for r in b]
+    nk = len(key_types)
+    nf = len(rows[0][1]) if rows else 1
+    nr = len(rows)
+    br = (C.c_int64 * max(len(blocks), 1))(*[len(b) for b in blocks])
+    kt = (C.c_int32 * max(nk, 1))(*key_types)
+    kl, kd, ks, kn = (C.c_int64 * max(nr * nk, 1))(), (C.c_double * max(nr * nk, 1))(), (C.c_char_p * max(nr * nk, 1))(), (C.c_uint8 * max(nr * nk, 1))()
+    counts, sums = (C.c_int64 * max(nr * nf, 1))(), (C.c_double * max(nr * nf, 1))()
+    mins, maxs, nulls = (C.c_double * max(nr * nf, 1))(), (C.c_double * max(nr * nf, 1))(), (C.c_uint8 * max(nr * nf, 1))()
+    for r, (key_values, cells) in enumerate(rows):
+        for k, v in enumerate(key_values):
+            at = r * nk + k
+            if v is None:
+                kn[at] = 1
+                ks[at] = b""
+            elif key_types[k] in (KEY_INT, KEY_LONG):
+                kl[at] = int(v)
+            elif key_types[k] == KEY_STRING:
+                ks[at] = str(v).encode()
+            else:
+                kd[at] = float(v)
+        for f, (c, s, mn, mx, is_null) in enumerate(cells):
+            at = r * nf + f
+            counts[at], sums[at], mins[at], maxs[at], nulls[at] = int(c), float(s), float(mn), float(mx), int(bool(is_null))
+    st = C.c_int32()
+    return _take_json(lib, lib.ph_group_by_combine(sql.encode(), len(blocks), br, kt, kl, kd, ks, kn, counts, sums, mins, maxs, nulls, C.byref(st)), st)
+
+
 def execute_sql_datatable(segments, sql, max_execution_threads=0):
     """The DataTable V4 bytes a server would send the broker for `sql` over these segments (combine, then
     InstanceResponseBlock.toDataTable().toBytes(); pinot_amd/csrc/host/datatable_v4.cpp)."""

@@ -70,6 +70,51 @@ def test_inter_segment_results_through_combine(golden_segments):
     assert combined["groups"][0]["final"][1] == float(d["column1"][m].max())
 
 
+def test_inter_segment_group_by_order_by_limit_goldens(golden_segments):
+    """InterSegmentAggregationSingleValueQueriesTest.java:36-203 with the reference's own SQL: GROUP BY column9 ORDER BY ... LIMIT 1 over the
+    four segments, through the combine operator's IndexedTable and the broker's reduce (host/indexed_table.cpp); all four statistics."""
+    _, segs = golden_segments
+    g = H.load_golden_queries()["inter_segment_x4"]
+    desc, asc = " GROUP BY column9 ORDER BY v1 DESC, v2 DESC LIMIT 1", " GROUP BY column9 ORDER BY v1, v2 LIMIT 1"
+
+    def run(sql):
+        out = host.execute_sql(segs, sql, max_execution_threads=4)
+        st = out["combined"]["stats"]
+        return out["reduced"], [st["numDocsScanned"], st["numEntriesScannedInFilter"], st["numEntriesScannedPostFilter"], st["numTotalDocs"]]
+
+    for flt, want, stats in (("", 64420, [120000, 0, 120000, 120000]), (FILTER, 17080, [24516, 252256, 24516, 120000])):
+        for sql in ("SELECT COUNT(*) FROM testTable" + flt + " GROUP BY column9 ORDER BY COUNT(*) DESC LIMIT 1",
+                    "SELECT COUNT(*) AS v1 FROM testTable" + flt + " GROUP BY column9 ORDER BY v1 DESC LIMIT 1"):
+            rows, st = run(sql)
+            assert len(rows) == 1 and rows[0][1] == want and st == stats
+    mx, mn = g["max_column1_column3"], g["min_column1_column3"]
+    for sql, want in (("SELECT MAX(column1) AS v1, MAX(column3) AS v2 FROM testTable" + desc, mx["group_by_top_desc"]),
+                      ("SELECT MAX(column1) AS v1, MAX(column3) AS v2 FROM testTable" + FILTER + desc, mx["filtered_group_by_top_desc"]),
+                      ("SELECT MIN(column1) AS v1, MIN(column3) AS v2 FROM testTable" + asc, mn["group_by_top_asc"]),
+                      ("SELECT MIN(column1) AS v1, MIN(column3) AS v2 FROM testTable" + FILTER + asc, mn["filtered_group_by_top_asc"])):
+        rows, st = run(sql)
+        assert len(rows) == 1 and rows[0][1:] == want["values"] and st == want["stats"], sql
+    for flt, key, stats in (("", "unfiltered", [120000, 0, 360000, 120000]), (FILTER, "filtered", [24516, 252256, 73548, 120000])):
+        rows, st = run("SELECT SUM(column1) AS v1, SUM(column3) AS v2 FROM testTable" + flt + desc)
+        assert rows[0][1:] == g["sum_group_by_top_desc"][key] and st == stats
+    rows, st = run("SELECT AVG(column1) AS v1, AVG(column3) AS v2 FROM testTable" + desc)
+    assert rows[0][1:] == g["avg_column1_column3"]["group_by_top_desc"]["values"] and st == [120000, 0, 360000, 120000]
+    rows, _ = run("SELECT AVG(column1) AS v1, AVG(column3) AS v2 FROM testTable" + FILTER + desc)
+    assert rows[0][1:] == [2142595699.0, 334963174.0]
+    # the server's combined block keeps max(5 * LIMIT, 5000) groups for the broker; without ORDER BY only LIMIT keys are admitted
+    out = host.execute_sql(segs, "SELECT COUNT(*) FROM testTable GROUP BY column9 LIMIT 7", max_execution_threads=1)
+    assert len(out["combined"]["groups"]) == 7 and len(out["reduced"]) == 7
+    first7 = list(dict.fromkeys(sorted(H.load_golden_columns()["column9"].tolist())))[:7]      # blocks list groups by ascending raw key = ascending value
+    assert [r[0] for r in out["reduced"]] == first7
+    # in-segment trim: ORDER BY + minSegmentGroupTrimSize keeps max(5 * LIMIT, size) groups of every segment block
+    out = host.execute_sql(segs[:1], "SET minSegmentGroupTrimSize = 20; SELECT COUNT(*) FROM testTable GROUP BY column9 ORDER BY COUNT(*) DESC, column9 LIMIT 3")
+    assert len(out["segments"][0]["groups"]) == 20 and out["reduced"][0][1] == 64420 // 4
+    counts = {}
+    for v in H.load_golden_columns()["column9"].tolist():
+        counts[v] = counts.get(v, 0) + 1
+    assert out["reduced"] == [[k, c] for k, c in sorted(counts.items(), key=lambda kv: (-kv[1], kv[0]))[:3]]
+
+
 def test_filtered_aggregations_run_as_swim_lanes(golden_segments):
     """FILTER (WHERE ...) aggregations (FilteredAggregationOperator.java:68-110; the reference's FilteredAggregationsTest compares a
     filtered-aggregation query with the equivalent separately filtered queries -- so does this)."""

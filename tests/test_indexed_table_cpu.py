@@ -1,0 +1,271 @@
+"""The group-by table behind the combine operator and the broker's reducer (pinot_amd/csrc/host/indexed_table.cpp): IndexedTable,
+TableResizer, GroupByUtils.  The known answers are the reference's own: IndexedTableTest.java, TableResizerTest.java and
+GroupByUtilsTest.java (pinot-core/src/test/java/org/apache/pinot/core/{data/table,util}), restated over the aggregations of this path
+(SUM / MAX / AVG / COUNT; DISTINCTCOUNT and post-aggregation ORDER BY expressions are not on it).  A Python model of the same rules checks
+random blocks, trims included."""
+import functools
+import math
+
+import numpy as np
+import pytest
+
+from pinot_amd import host
+
+INT_MAX = 2 ** 31 - 1
+S, I, D = host.KEY_STRING, host.KEY_INT, host.KEY_DOUBLE
+
+
+def cell(count=0, total=0.0, mn=0.0, mx=0.0, is_null=False):
+    return (count, total, mn, mx, is_null)
+
+
+# ---- GroupByUtilsTest.java:30-60 ---------------------------------------------------------------------------------------
+def test_group_by_utils_known_answers():
+    lib = host._lib()
+    cap = lambda limit: lib.ph_group_by_table_capacity(limit, 5000)
+    assert [cap(x) for x in (0, 1, 1000, 10000, 100000, 1000000, 10000000, 100000000, 1000000000)] == \
+        [5000, 5000, 5000, 50000, 500000, 5000000, 50000000, 500000000, INT_MAX]
+    thr = lib.ph_group_by_trim_threshold
+    assert [thr(5000, t) for t in (-1, 0, 10, 100, 1000, 10000, 100000, 1000000, 10000000, 100000000, 1000000000, 1000000001)] == \
+        [INT_MAX, INT_MAX, 10000, 10000, 10000, 10000, 100000, 1000000, 10000000, 100000000, 1000000000, INT_MAX]
+    assert (thr(INT_MAX, 10), thr(500000000, 10), thr(500000001, 10)) == (INT_MAX, 1000000000, INT_MAX)
+
+
+# ---- IndexedTableTest.java:153-236: SUM(m1), MAX(m2) GROUP BY d1, d2, d3, d4; 13 distinct keys, result size 5 -------------
+def _indexed_table_upserts():
+    rec = lambda d1, d2, d3, s, m: ((d1, d2, d3, 1000), [cell(total=s), cell(mx=m)])
+    seq = [rec("a", 1, 10.0, 10, 100), rec("b", 2, 20.0, 10, 200), rec("a", 1, 10.0, 10, 100), rec("a", 1, 10.0, 10, 100),
+           rec("c", 3, 30.0, 10, 300), rec("c", 3, 30.0, 10, 300), rec("d", 4, 40.0, 10, 400), rec("d", 4, 40.0, 10, 400),
+           rec("e", 5, 50.0, 10, 500), rec("e", 5, 50.0, 10, 500), rec("f", 6, 60.0, 10, 600), rec("g", 7, 70.0, 10, 700),
+           rec("h", 8, 80.0, 10, 800), rec("i", 9, 90.0, 10, 900), rec("j", 10, 100.0, 10, 1000), rec("b", 2, 20.0, 10, 200)]
+    merge_table = [rec("j", 10, 100.0, 10, 1000), rec("k", 11, 110.0, 10, 1100), rec("b", 2, 20.0, 10, 200), rec("l", 12, 120.0, 10, 1200)]
+    more = [rec("h", 8, 80.0, 100, 800), rec("i", 9, 90.0, 50, 900), rec("m", 13, 130.0, 600, 1300)]
+    return [seq, merge_table, more]
+
+
+@pytest.mark.parametrize("order_by, survivors", [
+    ("d1 DESC", ["m", "l", "k", "j", "i"]),
+    ("d1", ["a", "b", "c", "d", "e"]),
+    ("SUM(m1) DESC, d1", ["m", "h", "i", "a", "b"]),
+    ("d2 DESC", ["m", "l", "k", "j", "i"]),
+    ("d4, d1 ASC", ["a", "b", "c", "d", "e"]),
+])
+def test_indexed_table_survivors_of_the_reference_test(order_by, survivors):
+    sql = "SELECT SUM(m1), MAX(m2) FROM testTable GROUP BY d1, d2, d3, d4 ORDER BY %s LIMIT 5" % order_by
+    out = host.group_by_combine(sql, _indexed_table_upserts(), [S, I, D, I])
+    assert len(out["combined"]["groups"]) == 13                       # the server's table keeps max(5 * LIMIT, 5000) groups: all of them
+    assert [r[0] for r in out["reduced"]] == survivors                # checkSurvivors: the sorted top 5
+    by_key = {g["key"][0]: g["intermediate"] for g in out["combined"]["groups"]}
+    assert by_key["a"] == [30.0, 100.0] and by_key["b"] == [30.0, 200.0] and by_key["h"] == [110.0, 800.0] and by_key["m"] == [600.0, 1300.0]
+
+
+def test_no_more_new_records_without_order_by():
+    """IndexedTableTest.testNoMoreNewRecords (:253-296): result size 5, no ORDER BY -- f and g never make it, b still merges."""
+    rec = lambda d1, d2, d3: ((d1, d2, d3), [cell(total=10.0), cell(mx=d2 * 100.0)])
+    ups = [rec("a", 1, 10.0), rec("b", 2, 20.0), rec("a", 1, 10.0), rec("a", 1, 10.0), rec("c", 3, 30.0), rec("d", 4, 40.0), rec("e", 5, 50.0),
+           rec("f", 6, 60.0), rec("g", 7, 70.0), rec("b", 2, 20.0)]
+    out = host.group_by_combine("SELECT SUM(m1), MAX(m2) FROM testTable GROUP BY d1, d2, d3 LIMIT 5", [ups], [S, I, D])
+    got = {g["key"][0]: g["intermediate"][0] for g in out["combined"]["groups"]}
+    assert got == {"a": 30.0, "b": 20.0, "c": 10.0, "d": 10.0, "e": 10.0}
+    assert out["table"] == {"resultSize": 5, "trimSize": INT_MAX, "trimThreshold": INT_MAX, "numResizes": 0}
+    # without LIMIT the mirror keeps every group
+    out = host.group_by_combine("SELECT SUM(m1), MAX(m2) FROM testTable GROUP BY d1, d2, d3", [ups], [S, I, D])
+    assert len(out["combined"]["groups"]) == 7 and len(out["reduced"]) == 7
+
+
+# ---- TableResizerTest.java:66-80: five records; SUM(m1), MAX(m2), AVG(m4) GROUP BY d1, d2, d3 -----------------------------
+RESIZER_RECORDS = [(("a", 10, 1.0), [cell(total=10.0), cell(mx=100.0), cell(count=2, total=10.0)]),       # avg 5
+                   (("b", 10, 2.0), [cell(total=20.0), cell(mx=200.0), cell(count=3, total=10.0)]),       # avg 3.33
+                   (("c", 200, 3.0), [cell(total=30.0), cell(mx=300.0), cell(count=4, total=20.0)]),      # avg 5
+                   (("c", 50, 4.0), [cell(total=30.0), cell(mx=200.0), cell(count=10, total=30.0)]),      # avg 3
+                   (("c", 300, 5.0), [cell(total=20.0), cell(mx=100.0), cell(count=5, total=10.0)])]      # avg 2
+
+
+def _resizer(order_by, limit):
+    sql = "SELECT SUM(m1), MAX(m2), AVG(m4) FROM testTable GROUP BY d1, d2, d3 ORDER BY %s LIMIT %d" % (order_by, limit)
+    out = host.group_by_combine(sql, [RESIZER_RECORDS], [S, I, D])
+    return [RESIZER_RECORDS.index(next(r for r in RESIZER_RECORDS if list(r[0]) == row[:3])) for row in out["reduced"]]
+
+
+def test_table_resizer_sorted_top_records_of_the_reference_test():
+    # testSortTopRecords (:255-335)
+    assert _resizer("d1", 3)[:2] == [0, 1] and _resizer("d1", 1) == [0]
+    assert _resizer("d1, d3 DESC", 3) == [0, 1, 4] and _resizer("d1, d3 DESC", 1) == [0]
+    assert _resizer("d1, SUM(m1) DESC, max(m2) DESC", 3) == [0, 1, 2] and _resizer("d1, SUM(m1) DESC, max(m2) DESC", 1) == [0]
+    assert _resizer("AVG(m4)", 3) == [4, 3, 1]
+    # testResizeRecordsMap (:117-250): which keys stay
+    assert sorted(_resizer("d1 DESC", 3)) == [2, 3, 4]
+    assert sorted(_resizer("AVG(m4)", 2)) == [3, 4] and sorted(_resizer("d1", 2)) == [0, 1]
+    # testInSegmentTrim (:337-349): d3 DESC keeps records 4, 3, 2
+    assert _resizer("d3 DESC", 3) == [4, 3, 2]
+
+
+# ---- a Python model of the same rules, over random blocks -------------------------------------------------------------------
+def _final(kind, c):
+    if c[4]:
+        return None
+    if kind == "COUNT":
+        return c[0]
+    if kind == "SUM":
+        return c[1]
+    if kind == "MIN":
+        return c[2]
+    if kind == "MAX":
+        return c[3]
+    return -math.inf if c[0] == 0 else c[1] / c[0]
+
+
+def _merge(kind, a, b):
+    if a[4]:
+        return b
+    if b[4]:
+        return a
+    return (a[0] + b[0], a[1] + b[1], min(a[2], b[2]), max(a[3], b[3]), False)
+
+
+class Model:
+    """SimpleIndexedTable.upsert / IndexedTable.finish / TableResizer, with ties going to the earlier record."""
+
+    def __init__(self, kinds, order_by, result_size, trim_size, trim_threshold):
+        self.kinds, self.order_by = kinds, order_by           # order_by: [(is_agg, index, asc, nulls_last)]
+        self.result_size, self.trim_size, self.trim_threshold = result_size, trim_size, trim_threshold
+        self.records, self.resizes = {}, 0                    # dicts keep insertion order
+
+    def values(self, key, cells):
+        return [(_final(self.kinds[i], cells[i]) if is_agg else key[i]) for is_agg, i, _, _ in self.order_by]
+
+    def compare(self, a, b):
+        for (x, y), (_, _, asc, nulls_last) in zip(zip(a, b), self.order_by):
+            if x is None or y is None:
+                if x is None and y is None:
+                    continue
+                r = -1 if nulls_last else 1
+                return -r if x is None else r
+            c = (x > y) - (x < y)
+            if not asc:
+                c = -c
+            if c:
+                return c
+        return 0
+
+    def top(self, size, sort):
+        items = list(self.records.items())
+        order = sorted(range(len(items)), key=functools.cmp_to_key(lambda i, j: self.compare(self.values(*items[i]), self.values(*items[j])) or (i - j)))
+        keep = order[:size]
+        if not sort:
+            keep = sorted(keep)
+        return [items[i] for i in keep]
+
+    def upsert(self, key, cells):
+        if key in self.records:
+            self.records[key] = [_merge(k, a, b) for k, a, b in zip(self.kinds, self.records[key], cells)]
+        elif self.order_by:
+            self.records[key] = list(cells)
+            if len(self.records) >= self.trim_threshold:
+                self.records = dict(self.top(self.trim_size, False))
+                self.resizes += 1
+        elif len(self.records) < self.result_size:
+            self.records[key] = list(cells)
+
+    def finish(self, sort):
+        if self.order_by:
+            return self.top(self.result_size, sort)
+        return list(self.records.items())
+
+
+def _capacity(limit, min_groups):
+    return min(max(limit * 5, min_groups), INT_MAX)
+
+
+def _threshold(trim_size, thr):
+    return INT_MAX if thr <= 0 or thr > 10 ** 9 or trim_size > 5 * 10 ** 8 else max(thr, 2 * trim_size)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_combine_and_reduce_against_the_model(seed):
+    rng = np.random.default_rng(500 + seed)
+    kinds = ["COUNT", "SUM", "MIN", "MAX", "AVG"]
+    null_handling = bool(seed % 3 == 0)
+    n_keys = int(rng.integers(20, 400))
+    keys = [("k%03d" % int(rng.integers(0, 50)), int(rng.integers(0, 8)) if not (null_handling and rng.integers(0, 10) == 0) else None) for _ in range(n_keys)]
+    blocks = []
+    for b in range(int(rng.integers(1, 6))):
+        pick = rng.permutation(n_keys)[: int(rng.integers(1, n_keys + 1))]
+        rows, seen = [], set()
+        for i in pick:
+            if keys[i] in seen:
+                continue
+            seen.add(keys[i])
+            c = int(rng.integers(1, 50))
+            v = [float(x) for x in rng.integers(-100, 100, 4)]
+            null = lambda: null_handling and rng.integers(0, 12) == 0
+            rows.append((keys[i], [cell(count=c), cell(total=v[0], is_null=null()), cell(mn=v[1], is_null=null()), cell(mx=v[2], is_null=null()),
+                                   cell(count=c, total=v[3], is_null=null())]))
+        blocks.append(rows)
+    has_order = seed % 4 != 3
+    choices = [("d1", (False, 0)), ("d2", (False, 1)), ("COUNT(*)", (True, 0)), ("SUM(m1)", (True, 1)), ("MIN(m1)", (True, 2)), ("MAX(m1)", (True, 3)), ("AVG(m1)", (True, 4))]
+    order_sql, order_by = [], []
+    if has_order:
+        for j in rng.permutation(len(choices))[: int(rng.integers(1, 4))]:
+            asc = bool(rng.integers(0, 2))
+            nulls = [None, True, False][int(rng.integers(0, 3))] if null_handling else None
+            order_sql.append(choices[j][0] + ("" if asc else " DESC") + ("" if nulls is None else (" NULLS LAST" if nulls else " NULLS FIRST")))
+            order_by.append(choices[j][1] + (asc, asc if nulls is None else nulls))
+    limit = int(rng.choice([1, 3, 10, 40]))
+    min_server, thr, min_segment = int(rng.choice([5, 20, 5000])), int(rng.choice([-1, 30, 60, 1000000])), int(rng.choice([-1, -1, 4, 15]))
+    sql = "SET minServerGroupTrimSize = %d; SET groupTrimThreshold = %d; SET minSegmentGroupTrimSize = %d; " % (min_server, thr, min_segment)
+    if null_handling:
+        sql += "SET enableNullHandling = true; "
+    sql += "SELECT COUNT(*), SUM(m1), MIN(m1), MAX(m1), AVG(m1) FROM t GROUP BY d1, d2" + (" ORDER BY " + ", ".join(order_sql) if has_order else "") + " LIMIT %d" % limit
+    out = host.group_by_combine(sql, blocks, [S, I])
+
+    # the model: segment trim, the combine operator's table, then the reducer's
+    trim_size = _capacity(limit, min_server)
+    if has_order:
+        thr_eff = _threshold(trim_size, thr)
+        combine = Model(kinds, order_by, trim_size, INT_MAX if thr_eff == INT_MAX else trim_size, thr_eff)
+        reducer = Model(kinds, order_by, limit, INT_MAX if thr_eff == INT_MAX else trim_size, thr_eff)
+    else:
+        combine = Model(kinds, [], limit, INT_MAX, INT_MAX)
+        reducer = Model(kinds, [], limit, INT_MAX, INT_MAX)
+    for rows in blocks:
+        if has_order and min_segment > 0 and len(rows) > _capacity(limit, min_segment):
+            seg = Model(kinds, order_by, _capacity(limit, min_segment), INT_MAX, INT_MAX)
+            for k, c in rows:
+                seg.records[k] = list(c)
+            rows = seg.top(_capacity(limit, min_segment), False)
+        for k, c in rows:
+            combine.upsert(k, c)
+    combined = combine.finish(False)
+    assert out["table"]["numResizes"] == combine.resizes + (1 if has_order else 0)
+    got = [(tuple(g["key"]), g["intermediate"]) for g in out["combined"]["groups"]]
+
+    def intermediate(c):
+        row = []
+        for kind, x in zip(kinds, c):
+            if x[4]:
+                row.append(None)
+            else:
+                row.append({"COUNT": x[0], "SUM": x[1], "MIN": x[2], "MAX": x[3]}.get(kind, [x[1], x[0]]))
+        return row
+    assert got == [(k, intermediate(c)) for k, c in combined]
+    for k, c in combined:
+        reducer.upsert(k, c)
+    rows = reducer.finish(True)[:limit]
+    want = [list(k) + [_final(kind, x) for kind, x in zip(kinds, c)] for k, c in rows]
+    norm = lambda r: [("-Infinity" if isinstance(x, float) and x == -math.inf else x) for x in r]
+    assert out["reduced"] == [norm(r) for r in want]
+
+
+def test_parser_accepts_order_by_limit_and_rejects_what_is_not_on_the_path():
+    q = host.parse_sql("SELECT SUM(m1), COUNT(*) FROM t GROUP BY d1, d2 ORDER BY COUNT(*) DESC, d2 NULLS FIRST, sum(m1) ASC LIMIT 7")
+    assert q["limit"] == 7 and q["orderBy"] == [{"expression": "count(*)", "asc": False, "nullsLast": False},
+                                               {"expression": "d2", "asc": True, "nullsLast": False},
+                                               {"expression": "sum(m1)", "asc": True, "nullsLast": True}]
+    for sql, status in (("SELECT SUM(m1) FROM t GROUP BY d1 ORDER BY d9", 1),              # not in the GROUP BY clause (TableResizer.java:150)
+                        ("SELECT SUM(m1) FROM t GROUP BY d1 ORDER BY MAX(m1)", 2),         # not a selected aggregation: CPU plan
+                        ("SELECT SUM(m1) FROM t ORDER BY d1", 2),                          # selection-style ORDER BY
+                        ("SELECT SUM(m1) FROM t GROUP BY d1 LIMIT -3", 1)):
+        with pytest.raises(host.HostError) as e:
+            host.parse_sql(sql)
+        assert e.value.status == status, sql

@@ -2,6 +2,7 @@
 #include <cstdint>
 #include <cstring>
 #include <algorithm>
+#include <string>
 #include <vector>
 #include "../../include/pinot_host_c.h"
 int main() {
@@ -13,7 +14,10 @@ int main() {
     "SELECT a FROM t", "SELECT SUM(a + 1) FROM t", "SELECT SUM(*) FROM t", "SELECT SUM(a) FROM", "SELECT SUM(a) FROM t WHERE a >",
     "SELECT SUM(a) FILTER (b > 3) FROM t", "SELECT COUNT(*) FROM t WHERE a IS 3", "SET useStarTree = true; SELECT COUNT(*) FROM t",
     "SET numGroupsLimit = 5; SELECT COUNT(*) FROM t GROUP BY a", "SELECT COUNT(*) FROM t WHERE a IN ()", "", "SELECT", "SELECT COUNT(*) FROM t WHERE ((((a = 1",
-    "SELECT COUNT(*) FROM t WHERE a = 1.5e3 AND b = -0.0 AND c = '\xff\xfe'"};
+    "SELECT COUNT(*) FROM t WHERE a = 1.5e3 AND b = -0.0 AND c = '\xff\xfe'",
+    "SET minServerGroupTrimSize = 3; SELECT SUM(a), COUNT(*) FROM t GROUP BY k1, k2 ORDER BY COUNT(*) DESC NULLS LAST, k2, sum(a) ASC NULLS FIRST LIMIT 5",
+    "SELECT SUM(a) FROM t GROUP BY k ORDER BY", "SELECT SUM(a) FROM t GROUP BY k ORDER BY MAX(", "SELECT SUM(a) FROM t GROUP BY k LIMIT", "SELECT SUM(a) FROM t GROUP BY k LIMIT 99999999999",
+    "SELECT SUM(a) FROM t GROUP BY k ORDER BY k NULLS"};
   for (const char* q : qs) {
     int32_t st = 0;
     char* r = ph_parse_sql(q, &st);
@@ -56,6 +60,34 @@ int main() {
     std::vector<uint8_t> raw((size_t)ph_raw_size_fixed_v2((int32_t)longs.size(), 1000, 8));
     ph_raw_write_fixed_v2(longs.data(), (int32_t)longs.size(), 1000, 8, raw.data());
     printf("writers ok: inverted %lld bytes, roaring %zu bytes, raw %zu bytes\n", (long long)size, rb.size(), raw.size());
+  }
+  // the combine operator's table and the reducer: trims while upserting, NULL keys, null results, every key type
+  {
+    const int nb = 3, rows_per = 40, nk = 3, nf = 3;
+    std::vector<int64_t> block_rows(nb, rows_per), kl((size_t)nb * rows_per * nk), counts((size_t)nb * rows_per * nf);
+    std::vector<double> kd(kl.size()), sums(counts.size()), mins(counts.size()), maxs(counts.size());
+    std::vector<const char*> ks(kl.size(), "");
+    std::vector<uint8_t> kn(kl.size(), 0), nulls(counts.size(), 0);
+    std::vector<std::string> names;
+    for (int i = 0; i < 17; ++i) names.push_back("key" + std::to_string(i));
+    const int32_t kt[3] = {4, 0, 3};      // STRING, INT, DOUBLE
+    for (int r = 0; r < nb * rows_per; ++r) {
+      ks[(size_t)r * nk] = names[(size_t)(r * 7 % 17)].c_str();
+      kl[(size_t)r * nk + 1] = r % 5;
+      kn[(size_t)r * nk + 1] = r % 11 == 0;
+      kd[(size_t)r * nk + 2] = (r % 3) * 0.5;
+      for (int f = 0; f < nf; ++f) { counts[(size_t)r * nf + f] = 1 + r % 4; sums[(size_t)r * nf + f] = r * 1.5; maxs[(size_t)r * nf + f] = r; nulls[(size_t)r * nf + f] = (r + f) % 13 == 0; }
+    }
+    const char* sqls[] = {
+      "SET enableNullHandling = true; SET minServerGroupTrimSize = 4; SET groupTrimThreshold = 10; SET minSegmentGroupTrimSize = 6; "
+      "SELECT SUM(a), MAX(b), AVG(c) FROM t GROUP BY k1, k2, k3 ORDER BY AVG(c) DESC, k2 NULLS FIRST, k1 LIMIT 2",
+      "SELECT SUM(a), MAX(b), AVG(c) FROM t GROUP BY k1, k2, k3 LIMIT 7", "SELECT SUM(a), MAX(b), AVG(c) FROM t GROUP BY k1, k2, k3 ORDER BY k3, SUM(a) LIMIT 0"};
+    for (const char* q : sqls) {
+      int32_t st = 0;
+      char* r = ph_group_by_combine(q, nb, block_rows.data(), kt, kl.data(), kd.data(), ks.data(), kn.data(), counts.data(), sums.data(), mins.data(), maxs.data(), nulls.data(), &st);
+      printf("combine %d %zu bytes %s\n", st, r ? strlen(r) : (size_t)0, r ? "" : ph_last_error());
+      if (r) ph_free(r);
+    }
   }
   return 0;
 }
