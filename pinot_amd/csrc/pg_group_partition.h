@@ -24,6 +24,7 @@
 namespace pg {
 
 // raw key of the lane's 32 docs of a tile: sum dictId_c * mult_c (DictionaryBasedGroupKeyGenerator.java:437-445)
+template <bool kWide = false>
 __device__ __forceinline__ void decode_group_keys(const GroupParams& gp, long long tile, int lane, uint32_t (&g)[32]) {
   for (int c = 0; c < gp.num_group_cols; ++c) {
     const DevGroupKey& key = gp.group_keys[c];
@@ -35,7 +36,7 @@ __device__ __forceinline__ void decode_group_keys(const GroupParams& gp, long lo
       uint32_t d[16];
       if (h == 0) decode16_private_dispatch<0>(b, words, d); else decode16_private_dispatch<1>(b, words, d);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : key_term(d[j], mult, gp.wide_keys != 0) + g[16 * h + j];
+      for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : key_term<kWide>(d[j], mult) + g[16 * h + j];
     }
   }
 }
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(256) void group_partition_aggregate_kernel(const Pa
 // Table slots: SUM of LONG / INT: int64 add; SUM of FLOAT / DOUBLE: the slot holds a double (global_atomic_add_f64); MIN / MAX of raw LONG:
 // the value; of raw FLOAT / DOUBLE: its order-preserving 64-bit key (f64_order_key); of dictionary columns: the dictId.
 // ------------------------------------------------------------------------------------------------
+template <bool kWide>
 static __global__ __launch_bounds__(256) void group_typed_direct_kernel(const GroupParams gp) {
   const int lane = threadIdx.x & 63;
   const long long num_tiles = ((long long)gp.scan.num_docs + 2047) / 2048;
@@ -388,7 +390,7 @@ static __global__ __launch_bounds__(256) void group_typed_direct_kernel(const Gr
     const uint32_t m = eval_filter_private(gp.scan, tile, lane, entries) & tail_mask(gp, tile, lane);
     if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
     uint32_t g[32];
-    decode_group_keys(gp, tile, lane, g);
+    decode_group_keys<kWide>(gp, tile, lane, g);
     const long long first_doc = tile * 2048 + lane * 32;
 #pragma unroll
     for (int j = 0; j < 32; ++j) if ((m >> j) & 1u) __hip_atomic_fetch_add(&gp.table_count[g[j]], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

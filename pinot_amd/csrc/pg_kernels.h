@@ -913,15 +913,18 @@ __device__ __forceinline__ void group_max(long long* slot, int32_t v) {
 }
 
 // One term of the raw key, dictId * multiplier (DictionaryBasedGroupKeyGenerator.java:437-445).  Up to 2^24 slots both factors
-// fit the full-rate 24-bit multiply; `wide` (uniform: GroupParams::wide_keys) takes the 32-bit one.
-__device__ __forceinline__ uint32_t key_term(uint32_t d, uint32_t mult, bool wide) {
-  if (wide) return d * mult;
-  return __umul24(d, mult);
+// fit the full-rate 24-bit multiply; kWide (GroupParams::wide_keys: its own instantiations of the HBM-table kernels) takes the
+// 32-bit one.  (A run-time switch between the two inside the unrolled key loops made group_private_kernel<false> fault on the
+// device -- one more reason for the template than the spare multiply.)
+template <bool kWide>
+__device__ __forceinline__ uint32_t key_term(uint32_t d, uint32_t mult) {
+  if constexpr (kWide) return d * mult;
+  else return __umul24(d, mult);
 }
 
 // Aggregate four docs per lane (steps k[0..3]) into the group table.  kAllActive: every lane owns four real matching
 // docs (no exec masking around the atomics).
-template <bool kLds, bool kAllActive>
+template <bool kLds, bool kAllActive, bool kWide = false>
 __device__ __forceinline__ void group_process4(const GroupParams& gp, const uint8_t* stage, int tile, int lane, const int (&k)[4], const bool (&active)[4],
                                                unsigned long long* t_cnt, long long* t_acc) {
   const ScanParams& p = gp.scan;
@@ -935,10 +938,10 @@ __device__ __forceinline__ void group_process4(const GroupParams& gp, const uint
     const uint32_t mult = (uint32_t)key.mult;
     if (b <= 25) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] += key_term(decode_step<false>(slot, dec, k[j], b), mult, gp.wide_keys != 0);
+      for (int j = 0; j < 4; ++j) g[j] += key_term<kWide>(decode_step<false>(slot, dec, k[j], b), mult);
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] += key_term(decode_step<true>(slot, dec, k[j], b), mult, gp.wide_keys != 0);
+      for (int j = 0; j < 4; ++j) g[j] += key_term<kWide>(decode_step<true>(slot, dec, k[j], b), mult);
     }
   }
   const bool packed = kLds && gp.packed_agg >= 0;
@@ -1034,7 +1037,7 @@ __device__ __forceinline__ void group_process4(const GroupParams& gp, const uint
 // Sixteen consecutive steps of a tile whose docs all match: the group ids of the lane's sixteen docs stay in registers, the
 // column descriptors are read once per sixteen steps, and each column is decoded in one straight unrolled run (sixteen
 // LDS reads in flight, 3 VALU per decode) followed by its sixteen atomics.
-template <bool kLds>
+template <bool kLds, bool kWide = false>
 __device__ __forceinline__ void group_dense16(const GroupParams& gp, const uint8_t* stage, int tile, int lane, int k0,
                                               unsigned long long* t_cnt, long long* t_acc) {
   const ScanParams& p = gp.scan;
@@ -1053,7 +1056,7 @@ __device__ __forceinline__ void group_dense16(const GroupParams& gp, const uint8
       uint32_t d[8];
       decode_steps8(slot, dec, k0 + 8 * h, b, d);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) g[8 * h + j] = c == 0 ? d[j] : key_term(d[j], mult, gp.wide_keys != 0) + g[8 * h + j];
+      for (int j = 0; j < 8; ++j) g[8 * h + j] = c == 0 ? d[j] : key_term<kWide>(d[j], mult) + g[8 * h + j];
     }
   }
   const bool packed = kLds && gp.packed_agg >= 0;
@@ -1110,7 +1113,7 @@ __device__ __forceinline__ void group_dense16(const GroupParams& gp, const uint8
   }
 }
 
-template <bool kDma, bool kLdsTable>
+template <bool kDma, bool kLdsTable, bool kWide = false>
 __global__ __launch_bounds__(kGroupBlockThreads) void scan_group_kernel(const GroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const ScanParams& p = gp.scan;
@@ -1169,7 +1172,7 @@ __global__ __launch_bounds__(kGroupBlockThreads) void scan_group_kernel(const Gr
       }
       if (gp.dense_ok && __builtin_amdgcn_ballot_w64(m != fullm) == 0ull) {
         // every doc of the tile matches: walk the steps in order, no per-lane bookkeeping, no exec masking
-        for (int kb = 0; kb < steps; kb += 16) group_dense16<kLdsTable>(gp, wave_lds, tile, lane, kb, t_cnt, t_acc);
+        for (int kb = 0; kb < steps; kb += 16) group_dense16<kLdsTable, kWide>(gp, wave_lds, tile, lane, kb, t_cnt, t_acc);
       } else {
         uint32_t rem = m;
         for (;;) {
@@ -1182,7 +1185,7 @@ __global__ __launch_bounds__(kGroupBlockThreads) void scan_group_kernel(const Gr
             k[j] = active[j] ? __builtin_ctz(rem) : 0;
             rem &= rem - 1u;
           }
-          group_process4<kLdsTable, false>(gp, wave_lds, tile, lane, k, active, t_cnt, t_acc);
+          group_process4<kLdsTable, false, kWide>(gp, wave_lds, tile, lane, k, active, t_cnt, t_acc);
         }
       }
     }
@@ -1573,7 +1576,7 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
 
 // One 2048-doc tile.  kMasked: only the docs whose bit is set in the lane's mask `m` reach the table (a filter's result, and /
 // or the docs that exist in the last, partial tile); otherwise every doc of the tile does, with no exec masking around the atomics.
-template <bool kLds, bool kMasked>
+template <bool kLds, bool kMasked, bool kWide = false>
 __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long long tile, int lane, uint32_t m, unsigned long long* t_cnt, long long* t_acc) {
   const int G = gp.num_groups;
   const long long first_doc = tile * 2048 + lane * 32;
@@ -1588,7 +1591,7 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
       uint32_t d[16];
       if (h == 0) decode16_private_dispatch<0>(b, words, d); else decode16_private_dispatch<1>(b, words, d);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : key_term(d[j], mult, gp.wide_keys != 0) + g[16 * h + j];
+      for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : key_term<kWide>(d[j], mult) + g[16 * h + j];
     }
   }
   const bool packed = kLds && gp.packed_agg >= 0;
@@ -1640,7 +1643,7 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
   }
 }
 
-template <bool kLdsTable>
+template <bool kLdsTable, bool kWide = false>
 __global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const GroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63;
@@ -1678,8 +1681,8 @@ __global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const
     const long long rem = (long long)gp.scan.num_docs - (tile * 2048 + lane * 32);
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
     if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
-    if (__builtin_amdgcn_ballot_w64(m != 0xFFFFFFFFu) == 0ull) group_private_tile<kLdsTable, false>(gp, tile, lane, m, t_cnt, t_acc);
-    else group_private_tile<kLdsTable, true>(gp, tile, lane, m, t_cnt, t_acc);
+    if (__builtin_amdgcn_ballot_w64(m != 0xFFFFFFFFu) == 0ull) group_private_tile<kLdsTable, false, kWide>(gp, tile, lane, m, t_cnt, t_acc);
+    else group_private_tile<kLdsTable, true, kWide>(gp, tile, lane, m, t_cnt, t_acc);
   }
   flush_filter_entries(gp.scan, entries);
 

@@ -36,7 +36,8 @@ void launch_group_partition_aggregate(int work_items, size_t lds, hipStream_t st
 }
 
 void launch_group_typed_direct(int blocks, hipStream_t stream, const GroupParams& gp) {
-  group_typed_direct_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(gp);
+  if (gp.wide_keys) group_typed_direct_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(gp);
+  else group_typed_direct_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(gp);
 }
 
 int waves_group_partition_scatter() {
