@@ -68,6 +68,7 @@ struct Engine {
   bool group_private = true; // PINOT_GPU_GROUP_PRIVATE=0: unfiltered group-by through the LDS-staged kernel
   bool group_pack = true;    // PINOT_GPU_GROUP_PACK=0: separate count atomic in the group-by LDS table
   bool scan_typed_private = true;     // PINOT_GPU_SCAN_TYPED_PRIVATE=0: raw / 8-byte aggregated columns stay in the LDS-staged kernel
+  bool scan_narrow = true;            // PINOT_GPU_SCAN_NARROW=0: filters over columns of at most 8 bits stay in scan_private_kernel
   bool group_partition = true;        // PINOT_GPU_GROUP_PARTITION=0: key spaces above the LDS table always use direct HBM atomics
   long long partition_min_docs = 1ll << 22;   // ... =force: partition even tiny segments (tests)
   unsigned long long group_table_bytes = 64ull << 30;      // PINOT_GPU_GROUP_TABLE_BYTES: largest direct-indexed group table a query may ask for
@@ -1395,6 +1396,8 @@ pg_status pg_init(const pg_config* config) {
   const char* gpt = getenv("PINOT_GPU_GROUP_PARTITION");
   g_engine.group_partition = !(gpt && gpt[0] == '0');
   g_engine.partition_min_docs = (gpt && gpt[0] == 'f') ? 0 : (1ll << 22);
+  const char* snw = getenv("PINOT_GPU_SCAN_NARROW");
+  g_engine.scan_narrow = !(snw && snw[0] == '0');
   const char* gtb = getenv("PINOT_GPU_GROUP_TABLE_BYTES");
   g_engine.group_table_bytes = (gtb && atoll(gtb) > 0) ? (unsigned long long)atoll(gtb) : (64ull << 30);
   const char* gpk = getenv("PINOT_GPU_GROUP_PACK");
@@ -2130,6 +2133,26 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + 3) / 4, (long long)seg->num_cus * bpc));
       geo.threads = kBlockThreads;
     } else if ((size_t)sp.wave_lds_bytes > kLdsBudget) return fail(PG_ERR_UNSUPPORTED, "query needs %d bytes of LDS per wavefront", sp.wave_lds_bytes);
+    // Nothing but a filter over narrow dictionary columns (COUNT(*) and / or the bitmap): scan_narrow_kernel, four tiles per wave and iteration
+    bool use_narrow = g_engine.scan_narrow && use_private && !use_hist && pl.num_agg_cols == 0 && lw.tile_list == nullptr && sp.num_nodes > 0;
+    if (use_narrow) {
+      int depth = 0, max_depth = 0;
+      for (int n = 0; n < sp.num_nodes && use_narrow; ++n) {
+        const DevNode& dn = sp.nodes[n];
+        if (dn.op == PG_FILTER_LEAF) {
+          use_narrow = dn.kind == kLeafMatchAll || dn.kind == kLeafMatchNone || (dn.kind == kLeafDictRange && dn.bits >= 1 && dn.bits <= kNarrowMaxBits);
+          depth++;
+        } else if (dn.op != PG_FILTER_NOT) depth -= dn.num_children - 1;
+        max_depth = std::max(max_depth, depth);
+      }
+      use_narrow = use_narrow && max_depth <= kNarrowStack;
+    }
+    if (use_narrow) {
+      const long long quads = (((long long)seg->num_docs + 2047) / 2048 + kNarrowTiles - 1) / kNarrowTiles;
+      int bpc = std::max(1, waves_scan_narrow() / (kBlockThreads / 64));
+      if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
+      blocks = (int)std::max<long long>(1, std::min<long long>((quads + 3) / 4, (long long)seg->num_cus * bpc));
+    }
     sp.speculate = 1;
     sp.profile = (g_engine.flags & PG_CFG_PROFILE_WAVES) ? 1 : 0;
     st = ensure_partials(ctx, blocks);
@@ -2151,6 +2174,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
     if (use_hist) launch_scan_hist(hist_cw, hist_guarded, blocks, hist_lds, ctx->stream, sp);
+    else if (use_narrow) launch_scan_narrow(blocks, ctx->stream, sp);
     else if (use_private) launch_scan_private(one, blocks, ctx->stream, sp);
     else if (use_private_typed) launch_scan_private_typed(blocks, ctx->stream, sp);
     else launch_scan_agg(g_engine.use_dma, one, typed, blocks, geo.threads, lds, ctx->stream, sp);
@@ -2227,7 +2251,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
           }
         }
       }
-      out->dominant_kernel = use_hist ? PG_KERNEL_SCAN_HIST : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
+      out->dominant_kernel = use_hist ? PG_KERNEL_SCAN_HIST : use_narrow ? PG_KERNEL_SCAN_NARROW : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
       for (int c = 0; c < 4; ++c) out->profile_cycles[c] = fp.cyc[c];
       out->profile_waves = blocks * (geo.threads / 64);
       out->stats.num_docs_scanned = (int64_t)fp.count;

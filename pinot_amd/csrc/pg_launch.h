@@ -30,6 +30,9 @@ int waves_scan_agg(bool one_slot, bool typed);
 // scan_private_kernel<slots>: the lane-private scan -> filter -> aggregate kernel
 void launch_scan_private(bool one_slot, int blocks, hipStream_t stream, const ScanParams& p);
 int waves_scan_private(bool one_slot);
+// scan_narrow_kernel: COUNT(*) / docId bitmap of a filter over columns of at most 8 bits (pg_scan_narrow.h)
+void launch_scan_narrow(int blocks, hipStream_t stream, const ScanParams& p);
+int waves_scan_narrow();
 // scan_group_kernel<kDma, kLdsTable>: LDS-staged group-by
 void launch_scan_group(bool dma, bool lds_table, int blocks, int threads, size_t lds, hipStream_t stream, const GroupParams& gp);
 int waves_scan_group();

@@ -1,0 +1,139 @@
+// scan_narrow_kernel: filters over NARROW dictionary columns (at most 8 bits per dictId), COUNT(*) and / or the docId bitmap.
+//
+// A 2048-doc tile of a b-bit column is 256 b bytes: 1 KB at 4 bits.  scan_private_kernel evaluates leaf after leaf, tile after tile,
+// with ~130 registers per lane: four waves per SIMD, one tile's worth of one column in flight per wave -- 4 MB on the whole chip,
+// against the ~16 MB a 2 us HBM round trip needs at 8 TB/s.  Measured: 4 / 6 / 8-bit columns scan at 1.8-3.0 TB/s there, and giving
+// that kernel more state (four tiles of the narrow leaves up front) only pushed it into scratch (profiles/r2/README.md).
+// This kernel is the other answer: nothing but the filter, FOUR tiles per wave and iteration -- for every leaf the lane's words of all
+// four tiles are loaded before the first is decoded (4 b <= 32 registers), the filter program runs on four masks at a time -- and no
+// aggregation state beyond a count.  Same lane-private layout as the other kernels (lane i owns docs 32 i .. 32 i + 31 of a tile, its
+// mask is dword 64 tile + i of the doc-order bitmap), so the bitmap it writes is the one every other kernel reads.
+// Leaves: dictId ranges (PredicateEvaluator lowering of EQ / NOT_EQ / RANGE: SVScanDocIdIterator's matcher, SVScanDocIdIterator.java:
+// 108-145, over FixedBitSVForwardIndexReaderV2's stream), match-all / match-none; any AND / OR / NOT tree whose evaluation needs at
+// most kNarrowStack masks.
+#pragma once
+#include "pg_kernels.h"
+
+namespace pg {
+
+template <int B>
+__device__ __forceinline__ void narrow_leaf_quad(const uint8_t* fwd, const long long (&tiles)[kNarrowTiles], int lane, uint32_t lo, uint32_t span,
+                                                 uint32_t (&m)[kNarrowTiles]) {
+  uint32_t w[kNarrowTiles][B];
+#pragma unroll
+  for (int t = 0; t < kNarrowTiles; ++t) {
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(fwd + tiles[t] * (256ll * B)) + lane * B;
+#pragma unroll
+    for (int i = 0; i < B; ++i) w[t][i] = words[i];
+  }
+#pragma unroll
+  for (int t = 0; t < kNarrowTiles; ++t) {
+    uint32_t mm = 0;
+    range16_private<B, 0, false>(w[t], lo, span, mm);
+    range16_private<B, 1, false>(w[t], lo, span, mm);
+    m[t] = __builtin_bitreverse32(mm);          // value j -> bit j
+  }
+}
+
+struct NarrowStack {                              // kNarrowStack entries of four masks; selects instead of indexing keep it in registers
+  uint32_t v[kNarrowStack][kNarrowTiles];
+  int sp;
+  __device__ __forceinline__ void push(const uint32_t (&x)[kNarrowTiles]) {
+#pragma unroll
+    for (int i = 0; i < kNarrowStack; ++i)
+#pragma unroll
+      for (int t = 0; t < kNarrowTiles; ++t) v[i][t] = (i == sp) ? x[t] : v[i][t];
+    ++sp;
+  }
+  __device__ __forceinline__ void pop(uint32_t (&r)[kNarrowTiles]) {
+    --sp;
+#pragma unroll
+    for (int t = 0; t < kNarrowTiles; ++t) r[t] = 0u;
+#pragma unroll
+    for (int i = 0; i < kNarrowStack; ++i)
+#pragma unroll
+      for (int t = 0; t < kNarrowTiles; ++t) r[t] = (i == sp) ? v[i][t] : r[t];
+  }
+};
+
+static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_kernel(const ScanParams p) {
+  __shared__ unsigned long long red[kBlockThreads / 64];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  const long long total_waves = (long long)gridDim.x * waves_per_block;
+  const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
+  const long long num_quads = (num_tiles + kNarrowTiles - 1) / kNarrowTiles;
+  unsigned long long count = 0;
+  for (long long quad = (long long)blockIdx.x * waves_per_block + wave_in_block; quad < num_quads; quad += total_waves) {
+    long long tiles[kNarrowTiles];
+#pragma unroll
+    for (int t = 0; t < kNarrowTiles; ++t) tiles[t] = quad * kNarrowTiles + t < num_tiles ? quad * kNarrowTiles + t : quad * kNarrowTiles;   // past the end: a valid tile, masked below
+    NarrowStack st;
+#pragma unroll
+    for (int i = 0; i < kNarrowStack; ++i)
+#pragma unroll
+      for (int t = 0; t < kNarrowTiles; ++t) st.v[i][t] = 0u;
+    st.sp = 0;
+    for (int n = 0; n < p.num_nodes; ++n) {
+      const DevNode& nd = p.nodes[n];
+      uint32_t top[kNarrowTiles];
+      if (nd.op == PG_FILTER_LEAF) {
+#pragma unroll
+        for (int t = 0; t < kNarrowTiles; ++t) top[t] = nd.kind == kLeafMatchAll ? 0xFFFFFFFFu : 0u;
+        if (nd.kind == kLeafDictRange) {
+          const uint32_t lo = (uint32_t)nd.lo, span = nd.span;
+          switch (nd.bits) {
+#define PG_CASE(B) case B: narrow_leaf_quad<B>(nd.fwd, tiles, lane, lo, span, top); break;
+            PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8)
+#undef PG_CASE
+            default: break;
+          }
+        }
+        if (nd.exclusive) {
+#pragma unroll
+          for (int t = 0; t < kNarrowTiles; ++t) top[t] = ~top[t];
+        }
+      } else if (nd.op == PG_FILTER_NOT) {
+        st.pop(top);
+#pragma unroll
+        for (int t = 0; t < kNarrowTiles; ++t) top[t] = ~top[t];
+      } else {
+        st.pop(top);
+        for (int c = 1; c < nd.num_children; ++c) {
+          uint32_t o[kNarrowTiles];
+          st.pop(o);
+#pragma unroll
+          for (int t = 0; t < kNarrowTiles; ++t) top[t] = nd.op == PG_FILTER_AND ? (top[t] & o[t]) : (top[t] | o[t]);
+        }
+      }
+      st.push(top);
+    }
+    uint32_t m[kNarrowTiles];
+    if (p.num_nodes == 0) {
+#pragma unroll
+      for (int t = 0; t < kNarrowTiles; ++t) m[t] = 0xFFFFFFFFu;
+    } else {
+      st.pop(m);
+    }
+#pragma unroll
+    for (int t = 0; t < kNarrowTiles; ++t) {
+      const long long tile = quad * kNarrowTiles + t;
+      const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);          // docs past numDocs, and tiles past the last one
+      const uint32_t mt = m[t] & (rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u)));
+      if (p.out_bitmap && tile < num_tiles) reinterpret_cast<uint32_t*>(p.out_bitmap)[tile * 64 + lane] = mt;
+      count += (unsigned)__builtin_popcount(mt);
+    }
+  }
+  const unsigned long long wave_count = (unsigned long long)wave_sum_i64((long long)count);
+  if (lane == 0) red[wave_in_block] = wave_count;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    BlockPartial acc;
+    partial_identity(acc);
+    for (int w = 0; w < waves_per_block; ++w) acc.count += red[w];
+    p.partials[blockIdx.x] = acc;
+  }
+}
+
+}  // namespace pg

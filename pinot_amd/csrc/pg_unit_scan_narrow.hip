@@ -1,0 +1,16 @@
+// Instantiates scan_narrow_kernel (filters over columns of at most 8 bits, four tiles per wave and iteration) -- see pg_launch.h.
+#include "pg_scan_narrow.h"
+#include "pg_launch.h"
+
+namespace pg {
+
+void launch_scan_narrow(int blocks, hipStream_t stream, const ScanParams& p) {
+  scan_narrow_kernel<<<dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream>>>(p);
+}
+
+int waves_scan_narrow() {
+  static const int cap = max_waves_per_cu(scan_narrow_kernel);
+  return cap;
+}
+
+}  // namespace pg

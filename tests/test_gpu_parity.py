@@ -230,6 +230,47 @@ def test_group_by_whole_int_map_range(engine):
     run_both(engine, seg, Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 3), (Q.MIN, 3)], group_by=[0, 0, 1]))
 
 
+@pytest.mark.parametrize("n", [1, 2047, 4 * 2048, 4 * 2048 + 5, 9 * 2048 + 77, 300_007])
+def test_narrow_column_filters_four_tiles_at_a_time(engine, n):
+    """scan_narrow_kernel: COUNT(*) / the docId bitmap of filters over dictionary columns of 1..8 bits (any AND / OR / NOT tree of dictId
+    ranges), four tiles per wave and iteration.  Whole quads, ragged quads, a single doc."""
+    rng = np.random.default_rng(77 + n)
+    cols, ids = [], []
+    for b in range(1, 9):
+        card = 2 ** b - (1 if b in (3, 6) else 0)
+        c, i, _ = H.random_dict_column(rng, "c%d" % b, n, card)
+        assert c.bits == b
+        cols.append(c)
+        ids.append(i)
+    seg = S.SegmentData("narrow", n, cols)
+    R = lambda col, lo, hi, ex=False: Q.leaf(Q.Pred.dict_range(col, lo, hi, exclusive=ex))
+    trees = [R(3, 3, 4), R(0, 0, 1), R(7, 7, 100), R(5, 0, 33, ex=True),
+             Q.and_(R(3, 3, 4), R(5, 5, 6), R(7, 7, 8)),
+             Q.or_(R(1, 0, 2), Q.not_(R(4, 8, 20)), R(6, 100, 101)),
+             Q.and_(Q.or_(R(2, 1, 3), R(3, 0, 9)), Q.not_(Q.and_(R(4, 0, 16), R(5, 10, 60, ex=True))), R(6, 0, 127)),
+             Q.not_(Q.not_(Q.or_(Q.and_(R(0, 1, 2), R(1, 1, 3)), Q.and_(R(2, 2, 7), Q.leaf(Q.Pred.match_all())), Q.leaf(Q.Pred.match_none()))))]
+    with engine.open(seg) as g:
+        for tree in trees:
+            spec = Q.QuerySpec([(Q.COUNT, -1)], filter=tree)
+            got = g.execute(spec)
+            want = oracle.execute(seg, spec)
+            H.assert_results_equal(got, want)
+            assert got.dominant_kernel == "scan_narrow_kernel"
+            words, card = g.filter_bitmap(spec)
+            owords, ocard = oracle.filter_bitmap(seg, spec)
+            assert card == ocard == got.aggregations[0].count and np.array_equal(words, owords)
+        # five masks deep, a 9-bit column, an aggregated column: scan_private_kernel keeps those
+        deep = Q.or_(R(0, 0, 1), Q.and_(R(1, 0, 2), Q.or_(R(2, 0, 3), Q.and_(R(3, 0, 4), Q.or_(R(4, 0, 5), R(5, 0, 6))))))
+        got = g.execute(Q.QuerySpec([(Q.COUNT, -1)], filter=deep))
+        H.assert_results_equal(got, oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1)], filter=deep)))
+        assert got.dominant_kernel != "scan_narrow_kernel"
+        got = g.execute(Q.QuerySpec([(Q.COUNT, -1), (Q.MAX, 7)], filter=R(3, 3, 4)))
+        assert got.dominant_kernel != "scan_narrow_kernel"
+    m = (ids[3] == 3) & (ids[5] == 5) & (ids[7] == 7)
+    with engine.open(seg) as g:
+        assert g.execute(Q.QuerySpec([(Q.COUNT, -1)], filter=trees[4])).aggregations[0].count == int(m.sum())
+
+
 @pytest.mark.parametrize("run_optimize", [False, True])
 def test_inverted_index_leaves(engine, run_optimize):
     """InvertedIndexFilterOperator + AndDocIdSet: postings (array / bitset / run containers) expanded on device,
