@@ -161,6 +161,27 @@ ResultsBlock blockFromArrays(bool is_group_by, const std::vector<AggregationFunc
   return block;
 }
 
+std::string resultTableJson(const ResultTable& t) {
+  std::ostringstream o;
+  o << "{\"columns\": [";
+  for (size_t i = 0; i < t.columnNames.size(); ++i) o << (i ? ", " : "") << "\"" << jsonEscape(t.columnNames[i]) << "\"";
+  o << "], \"rows\": [";
+  for (size_t r = 0; r < t.rows.size(); ++r) {
+    o << (r ? ", " : "") << "[";
+    for (size_t i = 0; i < t.rows[r].size(); ++i) {
+      const OrderByValue& v = t.rows[r][i];
+      o << (i ? ", " : "");
+      if (std::holds_alternative<std::monostate>(v)) o << "null";
+      else if (std::holds_alternative<int64_t>(v)) o << std::get<int64_t>(v);
+      else if (std::holds_alternative<double>(v)) o << num(std::get<double>(v));
+      else o << "\"" << jsonEscape(std::get<std::string>(v)) << "\"";
+    }
+    o << "]";
+  }
+  o << "]}";
+  return o.str();
+}
+
 template <typename F>
 int guarded(F f) {
   try { f(); return 0; }
@@ -359,7 +380,7 @@ char* ph_parse_sql(const char* sql, int32_t* status) {
       }
       o << "]";
     }
-    if (q.limit >= 0) o << ", \"limit\": " << q.limit;
+    if (!q.groupByExpressions.empty()) o << ", \"limit\": " << q.limit;      // (aggregation-only results are one row whatever the limit)
     o << "}";
     out = o.str();
   });
@@ -404,7 +425,10 @@ char* ph_execute_sql(void** segments, int32_t num_segments, const char* sql, int
     }
     const ResultsBlock combined = g_planMaker.executeCombined(ctxs, q, max_execution_threads);
     o << "], \"combined\": " << blockJson(combined);
-    if (combined.isGroupBy) o << ", \"reduced\": " << reducedJson(reduceGroupBy(combined, q));      // what the broker would answer
+    if (combined.isGroupBy) {      // what the broker would answer: every key and final result ("reduced"), and the SELECT list's projection of it
+      const std::vector<ReducedRow> rows = reduceGroupBy(combined, q);
+      o << ", \"reduced\": " << reducedJson(rows) << ", \"resultTable\": " << resultTableJson(toResultTable(rows, combined, q));
+    }
     o << "}";
     out = o.str();
   });
@@ -494,7 +518,9 @@ char* ph_group_by_combine(const char* sql, int32_t num_blocks, const int64_t* bl
     table.finish(false);
     const ResultsBlock combined = combineGroupByBlocks(blocks, q);
     std::ostringstream o;
-    o << "{\"combined\": " << blockJson(combined) << ", \"reduced\": " << reducedJson(reduceGroupBy(combined, q)) << ", \"table\": {\"resultSize\": " << sizes.resultSize()
+    const std::vector<ReducedRow> reduced = reduceGroupBy(combined, q);
+    o << "{\"combined\": " << blockJson(combined) << ", \"reduced\": " << reducedJson(reduced) << ", \"resultTable\": " << resultTableJson(toResultTable(reduced, combined, q))
+      << ", \"table\": {\"resultSize\": " << sizes.resultSize()
       << ", \"trimSize\": " << sizes.trimSize() << ", \"trimThreshold\": " << sizes.trimThreshold() << ", \"numResizes\": " << table.getNumResizes() << "}}";
     out = o.str();
   });

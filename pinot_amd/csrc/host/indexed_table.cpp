@@ -209,4 +209,26 @@ std::vector<ReducedRow> reduceGroupBy(const ResultsBlock& combined, const QueryC
   return rows;
 }
 
+ResultTable toResultTable(const std::vector<ReducedRow>& rows, const ResultsBlock& combined, const QueryContext& qc) {
+  const GroupByResultsBlock& g = combined.groupBy;
+  ResultTable t;
+  // a query that selects only aggregations shows only them (the group keys are not part of the result: PostAggregationHandler)
+  std::vector<SelectExpression> select = qc.selectExpressions;
+  for (const auto& se : select)
+    t.columnNames.push_back(se.isAggregation ? g.functions.at((size_t)se.index).getResultColumnName() : g.groupByColumns.at((size_t)se.index));
+  for (const ReducedRow& r : rows) {
+    std::vector<OrderByValue> row;
+    for (const auto& se : select) {
+      if (se.isAggregation) { row.push_back(r.finals.at((size_t)se.index)); continue; }
+      const GroupKeyValue& k = r.keys.at((size_t)se.index);
+      if (std::holds_alternative<int64_t>(k)) row.emplace_back(std::get<int64_t>(k));
+      else if (std::holds_alternative<double>(k)) row.emplace_back(std::get<double>(k));
+      else if (std::holds_alternative<std::string>(k)) row.emplace_back(std::get<std::string>(k));
+      else row.emplace_back(std::monostate{});
+    }
+    t.rows.push_back(std::move(row));
+  }
+  return t;
+}
+
 }  // namespace pinot

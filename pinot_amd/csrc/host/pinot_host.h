@@ -219,9 +219,12 @@ struct OrderByExpressionContext {
   bool isNullsLast() const { return nullsLast < 0 ? isAsc : nullsLast != 0; }
 };
 
+struct SelectExpression { bool isAggregation; int index; };   // one item of the SELECT list: aggregations[index] or groupByExpressions[index]
+
 struct QueryContext {
   std::string tableName;
-  std::vector<AggregationExpression> aggregations;
+  std::vector<SelectExpression> selectExpressions;   // what the result table shows, in SELECT order
+  std::vector<AggregationExpression> aggregations;   // the selected aggregations, then those that are only ordered by (QueryContext._aggregationFunctions)
   std::vector<std::string> groupByExpressions;
   bool hasFilter = false;
   FilterContext filter;
@@ -229,13 +232,12 @@ struct QueryContext {
   int numGroupsLimit = 100000;
   bool nullHandlingEnabled = false;                  // query option enableNullHandling (QueryContext.isNullHandlingEnabled)
   std::vector<OrderByExpressionContext> orderByExpressions;   // empty = no ORDER BY (getOrderByExpressions() == null)
-  int limit = -1;                                    // LIMIT n; -1 = no LIMIT clause.  The reference's parser would default to 10; this mirror's SQL is a
-                                                     // test vehicle and keeps every group unless the query says otherwise (getLimit() -> Integer.MAX_VALUE)
+  int limit = 10;                                    // LIMIT n; the parser's default of 10 rows without a LIMIT clause (CalciteSqlParser / PinotQuery.limit)
   int minSegmentGroupTrimSize = -1;                  // InstancePlanMakerImplV2.java:82-91 defaults; query options of the same names override
   int minServerGroupTrimSize = 5000;
   int groupTrimThreshold = 1000000;
   bool hasOrderBy() const { return !orderByExpressions.empty(); }
-  int getLimit() const { return limit < 0 ? 0x7FFFFFFF : limit; }
+  int getLimit() const { return limit; }
 };
 
 // QueryContextConverterUtils.getQueryContext(sql) for the SQL subset of this path:
@@ -432,6 +434,9 @@ void trimSegmentGroupByBlock(ResultsBlock* block, const QueryContext& queryConte
 // GroupByDataTableReducer: the broker's rows for a combined block -- merged into the reducer's table, sorted by ORDER BY, first LIMIT rows,
 // aggregations as final results
 struct ReducedRow { std::vector<GroupKeyValue> keys; std::vector<OrderByValue> finals; };
+// BrokerResponseNative.resultTable: the reduced rows projected onto the SELECT list (column names as the reference prints them)
+struct ResultTable { std::vector<std::string> columnNames; std::vector<std::vector<OrderByValue>> rows; };
+ResultTable toResultTable(const std::vector<ReducedRow>& rows, const ResultsBlock& combined, const QueryContext& queryContext);
 std::vector<ReducedRow> reduceGroupBy(const ResultsBlock& combined, const QueryContext& queryContext);
 
 // ---- the C ABI, resolved at run time from libpinot_gpu.so ---------------------------------------------------------

@@ -326,9 +326,17 @@ QueryContext getQueryContext(const std::string& sql) {
     else throw UnsupportedOperationException("query option '" + key.text + "' is not handled on this path");
   }
   lx.expectKeyword("SELECT");
+  std::vector<std::string> selectedColumns;      // plain identifiers of the SELECT list, resolved against GROUP BY below
   do {
     const Token fn = lx.next();
     if (fn.kind != Token::IDENT) throw QueryException("expected an aggregation function near '" + fn.text + "'");
+    if (!(lx.peek().kind == Token::SYMBOL && lx.peek().text == "(")) {
+      // SELECT column11, SUM(column1) ... GROUP BY column11: a group-by column in the result (anything else is a selection query)
+      if (lx.acceptKeyword("AS")) lx.next();
+      q.selectExpressions.push_back(SelectExpression{false, (int)selectedColumns.size()});
+      selectedColumns.push_back(fn.text);
+      continue;
+    }
     std::string u = fn.text;
     for (auto& c : u) c = (char)toupper((unsigned char)c);
     AggregationExpression e;
@@ -362,6 +370,7 @@ QueryContext getQueryContext(const std::string& sql) {
       if (alias.kind != Token::IDENT) throw QueryException("expected an alias near '" + alias.text + "'");
       e.alias = alias.text;
     }
+    q.selectExpressions.push_back(SelectExpression{true, (int)q.aggregations.size()});
     q.aggregations.push_back(e);
   } while (lx.acceptSymbol(","));
   lx.expectKeyword("FROM");
@@ -379,6 +388,16 @@ QueryContext getQueryContext(const std::string& sql) {
       if (c.kind != Token::IDENT) throw QueryException("expected a group-by column");
       q.groupByExpressions.push_back(c.text);
     } while (lx.acceptSymbol(","));
+  }
+  // identifiers of the SELECT list must be group-by columns; without aggregations nothing is offloaded
+  if (!selectedColumns.empty() && q.groupByExpressions.empty())
+    throw UnsupportedOperationException("only aggregation / group-by queries are offloaded (selection stays on the CPU plan)");
+  for (auto& se : q.selectExpressions) {
+    if (se.isAggregation) continue;
+    int found = -1;
+    for (size_t g = 0; g < q.groupByExpressions.size(); ++g) if (q.groupByExpressions[g] == selectedColumns[(size_t)se.index]) found = (int)g;
+    if (found < 0) throw QueryException("'" + selectedColumns[(size_t)se.index] + "' should appear in GROUP BY clause.");
+    se.index = found;
   }
   if (lx.acceptKeyword("ORDER")) {
     // ORDER BY <group-by column | one of the selected aggregations> [ASC | DESC] [NULLS FIRST | NULLS LAST] [, ...]
@@ -405,8 +424,20 @@ QueryContext getQueryContext(const std::string& sql) {
           static const char* const names[] = {"COUNT", "SUM", "MIN", "MAX", "AVG"};
           if (!e.hasFilter && u == names[(int)e.function] && (e.column == column || (e.function == AggregationFunctionType::COUNT && (column == "*" || e.column == "*")))) found = (int)a;
         }
-        // (the reference appends an ORDER BY aggregation that is not selected to the query's functions; here it has to be selected)
-        if (found < 0) throw UnsupportedOperationException("ORDER BY " + first.text + "(" + column + ") is not one of the selected aggregations");
+        if (found < 0) {
+          // an aggregation that is only ordered by joins the query's functions after the selected ones (QueryContext.Builder
+          // generateAggregationFunctions: SELECT expressions first, then HAVING / ORDER BY); the result does not show it
+          AggregationExpression e;
+          int kind = -1;
+          static const char* const names[] = {"COUNT", "SUM", "MIN", "MAX", "AVG"};
+          for (int k = 0; k < 5; ++k) if (u == names[k]) kind = k;
+          if (kind < 0) throw UnsupportedOperationException("only COUNT/SUM/MIN/MAX/AVG are offloaded, got " + first.text);
+          e.function = (AggregationFunctionType)kind;
+          e.column = column;
+          if (e.function != AggregationFunctionType::COUNT && column == "*") throw QueryException("'*' is only valid in COUNT(*)");
+          found = (int)q.aggregations.size();
+          q.aggregations.push_back(e);
+        }
         ob.isAggregation = true;
         ob.index = found;
       } else {

@@ -57,7 +57,7 @@ def test_inter_segment_results_through_combine(golden_segments):
         assert combined["stats"]["numTotalDocs"] == 120000
     # GROUP BY column9 ORDER BY COUNT(*) DESC LIMIT 1 -> 64420 / 17080 (InterSegment...testCount)
     for want, flt in ((64420, ""), (17080, FILTER)):
-        combined = host.execute_sql(segs, "SELECT COUNT(*) FROM testTable" + flt + " GROUP BY column9")["combined"]
+        combined = host.execute_sql(segs, "SELECT COUNT(*) FROM testTable" + flt + " GROUP BY column9 LIMIT 100000")["combined"]      # (no LIMIT = 10 groups)
         assert max(r["final"][0] for r in combined["groups"]) == float(want)
     # string group key comes back as dictionary VALUES
     combined = host.execute_sql(segs[:2], "SELECT COUNT(*), MAX(column1) FROM testTable GROUP BY column11, column12")["combined"]
@@ -113,6 +113,83 @@ def test_inter_segment_group_by_order_by_limit_goldens(golden_segments):
     for v in H.load_golden_columns()["column9"].tolist():
         counts[v] = counts.get(v, 0) + 1
     assert out["reduced"] == [[k, c] for k, c in sorted(counts.items(), key=lambda kv: (-kv[1], kv[0]))[:3]]
+
+
+# InterSegmentGroupBySingleValueQueriesTest.groupByOrderByDataProvider (:61-327): the reference's SQL, its expected
+# numEntriesScannedPostFilter and its expected result tables (the DISTINCTCOUNT / PERCENTILE / transform-function entries are not on this path)
+_C1112 = ["column11", "column12", "sum(column1)"]
+GROUP_BY_ORDER_BY_GOLDENS = [
+    ("SELECT column11, SUM(column1) FROM testTable GROUP BY column11 ORDER BY column11", 240000, ["column11", "sum(column1)"],
+     [["", 5935285005452.0], ["P", 88832999206836.0], ["gFuH", 63202785888.0], ["o", 18105331533948.0], ["t", 16331923219264.0]]),
+    ("SELECT column11, sum(column1) FROM testTable GROUP BY column11 ORDER BY column11 DESC", 240000, ["column11", "sum(column1)"],
+     [["t", 16331923219264.0], ["o", 18105331533948.0], ["gFuH", 63202785888.0], ["P", 88832999206836.0], ["", 5935285005452.0]]),
+    ("SELECT column11, Sum(column1) FROM testTable GROUP BY column11 ORDER BY column11 LIMIT 3", 240000, ["column11", "sum(column1)"],
+     [["", 5935285005452.0], ["P", 88832999206836.0], ["gFuH", 63202785888.0]]),
+    ("SELECT column11, column12, SUM(column1) FROM testTable GROUP BY column11, column12 ORDER BY column11, column12", 360000, _C1112,
+     [["", "HEuxNvH", 3789390396216.0], ["", "KrNxpdycSiwoRohEiTIlLqDHnx", 733802350944.0], ["", "MaztCmmxxgguBUxPti", 1333941430664.0], ["", "dJWwFk", 55470665124.0],
+      ["", "oZgnrlDEtjjVpUoFLol", 22680162504.0], ["P", "HEuxNvH", 21998672845052.0], ["P", "KrNxpdycSiwoRohEiTIlLqDHnx", 18069909216728.0],
+      ["P", "MaztCmmxxgguBUxPti", 27177029040008.0], ["P", "TTltMtFiRqUjvOG", 4462670055540.0], ["P", "XcBNHe", 120021767504.0]]),
+    ("SELECT column11, column12, SUM(column1) FROM testTable GROUP BY column11, column12 ORDER BY column11, column12 LIMIT 15", 360000, _C1112,
+     [["", "HEuxNvH", 3789390396216.0], ["", "KrNxpdycSiwoRohEiTIlLqDHnx", 733802350944.0], ["", "MaztCmmxxgguBUxPti", 1333941430664.0], ["", "dJWwFk", 55470665124.0],
+      ["", "oZgnrlDEtjjVpUoFLol", 22680162504.0], ["P", "HEuxNvH", 21998672845052.0], ["P", "KrNxpdycSiwoRohEiTIlLqDHnx", 18069909216728.0],
+      ["P", "MaztCmmxxgguBUxPti", 27177029040008.0], ["P", "TTltMtFiRqUjvOG", 4462670055540.0], ["P", "XcBNHe", 120021767504.0],
+      ["P", "dJWwFk", 6224665921376.0], ["P", "fykKFqiw", 1574451324140.0], ["P", "gFuH", 860077643636.0], ["P", "oZgnrlDEtjjVpUoFLol", 8345501392852.0],
+      ["gFuH", "HEuxNvH", 29872400856.0]]),
+    ("SELECT column11, column12, SUM(column1) FROM testTable GROUP BY column11, column12 ORDER BY column11, column12 DESC", 360000, _C1112,
+     [["", "oZgnrlDEtjjVpUoFLol", 22680162504.0], ["", "dJWwFk", 55470665124.0], ["", "MaztCmmxxgguBUxPti", 1333941430664.0], ["", "KrNxpdycSiwoRohEiTIlLqDHnx", 733802350944.0],
+      ["", "HEuxNvH", 3789390396216.0], ["P", "oZgnrlDEtjjVpUoFLol", 8345501392852.0], ["P", "gFuH", 860077643636.0], ["P", "fykKFqiw", 1574451324140.0],
+      ["P", "dJWwFk", 6224665921376.0], ["P", "XcBNHe", 120021767504.0]]),
+    ("SELECT column11, column12, SUM(column1) FROM testTable GROUP BY column11, column12 ORDER BY column11, sum(column1)", 360000, _C1112,
+     [["", "oZgnrlDEtjjVpUoFLol", 22680162504.0], ["", "dJWwFk", 55470665124.0], ["", "KrNxpdycSiwoRohEiTIlLqDHnx", 733802350944.0], ["", "MaztCmmxxgguBUxPti", 1333941430664.0],
+      ["", "HEuxNvH", 3789390396216.0], ["P", "XcBNHe", 120021767504.0], ["P", "gFuH", 860077643636.0], ["P", "fykKFqiw", 1574451324140.0],
+      ["P", "TTltMtFiRqUjvOG", 4462670055540.0], ["P", "dJWwFk", 6224665921376.0]]),
+    ("SELECT column11, column12, SUM(column1) FROM testTable GROUP BY column11, column12 ORDER BY SUM(column1) DESC LIMIT 50", 360000, _C1112,
+     [["P", "MaztCmmxxgguBUxPti", 27177029040008.0], ["P", "HEuxNvH", 21998672845052.0], ["P", "KrNxpdycSiwoRohEiTIlLqDHnx", 18069909216728.0],
+      ["P", "oZgnrlDEtjjVpUoFLol", 8345501392852.0], ["o", "MaztCmmxxgguBUxPti", 6905624581072.0], ["P", "dJWwFk", 6224665921376.0], ["o", "HEuxNvH", 5026384681784.0],
+      ["t", "MaztCmmxxgguBUxPti", 4492405624940.0], ["P", "TTltMtFiRqUjvOG", 4462670055540.0], ["t", "HEuxNvH", 4424489490364.0],
+      ["o", "KrNxpdycSiwoRohEiTIlLqDHnx", 4051812250524.0], ["", "HEuxNvH", 3789390396216.0], ["t", "KrNxpdycSiwoRohEiTIlLqDHnx", 3529048341192.0],
+      ["P", "fykKFqiw", 1574451324140.0], ["t", "dJWwFk", 1349058948804.0], ["", "MaztCmmxxgguBUxPti", 1333941430664.0], ["o", "dJWwFk", 1152689463360.0],
+      ["t", "oZgnrlDEtjjVpUoFLol", 1039101333316.0], ["P", "gFuH", 860077643636.0], ["", "KrNxpdycSiwoRohEiTIlLqDHnx", 733802350944.0],
+      ["o", "oZgnrlDEtjjVpUoFLol", 699381633640.0], ["t", "TTltMtFiRqUjvOG", 675238030848.0], ["t", "fykKFqiw", 480973878052.0], ["t", "gFuH", 330331507792.0],
+      ["o", "TTltMtFiRqUjvOG", 203835153352.0], ["P", "XcBNHe", 120021767504.0], ["o", "fykKFqiw", 62975165296.0], ["", "dJWwFk", 55470665124.0],
+      ["gFuH", "HEuxNvH", 29872400856.0], ["gFuH", "MaztCmmxxgguBUxPti", 29170832184.0], ["", "oZgnrlDEtjjVpUoFLol", 22680162504.0], ["t", "XcBNHe", 11276063956.0],
+      ["gFuH", "KrNxpdycSiwoRohEiTIlLqDHnx", 4159552848.0], ["o", "gFuH", 2628604920.0]]),
+    ("SELECT sum(column1), MIN(column6) FROM testTable GROUP BY column11 ORDER BY column11", 360000, ["sum(column1)", "min(column6)"],
+     [[5935285005452.0, 2.96467636E8], [88832999206836.0, 1689277.0], [63202785888.0, 2.96467636E8], [18105331533948.0, 2.96467636E8], [16331923219264.0, 1980174.0]]),
+    ("SELECT column11, column12, SUM(column1) FROM testTable GROUP BY column11, column12 ORDER BY SUM  (\tcolumn1) DESC LIMIT 3", 360000, _C1112,
+     [["P", "MaztCmmxxgguBUxPti", 27177029040008.0], ["P", "HEuxNvH", 21998672845052.0], ["P", "KrNxpdycSiwoRohEiTIlLqDHnx", 18069909216728.0]]),
+    ("SELECT column12, MIN(column6) FROM testTable GROUP BY column12 ORDER BY Min(column6) DESC, column12", 240000, ["column12", "min(column6)"],
+     [["XcBNHe", 329467557.0], ["fykKFqiw", 296467636.0], ["gFuH", 296467636.0], ["HEuxNvH", 6043515.0], ["MaztCmmxxgguBUxPti", 6043515.0], ["dJWwFk", 6043515.0],
+      ["KrNxpdycSiwoRohEiTIlLqDHnx", 1980174.0], ["TTltMtFiRqUjvOG", 1980174.0], ["oZgnrlDEtjjVpUoFLol", 1689277.0]]),
+    ("SELECT column12 FROM testTable GROUP BY column12 ORDER BY Min(column6) DESC, column12", 240000, ["column12"],
+     [["XcBNHe"], ["fykKFqiw"], ["gFuH"], ["HEuxNvH"], ["MaztCmmxxgguBUxPti"], ["dJWwFk"], ["KrNxpdycSiwoRohEiTIlLqDHnx"], ["TTltMtFiRqUjvOG"], ["oZgnrlDEtjjVpUoFLol"]]),
+    ("SELECT column12 FROM testTable GROUP BY column12 ORDER BY Min(column6) DESC, SUM(column1) LIMIT 3", 360000, ["column12"], [["XcBNHe"], ["gFuH"], ["fykKFqiw"]]),
+    ("SELECT column12, MIN(column6) FROM testTable GROUP BY column12 ORDER BY Min(column6) DESC, SUM(column1) LIMIT 3", 360000, ["column12", "min(column6)"],
+     [["XcBNHe", 329467557.0], ["gFuH", 296467636.0], ["fykKFqiw", 296467636.0]]),
+    ("select column17, count(*) from testTable group by column17 order by column17 limit 15", 120000, ["column17", "count(*)"],
+     [[83386499, 2924], [217787432, 3892], [227908817, 6564], [402773817, 7304], [423049234, 6556], [561673250, 7420], [635942547, 3308], [638936844, 3816],
+      [939479517, 3116], [984091268, 3824], [1230252339, 5620], [1284373442, 7428], [1555255521, 2900], [1618904660, 2744], [1670085862, 3388]]),
+    ("SELECT column11, AVG(column6) FROM testTable GROUP BY column11  ORDER BY column11", 240000, ["column11", "avg(column6)"],
+     [["", 296467636.0], ["P", 909380310.3521485], ["gFuH", 296467636.0], ["o", 296467636.0], ["t", 526245333.3900426]]),
+    ("SELECT column11, AVG(column6) FROM testTable GROUP BY column11 ORDER BY AVG(column6), column11 DESC", 240000, ["column11", "avg(column6)"],
+     [["o", 296467636.0], ["gFuH", 296467636.0], ["", 296467636.0], ["t", 526245333.3900426], ["P", 909380310.3521485]]),
+]
+
+
+@pytest.mark.parametrize("trim", [False, True])
+def test_group_by_order_by_goldens_with_the_reference_sql(golden_segments, trim):
+    """testGroupByOrderBy / testGroupByOrderByWithTrim: the result table of every query and (120000, 0, numEntriesScannedPostFilter, 120000);
+    the trim variant runs with minSegmentGroupTrimSize = 1 like TRIM_ENABLED_PLAN_MAKER (:38-41)."""
+    _, segs = golden_segments
+    for sql, post_filter, columns, rows in GROUP_BY_ORDER_BY_GOLDENS:
+        out = host.execute_sql(segs, ("SET minSegmentGroupTrimSize = 1; " if trim else "") + sql, max_execution_threads=4)
+        st = out["combined"]["stats"]
+        assert [st["numDocsScanned"], st["numEntriesScannedInFilter"], st["numEntriesScannedPostFilter"], st["numTotalDocs"]] == [120000, 0, post_filter, 120000], sql
+        assert out["resultTable"]["columns"] == columns, sql
+        got = out["resultTable"]["rows"]
+        assert len(got) == len(rows), sql
+        for g, w in zip(got, rows):
+            assert all((a == pytest.approx(b, rel=1e-12) if isinstance(b, float) else a == b) for a, b in zip(g, w)) and len(g) == len(w), (sql, g, w)
 
 
 def test_filtered_aggregations_run_as_swim_lanes(golden_segments):
@@ -258,7 +335,7 @@ def test_string_key_group_by_goldens_through_sql(golden_segments):
     g = H.load_golden_queries()["inter_segment_group_by_x4"]
     combined = host.execute_sql(segs, "SELECT SUM(column1) FROM testTable GROUP BY column11", max_execution_threads=4)["combined"]
     assert sorted([r["key"][0], r["final"][0]] for r in combined["groups"]) == g["sum_column1_by_column11"]
-    combined = host.execute_sql(segs, "SELECT SUM(column1) FROM testTable GROUP BY column11, column12", max_execution_threads=2)["combined"]
+    combined = host.execute_sql(segs, "SELECT SUM(column1) FROM testTable GROUP BY column11, column12 LIMIT 1000", max_execution_threads=2)["combined"]
     assert sorted([r["key"][0], r["key"][1], r["final"][0]] for r in combined["groups"])[:15] == g["sum_column1_by_column11_column12_first15"]
 
 

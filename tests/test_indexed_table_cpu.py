@@ -68,9 +68,9 @@ def test_no_more_new_records_without_order_by():
     got = {g["key"][0]: g["intermediate"][0] for g in out["combined"]["groups"]}
     assert got == {"a": 30.0, "b": 20.0, "c": 10.0, "d": 10.0, "e": 10.0}
     assert out["table"] == {"resultSize": 5, "trimSize": INT_MAX, "trimThreshold": INT_MAX, "numResizes": 0}
-    # without LIMIT the mirror keeps every group
+    # no LIMIT clause: the parser's default of 10 rows
     out = host.group_by_combine("SELECT SUM(m1), MAX(m2) FROM testTable GROUP BY d1, d2, d3", [ups], [S, I, D])
-    assert len(out["combined"]["groups"]) == 7 and len(out["reduced"]) == 7
+    assert out["table"]["resultSize"] == 10 and len(out["combined"]["groups"]) == 7 and len(out["reduced"]) == 7
 
 
 # ---- TableResizerTest.java:66-80: five records; SUM(m1), MAX(m2), AVG(m4) GROUP BY d1, d2, d3 -----------------------------
@@ -263,9 +263,25 @@ def test_parser_accepts_order_by_limit_and_rejects_what_is_not_on_the_path():
                                                {"expression": "d2", "asc": True, "nullsLast": False},
                                                {"expression": "sum(m1)", "asc": True, "nullsLast": True}]
     for sql, status in (("SELECT SUM(m1) FROM t GROUP BY d1 ORDER BY d9", 1),              # not in the GROUP BY clause (TableResizer.java:150)
-                        ("SELECT SUM(m1) FROM t GROUP BY d1 ORDER BY MAX(m1)", 2),         # not a selected aggregation: CPU plan
+                        ("SELECT SUM(m1) FROM t GROUP BY d1 ORDER BY DISTINCTCOUNT(m1)", 2),   # not an aggregation of this path: CPU plan
+                        ("SELECT d2, SUM(m1) FROM t GROUP BY d1", 1),                      # 'd2' should appear in GROUP BY clause
+                        ("SELECT d1 FROM t", 2),                                           # a selection query
                         ("SELECT SUM(m1) FROM t ORDER BY d1", 2),                          # selection-style ORDER BY
                         ("SELECT SUM(m1) FROM t GROUP BY d1 LIMIT -3", 1)):
         with pytest.raises(host.HostError) as e:
             host.parse_sql(sql)
         assert e.value.status == status, sql
+
+
+def test_select_list_columns_hidden_order_by_aggregations_and_the_result_table():
+    """The reference's result table shows the SELECT list: group-by columns where they are named, aggregations that are only ordered by
+    nowhere (QueryContext.Builder.generateAggregationFunctions appends them to the functions; InterSegmentGroupBySingleValueQueriesTest.java:165-190)."""
+    q = host.parse_sql("SELECT d1, SUM(m1) FROM t GROUP BY d1, d2 ORDER BY Min(m2) DESC, d1")
+    assert q["aggregations"] == ["sum(m1)", "min(m2)"] and q["orderBy"][0]["expression"] == "min(m2)" and "limit" in q and q["limit"] == 10
+    rows = [(("a", 1), [cell(total=5.0), cell(mn=3.0)]), (("b", 1), [cell(total=7.0), cell(mn=9.0)]), (("c", 2), [cell(total=1.0), cell(mn=9.0)])]
+    out = host.group_by_combine("SELECT d1, SUM(m1) FROM t GROUP BY d1, d2 ORDER BY Min(m2) DESC, d1", [rows], [S, I])
+    assert out["resultTable"] == {"columns": ["d1", "sum(m1)"], "rows": [["b", 7.0], ["c", 1.0], ["a", 5.0]]}
+    out = host.group_by_combine("SELECT SUM(m1), MIN(m2) FROM t GROUP BY d1, d2 ORDER BY d1 DESC LIMIT 2", [rows], [S, I])
+    assert out["resultTable"] == {"columns": ["sum(m1)", "min(m2)"], "rows": [[1.0, 9.0], [7.0, 9.0]]}
+    out = host.group_by_combine("SELECT d2, d1 FROM t GROUP BY d1, d2 ORDER BY COUNT(*) DESC, d1", [[(k, [cell(count=c)]) for (k, _), c in zip(rows, (4, 9, 9))]], [S, I])
+    assert out["resultTable"] == {"columns": ["d2", "d1"], "rows": [[1, "b"], [2, "c"], [1, "a"]]}
