@@ -239,7 +239,21 @@ FilterContext parsePredicate(Lexer& lx) {
     lx.expectSymbol(")");
     return f;
   }
-  if (negated) throw QueryException("expected IN after NOT");
+  if (negated && lx.acceptKeyword("BETWEEN")) {
+    // col NOT BETWEEN a AND b -> NOT(RANGE [a, b]) (CalciteSqlParser rewrites it into a NOT filter over the BETWEEN)
+    FilterContext inner;
+    inner.type = FilterContext::Type::PREDICATE;
+    inner.predicate.column = col.text;
+    inner.predicate.type = Predicate::Type::RANGE;
+    inner.predicate.lowerBound = literal(lx); inner.predicate.lowerInclusive = true;
+    lx.expectKeyword("AND");
+    inner.predicate.upperBound = literal(lx); inner.predicate.upperInclusive = true;
+    FilterContext n;
+    n.type = FilterContext::Type::NOT;
+    n.children.push_back(std::move(inner));
+    return n;
+  }
+  if (negated) throw QueryException("expected IN or BETWEEN after NOT");
   const Token op = lx.next();
   if (op.kind != Token::SYMBOL) throw QueryException("expected a comparison operator near '" + op.text + "'");
   const std::string v = literal(lx);

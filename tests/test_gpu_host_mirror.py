@@ -385,3 +385,44 @@ def test_execute_combined_over_segments_on_different_devices():
     finally:
         for s in segs:
             s.destroy()
+
+
+def test_fast_filtered_count_cases_of_the_reference_test():
+    """FastFilteredCountTest.java:103-318 with its own SQL (the TEXT_MATCH / JSON_MATCH entries are not on this path): 1000 records,
+    `sorted` = i (sorted column, inverted index), `class` = i % 8 (inverted index), `intRangeCol` = 1000 - i (the reference gives it a range
+    index, here it is scanned).  COUNT(*) over filters the indexes answer alone never scans an entry."""
+    from pinot_amd import segment as S
+    n, bucket = 1000, 8
+    i = np.arange(n, dtype=np.int32)
+    cols = [S.Column.dict_encoded("sorted", i, with_inverted=True), S.Column.dict_encoded("class", i % bucket, with_inverted=True),
+            S.Column.dict_encoded("intRangeCol", n - i)]
+    seg = host.HostSegment(S.SegmentData("testSegment", n, cols))
+    bc, bcc, lo, hi = n // bucket, n - n // bucket, 20, n - 20
+    all_buckets, two = "(0, 1, 2, 3, 4, 5, 6, 7)", "(0, 7)"
+    t = "select count(*) from testTable"
+    cases = [(t, n), (t + " where class = 1", bc), (t + " where sorted = 1", 1), (t + " where sorted between %d and %d" % (lo, hi), hi - lo + 1),
+             (t + " where sorted not between %d and %d" % (lo, hi), n - (hi - lo + 1)), (t + " where sorted in " + all_buckets, bucket),
+             (t + " where sorted in " + all_buckets + " and class in " + all_buckets, bucket), (t + " where class <> 1", bcc),
+             (t + " where class in " + two, 2 * bc), (t + " where class not in " + two, n - 2 * bc),
+             (t + " where class in " + two + " and sorted < %d" % (n // 2), bc), (t + " where sorted = 1 and class = 1", 1),
+             (t + " where sorted = 1 and class <> 1", 0), (t + " where sorted = 1 and class <> 0", 1),
+             (t + " where sorted <> 1 and class = 1", bc - 1), (t + " where sorted >= 0 and class = 1", bc), (t + " where sorted > 1 and class = 1", bc - 1),
+             (t + " where sorted >= 0 and class <> 1", bcc), (t + " where sorted >= 0 or class <> 0", n),
+             (t + " where sorted < %d and class <> 0" % bc, bc - bc // bucket - 1), (t + " where sorted >= %d and class <> 0" % bc, bcc - bcc // bucket),
+             (t + " where sorted < %d and class = %d" % (bucket - 1, bucket - 1), 0), (t + " where sorted >= %d and class = %d" % (bucket - 2, bucket - 2), bc),
+             (t + " where sorted >= %d and sorted < %d and class = 0" % (lo, hi), bc - (lo + n - hi) // bucket),
+             (t + " where intRangeCol >= %d and intRangeCol < %d" % (lo, hi), hi - lo), (t + " where intRangeCol < %d" % hi, hi - 1),
+             (t + " where intRangeCol not between %d and %d" % (lo, hi), n - hi + lo - 1),
+             (t + " where intRangeCol between %d and %d and class = 0" % (lo, hi), bc - (lo + n - hi) // bucket),
+             (t + " where intRangeCol not between %d and %d and class = 0" % (lo, hi), (lo + n - hi) // bucket)]
+    try:
+        for sql, want in cases:
+            b = host.execute_sql([seg], sql)["segments"][0]
+            assert b["intermediate"] == [want], sql
+            assert b["stats"]["numDocsScanned"] == want and b["stats"]["numTotalDocs"] == n, sql
+            if "intRangeCol" not in sql:
+                assert b["stats"]["numEntriesScannedInFilter"] == 0, sql          # sorted / inverted indexes only: nothing is scanned
+        two_segments = host.execute_sql([seg, seg], t + " where class in " + two + " and sorted < 500")["combined"]       # getIndexSegments(): the segment twice
+        assert two_segments["final"] == [2.0 * bc]
+    finally:
+        seg.destroy()

@@ -285,3 +285,22 @@ def test_select_list_columns_hidden_order_by_aggregations_and_the_result_table()
     assert out["resultTable"] == {"columns": ["sum(m1)", "min(m2)"], "rows": [[1.0, 9.0], [7.0, 9.0]]}
     out = host.group_by_combine("SELECT d2, d1 FROM t GROUP BY d1, d2 ORDER BY COUNT(*) DESC, d1", [[(k, [cell(count=c)]) for (k, _), c in zip(rows, (4, 9, 9))]], [S, I])
     assert out["resultTable"] == {"columns": ["d2", "d1"], "rows": [[1, "b"], [2, "c"], [1, "a"]]}
+
+
+@pytest.mark.parametrize("limit, min_segment, min_server, kept", [
+    (1, 100, 5000, 100), (1, 100, -1, 100), (1, -1, 100, 100), (1, 5000, 100, 100),              # low limit + high min trim size
+    (50, 50, 5000, 250), (50, 200, -1, 250), (50, -1, 150, 250), (50, 5000, 10, 250), (50, 20, 30, 250),   # high limit + low min trim size
+    (10, -1, -1, 10000),                                                                          # trim disabled
+])
+def test_group_by_trim_cases_of_the_reference_test(limit, min_segment, min_server, kept):
+    """GroupByTrimTest.java:224-262: 10 000 rows, every key its own group (metric_0 = 10 + 11 i, metric_1 = 11 + 11 i),
+    SELECT metric_0, max(metric_1) ... GROUP BY metric_0 ORDER BY max(metric_1) DESC LIMIT n under the (minSegmentGroupTrimSize,
+    minServerGroupTrimSize) pairs of its data provider: the combine operator's table holds exactly the top `kept` groups."""
+    rows = [((10.0 + 11 * i,), [cell(mx=11.0 + 11 * i)]) for i in range(10000)]
+    sql = ("SET minSegmentGroupTrimSize = %d; SET minServerGroupTrimSize = %d; SELECT metric_0, max(metric_1) FROM testTable GROUP BY metric_0 "
+           "ORDER BY max(metric_1) DESC LIMIT %d" % (min_segment, min_server, limit))
+    out = host.group_by_combine(sql, [rows], [D])
+    got = sorted(((g["key"][0], g["intermediate"][0]) for g in out["combined"]["groups"]), key=lambda kv: -kv[1])
+    want = [(10.0 + 11 * i, 11.0 + 11 * i) for i in range(9999, 9999 - kept, -1)]
+    assert got == want
+    assert out["resultTable"]["columns"] == ["metric_0", "max(metric_1)"] and out["resultTable"]["rows"] == [list(r) for r in want[:limit]]
