@@ -101,7 +101,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
 
     # ---- C5: inverted-index AND of 3 postings -> docIds -> SUM, sparse (C = 16 / 64 / 256) and dense (C = 2 / 4 / 8) ----
     for vid, cards, seeds, picks in (("C5-sparse", (16, 64, 256), (11, 12, 13), (3, 5, 7)), ("C5-dense", (2, 4, 8), (21, 22, 23), (1, 2, 5))):
-        if not (want(vid) or want(vid + "-count")):
+        if not (want(vid) or want(vid + "-count") or (vid == "C5-sparse" and want("C5-scan-count"))):
             continue
         t0 = time.time()
         cols = []
@@ -131,6 +131,11 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                 report(vid + "-count", "BASELINE.json configs[4], two postings, COUNT", "SELECT COUNT(*) WHERE p=%d AND q=%d via inverted indexes" % picks[:2], n_c5, post[0] + post[1], g, seg5,
                        Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(inv(0, picks[0]), inv(1, picks[1]))),
                        oracle_spec=Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(scan(0, picks[0]), scan(1, picks[1]))))
+            if vid == "C5-sparse" and want("C5-scan-count"):
+                # the same three predicates by SCANNING the 4 / 6 / 8-bit columns (no inverted index): scan_narrow_kernel, four tiles per wave and iteration
+                sspec = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(scan(0, picks[0]), scan(1, picks[1]), scan(2, picks[2])))
+                report("C5-scan-count", "BASELINE.json configs[4] without the inverted indexes, COUNT", "SELECT COUNT(*) WHERE p=%d AND q=%d AND r=%d by scanning p, q, r (%d / %d / %d bits)"
+                       % (picks + tuple(c.bits for c in cols)), n_c5, sum(B(c) for c in cols), g, seg5, sspec)
         del seg5, cols
 
     # ---- C1: 10 M rows, raw int32 forward index (BASELINE.json configs[0] is the reference's CPU case; COUNT(*) itself is O(1)) ----
