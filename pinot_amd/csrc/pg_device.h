@@ -77,7 +77,7 @@ struct DevLeaf {
 };
 
 constexpr int32_t kNodeCountEntries = 2; // scan leaf on the root AND chain behind an index-based child: ScanBasedDocIdIterator.applyAnd looks at every doc still standing
-constexpr int kNarrowTiles = 4, kNarrowMaxBits = 8, kNarrowStack = 4;      // scan_narrow_kernel (pg_scan_narrow.h)
+constexpr int kNarrowTiles = 4, kNarrowMaxBits = 8, kNarrowStack = 4, kNarrowSingleTiles = 8;      // scan_narrow_kernel / scan_narrow_single_kernel (pg_scan_narrow.h)
 constexpr int32_t kNodeExitIfZero = 1;   // root AND chain: the tile is finished (mask 0) if the running result is wave-zero
 
 // Host-side plan node (DevColumn / DevLeaf / PlanNode are what the engine reasons with).

@@ -68,6 +68,7 @@ struct Engine {
   bool group_private = true; // PINOT_GPU_GROUP_PRIVATE=0: unfiltered group-by through the LDS-staged kernel
   bool group_pack = true;    // PINOT_GPU_GROUP_PACK=0: separate count atomic in the group-by LDS table
   bool scan_typed_private = true;     // PINOT_GPU_SCAN_TYPED_PRIVATE=0: raw / 8-byte aggregated columns stay in the LDS-staged kernel
+  bool scan_narrow_single = true;     // PINOT_GPU_SCAN_NARROW_SINGLE=0: a single narrow leaf takes the general narrow kernel (four tiles per iteration)
   bool scan_narrow = true;            // PINOT_GPU_SCAN_NARROW=0: filters over columns of at most 8 bits stay in scan_private_kernel
   bool group_partition = true;        // PINOT_GPU_GROUP_PARTITION=0: key spaces above the LDS table always use direct HBM atomics
   long long partition_min_docs = 1ll << 22;   // ... =force: partition even tiny segments (tests)
@@ -1396,6 +1397,8 @@ pg_status pg_init(const pg_config* config) {
   const char* gpt = getenv("PINOT_GPU_GROUP_PARTITION");
   g_engine.group_partition = !(gpt && gpt[0] == '0');
   g_engine.partition_min_docs = (gpt && gpt[0] == 'f') ? 0 : (1ll << 22);
+  const char* sns = getenv("PINOT_GPU_SCAN_NARROW_SINGLE");
+  g_engine.scan_narrow_single = !(sns && sns[0] == '0');
   const char* snw = getenv("PINOT_GPU_SCAN_NARROW");
   g_engine.scan_narrow = !(snw && snw[0] == '0');
   const char* gtb = getenv("PINOT_GPU_GROUP_TABLE_BYTES");
@@ -2147,9 +2150,11 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       }
       use_narrow = use_narrow && max_depth <= kNarrowStack;
     }
+    const bool narrow_single = use_narrow && g_engine.scan_narrow_single && sp.num_nodes == 1 && sp.nodes[0].kind == kLeafDictRange;
     if (use_narrow) {
-      const long long quads = (((long long)seg->num_docs + 2047) / 2048 + kNarrowTiles - 1) / kNarrowTiles;
-      int bpc = std::max(1, waves_scan_narrow() / (kBlockThreads / 64));
+      const int per_wave = narrow_single ? kNarrowSingleTiles : kNarrowTiles;
+      const long long quads = (((long long)seg->num_docs + 2047) / 2048 + per_wave - 1) / per_wave;
+      int bpc = std::max(1, waves_scan_narrow(narrow_single) / (kBlockThreads / 64));
       if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
       blocks = (int)std::max<long long>(1, std::min<long long>((quads + 3) / 4, (long long)seg->num_cus * bpc));
     }
@@ -2174,7 +2179,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
     if (use_hist) launch_scan_hist(hist_cw, hist_guarded, blocks, hist_lds, ctx->stream, sp);
-    else if (use_narrow) launch_scan_narrow(blocks, ctx->stream, sp);
+    else if (use_narrow) launch_scan_narrow(narrow_single, blocks, ctx->stream, sp);
     else if (use_private) launch_scan_private(one, blocks, ctx->stream, sp);
     else if (use_private_typed) launch_scan_private_typed(blocks, ctx->stream, sp);
     else launch_scan_agg(g_engine.use_dma, one, typed, blocks, geo.threads, lds, ctx->stream, sp);

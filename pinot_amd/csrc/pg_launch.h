@@ -31,8 +31,8 @@ int waves_scan_agg(bool one_slot, bool typed);
 void launch_scan_private(bool one_slot, int blocks, hipStream_t stream, const ScanParams& p);
 int waves_scan_private(bool one_slot);
 // scan_narrow_kernel: COUNT(*) / docId bitmap of a filter over columns of at most 8 bits (pg_scan_narrow.h)
-void launch_scan_narrow(int blocks, hipStream_t stream, const ScanParams& p);
-int waves_scan_narrow();
+void launch_scan_narrow(bool single_leaf, int blocks, hipStream_t stream, const ScanParams& p);      // single_leaf: scan_narrow_single_kernel, eight tiles per iteration
+int waves_scan_narrow(bool single_leaf);
 // scan_group_kernel<kDma, kLdsTable>: LDS-staged group-by
 void launch_scan_group(bool dma, bool lds_table, int blocks, int threads, size_t lds, hipStream_t stream, const GroupParams& gp);
 int waves_scan_group();

@@ -136,4 +136,61 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_kernel(const
   }
 }
 
+// A single dictId-range leaf (WHERE dim = x, the commonest narrow filter): no mask stack, so EIGHT tiles fit per wave and iteration
+// (8 b <= 64 registers of loads in flight) in a kernel of its own register budget.
+template <int B>
+__device__ __forceinline__ unsigned narrow_single_octet(const ScanParams& p, const DevNode& L, long long first_tile, long long num_tiles, int lane) {
+  uint32_t w[kNarrowSingleTiles][B];
+#pragma unroll
+  for (int t = 0; t < kNarrowSingleTiles; ++t) {
+    const long long tile = first_tile + t < num_tiles ? first_tile + t : first_tile;       // past the end: a valid tile, masked below
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(L.fwd + tile * (256ll * B)) + lane * B;
+#pragma unroll
+    for (int i = 0; i < B; ++i) w[t][i] = words[i];
+  }
+  unsigned count = 0;
+  const uint32_t lo = (uint32_t)L.lo, span = L.span, flip = L.exclusive ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+  for (int t = 0; t < kNarrowSingleTiles; ++t) {
+    uint32_t mm = 0;
+    range16_private<B, 0, false>(w[t], lo, span, mm);
+    range16_private<B, 1, false>(w[t], lo, span, mm);
+    const long long tile = first_tile + t;
+    const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
+    const uint32_t mt = (__builtin_bitreverse32(mm) ^ flip) & (rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u)));
+    if (p.out_bitmap && tile < num_tiles) reinterpret_cast<uint32_t*>(p.out_bitmap)[tile * 64 + lane] = mt;
+    count += (unsigned)__builtin_popcount(mt);
+  }
+  return count;
+}
+
+static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_single_kernel(const ScanParams p) {
+  __shared__ unsigned long long red[kBlockThreads / 64];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  const long long total_waves = (long long)gridDim.x * waves_per_block;
+  const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
+  const long long num_octets = (num_tiles + kNarrowSingleTiles - 1) / kNarrowSingleTiles;
+  const DevNode& L = p.nodes[0];
+  unsigned long long count = 0;
+  for (long long o = (long long)blockIdx.x * waves_per_block + wave_in_block; o < num_octets; o += total_waves) {
+    switch (L.bits) {
+#define PG_CASE(B) case B: count += narrow_single_octet<B>(p, L, o * kNarrowSingleTiles, num_tiles, lane); break;
+      PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8)
+#undef PG_CASE
+      default: break;
+    }
+  }
+  const unsigned long long wave_count = (unsigned long long)wave_sum_i64((long long)count);
+  if (lane == 0) red[wave_in_block] = wave_count;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    BlockPartial acc;
+    partial_identity(acc);
+    for (int w = 0; w < waves_per_block; ++w) acc.count += red[w];
+    p.partials[blockIdx.x] = acc;
+  }
+}
+
 }  // namespace pg

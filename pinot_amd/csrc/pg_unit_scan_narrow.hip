@@ -4,13 +4,15 @@
 
 namespace pg {
 
-void launch_scan_narrow(int blocks, hipStream_t stream, const ScanParams& p) {
-  scan_narrow_kernel<<<dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream>>>(p);
+void launch_scan_narrow(bool single_leaf, int blocks, hipStream_t stream, const ScanParams& p) {
+  if (single_leaf) scan_narrow_single_kernel<<<dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream>>>(p);
+  else scan_narrow_kernel<<<dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream>>>(p);
 }
 
-int waves_scan_narrow() {
+int waves_scan_narrow(bool single_leaf) {
   static const int cap = max_waves_per_cu(scan_narrow_kernel);
-  return cap;
+  static const int cap1 = max_waves_per_cu(scan_narrow_single_kernel);
+  return single_leaf ? cap1 : cap;
 }
 
 }  // namespace pg
