@@ -40,6 +40,11 @@ char* ph_segment_describe(void* segment, int32_t* status);          /* JSON: col
 int32_t ph_plan_maker_init(int32_t device, int32_t time_kernels);
 char* ph_parse_sql(const char* sql, int32_t* status);               /* QueryContextConverterUtils.getQueryContext for the SQL subset */
 char* ph_lower_predicate(const char* sql_predicate, const void* dict, int32_t cardinality, int32_t* status);   /* PredicateEvaluatorProvider */
+/* the physical filter operator tree of the WHERE clause (FilterPlanNode + FilterOperatorUtils: leaf operator per predicate, MatchAll / Empty folding,
+ * AND children by priority) as text; the segment need not be loaded on a device */
+char* ph_explain_filter(void* segment, const char* sql, int32_t* status);
+/* RangePredicateEvaluatorFactory.newDictionaryBasedEvaluator over an INT dictionary; bounds as strings, "*" = unbounded */
+char* ph_lower_range_predicate(const void* dict, int32_t cardinality, const char* lower, int32_t lower_inclusive, const char* upper, int32_t upper_inclusive, int32_t* status);
 char* ph_execute_sql(void** segments, int32_t num_segments, const char* sql, int32_t max_execution_threads, int32_t* status);
 
 /* ---- DataTable V4 (DataTableImplV4.toBytes of the intermediate results: what the server sends the broker; host/datatable_v4.cpp) ---- */

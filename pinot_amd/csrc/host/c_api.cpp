@@ -409,6 +409,37 @@ char* ph_lower_predicate(const char* sql_predicate, const void* dict, int32_t ca
   return *status == 0 ? strdup(out.c_str()) : nullptr;
 }
 
+// The physical filter tree of `sql`'s WHERE clause over a segment (which need not be loaded on a device): see explainFilter
+char* ph_explain_filter(void* segment, const char* sql, int32_t* status) {
+  std::string out;
+  *status = guarded([&] { out = explainFilter(*(const ImmutableSegment*)segment, getQueryContext(sql)); });
+  return *status == 0 ? strdup(out.c_str()) : nullptr;
+}
+
+// A RangePredicate given by its bounds ("*" = unbounded) against an INT dictionary buffer: RangePredicateEvaluatorFactory.newDictionaryBasedEvaluator
+// (the reference's RangeOfflineDictionaryPredicateEvaluatorTest builds its predicates this way; SQL can only say one side at a time)
+char* ph_lower_range_predicate(const void* dict, int32_t cardinality, const char* lower, int32_t lower_inclusive, const char* upper, int32_t upper_inclusive, int32_t* status) {
+  std::string out;
+  *status = guarded([&] {
+    Predicate p;
+    p.column = "column";
+    p.type = Predicate::Type::RANGE;
+    p.lowerBound = lower; p.lowerInclusive = lower_inclusive != 0;
+    p.upperBound = upper; p.upperInclusive = upper_inclusive != 0;
+    DataSource ds;
+    ds.name = p.column;
+    ds.cardinality = cardinality;
+    ds.dictionary = std::make_shared<IntDictionary>((const uint8_t*)dict, cardinality);
+    const PredicateEvaluator ev = getPredicateEvaluator(p, ds);
+    std::ostringstream o;
+    o << "{\"alwaysTrue\": " << (ev.alwaysTrue ? "true" : "false") << ", \"alwaysFalse\": " << (ev.alwaysFalse ? "true" : "false")
+      << ", \"isRange\": " << (ev.isRange ? "true" : "false") << ", \"start\": " << ev.startDictId << ", \"end\": " << ev.endDictId
+      << ", \"numMatchingItems\": " << ev.getNumMatchingItems() << "}";
+    out = o.str();
+  });
+  return *status == 0 ? strdup(out.c_str()) : nullptr;
+}
+
 // getOperator(sql).nextBlock() per segment + the combined block: {"segments": [...], "combined": {...}}
 char* ph_execute_sql(void** segments, int32_t num_segments, const char* sql, int32_t max_execution_threads, int32_t* status) {
   std::string out;

@@ -424,6 +424,10 @@ class IndexedTable {
   int _numResizes = 0;
 };
 
+// The physical filter operator tree FilterPlanNode / FilterOperatorUtils would build for the query's WHERE clause on this segment, as text
+// (SORTED / BITMAP / INVERTED / SCAN leaves, AND children in execution order); needs no device
+std::string explainFilter(const ImmutableSegment& segment, const QueryContext& queryContext);
+
 // GroupByCombineOperator: the segments' group-by blocks through one IndexedTable (plan_maker.cpp)
 ResultsBlock combineGroupByBlocks(const std::vector<ResultsBlock>& blocks, const QueryContext& queryContext);
 

@@ -351,6 +351,38 @@ PhysNode lowerFilter(const FilterContext& f, const ImmutableSegment& seg, bool n
   throw std::logic_error("unreachable filter type");
 }
 
+// The physical filter tree as text: which operator FilterOperatorUtils would build for every node, in the order the AND children run.
+//   SORTED(col docs a..b)   SortedIndexBasedFilterOperator     BITMAP(col IS [NOT] NULL)  BitmapBasedFilterOperator over the null vector
+//   INVERTED(col ...)       InvertedIndexFilterOperator        SCAN(col ...)              ScanBasedFilterOperator
+std::string explainPhysical(const PhysNode& n, const LoweredQuery& lq, const ImmutableSegment& seg) {
+  switch (n.kind) {
+    case PhysNode::MATCH_ALL: return "MATCH_ALL";
+    case PhysNode::EMPTY: return "EMPTY";
+    case PhysNode::NOT: return "NOT(" + explainPhysical(n.children[0], lq, seg) + ")";
+    case PhysNode::AND: case PhysNode::OR: {
+      std::string s = n.kind == PhysNode::AND ? "AND(" : "OR(";
+      for (size_t i = 0; i < n.children.size(); ++i) s += (i ? ", " : "") + explainPhysical(n.children[i], lq, seg);
+      return s + ")";
+    }
+    default: break;
+  }
+  const pg_predicate& p = lq.predicates.at((size_t)n.predicate);
+  const std::string col = p.column >= 0 && p.column < (int)seg.getDataSources().size() ? seg.getDataSources()[(size_t)p.column].name : std::string("?");
+  const std::string neg = p.exclusive ? " NOT" : "";
+  switch (p.kind) {
+    case PG_PRED_DOC_RANGE: return "SORTED(" + col + neg + " docs " + std::to_string(p.lo) + ".." + std::to_string(p.hi) + ")";
+    case PG_PRED_IS_NULL: return "BITMAP(" + col + " IS" + neg + " NULL)";
+    case PG_PRED_RAW_RANGE: return "SCAN(" + col + neg + " raw " + std::to_string(p.lo) + ".." + std::to_string(p.hi) + ")";
+    case PG_PRED_DICT_RANGE:
+      return std::string(p.eval == PG_EVAL_INVERTED ? "INVERTED(" : "SCAN(") + col + neg + " dictIds " + std::to_string(p.lo) + ".." + std::to_string(p.hi - 1) + ")";
+    default: {
+      int count = 0;
+      for (int w = 0; w < p.num_set_words; ++w) count += __builtin_popcount(p.set_words[w]);
+      return std::string(p.eval == PG_EVAL_INVERTED ? "INVERTED(" : "SCAN(") + col + neg + " in " + std::to_string(count) + " dictIds)";
+    }
+  }
+}
+
 void flattenFilter(const PhysNode& n, LoweredQuery* out) {
   switch (n.kind) {
     case PhysNode::MATCH_ALL: case PhysNode::EMPTY: {
@@ -509,6 +541,16 @@ class GpuAggregationPlanNode : public PlanNode {
 };
 
 }  // namespace
+
+// FilterPlanNode.run() of the query's WHERE clause over this segment, as text (no device involved)
+std::string explainFilter(const ImmutableSegment& seg, const QueryContext& qc) {
+  if (!qc.hasFilter) return "MATCH_ALL";
+  LoweredQuery lq;
+  lq.setWords.reserve(64);
+  lq.predicates.reserve(256);
+  const PhysNode root = lowerFilter(qc.filter, seg, qc.nullHandlingEnabled, &lq);
+  return explainPhysical(root, lq, seg);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // GpuPlanMaker

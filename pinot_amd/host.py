@@ -91,7 +91,9 @@ def _attach_null_vectors(lib, handle, columns):
 class HostSegment:
     """ImmutableSegment of the C++ host mirror built from a `SegmentData` (buffers stay owned by the SegmentData)."""
 
-    def __init__(self, segment_data, string_dicts=None, device=0):
+    def __init__(self, segment_data, string_dicts=None, device=0, load=True):
+        """load=False: the host-side segment only (data sources, dictionaries, sorted / inverted index metadata), nothing on a device --
+        enough for parse / plan inspection (`explain_filter`)."""
         lib = _lib()
         self.lib = lib
         self.data = segment_data
@@ -112,9 +114,10 @@ class HostSegment:
             if st != 0:
                 raise HostError(st, (lib.ph_last_error() or b"").decode())
         _attach_null_vectors(lib, self.handle, segment_data.columns)
-        st = lib.ph_segment_load(self.handle, device)
-        if st != 0:
-            raise HostError(st, (lib.ph_last_error() or b"").decode())
+        if load:
+            st = lib.ph_segment_load(self.handle, device)
+            if st != 0:
+                raise HostError(st, (lib.ph_last_error() or b"").decode())
 
     def destroy(self):
         if self.handle:
@@ -142,6 +145,21 @@ class DirectorySegment:
         if self.handle:
             self.lib.ph_segment_destroy(self.handle)
             self.handle = None
+
+
+def explain_filter(segment, sql):
+    """The physical filter operator tree (FilterPlanNode + FilterOperatorUtils) of `sql`'s WHERE clause over `segment`, as text."""
+    lib = _lib()
+    lib.ph_explain_filter.restype = C.c_void_p
+    lib.ph_explain_filter.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]
+    st = C.c_int32()
+    ptr = lib.ph_explain_filter(segment.handle, sql.encode(), C.byref(st))
+    if st.value != 0 or not ptr:
+        raise HostError(st.value, (lib.ph_last_error() or b"").decode("utf-8", "replace"))
+    try:
+        return C.string_at(ptr).decode("utf-8")
+    finally:
+        lib.ph_free(ptr)
 
 
 def execute_sql(segments, sql, max_execution_threads=0):

@@ -4,6 +4,7 @@ import pytest
 
 from oracle import oracle
 from pinot_amd import host
+from pinot_amd import segment as S
 
 
 def test_parse_sql_shapes():
@@ -61,3 +62,92 @@ def test_predicate_lowering_matches_the_oracle():
     one = oracle.dict_write(np.array([5], dtype=np.int32))
     assert host.lower_predicate("c = 5", one, 1)["alwaysTrue"]     # EqualsPredicateEvaluatorFactory.java:103-105
     assert host.lower_predicate("c != 5", one, 1)["alwaysFalse"]
+
+
+def test_range_evaluator_cases_of_the_reference_test():
+    """RangeOfflineDictionaryPredicateEvaluatorTest.java:35-250: a sorted dictionary of DICT_LEN = 10 entries whose insertion index of a bound
+    is the bound itself (here: the values 0..9), every combination of inclusive / exclusive bounds, the boundaries ("*" when the range
+    starts at dictId 0 inclusive or ends at DICT_LEN - 1 inclusive) and the zero range; getMatchingDictIds is [start, end)."""
+    import ctypes as C
+    import json
+    lib = host._lib()
+    lib.ph_lower_range_predicate.restype = C.c_void_p
+    lib.ph_lower_range_predicate.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
+    dict_len = 10
+    d = oracle.dict_write(np.arange(dict_len, dtype=np.int32))
+
+    def evaluator(lower, incl_lower, upper, incl_upper):
+        lo = "*" if (lower == 0 and incl_lower) else str(lower)               # createPredicate :262-272
+        hi = "*" if (upper == dict_len - 1 and incl_upper) else str(upper)
+        st = C.c_int32()
+        ptr = lib.ph_lower_range_predicate(d.ctypes.data, dict_len, lo.encode(), int(incl_lower), hi.encode(), int(incl_upper), C.byref(st))
+        assert st.value == 0 and ptr
+        try:
+            return json.loads(C.string_at(ptr).decode())
+        finally:
+            lib.ph_free(ptr)
+
+    def check(ev, first, last, always_false=False):
+        assert ev["alwaysFalse"] == always_false and not ev["alwaysTrue"] and ev["isRange"]
+        matching = list(range(ev["start"], ev["end"]))
+        assert matching == list(range(first, last + 1)) and ev["numMatchingItems"] == len(matching)      # verifyDictId
+        for dict_id in range(-1, dict_len + 1):                                                         # applySV
+            assert (ev["start"] <= dict_id < ev["end"]) == (first <= dict_id <= last)
+
+    check(evaluator(2, True, 5, True), 2, 5)          # testRanges: [2, 5]
+    check(evaluator(2, False, 5, True), 3, 5)         # (2, 5]
+    check(evaluator(2, True, 5, False), 2, 4)         # [2, 5)
+    check(evaluator(2, False, 5, False), 3, 4)        # (2, 5)
+    check(evaluator(0, True, 5, False), 0, 4)         # testBoundaries: [0, 5)
+    check(evaluator(0, True, 5, True), 0, 5)          # [0, 5]
+    check(evaluator(6, True, dict_len - 1, True), 6, dict_len - 1)       # [6, DICT_LEN - 1]
+    check(evaluator(6, False, dict_len - 1, True), 7, dict_len - 1)      # (6, DICT_LEN - 1]
+    check(evaluator(4, False, 5, False), 5, 4, always_false=True)        # testZeroRange: (4, 5)
+    whole = evaluator(0, True, dict_len - 1, True)                       # both unbounded: every dictId
+    assert whole["alwaysTrue"] and (whole["start"], whole["end"]) == (0, dict_len)
+
+
+def _plan_segment():
+    n = 1000
+    i = np.arange(n, dtype=np.int32)
+    nullable = S.Column.dict_encoded("n", (i * 3) % 50).with_nulls(i % 17 == 0)
+    cols = [S.Column.dict_encoded("s", i // 10, with_inverted=True), S.Column.dict_encoded("inv", i % 8, with_inverted=True),
+            S.Column.dict_encoded("scan", (i * 7) % 100), nullable]
+    return host.HostSegment(S.SegmentData("planSegment", n, cols), load=False)
+
+
+def test_filter_operator_folding_and_priorities_of_the_reference_test():
+    """FilterOperatorUtilsTest.java:47-200 through SQL: getAnd/Or/NotFilterOperator fold Empty and MatchAll children
+    (testGetAndFilterOperator, testGetOrFilterOperator), and the children of an AND run by priority whatever their order in the query
+    (testPriority: sorted, NOT(sorted) < bitmap < AND < OR, NOT(OR) < scan < unknown -- the inverted-index operator of this fork is
+    none of the classes the reorder knows).  The plan is read back with ph_explain_filter; no device."""
+    seg = _plan_segment()
+    ex = lambda where: host.explain_filter(seg, "SELECT COUNT(*) FROM planSegment WHERE " + where)
+    try:
+        empty, match_all, regular = "inv = 999", "inv != 999", "scan > 5"            # EmptyFilterOperator, MatchAllFilterOperator, a scan
+        scan = "SCAN(scan dictIds 6..99)"
+        assert ex(empty) == "EMPTY" and ex(match_all) == "MATCH_ALL" and ex(regular) == scan
+        assert ex(empty + " AND " + match_all) == "EMPTY" and ex(empty + " AND " + regular) == "EMPTY" and ex(match_all + " AND " + regular) == scan
+        assert ex(empty + " OR " + match_all) == "MATCH_ALL" and ex(empty + " OR " + regular) == scan and ex(match_all + " OR " + regular) == "MATCH_ALL"
+        assert ex("NOT " + empty) == "MATCH_ALL" and ex("NOT " + match_all) == "EMPTY" and ex("NOT " + regular) == "NOT(" + scan + ")"
+        # priority classes, highest first; every operator of a class before every operator of a later class, in either query order
+        classes = [[("s = 7", "SORTED(s docs 70..79)"), ("NOT s = 7", "NOT(SORTED(s docs 70..79))")],
+                   [("n IS NULL", "BITMAP(n IS NULL)")],
+                   [("(scan > 5 AND n IS NOT NULL)", "AND(BITMAP(n IS NOT NULL), SCAN(scan dictIds 6..99))")],
+                   [("(scan > 5 OR inv = 3)", "OR(SCAN(scan dictIds 6..99), INVERTED(inv dictIds 3..3))"),
+                    ("NOT (scan > 5 OR inv = 3)", "NOT(OR(SCAN(scan dictIds 6..99), INVERTED(inv dictIds 3..3)))")],
+                   [("scan < 50", "SCAN(scan dictIds 0..49)")],
+                   [("inv = 2", "INVERTED(inv dictIds 2..2)")]]
+        for a in range(len(classes)):
+            for high_sql, high in classes[a]:
+                for b in range(a + 1, len(classes)):
+                    for low_sql, low in classes[b]:
+                        want = "AND(" + high + ", " + low + ")"
+                        assert ex(low_sql + " AND " + high_sql) == want and ex(high_sql + " AND " + low_sql) == want
+        # the sort is stable: two scans keep the query's order
+        assert ex("scan < 50 AND scan > 5") == "AND(SCAN(scan dictIds 0..49), SCAN(scan dictIds 6..99))"
+        assert ex("scan > 5 AND scan < 50") == "AND(SCAN(scan dictIds 6..99), SCAN(scan dictIds 0..49))"
+        # sorted columns: IN / NOT IN are docId ranges of one sorted-index operator, adjacent dictIds merged
+        assert ex("s IN (1, 2, 5)") == "OR(SORTED(s docs 10..29), SORTED(s docs 50..59))" and ex("s NOT IN (0, 99)") == "SORTED(s docs 10..989)"
+    finally:
+        seg.destroy()
