@@ -45,6 +45,8 @@ char* ph_lower_predicate(const char* sql_predicate, const void* dict, int32_t ca
 char* ph_explain_filter(void* segment, const char* sql, int32_t* status);
 /* RangePredicateEvaluatorFactory.newDictionaryBasedEvaluator over an INT dictionary; bounds as strings, "*" = unbounded */
 char* ph_lower_range_predicate(const void* dict, int32_t cardinality, const char* lower, int32_t lower_inclusive, const char* upper, int32_t upper_inclusive, int32_t* status);
+/* the raw-value range evaluator of an INT (0) / LONG (1) column: inclusive [rawLower, rawUpper] */
+char* ph_lower_raw_range_predicate(int32_t data_type, const char* lower, int32_t lower_inclusive, const char* upper, int32_t upper_inclusive, int32_t* status);
 char* ph_execute_sql(void** segments, int32_t num_segments, const char* sql, int32_t max_execution_threads, int32_t* status);
 
 /* ---- DataTable V4 (DataTableImplV4.toBytes of the intermediate results: what the server sends the broker; host/datatable_v4.cpp) ---- */

@@ -440,6 +440,29 @@ char* ph_lower_range_predicate(const void* dict, int32_t cardinality, const char
   return *status == 0 ? strdup(out.c_str()) : nullptr;
 }
 
+// A RangePredicate on a RAW (no-dictionary) INT (data_type 0) or LONG (1) column: RangePredicateEvaluatorFactory.newRawValueBasedEvaluator;
+// the evaluator matches lower <= value <= upper (both inclusive after the exclusive bounds were stepped inwards)
+char* ph_lower_raw_range_predicate(int32_t data_type, const char* lower, int32_t lower_inclusive, const char* upper, int32_t upper_inclusive, int32_t* status) {
+  std::string out;
+  *status = guarded([&] {
+    Predicate p;
+    p.column = "column";
+    p.type = Predicate::Type::RANGE;
+    p.lowerBound = lower; p.lowerInclusive = lower_inclusive != 0;
+    p.upperBound = upper; p.upperInclusive = upper_inclusive != 0;
+    DataSource ds;
+    ds.name = p.column;
+    ds.hasDictionary = false;
+    ds.dataType = data_type == 1 ? DataType::LONG : DataType::INT;
+    const PredicateEvaluator ev = getPredicateEvaluator(p, ds);
+    std::ostringstream o;
+    o << "{\"alwaysTrue\": " << (ev.alwaysTrue ? "true" : "false") << ", \"alwaysFalse\": " << (ev.alwaysFalse ? "true" : "false")
+      << ", \"rawLower\": " << ev.rawLower << ", \"rawUpper\": " << ev.rawUpper << "}";
+    out = o.str();
+  });
+  return *status == 0 ? strdup(out.c_str()) : nullptr;
+}
+
 // getOperator(sql).nextBlock() per segment + the combined block: {"segments": [...], "combined": {...}}
 char* ph_execute_sql(void** segments, int32_t num_segments, const char* sql, int32_t max_execution_threads, int32_t* status) {
   std::string out;

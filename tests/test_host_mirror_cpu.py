@@ -151,3 +151,35 @@ def test_filter_operator_folding_and_priorities_of_the_reference_test():
         assert ex("s IN (1, 2, 5)") == "OR(SORTED(s docs 10..29), SORTED(s docs 50..59))" and ex("s NOT IN (0, 99)") == "SORTED(s docs 10..989)"
     finally:
         seg.destroy()
+
+
+@pytest.mark.parametrize("data_type, type_min, type_max", [(0, -2 ** 31, 2 ** 31 - 1), (1, -2 ** 63, 2 ** 63 - 1)])
+def test_raw_range_evaluator_cases_of_the_reference_test(data_type, type_min, type_max):
+    """NoDictionaryRangePredicateEvaluatorTest.java:35-140 (testIntPredicateEvaluator / testLongPredicateEvaluator): every bound shape of a
+    range on a raw INT / LONG column, applied to -20..19 and to the type's extremes."""
+    import ctypes as C
+    import json
+    lib = host._lib()
+    lib.ph_lower_raw_range_predicate.restype = C.c_void_p
+    lib.ph_lower_raw_range_predicate.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
+
+    def evaluator(lower, incl_lower, upper, incl_upper):
+        st = C.c_int32()
+        ptr = lib.ph_lower_raw_range_predicate(data_type, str(lower).encode(), int(incl_lower), str(upper).encode(), int(incl_upper), C.byref(st))
+        assert st.value == 0 and ptr, (lib.ph_last_error() or b"").decode()
+        try:
+            ev = json.loads(C.string_at(ptr).decode())
+        finally:
+            lib.ph_free(ptr)
+        return lambda v: (not ev["alwaysFalse"]) and ev["rawLower"] <= v <= ev["rawUpper"]
+
+    for bounds, want in ((( -10, True, 10, True), lambda i: -10 <= i <= 10), ((-10, False, 10, True), lambda i: -10 < i <= 10),
+                         ((-10, False, 10, False), lambda i: -10 < i < 10), (("*", False, 10, True), lambda i: i <= 10),
+                         (("*", False, 10, False), lambda i: i < 10), ((10, True, "*", True), lambda i: i >= 10),
+                         ((10, False, "*", False), lambda i: i > 10), (("*", False, "*", False), lambda i: True)):
+        apply_sv = evaluator(*bounds)
+        assert all(apply_sv(i) == want(i) for i in range(-20, 20)), bounds
+    unbounded = evaluator("*", False, "*", False)
+    assert unbounded(type_min) and unbounded(type_max)
+    open_extremes = evaluator(type_min, False, type_max, False)          # (MIN_VALUE, MAX_VALUE): everything but the extremes
+    assert all(open_extremes(i) for i in range(-20, 20)) and not open_extremes(type_min) and not open_extremes(type_max)
