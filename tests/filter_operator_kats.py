@@ -1,0 +1,93 @@
+"""Shared by test_oracle_filter_operator_kats.py (the oracle) and test_gpu_filter_operator_kats.py (the kernels): filter evaluation against the known answers of the reference's filter operator tests
+(pinot-core/src/test/java/org/apache/pinot/core/operator/filter/{And,Or,Not}FilterOperatorTest.java): the docId lists of their
+TestFilterOperators become columns whose value is 1 in those docs (and NULL in the tests' nullDocIds), the operators become the
+filter tree, and getTrues() / getFalses() are the docs matching the tree / its negation under null handling."""
+import numpy as np
+
+from pinot_amd import query as Q
+from pinot_amd import segment as S
+
+
+def segment(num_docs, doc_id_lists, null_lists=None, inverted=()):
+    cols = []
+    for k, ids in enumerate(doc_id_lists):
+        v = np.zeros(num_docs, dtype=np.int32)
+        v[list(ids)] = 1
+        col = S.Column.dict_encoded("f%d" % k, v, with_inverted=k in inverted)
+        if null_lists and null_lists[k]:
+            mask = np.zeros(num_docs, dtype=bool)
+            mask[list(null_lists[k])] = True
+            col = col.with_nulls(mask)
+        cols.append(col)
+    return S.SegmentData("ops", num_docs, cols)
+
+
+def leaf(seg, k, inverted=False):
+    card = seg.columns[k].cardinality          # {0, 1}: dictId 1 is the value 1; a column of all zeros has no dictId 1
+    return Q.leaf(Q.Pred.dict_range(k, 1, 2, inverted=inverted)) if card == 2 else Q.leaf(Q.Pred.match_none())
+
+
+def docs_of_bitmap(seg, words, card):
+    out = [d for d in range(seg.num_docs) if (int(words[d >> 6]) >> (d & 63)) & 1]
+    assert len(out) == card
+    return out
+
+
+def check_and_filter_operator_known_answers(docs):
+    # testIntersectionForTwoLists / ThreeLists / testComplex (AndFilterOperatorTest.java:35-92)
+    for inverted in ((), (0, 1, 2)):
+        seg = segment(40, [[2, 3, 10, 15, 16, 28], [3, 6, 8, 20, 28]], inverted=inverted)
+        assert docs(seg, Q.and_(leaf(seg, 0, 0 in inverted), leaf(seg, 1, 1 in inverted))) == [3, 28]
+        seg = segment(40, [[2, 3, 6, 10, 15, 16, 28], [3, 6, 8, 20, 28], [1, 2, 3, 6, 30]], inverted=inverted)
+        l = [leaf(seg, k, k in inverted) for k in range(3)]
+        assert docs(seg, Q.and_(*l)) == [3, 6]
+        assert docs(seg, Q.and_(Q.and_(l[0], l[1]), l[2])) == [3, 6]
+    # testAndDocIdSetReordering (:94-135): multiples of 2, 3, 4, 5 among 10 000 docs, in either child order
+    lists = [[j for j in range(10000) if j % i == 0] for i in range(2, 6)]
+    seg = segment(10000, lists, inverted=(0, 1, 2, 3))
+    for order in ((0, 1, 2, 3), (3, 2, 1, 0)):
+        assert docs(seg, Q.and_(*[leaf(seg, k, True) for k in order]))[:4] == [0, 60, 120, 180]
+
+
+def check_or_filter_operator_known_answers(docs):
+    # testUnionForTwoLists / ThreeLists / testComplex (OrFilterOperatorTest.java:37-110): the sorted union
+    a, b, c = [2, 3, 6, 10, 15, 16, 28], [3, 6, 8, 20, 28], [1, 2, 3, 6, 30]
+    seg = segment(40, [[2, 3, 10, 15, 16, 28], b])
+    assert docs(seg, Q.or_(leaf(seg, 0), leaf(seg, 1))) == sorted(set([2, 3, 10, 15, 16, 28]) | set(b))
+    seg = segment(40, [a, b, c])
+    l = [leaf(seg, k) for k in range(3)]
+    assert docs(seg, Q.or_(*l)) == sorted(set(a) | set(b) | set(c)) == docs(seg, Q.or_(Q.or_(l[0], l[1]), l[2]))
+
+
+def check_or_filter_operator_trues_and_falses_under_null_handling(docs):
+    # testOrWithNull (:113-127): trues 0..3, falses 8, 9 (docs 4..7 are unknown)
+    seg = segment(10, [[1, 2, 3], [0, 1, 2]], null_lists=[[4, 5, 6], [3, 4, 5, 6, 7]])
+    tree = Q.or_(leaf(seg, 0), leaf(seg, 1))
+    assert docs(seg, tree, True) == [0, 1, 2, 3] and docs(seg, Q.not_(tree), True) == [8, 9]
+    # testOrWithNullHandlingButNoNullValues (:129-143)
+    seg = segment(10, [[1, 2, 3], [0, 1, 2]])
+    tree = Q.or_(leaf(seg, 0), leaf(seg, 1))
+    assert docs(seg, tree, True) == [0, 1, 2, 3] and docs(seg, Q.not_(tree), True) == [4, 5, 6, 7, 8, 9]
+    # testOrWithNullOneFilterIsEmpty (:145-157) / ...IsMatchAll (:159-171) / testOrWithNullTwoFiltersAreEmpty (:173-183)
+    seg = segment(10, [[1, 2, 3]], null_lists=[[4, 5, 6]])
+    tree = Q.or_(leaf(seg, 0), Q.leaf(Q.Pred.match_none()))
+    assert docs(seg, tree, True) == [1, 2, 3] and docs(seg, Q.not_(tree), True) == [0, 7, 8, 9]
+    tree = Q.or_(leaf(seg, 0), Q.leaf(Q.Pred.match_all()))
+    assert docs(seg, tree, True) == list(range(10)) and docs(seg, Q.not_(tree), True) == []
+    tree = Q.or_(Q.leaf(Q.Pred.match_none()), Q.leaf(Q.Pred.match_none()))
+    assert docs(seg, tree, True) == [] and docs(seg, Q.not_(tree), True) == list(range(10))
+
+
+def check_not_filter_operator_known_answers(docs):
+    # testNotOperator (NotFilterOperatorTest.java:33-45): the complement within 30 docs
+    ids = [2, 3, 10, 15, 16, 17, 18, 21, 22, 23, 24, 26, 28]
+    seg = segment(30, [ids])
+    assert docs(seg, Q.not_(leaf(seg, 0))) == [d for d in range(30) if d not in ids]
+    # testNotWithNull (:47-58): trues 7..9, falses 0..3
+    seg = segment(10, [[0, 1, 2, 3]], null_lists=[[4, 5, 6]])
+    tree = Q.not_(leaf(seg, 0))
+    assert docs(seg, tree, True) == [7, 8, 9] and docs(seg, Q.not_(tree), True) == [0, 1, 2, 3]
+    # testNotEmptyFilterOperator (:60-68)
+    seg = segment(5, [[0]])
+    tree = Q.not_(Q.leaf(Q.Pred.match_none()))
+    assert docs(seg, tree, True) == [0, 1, 2, 3, 4] and docs(seg, Q.not_(tree), True) == []
