@@ -91,3 +91,23 @@ def check_not_filter_operator_known_answers(docs):
     seg = segment(5, [[0]])
     tree = Q.not_(Q.leaf(Q.Pred.match_none()))
     assert docs(seg, tree, True) == [0, 1, 2, 3, 4] and docs(seg, Q.not_(tree), True) == []
+
+
+def check_doc_id_iterator_sets(docs):
+    """operator/dociditerators/{And,Or,Not,Sorted}DocIdIteratorTest.java: the docId sets those iterators walk (their next / advance
+    sequences visit exactly these docs)."""
+    a = [[0, 1, 2, 3, 5, 7, 10, 12, 13, 15, 16, 18, 20], [1, 2, 4, 5, 6, 7, 9, 11, 12, 13, 15, 16, 17, 19, 20], [0, 2, 3, 4, 7, 8, 10, 11, 13, 15, 16, 19, 20]]
+    seg = segment(21, a, inverted=(0, 1, 2))
+    assert docs(seg, Q.and_(*[leaf(seg, k, True) for k in range(3)])) == [2, 7, 13, 15, 16, 20]          # AndDocIdIteratorTest :32-33
+    assert docs(seg, Q.and_(*[leaf(seg, k) for k in range(3)])) == [2, 7, 13, 15, 16, 20]
+    o = [[1, 4, 6, 10, 15, 17, 18, 20], [0, 1, 5, 8, 15, 18], [1, 2, 6, 13, 16, 19]]
+    seg = segment(21, o, inverted=(0, 1, 2))
+    want = [0, 1, 2, 4, 5, 6, 8, 10, 13, 15, 16, 17, 18, 19, 20]                                          # OrDocIdIteratorTest :32
+    assert docs(seg, Q.or_(*[leaf(seg, k, True) for k in range(3)])) == want == docs(seg, Q.or_(*[leaf(seg, k) for k in range(3)]))
+    seg = segment(25, [o[0]], inverted=(0,))                                                              # NotDocIdIteratorTest: 25 docs
+    assert docs(seg, Q.not_(leaf(seg, 0, True))) == [0, 2, 3, 5, 7, 8, 9, 11, 12, 13, 14, 16, 19, 21, 22, 23, 24]
+    seg = segment(40, [[0]])                                                                              # SortedDocIdIteratorTest: docId ranges
+    R = lambda lo, hi: Q.leaf(Q.Pred.doc_range(lo, hi))
+    assert docs(seg, R(1, 1)) == [1] and docs(seg, R(5, 15)) == list(range(5, 16))
+    assert docs(seg, Q.or_(R(20, 25), R(30, 35))) == list(range(20, 26)) + list(range(30, 36))
+    assert docs(seg, Q.or_(R(3, 3), R(8, 8), R(15, 15), R(20, 20))) == [3, 8, 15, 20]
