@@ -111,3 +111,26 @@ def check_doc_id_iterator_sets(docs):
     assert docs(seg, R(1, 1)) == [1] and docs(seg, R(5, 15)) == list(range(5, 16))
     assert docs(seg, Q.or_(R(20, 25), R(30, 35))) == list(range(20, 26)) + list(range(30, 36))
     assert docs(seg, Q.or_(R(3, 3), R(8, 8), R(15, 15), R(20, 20))) == [3, 8, 15, 20]
+
+
+# BitmapCollectionTest.java:30-205: (left docs, left inverted, right docs, right inverted, expected) over 10 docs
+_AND_CARDINALITY = [((0, 5), False, (0, 4), False, 1), ((0, 5), False, (1, 4), False, 0), ((0, 5), False, (), False, 0), ((), False, (0, 5), False, 0),
+                    ((), False, (), False, 0), ((0, 5), True, (0, 4), False, 1), ((0, 5), True, (1, 4), False, 2), ((0, 5), True, (), False, 0),
+                    ((), True, (0, 5), False, 2), ((), True, (), False, 0), ((0, 5), False, (0, 4), True, 1), ((0, 5), False, (1, 4), True, 2),
+                    ((0, 5), False, (), True, 2), ((), False, (), True, 0), ((), False, (0, 5), True, 0), ((0, 5), True, (0, 4), True, 7),
+                    ((0, 5), True, (1, 4), True, 6), ((0, 5), True, (), True, 8), ((), True, (0, 5), True, 8), ((), True, (), True, 10)]
+_OR_CARDINALITY = [((0, 5), False, (0, 4), False, 3), ((0, 5), False, (1, 4), False, 4), ((0, 5), False, (), False, 2), ((), False, (0, 5), False, 2),
+                   ((), False, (), False, 0), ((0, 5), True, (0, 4), False, 9), ((0, 5), True, (1, 4), False, 8), ((0, 5), True, (), False, 8),
+                   ((), True, (0, 5), False, 10), ((), True, (), False, 10), ((0, 5), False, (0, 4), True, 9), ((0, 5), False, (1, 4), True, 8),
+                   ((0, 5), False, (), True, 10), ((), False, (0, 5), True, 8), ((), False, (), True, 10), ((0, 5), True, (0, 4), True, 9),
+                   ((0, 5), True, (1, 4), True, 10), ((0, 5), True, (), True, 10), ((), True, (0, 5), True, 10), ((), True, (), True, 10)]
+
+
+def check_bitmap_collection_cardinalities(docs):
+    """andCardinality / orCardinality of two (possibly inverted) bitmaps: COUNT(*) of [NOT] left AND / OR [NOT] right over inverted-index leaves."""
+    for cases, combine in ((_AND_CARDINALITY, Q.and_), (_OR_CARDINALITY, Q.or_)):
+        for left, left_inverted, right, right_inverted, expected in cases:
+            seg = segment(10, [left, right], inverted=(0, 1))
+            l, r = leaf(seg, 0, True), leaf(seg, 1, True)
+            tree = combine(Q.not_(l) if left_inverted else l, Q.not_(r) if right_inverted else r)
+            assert len(docs(seg, tree)) == expected, (combine.__name__, left, left_inverted, right, right_inverted)

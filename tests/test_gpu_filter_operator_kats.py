@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("check", [K.check_and_filter_operator_known_answers, K.check_or_filter_operator_known_answers,
                                    K.check_or_filter_operator_trues_and_falses_under_null_handling, K.check_not_filter_operator_known_answers,
-                                   K.check_doc_id_iterator_sets])
+                                   K.check_doc_id_iterator_sets, K.check_bitmap_collection_cardinalities])
 def test_kernels_against_the_filter_operator_tests(engine, check):
     def docs(seg, tree, null_handling=False):
         spec = Q.QuerySpec([(Q.COUNT, -1)], filter=tree, null_handling=null_handling)

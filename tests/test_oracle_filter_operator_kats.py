@@ -13,6 +13,6 @@ def docs(seg, tree, null_handling=False):
 
 @pytest.mark.parametrize("check", [K.check_and_filter_operator_known_answers, K.check_or_filter_operator_known_answers,
                                    K.check_or_filter_operator_trues_and_falses_under_null_handling, K.check_not_filter_operator_known_answers,
-                                   K.check_doc_id_iterator_sets])
+                                   K.check_doc_id_iterator_sets, K.check_bitmap_collection_cardinalities])
 def test_oracle_against_the_filter_operator_tests(check):
     check(docs)
