@@ -183,3 +183,37 @@ def test_raw_range_evaluator_cases_of_the_reference_test(data_type, type_min, ty
     assert unbounded(type_min) and unbounded(type_max)
     open_extremes = evaluator(type_min, False, type_max, False)          # (MIN_VALUE, MAX_VALUE): everything but the extremes
     assert all(open_extremes(i) for i in range(-20, 20)) and not open_extremes(type_min) and not open_extremes(type_max)
+
+
+def test_sql_parser_never_crashes_on_mutated_queries():
+    """The SQL subset is a test vehicle, but it reads untrusted text: every mutation of valid queries must come back as a parsed query or as
+    one of the three error classes (1 QueryException, 2 UnsupportedOperationException, 3 other std::exception), never a crash."""
+    seeds = ["SELECT COUNT(*), SUM(a) FROM t WHERE a > 1 AND (b IN (1, 2, -3) OR NOT c BETWEEN 5 AND 9) AND d <> 'x''y' GROUP BY k1, k2 ORDER BY COUNT(*) DESC, k1 NULLS FIRST LIMIT 7",
+             "SET enableNullHandling = true; SET minServerGroupTrimSize = 3; SELECT k, AVG(a) AS v FROM t WHERE a IS NOT NULL GROUP BY k ORDER BY v, k DESC",
+             "SELECT SUM(a) FILTER (WHERE b > 3 AND c = 'x'), MAX(a) FROM t WHERE d NOT BETWEEN 1 AND 5 OR e NOT IN (1, 2) GROUP BY e LIMIT 0",
+             "select column17, count(*) from testTable group by column17 order by Min(column6) desc, column17 limit 15"]
+    tokens = ["SELECT", "FROM", "WHERE", "GROUP", "BY", "ORDER", "LIMIT", "AND", "OR", "NOT", "IN", "BETWEEN", "IS", "NULL", "NULLS", "FIRST", "LAST", "ASC", "DESC", "AS",
+              "FILTER", "SET", "(", ")", ",", ";", "*", "=", "<>", "<", ">=", "'", "''", "1", "-1", "1e400", "99999999999999999999", "a", "k", "COUNT", "SUM", "DISTINCTCOUNT", "\t", "\x00"[:0], "é"]
+    rng = np.random.default_rng(2024)
+    checked = 0
+    for seed_sql in seeds:
+        words = seed_sql.split(" ")
+        for _ in range(400):
+            w = list(words)
+            for _ in range(int(rng.integers(1, 4))):
+                op, at = int(rng.integers(0, 4)), int(rng.integers(0, len(w)))
+                if op == 0 and len(w) > 1:
+                    del w[at]
+                elif op == 1:
+                    w.insert(at, tokens[int(rng.integers(0, len(tokens)))])
+                elif op == 2:
+                    w[at] = tokens[int(rng.integers(0, len(tokens)))]
+                else:
+                    w[at] = w[at][: int(rng.integers(0, len(w[at]) + 1))]
+            sql = " ".join(w)
+            try:
+                host.parse_sql(sql)
+            except host.HostError as e:
+                assert e.status in (1, 2, 3), (sql, e.status)
+            checked += 1
+    assert checked == 1600
