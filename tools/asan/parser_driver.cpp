@@ -1,11 +1,44 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <algorithm>
 #include <string>
 #include <vector>
 #include "../../include/pinot_host_c.h"
+// PINOT_ASAN_SQL_FILE: one query per line, parsed (and, for group-by queries, combined over a tiny synthetic block) under the sanitizers
+static void run_sql_file(const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return;
+  char line[4096];
+  int n = 0, ok = 0;
+  // 3 rows, room for 8 key columns and 16 functions per row
+  const int64_t rows = 3;
+  int32_t kt[8]; int64_t kl[24], counts[48]; double kd[24], vals[48]; const char* ks[24]; uint8_t kn[24], nulls[48];
+  for (int i = 0; i < 8; ++i) kt[i] = i % 3 == 0 ? 4 : (i % 3 == 1 ? 0 : 3);      // STRING, INT, DOUBLE, ...
+  for (int i = 0; i < 24; ++i) { kl[i] = i % 5; kd[i] = (i % 4) * 0.5; ks[i] = (i / 8) % 2 ? "b" : "a"; kn[i] = i == 9; }
+  for (int i = 0; i < 48; ++i) { counts[i] = 1 + i % 7; vals[i] = (i * 37 % 11) - 3.5; nulls[i] = i % 13 == 5; }
+  while (fgets(line, sizeof(line), f)) {
+    size_t len = strlen(line);
+    while (len && (line[len - 1] == '\n' || line[len - 1] == '\r')) line[--len] = 0;
+    int32_t st = 0;
+    char* r = ph_parse_sql(line, &st);
+    ++n;
+    if (r) { ++ok; ph_free(r); }
+    // the combine entry reads (rows x keys) and (rows x functions) cells: only hand it queries whose shape fits the arrays above
+    int parens = 0, commas = 0;
+    for (const char* c = line; *c; ++c) { parens += *c == '('; commas += *c == ','; }
+    if (st == 0 && strstr(line, "GROUP BY k1, k2") && !strstr(line, "FILTER") && parens <= 12 && commas <= 7) {
+      r = ph_group_by_combine(line, 1, &rows, kt, kl, kd, ks, kn, counts, vals, vals, vals, nulls, &st);
+      if (r) ph_free(r);
+    }
+  }
+  fclose(f);
+  printf("sql file: %d queries, %d parsed\n", n, ok);
+}
+
 int main() {
+  if (const char* sql_file = getenv("PINOT_ASAN_SQL_FILE")) run_sql_file(sql_file);
   const char* qs[] = {
     "SELECT COUNT(*), SUM(column1), MAX(column3), MIN(column6), AVG(column7) FROM testTable",
     "select sum(a) as s from t where a > 1 and (b in (1, 2, -3) or not c between 5 and 9) and d <> 'x''y' group by k1, k2",
