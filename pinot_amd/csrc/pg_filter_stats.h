@@ -17,7 +17,9 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "../../include/pinot_gpu.h"
@@ -100,15 +102,21 @@ struct ScanIterator : Iterator {
     }
     return batch[cursor++];
   }
+  // SVScanDocIdIterator.advance (:91-106) looks at doc t, t + 1, ... until one matches, one entry each: here the next set bit of the
+  // leaf's bitmap is found a word at a time and the docs in between are charged in one addition.
   int32_t advance(int32_t t) override {
     next_doc = t;
     first_mismatch = 0;
-    while (next_doc < num_docs) {
-      const int32_t d = next_doc++;
-      ++*entries;
-      if (match(d)) return d;
-    }
-    return kEof;
+    if (t >= num_docs) return kEof;
+    const size_t nw = ((size_t)num_docs + 63) / 64;
+    size_t w = (size_t)t >> 6;
+    uint64_t bits = (*matches)[w] & (~0ull << (t & 63));
+    while (bits == 0ull && ++w < nw) bits = (*matches)[w];
+    const int64_t d = bits ? (int64_t)(w << 6) + __builtin_ctzll(bits) : (int64_t)num_docs;
+    if (d >= num_docs) { *entries += num_docs - t; next_doc = num_docs; return kEof; }
+    *entries += d - t + 1;
+    next_doc = (int32_t)d + 1;
+    return (int32_t)d;
   }
   Type type() const override { return Type::kScan; }
 };
@@ -394,14 +402,116 @@ inline Plan choose_plan(const pg_query* q, int* num_scan_leaves) {
   return Plan::kReplay;
 }
 
-// The walk itself: DocIdSetOperator pulls next() until EOF (core/operator/DocIdSetOperator.java:66-90).
-inline int64_t replay(const pg_query* q, int32_t num_docs, const std::vector<Words>& leaf_words) {
+// The commonest replayed shape -- a root AND whose children are all scan leaves -- without iterator objects: the loop of
+// AndDocIdIterator.next() (:41-74) over SVScanDocIdIterator.advance (:91-106), every advance a word-level search for the leaf's next
+// match that charges the docs it passes.  Same count as the generic walk (tests/test_filter_stats_cpu.py compares both with the oracle).
+inline int64_t replay_and_of_scans(const std::vector<const uint64_t*>& leaves, int32_t num_docs) {
+  const int n = (int)leaves.size();
+  const size_t nw = ((size_t)num_docs + 63) / 64;
   int64_t entries = 0;
-  TreeBuilder builder(q, &leaf_words);
-  const DocIdSet root = builder.trues(q->num_filter_nodes - 1);
+  int32_t next_doc = 0;
+  for (;;) {
+    int32_t max_doc = next_doc;
+    int max_index = -1, index = 0;
+    while (index < n) {
+      if (index == max_index) { ++index; continue; }
+      if (max_doc >= num_docs) return entries;                 // advance past the end: EOF, nothing looked at
+      const uint64_t* m = leaves[(size_t)index];
+      size_t w = (size_t)max_doc >> 6;
+      uint64_t bits = m[w] & (~0ull << (max_doc & 63));
+      while (bits == 0ull && ++w < nw) bits = m[w];
+      const int64_t d = bits ? (int64_t)(w << 6) + __builtin_ctzll(bits) : (int64_t)num_docs;
+      if (d >= num_docs) return entries + (num_docs - max_doc);
+      entries += d - max_doc + 1;
+      if (d == max_doc) ++index;
+      else { max_doc = (int32_t)d; max_index = index; index = 0; }
+    }
+    next_doc = max_doc + 1;                                    // a result doc; DocIdSetOperator asks for the next one
+  }
+}
+
+// The same count in parallel.  The loop above is a state machine over the docs: exactly one leaf is SCANNING at any doc (it looks at
+// every doc until one matches); at its match the other leaves are asked about that doc in child order, one entry each, until one says
+// no -- that one scans on from the next doc -- and when all say yes the doc is a result and child 0 scans on.  A chunk of docs is
+// therefore a function {scanning leaf at its first doc} -> {entries, scanning leaf after its last doc}: every chunk is simulated from
+// each of the k possible states on its own thread, and the chunks' tables are chained in order afterwards.
+struct ChunkOutcome { int64_t entries; int end_state; };
+
+inline ChunkOutcome simulate_and_chunk(const std::vector<const uint64_t*>& leaves, int32_t begin, int32_t end, int state) {
+  const int n = (int)leaves.size();
+  int64_t entries = 0;
+  int32_t d = begin;
+  const size_t last_word = ((size_t)end + 63) / 64;
+  while (d < end) {
+    const uint64_t* m = leaves[(size_t)state];
+    size_t w = (size_t)d >> 6;
+    uint64_t bits = m[w] & (~0ull << (d & 63));
+    while (bits == 0ull && ++w < last_word) bits = m[w];
+    const int64_t p = bits ? (int64_t)(w << 6) + __builtin_ctzll(bits) : (int64_t)end;
+    if (p >= end) { entries += end - d; break; }               // still scanning at the end of the chunk
+    entries += p - d + 1;
+    int next_state = 0;
+    for (int i = 0; i < n; ++i) {
+      if (i == state) continue;
+      ++entries;
+      if (!((leaves[(size_t)i][(size_t)p >> 6] >> (p & 63)) & 1ull)) { next_state = i; break; }
+    }
+    state = next_state;
+    d = (int32_t)p + 1;
+  }
+  return ChunkOutcome{entries, state};
+}
+
+inline int64_t replay_and_of_scans_parallel(const std::vector<const uint64_t*>& leaves, int32_t num_docs, int32_t chunk_docs, int num_threads) {
+  const int k = (int)leaves.size();
+  chunk_docs = std::max(chunk_docs, 64);
+  const int num_chunks = (int)(((int64_t)num_docs + chunk_docs - 1) / chunk_docs);
+  if (num_chunks <= 1 || num_threads <= 1) return replay_and_of_scans(leaves, num_docs);
+  std::vector<ChunkOutcome> table((size_t)num_chunks * (size_t)k);
+  std::atomic<int> next_chunk{0};
+  auto worker = [&] {
+    for (int c = next_chunk.fetch_add(1); c < num_chunks; c = next_chunk.fetch_add(1)) {
+      const int32_t begin = (int32_t)((int64_t)c * chunk_docs), end = (int32_t)std::min<int64_t>(num_docs, (int64_t)begin + chunk_docs);
+      // chunk 0 starts with child 0 scanning: its other rows are never read
+      for (int s = 0; s < (c == 0 ? 1 : k); ++s) table[(size_t)c * (size_t)k + (size_t)s] = simulate_and_chunk(leaves, begin, end, s);
+    }
+  };
+  std::vector<std::thread> threads;
+  for (int t = 1; t < std::min(num_threads, num_chunks); ++t) threads.emplace_back(worker);
+  worker();
+  for (auto& t : threads) t.join();
+  int64_t entries = 0;
+  int state = 0;
+  for (int c = 0; c < num_chunks; ++c) {
+    const ChunkOutcome& o = table[(size_t)c * (size_t)k + (size_t)state];
+    entries += o.entries;
+    state = o.end_state;
+  }
+  return entries;
+}
+
+// The walk itself: DocIdSetOperator pulls next() until EOF (core/operator/DocIdSetOperator.java:66-90).
+inline int64_t replay_generic(const DocIdSet& root, int32_t num_docs) {
+  int64_t entries = 0;
   IteratorPtr it = make_iterator(root, num_docs, &entries);
   while (it->next() != kEof) {}
   return entries;
+}
+
+// chunk_docs / num_threads <= 0: the defaults (1 Mi docs per chunk, the host's cores up to 32; small segments stay on one thread).
+// use_fast_paths = false forces the iterator objects (tests compare the two).
+inline int64_t replay(const pg_query* q, int32_t num_docs, const std::vector<Words>& leaf_words, bool use_fast_paths = true, int32_t chunk_docs = 0, int num_threads = 0) {
+  TreeBuilder builder(q, &leaf_words);
+  const DocIdSet root = builder.trues(q->num_filter_nodes - 1);
+  if (use_fast_paths && root.kind == DocIdSet::Kind::kAnd && root.children.size() >= 2) {
+    std::vector<const uint64_t*> scans;
+    for (const DocIdSet& c : root.children) if (c.kind == DocIdSet::Kind::kScan && c.words) scans.push_back(c.words->data());
+    if (scans.size() == root.children.size()) {
+      if (num_threads <= 0) num_threads = num_docs >= (1 << 22) ? (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u) : 1;
+      return replay_and_of_scans_parallel(scans, num_docs, chunk_docs > 0 ? chunk_docs : (1 << 20), num_threads);
+    }
+  }
+  return replay_generic(root, num_docs);
 }
 
 }  // namespace fstats

@@ -26,12 +26,27 @@ def driver(tmp_path_factory):
         pytest.skip("needs g++")
     out = str(tmp_path_factory.mktemp("fstats") / "libfstats_driver.so")
     src = os.path.join(ROOT, "tools", "fstats", "fstats_driver.cpp")
-    base = ["g++", "-std=c++17", "-O1", "-g", "-shared", "-fPIC", "-Wall", "-Werror", "-o", out, src]
+    base = ["g++", "-std=c++17", "-O1", "-g", "-shared", "-fPIC", "-pthread", "-Wall", "-Werror", "-o", out, src]
     subprocess.run(base, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     lib = C.CDLL(out)
     lib.fstats_replay.restype = C.c_int64
     lib.fstats_replay.argtypes = [C.POINTER(_abi.pg_query), C.c_int32, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.fstats_replay_mode.restype = C.c_int64
+    lib.fstats_replay_mode.argtypes = [C.POINTER(_abi.pg_query), C.c_int32, C.POINTER(C.POINTER(C.c_uint64)), C.c_int32, C.c_int32, C.c_int32]
     return lib
+
+
+def leaf_bitmaps(seg, spec):
+    preds = spec.predicates
+    keep, ptrs = [], (C.POINTER(C.c_uint64) * max(len(preds), 1))()
+    for i, p in enumerate(preds):
+        if p.kind in (_abi.PG_PRED_MATCH_ALL, _abi.PG_PRED_MATCH_NONE):
+            continue
+        words, _ = oracle.filter_bitmap(seg, Q.QuerySpec([], filter=Q.leaf(p)))
+        words = np.ascontiguousarray(np.concatenate([words, np.zeros(1, dtype=np.uint64)]))
+        keep.append(words)
+        ptrs[i] = words.ctypes.data_as(C.POINTER(C.c_uint64))
+    return keep, ptrs
 
 
 def replay(lib, seg, spec):
@@ -105,3 +120,28 @@ def test_replay_matches_the_oracle_on_random_trees(driver):
         if plan == PLAN_ZERO:
             assert entries == 0
     assert plans == {PLAN_ZERO, PLAN_PER_LEAF, PLAN_CHAIN, PLAN_REPLAY}
+
+
+def test_and_of_scan_leaves_three_ways(driver):
+    """The commonest replayed shape, an AND of k scan leaves: the iterator objects, the word-level loop and the parallel state machine
+    (chunks of 997 docs on 4 threads, so that every chunk boundary falls somewhere else) agree with each other, with the oracle and with
+    the state machine as tests/helpers.py states it."""
+    rng = np.random.default_rng(99)
+    for n in (1, 63, 64, 65, 1000, 20_011, 131_075):
+        k = int(rng.integers(2, 5))
+        cols, masks = [], []
+        for c in range(k):
+            card = int(rng.choice([2, 3, 10, 50]))
+            col, ids, _ = H.random_dict_column(rng, "c%d" % c, n, card)
+            lo = int(rng.integers(0, card)); hi = int(rng.integers(lo + 1, card + 1))
+            cols.append(col); masks.append(((ids >= lo) & (ids < hi), lo, hi))
+        seg = S.SegmentData("and", n, cols)
+        spec = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(*[Q.leaf(Q.Pred.dict_range(c, lo, hi)) for c, (_, lo, hi) in enumerate(masks)]))
+        if any(m.all() or not m.any() for m, _, _ in masks):
+            continue                                            # a constant leaf folds away: not this shape
+        keep, ptrs = leaf_bitmaps(seg, spec)
+        want = H.and_leapfrog_entries([m for m, _, _ in masks])
+        generic = driver.fstats_replay_mode(C.byref(spec.c), n, ptrs, 0, 0, 0)
+        sequential = driver.fstats_replay_mode(C.byref(spec.c), n, ptrs, 1, 0, 1)
+        parallel = driver.fstats_replay_mode(C.byref(spec.c), n, ptrs, 1, 997, 4)
+        assert generic == sequential == parallel == want == oracle.execute(seg, spec).stats[1], (n, k)

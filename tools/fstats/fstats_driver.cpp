@@ -15,3 +15,13 @@ extern "C" int64_t fstats_replay(const pg_query* q, int32_t num_docs, const uint
     if (leaf_words[i]) leaves[(size_t)i] = std::make_shared<std::vector<uint64_t>>(leaf_words[i], leaf_words[i] + (words ? words : 1));
   return pg::fstats::replay(q, num_docs, leaves);
 }
+
+// The same count with the fast paths off (mode 0: the iterator objects) or forced onto `threads` threads in chunks of `chunk_docs` docs (mode 1)
+extern "C" int64_t fstats_replay_mode(const pg_query* q, int32_t num_docs, const uint64_t* const* leaf_words, int32_t mode, int32_t chunk_docs, int32_t threads) {
+  if (q->num_filter_nodes == 0 || pg::fstats::malformed(q)) return 0;
+  const size_t words = ((size_t)num_docs + 63) / 64;
+  std::vector<pg::fstats::Words> leaves((size_t)q->num_predicates);
+  for (int i = 0; i < q->num_predicates; ++i)
+    if (leaf_words[i]) leaves[(size_t)i] = std::make_shared<std::vector<uint64_t>>(leaf_words[i], leaf_words[i] + (words ? words : 1));
+  return pg::fstats::replay(q, num_docs, leaves, mode != 0, chunk_docs, threads);
+}
