@@ -1,134 +1,222 @@
 /**
- * The segment-level operator of an offloaded aggregation or group-by query: what AggregationOperator / GroupByOperator are on the CPU
- * plan (core/operator/query/AggregationOperator.java:44-106, GroupByOperator.java:52-170), with the whole
- * filter -> projection -> aggregation subtree behind one native call.  It extends BaseOperator so that nextBlock() keeps the
- * interruption check and the trace scope (core/operator/BaseOperator.java:43-57), returns the reference's own results blocks
- * (AggregationResultsBlock / GroupByResultsBlock with the intermediate-result objects extractAggregationResult would produce: Long,
- * Double, AvgPair), and reports ExecutionStatistics the way the combine operator reads them (Operator.java:120-122).
+ * The segment-level operator of an offloaded aggregation or group-by query: what AggregationOperator / GroupByOperator -- and, when the
+ * query has FILTER (WHERE ...) aggregations, FilteredAggregationOperator / FilteredGroupByOperator -- are on the CPU plan
+ * (core/operator/query/AggregationOperator.java:44-106, GroupByOperator.java:52-170, FilteredAggregationOperator.java:47-110,
+ * FilteredGroupByOperator.java:108-190), with the whole filter -> projection -> aggregation subtree of every swim lane behind one native
+ * call.  It extends BaseOperator so that nextBlock() keeps the interruption check and the trace scope
+ * (core/operator/BaseOperator.java:43-57), returns the reference's own results blocks (AggregationResultsBlock / GroupByResultsBlock with
+ * the intermediate-result objects extractAggregationResult would produce: Long, Double, AvgPair), and reports ExecutionStatistics the way
+ * the combine operator reads them (Operator.java:120-122; lanes add up like FilteredAggregationOperator.java:96-99).
+ *
+ * <p>A run-time failure of a native call -- device out of memory, a tier pg_query_check admits by upper bound -- never fails the query:
+ * the segment is re-planned with the reference's own node (the one InstancePlanMakerImplV2 would have returned) and that operator's block
+ * and statistics are reported instead.
  */
 package org.apache.pinot.gpu;
 
 import java.util.ArrayList;
+import java.util.Arrays;
+import java.util.Collection;
 import java.util.Collections;
 import java.util.List;
+import org.apache.commons.lang3.tuple.Pair;
 import org.apache.pinot.common.request.context.ExpressionContext;
+import org.apache.pinot.common.request.context.FilterContext;
 import org.apache.pinot.common.utils.DataSchema;
 import org.apache.pinot.core.common.Operator;
+import org.apache.pinot.core.data.table.IntermediateRecord;
+import org.apache.pinot.core.data.table.TableResizer;
 import org.apache.pinot.core.operator.BaseOperator;
 import org.apache.pinot.core.operator.ExecutionStatistics;
 import org.apache.pinot.core.operator.blocks.results.AggregationResultsBlock;
 import org.apache.pinot.core.operator.blocks.results.BaseResultsBlock;
 import org.apache.pinot.core.operator.blocks.results.GroupByResultsBlock;
+import org.apache.pinot.core.plan.PlanNode;
 import org.apache.pinot.core.query.aggregation.function.AggregationFunction;
+import org.apache.pinot.core.query.aggregation.function.AggregationFunctionUtils;
 import org.apache.pinot.core.query.aggregation.groupby.AggregationGroupByResult;
 import org.apache.pinot.core.query.aggregation.groupby.DoubleGroupByResultHolder;
 import org.apache.pinot.core.query.aggregation.groupby.GroupByResultHolder;
 import org.apache.pinot.core.query.aggregation.groupby.ObjectGroupByResultHolder;
 import org.apache.pinot.core.query.request.context.QueryContext;
+import org.apache.pinot.core.util.GroupByUtils;
 import org.apache.pinot.segment.local.customobject.AvgPair;
 import org.apache.pinot.segment.spi.AggregationFunctionType;
 import org.apache.pinot.segment.spi.IndexSegment;
 import org.apache.pinot.segment.spi.index.reader.Dictionary;
 import org.apache.pinot.segment.spi.index.reader.NullValueVectorReader;
+import org.slf4j.Logger;
+import org.slf4j.LoggerFactory;
 
 
 final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
-  // header indexes of the native result (PGM_H_* in jni/pg_marshal.h)
-  private static final int H_NUM_DOCS_SCANNED = 0;
-  private static final int H_ENTRIES_IN_FILTER = 1;
-  private static final int H_ENTRIES_POST_FILTER = 2;
-  private static final int H_TOTAL_DOCS = 3;
-  private static final int H_GROUP_ID_UPPER_BOUND = 7;
-  private static final int H_NUM_GROUPS_LIMIT_REACHED = 8;
+  private static final Logger LOGGER = LoggerFactory.getLogger(GpuAggregationOperator.class);
+
+  /** One native call: a lowered query and, for each of its aggregations, the position of the function in the query's function array. */
+  static final class Lane {
+    final GpuQueryLowering.Lowered _query;
+    final int[] _positions;       // empty: the lane only creates groups (FilteredGroupByOperator's main-filter lane without functions)
+
+    Lane(GpuQueryLowering.Lowered query, int[] positions) {
+      _query = query;
+      _positions = positions;
+    }
+  }
+
+  /** What one lane brought back (the slots of PinotGpuNative.execute's Object[]). */
+  private static final class LaneResult {
+    long[] _header;
+    int[] _groupIds;
+    long[] _counts;
+    double[] _sums;
+    double[] _mins;
+    double[] _maxs;
+    int _width;                   // aggregations per row in this lane's arrays
+  }
 
   private final GpuSegment _segment;
+  private final IndexSegment _indexSegment;
   private final QueryContext _queryContext;
   private final AggregationFunction[] _functions;
-  private final GpuQueryLowering.Lowered _query;
-  private long[] _header;
+  private final List<Lane> _lanes;
+  private final PlanNode _cpuPlan;
+  private final long[] _statistics = new long[4];       // numDocsScanned, entriesInFilter, entriesPostFilter, totalDocs
+  private Operator<?> _cpuOperator;                     // set when a native call failed and the segment ran on the CPU plan
 
-  GpuAggregationOperator(GpuSegment segment, QueryContext queryContext, AggregationFunction[] functions, GpuQueryLowering.Lowered query) {
+  GpuAggregationOperator(GpuSegment segment, IndexSegment indexSegment, QueryContext queryContext, AggregationFunction[] functions,
+      List<Lane> lanes, PlanNode cpuPlan) {
     _segment = segment;
+    _indexSegment = indexSegment;
     _queryContext = queryContext;
     _functions = functions;
-    _query = query;
+    _lanes = lanes;
+    _cpuPlan = cpuPlan;
   }
 
   @Override
   protected BaseResultsBlock getNextBlock() {
-    Object[] result = PinotGpuNative.execute(_segment.handle(), _query._filterNodes, _query._predInts, _query._predLongs, _query._setOffsets,
-        _query._setWords, _query._aggregations, _query._groupBy, _query._numGroupsLimit, _query._flags);
-    _header = (long[]) result[0];
-    int[] groupIds = (int[]) result[1];
-    long[] counts = (long[]) result[2];
-    double[] sums = (double[]) result[3];
-    double[] mins = (double[]) result[6];
-    double[] maxs = (double[]) result[7];
-    int numFunctions = _functions.length;
-    boolean nullHandling = _queryContext.isNullHandlingEnabled();
-    if (_query._groupBy.length == 0) {
-      List<Object> results = new ArrayList<>(numFunctions);
-      for (int i = 0; i < numFunctions; i++) {
-        results.add(intermediate(i, 0, numFunctions, counts, sums, mins, maxs, nullHandling));
+    List<LaneResult> results = new ArrayList<>(_lanes.size());
+    try {
+      for (Lane lane : _lanes) {
+        results.add(execute(lane));
       }
-      return new AggregationResultsBlock(_functions, results, _queryContext);
+    } catch (RuntimeException e) {
+      // UnsupportedOperationException (PG_ERR_UNSUPPORTED at run time) and RuntimeException (pg_last_error: device / out of memory) alike
+      LOGGER.warn("Segment {} falls back to the CPU plan: {}", _segment.getSegmentName(), e.toString());
+      Arrays.fill(_statistics, 0);
+      _cpuOperator = _cpuPlan.run();
+      return (BaseResultsBlock) _cpuOperator.nextBlock();
     }
-    // group-by: holders indexed by the row of the native result, keys mapped back to dictionary values
+    for (LaneResult result : results) {
+      // FilteredAggregationOperator.java:96-99 / FilteredGroupByOperator.java:151-153: lanes add up; one lane is the plain operator
+      _statistics[0] += result._header[PinotGpuNative.PGM_H_NUM_DOCS_SCANNED];
+      _statistics[1] += result._header[PinotGpuNative.PGM_H_ENTRIES_IN_FILTER];
+      _statistics[2] += result._header[PinotGpuNative.PGM_H_ENTRIES_POST_FILTER];
+      _statistics[3] = result._header[PinotGpuNative.PGM_H_TOTAL_DOCS];
+    }
+    return _queryContext.getGroupByExpressions() == null ? aggregationBlock(results) : groupByBlock(results);
+  }
+
+  private LaneResult execute(Lane lane) {
+    GpuQueryLowering.Lowered q = lane._query;
+    Object[] raw = PinotGpuNative.execute(_segment.handle(), q._filterNodes, q._predInts, q._predLongs, q._setOffsets, q._setWords,
+        q._aggregations, q._groupBy, q._numGroupsLimit, q._flags);
+    if (raw == null || raw.length != PinotGpuNative.PGM_RESULT_ARRAYS) {
+      throw new IllegalStateException("native result does not match jni/pg_marshal.h");
+    }
+    LaneResult result = new LaneResult();
+    result._header = (long[]) raw[PinotGpuNative.PGM_R_HEADER];
+    result._groupIds = (int[]) raw[PinotGpuNative.PGM_R_GROUP_IDS];
+    result._counts = (long[]) raw[PinotGpuNative.PGM_R_COUNTS];
+    result._sums = (double[]) raw[PinotGpuNative.PGM_R_SUMS];
+    result._mins = (double[]) raw[PinotGpuNative.PGM_R_MINS];
+    result._maxs = (double[]) raw[PinotGpuNative.PGM_R_MAXS];
+    result._width = (int) result._header[PinotGpuNative.PGM_H_NUM_AGGREGATIONS];
+    if (result._header.length != PinotGpuNative.PGM_HEADER_LEN) {
+      throw new IllegalStateException("native result header does not match jni/pg_marshal.h");
+    }
+    return result;
+  }
+
+  private AggregationResultsBlock aggregationBlock(List<LaneResult> results) {
+    boolean nullHandling = _queryContext.isNullHandlingEnabled();
+    Object[] out = new Object[_functions.length];
+    for (int l = 0; l < _lanes.size(); l++) {
+      int[] positions = _lanes.get(l)._positions;
+      LaneResult result = results.get(l);
+      for (int i = 0; i < positions.length; i++) {
+        out[positions[i]] = intermediate(_functions[positions[i]].getType(), result, i, nullHandling);
+      }
+    }
+    return new AggregationResultsBlock(_functions, Arrays.asList(out), _queryContext);
+  }
+
+  /** The object extractAggregationResult of the reference's function returns (null for an empty SUM / MIN / MAX / AVG under null handling). */
+  private static Object intermediate(AggregationFunctionType type, LaneResult r, int at, boolean nullHandling) {
+    switch (type) {
+      case COUNT:
+        return r._counts[at];
+      case SUM:
+        return nullHandling && r._counts[at] == 0 ? null : (Object) r._sums[at];
+      case MIN:
+        return nullHandling && r._counts[at] == 0 ? null : (Object) r._mins[at];
+      case MAX:
+        return nullHandling && r._counts[at] == 0 ? null : (Object) r._maxs[at];
+      case AVG:
+        return nullHandling && r._counts[at] == 0 ? null : new AvgPair(r._sums[at], r._counts[at]);
+      default:
+        throw new IllegalStateException("not offloadable: " + type);
+    }
+  }
+
+  /**
+   * Group-by: the lanes share one key space (raw group ids are the same mixed-radix number in every lane), so the block's groups are
+   * the union of the lanes' groups in ascending raw id -- what sharing one GroupKeyGenerator across lanes gives the reference
+   * (FilteredGroupByOperator.java:121-143) -- and a function whose lane never saw a group keeps its holder's default there.
+   */
+  private GroupByResultsBlock groupByBlock(List<LaneResult> results) {
+    boolean nullHandling = _queryContext.isNullHandlingEnabled();
+    int numFunctions = _functions.length;
+    int[] groupIds = results.size() == 1 ? results.get(0)._groupIds : unionOf(results);
     int numGroups = groupIds.length;
+    int capacity = Math.max(numGroups, 1);
     GroupByResultHolder[] holders = new GroupByResultHolder[numFunctions];
-    for (int i = 0; i < numFunctions; i++) {
-      switch (_functions[i].getType()) {
-        case AVG: {
-          ObjectGroupByResultHolder holder = new ObjectGroupByResultHolder(Math.max(numGroups, 1), Math.max(numGroups, 1));
-          for (int g = 0; g < numGroups; g++) {
-            if (!nullHandling || counts[g * numFunctions + i] != 0) {
-              holder.setValueForKey(g, new AvgPair(sums[g * numFunctions + i], counts[g * numFunctions + i]));
+    for (int l = 0; l < _lanes.size(); l++) {
+      int[] positions = _lanes.get(l)._positions;
+      LaneResult r = results.get(l);
+      int[] rowOf = new int[r._groupIds.length];                // lane row -> row of the block
+      for (int g = 0; g < rowOf.length; g++) {
+        rowOf[g] = results.size() == 1 ? g : Arrays.binarySearch(groupIds, r._groupIds[g]);
+      }
+      for (int i = 0; i < positions.length; i++) {
+        AggregationFunctionType type = _functions[positions[i]].getType();
+        boolean object = type == AggregationFunctionType.AVG || (nullHandling && type != AggregationFunctionType.COUNT);
+        if (object) {
+          // AVG always, and SUM / MIN / MAX under null handling (NullableSingleInputAggregationFunction), keep an ObjectGroupByResultHolder
+          // that stays null until a value arrives
+          ObjectGroupByResultHolder holder = new ObjectGroupByResultHolder(capacity, capacity);
+          for (int g = 0; g < rowOf.length; g++) {
+            int at = g * r._width + i;
+            if (nullHandling && r._counts[at] == 0) {
+              continue;
             }
+            Object value = type == AggregationFunctionType.AVG ? new AvgPair(r._sums[at], r._counts[at])
+                : (Object) Double.valueOf(type == AggregationFunctionType.SUM ? r._sums[at] : (type == AggregationFunctionType.MIN ? r._mins[at] : r._maxs[at]));
+            holder.setValueForKey(rowOf[g], value);
           }
-          holders[i] = holder;
-          break;
-        }
-        case SUM:
-        case MIN:
-        case MAX:
-          if (nullHandling) {
-            // NullableSingleInputAggregationFunction keeps these in an ObjectGroupByResultHolder that stays null until a value arrives
-            ObjectGroupByResultHolder nullable = new ObjectGroupByResultHolder(Math.max(numGroups, 1), Math.max(numGroups, 1));
-            for (int g = 0; g < numGroups; g++) {
-              int at = g * numFunctions + i;
-              if (counts[at] != 0) {
-                nullable.setValueForKey(g, (Object) Double.valueOf(_functions[i].getType() == AggregationFunctionType.SUM ? sums[at]
-                    : (_functions[i].getType() == AggregationFunctionType.MIN ? mins[at] : maxs[at])));
-              }
-            }
-            holders[i] = nullable;
-            break;
+          holders[positions[i]] = holder;
+        } else {
+          // COUNT / SUM / MIN / MAX read getDoubleResult (CountAggregationFunction.extractGroupByResult casts it back to long); the default
+          // is what the function's own holder starts from: 0 for COUNT / SUM, +inf for MIN, -inf for MAX
+          double initial = type == AggregationFunctionType.MIN ? Double.POSITIVE_INFINITY : (type == AggregationFunctionType.MAX ? Double.NEGATIVE_INFINITY : 0.0);
+          DoubleGroupByResultHolder holder = new DoubleGroupByResultHolder(capacity, capacity, initial);
+          for (int g = 0; g < rowOf.length; g++) {
+            int at = g * r._width + i;
+            double value = type == AggregationFunctionType.COUNT ? r._counts[at]
+                : (type == AggregationFunctionType.SUM ? r._sums[at] : (type == AggregationFunctionType.MIN ? r._mins[at] : r._maxs[at]));
+            holder.setValueForKey(rowOf[g], value);
           }
-          // fall through
-        default: {
-          // COUNT / SUM / MIN / MAX read getDoubleResult (CountAggregationFunction.extractGroupByResult casts it back to long)
-          DoubleGroupByResultHolder holder = new DoubleGroupByResultHolder(Math.max(numGroups, 1), Math.max(numGroups, 1), 0.0);
-          for (int g = 0; g < numGroups; g++) {
-            int at = g * numFunctions + i;
-            double value;
-            switch (_functions[i].getType()) {
-              case COUNT:
-                value = counts[at];
-                break;
-              case SUM:
-                value = sums[at];
-                break;
-              case MIN:
-                value = mins[at];
-                break;
-              default:
-                value = maxs[at];
-                break;
-            }
-            holder.setValueForKey(g, value);
-          }
-          holders[i] = holder;
-          break;
+          holders[positions[i]] = holder;
         }
       }
     }
@@ -137,63 +225,89 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
     boolean[] nullableKeys = new boolean[groupBy.size()];
     String[] columnNames = new String[groupBy.size() + numFunctions];
     DataSchema.ColumnDataType[] columnTypes = new DataSchema.ColumnDataType[groupBy.size() + numFunctions];
-    IndexSegment indexSegment = _segment.getIndexSegment();
     for (int i = 0; i < groupBy.size(); i++) {
       String column = groupBy.get(i).getIdentifier();
-      dictionaries[i] = indexSegment.getDataSource(column).getDictionary();
-      NullValueVectorReader nullVector = indexSegment.getDataSource(column).getNullValueVector();
+      dictionaries[i] = _indexSegment.getDataSource(column).getDictionary();
+      NullValueVectorReader nullVector = _indexSegment.getDataSource(column).getNullValueVector();
       nullableKeys[i] = nullHandling && nullVector != null && nullVector.getNullBitmap() != null && !nullVector.getNullBitmap().isEmpty();
       columnNames[i] = groupBy.get(i).toString();
-      columnTypes[i] = DataSchema.ColumnDataType.fromDataTypeSV(indexSegment.getDataSource(column).getDataSourceMetadata().getDataType());
+      columnTypes[i] = DataSchema.ColumnDataType.fromDataTypeSV(_indexSegment.getDataSource(column).getDataSourceMetadata().getDataType());
     }
+    List<Pair<AggregationFunction, FilterContext>> filtered = _queryContext.getFilteredAggregationFunctions();
     for (int i = 0; i < numFunctions; i++) {
-      columnNames[groupBy.size() + i] = _functions[i].getResultColumnName();
+      // FilteredGroupByOperator.java:98-104 names a filtered function after its clause; unfiltered ones keep getResultColumnName
+      FilterContext clause = filtered != null && _queryContext.hasFilteredAggregations() ? filtered.get(i).getRight() : null;
+      columnNames[groupBy.size() + i] = AggregationFunctionUtils.getResultColumnName(_functions[i], clause);
       columnTypes[groupBy.size() + i] = _functions[i].getIntermediateResultColumnType();
     }
-    GpuGroupKeyGenerator keys = new GpuGroupKeyGenerator(groupIds, dictionaries, nullableKeys, (int) _header[H_GROUP_ID_UPPER_BOUND]);
-    GroupByResultsBlock block = new GroupByResultsBlock(new DataSchema(columnNames, columnTypes), new AggregationGroupByResult(keys, _functions, holders), _queryContext);
-    block.setNumGroupsLimitReached(_header[H_NUM_GROUPS_LIMIT_REACHED] != 0);      // GroupByOperator.java:114-115
+    long upperBound = 0;
+    boolean limitReached = false;
+    for (LaneResult r : results) {
+      upperBound = Math.max(upperBound, r._header[PinotGpuNative.PGM_H_GROUP_ID_UPPER_BOUND]);
+      limitReached |= r._header[PinotGpuNative.PGM_H_NUM_GROUPS_LIMIT_REACHED] != 0;
+    }
+    DataSchema dataSchema = new DataSchema(columnNames, columnTypes);
+    GpuGroupKeyGenerator keys = new GpuGroupKeyGenerator(groupIds, dictionaries, nullableKeys, (int) upperBound);
+    // In-segment trim, exactly GroupByOperator.java:119-135: ORDER BY + minSegmentGroupTrimSize > 0 + more groups than the trim size
+    int minGroupTrimSize = _queryContext.getMinSegmentGroupTrimSize();
+    if (_queryContext.getOrderByExpressions() != null && minGroupTrimSize > 0) {
+      int trimSize = GroupByUtils.getTableCapacity(_queryContext.getLimit(), minGroupTrimSize);
+      if (numGroups > trimSize) {
+        Collection<IntermediateRecord> records = new TableResizer(dataSchema, _queryContext).trimInSegmentResults(keys, holders, trimSize);
+        GroupByResultsBlock trimmed = new GroupByResultsBlock(dataSchema, records, _queryContext);
+        trimmed.setNumGroupsLimitReached(limitReached);
+        return trimmed;
+      }
+    }
+    GroupByResultsBlock block = new GroupByResultsBlock(dataSchema, new AggregationGroupByResult(keys, _functions, holders), _queryContext);
+    block.setNumGroupsLimitReached(limitReached);      // GroupByOperator.java:114-115
     return block;
   }
 
-  /** The object extractAggregationResult of the reference's function returns (null for an empty SUM / MIN / MAX / AVG under null handling). */
-  private Object intermediate(int function, int row, int numFunctions, long[] counts, double[] sums, double[] mins, double[] maxs, boolean nullHandling) {
-    int at = row * numFunctions + function;
-    switch (_functions[function].getType()) {
-      case COUNT:
-        return counts[at];
-      case SUM:
-        return nullHandling && counts[at] == 0 ? null : (Object) sums[at];
-      case MIN:
-        return nullHandling && counts[at] == 0 ? null : (Object) mins[at];
-      case MAX:
-        return nullHandling && counts[at] == 0 ? null : (Object) maxs[at];
-      case AVG:
-        return nullHandling && counts[at] == 0 ? null : new AvgPair(sums[at], counts[at]);
-      default:
-        throw new IllegalStateException("not offloadable: " + _functions[function].getType());
+  /** Ascending union of the lanes' (ascending) raw group ids. */
+  private static int[] unionOf(List<LaneResult> results) {
+    int total = 0;
+    for (LaneResult r : results) {
+      total += r._groupIds.length;
     }
+    int[] all = new int[total];
+    int at = 0;
+    for (LaneResult r : results) {
+      System.arraycopy(r._groupIds, 0, all, at, r._groupIds.length);
+      at += r._groupIds.length;
+    }
+    Arrays.sort(all);
+    int kept = 0;
+    for (int i = 0; i < all.length; i++) {
+      if (i == 0 || all[i] != all[i - 1]) {
+        all[kept++] = all[i];
+      }
+    }
+    return Arrays.copyOf(all, kept);
   }
 
   @Override
   public ExecutionStatistics getExecutionStatistics() {
-    long[] h = _header != null ? _header : new long[11];
-    return new ExecutionStatistics(h[H_NUM_DOCS_SCANNED], h[H_ENTRIES_IN_FILTER], h[H_ENTRIES_POST_FILTER], h[H_TOTAL_DOCS]);
+    if (_cpuOperator != null) {
+      return _cpuOperator.getExecutionStatistics();
+    }
+    return new ExecutionStatistics(_statistics[0], _statistics[1], _statistics[2], _statistics[3]);
   }
 
   @Override
   public IndexSegment getIndexSegment() {
-    return _segment.getIndexSegment();
+    return _indexSegment;
   }
 
   @Override
   @SuppressWarnings("rawtypes")
   public List<Operator> getChildOperators() {
-    return Collections.emptyList();
+    return _cpuOperator != null ? Collections.singletonList(_cpuOperator) : Collections.emptyList();
   }
 
   @Override
   public String toExplainString() {
-    return _query._groupBy.length == 0 ? "GPU_AGGREGATE" : "GPU_GROUP_BY";
+    String name = _queryContext.getGroupByExpressions() == null ? "GPU_AGGREGATE" : "GPU_GROUP_BY";
+    return _lanes.size() > 1 ? name + "_FILTERED" : name;
   }
 }

@@ -5,17 +5,41 @@
  * instance plans, combine operators, streaming, prefetch and query options stay the reference's.
  *
  * <p>makeSegmentPlanNode (InstancePlanMakerImplV2.java:270-289) swaps the per-segment plan node of an aggregation / group-by query for
- * the device operator when, at PLAN time, all of this holds: the segment is resident (GpuSegmentCache), the query lowers
- * (GpuQueryLowering) and pg_query_check admits it (PinotGpuNative.queryCheck -- the same decision pg_execute would take, nothing
- * launched).  Otherwise the reference's own node is returned, so an unsupported shape never fails at run time.
+ * the device operator when, at PLAN time, all of this holds: the segment is resident (GpuSegmentCache), every swim lane of the query
+ * lowers (GpuQueryLowering) and pg_query_check admits it (PinotGpuNative.queryCheck -- the same decision pg_execute would take, nothing
+ * launched).  Otherwise the reference's own node is returned.  The reference's node is ALSO kept inside the device operator: a run-time
+ * failure of the native call (device out of memory for a group table, a tier pg_query_check admits by upper bound) re-plans the segment on
+ * the CPU instead of failing the query (GpuAggregationOperator.getNextBlock).
+ *
+ * <p>Plan choices of the reference this class keeps or declines, one by one (AggregationPlanNode / GroupByPlanNode / FilterPlanNode):
+ * <ul>
+ *   <li>expression override hints: rewriteQueryContextWithHints runs first, as in the reference (:271);</li>
+ *   <li>upsert / dedup tables: FilterPlanNode.run ANDs SegmentContext.getQueryableDocIdsSnapshot() into every filter (:89-102).  The
+ *       device holds no valid-doc bitmap, so a segment context that carries one keeps the CPU plan;</li>
+ *   <li>FILTER (WHERE ...) aggregations: one lane per distinct clause over mainFilter AND clause, match-all clauses folded into the
+ *       unfiltered lane, plus -- for GROUP BY without skipEmptyGroups -- the lane that only creates the main filter's groups
+ *       (AggregationFunctionUtils.buildFilteredAggregationInfos :312-402).  Every lane is one native call;</li>
+ *   <li>star-tree: AggregationFunctionUtils.buildAggregationInfo prefers a fitting star-tree.  The device plan scans the forward indexes
+ *       instead (same results; a segment whose queries should stay on their star-tree is left to the CPU plan with gpu.skip.startree
+ *       segments, see INTEGRATION.md);</li>
+ *   <li>metadata / dictionary fast paths and FastFilteredCount: pg_execute applies the same rules (include/pinot_gpu.h).</li>
+ * </ul>
  */
 package org.apache.pinot.gpu;
 
+import java.util.ArrayList;
+import java.util.LinkedHashMap;
+import java.util.List;
+import java.util.Map;
+import org.apache.commons.lang3.tuple.Pair;
+import org.apache.pinot.common.request.context.FilterContext;
+import org.apache.pinot.common.utils.config.QueryOptionsUtils;
 import org.apache.pinot.core.plan.PlanNode;
 import org.apache.pinot.core.plan.maker.InstancePlanMakerImplV2;
 import org.apache.pinot.core.query.aggregation.function.AggregationFunction;
 import org.apache.pinot.core.query.request.context.QueryContext;
 import org.apache.pinot.core.query.request.context.utils.QueryContextUtils;
+import org.apache.pinot.segment.spi.IndexSegment;
 import org.apache.pinot.segment.spi.SegmentContext;
 import org.apache.pinot.spi.env.PinotConfiguration;
 import org.slf4j.Logger;
@@ -26,8 +50,10 @@ public class GpuPlanMaker extends InstancePlanMakerImplV2 {
   private static final Logger LOGGER = LoggerFactory.getLogger(GpuPlanMaker.class);
   public static final String DEVICE_KEY = "gpu.device";
   public static final String ENABLED_KEY = "gpu.enabled";
+  public static final String SKIP_STAR_TREE_SEGMENTS_KEY = "gpu.skip.startree";
 
   private volatile GpuSegmentCache _segments;
+  private boolean _skipStarTreeSegments;
 
   @Override
   public void init(PinotConfiguration queryExecutorConfig) {
@@ -36,6 +62,7 @@ public class GpuPlanMaker extends InstancePlanMakerImplV2 {
       return;
     }
     int device = queryExecutorConfig.getProperty(DEVICE_KEY, 0);
+    _skipStarTreeSegments = queryExecutorConfig.getProperty(SKIP_STAR_TREE_SEGMENTS_KEY, false);
     try {
       PinotGpuNative.init(device, 0);
       _segments = new GpuSegmentCache(device);
@@ -47,27 +74,115 @@ public class GpuPlanMaker extends InstancePlanMakerImplV2 {
 
   @Override
   public PlanNode makeSegmentPlanNode(SegmentContext segmentContext, QueryContext queryContext) {
+    PlanNode cpuPlan = super.makeSegmentPlanNode(segmentContext, queryContext);     // also applies rewriteQueryContextWithHints (:271)
     GpuSegmentCache segments = _segments;
-    if (segments == null || !QueryContextUtils.isAggregationQuery(queryContext) || queryContext.hasFilteredAggregations()) {
-      // (FILTER (WHERE ...) aggregations: one native call per distinct filter, the swim lanes of FilteredAggregationOperator -- the C++
-      //  host mirror implements it, pinot_amd/csrc/host/plan_maker.cpp GpuFilteredAggregationOperator; not wired here yet)
-      return super.makeSegmentPlanNode(segmentContext, queryContext);
+    IndexSegment indexSegment = segmentContext.getIndexSegment();
+    if (segments == null || !QueryContextUtils.isAggregationQuery(queryContext)
+        || segmentContext.getQueryableDocIdsSnapshot() != null                       // upsert / dedup: FilterPlanNode.java:89-102
+        || (_skipStarTreeSegments && indexSegment.getStarTrees() != null && !indexSegment.getStarTrees().isEmpty())) {
+      return cpuPlan;
     }
-    GpuSegment segment = segments.get(segmentContext.getIndexSegment());
     AggregationFunction[] functions = queryContext.getAggregationFunctions();
+    GpuSegment segment = segments.get(indexSegment);
     if (segment == null || functions == null) {
-      return super.makeSegmentPlanNode(segmentContext, queryContext);
+      return cpuPlan;
     }
-    GpuQueryLowering.Lowered lowered = GpuQueryLowering.lower(segment, queryContext, functions, queryContext.getFilter());
+    List<GpuAggregationOperator.Lane> lanes = queryContext.hasFilteredAggregations()
+        ? filteredLanes(segment, indexSegment, queryContext, functions)
+        : unfilteredLane(segment, indexSegment, queryContext, functions);
+    if (lanes == null) {
+      return cpuPlan;
+    }
+    for (GpuAggregationOperator.Lane lane : lanes) {
+      GpuQueryLowering.Lowered q = lane._query;
+      int admitted = PinotGpuNative.queryCheck(segment.handle(), q._filterNodes, q._predInts, q._predLongs, q._setOffsets, q._setWords,
+          q._aggregations, q._groupBy, q._numGroupsLimit, q._flags);
+      if (admitted != PinotGpuNative.PG_OK) {
+        LOGGER.debug("Segment {} keeps the CPU plan: {}", segment.getSegmentName(), PinotGpuNative.lastError());
+        return cpuPlan;
+      }
+    }
+    return () -> new GpuAggregationOperator(segment, indexSegment, queryContext, functions, lanes, cpuPlan);
+  }
+
+  private static List<GpuAggregationOperator.Lane> unfilteredLane(GpuSegment segment, IndexSegment indexSegment, QueryContext queryContext,
+      AggregationFunction[] functions) {
+    GpuQueryLowering.Lowered lowered = GpuQueryLowering.lower(segment, indexSegment, queryContext, functions, queryContext.getFilter());
     if (lowered == null) {
-      return super.makeSegmentPlanNode(segmentContext, queryContext);
+      return null;
     }
-    int admitted = PinotGpuNative.queryCheck(segment.handle(), lowered._filterNodes, lowered._predInts, lowered._predLongs, lowered._setOffsets,
-        lowered._setWords, lowered._aggregations, lowered._groupBy, lowered._numGroupsLimit, lowered._flags);
-    if (admitted != PinotGpuNative.PG_OK) {
-      LOGGER.debug("Segment {} keeps the CPU plan: {}", segment.getIndexSegment().getSegmentName(), PinotGpuNative.lastError());
-      return super.makeSegmentPlanNode(segmentContext, queryContext);
+    int[] positions = new int[functions.length];
+    for (int i = 0; i < positions.length; i++) {
+      positions[i] = i;
     }
-    return () -> new GpuAggregationOperator(segment, queryContext, functions, lowered);
+    List<GpuAggregationOperator.Lane> lanes = new ArrayList<>(1);
+    lanes.add(new GpuAggregationOperator.Lane(lowered, positions));
+    return lanes;
+  }
+
+  /**
+   * The swim lanes of FilteredAggregationOperator / FilteredGroupByOperator (AggregationFunctionUtils.buildFilteredAggregationInfos
+   * :312-402): functions grouped by their FILTER clause in first-appearance order; a clause that matches every doc of this segment joins
+   * the unfiltered lane (:351-358, :376-378); the unfiltered lane runs last and exists when it has functions or -- for GROUP BY without
+   * the skipEmptyGroups option -- to create every group of the main filter (:388-400).
+   */
+  private static List<GpuAggregationOperator.Lane> filteredLanes(GpuSegment segment, IndexSegment indexSegment, QueryContext queryContext,
+      AggregationFunction[] functions) {
+    List<Pair<AggregationFunction, FilterContext>> pairs = queryContext.getFilteredAggregationFunctions();
+    if (pairs == null || pairs.size() != functions.length) {
+      return null;
+    }
+    FilterContext mainFilter = queryContext.getFilter();
+    Map<FilterContext, List<Integer>> byClause = new LinkedHashMap<>();
+    List<Integer> unfiltered = new ArrayList<>();
+    for (int i = 0; i < functions.length; i++) {
+      FilterContext clause = pairs.get(i).getRight();
+      if (pairs.get(i).getLeft() != functions[i]) {
+        return null;                          // the two views of the query disagree on the order: not a shape this class knows
+      }
+      if (clause == null) {
+        unfiltered.add(i);
+        continue;
+      }
+      Integer folds = GpuQueryLowering.foldsTo(segment, indexSegment, queryContext, clause);
+      if (folds == null) {
+        return null;
+      }
+      if (folds > 0) {
+        unfiltered.add(i);
+      } else {
+        byClause.computeIfAbsent(clause, k -> new ArrayList<>()).add(i);
+      }
+    }
+    List<GpuAggregationOperator.Lane> lanes = new ArrayList<>();
+    for (Map.Entry<FilterContext, List<Integer>> entry : byClause.entrySet()) {
+      FilterContext combined = mainFilter == null ? entry.getKey() : FilterContext.forAnd(List.of(mainFilter, entry.getKey()));
+      if (!addLane(lanes, segment, indexSegment, queryContext, functions, entry.getValue(), combined)) {
+        return null;
+      }
+    }
+    boolean groupBy = queryContext.getGroupByExpressions() != null;
+    if (!unfiltered.isEmpty() || (groupBy && !QueryOptionsUtils.isFilteredAggregationsSkipEmptyGroups(queryContext.getQueryOptions()))) {
+      if (!addLane(lanes, segment, indexSegment, queryContext, functions, unfiltered, mainFilter)) {
+        return null;
+      }
+    }
+    return lanes.isEmpty() ? null : lanes;
+  }
+
+  private static boolean addLane(List<GpuAggregationOperator.Lane> lanes, GpuSegment segment, IndexSegment indexSegment,
+      QueryContext queryContext, AggregationFunction[] functions, List<Integer> members, FilterContext filter) {
+    AggregationFunction[] laneFunctions = new AggregationFunction[members.size()];
+    int[] positions = new int[members.size()];
+    for (int i = 0; i < positions.length; i++) {
+      positions[i] = members.get(i);
+      laneFunctions[i] = functions[positions[i]];
+    }
+    GpuQueryLowering.Lowered lowered = GpuQueryLowering.lower(segment, indexSegment, queryContext, laneFunctions, filter);
+    if (lowered == null) {
+      return false;
+    }
+    lanes.add(new GpuAggregationOperator.Lane(lowered, positions));
+    return true;
   }
 }

@@ -39,25 +39,29 @@ import org.roaringbitmap.buffer.ImmutableRoaringBitmap;
 
 
 final class GpuQueryLowering {
-  // pg_pred_kind / pg_eval_kind / pg_filter_op / pg_agg_function (include/pinot_gpu.h)
-  static final int PRED_MATCH_ALL = 0;
-  static final int PRED_MATCH_NONE = 1;
-  static final int PRED_DICT_RANGE = 2;
-  static final int PRED_DICT_SET = 3;
-  static final int PRED_RAW_RANGE = 4;
-  static final int PRED_IS_NULL = 5;
-  static final int PRED_DOC_RANGE = 6;
-  static final int EVAL_SCAN = 0;
-  static final int EVAL_INVERTED = 1;
-  static final int OP_LEAF = 0;
-  static final int OP_AND = 1;
-  static final int OP_OR = 2;
-  static final int OP_NOT = 3;
-  static final int AGG_COUNT = 0;
-  static final int AGG_SUM = 1;
-  static final int AGG_MIN = 2;
-  static final int AGG_MAX = 3;
-  static final int AGG_AVG = 4;
+  // pg_predicate_kind / pg_leaf_eval / pg_filter_op / pg_agg_function: the numbers live in PinotGpuNative, next to the header they mirror
+  static final int PRED_MATCH_ALL = PinotGpuNative.PG_PRED_MATCH_ALL;
+  static final int PRED_MATCH_NONE = PinotGpuNative.PG_PRED_MATCH_NONE;
+  static final int PRED_DICT_RANGE = PinotGpuNative.PG_PRED_DICT_RANGE;
+  static final int PRED_DICT_SET = PinotGpuNative.PG_PRED_DICT_SET;
+  static final int PRED_RAW_RANGE = PinotGpuNative.PG_PRED_RAW_RANGE;
+  static final int PRED_DOC_RANGE = PinotGpuNative.PG_PRED_DOC_RANGE;
+  static final int PRED_IS_NULL = PinotGpuNative.PG_PRED_IS_NULL;
+  static final int EVAL_SCAN = PinotGpuNative.PG_EVAL_SCAN;
+  static final int EVAL_INVERTED = PinotGpuNative.PG_EVAL_INVERTED;
+  static final int OP_LEAF = PinotGpuNative.PG_FILTER_LEAF;
+  static final int OP_AND = PinotGpuNative.PG_FILTER_AND;
+  static final int OP_OR = PinotGpuNative.PG_FILTER_OR;
+  static final int OP_NOT = PinotGpuNative.PG_FILTER_NOT;
+  static final int AGG_COUNT = PinotGpuNative.PG_AGG_COUNT;
+  static final int AGG_SUM = PinotGpuNative.PG_AGG_SUM;
+  static final int AGG_MIN = PinotGpuNative.PG_AGG_MIN;
+  static final int AGG_MAX = PinotGpuNative.PG_AGG_MAX;
+  static final int AGG_AVG = PinotGpuNative.PG_AGG_AVG;
+  private static final int NODE_INTS = PinotGpuNative.PGM_FILTER_NODE_INTS;
+  private static final int PRED_INTS = PinotGpuNative.PGM_PRED_INTS;
+  private static final int PRED_LONGS = PinotGpuNative.PGM_PRED_LONGS;
+  private static final int AGG_INTS = PinotGpuNative.PGM_AGG_INTS;
 
   // PrioritizedFilterOperator.java:32-39
   private static final int SORTED_PRIORITY = 0;
@@ -103,17 +107,33 @@ final class GpuQueryLowering {
   private final List<long[]> _predLongs = new ArrayList<>();
   private final List<int[]> _predSets = new ArrayList<>();
 
-  private GpuQueryLowering(GpuSegment segment, QueryContext queryContext) {
+  private GpuQueryLowering(GpuSegment segment, IndexSegment indexSegment, QueryContext queryContext) {
     _segment = segment;
-    _indexSegment = segment.getIndexSegment();
+    _indexSegment = indexSegment;          // handed in per query: the device copy keeps no reference to the IndexSegment (GpuSegmentCache)
     _queryContext = queryContext;
   }
 
   /** The lowered query, or null when it keeps the CPU plan (the reason is logged by the caller at debug level). */
   @Nullable
-  static Lowered lower(GpuSegment segment, QueryContext queryContext, AggregationFunction[] functions, @Nullable FilterContext filter) {
+  static Lowered lower(GpuSegment segment, IndexSegment indexSegment, QueryContext queryContext, AggregationFunction[] functions,
+      @Nullable FilterContext filter) {
     try {
-      return new GpuQueryLowering(segment, queryContext).run(functions, filter);
+      return new GpuQueryLowering(segment, indexSegment, queryContext).run(functions, filter);
+    } catch (NotOffloadable e) {
+      return null;
+    }
+  }
+
+  /**
+   * What a FILTER (WHERE ...) clause folds to on this segment: +1 matches every doc (MatchAllFilterOperator), -1 matches none
+   * (EmptyFilterOperator), 0 neither.  AggregationFunctionUtils.buildFilteredAggregationInfos (:351-358, :376-378) treats the functions of
+   * a match-all clause as non-filtered; the plan maker does the same with this answer.  Null when the clause has no device form.
+   */
+  @Nullable
+  static Integer foldsTo(GpuSegment segment, IndexSegment indexSegment, QueryContext queryContext, FilterContext filter) {
+    try {
+      Node root = new GpuQueryLowering(segment, indexSegment, queryContext).lowerFilter(filter);
+      return root._kind == Kind.MATCH_ALL ? 1 : (root._kind == Kind.EMPTY ? -1 : 0);
     } catch (NotOffloadable e) {
       return null;
     }
@@ -122,7 +142,9 @@ final class GpuQueryLowering {
   private Lowered run(AggregationFunction[] functions, @Nullable FilterContext filter) {
     Lowered out = new Lowered();
     // ---- aggregations: COUNT / SUM / MIN / MAX / AVG over one identifier (AggregationFunctionType) ----
-    out._aggregations = new int[2 * functions.length];
+    // (no functions at all: the group-by lane FilteredGroupByOperator runs over the main filter only to create its groups,
+    //  AggregationFunctionUtils.java:388-400 -- the device needs something to aggregate, so it counts; the operator ignores the value)
+    out._aggregations = functions.length == 0 ? new int[]{AGG_COUNT, -1} : new int[AGG_INTS * functions.length];
     for (int i = 0; i < functions.length; i++) {
       AggregationFunction function = functions[i];
       int code;
@@ -162,8 +184,8 @@ final class GpuQueryLowering {
           throw new NotOffloadable("aggregation of a non-numeric column");   // the reference throws BadQueryRequestException itself
         }
       }
-      out._aggregations[2 * i] = code;
-      out._aggregations[2 * i + 1] = column;
+      out._aggregations[AGG_INTS * i] = code;
+      out._aggregations[AGG_INTS * i + 1] = column;
     }
     // ---- group-by keys: dictionary-encoded identifiers ----
     List<ExpressionContext> groupBy = _queryContext.getGroupByExpressions();
@@ -187,13 +209,13 @@ final class GpuQueryLowering {
         flatten(root, nodes);
       }
     }
-    out._filterNodes = new int[3 * nodes.size()];
+    out._filterNodes = new int[NODE_INTS * nodes.size()];
     for (int i = 0; i < nodes.size(); i++) {
-      System.arraycopy(nodes.get(i), 0, out._filterNodes, 3 * i, 3);
+      System.arraycopy(nodes.get(i), 0, out._filterNodes, NODE_INTS * i, NODE_INTS);
     }
     int numPredicates = _predInts.size();
-    out._predInts = new int[4 * numPredicates];
-    out._predLongs = new long[2 * numPredicates];
+    out._predInts = new int[PRED_INTS * numPredicates];
+    out._predLongs = new long[PRED_LONGS * numPredicates];
     out._setOffsets = new int[numPredicates + 1];
     int totalWords = 0;
     for (int[] set : _predSets) {
@@ -202,8 +224,8 @@ final class GpuQueryLowering {
     out._setWords = new int[totalWords];
     int at = 0;
     for (int i = 0; i < numPredicates; i++) {
-      System.arraycopy(_predInts.get(i), 0, out._predInts, 4 * i, 4);
-      System.arraycopy(_predLongs.get(i), 0, out._predLongs, 2 * i, 2);
+      System.arraycopy(_predInts.get(i), 0, out._predInts, PRED_INTS * i, PRED_INTS);
+      System.arraycopy(_predLongs.get(i), 0, out._predLongs, PRED_LONGS * i, PRED_LONGS);
       int[] set = _predSets.get(i);
       System.arraycopy(set, 0, out._setWords, at, set.length);
       at += set.length;

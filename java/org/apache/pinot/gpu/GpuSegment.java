@@ -42,15 +42,17 @@ import org.apache.pinot.spi.utils.Pairs;
 
 
 final class GpuSegment implements Closeable {
-  // pg_data_type / pg_fwd_encoding
-  private static final int TYPE_INT = 0;
-  private static final int TYPE_LONG = 1;
-  private static final int TYPE_FLOAT = 2;
-  private static final int TYPE_DOUBLE = 3;
-  private static final int FWD_FIXED_BIT_DICT = 0;
-  private static final int FWD_RAW_FIXED_BYTE = 1;
+  // pg_data_type / pg_fwd_encoding (the numbers live in PinotGpuNative)
+  private static final int TYPE_INT = PinotGpuNative.PG_TYPE_INT;
+  private static final int TYPE_LONG = PinotGpuNative.PG_TYPE_LONG;
+  private static final int TYPE_FLOAT = PinotGpuNative.PG_TYPE_FLOAT;
+  private static final int TYPE_DOUBLE = PinotGpuNative.PG_TYPE_DOUBLE;
+  private static final int FWD_FIXED_BIT_DICT = PinotGpuNative.PG_FWD_FIXED_BIT_DICT;
+  private static final int FWD_RAW_FIXED_BYTE = PinotGpuNative.PG_FWD_RAW_FIXED_BYTE;
 
-  private final IndexSegment _indexSegment;
+  // NO reference to the IndexSegment: GpuSegmentCache keys a WeakHashMap by it, and a value that reached its key would pin both (and the
+  // HBM copy) for the JVM's lifetime.  Whoever needs the IndexSegment has it from the SegmentContext of the query at hand.
+  private final String _segmentName;
   private final Map<String, Integer> _columnIndex = new HashMap<>();
   private final List<String> _columnNames = new ArrayList<>();
   private final List<Boolean> _hasDictionary = new ArrayList<>();
@@ -59,12 +61,12 @@ final class GpuSegment implements Closeable {
   private volatile long _handle;
 
   private GpuSegment(IndexSegment indexSegment) {
-    _indexSegment = indexSegment;
+    _segmentName = indexSegment.getSegmentName();
     _numDocs = indexSegment.getSegmentMetadata().getTotalDocs();
   }
 
-  IndexSegment getIndexSegment() {
-    return _indexSegment;
+  String getSegmentName() {
+    return _segmentName;
   }
 
   long handle() {
@@ -177,10 +179,15 @@ final class GpuSegment implements Closeable {
         segment._columnNames.add(column);
         segment._hasDictionary.add(dictionary != null);
         segment._numeric.add(numeric);
-        for (int v : new int[]{storedCode, encoding, bits, cardinality, dictionary != null ? 1 : 0, 0}) {
+        int[] columnInts = {storedCode, encoding, bits, cardinality, dictionary != null ? 1 : 0, 0};
+        long[][] columnBuffers = {fwd, dict, inverted, nulls};
+        if (columnInts.length != PinotGpuNative.PGM_COLUMN_INTS || 2 * columnBuffers.length != PinotGpuNative.PGM_COLUMN_BUFFERS) {
+          throw new IllegalStateException("column record does not match jni/pg_marshal.h");
+        }
+        for (int v : columnInts) {
           ints.add(v);
         }
-        for (long[] pair : new long[][]{fwd, dict, inverted, nulls}) {
+        for (long[] pair : columnBuffers) {
           buffers.add(pair[0]);
           buffers.add(pair[1]);
         }

@@ -1,7 +1,9 @@
 /**
  * IndexSegment -> device-resident GpuSegment.  A segment is opened the first time a query reaches it and closed when the server drops
  * the IndexSegment: the cache holds the key weakly and registers the native handle with a Cleaner, so no hook into the segment data
- * manager is needed (IndexSegment.destroy() releases the mmap-ed buffers; the device copy does not depend on them).
+ * manager is needed (IndexSegment.destroy() releases the mmap-ed buffers; the device copy does not depend on them).  For that to work the
+ * VALUE must not reach the key: GpuSegment holds the segment's name and column table, never the IndexSegment, and the Cleaner's action
+ * captures only the native handle.  (A WeakHashMap whose value references its key strongly never clears the entry.)
  *
  * <p>Segments that cannot be opened (mutable segments, unsupported layouts, out of device memory) are remembered as such: their queries
  * keep the CPU plan without trying again on every query.

@@ -3,7 +3,7 @@
  * (jni/pinot_gpu_jni.c holds the JNI functions, jni/pg_marshal.c the array marshalling they share with the tests).
  *
  * <p>Arrays instead of objects: a query crosses as the flat arrays documented in jni/pg_marshal.h (GpuQueryLowering writes them), a result
- * comes back as {@code Object[8]} of primitive arrays (GpuResult reads them).  The only native state Java ever holds is the segment
+ * comes back as an {@code Object[]} of primitive arrays (GpuAggregationOperator reads them).  The only native state Java ever holds is the segment
  * handle, a {@code long}.
  */
 package org.apache.pinot.gpu;
@@ -19,12 +19,91 @@ public final class PinotGpuNative {
     System.loadLibrary("pinot_gpu_jni");
   }
 
-  /** pg_status values the Java side distinguishes (include/pinot_gpu.h:53-61). */
+  // ---- constants of the C boundary.  Every PG_* / PGM_* name below exists under the SAME name in include/pinot_gpu.h or
+  // jni/pg_marshal.h; tests/test_java_constants.py parses both languages and fails on any difference, and no other class of this package
+  // may spell one of these numbers as a literal.
+
+  /** PG_ABI_VERSION (include/pinot_gpu.h): checked against pg_version() in GpuPlanMaker.init. */
+  public static final int PG_ABI_VERSION = 2;
+
+  /** pg_status */
   public static final int PG_OK = 0;
+  public static final int PG_ERR_INVALID_ARGUMENT = 1;
   public static final int PG_ERR_UNSUPPORTED = 2;
+  public static final int PG_ERR_DEVICE = 3;
+  public static final int PG_ERR_OUT_OF_MEMORY = 4;
+  public static final int PG_ERR_NOT_INITIALIZED = 5;
+  public static final int PG_ERR_INTERNAL = 6;
+
+  /** pg_data_type */
+  public static final int PG_TYPE_INT = 0;
+  public static final int PG_TYPE_LONG = 1;
+  public static final int PG_TYPE_FLOAT = 2;
+  public static final int PG_TYPE_DOUBLE = 3;
+
+  /** pg_fwd_encoding */
+  public static final int PG_FWD_FIXED_BIT_DICT = 0;
+  public static final int PG_FWD_RAW_FIXED_BYTE = 1;
+
+  /** pg_predicate_kind */
+  public static final int PG_PRED_MATCH_ALL = 0;
+  public static final int PG_PRED_MATCH_NONE = 1;
+  public static final int PG_PRED_DICT_RANGE = 2;
+  public static final int PG_PRED_DICT_SET = 3;
+  public static final int PG_PRED_RAW_RANGE = 4;
+  public static final int PG_PRED_DOC_RANGE = 5;
+  public static final int PG_PRED_IS_NULL = 6;
+
+  /** pg_leaf_eval */
+  public static final int PG_EVAL_SCAN = 0;
+  public static final int PG_EVAL_INVERTED = 1;
+
+  /** pg_filter_op */
+  public static final int PG_FILTER_LEAF = 0;
+  public static final int PG_FILTER_AND = 1;
+  public static final int PG_FILTER_OR = 2;
+  public static final int PG_FILTER_NOT = 3;
+
+  /** pg_agg_function */
+  public static final int PG_AGG_COUNT = 0;
+  public static final int PG_AGG_SUM = 1;
+  public static final int PG_AGG_MIN = 2;
+  public static final int PG_AGG_MAX = 3;
+  public static final int PG_AGG_AVG = 4;
 
   /** pg_query.flags */
   public static final int PG_QUERY_NULL_HANDLING = 1;
+
+  /** Record sizes of the flat arrays and slots of the result array (jni/pg_marshal.h). */
+  public static final int PGM_FILTER_NODE_INTS = 3;
+  public static final int PGM_PRED_INTS = 4;
+  public static final int PGM_PRED_LONGS = 2;
+  public static final int PGM_AGG_INTS = 2;
+  public static final int PGM_COLUMN_INTS = 6;
+  public static final int PGM_COLUMN_BUFFERS = 8;
+  public static final int PGM_RESULT_ARRAYS = 8;
+  public static final int PGM_R_HEADER = 0;
+  public static final int PGM_R_GROUP_IDS = 1;
+  public static final int PGM_R_COUNTS = 2;
+  public static final int PGM_R_SUMS = 3;
+  public static final int PGM_R_SUMS_I64 = 4;
+  public static final int PGM_R_SUM_EXACT = 5;
+  public static final int PGM_R_MINS = 6;
+  public static final int PGM_R_MAXS = 7;
+
+  /** Indexes of the result header (PGM_H_* in jni/pg_marshal.h). */
+  public static final int PGM_H_NUM_DOCS_SCANNED = 0;
+  public static final int PGM_H_ENTRIES_IN_FILTER = 1;
+  public static final int PGM_H_ENTRIES_POST_FILTER = 2;
+  public static final int PGM_H_TOTAL_DOCS = 3;
+  public static final int PGM_H_FILTER_ENTRIES_EXACT = 4;
+  public static final int PGM_H_NUM_AGGREGATIONS = 5;
+  public static final int PGM_H_NUM_GROUPS = 6;
+  public static final int PGM_H_GROUP_ID_UPPER_BOUND = 7;
+  public static final int PGM_H_NUM_GROUPS_LIMIT_REACHED = 8;
+  public static final int PGM_H_DOMINANT_KERNEL = 9;
+  public static final int PGM_H_IS_GROUP_BY = 10;
+  public static final int PGM_HEADER_LEN = 11;
 
   /** pg_init: once per JVM, from GpuPlanMaker.init. */
   static native void init(int device, int flags);
@@ -42,8 +121,8 @@ public final class PinotGpuNative {
   static native long directBufferAddress(ByteBuffer buffer);
 
   /**
-   * pg_segment_open.  {@code columnInts}: 6 per column {storedType, fwdEncoding, bitsPerValue, cardinality, hasDictionary, 0};
-   * {@code columnBuffers}: 8 per column {fwd address, fwd size, dict address, dict size, inverted address, inverted size, null-vector
+   * pg_segment_open.  {@code columnInts}: PGM_COLUMN_INTS per column {storedType, fwdEncoding, bitsPerValue, cardinality, hasDictionary, 0};
+   * {@code columnBuffers}: PGM_COLUMN_BUFFERS per column {fwd address, fwd size, dict address, dict size, inverted address, inverted size, null-vector
    * address, null-vector size}, 0 / 0 where an index does not exist.  The buffers are read during the call only.
    */
   static native long segmentOpen(String name, long crc, int device, int numDocs, String[] columnNames, int[] columnInts, long[] columnBuffers);
@@ -59,8 +138,8 @@ public final class PinotGpuNative {
       int[] aggregations, int[] groupBy, int numGroupsLimit, int flags);
 
   /**
-   * pg_execute.  Returns {long[] header, int[] groupIds, long[] counts, double[] sums, long[] sumsI64, int[] sumExact, double[] mins,
-   * double[] maxs}; throws UnsupportedOperationException for PG_ERR_UNSUPPORTED, RuntimeException (pg_last_error) otherwise.
+   * pg_execute.  Returns Object[PGM_RESULT_ARRAYS], slots PGM_R_*: {long[] header, int[] groupIds, long[] counts, double[] sums,
+   * long[] sumsI64, int[] sumExact, double[] mins, double[] maxs}; throws UnsupportedOperationException for PG_ERR_UNSUPPORTED, RuntimeException (pg_last_error) otherwise.
    */
   static native Object[] execute(long handle, int[] filterNodes, int[] predInts, long[] predLongs, int[] setOffsets, int[] setWords,
       int[] aggregations, int[] groupBy, int numGroupsLimit, int flags);

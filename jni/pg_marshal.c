@@ -59,22 +59,22 @@ pgm_query* pgm_query_build(const int32_t* filter_nodes, int32_t num_nodes, const
   q->group_by = (int32_t*)copy_of(group_by, (size_t)num_group_by, sizeof(int32_t));
   if (!q->nodes || !q->predicates || !q->set_words || !q->aggregations || !q->group_by) { pgm_query_free(q); set_error("out of memory"); return NULL; }
   for (int32_t n = 0; n < num_nodes; n++) {
-    q->nodes[n].op = filter_nodes[3 * n];
-    q->nodes[n].predicate = filter_nodes[3 * n + 1];
-    q->nodes[n].num_children = filter_nodes[3 * n + 2];
+    q->nodes[n].op = filter_nodes[PGM_FILTER_NODE_INTS * n];
+    q->nodes[n].predicate = filter_nodes[PGM_FILTER_NODE_INTS * n + 1];
+    q->nodes[n].num_children = filter_nodes[PGM_FILTER_NODE_INTS * n + 2];
   }
   for (int32_t p = 0; p < num_preds; p++) {
     pg_predicate* d = &q->predicates[p];
-    d->kind = pred_ints[4 * p];
-    d->column = pred_ints[4 * p + 1];
-    d->eval = pred_ints[4 * p + 2];
-    d->exclusive = pred_ints[4 * p + 3];
-    d->lo = pred_longs[2 * p];
-    d->hi = pred_longs[2 * p + 1];
+    d->kind = pred_ints[PGM_PRED_INTS * p];
+    d->column = pred_ints[PGM_PRED_INTS * p + 1];
+    d->eval = pred_ints[PGM_PRED_INTS * p + 2];
+    d->exclusive = pred_ints[PGM_PRED_INTS * p + 3];
+    d->lo = pred_longs[PGM_PRED_LONGS * p];
+    d->hi = pred_longs[PGM_PRED_LONGS * p + 1];
     d->num_set_words = set_offsets[p + 1] - set_offsets[p];
     d->set_words = d->num_set_words ? q->set_words + set_offsets[p] : NULL;
   }
-  for (int32_t a = 0; a < num_aggs; a++) { q->aggregations[a].function = aggregations[2 * a]; q->aggregations[a].column = aggregations[2 * a + 1]; }
+  for (int32_t a = 0; a < num_aggs; a++) { q->aggregations[a].function = aggregations[PGM_AGG_INTS * a]; q->aggregations[a].column = aggregations[PGM_AGG_INTS * a + 1]; }
   q->query.filter = num_nodes ? q->nodes : NULL;
   q->query.num_filter_nodes = num_nodes;
   q->query.predicates = num_preds ? q->predicates : NULL;
@@ -126,8 +126,8 @@ pgm_segment* pgm_segment_build(const char* name, int64_t crc, int32_t device_id,
     s->column_names[c] = dup_string(names[c]);
     if (!s->column_names[c]) { pgm_segment_free(s); set_error("out of memory"); return NULL; }
     pg_column_desc* d = &s->columns[c];
-    const int32_t* ci = col_ints + 6 * (size_t)c;
-    const int64_t* cb = col_buffers + 8 * (size_t)c;
+    const int32_t* ci = col_ints + PGM_COLUMN_INTS * (size_t)c;
+    const int64_t* cb = col_buffers + PGM_COLUMN_BUFFERS * (size_t)c;
     d->name = s->column_names[c];
     d->stored_type = ci[0];
     d->fwd_encoding = ci[1];

@@ -30,6 +30,17 @@
 extern "C" {
 #endif
 
+/* Arities of the flat arrays above and the slots of the result array: ONE definition, used by pg_marshal.c, pinot_gpu_jni.c and -- under the
+ * same names -- by java/org/apache/pinot/gpu/PinotGpuNative.java (tests/test_java_constants.py compares the two languages). */
+enum {
+  PGM_FILTER_NODE_INTS = 3, PGM_PRED_INTS = 4, PGM_PRED_LONGS = 2, PGM_AGG_INTS = 2, PGM_COLUMN_INTS = 6, PGM_COLUMN_BUFFERS = 8,
+  PGM_RESULT_ARRAYS = 8
+};
+enum {
+  PGM_R_HEADER = 0, PGM_R_GROUP_IDS = 1, PGM_R_COUNTS = 2, PGM_R_SUMS = 3, PGM_R_SUMS_I64 = 4, PGM_R_SUM_EXACT = 5, PGM_R_MINS = 6,
+  PGM_R_MAXS = 7
+};
+
 typedef struct pgm_query pgm_query;      /* owns the pg_query and every array it points into */
 
 /* NULL (and pgm_last_error) on inconsistent arguments: negative counts, offsets that do not ascend or leave set_words. */

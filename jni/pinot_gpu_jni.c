@@ -62,8 +62,13 @@ JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_directBufferAdd
 JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_segmentOpen(JNIEnv* env, jclass cls, jstring name, jlong crc, jint device,
     jint numDocs, jobjectArray columnNames, jintArray columnInts, jlongArray columnBuffers) {
   (void)cls;
+  if (name == NULL || columnNames == NULL || columnInts == NULL || columnBuffers == NULL) {
+    throw_new(env, "java/lang/NullPointerException", "segmentOpen: null argument");
+    return 0;
+  }
   const jsize num_columns = (*env)->GetArrayLength(env, columnNames);
-  if ((*env)->GetArrayLength(env, columnInts) != 6 * num_columns || (*env)->GetArrayLength(env, columnBuffers) != 8 * num_columns) {
+  if ((int64_t)(*env)->GetArrayLength(env, columnInts) != (int64_t)PGM_COLUMN_INTS * num_columns ||
+      (int64_t)(*env)->GetArrayLength(env, columnBuffers) != (int64_t)PGM_COLUMN_BUFFERS * num_columns) {
     throw_new(env, "java/lang/IllegalArgumentException", "column arrays do not match the number of columns");
     return 0;
   }
@@ -141,12 +146,25 @@ static void release_query(JNIEnv* env, pinned_query* p, jintArray filterNodes, j
 static int pin_query(JNIEnv* env, pinned_query* p, jintArray filterNodes, jintArray predInts, jlongArray predLongs, jintArray setOffsets,
                      jintArray setWords, jintArray aggregations, jintArray groupBy, jint numGroupsLimit, jint flags) {
   memset(p, 0, sizeof(*p));
-  const jsize num_nodes = (*env)->GetArrayLength(env, filterNodes) / 3;
-  const jsize num_preds = (*env)->GetArrayLength(env, predInts) / 4;
+  if (filterNodes == NULL || predInts == NULL || predLongs == NULL || setOffsets == NULL || setWords == NULL || aggregations == NULL ||
+      groupBy == NULL) {
+    throw_new(env, "java/lang/NullPointerException", "query arrays must not be null (empty arrays stand for nothing)");
+    return 0;
+  }
+  const jsize len_nodes = (*env)->GetArrayLength(env, filterNodes);
+  const jsize len_pred_ints = (*env)->GetArrayLength(env, predInts);
+  const jsize len_aggs = (*env)->GetArrayLength(env, aggregations);
+  if (len_nodes % PGM_FILTER_NODE_INTS != 0 || len_pred_ints % PGM_PRED_INTS != 0 || len_aggs % PGM_AGG_INTS != 0) {
+    throw_new(env, "java/lang/IllegalArgumentException", "filterNodes / predInts / aggregations: length is not a whole number of records");
+    return 0;
+  }
+  const jsize num_nodes = len_nodes / PGM_FILTER_NODE_INTS;
+  const jsize num_preds = len_pred_ints / PGM_PRED_INTS;
   const jsize num_set_words = (*env)->GetArrayLength(env, setWords);
-  const jsize num_aggs = (*env)->GetArrayLength(env, aggregations) / 2;
+  const jsize num_aggs = len_aggs / PGM_AGG_INTS;
   const jsize num_group_by = (*env)->GetArrayLength(env, groupBy);
-  if ((*env)->GetArrayLength(env, predLongs) != 2 * num_preds || (*env)->GetArrayLength(env, setOffsets) != num_preds + 1) {
+  if ((int64_t)(*env)->GetArrayLength(env, predLongs) != (int64_t)PGM_PRED_LONGS * num_preds ||
+      (*env)->GetArrayLength(env, setOffsets) != num_preds + 1) {
     throw_new(env, "java/lang/IllegalArgumentException", "predicate arrays of different lengths");
     return 0;
   }
@@ -192,7 +210,7 @@ JNIEXPORT jstring JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_lastError(JNI
   return (*env)->NewStringUTF(env, pg_last_error());
 }
 
-/* pg_execute.  Returns Object[8]: {long[] header (PGM_H_* layout), int[] groupIds, long[] counts, double[] sums, long[] sumsI64,
+/* pg_execute.  Returns Object[PGM_RESULT_ARRAYS] (slots PGM_R_*): {long[] header (PGM_H_* layout), int[] groupIds, long[] counts, double[] sums, long[] sumsI64,
  * int[] sumExact, double[] mins, double[] maxs}, the value arrays row-major [row * numAggregations + a]. */
 JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(JNIEnv* env, jclass cls, jlong handle, jintArray filterNodes,
     jintArray predInts, jlongArray predLongs, jintArray setOffsets, jintArray setWords, jintArray aggregations, jintArray groupBy,
@@ -206,8 +224,15 @@ JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(
   release_query(env, &p, filterNodes, predInts, predLongs, setOffsets, setWords, aggregations, groupBy);
   if (status != PG_OK) { throw_status(env, status); return NULL; }     /* pg_execute freed the result */
 
-  const jsize rows = (jsize)pgm_result_rows(&result, is_group_by);
-  const jsize cells = rows * (jsize)result.num_aggregations;
+  const int64_t rows64 = pgm_result_rows(&result, is_group_by);
+  const int64_t cells64 = rows64 * (int64_t)result.num_aggregations;
+  if (rows64 < 0 || cells64 < 0 || cells64 > (int64_t)INT32_MAX - 8) {          /* a Java array holds fewer than 2^31 elements */
+    pg_result_free(&result);
+    throw_new(env, "java/lang/IllegalStateException", "the result has more cells than a Java array holds");
+    return NULL;
+  }
+  const jsize rows = (jsize)rows64;
+  const jsize cells = (jsize)cells64;
   jobjectArray out = NULL;
   jclass object_class = (*env)->FindClass(env, "java/lang/Object");
   jlongArray header = (*env)->NewLongArray(env, PGM_HEADER_LEN);
@@ -232,7 +257,7 @@ JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(
     jdouble* mx = (*env)->GetDoubleArrayElements(env, maxs, NULL);
     if (g && c && s && si && se && mn && mx) {
       (void)pgm_result_fill(&result, is_group_by, (int32_t*)g, (int64_t*)c, (double*)s, (int64_t*)si, (int32_t*)se, (double*)mn, (double*)mx);
-      out = (*env)->NewObjectArray(env, 8, object_class, NULL);
+      out = (*env)->NewObjectArray(env, PGM_RESULT_ARRAYS, object_class, NULL);
     }
     if (mx) (*env)->ReleaseDoubleArrayElements(env, maxs, mx, 0);
     if (mn) (*env)->ReleaseDoubleArrayElements(env, mins, mn, 0);
@@ -242,14 +267,14 @@ JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(
     if (c) (*env)->ReleaseLongArrayElements(env, counts, c, 0);
     if (g) (*env)->ReleaseIntArrayElements(env, group_ids, g, 0);
     if (out != NULL) {
-      (*env)->SetObjectArrayElement(env, out, 0, header);
-      (*env)->SetObjectArrayElement(env, out, 1, group_ids);
-      (*env)->SetObjectArrayElement(env, out, 2, counts);
-      (*env)->SetObjectArrayElement(env, out, 3, sums);
-      (*env)->SetObjectArrayElement(env, out, 4, sums_i64);
-      (*env)->SetObjectArrayElement(env, out, 5, sum_exact);
-      (*env)->SetObjectArrayElement(env, out, 6, mins);
-      (*env)->SetObjectArrayElement(env, out, 7, maxs);
+      (*env)->SetObjectArrayElement(env, out, PGM_R_HEADER, header);
+      (*env)->SetObjectArrayElement(env, out, PGM_R_GROUP_IDS, group_ids);
+      (*env)->SetObjectArrayElement(env, out, PGM_R_COUNTS, counts);
+      (*env)->SetObjectArrayElement(env, out, PGM_R_SUMS, sums);
+      (*env)->SetObjectArrayElement(env, out, PGM_R_SUMS_I64, sums_i64);
+      (*env)->SetObjectArrayElement(env, out, PGM_R_SUM_EXACT, sum_exact);
+      (*env)->SetObjectArrayElement(env, out, PGM_R_MINS, mins);
+      (*env)->SetObjectArrayElement(env, out, PGM_R_MAXS, maxs);
     }
   }
   pg_result_free(&result);

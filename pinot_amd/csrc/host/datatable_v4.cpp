@@ -132,10 +132,12 @@ class Builder {      // DataTableBuilderV4 + BaseDataTableBuilder
 // MetadataKey ids and value types (pinot-common/.../datatable/DataTable.java:104-142)
 void put(std::map<int, std::pair<char, std::string>>* m, int id, char type, const std::string& value) { (*m)[id] = {type, value}; }
 
-void setIntermediate(Builder* b, int column, const AggregationFunction& f, const IntermediateResult& r, std::vector<int32_t>* nullRows, int row) {
+void setIntermediate(Builder* b, int column, const AggregationFunction& f, const IntermediateResult& r, std::vector<int32_t>* nullRows, int row, bool isGroupBy) {
   const ColumnType t = intermediateType(f.getType());
   if (isNullResult(r)) {                               // null handling: placeholder + the column's null bitmap (AggregationResultsBlock.java:119-122)
-    if (t == ColumnType::OBJECT) b->setAvgPair(column, nullptr);
+    // AggregationResultsBlock.getDataTable adds row 0 to the null bitmap for EVERY null result, OBJECT included (:119-122); only
+    // GroupByResultsBlock leaves OBJECT columns out of the bitmaps (a null object already says so).
+    if (t == ColumnType::OBJECT) { if (!isGroupBy) nullRows->push_back(row); b->setAvgPair(column, nullptr); }
     else { nullRows->push_back(row); if (t == ColumnType::LONG) b->setLong(column, 0); else b->setDouble(column, 0.0); }
     return;
   }
@@ -168,7 +170,7 @@ std::vector<uint8_t> toDataTableV4(const ResultsBlock& block, bool nullHandlingE
   std::vector<std::vector<int32_t>> nullRows(names.size());
   if (!block.isGroupBy) {
     builder.startRow();
-    for (size_t a = 0; a < functions.size(); ++a) setIntermediate(&builder, (int)a, functions[a], block.aggregation.results[a], &nullRows[a], 0);
+    for (size_t a = 0; a < functions.size(); ++a) setIntermediate(&builder, (int)a, functions[a], block.aggregation.results[a], &nullRows[a], 0, false);
     builder.finishRow();
   } else {
     const size_t nk = block.groupBy.groupByColumns.size();
@@ -195,7 +197,7 @@ std::vector<uint8_t> toDataTableV4(const ResultsBlock& block, bool nullHandlingE
           default: builder.setString((int)k, std::get<std::string>(v)); break;
         }
       }
-      for (size_t a = 0; a < functions.size(); ++a) setIntermediate(&builder, (int)(nk + a), functions[a], block.groupBy.results[r][a], &nullRows[nk + a], (int)r);
+      for (size_t a = 0; a < functions.size(); ++a) setIntermediate(&builder, (int)(nk + a), functions[a], block.groupBy.results[r][a], &nullRows[nk + a], (int)r, true);
       builder.finishRow();
     }
   }

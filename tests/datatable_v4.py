@@ -31,8 +31,10 @@ def _roaring(rows):
     return struct.pack("<IIHH", 12346, 1, 0, len(rows) - 1) + struct.pack("<I", 16) + b"".join(struct.pack("<H", r) for r in rows)
 
 
-def encode(names, types, rows, metadata, null_handling=False):
-    """rows: list of lists; a STRING cell is a str, an OBJECT cell an (sum, count) AvgPair or None, any other None is a null (null handling)."""
+def encode(names, types, rows, metadata, null_handling=False, group_by=True):
+    """rows: list of lists; a STRING cell is a str, an OBJECT cell an (sum, count) AvgPair or None, any other None is a null (null handling).
+    An aggregation-only block (group_by=False) also lists a null OBJECT in its column's null bitmap (AggregationResultsBlock.java:119-122);
+    GroupByResultsBlock.java:210 leaves OBJECT columns out."""
     offsets, at = [], 0
     for t in types:
         offsets.append(at)
@@ -43,9 +45,9 @@ def encode(names, types, rows, metadata, null_handling=False):
         buf = bytearray(at)
         for c, (t, v) in enumerate(zip(types, row)):
             o = offsets[c]
-            if v is None and t != OBJECT:
+            if v is None and (t != OBJECT or not group_by):
                 null_rows[c].append(r)
-                v = "" if t == STRING else 0
+                v = None if t == OBJECT else ("" if t == STRING else 0)
             if t == INT:
                 buf[o:o + 4] = struct.pack(">i", v)
             elif t == LONG:

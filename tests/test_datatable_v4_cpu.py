@@ -80,7 +80,7 @@ def test_aggregation_block_of_the_reference_golden_query():
     rows = [((), cells)]
     data = build(functions, columns, [], [], rows, g["stats"])
     names, types = schema(functions, columns, [], [])
-    want = D.encode(names, types, python_rows(functions, rows), D.results_metadata(g["stats"], 1, 1))
+    want = D.encode(names, types, python_rows(functions, rows), D.results_metadata(g["stats"], 1, 1), group_by=False)
     assert data == want
     back = D.decode(data)
     assert back["names"] == ["count(*)", "sum(column1)", "max(column3)", "min(column6)", "avg(column7)"] and back["types"] == [D.LONG, D.DOUBLE, D.DOUBLE, D.DOUBLE, D.OBJECT]
@@ -118,6 +118,20 @@ def test_group_by_blocks_with_every_key_type_and_null_results():
             assert back["rows"][3][6] is None and back["rows"][3][5] == 0.0
         else:
             assert back["null_rows"] is None
+
+
+def test_aggregation_block_with_null_results_under_null_handling():
+    """AggregationResultsBlock.getDataTable (:113-131): every null result, a null AvgPair included, is row 0 of its column's null bitmap."""
+    functions, columns = [D.AGG_COUNT, D.AGG_SUM, D.AGG_AVG, D.AGG_MIN, D.AGG_AVG], ["*", "a", "a", "b", "b"]
+    cells = [(0, 0.0, 0.0, 0.0, False), (0, 0.0, 0.0, 0.0, True), (0, 0.0, 0.0, 0.0, True), (0, 0.0, 2.5, 0.0, False), (3, 7.5, 0.0, 0.0, False)]
+    rows = [((), cells)]
+    stats = [0, 10, 0, 10]
+    data = build(functions, columns, [], [], rows, stats, null_handling=True)
+    names, types = schema(functions, columns, [], [])
+    assert data == D.encode(names, types, python_rows(functions, rows), D.results_metadata(stats, 1, 1), null_handling=True, group_by=False)
+    back = D.decode(data)
+    assert back["null_rows"] == [[], [0], [0], [], []]
+    assert back["rows"] == [[0, 0.0, None, 2.5, (7.5, 3)]]
 
 
 def test_empty_group_by_block():
