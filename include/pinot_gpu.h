@@ -241,7 +241,8 @@ typedef enum pg_kernel_id {
   PG_KERNEL_GROUP_PRIVATE = 3,     /* group_private_kernel: lane-private group-by */
   PG_KERNEL_GROUP_PARTITION = 4,   /* group_partition_scatter_kernel (+ histogram / aggregate): key spaces above the LDS table */
   PG_KERNEL_SCAN_PRIVATE_TYPED = 5,/* scan_private_typed_kernel: lane-private scan, raw / 8-byte aggregated columns */
-  PG_KERNEL_INDEX_AND = 7,         /* index_and_kernel alone: COUNT(*) over a filter the inverted indexes answer (FastFilteredCountOperator) */
+  PG_KERNEL_INDEX_AND = 7,         /* index_and_kernel: COUNT(*) over a filter the inverted indexes answer (FastFilteredCountOperator), or an
+                                    * index-led aggregation whose index phase (index_and_kernel + its tile-list pass) outlasts the scan of the listed tiles */
   PG_KERNEL_SCAN_NARROW = 8,       /* scan_narrow_kernel: COUNT(*) / bitmap of a filter over dictionary columns of at most 8 bits, four tiles per wave */
   PG_KERNEL_SCAN_HIST = 6          /* scan_hist_kernel: lane-private scan, SUM = sum_d matches[d] * dictionary[d] through an LDS histogram */
 } pg_kernel_id;

@@ -185,10 +185,22 @@ struct ScanParams {
   const uint32_t* tile_list;       // lane-private kernels: visit only these 2048-doc tiles (index_and_kernel's survivors), or nullptr = all
   const uint32_t* tile_count;      //                       [1] how many of them
   int32_t raw64_coalesced;         // scan_private_typed_kernel: raw 8-byte columns are read 1 KB per instruction across the wave (pg_scan_typed.h)
-  int32_t reserved0;
+  int32_t lane_skip;               // lane-private aggregating kernels: a lane whose 32 docs hold no match does not load its value bytes
   unsigned long long* filter_entries;  // [1] numEntriesScannedInFilter of the kNodeCountEntries leaves (lane-private kernels), or nullptr
   unsigned long long* out_bitmap;  // optional doc-order bitmap output (num_tiles * tile_steps words)
-  BlockPartial* partials;          // [gridDim.x]
+  BlockPartial* partials;          // [gridDim.x] (+ 1: the folded record when host_out is null)
+  // "Last block done": the workgroup whose arrival completes `done_counter` folds the per-workgroup records inside the scan kernel
+  // itself (publish_block_partial in pg_kernels.h) -- no finalize launch follows.  nullptr: the records are left for finalize_partials_kernel.
+  uint32_t* done_counter;          // [1] device memory, zero between launches (the folding workgroup resets it)
+  struct HostRecord* host_out;     // pinned, device-mapped host record the fold is written to, or nullptr -> partials[gridDim.x]
+  unsigned long long host_seq;     // value stored into host_out->seq after the record (the host may poll it instead of synchronising the stream)
+};
+
+// What a query's scan brings back to the host: the folded record, then a sequence number written after it.
+struct HostRecord {
+  BlockPartial partial;
+  unsigned long long seq;
+  unsigned long long pad[7];
 };
 
 // Host-side plan (what lower_filter / execute build before it is flattened into ScanParams).

@@ -63,6 +63,9 @@ struct Engine {
   int tile_steps = 0;        // 0 auto, 16 or 32 forced (PINOT_GPU_TILE_STEPS)
   bool double_buffer = false;
   bool direct_result = true; // PINOT_GPU_DIRECT_RESULT=0: the folded partial is copied device -> host with a copy command
+  bool fold_finalize = true; // PINOT_GPU_FOLD_FINALIZE=0: the workgroups' records are folded by finalize_partials_kernel, a launch of its own
+  bool poll_result = false;  // PINOT_GPU_POLL_RESULT=1: pg_execute spins on the pinned record's sequence number instead of hipStreamSynchronize
+  bool lane_skip = true;     // PINOT_GPU_LANE_SKIP=0: the aggregating kernels load a tile's value bytes for every lane, matches or not
   bool plane_gcd = true;     // PINOT_GPU_PLANE_GCD=0: planes hold value - min unscaled, never alias the dictId stream
   bool scan_private = true;  // PINOT_GPU_SCAN_PRIVATE=0: always the LDS-staged scan kernel
   bool group_private = true; // PINOT_GPU_GROUP_PRIVATE=0: unfiltered group-by through the LDS-staged kernel
@@ -143,8 +146,13 @@ struct ExecCtx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   BlockPartial* d_partials = nullptr;
   int partial_capacity = 0;
-  BlockPartial* h_partial = nullptr;            // pinned and device-mapped: finalize_partials_kernel writes the result into it
-  BlockPartial* h_partial_dev = nullptr;        // its device-side address
+  HostRecord* h_record = nullptr;               // pinned and device-mapped: the folding workgroup (or finalize_partials_kernel) writes the result into it
+  HostRecord* h_record_dev = nullptr;           // its device-side address
+  BlockPartial* h_partial = nullptr;            // = &h_record->partial
+  uint32_t* d_done = nullptr;                   // "last block done" arrival counter of the scan kernels (zero between launches)
+  unsigned long long seq = 0;                   // sequence number of the context's last launch (HostRecord.seq)
+  bool pre_started = false;                     // timed runs: ev[0] has been recorded (some kernel runs before the scan)
+  int ev_last = 3;                              // timed runs: the event that closes the query's device work (2 when nothing follows the scan kernel)
   std::vector<unsigned long long*> d_bitmaps;   // each num_tiles*32 words
   std::vector<uint32_t*> d_sets;
   std::vector<size_t> set_capacity;
@@ -197,7 +205,8 @@ namespace {
 void destroy_ctx(ExecCtx* c) {
   if (!c) return;
   if (c->d_partials) (void)hipFree(c->d_partials);
-  if (c->h_partial) (void)hipHostFree(c->h_partial);
+  if (c->h_record) (void)hipHostFree(c->h_record);
+  if (c->d_done) (void)hipFree(c->d_done);
   for (auto* b : c->d_bitmaps) (void)hipFree(b);
   for (auto* s : c->d_sets) (void)hipFree(s);
   if (c->d_table) (void)hipFree(c->d_table);
@@ -229,8 +238,11 @@ pg_status acquire_ctx(pg_segment* seg, ExecCtx** out) {
   ExecCtx* c = new ExecCtx();
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) for (auto& ev : c->ev) { e = hipEventCreate(&ev); if (e != hipSuccess) break; }
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_partial, sizeof(BlockPartial), hipHostMallocMapped);
-  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->h_partial_dev, c->h_partial, 0);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_record, sizeof(HostRecord), hipHostMallocMapped);
+  if (e == hipSuccess) { memset(c->h_record, 0, sizeof(HostRecord)); c->h_partial = &c->h_record->partial; }
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->h_record_dev, c->h_record, 0);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_done, 64);
+  if (e == hipSuccess) e = hipMemset(c->d_done, 0, 64);
   if (e != hipSuccess) {
     destroy_ctx(c);
     return fail(PG_ERR_DEVICE, "creating execution context failed: %s", hipGetErrorString(e));
@@ -873,9 +885,18 @@ void build_sequence(const pg_query* q, std::vector<SeqNode>* seq, int* lazy_node
 }
 
 // kNodeCountEntries leaves: the device counter the lane-private kernels add their entries to, zeroed in stream order.
+// Timed runs (PG_CFG_TIME_KERNELS): ev[0] opens the query's device work.  It is recorded by the first thing that enqueues work BEFORE
+// the scan kernel (index AND, posting expansion, set uploads, table initialisation); a query that runs only its scan kernel opens with ev[1].
+hipError_t mark_pre_work(ExecCtx* ctx) {
+  if (!(g_engine.flags & PG_CFG_TIME_KERNELS) || ctx->pre_started) return hipSuccess;
+  ctx->pre_started = true;
+  return hipEventRecord(ctx->ev[0], ctx->stream);
+}
+
 pg_status arm_filter_entries(ExecCtx* ctx, unsigned long long** out_counter) {
   if (!ctx->d_filter_entries) HIP_TRY(hipMalloc((void**)&ctx->d_filter_entries, 8));
   if (!ctx->h_filter_entries) HIP_TRY(hipHostMalloc((void**)&ctx->h_filter_entries, 8, hipHostMallocDefault));
+  HIP_TRY(mark_pre_work(ctx));
   HIP_TRY(hipMemsetAsync(ctx->d_filter_entries, 0, 8, ctx->stream));
   *out_counter = ctx->d_filter_entries;
   return PG_OK;
@@ -884,6 +905,7 @@ pg_status arm_filter_entries(ExecCtx* ctx, unsigned long long** out_counter) {
 // Zeros in every tile index_and_kernel did not store: for the kernels that read the whole bitmap instead of the tile list.
 pg_status complete_index_and_bitmap(Lowered* lw, ExecCtx* ctx) {
   if (!lw->and_bitmap) return PG_OK;
+  HIP_TRY(mark_pre_work(ctx));
   index_and_zero_unlisted_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>(lw->and_info, lw->and_bitmap, lw->and_words);
   HIP_TRY(hipGetLastError());
   lw->and_bitmap = nullptr;
@@ -910,6 +932,7 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
     const long long words = (long long)seg->num_tiles * kMaxTileSteps;
     const unsigned num_windows = (unsigned)((words + 1023) / 1024);
     bool first_posting = true;
+    HIP_TRY(mark_pre_work(ctx));
     for (int d = 0; d < col.cardinality; ++d) {
       bool in;
       if (pr.kind == PG_PRED_DICT_RANGE) in = d >= pr.lo && d < pr.hi;
@@ -1038,6 +1061,7 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
       }
       unsigned long long* d_cardinality = ctx->d_and_counters;
       uint32_t* d_tile_count = reinterpret_cast<uint32_t*>(ctx->d_and_counters + 1);
+      HIP_TRY(mark_pre_work(ctx));
       if (num_windows) {
         index_and_kernel<<<dim3(num_windows), dim3(64), 0, ctx->stream>>>(ap);
         index_and_finalize_kernel<<<dim3((num_windows + 255) / 256), dim3(256), 0, ctx->stream>>>(ctx->d_window_info, (int)num_windows, cardinality_only ? nullptr : ctx->d_tile_list,
@@ -1134,7 +1158,7 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
           size_t bytes = (size_t)pr.num_set_words * 4;
           pg_status st = ensure_set(ctx, set_idx, bytes);
           if (st != PG_OK) return st;
-          if (bytes) HIP_TRY(hipMemcpyAsync(ctx->d_sets[set_idx], pr.set_words, bytes, hipMemcpyHostToDevice, ctx->stream));
+          if (bytes) { HIP_TRY(mark_pre_work(ctx)); HIP_TRY(hipMemcpyAsync(ctx->d_sets[set_idx], pr.set_words, bytes, hipMemcpyHostToDevice, ctx->stream)); }
           // the host words may go out of scope as soon as pg_execute returns; the copy is ordered before the kernel
           // on the same stream and the caller's buffer is read synchronously for pageable memory.
           L.kind = kLeafDictSet; L.col = s; L.set_words = ctx->d_sets[set_idx]; L.set_bytes = (int32_t)bytes;
@@ -1322,7 +1346,7 @@ void finish_geometry(const pg_segment* seg, Lowered* lw, size_t table_bytes, boo
   g->table_in_lds = best_table;
   g->threads = best_waves * 64;
   g->lds = (size_t)best_waves * sp.wave_lds_bytes + (best_table ? table_bytes : 0);
-  g->lds = std::max(g->lds, sizeof(BlockPartial) * (size_t)best_waves);
+  g->lds = std::max(g->lds, sizeof(BlockPartial) * (size_t)best_waves + 16);      // the waves' records + the fold flag (publish_block_partial)
   int bpc = std::max(1, std::min(wave_cap / best_waves, (int)(kLdsBudget / g->lds)));
   if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
   const long long want = ((long long)sp.num_tiles + best_waves - 1) / best_waves;
@@ -1386,6 +1410,12 @@ pg_status pg_init(const pg_config* config) {
   g_engine.double_buffer = db && db[0] == '1';
   const char* drv = getenv("PINOT_GPU_DIRECT_RESULT");
   g_engine.direct_result = !(drv && drv[0] == '0');
+  const char* ffz = getenv("PINOT_GPU_FOLD_FINALIZE");
+  g_engine.fold_finalize = !(ffz && ffz[0] == '0');
+  const char* prs = getenv("PINOT_GPU_POLL_RESULT");
+  g_engine.poll_result = prs && prs[0] == '1';
+  const char* lsk = getenv("PINOT_GPU_LANE_SKIP");
+  g_engine.lane_skip = !(lsk && lsk[0] == '0');
   const char* pgv = getenv("PINOT_GPU_PLANE_GCD");
   g_engine.plane_gcd = !(pgv && pgv[0] == '0');
   const char* spv = getenv("PINOT_GPU_SCAN_PRIVATE");
@@ -2005,7 +2035,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if (ready) { planes.columns.push_back(ag.column); lw.plane_cols[(size_t)ag.column] = 1; }
     }
   }
-  if (timed) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+  ctx->pre_started = false;      // ev[0] is recorded by the first piece of work that precedes the scan kernel (mark_pre_work)
+  ctx->ev_last = 3;
   if (out && !want_bitmap) lw.stats_plan = fstats::choose_plan(q, &lw.stats_scan_leaves);
   lw.cardinality_only_hint = ng == 0 && out && !want_bitmap && na > 0;
   for (int a = 0; a < na; ++a) lw.cardinality_only_hint = lw.cardinality_only_hint && q->aggregations[a].function == PG_AGG_COUNT;
@@ -2028,7 +2059,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (only_count) {
       unsigned long long* h_card = &ctx->h_partial->count;
       HIP_TRY(hipMemcpyAsync(h_card, lw.d_cardinality, 8, hipMemcpyDeviceToHost, ctx->stream));
-      if (timed) { HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream)); HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream)); HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
+      if (timed) { HIP_TRY(mark_pre_work(ctx)); HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       const int64_t card = (int64_t)*h_card;
       out->num_aggregations = na;
@@ -2117,7 +2148,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       // one histogram per workgroup of 16 wavefronts; as many workgroups per CU as LDS and registers admit
       const int per_word = 32 / hist_cw;
       hist_lds = (((size_t)(seg->cols[(size_t)hist_col].cardinality + per_word - 1) / per_word * 4) + 15) & ~(size_t)15;
-      hist_lds = std::max(hist_lds, sizeof(BlockPartial) * (kHistBlockThreads / 64));      // the reduction records reuse the counters' LDS
+      hist_lds = std::max(hist_lds, sizeof(BlockPartial) * (kHistBlockThreads / 64) + 16);      // the reduction records (+ the fold flag) reuse the counters' LDS
       const size_t per_block = hist_lds + 256;
       int bpc = std::max(1, std::min(waves_scan_hist(hist_cw, hist_guarded) / (kHistBlockThreads / 64), (int)((160 * 1024 - 2048) / per_block)));
       if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
@@ -2175,6 +2206,16 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     sp.filter_entries = nullptr;
     sp.raw64_coalesced = g_engine.raw64_coalesced ? 1 : 0;
     if (count_entries) { st = arm_filter_entries(ctx, &sp.filter_entries); if (st != PG_OK) return st; }
+    // The workgroups' records are folded by the scan kernel's last workgroup, straight into the pinned host record.
+    const bool folded = g_engine.fold_finalize;
+    const unsigned long long seq = ++ctx->seq;
+    sp.done_counter = folded ? ctx->d_done : nullptr;
+    sp.host_out = g_engine.direct_result ? ctx->h_record_dev : nullptr;
+    sp.host_seq = seq;
+    sp.lane_skip = g_engine.lane_skip ? 1 : 0;
+    // HIP events (PG_CFG_TIME_KERNELS): [ev_first, ev_last] brackets the query's device work, [ev[1], ev[2]] the scan kernel.  Each
+    // record is a packet of its own on the queue, so a query that runs nothing but the scan kernel records just the two.
+    const bool post_work = !folded || !g_engine.direct_result || count_entries || want_bitmap;
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
@@ -2185,8 +2226,10 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     else launch_scan_agg(g_engine.use_dma, one, typed, blocks, geo.threads, lds, ctx->stream, sp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-    finalize_partials_kernel<<<dim3(1), dim3(kBlockThreads), 0, ctx->stream>>>(ctx->d_partials, blocks, g_engine.direct_result ? ctx->h_partial_dev : nullptr);
-    HIP_TRY(hipGetLastError());
+    if (!folded) {
+      finalize_partials_kernel<<<dim3(1), dim3(kBlockThreads), 0, ctx->stream>>>(ctx->d_partials, blocks, g_engine.direct_result ? ctx->h_record_dev : nullptr, seq);
+      HIP_TRY(hipGetLastError());
+    }
     if (!g_engine.direct_result) HIP_TRY(hipMemcpyAsync(ctx->h_partial, ctx->d_partials + blocks, sizeof(BlockPartial), hipMemcpyDeviceToHost, ctx->stream));
     if (count_entries) HIP_TRY(hipMemcpyAsync(ctx->h_filter_entries, ctx->d_filter_entries, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (want_bitmap) {
@@ -2198,8 +2241,23 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         if (need) HIP_TRY(hipMemcpyAsync(host_bitmap, ctx->d_bitmaps[0], (size_t)need * 8, hipMemcpyDeviceToHost, ctx->stream));
       }
     }
-    if (timed) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (timed && post_work) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->ev_last = post_work ? 3 : 2;
+    if (g_engine.poll_result && !post_work && !timed) {
+      // nothing follows the kernel on the stream: the record's sequence number is the completion signal
+      volatile unsigned long long* flag = &ctx->h_record->seq;
+      long long spins = 0;
+      while (*flag != seq) {
+        if ((++spins & 0xFFFF) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) {      // finished (or failed) without publishing: fall back to the stream's verdict
+          HIP_TRY(hipStreamSynchronize(ctx->stream));
+          if (*flag != seq) return fail(PG_ERR_INTERNAL, "the scan kernel finished without publishing its record");
+        }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (g_engine.direct_result && ctx->h_record->seq != seq) return fail(PG_ERR_INTERNAL, "the scan kernel's record carries sequence %llu, expected %llu", ctx->h_record->seq, seq);
     const BlockPartial& fp = *ctx->h_partial;
     // plain narrow counters: the counters must add up to the matches (a wrapped counter always leaves the total short)
     const bool hist_wrapped = use_hist && !hist_guarded && hist_cw < 32 && (unsigned long long)fp.sum[1] != fp.count;
@@ -2408,6 +2466,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     gp.scan.tile_list = lw.tile_list;            // read by group_private_kernel only
     gp.scan.tile_count = lw.tile_count;
     gp.scan.filter_entries = nullptr;
+    HIP_TRY(mark_pre_work(ctx));
     init_group_table_kernel<<<dim3((unsigned)std::max<long long>(64, std::min<long long>(product >> 12, (long long)seg->num_cus * 16))), dim3(256), 0, ctx->stream>>>(gp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -2692,10 +2751,17 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   }
   if (timed && out) {
     float ms_all = 0.f, ms_scan = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms_all, ctx->ev[0], ctx->ev[3]));
     HIP_TRY(hipEventElapsedTime(&ms_scan, ctx->ev[1], ctx->ev[2]));
+    if (!ctx->pre_started && ctx->ev_last == 2) ms_all = ms_scan;
+    else HIP_TRY(hipEventElapsedTime(&ms_all, ctx->ev[ctx->pre_started ? 0 : 1], ctx->ev[ctx->ev_last]));
     out->device_ms = ms_all;
     out->dominant_kernel_ms = ms_scan;
+    if (ctx->pre_started && lw.tile_list != nullptr) {
+      // index-led query: when the index phase (index_and_kernel + its finalize) outlasts the scan of the listed tiles, IT is the dominant kernel
+      float ms_index = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms_index, ctx->ev[0], ctx->ev[1]));
+      if (ms_index > ms_scan) { out->dominant_kernel = PG_KERNEL_INDEX_AND; out->dominant_kernel_ms = ms_index; }
+    }
   }
   return PG_OK;
 }

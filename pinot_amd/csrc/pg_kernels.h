@@ -654,6 +654,123 @@ __device__ __forceinline__ void agg_raw_column_typed(const DevAggCol& ac, int nu
   }
 }
 
+// Reduce the per-workgroup partials into partials[num_blocks] (one record).  The order of the double additions is fixed by
+// the grid size, so a given launch geometry always returns the same floating-point sum.
+__device__ __forceinline__ void partial_identity(BlockPartial& acc) {
+  acc.count = 0;
+  acc.flags = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc.cyc[c] = 0;
+#pragma unroll
+  for (int a = 0; a < kMaxAggCols; ++a) {
+    acc.sum[a] = 0; acc.kmin[a] = 0x7FFFFFFF; acc.kmax[a] = (int32_t)0x80000000;
+    acc.fsum[a] = 0.0; acc.kmin64[a] = 0x7FFFFFFFFFFFFFFFll; acc.kmax64[a] = (long long)0x8000000000000000ull;
+  }
+}
+__device__ __forceinline__ void partial_merge(BlockPartial& acc, const BlockPartial& b) {
+  acc.count += b.count;
+  acc.flags |= b.flags;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc.cyc[c] += b.cyc[c];
+#pragma unroll
+  for (int a = 0; a < kMaxAggCols; ++a) {
+    acc.sum[a] += b.sum[a];
+    acc.kmin[a] = b.kmin[a] < acc.kmin[a] ? b.kmin[a] : acc.kmin[a];
+    acc.kmax[a] = b.kmax[a] > acc.kmax[a] ? b.kmax[a] : acc.kmax[a];
+    acc.fsum[a] += b.fsum[a];
+    acc.kmin64[a] = b.kmin64[a] < acc.kmin64[a] ? b.kmin64[a] : acc.kmin64[a];
+    acc.kmax64[a] = b.kmax64[a] > acc.kmax64[a] ? b.kmax64[a] : acc.kmax64[a];
+  }
+}
+
+// Every lane's record folded over the wave (all lanes return the same record).
+__device__ __forceinline__ void partial_wave_reduce(BlockPartial& acc) {
+  acc.count = (unsigned long long)wave_sum_i64((long long)acc.count);
+  acc.flags = __builtin_amdgcn_ballot_w64(acc.flags != 0ull) != 0ull ? 1ull : 0ull;      // single-bit vocabulary (kPartialHistAlarm)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc.cyc[c] = (unsigned long long)wave_sum_i64((long long)acc.cyc[c]);
+#pragma unroll
+  for (int a = 0; a < kMaxAggCols; ++a) {
+    acc.sum[a] = wave_sum_i64(acc.sum[a]);
+    acc.kmin[a] = wave_min_i32(acc.kmin[a]);
+    acc.kmax[a] = wave_max_i32(acc.kmax[a]);
+    acc.fsum[a] = wave_sum_f64(acc.fsum[a]);
+    acc.kmin64[a] = wave_min_i64(acc.kmin64[a]);
+    acc.kmax64[a] = wave_max_i64(acc.kmax64[a]);
+  }
+}
+
+// Fold of `num_records` per-workgroup records by ONE workgroup: thread t takes records t, t + blockDim, ..., then the wave, then the
+// waves through `red` (>= blockDim / 64 records of LDS).  The order of the double additions depends on the launch geometry only.
+// Returns the folded record in thread 0.
+__device__ __forceinline__ BlockPartial fold_partials(const BlockPartial* __restrict__ partials, int num_records, BlockPartial* red) {
+  BlockPartial acc;
+  partial_identity(acc);
+  for (int i = threadIdx.x; i < num_records; i += blockDim.x) partial_merge(acc, partials[i]);
+  partial_wave_reduce(acc);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();                 // `red` may still hold the waves' own records
+  if (lane == 0) red[w] = acc;
+  __syncthreads();
+  BlockPartial t = red[0];
+  if (threadIdx.x == 0)
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) partial_merge(t, red[i]);
+  return t;
+}
+
+__device__ __forceinline__ void store_host_record(HostRecord* host_out, const BlockPartial& t, unsigned long long seq) {
+  host_out->partial = t;
+  __threadfence_system();          // the record before the sequence number
+  __hip_atomic_store(&host_out->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+}
+
+// `host_out`: pinned, device-mapped host memory -- the folded record goes straight to the host, no copy command follows.
+// (The separate launch; the scan kernels fold their records themselves when ScanParams.done_counter is set, see publish_block_partial.)
+static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockPartial* partials, int num_blocks, HostRecord* host_out, unsigned long long seq) {
+  __shared__ BlockPartial red[kBlockThreads / 64];
+  const BlockPartial t = fold_partials(partials, num_blocks, red);
+  if (threadIdx.x == 0) {
+    if (host_out) store_host_record(host_out, t, seq);
+    else partials[num_blocks] = t;
+  }
+}
+
+// The end of every scan kernel: the waves' records are in red[0 .. waves_per_block) (written by each wave's lane 0, __syncthreads()
+// done).  Thread 0 merges them into the workgroup's record.  With ScanParams.done_counter set, the workgroup then ARRIVES on that
+// counter, and the one whose arrival completes it -- every other workgroup's record is published by then -- folds all of them and
+// writes the query's result: what finalize_partials_kernel did in a launch of its own (a dependent kernel boundary of 1.5-2 us,
+// the launch, and 5-10 us of a one-workgroup kernel on an otherwise idle chip -- half the device time of a 10 M-row segment).
+// Inter-workgroup visibility follows MI355X_MICROARCH.md's recipe: producer = plain stores, agent-scope release fence, drained
+// vmcnt, relaxed agent-scope arrive; consumer = the arrive's return value, ONE agent-scope acquire, __syncthreads(), plain loads.
+// `flag` is one dword of LDS the caller provides (scan_hist_kernel keeps its counters as the only static LDS object).
+__device__ __forceinline__ void publish_block_partial(const ScanParams& p, BlockPartial* red, int waves_per_block, uint32_t* flag) {
+  if (threadIdx.x == 0) {
+    BlockPartial acc = red[0];
+    for (int w = 1; w < waves_per_block; ++w) partial_merge(acc, red[w]);
+    p.partials[blockIdx.x] = acc;
+    uint32_t last = 0u;
+    if (p.done_counter != nullptr) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t before = __hip_atomic_fetch_add(p.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (before + 1u == gridDim.x) {
+        last = 1u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  if (*flag == 0u) return;
+  const BlockPartial t = fold_partials(p.partials, (int)gridDim.x, red);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(p.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the context's next launch
+    if (p.host_out) store_host_record(p.host_out, t, p.host_seq);
+    else p.partials[gridDim.x] = t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused scan -> filter -> aggregate.  One wavefront per tile, tiles dealt round-robin over a persistent grid.
 // ------------------------------------------------------------------------------------------------
@@ -802,85 +919,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
   mine.cyc[3] = p.profile ? __builtin_amdgcn_s_memtime() - cyc_start : 0ull;
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    BlockPartial acc = red[0];
-    for (int w = 1; w < waves_per_block; ++w) {
-      acc.count += red[w].count;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc.cyc[c] += red[w].cyc[c];
-#pragma unroll
-      for (int a = 0; a < kMaxAggCols; ++a) {
-        acc.sum[a] += red[w].sum[a];
-        acc.kmin[a] = red[w].kmin[a] < acc.kmin[a] ? red[w].kmin[a] : acc.kmin[a];
-        acc.kmax[a] = red[w].kmax[a] > acc.kmax[a] ? red[w].kmax[a] : acc.kmax[a];
-        if (kTyped) {
-          acc.fsum[a] += red[w].fsum[a];
-          acc.kmin64[a] = red[w].kmin64[a] < acc.kmin64[a] ? red[w].kmin64[a] : acc.kmin64[a];
-          acc.kmax64[a] = red[w].kmax64[a] > acc.kmax64[a] ? red[w].kmax64[a] : acc.kmax64[a];
-        }
-      }
-    }
-    p.partials[blockIdx.x] = acc;
-  }
-}
-
-// Reduce the per-workgroup partials into partials[num_blocks] (one record).  The order of the double additions is fixed by
-// the grid size, so a given launch geometry always returns the same floating-point sum.
-__device__ __forceinline__ void partial_identity(BlockPartial& acc) {
-  acc.count = 0;
-  acc.flags = 0;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) acc.cyc[c] = 0;
-#pragma unroll
-  for (int a = 0; a < kMaxAggCols; ++a) {
-    acc.sum[a] = 0; acc.kmin[a] = 0x7FFFFFFF; acc.kmax[a] = (int32_t)0x80000000;
-    acc.fsum[a] = 0.0; acc.kmin64[a] = 0x7FFFFFFFFFFFFFFFll; acc.kmax64[a] = (long long)0x8000000000000000ull;
-  }
-}
-__device__ __forceinline__ void partial_merge(BlockPartial& acc, const BlockPartial& b) {
-  acc.count += b.count;
-  acc.flags |= b.flags;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) acc.cyc[c] += b.cyc[c];
-#pragma unroll
-  for (int a = 0; a < kMaxAggCols; ++a) {
-    acc.sum[a] += b.sum[a];
-    acc.kmin[a] = b.kmin[a] < acc.kmin[a] ? b.kmin[a] : acc.kmin[a];
-    acc.kmax[a] = b.kmax[a] > acc.kmax[a] ? b.kmax[a] : acc.kmax[a];
-    acc.fsum[a] += b.fsum[a];
-    acc.kmin64[a] = b.kmin64[a] < acc.kmin64[a] ? b.kmin64[a] : acc.kmin64[a];
-    acc.kmax64[a] = b.kmax64[a] > acc.kmax64[a] ? b.kmax64[a] : acc.kmax64[a];
-  }
-}
-
-// `host_out`: pinned, device-mapped host memory -- the folded record goes straight to the host, no copy command follows.
-static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockPartial* partials, int num_blocks, BlockPartial* host_out) {
-  __shared__ BlockPartial red[kBlockThreads / 64];
-  BlockPartial acc;
-  partial_identity(acc);
-  for (int i = threadIdx.x; i < num_blocks; i += blockDim.x) partial_merge(acc, partials[i]);
-  acc.count = (unsigned long long)wave_sum_i64((long long)acc.count);
-  acc.flags = __builtin_amdgcn_ballot_w64(acc.flags != 0ull) != 0ull ? 1ull : 0ull;      // single-bit vocabulary (kPartialHistAlarm)
-#pragma unroll
-  for (int c = 0; c < 4; ++c) acc.cyc[c] = (unsigned long long)wave_sum_i64((long long)acc.cyc[c]);
-#pragma unroll
-  for (int a = 0; a < kMaxAggCols; ++a) {
-    acc.sum[a] = wave_sum_i64(acc.sum[a]);
-    acc.kmin[a] = wave_min_i32(acc.kmin[a]);
-    acc.kmax[a] = wave_max_i32(acc.kmax[a]);
-    acc.fsum[a] = wave_sum_f64(acc.fsum[a]);
-    acc.kmin64[a] = wave_min_i64(acc.kmin64[a]);
-    acc.kmax64[a] = wave_max_i64(acc.kmax64[a]);
-  }
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) red[w] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    BlockPartial t = red[0];
-    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) partial_merge(t, red[i]);
-    if (host_out) { *host_out = t; __threadfence_system(); }
-    else partials[num_blocks] = t;
-  }
+  // (untyped instantiations leave fsum / kmin64 / kmax64 at their identities: merging them is a no-op)
+  publish_block_partial(p, red, waves_per_block, reinterpret_cast<uint32_t*>(red + waves_per_block));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1484,6 +1524,7 @@ __device__ __forceinline__ void agg_private_dispatch(int b, const uint32_t* lane
 template <int kAggSlots>
 __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_kernel(const ScanParams p) {
   __shared__ BlockPartial red[kBlockThreads / 64];
+  __shared__ uint32_t fold_flag;
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
@@ -1536,12 +1577,17 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
     if (p.num_agg_cols == 0 || __builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
     // one instance of the width dispatch for all slots (a runtime loop: unrolling it four times quadruples the code and keeps
     // ~190 VGPRs live); the per-slot accumulators are selected with wave-uniform predicates
+    // A lane whose 32 docs hold no match has nothing to add: its loads are not issued (exec-masked), so at low selectivity the value
+    // column is read at cache-line granularity around the matches instead of in full -- the reference reads only the surviving docs
+    // (SVScanDocIdIterator.java:115-142 feeds ProjectionOperator 10 000 matching docIds at a time).  At 1 % selectivity 27 % of the
+    // lanes hold a match; from ~10 % on every lane does and the branch is never taken differently by two lanes.
+    const bool lane_active = p.lane_skip == 0 || m != 0u;
     for (int a = 0; a < p.num_agg_cols; ++a) {
       const DevAggCol& ac = p.agg_cols[a];
       const uint32_t* words = reinterpret_cast<const uint32_t*>(ac.fwd + tile * (256ll * ac.bits)) + lane * ac.bits;
       uint32_t psum = 0, tmin = 0xFFFFFFFFu, tmax = 0u;
       unsigned long long wsum = 0;
-      agg_private_dispatch(ac.bits, words, m, ac.need_sum != 0, ac.need_minmax != 0, psum, wsum, tmin, tmax);
+      if (lane_active) agg_private_dispatch(ac.bits, words, m, ac.need_sum != 0, ac.need_minmax != 0, psum, wsum, tmin, tmax);
       wsum += psum;
 #pragma unroll
       for (int s = 0; s < kAggSlots; ++s) {
@@ -1567,11 +1613,7 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
   }
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    BlockPartial acc = red[0];
-    for (int w = 1; w < waves_per_block; ++w) partial_merge(acc, red[w]);
-    p.partials[blockIdx.x] = acc;
-  }
+  publish_block_partial(p, red, waves_per_block, &fold_flag);
 }
 
 // One 2048-doc tile.  kMasked: only the docs whose bit is set in the lane's mask `m` reach the table (a filter's result, and /

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const Scan
     if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ac.fwd + tile * (256ll * ac.bits)) + lane * ac.bits;
     uint32_t mx = 0;
-    hist_private_dispatch<CW, kGuard>(ac.bits, words, m, hist, mx, ac.need_minmax != 0, umin, umax);
+    // (a lane without a match loads nothing: see scan_private_kernel)
+    if (p.lane_skip == 0 || m != 0u) hist_private_dispatch<CW, kGuard>(ac.bits, words, m, hist, mx, ac.need_minmax != 0, umin, umax);
     if constexpr (kGuard) {
       constexpr uint32_t G = 1u << (CW - 1);
       alarm |= mx >= G + G / 2 ? 1u : 0u;
@@ -238,11 +239,7 @@ __global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const Scan
   BlockPartial* red = reinterpret_cast<BlockPartial*>(hist);
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    BlockPartial acc = red[0];
-    for (int w = 1; w < waves_per_block; ++w) partial_merge(acc, red[w]);
-    p.partials[blockIdx.x] = acc;
-  }
+  publish_block_partial(p, red, waves_per_block, reinterpret_cast<uint32_t*>(red + waves_per_block));      // (the engine sizes the LDS for it)
 }
 
 }  // namespace pg

@@ -57,7 +57,8 @@ struct NarrowStack {                              // kNarrowStack entries of fou
 };
 
 static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_kernel(const ScanParams p) {
-  __shared__ unsigned long long red[kBlockThreads / 64];
+  __shared__ BlockPartial red[kBlockThreads / 64];
+  __shared__ uint32_t fold_flag;
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
@@ -125,15 +126,12 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_kernel(const
       count += (unsigned)__builtin_popcount(mt);
     }
   }
-  const unsigned long long wave_count = (unsigned long long)wave_sum_i64((long long)count);
-  if (lane == 0) red[wave_in_block] = wave_count;
+  BlockPartial mine;
+  partial_identity(mine);
+  mine.count = (unsigned long long)wave_sum_i64((long long)count);
+  if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    BlockPartial acc;
-    partial_identity(acc);
-    for (int w = 0; w < waves_per_block; ++w) acc.count += red[w];
-    p.partials[blockIdx.x] = acc;
-  }
+  publish_block_partial(p, red, waves_per_block, &fold_flag);
 }
 
 // A single dictId-range leaf (WHERE dim = x, the commonest narrow filter): no mask stack, so EIGHT tiles fit per wave and iteration
@@ -165,7 +163,8 @@ __device__ __forceinline__ unsigned narrow_single_octet(const ScanParams& p, con
 }
 
 static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_single_kernel(const ScanParams p) {
-  __shared__ unsigned long long red[kBlockThreads / 64];
+  __shared__ BlockPartial red[kBlockThreads / 64];
+  __shared__ uint32_t fold_flag;
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
@@ -182,15 +181,12 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_single_kerne
       default: break;
     }
   }
-  const unsigned long long wave_count = (unsigned long long)wave_sum_i64((long long)count);
-  if (lane == 0) red[wave_in_block] = wave_count;
+  BlockPartial mine;
+  partial_identity(mine);
+  mine.count = (unsigned long long)wave_sum_i64((long long)count);
+  if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    BlockPartial acc;
-    partial_identity(acc);
-    for (int w = 0; w < waves_per_block; ++w) acc.count += red[w];
-    p.partials[blockIdx.x] = acc;
-  }
+  publish_block_partial(p, red, waves_per_block, &fold_flag);
 }
 
 }  // namespace pg

@@ -161,6 +161,7 @@ __device__ __forceinline__ void agg_dict64_private(const DevAggCol& ac, long lon
 
 static __global__ __launch_bounds__(kBlockThreads, 4) void scan_private_typed_kernel(const ScanParams p) {
   __shared__ BlockPartial red[kBlockThreads / 64];
+  __shared__ uint32_t fold_flag;
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
@@ -225,11 +226,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void scan_private_typed_ke
   }
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    BlockPartial out = red[0];
-    for (int w = 1; w < waves_per_block; ++w) partial_merge(out, red[w]);
-    p.partials[blockIdx.x] = out;
-  }
+  publish_block_partial(p, red, waves_per_block, &fold_flag);
 }
 
 }  // namespace pg
