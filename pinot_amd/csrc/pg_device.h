@@ -191,9 +191,13 @@ struct ScanParams {
   BlockPartial* partials;          // [gridDim.x] (+ 1: the folded record when host_out is null)
   // "Last block done": the workgroup whose arrival completes `done_counter` folds the per-workgroup records inside the scan kernel
   // itself (publish_block_partial in pg_kernels.h) -- no finalize launch follows.  nullptr: the records are left for finalize_partials_kernel.
-  uint32_t* done_counter;          // [1] device memory, zero between launches (the folding workgroup resets it)
+  uint32_t* done_counter;          // [9 x 32] arrival counters (eight shards + the top one, 128 bytes apart), zero between launches (the folding workgroup resets them)
   struct HostRecord* host_out;     // pinned, device-mapped host record the fold is written to, or nullptr -> partials[gridDim.x]
   unsigned long long host_seq;     // value stored into host_out->seq after the record (the host may poll it instead of synchronising the stream)
+  int32_t fold_slots;              // aggregation slots a fold has to reduce (BlockPartial.sum / kmin / kmax [0 .. fold_slots))
+  int32_t fold_typed;              // 1: fsum / kmin64 / kmax64 are in use (typed kernels)
+  int32_t sparse_lanes;            // lane-private aggregating kernels: a tile in which at most this many lanes hold a match is aggregated by walking
+  int32_t reserved1;               //   the matches (one 8-byte load per matching doc) instead of decoding every lane's 32 values; 0 = never
 };
 
 // What a query's scan brings back to the host: the folded record, then a sequence number written after it.

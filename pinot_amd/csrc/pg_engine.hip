@@ -66,6 +66,7 @@ struct Engine {
   bool fold_finalize = true; // PINOT_GPU_FOLD_FINALIZE=0: the workgroups' records are folded by finalize_partials_kernel, a launch of its own
   bool poll_result = false;  // PINOT_GPU_POLL_RESULT=1: pg_execute spins on the pinned record's sequence number instead of hipStreamSynchronize
   bool lane_skip = true;     // PINOT_GPU_LANE_SKIP=0: the aggregating kernels load a tile's value bytes for every lane, matches or not
+  int sparse_lanes = 24;     // PINOT_GPU_SPARSE_LANES: tiles in which at most this many of the 64 lanes hold a match are aggregated match by match (0 = never)
   bool plane_gcd = true;     // PINOT_GPU_PLANE_GCD=0: planes hold value - min unscaled, never alias the dictId stream
   bool scan_private = true;  // PINOT_GPU_SCAN_PRIVATE=0: always the LDS-staged scan kernel
   bool group_private = true; // PINOT_GPU_GROUP_PRIVATE=0: unfiltered group-by through the LDS-staged kernel
@@ -241,8 +242,8 @@ pg_status acquire_ctx(pg_segment* seg, ExecCtx** out) {
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_record, sizeof(HostRecord), hipHostMallocMapped);
   if (e == hipSuccess) { memset(c->h_record, 0, sizeof(HostRecord)); c->h_partial = &c->h_record->partial; }
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->h_record_dev, c->h_record, 0);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_done, 64);
-  if (e == hipSuccess) e = hipMemset(c->d_done, 0, 64);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_done, 9 * 128);
+  if (e == hipSuccess) e = hipMemset(c->d_done, 0, 9 * 128);
   if (e != hipSuccess) {
     destroy_ctx(c);
     return fail(PG_ERR_DEVICE, "creating execution context failed: %s", hipGetErrorString(e));
@@ -1416,6 +1417,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.poll_result = prs && prs[0] == '1';
   const char* lsk = getenv("PINOT_GPU_LANE_SKIP");
   g_engine.lane_skip = !(lsk && lsk[0] == '0');
+  const char* spl = getenv("PINOT_GPU_SPARSE_LANES");
+  g_engine.sparse_lanes = spl ? std::max(0, std::min(64, atoi(spl))) : 24;
   const char* pgv = getenv("PINOT_GPU_PLANE_GCD");
   g_engine.plane_gcd = !(pgv && pgv[0] == '0');
   const char* spv = getenv("PINOT_GPU_SCAN_PRIVATE");
@@ -2212,10 +2215,14 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     sp.done_counter = folded ? ctx->d_done : nullptr;
     sp.host_out = g_engine.direct_result ? ctx->h_record_dev : nullptr;
     sp.host_seq = seq;
+    // fields a fold reduces: the aggregation slots in use (the histogram kernel keeps its checksum in slot 1), typed extras only for the typed kernels
+    sp.fold_slots = use_hist ? 2 : pl.num_agg_cols;
+    sp.fold_typed = (use_private_typed || (!use_hist && !use_narrow && !use_private && typed)) ? 1 : 0;
     sp.lane_skip = g_engine.lane_skip ? 1 : 0;
+    sp.sparse_lanes = g_engine.sparse_lanes;
     // HIP events (PG_CFG_TIME_KERNELS): [ev_first, ev_last] brackets the query's device work, [ev[1], ev[2]] the scan kernel.  Each
     // record is a packet of its own on the queue, so a query that runs nothing but the scan kernel records just the two.
-    const bool post_work = !folded || !g_engine.direct_result || count_entries || want_bitmap;
+    const bool post_work = !g_engine.direct_result || count_entries || want_bitmap;      // (copy commands behind the kernels)
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
@@ -2227,7 +2234,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     if (!folded) {
-      finalize_partials_kernel<<<dim3(1), dim3(kBlockThreads), 0, ctx->stream>>>(ctx->d_partials, blocks, g_engine.direct_result ? ctx->h_record_dev : nullptr, seq);
+      finalize_partials_kernel<<<dim3(1), dim3(kBlockThreads), 0, ctx->stream>>>(ctx->d_partials, blocks, g_engine.direct_result ? ctx->h_record_dev : nullptr, seq,
+                                                                                  sp.fold_slots, sp.fold_typed, sp.profile);
       HIP_TRY(hipGetLastError());
     }
     if (!g_engine.direct_result) HIP_TRY(hipMemcpyAsync(ctx->h_partial, ctx->d_partials + blocks, sizeof(BlockPartial), hipMemcpyDeviceToHost, ctx->stream));
@@ -2241,8 +2249,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         if (need) HIP_TRY(hipMemcpyAsync(host_bitmap, ctx->d_bitmaps[0], (size_t)need * 8, hipMemcpyDeviceToHost, ctx->stream));
       }
     }
-    if (timed && post_work) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-    ctx->ev_last = post_work ? 3 : 2;
+    if (timed && (post_work || !folded)) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->ev_last = (post_work || !folded) ? 3 : 2;
     if (g_engine.poll_result && !post_work && !timed) {
       // nothing follows the kernel on the stream: the record's sequence number is the completion signal
       volatile unsigned long long* flag = &ctx->h_record->seq;

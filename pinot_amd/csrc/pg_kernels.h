@@ -683,31 +683,62 @@ __device__ __forceinline__ void partial_merge(BlockPartial& acc, const BlockPart
   }
 }
 
+// What a fold has to look at: `slots` aggregation slots (BlockPartial.sum / kmin / kmax [0 .. slots)), the typed fields (fsum / kmin64 /
+// kmax64) and the PG_CFG_PROFILE_WAVES cycle counters only when the query uses them.  A record has thirty 64-bit-reduced fields; a
+// COUNT / one-column SUM needs five of them, and the wave-level reductions are what a one-workgroup fold spends its time on.
+struct FoldFields { int slots; bool typed; bool cycles; };
+__device__ __forceinline__ FoldFields fold_fields_of(const ScanParams& p) { return FoldFields{p.fold_slots, p.fold_typed != 0, p.profile != 0}; }
+
 // Every lane's record folded over the wave (all lanes return the same record).
-__device__ __forceinline__ void partial_wave_reduce(BlockPartial& acc) {
+__device__ __forceinline__ void partial_wave_reduce(BlockPartial& acc, const FoldFields ff) {
   acc.count = (unsigned long long)wave_sum_i64((long long)acc.count);
   acc.flags = __builtin_amdgcn_ballot_w64(acc.flags != 0ull) != 0ull ? 1ull : 0ull;      // single-bit vocabulary (kPartialHistAlarm)
+  if (ff.cycles) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c) acc.cyc[c] = (unsigned long long)wave_sum_i64((long long)acc.cyc[c]);
+    for (int c = 0; c < 4; ++c) acc.cyc[c] = (unsigned long long)wave_sum_i64((long long)acc.cyc[c]);
+  }
 #pragma unroll
   for (int a = 0; a < kMaxAggCols; ++a) {
+    if (a >= ff.slots) continue;
     acc.sum[a] = wave_sum_i64(acc.sum[a]);
     acc.kmin[a] = wave_min_i32(acc.kmin[a]);
     acc.kmax[a] = wave_max_i32(acc.kmax[a]);
-    acc.fsum[a] = wave_sum_f64(acc.fsum[a]);
-    acc.kmin64[a] = wave_min_i64(acc.kmin64[a]);
-    acc.kmax64[a] = wave_max_i64(acc.kmax64[a]);
+    if (ff.typed) {
+      acc.fsum[a] = wave_sum_f64(acc.fsum[a]);
+      acc.kmin64[a] = wave_min_i64(acc.kmin64[a]);
+      acc.kmax64[a] = wave_max_i64(acc.kmax64[a]);
+    }
   }
 }
 
 // Fold of `num_records` per-workgroup records by ONE workgroup: thread t takes records t, t + blockDim, ..., then the wave, then the
 // waves through `red` (>= blockDim / 64 records of LDS).  The order of the double additions depends on the launch geometry only.
-// Returns the folded record in thread 0.
-__device__ __forceinline__ BlockPartial fold_partials(const BlockPartial* __restrict__ partials, int num_records, BlockPartial* red) {
+// Returns the folded record in thread 0.  (Fields outside `ff` keep their identities.)
+__device__ __forceinline__ BlockPartial fold_partials(const BlockPartial* partials, int num_records, BlockPartial* red, const FoldFields ff) {
   BlockPartial acc;
   partial_identity(acc);
-  for (int i = threadIdx.x; i < num_records; i += blockDim.x) partial_merge(acc, partials[i]);
-  partial_wave_reduce(acc);
+  for (int i = threadIdx.x; i < num_records; i += blockDim.x) {
+    const BlockPartial& b = partials[i];
+    acc.count += b.count;
+    acc.flags |= b.flags;
+    if (ff.cycles) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc.cyc[c] += b.cyc[c];
+    }
+#pragma unroll
+    for (int a = 0; a < kMaxAggCols; ++a) {
+      if (a >= ff.slots) continue;
+      acc.sum[a] += b.sum[a];
+      acc.kmin[a] = b.kmin[a] < acc.kmin[a] ? b.kmin[a] : acc.kmin[a];
+      acc.kmax[a] = b.kmax[a] > acc.kmax[a] ? b.kmax[a] : acc.kmax[a];
+      if (ff.typed) {
+        acc.fsum[a] += b.fsum[a];
+        acc.kmin64[a] = b.kmin64[a] < acc.kmin64[a] ? b.kmin64[a] : acc.kmin64[a];
+        acc.kmax64[a] = b.kmax64[a] > acc.kmax64[a] ? b.kmax64[a] : acc.kmax64[a];
+      }
+    }
+  }
+  partial_wave_reduce(acc, ff);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   __syncthreads();                 // `red` may still hold the waves' own records
   if (lane == 0) red[w] = acc;
@@ -727,9 +758,10 @@ __device__ __forceinline__ void store_host_record(HostRecord* host_out, const Bl
 
 // `host_out`: pinned, device-mapped host memory -- the folded record goes straight to the host, no copy command follows.
 // (The separate launch; the scan kernels fold their records themselves when ScanParams.done_counter is set, see publish_block_partial.)
-static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockPartial* partials, int num_blocks, HostRecord* host_out, unsigned long long seq) {
+static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockPartial* partials, int num_blocks, HostRecord* host_out, unsigned long long seq,
+                                                                                 int slots, int typed, int cycles) {
   __shared__ BlockPartial red[kBlockThreads / 64];
-  const BlockPartial t = fold_partials(partials, num_blocks, red);
+  const BlockPartial t = fold_partials(partials, num_blocks, red, FoldFields{slots, typed != 0, cycles != 0});
   if (threadIdx.x == 0) {
     if (host_out) store_host_record(host_out, t, seq);
     else partials[num_blocks] = t;
@@ -737,35 +769,48 @@ static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel
 }
 
 // The end of every scan kernel: the waves' records are in red[0 .. waves_per_block) (written by each wave's lane 0, __syncthreads()
-// done).  Thread 0 merges them into the workgroup's record.  With ScanParams.done_counter set, the workgroup then ARRIVES on that
-// counter, and the one whose arrival completes it -- every other workgroup's record is published by then -- folds all of them and
-// writes the query's result: what finalize_partials_kernel did in a launch of its own (a dependent kernel boundary of 1.5-2 us,
-// the launch, and 5-10 us of a one-workgroup kernel on an otherwise idle chip -- half the device time of a 10 M-row segment).
-// Inter-workgroup visibility follows MI355X_MICROARCH.md's recipe: producer = plain stores, agent-scope release fence, drained
-// vmcnt, relaxed agent-scope arrive; consumer = the arrive's return value, ONE agent-scope acquire, __syncthreads(), plain loads.
-// `flag` is one dword of LDS the caller provides (scan_hist_kernel keeps its counters as the only static LDS object).
+// done).  Thread 0 merges them into the workgroup's record.  With ScanParams.done_counter set, the workgroup then ARRIVES, and the
+// one whose arrival completes the count -- every other workgroup's record is in memory by then -- folds all of them and writes the
+// query's result: what finalize_partials_kernel does in a launch of its own (a dependent kernel boundary, the launch, and a
+// one-workgroup kernel on an otherwise idle chip -- half the device time of a 10 M-row segment).
+// Inter-workgroup visibility is MI355X_MICROARCH.md's R1 form: the record is stored WRITE-THROUGH (8-byte agent-scope stores = sc1: they
+// reach memory, no L2 write-back -- a release fence per workgroup was measured at +30 us on a 1024-workgroup grid, 128 L2 write-backs
+// queueing per XCD), the writing lane drains vmcnt, arrives with a relaxed agent-scope atomic; the consumer takes ONE agent-scope
+// acquire after seeing the count complete, __syncthreads(), then plain loads.  Arrivals are sharded over eight counters (blockIdx & 7,
+// 128 bytes apart) so that a grid finishing at once does not serialise 1024 atomics on one word; the workgroup completing a shard
+// arrives on the ninth.  `flag` is one dword of LDS the caller provides (scan_hist_kernel keeps its counters as the only static LDS object).
+constexpr int kFoldShards = 8, kFoldStride = 32;      // counters are kFoldStride dwords apart; kFoldShards * kFoldStride is the top counter
 __device__ __forceinline__ void publish_block_partial(const ScanParams& p, BlockPartial* red, int waves_per_block, uint32_t* flag) {
   if (threadIdx.x == 0) {
     BlockPartial acc = red[0];
     for (int w = 1; w < waves_per_block; ++w) partial_merge(acc, red[w]);
-    p.partials[blockIdx.x] = acc;
     uint32_t last = 0u;
-    if (p.done_counter != nullptr) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (p.done_counter == nullptr) {
+      p.partials[blockIdx.x] = acc;
+    } else {
+      static_assert(sizeof(BlockPartial) % 8 == 0, "stored as 8-byte words");
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&acc);
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(&p.partials[blockIdx.x]);
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(BlockPartial) / 8); ++i) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const uint32_t before = __hip_atomic_fetch_add(p.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (before + 1u == gridDim.x) {
-        last = 1u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const uint32_t shard = blockIdx.x & (kFoldShards - 1);
+      const uint32_t in_shard = (gridDim.x + (kFoldShards - 1) - shard) / kFoldShards;          // workgroups b with (b & 7) == shard
+      const uint32_t shards = gridDim.x < (uint32_t)kFoldShards ? gridDim.x : (uint32_t)kFoldShards;
+      if (__hip_atomic_fetch_add(p.done_counter + shard * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_shard) {
+        if (__hip_atomic_fetch_add(p.done_counter + kFoldShards * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == shards) {
+          last = 1u;
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
       }
     }
     *flag = last;
   }
   __syncthreads();
   if (*flag == 0u) return;
-  const BlockPartial t = fold_partials(p.partials, (int)gridDim.x, red);
+  const BlockPartial t = fold_partials(p.partials, (int)gridDim.x, red, fold_fields_of(p));
   if (threadIdx.x == 0) {
-    __hip_atomic_store(p.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the context's next launch
+    for (int c = 0; c <= kFoldShards; ++c) __hip_atomic_store(p.done_counter + c * kFoldStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the context's next launch
     if (p.host_out) store_host_record(p.host_out, t, p.host_seq);
     else p.partials[gridDim.x] = t;
   }
@@ -1518,6 +1563,44 @@ __device__ __forceinline__ void agg_private_dispatch(int b, const uint32_t* lane
   }
 }
 
+// Sparse aggregation of a tile: the lane walks the set bits of its mask and reads each matching doc's value with ONE 8-byte load at
+// the doc's bit position (two dwords of the big-endian stream always hold a value of at most 31 bits; the second dword may be the next
+// lane's first, or the buffer's padding).  Four matches per lane are in flight per round; the rounds repeat while any lane has matches
+// left (wave-uniform).  At 1 % selectivity a lane holds 0.32 matches on average: one round of <= 64 sector-sized reads replaces the
+// 17-dword chunk load and the 32-value decode of every lane that holds a match -- the value column is touched one 64-byte sector per
+// matching doc (SURVEY.md 8(d)'s min(B(v), M x 64 B)), the way the reference's projection reads only the docIds its filter left
+// (SVScanDocIdIterator.java:115-142 -> ProjectionOperator).
+struct __attribute__((aligned(4))) Dwords2 { uint32_t x, y; };
+__device__ __forceinline__ void agg_sparse_private(const uint32_t* __restrict__ lane_words, int b, uint32_t m, bool need_sum, bool need_minmax,
+                                                   unsigned long long& wsum, uint32_t& umin, uint32_t& umax) {
+  const uint32_t field_mask = (1u << b) - 1u;
+  uint32_t rest = m;
+  while (__builtin_amdgcn_ballot_w64(rest != 0u) != 0ull) {
+    Dwords2 d[4];
+    uint32_t sh[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ok[k] = rest != 0u;
+      const uint32_t j = ok[k] ? (uint32_t)__builtin_ctz(rest) : 0u;
+      rest &= rest - 1u;                                   // (0 stays 0)
+      const uint32_t bit = j * (uint32_t)b;
+      sh[k] = 64u - (bit & 31u) - (uint32_t)b;
+      d[k].x = 0u; d[k].y = 0u;
+      if (ok[k]) d[k] = *reinterpret_cast<const Dwords2*>(lane_words + (bit >> 5));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long x = ((unsigned long long)__builtin_bswap32(d[k].x) << 32) | (unsigned long long)__builtin_bswap32(d[k].y);
+      const uint32_t v = (uint32_t)(x >> sh[k]) & field_mask;
+      if (ok[k]) {
+        if (need_sum) wsum += v;
+        if (need_minmax) { umax = v > umax ? v : umax; umin = v < umin ? v : umin; }
+      }
+    }
+  }
+}
+
 #ifndef PG_PRIVATE_WAVES
 #define PG_PRIVATE_WAVES 4      // wavefronts per SIMD the register allocation must allow; 5 and 6 spill in the hot path (measured)
 #endif
@@ -1582,12 +1665,15 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
     // (SVScanDocIdIterator.java:115-142 feeds ProjectionOperator 10 000 matching docIds at a time).  At 1 % selectivity 27 % of the
     // lanes hold a match; from ~10 % on every lane does and the branch is never taken differently by two lanes.
     const bool lane_active = p.lane_skip == 0 || m != 0u;
+    // few lanes of the tile hold a match: walk the matches instead of decoding whole chunks (agg_sparse_private)
+    const bool sparse_tile = __builtin_popcountll(__builtin_amdgcn_ballot_w64(m != 0u)) <= p.sparse_lanes;
     for (int a = 0; a < p.num_agg_cols; ++a) {
       const DevAggCol& ac = p.agg_cols[a];
       const uint32_t* words = reinterpret_cast<const uint32_t*>(ac.fwd + tile * (256ll * ac.bits)) + lane * ac.bits;
       uint32_t psum = 0, tmin = 0xFFFFFFFFu, tmax = 0u;
       unsigned long long wsum = 0;
-      if (lane_active) agg_private_dispatch(ac.bits, words, m, ac.need_sum != 0, ac.need_minmax != 0, psum, wsum, tmin, tmax);
+      if (sparse_tile) agg_sparse_private(words, ac.bits, m, ac.need_sum != 0, ac.need_minmax != 0, wsum, tmin, tmax);
+      else if (lane_active) agg_private_dispatch(ac.bits, words, m, ac.need_sum != 0, ac.need_minmax != 0, psum, wsum, tmin, tmax);
       wsum += psum;
 #pragma unroll
       for (int s = 0; s < kAggSlots; ++s) {

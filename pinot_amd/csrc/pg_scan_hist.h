@@ -197,6 +197,36 @@ __global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const Scan
     if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ac.fwd + tile * (256ll * ac.bits)) + lane * ac.bits;
     uint32_t mx = 0;
+    if (!kGuard && __builtin_popcountll(__builtin_amdgcn_ballot_w64(m != 0u)) <= p.sparse_lanes) {
+      // few lanes of the tile hold a match: walk the matches, one 8-byte load and one counter add per matching doc (agg_sparse_private)
+      const uint32_t field_mask = (1u << ac.bits) - 1u;
+      uint32_t rest = m;
+      while (__builtin_amdgcn_ballot_w64(rest != 0u) != 0ull) {
+        Dwords2 d[4];
+        uint32_t sh[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ok[k] = rest != 0u;
+          const uint32_t j = ok[k] ? (uint32_t)__builtin_ctz(rest) : 0u;
+          rest &= rest - 1u;
+          const uint32_t bit = j * (uint32_t)ac.bits;
+          sh[k] = 64u - (bit & 31u) - (uint32_t)ac.bits;
+          d[k].x = 0u; d[k].y = 0u;
+          if (ok[k]) d[k] = *reinterpret_cast<const Dwords2*>(words + (bit >> 5));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned long long x = ((unsigned long long)__builtin_bswap32(d[k].x) << 32) | (unsigned long long)__builtin_bswap32(d[k].y);
+          const uint32_t v = (uint32_t)(x >> sh[k]) & field_mask;
+          if (ok[k]) {
+            __hip_atomic_fetch_add(hist + HistField<CW>::word(v), 1u << HistField<CW>::shift(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ac.need_minmax) { umax = v > umax ? v : umax; umin = v < umin ? v : umin; }
+          }
+        }
+      }
+      continue;
+    }
     // (a lane without a match loads nothing: see scan_private_kernel)
     if (p.lane_skip == 0 || m != 0u) hist_private_dispatch<CW, kGuard>(ac.bits, words, m, hist, mx, ac.need_minmax != 0, umin, umax);
     if constexpr (kGuard) {

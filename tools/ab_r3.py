@@ -22,8 +22,13 @@ SETTINGS = {
     "default": {},
     "fold0": {"PINOT_GPU_FOLD_FINALIZE": "0"},
     "poll1": {"PINOT_GPU_POLL_RESULT": "1"},
-    "laneskip0": {"PINOT_GPU_LANE_SKIP": "0"},
-    "fold0_laneskip0": {"PINOT_GPU_FOLD_FINALIZE": "0", "PINOT_GPU_LANE_SKIP": "0"},
+    "fold0_poll1": {"PINOT_GPU_FOLD_FINALIZE": "0", "PINOT_GPU_POLL_RESULT": "1"},
+    "laneskip0": {"PINOT_GPU_LANE_SKIP": "0", "PINOT_GPU_SPARSE_LANES": "0"},
+    "sparse0": {"PINOT_GPU_SPARSE_LANES": "0"},
+    "sparse12": {"PINOT_GPU_SPARSE_LANES": "12"},
+    "sparse32": {"PINOT_GPU_SPARSE_LANES": "32"},
+    "sparse48": {"PINOT_GPU_SPARSE_LANES": "48"},
+    "sparse64": {"PINOT_GPU_SPARSE_LANES": "64"},
 }
 KNOBS = sorted({k for s in SETTINGS.values() for k in s})
 
@@ -70,6 +75,7 @@ def main():
     fl = lambda t: Q.leaf(Q.Pred.dict_range(1, 0, t))
     queries = [
         ("C2b-10pct", seg, Q.QuerySpec([(Q.SUM, 0)], filter=fl(100))),
+        ("C2b-3pct", seg, Q.QuerySpec([(Q.SUM, 0)], filter=fl(30))),
         ("C2b-1pct", seg, Q.QuerySpec([(Q.SUM, 0)], filter=fl(10))),
         ("C2b-0.1pct", seg, Q.QuerySpec([(Q.SUM, 0)], filter=fl(1))),
         ("C2b-irr-10pct", seg, Q.QuerySpec([(Q.SUM, 2)], filter=fl(100))),
