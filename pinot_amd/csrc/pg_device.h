@@ -78,6 +78,7 @@ struct DevLeaf {
 
 constexpr int32_t kNodeCountEntries = 2; // scan leaf on the root AND chain behind an index-based child: ScanBasedDocIdIterator.applyAnd looks at every doc still standing
 constexpr int kNarrowTiles = 4, kNarrowMaxBits = 8, kNarrowStack = 4, kNarrowSingleTiles = 8;      // scan_narrow_kernel / scan_narrow_single_kernel (pg_scan_narrow.h)
+constexpr int32_t kNodeLeapfrog2 = 4;    // the root AND of exactly two scan leaves: its two masks also drive the leap-frog entry count (leapfrog2_tile)
 constexpr int32_t kNodeExitIfZero = 1;   // root AND chain: the tile is finished (mask 0) if the running result is wave-zero
 
 // Host-side plan node (DevColumn / DevLeaf / PlanNode are what the engine reasons with).
@@ -198,6 +199,7 @@ struct ScanParams {
   int32_t fold_typed;              // 1: fsum / kmin64 / kmax64 are in use (typed kernels)
   int32_t sparse_lanes;            // lane-private aggregating kernels: a tile in which at most this many lanes hold a match is aggregated by walking
   int32_t reserved1;               //   the matches (one 8-byte load per matching doc) instead of decoding every lane's 32 values; 0 = never
+  uint32_t* leap_tables;           // [tiles] kNodeLeapfrog2: one packed summary per 2048-doc tile (leapfrog2_tile), chained by leapfrog2_chain_kernel
 };
 
 // What a query's scan brings back to the host: the folded record, then a sequence number written after it.

@@ -63,10 +63,11 @@ struct Engine {
   int tile_steps = 0;        // 0 auto, 16 or 32 forced (PINOT_GPU_TILE_STEPS)
   bool double_buffer = false;
   bool direct_result = true; // PINOT_GPU_DIRECT_RESULT=0: the folded partial is copied device -> host with a copy command
-  bool fold_finalize = true; // PINOT_GPU_FOLD_FINALIZE=0: the workgroups' records are folded by finalize_partials_kernel, a launch of its own
-  bool poll_result = false;  // PINOT_GPU_POLL_RESULT=1: pg_execute spins on the pinned record's sequence number instead of hipStreamSynchronize
+  int fold_finalize = -1;    // PINOT_GPU_FOLD_FINALIZE: 1 the scan kernel's last workgroup folds the workgroups' records itself, 0 finalize_partials_kernel
+                             // does in a launch of its own, -1 (default) fold on segments of at most kFoldMaxTiles tiles
+  bool poll_result = true;   // PINOT_GPU_POLL_RESULT=0: pg_execute always waits with hipStreamSynchronize instead of spinning on the pinned record's sequence number
   bool lane_skip = true;     // PINOT_GPU_LANE_SKIP=0: the aggregating kernels load a tile's value bytes for every lane, matches or not
-  int sparse_lanes = 24;     // PINOT_GPU_SPARSE_LANES: tiles in which at most this many of the 64 lanes hold a match are aggregated match by match (0 = never)
+  int sparse_lanes = 32;     // PINOT_GPU_SPARSE_LANES: tiles in which at most this many of the 64 lanes hold a match are aggregated match by match (0 = never)
   bool plane_gcd = true;     // PINOT_GPU_PLANE_GCD=0: planes hold value - min unscaled, never alias the dictId stream
   bool scan_private = true;  // PINOT_GPU_SCAN_PRIVATE=0: always the LDS-staged scan kernel
   bool group_private = true; // PINOT_GPU_GROUP_PRIVATE=0: unfiltered group-by through the LDS-staged kernel
@@ -174,6 +175,8 @@ struct ExecCtx {
   size_t h_groups_capacity = 0;
   unsigned long long* d_filter_entries = nullptr;   // kNodeCountEntries leaves: numEntriesScannedInFilter counted by the lane-private kernels
   unsigned long long* h_filter_entries = nullptr;   // pinned copy
+  uint32_t* d_leap_tables = nullptr;            // kNodeLeapfrog2: one summary per 2048-doc tile (leapfrog2_tile), chained by leapfrog2_chain_kernel
+  size_t leap_capacity = 0;
   WindowInfo* d_window_info = nullptr;          // index_and_kernel: {tile mask, matching docs} of every 65 536-doc window
   size_t tile_list_capacity = 0, window_info_capacity = 0;
 };
@@ -221,6 +224,7 @@ void destroy_ctx(ExecCtx* c) {
   if (c->d_arena) (void)hipFree(c->d_arena);
   if (c->h_groups) (void)hipHostFree(c->h_groups);
   if (c->d_filter_entries) (void)hipFree(c->d_filter_entries);
+  if (c->d_leap_tables) (void)hipFree(c->d_leap_tables);
   if (c->h_filter_entries) (void)hipHostFree(c->h_filter_entries);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -298,6 +302,7 @@ pg_status ensure_set(ExecCtx* c, size_t index, size_t bytes) {
   return PG_OK;
 }
 
+constexpr long long kFoldMaxTiles = 65536;        // segments up to 128 Mi docs fold their records in the scan kernel (ExecCtx::d_done)
 constexpr int kMaxGroupSlots = 0x7FFFFFFF;        // raw keys are ints: the reference's ArrayBasedHolder + IntMapBasedHolder range (DictionaryBasedGroupKeyGenerator.java:164-184)
 constexpr size_t kGroupTableKeepBytes = 1ull << 31; // a direct-indexed table above this is freed after the query instead of staying with the context
 constexpr size_t kArenaKeepBytes = 1ull << 30;      // same for the scratch arena
@@ -765,6 +770,7 @@ struct Lowered {
   fstats::Plan stats_plan = fstats::Plan::kZero;
   int stats_scan_leaves = 0;
   bool stats_chain_flagged = false;            // the chain's scan leaves carry kNodeCountEntries
+  bool stats_leap2_flagged = false;            // the root AND of two scan leaves carries kNodeLeapfrog2
   bool cardinality_only_hint = false;          // in: the query is COUNT(*) only, so an index-only filter needs neither bitmap nor tile list
 };
 
@@ -904,6 +910,21 @@ pg_status arm_filter_entries(ExecCtx* ctx, unsigned long long** out_counter) {
 }
 
 // Zeros in every tile index_and_kernel did not store: for the kernels that read the whole bitmap instead of the tile list.
+// kNodeLeapfrog2: the per-tile summaries and the counter leapfrog2_chain_kernel leaves the extra entries in
+pg_status arm_leap_tables(const pg_segment* seg, ExecCtx* ctx, uint32_t** out_tables) {
+  const size_t tiles = (size_t)std::max(seg->num_tiles, 1);
+  if (ctx->leap_capacity < tiles) {
+    if (ctx->d_leap_tables) (void)hipFree(ctx->d_leap_tables);
+    ctx->d_leap_tables = nullptr; ctx->leap_capacity = 0;
+    HIP_TRY(hipMalloc((void**)&ctx->d_leap_tables, tiles * 4));
+    ctx->leap_capacity = tiles;
+  }
+  if (!ctx->d_filter_entries) HIP_TRY(hipMalloc((void**)&ctx->d_filter_entries, 8));
+  if (!ctx->h_filter_entries) HIP_TRY(hipHostMalloc((void**)&ctx->h_filter_entries, 8, hipHostMallocDefault));
+  *out_tables = ctx->d_leap_tables;
+  return PG_OK;
+}
+
 pg_status complete_index_and_bitmap(Lowered* lw, ExecCtx* ctx) {
   if (!lw->and_bitmap) return PG_OK;
   HIP_TRY(mark_pre_work(ctx));
@@ -964,6 +985,12 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
     dn.leaf = -1;
     dn.num_children = fn.num_children;
     dn.flags = seq[(size_t)n].flags;
+    if (lw->stats_plan == fstats::Plan::kLeap2) {
+      // `a AND b`, two scan leaves: both masks of EVERY tile feed the leap-frog entry count, so no leaf may end a tile early
+      // (whichever leaf is scanning when a tile is entered keeps looking at its docs even where the other one matches nothing)
+      if (fn.op == PG_FILTER_LEAF) dn.flags &= ~kNodeExitIfZero;
+      else if (fn.op == PG_FILTER_AND && n == (int)seq.size() - 1 && seq.size() == 3) { dn.flags |= kNodeLeapfrog2; lw->stats_leap2_flagged = true; }
+    }
     if (lw->stats_plan == fstats::Plan::kChain && fn.op == PG_FILTER_LEAF && seq[(size_t)n].src >= 0 && fn.predicate >= 0 && fn.predicate < q->num_predicates &&
         fstats::classify(q->predicates[fn.predicate]) == fstats::LeafClass::kScan && n > 0) {
       // a scan-based child of the root AND, behind the index-based ones: ScanBasedDocIdIterator.applyAnd looks at every doc still standing
@@ -1412,13 +1439,13 @@ pg_status pg_init(const pg_config* config) {
   const char* drv = getenv("PINOT_GPU_DIRECT_RESULT");
   g_engine.direct_result = !(drv && drv[0] == '0');
   const char* ffz = getenv("PINOT_GPU_FOLD_FINALIZE");
-  g_engine.fold_finalize = !(ffz && ffz[0] == '0');
+  g_engine.fold_finalize = ffz ? (ffz[0] == '0' ? 0 : 1) : -1;
   const char* prs = getenv("PINOT_GPU_POLL_RESULT");
-  g_engine.poll_result = prs && prs[0] == '1';
+  g_engine.poll_result = !(prs && prs[0] == '0');
   const char* lsk = getenv("PINOT_GPU_LANE_SKIP");
   g_engine.lane_skip = !(lsk && lsk[0] == '0');
   const char* spl = getenv("PINOT_GPU_SPARSE_LANES");
-  g_engine.sparse_lanes = spl ? std::max(0, std::min(64, atoi(spl))) : 24;
+  g_engine.sparse_lanes = spl ? std::max(0, std::min(64, atoi(spl))) : 32;
   const char* pgv = getenv("PINOT_GPU_PLANE_GCD");
   g_engine.plane_gcd = !(pgv && pgv[0] == '0');
   const char* spv = getenv("PINOT_GPU_SCAN_PRIVATE");
@@ -1924,6 +1951,10 @@ static void finish_filter_stats(const Lowered& lw, const pg_segment* seg, const 
   switch (lw.stats_plan) {
     case fstats::Plan::kZero: out->stats.num_entries_scanned_in_filter = 0; out->filter_entries_exact = 1; break;
     case fstats::Plan::kPerLeaf: out->stats.num_entries_scanned_in_filter = upper_bound; out->filter_entries_exact = 1; break;
+    case fstats::Plan::kLeap2:
+      // one entry per doc for whichever leaf is scanning there, plus the device's count of the docs where the other leaf was asked
+      if (counted) { out->stats.num_entries_scanned_in_filter = (int64_t)seg->num_docs + (int64_t)*ctx->h_filter_entries; out->filter_entries_exact = 1; break; }
+      out->stats.num_entries_scanned_in_filter = upper_bound; out->filter_entries_exact = 0; break;
     case fstats::Plan::kChain:
       if (counted) { out->stats.num_entries_scanned_in_filter = (int64_t)*ctx->h_filter_entries; out->filter_entries_exact = 1; break; }
       [[fallthrough]];                                                            // an LDS-staged kernel ran: replayed by pg_execute
@@ -2171,7 +2202,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       geo.threads = kBlockThreads;
     } else if ((size_t)sp.wave_lds_bytes > kLdsBudget) return fail(PG_ERR_UNSUPPORTED, "query needs %d bytes of LDS per wavefront", sp.wave_lds_bytes);
     // Nothing but a filter over narrow dictionary columns (COUNT(*) and / or the bitmap): scan_narrow_kernel, four tiles per wave and iteration
-    bool use_narrow = g_engine.scan_narrow && use_private && !use_hist && pl.num_agg_cols == 0 && lw.tile_list == nullptr && sp.num_nodes > 0;
+    // (a leap-frogging `a AND b` is counted by eval_filter_private's hook: the narrow kernels have their own evaluator and do not carry it)
+    bool use_narrow = g_engine.scan_narrow && use_private && !use_hist && pl.num_agg_cols == 0 && lw.tile_list == nullptr && sp.num_nodes > 0 && !(out && lw.stats_leap2_flagged);
     if (use_narrow) {
       int depth = 0, max_depth = 0;
       for (int n = 0; n < sp.num_nodes && use_narrow; ++n) {
@@ -2205,12 +2237,19 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
     if (!want_bitmap && (use_hist || use_private || use_private_typed)) { sp.tile_list = lw.tile_list; sp.tile_count = lw.tile_count; }
     else { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
-    const bool count_entries = out && lw.stats_chain_flagged && (use_hist || use_private || use_private_typed);
+    const bool count_leap2 = out && lw.stats_leap2_flagged && !use_narrow && (use_hist || use_private || use_private_typed);
+    const bool count_entries = (out && lw.stats_chain_flagged && (use_hist || use_private || use_private_typed)) || count_leap2;
     sp.filter_entries = nullptr;
+    sp.leap_tables = nullptr;
+    if (count_leap2) { st = arm_leap_tables(seg, ctx, &sp.leap_tables); if (st != PG_OK) return st; }
+    else if (lw.stats_leap2_flagged) for (int n = 0; n < sp.num_nodes; ++n) sp.nodes[n].flags &= ~kNodeLeapfrog2;      // a kernel without the count runs this query
     sp.raw64_coalesced = g_engine.raw64_coalesced ? 1 : 0;
-    if (count_entries) { st = arm_filter_entries(ctx, &sp.filter_entries); if (st != PG_OK) return st; }
+    if (count_entries && !count_leap2) { st = arm_filter_entries(ctx, &sp.filter_entries); if (st != PG_OK) return st; }
     // The workgroups' records are folded by the scan kernel's last workgroup, straight into the pinned host record.
-    const bool folded = g_engine.fold_finalize;
+    // Measured (profiles/r3, tools/ab_r3.py): the fold costs the kernel 5.5 us of tail on a 1024-workgroup grid where the finalize launch
+    // costs 8.8 us (boundary + a one-workgroup kernel); at 10 M rows that is 13 % of the query's device time, at 1 B rows nothing -- there
+    // the scan kernel is left alone, so that its HIP-event / rocprofv3 duration is the scan and nothing else.
+    const bool folded = g_engine.fold_finalize >= 0 ? g_engine.fold_finalize != 0 : ((long long)seg->num_docs + 2047) / 2048 <= kFoldMaxTiles;
     const unsigned long long seq = ++ctx->seq;
     sp.done_counter = folded ? ctx->d_done : nullptr;
     sp.host_out = g_engine.direct_result ? ctx->h_record_dev : nullptr;
@@ -2239,6 +2278,11 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       HIP_TRY(hipGetLastError());
     }
     if (!g_engine.direct_result) HIP_TRY(hipMemcpyAsync(ctx->h_partial, ctx->d_partials + blocks, sizeof(BlockPartial), hipMemcpyDeviceToHost, ctx->stream));
+    if (count_leap2) {
+      // the tiles' summaries chained in tile order: one small workgroup behind the scan kernel
+      leapfrog2_chain_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(sp.leap_tables, ((long long)seg->num_docs + 2047) / 2048, ctx->d_filter_entries);
+      HIP_TRY(hipGetLastError());
+    }
     if (count_entries) HIP_TRY(hipMemcpyAsync(ctx->h_filter_entries, ctx->d_filter_entries, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (want_bitmap) {
       const int64_t need = ((int64_t)seg->num_docs + 63) / 64;
@@ -2486,8 +2530,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const bool use_partition = !typed_direct && map_based && g_engine.group_partition && g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap &&
                                gp.num_group_aggs <= kMaxPartitionAggs && num_partitions <= kMaxPartitions && (long long)seg->num_docs >= g_engine.partition_min_docs;
     if (use_partition || !(use_private || typed_direct)) { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
-    const bool count_entries = out && lw.stats_chain_flagged && ((use_private && !use_partition) || typed_direct);
-    if (count_entries) { st = arm_filter_entries(ctx, &gp.scan.filter_entries); if (st != PG_OK) return st; }
+    const bool count_leap2 = out && lw.stats_leap2_flagged && ((use_private && !use_partition) || typed_direct);
+    const bool count_entries = (out && lw.stats_chain_flagged && ((use_private && !use_partition) || typed_direct)) || count_leap2;
+    gp.scan.leap_tables = nullptr;
+    if (count_leap2) { st = arm_leap_tables(seg, ctx, &gp.scan.leap_tables); if (st != PG_OK) return st; }
+    else if (lw.stats_leap2_flagged) for (int n = 0; n < gp.scan.num_nodes; ++n) gp.scan.nodes[n].flags &= ~kNodeLeapfrog2;
+    if (count_entries && !count_leap2) { st = arm_filter_entries(ctx, &gp.scan.filter_entries); if (st != PG_OK) return st; }
     if (use_partition) {
       const int P = (int)num_partitions;
       const size_t N = (size_t)std::max(seg->num_tiles, 1) * 2048;
@@ -2573,8 +2621,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     else if (use_private) launch_group_private(gp.use_lds_table != 0, pblocks, pthreads, plds, ctx->stream, gp);
     else launch_scan_group(g_engine.use_dma, gp.use_lds_table != 0, blocks, geo.threads, lds, ctx->stream, gp);
     HIP_TRY(hipGetLastError());
-    if (count_entries) HIP_TRY(hipMemcpyAsync(ctx->h_filter_entries, ctx->d_filter_entries, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    if (count_leap2) {
+      leapfrog2_chain_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(gp.scan.leap_tables, ((long long)seg->num_docs + 2047) / 2048, ctx->d_filter_entries);
+      HIP_TRY(hipGetLastError());
+    }
+    if (count_entries) HIP_TRY(hipMemcpyAsync(ctx->h_filter_entries, ctx->d_filter_entries, 8, hipMemcpyDeviceToHost, ctx->stream));
     // The groups that exist, in ascending raw-key order: (raw key, doc count, accumulators[a * num_present + k]).
     std::vector<int32_t> present_ids;
     std::vector<unsigned long long> present_counts;

@@ -362,7 +362,9 @@ enum class Plan {
   kZero,          // no filter, or no scan-based leaf
   kPerLeaf,       // no AND above any scan leaf: numDocs per scan leaf
   kChain,         // root AND of plain leaves with an index-based child: counted by the lane-private kernels (kNodeCountEntries)
-  kReplay         // the iterator walk below
+  kReplay,        // the iterator walk below
+  kLeap2          // root AND of exactly two scan leaves: the leap-frog of AndDocIdIterator over two SVScanDocIdIterators, counted by the
+                  // lane-private kernels as a two-state carry chain (kNodeLeapfrog2, leapfrog2_tile in pg_kernels.h)
 };
 
 inline bool malformed(const pg_query* q) {
@@ -398,6 +400,7 @@ inline Plan choose_plan(const pg_query* q, int* num_scan_leaves) {
     int num_index = 0;
     for (int i = 0; i + 1 < q->num_filter_nodes; ++i) num_index += classify(q->predicates[q->filter[i].predicate]) != LeafClass::kScan ? 1 : 0;
     if (num_index > 0) return Plan::kChain;
+    if (root.num_children == 2) return Plan::kLeap2;
   }
   return Plan::kReplay;
 }
@@ -488,6 +491,62 @@ inline int64_t replay_and_of_scans_parallel(const std::vector<const uint64_t*>& 
     state = o.end_state;
   }
   return entries;
+}
+
+// Plan::kLeap2 on the host, in the device's own structure (leapfrog2_tile / leapfrog2_chain_kernel in pg_kernels.h): 32-doc lanes whose
+// "child 1 is scanning" state is the carry of one addition (generate a & ~b, propagate ~(a | b)), 64 lanes per tile chained through a
+// 64-bit add of their generate / propagate ballots, tiles summarised for entry state 0 plus the correction for entry state 1, summaries
+// chained in order.  Returns the EXTRA entries (numEntriesScannedInFilter - numDocs).  tests/test_filter_stats_cpu.py holds it against
+// the oracle and the iterator walk; the device code is the same arithmetic.
+inline int64_t leap2_extra_entries(const uint64_t* a_words, const uint64_t* b_words, int32_t num_docs) {
+  const int64_t num_tiles = ((int64_t)num_docs + 2047) / 2048;
+  const size_t nw = ((size_t)num_docs + 63) / 64;
+  auto lane_word = [&](const uint64_t* w, int64_t tile, int lane) -> uint32_t {
+    const int64_t first = tile * 2048 + (int64_t)lane * 32;
+    if (first >= num_docs) return 0u;
+    const size_t i = (size_t)(first >> 6);
+    uint32_t v = i < nw ? (uint32_t)(w[i] >> (first & 63)) : 0u;
+    const int64_t rem = (int64_t)num_docs - first;
+    return rem >= 32 ? v : (v & ((1u << (int)rem) - 1u));
+  };
+  uint64_t total = 0;
+  uint32_t g_all = 0, p_all = 1;
+  int d_all = 0;                                  // (kept for symmetry with the device's summaries; the chain starts in state 0)
+  for (int64_t tile = 0; tile < num_tiles; ++tile) {
+    uint32_t A[64], B[64];
+    uint64_t sum0[64];
+    uint64_t Gm = 0, Pm = 0;
+    for (int lane = 0; lane < 64; ++lane) {
+      A[lane] = lane_word(a_words, tile, lane); B[lane] = lane_word(b_words, tile, lane);
+      const uint32_t E = A[lane] | B[lane], X = A[lane] & ~B[lane], prop = ~E;
+      sum0[lane] = (uint64_t)(X | prop) + (uint64_t)X;
+      if ((uint32_t)(sum0[lane] >> 32)) Gm |= 1ull << lane;
+      if (E == 0) Pm |= 1ull << lane;
+    }
+    unsigned long long wsum;
+    const bool tile_carry = __builtin_uaddll_overflow(Gm | Pm, Gm, &wsum);
+    const uint64_t cins = wsum ^ Pm;
+    uint32_t cost0 = 0;
+    for (int lane = 0; lane < 64; ++lane) {
+      const uint32_t E = A[lane] | B[lane], X = A[lane] & ~B[lane], Y = B[lane] & ~A[lane], T = A[lane] & B[lane];
+      const uint32_t S = (uint32_t)(sum0[lane] + ((cins >> lane) & 1ull)) ^ ~E;
+      cost0 += (uint32_t)(__builtin_popcount(T) + __builtin_popcount(X & ~S) + __builtin_popcount(Y & S));
+    }
+    int delta = 0;
+    const uint64_t with_events = ~Pm;
+    if (with_events) {
+      const int first = __builtin_ctzll(with_events);
+      const uint32_t Ef = A[first] | B[first];
+      const int bit = __builtin_ctz(Ef);
+      delta = (int)(((B[first] & ~A[first]) >> bit) & 1u) - (int)(((A[first] & ~B[first]) >> bit) & 1u);
+    }
+    const uint32_t g = tile_carry ? 1u : 0u, pp = with_events == 0 ? 1u : 0u;
+    total += cost0 + (g_all ? (int64_t)delta : 0);
+    d_all += p_all ? delta : 0;
+    g_all = g | (pp & g_all);
+    p_all &= pp;
+  }
+  return (int64_t)total;
 }
 
 // The walk itself: DocIdSetOperator pulls next() until EOF (core/operator/DocIdSetOperator.java:66-90).

@@ -1478,6 +1478,74 @@ __device__ __forceinline__ uint32_t eval_leaf_private(const ScanParams& p, const
   return L.exclusive ? ~m : m;
 }
 
+// numEntriesScannedInFilter of `a AND b`, both scan leaves -- AndDocIdIterator.next() (dociditerators/AndDocIdIterator.java:41-74)
+// leap-frogging two SVScanDocIdIterators (SVScanDocIdIterator.java:91-106: advance(t) looks at doc t, t + 1, ... until one matches, one
+// entry each).  At every doc exactly ONE leaf is scanning (one entry per doc: numDocs in total, added by the host); where the scanning
+// leaf matches, the other one is asked about that doc (one more entry) -- if it says no IT scans on from the next doc, if it says yes
+// the doc is a result and child 0 scans on.  With s = "child 1 is scanning", per doc:
+//     (a, b) = (0, 0): s stays                      (1, 0): s := 1, extra entry iff s was 0
+//     (0, 1): s := 0, extra entry iff s was 1       (1, 1): s := 0, extra entry either way
+// so s is the carry of a binary addition with generate = a & ~b and propagate = ~(a | b): ONE 64-bit add per lane gives the state before
+// each of its 32 docs, one 64-bit scalar add over the wave's ballots gives every lane's carry-in, and three popcounts give the entries.
+// Tiles are dealt round-robin, so a tile does not know the state it is entered in: it is summarised for entry state 0 plus what changes
+// for entry state 1 (only the docs before the tile's first event can tell: delta in {-1, 0, +1}), and leapfrog2_chain_kernel chains
+// the summaries in tile order.  ~40 instructions per 2048 docs next to the ~230 the two leaves cost.
+//     summary = extra entries (entry state 0) | (delta + 1) << 16 | (state after the tile, entered in 0) << 18 | (tile has no event) << 19
+__device__ __forceinline__ void leapfrog2_tile(const ScanParams& p, long long tile, int lane, uint32_t a, uint32_t b) {
+  const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
+  const uint32_t valid = rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));      // docs past numDocs are not there
+  a &= valid; b &= valid;
+  const uint32_t E = a | b, X = a & ~b, Y = b & ~a, T = a & b, prop = ~E;
+  const unsigned long long sum0 = (unsigned long long)(X | prop) + (unsigned long long)X;
+  const unsigned long long Gm = __builtin_amdgcn_ballot_w64((uint32_t)(sum0 >> 32) != 0u), Pm = __builtin_amdgcn_ballot_w64(E == 0u);
+  unsigned long long wsum;
+  const bool tile_carry = __builtin_uaddll_overflow(Gm | Pm, Gm, &wsum);
+  const uint32_t cin = (uint32_t)((wsum ^ Pm) >> lane) & 1u;                // the lane is entered in state 1 (the tile in state 0)
+  const uint32_t S = (uint32_t)(sum0 + cin) ^ prop;                         // state before each of the lane's docs
+  const uint32_t extra = (uint32_t)(__builtin_popcount(T) + __builtin_popcount(X & ~S) + __builtin_popcount(Y & S));
+  uint32_t cost0 = extra;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cost0 += (uint32_t)__shfl_xor((int)cost0, o, 64);
+  int delta = 0;
+  const unsigned long long with_events = ~Pm;
+  if (with_events != 0ull) {
+    const int first = __builtin_ctzll(with_events);
+    const uint32_t Ef = (uint32_t)__builtin_amdgcn_readlane((int)E, first), Xf = (uint32_t)__builtin_amdgcn_readlane((int)X, first),
+                   Yf = (uint32_t)__builtin_amdgcn_readlane((int)Y, first);
+    const int bit = __builtin_ctz(Ef);
+    delta = (int)((Yf >> bit) & 1u) - (int)((Xf >> bit) & 1u);
+  }
+  if (lane == 0) p.leap_tables[tile] = cost0 | ((uint32_t)(delta + 1) << 16) | ((tile_carry ? 1u : 0u) << 18) | ((with_events == 0ull ? 1u : 0u) << 19);
+}
+
+// Chains the tile summaries of leapfrog2_tile in tile order (entry state 0 at doc 0): one workgroup, every thread a contiguous run of
+// tiles, thread 0 the threads' summaries.  *out = the extra entries of the whole segment (numEntriesScannedInFilter - numDocs).
+struct Leap2Summary { unsigned long long cost; int delta; uint32_t g, p; };
+// `cur` followed by a piece summarised as (c0, d, g, pp)
+__device__ __forceinline__ void leap2_append(Leap2Summary& cur, unsigned long long c0, int d, uint32_t g, uint32_t pp) {
+  cur.cost += c0 + (cur.g ? (long long)d : 0ll);      // the piece is entered in state cur.g (the run was entered in 0) ...
+  cur.delta += cur.p ? d : 0;                          // ... or in 1 instead, if the run was and nothing has happened in it yet
+  cur.g = g | (pp & cur.g);
+  cur.p &= pp;
+}
+static __global__ __launch_bounds__(1024) void leapfrog2_chain_kernel(const uint32_t* __restrict__ tables, long long num_tiles, unsigned long long* out) {
+  __shared__ Leap2Summary part[1024];
+  const long long per = (num_tiles + blockDim.x - 1) / blockDim.x;
+  const long long begin = (long long)threadIdx.x * per, end = begin + per < num_tiles ? begin + per : num_tiles;
+  Leap2Summary cur{0ull, 0, 0u, 1u};
+  for (long long t = begin; t < end; ++t) {
+    const uint32_t e = tables[t];
+    leap2_append(cur, e & 0xFFFFu, (int)((e >> 16) & 3u) - 1, (e >> 18) & 1u, (e >> 19) & 1u);
+  }
+  part[threadIdx.x] = cur;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Leap2Summary all{0ull, 0, 0u, 1u};
+    for (int i = 0; i < (int)blockDim.x; ++i) leap2_append(all, part[i].cost, part[i].delta, part[i].g, part[i].p);
+    *out = all.cost;
+  }
+}
+
 // `entries`: per-lane share of numEntriesScannedInFilter -- a kNodeCountEntries leaf is a scan-based child of the root AND that the
 // reference and-s into the docIds left by the children before it (ScanBasedDocIdIterator.applyAnd, AndDocIdSet.java:161-163,
 // SVScanDocIdIterator.java:115-145: one entry per doc of that bitmap).  On the AND chain the only mask on the stack is that bitmap.
@@ -1501,6 +1569,7 @@ __device__ __forceinline__ uint32_t eval_filter_private(const ScanParams& p, lon
       top = ~st.pop();
     } else {
       top = st.pop();
+      if (nd.flags & kNodeLeapfrog2) leapfrog2_tile(p, tile, lane, st.v[0], top);      // the root AND of two leaves: child 0 is the stack's only entry, child 1 was on top
       for (int c = 1; c < nd.num_children; ++c) {
         const uint32_t o = st.pop();
         top = nd.op == PG_FILTER_AND ? (top & o) : (top | o);

@@ -17,7 +17,7 @@ from pinot_amd import segment as S
 import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PLAN_ZERO, PLAN_PER_LEAF, PLAN_CHAIN, PLAN_REPLAY = 0, 1, 2, 3
+PLAN_ZERO, PLAN_PER_LEAF, PLAN_CHAIN, PLAN_REPLAY, PLAN_LEAP2 = 0, 1, 2, 3, 4
 
 
 @pytest.fixture(scope="module")
@@ -33,6 +33,8 @@ def driver(tmp_path_factory):
     lib.fstats_replay.argtypes = [C.POINTER(_abi.pg_query), C.c_int32, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.fstats_replay_mode.restype = C.c_int64
     lib.fstats_replay_mode.argtypes = [C.POINTER(_abi.pg_query), C.c_int32, C.POINTER(C.POINTER(C.c_uint64)), C.c_int32, C.c_int32, C.c_int32]
+    lib.fstats_leap2.restype = C.c_int64
+    lib.fstats_leap2.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
     return lib
 
 
@@ -119,7 +121,7 @@ def test_replay_matches_the_oracle_on_random_trees(driver):
             assert entries == leaves * n            # no AND above a scan leaf: every scan leaf looks at every doc
         if plan == PLAN_ZERO:
             assert entries == 0
-    assert plans == {PLAN_ZERO, PLAN_PER_LEAF, PLAN_CHAIN, PLAN_REPLAY}
+    assert plans >= {PLAN_ZERO, PLAN_PER_LEAF, PLAN_CHAIN, PLAN_REPLAY} and plans <= {PLAN_ZERO, PLAN_PER_LEAF, PLAN_CHAIN, PLAN_REPLAY, PLAN_LEAP2}
 
 
 def test_and_of_scan_leaves_three_ways(driver):
@@ -145,3 +147,33 @@ def test_and_of_scan_leaves_three_ways(driver):
         sequential = driver.fstats_replay_mode(C.byref(spec.c), n, ptrs, 1, 0, 1)
         parallel = driver.fstats_replay_mode(C.byref(spec.c), n, ptrs, 1, 997, 4)
         assert generic == sequential == parallel == want == oracle.execute(seg, spec).stats[1], (n, k)
+
+
+def test_two_scan_leaves_as_a_carry_chain(driver):
+    """Plan::kLeap2 -- `a AND b`, both scan leaves -- as the device counts it (leapfrog2_tile / leapfrog2_chain_kernel in pg_kernels.h, restated
+    on the host in pg_filter_stats.h): 32-doc lanes, 2048-doc tiles summarised for either entry state, summaries chained.  Against the
+    iterator walk, the oracle and the state machine of tests/helpers.py, at sizes around every boundary and at selectivities from
+    nothing to everything (long runs without an event, and events in every doc)."""
+    rng = np.random.default_rng(2026)
+    sizes = [1, 31, 32, 33, 63, 64, 65, 2047, 2048, 2049, 4096, 70_001, 131_072, 300_007]
+    for n in sizes:
+        for pa, pb in ((0.5, 0.5), (0.1, 0.1), (0.9, 0.02), (0.001, 0.7), (0.02, 0.02), (1.0, 0.3), (0.3, 0.0)):
+            a = rng.random(n) < pa
+            b = rng.random(n) < pb
+            if n > 5000:                                      # long stretches without any event, and a state handed across many tiles
+                a[1000:n - 1000] &= rng.random(n - 2000) < 0.05
+                b[3000:n // 2] = False
+            pack = lambda m: np.ascontiguousarray(np.concatenate([np.packbits(m.astype(np.uint8), bitorder="little"), np.zeros(16, dtype=np.uint8)])[: 8 * ((n + 63) // 64 + 1)].view(np.uint64))
+            wa, wb = pack(a), pack(b)
+            got = driver.fstats_leap2(wa.ctypes.data_as(C.POINTER(C.c_uint64)), wb.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+            assert got == H.and_leapfrog_entries([a, b]), (n, pa, pb)
+    # and through the query path: the plan is kLeap2, the count equals the oracle's iterator tree
+    n = 70_001
+    ca, ia, _ = H.random_dict_column(rng, "a", n, 20)
+    cb, ib, _ = H.random_dict_column(rng, "b", n, 7)
+    seg = S.SegmentData("leap2", n, [ca, cb])
+    spec = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(Q.leaf(Q.Pred.dict_range(0, 3, 9)), Q.leaf(Q.Pred.dict_range(1, 2, 5, exclusive=True))))
+    entries, plan, leaves = replay(driver, seg, spec)
+    assert plan == PLAN_LEAP2 and leaves == 2
+    keep, ptrs = leaf_bitmaps(seg, spec)
+    assert driver.fstats_leap2(ptrs[0], ptrs[1], n) == entries == oracle.execute(seg, spec).stats[1]

@@ -1,0 +1,105 @@
+"""GPU tests of numEntriesScannedInFilter for filters that leap-frog (AndDocIdIterator over scan-based children).
+
+`a AND b` with two scan leaves is counted ON THE DEVICE (Plan::kLeap2: leapfrog2_tile in the lane-private kernels + leapfrog2_chain_kernel),
+at any segment size and with no host pass; the host replay (pg_filter_stats.h) stays for every other leap-frogging shape up to
+PINOT_GPU_EXACT_FILTER_STATS_DOCS docs.  The first test turns the replay OFF, so an exact count can only have come from the device."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from pinot_amd import query as Q
+from pinot_amd import segment as S
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def engine_without_replay(monkeypatch):
+    """pg_init re-reads the environment: the same process-wide engine, with the host replay of leap-frogging filters disabled."""
+    import torch  # noqa: F401
+    from pinot_amd.engine import Engine
+    monkeypatch.setenv("PINOT_GPU_EXACT_FILTER_STATS_DOCS", "0")
+    eng = Engine(device_id=0, time_kernels=True)
+    yield eng
+    monkeypatch.delenv("PINOT_GPU_EXACT_FILTER_STATS_DOCS")
+    Engine(device_id=0, time_kernels=True)
+
+
+@pytest.mark.parametrize("n", [1, 33, 2047, 2049, 70001, 1000003, 5000011])
+def test_two_scan_leaves_are_counted_on_the_device(engine_without_replay, n):
+    rng = np.random.default_rng(n)
+    ca, ia, _ = H.random_dict_column(rng, "a", n, 100)
+    cb, ib, _ = H.random_dict_column(rng, "b", n, 10)
+    if n > 5000:                                  # a long stretch in which only one leaf ever matches, then one in which neither does
+        ib[n // 5:n // 2] = 9
+        ia[n // 2:(3 * n) // 4] = 99
+        cb = S.Column.from_dict_ids("b", np.arange(10, dtype=np.int32) * 3, ib)
+        ca = S.Column.from_dict_ids("a", np.arange(100, dtype=np.int32) * 5 - 7, ia)
+    v, _, _ = H.random_dict_column(rng, "v", n, 40000)                                           # irregular: SUM runs in scan_hist_kernel
+    w = S.Column.synthetic_uniform("w", n, (np.arange(2000, dtype=np.int64) * 3 + 1).astype(np.int32), seed=7)   # affine: scan_private_kernel
+    k = S.Column.synthetic_uniform("k", n, np.arange(50, dtype=np.int32), seed=8)
+    seg = S.SegmentData("leap2_%d" % n, n, [ca, cb, v, w, k])
+    filters = [Q.and_(Q.leaf(Q.Pred.dict_range(0, 0, 10)), Q.leaf(Q.Pred.dict_range(1, 0, 3))),                 # 10 % AND 30 %
+               Q.and_(Q.leaf(Q.Pred.dict_range(0, 5, 95)), Q.leaf(Q.Pred.dict_range(1, 8, 9, exclusive=True))),  # 90 % AND NOT 10 %
+               Q.and_(Q.leaf(Q.Pred.dict_range(1, 9, 10)), Q.leaf(Q.Pred.dict_set(0, [1, 50, 99], 100)))]        # EQ AND IN
+    with engine_without_replay.open(seg) as g:
+        for flt in filters:
+            for aggs, group_by in (([(Q.COUNT, -1)], []), ([(Q.SUM, 3), (Q.MAX, 3)], []), ([(Q.SUM, 2)], []), ([(Q.SUM, 3), (Q.COUNT, -1)], [4])):
+                spec = Q.QuerySpec(aggs, filter=flt, group_by=group_by)
+                got = g.execute(spec)
+                want = oracle.execute(seg, spec)
+                H.assert_results_equal(got, want)
+                assert got.filter_entries_exact, (n, aggs, group_by)
+                assert got.stats[1] == want.stats[1]
+
+
+def test_random_filter_trees_on_the_device(engine):
+    """The trees of tests/test_filter_stats_cpu.py on the device: whatever plan the engine picks (closed forms, applyAnd counting in the
+    kernels, the two-leaf carry chain, the host replay), an exact count equals the oracle's iterator tree."""
+    rng = np.random.default_rng(20260921)
+    n = 20_011
+    cols = [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "b", n, 7, with_inverted=True)[0],
+            H.random_dict_column(rng, "c", n, 300, with_inverted=True)[0], H.random_dict_column(rng, "d", n, 3)[0]]
+    seg = S.SegmentData("fs", n, cols)
+
+    def leaf():
+        k = int(rng.integers(0, 7))
+        if k == 0:
+            lo = int(rng.integers(0, 40)); return Q.leaf(Q.Pred.dict_range(0, lo, lo + int(rng.integers(1, 12)), exclusive=bool(rng.integers(0, 2))))
+        if k == 1:
+            return Q.leaf(Q.Pred.dict_range(1, int(rng.integers(0, 6)), 7, inverted=True, exclusive=bool(rng.integers(0, 2))))
+        if k == 2:
+            return Q.leaf(Q.Pred.dict_set(2, sorted(set(int(x) for x in rng.integers(0, 300, size=40))), 300, inverted=bool(rng.integers(0, 2))))
+        if k == 3:
+            lo = int(rng.integers(0, n)); return Q.leaf(Q.Pred.doc_range(lo, min(n - 1, lo + int(rng.integers(0, n))), exclusive=bool(rng.integers(0, 4) == 0)))
+        if k == 4:
+            return Q.leaf(Q.Pred.dict_range(3, int(rng.integers(0, 2)), 3))
+        if k == 5:
+            return Q.leaf(Q.Pred.dict_set(0, sorted(set(int(x) for x in rng.integers(0, 50, size=5))), 50, exclusive=bool(rng.integers(0, 2))))
+        return Q.leaf(Q.Pred.dict_range(2, 0, int(rng.integers(1, 300))))
+
+    def tree(depth):
+        k = int(rng.integers(0, 10))
+        if depth == 0 or k < 3:
+            return leaf()
+        if k < 6:
+            return Q.and_(*[tree(depth - 1) for _ in range(int(rng.integers(2, 4)))])
+        if k < 9:
+            return Q.or_(*[tree(depth - 1) for _ in range(int(rng.integers(2, 4)))])
+        return Q.not_(tree(depth - 1))
+
+    ran = exact = 0
+    with engine.open(seg) as g:
+        for _ in range(300):
+            spec = Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0)], filter=tree(3))
+            if spec.c.num_filter_nodes > 24 or g.check(spec) != 0:
+                continue
+            got = g.execute(spec)
+            want = oracle.execute(seg, spec)
+            H.assert_results_equal(got, want)
+            ran += 1
+            if got.filter_entries_exact:
+                exact += 1
+                assert got.stats[1] == want.stats[1]
+    assert ran >= 150 and exact >= ran * 0.9, (ran, exact)

@@ -25,3 +25,9 @@ extern "C" int64_t fstats_replay_mode(const pg_query* q, int32_t num_docs, const
     if (leaf_words[i]) leaves[(size_t)i] = std::make_shared<std::vector<uint64_t>>(leaf_words[i], leaf_words[i] + (words ? words : 1));
   return pg::fstats::replay(q, num_docs, leaves, mode != 0, chunk_docs, threads);
 }
+
+// Plan::kLeap2 (an AND of exactly two scan leaves) the way the device counts it: numDocs + the carry-chain count of the docs where the
+// leaf that is not scanning gets asked.
+extern "C" int64_t fstats_leap2(const uint64_t* a_words, const uint64_t* b_words, int32_t num_docs) {
+  return (int64_t)num_docs + pg::fstats::leap2_extra_entries(a_words, b_words, num_docs);
+}
