@@ -1477,6 +1477,9 @@ pg_status pg_init(const pg_config* config) {
   g_engine.hist_bits = (hb && (atoi(hb) == 8 || atoi(hb) == 16)) ? atoi(hb) : 0;
   const char* ts = getenv("PINOT_GPU_TILE_STEPS");
   g_engine.tile_steps = (ts && (atoi(ts) == 16 || atoi(ts) == 32)) ? atoi(ts) : 0;
+  // (pg_init may be called again with another environment -- tools/ab_r3.py, tests: every switch goes back to its default first)
+  g_engine.raw64_coalesced = true; g_engine.wide_plane = -1; g_engine.partition_stats_cache = true; g_engine.partition_packed = true;
+  g_engine.plane_async = true; g_engine.staged_h2d = true; g_engine.exact_stats_docs = 64ll << 20;
   const char* r64 = getenv("PINOT_GPU_RAW64_COALESCED");
   if (r64) g_engine.raw64_coalesced = atoi(r64) != 0;
   const char* wpl = getenv("PINOT_GPU_WIDE_PLANE");
