@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 2   /* 2: pg_result.filter_entries_exact, pg_query_check, pg_config.plane_budget_bytes */
+#define PG_ABI_VERSION 3   /* 2: pg_result.filter_entries_exact, pg_query_check, pg_config.plane_budget_bytes; 3: pg_execute_batch */
 
 typedef enum pg_status {
   PG_OK = 0,
@@ -308,6 +308,21 @@ pg_status pg_query_check(const pg_segment* segment, const pg_query* query);
 
 pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_result);
 void pg_result_free(pg_result* result);
+
+/* One query over MANY resident segments in one call: what BaseCombineOperator does with a thread pool (core/operator/combine/
+ * BaseCombineOperator.java:85-142: numTasks worker threads, each pulling the next segment's operator and merging its block; CombinePlanNode.java:
+ * 92-110 builds one PlanNode per segment).  queries[i] is the query as lowered FOR segments[i] (dictIds differ from segment to segment);
+ * results[i] / statuses[i] are what pg_execute(segments[i], queries[i], &results[i]) would have produced, item by item -- an item that
+ * fails does not stop the others (the combine operator collects the exception of one segment and still answers with the rest).
+ *
+ * A server holds hundreds of few-million-row segments per table; launched one by one each is a ~20 us kernel whose launch latency, ramp
+ * and drain are most of its device time.  Items whose whole device work is one launch of the lane-private scan kernel (aggregations
+ * without GROUP BY over scan / sorted leaves) are therefore put into ONE launch (scan_private_batch_kernel: every item owns a share of the
+ * grid, folds its own records and publishes its own pinned result); every other item runs as a pg_execute of its own, concurrently, on
+ * the library's worker threads and on streams of their own.  The call returns when every item has finished.  Returns PG_OK whenever the
+ * arguments were usable; per-item outcomes are in statuses[], pg_last_error() names the first failed item.  Every results[i] must be
+ * released with pg_result_free (a failed item's is already empty). */
+pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* queries, int32_t count, pg_result* results, pg_status* statuses);
 
 /* Evaluates only the filter and returns the matching docIds as a dense bitmap:
  * bit (docId & 63) of out_words[docId >> 6]; num_words >= ceil(num_docs / 64).  out_cardinality may be NULL. */

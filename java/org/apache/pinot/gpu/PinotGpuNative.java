@@ -24,7 +24,7 @@ public final class PinotGpuNative {
   // may spell one of these numbers as a literal.
 
   /** PG_ABI_VERSION (include/pinot_gpu.h): checked against pg_version() in GpuPlanMaker.init. */
-  public static final int PG_ABI_VERSION = 2;
+  public static final int PG_ABI_VERSION = 3;
 
   /** pg_status */
   public static final int PG_OK = 0;

@@ -7,7 +7,7 @@ C ABI into the HIP kernels, and loading fails loudly when the library has not be
 import ctypes as C
 import os
 
-PG_ABI_VERSION = 2
+PG_ABI_VERSION = 3
 
 # pg_status
 PG_OK, PG_ERR_INVALID_ARGUMENT, PG_ERR_UNSUPPORTED, PG_ERR_DEVICE, PG_ERR_OUT_OF_MEMORY, PG_ERR_NOT_INITIALIZED, PG_ERR_INTERNAL = range(7)
@@ -105,6 +105,7 @@ ABI_SYMBOLS = [
     ("pg_query_check", C.c_int, [C.c_void_p, _P(pg_query)]),
     ("pg_execute", C.c_int, [C.c_void_p, _P(pg_query), _P(pg_result)]),
     ("pg_result_free", None, [_P(pg_result)]),
+    ("pg_execute_batch", C.c_int, [_P(C.c_void_p), _P(_P(pg_query)), C.c_int32, _P(pg_result), _P(C.c_int)]),
     ("pg_filter_bitmap", C.c_int, [C.c_void_p, _P(pg_query), _P(C.c_uint64), C.c_int64, _P(C.c_int64)]),
     ("pg_read_dict_ids", C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), C.c_int32, _P(C.c_int32)]),
     ("pg_read_int_values", C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), C.c_int32, _P(C.c_int32)]),

@@ -5,6 +5,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -67,6 +70,8 @@ struct Engine {
                              // does in a launch of its own, -1 (default) fold on segments of at most kFoldMaxTiles tiles
   bool poll_result = true;   // PINOT_GPU_POLL_RESULT=0: pg_execute always waits with hipStreamSynchronize instead of spinning on the pinned record's sequence number
   bool lane_skip = true;     // PINOT_GPU_LANE_SKIP=0: the aggregating kernels load a tile's value bytes for every lane, matches or not
+  bool batch_launch = true;  // PINOT_GPU_BATCH_LAUNCH=0: pg_execute_batch runs every item as a pg_execute of its own on the worker threads (no shared launch)
+  bool leap2 = true;         // PINOT_GPU_LEAP2=0: a leap-frogging `a AND b` is not counted on the device (host replay / upper bound instead)
   int sparse_lanes = 32;     // PINOT_GPU_SPARSE_LANES: tiles in which at most this many of the 64 lanes hold a match are aggregated match by match (0 = never)
   bool plane_gcd = true;     // PINOT_GPU_PLANE_GCD=0: planes hold value - min unscaled, never alias the dictId stream
   bool scan_private = true;  // PINOT_GPU_SCAN_PRIVATE=0: always the LDS-staged scan kernel
@@ -154,6 +159,7 @@ struct ExecCtx {
   uint32_t* d_done = nullptr;                   // "last block done" arrival counter of the scan kernels (zero between launches)
   unsigned long long seq = 0;                   // sequence number of the context's last launch (HostRecord.seq)
   bool pre_started = false;                     // timed runs: ev[0] has been recorded (some kernel runs before the scan)
+  bool pre_enqueued = false;                    // something has been put on the stream ahead of the scan kernel (any run, timed or not)
   int ev_last = 3;                              // timed runs: the event that closes the query's device work (2 when nothing follows the scan kernel)
   std::vector<unsigned long long*> d_bitmaps;   // each num_tiles*32 words
   std::vector<uint32_t*> d_sets;
@@ -745,6 +751,10 @@ void release_plane(pg_segment* seg, int column) {
 struct PlaneHold {
   pg_segment* seg;
   std::vector<int> columns;
+  PlaneHold(pg_segment* s, std::vector<int> c) : seg(s), columns(std::move(c)) {}
+  PlaneHold(const PlaneHold&) = delete;
+  PlaneHold& operator=(const PlaneHold&) = delete;
+  PlaneHold(PlaneHold&& o) noexcept : seg(o.seg), columns(std::move(o.columns)) { o.columns.clear(); }
   ~PlaneHold() { for (int c : columns) release_plane(seg, c); }
 };
 
@@ -895,6 +905,7 @@ void build_sequence(const pg_query* q, std::vector<SeqNode>* seq, int* lazy_node
 // Timed runs (PG_CFG_TIME_KERNELS): ev[0] opens the query's device work.  It is recorded by the first thing that enqueues work BEFORE
 // the scan kernel (index AND, posting expansion, set uploads, table initialisation); a query that runs only its scan kernel opens with ev[1].
 hipError_t mark_pre_work(ExecCtx* ctx) {
+  ctx->pre_enqueued = true;          // (pg_execute_batch: such a query runs on its own context, not in the shared launch)
   if (!(g_engine.flags & PG_CFG_TIME_KERNELS) || ctx->pre_started) return hipSuccess;
   ctx->pre_started = true;
   return hipEventRecord(ctx->ev[0], ctx->stream);
@@ -1444,6 +1455,10 @@ pg_status pg_init(const pg_config* config) {
   g_engine.poll_result = !(prs && prs[0] == '0');
   const char* lsk = getenv("PINOT_GPU_LANE_SKIP");
   g_engine.lane_skip = !(lsk && lsk[0] == '0');
+  const char* bla = getenv("PINOT_GPU_BATCH_LAUNCH");
+  g_engine.batch_launch = !(bla && bla[0] == '0');
+  const char* lp2 = getenv("PINOT_GPU_LEAP2");
+  g_engine.leap2 = !(lp2 && lp2[0] == '0');
   const char* spl = getenv("PINOT_GPU_SPARSE_LANES");
   g_engine.sparse_lanes = spl ? std::max(0, std::min(64, atoi(spl))) : 32;
   const char* pgv = getenv("PINOT_GPU_PLANE_GCD");
@@ -1949,24 +1964,37 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
 
 // ExecutionStatistics.numEntriesScannedInFilter from the plan pg_filter_stats.h chose; `counted`: the kernel that ran carried the
 // kNodeCountEntries counter (its value has been copied to ctx->h_filter_entries and the stream is idle).
-static void finish_filter_stats(const Lowered& lw, const pg_segment* seg, const ExecCtx* ctx, bool counted, pg_result* out) {
+static void finish_filter_stats(const Lowered& lw, const pg_segment* seg, const unsigned long long* h_filter_entries, bool counted, pg_result* out) {
   const int64_t upper_bound = (int64_t)lw.stats_scan_leaves * seg->num_docs;      // every scan leaf looking at every doc
   switch (lw.stats_plan) {
     case fstats::Plan::kZero: out->stats.num_entries_scanned_in_filter = 0; out->filter_entries_exact = 1; break;
     case fstats::Plan::kPerLeaf: out->stats.num_entries_scanned_in_filter = upper_bound; out->filter_entries_exact = 1; break;
     case fstats::Plan::kLeap2:
       // one entry per doc for whichever leaf is scanning there, plus the device's count of the docs where the other leaf was asked
-      if (counted) { out->stats.num_entries_scanned_in_filter = (int64_t)seg->num_docs + (int64_t)*ctx->h_filter_entries; out->filter_entries_exact = 1; break; }
+      if (counted) { out->stats.num_entries_scanned_in_filter = (int64_t)seg->num_docs + (int64_t)*h_filter_entries; out->filter_entries_exact = 1; break; }
       out->stats.num_entries_scanned_in_filter = upper_bound; out->filter_entries_exact = 0; break;
     case fstats::Plan::kChain:
-      if (counted) { out->stats.num_entries_scanned_in_filter = (int64_t)*ctx->h_filter_entries; out->filter_entries_exact = 1; break; }
+      if (counted) { out->stats.num_entries_scanned_in_filter = (int64_t)*h_filter_entries; out->filter_entries_exact = 1; break; }
       [[fallthrough]];                                                            // an LDS-staged kernel ran: replayed by pg_execute
     default: out->stats.num_entries_scanned_in_filter = upper_bound; out->filter_entries_exact = 0; break;
   }
 }
 
+// pg_execute_batch: a query whose whole device work is ONE launch of scan_private_kernel -- nothing ahead of it on the stream, no index
+// phase, no entry counter, no histogram -- is not launched by execute_impl but handed back as its kernel parameters plus the
+// conversion of the folded record into a pg_result; the batch puts many of them into one launch (scan_private_batch_kernel).
+static const pg_status kDeferred = static_cast<pg_status>(100);      // (internal: never leaves the library)
+struct Deferred {
+  ScanParams sp;
+  int blocks = 0;
+  bool one_slot = true;
+  std::function<void(const BlockPartial&, pg_result*)> convert;
+  std::unique_ptr<PlaneHold> planes;           // value planes the kernel reads stay held until the batch has run
+};
+
 static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out, unsigned long long* d_out_bitmap_request,
-                              uint64_t* host_bitmap, int64_t host_bitmap_words, int64_t* out_cardinality, bool allow_metadata_plan = true) {
+                              uint64_t* host_bitmap, int64_t host_bitmap_words, int64_t* out_cardinality, bool allow_metadata_plan = true,
+                              Deferred* defer = nullptr) {
   if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");
   if (!seg || !q) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
   // d_out_bitmap_request: like host_bitmap, but the filter's doc-order bitmap is copied device to device into the caller's
@@ -2038,7 +2066,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   // Columns that are summed are read through their value plane (built on first use); decided before the filter is
   // lowered so that a range predicate on the same column can be evaluated on the plane too.
   lw.plane_cols.assign((size_t)std::max(num_cols_total, 1), 0);
-  PlaneHold planes{seg, {}};
+  PlaneHold planes(seg, {});
   // At most one summed column goes through the LDS histogram instead (scan_hist_kernel); it needs the lane-private kernel, so the
   // shapes that kernel does not take are ruled out here, before a plane is (not) built.
   int hist_col = -1;
@@ -2072,9 +2100,11 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if (ready) { planes.columns.push_back(ag.column); lw.plane_cols[(size_t)ag.column] = 1; }
     }
   }
+  ctx->pre_enqueued = false;
   ctx->pre_started = false;      // ev[0] is recorded by the first piece of work that precedes the scan kernel (mark_pre_work)
   ctx->ev_last = 3;
   if (out && !want_bitmap) lw.stats_plan = fstats::choose_plan(q, &lw.stats_scan_leaves);
+  if (lw.stats_plan == fstats::Plan::kLeap2 && !g_engine.leap2) lw.stats_plan = fstats::Plan::kReplay;
   lw.cardinality_only_hint = ng == 0 && out && !want_bitmap && na > 0;
   for (int a = 0; a < na; ++a) lw.cardinality_only_hint = lw.cardinality_only_hint && q->aggregations[a].function == PG_AGG_COUNT;
   st = lower_filter(seg, ctx, q, &lw);
@@ -2248,6 +2278,64 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     else if (lw.stats_leap2_flagged) for (int n = 0; n < sp.num_nodes; ++n) sp.nodes[n].flags &= ~kNodeLeapfrog2;      // a kernel without the count runs this query
     sp.raw64_coalesced = g_engine.raw64_coalesced ? 1 : 0;
     if (count_entries && !count_leap2) { st = arm_filter_entries(ctx, &sp.filter_entries); if (st != PG_OK) return st; }
+    // The folded record -> the reference's holder types.  Everything is captured by value: pg_execute_batch calls it after this function
+    // has returned (the query, the segment and the context's pinned counter outlive the batch).
+    const int kernel_id = use_hist ? PG_KERNEL_SCAN_HIST : use_narrow ? PG_KERNEL_SCAN_NARROW : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
+    const unsigned long long* h_filter_entries = ctx->h_filter_entries;
+    const int profile_waves = blocks * (geo.threads / 64);
+    const size_t num_projected = projected.size();
+    auto convert = [q, seg, na, agg_slot_of, lw, kernel_id, h_filter_entries, count_entries, profile_waves, num_projected](const BlockPartial& fp, pg_result* out) {
+      out->num_aggregations = na;
+      out->aggregations = (pg_agg_value*)calloc((size_t)std::max(na, 1), sizeof(pg_agg_value));
+      for (int a = 0; a < na; ++a) {
+        const pg_aggregation& ag = q->aggregations[a];
+        pg_agg_value& v = out->aggregations[a];
+        v.count = (int64_t)fp.count;
+        v.min = std::numeric_limits<double>::infinity();
+        v.max = -std::numeric_limits<double>::infinity();
+        if (ag.function == PG_AGG_COUNT) continue;
+        const int ac = agg_slot_of[(size_t)a];
+        const ColumnDev& col = seg->cols[(size_t)ag.column];
+        const bool plane = lw.plane_cols[(size_t)ag.column] != 0;
+        const bool raw = col.encoding == PG_FWD_RAW_FIXED_BYTE;
+        if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) {
+          if (col.vkind == kValF64 || col.vkind == kValF32) {
+            // SumAggregationFunction on FLOAT / DOUBLE: a double sum; the addition order differs from the reference's
+            // doc order, so the last bits may (tests/test_gpu_typed.py states the tolerance)
+            v.sum = fp.fsum[ac];
+            v.sum_i64 = 0;
+            v.sum_exact = 0;
+          } else if (col.vkind == kValI64) {
+            // LONG values: the int64 sum is exact unless it wrapped, which the double image of the same sum reveals (a wrap moves
+            // it by a multiple of 2^64).  Wrapped: report the double sum, like the reference's double accumulation, inexact.
+            v.sum_i64 = fp.sum[ac];
+            const bool wrapped = std::fabs(fp.fsum[ac] - (double)fp.sum[ac]) > 4.6e18;
+            v.sum_exact = wrapped ? 0 : 1;
+            v.sum = wrapped ? fp.fsum[ac] : (double)v.sum_i64;
+          } else {
+            // value plane: sum(value) = count * base + sum(value - base); offset dictionaries add count * value_base
+            set_integer_sum(&v, (__int128)fp.sum[ac] * (__int128)sum_scale(col, plane) + (__int128)fp.count * (__int128)sum_base(col, plane));
+          }
+        } else if (fp.count > 0) {
+          if (raw && col.vkind != kValI32) {
+            double mn = key64_to_double(col, fp.kmin64[ac]), mx = key64_to_double(col, fp.kmax64[ac]);
+            if (mx != mx) mn = mx;      // Math.min / Math.max propagate NaN
+            if (ag.function == PG_AGG_MIN) v.min = mn;
+            if (ag.function == PG_AGG_MAX) v.max = mx;
+          } else {
+            if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, fp.kmin[ac], plane);
+            if (ag.function == PG_AGG_MAX) v.max = agg_value_double(col, fp.kmax[ac], plane);
+          }
+        }
+      }
+      out->dominant_kernel = kernel_id;
+      for (int c = 0; c < 4; ++c) out->profile_cycles[c] = fp.cyc[c];
+      out->profile_waves = profile_waves;
+      out->stats.num_docs_scanned = (int64_t)fp.count;
+      finish_filter_stats(lw, seg, h_filter_entries, count_entries, out);
+      out->stats.num_entries_scanned_post_filter = (int64_t)fp.count * (int64_t)num_projected;
+      out->stats.num_total_docs = seg->num_docs;
+    };
     // The workgroups' records are folded by the scan kernel's last workgroup, straight into the pinned host record.
     // Measured (profiles/r3, tools/ab_r3.py): the fold costs the kernel 5.5 us of tail on a 1024-workgroup grid where the finalize launch
     // costs 8.8 us (boundary + a one-workgroup kernel); at 10 M rows that is 13 % of the query's device time, at 1 B rows nothing -- there
@@ -2262,6 +2350,17 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     sp.fold_typed = (use_private_typed || (!use_hist && !use_narrow && !use_private && typed)) ? 1 : 0;
     sp.lane_skip = g_engine.lane_skip ? 1 : 0;
     sp.sparse_lanes = g_engine.sparse_lanes;
+    if (defer != nullptr) {
+      if (use_private && !use_hist && !use_narrow && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
+          (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf)) {
+        defer->sp = sp;
+        defer->blocks = blocks;
+        defer->one_slot = pl.num_agg_cols <= 1;
+        defer->convert = convert;
+        defer->planes.reset(new PlaneHold(std::move(planes)));
+        return kDeferred;
+      }
+    }
     // HIP events (PG_CFG_TIME_KERNELS): [ev_first, ev_last] brackets the query's device work, [ev[1], ev[2]] the scan kernel.  Each
     // record is a packet of its own on the queue, so a query that runs nothing but the scan kernel records just the two.
     const bool post_work = !g_engine.direct_result || count_entries || want_bitmap;      // (copy commands behind the kernels)
@@ -2325,58 +2424,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       return execute_impl(seg, q, out, d_out_bitmap_request, host_bitmap, host_bitmap_words, out_cardinality, allow_metadata_plan);
     }
     if (out_cardinality) *out_cardinality = (int64_t)fp.count;
-    if (out) {
-      out->num_aggregations = na;
-      out->aggregations = (pg_agg_value*)calloc((size_t)std::max(na, 1), sizeof(pg_agg_value));
-      for (int a = 0; a < na; ++a) {
-        const pg_aggregation& ag = q->aggregations[a];
-        pg_agg_value& v = out->aggregations[a];
-        v.count = (int64_t)fp.count;
-        v.min = std::numeric_limits<double>::infinity();
-        v.max = -std::numeric_limits<double>::infinity();
-        if (ag.function == PG_AGG_COUNT) continue;
-        const int ac = agg_slot_of[(size_t)a];
-        const ColumnDev& col = seg->cols[(size_t)ag.column];
-        const bool plane = lw.plane_cols[(size_t)ag.column] != 0;
-        const bool raw = col.encoding == PG_FWD_RAW_FIXED_BYTE;
-        if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) {
-          if (col.vkind == kValF64 || col.vkind == kValF32) {
-            // SumAggregationFunction on FLOAT / DOUBLE: a double sum; the addition order differs from the reference's
-            // doc order, so the last bits may (tests/test_gpu_typed.py states the tolerance)
-            v.sum = fp.fsum[ac];
-            v.sum_i64 = 0;
-            v.sum_exact = 0;
-          } else if (col.vkind == kValI64) {
-            // LONG values: the int64 sum is exact unless it wrapped, which the double image of the same sum reveals (a wrap moves
-            // it by a multiple of 2^64).  Wrapped: report the double sum, like the reference's double accumulation, inexact.
-            v.sum_i64 = fp.sum[ac];
-            const bool wrapped = std::fabs(fp.fsum[ac] - (double)fp.sum[ac]) > 4.6e18;
-            v.sum_exact = wrapped ? 0 : 1;
-            v.sum = wrapped ? fp.fsum[ac] : (double)v.sum_i64;
-          } else {
-            // value plane: sum(value) = count * base + sum(value - base); offset dictionaries add count * value_base
-            set_integer_sum(&v, (__int128)fp.sum[ac] * (__int128)sum_scale(col, plane) + (__int128)fp.count * (__int128)sum_base(col, plane));
-          }
-        } else if (fp.count > 0) {
-          if (raw && col.vkind != kValI32) {
-            double mn = key64_to_double(col, fp.kmin64[ac]), mx = key64_to_double(col, fp.kmax64[ac]);
-            if (mx != mx) mn = mx;      // Math.min / Math.max propagate NaN
-            if (ag.function == PG_AGG_MIN) v.min = mn;
-            if (ag.function == PG_AGG_MAX) v.max = mx;
-          } else {
-            if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, fp.kmin[ac], plane);
-            if (ag.function == PG_AGG_MAX) v.max = agg_value_double(col, fp.kmax[ac], plane);
-          }
-        }
-      }
-      out->dominant_kernel = use_hist ? PG_KERNEL_SCAN_HIST : use_narrow ? PG_KERNEL_SCAN_NARROW : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
-      for (int c = 0; c < 4; ++c) out->profile_cycles[c] = fp.cyc[c];
-      out->profile_waves = blocks * (geo.threads / 64);
-      out->stats.num_docs_scanned = (int64_t)fp.count;
-      finish_filter_stats(lw, seg, ctx, count_entries, out);
-      out->stats.num_entries_scanned_post_filter = (int64_t)fp.count * (int64_t)projected.size();
-      out->stats.num_total_docs = seg->num_docs;
-    }
+    if (out) convert(fp, out);
   } else {
     // ---------------- group-by (ArrayBasedHolder) ----------------
     GroupParams gp;
@@ -2808,7 +2856,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       for (auto& w : workers) w.join();
     }
     out->stats.num_docs_scanned = docs;
-    finish_filter_stats(lw, seg, ctx, count_entries, out);
+    finish_filter_stats(lw, seg, ctx->h_filter_entries, count_entries, out);
     out->stats.num_entries_scanned_post_filter = docs * (int64_t)projected.size();
     out->stats.num_total_docs = seg->num_docs;
   }
@@ -3127,15 +3175,243 @@ static pg_status replay_filter_stats(pg_segment* seg, const pg_query* q, pg_resu
   return PG_OK;
 }
 
-pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_result) {
+// pg_execute, or -- with `defer` -- its first half: kDeferred means the query was lowered but not launched (see Deferred).
+static pg_status execute_one(pg_segment* segment, const pg_query* query, pg_result* out_result, Deferred* defer) {
   if (!out_result) return fail(PG_ERR_INVALID_ARGUMENT, "null result");
   memset(out_result, 0, sizeof(*out_result));     // before anything can fail: every error path below ends in pg_result_free(out_result)
   const bool null_handling = query && (query->flags & PG_QUERY_NULL_HANDLING);
-  pg_status st = null_handling ? execute_null_handling(segment, query, out_result, nullptr, 0, nullptr) : execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr);
+  pg_status st = null_handling ? execute_null_handling(segment, query, out_result, nullptr, 0, nullptr)
+                               : execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr, true, defer);
+  if (st == kDeferred) return st;
   // (enableNullHandling changes the iterator tree -- nulls are or-ed in, NOT takes the falses: the upper bound stands there)
   if (st == PG_OK && !null_handling && !out_result->filter_entries_exact && (int64_t)segment->num_docs <= g_engine.exact_stats_docs) st = replay_filter_stats(segment, query, out_result);
   if (st != PG_OK) pg_result_free(out_result);
   return st;
+}
+
+pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_result) { return execute_one(segment, query, out_result, nullptr); }
+
+// ---- pg_execute_batch ----
+namespace {
+
+// Worker threads of the library: lowering (and, for queries that cannot share the batch launch, running) the items of a batch side by
+// side.  Started on first use, parked on a condition variable in between.
+struct WorkerPool {
+  std::mutex mu;
+  std::condition_variable wake, done;
+  std::vector<std::thread> threads;
+  std::function<void(int)> job;        // job(item)
+  int next = 0, count = 0, running = 0;
+  unsigned long long generation = 0;
+  bool stop = false;
+
+  void worker() {
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      wake.wait(lk, [&] { return stop || (generation != seen && next < count); });
+      if (stop) return;
+      seen = generation;
+      ++running;
+      while (next < count) {
+        const int item = next++;
+        lk.unlock();
+        job(item);
+        lk.lock();
+      }
+      if (--running == 0) done.notify_all();
+    }
+  }
+  // Runs job(0 .. n) on the pool and the calling thread; returns when all are done.
+  void run(int n, int max_threads, std::function<void(int)> fn) {
+    std::unique_lock<std::mutex> lk(mu);
+    const int want = std::max(0, std::min(max_threads, n) - 1);
+    while ((int)threads.size() < want) threads.emplace_back([this] { worker(); });
+    job = std::move(fn);
+    next = 0; count = n;
+    ++generation;
+    ++running;
+    wake.notify_all();
+    while (next < count) {
+      const int item = next++;
+      lk.unlock();
+      job(item);
+      lk.lock();
+    }
+    --running;
+    done.wait(lk, [&] { return running == 0; });
+    count = 0;
+  }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    wake.notify_all();
+    for (auto& t : threads) t.join();
+  }
+};
+WorkerPool g_pool;
+std::mutex g_batch_call_mu;              // one batch at a time uses the pool (a second caller waits its turn)
+
+// Device-side state of one batch launch, reused from call to call.
+struct BatchCtx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  ScanParams* h_items = nullptr; ScanParams* d_items = nullptr;          // pinned staging / device copy of the items' kernel parameters
+  uint32_t* h_first = nullptr; uint32_t* d_first = nullptr;
+  HostRecord* h_records = nullptr; HostRecord* h_records_dev = nullptr;  // pinned, device-mapped: one folded record per item
+  uint32_t* d_done = nullptr;                                            // kFoldShards + 1 arrival counters per item
+  BlockPartial* d_partials = nullptr;
+  int item_capacity = 0;
+  size_t partial_capacity = 0;
+  unsigned long long seq = 0;
+};
+std::mutex g_batch_mu;
+std::vector<BatchCtx*> g_batch_free;
+
+void destroy_batch_ctx(BatchCtx* b) {
+  if (!b) return;
+  if (b->h_items) (void)hipHostFree(b->h_items);
+  if (b->d_items) (void)hipFree(b->d_items);
+  if (b->h_first) (void)hipHostFree(b->h_first);
+  if (b->d_first) (void)hipFree(b->d_first);
+  if (b->h_records) (void)hipHostFree(b->h_records);
+  if (b->d_done) (void)hipFree(b->d_done);
+  if (b->d_partials) (void)hipFree(b->d_partials);
+  for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+}
+
+pg_status ensure_batch_ctx(BatchCtx* b, int items, size_t partials) {
+  if (!b->stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
+  }
+  if (b->item_capacity < items) {
+    const int cap = std::max(items, 64);
+    if (b->h_items) (void)hipHostFree(b->h_items);
+    if (b->d_items) (void)hipFree(b->d_items);
+    if (b->h_first) (void)hipHostFree(b->h_first);
+    if (b->d_first) (void)hipFree(b->d_first);
+    if (b->h_records) (void)hipHostFree(b->h_records);
+    if (b->d_done) (void)hipFree(b->d_done);
+    b->h_items = nullptr; b->d_items = nullptr; b->h_first = nullptr; b->d_first = nullptr; b->h_records = nullptr; b->d_done = nullptr; b->item_capacity = 0;
+    HIP_TRY(hipHostMalloc((void**)&b->h_items, sizeof(ScanParams) * (size_t)cap, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&b->d_items, sizeof(ScanParams) * (size_t)cap));
+    HIP_TRY(hipHostMalloc((void**)&b->h_first, 4 * (size_t)(cap + 1), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&b->d_first, 4 * (size_t)(cap + 1)));
+    HIP_TRY(hipHostMalloc((void**)&b->h_records, sizeof(HostRecord) * (size_t)cap, hipHostMallocMapped));
+    memset(b->h_records, 0, sizeof(HostRecord) * (size_t)cap);
+    HIP_TRY(hipHostGetDevicePointer((void**)&b->h_records_dev, b->h_records, 0));
+    HIP_TRY(hipMalloc((void**)&b->d_done, (size_t)cap * (kFoldShards + 1) * kFoldStride * 4));
+    HIP_TRY(hipMemset(b->d_done, 0, (size_t)cap * (kFoldShards + 1) * kFoldStride * 4));
+    b->item_capacity = cap;
+  }
+  if (b->partial_capacity < partials) {
+    if (b->d_partials) (void)hipFree(b->d_partials);
+    b->d_partials = nullptr; b->partial_capacity = 0;
+    HIP_TRY(hipMalloc((void**)&b->d_partials, sizeof(BlockPartial) * partials));
+    b->partial_capacity = partials;
+  }
+  return PG_OK;
+}
+
+// The deferred items of one device: one launch, every item folding into its own pinned record.
+pg_status run_deferred(int device, const std::vector<int>& items, std::vector<Deferred>& defs, pg_segment* const* segments, pg_result* results, pg_status* statuses) {
+  HIP_TRY(hipSetDevice(device));
+  BatchCtx* b = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_batch_mu);
+    for (size_t i = 0; i < g_batch_free.size(); ++i) if (g_batch_free[i]->device == device) { b = g_batch_free[i]; g_batch_free.erase(g_batch_free.begin() + (long)i); break; }
+  }
+  if (!b) { b = new BatchCtx(); b->device = device; }
+  struct Return { BatchCtx* b; ~Return() { std::lock_guard<std::mutex> lk(g_batch_mu); g_batch_free.push_back(b); } } give_back{b};
+  const int n = (int)items.size();
+  // Workgroups per item in proportion to its tiles, about sixteen per CU in total (four waves each: ~4x what is resident, so that
+  // the items' tails overlap other items' scans); never more than the item would get on its own.
+  long long total_tiles = 0;
+  for (int i : items) total_tiles += ((long long)segments[i]->num_docs + 2047) / 2048;
+  const long long budget = (long long)segments[items[0]]->num_cus * 16;
+  std::vector<int> blocks((size_t)n);
+  size_t partials = 0;
+  long long total_blocks = 0;
+  bool one_slot = true;
+  for (int k = 0; k < n; ++k) {
+    const Deferred& d = defs[(size_t)items[(size_t)k]];
+    const long long tiles = ((long long)segments[items[(size_t)k]]->num_docs + 2047) / 2048;
+    const long long share = total_tiles > 0 ? (tiles * budget + total_tiles - 1) / total_tiles : 1;
+    blocks[(size_t)k] = (int)std::max<long long>(1, std::min<long long>({(long long)d.blocks, share, (tiles + 3) / 4}));
+    partials += (size_t)blocks[(size_t)k] + 1;
+    total_blocks += blocks[(size_t)k];
+    one_slot = one_slot && d.one_slot;
+  }
+  pg_status st = ensure_batch_ctx(b, n, partials);
+  if (st != PG_OK) return st;
+  size_t off = 0;
+  uint32_t first = 0;
+  const unsigned long long seq = ++b->seq;
+  for (int k = 0; k < n; ++k) {
+    ScanParams sp = defs[(size_t)items[(size_t)k]].sp;
+    sp.partials = b->d_partials + off;
+    off += (size_t)blocks[(size_t)k] + 1;
+    sp.done_counter = b->d_done + (size_t)k * (kFoldShards + 1) * kFoldStride;
+    sp.host_out = b->h_records_dev + k;
+    sp.host_seq = seq;
+    b->h_items[k] = sp;
+    b->h_first[k] = first;
+    first += (uint32_t)blocks[(size_t)k];
+  }
+  b->h_first[n] = first;
+  const bool timed = (g_engine.flags & PG_CFG_TIME_KERNELS) != 0;
+  HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, sizeof(ScanParams) * (size_t)n, hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(b->d_first, b->h_first, 4 * (size_t)(n + 1), hipMemcpyHostToDevice, b->stream));
+  if (timed) HIP_TRY(hipEventRecord(b->ev[0], b->stream));
+  launch_scan_private_batch(one_slot, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
+  HIP_TRY(hipGetLastError());
+  if (timed) HIP_TRY(hipEventRecord(b->ev[1], b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  float ms = 0.f;
+  if (timed) HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
+  for (int k = 0; k < n; ++k) {
+    const int i = items[(size_t)k];
+    if (b->h_records[k].seq != seq) { statuses[i] = fail(PG_ERR_INTERNAL, "batch item %d did not publish its record", i); continue; }
+    defs[(size_t)i].convert(b->h_records[k].partial, &results[i]);
+    results[i].device_ms = ms;                 // the ONE launch all items of the batch share
+    results[i].dominant_kernel_ms = ms;
+    statuses[i] = PG_OK;
+  }
+  return PG_OK;
+}
+
+}  // namespace
+
+pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* queries, int32_t count, pg_result* results, pg_status* statuses) {
+  if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");
+  if (count < 0 || (count > 0 && (!segments || !queries || !results || !statuses))) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
+  for (int i = 0; i < count; ++i) { memset(&results[i], 0, sizeof(pg_result)); statuses[i] = PG_ERR_INVALID_ARGUMENT; }
+  if (count == 0) return PG_OK;
+  std::lock_guard<std::mutex> one_batch(g_batch_call_mu);
+  std::vector<Deferred> defs((size_t)count);
+  std::vector<std::string> errors((size_t)count);
+  // 1. every item is lowered (and, when it cannot share the launch, run on a context of its own) on the library's worker threads
+  const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2));
+  g_pool.run(count, g_engine.batch_launch ? threads : std::min(threads, count), [&](int i) {
+    if (!segments[i] || !queries[i]) { statuses[i] = PG_ERR_INVALID_ARGUMENT; errors[(size_t)i] = "null segment or query"; return; }
+    statuses[i] = execute_one(segments[i], queries[i], &results[i], g_engine.batch_launch ? &defs[(size_t)i] : nullptr);
+    if (statuses[i] != PG_OK && statuses[i] != kDeferred) errors[(size_t)i] = g_error;      // (g_error is the worker's thread-local)
+  });
+  // 2. the deferred items, one launch per device
+  std::vector<int> devices;
+  for (int i = 0; i < count; ++i) if (statuses[i] == kDeferred && std::find(devices.begin(), devices.end(), segments[i]->device) == devices.end()) devices.push_back(segments[i]->device);
+  for (int dev : devices) {
+    std::vector<int> items;
+    for (int i = 0; i < count; ++i) if (statuses[i] == kDeferred && segments[i]->device == dev) items.push_back(i);
+    const pg_status st = run_deferred(dev, items, defs, segments, results, statuses);
+    if (st != PG_OK) for (int i : items) if (statuses[i] == kDeferred) { statuses[i] = st; errors[(size_t)i] = g_error; pg_result_free(&results[i]); }
+  }
+  // pg_last_error of the caller: the first failed item's message
+  for (int i = 0; i < count; ++i) if (statuses[i] != PG_OK) { g_error = "batch item " + std::to_string(i) + ": " + errors[(size_t)i]; break; }
+  return PG_OK;
 }
 
 pg_status pg_segment_plane_bytes(const pg_segment* segment, uint64_t* out_bytes) {

@@ -780,23 +780,26 @@ static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel
 // 128 bytes apart) so that a grid finishing at once does not serialise 1024 atomics on one word; the workgroup completing a shard
 // arrives on the ninth.  `flag` is one dword of LDS the caller provides (scan_hist_kernel keeps its counters as the only static LDS object).
 constexpr int kFoldShards = 8, kFoldStride = 32;      // counters are kFoldStride dwords apart; kFoldShards * kFoldStride is the top counter
-__device__ __forceinline__ void publish_block_partial(const ScanParams& p, BlockPartial* red, int waves_per_block, uint32_t* flag) {
+// `block_index` of `num_blocks`: the workgroup's place among those that work on this ScanParams (the whole grid, or one query's share of
+// a batch launch -- scan_private_batch_kernel).
+__device__ __forceinline__ void publish_block_partial(const ScanParams& p, BlockPartial* red, int waves_per_block, uint32_t* flag, uint32_t block_index,
+                                                      uint32_t num_blocks) {
   if (threadIdx.x == 0) {
     BlockPartial acc = red[0];
     for (int w = 1; w < waves_per_block; ++w) partial_merge(acc, red[w]);
     uint32_t last = 0u;
     if (p.done_counter == nullptr) {
-      p.partials[blockIdx.x] = acc;
+      p.partials[block_index] = acc;
     } else {
       static_assert(sizeof(BlockPartial) % 8 == 0, "stored as 8-byte words");
       const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&acc);
-      unsigned long long* dst = reinterpret_cast<unsigned long long*>(&p.partials[blockIdx.x]);
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(&p.partials[block_index]);
 #pragma unroll
       for (int i = 0; i < (int)(sizeof(BlockPartial) / 8); ++i) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const uint32_t shard = blockIdx.x & (kFoldShards - 1);
-      const uint32_t in_shard = (gridDim.x + (kFoldShards - 1) - shard) / kFoldShards;          // workgroups b with (b & 7) == shard
-      const uint32_t shards = gridDim.x < (uint32_t)kFoldShards ? gridDim.x : (uint32_t)kFoldShards;
+      const uint32_t shard = block_index & (kFoldShards - 1);
+      const uint32_t in_shard = (num_blocks + (kFoldShards - 1) - shard) / kFoldShards;          // workgroups b with (b & 7) == shard
+      const uint32_t shards = num_blocks < (uint32_t)kFoldShards ? num_blocks : (uint32_t)kFoldShards;
       if (__hip_atomic_fetch_add(p.done_counter + shard * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_shard) {
         if (__hip_atomic_fetch_add(p.done_counter + kFoldShards * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == shards) {
           last = 1u;
@@ -808,12 +811,15 @@ __device__ __forceinline__ void publish_block_partial(const ScanParams& p, Block
   }
   __syncthreads();
   if (*flag == 0u) return;
-  const BlockPartial t = fold_partials(p.partials, (int)gridDim.x, red, fold_fields_of(p));
+  const BlockPartial t = fold_partials(p.partials, (int)num_blocks, red, fold_fields_of(p));
   if (threadIdx.x == 0) {
     for (int c = 0; c <= kFoldShards; ++c) __hip_atomic_store(p.done_counter + c * kFoldStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the context's next launch
     if (p.host_out) store_host_record(p.host_out, t, p.host_seq);
-    else p.partials[gridDim.x] = t;
+    else p.partials[num_blocks] = t;
   }
+}
+__device__ __forceinline__ void publish_block_partial(const ScanParams& p, BlockPartial* red, int waves_per_block, uint32_t* flag) {
+  publish_block_partial(p, red, waves_per_block, flag, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1673,14 +1679,14 @@ __device__ __forceinline__ void agg_sparse_private(const uint32_t* __restrict__ 
 #ifndef PG_PRIVATE_WAVES
 #define PG_PRIVATE_WAVES 4      // wavefronts per SIMD the register allocation must allow; 5 and 6 spill in the hot path (measured)
 #endif
+// The kernel's body: workgroup `block_index` of the `num_blocks` that work on `p` (the whole grid in scan_private_kernel; one query's
+// share of the grid in scan_private_batch_kernel, where p is read from device memory).
 template <int kAggSlots>
-__global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_kernel(const ScanParams p) {
-  __shared__ BlockPartial red[kBlockThreads / 64];
-  __shared__ uint32_t fold_flag;
+__device__ __forceinline__ void scan_private_body(const ScanParams& p, const uint32_t block_index, const uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
-  const long long total_waves = (long long)gridDim.x * waves_per_block;
+  const long long total_waves = (long long)num_blocks * waves_per_block;
   const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
 
   unsigned long long count = 0;
@@ -1706,7 +1712,7 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
   uint32_t entries = 0u;                                   // numEntriesScannedInFilter, this lane's share
   const bool listed = p.tile_list != nullptr;
   const long long tile_limit = listed ? (long long)*p.tile_count : num_tiles;
-  for (long long tile_it = (long long)blockIdx.x * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
+  for (long long tile_it = (long long)block_index * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
     const long long tile = listed ? (long long)p.tile_list[tile_it] : tile_it;
     if (fused) {
       const DevNode& L = p.nodes[0];
@@ -1768,7 +1774,38 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
   }
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
-  publish_block_partial(p, red, waves_per_block, &fold_flag);
+  publish_block_partial(p, red, waves_per_block, fold_flag_ptr, block_index, num_blocks);
+}
+
+template <int kAggSlots>
+__global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_kernel(const ScanParams p) {
+  __shared__ BlockPartial red[kBlockThreads / 64];
+  __shared__ uint32_t fold_flag;
+  scan_private_body<kAggSlots>(p, blockIdx.x, gridDim.x, red, &fold_flag);
+}
+
+// Many queries, one launch (pg_execute_batch): workgroups [block_first[i], block_first[i + 1]) work on items[i] -- its own columns,
+// filter program, record buffer, arrival counters and pinned host record, so every query folds and publishes its result on its own
+// while the others are still scanning.  BaseCombineOperator runs a query's segments as tasks of a thread pool
+// (core/operator/combine/BaseCombineOperator.java:85-142); a server holds hundreds of few-million-row segments, each a ~20 us kernel
+// when launched alone -- launch latency, the ramp of an empty chip and its drain are then most of the device time.
+struct BatchParams {
+  const ScanParams* items;           // device memory
+  const uint32_t* block_first;       // [num_items + 1] device memory
+  int32_t num_items;
+  int32_t reserved;
+};
+template <int kAggSlots>
+__global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_batch_kernel(const BatchParams bp) {
+  __shared__ BlockPartial red[kBlockThreads / 64];
+  __shared__ uint32_t fold_flag;
+  int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (bp.block_first[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const uint32_t first = bp.block_first[lo];
+  scan_private_body<kAggSlots>(bp.items[lo], blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
 }
 
 // One 2048-doc tile.  kMasked: only the docs whose bit is set in the lane's mask `m` reach the table (a filter's result, and /

@@ -30,6 +30,8 @@ int waves_scan_agg(bool one_slot, bool typed);
 // scan_private_kernel<slots>: the lane-private scan -> filter -> aggregate kernel
 void launch_scan_private(bool one_slot, int blocks, hipStream_t stream, const ScanParams& p);
 int waves_scan_private(bool one_slot);
+// scan_private_batch_kernel<slots>: many queries in one launch (pg_execute_batch); items / block_first are device memory
+void launch_scan_private_batch(bool one_slot, int total_blocks, hipStream_t stream, const ScanParams* items, const uint32_t* block_first, int num_items);
 // scan_narrow_kernel: COUNT(*) / docId bitmap of a filter over columns of at most 8 bits (pg_scan_narrow.h)
 void launch_scan_narrow(bool single_leaf, int blocks, hipStream_t stream, const ScanParams& p);      // single_leaf: scan_narrow_single_kernel, eight tiles per iteration
 int waves_scan_narrow(bool single_leaf);

@@ -23,6 +23,24 @@ class Engine:
         _abi.check(self.lib, self.lib.pg_device_info(self.device_id, name, 64, C.byref(cus), C.byref(hbm)))
         return name.value.decode(), int(cus.value), int(hbm.value)
 
+    def execute_batch(self, gsegs, specs):
+        """pg_execute_batch: specs[i] over gsegs[i] (the same query lowered per segment).  Returns [(status, Result | None)]."""
+        n = len(gsegs)
+        handles = (C.c_void_p * max(n, 1))(*[g.handle for g in gsegs])
+        queries = (C.POINTER(_abi.pg_query) * max(n, 1))(*[C.pointer(s.c) for s in specs])
+        results = (_abi.pg_result * max(n, 1))()
+        statuses = (C.c_int * max(n, 1))()
+        _abi.check(self.lib, self.lib.pg_execute_batch(handles, queries, n, results, statuses))
+        out = []
+        for i in range(n):
+            out.append((int(statuses[i]), Result(results[i], specs[i]) if statuses[i] == _abi.PG_OK else None))
+            self.lib.pg_result_free(C.byref(results[i]))
+        return out
+
+    def execute_batch_raw(self, handles, queries, n, results, statuses):
+        """Hot-loop variant for bench.py: ctypes arrays prepared by the caller, who frees the results."""
+        return self.lib.pg_execute_batch(handles, queries, n, results, statuses)
+
     def open(self, segment_data):
         handle = C.c_void_p()
         _abi.check(self.lib, self.lib.pg_segment_open(C.byref(segment_data.desc), C.byref(handle)))

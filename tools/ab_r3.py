@@ -24,6 +24,7 @@ SETTINGS = {
     "poll1": {"PINOT_GPU_POLL_RESULT": "1"},
     "fold0_poll1": {"PINOT_GPU_FOLD_FINALIZE": "0", "PINOT_GPU_POLL_RESULT": "1"},
     "laneskip0": {"PINOT_GPU_LANE_SKIP": "0", "PINOT_GPU_SPARSE_LANES": "0"},
+    "leap0": {"PINOT_GPU_LEAP2": "0"},
     "sparse0": {"PINOT_GPU_SPARSE_LANES": "0"},
     "sparse12": {"PINOT_GPU_SPARSE_LANES": "12"},
     "sparse32": {"PINOT_GPU_SPARSE_LANES": "32"},
@@ -80,6 +81,8 @@ def main():
         ("C2b-0.1pct", seg, Q.QuerySpec([(Q.SUM, 0)], filter=fl(1))),
         ("C2b-irr-10pct", seg, Q.QuerySpec([(Q.SUM, 2)], filter=fl(100))),
         ("C2b-irr-1pct", seg, Q.QuerySpec([(Q.SUM, 2)], filter=fl(10))),
+        ("AND2-count", seg, Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(fl(100), Q.leaf(Q.Pred.dict_range(0, 0, 30000))))),
+        ("AND2-sum", seg, Q.QuerySpec([(Q.SUM, 0)], filter=Q.and_(fl(300), Q.leaf(Q.Pred.dict_range(2, 10000, 60000))))),
         ("C2a", seg, Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, 45000, 55000)))),
         ("COUNT-filter", seg, Q.QuerySpec([(Q.COUNT, -1)], filter=fl(100))),
         ("MINMAXAVG", seg, Q.QuerySpec([(Q.MIN, 0), (Q.MAX, 0), (Q.AVG, 0)], filter=fl(100))),
@@ -145,6 +148,8 @@ def main():
                 want = oracle.execute_sliced(sd, ospec)
                 rec["bit_exact_vs_oracle"] = bool(oracle.matches_sliced(got, want, [fn for fn, _ in spec.aggregations]) and got.stats[0] == want["docs_scanned"])
             rec["docs_matched"] = got.stats[0]
+            rec["entries_in_filter"] = got.stats[1]
+            rec["entries_exact"] = got.filter_entries_exact
             print(json.dumps(rec), flush=True)
     for g in opened.values():
         g.close()
