@@ -199,7 +199,7 @@ struct ScanParams {
   int32_t fold_typed;              // 1: fsum / kmin64 / kmax64 are in use (typed kernels)
   int32_t sparse_lanes;            // lane-private aggregating kernels: a tile in which at most this many lanes hold a match is aggregated by walking
   int32_t reserved1;               //   the matches (one 8-byte load per matching doc) instead of decoding every lane's 32 values; 0 = never
-  uint32_t* leap_tables;           // [tiles] kNodeLeapfrog2: one packed summary per 2048-doc tile (leapfrog2_tile), chained by leapfrog2_chain_kernel
+  uint8_t* leap_tables;            // [tiles] kNodeLeapfrog2: one byte per 2048-doc tile (leapfrog2_tile), chained by the leapfrog2_chain_*_kernels
 };
 
 // What a query's scan brings back to the host: the folded record, then a sequence number written after it.

@@ -181,7 +181,8 @@ struct ExecCtx {
   size_t h_groups_capacity = 0;
   unsigned long long* d_filter_entries = nullptr;   // kNodeCountEntries leaves: numEntriesScannedInFilter counted by the lane-private kernels
   unsigned long long* h_filter_entries = nullptr;   // pinned copy
-  uint32_t* d_leap_tables = nullptr;            // kNodeLeapfrog2: one summary per 2048-doc tile (leapfrog2_tile), chained by leapfrog2_chain_kernel
+  uint8_t* d_leap_tables = nullptr;             // kNodeLeapfrog2: one byte per 2048-doc tile (leapfrog2_tile), then one Leap2Summary per 1024 tiles
+  Leap2Summary* d_leap_blocks = nullptr;        //   (leapfrog2_chain_tiles_kernel -> leapfrog2_chain_blocks_kernel)
   size_t leap_capacity = 0;
   WindowInfo* d_window_info = nullptr;          // index_and_kernel: {tile mask, matching docs} of every 65 536-doc window
   size_t tile_list_capacity = 0, window_info_capacity = 0;
@@ -921,18 +922,29 @@ pg_status arm_filter_entries(ExecCtx* ctx, unsigned long long** out_counter) {
 }
 
 // Zeros in every tile index_and_kernel did not store: for the kernels that read the whole bitmap instead of the tile list.
-// kNodeLeapfrog2: the per-tile summaries and the counter leapfrog2_chain_kernel leaves the extra entries in
-pg_status arm_leap_tables(const pg_segment* seg, ExecCtx* ctx, uint32_t** out_tables) {
+// kNodeLeapfrog2: the per-tile bytes, the per-1024-tile summaries, and the (zeroed) entries counter the kernels and the chain add to
+pg_status arm_leap_tables(const pg_segment* seg, ExecCtx* ctx, uint8_t** out_tables, unsigned long long** out_counter) {
   const size_t tiles = (size_t)std::max(seg->num_tiles, 1);
   if (ctx->leap_capacity < tiles) {
     if (ctx->d_leap_tables) (void)hipFree(ctx->d_leap_tables);
-    ctx->d_leap_tables = nullptr; ctx->leap_capacity = 0;
-    HIP_TRY(hipMalloc((void**)&ctx->d_leap_tables, tiles * 4));
+    ctx->d_leap_tables = nullptr; ctx->d_leap_blocks = nullptr; ctx->leap_capacity = 0;
+    const size_t table_bytes = (tiles + 255) & ~(size_t)255;
+    HIP_TRY(hipMalloc((void**)&ctx->d_leap_tables, table_bytes + ((tiles + 1023) / 1024) * sizeof(Leap2Summary)));
+    ctx->d_leap_blocks = reinterpret_cast<Leap2Summary*>(ctx->d_leap_tables + table_bytes);
     ctx->leap_capacity = tiles;
   }
-  if (!ctx->d_filter_entries) HIP_TRY(hipMalloc((void**)&ctx->d_filter_entries, 8));
-  if (!ctx->h_filter_entries) HIP_TRY(hipHostMalloc((void**)&ctx->h_filter_entries, 8, hipHostMallocDefault));
   *out_tables = ctx->d_leap_tables;
+  return arm_filter_entries(ctx, out_counter);
+}
+
+// behind the scan kernel: the entry states of the tiles, chained in tile order, decide which tiles' corrections count
+pg_status launch_leap_chain(const pg_segment* seg, ExecCtx* ctx) {
+  const long long tiles = ((long long)seg->num_docs + 2047) / 2048;
+  const int blocks = (int)std::max<long long>(1, (tiles + 1023) / 1024);
+  leapfrog2_chain_tiles_kernel<<<dim3((unsigned)blocks), dim3(1024), 0, ctx->stream>>>(ctx->d_leap_tables, tiles, ctx->d_leap_blocks);
+  HIP_TRY(hipGetLastError());
+  leapfrog2_chain_blocks_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(ctx->d_leap_blocks, blocks, ctx->d_filter_entries);
+  HIP_TRY(hipGetLastError());
   return PG_OK;
 }
 
@@ -2274,7 +2286,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const bool count_entries = (out && lw.stats_chain_flagged && (use_hist || use_private || use_private_typed)) || count_leap2;
     sp.filter_entries = nullptr;
     sp.leap_tables = nullptr;
-    if (count_leap2) { st = arm_leap_tables(seg, ctx, &sp.leap_tables); if (st != PG_OK) return st; }
+    if (count_leap2) { st = arm_leap_tables(seg, ctx, &sp.leap_tables, &sp.filter_entries); if (st != PG_OK) return st; }
     else if (lw.stats_leap2_flagged) for (int n = 0; n < sp.num_nodes; ++n) sp.nodes[n].flags &= ~kNodeLeapfrog2;      // a kernel without the count runs this query
     sp.raw64_coalesced = g_engine.raw64_coalesced ? 1 : 0;
     if (count_entries && !count_leap2) { st = arm_filter_entries(ctx, &sp.filter_entries); if (st != PG_OK) return st; }
@@ -2380,11 +2392,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       HIP_TRY(hipGetLastError());
     }
     if (!g_engine.direct_result) HIP_TRY(hipMemcpyAsync(ctx->h_partial, ctx->d_partials + blocks, sizeof(BlockPartial), hipMemcpyDeviceToHost, ctx->stream));
-    if (count_leap2) {
-      // the tiles' summaries chained in tile order: one small workgroup behind the scan kernel
-      leapfrog2_chain_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(sp.leap_tables, ((long long)seg->num_docs + 2047) / 2048, ctx->d_filter_entries);
-      HIP_TRY(hipGetLastError());
-    }
+    if (count_leap2) { st = launch_leap_chain(seg, ctx); if (st != PG_OK) return st; }
     if (count_entries) HIP_TRY(hipMemcpyAsync(ctx->h_filter_entries, ctx->d_filter_entries, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (want_bitmap) {
       const int64_t need = ((int64_t)seg->num_docs + 63) / 64;
@@ -2584,7 +2592,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const bool count_leap2 = out && lw.stats_leap2_flagged && ((use_private && !use_partition) || typed_direct);
     const bool count_entries = (out && lw.stats_chain_flagged && ((use_private && !use_partition) || typed_direct)) || count_leap2;
     gp.scan.leap_tables = nullptr;
-    if (count_leap2) { st = arm_leap_tables(seg, ctx, &gp.scan.leap_tables); if (st != PG_OK) return st; }
+    if (count_leap2) { st = arm_leap_tables(seg, ctx, &gp.scan.leap_tables, &gp.scan.filter_entries); if (st != PG_OK) return st; }
     else if (lw.stats_leap2_flagged) for (int n = 0; n < gp.scan.num_nodes; ++n) gp.scan.nodes[n].flags &= ~kNodeLeapfrog2;
     if (count_entries && !count_leap2) { st = arm_filter_entries(ctx, &gp.scan.filter_entries); if (st != PG_OK) return st; }
     if (use_partition) {
@@ -2673,10 +2681,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     else launch_scan_group(g_engine.use_dma, gp.use_lds_table != 0, blocks, geo.threads, lds, ctx->stream, gp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-    if (count_leap2) {
-      leapfrog2_chain_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(gp.scan.leap_tables, ((long long)seg->num_docs + 2047) / 2048, ctx->d_filter_entries);
-      HIP_TRY(hipGetLastError());
-    }
+    if (count_leap2) { st = launch_leap_chain(seg, ctx); if (st != PG_OK) return st; }
     if (count_entries) HIP_TRY(hipMemcpyAsync(ctx->h_filter_entries, ctx->d_filter_entries, 8, hipMemcpyDeviceToHost, ctx->stream));
     // The groups that exist, in ascending raw-key order: (raw key, doc count, accumulators[a * num_present + k]).
     std::vector<int32_t> present_ids;

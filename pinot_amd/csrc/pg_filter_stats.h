@@ -364,7 +364,7 @@ enum class Plan {
   kChain,         // root AND of plain leaves with an index-based child: counted by the lane-private kernels (kNodeCountEntries)
   kReplay,        // the iterator walk below
   kLeap2          // root AND of exactly two scan leaves: the leap-frog of AndDocIdIterator over two SVScanDocIdIterators, counted by the
-                  // lane-private kernels as a two-state carry chain (kNodeLeapfrog2, leapfrog2_tile in pg_kernels.h)
+                  // lane-private kernels as a two-state carry chain (kNodeLeapfrog2, leapfrog2_tile / leapfrog2_chain_*_kernel in pg_kernels.h)
 };
 
 inline bool malformed(const pg_query* q) {

@@ -1493,11 +1493,13 @@ __device__ __forceinline__ uint32_t eval_leaf_private(const ScanParams& p, const
 //     (0, 1): s := 0, extra entry iff s was 1       (1, 1): s := 0, extra entry either way
 // so s is the carry of a binary addition with generate = a & ~b and propagate = ~(a | b): ONE 64-bit add per lane gives the state before
 // each of its 32 docs, one 64-bit scalar add over the wave's ballots gives every lane's carry-in, and three popcounts give the entries.
-// Tiles are dealt round-robin, so a tile does not know the state it is entered in: it is summarised for entry state 0 plus what changes
-// for entry state 1 (only the docs before the tile's first event can tell: delta in {-1, 0, +1}), and leapfrog2_chain_kernel chains
-// the summaries in tile order.  ~40 instructions per 2048 docs next to the ~230 the two leaves cost.
-//     summary = extra entries (entry state 0) | (delta + 1) << 16 | (state after the tile, entered in 0) << 18 | (tile has no event) << 19
-__device__ __forceinline__ void leapfrog2_tile(const ScanParams& p, long long tile, int lane, uint32_t a, uint32_t b) {
+// Tiles are dealt round-robin, so a tile does not know the state it is entered in: its extra entries are counted for entry state 0
+// (into the lane's `entries`, reduced once per wave at the end like the kNodeCountEntries count) and ONE byte per tile records what the
+// chain needs: delta in {-1, 0, +1} = what entry state 1 would change (only the docs before the tile's first event can tell), the
+// state after the tile, and whether the tile has no event at all.  leapfrog2_chain_kernels add the sum of delta over the tiles that are
+// entered in state 1.  ~30 vector + ~15 scalar instructions per 2048 docs next to the ~230 the two leaves cost.
+//     byte = (delta + 1) | (state after the tile, entered in 0) << 2 | (tile has no event) << 3
+__device__ __forceinline__ void leapfrog2_tile(const ScanParams& p, long long tile, int lane, uint32_t a, uint32_t b, uint32_t& entries) {
   const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
   const uint32_t valid = rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));      // docs past numDocs are not there
   a &= valid; b &= valid;
@@ -1508,10 +1510,7 @@ __device__ __forceinline__ void leapfrog2_tile(const ScanParams& p, long long ti
   const bool tile_carry = __builtin_uaddll_overflow(Gm | Pm, Gm, &wsum);
   const uint32_t cin = (uint32_t)((wsum ^ Pm) >> lane) & 1u;                // the lane is entered in state 1 (the tile in state 0)
   const uint32_t S = (uint32_t)(sum0 + cin) ^ prop;                         // state before each of the lane's docs
-  const uint32_t extra = (uint32_t)(__builtin_popcount(T) + __builtin_popcount(X & ~S) + __builtin_popcount(Y & S));
-  uint32_t cost0 = extra;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) cost0 += (uint32_t)__shfl_xor((int)cost0, o, 64);
+  entries += (uint32_t)(__builtin_popcount(T) + __builtin_popcount(X & ~S) + __builtin_popcount(Y & S));
   int delta = 0;
   const unsigned long long with_events = ~Pm;
   if (with_events != 0ull) {
@@ -1521,35 +1520,60 @@ __device__ __forceinline__ void leapfrog2_tile(const ScanParams& p, long long ti
     const int bit = __builtin_ctz(Ef);
     delta = (int)((Yf >> bit) & 1u) - (int)((Xf >> bit) & 1u);
   }
-  if (lane == 0) p.leap_tables[tile] = cost0 | ((uint32_t)(delta + 1) << 16) | ((tile_carry ? 1u : 0u) << 18) | ((with_events == 0ull ? 1u : 0u) << 19);
+  if (lane == 0) p.leap_tables[tile] = (uint8_t)((uint32_t)(delta + 1) | ((tile_carry ? 1u : 0u) << 2) | ((with_events == 0ull ? 1u : 0u) << 3));
 }
 
-// Chains the tile summaries of leapfrog2_tile in tile order (entry state 0 at doc 0): one workgroup, every thread a contiguous run of
-// tiles, thread 0 the threads' summaries.  *out = the extra entries of the whole segment (numEntriesScannedInFilter - numDocs).
-struct Leap2Summary { unsigned long long cost; int delta; uint32_t g, p; };
-// `cur` followed by a piece summarised as (c0, d, g, pp)
-__device__ __forceinline__ void leap2_append(Leap2Summary& cur, unsigned long long c0, int d, uint32_t g, uint32_t pp) {
-  cur.cost += c0 + (cur.g ? (long long)d : 0ll);      // the piece is entered in state cur.g (the run was entered in 0) ...
-  cur.delta += cur.p ? d : 0;                          // ... or in 1 instead, if the run was and nothing has happened in it yet
-  cur.g = g | (pp & cur.g);
-  cur.p &= pp;
+// The chain: sum over the tiles of [tile entered in state 1] * delta(tile), the entry states being the carries of (generate, propagate)
+// = (state after, no event) in tile order, entry state 0 at doc 0.  The same carry trick one level up: a wavefront takes 64 consecutive
+// pieces, their generate / propagate ballots and ONE 64-bit add give every piece's entry state; the wave's own summary
+//     {sum (entered in 0), delta (what entering in 1 adds: only pieces before the first event can tell), state after, no event}
+// is a piece of the next level.  Level 1: a workgroup of 16 waves per 1024 tiles (leapfrog2_chain_tiles_kernel); level 2: one workgroup
+// over the <= 1024 workgroup summaries (a segment has < 2^31 docs = 2^20 tiles), which adds the result to the entries counter.
+struct Leap2Summary { long long sum; int delta; uint32_t g, p; };
+__device__ __forceinline__ Leap2Summary leap2_wave(long long sum, int delta, uint32_t g, uint32_t pp, int lane) {
+  const unsigned long long Gm = __builtin_amdgcn_ballot_w64(g != 0u), Pm = __builtin_amdgcn_ballot_w64(pp != 0u);
+  unsigned long long wsum;
+  const bool carry = __builtin_uaddll_overflow(Gm | Pm, Gm, &wsum);
+  const bool entered_in_1 = (((wsum ^ Pm) >> lane) & 1ull) != 0ull;
+  long long mine = sum + (entered_in_1 ? (long long)delta : 0ll);
+  mine = wave_sum_i64(mine);
+  int wave_delta = 0;
+  const unsigned long long with_events = ~Pm;
+  if (with_events != 0ull) wave_delta = __builtin_amdgcn_readlane(delta, __builtin_ctzll(with_events));      // pieces before it have delta 0 (no event)
+  return Leap2Summary{mine, wave_delta, carry ? 1u : 0u, with_events == 0ull ? 1u : 0u};
 }
-static __global__ __launch_bounds__(1024) void leapfrog2_chain_kernel(const uint32_t* __restrict__ tables, long long num_tiles, unsigned long long* out) {
-  __shared__ Leap2Summary part[1024];
-  const long long per = (num_tiles + blockDim.x - 1) / blockDim.x;
-  const long long begin = (long long)threadIdx.x * per, end = begin + per < num_tiles ? begin + per : num_tiles;
-  Leap2Summary cur{0ull, 0, 0u, 1u};
-  for (long long t = begin; t < end; ++t) {
-    const uint32_t e = tables[t];
-    leap2_append(cur, e & 0xFFFFu, (int)((e >> 16) & 3u) - 1, (e >> 18) & 1u, (e >> 19) & 1u);
-  }
-  part[threadIdx.x] = cur;
+// thread 0 chains the waves' summaries of its workgroup (in wave order)
+__device__ __forceinline__ Leap2Summary leap2_block(const Leap2Summary w, Leap2Summary* part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) part[wave] = w;
   __syncthreads();
+  Leap2Summary all{0ll, 0, 0u, 1u};
   if (threadIdx.x == 0) {
-    Leap2Summary all{0ull, 0, 0u, 1u};
-    for (int i = 0; i < (int)blockDim.x; ++i) leap2_append(all, part[i].cost, part[i].delta, part[i].g, part[i].p);
-    *out = all.cost;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
+      const Leap2Summary s = part[i];
+      all.sum += s.sum + (all.g ? (long long)s.delta : 0ll);
+      all.delta += all.p ? s.delta : 0;
+      all.g = s.g | (s.p & all.g);
+      all.p &= s.p;
+    }
   }
+  return all;
+}
+static __global__ __launch_bounds__(1024) void leapfrog2_chain_tiles_kernel(const uint8_t* __restrict__ tables, long long num_tiles, Leap2Summary* __restrict__ block_out) {
+  __shared__ Leap2Summary part[16];
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t e = t < num_tiles ? (uint32_t)tables[t] : 0x9u;           // past the end: delta 0, no event
+  const Leap2Summary w = leap2_wave(0ll, (int)(e & 3u) - 1, (e >> 2) & 1u, (e >> 3) & 1u, threadIdx.x & 63);
+  const Leap2Summary all = leap2_block(w, part);
+  if (threadIdx.x == 0) block_out[blockIdx.x] = all;
+}
+static __global__ __launch_bounds__(1024) void leapfrog2_chain_blocks_kernel(const Leap2Summary* __restrict__ blocks, int num_blocks, unsigned long long* entries) {
+  __shared__ Leap2Summary part[16];
+  Leap2Summary in{0ll, 0, 0u, 1u};
+  if ((int)threadIdx.x < num_blocks) in = blocks[threadIdx.x];
+  const Leap2Summary w = leap2_wave(in.sum, in.delta, in.g, in.p, threadIdx.x & 63);
+  const Leap2Summary all = leap2_block(w, part);
+  if (threadIdx.x == 0 && all.sum != 0ll) atomicAdd(entries, (unsigned long long)all.sum);      // (the segment is entered in state 0; a negative sum wraps the unsigned counter the right way)
 }
 
 // `entries`: per-lane share of numEntriesScannedInFilter -- a kNodeCountEntries leaf is a scan-based child of the root AND that the
@@ -1575,7 +1599,7 @@ __device__ __forceinline__ uint32_t eval_filter_private(const ScanParams& p, lon
       top = ~st.pop();
     } else {
       top = st.pop();
-      if (nd.flags & kNodeLeapfrog2) leapfrog2_tile(p, tile, lane, st.v[0], top);      // the root AND of two leaves: child 0 is the stack's only entry, child 1 was on top
+      if (nd.flags & kNodeLeapfrog2) leapfrog2_tile(p, tile, lane, st.v[0], top, entries);      // the root AND of two leaves: child 0 is the stack's only entry, child 1 was on top
       for (int c = 1; c < nd.num_children; ++c) {
         const uint32_t o = st.pop();
         top = nd.op == PG_FILTER_AND ? (top & o) : (top | o);
