@@ -148,6 +148,7 @@ struct BlockPartial {
   int32_t kmax[kMaxAggCols];
   unsigned long long cyc[4];   // PG_CFG_PROFILE_WAVES: shader cycles per wave summed: memory wait, filter, aggregate, whole loop
   unsigned long long flags;    // OR over the workgroups: kPartialHistAlarm (pg_scan_hist.h) = a histogram counter may have left its field
+  unsigned long long entries;  // numEntriesScannedInFilter counted by the kernel: applyAnd entries of kNodeCountEntries leaves / the extra entries of kNodeLeapfrog2
   // typed columns only (scan_agg_kernel<.., kTyped = true>): double sums, and 64-bit min / max keys (raw LONG value, or the
   // order-preserving integer image of a raw FLOAT / DOUBLE value)
   double fsum[kMaxAggCols];
@@ -206,7 +207,9 @@ struct ScanParams {
 struct HostRecord {
   BlockPartial partial;
   unsigned long long seq;
-  unsigned long long pad[7];
+  long long leap_correction;        // kNodeLeapfrog2: what leapfrog2_chain_kernel found (sum of delta over the tiles entered in state 1) ...
+  unsigned long long leap_seq;      // ... and the sequence number it stored after it
+  unsigned long long pad[4];
 };
 
 // Host-side plan (what lower_filter / execute build before it is flattened into ScanParams).

@@ -253,8 +253,8 @@ pg_status acquire_ctx(pg_segment* seg, ExecCtx** out) {
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_record, sizeof(HostRecord), hipHostMallocMapped);
   if (e == hipSuccess) { memset(c->h_record, 0, sizeof(HostRecord)); c->h_partial = &c->h_record->partial; }
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->h_record_dev, c->h_record, 0);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_done, 9 * 128);
-  if (e == hipSuccess) e = hipMemset(c->d_done, 0, 9 * 128);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_done, 10 * 128);      // fold: eight shards + the top counter; leapfrog2_chain_kernel: one more
+  if (e == hipSuccess) e = hipMemset(c->d_done, 0, 10 * 128);
   if (e != hipSuccess) {
     destroy_ctx(c);
     return fail(PG_ERR_DEVICE, "creating execution context failed: %s", hipGetErrorString(e));
@@ -923,7 +923,7 @@ pg_status arm_filter_entries(ExecCtx* ctx, unsigned long long** out_counter) {
 
 // Zeros in every tile index_and_kernel did not store: for the kernels that read the whole bitmap instead of the tile list.
 // kNodeLeapfrog2: the per-tile bytes, the per-1024-tile summaries, and the (zeroed) entries counter the kernels and the chain add to
-pg_status arm_leap_tables(const pg_segment* seg, ExecCtx* ctx, uint8_t** out_tables, unsigned long long** out_counter) {
+pg_status arm_leap_tables(const pg_segment* seg, ExecCtx* ctx, uint8_t** out_tables, unsigned long long** out_counter /* nullptr: the scan kernel's record carries the count */) {
   const size_t tiles = (size_t)std::max(seg->num_tiles, 1);
   if (ctx->leap_capacity < tiles) {
     if (ctx->d_leap_tables) (void)hipFree(ctx->d_leap_tables);
@@ -934,16 +934,16 @@ pg_status arm_leap_tables(const pg_segment* seg, ExecCtx* ctx, uint8_t** out_tab
     ctx->leap_capacity = tiles;
   }
   *out_tables = ctx->d_leap_tables;
-  return arm_filter_entries(ctx, out_counter);
+  return out_counter ? arm_filter_entries(ctx, out_counter) : PG_OK;
 }
 
-// behind the scan kernel: the entry states of the tiles, chained in tile order, decide which tiles' corrections count
-pg_status launch_leap_chain(const pg_segment* seg, ExecCtx* ctx) {
+// behind the scan kernel: the entry states of the tiles, chained in tile order, decide which tiles' corrections count.  The result goes
+// into the context's pinned record (host_seq != 0: aggregation queries) or onto the device counter (group-by queries).
+pg_status launch_leap_chain(const pg_segment* seg, ExecCtx* ctx, unsigned long long host_seq) {
   const long long tiles = ((long long)seg->num_docs + 2047) / 2048;
   const int blocks = (int)std::max<long long>(1, (tiles + 1023) / 1024);
-  leapfrog2_chain_tiles_kernel<<<dim3((unsigned)blocks), dim3(1024), 0, ctx->stream>>>(ctx->d_leap_tables, tiles, ctx->d_leap_blocks);
-  HIP_TRY(hipGetLastError());
-  leapfrog2_chain_blocks_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(ctx->d_leap_blocks, blocks, ctx->d_filter_entries);
+  leapfrog2_chain_kernel<<<dim3((unsigned)blocks), dim3(1024), 0, ctx->stream>>>(ctx->d_leap_tables, tiles, ctx->d_leap_blocks, ctx->d_done + (kFoldShards + 1) * kFoldStride,
+                                                                                  host_seq ? ctx->h_record_dev : nullptr, host_seq, host_seq ? nullptr : ctx->d_filter_entries);
   HIP_TRY(hipGetLastError());
   return PG_OK;
 }
@@ -1976,17 +1976,17 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
 
 // ExecutionStatistics.numEntriesScannedInFilter from the plan pg_filter_stats.h chose; `counted`: the kernel that ran carried the
 // kNodeCountEntries counter (its value has been copied to ctx->h_filter_entries and the stream is idle).
-static void finish_filter_stats(const Lowered& lw, const pg_segment* seg, const unsigned long long* h_filter_entries, bool counted, pg_result* out) {
+static void finish_filter_stats(const Lowered& lw, const pg_segment* seg, int64_t counted_entries, bool counted, pg_result* out) {
   const int64_t upper_bound = (int64_t)lw.stats_scan_leaves * seg->num_docs;      // every scan leaf looking at every doc
   switch (lw.stats_plan) {
     case fstats::Plan::kZero: out->stats.num_entries_scanned_in_filter = 0; out->filter_entries_exact = 1; break;
     case fstats::Plan::kPerLeaf: out->stats.num_entries_scanned_in_filter = upper_bound; out->filter_entries_exact = 1; break;
     case fstats::Plan::kLeap2:
       // one entry per doc for whichever leaf is scanning there, plus the device's count of the docs where the other leaf was asked
-      if (counted) { out->stats.num_entries_scanned_in_filter = (int64_t)seg->num_docs + (int64_t)*h_filter_entries; out->filter_entries_exact = 1; break; }
+      if (counted) { out->stats.num_entries_scanned_in_filter = (int64_t)seg->num_docs + counted_entries; out->filter_entries_exact = 1; break; }
       out->stats.num_entries_scanned_in_filter = upper_bound; out->filter_entries_exact = 0; break;
     case fstats::Plan::kChain:
-      if (counted) { out->stats.num_entries_scanned_in_filter = (int64_t)*h_filter_entries; out->filter_entries_exact = 1; break; }
+      if (counted) { out->stats.num_entries_scanned_in_filter = counted_entries; out->filter_entries_exact = 1; break; }
       [[fallthrough]];                                                            // an LDS-staged kernel ran: replayed by pg_execute
     default: out->stats.num_entries_scanned_in_filter = upper_bound; out->filter_entries_exact = 0; break;
   }
@@ -2286,17 +2286,17 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const bool count_entries = (out && lw.stats_chain_flagged && (use_hist || use_private || use_private_typed)) || count_leap2;
     sp.filter_entries = nullptr;
     sp.leap_tables = nullptr;
-    if (count_leap2) { st = arm_leap_tables(seg, ctx, &sp.leap_tables, &sp.filter_entries); if (st != PG_OK) return st; }
+    if (count_leap2) { st = arm_leap_tables(seg, ctx, &sp.leap_tables, nullptr); if (st != PG_OK) return st; }
     else if (lw.stats_leap2_flagged) for (int n = 0; n < sp.num_nodes; ++n) sp.nodes[n].flags &= ~kNodeLeapfrog2;      // a kernel without the count runs this query
     sp.raw64_coalesced = g_engine.raw64_coalesced ? 1 : 0;
-    if (count_entries && !count_leap2) { st = arm_filter_entries(ctx, &sp.filter_entries); if (st != PG_OK) return st; }
+    // (the entries counted by the kernel travel in its record: BlockPartial.entries -- no counter to zero, no copy command)
     // The folded record -> the reference's holder types.  Everything is captured by value: pg_execute_batch calls it after this function
     // has returned (the query, the segment and the context's pinned counter outlive the batch).
     const int kernel_id = use_hist ? PG_KERNEL_SCAN_HIST : use_narrow ? PG_KERNEL_SCAN_NARROW : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
-    const unsigned long long* h_filter_entries = ctx->h_filter_entries;
+    const HostRecord* host_record = ctx->h_record;
     const int profile_waves = blocks * (geo.threads / 64);
     const size_t num_projected = projected.size();
-    auto convert = [q, seg, na, agg_slot_of, lw, kernel_id, h_filter_entries, count_entries, profile_waves, num_projected](const BlockPartial& fp, pg_result* out) {
+    auto convert = [q, seg, na, agg_slot_of, lw, kernel_id, host_record, count_entries, count_leap2, profile_waves, num_projected](const BlockPartial& fp, pg_result* out) {
       out->num_aggregations = na;
       out->aggregations = (pg_agg_value*)calloc((size_t)std::max(na, 1), sizeof(pg_agg_value));
       for (int a = 0; a < na; ++a) {
@@ -2344,7 +2344,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       for (int c = 0; c < 4; ++c) out->profile_cycles[c] = fp.cyc[c];
       out->profile_waves = profile_waves;
       out->stats.num_docs_scanned = (int64_t)fp.count;
-      finish_filter_stats(lw, seg, h_filter_entries, count_entries, out);
+      // (the scan kernels count into their records; a leap-frogging a AND b adds what leapfrog2_chain_kernel left in the pinned record)
+      finish_filter_stats(lw, seg, (int64_t)fp.entries + (count_leap2 ? host_record->leap_correction : 0), count_entries, out);
       out->stats.num_entries_scanned_post_filter = (int64_t)fp.count * (int64_t)num_projected;
       out->stats.num_total_docs = seg->num_docs;
     };
@@ -2375,7 +2376,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
     // HIP events (PG_CFG_TIME_KERNELS): [ev_first, ev_last] brackets the query's device work, [ev[1], ev[2]] the scan kernel.  Each
     // record is a packet of its own on the queue, so a query that runs nothing but the scan kernel records just the two.
-    const bool post_work = !g_engine.direct_result || count_entries || want_bitmap;      // (copy commands behind the kernels)
+    const bool post_work = !g_engine.direct_result || count_leap2 || want_bitmap;      // (the chain kernel / copy commands behind the scan kernel)
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
@@ -2392,8 +2393,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       HIP_TRY(hipGetLastError());
     }
     if (!g_engine.direct_result) HIP_TRY(hipMemcpyAsync(ctx->h_partial, ctx->d_partials + blocks, sizeof(BlockPartial), hipMemcpyDeviceToHost, ctx->stream));
-    if (count_leap2) { st = launch_leap_chain(seg, ctx); if (st != PG_OK) return st; }
-    if (count_entries) HIP_TRY(hipMemcpyAsync(ctx->h_filter_entries, ctx->d_filter_entries, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (count_leap2) { st = launch_leap_chain(seg, ctx, seq); if (st != PG_OK) return st; }
     if (want_bitmap) {
       const int64_t need = ((int64_t)seg->num_docs + 63) / 64;
       if (d_out_bitmap_request) {
@@ -2419,6 +2419,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     } else {
       HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    if (count_leap2 && ctx->h_record->leap_seq != seq) return fail(PG_ERR_INTERNAL, "the leap-frog chain kernel did not publish its result");
     if (g_engine.direct_result && ctx->h_record->seq != seq) return fail(PG_ERR_INTERNAL, "the scan kernel's record carries sequence %llu, expected %llu", ctx->h_record->seq, seq);
     const BlockPartial& fp = *ctx->h_partial;
     // plain narrow counters: the counters must add up to the matches (a wrapped counter always leaves the total short)
@@ -2681,7 +2682,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     else launch_scan_group(g_engine.use_dma, gp.use_lds_table != 0, blocks, geo.threads, lds, ctx->stream, gp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-    if (count_leap2) { st = launch_leap_chain(seg, ctx); if (st != PG_OK) return st; }
+    if (count_leap2) { st = launch_leap_chain(seg, ctx, 0); if (st != PG_OK) return st; }
     if (count_entries) HIP_TRY(hipMemcpyAsync(ctx->h_filter_entries, ctx->d_filter_entries, 8, hipMemcpyDeviceToHost, ctx->stream));
     // The groups that exist, in ascending raw-key order: (raw key, doc count, accumulators[a * num_present + k]).
     std::vector<int32_t> present_ids;
@@ -2861,7 +2862,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       for (auto& w : workers) w.join();
     }
     out->stats.num_docs_scanned = docs;
-    finish_filter_stats(lw, seg, ctx->h_filter_entries, count_entries, out);
+    finish_filter_stats(lw, seg, count_entries ? (int64_t)*ctx->h_filter_entries : 0, count_entries, out);
     out->stats.num_entries_scanned_post_filter = docs * (int64_t)projected.size();
     out->stats.num_total_docs = seg->num_docs;
   }

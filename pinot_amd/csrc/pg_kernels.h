@@ -659,6 +659,7 @@ __device__ __forceinline__ void agg_raw_column_typed(const DevAggCol& ac, int nu
 __device__ __forceinline__ void partial_identity(BlockPartial& acc) {
   acc.count = 0;
   acc.flags = 0;
+  acc.entries = 0;
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc.cyc[c] = 0;
 #pragma unroll
@@ -670,6 +671,7 @@ __device__ __forceinline__ void partial_identity(BlockPartial& acc) {
 __device__ __forceinline__ void partial_merge(BlockPartial& acc, const BlockPartial& b) {
   acc.count += b.count;
   acc.flags |= b.flags;
+  acc.entries += b.entries;
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc.cyc[c] += b.cyc[c];
 #pragma unroll
@@ -692,6 +694,7 @@ __device__ __forceinline__ FoldFields fold_fields_of(const ScanParams& p) { retu
 // Every lane's record folded over the wave (all lanes return the same record).
 __device__ __forceinline__ void partial_wave_reduce(BlockPartial& acc, const FoldFields ff) {
   acc.count = (unsigned long long)wave_sum_i64((long long)acc.count);
+  acc.entries = (unsigned long long)wave_sum_i64((long long)acc.entries);
   acc.flags = __builtin_amdgcn_ballot_w64(acc.flags != 0ull) != 0ull ? 1ull : 0ull;      // single-bit vocabulary (kPartialHistAlarm)
   if (ff.cycles) {
 #pragma unroll
@@ -721,6 +724,7 @@ __device__ __forceinline__ BlockPartial fold_partials(const BlockPartial* partia
     const BlockPartial& b = partials[i];
     acc.count += b.count;
     acc.flags |= b.flags;
+    acc.entries += b.entries;
     if (ff.cycles) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc.cyc[c] += b.cyc[c];
@@ -948,6 +952,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_agg_kernel(const ScanParam
   BlockPartial* red = reinterpret_cast<BlockPartial*>(smem);
   BlockPartial mine;
   mine.flags = 0ull;
+  mine.entries = 0ull;
   mine.count = (unsigned long long)wave_sum_i64((long long)count);
 #pragma unroll
   for (int a = 0; a < kMaxAggCols; ++a) {
@@ -1559,21 +1564,56 @@ __device__ __forceinline__ Leap2Summary leap2_block(const Leap2Summary w, Leap2S
   }
   return all;
 }
-static __global__ __launch_bounds__(1024) void leapfrog2_chain_tiles_kernel(const uint8_t* __restrict__ tables, long long num_tiles, Leap2Summary* __restrict__ block_out) {
+// One launch: every workgroup summarises its 1024 tiles, stores the summary write-through and arrives (the R1 hand-off of
+// publish_block_partial); the workgroup whose arrival completes the count chains the workgroups' summaries and publishes the result --
+// into the pinned host record (aggregation queries: no copy command follows) or onto the device counter (group-by queries).
+static __global__ __launch_bounds__(1024) void leapfrog2_chain_kernel(const uint8_t* __restrict__ tables, long long num_tiles, Leap2Summary* block_out, uint32_t* arrivals,
+                                                                     HostRecord* host_out, unsigned long long host_seq, unsigned long long* entries) {
   __shared__ Leap2Summary part[16];
+  __shared__ uint32_t last_flag;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t e = t < num_tiles ? (uint32_t)tables[t] : 0x9u;           // past the end: delta 0, no event
   const Leap2Summary w = leap2_wave(0ll, (int)(e & 3u) - 1, (e >> 2) & 1u, (e >> 3) & 1u, threadIdx.x & 63);
-  const Leap2Summary all = leap2_block(w, part);
-  if (threadIdx.x == 0) block_out[blockIdx.x] = all;
-}
-static __global__ __launch_bounds__(1024) void leapfrog2_chain_blocks_kernel(const Leap2Summary* __restrict__ blocks, int num_blocks, unsigned long long* entries) {
-  __shared__ Leap2Summary part[16];
-  Leap2Summary in{0ll, 0, 0u, 1u};
-  if ((int)threadIdx.x < num_blocks) in = blocks[threadIdx.x];
-  const Leap2Summary w = leap2_wave(in.sum, in.delta, in.g, in.p, threadIdx.x & 63);
-  const Leap2Summary all = leap2_block(w, part);
-  if (threadIdx.x == 0 && all.sum != 0ll) atomicAdd(entries, (unsigned long long)all.sum);      // (the segment is entered in state 0; a negative sum wraps the unsigned counter the right way)
+  Leap2Summary all = leap2_block(w, part);
+  if (threadIdx.x == 0) {
+    uint32_t last = 1u;
+    if (gridDim.x > 1u) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(&block_out[blockIdx.x]);
+      static_assert(sizeof(Leap2Summary) == 24, "three 8-byte words");
+      __hip_atomic_store(dst, (unsigned long long)all.sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 1, (unsigned long long)(uint32_t)all.delta | ((unsigned long long)all.g << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 2, (unsigned long long)all.p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      last = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x ? 1u : 0u;
+      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    last_flag = last;
+  }
+  __syncthreads();
+  if (last_flag == 0u) return;
+  if (gridDim.x > 1u) {
+    // (a segment has < 2^31 docs = 2^20 tiles: at most 1024 workgroup summaries, one per thread)
+    Leap2Summary in{0ll, 0, 0u, 1u};
+    if (threadIdx.x < gridDim.x) {
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&block_out[threadIdx.x]);
+      const unsigned long long w1 = src[1];
+      in = Leap2Summary{(long long)src[0], (int)(uint32_t)w1, (uint32_t)(w1 >> 32), (uint32_t)src[2]};
+    }
+    __syncthreads();
+    const Leap2Summary w2 = leap2_wave(in.sum, in.delta, in.g, in.p, threadIdx.x & 63);
+    all = leap2_block(w2, part);
+  }
+  if (threadIdx.x == 0) {
+    if (gridDim.x > 1u) __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the segment is entered in state 0; a negative sum wraps the unsigned counter the right way)
+    if (entries != nullptr && all.sum != 0ll) atomicAdd(entries, (unsigned long long)all.sum);
+    if (host_out != nullptr) {
+      host_out->leap_correction = all.sum;
+      __threadfence_system();
+      __hip_atomic_store(&host_out->leap_seq, host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+    }
+  }
 }
 
 // `entries`: per-lane share of numEntriesScannedInFilter -- a kNodeCountEntries leaf is a scan-based child of the root AND that the
@@ -1789,6 +1829,7 @@ __device__ __forceinline__ void scan_private_body(const ScanParams& p, const uin
   BlockPartial mine;
   partial_identity(mine);
   mine.count = (unsigned long long)wave_sum_i64((long long)count);
+  mine.entries = (unsigned long long)wave_sum_i64((long long)entries);
 #pragma unroll
   for (int a = 0; a < kAggSlots; ++a) {
     mine.sum[a] = wave_sum_i64((long long)sum[a]);

@@ -260,6 +260,7 @@ __global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const Scan
   BlockPartial mine;
   partial_identity(mine);
   mine.count = (unsigned long long)wave_sum_i64((long long)count);
+  mine.entries = (unsigned long long)wave_sum_i64((long long)entries);
   mine.flags = __builtin_amdgcn_ballot_w64(alarm != 0u) != 0ull ? kPartialHistAlarm : 0ull;
   mine.sum[0] = wave_sum_i64(hsum);
   if constexpr (!kGuard && CW < 32) mine.sum[1] = wave_sum_i64((long long)csum);      // the host compares it with `count`

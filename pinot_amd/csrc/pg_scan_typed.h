@@ -212,6 +212,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void scan_private_typed_ke
   BlockPartial mine;
   partial_identity(mine);
   mine.count = (unsigned long long)wave_sum_i64((long long)count);
+  mine.entries = (unsigned long long)wave_sum_i64((long long)entries);
 #pragma unroll
   for (int a = 0; a < kMaxAggCols; ++a) {
     if (a >= p.num_agg_cols) continue;             // unused slots keep the identities: six wave reductions less each

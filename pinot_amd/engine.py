@@ -12,9 +12,18 @@ class Engine:
     def __init__(self, device_id=0, time_kernels=False, blocks_per_cu=0, lib_path=None, profile_waves=False):
         self.lib = _abi.load_gpu_library(lib_path)
         flags = (_abi.PG_CFG_TIME_KERNELS if time_kernels else 0) | (_abi.PG_CFG_PROFILE_WAVES if profile_waves else 0)
-        cfg = _abi.pg_config(_abi.PG_ABI_VERSION, device_id, blocks_per_cu, flags)
-        _abi.check(self.lib, self.lib.pg_init(C.byref(cfg)))
+        self._cfg = _abi.pg_config(_abi.PG_ABI_VERSION, device_id, blocks_per_cu, flags)
+        _abi.check(self.lib, self.lib.pg_init(C.byref(self._cfg)))
         self.device_id = device_id
+
+    def reinit(self, **env):
+        """pg_init again with environment switches changed (value None = unset): the library re-reads them; open segments stay open."""
+        for k, v in env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        _abi.check(self.lib, self.lib.pg_init(C.byref(self._cfg)))
 
     def device_info(self):
         name = C.create_string_buffer(64)

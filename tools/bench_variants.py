@@ -212,7 +212,9 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                     [t.join() for t in ts]
                     return 0.0
 
-                for mode, fn in (("batch", run_batch), ("threads16", run_threads), ("serial", run_serial)):
+                for mode, fn in (("batch", run_batch), ("worker_threads", run_batch), ("python_threads16", run_threads), ("serial", run_serial)):
+                    if mode == "worker_threads":      # the same call with the shared launch off: every segment a pg_execute of its own on the library's worker threads
+                        engine.reinit(PINOT_GPU_BATCH_LAUNCH=0)
                     for _ in range(5):
                         fn()
                     walls, dev = [], []
@@ -223,6 +225,8 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                         dev.append(d)
                     modes[mode] = {"wall_ms": sum(walls) / len(walls), "wall_ms_min": min(walls), "aggregate_GBps": nbytes / (sum(walls) / len(walls)) / 1e6,
                                    "frac_of_8TBps": nbytes / (sum(walls) / len(walls)) / 1e6 / HBM_PEAK_GBPS}
+                    if mode == "worker_threads":
+                        engine.reinit(PINOT_GPU_BATCH_LAUNCH=None)
                     if mode == "batch":
                         modes[mode]["kernel_ms"] = sum(dev) / len(dev)
                         modes[mode]["kernel_GBps"] = nbytes / (sum(dev) / len(dev)) / 1e6 if sum(dev) > 0 else None
