@@ -48,7 +48,8 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 3   /* 2: pg_result.filter_entries_exact, pg_query_check, pg_config.plane_budget_bytes; 3: pg_execute_batch */
+#define PG_ABI_VERSION 3   /* 2: pg_result.filter_entries_exact, pg_query_check, pg_config.plane_budget_bytes;
+                            * 3: pg_execute_batch, pg_result.group_key_kind / group_ids64 / group_key_dict_ids (Long / ArrayMap holders) */
 
 typedef enum pg_status {
   PG_OK = 0,
@@ -197,8 +198,11 @@ typedef struct pg_query {
                                       * (the reference's insertion-order group ids are internal to its hash map), at most num_groups_limit of
                                       * them: the groups whose first doc comes earliest, exactly those IntGroupIdMap.getGroupId :1022-1047
                                       * would have admitted.  The table is direct-indexed in HBM, 8 * (1 + distinct aggregations) bytes per raw
-                                      * key, at most PINOT_GPU_GROUP_TABLE_BYTES (default 64 GiB of the 288) per query.  Beyond an int (Long /
-                                      * ArrayMap holders) or beyond that budget: PG_ERR_UNSUPPORTED at plan time. */
+                                      * key, at most PINOT_GPU_GROUP_TABLE_BYTES (default 64 GiB of the 288) per query.  Beyond an int (the
+                                      * reference's LongMapBasedHolder / ArrayMapBasedHolder, :628-806, :808+): a HASHED table in HBM of at
+                                      * least 2 * min(numDocs, product) slots (same budget; segments up to 2^29 docs; aggregations of INT-domain
+                                      * columns), keys come back in pg_result.group_ids64 / group_key_dict_ids.  Beyond the budget:
+                                      * PG_ERR_UNSUPPORTED at plan time. */
   int32_t num_groups_limit;          /* InstancePlanMakerImplV2 numGroupsLimit (default 100000); 0 = default */
   int32_t flags;                     /* PG_QUERY_* */
 } pg_query;
@@ -269,10 +273,19 @@ typedef struct pg_result {
   int32_t profile_waves;           /* number of wavefronts the sums cover */
   int32_t dominant_kernel;         /* pg_kernel_id of the kernel dominant_kernel_ms refers to */
   int32_t filter_entries_exact;    /* stats.num_entries_scanned_in_filter is the reference's count (AndDocIdSet / SVScanDocIdIterator accounting);
-                                    * 0: an upper bound (numDocs per scan leaf) -- filters whose iterators leap-frog, on segments above
-                                    * PINOT_GPU_EXACT_FILTER_STATS_DOCS docs, and enableNullHandling queries */
-  int32_t reserved;
+                                    * 0: an upper bound (numDocs per scan leaf) -- filters whose iterators leap-frog (other than `a AND b` over
+                                    * two scan leaves, which the device counts), on segments above PINOT_GPU_EXACT_FILTER_STATS_DOCS docs,
+                                    * and enableNullHandling queries */
+  int32_t group_key_kind;          /* which of the reference's RawKeyHolders the key space calls for (DictionaryBasedGroupKeyGenerator.java:150-184):
+                                    * 0 the raw key is an int (Array / IntMapBasedHolder): group_ids hold it;
+                                    * 1 it is a long (LongMapBasedHolder, :628-700): group_ids64 hold it, group_ids are row numbers;
+                                    * 2 it is beyond a long (ArrayMapBasedHolder, :808+): only the dictId tuples identify a group.
+                                    * Kinds 1 and 2: group_id_upper_bound = numGroupsLimit (:150-163), groups admitted in order of first appearance. */
   void* internal;
+  int64_t* group_ids64;            /* [num_groups] kind 1: raw key = sum dictId_j * prod_{k<j} cardinality_k */
+  int32_t* group_key_dict_ids;     /* [num_groups * num_group_by] every kind: the dictIds of each group's key, group-by column order (under
+                                    * PG_QUERY_NULL_HANDLING the digit of a nullable key runs to cardinality inclusive = NULL).  Rows come
+                                    * in ascending raw-key order (the last group-by column is the most significant digit). */
 } pg_result;
 
 pg_status pg_init(const pg_config* config);

@@ -1308,9 +1308,10 @@ static void holder_init(po_holder* h, int func) {
 
 /* One aggregate() call of a function over values[from, to) of a block (the reducer body that foldNotNull applies to each non-null range,
  * NullableSingleInputAggregationFunction.java:118-160; the whole block [0, length) when there are no nulls). */
-static __thread const int32_t* po_sort_keys;
+typedef unsigned __int128 po_key;      /* a raw group key: int (Array / IntMap holders), long (LongMapBasedHolder) or beyond (ArrayMapBasedHolder) */
+static __thread const po_key* po_sort_keys;
 static int po_cmp_by_key(const void* a, const void* b) {
-  const int32_t ka = po_sort_keys[*(const int32_t*)a], kb = po_sort_keys[*(const int32_t*)b];
+  const po_key ka = po_sort_keys[*(const int32_t*)a], kb = po_sort_keys[*(const int32_t*)b];
   return ka < kb ? -1 : (ka > kb ? 1 : 0);
 }
 
@@ -1469,6 +1470,8 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   int na = q->num_aggregations;
   int ng = q->num_group_by;
   int64_t group_upper = 1;
+  po_key wide_upper = 1;          /* the product of the cardinalities, however large */
+  int key_kind = 0;               /* 0 int raw keys, 1 long (LongMapBasedHolder), 2 beyond a long (ArrayMapBasedHolder) */
   int32_t cards[8];
   uint64_t* key_nulls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int nullable_group_by = 0;      /* null handling with nulls in a key or an aggregated column: the no-dictionary generators' semantics */
@@ -1477,20 +1480,25 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
     const pg_column_desc* d = &seg->columns[q->group_by_columns[g]];
     if (d->fwd_encoding != PG_FWD_FIXED_BIT_DICT) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by on raw column"); goto done; }
     cards[g] = d->cardinality;
-    group_upper *= d->cardinality;
-    /* DictionaryBasedGroupKeyGenerator.java:164-184: ArrayBasedHolder up to arrayBasedThreshold, IntMapBasedHolder while the product
-     * fits an int; the Long / ArrayMap holders beyond that are not restated */
-    if (group_upper > 2147483647ll) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by cardinality product > Integer.MAX_VALUE"); goto done; }
+    /* DictionaryBasedGroupKeyGenerator.java:150-184: ArrayBasedHolder up to arrayBasedThreshold, IntMapBasedHolder while the product
+     * fits an int, LongMapBasedHolder while it fits a long (:628-700), ArrayMapBasedHolder beyond (:808+).  The three map-based holders
+     * differ in the key type only: group ids in order of first appearance, new keys refused once the map holds
+     * _globalGroupIdUpperBound of them -- min(product, numGroupsLimit) for the int holder, numGroupsLimit for the other two.  One
+     * 128-bit mixed-radix key restates all of them (three key columns of < 2^31 values each stay below 2^93). */
+    if (wide_upper > ((po_key)1 << 96)) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by key space beyond 2^96"); goto done; }
+    wide_upper *= (po_key)(d->cardinality > 0 ? d->cardinality : 1);
     if (null_handling) {
       /* DefaultGroupByExecutor.java:106-121: under null handling the keys come from the no-dictionary generators
        * (NoDictionarySingleColumnGroupKeyGenerator / NoDictionaryMultiColumnGroupKeyGenerator with nullHandlingEnabled): a null key value
        * is a key of its own, group ids are handed out in order of first appearance up to numGroupsLimit.  Restated on the raw-key
        * scale of the ABI: a nullable key column has one more digit value, `cardinality`, meaning NULL. */
       key_nulls[g] = column_null_words(seg, q->group_by_columns[g]);
-      if (key_nulls[g]) { cards[g] = d->cardinality + 1; group_upper = group_upper / d->cardinality * cards[g]; nullable_group_by = 1; }
-      if (group_upper > 2147483647ll) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by cardinality product > Integer.MAX_VALUE"); goto done; }
+      if (key_nulls[g]) { cards[g] = d->cardinality + 1; wide_upper = wide_upper / (po_key)d->cardinality * (po_key)cards[g]; nullable_group_by = 1; }
     }
   }
+  key_kind = wide_upper > (po_key)0x7FFFFFFFFFFFFFFFull ? 2 : (wide_upper > (po_key)2147483647 ? 1 : 0);
+  if (key_kind != 0 && null_handling) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by key space beyond an int under null handling"); goto done; }
+  group_upper = key_kind == 0 ? (int64_t)wide_upper : 0x7FFFFFFFll;      /* (only an upper bound for the map-based sizing below) */
   if (null_handling && ng > 0 && has_null_values) nullable_group_by = 1;
 
   /* IntMapBasedHolder (DictionaryBasedGroupKeyGenerator.java:415-490) + IntGroupIdMap.getGroupId (:1022-1047): raw key -> group id in
@@ -1499,14 +1507,14 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   const int map_based = ng > 0 && (group_upper > 10000 || nullable_group_by);
   const int64_t raw_key_upper = group_upper;
   int32_t num_groups_limit = q->num_groups_limit > 0 ? q->num_groups_limit : 100000;
-  int64_t map_capacity = 0; int32_t* map_keys = NULL; int32_t* map_ids = NULL; int32_t* raw_of_gid = NULL; int32_t map_size = 0;
+  int64_t map_capacity = 0; po_key* map_keys = NULL; uint8_t* map_used = NULL; int32_t* map_ids = NULL; po_key* raw_of_gid = NULL; int32_t map_size = 0;
   if (map_based) {
     group_upper = group_upper < num_groups_limit ? group_upper : num_groups_limit;     /* _globalGroupIdUpperBound */
     map_capacity = 16; while (map_capacity < 2 * group_upper + 2) map_capacity <<= 1;
-    map_keys = (int32_t*)malloc(sizeof(int32_t) * (size_t)map_capacity);
+    map_keys = (po_key*)malloc(sizeof(po_key) * (size_t)map_capacity);
+    map_used = (uint8_t*)calloc((size_t)map_capacity, 1);
     map_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)map_capacity);
-    raw_of_gid = (int32_t*)malloc(sizeof(int32_t) * (size_t)(group_upper > 0 ? group_upper : 1));
-    for (int64_t i = 0; i < map_capacity; i++) map_keys[i] = -1;
+    raw_of_gid = (po_key*)malloc(sizeof(po_key) * (size_t)(group_upper > 0 ? group_upper : 1));
   }
 
   po_holder* holders = NULL;       /* aggregation only */
@@ -1541,6 +1549,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   vals.d = (double*)malloc(sizeof(double) * PO_MAX_DOC_PER_CALL);
   double* dbl_values = (double*)malloc(sizeof(double) * PO_MAX_DOC_PER_CALL);
   int32_t* group_ids = (int32_t*)malloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  po_key* raw_keys = (po_key*)malloc(sizeof(po_key) * PO_MAX_DOC_PER_CALL);
   int32_t* nn_gids = (int32_t*)malloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
   int64_t* gnn = ng > 0 ? (int64_t*)calloc((size_t)group_upper * (size_t)(na > 0 ? na : 1), sizeof(int64_t)) : NULL;   /* docs that reached the holder, per group and function */
   int64_t num_docs_scanned = 0;
@@ -1558,25 +1567,26 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
 
     if (ng > 0) {
       /* DictionaryBasedGroupKeyGenerator.ArrayBasedHolder.processSingleValue, :298-338 */
-      for (int32_t i = 0; i < pos; i++) group_ids[i] = 0;
+      for (int32_t i = 0; i < pos; i++) raw_keys[i] = 0;
       for (int g = ng - 1; g >= 0; g--) {
         fetch_dict_ids(&cols[q->group_by_columns[g]], num_docs, doc_ids, pos, dict_scratch);
         if (key_nulls[g]) for (int32_t i = 0; i < pos; i++) if ((key_nulls[g][doc_ids[i] >> 6] >> (doc_ids[i] & 63)) & 1) dict_scratch[i] = cards[g] - 1;   /* NULL */
-        for (int32_t i = 0; i < pos; i++) group_ids[i] = group_ids[i] * cards[g] + dict_scratch[i];
+        for (int32_t i = 0; i < pos; i++) raw_keys[i] = raw_keys[i] * (po_key)cards[g] + (po_key)dict_scratch[i];
       }
+      if (!map_based) for (int32_t i = 0; i < pos; i++) group_ids[i] = (int32_t)raw_keys[i];
       if (map_based) {
         /* group ids in first-appearance order; docs of keys refused by the full map drop out of every aggregation (the holders
          * ignore INVALID_ID) but still count as scanned */
         int32_t kept = 0;
         for (int32_t i = 0; i < pos; i++) {
-          const int32_t raw = group_ids[i];
-          uint64_t h = ((uint64_t)(uint32_t)raw * 0x9E3779B97F4A7C15ull) >> 20;
+          const po_key raw = raw_keys[i];
+          uint64_t h = (((uint64_t)raw ^ ((uint64_t)(raw >> 64) * 0xC2B2AE3D27D4EB4Full)) * 0x9E3779B97F4A7C15ull) >> 20;
           int64_t slot = (int64_t)(h & (uint64_t)(map_capacity - 1));
           int32_t gid = -1;
           for (;;) {
-            if (map_keys[slot] == raw) { gid = map_ids[slot]; break; }
-            if (map_keys[slot] == -1) {
-              if (map_size < group_upper) { map_keys[slot] = raw; map_ids[slot] = map_size; raw_of_gid[map_size] = raw; gid = map_size++; }
+            if (map_used[slot] && map_keys[slot] == raw) { gid = map_ids[slot]; break; }
+            if (!map_used[slot]) {
+              if (map_size < group_upper) { map_used[slot] = 1; map_keys[slot] = raw; map_ids[slot] = map_size; raw_of_gid[map_size] = raw; gid = map_size++; }
               break;
             }
             slot = (slot + 1) & (map_capacity - 1);
@@ -1697,6 +1707,9 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
     res->num_groups = num_groups;
     res->group_id_upper_bound = (int32_t)group_upper;
     res->group_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)(num_groups > 0 ? num_groups : 1));
+    res->group_key_kind = key_kind;
+    res->group_key_dict_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)(num_groups > 0 ? num_groups : 1) * (size_t)(ng > 0 ? ng : 1));
+    if (key_kind == 1) res->group_ids64 = (int64_t*)malloc(sizeof(int64_t) * (size_t)(num_groups > 0 ? num_groups : 1));
     res->group_aggregations = (pg_agg_value*)calloc((size_t)(num_groups > 0 ? num_groups : 1) * (size_t)(na > 0 ? na : 1), sizeof(pg_agg_value));
     int32_t k = 0;
     /* result rows in ascending raw-key order (the ABI's order; the reference's own iteration order is the hash map's) */
@@ -1711,7 +1724,13 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
     for (size_t idx = 0; idx < (map_based ? (size_t)map_size : G); idx++) {
       const size_t g = map_based ? (size_t)order[idx] : idx;
       if (!flags[g]) continue;
-      res->group_ids[k] = map_based ? raw_of_gid[g] : (int32_t)g;
+      {
+        /* the key as the ABI returns it: int raw key / long raw key / row number, and always the dictId tuple */
+        po_key raw = map_based ? raw_of_gid[g] : (po_key)g;
+        res->group_ids[k] = key_kind == 0 ? (int32_t)raw : k;
+        if (key_kind == 1) res->group_ids64[k] = (int64_t)raw;
+        for (int c = 0; c < ng; c++) { res->group_key_dict_ids[(size_t)k * (size_t)ng + (size_t)c] = (int32_t)(raw % (po_key)cards[c]); raw /= (po_key)cards[c]; }
+      }
       for (int a = 0; a < na; a++) {
         pg_agg_value* v = &res->group_aggregations[(size_t)k * (size_t)na + (size_t)a];
         int func = q->aggregations[a].function;
@@ -1726,7 +1745,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       k++;
     }
     free(order);
-    res->group_id_upper_bound = (int32_t)raw_key_upper;
+    res->group_id_upper_bound = key_kind == 0 ? (int32_t)raw_key_upper : num_groups_limit;      /* LongMap / ArrayMap: _globalGroupIdUpperBound = numGroupsLimit (:150-163) */
   }
   /* ExecutionStatistics: AggregationOperator.java:88-93 (numDocsScanned, inFilter, numDocsScanned * numProjectedColumns, totalDocs) */
   {
@@ -1742,10 +1761,10 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   }
 
 cleanup:
-  free(doc_ids); free(dict_scratch); free(vals.i); free(vals.l); free(vals.f); free(vals.d); free(dbl_values); free(group_ids); free(nn_gids); free(gnn);
+  free(doc_ids); free(dict_scratch); free(vals.i); free(vals.l); free(vals.f); free(vals.d); free(dbl_values); free(group_ids); free(raw_keys); free(nn_gids); free(gnn);
   for (int g = 0; g < 8; g++) free(key_nulls[g]);
   free(holders); free(gholders); free(gavg_sum); free(gavg_cnt); free(gexact); free(gover); free(gcount); free(flags);
-  free(map_keys); free(map_ids); free(raw_of_gid);
+  free(map_keys); free(map_used); free(map_ids); free(raw_of_gid);
 done:
   if (agg_nulls) for (int a = 0; a < q->num_aggregations; a++) free(agg_nulls[a]);
   free(agg_nulls);
@@ -1755,7 +1774,7 @@ done:
 
 void po_result_free(pg_result* res) {
   if (!res) return;
-  free(res->aggregations); free(res->group_ids); free(res->group_aggregations);
+  free(res->aggregations); free(res->group_ids); free(res->group_ids64); free(res->group_key_dict_ids); free(res->group_aggregations);
   memset(res, 0, sizeof(*res));
 }
 

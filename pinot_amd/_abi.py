@@ -84,7 +84,8 @@ class pg_result(C.Structure):
                 ("group_aggregations", C.POINTER(pg_agg_value)), ("group_id_upper_bound", C.c_int32),
                 ("num_groups_limit_reached", C.c_int32), ("device_ms", C.c_double), ("dominant_kernel_ms", C.c_double),
                 ("profile_cycles", C.c_uint64 * 4), ("profile_waves", C.c_int32), ("dominant_kernel", C.c_int32),
-                ("filter_entries_exact", C.c_int32), ("reserved", C.c_int32), ("internal", C.c_void_p)]
+                ("filter_entries_exact", C.c_int32), ("group_key_kind", C.c_int32), ("internal", C.c_void_p),
+                ("group_ids64", C.POINTER(C.c_int64)), ("group_key_dict_ids", C.POINTER(C.c_int32))]
 
 
 # every symbol include/pinot_gpu.h declares: (name, restype, argtypes)

@@ -268,7 +268,22 @@ struct GroupParams {
   DevGroupAgg group_aggs[kMaxGroupAggs];
   unsigned long long* table_count; // [num_groups]
   long long* table_acc;            // [num_group_aggs * num_groups]
+  // Raw keys beyond an int (the reference's LongMapBasedHolder / ArrayMapBasedHolder, DictionaryBasedGroupKeyGenerator.java:162-176,
+  // 628-806, 808+): the table above is no longer indexed by the raw key but HASHED -- num_groups slots (a power of two, at least twice
+  // the keys that can exist), open addressing, linear probing, the 64-bit key of a slot in hash_keys[slot] (kHashEmpty = free).
+  //   hash_kind 1: the raw key sum dictId_j * key_mult[j] fits a long and is the key.
+  //   hash_kind 2: it does not.  Columns [0, hash_split) form a first key that a first table (hash_keys1) turns into its slot number;
+  //                key = that slot + sum over the remaining columns dictId_j * key_mult[j] (key_mult carries the first table's size).
+  int32_t hash_kind;
+  int32_t hash_split;
+  unsigned long long hash_mask;     // num_groups - 1
+  unsigned long long hash_mask1;    // slots of the first table - 1 (hash_kind 2)
+  unsigned long long* hash_keys;    // [num_groups]
+  unsigned long long* hash_keys1;   // [hash_mask1 + 1]
+  unsigned long long key_mult[kMaxGroupCols];
+  uint32_t* first_doc;              // non-null: the numGroupsLimit pass -- no aggregation, atomicMin of the docId into first_doc[slot]
 };
+constexpr unsigned long long kHashEmpty = ~0ull;
 
 // ---- partitioned group-by (pg_group_partition.h) ----
 constexpr int kMaxPartitions = 512;

@@ -70,6 +70,7 @@ struct Engine {
                              // does in a launch of its own, -1 (default) fold on segments of at most kFoldMaxTiles tiles
   bool poll_result = true;   // PINOT_GPU_POLL_RESULT=0: pg_execute always waits with hipStreamSynchronize instead of spinning on the pinned record's sequence number
   bool lane_skip = true;     // PINOT_GPU_LANE_SKIP=0: the aggregating kernels load a tile's value bytes for every lane, matches or not
+  int batch_blocks_per_cu = 4;    // PINOT_GPU_BATCH_BLOCKS_PER_CU: workgroups per CU a batch launch is cut into (all items together)
   bool batch_launch = true;  // PINOT_GPU_BATCH_LAUNCH=0: pg_execute_batch runs every item as a pg_execute of its own on the worker threads (no shared launch)
   bool leap2 = true;         // PINOT_GPU_LEAP2=0: a leap-frogging `a AND b` is not counted on the device (host replay / upper bound instead)
   int sparse_lanes = 32;     // PINOT_GPU_SPARSE_LANES: tiles in which at most this many of the 64 lanes hold a match are aggregated match by match (0 = never)
@@ -1467,6 +1468,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.poll_result = !(prs && prs[0] == '0');
   const char* lsk = getenv("PINOT_GPU_LANE_SKIP");
   g_engine.lane_skip = !(lsk && lsk[0] == '0');
+  const char* bbc = getenv("PINOT_GPU_BATCH_BLOCKS_PER_CU");
+  g_engine.batch_blocks_per_cu = (bbc && atoi(bbc) > 0) ? atoi(bbc) : 4;      // measured on 64 x 10 M rows: 2 / 4 / 8 / 16 / 32 / 64 -> 0.77 / 0.55 / 0.57 / 0.59 / 0.61 / 0.65 ms
   const char* bla = getenv("PINOT_GPU_BATCH_LAUNCH");
   g_engine.batch_launch = !(bla && bla[0] == '0');
   const char* lp2 = getenv("PINOT_GPU_LEAP2");
@@ -1844,6 +1847,8 @@ void pg_result_free(pg_result* r) {
   if (!r) return;
   free(r->aggregations);
   free(r->group_ids);
+  free(r->group_ids64);
+  free(r->group_key_dict_ids);
   free(r->group_aggregations);
   memset(r, 0, sizeof(*r));
 }
@@ -1856,6 +1861,41 @@ constexpr int32_t kQueryHashHolder = 1 << 30;      // internal pg_query.flags bi
 // execution path are safety nets behind it.  Where the exact resource use depends on run-time state (which summed columns read a
 // value plane decides how many column streams a query stages) the check takes the upper bound: it may decline a query whose streams
 // would just have fitted, never the other way round.  InstancePlanMakerImplV2.makeSegmentPlanNode (:270-289) is where the caller asks.
+// Group-by key spaces beyond an int: the reference's LongMapBasedHolder (the raw key fits a long) and ArrayMapBasedHolder (it does not)
+// -- DictionaryBasedGroupKeyGenerator.java:162-176.  Here: a hashed table in HBM (GroupParams.hash_*), sized at plan time to at least
+// twice the keys that can exist (min(numDocs, product)), so that it cannot fill up at run time.
+struct HashPlan {
+  int kind = 0;                    // 0: int raw keys (direct-indexed table); 1: long raw keys; 2: beyond a long (two chained tables)
+  int split = 0;
+  long long slots = 0, slots1 = 0;
+  unsigned long long mult[kMaxGroupCols] = {0, 0, 0};
+};
+static pg_status plan_hash_holder(const pg_segment* seg, const std::vector<int>& cards, HashPlan* hp) {
+  *hp = HashPlan();
+  unsigned __int128 prod = 1;
+  for (int c : cards) prod *= (unsigned __int128)std::max(c, 1);
+  if (prod <= (unsigned __int128)kMaxGroupSlots) return PG_OK;
+  if ((long long)seg->num_docs > (1ll << 29))
+    return fail(PG_ERR_UNSUPPORTED, "group-by with raw keys beyond an int on a segment of more than 2^29 docs (the hashed table would need more than 2^30 slots)");
+  auto pow2_at_least = [](unsigned __int128 v) { long long p = 1 << 16; while ((unsigned __int128)p < v) p <<= 1; return p; };
+  const int n = (int)cards.size();
+  hp->kind = prod > (unsigned __int128)0x7FFFFFFFFFFFFFFFull ? 2 : 1;
+  hp->slots = pow2_at_least(2 * std::min<unsigned __int128>((unsigned __int128)seg->num_docs, prod));
+  if (hp->kind == 1) {
+    hp->split = n;
+    unsigned long long m = 1;
+    for (int c = 0; c < n; ++c) { hp->mult[c] = m; m *= (unsigned long long)std::max(cards[(size_t)c], 1); }
+  } else {
+    // three columns of up to 2^31 - 1 values each: the first two are one key (< 2^62) that a first table turns into its slot number
+    if (n != 3) return fail(PG_ERR_INTERNAL, "a raw key beyond a long needs three key columns");
+    hp->split = 2;
+    const unsigned __int128 lo = (unsigned __int128)std::max(cards[0], 1) * (unsigned __int128)std::max(cards[1], 1);
+    hp->slots1 = pow2_at_least(2 * std::min<unsigned __int128>((unsigned __int128)seg->num_docs, lo));
+    hp->mult[0] = 1; hp->mult[1] = (unsigned long long)std::max(cards[0], 1); hp->mult[2] = (unsigned long long)hp->slots1;
+  }
+  return PG_OK;
+}
+
 static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int extra_and_leaves) {
   const int num_cols_total = (int)seg->cols.size();
   if (q->num_filter_nodes < 0 || q->num_filter_nodes > kMaxNodes) return fail(PG_ERR_UNSUPPORTED, "filter tree has %d nodes (max %d)", q->num_filter_nodes, kMaxNodes);
@@ -1903,16 +1943,29 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
   const int na = q->num_aggregations, ng = q->num_group_by;
   if (na < 0 || ng < 0 || (na > 0 && !q->aggregations) || (ng > 0 && !q->group_by_columns)) return fail(PG_ERR_INVALID_ARGUMENT, "bad aggregation / group-by lists");
   if (ng > kMaxGroupCols) return fail(PG_ERR_UNSUPPORTED, "more than %d group-by columns", kMaxGroupCols);
-  std::vector<int> key_cols, agg_cols;
+  std::vector<int> key_cols, agg_cols, key_cards;
   long long product = 1;
   for (int g = 0; g < ng; ++g) {
     const int c = q->group_by_columns[g];
     if (c < 0 || c >= num_cols_total) return fail(PG_ERR_INVALID_ARGUMENT, "group-by column %d out of range", c);
     const ColumnDev& col = seg->cols[(size_t)c];
     if (col.encoding != PG_FWD_FIXED_BIT_DICT) return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s", col.name.c_str());
-    product *= std::max(col.cardinality, 1);
-    if (product > kMaxGroupSlots) return fail(PG_ERR_UNSUPPORTED, "group-by cardinality product exceeds the int raw-key range (%d): Long / ArrayMap holders keep the CPU plan", kMaxGroupSlots);
+    key_cards.push_back(col.cardinality);
     if (std::find(key_cols.begin(), key_cols.end(), c) == key_cols.end()) key_cols.push_back(c);
+  }
+  HashPlan hash_plan;
+  if (ng > 0) { const pg_status hst = plan_hash_holder(seg, key_cards, &hash_plan); if (hst != PG_OK) return hst; }
+  if (hash_plan.kind == 0) for (int card : key_cards) product *= std::max(card, 1);
+  else {
+    // Long / ArrayMap holders run in the lane-private group-by kernel only: 32-bit-domain aggregations, lane-private filter leaves
+    product = hash_plan.slots;
+    if (q->flags & kQueryHashHolder) return fail(PG_ERR_UNSUPPORTED, "group-by with raw keys beyond an int under null handling (plan-time fallback)");
+    for (int n = 0; n < q->num_filter_nodes; ++n) {
+      if (q->filter[n].op != PG_FILTER_LEAF) continue;
+      const pg_predicate& pr = q->predicates[q->filter[n].predicate];
+      if (pr.kind == PG_PRED_RAW_RANGE && pr.column >= 0 && pr.column < num_cols_total && seg->cols[(size_t)pr.column].stored_type != PG_TYPE_INT)
+        return fail(PG_ERR_UNSUPPORTED, "group-by with raw keys beyond an int under a raw 8-byte range predicate (plan-time fallback)");
+    }
   }
   std::vector<std::pair<int, int>> group_aggs;     // distinct (column, SUM | MIN | MAX)
   for (int a = 0; a < na; ++a) {
@@ -1934,6 +1987,8 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
             return fail(PG_ERR_UNSUPPORTED, "group-by aggregation of a raw 8-byte column under a raw 8-byte range predicate (plan-time fallback)");
         }
       }
+      if (hash_plan.kind != 0 && ((kind == 0 && col.vkind != kValI32) || (col.encoding == PG_FWD_RAW_FIXED_BYTE && col.vkind != kValI32)))
+        return fail(PG_ERR_UNSUPPORTED, "group-by with raw keys beyond an int aggregating the 8-byte column %s (plan-time fallback)", col.name.c_str());
       if (kind == 0 && col.vkind == kValI64 && !col.h_dict_i64.empty()) {
         const double max_abs = std::max(std::fabs((double)col.h_dict_i64.front()), std::fabs((double)col.h_dict_i64.back()));
         if ((double)seg->num_docs * max_abs >= 9.2e18) return fail(PG_ERR_UNSUPPORTED, "group-by SUM of LONG column %s could overflow int64", col.name.c_str());
@@ -1942,7 +1997,7 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
   }
   if (ng == 0 && (int)agg_cols.size() > kMaxAggCols) return fail(PG_ERR_UNSUPPORTED, "more than %d aggregated columns", kMaxAggCols);
   if ((int)group_aggs.size() > kMaxGroupAggs) return fail(PG_ERR_UNSUPPORTED, "more than %d distinct group-by aggregations", kMaxGroupAggs);
-  if (ng > 0 && (unsigned long long)product * (1ull + group_aggs.size()) * 8ull > g_engine.group_table_bytes)
+  if (ng > 0 && ((unsigned long long)product * (1ull + group_aggs.size() + (hash_plan.kind ? 1 : 0)) + (unsigned long long)hash_plan.slots1) * 8ull > g_engine.group_table_bytes)
     return fail(PG_ERR_UNSUPPORTED, "group-by table of %lld slots x %zu words exceeds the %llu-byte budget (PINOT_GPU_GROUP_TABLE_BYTES)", product, 1 + group_aggs.size(),
                 (unsigned long long)g_engine.group_table_bytes);
   // Column streams, as slot_for hands them out: (column, read through its value plane?).  A column summed through its plane is read
@@ -2452,17 +2507,24 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
       pl.cols[s].in_agg = 1;
       group_slot[g] = s;
-      group_mult[g] = (int32_t)product;
-      product *= col.cardinality;
       cards.push_back(col.cardinality);
-      // DictionaryBasedGroupKeyGenerator.java:164-184: up to arrayBasedThreshold (10 000) the raw key IS the group id (ArrayBasedHolder);
-      // above it the reference hashes raw keys (IntMapBasedHolder) -- here the table stays direct-indexed, in HBM, one slot per raw
-      // key, and only the groups that exist come back.  2^24 slots keep the 24-bit key multiplies exact and the table <= 1.2 GB.
-      if (product > kMaxGroupSlots) return fail(PG_ERR_UNSUPPORTED, "group-by cardinality product exceeds the int raw-key range (%d): Long / ArrayMap holders keep the CPU plan", kMaxGroupSlots);
+    }
+    // DictionaryBasedGroupKeyGenerator.java:164-184: up to arrayBasedThreshold (10 000) the raw key IS the group id (ArrayBasedHolder);
+    // above it the reference hashes raw keys (IntMapBasedHolder) -- here the table stays direct-indexed, in HBM, one slot per raw
+    // key, and only the groups that exist come back.  2^24 slots keep the 24-bit key multiplies exact and the table <= 1.2 GB.
+    // Beyond an int (Long / ArrayMap holders) the table is hashed: `product` is then its number of slots (plan_hash_holder).
+    HashPlan hash_plan;
+    st = plan_hash_holder(seg, cards, &hash_plan);
+    if (st != PG_OK) return st;
+    if (hash_plan.kind == 0) {
+      for (int g = 0; g < ng; ++g) { group_mult[g] = (int32_t)product; product *= cards[(size_t)g]; }
+    } else {
+      product = hash_plan.slots;
+      if (q->flags & kQueryHashHolder) return fail(PG_ERR_UNSUPPORTED, "group-by with raw keys beyond an int under null handling (plan-time fallback)");
     }
     // (kQueryHashHolder: the no-dictionary key generators of null handling hand out group ids by first appearance up to numGroupsLimit
     //  whatever the key space: the compaction path below is the one that honours the limit)
-    const bool map_based = product > 10000 || (q->flags & kQueryHashHolder) != 0;
+    const bool map_based = product > 10000 || (q->flags & kQueryHashHolder) != 0 || hash_plan.kind != 0;
     bool typed_direct = false;            // an aggregation input is a raw LONG / FLOAT / DOUBLE column: group_typed_direct_kernel
     gp.num_group_cols = ng;
     gp.num_groups = (int32_t)product;
@@ -2488,7 +2550,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       dev_agg_of[(size_t)a] = da;
     }
     gp.wide_keys = product > (1ll << 24) ? 1 : 0;
-    const size_t table_words = (size_t)gp.num_groups * (size_t)(1 + gp.num_group_aggs);
+    // (hashed holders: one more word per slot for its key, and the first table of an ArrayMap-range key)
+    const size_t table_words = (size_t)gp.num_groups * (size_t)(1 + gp.num_group_aggs + (hash_plan.kind ? 1 : 0)) + (size_t)hash_plan.slots1;
     if ((unsigned long long)table_words * 8ull > g_engine.group_table_bytes)
       return fail(PG_ERR_UNSUPPORTED, "group-by table of %lld slots x %d words exceeds the %llu-byte budget (PINOT_GPU_GROUP_TABLE_BYTES)", product, 1 + gp.num_group_aggs,
                   (unsigned long long)g_engine.group_table_bytes);
@@ -2502,6 +2565,15 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     } table_trim{ctx};
     gp.table_count = ctx->d_table;
     gp.table_acc = reinterpret_cast<long long*>(ctx->d_table + gp.num_groups);
+    gp.hash_kind = hash_plan.kind;
+    gp.hash_split = hash_plan.split;
+    if (hash_plan.kind != 0) {
+      gp.hash_mask = (unsigned long long)gp.num_groups - 1ull;
+      gp.hash_keys = ctx->d_table + (size_t)gp.num_groups * (size_t)(1 + gp.num_group_aggs);
+      gp.hash_mask1 = hash_plan.slots1 ? (unsigned long long)hash_plan.slots1 - 1ull : 0ull;
+      gp.hash_keys1 = hash_plan.slots1 ? gp.hash_keys + gp.num_groups : nullptr;
+      for (int g = 0; g < ng; ++g) gp.key_mult[g] = hash_plan.mult[g];
+    }
     const size_t table_bytes = table_words * 8;
     Geometry geo;
     const int group_wave_cap = waves_scan_group();
@@ -2537,7 +2609,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     bool private_leaves = true;
     for (int l = 0; l < pl.num_leaves; ++l) private_leaves &= pl.leaves[l].kind <= kLeafBitmap || pl.leaves[l].kind == kLeafDocRange;
     if (typed_direct && !private_leaves) return fail(PG_ERR_UNSUPPORTED, "group-by aggregation of a raw 8-byte column under a raw 8-byte range predicate (plan-time fallback)");
-    const bool use_private = g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap && !typed_direct;
+    const bool use_private = (g_engine.group_private || hash_plan.kind != 0) && private_leaves && gp.dense_ok && !want_bitmap && !typed_direct;
+    if (hash_plan.kind != 0 && !use_private) return fail(PG_ERR_UNSUPPORTED, "group-by with raw keys beyond an int: only 32-bit-domain aggregations under lane-private filter leaves");
     int pblocks = blocks, pthreads = geo.threads;
     size_t plds = lds;
     if (use_private) {
@@ -2587,7 +2660,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const int partition_entry_bytes = 4 + 8 * gp.num_group_aggs;
     const int partition_shift = partition_entry_bytes <= 20 ? 12 : 11;
     const long long num_partitions = (product + (1ll << partition_shift) - 1) >> partition_shift;
-    const bool use_partition = !typed_direct && map_based && g_engine.group_partition && g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap &&
+    const bool use_partition = hash_plan.kind == 0 && !typed_direct && map_based && g_engine.group_partition && g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap &&
                                gp.num_group_aggs <= kMaxPartitionAggs && num_partitions <= kMaxPartitions && (long long)seg->num_docs >= g_engine.partition_min_docs;
     if (use_partition || !(use_private || typed_direct)) { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
     const bool count_leap2 = out && lw.stats_leap2_flagged && ((use_private && !use_partition) || typed_direct);
@@ -2685,6 +2758,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (count_leap2) { st = launch_leap_chain(seg, ctx, 0); if (st != PG_OK) return st; }
     if (count_entries) HIP_TRY(hipMemcpyAsync(ctx->h_filter_entries, ctx->d_filter_entries, 8, hipMemcpyDeviceToHost, ctx->stream));
     // The groups that exist, in ascending raw-key order: (raw key, doc count, accumulators[a * num_present + k]).
+    std::vector<unsigned long long> hash_keys, hash_keys_lo;      // hashed holders: the keys of the present slots
     std::vector<int32_t> present_ids;
     std::vector<unsigned long long> present_counts;
     std::vector<long long> present_acc;
@@ -2713,7 +2787,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       // IntMapBasedHolder range: compact the HBM table on the device; honour numGroupsLimit the way the reference does
       // (_globalGroupIdUpperBound = min(product, numGroupsLimit), DictionaryBasedGroupKeyGenerator.java:176).
       const int limit = q->num_groups_limit > 0 ? q->num_groups_limit : 100000;
-      const long long bound = std::min<long long>(product, limit);
+      const long long bound = hash_plan.kind != 0 ? (long long)limit : std::min<long long>(product, limit);      // LongMap / ArrayMap holders: _globalGroupIdUpperBound = numGroupsLimit (:150-163)
       const int num_chunks = (int)(((long long)gp.num_groups + kGroupChunk - 1) / kGroupChunk);
       DeviceScratch scratch(ctx);
       uint32_t* d_chunk_counts = (uint32_t*)scratch.alloc((size_t)num_chunks * 4);
@@ -2744,7 +2818,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         // More groups than the reference would have created: it hands out group ids in order of first appearance (docId order)
         // and drops the docs of later keys, so the survivors are the `bound` groups whose first doc comes earliest.
         unsigned long long* d_filter = nullptr;
-        if (q->num_filter_nodes > 0) {
+        if (q->num_filter_nodes > 0 && hash_plan.kind == 0) {
           d_filter = (unsigned long long*)scratch.alloc((((size_t)seg->num_docs + 63) / 64 + 1) * 8);
           if (!d_filter) return fail(PG_ERR_OUT_OF_MEMORY, "group-by first-doc pass: filter bitmap");
           pg_query fq = *q;
@@ -2761,6 +2835,20 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         uint32_t seen = 0;
         long long done_docs = 0;
         long long step_docs = std::max<long long>(1 << 16, 4 * bound);
+        if (hash_plan.kind != 0) {
+          // hashed holders: the group-by kernel once more, in its first-doc mode (same filter, same keys, every key already has its slot)
+          GroupParams fg = gp;
+          fg.first_doc = d_first_doc;
+          fg.scan.filter_entries = nullptr; fg.scan.leap_tables = nullptr;
+          for (int n = 0; n < fg.scan.num_nodes; ++n) fg.scan.nodes[n].flags &= ~(kNodeLeapfrog2 | kNodeCountEntries);
+          launch_group_private(false, pblocks, pthreads, 0, ctx->stream, fg);
+          HIP_TRY(hipGetLastError());
+          done_docs = seg->num_docs;
+          max_first_doc = 0xFFFFFFFEu;
+          st = count_groups(false, &seen);
+          if (st != PG_OK) return st;
+          HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
         while (done_docs < (long long)seg->num_docs && (long long)seen < bound) {
           const long long hi = std::min<long long>((long long)seg->num_docs, done_docs + step_docs);
           const long long span = hi - done_docs;
@@ -2807,6 +2895,22 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         HIP_TRY(hipMemcpyAsync(h_ids, d_ids, (size_t)num_present * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipMemcpyAsync(h_counts, d_counts, counts_bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (gp.num_group_aggs > 0) HIP_TRY(hipMemcpyAsync(h_acc, d_acc, acc_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (hash_plan.kind != 0) {
+          // the slots that hold a group -> their 64-bit keys (and, for a key beyond a long, the first table's key behind its slot number)
+          unsigned long long* d_keys = (unsigned long long*)scratch.alloc((size_t)num_present * 8 * 2);
+          if (!d_keys) return fail(PG_ERR_OUT_OF_MEMORY, "group-by keys of %d groups", num_present);
+          hash_keys.resize((size_t)num_present);
+          const unsigned gblocks = (unsigned)std::min<long long>(((long long)num_present + 255) / 256, (long long)seg->num_cus * 8);
+          gather_u64_kernel<<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(gp.hash_keys, d_ids, num_present, gp.hash_mask, d_keys);
+          HIP_TRY(hipGetLastError());
+          HIP_TRY(hipMemcpyAsync(hash_keys.data(), d_keys, (size_t)num_present * 8, hipMemcpyDeviceToHost, ctx->stream));
+          if (hash_plan.kind == 2) {
+            hash_keys_lo.resize((size_t)num_present);
+            gather_u64_by_key_kernel<<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(gp.hash_keys1, d_keys, num_present, gp.hash_mask1, d_keys + num_present);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(hash_keys_lo.data(), d_keys + num_present, (size_t)num_present * 8, hipMemcpyDeviceToHost, ctx->stream));
+          }
+        }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
       }
     }
@@ -2814,15 +2918,52 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     out->num_aggregations = na;
     out->dominant_kernel = use_partition ? PG_KERNEL_GROUP_PARTITION : (use_private ? PG_KERNEL_GROUP_PRIVATE : PG_KERNEL_SCAN_GROUP);
     out->num_groups = num_present;
-    out->group_id_upper_bound = gp.num_groups;
+    out->group_id_upper_bound = hash_plan.kind != 0 ? (q->num_groups_limit > 0 ? q->num_groups_limit : 100000) : gp.num_groups;      // hashed holders: numGroupsLimit, like the reference (:150-163)
     out->group_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)std::max(num_present, 1));
     out->group_aggregations = (pg_agg_value*)calloc((size_t)std::max(num_present, 1) * (size_t)std::max(na, 1), sizeof(pg_agg_value));
+    // The keys as dictId tuples, for every kind of holder (what GroupKeyGenerator.getGroupKeys turns into values); rows in ascending
+    // raw-key order.  Hashed holders come out of the table in slot order: `perm` sorts them.
+    out->group_key_dict_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)std::max(num_present, 1) * (size_t)ng);
+    out->group_key_kind = hash_plan.kind;
+    std::vector<int> perm;
+    if (hash_plan.kind == 0) {
+      for (int k = 0; k < num_present; ++k) {
+        long long raw = ids_of[(size_t)k];
+        for (int g = 0; g < ng; ++g) { out->group_key_dict_ids[(size_t)k * (size_t)ng + (size_t)g] = (int32_t)(raw % cards[(size_t)g]); raw /= cards[(size_t)g]; }
+      }
+    } else {
+      std::vector<int32_t> tuples((size_t)num_present * (size_t)ng);
+      for (int k = 0; k < num_present; ++k) {
+        unsigned long long lo = hash_plan.kind == 2 ? hash_keys_lo[(size_t)k] : hash_keys[(size_t)k];
+        for (int g = 0; g < hash_plan.split; ++g) { tuples[(size_t)k * (size_t)ng + (size_t)g] = (int32_t)(lo % (unsigned long long)cards[(size_t)g]); lo /= (unsigned long long)cards[(size_t)g]; }
+        if (hash_plan.kind == 2) {
+          unsigned long long hi = hash_keys[(size_t)k] / (unsigned long long)hash_plan.slots1;
+          for (int g = hash_plan.split; g < ng; ++g) { tuples[(size_t)k * (size_t)ng + (size_t)g] = (int32_t)(hi % (unsigned long long)cards[(size_t)g]); hi /= (unsigned long long)cards[(size_t)g]; }
+        }
+      }
+      perm.resize((size_t)num_present);
+      for (int k = 0; k < num_present; ++k) perm[(size_t)k] = k;
+      std::sort(perm.begin(), perm.end(), [&](int a, int b) {
+        for (int g = ng - 1; g >= 0; --g) {      // the last column is the most significant digit of the raw key
+          const int32_t x = tuples[(size_t)a * (size_t)ng + (size_t)g], y = tuples[(size_t)b * (size_t)ng + (size_t)g];
+          if (x != y) return x < y;
+        }
+        return false;
+      });
+      if (hash_plan.kind == 1) out->group_ids64 = (int64_t*)malloc(sizeof(int64_t) * (size_t)std::max(num_present, 1));
+      for (int k = 0; k < num_present; ++k) {
+        const int src = perm[(size_t)k];
+        memcpy(out->group_key_dict_ids + (size_t)k * (size_t)ng, tuples.data() + (size_t)src * (size_t)ng, sizeof(int32_t) * (size_t)ng);
+        if (hash_plan.kind == 1) out->group_ids64[k] = (int64_t)hash_keys[(size_t)src];
+      }
+    }
     // Turning accumulators into the reference's holder values is independent per group: large results (the IntMapBasedHolder range
     // returns up to numGroupsLimit rows) are converted by a few host threads, each touching its own pages of the result.
     auto convert_groups = [&](int k_begin, int k_end) {
     for (int k = k_begin; k < k_end; ++k) {
-      const unsigned long long group_docs = counts_of[(size_t)k];
-      out->group_ids[k] = ids_of[(size_t)k];
+      const int src = perm.empty() ? k : perm[(size_t)k];       // the row of the compacted table behind result row k
+      const unsigned long long group_docs = counts_of[(size_t)src];
+      out->group_ids[k] = perm.empty() ? ids_of[(size_t)src] : k;      // (hashed holders: a row number; the key is in group_ids64 / group_key_dict_ids)
       for (int a = 0; a < na; ++a) {
         const pg_aggregation& ag = q->aggregations[a];
         pg_agg_value& v = out->group_aggregations[(size_t)k * (size_t)na + (size_t)a];
@@ -2830,7 +2971,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         v.min = std::numeric_limits<double>::infinity();
         v.max = -std::numeric_limits<double>::infinity();
         if (ag.function == PG_AGG_COUNT) continue;
-        const long long acc = acc_of[(size_t)dev_agg_of[(size_t)a] * (size_t)num_present + (size_t)k];
+        const long long acc = acc_of[(size_t)dev_agg_of[(size_t)a] * (size_t)num_present + (size_t)src];
         const ColumnDev& col = seg->cols[(size_t)ag.column];
         const bool plane = lw.plane_cols[(size_t)ag.column] != 0;
         if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) {
@@ -3067,6 +3208,9 @@ static pg_status execute_null_handling(pg_segment* seg, const pg_query* q, pg_re
       }
       if (!synthetic_count) for (size_t i = 0; i < base_pos.size(); ++i) out->group_aggregations[(size_t)k * (size_t)na + (size_t)base_pos[i]] = part.group_aggregations[(size_t)k * (size_t)base_na + i];
     }
+    out->group_key_kind = part.group_key_kind;
+    out->group_key_dict_ids = part.group_key_dict_ids;      // (digits of nullable keys run to cardinality inclusive: the last one is NULL)
+    part.group_key_dict_ids = nullptr;
     pg_result_free(&part);
     // numEntriesScannedPostFilter = numDocsScanned * projected columns of the WHOLE query (GroupByOperator.java:160-166): keys + inputs
     std::vector<int> projected;
@@ -3337,7 +3481,7 @@ pg_status run_deferred(int device, const std::vector<int>& items, std::vector<De
   // the items' tails overlap other items' scans); never more than the item would get on its own.
   long long total_tiles = 0;
   for (int i : items) total_tiles += ((long long)segments[i]->num_docs + 2047) / 2048;
-  const long long budget = (long long)segments[items[0]]->num_cus * 16;
+  const long long budget = (long long)segments[items[0]]->num_cus * g_engine.batch_blocks_per_cu;
   std::vector<int> blocks((size_t)n);
   size_t partials = 0;
   long long total_blocks = 0;

@@ -1873,13 +1873,66 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
   scan_private_body<kAggSlots>(bp.items[lo], blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
 }
 
+// The slot of `key` in an open-addressing table of (mask + 1) slots, claiming a free one if the key is new (kHashEmpty = free).  The
+// engine sizes the table to at least twice the keys that can exist, so a probe sequence always ends.
+__device__ __forceinline__ uint32_t hash_slot_of(unsigned long long* keys, unsigned long long mask, unsigned long long key) {
+  unsigned long long h = key * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 32;
+  unsigned long long slot = h & mask;
+  for (;;) {
+    unsigned long long cur = __hip_atomic_load(keys + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == kHashEmpty) {
+      unsigned long long expected = kHashEmpty;
+      if (__hip_atomic_compare_exchange_strong(keys + slot, &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return (uint32_t)slot;
+      cur = expected;
+    }
+    if (cur == key) return (uint32_t)slot;
+    slot = (slot + 1ull) & mask;
+  }
+}
+
 // One 2048-doc tile.  kMasked: only the docs whose bit is set in the lane's mask `m` reach the table (a filter's result, and /
 // or the docs that exist in the last, partial tile); otherwise every doc of the tile does, with no exec masking around the atomics.
-template <bool kLds, bool kMasked, bool kWide = false>
+template <bool kLds, bool kMasked, bool kWide = false, bool kHash = false>
 __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long long tile, int lane, uint32_t m, unsigned long long* t_cnt, long long* t_acc) {
   const int G = gp.num_groups;
   const long long first_doc = tile * 2048 + lane * 32;
   uint32_t g[32];
+  if constexpr (kHash) {
+    // Long / ArrayMap holders: the 64-bit key of every (matching) doc, then its slot in the hashed table; sixteen docs at a time
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      unsigned long long k[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) k[j] = 0ull;
+      for (int c = 0; c < gp.num_group_cols; ++c) {
+        if (gp.hash_kind == 2 && c == gp.hash_split) {
+          // the columns so far are the first table's key: from here on its slot number stands for them
+#pragma unroll
+          for (int j = 0; j < 16; ++j) if (!kMasked || ((m >> (16 * h + j)) & 1u)) k[j] = (unsigned long long)hash_slot_of(gp.hash_keys1, gp.hash_mask1, k[j]);
+        }
+        const DevGroupKey& key = gp.group_keys[c];
+        const int b = key.bits;
+        const unsigned long long mult = gp.key_mult[c];
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(key.fwd + tile * (256ll * b)) + lane * b;
+        uint32_t d[16];
+        if (h == 0) decode16_private_dispatch<0>(b, words, d); else decode16_private_dispatch<1>(b, words, d);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) k[j] += (unsigned long long)d[j] * mult;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        g[16 * h + j] = 0u;
+        if (!kMasked || ((m >> (16 * h + j)) & 1u)) g[16 * h + j] = hash_slot_of(gp.hash_keys, gp.hash_mask, k[j]);
+      }
+    }
+    if (gp.first_doc != nullptr) {
+      // numGroupsLimit pass: which docId created every group (the reference admits keys in docId order until the limit is reached)
+#pragma unroll
+      for (int j = 0; j < 32; ++j) if (!kMasked || ((m >> j) & 1u)) atomicMin(gp.first_doc + g[j], (uint32_t)(first_doc + j));
+      return;
+    }
+  } else {
   for (int c = 0; c < gp.num_group_cols; ++c) {
     const DevGroupKey& key = gp.group_keys[c];
     const int b = key.bits;
@@ -1892,6 +1945,7 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
 #pragma unroll
       for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : key_term<kWide>(d[j], mult) + g[16 * h + j];
     }
+  }
   }
   const bool packed = kLds && gp.packed_agg >= 0;
   if (!packed) {
@@ -1942,7 +1996,7 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
   }
 }
 
-template <bool kLdsTable, bool kWide = false>
+template <bool kLdsTable, bool kWide = false, bool kHash = false>
 __global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const GroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63;
@@ -1980,8 +2034,8 @@ __global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const
     const long long rem = (long long)gp.scan.num_docs - (tile * 2048 + lane * 32);
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
     if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
-    if (__builtin_amdgcn_ballot_w64(m != 0xFFFFFFFFu) == 0ull) group_private_tile<kLdsTable, false, kWide>(gp, tile, lane, m, t_cnt, t_acc);
-    else group_private_tile<kLdsTable, true, kWide>(gp, tile, lane, m, t_cnt, t_acc);
+    if (__builtin_amdgcn_ballot_w64(m != 0xFFFFFFFFu) == 0ull) group_private_tile<kLdsTable, false, kWide, kHash>(gp, tile, lane, m, t_cnt, t_acc);
+    else group_private_tile<kLdsTable, true, kWide, kHash>(gp, tile, lane, m, t_cnt, t_acc);
   }
   flush_filter_entries(gp.scan, entries);
 
@@ -2008,7 +2062,10 @@ __global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const
 
 static __global__ void init_group_table_kernel(GroupParams gp) {
   const long long G = gp.num_groups;
+  if (gp.hash_kind == 2)
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g <= (long long)gp.hash_mask1; g += (long long)gridDim.x * blockDim.x) gp.hash_keys1[g] = kHashEmpty;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += (long long)gridDim.x * blockDim.x) {
+    if (gp.hash_kind != 0) gp.hash_keys[g] = kHashEmpty;
     gp.table_count[g] = 0ull;
     for (int a = 0; a < gp.num_group_aggs; ++a) {
       const int kind = gp.group_aggs[a].kind;
@@ -2526,6 +2583,16 @@ static __global__ __launch_bounds__(256) void group_compact_kernel(const unsigne
 }
 
 __device__ __forceinline__ uint32_t read_packed(const uint8_t* fwd, long long doc, int b);
+
+// keys[ids[i]] -> out[i] (the 64-bit keys of the slots that hold a group)
+static __global__ __launch_bounds__(256) void gather_u64_kernel(const unsigned long long* __restrict__ src, const int32_t* __restrict__ ids, int n, unsigned long long mask,
+                                                                 unsigned long long* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = src[(unsigned long long)(uint32_t)ids[i] & mask];
+}
+static __global__ __launch_bounds__(256) void gather_u64_by_key_kernel(const unsigned long long* __restrict__ src, const unsigned long long* __restrict__ keys, int n,
+                                                                        unsigned long long mask, unsigned long long* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = src[keys[i] & mask];
+}
 
 // One thread per doc: atomicMin of the docId into the slot of the doc's raw key.  `bitmap` is the filter result in doc order
 // (nullptr = every doc matches).  Only runs when a query created more groups than numGroupsLimit.

@@ -195,9 +195,17 @@ class Result:
         self.groups = {}
         self.group_id_upper_bound = int(res.group_id_upper_bound)
         self.num_groups_limit_reached = bool(res.num_groups_limit_reached)
+        # Keys: the int raw key (Array / IntMap holders), or -- when the raw key is beyond an int (Long / ArrayMap holders) -- the tuple
+        # of the key's dictIds in group-by column order.  `group_keys` holds the dictId tuples of every kind, row by row.
+        self.group_key_kind = int(getattr(res, "group_key_kind", 0))
+        ng = len(spec.group_by)
+        self.group_keys = []
         for g in range(int(res.num_groups)):
-            gid = int(res.group_ids[g])
+            tup = tuple(int(res.group_key_dict_ids[g * ng + j]) for j in range(ng)) if res.group_key_dict_ids else None
+            self.group_keys.append(tup)
+            gid = int(res.group_ids[g]) if self.group_key_kind == 0 else tup
             self.groups[gid] = [AggValue(res.group_aggregations[g * na + a]) for a in range(na)]
+        self.group_ids64 = [int(res.group_ids64[g]) for g in range(int(res.num_groups))] if (self.group_key_kind == 1 and res.group_ids64) else None
 
     def intermediates(self):
         return [v.intermediate(f) for v, f in zip(self.aggregations, self.functions)]

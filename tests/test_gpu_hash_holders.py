@@ -1,0 +1,65 @@
+"""GPU tests of group-by key spaces beyond an int: the reference's LongMapBasedHolder and ArrayMapBasedHolder
+(core/query/aggregation/groupby/DictionaryBasedGroupKeyGenerator.java:150-184, 628-700, 808+) as a hashed table in HBM
+(group_private_kernel<.., kHash>: 64-bit keys, open addressing; two chained tables when the key does not fit a long), keys back as long
+raw keys / dictId tuples, numGroupsLimit honoured in docId order.  Against the oracle, which tests/test_oracle_hash_holders.py holds
+against a per-doc restatement."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from pinot_amd import _abi
+from pinot_amd import query as Q
+import hash_holder_cases as HC
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", HC.cases(), ids=[c[0] for c in HC.cases()])
+def test_long_and_array_map_holders(engine, case):
+    seg, ids, specs = HC.build(case)
+    with engine.open(seg) as g:
+        for spec in specs:
+            assert g.check(spec) == _abi.PG_OK
+            got = g.execute(spec)
+            want = oracle.execute(seg, spec)
+            H.assert_results_equal(got, want)
+            assert got.group_key_kind == want.group_key_kind == case[3]
+            assert got.group_keys == want.group_keys                       # same rows, same (ascending raw key) order
+            assert got.group_ids64 == want.group_ids64
+            assert got.num_groups_limit_reached == want.num_groups_limit_reached
+            assert got.group_id_upper_bound == want.group_id_upper_bound
+
+
+def test_int_holders_also_return_the_dict_id_tuples(engine):
+    rng = np.random.default_rng(5)
+    n = 30_011
+    a, ia, _ = H.random_dict_column(rng, "a", n, 13)
+    b, ib, _ = H.random_dict_column(rng, "b", n, 700)
+    from pinot_amd import segment as S
+    seg = S.SegmentData("tuples", n, [a, b])
+    for group_by in ([0], [0, 1], [1, 0]):
+        spec = Q.QuerySpec([(Q.COUNT, -1)], group_by=group_by)
+        with engine.open(seg) as g:
+            got = g.execute(spec)
+        want = oracle.execute(seg, spec)
+        H.assert_results_equal(got, want)
+        assert got.group_key_kind == 0 and got.group_keys == want.group_keys
+        cards = [seg.columns[c].cardinality for c in group_by]
+        for gid, tup in zip(sorted(got.groups), got.group_keys):
+            raw, mult = 0, 1
+            for d, c in zip(tup, cards):
+                raw += d * mult; mult *= c
+            assert raw == gid
+
+
+def test_plan_time_limits_of_the_hashed_holders(engine):
+    """What pg_query_check declines: 8-byte aggregation inputs, and a table beyond PINOT_GPU_GROUP_TABLE_BYTES."""
+    from pinot_amd import segment as S
+    case = HC.cases()[0]
+    seg, ids, specs = HC.build(case)
+    wide = S.Column.dict_encoded_typed("big", (np.arange(seg.num_docs, dtype=np.int64) % 977) * (1 << 40))
+    seg2 = S.SegmentData("hash_wide", seg.num_docs, list(seg.columns) + [wide])
+    with engine.open(seg2) as g:
+        assert g.check(Q.QuerySpec([(Q.SUM, len(seg.columns))], group_by=[0, 1])) == _abi.PG_ERR_UNSUPPORTED
+        assert g.check(Q.QuerySpec([(Q.MAX, len(seg.columns))], group_by=[0, 1])) == _abi.PG_OK      # MIN / MAX run on dictIds

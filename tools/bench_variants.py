@@ -212,7 +212,11 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                     [t.join() for t in ts]
                     return 0.0
 
-                for mode, fn in (("batch", run_batch), ("worker_threads", run_batch), ("python_threads16", run_threads), ("serial", run_serial)):
+                import os
+                sweep = [("batch_bpc%s" % b, run_batch) for b in os.environ.get("PINOT_BENCH_BATCH_SWEEP", "").split(",") if b]
+                for mode, fn in [("batch", run_batch), ("worker_threads", run_batch), ("python_threads16", run_threads), ("serial", run_serial)] + sweep:
+                    if mode.startswith("batch_bpc"):
+                        engine.reinit(PINOT_GPU_BATCH_BLOCKS_PER_CU=mode[len("batch_bpc"):])
                     if mode == "worker_threads":      # the same call with the shared launch off: every segment a pg_execute of its own on the library's worker threads
                         engine.reinit(PINOT_GPU_BATCH_LAUNCH=0)
                     for _ in range(5):
@@ -227,7 +231,9 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                                    "frac_of_8TBps": nbytes / (sum(walls) / len(walls)) / 1e6 / HBM_PEAK_GBPS}
                     if mode == "worker_threads":
                         engine.reinit(PINOT_GPU_BATCH_LAUNCH=None)
-                    if mode == "batch":
+                    if mode.startswith("batch_bpc"):
+                        engine.reinit(PINOT_GPU_BATCH_BLOCKS_PER_CU=None)
+                    if mode.startswith("batch"):
                         modes[mode]["kernel_ms"] = sum(dev) / len(dev)
                         modes[mode]["kernel_GBps"] = nbytes / (sum(dev) / len(dev)) / 1e6 if sum(dev) > 0 else None
                 exact = None
