@@ -202,7 +202,7 @@ def assert_results_equal(got, want, check_stats=True):
     assert sorted(got.groups) == sorted(want.groups), "group ids differ"
     for gid, vals in want.groups.items():
         for i, f in enumerate(want.functions):
-            assert_agg_equal(got.groups[gid][i], vals[i], f, "group %d agg %d" % (gid, i))
+            assert_agg_equal(got.groups[gid][i], vals[i], f, "group %r agg %d" % (gid, i))
     if check_stats:
         assert got.stats[0] == want.stats[0], "numDocsScanned %r != %r" % (got.stats, want.stats)
         # numEntriesScannedInFilter: the reference's iterator accounting on both sides, unless one of them declares an upper bound
