@@ -44,7 +44,6 @@ import org.apache.pinot.segment.local.customobject.AvgPair;
 import org.apache.pinot.segment.spi.AggregationFunctionType;
 import org.apache.pinot.segment.spi.IndexSegment;
 import org.apache.pinot.segment.spi.index.reader.Dictionary;
-import org.apache.pinot.segment.spi.index.reader.NullValueVectorReader;
 import org.slf4j.Logger;
 import org.slf4j.LoggerFactory;
 
@@ -67,6 +66,7 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
   private static final class LaneResult {
     long[] _header;
     int[] _groupIds;
+    int[] _groupKeys;              // dictId tuples, row-major: what identifies a group whichever holder the key space calls for
     long[] _counts;
     double[] _sums;
     double[] _mins;
@@ -127,6 +127,7 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
     LaneResult result = new LaneResult();
     result._header = (long[]) raw[PinotGpuNative.PGM_R_HEADER];
     result._groupIds = (int[]) raw[PinotGpuNative.PGM_R_GROUP_IDS];
+    result._groupKeys = (int[]) raw[PinotGpuNative.PGM_R_GROUP_KEYS];
     result._counts = (long[]) raw[PinotGpuNative.PGM_R_COUNTS];
     result._sums = (double[]) raw[PinotGpuNative.PGM_R_SUMS];
     result._mins = (double[]) raw[PinotGpuNative.PGM_R_MINS];
@@ -170,23 +171,27 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
   }
 
   /**
-   * Group-by: the lanes share one key space (raw group ids are the same mixed-radix number in every lane), so the block's groups are
-   * the union of the lanes' groups in ascending raw id -- what sharing one GroupKeyGenerator across lanes gives the reference
+   * Group-by: the lanes share one key space (a key's dictIds are the same in every lane), so the block's groups are the union of the
+   * lanes' groups in ascending raw-key order -- what sharing one GroupKeyGenerator across lanes gives the reference
    * (FilteredGroupByOperator.java:121-143) -- and a function whose lane never saw a group keeps its holder's default there.
    */
   private GroupByResultsBlock groupByBlock(List<LaneResult> results) {
     boolean nullHandling = _queryContext.isNullHandlingEnabled();
     int numFunctions = _functions.length;
-    int[] groupIds = results.size() == 1 ? results.get(0)._groupIds : unionOf(results);
-    int numGroups = groupIds.length;
+    int numKeyColumns = _queryContext.getGroupByExpressions().size();
+    // the block's groups: one lane's rows as they are, or the union of the lanes' keys (dictId tuples, compared like the raw key:
+    // the last column is the most significant digit)
+    int[] groupKeys = results.size() == 1 ? results.get(0)._groupKeys : unionOf(results, numKeyColumns);
+    int numGroups = numKeyColumns == 0 ? 0 : groupKeys.length / numKeyColumns;
     int capacity = Math.max(numGroups, 1);
     GroupByResultHolder[] holders = new GroupByResultHolder[numFunctions];
     for (int l = 0; l < _lanes.size(); l++) {
       int[] positions = _lanes.get(l)._positions;
       LaneResult r = results.get(l);
-      int[] rowOf = new int[r._groupIds.length];                // lane row -> row of the block
-      for (int g = 0; g < rowOf.length; g++) {
-        rowOf[g] = results.size() == 1 ? g : Arrays.binarySearch(groupIds, r._groupIds[g]);
+      int laneGroups = r._groupIds.length;
+      int[] rowOf = new int[laneGroups];                          // lane row -> row of the block
+      for (int g = 0; g < laneGroups; g++) {
+        rowOf[g] = results.size() == 1 ? g : find(groupKeys, numGroups, numKeyColumns, r._groupKeys, g);
       }
       for (int i = 0; i < positions.length; i++) {
         AggregationFunctionType type = _functions[positions[i]].getType();
@@ -222,14 +227,11 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
     }
     List<ExpressionContext> groupBy = _queryContext.getGroupByExpressions();
     Dictionary[] dictionaries = new Dictionary[groupBy.size()];
-    boolean[] nullableKeys = new boolean[groupBy.size()];
     String[] columnNames = new String[groupBy.size() + numFunctions];
     DataSchema.ColumnDataType[] columnTypes = new DataSchema.ColumnDataType[groupBy.size() + numFunctions];
     for (int i = 0; i < groupBy.size(); i++) {
       String column = groupBy.get(i).getIdentifier();
       dictionaries[i] = _indexSegment.getDataSource(column).getDictionary();
-      NullValueVectorReader nullVector = _indexSegment.getDataSource(column).getNullValueVector();
-      nullableKeys[i] = nullHandling && nullVector != null && nullVector.getNullBitmap() != null && !nullVector.getNullBitmap().isEmpty();
       columnNames[i] = groupBy.get(i).toString();
       columnTypes[i] = DataSchema.ColumnDataType.fromDataTypeSV(_indexSegment.getDataSource(column).getDataSourceMetadata().getDataType());
     }
@@ -247,7 +249,7 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
       limitReached |= r._header[PinotGpuNative.PGM_H_NUM_GROUPS_LIMIT_REACHED] != 0;
     }
     DataSchema dataSchema = new DataSchema(columnNames, columnTypes);
-    GpuGroupKeyGenerator keys = new GpuGroupKeyGenerator(groupIds, dictionaries, nullableKeys, (int) upperBound);
+    GpuGroupKeyGenerator keys = new GpuGroupKeyGenerator(numGroups, groupKeys, dictionaries, (int) upperBound);
     // In-segment trim, exactly GroupByOperator.java:119-135: ORDER BY + minSegmentGroupTrimSize > 0 + more groups than the trim size
     int minGroupTrimSize = _queryContext.getMinSegmentGroupTrimSize();
     if (_queryContext.getOrderByExpressions() != null && minGroupTrimSize > 0) {
@@ -264,26 +266,64 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
     return block;
   }
 
-  /** Ascending union of the lanes' (ascending) raw group ids. */
-  private static int[] unionOf(List<LaneResult> results) {
-    int total = 0;
-    for (LaneResult r : results) {
-      total += r._groupIds.length;
-    }
-    int[] all = new int[total];
-    int at = 0;
-    for (LaneResult r : results) {
-      System.arraycopy(r._groupIds, 0, all, at, r._groupIds.length);
-      at += r._groupIds.length;
-    }
-    Arrays.sort(all);
-    int kept = 0;
-    for (int i = 0; i < all.length; i++) {
-      if (i == 0 || all[i] != all[i - 1]) {
-        all[kept++] = all[i];
+  /** The order of the native rows: ascending raw key = the dictId tuples compared from the last column (most significant digit) down. */
+  private static int compareKeys(int[] a, int rowA, int[] b, int rowB, int columns) {
+    for (int c = columns - 1; c >= 0; c--) {
+      int x = a[rowA * columns + c];
+      int y = b[rowB * columns + c];
+      if (x != y) {
+        return x < y ? -1 : 1;
       }
     }
-    return Arrays.copyOf(all, kept);
+    return 0;
+  }
+
+  /** The sorted union of the lanes' (sorted) key tuples. */
+  private static int[] unionOf(List<LaneResult> results, int columns) {
+    int[] merged = new int[0];
+    for (LaneResult r : results) {
+      int rowsA = columns == 0 ? 0 : merged.length / columns;
+      int rowsB = r._groupIds.length;
+      int[] out = new int[(rowsA + rowsB) * columns];
+      int i = 0;
+      int j = 0;
+      int k = 0;
+      while (i < rowsA || j < rowsB) {
+        int cmp = i >= rowsA ? 1 : (j >= rowsB ? -1 : compareKeys(merged, i, r._groupKeys, j, columns));
+        if (cmp <= 0) {
+          System.arraycopy(merged, i * columns, out, k * columns, columns);
+          i++;
+          if (cmp == 0) {
+            j++;
+          }
+        } else {
+          System.arraycopy(r._groupKeys, j * columns, out, k * columns, columns);
+          j++;
+        }
+        k++;
+      }
+      merged = Arrays.copyOf(out, k * columns);
+    }
+    return merged;
+  }
+
+  /** Row of the key tuple keys[row] in the sorted union. */
+  private static int find(int[] union, int unionRows, int columns, int[] keys, int row) {
+    int lo = 0;
+    int hi = unionRows - 1;
+    while (lo <= hi) {
+      int mid = (lo + hi) >>> 1;
+      int cmp = compareKeys(union, mid, keys, row, columns);
+      if (cmp == 0) {
+        return mid;
+      }
+      if (cmp < 0) {
+        lo = mid + 1;
+      } else {
+        hi = mid - 1;
+      }
+    }
+    throw new IllegalStateException("a lane's group is missing from the union of the lanes");
   }
 
   @Override

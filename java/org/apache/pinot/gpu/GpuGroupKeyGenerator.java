@@ -1,8 +1,9 @@
 /**
- * GroupKeyGenerator over the groups the device returned: group id k = row k of the native result, keys = the dictionary VALUES of the raw
- * group id's digits (raw id = sum dictId_j * prod_{i<j} cardinality_i, DictionaryBasedGroupKeyGenerator.java:298-338,437-445 -- the
- * same mixed-radix key the reference's ArrayBasedHolder / IntMapBasedHolder use).  Only the result-side methods are meaningful: the
- * keys were generated on the device, so generateKeysForBlock is never called.
+ * GroupKeyGenerator over the groups the device returned: group id k = row k of the native result, keys = the dictionary VALUES of the
+ * key's dictIds, which the device hands back as they are (pg_result.group_key_dict_ids: one dictId per group-by column and group) --
+ * whichever RawKeyHolder the key space calls for in the reference: Array / IntMap (raw key an int), LongMap (a long) or ArrayMap
+ * (beyond a long), DictionaryBasedGroupKeyGenerator.java:150-184.  Only the result-side methods are meaningful: the keys were
+ * generated on the device, so generateKeysForBlock is never called.
  */
 package org.apache.pinot.gpu;
 
@@ -13,25 +14,28 @@ import org.apache.pinot.segment.spi.index.reader.Dictionary;
 
 
 final class GpuGroupKeyGenerator implements GroupKeyGenerator {
-  private final int[] _rawGroupIds;
+  private final int _numGroups;
+  private final int[] _keyDictIds;            // [group * columns + column]
   private final Dictionary[] _dictionaries;
   private final int[] _cardinalities;
-  private final int[] _radix;
   private final int _globalUpperBound;
 
   /**
-   * @param nullableKeys under enableNullHandling, the key columns that have null docs: their digit runs to cardinality INCLUSIVE, the last
-   *                     value meaning NULL (include/pinot_gpu.h, PG_QUERY_NULL_HANDLING: the no-dictionary key generators of
-   *                     DefaultGroupByExecutor.java:106-121 treat NULL as a key value of its own)
+   * @param keyDictIds the dictId of every group's key in every group-by column, row-major by group.  Under enableNullHandling the digit of a
+   *                   key column that has null docs runs to cardinality INCLUSIVE, the last value meaning NULL (include/pinot_gpu.h,
+   *                   PG_QUERY_NULL_HANDLING: the no-dictionary key generators of DefaultGroupByExecutor.java:106-121 treat NULL as a
+   *                   key value of its own)
    */
-  GpuGroupKeyGenerator(int[] rawGroupIds, Dictionary[] dictionaries, boolean[] nullableKeys, int globalUpperBound) {
-    _rawGroupIds = rawGroupIds;
+  GpuGroupKeyGenerator(int numGroups, int[] keyDictIds, Dictionary[] dictionaries, int globalUpperBound) {
+    if (keyDictIds.length != numGroups * dictionaries.length) {
+      throw new IllegalStateException("native result: " + keyDictIds.length + " key dictIds for " + numGroups + " groups of " + dictionaries.length + " columns");
+    }
+    _numGroups = numGroups;
+    _keyDictIds = keyDictIds;
     _dictionaries = dictionaries;
     _cardinalities = new int[dictionaries.length];
-    _radix = new int[dictionaries.length];
     for (int i = 0; i < dictionaries.length; i++) {
       _cardinalities[i] = dictionaries[i].length();
-      _radix[i] = _cardinalities[i] + (nullableKeys[i] ? 1 : 0);
     }
     _globalUpperBound = globalUpperBound;
   }
@@ -53,12 +57,12 @@ final class GpuGroupKeyGenerator implements GroupKeyGenerator {
 
   @Override
   public int getCurrentGroupKeyUpperBound() {
-    return _rawGroupIds.length;
+    return _numGroups;
   }
 
   @Override
   public int getNumKeys() {
-    return _rawGroupIds.length;
+    return _numGroups;
   }
 
   @Override
@@ -69,17 +73,16 @@ final class GpuGroupKeyGenerator implements GroupKeyGenerator {
 
       @Override
       public boolean hasNext() {
-        return _next < _rawGroupIds.length;
+        return _next < _numGroups;
       }
 
       @Override
       public GroupKey next() {
-        int raw = _rawGroupIds[_next];
-        Object[] keys = new Object[_dictionaries.length];
-        for (int i = 0; i < _dictionaries.length; i++) {
-          int digit = raw % _radix[i];
-          keys[i] = digit == _cardinalities[i] ? null : _dictionaries[i].getInternal(digit);
-          raw /= _radix[i];
+        int columns = _dictionaries.length;
+        Object[] keys = new Object[columns];
+        for (int i = 0; i < columns; i++) {
+          int dictId = _keyDictIds[_next * columns + i];
+          keys[i] = dictId == _cardinalities[i] ? null : _dictionaries[i].getInternal(dictId);
         }
         _groupKey._groupId = _next++;
         _groupKey._keys = keys;

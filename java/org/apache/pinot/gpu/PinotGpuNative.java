@@ -81,7 +81,7 @@ public final class PinotGpuNative {
   public static final int PGM_AGG_INTS = 2;
   public static final int PGM_COLUMN_INTS = 6;
   public static final int PGM_COLUMN_BUFFERS = 8;
-  public static final int PGM_RESULT_ARRAYS = 8;
+  public static final int PGM_RESULT_ARRAYS = 9;
   public static final int PGM_R_HEADER = 0;
   public static final int PGM_R_GROUP_IDS = 1;
   public static final int PGM_R_COUNTS = 2;
@@ -90,6 +90,7 @@ public final class PinotGpuNative {
   public static final int PGM_R_SUM_EXACT = 5;
   public static final int PGM_R_MINS = 6;
   public static final int PGM_R_MAXS = 7;
+  public static final int PGM_R_GROUP_KEYS = 8;
 
   /** Indexes of the result header (PGM_H_* in jni/pg_marshal.h). */
   public static final int PGM_H_NUM_DOCS_SCANNED = 0;
@@ -103,7 +104,9 @@ public final class PinotGpuNative {
   public static final int PGM_H_NUM_GROUPS_LIMIT_REACHED = 8;
   public static final int PGM_H_DOMINANT_KERNEL = 9;
   public static final int PGM_H_IS_GROUP_BY = 10;
-  public static final int PGM_HEADER_LEN = 11;
+  public static final int PGM_H_GROUP_KEY_KIND = 11;
+  public static final int PGM_H_NUM_GROUP_BY = 12;
+  public static final int PGM_HEADER_LEN = 13;
 
   /** pg_init: once per JVM, from GpuPlanMaker.init. */
   static native void init(int device, int flags);
@@ -139,7 +142,7 @@ public final class PinotGpuNative {
 
   /**
    * pg_execute.  Returns Object[PGM_RESULT_ARRAYS], slots PGM_R_*: {long[] header, int[] groupIds, long[] counts, double[] sums,
-   * long[] sumsI64, int[] sumExact, double[] mins, double[] maxs}; throws UnsupportedOperationException for PG_ERR_UNSUPPORTED, RuntimeException (pg_last_error) otherwise.
+   * long[] sumsI64, int[] sumExact, double[] mins, double[] maxs, int[] groupKeys (rows x group-by columns dictIds)}; throws UnsupportedOperationException for PG_ERR_UNSUPPORTED, RuntimeException (pg_last_error) otherwise.
    */
   static native Object[] execute(long handle, int[] filterNodes, int[] predInts, long[] predLongs, int[] setOffsets, int[] setWords,
       int[] aggregations, int[] groupBy, int numGroupsLimit, int flags);

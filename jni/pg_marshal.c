@@ -163,6 +163,7 @@ void pgm_result_header(const pg_result* r, int32_t is_group_by, int64_t* h) {
   h[PGM_H_NUM_GROUPS_LIMIT_REACHED] = r->num_groups_limit_reached;
   h[PGM_H_DOMINANT_KERNEL] = r->dominant_kernel;
   h[PGM_H_IS_GROUP_BY] = is_group_by ? 1 : 0;
+  h[PGM_H_GROUP_KEY_KIND] = r->group_key_kind;
 }
 
 int64_t pgm_result_fill(const pg_result* r, int32_t is_group_by, int32_t* group_ids, int64_t* counts, double* sums, int64_t* sums_i64,
@@ -185,4 +186,11 @@ int64_t pgm_result_fill(const pg_result* r, int32_t is_group_by, int32_t* group_
     }
   }
   return rows;
+}
+
+int64_t pgm_result_fill_keys(const pg_result* r, int32_t num_group_by, int32_t* group_keys) {
+  if (!r || !group_keys || num_group_by <= 0 || !r->group_key_dict_ids) return 0;
+  const int64_t cells = (int64_t)r->num_groups * (int64_t)num_group_by;
+  memcpy(group_keys, r->group_key_dict_ids, sizeof(int32_t) * (size_t)cells);
+  return cells;
 }

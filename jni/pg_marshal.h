@@ -15,7 +15,9 @@
  *   group_by       int32[num_group_by]
  * Result arrays (sized by the caller from pgm_result_rows / num_aggregations):
  *   header         int64[PGM_HEADER_LEN]    see the PGM_H_* indexes
- *   group_ids      int32[rows]              raw group ids (group-by only)
+ *   group_ids      int32[rows]              raw group ids (group-by only; row numbers when the raw key is beyond an int: PGM_H_GROUP_KEY_KIND)
+ *   group_keys     int32[rows * num_group_by]  the dictIds of every group's key, group-by column order (what identifies a group whichever
+ *                                           holder the key space calls for: pg_result.group_key_dict_ids)
  *   counts         int64[rows * num_aggs]   row-major by row, like pg_result.group_aggregations
  *   sums / mins / maxs  double[rows * num_aggs];  sums_i64 int64[...], sum_exact int32[...]
  */
@@ -34,11 +36,11 @@ extern "C" {
  * same names -- by java/org/apache/pinot/gpu/PinotGpuNative.java (tests/test_java_constants.py compares the two languages). */
 enum {
   PGM_FILTER_NODE_INTS = 3, PGM_PRED_INTS = 4, PGM_PRED_LONGS = 2, PGM_AGG_INTS = 2, PGM_COLUMN_INTS = 6, PGM_COLUMN_BUFFERS = 8,
-  PGM_RESULT_ARRAYS = 8
+  PGM_RESULT_ARRAYS = 9
 };
 enum {
   PGM_R_HEADER = 0, PGM_R_GROUP_IDS = 1, PGM_R_COUNTS = 2, PGM_R_SUMS = 3, PGM_R_SUMS_I64 = 4, PGM_R_SUM_EXACT = 5, PGM_R_MINS = 6,
-  PGM_R_MAXS = 7
+  PGM_R_MAXS = 7, PGM_R_GROUP_KEYS = 8
 };
 
 typedef struct pgm_query pgm_query;      /* owns the pg_query and every array it points into */
@@ -64,15 +66,17 @@ void pgm_segment_free(pgm_segment* s);
 enum {
   PGM_H_NUM_DOCS_SCANNED = 0, PGM_H_ENTRIES_IN_FILTER = 1, PGM_H_ENTRIES_POST_FILTER = 2, PGM_H_TOTAL_DOCS = 3,
   PGM_H_FILTER_ENTRIES_EXACT = 4, PGM_H_NUM_AGGREGATIONS = 5, PGM_H_NUM_GROUPS = 6, PGM_H_GROUP_ID_UPPER_BOUND = 7,
-  PGM_H_NUM_GROUPS_LIMIT_REACHED = 8, PGM_H_DOMINANT_KERNEL = 9, PGM_H_IS_GROUP_BY = 10, PGM_HEADER_LEN = 11
+  PGM_H_NUM_GROUPS_LIMIT_REACHED = 8, PGM_H_DOMINANT_KERNEL = 9, PGM_H_IS_GROUP_BY = 10, PGM_H_GROUP_KEY_KIND = 11, PGM_H_NUM_GROUP_BY = 12, PGM_HEADER_LEN = 13
 };
 
 /* Rows of the result: 1 for an aggregation-only result, num_groups for a group-by. */
 int64_t pgm_result_rows(const pg_result* r, int32_t is_group_by);
-void pgm_result_header(const pg_result* r, int32_t is_group_by, int64_t* header);
+void pgm_result_header(const pg_result* r, int32_t is_group_by, int64_t* header);      /* (PGM_H_NUM_GROUP_BY is the caller's to fill in) */
 /* Copies the rows out; any output pointer may be NULL (not wanted).  Returns the number of rows written. */
 int64_t pgm_result_fill(const pg_result* r, int32_t is_group_by, int32_t* group_ids, int64_t* counts, double* sums, int64_t* sums_i64,
                         int32_t* sum_exact, double* mins, double* maxs);
+/* The dictId tuples of a group-by result: rows * num_group_by ints (num_group_by from the query the result answers). */
+int64_t pgm_result_fill_keys(const pg_result* r, int32_t num_group_by, int32_t* group_keys);
 
 const char* pgm_last_error(void);
 

@@ -211,14 +211,15 @@ JNIEXPORT jstring JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_lastError(JNI
 }
 
 /* pg_execute.  Returns Object[PGM_RESULT_ARRAYS] (slots PGM_R_*): {long[] header (PGM_H_* layout), int[] groupIds, long[] counts, double[] sums, long[] sumsI64,
- * int[] sumExact, double[] mins, double[] maxs}, the value arrays row-major [row * numAggregations + a]. */
+ * int[] sumExact, double[] mins, double[] maxs, int[] groupKeys (dictId tuples)}, the value arrays row-major [row * numAggregations + a]. */
 JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(JNIEnv* env, jclass cls, jlong handle, jintArray filterNodes,
     jintArray predInts, jlongArray predLongs, jintArray setOffsets, jintArray setWords, jintArray aggregations, jintArray groupBy,
     jint numGroupsLimit, jint flags) {
   (void)cls;
   pinned_query p;
   if (!pin_query(env, &p, filterNodes, predInts, predLongs, setOffsets, setWords, aggregations, groupBy, numGroupsLimit, flags)) return NULL;
-  const int32_t is_group_by = pgm_query_get(p.built)->num_group_by > 0;
+  const int32_t num_group_by = pgm_query_get(p.built)->num_group_by;
+  const int32_t is_group_by = num_group_by > 0;
   pg_result result;
   const pg_status status = pg_execute((pg_segment*)(intptr_t)handle, pgm_query_get(p.built), &result);
   release_query(env, &p, filterNodes, predInts, predLongs, setOffsets, setWords, aggregations, groupBy);
@@ -226,7 +227,7 @@ JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(
 
   const int64_t rows64 = pgm_result_rows(&result, is_group_by);
   const int64_t cells64 = rows64 * (int64_t)result.num_aggregations;
-  if (rows64 < 0 || cells64 < 0 || cells64 > (int64_t)INT32_MAX - 8) {          /* a Java array holds fewer than 2^31 elements */
+  if (rows64 < 0 || cells64 < 0 || cells64 > (int64_t)INT32_MAX - 8 || rows64 * (int64_t)num_group_by > (int64_t)INT32_MAX - 8) {          /* a Java array holds fewer than 2^31 elements */
     pg_result_free(&result);
     throw_new(env, "java/lang/IllegalStateException", "the result has more cells than a Java array holds");
     return NULL;
@@ -237,26 +238,30 @@ JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(
   jclass object_class = (*env)->FindClass(env, "java/lang/Object");
   jlongArray header = (*env)->NewLongArray(env, PGM_HEADER_LEN);
   jintArray group_ids = (*env)->NewIntArray(env, is_group_by ? rows : 0);
+  jintArray group_keys = (*env)->NewIntArray(env, is_group_by ? rows * (jsize)num_group_by : 0);
   jlongArray counts = (*env)->NewLongArray(env, cells);
   jdoubleArray sums = (*env)->NewDoubleArray(env, cells);
   jlongArray sums_i64 = (*env)->NewLongArray(env, cells);
   jintArray sum_exact = (*env)->NewIntArray(env, cells);
   jdoubleArray mins = (*env)->NewDoubleArray(env, cells);
   jdoubleArray maxs = (*env)->NewDoubleArray(env, cells);
-  if (object_class && header && group_ids && counts && sums && sums_i64 && sum_exact && mins && maxs) {
+  if (object_class && header && group_ids && group_keys && counts && sums && sums_i64 && sum_exact && mins && maxs) {
     int64_t h[PGM_HEADER_LEN];
     pgm_result_header(&result, is_group_by, h);
+    h[PGM_H_NUM_GROUP_BY] = num_group_by;
     (*env)->SetLongArrayRegion(env, header, 0, PGM_HEADER_LEN, (const jlong*)h);
     /* the value arrays are filled in place: GetPrimitiveArrayCritical would forbid the JNI calls in between, plain element access does not */
     jint* g = (*env)->GetIntArrayElements(env, group_ids, NULL);
+    jint* gk = (*env)->GetIntArrayElements(env, group_keys, NULL);
     jlong* c = (*env)->GetLongArrayElements(env, counts, NULL);
     jdouble* s = (*env)->GetDoubleArrayElements(env, sums, NULL);
     jlong* si = (*env)->GetLongArrayElements(env, sums_i64, NULL);
     jint* se = (*env)->GetIntArrayElements(env, sum_exact, NULL);
     jdouble* mn = (*env)->GetDoubleArrayElements(env, mins, NULL);
     jdouble* mx = (*env)->GetDoubleArrayElements(env, maxs, NULL);
-    if (g && c && s && si && se && mn && mx) {
+    if (g && gk && c && s && si && se && mn && mx) {
       (void)pgm_result_fill(&result, is_group_by, (int32_t*)g, (int64_t*)c, (double*)s, (int64_t*)si, (int32_t*)se, (double*)mn, (double*)mx);
+      if (is_group_by) (void)pgm_result_fill_keys(&result, num_group_by, (int32_t*)gk);
       out = (*env)->NewObjectArray(env, PGM_RESULT_ARRAYS, object_class, NULL);
     }
     if (mx) (*env)->ReleaseDoubleArrayElements(env, maxs, mx, 0);
@@ -265,6 +270,7 @@ JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(
     if (si) (*env)->ReleaseLongArrayElements(env, sums_i64, si, 0);
     if (s) (*env)->ReleaseDoubleArrayElements(env, sums, s, 0);
     if (c) (*env)->ReleaseLongArrayElements(env, counts, c, 0);
+    if (gk) (*env)->ReleaseIntArrayElements(env, group_keys, gk, 0);
     if (g) (*env)->ReleaseIntArrayElements(env, group_ids, g, 0);
     if (out != NULL) {
       (*env)->SetObjectArrayElement(env, out, PGM_R_HEADER, header);
@@ -275,6 +281,7 @@ JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(
       (*env)->SetObjectArrayElement(env, out, PGM_R_SUM_EXACT, sum_exact);
       (*env)->SetObjectArrayElement(env, out, PGM_R_MINS, mins);
       (*env)->SetObjectArrayElement(env, out, PGM_R_MAXS, maxs);
+      (*env)->SetObjectArrayElement(env, out, PGM_R_GROUP_KEYS, group_keys);
     }
   }
   pg_result_free(&result);

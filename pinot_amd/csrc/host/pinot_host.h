@@ -291,7 +291,7 @@ struct ExecutionStatistics {
 
 // ---- operator/blocks/results --------------------------------------------------------------------------------------
 using GroupKeyValue = std::variant<int64_t, std::string, double, std::monostate>;   // INT / LONG keys, STRING keys, FLOAT / DOUBLE keys, NULL (null handling)
-struct GroupKey { int groupId; std::vector<GroupKeyValue> keys; };        // groupby/GroupKeyGenerator.GroupKey
+struct GroupKey { int groupId; std::vector<GroupKeyValue> keys; std::vector<int32_t> dictIds; };        // groupby/GroupKeyGenerator.GroupKey (+ the key's dictIds: what identifies a group of ONE segment whatever the holder, int / long / array keyed)
 
 struct AggregationResultsBlock {                    // operator/blocks/results/AggregationResultsBlock.java:54-59
   std::vector<AggregationFunction> functions;

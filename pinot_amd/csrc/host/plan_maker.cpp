@@ -490,12 +490,12 @@ class GpuAggregationOperator : public Operator {
         // DictionaryBasedGroupKeyGenerator.getKeys: groupId -> dictIds (mixed radix) -> dictionary VALUES
         // Under null handling a nullable key column has one more digit value, `cardinality` = NULL (include/pinot_gpu.h, pg_query.flags):
         // the no-dictionary key generators of DefaultGroupByExecutor.java:106-121 treat NULL as a key value of its own.
-        int rem = key.groupId;
-        for (const DataSource* ds : keyCols) {
-          const bool nullable = _queryContext.nullHandlingEnabled && ds->nullValueVector != nullptr && ds->nullValueVectorSize > 0;
-          const int radix = ds->cardinality + (nullable ? 1 : 0);
-          const int d = rem % radix;
-          rem /= radix;
+        // (the device hands the digits over as they are -- pg_result.group_key_dict_ids -- for every holder: int, long and array keyed)
+        const size_t nk = keyCols.size();
+        for (size_t j = 0; j < nk; ++j) {
+          const DataSource* ds = keyCols[j];
+          const int d = res.group_key_dict_ids[(size_t)i * nk + j];
+          key.dictIds.push_back(d);
           if (d == ds->cardinality) key.keys.emplace_back(std::monostate{});
           else if (ds->dataType == DataType::STRING) key.keys.emplace_back(ds->dictionary->getStringValue(d));
           else if (ds->dataType == DataType::FLOAT || ds->dataType == DataType::DOUBLE) key.keys.emplace_back(ds->dictionary->getDoubleValue(d));
@@ -611,14 +611,14 @@ class GpuFilteredAggregationOperator : public Operator {
     empty.min = INFINITY; empty.max = -INFINITY;
     std::vector<IntermediateResult> defaults;
     for (const auto& f : g.functions) defaults.push_back(AggregationFunction(f.getType(), f.getColumn(), _queryContext.nullHandlingEnabled).fromDevice(empty));
-    std::map<int, size_t> rowOf;                          // raw group id -> row
+    std::map<std::vector<int32_t>, size_t> rowOf;         // the key's dictIds -> row (the same in every lane, whichever holder the key space calls for)
     for (auto& lane : _lanes) {
       ResultsBlock b = lane.op->nextBlock();
       for (size_t r = 0; r < b.groupBy.groupKeys.size(); ++r) {
         const GroupKey& key = b.groupBy.groupKeys[r];
-        auto it = rowOf.find(key.groupId);
+        auto it = rowOf.find(key.dictIds);
         if (it == rowOf.end()) {
-          it = rowOf.emplace(key.groupId, g.groupKeys.size()).first;
+          it = rowOf.emplace(key.dictIds, g.groupKeys.size()).first;
           g.groupKeys.push_back(key);
           g.results.push_back(defaults);
         }
@@ -635,7 +635,12 @@ class GpuFilteredAggregationOperator : public Operator {
     // ascending raw group id, like every other group-by block of this path
     std::vector<size_t> order(g.groupKeys.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](size_t a, size_t b2) { return g.groupKeys[a].groupId < g.groupKeys[b2].groupId; });
+    // ascending raw key: the last key column is the most significant digit
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b2) {
+      const auto& x = g.groupKeys[a].dictIds; const auto& y = g.groupKeys[b2].dictIds;
+      for (size_t j = x.size(); j-- > 0;) if (x[j] != y[j]) return x[j] < y[j];
+      return false;
+    });
     std::vector<GroupKey> keys;
     std::vector<std::vector<IntermediateResult>> rows;
     for (size_t i : order) { keys.push_back(std::move(g.groupKeys[i])); rows.push_back(std::move(g.results[i])); }

@@ -10,9 +10,9 @@ from . import _abi
 
 JNI_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jni")
 LIB_PATH = os.path.join(JNI_DIR, "libpinot_gpu_marshal.so")
-HEADER_LEN = 11
+HEADER_LEN = 13
 (H_NUM_DOCS_SCANNED, H_ENTRIES_IN_FILTER, H_ENTRIES_POST_FILTER, H_TOTAL_DOCS, H_FILTER_ENTRIES_EXACT, H_NUM_AGGREGATIONS, H_NUM_GROUPS,
- H_GROUP_ID_UPPER_BOUND, H_NUM_GROUPS_LIMIT_REACHED, H_DOMINANT_KERNEL, H_IS_GROUP_BY) = range(HEADER_LEN)
+ H_GROUP_ID_UPPER_BOUND, H_NUM_GROUPS_LIMIT_REACHED, H_DOMINANT_KERNEL, H_IS_GROUP_BY, H_GROUP_KEY_KIND, H_NUM_GROUP_BY) = range(HEADER_LEN)
 
 _lib = None
 
@@ -41,6 +41,8 @@ def load():
     lib.pgm_result_header.argtypes = [P(_abi.pg_result), C.c_int32, P(C.c_int64)]
     lib.pgm_result_fill.restype = C.c_int64
     lib.pgm_result_fill.argtypes = [P(_abi.pg_result), C.c_int32, P(C.c_int32), P(C.c_int64), P(C.c_double), P(C.c_int64), P(C.c_int32), P(C.c_double), P(C.c_double)]
+    lib.pgm_result_fill_keys.restype = C.c_int64
+    lib.pgm_result_fill_keys.argtypes = [P(_abi.pg_result), C.c_int32, P(C.c_int32)]
     lib.pgm_last_error.restype = C.c_char_p
     _lib = lib
     return lib
@@ -115,3 +117,13 @@ def unpack_result(res, is_group_by):
                                 _p(sum_exact, C.c_int32), _p(mins, C.c_double), _p(maxs, C.c_double))
     assert wrote == rows
     return header, group_ids, counts, sums, sums_i64, sum_exact, mins, maxs
+
+
+def unpack_keys(res, num_group_by):
+    """The dictId tuples of a group-by result ([rows, num_group_by]), through pgm_result_fill_keys."""
+    lib = load()
+    rows = int(res.num_groups)
+    keys = np.zeros(rows * num_group_by, dtype=np.int32)
+    wrote = lib.pgm_result_fill_keys(C.byref(res), int(num_group_by), _p(keys, C.c_int32))
+    assert wrote == rows * num_group_by
+    return keys.reshape(rows, num_group_by)

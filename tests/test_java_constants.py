@@ -92,7 +92,7 @@ def check_java_against_c(files, c):
 
 def test_java_constants_equal_the_c_headers():
     c = c_constants()
-    assert c["PG_PRED_DOC_RANGE"] == 5 and c["PG_PRED_IS_NULL"] == 6 and c["PGM_HEADER_LEN"] == 11      # the parser sees the headers
+    assert c["PG_PRED_DOC_RANGE"] == 5 and c["PG_PRED_IS_NULL"] == 6 and c["PGM_HEADER_LEN"] == 13      # the parser sees the headers
     problems = check_java_against_c(java_files(), c)
     assert not problems, "\n".join(problems)
 

@@ -101,6 +101,9 @@ def test_results_unpack_into_arrays():
             na = len(spec.aggregations)
             rows = [(None, want.aggregations)] if not is_group_by else [(int(gid), want.groups[int(gid)]) for gid in group_ids]
             assert len(rows) == (1 if not is_group_by else len(want.groups))
+            if is_group_by:
+                keys = M.unpack_keys(res, len(spec.group_by))
+                assert [tuple(int(x) for x in row) for row in keys] == want.group_keys and header[M.H_GROUP_KEY_KIND] == 0
             for r, (_, values) in enumerate(rows):
                 for a, v in enumerate(values):
                     at = r * na + a
@@ -129,3 +132,22 @@ def test_jni_functions_type_check_against_the_stand_in_header():
     declared = set(re.findall(r"static native [\w\[\]<>]+ (\w+)\(", java))
     defined = set(re.findall(r"Java_org_apache_pinot_gpu_PinotGpuNative_(\w+)\(", c))
     assert declared == defined and len(declared) >= 8, (declared, defined)
+
+
+def test_keys_of_a_long_keyed_group_by_cross_as_dict_id_tuples():
+    """A raw key beyond an int (LongMapBasedHolder): the int group ids are row numbers, the dictId tuples identify the groups."""
+    import hash_holder_cases as HC
+    seg, ids, specs = HC.build(HC.cases()[0])
+    res = _abi.pg_result()
+    spec = specs[2]                                                # numGroupsLimit 50
+    with M.MarshalledQuery(spec) as mq:
+        assert oracle.load().po_execute(C.byref(seg.desc), C.byref(mq.c), C.byref(res)) == 0
+    try:
+        header, group_ids, counts, *_ = M.unpack_result(res, True)
+        keys = M.unpack_keys(res, len(spec.group_by))
+        want = Q.Result(res, spec)
+        assert header[M.H_GROUP_KEY_KIND] == 1 and header[M.H_NUM_GROUPS] == 50 and header[M.H_NUM_GROUPS_LIMIT_REACHED] == 1
+        assert list(group_ids) == list(range(50))
+        assert [tuple(int(x) for x in row) for row in keys] == want.group_keys
+    finally:
+        oracle.load().po_result_free(C.byref(res))
