@@ -78,6 +78,7 @@ struct DevLeaf {
 
 constexpr int32_t kNodeCountEntries = 2; // scan leaf on the root AND chain behind an index-based child: ScanBasedDocIdIterator.applyAnd looks at every doc still standing
 constexpr int kNarrowTiles = 4, kNarrowMaxBits = 8, kNarrowStack = 4, kNarrowSingleTiles = 8;      // scan_narrow_kernel / scan_narrow_single_kernel (pg_scan_narrow.h)
+constexpr int kSparseTiles = 8;          // scan_sparse_kernel: tiles per wave and iteration (pg_scan_sparse.h)
 constexpr int32_t kNodeLeapfrog2 = 4;    // the root AND of exactly two scan leaves: its two masks also drive the leap-frog entry count (leapfrog2_tile)
 constexpr int32_t kNodeExitIfZero = 1;   // root AND chain: the tile is finished (mask 0) if the running result is wave-zero
 

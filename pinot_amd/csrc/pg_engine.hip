@@ -71,6 +71,7 @@ struct Engine {
   bool poll_result = true;   // PINOT_GPU_POLL_RESULT=0: pg_execute always waits with hipStreamSynchronize instead of spinning on the pinned record's sequence number
   bool lane_skip = true;     // PINOT_GPU_LANE_SKIP=0: the aggregating kernels load a tile's value bytes for every lane, matches or not
   int batch_blocks_per_cu = 4;    // PINOT_GPU_BATCH_BLOCKS_PER_CU: workgroups per CU a batch launch is cut into (all items together)
+  bool scan_sparse = true;   // PINOT_GPU_SCAN_SPARSE=0: index-led aggregations scan their listed tiles in scan_private_kernel (one tile per wave and iteration)
   bool batch_launch = true;  // PINOT_GPU_BATCH_LAUNCH=0: pg_execute_batch runs every item as a pg_execute of its own on the worker threads (no shared launch)
   bool leap2 = true;         // PINOT_GPU_LEAP2=0: a leap-frogging `a AND b` is not counted on the device (host replay / upper bound instead)
   int sparse_lanes = 32;     // PINOT_GPU_SPARSE_LANES: tiles in which at most this many of the 64 lanes hold a match are aggregated match by match (0 = never)
@@ -1470,6 +1471,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.lane_skip = !(lsk && lsk[0] == '0');
   const char* bbc = getenv("PINOT_GPU_BATCH_BLOCKS_PER_CU");
   g_engine.batch_blocks_per_cu = (bbc && atoi(bbc) > 0) ? atoi(bbc) : 4;      // measured on 64 x 10 M rows: 2 / 4 / 8 / 16 / 32 / 64 -> 0.77 / 0.55 / 0.57 / 0.59 / 0.61 / 0.65 ms
+  const char* ssp = getenv("PINOT_GPU_SCAN_SPARSE");
+  g_engine.scan_sparse = !(ssp && ssp[0] == '0');
   const char* bla = getenv("PINOT_GPU_BATCH_LAUNCH");
   g_engine.batch_launch = !(bla && bla[0] == '0');
   const char* lp2 = getenv("PINOT_GPU_LEAP2");
@@ -2317,6 +2320,16 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       use_narrow = use_narrow && max_depth <= kNarrowStack;
     }
     const bool narrow_single = use_narrow && g_engine.scan_narrow_single && sp.num_nodes == 1 && sp.nodes[0].kind == kLeafDictRange;
+    // The whole filter is ONE bitmap that index_and_kernel made (its tiles listed), and every aggregated column is read as bit-packed
+    // fields: eight tiles per wave and iteration, only the matching docs' values are touched (scan_sparse_kernel)
+    const bool use_sparse = g_engine.scan_sparse && use_private && !use_hist && !use_narrow && !want_bitmap && pl.num_agg_cols > 0 && lw.tile_list != nullptr &&
+                            sp.num_nodes == 1 && sp.nodes[0].kind == kLeafBitmap && sp.nodes[0].exclusive == 0 && !(g_engine.flags & PG_CFG_PROFILE_WAVES);
+    if (use_sparse) {
+      const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
+      int bpc = std::max(1, waves_scan_sparse() / (kBlockThreads / 64));
+      if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
+      blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + 4 * kSparseTiles - 1) / (4 * kSparseTiles), (long long)seg->num_cus * bpc));
+    }
     if (use_narrow) {
       const int per_wave = narrow_single ? kNarrowSingleTiles : kNarrowTiles;
       const long long quads = (((long long)seg->num_docs + 2047) / 2048 + per_wave - 1) / per_wave;
@@ -2347,7 +2360,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // (the entries counted by the kernel travel in its record: BlockPartial.entries -- no counter to zero, no copy command)
     // The folded record -> the reference's holder types.  Everything is captured by value: pg_execute_batch calls it after this function
     // has returned (the query, the segment and the context's pinned counter outlive the batch).
-    const int kernel_id = use_hist ? PG_KERNEL_SCAN_HIST : use_narrow ? PG_KERNEL_SCAN_NARROW : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
+    const int kernel_id = use_hist ? PG_KERNEL_SCAN_HIST : use_narrow ? PG_KERNEL_SCAN_NARROW : use_sparse ? PG_KERNEL_SCAN_SPARSE : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
     const HostRecord* host_record = ctx->h_record;
     const int profile_waves = blocks * (geo.threads / 64);
     const size_t num_projected = projected.size();
@@ -2419,7 +2432,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     sp.lane_skip = g_engine.lane_skip ? 1 : 0;
     sp.sparse_lanes = g_engine.sparse_lanes;
     if (defer != nullptr) {
-      if (use_private && !use_hist && !use_narrow && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
+      if (use_private && !use_hist && !use_narrow && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
           (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf)) {
         defer->sp = sp;
         defer->blocks = blocks;
@@ -2437,6 +2450,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const bool one = pl.num_agg_cols <= 1;
     if (use_hist) launch_scan_hist(hist_cw, hist_guarded, blocks, hist_lds, ctx->stream, sp);
     else if (use_narrow) launch_scan_narrow(narrow_single, blocks, ctx->stream, sp);
+    else if (use_sparse) launch_scan_sparse(blocks, ctx->stream, sp);
     else if (use_private) launch_scan_private(one, blocks, ctx->stream, sp);
     else if (use_private_typed) launch_scan_private_typed(blocks, ctx->stream, sp);
     else launch_scan_agg(g_engine.use_dma, one, typed, blocks, geo.threads, lds, ctx->stream, sp);

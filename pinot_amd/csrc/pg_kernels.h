@@ -997,24 +997,18 @@ template <bool kLds>
 __device__ __forceinline__ void group_sum(long long* slot, long long v) {
   __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, kLds ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT);
 }
-// MIN / MAX in the LDS table: a running extreme moves rarely (the i-th doc of a group improves on the first i - 1 with probability
-// 1 / i for values in any order that is not sorted), so the slot is READ first and the atomic issued only by the lanes that would change
-// it.  A stale read can only be on the safe side (the slot moves one way), so at worst an atomic is issued that changes nothing.  A
-// plain ds_read_b32 costs the LDS pipe a fraction of a read-modify-write, and the exec-masked atomic that is left has few lanes to
-// serialise on a bank (SQ_LDS_BANK_CONFLICT was 73 % of the LDS-active cycles of C3 with unconditional atomics).
+// (Tried and dropped, profiles/r3/README.md: reading the slot first and issuing the MIN / MAX atomic only where it would change -- a
+//  running extreme moves rarely -- made C3 SLOWER, 0.98 -> 1.15 ms per 1 B rows: the read's result has to come back before the exec
+//  mask of the atomic is known, so every doc pays an LDS round trip where the unconditional atomic was fire-and-forget.)
 template <bool kLds>
 __device__ __forceinline__ void group_min(long long* slot, int32_t v) {
-  if constexpr (kLds) {
-    int32_t* s32 = reinterpret_cast<int32_t*>(slot);
-    if (v < __hip_atomic_load(s32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) __hip_atomic_fetch_min(s32, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  } else __hip_atomic_fetch_min(slot, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if constexpr (kLds) __hip_atomic_fetch_min(reinterpret_cast<int32_t*>(slot), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_fetch_min(slot, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool kLds>
 __device__ __forceinline__ void group_max(long long* slot, int32_t v) {
-  if constexpr (kLds) {
-    int32_t* s32 = reinterpret_cast<int32_t*>(slot);
-    if (v > __hip_atomic_load(s32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) __hip_atomic_fetch_max(s32, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  } else __hip_atomic_fetch_max(slot, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if constexpr (kLds) __hip_atomic_fetch_max(reinterpret_cast<int32_t*>(slot), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_fetch_max(slot, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One term of the raw key, dictId * multiplier (DictionaryBasedGroupKeyGenerator.java:437-445).  Up to 2^24 slots both factors

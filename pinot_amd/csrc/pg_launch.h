@@ -32,6 +32,9 @@ void launch_scan_private(bool one_slot, int blocks, hipStream_t stream, const Sc
 int waves_scan_private(bool one_slot);
 // scan_private_batch_kernel<slots>: many queries in one launch (pg_execute_batch); items / block_first are device memory
 void launch_scan_private_batch(bool one_slot, int total_blocks, hipStream_t stream, const ScanParams* items, const uint32_t* block_first, int num_items);
+// scan_sparse_kernel: aggregation of the docs one sparse bitmap names, eight tiles per wave and iteration (pg_scan_sparse.h)
+void launch_scan_sparse(int blocks, hipStream_t stream, const ScanParams& p);
+int waves_scan_sparse();
 // scan_narrow_kernel: COUNT(*) / docId bitmap of a filter over columns of at most 8 bits (pg_scan_narrow.h)
 void launch_scan_narrow(bool single_leaf, int blocks, hipStream_t stream, const ScanParams& p);      // single_leaf: scan_narrow_single_kernel, eight tiles per iteration
 int waves_scan_narrow(bool single_leaf);
