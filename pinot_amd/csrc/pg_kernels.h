@@ -1713,8 +1713,8 @@ __device__ __forceinline__ void agg_private_dispatch(int b, const uint32_t* lane
 // matching doc (SURVEY.md 8(d)'s min(B(v), M x 64 B)), the way the reference's projection reads only the docIds its filter left
 // (SVScanDocIdIterator.java:115-142 -> ProjectionOperator).
 struct __attribute__((aligned(4))) Dwords2 { uint32_t x, y; };
-__device__ __forceinline__ void agg_sparse_private(const uint32_t* __restrict__ lane_words, int b, uint32_t m, bool need_sum, bool need_minmax,
-                                                   unsigned long long& wsum, uint32_t& umin, uint32_t& umax) {
+__device__ __forceinline__ void agg_sparse_private(const uint32_t* __restrict__ lane_words, const uint32_t* __restrict__ tile_words, int b, uint32_t m, bool need_sum,
+                                                   bool need_minmax, unsigned long long& wsum, uint32_t& umin, uint32_t& umax) {
   const uint32_t field_mask = (1u << b) - 1u;
   uint32_t rest = m;
   while (__builtin_amdgcn_ballot_w64(rest != 0u) != 0ull) {
@@ -1728,8 +1728,9 @@ __device__ __forceinline__ void agg_sparse_private(const uint32_t* __restrict__ 
       rest &= rest - 1u;                                   // (0 stays 0)
       const uint32_t bit = j * (uint32_t)b;
       sh[k] = 64u - (bit & 31u) - (uint32_t)b;
-      d[k].x = 0u; d[k].y = 0u;
-      if (ok[k]) d[k] = *reinterpret_cast<const Dwords2*>(lane_words + (bit >> 5));
+      // unconditional (a lane without a k-th match reads the tile's first dwords, one sector for the whole wave): a load inside an
+      // exec-masked branch is waited for before the branch is left, which would make the four loads four round trips
+      d[k] = *reinterpret_cast<const Dwords2*>(ok[k] ? lane_words + (bit >> 5) : tile_words);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1814,7 +1815,7 @@ __device__ __forceinline__ void scan_private_body(const ScanParams& p, const uin
       const uint32_t* words = reinterpret_cast<const uint32_t*>(ac.fwd + tile * (256ll * ac.bits)) + lane * ac.bits;
       uint32_t psum = 0, tmin = 0xFFFFFFFFu, tmax = 0u;
       unsigned long long wsum = 0;
-      if (sparse_tile) agg_sparse_private(words, ac.bits, m, ac.need_sum != 0, ac.need_minmax != 0, wsum, tmin, tmax);
+      if (sparse_tile) agg_sparse_private(words, words - lane * ac.bits, ac.bits, m, ac.need_sum != 0, ac.need_minmax != 0, wsum, tmin, tmax);
       else if (lane_active) agg_private_dispatch(ac.bits, words, m, ac.need_sum != 0, ac.need_minmax != 0, psum, wsum, tmin, tmax);
       wsum += psum;
 #pragma unroll

@@ -212,8 +212,7 @@ __global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const Scan
           rest &= rest - 1u;
           const uint32_t bit = j * (uint32_t)ac.bits;
           sh[k] = 64u - (bit & 31u) - (uint32_t)ac.bits;
-          d[k].x = 0u; d[k].y = 0u;
-          if (ok[k]) d[k] = *reinterpret_cast<const Dwords2*>(words + (bit >> 5));
+          d[k] = *reinterpret_cast<const Dwords2*>(ok[k] ? words + (bit >> 5) : words - lane * ac.bits);          // unconditional: see agg_sparse_private
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

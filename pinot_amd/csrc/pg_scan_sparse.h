@@ -43,17 +43,25 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_sparse_kernel(const
   for (long long base = ((long long)blockIdx.x * waves_per_block + wave_in_block) * kSparseTiles; base < tile_limit; base += total_waves * kSparseTiles) {
     long long tile[kSparseTiles];
     uint32_t m[kSparseTiles];
+    // Every load below is UNCONDITIONAL (a lane or a tile with nothing to read points at an address that is always there): a load inside
+    // an exec-masked branch is waited for before the branch is left, which made the eight loads of a round eight round trips.
+    if (listed) {
+      uint32_t listed_tile[kSparseTiles];
 #pragma unroll
-    for (int i = 0; i < kSparseTiles; ++i) {
-      const long long idx = base + i;
-      const bool there = idx < tile_limit;
-      tile[i] = there ? (listed ? (long long)p.tile_list[idx] : idx) : 0;
-      m[i] = there ? mask_words[tile[i] * 64 + lane] : 0u;
+      for (int i = 0; i < kSparseTiles; ++i) listed_tile[i] = p.tile_list[base + i < tile_limit ? base + i : tile_limit - 1];
+#pragma unroll
+      for (int i = 0; i < kSparseTiles; ++i) tile[i] = (long long)listed_tile[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < kSparseTiles; ++i) tile[i] = base + i < tile_limit ? base + i : tile_limit - 1;
     }
+#pragma unroll
+    for (int i = 0; i < kSparseTiles; ++i) m[i] = mask_words[tile[i] * 64 + lane];
 #pragma unroll
     for (int i = 0; i < kSparseTiles; ++i) {
       const long long rem = (long long)p.num_docs - (tile[i] * 2048 + lane * 32);          // docs past numDocs (last tile only)
       m[i] &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
+      if (base + i >= tile_limit) m[i] = 0u;                                                // past the last tile of the list
       count += (unsigned)__builtin_popcount(m[i]);
     }
     for (int a = 0; a < p.num_agg_cols; ++a) {
@@ -80,8 +88,9 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_sparse_kernel(const
           any |= rest[i] != 0u;
           const uint32_t bit = j * b;
           sh[i] = 64u - (bit & 31u) - b;
-          d[i].x = 0u; d[i].y = 0u;
-          if (ok[i]) d[i] = *reinterpret_cast<const Dwords2*>(reinterpret_cast<const uint32_t*>(ac.fwd + tile[i] * (256ll * (long long)b)) + (uint32_t)lane * b + (bit >> 5));
+          // (a lane without a match in this tile reads the column's first dwords: one line the whole chip shares)
+          const uint32_t* at = reinterpret_cast<const uint32_t*>(ac.fwd + tile[i] * (256ll * (long long)b)) + (uint32_t)lane * b + (bit >> 5);
+          d[i] = *reinterpret_cast<const Dwords2*>(ok[i] ? at : reinterpret_cast<const uint32_t*>(ac.fwd));
         }
 #pragma unroll
         for (int i = 0; i < kSparseTiles; ++i) {
