@@ -256,7 +256,7 @@ pg_status acquire_ctx(pg_segment* seg, ExecCtx** out) {
   if (e == hipSuccess) { memset(c->h_record, 0, sizeof(HostRecord)); c->h_partial = &c->h_record->partial; }
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->h_record_dev, c->h_record, 0);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_done, 10 * 128);      // fold: eight shards + the top counter; leapfrog2_chain_kernel: one more
-  if (e == hipSuccess) e = hipMemset(c->d_done, 0, 10 * 128);
+  if (e == hipSuccess) e = hipMemsetAsync(c->d_done, 0, 10 * 128, c->stream);      // on the context's OWN stream: ordered before its first kernel (a null-stream memset is not)
   if (e != hipSuccess) {
     destroy_ctx(c);
     return fail(PG_ERR_DEVICE, "creating execution context failed: %s", hipGetErrorString(e));
@@ -1822,6 +1822,12 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
     seg->device_bytes += image.fwd_alloc_bytes;
     seg->cols[(size_t)i].nullkey_column = (int)seg->cols.size();
     seg->cols.push_back(std::move(image));
+  }
+  // Everything enqueued above (null-stream memsets of the padding, the posting expansion) has run before the first query can: the
+  // queries' streams are non-blocking, they do not wait for the null stream by themselves.
+  {
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "opening segment %s: %s", seg->name.c_str(), hipGetErrorString(e)));
   }
   *out_segment = seg;
   return PG_OK;
@@ -3468,7 +3474,7 @@ pg_status ensure_batch_ctx(BatchCtx* b, int items, size_t partials) {
     memset(b->h_records, 0, sizeof(HostRecord) * (size_t)cap);
     HIP_TRY(hipHostGetDevicePointer((void**)&b->h_records_dev, b->h_records, 0));
     HIP_TRY(hipMalloc((void**)&b->d_done, (size_t)cap * (kFoldShards + 1) * kFoldStride * 4));
-    HIP_TRY(hipMemset(b->d_done, 0, (size_t)cap * (kFoldShards + 1) * kFoldStride * 4));
+    HIP_TRY(hipMemsetAsync(b->d_done, 0, (size_t)cap * (kFoldShards + 1) * kFoldStride * 4, b->stream));      // ordered before the batch's launches
     b->item_capacity = cap;
   }
   if (b->partial_capacity < partials) {
