@@ -7,8 +7,9 @@ Headline workload, C2b of BASELINE.md section 3:   SELECT SUM(v) FROM t WHERE f 
   predicate lowered to the dictId range [0, 100) (10 % selectivity); s = segment number.
 C4: `--segments S` (default 8) segments IN TOTAL at every N; segment s lives on GPU (s mod N), one process
 per GPU, no collective on the data path: the 16-byte partials travel over gloo and are merged on the host (SumAggregationFunction.merge).
-A step = one pg_execute per resident segment of the rank (fused scan -> filter -> SUM kernel + a one-block partial reduction +
-200-byte readback + stream sync).  value = S * rows * steps / time, "scaling": "strong".  Columns are generated on the host by the
+A step = one pg_execute per resident segment of the rank, one after the other (fused scan -> filter -> SUM kernel, its records folded
+into a pinned 200-byte host record).  `overlapped` reports the same step with the rank's segments in flight together (pg_execute_batch:
+one launch for all of them; or one pg_execute per segment on the library's worker threads).  value = S * rows * steps / time, "scaling": "strong".  Columns are generated on the host by the
 product's C++ writer in Pinot's on-disk layout and copied to HBM by pg_segment_open before the timed region.
 
 Launch:  python bench.py --gpus 1 --steps 20 --warmup 3
@@ -186,6 +187,45 @@ def main():
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
     kernel_name = _abi.KERNEL_NAMES[kernel_id[0]]
 
+    # The same step with the rank's segments in flight TOGETHER, the way a server's combine workers would issue them (BaseCombineOperator:
+    # one task per segment on a thread pool): (a) pg_execute_batch -- ONE launch, every segment folding its own record; (b) the library's
+    # worker threads, one pg_execute per segment on a stream of its own.  Reported next to the serial step above (which stays `value`).
+    overlapped = None
+    if len(gsegs) > 1:
+        nseg = len(gsegs)
+        handles = (C.c_void_p * nseg)(*[g.handle for g in gsegs])
+        queries = (C.POINTER(_abi.pg_query) * nseg)(*[C.pointer(spec.c) for _ in gsegs])
+        bres = (_abi.pg_result * nseg)()
+        bst = (C.c_int * nseg)()
+        overlapped = {}
+
+        def batch_step():
+            if engine.execute_batch_raw(handles, queries, nseg, bres, bst) != _abi.PG_OK:
+                raise RuntimeError(lib.pg_last_error().decode())
+            ms = bres[0].device_ms
+            for i in range(nseg):
+                if bst[i] != _abi.PG_OK or (int(bres[i].aggregations[0].sum_i64), int(bres[i].aggregations[0].count)) != partials[i]:
+                    raise RuntimeError("batch item %d differs from pg_execute" % i)
+                lib.pg_result_free(C.byref(bres[i]))
+            return ms
+
+        for mode, env in (("batch_one_launch", None), ("worker_threads", "0")):
+            if env is not None:
+                engine.reinit(PINOT_GPU_BATCH_LAUNCH=env)
+            for _ in range(max(args.warmup, 2)):
+                batch_step()
+            barrier()
+            t0 = time.perf_counter()
+            dev = [batch_step() for _ in range(args.steps)]
+            barrier()
+            secs = D.max_over_ranks(time.perf_counter() - t0, "cpu")
+            overlapped[mode] = {"ms_per_step": secs / args.steps * 1e3, "rows_per_s": num_segments * n * args.steps / secs,
+                                "hbm_GBps_whole_step": num_segments * algorithmic_bytes * args.steps / secs / 1e9}
+            if env is None:
+                overlapped[mode]["kernel_ms"] = sum(dev) / len(dev)
+            else:
+                engine.reinit(PINOT_GPU_BATCH_LAUNCH=None)
+
     result = None
     if rank == 0:
         # HBM traffic per launch comes from a separate rocprofv3 --pmc pass (counters cannot be collected inside this process):
@@ -223,6 +263,7 @@ def main():
                          "launches_timed": len(kernel_ms), "algorithmic_bytes_per_launch": algorithmic_bytes},
             "clock_settle_launches": settle,
             "hbm_GBps_whole_step": num_segments * algorithmic_bytes * args.steps / elapsed / 1e9,
+            "overlapped": overlapped,
             "result": {"sum": merged_sum, "count": merged_count},
             "setup": {"host_generate_s": gen_s, "segment_open_h2d_s": h2d_s, "device_bytes": device_bytes,
                       "h2d_GBps": device_bytes / h2d_s / 1e9, "host_threads": S.host_threads()},

@@ -689,7 +689,8 @@ __device__ __forceinline__ void partial_merge(BlockPartial& acc, const BlockPart
 // kmax64) and the PG_CFG_PROFILE_WAVES cycle counters only when the query uses them.  A record has thirty 64-bit-reduced fields; a
 // COUNT / one-column SUM needs five of them, and the wave-level reductions are what a one-workgroup fold spends its time on.
 struct FoldFields { int slots; bool typed; bool cycles; };
-__device__ __forceinline__ FoldFields fold_fields_of(const ScanParams& p) { return FoldFields{p.fold_slots, p.fold_typed != 0, p.profile != 0}; }
+template <typename P>
+__device__ __forceinline__ FoldFields fold_fields_of(const P& p) { return FoldFields{p.fold_slots, p.fold_typed != 0, p.profile != 0}; }
 
 // Every lane's record folded over the wave (all lanes return the same record).
 __device__ __forceinline__ void partial_wave_reduce(BlockPartial& acc, const FoldFields ff) {
@@ -786,7 +787,8 @@ static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel
 constexpr int kFoldShards = 8, kFoldStride = 32;      // counters are kFoldStride dwords apart; kFoldShards * kFoldStride is the top counter
 // `block_index` of `num_blocks`: the workgroup's place among those that work on this ScanParams (the whole grid, or one query's share of
 // a batch launch -- scan_private_batch_kernel).
-__device__ __forceinline__ void publish_block_partial(const ScanParams& p, BlockPartial* red, int waves_per_block, uint32_t* flag, uint32_t block_index,
+template <typename P>
+__device__ __forceinline__ void publish_block_partial(const P& p, BlockPartial* red, int waves_per_block, uint32_t* flag, uint32_t block_index,
                                                       uint32_t num_blocks) {
   if (threadIdx.x == 0) {
     BlockPartial acc = red[0];
@@ -822,7 +824,8 @@ __device__ __forceinline__ void publish_block_partial(const ScanParams& p, Block
     else p.partials[num_blocks] = t;
   }
 }
-__device__ __forceinline__ void publish_block_partial(const ScanParams& p, BlockPartial* red, int waves_per_block, uint32_t* flag) {
+template <typename P>
+__device__ __forceinline__ void publish_block_partial(const P& p, BlockPartial* red, int waves_per_block, uint32_t* flag) {
   publish_block_partial(p, red, waves_per_block, flag, blockIdx.x, gridDim.x);
 }
 
@@ -1327,9 +1330,26 @@ __global__ __launch_bounds__(kGroupBlockThreads) void scan_group_kernel(const Gr
 // byte swap per dword.  The LDS pipe, which bounds the staged kernel (three 8-byte reads per doc + the DMA writes + the atomics),
 // is left with the group-table atomics only.
 // ------------------------------------------------------------------------------------------------
+// A pointer read from DEVICE MEMORY (scan_private_batch_kernel's items) is a generic pointer to the compiler: every load through it is a
+// flat_load -- LDS-aperture check, counted in BOTH vmcnt and lgkmcnt so that scalar and LDS waits serialise behind it (measured: the
+// batch kernel ran at 65 % of the single launch's rate, 1373 flat_loads in place of global_loads).  Kernel-argument pointers are known
+// to be global; for a pointer that came from memory the LOAD has to say so -- an address_space(1) pointer type, which the decode
+// helpers below take as a template parameter (a cast back to a generic pointer loses it again).
+typedef const __attribute__((address_space(1))) uint32_t* GlobalWords;
+typedef __attribute__((address_space(1))) uint32_t* GlobalWordsOut;
+__device__ __forceinline__ GlobalWords global_words(const void* ptr) { return (GlobalWords)(const uint32_t*)ptr; }
+struct __attribute__((aligned(4))) Dwords2 { uint32_t x, y; };
+// the two dwords at `at` (4-byte aligned), whichever address space the pointer type names
+__device__ __forceinline__ Dwords2 load_dwords2(const uint32_t* at) { return *reinterpret_cast<const Dwords2*>(at); }
+typedef uint32_t DwordPair __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ Dwords2 load_dwords2(GlobalWords at) {
+  const DwordPair v = *(const __attribute__((address_space(1))) DwordPair*)at;
+  return Dwords2{v.x, v.y};
+}
+
 // Values 16*H .. 16*H+15 of the lane's 32 (H = 0, 1).  `lane_words` = first dword of the lane's B-dword chunk.
-template <int B, int H>
-__device__ __forceinline__ void decode16_private(const uint32_t* __restrict__ lane_words, uint32_t (&v)[16]) {
+template <int B, int H, typename WP>
+__device__ __forceinline__ void decode16_private(WP __restrict__ lane_words, uint32_t (&v)[16]) {
   constexpr int first_bit = 16 * B * H;
   constexpr int w0 = first_bit >> 5;
   constexpr int w1 = (16 * B * (H + 1) - 1) >> 5;
@@ -1346,8 +1366,8 @@ __device__ __forceinline__ void decode16_private(const uint32_t* __restrict__ la
   }
 }
 
-template <int H>
-__device__ __forceinline__ void decode16_private_dispatch(int b, const uint32_t* lane_words, uint32_t (&v)[16]) {
+template <int H, typename WP>
+__device__ __forceinline__ void decode16_private_dispatch(int b, WP lane_words, uint32_t (&v)[16]) {
   switch (b) {
 #define PG_CASE(B) case B: decode16_private<B, H>(lane_words, v); break;
     PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10)
@@ -1373,8 +1393,8 @@ __device__ __forceinline__ void decode16_private_dispatch(int b, const uint32_t*
 // against ~4.5 and ~4-12 in the LDS-staged kernel, whose decode needs a per-lane byte gather (v_perm) on top of the extract.
 // ------------------------------------------------------------------------------------------------
 // Sixteen values (half H) of the lane's chunk of a B-bit column: mask bits of ((value - lo) < span), most recent value in bit 0.
-template <int B, int H, bool kLoZero>
-__device__ __forceinline__ void range16_private(const uint32_t* __restrict__ lane_words, uint32_t lo, uint32_t span, uint32_t& m) {
+template <int B, int H, bool kLoZero, typename WP>
+__device__ __forceinline__ void range16_private(WP __restrict__ lane_words, uint32_t lo, uint32_t span, uint32_t& m) {
   uint32_t v[16];
   decode16_private<B, H>(lane_words, v);
 #pragma unroll
@@ -1383,8 +1403,8 @@ __device__ __forceinline__ void range16_private(const uint32_t* __restrict__ lan
 
 // C2a shape -- SUM(col) WHERE col in range, one leaf and one summed column reading the SAME stream: decode once, and use the
 // compare's VCC twice (select the value for the sum, then shift the match into the mask).  One load phase per tile instead of two.
-template <int B, int H, bool kLoZero>
-__device__ __forceinline__ void range_sum16_private(const uint32_t* __restrict__ lane_words, uint32_t lo, uint32_t span, uint32_t& m, uint32_t& psum,
+template <int B, int H, bool kLoZero, typename WP>
+__device__ __forceinline__ void range_sum16_private(WP __restrict__ lane_words, uint32_t lo, uint32_t span, uint32_t& m, uint32_t& psum,
                                                     unsigned long long& wsum) {
   uint32_t v[16];
   decode16_private<B, H>(lane_words, v);
@@ -1399,8 +1419,8 @@ __device__ __forceinline__ void range_sum16_private(const uint32_t* __restrict__
   }
 }
 
-template <bool kLoZero>
-__device__ __forceinline__ uint32_t range_sum_private_dispatch(int b, const uint32_t* lane_words, uint32_t lo, uint32_t span, unsigned long long& wsum) {
+template <bool kLoZero, typename WP>
+__device__ __forceinline__ uint32_t range_sum_private_dispatch(int b, WP lane_words, uint32_t lo, uint32_t span, unsigned long long& wsum) {
   uint32_t m = 0, psum = 0;
   switch (b) {
 #define PG_CASE(B) case B: range_sum16_private<B, 0, kLoZero>(lane_words, lo, span, m, psum, wsum); range_sum16_private<B, 1, kLoZero>(lane_words, lo, span, m, psum, wsum); break;
@@ -1415,8 +1435,8 @@ __device__ __forceinline__ uint32_t range_sum_private_dispatch(int b, const uint
   return __builtin_bitreverse32(m);
 }
 
-template <bool kLoZero>
-__device__ __forceinline__ uint32_t range_private_dispatch(int b, const uint32_t* lane_words, uint32_t lo, uint32_t span) {
+template <bool kLoZero, typename WP>
+__device__ __forceinline__ uint32_t range_private_dispatch(int b, WP lane_words, uint32_t lo, uint32_t span) {
   uint32_t m = 0;
   switch (b) {
 #define PG_CASE(B) case B: range16_private<B, 0, kLoZero>(lane_words, lo, span, m); range16_private<B, 1, kLoZero>(lane_words, lo, span, m); break;
@@ -1430,19 +1450,21 @@ __device__ __forceinline__ uint32_t range_private_dispatch(int b, const uint32_t
   return __builtin_bitreverse32(m);      // value j -> bit j
 }
 
-__device__ __forceinline__ uint32_t eval_leaf_private(const ScanParams& p, const DevNode& L, long long tile, int lane) {
+// (P / N: ScanParams / DevNode, or their constant-address-space forms in scan_private_batch_kernel)
+template <typename P, typename N>
+__device__ __forceinline__ uint32_t eval_leaf_private(const P& p, const N& L, long long tile, int lane) {
   uint32_t m;
   switch (L.kind) {
     case kLeafMatchAll: m = 0xFFFFFFFFu; break;
     case kLeafMatchNone: m = 0u; break;
     case kLeafDictRange: {
-      const uint32_t* words = reinterpret_cast<const uint32_t*>(L.fwd + tile * (256ll * L.bits)) + lane * L.bits;
+      const GlobalWords words = global_words(L.fwd + tile * (256ll * L.bits)) + lane * L.bits;
       m = L.lo == 0 ? range_private_dispatch<true>(L.bits, words, 0u, L.span) : range_private_dispatch<false>(L.bits, words, (uint32_t)L.lo, L.span);
       break;
     }
     case kLeafDictSet: {
       // InPredicateEvaluator: bit dictId of the set (the words stay L1-resident)
-      const uint32_t* words = reinterpret_cast<const uint32_t*>(L.fwd + tile * (256ll * L.bits)) + lane * L.bits;
+      const GlobalWords words = global_words(L.fwd + tile * (256ll * L.bits)) + lane * L.bits;
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)L.set_words, 0, L.set_bytes, 0x00020000);
       m = 0;
 #pragma unroll
@@ -1459,7 +1481,7 @@ __device__ __forceinline__ uint32_t eval_leaf_private(const ScanParams& p, const
     case kLeafRawRange: {
       // raw INT column: the lane's 32 docs are 128 contiguous bytes (pg_segment_open pads raw buffers to whole 2048-doc tiles, so
       // the last tile needs no clamping; its surplus docs are masked by the caller)
-      const uint32_t* vals = reinterpret_cast<const uint32_t*>(L.fwd) + tile * 2048 + lane * 32;
+      const GlobalWords vals = global_words(L.fwd) + tile * 2048 + lane * 32;
       const uint32_t lo = (uint32_t)L.lo, span = L.span;
       m = 0;
 #pragma unroll
@@ -1485,7 +1507,7 @@ __device__ __forceinline__ uint32_t eval_leaf_private(const ScanParams& p, const
       break;
     }
     default: {  // kLeafBitmap: the lane's mask is one dword of the doc-order bitmap
-      m = L.set_words[tile * 64 + lane];
+      m = global_words(L.set_words)[tile * 64 + lane];
       break;
     }
   }
@@ -1507,7 +1529,8 @@ __device__ __forceinline__ uint32_t eval_leaf_private(const ScanParams& p, const
 // state after the tile, and whether the tile has no event at all.  leapfrog2_chain_kernels add the sum of delta over the tiles that are
 // entered in state 1.  ~30 vector + ~15 scalar instructions per 2048 docs next to the ~230 the two leaves cost.
 //     byte = (delta + 1) | (state after the tile, entered in 0) << 2 | (tile has no event) << 3
-__device__ __forceinline__ void leapfrog2_tile(const ScanParams& p, long long tile, int lane, uint32_t a, uint32_t b, uint32_t& entries) {
+template <typename P>
+__device__ __forceinline__ void leapfrog2_tile(const P& p, long long tile, int lane, uint32_t a, uint32_t b, uint32_t& entries) {
   const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
   const uint32_t valid = rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));      // docs past numDocs are not there
   a &= valid; b &= valid;
@@ -1528,7 +1551,7 @@ __device__ __forceinline__ void leapfrog2_tile(const ScanParams& p, long long ti
     const int bit = __builtin_ctz(Ef);
     delta = (int)((Yf >> bit) & 1u) - (int)((Xf >> bit) & 1u);
   }
-  if (lane == 0) p.leap_tables[tile] = (uint8_t)((uint32_t)(delta + 1) | ((tile_carry ? 1u : 0u) << 2) | ((with_events == 0ull ? 1u : 0u) << 3));
+  if (lane == 0) ((__attribute__((address_space(1))) uint8_t*)p.leap_tables)[tile] = (uint8_t)((uint32_t)(delta + 1) | ((tile_carry ? 1u : 0u) << 2) | ((with_events == 0ull ? 1u : 0u) << 3));
 }
 
 // The chain: sum over the tiles of [tile entered in state 1] * delta(tile), the entry states being the carries of (generate, propagate)
@@ -1622,7 +1645,8 @@ static __global__ __launch_bounds__(1024) void leapfrog2_chain_kernel(const uint
 // `entries`: per-lane share of numEntriesScannedInFilter -- a kNodeCountEntries leaf is a scan-based child of the root AND that the
 // reference and-s into the docIds left by the children before it (ScanBasedDocIdIterator.applyAnd, AndDocIdSet.java:161-163,
 // SVScanDocIdIterator.java:115-145: one entry per doc of that bitmap).  On the AND chain the only mask on the stack is that bitmap.
-__device__ __forceinline__ uint32_t eval_filter_private(const ScanParams& p, long long tile, int lane, uint32_t& entries) {
+template <typename P>
+__device__ __forceinline__ uint32_t eval_filter_private(const P& p, long long tile, int lane, uint32_t& entries) {
   if (p.num_nodes == 0) return 0xFFFFFFFFu;
   if (p.num_nodes == 1) return eval_leaf_private(p, p.nodes[0], tile, lane);
   MaskStack st;
@@ -1630,7 +1654,7 @@ __device__ __forceinline__ uint32_t eval_filter_private(const ScanParams& p, lon
   for (int i = 0; i < kStackDepth; ++i) st.v[i] = 0;
   st.sp = 0;
   for (int n = 0; n < p.num_nodes; ++n) {
-    const DevNode& nd = p.nodes[n];
+    const auto& nd = p.nodes[n];
     uint32_t top;
     if (nd.op == PG_FILTER_LEAF) {
       if (nd.flags & kNodeCountEntries) {
@@ -1655,15 +1679,16 @@ __device__ __forceinline__ uint32_t eval_filter_private(const ScanParams& p, lon
   return st.pop();
 }
 
-__device__ __forceinline__ void flush_filter_entries(const ScanParams& p, uint32_t entries) {
+template <typename P>
+__device__ __forceinline__ void flush_filter_entries(const P& p, uint32_t entries) {
   if (p.filter_entries == nullptr) return;
   const unsigned long long total = (unsigned long long)wave_sum_i64((long long)entries);
   if ((threadIdx.x & 63u) == 0u && total != 0ull) atomicAdd(p.filter_entries, total);
 }
 
 // Masked aggregation of one half (16 values) of a column chunk.  Keys (dictIds / plane fields) are below 2^31.
-template <int B, int H>
-__device__ __forceinline__ void agg16_private(const uint32_t* __restrict__ lane_words, uint32_t m, bool need_sum, bool need_minmax,
+template <int B, int H, typename WP>
+__device__ __forceinline__ void agg16_private(WP __restrict__ lane_words, uint32_t m, bool need_sum, bool need_minmax,
                                               uint32_t& psum, unsigned long long& wsum, uint32_t& umin, uint32_t& umax) {
   uint32_t v[16];
   decode16_private<B, H>(lane_words, v);
@@ -1691,7 +1716,8 @@ __device__ __forceinline__ void agg16_private(const uint32_t* __restrict__ lane_
   }
 }
 
-__device__ __forceinline__ void agg_private_dispatch(int b, const uint32_t* lane_words, uint32_t m, bool need_sum, bool need_minmax,
+template <typename WP>
+__device__ __forceinline__ void agg_private_dispatch(int b, WP lane_words, uint32_t m, bool need_sum, bool need_minmax,
                                                      uint32_t& psum, unsigned long long& wsum, uint32_t& umin, uint32_t& umax) {
   switch (b) {
 #define PG_CASE(B) case B: agg16_private<B, 0>(lane_words, m, need_sum, need_minmax, psum, wsum, umin, umax); \
@@ -1712,8 +1738,8 @@ __device__ __forceinline__ void agg_private_dispatch(int b, const uint32_t* lane
 // 17-dword chunk load and the 32-value decode of every lane that holds a match -- the value column is touched one 64-byte sector per
 // matching doc (SURVEY.md 8(d)'s min(B(v), M x 64 B)), the way the reference's projection reads only the docIds its filter left
 // (SVScanDocIdIterator.java:115-142 -> ProjectionOperator).
-struct __attribute__((aligned(4))) Dwords2 { uint32_t x, y; };
-__device__ __forceinline__ void agg_sparse_private(const uint32_t* __restrict__ lane_words, const uint32_t* __restrict__ tile_words, int b, uint32_t m, bool need_sum,
+template <typename WP>
+__device__ __forceinline__ void agg_sparse_private(WP __restrict__ lane_words, WP __restrict__ tile_words, int b, uint32_t m, bool need_sum,
                                                    bool need_minmax, unsigned long long& wsum, uint32_t& umin, uint32_t& umax) {
   const uint32_t field_mask = (1u << b) - 1u;
   uint32_t rest = m;
@@ -1730,7 +1756,7 @@ __device__ __forceinline__ void agg_sparse_private(const uint32_t* __restrict__ 
       sh[k] = 64u - (bit & 31u) - (uint32_t)b;
       // unconditional (a lane without a k-th match reads the tile's first dwords, one sector for the whole wave): a load inside an
       // exec-masked branch is waited for before the branch is left, which would make the four loads four round trips
-      d[k] = *reinterpret_cast<const Dwords2*>(ok[k] ? lane_words + (bit >> 5) : tile_words);
+      d[k] = load_dwords2(ok[k] ? lane_words + (bit >> 5) : tile_words);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1749,8 +1775,8 @@ __device__ __forceinline__ void agg_sparse_private(const uint32_t* __restrict__ 
 #endif
 // The kernel's body: workgroup `block_index` of the `num_blocks` that work on `p` (the whole grid in scan_private_kernel; one query's
 // share of the grid in scan_private_batch_kernel, where p is read from device memory).
-template <int kAggSlots>
-__device__ __forceinline__ void scan_private_body(const ScanParams& p, const uint32_t block_index, const uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr) {
+template <int kAggSlots, typename P>
+__device__ __forceinline__ void scan_private_body(const P& p, const uint32_t block_index, const uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
@@ -1779,12 +1805,12 @@ __device__ __forceinline__ void scan_private_body(const ScanParams& p, const uin
   // index-driven filters: only the tiles index_and_kernel listed hold a match (any order)
   uint32_t entries = 0u;                                   // numEntriesScannedInFilter, this lane's share
   const bool listed = p.tile_list != nullptr;
-  const long long tile_limit = listed ? (long long)*p.tile_count : num_tiles;
+  const long long tile_limit = listed ? (long long)*global_words(p.tile_count) : num_tiles;
   for (long long tile_it = (long long)block_index * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
-    const long long tile = listed ? (long long)p.tile_list[tile_it] : tile_it;
+    const long long tile = listed ? (long long)global_words(p.tile_list)[tile_it] : tile_it;
     if (fused) {
-      const DevNode& L = p.nodes[0];
-      const uint32_t* words = reinterpret_cast<const uint32_t*>(L.fwd + tile * (256ll * L.bits)) + lane * L.bits;
+      const auto& L = p.nodes[0];
+      const GlobalWords words = global_words(L.fwd + tile * (256ll * L.bits)) + lane * L.bits;
       unsigned long long wsum = 0;
       uint32_t fm = L.lo == 0 ? range_sum_private_dispatch<true>(L.bits, words, 0u, L.span, wsum) : range_sum_private_dispatch<false>(L.bits, words, (uint32_t)L.lo, L.span, wsum);
       // the padding past numDocs decodes to field 0: it can only match when lo == 0, and then it adds 0 to the sum
@@ -1798,7 +1824,7 @@ __device__ __forceinline__ void scan_private_body(const ScanParams& p, const uin
     // docs past numDocs (last tile only)
     const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
-    if (p.out_bitmap) reinterpret_cast<uint32_t*>(p.out_bitmap)[tile * 64 + lane] = m;
+    if (p.out_bitmap) ((GlobalWordsOut)reinterpret_cast<uint32_t*>(p.out_bitmap))[tile * 64 + lane] = m;
     count += (unsigned)__builtin_popcount(m);
     if (p.num_agg_cols == 0 || __builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
     // one instance of the width dispatch for all slots (a runtime loop: unrolling it four times quadruples the code and keeps
@@ -1811,8 +1837,8 @@ __device__ __forceinline__ void scan_private_body(const ScanParams& p, const uin
     // few lanes of the tile hold a match: walk the matches instead of decoding whole chunks (agg_sparse_private)
     const bool sparse_tile = __builtin_popcountll(__builtin_amdgcn_ballot_w64(m != 0u)) <= p.sparse_lanes;
     for (int a = 0; a < p.num_agg_cols; ++a) {
-      const DevAggCol& ac = p.agg_cols[a];
-      const uint32_t* words = reinterpret_cast<const uint32_t*>(ac.fwd + tile * (256ll * ac.bits)) + lane * ac.bits;
+      const auto& ac = p.agg_cols[a];
+      const GlobalWords words = global_words(ac.fwd + tile * (256ll * ac.bits)) + lane * ac.bits;
       uint32_t psum = 0, tmin = 0xFFFFFFFFu, tmax = 0u;
       unsigned long long wsum = 0;
       if (sparse_tile) agg_sparse_private(words, words - lane * ac.bits, ac.bits, m, ac.need_sum != 0, ac.need_minmax != 0, wsum, tmin, tmax);
@@ -1874,7 +1900,14 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
     if (bp.block_first[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const uint32_t first = bp.block_first[lo];
-  scan_private_body<kAggSlots>(bp.items[lo], blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
+  // The item is read through a CONSTANT-address-space reference: memory the kernel never writes, so its (wave-uniform) fields are scalar
+  // loads the compiler may repeat or hoist at will, like kernel arguments.  Through a plain pointer they were VECTOR loads inside the
+  // tile loop (a uniform load is only selected as s_load when no store of the kernel can have clobbered it; the loop stores bitmaps and
+  // leap-frog tables): global_load + s_waitcnt vmcnt(0) + v_readfirstlane per field and tile, a third dependent round trip per tile.
+  // Measured on one 1 B-row item: 0.91 ms against the single launch's 0.69.
+  typedef const __attribute__((address_space(4))) ScanParams ConstantScanParams;
+  const ConstantScanParams& item = *(ConstantScanParams*)(bp.items + lo);
+  scan_private_body<kAggSlots>(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
 }
 
 // The slot of `key` in an open-addressing table of (mask + 1) slots, claiming a free one if the key is new (kHashEmpty = free).  The

@@ -31,6 +31,9 @@ SETTINGS = {
     "sparse32": {"PINOT_GPU_SPARSE_LANES": "32"},
     "sparse48": {"PINOT_GPU_SPARSE_LANES": "48"},
     "sparse64": {"PINOT_GPU_SPARSE_LANES": "64"},
+    "bpc8": {"PINOT_GPU_BLOCKS_PER_CU": "8"},
+    "bpc16": {"PINOT_GPU_BLOCKS_PER_CU": "16"},
+    "bpc32": {"PINOT_GPU_BLOCKS_PER_CU": "32"},
 }
 KNOBS = sorted({k for s in SETTINGS.values() for k in s})
 
