@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -3368,49 +3369,64 @@ namespace {
 // side.  Started on first use, parked on a condition variable in between.
 struct WorkerPool {
   std::mutex mu;
-  std::condition_variable wake, done;
+  std::condition_variable wake;
   std::vector<std::thread> threads;
   std::function<void(int)> job;        // job(item)
-  int next = 0, count = 0, running = 0;
+  std::atomic<int> next{0}, remaining{0}, inside{0};
+  int count = 0, grain = 1, helpers = 0;
   unsigned long long generation = 0;
   bool stop = false;
 
-  void worker() {
+  // Items are claimed `grain` at a time with ONE atomic add (a mutex hand-off per item cost more than lowering a query: 64 items of
+  // ~2 us each took 80 us on 16 threads); whoever finishes the last item ends the run.
+  void drain() {
+    for (;;) {
+      const int first = next.fetch_add(grain, std::memory_order_relaxed);
+      if (first >= count) return;
+      const int last = std::min(count, first + grain);
+      for (int item = first; item < last; ++item) job(item);
+      remaining.fetch_sub(last - first, std::memory_order_release);
+    }
+  }
+  void worker(int index) {
     unsigned long long seen = 0;
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
-      wake.wait(lk, [&] { return stop || (generation != seen && next < count); });
+      wake.wait(lk, [&] { return stop || generation != seen; });
       if (stop) return;
       seen = generation;
-      ++running;
-      while (next < count) {
-        const int item = next++;
-        lk.unlock();
-        job(item);
-        lk.lock();
-      }
-      if (--running == 0) done.notify_all();
-    }
-  }
-  // Runs job(0 .. n) on the pool and the calling thread; returns when all are done.
-  void run(int n, int max_threads, std::function<void(int)> fn) {
-    std::unique_lock<std::mutex> lk(mu);
-    const int want = std::max(0, std::min(max_threads, n) - 1);
-    while ((int)threads.size() < want) threads.emplace_back([this] { worker(); });
-    job = std::move(fn);
-    next = 0; count = n;
-    ++generation;
-    ++running;
-    wake.notify_all();
-    while (next < count) {
-      const int item = next++;
+      if (index >= helpers) continue;
+      inside.fetch_add(1, std::memory_order_acquire);
       lk.unlock();
-      job(item);
+      drain();
+      inside.fetch_sub(1, std::memory_order_release);
       lk.lock();
     }
-    --running;
-    done.wait(lk, [&] { return running == 0; });
-    count = 0;
+  }
+  // Runs job(0 .. n) on the pool and the calling thread; returns when all are done.  `items_per_claim`: how many items a thread takes
+  // at a time (1 for items that wait for the device, more for items of a few microseconds).
+  void run(int n, int max_threads, int items_per_claim, std::function<void(int)> fn) {
+    if (n <= 0) return;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      const int want = std::max(0, std::min(max_threads, (n + items_per_claim - 1) / items_per_claim) - 1);
+      while ((int)threads.size() < want) { const int index = (int)threads.size(); threads.emplace_back([this, index] { worker(index); }); }
+      // a helper woken late for the previous run may be inside drain() (it enters under this mutex and finds nothing left): let it leave
+      while (inside.load(std::memory_order_acquire) != 0) {}
+      job = std::move(fn);
+      count = n; grain = std::max(1, items_per_claim); helpers = want;
+      next.store(0, std::memory_order_relaxed);
+      remaining.store(n, std::memory_order_relaxed);
+      ++generation;
+      if (want > 0) wake.notify_all();
+    }
+    drain();
+    // the last items are in other threads' hands for microseconds (lowering) or for a kernel's duration (worker_threads mode): spin
+    // briefly, then yield; no helper may still be inside drain() when the next run rewrites job / count
+    long long spins = 0;
+    while (remaining.load(std::memory_order_acquire) != 0 || inside.load(std::memory_order_acquire) != 0) {
+      if (++spins > 2000) std::this_thread::yield();
+    }
   }
   ~WorkerPool() {
     { std::lock_guard<std::mutex> lk(mu); stop = true; }
@@ -3533,15 +3549,33 @@ pg_status run_deferred(int device, const std::vector<int>& items, std::vector<De
   }
   b->h_first[n] = first;
   const bool timed = (g_engine.flags & PG_CFG_TIME_KERNELS) != 0;
+  static const bool trace = getenv("PINOT_GPU_BATCH_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, sizeof(ScanParams) * (size_t)n, hipMemcpyHostToDevice, b->stream));
   HIP_TRY(hipMemcpyAsync(b->d_first, b->h_first, 4 * (size_t)(n + 1), hipMemcpyHostToDevice, b->stream));
   if (timed) HIP_TRY(hipEventRecord(b->ev[0], b->stream));
   launch_scan_private_batch(one_slot, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
   HIP_TRY(hipGetLastError());
   if (timed) HIP_TRY(hipEventRecord(b->ev[1], b->stream));
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  const auto t1 = std::chrono::steady_clock::now();
+  if (g_engine.poll_result && !timed) {
+    // every item publishes its own pinned record: their sequence numbers are the completion signal (as in pg_execute)
+    long long spins = 0;
+    for (int k = 0; k < n; ++k) {
+      volatile unsigned long long* flag = &b->h_records[k].seq;
+      while (*flag != seq) {
+        if ((++spins & 0xFFFF) == 0 && hipStreamQuery(b->stream) != hipErrorNotReady) { HIP_TRY(hipStreamSynchronize(b->stream)); break; }
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  } else {
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  const auto t2 = std::chrono::steady_clock::now();
   float ms = 0.f;
   if (timed) HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
+  if (trace) fprintf(stderr, "  run_deferred: %d items %lld workgroups, sizeof(ScanParams) %zu, enqueue %.1f us, wait %.1f us, kernel %.1f us\n", n, total_blocks, sizeof(ScanParams),
+                     std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(), ms * 1e3);
   for (int k = 0; k < n; ++k) {
     const int i = items[(size_t)k];
     if (b->h_records[k].seq != seq) { statuses[i] = fail(PG_ERR_INTERNAL, "batch item %d did not publish its record", i); continue; }
@@ -3561,15 +3595,23 @@ pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* q
   for (int i = 0; i < count; ++i) { memset(&results[i], 0, sizeof(pg_result)); statuses[i] = PG_ERR_INVALID_ARGUMENT; }
   if (count == 0) return PG_OK;
   std::lock_guard<std::mutex> one_batch(g_batch_call_mu);
+  static const bool trace = getenv("PINOT_GPU_BATCH_TRACE") != nullptr;      // host phases of every call on stderr
+  const auto t_begin = std::chrono::steady_clock::now();
   std::vector<Deferred> defs((size_t)count);
   std::vector<std::string> errors((size_t)count);
   // 1. every item is lowered (and, when it cannot share the launch, run on a context of its own) on the library's worker threads
   const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2));
-  g_pool.run(count, g_engine.batch_launch ? threads : std::min(threads, count), [&](int i) {
+  std::vector<float> item_us(trace ? (size_t)count : 0);
+  // (a deferred item is ~2 us of lowering: eight per claim, so 64 items wake at most seven helpers; an item that runs its own kernel
+  // is claimed alone)
+  g_pool.run(count, g_engine.batch_launch ? threads : std::min(threads, count), g_engine.batch_launch ? 8 : 1, [&](int i) {
     if (!segments[i] || !queries[i]) { statuses[i] = PG_ERR_INVALID_ARGUMENT; errors[(size_t)i] = "null segment or query"; return; }
+    const auto t_item = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     statuses[i] = execute_one(segments[i], queries[i], &results[i], g_engine.batch_launch ? &defs[(size_t)i] : nullptr);
+    if (trace) item_us[(size_t)i] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t_item).count();
     if (statuses[i] != PG_OK && statuses[i] != kDeferred) errors[(size_t)i] = g_error;      // (g_error is the worker's thread-local)
   });
+  const auto t_lowered = std::chrono::steady_clock::now();
   // 2. the deferred items, one launch per device
   std::vector<int> devices;
   for (int i = 0; i < count; ++i) if (statuses[i] == kDeferred && std::find(devices.begin(), devices.end(), segments[i]->device) == devices.end()) devices.push_back(segments[i]->device);
@@ -3581,6 +3623,13 @@ pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* q
   }
   // pg_last_error of the caller: the first failed item's message
   for (int i = 0; i < count; ++i) if (statuses[i] != PG_OK) { g_error = "batch item " + std::to_string(i) + ": " + errors[(size_t)i]; break; }
+  if (trace) {
+    const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    float sum_us = 0.f, max_us = 0.f;
+    for (float v : item_us) { sum_us += v; max_us = std::max(max_us, v); }
+    fprintf(stderr, "pg_execute_batch: %d items, lower %.1f us (items: sum %.1f us, max %.1f us, %d threads), launches %.1f us\n", count, us(t_begin, t_lowered), sum_us, max_us, threads,
+            us(t_lowered, std::chrono::steady_clock::now()));
+  }
   return PG_OK;
 }
 
