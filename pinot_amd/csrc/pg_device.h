@@ -265,6 +265,8 @@ struct GroupParams {
   int32_t packed_shift;            //       (count << packed_shift) | sum ; no separate count atomic
   int32_t dense_ok;                // 1: every aggregation is in the 32-bit value domain (the dense 16-step path applies)
   int32_t wide_keys;               // 1: num_groups > 2^24, so dictIds / multipliers may not fit the full-rate 24-bit multiply
+  int32_t lds_log_replicas;        // group_private_kernel<true>: log2 of the copies of the LDS table a workgroup keeps (lane l uses copy l % R; pg_kernels.h)
+  int32_t reserved_gp;
   DevGroupKey group_keys[kMaxGroupCols];
   DevGroupAgg group_aggs[kMaxGroupAggs];
   unsigned long long* table_count; // [num_groups]

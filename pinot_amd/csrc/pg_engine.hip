@@ -79,6 +79,7 @@ struct Engine {
   bool plane_gcd = true;     // PINOT_GPU_PLANE_GCD=0: planes hold value - min unscaled, never alias the dictId stream
   bool scan_private = true;  // PINOT_GPU_SCAN_PRIVATE=0: always the LDS-staged scan kernel
   bool group_private = true; // PINOT_GPU_GROUP_PRIVATE=0: unfiltered group-by through the LDS-staged kernel
+  int group_log_replicas = 3; // PINOT_GPU_GROUP_REPLICAS=0..4: log2 of the most copies of its LDS table group_private_kernel keeps (as many as fit)
   bool group_pack = true;    // PINOT_GPU_GROUP_PACK=0: separate count atomic in the group-by LDS table
   bool scan_typed_private = true;     // PINOT_GPU_SCAN_TYPED_PRIVATE=0: raw / 8-byte aggregated columns stay in the LDS-staged kernel
   bool scan_narrow_single = true;     // PINOT_GPU_SCAN_NARROW_SINGLE=0: a single narrow leaf takes the general narrow kernel (four tiles per iteration)
@@ -1486,6 +1487,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.scan_private = !(spv && spv[0] == '0');
   const char* gpv = getenv("PINOT_GPU_GROUP_PRIVATE");
   g_engine.group_private = !(gpv && gpv[0] == '0');
+  const char* grv = getenv("PINOT_GPU_GROUP_REPLICAS");
+  g_engine.group_log_replicas = grv ? std::max(0, std::min(4, atoi(grv))) : 3;
   const char* stp = getenv("PINOT_GPU_SCAN_TYPED_PRIVATE");
   g_engine.scan_typed_private = !(stp && stp[0] == '0');
   const char* gpt = getenv("PINOT_GPU_GROUP_PARTITION");
@@ -2665,6 +2668,17 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         const DevGroupAgg& ga = gp.group_aggs[a];
         if (ga.kind == kGroupSum && ga.is_plane && !ga.is_raw && 2 * cbits + ga.bits <= 64) { gp.packed_agg = a; gp.packed_shift = std::max(32, cbits + ga.bits); break; }
       }
+    }
+    // group_private_kernel's LDS table in as many bank-interleaved copies as the workgroup's share of the CU's LDS holds (pg_kernels.h,
+    // lds_group_table_bytes): C3's 1000 groups x (SUM + MAX) are 12 KB a copy, eight copies for the one 16-wave workgroup of a CU.
+    gp.lds_log_replicas = 0;
+    if (use_private && gp.use_lds_table) {
+      const int resident = std::max(1, std::min(waves_group_private() / std::max(1, pthreads / 64), g_engine.blocks_per_cu > 0 ? g_engine.blocks_per_cu : 1 << 30));
+      const size_t budget = kLdsBudget / (size_t)resident;
+      int log_r = 0;
+      while (log_r < g_engine.group_log_replicas && (size_t)lds_group_table_bytes(gp, log_r + 1) <= budget) ++log_r;
+      gp.lds_log_replicas = log_r;
+      plds = lds_group_table_bytes(gp, log_r);
     }
     gp.scan = sp;
     gp.scan.partials = nullptr;

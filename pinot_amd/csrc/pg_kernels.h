@@ -1928,11 +1928,30 @@ __device__ __forceinline__ uint32_t hash_slot_of(unsigned long long* keys, unsig
   }
 }
 
+// ---- group_private_kernel's LDS table: replicated and bank-interleaved ----
+// A wave's 64 docs of one step go to 64 random slots: an LDS atomic is serviced in lane groups (32 lanes of a 4-byte, 16 of an 8-byte
+// operation) and every extra distinct address on a bank within a group costs a cycle -- with one table, ~3 of every 4 LDS cycles of
+// C3 were such conflicts (profiles/r2/pmc_c3_sq_summary.json).  The table is therefore kept R = 2^logR times, slot (g, c) at index
+// g * R + c, and a lane only ever touches copy c = lane % R: lanes of different copies sit on different banks BY CONSTRUCTION (4-byte
+// slots: bank (g * R + c) % 32; 8-byte: bank pair (g * R + c) % 16), so only the 32 / R (16 / R) lanes of one copy can still collide.
+// The address costs what it cost before -- one v_lshl_add_u32, the shift now 2 or 3 + logR and the base a per-lane register.
+// Sub-tables in order: counts (u32; absent when a SUM slot carries the count), then per aggregation SUM i64 / MIN, MAX i32 -- the
+// 4-byte MIN / MAX slots are dense now (they were the low dwords of 8-byte slots: even banks only).
+__host__ __device__ __forceinline__ uint32_t lds_subtable_bytes(int G, int logR, int elem) { return ((((uint32_t)G << logR) * (uint32_t)elem) + 7u) & ~7u; }
+__host__ __device__ __forceinline__ uint32_t lds_group_table_bytes(const GroupParams& gp, int logR) {
+  uint32_t bytes = gp.packed_agg >= 0 ? 0u : lds_subtable_bytes(gp.num_groups, logR, 4);
+  for (int a = 0; a < gp.num_group_aggs; ++a) bytes += lds_subtable_bytes(gp.num_groups, logR, gp.group_aggs[a].kind == kGroupSum ? 8 : 4);
+  return bytes;
+}
+
 // One 2048-doc tile.  kMasked: only the docs whose bit is set in the lane's mask `m` reach the table (a filter's result, and /
 // or the docs that exist in the last, partial tile); otherwise every doc of the tile does, with no exec masking around the atomics.
 template <bool kLds, bool kMasked, bool kWide = false, bool kHash = false>
-__device__ __forceinline__ void group_private_tile(const GroupParams& gp, long long tile, int lane, uint32_t m, unsigned long long* t_cnt, long long* t_acc) {
+__device__ __forceinline__ void group_private_tile(const GroupParams& gp, long long tile, int lane, uint32_t m, unsigned long long* t_cnt, long long* t_acc, uint8_t* lds) {
   const int G = gp.num_groups;
+  const int logR = kLds ? gp.lds_log_replicas : 0;                       // (see lds_group_table_bytes)
+  const uint32_t cls = (uint32_t)lane & ((1u << logR) - 1u);
+  uint32_t lds_off = 0u;                                                // uniform: where the next sub-table starts
   const long long first_doc = tile * 2048 + lane * 32;
   uint32_t g[32];
   if constexpr (kHash) {
@@ -1986,12 +2005,22 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
   }
   const bool packed = kLds && gp.packed_agg >= 0;
   if (!packed) {
+    if constexpr (kLds) {
+      uint32_t* cnt_lane = reinterpret_cast<uint32_t*>(lds) + cls;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) if (!kMasked || ((m >> j) & 1u)) group_count<kLds>(t_cnt, g[j]);
+      for (int j = 0; j < 32; ++j)
+        if (!kMasked || ((m >> j) & 1u)) __hip_atomic_fetch_add(cnt_lane + (g[j] << logR), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      lds_off = lds_subtable_bytes(G, logR, 4);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) if (!kMasked || ((m >> j) & 1u)) group_count<kLds>(t_cnt, g[j]);
+    }
   }
   for (int a = 0; a < gp.num_group_aggs; ++a) {
     const DevGroupAgg& ga = gp.group_aggs[a];
-    long long* acc = t_acc + (long long)a * G;
+    long long* acc = kLds ? reinterpret_cast<long long*>(lds + lds_off) + cls : t_acc + (long long)a * G;      // kLds: this lane's copy of a SUM sub-table,
+    int32_t* acc32 = reinterpret_cast<int32_t*>(lds + lds_off) + cls;                                          //       or of a MIN / MAX one
+    if constexpr (kLds) lds_off += lds_subtable_bytes(G, logR, ga.kind == kGroupSum ? 8 : 4);
     const int b = ga.bits;
     const uint32_t* words = ga.is_raw ? reinterpret_cast<const uint32_t*>(ga.fwd) + first_doc
                                       : reinterpret_cast<const uint32_t*>(ga.fwd + tile * (256ll * b)) + lane * b;
@@ -2017,17 +2046,27 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
         // plane field; the packed count lives entirely in the high dword: the operand is the register pair {field, one_hi}
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-          if (!kMasked || ((m >> (16 * h + j)) & 1u)) group_sum<kLds>(acc + g[16 * h + j], (long long)(((unsigned long long)one_hi << 32) | (unsigned long long)d[j]));
+          if (!kMasked || ((m >> (16 * h + j)) & 1u)) group_sum<kLds>(acc + (g[16 * h + j] << logR), (long long)(((unsigned long long)one_hi << 32) | (unsigned long long)d[j]));
       } else if (ga.kind == kGroupSum) {
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-          if (!kMasked || ((m >> (16 * h + j)) & 1u)) group_sum<kLds>(acc + g[16 * h + j], (long long)(int32_t)d[j]);
+          if (!kMasked || ((m >> (16 * h + j)) & 1u)) group_sum<kLds>(acc + (g[16 * h + j] << logR), (long long)(int32_t)d[j]);
       } else if (ga.kind == kGroupMin) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) if (!kMasked || ((m >> (16 * h + j)) & 1u)) group_min<kLds>(acc + g[16 * h + j], (int32_t)d[j]);
+        for (int j = 0; j < 16; ++j) {
+          if (!kMasked || ((m >> (16 * h + j)) & 1u)) {
+            if constexpr (kLds) __hip_atomic_fetch_min(acc32 + (g[16 * h + j] << logR), (int32_t)d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else group_min<false>(acc + g[16 * h + j], (int32_t)d[j]);
+          }
+        }
       } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) if (!kMasked || ((m >> (16 * h + j)) & 1u)) group_max<kLds>(acc + g[16 * h + j], (int32_t)d[j]);
+        for (int j = 0; j < 16; ++j) {
+          if (!kMasked || ((m >> (16 * h + j)) & 1u)) {
+            if constexpr (kLds) __hip_atomic_fetch_max(acc32 + (g[16 * h + j] << logR), (int32_t)d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else group_max<false>(acc + g[16 * h + j], (int32_t)d[j]);
+          }
+        }
       }
     }
   }
@@ -2044,15 +2083,21 @@ __global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const
   const int NA = gp.num_group_aggs;
   unsigned long long* t_cnt;
   long long* t_acc;
+  const int logR = kLdsTable ? gp.lds_log_replicas : 0;
   if constexpr (kLdsTable) {
-    t_cnt = reinterpret_cast<unsigned long long*>(smem);
-    t_acc = reinterpret_cast<long long*>(t_cnt + G);
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
-      t_cnt[g] = 0ull;
-      for (int a = 0; a < NA; ++a) {
-        const int kind = gp.group_aggs[a].kind;
-        t_acc[(long long)a * G + g] = kind == kGroupSum ? 0ll : (kind == kGroupMin ? 0x7FFFFFFFll : (long long)(uint32_t)0x80000000u);
-      }
+    t_cnt = nullptr;
+    t_acc = nullptr;
+    const int slots = G << logR;
+    uint32_t off = 0u;
+    if (gp.packed_agg < 0) {
+      for (int i = threadIdx.x; i < slots; i += blockDim.x) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+      off = lds_subtable_bytes(G, logR, 4);
+    }
+    for (int a = 0; a < NA; ++a) {
+      const int kind = gp.group_aggs[a].kind;
+      if (kind == kGroupSum) for (int i = threadIdx.x; i < slots; i += blockDim.x) reinterpret_cast<long long*>(smem + off)[i] = 0ll;
+      else for (int i = threadIdx.x; i < slots; i += blockDim.x) reinterpret_cast<int32_t*>(smem + off)[i] = kind == kGroupMin ? 0x7FFFFFFF : (int32_t)0x80000000u;
+      off += lds_subtable_bytes(G, logR, kind == kGroupSum ? 8 : 4);
     }
     __syncthreads();
   } else {
@@ -2071,27 +2116,49 @@ __global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const
     const long long rem = (long long)gp.scan.num_docs - (tile * 2048 + lane * 32);
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
     if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
-    if (__builtin_amdgcn_ballot_w64(m != 0xFFFFFFFFu) == 0ull) group_private_tile<kLdsTable, false, kWide, kHash>(gp, tile, lane, m, t_cnt, t_acc);
-    else group_private_tile<kLdsTable, true, kWide, kHash>(gp, tile, lane, m, t_cnt, t_acc);
+    if (__builtin_amdgcn_ballot_w64(m != 0xFFFFFFFFu) == 0ull) group_private_tile<kLdsTable, false, kWide, kHash>(gp, tile, lane, m, t_cnt, t_acc, smem);
+    else group_private_tile<kLdsTable, true, kWide, kHash>(gp, tile, lane, m, t_cnt, t_acc, smem);
   }
   flush_filter_entries(gp.scan, entries);
 
   if constexpr (kLdsTable) {
+    // flush: thread g folds the R copies of group g (the packed count and sum fold as one add: together they stay below the
+    // bounds the packing was chosen for, which are per workgroup), then one global atomic per group and accumulator
     __syncthreads();
+    const int R = 1 << logR;
+    const bool packed = gp.packed_agg >= 0;
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
-      const bool packed = gp.packed_agg >= 0;
-      const unsigned long long pk = packed ? (unsigned long long)t_acc[(long long)gp.packed_agg * G + g] : 0ull;
-      const unsigned long long c = packed ? (pk >> gp.packed_shift) : (unsigned long long)(uint32_t)t_cnt[g];
-      if (c == 0ull) continue;
-      __hip_atomic_fetch_add(&gp.table_count[g], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t off = 0u;
+      unsigned long long c = 0ull;
+      if (!packed) {
+        for (int r = 0; r < R; ++r) c += (unsigned long long)reinterpret_cast<const uint32_t*>(smem)[(g << logR) + r];
+        off = lds_subtable_bytes(G, logR, 4);
+      } else {
+        uint32_t poff = 0u;
+        for (int a = 0; a < gp.packed_agg; ++a) poff += lds_subtable_bytes(G, logR, gp.group_aggs[a].kind == kGroupSum ? 8 : 4);
+        unsigned long long pk = 0ull;
+        for (int r = 0; r < R; ++r) pk += reinterpret_cast<const unsigned long long*>(smem + poff)[(g << logR) + r];
+        c = pk >> gp.packed_shift;
+      }
+      if (c != 0ull) __hip_atomic_fetch_add(&gp.table_count[g], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int a = 0; a < NA; ++a) {
         const int kind = gp.group_aggs[a].kind;
         long long* slot = gp.table_acc + (long long)a * G + g;
-        long long v = t_acc[(long long)a * G + g];
-        if (packed && a == gp.packed_agg) v = (long long)(pk & ((1ull << gp.packed_shift) - 1ull));
-        if (kind == kGroupSum) __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else if (kind == kGroupMin) __hip_atomic_fetch_min(slot, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_fetch_max(slot, (long long)(int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (kind == kGroupSum) {
+          unsigned long long v = 0ull;
+          for (int r = 0; r < R; ++r) v += reinterpret_cast<const unsigned long long*>(smem + off)[(g << logR) + r];
+          if (packed && a == gp.packed_agg) v &= (1ull << gp.packed_shift) - 1ull;
+          if (c != 0ull) __hip_atomic_fetch_add(slot, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          const int32_t* t = reinterpret_cast<const int32_t*>(smem + off) + (g << logR);
+          int32_t v = t[0];
+          for (int r = 1; r < R; ++r) v = kind == kGroupMin ? (t[r] < v ? t[r] : v) : (t[r] > v ? t[r] : v);
+          if (c != 0ull) {
+            if (kind == kGroupMin) __hip_atomic_fetch_min(slot, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_fetch_max(slot, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        off += lds_subtable_bytes(G, logR, kind == kGroupSum ? 8 : 4);
       }
     }
   }

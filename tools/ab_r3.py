@@ -31,6 +31,11 @@ SETTINGS = {
     "sparse32": {"PINOT_GPU_SPARSE_LANES": "32"},
     "sparse48": {"PINOT_GPU_SPARSE_LANES": "48"},
     "sparse64": {"PINOT_GPU_SPARSE_LANES": "64"},
+    "rep0": {"PINOT_GPU_GROUP_REPLICAS": "0"},
+    "rep1": {"PINOT_GPU_GROUP_REPLICAS": "1"},
+    "rep2": {"PINOT_GPU_GROUP_REPLICAS": "2"},
+    "rep3": {"PINOT_GPU_GROUP_REPLICAS": "3"},
+    "rep4": {"PINOT_GPU_GROUP_REPLICAS": "4"},
     "bpc8": {"PINOT_GPU_BLOCKS_PER_CU": "8"},
     "bpc16": {"PINOT_GPU_BLOCKS_PER_CU": "16"},
     "bpc32": {"PINOT_GPU_BLOCKS_PER_CU": "32"},
@@ -46,6 +51,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--c3", action="store_true", help="also the C3 group-by queries (k, a, b columns: three more 1 B-row columns)")
     ap.add_argument("--c5", action="store_true", help="also the C5 dense / sparse index-led queries (12 s of host-side index generation each)")
     args = ap.parse_args()
     import numpy as np
@@ -94,6 +100,20 @@ def main():
         ("C1-sum", seg1, Q.QuerySpec([(Q.SUM, 0)])),
         ("C1-dict-sum", seg1, Q.QuerySpec([(Q.SUM, 2)], filter=fl(100))),
     ]
+    if args.c3:
+        k = S.Column.synthetic_uniform("k", n, np.arange(1000, dtype=np.int32) * 3, seed=3)
+        a = S.Column.synthetic_uniform("a", n, (np.arange(100000, dtype=np.int64) * 5 + 1).astype(np.int32), seed=4)
+        b = S.Column.synthetic_uniform("b", n, np.arange(65536, dtype=np.int32) * 2, seed=5)
+        k40 = S.Column.synthetic_uniform("k40", n, np.arange(40, dtype=np.int32), seed=6)
+        seg3 = S.SegmentData("c3", n, [k, a, b, f, k40])
+        queries += [
+            ("C3", seg3, Q.QuerySpec([(Q.SUM, 1), (Q.MAX, 2)], group_by=[0])),
+            ("C3-filter", seg3, Q.QuerySpec([(Q.SUM, 1), (Q.MAX, 2)], filter=Q.leaf(Q.Pred.dict_range(3, 0, 100)), group_by=[0])),
+            ("C3-count", seg3, Q.QuerySpec([(Q.COUNT, -1)], group_by=[0])),
+            ("C3-minmaxavg", seg3, Q.QuerySpec([(Q.MIN, 1), (Q.MAX, 1), (Q.AVG, 2)], group_by=[0])),
+            ("C3-40groups", seg3, Q.QuerySpec([(Q.SUM, 1), (Q.MAX, 2)], group_by=[4])),
+            ("C3-2keys", seg3, Q.QuerySpec([(Q.SUM, 1)], group_by=[4, 0])),
+        ]
     opened = {}
     segs_c5 = []
     if args.c5:
@@ -145,7 +165,8 @@ def main():
                 else:
                     rec.update({"wall_ms_untimed": round(mean(wall), 5), "wall_ms_untimed_min": round(min(wall), 5)})
             got = g.execute(spec)
-            key = repr([(a.count, a.sum_i64, a.sum, a.min, a.max) for a in got.aggregations]) + repr(got.stats)
+            key = repr([(a.count, a.sum_i64, a.sum, a.min, a.max) for a in got.aggregations]) + repr(got.stats) + \
+                repr(sorted((gid, [(a.count, a.sum_i64, a.sum, a.min, a.max) for a in vals]) for gid, vals in got.groups.items()))
             rec["same_as_first_setting"] = first.setdefault(qname, key) == key
             if args.check and sname == args.settings.split(",")[0]:
                 from oracle import oracle
