@@ -718,28 +718,52 @@ __device__ __forceinline__ void partial_wave_reduce(BlockPartial& acc, const Fol
 // Fold of `num_records` per-workgroup records by ONE workgroup: thread t takes records t, t + blockDim, ..., then the wave, then the
 // waves through `red` (>= blockDim / 64 records of LDS).  The order of the double additions depends on the launch geometry only.
 // Returns the folded record in thread 0.  (Fields outside `ff` keep their identities.)
+//
+// kCoherent: the records were stored by other workgroups of THIS launch with agent-scope (sc1, write-through) stores, and are read with
+// agent-scope loads (sc1: past the L1, served by the L2 / memory) -- MI355X_MICROARCH.md: "sc1 loads may replace the acquire only when
+// the producer stored sc1".  The agent-scope acquire fence this replaces (buffer_inv sc1) cost the folding workgroup ~1.7 us on the
+// critical path of every query.  Without it (finalize_partials_kernel: a kernel boundary lies between writers and reader) plain loads.
+template <bool kCoherent>
+__device__ __forceinline__ unsigned long long partial_word(const BlockPartial* rec, size_t byte_off) {
+  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const uint8_t*>(rec) + byte_off);
+  if constexpr (kCoherent) return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *w;
+}
+template <bool kCoherent = false>
 __device__ __forceinline__ BlockPartial fold_partials(const BlockPartial* partials, int num_records, BlockPartial* red, const FoldFields ff) {
+  static_assert(kMaxAggCols % 2 == 0, "kmin / kmax are read as pairs");
   BlockPartial acc;
   partial_identity(acc);
   for (int i = threadIdx.x; i < num_records; i += blockDim.x) {
-    const BlockPartial& b = partials[i];
-    acc.count += b.count;
-    acc.flags |= b.flags;
-    acc.entries += b.entries;
+    const BlockPartial* b = partials + i;
+    acc.count += partial_word<kCoherent>(b, offsetof(BlockPartial, count));
+    acc.flags |= partial_word<kCoherent>(b, offsetof(BlockPartial, flags));
+    acc.entries += partial_word<kCoherent>(b, offsetof(BlockPartial, entries));
     if (ff.cycles) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc.cyc[c] += b.cyc[c];
+      for (int c = 0; c < 4; ++c) acc.cyc[c] += partial_word<kCoherent>(b, offsetof(BlockPartial, cyc) + 8 * c);
+    }
+#pragma unroll
+    for (int a = 0; a < kMaxAggCols; a += 2) {
+      if (a >= ff.slots) continue;
+      // kmin / kmax of slots a, a + 1 are one 8-byte word each (an unused odd slot holds the identities)
+      const unsigned long long mins = partial_word<kCoherent>(b, offsetof(BlockPartial, kmin) + 4 * a), maxs = partial_word<kCoherent>(b, offsetof(BlockPartial, kmax) + 4 * a);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int32_t bmin = (int32_t)(uint32_t)(mins >> (32 * h)), bmax = (int32_t)(uint32_t)(maxs >> (32 * h));
+        acc.kmin[a + h] = bmin < acc.kmin[a + h] ? bmin : acc.kmin[a + h];
+        acc.kmax[a + h] = bmax > acc.kmax[a + h] ? bmax : acc.kmax[a + h];
+      }
     }
 #pragma unroll
     for (int a = 0; a < kMaxAggCols; ++a) {
       if (a >= ff.slots) continue;
-      acc.sum[a] += b.sum[a];
-      acc.kmin[a] = b.kmin[a] < acc.kmin[a] ? b.kmin[a] : acc.kmin[a];
-      acc.kmax[a] = b.kmax[a] > acc.kmax[a] ? b.kmax[a] : acc.kmax[a];
+      acc.sum[a] += (long long)partial_word<kCoherent>(b, offsetof(BlockPartial, sum) + 8 * a);
       if (ff.typed) {
-        acc.fsum[a] += b.fsum[a];
-        acc.kmin64[a] = b.kmin64[a] < acc.kmin64[a] ? b.kmin64[a] : acc.kmin64[a];
-        acc.kmax64[a] = b.kmax64[a] > acc.kmax64[a] ? b.kmax64[a] : acc.kmax64[a];
+        acc.fsum[a] += __longlong_as_double((long long)partial_word<kCoherent>(b, offsetof(BlockPartial, fsum) + 8 * a));
+        const long long bmin = (long long)partial_word<kCoherent>(b, offsetof(BlockPartial, kmin64) + 8 * a), bmax = (long long)partial_word<kCoherent>(b, offsetof(BlockPartial, kmax64) + 8 * a);
+        acc.kmin64[a] = bmin < acc.kmin64[a] ? bmin : acc.kmin64[a];
+        acc.kmax64[a] = bmax > acc.kmax64[a] ? bmax : acc.kmax64[a];
       }
     }
   }
@@ -754,11 +778,34 @@ __device__ __forceinline__ BlockPartial fold_partials(const BlockPartial* partia
   return t;
 }
 
-__device__ __forceinline__ void store_host_record(HostRecord* host_out, const BlockPartial& t, unsigned long long seq) {
-  host_out->partial = t;
-  __threadfence_system();          // the record before the sequence number
-  __hip_atomic_store(&host_out->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __threadfence_system();
+// A record leaves its workgroup as ONE store instruction: the record sits in LDS (`rec`) and lane i of wave 0 stores its i-th 8-byte
+// word -- 240 contiguous bytes, a handful of write-through requests, where lane 0 storing the thirty words one after the other was
+// thirty (a scalar sc1 store is a fabric write of its own: MI355X_MICROARCH.md).  Called by every lane of wave 0 after lane 0 wrote
+// `rec` (LDS operations of one wave execute in order).  kSystem: pinned host memory (sc0 sc1), else device memory read by another
+// workgroup (sc1).  Returns once the stores are acknowledged (s_waitcnt vmcnt(0) through inline asm: the guide's compiler hazard).
+constexpr int kRecordWords = (int)(sizeof(BlockPartial) / 8);
+static_assert(sizeof(BlockPartial) % 8 == 0 && kRecordWords <= 64, "a record is stored as 8-byte words, one per lane of a wave");
+template <bool kSystem>
+__device__ __forceinline__ void store_record_by_wave0(const BlockPartial* rec, BlockPartial* out) {
+  __builtin_amdgcn_wave_barrier();
+  const int lane = threadIdx.x;              // wave 0
+  if (lane < kRecordWords) {
+    const unsigned long long w = reinterpret_cast<const unsigned long long*>(rec)[lane];
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out) + lane;
+    if constexpr (kSystem) __hip_atomic_store(dst, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __hip_atomic_store(dst, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// The query's record into pinned host memory, then the sequence number the host polls.  Every word is a system-scope (sc0 sc1,
+// write-through) store: nothing of the record is left dirty in the L2, so "the record before the sequence number" needs no release
+// fence (buffer_wbl2 sc0 sc1 writes back EVERY dirty line of the XCD's L2 -- a bitmap the same kernel wrote, say), only the stores'
+// acknowledgements.  Nothing follows the sequence number: the two system fences this replaces were ~3 us at the end of every query's
+// kernel.  Wave 0, `rec` in LDS (store_record_by_wave0).
+__device__ __forceinline__ void store_host_record_by_wave0(HostRecord* host_out, const BlockPartial* rec, unsigned long long seq) {
+  static_assert(offsetof(HostRecord, partial) == 0, "the record leads");
+  store_record_by_wave0<true>(rec, &host_out->partial);
+  if (threadIdx.x == 0) __hip_atomic_store(&host_out->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // `host_out`: pinned, device-mapped host memory -- the folded record goes straight to the host, no copy command follows.
@@ -768,9 +815,10 @@ static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel
   __shared__ BlockPartial red[kBlockThreads / 64];
   const BlockPartial t = fold_partials(partials, num_blocks, red, FoldFields{slots, typed != 0, cycles != 0});
   if (threadIdx.x == 0) {
-    if (host_out) store_host_record(host_out, t, seq);
+    if (host_out) red[0] = t;
     else partials[num_blocks] = t;
   }
+  if (host_out && threadIdx.x < 64) store_host_record_by_wave0(host_out, &red[0], seq);
 }
 
 // The end of every scan kernel: the waves' records are in red[0 .. waves_per_block) (written by each wave's lane 0, __syncthreads()
@@ -790,39 +838,43 @@ constexpr int kFoldShards = 8, kFoldStride = 32;      // counters are kFoldStrid
 template <typename P>
 __device__ __forceinline__ void publish_block_partial(const P& p, BlockPartial* red, int waves_per_block, uint32_t* flag, uint32_t block_index,
                                                       uint32_t num_blocks) {
-  if (threadIdx.x == 0) {
-    BlockPartial acc = red[0];
-    for (int w = 1; w < waves_per_block; ++w) partial_merge(acc, red[w]);
-    uint32_t last = 0u;
-    if (p.done_counter == nullptr) {
-      p.partials[block_index] = acc;
-    } else {
-      static_assert(sizeof(BlockPartial) % 8 == 0, "stored as 8-byte words");
-      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&acc);
-      unsigned long long* dst = reinterpret_cast<unsigned long long*>(&p.partials[block_index]);
-#pragma unroll
-      for (int i = 0; i < (int)(sizeof(BlockPartial) / 8); ++i) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const uint32_t shard = block_index & (kFoldShards - 1);
-      const uint32_t in_shard = (num_blocks + (kFoldShards - 1) - shard) / kFoldShards;          // workgroups b with (b & 7) == shard
-      const uint32_t shards = num_blocks < (uint32_t)kFoldShards ? num_blocks : (uint32_t)kFoldShards;
-      if (__hip_atomic_fetch_add(p.done_counter + shard * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_shard) {
-        if (__hip_atomic_fetch_add(p.done_counter + kFoldShards * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == shards) {
-          last = 1u;
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const bool arrive = p.done_counter != nullptr && num_blocks > 1u;
+  if (threadIdx.x < 64) {                                  // wave 0
+    if (threadIdx.x == 0) {
+      BlockPartial acc = red[0];
+      for (int w = 1; w < waves_per_block; ++w) partial_merge(acc, red[w]);
+      if (p.done_counter == nullptr) p.partials[block_index] = acc;
+      else if (!arrive && p.host_out == nullptr) p.partials[1] = acc;
+      else red[0] = acc;
+    }
+    if (p.done_counter != nullptr && !arrive) {
+      // the only workgroup: its record IS the query's (a segment of a few thousand docs: no store / arrive / fold round trips at all)
+      if (p.host_out) store_host_record_by_wave0(p.host_out, &red[0], p.host_seq);
+    } else if (arrive) {
+      store_record_by_wave0<false>(&red[0], &p.partials[block_index]);
+    }
+    if (threadIdx.x == 0) {
+      uint32_t last = 0u;
+      if (arrive) {
+        const uint32_t shard = block_index & (kFoldShards - 1);
+        const uint32_t in_shard = (num_blocks + (kFoldShards - 1) - shard) / kFoldShards;          // workgroups b with (b & 7) == shard
+        const uint32_t shards = num_blocks < (uint32_t)kFoldShards ? num_blocks : (uint32_t)kFoldShards;
+        if (__hip_atomic_fetch_add(p.done_counter + shard * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_shard) {
+          if (__hip_atomic_fetch_add(p.done_counter + kFoldShards * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == shards) last = 1u;
         }
       }
+      *flag = last;
     }
-    *flag = last;
   }
   __syncthreads();
   if (*flag == 0u) return;
-  const BlockPartial t = fold_partials(p.partials, (int)num_blocks, red, fold_fields_of(p));
+  const BlockPartial t = fold_partials<true>(p.partials, (int)num_blocks, red, fold_fields_of(p));
   if (threadIdx.x == 0) {
     for (int c = 0; c <= kFoldShards; ++c) __hip_atomic_store(p.done_counter + c * kFoldStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the context's next launch
-    if (p.host_out) store_host_record(p.host_out, t, p.host_seq);
+    if (p.host_out) red[0] = t;
     else p.partials[num_blocks] = t;
   }
+  if (p.host_out && threadIdx.x < 64) store_host_record_by_wave0(p.host_out, &red[0], p.host_seq);
 }
 template <typename P>
 __device__ __forceinline__ void publish_block_partial(const P& p, BlockPartial* red, int waves_per_block, uint32_t* flag) {
@@ -1611,7 +1663,6 @@ static __global__ __launch_bounds__(1024) void leapfrog2_chain_kernel(const uint
       __hip_atomic_store(dst + 2, (unsigned long long)all.p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       last = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x ? 1u : 0u;
-      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     last_flag = last;
   }
@@ -1621,9 +1672,11 @@ static __global__ __launch_bounds__(1024) void leapfrog2_chain_kernel(const uint
     // (a segment has < 2^31 docs = 2^20 tiles: at most 1024 workgroup summaries, one per thread)
     Leap2Summary in{0ll, 0, 0u, 1u};
     if (threadIdx.x < gridDim.x) {
+      // agent-scope (sc1) loads of what was stored sc1: no acquire fence (see fold_partials)
       const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&block_out[threadIdx.x]);
-      const unsigned long long w1 = src[1];
-      in = Leap2Summary{(long long)src[0], (int)(uint32_t)w1, (uint32_t)(w1 >> 32), (uint32_t)src[2]};
+      const unsigned long long s0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), s1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                               s2 = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      in = Leap2Summary{(long long)s0, (int)(uint32_t)s1, (uint32_t)(s1 >> 32), (uint32_t)s2};
     }
     __syncthreads();
     const Leap2Summary w2 = leap2_wave(in.sum, in.delta, in.g, in.p, threadIdx.x & 63);
@@ -1634,10 +1687,10 @@ static __global__ __launch_bounds__(1024) void leapfrog2_chain_kernel(const uint
     // (the segment is entered in state 0; a negative sum wraps the unsigned counter the right way)
     if (entries != nullptr && all.sum != 0ll) atomicAdd(entries, (unsigned long long)all.sum);
     if (host_out != nullptr) {
-      host_out->leap_correction = all.sum;
-      __threadfence_system();
+      // write-through system stores, their acknowledgement, then the sequence number (store_host_record)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(&host_out->leap_correction), (unsigned long long)all.sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(&host_out->leap_seq, host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __threadfence_system();
     }
   }
 }

@@ -1,15 +1,16 @@
 #!/bin/bash
-# tools/profile_round.sh <round>: the rocprofv3 evidence of a round, left under gpurun_out/<round>/ (copy what is to be judged into profiles/<round>/)
-#   1. kernel trace + stats of the driver's own command line (python bench.py, all variants)
-#   2. HBM traffic of the headline kernel (FETCH_SIZE, TCC) -- separate --pmc passes, as MI355X_MICROARCH.md prescribes
-#   3. SQ / LDS counters of the C3 group-by kernel and HBM traffic of the C5 kernels
-R=${1:-r2}
+# tools/profile_round.sh <round> [step...]: the rocprofv3 evidence of a round, left under gpurun_out/<round>/ (copy what is to be judged into profiles/<round>/)
+#   stats     kernel trace + stats of the driver's own command line (python bench.py, all variants)
+#   head      HBM traffic of the headline kernel (FETCH_SIZE, TCC) -- separate --pmc passes, as MI355X_MICROARCH.md prescribes
+#   c3        SQ / LDS counters and HBM traffic of the C3 group-by kernel
+#   c5        HBM traffic of the C5 kernels (index_and_kernel, scan_sparse_kernel), one counter per pass
+#   hist narrow lowsel    HBM traffic of scan_hist_kernel (C2b-irregular), scan_narrow_kernel (C5-scan-count), scan_private_kernel at 1 % (C2b-1pct)
+#   per-variant           kernel stats of one variant per rocprofv3 run (averages not mixed across variants)
+# no step = stats head c3 c5
+R=${1:-r2}; shift
+STEPS=${@:-stats head c3 c5}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-echo "== 1. kernel stats, python bench.py (all variants)"
-timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $GRAFT_REPO_ROOT/bench.py > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
-find $OUT/stats -name "*kernel_stats*.csv" -exec cat {} \; | cut -c1-200 | head -24
-find $OUT/stats -name "*kernel_trace*.csv" -size +8M -delete
 pmc() {   # pmc <tag> <kernel regexp> <bench args> <counters...>
   local tag=$1 kern=$2 args=$3; shift 3
   rm -rf $OUT/pmc_$tag
@@ -29,11 +30,46 @@ PY
   done
   find $OUT/pmc_$tag -name "*.csv" -size +8M -delete
 }
-echo "== 2. headline HBM traffic"
-pmc head_fetch "scan_private_kernel" "--steps 3 --warmup 1 --segments 1 --no-cpu-baseline --no-variants" FETCH_SIZE
-pmc head_tcc "scan_private_kernel" "--steps 3 --warmup 1 --segments 1 --no-cpu-baseline --no-variants" TCC_HIT_sum TCC_MISS_sum
-echo "== 3. C3 group-by kernel: SQ / LDS counters; C5 kernels: HBM traffic"
-pmc c3_sq "group_private_kernel" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --variants ^C3$" SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
-pmc c3_sq2 "group_private_kernel" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --variants ^C3$" SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SALU
-pmc c3_fetch "group_private_kernel" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --variants ^C3$" FETCH_SIZE
-pmc c5_fetch "index_and|scan_private_kernel" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --rows 100000 --rows-c5 1000000000 --variants C5" FETCH_SIZE WRITE_SIZE
+ONE="--steps 3 --warmup 1 --segments 1 --no-cpu-baseline"
+for step in $STEPS; do
+case $step in
+stats)
+  echo "== kernel stats, python bench.py (all variants)"
+  timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $GRAFT_REPO_ROOT/bench.py > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+  find $OUT/stats -name "*kernel_stats*.csv" -exec cat {} \; | cut -c1-200 | head -24
+  find $OUT/stats -name "*kernel_trace*.csv" -size +8M -delete ;;
+head)
+  echo "== headline HBM traffic"
+  pmc head_fetch "scan_private_kernel" "$ONE --no-variants" FETCH_SIZE
+  pmc head_tcc "scan_private_kernel" "$ONE --no-variants" TCC_HIT_sum TCC_MISS_sum ;;
+c3)
+  echo "== C3 group-by kernel: SQ / LDS counters, HBM traffic"
+  pmc c3_sq "group_private_kernel" "$ONE --variants ^C3$" SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+  pmc c3_sq2 "group_private_kernel" "$ONE --variants ^C3$" SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SALU
+  pmc c3_fetch "group_private_kernel" "$ONE --variants ^C3$" FETCH_SIZE ;;
+c3lds)
+  echo "== C3 group-by kernel: LDS conflict counters only"
+  pmc c3_sq "group_private_kernel" "$ONE --variants ^C3$" SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE ;;
+c5)
+  echo "== C5 kernels: HBM traffic (one counter per pass)"
+  pmc c5_fetch "index_and|scan_private_kernel|scan_sparse" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --rows 100000 --rows-c5 1000000000 --variants ^C5-(sparse|dense)$" FETCH_SIZE ;;
+hist)
+  echo "== scan_hist_kernel (C2b-irregular): HBM traffic"
+  pmc hist_fetch "scan_hist_kernel" "$ONE --variants ^C2b-irregular$" FETCH_SIZE ;;
+narrow)
+  echo "== scan_narrow_kernel (C5-scan-count): HBM traffic"
+  pmc narrow_fetch "scan_narrow" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --rows 100000 --rows-c5 1000000000 --variants ^C5-scan-count$" FETCH_SIZE ;;
+lowsel)
+  echo "== scan_private_kernel at 1 % (C2b-1pct): HBM traffic"
+  pmc lowsel_fetch "scan_private_kernel" "$ONE --variants ^C2b-1pct$" FETCH_SIZE ;;
+per-variant)
+  echo "== kernel stats, one variant per run"
+  for v in C2b-irregular C2b-1pct C2a-affine C3 C3-filter COUNT-filter; do
+    rm -rf $OUT/stats_$v
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$v -o v -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --segments 1 --no-cpu-baseline --variants "^$v\$" > $OUT/stats_$v.json 2> $OUT/stats_$v.err
+    echo "-- $v"; find $OUT/stats_$v -name "*kernel_stats*.csv" -exec cat {} \; | cut -c1-160 | head -4
+    find $OUT/stats_$v -name "*kernel_trace*.csv" -delete
+  done ;;
+*) echo "unknown step $step" ;;
+esac
+done
