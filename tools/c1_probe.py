@@ -24,7 +24,6 @@ SETTINGS = {
     "bpc4": {"PINOT_GPU_BLOCKS_PER_CU": "4"},
     "bpc8": {"PINOT_GPU_BLOCKS_PER_CU": "8"},
     "fold0": {"PINOT_GPU_FOLD_FINALIZE": "0"},
-    "small0": {"PINOT_GPU_SMALL_SEGMENT": "0"},
 }
 KNOBS = sorted({k for s in SETTINGS.values() for k in s})
 
