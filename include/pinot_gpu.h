@@ -323,6 +323,15 @@ pg_status pg_query_check(const pg_segment* segment, const pg_query* query);
 pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_result);
 void pg_result_free(pg_result* result);
 
+/* How a group-by column's entries of pg_result.group_key_dict_ids turn into key values.  A dictionary column: *out_is_offset = 0, the
+ * entry is a dictId (GroupKeyGenerator.getGroupKeys looks it up, DictionaryBasedGroupKeyGenerator.java:260-290).  A raw (no-dictionary)
+ * INT / LONG column -- the reference groups it by VALUE with NoDictionarySingleColumnGroupKeyGenerator / NoDictionaryMultiColumnGroupKey
+ * Generator (core/query/aggregation/groupby/DefaultGroupByExecutor.java:106-121) --: *out_is_offset = 1 and the key value is
+ * *out_base + entry (the column is grouped by through the stream of value - min; *out_base = the column's smallest value).  Under
+ * PG_QUERY_NULL_HANDLING the entry `cardinality` (dictionary column) / max - min + 1 (raw column) means NULL, as before.
+ * PG_ERR_UNSUPPORTED for a raw column pg_query_check declines as a group key (FLOAT / DOUBLE, or a value range beyond an int). */
+pg_status pg_group_key_base(const pg_segment* segment, int32_t column, int64_t* out_base, int32_t* out_is_offset);
+
 /* One query over MANY resident segments in one call: what BaseCombineOperator does with a thread pool (core/operator/combine/
  * BaseCombineOperator.java:85-142: numTasks worker threads, each pulling the next segment's operator and merging its block; CombinePlanNode.java:
  * 92-110 builds one PlanNode per segment).  queries[i] is the query as lowered FOR segments[i] (dictIds differ from segment to segment);

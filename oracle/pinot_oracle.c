@@ -1476,30 +1476,50 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   uint64_t* key_nulls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int nullable_group_by = 0;      /* null handling with nulls in a key or an aggregated column: the no-dictionary generators' semantics */
   if (ng > 8) { rc = 2; snprintf(po_error, sizeof(po_error), "too many group-by columns"); goto done; }
+  int64_t key_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int key_raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int no_dict_keys = 0;           /* a key column without a dictionary: NoDictionarySingle / MultiColumnGroupKeyGenerator */
   for (int g = 0; g < ng; g++) {
     const pg_column_desc* d = &seg->columns[q->group_by_columns[g]];
-    if (d->fwd_encoding != PG_FWD_FIXED_BIT_DICT) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by on raw column"); goto done; }
     cards[g] = d->cardinality;
+    if (d->fwd_encoding != PG_FWD_FIXED_BIT_DICT) {
+      /* DefaultGroupByExecutor.java:106-121: one key column without a dictionary sends the whole query to the no-dictionary generators,
+       * which key by VALUE -- value -> group id in order of first appearance (NoDictionarySingleColumnGroupKeyGenerator.java:100-113,
+       * 240-247; NoDictionaryMultiColumnGroupKeyGenerator: the tuple of values / dictIds), _globalGroupIdUpperBound = numGroupsLimit
+       * (:73-79).  Restated on the raw-key scale of the ABI (include/pinot_gpu.h, pg_group_key_base): the column's digit is
+       * value - min, its digit count max - min + 1; INT / LONG columns whose range fits an int. */
+      const po_column* kc = &cols[q->group_by_columns[g]];
+      if (d->stored_type != PG_TYPE_INT && d->stored_type != PG_TYPE_LONG) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by on raw FLOAT / DOUBLE column"); goto done; }
+      int64_t lo = INT64_MAX, hi = INT64_MIN;
+      for (int32_t doc = 0; doc < num_docs; doc++) {
+        const int64_t v = d->stored_type == PG_TYPE_INT ? (int64_t)raw_get_int(&kc->raw, doc) : raw_get_long(&kc->raw, doc);
+        if (v < lo) lo = v;
+        if (v > hi) hi = v;
+      }
+      if (num_docs <= 0 || (uint64_t)(hi - lo) >= 0x7FFFFFFEull) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by on raw column: value range beyond an int"); goto done; }
+      key_base[g] = lo; key_raw[g] = 1; cards[g] = (int32_t)(hi - lo + 1); no_dict_keys = 1;
+    }
     /* DictionaryBasedGroupKeyGenerator.java:150-184: ArrayBasedHolder up to arrayBasedThreshold, IntMapBasedHolder while the product
      * fits an int, LongMapBasedHolder while it fits a long (:628-700), ArrayMapBasedHolder beyond (:808+).  The three map-based holders
      * differ in the key type only: group ids in order of first appearance, new keys refused once the map holds
      * _globalGroupIdUpperBound of them -- min(product, numGroupsLimit) for the int holder, numGroupsLimit for the other two.  One
      * 128-bit mixed-radix key restates all of them (three key columns of < 2^31 values each stay below 2^93). */
     if (wide_upper > ((po_key)1 << 96)) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by key space beyond 2^96"); goto done; }
-    wide_upper *= (po_key)(d->cardinality > 0 ? d->cardinality : 1);
+    wide_upper *= (po_key)(cards[g] > 0 ? cards[g] : 1);
     if (null_handling) {
       /* DefaultGroupByExecutor.java:106-121: under null handling the keys come from the no-dictionary generators
        * (NoDictionarySingleColumnGroupKeyGenerator / NoDictionaryMultiColumnGroupKeyGenerator with nullHandlingEnabled): a null key value
        * is a key of its own, group ids are handed out in order of first appearance up to numGroupsLimit.  Restated on the raw-key
        * scale of the ABI: a nullable key column has one more digit value, `cardinality`, meaning NULL. */
       key_nulls[g] = column_null_words(seg, q->group_by_columns[g]);
-      if (key_nulls[g]) { cards[g] = d->cardinality + 1; wide_upper = wide_upper / (po_key)d->cardinality * (po_key)cards[g]; nullable_group_by = 1; }
+      if (key_nulls[g]) { const int32_t card0 = cards[g]; cards[g] = card0 + 1; wide_upper = wide_upper / (po_key)(card0 > 0 ? card0 : 1) * (po_key)cards[g]; nullable_group_by = 1; }
     }
   }
   key_kind = wide_upper > (po_key)0x7FFFFFFFFFFFFFFFull ? 2 : (wide_upper > (po_key)2147483647 ? 1 : 0);
   if (key_kind != 0 && null_handling) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by key space beyond an int under null handling"); goto done; }
   group_upper = key_kind == 0 ? (int64_t)wide_upper : 0x7FFFFFFFll;      /* (only an upper bound for the map-based sizing below) */
   if (null_handling && ng > 0 && has_null_values) nullable_group_by = 1;
+  if (no_dict_keys && key_kind == 0) nullable_group_by = 1;      /* the same generators: ids by first appearance up to numGroupsLimit whatever the key space */
 
   /* IntMapBasedHolder (DictionaryBasedGroupKeyGenerator.java:415-490) + IntGroupIdMap.getGroupId (:1022-1047): raw key -> group id in
    * order of first appearance; once _size == groupIdUpperBound = min(product, numGroupsLimit) (:176) new keys get INVALID_ID and the
@@ -1569,7 +1589,11 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       /* DictionaryBasedGroupKeyGenerator.ArrayBasedHolder.processSingleValue, :298-338 */
       for (int32_t i = 0; i < pos; i++) raw_keys[i] = 0;
       for (int g = ng - 1; g >= 0; g--) {
-        fetch_dict_ids(&cols[q->group_by_columns[g]], num_docs, doc_ids, pos, dict_scratch);
+        if (key_raw[g]) {
+          const po_column* kc = &cols[q->group_by_columns[g]];
+          const int is_int = kc->desc->stored_type == PG_TYPE_INT;
+          for (int32_t i = 0; i < pos; i++) dict_scratch[i] = (int32_t)((is_int ? (int64_t)raw_get_int(&kc->raw, doc_ids[i]) : raw_get_long(&kc->raw, doc_ids[i])) - key_base[g]);
+        } else fetch_dict_ids(&cols[q->group_by_columns[g]], num_docs, doc_ids, pos, dict_scratch);
         if (key_nulls[g]) for (int32_t i = 0; i < pos; i++) if ((key_nulls[g][doc_ids[i] >> 6] >> (doc_ids[i] & 63)) & 1) dict_scratch[i] = cards[g] - 1;   /* NULL */
         for (int32_t i = 0; i < pos; i++) raw_keys[i] = raw_keys[i] * (po_key)cards[g] + (po_key)dict_scratch[i];
       }
@@ -1745,7 +1769,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       k++;
     }
     free(order);
-    res->group_id_upper_bound = key_kind == 0 ? (int32_t)raw_key_upper : num_groups_limit;      /* LongMap / ArrayMap: _globalGroupIdUpperBound = numGroupsLimit (:150-163) */
+    res->group_id_upper_bound = (key_kind == 0 && !no_dict_keys) ? (int32_t)raw_key_upper : num_groups_limit;      /* LongMap / ArrayMap / no-dictionary generators: _globalGroupIdUpperBound = numGroupsLimit (:150-163) */
   }
   /* ExecutionStatistics: AggregationOperator.java:88-93 (numDocsScanned, inFilter, numDocsScanned * numProjectedColumns, totalDocs) */
   {

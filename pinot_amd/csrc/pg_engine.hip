@@ -126,6 +126,14 @@ struct ColumnDev {
   std::vector<int64_t> posting_first;   // [cardinality + 1] index into the container directory
   unsigned long long* d_null_bitmap = nullptr;   // null value vector expanded to a doc-order bitmap (num_tiles * 32 words), or nullptr
   int nullkey_column = -1;              // nullable dictionary column: index of its hidden null-key image (dictId = cardinality where the doc is null)
+  // Raw INT / LONG column as a group key: index of its hidden KEY IMAGE -- the fixed-bit stream of (value - raw_min), cardinality
+  // raw_max - raw_min + 1, built the first time the column is grouped by (ensure_key_image).  -1: not a raw INT / LONG column, or its
+  // value range does not fit the int dictId domain.  On the image itself: key_image_of = the raw column, key_base = its raw_min.
+  int keyimage_column = -1;
+  int64_t raw_min = 0, raw_max = -1;    // raw INT / LONG columns: smallest / largest value (one pass at open)
+  int key_image_of = -1;
+  int64_t key_base = 0;
+  int key_image_state = 0;              // 0 placeholder (no stream yet), 2 built; pg_segment::key_image_mu
   bool borrows_dictionary = false;      // hidden image: d_dict / d_dict64 belong to the column it was made from
   int64_t num_nulls = 0;
   // value plane (built lazily on the device the first time the column is summed)
@@ -201,8 +209,9 @@ struct pg_segment {
   int num_cus = 256;
   uint64_t device_bytes = 0;
   std::string name;
-  std::vector<ColumnDev> cols;          // the caller's columns, then hidden null-key images (ColumnDev.nullkey_column)
+  std::vector<ColumnDev> cols;          // the caller's columns, then hidden images: key images of raw columns (ColumnDev.keyimage_column), null-key images (nullkey_column)
   int num_user_cols = 0;
+  std::mutex key_image_mu;              // building a key image (once per raw column)
   std::mutex ctx_mu;
   // Partitioned group-by: docs per partition of a key-column set, ignoring the filter -- a property of the segment, not of the query.
   // Pass 0 (group_partition_histogram_kernel) computes it the first time a (key columns, shift) combination is grouped by; later
@@ -514,6 +523,40 @@ void free_segment(pg_segment* seg) {
     if (col.plane_event) (void)hipEventDestroy(col.plane_event);
   }
   delete seg;
+}
+
+// The key image of raw INT / LONG column `c` (ColumnDev.keyimage_column), built on first use: one pass over the resident column on a
+// stream of its own (the queries' streams are non-blocking), under the segment's key-image mutex.  *out_column = the image's index.
+pg_status ensure_key_image(pg_segment* seg, int c, int* out_column) {
+  ColumnDev& col = seg->cols[(size_t)c];
+  if (col.keyimage_column < 0)
+    return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s: only INT / LONG columns whose value range fits an int have a key image", col.name.c_str());
+  ColumnDev& image = seg->cols[(size_t)col.keyimage_column];
+  if (__atomic_load_n(&image.key_image_state, __ATOMIC_ACQUIRE) != 2) {
+    std::lock_guard<std::mutex> lk(seg->key_image_mu);
+    if (image.key_image_state != 2) {
+      const size_t bytes = (size_t)std::max(seg->num_tiles, 1) * 256 * (size_t)image.bits + 64;
+      uint8_t* d = nullptr;
+      hipStream_t stream = nullptr;
+      hipError_t e = hipMalloc((void**)&d, bytes);
+      if (e != hipSuccess) return fail(PG_ERR_OUT_OF_MEMORY, "key image of column %s: hipMalloc(%zu): %s", col.name.c_str(), bytes, hipGetErrorString(e));
+      e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipMemsetAsync(d, 0, bytes, stream);
+      if (e == hipSuccess) {
+        build_raw_key_image_kernel<<<dim3((unsigned)std::max(1, std::min(seg->num_tiles / 4 + 1, seg->num_cus * 8))), dim3(256), 0, stream>>>(col.d_fwd, col.vkind == kValI32 ? 4 : 8, image.key_base, d,
+                                                                                                                                               image.bits, seg->num_tiles, seg->num_docs);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      if (stream) (void)hipStreamDestroy(stream);
+      if (e != hipSuccess) { (void)hipFree(d); return fail(PG_ERR_DEVICE, "key image of column %s: %s", col.name.c_str(), hipGetErrorString(e)); }
+      image.d_fwd_alloc = d; image.d_fwd = d; image.fwd_alloc_bytes = bytes;
+      seg->device_bytes += bytes;
+      __atomic_store_n(&image.key_image_state, 2, __ATOMIC_RELEASE);
+    }
+  }
+  if (out_column) *out_column = col.keyimage_column;
+  return PG_OK;
 }
 
 // ---- value planes ----
@@ -1794,18 +1837,58 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       }
     }
   }
+  seg->num_user_cols = (int)seg->cols.size();
+  seg->cols.reserve(seg->cols.size() * 3);      // hidden images are appended (at most two per column); the vector never reallocates after open
+  // Raw INT / LONG columns as group keys: the value range (one pass over the resident column), and -- when it fits the int dictId
+  // domain -- a placeholder for the column's KEY IMAGE, the fixed-bit stream of (value - min) that ensure_key_image builds the first
+  // time the column is grouped by (pg_kernels.h, build_raw_key_image_kernel).  Nullable ones are built right away: their null-key image
+  // below is made from it.
+  {
+    long long* d_mm = nullptr;
+    for (int i = 0; i < seg->num_user_cols; ++i) {
+      ColumnDev& col = seg->cols[(size_t)i];
+      if (col.encoding != PG_FWD_RAW_FIXED_BYTE || (col.vkind != kValI32 && col.vkind != kValI64) || seg->num_docs <= 0) continue;
+      long long mm[2] = {0x7FFFFFFFFFFFFFFFll, (long long)0x8000000000000000ull};
+      hipError_t e = d_mm ? hipSuccess : hipMalloc((void**)&d_mm, 16);
+      if (e == hipSuccess) e = hipMemcpy(d_mm, mm, 16, hipMemcpyHostToDevice);
+      if (e == hipSuccess) {
+        raw_min_max_kernel<<<dim3((unsigned)std::max(1, std::min(seg->num_docs / 1024 + 1, seg->num_cus * 8))), dim3(256), 0, 0>>>(col.d_fwd, col.vkind == kValI32 ? 4 : 8, seg->num_docs, d_mm);
+        e = hipMemcpy(mm, d_mm, 16, hipMemcpyDeviceToHost);
+      }
+      if (e != hipSuccess) { if (d_mm) (void)hipFree(d_mm); return bail(fail(PG_ERR_DEVICE, "column %s: value range: %s", col.name.c_str(), hipGetErrorString(e))); }
+      col.raw_min = mm[0]; col.raw_max = mm[1];
+      if ((unsigned long long)(mm[1] - mm[0]) >= 0x7FFFFFFEull) continue;      // cardinality max - min + 1 has to be an int (and leave room for a null digit)
+      ColumnDev image;
+      image.name = col.name + "$keyimage";
+      image.stored_type = col.stored_type; image.encoding = PG_FWD_FIXED_BIT_DICT; image.vkind = kValI32;
+      image.cardinality = (int)(mm[1] - mm[0] + 1);
+      image.bits = 1;
+      while (image.bits < 31 && (1ll << image.bits) < (long long)image.cardinality) ++image.bits;      // PinotDataBitSet.getNumBitsPerValue(cardinality - 1)
+      image.key_image_of = i; image.key_base = mm[0];
+      col.keyimage_column = (int)seg->cols.size();
+      seg->cols.push_back(std::move(image));
+    }
+    if (d_mm) (void)hipFree(d_mm);
+    for (int i = 0; i < seg->num_user_cols; ++i) {
+      if (seg->cols[(size_t)i].keyimage_column < 0 || !seg->cols[(size_t)i].d_null_bitmap) continue;
+      const pg_status kst = ensure_key_image(seg, i, nullptr);
+      if (kst != PG_OK) return bail(kst);
+    }
+  }
   // GROUP BY under enableNullHandling treats NULL as a key of its own (DefaultGroupByExecutor.java:106-121: the no-dictionary key
   // generators).  A nullable dictionary column therefore gets a second forward index whose dictId is `cardinality` wherever the doc is
-  // null: the group-by kernels then need no notion of null (execute_null_handling points the key at this image).
-  seg->num_user_cols = (int)seg->cols.size();
-  seg->cols.reserve(seg->cols.size() * 2);
+  // null: the group-by kernels then need no notion of null (execute_null_handling points the key at this image).  A nullable raw
+  // INT / LONG column gets the same image, made from its key image.
   for (int i = 0; i < seg->num_user_cols; ++i) {
-    if (!seg->cols[(size_t)i].d_null_bitmap || seg->cols[(size_t)i].encoding != PG_FWD_FIXED_BIT_DICT) continue;
+    if (!seg->cols[(size_t)i].d_null_bitmap) continue;
+    const int src = seg->cols[(size_t)i].encoding == PG_FWD_FIXED_BIT_DICT ? i : seg->cols[(size_t)i].keyimage_column;
+    if (src < 0) continue;
     int bits_out = 1;
-    while (bits_out < 31 && (1ll << bits_out) <= (long long)seg->cols[(size_t)i].cardinality) ++bits_out;      // PinotDataBitSet.getNumBitsPerValue(cardinality)
+    while (bits_out < 31 && (1ll << bits_out) <= (long long)seg->cols[(size_t)src].cardinality) ++bits_out;      // PinotDataBitSet.getNumBitsPerValue(cardinality)
     ColumnDev image;
-    const ColumnDev& col = seg->cols[(size_t)i];
-    image.name = col.name + "$nullkey";
+    const ColumnDev& col = seg->cols[(size_t)src];
+    image.key_image_of = col.key_image_of; image.key_base = col.key_base;      // (null-key image of a key image: still min + digit, digit == cardinality - 1 is NULL)
+    image.name = seg->cols[(size_t)i].name + "$nullkey";
     image.stored_type = col.stored_type; image.encoding = col.encoding; image.vkind = col.vkind; image.value_base = col.value_base;
     image.bits = bits_out;
     image.cardinality = col.cardinality + 1;
@@ -1817,7 +1900,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
     hipError_t e = hipMalloc((void**)&image.d_fwd_alloc, image.fwd_alloc_bytes);
     if (e == hipSuccess) e = hipMemset(image.d_fwd_alloc, 0, image.fwd_alloc_bytes);
     if (e == hipSuccess) {
-      build_nullkey_fwd_kernel<<<dim3((unsigned)std::max(1, std::min(seg->num_tiles / 4 + 1, seg->num_cus * 8))), dim3(256), 0, 0>>>(col.d_fwd, col.bits, col.d_null_bitmap, image.d_fwd_alloc,
+      build_nullkey_fwd_kernel<<<dim3((unsigned)std::max(1, std::min(seg->num_tiles / 4 + 1, seg->num_cus * 8))), dim3(256), 0, 0>>>(col.d_fwd, col.bits, seg->cols[(size_t)i].d_null_bitmap, image.d_fwd_alloc,
                                                                                                                                      bits_out, (uint32_t)col.cardinality, seg->num_tiles);
       e = hipDeviceSynchronize();
     }
@@ -1853,6 +1936,17 @@ pg_status pg_segment_num_docs(const pg_segment* segment, int32_t* out_num_docs) 
 pg_status pg_segment_device_bytes(const pg_segment* segment, uint64_t* out_bytes) {
   if (!segment || !out_bytes) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
   *out_bytes = segment->device_bytes;
+  return PG_OK;
+}
+
+pg_status pg_group_key_base(const pg_segment* segment, int32_t column, int64_t* out_base, int32_t* out_is_offset) {
+  if (!segment || !out_base || !out_is_offset) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
+  if (column < 0 || column >= segment->num_user_cols) return fail(PG_ERR_INVALID_ARGUMENT, "column %d out of range", column);
+  const ColumnDev& col = segment->cols[(size_t)column];
+  *out_base = 0; *out_is_offset = 0;
+  if (col.encoding == PG_FWD_FIXED_BIT_DICT) return PG_OK;
+  if (col.keyimage_column < 0) return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s: only INT / LONG columns whose value range fits an int have a key image", col.name.c_str());
+  *out_base = col.raw_min; *out_is_offset = 1;
   return PG_OK;
 }
 
@@ -1959,10 +2053,15 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
   std::vector<int> key_cols, agg_cols, key_cards;
   long long product = 1;
   for (int g = 0; g < ng; ++g) {
-    const int c = q->group_by_columns[g];
+    int c = q->group_by_columns[g];
     if (c < 0 || c >= num_cols_total) return fail(PG_ERR_INVALID_ARGUMENT, "group-by column %d out of range", c);
+    if (seg->cols[(size_t)c].encoding != PG_FWD_FIXED_BIT_DICT) {
+      // a raw INT / LONG column is grouped by through its key image (cardinality and width are known since open; nothing is built here)
+      if (seg->cols[(size_t)c].keyimage_column < 0)
+        return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s: only INT / LONG columns whose value range fits an int have a key image", seg->cols[(size_t)c].name.c_str());
+      c = seg->cols[(size_t)c].keyimage_column;
+    }
     const ColumnDev& col = seg->cols[(size_t)c];
-    if (col.encoding != PG_FWD_FIXED_BIT_DICT) return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s", col.name.c_str());
     key_cards.push_back(col.cardinality);
     if (std::find(key_cols.begin(), key_cols.end(), c) == key_cols.end()) key_cols.push_back(c);
   }
@@ -2521,12 +2620,18 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     PlanGroupAgg plan_aggs[kMaxGroupAggs];
     long long product = 1;
     std::vector<int> cards;
+    bool no_dict_keys = false;            // a key is a raw column read through its key image, or the null-key image of one
     for (int g = 0; g < ng; ++g) {
-      const int c = q->group_by_columns[g];
+      int c = q->group_by_columns[g];
       if (c < 0 || c >= num_cols_total) return fail(PG_ERR_INVALID_ARGUMENT, "group-by column %d out of range", c);
+      add_projected(seg->cols[(size_t)c].key_image_of >= 0 ? seg->cols[(size_t)c].key_image_of : c);      // numEntriesScannedPostFilter counts the caller's column
+      if (seg->cols[(size_t)c].encoding != PG_FWD_FIXED_BIT_DICT) {
+        // NoDictionarySingle/MultiColumnGroupKeyGenerator: the raw INT / LONG column through its key image (value - min as the dictId)
+        st = ensure_key_image(seg, c, &c);
+        if (st != PG_OK) return st;
+      }
       const ColumnDev& col = seg->cols[(size_t)c];
-      if (col.encoding != PG_FWD_FIXED_BIT_DICT) return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s", col.name.c_str());
-      add_projected(c);
+      no_dict_keys |= col.key_image_of >= 0;
       int s = slot_for(&lw, seg, c);
       if (s < 0) return fail(PG_ERR_UNSUPPORTED, "query references more than %d columns", kMaxCols);
       pl.cols[s].in_agg = 1;
@@ -2548,7 +2653,10 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
     // (kQueryHashHolder: the no-dictionary key generators of null handling hand out group ids by first appearance up to numGroupsLimit
     //  whatever the key space: the compaction path below is the one that honours the limit)
-    const bool map_based = product > 10000 || (q->flags & kQueryHashHolder) != 0 || hash_plan.kind != 0;
+    // A raw key column always runs the no-dictionary generators (DefaultGroupByExecutor.java:106-121): _globalGroupIdUpperBound =
+    // numGroupsLimit whatever the key space (NoDictionarySingleColumnGroupKeyGenerator.java:73-79), ids by first appearance.
+    const bool first_appearance = (q->flags & kQueryHashHolder) != 0 || (no_dict_keys && hash_plan.kind == 0 && (long long)(q->num_groups_limit > 0 ? q->num_groups_limit : 100000) < product);
+    const bool map_based = product > 10000 || first_appearance || hash_plan.kind != 0;
     bool typed_direct = false;            // an aggregation input is a raw LONG / FLOAT / DOUBLE column: group_typed_direct_kernel
     gp.num_group_cols = ng;
     gp.num_groups = (int32_t)product;
@@ -2953,7 +3061,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     out->num_aggregations = na;
     out->dominant_kernel = use_partition ? PG_KERNEL_GROUP_PARTITION : (use_private ? PG_KERNEL_GROUP_PRIVATE : PG_KERNEL_SCAN_GROUP);
     out->num_groups = num_present;
-    out->group_id_upper_bound = hash_plan.kind != 0 ? (q->num_groups_limit > 0 ? q->num_groups_limit : 100000) : gp.num_groups;      // hashed holders: numGroupsLimit, like the reference (:150-163)
+    out->group_id_upper_bound = (hash_plan.kind != 0 || no_dict_keys) ? (q->num_groups_limit > 0 ? q->num_groups_limit : 100000) : gp.num_groups;      // hashed holders / no-dictionary generators: numGroupsLimit, like the reference (:150-163)
     out->group_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)std::max(num_present, 1));
     out->group_aggregations = (pg_agg_value*)calloc((size_t)std::max(num_present, 1) * (size_t)std::max(na, 1), sizeof(pg_agg_value));
     // The keys as dictId tuples, for every kind of holder (what GroupKeyGenerator.getGroupKeys turns into values); rows in ascending

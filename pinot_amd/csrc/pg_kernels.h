@@ -2802,6 +2802,47 @@ static __global__ __launch_bounds__(256) void build_nullkey_fwd_kernel(const uin
   }
 }
 
+// ---- raw INT / LONG columns as group keys (NoDictionarySingleColumnGroupKeyGenerator / NoDictionaryMultiColumnGroupKeyGenerator) ----
+// The reference keys such a column by VALUE (value -> group id in order of first appearance, NoDictionarySingleColumnGroupKeyGenerator
+// .java:100-113, 240-247).  Here the column gets a KEY IMAGE the first time it is grouped by: the fixed-bit stream of (value - min), as
+// if it had the dense dictionary {min .. max} -- every group-by kernel then reads it like any dictionary column, and a key comes back as
+// min + digit.  HBM capacity spent on a derived stream instead of a value-keyed hash in the kernels, like the value planes.
+static __global__ __launch_bounds__(256) void raw_min_max_kernel(const uint8_t* __restrict__ raw, int value_bytes, long long num_docs, long long* __restrict__ out_min_max) {
+  long long lo = 0x7FFFFFFFFFFFFFFFll, hi = (long long)0x8000000000000000ull;
+  for (long long doc = (long long)blockIdx.x * blockDim.x + threadIdx.x; doc < num_docs; doc += (long long)gridDim.x * blockDim.x) {
+    const long long v = value_bytes == 4 ? (long long)(int32_t)__builtin_bswap32(reinterpret_cast<const uint32_t*>(raw)[doc])
+                                         : (long long)__builtin_bswap64(reinterpret_cast<const unsigned long long*>(raw)[doc]);
+    lo = v < lo ? v : lo;
+    hi = v > hi ? v : hi;
+  }
+  lo = wave_min_i64(lo);
+  hi = wave_max_i64(hi);
+  if ((threadIdx.x & 63) == 0) { atomicMin(out_min_max, lo); atomicMax(out_min_max + 1, hi); }
+}
+
+// Lane-private layout like the scan kernels: a lane owns 32 docs of a 2048-doc tile and writes their bits_out-bit digits MSB-first
+// (PinotDataBitSet.writeInt).  Docs past numDocs get digit 0 (the raw buffer is padded to whole tiles with zeros, which need not be >= base).
+static __global__ __launch_bounds__(256) void build_raw_key_image_kernel(const uint8_t* __restrict__ raw, int value_bytes, long long base, uint8_t* __restrict__ out, int bits_out,
+                                                                          int num_tiles, long long num_docs) {
+  const int lane = threadIdx.x & 63;
+  for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < (long long)num_tiles; tile += (long long)gridDim.x * 4) {
+    const long long first = tile * 2048 + (long long)lane * 32;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + tile * (256ll * bits_out)) + lane * bits_out;
+    unsigned long long acc = 0ull;
+    int have = 0, k = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const long long doc = first + j;
+      const long long v = value_bytes == 4 ? (long long)(int32_t)__builtin_bswap32(reinterpret_cast<const uint32_t*>(raw)[doc])
+                                           : (long long)__builtin_bswap64(reinterpret_cast<const unsigned long long*>(raw)[doc]);
+      const uint32_t id = doc < num_docs ? (uint32_t)(unsigned long long)(v - base) : 0u;
+      acc = (acc << bits_out) | (unsigned long long)id;
+      have += bits_out;
+      if (have >= 32) { dst[k++] = __builtin_bswap32((uint32_t)(acc >> (have - 32))); have -= 32; }
+    }
+  }
+}
+
 // Wide value plane (pg_engine.hip want_wide_plane): out[doc] = the 8-byte dictionary entry of the doc's dictId, big-endian like the
 // value area of a raw LONG / DOUBLE forward index.  One-time build per column: a plain gather.
 static __global__ __launch_bounds__(256) void materialize_wide_plane_kernel(const uint8_t* __restrict__ fwd, int bits, const unsigned long long* __restrict__ dict64,
