@@ -327,10 +327,11 @@ void pg_result_free(pg_result* result);
  * entry is a dictId (GroupKeyGenerator.getGroupKeys looks it up, DictionaryBasedGroupKeyGenerator.java:260-290).  A raw (no-dictionary)
  * INT / LONG column -- the reference groups it by VALUE with NoDictionarySingleColumnGroupKeyGenerator / NoDictionaryMultiColumnGroupKey
  * Generator (core/query/aggregation/groupby/DefaultGroupByExecutor.java:106-121) --: *out_is_offset = 1 and the key value is
- * *out_base + entry (the column is grouped by through the stream of value - min; *out_base = the column's smallest value).  Under
- * PG_QUERY_NULL_HANDLING the entry `cardinality` (dictionary column) / max - min + 1 (raw column) means NULL, as before.
- * PG_ERR_UNSUPPORTED for a raw column pg_query_check declines as a group key (FLOAT / DOUBLE, or a value range beyond an int). */
-pg_status pg_group_key_base(const pg_segment* segment, int32_t column, int64_t* out_base, int32_t* out_is_offset);
+ * *out_base + entry (the column is grouped by through the stream of value - min; *out_base = the column's smallest value).
+ * *out_null_entry: the entry that means NULL under PG_QUERY_NULL_HANDLING -- `cardinality` of a dictionary column, max - min + 1 of a raw
+ * one (a column without a null value vector never produces it).  PG_ERR_UNSUPPORTED for a raw column pg_query_check declines as a group
+ * key (FLOAT / DOUBLE, or a value range beyond an int). */
+pg_status pg_group_key_info(const pg_segment* segment, int32_t column, int64_t* out_base, int32_t* out_is_offset, int32_t* out_null_entry);
 
 /* One query over MANY resident segments in one call: what BaseCombineOperator does with a thread pool (core/operator/combine/
  * BaseCombineOperator.java:85-142: numTasks worker threads, each pulling the next segment's operator and merging its block; CombinePlanNode.java:

@@ -44,6 +44,7 @@ import org.apache.pinot.segment.local.customobject.AvgPair;
 import org.apache.pinot.segment.spi.AggregationFunctionType;
 import org.apache.pinot.segment.spi.IndexSegment;
 import org.apache.pinot.segment.spi.index.reader.Dictionary;
+import org.apache.pinot.spi.data.FieldSpec;
 import org.slf4j.Logger;
 import org.slf4j.LoggerFactory;
 
@@ -226,12 +227,16 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
       }
     }
     List<ExpressionContext> groupBy = _queryContext.getGroupByExpressions();
-    Dictionary[] dictionaries = new Dictionary[groupBy.size()];
+    Dictionary[] dictionaries = new Dictionary[groupBy.size()];      // null: a raw key column (the no-dictionary key generators' case)
+    long[][] keyInfo = new long[groupBy.size()][];
+    boolean[] longKeys = new boolean[groupBy.size()];
     String[] columnNames = new String[groupBy.size() + numFunctions];
     DataSchema.ColumnDataType[] columnTypes = new DataSchema.ColumnDataType[groupBy.size() + numFunctions];
     for (int i = 0; i < groupBy.size(); i++) {
       String column = groupBy.get(i).getIdentifier();
       dictionaries[i] = _indexSegment.getDataSource(column).getDictionary();
+      keyInfo[i] = PinotGpuNative.groupKeyInfo(_segment.handle(), _segment.columnIndex(column));
+      longKeys[i] = _indexSegment.getDataSource(column).getDataSourceMetadata().getDataType().getStoredType() == FieldSpec.DataType.LONG;
       columnNames[i] = groupBy.get(i).toString();
       columnTypes[i] = DataSchema.ColumnDataType.fromDataTypeSV(_indexSegment.getDataSource(column).getDataSourceMetadata().getDataType());
     }
@@ -249,7 +254,7 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
       limitReached |= r._header[PinotGpuNative.PGM_H_NUM_GROUPS_LIMIT_REACHED] != 0;
     }
     DataSchema dataSchema = new DataSchema(columnNames, columnTypes);
-    GpuGroupKeyGenerator keys = new GpuGroupKeyGenerator(numGroups, groupKeys, dictionaries, (int) upperBound);
+    GpuGroupKeyGenerator keys = new GpuGroupKeyGenerator(numGroups, groupKeys, dictionaries, keyInfo, longKeys, (int) upperBound);
     // In-segment trim, exactly GroupByOperator.java:119-135: ORDER BY + minSegmentGroupTrimSize > 0 + more groups than the trim size
     int minGroupTrimSize = _queryContext.getMinSegmentGroupTrimSize();
     if (_queryContext.getOrderByExpressions() != null && minGroupTrimSize > 0) {

@@ -197,7 +197,13 @@ final class GpuQueryLowering {
       }
       int column = _segment.columnIndex(expression.getIdentifier());
       if (!_segment.hasDictionary(column)) {
-        throw new NotOffloadable("group-by on a raw column (NoDictionary key generators)");
+        // DefaultGroupByExecutor.java:106-121: the no-dictionary key generators (keys by value).  The device groups a raw INT / LONG
+        // column through its key image (value - min as the dictId, include/pinot_gpu.h pg_group_key_info); whether the column's value
+        // range allows one is pg_query_check's decision (GpuPlanMaker keeps the CPU plan on PG_ERR_UNSUPPORTED).
+        DataType storedType = _indexSegment.getDataSource(expression.getIdentifier()).getDataSourceMetadata().getDataType().getStoredType();
+        if (storedType != DataType.INT && storedType != DataType.LONG) {
+          throw new NotOffloadable("group-by on a raw " + storedType + " column (NoDictionary key generators)");
+        }
       }
       out._groupBy[i] = column;
     }

@@ -136,6 +136,14 @@ public final class PinotGpuNative {
   /** pg_segment_device_bytes */
   static native long segmentDeviceBytes(long handle);
 
+  /**
+   * pg_group_key_info: {base, isOffset, nullEntry} of a group-by column -- a dictionary column's key entries are dictIds (isOffset 0); a raw
+   * INT / LONG column's are offsets from its smallest value (isOffset 1, key value = base + entry: the reference's no-dictionary key
+   * generators key by value); nullEntry is the entry that means NULL under enableNullHandling.  Throws UnsupportedOperationException for a
+   * raw column without a key image.
+   */
+  static native long[] groupKeyInfo(long handle, int column);
+
   /** pg_query_check: PG_OK or PG_ERR_UNSUPPORTED; nothing is launched. */
   static native int queryCheck(long handle, int[] filterNodes, int[] predInts, long[] predLongs, int[] setOffsets, int[] setWords,
       int[] aggregations, int[] groupBy, int numGroupsLimit, int flags);

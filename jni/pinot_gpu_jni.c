@@ -123,6 +123,18 @@ JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_segmentDeviceBy
   return (jlong)bytes;
 }
 
+JNIEXPORT jlongArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_groupKeyInfo(JNIEnv* env, jclass cls, jlong handle, jint column) {
+  (void)cls;
+  int64_t base = 0;
+  int32_t is_offset = 0, null_entry = 0;
+  const pg_status status = pg_group_key_info((const pg_segment*)(intptr_t)handle, (int32_t)column, &base, &is_offset, &null_entry);
+  if (status != PG_OK) { throw_status(env, status); return NULL; }
+  const jlong values[3] = {(jlong)base, (jlong)is_offset, (jlong)null_entry};
+  jlongArray out = (*env)->NewLongArray(env, 3);
+  if (out != NULL) (*env)->SetLongArrayRegion(env, out, 0, 3, values);
+  return out;
+}
+
 /* The query arrays of pg_marshal.h, pinned for the duration of one call. */
 typedef struct pinned_query {
   jint *nodes, *pred_ints, *set_offsets, *set_words, *aggregations, *group_by;

@@ -1486,7 +1486,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       /* DefaultGroupByExecutor.java:106-121: one key column without a dictionary sends the whole query to the no-dictionary generators,
        * which key by VALUE -- value -> group id in order of first appearance (NoDictionarySingleColumnGroupKeyGenerator.java:100-113,
        * 240-247; NoDictionaryMultiColumnGroupKeyGenerator: the tuple of values / dictIds), _globalGroupIdUpperBound = numGroupsLimit
-       * (:73-79).  Restated on the raw-key scale of the ABI (include/pinot_gpu.h, pg_group_key_base): the column's digit is
+       * (:73-79).  Restated on the raw-key scale of the ABI (include/pinot_gpu.h, pg_group_key_info): the column's digit is
        * value - min, its digit count max - min + 1; INT / LONG columns whose range fits an int. */
       const po_column* kc = &cols[q->group_by_columns[g]];
       if (d->stored_type != PG_TYPE_INT && d->stored_type != PG_TYPE_LONG) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by on raw FLOAT / DOUBLE column"); goto done; }

@@ -46,6 +46,7 @@ const GpuAbi& gpuAbi() {
     abi.execute = (decltype(abi.execute))sym("pg_execute");
     abi.result_free = (decltype(abi.result_free))sym("pg_result_free");
     abi.filter_bitmap = (decltype(abi.filter_bitmap))sym("pg_filter_bitmap");
+    abi.group_key_info = (decltype(abi.group_key_info))sym("pg_group_key_info");
   });
   if (!error.empty()) throw std::runtime_error("pinot GPU engine unavailable (no CPU fallback in this library): " + error);
   return abi;
@@ -428,12 +429,17 @@ std::unique_ptr<LoweredQuery> lowerQuery(const ImmutableSegment& seg, const Quer
   long long product = 1;
   for (const auto& g : qc.groupByExpressions) {
     const DataSource& ds = seg.getDataSource(g);
-    if (!ds.hasDictionary) throw UnsupportedOperationException("group-by on a raw column uses the no-dictionary key generator (CPU plan)");
-    product *= ds.cardinality + ((qc.nullHandlingEnabled && ds.nullValueVector != nullptr && ds.nullValueVectorSize > 0) ? 1 : 0);   // NULL is a key value of its own
-    // DictionaryBasedGroupKeyGenerator.java:164-184: ArrayBasedHolder up to arrayBasedThreshold, IntMapBasedHolder above it -- both are
-    // one direct-indexed device table while the raw key is an int (pg_query_check also prices the table against the device's budget);
-    // the Long / ArrayMap holders beyond that keep the CPU plan
-    if (product > 0x7FFFFFFFll) throw UnsupportedOperationException("group-by cardinality product exceeds the int raw-key range of the device's direct-indexed table");
+    if (!ds.hasDictionary) {
+      // DefaultGroupByExecutor.java:106-121: the no-dictionary key generators (keys by value).  The device groups a raw INT / LONG column
+      // through its key image (value - min as the dictId); whether the column's value range allows one is pg_query_check's decision.
+      if (ds.dataType != DataType::INT && ds.dataType != DataType::LONG)
+        throw UnsupportedOperationException("group-by on a raw " + std::string(ds.dataType == DataType::STRING ? "STRING" : "FLOAT / DOUBLE") + " column uses the no-dictionary key generator (CPU plan)");
+      lq->groupBy.push_back(seg.getColumnIndex(g));
+      continue;
+    }
+    // (a key space beyond an int -- the Long / ArrayMap holders -- is the device's hashed table; pg_query_check prices either table
+    //  against the device's budget: DictionaryBasedGroupKeyGenerator.java:164-184)
+    if (product <= 0x7FFFFFFFll) product *= ds.cardinality + ((qc.nullHandlingEnabled && ds.nullValueVector != nullptr && ds.nullValueVectorSize > 0) ? 1 : 0);   // NULL is a key value of its own
     lq->groupBy.push_back(seg.getColumnIndex(g));
   }
   pg_query& q = lq->query;
@@ -484,6 +490,11 @@ class GpuAggregationOperator : public Operator {
       std::vector<const DataSource*> keyCols;
       for (const auto& c : g.groupByColumns) keyCols.push_back(&_segment->getDataSource(c));
       for (const DataSource* ds : keyCols) g.groupByTypes.push_back(ds->dataType);
+      // raw key columns: the entry is an offset from the column's smallest value (pg_group_key_info); dictionary columns: a dictId
+      std::vector<int64_t> keyBase(keyCols.size(), 0);
+      std::vector<int32_t> keyIsOffset(keyCols.size(), 0), keyNullEntry(keyCols.size(), 0);
+      for (size_t j = 0; j < keyCols.size(); ++j)
+        checkStatus(gpuAbi().group_key_info((const pg_segment*)_segment->handle(), _lowered->groupBy[j], &keyBase[j], &keyIsOffset[j], &keyNullEntry[j]), "reading the group keys");
       for (int i = 0; i < res.num_groups; ++i) {
         GroupKey key;
         key.groupId = res.group_ids[i];
@@ -496,7 +507,8 @@ class GpuAggregationOperator : public Operator {
           const DataSource* ds = keyCols[j];
           const int d = res.group_key_dict_ids[(size_t)i * nk + j];
           key.dictIds.push_back(d);
-          if (d == ds->cardinality) key.keys.emplace_back(std::monostate{});
+          if (d == keyNullEntry[j]) key.keys.emplace_back(std::monostate{});
+          else if (keyIsOffset[j]) key.keys.emplace_back((int64_t)(keyBase[j] + (int64_t)d));      // NoDictionary*GroupKeyGenerator: the key IS the value
           else if (ds->dataType == DataType::STRING) key.keys.emplace_back(ds->dictionary->getStringValue(d));
           else if (ds->dataType == DataType::FLOAT || ds->dataType == DataType::DOUBLE) key.keys.emplace_back(ds->dictionary->getDoubleValue(d));
           else key.keys.emplace_back(ds->dictionary->getLongValue(d));

@@ -1939,14 +1939,14 @@ pg_status pg_segment_device_bytes(const pg_segment* segment, uint64_t* out_bytes
   return PG_OK;
 }
 
-pg_status pg_group_key_base(const pg_segment* segment, int32_t column, int64_t* out_base, int32_t* out_is_offset) {
-  if (!segment || !out_base || !out_is_offset) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
+pg_status pg_group_key_info(const pg_segment* segment, int32_t column, int64_t* out_base, int32_t* out_is_offset, int32_t* out_null_entry) {
+  if (!segment || !out_base || !out_is_offset || !out_null_entry) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
   if (column < 0 || column >= segment->num_user_cols) return fail(PG_ERR_INVALID_ARGUMENT, "column %d out of range", column);
   const ColumnDev& col = segment->cols[(size_t)column];
-  *out_base = 0; *out_is_offset = 0;
+  *out_base = 0; *out_is_offset = 0; *out_null_entry = col.cardinality;
   if (col.encoding == PG_FWD_FIXED_BIT_DICT) return PG_OK;
   if (col.keyimage_column < 0) return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s: only INT / LONG columns whose value range fits an int have a key image", col.name.c_str());
-  *out_base = col.raw_min; *out_is_offset = 1;
+  *out_base = col.raw_min; *out_is_offset = 1; *out_null_entry = segment->cols[(size_t)col.keyimage_column].cardinality;
   return PG_OK;
 }
 

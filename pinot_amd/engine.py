@@ -99,11 +99,12 @@ class GpuSegment:
         finally:
             self.lib.pg_result_free(C.byref(res))
 
-    def group_key_base(self, column):
-        """pg_group_key_base: (base, is_offset) -- a raw INT / LONG group-by column's key value is base + its entry of Result.group_keys."""
-        base, is_offset = C.c_int64(0), C.c_int32(0)
-        _abi.check(self.lib, self.lib.pg_group_key_base(self.handle, int(column), C.byref(base), C.byref(is_offset)))
-        return int(base.value), bool(is_offset.value)
+    def group_key_info(self, column):
+        """pg_group_key_info: (base, is_offset, null_entry) -- a raw INT / LONG group-by column's key value is base + its entry of
+        Result.group_keys; null_entry is the entry that means NULL under null handling."""
+        base, is_offset, null_entry = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        _abi.check(self.lib, self.lib.pg_group_key_info(self.handle, int(column), C.byref(base), C.byref(is_offset), C.byref(null_entry)))
+        return int(base.value), bool(is_offset.value), int(null_entry.value)
 
     def check(self, spec):
         """pg_query_check: the status pg_execute would return for eligibility reasons (0 = PG_OK, 2 = PG_ERR_UNSUPPORTED), nothing launched."""

@@ -65,7 +65,7 @@ def is_raw(seg, column):
 
 
 def key_tuples(result, seg, spec, base_of):
-    """Result rows keyed by what the reference's generators key them by: the VALUE of a raw column (base + digit, pg_group_key_base), the
+    """Result rows keyed by what the reference's generators key them by: the VALUE of a raw column (base + digit, pg_group_key_info), the
     dictId of a dictionary column.  -> {tuple: [AggValue...]} in row order."""
     bases = [base_of(c) if is_raw(seg, c) else 0 for c in spec.group_by]
     out = {}

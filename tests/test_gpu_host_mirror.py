@@ -426,3 +426,36 @@ def test_fast_filtered_count_cases_of_the_reference_test():
         assert two_segments["final"] == [2.0 * bc]
     finally:
         seg.destroy()
+
+
+def test_group_by_raw_key_columns_through_sql():
+    """GROUP BY over no-dictionary INT / LONG columns (DefaultGroupByExecutor.java:106-121: the no-dictionary key generators) through
+    the plan maker: the device's entries are offsets from the column's smallest value, the block's keys are the values; two segments
+    with different value ranges merge on the values."""
+    from pinot_amd import segment as S
+    rng = np.random.default_rng(21)
+    segs, values = [], []
+    try:
+        for s, (lo, span) in enumerate(((-40, 90), (10, 200))):
+            n = 20_000 + 7 * s
+            k = rng.integers(lo, lo + span, n).astype(np.int32)
+            big = (rng.integers(0, 50, n).astype(np.int64) * 1_000_003 + 10 ** 11)
+            d = rng.integers(0, 9, n).astype(np.int32)
+            v = rng.integers(0, 1000, n).astype(np.int32)
+            segs.append(host.HostSegment(S.SegmentData("rawkeys%d" % s, n, [S.Column.raw("k", k), S.Column.raw_typed("big", big), S.Column.dict_encoded("d", d), S.Column.dict_encoded("v", v)])))
+            values.append((k, big, d, v))
+        for key_cols, sql in ((("k",), "SELECT k, SUM(v), COUNT(*) FROM testTable GROUP BY k LIMIT 100000"),
+                              (("big", "d"), "SELECT big, d, SUM(v), COUNT(*) FROM testTable WHERE v < 700 GROUP BY big, d LIMIT 100000")):
+            out = host.execute_sql(segs, sql)
+            want = {}
+            for k, big, d, v in values:
+                cols = {"k": k, "big": big, "d": d}
+                mask = v < 700 if "WHERE" in sql else np.ones(len(v), bool)
+                for row, val in zip(zip(*[cols[c][mask].tolist() for c in key_cols]), v[mask].tolist()):
+                    acc = want.setdefault(tuple(row), [0.0, 0])
+                    acc[0] += val; acc[1] += 1
+            got = {tuple(g["key"]): g["final"] for g in out["combined"]["groups"]}
+            assert got == {k: [float(s), c] for k, (s, c) in want.items()}, sql
+    finally:
+        for seg in segs:
+            seg.destroy()

@@ -1,7 +1,7 @@
 """GPU tests of GROUP BY over raw (no-dictionary) INT / LONG columns -- the reference's NoDictionarySingleColumnGroupKeyGenerator /
 NoDictionaryMultiColumnGroupKeyGenerator (core/query/aggregation/groupby/DefaultGroupByExecutor.java:106-121) -- run through the column's
 KEY IMAGE (the fixed-bit stream of value - min built on first use: pg_kernels.h build_raw_key_image_kernel), keys back as min + digit
-(pg_group_key_base), numGroupsLimit honoured in docId order.  Against the oracle, which tests/test_oracle_raw_keys.py holds against a
+(pg_group_key_info), numGroupsLimit honoured in docId order.  Against the oracle, which tests/test_oracle_raw_keys.py holds against a
 per-doc restatement keyed by the true values."""
 import numpy as np
 import pytest
@@ -37,11 +37,12 @@ def test_no_dictionary_group_key_generators(engine, case):
                 words, _ = oracle.filter_bitmap(seg, Q.QuerySpec([], filter=spec.filter))
                 mask = np.unpackbits(words.view(np.uint8), bitorder="little")[: seg.num_docs].astype(bool)
             rows, _ = RC.numpy_groups(key_values, spec, mask, seg.num_docs)
-            assert sorted(RC.key_tuples(got, seg, spec, lambda c: g.group_key_base(c)[0])) == sorted(rows)
+            assert sorted(RC.key_tuples(got, seg, spec, lambda c: g.group_key_info(c)[0])) == sorted(rows)
         for c in range(len(case[2])):
-            base, is_offset = g.group_key_base(c)
+            base, is_offset, null_entry = g.group_key_info(c)
             assert is_offset == RC.is_raw(seg, c)
             assert base == (int(key_values[c].min()) if is_offset else 0)
+            assert null_entry == (int(key_values[c].max() - key_values[c].min()) + 1 if is_offset else seg.columns[c].cardinality)
         assert g.device_bytes() > before                                   # the key images are resident now (and counted)
 
 
@@ -60,7 +61,7 @@ def test_key_columns_outside_the_key_image_keep_the_cpu_plan(engine):
                 g.execute(spec)
             assert e.value.status == _abi.PG_ERR_UNSUPPORTED
             with pytest.raises(_abi.PinotGpuError):
-                g.group_key_base(col)
+                g.group_key_info(col)
         # the same columns are still aggregated, and a dictionary column is still grouped by
         got = g.execute(Q.QuerySpec([(Q.MAX, 0), (Q.COUNT, -1)], group_by=[2]))
         H.assert_results_equal(got, oracle.execute(seg, Q.QuerySpec([(Q.MAX, 0), (Q.COUNT, -1)], group_by=[2])))
@@ -84,6 +85,7 @@ def test_nullable_raw_key_under_null_handling(engine):
             assert g.check(spec) == _abi.PG_OK
             want = oracle.execute(seg, spec)
             got = g.execute(spec)
+            assert g.group_key_info(0) == (-50, True, 500)
             assert any(t[0] == 500 for t in got.group_keys)               # the NULL key: digit max - min + 1 of the value range [-50, 449]
             H.assert_results_equal(got, want, check_stats=False)
             assert got.group_keys == want.group_keys

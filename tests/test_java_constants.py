@@ -170,7 +170,7 @@ def test_java_sources_are_balanced_and_reference_only_existing_members():
     """No javac here: at least brackets balance, every PinotGpuNative.<member> exists, and every in-package call GpuX.method( resolves to a
     method that class declares with that many parameters."""
     files = java_files()
-    native_members = set(re.findall(r"\b(?:int|long|String|void|Object\[\])\s+(\w+)\s*[=(]", strip_c_comments(files["PinotGpuNative.java"])))
+    native_members = set(re.findall(r"\b(?:int|long|String|void|Object\[\]|long\[\])\s+(\w+)\s*[=(]", strip_c_comments(files["PinotGpuNative.java"])))
     declared = {}
     for fname, text in files.items():
         code = _strip_java_literals(text)
