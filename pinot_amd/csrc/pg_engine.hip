@@ -292,11 +292,11 @@ struct CtxGuard {
 };
 
 pg_status ensure_partials(ExecCtx* c, int blocks) {
-  if (c->partial_capacity >= blocks + 1) return PG_OK;
+  if (c->partial_capacity >= blocks + kFoldExtraRecords) return PG_OK;
   if (c->d_partials) (void)hipFree(c->d_partials);
   c->d_partials = nullptr;
-  HIP_TRY(hipMalloc((void**)&c->d_partials, sizeof(BlockPartial) * (size_t)(blocks + 1)));
-  c->partial_capacity = blocks + 1;
+  HIP_TRY(hipMalloc((void**)&c->d_partials, sizeof(BlockPartial) * (size_t)(blocks + kFoldExtraRecords)));
+  c->partial_capacity = blocks + kFoldExtraRecords;
   return PG_OK;
 }
 
@@ -3649,7 +3649,7 @@ pg_status run_deferred(int device, const std::vector<int>& items, std::vector<De
     const long long tiles = ((long long)segments[items[(size_t)k]]->num_docs + 2047) / 2048;
     const long long share = total_tiles > 0 ? (tiles * budget + total_tiles - 1) / total_tiles : 1;
     blocks[(size_t)k] = (int)std::max<long long>(1, std::min<long long>({(long long)d.blocks, share, (tiles + 3) / 4}));
-    partials += (size_t)blocks[(size_t)k] + 1;
+    partials += (size_t)blocks[(size_t)k] + (size_t)kFoldExtraRecords;
     total_blocks += blocks[(size_t)k];
     one_slot = one_slot && d.one_slot;
   }
@@ -3661,7 +3661,7 @@ pg_status run_deferred(int device, const std::vector<int>& items, std::vector<De
   for (int k = 0; k < n; ++k) {
     ScanParams sp = defs[(size_t)items[(size_t)k]].sp;
     sp.partials = b->d_partials + off;
-    off += (size_t)blocks[(size_t)k] + 1;
+    off += (size_t)blocks[(size_t)k] + (size_t)kFoldExtraRecords;
     sp.done_counter = b->d_done + (size_t)k * (kFoldShards + 1) * kFoldStride;
     sp.host_out = b->h_records_dev + k;
     sp.host_seq = seq;

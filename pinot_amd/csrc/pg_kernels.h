@@ -729,13 +729,14 @@ __device__ __forceinline__ unsigned long long partial_word(const BlockPartial* r
   if constexpr (kCoherent) return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else return *w;
 }
+// The records folded are partials[first + j * stride], j < num_records.
 template <bool kCoherent = false>
-__device__ __forceinline__ BlockPartial fold_partials(const BlockPartial* partials, int num_records, BlockPartial* red, const FoldFields ff) {
+__device__ __forceinline__ BlockPartial fold_partials(const BlockPartial* partials, int first, int stride, int num_records, BlockPartial* red, const FoldFields ff) {
   static_assert(kMaxAggCols % 2 == 0, "kmin / kmax are read as pairs");
   BlockPartial acc;
   partial_identity(acc);
   for (int i = threadIdx.x; i < num_records; i += blockDim.x) {
-    const BlockPartial* b = partials + i;
+    const BlockPartial* b = partials + first + (long long)i * stride;
     acc.count += partial_word<kCoherent>(b, offsetof(BlockPartial, count));
     acc.flags |= partial_word<kCoherent>(b, offsetof(BlockPartial, flags));
     acc.entries += partial_word<kCoherent>(b, offsetof(BlockPartial, entries));
@@ -813,7 +814,7 @@ __device__ __forceinline__ void store_host_record_by_wave0(HostRecord* host_out,
 static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockPartial* partials, int num_blocks, HostRecord* host_out, unsigned long long seq,
                                                                                  int slots, int typed, int cycles) {
   __shared__ BlockPartial red[kBlockThreads / 64];
-  const BlockPartial t = fold_partials(partials, num_blocks, red, FoldFields{slots, typed != 0, cycles != 0});
+  const BlockPartial t = fold_partials(partials, 0, 1, num_blocks, red, FoldFields{slots, typed != 0, cycles != 0});
   if (threadIdx.x == 0) {
     if (host_out) red[0] = t;
     else partials[num_blocks] = t;
@@ -833,12 +834,17 @@ static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel
 // 128 bytes apart) so that a grid finishing at once does not serialise 1024 atomics on one word; the workgroup completing a shard
 // arrives on the ninth.  `flag` is one dword of LDS the caller provides (scan_hist_kernel keeps its counters as the only static LDS object).
 constexpr int kFoldShards = 8, kFoldStride = 32;      // counters are kFoldStride dwords apart; kFoldShards * kFoldStride is the top counter
+constexpr int kFoldExtraRecords = 1 + kFoldShards;    // behind the workgroups' records: the query's record, then one record per shard
+constexpr int kFoldOneLevel = 1536;                   // grids up to this many workgroups are folded by one workgroup in one level (publish_block_partial)
 // `block_index` of `num_blocks`: the workgroup's place among those that work on this ScanParams (the whole grid, or one query's share of
 // a batch launch -- scan_private_batch_kernel).
 template <typename P>
 __device__ __forceinline__ void publish_block_partial(const P& p, BlockPartial* red, int waves_per_block, uint32_t* flag, uint32_t block_index,
                                                       uint32_t num_blocks) {
   const bool arrive = p.done_counter != nullptr && num_blocks > 1u;
+  const uint32_t shard = block_index & (kFoldShards - 1);
+  const uint32_t in_shard = (num_blocks + (kFoldShards - 1) - shard) / kFoldShards;          // workgroups b with (b & 7) == shard
+  const uint32_t shards = num_blocks < (uint32_t)kFoldShards ? num_blocks : (uint32_t)kFoldShards;
   if (threadIdx.x < 64) {                                  // wave 0
     if (threadIdx.x == 0) {
       BlockPartial acc = red[0];
@@ -854,21 +860,37 @@ __device__ __forceinline__ void publish_block_partial(const P& p, BlockPartial* 
       store_record_by_wave0<false>(&red[0], &p.partials[block_index]);
     }
     if (threadIdx.x == 0) {
-      uint32_t last = 0u;
-      if (arrive) {
-        const uint32_t shard = block_index & (kFoldShards - 1);
-        const uint32_t in_shard = (num_blocks + (kFoldShards - 1) - shard) / kFoldShards;          // workgroups b with (b & 7) == shard
-        const uint32_t shards = num_blocks < (uint32_t)kFoldShards ? num_blocks : (uint32_t)kFoldShards;
-        if (__hip_atomic_fetch_add(p.done_counter + shard * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_shard) {
-          if (__hip_atomic_fetch_add(p.done_counter + kFoldShards * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == shards) last = 1u;
-        }
-      }
-      *flag = last;
+      // a workgroup whose arrival completes its shard goes on; on a small grid it arrives on the top counter right away and only the
+      // workgroup completing THAT goes on (one flag write per phase: the other waves read it behind the barrier below)
+      uint32_t go = (arrive && __hip_atomic_fetch_add(p.done_counter + shard * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_shard) ? 1u : 0u;
+      if (go != 0u && num_blocks <= (uint32_t)kFoldOneLevel)
+        go = __hip_atomic_fetch_add(p.done_counter + kFoldShards * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == shards ? 1u : 0u;
+      *flag = go;
     }
   }
   __syncthreads();
   if (*flag == 0u) return;
-  const BlockPartial t = fold_partials<true>(p.partials, (int)num_blocks, red, fold_fields_of(p));
+  const FoldFields ff = fold_fields_of(p);
+  BlockPartial t;
+  if (num_blocks <= (uint32_t)kFoldOneLevel) {
+    // every workgroup has arrived: fold every workgroup's record (at most six per thread) and publish the query's result
+    t = fold_partials<true>(p.partials, 0, 1, (int)num_blocks, red, ff);
+  } else {
+    // Larger grids, two levels of one pass each: the workgroup that completed a shard folds the shard's records (every eighth of the
+    // grid's, one per thread up to 2048 workgroups -- ONE round of loads where one workgroup folding the whole grid walked eight records
+    // per thread one after the other, 12 us at the end of a 1 B-row scan), leaves the shard's record behind the grid's and arrives on
+    // the top counter; the workgroup completing that folds the eight shard records.  (On small grids the second hand-off costs more
+    // than the shorter walk saves: 123 workgroups 13.7 -> 16.2 us.)
+    t = fold_partials<true>(p.partials, (int)shard, kFoldShards, (int)in_shard, red, ff);
+    if (threadIdx.x == 0) red[0] = t;
+    if (threadIdx.x < 64) {
+      store_record_by_wave0<false>(&red[0], &p.partials[num_blocks + 1u + shard]);
+      if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(p.done_counter + kFoldShards * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == shards ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+    t = fold_partials<true>(p.partials, (int)num_blocks + 1, 1, (int)shards, red, ff);
+  }
   if (threadIdx.x == 0) {
     for (int c = 0; c <= kFoldShards; ++c) __hip_atomic_store(p.done_counter + c * kFoldStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the context's next launch
     if (p.host_out) red[0] = t;

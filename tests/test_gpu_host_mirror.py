@@ -270,13 +270,26 @@ def test_group_by_over_144_million_raw_keys(golden_segments):
 def test_plan_time_rejection_and_errors(golden_segments):
     _, segs = golden_segments
     for sql, status in (("SELECT column1 FROM testTable", 2),
-                        ("SELECT SUM(column1) FROM testTable GROUP BY column1, column3, column6", 2),     # 6582 * 21910 * 608 raw keys are not an int
                         ("SELECT SUM(nope) FROM testTable", 1),
                         ("SELECT SUM(column11) FROM testTable", 1),
                         ("SELECT SUM(column1) FROM testTable WHERE column1 = 'abc'", 1)):
         with pytest.raises(host.HostError) as e:
             host.execute_sql(segs[:1], sql)
         assert e.value.status == status, sql
+
+
+def test_group_by_key_space_beyond_an_int_through_sql(golden_segments):
+    """GROUP BY column1, column3, column6: 6582 * 21910 * 608 raw keys are not an int -- the reference's LongMapBasedHolder, the device's
+    hashed table; the plan maker hands the query over like any other and the keys come back as values."""
+    _, segs = golden_segments
+    d = H.load_golden_columns()
+    out = host.execute_sql(segs[:1], "SELECT column1, column3, column6, SUM(column1), COUNT(*) FROM testTable GROUP BY column1, column3, column6 LIMIT 100000")["segments"][0]
+    keys = np.stack([d["column1"], d["column3"], d["column6"]], axis=1)
+    uniq, counts = np.unique(keys, axis=0, return_counts=True)
+    got = {tuple(g["key"]): g["intermediate"] for g in out["groups"]}
+    assert len(got) == len(uniq)
+    for row, c in list(zip(uniq.tolist(), counts.tolist()))[:: max(1, len(uniq) // 500)]:
+        assert got[tuple(row)] == [float(row[0]) * c, c]
 
 
 def test_sql_over_the_segment_written_by_the_reference():

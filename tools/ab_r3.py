@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 SETTINGS = {
     "default": {},
     "fold0": {"PINOT_GPU_FOLD_FINALIZE": "0"},
+    "fold1": {"PINOT_GPU_FOLD_FINALIZE": "1"},
     "poll1": {"PINOT_GPU_POLL_RESULT": "1"},
     "fold0_poll1": {"PINOT_GPU_FOLD_FINALIZE": "0", "PINOT_GPU_POLL_RESULT": "1"},
     "laneskip0": {"PINOT_GPU_LANE_SKIP": "0", "PINOT_GPU_SPARSE_LANES": "0"},
