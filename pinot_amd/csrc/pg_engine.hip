@@ -142,6 +142,8 @@ struct ColumnDev {
   int64_t plane_base = 0;               // value = plane_base + plane_scale * decoded field (0 / 1 for plane_bits == 32)
   int64_t plane_scale = 1;              // gcd of (value - min): frame of reference + GCD scaling
   bool plane_is_fwd = false;            // arithmetic-progression dictionary: the dictId stream itself is the plane (d_plane == d_fwd)
+  int plane_fwd_published = 0;          // 1 once plane_is_fwd and the plane_* fields above are set (release / acquire): such a plane is never built, budgeted or dropped,
+                                        // so queries take it without g_planes.mu (64 items of a batch lowered side by side met on that mutex twice each)
   // what the plane of this column would look like (computed once at open: the gcd walks the whole dictionary)
   int64_t shape_base = 0, shape_scale = 1;
   int shape_bits = 0;
@@ -659,6 +661,7 @@ void drop_plane_locked(pg_segment* seg, int column) {
   col.d_plane = nullptr;
   col.plane_ready = false;
   col.plane_state = 0;
+  __atomic_store_n(&col.plane_fwd_published, 0, __ATOMIC_RELEASE);      // (only a closing segment drops a plane that aliases its forward index)
   g_planes.total_bytes -= col.plane_bytes;
   seg->plane_bytes -= col.plane_bytes;
   seg->device_bytes -= col.plane_bytes;
@@ -684,6 +687,7 @@ void drop_planes_of(pg_segment* seg) {
 pg_status acquire_plane(pg_segment* seg, int column, bool* ready) {
   *ready = false;
   ColumnDev& col = seg->cols[(size_t)column];
+  if (__atomic_load_n(&col.plane_fwd_published, __ATOMIC_ACQUIRE) != 0) { *ready = true; return PG_OK; }
   std::lock_guard<std::mutex> lk(g_planes.mu);
   if (col.plane_state == 0 && col.vkind != kValI32) {
     // wide plane (want_wide_plane): 8 bytes per doc, padded to whole 2048-doc tiles like a raw column
@@ -726,6 +730,7 @@ pg_status acquire_plane(pg_segment* seg, int column, bool* ready) {
       col.d_plane = col.d_fwd;
       col.plane_ready = true;
       col.plane_state = 2;
+      __atomic_store_n(&col.plane_fwd_published, 1, __ATOMIC_RELEASE);
       *ready = true;
       return PG_OK;
     }
@@ -790,8 +795,9 @@ pg_status acquire_plane(pg_segment* seg, int column, bool* ready) {
 }
 
 void release_plane(pg_segment* seg, int column) {
-  std::lock_guard<std::mutex> lk(g_planes.mu);
   ColumnDev& col = seg->cols[(size_t)column];
+  if (__atomic_load_n(&col.plane_fwd_published, __ATOMIC_ACQUIRE) != 0) return;      // (never counted: acquire_plane)
+  std::lock_guard<std::mutex> lk(g_planes.mu);
   if (col.plane_users > 0) col.plane_users--;
 }
 
@@ -3497,6 +3503,7 @@ struct WorkerPool {
   std::atomic<int> next{0}, remaining{0}, inside{0};
   int count = 0, grain = 1, helpers = 0;
   unsigned long long generation = 0;
+  std::atomic<unsigned long long> generation_hint{0};      // == generation, readable without the mutex (the helpers' spin)
   bool stop = false;
 
   // Items are claimed `grain` at a time with ONE atomic add (a mutex hand-off per item cost more than lowering a query: 64 items of
@@ -3510,14 +3517,30 @@ struct WorkerPool {
       remaining.fetch_sub(last - first, std::memory_order_release);
     }
   }
+  // A helper that has just worked stays on its core for a moment: a batch is two runs ~0.5 ms apart (lowering, conversion) and a busy
+  // server's batches follow each other; being woken through the condition variable cost the first run of a call ~30 us of its ~40
+  // (64 items of 1.6 us each on eight threads).  kSpinNs without a new run and the helper parks.
+  static constexpr long long kSpinNs = 1'000'000;
   void worker(int index) {
     unsigned long long seen = 0;
+    bool worked = false;
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
+      if (worked && !stop && generation == seen) {
+        lk.unlock();
+        const auto until = std::chrono::steady_clock::now() + std::chrono::nanoseconds(kSpinNs);
+        for (int i = 0; generation_hint.load(std::memory_order_relaxed) == seen; ++i) {
+          __builtin_ia32_pause();
+          if ((i & 255) == 255 && std::chrono::steady_clock::now() >= until) break;
+        }
+        lk.lock();
+      }
+      worked = false;
       wake.wait(lk, [&] { return stop || generation != seen; });
       if (stop) return;
       seen = generation;
       if (index >= helpers) continue;
+      worked = true;
       inside.fetch_add(1, std::memory_order_acquire);
       lk.unlock();
       drain();
@@ -3540,6 +3563,7 @@ struct WorkerPool {
       next.store(0, std::memory_order_relaxed);
       remaining.store(n, std::memory_order_relaxed);
       ++generation;
+      generation_hint.store(generation, std::memory_order_relaxed);
       if (want > 0) wake.notify_all();
     }
     drain();
@@ -3564,7 +3588,11 @@ struct BatchCtx {
   int device = -1;
   hipStream_t stream = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
-  ScanParams* h_items = nullptr; ScanParams* d_items = nullptr;          // pinned staging / device copy of the items' kernel parameters
+  // pinned staging / device copy of what the launch reads: [first workgroup of every item | the items' kernel parameters], ONE
+  // allocation each so that ONE copy command precedes the launch
+  uint8_t* h_blob = nullptr; uint8_t* d_blob = nullptr;
+  size_t items_offset = 0;
+  ScanParams* h_items = nullptr; ScanParams* d_items = nullptr;
   uint32_t* h_first = nullptr; uint32_t* d_first = nullptr;
   HostRecord* h_records = nullptr; HostRecord* h_records_dev = nullptr;  // pinned, device-mapped: one folded record per item
   uint32_t* d_done = nullptr;                                            // kFoldShards + 1 arrival counters per item
@@ -3578,10 +3606,8 @@ std::vector<BatchCtx*> g_batch_free;
 
 void destroy_batch_ctx(BatchCtx* b) {
   if (!b) return;
-  if (b->h_items) (void)hipHostFree(b->h_items);
-  if (b->d_items) (void)hipFree(b->d_items);
-  if (b->h_first) (void)hipHostFree(b->h_first);
-  if (b->d_first) (void)hipFree(b->d_first);
+  if (b->h_blob) (void)hipHostFree(b->h_blob);
+  if (b->d_blob) (void)hipFree(b->d_blob);
   if (b->h_records) (void)hipHostFree(b->h_records);
   if (b->d_done) (void)hipFree(b->d_done);
   if (b->d_partials) (void)hipFree(b->d_partials);
@@ -3597,17 +3623,19 @@ pg_status ensure_batch_ctx(BatchCtx* b, int items, size_t partials) {
   }
   if (b->item_capacity < items) {
     const int cap = std::max(items, 64);
-    if (b->h_items) (void)hipHostFree(b->h_items);
-    if (b->d_items) (void)hipFree(b->d_items);
-    if (b->h_first) (void)hipHostFree(b->h_first);
-    if (b->d_first) (void)hipFree(b->d_first);
+    if (b->h_blob) (void)hipHostFree(b->h_blob);
+    if (b->d_blob) (void)hipFree(b->d_blob);
     if (b->h_records) (void)hipHostFree(b->h_records);
     if (b->d_done) (void)hipFree(b->d_done);
-    b->h_items = nullptr; b->d_items = nullptr; b->h_first = nullptr; b->d_first = nullptr; b->h_records = nullptr; b->d_done = nullptr; b->item_capacity = 0;
-    HIP_TRY(hipHostMalloc((void**)&b->h_items, sizeof(ScanParams) * (size_t)cap, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void**)&b->d_items, sizeof(ScanParams) * (size_t)cap));
-    HIP_TRY(hipHostMalloc((void**)&b->h_first, 4 * (size_t)(cap + 1), hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void**)&b->d_first, 4 * (size_t)(cap + 1)));
+    b->h_blob = nullptr; b->d_blob = nullptr; b->h_items = nullptr; b->d_items = nullptr; b->h_first = nullptr; b->d_first = nullptr; b->h_records = nullptr; b->d_done = nullptr;
+    b->item_capacity = 0;
+    b->items_offset = (4 * (size_t)(cap + 1) + 255) & ~(size_t)255;
+    const size_t blob_bytes = b->items_offset + sizeof(ScanParams) * (size_t)cap;
+    HIP_TRY(hipHostMalloc((void**)&b->h_blob, blob_bytes, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&b->d_blob, blob_bytes));
+    memset(b->h_blob, 0, blob_bytes);
+    b->h_first = reinterpret_cast<uint32_t*>(b->h_blob); b->d_first = reinterpret_cast<uint32_t*>(b->d_blob);
+    b->h_items = reinterpret_cast<ScanParams*>(b->h_blob + b->items_offset); b->d_items = reinterpret_cast<ScanParams*>(b->d_blob + b->items_offset);
     HIP_TRY(hipHostMalloc((void**)&b->h_records, sizeof(HostRecord) * (size_t)cap, hipHostMallocMapped));
     memset(b->h_records, 0, sizeof(HostRecord) * (size_t)cap);
     HIP_TRY(hipHostGetDevicePointer((void**)&b->h_records_dev, b->h_records, 0));
@@ -3673,8 +3701,7 @@ pg_status run_deferred(int device, const std::vector<int>& items, std::vector<De
   const bool timed = (g_engine.flags & PG_CFG_TIME_KERNELS) != 0;
   static const bool trace = getenv("PINOT_GPU_BATCH_TRACE") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, sizeof(ScanParams) * (size_t)n, hipMemcpyHostToDevice, b->stream));
-  HIP_TRY(hipMemcpyAsync(b->d_first, b->h_first, 4 * (size_t)(n + 1), hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(b->d_blob, b->h_blob, b->items_offset + sizeof(ScanParams) * (size_t)n, hipMemcpyHostToDevice, b->stream));
   if (timed) HIP_TRY(hipEventRecord(b->ev[0], b->stream));
   launch_scan_private_batch(one_slot, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
   HIP_TRY(hipGetLastError());

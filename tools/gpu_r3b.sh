@@ -1,0 +1,42 @@
+#!/bin/bash
+# Round-3 probes: tools/gpu_r3b.sh <step>...   (everything lands under gpurun_out/r3/)
+set -u
+cd $GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r3
+mkdir -p $OUT
+for step in "$@"; do
+case $step in
+leap)
+  echo "== A/B: two-leaf AND counted on the device vs not; sparse walk thresholds =="
+  timeout 600 python tools/ab_r3.py --match "AND2|C2b-1pct|C2b-0.1pct" --settings default,leap0,sparse0,sparse64 --check > $OUT/ab_leap_sparse.jsonl 2> $OUT/ab_leap_sparse.err
+  tail -3 $OUT/ab_leap_sparse.err
+  python - <<'PY'
+import json, os
+for l in open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out/r3/ab_leap_sparse.jsonl")):
+    if l.startswith("{"):
+        r = json.loads(l)
+        print("   %-10s %-12s %-24s kernel %.4f all %.4f wall %.4f entries %d exact=%s same=%s oracle=%s" % (r["setting"], r["query"], r["kernel"], r["kernel_ms"], r["all_kernels_ms"],
+              r["wall_ms_untimed"], r["entries_in_filter"], r["entries_exact"], r["same_as_first_setting"], r.get("bit_exact_vs_oracle")))
+PY
+  ;;
+batchtrace)
+  echo "== host phases of pg_execute_batch (C1x64) =="
+  PINOT_GPU_BATCH_TRACE=1 timeout 600 python bench.py --steps 2 --warmup 1 --segments 1 --rows 1000000 --no-cpu-baseline --no-clock-settle --variants "^C1x64" > $OUT/batch_trace.json 2> $OUT/batch_trace.err
+  grep -c "pg_execute_batch" $OUT/batch_trace.err
+  grep "pg_execute_batch\|run_deferred" $OUT/batch_trace.err | tail -12 ;;
+batchtest)
+  echo "== pytest: batch, planes, fold, concurrency =="; timeout 900 python -m pytest tests/test_gpu_batch.py tests/test_gpu_planes.py tests/test_gpu_fold.py tests/test_gpu_hist.py -m gpu -x -q 2>&1 | tail -4
+  timeout 300 python tools/stress_concurrency.py 2>&1 | tail -3 ;;
+batchbench)
+  echo "== C1x64 variants (driver-style bench line, only these variants) =="
+  timeout 600 python bench.py --steps 3 --warmup 1 --segments 1 --rows 1000000 --no-cpu-baseline --no-clock-settle --variants "^C1x64" > $OUT/bench_c1x64.json 2> $OUT/bench_c1x64.err
+  python - <<'PY'
+import json, os
+d = json.load(open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out/r3/bench_c1x64.json")))
+for v in d.get("variants", []):
+    print("   %-18s kernel %.4f  %s  exact=%s" % (v["id"], v["kernel_ms"], "  ".join("%s %.4f (min %.4f)" % (m, x["wall_ms"], x["wall_ms_min"]) for m, x in v["modes"].items()), v["bit_exact_vs_oracle"]))
+PY
+  ;;
+*) echo "unknown step $step" ;;
+esac
+done
