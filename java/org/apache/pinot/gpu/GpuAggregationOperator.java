@@ -81,25 +81,29 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
   private final AggregationFunction[] _functions;
   private final List<Lane> _lanes;
   private final PlanNode _cpuPlan;
+  private final GpuBatch _batch;                        // the native calls of the whole query made as one (GpuBatch), or null
+  private final int[] _batchSlots;                      // this operator's lanes in the batch, lane order
   private final long[] _statistics = new long[4];       // numDocsScanned, entriesInFilter, entriesPostFilter, totalDocs
   private Operator<?> _cpuOperator;                     // set when a native call failed and the segment ran on the CPU plan
 
   GpuAggregationOperator(GpuSegment segment, IndexSegment indexSegment, QueryContext queryContext, AggregationFunction[] functions,
-      List<Lane> lanes, PlanNode cpuPlan) {
+      List<Lane> lanes, PlanNode cpuPlan, GpuBatch batch, int[] batchSlots) {
     _segment = segment;
     _indexSegment = indexSegment;
     _queryContext = queryContext;
     _functions = functions;
     _lanes = lanes;
     _cpuPlan = cpuPlan;
+    _batch = batch;
+    _batchSlots = batchSlots;
   }
 
   @Override
   protected BaseResultsBlock getNextBlock() {
     List<LaneResult> results = new ArrayList<>(_lanes.size());
     try {
-      for (Lane lane : _lanes) {
-        results.add(execute(lane));
+      for (int i = 0; i < _lanes.size(); i++) {
+        results.add(execute(i));
       }
     } catch (RuntimeException e) {
       // UnsupportedOperationException (PG_ERR_UNSUPPORTED at run time) and RuntimeException (pg_last_error: device / out of memory) alike
@@ -118,10 +122,12 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
     return _queryContext.getGroupByExpressions() == null ? aggregationBlock(results) : groupByBlock(results);
   }
 
-  private LaneResult execute(Lane lane) {
-    GpuQueryLowering.Lowered q = lane._query;
-    Object[] raw = PinotGpuNative.execute(_segment.handle(), q._filterNodes, q._predInts, q._predLongs, q._setOffsets, q._setWords,
-        q._aggregations, q._groupBy, q._numGroupsLimit, q._flags);
+  private LaneResult execute(int laneIndex) {
+    GpuQueryLowering.Lowered q = _lanes.get(laneIndex)._query;
+    // in a batch: the first lane of the first segment a combine task reaches makes the native call for every lane of every segment
+    Object[] raw = _batch != null ? _batch.take(_batchSlots[laneIndex])
+        : PinotGpuNative.execute(_segment.handle(), q._filterNodes, q._predInts, q._predLongs, q._setOffsets, q._setWords,
+            q._aggregations, q._groupBy, q._numGroupsLimit, q._flags);
     if (raw == null || raw.length != PinotGpuNative.PGM_RESULT_ARRAYS) {
       throw new IllegalStateException("native result does not match jni/pg_marshal.h");
     }

@@ -2,7 +2,9 @@
  * The plan maker of the MI355X segment executor.  Named in the server configuration
  * ({@code pinot.server.query.executor.plan.maker.class=org.apache.pinot.gpu.GpuPlanMaker}; ServerQueryExecutorV1Impl instantiates it
  * reflectively, core/query/executor/ServerQueryExecutorV1Impl.java:116-123); everything except makeSegmentPlanNode is inherited, so
- * instance plans, combine operators, streaming, prefetch and query options stay the reference's.
+ * instance plans, combine operators, streaming, prefetch and query options stay the reference's -- makeInstancePlan is overridden only to
+ * open a GpuBatch around the reference's own planning loop, so that the query's segments share one native call ({@code gpu.batch=false}
+ * turns that off).
  *
  * <p>makeSegmentPlanNode (InstancePlanMakerImplV2.java:270-289) swaps the per-segment plan node of an aggregation / group-by query for
  * the device operator when, at PLAN time, all of this holds: the segment is resident (GpuSegmentCache), every swim lane of the query
@@ -31,9 +33,12 @@ import java.util.ArrayList;
 import java.util.LinkedHashMap;
 import java.util.List;
 import java.util.Map;
+import java.util.concurrent.ExecutorService;
 import org.apache.commons.lang3.tuple.Pair;
+import org.apache.pinot.common.metrics.ServerMetrics;
 import org.apache.pinot.common.request.context.FilterContext;
 import org.apache.pinot.common.utils.config.QueryOptionsUtils;
+import org.apache.pinot.core.plan.Plan;
 import org.apache.pinot.core.plan.PlanNode;
 import org.apache.pinot.core.plan.maker.InstancePlanMakerImplV2;
 import org.apache.pinot.core.query.aggregation.function.AggregationFunction;
@@ -52,8 +57,12 @@ public class GpuPlanMaker extends InstancePlanMakerImplV2 {
   public static final String ENABLED_KEY = "gpu.enabled";
   public static final String SKIP_STAR_TREE_SEGMENTS_KEY = "gpu.skip.startree";
 
+  public static final String BATCH_KEY = "gpu.batch";
+
   private volatile GpuSegmentCache _segments;
   private boolean _skipStarTreeSegments;
+  private boolean _batchEnabled = true;
+  private final ThreadLocal<GpuBatch> _planningBatch = new ThreadLocal<>();      // set while makeInstancePlan plans a query's segments
 
   @Override
   public void init(PinotConfiguration queryExecutorConfig) {
@@ -63,6 +72,7 @@ public class GpuPlanMaker extends InstancePlanMakerImplV2 {
     }
     int device = queryExecutorConfig.getProperty(DEVICE_KEY, 0);
     _skipStarTreeSegments = queryExecutorConfig.getProperty(SKIP_STAR_TREE_SEGMENTS_KEY, false);
+    _batchEnabled = queryExecutorConfig.getProperty(BATCH_KEY, true);
     try {
       PinotGpuNative.init(device, 0);
       _segments = new GpuSegmentCache(device);
@@ -102,7 +112,37 @@ public class GpuPlanMaker extends InstancePlanMakerImplV2 {
         return cpuPlan;
       }
     }
-    return () -> new GpuAggregationOperator(segment, indexSegment, queryContext, functions, lanes, cpuPlan);
+    // makeInstancePlan below is planning a whole query: its lanes join the query's batch, in plan order
+    GpuBatch batch = _planningBatch.get();
+    int[] batchSlots = null;
+    if (batch != null) {
+      batchSlots = new int[lanes.size()];
+      for (int i = 0; i < batchSlots.length; i++) {
+        batchSlots[i] = batch.add(segment.handle(), lanes.get(i)._query);
+      }
+    }
+    final int[] slots = batchSlots;
+    return () -> new GpuAggregationOperator(segment, indexSegment, queryContext, functions, lanes, cpuPlan, batch, slots);
+  }
+
+  /**
+   * InstancePlanMakerImplV2.makeInstancePlan (:166-193) plans every segment of the query on this thread -- through makeSegmentPlanNode above
+   * -- and hands the nodes to one CombinePlanNode.  While it does, the lanes of every offloaded segment register with one GpuBatch, so
+   * that the combine operator's tasks make ONE native call for the whole query (pg_execute_batch) instead of one per segment and lane.
+   * Everything else -- prefetch, the combine operator chosen, the instance response -- is the reference's.
+   */
+  @Override
+  public Plan makeInstancePlan(List<SegmentContext> segmentContexts, QueryContext queryContext, ExecutorService executorService,
+      ServerMetrics serverMetrics) {
+    if (_segments == null || !_batchEnabled || segmentContexts.size() < 2 || !QueryContextUtils.isAggregationQuery(queryContext)) {
+      return super.makeInstancePlan(segmentContexts, queryContext, executorService, serverMetrics);
+    }
+    _planningBatch.set(new GpuBatch());
+    try {
+      return super.makeInstancePlan(segmentContexts, queryContext, executorService, serverMetrics);
+    } finally {
+      _planningBatch.remove();
+    }
   }
 
   private static List<GpuAggregationOperator.Lane> unfilteredLane(GpuSegment segment, IndexSegment indexSegment, QueryContext queryContext,

@@ -82,6 +82,17 @@ public final class PinotGpuNative {
   public static final int PGM_COLUMN_INTS = 6;
   public static final int PGM_COLUMN_BUFFERS = 8;
   public static final int PGM_RESULT_ARRAYS = 9;
+  /** One query of executeBatch: Object[PGM_QUERY_ARRAYS], slots PGM_Q_*; the last slot is int[PGM_Q_LIMIT_FLAGS_LEN] {numGroupsLimit, flags}. */
+  public static final int PGM_Q_FILTER_NODES = 0;
+  public static final int PGM_Q_PRED_INTS = 1;
+  public static final int PGM_Q_PRED_LONGS = 2;
+  public static final int PGM_Q_SET_OFFSETS = 3;
+  public static final int PGM_Q_SET_WORDS = 4;
+  public static final int PGM_Q_AGGREGATIONS = 5;
+  public static final int PGM_Q_GROUP_BY = 6;
+  public static final int PGM_Q_LIMIT_FLAGS = 7;
+  public static final int PGM_QUERY_ARRAYS = 8;
+  public static final int PGM_Q_LIMIT_FLAGS_LEN = 2;
   public static final int PGM_R_HEADER = 0;
   public static final int PGM_R_GROUP_IDS = 1;
   public static final int PGM_R_COUNTS = 2;
@@ -154,4 +165,13 @@ public final class PinotGpuNative {
    */
   static native Object[] execute(long handle, int[] filterNodes, int[] predInts, long[] predLongs, int[] setOffsets, int[] setWords,
       int[] aggregations, int[] groupBy, int numGroupsLimit, int flags);
+
+  /**
+   * pg_execute_batch: {@code queries[i]} (Object[PGM_QUERY_ARRAYS], slots PGM_Q_*) over {@code handles[i]} -- the segments of ONE query, the
+   * way BaseCombineOperator hands them to its worker threads, in one native call (aggregations over scan / sorted leaves share one
+   * kernel launch over all the segments; everything else runs side by side on the library's own threads).  Returns Object[n]: element i
+   * is the Object[PGM_RESULT_ARRAYS] execute() would have returned for item i, or a String {@code "<pg_status>\n<message>"} when that
+   * item failed (the others do not stop for it).  Throws only when the call as a whole could not be made.
+   */
+  static native Object[] executeBatch(long[] handles, Object[][] queries);
 }

@@ -38,6 +38,12 @@ enum {
   PGM_FILTER_NODE_INTS = 3, PGM_PRED_INTS = 4, PGM_PRED_LONGS = 2, PGM_AGG_INTS = 2, PGM_COLUMN_INTS = 6, PGM_COLUMN_BUFFERS = 8,
   PGM_RESULT_ARRAYS = 9
 };
+/* One query of a batch call (PinotGpuNative.executeBatch): Object[PGM_QUERY_ARRAYS] = the seven flat arrays above in this order, then
+ * int[PGM_Q_LIMIT_FLAGS_LEN] {numGroupsLimit, flags}. */
+enum {
+  PGM_Q_FILTER_NODES = 0, PGM_Q_PRED_INTS = 1, PGM_Q_PRED_LONGS = 2, PGM_Q_SET_OFFSETS = 3, PGM_Q_SET_WORDS = 4, PGM_Q_AGGREGATIONS = 5,
+  PGM_Q_GROUP_BY = 6, PGM_Q_LIMIT_FLAGS = 7, PGM_QUERY_ARRAYS = 8, PGM_Q_LIMIT_FLAGS_LEN = 2
+};
 enum {
   PGM_R_HEADER = 0, PGM_R_GROUP_IDS = 1, PGM_R_COUNTS = 2, PGM_R_SUMS = 3, PGM_R_SUMS_I64 = 4, PGM_R_SUM_EXACT = 5, PGM_R_MINS = 6,
   PGM_R_MAXS = 7, PGM_R_GROUP_KEYS = 8

@@ -222,25 +222,15 @@ JNIEXPORT jstring JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_lastError(JNI
   return (*env)->NewStringUTF(env, pg_last_error());
 }
 
-/* pg_execute.  Returns Object[PGM_RESULT_ARRAYS] (slots PGM_R_*): {long[] header (PGM_H_* layout), int[] groupIds, long[] counts, double[] sums, long[] sumsI64,
- * int[] sumExact, double[] mins, double[] maxs, int[] groupKeys (dictId tuples)}, the value arrays row-major [row * numAggregations + a]. */
-JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(JNIEnv* env, jclass cls, jlong handle, jintArray filterNodes,
-    jintArray predInts, jlongArray predLongs, jintArray setOffsets, jintArray setWords, jintArray aggregations, jintArray groupBy,
-    jint numGroupsLimit, jint flags) {
-  (void)cls;
-  pinned_query p;
-  if (!pin_query(env, &p, filterNodes, predInts, predLongs, setOffsets, setWords, aggregations, groupBy, numGroupsLimit, flags)) return NULL;
-  const int32_t num_group_by = pgm_query_get(p.built)->num_group_by;
+/* A pg_result as Object[PGM_RESULT_ARRAYS] (slots PGM_R_*): {long[] header (PGM_H_* layout), int[] groupIds, long[] counts, double[] sums, long[] sumsI64,
+ * int[] sumExact, double[] mins, double[] maxs, int[] groupKeys (dictId tuples)}, the value arrays row-major [row * numAggregations + a].
+ * Frees the result.  NULL with a Java exception pending on failure. */
+static jobjectArray result_to_java(JNIEnv* env, pg_result* result, int32_t num_group_by) {
   const int32_t is_group_by = num_group_by > 0;
-  pg_result result;
-  const pg_status status = pg_execute((pg_segment*)(intptr_t)handle, pgm_query_get(p.built), &result);
-  release_query(env, &p, filterNodes, predInts, predLongs, setOffsets, setWords, aggregations, groupBy);
-  if (status != PG_OK) { throw_status(env, status); return NULL; }     /* pg_execute freed the result */
-
-  const int64_t rows64 = pgm_result_rows(&result, is_group_by);
-  const int64_t cells64 = rows64 * (int64_t)result.num_aggregations;
+  const int64_t rows64 = pgm_result_rows(result, is_group_by);
+  const int64_t cells64 = rows64 * (int64_t)result->num_aggregations;
   if (rows64 < 0 || cells64 < 0 || cells64 > (int64_t)INT32_MAX - 8 || rows64 * (int64_t)num_group_by > (int64_t)INT32_MAX - 8) {          /* a Java array holds fewer than 2^31 elements */
-    pg_result_free(&result);
+    pg_result_free(result);
     throw_new(env, "java/lang/IllegalStateException", "the result has more cells than a Java array holds");
     return NULL;
   }
@@ -259,7 +249,7 @@ JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(
   jdoubleArray maxs = (*env)->NewDoubleArray(env, cells);
   if (object_class && header && group_ids && group_keys && counts && sums && sums_i64 && sum_exact && mins && maxs) {
     int64_t h[PGM_HEADER_LEN];
-    pgm_result_header(&result, is_group_by, h);
+    pgm_result_header(result, is_group_by, h);
     h[PGM_H_NUM_GROUP_BY] = num_group_by;
     (*env)->SetLongArrayRegion(env, header, 0, PGM_HEADER_LEN, (const jlong*)h);
     /* the value arrays are filled in place: GetPrimitiveArrayCritical would forbid the JNI calls in between, plain element access does not */
@@ -272,8 +262,8 @@ JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(
     jdouble* mn = (*env)->GetDoubleArrayElements(env, mins, NULL);
     jdouble* mx = (*env)->GetDoubleArrayElements(env, maxs, NULL);
     if (g && gk && c && s && si && se && mn && mx) {
-      (void)pgm_result_fill(&result, is_group_by, (int32_t*)g, (int64_t*)c, (double*)s, (int64_t*)si, (int32_t*)se, (double*)mn, (double*)mx);
-      if (is_group_by) (void)pgm_result_fill_keys(&result, num_group_by, (int32_t*)gk);
+      (void)pgm_result_fill(result, is_group_by, (int32_t*)g, (int64_t*)c, (double*)s, (int64_t*)si, (int32_t*)se, (double*)mn, (double*)mx);
+      if (is_group_by) (void)pgm_result_fill_keys(result, num_group_by, (int32_t*)gk);
       out = (*env)->NewObjectArray(env, PGM_RESULT_ARRAYS, object_class, NULL);
     }
     if (mx) (*env)->ReleaseDoubleArrayElements(env, maxs, mx, 0);
@@ -296,7 +286,145 @@ JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(
       (*env)->SetObjectArrayElement(env, out, PGM_R_GROUP_KEYS, group_keys);
     }
   }
-  pg_result_free(&result);
+  /* (a batch call builds one of these per segment: the local references are given back here, not at the end of the native call) */
+  if (maxs) (*env)->DeleteLocalRef(env, maxs);
+  if (mins) (*env)->DeleteLocalRef(env, mins);
+  if (sum_exact) (*env)->DeleteLocalRef(env, sum_exact);
+  if (sums_i64) (*env)->DeleteLocalRef(env, sums_i64);
+  if (sums) (*env)->DeleteLocalRef(env, sums);
+  if (counts) (*env)->DeleteLocalRef(env, counts);
+  if (group_keys) (*env)->DeleteLocalRef(env, group_keys);
+  if (group_ids) (*env)->DeleteLocalRef(env, group_ids);
+  if (header) (*env)->DeleteLocalRef(env, header);
+  if (object_class) (*env)->DeleteLocalRef(env, object_class);
+  pg_result_free(result);
   if (out == NULL && !(*env)->ExceptionCheck(env)) throw_new(env, "java/lang/OutOfMemoryError", "allocating the result arrays failed");
   return out;
+}
+
+/* pg_execute.  Returns the Object[PGM_RESULT_ARRAYS] of result_to_java. */
+JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_execute(JNIEnv* env, jclass cls, jlong handle, jintArray filterNodes,
+    jintArray predInts, jlongArray predLongs, jintArray setOffsets, jintArray setWords, jintArray aggregations, jintArray groupBy,
+    jint numGroupsLimit, jint flags) {
+  (void)cls;
+  pinned_query p;
+  if (!pin_query(env, &p, filterNodes, predInts, predLongs, setOffsets, setWords, aggregations, groupBy, numGroupsLimit, flags)) return NULL;
+  const int32_t num_group_by = pgm_query_get(p.built)->num_group_by;
+  pg_result result;
+  const pg_status status = pg_execute((pg_segment*)(intptr_t)handle, pgm_query_get(p.built), &result);
+  release_query(env, &p, filterNodes, predInts, predLongs, setOffsets, setWords, aggregations, groupBy);
+  if (status != PG_OK) { throw_status(env, status); return NULL; }     /* pg_execute freed the result */
+  return result_to_java(env, &result, num_group_by);
+}
+
+/* pg_execute_batch: queries[i] (Object[PGM_QUERY_ARRAYS], slots PGM_Q_*) over handles[i] -- the segments of ONE query as the combine operator
+ * would hand them to its worker threads (BaseCombineOperator.java:85-142).  Returns Object[n]: element i is the Object[PGM_RESULT_ARRAYS]
+ * execute() would have returned for item i, or -- the item failed, the others did not stop for it -- a String "<pg_status>\n<message>".
+ * Throws only when the call as a whole could not be made (malformed arrays, library not initialised). */
+JNIEXPORT jobjectArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_executeBatch(JNIEnv* env, jclass cls, jlongArray handles, jobjectArray queries) {
+  (void)cls;
+  if (handles == NULL || queries == NULL) { throw_new(env, "java/lang/NullPointerException", "handles / queries must not be null"); return NULL; }
+  const jsize n = (*env)->GetArrayLength(env, handles);
+  if ((*env)->GetArrayLength(env, queries) != n) { throw_new(env, "java/lang/IllegalArgumentException", "one query per segment handle"); return NULL; }
+  jclass object_class = (*env)->FindClass(env, "java/lang/Object");
+  if (object_class == NULL) return NULL;
+  jobjectArray out = (*env)->NewObjectArray(env, n, object_class, NULL);
+  if (out == NULL || n == 0) return out;
+  const size_t count = (size_t)n;
+  pgm_query** built = (pgm_query**)calloc(count, sizeof(pgm_query*));
+  pg_segment** segments = (pg_segment**)calloc(count, sizeof(pg_segment*));
+  const pg_query** lowered = (const pg_query**)calloc(count, sizeof(pg_query*));
+  pg_result* results = (pg_result*)calloc(count, sizeof(pg_result));
+  pg_status* statuses = (pg_status*)calloc(count, sizeof(pg_status));
+  jlong* h = (*env)->GetLongArrayElements(env, handles, NULL);
+  int ok = built && segments && lowered && results && statuses && h;
+  if (!ok && !(*env)->ExceptionCheck(env)) throw_new(env, "java/lang/OutOfMemoryError", "allocating the batch failed");
+  for (jsize i = 0; ok && i < n; i++) {
+    jobjectArray q = (jobjectArray)(*env)->GetObjectArrayElement(env, queries, i);
+    if (q == NULL || (*env)->GetArrayLength(env, q) != PGM_QUERY_ARRAYS) {
+      throw_new(env, "java/lang/IllegalArgumentException", "a batch query is Object[PGM_QUERY_ARRAYS]");
+      ok = 0;
+      break;
+    }
+    jintArray nodes = (jintArray)(*env)->GetObjectArrayElement(env, q, PGM_Q_FILTER_NODES);
+    jintArray pred_ints = (jintArray)(*env)->GetObjectArrayElement(env, q, PGM_Q_PRED_INTS);
+    jlongArray pred_longs = (jlongArray)(*env)->GetObjectArrayElement(env, q, PGM_Q_PRED_LONGS);
+    jintArray set_offsets = (jintArray)(*env)->GetObjectArrayElement(env, q, PGM_Q_SET_OFFSETS);
+    jintArray set_words = (jintArray)(*env)->GetObjectArrayElement(env, q, PGM_Q_SET_WORDS);
+    jintArray aggregations = (jintArray)(*env)->GetObjectArrayElement(env, q, PGM_Q_AGGREGATIONS);
+    jintArray group_by = (jintArray)(*env)->GetObjectArrayElement(env, q, PGM_Q_GROUP_BY);
+    jintArray limit_flags = (jintArray)(*env)->GetObjectArrayElement(env, q, PGM_Q_LIMIT_FLAGS);
+    jint limit = 0, flags = 0;
+    jint* lf = (limit_flags != NULL && (*env)->GetArrayLength(env, limit_flags) == PGM_Q_LIMIT_FLAGS_LEN) ? (*env)->GetIntArrayElements(env, limit_flags, NULL) : NULL;
+    if (lf == NULL) {
+      if (!(*env)->ExceptionCheck(env)) throw_new(env, "java/lang/IllegalArgumentException", "a batch query ends with int[PGM_Q_LIMIT_FLAGS_LEN] {numGroupsLimit, flags}");
+      ok = 0;
+    } else {
+      limit = lf[0];
+      flags = lf[1];
+      (*env)->ReleaseIntArrayElements(env, limit_flags, lf, JNI_ABORT);
+      pinned_query p;
+      if (!pin_query(env, &p, nodes, pred_ints, pred_longs, set_offsets, set_words, aggregations, group_by, limit, flags)) {
+        ok = 0;
+      } else {
+        built[i] = p.built;              /* owns copies of everything (pg_marshal.c): the Java arrays are let go right away */
+        p.built = NULL;
+        release_query(env, &p, nodes, pred_ints, pred_longs, set_offsets, set_words, aggregations, group_by);
+        segments[i] = (pg_segment*)(intptr_t)h[i];
+        lowered[i] = pgm_query_get(built[i]);
+      }
+    }
+    if (limit_flags) (*env)->DeleteLocalRef(env, limit_flags);
+    if (group_by) (*env)->DeleteLocalRef(env, group_by);
+    if (aggregations) (*env)->DeleteLocalRef(env, aggregations);
+    if (set_words) (*env)->DeleteLocalRef(env, set_words);
+    if (set_offsets) (*env)->DeleteLocalRef(env, set_offsets);
+    if (pred_longs) (*env)->DeleteLocalRef(env, pred_longs);
+    if (pred_ints) (*env)->DeleteLocalRef(env, pred_ints);
+    if (nodes) (*env)->DeleteLocalRef(env, nodes);
+    (*env)->DeleteLocalRef(env, q);
+  }
+  if (ok) {
+    const pg_status status = pg_execute_batch(segments, lowered, (int32_t)n, results, statuses);
+    if (status != PG_OK) {
+      throw_status(env, status);           /* nothing ran: every result is still empty */
+      ok = 0;
+    }
+  }
+  if (ok) {
+    int first_failure = 1;
+    for (jsize i = 0; i < n; i++) {
+      jobject element = NULL;
+      if (statuses[i] == PG_OK) {
+        if (ok) element = result_to_java(env, &results[i], lowered[i]->num_group_by);      /* frees results[i] */
+        else pg_result_free(&results[i]);                                                  /* an exception is pending: only release */
+        if (element == NULL) { ok = 0; continue; }
+      } else if (ok) {
+        /* pg_last_error() of this thread names the first failed item (pg_execute_batch); later failures carry their status only */
+        char message[512];
+        const char* text = first_failure ? pg_last_error() : "see the first failed item of the batch";
+        first_failure = 0;
+        size_t at = 0;
+        int32_t st = (int32_t)statuses[i];
+        char digits[12];
+        int nd = 0;
+        do { digits[nd++] = (char)('0' + st % 10); st /= 10; } while (st > 0 && nd < 11);
+        while (nd > 0) message[at++] = digits[--nd];
+        message[at++] = '\n';
+        for (size_t k = 0; text && text[k] && at + 1 < sizeof(message); k++) message[at++] = text[k];
+        message[at] = 0;
+        element = (*env)->NewStringUTF(env, message);
+        if (element == NULL) { ok = 0; continue; }
+      }
+      if (element != NULL) {
+        (*env)->SetObjectArrayElement(env, out, i, element);
+        (*env)->DeleteLocalRef(env, element);
+      }
+    }
+  }
+  if (h) (*env)->ReleaseLongArrayElements(env, handles, h, JNI_ABORT);
+  if (built) for (size_t i = 0; i < count; i++) pgm_query_free(built[i]);
+  free(built); free(segments); free((void*)lowered); free(results); free(statuses);
+  (*env)->DeleteLocalRef(env, object_class);
+  return ok ? out : NULL;
 }

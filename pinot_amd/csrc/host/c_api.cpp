@@ -351,6 +351,8 @@ int32_t ph_plan_maker_init(int32_t device, int32_t time_kernels) {
     std::map<std::string, std::string> cfg;
     cfg[GpuPlanMaker::kConfigDevice] = std::to_string(device);
     cfg[GpuPlanMaker::kConfigTimeKernels] = time_kernels ? "true" : "false";
+    const char* batch = getenv("PINOT_GPU_HOST_BATCH");          // tests: "0" = every segment operator runs its own pg_execute
+    cfg[GpuPlanMaker::kConfigBatch] = (batch && batch[0] == '0') ? "false" : "true";
     g_planMaker.init(cfg);
   });
 }

@@ -352,10 +352,13 @@ class GpuPlanMaker : public PlanMaker {
   // makeInstancePlan + CombinePlanNode: one worker per segment, results merged like
   // AggregationResultsBlockMerger.java:34-44 / GroupByCombineOperator.java:132-147 (keys are VALUES, not dictIds).
   ResultsBlock executeCombined(const std::vector<SegmentContext>& segments, const QueryContext& queryContext, int maxExecutionThreads);
+  // pinot.server.query.executor.gpu.batch (default true): the segment operators of one executeCombined share ONE pg_execute_batch
+  static constexpr const char* kConfigBatch = "pinot.server.query.executor.gpu.batch";
   static constexpr const char* kConfigDevice = "pinot.server.query.executor.gpu.device";
   static constexpr const char* kConfigTimeKernels = "pinot.server.query.executor.gpu.time.kernels";
  private:
   int _device = 0;
+  bool _batch = true;
 };
 
 // DataTable V4 bytes of a results block (host/datatable_v4.cpp): what InstanceResponseBlock.toDataTable().toBytes() hands the broker.
@@ -451,6 +454,7 @@ struct GpuAbi {
   decltype(&pg_segment_close) segment_close;
   decltype(&pg_query_check) query_check;
   decltype(&pg_execute) execute;
+  decltype(&pg_execute_batch) execute_batch;
   decltype(&pg_result_free) result_free;
   decltype(&pg_filter_bitmap) filter_bitmap;
   decltype(&pg_group_key_info) group_key_info;

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <limits>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 
@@ -44,6 +45,7 @@ const GpuAbi& gpuAbi() {
     abi.segment_close = (decltype(abi.segment_close))sym("pg_segment_close");
     abi.query_check = (decltype(abi.query_check))sym("pg_query_check");
     abi.execute = (decltype(abi.execute))sym("pg_execute");
+    abi.execute_batch = (decltype(abi.execute_batch))sym("pg_execute_batch");
     abi.result_free = (decltype(abi.result_free))sym("pg_result_free");
     abi.filter_bitmap = (decltype(abi.filter_bitmap))sym("pg_filter_bitmap");
     abi.group_key_info = (decltype(abi.group_key_info))sym("pg_group_key_info");
@@ -457,16 +459,94 @@ std::unique_ptr<LoweredQuery> lowerQuery(const ImmutableSegment& seg, const Quer
   return lq;
 }
 
+// The segment operators of ONE query share one pg_execute_batch.  CombinePlanNode plans every segment of a query before anything runs
+// (core/plan/CombinePlanNode.java:92-110) and BaseCombineOperator's tasks then call the operators from a thread pool
+// (core/operator/combine/BaseCombineOperator.java:85-142): the operators register here at plan time; whichever task asks for its block
+// first runs the whole batch -- one launch over all the query's resident segments where the library can share it (include/pinot_gpu.h,
+// pg_execute_batch) -- and the others take their results as they come to ask.  A batch of one is a plain pg_execute.
+class GpuBatch {
+ public:
+  ~GpuBatch() {
+    for (size_t i = 0; i < _results.size(); ++i) if (_ran && !_taken[i] && _statuses[i] == PG_OK) gpuAbi().result_free(&_results[i]);
+  }
+  int add(pg_segment* handle, const pg_query* query) {
+    _handles.push_back(handle);
+    _queries.push_back(query);
+    return (int)_handles.size() - 1;
+  }
+  // The result of item `index` (the caller owns it: pg_result_free); throws what a pg_execute of the item would have thrown.
+  void take(int index, const std::string& what, pg_result* out) {
+    std::unique_lock<std::mutex> lk(_mu);
+    if (!_started) {
+      _started = true;
+      lk.unlock();
+      const size_t n = _handles.size();
+      std::vector<pg_result> results(n);
+      std::vector<pg_status> statuses(n, PG_ERR_INTERNAL);
+      pg_status st;
+      std::string error;
+      if (n == 1) {
+        memset(&results[0], 0, sizeof(pg_result));
+        st = statuses[0] = gpuAbi().execute(_handles[0], _queries[0], &results[0]);
+        if (st != PG_OK) error = gpuAbi().last_error();
+        st = PG_OK;
+      } else {
+        st = gpuAbi().execute_batch(_handles.data(), _queries.data(), (int32_t)n, results.data(), statuses.data());
+        bool anyFailed = st != PG_OK;
+        for (pg_status s : statuses) anyFailed = anyFailed || s != PG_OK;
+        if (anyFailed) error = gpuAbi().last_error();      // the call's, or the first failed item's (pg_execute_batch)
+      }
+      lk.lock();
+      _results = std::move(results);
+      _statuses = std::move(statuses);
+      _taken.assign(n, false);
+      _callStatus = st;
+      _error = std::move(error);
+      _ran = true;
+      _cv.notify_all();
+    } else {
+      _cv.wait(lk, [&] { return _ran; });
+    }
+    const pg_status st = _callStatus != PG_OK ? _callStatus : _statuses[(size_t)index];
+    if (st != PG_OK) {
+      const std::string msg = what + ": " + _error;
+      if (st == PG_ERR_UNSUPPORTED) throw UnsupportedOperationException(msg);
+      if (st == PG_ERR_INVALID_ARGUMENT) throw QueryException(msg);
+      throw std::runtime_error(msg);
+    }
+    if (_taken[(size_t)index]) throw std::runtime_error(what + ": the block of this operator was already taken");
+    _taken[(size_t)index] = true;
+    *out = _results[(size_t)index];
+  }
+ private:
+  std::vector<pg_segment*> _handles;
+  std::vector<const pg_query*> _queries;
+  std::mutex _mu;
+  std::condition_variable _cv;
+  bool _started = false, _ran = false;
+  pg_status _callStatus = PG_OK;
+  std::string _error;
+  std::vector<pg_result> _results;
+  std::vector<pg_status> _statuses;
+  std::vector<bool> _taken;
+};
+// Set by executeCombined around the planning of a query's segments (one thread plans: InstancePlanMakerImplV2.makeInstancePlan :166-193).
+static thread_local std::shared_ptr<GpuBatch> t_planningBatch;
+
 // One operator class serves both AggregationOperator and GroupByOperator roles: the device does the whole
 // filter -> project -> aggregate pull loop in one fused launch, nextBlock() is called exactly once (Operator.java:35-44).
 class GpuAggregationOperator : public Operator {
  public:
-  GpuAggregationOperator(const ImmutableSegment* seg, QueryContext qc, std::unique_ptr<LoweredQuery> lq)
-      : _segment(seg), _queryContext(std::move(qc)), _lowered(std::move(lq)) {}
+  GpuAggregationOperator(const ImmutableSegment* seg, QueryContext qc, std::unique_ptr<LoweredQuery> lq, std::shared_ptr<GpuBatch> batch)
+      : _segment(seg), _queryContext(std::move(qc)), _lowered(std::move(lq)), _batch(std::move(batch)) {
+    if (_batch) _batchIndex = _batch->add((pg_segment*)_segment->handle(), &_lowered->query);
+  }
 
   ResultsBlock nextBlock() override {
     pg_result res{};      // zero-initialised: pg_execute also clears it first thing, whatever path fails
-    checkStatus(gpuAbi().execute(_segment->handle(), &_lowered->query, &res), ("executing on segment " + _segment->getSegmentName()).c_str());
+    const std::string what = "executing on segment " + _segment->getSegmentName();
+    if (_batch) _batch->take(_batchIndex, what, &res);
+    else checkStatus(gpuAbi().execute(_segment->handle(), &_lowered->query, &res), what.c_str());
     ResultsBlock block;
     std::vector<AggregationFunction> functions;
     for (const auto& a : _queryContext.aggregations) functions.emplace_back(a.function, a.column, _queryContext.nullHandlingEnabled);
@@ -533,6 +613,8 @@ class GpuAggregationOperator : public Operator {
   const ImmutableSegment* _segment;
   QueryContext _queryContext;
   std::unique_ptr<LoweredQuery> _lowered;
+  std::shared_ptr<GpuBatch> _batch;       // null: the operator runs its own pg_execute
+  int _batchIndex = -1;
   ExecutionStatistics _stats;
 };
 
@@ -542,14 +624,15 @@ class GpuAggregationPlanNode : public PlanNode {
   // nullable group-by ...) without launching anything; PG_ERR_UNSUPPORTED becomes the UnsupportedOperationException on which the
   // caller keeps the CPU plan (InstancePlanMakerImplV2.makeSegmentPlanNode :270-289).  Nothing is rejected at run time.
   GpuAggregationPlanNode(const ImmutableSegment* seg, QueryContext qc, std::unique_ptr<LoweredQuery> lq)
-      : _segment(seg), _queryContext(std::move(qc)), _lowered(std::move(lq)) {
+      : _segment(seg), _queryContext(std::move(qc)), _lowered(std::move(lq)), _batch(t_planningBatch) {
     checkStatus(gpuAbi().query_check((const pg_segment*)seg->handle(), &_lowered->query), "planning the segment query");
   }
-  std::unique_ptr<Operator> run() override { return std::make_unique<GpuAggregationOperator>(_segment, _queryContext, std::move(_lowered)); }
+  std::unique_ptr<Operator> run() override { return std::make_unique<GpuAggregationOperator>(_segment, _queryContext, std::move(_lowered), _batch); }
  private:
   const ImmutableSegment* _segment;
   QueryContext _queryContext;
   std::unique_ptr<LoweredQuery> _lowered;
+  std::shared_ptr<GpuBatch> _batch;       // the batch of the query being planned (executeCombined), if any
 };
 
 }  // namespace
@@ -576,6 +659,8 @@ void GpuPlanMaker::init(const std::map<std::string, std::string>& cfg) {
   c.device_id = _device;
   it = cfg.find(kConfigTimeKernels);
   if (it != cfg.end() && it->second == "true") c.flags |= PG_CFG_TIME_KERNELS;
+  it = cfg.find(kConfigBatch);
+  _batch = it == cfg.end() || it->second != "false";
   checkStatus(gpuAbi().init(&c), "initialising the GPU plan maker");
 }
 
@@ -767,7 +852,11 @@ ResultsBlock GpuPlanMaker::executeCombined(const std::vector<SegmentContext>& se
   // CombinePlanNode: plan every segment first (plan-time rejection), then BaseCombineOperator: one task per segment,
   // numTasks = min(numSegments, maxExecutionThreads) (QueryMultiThreadingUtils.java:46-65).
   std::vector<std::unique_ptr<Operator>> operators;
-  for (const auto& sc : segments) operators.push_back(makeSegmentPlanNode(sc, qc)->run());
+  {
+    // every device operator planned below (FILTER (WHERE) lanes included) joins ONE pg_execute_batch (GpuBatch)
+    struct Planning { Planning(bool on) { if (on) t_planningBatch = std::make_shared<GpuBatch>(); } ~Planning() { t_planningBatch.reset(); } } planning(_batch && segments.size() > 1);
+    for (const auto& sc : segments) operators.push_back(makeSegmentPlanNode(sc, qc)->run());
+  }
   std::vector<ResultsBlock> blocks(operators.size());
   std::vector<std::string> errors(operators.size());
   std::vector<int> errorKinds(operators.size(), 0);       // 1 UnsupportedOperationException, 2 QueryException, 3 anything else

@@ -472,3 +472,42 @@ def test_group_by_raw_key_columns_through_sql():
     finally:
         for seg in segs:
             seg.destroy()
+
+
+def test_combine_through_one_batch_equals_one_execute_per_segment(golden_segments, monkeypatch):
+    """executeCombined registers the segment operators of a query with ONE pg_execute_batch (GpuBatch in host/plan_maker.cpp: the first
+    BaseCombineOperator task to ask for its block runs the batch, BaseCombineOperator.java:85-142); with
+    pinot.server.query.executor.gpu.batch = false every operator runs its own pg_execute.  Same blocks either way -- aggregations,
+    filters, group-by (int and string keys), FILTER (WHERE) swim lanes, fewer tasks than segments."""
+    _, segs = golden_segments
+    f1 = "column1 > 100000000 AND column11 NOT IN ('t', 'P')"
+    sqls = ["SELECT COUNT(*), SUM(column1), MAX(column3), MIN(column6), AVG(column7) FROM testTable",
+            "SELECT COUNT(*), SUM(column1), SUM(column3) FROM testTable" + FILTER,
+            "SELECT COUNT(*), SUM(column1) FROM testTable WHERE column1 > 100000000 AND column3 < 1000000000",
+            "SELECT SUM(column1), MAX(column3) FROM testTable GROUP BY column9 LIMIT 100000",
+            "SELECT COUNT(*), MAX(column1) FROM testTable" + FILTER + " GROUP BY column11, column12 LIMIT 100000",
+            f"SELECT SUM(column1) FILTER (WHERE {f1}), COUNT(*), AVG(column7) FILTER (WHERE {f1}) FROM testTable WHERE column3 BETWEEN 20000000 AND 1000000000"]
+
+    def strip(block):
+        return {k: v for k, v in block.items() if k not in ("deviceMs", "kernelMs")}
+
+    def run_all():
+        return [[strip(host.execute_sql(segs, sql, max_execution_threads=t)["combined"]) for t in (4, 2, 1)] for sql in sqls]
+
+    try:
+        monkeypatch.setenv("PINOT_GPU_HOST_BATCH", "0")
+        host.init_plan_maker(device=0, time_kernels=True)
+        one_by_one = run_all()
+        monkeypatch.delenv("PINOT_GPU_HOST_BATCH")
+        host.init_plan_maker(device=0, time_kernels=True)
+        batched = run_all()
+    finally:
+        monkeypatch.delenv("PINOT_GPU_HOST_BATCH", raising=False)
+        host.init_plan_maker(device=0, time_kernels=True)
+    assert batched == one_by_one
+    for per_threads in batched:
+        assert per_threads[0] == per_threads[1] == per_threads[2]
+    assert batched[0][0]["stats"]["numTotalDocs"] == 120000
+    # a query the device declines at plan time is still declined for every segment before anything runs
+    with pytest.raises(host.HostError):
+        host.execute_sql(segs, "SELECT column1 FROM testTable LIMIT 5")

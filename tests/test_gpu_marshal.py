@@ -67,3 +67,42 @@ def test_query_check_declines_what_execute_declines(engine):
             assert gseg.lib.pg_execute(gseg.handle, C.byref(mq.c), C.byref(res)) == _abi.PG_ERR_UNSUPPORTED
         eight = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(*nine.children[:8]))
         assert gseg.check(eight) == _abi.PG_OK and gseg.execute(eight).stats[0] == oracle.execute(seg, eight).stats[0]
+
+
+def test_a_batch_through_the_marshalling_layer(engine):
+    """The native steps of PinotGpuNative.executeBatch (jni/pinot_gpu_jni.c) except the JNI array handling: one pgm_query_build per item,
+    ONE pg_execute_batch over the built queries, pgm_result_* per item -- equal to one pg_execute per item, statistics included; an item
+    the device declines fails alone."""
+    seg = H.golden_segment()
+    aggs = H.golden_aggregations(seg)
+    c1, c9 = seg.column_index("column1"), seg.column_index("column9")
+    nine = Q.and_(*[Q.leaf(Q.Pred.dict_range(c1, i, i + 100)) for i in range(9)])            # over the leaf table: PG_ERR_UNSUPPORTED
+    specs = [Q.QuerySpec(aggs), Q.QuerySpec(aggs, filter=H.golden_filter_physical(seg)), Q.QuerySpec([(Q.COUNT, -1)], filter=nine),
+             Q.QuerySpec([(Q.SUM, c1), (Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(c1, 10, 4000))),
+             Q.QuerySpec(aggs, group_by=[c9])]
+    with engine.open(seg) as gseg:
+        built = [M.MarshalledQuery(s) for s in specs]
+        try:
+            n = len(specs)
+            handles = (C.c_void_p * n)(*[gseg.handle] * n)
+            queries = (C.POINTER(_abi.pg_query) * n)(*[C.pointer(b.c) for b in built])
+            results = (_abi.pg_result * n)()
+            statuses = (C.c_int * n)()
+            assert gseg.lib.pg_execute_batch(handles, queries, n, results, statuses) == _abi.PG_OK
+            assert list(statuses) == [_abi.PG_OK, _abi.PG_OK, _abi.PG_ERR_UNSUPPORTED, _abi.PG_OK, _abi.PG_OK]
+            assert b"batch item 2" in gseg.lib.pg_last_error()
+            for i, spec in enumerate(specs):
+                if statuses[i] != _abi.PG_OK:
+                    continue
+                got = M.unpack_result(results[i], bool(spec.group_by))
+                keys = M.unpack_keys(results[i], len(spec.group_by)) if spec.group_by else None
+                gseg.lib.pg_result_free(C.byref(results[i]))
+                want = run(gseg, spec)
+                got[0][M.H_DOMINANT_KERNEL] = want[0][M.H_DOMINANT_KERNEL] = 0      # (a diagnostic: the shared launch is a kernel of its own)
+                for a, b in zip(got, want):
+                    assert np.array_equal(a, b), i
+                if keys is not None:
+                    assert keys.shape == (len(got[1]), 1) and np.array_equal(keys[:, 0], got[1])      # one int key column: the raw key is the dictId
+        finally:
+            for b in built:
+                b.close()

@@ -141,7 +141,7 @@ def test_flat_array_records_are_never_bare_numbers():
 
 
 JNI_TYPES = {"void": "void", "int": "jint", "long": "jlong", "String": "jstring", "ByteBuffer": "jobject", "int[]": "jintArray",
-             "long[]": "jlongArray", "String[]": "jobjectArray", "Object[]": "jobjectArray"}
+             "long[]": "jlongArray", "String[]": "jobjectArray", "Object[]": "jobjectArray", "Object[][]": "jobjectArray"}
 
 
 def test_jni_functions_match_the_native_declarations():
