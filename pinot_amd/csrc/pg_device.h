@@ -78,6 +78,7 @@ struct DevLeaf {
 
 constexpr int32_t kNodeCountEntries = 2; // scan leaf on the root AND chain behind an index-based child: ScanBasedDocIdIterator.applyAnd looks at every doc still standing
 constexpr int kNarrowTiles = 4, kNarrowMaxBits = 8, kNarrowStack = 4, kNarrowSingleTiles = 8;      // scan_narrow_kernel / scan_narrow_single_kernel (pg_scan_narrow.h)
+constexpr int kSimpleMaxBits = 20;       // scan_simple_kernel: widest column it is instantiated for (pg_scan_simple.h)
 constexpr int kSparseTiles = 8;          // scan_sparse_kernel: tiles per wave and iteration (pg_scan_sparse.h)
 constexpr int32_t kNodeLeapfrog2 = 4;    // the root AND of exactly two scan leaves: its two masks also drive the leap-frog entry count (leapfrog2_tile)
 constexpr int32_t kNodeExitIfZero = 1;   // root AND chain: the tile is finished (mask 0) if the running result is wave-zero
@@ -200,7 +201,9 @@ struct ScanParams {
   int32_t fold_slots;              // aggregation slots a fold has to reduce (BlockPartial.sum / kmin / kmax [0 .. fold_slots))
   int32_t fold_typed;              // 1: fsum / kmin64 / kmax64 are in use (typed kernels)
   int32_t sparse_lanes;            // lane-private aggregating kernels: a tile in which at most this many lanes hold a match is aggregated by walking
-  int32_t reserved1;               //   the matches (one 8-byte load per matching doc) instead of decoding every lane's 32 values; 0 = never
+                                   //   the matches (one 8-byte load per matching doc) instead of decoding every lane's 32 values; 0 = never
+  int32_t fold_one_counter;        // 1: grids of at most kFoldOneCounterMax workgroups arrive on ONE counter (no shard hand-off: publish_block_partial);
+                                   //    0: always eight shard counters + the top one
   uint8_t* leap_tables;            // [tiles] kNodeLeapfrog2: one byte per 2048-doc tile (leapfrog2_tile), chained by the leapfrog2_chain_*_kernels
 };
 

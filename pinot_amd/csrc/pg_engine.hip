@@ -69,9 +69,11 @@ struct Engine {
   bool direct_result = true; // PINOT_GPU_DIRECT_RESULT=0: the folded partial is copied device -> host with a copy command
   int fold_finalize = -1;    // PINOT_GPU_FOLD_FINALIZE: 1 the scan kernel's last workgroup folds the workgroups' records itself, 0 finalize_partials_kernel
                              // does in a launch of its own, -1 (default) fold on segments of at most kFoldMaxTiles tiles
+  int fold_one_counter = 1;  // PINOT_GPU_FOLD_ONE_COUNTER=0: grids of at most 64 workgroups also arrive on eight shard counters + the top one
   bool poll_result = true;   // PINOT_GPU_POLL_RESULT=0: pg_execute always waits with hipStreamSynchronize instead of spinning on the pinned record's sequence number
   bool lane_skip = true;     // PINOT_GPU_LANE_SKIP=0: the aggregating kernels load a tile's value bytes for every lane, matches or not
   int batch_blocks_per_cu = 4;    // PINOT_GPU_BATCH_BLOCKS_PER_CU: workgroups per CU a batch launch is cut into (all items together)
+  bool scan_simple = true;   // PINOT_GPU_SCAN_SIMPLE=0: one-leaf / one-column queries stay in scan_private_kernel (half the waves per SIMD)
   bool scan_sparse = true;   // PINOT_GPU_SCAN_SPARSE=0: index-led aggregations scan their listed tiles in scan_private_kernel (one tile per wave and iteration)
   bool batch_launch = true;  // PINOT_GPU_BATCH_LAUNCH=0: pg_execute_batch runs every item as a pg_execute of its own on the worker threads (no shared launch)
   bool leap2 = true;         // PINOT_GPU_LEAP2=0: a leap-frogging `a AND b` is not counted on the device (host replay / upper bound instead)
@@ -1516,6 +1518,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.direct_result = !(drv && drv[0] == '0');
   const char* ffz = getenv("PINOT_GPU_FOLD_FINALIZE");
   g_engine.fold_finalize = ffz ? (ffz[0] == '0' ? 0 : 1) : -1;
+  const char* foc = getenv("PINOT_GPU_FOLD_ONE_COUNTER");
+  g_engine.fold_one_counter = foc ? (foc[0] == '0' ? 0 : 1) : 1;
   const char* prs = getenv("PINOT_GPU_POLL_RESULT");
   g_engine.poll_result = !(prs && prs[0] == '0');
   const char* lsk = getenv("PINOT_GPU_LANE_SKIP");
@@ -1524,6 +1528,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.batch_blocks_per_cu = (bbc && atoi(bbc) > 0) ? atoi(bbc) : 4;      // measured on 64 x 10 M rows: 2 / 4 / 8 / 16 / 32 / 64 -> 0.77 / 0.55 / 0.57 / 0.59 / 0.61 / 0.65 ms
   const char* ssp = getenv("PINOT_GPU_SCAN_SPARSE");
   g_engine.scan_sparse = !(ssp && ssp[0] == '0');
+  const char* ssm = getenv("PINOT_GPU_SCAN_SIMPLE");
+  g_engine.scan_simple = !(ssm && ssm[0] == '0');
   const char* bla = getenv("PINOT_GPU_BATCH_LAUNCH");
   g_engine.batch_launch = !(bla && bla[0] == '0');
   const char* lp2 = getenv("PINOT_GPU_LEAP2");
@@ -2445,6 +2451,26 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
       blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + 4 * kSparseTiles - 1) / (4 * kSparseTiles), (long long)seg->num_cus * bpc));
     }
+    // One dictionary-range leaf (or no filter) in front of at most one aggregated packed column, both of at most kSimpleMaxBits bits:
+    // scan_simple_kernel -- the same per-tile code with none of the general machinery, at twice the waves per SIMD (pg_scan_simple.h).
+    // (the one-stream shape `SUM(v) WHERE v in range` keeps scan_private_kernel's fused decode)
+    bool use_simple = g_engine.scan_simple && use_private && !use_hist && !use_narrow && !use_sparse && !want_bitmap && lw.tile_list == nullptr && sp.num_nodes <= 1 &&
+                      pl.num_agg_cols <= 1 && !(g_engine.flags & PG_CFG_PROFILE_WAVES) && !(out && (lw.stats_leap2_flagged || lw.stats_chain_flagged));
+    if (use_simple && sp.num_nodes == 1) {
+      const DevNode& dn = sp.nodes[0];
+      use_simple = dn.op == PG_FILTER_LEAF && dn.kind == kLeafDictRange && dn.bits >= 1 && dn.bits <= kSimpleMaxBits && (dn.flags & (kNodeCountEntries | kNodeLeapfrog2)) == 0;
+    }
+    if (use_simple && pl.num_agg_cols == 1) {
+      const DevAggCol& ac = sp.agg_cols[0];
+      use_simple = ac.bits >= 1 && ac.bits <= kSimpleMaxBits && !ac.is_raw;
+      if (use_simple && sp.num_nodes == 1 && sp.nodes[0].fwd == ac.fwd && sp.nodes[0].bits == ac.bits && ac.need_sum != 0 && ac.need_minmax == 0 && sp.nodes[0].exclusive == 0) use_simple = false;
+    }
+    if (use_simple) {
+      const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
+      int bpc = std::max(1, waves_scan_simple() / (kBlockThreads / 64));
+      if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
+      blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + 3) / 4, (long long)seg->num_cus * bpc));
+    }
     if (use_narrow) {
       const int per_wave = narrow_single ? kNarrowSingleTiles : kNarrowTiles;
       const long long quads = (((long long)seg->num_docs + 2047) / 2048 + per_wave - 1) / per_wave;
@@ -2475,7 +2501,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // (the entries counted by the kernel travel in its record: BlockPartial.entries -- no counter to zero, no copy command)
     // The folded record -> the reference's holder types.  Everything is captured by value: pg_execute_batch calls it after this function
     // has returned (the query, the segment and the context's pinned counter outlive the batch).
-    const int kernel_id = use_hist ? PG_KERNEL_SCAN_HIST : use_narrow ? PG_KERNEL_SCAN_NARROW : use_sparse ? PG_KERNEL_SCAN_SPARSE : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
+    const int kernel_id = use_hist ? PG_KERNEL_SCAN_HIST : use_narrow ? PG_KERNEL_SCAN_NARROW : use_sparse ? PG_KERNEL_SCAN_SPARSE : use_simple ? PG_KERNEL_SCAN_SIMPLE : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
     const HostRecord* host_record = ctx->h_record;
     const int profile_waves = blocks * (geo.threads / 64);
     const size_t num_projected = projected.size();
@@ -2546,6 +2572,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     sp.fold_typed = (use_private_typed || (!use_hist && !use_narrow && !use_private && typed)) ? 1 : 0;
     sp.lane_skip = g_engine.lane_skip ? 1 : 0;
     sp.sparse_lanes = g_engine.sparse_lanes;
+    sp.fold_one_counter = g_engine.fold_one_counter;
     if (defer != nullptr) {
       if (use_private && !use_hist && !use_narrow && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
           (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf)) {
@@ -2566,6 +2593,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (use_hist) launch_scan_hist(hist_cw, hist_guarded, blocks, hist_lds, ctx->stream, sp);
     else if (use_narrow) launch_scan_narrow(narrow_single, blocks, ctx->stream, sp);
     else if (use_sparse) launch_scan_sparse(blocks, ctx->stream, sp);
+    else if (use_simple) launch_scan_simple(blocks, ctx->stream, sp);
     else if (use_private) launch_scan_private(one, blocks, ctx->stream, sp);
     else if (use_private_typed) launch_scan_private_typed(blocks, ctx->stream, sp);
     else launch_scan_agg(g_engine.use_dma, one, typed, blocks, geo.threads, lds, ctx->stream, sp);

@@ -835,6 +835,7 @@ static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel
 // arrives on the ninth.  `flag` is one dword of LDS the caller provides (scan_hist_kernel keeps its counters as the only static LDS object).
 constexpr int kFoldShards = 8, kFoldStride = 32;      // counters are kFoldStride dwords apart; kFoldShards * kFoldStride is the top counter
 constexpr int kFoldExtraRecords = 1 + kFoldShards;    // behind the workgroups' records: the query's record, then one record per shard
+constexpr int kFoldOneCounterMax = 64;               // grids up to this many workgroups arrive on one counter (no shard hand-off)
 constexpr int kFoldOneLevel = 1536;                   // grids up to this many workgroups are folded by one workgroup in one level (publish_block_partial)
 // `block_index` of `num_blocks`: the workgroup's place among those that work on this ScanParams (the whole grid, or one query's share of
 // a batch launch -- scan_private_batch_kernel).
@@ -842,8 +843,13 @@ template <typename P>
 __device__ __forceinline__ void publish_block_partial(const P& p, BlockPartial* red, int waves_per_block, uint32_t* flag, uint32_t block_index,
                                                       uint32_t num_blocks) {
   const bool arrive = p.done_counter != nullptr && num_blocks > 1u;
-  const uint32_t shard = block_index & (kFoldShards - 1);
-  const uint32_t in_shard = (num_blocks + (kFoldShards - 1) - shard) / kFoldShards;          // workgroups b with (b & 7) == shard
+  // Small grids arrive on ONE counter: with shards the last arriver of a shard arrives a second time on the top counter -- a second
+  // dependent device-scope atomic at the very end of the query.  Measured (profiles/r3/c1_probe_one_arrival_counter.jsonl): 25 workgroups
+  // 14.2 -> 13.5 us, 122 equal, 489 +2 us, 1024 +5 us -- same-address device-scope atomics retire at ~5 ns apiece when a grid finishes at
+  // once, which is what the shards are for.
+  const bool one_counter = p.fold_one_counter != 0 && num_blocks <= (uint32_t)kFoldOneCounterMax;
+  const uint32_t shard = one_counter ? 0u : block_index & (kFoldShards - 1);
+  const uint32_t in_shard = one_counter ? num_blocks : (num_blocks + (kFoldShards - 1) - shard) / kFoldShards;          // workgroups b with (b & 7) == shard
   const uint32_t shards = num_blocks < (uint32_t)kFoldShards ? num_blocks : (uint32_t)kFoldShards;
   if (threadIdx.x < 64) {                                  // wave 0
     if (threadIdx.x == 0) {
@@ -863,7 +869,7 @@ __device__ __forceinline__ void publish_block_partial(const P& p, BlockPartial* 
       // a workgroup whose arrival completes its shard goes on; on a small grid it arrives on the top counter right away and only the
       // workgroup completing THAT goes on (one flag write per phase: the other waves read it behind the barrier below)
       uint32_t go = (arrive && __hip_atomic_fetch_add(p.done_counter + shard * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_shard) ? 1u : 0u;
-      if (go != 0u && num_blocks <= (uint32_t)kFoldOneLevel)
+      if (go != 0u && !one_counter && num_blocks <= (uint32_t)kFoldOneLevel)
         go = __hip_atomic_fetch_add(p.done_counter + kFoldShards * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == shards ? 1u : 0u;
       *flag = go;
     }

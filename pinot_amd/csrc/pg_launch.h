@@ -19,6 +19,14 @@ int max_waves_per_cu(K kernel) {
   const int alloc = ((attr.numRegs + 7) / 8) * 8;
   return std::max(1, std::min(6, 512 / alloc)) * 4;
 }
+// (kernels with few SGPRs: up to eight waves per SIMD)
+template <typename K>
+int max_waves_per_cu_lean(K kernel) {
+  hipFuncAttributes attr;
+  if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) != hipSuccess || attr.numRegs <= 0) return 16;
+  const int alloc = ((attr.numRegs + 7) / 8) * 8;
+  return std::max(1, std::min(8, 512 / alloc)) * 4;
+}
 template <typename K>
 void set_dynamic_lds(K kernel, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -35,6 +43,9 @@ void launch_scan_private_batch(bool one_slot, int total_blocks, hipStream_t stre
 // scan_sparse_kernel: aggregation of the docs one sparse bitmap names, eight tiles per wave and iteration (pg_scan_sparse.h)
 void launch_scan_sparse(int blocks, hipStream_t stream, const ScanParams& p);
 int waves_scan_sparse();
+// scan_simple_kernel: one dictionary-range leaf (or none) + at most one aggregated packed column of <= 20 bits (pg_scan_simple.h)
+void launch_scan_simple(int blocks, hipStream_t stream, const ScanParams& p);
+int waves_scan_simple();
 // scan_narrow_kernel: COUNT(*) / docId bitmap of a filter over columns of at most 8 bits (pg_scan_narrow.h)
 void launch_scan_narrow(bool single_leaf, int blocks, hipStream_t stream, const ScanParams& p);      // single_leaf: scan_narrow_single_kernel, eight tiles per iteration
 int waves_scan_narrow(bool single_leaf);

@@ -26,6 +26,7 @@ SETTINGS = {
     "fold0_poll1": {"PINOT_GPU_FOLD_FINALIZE": "0", "PINOT_GPU_POLL_RESULT": "1"},
     "laneskip0": {"PINOT_GPU_LANE_SKIP": "0", "PINOT_GPU_SPARSE_LANES": "0"},
     "leap0": {"PINOT_GPU_LEAP2": "0"},
+    "simple0": {"PINOT_GPU_SCAN_SIMPLE": "0"},
     "scansparse0": {"PINOT_GPU_SCAN_SPARSE": "0"},
     "sparse0": {"PINOT_GPU_SPARSE_LANES": "0"},
     "sparse12": {"PINOT_GPU_SPARSE_LANES": "12"},

@@ -24,6 +24,7 @@ SETTINGS = {
     "bpc4": {"PINOT_GPU_BLOCKS_PER_CU": "4"},
     "bpc8": {"PINOT_GPU_BLOCKS_PER_CU": "8"},
     "fold0": {"PINOT_GPU_FOLD_FINALIZE": "0"},
+    "onecounter": {"PINOT_GPU_FOLD_ONE_COUNTER": "1"},
 }
 KNOBS = sorted({k for s in SETTINGS.values() for k in s})
 

@@ -37,6 +37,47 @@ for v in d.get("variants", []):
     print("   %-18s kernel %.4f  %s  exact=%s" % (v["id"], v["kernel_ms"], "  ".join("%s %.4f (min %.4f)" % (m, x["wall_ms"], x["wall_ms_min"]) for m, x in v["modes"].items()), v["bit_exact_vs_oracle"]))
 PY
   ;;
+kernarg)
+  echo "== C1 probe with kernel arguments in device memory (HIP_FORCE_DEV_KERNARG) =="
+  for v in 0 1; do
+    HIP_FORCE_DEV_KERNARG=$v timeout 300 python tools/c1_probe.py --sizes 2048,1000000,10000000 > $OUT/c1_probe_kernarg$v.jsonl 2> $OUT/c1_probe_kernarg$v.err
+    echo "-- HIP_FORCE_DEV_KERNARG=$v"; python - $OUT/c1_probe_kernarg$v.jsonl <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith("{"):
+        r = json.loads(l)
+        print("   %9d %-12s kernel %6.2f us (min %6.2f)  wall %6.2f us (min %6.2f)" % (r["rows"], r["query"], r["kernel_us"], r["kernel_us_min"], r["wall_us"], r["wall_us_min"]))
+PY
+  done ;;
+onecounter)
+  echo "== fold with one arrival counter: tests, then C1 probe default / onecounter =="
+  PINOT_GPU_FOLD_ONE_COUNTER=1 timeout 600 python -m pytest tests/test_gpu_fold.py tests/test_gpu_batch.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
+  timeout 300 python tools/c1_probe.py --sizes 2048,200000,1000000,4000000,10000000,40000000 --settings default,onecounter > $OUT/c1_probe_onecounter.jsonl 2> $OUT/c1_probe_onecounter.err
+  tail -2 $OUT/c1_probe_onecounter.err
+  python - $OUT/c1_probe_onecounter.jsonl <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith("{"):
+        r = json.loads(l)
+        print("   %-10s %9d %-12s kernel %6.2f us (min %6.2f)  wall %6.2f us (min %6.2f) exact=%s" % (r["setting"], r["rows"], r["query"], r["kernel_us"], r["kernel_us_min"], r["wall_us"], r["wall_us_min"], r.get("bit_exact_vs_oracle")))
+PY
+  ;;
+simple)
+  echo "== scan_simple_kernel: parity tests, then A/B against scan_private_kernel (and the six-waves build) =="
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fold.py tests/test_gpu_fuzz.py tests/test_gpu_golden.py tests/test_gpu_nulls.py -m gpu -x -q 2>&1 | tail -4
+  show() { python - "$1" <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith("{"):
+        r = json.loads(l)
+        print("   %-10s %-14s %-22s kernel %.4f all %.4f wall %.4f same=%s oracle=%s" % (r["setting"], r["query"], r["kernel"], r["kernel_ms"], r["all_kernels_ms"], r["wall_ms_untimed"], r["same_as_first_setting"], r.get("bit_exact_vs_oracle")))
+PY
+  }
+  M="C2b-10pct|C2b-3pct|C2b-1pct|COUNT-filter|MINMAXAVG|C1-dict-sum"
+  timeout 600 python tools/ab_r3.py --match "$M" --settings default,simple0 --check > $OUT/ab_simple.jsonl 2> $OUT/ab_simple.err; tail -2 $OUT/ab_simple.err; show $OUT/ab_simple.jsonl
+  echo "-- six waves per SIMD (80 VGPRs, 26 spilled)"
+  PINOT_GPU_LIB=$GRAFT_REPO_ROOT/tools/libpinot_gpu_simple6.so timeout 600 python tools/ab_r3.py --match "$M" --settings default > $OUT/ab_simple6.jsonl 2> $OUT/ab_simple6.err; tail -2 $OUT/ab_simple6.err; show $OUT/ab_simple6.jsonl
+  ;;
 *) echo "unknown step $step" ;;
 esac
 done
