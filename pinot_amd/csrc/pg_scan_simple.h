@@ -65,6 +65,9 @@ __global__ __launch_bounds__(kBlockThreads, PG_SIMPLE_WAVES) void scan_simple_ke
 
   unsigned long long count = 0, sum = 0;
   uint32_t umin = 0xFFFFFFFFu, umax = 0u;
+  // (Two tiles per iteration -- both tiles' chunks of a column loaded before either is decoded -- was measured on this kernel and lost:
+  // C2b at 10 % 0.580 -> 0.601 ms, 3 % 0.543 -> 0.569, profiles/r3/ab_scan_simple_pair_*.jsonl.  A wave's own second request buys nothing
+  // the fifth wave has not already bought, and the longer decode blocks cost more than they hide.)
   for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
     uint32_t m = 0xFFFFFFFFu;
     if (has_filter) {

@@ -1,6 +1,8 @@
 """Randomised parity: random segments (every packed width 1..31, affine and irregular dictionaries, ragged sizes), random filter
 trees (range / set / docId-range / inverted leaves, AND / OR / NOT, exclusive predicates) and random aggregation lists and
 group-bys, HIP path vs. oracle, bit exact.  Seeds are fixed: a failure reproduces."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,6 +12,8 @@ from pinot_amd import _abi
 from pinot_amd import query as Q
 from pinot_amd import segment as S
 
+# tools/gpu_r3b.sh soak: the same tests over other seeds (PINOT_FUZZ_SEED_BASE=100, 200, ...)
+SEED_BASE = int(os.environ.get("PINOT_FUZZ_SEED_BASE", "0"))
 pytestmark = pytest.mark.gpu
 
 
@@ -66,7 +70,7 @@ def random_tree(rng, seg, n, depth):
 
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_random_segments_and_queries(engine, seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + SEED_BASE + seed)
     n = int(rng.choice([1, 31, 32, 33, 2047, 2048, 2049, 4097, 9001, 20_011]))
     cols = []
     for c in range(3):
@@ -121,7 +125,7 @@ def random_tree_with_nulls(rng, seg, n, depth):
 def test_random_null_vectors_null_handling_and_wide_group_bys(engine, seed):
     """Same idea with the later features switched on at random: null value vectors (sparse, dense, runs), IS NULL leaves, the
     enableNullHandling option, group-by key spaces above the array-based threshold and small numGroupsLimit values."""
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + SEED_BASE + seed)
     n = int(rng.choice([1, 33, 2049, 9001, 70_001, 140_000]))
     cols = []
     for c in range(3):

@@ -78,6 +78,27 @@ PY
   echo "-- six waves per SIMD (80 VGPRs, 26 spilled)"
   PINOT_GPU_LIB=$GRAFT_REPO_ROOT/tools/libpinot_gpu_simple6.so timeout 600 python tools/ab_r3.py --match "$M" --settings default > $OUT/ab_simple6.jsonl 2> $OUT/ab_simple6.err; tail -2 $OUT/ab_simple6.err; show $OUT/ab_simple6.jsonl
   ;;
+pair)
+  echo "== scan_simple_kernel: two tiles per iteration vs one (PINOT_GPU_LIB=tools/libpinot_gpu_nopair.so) =="
+  timeout 600 python -m pytest tests/test_gpu_scan_simple.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
+  show() { python - "$1" <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith("{"):
+        r = json.loads(l)
+        print("   %-10s %-14s %-22s kernel %.4f all %.4f wall %.4f (min %.4f) same=%s oracle=%s" % (r["setting"], r["query"], r["kernel"], r["kernel_ms"], r["all_kernels_ms"], r["wall_ms_untimed"], r["wall_ms_untimed_min"], r["same_as_first_setting"], r.get("bit_exact_vs_oracle")))
+PY
+  }
+  M="C2b-10pct|C2b-3pct|C2b-1pct|COUNT-filter|MINMAXAVG|C1-dict-sum"
+  for round in 1 2; do
+    echo "-- pair (round $round)"; timeout 600 python tools/ab_r3.py --match "$M" --settings default --check > $OUT/ab_pair_$round.jsonl 2> $OUT/ab_pair.err; tail -2 $OUT/ab_pair.err; show $OUT/ab_pair_$round.jsonl
+    echo "-- no pair (round $round)"; PINOT_GPU_LIB=$GRAFT_REPO_ROOT/tools/libpinot_gpu_nopair.so timeout 600 python tools/ab_r3.py --match "$M" --settings default > $OUT/ab_nopair_$round.jsonl 2> $OUT/ab_nopair.err; tail -2 $OUT/ab_nopair.err; show $OUT/ab_nopair_$round.jsonl
+  done ;;
+soak)
+  echo "== fuzz soak over other seeds =="
+  for base in ${SOAK_BASES:-100 200 300 400 500 600}; do
+    echo "-- seed base $base"; PINOT_FUZZ_SEED_BASE=$base timeout 600 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -3
+  done ;;
 *) echo "unknown step $step" ;;
 esac
 done
