@@ -2418,7 +2418,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       sp.hist_slot = hist_slot;
       sp.hist_bins = seg->cols[(size_t)hist_col].cardinality;
     } else if (use_private || use_private_typed) {
-      const int cap = use_private_typed ? waves_scan_private_typed() : waves_scan_private(pl.num_agg_cols <= 1);
+      const int cap = use_private_typed ? waves_scan_private_typed(pl.num_agg_cols) : waves_scan_private(pl.num_agg_cols);
       int bpc = std::max(1, cap / (kBlockThreads / 64));
       if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
       const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
@@ -2447,7 +2447,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
                             sp.num_nodes == 1 && sp.nodes[0].kind == kLeafBitmap && sp.nodes[0].exclusive == 0 && !(g_engine.flags & PG_CFG_PROFILE_WAVES);
     if (use_sparse) {
       const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
-      int bpc = std::max(1, waves_scan_sparse() / (kBlockThreads / 64));
+      int bpc = std::max(1, waves_scan_sparse(pl.num_agg_cols <= 1) / (kBlockThreads / 64));
       if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
       blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + 4 * kSparseTiles - 1) / (4 * kSparseTiles), (long long)seg->num_cus * bpc));
     }
@@ -2592,10 +2592,10 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const bool one = pl.num_agg_cols <= 1;
     if (use_hist) launch_scan_hist(hist_cw, hist_guarded, blocks, hist_lds, ctx->stream, sp);
     else if (use_narrow) launch_scan_narrow(narrow_single, blocks, ctx->stream, sp);
-    else if (use_sparse) launch_scan_sparse(blocks, ctx->stream, sp);
+    else if (use_sparse) launch_scan_sparse(one, blocks, ctx->stream, sp);
     else if (use_simple) launch_scan_simple(blocks, ctx->stream, sp);
-    else if (use_private) launch_scan_private(one, blocks, ctx->stream, sp);
-    else if (use_private_typed) launch_scan_private_typed(blocks, ctx->stream, sp);
+    else if (use_private) launch_scan_private(pl.num_agg_cols, blocks, ctx->stream, sp);
+    else if (use_private_typed) launch_scan_private_typed(pl.num_agg_cols, blocks, ctx->stream, sp);
     else launch_scan_agg(g_engine.use_dma, one, typed, blocks, geo.threads, lds, ctx->stream, sp);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));

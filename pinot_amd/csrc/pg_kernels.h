@@ -1856,8 +1856,21 @@ __device__ __forceinline__ void agg_sparse_private(WP __restrict__ lane_words, W
 #endif
 // The kernel's body: workgroup `block_index` of the `num_blocks` that work on `p` (the whole grid in scan_private_kernel; one query's
 // share of the grid in scan_private_batch_kernel, where p is read from device memory).
+// Accumulators of the multi-column instantiations live in LDS, one entry per thread and slot: sixteen more registers per lane across
+// the tile loop (a 64-bit sum and two keys per slot, selected by a run-time column index) was what turned the four-slot kernel's
+// 127 registers into 43 spilled ones IN the loop -- two aggregated columns ran at half the rate of one (1.59 vs 0.80 ms per 1 B
+// rows, profiles/r3/ab_two_aggregated_columns.jsonl).  Three LDS operations per column and tile instead; a thread only ever touches its
+// own entries, so there is nothing to synchronise.
+template <int kAggSlots>
+struct PrivateAccLds {
+  unsigned long long sum[kAggSlots][kBlockThreads];
+  uint32_t umin[kAggSlots][kBlockThreads], umax[kAggSlots][kBlockThreads];
+};
+template <>
+struct PrivateAccLds<1> { uint32_t unused; };          // the one-slot form keeps its accumulators in registers
 template <int kAggSlots, typename P>
-__device__ __forceinline__ void scan_private_body(const P& p, const uint32_t block_index, const uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr) {
+__device__ __forceinline__ void scan_private_body(const P& p, const uint32_t block_index, const uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr,
+                                                  PrivateAccLds<kAggSlots>* acc_lds) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
@@ -1865,10 +1878,15 @@ __device__ __forceinline__ void scan_private_body(const P& p, const uint32_t blo
   const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
 
   unsigned long long count = 0;
-  unsigned long long sum[kAggSlots];
-  uint32_t umin[kAggSlots], umax[kAggSlots];
+  constexpr bool kAccInLds = kAggSlots > 1;
+  unsigned long long sum[kAccInLds ? 1 : kAggSlots];
+  uint32_t umin[kAccInLds ? 1 : kAggSlots], umax[kAccInLds ? 1 : kAggSlots];
 #pragma unroll
-  for (int a = 0; a < kAggSlots; ++a) { sum[a] = 0; umin[a] = 0xFFFFFFFFu; umax[a] = 0u; }
+  for (int a = 0; a < (kAccInLds ? 1 : kAggSlots); ++a) { sum[a] = 0; umin[a] = 0xFFFFFFFFu; umax[a] = 0u; }
+  if constexpr (kAccInLds) {
+#pragma unroll
+    for (int a = 0; a < kAggSlots; ++a) { acc_lds->sum[a][threadIdx.x] = 0ull; acc_lds->umin[a][threadIdx.x] = 0xFFFFFFFFu; acc_lds->umax[a][threadIdx.x] = 0u; }
+  }
 
   // (Early "touch" loads of the next column chunks were tried and lost 30 %: vmcnt retires in order, so a wave's own L2 hits
   // queue behind its prefetches that are still on their way from HBM.  Latency is hidden by the other resident waves instead.)
@@ -1925,13 +1943,17 @@ __device__ __forceinline__ void scan_private_body(const P& p, const uint32_t blo
       if (sparse_tile) agg_sparse_private(words, words - lane * ac.bits, ac.bits, m, ac.need_sum != 0, ac.need_minmax != 0, wsum, tmin, tmax);
       else if (lane_active) agg_private_dispatch(ac.bits, words, m, ac.need_sum != 0, ac.need_minmax != 0, psum, wsum, tmin, tmax);
       wsum += psum;
-#pragma unroll
-      for (int s = 0; s < kAggSlots; ++s) {
-        if (s == a) {
-          sum[s] += wsum;
-          umin[s] = tmin < umin[s] ? tmin : umin[s];
-          umax[s] = tmax > umax[s] ? tmax : umax[s];
+      if constexpr (kAccInLds) {
+        acc_lds->sum[a][threadIdx.x] += wsum;
+        if (ac.need_minmax != 0) {
+          const uint32_t lo_key = acc_lds->umin[a][threadIdx.x], hi_key = acc_lds->umax[a][threadIdx.x];
+          acc_lds->umin[a][threadIdx.x] = tmin < lo_key ? tmin : lo_key;
+          acc_lds->umax[a][threadIdx.x] = tmax > hi_key ? tmax : hi_key;
         }
+      } else {
+        sum[0] += wsum;
+        umin[0] = tmin < umin[0] ? tmin : umin[0];
+        umax[0] = tmax > umax[0] ? tmax : umax[0];
       }
     }
   }
@@ -1943,10 +1965,14 @@ __device__ __forceinline__ void scan_private_body(const P& p, const uint32_t blo
   mine.entries = (unsigned long long)wave_sum_i64((long long)entries);
 #pragma unroll
   for (int a = 0; a < kAggSlots; ++a) {
-    mine.sum[a] = wave_sum_i64((long long)sum[a]);
+    unsigned long long my_sum;
+    uint32_t my_min, my_max;
+    if constexpr (kAccInLds) { my_sum = acc_lds->sum[a][threadIdx.x]; my_min = acc_lds->umin[a][threadIdx.x]; my_max = acc_lds->umax[a][threadIdx.x]; }
+    else { my_sum = sum[a]; my_min = umin[a]; my_max = umax[a]; }
+    mine.sum[a] = wave_sum_i64((long long)my_sum);
     // unsigned keys below 2^31 -> the int32 keys of BlockPartial; lanes that matched nothing keep the identities
-    mine.kmin[a] = wave_min_i32(umin[a] == 0xFFFFFFFFu ? 0x7FFFFFFF : (int32_t)umin[a]);
-    mine.kmax[a] = wave_max_i32(count == 0ull ? (int32_t)0x80000000 : (int32_t)umax[a]);
+    mine.kmin[a] = wave_min_i32(my_min == 0xFFFFFFFFu ? 0x7FFFFFFF : (int32_t)my_min);
+    mine.kmax[a] = wave_max_i32(count == 0ull ? (int32_t)0x80000000 : (int32_t)my_max);
   }
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
@@ -1957,7 +1983,8 @@ template <int kAggSlots>
 __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_kernel(const ScanParams p) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
-  scan_private_body<kAggSlots>(p, blockIdx.x, gridDim.x, red, &fold_flag);
+  __shared__ PrivateAccLds<kAggSlots> acc;
+  scan_private_body<kAggSlots>(p, blockIdx.x, gridDim.x, red, &fold_flag, &acc);
 }
 
 // Many queries, one launch (pg_execute_batch): workgroups [block_first[i], block_first[i + 1]) work on items[i] -- its own columns,
@@ -1975,6 +2002,7 @@ template <int kAggSlots>
 __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_batch_kernel(const BatchParams bp) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
+  __shared__ PrivateAccLds<kAggSlots> acc;
   int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -1988,7 +2016,7 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
   // Measured on one 1 B-row item: 0.91 ms against the single launch's 0.69.
   typedef const __attribute__((address_space(4))) ScanParams ConstantScanParams;
   const ConstantScanParams& item = *(ConstantScanParams*)(bp.items + lo);
-  scan_private_body<kAggSlots>(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
+  scan_private_body<kAggSlots>(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag, &acc);
 }
 
 // The slot of `key` in an open-addressing table of (mask + 1) slots, claiming a free one if the key is new (kHashEmpty = free).  The

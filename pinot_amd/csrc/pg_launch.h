@@ -36,13 +36,13 @@ void set_dynamic_lds(K kernel, size_t bytes) {
 void launch_scan_agg(bool dma, bool one_slot, bool typed, int blocks, int threads, size_t lds, hipStream_t stream, const ScanParams& p);
 int waves_scan_agg(bool one_slot, bool typed);
 // scan_private_kernel<slots>: the lane-private scan -> filter -> aggregate kernel
-void launch_scan_private(bool one_slot, int blocks, hipStream_t stream, const ScanParams& p);
-int waves_scan_private(bool one_slot);
+void launch_scan_private(int agg_cols, int blocks, hipStream_t stream, const ScanParams& p);      // instantiated for 1 and kMaxAggCols slots
+int waves_scan_private(int agg_cols);
 // scan_private_batch_kernel<slots>: many queries in one launch (pg_execute_batch); items / block_first are device memory
 void launch_scan_private_batch(bool one_slot, int total_blocks, hipStream_t stream, const ScanParams* items, const uint32_t* block_first, int num_items);
 // scan_sparse_kernel: aggregation of the docs one sparse bitmap names, eight tiles per wave and iteration (pg_scan_sparse.h)
-void launch_scan_sparse(int blocks, hipStream_t stream, const ScanParams& p);
-int waves_scan_sparse();
+void launch_scan_sparse(bool one_slot, int blocks, hipStream_t stream, const ScanParams& p);      // one_slot: at most one aggregated column
+int waves_scan_sparse(bool one_slot);
 // scan_simple_kernel: one dictionary-range leaf (or none) + at most one aggregated packed column of <= 20 bits (pg_scan_simple.h)
 void launch_scan_simple(int blocks, hipStream_t stream, const ScanParams& p);
 int waves_scan_simple();
@@ -61,8 +61,8 @@ void launch_scan_hist(int counter_bits, bool guarded, int blocks, size_t lds, hi
 int waves_scan_hist(int counter_bits, bool guarded);
 
 // scan_private_typed_kernel: lane-private scan for raw / 8-byte aggregated columns (pg_scan_typed.h)
-void launch_scan_private_typed(int blocks, hipStream_t stream, const ScanParams& p);
-int waves_scan_private_typed();
+void launch_scan_private_typed(int agg_cols, int blocks, hipStream_t stream, const ScanParams& p);      // instantiated for 1, 2 and kMaxAggCols slots
+int waves_scan_private_typed(int agg_cols);
 // partitioned group-by for key spaces above the LDS table (pg_group_partition.h): histogram, scatter, aggregate
 void launch_group_partition_histogram(int blocks, hipStream_t stream, const PartitionParams& pp);
 void launch_group_partition_scatter(int blocks, hipStream_t stream, const PartitionParams& pp);

@@ -22,7 +22,12 @@
 
 namespace pg {
 
-static __global__ __launch_bounds__(kBlockThreads) void scan_sparse_kernel(const ScanParams p) {
+#ifndef PG_SPARSE_WAVES
+#define PG_SPARSE_WAVES 4      // five waves (96 VGPRs, three spilled) measured: C5-dense 0.269 -> 0.308 ms -- the eight tiles in flight need the registers
+#endif
+// kAggSlots: 1 for queries with at most one aggregated column (fewer accumulators live across the walk), else kMaxAggCols
+template <int kAggSlots>
+__global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_SPARSE_WAVES : 4)) void scan_sparse_kernel(const ScanParams p) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
   const int lane = threadIdx.x & 63;
@@ -35,13 +40,13 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_sparse_kernel(const
   const uint32_t* __restrict__ mask_words = p.nodes[0].set_words;      // the filter is ONE bitmap leaf: dword 64 * tile + lane = the lane's 32 docs
 
   unsigned long long count = 0;
-  unsigned long long sum[kMaxAggCols];
-  uint32_t umin[kMaxAggCols], umax[kMaxAggCols];
+  unsigned long long sum[kAggSlots];
+  uint32_t umin[kAggSlots], umax[kAggSlots];
 #pragma unroll
-  for (int a = 0; a < kMaxAggCols; ++a) { sum[a] = 0; umin[a] = 0xFFFFFFFFu; umax[a] = 0u; }
+  for (int a = 0; a < kAggSlots; ++a) { sum[a] = 0; umin[a] = 0xFFFFFFFFu; umax[a] = 0u; }
 
   for (long long base = ((long long)blockIdx.x * waves_per_block + wave_in_block) * kSparseTiles; base < tile_limit; base += total_waves * kSparseTiles) {
-    long long tile[kSparseTiles];
+    uint32_t tile[kSparseTiles];                              // (a segment has fewer than 2^20 tiles)
     uint32_t m[kSparseTiles];
     // Every load below is UNCONDITIONAL (a lane or a tile with nothing to read points at an address that is always there): a load inside
     // an exec-masked branch is waited for before the branch is left, which made the eight loads of a round eight round trips.
@@ -50,16 +55,16 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_sparse_kernel(const
 #pragma unroll
       for (int i = 0; i < kSparseTiles; ++i) listed_tile[i] = p.tile_list[base + i < tile_limit ? base + i : tile_limit - 1];
 #pragma unroll
-      for (int i = 0; i < kSparseTiles; ++i) tile[i] = (long long)listed_tile[i];
+      for (int i = 0; i < kSparseTiles; ++i) tile[i] = listed_tile[i];
     } else {
 #pragma unroll
-      for (int i = 0; i < kSparseTiles; ++i) tile[i] = base + i < tile_limit ? base + i : tile_limit - 1;
+      for (int i = 0; i < kSparseTiles; ++i) tile[i] = (uint32_t)(base + i < tile_limit ? base + i : tile_limit - 1);
     }
 #pragma unroll
-    for (int i = 0; i < kSparseTiles; ++i) m[i] = mask_words[tile[i] * 64 + lane];
+    for (int i = 0; i < kSparseTiles; ++i) m[i] = mask_words[(long long)tile[i] * 64 + lane];
 #pragma unroll
     for (int i = 0; i < kSparseTiles; ++i) {
-      const long long rem = (long long)p.num_docs - (tile[i] * 2048 + lane * 32);          // docs past numDocs (last tile only)
+      const long long rem = (long long)p.num_docs - ((long long)tile[i] * 2048 + lane * 32);          // docs past numDocs (last tile only)
       m[i] &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
       if (base + i >= tile_limit) m[i] = 0u;                                                // past the last tile of the list
       count += (unsigned)__builtin_popcount(m[i]);
@@ -89,7 +94,7 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_sparse_kernel(const
           const uint32_t bit = j * b;
           sh[i] = 64u - (bit & 31u) - b;
           // (a lane without a match in this tile reads the column's first dwords: one line the whole chip shares)
-          const uint32_t* at = reinterpret_cast<const uint32_t*>(ac.fwd + tile[i] * (256ll * (long long)b)) + (uint32_t)lane * b + (bit >> 5);
+          const uint32_t* at = reinterpret_cast<const uint32_t*>(ac.fwd + (long long)tile[i] * (256ll * (long long)b)) + (uint32_t)lane * b + (bit >> 5);
           d[i] = *reinterpret_cast<const Dwords2*>(ok[i] ? at : reinterpret_cast<const uint32_t*>(ac.fwd));
         }
 #pragma unroll
@@ -103,7 +108,7 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_sparse_kernel(const
         }
       }
 #pragma unroll
-      for (int s = 0; s < kMaxAggCols; ++s) {
+      for (int s = 0; s < kAggSlots; ++s) {
         if (s == a) {
           sum[s] += wsum;
           umin[s] = tmin < umin[s] ? tmin : umin[s];
@@ -117,7 +122,7 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_sparse_kernel(const
   partial_identity(mine);
   mine.count = (unsigned long long)wave_sum_i64((long long)count);
 #pragma unroll
-  for (int a = 0; a < kMaxAggCols; ++a) {
+  for (int a = 0; a < kAggSlots; ++a) {
     if (a >= p.num_agg_cols) continue;
     mine.sum[a] = wave_sum_i64((long long)sum[a]);
     mine.kmin[a] = wave_min_i32(umin[a] == 0xFFFFFFFFu ? 0x7FFFFFFF : (int32_t)umin[a]);

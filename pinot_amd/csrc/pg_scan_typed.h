@@ -159,7 +159,13 @@ __device__ __forceinline__ void agg_dict64_private(const DevAggCol& ac, long lon
   }
 }
 
-static __global__ __launch_bounds__(kBlockThreads, 4) void scan_private_typed_kernel(const ScanParams p) {
+// kAggSlots: 1 for queries with at most one aggregated column (a TypedAcc is ten registers: the four-slot instantiation keeps forty of
+// them live across the tile loop and spills 32 of its 128; the one-slot form does not), else kMaxAggCols.
+#ifndef PG_TYPED_WAVES
+#define PG_TYPED_WAVES 4
+#endif
+template <int kAggSlots>
+__global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : 4)) void scan_private_typed_kernel(const ScanParams p) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
   const int lane = threadIdx.x & 63;
@@ -169,9 +175,9 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void scan_private_typed_ke
   const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
 
   unsigned long long count = 0;
-  TypedAcc acc[kMaxAggCols];
+  TypedAcc acc[kAggSlots];
 #pragma unroll
-  for (int a = 0; a < kMaxAggCols; ++a) typed_acc_identity(acc[a]);
+  for (int a = 0; a < kAggSlots; ++a) typed_acc_identity(acc[a]);
 
   uint32_t entries = 0u;
   const bool listed = p.tile_list != nullptr;              // index-driven filters: only the tiles index_and_kernel listed hold a match
@@ -195,7 +201,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void scan_private_typed_ke
         agg_dict64_private(ac, tile, lane, m, t);          // the host sends 32-bit-domain dictionary columns elsewhere
       }
 #pragma unroll
-      for (int s = 0; s < kMaxAggCols; ++s) {
+      for (int s = 0; s < kAggSlots; ++s) {
         if (s == a) {
           acc[s].isum += t.isum;
           acc[s].fsum += t.fsum;
@@ -214,7 +220,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void scan_private_typed_ke
   mine.count = (unsigned long long)wave_sum_i64((long long)count);
   mine.entries = (unsigned long long)wave_sum_i64((long long)entries);
 #pragma unroll
-  for (int a = 0; a < kMaxAggCols; ++a) {
+  for (int a = 0; a < kAggSlots; ++a) {
     if (a >= p.num_agg_cols) continue;             // unused slots keep the identities: six wave reductions less each
     const DevAggCol& ac = p.agg_cols[a];
     const bool wide_keys = ac.is_raw && ac.vkind != kValI32;

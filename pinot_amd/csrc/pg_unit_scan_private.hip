@@ -4,15 +4,16 @@
 
 namespace pg {
 
-void launch_scan_private(bool one_slot, int blocks, hipStream_t stream, const ScanParams& p) {
-  if (one_slot) scan_private_kernel<1><<<dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream>>>(p);
+// agg_cols: how many aggregated columns the query has (the multi-column form keeps its accumulators in LDS: PrivateAccLds)
+void launch_scan_private(int agg_cols, int blocks, hipStream_t stream, const ScanParams& p) {
+  if (agg_cols <= 1) scan_private_kernel<1><<<dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream>>>(p);
   else scan_private_kernel<kMaxAggCols><<<dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream>>>(p);
 }
 
-int waves_scan_private(bool one_slot) {
+int waves_scan_private(int agg_cols) {
   static const int cap1 = max_waves_per_cu(scan_private_kernel<1>);
   static const int cap4 = max_waves_per_cu(scan_private_kernel<kMaxAggCols>);
-  return one_slot ? cap1 : cap4;
+  return agg_cols <= 1 ? cap1 : cap4;
 }
 
 }  // namespace pg

@@ -95,6 +95,8 @@ def main():
         ("C2b-irr-1pct", seg, Q.QuerySpec([(Q.SUM, 2)], filter=fl(10))),
         ("AND2-count", seg, Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(fl(100), Q.leaf(Q.Pred.dict_range(0, 0, 30000))))),
         ("AND2-sum", seg, Q.QuerySpec([(Q.SUM, 0)], filter=Q.and_(fl(300), Q.leaf(Q.Pred.dict_range(2, 10000, 60000))))),
+        ("TWOCOL-sum-max", seg, Q.QuerySpec([(Q.SUM, 0), (Q.MAX, 1)], filter=fl(100))),
+        ("TWOCOL-sum-sum", seg, Q.QuerySpec([(Q.SUM, 0), (Q.SUM, 1)], filter=Q.leaf(Q.Pred.dict_range(0, 0, 50000)))),
         ("C2a", seg, Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(0, 45000, 55000)))),
         ("COUNT-filter", seg, Q.QuerySpec([(Q.COUNT, -1)], filter=fl(100))),
         ("MINMAXAVG", seg, Q.QuerySpec([(Q.MIN, 0), (Q.MAX, 0), (Q.AVG, 0)], filter=fl(100))),

@@ -99,6 +99,48 @@ soak)
   for base in ${SOAK_BASES:-100 200 300 400 500 600}; do
     echo "-- seed base $base"; PINOT_FUZZ_SEED_BASE=$base timeout 600 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -3
   done ;;
+slots)
+  echo "== one-slot typed / sparse kernels: tests, C7 + C1 (typed), C5 five vs four waves (sparse) =="
+  timeout 900 python -m pytest tests/test_gpu_typed.py tests/test_gpu_index_and.py tests/test_gpu_planes.py tests/test_gpu_fold.py -m gpu -x -q 2>&1 | tail -3
+  timeout 600 python tools/bench_configs.py --match "C7" > $OUT/configs_C7_one_slot.jsonl 2> $OUT/configs_C7_one_slot.err; tail -2 $OUT/configs_C7_one_slot.err
+  python - $OUT/configs_C7_one_slot.jsonl <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith("{"):
+        d = json.loads(l)
+        print("   %-70s %-28s %.4f ms %6.0f GB/s exact=%s" % (d["config"][:70], d.get("kernel", ""), d["kernel_ms"], d["GBps"], d.get("bit_exact_vs_oracle")))
+PY
+  timeout 300 python tools/c1_probe.py --sizes 10000000,40000000 > $OUT/c1_probe_one_slot.jsonl 2> $OUT/c1_probe_one_slot.err
+  python - $OUT/c1_probe_one_slot.jsonl <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith("{"):
+        r = json.loads(l)
+        print("   %9d %-12s %-26s kernel %6.2f us (min %6.2f)  wall %6.2f us" % (r["rows"], r["query"], r["kernel"], r["kernel_us"], r["kernel_us_min"], r["wall_us"]))
+PY
+  show() { python - "$1" <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith("{"):
+        r = json.loads(l)
+        print("   %-10s %-16s %-22s kernel %.4f all %.4f wall %.4f same=%s oracle=%s" % (r["setting"], r["query"], r["kernel"], r["kernel_ms"], r["all_kernels_ms"], r["wall_ms_untimed"], r["same_as_first_setting"], r.get("bit_exact_vs_oracle")))
+PY
+  }
+  echo "-- C5, scan_sparse_kernel<1> at five waves per SIMD"; timeout 900 python tools/ab_r3.py --c5 --match "C5" --settings default --check > $OUT/ab_sparse5.jsonl 2> $OUT/ab_sparse5.err; tail -2 $OUT/ab_sparse5.err; show $OUT/ab_sparse5.jsonl
+  echo "-- four waves"; PINOT_GPU_LIB=$GRAFT_REPO_ROOT/tools/libpinot_gpu_sparse4.so timeout 900 python tools/ab_r3.py --c5 --match "C5" --settings default > $OUT/ab_sparse4.jsonl 2> $OUT/ab_sparse4.err; tail -2 $OUT/ab_sparse4.err; show $OUT/ab_sparse4.jsonl
+  ;;
+twoslots)
+  echo "== scan_private_kernel<2> vs <4> for two aggregated columns; tests =="
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gpu_fuzz.py tests/test_gpu_index_and.py -m gpu -x -q 2>&1 | tail -3
+  timeout 600 python tools/ab_r3.py --match "TWOCOL" --settings default --check > $OUT/ab_twoslots.jsonl 2> $OUT/ab_twoslots.err; tail -2 $OUT/ab_twoslots.err
+  python - $OUT/ab_twoslots.jsonl <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith("{"):
+        r = json.loads(l)
+        print("   %-10s %-16s %-22s kernel %.4f all %.4f wall %.4f same=%s oracle=%s" % (r["setting"], r["query"], r["kernel"], r["kernel_ms"], r["all_kernels_ms"], r["wall_ms_untimed"], r["same_as_first_setting"], r.get("bit_exact_vs_oracle")))
+PY
+  ;;
 *) echo "unknown step $step" ;;
 esac
 done

@@ -40,8 +40,8 @@ stats)
   find $OUT/stats -name "*kernel_trace*.csv" -size +8M -delete ;;
 head)
   echo "== headline HBM traffic"
-  pmc head_fetch "scan_private_kernel" "$ONE --no-variants" FETCH_SIZE
-  pmc head_tcc "scan_private_kernel" "$ONE --no-variants" TCC_HIT_sum TCC_MISS_sum ;;
+  pmc head_fetch "scan_simple_kernel|scan_private_kernel" "$ONE --no-variants" FETCH_SIZE
+  pmc head_tcc "scan_simple_kernel|scan_private_kernel" "$ONE --no-variants" TCC_HIT_sum TCC_MISS_sum ;;
 c3)
   echo "== C3 group-by kernel: SQ / LDS counters, HBM traffic"
   pmc c3_sq "group_private_kernel" "$ONE --variants ^C3$" SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
@@ -61,7 +61,7 @@ narrow)
   pmc narrow_fetch "scan_narrow" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --rows 100000 --rows-c5 1000000000 --variants ^C5-scan-count$" FETCH_SIZE ;;
 lowsel)
   echo "== scan_private_kernel at 1 % (C2b-1pct): HBM traffic"
-  pmc lowsel_fetch "scan_private_kernel" "$ONE --variants ^C2b-1pct$" FETCH_SIZE ;;
+  pmc lowsel_fetch "scan_simple_kernel|scan_private_kernel" "$ONE --variants ^C2b-1pct$" FETCH_SIZE ;;
 per-variant)
   echo "== kernel stats, one variant per run"
   for v in C2b-irregular C2b-1pct C2a-affine C3 C3-filter COUNT-filter; do
