@@ -8,8 +8,9 @@ Headline workload, C2b of BASELINE.md section 3:   SELECT SUM(v) FROM t WHERE f 
 C4: `--segments S` (default 8) segments IN TOTAL at every N; segment s lives on GPU (s mod N), one process
 per GPU, no collective on the data path: the 16-byte partials travel over gloo and are merged on the host (SumAggregationFunction.merge).
 A step = one pg_execute per resident segment of the rank, one after the other (fused scan -> filter -> SUM kernel, its records folded
-into a pinned 200-byte host record).  `overlapped` reports the same step with the rank's segments in flight together (pg_execute_batch:
-one launch for all of them; or one pg_execute per segment on the library's worker threads).  value = S * rows * steps / time, "scaling": "strong".  Columns are generated on the host by the
+into a pinned 200-byte host record).  `overlapped` reports the same step with the rank's segments in flight together through ONE
+pg_execute_batch call (small segments share one launch; segments that fill the chip on their own -- these -- run their own kernels
+concurrently on the library's worker threads and streams; PINOT_GPU_BATCH_LAUNCH=0 forces the latter for every size).  value = S * rows * steps / time, "scaling": "strong".  Columns are generated on the host by the
 product's C++ writer in Pinot's on-disk layout and copied to HBM by pg_segment_open before the timed region.
 
 Launch:  python bench.py --gpus 1 --steps 20 --warmup 3
@@ -188,8 +189,9 @@ def main():
     kernel_name = _abi.KERNEL_NAMES[kernel_id[0]]
 
     # The same step with the rank's segments in flight TOGETHER, the way a server's combine workers would issue them (BaseCombineOperator:
-    # one task per segment on a thread pool): (a) pg_execute_batch -- ONE launch, every segment folding its own record; (b) the library's
-    # worker threads, one pg_execute per segment on a stream of its own.  Reported next to the serial step above (which stays `value`).
+    # one task per segment on a thread pool): (a) one pg_execute_batch call as the library plans it -- items of up to 64 Mi docs share ONE
+    # launch, larger ones (the 1 B-row segments of the default run) overlap as launches of their own; (b) the same call with the shared
+    # launch switched off.  Reported next to the serial step above (which stays `value`).
     overlapped = None
     if len(gsegs) > 1:
         nseg = len(gsegs)
@@ -209,7 +211,7 @@ def main():
                 lib.pg_result_free(C.byref(bres[i]))
             return ms
 
-        for mode, env in (("batch_one_launch", None), ("worker_threads", "0")):
+        for mode, env in (("pg_execute_batch", None), ("worker_threads", "0")):
             if env is not None:
                 engine.reinit(PINOT_GPU_BATCH_LAUNCH=env)
             for _ in range(max(args.warmup, 2)):

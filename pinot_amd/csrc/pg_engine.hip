@@ -326,6 +326,7 @@ pg_status ensure_set(ExecCtx* c, size_t index, size_t bytes) {
   return PG_OK;
 }
 
+constexpr long long kBatchMaxTiles = 32768;       // items of up to 64 Mi docs may share a batch launch (pg_execute_batch); larger ones run their own kernel
 constexpr long long kFoldMaxTiles = 65536;        // segments up to 128 Mi docs fold their records in the scan kernel (ExecCtx::d_done)
 constexpr int kMaxGroupSlots = 0x7FFFFFFF;        // raw keys are ints: the reference's ArrayBasedHolder + IntMapBasedHolder range (DictionaryBasedGroupKeyGenerator.java:164-184)
 constexpr size_t kGroupTableKeepBytes = 1ull << 31; // a direct-indexed table above this is freed after the query instead of staying with the context
@@ -2574,7 +2575,11 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     sp.sparse_lanes = g_engine.sparse_lanes;
     sp.fold_one_counter = g_engine.fold_one_counter;
     if (defer != nullptr) {
+      // (the shared launch is for the many small segments of a server: a segment that fills the chip on its own -- more tiles than a few
+      //  rounds of resident waves -- runs the kernel the planner picked for it, concurrently with the others, on a worker thread's stream:
+      //  eight 1 B-row items 4.72 ms in one launch, 4.45 ms as eight overlapping launches)
       if (use_private && !use_hist && !use_narrow && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
+          ((long long)seg->num_docs + 2047) / 2048 <= kBatchMaxTiles &&
           (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf)) {
         defer->sp = sp;
         defer->blocks = blocks;
@@ -3781,7 +3786,10 @@ pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* q
   std::vector<float> item_us(trace ? (size_t)count : 0);
   // (a deferred item is ~2 us of lowering: eight per claim, so 64 items wake at most seven helpers; an item that runs its own kernel
   // is claimed alone)
-  g_pool.run(count, g_engine.batch_launch ? threads : std::min(threads, count), g_engine.batch_launch ? 8 : 1, [&](int i) {
+  // (an item too large for the shared launch runs its whole kernel inside its claim: such batches are claimed one item at a time)
+  bool all_small = g_engine.batch_launch;
+  for (int i = 0; i < count && all_small; ++i) all_small = segments[i] != nullptr && ((long long)segments[i]->num_docs + 2047) / 2048 <= kBatchMaxTiles;
+  g_pool.run(count, all_small ? threads : std::min(threads, count), all_small ? 8 : 1, [&](int i) {
     if (!segments[i] || !queries[i]) { statuses[i] = PG_ERR_INVALID_ARGUMENT; errors[(size_t)i] = "null segment or query"; return; }
     const auto t_item = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     statuses[i] = execute_one(segments[i], queries[i], &results[i], g_engine.batch_launch ? &defs[(size_t)i] : nullptr);
