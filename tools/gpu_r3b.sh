@@ -1,5 +1,9 @@
 #!/bin/bash
 # Round-3 probes: tools/gpu_r3b.sh <step>...   (everything lands under gpurun_out/r3/)
+# Steps that compare two BUILDS expect the variant library under tools/ (git-ignored, shipped by gpurun); build it first with
+#   make -C pinot_amd/csrc variant NAME=simple6 UNIT=pg_unit_scan_simple DEFS=-DPG_SIMPLE_WAVES=6     (step `simple`)
+#   make -C pinot_amd/csrc variant NAME=nopair  UNIT=pg_unit_scan_simple DEFS=-DPG_SIMPLE_PAIR=0      (step `pair`: the pair path itself was removed after the measurement)
+#   make -C pinot_amd/csrc variant NAME=sparse4 UNIT=pg_unit_scan_sparse DEFS=-DPG_SPARSE_WAVES=4     (step `slots`; the default is 4 again: use =5 for the other side)
 set -u
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r3
