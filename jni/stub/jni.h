@@ -3,7 +3,9 @@
  * This environment has no JDK, so there is no jni.h to compile jni/pinot_gpu_jni.c against.  This file declares, with the JNI
  * specification's names and signatures, exactly the types and JNIEnv functions that file uses, so that `gcc -fsyntax-only -Wall -Werror`
  * can type-check it (tests/test_marshal.py does).  The function table below has neither the real table's order nor its size: nothing
- * may ever be linked or run against this header.  On a box with a JDK the real <jni.h> is found first (jni/Makefile puts
+ * built against this header may ever meet a real JVM.  The one thing that is linked against it is the JVM stand-in of the tests,
+ * jni/fake_jvm.c, which implements exactly this table (libpinot_gpu_jni_fake.so: pinot_gpu_jni.c and fake_jvm.c compiled against the same
+ * header, so the two agree by construction).  On a box with a JDK the real <jni.h> is found first (jni/Makefile puts
  * $(JAVA_HOME)/include on the include path and never this directory). */
 #ifndef PINOT_GPU_JNI_STUB_H
 #define PINOT_GPU_JNI_STUB_H

@@ -1,0 +1,110 @@
+"""GPU leg of the JNI functions, EXECUTED through the JVM stand-in (jni/fake_jvm.c via pinot_amd/jni_harness.py): every native method of
+PinotGpuNative.java that touches the device -- init, segmentOpen, queryCheck, execute, executeBatch, groupKeyInfo, segmentDeviceBytes,
+segmentClose -- called the way the Java classes call them, over the reference's golden segment, against the same queries through the
+C ABI (tests/test_gpu_marshal.py's path) and the oracle.  What stays untested without a JDK is the Java half itself."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from pinot_amd import _abi
+from pinot_amd import jni_harness as J
+from pinot_amd import marshal as M
+from pinot_amd import query as Q
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def jvm(engine):
+    j = J.FakeJvm()
+    j.call("init", None, C.c_int32(0), C.c_int32(0))
+    version = j.call("version", C.c_void_p)
+    assert "gfx950" in j.to_python(version)
+    j.release(C.c_void_p(version))
+    yield j
+    engine.reinit()                          # the suite's engine goes on with its own configuration (PG_CFG_TIME_KERNELS)
+
+
+def through_the_c_abi(gseg, spec):
+    res = _abi.pg_result()
+    with M.MarshalledQuery(spec) as mq:
+        _abi.check(gseg.lib, gseg.lib.pg_execute(gseg.handle, C.byref(mq.c), C.byref(res)))
+    try:
+        out = list(M.unpack_result(res, bool(spec.group_by)))
+        keys = M.unpack_keys(res, len(spec.group_by)).reshape(-1) if spec.group_by else np.zeros(0, np.int32)
+    finally:
+        gseg.lib.pg_result_free(C.byref(res))
+    out[0][M.H_NUM_GROUP_BY] = len(spec.group_by)          # (the JNI function fills this header slot in)
+    return out + [keys]
+
+
+def same(result, want):
+    header, group_ids, counts, sums, sums_i64, sum_exact, mins, maxs, keys = result
+    w_header, w_ids, w_counts, w_sums, w_i64, w_exact, w_mins, w_maxs, w_keys = want
+    header, w_header = header.copy(), w_header.copy()
+    header[M.H_DOMINANT_KERNEL] = w_header[M.H_DOMINANT_KERNEL] = 0
+    for a, b in ((header, w_header), (group_ids, w_ids), (counts, w_counts), (sums, w_sums), (sums_i64, w_i64), (sum_exact, w_exact), (mins, w_mins), (maxs, w_maxs), (keys, w_keys)):
+        assert np.array_equal(a, b)
+
+
+def test_the_native_methods_over_the_golden_segment(engine, jvm):
+    g = H.load_golden_queries()
+    seg = H.golden_segment()
+    aggs = H.golden_aggregations(seg)
+    c1, c9 = seg.column_index("column1"), seg.column_index("column9")
+    refs_before, objects_before = jvm.lib.fj_live_refs(), jvm.lib.fj_live_objects()
+    handle = jvm.segment_open(seg)
+    assert handle != 0
+    try:
+        assert jvm.call("segmentDeviceBytes", C.c_int64, C.c_int64(handle)) > 0
+        with engine.open(seg) as gseg:
+            for key, flt in (("unfiltered", None), ("filtered", H.golden_filter_physical(seg))):
+                spec = Q.QuerySpec(aggs, filter=flt)
+                assert jvm.query_check(handle, spec) == _abi.PG_OK
+                got = jvm.execute(handle, spec)
+                # PinotGpuNative.execute's slots: {header, groupIds, counts, sums, sumsI64, sumExact, mins, maxs, groupKeys}
+                want = g["inner_segment"][key]
+                assert list(got[0][:4]) == want["stats"] and got[0][M.H_FILTER_ENTRIES_EXACT] == 1
+                assert (got[2][0], got[4][1], got[7][2], got[6][3]) == (want["count"], want["sum_column1"], float(want["max_column3"]), float(want["min_column6"]))
+                same([got[i] for i in (0, 1, 2, 3, 4, 5, 6, 7, 8)], through_the_c_abi(gseg, spec))
+                grouped = Q.QuerySpec(aggs, filter=flt, group_by=[c9])
+                same(jvm.execute(handle, grouped), through_the_c_abi(gseg, grouped))
+            # what the device declines comes back as PG_ERR_UNSUPPORTED from queryCheck and as UnsupportedOperationException from execute
+            nine = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(*[Q.leaf(Q.Pred.dict_range(c1, i, i + 100)) for i in range(9)]))
+            assert jvm.query_check(handle, nine) == _abi.PG_ERR_UNSUPPORTED
+            with pytest.raises(J.JavaException) as e:
+                jvm.execute(handle, nine)
+            assert e.value.cls == "java/lang/UnsupportedOperationException"
+            # groupKeyInfo of a dictionary column: entries are dictIds (no offset), the NULL entry is the cardinality
+            info = jvm.call("groupKeyInfo", C.c_void_p, C.c_int64(handle), C.c_int32(c9))
+            assert list(jvm.to_python(info))[:2] == [0, 0]
+            jvm.release(C.c_void_p(info))
+
+            # executeBatch: one call for many lanes -- results item by item as execute() returns them; a declined item fails alone
+            specs = [Q.QuerySpec(aggs), Q.QuerySpec(aggs, filter=H.golden_filter_physical(seg)), nine,
+                     Q.QuerySpec([(Q.SUM, c1), (Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(c1, 10, 4000))), Q.QuerySpec(aggs, group_by=[c9])]
+            out = jvm.execute_batch([handle] * len(specs), specs)
+            assert len(out) == len(specs)
+            for i, spec in enumerate(specs):
+                if i == 2:
+                    assert isinstance(out[i], str) and out[i].startswith("%d\n" % _abi.PG_ERR_UNSUPPORTED) and "batch item 2" in out[i]
+                else:
+                    same(out[i], through_the_c_abi(gseg, spec))
+            # 64 items: the native method gives its local references back item by item (a JVM guarantees 16 without EnsureLocalCapacity)
+            many = [Q.QuerySpec([(Q.SUM, c1), (Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(c1, 10 * i, 10 * i + 3000))) for i in range(64)]
+            jh, jq = jvm.longs([handle] * len(many)), jvm.batch_queries(many)
+            held = jvm.lib.fj_live_refs()
+            jvm.lib.fj_reset_peak()
+            res = jvm.call("executeBatch", C.c_void_p, jh, jq)
+            assert jvm.lib.fj_peak_refs() - held <= 24, jvm.lib.fj_peak_refs() - held
+            items = jvm.to_python(res)
+            jvm.release(C.c_void_p(res), jh, jq)
+            for spec, item in zip(many, items):
+                want = oracle.execute(seg, spec)
+                assert item[2][1] == want.aggregations[1].count and item[4][0] == want.aggregations[0].sum_i64
+    finally:
+        jvm.call("segmentClose", None, C.c_int64(handle))
+    assert jvm.lib.fj_pins() == 0 and jvm.lib.fj_live_refs() == refs_before and jvm.lib.fj_live_objects() == objects_before
