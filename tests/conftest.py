@@ -17,9 +17,10 @@ def pytest_configure(config):
 def pytest_sessionstart(session):
     """The native libraries are build artefacts (git-ignored): a fresh checkout that runs the tests before
     `__graft_entry__.build()` gets them built here (hipcc cross-compiles gfx950 without a GPU; make is a no-op when they are current).
-    On the GPU box the prebuilt files travel with the snapshot and there may be no compiler: nothing is built when all three exist."""
+    On the GPU box the prebuilt files travel with the snapshot and there may be no compiler: nothing is built when all of them exist."""
     libs = [os.path.join(ROOT, "pinot_amd", "csrc", "libpinot_gpu.so"), os.path.join(ROOT, "pinot_amd", "csrc", "libpinot_host.so"),
-            os.path.join(ROOT, "oracle", "_build", "libpinot_oracle.so")]
+            os.path.join(ROOT, "oracle", "_build", "libpinot_oracle.so"), os.path.join(ROOT, "jni", "libpinot_gpu_marshal.so"),
+            os.path.join(ROOT, "jni", "libpinot_gpu_jni_fake.so")]
     if not all(os.path.exists(p) for p in libs):
         import __graft_entry__
         __graft_entry__.build()
