@@ -13,7 +13,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(ROOT, "jni", "libpinot_gpu_jni_fake.so")
 PREFIX = "Java_org_apache_pinot_gpu_PinotGpuNative_"
 FJ_INT_ARRAY, FJ_LONG_ARRAY, FJ_DOUBLE_ARRAY, FJ_OBJECT_ARRAY, FJ_STRING = 1, 2, 3, 4, 5
-COLUMN_INTS, COLUMN_BUFFERS, QUERY_ARRAYS = 6, 8, 8         # PGM_COLUMN_INTS / PGM_COLUMN_BUFFERS / PGM_QUERY_ARRAYS (tests/test_java_constants.py holds them to the header)
+
+
+def _header_constants():
+    """The PGM_* enumerators of jni/pg_marshal.h (record sizes of the flat arrays): read from the header, not restated here."""
+    import re
+    text = open(os.path.join(ROOT, "jni", "pg_marshal.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return {name: int(value) for name, value in re.findall(r"\b(PGM_[A-Z0-9_]+)\s*=\s*(\d+)", text)}
+
+
+_PGM = _header_constants()
+COLUMN_INTS, COLUMN_BUFFERS, QUERY_ARRAYS = _PGM["PGM_COLUMN_INTS"], _PGM["PGM_COLUMN_BUFFERS"], _PGM["PGM_QUERY_ARRAYS"]
 
 
 class JavaException(Exception):
