@@ -34,6 +34,7 @@
 
 #define PO_SCAN_BATCH 256      /* core/common/BlockDocIdIterator.java:49 */
 #define PO_MAX_DOC_PER_CALL 10000 /* core/plan/DocIdSetPlanNode.java:29 */
+#define PO_MAX_GROUP_COLS 16   /* group-by key columns (the raw key is one 128-bit number: key spaces up to 2^96 x one more column) */
 #define PO_EOF (-1)            /* segl Constants.EOF is Integer.MIN_VALUE in the reference; any negative works here */
 
 static __thread char po_error[512];
@@ -1308,11 +1309,23 @@ static void holder_init(po_holder* h, int func) {
 
 /* One aggregate() call of a function over values[from, to) of a block (the reducer body that foldNotNull applies to each non-null range,
  * NullableSingleInputAggregationFunction.java:118-160; the whole block [0, length) when there are no nulls). */
-typedef unsigned __int128 po_key;      /* a raw group key: int (Array / IntMap holders), long (LongMapBasedHolder) or beyond (ArrayMapBasedHolder) */
+/* A raw group key as the tuple of its digits (dictIds; value - min of a raw column), group-by column order: what ArrayMapBasedHolder keys
+ * by (an IntArray, DictionaryBasedGroupKeyGenerator.java:808+).  The int / long raw key of the narrower holders is its mixed-radix value
+ * sum d[j] * prod_{k<j} cardinality_k (:437-445, :650-660); rows are ordered by that value, i.e. the LAST column is the most significant. */
+typedef struct po_key { int32_t d[PO_MAX_GROUP_COLS]; } po_key;
 static __thread const po_key* po_sort_keys;
+static __thread int po_sort_ng;
+static int po_key_cmp(const po_key* a, const po_key* b, int ng) {
+  for (int c = ng - 1; c >= 0; c--) if (a->d[c] != b->d[c]) return a->d[c] < b->d[c] ? -1 : 1;
+  return 0;
+}
 static int po_cmp_by_key(const void* a, const void* b) {
-  const po_key ka = po_sort_keys[*(const int32_t*)a], kb = po_sort_keys[*(const int32_t*)b];
-  return ka < kb ? -1 : (ka > kb ? 1 : 0);
+  return po_key_cmp(&po_sort_keys[*(const int32_t*)a], &po_sort_keys[*(const int32_t*)b], po_sort_ng);
+}
+static uint64_t po_key_value(const po_key* k, const int32_t* cards, int ng) {      /* the int / long raw key (key kinds 0 and 1) */
+  uint64_t raw = 0;
+  for (int c = ng - 1; c >= 0; c--) raw = raw * (uint64_t)cards[c] + (uint64_t)k->d[c];
+  return raw;
 }
 
 static int agg_range(po_holder* h, int func, int st, const po_values* vals, int32_t from, int32_t to, double* dbl_values) {
@@ -1470,14 +1483,14 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   int na = q->num_aggregations;
   int ng = q->num_group_by;
   int64_t group_upper = 1;
-  po_key wide_upper = 1;          /* the product of the cardinalities, however large */
+  unsigned __int128 wide_upper = 1;   /* the product of the cardinalities, saturating at 2^100 (only compared with Integer / Long.MAX_VALUE) */
   int key_kind = 0;               /* 0 int raw keys, 1 long (LongMapBasedHolder), 2 beyond a long (ArrayMapBasedHolder) */
-  int32_t cards[8];
-  uint64_t* key_nulls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t cards[PO_MAX_GROUP_COLS];
+  uint64_t* key_nulls[PO_MAX_GROUP_COLS] = {0};
   int nullable_group_by = 0;      /* null handling with nulls in a key or an aggregated column: the no-dictionary generators' semantics */
-  if (ng > 8) { rc = 2; snprintf(po_error, sizeof(po_error), "too many group-by columns"); goto done; }
-  int64_t key_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int key_raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (ng > PO_MAX_GROUP_COLS) { rc = 2; snprintf(po_error, sizeof(po_error), "too many group-by columns"); goto done; }
+  int64_t key_base[PO_MAX_GROUP_COLS] = {0};
+  int key_raw[PO_MAX_GROUP_COLS] = {0};
   int no_dict_keys = 0;           /* a key column without a dictionary: NoDictionarySingle / MultiColumnGroupKeyGenerator */
   for (int g = 0; g < ng; g++) {
     const pg_column_desc* d = &seg->columns[q->group_by_columns[g]];
@@ -1503,19 +1516,21 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
      * fits an int, LongMapBasedHolder while it fits a long (:628-700), ArrayMapBasedHolder beyond (:808+).  The three map-based holders
      * differ in the key type only: group ids in order of first appearance, new keys refused once the map holds
      * _globalGroupIdUpperBound of them -- min(product, numGroupsLimit) for the int holder, numGroupsLimit for the other two.  One
-     * 128-bit mixed-radix key restates all of them (three key columns of < 2^31 values each stay below 2^93). */
-    if (wide_upper > ((po_key)1 << 96)) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by key space beyond 2^96"); goto done; }
-    wide_upper *= (po_key)(cards[g] > 0 ? cards[g] : 1);
+     * key type -- the digit tuple, po_key -- restates all of them. */
+    {
+      const unsigned __int128 sat = (unsigned __int128)1 << 100, card = (unsigned __int128)(cards[g] > 0 ? cards[g] : 1);
+      wide_upper = (wide_upper >= sat || wide_upper * card >= sat) ? sat : wide_upper * card;
+    }
     if (null_handling) {
       /* DefaultGroupByExecutor.java:106-121: under null handling the keys come from the no-dictionary generators
        * (NoDictionarySingleColumnGroupKeyGenerator / NoDictionaryMultiColumnGroupKeyGenerator with nullHandlingEnabled): a null key value
        * is a key of its own, group ids are handed out in order of first appearance up to numGroupsLimit.  Restated on the raw-key
        * scale of the ABI: a nullable key column has one more digit value, `cardinality`, meaning NULL. */
       key_nulls[g] = column_null_words(seg, q->group_by_columns[g]);
-      if (key_nulls[g]) { const int32_t card0 = cards[g]; cards[g] = card0 + 1; wide_upper = wide_upper / (po_key)(card0 > 0 ? card0 : 1) * (po_key)cards[g]; nullable_group_by = 1; }
+      if (key_nulls[g]) { const int32_t card0 = cards[g]; cards[g] = card0 + 1; if (wide_upper < ((unsigned __int128)1 << 100)) wide_upper = wide_upper / (unsigned __int128)(card0 > 0 ? card0 : 1) * (unsigned __int128)cards[g]; nullable_group_by = 1; }
     }
   }
-  key_kind = wide_upper > (po_key)0x7FFFFFFFFFFFFFFFull ? 2 : (wide_upper > (po_key)2147483647 ? 1 : 0);
+  key_kind = wide_upper > (unsigned __int128)0x7FFFFFFFFFFFFFFFull ? 2 : (wide_upper > (unsigned __int128)2147483647 ? 1 : 0);
   if (key_kind != 0 && null_handling) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by key space beyond an int under null handling"); goto done; }
   group_upper = key_kind == 0 ? (int64_t)wide_upper : 0x7FFFFFFFll;      /* (only an upper bound for the map-based sizing below) */
   if (null_handling && ng > 0 && has_null_values) nullable_group_by = 1;
@@ -1587,7 +1602,6 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
 
     if (ng > 0) {
       /* DictionaryBasedGroupKeyGenerator.ArrayBasedHolder.processSingleValue, :298-338 */
-      for (int32_t i = 0; i < pos; i++) raw_keys[i] = 0;
       for (int g = ng - 1; g >= 0; g--) {
         if (key_raw[g]) {
           const po_column* kc = &cols[q->group_by_columns[g]];
@@ -1595,20 +1609,22 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
           for (int32_t i = 0; i < pos; i++) dict_scratch[i] = (int32_t)((is_int ? (int64_t)raw_get_int(&kc->raw, doc_ids[i]) : raw_get_long(&kc->raw, doc_ids[i])) - key_base[g]);
         } else fetch_dict_ids(&cols[q->group_by_columns[g]], num_docs, doc_ids, pos, dict_scratch);
         if (key_nulls[g]) for (int32_t i = 0; i < pos; i++) if ((key_nulls[g][doc_ids[i] >> 6] >> (doc_ids[i] & 63)) & 1) dict_scratch[i] = cards[g] - 1;   /* NULL */
-        for (int32_t i = 0; i < pos; i++) raw_keys[i] = raw_keys[i] * (po_key)cards[g] + (po_key)dict_scratch[i];
+        for (int32_t i = 0; i < pos; i++) raw_keys[i].d[g] = dict_scratch[i];
       }
-      if (!map_based) for (int32_t i = 0; i < pos; i++) group_ids[i] = (int32_t)raw_keys[i];
+      if (!map_based) for (int32_t i = 0; i < pos; i++) group_ids[i] = (int32_t)po_key_value(&raw_keys[i], cards, ng);
       if (map_based) {
         /* group ids in first-appearance order; docs of keys refused by the full map drop out of every aggregation (the holders
          * ignore INVALID_ID) but still count as scanned */
         int32_t kept = 0;
         for (int32_t i = 0; i < pos; i++) {
           const po_key raw = raw_keys[i];
-          uint64_t h = (((uint64_t)raw ^ ((uint64_t)(raw >> 64) * 0xC2B2AE3D27D4EB4Full)) * 0x9E3779B97F4A7C15ull) >> 20;
+          uint64_t h = 0;
+          for (int c = 0; c < ng; c++) h = (h ^ (uint64_t)(uint32_t)raw.d[c]) * 0x9E3779B97F4A7C15ull + 0xC2B2AE3D27D4EB4Full;
+          h >>= 20;
           int64_t slot = (int64_t)(h & (uint64_t)(map_capacity - 1));
           int32_t gid = -1;
           for (;;) {
-            if (map_used[slot] && map_keys[slot] == raw) { gid = map_ids[slot]; break; }
+            if (map_used[slot] && po_key_cmp(&map_keys[slot], &raw, ng) == 0) { gid = map_ids[slot]; break; }
             if (!map_used[slot]) {
               if (map_size < group_upper) { map_used[slot] = 1; map_keys[slot] = raw; map_ids[slot] = map_size; raw_of_gid[map_size] = raw; gid = map_size++; }
               break;
@@ -1741,7 +1757,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
     if (map_based) {
       order = (int32_t*)malloc(sizeof(int32_t) * (size_t)(map_size > 0 ? map_size : 1));
       for (int32_t i = 0; i < map_size; i++) order[i] = i;
-      po_sort_keys = raw_of_gid;
+      po_sort_keys = raw_of_gid; po_sort_ng = ng;
       qsort(order, (size_t)map_size, sizeof(int32_t), po_cmp_by_key);
       res->num_groups_limit_reached = map_size >= num_groups_limit;      /* GroupByOperator.java:114-115 */
     }
@@ -1750,10 +1766,12 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
       if (!flags[g]) continue;
       {
         /* the key as the ABI returns it: int raw key / long raw key / row number, and always the dictId tuple */
-        po_key raw = map_based ? raw_of_gid[g] : (po_key)g;
-        res->group_ids[k] = key_kind == 0 ? (int32_t)raw : k;
-        if (key_kind == 1) res->group_ids64[k] = (int64_t)raw;
-        for (int c = 0; c < ng; c++) { res->group_key_dict_ids[(size_t)k * (size_t)ng + (size_t)c] = (int32_t)(raw % (po_key)cards[c]); raw /= (po_key)cards[c]; }
+        po_key key;
+        if (map_based) key = raw_of_gid[g];
+        else { uint64_t raw = (uint64_t)g; for (int c = 0; c < ng; c++) { key.d[c] = (int32_t)(raw % (uint64_t)cards[c]); raw /= (uint64_t)cards[c]; } }
+        res->group_ids[k] = key_kind == 0 ? (int32_t)po_key_value(&key, cards, ng) : k;
+        if (key_kind == 1) res->group_ids64[k] = (int64_t)po_key_value(&key, cards, ng);
+        for (int c = 0; c < ng; c++) res->group_key_dict_ids[(size_t)k * (size_t)ng + (size_t)c] = key.d[c];
       }
       for (int a = 0; a < na; a++) {
         pg_agg_value* v = &res->group_aggregations[(size_t)k * (size_t)na + (size_t)a];
@@ -1786,7 +1804,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
 
 cleanup:
   free(doc_ids); free(dict_scratch); free(vals.i); free(vals.l); free(vals.f); free(vals.d); free(dbl_values); free(group_ids); free(raw_keys); free(nn_gids); free(gnn);
-  for (int g = 0; g < 8; g++) free(key_nulls[g]);
+  for (int g = 0; g < PO_MAX_GROUP_COLS; g++) free(key_nulls[g]);
   free(holders); free(gholders); free(gavg_sum); free(gavg_cnt); free(gexact); free(gover); free(gcount); free(flags);
   free(map_keys); free(map_used); free(map_ids); free(raw_of_gid);
 done:

@@ -12,11 +12,13 @@ namespace pg {
 constexpr int kWave = 64;
 constexpr int kMaxTileSteps = 32;
 constexpr int kMaxTileDocs = kWave * kMaxTileSteps;   // 2048: device buffers are padded to whole 2048-doc tiles
-constexpr int kMaxCols = 8;                     // distinct column streams referenced by one query
+constexpr int kMaxCols = 16;                    // distinct column streams referenced by one query (the reference's nine-column ArrayMapBasedHolder golden
+                                                // stages nine key streams + its aggregation planes + its filter columns)
 constexpr int kMaxLeaves = 8;
 constexpr int kMaxNodes = 24;
 constexpr int kMaxAggCols = 4;                  // distinct aggregated columns
-constexpr int kMaxGroupCols = 3;                // ArrayBasedHolder fast paths cover 1..3 keys
+constexpr int kMaxGroupCols = 10;               // group-by key columns (InnerSegmentAggregationSingleValueQueriesTest.java:39-41 groups by nine)
+constexpr int kMaxHashLevels = 8;               // chained first tables of a key beyond a long (GroupParams.hash_*): each takes >= 1 column, the first key >= 2
 constexpr int kMaxGroupAggs = 8;                // distinct (column, SUM|MIN|MAX) pairs of a group-by query
 constexpr int kStackDepth = 8;
 constexpr int kBlockThreads = 256;              // scan_agg_kernel: at most 4 wavefronts per workgroup
@@ -278,14 +280,17 @@ struct GroupParams {
   // 628-806, 808+): the table above is no longer indexed by the raw key but HASHED -- num_groups slots (a power of two, at least twice
   // the keys that can exist), open addressing, linear probing, the 64-bit key of a slot in hash_keys[slot] (kHashEmpty = free).
   //   hash_kind 1: the raw key sum dictId_j * key_mult[j] fits a long and is the key.
-  //   hash_kind 2: it does not.  Columns [0, hash_split) form a first key that a first table (hash_keys1) turns into its slot number;
-  //                key = that slot + sum over the remaining columns dictId_j * key_mult[j] (key_mult carries the first table's size).
+  //   hash_kind 2: it does not.  The columns are taken in order while the key still fits a long; at column hash_split[l] the key so far
+  //                is handed to first table l (hash_keys_lvl[l]), which turns it into its slot number, and the sum goes on from there:
+  //                key = that slot + sum over the next columns dictId_j * key_mult[j] (key_mult carries the table's size).  hash_levels
+  //                such tables are chained (one is enough up to ~96 bits of key; nine 31-bit columns need seven).
   int32_t hash_kind;
-  int32_t hash_split;
+  int32_t hash_levels;
   unsigned long long hash_mask;     // num_groups - 1
-  unsigned long long hash_mask1;    // slots of the first table - 1 (hash_kind 2)
   unsigned long long* hash_keys;    // [num_groups]
-  unsigned long long* hash_keys1;   // [hash_mask1 + 1]
+  int32_t hash_split[kMaxHashLevels];
+  unsigned long long hash_mask_lvl[kMaxHashLevels];     // slots of first table l - 1
+  unsigned long long* hash_keys_lvl[kMaxHashLevels];    // [hash_mask_lvl[l] + 1]
   unsigned long long key_mult[kMaxGroupCols];
   uint32_t* first_doc;              // non-null: the numGroupsLimit pass -- no aggregation, atomicMin of the docId into first_doc[slot]
 };

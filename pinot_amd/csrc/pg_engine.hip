@@ -1985,33 +1985,45 @@ constexpr int32_t kQueryHashHolder = 1 << 30;      // internal pg_query.flags bi
 // -- DictionaryBasedGroupKeyGenerator.java:162-176.  Here: a hashed table in HBM (GroupParams.hash_*), sized at plan time to at least
 // twice the keys that can exist (min(numDocs, product)), so that it cannot fill up at run time.
 struct HashPlan {
-  int kind = 0;                    // 0: int raw keys (direct-indexed table); 1: long raw keys; 2: beyond a long (two chained tables)
-  int split = 0;
-  long long slots = 0, slots1 = 0;
-  unsigned long long mult[kMaxGroupCols] = {0, 0, 0};
+  int kind = 0;                    // 0: int raw keys (direct-indexed table); 1: long raw keys; 2: beyond a long (chained tables)
+  int levels = 0;                  // first tables of a key beyond a long: table l takes over at column split[l]
+  int split[kMaxHashLevels] = {};
+  long long slots = 0, slots_lvl[kMaxHashLevels] = {};
+  unsigned long long mult[kMaxGroupCols] = {};
+  long long level_slots() const { long long t = 0; for (int l = 0; l < levels; ++l) t += slots_lvl[l]; return t; }
+  int segment_begin(int l) const { return l == 0 ? 0 : split[l - 1]; }        // key l (l in [0, levels]) covers columns [segment_begin(l), segment_end(l, n))
+  int segment_end(int l, int n) const { return l < levels ? split[l] : n; }
 };
 static pg_status plan_hash_holder(const pg_segment* seg, const std::vector<int>& cards, HashPlan* hp) {
   *hp = HashPlan();
+  // the product of up to kMaxGroupCols 31-bit cardinalities does not fit 128 bits: saturate far above anything compared against
+  const unsigned __int128 kSat = (unsigned __int128)1 << 100;
+  auto sat_mul = [&](unsigned __int128 a, unsigned __int128 b) { return (a >= kSat || b >= kSat || a * b >= kSat) ? kSat : a * b; };
   unsigned __int128 prod = 1;
-  for (int c : cards) prod *= (unsigned __int128)std::max(c, 1);
+  for (int c : cards) prod = sat_mul(prod, (unsigned __int128)std::max(c, 1));
   if (prod <= (unsigned __int128)kMaxGroupSlots) return PG_OK;
   if ((long long)seg->num_docs > (1ll << 29))
     return fail(PG_ERR_UNSUPPORTED, "group-by with raw keys beyond an int on a segment of more than 2^29 docs (the hashed table would need more than 2^30 slots)");
   auto pow2_at_least = [](unsigned __int128 v) { long long p = 1 << 16; while ((unsigned __int128)p < v) p <<= 1; return p; };
   const int n = (int)cards.size();
-  hp->kind = prod > (unsigned __int128)0x7FFFFFFFFFFFFFFFull ? 2 : 1;
+  const unsigned __int128 kLongMax = (unsigned __int128)0x7FFFFFFFFFFFFFFFull;
+  hp->kind = prod > kLongMax ? 2 : 1;
   hp->slots = pow2_at_least(2 * std::min<unsigned __int128>((unsigned __int128)seg->num_docs, prod));
-  if (hp->kind == 1) {
-    hp->split = n;
-    unsigned long long m = 1;
-    for (int c = 0; c < n; ++c) { hp->mult[c] = m; m *= (unsigned long long)std::max(cards[(size_t)c], 1); }
-  } else {
-    // three columns of up to 2^31 - 1 values each: the first two are one key (< 2^62) that a first table turns into its slot number
-    if (n != 3) return fail(PG_ERR_INTERNAL, "a raw key beyond a long needs three key columns");
-    hp->split = 2;
-    const unsigned __int128 lo = (unsigned __int128)std::max(cards[0], 1) * (unsigned __int128)std::max(cards[1], 1);
-    hp->slots1 = pow2_at_least(2 * std::min<unsigned __int128>((unsigned __int128)seg->num_docs, lo));
-    hp->mult[0] = 1; hp->mult[1] = (unsigned long long)std::max(cards[0], 1); hp->mult[2] = (unsigned long long)hp->slots1;
+  // Columns are taken in order while the key so far still fits a long; when the next column would push it beyond, the key so far goes
+  // through a first table and its slot number (< 2^30) stands for it from there on (slot * card always fits: 2^30 * 2^31).
+  unsigned __int128 bound = 1;             // exclusive upper bound of the running key
+  unsigned __int128 seen = 1;              // distinct keys the columns so far can form
+  for (int c = 0; c < n; ++c) {
+    const unsigned __int128 card = (unsigned __int128)std::max(cards[(size_t)c], 1);
+    if (bound * card > kLongMax) {
+      if (hp->levels == kMaxHashLevels) return fail(PG_ERR_UNSUPPORTED, "group-by raw key needs more than %d chained tables", kMaxHashLevels);
+      const long long s = pow2_at_least(2 * std::min<unsigned __int128>((unsigned __int128)seg->num_docs, seen));
+      hp->split[hp->levels] = c; hp->slots_lvl[hp->levels] = s; hp->levels++;
+      bound = (unsigned __int128)s;
+    }
+    hp->mult[c] = (unsigned long long)bound;
+    bound *= card;
+    seen = sat_mul(seen, card);
   }
   return PG_OK;
 }
@@ -2122,7 +2134,7 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
   }
   if (ng == 0 && (int)agg_cols.size() > kMaxAggCols) return fail(PG_ERR_UNSUPPORTED, "more than %d aggregated columns", kMaxAggCols);
   if ((int)group_aggs.size() > kMaxGroupAggs) return fail(PG_ERR_UNSUPPORTED, "more than %d distinct group-by aggregations", kMaxGroupAggs);
-  if (ng > 0 && ((unsigned long long)product * (1ull + group_aggs.size() + (hash_plan.kind ? 1 : 0)) + (unsigned long long)hash_plan.slots1) * 8ull > g_engine.group_table_bytes)
+  if (ng > 0 && ((unsigned long long)product * (1ull + group_aggs.size() + (hash_plan.kind ? 1 : 0)) + (unsigned long long)hash_plan.level_slots()) * 8ull > g_engine.group_table_bytes)
     return fail(PG_ERR_UNSUPPORTED, "group-by table of %lld slots x %zu words exceeds the %llu-byte budget (PINOT_GPU_GROUP_TABLE_BYTES)", product, 1 + group_aggs.size(),
                 (unsigned long long)g_engine.group_table_bytes);
   // Column streams, as slot_for hands them out: (column, read through its value plane?).  A column summed through its plane is read
@@ -2655,7 +2667,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // ---------------- group-by (ArrayBasedHolder) ----------------
     GroupParams gp;
     memset(&gp, 0, sizeof(gp));
-    int group_slot[kMaxGroupCols] = {0, 0, 0}, group_mult[kMaxGroupCols] = {0, 0, 0};
+    int group_slot[kMaxGroupCols] = {}, group_mult[kMaxGroupCols] = {};
     PlanGroupAgg plan_aggs[kMaxGroupAggs];
     long long product = 1;
     std::vector<int> cards;
@@ -2722,7 +2734,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
     gp.wide_keys = product > (1ll << 24) ? 1 : 0;
     // (hashed holders: one more word per slot for its key, and the first table of an ArrayMap-range key)
-    const size_t table_words = (size_t)gp.num_groups * (size_t)(1 + gp.num_group_aggs + (hash_plan.kind ? 1 : 0)) + (size_t)hash_plan.slots1;
+    const size_t table_words = (size_t)gp.num_groups * (size_t)(1 + gp.num_group_aggs + (hash_plan.kind ? 1 : 0)) + (size_t)hash_plan.level_slots();
     if ((unsigned long long)table_words * 8ull > g_engine.group_table_bytes)
       return fail(PG_ERR_UNSUPPORTED, "group-by table of %lld slots x %d words exceeds the %llu-byte budget (PINOT_GPU_GROUP_TABLE_BYTES)", product, 1 + gp.num_group_aggs,
                   (unsigned long long)g_engine.group_table_bytes);
@@ -2737,12 +2749,17 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     gp.table_count = ctx->d_table;
     gp.table_acc = reinterpret_cast<long long*>(ctx->d_table + gp.num_groups);
     gp.hash_kind = hash_plan.kind;
-    gp.hash_split = hash_plan.split;
+    gp.hash_levels = hash_plan.levels;
     if (hash_plan.kind != 0) {
       gp.hash_mask = (unsigned long long)gp.num_groups - 1ull;
       gp.hash_keys = ctx->d_table + (size_t)gp.num_groups * (size_t)(1 + gp.num_group_aggs);
-      gp.hash_mask1 = hash_plan.slots1 ? (unsigned long long)hash_plan.slots1 - 1ull : 0ull;
-      gp.hash_keys1 = hash_plan.slots1 ? gp.hash_keys + gp.num_groups : nullptr;
+      unsigned long long* next_table = gp.hash_keys + gp.num_groups;
+      for (int l = 0; l < hash_plan.levels; ++l) {
+        gp.hash_split[l] = hash_plan.split[l];
+        gp.hash_mask_lvl[l] = (unsigned long long)hash_plan.slots_lvl[l] - 1ull;
+        gp.hash_keys_lvl[l] = next_table;
+        next_table += hash_plan.slots_lvl[l];
+      }
       for (int g = 0; g < ng; ++g) gp.key_mult[g] = hash_plan.mult[g];
     }
     const size_t table_bytes = table_words * 8;
@@ -2940,7 +2957,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (count_leap2) { st = launch_leap_chain(seg, ctx, 0); if (st != PG_OK) return st; }
     if (count_entries) HIP_TRY(hipMemcpyAsync(ctx->h_filter_entries, ctx->d_filter_entries, 8, hipMemcpyDeviceToHost, ctx->stream));
     // The groups that exist, in ascending raw-key order: (raw key, doc count, accumulators[a * num_present + k]).
-    std::vector<unsigned long long> hash_keys, hash_keys_lo;      // hashed holders: the keys of the present slots
+    std::vector<unsigned long long> hash_keys;                    // hashed holders: the keys of the present slots ...
+    std::vector<std::vector<unsigned long long>> hash_keys_lvl;    // ... and, per chained first table, the key behind the slot number a later key starts with
     std::vector<int32_t> present_ids;
     std::vector<unsigned long long> present_counts;
     std::vector<long long> present_acc;
@@ -3079,18 +3097,21 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         if (gp.num_group_aggs > 0) HIP_TRY(hipMemcpyAsync(h_acc, d_acc, acc_bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (hash_plan.kind != 0) {
           // the slots that hold a group -> their 64-bit keys (and, for a key beyond a long, the first table's key behind its slot number)
-          unsigned long long* d_keys = (unsigned long long*)scratch.alloc((size_t)num_present * 8 * 2);
+          unsigned long long* d_keys = (unsigned long long*)scratch.alloc((size_t)num_present * 8 * (size_t)(1 + hash_plan.levels));
           if (!d_keys) return fail(PG_ERR_OUT_OF_MEMORY, "group-by keys of %d groups", num_present);
           hash_keys.resize((size_t)num_present);
           const unsigned gblocks = (unsigned)std::min<long long>(((long long)num_present + 255) / 256, (long long)seg->num_cus * 8);
           gather_u64_kernel<<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(gp.hash_keys, d_ids, num_present, gp.hash_mask, d_keys);
           HIP_TRY(hipGetLastError());
           HIP_TRY(hipMemcpyAsync(hash_keys.data(), d_keys, (size_t)num_present * 8, hipMemcpyDeviceToHost, ctx->stream));
-          if (hash_plan.kind == 2) {
-            hash_keys_lo.resize((size_t)num_present);
-            gather_u64_by_key_kernel<<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(gp.hash_keys1, d_keys, num_present, gp.hash_mask1, d_keys + num_present);
+          // chained first tables, last one first: the low part of a key is the slot number of the table before it
+          hash_keys_lvl.resize((size_t)hash_plan.levels);
+          for (int l = hash_plan.levels - 1; l >= 0; --l) {
+            unsigned long long* src = d_keys + (size_t)(hash_plan.levels - 1 - l) * (size_t)num_present;
+            hash_keys_lvl[(size_t)l].resize((size_t)num_present);
+            gather_u64_by_key_kernel<<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(gp.hash_keys_lvl[l], src, num_present, gp.hash_mask_lvl[l], src + num_present);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(hash_keys_lo.data(), d_keys + num_present, (size_t)num_present * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(hash_keys_lvl[(size_t)l].data(), src + num_present, (size_t)num_present * 8, hipMemcpyDeviceToHost, ctx->stream));
           }
         }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -3116,11 +3137,14 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     } else {
       std::vector<int32_t> tuples((size_t)num_present * (size_t)ng);
       for (int k = 0; k < num_present; ++k) {
-        unsigned long long lo = hash_plan.kind == 2 ? hash_keys_lo[(size_t)k] : hash_keys[(size_t)k];
-        for (int g = 0; g < hash_plan.split; ++g) { tuples[(size_t)k * (size_t)ng + (size_t)g] = (int32_t)(lo % (unsigned long long)cards[(size_t)g]); lo /= (unsigned long long)cards[(size_t)g]; }
-        if (hash_plan.kind == 2) {
-          unsigned long long hi = hash_keys[(size_t)k] / (unsigned long long)hash_plan.slots1;
-          for (int g = hash_plan.split; g < ng; ++g) { tuples[(size_t)k * (size_t)ng + (size_t)g] = (int32_t)(hi % (unsigned long long)cards[(size_t)g]); hi /= (unsigned long long)cards[(size_t)g]; }
+        // key l covers the columns [segment_begin(l), segment_end(l)); above its lowest digit -- the slot number of table l - 1 -- it is
+        // a mixed-radix number of those columns' dictIds
+        for (int l = 0; l <= hash_plan.levels; ++l) {
+          unsigned long long key = l == hash_plan.levels ? hash_keys[(size_t)k] : hash_keys_lvl[(size_t)l][(size_t)k];
+          if (l > 0) key /= (unsigned long long)hash_plan.slots_lvl[l - 1];
+          for (int g = hash_plan.segment_begin(l); g < hash_plan.segment_end(l, ng); ++g) {
+            tuples[(size_t)k * (size_t)ng + (size_t)g] = (int32_t)(key % (unsigned long long)cards[(size_t)g]); key /= (unsigned long long)cards[(size_t)g];
+          }
         }
       }
       perm.resize((size_t)num_present);

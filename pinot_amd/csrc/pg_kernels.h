@@ -2070,11 +2070,15 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
       unsigned long long k[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) k[j] = 0ull;
+      int lvl = 0;
       for (int c = 0; c < gp.num_group_cols; ++c) {
-        if (gp.hash_kind == 2 && c == gp.hash_split) {
-          // the columns so far are the first table's key: from here on its slot number stands for them
+        if (lvl < gp.hash_levels && c == gp.hash_split[lvl]) {
+          // the columns so far are first table lvl's key: from here on its slot number stands for them
+          unsigned long long* const keys_lvl = gp.hash_keys_lvl[lvl];
+          const unsigned long long mask_lvl = gp.hash_mask_lvl[lvl];
 #pragma unroll
-          for (int j = 0; j < 16; ++j) if (!kMasked || ((m >> (16 * h + j)) & 1u)) k[j] = (unsigned long long)hash_slot_of(gp.hash_keys1, gp.hash_mask1, k[j]);
+          for (int j = 0; j < 16; ++j) if (!kMasked || ((m >> (16 * h + j)) & 1u)) k[j] = (unsigned long long)hash_slot_of(keys_lvl, mask_lvl, k[j]);
+          ++lvl;
         }
         const DevGroupKey& key = gp.group_keys[c];
         const int b = key.bits;
@@ -2275,8 +2279,8 @@ __global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const
 
 static __global__ void init_group_table_kernel(GroupParams gp) {
   const long long G = gp.num_groups;
-  if (gp.hash_kind == 2)
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g <= (long long)gp.hash_mask1; g += (long long)gridDim.x * blockDim.x) gp.hash_keys1[g] = kHashEmpty;
+  for (int lvl = 0; lvl < gp.hash_levels; ++lvl)
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g <= (long long)gp.hash_mask_lvl[lvl]; g += (long long)gridDim.x * blockDim.x) gp.hash_keys_lvl[lvl][g] = kHashEmpty;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += (long long)gridDim.x * blockDim.x) {
     if (gp.hash_kind != 0) gp.hash_keys[g] = kHashEmpty;
     gp.table_count[g] = 0ull;

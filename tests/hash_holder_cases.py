@@ -25,6 +25,8 @@ def cases():
         ("long-3cols", 100_003, [(3_000, 40), (3_000, 50), (3_000, 30)], 1),          # 2.7e10
         ("array-3cols", 80_021, [(2_200_000, 60), (2_100_000, 50), (2_300_000, 40)], 2),   # 1.06e19 > Long.MAX_VALUE
         ("long-dense", 150_001, [(66_000, 66_000), (40_000, 5)], 1),                 # many groups: most docs have a group of their own
+        # eight columns of ~2^21 entries each (2^168 raw keys): three chained first tables in front of the aggregating one
+        ("array-8cols", 40_009, [(2_200_000, 9), (2_100_000, 7), (2_300_000, 5), (2_150_000, 6), (2_250_000, 4), (2_120_000, 5), (2_310_000, 3), (2_170_000, 4)], 2),
     ]
 
 

@@ -26,12 +26,17 @@ def load_golden_queries():
         return json.load(f)
 
 
-def golden_segment(use_inverted=True):
+def golden_segment(use_inverted=True, raw_columns=()):
     """The segment BaseSingleValueQueriesTest builds from test_data-sv.avro (every column dictionary encoded).
-    String columns carry their dictIds with a placeholder int dictionary: string values never reach the device."""
+    String columns carry their dictIds with a placeholder int dictionary: string values never reach the device.
+    `raw_columns`: INT columns stored WITHOUT a dictionary (raw PASS_THROUGH forward index) instead -- query results do not depend on
+    the encoding, so the reference's goldens also pin the no-dictionary readers and key generators."""
     d = load_golden_columns()
     cols = []
     for name in GOLDEN_INT:
+        if name in raw_columns:
+            cols.append(S.Column.raw(name, d[name]))
+            continue
         cols.append(S.Column.dict_encoded(name, d[name], with_inverted=use_inverted and name in GOLDEN_INVERTED))
     for name in GOLDEN_STR:
         ids = d[name + "__ids"]
@@ -48,6 +53,11 @@ def range_pred(seg, name, lower=None, upper=None, lower_inclusive=True, upper_in
     (RangePredicateEvaluatorFactory.java:126-169), with the alwaysTrue / alwaysFalse short-circuits (:163-168)."""
     ci = seg.column_index(name)
     col = seg.columns[ci]
+    if col.dictionary is None:
+        # raw INT column: IntRawValueBasedRangePredicateEvaluator (RangePredicateEvaluatorFactory.java:331-366), inclusive bounds
+        lo = -2 ** 31 if lower is None else (lower if lower_inclusive else lower + 1)
+        hi = 2 ** 31 - 1 if upper is None else (upper if upper_inclusive else upper - 1)
+        return Q.Pred.match_none() if lo > hi else Q.Pred.raw_range(ci, lo, hi)
     s, e = oracle.lower_range(col.dictionary, col.cardinality, lower, upper, lower_inclusive, upper_inclusive)
     n = max(e - s, 0)
     if n == 0:
@@ -158,6 +168,37 @@ def golden_medium_group(seg, want):
         mult *= c.cardinality
         cols.append(ci)
     return cols, raw
+
+
+def golden_group_key(seg, names, key, base_of=None):
+    """(group-by column indexes, key tuple as the result rows carry it) of a golden row with any number of group-by columns: the dictId
+    of every dictionary column (strings through the fixture's string dictionaries); for a raw (no-dictionary) column the VALUE, which
+    NoDictionary*GroupKeyGenerator keys by -- callers turn the result's digits into values with pg_group_key_info's base."""
+    cols, tup = [], []
+    for name, value in zip(names, key):
+        ci = seg.column_index(name)
+        c = seg.columns[ci]
+        cols.append(ci)
+        if name in getattr(seg, "string_dicts", {}):
+            tup.append(seg.string_dicts[name].index(value))
+        elif c.dictionary is None:
+            tup.append(int(value))
+        else:
+            d = int(np.searchsorted(c.dict_values, value))
+            assert c.value_of(d) == value
+            tup.append(d)
+    return cols, tuple(tup)
+
+
+def check_golden_row(vals, want):
+    """One group (or the aggregation-only row) of SELECT COUNT(*), SUM(column1), MAX(column3), MIN(column6), AVG(column7) against the
+    literals of QueriesTestUtils.testInnerSegmentAggregation[GroupBy]Result."""
+    count, s1, mx3, mn6, avg7 = vals
+    assert count.intermediate(Q.COUNT) == want["count"]
+    assert s1.intermediate(Q.SUM) == float(want["sum_column1"]) and s1.sum_i64 == want["sum_column1"]
+    assert mx3.intermediate(Q.MAX) == float(want["max_column3"])
+    assert mn6.intermediate(Q.MIN) == float(want["min_column6"])
+    assert avg7.intermediate(Q.AVG) == (float(want["avg_column7"][0]), want["avg_column7"][1])
 
 
 def golden_aggregations(seg):

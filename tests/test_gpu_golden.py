@@ -83,6 +83,52 @@ def test_inner_segment_goldens(engine):
             H.assert_results_equal(mres, oracle.execute(seg, mspec))
 
 
+def test_large_and_very_large_group_by_goldens_long_and_array_map_holders(engine):
+    """InnerSegmentAggregationSingleValueQueriesTest.testLargeAggregationGroupBy :134-153 (five key columns, LONG_MAP_BASED) and
+    testVeryLargeAggregationGroupBy :155-176 (nine, ARRAY_MAP_BASED: the hashed table behind two chained first tables), both filter
+    variants -- the reference's key tuples, values and all four statistics -- and every row against the oracle."""
+    from test_oracle_golden import LARGE_GOLDENS, check_large_group_by_goldens
+    g = H.load_golden_queries()
+    seg = H.golden_segment()
+    with engine.open(seg) as gseg:
+        check_large_group_by_goldens(gseg.execute, seg)
+        for row, kind in LARGE_GOLDENS:
+            cols = [seg.column_index(c) for c in g[row]["group_by"]]
+            for flt in (None, H.golden_filter_physical(seg), H.golden_filter(seg)):
+                spec = Q.QuerySpec(H.golden_aggregations(seg), filter=flt, group_by=cols)
+                got, want = gseg.execute(spec), oracle.execute(seg, spec)
+                H.assert_results_equal(got, want)
+                assert got.group_key_kind == want.group_key_kind == kind
+                assert got.group_keys == want.group_keys and got.group_ids64 == want.group_ids64
+            # numGroupsLimit binds: the first keys in docId order survive (LongGroupIdMap / ArrayGroupIdMap hand out ids by first appearance)
+            spec = Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, seg.column_index("column1"))], group_by=cols, num_groups_limit=1000)
+            got, want = gseg.execute(spec), oracle.execute(seg, spec)
+            H.assert_results_equal(got, want)
+            assert got.num_groups_limit_reached and len(got.groups) == 1000 and got.group_keys == want.group_keys
+
+
+def test_large_group_by_goldens_with_raw_key_columns(engine):
+    """The same goldens with column1 / column3 / column9 stored without a dictionary: NoDictionaryMultiColumnGroupKeyGenerator's keys by
+    value (through pg_group_key_info), raw range leaves, raw SUM / MAX inputs -- the reference's results do not depend on the encoding."""
+    from test_oracle_golden import RAW_KEY_COLUMNS, check_large_group_by_goldens
+    g = H.load_golden_queries()
+    seg = H.golden_segment(raw_columns=RAW_KEY_COLUMNS)
+    with engine.open(seg) as gseg:
+        def base_of(c):
+            base, is_offset, _ = gseg.group_key_info(c)
+            assert is_offset
+            return base
+        check_large_group_by_goldens(gseg.execute, seg, base_of=base_of, check_kind=False)
+        for key, flt in (("unfiltered", None), ("filtered", H.golden_filter_physical(seg))):
+            spec = Q.QuerySpec(H.golden_aggregations(seg), filter=flt)
+            res = gseg.execute(spec)
+            _check_inner(res.aggregations, g["inner_segment"][key])
+            assert list(res.stats) == g["inner_segment"][key]["stats"]
+            for row in ("inner_segment_group_by_large", "inner_segment_group_by_very_large"):
+                gspec = Q.QuerySpec(H.golden_aggregations(seg), filter=flt, group_by=[seg.column_index(c) for c in g[row]["group_by"]])
+                H.assert_results_equal(gseg.execute(gspec), oracle.execute(seg, gspec))
+
+
 def test_inter_segment_goldens(engine):
     g = H.load_golden_queries()["inter_segment_x4"]
     seg = H.golden_segment()

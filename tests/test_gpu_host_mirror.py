@@ -253,6 +253,23 @@ def test_medium_group_by_golden_and_num_groups_limit_through_sql(golden_segments
     assert limited["stats"]["numDocsScanned"] == 30000
 
 
+def test_large_and_very_large_group_by_goldens_through_sql(golden_segments):
+    """testLargeAggregationGroupBy / testVeryLargeAggregationGroupBy (InnerSegmentAggregationSingleValueQueriesTest.java:134-176) as the
+    reference's own SQL through the C++ plan maker: five and nine group-by columns, the Long / ArrayMap holders, keys back as VALUES."""
+    _, segs = golden_segments
+    g = H.load_golden_queries()
+    for row in ("inner_segment_group_by_large", "inner_segment_group_by_very_large"):
+        group_by = " GROUP BY " + ", ".join(g[row]["group_by"])
+        for sql, want in ((QUERY + group_by, g[row]["unfiltered"]), (QUERY + FILTER + group_by, g[row]["filtered"])):
+            block = host.execute_sql(segs[:1], sql)["segments"][0]
+            hit = [r for r in block["groups"] if r["key"] == want["key"]]
+            assert len(hit) == 1 and not block["numGroupsLimitReached"]
+            assert hit[0]["intermediate"] == [want["count"], float(want["sum_column1"]), float(want["max_column3"]),
+                                              float(want["min_column6"]), [float(want["avg_column7"][0]), want["avg_column7"][1]]]
+            st = block["stats"]
+            assert (st["numDocsScanned"], st["numEntriesScannedInFilter"], st["numEntriesScannedPostFilter"], st["numTotalDocs"]) == tuple(want["stats"])
+
+
 def test_group_by_over_144_million_raw_keys(golden_segments):
     """GROUP BY column1, column3: 6582 * 21910 raw keys, the upper IntMapBasedHolder range, one direct-indexed table in HBM."""
     d, segs = golden_segments

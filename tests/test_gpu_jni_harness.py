@@ -72,6 +72,24 @@ def test_the_native_methods_over_the_golden_segment(engine, jvm):
                 same([got[i] for i in (0, 1, 2, 3, 4, 5, 6, 7, 8)], through_the_c_abi(gseg, spec))
                 grouped = Q.QuerySpec(aggs, filter=flt, group_by=[c9])
                 same(jvm.execute(handle, grouped), through_the_c_abi(gseg, grouped))
+            # testLargeAggregationGroupBy / testVeryLargeAggregationGroupBy (:134-176): the Long / ArrayMap holders through the native methods --
+            # the golden key is found among the rows' dictId tuples (slot groupKeys), its values in the same row
+            for row in ("inner_segment_group_by_large", "inner_segment_group_by_very_large"):
+                for key, flt in (("unfiltered", None), ("filtered", H.golden_filter_physical(seg))):
+                    want = g[row][key]
+                    cols, tup = H.golden_group_key(seg, g[row]["group_by"], want["key"])
+                    spec = Q.QuerySpec(aggs, filter=flt, group_by=cols)
+                    assert jvm.query_check(handle, spec) == _abi.PG_OK
+                    got = jvm.execute(handle, spec)
+                    assert list(got[0][:4]) == want["stats"] and got[0][M.H_GROUP_KEY_KIND] == (1 if len(cols) == 5 else 2)
+                    keys = got[8].reshape(-1, len(cols))
+                    hit = np.flatnonzero((keys == np.asarray(tup, dtype=keys.dtype)).all(axis=1))
+                    assert hit.shape[0] == 1
+                    r, na = int(hit[0]), len(aggs)
+                    assert (got[2][r * na], got[4][r * na + 1], got[7][r * na + 2], got[6][r * na + 3]) == \
+                        (want["count"], want["sum_column1"], float(want["max_column3"]), float(want["min_column6"]))
+                    assert (got[4][r * na + 4], got[2][r * na + 4]) == tuple(want["avg_column7"])
+                    same(got, through_the_c_abi(gseg, spec))
             # what the device declines comes back as PG_ERR_UNSUPPORTED from queryCheck and as UnsupportedOperationException from execute
             nine = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(*[Q.leaf(Q.Pred.dict_range(c1, i, i + 100)) for i in range(9)]))
             assert jvm.query_check(handle, nine) == _abi.PG_ERR_UNSUPPORTED

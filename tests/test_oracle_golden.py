@@ -81,6 +81,55 @@ def test_inner_segment_medium_group_by_goldens_int_map_holder():
         assert sum(v[0].count for v in res.groups.values()) == want["stats"][0]
 
 
+LARGE_GOLDENS = (("inner_segment_group_by_large", 1), ("inner_segment_group_by_very_large", 2))      # (fixture row, pg_result.group_key_kind)
+RAW_KEY_COLUMNS = ("column1", "column3", "column9")
+
+
+def check_large_group_by_goldens(execute, seg, base_of=None, exact_filter_stats=True, check_kind=True):
+    """testLargeAggregationGroupBy :134-153 (LONG_MAP_BASED holder) and testVeryLargeAggregationGroupBy :155-176 (ARRAY_MAP_BASED), both
+    filter variants: the key tuple, the five values and all four ExecutionStatistics, with `execute(spec) -> Result` for one segment.
+    `base_of(column index)`: value of digit 0 of a raw (no-dictionary) key column (pg_group_key_info), None when every key column has a
+    dictionary.  `check_kind`: the holder kind is a property of the dictionary-encoded segment the reference's test builds (a raw key
+    column spans max - min + 1 digits on the ABI's raw-key scale, so the same query lands in a wider holder)."""
+    g = H.load_golden_queries()
+    for row, kind in LARGE_GOLDENS:
+        for key, flt in (("unfiltered", None), ("filtered", H.golden_filter_physical(seg))):
+            want = g[row][key]
+            cols, tup = H.golden_group_key(seg, g[row]["group_by"], want["key"])
+            res = execute(Q.QuerySpec(H.golden_aggregations(seg), filter=flt, group_by=cols))
+            assert not check_kind or res.group_key_kind == kind, (row, res.group_key_kind)
+            assert not res.num_groups_limit_reached
+            groups = res.groups
+            if base_of is not None:
+                bases = [base_of(c) if seg.columns[c].dictionary is None else 0 for c in cols]
+                groups = {tuple(int(d) + b for d, b in zip(t, bases)): v for t, v in res.groups.items()}
+            H.check_golden_row(groups[tup], want)
+            if exact_filter_stats:
+                assert res.filter_entries_exact and list(res.stats) == want["stats"], (row, key, res.stats)
+            else:
+                assert (res.stats[0], res.stats[2], res.stats[3]) == (want["stats"][0], want["stats"][2], want["stats"][3])
+            assert sum(v[0].count for v in res.groups.values()) == want["stats"][0]
+
+
+def test_inner_segment_large_and_very_large_group_by_goldens_long_and_array_map_holders():
+    seg = H.golden_segment()
+    check_large_group_by_goldens(lambda spec: oracle.execute(seg, spec), seg)
+
+
+def test_large_group_by_goldens_with_raw_key_columns():
+    """The same four goldens with column1 / column3 / column9 stored WITHOUT a dictionary: the reference's results do not depend on the
+    encoding, so they also pin NoDictionaryMultiColumnGroupKeyGenerator's restatement (keys by value, raw range leaves, raw SUM / MAX)."""
+    seg = H.golden_segment(raw_columns=RAW_KEY_COLUMNS)
+    d = H.load_golden_columns()
+    check_large_group_by_goldens(lambda spec: oracle.execute(seg, spec), seg, base_of=lambda c: int(d[seg.columns[c].name].min()), check_kind=False)
+    # and the aggregation-only / small / medium goldens over the raw columns
+    g = H.load_golden_queries()
+    for key, flt in (("unfiltered", None), ("filtered", H.golden_filter_physical(seg))):
+        res = oracle.execute(seg, Q.QuerySpec(H.golden_aggregations(seg), filter=flt))
+        H.check_golden_row(res.aggregations, g["inner_segment"][key])
+        assert list(res.stats) == g["inner_segment"][key]["stats"]
+
+
 def test_inter_segment_goldens_by_merging_four_copies():
     # InterSegmentAggregationSingleValueQueriesTest: 4 identical segments through combine + reduce;
     # merge rule = AggregationFunction.merge (SUM '+', COUNT '+'), AggregationResultsBlockMerger.java:34-44
