@@ -55,6 +55,9 @@ def parse_args():
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--variants", default="", help="regexp: only the variants whose id matches")
     ap.add_argument("--no-clock-settle", action="store_true", help="skip the 48 untimed launches that step through the GPU clock transient")
+    ap.add_argument("--single-process", action="store_true",
+                    help="the deployment shape: ONE process (a Pinot server is one JVM) drives all --gpus N devices -- segment s resident on device s mod N, "
+                         "one pg_execute_batch call per step (launch plain `python bench.py --single-process --gpus N`, no torch.distributed.run)")
     return ap.parse_args()
 
 
@@ -109,8 +112,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+    single = args.single_process
+    if single and world != 1:
+        raise SystemExit("--single-process is one process: do not launch it through torch.distributed.run")
+    if not single and world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run (or --single-process)" % (args.gpus, world))
+    num_devices = args.gpus if single else 1                 # devices THIS process drives
+    if single and torch.cuda.device_count() < num_devices:
+        raise SystemExit("--single-process --gpus %d but %d devices visible" % (num_devices, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         # no collective on the data path: gloo carries the barrier, the timing MAX and the 16-byte partials (no RCCL needed)
@@ -124,10 +133,13 @@ def main():
     from pinot_amd.engine import Engine
 
     n = args.rows
-    num_segments = max(args.segments, world)
+    num_segments = max(args.segments, world, num_devices)
     mine = [s for s in range(num_segments) if s % world == rank]          # BASELINE.md C4 / SURVEY.md 8(e): segment s -> device s mod N
     t0 = time.time()
     segs = [c2b_segment(S, s, n, args.dictionary) for s in mine]
+    if single:
+        for s, seg in zip(mine, segs):
+            seg.desc.device_id = s % num_devices              # one process, N devices: pg_segment_open places the segment, every call switches to its device
     gen_s = time.time() - t0
     spec = Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, args.threshold)))
     algorithmic_bytes = segs[0].columns[0].fwd.nbytes + segs[0].columns[1].fwd.nbytes   # B(f) + B(v) = 3.375 B/row
@@ -140,13 +152,15 @@ def main():
     device_bytes = sum(g.device_bytes() for g in gsegs)
 
     def barrier():
-        torch.cuda.synchronize()
+        for d in range(num_devices):
+            torch.cuda.synchronize(d)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        for d in range(num_devices):
+            torch.cuda.synchronize(d)
 
     res = _abi.pg_result()
-    kernel_ms, partials = [], [None] * len(gsegs)
+    kernel_ms, query_ms, partials = [], [], [None] * len(gsegs)
     kernel_id = [-1]
 
     def step(record=False):
@@ -157,8 +171,31 @@ def main():
             partials[i] = (int(res.aggregations[0].sum_i64), int(res.aggregations[0].count))
             if record:
                 kernel_ms.append(res.dominant_kernel_ms)
+                query_ms.append(res.device_ms)               # every kernel of the query (HIP events around all of its launches)
             kernel_id[0] = int(res.dominant_kernel)
             lib.pg_result_free(C.byref(res))
+
+    if single and num_devices > 1:
+        # The deployment shape's step: ONE pg_execute_batch over all segments (BaseCombineOperator hands a query's segments to one pool).
+        # Items of this size run their own kernel on the library's worker threads, each on its segment's device and stream.
+        nall = len(gsegs)
+        sp_handles = (C.c_void_p * nall)(*[g.handle for g in gsegs])
+        sp_queries = (C.POINTER(_abi.pg_query) * nall)(*[C.pointer(spec.c) for _ in gsegs])
+        sp_res = (_abi.pg_result * nall)()
+        sp_st = (C.c_int * nall)()
+
+        def step(record=False):      # noqa: F811
+            if engine.execute_batch_raw(sp_handles, sp_queries, nall, sp_res, sp_st) != _abi.PG_OK:
+                raise RuntimeError(lib.pg_last_error().decode())
+            for i in range(nall):
+                if sp_st[i] != _abi.PG_OK:
+                    raise RuntimeError("batch item %d: status %d" % (i, sp_st[i]))
+                partials[i] = (int(sp_res[i].aggregations[0].sum_i64), int(sp_res[i].aggregations[0].count))
+                if record:
+                    kernel_ms.append(sp_res[i].dominant_kernel_ms)
+                    query_ms.append(sp_res[i].device_ms)
+                kernel_id[0] = int(sp_res[i].dominant_kernel)
+                lib.pg_result_free(C.byref(sp_res[i]))
 
     # Clock settle: the first ~35 launches after an idle period run through the GPU's power-management transient (0.72 -> 0.58 ->
     # 0.69 -> 0.575 ms for this kernel, tools/steps_probe.py); a resident query engine is never in that state, so it is stepped through
@@ -186,14 +223,28 @@ def main():
             per_segment[s] = (vals[2 * i], vals[2 * i + 1])
     merged_sum, merged_count = D.merge_sum_count([per_segment[s] for s in range(num_segments)])
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    avg_query_ms = sum(query_ms) / len(query_ms)
     kernel_name = _abi.KERNEL_NAMES[kernel_id[0]]
+
+    # A query after idle: Pinot's queries arrive whenever they arrive.  >= 1 s without a launch, then ONE query, no settle launches.
+    cold = None
+    if rank == 0 and world == 1 and not single:
+        cold = []
+        for _ in range(3):
+            time.sleep(1.2)
+            t0 = time.perf_counter()
+            st = gsegs[0].execute_raw(spec, res)
+            wall = (time.perf_counter() - t0) * 1e3
+            assert st == _abi.PG_OK
+            cold.append({"all_kernels_ms": res.device_ms, "host_clock_ms": wall})
+            lib.pg_result_free(C.byref(res))
 
     # The same step with the rank's segments in flight TOGETHER, the way a server's combine workers would issue them (BaseCombineOperator:
     # one task per segment on a thread pool): (a) one pg_execute_batch call as the library plans it -- items of up to 64 Mi docs share ONE
     # launch, larger ones (the 1 B-row segments of the default run) overlap as launches of their own; (b) the same call with the shared
     # launch switched off.  Reported next to the serial step above (which stays `value`).
     overlapped = None
-    if len(gsegs) > 1:
+    if len(gsegs) > 1 and not (single and num_devices > 1):
         nseg = len(gsegs)
         handles = (C.c_void_p * nseg)(*[g.handle for g in gsegs])
         queries = (C.POINTER(_abi.pg_query) * nseg)(*[C.pointer(spec.c) for _ in gsegs])
@@ -241,17 +292,20 @@ def main():
                 traffic_source = {"replayed": True, "file": "profiles/traffic.json", "from": t.get("source"),
                                   "note": "FETCH_SIZE x2 (gfx950) of a separate rocprofv3 --pmc run of this command; not measured in this run"}
         rows_per_s = num_segments * n * args.steps / elapsed
-        achieved = algorithmic_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        achieved = algorithmic_bytes / (avg_query_ms * 1e-3) / 1e9                 # on EVERY kernel of the query (one launch since round 4: the fold is inside the scan)
+        achieved_dominant = algorithmic_bytes / (avg_kernel_ms * 1e-3) / 1e9
         result = {
             "metric": "scanned rows/sec + achieved HBM GB/s, filtered SUM on 1B-row segment",
             "value": rows_per_s,
             "unit": "rows/s",
-            "n_gpus": world,
+            "n_gpus": args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
+            "process_model": ("one process drives all %d devices (segment s on device s mod N, one pg_execute_batch per step)" % num_devices) if single
+                             else "one process per GPU (torch.distributed.run), gloo for the barrier / timing / 16-byte partials",
             "vs_baseline": None,
             "dtype": "int64",
             "data": "synthetic",
@@ -262,8 +316,14 @@ def main():
                        "dictionary": args.dictionary},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms": avg_kernel_ms,
+                         "all_kernels_ms": avg_query_ms, "frac_dominant_kernel": achieved_dominant / HBM_PEAK_GBPS,
+                         "frac_note": "achieved / frac are algorithmic bytes over ALL kernels of the query (HIP events around every launch of a pg_execute); "
+                                      "frac_dominant_kernel is the scan kernel alone",
                          "launches_timed": len(kernel_ms), "algorithmic_bytes_per_launch": algorithmic_bytes},
             "clock_settle_launches": settle,
+            "cold_launch_ms": None if not cold else min(c["all_kernels_ms"] for c in cold),
+            "cold_launch": None if not cold else {"samples": cold, "frac": algorithmic_bytes / (min(c["all_kernels_ms"] for c in cold) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                   "note": "one query after >= 1.2 s without a launch, no settle launches, three times; cold_launch_ms = the best of the three"},
             "hbm_GBps_whole_step": num_segments * algorithmic_bytes * args.steps / elapsed / 1e9,
             "overlapped": overlapped,
             "result": {"sum": merged_sum, "count": merged_count},
@@ -320,6 +380,13 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        # LAST key of the line: one compact entry per configuration -- [frac of 8 TB/s on all kernels of the query, all_kernels_ms, bit exact vs oracle]
+        # (the variants array is long; whoever keeps only the tail of the line still sees BASELINE.json configs[0]..[4])
+        summary = {"headline(configs[1],[3])": [round(result["roofline"]["frac"], 4), round(result["roofline"]["all_kernels_ms"], 4),
+                                                 (result.get("parity") or {}).get("bit_exact_vs_oracle")]}
+        for v in result.get("variants") or []:
+            summary[v["id"]] = [None if v.get("frac") is None else round(v["frac"], 4), None if v.get("all_kernels_ms") is None else round(v["all_kernels_ms"], 4), v.get("bit_exact_vs_oracle")]
+        result["summary"] = summary
         print(json.dumps(result))
 
 

@@ -119,15 +119,62 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
       _statistics[2] += result._header[PinotGpuNative.PGM_H_ENTRIES_POST_FILTER];
       _statistics[3] = result._header[PinotGpuNative.PGM_H_TOTAL_DOCS];
     }
-    return _queryContext.getGroupByExpressions() == null ? aggregationBlock(results) : groupByBlock(results);
+    if (_queryContext.getGroupByExpressions() == null) {
+      return aggregationBlock(results);
+    }
+    // FILTER (WHERE ...) lanes under GROUP BY: the reference shares ONE GroupKeyGenerator across the lanes (FilteredGroupByOperator.java
+    // :121-143), so numGroupsLimit bounds the groups of all lanes TOGETHER and ids go to keys by first appearance across lanes.  Here every
+    // lane applied the limit on its own: whenever the limit can have shaped the result -- a lane reached it, or the union of the lanes'
+    // groups exceeds it -- the segment runs on the CPU plan instead of returning other (or more) groups than the reference.
+    if (results.size() > 1) {
+      int numKeyColumns = _queryContext.getGroupByExpressions().size();
+      int limit = 0;
+      boolean reached = false;
+      for (int l = 0; l < results.size(); l++) {
+        reached |= results.get(l)._header[PinotGpuNative.PGM_H_NUM_GROUPS_LIMIT_REACHED] != 0;
+        limit = Math.max(limit, _lanes.get(l)._query._numGroupsLimit);
+      }
+      if (!reached && limit > 0 && numKeyColumns > 0) {
+        reached = unionOf(results, numKeyColumns).length / numKeyColumns >= limit;
+      }
+      if (reached) {
+        LOGGER.debug("Segment {}: numGroupsLimit binds across FILTER lanes; CPU plan", _segment.getSegmentName());
+        Arrays.fill(_statistics, 0);
+        _cpuOperator = _cpuPlan.run();
+        return (BaseResultsBlock) _cpuOperator.nextBlock();
+      }
+    }
+    // the group-by block asks the device how each key column's digits map to values (groupKeyInfo): the segment must still be resident
+    if (!_segment.tryPin()) {
+      LOGGER.warn("Segment {} left the device while its group-by result was assembled; it runs on the CPU plan", _segment.getSegmentName());
+      Arrays.fill(_statistics, 0);
+      _cpuOperator = _cpuPlan.run();
+      return (BaseResultsBlock) _cpuOperator.nextBlock();
+    }
+    try {
+      return groupByBlock(results);
+    } finally {
+      _segment.unpin();
+    }
+  }
+
+  /** One pg_execute; the segment stays pinned for its duration (GpuSegmentCache may otherwise evict it under the HBM budget). */
+  private Object[] executeAlone(GpuQueryLowering.Lowered q) {
+    if (!_segment.tryPin()) {
+      throw new UnsupportedOperationException("segment " + _segment.getSegmentName() + " is no longer resident on the device");
+    }
+    try {
+      return PinotGpuNative.execute(_segment.handle(), q._filterNodes, q._predInts, q._predLongs, q._setOffsets, q._setWords,
+          q._aggregations, q._groupBy, q._numGroupsLimit, q._flags);
+    } finally {
+      _segment.unpin();
+    }
   }
 
   private LaneResult execute(int laneIndex) {
     GpuQueryLowering.Lowered q = _lanes.get(laneIndex)._query;
     // in a batch: the first lane of the first segment a combine task reaches makes the native call for every lane of every segment
-    Object[] raw = _batch != null ? _batch.take(_batchSlots[laneIndex])
-        : PinotGpuNative.execute(_segment.handle(), q._filterNodes, q._predInts, q._predLongs, q._setOffsets, q._setWords,
-            q._aggregations, q._groupBy, q._numGroupsLimit, q._flags);
+    Object[] raw = _batch != null ? _batch.take(_batchSlots[laneIndex]) : executeAlone(q);
     if (raw == null || raw.length != PinotGpuNative.PGM_RESULT_ARRAYS) {
       throw new IllegalStateException("native result does not match jni/pg_marshal.h");
     }

@@ -18,7 +18,7 @@ import java.util.List;
 
 
 final class GpuBatch {
-  private final List<Long> _handles = new ArrayList<>();
+  private final List<GpuSegment> _segments = new ArrayList<>();
   private final List<GpuQueryLowering.Lowered> _queries = new ArrayList<>();
   private boolean _started;
   private boolean _done;
@@ -26,17 +26,17 @@ final class GpuBatch {
   private RuntimeException _failure;
 
   /** Plan time (one thread): the lane's slot in the batch. */
-  synchronized int add(long handle, GpuQueryLowering.Lowered query) {
+  synchronized int add(GpuSegment segment, GpuQueryLowering.Lowered query) {
     if (_started) {
       throw new IllegalStateException("the batch is already running");
     }
-    _handles.add(handle);
+    _segments.add(segment);
     _queries.add(query);
-    return _handles.size() - 1;
+    return _segments.size() - 1;
   }
 
   synchronized int size() {
-    return _handles.size();
+    return _segments.size();
   }
 
   /** Run time (any combine task): the Object[PGM_RESULT_ARRAYS] of slot {@code index}; throws what PinotGpuNative.execute would have thrown. */
@@ -101,11 +101,27 @@ final class GpuBatch {
   }
 
   private Object[] call() {
-    int n = _handles.size();
+    int n = _segments.size();
     long[] handles = new long[n];
+    boolean[] pinned = new boolean[n];
     Object[][] queries = new Object[n][];
+    try {
+      return callPinned(n, handles, pinned, queries);
+    } finally {
+      for (int i = 0; i < n; i++) {
+        if (pinned[i]) {
+          _segments.get(i).unpin();
+        }
+      }
+    }
+  }
+
+  private Object[] callPinned(int n, long[] handles, boolean[] pinned, Object[][] queries) {
     for (int i = 0; i < n; i++) {
-      handles[i] = _handles.get(i);
+      // a segment whose device copy left between plan time and now (HBM budget, release) travels as handle 0: pg_execute_batch fails that
+      // item alone (PG_ERR_INVALID_ARGUMENT), its operator re-plans on the CPU like for any failed item
+      pinned[i] = _segments.get(i).tryPin();
+      handles[i] = pinned[i] ? _segments.get(i).handle() : 0;
       GpuQueryLowering.Lowered q = _queries.get(i);
       Object[] arrays = new Object[PinotGpuNative.PGM_QUERY_ARRAYS];
       arrays[PinotGpuNative.PGM_Q_FILTER_NODES] = q._filterNodes;

@@ -30,6 +30,7 @@
 package org.apache.pinot.gpu;
 
 import java.util.ArrayList;
+import java.util.Arrays;
 import java.util.LinkedHashMap;
 import java.util.List;
 import java.util.Map;
@@ -54,6 +55,10 @@ import org.slf4j.LoggerFactory;
 public class GpuPlanMaker extends InstancePlanMakerImplV2 {
   private static final Logger LOGGER = LoggerFactory.getLogger(GpuPlanMaker.class);
   public static final String DEVICE_KEY = "gpu.device";
+  /** The devices this server drives: "0-7", "0,2,4" or a mix ("0-3,6"); default: the single device of {@code gpu.device}. */
+  public static final String DEVICES_KEY = "gpu.devices";
+  /** Bytes of HBM per device the resident segments may take; least recently used idle segments leave first (0 = no budget). */
+  public static final String HBM_BUDGET_KEY = "gpu.hbm.budget.bytes";
   public static final String ENABLED_KEY = "gpu.enabled";
   public static final String SKIP_STAR_TREE_SEGMENTS_KEY = "gpu.skip.startree";
 
@@ -74,11 +79,56 @@ public class GpuPlanMaker extends InstancePlanMakerImplV2 {
     _skipStarTreeSegments = queryExecutorConfig.getProperty(SKIP_STAR_TREE_SEGMENTS_KEY, false);
     _batchEnabled = queryExecutorConfig.getProperty(BATCH_KEY, true);
     try {
-      PinotGpuNative.init(device, 0);
-      _segments = new GpuSegmentCache(device);
-      LOGGER.info("Segment executor on device {}: {}", device, PinotGpuNative.version());
+      // One process, every device of the node: pg_init once (its device is only the default for segments that name none), segments
+      // placed over the devices by GpuSegmentCache, the library switching to a segment's device in every call.
+      int[] devices = parseDevices(queryExecutorConfig.getProperty(DEVICES_KEY, Integer.toString(device)));
+      long budget = queryExecutorConfig.getProperty(HBM_BUDGET_KEY, 0L);
+      PinotGpuNative.init(devices[0], 0);
+      _segments = new GpuSegmentCache(devices, budget);
+      LOGGER.info("Segment executor on devices {}: {}", Arrays.toString(devices), PinotGpuNative.version());
     } catch (RuntimeException | UnsatisfiedLinkError e) {
       LOGGER.warn("No device executor, every query keeps the CPU plan: {}", e.toString());
+    }
+  }
+
+  /** "0-7", "0,2,4", "0-3,6" -> the device numbers in the order written, duplicates dropped. */
+  static int[] parseDevices(String text) {
+    List<Integer> devices = new ArrayList<>();
+    for (String part : text.split(",")) {
+      String item = part.trim();
+      if (item.isEmpty()) {
+        continue;
+      }
+      int dash = item.indexOf('-', 1);
+      int first = Integer.parseInt(dash > 0 ? item.substring(0, dash).trim() : item);
+      int last = dash > 0 ? Integer.parseInt(item.substring(dash + 1).trim()) : first;
+      if (first < 0 || last < first) {
+        throw new IllegalArgumentException("bad device range: " + item);
+      }
+      for (int d = first; d <= last; d++) {
+        if (!devices.contains(d)) {
+          devices.add(d);
+        }
+      }
+    }
+    if (devices.isEmpty()) {
+      throw new IllegalArgumentException("no device in: " + text);
+    }
+    int[] out = new int[devices.size()];
+    for (int i = 0; i < out.length; i++) {
+      out[i] = devices.get(i);
+    }
+    return out;
+  }
+
+  /**
+   * For the deployment's segment-drop path (next to IndexSegment.destroy(), INTEGRATION.md): gives the segment's HBM back at once instead
+   * of when the garbage collector finds the IndexSegment unreachable.
+   */
+  public void releaseSegment(IndexSegment indexSegment) {
+    GpuSegmentCache segments = _segments;
+    if (segments != null) {
+      segments.release(indexSegment);
     }
   }
 
@@ -118,7 +168,7 @@ public class GpuPlanMaker extends InstancePlanMakerImplV2 {
     if (batch != null) {
       batchSlots = new int[lanes.size()];
       for (int i = 0; i < batchSlots.length; i++) {
-        batchSlots[i] = batch.add(segment.handle(), lanes.get(i)._query);
+        batchSlots[i] = batch.add(segment, lanes.get(i)._query);
       }
     }
     final int[] slots = batchSlots;

@@ -58,11 +58,87 @@ final class GpuSegment implements Closeable {
   private final List<Boolean> _hasDictionary = new ArrayList<>();
   private final List<Boolean> _numeric = new ArrayList<>();
   private final int _numDocs;
-  private volatile long _handle;
+  private final int _device;
+  // The native handle lives in a box of its own: the Cleaner action GpuSegmentCache registers against the IndexSegment shares the box (not
+  // this object, which must stay collectable with its key) -- whoever closes first wins, nobody closes twice.
+  private final HandleBox _box = new HandleBox();
+  private int _pins;                                     // native calls in flight on the handle (guarded by `this`)
+  private volatile long _lastUsedNanos = System.nanoTime();
+  private volatile long _deviceBytes;
 
-  private GpuSegment(IndexSegment indexSegment) {
+  /** The native handle and its one-time close. */
+  static final class HandleBox {
+    private long _handle;
+
+    synchronized long get() {
+      return _handle;
+    }
+
+    synchronized void set(long handle) {
+      _handle = handle;
+    }
+
+    /** pg_segment_close, once; returns whether this call closed it. */
+    synchronized boolean close() {
+      if (_handle == 0) {
+        return false;
+      }
+      PinotGpuNative.segmentClose(_handle);
+      _handle = 0;
+      return true;
+    }
+  }
+
+  private GpuSegment(IndexSegment indexSegment, int device) {
     _segmentName = indexSegment.getSegmentName();
     _numDocs = indexSegment.getSegmentMetadata().getTotalDocs();
+    _device = device;
+  }
+
+  HandleBox box() {
+    return _box;
+  }
+
+  int device() {
+    return _device;
+  }
+
+  long deviceBytes() {
+    return _deviceBytes;
+  }
+
+  long lastUsedNanos() {
+    return _lastUsedNanos;
+  }
+
+  void touch() {
+    _lastUsedNanos = System.nanoTime();
+  }
+
+  /**
+   * Before a native call on the handle: false when the device copy is gone (evicted under the HBM budget between plan time and run time,
+   * or released with its IndexSegment) -- the caller then runs its CPU plan.  pg_segment_close assumes no pg_execute in flight on the
+   * handle (include/pinot_gpu.h): a pinned segment is never closed, closeIfIdle() refuses.
+   */
+  synchronized boolean tryPin() {
+    if (_box.get() == 0) {
+      return false;
+    }
+    _pins++;
+    return true;
+  }
+
+  synchronized void unpin() {
+    _pins--;
+  }
+
+  /** Eviction: closes the device copy unless a native call is using it. */
+  synchronized boolean closeIfIdle() {
+    if (_pins > 0) {
+      return false;
+    }
+    _box.close();
+    return true;
   }
 
   String getSegmentName() {
@@ -70,7 +146,7 @@ final class GpuSegment implements Closeable {
   }
 
   long handle() {
-    return _handle;
+    return _box.get();
   }
 
   int numDocs() {
@@ -100,15 +176,12 @@ final class GpuSegment implements Closeable {
 
   @Override
   public synchronized void close() {
-    if (_handle != 0) {
-      PinotGpuNative.segmentClose(_handle);
-      _handle = 0;
-    }
+    _box.close();
   }
 
   static GpuSegment open(IndexSegment indexSegment, int device)
       throws Exception {
-    GpuSegment segment = new GpuSegment(indexSegment);
+    GpuSegment segment = new GpuSegment(indexSegment, device);
     File indexDir = indexSegment.getSegmentMetadata().getIndexDir();
     SegmentDirectoryLoaderContext context = new SegmentDirectoryLoaderContext.Builder()
         .setSegmentName(indexSegment.getSegmentName())
@@ -193,9 +266,10 @@ final class GpuSegment implements Closeable {
         }
       }
       long crc = Long.parseLong(indexSegment.getSegmentMetadata().getCrc());
-      segment._handle = PinotGpuNative.segmentOpen(indexSegment.getSegmentName(), crc, device, segment._numDocs,
+      segment._box.set(PinotGpuNative.segmentOpen(indexSegment.getSegmentName(), crc, device, segment._numDocs,
           segment._columnNames.toArray(new String[0]), ints.stream().mapToInt(Integer::intValue).toArray(),
-          buffers.stream().mapToLong(Long::longValue).toArray());
+          buffers.stream().mapToLong(Long::longValue).toArray()));
+      segment._deviceBytes = PinotGpuNative.segmentDeviceBytes(segment._box.get());
     }
     keepAlive.clear();       // pg_segment_open has copied everything to the device
     return segment;

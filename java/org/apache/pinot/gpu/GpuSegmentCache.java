@@ -5,16 +5,32 @@
  * VALUE must not reach the key: GpuSegment holds the segment's name and column table, never the IndexSegment, and the Cleaner's action
  * captures only the native handle.  (A WeakHashMap whose value references its key strongly never clears the entry.)
  *
+ * <p><b>Devices.</b> One server process drives every device of the node (a Pinot server is one JVM; SURVEY.md section 8e: segment s on
+ * device s mod N).  A segment goes to the device with the fewest resident bytes at the time it is opened -- for equal-sized segments
+ * that IS s mod N in open order, and it stays balanced when sizes differ or segments come and go.  pg_segment_open places it; every
+ * later native call switches to the segment's device by itself, and a query's lanes on different devices run side by side inside one
+ * pg_execute_batch call.
+ *
+ * <p><b>HBM is released with the segment, not with the garbage collector.</b> Three ways, first one wins (the handle closes once:
+ * GpuSegment.HandleBox): {@link #release(IndexSegment)} -- the call to add next to IndexSegment.destroy() where the deployment can
+ * (INTEGRATION.md) --; the per-device budget ({@code gpu.hbm.budget.bytes}): opening a segment that would exceed it first closes the least
+ * recently used segments of that device that no native call is using (they are re-opened when a query reaches them again); and the
+ * Cleaner, as the safety net for an IndexSegment that simply becomes unreachable.
+ *
  * <p>Segments that cannot be opened (mutable segments, unsupported layouts, out of device memory) are remembered as such: their queries
  * keep the CPU plan without trying again on every query.
  */
 package org.apache.pinot.gpu;
 
 import java.lang.ref.Cleaner;
+import java.util.ArrayList;
 import java.util.Collections;
+import java.util.Comparator;
+import java.util.List;
 import java.util.Map;
 import java.util.Optional;
 import java.util.WeakHashMap;
+import java.util.concurrent.atomic.AtomicLongArray;
 import org.apache.pinot.segment.spi.ImmutableSegment;
 import org.apache.pinot.segment.spi.IndexSegment;
 import org.slf4j.Logger;
@@ -26,10 +42,29 @@ final class GpuSegmentCache {
   private static final Cleaner CLEANER = Cleaner.create();
 
   private final Map<IndexSegment, Optional<GpuSegment>> _segments = Collections.synchronizedMap(new WeakHashMap<>());
-  private final int _device;
+  private final int[] _devices;
+  private final AtomicLongArray _residentBytes;          // per entry of _devices: bytes of the segments this cache holds there
+  private final long _budgetBytesPerDevice;              // 0 = no budget
+
+  GpuSegmentCache(int[] devices, long budgetBytesPerDevice) {
+    if (devices == null || devices.length == 0) {
+      throw new IllegalArgumentException("no device");
+    }
+    _devices = devices.clone();
+    _residentBytes = new AtomicLongArray(_devices.length);
+    _budgetBytesPerDevice = Math.max(0, budgetBytesPerDevice);
+  }
 
   GpuSegmentCache(int device) {
-    _device = device;
+    this(new int[]{device}, 0);
+  }
+
+  int[] devices() {
+    return _devices.clone();
+  }
+
+  long residentBytes(int deviceSlot) {
+    return _residentBytes.get(deviceSlot);
   }
 
   /** The device copy of the segment, or null when its queries keep the CPU plan. */
@@ -38,26 +73,110 @@ final class GpuSegmentCache {
       return null;
     }
     Optional<GpuSegment> cached = _segments.get(indexSegment);
-    if (cached == null) {
+    if (cached == null || (cached.isPresent() && cached.get().handle() == 0)) {       // never opened, or evicted under the budget since
       synchronized (this) {
         cached = _segments.get(indexSegment);
-        if (cached == null) {
+        if (cached == null || (cached.isPresent() && cached.get().handle() == 0)) {
+          if (cached != null) {
+            forget(cached.get());
+          }
           cached = open(indexSegment);
           _segments.put(indexSegment, cached);
         }
       }
     }
+    cached.ifPresent(GpuSegment::touch);
     return cached.orElse(null);
   }
 
-  private Optional<GpuSegment> open(IndexSegment indexSegment) {
+  /**
+   * The segment is going away (IndexSegment.destroy(): the server dropped, replaced or reloaded it; no query holds it any more --
+   * SegmentDataManager's reference count guarantees that before destroy() runs): its HBM is given back now.
+   */
+  void release(IndexSegment indexSegment) {
+    Optional<GpuSegment> cached = _segments.remove(indexSegment);
+    if (cached != null && cached.isPresent()) {
+      GpuSegment segment = cached.get();
+      if (segment.closeIfIdle()) {
+        forget(segment);
+      }
+      // (a pinned segment -- a caller broke the contract above -- is left to the Cleaner)
+    }
+  }
+
+  private int slotOf(int device) {
+    for (int i = 0; i < _devices.length; i++) {
+      if (_devices[i] == device) {
+        return i;
+      }
+    }
+    return 0;
+  }
+
+  private void forget(GpuSegment segment) {
+    long bytes = segment.deviceBytes();
+    if (bytes > 0) {
+      _residentBytes.addAndGet(slotOf(segment.device()), -bytes);
+    }
+  }
+
+  /** The device a new segment goes to: the one with the fewest resident bytes (the lowest-numbered one among equals). */
+  private int leastLoadedSlot() {
+    int best = 0;
+    for (int i = 1; i < _devices.length; i++) {
+      if (_residentBytes.get(i) < _residentBytes.get(best)) {
+        best = i;
+      }
+    }
+    return best;
+  }
+
+  /** Under the budget: close least-recently-used idle segments of the device until `incomingBytes` more fit (or nothing idle is left). */
+  private void makeRoom(int slot, long incomingBytes) {
+    if (_budgetBytesPerDevice == 0 || _residentBytes.get(slot) + incomingBytes <= _budgetBytesPerDevice) {
+      return;
+    }
+    List<GpuSegment> candidates = new ArrayList<>();
+    synchronized (_segments) {
+      for (Optional<GpuSegment> value : _segments.values()) {
+        if (value.isPresent() && value.get().device() == _devices[slot] && value.get().handle() != 0) {
+          candidates.add(value.get());
+        }
+      }
+    }
+    candidates.sort(Comparator.comparingLong(GpuSegment::lastUsedNanos));
+    for (GpuSegment victim : candidates) {
+      if (_residentBytes.get(slot) + incomingBytes <= _budgetBytesPerDevice) {
+        return;
+      }
+      if (victim.closeIfIdle()) {
+        forget(victim);
+        LOGGER.info("Segment {} left device {} (HBM budget); it is re-opened by the next query that reaches it", victim.getSegmentName(), _devices[slot]);
+      }
+    }
+  }
+
+  /** On-disk bytes of the segment: what its device copy will roughly take (index buffers are copied as they are). */
+  private static long estimatedBytes(IndexSegment indexSegment) {
     try {
-      GpuSegment segment = GpuSegment.open(indexSegment, _device);
-      long handle = segment.handle();
-      // the action must not reference `segment` or `indexSegment` (it would keep them reachable)
-      CLEANER.register(indexSegment, () -> PinotGpuNative.segmentClose(handle));
-      LOGGER.info("Segment {} resident on device {}: {} bytes of HBM", indexSegment.getSegmentName(), _device,
-          PinotGpuNative.segmentDeviceBytes(handle));
+      return indexSegment instanceof ImmutableSegment ? Math.max(0, ((ImmutableSegment) indexSegment).getSegmentSizeBytes()) : 0;
+    } catch (RuntimeException e) {
+      return 0;
+    }
+  }
+
+  private Optional<GpuSegment> open(IndexSegment indexSegment) {
+    int slot = leastLoadedSlot();
+    int device = _devices[slot];
+    try {
+      makeRoom(slot, estimatedBytes(indexSegment));
+      GpuSegment segment = GpuSegment.open(indexSegment, device);
+      _residentBytes.addAndGet(slot, segment.deviceBytes());
+      GpuSegment.HandleBox box = segment.box();
+      // the action must not reference `segment` or `indexSegment` (it would keep them reachable): the box holds the handle and nothing else
+      CLEANER.register(indexSegment, box::close);
+      LOGGER.info("Segment {} resident on device {}: {} bytes of HBM ({} bytes on that device now)", indexSegment.getSegmentName(), device,
+          segment.deviceBytes(), _residentBytes.get(slot));
       return Optional.of(segment);
     } catch (Exception | UnsatisfiedLinkError e) {
       LOGGER.warn("Segment {} stays on the CPU plan: {}", indexSegment.getSegmentName(), e.toString());

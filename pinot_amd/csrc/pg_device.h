@@ -24,6 +24,7 @@ constexpr int kStackDepth = 8;
 constexpr int kBlockThreads = 256;              // scan_agg_kernel: at most 4 wavefronts per workgroup
 constexpr int kHistBlockThreads = 1024;         // scan_hist_kernel: 16 wavefronts share one LDS histogram
 constexpr unsigned long long kPartialHistAlarm = 1ull;   // BlockPartial.flags
+constexpr unsigned long long kPartialStale = 2ull;       // BlockPartial.flags of a FOLDED record: a workgroup's record did not carry this launch's stamp
 constexpr int kGroupBlockThreads = 1024;        // scan_group_kernel: up to 16 wavefronts share one LDS group table
 
 enum LeafKind : int32_t {
@@ -153,6 +154,8 @@ struct BlockPartial {
   unsigned long long cyc[4];   // PG_CFG_PROFILE_WAVES: shader cycles per wave summed: memory wait, filter, aggregate, whole loop
   unsigned long long flags;    // OR over the workgroups: kPartialHistAlarm (pg_scan_hist.h) = a histogram counter may have left its field
   unsigned long long entries;  // numEntriesScannedInFilter counted by the kernel: applyAnd entries of kNodeCountEntries leaves / the extra entries of kNodeLeapfrog2
+  unsigned long long stamp;    // in-kernel fold: ScanParams.host_seq of the launch that wrote this record (publish_block_partial checks it: a record of
+                               // an earlier launch in the same slot turns into kPartialStale -> PG_ERR_INTERNAL, never into a wrong COUNT / SUM)
   // typed columns only (scan_agg_kernel<.., kTyped = true>): double sums, and 64-bit min / max keys (raw LONG value, or the
   // order-preserving integer image of a raw FLOAT / DOUBLE value)
   double fsum[kMaxAggCols];

@@ -68,7 +68,7 @@ struct Engine {
   bool double_buffer = false;
   bool direct_result = true; // PINOT_GPU_DIRECT_RESULT=0: the folded partial is copied device -> host with a copy command
   int fold_finalize = -1;    // PINOT_GPU_FOLD_FINALIZE: 1 the scan kernel's last workgroup folds the workgroups' records itself, 0 finalize_partials_kernel
-                             // does in a launch of its own, -1 (default) fold on segments of at most kFoldMaxTiles tiles
+                             // does in a launch of its own, -1 (default) = 1: at every size
   int fold_one_counter = 1;  // PINOT_GPU_FOLD_ONE_COUNTER=0: grids of at most 64 workgroups also arrive on eight shard counters + the top one
   bool poll_result = true;   // PINOT_GPU_POLL_RESULT=0: pg_execute always waits with hipStreamSynchronize instead of spinning on the pinned record's sequence number
   bool lane_skip = true;     // PINOT_GPU_LANE_SKIP=0: the aggregating kernels load a tile's value bytes for every lane, matches or not
@@ -327,7 +327,6 @@ pg_status ensure_set(ExecCtx* c, size_t index, size_t bytes) {
 }
 
 constexpr long long kBatchMaxTiles = 32768;       // items of up to 64 Mi docs may share a batch launch (pg_execute_batch); larger ones run their own kernel
-constexpr long long kFoldMaxTiles = 65536;        // segments up to 128 Mi docs fold their records in the scan kernel (ExecCtx::d_done)
 constexpr int kMaxGroupSlots = 0x7FFFFFFF;        // raw keys are ints: the reference's ArrayBasedHolder + IntMapBasedHolder range (DictionaryBasedGroupKeyGenerator.java:164-184)
 constexpr size_t kGroupTableKeepBytes = 1ull << 31; // a direct-indexed table above this is freed after the query instead of staying with the context
 constexpr size_t kArenaKeepBytes = 1ull << 30;      // same for the scratch arena
@@ -1488,6 +1487,35 @@ double key64_to_double(const ColumnDev& col, long long key) {
   return v;
 }
 
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  std::this_thread::yield();
+#endif
+}
+
+// Bounded spin on a pinned sequence number (a query is tens of microseconds to a millisecond of device time: polling beats the
+// stream-synchronise wake-up by ~10 us), then the blocking wait: a combine pool may have twice as many such threads as the host has
+// cores, none of them may hold a core for longer than its kernel plausibly runs.  `docs`: what the launch scans -- the bound is
+// 300 us + 1 ns per 1000 docs (a 1 B-row scan is ~0.6 ms).
+template <typename Done>
+pg_status wait_polled(hipStream_t stream, long long docs, Done&& done) {
+  long long spins = 0;
+  std::chrono::steady_clock::time_point until;
+  while (!done()) {
+    cpu_relax();
+    if ((++spins & 0x3FF) != 0) continue;
+    const auto now = std::chrono::steady_clock::now();
+    if (spins == 0x400) { until = now + std::chrono::nanoseconds(300'000 + docs / 1000); continue; }
+    if (now >= until || hipStreamQuery(stream) != hipErrorNotReady) { HIP_TRY(hipStreamSynchronize(stream)); break; }      // finished (or failed) without publishing: the stream's verdict
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return PG_OK;
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -2573,9 +2601,10 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     };
     // The workgroups' records are folded by the scan kernel's last workgroup, straight into the pinned host record.
     // Measured (profiles/r3, tools/ab_r3.py): the fold costs the kernel 5.5 us of tail on a 1024-workgroup grid where the finalize launch
-    // costs 8.8 us (boundary + a one-workgroup kernel); at 10 M rows that is 13 % of the query's device time, at 1 B rows nothing -- there
-    // the scan kernel is left alone, so that its HIP-event / rocprofv3 duration is the scan and nothing else.
-    const bool folded = g_engine.fold_finalize >= 0 ? g_engine.fold_finalize != 0 : ((long long)seg->num_docs + 2047) / 2048 <= kFoldMaxTiles;
+    // costs 8.8 us (boundary + a one-workgroup kernel) -- 13 % of a 10 M-row query's device time.  Round 4: at EVERY size (1 B-row scans
+    // were left with the separate launch so that the scan kernel's profiler duration was "the scan and nothing else"; the query paid
+    // ~15 us for that, and its roofline fraction is a statement about the query, not about its largest kernel).
+    const bool folded = g_engine.fold_finalize >= 0 ? g_engine.fold_finalize != 0 : true;
     const unsigned long long seq = ++ctx->seq;
     sp.done_counter = folded ? ctx->d_done : nullptr;
     sp.host_out = g_engine.direct_result ? ctx->h_record_dev : nullptr;
@@ -2637,20 +2666,18 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (g_engine.poll_result && !post_work && !timed) {
       // nothing follows the kernel on the stream: the record's sequence number is the completion signal
       volatile unsigned long long* flag = &ctx->h_record->seq;
-      long long spins = 0;
-      while (*flag != seq) {
-        if ((++spins & 0xFFFF) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) {      // finished (or failed) without publishing: fall back to the stream's verdict
-          HIP_TRY(hipStreamSynchronize(ctx->stream));
-          if (*flag != seq) return fail(PG_ERR_INTERNAL, "the scan kernel finished without publishing its record");
-        }
-      }
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      st = wait_polled(ctx->stream, (long long)seg->num_docs, [&] { return *flag == seq; });
+      if (st != PG_OK) return st;
+      if (*flag != seq) return fail(PG_ERR_INTERNAL, "the scan kernel finished without publishing its record");
     } else {
       HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     if (count_leap2 && ctx->h_record->leap_seq != seq) return fail(PG_ERR_INTERNAL, "the leap-frog chain kernel did not publish its result");
     if (g_engine.direct_result && ctx->h_record->seq != seq) return fail(PG_ERR_INTERNAL, "the scan kernel's record carries sequence %llu, expected %llu", ctx->h_record->seq, seq);
     const BlockPartial& fp = *ctx->h_partial;
+    // (the in-kernel fold orders the workgroups' records against their arrival counter through write-through stores, not through a
+    //  release / acquire pair: every record carries its launch's stamp and a foreign one is an error, never an answer)
+    if (fp.flags & kPartialStale) return fail(PG_ERR_INTERNAL, "the scan kernel's fold read a record that was not written by this launch (sequence %llu)", seq);
     // plain narrow counters: the counters must add up to the matches (a wrapped counter always leaves the total short)
     const bool hist_wrapped = use_hist && !hist_guarded && hist_cw < 32 && (unsigned long long)fp.sum[1] != fp.count;
     if (use_hist && (hist_wrapped || (fp.flags & kPartialHistAlarm))) {
@@ -3587,7 +3614,7 @@ struct WorkerPool {
         lk.unlock();
         const auto until = std::chrono::steady_clock::now() + std::chrono::nanoseconds(kSpinNs);
         for (int i = 0; generation_hint.load(std::memory_order_relaxed) == seen; ++i) {
-          __builtin_ia32_pause();
+          cpu_relax();
           if ((i & 255) == 255 && std::chrono::steady_clock::now() >= until) break;
         }
         lk.lock();
@@ -3638,7 +3665,25 @@ struct WorkerPool {
   }
 };
 WorkerPool g_pool;
-std::mutex g_batch_call_mu;              // one batch at a time uses the pool (a second caller waits its turn)
+// The pool runs one job at a time.  A second pg_execute_batch does NOT wait for it (two queries of a server used to run one after the
+// other, end to end): it lowers its items on its own thread -- microseconds each -- or, when its items run whole kernels inside their
+// claim (group-bys, 1 B-row scans), on short-lived threads of its own.  The lock covers the lowering phase only; the shared launches
+// and their waits run on per-call BatchCtx's outside it.
+std::mutex g_pool_mu;
+void run_items(int count, int threads, int items_per_claim, bool heavy, const std::function<void(int)>& fn) {
+  {
+    std::unique_lock<std::mutex> lk(g_pool_mu, std::try_to_lock);
+    if (lk.owns_lock()) { g_pool.run(count, threads, items_per_claim, fn); return; }
+  }
+  const int extra = heavy ? std::min(threads, count) - 1 : 0;
+  if (extra <= 0) { for (int i = 0; i < count; ++i) fn(i); return; }
+  std::atomic<int> next{0};
+  auto drain = [&] { for (;;) { const int i = next.fetch_add(1, std::memory_order_relaxed); if (i >= count) return; fn(i); } };
+  std::vector<std::thread> own;
+  for (int t = 0; t < extra; ++t) own.emplace_back(drain);
+  drain();
+  for (auto& t : own) t.join();
+}
 
 // Device-side state of one batch launch, reused from call to call.
 struct BatchCtx {
@@ -3709,8 +3754,23 @@ pg_status ensure_batch_ctx(BatchCtx* b, int items, size_t partials) {
   return PG_OK;
 }
 
-// The deferred items of one device: one launch, every item folding into its own pinned record.
-pg_status run_deferred(int device, const std::vector<int>& items, std::vector<Deferred>& defs, pg_segment* const* segments, pg_result* results, pg_status* statuses) {
+// The deferred items of one device: one launch, every item folding into its own pinned record.  Two halves, so that a batch spanning
+// several devices has every device's launch in flight before it waits for any (segment s on device s mod N: BaseCombineOperator.java:85-142
+// runs all segments of a query on one pool): enqueue_deferred copies the items and launches, finish_deferred waits and converts.
+struct DeferredLaunch {
+  BatchCtx* b = nullptr;
+  int device = -1, n = 0;
+  std::vector<int> items, blocks;
+  long long total_blocks = 0, docs = 0;
+  unsigned long long seq = 0;
+  bool timed = false, launched = false;
+  std::chrono::steady_clock::time_point t0, t1;
+  ~DeferredLaunch() { if (b) { std::lock_guard<std::mutex> lk(g_batch_mu); g_batch_free.push_back(b); } }
+};
+
+pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_segment* const* segments) {
+  const int device = L->device;
+  const std::vector<int>& items = L->items;
   HIP_TRY(hipSetDevice(device));
   BatchCtx* b = nullptr;
   {
@@ -3718,14 +3778,15 @@ pg_status run_deferred(int device, const std::vector<int>& items, std::vector<De
     for (size_t i = 0; i < g_batch_free.size(); ++i) if (g_batch_free[i]->device == device) { b = g_batch_free[i]; g_batch_free.erase(g_batch_free.begin() + (long)i); break; }
   }
   if (!b) { b = new BatchCtx(); b->device = device; }
-  struct Return { BatchCtx* b; ~Return() { std::lock_guard<std::mutex> lk(g_batch_mu); g_batch_free.push_back(b); } } give_back{b};
-  const int n = (int)items.size();
+  L->b = b;
+  const int n = L->n = (int)items.size();
   // Workgroups per item in proportion to its tiles, about sixteen per CU in total (four waves each: ~4x what is resident, so that
   // the items' tails overlap other items' scans); never more than the item would get on its own.
   long long total_tiles = 0;
-  for (int i : items) total_tiles += ((long long)segments[i]->num_docs + 2047) / 2048;
+  for (int i : items) { total_tiles += ((long long)segments[i]->num_docs + 2047) / 2048; L->docs += (long long)segments[i]->num_docs; }
   const long long budget = (long long)segments[items[0]]->num_cus * g_engine.batch_blocks_per_cu;
-  std::vector<int> blocks((size_t)n);
+  std::vector<int>& blocks = L->blocks;
+  blocks.assign((size_t)n, 0);
   size_t partials = 0;
   long long total_blocks = 0;
   bool one_slot = true;
@@ -3738,11 +3799,12 @@ pg_status run_deferred(int device, const std::vector<int>& items, std::vector<De
     total_blocks += blocks[(size_t)k];
     one_slot = one_slot && d.one_slot;
   }
+  L->total_blocks = total_blocks;
   pg_status st = ensure_batch_ctx(b, n, partials);
   if (st != PG_OK) return st;
   size_t off = 0;
   uint32_t first = 0;
-  const unsigned long long seq = ++b->seq;
+  const unsigned long long seq = L->seq = ++b->seq;
   for (int k = 0; k < n; ++k) {
     ScanParams sp = defs[(size_t)items[(size_t)k]].sp;
     sp.partials = b->d_partials + off;
@@ -3755,39 +3817,47 @@ pg_status run_deferred(int device, const std::vector<int>& items, std::vector<De
     first += (uint32_t)blocks[(size_t)k];
   }
   b->h_first[n] = first;
-  const bool timed = (g_engine.flags & PG_CFG_TIME_KERNELS) != 0;
-  static const bool trace = getenv("PINOT_GPU_BATCH_TRACE") != nullptr;
-  const auto t0 = std::chrono::steady_clock::now();
+  L->timed = (g_engine.flags & PG_CFG_TIME_KERNELS) != 0;
+  L->t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipMemcpyAsync(b->d_blob, b->h_blob, b->items_offset + sizeof(ScanParams) * (size_t)n, hipMemcpyHostToDevice, b->stream));
-  if (timed) HIP_TRY(hipEventRecord(b->ev[0], b->stream));
+  if (L->timed) HIP_TRY(hipEventRecord(b->ev[0], b->stream));
   launch_scan_private_batch(one_slot, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
   HIP_TRY(hipGetLastError());
-  if (timed) HIP_TRY(hipEventRecord(b->ev[1], b->stream));
-  const auto t1 = std::chrono::steady_clock::now();
-  if (g_engine.poll_result && !timed) {
+  if (L->timed) HIP_TRY(hipEventRecord(b->ev[1], b->stream));
+  L->t1 = std::chrono::steady_clock::now();
+  L->launched = true;
+  return PG_OK;
+}
+
+pg_status finish_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_result* results, pg_status* statuses) {
+  BatchCtx* b = L->b;
+  const int n = L->n;
+  const unsigned long long seq = L->seq;
+  static const bool trace = getenv("PINOT_GPU_BATCH_TRACE") != nullptr;
+  HIP_TRY(hipSetDevice(L->device));
+  if (g_engine.poll_result && !L->timed) {
     // every item publishes its own pinned record: their sequence numbers are the completion signal (as in pg_execute)
-    long long spins = 0;
-    for (int k = 0; k < n; ++k) {
-      volatile unsigned long long* flag = &b->h_records[k].seq;
-      while (*flag != seq) {
-        if ((++spins & 0xFFFF) == 0 && hipStreamQuery(b->stream) != hipErrorNotReady) { HIP_TRY(hipStreamSynchronize(b->stream)); break; }
-      }
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    int k = 0;
+    const pg_status st = wait_polled(b->stream, L->docs, [&] { while (k < n && *(volatile unsigned long long*)&b->h_records[k].seq == seq) ++k; return k == n; });
+    if (st != PG_OK) return st;
   } else {
     HIP_TRY(hipStreamSynchronize(b->stream));
   }
   const auto t2 = std::chrono::steady_clock::now();
   float ms = 0.f;
-  if (timed) HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
-  if (trace) fprintf(stderr, "  run_deferred: %d items %lld workgroups, sizeof(ScanParams) %zu, enqueue %.1f us, wait %.1f us, kernel %.1f us\n", n, total_blocks, sizeof(ScanParams),
-                     std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(), ms * 1e3);
+  if (L->timed) HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
+  if (trace) fprintf(stderr, "  deferred launch on device %d: %d items %lld workgroups, sizeof(ScanParams) %zu, enqueue %.1f us, wait %.1f us, kernel %.1f us\n", L->device, n, L->total_blocks,
+                     sizeof(ScanParams), std::chrono::duration<double, std::micro>(L->t1 - L->t0).count(), std::chrono::duration<double, std::micro>(t2 - L->t1).count(), ms * 1e3);
   for (int k = 0; k < n; ++k) {
-    const int i = items[(size_t)k];
+    const int i = L->items[(size_t)k];
     if (b->h_records[k].seq != seq) { statuses[i] = fail(PG_ERR_INTERNAL, "batch item %d did not publish its record", i); continue; }
+    if (b->h_records[k].partial.flags & kPartialStale) { statuses[i] = fail(PG_ERR_INTERNAL, "batch item %d: the fold read a record that was not written by this launch", i); continue; }
     defs[(size_t)i].convert(b->h_records[k].partial, &results[i]);
-    results[i].device_ms = ms;                 // the ONE launch all items of the batch share
-    results[i].dominant_kernel_ms = ms;
+    // ONE launch serves all items of the device: each item is charged its share of the workgroups, so that summing device_ms over a
+    // batch's results gives the launch's time once (pg_result.device_ms of a batch item is an apportioned figure, not a measurement of its own)
+    const float share = L->total_blocks > 0 ? ms * (float)L->blocks[(size_t)k] / (float)L->total_blocks : 0.f;
+    results[i].device_ms = share;
+    results[i].dominant_kernel_ms = share;
     statuses[i] = PG_OK;
   }
   return PG_OK;
@@ -3800,7 +3870,6 @@ pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* q
   if (count < 0 || (count > 0 && (!segments || !queries || !results || !statuses))) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
   for (int i = 0; i < count; ++i) { memset(&results[i], 0, sizeof(pg_result)); statuses[i] = PG_ERR_INVALID_ARGUMENT; }
   if (count == 0) return PG_OK;
-  std::lock_guard<std::mutex> one_batch(g_batch_call_mu);
   static const bool trace = getenv("PINOT_GPU_BATCH_TRACE") != nullptr;      // host phases of every call on stderr
   const auto t_begin = std::chrono::steady_clock::now();
   std::vector<Deferred> defs((size_t)count);
@@ -3813,7 +3882,7 @@ pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* q
   // (an item too large for the shared launch runs its whole kernel inside its claim: such batches are claimed one item at a time)
   bool all_small = g_engine.batch_launch;
   for (int i = 0; i < count && all_small; ++i) all_small = segments[i] != nullptr && ((long long)segments[i]->num_docs + 2047) / 2048 <= kBatchMaxTiles;
-  g_pool.run(count, all_small ? threads : std::min(threads, count), all_small ? 8 : 1, [&](int i) {
+  run_items(count, all_small ? threads : std::min(threads, count), all_small ? 8 : 1, !all_small, [&](int i) {
     if (!segments[i] || !queries[i]) { statuses[i] = PG_ERR_INVALID_ARGUMENT; errors[(size_t)i] = "null segment or query"; return; }
     const auto t_item = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     statuses[i] = execute_one(segments[i], queries[i], &results[i], g_engine.batch_launch ? &defs[(size_t)i] : nullptr);
@@ -3821,14 +3890,24 @@ pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* q
     if (statuses[i] != PG_OK && statuses[i] != kDeferred) errors[(size_t)i] = g_error;      // (g_error is the worker's thread-local)
   });
   const auto t_lowered = std::chrono::steady_clock::now();
-  // 2. the deferred items, one launch per device
-  std::vector<int> devices;
-  for (int i = 0; i < count; ++i) if (statuses[i] == kDeferred && std::find(devices.begin(), devices.end(), segments[i]->device) == devices.end()) devices.push_back(segments[i]->device);
-  for (int dev : devices) {
-    std::vector<int> items;
-    for (int i = 0; i < count; ++i) if (statuses[i] == kDeferred && segments[i]->device == dev) items.push_back(i);
-    const pg_status st = run_deferred(dev, items, defs, segments, results, statuses);
-    if (st != PG_OK) for (int i : items) if (statuses[i] == kDeferred) { statuses[i] = st; errors[(size_t)i] = g_error; pg_result_free(&results[i]); }
+  // 2. the deferred items, one launch per device: every device's launch is enqueued before any of them is waited for
+  std::vector<std::unique_ptr<DeferredLaunch>> launches;
+  for (int i = 0; i < count; ++i) {
+    if (statuses[i] != kDeferred) continue;
+    DeferredLaunch* L = nullptr;
+    for (auto& l : launches) if (l->device == segments[i]->device) L = l.get();
+    if (!L) { launches.emplace_back(new DeferredLaunch()); L = launches.back().get(); L->device = segments[i]->device; }
+    L->items.push_back(i);
+  }
+  auto fail_items = [&](DeferredLaunch* L, pg_status st) {
+    for (int i : L->items) if (statuses[i] == kDeferred) { statuses[i] = st; errors[(size_t)i] = g_error; pg_result_free(&results[i]); }
+  };
+  for (auto& l : launches) { const pg_status st = enqueue_deferred(l.get(), defs, segments); if (st != PG_OK) fail_items(l.get(), st); }
+  for (auto& l : launches) {
+    if (!l->launched) continue;
+    const pg_status st = finish_deferred(l.get(), defs, results, statuses);
+    if (st != PG_OK) fail_items(l.get(), st);
+    else for (int i : l->items) if (statuses[i] != PG_OK) errors[(size_t)i] = g_error;
   }
   // pg_last_error of the caller: the first failed item's message
   for (int i = 0; i < count; ++i) if (statuses[i] != PG_OK) { g_error = "batch item " + std::to_string(i) + ": " + errors[(size_t)i]; break; }

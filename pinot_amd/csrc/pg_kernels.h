@@ -660,6 +660,7 @@ __device__ __forceinline__ void partial_identity(BlockPartial& acc) {
   acc.count = 0;
   acc.flags = 0;
   acc.entries = 0;
+  acc.stamp = 0;
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc.cyc[c] = 0;
 #pragma unroll
@@ -688,15 +689,16 @@ __device__ __forceinline__ void partial_merge(BlockPartial& acc, const BlockPart
 // What a fold has to look at: `slots` aggregation slots (BlockPartial.sum / kmin / kmax [0 .. slots)), the typed fields (fsum / kmin64 /
 // kmax64) and the PG_CFG_PROFILE_WAVES cycle counters only when the query uses them.  A record has thirty 64-bit-reduced fields; a
 // COUNT / one-column SUM needs five of them, and the wave-level reductions are what a one-workgroup fold spends its time on.
-struct FoldFields { int slots; bool typed; bool cycles; };
+struct FoldFields { int slots; bool typed; bool cycles; unsigned long long stamp; };      // stamp: what every record folded must carry (kCoherent folds)
 template <typename P>
-__device__ __forceinline__ FoldFields fold_fields_of(const P& p) { return FoldFields{p.fold_slots, p.fold_typed != 0, p.profile != 0}; }
+__device__ __forceinline__ FoldFields fold_fields_of(const P& p) { return FoldFields{p.fold_slots, p.fold_typed != 0, p.profile != 0, p.host_seq}; }
 
 // Every lane's record folded over the wave (all lanes return the same record).
 __device__ __forceinline__ void partial_wave_reduce(BlockPartial& acc, const FoldFields ff) {
   acc.count = (unsigned long long)wave_sum_i64((long long)acc.count);
   acc.entries = (unsigned long long)wave_sum_i64((long long)acc.entries);
-  acc.flags = __builtin_amdgcn_ballot_w64(acc.flags != 0ull) != 0ull ? 1ull : 0ull;      // single-bit vocabulary (kPartialHistAlarm)
+  acc.flags = (__builtin_amdgcn_ballot_w64((acc.flags & kPartialHistAlarm) != 0ull) != 0ull ? kPartialHistAlarm : 0ull) |      // two-bit vocabulary
+              (__builtin_amdgcn_ballot_w64((acc.flags & kPartialStale) != 0ull) != 0ull ? kPartialStale : 0ull);
   if (ff.cycles) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc.cyc[c] = (unsigned long long)wave_sum_i64((long long)acc.cyc[c]);
@@ -739,6 +741,9 @@ __device__ __forceinline__ BlockPartial fold_partials(const BlockPartial* partia
     const BlockPartial* b = partials + first + (long long)i * stride;
     acc.count += partial_word<kCoherent>(b, offsetof(BlockPartial, count));
     acc.flags |= partial_word<kCoherent>(b, offsetof(BlockPartial, flags));
+    // Records written by other workgroups of this launch are ordered against the arrival counter by the hardware's write-through
+    // stores, not by a release / acquire pair of the memory model: a record that is not this launch's must not become an answer.
+    if constexpr (kCoherent) acc.flags |= partial_word<kCoherent>(b, offsetof(BlockPartial, stamp)) != ff.stamp ? kPartialStale : 0ull;
     acc.entries += partial_word<kCoherent>(b, offsetof(BlockPartial, entries));
     if (ff.cycles) {
 #pragma unroll
@@ -814,7 +819,7 @@ __device__ __forceinline__ void store_host_record_by_wave0(HostRecord* host_out,
 static __global__ __launch_bounds__(kBlockThreads) void finalize_partials_kernel(BlockPartial* partials, int num_blocks, HostRecord* host_out, unsigned long long seq,
                                                                                  int slots, int typed, int cycles) {
   __shared__ BlockPartial red[kBlockThreads / 64];
-  const BlockPartial t = fold_partials(partials, 0, 1, num_blocks, red, FoldFields{slots, typed != 0, cycles != 0});
+  const BlockPartial t = fold_partials(partials, 0, 1, num_blocks, red, FoldFields{slots, typed != 0, cycles != 0, 0ull});
   if (threadIdx.x == 0) {
     if (host_out) red[0] = t;
     else partials[num_blocks] = t;
@@ -855,6 +860,7 @@ __device__ __forceinline__ void publish_block_partial(const P& p, BlockPartial* 
     if (threadIdx.x == 0) {
       BlockPartial acc = red[0];
       for (int w = 1; w < waves_per_block; ++w) partial_merge(acc, red[w]);
+      acc.stamp = p.host_seq;
       if (p.done_counter == nullptr) p.partials[block_index] = acc;
       else if (!arrive && p.host_out == nullptr) p.partials[1] = acc;
       else red[0] = acc;
@@ -888,7 +894,7 @@ __device__ __forceinline__ void publish_block_partial(const P& p, BlockPartial* 
     // the top counter; the workgroup completing that folds the eight shard records.  (On small grids the second hand-off costs more
     // than the shorter walk saves: 123 workgroups 13.7 -> 16.2 us.)
     t = fold_partials<true>(p.partials, (int)shard, kFoldShards, (int)in_shard, red, ff);
-    if (threadIdx.x == 0) red[0] = t;
+    if (threadIdx.x == 0) { t.stamp = p.host_seq; red[0] = t; }
     if (threadIdx.x < 64) {
       store_record_by_wave0<false>(&red[0], &p.partials[num_blocks + 1u + shard]);
       if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(p.done_counter + kFoldShards * kFoldStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == shards ? 1u : 0u;

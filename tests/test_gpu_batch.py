@@ -99,3 +99,114 @@ def test_batch_without_the_shared_launch(monkeypatch):
     finally:
         monkeypatch.delenv("PINOT_GPU_BATCH_LAUNCH")
         Engine(device_id=0, time_kernels=True)
+
+
+def _heavy_segment(n=48_000_017):
+    rng = np.random.default_rng(77)
+    v = S.Column.synthetic_uniform("v", n, (np.arange(5000, dtype=np.int64) * 7 + 3).astype(np.int32), seed=5)
+    k1 = S.Column.synthetic_uniform("k1", n, np.arange(700, dtype=np.int32) * 3 - 50, seed=8)
+    f = S.Column.synthetic_uniform("f", n, np.arange(100, dtype=np.int32), seed=6)
+    return S.SegmentData("heavy", n, [v, k1, f])
+
+
+def test_concurrent_batches_do_not_serialise(engine):
+    """Two queries of one server = two threads inside pg_execute_batch (SURVEY.md 8b Threading).  Thread A keeps the library busy with
+    batches of 32 group-bys over a 48 M-row segment (items that run whole kernels inside their claim: milliseconds per call, all of it
+    inside the native call -- the raw ctypes entry point, no Python-side conversion holding the GIL); thread B's small batch must come
+    back in its own time, not after A's call (it did, behind a process-wide mutex), and both get the oracle's answers."""
+    import ctypes as C
+    import threading
+    import time
+    heavy, small = _heavy_segment(), _segments()[:6]
+    gh, gs = engine.open(heavy), [engine.open(s) for s in small]
+    try:
+        hspecs = [Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(2, 0, 40 + i)), group_by=[1]) for i in range(32)]
+        sspecs = [_spec(seg, s, "sum") for s, seg in enumerate(small)]
+        want_h = oracle.execute(heavy, hspecs[3])
+        want_s = [oracle.execute(seg, sp) for seg, sp in zip(small, sspecs)]
+        nh = len(hspecs)
+        handles = (C.c_void_p * nh)(*[gh.handle] * nh)
+        queries = (C.POINTER(_abi.pg_query) * nh)(*[C.pointer(sp.c) for sp in hspecs])
+
+        def run_heavy(results, statuses):
+            t = time.perf_counter()
+            assert engine.execute_batch_raw(handles, queries, nh, results, statuses) == _abi.PG_OK
+            dt = time.perf_counter() - t
+            assert all(statuses[i] == _abi.PG_OK for i in range(nh))
+            from pinot_amd.query import Result
+            got = Result(results[3], hspecs[3])
+            for i in range(nh):
+                engine.lib.pg_result_free(C.byref(results[i]))
+            return dt, got
+
+        def run_small():
+            t = time.perf_counter()
+            got = engine.execute_batch(gs, sspecs)
+            return time.perf_counter() - t, got
+
+        for _ in range(3):
+            run_small()
+        solo = sorted(run_small()[0] for _ in range(15))[7]
+        res0, st0 = (_abi.pg_result * nh)(), (C.c_int * nh)()
+        run_heavy(res0, st0)
+        heavy_alone, got_h = run_heavy(res0, st0)
+        H.assert_results_equal(got_h, want_h)
+
+        stop, errors, heavy_calls = threading.Event(), [], []
+
+        def keep_busy():
+            try:
+                res, st = (_abi.pg_result * nh)(), (C.c_int * nh)()
+                while not stop.is_set():
+                    dt, got = run_heavy(res, st)
+                    heavy_calls.append(dt)
+                    H.assert_results_equal(got, want_h)
+            except Exception as e:      # noqa: BLE001
+                errors.append(e)
+
+        th = threading.Thread(target=keep_busy)
+        th.start()
+        try:
+            time.sleep(0.05)
+            lat = []
+            for _ in range(40):
+                dt, got = run_small()
+                lat.append(dt)
+                for s, (status, res) in enumerate(got):
+                    assert status == _abi.PG_OK
+                    H.assert_results_equal(res, want_s[s])
+        finally:
+            stop.set()
+            th.join()
+        assert not errors, errors
+        med = sorted(lat)[len(lat) // 2]
+        busy_call = sorted(heavy_calls)[len(heavy_calls) // 2]
+        print("small batch solo %.3f ms, beside the heavy batches %.3f ms; heavy call %.3f ms (alone %.3f ms), %d heavy calls meanwhile"
+              % (solo * 1e3, med * 1e3, busy_call * 1e3, heavy_alone * 1e3, len(heavy_calls)))
+        # behind a process-wide lock the small batch waited for the rest of a heavy call: half of one on average
+        assert busy_call > 8 * solo, "the heavy batch is not heavy enough to tell"
+        assert med < 0.3 * busy_call, "the small batch waited for the other query's batch: %.3f ms vs %.3f ms" % (med * 1e3, busy_call * 1e3)
+    finally:
+        gh.close()
+        [g.close() for g in gs]
+
+
+def test_batch_spanning_two_devices(engine):
+    """Segment s on device s mod N inside ONE process (the deployment shape: a Pinot server is one JVM): one pg_execute_batch
+    whose items live on two devices -- one launch per device, both in flight before either is waited for."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    segs = _segments()
+    for s, seg in enumerate(segs):
+        seg.desc.device_id = s % 2
+    opened = [engine.open(seg) for seg in segs]
+    try:
+        for shapes in (["sum"], ["sum", "group", "inverted", "minmax", "and2", "nofilter"]):
+            specs = [_spec(seg, s, shapes[s % len(shapes)]) for s, seg in enumerate(segs)]
+            for rep in range(2):
+                for s, (status, res) in enumerate(engine.execute_batch(opened, specs)):
+                    assert status == _abi.PG_OK
+                    H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
+    finally:
+        [g.close() for g in opened]
