@@ -38,6 +38,10 @@ char* ph_segment_describe(void* segment, int32_t* status);          /* JSON: col
 
 /* ---- GpuPlanMaker (InstancePlanMakerImplV2.makeSegmentPlanNode) + combine ---- */
 int32_t ph_plan_maker_init(int32_t device, int32_t time_kernels);
+/* gpu.devices ("0-7", "0,2,4", "0-3,6") parsed, and the device each of `count` segments of the given sizes goes to when opened in that
+ * order (least resident bytes first; an entry -(device << 48 | bytes) gives bytes back): JSON {"devices": [...], "placement": [...]}.
+ * No device is touched. */
+char* ph_plan_maker_placement(const char* devices_text, const int64_t* segment_bytes, int32_t count, int32_t* status);
 char* ph_parse_sql(const char* sql, int32_t* status);               /* QueryContextConverterUtils.getQueryContext for the SQL subset */
 char* ph_lower_predicate(const char* sql_predicate, const void* dict, int32_t cardinality, int32_t* status);   /* PredicateEvaluatorProvider */
 /* the physical filter operator tree of the WHERE clause (FilterPlanNode + FilterOperatorUtils: leaf operator per predicate, MatchAll / Empty folding,

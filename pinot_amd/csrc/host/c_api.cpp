@@ -357,6 +357,27 @@ int32_t ph_plan_maker_init(int32_t device, int32_t time_kernels) {
   });
 }
 
+// gpu.devices parsing and least-loaded placement (no device touched): "[d0, d1, ...]" for `text`, then the device each of the `count`
+// segment sizes goes to when opened in order -- the logic GpuPlanMaker.java / GpuSegmentCache.java carry in Java.
+char* ph_plan_maker_placement(const char* devices_text, const int64_t* segment_bytes, int32_t count, int32_t* status) {
+  std::string out;
+  *status = guarded([&] {
+    GpuPlanMaker pm;      // (not initialised: no device, no pg_init -- only its placement book)
+    try { pm.setDevices(GpuPlanMaker::parseDevices(devices_text ? devices_text : "")); } catch (const std::invalid_argument& e) { throw QueryException(e.what()); }
+    std::ostringstream o;
+    o << "{\"devices\": [";
+    for (size_t i = 0; i < pm.devices().size(); ++i) o << (i ? ", " : "") << pm.devices()[i];
+    o << "], \"placement\": [";
+    for (int32_t s = 0; s < count; ++s) {
+      if (segment_bytes[s] < 0) pm.releaseSegment((int)(-segment_bytes[s] >> 48), (-segment_bytes[s]) & ((1ll << 48) - 1));      // tests: -(device << 48 | bytes) releases
+      o << (s ? ", " : "") << (segment_bytes[s] < 0 ? -1 : pm.placeSegment((long long)segment_bytes[s]));
+    }
+    o << "]}";
+    out = o.str();
+  });
+  return *status == 0 ? strdup(out.c_str()) : nullptr;
+}
+
 // Parse only (no device): returns a JSON description of the QueryContext; used by the CPU-side tests.
 char* ph_parse_sql(const char* sql, int32_t* status) {
   std::string out;

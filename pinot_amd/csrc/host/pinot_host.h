@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -356,9 +357,22 @@ class GpuPlanMaker : public PlanMaker {
   static constexpr const char* kConfigBatch = "pinot.server.query.executor.gpu.batch";
   static constexpr const char* kConfigDevice = "pinot.server.query.executor.gpu.device";
   static constexpr const char* kConfigTimeKernels = "pinot.server.query.executor.gpu.time.kernels";
+  // pinot.server.query.executor.gpu.devices: "0-7", "0,2,4", "0-3,6" -- the devices ONE server process drives (a Pinot server is one JVM;
+  // segment s on device s mod N).  Default: the single device of gpu.device.  Twin of GpuPlanMaker.java / GpuSegmentCache.java.
+  static constexpr const char* kConfigDevices = "pinot.server.query.executor.gpu.devices";
+  static std::vector<int> parseDevices(const std::string& text);      // throws std::invalid_argument
+  const std::vector<int>& devices() const { return _devices; }
+  void setDevices(std::vector<int> devices) { _devices = std::move(devices); _residentBytes.assign(_devices.size(), 0); }
+  // The device a segment of `bytes` goes to: the one with the fewest resident bytes, the lowest-numbered among equals (for equal-sized
+  // segments that is s mod N in open order).  The bytes are booked there; releaseSegment gives them back.
+  int placeSegment(long long bytes);
+  void releaseSegment(int device, long long bytes);
  private:
   int _device = 0;
   bool _batch = true;
+  std::vector<int> _devices{0};
+  std::vector<long long> _residentBytes{0};
+  std::mutex _placementMu;
 };
 
 // DataTable V4 bytes of a results block (host/datatable_v4.cpp): what InstanceResponseBlock.toDataTable().toBytes() hands the broker.

@@ -657,11 +657,54 @@ void GpuPlanMaker::init(const std::map<std::string, std::string>& cfg) {
   auto it = cfg.find(kConfigDevice);
   _device = it == cfg.end() ? 0 : atoi(it->second.c_str());
   c.device_id = _device;
+  it = cfg.find(kConfigDevices);
+  setDevices(it == cfg.end() ? std::vector<int>{_device} : parseDevices(it->second));
+  c.device_id = _device = _devices[0];      // pg_init's device is only the default of segments that name none: the library switches to a segment's device in every call
   it = cfg.find(kConfigTimeKernels);
   if (it != cfg.end() && it->second == "true") c.flags |= PG_CFG_TIME_KERNELS;
   it = cfg.find(kConfigBatch);
   _batch = it == cfg.end() || it->second != "false";
   checkStatus(gpuAbi().init(&c), "initialising the GPU plan maker");
+}
+
+std::vector<int> GpuPlanMaker::parseDevices(const std::string& text) {
+  std::vector<int> out;
+  size_t pos = 0;
+  auto number = [](const std::string& t) {
+    size_t used = 0;
+    const int v = std::stoi(t, &used);
+    while (used < t.size() && isspace((unsigned char)t[used])) ++used;
+    if (used != t.size() || v < 0) throw std::invalid_argument("bad device number: " + t);
+    return v;
+  };
+  while (pos <= text.size()) {
+    const size_t comma = std::min(text.find(',', pos), text.size());
+    std::string item = text.substr(pos, comma - pos);
+    pos = comma + 1;
+    const size_t b = item.find_first_not_of(" \t"), e = item.find_last_not_of(" \t");
+    if (b == std::string::npos) continue;
+    item = item.substr(b, e - b + 1);
+    const size_t dash = item.find('-', 1);
+    const int first = number(dash == std::string::npos ? item : item.substr(0, dash));
+    const int last = dash == std::string::npos ? first : number(item.substr(dash + 1));
+    if (last < first) throw std::invalid_argument("bad device range: " + item);
+    for (int d = first; d <= last; ++d) if (std::find(out.begin(), out.end(), d) == out.end()) out.push_back(d);
+  }
+  if (out.empty()) throw std::invalid_argument("no device in: " + text);
+  return out;
+}
+
+int GpuPlanMaker::placeSegment(long long bytes) {
+  std::lock_guard<std::mutex> lk(_placementMu);
+  size_t best = 0;
+  for (size_t i = 1; i < _devices.size(); ++i) if (_residentBytes[i] < _residentBytes[best]) best = i;
+  _residentBytes[best] += std::max<long long>(bytes, 0);
+  return _devices[best];
+}
+
+void GpuPlanMaker::releaseSegment(int device, long long bytes) {
+  std::lock_guard<std::mutex> lk(_placementMu);
+  for (size_t i = 0; i < _devices.size(); ++i) if (_devices[i] == device) { _residentBytes[i] = std::max<long long>(0, _residentBytes[i] - std::max<long long>(bytes, 0)); return; }
 }
 
 // FilteredAggregationOperator (core/operator/query/FilteredAggregationOperator.java:68-110; lanes built by

@@ -43,7 +43,8 @@ def _lib():
     lib.ph_segment_load_directory.restype = vp
     lib.ph_segment_load_directory.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
     lib.ph_segment_describe.argtypes = [vp, C.POINTER(C.c_int32)]
-    for name in ("ph_parse_sql", "ph_lower_predicate", "ph_execute_sql", "ph_segment_describe"):
+    lib.ph_plan_maker_placement.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int32)]
+    for name in ("ph_parse_sql", "ph_lower_predicate", "ph_execute_sql", "ph_segment_describe", "ph_plan_maker_placement"):
         getattr(lib, name).restype = vp
     lib.ph_parse_sql.argtypes = [C.c_char_p, C.POINTER(C.c_int32)]
     lib.ph_lower_predicate.argtypes = [C.c_char_p, vp, C.c_int32, C.POINTER(C.c_int32)]
@@ -71,6 +72,15 @@ def lower_predicate(predicate_sql, dictionary_bytes, cardinality):
     lib = _lib()
     st = C.c_int32()
     return _take_json(lib, lib.ph_lower_predicate(predicate_sql.encode(), dictionary_bytes.ctypes.data, cardinality, C.byref(st)), st)
+
+
+def placement(devices_text, segment_bytes):
+    """GpuPlanMaker's gpu.devices parsing + least-loaded placement (no device touched): {"devices": [...], "placement": [...]}.
+    A negative entry -(device << 48 | bytes) gives bytes back (placement -1)."""
+    lib = _lib()
+    st = C.c_int32()
+    arr = (C.c_int64 * max(len(segment_bytes), 1))(*segment_bytes)
+    return _take_json(lib, lib.ph_plan_maker_placement(devices_text.encode(), arr, len(segment_bytes), C.byref(st)), st)
 
 
 def init_plan_maker(device=0, time_kernels=True):

@@ -111,6 +111,12 @@ def test_the_native_methods_over_the_golden_segment(engine, jvm):
                     assert isinstance(out[i], str) and out[i].startswith("%d\n" % _abi.PG_ERR_UNSUPPORTED) and "batch item 2" in out[i]
                 else:
                     same(out[i], through_the_c_abi(gseg, spec))
+            # a lane whose segment left the device between plan time and run time travels as handle 0 (GpuBatch.call): that item fails
+            # alone, the operators of the other lanes get their results
+            out = jvm.execute_batch([handle, 0, handle], [specs[0], specs[0], specs[1]])
+            assert isinstance(out[1], str) and out[1].startswith("%d\n" % _abi.PG_ERR_INVALID_ARGUMENT)
+            same(out[0], through_the_c_abi(gseg, specs[0]))
+            same(out[2], through_the_c_abi(gseg, specs[1]))
             # 64 items: the native method gives its local references back item by item (a JVM guarantees 16 without EnsureLocalCapacity)
             many = [Q.QuerySpec([(Q.SUM, c1), (Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(c1, 10 * i, 10 * i + 3000))) for i in range(64)]
             jh, jq = jvm.longs([handle] * len(many)), jvm.batch_queries(many)

@@ -217,3 +217,22 @@ def test_sql_parser_never_crashes_on_mutated_queries():
                 assert e.status in (1, 2, 3), (sql, e.status)
             checked += 1
     assert checked == 1600
+
+
+def test_gpu_devices_config_and_least_loaded_placement():
+    """pinot.server.query.executor.gpu.devices and where segments go (GpuPlanMaker / GpuSegmentCache, Java and C++ twins): one server
+    process drives every device of the node; equal-sized segments land on device s mod N in open order, unequal ones keep
+    the devices' resident bytes balanced, and a dropped segment's bytes make room again."""
+    from pinot_amd import host
+    assert host.placement("0-7", [])["devices"] == list(range(8))
+    assert host.placement("0,2,4", [])["devices"] == [0, 2, 4]
+    assert host.placement(" 0-3, 6 ,2", [])["devices"] == [0, 1, 2, 3, 6]
+    assert host.placement("5", [10, 10])["placement"] == [5, 5]
+    for bad in ("", "3-1", "a", "-1", "1-x"):
+        with pytest.raises(host.HostError):
+            host.placement(bad, [])
+    gb = 1 << 30
+    assert host.placement("0-7", [3 * gb] * 16)["placement"] == [s % 8 for s in range(16)]
+    assert host.placement("0-3", [8 * gb, 1 * gb, 1 * gb, 1 * gb, 1 * gb, 1 * gb, 1 * gb])["placement"] == [0, 1, 2, 3, 1, 2, 3]
+    # device 2 loses its 5 GB segment: the next segments go there first
+    assert host.placement("0-3", [5 * gb] * 4 + [-((2 << 48) | (5 * gb)), 2 * gb, 2 * gb, 2 * gb, 2 * gb])["placement"] == [0, 1, 2, 3, -1, 2, 2, 2, 0]
