@@ -23,6 +23,8 @@
 #include "../../include/pinot_gpu.h"
 #include "pg_device.h"
 #include "pg_filter_stats.h"
+#include "pg_filter_fsm.h"
+#include "pg_fsm_kernels.h"
 #include "pg_kernels.h"
 #include "pg_launch.h"
 
@@ -3558,6 +3560,60 @@ static pg_status replay_filter_stats(pg_segment* seg, const pg_query* q, pg_resu
   return PG_OK;
 }
 
+// The same count ON THE DEVICE, at any segment size, for the root ANDs pg_filter_fsm.h can compile (scan leaves, index-based leaves, ORs
+// of leaves -- `a AND b AND c`, `a AND (b OR c)`, the reference's golden filter): every leaf's docId set stays on the device as a
+// doc-order bitmap, the transducer's tables are built tile by tile and chained (pg_fsm_kernels.h).  Nothing but the count comes back.
+static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, const fstats::Fsm& fsm, pg_result* out) {
+  HIP_TRY(hipSetDevice(seg->device));
+  const long long tiles = std::max<long long>(1, ((long long)seg->num_docs + 2047) / 2048);
+  const size_t bitmap_bytes = (size_t)tiles * 256;
+  const int L = fsm.num_inputs, S = fsm.num_states;
+  const long long chunks = (tiles + kFsmChunk - 1) / kFsmChunk;
+  const size_t delta_bytes = ((size_t)S << L), tables_bytes = (size_t)tiles * (size_t)S * 4, chunk_bytes = (size_t)chunks * (size_t)S * 4;
+  const size_t total = bitmap_bytes * (size_t)L + ((delta_bytes + 255) & ~(size_t)255) + tables_bytes + ((chunk_bytes + 255) & ~(size_t)255) + 256;
+  uint8_t* d_base = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_base, total));
+  struct Free { uint8_t* p; ~Free() { (void)hipFree(p); } } free_it{d_base};
+  HIP_TRY(hipMemset(d_base, 0, bitmap_bytes * (size_t)L));          // the last tile's dwords past numDocs
+  FsmParams fp;
+  memset(&fp, 0, sizeof(fp));
+  for (int i = 0; i < L; ++i) {
+    pg_filter_node leaf;
+    memset(&leaf, 0, sizeof(leaf));
+    leaf.op = PG_FILTER_LEAF; leaf.predicate = fsm.input_predicate[(size_t)i];
+    pg_query lq;
+    memset(&lq, 0, sizeof(lq));
+    lq.filter = &leaf; lq.num_filter_nodes = 1;
+    lq.predicates = q->predicates; lq.num_predicates = q->num_predicates;
+    unsigned long long* d_bitmap = reinterpret_cast<unsigned long long*>(d_base + bitmap_bytes * (size_t)i);
+    const pg_status st = execute_impl(seg, &lq, nullptr, d_bitmap, nullptr, 0, nullptr);      // (returns with the copy done)
+    if (st != PG_OK) return st;
+    fp.leaf[i] = reinterpret_cast<const uint32_t*>(d_bitmap);
+  }
+  uint8_t* at = d_base + bitmap_bytes * (size_t)L;
+  uint8_t* d_delta = at; at += (delta_bytes + 255) & ~(size_t)255;
+  uint32_t* d_tables = reinterpret_cast<uint32_t*>(at); at += tables_bytes;
+  uint32_t* d_chunks = reinterpret_cast<uint32_t*>(at); at += (chunk_bytes + 255) & ~(size_t)255;
+  unsigned long long* d_entries = reinterpret_cast<unsigned long long*>(at);
+  HIP_TRY(hipMemcpy(d_delta, fsm.delta.data(), delta_bytes, hipMemcpyHostToDevice));
+  fp.delta = d_delta; fp.tables = d_tables;
+  fp.num_inputs = L; fp.num_states = S; fp.num_docs = seg->num_docs; fp.num_tiles = (int32_t)tiles;
+  const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)seg->num_cus * 8));
+  if (S <= 4) fsm_tiles_kernel<4><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
+  else if (S <= 8) fsm_tiles_kernel<8><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
+  else fsm_tiles_kernel<16><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
+  HIP_TRY(hipGetLastError());
+  fsm_chain_kernel<<<dim3((unsigned)chunks), dim3(1024), 0, 0>>>(d_tables, tiles, S, d_chunks);
+  HIP_TRY(hipGetLastError());
+  fsm_finish_kernel<<<dim3(1), dim3(1024), (size_t)chunks * (size_t)S * 4, 0>>>(d_chunks, (int)chunks, S, d_entries);
+  HIP_TRY(hipGetLastError());
+  unsigned long long entries = 0;
+  HIP_TRY(hipMemcpy(&entries, d_entries, 8, hipMemcpyDeviceToHost));
+  out->stats.num_entries_scanned_in_filter = (int64_t)entries;
+  out->filter_entries_exact = 1;
+  return PG_OK;
+}
+
 // pg_execute, or -- with `defer` -- its first half: kDeferred means the query was lowered but not launched (see Deferred).
 static pg_status execute_one(pg_segment* segment, const pg_query* query, pg_result* out_result, Deferred* defer) {
   if (!out_result) return fail(PG_ERR_INVALID_ARGUMENT, "null result");
@@ -3567,7 +3623,15 @@ static pg_status execute_one(pg_segment* segment, const pg_query* query, pg_resu
                                : execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr, true, defer);
   if (st == kDeferred) return st;
   // (enableNullHandling changes the iterator tree -- nulls are or-ed in, NOT takes the falses: the upper bound stands there)
-  if (st == PG_OK && !null_handling && !out_result->filter_entries_exact && (int64_t)segment->num_docs <= g_engine.exact_stats_docs) st = replay_filter_stats(segment, query, out_result);
+  if (st == PG_OK && !null_handling && !out_result->filter_entries_exact) {
+    // a leap-frogging filter: the transducer on the device where the shape compiles (any size; PINOT_GPU_FSM_STATS=0: never), else the
+    // host's replay of the iterator tree up to PINOT_GPU_EXACT_FILTER_STATS_DOCS docs, else the upper bound stands
+    fstats::Fsm fsm;
+    static const bool use_fsm = !(getenv("PINOT_GPU_FSM_STATS") && getenv("PINOT_GPU_FSM_STATS")[0] == '0');
+    static const long long fsm_min_docs = getenv("PINOT_GPU_FSM_MIN_DOCS") ? atoll(getenv("PINOT_GPU_FSM_MIN_DOCS")) : 0;
+    if (use_fsm && (long long)segment->num_docs >= fsm_min_docs && fstats::compile_fsm(query, &fsm)) st = device_fsm_filter_stats(segment, query, fsm, out_result);
+    else if ((int64_t)segment->num_docs <= g_engine.exact_stats_docs) st = replay_filter_stats(segment, query, out_result);
+  }
   if (st != PG_OK) pg_result_free(out_result);
   return st;
 }

@@ -1,0 +1,273 @@
+// numEntriesScannedInFilter of a leap-frogging root AND as a finite-state transducer over the docs -- what lets the DEVICE count it at any
+// segment size (pg_filter_stats.h replays the reference's iterator objects on the host, one advance() at a time, up to 64 Mi docs).
+//
+// Shapes: a root AND whose children are scan leaves, index-based leaves (sorted docId ranges, inverted-index / null bitmaps) or ORs of
+// such leaves -- `a AND b AND c`, `a AND (b OR c)`, the reference's own golden filter (sorted range AND (scan OR posting) AND scan AND scan).
+// What the reference does with them (docidsets/AndDocIdSet.java:73-172, dociditerators/AndDocIdIterator.java:41-80,
+// OrDocIdIterator.java:52-140, SVScanDocIdIterator.java:76-145), as a walk over the docs x = 0, 1, 2, ...:
+//   * AndDocIdSet first merges its index-based children into one bitmap and and-s its scan children into it in list order
+//     (ScanBasedDocIdIterator.applyAnd: one entry per docId still standing) -- per doc, an entry count that depends on the leaves' match
+//     bits only; the merged bitmap then leads the remaining (OR) children as one index-based child.  Without an index-based child the
+//     children leap-frog as they are.
+//   * AndDocIdIterator: exactly one child LEADS at any doc.  A leading scan leaf looks at every doc (one entry each) until it matches;
+//     at the leader's match the other children are asked about that doc in child order (a scan leaf: one entry) until one does not
+//     contain it -- that one leads from there -- and when all contain it the doc is a result and child 0 leads from the next doc,
+//     which it is asked about afresh.
+//   * An OR child is asked through OrDocIdIterator.advance(t): every member whose look-ahead is behind t scans on from t to ITS next
+//     match.  So a scan member of an OR looks at doc x iff x is a doc the OR is asked about, or it looked at x - 1 and did not match
+//     there ("open").  One bit of state per such member.
+// State = (leading child, "the next doc is asked afresh", the open bits); input = the leaves' match bits at the doc; output = entries.
+// The reachable states are enumerated here (at most kFsmMaxStates, else the shape stays with the host replay) into a table
+// delta[state << L | input] = next state | entries << 4.  Chunks of docs are functions {entry state} -> {exit state, entries}: lanes of
+// 32 docs, tiles of 64 lanes, tiles chained in order -- fsm_count_tiled below is that structure on the host (the CPU tests hold it
+// against the iterator replay and the oracle), the kernels in pg_fsm_kernels.h are the same arithmetic.
+// Host-side C++ only.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <map>
+#include <tuple>
+#include <vector>
+
+#include "pg_filter_stats.h"
+
+namespace pg {
+namespace fstats {
+
+constexpr int kFsmMaxStates = 16, kFsmMaxInputs = 8;
+
+struct Fsm {
+  int num_inputs = 0;                  // L: leaf bitmaps the walk reads
+  std::vector<int> input_predicate;    // [L] predicate index behind every input bit
+  int num_states = 0;                  // S; state 0 is where doc 0 is entered
+  std::vector<uint8_t> delta;          // [S << L] next state | entries << 4
+};
+
+namespace fsm_detail {
+
+struct Leaf { int input; bool scan; };                       // a leaf as the walk sees it: which input bit, and whether looking at a doc costs an entry
+struct Child {
+  enum Kind { kSet, kScan, kOr } kind = kSet;
+  std::vector<Leaf> members;                                  // kSet: the leaves and-ed into it (one, or the merged ones); kScan: one leaf; kOr: its members
+  std::vector<int> open_bit;                                  // kOr: per member, its bit in the state's open mask (-1: an index-based member)
+};
+struct Model {
+  int num_inputs = 0;
+  std::vector<Child> children;                                // of the AndDocIdIterator
+  std::vector<std::vector<int>> standing;                     // applyAnd: per and-ed scan leaf, the inputs that must all be set for its entry at a doc
+  int num_open = 0;
+};
+
+inline bool contains(const Child& c, unsigned input) {
+  if (c.kind == Child::kOr) { for (const Leaf& l : c.members) if ((input >> l.input) & 1u) return true; return false; }
+  for (const Leaf& l : c.members) if (!((input >> l.input) & 1u)) return false;
+  return true;
+}
+
+struct State { int leader; int fresh; unsigned open; };
+inline bool operator<(const State& a, const State& b) { return std::tie(a.leader, a.fresh, a.open) < std::tie(b.leader, b.fresh, b.open); }
+
+inline State step(const Model& m, State s, unsigned input, int* entries) {
+  int inc = 0;
+  for (const auto& need : m.standing) { bool all = true; for (int i : need) all = all && ((input >> i) & 1u); inc += all ? 1 : 0; }
+  const int k = (int)m.children.size();
+  std::vector<char> asked((size_t)k, 0);
+  if (s.fresh) asked[0] = 1;                                   // child 0 is advanced to this doc afresh (AndDocIdIterator.next() after a result / at doc 0)
+  State out = s;
+  out.fresh = 0;
+  if (m.children[(size_t)s.leader].kind == Child::kScan) inc += 1;           // the leading scan leaf looks at every doc
+  if (contains(m.children[(size_t)s.leader], input)) {
+    int next_leader = 0, result = 1;
+    for (int i = 0; i < k; ++i) {
+      if (i == s.leader) continue;
+      asked[(size_t)i] = 1;
+      if (m.children[(size_t)i].kind == Child::kScan) inc += 1;
+      if (!contains(m.children[(size_t)i], input)) { next_leader = i; result = 0; break; }
+    }
+    out.leader = next_leader;
+    out.fresh = result;
+  }
+  for (int c = 0; c < k; ++c) {
+    const Child& ch = m.children[(size_t)c];
+    if (ch.kind != Child::kOr) continue;
+    for (size_t j = 0; j < ch.members.size(); ++j) {
+      const int bit = ch.open_bit[j];
+      if (bit < 0) continue;
+      const bool cover = asked[(size_t)c] || ((s.open >> bit) & 1u);
+      inc += cover ? 1 : 0;
+      const bool still_open = cover && !((input >> ch.members[j].input) & 1u);
+      out.open = (out.open & ~(1u << bit)) | ((still_open ? 1u : 0u) << bit);
+    }
+  }
+  *entries = inc;
+  return out;
+}
+
+}  // namespace fsm_detail
+
+// The root AND of `q` as a transducer; false when the shape is not one of the above or needs more than kFsmMaxStates states.
+inline bool compile_fsm(const pg_query* q, Fsm* out) {
+  using namespace fsm_detail;
+  if (q->num_filter_nodes < 3 || malformed(q)) return false;
+  const std::vector<Words> no_words((size_t)std::max(q->num_predicates, 1));
+  TreeBuilder tb(q, &no_words);
+  const int root = q->num_filter_nodes - 1;
+  if (q->filter[root].op != PG_FILTER_AND) return false;
+  Model m;
+  std::vector<int> input_predicate;
+  auto leaf_of = [&](int node, Leaf* l) {
+    const pg_filter_node& n = q->filter[node];
+    if (n.op != PG_FILTER_LEAF) return false;
+    const LeafClass c = classify(q->predicates[n.predicate]);
+    if (c == LeafClass::kMatchAll || c == LeafClass::kEmpty) return false;      // (FilterOperatorUtils folds constants away before a tree exists)
+    auto it = std::find(input_predicate.begin(), input_predicate.end(), n.predicate);
+    if (it == input_predicate.end()) { input_predicate.push_back(n.predicate); it = input_predicate.end() - 1; }
+    l->input = (int)(it - input_predicate.begin());
+    l->scan = c == LeafClass::kScan;
+    return true;
+  };
+  struct Raw { Child child; bool index; };
+  std::vector<Raw> raw;
+  for (int kid : tb.children_of(root)) {
+    Raw r;
+    r.index = false;
+    Leaf l;
+    if (leaf_of(kid, &l)) {
+      r.child.kind = l.scan ? Child::kScan : Child::kSet;
+      r.child.members.push_back(l);
+      r.index = !l.scan;
+    } else if (q->filter[kid].op == PG_FILTER_OR) {
+      r.child.kind = Child::kOr;
+      int num_sorted = 0, num_members = 0;
+      for (int g : tb.children_of(kid)) {
+        if (!leaf_of(g, &l)) return false;
+        r.child.members.push_back(l);
+        num_members++;
+        num_sorted += classify(q->predicates[q->filter[g].predicate]) == LeafClass::kSorted ? 1 : 0;
+      }
+      if (num_members < 2) return false;
+      // (OrDocIdSet.java:62-126 merges two or more SORTED members into one bitmap iterator; an OR of nothing else IS that iterator, an
+      //  index-based child of the AND -- a shape left to the replay)
+      if (num_sorted == num_members) return false;
+    } else {
+      return false;                                             // NOT / nested AND under the root AND: the host replay's
+    }
+    raw.push_back(std::move(r));
+  }
+  if ((int)input_predicate.size() > kFsmMaxInputs) return false;
+  int num_index = 0, num_scan = 0;
+  for (const Raw& r : raw) { num_index += r.index ? 1 : 0; num_scan += r.child.kind == Child::kScan ? 1 : 0; }
+  if ((num_index > 0 && num_scan > 0) || num_index > 1) {
+    // AndDocIdSet.java:127-165: one bitmap of the index-based children, the scan children and-ed into it in list order
+    Child merged;
+    merged.kind = Child::kSet;
+    for (const Raw& r : raw) if (r.index) merged.members.push_back(r.child.members[0]);
+    for (const Raw& r : raw) {
+      if (r.child.kind != Child::kScan) continue;
+      std::vector<int> need;
+      for (const Leaf& l : merged.members) need.push_back(l.input);
+      m.standing.push_back(need);
+      merged.members.push_back(Leaf{r.child.members[0].input, false});
+    }
+    m.children.push_back(merged);
+    for (const Raw& r : raw) if (r.child.kind == Child::kOr) m.children.push_back(r.child);
+  } else {
+    for (const Raw& r : raw) m.children.push_back(r.child);
+  }
+  for (Child& c : m.children) {
+    if (c.kind != Child::kOr) continue;
+    for (const Leaf& l : c.members) c.open_bit.push_back(l.scan ? m.num_open++ : -1);
+  }
+  m.num_inputs = (int)input_predicate.size();
+  const int L = m.num_inputs;
+  // reachable states, breadth first from (child 0 leads, asked afresh, nothing open)
+  std::map<State, int> id;
+  std::vector<State> states;
+  id[State{0, 1, 0u}] = 0;
+  states.push_back(State{0, 1, 0u});
+  std::vector<std::vector<uint8_t>> rows;
+  for (size_t at = 0; at < states.size(); ++at) {
+    std::vector<uint8_t> row((size_t)1 << L);
+    for (unsigned input = 0; input < (1u << L); ++input) {
+      int inc = 0;
+      const State nxt = step(m, states[at], input, &inc);
+      auto it = id.find(nxt);
+      if (it == id.end()) {
+        if ((int)states.size() >= kFsmMaxStates) return false;
+        it = id.emplace(nxt, (int)states.size()).first;
+        states.push_back(nxt);
+      }
+      if (inc > 15) return false;
+      row[input] = (uint8_t)(it->second | (inc << 4));
+    }
+    rows.push_back(std::move(row));
+  }
+  out->num_inputs = L;
+  out->input_predicate = input_predicate;
+  out->num_states = (int)states.size();
+  out->delta.clear();
+  for (const auto& row : rows) out->delta.insert(out->delta.end(), row.begin(), row.end());
+  return true;
+}
+
+// The walk itself, doc by doc (reference for the tiled form below).
+inline int64_t fsm_count_sequential(const Fsm& f, const std::vector<const uint64_t*>& leaf_words, int32_t num_docs) {
+  int64_t entries = 0;
+  int state = 0;
+  for (int32_t x = 0; x < num_docs; ++x) {
+    unsigned input = 0;
+    for (int i = 0; i < f.num_inputs; ++i) input |= (unsigned)((leaf_words[(size_t)i][(size_t)x >> 6] >> (x & 63)) & 1ull) << i;
+    const uint8_t d = f.delta[((size_t)state << f.num_inputs) | input];
+    entries += d >> 4;
+    state = d & 15;
+  }
+  return entries;
+}
+
+// One chunk's table: entry state -> exit state, entries.
+struct FsmTable { uint8_t next[kFsmMaxStates]; uint32_t entries[kFsmMaxStates]; };
+
+// The device's structure (pg_fsm_kernels.h) on the host: lanes of 32 docs walked from every entry state, 64 lane tables composed into
+// the tile's table, tile tables chained in order from state 0.  Docs past numDocs do not exist: a lane stops at the last doc.
+inline int64_t fsm_count_tiled(const Fsm& f, const std::vector<const uint64_t*>& leaf_words, int32_t num_docs) {
+  const int S = f.num_states, L = f.num_inputs;
+  const int64_t num_tiles = ((int64_t)num_docs + 2047) / 2048;
+  int64_t entries = 0;
+  int state = 0;
+  for (int64_t tile = 0; tile < num_tiles; ++tile) {
+    FsmTable tile_table;
+    for (int s = 0; s < S; ++s) { tile_table.next[s] = (uint8_t)s; tile_table.entries[s] = 0; }
+    for (int lane = 0; lane < 64; ++lane) {
+      const int64_t first = tile * 2048 + (int64_t)lane * 32;
+      const int docs = (int)std::max<int64_t>(0, std::min<int64_t>(32, (int64_t)num_docs - first));
+      uint32_t w[kFsmMaxInputs];
+      for (int i = 0; i < L; ++i) w[i] = docs > 0 ? (uint32_t)(leaf_words[(size_t)i][(size_t)first >> 6] >> (first & 63)) : 0u;
+      FsmTable lane_table;
+      for (int s = 0; s < S; ++s) {
+        int cur = s;
+        uint32_t e = 0;
+        for (int d = 0; d < docs; ++d) {
+          unsigned input = 0;
+          for (int i = 0; i < L; ++i) input |= ((w[i] >> d) & 1u) << i;
+          const uint8_t t = f.delta[((size_t)cur << L) | input];
+          e += t >> 4;
+          cur = t & 15;
+        }
+        lane_table.next[s] = (uint8_t)cur;
+        lane_table.entries[s] = e;
+      }
+      for (int s = 0; s < S; ++s) {          // tile_table := lane_table after tile_table
+        const int mid = tile_table.next[s];
+        tile_table.entries[s] += lane_table.entries[mid];
+        tile_table.next[s] = lane_table.next[mid];
+      }
+    }
+    entries += tile_table.entries[state];
+    state = tile_table.next[state];
+  }
+  return entries;
+}
+
+}  // namespace fstats
+}  // namespace pg

@@ -35,6 +35,8 @@ def driver(tmp_path_factory):
     lib.fstats_replay_mode.argtypes = [C.POINTER(_abi.pg_query), C.c_int32, C.POINTER(C.POINTER(C.c_uint64)), C.c_int32, C.c_int32, C.c_int32]
     lib.fstats_leap2.restype = C.c_int64
     lib.fstats_leap2.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
+    lib.fstats_fsm.restype = C.c_int64
+    lib.fstats_fsm.argtypes = [C.POINTER(_abi.pg_query), C.c_int32, C.POINTER(C.POINTER(C.c_uint64)), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     return lib
 
 
@@ -177,3 +179,74 @@ def test_two_scan_leaves_as_a_carry_chain(driver):
     assert plan == PLAN_LEAP2 and leaves == 2
     keep, ptrs = leaf_bitmaps(seg, spec)
     assert driver.fstats_leap2(ptrs[0], ptrs[1], n) == entries == oracle.execute(seg, spec).stats[1]
+
+
+def fsm(lib, seg, spec, mode):
+    keep, ptrs = leaf_bitmaps(seg, spec)
+    states, inputs = C.c_int32(), C.c_int32()
+    return int(lib.fstats_fsm(C.byref(spec.c), seg.num_docs, ptrs, mode, C.byref(states), C.byref(inputs))), int(states.value), int(inputs.value)
+
+
+def test_the_golden_filter_as_a_transducer(driver):
+    """The reference's own filter -- sorted docId range AND (scan OR posting) AND scan AND scan -- compiled into the finite-state walk the
+    device runs (pg_filter_fsm.h): 63064, InnerSegmentAggregationSingleValueQueriesTest.java:56, doc by doc and in the tiled form."""
+    seg = H.golden_segment()
+    spec = Q.QuerySpec(H.golden_aggregations(seg), filter=H.golden_filter_physical(seg))
+    for mode in (0, 1):
+        entries, states, inputs = fsm(driver, seg, spec, mode)
+        assert entries == 63064 and inputs == 5 and 2 <= states <= 16, (entries, states, inputs)
+
+
+def test_transducer_matches_the_iterator_replay_on_random_and_trees(driver):
+    """Root ANDs of scan leaves, index-based leaves and ORs of such leaves over random columns: the transducer (both forms) against the
+    replay of the reference's iterator objects and against the oracle.  Sizes around the lane / tile boundaries."""
+    rng = np.random.default_rng(4)
+    shapes_seen, compiled = set(), 0
+    for n in (1, 31, 33, 2047, 2049, 4100, 20_011, 70_003):
+        cols = [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "b", n, 7, with_inverted=True)[0],
+                H.random_dict_column(rng, "c", n, 300, with_inverted=True)[0], H.random_dict_column(rng, "d", n, 3)[0],
+                H.random_dict_column(rng, "e", n, 11)[0]]
+        seg = S.SegmentData("fsm", n, cols)
+
+        def scan_leaf():
+            k = int(rng.integers(0, 4))
+            if k == 0:
+                lo = int(rng.integers(0, 40)); return Q.leaf(Q.Pred.dict_range(0, lo, lo + int(rng.integers(1, 25)), exclusive=bool(rng.integers(0, 2))))
+            if k == 1:
+                return Q.leaf(Q.Pred.dict_range(3, int(rng.integers(0, 2)), int(rng.integers(2, 4))))
+            if k == 2:
+                lo = int(rng.integers(0, 9)); return Q.leaf(Q.Pred.dict_range(4, lo, lo + int(rng.integers(1, 6))))
+            return Q.leaf(Q.Pred.dict_set(0, sorted(set(int(x) for x in rng.integers(0, 50, size=12))), 50, exclusive=bool(rng.integers(0, 2))))
+
+        def index_leaf():
+            k = int(rng.integers(0, 3))
+            if k == 0:
+                return Q.leaf(Q.Pred.dict_range(1, int(rng.integers(0, 5)), 7, inverted=True, exclusive=bool(rng.integers(0, 2))))
+            if k == 1:
+                return Q.leaf(Q.Pred.dict_set(2, sorted(set(int(x) for x in rng.integers(0, 300, size=60))), 300, inverted=True))
+            lo = int(rng.integers(0, n)); return Q.leaf(Q.Pred.doc_range(lo, min(n - 1, lo + int(rng.integers(0, n)))))
+
+        for _ in range(60):
+            kids = []
+            for _c in range(int(rng.integers(2, 5))):
+                r = int(rng.integers(0, 10))
+                if r < 5:
+                    kids.append(scan_leaf())
+                elif r < 7:
+                    kids.append(index_leaf())
+                else:
+                    kids.append(Q.or_(*[scan_leaf() if rng.integers(0, 3) else index_leaf() for _m in range(int(rng.integers(2, 4)))]))
+            spec = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(*kids))
+            if len(spec.predicates) > 8 or any(p.kind in (_abi.PG_PRED_MATCH_ALL, _abi.PG_PRED_MATCH_NONE) for p in spec.predicates):
+                continue
+            want = oracle.execute(seg, spec).stats[1]
+            keep, ptrs = leaf_bitmaps(seg, spec)
+            assert driver.fstats_replay_mode(C.byref(spec.c), n, ptrs, 0, 0, 0) == want
+            seq, states, inputs = fsm(driver, seg, spec, 0)
+            if seq < 0:
+                continue                                         # more than 16 states (or an OR of sorted members only): the replay keeps it
+            compiled += 1
+            shapes_seen.add((len(kids), states))
+            tiled, _, _ = fsm(driver, seg, spec, 1)
+            assert seq == tiled == want, (n, states, inputs, seq, tiled, want)
+    assert compiled > 200 and len(shapes_seen) > 8, (compiled, shapes_seen)

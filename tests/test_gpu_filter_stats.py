@@ -103,3 +103,81 @@ def test_random_filter_trees_on_the_device(engine):
                 exact += 1
                 assert got.stats[1] == want.stats[1]
     assert ran >= 150 and exact >= ran * 0.9, (ran, exact)
+
+
+def _and_tree_segment(rng, n):
+    cols = [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "b", n, 7, with_inverted=True)[0],
+            H.random_dict_column(rng, "c", n, 300, with_inverted=True)[0], H.random_dict_column(rng, "d", n, 3)[0],
+            H.random_dict_column(rng, "e", n, 11)[0]]
+    return S.SegmentData("fsm_%d" % n, n, cols)
+
+
+def _random_and_tree(rng, n):
+    def scan_leaf():
+        k = int(rng.integers(0, 4))
+        if k == 0:
+            lo = int(rng.integers(0, 40)); return Q.leaf(Q.Pred.dict_range(0, lo, lo + int(rng.integers(1, 25)), exclusive=bool(rng.integers(0, 2))))
+        if k == 1:
+            return Q.leaf(Q.Pred.dict_range(3, int(rng.integers(0, 2)), int(rng.integers(2, 4))))
+        if k == 2:
+            lo = int(rng.integers(0, 9)); return Q.leaf(Q.Pred.dict_range(4, lo, lo + int(rng.integers(1, 6))))
+        return Q.leaf(Q.Pred.dict_set(0, sorted(set(int(x) for x in rng.integers(0, 50, size=12))), 50, exclusive=bool(rng.integers(0, 2))))
+
+    def index_leaf():
+        k = int(rng.integers(0, 3))
+        if k == 0:
+            return Q.leaf(Q.Pred.dict_range(1, int(rng.integers(0, 5)), 7, inverted=True, exclusive=bool(rng.integers(0, 2))))
+        if k == 1:
+            return Q.leaf(Q.Pred.dict_set(2, sorted(set(int(x) for x in rng.integers(0, 300, size=60))), 300, inverted=True))
+        lo = int(rng.integers(0, n)); return Q.leaf(Q.Pred.doc_range(lo, min(n - 1, lo + int(rng.integers(0, n)))))
+
+    kids = []
+    for _c in range(int(rng.integers(2, 5))):
+        r = int(rng.integers(0, 10))
+        if r < 5:
+            kids.append(scan_leaf())
+        elif r < 7:
+            kids.append(index_leaf())
+        else:
+            kids.append(Q.or_(*[scan_leaf() if rng.integers(0, 3) else index_leaf() for _m in range(int(rng.integers(2, 4)))]))
+    return Q.and_(*kids)
+
+
+@pytest.mark.parametrize("n", [1, 33, 2049, 70_003, 2_200_013])
+def test_leapfrogging_ands_are_counted_on_the_device_by_the_transducer(engine_without_replay, n):
+    """Root ANDs of scan leaves, index-based leaves and ORs of leaves (a AND b AND c, a AND (b OR c), the golden filter's shape) with the
+    host replay switched OFF: an exact numEntriesScannedInFilter can only have come from fsm_tiles_kernel / fsm_chain_kernel / fsm_finish_kernel
+    (pg_filter_fsm.h compiles the reference's iterator tree into a finite-state walk) -- equal to the oracle's iterator tree."""
+    rng = np.random.default_rng(1000 + n)
+    seg = _and_tree_segment(rng, n)
+    exact = ran = 0
+    with engine_without_replay.open(seg) as g:
+        for _ in range(12 if n > 1_000_000 else 40):
+            spec = Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0)], filter=_random_and_tree(rng, n))
+            if len(spec.predicates) > 8 or spec.c.num_filter_nodes > 24 or g.check(spec) != 0:
+                continue
+            got = g.execute(spec)
+            want = oracle.execute(seg, spec)
+            H.assert_results_equal(got, want)
+            ran += 1
+            if got.filter_entries_exact:
+                exact += 1
+                assert got.stats[1] == want.stats[1]
+        # three scan leaves, and a scan leaf AND an OR of two: the two shapes named by the review
+        a, d, e = Q.leaf(Q.Pred.dict_range(0, 0, 10)), Q.leaf(Q.Pred.dict_range(3, 0, 1)), Q.leaf(Q.Pred.dict_range(4, 2, 6))
+        for flt in (Q.and_(a, d, e), Q.and_(a, Q.or_(d, e)), Q.and_(Q.or_(d, e), a), Q.and_(a, d, e, Q.leaf(Q.Pred.dict_range(0, 5, 40)))):
+            for group_by in ([], [3]):
+                spec = Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0)], filter=flt, group_by=group_by)
+                got, want = g.execute(spec), oracle.execute(seg, spec)
+                H.assert_results_equal(got, want)
+                assert got.filter_entries_exact and got.stats[1] == want.stats[1], (n, got.stats, want.stats)
+    assert ran >= 8 and exact >= ran * 0.7, (n, ran, exact)
+
+
+def test_the_golden_filter_is_counted_on_the_device(engine_without_replay):
+    """InnerSegmentAggregationSingleValueQueriesTest.java:56: 63064, with the host replay off."""
+    seg = H.golden_segment()
+    spec = Q.QuerySpec(H.golden_aggregations(seg), filter=H.golden_filter_physical(seg))
+    with engine_without_replay.open(seg) as g:
+        got = g.execute(spec)
+    assert got.filter_entries_exact and list(got.stats) == [6129, 63064, 24516, 30000]

@@ -2,6 +2,7 @@
 // so tests/test_filter_stats_cpu.py builds this file with g++ (-fsanitize=address,undefined when available) and compares the replay
 // with the oracle's restatement of the reference's iterators on random filter trees -- no GPU involved.
 #include "../../pinot_amd/csrc/pg_filter_stats.h"
+#include "../../pinot_amd/csrc/pg_filter_fsm.h"
 
 extern "C" int64_t fstats_replay(const pg_query* q, int32_t num_docs, const uint64_t* const* leaf_words, int32_t* out_plan, int32_t* out_scan_leaves) {
   int scan_leaves = 0;
@@ -30,4 +31,16 @@ extern "C" int64_t fstats_replay_mode(const pg_query* q, int32_t num_docs, const
 // leaf that is not scanning gets asked.
 extern "C" int64_t fstats_leap2(const uint64_t* a_words, const uint64_t* b_words, int32_t num_docs) {
   return (int64_t)num_docs + pg::fstats::leap2_extra_entries(a_words, b_words, num_docs);
+}
+
+// The root AND as a finite-state transducer (pg_filter_fsm.h): -1 when the shape does not compile; else the count by the doc-by-doc walk
+// (mode 0) or in the device's lane / tile / chain structure (mode 1).  *out_states = the number of reachable states.
+extern "C" int64_t fstats_fsm(const pg_query* q, int32_t num_docs, const uint64_t* const* leaf_words, int32_t mode, int32_t* out_states, int32_t* out_inputs) {
+  pg::fstats::Fsm f;
+  if (!pg::fstats::compile_fsm(q, &f)) return -1;
+  if (out_states) *out_states = f.num_states;
+  if (out_inputs) *out_inputs = f.num_inputs;
+  std::vector<const uint64_t*> words;
+  for (int p : f.input_predicate) words.push_back(leaf_words[p]);
+  return mode == 0 ? pg::fstats::fsm_count_sequential(f, words, num_docs) : pg::fstats::fsm_count_tiled(f, words, num_docs);
 }
