@@ -210,6 +210,12 @@ struct ScanParams {
   int32_t fold_one_counter;        // 1: grids of at most kFoldOneCounterMax workgroups arrive on ONE counter (no shard hand-off: publish_block_partial);
                                    //    0: always eight shard counters + the top one
   uint8_t* leap_tables;            // [tiles] kNodeLeapfrog2: one byte per 2048-doc tile (leapfrog2_tile), chained by the leapfrog2_chain_*_kernels
+  // numEntriesScannedInFilter by the transducer pass (pg_filter_fsm.h / pg_fsm_kernels.h): the lane-private filter also leaves every
+  // leaf's own match bits behind -- dword tile * 64 + lane of a doc-order bitmap per leaf, in the order the LEAF nodes are evaluated
+  // (nullptr: that leaf is not wanted) -- so that the pass does not have to scan the leaves' columns again.
+  uint32_t* leaf_out[kMaxLeaves];
+  int32_t leaf_out_enabled;
+  int32_t reserved_lo;
 };
 
 // What a query's scan brings back to the host: the folded record, then a sequence number written after it.

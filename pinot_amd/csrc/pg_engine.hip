@@ -228,6 +228,18 @@ struct pg_segment {
   uint64_t plane_bytes = 0;             // HBM held by materialised value planes (part of device_bytes)
   std::vector<ExecCtx*> free_ctx;
   std::vector<ExecCtx*> all_ctx;
+  // the transducer pass of numEntriesScannedInFilter (device_fsm_filter_stats): leaf bitmaps + tables, one query at a time per segment
+  std::mutex fsm_mu;
+  uint8_t* d_fsm_scratch = nullptr;
+  size_t fsm_scratch_bytes = 0;
+};
+
+// What a query's scan kernel leaves behind for the transducer pass: the bitmap of every input leaf it evaluated itself.
+struct FsmSide {
+  const pg::fstats::Fsm* fsm = nullptr;
+  uint32_t* bitmap[pg::kFsmInputs] = {};        // where input i's doc-order bitmap goes
+  bool mapped[pg::kFsmInputs] = {};             // the lowered filter has a LEAF node of its own for input i
+  bool kernel_wrote = false;                    // the kernel that ran carries the store (eval_filter_private, no tile list)
 };
 
 namespace {
@@ -519,6 +531,7 @@ void free_segment(pg_segment* seg) {
   drop_planes_of(seg);
   if (seg->plane_stream) (void)hipStreamDestroy(seg->plane_stream);
   for (auto* c : seg->all_ctx) destroy_ctx(c);
+  if (seg->d_fsm_scratch) (void)hipFree(seg->d_fsm_scratch);
   for (auto& col : seg->cols) {
     if (col.d_fwd_alloc) (void)hipFree(col.d_fwd_alloc);
     if (col.d_dict && !col.borrows_dictionary) (void)hipFree(col.d_dict);
@@ -840,6 +853,8 @@ struct Lowered {
   bool stats_chain_flagged = false;            // the chain's scan leaves carry kNodeCountEntries
   bool stats_leap2_flagged = false;            // the root AND of two scan leaves carries kNodeLeapfrog2
   bool cardinality_only_hint = false;          // in: the query is COUNT(*) only, so an index-only filter needs neither bitmap nor tile list
+  FsmSide* side = nullptr;                     // in: the transducer pass wants the leaves' bitmaps (ScanParams.leaf_out)
+  uint32_t* sp_leaf_out[kMaxLeaves] = {};      // out: ScanParams.leaf_out, by LEAF node ordinal
 };
 
 int slot_for(Lowered* lw, const pg_segment* seg, int column, bool plane = false) {
@@ -1065,6 +1080,22 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
     dn.leaf = -1;
     dn.num_children = fn.num_children;
     dn.flags = seq[(size_t)n].flags;
+    if (lw->side != nullptr) {
+      // every leaf's mask of every tile feeds the walk: no leaf may end a tile early; a leaf that is one of the walk's inputs stores its mask
+      dn.flags &= ~kNodeExitIfZero;
+      if (fn.op == PG_FILTER_LEAF) {
+        int ordinal = 0;
+        for (int m = 0; m < n; ++m) ordinal += seq[(size_t)m].op == PG_FILTER_LEAF ? 1 : 0;
+        if (seq[(size_t)n].src >= 0 && ordinal < kMaxLeaves) {
+          const std::vector<int>& inputs = lw->side->fsm->input_predicate;
+          for (size_t i = 0; i < inputs.size(); ++i) {
+            if (inputs[i] != fn.predicate || lw->side->mapped[i]) continue;
+            lw->sp_leaf_out[ordinal] = lw->side->bitmap[i];
+            lw->side->mapped[i] = true;
+          }
+        }
+      }
+    }
     if (lw->stats_plan == fstats::Plan::kLeap2) {
       // `a AND b`, two scan leaves: both masks of EVERY tile feed the leap-frog entry count, so no leaf may end a tile early
       // (whichever leaf is scanning when a tile is entered keeps looking at its docs even where the other one matches nothing)
@@ -2228,7 +2259,7 @@ struct Deferred {
 
 static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out, unsigned long long* d_out_bitmap_request,
                               uint64_t* host_bitmap, int64_t host_bitmap_words, int64_t* out_cardinality, bool allow_metadata_plan = true,
-                              Deferred* defer = nullptr) {
+                              Deferred* defer = nullptr, FsmSide* side = nullptr) {
   if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");
   if (!seg || !q) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
   // d_out_bitmap_request: like host_bitmap, but the filter's doc-order bitmap is copied device to device into the caller's
@@ -2341,6 +2372,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   if (lw.stats_plan == fstats::Plan::kLeap2 && !g_engine.leap2) lw.stats_plan = fstats::Plan::kReplay;
   lw.cardinality_only_hint = ng == 0 && out && !want_bitmap && na > 0;
   for (int a = 0; a < na; ++a) lw.cardinality_only_hint = lw.cardinality_only_hint && q->aggregations[a].function == PG_AGG_COUNT;
+  lw.side = (out && !want_bitmap && lw.stats_plan == fstats::Plan::kReplay) ? side : nullptr;
   st = lower_filter(seg, ctx, q, &lw);
   if (st != PG_OK) return st;
   ScanParams& sp = lw.sp;
@@ -2536,6 +2568,13 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     else { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
     const bool count_leap2 = out && lw.stats_leap2_flagged && !use_narrow && (use_hist || use_private || use_private_typed);
     const bool count_entries = (out && lw.stats_chain_flagged && (use_hist || use_private || use_private_typed)) || count_leap2;
+    if (lw.side != nullptr) {
+      // the transducer pass behind this query: a kernel that evaluates the filter with eval_filter_private over every tile leaves the leaves' bitmaps behind
+      const bool wrote = !use_narrow && !use_sparse && !use_simple && (use_hist || use_private || use_private_typed) && sp.tile_list == nullptr;
+      for (int l = 0; l < kMaxLeaves; ++l) sp.leaf_out[l] = wrote ? lw.sp_leaf_out[l] : nullptr;
+      sp.leaf_out_enabled = wrote ? 1 : 0;
+      lw.side->kernel_wrote = wrote;
+    }
     sp.filter_entries = nullptr;
     sp.leap_tables = nullptr;
     if (count_leap2) { st = arm_leap_tables(seg, ctx, &sp.leap_tables, nullptr); if (st != PG_OK) return st; }
@@ -2688,7 +2727,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       __atomic_store_n(&seg->cols[(size_t)hist_col].hist_tier, hist_wrapped ? 1 : 2, __ATOMIC_RELAXED);
       release_ctx(seg, ctx);
       guard.ctx = nullptr;
-      return execute_impl(seg, q, out, d_out_bitmap_request, host_bitmap, host_bitmap_words, out_cardinality, allow_metadata_plan);
+      return execute_impl(seg, q, out, d_out_bitmap_request, host_bitmap, host_bitmap_words, out_cardinality, allow_metadata_plan, nullptr, side);
     }
     if (out_cardinality) *out_cardinality = (int64_t)fp.count;
     if (out) convert(fp, out);
@@ -2891,6 +2930,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const bool use_partition = hash_plan.kind == 0 && !typed_direct && map_based && g_engine.group_partition && g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap &&
                                gp.num_group_aggs <= kMaxPartitionAggs && num_partitions <= kMaxPartitions && (long long)seg->num_docs >= g_engine.partition_min_docs;
     if (use_partition || !(use_private || typed_direct)) { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
+    if (lw.side != nullptr) {
+      const bool wrote = ((use_private && !use_partition) || typed_direct) && gp.scan.tile_list == nullptr;
+      for (int l = 0; l < kMaxLeaves; ++l) gp.scan.leaf_out[l] = wrote ? lw.sp_leaf_out[l] : nullptr;
+      gp.scan.leaf_out_enabled = wrote ? 1 : 0;
+      lw.side->kernel_wrote = wrote;
+    }
     const bool count_leap2 = out && lw.stats_leap2_flagged && ((use_private && !use_partition) || typed_direct);
     const bool count_entries = (out && lw.stats_chain_flagged && ((use_private && !use_partition) || typed_direct)) || count_leap2;
     gp.scan.leap_tables = nullptr;
@@ -3563,21 +3608,56 @@ static pg_status replay_filter_stats(pg_segment* seg, const pg_query* q, pg_resu
 // The same count ON THE DEVICE, at any segment size, for the root ANDs pg_filter_fsm.h can compile (scan leaves, index-based leaves, ORs
 // of leaves -- `a AND b AND c`, `a AND (b OR c)`, the reference's golden filter): every leaf's docId set stays on the device as a
 // doc-order bitmap, the transducer's tables are built tile by tile and chained (pg_fsm_kernels.h).  Nothing but the count comes back.
-static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, const fstats::Fsm& fsm, pg_result* out) {
+// Layout of the pass's scratch (pg_segment.d_fsm_scratch): L bitmaps of whole tiles | delta | tile tables | chunk tables | the count.
+struct FsmScratch {
+  size_t bitmap_bytes = 0, delta_bytes = 0, tables_bytes = 0, chunk_bytes = 0, total = 0;
+  long long tiles = 0, chunks = 0;
+  FsmScratch(const pg_segment* seg, const fstats::Fsm& fsm) {
+    tiles = std::max<long long>(1, ((long long)seg->num_docs + 2047) / 2048);
+    chunks = (tiles + kFsmChunk - 1) / kFsmChunk;
+    bitmap_bytes = (size_t)tiles * 256;
+    delta_bytes = (((size_t)fsm.num_states << fsm.num_inputs) + 255) & ~(size_t)255;
+    tables_bytes = (size_t)tiles * (size_t)fsm.num_states * 4;
+    chunk_bytes = ((size_t)chunks * (size_t)fsm.num_states * 4 + 255) & ~(size_t)255;
+    total = bitmap_bytes * (size_t)fsm.num_inputs + delta_bytes + tables_bytes + chunk_bytes + 256;
+  }
+};
+// (under seg->fsm_mu) the scratch, grown when needed, and where every input's bitmap goes
+static pg_status prepare_fsm_side(pg_segment* seg, const fstats::Fsm& fsm, FsmSide* side) {
+  const FsmScratch lay(seg, fsm);
   HIP_TRY(hipSetDevice(seg->device));
-  const long long tiles = std::max<long long>(1, ((long long)seg->num_docs + 2047) / 2048);
-  const size_t bitmap_bytes = (size_t)tiles * 256;
+  if (seg->fsm_scratch_bytes < lay.total) {
+    if (seg->d_fsm_scratch) (void)hipFree(seg->d_fsm_scratch);
+    seg->d_fsm_scratch = nullptr; seg->fsm_scratch_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&seg->d_fsm_scratch, lay.total));
+    seg->fsm_scratch_bytes = lay.total;
+  }
+  *side = FsmSide();
+  side->fsm = &fsm;
+  for (int i = 0; i < fsm.num_inputs; ++i) side->bitmap[i] = reinterpret_cast<uint32_t*>(seg->d_fsm_scratch + lay.bitmap_bytes * (size_t)i);
+  return PG_OK;
+}
+
+static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, const fstats::Fsm& fsm, const FsmSide& side, pg_result* out) {
+  HIP_TRY(hipSetDevice(seg->device));
+  const FsmScratch lay(seg, fsm);
+  const long long tiles = lay.tiles, chunks = lay.chunks;
   const int L = fsm.num_inputs, S = fsm.num_states;
-  const long long chunks = (tiles + kFsmChunk - 1) / kFsmChunk;
-  const size_t delta_bytes = ((size_t)S << L), tables_bytes = (size_t)tiles * (size_t)S * 4, chunk_bytes = (size_t)chunks * (size_t)S * 4;
-  const size_t total = bitmap_bytes * (size_t)L + ((delta_bytes + 255) & ~(size_t)255) + tables_bytes + ((chunk_bytes + 255) & ~(size_t)255) + 256;
-  uint8_t* d_base = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_base, total));
-  struct Free { uint8_t* p; ~Free() { (void)hipFree(p); } } free_it{d_base};
-  HIP_TRY(hipMemset(d_base, 0, bitmap_bytes * (size_t)L));          // the last tile's dwords past numDocs
+  static const bool trace = getenv("PINOT_GPU_FSM_TRACE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+  const auto t_begin = now();
+  uint8_t* d_base = seg->d_fsm_scratch;
   FsmParams fp;
   memset(&fp, 0, sizeof(fp));
+  int scanned_again = 0;
   for (int i = 0; i < L; ++i) {
+    fp.leaf[i] = side.bitmap[i];
+    if (side.kernel_wrote && side.mapped[i]) continue;        // the query's own kernel left it behind
+    // a leaf the kernel did not evaluate as a node of its own (the inverted-index children of the root AND are one merged leaf there),
+    // or a kernel without the store: this leaf's docId set by a pass of its own
+    ++scanned_again;
+    HIP_TRY(hipMemset(reinterpret_cast<uint8_t*>(side.bitmap[i]) + (lay.bitmap_bytes - 256), 0, 256));      // the last tile's dwords past numDocs
     pg_filter_node leaf;
     memset(&leaf, 0, sizeof(leaf));
     leaf.op = PG_FILTER_LEAF; leaf.predicate = fsm.input_predicate[(size_t)i];
@@ -3585,30 +3665,38 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
     memset(&lq, 0, sizeof(lq));
     lq.filter = &leaf; lq.num_filter_nodes = 1;
     lq.predicates = q->predicates; lq.num_predicates = q->num_predicates;
-    unsigned long long* d_bitmap = reinterpret_cast<unsigned long long*>(d_base + bitmap_bytes * (size_t)i);
-    const pg_status st = execute_impl(seg, &lq, nullptr, d_bitmap, nullptr, 0, nullptr);      // (returns with the copy done)
+    const pg_status st = execute_impl(seg, &lq, nullptr, reinterpret_cast<unsigned long long*>(side.bitmap[i]), nullptr, 0, nullptr);      // (returns with the copy done)
     if (st != PG_OK) return st;
-    fp.leaf[i] = reinterpret_cast<const uint32_t*>(d_bitmap);
   }
-  uint8_t* at = d_base + bitmap_bytes * (size_t)L;
-  uint8_t* d_delta = at; at += (delta_bytes + 255) & ~(size_t)255;
-  uint32_t* d_tables = reinterpret_cast<uint32_t*>(at); at += tables_bytes;
-  uint32_t* d_chunks = reinterpret_cast<uint32_t*>(at); at += (chunk_bytes + 255) & ~(size_t)255;
+  const auto t_leaves = now();
+  uint8_t* at = d_base + lay.bitmap_bytes * (size_t)L;
+  uint8_t* d_delta = at; at += lay.delta_bytes;
+  uint32_t* d_tables = reinterpret_cast<uint32_t*>(at); at += lay.tables_bytes;
+  uint32_t* d_chunks = reinterpret_cast<uint32_t*>(at); at += lay.chunk_bytes;
   unsigned long long* d_entries = reinterpret_cast<unsigned long long*>(at);
-  HIP_TRY(hipMemcpy(d_delta, fsm.delta.data(), delta_bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_delta, fsm.delta.data(), (size_t)S << L, hipMemcpyHostToDevice));
   fp.delta = d_delta; fp.tables = d_tables;
   fp.num_inputs = L; fp.num_states = S; fp.num_docs = seg->num_docs; fp.num_tiles = (int32_t)tiles;
   const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)seg->num_cus * 8));
-  if (S <= 4) fsm_tiles_kernel<4><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
-  else if (S <= 8) fsm_tiles_kernel<8><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
-  else fsm_tiles_kernel<16><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
+#define PG_FSM_LAUNCH(SM, LM) fsm_tiles_kernel<SM, LM><<<dim3(blocks), dim3(256), 0, 0>>>(fp)
+#define PG_FSM_LAUNCH_L(SM) do { if (L <= 2) PG_FSM_LAUNCH(SM, 2); else if (L <= 3) PG_FSM_LAUNCH(SM, 3); else if (L <= 4) PG_FSM_LAUNCH(SM, 4); else if (L <= 6) PG_FSM_LAUNCH(SM, 6); else PG_FSM_LAUNCH(SM, 8); } while (0)
+  if (S <= 2) PG_FSM_LAUNCH_L(2);
+  else if (S <= 4) PG_FSM_LAUNCH_L(4);
+  else if (S <= 8) PG_FSM_LAUNCH_L(8);
+  else PG_FSM_LAUNCH_L(16);
+#undef PG_FSM_LAUNCH_L
+#undef PG_FSM_LAUNCH
   HIP_TRY(hipGetLastError());
+  if (trace) HIP_TRY(hipDeviceSynchronize());
+  const auto t_tiles = now();
   fsm_chain_kernel<<<dim3((unsigned)chunks), dim3(1024), 0, 0>>>(d_tables, tiles, S, d_chunks);
   HIP_TRY(hipGetLastError());
   fsm_finish_kernel<<<dim3(1), dim3(1024), (size_t)chunks * (size_t)S * 4, 0>>>(d_chunks, (int)chunks, S, d_entries);
   HIP_TRY(hipGetLastError());
   unsigned long long entries = 0;
   HIP_TRY(hipMemcpy(&entries, d_entries, 8, hipMemcpyDeviceToHost));
+  if (trace) fprintf(stderr, "fsm stats: %d inputs %d states %lld tiles: %d leaf bitmaps scanned again %.1f us, tables kernel %.1f us, chain+finish+copy %.1f us\n", L, S, tiles,
+                     scanned_again, us(t_begin, t_leaves), us(t_leaves, t_tiles), us(t_tiles, now()));
   out->stats.num_entries_scanned_in_filter = (int64_t)entries;
   out->filter_entries_exact = 1;
   return PG_OK;
@@ -3619,18 +3707,38 @@ static pg_status execute_one(pg_segment* segment, const pg_query* query, pg_resu
   if (!out_result) return fail(PG_ERR_INVALID_ARGUMENT, "null result");
   memset(out_result, 0, sizeof(*out_result));     // before anything can fail: every error path below ends in pg_result_free(out_result)
   const bool null_handling = query && (query->flags & PG_QUERY_NULL_HANDLING);
+  // A leap-frogging filter whose shape compiles into the transducer of pg_filter_fsm.h is counted on the device at any size
+  // (PINOT_GPU_FSM_STATS=0: never): the query's own kernel leaves the leaves' bitmaps in the segment's scratch (one such query at a
+  // time per segment), the pass follows.  Other shapes: the host's replay of the iterator tree up to
+  // PINOT_GPU_EXACT_FILTER_STATS_DOCS docs, else the upper bound stands.
+  static const bool use_fsm = !(getenv("PINOT_GPU_FSM_STATS") && getenv("PINOT_GPU_FSM_STATS")[0] == '0');
+  fstats::Fsm fsm;
+  FsmSide side;
+  std::unique_lock<std::mutex> fsm_lock;
+  bool fsm_ready = false;
+  if (use_fsm && !null_handling && segment && query && query->num_filter_nodes >= 3 && query->filter && query->predicates) {
+    int scan_leaves = 0;
+    if (fstats::choose_plan(query, &scan_leaves) == fstats::Plan::kReplay && fstats::compile_fsm(query, &fsm)) {
+      fsm_lock = std::unique_lock<std::mutex>(segment->fsm_mu);
+      const pg_status pst = prepare_fsm_side(segment, fsm, &side);
+      if (pst != PG_OK) return pst;
+      fsm_ready = true;
+    }
+  }
   pg_status st = null_handling ? execute_null_handling(segment, query, out_result, nullptr, 0, nullptr)
-                               : execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr, true, defer);
+                               : execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr, true, defer, fsm_ready ? &side : nullptr);
   if (st == kDeferred) return st;
   // (enableNullHandling changes the iterator tree -- nulls are or-ed in, NOT takes the falses: the upper bound stands there)
   if (st == PG_OK && !null_handling && !out_result->filter_entries_exact) {
-    // a leap-frogging filter: the transducer on the device where the shape compiles (any size; PINOT_GPU_FSM_STATS=0: never), else the
-    // host's replay of the iterator tree up to PINOT_GPU_EXACT_FILTER_STATS_DOCS docs, else the upper bound stands
-    fstats::Fsm fsm;
-    static const bool use_fsm = !(getenv("PINOT_GPU_FSM_STATS") && getenv("PINOT_GPU_FSM_STATS")[0] == '0');
-    static const long long fsm_min_docs = getenv("PINOT_GPU_FSM_MIN_DOCS") ? atoll(getenv("PINOT_GPU_FSM_MIN_DOCS")) : 0;
-    if (use_fsm && (long long)segment->num_docs >= fsm_min_docs && fstats::compile_fsm(query, &fsm)) st = device_fsm_filter_stats(segment, query, fsm, out_result);
-    else if ((int64_t)segment->num_docs <= g_engine.exact_stats_docs) st = replay_filter_stats(segment, query, out_result);
+    if (fsm_ready) {
+      const auto t0 = std::chrono::steady_clock::now();
+      st = device_fsm_filter_stats(segment, query, fsm, side, out_result);
+      // (timed runs: the pass is charged to the query on the host clock: it has no event bracket of its own, and a clock that includes
+      //  its copies overstates rather than hides it)
+      if (g_engine.flags & PG_CFG_TIME_KERNELS) out_result->device_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    } else if ((int64_t)segment->num_docs <= g_engine.exact_stats_docs) {
+      st = replay_filter_stats(segment, query, out_result);
+    }
   }
   if (st != PG_OK) pg_result_free(out_result);
   return st;

@@ -203,11 +203,33 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
     }
     rows.push_back(std::move(row));
   }
+  // Mealy minimisation: two states are one when, for every input, they count the same entries and go on to states that are one ("asked
+  // afresh" only matters in front of an OR: `a AND b AND c` has three states, one per leading child).  Classes are numbered by first
+  // appearance, so the entry state stays 0.
+  const int S0 = (int)states.size();
+  std::vector<int> cls((size_t)S0, 0);
+  for (int num_classes = 1;;) {
+    std::map<std::vector<int>, int> sig_id;
+    std::vector<int> next_cls((size_t)S0, 0);
+    for (int st = 0; st < S0; ++st) {
+      std::vector<int> sig{cls[(size_t)st]};
+      for (unsigned input = 0; input < (1u << L); ++input) { const uint8_t d = rows[(size_t)st][input]; sig.push_back(d >> 4); sig.push_back(cls[(size_t)(d & 15)]); }
+      next_cls[(size_t)st] = sig_id.emplace(std::move(sig), (int)sig_id.size()).first->second;
+    }
+    cls = next_cls;
+    if ((int)sig_id.size() == num_classes) break;
+    num_classes = (int)sig_id.size();
+  }
+  const int S = 1 + *std::max_element(cls.begin(), cls.end());
   out->num_inputs = L;
   out->input_predicate = input_predicate;
-  out->num_states = (int)states.size();
-  out->delta.clear();
-  for (const auto& row : rows) out->delta.insert(out->delta.end(), row.begin(), row.end());
+  out->num_states = S;
+  out->delta.assign((size_t)S << L, 0);
+  for (int st = 0; st < S0; ++st)
+    for (unsigned input = 0; input < (1u << L); ++input) {
+      const uint8_t d = rows[(size_t)st][input];
+      out->delta[((size_t)cls[(size_t)st] << L) | input] = (uint8_t)(cls[(size_t)(d & 15)] | (d & 0xF0));
+    }
   return true;
 }
 

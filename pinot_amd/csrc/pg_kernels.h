@@ -1740,6 +1740,7 @@ __device__ __forceinline__ uint32_t eval_filter_private(const P& p, long long ti
 #pragma unroll
   for (int i = 0; i < kStackDepth; ++i) st.v[i] = 0;
   st.sp = 0;
+  int leaf_ordinal = 0;
   for (int n = 0; n < p.num_nodes; ++n) {
     const auto& nd = p.nodes[n];
     uint32_t top;
@@ -1749,6 +1750,11 @@ __device__ __forceinline__ uint32_t eval_filter_private(const P& p, long long ti
         entries += (uint32_t)__builtin_popcount(st.v[0] & (rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u))));
       }
       top = eval_leaf_private(p, nd, tile, lane);
+      if (p.leaf_out_enabled != 0) {
+        uint32_t* const leaf_bits = p.leaf_out[leaf_ordinal];          // (uniform: one scalar load)
+        if (leaf_bits != nullptr) leaf_bits[tile * 64 + lane] = top;   // one coalesced 256-byte store per leaf and tile
+      }
+      ++leaf_ordinal;
     } else if (nd.op == PG_FILTER_NOT) {
       top = ~st.pop();
     } else {

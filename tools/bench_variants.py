@@ -67,7 +67,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
         return lambda matched: B(col) if matched * 16 >= rows else min(B(col), matched * 64)
 
     # ---- C2 / C3 on 1 B rows: the headline's v and f, v under two dictionaries without structure, and the C3 columns ----
-    if any(want(x) for x in ("C2b-irregular", "C2b-window", "C2a-affine", "C2a-irregular", "C3", "C3-filter", "C3-irregular", "COUNT-filter", "C2b-1pct", "C2b-50pct")):
+    if any(want(x) for x in ("C2b-irregular", "C2b-window", "C2a-affine", "C2a-irregular", "C3", "C3-filter", "C3-irregular", "COUNT-filter", "C2b-1pct", "C2b-50pct", "AND3-scan", "AND-OR-scan")):
         t0 = time.time()
         v_irr = _shared(S, v, "v_irr", v_dictionary("irregular"))
         v_win = _shared(S, v, "v_win", v_dictionary("window"))
@@ -102,6 +102,20 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
             if want("C3-irregular"):
                 report("C3-irregular", "BASELINE.json configs[2], summed column with a dictionary without structure", "SELECT SUM(a_irr), MAX(b) GROUP BY k", n, B(k) + B(a) + B(b), g, seg,
                        Q.QuerySpec([(Q.SUM, 7), (Q.MAX, 6)], group_by=[4]), extra={"dictionary": "irregular"})
+            # leap-frogging filters whose numEntriesScannedInFilter the device counts with the transducer pass (pg_filter_fsm.h): all_kernels_ms
+            # includes that pass (the leaves' bitmaps + fsm_*_kernel, on the host clock)
+            for vid, sql, flt3 in (("AND3-scan", "SELECT SUM(v) WHERE f < 300 AND k < 1500 AND b < 60000 (three scan leaves: 30% / 50% / 46%)",
+                                    Q.and_(Q.leaf(Q.Pred.dict_range(1, 0, 300)), Q.leaf(Q.Pred.dict_range(4, 0, 500)), Q.leaf(Q.Pred.dict_range(6, 0, 30000)))),
+                                   ("AND-OR-scan", "SELECT SUM(v) WHERE f < 300 AND (k < 300 OR b < 6000) (a scan leaf AND an OR of two)",
+                                    Q.and_(Q.leaf(Q.Pred.dict_range(1, 0, 300)), Q.or_(Q.leaf(Q.Pred.dict_range(4, 0, 100)), Q.leaf(Q.Pred.dict_range(6, 0, 3000)))))):
+                if want(vid):
+                    sp3 = Q.QuerySpec([(Q.SUM, 0)], filter=flt3)
+                    report(vid, "numEntriesScannedInFilter of a leap-frogging filter at 1 B rows", sql, n, B(v) + B(f) + B(k) + B(b), g, seg, sp3)
+                    r3 = g.execute(sp3)
+                    out[-1]["filter_entries_exact"] = bool(r3.filter_entries_exact)
+                    out[-1]["num_entries_scanned_in_filter"] = int(r3.stats[1])
+                    if check:
+                        out[-1]["entries_match_oracle"] = bool(r3.stats[1] == oracle.execute(seg, sp3).stats[1]) if n <= 200_000_000 else None
             if want("COUNT-filter"):
                 report("COUNT-filter", "filter only", "SELECT COUNT(*) WHERE f < 100", n, B(f), g, seg, Q.QuerySpec([(Q.COUNT, -1)], filter=flt))
             if out:
