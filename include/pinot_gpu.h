@@ -249,6 +249,7 @@ typedef enum pg_kernel_id {
                                     * index-led aggregation whose index phase (index_and_kernel + its tile-list pass) outlasts the scan of the listed tiles */
   PG_KERNEL_SCAN_NARROW = 8,       /* scan_narrow_kernel: COUNT(*) / bitmap of a filter over dictionary columns of at most 8 bits, four tiles per wave */
   PG_KERNEL_SCAN_SPARSE = 9,       /* scan_sparse_kernel: aggregation of the docs a sparse docId bitmap names (index-led filters), eight tiles per wave */
+  PG_KERNEL_SCAN_RAW = 11,         /* scan_raw_kernel: one raw INT range leaf + at most one aggregated raw INT column, five waves per SIMD, coalesced reads */
   PG_KERNEL_SCAN_SIMPLE = 10,      /* scan_simple_kernel: one dictionary-range leaf + at most one aggregated packed column, twice the waves per SIMD */
   PG_KERNEL_SCAN_HIST = 6          /* scan_hist_kernel: lane-private scan, SUM = sum_d matches[d] * dictionary[d] through an LDS histogram */
 } pg_kernel_id;

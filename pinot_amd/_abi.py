@@ -13,7 +13,7 @@ PG_ABI_VERSION = 3
 PG_OK, PG_ERR_INVALID_ARGUMENT, PG_ERR_UNSUPPORTED, PG_ERR_DEVICE, PG_ERR_OUT_OF_MEMORY, PG_ERR_NOT_INITIALIZED, PG_ERR_INTERNAL = range(7)
 # pg_data_type / pg_fwd_encoding
 KERNEL_NAMES = {0: "scan_agg_kernel", 1: "scan_private_kernel", 2: "scan_group_kernel", 3: "group_private_kernel",
-                4: "group_partition_scatter_kernel", 5: "scan_private_typed_kernel", 6: "scan_hist_kernel", 7: "index_and_kernel", 8: "scan_narrow_kernel", 9: "scan_sparse_kernel", 10: "scan_simple_kernel"}
+                4: "group_partition_scatter_kernel", 5: "scan_private_typed_kernel", 6: "scan_hist_kernel", 7: "index_and_kernel", 8: "scan_narrow_kernel", 9: "scan_sparse_kernel", 10: "scan_simple_kernel", 11: "scan_raw_kernel"}
 PG_TYPE_INT, PG_TYPE_LONG, PG_TYPE_FLOAT, PG_TYPE_DOUBLE = range(4)
 PG_FWD_FIXED_BIT_DICT, PG_FWD_RAW_FIXED_BYTE = 0, 1
 # pg_predicate_kind / pg_leaf_eval

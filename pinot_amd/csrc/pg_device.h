@@ -22,6 +22,8 @@ constexpr int kMaxHashLevels = 8;               // chained first tables of a key
 constexpr int kMaxGroupAggs = 8;                // distinct (column, SUM|MIN|MAX) pairs of a group-by query
 constexpr int kStackDepth = 8;
 constexpr int kBlockThreads = 256;              // scan_agg_kernel: at most 4 wavefronts per workgroup
+constexpr int kWideBlockThreads = 640;          // scan_simple_kernel / scan_raw_kernel on a segment whose tiles all fit the chip at once: ten wavefronts per workgroup,
+                                                // two such workgroups per CU at five waves per SIMD -- 2.5x fewer records to hand to the fold, folded by 640 threads in one round
 constexpr int kHistBlockThreads = 1024;         // scan_hist_kernel: 16 wavefronts share one LDS histogram
 constexpr unsigned long long kPartialHistAlarm = 1ull;   // BlockPartial.flags
 constexpr unsigned long long kPartialStale = 2ull;       // BlockPartial.flags of a FOLDED record: a workgroup's record did not carry this launch's stamp

@@ -75,6 +75,7 @@ struct Engine {
   bool poll_result = true;   // PINOT_GPU_POLL_RESULT=0: pg_execute always waits with hipStreamSynchronize instead of spinning on the pinned record's sequence number
   bool lane_skip = true;     // PINOT_GPU_LANE_SKIP=0: the aggregating kernels load a tile's value bytes for every lane, matches or not
   int batch_blocks_per_cu = 4;    // PINOT_GPU_BATCH_BLOCKS_PER_CU: workgroups per CU a batch launch is cut into (all items together)
+  bool scan_raw = true;      // PINOT_GPU_SCAN_RAW=0: raw INT scans stay in scan_private_kernel / scan_private_typed_kernel (four waves per SIMD)
   bool scan_simple = true;   // PINOT_GPU_SCAN_SIMPLE=0: one-leaf / one-column queries stay in scan_private_kernel (half the waves per SIMD)
   bool scan_sparse = true;   // PINOT_GPU_SCAN_SPARSE=0: index-led aggregations scan their listed tiles in scan_private_kernel (one tile per wave and iteration)
   bool batch_launch = true;  // PINOT_GPU_BATCH_LAUNCH=0: pg_execute_batch runs every item as a pg_execute of its own on the worker threads (no shared launch)
@@ -1592,6 +1593,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.scan_sparse = !(ssp && ssp[0] == '0');
   const char* ssm = getenv("PINOT_GPU_SCAN_SIMPLE");
   g_engine.scan_simple = !(ssm && ssm[0] == '0');
+  const char* srw = getenv("PINOT_GPU_SCAN_RAW");
+  g_engine.scan_raw = !(srw && srw[0] == '0');
   const char* bla = getenv("PINOT_GPU_BATCH_LAUNCH");
   g_engine.batch_launch = !(bla && bla[0] == '0');
   const char* lp2 = getenv("PINOT_GPU_LEAP2");
@@ -2540,12 +2543,42 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       use_simple = ac.bits >= 1 && ac.bits <= kSimpleMaxBits && !ac.is_raw;
       if (use_simple && sp.num_nodes == 1 && sp.nodes[0].fwd == ac.fwd && sp.nodes[0].bits == ac.bits && ac.need_sum != 0 && ac.need_minmax == 0 && sp.nodes[0].exclusive == 0) use_simple = false;
     }
-    if (use_simple) {
+    // A segment whose tiles all fit the chip at once (one tile per wave: a 10 M-row segment at five waves per SIMD) is latency from end
+    // to end -- launch, one round of loads, the hand-off of the workgroups' records to the fold.  Ten waves per workgroup there: 2.5x
+    // fewer records, and a folding workgroup of 640 threads takes them in ONE round of loads (256 threads took five for 1221 records).
+    int lean_threads = kBlockThreads;
+    auto lean_geometry = [&](int wave_cap) {
       const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
-      int bpc = std::max(1, waves_scan_simple() / (kBlockThreads / 64));
+      static const bool wide_ok = getenv("PINOT_GPU_WIDE_BLOCKS") && getenv("PINOT_GPU_WIDE_BLOCKS")[0] == '1';      // (measured slower at every size: off unless asked for)
+      const int wide_waves = kWideBlockThreads / 64;
+      const bool wide = wide_ok && wave_cap >= 2 * wide_waves && tiles2k > 64 && tiles2k <= (long long)seg->num_cus * wave_cap && g_engine.blocks_per_cu <= 0;
+      lean_threads = wide ? kWideBlockThreads : kBlockThreads;
+      const int wpb = lean_threads / 64;
+      int bpc = std::max(1, wave_cap / wpb);
+      // Up to two rounds of resident waves' worth of tiles (~20 M rows), the hand-off of the workgroups' records to the fold weighs more
+      // than a second round of loads: two workgroups per CU (profiles/r4/c1_probe_blocks_per_cu.jsonl: 10 M rows, 1221 workgroups
+      // 21.4 us, 512 workgroups 17.8 us; the scan alone 12.9 us)
+      static const int small_bpc = getenv("PINOT_GPU_SMALL_BLOCKS_PER_CU") ? atoi(getenv("PINOT_GPU_SMALL_BLOCKS_PER_CU")) : 2;
+      if (!wide && small_bpc > 0 && tiles2k <= 2ll * seg->num_cus * wave_cap) bpc = std::min(bpc, small_bpc);
       if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
-      blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + 3) / 4, (long long)seg->num_cus * bpc));
+      blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + wpb - 1) / wpb, (long long)seg->num_cus * bpc));
+    };
+    if (use_simple) lean_geometry(waves_scan_simple());
+    // The same idea for raw INT columns (BASELINE.json configs[0]'s scan pair): one raw-range leaf (or no filter) in front of at most one
+    // aggregated raw INT column -- scan_raw_kernel, five waves per SIMD, coalesced reads (pg_scan_raw.h).
+    bool use_raw = g_engine.scan_raw && (use_private || use_private_typed) && !use_hist && !use_narrow && !use_sparse && !use_simple && !want_bitmap && lw.tile_list == nullptr &&
+                   lw.side == nullptr && sp.num_nodes <= 1 && pl.num_agg_cols <= 1 && sp.num_nodes + pl.num_agg_cols >= 1 && !(g_engine.flags & PG_CFG_PROFILE_WAVES) &&
+                   (defer == nullptr || ((long long)seg->num_docs + 2047) / 2048 > kBatchMaxTiles) &&      // (an item of a batch shares the batch's launch instead)
+                   !(out && (lw.stats_leap2_flagged || lw.stats_chain_flagged));
+    if (use_raw && sp.num_nodes == 1) {
+      const DevNode& dn = sp.nodes[0];
+      use_raw = dn.op == PG_FILTER_LEAF && dn.kind == kLeafRawRange && dn.fwd != nullptr && (dn.flags & (kNodeCountEntries | kNodeLeapfrog2)) == 0;
     }
+    if (use_raw && pl.num_agg_cols == 1) {
+      const DevAggCol& ac = sp.agg_cols[0];
+      use_raw = ac.is_raw != 0 && ac.vkind == kValI32 && ac.is_plane == 0 && ac.bits == 32;
+    }
+    if (use_raw) lean_geometry(waves_scan_raw());
     if (use_narrow) {
       const int per_wave = narrow_single ? kNarrowSingleTiles : kNarrowTiles;
       const long long quads = (((long long)seg->num_docs + 2047) / 2048 + per_wave - 1) / per_wave;
@@ -2583,7 +2616,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // (the entries counted by the kernel travel in its record: BlockPartial.entries -- no counter to zero, no copy command)
     // The folded record -> the reference's holder types.  Everything is captured by value: pg_execute_batch calls it after this function
     // has returned (the query, the segment and the context's pinned counter outlive the batch).
-    const int kernel_id = use_hist ? PG_KERNEL_SCAN_HIST : use_narrow ? PG_KERNEL_SCAN_NARROW : use_sparse ? PG_KERNEL_SCAN_SPARSE : use_simple ? PG_KERNEL_SCAN_SIMPLE : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
+    const int kernel_id = use_hist ? PG_KERNEL_SCAN_HIST : use_narrow ? PG_KERNEL_SCAN_NARROW : use_sparse ? PG_KERNEL_SCAN_SPARSE : use_simple ? PG_KERNEL_SCAN_SIMPLE : use_raw ? PG_KERNEL_SCAN_RAW : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
     const HostRecord* host_record = ctx->h_record;
     const int profile_waves = blocks * (geo.threads / 64);
     const size_t num_projected = projected.size();
@@ -2652,7 +2685,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     sp.host_seq = seq;
     // fields a fold reduces: the aggregation slots in use (the histogram kernel keeps its checksum in slot 1), typed extras only for the typed kernels
     sp.fold_slots = use_hist ? 2 : pl.num_agg_cols;
-    sp.fold_typed = (use_private_typed || (!use_hist && !use_narrow && !use_private && typed)) ? 1 : 0;
+    sp.fold_typed = (!use_raw && (use_private_typed || (!use_hist && !use_narrow && !use_private && typed))) ? 1 : 0;
     sp.lane_skip = g_engine.lane_skip ? 1 : 0;
     sp.sparse_lanes = g_engine.sparse_lanes;
     sp.fold_one_counter = g_engine.fold_one_counter;
@@ -2660,7 +2693,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       // (the shared launch is for the many small segments of a server: a segment that fills the chip on its own -- more tiles than a few
       //  rounds of resident waves -- runs the kernel the planner picked for it, concurrently with the others, on a worker thread's stream:
       //  eight 1 B-row items 4.72 ms in one launch, 4.45 ms as eight overlapping launches)
-      if (use_private && !use_hist && !use_narrow && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
+      if (use_private && !use_raw && !use_hist && !use_narrow && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
           ((long long)seg->num_docs + 2047) / 2048 <= kBatchMaxTiles &&
           (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf)) {
         defer->sp = sp;
@@ -2680,7 +2713,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (use_hist) launch_scan_hist(hist_cw, hist_guarded, blocks, hist_lds, ctx->stream, sp);
     else if (use_narrow) launch_scan_narrow(narrow_single, blocks, ctx->stream, sp);
     else if (use_sparse) launch_scan_sparse(one, blocks, ctx->stream, sp);
-    else if (use_simple) launch_scan_simple(blocks, ctx->stream, sp);
+    else if (use_simple) launch_scan_simple(blocks, lean_threads, ctx->stream, sp);
+    else if (use_raw) launch_scan_raw(blocks, lean_threads, ctx->stream, sp);
     else if (use_private) launch_scan_private(pl.num_agg_cols, blocks, ctx->stream, sp);
     else if (use_private_typed) launch_scan_private_typed(pl.num_agg_cols, blocks, ctx->stream, sp);
     else launch_scan_agg(g_engine.use_dma, one, typed, blocks, geo.threads, lds, ctx->stream, sp);

@@ -44,8 +44,11 @@ void launch_scan_private_batch(bool one_slot, int total_blocks, hipStream_t stre
 void launch_scan_sparse(bool one_slot, int blocks, hipStream_t stream, const ScanParams& p);      // one_slot: at most one aggregated column
 int waves_scan_sparse(bool one_slot);
 // scan_simple_kernel: one dictionary-range leaf (or none) + at most one aggregated packed column of <= 20 bits (pg_scan_simple.h)
-void launch_scan_simple(int blocks, hipStream_t stream, const ScanParams& p);
+void launch_scan_simple(int blocks, int threads, hipStream_t stream, const ScanParams& p);      // threads: kBlockThreads or kWideBlockThreads
 int waves_scan_simple();
+// scan_raw_kernel: one raw INT range leaf (or no filter) + at most one aggregated raw INT column, five waves per SIMD, coalesced reads (pg_scan_raw.h)
+void launch_scan_raw(int blocks, int threads, hipStream_t stream, const ScanParams& p);
+int waves_scan_raw();
 // scan_narrow_kernel: COUNT(*) / docId bitmap of a filter over columns of at most 8 bits (pg_scan_narrow.h)
 void launch_scan_narrow(bool single_leaf, int blocks, hipStream_t stream, const ScanParams& p);      // single_leaf: scan_narrow_single_kernel, eight tiles per iteration
 int waves_scan_narrow(bool single_leaf);

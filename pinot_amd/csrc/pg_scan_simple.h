@@ -50,8 +50,8 @@ __device__ __forceinline__ void simple_agg_dispatch(int b, WP lane_words, uint32
   }
 }
 
-__global__ __launch_bounds__(kBlockThreads, PG_SIMPLE_WAVES) void scan_simple_kernel(const ScanParams p) {
-  __shared__ BlockPartial red[kBlockThreads / 64];
+__global__ __launch_bounds__(kWideBlockThreads, PG_SIMPLE_WAVES) void scan_simple_kernel(const ScanParams p) {
+  __shared__ BlockPartial red[kWideBlockThreads / 64];      // (launched with kBlockThreads or kWideBlockThreads threads)
   __shared__ uint32_t fold_flag;
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;

@@ -4,8 +4,8 @@
 
 namespace pg {
 
-void launch_scan_simple(int blocks, hipStream_t stream, const ScanParams& p) {
-  scan_simple_kernel<<<dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream>>>(p);
+void launch_scan_simple(int blocks, int threads, hipStream_t stream, const ScanParams& p) {
+  scan_simple_kernel<<<dim3((unsigned)blocks), dim3((unsigned)threads), 0, stream>>>(p);
 }
 
 int waves_scan_simple() {
