@@ -217,7 +217,8 @@ struct ScanParams {
   // (nullptr: that leaf is not wanted) -- so that the pass does not have to scan the leaves' columns again.
   uint32_t* leaf_out[kMaxLeaves];
   int32_t leaf_out_enabled;
-  int32_t reserved_lo;
+  int32_t lean_kind;               // pg_execute_batch: 0 the general lane-private body, 1 the item has scan_simple_kernel's shape, 2 scan_raw_kernel's
+                                   // (scan_lean_batch_kernel runs those at five waves per SIMD)
 };
 
 // What a query's scan brings back to the host: the folded record, then a sequence number written after it.

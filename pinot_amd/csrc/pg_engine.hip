@@ -2568,7 +2568,6 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // aggregated raw INT column -- scan_raw_kernel, five waves per SIMD, coalesced reads (pg_scan_raw.h).
     bool use_raw = g_engine.scan_raw && (use_private || use_private_typed) && !use_hist && !use_narrow && !use_sparse && !use_simple && !want_bitmap && lw.tile_list == nullptr &&
                    lw.side == nullptr && sp.num_nodes <= 1 && pl.num_agg_cols <= 1 && sp.num_nodes + pl.num_agg_cols >= 1 && !(g_engine.flags & PG_CFG_PROFILE_WAVES) &&
-                   (defer == nullptr || ((long long)seg->num_docs + 2047) / 2048 > kBatchMaxTiles) &&      // (an item of a batch shares the batch's launch instead)
                    !(out && (lw.stats_leap2_flagged || lw.stats_chain_flagged));
     if (use_raw && sp.num_nodes == 1) {
       const DevNode& dn = sp.nodes[0];
@@ -2693,9 +2692,14 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       // (the shared launch is for the many small segments of a server: a segment that fills the chip on its own -- more tiles than a few
       //  rounds of resident waves -- runs the kernel the planner picked for it, concurrently with the others, on a worker thread's stream:
       //  eight 1 B-row items 4.72 ms in one launch, 4.45 ms as eight overlapping launches)
-      if (use_private && !use_raw && !use_hist && !use_narrow && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
+      if ((use_private || use_raw) && !use_hist && !use_narrow && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
           ((long long)seg->num_docs + 2047) / 2048 <= kBatchMaxTiles &&
           (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf)) {
+        // items of scan_simple_kernel's / scan_raw_kernel's shape share a launch of their own kind (scan_lean_batch_kernel), the rest the general one
+        static const bool lean_batch = !(getenv("PINOT_GPU_LEAN_BATCH") && getenv("PINOT_GPU_LEAN_BATCH")[0] == '0');
+        sp.lean_kind = use_simple ? 1 : (use_raw ? 2 : 0);
+        if (!lean_batch && sp.lean_kind == 1) sp.lean_kind = 0;      // (a raw-shaped item has no general form when its column is aggregated: it stays lean)
+        if (sp.lean_kind == 2 && !lean_batch && use_private) sp.lean_kind = 0;
         defer->sp = sp;
         defer->blocks = blocks;
         defer->one_slot = pl.num_agg_cols <= 1;
@@ -3965,7 +3969,7 @@ pg_status ensure_batch_ctx(BatchCtx* b, int items, size_t partials) {
 // runs all segments of a query on one pool): enqueue_deferred copies the items and launches, finish_deferred waits and converts.
 struct DeferredLaunch {
   BatchCtx* b = nullptr;
-  int device = -1, n = 0;
+  int device = -1, n = 0, lean_kind = 0;       // lean_kind: ScanParams.lean_kind of every item (0: scan_private_batch_kernel, 1 / 2: scan_lean_batch_kernel)
   std::vector<int> items, blocks;
   long long total_blocks = 0, docs = 0;
   unsigned long long seq = 0;
@@ -3990,7 +3994,10 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
   // the items' tails overlap other items' scans); never more than the item would get on its own.
   long long total_tiles = 0;
   for (int i : items) { total_tiles += ((long long)segments[i]->num_docs + 2047) / 2048; L->docs += (long long)segments[i]->num_docs; }
-  const long long budget = (long long)segments[items[0]]->num_cus * g_engine.batch_blocks_per_cu;
+  // (the lean kernels hold five -- raw: four -- waves per SIMD: a workgroup per CU more than the general body's four)
+  const int lean_bpc = L->lean_kind != 0 ? std::max(1, waves_scan_lean_batch(L->lean_kind) / (kBlockThreads / 64)) : 0;
+  const bool bpc_forced = getenv("PINOT_GPU_BATCH_BLOCKS_PER_CU") != nullptr;      // (bench sweeps re-initialise the engine with it)
+  const long long budget = (long long)segments[items[0]]->num_cus * ((L->lean_kind != 0 && !bpc_forced) ? lean_bpc : g_engine.batch_blocks_per_cu);
   std::vector<int>& blocks = L->blocks;
   blocks.assign((size_t)n, 0);
   size_t partials = 0;
@@ -4027,7 +4034,8 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
   L->t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipMemcpyAsync(b->d_blob, b->h_blob, b->items_offset + sizeof(ScanParams) * (size_t)n, hipMemcpyHostToDevice, b->stream));
   if (L->timed) HIP_TRY(hipEventRecord(b->ev[0], b->stream));
-  launch_scan_private_batch(one_slot, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
+  if (L->lean_kind != 0) launch_scan_lean_batch(L->lean_kind, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
+  else launch_scan_private_batch(one_slot, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
   HIP_TRY(hipGetLastError());
   if (L->timed) HIP_TRY(hipEventRecord(b->ev[1], b->stream));
   L->t1 = std::chrono::steady_clock::now();
@@ -4101,8 +4109,9 @@ pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* q
   for (int i = 0; i < count; ++i) {
     if (statuses[i] != kDeferred) continue;
     DeferredLaunch* L = nullptr;
-    for (auto& l : launches) if (l->device == segments[i]->device) L = l.get();
-    if (!L) { launches.emplace_back(new DeferredLaunch()); L = launches.back().get(); L->device = segments[i]->device; }
+    const int kind = defs[(size_t)i].sp.lean_kind;
+    for (auto& l : launches) if (l->device == segments[i]->device && l->lean_kind == kind) L = l.get();
+    if (!L) { launches.emplace_back(new DeferredLaunch()); L = launches.back().get(); L->device = segments[i]->device; L->lean_kind = kind; }
     L->items.push_back(i);
   }
   auto fail_items = [&](DeferredLaunch* L, pg_status st) {

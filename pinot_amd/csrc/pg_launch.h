@@ -49,6 +49,9 @@ int waves_scan_simple();
 // scan_raw_kernel: one raw INT range leaf (or no filter) + at most one aggregated raw INT column, five waves per SIMD, coalesced reads (pg_scan_raw.h)
 void launch_scan_raw(int blocks, int threads, hipStream_t stream, const ScanParams& p);
 int waves_scan_raw();
+// scan_lean_batch_kernel: the shared launch of pg_execute_batch for items of those two shapes (ScanParams.lean_kind), five waves per SIMD
+void launch_scan_lean_batch(int kind, int total_blocks, hipStream_t stream, const ScanParams* items, const uint32_t* block_first, int num_items);      // kind: 1 simple, 2 raw (every item)
+int waves_scan_lean_batch(int kind);
 // scan_narrow_kernel: COUNT(*) / docId bitmap of a filter over columns of at most 8 bits (pg_scan_narrow.h)
 void launch_scan_narrow(bool single_leaf, int blocks, hipStream_t stream, const ScanParams& p);      // single_leaf: scan_narrow_single_kernel, eight tiles per iteration
 int waves_scan_narrow(bool single_leaf);

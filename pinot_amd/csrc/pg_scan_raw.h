@@ -34,13 +34,14 @@ __device__ __forceinline__ uint32_t raw_value(const RawTile& t, int j, int k) {
   return __builtin_bswap32(be);
 }
 
-__global__ __launch_bounds__(kWideBlockThreads, PG_RAW_WAVES) void scan_raw_kernel(const ScanParams p) {
-  __shared__ BlockPartial red[kWideBlockThreads / 64];      // (launched with kBlockThreads or kWideBlockThreads threads)
-  __shared__ uint32_t fold_flag;
+// `block_index` of `num_blocks`: the workgroup's place among those that work on this query (the whole grid, or one item's share of a
+// batch launch: scan_lean_batch_kernel).  P: ScanParams, or its constant-address-space form there.
+template <typename P>
+__device__ __forceinline__ void scan_raw_body(const P& p, uint32_t block_index, uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
-  const long long total_waves = (long long)gridDim.x * waves_per_block;
+  const long long total_waves = (long long)num_blocks * waves_per_block;
   const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
   const bool has_filter = p.num_nodes == 1;
   const bool has_agg = p.num_agg_cols == 1;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(kWideBlockThreads, PG_RAW_WAVES) void scan_raw_kern
   unsigned long long count = 0;
   long long sum = 0;
   int32_t vmin = 0x7FFFFFFF, vmax = (int32_t)0x80000000;
-  for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
+  for (long long tile = (long long)block_index * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
     const long long rem = (long long)p.num_docs - tile * 2048;           // docs of this tile that exist (the last tile: fewer than 2048)
     RawTile t;
     uint32_t m = 0xFFFFFFFFu;                                            // bit 4 j + k: doc 256 j + 4 lane + k matches
@@ -104,7 +105,9 @@ __global__ __launch_bounds__(kWideBlockThreads, PG_RAW_WAVES) void scan_raw_kern
   mine.kmax[0] = wave_max_i32(vmax);
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
-  publish_block_partial(p, red, waves_per_block, &fold_flag);
+  publish_block_partial(p, red, waves_per_block, fold_flag_ptr, block_index, num_blocks);
 }
+
+// (scan_raw_kernel itself -- the body over the whole grid -- is defined in pg_unit_scan_raw.hip: this header is also included by the batch kernel's unit)
 
 }  // namespace pg

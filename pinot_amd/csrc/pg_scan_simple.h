@@ -50,13 +50,14 @@ __device__ __forceinline__ void simple_agg_dispatch(int b, WP lane_words, uint32
   }
 }
 
-__global__ __launch_bounds__(kWideBlockThreads, PG_SIMPLE_WAVES) void scan_simple_kernel(const ScanParams p) {
-  __shared__ BlockPartial red[kWideBlockThreads / 64];      // (launched with kBlockThreads or kWideBlockThreads threads)
-  __shared__ uint32_t fold_flag;
+// `block_index` of `num_blocks`: the workgroup's place among those that work on this query (the whole grid, or one item's share of a
+// batch launch: scan_lean_batch_kernel).  P: ScanParams, or its constant-address-space form there.
+template <typename P>
+__device__ __forceinline__ void scan_simple_body(const P& p, uint32_t block_index, uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
-  const long long total_waves = (long long)gridDim.x * waves_per_block;
+  const long long total_waves = (long long)num_blocks * waves_per_block;
   const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
   const bool has_filter = p.num_nodes == 1;
   const bool has_agg = p.num_agg_cols == 1;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kWideBlockThreads, PG_SIMPLE_WAVES) void scan_simpl
   // (Two tiles per iteration -- both tiles' chunks of a column loaded before either is decoded -- was measured on this kernel and lost:
   // C2b at 10 % 0.580 -> 0.601 ms, 3 % 0.543 -> 0.569, profiles/r3/ab_scan_simple_pair_*.jsonl.  A wave's own second request buys nothing
   // the fifth wave has not already bought, and the longer decode blocks cost more than they hide.)
-  for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
+  for (long long tile = (long long)block_index * waves_per_block + wave_in_block; tile < num_tiles; tile += total_waves) {
     uint32_t m = 0xFFFFFFFFu;
     if (has_filter) {
       const GlobalWords words = global_words(L.fwd + tile * (256ll * L.bits)) + lane * L.bits;
@@ -100,7 +101,9 @@ __global__ __launch_bounds__(kWideBlockThreads, PG_SIMPLE_WAVES) void scan_simpl
   mine.kmax[0] = wave_max_i32(count == 0ull ? (int32_t)0x80000000 : (int32_t)umax);
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
-  publish_block_partial(p, red, waves_per_block, &fold_flag);
+  publish_block_partial(p, red, waves_per_block, fold_flag_ptr, block_index, num_blocks);
 }
+
+// (scan_simple_kernel itself -- the body over the whole grid -- is defined in pg_unit_scan_simple.hip: this header is also included by the batch kernel's unit)
 
 }  // namespace pg

@@ -4,6 +4,12 @@
 
 namespace pg {
 
+__global__ __launch_bounds__(kWideBlockThreads, PG_SIMPLE_WAVES) void scan_simple_kernel(const ScanParams p) {
+  __shared__ BlockPartial red[kWideBlockThreads / 64];      // (launched with kBlockThreads or kWideBlockThreads threads)
+  __shared__ uint32_t fold_flag;
+  scan_simple_body(p, blockIdx.x, gridDim.x, red, &fold_flag);
+}
+
 void launch_scan_simple(int blocks, int threads, hipStream_t stream, const ScanParams& p) {
   scan_simple_kernel<<<dim3((unsigned)blocks), dim3((unsigned)threads), 0, stream>>>(p);
 }
