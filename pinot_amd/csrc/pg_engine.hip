@@ -2602,7 +2602,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const bool count_entries = (out && lw.stats_chain_flagged && (use_hist || use_private || use_private_typed)) || count_leap2;
     if (lw.side != nullptr) {
       // the transducer pass behind this query: a kernel that evaluates the filter with eval_filter_private over every tile leaves the leaves' bitmaps behind
-      const bool wrote = !use_narrow && !use_sparse && !use_simple && (use_hist || use_private || use_private_typed) && sp.tile_list == nullptr;
+      const bool wrote = !(use_narrow && narrow_single) && !use_sparse && !use_simple && !use_raw && (use_hist || use_private || use_private_typed) && sp.tile_list == nullptr;
       for (int l = 0; l < kMaxLeaves; ++l) sp.leaf_out[l] = wrote ? lw.sp_leaf_out[l] : nullptr;
       sp.leaf_out_enabled = wrote ? 1 : 0;
       lw.side->kernel_wrote = wrote;

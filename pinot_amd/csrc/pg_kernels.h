@@ -2506,8 +2506,17 @@ static __global__ __launch_bounds__(64) void index_and_kernel(const IndexAndPara
                                        ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)c_off_hi, last) << 32);
         const uint32_t lead = (uint32_t)(off & 3ull);
         const uint32_t* origin = reinterpret_cast<const uint32_t*>(ch.inv + (off - lead));
+        // Behind the smaller children only the pieces where something still stands are wanted (three postings of 1 / 256, 1 / 64 and
+        // 1 / 16 of the docs: ~4 docs of the window are left when the 8 KB bitset of the largest comes up -- AndDocIdSet.java:127-165
+        // and-s smallest first for the same reason).  A lane whose piece is not wanted reads piece 0 instead -- one line for the whole
+        // wave -- so that the eight loads stay unconditional (a load under an exec mask is waited for before the branch is left).
+        const bool probe = c > 0 && !ch.exclusive;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const Dwords4 d = load16_stream(origin, lead, lane + 64 * i); v[i] = make_uint4(d.x, d.y, d.z, d.w); }
+        for (int i = 0; i < 8; ++i) {
+          const bool wanted = !probe || (acc[i].x | acc[i].y | acc[i].z | acc[i].w) != 0u;
+          const Dwords4 d = load16_stream(origin, lead, wanted ? lane + 64 * i : 0);
+          v[i] = wanted ? make_uint4(d.x, d.y, d.z, d.w) : make_uint4(0u, 0u, 0u, 0u);
+        }
       } else {
         for (int q = ch.posting_begin; q < ch.posting_end; ++q) {
           if (!__builtin_amdgcn_readlane(c_valid, q)) continue;

@@ -76,6 +76,7 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_kernel(const
 #pragma unroll
       for (int t = 0; t < kNarrowTiles; ++t) st.v[i][t] = 0u;
     st.sp = 0;
+    int leaf_ordinal = 0;
     for (int n = 0; n < p.num_nodes; ++n) {
       const DevNode& nd = p.nodes[n];
       uint32_t top[kNarrowTiles];
@@ -95,6 +96,15 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_kernel(const
 #pragma unroll
           for (int t = 0; t < kNarrowTiles; ++t) top[t] = ~top[t];
         }
+        if (p.leaf_out_enabled != 0) {
+          // the transducer pass of numEntriesScannedInFilter wants this leaf's own match bits (ScanParams.leaf_out, pg_filter_fsm.h)
+          uint32_t* const leaf_bits = p.leaf_out[leaf_ordinal];
+          if (leaf_bits != nullptr) {
+#pragma unroll
+            for (int t = 0; t < kNarrowTiles; ++t) if (quad * kNarrowTiles + t < num_tiles) leaf_bits[(quad * kNarrowTiles + t) * 64 + lane] = top[t];
+          }
+        }
+        ++leaf_ordinal;
       } else if (nd.op == PG_FILTER_NOT) {
         st.pop(top);
 #pragma unroll

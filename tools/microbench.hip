@@ -199,6 +199,23 @@ __global__ __launch_bounds__(256) void lane_contiguous_read(const uint8_t* __res
 }
 
 
+// 8. FETCH_SIZE calibration for sparse access: every lane reads kBytes (8 / 16) at a stride of kStride bytes -- one piece per 128-byte
+// line (kStride 128), per 64-byte half (64), or every kStride-th line -- over a buffer far larger than the 256 MiB Infinity Cache.  The
+// bytes the kernel asks for are known exactly; what rocprofv3's FETCH_SIZE reports for them is the calibration factor of the walks that
+// read a few bytes around each matching doc (agg_sparse_private, scan_sparse_kernel).  Run under
+//   rocprofv3 --kernel-trace --pmc FETCH_SIZE -- ./tools/microbench sparse
+template <int kStride, int kBytes>
+__global__ __launch_bounds__(256) void sparse_read(const uint8_t* __restrict__ src, size_t pieces, unsigned long long* out) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, total = (size_t)gridDim.x * blockDim.x;
+  unsigned long long acc = 0;
+  for (size_t i = gid; i < pieces; i += total) {
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(src + i * kStride);
+    acc ^= p[0];
+    if (kBytes == 16) acc ^= p[1];
+  }
+  if (acc == 0x12345678ull) out[0] = acc;
+}
+
 // 6. VALU issue rate of the integer ops the decode loop is made of (is a wave64 op 2 or 4 cycles on a SIMD?)
 template <int kOp>
 __global__ __launch_bounds__(256) void valu_rate(int iters, unsigned long long* out) {
@@ -272,6 +289,24 @@ int main(int argc, char** argv) {
   const int cus = prop.multiProcessorCount;
   unsigned long long* d_out;
   CHECK(hipMalloc((void**)&d_out, 64));
+
+  if (argc > 1 && !strcmp(argv[1], "sparse")) {
+    const size_t bytes = 4ull << 30;
+    uint8_t* d_buf;
+    CHECK(hipMalloc((void**)&d_buf, bytes));
+    CHECK(hipMemset(d_buf, 0x5a, bytes));
+    const int blocks = cus * 8;
+    // (one launch each, so that a per-kernel FETCH_SIZE is one dispatch; the names carry the pattern)
+    double a = time_ms([&] { sparse_read<128, 8><<<blocks, 256>>>(d_buf, bytes / 128, d_out); }, 1);
+    double b = time_ms([&] { sparse_read<64, 8><<<blocks, 256>>>(d_buf, bytes / 64, d_out); }, 1);
+    double c = time_ms([&] { sparse_read<256, 8><<<blocks, 256>>>(d_buf, bytes / 256, d_out); }, 1);
+    double d = time_ms([&] { sparse_read<512, 16><<<blocks, 256>>>(d_buf, bytes / 512, d_out); }, 1);
+    double e = time_ms([&] { stream_read<<<blocks, 256>>>((const uint4*)d_buf, bytes / 16, d_out); }, 1);
+    printf("{\"bench\": \"sparse_read\", \"buffer_bytes\": %zu, \"ms\": {\"8B_per_128B_line\": %.3f, \"8B_per_64B_half\": %.3f, \"8B_per_256B\": %.3f, \"16B_per_512B\": %.3f, \"stream_16B_per_lane\": %.3f},"
+           " \"lines_touched\": {\"8B_per_128B_line\": %zu, \"8B_per_64B_half\": %zu, \"8B_per_256B\": %zu, \"16B_per_512B\": %zu, \"stream_16B_per_lane\": %zu}}\n",
+           bytes, a, b, c, d, e, bytes / 128, bytes / 128, bytes / 256, bytes / 512, bytes / 128);
+    return 0;
+  }
 
   if (only_lane) {
     const size_t bytes = 4ull << 30;
