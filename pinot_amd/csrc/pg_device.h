@@ -332,6 +332,29 @@ struct PartitionParams {
   uint32_t* part_key;               // [num_docs] raw keys
   uint32_t* part_val[kMaxPartitionAggs];   // [num_docs] 32-bit aggregation inputs (dictIds, plane fields or raw values)
   const PartitionWork* work;        // pass B work list
+  const uint32_t* work_count;       // two-level runs: the list was built on the device (group_repartition_plan_kernel) -- workgroups past *work_count leave; else nullptr
+};
+
+// ---- two-level partitioning (key spaces of 2 M .. 2^31 raw keys: pg_group_partition.h) ----
+// Pass A scatters by COARSE partition (at most kMaxPartitions of them, 2^log2_fine_per_coarse fine partitions each); the records of every
+// coarse partition are then scattered once more, by fine partition, into a second buffer -- pass B aggregates fine partitions as before.
+constexpr int kMaxFinePerCoarse = 1024;
+constexpr uint32_t kRepartitionChunk = 1u << 16;      // records one workgroup of the re-scatter takes (counted, then placed: two reads, the second out of L2)
+struct RepartitionParams {
+  const uint32_t* src_key;                   // pass A's records, by coarse partition
+  const uint32_t* src_val[kMaxPartitionAggs];
+  uint32_t* dst_key;                         // the same records, by fine partition
+  uint32_t* dst_val[kMaxPartitionAggs];
+  const uint32_t* coarse_offsets;            // [P1 + 1] first record of every coarse partition's buffer
+  const uint32_t* coarse_cursor;             // [P1] records pass A wrote
+  uint32_t* fine_count;                      // [P1 << k] records per fine partition (counted by group_repartition_count_kernel)
+  uint32_t* fine_offsets;                    // [P1 << k] first record of every fine partition inside its coarse partition's range of the second buffer
+  uint32_t* fine_cursor;                     // [P1 << k] records placed so far
+  PartitionWork* work;                       // pass B's work list, built by group_repartition_plan_kernel
+  uint32_t* work_count;
+  const PartitionWork* chunks;               // the re-scatter's own work list: (coarse partition, start, length) chunks of at most kRepartitionChunk records
+  int32_t num_coarse, log2_fine_per_coarse, fine_shift, packed_bits, num_vals;
+  uint32_t aggregate_chunk;                  // most records one pass-B workgroup takes
 };
 
 // ---- index-only AND (index_and_kernel): the inverted-index children of a root AND, intersected window by window ----

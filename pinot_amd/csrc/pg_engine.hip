@@ -2964,9 +2964,24 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // (pg_group_partition.h) instead of one global atomic per doc and aggregation.
     const int partition_entry_bytes = 4 + 8 * gp.num_group_aggs;
     const int partition_shift = partition_entry_bytes <= 20 ? 12 : 11;
-    const long long num_partitions = (product + (1ll << partition_shift) - 1) >> partition_shift;
+    const long long fine_partitions = (product + (1ll << partition_shift) - 1) >> partition_shift;
+    // More fine partitions than one scatter pass can address (key spaces of 2 M .. 2^31 raw keys): two levels -- pass A scatters by
+    // coarse partition (2^k fine ones each), group_repartition_*_kernel scatter every coarse partition's records by fine partition
+    // (pg_group_partition.h).  PINOT_GPU_PARTITION_TWO_LEVEL=0: such key spaces keep the direct HBM atomics.
+    static const bool two_level_on = !(getenv("PINOT_GPU_PARTITION_TWO_LEVEL") && getenv("PINOT_GPU_PARTITION_TWO_LEVEL")[0] == '0');
+    int log2_fine_per_coarse = 0;
+    while (((fine_partitions + (1ll << log2_fine_per_coarse) - 1) >> log2_fine_per_coarse) > kMaxPartitions) ++log2_fine_per_coarse;
+    const bool two_level = log2_fine_per_coarse > 0;
+    const long long num_partitions = (fine_partitions + (1ll << log2_fine_per_coarse) - 1) >> log2_fine_per_coarse;       // what pass A scatters into
+    const int scatter_shift = partition_shift + log2_fine_per_coarse;
     const bool use_partition = hash_plan.kind == 0 && !typed_direct && map_based && g_engine.group_partition && g_engine.group_private && private_leaves && gp.dense_ok && !want_bitmap &&
-                               gp.num_group_aggs <= kMaxPartitionAggs && num_partitions <= kMaxPartitions && (long long)seg->num_docs >= g_engine.partition_min_docs;
+                               gp.num_group_aggs <= kMaxPartitionAggs && (!two_level || (two_level_on && (1 << log2_fine_per_coarse) <= kMaxFinePerCoarse)) &&
+                               (long long)seg->num_docs >= g_engine.partition_min_docs;
+    static const bool partition_trace = getenv("PINOT_GPU_PARTITION_TRACE") != nullptr;
+    if (partition_trace)
+      fprintf(stderr, "group-by plan: product %lld, fine partitions %lld (shift %d), 2^%d per coarse -> %lld scatter partitions; partition %d (hash %d typed_direct %d map_based %d "
+                      "private_leaves %d dense_ok %d aggs %d docs %d)\n", product, fine_partitions, partition_shift, log2_fine_per_coarse, num_partitions, (int)use_partition,
+              hash_plan.kind, (int)typed_direct, (int)map_based, (int)private_leaves, gp.dense_ok, gp.num_group_aggs, seg->num_docs);
     if (use_partition || !(use_private || typed_direct)) { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
     if (lw.side != nullptr) {
       const bool wrote = ((use_private && !use_partition) || typed_direct) && gp.scan.tile_list == nullptr;
@@ -2994,10 +3009,20 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         else if (gp.num_group_aggs == 1) {
           const DevGroupAgg& ga = gp.group_aggs[0];
           const bool unsigned_field = !ga.is_raw && ga.vkind == kValI32 && (ga.kind != kGroupSum || ga.is_plane);
-          if (unsigned_field && ga.bits + partition_shift <= 32) packed_bits = ga.bits;
+          if (unsigned_field && ga.bits + scatter_shift <= 32) packed_bits = ga.bits;
         }
       }
-      const size_t off_val = align(off_key + N * 4), bytes = off_val + (packed_bits > 0 ? 0 : (size_t)gp.num_group_aggs * align(N * 4));
+      const size_t off_val = align(off_key + N * 4), level1_bytes = off_val + (packed_bits > 0 ? 0 : (size_t)gp.num_group_aggs * align(N * 4));
+      // two levels: the second record buffer(s), the fine partitions' count / offset / cursor arrays, pass B's device-built work list and its
+      // length, and the re-scatter's own chunk list
+      const int num_vals = packed_bits > 0 ? 0 : gp.num_group_aggs;
+      const size_t fine_slots = (size_t)P << log2_fine_per_coarse;
+      const size_t max_work2 = N / (1u << 16) + fine_slots + 1, max_chunks = N / kRepartitionChunk + (size_t)P + 1;
+      const size_t off_key2 = align(level1_bytes), off_val2 = align(off_key2 + N * 4);
+      const size_t off_fine = align(off_val2 + (size_t)num_vals * align(N * 4));                       // count | cursor | work_count (zeroed together), then offsets
+      const size_t off_fine_offsets = align(off_fine + 2 * fine_slots * 4 + 64);
+      const size_t off_work2 = align(off_fine_offsets + fine_slots * 4), off_chunks = align(off_work2 + max_work2 * sizeof(PartitionWork));
+      const size_t bytes = two_level ? align(off_chunks + max_chunks * sizeof(PartitionWork)) : level1_bytes;
       if (ctx->partition_capacity < bytes) {
         if (ctx->d_partition) (void)hipFree(ctx->d_partition);
         ctx->d_partition = nullptr; ctx->partition_capacity = 0;
@@ -3007,7 +3032,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       PartitionParams pp;
       memset(&pp, 0, sizeof(pp));
       pp.gp = gp;
-      pp.shift = partition_shift;
+      pp.shift = scatter_shift;                     // (two levels: pass 0 and pass A work on coarse partitions)
       pp.num_partitions = P;
       pp.packed_bits = packed_bits;
       pp.upper = reinterpret_cast<uint32_t*>(ctx->d_partition + off_upper);
@@ -3019,7 +3044,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       HIP_TRY(hipMemsetAsync(ctx->d_partition, 0, off_offsets, ctx->stream));          // upper and cursor
       const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;
       const int hist_blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + 3) / 4, (long long)seg->num_cus * 6));
-      std::vector<int> stats_key{partition_shift};
+      std::vector<int> stats_key{scatter_shift};
       for (int g = 0; g < ng; ++g) stats_key.push_back(q->group_by_columns[g]);
       std::vector<uint32_t> upper;
       if (g_engine.partition_stats_cache) {
@@ -3055,8 +3080,41 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       const int scatter_blocks = (int)std::max<long long>(1, std::min<long long>((tiles2k + 3) / 4, (long long)seg->num_cus * scatter_bpc));
       launch_group_partition_scatter(scatter_blocks, ctx->stream, pp);
       HIP_TRY(hipGetLastError());
-      if (!work.empty()) launch_group_partition_aggregate((int)work.size(), ((size_t)partition_entry_bytes) << partition_shift, ctx->stream, pp);
-      HIP_TRY(hipStreamSynchronize(ctx->stream));      // `offsets` / `work` are pageable host vectors: keep them alive until the copies ran
+      std::vector<PartitionWork> chunks;
+      if (two_level && !work.empty()) {
+        RepartitionParams rp;
+        memset(&rp, 0, sizeof(rp));
+        rp.src_key = pp.part_key;
+        rp.dst_key = reinterpret_cast<uint32_t*>(ctx->d_partition + off_key2);
+        for (int a = 0; a < num_vals; ++a) { rp.src_val[a] = pp.part_val[a]; rp.dst_val[a] = reinterpret_cast<uint32_t*>(ctx->d_partition + off_val2 + (size_t)a * align(N * 4)); }
+        rp.coarse_offsets = pp.offsets; rp.coarse_cursor = pp.cursor;
+        rp.fine_count = reinterpret_cast<uint32_t*>(ctx->d_partition + off_fine);
+        rp.fine_cursor = rp.fine_count + fine_slots;
+        rp.work_count = rp.fine_cursor + fine_slots;
+        rp.fine_offsets = reinterpret_cast<uint32_t*>(ctx->d_partition + off_fine_offsets);
+        rp.work = reinterpret_cast<PartitionWork*>(ctx->d_partition + off_work2);
+        rp.chunks = reinterpret_cast<const PartitionWork*>(ctx->d_partition + off_chunks);
+        rp.num_coarse = P; rp.log2_fine_per_coarse = log2_fine_per_coarse; rp.fine_shift = partition_shift; rp.packed_bits = packed_bits; rp.num_vals = num_vals;
+        rp.aggregate_chunk = chunk;
+        for (int p = 0; p < P; ++p)
+          for (uint32_t s0 = 0; s0 < upper[(size_t)p]; s0 += kRepartitionChunk) chunks.push_back(PartitionWork{p, s0, std::min<uint32_t>(kRepartitionChunk, upper[(size_t)p] - s0), 0u});
+        HIP_TRY(hipMemsetAsync(ctx->d_partition + off_fine, 0, 2 * fine_slots * 4 + 64, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->d_partition + off_chunks, chunks.data(), chunks.size() * sizeof(PartitionWork), hipMemcpyHostToDevice, ctx->stream));
+        launch_group_repartition((int)chunks.size(), ctx->stream, rp);
+        HIP_TRY(hipGetLastError());
+        // pass B over the fine partitions: the second buffer, the device-built work list (as many workgroups as it can have entries)
+        PartitionParams fine = pp;
+        fine.shift = partition_shift;
+        fine.num_partitions = (int32_t)fine_slots;
+        fine.cursor = rp.fine_cursor; fine.offsets = rp.fine_offsets;
+        fine.work = rp.work; fine.work_count = rp.work_count;
+        fine.part_key = rp.dst_key;
+        for (int a = 0; a < num_vals; ++a) fine.part_val[a] = rp.dst_val[a];
+        launch_group_partition_aggregate((int)max_work2, ((size_t)partition_entry_bytes) << partition_shift, ctx->stream, fine);
+      } else if (!work.empty()) {
+        launch_group_partition_aggregate((int)work.size(), ((size_t)partition_entry_bytes) << partition_shift, ctx->stream, pp);
+      }
+      HIP_TRY(hipStreamSynchronize(ctx->stream));      // `offsets` / `work` / `chunks` are pageable host vectors: keep them alive until the copies ran
     }
     else if (typed_direct) {
       const long long tiles2k = ((long long)seg->num_docs + 2047) / 2048;

@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256) void group_partition_aggregate_kernel(const Pa
   const int S = 1 << pp.shift;
   long long* acc = reinterpret_cast<long long*>(smem);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(acc + (size_t)NA * S);
+  if (pp.work_count != nullptr && blockIdx.x >= *pp.work_count) return;      // (two-level runs launch the most work items there can be)
   const PartitionWork w = pp.work[blockIdx.x];
   const uint32_t written = pp.cursor[w.partition];
   if (w.start >= written) return;                        // workgroup-uniform: the filter left this chunk empty
@@ -330,7 +331,8 @@ __global__ __launch_bounds__(256) void group_partition_aggregate_kernel(const Pa
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       if (i0 + 256u * u >= n) continue;
-      const uint32_t slot = kPacked ? key[u] >> pp.packed_bits : key[u] - key_base;
+      // (a packed record carries the slot inside its COARSE partition when the run is two-level: the fine slot is its low bits)
+      const uint32_t slot = kPacked ? (key[u] >> pp.packed_bits) & (uint32_t)(S - 1) : key[u] - key_base;
       __hip_atomic_fetch_add(&cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
       for (int a = 0; a < NA; ++a) {
@@ -367,6 +369,103 @@ __global__ __launch_bounds__(256) void group_partition_aggregate_kernel(const Pa
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Two-level partitioning: key spaces of more than kMaxPartitions fine partitions (2 M .. 2^31 raw keys -- the upper IntMapBasedHolder
+// range, DictionaryBasedGroupKeyGenerator.java:164-181, 415-460).  One scatter pass cannot address more than a few hundred
+// destinations (its ranking and staging live in LDS), and the direct HBM table costs one global atomic per doc and accumulator
+// (23.7 G/s: 42 ms per atomic stream over 1 B rows).  So pass A scatters by COARSE partition (P1 <= 512, each 2^k fine partitions
+// wide), and the records of every coarse partition -- contiguous in the first buffer -- are scattered once more by fine partition
+// into a second buffer:
+//   group_repartition_count_kernel   a workgroup per chunk of <= 65 536 records of one coarse partition: LDS histogram over the 2^k
+//                                    fine partitions, one global atomic per (chunk, fine partition it touches)
+//   group_repartition_plan_kernel    a workgroup per coarse partition: exclusive scan of its fine counts -> where every fine partition
+//                                    starts (inside the coarse partition's own range of the second buffer), and pass B's work list
+//   group_repartition_scatter_kernel the same chunks again: count, reserve (one global atomic per chunk and fine partition), then
+//                                    every record goes to  fine_offsets + reserved + its rank  (the second read of the chunk comes
+//                                    out of the L2)
+// Pass B (group_partition_aggregate_kernel) then runs over fine partitions exactly as in a one-level run.  Per doc: 4 B x (1 + inputs)
+// written and read twice more than one level, against the 42 ms of every atomic stream.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fine_of_record(const RepartitionParams& rp, uint32_t rec) {
+  // unpacked: the raw key; packed: (slot inside the coarse partition) << packed_bits | value
+  const uint32_t in_coarse = rp.packed_bits > 0 ? rec >> rp.packed_bits : rec;
+  return (in_coarse >> rp.fine_shift) & ((1u << rp.log2_fine_per_coarse) - 1u);
+}
+
+static __global__ __launch_bounds__(256) void group_repartition_count_kernel(const RepartitionParams rp) {
+  __shared__ uint32_t hist[kMaxFinePerCoarse];
+  const PartitionWork w = rp.chunks[blockIdx.x];
+  const uint32_t written = rp.coarse_cursor[w.partition];
+  if (w.start >= written) return;                        // the filter left this chunk empty
+  const uint32_t n = min(w.len, written - w.start);
+  const int F = 1 << rp.log2_fine_per_coarse;
+  for (int i = threadIdx.x; i < F; i += 256) hist[i] = 0u;
+  __syncthreads();
+  const uint32_t* __restrict__ keys = rp.src_key + rp.coarse_offsets[w.partition] + w.start;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) __hip_atomic_fetch_add(&hist[fine_of_record(rp, keys[i])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __syncthreads();
+  uint32_t* out = rp.fine_count + ((size_t)w.partition << rp.log2_fine_per_coarse);
+  for (int i = threadIdx.x; i < F; i += 256) { const uint32_t c = hist[i]; if (c) __hip_atomic_fetch_add(&out[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
+
+// one workgroup of 1024 threads per coarse partition (2^k <= 1024 fine partitions: one per thread)
+static __global__ __launch_bounds__(1024) void group_repartition_plan_kernel(const RepartitionParams rp) {
+  __shared__ uint32_t wave_sum[16], wave_items[16];
+  __shared__ uint32_t items_base;
+  const int F = 1 << rp.log2_fine_per_coarse;
+  const int p1 = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const size_t q = ((size_t)p1 << rp.log2_fine_per_coarse) + (size_t)t;
+  const uint32_t c = t < F ? rp.fine_count[q] : 0u;
+  const uint32_t items = (c + rp.aggregate_chunk - 1u) / rp.aggregate_chunk;
+  uint32_t incl = c, incl_items = items;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d, 64), up_items = __shfl_up(incl_items, d, 64);
+    if (lane >= d) { incl += up; incl_items += up_items; }
+  }
+  if (lane == 63) { wave_sum[wave] = incl; wave_items[wave] = incl_items; }
+  __syncthreads();
+  uint32_t before = 0u, before_items = 0u, all_items = 0u;
+  for (int v = 0; v < 16; ++v) { if (v < wave) { before += wave_sum[v]; before_items += wave_items[v]; } all_items += wave_items[v]; }
+  if (t == 0) items_base = all_items ? __hip_atomic_fetch_add(rp.work_count, all_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  __syncthreads();
+  if (t < F) {
+    rp.fine_offsets[q] = rp.coarse_offsets[p1] + before + incl - c;
+    uint32_t at = items_base + before_items + incl_items - items;
+    for (uint32_t s0 = 0; s0 < c; s0 += rp.aggregate_chunk) rp.work[at++] = PartitionWork{(int32_t)q, s0, min(rp.aggregate_chunk, c - s0), 0u};
+  }
+}
+
+static __global__ __launch_bounds__(256) void group_repartition_scatter_kernel(const RepartitionParams rp) {
+  __shared__ uint32_t hist[kMaxFinePerCoarse];          // counts, then the next free rank of every fine partition
+  __shared__ uint32_t base[kMaxFinePerCoarse];          // where the chunk's records of a fine partition start in the second buffer
+  const PartitionWork w = rp.chunks[blockIdx.x];
+  const uint32_t written = rp.coarse_cursor[w.partition];
+  if (w.start >= written) return;
+  const uint32_t n = min(w.len, written - w.start);
+  const int F = 1 << rp.log2_fine_per_coarse;
+  for (int i = threadIdx.x; i < F; i += 256) hist[i] = 0u;
+  __syncthreads();
+  const uint32_t first = rp.coarse_offsets[w.partition] + w.start;
+  const uint32_t* __restrict__ keys = rp.src_key + first;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) __hip_atomic_fetch_add(&hist[fine_of_record(rp, keys[i])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __syncthreads();
+  const size_t q0 = (size_t)w.partition << rp.log2_fine_per_coarse;
+  for (int i = threadIdx.x; i < F; i += 256) {
+    const uint32_t c = hist[i];
+    base[i] = c ? rp.fine_offsets[q0 + i] + __hip_atomic_fetch_add(&rp.fine_cursor[q0 + i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    hist[i] = 0u;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    const uint32_t rec = keys[i];
+    const uint32_t f = fine_of_record(rp, rec);
+    const uint32_t at = base[f] + __hip_atomic_fetch_add(&hist[f], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    rp.dst_key[at] = rec;
+    for (int a = 0; a < rp.num_vals; ++a) rp.dst_val[a][at] = rp.src_val[a][first + i];
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // group_typed_direct_kernel: group-by whose aggregation inputs include a RAW LONG / FLOAT / DOUBLE column

@@ -73,6 +73,8 @@ int waves_scan_private_typed(int agg_cols);
 void launch_group_partition_histogram(int blocks, hipStream_t stream, const PartitionParams& pp);
 void launch_group_partition_scatter(int blocks, hipStream_t stream, const PartitionParams& pp);
 void launch_group_partition_aggregate(int work_items, size_t lds, hipStream_t stream, const PartitionParams& pp);
+// two-level runs: count / plan / scatter of pass A's records by fine partition (pg_group_partition.h)
+void launch_group_repartition(int num_chunks, hipStream_t stream, const RepartitionParams& rp);
 void launch_group_typed_direct(int blocks, hipStream_t stream, const GroupParams& gp);   // raw 8-byte aggregation inputs: direct HBM table
 int waves_group_partition_scatter();
 int blocks_per_cu_group_partition_scatter_packed(int num_partitions);

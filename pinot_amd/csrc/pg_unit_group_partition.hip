@@ -35,6 +35,12 @@ void launch_group_partition_aggregate(int work_items, size_t lds, hipStream_t st
   }
 }
 
+void launch_group_repartition(int num_chunks, hipStream_t stream, const RepartitionParams& rp) {
+  group_repartition_count_kernel<<<dim3((unsigned)num_chunks), dim3(256), 0, stream>>>(rp);
+  group_repartition_plan_kernel<<<dim3((unsigned)rp.num_coarse), dim3(1024), 0, stream>>>(rp);
+  group_repartition_scatter_kernel<<<dim3((unsigned)num_chunks), dim3(256), 0, stream>>>(rp);
+}
+
 void launch_group_typed_direct(int blocks, hipStream_t stream, const GroupParams& gp) {
   if (gp.wide_keys) group_typed_direct_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(gp);
   else group_typed_direct_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(gp);

@@ -88,3 +88,44 @@ def test_partitioned_path_on_a_segment_large_enough_to_take_it(engine):
         got = gseg.execute(spec)
         H.assert_results_equal(got, oracle.execute(seg, spec))
         assert got.dominant_kernel != "group_partition_scatter_kernel"
+
+
+@pytest.mark.parametrize("cards,num_docs", [((3000, 2500), 4_300_000), ((60_000, 30_000), 4_500_000)])
+def test_two_level_partitioning_above_two_million_keys(engine, cards, num_docs):
+    """Key spaces of 7.5 M and 1.8 G raw keys (the upper IntMapBasedHolder range, DictionaryBasedGroupKeyGenerator.java:164-181): more fine
+    partitions than one scatter pass addresses -- the docs are scattered by coarse partition, every coarse partition's records once more by
+    fine partition, then aggregated in LDS as before (group_repartition_*_kernel, pg_group_partition.h).  COUNT (packed records), one
+    unsigned input (packed with the slot when it fits), two / three inputs (separate value columns), with and without a filter; against
+    the oracle, and against the direct HBM-atomic path the same key spaces took before."""
+    default_routing = not any(os.environ.get(k) for k in ("PINOT_GPU_GROUP_PARTITION", "PINOT_GPU_GROUP_PRIVATE", "PINOT_GPU_SCAN_PRIVATE", "PINOT_GPU_PARTITION_TWO_LEVEL"))
+    import hash_holder_cases as HC
+    from pinot_amd import segment as S
+    rng = np.random.default_rng(cards[0])
+    # huge key SPACE, moderate number of groups (the dictIds that occur are spread over the whole range: many partitions, sparsely filled)
+    k0, _ = HC.big_card_column("k0", num_docs, cards[0], 300, seed=11)
+    k1, _ = HC.big_card_column("k1", num_docs, cards[1], 150, seed=12)
+    vv = rng.integers(-1000, 100000, num_docs).astype(np.int32)
+    ff = rng.integers(0, 1000, num_docs).astype(np.int32)
+    seg = S.SegmentData("two_level", num_docs, [k0, k1, S.Column.dict_encoded("v", vv), S.Column.dict_encoded("f", ff)])
+    ci = seg.column_index
+    keys = [ci("k0"), ci("k1")]
+    agg_lists = [[(Q.COUNT, -1)],
+                 [(Q.MAX, ci("f")), (Q.COUNT, -1)],
+                 [(Q.SUM, ci("v")), (Q.COUNT, -1)],
+                 [(Q.SUM, ci("v")), (Q.MAX, ci("f")), (Q.AVG, ci("v"))],
+                 [(Q.MIN, ci("v")), (Q.MAX, ci("v")), (Q.SUM, ci("f"))]]
+    filters = [None, Q.leaf(H.range_pred(seg, "f", upper=100, upper_inclusive=False))]
+    with engine.open(seg) as gseg:
+        for aggs in agg_lists:
+            for flt in filters:
+                spec = Q.QuerySpec(aggs, filter=flt, group_by=keys, num_groups_limit=10_000_000)
+                got, want = gseg.execute(spec), oracle.execute(seg, spec)
+                H.assert_results_equal(got, want)
+                # (three accumulators halve the LDS slots of a fine partition: 1.8 G keys are then 2^11 fine partitions per coarse one,
+                #  beyond kMaxFinePerCoarse -- that combination keeps the direct HBM atomics)
+                expect_partition = not (len(aggs) == 3 and aggs[0][0] == Q.MIN and int(np.prod(cards)) > 2 ** 30)
+                assert (got.dominant_kernel == "group_partition_scatter_kernel") == expect_partition or not default_routing
+        spec = Q.QuerySpec([(Q.SUM, ci("v"))], group_by=keys, num_groups_limit=5000)
+        got = gseg.execute(spec)
+        H.assert_results_equal(got, oracle.execute(seg, spec))
+        assert len(got.groups) == 5000 and got.num_groups_limit_reached
