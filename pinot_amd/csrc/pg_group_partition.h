@@ -24,19 +24,27 @@
 namespace pg {
 
 // raw key of the lane's 32 docs of a tile: sum dictId_c * mult_c (DictionaryBasedGroupKeyGenerator.java:437-445)
+// (kWide = false: the full-rate 24-bit multiply while every multiplier stays below 2^24 -- GroupParams.wide_keys says when one does not:
+//  key spaces above 2^24 with three or more key columns, which the two-level runs admit, take the 32-bit multiply)
 template <bool kWide = false>
 __device__ __forceinline__ void decode_group_keys(const GroupParams& gp, long long tile, int lane, uint32_t (&g)[32]) {
   for (int c = 0; c < gp.num_group_cols; ++c) {
     const DevGroupKey& key = gp.group_keys[c];
     const int b = key.bits;
     const uint32_t mult = (uint32_t)key.mult;
+    const bool wide = kWide || gp.wide_keys != 0;            // (uniform)
     const uint32_t* words = reinterpret_cast<const uint32_t*>(key.fwd + tile * (256ll * b)) + lane * b;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       uint32_t d[16];
       if (h == 0) decode16_private_dispatch<0>(b, words, d); else decode16_private_dispatch<1>(b, words, d);
+      if (wide) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : key_term<kWide>(d[j], mult) + g[16 * h + j];
+        for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : key_term<true>(d[j], mult) + g[16 * h + j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : key_term<false>(d[j], mult) + g[16 * h + j];
+      }
     }
   }
 }

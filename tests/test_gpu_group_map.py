@@ -90,7 +90,7 @@ def test_partitioned_path_on_a_segment_large_enough_to_take_it(engine):
         assert got.dominant_kernel != "group_partition_scatter_kernel"
 
 
-@pytest.mark.parametrize("cards,num_docs", [((3000, 2500), 4_300_000), ((60_000, 30_000), 4_500_000)])
+@pytest.mark.parametrize("cards,num_docs", [((3000, 2500), 4_300_000), ((60_000, 30_000), 4_500_000), ((6000, 5000, 40), 4_400_000)])
 def test_two_level_partitioning_above_two_million_keys(engine, cards, num_docs):
     """Key spaces of 7.5 M and 1.8 G raw keys (the upper IntMapBasedHolder range, DictionaryBasedGroupKeyGenerator.java:164-181): more fine
     partitions than one scatter pass addresses -- the docs are scattered by coarse partition, every coarse partition's records once more by
@@ -102,13 +102,13 @@ def test_two_level_partitioning_above_two_million_keys(engine, cards, num_docs):
     from pinot_amd import segment as S
     rng = np.random.default_rng(cards[0])
     # huge key SPACE, moderate number of groups (the dictIds that occur are spread over the whole range: many partitions, sparsely filled)
-    k0, _ = HC.big_card_column("k0", num_docs, cards[0], 300, seed=11)
-    k1, _ = HC.big_card_column("k1", num_docs, cards[1], 150, seed=12)
+    # (three key columns: the third one's multiplier, 30 M, is beyond the 24-bit multiply of the narrow key spaces)
+    kcols = [HC.big_card_column("k%d" % i, num_docs, c, (120, 60, 7)[i], seed=11 + i)[0] for i, c in enumerate(cards)]
     vv = rng.integers(-1000, 100000, num_docs).astype(np.int32)
     ff = rng.integers(0, 1000, num_docs).astype(np.int32)
-    seg = S.SegmentData("two_level", num_docs, [k0, k1, S.Column.dict_encoded("v", vv), S.Column.dict_encoded("f", ff)])
+    seg = S.SegmentData("two_level", num_docs, kcols + [S.Column.dict_encoded("v", vv), S.Column.dict_encoded("f", ff)])
     ci = seg.column_index
-    keys = [ci("k0"), ci("k1")]
+    keys = [ci("k%d" % i) for i in range(len(cards))]
     agg_lists = [[(Q.COUNT, -1)],
                  [(Q.MAX, ci("f")), (Q.COUNT, -1)],
                  [(Q.SUM, ci("v")), (Q.COUNT, -1)],

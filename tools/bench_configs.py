@@ -134,6 +134,11 @@ def main():
         report(out, "C6 SUM(a), MAX(b) WHERE f < 100 GROUP BY k, f (100k of 1M raw keys present)", n, B(k) + B(f) + B(a) + B(b), g, seg,
                Q.QuerySpec([(Q.SUM, 3), (Q.MAX, 4)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100)), group_by=[2, 1], num_groups_limit=2_000_000), check)
         report(out, "C6 SUM(a) GROUP BY k, f LIMITED to 100000 groups (first-doc pass)", n, B(k) + B(f) + B(a), g, seg, Q.QuerySpec([(Q.SUM, 3)], group_by=[2, 1]), check)
+        # 100 M raw keys (v x k): above what one scatter pass partitions -- two-level partitioning (PINOT_GPU_PARTITION_TWO_LEVEL=0: direct HBM atomics)
+        report(out, "C8 COUNT(*) GROUP BY v, k (100M raw keys)", n, B(v) + B(k), g, seg, Q.QuerySpec([(Q.COUNT, -1)], group_by=[0, 2]), check)
+        report(out, "C8 MAX(f) GROUP BY v, k (100M raw keys)", n, B(v) + B(k) + B(f), g, seg, Q.QuerySpec([(Q.MAX, 1)], group_by=[0, 2]), check)
+        report(out, "C8 SUM(a), MAX(b) WHERE f < 100 GROUP BY v, k (100M raw keys)", n, B(v) + B(k) + B(a) + B(b) + B(f), g, seg,
+               Q.QuerySpec([(Q.SUM, 3), (Q.MAX, 4)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100)), group_by=[0, 2]), check)
         report(out, "COUNT(*) WHERE f < 100", n, B(f), g, seg, Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), check)
         report(out, "MIN(v), MAX(v), AVG(v) WHERE f < 100", n, B(v) + B(f), g, seg,
                Q.QuerySpec([(Q.MIN, 0), (Q.MAX, 0), (Q.AVG, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), check)
