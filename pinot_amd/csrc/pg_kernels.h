@@ -2222,8 +2222,10 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
   }
 }
 
+// (the forms without an LDS table are launched with kBlockThreads threads: at that bound the register allocation has the whole file --
+//  at the 1024-thread bound of the LDS-table form they spilled ~40 registers inside the tile loop)
 template <bool kLdsTable, bool kWide = false, bool kHash = false>
-__global__ __launch_bounds__(kGroupBlockThreads) void group_private_kernel(const GroupParams gp) {
+__global__ __launch_bounds__(kLdsTable ? kGroupBlockThreads : kBlockThreads) void group_private_kernel(const GroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
