@@ -17,15 +17,25 @@ pmc() {   # pmc <tag> <kernel regexp> <bench args> <counters...>
   timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$tag -o p -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/pmc_$tag.log 2>&1
   for f in $(find $OUT/pmc_$tag -name "*counter_collection*.csv"); do python - "$f" "$kern" "$tag" <<'PY'
 import csv, sys, collections, re, json
+import os
 per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
 for r in csv.DictReader(open(sys.argv[1])):
     if re.search(sys.argv[2], r["Kernel_Name"]):
-        per[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        per[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+# PMC_LAST=N: only the LAST N dispatches of every kernel count.  A bench run launches the headline query first (clock settle, warm-up,
+# steps) and the named variant after it: the same kernel serves both, and a mean over all of its dispatches mixes two queries (round 3's
+# "1.5x over-fetch" of the 1 % query was that mix: 52 dispatches of the 10 % headline averaged with 51 of the variant).
+last = int(os.environ.get("PMC_LAST", "0"))
 out = {}
 for k, cs in per.items():
-    out[k] = {c: {"mean_per_dispatch": sum(d.values()) / len(d), "dispatches": len(d)} for c, d in cs.items()}
+    out[k] = {}
+    for c, d in cs.items():
+        ids = sorted(d)
+        if last > 0: ids = ids[-last:]
+        vals = [d[i] for i in ids]
+        out[k][c] = {"mean_per_dispatch": sum(vals) / len(vals), "dispatches": len(vals), "min": min(vals), "max": max(vals), "last_n_only": last}
     print("  %-40s %s" % (k[-40:], "  ".join("%s=%.4g" % (c, v["mean_per_dispatch"]) for c, v in out[k].items())))
-json.dump(out, open(sys.argv[1].rsplit("/", 1)[0] + "/../../pmc_%s_summary.json" % sys.argv[3], "w"), indent=1)
+json.dump(out, open(sys.argv[1].rsplit("/", 1)[0] + "/../pmc_%s_summary.json" % sys.argv[3], "w"), indent=1)
 PY
   done
   find $OUT/pmc_$tag -name "*.csv" -size +8M -delete
@@ -40,8 +50,8 @@ stats)
   find $OUT/stats -name "*kernel_trace*.csv" -size +8M -delete ;;
 head)
   echo "== headline HBM traffic"
-  pmc head_fetch "scan_simple_kernel|scan_private_kernel" "$ONE --no-variants" FETCH_SIZE
-  pmc head_tcc "scan_simple_kernel|scan_private_kernel" "$ONE --no-variants" TCC_HIT_sum TCC_MISS_sum ;;
+  pmc head_fetch "scan_simple_kernel|scan_private_kernel" "$ONE --no-variants --no-clock-settle" FETCH_SIZE
+  pmc head_tcc "scan_simple_kernel|scan_private_kernel" "$ONE --no-variants --no-clock-settle" TCC_HIT_sum TCC_MISS_sum ;;
 c3)
   echo "== C3 group-by kernel: SQ / LDS counters, HBM traffic"
   pmc c3_sq "group_private_kernel" "$ONE --variants ^C3$" SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
@@ -52,7 +62,8 @@ c3lds)
   pmc c3_sq "group_private_kernel" "$ONE --variants ^C3$" SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE ;;
 c5)
   echo "== C5 kernels: HBM traffic (one counter per pass)"
-  pmc c5_fetch "index_and|scan_private_kernel|scan_sparse" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --rows 100000 --rows-c5 1000000000 --variants ^C5-(sparse|dense)$" FETCH_SIZE ;;
+  pmc c5_fetch "index_and|scan_private_kernel|scan_sparse" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --rows 100000 --rows-c5 1000000000 --variants ^C5-dense$" FETCH_SIZE
+  pmc c5s_fetch "index_and|scan_private_kernel|scan_sparse" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --rows 100000 --rows-c5 1000000000 --variants ^C5-sparse$" FETCH_SIZE ;;
 hist)
   echo "== scan_hist_kernel (C2b-irregular): HBM traffic"
   pmc hist_fetch "scan_hist_kernel" "$ONE --variants ^C2b-irregular$" FETCH_SIZE ;;
@@ -61,7 +72,7 @@ narrow)
   pmc narrow_fetch "scan_narrow" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --rows 100000 --rows-c5 1000000000 --variants ^C5-scan-count$" FETCH_SIZE ;;
 lowsel)
   echo "== scan_private_kernel at 1 % (C2b-1pct): HBM traffic"
-  pmc lowsel_fetch "scan_simple_kernel|scan_private_kernel" "$ONE --variants ^C2b-1pct$" FETCH_SIZE ;;
+  PMC_LAST=40 pmc lowsel_fetch "scan_simple_kernel|scan_private_kernel" "$ONE --no-clock-settle --variants ^C2b-1pct$" FETCH_SIZE ;;
 per-variant)
   echo "== kernel stats, one variant per run"
   for v in C2b-irregular C2b-1pct C2a-affine C3 C3-filter COUNT-filter; do
