@@ -8,8 +8,8 @@
 // Why a kernel of its own (the sibling of scan_simple_kernel for raw columns): a lone 10 M-row segment is 4 883 tiles, and at the four
 // waves per SIMD of scan_private_kernel / scan_private_typed_kernel the chip holds 4 096 -- the last 787 tiles wait for a second round
 // of loads behind a launch (a whole memory round trip for a sixth of the data: profiles/r3/c1_probe_final.jsonl, 24.4 / 30.5 us for
-// 40 MB).  This kernel carries no filter program, no slot arrays, no typed accumulators: five waves per SIMD = 5 120 resident waves,
-// every tile of such a segment in flight at once.  COUNT / SUM / MIN / MAX do not care which lane sees which doc, so the tile is read
+// 40 MB).  This kernel carries no filter program, no slot arrays, no typed accumulators, and small grids run two workgroups per CU
+// (pg_engine.hip lean_geometry).  COUNT / SUM / MIN / MAX do not care which lane sees which doc, so the tile is read
 // fully coalesced -- instruction j of a wave covers the contiguous kilobyte of docs [256 j, 256 j + 256), 16 bytes per lane -- instead
 // of lane-contiguously.  Bit exact with the kernels it replaces (same integer sums and keys).
 #pragma once
@@ -18,7 +18,9 @@
 namespace pg {
 
 #ifndef PG_RAW_WAVES
-#define PG_RAW_WAVES 5                  // wavefronts per SIMD the register allocation must allow
+#define PG_RAW_WAVES 4                  // wavefronts per SIMD the register allocation must allow: 123 VGPRs, no scratch.  Five (96 VGPRs) spills 21 registers
+                                        // -- the compiler keeps the next tile's loads of both columns in flight -- and measured slower at every size
+                                        // (profiles/r4/c1_probe_raw_waves_4_vs_5.json: 10 M rows COUNT 18.4 -> 15.6 us, SUM 24.8 -> 18.9; 400 M rows SUM 346 -> 264 us)
 #endif
 
 // the 32 docs a lane sees of a tile, as four-doc pieces: piece j holds docs 256 j + 4 lane .. + 3 of the tile
