@@ -54,6 +54,7 @@ pg_status fail(pg_status st, const char* fmt, ...) {
 
 struct Engine {
   bool initialized = false;
+  std::atomic<uint64_t> epoch{0};      // moves with every pg_init: what was lowered under other settings is not reused (pg_segment.plan_cache)
   int device = 0;
   int blocks_per_cu = 0;
   bool raw64_coalesced = true;   // PINOT_GPU_RAW64_COALESCED=0: raw LONG / DOUBLE columns are read lane-contiguously (256 bytes per lane)
@@ -233,6 +234,12 @@ struct pg_segment {
   std::mutex fsm_mu;
   uint8_t* d_fsm_scratch = nullptr;
   size_t fsm_scratch_bytes = 0;
+  // pg_execute_batch: the last few queries lowered for the shared launch (LoweredItem), so that a server that sends the same query to
+  // its segments again and again -- one batch per broker request -- does not lower it again.  plane_epoch moves whenever a value plane of
+  // this segment is built or dropped: an item lowered before that reads addresses that may be gone.
+  std::atomic<uint64_t> plane_epoch{0};
+  std::mutex plan_cache_mu;
+  std::vector<std::shared_ptr<const struct LoweredItem>> plan_cache;
 };
 
 // What a query's scan kernel leaves behind for the transducer pass: the bitmap of every input leaf it evaluated itself.
@@ -684,6 +691,7 @@ void drop_plane_locked(pg_segment* seg, int column) {
   seg->plane_bytes -= col.plane_bytes;
   seg->device_bytes -= col.plane_bytes;
   col.plane_bytes = 0;
+  seg->plane_epoch.fetch_add(1, std::memory_order_release);
   auto& r = g_planes.resident;
   r.erase(std::remove(r.begin(), r.end(), std::make_pair(seg, column)), r.end());
 }
@@ -737,6 +745,7 @@ pg_status acquire_plane(pg_segment* seg, int column, bool* ready) {
     seg->plane_bytes += bytes;
     seg->device_bytes += bytes;
     g_planes.resident.emplace_back(seg, column);
+    seg->plane_epoch.fetch_add(1, std::memory_order_release);
   }
   if (col.plane_state == 0) {
     const PlaneShape ps = plane_shape(col);
@@ -749,6 +758,7 @@ pg_status acquire_plane(pg_segment* seg, int column, bool* ready) {
       col.plane_ready = true;
       col.plane_state = 2;
       __atomic_store_n(&col.plane_fwd_published, 1, __ATOMIC_RELEASE);
+      seg->plane_epoch.fetch_add(1, std::memory_order_release);
       *ready = true;
       return PG_OK;
     }
@@ -797,6 +807,7 @@ pg_status acquire_plane(pg_segment* seg, int column, bool* ready) {
     seg->plane_bytes += bytes;
     seg->device_bytes += bytes;
     g_planes.resident.emplace_back(seg, column);
+    seg->plane_epoch.fetch_add(1, std::memory_order_release);
   }
   if (col.plane_state == 1) {
     const hipError_t built = g_engine.plane_async ? hipEventQuery(col.plane_event) : hipEventSynchronize(col.plane_event);
@@ -805,6 +816,7 @@ pg_status acquire_plane(pg_segment* seg, int column, bool* ready) {
     if (col.d_plane_fields) { (void)hipFree(col.d_plane_fields); col.d_plane_fields = nullptr; }
     col.plane_ready = true;
     col.plane_state = 2;
+    seg->plane_epoch.fetch_add(1, std::memory_order_release);
   }
   col.plane_users++;
   col.plane_last_use = ++g_planes.tick;
@@ -853,6 +865,7 @@ struct Lowered {
   int stats_scan_leaves = 0;
   bool stats_chain_flagged = false;            // the chain's scan leaves carry kNodeCountEntries
   bool stats_leap2_flagged = false;            // the root AND of two scan leaves carries kNodeLeapfrog2
+  bool plane_pending = false;                  // a value plane this query wanted is still being built (or had no room): the lowering is not the one to keep
   bool cardinality_only_hint = false;          // in: the query is COUNT(*) only, so an index-only filter needs neither bitmap nor tile list
   FsmSide* side = nullptr;                     // in: the transducer pass wants the leaves' bitmaps (ScanParams.leaf_out)
   uint32_t* sp_leaf_out[kMaxLeaves] = {};      // out: ScanParams.leaf_out, by LEAF node ordinal
@@ -1666,6 +1679,7 @@ pg_status pg_init(const pg_config* config) {
   if (esd) g_engine.exact_stats_docs = atoll(esd);
   const char* bpc = getenv("PINOT_GPU_BLOCKS_PER_CU");
   if (bpc && atoi(bpc) > 0) g_engine.blocks_per_cu = atoi(bpc);
+  g_engine.epoch.fetch_add(1, std::memory_order_release);      // (what segments remember of earlier lowerings was made under the previous settings)
   g_engine.initialized = true;
   return PG_OK;
 }
@@ -2252,13 +2266,71 @@ static void finish_filter_stats(const Lowered& lw, const pg_segment* seg, int64_
 // phase, no entry counter, no histogram -- is not launched by execute_impl but handed back as its kernel parameters plus the
 // conversion of the folded record into a pg_result; the batch puts many of them into one launch (scan_private_batch_kernel).
 static const pg_status kDeferred = static_cast<pg_status>(100);      // (internal: never leaves the library)
-struct Deferred {
+// A query lowered for the shared launch of pg_execute_batch: the kernel's parameter block (the launch fills in where this item's records
+// go), the workgroups it would get on its own, and the conversion of its folded record into the reference's holder types.  Immutable
+// once built: the segment's plan_cache hands the same item to later batches.
+struct OwnedQuery {                               // a deep copy of a pg_query (the caller's arrays are only valid during its call)
+  pg_query q;
+  std::vector<pg_filter_node> filter;
+  std::vector<pg_predicate> predicates;
+  std::vector<std::vector<uint32_t>> set_words;
+  std::vector<pg_aggregation> aggregations;
+  std::vector<int32_t> group_by;
+};
+struct LoweredItem {
   ScanParams sp;
   int blocks = 0;
   bool one_slot = true;
   std::function<void(const BlockPartial&, pg_result*)> convert;
-  std::unique_ptr<PlaneHold> planes;           // value planes the kernel reads stay held until the batch has run
+  std::vector<int> plane_columns;                 // value planes sp reads: held (PlaneHold) by every batch that launches this item
+  // the cache's side (empty key: not cacheable)
+  std::string key;                                // query_key of the query
+  uint64_t engine_epoch = 0, plane_epoch = 0;
+  std::shared_ptr<const OwnedQuery> query;        // `convert` reads the query through this copy
 };
+struct Deferred {
+  std::shared_ptr<const LoweredItem> item;
+  std::unique_ptr<PlaneHold> planes;           // value planes the kernel reads stay held until the batch has run
+  bool cacheable = false;                      // out of execute_impl: nothing about this lowering was provisional
+};
+
+// The query's content as bytes: two queries with equal keys lower to the same item on the same segment.
+static bool query_key(const pg_query* q, std::string* key) {
+  key->clear();
+  if (q->num_filter_nodes < 0 || q->num_predicates < 0 || q->num_aggregations < 0 || q->num_group_by != 0) return false;
+  if ((q->num_filter_nodes > 0 && !q->filter) || (q->num_predicates > 0 && !q->predicates) || (q->num_aggregations > 0 && !q->aggregations)) return false;
+  const int32_t head[6] = {q->num_filter_nodes, q->num_predicates, q->num_aggregations, q->num_group_by, q->num_groups_limit, q->flags};
+  key->append(reinterpret_cast<const char*>(head), sizeof(head));
+  key->append(reinterpret_cast<const char*>(q->filter), sizeof(pg_filter_node) * (size_t)q->num_filter_nodes);
+  for (int i = 0; i < q->num_predicates; ++i) {
+    const pg_predicate& pr = q->predicates[i];
+    if (pr.num_set_words < 0 || (pr.num_set_words > 0 && !pr.set_words)) return false;
+    const int64_t fields[8] = {pr.kind, pr.column, pr.eval, pr.exclusive, pr.lo, pr.hi, pr.num_set_words, pr.reserved};
+    key->append(reinterpret_cast<const char*>(fields), sizeof(fields));
+    key->append(reinterpret_cast<const char*>(pr.set_words), sizeof(uint32_t) * (size_t)pr.num_set_words);
+  }
+  key->append(reinterpret_cast<const char*>(q->aggregations), sizeof(pg_aggregation) * (size_t)q->num_aggregations);
+  return true;
+}
+
+static std::shared_ptr<const OwnedQuery> own_query(const pg_query* q) {
+  auto o = std::make_shared<OwnedQuery>();
+  o->q = *q;
+  if (q->num_filter_nodes > 0) o->filter.assign(q->filter, q->filter + q->num_filter_nodes);
+  if (q->num_predicates > 0) o->predicates.assign(q->predicates, q->predicates + q->num_predicates);
+  o->set_words.resize(o->predicates.size());
+  for (size_t i = 0; i < o->predicates.size(); ++i) {
+    pg_predicate& pr = o->predicates[i];
+    if (pr.num_set_words > 0) { o->set_words[i].assign(pr.set_words, pr.set_words + pr.num_set_words); pr.set_words = o->set_words[i].data(); }
+    else pr.set_words = nullptr;
+  }
+  if (q->num_aggregations > 0) o->aggregations.assign(q->aggregations, q->aggregations + q->num_aggregations);
+  o->q.filter = o->filter.empty() ? nullptr : o->filter.data();
+  o->q.predicates = o->predicates.empty() ? nullptr : o->predicates.data();
+  o->q.aggregations = o->aggregations.empty() ? nullptr : o->aggregations.data();
+  o->q.group_by_columns = nullptr;
+  return o;
+}
 
 static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out, unsigned long long* d_out_bitmap_request,
                               uint64_t* host_bitmap, int64_t host_bitmap_words, int64_t* out_cardinality, bool allow_metadata_plan = true,
@@ -2366,6 +2438,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       st = acquire_plane(seg, ag.column, &ready);
       if (st != PG_OK) return st;
       if (ready) { planes.columns.push_back(ag.column); lw.plane_cols[(size_t)ag.column] = 1; }
+      else lw.plane_pending = true;
     }
   }
   ctx->pre_enqueued = false;
@@ -2700,10 +2773,14 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         sp.lean_kind = use_simple ? 1 : (use_raw ? 2 : 0);
         if (!lean_batch && sp.lean_kind == 1) sp.lean_kind = 0;      // (a raw-shaped item has no general form when its column is aggregated: it stays lean)
         if (sp.lean_kind == 2 && !lean_batch && use_private) sp.lean_kind = 0;
-        defer->sp = sp;
-        defer->blocks = blocks;
-        defer->one_slot = pl.num_agg_cols <= 1;
-        defer->convert = convert;
+        auto item = std::make_shared<LoweredItem>();
+        item->sp = sp;
+        item->blocks = blocks;
+        item->one_slot = pl.num_agg_cols <= 1;
+        item->convert = convert;
+        item->plane_columns = planes.columns;
+        defer->item = std::move(item);
+        defer->cacheable = !lw.plane_pending;
         defer->planes.reset(new PlaneHold(std::move(planes)));
         return kDeferred;
       }
@@ -4025,6 +4102,60 @@ pg_status ensure_batch_ctx(BatchCtx* b, int items, size_t partials) {
 // The deferred items of one device: one launch, every item folding into its own pinned record.  Two halves, so that a batch spanning
 // several devices has every device's launch in flight before it waits for any (segment s on device s mod N: BaseCombineOperator.java:85-142
 // runs all segments of a query on one pool): enqueue_deferred copies the items and launches, finish_deferred waits and converts.
+// The plan cache of a segment (pg_segment.plan_cache): at most kPlanCacheEntries items, most recently used first.
+constexpr size_t kPlanCacheEntries = 4;
+
+// A hit hands out the item with its value planes held again; an item lowered under other engine settings, or before a plane of the
+// segment came or went, is dropped.
+bool cached_item(pg_segment* seg, const std::string& key, Deferred* out) {
+  std::shared_ptr<const LoweredItem> item;
+  {
+    std::lock_guard<std::mutex> lk(seg->plan_cache_mu);
+    auto& cache = seg->plan_cache;
+    for (size_t i = 0; i < cache.size(); ++i) {
+      if (cache[i]->key != key) continue;
+      item = cache[i];
+      if (i != 0) std::rotate(cache.begin(), cache.begin() + (long)i, cache.begin() + (long)i + 1);
+      break;
+    }
+  }
+  if (!item) return false;
+  bool fresh = item->engine_epoch == g_engine.epoch.load(std::memory_order_acquire);
+  std::vector<int> held;
+  for (size_t c = 0; c < item->plane_columns.size() && fresh; ++c) {
+    bool ready = false;
+    if (acquire_plane(seg, item->plane_columns[c], &ready) != PG_OK || !ready) { fresh = false; break; }
+    held.push_back(item->plane_columns[c]);
+  }
+  // (the planes are held now: the epoch cannot move under this batch for the columns the item reads)
+  fresh = fresh && item->plane_epoch == seg->plane_epoch.load(std::memory_order_acquire);
+  std::unique_ptr<PlaneHold> hold(new PlaneHold(seg, std::move(held)));
+  if (!fresh) {
+    std::lock_guard<std::mutex> lk(seg->plan_cache_mu);
+    auto& cache = seg->plan_cache;
+    cache.erase(std::remove(cache.begin(), cache.end(), item), cache.end());
+    return false;                                   // (`hold` releases what was acquired)
+  }
+  out->item = std::move(item);
+  out->planes = std::move(hold);
+  out->cacheable = true;
+  return true;
+}
+
+void remember_item(pg_segment* seg, std::string&& key, const std::shared_ptr<const OwnedQuery>& query, Deferred* d) {
+  // (the item was made by this thread a moment ago and nobody else has seen it yet)
+  LoweredItem* item = std::const_pointer_cast<LoweredItem>(d->item).get();
+  item->query = query;
+  item->key = std::move(key);
+  item->engine_epoch = g_engine.epoch.load(std::memory_order_acquire);
+  item->plane_epoch = seg->plane_epoch.load(std::memory_order_acquire);
+  std::lock_guard<std::mutex> lk(seg->plan_cache_mu);
+  auto& cache = seg->plan_cache;
+  for (size_t i = 0; i < cache.size(); ++i) if (cache[i]->key == item->key) { cache.erase(cache.begin() + (long)i); break; }
+  cache.insert(cache.begin(), d->item);
+  if (cache.size() > kPlanCacheEntries) cache.pop_back();
+}
+
 struct DeferredLaunch {
   BatchCtx* b = nullptr;
   int device = -1, n = 0, lean_kind = 0;       // lean_kind: ScanParams.lean_kind of every item (0: scan_private_batch_kernel, 1 / 2: scan_lean_batch_kernel)
@@ -4062,7 +4193,7 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
   long long total_blocks = 0;
   bool one_slot = true;
   for (int k = 0; k < n; ++k) {
-    const Deferred& d = defs[(size_t)items[(size_t)k]];
+    const LoweredItem& d = *defs[(size_t)items[(size_t)k]].item;
     const long long tiles = ((long long)segments[items[(size_t)k]]->num_docs + 2047) / 2048;
     const long long share = total_tiles > 0 ? (tiles * budget + total_tiles - 1) / total_tiles : 1;
     blocks[(size_t)k] = (int)std::max<long long>(1, std::min<long long>({(long long)d.blocks, share, (tiles + 3) / 4}));
@@ -4077,13 +4208,13 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
   uint32_t first = 0;
   const unsigned long long seq = L->seq = ++b->seq;
   for (int k = 0; k < n; ++k) {
-    ScanParams sp = defs[(size_t)items[(size_t)k]].sp;
+    ScanParams& sp = b->h_items[k];               // (the pinned copy the device reads: filled in place)
+    sp = defs[(size_t)items[(size_t)k]].item->sp;
     sp.partials = b->d_partials + off;
     off += (size_t)blocks[(size_t)k] + (size_t)kFoldExtraRecords;
     sp.done_counter = b->d_done + (size_t)k * (kFoldShards + 1) * kFoldStride;
     sp.host_out = b->h_records_dev + k;
     sp.host_seq = seq;
-    b->h_items[k] = sp;
     b->h_first[k] = first;
     first += (uint32_t)blocks[(size_t)k];
   }
@@ -4124,7 +4255,7 @@ pg_status finish_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_res
     const int i = L->items[(size_t)k];
     if (b->h_records[k].seq != seq) { statuses[i] = fail(PG_ERR_INTERNAL, "batch item %d did not publish its record", i); continue; }
     if (b->h_records[k].partial.flags & kPartialStale) { statuses[i] = fail(PG_ERR_INTERNAL, "batch item %d: the fold read a record that was not written by this launch", i); continue; }
-    defs[(size_t)i].convert(b->h_records[k].partial, &results[i]);
+    defs[(size_t)i].item->convert(b->h_records[k].partial, &results[i]);
     // ONE launch serves all items of the device: each item is charged its share of the workgroups, so that summing device_ms over a
     // batch's results gives the launch's time once (pg_result.device_ms of a batch item is an apportioned figure, not a measurement of its own)
     const float share = L->total_blocks > 0 ? ms * (float)L->blocks[(size_t)k] / (float)L->total_blocks : 0.f;
@@ -4146,18 +4277,36 @@ pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* q
   const auto t_begin = std::chrono::steady_clock::now();
   std::vector<Deferred> defs((size_t)count);
   std::vector<std::string> errors((size_t)count);
-  // 1. every item is lowered (and, when it cannot share the launch, run on a context of its own) on the library's worker threads
+  // 1. every item is lowered (and, when it cannot share the launch, run on a context of its own) on the library's worker threads --
+  // except the items whose segment has this very query in its plan cache: those are picked up on the calling thread (~0.2 us each)
   const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2));
   std::vector<float> item_us(trace ? (size_t)count : 0);
+  static const bool plan_cache = !(getenv("PINOT_GPU_PLAN_CACHE") && getenv("PINOT_GPU_PLAN_CACHE")[0] == '0');
+  std::vector<int> todo;
+  std::vector<std::string> keys(plan_cache && g_engine.batch_launch ? (size_t)count : 0);
+  int cache_hits = 0;
+  for (int i = 0; i < count; ++i) {
+    if (!keys.empty() && segments[i] && queries[i] && !(queries[i]->flags & PG_QUERY_NULL_HANDLING) && query_key(queries[i], &keys[(size_t)i]) &&
+        cached_item(segments[i], keys[(size_t)i], &defs[(size_t)i])) { statuses[i] = kDeferred; ++cache_hits; continue; }
+    todo.push_back(i);
+  }
   // (a deferred item is ~2 us of lowering: eight per claim, so 64 items wake at most seven helpers; an item that runs its own kernel
   // is claimed alone)
   // (an item too large for the shared launch runs its whole kernel inside its claim: such batches are claimed one item at a time)
   bool all_small = g_engine.batch_launch;
-  for (int i = 0; i < count && all_small; ++i) all_small = segments[i] != nullptr && ((long long)segments[i]->num_docs + 2047) / 2048 <= kBatchMaxTiles;
-  run_items(count, all_small ? threads : std::min(threads, count), all_small ? 8 : 1, !all_small, [&](int i) {
+  for (int i : todo) all_small = all_small && segments[i] != nullptr && ((long long)segments[i]->num_docs + 2047) / 2048 <= kBatchMaxTiles;
+  const int todo_count = (int)todo.size();
+  if (todo_count > 0) run_items(todo_count, all_small ? threads : std::min(threads, todo_count), all_small ? 8 : 1, !all_small, [&](int t) {
+    const int i = todo[(size_t)t];
     if (!segments[i] || !queries[i]) { statuses[i] = PG_ERR_INVALID_ARGUMENT; errors[(size_t)i] = "null segment or query"; return; }
     const auto t_item = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-    statuses[i] = execute_one(segments[i], queries[i], &results[i], g_engine.batch_launch ? &defs[(size_t)i] : nullptr);
+    // (a query that may enter the plan cache is lowered from a copy of its own: the item's conversion reads the query after this call has returned)
+    const pg_query* q = queries[i];
+    std::shared_ptr<const OwnedQuery> copy;
+    if (!keys.empty() && !keys[(size_t)i].empty()) { copy = own_query(q); q = &copy->q; }
+    statuses[i] = execute_one(segments[i], q, &results[i], g_engine.batch_launch ? &defs[(size_t)i] : nullptr);
+    if (statuses[i] == kDeferred && copy && defs[(size_t)i].cacheable) remember_item(segments[i], std::move(keys[(size_t)i]), copy, &defs[(size_t)i]);
+    else if (statuses[i] == kDeferred && copy) std::const_pointer_cast<LoweredItem>(defs[(size_t)i].item)->query = copy;
     if (trace) item_us[(size_t)i] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t_item).count();
     if (statuses[i] != PG_OK && statuses[i] != kDeferred) errors[(size_t)i] = g_error;      // (g_error is the worker's thread-local)
   });
@@ -4167,7 +4316,7 @@ pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* q
   for (int i = 0; i < count; ++i) {
     if (statuses[i] != kDeferred) continue;
     DeferredLaunch* L = nullptr;
-    const int kind = defs[(size_t)i].sp.lean_kind;
+    const int kind = defs[(size_t)i].item->sp.lean_kind;
     for (auto& l : launches) if (l->device == segments[i]->device && l->lean_kind == kind) L = l.get();
     if (!L) { launches.emplace_back(new DeferredLaunch()); L = launches.back().get(); L->device = segments[i]->device; L->lean_kind = kind; }
     L->items.push_back(i);
@@ -4188,8 +4337,8 @@ pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* q
     const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     float sum_us = 0.f, max_us = 0.f;
     for (float v : item_us) { sum_us += v; max_us = std::max(max_us, v); }
-    fprintf(stderr, "pg_execute_batch: %d items, lower %.1f us (items: sum %.1f us, max %.1f us, %d threads), launches %.1f us\n", count, us(t_begin, t_lowered), sum_us, max_us, threads,
-            us(t_lowered, std::chrono::steady_clock::now()));
+    fprintf(stderr, "pg_execute_batch: %d items (%d from the plan cache), lower %.1f us (items: sum %.1f us, max %.1f us, %d threads), launches %.1f us\n", count, cache_hits,
+            us(t_begin, t_lowered), sum_us, max_us, threads, us(t_lowered, std::chrono::steady_clock::now()));
   }
   return PG_OK;
 }

@@ -210,3 +210,108 @@ def test_batch_spanning_two_devices(engine):
                     H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
     finally:
         [g.close() for g in opened]
+
+
+def _cache_specs(segs, variant):
+    """New QuerySpec objects on every call (new addresses for the same -- or almost the same -- content)."""
+    out = []
+    for s, seg in enumerate(segs):
+        card_f = seg.columns[1].cardinality
+        if variant == "range-a":
+            flt = Q.leaf(Q.Pred.dict_range(1, 1, min(card_f, 7)))
+        elif variant == "range-b":                      # same shape, other bounds
+            flt = Q.leaf(Q.Pred.dict_range(1, 2, min(card_f, 9)))
+        elif variant == "set-a":
+            flt = Q.leaf(Q.Pred.dict_set(1, [0, 3, 5, 11], card_f))
+        elif variant == "set-b":                        # same number of set words, other bits
+            flt = Q.leaf(Q.Pred.dict_set(1, [1, 3, 6, 10], card_f))
+        elif variant == "sum-w":                        # other aggregated column
+            out.append(Q.QuerySpec([(Q.SUM, 3), (Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(1, 1, min(card_f, 7)))))
+            continue
+        else:
+            raise ValueError(variant)
+        out.append(Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1)], filter=flt))
+    return out
+
+
+def test_the_plan_cache_goes_by_the_content_of_the_query(engine):
+    """pg_execute_batch keeps the last few lowered queries of a segment (pg_segment.plan_cache): the same query again skips the lowering, a
+    query that differs in one bound / one set bit / one column must not be served from it, and the caller's pg_query may be gone by then."""
+    import gc
+    segs = _segments()[:6]
+    opened = [engine.open(seg) for seg in segs]
+    try:
+        order = ["range-a", "range-a", "range-b", "range-a", "set-a", "set-b", "set-a", "sum-w", "range-b", "range-a", "set-b", "sum-w", "sum-w", "range-a"]
+        for step, variant in enumerate(order):
+            specs = _cache_specs(segs, variant)
+            got = engine.execute_batch(opened, specs)
+            for s, (status, res) in enumerate(got):
+                assert status == _abi.PG_OK, (step, variant, s)
+                H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
+            del specs, got
+            gc.collect()
+        # other engine settings: what was lowered before them is not reused (the general kernel's body instead of the lean one here)
+        engine.reinit(PINOT_GPU_SCAN_SIMPLE=0)
+        try:
+            for variant in ("range-a", "set-a", "range-a"):
+                specs = _cache_specs(segs, variant)
+                for s, (status, res) in enumerate(engine.execute_batch(opened, specs)):
+                    assert status == _abi.PG_OK
+                    H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
+                    if s == 5 and variant == "range-a":
+                        assert res.dominant_kernel == "scan_private_kernel", res.dominant_kernel
+        finally:
+            engine.reinit(PINOT_GPU_SCAN_SIMPLE=None)
+        specs = _cache_specs(segs, "range-a")
+        for s, (status, res) in enumerate(engine.execute_batch(opened, specs)):
+            assert status == _abi.PG_OK and (s != 5 or res.dominant_kernel == "scan_simple_kernel"), res.dominant_kernel
+            H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
+    finally:
+        [g.close() for g in opened]
+
+
+def test_the_plan_cache_follows_the_value_planes(engine):
+    """A cached item reads a value plane by address: when planes are built, evicted and built again between batches the item is lowered anew."""
+    import ctypes as C
+    import time
+    rng = np.random.default_rng(404)
+    n = 400_003
+    segs = []
+    for s in range(3):
+        irregular = lambda card: np.sort(rng.choice(np.arange(-2_000_000, 2_000_000, dtype=np.int64), size=card, replace=False)).astype(np.int32)
+        x = S.Column.synthetic_uniform("x", n, irregular(12_000), seed=31 + s)              # no structure: the plane is materialised
+        y = S.Column.synthetic_uniform("y", n, irregular(9_000), seed=41 + s)
+        f = H.random_dict_column(rng, "f", n, 25)[0]
+        segs.append(S.SegmentData("pc%d" % s, n, [x, y, f]))
+    mk = lambda c: [Q.QuerySpec([(Q.SUM, c), (Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(2, 3, 17))) for _ in segs]
+    wants = {c: [oracle.execute(seg, sp) for seg, sp in zip(segs, mk(c))] for c in (0, 1)}
+    lib = engine.lib
+    previous = C.c_uint64()
+    engine.reinit(PINOT_GPU_HIST=0)                          # (12 000 values fit the LDS histogram, which needs no plane and does not share launches)
+    opened = [engine.open(seg) for seg in segs]
+    try:
+        def batch(c):
+            for s, (status, res) in enumerate(engine.execute_batch(opened, mk(c))):
+                assert status == _abi.PG_OK
+                H.assert_results_equal(res, wants[c][s])
+        for _ in range(8):                                   # before, while and after x's planes are built
+            batch(0)
+            time.sleep(0.02)
+        one = max(g.plane_bytes() for g in opened)
+        assert one > 0
+        # room for the planes of ONE column of the three segments: x and y take turns, every turn evicts what the other's items read
+        assert lib.pg_set_plane_budget(int(3.5 * one), C.byref(previous)) == 0
+        try:
+            for turn in range(4):
+                for c in (1, 0):
+                    for _ in range(6):
+                        batch(c)
+                        time.sleep(0.02)
+            assert lib.pg_set_plane_budget(0, None) == 0     # and with no planes at all
+            for c in (0, 1, 0):
+                batch(c)
+        finally:
+            assert lib.pg_set_plane_budget(previous.value, None) == 0
+    finally:
+        [g.close() for g in opened]
+        engine.reinit(PINOT_GPU_HIST=None)
