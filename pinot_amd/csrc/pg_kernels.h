@@ -2461,7 +2461,15 @@ __device__ __forceinline__ Dwords4 load16_stream(const uint32_t* __restrict__ or
 
 __device__ __forceinline__ void or_doc(uint32_t* w32, uint32_t doc) { atomicOr(&w32[doc >> 5], 1u << (doc & 31u)); }
 
-static __global__ __launch_bounds__(64) void index_and_kernel(const IndexAndParams ap) {
+// Round 4, what did NOT move this kernel (C5-sparse, 1 B rows, 15 259 windows, 66 us; rocprofv3 SQ counters in profiles/r4/pmc_c5s_sq*_summary.json:
+// ~1 660 instructions and ~11.6 us per window, 29 % of it issuing, 60 % waiting, ~2 850 of 4 096 possible windows in flight):
+//   five windows per SIMD (96 VGPRs, 7 spilled)                                        66.4 -> 63.7 us, the dense AND 55.1 -> 59.7
+//   touching every later child's array / run container right after the directory lookup   66.9 -> 71.9 us (twice, two codings)
+//   the lanes' arguments through scalar loads + selects instead of lane-indexed loads      66.2 -> 66.4 us
+#ifndef PG_INDEX_AND_WAVES
+#define PG_INDEX_AND_WAVES 4           // wavefronts (= windows) per SIMD the register allocation must allow
+#endif
+static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kernel(const IndexAndParams ap) {
   __shared__ uint4 window[512];                         // 1024 64-bit words; all zero whenever no child is being expanded
   uint32_t* w32 = reinterpret_cast<uint32_t*>(window);
   const int lane = (int)threadIdx.x;

@@ -64,6 +64,12 @@ c5)
   echo "== C5 kernels: HBM traffic (one counter per pass)"
   pmc c5_fetch "index_and|scan_private_kernel|scan_sparse" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --rows 100000 --rows-c5 1000000000 --variants ^C5-dense$" FETCH_SIZE
   pmc c5s_fetch "index_and|scan_private_kernel|scan_sparse" "--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --rows 100000 --rows-c5 1000000000 --variants ^C5-sparse$" FETCH_SIZE ;;
+c5s_sq)
+  echo "== what index_and_kernel's wavefronts do with their time (C5-sparse-count: the AND alone)"
+  C5S="--steps 2 --warmup 1 --segments 1 --no-cpu-baseline --rows 100000 --rows-c5 1000000000 --variants ^C5-sparse-count$"
+  pmc c5s_sq "index_and_kernel" "$C5S" SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD
+  pmc c5s_sq2 "index_and_kernel" "$C5S" SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS
+  pmc c5s_sq3 "index_and_kernel" "$C5S" GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH ;;
 hist)
   echo "== scan_hist_kernel (C2b-irregular): HBM traffic"
   pmc hist_fetch "scan_hist_kernel" "$ONE --variants ^C2b-irregular$" FETCH_SIZE ;;
