@@ -3853,7 +3853,13 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
   const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)seg->num_cus * 8));
 #define PG_FSM_LAUNCH(SM, LM) fsm_tiles_kernel<SM, LM><<<dim3(blocks), dim3(256), 0, 0>>>(fp)
 #define PG_FSM_LAUNCH_L(SM) do { if (L <= 2) PG_FSM_LAUNCH(SM, 2); else if (L <= 3) PG_FSM_LAUNCH(SM, 3); else if (L <= 4) PG_FSM_LAUNCH(SM, 4); else if (L <= 6) PG_FSM_LAUNCH(SM, 6); else PG_FSM_LAUNCH(SM, 8); } while (0)
-  if (S <= 2) PG_FSM_LAUNCH_L(2);
+  static const bool perm_walk = !(getenv("PINOT_GPU_FSM_PERM") && getenv("PINOT_GPU_FSM_PERM")[0] == '0');
+  if (S <= 4 && L <= 4 && perm_walk) {
+    if (L <= 2) fsm_tiles_perm_kernel<2><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
+    else if (L <= 3) fsm_tiles_perm_kernel<3><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
+    else fsm_tiles_perm_kernel<4><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
+  }
+  else if (S <= 2) PG_FSM_LAUNCH_L(2);
   else if (S <= 4) PG_FSM_LAUNCH_L(4);
   else if (S <= 8) PG_FSM_LAUNCH_L(8);
   else PG_FSM_LAUNCH_L(16);

@@ -22,15 +22,22 @@ struct FsmParams {
   int32_t num_inputs, num_states, num_docs, num_tiles;
 };
 
+// Round 4b: the walk's table entry is 32 bits --  low half: the BYTE offset of the next state's row in the table, high half: the entries
+// of the step -- so that a step of a chain is one LDS read, one or (row offset | input offset: the address of the next read) and one add
+// of the entry's high half (both SDWA word selects: no shift, no mask); the 16 steps of a whole lane are unrolled with immediate bit
+// offsets.  The first coding kept state and entries apart (shift + add + and + shift + or per step) in a loop with a lane-dependent trip
+// count: 575 us for the 488 282 tiles of 1 B rows x 3 leaves x 4 states.
 template <int SMAX, int LMAX>
 __global__ __launch_bounds__(256) void fsm_tiles_kernel(const FsmParams p) {
-  // Up to four input bits: TWO docs per table lookup (a 2 * LMAX-bit index, leaf i's bits for docs d, d + 1 side by side at 2i, 2i + 1 --
-  // one v_bfe_u32 + one v_lshl_or_b32 per leaf and pair); the walk is a chain of dependent LDS reads, half as long this way.
+  // Up to four input bits: TWO docs per table lookup (a 2 * LMAX-bit index, leaf i's bits for docs d, d + 1 side by side at 2i, 2i + 1);
+  // the walk is a chain of dependent LDS reads, half as long this way.
   constexpr bool kPair = LMAX <= 4;
   constexpr int kIndexBits = kPair ? 2 * LMAX : LMAX;
-  __shared__ uint8_t delta[SMAX << LMAX];
-  __shared__ uint16_t delta2[kPair ? (SMAX << kIndexBits) : 1];
-  __shared__ uint32_t lane_tables[4][64 * SMAX];
+  constexpr uint32_t kRowBytes = 4u << kIndexBits;                   // SMAX rows: at most 16 x 1 KB (pairs of four leaves) or 16 x 1 KB (eight leaves)
+  static_assert(SMAX * kRowBytes <= 65536u, "row offsets are 16 bits");
+  __shared__ uint8_t delta[SMAX << LMAX];                            // one doc: next | entries << 4 (the last tile's partial lanes)
+  __shared__ uint32_t step[SMAX << kIndexBits];                      // one step (a pair of docs, or one): next row's byte offset | entries << 16
+  __shared__ uint32_t lane_tables[4][64 * SMAX];                     // state | entries << 16
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int L = p.num_inputs, S = p.num_states;
   // the table is re-laid for LMAX input bits per state (unused states / inputs: entries that are never read)
@@ -39,17 +46,23 @@ __global__ __launch_bounds__(256) void fsm_tiles_kernel(const FsmParams p) {
     delta[i] = (st < S && in < (1 << L)) ? p.delta[(st << L) | in] : (uint8_t)0;
   }
   __syncthreads();
-  if constexpr (kPair) {
-    for (int i = threadIdx.x; i < (SMAX << kIndexBits); i += blockDim.x) {
-      const int st = i >> kIndexBits, idx = i & ((1 << kIndexBits) - 1);
+  for (int i = threadIdx.x; i < (SMAX << kIndexBits); i += blockDim.x) {
+    const int st = i >> kIndexBits, idx = i & ((1 << kIndexBits) - 1);
+    uint32_t next, inc;
+    if constexpr (kPair) {
       int in0 = 0, in1 = 0;
       for (int l = 0; l < LMAX; ++l) { in0 |= ((idx >> (2 * l)) & 1) << l; in1 |= ((idx >> (2 * l + 1)) & 1) << l; }
       const uint32_t t0 = delta[(st << LMAX) | in0], t1 = delta[((t0 & 15u) << LMAX) | in1];
-      delta2[i] = (uint16_t)((t1 & 15u) | (((t0 >> 4) + (t1 >> 4)) << 4));
+      next = t1 & 15u; inc = (t0 >> 4) + (t1 >> 4);
+    } else {
+      const uint32_t t0 = delta[(st << LMAX) | idx];
+      next = t0 & 15u; inc = t0 >> 4;
     }
-    __syncthreads();
+    step[i] = (next * kRowBytes) | (inc << 16);
   }
+  __syncthreads();
   uint32_t* mine = lane_tables[wave];
+  const char* const step_bytes = reinterpret_cast<const char*>(step);
   for (long long tile = (long long)blockIdx.x * 4 + wave; tile < p.num_tiles; tile += (long long)gridDim.x * 4) {
     const long long first = tile * 2048 + lane * 32;
     const long long rem = (long long)p.num_docs - first;
@@ -57,42 +70,51 @@ __global__ __launch_bounds__(256) void fsm_tiles_kernel(const FsmParams p) {
     uint32_t w[LMAX];
 #pragma unroll
     for (int i = 0; i < LMAX; ++i) w[i] = i < L ? p.leaf[i][tile * 64 + lane] : 0u;
-    uint32_t cur[SMAX], ent[SMAX];                 // cur: the state, kept shifted into the table index
+    uint32_t st_out[SMAX], ent[SMAX];
+    if (__builtin_amdgcn_ballot_w64(docs != 32) == 0ull) {
+      // ---- every lane has its 32 docs (all tiles but the last): straight-line code, immediate bit offsets ----
+      uint32_t row[SMAX];                                             // byte offset of the chain's current row
 #pragma unroll
-    for (int s = 0; s < SMAX; ++s) { cur[s] = (uint32_t)s << kIndexBits; ent[s] = 0u; }
-    int d = 0;
-    if constexpr (kPair) {
-      for (; d + 2 <= docs; d += 2) {
+      for (int s = 0; s < SMAX; ++s) { row[s] = (uint32_t)s * kRowBytes; ent[s] = 0u; }
+      constexpr int kDocsPerStep = kPair ? 2 : 1;
+#pragma unroll
+      for (int d = 0; d < 32; d += kDocsPerStep) {
+        uint32_t in4 = 0u;                                            // the step's input as a byte offset inside a row
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i) in4 |= __builtin_amdgcn_ubfe(w[i], d, kDocsPerStep) << (kDocsPerStep * i + 2);
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) {                              // SMAX independent chains: their LDS reads are in flight together
+          const uint32_t t = *reinterpret_cast<const uint32_t*>(step_bytes + (row[s] | in4));
+          ent[s] += t >> 16;
+          row[s] = t & 0xFFFFu;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < SMAX; ++s) st_out[s] = row[s] / kRowBytes;
+    } else {
+#pragma unroll
+      for (int s = 0; s < SMAX; ++s) { st_out[s] = (uint32_t)s; ent[s] = 0u; }
+      for (int d = 0; d < docs; ++d) {
         uint32_t in = 0u;
 #pragma unroll
-        for (int i = 0; i < LMAX; ++i) in |= __builtin_amdgcn_ubfe(w[i], d, 2) << (2 * i);
+        for (int i = 0; i < LMAX; ++i) in |= __builtin_amdgcn_ubfe(w[i], d, 1) << i;
 #pragma unroll
-        for (int s = 0; s < SMAX; ++s) {          // SMAX independent chains: their LDS reads are in flight together
-          const uint32_t t = delta2[cur[s] | in];
+        for (int s = 0; s < SMAX; ++s) {
+          const uint32_t t = delta[(st_out[s] << LMAX) | in];
           ent[s] += t >> 4;
-          cur[s] = (t & 15u) << kIndexBits;
+          st_out[s] = t & 15u;
         }
       }
     }
-    for (; d < docs; ++d) {
-      uint32_t in = 0u;
 #pragma unroll
-      for (int i = 0; i < LMAX; ++i) in |= __builtin_amdgcn_ubfe(w[i], d, 1) << i;
-#pragma unroll
-      for (int s = 0; s < SMAX; ++s) {
-        const uint32_t t = delta[((cur[s] >> kIndexBits) << LMAX) | in];
-        ent[s] += t >> 4;
-        cur[s] = (t & 15u) << kIndexBits;
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < SMAX; ++s) mine[lane * SMAX + s] = (cur[s] >> kIndexBits) | (ent[s] << 4);
+    for (int s = 0; s < SMAX; ++s) mine[lane * SMAX + s] = st_out[s] | (ent[s] << 16);      // (a lane: at most 32 docs x 8 entries)
     __builtin_amdgcn_wave_barrier();
     // The 64 lane tables composed in lane order, as a tree: at level j the lanes whose low j + 1 bits are zero append the table 2^j lanes
     // further on (which by then stands for 2^j lanes) to their own.  Six dependent rounds of SMAX LDS reads instead of a 64-step walk.
+    // (a tile: at most 2048 docs x 8 entries = 2^14: the 16-bit halves hold)
     uint32_t c[SMAX], e[SMAX];
 #pragma unroll
-    for (int s = 0; s < SMAX; ++s) { c[s] = cur[s] >> kIndexBits; e[s] = ent[s]; }
+    for (int s = 0; s < SMAX; ++s) { c[s] = st_out[s]; e[s] = ent[s]; }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const bool active = (lane & ((2 << j) - 1)) == 0;
@@ -100,14 +122,14 @@ __global__ __launch_bounds__(256) void fsm_tiles_kernel(const FsmParams p) {
 #pragma unroll
         for (int s = 0; s < SMAX; ++s) {
           const uint32_t t = mine[(lane + (1 << j)) * SMAX + (int)c[s]];
-          e[s] += t >> 4;
-          c[s] = t & 15u;
+          e[s] += t >> 16;
+          c[s] = t & 0xFFFFu;
         }
       }
       __builtin_amdgcn_wave_barrier();
       if (active) {
 #pragma unroll
-        for (int s = 0; s < SMAX; ++s) mine[lane * SMAX + s] = c[s] | (e[s] << 4);
+        for (int s = 0; s < SMAX; ++s) mine[lane * SMAX + s] = c[s] | (e[s] << 16);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -118,17 +140,123 @@ __global__ __launch_bounds__(256) void fsm_tiles_kernel(const FsmParams p) {
   }
 }
 
-// `count` tables of S entries each -> ceil(count / 1024) tables: thread t < S of every wavefront walks the wavefront's 64 tables from
-// entry state t, then the first wavefront walks the (up to 16) wavefront tables.
+// At most FOUR states and four input bits (a AND b AND c, a AND (b OR c), ... after minimisation): no table walk at all.  A function
+// {entry state} -> {exit state} of four states is four BYTES of one register, and composing two of them is ONE v_perm_b32 (the first
+// function's bytes are the selectors into the second's); the entries per entry state ride along as four more bytes, gathered by the
+// same selectors.  A step of the lane's walk: one 8-byte LDS read (the pair-of-docs functions {next, entries}, indexed by the lane's
+// input bits), two v_perm_b32, one add -- against four dependent table reads of fsm_tiles_kernel, which measured LDS-bound (64 lanes
+// reading 64 random entries of a 256-byte row: ~5-way bank conflicts, ~100 LDS instructions per tile: 580 us per 1 B docs whatever the
+// VALU did).  The 64 lane functions are composed in lane order by a tree over ds_bpermute (no LDS storage, no conflicts), the entries
+// widened to 16 bits there (a tile: at most 2048 docs x 4 entries).
+template <int LMAX>
+__global__ __launch_bounds__(256) void fsm_tiles_perm_kernel(const FsmParams p) {
+  static_assert(LMAX <= 4, "two docs per lookup: an index of at most eight bits");
+  constexpr int kIndexBits = 2 * LMAX;
+  __shared__ uint8_t delta[4 << LMAX];                               // one doc: next | entries << 4
+  __shared__ uint2 pair_fn[1 << kIndexBits];                         // two docs with input idx: x = next state of s in byte s, y = entries of s in byte s
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = p.num_inputs, S = p.num_states;
+  for (int i = threadIdx.x; i < (4 << LMAX); i += blockDim.x) {
+    const int st = i >> LMAX, in = i & ((1 << LMAX) - 1);
+    delta[i] = (st < S && in < (1 << L)) ? p.delta[(st << L) | in] : (uint8_t)0;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < (1 << kIndexBits); idx += blockDim.x) {
+    int in0 = 0, in1 = 0;
+    for (int l = 0; l < LMAX; ++l) { in0 |= ((idx >> (2 * l)) & 1) << l; in1 |= ((idx >> (2 * l + 1)) & 1) << l; }
+    uint32_t next = 0u, inc = 0u;
+    for (int st = 0; st < 4; ++st) {
+      const uint32_t t0 = delta[(st << LMAX) | in0], t1 = delta[((t0 & 15u) << LMAX) | in1];
+      next |= ((t1 & 15u) & 3u) << (8 * st);
+      inc |= ((t0 >> 4) + (t1 >> 4)) << (8 * st);
+    }
+    pair_fn[idx] = make_uint2(next, inc);
+  }
+  __syncthreads();
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < p.num_tiles; tile += (long long)gridDim.x * 4) {
+    const long long first = tile * 2048 + lane * 32;
+    const long long rem = (long long)p.num_docs - first;
+    const int docs = rem >= 32 ? 32 : (rem <= 0 ? 0 : (int)rem);      // (docs past numDocs do not exist; the lanes of the last tile stop at different docs)
+    uint32_t w[LMAX];
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) w[i] = i < L ? p.leaf[i][tile * 64 + lane] : 0u;
+    uint32_t F = 0x03020100u, E = 0u;                                 // the identity; no entries
+    if (__builtin_amdgcn_ballot_w64(docs != 32) == 0ull) {
+      // the leaves' words regrouped once per tile so that a step's index is one bit-field extract per two leaves: nibble k of lo_even holds
+      // (leaf 0: docs 4k, 4k + 1; leaf 1: docs 4k, 4k + 1), of lo_odd the same for docs 4k + 2, 4k + 3; hi_* for leaves 2 and 3
+      constexpr uint32_t kM = 0x33333333u;
+      const uint32_t lo_even = (w[0] & kM) | (LMAX > 1 ? (w[LMAX > 1 ? 1 : 0] & kM) << 2 : 0u);
+      const uint32_t lo_odd = ((w[0] >> 2) & kM) | (LMAX > 1 ? (w[LMAX > 1 ? 1 : 0] & ~kM) : 0u);
+      const uint32_t hi_even = LMAX > 2 ? ((w[LMAX > 2 ? 2 : 0] & kM) | (LMAX > 3 ? (w[LMAX > 3 ? 3 : 0] & kM) << 2 : 0u)) : 0u;
+      const uint32_t hi_odd = LMAX > 2 ? (((w[LMAX > 2 ? 2 : 0] >> 2) & kM) | (LMAX > 3 ? (w[LMAX > 3 ? 3 : 0] & ~kM) : 0u)) : 0u;
+#pragma unroll
+      for (int d = 0; d < 32; d += 2) {
+        const uint32_t lo = (d & 2) ? lo_odd : lo_even, hi = (d & 2) ? hi_odd : hi_even;
+        uint32_t idx = __builtin_amdgcn_ubfe(lo, d & ~3, 4);
+        if (LMAX > 2) idx |= __builtin_amdgcn_ubfe(hi, d & ~3, 4) << 4;
+        const uint2 t = pair_fn[idx];
+        E += __builtin_amdgcn_perm(t.y, t.y, F);                      // entries of the transition each chain takes (a lane: at most 32 docs x 4: a byte holds)
+        F = __builtin_amdgcn_perm(t.x, t.x, F);
+      }
+    } else {
+      uint32_t st[4] = {0u, 1u, 2u, 3u}, ent[4] = {0u, 0u, 0u, 0u};
+      for (int d = 0; d < docs; ++d) {
+        uint32_t in = 0u;
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i) in |= __builtin_amdgcn_ubfe(w[i], d, 1) << i;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t t = delta[(st[c] << LMAX) | in];
+          ent[c] += t >> 4;
+          st[c] = t & 3u;
+        }
+      }
+      F = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
+      E = ent[0] | (ent[1] << 8) | (ent[2] << 16) | (ent[3] << 24);
+    }
+    // entries as 16-bit fields: EA = chains 0, 1; EB = chains 2, 3
+    uint32_t EA = __builtin_amdgcn_perm(0u, E, 0x0c010c00u), EB = __builtin_amdgcn_perm(0u, E, 0x0c030c02u);
+    // The 64 lane functions composed in lane order, as a tree: at level j lane l appends the function of lane l + 2^j (which by then stands
+    // for 2^j lanes) to its own.  Every lane computes; only the lanes that are multiples of 2^(j+1) hold something meaningful, and they
+    // read only such lanes.
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int from = ((lane + (1 << j)) & 63) << 2;
+      const uint32_t G = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)F);
+      const uint32_t HA = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)EA), HB = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)EB);
+      // selectors of the 16-bit entries H[F[s]]: bytes (2 F[s], 2 F[s] + 1) of {HB : HA}
+      const uint32_t selA = (__builtin_amdgcn_perm(F, F, 0x01010000u) << 1) + 0x01000100u;
+      const uint32_t selB = (__builtin_amdgcn_perm(F, F, 0x03030202u) << 1) + 0x01000100u;
+      EA += __builtin_amdgcn_perm(HB, HA, selA);
+      EB += __builtin_amdgcn_perm(HB, HA, selB);
+      F = __builtin_amdgcn_perm(G, G, F);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t e = ((c < 2 ? EA : EB) >> (16 * (c & 1))) & 0xFFFFu;
+        if (c < S) p.tables[tile * S + c] = ((F >> (8 * c)) & 3u) | (e << 4);
+      }
+    }
+  }
+}
+
+// `count` tables of S entries each -> ceil(count / 1024) tables.  Every wavefront stages its 64 tables in LDS with coalesced loads (walking
+// them straight from memory was 64 DEPENDENT loads per lane: ~35 us of a 60 us tail), thread t < S walks them from entry state t, then the
+// first wavefront walks the (up to 16) wavefront tables.
 static __global__ __launch_bounds__(1024) void fsm_chain_kernel(const uint32_t* __restrict__ in, long long count, int S, uint32_t* __restrict__ out) {
+  __shared__ uint32_t staged[16][64 * kFsmStates];
   __shared__ uint32_t wave_tables[16 * kFsmStates];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long base = (long long)blockIdx.x * kFsmChunk + wave * 64;
+  const long long left = count - base;
+  const int here = left >= 64 ? 64 : (left <= 0 ? 0 : (int)left);
+  for (int i = lane; i < here * S; i += 64) staged[wave][i] = in[base * S + i];
+  __builtin_amdgcn_wave_barrier();
   if (lane < S) {
     uint32_t c = (uint32_t)lane, e = 0u;
-    for (int i = 0; i < 64; ++i) {
-      if (base + i >= count) break;
-      const uint32_t t = in[(base + i) * S + (int)c];
+    for (int i = 0; i < here; ++i) {
+      const uint32_t t = staged[wave][i * S + (int)c];
       e += t >> 4;
       c = t & 15u;
     }
@@ -146,19 +274,35 @@ static __global__ __launch_bounds__(1024) void fsm_chain_kernel(const uint32_t* 
   }
 }
 
-// The last level: at most 1024 tables (a segment has < 2^20 tiles: one chain level leaves at most 1024), staged in LDS and walked from
-// state 0 by one thread, the entries added in 64 bits (a table entry carries at most 2^21 docs x 15).
+// The last level: at most 1024 tables (a segment has < 2^20 tiles: one chain level leaves at most 1024), staged in LDS; every wavefront
+// walks its 64 from every entry state, one thread then walks the 16 wavefront tables from state 0 -- the entries added in 64 bits
+// (a table entry carries at most 2^21 docs x 15).
 static __global__ __launch_bounds__(1024) void fsm_finish_kernel(const uint32_t* __restrict__ in, int count, int S, unsigned long long* __restrict__ out_entries) {
   extern __shared__ uint32_t staged[];
+  __shared__ unsigned long long wave_entries[16 * kFsmStates];
+  __shared__ uint32_t wave_state[16 * kFsmStates];
   for (int i = threadIdx.x; i < count * S; i += blockDim.x) staged[i] = in[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < S) {
+    uint32_t c = (uint32_t)lane;
+    unsigned long long e = 0ull;
+    const int first = wave * 64, last = first + 64 < count ? first + 64 : count;
+    for (int i = first; i < last; ++i) {
+      const uint32_t t = staged[i * S + (int)c];
+      e += t >> 4;
+      c = t & 15u;
+    }
+    wave_state[wave * kFsmStates + lane] = c;
+    wave_entries[wave * kFsmStates + lane] = e;
+  }
   __syncthreads();
   if (threadIdx.x != 0) return;
   uint32_t c = 0u;
   unsigned long long e = 0ull;
-  for (int i = 0; i < count; ++i) {
-    const uint32_t t = staged[i * S + (int)c];
-    e += t >> 4;
-    c = t & 15u;
+  for (int v = 0; v < 16; ++v) {
+    e += wave_entries[v * kFsmStates + (int)c];
+    c = wave_state[v * kFsmStates + (int)c];
   }
   *out_entries = e;
 }
