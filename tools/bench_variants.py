@@ -259,6 +259,9 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                         modes[mode]["kernel_ms"] = sum(dev) / len(dev)
                         modes[mode]["kernel_GBps"] = nbytes / (sum(dev) / len(dev)) / 1e6 if sum(dev) > 0 else None
                 exact = None
+                # (the body that ran, as the library reports it per item; the shared launch is scan_lean_batch_kernel for the simple / raw shapes, scan_private_batch_kernel otherwise)
+                body = engine.execute_batch(opened[:1], specs[:1])[0][1].dominant_kernel
+                launch = "scan_lean_batch_kernel" if body in ("scan_simple_kernel", "scan_raw_kernel") else "scan_private_batch_kernel"
                 if check:
                     got = engine.execute_batch(opened, specs)
                     exact = True
@@ -266,7 +269,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                         wanted = oracle.execute_sliced(sd, sp)
                         exact = exact and st == _abi.PG_OK and bool(oracle.matches_sliced(res, wanted, [f for f, _ in sp.aggregations]) and res.stats[0] == wanted["docs_scanned"])
                 out.append({"id": vid, "config": "BASELINE.json configs[0] x 64 segments: the small-segment regime of a real server", "query": sql + " over 64 segments of 10 M rows",
-                            "rows": n1 * nseg, "algorithmic_bytes": int(nbytes), "modes": modes, "kernel": "scan_private_batch_kernel", "kernel_ms": modes["batch"].get("kernel_ms"),
+                            "rows": n1 * nseg, "algorithmic_bytes": int(nbytes), "modes": modes, "kernel": launch, "kernel_body": body, "kernel_ms": modes["batch"].get("kernel_ms"),
                             "all_kernels_ms": modes["batch"].get("kernel_ms"), "step_ms_host_clock": modes["batch"]["wall_ms"], "achieved_GBps": modes["batch"]["aggregate_GBps"],
                             "frac": modes["batch"]["frac_of_8TBps"], "frac_dominant_kernel": (modes["batch"]["kernel_GBps"] / HBM_PEAK_GBPS) if modes["batch"].get("kernel_GBps") else None,
                             "rows_per_s": n1 * nseg / modes["batch"]["wall_ms"] * 1e3, "bit_exact_vs_oracle": exact, "host_generate_s": gen_s,
