@@ -1753,6 +1753,11 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
     e = hipGetDeviceProperties(&prop, seg->device);
     if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e)));
     seg->num_cus = prop.multiProcessorCount;
+    // Test switch: every grid of this segment is sized as if the device had this many CUs.  With 1, a 100 000-doc segment is ~50 tiles for
+    // ~32 waves -- every kernel's tile loop runs more than once per wave on the suite's SMALL segments (a kernel that was
+    // wrong from a wave's second tile on passed every test below 4.5 M docs on the full grid).
+    const char* tc = getenv("PINOT_GPU_TEST_CUS");
+    if (tc && atoi(tc) > 0) seg->num_cus = atoi(tc);
   }
   seg->cols.resize((size_t)desc->num_columns);
   for (int i = 0; i < desc->num_columns; ++i) {
