@@ -3957,10 +3957,11 @@ struct WorkerPool {
       remaining.fetch_sub(last - first, std::memory_order_release);
     }
   }
-  // A helper that has just worked stays on its core for a moment: a batch is two runs ~0.5 ms apart (lowering, conversion) and a busy
-  // server's batches follow each other; being woken through the condition variable cost the first run of a call ~30 us of its ~40
-  // (64 items of 1.6 us each on eight threads).  kSpinNs without a new run and the helper parks.
-  static constexpr long long kSpinNs = 1'000'000;
+  // A helper that has just worked stays on its core for a moment (being woken through the condition variable costs a run ~30 us of
+  // latency, and a batch's items that miss the plan cache come in bursts); kSpinNs without a new run and the helper parks.  Round 4: 1 ms
+  // -> 100 us -- with the plan cache a busy server's batches rarely need the helpers at all, and a millisecond of spinning per helper
+  // after every miss was a core's worth of idle work per sixteen of them.
+  static constexpr long long kSpinNs = 100'000;
   void worker(int index) {
     unsigned long long seen = 0;
     bool worked = false;
@@ -3997,7 +3998,7 @@ struct WorkerPool {
       const int want = std::max(0, std::min(max_threads, (n + items_per_claim - 1) / items_per_claim) - 1);
       while ((int)threads.size() < want) { const int index = (int)threads.size(); threads.emplace_back([this, index] { worker(index); }); }
       // a helper woken late for the previous run may be inside drain() (it enters under this mutex and finds nothing left): let it leave
-      while (inside.load(std::memory_order_acquire) != 0) {}
+      while (inside.load(std::memory_order_acquire) != 0) cpu_relax();
       job = std::move(fn);
       count = n; grain = std::max(1, items_per_claim); helpers = want;
       next.store(0, std::memory_order_relaxed);
