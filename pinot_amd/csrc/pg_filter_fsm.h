@@ -291,5 +291,87 @@ inline int64_t fsm_count_tiled(const Fsm& f, const std::vector<const uint64_t*>&
   return entries;
 }
 
+// fsm_tiles_perm_kernel's arithmetic on the host (machines of at most four states and four inputs): a function {entry state} -> {exit
+// state} is four bytes of one word, composition is a byte permute (V_PERM_B32: selector byte k in 0..3 picks byte k of the second source,
+// 4..7 of the first, 0x0c gives zero), the entries ride along as bytes (lane) / 16-bit fields (tile) gathered by the same selectors, two
+// docs per step.  -1 when the machine is larger.  The CPU tests hold it against the doc-by-doc walk; the kernel is the same arithmetic.
+inline uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) {
+  const uint64_t both = ((uint64_t)s0 << 32) | s1;
+  uint32_t out = 0;
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t c = (sel >> (8 * k)) & 0xFFu;
+    const uint32_t byte = c < 8 ? (uint32_t)((both >> (8 * c)) & 0xFFu) : (c == 0x0c ? 0u : 0xFFu);      // (the sign-extending selectors 8..11 and 13+ are not used)
+    out |= byte << (8 * k);
+  }
+  return out;
+}
+inline int64_t fsm_count_perm(const Fsm& f, const std::vector<const uint64_t*>& leaf_words, int32_t num_docs) {
+  const int S = f.num_states, L = f.num_inputs;
+  if (S > 4 || L > 4) return -1;
+  auto delta = [&](uint32_t st, uint32_t in) -> uint32_t { return (st < (uint32_t)S && in < (1u << L)) ? f.delta[((size_t)st << L) | in] : 0u; };
+  // pair_fn[idx]: leaf l's bits for docs d, d + 1 at bits 2l, 2l + 1 of idx
+  std::vector<uint32_t> pair_next((size_t)1 << (2 * L)), pair_inc((size_t)1 << (2 * L));
+  for (uint32_t idx = 0; idx < (1u << (2 * L)); ++idx) {
+    uint32_t in0 = 0, in1 = 0, next = 0, inc = 0;
+    for (int l = 0; l < L; ++l) { in0 |= ((idx >> (2 * l)) & 1u) << l; in1 |= ((idx >> (2 * l + 1)) & 1u) << l; }
+    for (uint32_t st = 0; st < 4; ++st) {
+      const uint32_t t0 = delta(st, in0), t1 = delta(t0 & 15u, in1);
+      next |= ((t1 & 15u) & 3u) << (8 * st);
+      inc |= ((t0 >> 4) + (t1 >> 4)) << (8 * st);
+    }
+    pair_next[idx] = next; pair_inc[idx] = inc;
+  }
+  const int64_t num_tiles = ((int64_t)num_docs + 2047) / 2048;
+  int64_t entries = 0;
+  uint32_t state = 0;
+  for (int64_t tile = 0; tile < num_tiles; ++tile) {
+    uint32_t F[64], EA[64], EB[64];
+    for (int lane = 0; lane < 64; ++lane) {
+      const int64_t first = tile * 2048 + (int64_t)lane * 32;
+      const int docs = (int)std::max<int64_t>(0, std::min<int64_t>(32, (int64_t)num_docs - first));
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      for (int i = 0; i < L; ++i) w[i] = docs > 0 ? (uint32_t)(leaf_words[(size_t)i][(size_t)first >> 6] >> (first & 63)) : 0u;
+      uint32_t fn = 0x03020100u, e = 0u;
+      if (docs == 32) {
+        for (int d = 0; d < 32; d += 2) {
+          uint32_t idx = 0;
+          for (int i = 0; i < L; ++i) idx |= ((w[i] >> d) & 3u) << (2 * i);
+          e += perm_b32(pair_inc[idx], pair_inc[idx], fn);
+          fn = perm_b32(pair_next[idx], pair_next[idx], fn);
+        }
+      } else {
+        uint32_t st[4] = {0u, 1u, 2u, 3u}, ent[4] = {0u, 0u, 0u, 0u};
+        for (int d = 0; d < docs; ++d) {
+          uint32_t in = 0;
+          for (int i = 0; i < L; ++i) in |= ((w[i] >> d) & 1u) << i;
+          for (int c = 0; c < 4; ++c) { const uint32_t t = delta(st[c], in); ent[c] += t >> 4; st[c] = t & 3u; }
+        }
+        fn = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
+        e = ent[0] | (ent[1] << 8) | (ent[2] << 16) | (ent[3] << 24);
+      }
+      F[lane] = fn;
+      EA[lane] = perm_b32(0u, e, 0x0c010c00u);
+      EB[lane] = perm_b32(0u, e, 0x0c030c02u);
+    }
+    for (int j = 0; j < 6; ++j) {                    // the tree: every lane computes, like the wavefront does
+      uint32_t nF[64], nA[64], nB[64];
+      for (int lane = 0; lane < 64; ++lane) {
+        const int from = (lane + (1 << j)) & 63;
+        const uint32_t G = F[from], HA = EA[from], HB = EB[from];
+        const uint32_t selA = (perm_b32(F[lane], F[lane], 0x01010000u) << 1) + 0x01000100u;
+        const uint32_t selB = (perm_b32(F[lane], F[lane], 0x03030202u) << 1) + 0x01000100u;
+        nA[lane] = EA[lane] + perm_b32(HB, HA, selA);
+        nB[lane] = EB[lane] + perm_b32(HB, HA, selB);
+        nF[lane] = perm_b32(G, G, F[lane]);
+      }
+      for (int lane = 0; lane < 64; ++lane) { F[lane] = nF[lane]; EA[lane] = nA[lane]; EB[lane] = nB[lane]; }
+    }
+    const uint32_t e_of_state = ((state < 2 ? EA[0] : EB[0]) >> (16 * (state & 1u))) & 0xFFFFu;
+    entries += e_of_state;
+    state = (F[0] >> (8 * state)) & 3u;
+  }
+  return entries;
+}
+
 }  // namespace fstats
 }  // namespace pg

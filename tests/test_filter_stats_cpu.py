@@ -201,7 +201,7 @@ def test_transducer_matches_the_iterator_replay_on_random_and_trees(driver):
     """Root ANDs of scan leaves, index-based leaves and ORs of such leaves over random columns: the transducer (both forms) against the
     replay of the reference's iterator objects and against the oracle.  Sizes around the lane / tile boundaries."""
     rng = np.random.default_rng(4)
-    shapes_seen, compiled = set(), 0
+    shapes_seen, compiled, small = set(), 0, 0
     for n in (1, 31, 33, 2047, 2049, 4100, 20_011, 70_003):
         cols = [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "b", n, 7, with_inverted=True)[0],
                 H.random_dict_column(rng, "c", n, 300, with_inverted=True)[0], H.random_dict_column(rng, "d", n, 3)[0],
@@ -249,4 +249,11 @@ def test_transducer_matches_the_iterator_replay_on_random_and_trees(driver):
             shapes_seen.add((len(kids), states))
             tiled, _, _ = fsm(driver, seg, spec, 1)
             assert seq == tiled == want, (n, states, inputs, seq, tiled, want)
-    assert compiled > 200 and len(shapes_seen) > 8, (compiled, shapes_seen)
+            # the byte-function form (fsm_tiles_perm_kernel's arithmetic): machines of at most four states and four inputs
+            perm, _, _ = fsm(driver, seg, spec, 2)
+            if states <= 4 and inputs <= 4:
+                small += 1
+                assert perm == want, (n, states, inputs, perm, want)
+            else:
+                assert perm == -1
+    assert compiled > 200 and len(shapes_seen) > 8 and small > 60, (compiled, shapes_seen, small)

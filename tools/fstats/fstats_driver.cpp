@@ -34,7 +34,8 @@ extern "C" int64_t fstats_leap2(const uint64_t* a_words, const uint64_t* b_words
 }
 
 // The root AND as a finite-state transducer (pg_filter_fsm.h): -1 when the shape does not compile; else the count by the doc-by-doc walk
-// (mode 0) or in the device's lane / tile / chain structure (mode 1).  *out_states = the number of reachable states.
+// (mode 0), in the device's lane / tile / chain structure (mode 1: fsm_tiles_kernel's table walk) or in fsm_tiles_perm_kernel's byte-function
+// arithmetic (mode 2: -1 when the machine has more than four states or inputs).  *out_states = the number of reachable states.
 extern "C" int64_t fstats_fsm(const pg_query* q, int32_t num_docs, const uint64_t* const* leaf_words, int32_t mode, int32_t* out_states, int32_t* out_inputs) {
   pg::fstats::Fsm f;
   if (!pg::fstats::compile_fsm(q, &f)) return -1;
@@ -42,5 +43,6 @@ extern "C" int64_t fstats_fsm(const pg_query* q, int32_t num_docs, const uint64_
   if (out_inputs) *out_inputs = f.num_inputs;
   std::vector<const uint64_t*> words;
   for (int p : f.input_predicate) words.push_back(leaf_words[p]);
+  if (mode == 2) return pg::fstats::fsm_count_perm(f, words, num_docs);
   return mode == 0 ? pg::fstats::fsm_count_sequential(f, words, num_docs) : pg::fstats::fsm_count_tiled(f, words, num_docs);
 }
