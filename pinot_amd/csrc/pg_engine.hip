@@ -3859,7 +3859,11 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
 #define PG_FSM_LAUNCH(SM, LM) fsm_tiles_kernel<SM, LM><<<dim3(blocks), dim3(256), 0, 0>>>(fp)
 #define PG_FSM_LAUNCH_L(SM) do { if (L <= 2) PG_FSM_LAUNCH(SM, 2); else if (L <= 3) PG_FSM_LAUNCH(SM, 3); else if (L <= 4) PG_FSM_LAUNCH(SM, 4); else if (L <= 6) PG_FSM_LAUNCH(SM, 6); else PG_FSM_LAUNCH(SM, 8); } while (0)
   static const bool perm_walk = !(getenv("PINOT_GPU_FSM_PERM") && getenv("PINOT_GPU_FSM_PERM")[0] == '0');
-  if (S <= 4 && L <= 4 && perm_walk) {
+  // (the byte-function walk keeps a lane's entries per entry state in ONE byte: 16 steps x two docs x at most 7 entries per doc.  A doc
+  //  costs more than 7 only when the tree names the same predicate in many leaves -- such machines walk tables)
+  int max_inc = 0;
+  for (uint8_t d : fsm.delta) max_inc = std::max(max_inc, (int)(d >> 4));
+  if (S <= 4 && L <= 4 && max_inc <= 7 && perm_walk) {
     if (L <= 2) fsm_tiles_perm_kernel<2><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
     else if (L <= 3) fsm_tiles_perm_kernel<3><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
     else fsm_tiles_perm_kernel<4><<<dim3(blocks), dim3(256), 0, 0>>>(fp);

@@ -308,6 +308,7 @@ inline uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) {
 inline int64_t fsm_count_perm(const Fsm& f, const std::vector<const uint64_t*>& leaf_words, int32_t num_docs) {
   const int S = f.num_states, L = f.num_inputs;
   if (S > 4 || L > 4) return -1;
+  for (uint8_t d : f.delta) if ((d >> 4) > 7) return -1;      // (a lane's entries per entry state are one byte: 32 docs x at most 7)
   auto delta = [&](uint32_t st, uint32_t in) -> uint32_t { return (st < (uint32_t)S && in < (1u << L)) ? f.delta[((size_t)st << L) | in] : 0u; };
   // pair_fn[idx]: leaf l's bits for docs d, d + 1 at bits 2l, 2l + 1 of idx
   std::vector<uint32_t> pair_next((size_t)1 << (2 * L)), pair_inc((size_t)1 << (2 * L));
