@@ -23,6 +23,11 @@ Prints ONE JSON line on rank 0.  At N=1 the line also carries
                           structure (irregular / 2^20 window), C2a, C3 (config 3) with and without a filter, C5 sparse and dense
                           (config 5), C1 (config 0's scan pair)
   roofline.empirical_peak the box's own 16 B/lane streaming-read ceiling, measured in this run
+  roofline.frac           on ALL kernels of the query (HIP events around every launch); frac_dominant_kernel: the scan kernel alone
+  cold_launch_ms          one query after >= 1.2 s without a launch, no settle launches (best of three)
+  summary                 LAST key: {variant id: [frac on all kernels, all_kernels_ms, bit exact]} for the headline and every variant
+`--single-process --gpus N`: ONE process drives N devices (segment s on device s mod N, one pg_execute_batch per step) -- the
+deployment shape of a Pinot server; the driver's torchrun launch stays one process per GPU.
 """
 import argparse
 import ctypes as C
