@@ -315,3 +315,50 @@ def test_the_plan_cache_follows_the_value_planes(engine):
     finally:
         [g.close() for g in opened]
         engine.reinit(PINOT_GPU_HIST=None)
+
+
+def test_the_plan_cache_under_concurrent_batches(engine):
+    """Several threads inside pg_execute_batch over the SAME segments, each cycling through its own order of five queries (more shapes
+    than a segment remembers: entries are inserted, moved to the front and pushed out all the time while other threads hold them);
+    every item of every call must carry its own query's answer."""
+    import ctypes as C
+    import threading
+    segs = _segments()[4:10]
+    opened = [engine.open(seg) for seg in segs]
+    try:
+        variants = ["range-a", "range-b", "set-a", "set-b", "sum-w"]
+        specs = {v: _cache_specs(segs, v) for v in variants}
+        want = {}
+        for v in variants:
+            want[v] = []
+            for g, seg, sp in zip(opened, segs, specs[v]):
+                single = g.execute(sp)
+                H.assert_results_equal(single, oracle.execute(seg, sp))
+                want[v].append((int(single.aggregations[0].sum_i64), int(single.stats[0])))
+        n = len(segs)
+        handles = (C.c_void_p * n)(*[g.handle for g in opened])
+        errors = []
+
+        def worker(t):
+            try:
+                results = (_abi.pg_result * n)()
+                statuses = (C.c_int * n)()
+                order = variants[t % len(variants):] + variants[:t % len(variants)]
+                for it in range(60):
+                    v = order[(it * (t + 1)) % len(order)]
+                    queries = (C.POINTER(_abi.pg_query) * n)(*[C.pointer(sp.c) for sp in specs[v]])
+                    assert engine.execute_batch_raw(handles, queries, n, results, statuses) == _abi.PG_OK
+                    for i in range(n):
+                        assert statuses[i] == _abi.PG_OK, (t, it, v, i)
+                        got = (int(results[i].aggregations[0].sum_i64), int(results[i].stats.num_docs_scanned))
+                        engine.lib.pg_result_free(C.byref(results[i]))
+                        assert got == want[v][i], (t, it, v, i, got, want[v][i])
+            except BaseException as e:      # noqa: BLE001 -- reported on the main thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        assert not errors, errors[:2]
+    finally:
+        [g.close() for g in opened]
