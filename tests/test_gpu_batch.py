@@ -2,6 +2,8 @@
 core/operator/combine/BaseCombineOperator.java:85-142).  Items whose device work is one launch of the lane-private scan kernel share ONE
 launch (scan_private_batch_kernel: every item folds and publishes its own record); every other item runs as a pg_execute of its own on
 the library's worker threads.  Item by item the results must be what pg_execute returns -- and what the oracle says."""
+import os
+
 import numpy as np
 import pytest
 
@@ -344,7 +346,7 @@ def test_the_plan_cache_under_concurrent_batches(engine):
                 results = (_abi.pg_result * n)()
                 statuses = (C.c_int * n)()
                 order = variants[t % len(variants):] + variants[:t % len(variants)]
-                for it in range(60):
+                for it in range(int(os.environ.get("PINOT_STRESS_ITERS", "60"))):      # (a soak: PINOT_STRESS_ITERS=2000 PINOT_STRESS_THREADS=16)
                     v = order[(it * (t + 1)) % len(order)]
                     queries = (C.POINTER(_abi.pg_query) * n)(*[C.pointer(sp.c) for sp in specs[v]])
                     assert engine.execute_batch_raw(handles, queries, n, results, statuses) == _abi.PG_OK
@@ -356,7 +358,7 @@ def test_the_plan_cache_under_concurrent_batches(engine):
             except BaseException as e:      # noqa: BLE001 -- reported on the main thread
                 errors.append(e)
 
-        threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(int(os.environ.get("PINOT_STRESS_THREADS", "6")))]
         [t.start() for t in threads]
         [t.join() for t in threads]
         assert not errors, errors[:2]
