@@ -3868,6 +3868,11 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
     else if (L <= 3) fsm_tiles_perm_kernel<3><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
     else fsm_tiles_perm_kernel<4><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
   }
+  else if (S <= 8 && L <= 4 && max_inc <= 7 && perm_walk) {
+    if (L <= 2) fsm_tiles_perm8_kernel<2><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
+    else if (L <= 3) fsm_tiles_perm8_kernel<3><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
+    else fsm_tiles_perm8_kernel<4><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
+  }
   else if (S <= 2) PG_FSM_LAUNCH_L(2);
   else if (S <= 4) PG_FSM_LAUNCH_L(4);
   else if (S <= 8) PG_FSM_LAUNCH_L(8);

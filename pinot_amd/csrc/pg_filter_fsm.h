@@ -374,5 +374,91 @@ inline int64_t fsm_count_perm(const Fsm& f, const std::vector<const uint64_t*>& 
   return entries;
 }
 
+// fsm_tiles_perm8_kernel's arithmetic on the host: five to eight states -- a function is eight bytes (two words: states 0..3, 4..7), one
+// step is four byte permutes over the pair's {next, entries} words, the tree gathers 16-bit entries from four words (two candidates per
+// field, picked by bit 2 of the selector).  -1 when the machine does not fit (more than eight states, more than four inputs, a doc of
+// more than 7 entries).
+inline int64_t fsm_count_perm8(const Fsm& f, const std::vector<const uint64_t*>& leaf_words, int32_t num_docs) {
+  const int S = f.num_states, L = f.num_inputs;
+  if (S > 8 || L > 4) return -1;
+  for (uint8_t d : f.delta) if ((d >> 4) > 7) return -1;
+  auto delta = [&](uint32_t st, uint32_t in) -> uint32_t { return (st < (uint32_t)S && in < (1u << L)) ? f.delta[((size_t)st << L) | in] : 0u; };
+  struct Pair { uint32_t nlo, nhi, ilo, ihi; };
+  std::vector<Pair> pair_fn((size_t)1 << (2 * L));
+  for (uint32_t idx = 0; idx < (1u << (2 * L)); ++idx) {
+    uint32_t in0 = 0, in1 = 0;
+    for (int l = 0; l < L; ++l) { in0 |= ((idx >> (2 * l)) & 1u) << l; in1 |= ((idx >> (2 * l + 1)) & 1u) << l; }
+    Pair p{0u, 0u, 0u, 0u};
+    for (uint32_t st = 0; st < 8; ++st) {
+      const uint32_t t0 = delta(st, in0), t1 = delta(t0 & 15u, in1);
+      const uint32_t next = (t1 & 15u) & 7u, inc = (t0 >> 4) + (t1 >> 4);
+      if (st < 4) { p.nlo |= next << (8 * st); p.ilo |= inc << (8 * st); } else { p.nhi |= next << (8 * (st - 4)); p.ihi |= inc << (8 * (st - 4)); }
+    }
+    pair_fn[idx] = p;
+  }
+  const int64_t num_tiles = ((int64_t)num_docs + 2047) / 2048;
+  int64_t entries = 0;
+  uint32_t state = 0;
+  for (int64_t tile = 0; tile < num_tiles; ++tile) {
+    uint32_t Flo[64], Fhi[64], E[4][64];
+    for (int lane = 0; lane < 64; ++lane) {
+      const int64_t first = tile * 2048 + (int64_t)lane * 32;
+      const int docs = (int)std::max<int64_t>(0, std::min<int64_t>(32, (int64_t)num_docs - first));
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      for (int i = 0; i < L; ++i) w[i] = docs > 0 ? (uint32_t)(leaf_words[(size_t)i][(size_t)first >> 6] >> (first & 63)) : 0u;
+      uint32_t flo = 0x03020100u, fhi = 0x07060504u, elo = 0u, ehi = 0u;
+      if (docs == 32) {
+        for (int d = 0; d < 32; d += 2) {
+          uint32_t idx = 0;
+          for (int i = 0; i < L; ++i) idx |= ((w[i] >> d) & 3u) << (2 * i);
+          const Pair& t = pair_fn[idx];
+          elo += perm_b32(t.ihi, t.ilo, flo);
+          ehi += perm_b32(t.ihi, t.ilo, fhi);
+          const uint32_t nlo = perm_b32(t.nhi, t.nlo, flo), nhi = perm_b32(t.nhi, t.nlo, fhi);
+          flo = nlo; fhi = nhi;
+        }
+      } else {
+        uint32_t st[8], ent[8];
+        for (int c = 0; c < 8; ++c) { st[c] = (uint32_t)c; ent[c] = 0u; }
+        for (int d = 0; d < docs; ++d) {
+          uint32_t in = 0;
+          for (int i = 0; i < L; ++i) in |= ((w[i] >> d) & 1u) << i;
+          for (int c = 0; c < 8; ++c) { const uint32_t t = delta(st[c], in); ent[c] += t >> 4; st[c] = t & 7u; }
+        }
+        flo = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
+        fhi = st[4] | (st[5] << 8) | (st[6] << 16) | (st[7] << 24);
+        elo = ent[0] | (ent[1] << 8) | (ent[2] << 16) | (ent[3] << 24);
+        ehi = ent[4] | (ent[5] << 8) | (ent[6] << 16) | (ent[7] << 24);
+      }
+      Flo[lane] = flo; Fhi[lane] = fhi;
+      E[0][lane] = perm_b32(0u, elo, 0x0c010c00u); E[1][lane] = perm_b32(0u, elo, 0x0c030c02u);
+      E[2][lane] = perm_b32(0u, ehi, 0x0c010c00u); E[3][lane] = perm_b32(0u, ehi, 0x0c030c02u);
+    }
+    for (int j = 0; j < 6; ++j) {
+      uint32_t nFlo[64], nFhi[64], nE[4][64];
+      for (int lane = 0; lane < 64; ++lane) {
+        const int from = (lane + (1 << j)) & 63;
+        const uint32_t Glo = Flo[from], Ghi = Fhi[from];
+        const uint32_t H01 = E[0][from], H23 = E[1][from], H45 = E[2][from], H67 = E[3][from];
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t src = r < 2 ? Flo[lane] : Fhi[lane];
+          const uint32_t dup = perm_b32(src, src, (r & 1) ? 0x03030202u : 0x01010000u);
+          const uint32_t sel = ((dup & 0x03030303u) << 1) + 0x01000100u;
+          const uint32_t lo = perm_b32(H23, H01, sel), hi = perm_b32(H67, H45, sel);
+          const uint32_t m = (dup >> 2) & 0x01010101u;
+          const uint32_t mask = (m << 8) - m;
+          nE[r][lane] = E[r][lane] + ((hi & mask) | (lo & ~mask));
+        }
+        nFlo[lane] = perm_b32(Ghi, Glo, Flo[lane]);
+        nFhi[lane] = perm_b32(Ghi, Glo, Fhi[lane]);
+      }
+      for (int lane = 0; lane < 64; ++lane) { Flo[lane] = nFlo[lane]; Fhi[lane] = nFhi[lane]; for (int r = 0; r < 4; ++r) E[r][lane] = nE[r][lane]; }
+    }
+    entries += (E[state >> 1][0] >> (16 * (state & 1u))) & 0xFFFFu;
+    state = ((state < 4 ? Flo[0] : Fhi[0]) >> (8 * (state & 3u))) & 7u;
+  }
+  return entries;
+}
+
 }  // namespace fstats
 }  // namespace pg

@@ -241,6 +241,113 @@ __global__ __launch_bounds__(256) void fsm_tiles_perm_kernel(const FsmParams p) 
   }
 }
 
+// Five to eight states (an OR with three scan members, five-leaf ANDs): the same byte-function walk with a function in TWO registers
+// (states 0..3, 4..7).  A step is one 16-byte LDS read and four v_perm_b32 (selector bytes 0..7 pick from the pair of source words); the
+// tree gathers each 16-bit entry from four words -- two candidates per field, picked by bit 2 of the selector.  pg_filter_fsm.h
+// fsm_count_perm8 is the same arithmetic on the host.
+template <int LMAX>
+__global__ __launch_bounds__(256) void fsm_tiles_perm8_kernel(const FsmParams p) {
+  static_assert(LMAX <= 4, "two docs per lookup: an index of at most eight bits");
+  constexpr int kIndexBits = 2 * LMAX;
+  __shared__ uint8_t delta[8 << LMAX];                               // one doc: next | entries << 4
+  __shared__ uint4 pair_fn[1 << kIndexBits];                         // two docs with input idx: x, y = next state of s in byte s (s < 4, s >= 4); z, w = entries
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = p.num_inputs, S = p.num_states;
+  for (int i = threadIdx.x; i < (8 << LMAX); i += blockDim.x) {
+    const int st = i >> LMAX, in = i & ((1 << LMAX) - 1);
+    delta[i] = (st < S && in < (1 << L)) ? p.delta[(st << L) | in] : (uint8_t)0;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < (1 << kIndexBits); idx += blockDim.x) {
+    int in0 = 0, in1 = 0;
+    for (int l = 0; l < LMAX; ++l) { in0 |= ((idx >> (2 * l)) & 1) << l; in1 |= ((idx >> (2 * l + 1)) & 1) << l; }
+    uint4 t = make_uint4(0u, 0u, 0u, 0u);
+    for (int st = 0; st < 8; ++st) {
+      const uint32_t t0 = delta[(st << LMAX) | in0], t1 = delta[((t0 & 7u) << LMAX) | in1];
+      const uint32_t next = t1 & 7u, inc = (t0 >> 4) + (t1 >> 4);
+      if (st < 4) { t.x |= next << (8 * st); t.z |= inc << (8 * st); } else { t.y |= next << (8 * (st - 4)); t.w |= inc << (8 * (st - 4)); }
+    }
+    pair_fn[idx] = t;
+  }
+  __syncthreads();
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < p.num_tiles; tile += (long long)gridDim.x * 4) {
+    const long long first = tile * 2048 + lane * 32;
+    const long long rem = (long long)p.num_docs - first;
+    const int docs = rem >= 32 ? 32 : (rem <= 0 ? 0 : (int)rem);
+    uint32_t w[LMAX];
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) w[i] = i < L ? p.leaf[i][tile * 64 + lane] : 0u;
+    uint32_t Flo = 0x03020100u, Fhi = 0x07060504u, Elo = 0u, Ehi = 0u;
+    if (__builtin_amdgcn_ballot_w64(docs != 32) == 0ull) {
+      constexpr uint32_t kM = 0x33333333u;
+      const uint32_t lo_even = (w[0] & kM) | (LMAX > 1 ? (w[LMAX > 1 ? 1 : 0] & kM) << 2 : 0u);
+      const uint32_t lo_odd = ((w[0] >> 2) & kM) | (LMAX > 1 ? (w[LMAX > 1 ? 1 : 0] & ~kM) : 0u);
+      const uint32_t hi_even = LMAX > 2 ? ((w[LMAX > 2 ? 2 : 0] & kM) | (LMAX > 3 ? (w[LMAX > 3 ? 3 : 0] & kM) << 2 : 0u)) : 0u;
+      const uint32_t hi_odd = LMAX > 2 ? (((w[LMAX > 2 ? 2 : 0] >> 2) & kM) | (LMAX > 3 ? (w[LMAX > 3 ? 3 : 0] & ~kM) : 0u)) : 0u;
+#pragma unroll
+      for (int d = 0; d < 32; d += 2) {
+        const uint32_t lo = (d & 2) ? lo_odd : lo_even, hi = (d & 2) ? hi_odd : hi_even;
+        uint32_t idx = __builtin_amdgcn_ubfe(lo, d & ~3, 4);
+        if (LMAX > 2) idx |= __builtin_amdgcn_ubfe(hi, d & ~3, 4) << 4;
+        const uint4 t = pair_fn[idx];
+        Elo += __builtin_amdgcn_perm(t.w, t.z, Flo);                  // (a lane: at most 32 docs x 7: a byte holds -- the engine sends larger machines to the table walk)
+        Ehi += __builtin_amdgcn_perm(t.w, t.z, Fhi);
+        const uint32_t nlo = __builtin_amdgcn_perm(t.y, t.x, Flo), nhi = __builtin_amdgcn_perm(t.y, t.x, Fhi);
+        Flo = nlo; Fhi = nhi;
+      }
+    } else {
+      uint32_t st[8], ent[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { st[c] = (uint32_t)c; ent[c] = 0u; }
+      for (int d = 0; d < docs; ++d) {
+        uint32_t in = 0u;
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i) in |= __builtin_amdgcn_ubfe(w[i], d, 1) << i;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const uint32_t t = delta[(st[c] << LMAX) | in];
+          ent[c] += t >> 4;
+          st[c] = t & 7u;
+        }
+      }
+      Flo = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
+      Fhi = st[4] | (st[5] << 8) | (st[6] << 16) | (st[7] << 24);
+      Elo = ent[0] | (ent[1] << 8) | (ent[2] << 16) | (ent[3] << 24);
+      Ehi = ent[4] | (ent[5] << 8) | (ent[6] << 16) | (ent[7] << 24);
+    }
+    // entries as 16-bit fields: E[r] = chains 2r, 2r + 1
+    uint32_t E[4] = {__builtin_amdgcn_perm(0u, Elo, 0x0c010c00u), __builtin_amdgcn_perm(0u, Elo, 0x0c030c02u),
+                     __builtin_amdgcn_perm(0u, Ehi, 0x0c010c00u), __builtin_amdgcn_perm(0u, Ehi, 0x0c030c02u)};
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int from = ((lane + (1 << j)) & 63) << 2;
+      const uint32_t Glo = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)Flo), Ghi = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)Fhi);
+      uint32_t H[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H[r] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)E[r]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t src = r < 2 ? Flo : Fhi;
+        const uint32_t dup = __builtin_amdgcn_perm(src, src, (r & 1) ? 0x03030202u : 0x01010000u);      // [f0 f0 f1 f1], f in 0..7
+        const uint32_t sel = ((dup & 0x03030303u) << 1) + 0x01000100u;
+        const uint32_t lo = __builtin_amdgcn_perm(H[1], H[0], sel), hi = __builtin_amdgcn_perm(H[3], H[2], sel);
+        const uint32_t m = (dup >> 2) & 0x01010101u;
+        const uint32_t mask = (m << 8) - m;                            // 0xFF in the bytes whose selector names a state >= 4
+        E[r] += (hi & mask) | (lo & ~mask);
+      }
+      const uint32_t nlo = __builtin_amdgcn_perm(Ghi, Glo, Flo), nhi = __builtin_amdgcn_perm(Ghi, Glo, Fhi);
+      Flo = nlo; Fhi = nhi;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t e = (E[c >> 1] >> (16 * (c & 1))) & 0xFFFFu;
+        if (c < S) p.tables[tile * S + c] = (((c < 4 ? Flo : Fhi) >> (8 * (c & 3))) & 7u) | (e << 4);
+      }
+    }
+  }
+}
+
 // `count` tables of S entries each -> ceil(count / 1024) tables.  Every wavefront stages its 64 tables in LDS with coalesced loads (walking
 // them straight from memory was 64 DEPENDENT loads per lane: ~35 us of a 60 us tail), thread t < S walks them from entry state t, then the
 // first wavefront walks the (up to 16) wavefront tables.

@@ -201,7 +201,7 @@ def test_transducer_matches_the_iterator_replay_on_random_and_trees(driver):
     """Root ANDs of scan leaves, index-based leaves and ORs of such leaves over random columns: the transducer (both forms) against the
     replay of the reference's iterator objects and against the oracle.  Sizes around the lane / tile boundaries."""
     rng = np.random.default_rng(4)
-    shapes_seen, compiled, small = set(), 0, 0
+    shapes_seen, compiled, small, medium = set(), 0, 0, 0
     for n in (1, 31, 33, 2047, 2049, 4100, 20_011, 70_003):
         cols = [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "b", n, 7, with_inverted=True)[0],
                 H.random_dict_column(rng, "c", n, 300, with_inverted=True)[0], H.random_dict_column(rng, "d", n, 3)[0],
@@ -256,4 +256,10 @@ def test_transducer_matches_the_iterator_replay_on_random_and_trees(driver):
                 assert perm == want, (n, states, inputs, perm, want)
             else:
                 assert perm == -1
-    assert compiled > 200 and len(shapes_seen) > 8 and small > 60, (compiled, shapes_seen, small)
+            perm8, _, _ = fsm(driver, seg, spec, 3)          # the eight-state form takes the small machines too
+            if states <= 8 and inputs <= 4:
+                medium += 1 if states > 4 else 0
+                assert perm8 == want, (n, states, inputs, perm8, want)
+            else:
+                assert perm8 == -1
+    assert compiled > 200 and len(shapes_seen) > 8 and small > 60 and medium > 20, (compiled, shapes_seen, small, medium)

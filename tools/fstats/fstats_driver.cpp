@@ -44,5 +44,6 @@ extern "C" int64_t fstats_fsm(const pg_query* q, int32_t num_docs, const uint64_
   std::vector<const uint64_t*> words;
   for (int p : f.input_predicate) words.push_back(leaf_words[p]);
   if (mode == 2) return pg::fstats::fsm_count_perm(f, words, num_docs);
+  if (mode == 3) return pg::fstats::fsm_count_perm8(f, words, num_docs);      // (fsm_tiles_perm8_kernel: up to eight states)
   return mode == 0 ? pg::fstats::fsm_count_sequential(f, words, num_docs) : pg::fstats::fsm_count_tiled(f, words, num_docs);
 }
