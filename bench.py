@@ -26,6 +26,8 @@ Prints ONE JSON line on rank 0.  At N=1 the line also carries
   roofline.frac           on ALL kernels of the query (HIP events around every launch); frac_dominant_kernel: the scan kernel alone
   cold_launch_ms          one query after >= 1.2 s without a launch, no settle launches (best of three)
   summary                 LAST key: {variant id: [frac on all kernels, all_kernels_ms, bit exact]} for the headline and every variant
+The printed line stays under 8 KB (tools/bench_line.py): the `variants` array goes to gpurun_out/bench_variants.json and the uncut
+result to gpurun_out/bench_full.json, both named in the line.
 `--single-process --gpus N`: ONE process drives N devices (segment s on device s mod N, one pg_execute_batch per step) -- the
 deployment shape of a Pinot server; the driver's torchrun launch stays one process per GPU.
 """
@@ -385,14 +387,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # LAST key of the line: one compact entry per configuration -- [frac of 8 TB/s on all kernels of the query, all_kernels_ms, bit exact vs oracle]
-        # (the variants array is long; whoever keeps only the tail of the line still sees BASELINE.json configs[0]..[4])
-        summary = {"headline(configs[1],[3])": [round(result["roofline"]["frac"], 4), round(result["roofline"]["all_kernels_ms"], 4),
-                                                 (result.get("parity") or {}).get("bit_exact_vs_oracle")]}
-        for v in result.get("variants") or []:
-            summary[v["id"]] = [None if v.get("frac") is None else round(v["frac"], 4), None if v.get("all_kernels_ms") is None else round(v["all_kernels_ms"], 4), v.get("bit_exact_vs_oracle")]
-        result["summary"] = summary
-        print(json.dumps(result))
+        # ONE line under 8 KB (tools/bench_line.py): the variants array and the uncut result go to side files under gpurun_out/, the
+        # line keeps the contract's keys + config / roofline / cpu_baseline / parity / overlapped, and `summary` as its LAST key:
+        # {configuration: [frac of 8 TB/s on all kernels of the query, all_kernels_ms, bit exact vs oracle]} for BASELINE.json configs[0]..[4]
+        from tools import bench_line
+        out_dir = os.environ.get("PINOT_BENCH_OUT", os.path.join(ROOT, "gpurun_out"))
+        vpath, fpath = bench_line.write_side_files(result, out_dir)
+        rel = lambda p: None if p is None else os.path.relpath(p, ROOT)
+        print(json.dumps(bench_line.compact(result, rel(vpath) if result.get("variants") else None, rel(fpath))), flush=True)
 
 
 if __name__ == "__main__":
