@@ -65,7 +65,10 @@ def compact(result, variants_file=None, full_file=None, limit=LIMIT_BYTES):
         line["variants_file"] = variants_file
     if full_file:
         line["full_result_file"] = full_file
+    exact = line.get("result")                  # the merged SUM / COUNT stay as computed
     line = _round(_strip_notes(line))
+    if exact is not None:
+        line["result"] = exact
     cfg = line.get("config")
     if isinstance(cfg, dict) and isinstance(cfg.get("workload"), str):
         cfg["workload"] = _clip(cfg["workload"], 400)
