@@ -299,6 +299,12 @@ const char* pg_version(void);
 pg_status pg_device_info(int32_t device_id, char* arch_name, int32_t arch_name_len, int32_t* num_cus,
                          uint64_t* hbm_bytes);
 
+/* Device ids the library accepts (pg_config.device_id, pg_segment_desc.device_id): 0 .. *out_devices - 1.  Normally the number of HIP
+ * devices.  With PINOT_GPU_ALIAS_DEVICES=N in the environment at pg_init (N above the physical count) N ids are accepted and id d runs
+ * on HIP device d mod *out_physical, each id with its own batch contexts / streams / placement: a one-GPU box then executes the
+ * multi-device paths of pg_execute_batch (what a server's `gpu.devices` list drives). */
+pg_status pg_device_count(int32_t* out_devices, int32_t* out_physical);
+
 /* Diagnostic: the box's empirical HBM read ceiling -- a pure 16 B/lane read-reduce kernel over `bytes` of device memory, best of
  * `launches` timed launches, in GB/s (BASELINE.md section 2 asks for it next to the 8 TB/s vendor figure).  Not on the query path. */
 pg_status pg_measure_stream_read(int32_t device_id, uint64_t bytes, int32_t launches, double* out_gbps);

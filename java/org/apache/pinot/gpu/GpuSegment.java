@@ -65,6 +65,7 @@ final class GpuSegment implements Closeable {
   private int _pins;                                     // native calls in flight on the handle (guarded by `this`)
   private volatile long _lastUsedNanos = System.nanoTime();
   private volatile long _deviceBytes;
+  private volatile GpuSegmentCache.Account _account;
 
   /** The native handle and its one-time close. */
   static final class HandleBox {
@@ -105,6 +106,15 @@ final class GpuSegment implements Closeable {
 
   long deviceBytes() {
     return _deviceBytes;
+  }
+
+  /** This copy's share of the cache's per-device byte count (GpuSegmentCache.Account: given back once). */
+  GpuSegmentCache.Account account() {
+    return _account;
+  }
+
+  void setAccount(GpuSegmentCache.Account account) {
+    _account = account;
   }
 
   long lastUsedNanos() {

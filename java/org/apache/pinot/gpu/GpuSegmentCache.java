@@ -30,6 +30,7 @@ import java.util.List;
 import java.util.Map;
 import java.util.Optional;
 import java.util.WeakHashMap;
+import java.util.concurrent.atomic.AtomicBoolean;
 import java.util.concurrent.atomic.AtomicLongArray;
 import org.apache.pinot.segment.spi.ImmutableSegment;
 import org.apache.pinot.segment.spi.IndexSegment;
@@ -104,19 +105,36 @@ final class GpuSegmentCache {
     }
   }
 
-  private int slotOf(int device) {
-    for (int i = 0; i < _devices.length; i++) {
-      if (_devices[i] == device) {
-        return i;
+  /**
+   * One open device copy's share of {@link #_residentBytes}: given back exactly once, whoever gets there first -- release(), eviction
+   * under the budget, the re-open of an evicted segment, or the Cleaner.  (Round 4 subtracted an evicted segment's bytes a second time
+   * when a query re-opened it, and never gave back the bytes of a garbage-collected segment: the counter drifted, makeRoom() stopped
+   * evicting and leastLoadedSlot() was skewed.)  Holds no reference to the segment, so the Cleaner's action may capture it.
+   */
+  static final class Account {
+    private final AtomicLongArray _resident;
+    private final int _slot;
+    private final long _bytes;
+    private final AtomicBoolean _returned = new AtomicBoolean();
+
+    Account(AtomicLongArray resident, int slot, long bytes) {
+      _resident = resident;
+      _slot = slot;
+      _bytes = Math.max(0, bytes);
+      _resident.addAndGet(slot, _bytes);
+    }
+
+    void giveBack() {
+      if (_returned.compareAndSet(false, true)) {
+        _resident.addAndGet(_slot, -_bytes);
       }
     }
-    return 0;
   }
 
-  private void forget(GpuSegment segment) {
-    long bytes = segment.deviceBytes();
-    if (bytes > 0) {
-      _residentBytes.addAndGet(slotOf(segment.device()), -bytes);
+  private static void forget(GpuSegment segment) {
+    Account account = segment.account();
+    if (account != null) {
+      account.giveBack();
     }
   }
 
@@ -171,10 +189,15 @@ final class GpuSegmentCache {
     try {
       makeRoom(slot, estimatedBytes(indexSegment));
       GpuSegment segment = GpuSegment.open(indexSegment, device);
-      _residentBytes.addAndGet(slot, segment.deviceBytes());
+      Account account = new Account(_residentBytes, slot, segment.deviceBytes());
+      segment.setAccount(account);
       GpuSegment.HandleBox box = segment.box();
-      // the action must not reference `segment` or `indexSegment` (it would keep them reachable): the box holds the handle and nothing else
-      CLEANER.register(indexSegment, box::close);
+      // the action must not reference `segment` or `indexSegment` (it would keep them reachable): the box holds the handle and the
+      // account a slot number and a byte count, nothing else
+      CLEANER.register(indexSegment, () -> {
+        box.close();
+        account.giveBack();
+      });
       LOGGER.info("Segment {} resident on device {}: {} bytes of HBM ({} bytes on that device now)", indexSegment.getSegmentName(), device,
           segment.deviceBytes(), _residentBytes.get(slot));
       return Optional.of(segment);

@@ -96,6 +96,7 @@ ABI_SYMBOLS = [
     ("pg_last_error", C.c_char_p, []),
     ("pg_version", C.c_char_p, []),
     ("pg_device_info", C.c_int, [C.c_int32, C.c_char_p, C.c_int32, _P(C.c_int32), _P(C.c_uint64)]),
+    ("pg_device_count", C.c_int, [_P(C.c_int32), _P(C.c_int32)]),
     ("pg_segment_open", C.c_int, [_P(pg_segment_desc), _P(C.c_void_p)]),
     ("pg_segment_close", C.c_int, [C.c_void_p]),
     ("pg_segment_num_docs", C.c_int, [C.c_void_p, _P(C.c_int32)]),

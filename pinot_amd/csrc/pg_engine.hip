@@ -75,6 +75,7 @@ struct Engine {
   int fold_one_counter = 1;  // PINOT_GPU_FOLD_ONE_COUNTER=0: grids of at most 64 workgroups also arrive on eight shard counters + the top one
   bool poll_result = true;   // PINOT_GPU_POLL_RESULT=0: pg_execute always waits with hipStreamSynchronize instead of spinning on the pinned record's sequence number
   bool lane_skip = true;     // PINOT_GPU_LANE_SKIP=0: the aggregating kernels load a tile's value bytes for every lane, matches or not
+  bool batch_blocks_per_cu_forced = false;
   int batch_blocks_per_cu = 4;    // PINOT_GPU_BATCH_BLOCKS_PER_CU: workgroups per CU a batch launch is cut into (all items together)
   bool scan_raw = true;      // PINOT_GPU_SCAN_RAW=0: raw INT scans stay in scan_private_kernel / scan_private_typed_kernel (four waves per SIMD)
   bool scan_simple = true;   // PINOT_GPU_SCAN_SIMPLE=0: one-leaf / one-column queries stay in scan_private_kernel (half the waves per SIMD)
@@ -98,9 +99,15 @@ struct Engine {
   bool hist_guard = false;   // PINOT_GPU_HIST_GUARD=1: start every column in the guarded tier (tests)
   int hist_bits = 0;         // PINOT_GPU_HIST_BITS: 8 / 16 force narrower counters than the cardinality needs (tests of the guard protocol)
   int group_waves = 0;       // PINOT_GPU_GROUP_WAVES: cap on wavefronts per group-by workgroup (default 16)
+  int physical_devices = 1;  // hipGetDeviceCount at pg_init
+  int logical_devices = 1;   // PINOT_GPU_ALIAS_DEVICES=N (> physical): device ids 0..N-1 are accepted, id d runs on HIP device d mod physical.  Every
+                             // per-device structure (batch contexts, deferred launches, placement) is keyed by the LOGICAL id, so a one-GPU box
+                             // executes the multi-device paths of pg_execute_batch with N contexts on one chip.
   std::mutex mu;
 };
 Engine g_engine;
+// the HIP device behind a device id of the C ABI (pg_segment_desc.device_id, pg_config.device_id)
+inline int phys_device(int logical) { return g_engine.physical_devices > 0 ? logical % g_engine.physical_devices : logical; }
 
 inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
 inline uint32_t le16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
@@ -510,7 +517,7 @@ hipError_t h2d_copy(void* dst, const void* src, size_t bytes, int device) {
   for (int t = 0; t < threads; ++t) {
     workers.emplace_back([&, t] {
       StageSlot& sl = g_stage.slots[t];
-      hipError_t e = hipSetDevice(device);
+      hipError_t e = hipSetDevice(phys_device(device));
       int b = 0;
       while (e == hipSuccess) {
         const size_t c = next.fetch_add(1);
@@ -728,7 +735,7 @@ pg_status acquire_plane(pg_segment* seg, int column, bool* ready) {
       if (best < 0) return PG_OK;
       drop_plane_locked(g_planes.resident[(size_t)best].first, g_planes.resident[(size_t)best].second);
     }
-    HIP_TRY(hipSetDevice(seg->device));
+    HIP_TRY(hipSetDevice(phys_device(seg->device)));
     if (!seg->plane_stream) HIP_TRY(hipStreamCreateWithFlags(&seg->plane_stream, hipStreamNonBlocking));
     if (!col.plane_event) HIP_TRY(hipEventCreateWithFlags(&col.plane_event, hipEventDisableTiming));
     uint8_t* plane = nullptr;
@@ -775,7 +782,7 @@ pg_status acquire_plane(pg_segment* seg, int column, bool* ready) {
       if (best < 0) return PG_OK;          // nothing can go: this column is served without a plane
       drop_plane_locked(g_planes.resident[(size_t)best].first, g_planes.resident[(size_t)best].second);
     }
-    HIP_TRY(hipSetDevice(seg->device));
+    HIP_TRY(hipSetDevice(phys_device(seg->device)));
     if (!seg->plane_stream) HIP_TRY(hipStreamCreateWithFlags(&seg->plane_stream, hipStreamNonBlocking));
     if (!col.plane_event) HIP_TRY(hipEventCreateWithFlags(&col.plane_event, hipEventDisableTiming));
     uint8_t* plane = nullptr;
@@ -1579,8 +1586,11 @@ pg_status pg_init(const pg_config* config) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count == 0) return fail(PG_ERR_DEVICE, "no HIP device available: %s", hipGetErrorString(e));
+  g_engine.physical_devices = count;
+  const char* ald = getenv("PINOT_GPU_ALIAS_DEVICES");
+  g_engine.logical_devices = (ald && atoi(ald) > count) ? std::min(atoi(ald), 64) : count;
   int dev = config ? config->device_id : 0;
-  if (dev < 0 || dev >= count) return fail(PG_ERR_INVALID_ARGUMENT, "device %d out of range (have %d)", dev, count);
+  if (dev < 0 || dev >= g_engine.logical_devices) return fail(PG_ERR_INVALID_ARGUMENT, "device %d out of range (have %d)", dev, g_engine.logical_devices);
   g_engine.device = dev;
   g_engine.blocks_per_cu = config ? config->blocks_per_cu : 0;
   g_engine.flags = config ? config->flags : 0;
@@ -1601,6 +1611,7 @@ pg_status pg_init(const pg_config* config) {
   const char* lsk = getenv("PINOT_GPU_LANE_SKIP");
   g_engine.lane_skip = !(lsk && lsk[0] == '0');
   const char* bbc = getenv("PINOT_GPU_BATCH_BLOCKS_PER_CU");
+  g_engine.batch_blocks_per_cu_forced = bbc != nullptr;
   g_engine.batch_blocks_per_cu = (bbc && atoi(bbc) > 0) ? atoi(bbc) : 4;      // measured on 64 x 10 M rows: 2 / 4 / 8 / 16 / 32 / 64 -> 0.77 / 0.55 / 0.57 / 0.59 / 0.61 / 0.65 ms
   const char* ssp = getenv("PINOT_GPU_SCAN_SPARSE");
   g_engine.scan_sparse = !(ssp && ssp[0] == '0');
@@ -1669,7 +1680,7 @@ pg_status pg_init(const pg_config* config) {
     if (pb) budget = strtoull(pb, nullptr, 10);
     if (budget == 0) {
       size_t free_bytes = 0, total_bytes = 0;
-      (void)hipSetDevice(dev);
+      (void)hipSetDevice(phys_device(dev));
       if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) budget = total_bytes / 4; else budget = 64ull << 30;
     }
     std::lock_guard<std::mutex> lk(g_planes.mu);
@@ -1693,18 +1704,25 @@ pg_status pg_shutdown(void) {
 
 pg_status pg_device_info(int32_t device_id, char* arch_name, int32_t arch_name_len, int32_t* num_cus, uint64_t* hbm_bytes) {
   hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  HIP_TRY(hipGetDeviceProperties(&prop, phys_device(device_id)));
   if (arch_name && arch_name_len > 0) { strncpy(arch_name, prop.gcnArchName, (size_t)arch_name_len - 1); arch_name[arch_name_len - 1] = 0; }
   if (num_cus) *num_cus = prop.multiProcessorCount;
   if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
   return PG_OK;
 }
 
+pg_status pg_device_count(int32_t* out_devices, int32_t* out_physical) {
+  if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");
+  if (out_devices) *out_devices = g_engine.logical_devices;
+  if (out_physical) *out_physical = g_engine.physical_devices;
+  return PG_OK;
+}
+
 pg_status pg_measure_stream_read(int32_t device_id, uint64_t bytes, int32_t launches, double* out_gbps) {
   if (!out_gbps || bytes < (1u << 20) || launches < 1) return fail(PG_ERR_INVALID_ARGUMENT, "bad stream probe arguments");
-  HIP_TRY(hipSetDevice(device_id));
+  HIP_TRY(hipSetDevice(phys_device(device_id)));
   hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  HIP_TRY(hipGetDeviceProperties(&prop, phys_device(device_id)));
   uint8_t* buf = nullptr;
   unsigned long long* sink = nullptr;
   HIP_TRY(hipMalloc((void**)&buf, bytes));
@@ -1741,16 +1759,17 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
   if (desc->num_docs < 0 || desc->num_columns < 0 || (desc->num_columns > 0 && !desc->columns)) return fail(PG_ERR_INVALID_ARGUMENT, "bad segment descriptor");
   pg_segment* seg = new pg_segment();
   seg->device = desc->device_id >= 0 ? desc->device_id : g_engine.device;
+  if (seg->device >= g_engine.logical_devices) { const int d = seg->device; delete seg; return fail(PG_ERR_INVALID_ARGUMENT, "pg_segment_desc.device_id %d out of range (have %d)", d, g_engine.logical_devices); }
   seg->num_docs = desc->num_docs;
   seg->num_tiles = (int)(((long long)desc->num_docs + kMaxTileDocs - 1) / kMaxTileDocs);   // 2048-doc tiles (buffer padding unit)
   seg->name = desc->name ? desc->name : "";
   pg_status st = PG_OK;
   auto bail = [&](pg_status s) { free_segment(seg); return s; };
   {
-    hipError_t e = hipSetDevice(seg->device);
+    hipError_t e = hipSetDevice(phys_device(seg->device));
     if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "hipSetDevice(%d): %s", seg->device, hipGetErrorString(e)));
     hipDeviceProp_t prop;
-    e = hipGetDeviceProperties(&prop, seg->device);
+    e = hipGetDeviceProperties(&prop, phys_device(seg->device));
     if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e)));
     seg->num_cus = prop.multiProcessorCount;
     // Test switch: every grid of this segment is sized as if the device had this many CUs.  With 1, a 100 000-doc segment is ~50 tiles for
@@ -1786,7 +1805,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       // zero the padding past the file bytes so tail tiles decode deterministic (masked) values
       size_t tail = col.fwd_alloc_bytes - (size_t)cd.fwd_size;
       e = hipMemset(col.d_fwd_alloc + cd.fwd_size, 0, tail);
-      if (e == hipSuccess && cd.fwd_size) e = h2d_copy(col.d_fwd_alloc, fwd, (size_t)cd.fwd_size, seg->device);
+      if (e == hipSuccess && cd.fwd_size) e = h2d_copy(col.d_fwd_alloc, fwd, (size_t)cd.fwd_size, phys_device(seg->device));
       if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "column %s: H2D copy: %s", col.name.c_str(), hipGetErrorString(e)));
       // Dictionary values -> host order (IntDictionary / LongDictionary / FloatDictionary / DoubleDictionary: C big-endian
       // fixed-width values, ascending; FixedByteValueReaderWriter.getInt/getLong/getFloat/getDouble)
@@ -1865,7 +1884,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       hipError_t e = hipMalloc((void**)&col.d_fwd_alloc, col.fwd_alloc_bytes);
       if (e != hipSuccess) return bail(fail(PG_ERR_OUT_OF_MEMORY, "column %s: hipMalloc(%zu): %s", col.name.c_str(), col.fwd_alloc_bytes, hipGetErrorString(e)));
       e = hipMemset(col.d_fwd_alloc, 0, col.fwd_alloc_bytes);
-      if (e == hipSuccess) e = h2d_copy(col.d_fwd_alloc + lead, fwd, (size_t)cd.fwd_size, seg->device);
+      if (e == hipSuccess) e = h2d_copy(col.d_fwd_alloc + lead, fwd, (size_t)cd.fwd_size, phys_device(seg->device));
       if (e != hipSuccess) return bail(fail(PG_ERR_DEVICE, "column %s: H2D copy: %s", col.name.c_str(), hipGetErrorString(e)));
       col.d_fwd = col.d_fwd_alloc + lead + raw_start;
       col.bits = 32;
@@ -1890,7 +1909,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       }
       col.posting_first[(size_t)cd.cardinality] = (int64_t)col.h_dir.size();
       hipError_t e = hipMalloc((void**)&col.d_inv, (size_t)cd.inv_size + 64);
-      if (e == hipSuccess) e = h2d_copy(col.d_inv, inv, (size_t)cd.inv_size, seg->device);
+      if (e == hipSuccess) e = h2d_copy(col.d_inv, inv, (size_t)cd.inv_size, phys_device(seg->device));
       if (e == hipSuccess && !col.h_dir.empty()) {
         e = hipMalloc((void**)&col.d_dir, col.h_dir.size() * sizeof(DevContainer));
         if (e == hipSuccess) e = hipMemcpy(col.d_dir, col.h_dir.data(), col.h_dir.size() * sizeof(DevContainer), hipMemcpyHostToDevice);
@@ -2018,7 +2037,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
 
 pg_status pg_segment_close(pg_segment* segment) {
   if (!segment) return fail(PG_ERR_INVALID_ARGUMENT, "null segment");
-  (void)hipSetDevice(segment->device);
+  (void)hipSetDevice(phys_device(segment->device));
   free_segment(segment);
   return PG_OK;
 }
@@ -2309,7 +2328,7 @@ static bool query_key(const pg_query* q, std::string* key) {
   key->append(reinterpret_cast<const char*>(q->filter), sizeof(pg_filter_node) * (size_t)q->num_filter_nodes);
   for (int i = 0; i < q->num_predicates; ++i) {
     const pg_predicate& pr = q->predicates[i];
-    if (pr.num_set_words < 0 || (pr.num_set_words > 0 && !pr.set_words)) return false;
+    if (pr.num_set_words < 0 || (pr.num_set_words > 0 && !pr.set_words)) { key->clear(); return false; }      // (an empty key = not cacheable)
     const int64_t fields[8] = {pr.kind, pr.column, pr.eval, pr.exclusive, pr.lo, pr.hi, pr.num_set_words, pr.reserved};
     key->append(reinterpret_cast<const char*>(fields), sizeof(fields));
     key->append(reinterpret_cast<const char*>(pr.set_words), sizeof(uint32_t) * (size_t)pr.num_set_words);
@@ -2350,7 +2369,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const pg_status eligible = check_query_plan(seg, &shape, 0);
     if (eligible != PG_OK) return eligible;
   }
-  HIP_TRY(hipSetDevice(seg->device));
+  HIP_TRY(hipSetDevice(phys_device(seg->device)));
   ExecCtx* ctx = nullptr;
   pg_status st = acquire_ctx(seg, &ctx);
   if (st != PG_OK) return st;
@@ -2792,7 +2811,9 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
     // HIP events (PG_CFG_TIME_KERNELS): [ev_first, ev_last] brackets the query's device work, [ev[1], ev[2]] the scan kernel.  Each
     // record is a packet of its own on the queue, so a query that runs nothing but the scan kernel records just the two.
-    const bool post_work = !g_engine.direct_result || count_leap2 || want_bitmap;      // (the chain kernel / copy commands behind the scan kernel)
+    // (the chain kernel / copy commands behind the scan kernel; a kernel that leaves leaf bitmaps behind for the transducer pass must have
+    //  RETIRED before that pass reads them -- its plain stores are only ordered by the end of the kernel, not by the pinned record's seq)
+    const bool post_work = !g_engine.direct_result || count_leap2 || want_bitmap || sp.leaf_out_enabled;
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
@@ -3803,12 +3824,16 @@ struct FsmScratch {
 // (under seg->fsm_mu) the scratch, grown when needed, and where every input's bitmap goes
 static pg_status prepare_fsm_side(pg_segment* seg, const fstats::Fsm& fsm, FsmSide* side) {
   const FsmScratch lay(seg, fsm);
-  HIP_TRY(hipSetDevice(seg->device));
+  // fsm_finish_kernel keeps one table per chunk in LDS (chunks * S * 4 bytes): 16 states near 2^31 docs pass 64 KB -- such a machine is not counted here
+  if ((size_t)lay.chunks * (size_t)fsm.num_states * 4 > (60u << 10)) return fail(PG_ERR_UNSUPPORTED, "transducer pass: %lld chunks x %d states exceed the finish kernel's LDS", lay.chunks, fsm.num_states);
+  HIP_TRY(hipSetDevice(phys_device(seg->device)));
   if (seg->fsm_scratch_bytes < lay.total) {
     if (seg->d_fsm_scratch) (void)hipFree(seg->d_fsm_scratch);
+    seg->device_bytes -= seg->fsm_scratch_bytes;               // (the scratch is part of what pg_segment_device_bytes reports: the HBM budget of the caller sees it)
     seg->d_fsm_scratch = nullptr; seg->fsm_scratch_bytes = 0;
     HIP_TRY(hipMalloc((void**)&seg->d_fsm_scratch, lay.total));
     seg->fsm_scratch_bytes = lay.total;
+    seg->device_bytes += lay.total;
   }
   *side = FsmSide();
   side->fsm = &fsm;
@@ -3817,7 +3842,7 @@ static pg_status prepare_fsm_side(pg_segment* seg, const fstats::Fsm& fsm, FsmSi
 }
 
 static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, const fstats::Fsm& fsm, const FsmSide& side, pg_result* out) {
-  HIP_TRY(hipSetDevice(seg->device));
+  HIP_TRY(hipSetDevice(phys_device(seg->device)));
   const FsmScratch lay(seg, fsm);
   const long long tiles = lay.tiles, chunks = lay.chunks;
   const int L = fsm.num_inputs, S = fsm.num_states;
@@ -3913,9 +3938,10 @@ static pg_status execute_one(pg_segment* segment, const pg_query* query, pg_resu
     int scan_leaves = 0;
     if (fstats::choose_plan(query, &scan_leaves) == fstats::Plan::kReplay && fstats::compile_fsm(query, &fsm)) {
       fsm_lock = std::unique_lock<std::mutex>(segment->fsm_mu);
-      const pg_status pst = prepare_fsm_side(segment, fsm, &side);
-      if (pst != PG_OK) return pst;
-      fsm_ready = true;
+      // numEntriesScannedInFilter is a statistic: a pass that cannot get its scratch (or fails later) leaves the query's answer standing
+      // with filter_entries_exact = 0 (the host replay below still applies at its sizes) -- it never fails the query
+      fsm_ready = prepare_fsm_side(segment, fsm, &side) == PG_OK;
+      if (!fsm_ready) { (void)hipGetLastError(); fsm_lock.unlock(); }
     }
   }
   pg_status st = null_handling ? execute_null_handling(segment, query, out_result, nullptr, 0, nullptr)
@@ -3925,7 +3951,11 @@ static pg_status execute_one(pg_segment* segment, const pg_query* query, pg_resu
   if (st == PG_OK && !null_handling && !out_result->filter_entries_exact) {
     if (fsm_ready) {
       const auto t0 = std::chrono::steady_clock::now();
-      st = device_fsm_filter_stats(segment, query, fsm, side, out_result);
+      if (device_fsm_filter_stats(segment, query, fsm, side, out_result) != PG_OK) {
+        (void)hipGetLastError();
+        out_result->filter_entries_exact = 0;
+        if ((int64_t)segment->num_docs <= g_engine.exact_stats_docs) st = replay_filter_stats(segment, query, out_result);
+      }
       // (timed runs: the pass is charged to the query on the host clock: it has no event bracket of its own, and a clock that includes
       //  its copies overstates rather than hides it)
       if (g_engine.flags & PG_CFG_TIME_KERNELS) out_result->device_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -4191,7 +4221,7 @@ struct DeferredLaunch {
 pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_segment* const* segments) {
   const int device = L->device;
   const std::vector<int>& items = L->items;
-  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipSetDevice(phys_device(device)));
   BatchCtx* b = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_batch_mu);
@@ -4206,7 +4236,7 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
   for (int i : items) { total_tiles += ((long long)segments[i]->num_docs + 2047) / 2048; L->docs += (long long)segments[i]->num_docs; }
   // (the lean kernels hold five -- raw: four -- waves per SIMD: a workgroup per CU more than the general body's four)
   const int lean_bpc = L->lean_kind != 0 ? std::max(1, waves_scan_lean_batch(L->lean_kind) / (kBlockThreads / 64)) : 0;
-  const bool bpc_forced = getenv("PINOT_GPU_BATCH_BLOCKS_PER_CU") != nullptr;      // (bench sweeps re-initialise the engine with it)
+  const bool bpc_forced = g_engine.batch_blocks_per_cu_forced;      // (read once per pg_init: bench sweeps re-initialise the engine with it)
   const long long budget = (long long)segments[items[0]]->num_cus * ((L->lean_kind != 0 && !bpc_forced) ? lean_bpc : g_engine.batch_blocks_per_cu);
   std::vector<int>& blocks = L->blocks;
   blocks.assign((size_t)n, 0);
@@ -4258,7 +4288,7 @@ pg_status finish_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_res
   const int n = L->n;
   const unsigned long long seq = L->seq;
   static const bool trace = getenv("PINOT_GPU_BATCH_TRACE") != nullptr;
-  HIP_TRY(hipSetDevice(L->device));
+  HIP_TRY(hipSetDevice(phys_device(L->device)));
   if (g_engine.poll_result && !L->timed) {
     // every item publishes its own pinned record: their sequence numbers are the completion signal (as in pg_execute)
     int k = 0;
@@ -4425,7 +4455,7 @@ static pg_status gather_impl(pg_segment* seg, int32_t column, const int32_t* doc
   const ColumnDev& col = seg->cols[(size_t)column];
   if (out_dict && col.encoding != PG_FWD_FIXED_BIT_DICT) return fail(PG_ERR_INVALID_ARGUMENT, "column %s is not dictionary encoded", col.name.c_str());
   if (out_int && col.stored_type != PG_TYPE_INT) return fail(PG_ERR_INVALID_ARGUMENT, "column %s is not INT: use pg_read_long_values / pg_read_double_values", col.name.c_str());
-  HIP_TRY(hipSetDevice(seg->device));
+  HIP_TRY(hipSetDevice(phys_device(seg->device)));
   ExecCtx* ctx = nullptr;
   pg_status st = acquire_ctx(seg, &ctx);
   if (st != PG_OK) return st;

@@ -65,6 +65,9 @@ int waves_group_private();
 // scan_hist_kernel<8 | 16 | 32, guarded>: lane-private scan whose SUM column is counted per dictId in an LDS histogram (pg_scan_hist.h)
 void launch_scan_hist(int counter_bits, bool guarded, int blocks, size_t lds, hipStream_t stream, const ScanParams& p);
 int waves_scan_hist(int counter_bits, bool guarded);
+// scan_hist_batch_kernel<8 | 16 | 32>: pg_execute_batch's shared launch for items of that shape (plain counters; `lds` = the largest item's histogram)
+void launch_scan_hist_batch(int counter_bits, int total_blocks, size_t lds, hipStream_t stream, const ScanParams* items, const uint32_t* block_first, int num_items);
+int waves_scan_hist_batch(int counter_bits);
 
 // scan_private_typed_kernel: lane-private scan for raw / 8-byte aggregated columns (pg_scan_typed.h)
 void launch_scan_private_typed(int agg_cols, int blocks, hipStream_t stream, const ScanParams& p);      // instantiated for 1, 2 and kMaxAggCols slots

@@ -152,14 +152,15 @@ __device__ __noinline__ void hist_sweep(const uint32_t* lane_words, int b, uint3
   }
 }
 
-template <int CW, bool kGuard>
-__global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const ScanParams p) {
+// `block_index` of `num_blocks`: the workgroup's place among those that work on this parameter block -- the whole grid (scan_hist_kernel),
+// or one item's share of a batch launch (scan_hist_batch_kernel).  P: ScanParams, or its constant-address-space form in device memory.
+template <int CW, bool kGuard, typename P>
+__device__ __forceinline__ void scan_hist_body(const P& p, uint32_t block_index, uint32_t num_blocks, uint32_t* hist) {
   static_assert(!(kGuard && CW == 32), "32-bit counters need no guard");
-  extern __shared__ __attribute__((aligned(16))) uint32_t hist[];      // the only LDS object: counter addresses need no base add
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
-  const long long total_waves = (long long)gridDim.x * waves_per_block;
+  const long long total_waves = (long long)num_blocks * waves_per_block;
   const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
   const int C = p.hist_bins;
   constexpr int kPerWord = 32 / CW;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const Scan
   uint32_t alarm = 0;
   // the one aggregated column (the engine sends other shapes to scan_private_kernel): summed through the histogram, MIN / MAX on
   // its dictIds in registers
-  const DevAggCol& ac = p.agg_cols[0];
+  const auto& ac = p.agg_cols[0];
 
   // one inclusive-range leaf on the summed column itself (C2a), plain counters, no MIN / MAX: one decode per tile instead of two
   const bool fused = !kGuard && p.num_nodes == 1 && p.nodes[0].kind == kLeafDictRange && p.nodes[0].exclusive == 0 && p.nodes[0].fwd == ac.fwd &&
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const Scan
   uint32_t entries = 0u;
   const bool listed = p.tile_list != nullptr;              // index-driven filters: only the tiles index_and_kernel listed hold a match
   const long long tile_limit = listed ? (long long)*p.tile_count : num_tiles;
-  for (long long tile_it = (long long)blockIdx.x * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
+  for (long long tile_it = (long long)block_index * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
     const long long tile = listed ? (long long)p.tile_list[tile_it] : tile_it;
     if constexpr (!kGuard) {
       if (fused && (tile + 1) * 2048 <= (long long)p.num_docs) {
@@ -269,7 +270,33 @@ __global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const Scan
   BlockPartial* red = reinterpret_cast<BlockPartial*>(hist);
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
-  publish_block_partial(p, red, waves_per_block, reinterpret_cast<uint32_t*>(red + waves_per_block));      // (the engine sizes the LDS for it)
+  publish_block_partial(p, red, waves_per_block, reinterpret_cast<uint32_t*>(red + waves_per_block), block_index, num_blocks);      // (the engine sizes the LDS for it)
+}
+
+template <int CW, bool kGuard>
+__global__ __launch_bounds__(kHistBlockThreads) void scan_hist_kernel(const ScanParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t hist[];      // the only LDS object: counter addresses need no base add
+  scan_hist_body<CW, kGuard>(p, blockIdx.x, gridDim.x, hist);
+}
+
+// pg_execute_batch's shared launch for items of scan_hist_kernel's shape (SUM over a dictionary without structure -- the normal case of
+// a real Pinot dictionary -- on each of a server's many small segments: BaseCombineOperator.java:85-142).  Workgroups
+// [block_first[i], block_first[i + 1]) work on items[i]; each keeps the item's whole histogram in its LDS (the launch's dynamic LDS is
+// the largest item's), multiplies by the item's dictionary at the end and arrives on the item's counters: every item folds and
+// publishes its own pinned record.  Plain counters only: an item whose column is in the guarded tier runs scan_hist_kernel<CW, true>
+// on its own, and an item whose checksum shows a wrapped counter is answered again by pg_execute (the engine checks every record).
+template <int CW>
+__global__ __launch_bounds__(kHistBlockThreads) void scan_hist_batch_kernel(const BatchParams bp) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+  int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (bp.block_first[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const uint32_t first = bp.block_first[lo];
+  typedef const __attribute__((address_space(4))) ScanParams ConstantScanParams;      // (scalar loads of the item's fields: see scan_private_batch_kernel)
+  const ConstantScanParams& item = *(ConstantScanParams*)(bp.items + lo);
+  scan_hist_body<CW, false>(item, blockIdx.x - first, bp.block_first[lo + 1] - first, hist);
 }
 
 }  // namespace pg

@@ -32,6 +32,12 @@ class Engine:
         _abi.check(self.lib, self.lib.pg_device_info(self.device_id, name, 64, C.byref(cus), C.byref(hbm)))
         return name.value.decode(), int(cus.value), int(hbm.value)
 
+    def device_count(self):
+        """pg_device_count: (device ids accepted, HIP devices behind them) -- they differ under PINOT_GPU_ALIAS_DEVICES."""
+        n, phys = C.c_int32(), C.c_int32()
+        _abi.check(self.lib, self.lib.pg_device_count(C.byref(n), C.byref(phys)))
+        return int(n.value), int(phys.value)
+
     def execute_batch(self, gsegs, specs):
         """pg_execute_batch: specs[i] over gsegs[i] (the same query lowered per segment).  Returns [(status, Result | None)]."""
         n = len(gsegs)

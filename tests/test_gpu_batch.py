@@ -195,23 +195,36 @@ def test_concurrent_batches_do_not_serialise(engine):
 
 def test_batch_spanning_two_devices(engine):
     """Segment s on device s mod N inside ONE process (the deployment shape: a Pinot server is one JVM): one pg_execute_batch
-    whose items live on two devices -- one launch per device, both in flight before either is waited for."""
-    import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip("one GPU visible")
+    whose items live on two devices -- one launch per device, both in flight before either is waited for.
+    On a one-GPU box the two device ids alias the one chip (PINOT_GPU_ALIAS_DEVICES=2: own batch contexts, streams and launches per id),
+    so the per-device grouping, enqueue_deferred / finish_deferred per device and the placement all execute here too."""
+    aliased = engine.device_count()[0] < 2
+    if aliased:
+        engine.reinit(PINOT_GPU_ALIAS_DEVICES=2)
+    assert engine.device_count()[0] >= 2
     segs = _segments()
     for s, seg in enumerate(segs):
         seg.desc.device_id = s % 2
-    opened = [engine.open(seg) for seg in segs]
+    opened = []
     try:
+        opened = [engine.open(seg) for seg in segs]
         for shapes in (["sum"], ["sum", "group", "inverted", "minmax", "and2", "nofilter"]):
             specs = [_spec(seg, s, shapes[s % len(shapes)]) for s, seg in enumerate(segs)]
             for rep in range(2):
                 for s, (status, res) in enumerate(engine.execute_batch(opened, specs)):
                     assert status == _abi.PG_OK
                     H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
+        # a device id past the accepted ones is refused at open, not mapped somewhere
+        bad = _segments()[0]
+        bad.desc.device_id = engine.device_count()[0]
+        with pytest.raises(_abi.PinotGpuError):
+            engine.open(bad)
     finally:
         [g.close() for g in opened]
+        for seg in segs:
+            seg.desc.device_id = -1
+        if aliased:
+            engine.reinit(PINOT_GPU_ALIAS_DEVICES=None)
 
 
 def _cache_specs(segs, variant):
