@@ -283,7 +283,7 @@ struct GroupParams {
   int32_t dense_ok;                // 1: every aggregation is in the 32-bit value domain (the dense 16-step path applies)
   int32_t wide_keys;               // 1: num_groups > 2^24, so dictIds / multipliers may not fit the full-rate 24-bit multiply
   int32_t lds_log_replicas;        // group_private_kernel<true>: log2 of the copies of the LDS table a workgroup keeps (lane l uses copy l % R; pg_kernels.h)
-  int32_t reserved_gp;
+  int32_t zero_identity;           // 1: the global table is all-zero before the launch and MIN / MAX reach it as keys whose identity is 0 (group_lds_batch_kernel)
   DevGroupKey group_keys[kMaxGroupCols];
   DevGroupAgg group_aggs[kMaxGroupAggs];
   unsigned long long* table_count; // [num_groups]

@@ -80,6 +80,7 @@ struct Engine {
   bool scan_raw = true;      // PINOT_GPU_SCAN_RAW=0: raw INT scans stay in scan_private_kernel / scan_private_typed_kernel (four waves per SIMD)
   bool scan_simple = true;   // PINOT_GPU_SCAN_SIMPLE=0: one-leaf / one-column queries stay in scan_private_kernel (half the waves per SIMD)
   bool scan_sparse = true;   // PINOT_GPU_SCAN_SPARSE=0: index-led aggregations scan their listed tiles in scan_private_kernel (one tile per wave and iteration)
+  bool batch_hist = true;    // PINOT_GPU_BATCH_HIST=0: items of scan_hist_kernel's shape run their own launch on a worker thread
   bool batch_launch = true;  // PINOT_GPU_BATCH_LAUNCH=0: pg_execute_batch runs every item as a pg_execute of its own on the worker threads (no shared launch)
   bool leap2 = true;         // PINOT_GPU_LEAP2=0: a leap-frogging `a AND b` is not counted on the device (host replay / upper bound instead)
   int sparse_lanes = 32;     // PINOT_GPU_SPARSE_LANES: tiles in which at most this many of the 64 lanes hold a match are aggregated match by match (0 = never)
@@ -1621,6 +1622,8 @@ pg_status pg_init(const pg_config* config) {
   g_engine.scan_raw = !(srw && srw[0] == '0');
   const char* bla = getenv("PINOT_GPU_BATCH_LAUNCH");
   g_engine.batch_launch = !(bla && bla[0] == '0');
+  const char* bhi = getenv("PINOT_GPU_BATCH_HIST");
+  g_engine.batch_hist = !(bhi && bhi[0] == '0');
   const char* lp2 = getenv("PINOT_GPU_LEAP2");
   g_engine.leap2 = !(lp2 && lp2[0] == '0');
   const char* spl = getenv("PINOT_GPU_SPARSE_LANES");
@@ -2290,6 +2293,7 @@ static void finish_filter_stats(const Lowered& lw, const pg_segment* seg, int64_
 // phase, no entry counter, no histogram -- is not launched by execute_impl but handed back as its kernel parameters plus the
 // conversion of the folded record into a pg_result; the batch puts many of them into one launch (scan_private_batch_kernel).
 static const pg_status kDeferred = static_cast<pg_status>(100);      // (internal: never leaves the library)
+static const pg_status kRunAlone = static_cast<pg_status>(101);      // (internal: a batch item whose shared launch could not answer it -- pg_execute_batch runs it by itself)
 // A query lowered for the shared launch of pg_execute_batch: the kernel's parameter block (the launch fills in where this item's records
 // go), the workgroups it would get on its own, and the conversion of its folded record into the reference's holder types.  Immutable
 // once built: the segment's plan_cache hands the same item to later batches.
@@ -2307,6 +2311,8 @@ struct LoweredItem {
   bool one_slot = true;
   std::function<void(const BlockPartial&, pg_result*)> convert;
   std::vector<int> plane_columns;                 // value planes sp reads: held (PlaneHold) by every batch that launches this item
+  size_t hist_lds = 0;                            // lean_kind 3..5: the item's histogram (the launch's dynamic LDS is the largest item's)
+  int hist_cw = 0, hist_col = -1;                 //   counter width; the summed column (a wrapped counter moves it to the guarded tier)
   // the cache's side (empty key: not cacheable)
   std::string key;                                // query_key of the query
   uint64_t engine_epoch = 0, plane_epoch = 0;
@@ -2789,12 +2795,16 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       // (the shared launch is for the many small segments of a server: a segment that fills the chip on its own -- more tiles than a few
       //  rounds of resident waves -- runs the kernel the planner picked for it, concurrently with the others, on a worker thread's stream:
       //  eight 1 B-row items 4.72 ms in one launch, 4.45 ms as eight overlapping launches)
-      if ((use_private || use_raw) && !use_hist && !use_narrow && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
-          ((long long)seg->num_docs + 2047) / 2048 <= kBatchMaxTiles &&
+      // kinds of shared launch (ScanParams.lean_kind; pg_execute_batch groups a batch's deferred items by device and kind, one launch each):
+      //   0 scan_private_batch_kernel (the general body)   1 / 2 scan_lean_batch_kernel (scan_simple / scan_raw shape)
+      //   3 / 4 / 5 scan_hist_batch_kernel<8 | 16 | 32> (SUM through the LDS histogram: dictionaries without structure, plain counters)
+      const bool hist_item = use_hist && !hist_guarded && g_engine.batch_hist;
+      if (((use_private && !use_hist) || use_raw || hist_item) && !use_narrow && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
+          lw.side == nullptr && ((long long)seg->num_docs + 2047) / 2048 <= kBatchMaxTiles &&
           (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf)) {
         // items of scan_simple_kernel's / scan_raw_kernel's shape share a launch of their own kind (scan_lean_batch_kernel), the rest the general one
         static const bool lean_batch = !(getenv("PINOT_GPU_LEAN_BATCH") && getenv("PINOT_GPU_LEAN_BATCH")[0] == '0');
-        sp.lean_kind = use_simple ? 1 : (use_raw ? 2 : 0);
+        sp.lean_kind = hist_item ? (hist_cw == 8 ? 3 : (hist_cw == 16 ? 4 : 5)) : use_simple ? 1 : (use_raw ? 2 : 0);
         if (!lean_batch && sp.lean_kind == 1) sp.lean_kind = 0;      // (a raw-shaped item has no general form when its column is aggregated: it stays lean)
         if (sp.lean_kind == 2 && !lean_batch && use_private) sp.lean_kind = 0;
         auto item = std::make_shared<LoweredItem>();
@@ -2803,6 +2813,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         item->one_slot = pl.num_agg_cols <= 1;
         item->convert = convert;
         item->plane_columns = planes.columns;
+        if (hist_item) { item->hist_lds = hist_lds; item->hist_cw = hist_cw; item->hist_col = hist_col; }
         defer->item = std::move(item);
         defer->cacheable = !lw.plane_pending;
         defer->planes.reset(new PlaneHold(std::move(planes)));
@@ -2866,6 +2877,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       // Skewed dictIds: the histogram's sum is not used.  From now on the column runs in the next tier -- guarded counters, which count
       // hot dictIds exactly through guard-bit claims, then the value plane / gather path -- and this query is answered again.
       __atomic_store_n(&seg->cols[(size_t)hist_col].hist_tier, hist_wrapped ? 1 : 2, __ATOMIC_RELAXED);
+      seg->plane_epoch.fetch_add(1, std::memory_order_acq_rel);      // (what the plan cache holds for this segment was lowered for the plain tier)
       release_ctx(seg, ctx);
       guard.ctx = nullptr;
       return execute_impl(seg, q, out, d_out_bitmap_request, host_bitmap, host_bitmap_words, out_cardinality, allow_metadata_plan, nullptr, side);
@@ -4212,6 +4224,7 @@ struct DeferredLaunch {
   int device = -1, n = 0, lean_kind = 0;       // lean_kind: ScanParams.lean_kind of every item (0: scan_private_batch_kernel, 1 / 2: scan_lean_batch_kernel)
   std::vector<int> items, blocks;
   long long total_blocks = 0, docs = 0;
+  size_t lds = 0;
   unsigned long long seq = 0;
   bool timed = false, launched = false;
   std::chrono::steady_clock::time_point t0, t1;
@@ -4235,9 +4248,16 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
   long long total_tiles = 0;
   for (int i : items) { total_tiles += ((long long)segments[i]->num_docs + 2047) / 2048; L->docs += (long long)segments[i]->num_docs; }
   // (the lean kernels hold five -- raw: four -- waves per SIMD: a workgroup per CU more than the general body's four)
-  const int lean_bpc = L->lean_kind != 0 ? std::max(1, waves_scan_lean_batch(L->lean_kind) / (kBlockThreads / 64)) : 0;
+  const bool hist_kind = L->lean_kind >= 3 && L->lean_kind <= 5;
+  const int hist_cw = L->lean_kind == 3 ? 8 : (L->lean_kind == 4 ? 16 : 32);
+  const int wpb = hist_kind ? kHistBlockThreads / 64 : kBlockThreads / 64;      // wavefronts (= tiles per round) of a workgroup
+  size_t launch_lds = 0;
+  for (int i : items) launch_lds = std::max(launch_lds, defs[(size_t)i].item->hist_lds);
+  L->lds = launch_lds;
+  const int lean_bpc = hist_kind ? std::max(1, std::min(waves_scan_hist_batch(hist_cw) / wpb, (int)((160 * 1024 - 2048) / (launch_lds + 256))))
+                                 : (L->lean_kind != 0 ? std::max(1, waves_scan_lean_batch(L->lean_kind) / wpb) : 0);
   const bool bpc_forced = g_engine.batch_blocks_per_cu_forced;      // (read once per pg_init: bench sweeps re-initialise the engine with it)
-  const long long budget = (long long)segments[items[0]]->num_cus * ((L->lean_kind != 0 && !bpc_forced) ? lean_bpc : g_engine.batch_blocks_per_cu);
+  const long long budget = (long long)segments[items[0]]->num_cus * ((L->lean_kind != 0 && (!bpc_forced || hist_kind)) ? lean_bpc : g_engine.batch_blocks_per_cu);
   std::vector<int>& blocks = L->blocks;
   blocks.assign((size_t)n, 0);
   size_t partials = 0;
@@ -4247,7 +4267,7 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
     const LoweredItem& d = *defs[(size_t)items[(size_t)k]].item;
     const long long tiles = ((long long)segments[items[(size_t)k]]->num_docs + 2047) / 2048;
     const long long share = total_tiles > 0 ? (tiles * budget + total_tiles - 1) / total_tiles : 1;
-    blocks[(size_t)k] = (int)std::max<long long>(1, std::min<long long>({(long long)d.blocks, share, (tiles + 3) / 4}));
+    blocks[(size_t)k] = (int)std::max<long long>(1, std::min<long long>({(long long)d.blocks, share, (tiles + wpb - 1) / wpb}));
     partials += (size_t)blocks[(size_t)k] + (size_t)kFoldExtraRecords;
     total_blocks += blocks[(size_t)k];
     one_slot = one_slot && d.one_slot;
@@ -4274,7 +4294,8 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
   L->t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipMemcpyAsync(b->d_blob, b->h_blob, b->items_offset + sizeof(ScanParams) * (size_t)n, hipMemcpyHostToDevice, b->stream));
   if (L->timed) HIP_TRY(hipEventRecord(b->ev[0], b->stream));
-  if (L->lean_kind != 0) launch_scan_lean_batch(L->lean_kind, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
+  if (hist_kind) launch_scan_hist_batch(hist_cw, (int)total_blocks, launch_lds, b->stream, b->d_items, b->d_first, n);
+  else if (L->lean_kind != 0) launch_scan_lean_batch(L->lean_kind, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
   else launch_scan_private_batch(one_slot, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
   HIP_TRY(hipGetLastError());
   if (L->timed) HIP_TRY(hipEventRecord(b->ev[1], b->stream));
@@ -4306,6 +4327,13 @@ pg_status finish_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_res
     const int i = L->items[(size_t)k];
     if (b->h_records[k].seq != seq) { statuses[i] = fail(PG_ERR_INTERNAL, "batch item %d did not publish its record", i); continue; }
     if (b->h_records[k].partial.flags & kPartialStale) { statuses[i] = fail(PG_ERR_INTERNAL, "batch item %d: the fold read a record that was not written by this launch", i); continue; }
+    const LoweredItem& it = *defs[(size_t)i].item;
+    if (it.hist_cw != 0 && it.hist_cw < 32 && (unsigned long long)b->h_records[k].partial.sum[1] != b->h_records[k].partial.count) {
+      // a plain narrow counter wrapped (skewed dictIds): the histogram's sum is not used -- pg_execute answers this item again and moves
+      // the column to the guarded tier, where its items run launches of their own (scan_hist_kernel's header: exact or not used)
+      statuses[i] = kRunAlone;
+      continue;
+    }
     defs[(size_t)i].item->convert(b->h_records[k].partial, &results[i]);
     // ONE launch serves all items of the device: each item is charged its share of the workgroups, so that summing device_ms over a
     // batch's results gives the launch's time once (pg_result.device_ms of a batch item is an apportioned figure, not a measurement of its own)
@@ -4381,6 +4409,12 @@ pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* q
     const pg_status st = finish_deferred(l.get(), defs, results, statuses);
     if (st != PG_OK) fail_items(l.get(), st);
     else for (int i : l->items) if (statuses[i] != PG_OK) errors[(size_t)i] = g_error;
+  }
+  for (int i = 0; i < count; ++i) {
+    if (statuses[i] != kRunAlone) continue;
+    defs[(size_t)i].planes.reset();
+    statuses[i] = execute_one(segments[i], queries[i], &results[i], nullptr);
+    if (statuses[i] != PG_OK) errors[(size_t)i] = g_error;
   }
   // pg_last_error of the caller: the first failed item's message
   for (int i = 0; i < count; ++i) if (statuses[i] != PG_OK) { g_error = "batch item " + std::to_string(i) + ": " + errors[(size_t)i]; break; }

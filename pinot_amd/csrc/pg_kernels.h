@@ -2092,8 +2092,9 @@ __host__ __device__ __forceinline__ uint32_t lds_group_table_bytes(const GroupPa
 
 // One 2048-doc tile.  kMasked: only the docs whose bit is set in the lane's mask `m` reach the table (a filter's result, and /
 // or the docs that exist in the last, partial tile); otherwise every doc of the tile does, with no exec masking around the atomics.
-template <bool kLds, bool kMasked, bool kWide = false, bool kHash = false>
-__device__ __forceinline__ void group_private_tile(const GroupParams& gp, long long tile, int lane, uint32_t m, unsigned long long* t_cnt, long long* t_acc, uint8_t* lds) {
+// GP: GroupParams, or its constant-address-space form in device memory (an item of group_lds_batch_kernel)
+template <bool kLds, bool kMasked, bool kWide = false, bool kHash = false, typename GP = GroupParams>
+__device__ __forceinline__ void group_private_tile(const GP& gp, long long tile, int lane, uint32_t m, unsigned long long* t_cnt, long long* t_acc, uint8_t* lds) {
   const int G = gp.num_groups;
   const int logR = kLds ? gp.lds_log_replicas : 0;                       // (see lds_group_table_bytes)
   const uint32_t cls = (uint32_t)lane & ((1u << logR) - 1u);
@@ -2117,7 +2118,7 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
           for (int j = 0; j < 16; ++j) if (!kMasked || ((m >> (16 * h + j)) & 1u)) k[j] = (unsigned long long)hash_slot_of(keys_lvl, mask_lvl, k[j]);
           ++lvl;
         }
-        const DevGroupKey& key = gp.group_keys[c];
+        const auto& key = gp.group_keys[c];
         const int b = key.bits;
         const unsigned long long mult = gp.key_mult[c];
         const uint32_t* words = reinterpret_cast<const uint32_t*>(key.fwd + tile * (256ll * b)) + lane * b;
@@ -2140,7 +2141,7 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
     }
   } else {
   for (int c = 0; c < gp.num_group_cols; ++c) {
-    const DevGroupKey& key = gp.group_keys[c];
+    const auto& key = gp.group_keys[c];
     const int b = key.bits;
     const uint32_t mult = (uint32_t)key.mult;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(key.fwd + tile * (256ll * b)) + lane * b;
@@ -2167,7 +2168,7 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
     }
   }
   for (int a = 0; a < gp.num_group_aggs; ++a) {
-    const DevGroupAgg& ga = gp.group_aggs[a];
+    const auto& ga = gp.group_aggs[a];
     long long* acc = kLds ? reinterpret_cast<long long*>(lds + lds_off) + cls : t_acc + (long long)a * G;      // kLds: this lane's copy of a SUM sub-table,
     int32_t* acc32 = reinterpret_cast<int32_t*>(lds + lds_off) + cls;                                          //       or of a MIN / MAX one
     if constexpr (kLds) lds_off += lds_subtable_bytes(G, logR, ga.kind == kGroupSum ? 8 : 4);
@@ -2222,15 +2223,14 @@ __device__ __forceinline__ void group_private_tile(const GroupParams& gp, long l
   }
 }
 
-// (the forms without an LDS table are launched with kBlockThreads threads: at that bound the register allocation has the whole file --
-//  at the 1024-thread bound of the LDS-table form they spilled ~40 registers inside the tile loop)
-template <bool kLdsTable, bool kWide = false, bool kHash = false>
-__global__ __launch_bounds__(kLdsTable ? kGroupBlockThreads : kBlockThreads) void group_private_kernel(const GroupParams gp) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// `block_index` of `num_blocks`: the workgroup's place among those that work on this parameter block (the whole grid, or one item's share
+// of group_lds_batch_kernel's launch).  gp.zero_identity: MIN / MAX reach the global table as keys whose identity is 0 (see the flush).
+template <bool kLdsTable, bool kWide, bool kHash, typename GP>
+__device__ __forceinline__ void group_private_body(const GP& gp, uint32_t block_index, uint32_t num_blocks, uint8_t* smem) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
-  const long long total_waves = (long long)gridDim.x * waves_per_block;
+  const long long total_waves = (long long)num_blocks * waves_per_block;
   const int G = gp.num_groups;
   const int NA = gp.num_group_aggs;
   unsigned long long* t_cnt;
@@ -2257,7 +2257,7 @@ __global__ __launch_bounds__(kLdsTable ? kGroupBlockThreads : kBlockThreads) voi
     t_acc = gp.table_acc;
   }
   const long long num_tiles = ((long long)gp.scan.num_docs + 2047) / 2048;
-  const long long wave = (long long)blockIdx.x * waves_per_block + wave_in_block;
+  const long long wave = (long long)block_index * waves_per_block + wave_in_block;
   uint32_t entries = 0u;
   const bool listed = gp.scan.tile_list != nullptr;        // index-driven filters: only the tiles index_and_kernel listed hold a match
   const long long tile_limit = listed ? (long long)*gp.scan.tile_count : num_tiles;
@@ -2306,7 +2306,10 @@ __global__ __launch_bounds__(kLdsTable ? kGroupBlockThreads : kBlockThreads) voi
           int32_t v = t[0];
           for (int r = 1; r < R; ++r) v = kind == kGroupMin ? (t[r] < v ? t[r] : v) : (t[r] > v ? t[r] : v);
           if (c != 0ull) {
-            if (kind == kGroupMin) __hip_atomic_fetch_min(slot, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // zero_identity (the shared batch launch: its tables are only ever memset): MIN as 2^31 - v, MAX as v + 2^31 + 1, both in
+            // [1, 2^32] under fetch_max -- a slot nobody touched stays 0 whatever its kind (group_zero_identity_decode on the host)
+            if (gp.zero_identity != 0) __hip_atomic_fetch_max(slot, kind == kGroupMin ? 0x80000000ll - (long long)v : (long long)v + 0x80000001ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (kind == kGroupMin) __hip_atomic_fetch_min(slot, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else __hip_atomic_fetch_max(slot, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
@@ -2314,6 +2317,37 @@ __global__ __launch_bounds__(kLdsTable ? kGroupBlockThreads : kBlockThreads) voi
       }
     }
   }
+}
+
+// (the forms without an LDS table are launched with kBlockThreads threads: at that bound the register allocation has the whole file --
+//  at the 1024-thread bound of the LDS-table form they spilled ~40 registers inside the tile loop)
+template <bool kLdsTable, bool kWide = false, bool kHash = false>
+__global__ __launch_bounds__(kLdsTable ? kGroupBlockThreads : kBlockThreads) void group_private_kernel(const GroupParams gp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  group_private_body<kLdsTable, kWide, kHash>(gp, blockIdx.x, gridDim.x, smem);
+}
+
+// Many group-bys, one launch (pg_execute_batch): the LDS-table form over items -- workgroups [block_first[i], block_first[i + 1]) work
+// on items[i], each item with its own key / aggregation columns, filter program and slice of ONE global table allocation (count[G] |
+// acc[NA][G], all-zero before the launch: zero_identity).  The dynamic LDS is the largest item's table.  What GroupByCombineOperator
+// (core/operator/combine/GroupByCombineOperator.java:102-165) gets from a task per segment, for the many small segments of a server.
+struct GroupBatchParams {
+  const GroupParams* items;          // device memory
+  const uint32_t* block_first;       // [num_items + 1] device memory
+  int32_t num_items;
+  int32_t reserved;
+};
+__global__ __launch_bounds__(kGroupBlockThreads) void group_lds_batch_kernel(const GroupBatchParams bp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (bp.block_first[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const uint32_t first = bp.block_first[lo];
+  typedef const __attribute__((address_space(4))) GroupParams ConstantGroupParams;      // (scalar loads of the item's fields: see scan_private_batch_kernel)
+  const ConstantGroupParams& item = *(ConstantGroupParams*)(bp.items + lo);
+  group_private_body<true, false, false>(item, blockIdx.x - first, bp.block_first[lo + 1] - first, smem);
 }
 
 static __global__ void init_group_table_kernel(GroupParams gp) {

@@ -61,6 +61,9 @@ int waves_scan_group();
 // group_private_kernel<kLdsTable>: lane-private group-by (no filter)
 void launch_group_private(bool lds_table, int blocks, int threads, size_t lds, hipStream_t stream, const GroupParams& gp);
 int waves_group_private();
+// group_lds_batch_kernel: pg_execute_batch's shared launch for group-bys of the LDS-table form (items in device memory, one table slice each, `lds` = the largest item's table)
+void launch_group_lds_batch(int total_blocks, int threads, size_t lds, hipStream_t stream, const GroupParams* items, const uint32_t* block_first, int num_items);
+int waves_group_lds_batch();
 
 // scan_hist_kernel<8 | 16 | 32, guarded>: lane-private scan whose SUM column is counted per dictId in an LDS histogram (pg_scan_hist.h)
 void launch_scan_hist(int counter_bits, bool guarded, int blocks, size_t lds, hipStream_t stream, const ScanParams& p);

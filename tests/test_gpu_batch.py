@@ -377,3 +377,63 @@ def test_the_plan_cache_under_concurrent_batches(engine):
         assert not errors, errors[:2]
     finally:
         [g.close() for g in opened]
+
+
+# ---- items of scan_hist_kernel's shape share a launch too (round 5): SUM over dictionaries without structure ----
+def _hist_segments(cards, n_of=lambda s: 150_000 + 37_001 * s, skew=None):
+    from test_gpu_hist import irregular_dictionary
+    segs = []
+    for s, card in enumerate(cards):
+        n = n_of(s)
+        rng = np.random.default_rng(4000 + s)
+        ids = rng.integers(0, card, n).astype(np.int32)
+        if skew is not None and s in skew:
+            ids[: n * 3 // 4] = skew[s]                  # one hot dictId: an 8- / 16-bit counter of a workgroup wraps
+        v = S.Column.from_dict_ids("v", irregular_dictionary(card, 5000 + s), ids)
+        f = S.Column.from_dict_ids("f", np.arange(1000, dtype=np.int32) * 3 - 7, rng.integers(0, 1000, n).astype(np.int32))
+        segs.append(S.SegmentData("hb%d" % s, n, [v, f]))
+    return segs
+
+
+def test_irregular_dictionary_sums_share_one_launch(engine):
+    """`SUM(v) WHERE f < x` over segments whose dictionaries have no structure: every item is scan_hist_kernel-shaped (the normal case of a
+    real Pinot dictionary).  Items of one counter width share a launch (scan_hist_batch_kernel<8 | 16 | 32>), each with its own dictionary,
+    histogram size and record; the answers are the oracle's and pg_execute's, and the library reports the body that ran."""
+    cards = [100000, 90000, 155648, 100000, 50000, 77824, 1000, 38912, 3, 100000, 120000, 60000]
+    segs = _hist_segments(cards)
+    opened = [engine.open(seg) for seg in segs]
+    try:
+        for variant in range(3):
+            if variant == 0:
+                specs = [Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100 + 10 * s))) for s in range(len(segs))]
+            elif variant == 1:
+                specs = [Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0), (Q.MIN, 0), (Q.MAX, 0), (Q.AVG, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 5, 600))) for s in range(len(segs))]
+            else:       # the predicate on the summed column itself (C2a: the fused decode), and no filter at all
+                specs = [Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(0, cards[s] // 3, max(cards[s] // 3 + 1, 2 * cards[s] // 3)))) if s % 2 else
+                         Q.QuerySpec([(Q.SUM, 0)]) for s in range(len(segs))]
+            for rep in range(2):            # (the second call takes the items from the plan cache)
+                got = engine.execute_batch(opened, specs)
+                for s, (status, res) in enumerate(got):
+                    assert status == _abi.PG_OK, s
+                    H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
+                    assert res.dominant_kernel == "scan_hist_kernel", (s, res.dominant_kernel)
+                    single = opened[s].execute(specs[s])
+                    assert res.stats == single.stats and [a.sum_i64 for a in res.aggregations] == [a.sum_i64 for a in single.aggregations]
+    finally:
+        [g.close() for g in opened]
+
+
+def test_a_wrapped_counter_in_the_shared_launch_is_answered_again(engine):
+    """Skewed dictIds: a plain 8- or 16-bit counter of the shared launch wraps, the item's checksum says so, and the library answers that
+    item through pg_execute (guarded tier from then on) -- the other items of the launch are untouched; the next batch is exact as well."""
+    cards = [100000, 100000, 50000, 100000]
+    segs = _hist_segments(cards, n_of=lambda s: 400_000, skew={1: 777, 2: 5})
+    opened = [engine.open(seg) for seg in segs]
+    try:
+        specs = [Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1)]) for _ in segs]
+        for rep in range(3):
+            for s, (status, res) in enumerate(engine.execute_batch(opened, specs)):
+                assert status == _abi.PG_OK, (rep, s)
+                H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
+    finally:
+        [g.close() for g in opened]

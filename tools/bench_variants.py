@@ -175,7 +175,8 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
     # ---- the small-segment regime: 64 segments of 10 M rows (BASELINE.json configs[0]'s size), one query over all of them ----
     # (a) pg_execute_batch: one launch, every segment folds its own result; (b) the way BaseCombineOperator would drive pg_execute: 16
     # host threads, each with the next segment, every pg_execute on a stream of its own; (c) one pg_execute after the other.
-    if want("C1x64"):
+    c1x64_ids = ("C1x64-count-range", "C1x64-dict-sum", "C1x64-dict-sum-irregular", "C1x64-group-by")
+    if any(want(x) for x in c1x64_ids):
         import ctypes as C
         import threading
         n1, nseg = 10_000_000, 64
@@ -185,13 +186,22 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
             raw = S.Column.raw("raw_i32", S.synthetic_dict_ids(4200 + s, 0, n1, 1_000_000))
             fcol = S.Column.synthetic_uniform("f", n1, np.arange(1000, dtype=np.int32), seed=7000 + s)
             vcol = S.Column.synthetic_uniform("v", n1, (np.arange(100000, dtype=np.int64) * 7 + 3 + s).astype(np.int32), seed=8000 + s)
-            segs.append(S.SegmentData("c1_%d" % s, n1, [raw, fcol, vcol]))
+            # (columns 3, 4: the same sum through a dictionary WITHOUT structure -- the normal case of a real Pinot dictionary -- and a 1000-value key)
+            wcol = S.Column.synthetic_uniform("w", n1, v_dictionary("irregular", seed=9000 + s), seed=8500 + s)
+            kcol = S.Column.synthetic_uniform("k", n1, np.arange(1000, dtype=np.int32), seed=9500 + s)
+            segs.append(S.SegmentData("c1_%d" % s, n1, [raw, fcol, vcol, wcol, kcol]))
         gen_s = time.time() - t0
         opened = [engine.open(sd) for sd in segs]
         try:
             shapes = [("C1x64-count-range", "SELECT COUNT(*) WHERE raw_i32 BETWEEN 1 AND 10", lambda sd: Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.raw_range(0, 1, 10))), lambda sd: B(sd.columns[0])),
-                      ("C1x64-dict-sum", "SELECT SUM(v) WHERE f < 100", lambda sd: Q.QuerySpec([(Q.SUM, 2)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), lambda sd: B(sd.columns[1]) + B(sd.columns[2]))]
+                      ("C1x64-dict-sum", "SELECT SUM(v) WHERE f < 100", lambda sd: Q.QuerySpec([(Q.SUM, 2)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), lambda sd: B(sd.columns[1]) + B(sd.columns[2])),
+                      ("C1x64-dict-sum-irregular", "SELECT SUM(w) WHERE f < 100 (w: 100000 sorted distinct values from the whole int32 range, another set per segment)",
+                       lambda sd: Q.QuerySpec([(Q.SUM, 3)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), lambda sd: B(sd.columns[1]) + B(sd.columns[3])),
+                      ("C1x64-group-by", "SELECT SUM(v), MAX(f) GROUP BY k (1000 groups)", lambda sd: Q.QuerySpec([(Q.SUM, 2), (Q.MAX, 1)], group_by=[4]),
+                       lambda sd: B(sd.columns[1]) + B(sd.columns[2]) + B(sd.columns[4]))]
             for vid, sql, mk, nb in shapes:
+                if not want(vid):
+                    continue
                 specs = [mk(sd) for sd in segs]
                 nbytes = sum(nb(sd) for sd in segs)
                 handles = (C.c_void_p * nseg)(*[g.handle for g in opened])
@@ -261,7 +271,8 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                 exact = None
                 # (the body that ran, as the library reports it per item; the shared launch is scan_lean_batch_kernel for the simple / raw shapes, scan_private_batch_kernel otherwise)
                 body = engine.execute_batch(opened[:1], specs[:1])[0][1].dominant_kernel
-                launch = "scan_lean_batch_kernel" if body in ("scan_simple_kernel", "scan_raw_kernel") else "scan_private_batch_kernel"
+                launch = {"scan_simple_kernel": "scan_lean_batch_kernel", "scan_raw_kernel": "scan_lean_batch_kernel", "scan_hist_kernel": "scan_hist_batch_kernel",
+                          "group_private_kernel": "group_lds_batch_kernel"}.get(body, "scan_private_batch_kernel")
                 if check:
                     got = engine.execute_batch(opened, specs)
                     exact = True
