@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <array>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -80,6 +81,8 @@ struct Engine {
   bool scan_raw = true;      // PINOT_GPU_SCAN_RAW=0: raw INT scans stay in scan_private_kernel / scan_private_typed_kernel (four waves per SIMD)
   bool scan_simple = true;   // PINOT_GPU_SCAN_SIMPLE=0: one-leaf / one-column queries stay in scan_private_kernel (half the waves per SIMD)
   bool scan_sparse = true;   // PINOT_GPU_SCAN_SPARSE=0: index-led aggregations scan their listed tiles in scan_private_kernel (one tile per wave and iteration)
+  bool batch_more = true;    // PINOT_GPU_BATCH_MORE=0: items of scan_narrow_kernel's / scan_private_typed_kernel's shape run their own launches
+  bool batch_group = true;   // PINOT_GPU_BATCH_GROUP=0: group-by items run their own launches on a worker thread
   bool batch_hist = true;    // PINOT_GPU_BATCH_HIST=0: items of scan_hist_kernel's shape run their own launch on a worker thread
   bool batch_launch = true;  // PINOT_GPU_BATCH_LAUNCH=0: pg_execute_batch runs every item as a pg_execute of its own on the worker threads (no shared launch)
   bool leap2 = true;         // PINOT_GPU_LEAP2=0: a leap-frogging `a AND b` is not counted on the device (host replay / upper bound instead)
@@ -1622,6 +1625,10 @@ pg_status pg_init(const pg_config* config) {
   g_engine.scan_raw = !(srw && srw[0] == '0');
   const char* bla = getenv("PINOT_GPU_BATCH_LAUNCH");
   g_engine.batch_launch = !(bla && bla[0] == '0');
+  const char* bmo = getenv("PINOT_GPU_BATCH_MORE");
+  g_engine.batch_more = !(bmo && bmo[0] == '0');
+  const char* bgr = getenv("PINOT_GPU_BATCH_GROUP");
+  g_engine.batch_group = !(bgr && bgr[0] == '0');
   const char* bhi = getenv("PINOT_GPU_BATCH_HIST");
   g_engine.batch_hist = !(bhi && bhi[0] == '0');
   const char* lp2 = getenv("PINOT_GPU_LEAP2");
@@ -2311,6 +2318,11 @@ struct LoweredItem {
   bool one_slot = true;
   std::function<void(const BlockPartial&, pg_result*)> convert;
   std::vector<int> plane_columns;                 // value planes sp reads: held (PlaneHold) by every batch that launches this item
+  // lean_kind 6 (group_lds_batch_kernel): the item is a GroupParams; its table slice is count[G] | acc[NA][G], zero-identity keys
+  std::shared_ptr<GroupParams> gp;
+  int group_threads = 0;
+  size_t group_lds = 0, group_table_words = 0;
+  std::function<void(const unsigned long long*, pg_result*)> convert_group;      // the item's slice (on the host) -> the result
   size_t hist_lds = 0;                            // lean_kind 3..5: the item's histogram (the launch's dynamic LDS is the largest item's)
   int hist_cw = 0, hist_col = -1;                 //   counter width; the summed column (a wrapped counter moves it to the guarded tier)
   // the cache's side (empty key: not cacheable)
@@ -2327,8 +2339,9 @@ struct Deferred {
 // The query's content as bytes: two queries with equal keys lower to the same item on the same segment.
 static bool query_key(const pg_query* q, std::string* key) {
   key->clear();
-  if (q->num_filter_nodes < 0 || q->num_predicates < 0 || q->num_aggregations < 0 || q->num_group_by != 0) return false;
-  if ((q->num_filter_nodes > 0 && !q->filter) || (q->num_predicates > 0 && !q->predicates) || (q->num_aggregations > 0 && !q->aggregations)) return false;
+  if (q->num_filter_nodes < 0 || q->num_predicates < 0 || q->num_aggregations < 0 || q->num_group_by < 0) return false;
+  if ((q->num_filter_nodes > 0 && !q->filter) || (q->num_predicates > 0 && !q->predicates) || (q->num_aggregations > 0 && !q->aggregations) ||
+      (q->num_group_by > 0 && !q->group_by_columns)) return false;
   const int32_t head[6] = {q->num_filter_nodes, q->num_predicates, q->num_aggregations, q->num_group_by, q->num_groups_limit, q->flags};
   key->append(reinterpret_cast<const char*>(head), sizeof(head));
   key->append(reinterpret_cast<const char*>(q->filter), sizeof(pg_filter_node) * (size_t)q->num_filter_nodes);
@@ -2340,6 +2353,7 @@ static bool query_key(const pg_query* q, std::string* key) {
     key->append(reinterpret_cast<const char*>(pr.set_words), sizeof(uint32_t) * (size_t)pr.num_set_words);
   }
   key->append(reinterpret_cast<const char*>(q->aggregations), sizeof(pg_aggregation) * (size_t)q->num_aggregations);
+  key->append(reinterpret_cast<const char*>(q->group_by_columns), sizeof(int32_t) * (size_t)q->num_group_by);
   return true;
 }
 
@@ -2358,7 +2372,8 @@ static std::shared_ptr<const OwnedQuery> own_query(const pg_query* q) {
   o->q.filter = o->filter.empty() ? nullptr : o->filter.data();
   o->q.predicates = o->predicates.empty() ? nullptr : o->predicates.data();
   o->q.aggregations = o->aggregations.empty() ? nullptr : o->aggregations.data();
-  o->q.group_by_columns = nullptr;
+  if (q->num_group_by > 0) o->group_by.assign(q->group_by_columns, q->group_by_columns + q->num_group_by);
+  o->q.group_by_columns = o->group_by.empty() ? nullptr : o->group_by.data();
   return o;
 }
 
@@ -2798,13 +2813,19 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       // kinds of shared launch (ScanParams.lean_kind; pg_execute_batch groups a batch's deferred items by device and kind, one launch each):
       //   0 scan_private_batch_kernel (the general body)   1 / 2 scan_lean_batch_kernel (scan_simple / scan_raw shape)
       //   3 / 4 / 5 scan_hist_batch_kernel<8 | 16 | 32> (SUM through the LDS histogram: dictionaries without structure, plain counters)
+      //   6 group_lds_batch_kernel (group-bys of the LDS-table form: lowered in the group-by branch below)
+      //   7 / 8 scan_narrow_batch_kernel<general | single leaf> (COUNT under filters over columns of at most 8 bits)
+      //   9 / 10 / 11 scan_typed_batch_kernel<1 | 2 | kMaxAggCols> (raw and 8-byte aggregated columns)
       const bool hist_item = use_hist && !hist_guarded && g_engine.batch_hist;
-      if (((use_private && !use_hist) || use_raw || hist_item) && !use_narrow && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
+      const bool narrow_item = use_narrow && g_engine.batch_more;
+      const bool typed_item = use_private_typed && !use_raw && !use_sparse && g_engine.batch_more;
+      if (((use_private && !use_hist && !use_narrow) || use_raw || hist_item || narrow_item || typed_item) && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
           lw.side == nullptr && ((long long)seg->num_docs + 2047) / 2048 <= kBatchMaxTiles &&
           (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf)) {
         // items of scan_simple_kernel's / scan_raw_kernel's shape share a launch of their own kind (scan_lean_batch_kernel), the rest the general one
         static const bool lean_batch = !(getenv("PINOT_GPU_LEAN_BATCH") && getenv("PINOT_GPU_LEAN_BATCH")[0] == '0');
-        sp.lean_kind = hist_item ? (hist_cw == 8 ? 3 : (hist_cw == 16 ? 4 : 5)) : use_simple ? 1 : (use_raw ? 2 : 0);
+        sp.lean_kind = hist_item ? (hist_cw == 8 ? 3 : (hist_cw == 16 ? 4 : 5)) : narrow_item ? (narrow_single ? 8 : 7) : typed_item ? (pl.num_agg_cols <= 1 ? 9 : (pl.num_agg_cols == 2 ? 10 : 11))
+                       : use_simple ? 1 : (use_raw ? 2 : 0);
         if (!lean_batch && sp.lean_kind == 1) sp.lean_kind = 0;      // (a raw-shaped item has no general form when its column is aggregated: it stays lean)
         if (sp.lean_kind == 2 && !lean_batch && use_private) sp.lean_kind = 0;
         auto item = std::make_shared<LoweredItem>();
@@ -3071,6 +3092,80 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     gp.scan.tile_list = lw.tile_list;            // read by group_private_kernel only
     gp.scan.tile_count = lw.tile_count;
     gp.scan.filter_entries = nullptr;
+    // pg_execute_batch: a group-by of the LDS-table form over a small segment shares ONE launch with the batch's other such items
+    // (group_lds_batch_kernel; ScanParams.lean_kind 6) -- no table init, no compaction launches: the item's slice of the batch's table is
+    // all-zero before the launch (zero-identity keys), comes back whole in the batch's one copy, and the host keeps the slots whose
+    // count is not zero.  What GroupByCombineOperator.java:102-165 gets from one task per segment.
+    if (defer != nullptr && g_engine.batch_group && use_private && gp.use_lds_table && hash_plan.kind == 0 && !first_appearance && !typed_direct && !want_bitmap && out &&
+        lw.tile_list == nullptr && lw.side == nullptr && !lw.stats_leap2_flagged && !lw.stats_chain_flagged && !ctx->pre_enqueued &&
+        (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf) &&
+        (long long)(q->num_groups_limit > 0 ? q->num_groups_limit : 100000) >= product && ((long long)seg->num_docs + 2047) / 2048 <= kBatchMaxTiles) {
+      auto item = std::make_shared<LoweredItem>();
+      item->gp = std::make_shared<GroupParams>(gp);
+      item->gp->zero_identity = 1;
+      item->gp->scan.lean_kind = 6;
+      item->sp.lean_kind = 6;
+      item->blocks = pblocks;
+      item->group_threads = pthreads;
+      item->group_lds = plds;
+      item->group_table_words = ((size_t)gp.num_groups * (size_t)(1 + gp.num_group_aggs) + 31) & ~(size_t)31;      // (slices start on 256-byte boundaries)
+      item->plane_columns = planes.columns;
+      const int G = gp.num_groups, NA = gp.num_group_aggs;
+      int agg_kind[kMaxGroupAggs] = {};
+      for (int a = 0; a < NA; ++a) agg_kind[a] = gp.group_aggs[a].kind;
+      std::array<int, kMaxGroupAggs> kinds{};
+      for (int a = 0; a < NA; ++a) kinds[(size_t)a] = agg_kind[a];
+      const size_t num_projected = projected.size();
+      item->convert_group = [q, seg, na, ng, cards, dev_agg_of, lw, G, NA, kinds, num_projected, no_dict_keys](const unsigned long long* table, pg_result* out) {
+        int num_present = 0;
+        for (int g = 0; g < G; ++g) num_present += table[g] != 0ull ? 1 : 0;
+        out->num_aggregations = na;
+        out->dominant_kernel = PG_KERNEL_GROUP_PRIVATE;
+        out->num_groups = num_present;
+        out->group_id_upper_bound = no_dict_keys ? (q->num_groups_limit > 0 ? q->num_groups_limit : 100000) : G;
+        out->group_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)std::max(num_present, 1));
+        out->group_aggregations = (pg_agg_value*)calloc((size_t)std::max(num_present, 1) * (size_t)std::max(na, 1), sizeof(pg_agg_value));
+        out->group_key_dict_ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)std::max(num_present, 1) * (size_t)ng);
+        out->group_key_kind = 0;
+        long long docs = 0;
+        int k = 0;
+        for (int g = 0; g < G; ++g) {
+          const unsigned long long group_docs = table[g];
+          if (group_docs == 0ull) continue;
+          docs += (long long)group_docs;
+          out->group_ids[k] = g;
+          long long raw = g;
+          for (int c = 0; c < ng; ++c) { out->group_key_dict_ids[(size_t)k * (size_t)ng + (size_t)c] = (int32_t)(raw % cards[(size_t)c]); raw /= cards[(size_t)c]; }
+          for (int a = 0; a < na; ++a) {
+            const pg_aggregation& ag = q->aggregations[a];
+            pg_agg_value& v = out->group_aggregations[(size_t)k * (size_t)na + (size_t)a];
+            v.count = (int64_t)group_docs;
+            v.min = std::numeric_limits<double>::infinity();
+            v.max = -std::numeric_limits<double>::infinity();
+            if (ag.function == PG_AGG_COUNT) continue;
+            const int da = dev_agg_of[(size_t)a];
+            long long acc = (long long)table[(size_t)G * (size_t)(1 + da) + (size_t)g];
+            // zero-identity keys of the shared launch (group_private_body's flush): MIN travelled as 2^31 - v, MAX as v + 2^31 + 1
+            if (kinds[(size_t)da] == kGroupMin) acc = 0x80000000ll - acc;
+            else if (kinds[(size_t)da] == kGroupMax) acc = acc - 0x80000001ll;
+            const ColumnDev& col = seg->cols[(size_t)ag.column];
+            const bool plane = lw.plane_cols[(size_t)ag.column] != 0;
+            if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) set_integer_sum(&v, (__int128)acc * (__int128)sum_scale(col, plane) + (__int128)group_docs * (__int128)sum_base(col, plane));
+            else if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, (int32_t)acc, plane);
+            else v.max = agg_value_double(col, (int32_t)acc, plane);
+          }
+          ++k;
+        }
+        out->stats.num_docs_scanned = docs;
+        finish_filter_stats(lw, seg, 0, false, out);
+        out->stats.num_entries_scanned_post_filter = docs * (int64_t)num_projected;
+        out->stats.num_total_docs = seg->num_docs;
+      };
+      defer->item = std::move(item);
+      defer->cacheable = !lw.plane_pending;
+      defer->planes.reset(new PlaneHold(std::move(planes)));
+      return kDeferred;
+    }
     HIP_TRY(mark_pre_work(ctx));
     init_group_table_kernel<<<dim3((unsigned)std::max<long long>(64, std::min<long long>(product >> 12, (long long)seg->num_cus * 16))), dim3(256), 0, ctx->stream>>>(gp);
     HIP_TRY(hipGetLastError());
@@ -4097,7 +4192,7 @@ void run_items(int count, int threads, int items_per_claim, bool heavy, const st
 struct BatchCtx {
   int device = -1;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[2] = {nullptr, nullptr};
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};      // [0], [1]: around the kernel (timed runs); [2]: the group tables' copy has landed
   // pinned staging / device copy of what the launch reads: [first workgroup of every item | the items' kernel parameters], ONE
   // allocation each so that ONE copy command precedes the launch
   uint8_t* h_blob = nullptr; uint8_t* d_blob = nullptr;
@@ -4110,7 +4205,12 @@ struct BatchCtx {
   int item_capacity = 0;
   size_t partial_capacity = 0;
   unsigned long long seq = 0;
+  // group-by launches (lean_kind 6): the items' table slices -- ONE device allocation, all-zero between launches, and its pinned host image
+  unsigned long long* d_gtable = nullptr; unsigned long long* h_gtable = nullptr;
+  size_t gtable_capacity = 0;      // words
+  bool gtable_dirty = false;       // a launch was enqueued and the memset behind it was not: zero the whole table before the next launch
 };
+constexpr size_t kBatchItemSlot = sizeof(GroupParams) > sizeof(ScanParams) ? sizeof(GroupParams) : sizeof(ScanParams);      // a slot of the blob holds an item of either kind
 std::mutex g_batch_mu;
 std::vector<BatchCtx*> g_batch_free;
 
@@ -4121,6 +4221,8 @@ void destroy_batch_ctx(BatchCtx* b) {
   if (b->h_records) (void)hipHostFree(b->h_records);
   if (b->d_done) (void)hipFree(b->d_done);
   if (b->d_partials) (void)hipFree(b->d_partials);
+  if (b->d_gtable) (void)hipFree(b->d_gtable);
+  if (b->h_gtable) (void)hipHostFree(b->h_gtable);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
@@ -4140,7 +4242,7 @@ pg_status ensure_batch_ctx(BatchCtx* b, int items, size_t partials) {
     b->h_blob = nullptr; b->d_blob = nullptr; b->h_items = nullptr; b->d_items = nullptr; b->h_first = nullptr; b->d_first = nullptr; b->h_records = nullptr; b->d_done = nullptr;
     b->item_capacity = 0;
     b->items_offset = (4 * (size_t)(cap + 1) + 255) & ~(size_t)255;
-    const size_t blob_bytes = b->items_offset + sizeof(ScanParams) * (size_t)cap;
+    const size_t blob_bytes = b->items_offset + kBatchItemSlot * (size_t)cap;
     HIP_TRY(hipHostMalloc((void**)&b->h_blob, blob_bytes, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void**)&b->d_blob, blob_bytes));
     memset(b->h_blob, 0, blob_bytes);
@@ -4223,6 +4325,7 @@ struct DeferredLaunch {
   BatchCtx* b = nullptr;
   int device = -1, n = 0, lean_kind = 0;       // lean_kind: ScanParams.lean_kind of every item (0: scan_private_batch_kernel, 1 / 2: scan_lean_batch_kernel)
   std::vector<int> items, blocks;
+  std::vector<size_t> table_offsets;       // lean_kind 6: where every item's slice starts in the context's table (words)
   long long total_blocks = 0, docs = 0;
   size_t lds = 0;
   unsigned long long seq = 0;
@@ -4230,6 +4333,111 @@ struct DeferredLaunch {
   std::chrono::steady_clock::time_point t0, t1;
   ~DeferredLaunch() { if (b) { std::lock_guard<std::mutex> lk(g_batch_mu); g_batch_free.push_back(b); } }
 };
+
+// The group-by items of one device (lean_kind 6): one launch of group_lds_batch_kernel over the items' GroupParams, each with a slice of the
+// context's table; then ONE copy of all slices to the pinned host image and a memset that leaves the table all-zero for the next launch.
+pg_status enqueue_group_launch(DeferredLaunch* L, BatchCtx* b, std::vector<Deferred>& defs, pg_segment* const* segments) {
+  const std::vector<int>& items = L->items;
+  const int n = L->n;
+  long long total_tiles = 0;
+  size_t launch_lds = 0, table_words = 0;
+  int threads = 64;
+  for (int i : items) {
+    const LoweredItem& d = *defs[(size_t)i].item;
+    total_tiles += ((long long)segments[i]->num_docs + 2047) / 2048;
+    L->docs += (long long)segments[i]->num_docs;
+    launch_lds = std::max(launch_lds, d.group_lds);
+    threads = std::max(threads, d.group_threads);
+    table_words += d.group_table_words;
+  }
+  L->lds = launch_lds;
+  const int wpb = threads / 64;
+  int bpc = std::max(1, std::min(waves_group_lds_batch() / wpb, (int)(kLdsBudget / std::max<size_t>(launch_lds, 1))));
+  if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
+  const long long budget = (long long)segments[items[0]]->num_cus * bpc;
+  std::vector<int>& blocks = L->blocks;
+  blocks.assign((size_t)n, 0);
+  long long total_blocks = 0;
+  for (int k = 0; k < n; ++k) {
+    const LoweredItem& d = *defs[(size_t)items[(size_t)k]].item;
+    const long long tiles = ((long long)segments[items[(size_t)k]]->num_docs + 2047) / 2048;
+    const long long share = total_tiles > 0 ? (tiles * budget + total_tiles - 1) / total_tiles : 1;
+    blocks[(size_t)k] = (int)std::max<long long>(1, std::min<long long>({(long long)d.blocks, share, (tiles + wpb - 1) / wpb}));
+    total_blocks += blocks[(size_t)k];
+  }
+  L->total_blocks = total_blocks;
+  pg_status st = ensure_batch_ctx(b, n, 0);
+  if (st != PG_OK) return st;
+  if (b->gtable_capacity < table_words) {
+    if (b->d_gtable) (void)hipFree(b->d_gtable);
+    if (b->h_gtable) (void)hipHostFree(b->h_gtable);
+    b->d_gtable = nullptr; b->h_gtable = nullptr; b->gtable_capacity = 0;
+    const size_t cap = std::max(table_words, (size_t)1 << 18);
+    HIP_TRY(hipMalloc((void**)&b->d_gtable, cap * 8));
+    HIP_TRY(hipHostMalloc((void**)&b->h_gtable, cap * 8, hipHostMallocDefault));
+    HIP_TRY(hipMemsetAsync(b->d_gtable, 0, cap * 8, b->stream));      // ordered before the launch below
+    b->gtable_capacity = cap;
+    b->gtable_dirty = false;
+  }
+  if (b->gtable_dirty) { HIP_TRY(hipMemsetAsync(b->d_gtable, 0, b->gtable_capacity * 8, b->stream)); b->gtable_dirty = false; }
+  GroupParams* h_items = reinterpret_cast<GroupParams*>(b->h_blob + b->items_offset);
+  GroupParams* d_items = reinterpret_cast<GroupParams*>(b->d_blob + b->items_offset);
+  size_t off = 0;
+  uint32_t first = 0;
+  L->seq = ++b->seq;
+  L->table_offsets.assign((size_t)n, 0);
+  for (int k = 0; k < n; ++k) {
+    const LoweredItem& d = *defs[(size_t)items[(size_t)k]].item;
+    GroupParams& gp = h_items[k];                 // (the pinned copy the device reads: filled in place)
+    gp = *d.gp;
+    gp.table_count = b->d_gtable + off;
+    gp.table_acc = reinterpret_cast<long long*>(b->d_gtable + off + (size_t)gp.num_groups);
+    L->table_offsets[(size_t)k] = off;
+    off += d.group_table_words;
+    b->h_first[k] = first;
+    first += (uint32_t)blocks[(size_t)k];
+  }
+  b->h_first[n] = first;
+  L->timed = (g_engine.flags & PG_CFG_TIME_KERNELS) != 0;
+  L->t0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipMemcpyAsync(b->d_blob, b->h_blob, b->items_offset + sizeof(GroupParams) * (size_t)n, hipMemcpyHostToDevice, b->stream));
+  if (L->timed) HIP_TRY(hipEventRecord(b->ev[0], b->stream));
+  b->gtable_dirty = true;
+  launch_group_lds_batch((int)total_blocks, threads, launch_lds, b->stream, d_items, b->d_first, n);
+  HIP_TRY(hipGetLastError());
+  if (L->timed) HIP_TRY(hipEventRecord(b->ev[1], b->stream));
+  HIP_TRY(hipMemcpyAsync(b->h_gtable, b->d_gtable, off * 8, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipEventRecord(b->ev[2], b->stream));
+  HIP_TRY(hipMemsetAsync(b->d_gtable, 0, off * 8, b->stream));          // all-zero again: the next launch's precondition (nobody waits for it here)
+  b->gtable_dirty = false;
+  L->t1 = std::chrono::steady_clock::now();
+  L->launched = true;
+  return PG_OK;
+}
+
+pg_status finish_group_launch(DeferredLaunch* L, std::vector<Deferred>& defs, pg_result* results, pg_status* statuses) {
+  BatchCtx* b = L->b;
+  const int n = L->n;
+  static const bool trace = getenv("PINOT_GPU_BATCH_TRACE") != nullptr;
+  HIP_TRY(hipSetDevice(phys_device(L->device)));
+  HIP_TRY(hipEventSynchronize(b->ev[2]));
+  const auto t2 = std::chrono::steady_clock::now();
+  float ms = 0.f;
+  if (L->timed) HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
+  // the items' conversions (a thousand groups each: ~10 us) side by side on the library's worker threads
+  run_items(n, (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 2)), 1, false, [&](int k) {
+    const int i = L->items[(size_t)k];
+    defs[(size_t)i].item->convert_group(b->h_gtable + L->table_offsets[(size_t)k], &results[i]);
+    const float share = L->total_blocks > 0 ? ms * (float)L->blocks[(size_t)k] / (float)L->total_blocks : 0.f;
+    results[i].device_ms = share;
+    results[i].dominant_kernel_ms = share;
+    statuses[i] = PG_OK;
+  });
+  if (trace) fprintf(stderr, "  deferred group-by launch on device %d: %d items %lld workgroups, lds %zu, enqueue %.1f us, wait %.1f us, kernel %.1f us, convert %.1f us\n", L->device, n, L->total_blocks, L->lds,
+                     std::chrono::duration<double, std::micro>(L->t1 - L->t0).count(), std::chrono::duration<double, std::micro>(t2 - L->t1).count(), ms * 1e3,
+                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t2).count());
+  return PG_OK;
+}
 
 pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_segment* const* segments) {
   const int device = L->device;
@@ -4243,6 +4451,7 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
   if (!b) { b = new BatchCtx(); b->device = device; }
   L->b = b;
   const int n = L->n = (int)items.size();
+  if (L->lean_kind == 6) return enqueue_group_launch(L, b, defs, segments);
   // Workgroups per item in proportion to its tiles, about sixteen per CU in total (four waves each: ~4x what is resident, so that
   // the items' tails overlap other items' scans); never more than the item would get on its own.
   long long total_tiles = 0;
@@ -4250,12 +4459,18 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
   // (the lean kernels hold five -- raw: four -- waves per SIMD: a workgroup per CU more than the general body's four)
   const bool hist_kind = L->lean_kind >= 3 && L->lean_kind <= 5;
   const int hist_cw = L->lean_kind == 3 ? 8 : (L->lean_kind == 4 ? 16 : 32);
-  const int wpb = hist_kind ? kHistBlockThreads / 64 : kBlockThreads / 64;      // wavefronts (= tiles per round) of a workgroup
+  const int wpb = hist_kind ? kHistBlockThreads / 64 : kBlockThreads / 64;      // wavefronts of a workgroup
+  const bool narrow_kind = L->lean_kind == 7 || L->lean_kind == 8, typed_kind = L->lean_kind >= 9 && L->lean_kind <= 11;
+  const int typed_slots = L->lean_kind == 9 ? 1 : (L->lean_kind == 10 ? 2 : kMaxAggCols);
+  // tiles a wave takes per iteration (the narrow kernels walk four / eight tiles at a time)
+  const int tiles_per_wave = L->lean_kind == 7 ? kNarrowTiles : (L->lean_kind == 8 ? kNarrowSingleTiles : 1);
   size_t launch_lds = 0;
   for (int i : items) launch_lds = std::max(launch_lds, defs[(size_t)i].item->hist_lds);
   L->lds = launch_lds;
   const int lean_bpc = hist_kind ? std::max(1, std::min(waves_scan_hist_batch(hist_cw) / wpb, (int)((160 * 1024 - 2048) / (launch_lds + 256))))
-                                 : (L->lean_kind != 0 ? std::max(1, waves_scan_lean_batch(L->lean_kind) / wpb) : 0);
+                       : narrow_kind ? std::max(1, waves_scan_narrow_batch(L->lean_kind == 8) / wpb)
+                       : typed_kind ? std::max(1, waves_scan_typed_batch(typed_slots) / wpb)
+                       : (L->lean_kind != 0 ? std::max(1, waves_scan_lean_batch(L->lean_kind) / wpb) : 0);
   const bool bpc_forced = g_engine.batch_blocks_per_cu_forced;      // (read once per pg_init: bench sweeps re-initialise the engine with it)
   const long long budget = (long long)segments[items[0]]->num_cus * ((L->lean_kind != 0 && (!bpc_forced || hist_kind)) ? lean_bpc : g_engine.batch_blocks_per_cu);
   std::vector<int>& blocks = L->blocks;
@@ -4267,7 +4482,7 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
     const LoweredItem& d = *defs[(size_t)items[(size_t)k]].item;
     const long long tiles = ((long long)segments[items[(size_t)k]]->num_docs + 2047) / 2048;
     const long long share = total_tiles > 0 ? (tiles * budget + total_tiles - 1) / total_tiles : 1;
-    blocks[(size_t)k] = (int)std::max<long long>(1, std::min<long long>({(long long)d.blocks, share, (tiles + wpb - 1) / wpb}));
+    blocks[(size_t)k] = (int)std::max<long long>(1, std::min<long long>({(long long)d.blocks, share, (tiles + (long long)wpb * tiles_per_wave - 1) / ((long long)wpb * tiles_per_wave)}));
     partials += (size_t)blocks[(size_t)k] + (size_t)kFoldExtraRecords;
     total_blocks += blocks[(size_t)k];
     one_slot = one_slot && d.one_slot;
@@ -4295,6 +4510,8 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
   HIP_TRY(hipMemcpyAsync(b->d_blob, b->h_blob, b->items_offset + sizeof(ScanParams) * (size_t)n, hipMemcpyHostToDevice, b->stream));
   if (L->timed) HIP_TRY(hipEventRecord(b->ev[0], b->stream));
   if (hist_kind) launch_scan_hist_batch(hist_cw, (int)total_blocks, launch_lds, b->stream, b->d_items, b->d_first, n);
+  else if (narrow_kind) launch_scan_narrow_batch(L->lean_kind == 8, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
+  else if (typed_kind) launch_scan_typed_batch(typed_slots, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
   else if (L->lean_kind != 0) launch_scan_lean_batch(L->lean_kind, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
   else launch_scan_private_batch(one_slot, (int)total_blocks, b->stream, b->d_items, b->d_first, n);
   HIP_TRY(hipGetLastError());
@@ -4305,6 +4522,7 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
 }
 
 pg_status finish_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_result* results, pg_status* statuses) {
+  if (L->lean_kind == 6) return finish_group_launch(L, defs, results, statuses);
   BatchCtx* b = L->b;
   const int n = L->n;
   const unsigned long long seq = L->seq;

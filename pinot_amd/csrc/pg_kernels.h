@@ -2337,6 +2337,7 @@ struct GroupBatchParams {
   int32_t num_items;
   int32_t reserved;
 };
+template <bool kWide = false>      // (a template so that only pg_unit_group_batch.hip instantiates it)
 __global__ __launch_bounds__(kGroupBlockThreads) void group_lds_batch_kernel(const GroupBatchParams bp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one
@@ -2347,7 +2348,7 @@ __global__ __launch_bounds__(kGroupBlockThreads) void group_lds_batch_kernel(con
   const uint32_t first = bp.block_first[lo];
   typedef const __attribute__((address_space(4))) GroupParams ConstantGroupParams;      // (scalar loads of the item's fields: see scan_private_batch_kernel)
   const ConstantGroupParams& item = *(ConstantGroupParams*)(bp.items + lo);
-  group_private_body<true, false, false>(item, blockIdx.x - first, bp.block_first[lo + 1] - first, smem);
+  group_private_body<true, kWide, false>(item, blockIdx.x - first, bp.block_first[lo + 1] - first, smem);
 }
 
 static __global__ void init_group_table_kernel(GroupParams gp) {

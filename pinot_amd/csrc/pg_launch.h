@@ -55,6 +55,12 @@ int waves_scan_lean_batch(int kind);
 // scan_narrow_kernel: COUNT(*) / docId bitmap of a filter over columns of at most 8 bits (pg_scan_narrow.h)
 void launch_scan_narrow(bool single_leaf, int blocks, hipStream_t stream, const ScanParams& p);      // single_leaf: scan_narrow_single_kernel, eight tiles per iteration
 int waves_scan_narrow(bool single_leaf);
+// scan_narrow_batch_kernel<single>: pg_execute_batch's shared launch for items of those two shapes
+void launch_scan_narrow_batch(bool single_leaf, int total_blocks, hipStream_t stream, const ScanParams* items, const uint32_t* block_first, int num_items);
+int waves_scan_narrow_batch(bool single_leaf);
+// scan_typed_batch_kernel<slots>: the same for items of scan_private_typed_kernel's shape (agg_slots: the most any item needs -- 1, 2 or kMaxAggCols)
+void launch_scan_typed_batch(int agg_slots, int total_blocks, hipStream_t stream, const ScanParams* items, const uint32_t* block_first, int num_items);
+int waves_scan_typed_batch(int agg_slots);
 // scan_group_kernel<kDma, kLdsTable>: LDS-staged group-by
 void launch_scan_group(bool dma, bool lds_table, int blocks, int threads, size_t lds, hipStream_t stream, const GroupParams& gp);
 int waves_scan_group();

@@ -56,17 +56,16 @@ struct NarrowStack {                              // kNarrowStack entries of fou
   }
 };
 
-static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_kernel(const ScanParams p) {
-  __shared__ BlockPartial red[kBlockThreads / 64];
-  __shared__ uint32_t fold_flag;
+template <typename P>
+__device__ __forceinline__ void scan_narrow_body(const P& p, uint32_t block_index, uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
-  const long long total_waves = (long long)gridDim.x * waves_per_block;
+  const long long total_waves = (long long)num_blocks * waves_per_block;
   const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
   const long long num_quads = (num_tiles + kNarrowTiles - 1) / kNarrowTiles;
   unsigned long long count = 0;
-  for (long long quad = (long long)blockIdx.x * waves_per_block + wave_in_block; quad < num_quads; quad += total_waves) {
+  for (long long quad = (long long)block_index * waves_per_block + wave_in_block; quad < num_quads; quad += total_waves) {
     long long tiles[kNarrowTiles];
 #pragma unroll
     for (int t = 0; t < kNarrowTiles; ++t) tiles[t] = quad * kNarrowTiles + t < num_tiles ? quad * kNarrowTiles + t : quad * kNarrowTiles;   // past the end: a valid tile, masked below
@@ -78,7 +77,7 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_kernel(const
     st.sp = 0;
     int leaf_ordinal = 0;
     for (int n = 0; n < p.num_nodes; ++n) {
-      const DevNode& nd = p.nodes[n];
+      const auto& nd = p.nodes[n];
       uint32_t top[kNarrowTiles];
       if (nd.op == PG_FILTER_LEAF) {
 #pragma unroll
@@ -141,13 +140,19 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_kernel(const
   mine.count = (unsigned long long)wave_sum_i64((long long)count);
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
-  publish_block_partial(p, red, waves_per_block, &fold_flag);
+  publish_block_partial(p, red, waves_per_block, fold_flag_ptr, block_index, num_blocks);
+}
+
+static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_kernel(const ScanParams p) {
+  __shared__ BlockPartial red[kBlockThreads / 64];
+  __shared__ uint32_t fold_flag;
+  scan_narrow_body(p, blockIdx.x, gridDim.x, red, &fold_flag);
 }
 
 // A single dictId-range leaf (WHERE dim = x, the commonest narrow filter): no mask stack, so EIGHT tiles fit per wave and iteration
 // (8 b <= 64 registers of loads in flight) in a kernel of its own register budget.
-template <int B>
-__device__ __forceinline__ unsigned narrow_single_octet(const ScanParams& p, const DevNode& L, long long first_tile, long long num_tiles, int lane) {
+template <int B, typename P, typename LN>
+__device__ __forceinline__ unsigned narrow_single_octet(const P& p, const LN& L, long long first_tile, long long num_tiles, int lane) {
   uint32_t w[kNarrowSingleTiles][B];
 #pragma unroll
   for (int t = 0; t < kNarrowSingleTiles; ++t) {
@@ -172,18 +177,17 @@ __device__ __forceinline__ unsigned narrow_single_octet(const ScanParams& p, con
   return count;
 }
 
-static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_single_kernel(const ScanParams p) {
-  __shared__ BlockPartial red[kBlockThreads / 64];
-  __shared__ uint32_t fold_flag;
+template <typename P>
+__device__ __forceinline__ void scan_narrow_single_body(const P& p, uint32_t block_index, uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
-  const long long total_waves = (long long)gridDim.x * waves_per_block;
+  const long long total_waves = (long long)num_blocks * waves_per_block;
   const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
   const long long num_octets = (num_tiles + kNarrowSingleTiles - 1) / kNarrowSingleTiles;
-  const DevNode& L = p.nodes[0];
+  const auto& L = p.nodes[0];
   unsigned long long count = 0;
-  for (long long o = (long long)blockIdx.x * waves_per_block + wave_in_block; o < num_octets; o += total_waves) {
+  for (long long o = (long long)block_index * waves_per_block + wave_in_block; o < num_octets; o += total_waves) {
     switch (L.bits) {
 #define PG_CASE(B) case B: count += narrow_single_octet<B>(p, L, o * kNarrowSingleTiles, num_tiles, lane); break;
       PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8)
@@ -196,7 +200,32 @@ static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_single_kerne
   mine.count = (unsigned long long)wave_sum_i64((long long)count);
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
-  publish_block_partial(p, red, waves_per_block, &fold_flag);
+  publish_block_partial(p, red, waves_per_block, fold_flag_ptr, block_index, num_blocks);
+}
+
+static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_single_kernel(const ScanParams p) {
+  __shared__ BlockPartial red[kBlockThreads / 64];
+  __shared__ uint32_t fold_flag;
+  scan_narrow_single_body(p, blockIdx.x, gridDim.x, red, &fold_flag);
+}
+
+// pg_execute_batch's shared launch for items of the two kernels' shape (COUNT(*) under a filter over columns of at most 8 bits on a server's
+// many small segments): workgroups [block_first[i], block_first[i + 1]) work on items[i] (see scan_private_batch_kernel).
+// kSingle: every item is one dictionary-range leaf (scan_narrow_single_kernel's shape), else the general narrow evaluator.
+template <bool kSingle>
+__global__ __launch_bounds__(kBlockThreads) void scan_narrow_batch_kernel(const BatchParams bp) {
+  __shared__ BlockPartial red[kBlockThreads / 64];
+  __shared__ uint32_t fold_flag;
+  int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (bp.block_first[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const uint32_t first = bp.block_first[lo];
+  typedef const __attribute__((address_space(4))) ScanParams ConstantScanParams;
+  const ConstantScanParams& item = *(ConstantScanParams*)(bp.items + lo);
+  if constexpr (kSingle) scan_narrow_single_body(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
+  else scan_narrow_body(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
 }
 
 }  // namespace pg

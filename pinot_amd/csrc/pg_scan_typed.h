@@ -31,7 +31,8 @@ __device__ __forceinline__ long long be64(uint32_t first, uint32_t second) {
   return (long long)(((unsigned long long)__builtin_bswap32(first) << 32) | (unsigned long long)__builtin_bswap32(second));
 }
 
-__device__ __forceinline__ void typed_fold64(const DevAggCol& ac, long long bits, bool match, TypedAcc& t) {
+template <typename AC>
+__device__ __forceinline__ void typed_fold64(const AC& ac, long long bits, bool match, TypedAcc& t) {
   long long key;
   if (ac.vkind == kValI64) {
     t.isum += match ? bits : 0ll;
@@ -49,7 +50,8 @@ __device__ __forceinline__ void typed_fold64(const DevAggCol& ac, long long bits
 }
 
 // raw LONG / DOUBLE: 32 docs = 256 contiguous bytes per lane
-__device__ __forceinline__ void agg_raw64_private(const DevAggCol& ac, long long tile, int lane, uint32_t m, TypedAcc& t) {
+template <typename AC>
+__device__ __forceinline__ void agg_raw64_private(const AC& ac, long long tile, int lane, uint32_t m, TypedAcc& t) {
   const uint4* src = reinterpret_cast<const uint4*>(ac.fwd + (tile * 2048 + (long long)lane * 32) * 8);
 #pragma unroll 1      // unrolled, all sixteen loads are hoisted to the top: 256 VGPRs, two waves per SIMD
   for (int c = 0; c < 4; ++c) {
@@ -69,7 +71,8 @@ __device__ __forceinline__ void agg_raw64_private(const DevAggCol& ac, long long
 // eight 128-byte lines instead of the 64 half-used lines of the lane-contiguous pattern -- so the lane holds docs 128 i + 2 lane (+1)
 // of the tile instead of its own 32.  The filter mask stays in the lane-private layout (bit j of lane L = doc 32 L + j); the two mask
 // bits a lane needs per load are lane (4 i + lane / 16)'s bits 2 (lane % 16) (+1): one ds_bpermute per load.
-__device__ __forceinline__ void agg_raw64_coalesced(const DevAggCol& ac, long long tile, int lane, uint32_t m, TypedAcc& t) {
+template <typename AC>
+__device__ __forceinline__ void agg_raw64_coalesced(const AC& ac, long long tile, int lane, uint32_t m, TypedAcc& t) {
   const uint4* src = reinterpret_cast<const uint4*>(ac.fwd + tile * 2048 * 8) + lane;
   const int bit = (2 * lane) & 31;
 #pragma unroll 1
@@ -87,7 +90,8 @@ __device__ __forceinline__ void agg_raw64_coalesced(const DevAggCol& ac, long lo
 }
 
 // raw INT / FLOAT: 32 docs = 128 contiguous bytes per lane
-__device__ __forceinline__ void agg_raw32_private(const DevAggCol& ac, long long tile, int lane, uint32_t m, TypedAcc& t) {
+template <typename AC>
+__device__ __forceinline__ void agg_raw32_private(const AC& ac, long long tile, int lane, uint32_t m, TypedAcc& t) {
   const uint4* src = reinterpret_cast<const uint4*>(ac.fwd + (tile * 2048 + (long long)lane * 32) * 4);
 #pragma unroll 1
   for (int c = 0; c < 2; ++c) {
@@ -124,7 +128,8 @@ __device__ __forceinline__ void agg_raw32_private(const DevAggCol& ac, long long
 
 // LONG / DOUBLE dictionary: dictIds decoded at compile-time bit positions, then sixteen 8-byte dictionary gathers in flight.
 // MIN / MAX run on the dictIds (the dictionary is sorted).
-__device__ __forceinline__ void agg_dict64_private(const DevAggCol& ac, long long tile, int lane, uint32_t m, TypedAcc& t) {
+template <typename AC>
+__device__ __forceinline__ void agg_dict64_private(const AC& ac, long long tile, int lane, uint32_t m, TypedAcc& t) {
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   const int b = ac.bits;
   const uint32_t* words = reinterpret_cast<const uint32_t*>(ac.fwd + tile * (256ll * b)) + lane * b;
@@ -164,14 +169,14 @@ __device__ __forceinline__ void agg_dict64_private(const DevAggCol& ac, long lon
 #ifndef PG_TYPED_WAVES
 #define PG_TYPED_WAVES 4
 #endif
-template <int kAggSlots>
-__global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : 4)) void scan_private_typed_kernel(const ScanParams p) {
-  __shared__ BlockPartial red[kBlockThreads / 64];
-  __shared__ uint32_t fold_flag;
+// `block_index` of `num_blocks`: the workgroup's place among those working on this parameter block (the whole grid, or an item's share of
+// scan_typed_batch_kernel's launch).  P: ScanParams, or its constant-address-space form in device memory.
+template <int kAggSlots, typename P>
+__device__ __forceinline__ void scan_private_typed_body(const P& p, uint32_t block_index, uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
-  const long long total_waves = (long long)gridDim.x * waves_per_block;
+  const long long total_waves = (long long)num_blocks * waves_per_block;
   const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
 
   unsigned long long count = 0;
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : 4
   uint32_t entries = 0u;
   const bool listed = p.tile_list != nullptr;              // index-driven filters: only the tiles index_and_kernel listed hold a match
   const long long tile_limit = listed ? (long long)*p.tile_count : num_tiles;
-  for (long long tile_it = (long long)blockIdx.x * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
+  for (long long tile_it = (long long)block_index * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
     const long long tile = listed ? (long long)p.tile_list[tile_it] : tile_it;
     uint32_t m = eval_filter_private(p, tile, lane, entries);
     const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : 4
     count += (unsigned)__builtin_popcount(m);
     if (p.num_agg_cols == 0 || __builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
     for (int a = 0; a < p.num_agg_cols; ++a) {
-      const DevAggCol& ac = p.agg_cols[a];
+      const auto& ac = p.agg_cols[a];
       TypedAcc t;
       typed_acc_identity(t);
       if (ac.is_raw) {
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : 4
 #pragma unroll
   for (int a = 0; a < kAggSlots; ++a) {
     if (a >= p.num_agg_cols) continue;             // unused slots keep the identities: six wave reductions less each
-    const DevAggCol& ac = p.agg_cols[a];
+    const auto& ac = p.agg_cols[a];
     const bool wide_keys = ac.is_raw && ac.vkind != kValI32;
     if (ac.need_sum) {
       mine.sum[a] = wave_sum_i64(acc[a].isum);
@@ -233,7 +238,32 @@ __global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : 4
   }
   if (lane == 0) red[wave_in_block] = mine;
   __syncthreads();
-  publish_block_partial(p, red, waves_per_block, &fold_flag);
+  publish_block_partial(p, red, waves_per_block, fold_flag_ptr, block_index, num_blocks);
+}
+
+template <int kAggSlots>
+__global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : 4)) void scan_private_typed_kernel(const ScanParams p) {
+  __shared__ BlockPartial red[kBlockThreads / 64];
+  __shared__ uint32_t fold_flag;
+  scan_private_typed_body<kAggSlots>(p, blockIdx.x, gridDim.x, red, &fold_flag);
+}
+
+// pg_execute_batch's shared launch for items of this kernel's shape (aggregations over raw INT / LONG / FLOAT / DOUBLE columns and 8-byte
+// dictionaries on a server's many small segments): workgroups [block_first[i], block_first[i + 1]) work on items[i], every item folds and
+// publishes its own record (see scan_private_batch_kernel).
+template <int kAggSlots>
+__global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : 4)) void scan_typed_batch_kernel(const BatchParams bp) {
+  __shared__ BlockPartial red[kBlockThreads / 64];
+  __shared__ uint32_t fold_flag;
+  int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (bp.block_first[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const uint32_t first = bp.block_first[lo];
+  typedef const __attribute__((address_space(4))) ScanParams ConstantScanParams;
+  const ConstantScanParams& item = *(ConstantScanParams*)(bp.items + lo);
+  scan_private_typed_body<kAggSlots>(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
 }
 
 }  // namespace pg

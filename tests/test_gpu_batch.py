@@ -437,3 +437,124 @@ def test_a_wrapped_counter_in_the_shared_launch_is_answered_again(engine):
                 H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
     finally:
         [g.close() for g in opened]
+
+
+# ---- group-bys of the LDS-table form share a launch (round 5): GroupByCombineOperator's one task per segment ----
+def _group_specs(segs, variant):
+    out = []
+    for s, seg in enumerate(segs):
+        card_f = seg.columns[1].cardinality
+        flt = Q.leaf(Q.Pred.dict_range(1, s % 5, min(card_f, s % 5 + 9)))
+        if variant == "sum-max":
+            out.append(Q.QuerySpec([(Q.SUM, 0), (Q.MAX, 1)], group_by=[2]))
+        elif variant == "filtered":
+            out.append(Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1), (Q.MIN, 0), (Q.MAX, 0), (Q.AVG, 1)], filter=flt, group_by=[2]))
+        elif variant == "two-keys":
+            out.append(Q.QuerySpec([(Q.COUNT, -1), (Q.MIN, 1), (Q.SUM, 1)], filter=Q.or_(flt, Q.leaf(Q.Pred.dict_range(0, 0, 7))), group_by=[2, 3]))
+        elif variant == "count-only":
+            out.append(Q.QuerySpec([(Q.COUNT, -1)], group_by=[3]))
+        elif variant == "nothing-matches":
+            out.append(Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 3, 3)), group_by=[2]))
+        else:
+            raise ValueError(variant)
+    return out
+
+
+@pytest.mark.parametrize("variant", ["sum-max", "filtered", "two-keys", "count-only", "nothing-matches"])
+def test_group_bys_share_one_launch(engine, variant):
+    """Every item a group-by whose table fits the LDS: one launch of group_lds_batch_kernel for the batch, each item with its own slice of
+    the batch's table (all-zero before the launch, MIN / MAX as zero-identity keys), the groups kept on the host from the slots whose count
+    is not zero.  Twice per variant: the second call takes the items from the plan cache and finds the table zeroed again."""
+    segs = _segments()
+    opened = [engine.open(seg) for seg in segs]
+    try:
+        for rep in range(2):
+            specs = _group_specs(segs, variant)
+            got = engine.execute_batch(opened, specs)
+            for s, (status, res) in enumerate(got):
+                assert status == _abi.PG_OK, (variant, s)
+                H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
+                single = opened[s].execute(specs[s])
+                assert res.stats == single.stats and res.filter_entries_exact == single.filter_entries_exact
+                assert sorted(res.groups) == sorted(single.groups)
+    finally:
+        [g.close() for g in opened]
+
+
+def test_group_bys_beside_other_shapes_and_with_a_groups_limit(engine):
+    """A batch that mixes group-bys with scans (a launch per kind), and a group-by whose numGroupsLimit is below its key space (that item
+    keeps its own launches: the limit's first-appearance order is not the shared launch's business)."""
+    segs = _segments()
+    opened = [engine.open(seg) for seg in segs]
+    try:
+        specs = []
+        for s, seg in enumerate(segs):
+            if s % 3 == 0:
+                specs.append(Q.QuerySpec([(Q.SUM, 0), (Q.MAX, 1)], group_by=[2]))
+            elif s % 3 == 1:
+                specs.append(_spec(seg, s, "sum"))
+            else:
+                specs.append(Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0)], group_by=[2, 3], num_groups_limit=5))
+        for rep in range(2):
+            for s, (status, res) in enumerate(engine.execute_batch(opened, specs)):
+                assert status == _abi.PG_OK, s
+                single = opened[s].execute(specs[s])
+                assert res.stats == single.stats and sorted(res.groups) == sorted(single.groups)
+                if s % 3 != 2:
+                    H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
+    finally:
+        [g.close() for g in opened]
+
+
+# ---- narrow-filter COUNTs and typed aggregations share launches as well (round 5) ----
+def _narrow_typed_segments(count=9):
+    segs = []
+    for s in range(count):
+        n = 90_000 + 41_003 * s
+        rng = np.random.default_rng(7000 + s)
+        a = S.Column.dict_encoded("a", rng.integers(0, 200, n).astype(np.int32))          # 8 bits
+        b = S.Column.dict_encoded("b", rng.integers(0, 13, n).astype(np.int32) * 5)       # 4 bits
+        c = S.Column.dict_encoded("c", rng.integers(0, 3, n).astype(np.int32))            # 2 bits
+        raw_l = S.Column.raw_typed("rl", rng.integers(-2 ** 40, 2 ** 40, n).astype(np.int64))
+        raw_d = S.Column.raw_typed("rd", rng.normal(0, 1e6, n).astype(np.float64))
+        dl = S.Column.dict_encoded_typed("dl", (rng.integers(0, 500, n).astype(np.int64) - 250) * (2 ** 33 + 7))
+        segs.append(S.SegmentData("nt%d" % s, n, [a, b, c, raw_l, raw_d, dl]))
+    return segs
+
+
+def _narrow_typed_spec(seg, s, shape):
+    ca, cb = seg.columns[0].cardinality, seg.columns[1].cardinality
+    if shape == "narrow-single":
+        return Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(0, s % 7, min(ca, 90 + s))))
+    if shape == "narrow-tree":
+        return Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(Q.leaf(Q.Pred.dict_range(0, 10, min(ca, 150))),
+                                                         Q.or_(Q.leaf(Q.Pred.dict_range(1, 0, min(cb, 4 + s % 3))), Q.not_(Q.leaf(Q.Pred.dict_range(2, 0, 1))))))
+    flt = Q.leaf(Q.Pred.dict_range(1, s % 3, min(cb, s % 3 + 6)))
+    if shape == "typed-1":
+        return Q.QuerySpec([(Q.SUM, 3), (Q.MIN, 3), (Q.MAX, 3), (Q.COUNT, -1)], filter=flt)
+    if shape == "typed-2":
+        return Q.QuerySpec([(Q.SUM, 4), (Q.MAX, 5), (Q.AVG, 5)], filter=flt)
+    if shape == "typed-3":
+        return Q.QuerySpec([(Q.SUM, 3), (Q.MIN, 4), (Q.SUM, 5), (Q.MAX, 3)])
+    raise ValueError(shape)
+
+
+@pytest.mark.parametrize("shapes", [["narrow-single"], ["narrow-tree"], ["typed-1"], ["typed-2"], ["typed-3"],
+                                    ["narrow-single", "typed-1", "narrow-tree", "typed-3", "typed-2"]])
+def test_narrow_and_typed_items_share_launches(engine, shapes):
+    """Items of scan_narrow_kernel's, scan_narrow_single_kernel's and scan_private_typed_kernel's shape: a launch per kind (the mixed batch
+    is five launches), same answers as the oracle and as pg_execute, twice (the second call through the plan cache)."""
+    segs = _narrow_typed_segments()
+    if not hasattr(Q, "not_"):
+        pytest.skip("no NOT constructor")
+    opened = [engine.open(seg) for seg in segs]
+    try:
+        specs = [_narrow_typed_spec(seg, s, shapes[s % len(shapes)]) for s, seg in enumerate(segs)]
+        for rep in range(2):
+            for s, (status, res) in enumerate(engine.execute_batch(opened, specs)):
+                assert status == _abi.PG_OK, (shapes[s % len(shapes)], s)
+                H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
+                single = opened[s].execute(specs[s])
+                assert res.stats == single.stats and res.dominant_kernel == single.dominant_kernel
+    finally:
+        [g.close() for g in opened]
