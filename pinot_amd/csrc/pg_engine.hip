@@ -81,6 +81,13 @@ struct Engine {
   bool scan_raw = true;      // PINOT_GPU_SCAN_RAW=0: raw INT scans stay in scan_private_kernel / scan_private_typed_kernel (four waves per SIMD)
   bool scan_simple = true;   // PINOT_GPU_SCAN_SIMPLE=0: one-leaf / one-column queries stay in scan_private_kernel (half the waves per SIMD)
   bool scan_sparse = true;   // PINOT_GPU_SCAN_SPARSE=0: index-led aggregations scan their listed tiles in scan_private_kernel (one tile per wave and iteration)
+  // (read at every pg_init like the rest: they were function-local statics, fixed at their first use in the process, until the kernel
+  //  coverage run of round 5 needed both settings in one process)
+  bool lean_batch = true;    // PINOT_GPU_LEAN_BATCH=0: items of scan_simple_kernel's shape share the general batch launch
+  bool partition_two_level = true;   // PINOT_GPU_PARTITION_TWO_LEVEL=0: key spaces above one scatter pass keep the direct HBM atomics
+  bool fsm_perm = true;      // PINOT_GPU_FSM_PERM=0: the transducer pass always walks tables (fsm_tiles_kernel), never byte functions
+  bool fsm_stats = true;     // PINOT_GPU_FSM_STATS=0: no transducer pass (host replay / upper bound)
+  bool plan_cache = true;    // PINOT_GPU_PLAN_CACHE=0: pg_execute_batch lowers every item of every call
   bool batch_more = true;    // PINOT_GPU_BATCH_MORE=0: items of scan_narrow_kernel's / scan_private_typed_kernel's shape run their own launches
   bool batch_group = true;   // PINOT_GPU_BATCH_GROUP=0: group-by items run their own launches on a worker thread
   bool batch_hist = true;    // PINOT_GPU_BATCH_HIST=0: items of scan_hist_kernel's shape run their own launch on a worker thread
@@ -1625,6 +1632,12 @@ pg_status pg_init(const pg_config* config) {
   g_engine.scan_raw = !(srw && srw[0] == '0');
   const char* bla = getenv("PINOT_GPU_BATCH_LAUNCH");
   g_engine.batch_launch = !(bla && bla[0] == '0');
+  auto env_on = [](const char* name) { const char* v = getenv(name); return !(v && v[0] == '0'); };
+  g_engine.lean_batch = env_on("PINOT_GPU_LEAN_BATCH");
+  g_engine.partition_two_level = env_on("PINOT_GPU_PARTITION_TWO_LEVEL");
+  g_engine.fsm_perm = env_on("PINOT_GPU_FSM_PERM");
+  g_engine.fsm_stats = env_on("PINOT_GPU_FSM_STATS");
+  g_engine.plan_cache = env_on("PINOT_GPU_PLAN_CACHE");
   const char* bmo = getenv("PINOT_GPU_BATCH_MORE");
   g_engine.batch_more = !(bmo && bmo[0] == '0');
   const char* bgr = getenv("PINOT_GPU_BATCH_GROUP");
@@ -2823,7 +2836,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
           lw.side == nullptr && ((long long)seg->num_docs + 2047) / 2048 <= kBatchMaxTiles &&
           (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf)) {
         // items of scan_simple_kernel's / scan_raw_kernel's shape share a launch of their own kind (scan_lean_batch_kernel), the rest the general one
-        static const bool lean_batch = !(getenv("PINOT_GPU_LEAN_BATCH") && getenv("PINOT_GPU_LEAN_BATCH")[0] == '0');
+        const bool lean_batch = g_engine.lean_batch;
         sp.lean_kind = hist_item ? (hist_cw == 8 ? 3 : (hist_cw == 16 ? 4 : 5)) : narrow_item ? (narrow_single ? 8 : 7) : typed_item ? (pl.num_agg_cols <= 1 ? 9 : (pl.num_agg_cols == 2 ? 10 : 11))
                        : use_simple ? 1 : (use_raw ? 2 : 0);
         if (!lean_batch && sp.lean_kind == 1) sp.lean_kind = 0;      // (a raw-shaped item has no general form when its column is aggregated: it stays lean)
@@ -3178,7 +3191,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // More fine partitions than one scatter pass can address (key spaces of 2 M .. 2^31 raw keys): two levels -- pass A scatters by
     // coarse partition (2^k fine ones each), group_repartition_*_kernel scatter every coarse partition's records by fine partition
     // (pg_group_partition.h).  PINOT_GPU_PARTITION_TWO_LEVEL=0: such key spaces keep the direct HBM atomics.
-    static const bool two_level_on = !(getenv("PINOT_GPU_PARTITION_TWO_LEVEL") && getenv("PINOT_GPU_PARTITION_TWO_LEVEL")[0] == '0');
+    const bool two_level_on = g_engine.partition_two_level;
     int log2_fine_per_coarse = 0;
     while (((fine_partitions + (1ll << log2_fine_per_coarse) - 1) >> log2_fine_per_coarse) > kMaxPartitions) ++log2_fine_per_coarse;
     const bool two_level = log2_fine_per_coarse > 0;
@@ -3989,8 +4002,11 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
   fp.num_inputs = L; fp.num_states = S; fp.num_docs = seg->num_docs; fp.num_tiles = (int32_t)tiles;
   const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)seg->num_cus * 8));
 #define PG_FSM_LAUNCH(SM, LM) fsm_tiles_kernel<SM, LM><<<dim3(blocks), dim3(256), 0, 0>>>(fp)
-#define PG_FSM_LAUNCH_L(SM) do { if (L <= 2) PG_FSM_LAUNCH(SM, 2); else if (L <= 3) PG_FSM_LAUNCH(SM, 3); else if (L <= 4) PG_FSM_LAUNCH(SM, 4); else if (L <= 6) PG_FSM_LAUNCH(SM, 6); else PG_FSM_LAUNCH(SM, 8); } while (0)
-  static const bool perm_walk = !(getenv("PINOT_GPU_FSM_PERM") && getenv("PINOT_GPU_FSM_PERM")[0] == '0');
+// (a machine over two inputs has at most three states -- 350 000 random root ANDs over two predicates, tools/kernel_coverage.py's search:
+//  the <8, 2>, <16, 2> table walks and the eight-state byte-function walk over two inputs were instantiations no query could reach;
+//  the coverage gate of round 5 found them, they are gone: such a machine, should one ever exist, walks the three-input form)
+#define PG_FSM_LAUNCH_L(SM) do { if (L <= 2 && SM <= 4) PG_FSM_LAUNCH((SM <= 4 ? SM : 4), 2); else if (L <= 3) PG_FSM_LAUNCH(SM, 3); else if (L <= 4) PG_FSM_LAUNCH(SM, 4); else if (L <= 6) PG_FSM_LAUNCH(SM, 6); else PG_FSM_LAUNCH(SM, 8); } while (0)
+  const bool perm_walk = g_engine.fsm_perm;
   // (the byte-function walk keeps a lane's entries per entry state in ONE byte: 16 steps x two docs x at most 7 entries per doc.  A doc
   //  costs more than 7 only when the tree names the same predicate in many leaves -- such machines walk tables)
   int max_inc = 0;
@@ -4001,8 +4017,7 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
     else fsm_tiles_perm_kernel<4><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
   }
   else if (S <= 8 && L <= 4 && max_inc <= 7 && perm_walk) {
-    if (L <= 2) fsm_tiles_perm8_kernel<2><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
-    else if (L <= 3) fsm_tiles_perm8_kernel<3><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
+    if (L <= 3) fsm_tiles_perm8_kernel<3><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
     else fsm_tiles_perm8_kernel<4><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
   }
   else if (S <= 2) PG_FSM_LAUNCH_L(2);
@@ -4036,7 +4051,7 @@ static pg_status execute_one(pg_segment* segment, const pg_query* query, pg_resu
   // (PINOT_GPU_FSM_STATS=0: never): the query's own kernel leaves the leaves' bitmaps in the segment's scratch (one such query at a
   // time per segment), the pass follows.  Other shapes: the host's replay of the iterator tree up to
   // PINOT_GPU_EXACT_FILTER_STATS_DOCS docs, else the upper bound stands.
-  static const bool use_fsm = !(getenv("PINOT_GPU_FSM_STATS") && getenv("PINOT_GPU_FSM_STATS")[0] == '0');
+  const bool use_fsm = g_engine.fsm_stats;
   fstats::Fsm fsm;
   FsmSide side;
   std::unique_lock<std::mutex> fsm_lock;
@@ -4578,7 +4593,7 @@ pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* q
   // except the items whose segment has this very query in its plan cache: those are picked up on the calling thread (~0.2 us each)
   const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2));
   std::vector<float> item_us(trace ? (size_t)count : 0);
-  static const bool plan_cache = !(getenv("PINOT_GPU_PLAN_CACHE") && getenv("PINOT_GPU_PLAN_CACHE")[0] == '0');
+  const bool plan_cache = g_engine.plan_cache;
   std::vector<int> todo;
   std::vector<std::string> keys(plan_cache && g_engine.batch_launch ? (size_t)count : 0);
   int cache_hits = 0;

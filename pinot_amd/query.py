@@ -113,8 +113,13 @@ class QuerySpec:
 
         def walk(n):
             if n.op == _abi.PG_FILTER_LEAF:
-                preds.append(n.pred)
-                nodes.append((n.op, len(preds) - 1, 0))
+                # one Pred OBJECT behind several leaves is ONE predicate of the query (pg_filter_node.predicate may repeat: the
+                # transducer of numEntriesScannedInFilter takes its inputs per predicate, not per leaf)
+                at = next((i for i, p in enumerate(preds) if p is n.pred), -1)
+                if at < 0:
+                    preds.append(n.pred)
+                    at = len(preds) - 1
+                nodes.append((n.op, at, 0))
             else:
                 for ch in n.children:
                     walk(ch)

@@ -263,3 +263,32 @@ def test_transducer_matches_the_iterator_replay_on_random_and_trees(driver):
             else:
                 assert perm8 == -1
     assert compiled > 200 and len(shapes_seen) > 8 and small > 60 and medium > 20, (compiled, shapes_seen, small, medium)
+
+
+def test_an_or_of_index_based_members_only_is_not_a_leap_frogging_child(driver):
+    """`posting AND scan AND (posting OR sorted OR sorted)`: OrDocIdSet.iterator() merges the two sorted members (and, in the oracle's
+    reading, the bitmap member beside them) into ONE bitmap iterator (OrDocIdSet.java:62-126) -- an index-based child of the AND, and-ed
+    into its bitmap before the scan leaf sees a doc.  Round 4's transducer walked it as a leap-frogging OR (it bailed out only when every
+    member was sorted) and reported 27 559 entries with filter_entries_exact = 1 where the iterators count 15 468; found by round 5's
+    kernel-coverage table (tools/kernel_coverage.py, tree 313).  The shape stays with the replay; shared predicates (one predicate
+    behind several leaves) compile and agree."""
+    rng = np.random.default_rng(12)
+    n = 50_021
+    cols = [H.random_dict_column(rng, "a", n, 200)[0], H.random_dict_column(rng, "x", n, 50, with_inverted=True)[0],
+            H.random_dict_column(rng, "y", n, 40, with_inverted=True)[0]]
+    seg = S.SegmentData("fsm_or", n, cols)
+    a = Q.leaf(Q.Pred.dict_range(0, 12, 60))
+    y = Q.leaf(Q.Pred.dict_set(2, [1, 4, 9, 16, 25, 36], 40, inverted=True))
+    x = Q.leaf(Q.Pred.dict_range(1, 0, 7, inverted=True))
+    lo, hi = Q.leaf(Q.Pred.doc_range(4808, 30822)), Q.leaf(Q.Pred.doc_range(35000, n - 1))
+    for flt, compiles in ((Q.and_(y, a, Q.or_(x, hi, lo)), False), (Q.and_(y, a, Q.or_(hi, lo)), False), (Q.and_(y, a, Q.or_(x, lo)), True),
+                          (Q.and_(y, a, Q.or_(x, hi, lo, Q.leaf(Q.Pred.dict_range(0, 100, 150)))), True),
+                          (Q.and_(a, Q.or_(x, a), Q.or_(a, lo)), True)):
+        spec = Q.QuerySpec([(Q.COUNT, -1)], filter=flt)
+        want = oracle.execute(seg, spec).stats[1]
+        entries, plan, _ = replay(driver, seg, spec)
+        assert entries == want and plan == PLAN_REPLAY
+        got, states, inputs = fsm(driver, seg, spec, 0)
+        assert (got >= 0) == compiles, (got, states, inputs)
+        if compiles:
+            assert got == want == fsm(driver, seg, spec, 1)[0]

@@ -47,3 +47,17 @@ extern "C" int64_t fstats_fsm(const pg_query* q, int32_t num_docs, const uint64_
   if (mode == 3) return pg::fstats::fsm_count_perm8(f, words, num_docs);      // (fsm_tiles_perm8_kernel: up to eight states)
   return mode == 0 ? pg::fstats::fsm_count_sequential(f, words, num_docs) : pg::fstats::fsm_count_tiled(f, words, num_docs);
 }
+
+// Which of the device's walks a root AND takes (tools/kernel_coverage.py picks its machines with this): 0 when the shape does not compile
+// or is not a replayed plan; else 1 with the machine's states, inputs and the most entries one doc can cost (the byte-function walks carry
+// at most 7 per doc: pg_engine.hip device_fsm_filter_stats).
+extern "C" int32_t fstats_fsm_class(const pg_query* q, int32_t* out_states, int32_t* out_inputs, int32_t* out_max_inc) {
+  int scan_leaves = 0;
+  if (q->num_filter_nodes < 3 || pg::fstats::choose_plan(q, &scan_leaves) != pg::fstats::Plan::kReplay) return 0;
+  pg::fstats::Fsm f;
+  if (!pg::fstats::compile_fsm(q, &f)) return 0;
+  int max_inc = 0;
+  for (uint8_t d : f.delta) max_inc = std::max(max_inc, (int)(d >> 4));
+  *out_states = f.num_states; *out_inputs = f.num_inputs; *out_max_inc = max_inc;
+  return 1;
+}
