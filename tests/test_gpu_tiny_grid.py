@@ -2,7 +2,9 @@
 persistent kernel's tile loop then runs many times per wavefront on a 100 000-doc segment -- second tiles, carried accumulators, the
 records of waves that end early.  DESIGN.md 4.3f: `group_private_kernel`'s direct-table forms were wrong from a wave's second tile on and
 passed every test below 4.5 M docs on the full 256-CU grid for two rounds.  The WHOLE GPU suite passes under the switch
-(`PINOT_GPU_TEST_CUS=1 python -m pytest tests -m gpu`, profiles/r4/gpu_suite_one_cu_grid.txt); the driver's plain run gets this sample of it."""
+(`PINOT_GPU_TEST_CUS=1 python -m pytest tests -m gpu`, profiles/r4/gpu_suite_one_cu_grid.txt); the driver's plain run gets the whole fuzz
+(tests/test_gpu_fuzz.py, every seed) under this grid as well as the full one, the samples below, and tests/test_gpu_kernel_coverage.py --
+every kernel of the library dispatched under this grid and on a 12.3 M-doc segment."""
 import pytest
 
 import test_gpu_fuzz as F
@@ -18,12 +20,12 @@ def one_cu(monkeypatch):
     monkeypatch.setenv("PINOT_GPU_TEST_CUS", "1")
 
 
-@pytest.mark.parametrize("seed", [1, 6, 13, 20])
+@pytest.mark.parametrize("seed", list(range(24)))          # (round 5: every seed of the fuzz under both grids, not a sample of four)
 def test_random_segments_and_queries(engine, one_cu, seed):
     F.test_random_segments_and_queries(engine, seed)
 
 
-@pytest.mark.parametrize("seed", [2, 9])
+@pytest.mark.parametrize("seed", list(range(16)))
 def test_null_vectors_and_wide_group_bys(engine, one_cu, seed):
     F.test_random_null_vectors_null_handling_and_wide_group_bys(engine, seed)
 
