@@ -217,6 +217,13 @@ struct ScanParams {
   // (nullptr: that leaf is not wanted) -- so that the pass does not have to scan the leaves' columns again.
   uint32_t* leaf_out[kMaxLeaves];
   int32_t leaf_out_enabled;
+  // numEntriesScannedInFilter walked INSIDE the scan kernel (scan_private_fsm_kernel; pg_filter_fsm.h's transducer, machines of at most
+  // four states and four inputs): every leaf's mask of the tile is an input word, the tile's table {entry state -> exit state, entries}
+  // goes to fsm_tables[tile * fsm_states + s]; fsm_chain_kernel / fsm_finish_kernel join the tiles behind the scan.  Nothing else set: 0 states.
+  uint32_t* fsm_tables;
+  int32_t fsm_states, fsm_inputs;
+  int8_t fsm_input_of_leaf[kMaxLeaves];      // the transducer's input behind the filter's leaf of that ordinal (-1: none)
+  uint8_t fsm_delta[64];                     // [state << 4 | input]: next state | entries << 4 (pg_filter_fsm.h's delta, four input bits wide)
   int32_t lean_kind;               // pg_execute_batch: 0 the general lane-private body, 1 the item has scan_simple_kernel's shape, 2 scan_raw_kernel's
                                    // (scan_lean_batch_kernel runs those at five waves per SIMD)
 };

@@ -86,6 +86,7 @@ struct Engine {
   bool lean_batch = true;    // PINOT_GPU_LEAN_BATCH=0: items of scan_simple_kernel's shape share the general batch launch
   bool partition_two_level = true;   // PINOT_GPU_PARTITION_TWO_LEVEL=0: key spaces above one scatter pass keep the direct HBM atomics
   bool fsm_perm = true;      // PINOT_GPU_FSM_PERM=0: the transducer pass always walks tables (fsm_tiles_kernel), never byte functions
+  bool fsm_fused = true;     // PINOT_GPU_FSM_FUSED=0: the transducer always runs as a pass of its own behind the scan (leaf bitmaps through HBM)
   bool fsm_stats = true;     // PINOT_GPU_FSM_STATS=0: no transducer pass (host replay / upper bound)
   bool plan_cache = true;    // PINOT_GPU_PLAN_CACHE=0: pg_execute_batch lowers every item of every call
   bool batch_more = true;    // PINOT_GPU_BATCH_MORE=0: items of scan_narrow_kernel's / scan_private_typed_kernel's shape run their own launches
@@ -266,6 +267,12 @@ struct FsmSide {
   uint32_t* bitmap[pg::kFsmInputs] = {};        // where input i's doc-order bitmap goes
   bool mapped[pg::kFsmInputs] = {};             // the lowered filter has a LEAF node of its own for input i
   bool kernel_wrote = false;                    // the kernel that ran carries the store (eval_filter_private, no tile list)
+  // the rest of the pass's scratch (prepare_fsm_side), for the walk INSIDE the scan kernel (scan_private_fsm_kernel)
+  uint32_t* tables = nullptr;                   // [tiles * S] the tiles' tables
+  uint32_t* chunks = nullptr;                   // [chunks * S] fsm_chain_kernel's output
+  unsigned long long* entries = nullptr;        // fsm_finish_kernel's output
+  long long num_tiles = 0, num_chunks = 0;
+  bool fused = false;                           // out: the scan kernel walked the transducer itself; its count is in the context's pinned counter
 };
 
 namespace {
@@ -1637,6 +1644,7 @@ pg_status pg_init(const pg_config* config) {
   g_engine.partition_two_level = env_on("PINOT_GPU_PARTITION_TWO_LEVEL");
   g_engine.fsm_perm = env_on("PINOT_GPU_FSM_PERM");
   g_engine.fsm_stats = env_on("PINOT_GPU_FSM_STATS");
+  g_engine.fsm_fused = env_on("PINOT_GPU_FSM_FUSED");
   g_engine.plan_cache = env_on("PINOT_GPU_PLAN_CACHE");
   const char* bmo = getenv("PINOT_GPU_BATCH_MORE");
   g_engine.batch_more = !(bmo && bmo[0] == '0');
@@ -2738,6 +2746,35 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       sp.leaf_out_enabled = wrote ? 1 : 0;
       lw.side->kernel_wrote = wrote;
     }
+    // The transducer walked INSIDE the general lane-private kernel (scan_private_fsm_kernel): machines of at most four states over at most
+    // four inputs, every input a leaf of its own in the lowered filter.  No leaf bitmap is written or read back; the tiles' tables are
+    // joined by fsm_chain_kernel / fsm_finish_kernel behind the scan, on the query's stream.  PINOT_GPU_FSM_FUSED=0: the separate pass.
+    bool fuse_fsm = false;
+    sp.fsm_tables = nullptr; sp.fsm_states = 0; sp.fsm_inputs = 0;
+    // (NOT in scan_narrow_kernel: measured on `COUNT(*) WHERE p = 3 AND q = 5 AND r = 7` over 4 / 6 / 8-bit columns, 1 B rows -- the walk takes the
+    //  kernel from 164 to 199 registers, three to two waves per SIMD, 0.53 -> 0.85 ms, more than the 0.24 ms pass it replaces: 0.767 -> 0.868 ms
+    //  for the query; the same query through this kernel: 1.06 ms.  profiles/r5/fsm_walk_inside_the_scan_ab.txt)
+    if (lw.side != nullptr && sp.leaf_out_enabled != 0 && g_engine.fsm_fused && g_engine.fsm_perm && use_private && !use_hist && !use_narrow && !use_sparse && !use_simple && !use_raw && out) {
+      const fstats::Fsm& f = *lw.side->fsm;
+      int max_inc = 0;
+      for (uint8_t d : f.delta) max_inc = std::max(max_inc, (int)(d >> 4));
+      bool fits = f.num_states <= 4 && f.num_inputs <= 4 && max_inc <= 7;
+      for (int i = 0; i < f.num_inputs && fits; ++i) fits = lw.side->mapped[i];
+      if (fits) {
+        fuse_fsm = true;
+        sp.fsm_tables = lw.side->tables; sp.fsm_states = f.num_states; sp.fsm_inputs = f.num_inputs;
+        for (int l = 0; l < kMaxLeaves; ++l) {
+          sp.fsm_input_of_leaf[l] = -1;
+          for (int i = 0; i < f.num_inputs; ++i) if (sp.leaf_out[l] != nullptr && sp.leaf_out[l] == lw.side->bitmap[i]) sp.fsm_input_of_leaf[l] = (int8_t)i;
+          sp.leaf_out[l] = nullptr;
+        }
+        sp.leaf_out_enabled = 0;
+        memset(sp.fsm_delta, 0, sizeof(sp.fsm_delta));
+        for (int st8 = 0; st8 < f.num_states; ++st8)
+          for (int in = 0; in < (1 << f.num_inputs); ++in) sp.fsm_delta[(st8 << 4) | in] = f.delta[(size_t)((st8 << f.num_inputs) | in)];
+        if (!ctx->h_filter_entries) HIP_TRY(hipHostMalloc((void**)&ctx->h_filter_entries, 8, hipHostMallocDefault));
+      }
+    }
     sp.filter_entries = nullptr;
     sp.leap_tables = nullptr;
     if (count_leap2) { st = arm_leap_tables(seg, ctx, &sp.leap_tables, nullptr); if (st != PG_OK) return st; }
@@ -2858,7 +2895,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // record is a packet of its own on the queue, so a query that runs nothing but the scan kernel records just the two.
     // (the chain kernel / copy commands behind the scan kernel; a kernel that leaves leaf bitmaps behind for the transducer pass must have
     //  RETIRED before that pass reads them -- its plain stores are only ordered by the end of the kernel, not by the pinned record's seq)
-    const bool post_work = !g_engine.direct_result || count_leap2 || want_bitmap || sp.leaf_out_enabled;
+    const bool post_work = !g_engine.direct_result || count_leap2 || want_bitmap || sp.leaf_out_enabled || fuse_fsm;
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
     const bool one = pl.num_agg_cols <= 1;
@@ -2867,6 +2904,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     else if (use_sparse) launch_scan_sparse(one, blocks, ctx->stream, sp);
     else if (use_simple) launch_scan_simple(blocks, lean_threads, ctx->stream, sp);
     else if (use_raw) launch_scan_raw(blocks, lean_threads, ctx->stream, sp);
+    else if (use_private && fuse_fsm) launch_scan_private_fsm(pl.num_agg_cols, blocks, ctx->stream, sp);
     else if (use_private) launch_scan_private(pl.num_agg_cols, blocks, ctx->stream, sp);
     else if (use_private_typed) launch_scan_private_typed(pl.num_agg_cols, blocks, ctx->stream, sp);
     else launch_scan_agg(g_engine.use_dma, one, typed, blocks, geo.threads, lds, ctx->stream, sp);
@@ -2879,6 +2917,15 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
     if (!g_engine.direct_result) HIP_TRY(hipMemcpyAsync(ctx->h_partial, ctx->d_partials + blocks, sizeof(BlockPartial), hipMemcpyDeviceToHost, ctx->stream));
     if (count_leap2) { st = launch_leap_chain(seg, ctx, seq); if (st != PG_OK) return st; }
+    if (fuse_fsm) {
+      // the tiles' tables -> the count (the same two kernels that end the separate pass), then eight bytes to the context's pinned counter
+      const FsmSide& fs = *lw.side;
+      fsm_chain_kernel<<<dim3((unsigned)fs.num_chunks), dim3(1024), 0, ctx->stream>>>(fs.tables, fs.num_tiles, sp.fsm_states, fs.chunks);
+      HIP_TRY(hipGetLastError());
+      fsm_finish_kernel<<<dim3(1), dim3(1024), (size_t)fs.num_chunks * (size_t)sp.fsm_states * 4, ctx->stream>>>(fs.chunks, (int)fs.num_chunks, sp.fsm_states, fs.entries);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(ctx->h_filter_entries, fs.entries, 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (want_bitmap) {
       const int64_t need = ((int64_t)seg->num_docs + 63) / 64;
       if (d_out_bitmap_request) {
@@ -2918,6 +2965,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
     if (out_cardinality) *out_cardinality = (int64_t)fp.count;
     if (out) convert(fp, out);
+    if (out && fuse_fsm) {
+      // (the stream was synchronised: the walk's count is in the pinned counter)
+      out->stats.num_entries_scanned_in_filter = (int64_t)*ctx->h_filter_entries;
+      out->filter_entries_exact = 1;
+      lw.side->fused = true;
+    }
   } else {
     // ---------------- group-by (ArrayBasedHolder) ----------------
     GroupParams gp;
@@ -3958,6 +4011,11 @@ static pg_status prepare_fsm_side(pg_segment* seg, const fstats::Fsm& fsm, FsmSi
   *side = FsmSide();
   side->fsm = &fsm;
   for (int i = 0; i < fsm.num_inputs; ++i) side->bitmap[i] = reinterpret_cast<uint32_t*>(seg->d_fsm_scratch + lay.bitmap_bytes * (size_t)i);
+  uint8_t* at = seg->d_fsm_scratch + lay.bitmap_bytes * (size_t)fsm.num_inputs + lay.delta_bytes;
+  side->tables = reinterpret_cast<uint32_t*>(at); at += lay.tables_bytes;
+  side->chunks = reinterpret_cast<uint32_t*>(at); at += lay.chunk_bytes;
+  side->entries = reinterpret_cast<unsigned long long*>(at);
+  side->num_tiles = lay.tiles; side->num_chunks = lay.chunks;
   return PG_OK;
 }
 

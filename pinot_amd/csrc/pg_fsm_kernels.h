@@ -148,17 +148,15 @@ __global__ __launch_bounds__(256) void fsm_tiles_kernel(const FsmParams p) {
 // reading 64 random entries of a 256-byte row: ~5-way bank conflicts, ~100 LDS instructions per tile: 580 us per 1 B docs whatever the
 // VALU did).  The 64 lane functions are composed in lane order by a tree over ds_bpermute (no LDS storage, no conflicts), the entries
 // widened to 16 bits there (a tile: at most 2048 docs x 4 entries).
-template <int LMAX>
-__global__ __launch_bounds__(256) void fsm_tiles_perm_kernel(const FsmParams p) {
-  static_assert(LMAX <= 4, "two docs per lookup: an index of at most eight bits");
+// The walk's LDS tables, built by the whole workgroup (256 threads): `delta` [4 << LMAX] one doc: next | entries << 4, and `pair_fn`
+// [1 << 2 LMAX] two docs with that input index: x = next state of s in byte s, y = entries of s in byte s.  `src` is the machine's delta with
+// `src_shift` input bits per state (pg_filter_fsm.h: L; ScanParams.fsm_delta: 4), S states, L inputs.  Ends with __syncthreads().
+template <int LMAX, typename Src>
+__device__ __forceinline__ void fsm_perm_build_tables(Src src, int src_shift, int S, int L, uint8_t* delta, uint2* pair_fn) {
   constexpr int kIndexBits = 2 * LMAX;
-  __shared__ uint8_t delta[4 << LMAX];                               // one doc: next | entries << 4
-  __shared__ uint2 pair_fn[1 << kIndexBits];                         // two docs with input idx: x = next state of s in byte s, y = entries of s in byte s
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int L = p.num_inputs, S = p.num_states;
   for (int i = threadIdx.x; i < (4 << LMAX); i += blockDim.x) {
     const int st = i >> LMAX, in = i & ((1 << LMAX) - 1);
-    delta[i] = (st < S && in < (1 << L)) ? p.delta[(st << L) | in] : (uint8_t)0;
+    delta[i] = (st < S && in < (1 << L)) ? src[(st << src_shift) | in] : (uint8_t)0;
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < (1 << kIndexBits); idx += blockDim.x) {
@@ -173,13 +171,12 @@ __global__ __launch_bounds__(256) void fsm_tiles_perm_kernel(const FsmParams p) 
     pair_fn[idx] = make_uint2(next, inc);
   }
   __syncthreads();
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < p.num_tiles; tile += (long long)gridDim.x * 4) {
-    const long long first = tile * 2048 + lane * 32;
-    const long long rem = (long long)p.num_docs - first;
-    const int docs = rem >= 32 ? 32 : (rem <= 0 ? 0 : (int)rem);      // (docs past numDocs do not exist; the lanes of the last tile stop at different docs)
-    uint32_t w[LMAX];
-#pragma unroll
-    for (int i = 0; i < LMAX; ++i) w[i] = i < L ? p.leaf[i][tile * 64 + lane] : 0u;
+}
+
+// One 2048-doc tile: the lane's 32 docs (input words w[0 .. LMAX), `docs` of them exist) walked from every entry state, the 64 lane
+// functions composed in lane order; lane 0 leaves the tile's table in out[0 .. S).
+template <int LMAX>
+__device__ __forceinline__ void fsm_perm_tile(const uint32_t (&w)[LMAX], int docs, const uint8_t* delta, const uint2* pair_fn, int lane, int S, uint32_t* out) {
     uint32_t F = 0x03020100u, E = 0u;                                 // the identity; no entries
     if (__builtin_amdgcn_ballot_w64(docs != 32) == 0ull) {
       // the leaves' words regrouped once per tile so that a step's index is one bit-field extract per two leaves: nibble k of lo_even holds
@@ -235,9 +232,27 @@ __global__ __launch_bounds__(256) void fsm_tiles_perm_kernel(const FsmParams p) 
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const uint32_t e = ((c < 2 ? EA : EB) >> (16 * (c & 1))) & 0xFFFFu;
-        if (c < S) p.tables[tile * S + c] = ((F >> (8 * c)) & 3u) | (e << 4);
+        if (c < S) out[c] = ((F >> (8 * c)) & 3u) | (e << 4);
       }
     }
+}
+
+template <int LMAX>
+__global__ __launch_bounds__(256) void fsm_tiles_perm_kernel(const FsmParams p) {
+  static_assert(LMAX <= 4, "two docs per lookup: an index of at most eight bits");
+  __shared__ uint8_t delta[4 << LMAX];                               // one doc: next | entries << 4
+  __shared__ uint2 pair_fn[1 << (2 * LMAX)];                         // two docs with input idx: x = next state of s in byte s, y = entries of s in byte s
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = p.num_inputs, S = p.num_states;
+  fsm_perm_build_tables<LMAX>(p.delta, L, S, L, delta, pair_fn);
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < p.num_tiles; tile += (long long)gridDim.x * 4) {
+    const long long first = tile * 2048 + lane * 32;
+    const long long rem = (long long)p.num_docs - first;
+    const int docs = rem >= 32 ? 32 : (rem <= 0 ? 0 : (int)rem);      // (docs past numDocs do not exist; the lanes of the last tile stop at different docs)
+    uint32_t w[LMAX];
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) w[i] = i < L ? p.leaf[i][tile * 64 + lane] : 0u;
+    fsm_perm_tile<LMAX>(w, docs, delta, pair_fn, lane, S, p.tables + tile * S);
   }
 }
 

@@ -28,6 +28,7 @@
 
 #include "../../include/pinot_gpu.h"
 #include "pg_device.h"
+#include "pg_fsm_kernels.h"
 
 namespace pg {
 
@@ -1757,8 +1758,10 @@ static __global__ __launch_bounds__(1024) void leapfrog2_chain_kernel(const uint
 // `entries`: per-lane share of numEntriesScannedInFilter -- a kNodeCountEntries leaf is a scan-based child of the root AND that the
 // reference and-s into the docIds left by the children before it (ScanBasedDocIdIterator.applyAnd, AndDocIdSet.java:161-163,
 // SVScanDocIdIterator.java:115-145: one entry per doc of that bitmap).  On the AND chain the only mask on the stack is that bitmap.
-template <typename P>
-__device__ __forceinline__ uint32_t eval_filter_private(const P& p, long long tile, int lane, uint32_t& entries) {
+// kCollect: every leaf's own mask also goes to w[fsm_input_of_leaf[ordinal]] (the in-kernel transducer walk: scan_private_fsm_kernel) --
+// four registers picked with wave-uniform selects, no store to memory.
+template <bool kCollect = false, typename P>
+__device__ __forceinline__ uint32_t eval_filter_private(const P& p, long long tile, int lane, uint32_t& entries, uint32_t (*w)[4] = nullptr) {
   if (p.num_nodes == 0) return 0xFFFFFFFFu;
   if (p.num_nodes == 1) return eval_leaf_private(p, p.nodes[0], tile, lane);
   MaskStack st;
@@ -1775,6 +1778,11 @@ __device__ __forceinline__ uint32_t eval_filter_private(const P& p, long long ti
         entries += (uint32_t)__builtin_popcount(st.v[0] & (rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u))));
       }
       top = eval_leaf_private(p, nd, tile, lane);
+      if constexpr (kCollect) {
+        const int in = p.fsm_input_of_leaf[leaf_ordinal];                  // (uniform)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) (*w)[i] = in == i ? top : (*w)[i];
+      } else
       if (p.leaf_out_enabled != 0) {
         uint32_t* const leaf_bits = p.leaf_out[leaf_ordinal];          // (uniform: one scalar load)
         if (leaf_bits != nullptr) leaf_bits[tile * 64 + lane] = top;   // one coalesced 256-byte store per leaf and tile
@@ -1905,9 +1913,14 @@ struct PrivateAccLds {
 };
 template <>
 struct PrivateAccLds<1> { uint32_t unused; };          // the one-slot form keeps its accumulators in registers
-template <int kAggSlots, typename P>
+// kFsm: numEntriesScannedInFilter of a leap-frogging root AND is walked here, tile by tile, on the leaves' masks while they are still in
+// registers (fsm_perm_tile, pg_fsm_kernels.h: machines of at most four states and four inputs) -- the separate pass wrote every leaf's
+// bitmap to HBM and read it back (AndDocIdIterator.java:40-73 is what is being counted).  fsm_delta / fsm_pair: the walk's LDS tables.
+struct FsmWalkLds { uint8_t delta[64]; uint2 pair_fn[256]; };
+template <int kAggSlots, typename P, bool kFsm = false>
 __device__ __forceinline__ void scan_private_body(const P& p, const uint32_t block_index, const uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr,
-                                                  PrivateAccLds<kAggSlots>* acc_lds) {
+                                                  PrivateAccLds<kAggSlots>* acc_lds, FsmWalkLds* fsm_lds = nullptr) {
+  if constexpr (kFsm) fsm_perm_build_tables<4>(p.fsm_delta, 4, p.fsm_states, p.fsm_inputs, fsm_lds->delta, fsm_lds->pair_fn);
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
@@ -1956,9 +1969,16 @@ __device__ __forceinline__ void scan_private_body(const P& p, const uint32_t blo
       sum[0] += wsum;
       continue;
     }
-    uint32_t m = eval_filter_private(p, tile, lane, entries);
-    // docs past numDocs (last tile only)
+    uint32_t m;
     const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
+    if constexpr (kFsm) {
+      uint32_t fw[4] = {0u, 0u, 0u, 0u};
+      m = eval_filter_private<true>(p, tile, lane, entries, &fw);
+      fsm_perm_tile<4>(fw, rem >= 32 ? 32 : (rem <= 0 ? 0 : (int)rem), fsm_lds->delta, fsm_lds->pair_fn, lane, p.fsm_states, p.fsm_tables + tile * p.fsm_states);
+    } else {
+      m = eval_filter_private(p, tile, lane, entries);
+    }
+    // docs past numDocs (last tile only)
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
     if (p.out_bitmap) ((GlobalWordsOut)reinterpret_cast<uint32_t*>(p.out_bitmap))[tile * 64 + lane] = m;
     count += (unsigned)__builtin_popcount(m);
@@ -2022,6 +2042,16 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
   __shared__ uint32_t fold_flag;
   __shared__ PrivateAccLds<kAggSlots> acc;
   scan_private_body<kAggSlots>(p, blockIdx.x, gridDim.x, red, &fold_flag, &acc);
+}
+
+// The same kernel with the transducer walk inside (kFsm): a leap-frogging root AND of at most four leaves-as-inputs and four states.
+template <int kAggSlots>
+__global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_fsm_kernel(const ScanParams p) {
+  __shared__ BlockPartial red[kBlockThreads / 64];
+  __shared__ uint32_t fold_flag;
+  __shared__ PrivateAccLds<kAggSlots> acc;
+  __shared__ FsmWalkLds fsm_lds;
+  scan_private_body<kAggSlots, ScanParams, true>(p, blockIdx.x, gridDim.x, red, &fold_flag, &acc, &fsm_lds);
 }
 
 // Many queries, one launch (pg_execute_batch): workgroups [block_first[i], block_first[i + 1]) work on items[i] -- its own columns,

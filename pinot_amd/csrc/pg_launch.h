@@ -38,6 +38,9 @@ int waves_scan_agg(bool one_slot, bool typed);
 // scan_private_kernel<slots>: the lane-private scan -> filter -> aggregate kernel
 void launch_scan_private(int agg_cols, int blocks, hipStream_t stream, const ScanParams& p);      // instantiated for 1 and kMaxAggCols slots
 int waves_scan_private(int agg_cols);
+// scan_private_fsm_kernel<1 | kMaxAggCols>: the same with numEntriesScannedInFilter's transducer walked inside (ScanParams.fsm_*)
+void launch_scan_private_fsm(int agg_cols, int blocks, hipStream_t stream, const ScanParams& p);
+int waves_scan_private_fsm(int agg_cols);
 // scan_private_batch_kernel<slots>: many queries in one launch (pg_execute_batch); items / block_first are device memory
 void launch_scan_private_batch(bool one_slot, int total_blocks, hipStream_t stream, const ScanParams* items, const uint32_t* block_first, int num_items);
 // scan_sparse_kernel: aggregation of the docs one sparse bitmap names, eight tiles per wave and iteration (pg_scan_sparse.h)

@@ -150,6 +150,10 @@ def table(Q, n):
     add("group-staged-hbm-nodma", gnodma, "scan_group_kernel", Q.QuerySpec([(Q.SUM, V)], filter=f_lt(500), group_by=[K, K3]))
     add("group-staged-wide-nodma", gnodma, "scan_group_kernel", Q.QuerySpec([(Q.COUNT, -1)], filter=f_lt(30), group_by=[K1, K4]))
     # ---- numEntriesScannedInFilter on the device ----
+    and3 = Q.and_(f_lt(300), L(Q.Pred.dict_range(K, 0, 500)), L(Q.Pred.dict_range(K3, 100, 600)))
+    add("fsm-fused-1", {}, "scan_private_kernel", Q.QuerySpec([(Q.SUM, V)], filter=and3))                                    # scan_private_fsm_kernel<1>: the walk inside the scan
+    add("fsm-fused-4", {}, "scan_private_kernel", Q.QuerySpec([(Q.SUM, V), (Q.MAX, F), (Q.MIN, K)], filter=Q.and_(f_lt(300), Q.or_(L(Q.Pred.dict_range(K, 0, 100)), L(Q.Pred.dict_range(K3, 0, 50))))))
+    add("fsm-pass-behind-the-scan", {"PINOT_GPU_FSM_FUSED": "0"}, "scan_private_kernel", Q.QuerySpec([(Q.SUM, V)], filter=and3))
     add("leap2", {"PINOT_GPU_FSM_STATS": "0", "PINOT_GPU_EXACT_FILTER_STATS_DOCS": "0"}, None, Q.QuerySpec([(Q.SUM, V)], filter=Q.and_(f_lt(100), a_lt(50))))
     return T
 
