@@ -2120,6 +2120,12 @@ __host__ __device__ __forceinline__ uint32_t lds_group_table_bytes(const GroupPa
   return bytes;
 }
 
+// PG_GROUP_MINMAX_LOOK=1: an LDS MIN / MAX slot is READ first and the atomic issued only when the doc's value beats it (a slot's extreme
+// moves ~ln(n) times in n docs).  Measured on C3 (1 B rows, 1000 groups, SUM + MAX): 0.987 -> 1.028 ms -- the returning read and the
+// divergent branch cost more than the atomics they save (profiles/r5/c3_look_before_atomic_ab.txt).  Off.
+#ifndef PG_GROUP_MINMAX_LOOK
+#define PG_GROUP_MINMAX_LOOK 0
+#endif
 // One 2048-doc tile.  kMasked: only the docs whose bit is set in the lane's mask `m` reach the table (a filter's result, and /
 // or the docs that exist in the last, partial tile); otherwise every doc of the tile does, with no exec masking around the atomics.
 // GP: GroupParams, or its constant-address-space form in device memory (an item of group_lds_batch_kernel)
@@ -2131,6 +2137,11 @@ __device__ __forceinline__ void group_private_tile(const GP& gp, long long tile,
   uint32_t lds_off = 0u;                                                // uniform: where the next sub-table starts
   const long long first_doc = tile * 2048 + lane * 32;
   uint32_t g[32];
+  // (Round 5: the tile's columns are read one after the other -- three dependent HBM round trips per tile and wave, 72 % of a wave's cycles
+  //  are waits.  One "touch" load per later column ahead of the first decode, so that the later loads find their lines on the way or in
+  //  the L2, made C3 21 % SLOWER (0.985 -> 1.195 ms; profiles/r5/c3_touch_columns_ab.txt): loads return in order, the real loads queue
+  //  behind the touches, and the touches compete with the other fifteen waves' demand loads for the same queues.  Round 3 saw the same in
+  //  scan_private_kernel.  Latency is hidden by the resident waves, not inside a wave.)
   if constexpr (kHash) {
     // Long / ArrayMap holders: the 64-bit key of every (matching) doc, then its slot in the hashed table; sixteen docs at a time
 #pragma unroll
@@ -2233,18 +2244,32 @@ __device__ __forceinline__ void group_private_tile(const GP& gp, long long tile,
         for (int j = 0; j < 16; ++j)
           if (!kMasked || ((m >> (16 * h + j)) & 1u)) group_sum<kLds>(acc + (g[16 * h + j] << logR), (long long)(int32_t)d[j]);
       } else if (ga.kind == kGroupMin) {
+        // LDS table: LOOK before the atomic.  A slot's extreme moves ~ln(n) times in n docs (a few thousand docs per group, copy and
+        // workgroup: a handful of updates), so after the first tiles nearly every doc finds the slot already at or beyond its value and the
+        // read-modify-write -- the expensive LDS operation, serialised per bank -- is not issued at all.  A stale read only costs an atomic
+        // that changes nothing: the extreme is monotonic.  (PG_GROUP_MINMAX_LOOK=0 at compile time: the unconditional atomic of rounds 1-4.)
+        int32_t cur[16];
+        if constexpr (kLds && PG_GROUP_MINMAX_LOOK) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) cur[j] = __hip_atomic_load(acc32 + (g[16 * h + j] << logR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           if (!kMasked || ((m >> (16 * h + j)) & 1u)) {
-            if constexpr (kLds) __hip_atomic_fetch_min(acc32 + (g[16 * h + j] << logR), (int32_t)d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (kLds) { if (!PG_GROUP_MINMAX_LOOK || (int32_t)d[j] < cur[j]) __hip_atomic_fetch_min(acc32 + (g[16 * h + j] << logR), (int32_t)d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
             else group_min<false>(acc + g[16 * h + j], (int32_t)d[j]);
           }
         }
       } else {
+        int32_t cur[16];
+        if constexpr (kLds && PG_GROUP_MINMAX_LOOK) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) cur[j] = __hip_atomic_load(acc32 + (g[16 * h + j] << logR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           if (!kMasked || ((m >> (16 * h + j)) & 1u)) {
-            if constexpr (kLds) __hip_atomic_fetch_max(acc32 + (g[16 * h + j] << logR), (int32_t)d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (kLds) { if (!PG_GROUP_MINMAX_LOOK || (int32_t)d[j] > cur[j]) __hip_atomic_fetch_max(acc32 + (g[16 * h + j] << logR), (int32_t)d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
             else group_max<false>(acc + g[16 * h + j], (int32_t)d[j]);
           }
         }
@@ -2252,6 +2277,7 @@ __device__ __forceinline__ void group_private_tile(const GP& gp, long long tile,
     }
   }
 }
+
 
 // `block_index` of `num_blocks`: the workgroup's place among those that work on this parameter block (the whole grid, or one item's share
 // of group_lds_batch_kernel's launch).  gp.zero_identity: MIN / MAX reach the global table as keys whose identity is 0 (see the flush).

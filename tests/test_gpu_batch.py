@@ -122,7 +122,8 @@ def test_concurrent_batches_do_not_serialise(engine):
     heavy, small = _heavy_segment(), _segments()[:6]
     gh, gs = engine.open(heavy), [engine.open(s) for s in small]
     try:
-        hspecs = [Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(2, 0, 40 + i)), group_by=[1]) for i in range(32)]
+        # (round 5: these group-bys share ONE launch now -- 48 of them keep the call in the milliseconds the comparison below needs)
+        hspecs = [Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1)], filter=Q.leaf(Q.Pred.dict_range(2, 0, 40 + i)), group_by=[1]) for i in range(48)]
         sspecs = [_spec(seg, s, "sum") for s, seg in enumerate(small)]
         want_h = oracle.execute(heavy, hspecs[3])
         want_s = [oracle.execute(seg, sp) for seg, sp in zip(small, sspecs)]
