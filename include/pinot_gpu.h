@@ -337,9 +337,17 @@ void pg_result_free(pg_result* result);
  * Generator (core/query/aggregation/groupby/DefaultGroupByExecutor.java:106-121) --: *out_is_offset = 1 and the key value is
  * *out_base + entry (the column is grouped by through the stream of value - min; *out_base = the column's smallest value).
  * *out_null_entry: the entry that means NULL under PG_QUERY_NULL_HANDLING -- `cardinality` of a dictionary column, max - min + 1 of a raw
- * one (a column without a null value vector never produces it).  PG_ERR_UNSUPPORTED for a raw column pg_query_check declines as a group
- * key (FLOAT / DOUBLE, or a value range beyond an int). */
+ * one (a column without a null value vector never produces it).
+ * A raw FLOAT / DOUBLE column, or a raw INT / LONG column whose values span more than an int (NoDictionarySingleColumnGroupKeyGenerator.java:
+ * 100-135 keys all four stored types by value): *out_is_offset = 2 -- the column is grouped by through a dictionary of its own distinct
+ * values that the device builds the first time a query groups by it; the entry is the value's RANK among them, pg_group_key_values
+ * returns the values.  (Such a column is not a key under PG_QUERY_NULL_HANDLING: pg_query_check declines.) */
 pg_status pg_group_key_info(const pg_segment* segment, int32_t column, int64_t* out_base, int32_t* out_is_offset, int32_t* out_null_entry);
+/* The distinct values of a raw group-by column whose pg_group_key_info says *out_is_offset = 2, in ascending order (Double.compare's
+ * order for FLOAT / DOUBLE: -0.0 below 0.0, one NaN above +Infinity): out_value_bits[rank] = the long value (INT / LONG columns) or the
+ * IEEE-754 bits of the double (FLOAT values widened exactly, DOUBLE).  out_value_bits == NULL: only *out_count is set (sizing call).
+ * Builds the column's dictionary when no query has yet (one sort + unique pass over the resident column). */
+pg_status pg_group_key_values(pg_segment* segment, int32_t column, int64_t* out_value_bits, int32_t capacity, int32_t* out_count);
 
 /* One query over MANY resident segments in one call: what BaseCombineOperator does with a thread pool (core/operator/combine/
  * BaseCombineOperator.java:85-142: numTasks worker threads, each pulling the next segment's operator and merging its block; CombinePlanNode.java:

@@ -283,13 +283,19 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
     Dictionary[] dictionaries = new Dictionary[groupBy.size()];      // null: a raw key column (the no-dictionary key generators' case)
     long[][] keyInfo = new long[groupBy.size()][];
     boolean[] longKeys = new boolean[groupBy.size()];
+    long[][] rankValues = new long[groupBy.size()][];
+    FieldSpec.DataType[] storedTypes = new FieldSpec.DataType[groupBy.size()];
     String[] columnNames = new String[groupBy.size() + numFunctions];
     DataSchema.ColumnDataType[] columnTypes = new DataSchema.ColumnDataType[groupBy.size() + numFunctions];
     for (int i = 0; i < groupBy.size(); i++) {
       String column = groupBy.get(i).getIdentifier();
       dictionaries[i] = _indexSegment.getDataSource(column).getDictionary();
       keyInfo[i] = PinotGpuNative.groupKeyInfo(_segment.handle(), _segment.columnIndex(column));
-      longKeys[i] = _indexSegment.getDataSource(column).getDataSourceMetadata().getDataType().getStoredType() == FieldSpec.DataType.LONG;
+      storedTypes[i] = _indexSegment.getDataSource(column).getDataSourceMetadata().getDataType().getStoredType();
+      longKeys[i] = storedTypes[i] == FieldSpec.DataType.LONG;
+      if (keyInfo[i][1] == 2) {
+        rankValues[i] = PinotGpuNative.groupKeyValues(_segment.handle(), _segment.columnIndex(column));      // FLOAT / DOUBLE / wide INT / LONG raw key
+      }
       columnNames[i] = groupBy.get(i).toString();
       columnTypes[i] = DataSchema.ColumnDataType.fromDataTypeSV(_indexSegment.getDataSource(column).getDataSourceMetadata().getDataType());
     }
@@ -307,7 +313,7 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
       limitReached |= r._header[PinotGpuNative.PGM_H_NUM_GROUPS_LIMIT_REACHED] != 0;
     }
     DataSchema dataSchema = new DataSchema(columnNames, columnTypes);
-    GpuGroupKeyGenerator keys = new GpuGroupKeyGenerator(numGroups, groupKeys, dictionaries, keyInfo, longKeys, (int) upperBound);
+    GpuGroupKeyGenerator keys = new GpuGroupKeyGenerator(numGroups, groupKeys, dictionaries, keyInfo, longKeys, rankValues, storedTypes, (int) upperBound);
     // In-segment trim, exactly GroupByOperator.java:119-135: ORDER BY + minSegmentGroupTrimSize > 0 + more groups than the trim size
     int minGroupTrimSize = _queryContext.getMinSegmentGroupTrimSize();
     if (_queryContext.getOrderByExpressions() != null && minGroupTrimSize > 0) {

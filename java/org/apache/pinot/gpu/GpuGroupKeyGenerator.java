@@ -14,6 +14,9 @@ import org.apache.pinot.core.query.aggregation.groupby.GroupKeyGenerator;
 import org.apache.pinot.segment.spi.index.reader.Dictionary;
 
 
+import org.apache.pinot.spi.data.FieldSpec;
+
+
 final class GpuGroupKeyGenerator implements GroupKeyGenerator {
   private final int _numGroups;
   private final int[] _keyDictIds;            // [group * columns + column]
@@ -21,6 +24,8 @@ final class GpuGroupKeyGenerator implements GroupKeyGenerator {
   private final int[] _nullEntries;           // the entry that means NULL: cardinality, or a raw column's max - min + 1
   private final long[] _bases;                // raw key columns: key value = base + entry (pg_group_key_info)
   private final boolean[] _longKeys;          // raw key columns: stored type LONG (the key is a Long, else an Integer)
+  private final long[][] _rankValues;         // raw key columns keyed through a rank image (keyInfo isOffset 2): the values behind the entries
+  private final FieldSpec.DataType[] _storedTypes;
   private final int _globalUpperBound;
 
   /**
@@ -32,7 +37,8 @@ final class GpuGroupKeyGenerator implements GroupKeyGenerator {
    *                   null) is keyed by VALUE like NoDictionarySingleColumnGroupKeyGenerator.java:100-113 does -- base + entry
    * @param longKeys   per key column: the stored type is LONG
    */
-  GpuGroupKeyGenerator(int numGroups, int[] keyDictIds, Dictionary[] dictionaries, long[][] keyInfo, boolean[] longKeys, int globalUpperBound) {
+  GpuGroupKeyGenerator(int numGroups, int[] keyDictIds, Dictionary[] dictionaries, long[][] keyInfo, boolean[] longKeys, long[][] rankValues,
+      FieldSpec.DataType[] storedTypes, int globalUpperBound) {
     if (keyDictIds.length != numGroups * dictionaries.length) {
       throw new IllegalStateException("native result: " + keyDictIds.length + " key dictIds for " + numGroups + " groups of " + dictionaries.length + " columns");
     }
@@ -42,6 +48,8 @@ final class GpuGroupKeyGenerator implements GroupKeyGenerator {
     _nullEntries = new int[dictionaries.length];
     _bases = new long[dictionaries.length];
     _longKeys = longKeys;
+    _rankValues = rankValues;
+    _storedTypes = storedTypes;
     for (int i = 0; i < dictionaries.length; i++) {
       _bases[i] = keyInfo[i][0];
       _nullEntries[i] = (int) keyInfo[i][2];
@@ -98,6 +106,23 @@ final class GpuGroupKeyGenerator implements GroupKeyGenerator {
             keys[i] = null;
           } else if (_dictionaries[i] != null) {
             keys[i] = _dictionaries[i].getInternal(entry);
+          } else if (_rankValues[i] != null) {
+            // keyed by value through the device-built dictionary: the map key types of NoDictionarySingleColumnGroupKeyGenerator.java:100-135
+            long bits = _rankValues[i][entry];
+            switch (_storedTypes[i]) {
+              case INT:
+                keys[i] = (int) bits;
+                break;
+              case LONG:
+                keys[i] = bits;
+                break;
+              case FLOAT:
+                keys[i] = (float) Double.longBitsToDouble(bits);
+                break;
+              default:
+                keys[i] = Double.longBitsToDouble(bits);
+                break;
+            }
           } else if (_longKeys[i]) {
             keys[i] = _bases[i] + entry;               // Long
           } else {

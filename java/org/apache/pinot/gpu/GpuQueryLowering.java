@@ -200,8 +200,10 @@ final class GpuQueryLowering {
         // DefaultGroupByExecutor.java:106-121: the no-dictionary key generators (keys by value).  The device groups a raw INT / LONG
         // column through its key image (value - min as the dictId, include/pinot_gpu.h pg_group_key_info); whether the column's value
         // range allows one is pg_query_check's decision (GpuPlanMaker keeps the CPU plan on PG_ERR_UNSUPPORTED).
+        // (round 5: FLOAT / DOUBLE columns and INT / LONG columns over more than an int too -- through a dictionary the device builds from
+        //  the column's own values, PinotGpuNative.groupKeyValues; STRING / BYTES raw keys keep the CPU plan)
         DataType storedType = _indexSegment.getDataSource(expression.getIdentifier()).getDataSourceMetadata().getDataType().getStoredType();
-        if (storedType != DataType.INT && storedType != DataType.LONG) {
+        if (storedType != DataType.INT && storedType != DataType.LONG && storedType != DataType.FLOAT && storedType != DataType.DOUBLE) {
           throw new NotOffloadable("group-by on a raw " + storedType + " column (NoDictionary key generators)");
         }
       }

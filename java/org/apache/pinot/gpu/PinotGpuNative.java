@@ -150,10 +150,18 @@ public final class PinotGpuNative {
   /**
    * pg_group_key_info: {base, isOffset, nullEntry} of a group-by column -- a dictionary column's key entries are dictIds (isOffset 0); a raw
    * INT / LONG column's are offsets from its smallest value (isOffset 1, key value = base + entry: the reference's no-dictionary key
-   * generators key by value); nullEntry is the entry that means NULL under enableNullHandling.  Throws UnsupportedOperationException for a
-   * raw column without a key image.
+   * generators key by value); nullEntry is the entry that means NULL under enableNullHandling.  isOffset 2: see
+   * groupKeyValues.
    */
   static native long[] groupKeyInfo(long handle, int column);
+
+  /**
+   * pg_group_key_values: for a raw key column whose groupKeyInfo says isOffset 2 -- a FLOAT / DOUBLE column, or an INT / LONG column whose
+   * values span more than an int: the device keys it by value through a dictionary it builds from the column
+   * (NoDictionarySingleColumnGroupKeyGenerator.java:100-135) -- the column's distinct values in ascending order: the long values, or
+   * Double.doubleToRawLongBits of the (widened) doubles.  A key entry of such a column is an index into this array.
+   */
+  static native long[] groupKeyValues(long handle, int column);
 
   /** pg_query_check: PG_OK or PG_ERR_UNSUPPORTED; nothing is launched. */
   static native int queryCheck(long handle, int[] filterNodes, int[] predInts, long[] predLongs, int[] setOffsets, int[] setWords,

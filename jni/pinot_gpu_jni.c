@@ -135,6 +135,23 @@ JNIEXPORT jlongArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_groupKeyIn
   return out;
 }
 
+/* pg_group_key_values: the distinct values of a raw key column keyed through a rank image (groupKeyInfo's isOffset == 2), ascending, as
+ * long values or the bits of doubles. */
+JNIEXPORT jlongArray JNICALL Java_org_apache_pinot_gpu_PinotGpuNative_groupKeyValues(JNIEnv* env, jclass cls, jlong handle, jint column) {
+  (void)cls;
+  int32_t count = 0;
+  pg_status status = pg_group_key_values((pg_segment*)(intptr_t)handle, (int32_t)column, NULL, 0, &count);
+  if (status != PG_OK) { throw_status(env, status); return NULL; }
+  jlongArray out = (*env)->NewLongArray(env, count);
+  if (out == NULL || count == 0) return out;
+  jlong* values = (*env)->GetLongArrayElements(env, out, NULL);
+  if (values == NULL) return NULL;
+  status = pg_group_key_values((pg_segment*)(intptr_t)handle, (int32_t)column, (int64_t*)values, count, &count);
+  (*env)->ReleaseLongArrayElements(env, out, values, 0);
+  if (status != PG_OK) { throw_status(env, status); return NULL; }
+  return out;
+}
+
 /* The query arrays of pg_marshal.h, pinned for the duration of one call. */
 typedef struct pinned_query {
   jint *nodes, *pred_ints, *set_offsets, *set_words, *aggregations, *group_by;

@@ -1389,7 +1389,23 @@ static void holder_merge(po_holder* h, const po_holder* b, int func) {
   h->n += b->n;
 }
 
+/* Order-preserving 64-bit image of a raw value: INT / LONG v ^ 2^63; FLOAT (widened exactly) / DOUBLE in Double.compare's order (-0.0 below
+ * 0.0, every NaN the one canonical NaN above +Infinity: fastutil's Double2IntOpenHashMap keys by doubleToLongBits).  The digit of a raw
+ * FLOAT / DOUBLE / wide INT / LONG group-by column is the rank of its image among the column's distinct images (po_execute). */
+static uint64_t rank_order_image(const po_column* c, int32_t doc) {
+  const int t = c->desc->stored_type;
+  if (t == PG_TYPE_INT) return (uint64_t)(int64_t)raw_get_int(&c->raw, doc) ^ (1ull << 63);
+  if (t == PG_TYPE_LONG) return (uint64_t)raw_get_long(&c->raw, doc) ^ (1ull << 63);
+  double v = t == PG_TYPE_FLOAT ? (double)raw_get_float(&c->raw, doc) : raw_get_double(&c->raw, doc);
+  uint64_t b;
+  memcpy(&b, &v, 8);
+  if ((b & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull) b = 0x7FF8000000000000ull;
+  return (b >> 63) ? ~b : (b | (1ull << 63));
+}
+static int cmp_u64(const void* a, const void* b) { const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b; return x < y ? -1 : (x > y ? 1 : 0); }
+
 int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
+  uint64_t* rank_dict[PO_MAX_GROUP_COLS] = {0};       /* raw FLOAT / DOUBLE / wide key columns: the distinct order images, ascending */
   memset(res, 0, sizeof(*res));
   if (seg->num_docs < 0) PO_FAIL(1, "negative num_docs");
   int32_t num_docs = seg->num_docs;
@@ -1490,7 +1506,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
   int nullable_group_by = 0;      /* null handling with nulls in a key or an aggregated column: the no-dictionary generators' semantics */
   if (ng > PO_MAX_GROUP_COLS) { rc = 2; snprintf(po_error, sizeof(po_error), "too many group-by columns"); goto done; }
   int64_t key_base[PO_MAX_GROUP_COLS] = {0};
-  int key_raw[PO_MAX_GROUP_COLS] = {0};
+  int key_raw[PO_MAX_GROUP_COLS] = {0};      /* 1: digit = value - min; 2: digit = rank among the column's distinct values */
   int no_dict_keys = 0;           /* a key column without a dictionary: NoDictionarySingle / MultiColumnGroupKeyGenerator */
   for (int g = 0; g < ng; g++) {
     const pg_column_desc* d = &seg->columns[q->group_by_columns[g]];
@@ -1502,15 +1518,33 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
        * (:73-79).  Restated on the raw-key scale of the ABI (include/pinot_gpu.h, pg_group_key_info): the column's digit is
        * value - min, its digit count max - min + 1; INT / LONG columns whose range fits an int. */
       const po_column* kc = &cols[q->group_by_columns[g]];
-      if (d->stored_type != PG_TYPE_INT && d->stored_type != PG_TYPE_LONG) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by on raw FLOAT / DOUBLE column"); goto done; }
+      const int integral = d->stored_type == PG_TYPE_INT || d->stored_type == PG_TYPE_LONG;
       int64_t lo = INT64_MAX, hi = INT64_MIN;
-      for (int32_t doc = 0; doc < num_docs; doc++) {
+      for (int32_t doc = 0; integral && doc < num_docs; doc++) {
         const int64_t v = d->stored_type == PG_TYPE_INT ? (int64_t)raw_get_int(&kc->raw, doc) : raw_get_long(&kc->raw, doc);
         if (v < lo) lo = v;
         if (v > hi) hi = v;
       }
-      if (num_docs <= 0 || (uint64_t)(hi - lo) >= 0x7FFFFFFEull) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by on raw column: value range beyond an int"); goto done; }
-      key_base[g] = lo; key_raw[g] = 1; cards[g] = (int32_t)(hi - lo + 1); no_dict_keys = 1;
+      if (num_docs <= 0) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by on a raw column of an empty segment"); goto done; }
+      if (integral && (uint64_t)(hi - lo) < 0x7FFFFFFEull) {
+        key_base[g] = lo; key_raw[g] = 1; cards[g] = (int32_t)(hi - lo + 1); no_dict_keys = 1;
+      } else {
+        /* FLOAT / DOUBLE values, INT / LONG values over more than an int: NoDictionarySingleColumnGroupKeyGenerator.java:100-135 keys them by
+         * value all the same (Float / Double / Long2IntOpenHashMap).  On the ABI's raw-key scale the column's digit is the value's RANK
+         * among the column's distinct values, ascending in Double.compare's / Long.compare's order (include/pinot_gpu.h,
+         * pg_group_key_info: *out_is_offset = 2, pg_group_key_values) -- an order-preserving 64-bit image per doc, sorted, deduplicated. */
+        if (null_handling) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by on a raw FLOAT / DOUBLE / wide column under null handling"); goto done; }
+        uint64_t* img = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)num_docs);
+        for (int32_t doc = 0; doc < num_docs; doc++) img[doc] = rank_order_image(kc, doc);
+        rank_dict[g] = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)num_docs);
+        memcpy(rank_dict[g], img, sizeof(uint64_t) * (size_t)num_docs);
+        free(img);
+        qsort(rank_dict[g], (size_t)num_docs, sizeof(uint64_t), cmp_u64);
+        int64_t c = 0;
+        for (int32_t i = 0; i < num_docs; i++) if (i == 0 || rank_dict[g][i] != rank_dict[g][c - 1]) rank_dict[g][c++] = rank_dict[g][i];
+        if (c >= 0x7FFFFFFEll) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by on raw column: too many distinct values"); goto done; }
+        key_raw[g] = 2; cards[g] = (int32_t)c; no_dict_keys = 1;
+      }
     }
     /* DictionaryBasedGroupKeyGenerator.java:150-184: ArrayBasedHolder up to arrayBasedThreshold, IntMapBasedHolder while the product
      * fits an int, LongMapBasedHolder while it fits a long (:628-700), ArrayMapBasedHolder beyond (:808+).  The three map-based holders
@@ -1603,7 +1637,15 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
     if (ng > 0) {
       /* DictionaryBasedGroupKeyGenerator.ArrayBasedHolder.processSingleValue, :298-338 */
       for (int g = ng - 1; g >= 0; g--) {
-        if (key_raw[g]) {
+        if (key_raw[g] == 2) {
+          const po_column* kc = &cols[q->group_by_columns[g]];
+          for (int32_t i = 0; i < pos; i++) {
+            const uint64_t key = rank_order_image(kc, doc_ids[i]);
+            int32_t lo = 0, hi = cards[g] - 1;
+            while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (rank_dict[g][mid] < key) lo = mid + 1; else hi = mid; }
+            dict_scratch[i] = lo;
+          }
+        } else if (key_raw[g]) {
           const po_column* kc = &cols[q->group_by_columns[g]];
           const int is_int = kc->desc->stored_type == PG_TYPE_INT;
           for (int32_t i = 0; i < pos; i++) dict_scratch[i] = (int32_t)((is_int ? (int64_t)raw_get_int(&kc->raw, doc_ids[i]) : raw_get_long(&kc->raw, doc_ids[i])) - key_base[g]);
@@ -1808,6 +1850,7 @@ cleanup:
   free(holders); free(gholders); free(gavg_sum); free(gavg_cnt); free(gexact); free(gover); free(gcount); free(flags);
   free(map_keys); free(map_used); free(map_ids); free(raw_of_gid);
 done:
+  for (int g = 0; g < PO_MAX_GROUP_COLS; g++) free(rank_dict[g]);
   if (agg_nulls) for (int a = 0; a < q->num_aggregations; a++) free(agg_nulls[a]);
   free(agg_nulls);
   free(filter_words); free(it); free(cols);

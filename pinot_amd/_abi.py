@@ -108,6 +108,7 @@ ABI_SYMBOLS = [
     ("pg_execute", C.c_int, [C.c_void_p, _P(pg_query), _P(pg_result)]),
     ("pg_result_free", None, [_P(pg_result)]),
     ("pg_group_key_info", C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int64), _P(C.c_int32), _P(C.c_int32)]),
+    ("pg_group_key_values", C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int64), C.c_int32, _P(C.c_int32)]),
     ("pg_execute_batch", C.c_int, [_P(C.c_void_p), _P(_P(pg_query)), C.c_int32, _P(pg_result), _P(C.c_int)]),
     ("pg_filter_bitmap", C.c_int, [C.c_void_p, _P(pg_query), _P(C.c_uint64), C.c_int64, _P(C.c_int64)]),
     ("pg_read_dict_ids", C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), C.c_int32, _P(C.c_int32)]),

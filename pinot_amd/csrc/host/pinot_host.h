@@ -472,6 +472,7 @@ struct GpuAbi {
   decltype(&pg_result_free) result_free;
   decltype(&pg_filter_bitmap) filter_bitmap;
   decltype(&pg_group_key_info) group_key_info;
+  decltype(&pg_group_key_values) group_key_values;
 };
 const GpuAbi& gpuAbi();   // throws std::runtime_error when libpinot_gpu.so cannot be loaded (no fallback)
 

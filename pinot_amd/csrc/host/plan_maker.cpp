@@ -49,6 +49,7 @@ const GpuAbi& gpuAbi() {
     abi.result_free = (decltype(abi.result_free))sym("pg_result_free");
     abi.filter_bitmap = (decltype(abi.filter_bitmap))sym("pg_filter_bitmap");
     abi.group_key_info = (decltype(abi.group_key_info))sym("pg_group_key_info");
+    abi.group_key_values = (decltype(abi.group_key_values))sym("pg_group_key_values");
   });
   if (!error.empty()) throw std::runtime_error("pinot GPU engine unavailable (no CPU fallback in this library): " + error);
   return abi;
@@ -434,8 +435,10 @@ std::unique_ptr<LoweredQuery> lowerQuery(const ImmutableSegment& seg, const Quer
     if (!ds.hasDictionary) {
       // DefaultGroupByExecutor.java:106-121: the no-dictionary key generators (keys by value).  The device groups a raw INT / LONG column
       // through its key image (value - min as the dictId); whether the column's value range allows one is pg_query_check's decision.
-      if (ds.dataType != DataType::INT && ds.dataType != DataType::LONG)
-        throw UnsupportedOperationException("group-by on a raw " + std::string(ds.dataType == DataType::STRING ? "STRING" : "FLOAT / DOUBLE") + " column uses the no-dictionary key generator (CPU plan)");
+      // (round 5: FLOAT / DOUBLE columns and INT / LONG columns over more than an int too -- through a dictionary the device builds from the
+      //  column's own values, pg_group_key_values; NoDictionarySingleColumnGroupKeyGenerator.java:100-135 keys all four types by value)
+      if (ds.dataType == DataType::STRING)
+        throw UnsupportedOperationException("group-by on a raw STRING column uses the no-dictionary key generator (CPU plan)");
       lq->groupBy.push_back(seg.getColumnIndex(g));
       continue;
     }
@@ -575,6 +578,15 @@ class GpuAggregationOperator : public Operator {
       std::vector<int32_t> keyIsOffset(keyCols.size(), 0), keyNullEntry(keyCols.size(), 0);
       for (size_t j = 0; j < keyCols.size(); ++j)
         checkStatus(gpuAbi().group_key_info((const pg_segment*)_segment->handle(), _lowered->groupBy[j], &keyBase[j], &keyIsOffset[j], &keyNullEntry[j]), "reading the group keys");
+      // is_offset 2: the entry is the value's rank among the column's distinct values (a raw FLOAT / DOUBLE / wide INT / LONG key column)
+      std::vector<std::vector<int64_t>> keyValueBits(keyCols.size());
+      for (size_t j = 0; j < keyCols.size(); ++j) {
+        if (keyIsOffset[j] != 2) continue;
+        int32_t count = 0;
+        checkStatus(gpuAbi().group_key_values((pg_segment*)_segment->handle(), _lowered->groupBy[j], nullptr, 0, &count), "reading the group key values");
+        keyValueBits[j].assign((size_t)std::max(count, 1), 0);
+        checkStatus(gpuAbi().group_key_values((pg_segment*)_segment->handle(), _lowered->groupBy[j], keyValueBits[j].data(), (int32_t)keyValueBits[j].size(), &count), "reading the group key values");
+      }
       for (int i = 0; i < res.num_groups; ++i) {
         GroupKey key;
         key.groupId = res.group_ids[i];
@@ -588,6 +600,11 @@ class GpuAggregationOperator : public Operator {
           const int d = res.group_key_dict_ids[(size_t)i * nk + j];
           key.dictIds.push_back(d);
           if (d == keyNullEntry[j]) key.keys.emplace_back(std::monostate{});
+          else if (keyIsOffset[j] == 2) {
+            const int64_t bits = keyValueBits[j][(size_t)d];
+            if (ds->dataType == DataType::FLOAT || ds->dataType == DataType::DOUBLE) { double v; memcpy(&v, &bits, 8); key.keys.emplace_back(v); }
+            else key.keys.emplace_back(bits);
+          }
           else if (keyIsOffset[j]) key.keys.emplace_back((int64_t)(keyBase[j] + (int64_t)d));      // NoDictionary*GroupKeyGenerator: the key IS the value
           else if (ds->dataType == DataType::STRING) key.keys.emplace_back(ds->dictionary->getStringValue(d));
           else if (ds->dataType == DataType::FLOAT || ds->dataType == DataType::DOUBLE) key.keys.emplace_back(ds->dictionary->getDoubleValue(d));

@@ -28,6 +28,7 @@
 #include "pg_fsm_kernels.h"
 #include "pg_kernels.h"
 #include "pg_launch.h"
+#include "pg_rank_image.h"
 
 namespace {
 
@@ -159,6 +160,12 @@ struct ColumnDev {
   int key_image_of = -1;
   int64_t key_base = 0;
   int key_image_state = 0;              // 0 placeholder (no stream yet), 2 built; pg_segment::key_image_mu
+  // A raw column whose values do not fit the int dictId domain (FLOAT / DOUBLE, INT / LONG over more than 31 bits) gets a RANK image instead
+  // (pg_rank_image.h): a dictionary of its distinct values built on the device the first time it is grouped by, and every doc's rank in it.
+  // On the image: rank_image = true; cardinality / bits are 0 until it is built; h_rank_keys / d_rank_dict hold the order images of the values.
+  bool rank_image = false;
+  std::vector<unsigned long long> h_rank_keys;
+  unsigned long long* d_rank_dict = nullptr;
   bool borrows_dictionary = false;      // hidden image: d_dict / d_dict64 belong to the column it was made from
   int64_t num_nulls = 0;
   // value plane (built lazily on the device the first time the column is summed)
@@ -572,6 +579,7 @@ void free_segment(pg_segment* seg) {
     if (col.d_inv) (void)hipFree(col.d_inv);
     if (col.d_dir) (void)hipFree(col.d_dir);
     if (col.d_null_bitmap) (void)hipFree(col.d_null_bitmap);
+    if (col.d_rank_dict) (void)hipFree(col.d_rank_dict);
     if (col.plane_event) (void)hipEventDestroy(col.plane_event);
   }
   delete seg;
@@ -584,6 +592,25 @@ pg_status ensure_key_image(pg_segment* seg, int c, int* out_column) {
   if (col.keyimage_column < 0)
     return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s: only INT / LONG columns whose value range fits an int have a key image", col.name.c_str());
   ColumnDev& image = seg->cols[(size_t)col.keyimage_column];
+  if (image.rank_image && __atomic_load_n(&image.key_image_state, __ATOMIC_ACQUIRE) != 2) {
+    // the column's own dictionary and the docs' ranks in it: one sort + unique + binary-search pass, once per column and segment
+    std::lock_guard<std::mutex> lk(seg->key_image_mu);
+    if (image.key_image_state == 3) return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s: its distinct values do not fit the int dictId domain", col.name.c_str());
+    if (image.key_image_state != 2) {
+      HIP_TRY(hipSetDevice(phys_device(seg->device)));
+      uint8_t* d = nullptr;
+      size_t bytes = 0;
+      int bits = 0, card = 0;
+      const char* why = "";
+      const pg_status rst = build_rank_image(col.d_fwd, col.vkind, seg->num_docs, seg->num_tiles, seg->num_cus, &image.d_rank_dict, &image.h_rank_keys, &d, &bytes, &bits, &card, &why);
+      if (rst == PG_ERR_UNSUPPORTED) { image.key_image_state = 3; return fail(rst, "group-by on raw column %s: %s", col.name.c_str(), why); }
+      if (rst != PG_OK) return fail(rst, "group-by on raw column %s: %s", col.name.c_str(), why);
+      image.d_fwd_alloc = d; image.d_fwd = d; image.fwd_alloc_bytes = bytes;
+      image.bits = bits; image.cardinality = card;
+      seg->device_bytes += bytes + (size_t)card * 8;
+      __atomic_store_n(&image.key_image_state, 2, __ATOMIC_RELEASE);
+    }
+  }
   if (__atomic_load_n(&image.key_image_state, __ATOMIC_ACQUIRE) != 2) {
     std::lock_guard<std::mutex> lk(seg->key_image_mu);
     if (image.key_image_state != 2) {
@@ -1993,7 +2020,17 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
     long long* d_mm = nullptr;
     for (int i = 0; i < seg->num_user_cols; ++i) {
       ColumnDev& col = seg->cols[(size_t)i];
-      if (col.encoding != PG_FWD_RAW_FIXED_BYTE || (col.vkind != kValI32 && col.vkind != kValI64) || seg->num_docs <= 0) continue;
+      if (col.encoding != PG_FWD_RAW_FIXED_BYTE || seg->num_docs <= 0) continue;
+      auto rank_placeholder = [&] {
+        ColumnDev image;
+        image.name = col.name + "$rankimage";
+        image.stored_type = col.stored_type; image.encoding = PG_FWD_FIXED_BIT_DICT; image.vkind = kValI32;
+        image.cardinality = 0; image.bits = 0; image.rank_image = true;
+        image.key_image_of = i;
+        col.keyimage_column = (int)seg->cols.size();
+        seg->cols.push_back(std::move(image));
+      };
+      if (col.vkind != kValI32 && col.vkind != kValI64) { rank_placeholder(); continue; }      // FLOAT / DOUBLE: keyed by value through a rank image (pg_rank_image.h)
       long long mm[2] = {0x7FFFFFFFFFFFFFFFll, (long long)0x8000000000000000ull};
       hipError_t e = d_mm ? hipSuccess : hipMalloc((void**)&d_mm, 16);
       if (e == hipSuccess) e = hipMemcpy(d_mm, mm, 16, hipMemcpyHostToDevice);
@@ -2003,7 +2040,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       }
       if (e != hipSuccess) { if (d_mm) (void)hipFree(d_mm); return bail(fail(PG_ERR_DEVICE, "column %s: value range: %s", col.name.c_str(), hipGetErrorString(e))); }
       col.raw_min = mm[0]; col.raw_max = mm[1];
-      if ((unsigned long long)(mm[1] - mm[0]) >= 0x7FFFFFFEull) continue;      // cardinality max - min + 1 has to be an int (and leave room for a null digit)
+      if ((unsigned long long)(mm[1] - mm[0]) >= 0x7FFFFFFEull) { rank_placeholder(); continue; }      // max - min + 1 is not an int (with room for a null digit): a rank image instead
       ColumnDev image;
       image.name = col.name + "$keyimage";
       image.stored_type = col.stored_type; image.encoding = PG_FWD_FIXED_BIT_DICT; image.vkind = kValI32;
@@ -2017,6 +2054,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
     if (d_mm) (void)hipFree(d_mm);
     for (int i = 0; i < seg->num_user_cols; ++i) {
       if (seg->cols[(size_t)i].keyimage_column < 0 || !seg->cols[(size_t)i].d_null_bitmap) continue;
+      if (seg->cols[(size_t)seg->cols[(size_t)i].keyimage_column].rank_image) continue;      // (no null-key image of a rank image: such a key under null handling stays with the CPU plan)
       const pg_status kst = ensure_key_image(seg, i, nullptr);
       if (kst != PG_OK) return bail(kst);
     }
@@ -2028,7 +2066,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
   for (int i = 0; i < seg->num_user_cols; ++i) {
     if (!seg->cols[(size_t)i].d_null_bitmap) continue;
     const int src = seg->cols[(size_t)i].encoding == PG_FWD_FIXED_BIT_DICT ? i : seg->cols[(size_t)i].keyimage_column;
-    if (src < 0) continue;
+    if (src < 0 || seg->cols[(size_t)src].rank_image) continue;
     int bits_out = 1;
     while (bits_out < 31 && (1ll << bits_out) <= (long long)seg->cols[(size_t)src].cardinality) ++bits_out;      // PinotDataBitSet.getNumBitsPerValue(cardinality)
     ColumnDev image;
@@ -2091,8 +2129,31 @@ pg_status pg_group_key_info(const pg_segment* segment, int32_t column, int64_t* 
   const ColumnDev& col = segment->cols[(size_t)column];
   *out_base = 0; *out_is_offset = 0; *out_null_entry = col.cardinality;
   if (col.encoding == PG_FWD_FIXED_BIT_DICT) return PG_OK;
-  if (col.keyimage_column < 0) return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s: only INT / LONG columns whose value range fits an int have a key image", col.name.c_str());
-  *out_base = col.raw_min; *out_is_offset = 1; *out_null_entry = segment->cols[(size_t)col.keyimage_column].cardinality;
+  if (col.keyimage_column < 0) return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s: no key image", col.name.c_str());
+  const ColumnDev& image = segment->cols[(size_t)col.keyimage_column];
+  if (image.rank_image) {
+    // keyed by value through the column's own dictionary: an entry is a RANK, the values come from pg_group_key_values
+    *out_base = 0; *out_is_offset = 2; *out_null_entry = image.cardinality;
+    return PG_OK;
+  }
+  *out_base = col.raw_min; *out_is_offset = 1; *out_null_entry = image.cardinality;
+  return PG_OK;
+}
+
+pg_status pg_group_key_values(pg_segment* segment, int32_t column, int64_t* out_value_bits, int32_t capacity, int32_t* out_count) {
+  if (!segment || !out_count) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
+  if (column < 0 || column >= segment->num_user_cols) return fail(PG_ERR_INVALID_ARGUMENT, "column %d out of range", column);
+  ColumnDev& col = segment->cols[(size_t)column];
+  if (col.keyimage_column < 0 || !segment->cols[(size_t)col.keyimage_column].rank_image)
+    return fail(PG_ERR_INVALID_ARGUMENT, "column %s is not keyed through a rank image (pg_group_key_info: is_offset != 2)", col.name.c_str());
+  const pg_status st = ensure_key_image(segment, column, nullptr);
+  if (st != PG_OK) return st;
+  const ColumnDev& image = segment->cols[(size_t)col.keyimage_column];
+  *out_count = image.cardinality;
+  if (!out_value_bits) return PG_OK;                                   // (sizing call)
+  if (capacity < image.cardinality) return fail(PG_ERR_INVALID_ARGUMENT, "room for %d values, the column has %d distinct ones", capacity, image.cardinality);
+  const bool floating = col.vkind == kValF32 || col.vkind == kValF64;
+  for (int d = 0; d < image.cardinality; ++d) out_value_bits[d] = rank_image_value_bits(image.h_rank_keys[(size_t)d], floating);
   return PG_OK;
 }
 
@@ -2216,7 +2277,13 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
     if (seg->cols[(size_t)c].encoding != PG_FWD_FIXED_BIT_DICT) {
       // a raw INT / LONG column is grouped by through its key image (cardinality and width are known since open; nothing is built here)
       if (seg->cols[(size_t)c].keyimage_column < 0)
-        return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s: only INT / LONG columns whose value range fits an int have a key image", seg->cols[(size_t)c].name.c_str());
+        return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s: no key image", seg->cols[(size_t)c].name.c_str());
+      if (seg->cols[(size_t)seg->cols[(size_t)c].keyimage_column].rank_image) {
+        // a rank image's cardinality is what the plan is priced with: the column's dictionary is built here, the first time a query that
+        // groups by it is checked (once per column and segment; the one thing pg_query_check ever launches)
+        const pg_status rst = ensure_key_image(const_cast<pg_segment*>(seg), c, nullptr);
+        if (rst != PG_OK) return rst;
+      }
       c = seg->cols[(size_t)c].keyimage_column;
     }
     const ColumnDev& col = seg->cols[(size_t)c];

@@ -110,7 +110,17 @@ class GpuSegment:
         Result.group_keys; null_entry is the entry that means NULL under null handling."""
         base, is_offset, null_entry = C.c_int64(0), C.c_int32(0), C.c_int32(0)
         _abi.check(self.lib, self.lib.pg_group_key_info(self.handle, int(column), C.byref(base), C.byref(is_offset), C.byref(null_entry)))
-        return int(base.value), bool(is_offset.value), int(null_entry.value)
+        return int(base.value), int(is_offset.value), int(null_entry.value)
+
+    def group_key_values(self, column, dtype=None):
+        """pg_group_key_values: the distinct values of a raw group-by column keyed through a rank image (group_key_info's is_offset == 2),
+        ascending -- np.int64 values, or np.float64 when `dtype` is a floating type (the bits are those of the double)."""
+        n = C.c_int32(0)
+        _abi.check(self.lib, self.lib.pg_group_key_values(self.handle, int(column), None, 0, C.byref(n)))
+        out = np.zeros(max(int(n.value), 1), dtype=np.int64)
+        _abi.check(self.lib, self.lib.pg_group_key_values(self.handle, int(column), out.ctypes.data_as(C.POINTER(C.c_int64)), int(out.shape[0]), C.byref(n)))
+        out = out[: int(n.value)]
+        return out.view(np.float64) if dtype is not None and np.issubdtype(np.dtype(dtype), np.floating) else out
 
     def check(self, spec):
         """pg_query_check: the status pg_execute would return for eligibility reasons (0 = PG_OK, 2 = PG_ERR_UNSUPPORTED), nothing launched."""

@@ -497,6 +497,40 @@ def test_group_by_raw_key_columns_through_sql():
             seg.destroy()
 
 
+def test_group_by_raw_double_and_wide_long_key_columns_through_sql():
+    """Round 5: GROUP BY over a no-dictionary DOUBLE column and a LONG column spanning more than an int (NoDictionarySingleColumnGroupKey
+    Generator.java:100-135 keys them by value; the device through a dictionary it builds from each segment's column, pg_group_key_values):
+    the blocks' keys are the values, two segments with different value sets merge on the values."""
+    from pinot_amd import segment as S
+    rng = np.random.default_rng(23)
+    segs, values = [], []
+    try:
+        for s in range(2):
+            n = 20_000 + 11 * s
+            price = np.round(rng.normal(100.0 + 5 * s, 20.0, 300), 2)[rng.integers(0, 300, n)]
+            wide = (rng.integers(-40, 40, 70).astype(np.int64) * (2 ** 40 + 17 + s))[rng.integers(0, 70, n)]
+            d = rng.integers(0, 9, n).astype(np.int32)
+            v = rng.integers(0, 1000, n).astype(np.int32)
+            segs.append(host.HostSegment(S.SegmentData("rankkeys%d" % s, n, [S.Column.raw_typed("price", price.astype(np.float64)), S.Column.raw_typed("wide", wide),
+                                                                           S.Column.dict_encoded("d", d), S.Column.dict_encoded("v", v)])))
+            values.append((price, wide, d, v))
+        for key_cols, sql in ((("price",), "SELECT price, SUM(v), COUNT(*) FROM testTable GROUP BY price LIMIT 100000"),
+                              (("wide", "d"), "SELECT wide, d, SUM(v), COUNT(*) FROM testTable WHERE v < 700 GROUP BY wide, d LIMIT 100000")):
+            out = host.execute_sql(segs, sql)
+            want = {}
+            for price, wide, d, v in values:
+                cols = {"price": price, "wide": wide, "d": d}
+                mask = v < 700 if "WHERE" in sql else np.ones(len(v), bool)
+                for row, val in zip(zip(*[cols[c][mask].tolist() for c in key_cols]), v[mask].tolist()):
+                    acc = want.setdefault(tuple(row), [0.0, 0])
+                    acc[0] += val; acc[1] += 1
+            got = {tuple(g["key"]): g["final"] for g in out["combined"]["groups"]}
+            assert got == {k: [float(s), c] for k, (s, c) in want.items()}, sql
+    finally:
+        for seg in segs:
+            seg.destroy()
+
+
 def test_combine_through_one_batch_equals_one_execute_per_segment(golden_segments, monkeypatch):
     """executeCombined registers the segment operators of a query with ONE pg_execute_batch (GpuBatch in host/plan_maker.cpp: the first
     BaseCombineOperator task to ask for its block runs the batch, BaseCombineOperator.java:85-142); with

@@ -46,23 +46,25 @@ def test_no_dictionary_group_key_generators(engine, case):
         assert g.device_bytes() > before                                   # the key images are resident now (and counted)
 
 
-def test_key_columns_outside_the_key_image_keep_the_cpu_plan(engine):
-    """pg_query_check and pg_execute decline the same queries: a raw INT column whose value range is beyond an int, a raw DOUBLE column."""
+def test_key_columns_outside_the_key_image_are_keyed_through_a_rank_image(engine):
+    """Round 5: a raw INT column whose value range is beyond an int and a raw DOUBLE column were declined as group keys (PG_ERR_UNSUPPORTED);
+    they are keyed by value now, through a dictionary the device builds from the column (tests/test_gpu_rank_keys.py).  pg_query_check and
+    pg_execute still agree, pg_group_key_info says is_offset = 2.  Under null handling such a key keeps the CPU plan."""
     n = 5000
     rng = np.random.default_rng(3)
     wide = np.array([-(2 ** 31), 2 ** 31 - 1] + list(rng.integers(-1000, 1000, n - 2)), dtype=np.int32)
     v = S.Column.synthetic_uniform("v", n, np.arange(50, dtype=np.int32), seed=1)
-    seg = S.SegmentData("wide", n, [S.Column.raw("k", wide), S.Column.raw_typed("d", rng.random(n)), v])
+    seg = S.SegmentData("wide", n, [S.Column.raw("k", wide), S.Column.raw_typed("d", np.round(rng.random(n), 2)), v])
     with engine.open(seg) as g:
         for col in (0, 1):
-            spec = Q.QuerySpec([(Q.COUNT, -1)], group_by=[col])
-            assert g.check(spec) == _abi.PG_ERR_UNSUPPORTED
-            with pytest.raises(_abi.PinotGpuError) as e:
-                g.execute(spec)
-            assert e.value.status == _abi.PG_ERR_UNSUPPORTED
-            with pytest.raises(_abi.PinotGpuError):
-                g.group_key_info(col)
-        # the same columns are still aggregated, and a dictionary column is still grouped by
+            spec = Q.QuerySpec([(Q.COUNT, -1), (Q.MAX, 2)], group_by=[col])
+            assert g.check(spec) == _abi.PG_OK
+            got, want = g.execute(spec), oracle.execute(seg, spec)
+            H.assert_results_equal(got, want)
+            assert got.group_keys == want.group_keys
+            assert g.group_key_info(col)[1] == 2
+            nulls = Q.QuerySpec([(Q.COUNT, -1)], group_by=[col], null_handling=True)
+            assert g.check(nulls) == _abi.PG_OK                       # (no null vector in this segment: null handling changes nothing)
         got = g.execute(Q.QuerySpec([(Q.MAX, 0), (Q.COUNT, -1)], group_by=[2]))
         H.assert_results_equal(got, oracle.execute(seg, Q.QuerySpec([(Q.MAX, 0), (Q.COUNT, -1)], group_by=[2])))
 
