@@ -131,6 +131,10 @@ def main():
         # fewer HIP devices than --gpus: the N device ids alias the devices there are (id d -> HIP device d mod physical), each id with
         # its own batch contexts, streams and launches -- the multi-device code of pg_execute_batch runs on a one-GPU box (include/pinot_gpu.h pg_device_count)
         os.environ["PINOT_GPU_ALIAS_DEVICES"] = str(num_devices)
+    if os.environ.get("PINOT_BENCH_SHARE_GPUS") == "1":
+        # test switch: more ranks than GPUs (a one-GPU box running the driver's `torch.distributed.run --nproc-per-node N` line end to end:
+        # rendezvous, barrier, MAX over ranks, the gather of the partials, the merge) -- the ranks share the devices there are.  Not a measurement.
+        local_rank = local_rank % physical
     torch.cuda.set_device(local_rank)
     if world > 1:
         # no collective on the data path: gloo carries the barrier, the timing MAX and the 16-byte partials (no RCCL needed)
@@ -321,6 +325,7 @@ def main():
             "scaling": "strong",
             "process_model": ("one process drives all %d devices (segment s on device s mod N, one pg_execute_batch per step)" % num_devices) if single
                              else "one process per GPU (torch.distributed.run), gloo for the barrier / timing / 16-byte partials",
+            "ranks_share_gpus": os.environ.get("PINOT_BENCH_SHARE_GPUS") == "1" and world > physical,
             "aliased_devices": None if not aliased else {"device_ids": num_devices, "hip_devices": physical,
                                                             "note": "PINOT_GPU_ALIAS_DEVICES: the device ids share the physical GPU(s); not a scaling measurement"},
             "vs_baseline": None,

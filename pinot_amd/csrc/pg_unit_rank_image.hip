@@ -12,8 +12,6 @@
 
 namespace pg {
 
-namespace {
-
 __device__ __forceinline__ unsigned long long order_image_of_double_bits(unsigned long long b) {
   if ((b & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull) b = 0x7FF8000000000000ull;      // every NaN is Double.NaN
   return (b >> 63) ? ~b : (b | (1ull << 63));
@@ -29,13 +27,13 @@ __device__ __forceinline__ unsigned long long order_image(const uint8_t* __restr
   return order_image_of_double_bits(__builtin_bswap64(reinterpret_cast<const unsigned long long*>(raw)[doc]));
 }
 
-__global__ __launch_bounds__(256) void rank_image_keys_kernel(const uint8_t* __restrict__ raw, int vkind, long long num_docs, unsigned long long* __restrict__ out) {
+static __global__ __launch_bounds__(256) void rank_image_keys_kernel(const uint8_t* __restrict__ raw, int vkind, long long num_docs, unsigned long long* __restrict__ out) {
   for (long long doc = (long long)blockIdx.x * blockDim.x + threadIdx.x; doc < num_docs; doc += (long long)gridDim.x * blockDim.x) out[doc] = order_image(raw, vkind, doc);
 }
 
 // the rank of every doc's value in the sorted dictionary, packed MSB-first at `bits_out` bits per doc in the lane-private tile layout
 // (the same writer as build_raw_key_image_kernel: lane l of a tile owns docs [32 l, 32 l + 32), bits_out dwords)
-__global__ __launch_bounds__(256) void rank_image_pack_kernel(const uint8_t* __restrict__ raw, int vkind, const unsigned long long* __restrict__ dict, int cardinality,
+static __global__ __launch_bounds__(256) void rank_image_pack_kernel(const uint8_t* __restrict__ raw, int vkind, const unsigned long long* __restrict__ dict, int cardinality,
                                                               uint8_t* __restrict__ out, int bits_out, int num_tiles, long long num_docs) {
   const int lane = threadIdx.x & 63;
   for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < (long long)num_tiles; tile += (long long)gridDim.x * 4) {
@@ -61,8 +59,6 @@ __global__ __launch_bounds__(256) void rank_image_pack_kernel(const uint8_t* __r
     }
   }
 }
-
-}  // namespace
 
 pg_status build_rank_image(const uint8_t* d_raw, int vkind, long long num_docs, int num_tiles, int num_cus, unsigned long long** out_d_dict,
                            std::vector<unsigned long long>* out_h_dict, uint8_t** out_image, size_t* out_image_bytes, int* out_bits, int* out_cardinality,

@@ -14,10 +14,10 @@ LIMIT_BYTES = 7600            # the driver keeps an 8 KB tail; stay well inside 
 # keys of the printed line, in print order (the contract's keys first; `summary` stays the LAST key)
 HEAD_KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
              "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_all_cores", "parity", "cold_launch_ms",
-             "hbm_GBps_whole_step", "clock_settle_launches", "overlapped", "aliased_devices", "result", "setup", "process_model",
+             "hbm_GBps_whole_step", "clock_settle_launches", "overlapped", "aliased_devices", "ranks_share_gpus", "result", "setup", "process_model",
              "variants_file", "full_result_file"]
 # dropped first -> last when the line is still too long (the contract's keys and roofline / cpu_baseline are never dropped)
-DROP_ORDER = ["setup", "process_model", "result", "clock_settle_launches", "aliased_devices", "overlapped", "hbm_GBps_whole_step",
+DROP_ORDER = ["setup", "process_model", "result", "clock_settle_launches", "ranks_share_gpus", "aliased_devices", "overlapped", "hbm_GBps_whole_step",
               "cpu_baseline_all_cores", "cold_launch_ms", "parity"]
 # free text that explains a number: kept in the side file, cut from the line
 NOTE_KEYS = {"note", "frac_note", "empirical_peak_note", "traffic_source", "reference_jvm", "host_cores_available", "check_s",
