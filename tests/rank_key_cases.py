@@ -40,7 +40,8 @@ def build(case, seed=0):
             vals = pool[pick].astype(np.float64)
             cols.append(S.Column.raw_typed("k%d" % j, vals))
         elif typ == "float":
-            pool = np.concatenate([special_doubles().astype(np.float32), rng.normal(0, 1e3, distinct).astype(np.float32)])[:distinct]
+            with np.errstate(over="ignore"):           # (+-max of a double is +-inf as a float: wanted)
+                pool = np.concatenate([special_doubles().astype(np.float32), rng.normal(0, 1e3, distinct).astype(np.float32)])[:distinct]
             vals = pool[pick].astype(np.float32)
             cols.append(S.Column.raw_typed("k%d" % j, vals))
         elif typ == "wide-int":

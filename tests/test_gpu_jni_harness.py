@@ -132,3 +132,30 @@ def test_the_native_methods_over_the_golden_segment(engine, jvm):
     finally:
         jvm.call("segmentClose", None, C.c_int64(handle))
     assert jvm.lib.fj_pins() == 0 and jvm.lib.fj_live_refs() == refs_before and jvm.lib.fj_live_objects() == objects_before
+
+
+def test_group_key_values_of_a_rank_keyed_column_through_the_native_method(engine, jvm):
+    """Round 5: GROUP BY on a raw DOUBLE column -- groupKeyInfo says isOffset 2, groupKeyValues hands the column's distinct values over as
+    doubleToRawLongBits, ascending; the rows of execute() carry ranks into them (what GpuGroupKeyGenerator turns into Double keys)."""
+    import rank_key_cases as KC
+    seg, identities, specs = KC.build(("jni-double", 20_011, [("double", 60), ("dict", 9)]))
+    handle = jvm.segment_open(seg)
+    assert handle != 0
+    try:
+        assert jvm.query_check(handle, specs[0]) == _abi.PG_OK
+        got = jvm.execute(handle, specs[0])
+        info = jvm.call("groupKeyInfo", C.c_void_p, C.c_int64(handle), C.c_int32(0))
+        base, is_offset, null_entry = list(jvm.to_python(info))
+        jvm.release(C.c_void_p(info))
+        vals = jvm.call("groupKeyValues", C.c_void_p, C.c_int64(handle), C.c_int32(0))
+        values = np.asarray(jvm.to_python(vals), dtype=np.int64)
+        jvm.release(C.c_void_p(vals))
+        assert is_offset == 2 and null_entry == len(values) and np.array_equal(values, KC.rank_values(seg, 0))
+        want = oracle.execute(seg, specs[0])
+        keys = got[8].reshape(-1, 2)
+        assert sorted(map(tuple, keys.tolist())) == sorted(tuple(t) for t in want.group_keys)
+        # a dictionary column has no values to hand over
+        with pytest.raises(J.JavaException):
+            jvm.call("groupKeyValues", C.c_void_p, C.c_int64(handle), C.c_int32(1))
+    finally:
+        jvm.call("segmentClose", None, C.c_int64(handle))
