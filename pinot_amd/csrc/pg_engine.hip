@@ -91,6 +91,7 @@ struct Engine {
   bool fsm_stats = true;     // PINOT_GPU_FSM_STATS=0: no transducer pass (host replay / upper bound)
   bool plan_cache = true;    // PINOT_GPU_PLAN_CACHE=0: pg_execute_batch lowers every item of every call
   bool batch_more = true;    // PINOT_GPU_BATCH_MORE=0: items of scan_narrow_kernel's / scan_private_typed_kernel's shape run their own launches
+  bool group_one_launch = true;   // PINOT_GPU_GROUP_ONE_LAUNCH=0: pg_execute runs a small group-by as init + kernel + count + scan + compact launches (rounds 1-4)
   bool batch_group = true;   // PINOT_GPU_BATCH_GROUP=0: group-by items run their own launches on a worker thread
   bool batch_hist = true;    // PINOT_GPU_BATCH_HIST=0: items of scan_hist_kernel's shape run their own launch on a worker thread
   bool batch_launch = true;  // PINOT_GPU_BATCH_LAUNCH=0: pg_execute_batch runs every item as a pg_execute of its own on the worker threads (no shared launch)
@@ -1672,6 +1673,7 @@ pg_status pg_init(const pg_config* config) {
   g_engine.fsm_perm = env_on("PINOT_GPU_FSM_PERM");
   g_engine.fsm_stats = env_on("PINOT_GPU_FSM_STATS");
   g_engine.fsm_fused = env_on("PINOT_GPU_FSM_FUSED");
+  g_engine.group_one_launch = env_on("PINOT_GPU_GROUP_ONE_LAUNCH");
   g_engine.plan_cache = env_on("PINOT_GPU_PLAN_CACHE");
   const char* bmo = getenv("PINOT_GPU_BATCH_MORE");
   g_engine.batch_more = !(bmo && bmo[0] == '0');
@@ -2422,6 +2424,7 @@ struct Deferred {
   std::shared_ptr<const LoweredItem> item;
   std::unique_ptr<PlaneHold> planes;           // value planes the kernel reads stay held until the batch has run
   bool cacheable = false;                      // out of execute_impl: nothing about this lowering was provisional
+  bool single = false;                         // in: pg_execute's own call -- only a group-by of the LDS-table form is deferred (at any size), scans run as they always did
 };
 
 // The query's content as bytes: two queries with equal keys lower to the same item on the same segment.
@@ -2936,7 +2939,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       const bool hist_item = use_hist && !hist_guarded && g_engine.batch_hist;
       const bool narrow_item = use_narrow && g_engine.batch_more;
       const bool typed_item = use_private_typed && !use_raw && !use_sparse && g_engine.batch_more;
-      if (((use_private && !use_hist && !use_narrow) || use_raw || hist_item || narrow_item || typed_item) && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
+      if (!defer->single && ((use_private && !use_hist && !use_narrow) || use_raw || hist_item || narrow_item || typed_item) && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
           lw.side == nullptr && ((long long)seg->num_docs + 2047) / 2048 <= kBatchMaxTiles &&
           (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf)) {
         // items of scan_simple_kernel's / scan_raw_kernel's shape share a launch of their own kind (scan_lean_batch_kernel), the rest the general one
@@ -3232,7 +3235,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (defer != nullptr && g_engine.batch_group && use_private && gp.use_lds_table && hash_plan.kind == 0 && !first_appearance && !typed_direct && !want_bitmap && out &&
         lw.tile_list == nullptr && lw.side == nullptr && !lw.stats_leap2_flagged && !lw.stats_chain_flagged && !ctx->pre_enqueued &&
         (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf) &&
-        (long long)(q->num_groups_limit > 0 ? q->num_groups_limit : 100000) >= product && ((long long)seg->num_docs + 2047) / 2048 <= kBatchMaxTiles) {
+        (long long)(q->num_groups_limit > 0 ? q->num_groups_limit : 100000) >= product && (defer->single || ((long long)seg->num_docs + 2047) / 2048 <= kBatchMaxTiles)) {
       auto item = std::make_shared<LoweredItem>();
       item->gp = std::make_shared<GroupParams>(gp);
       item->gp->zero_identity = 1;
@@ -4214,7 +4217,7 @@ static pg_status execute_one(pg_segment* segment, const pg_query* query, pg_resu
   return st;
 }
 
-pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_result) { return execute_one(segment, query, out_result, nullptr); }
+// (pg_execute: below, behind the batch machinery -- a small group-by runs as a one-item launch of the batch's group-by kernel)
 
 // ---- pg_execute_batch ----
 namespace {
@@ -4704,6 +4707,43 @@ pg_status finish_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_res
 }
 
 }  // namespace
+
+// A group-by of the LDS-table form (key space up to the LDS table: the C3 shape) is ONE launch here too: the one-item form of the batch's
+// group_lds_batch_kernel -- no init_group_table_kernel, no count / scan / compact launches and the two waits between them; the item's
+// all-zero table slice comes back whole and the host keeps the slots whose count is not zero (§4.1k).  Its lowering is remembered in the
+// segment's plan cache like a batch item's.  Everything else takes execute_one as before.  PINOT_GPU_GROUP_ONE_LAUNCH=0: never.
+pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_result) {
+  if (!(g_engine.group_one_launch && g_engine.batch_launch && g_engine.batch_group && segment && query && out_result && query->num_group_by > 0 &&
+        !(query->flags & PG_QUERY_NULL_HANDLING) && g_engine.initialized))
+    return execute_one(segment, query, out_result, nullptr);
+  std::vector<Deferred> defs(1);
+  defs[0].single = true;
+  std::string key;
+  pg_status st = kDeferred;
+  const bool keyed = g_engine.plan_cache && query_key(query, &key);
+  if (keyed && cached_item(segment, key, &defs[0]) && defs[0].item->gp != nullptr) {
+    memset(out_result, 0, sizeof(*out_result));
+  } else {
+    defs[0] = Deferred();
+    defs[0].single = true;
+    std::shared_ptr<const OwnedQuery> copy;
+    const pg_query* q = query;
+    if (keyed && !key.empty()) { copy = own_query(query); q = &copy->q; }
+    st = execute_one(segment, q, out_result, &defs[0]);
+    if (st == kDeferred && copy && defs[0].cacheable) remember_item(segment, std::move(key), copy, &defs[0]);
+    else if (st == kDeferred && copy) std::const_pointer_cast<LoweredItem>(defs[0].item)->query = copy;
+    if (st != kDeferred) return st;                     // ran the usual way (or failed): nothing was deferred
+  }
+  DeferredLaunch L;
+  L.device = segment->device; L.lean_kind = 6; L.items.push_back(0);
+  pg_segment* const segs[1] = {segment};
+  pg_status item_status = PG_ERR_INTERNAL;
+  st = enqueue_deferred(&L, defs, segs);
+  if (st == PG_OK) st = finish_deferred(&L, defs, out_result, &item_status);
+  if (st == PG_OK) st = item_status;
+  if (st != PG_OK) pg_result_free(out_result);
+  return st;
+}
 
 pg_status pg_execute_batch(pg_segment* const* segments, const pg_query* const* queries, int32_t count, pg_result* results, pg_status* statuses) {
   if (!g_engine.initialized) return fail(PG_ERR_NOT_INITIALIZED, "pg_init has not been called");

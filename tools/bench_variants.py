@@ -162,7 +162,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
         del seg5, cols
 
     # ---- C1: 10 M rows, raw int32 forward index (BASELINE.json configs[0] is the reference's CPU case; COUNT(*) itself is O(1)) ----
-    if want("C1"):
+    if any(want(x) for x in ("C1-count-range", "C1-sum", "C1-count", "C1-group-by")):
         n1 = 10_000_000
         raw = S.Column.raw("raw_i32", S.synthetic_dict_ids(42, 0, n1, 1_000_000))
         seg1 = S.SegmentData("c1", n1, [raw])
@@ -172,6 +172,15 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
             report("C1-sum", "BASELINE.json configs[0], scan-forcing companion", "SELECT SUM(raw_i32) (10 M rows, raw)", n1, 4 * n1, g, seg1, Q.QuerySpec([(Q.SUM, 0)]))
             report("C1-count", "BASELINE.json configs[0] literally: O(1) in the reference (NonScanBasedAggregationOperator) and here", "SELECT COUNT(*) (10 M rows)", n1, 0, g, seg1,
                    Q.QuerySpec([(Q.COUNT, -1)]))
+        if want("C1-group-by"):
+            # the C3 query on ONE 10 M-row segment: since round 5 a single launch (the one-item form of the batch's group-by kernel)
+            kc = S.Column.synthetic_uniform("k", n1, np.arange(1000, dtype=np.int32) * 3, seed=31)
+            ac = S.Column.synthetic_uniform("a", n1, (np.arange(100000, dtype=np.int64) * 5 + 1).astype(np.int32), seed=32)
+            bc = S.Column.synthetic_uniform("b", n1, np.arange(65536, dtype=np.int32) * 2, seed=33)
+            segg = S.SegmentData("c1g", n1, [kc, ac, bc])
+            with engine.open(segg) as g:
+                report("C1-group-by", "BASELINE.json configs[2]'s query on one 10 M-row segment", "SELECT SUM(a), MAX(b) GROUP BY k (1000 groups, 10 M rows)", n1, B(kc) + B(ac) + B(bc), g, segg,
+                       Q.QuerySpec([(Q.SUM, 1), (Q.MAX, 2)], group_by=[0]))
     # ---- the small-segment regime: 64 segments of 10 M rows (BASELINE.json configs[0]'s size), one query over all of them ----
     # (a) pg_execute_batch: one launch, every segment folds its own result; (b) the way BaseCombineOperator would drive pg_execute: 16
     # host threads, each with the next segment, every pg_execute on a stream of its own; (c) one pg_execute after the other.
