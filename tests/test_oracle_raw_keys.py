@@ -51,12 +51,18 @@ def test_oracle_no_dictionary_group_key_generators(case):
         _check_against_numpy(seg, key_values, spec, got, base_of)
 
 
-def test_oracle_declines_key_columns_outside_the_key_image():
+def test_oracle_keys_columns_outside_the_key_image_by_rank():
+    """Round 5: a raw INT column whose range is beyond an int and a raw DOUBLE column are no longer declined -- they are keyed by value
+    on the rank scale (tests/test_oracle_rank_keys.py holds that restatement against numpy); under null handling they still are."""
     n = 1000
     rng = np.random.default_rng(3)
     wide = np.array([-(2 ** 31), 2 ** 31 - 1] + list(rng.integers(-1000, 1000, n - 2)), dtype=np.int32)
     v = S.Column.synthetic_uniform("v", n, np.arange(50, dtype=np.int32), seed=1)
-    seg = S.SegmentData("wide", n, [S.Column.raw("k", wide), S.Column.raw_typed("d", rng.random(n)), v])
-    for col in (0, 1):
+    seg = S.SegmentData("wide", n, [S.Column.raw("k", wide), S.Column.raw_typed("d", np.round(rng.random(n), 2)), v])
+    for col, values in ((0, wide.astype(np.int64)), (1, None)):
+        got = oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1)], group_by=[col]))
+        distinct = len(np.unique(values)) if values is not None else len(got.groups)
+        assert len(got.groups) == distinct and sum(vals[0].count for vals in got.groups.values()) == n
+        assert sorted(t[0] for t in got.group_keys) == list(range(distinct))              # every rank occurs once
         with pytest.raises(Exception):
-            oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1)], group_by=[col]))
+            oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1)], group_by=[col], null_handling=True))
