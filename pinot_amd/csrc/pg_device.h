@@ -223,6 +223,10 @@ struct ScanParams {
   uint32_t* fsm_tables;
   int32_t fsm_states, fsm_inputs;
   int8_t fsm_input_of_leaf[kMaxLeaves];      // the transducer's input behind the filter's leaf of that ordinal (-1: none)
+  // scan_sparse_kernel walks index_and_kernel's per-window tile masks directly (no tile list, no index_and_finalize_kernel in front of it)
+  const struct WindowInfo* sparse_windows;
+  int32_t sparse_num_windows;
+  int32_t reserved_sparse;
   uint8_t fsm_delta[64];                     // [state << 4 | input]: next state | entries << 4 (pg_filter_fsm.h's delta, four input bits wide)
   int32_t lean_kind;               // pg_execute_batch: 0 the general lane-private body, 1 the item has scan_simple_kernel's shape, 2 scan_raw_kernel's
                                    // (scan_lean_batch_kernel runs those at five waves per SIMD)
@@ -369,6 +373,8 @@ constexpr int kMaxAndChildren = 8;
 constexpr int kMaxAndPostings = 64;      // postings of all children together: one directory lookup per lane of the window's wavefront
 constexpr int kMaxChildPostings = 16;    // postings OR-ed into one child before it is expanded densely instead (EQ: 1; IN lists, short ranges)
 
+constexpr int kMaxAndGather = 2;              // IndexAndParams.gather_col
+constexpr int kAndCardinalityShards = 64;      // IndexAndParams.cardinality_out: this many counters, 16 words (128 bytes) apart
 struct WindowInfo { uint32_t tiles; uint32_t docs; };   // mask of the window's 32 2048-doc tiles that hold a match; matching docs
 
 struct AndChild {
@@ -388,6 +394,16 @@ struct IndexAndParams {
   long long num_words;                   // 64-bit words of the output bitmap (2048-doc tiles * 32)
   unsigned long long* out;               // doc-order result; nullptr = only the cardinality is wanted
   struct WindowInfo* window_info;        // [windows]
+  unsigned long long* cardinality_out;   // non-null: every window adds its matching docs to counter (window & 63) * 16 of these (the host keeps them at zero between queries): COUNT(*) over an
+                                         //   index-only filter is index_and_kernel and nothing else (FastFilteredCountOperator.java:66-72) -- no finalize launch
+  // The aggregation INSIDE this kernel (round 5): when the AND is expected to leave a handful of docs per window, the window's wave reads the
+  // survivors' values itself -- bit-packed fields of up to kMaxAndGather columns (dictIds for MIN / MAX, plane fields / arithmetic-progression
+  // dictIds for SUM: what scan_sparse_kernel reads) -- and adds them to gather_out: the cardinality counters' own lines, words 1 + 3 a ..: per column
+  // {sum, 2^32 - 1 - min, max} (all-zero identities), no bitmap is stored and no second kernel runs.  AndDocIdSet.java:127-172 + ProjectionOperator.
+  int32_t gather_cols;
+  int32_t reserved_gather;
+  DevAggCol gather_col[2];
+  unsigned long long* gather_out;
   AndChild child[kMaxAndChildren];
   int32_t first[kMaxAndPostings];        // directory slice [first, first + count) of every posting
   int32_t count[kMaxAndPostings];

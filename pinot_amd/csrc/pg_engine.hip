@@ -87,6 +87,7 @@ struct Engine {
   bool lean_batch = true;    // PINOT_GPU_LEAN_BATCH=0: items of scan_simple_kernel's shape share the general batch launch
   bool partition_two_level = true;   // PINOT_GPU_PARTITION_TWO_LEVEL=0: key spaces above one scatter pass keep the direct HBM atomics
   bool fsm_perm = true;      // PINOT_GPU_FSM_PERM=0: the transducer pass always walks tables (fsm_tiles_kernel), never byte functions
+  bool index_gather = true;  // PINOT_GPU_INDEX_GATHER=0: an index-led aggregation always runs scan_sparse_kernel behind index_and_kernel (never inside it)
   bool fsm_fused = true;     // PINOT_GPU_FSM_FUSED=0: the transducer always runs as a pass of its own behind the scan (leaf bitmaps through HBM)
   bool fsm_stats = true;     // PINOT_GPU_FSM_STATS=0: no transducer pass (host replay / upper bound)
   bool plan_cache = true;    // PINOT_GPU_PLAN_CACHE=0: pg_execute_batch lowers every item of every call
@@ -207,6 +208,8 @@ struct ExecCtx {
   unsigned long long seq = 0;                   // sequence number of the context's last launch (HostRecord.seq)
   bool pre_started = false;                     // timed runs: ev[0] has been recorded (some kernel runs before the scan)
   bool pre_enqueued = false;                    // something has been put on the stream ahead of the scan kernel (any run, timed or not)
+  bool and_counter_dirty = false;               // index_and_kernel's cardinality counters (d_and_counters[2 ...]) were added to and not yet zeroed again
+  unsigned long long* h_and_shards = nullptr;   // pinned: where the 64 counters land
   int ev_last = 3;                              // timed runs: the event that closes the query's device work (2 when nothing follows the scan kernel)
   std::vector<unsigned long long*> d_bitmaps;   // each num_tiles*32 words
   std::vector<uint32_t*> d_sets;
@@ -270,6 +273,8 @@ struct pg_segment {
 };
 
 // What a query's scan kernel leaves behind for the transducer pass: the bitmap of every input leaf it evaluated itself.
+constexpr size_t kAndShardBytes = (size_t)pg::kAndCardinalityShards * 128;
+
 struct FsmSide {
   const pg::fstats::Fsm* fsm = nullptr;
   uint32_t* bitmap[pg::kFsmInputs] = {};        // where input i's doc-order bitmap goes
@@ -287,6 +292,10 @@ namespace {
 
 void destroy_ctx(ExecCtx* c) {
   if (!c) return;
+  // (round 5: a COUNT(*) over an index-only filter leaves a memset of its counters on the stream BEHIND the answer -- nothing of the context
+  //  may be freed under it)
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->h_and_shards) (void)hipHostFree(c->h_and_shards);
   if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->h_record) (void)hipHostFree(c->h_record);
   if (c->d_done) (void)hipFree(c->d_done);
@@ -920,6 +929,17 @@ struct Lowered {
   bool stats_leap2_flagged = false;            // the root AND of two scan leaves carries kNodeLeapfrog2
   bool plane_pending = false;                  // a value plane this query wanted is still being built (or had no room): the lowering is not the one to keep
   bool cardinality_only_hint = false;          // in: the query is COUNT(*) only, so an index-only filter needs neither bitmap nor tile list
+  // index_and_finalize_kernel (window masks -> the ascending tile list, its length, the cardinality) is launched only when somebody reads its
+  // output: scan_sparse_kernel walks the window masks themselves and COUNT(*) takes the cardinality from index_and_kernel's own counter
+  bool finalize_pending = false;
+  bool cardinality_atomic = false;             // d_cardinality is the kernel's atomic counter (kept at zero between queries by whoever reads it)
+  unsigned finalize_windows = 0;
+  // index_and_kernel itself is launched when the planner knows what follows it (launch_index_and): a COUNT(*) wants its cardinality counters,
+  // an aggregation over a handful of survivors per window is done INSIDE it (gathered: no bitmap, no second kernel), everything else its
+  // bitmap and window masks.  Lowering only prepares the kernel's arguments.
+  bool and_pending = false, and_cardinality_only = false, gathered = false;
+  IndexAndParams and_params;
+  double and_expected_docs = 0;                // the planner's estimate of the AND's cardinality (independent postings)
   FsmSide* side = nullptr;                     // in: the transducer pass wants the leaves' bitmaps (ScanParams.leaf_out)
   uint32_t* sp_leaf_out[kMaxLeaves] = {};      // out: ScanParams.leaf_out, by LEAF node ordinal
 };
@@ -1087,7 +1107,53 @@ pg_status launch_leap_chain(const pg_segment* seg, ExecCtx* ctx, unsigned long l
   return PG_OK;
 }
 
+// index_and_kernel, launched when its consumer is known.  `gather_from`: the aggregation runs inside the kernel (ScanParams.agg_cols are the
+// columns it reads; no bitmap is stored); else the kernel leaves its bitmap / window masks (or, for COUNT(*), only its cardinality counters).
+pg_status launch_index_and(Lowered* lw, ExecCtx* ctx, const ScanParams* gather_from) {
+  if (!lw->and_pending) return PG_OK;
+  lw->and_pending = false;
+  IndexAndParams& ap = lw->and_params;
+  const unsigned num_windows = lw->finalize_windows;
+  if (lw->and_cardinality_only || gather_from != nullptr) {
+    // the windows add their matching docs (and, gathered, the survivors' values) to counters the host keeps at zero between queries
+    if (ctx->and_counter_dirty) HIP_TRY(hipMemsetAsync(ctx->d_and_counters + 2, 0, kAndShardBytes, ctx->stream));      // (a query that failed before it read them)
+    ap.cardinality_out = ctx->d_and_counters + 2;
+    ctx->and_counter_dirty = true;
+  }
+  if (gather_from != nullptr) {
+    ap.gather_cols = gather_from->num_agg_cols;
+    for (int a = 0; a < gather_from->num_agg_cols && a < kMaxAndGather; ++a) ap.gather_col[a] = gather_from->agg_cols[a];
+    ap.gather_out = ctx->d_and_counters + 2;       // (the cardinality counters' lines: words 1 ..)
+    ap.out = nullptr;                              // nobody reads a bitmap
+    lw->gathered = true;
+    lw->d_cardinality = ctx->d_and_counters + 2;
+    lw->cardinality_atomic = true;
+  }
+  if (num_windows) {
+    index_and_kernel<<<dim3(num_windows), dim3(64), 0, ctx->stream>>>(ap);
+    HIP_TRY(hipGetLastError());
+    // (index_and_finalize_kernel: only when the tile list is read -- complete_index_list)
+    lw->finalize_pending = !lw->and_cardinality_only && gather_from == nullptr;
+  } else if (!lw->and_cardinality_only && gather_from == nullptr) {
+    HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16, ctx->stream));
+  }
+  return PG_OK;
+}
+
+// The tile list of an index-led filter, for the kernels that read one (everything but scan_sparse_kernel): index_and_finalize_kernel behind
+// index_and_kernel, on the query's stream, the first time the list is asked for.
+pg_status complete_index_list(Lowered* lw, ExecCtx* ctx) {
+  { const pg_status ls = launch_index_and(lw, ctx, nullptr); if (ls != PG_OK) return ls; }
+  if (!lw->finalize_pending) return PG_OK;
+  lw->finalize_pending = false;
+  index_and_finalize_kernel<<<dim3((lw->finalize_windows + 255) / 256), dim3(256), 0, ctx->stream>>>(ctx->d_window_info, (int)lw->finalize_windows, ctx->d_tile_list,
+                                                                                                    reinterpret_cast<uint32_t*>(ctx->d_and_counters + 1), ctx->d_and_counters);
+  HIP_TRY(hipGetLastError());
+  return PG_OK;
+}
+
 pg_status complete_index_and_bitmap(Lowered* lw, ExecCtx* ctx) {
+  { const pg_status ls = launch_index_and(lw, ctx, nullptr); if (ls != PG_OK) return ls; }
   if (!lw->and_bitmap) return PG_OK;
   HIP_TRY(mark_pre_work(ctx));
   index_and_zero_unlisted_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>(lw->and_info, lw->and_bitmap, lw->and_words);
@@ -1247,7 +1313,14 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
         HIP_TRY(hipMalloc((void**)&ctx->d_tile_list, ctx->tile_list_capacity * 4));
         HIP_TRY(hipMalloc((void**)&ctx->d_window_info, ctx->window_info_capacity * sizeof(WindowInfo)));
       }
-      if (!ctx->d_and_counters) HIP_TRY(hipMalloc((void**)&ctx->d_and_counters, 16));
+      if (!ctx->d_and_counters) {
+        // [0] cardinality and [1] tile count (index_and_finalize_kernel's outputs), then index_and_kernel's own counters, zero between queries:
+        // 64 lines: word 0 the cardinality, words 1 .. 6 the gathered sums / extremes of up to two columns
+        HIP_TRY(hipMalloc((void**)&ctx->d_and_counters, 16 + kAndShardBytes));
+        HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16 + kAndShardBytes, ctx->stream));
+        HIP_TRY(hipHostMalloc((void**)&ctx->h_and_shards, kAndShardBytes, hipHostMallocDefault));
+        ctx->and_counter_dirty = false;
+      }
       IndexAndParams ap;
       memset(&ap, 0, sizeof(ap));
       ap.num_children = (int32_t)members.size();
@@ -1265,18 +1338,21 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
         }
         ap.child[c].posting_end = ap.num_postings;
       }
-      unsigned long long* d_cardinality = ctx->d_and_counters;
+      unsigned long long* d_cardinality = cardinality_only ? ctx->d_and_counters + 2 : ctx->d_and_counters;
       uint32_t* d_tile_count = reinterpret_cast<uint32_t*>(ctx->d_and_counters + 1);
       HIP_TRY(mark_pre_work(ctx));
-      if (num_windows) {
-        index_and_kernel<<<dim3(num_windows), dim3(64), 0, ctx->stream>>>(ap);
-        index_and_finalize_kernel<<<dim3((num_windows + 255) / 256), dim3(256), 0, ctx->stream>>>(ctx->d_window_info, (int)num_windows, cardinality_only ? nullptr : ctx->d_tile_list,
-                                                                                                  d_tile_count, d_cardinality);
-      } else {
-        HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16, ctx->stream));
+      // (the launch itself: launch_index_and, once the planner knows what reads the kernel's output)
+      lw->and_params = ap;
+      lw->and_pending = true;
+      lw->and_cardinality_only = cardinality_only;
+      lw->finalize_windows = num_windows;
+      {
+        double expected = (double)seg->num_docs;
+        for (const Member& mb : members) expected *= std::min(1.0, std::max(0.0, (double)mb.estimate) / std::max(1.0, (double)seg->num_docs));
+        lw->and_expected_docs = expected;
       }
-      HIP_TRY(hipGetLastError());
       lw->d_cardinality = d_cardinality;
+      lw->cardinality_atomic = cardinality_only;
       lw->index_and_is_whole_filter = seq.size() == 1;
       if (cardinality_only) { L.kind = kLeafMatchAll; depth++; max_depth = std::max(max_depth, depth); continue; }   // never evaluated: execute_impl answers from the cardinality
       L.kind = kLeafBitmap;
@@ -1673,6 +1749,7 @@ pg_status pg_init(const pg_config* config) {
   g_engine.fsm_perm = env_on("PINOT_GPU_FSM_PERM");
   g_engine.fsm_stats = env_on("PINOT_GPU_FSM_STATS");
   g_engine.fsm_fused = env_on("PINOT_GPU_FSM_FUSED");
+  g_engine.index_gather = env_on("PINOT_GPU_INDEX_GATHER");
   g_engine.group_one_launch = env_on("PINOT_GPU_GROUP_ONE_LAUNCH");
   g_engine.plan_cache = env_on("PINOT_GPU_PLAN_CACHE");
   const char* bmo = getenv("PINOT_GPU_BATCH_MORE");
@@ -2135,6 +2212,9 @@ pg_status pg_group_key_info(const pg_segment* segment, int32_t column, int64_t* 
   const ColumnDev& image = segment->cols[(size_t)col.keyimage_column];
   if (image.rank_image) {
     // keyed by value through the column's own dictionary: an entry is a RANK, the values come from pg_group_key_values
+    // (the NULL entry is the cardinality: known once the dictionary exists -- built here when no query has grouped by the column yet)
+    const pg_status rst = ensure_key_image(const_cast<pg_segment*>(segment), column, nullptr);
+    if (rst != PG_OK) return rst;
     *out_base = 0; *out_is_offset = 2; *out_null_entry = image.cardinality;
     return PG_OK;
   }
@@ -2602,10 +2682,21 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     bool only_count = true;
     for (int a = 0; a < na; ++a) only_count &= q->aggregations[a].function == PG_AGG_COUNT;
     if (only_count) {
+      st = launch_index_and(&lw, ctx, nullptr);
+      if (st != PG_OK) return st;
       unsigned long long* h_card = &ctx->h_partial->count;
-      HIP_TRY(hipMemcpyAsync(h_card, lw.d_cardinality, 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (lw.cardinality_atomic) HIP_TRY(hipMemcpyAsync(ctx->h_and_shards, lw.d_cardinality, kAndShardBytes, hipMemcpyDeviceToHost, ctx->stream));
+      else HIP_TRY(hipMemcpyAsync(h_card, lw.d_cardinality, 8, hipMemcpyDeviceToHost, ctx->stream));
       if (timed) { HIP_TRY(mark_pre_work(ctx)); HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
       HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (lw.cardinality_atomic) {
+        // the counters go back to zero behind the answer (nobody waits for this): the next COUNT(*) on this context starts from zero
+        HIP_TRY(hipMemsetAsync(ctx->d_and_counters + 2, 0, kAndShardBytes, ctx->stream));
+        ctx->and_counter_dirty = false;
+        unsigned long long total = 0ull;
+        for (int sh = 0; sh < kAndCardinalityShards; ++sh) total += ctx->h_and_shards[(size_t)sh * 16];
+        *h_card = total;
+      }
       const int64_t card = (int64_t)*h_card;
       out->num_aggregations = na;
       out->aggregations = (pg_agg_value*)calloc((size_t)na, sizeof(pg_agg_value));
@@ -2805,7 +2896,21 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if (st != PG_OK) return st;
       sp.out_bitmap = ctx->d_bitmaps[0];
     }
-    if (!want_bitmap && (use_hist || use_private || use_private_typed)) { sp.tile_list = lw.tile_list; sp.tile_count = lw.tile_count; }
+    sp.sparse_windows = nullptr; sp.sparse_num_windows = 0;
+    if (use_sparse) {
+      // A handful of survivors per window (the planner's estimate from the postings' sizes: independent predicates): index_and_kernel reads
+      // their values itself -- ONE launch for `SUM(v) WHERE p = 3 AND q = 5 AND r = 7` (BASELINE.json configs[4]); else scan_sparse_kernel
+      // walks the window masks behind it (no list, no index_and_finalize_kernel between the two kernels).  PINOT_GPU_INDEX_GATHER=0: never.
+      const bool gather = g_engine.index_gather && lw.and_pending && lw.index_and_is_whole_filter && out && pl.num_agg_cols <= kMaxAndGather &&
+                          lw.and_expected_docs <= 4.0 * (double)lw.finalize_windows;
+      st = launch_index_and(&lw, ctx, gather ? &sp : nullptr);
+      if (st != PG_OK) return st;
+      sp.tile_list = lw.tile_list; sp.tile_count = lw.tile_count;      // (not read by the kernel; "listed" is what the planner and the statistics go by)
+      sp.sparse_windows = lw.and_info; sp.sparse_num_windows = (int32_t)lw.finalize_windows;
+    } else if (!want_bitmap && (use_hist || use_private || use_private_typed)) {
+      st = complete_index_list(&lw, ctx); if (st != PG_OK) return st;
+      sp.tile_list = lw.tile_list; sp.tile_count = lw.tile_count;
+    }
     else { st = complete_index_and_bitmap(&lw, ctx); if (st != PG_OK) return st; }
     const bool count_leap2 = out && lw.stats_leap2_flagged && !use_narrow && (use_hist || use_private || use_private_typed);
     const bool count_entries = (out && lw.stats_chain_flagged && (use_hist || use_private || use_private_typed)) || count_leap2;
@@ -2853,7 +2958,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // (the entries counted by the kernel travel in its record: BlockPartial.entries -- no counter to zero, no copy command)
     // The folded record -> the reference's holder types.  Everything is captured by value: pg_execute_batch calls it after this function
     // has returned (the query, the segment and the context's pinned counter outlive the batch).
-    const int kernel_id = use_hist ? PG_KERNEL_SCAN_HIST : use_narrow ? PG_KERNEL_SCAN_NARROW : use_sparse ? PG_KERNEL_SCAN_SPARSE : use_simple ? PG_KERNEL_SCAN_SIMPLE : use_raw ? PG_KERNEL_SCAN_RAW : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
+    const int kernel_id = lw.gathered ? PG_KERNEL_INDEX_AND : use_hist ? PG_KERNEL_SCAN_HIST : use_narrow ? PG_KERNEL_SCAN_NARROW : use_sparse ? PG_KERNEL_SCAN_SPARSE : use_simple ? PG_KERNEL_SCAN_SIMPLE : use_raw ? PG_KERNEL_SCAN_RAW : use_private ? PG_KERNEL_SCAN_PRIVATE : (use_private_typed ? PG_KERNEL_SCAN_PRIVATE_TYPED : PG_KERNEL_SCAN_AGG);
     const HostRecord* host_record = ctx->h_record;
     const int profile_waves = blocks * (geo.threads / 64);
     const size_t num_projected = projected.size();
@@ -2965,6 +3070,31 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // record is a packet of its own on the queue, so a query that runs nothing but the scan kernel records just the two.
     // (the chain kernel / copy commands behind the scan kernel; a kernel that leaves leaf bitmaps behind for the transducer pass must have
     //  RETIRED before that pass reads them -- its plain stores are only ordered by the end of the kernel, not by the pinned record's seq)
+    if (lw.gathered) {
+      // index_and_kernel did the aggregation: its 64 + 64 lines of counters are the query's record
+      if (timed) { HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream)); HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream)); }
+      HIP_TRY(hipMemcpyAsync(ctx->h_and_shards, ctx->d_and_counters + 2, kAndShardBytes, hipMemcpyDeviceToHost, ctx->stream));
+      if (timed) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+      ctx->ev_last = 3;
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      HIP_TRY(hipMemsetAsync(ctx->d_and_counters + 2, 0, kAndShardBytes, ctx->stream));      // zero again behind the answer: nobody waits for this
+      ctx->and_counter_dirty = false;
+      BlockPartial g;
+      memset(&g, 0, sizeof(g));
+      for (int a = 0; a < kMaxAggCols; ++a) { g.kmin[a] = 0x7FFFFFFF; g.kmax[a] = (int32_t)0x80000000; }
+      const unsigned long long* cards = ctx->h_and_shards;
+      for (int sh = 0; sh < kAndCardinalityShards; ++sh) {
+        if (cards[(size_t)sh * 16] == 0ull) continue;
+        g.count += cards[(size_t)sh * 16];
+        for (int a = 0; a < pl.num_agg_cols; ++a) {
+          const unsigned long long* o = cards + (size_t)sh * 16 + 1 + 3 * a;
+          g.sum[a] += (long long)o[0];
+          g.kmin[a] = std::min(g.kmin[a], (int32_t)(0xFFFFFFFFu - (uint32_t)o[1]));
+          g.kmax[a] = std::max(g.kmax[a], (int32_t)(uint32_t)o[2]);
+        }
+      }
+      *ctx->h_partial = g;
+    } else {
     const bool post_work = !g_engine.direct_result || count_leap2 || want_bitmap || sp.leaf_out_enabled || fuse_fsm;
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     // the single-aggregated-column instantiation needs a third fewer registers (one more wavefront per SIMD)
@@ -3018,6 +3148,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
     if (count_leap2 && ctx->h_record->leap_seq != seq) return fail(PG_ERR_INTERNAL, "the leap-frog chain kernel did not publish its result");
     if (g_engine.direct_result && ctx->h_record->seq != seq) return fail(PG_ERR_INTERNAL, "the scan kernel's record carries sequence %llu, expected %llu", ctx->h_record->seq, seq);
+    }
     const BlockPartial& fp = *ctx->h_partial;
     // (the in-kernel fold orders the workgroups' records against their arrival counter through write-through stores, not through a
     //  release / acquire pair: every record carries its launch's stamp and a foreign one is an error, never an answer)
@@ -3225,6 +3356,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     gp.scan = sp;
     gp.scan.partials = nullptr;
     gp.scan.out_bitmap = nullptr;
+    if (lw.tile_list != nullptr) { st = complete_index_list(&lw, ctx); if (st != PG_OK) return st; }
     gp.scan.tile_list = lw.tile_list;            // read by group_private_kernel only
     gp.scan.tile_count = lw.tile_count;
     gp.scan.filter_entries = nullptr;
@@ -4359,6 +4491,7 @@ std::vector<BatchCtx*> g_batch_free;
 
 void destroy_batch_ctx(BatchCtx* b) {
   if (!b) return;
+  if (b->stream) (void)hipStreamSynchronize(b->stream);      // (the group-by tables are zeroed behind the answers)
   if (b->h_blob) (void)hipHostFree(b->h_blob);
   if (b->d_blob) (void)hipFree(b->d_blob);
   if (b->h_records) (void)hipHostFree(b->h_records);

@@ -2693,6 +2693,8 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
   // ---- the window's result: docs past numDocs cleared (an exclusive child sets them), words, tile mask, cardinality ----
   uint32_t tiles = 0u;
   uint32_t card = 0u;
+  unsigned long long gsum[kMaxAndGather] = {0ull, 0ull};       // gather mode: the survivors' values of this lane
+  uint32_t gmin[kMaxAndGather] = {0xFFFFFFFFu, 0xFFFFFFFFu}, gmax[kMaxAndGather] = {0u, 0u};
   const long long docs_left = (long long)ap.num_docs - base * 64;      // docs of the segment from this window on
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -2707,6 +2709,33 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
       }
     }
     card += (uint32_t)(__builtin_popcount(x.x) + __builtin_popcount(x.y) + __builtin_popcount(x.z) + __builtin_popcount(x.w));
+    if (ap.gather_cols != 0 && (x.x | x.y | x.z | x.w) != 0u) {
+      // the survivors' values, read here (a handful per window by the planner's estimate): doc -> (tile, lane, position) of the packed column
+      const uint32_t xs4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint32_t w = xs4[k];
+        while (w != 0u) {
+          const uint32_t j = (uint32_t)__builtin_ctz(w);
+          w &= w - 1u;
+          const long long doc = base * 64 + bit0 + 32 * k + (long long)j;
+#pragma unroll
+          for (int a = 0; a < kMaxAndGather; ++a) {
+            if (a < ap.gather_cols) {
+              const DevAggCol& gc = ap.gather_col[a];
+              const uint32_t b = (uint32_t)gc.bits, bit = ((uint32_t)doc & 31u) * b;
+              const uint32_t* at = reinterpret_cast<const uint32_t*>(gc.fwd + (doc >> 11) * (256ll * (long long)b)) + (((uint32_t)doc >> 5) & 63u) * b + (bit >> 5);
+              const Dwords2 d = *reinterpret_cast<const Dwords2*>(at);
+              const unsigned long long x64 = ((unsigned long long)__builtin_bswap32(d.x) << 32) | (unsigned long long)__builtin_bswap32(d.y);
+              const uint32_t v = (uint32_t)(x64 >> (64u - (bit & 31u) - b)) & ((1u << b) - 1u);
+              gsum[a] += v;
+              gmin[a] = v < gmin[a] ? v : gmin[a];
+              gmax[a] = v > gmax[a] ? v : gmax[a];
+            }
+          }
+        }
+      }
+    }
     // pair 2 (l + 64 i) lies in tile 4 i + (l >> 4)
     const unsigned long long nz = __builtin_amdgcn_ballot_w64((x.x | x.y | x.z | x.w) != 0u);
     // sparse output: only the tiles that hold a match are stored (the list-driven kernels read no others; anybody else calls
@@ -2717,7 +2746,29 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
     for (int g = 0; g < 4; ++g) if ((nz >> (16 * g)) & 0xffffull) tiles |= 1u << (4 * i + g);
   }
   const uint32_t total = (uint32_t)wave_sum_i64((long long)card);
-  if (lane == 0) ap.window_info[key] = WindowInfo{tiles, total};
+  if (lane == 0) {
+    ap.window_info[key] = WindowInfo{tiles, total};
+    // (kAndCardinalityShards counters, one 128-byte line each: ONE counter made the kernel 58 -> 194 us on C5-sparse -- ~3 700 same-address
+    //  device-scope atomics at ~37 ns apiece, each holding its wave's slot until it retires)
+    if (ap.cardinality_out != nullptr && total != 0u)
+      __hip_atomic_fetch_add(ap.cardinality_out + (size_t)(key & (kAndCardinalityShards - 1)) * 16, (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (ap.gather_cols != 0 && total != 0u) {
+#pragma unroll
+    for (int a = 0; a < kMaxAndGather; ++a) {
+      if (a >= ap.gather_cols) continue;
+      const unsigned long long s = (unsigned long long)wave_sum_i64((long long)gsum[a]);
+      // (keys are below 2^31: dictIds / plane fields -- the signed wave reductions take them as they are)
+      const uint32_t kmin = (uint32_t)wave_min_i32((int32_t)(gmin[a] == 0xFFFFFFFFu ? 0x7FFFFFFF : gmin[a]));
+      const uint32_t kmax = (uint32_t)wave_max_i32((int32_t)gmax[a]);
+      if (lane == 0) {
+        unsigned long long* o = ap.gather_out + (size_t)(key & (kAndCardinalityShards - 1)) * 16 + 1 + 3 * a;      // (word 0 of the line: the cardinality)
+        __hip_atomic_fetch_add(o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(o + 1, (unsigned long long)(0xFFFFFFFFu - kmin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(o + 2, (unsigned long long)kmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 // Completes a sparsely stored result (IndexAndParams.sparse_out) for a reader that does not go by the tile list: zeros in every

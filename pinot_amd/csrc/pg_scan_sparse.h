@@ -34,9 +34,9 @@ __global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_SPARSE_WAVES : 
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
   const long long total_waves = (long long)gridDim.x * waves_per_block;
-  const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
-  const bool listed = p.tile_list != nullptr;              // only the tiles index_and_kernel listed hold a match (and only they are stored)
-  const long long tile_limit = listed ? (long long)*p.tile_count : num_tiles;
+  // Round 5: the kernel walks index_and_kernel's per-WINDOW tile masks (p.sparse_windows: 32 tiles = 65 536 docs per window) instead of a
+  // tile list: the list cost a launch of its own between the two kernels (index_and_finalize_kernel: a prefix over the windows, ~10 us on a
+  // query of 86).  A wave takes windows round-robin; an empty window is one scalar load, a window's set tiles go eight at a time.
   const uint32_t* __restrict__ mask_words = p.nodes[0].set_words;      // the filter is ONE bitmap leaf: dword 64 * tile + lane = the lane's 32 docs
 
   unsigned long long count = 0;
@@ -45,20 +45,29 @@ __global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_SPARSE_WAVES : 
 #pragma unroll
   for (int a = 0; a < kAggSlots; ++a) { sum[a] = 0; umin[a] = 0xFFFFFFFFu; umax[a] = 0u; }
 
-  for (long long base = ((long long)blockIdx.x * waves_per_block + wave_in_block) * kSparseTiles; base < tile_limit; base += total_waves * kSparseTiles) {
+  // (a wave's next four windows' masks are loaded together: on the sparse AND nearly every window is empty and a wave's work is its chain of
+  //  mask loads -- four independent scalar loads instead of four dependent round trips)
+  constexpr int kAhead = 4;
+  for (long long window0 = (long long)blockIdx.x * waves_per_block + wave_in_block; window0 < (long long)p.sparse_num_windows; window0 += total_waves * kAhead) {
+   uint32_t ahead[kAhead];
+#pragma unroll
+   for (int k = 0; k < kAhead; ++k) ahead[k] = window0 + k * total_waves < (long long)p.sparse_num_windows ? p.sparse_windows[window0 + k * total_waves].tiles : 0u;
+#pragma unroll
+   for (int k = 0; k < kAhead; ++k) {
+   const long long window = window0 + k * total_waves;
+   uint32_t window_tiles = ahead[k];
+   while (window_tiles != 0u) {
     uint32_t tile[kSparseTiles];                              // (a segment has fewer than 2^20 tiles)
     uint32_t m[kSparseTiles];
+    bool in_use[kSparseTiles];
     // Every load below is UNCONDITIONAL (a lane or a tile with nothing to read points at an address that is always there): a load inside
     // an exec-masked branch is waited for before the branch is left, which made the eight loads of a round eight round trips.
-    if (listed) {
-      uint32_t listed_tile[kSparseTiles];
+    uint32_t last_tile = 0u;
 #pragma unroll
-      for (int i = 0; i < kSparseTiles; ++i) listed_tile[i] = p.tile_list[base + i < tile_limit ? base + i : tile_limit - 1];
-#pragma unroll
-      for (int i = 0; i < kSparseTiles; ++i) tile[i] = listed_tile[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < kSparseTiles; ++i) tile[i] = (uint32_t)(base + i < tile_limit ? base + i : tile_limit - 1);
+    for (int i = 0; i < kSparseTiles; ++i) {
+      in_use[i] = window_tiles != 0u;
+      if (in_use[i]) { last_tile = (uint32_t)window * 32u + (uint32_t)__builtin_ctz(window_tiles); window_tiles &= window_tiles - 1u; }
+      tile[i] = last_tile;                                   // (an unused slot repeats a tile of the window: its mask is dropped below)
     }
 #pragma unroll
     for (int i = 0; i < kSparseTiles; ++i) m[i] = mask_words[(long long)tile[i] * 64 + lane];
@@ -66,7 +75,7 @@ __global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_SPARSE_WAVES : 
     for (int i = 0; i < kSparseTiles; ++i) {
       const long long rem = (long long)p.num_docs - ((long long)tile[i] * 2048 + lane * 32);          // docs past numDocs (last tile only)
       m[i] &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
-      if (base + i >= tile_limit) m[i] = 0u;                                                // past the last tile of the list
+      if (!in_use[i]) m[i] = 0u;                                                            // fewer than eight tiles were left in the window
       count += (unsigned)__builtin_popcount(m[i]);
     }
     for (int a = 0; a < p.num_agg_cols; ++a) {
@@ -116,6 +125,8 @@ __global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_SPARSE_WAVES : 
         }
       }
     }
+   }
+   }
   }
 
   BlockPartial mine;

@@ -93,3 +93,32 @@ def test_window_edges(engine, n):
     with engine.open(seg) as g:
         for flt in (Q.and_(inv(0, 0), inv(1, 0)), Q.and_(Q.leaf(P.dict_range(0, 0, 1, exclusive=True, inverted=True)), inv(1, 0)), inv(0, card - 1)):
             check(g, seg, Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0), (Q.MAX, 1)], filter=flt))
+
+
+@pytest.mark.parametrize("n", [70_001, 2_300_017])
+def test_sparse_and_aggregated_inside_index_and_kernel(engine, n):
+    """Round 5: when the postings' sizes say the AND leaves a handful of docs per 65 536-doc window, index_and_kernel reads the survivors'
+    values itself (IndexAndParams.gather_*): ONE launch for `SUM(v) WHERE p = a AND q = b AND r = c` -- no bitmap, no scan_sparse_kernel
+    behind it (AndDocIdSet.java:127-172 + the projection of the surviving docs).  Same answers and statistics as the oracle; the denser
+    filters of the same query shape still take scan_sparse_kernel."""
+    rng = np.random.default_rng(n + 5)
+    p, idp, _ = H.random_dict_column(rng, "p", n, 16, with_inverted=True)
+    q, idq, _ = H.random_dict_column(rng, "q", n, 64, with_inverted=True)
+    r, idr, _ = H.random_dict_column(rng, "r", n, 256, with_inverted=True)
+    v, idv, dv = H.random_dict_column(rng, "v", n, 100000, value_stride=7)          # arithmetic progression: the dictId stream is the plane
+    f, idf, _ = H.random_dict_column(rng, "f", n, 1000, value_stride=3)
+    seg = S.SegmentData("ig", n, [p, q, r, v, f])
+    sparse = [Q.and_(inv(0, 3), inv(1, 5), inv(2, 7)), Q.and_(inv(1, 60), inv(2, 255)), Q.and_(inv(0, 15), inv(1, 0), inv(2, 100)),
+              Q.and_(inv(2, 1), inv(2, 2))]                                                                        # (disjoint: nothing survives)
+    with engine.open(seg) as g:
+        for flt in sparse:
+            for aggs in ([(Q.SUM, 3)], [(Q.COUNT, -1), (Q.SUM, 3), (Q.MIN, 3), (Q.MAX, 3), (Q.AVG, 3)], [(Q.SUM, 3), (Q.MAX, 4)], [(Q.MIN, 4), (Q.COUNT, -1)]):
+                got = check(g, seg, Q.QuerySpec(aggs, filter=flt), kernel="index_and_kernel")
+                again = g.execute(Q.QuerySpec(aggs, filter=flt))                   # the counters were zeroed behind the first answer
+                H.assert_results_equal(again, oracle.execute(seg, Q.QuerySpec(aggs, filter=flt)))
+            check(g, seg, Q.QuerySpec([(Q.COUNT, -1)], filter=flt), kernel="index_and_kernel")       # COUNT(*): the cardinality counters alone
+            # three aggregated columns: more than the kernel gathers -> the two-kernel path
+            check(g, seg, Q.QuerySpec([(Q.SUM, 3), (Q.MAX, 4), (Q.MIN, 0)], filter=flt))
+        dense = Q.and_(inv(0, 3), inv(1, 5))                                       # 1 / 1024 of the docs: 64 per window -> scan_sparse_kernel
+        got = check(g, seg, Q.QuerySpec([(Q.SUM, 3)], filter=dense))
+        assert got.dominant_kernel in ("scan_sparse_kernel", "index_and_kernel")

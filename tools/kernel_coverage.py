@@ -104,6 +104,9 @@ def table(Q, n):
     # ---- index-led ----
     add("sparse-1", {}, None, Q.QuerySpec([(Q.SUM, V)], filter=and3_inv))
     add("sparse-4", {}, None, Q.QuerySpec([(Q.SUM, V), (Q.MAX, F), (Q.MIN, K)], filter=and3_inv))
+    eq3 = Q.and_(inv(X, 3, 4), inv(Y, 5, 6), inv(Z, 7, 8))                        # ~1 survivor per window: aggregated inside index_and_kernel
+    add("index-gather-1", {}, "index_and_kernel", Q.QuerySpec([(Q.SUM, V), (Q.COUNT, -1)], filter=eq3))
+    add("index-gather-2", {}, "index_and_kernel", Q.QuerySpec([(Q.SUM, V), (Q.MAX, F), (Q.MIN, V)], filter=eq3))
     add("index-count", {}, None, Q.QuerySpec([(Q.COUNT, -1)], filter=and3_inv))
     add("index-or-scan", {}, None, Q.QuerySpec([(Q.SUM, V)], filter=Q.or_(inv(X, 3, 5), f_lt(20))))
     add("index-and-scan", {}, None, Q.QuerySpec([(Q.SUM, V), (Q.SUM, RL)], filter=Q.and_(inv(X, 3, 20), inv(Y, 0, 30), f_lt(500))))
