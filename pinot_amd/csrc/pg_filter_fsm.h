@@ -42,14 +42,27 @@ struct Fsm {
   std::vector<int> input_predicate;    // [L] predicate index behind every input bit
   int num_states = 0;                  // S; state 0 is where doc 0 is entered
   std::vector<uint8_t> delta;          // [S << L] next state | entries << 4
+  // A NOT child over a scan leaf (see "NOT children" below): the batches its leaf scans are charged per EPISODE, not per doc.
+  std::vector<uint8_t> marks;          // [S << L] kMarkOpen / kMarkClose / 0; empty when the machine has no episodes
+  uint32_t pending_states = 0;         // bit s: in state s an episode is open (the leaf's next() is scanning ahead) -- what the end of the docs closes
+  bool has_episodes() const { return !marks.empty(); }
 };
+constexpr uint8_t kMarkOpen = 1, kMarkClose = 2;
+
+// What an episode costs: the leaf's next() scans whole batches of kScanBatch = 256 docs (pg_filter_stats.h) from `origin` until the batch that holds the first match it
+// does not hand on (`close`; num_docs: there is none) -- SVScanDocIdIterator.java:76-98, the last batch stops at numDocs.
+inline int64_t episode_entries(int64_t origin, int64_t close, int64_t num_docs) {
+  if (origin >= num_docs) return 0;
+  if (close >= num_docs) return num_docs - origin;
+  return std::min<int64_t>(((close - origin) / kScanBatch + 1) * kScanBatch, num_docs - origin);
+}
 
 namespace fsm_detail {
 
 struct Leaf { int input; bool scan; };                       // a leaf as the walk sees it: which input bit, and whether looking at a doc costs an entry
 struct Child {
-  enum Kind { kSet, kScan, kOr } kind = kSet;
-  std::vector<Leaf> members;                                  // kSet: the leaves and-ed into it (one, or the merged ones); kScan: one leaf; kOr: its members
+  enum Kind { kSet, kScan, kOr, kNot } kind = kSet;
+  std::vector<Leaf> members;                                  // kSet: the leaves and-ed into it (one, or the merged ones); kScan: one leaf; kOr: its members; kNot: the leaf under it
   std::vector<int> open_bit;                                  // kOr: per member, its bit in the state's open mask (-1: an index-based member)
 };
 struct Model {
@@ -60,15 +73,32 @@ struct Model {
 };
 
 inline bool contains(const Child& c, unsigned input) {
+  if (c.kind == Child::kNot) return !((input >> c.members[0].input) & 1u);
   if (c.kind == Child::kOr) { for (const Leaf& l : c.members) if ((input >> l.input) & 1u) return true; return false; }
   for (const Leaf& l : c.members) if (!((input >> l.input) & 1u)) return false;
   return true;
 }
 
-struct State { int leader; int fresh; unsigned open; };
-inline bool operator<(const State& a, const State& b) { return std::tie(a.leader, a.fresh, a.open) < std::tie(b.leader, b.fresh, b.open); }
+// NOT children (NotDocIdIterator.java:36-76 over SVScanDocIdIterator.java:76-112).  The iterator knows ONE doc of its leaf ahead
+// (_nextNonMatchingDocId).  Asked about a doc behind that one it answers without touching the leaf; asked about that very doc (or walking
+// over it while it leads: the while loop of next()) it HANDS IT ON and pulls the leaf's next(), which scans whole 256-doc batches from
+// where the leaf stands; asked about a doc beyond it, it advance()s the leaf -- doc by doc to the leaf's next match, which becomes the
+// known doc, and the batches start afresh behind it.  Per doc that is three states of the NOT child:
+//   kNotPending   the leaf's next() has been pulled and everything up to the leaf's next match is (being) scanned in batches -- an
+//                 EPISODE is open; a match of the leaf that is handed on keeps it open, a match nobody asks about closes it (mark
+//                 kMarkClose at that doc) and the child is stale
+//   kNotStale     the known doc lies behind; the next time the child is asked it advances the leaf: one entry at that doc and
+//   kNotAdvancing one entry per doc up to the leaf's next match.  If that match is asked about (handed on) an episode opens behind it
+//                 (mark kMarkOpen: origin = that doc + 1) -> pending; if nobody asks, the child is stale again.
+// The constructor pulls next() once: doc 0 is entered pending, origin 0.  An episode's batches are a function of its origin and of the
+// doc that closes it (episode_entries above) -- the batch phase never becomes part of the state; the walk only has to say where episodes
+// open and close, and they alternate.  One such child per machine.
+constexpr int kNotPending = 0, kNotStale = 1, kNotAdvancing = 2;
 
-inline State step(const Model& m, State s, unsigned input, int* entries) {
+struct State { int leader; int fresh; unsigned open; int not_state; };
+inline bool operator<(const State& a, const State& b) { return std::tie(a.leader, a.fresh, a.open, a.not_state) < std::tie(b.leader, b.fresh, b.open, b.not_state); }
+
+inline State step(const Model& m, State s, unsigned input, int* entries, int* mark = nullptr) {
   int inc = 0;
   for (const auto& need : m.standing) { bool all = true; for (int i : need) all = all && ((input >> i) & 1u); inc += all ? 1 : 0; }
   const int k = (int)m.children.size();
@@ -100,7 +130,27 @@ inline State step(const Model& m, State s, unsigned input, int* entries) {
       out.open = (out.open & ~(1u << bit)) | ((still_open ? 1u : 0u) << bit);
     }
   }
+  int mk = 0;
+  for (int c = 0; c < k; ++c) {
+    const Child& ch = m.children[(size_t)c];
+    if (ch.kind != Child::kNot || !ch.members[0].scan) continue;      // (NOT over an index-based leaf: a bitmap iterator underneath, nothing is counted)
+    const bool is_asked = asked[(size_t)c] || s.leader == c;          // (a leading child is asked about every doc it leads over)
+    const bool match = (input >> ch.members[0].input) & 1u;
+    switch (s.not_state) {
+      case kNotPending:
+        if (match && !is_asked) { mk = kMarkClose; out.not_state = kNotStale; }
+        break;                                                        // (a match that is asked about is handed on: next() again, the episode goes on)
+      case kNotStale:
+        if (is_asked) { inc += 1; if (match) { mk = kMarkOpen; out.not_state = kNotPending; } else out.not_state = kNotAdvancing; }
+        break;
+      default:                                                        // kNotAdvancing
+        inc += 1;
+        if (match) { if (is_asked) { mk = kMarkOpen; out.not_state = kNotPending; } else out.not_state = kNotStale; }
+        break;
+    }
+  }
   *entries = inc;
+  if (mark) *mark = mk;
   return out;
 }
 
@@ -129,6 +179,7 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
   };
   struct Raw { Child child; bool index; };
   std::vector<Raw> raw;
+  bool has_not_scan = false;
   for (int kid : tb.children_of(root)) {
     Raw r;
     r.index = false;
@@ -153,8 +204,16 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
       //  the replay.  Round 4 bailed out only when EVERY member was sorted: `idx AND scan AND (bitmap OR sorted OR sorted)` was walked as a
       //  leap-frogging OR and counted 27 559 entries where the iterators count 15 468 -- found by the kernel-coverage table of round 5.)
       if (num_sorted > 1 && num_scans == 0) return false;
+    } else if (q->filter[kid].op == PG_FILTER_NOT) {
+      // NotFilterOperator.getTrues = the child's getFalses (NotFilterOperator.java:52-63); a leaf's getFalses is a NotDocIdSet over its
+      // docId set (BaseFilterOperator.java:96-113): a leap-frogging child.  NOT over anything but a leaf stays with the replay.
+      const std::vector<int> under = tb.children_of(kid);
+      if (under.size() != 1 || !leaf_of(under[0], &l)) return false;
+      r.child.kind = Child::kNot;
+      r.child.members.push_back(l);
+      if (l.scan) { if (has_not_scan) return false; has_not_scan = true; }      // one episode stream per machine
     } else {
-      return false;                                             // NOT / nested AND under the root AND: the host replay's
+      return false;                                             // nested AND under the root AND: the host replay's
     }
     raw.push_back(std::move(r));
   }
@@ -174,7 +233,7 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
       merged.members.push_back(Leaf{r.child.members[0].input, false});
     }
     m.children.push_back(merged);
-    for (const Raw& r : raw) if (r.child.kind == Child::kOr) m.children.push_back(r.child);
+    for (const Raw& r : raw) if (r.child.kind == Child::kOr || r.child.kind == Child::kNot) m.children.push_back(r.child);
   } else {
     for (const Raw& r : raw) m.children.push_back(r.child);
   }
@@ -187,14 +246,15 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
   // reachable states, breadth first from (child 0 leads, asked afresh, nothing open)
   std::map<State, int> id;
   std::vector<State> states;
-  id[State{0, 1, 0u}] = 0;
-  states.push_back(State{0, 1, 0u});
-  std::vector<std::vector<uint8_t>> rows;
+  id[State{0, 1, 0u, kNotPending}] = 0;                         // (NotDocIdIterator's constructor has pulled next(): an episode from doc 0)
+  states.push_back(State{0, 1, 0u, kNotPending});
+  std::vector<std::vector<uint8_t>> rows, mark_rows;
   for (size_t at = 0; at < states.size(); ++at) {
-    std::vector<uint8_t> row((size_t)1 << L);
+    std::vector<uint8_t> row((size_t)1 << L), mark_row((size_t)1 << L);
     for (unsigned input = 0; input < (1u << L); ++input) {
-      int inc = 0;
-      const State nxt = step(m, states[at], input, &inc);
+      int inc = 0, mk = 0;
+      const State nxt = step(m, states[at], input, &inc, &mk);
+      mark_row[input] = (uint8_t)mk;
       auto it = id.find(nxt);
       if (it == id.end()) {
         if ((int)states.size() >= kFsmMaxStates) return false;
@@ -205,18 +265,24 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
       row[input] = (uint8_t)(it->second | (inc << 4));
     }
     rows.push_back(std::move(row));
+    mark_rows.push_back(std::move(mark_row));
   }
   // Mealy minimisation: two states are one when, for every input, they count the same entries and go on to states that are one ("asked
   // afresh" only matters in front of an OR: `a AND b AND c` has three states, one per leading child).  Classes are numbered by first
   // appearance, so the entry state stays 0.
   const int S0 = (int)states.size();
   std::vector<int> cls((size_t)S0, 0);
-  for (int num_classes = 1;;) {
+  // (with a NOT child: the end of the docs closes an open episode -- an output of the STATE; pending and other states start in different classes)
+  int num_start = 1;
+  if (has_not_scan) {
+    for (int st = 0; st < S0; ++st) { cls[(size_t)st] = states[(size_t)st].not_state == kNotPending ? 0 : 1; num_start = std::max(num_start, cls[(size_t)st] + 1); }
+  }
+  for (int num_classes = num_start;;) {
     std::map<std::vector<int>, int> sig_id;
     std::vector<int> next_cls((size_t)S0, 0);
     for (int st = 0; st < S0; ++st) {
       std::vector<int> sig{cls[(size_t)st]};
-      for (unsigned input = 0; input < (1u << L); ++input) { const uint8_t d = rows[(size_t)st][input]; sig.push_back(d >> 4); sig.push_back(cls[(size_t)(d & 15)]); }
+      for (unsigned input = 0; input < (1u << L); ++input) { const uint8_t d = rows[(size_t)st][input]; sig.push_back((d >> 4) | (mark_rows[(size_t)st][input] << 8)); sig.push_back(cls[(size_t)(d & 15)]); }
       next_cls[(size_t)st] = sig_id.emplace(std::move(sig), (int)sig_id.size()).first->second;
     }
     cls = next_cls;
@@ -233,20 +299,35 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
       const uint8_t d = rows[(size_t)st][input];
       out->delta[((size_t)cls[(size_t)st] << L) | input] = (uint8_t)(cls[(size_t)(d & 15)] | (d & 0xF0));
     }
+  out->marks.clear();
+  out->pending_states = 0;
+  if (has_not_scan) {
+    out->marks.assign((size_t)S << L, 0);
+    for (int st = 0; st < S0; ++st) {
+      for (unsigned input = 0; input < (1u << L); ++input) out->marks[((size_t)cls[(size_t)st] << L) | input] = mark_rows[(size_t)st][input];
+      if (states[(size_t)st].not_state == kNotPending) out->pending_states |= 1u << cls[(size_t)st];
+    }
+  }
   return true;
 }
 
 // The walk itself, doc by doc (reference for the tiled form below).
 inline int64_t fsm_count_sequential(const Fsm& f, const std::vector<const uint64_t*>& leaf_words, int32_t num_docs) {
-  int64_t entries = 0;
+  int64_t entries = 0, origin = 0;                               // (origin: of the episode that is open, when the machine has episodes)
   int state = 0;
   for (int32_t x = 0; x < num_docs; ++x) {
     unsigned input = 0;
     for (int i = 0; i < f.num_inputs; ++i) input |= (unsigned)((leaf_words[(size_t)i][(size_t)x >> 6] >> (x & 63)) & 1ull) << i;
-    const uint8_t d = f.delta[((size_t)state << f.num_inputs) | input];
+    const size_t at = ((size_t)state << f.num_inputs) | input;
+    const uint8_t d = f.delta[at];
     entries += d >> 4;
     state = d & 15;
+    if (f.has_episodes()) {
+      if (f.marks[at] == kMarkClose) entries += episode_entries(origin, x, num_docs);
+      else if (f.marks[at] == kMarkOpen) origin = (int64_t)x + 1;
+    }
   }
+  if (f.has_episodes() && ((f.pending_states >> state) & 1u)) entries += episode_entries(origin, num_docs, num_docs);
   return entries;
 }
 
@@ -292,6 +373,78 @@ inline int64_t fsm_count_tiled(const Fsm& f, const std::vector<const uint64_t*>&
     state = tile_table.next[state];
   }
   return entries;
+}
+
+// The episodes of a machine with a NOT child (Fsm::marks), in the device's structure -- pg_fsm_kernels.h: fsm_chunk_states_kernel /
+// fsm_tile_states_kernel hand every tile the state it is entered in (the tiles' tables walked from state 0), fsm_episode_tiles_kernel walks
+// every lane's 32 docs from ITS entry state (the 64 lane tables walked from the tile's), leaves an open word and a close word per lane,
+// pairs every close with the last open in front of it inside the tile and keeps, per tile, the close that has none (there is at most one:
+// opens and closes alternate) and its last open; fsm_episode_finish_kernel pairs those across tiles and closes what the end of the docs
+// leaves open.  Returns the episodes' entries only (fsm_count_tiled counts the per-doc ones).
+inline int64_t fsm_episode_entries_tiled(const Fsm& f, const std::vector<const uint64_t*>& leaf_words, int32_t num_docs) {
+  if (!f.has_episodes() || num_docs <= 0) return 0;
+  const int S = f.num_states, L = f.num_inputs;
+  const int64_t num_tiles = ((int64_t)num_docs + 2047) / 2048;
+  auto lane_words = [&](int64_t first, int docs, uint32_t* w) { for (int i = 0; i < L; ++i) w[i] = docs > 0 ? (uint32_t)(leaf_words[(size_t)i][(size_t)first >> 6] >> (first & 63)) : 0u; };
+  auto input_of = [&](const uint32_t* w, int d) { unsigned in = 0; for (int i = 0; i < L; ++i) in |= ((w[i] >> d) & 1u) << i; return in; };
+  // the tiles' entry states
+  std::vector<uint8_t> tile_state((size_t)num_tiles);
+  std::vector<int32_t> tile_first_close((size_t)num_tiles, -1), tile_last_open((size_t)num_tiles, -1);
+  int64_t sum = 0;
+  int state = 0, final_pending = 0;
+  for (int64_t tile = 0; tile < num_tiles; ++tile) {
+    tile_state[(size_t)tile] = (uint8_t)state;
+    uint8_t lane_next[64][kFsmMaxStates];
+    for (int lane = 0; lane < 64; ++lane) {
+      const int64_t first = tile * 2048 + (int64_t)lane * 32;
+      const int docs = (int)std::max<int64_t>(0, std::min<int64_t>(32, (int64_t)num_docs - first));
+      uint32_t w[kFsmMaxInputs];
+      lane_words(first, docs, w);
+      for (int s = 0; s < S; ++s) {
+        int cur = s;
+        for (int d = 0; d < docs; ++d) cur = f.delta[((size_t)cur << L) | input_of(w, d)] & 15;
+        lane_next[lane][s] = (uint8_t)cur;
+      }
+    }
+    // the lanes' entry states; every lane again from its own: the open / close words
+    int cur = state;
+    int32_t prev_open = -1;                                    // the last open of the lanes in front (the device: a prefix maximum over the wavefront)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int64_t first = tile * 2048 + (int64_t)lane * 32;
+      const int docs = (int)std::max<int64_t>(0, std::min<int64_t>(32, (int64_t)num_docs - first));
+      uint32_t w[kFsmMaxInputs];
+      lane_words(first, docs, w);
+      uint32_t open_word = 0, close_word = 0;
+      int st = cur;
+      for (int d = 0; d < docs; ++d) {
+        const size_t at = ((size_t)st << L) | input_of(w, d);
+        open_word |= (f.marks[at] == kMarkOpen ? 1u : 0u) << d;
+        close_word |= (f.marks[at] == kMarkClose ? 1u : 0u) << d;
+        st = f.delta[at] & 15;
+      }
+      if (docs > 0 && first + docs == (int64_t)num_docs) final_pending = (int)((f.pending_states >> st) & 1u);      // the lane that holds the last doc
+      for (uint32_t cw = close_word; cw != 0; cw &= cw - 1) {
+        const int d = __builtin_ctz(cw);
+        const uint32_t below = open_word & ((1u << d) - 1u);
+        const int32_t open_at = below ? (int32_t)(first + 31 - __builtin_clz(below)) : prev_open;
+        const int64_t x = first + d;
+        if (open_at >= 0) sum += episode_entries((int64_t)open_at + 1, x, num_docs);
+        else tile_first_close[(size_t)tile] = (int32_t)x;       // (its open lies in an earlier tile, or it is the episode of doc 0)
+      }
+      if (open_word) prev_open = (int32_t)(first + 31 - __builtin_clz(open_word));
+      cur = lane_next[lane][cur];
+    }
+    tile_last_open[(size_t)tile] = prev_open;
+    state = cur;
+  }
+  // across tiles
+  int32_t last_open = -1;
+  for (int64_t tile = 0; tile < num_tiles; ++tile) {
+    if (tile_first_close[(size_t)tile] >= 0) sum += episode_entries((int64_t)last_open + 1, tile_first_close[(size_t)tile], num_docs);
+    last_open = std::max(last_open, tile_last_open[(size_t)tile]);
+  }
+  if (final_pending) sum += episode_entries((int64_t)last_open + 1, num_docs, num_docs);
+  return sum;
 }
 
 // fsm_tiles_perm_kernel's arithmetic on the host (machines of at most four states and four inputs): a function {entry state} -> {exit

@@ -292,3 +292,81 @@ def test_an_or_of_index_based_members_only_is_not_a_leap_frogging_child(driver):
         assert (got >= 0) == compiles, (got, states, inputs)
         if compiles:
             assert got == want == fsm(driver, seg, spec, 1)[0]
+
+
+def test_not_children_are_episodes_of_the_transducer(driver):
+    """`a AND NOT b` and its relatives: a NOT child over a scan leaf pulls its leaf with next() -- whole 256-doc batches from wherever the
+    last advance() left it (NotDocIdIterator.java:45-76, SVScanDocIdIterator.java:76-112).  The batch phase does not become state: the walk
+    marks where an episode of batches opens and where it closes, an episode costs episode_entries(origin, close) (pg_filter_fsm.h "NOT
+    children").  The doc-by-doc walk and the device's tile structure (fsm_episode_entries_tiled: the twin of fsm_episode_tiles_kernel /
+    fsm_episode_finish_kernel) against the replay of the iterator objects and the oracle, sizes around the batch, lane and tile edges;
+    leaves with rare matches (episodes of many batches) and with dense ones."""
+    rng = np.random.default_rng(7)
+    compiled, with_not, shapes = 0, 0, set()
+    for n in (1, 31, 33, 255, 257, 513, 2047, 2049, 4100, 20_011, 70_003):
+        cols = [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "b", n, 7, with_inverted=True)[0],
+                H.random_dict_column(rng, "c", n, 300, with_inverted=True)[0], H.random_dict_column(rng, "d", n, 3)[0],
+                H.random_dict_column(rng, "e", n, 11)[0], H.random_dict_column(rng, "f", n, 2000)[0]]
+        seg = S.SegmentData("fsm_not", n, cols)
+
+        def scan_leaf():
+            k = int(rng.integers(0, 6))
+            if k == 0:
+                lo = int(rng.integers(0, 40)); return Q.leaf(Q.Pred.dict_range(0, lo, lo + int(rng.integers(1, 25)), exclusive=bool(rng.integers(0, 2))))
+            if k == 1:
+                return Q.leaf(Q.Pred.dict_range(3, int(rng.integers(0, 2)), int(rng.integers(2, 4))))
+            if k == 2:
+                lo = int(rng.integers(0, 9)); return Q.leaf(Q.Pred.dict_range(4, lo, lo + int(rng.integers(1, 6))))
+            if k == 3:
+                lo = int(rng.integers(0, 1990)); return Q.leaf(Q.Pred.dict_range(5, lo, lo + int(rng.integers(1, 8))))          # rare: episodes of many batches
+            if k == 4:
+                lo = int(rng.integers(0, 1000)); return Q.leaf(Q.Pred.dict_range(5, lo, lo + int(rng.integers(900, 1000)), exclusive=bool(rng.integers(0, 2))))
+            return Q.leaf(Q.Pred.dict_set(0, sorted(set(int(x) for x in rng.integers(0, 50, size=12))), 50, exclusive=bool(rng.integers(0, 2))))
+
+        def index_leaf():
+            k = int(rng.integers(0, 3))
+            if k == 0:
+                return Q.leaf(Q.Pred.dict_range(1, int(rng.integers(0, 5)), 7, inverted=True, exclusive=bool(rng.integers(0, 2))))
+            if k == 1:
+                return Q.leaf(Q.Pred.dict_set(2, sorted(set(int(x) for x in rng.integers(0, 300, size=60))), 300, inverted=True))
+            lo = int(rng.integers(0, n)); return Q.leaf(Q.Pred.doc_range(lo, min(n - 1, lo + int(rng.integers(0, n)))))
+
+        for _ in range(40):
+            kids, nots = [], 0
+            for _c in range(int(rng.integers(2, 5))):
+                r = int(rng.integers(0, 12))
+                if r < 4:
+                    kids.append(scan_leaf())
+                elif r < 6:
+                    kids.append(index_leaf())
+                elif r < 8:
+                    kids.append(Q.or_(*[scan_leaf() if rng.integers(0, 3) else index_leaf() for _m in range(int(rng.integers(2, 4)))]))
+                elif r < 11 and nots == 0:
+                    kids.append(Q.not_(scan_leaf())); nots += 1
+                else:
+                    kids.append(Q.not_(index_leaf()))
+            spec = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(*kids))
+            if len(spec.predicates) > 8 or any(p.kind in (_abi.PG_PRED_MATCH_ALL, _abi.PG_PRED_MATCH_NONE) for p in spec.predicates):
+                continue
+            want = oracle.execute(seg, spec).stats[1]
+            keep, ptrs = leaf_bitmaps(seg, spec)
+            assert driver.fstats_replay_mode(C.byref(spec.c), n, ptrs, 0, 0, 0) == want
+            seq, states, inputs = fsm(driver, seg, spec, 0)
+            if seq < 0:
+                continue
+            compiled += 1
+            with_not += nots
+            shapes.add((len(kids), nots, states))
+            tiled, _, _ = fsm(driver, seg, spec, 1)
+            assert seq == tiled == want, (n, states, inputs, seq, tiled, want)
+    assert compiled > 250 and with_not > 120 and len(shapes) > 20, (compiled, with_not, len(shapes))
+    # two NOT children over scan leaves (two episode streams) and NOT over an OR stay with the replay
+    n = 5000
+    seg = S.SegmentData("fsm_not2", n, [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "d", n, 3)[0]])
+    a, d = Q.leaf(Q.Pred.dict_range(0, 3, 20)), Q.leaf(Q.Pred.dict_range(1, 1, 2))
+    for flt, compiles in ((Q.and_(Q.not_(a), Q.not_(d)), False), (Q.and_(a, Q.not_(Q.or_(a, d))), False), (Q.and_(a, Q.not_(d)), True), (Q.and_(Q.not_(d), a), True)):
+        spec = Q.QuerySpec([(Q.COUNT, -1)], filter=flt)
+        got, _, _ = fsm(driver, seg, spec, 0)
+        assert (got >= 0) == compiles
+        if compiles:
+            assert got == oracle.execute(seg, spec).stats[1] == fsm(driver, seg, spec, 1)[0]

@@ -43,9 +43,13 @@ extern "C" int64_t fstats_fsm(const pg_query* q, int32_t num_docs, const uint64_
   if (out_inputs) *out_inputs = f.num_inputs;
   std::vector<const uint64_t*> words;
   for (int p : f.input_predicate) words.push_back(leaf_words[p]);
-  if (mode == 2) return pg::fstats::fsm_count_perm(f, words, num_docs);
-  if (mode == 3) return pg::fstats::fsm_count_perm8(f, words, num_docs);      // (fsm_tiles_perm8_kernel: up to eight states)
-  return mode == 0 ? pg::fstats::fsm_count_sequential(f, words, num_docs) : pg::fstats::fsm_count_tiled(f, words, num_docs);
+  if (mode == 0) return pg::fstats::fsm_count_sequential(f, words, num_docs);
+  // (a machine with a NOT child: the per-doc entries by the chosen walk, the episodes by the device's episode structure)
+  int64_t per_doc;
+  if (mode == 2) per_doc = pg::fstats::fsm_count_perm(f, words, num_docs);
+  else if (mode == 3) per_doc = pg::fstats::fsm_count_perm8(f, words, num_docs);      // (fsm_tiles_perm8_kernel: up to eight states)
+  else per_doc = pg::fstats::fsm_count_tiled(f, words, num_docs);
+  return per_doc < 0 ? per_doc : per_doc + pg::fstats::fsm_episode_entries_tiled(f, words, num_docs);
 }
 
 // Which of the device's walks a root AND takes (tools/kernel_coverage.py picks its machines with this): 0 when the shape does not compile
