@@ -90,6 +90,7 @@ struct Engine {
   bool index_gather = true;  // PINOT_GPU_INDEX_GATHER=0: an index-led aggregation always runs scan_sparse_kernel behind index_and_kernel (never inside it)
   bool fsm_fused = true;     // PINOT_GPU_FSM_FUSED=0: the transducer always runs as a pass of its own behind the scan (leaf bitmaps through HBM)
   bool fsm_stats = true;     // PINOT_GPU_FSM_STATS=0: no transducer pass (host replay / upper bound)
+  bool fsm_episodes = true;  // PINOT_GPU_FSM_EPISODES=0: a NOT child over a scan leaf stays with the host replay / upper bound (round 4's behaviour)
   bool plan_cache = true;    // PINOT_GPU_PLAN_CACHE=0: pg_execute_batch lowers every item of every call
   bool batch_more = true;    // PINOT_GPU_BATCH_MORE=0: items of scan_narrow_kernel's / scan_private_typed_kernel's shape run their own launches
   bool group_one_launch = true;   // PINOT_GPU_GROUP_ONE_LAUNCH=0: pg_execute runs a small group-by as init + kernel + count + scan + compact launches (rounds 1-4)
@@ -1749,6 +1750,7 @@ pg_status pg_init(const pg_config* config) {
   g_engine.fsm_perm = env_on("PINOT_GPU_FSM_PERM");
   g_engine.fsm_stats = env_on("PINOT_GPU_FSM_STATS");
   g_engine.fsm_fused = env_on("PINOT_GPU_FSM_FUSED");
+  g_engine.fsm_episodes = env_on("PINOT_GPU_FSM_EPISODES");
   g_engine.index_gather = env_on("PINOT_GPU_INDEX_GATHER");
   g_engine.group_one_launch = env_on("PINOT_GPU_GROUP_ONE_LAUNCH");
   g_engine.plan_cache = env_on("PINOT_GPU_PLAN_CACHE");
@@ -2933,7 +2935,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       const fstats::Fsm& f = *lw.side->fsm;
       int max_inc = 0;
       for (uint8_t d : f.delta) max_inc = std::max(max_inc, (int)(d >> 4));
-      bool fits = f.num_states <= 4 && f.num_inputs <= 4 && max_inc <= 7;
+      bool fits = f.num_states <= 4 && f.num_inputs <= 4 && max_inc <= 7 && !f.has_episodes();      // (episodes need the second walk of the pass)
       for (int i = 0; i < f.num_inputs && fits; ++i) fits = lw.side->mapped[i];
       if (fits) {
         fuse_fsm = true;
@@ -4182,9 +4184,12 @@ static pg_status replay_filter_stats(pg_segment* seg, const pg_query* q, pg_resu
 // The same count ON THE DEVICE, at any segment size, for the root ANDs pg_filter_fsm.h can compile (scan leaves, index-based leaves, ORs
 // of leaves -- `a AND b AND c`, `a AND (b OR c)`, the reference's golden filter): every leaf's docId set stays on the device as a
 // doc-order bitmap, the transducer's tables are built tile by tile and chained (pg_fsm_kernels.h).  Nothing but the count comes back.
-// Layout of the pass's scratch (pg_segment.d_fsm_scratch): L bitmaps of whole tiles | delta | tile tables | chunk tables | the count.
+// Layout of the pass's scratch (pg_segment.d_fsm_scratch): L bitmaps of whole tiles | delta | tile tables | chunk tables | the count --
+// and, for a machine with a NOT child (Fsm::marks: the episodes of pg_fsm_kernels.h), from the next 256-byte boundary on:
+// episode count + final-pending flag | marks | chunk states | tile states | the tiles' unpaired closes | the tiles' last opens.
 struct FsmScratch {
   size_t bitmap_bytes = 0, delta_bytes = 0, tables_bytes = 0, chunk_bytes = 0, total = 0;
+  size_t episode_base = 0, chunk_state_bytes = 0, tile_state_bytes = 0, tile_pos_bytes = 0;
   long long tiles = 0, chunks = 0;
   FsmScratch(const pg_segment* seg, const fstats::Fsm& fsm) {
     tiles = std::max<long long>(1, ((long long)seg->num_docs + 2047) / 2048);
@@ -4194,6 +4199,13 @@ struct FsmScratch {
     tables_bytes = (size_t)tiles * (size_t)fsm.num_states * 4;
     chunk_bytes = ((size_t)chunks * (size_t)fsm.num_states * 4 + 255) & ~(size_t)255;
     total = bitmap_bytes * (size_t)fsm.num_inputs + delta_bytes + tables_bytes + chunk_bytes + 256;
+    if (fsm.has_episodes()) {
+      episode_base = (total + 255) & ~(size_t)255;
+      chunk_state_bytes = ((size_t)chunks + 255) & ~(size_t)255;
+      tile_state_bytes = ((size_t)tiles + 255) & ~(size_t)255;
+      tile_pos_bytes = ((size_t)tiles * 4 + 255) & ~(size_t)255;
+      total = episode_base + 256 + delta_bytes + chunk_state_bytes + tile_state_bytes + 2 * tile_pos_bytes;
+    }
   }
 };
 // (under seg->fsm_mu) the scratch, grown when needed, and where every input's bitmap goes
@@ -4293,10 +4305,42 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
   HIP_TRY(hipGetLastError());
   fsm_finish_kernel<<<dim3(1), dim3(1024), (size_t)chunks * (size_t)S * 4, 0>>>(d_chunks, (int)chunks, S, d_entries);
   HIP_TRY(hipGetLastError());
-  unsigned long long entries = 0;
+  unsigned long long entries = 0, episodes = 0;
+  if (fsm.has_episodes()) {
+    // A NOT child over a scan leaf: what its leaf scans in 256-doc batches is charged per episode (pg_fsm_kernels.h "NOT children").  The
+    // tables of the count, walked downwards, give every tile its entry state; a second walk of the docs pairs the opens and the closes.
+    uint8_t* eb = d_base + lay.episode_base;
+    unsigned long long* d_episodes = reinterpret_cast<unsigned long long*>(eb);
+    int32_t* d_final_pending = reinterpret_cast<int32_t*>(eb + 8);
+    uint8_t* d_marks = eb + 256;
+    uint8_t* d_chunk_state = d_marks + lay.delta_bytes;
+    uint8_t* d_tile_state = d_chunk_state + lay.chunk_state_bytes;
+    int32_t* d_first_close = reinterpret_cast<int32_t*>(d_tile_state + lay.tile_state_bytes);
+    int32_t* d_last_open = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(d_first_close) + lay.tile_pos_bytes);
+    HIP_TRY(hipMemsetAsync(eb, 0, 16, 0));
+    HIP_TRY(hipMemcpy(d_marks, fsm.marks.data(), (size_t)S << L, hipMemcpyHostToDevice));
+    fsm_chunk_states_kernel<<<dim3(1), dim3(1024), (size_t)chunks * (size_t)S * 4, 0>>>(d_chunks, (int)chunks, S, d_chunk_state);
+    HIP_TRY(hipGetLastError());
+    fsm_tile_states_kernel<<<dim3((unsigned)chunks), dim3(1024), 0, 0>>>(d_tables, tiles, S, d_chunk_state, d_tile_state);
+    HIP_TRY(hipGetLastError());
+    FsmEpisodeParams ep;
+    memset(&ep, 0, sizeof(ep));
+    for (int i = 0; i < L; ++i) ep.leaf[i] = fp.leaf[i];
+    ep.delta = d_delta; ep.marks = d_marks; ep.tile_state = d_tile_state;
+    ep.tile_first_close = d_first_close; ep.tile_last_open = d_last_open;
+    ep.episode_entries = d_episodes; ep.final_pending = d_final_pending;
+    ep.pending_states = fsm.pending_states;
+    ep.num_inputs = L; ep.num_states = S; ep.num_docs = seg->num_docs; ep.num_tiles = (int32_t)tiles;
+    fsm_episode_tiles_kernel<<<dim3(blocks), dim3(256), 0, 0>>>(ep);
+    HIP_TRY(hipGetLastError());
+    fsm_episode_finish_kernel<<<dim3(1), dim3(1024), 0, 0>>>(d_first_close, d_last_open, (int)tiles, seg->num_docs, d_final_pending, d_episodes);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(&episodes, d_episodes, 8, hipMemcpyDeviceToHost));
+  }
   HIP_TRY(hipMemcpy(&entries, d_entries, 8, hipMemcpyDeviceToHost));
-  if (trace) fprintf(stderr, "fsm stats: %d inputs %d states %lld tiles: %d leaf bitmaps scanned again %.1f us, tables kernel %.1f us, chain+finish+copy %.1f us\n", L, S, tiles,
-                     scanned_again, us(t_begin, t_leaves), us(t_leaves, t_tiles), us(t_tiles, now()));
+  entries += episodes;
+  if (trace) fprintf(stderr, "fsm stats: %d inputs %d states %lld tiles: %d leaf bitmaps scanned again %.1f us, tables kernel %.1f us, chain+finish+copy %.1f us%s\n", L, S, tiles,
+                     scanned_again, us(t_begin, t_leaves), us(t_leaves, t_tiles), us(t_tiles, now()), fsm.has_episodes() ? " (with the episodes of a NOT child)" : "");
   out->stats.num_entries_scanned_in_filter = (int64_t)entries;
   out->filter_entries_exact = 1;
   return PG_OK;
@@ -4318,7 +4362,7 @@ static pg_status execute_one(pg_segment* segment, const pg_query* query, pg_resu
   bool fsm_ready = false;
   if (use_fsm && !null_handling && segment && query && query->num_filter_nodes >= 3 && query->filter && query->predicates) {
     int scan_leaves = 0;
-    if (fstats::choose_plan(query, &scan_leaves) == fstats::Plan::kReplay && fstats::compile_fsm(query, &fsm)) {
+    if (fstats::choose_plan(query, &scan_leaves) == fstats::Plan::kReplay && fstats::compile_fsm(query, &fsm) && (g_engine.fsm_episodes || !fsm.has_episodes())) {
       fsm_lock = std::unique_lock<std::mutex>(segment->fsm_mu);
       // numEntriesScannedInFilter is a statistic: a pass that cannot get its scratch (or fails later) leaves the query's answer standing
       // with filter_entries_exact = 0 (the host replay below still applies at its sizes) -- it never fails the query

@@ -429,4 +429,210 @@ static __global__ __launch_bounds__(1024) void fsm_finish_kernel(const uint32_t*
   *out_entries = e;
 }
 
+// ---- NOT children: the episodes (pg_filter_fsm.h "NOT children"; the host twin: fsm_episode_entries_tiled) -------------------------------
+// A NOT child over a scan leaf pulls its leaf with next(): whole 256-doc batches from wherever the last advance() left it
+// (NotDocIdIterator.java:45-76, SVScanDocIdIterator.java:76-112).  The machine's delta counts what is charged doc by doc; its `marks` say
+// where an EPISODE of batches opens (kMarkOpen at doc m: the batches start at m + 1) and where it closes (kMarkClose at doc x: the batch
+// that holds x is the last one).  Opens and closes alternate, doc 0 is entered with the episode of origin 0 open.  Pairing them needs
+// every tile's entry state (the tables of the count, walked downwards) and a second walk of the docs:
+//   fsm_chunk_states_kernel     the <= 1024 chunk tables walked from state 0: the state every chunk is entered in
+//   fsm_tile_states_kernel      per chunk, its 1024 tile tables walked from that state: the state every tile is entered in
+//   fsm_episode_tiles_kernel    one wavefront per tile: lane functions -> lane entry states -> every lane's open / close words; closes paired
+//                               with the last open in front of them inside the tile, the tile's one unpaired close and its last open kept
+//   fsm_episode_finish_kernel   those paired across tiles; the end of the docs closes what is open.
+constexpr uint32_t kFsmMarkOpen = 1u, kFsmMarkClose = 2u;
+constexpr int kFsmScanBatch = 256;                                  // BlockDocIdIterator.OPTIMAL_ITERATOR_BATCH_SIZE
+
+struct FsmEpisodeParams {
+  const uint32_t* leaf[kFsmInputs];     // as FsmParams
+  const uint8_t* delta;                 // [S << L] next state | entries << 4
+  const uint8_t* marks;                 // [S << L]
+  const uint8_t* tile_state;            // [num_tiles] fsm_tile_states_kernel's output
+  int32_t* tile_first_close;            // [num_tiles] the close of the tile that has no open in front of it inside the tile; -1
+  int32_t* tile_last_open;              // [num_tiles] -1: none
+  unsigned long long* episode_entries;  // += the episodes paired inside tiles
+  int32_t* final_pending;               // = 1 when the state behind the last doc has an episode open
+  uint32_t pending_states;
+  int32_t num_inputs, num_states, num_docs, num_tiles;
+};
+
+__device__ __forceinline__ unsigned long long fsm_episode_cost(long long origin, long long close, long long num_docs) {
+  if (origin >= num_docs) return 0ull;
+  if (close >= num_docs) return (unsigned long long)(num_docs - origin);
+  const long long batches = ((close - origin) / kFsmScanBatch + 1) * kFsmScanBatch;
+  return (unsigned long long)(batches < num_docs - origin ? batches : num_docs - origin);
+}
+
+static __global__ __launch_bounds__(1024) void fsm_chunk_states_kernel(const uint32_t* __restrict__ in, int count, int S, uint8_t* __restrict__ chunk_state) {
+  extern __shared__ uint32_t staged[];
+  __shared__ uint32_t wave_exit[16 * kFsmStates];
+  __shared__ uint32_t wave_entry[16];
+  for (int i = threadIdx.x; i < count * S; i += blockDim.x) staged[i] = in[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int first = wave * 64, last = first + 64 < count ? first + 64 : count;
+  if (lane < S) {
+    uint32_t c = (uint32_t)lane;
+    for (int i = first; i < last; ++i) c = staged[i * S + (int)c] & 15u;
+    wave_exit[wave * kFsmStates + lane] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t c = 0u;
+    for (int v = 0; v < 16; ++v) { wave_entry[v] = c; c = wave_exit[v * kFsmStates + (int)c]; }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    uint32_t c = wave_entry[wave];
+    for (int i = first; i < last; ++i) { chunk_state[i] = (uint8_t)c; c = staged[i * S + (int)c] & 15u; }
+  }
+}
+
+static __global__ __launch_bounds__(1024) void fsm_tile_states_kernel(const uint32_t* __restrict__ in, long long count, int S, const uint8_t* __restrict__ chunk_state,
+                                                                       uint8_t* __restrict__ tile_state) {
+  __shared__ uint32_t staged[16][64 * kFsmStates];
+  __shared__ uint32_t wave_exit[16 * kFsmStates];
+  __shared__ uint32_t wave_entry[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long base = (long long)blockIdx.x * kFsmChunk + wave * 64;
+  const long long left = count - base;
+  const int here = left >= 64 ? 64 : (left <= 0 ? 0 : (int)left);
+  for (int i = lane; i < here * S; i += 64) staged[wave][i] = in[base * S + i];
+  __builtin_amdgcn_wave_barrier();
+  if (lane < S) {
+    uint32_t c = (uint32_t)lane;
+    for (int i = 0; i < here; ++i) c = staged[wave][i * S + (int)c] & 15u;
+    wave_exit[wave * kFsmStates + lane] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t c = chunk_state[blockIdx.x];
+    for (int v = 0; v < 16; ++v) { wave_entry[v] = c; c = wave_exit[v * kFsmStates + (int)c]; }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    uint32_t c = wave_entry[wave];
+    for (int i = 0; i < here; ++i) { tile_state[base + i] = (uint8_t)c; c = staged[wave][i * S + (int)c] & 15u; }
+  }
+}
+
+static __global__ __launch_bounds__(256) void fsm_episode_tiles_kernel(const FsmEpisodeParams p) {
+  __shared__ uint8_t dm[kFsmStates << kFsmInputs];                   // next state | mark << 4
+  __shared__ uint8_t lane_next[4][64 * kFsmStates];
+  __shared__ uint8_t lane_entry[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = p.num_inputs, S = p.num_states;
+  for (int i = threadIdx.x; i < (S << L); i += blockDim.x) dm[i] = (uint8_t)((p.delta[i] & 15u) | ((uint32_t)p.marks[i] << 4));
+  __syncthreads();
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < p.num_tiles; tile += (long long)gridDim.x * 4) {
+    const long long first = tile * 2048 + lane * 32;
+    const long long rem = (long long)p.num_docs - first;
+    const int docs = rem >= 32 ? 32 : (rem <= 0 ? 0 : (int)rem);
+    uint32_t w[kFsmInputs];
+#pragma unroll
+    for (int i = 0; i < kFsmInputs; ++i) w[i] = i < L ? p.leaf[i][tile * 64 + lane] : 0u;
+    // the lane's function: its docs from every entry state
+    uint32_t st[kFsmStates];
+#pragma unroll
+    for (int s = 0; s < kFsmStates; ++s) st[s] = (uint32_t)s;
+    for (int d = 0; d < docs; ++d) {
+      uint32_t in = 0u;
+#pragma unroll
+      for (int i = 0; i < kFsmInputs; ++i) in |= ((w[i] >> d) & 1u) << i;
+#pragma unroll
+      for (int s = 0; s < kFsmStates; ++s) if (s < S) st[s] = dm[(st[s] << L) | in] & 15u;
+    }
+#pragma unroll
+    for (int s = 0; s < kFsmStates; ++s) lane_next[wave][lane * kFsmStates + s] = (uint8_t)st[s];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      uint32_t c = p.tile_state[tile];
+      for (int l = 0; l < 64; ++l) { lane_entry[wave][l] = (uint8_t)c; c = lane_next[wave][l * kFsmStates + (int)c]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the lane's docs again, from the state it is entered in: where episodes open and close
+    uint32_t cur = lane_entry[wave][lane], open_word = 0u, close_word = 0u;
+    for (int d = 0; d < docs; ++d) {
+      uint32_t in = 0u;
+#pragma unroll
+      for (int i = 0; i < kFsmInputs; ++i) in |= ((w[i] >> d) & 1u) << i;
+      const uint32_t t = dm[(cur << L) | in];
+      open_word |= ((t >> 4) == kFsmMarkOpen ? 1u : 0u) << d;
+      close_word |= ((t >> 4) == kFsmMarkClose ? 1u : 0u) << d;
+      cur = t & 15u;
+    }
+    if (docs > 0 && first + docs == (long long)p.num_docs) *p.final_pending = (int32_t)((p.pending_states >> cur) & 1u);      // the lane that holds the last doc
+    // the last open in front of every lane: an inclusive prefix maximum over the wavefront, shifted by one lane
+    const int32_t mine = open_word ? (int32_t)(first + 31 - __builtin_clz(open_word)) : -1;
+    int32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t other = __shfl_up(incl, off);
+      if (lane >= off) incl = other > incl ? other : incl;
+    }
+    int32_t prev = __shfl_up(incl, 1);
+    if (lane == 0) prev = -1;
+    unsigned long long sum = 0ull;
+    int32_t unpaired = -1;
+    for (uint32_t c = close_word; c != 0u; c &= c - 1u) {
+      const int d = __builtin_ctz(c);
+      const uint32_t below = open_word & ((1u << d) - 1u);
+      const int32_t open_at = below ? (int32_t)(first + 31 - __builtin_clz(below)) : prev;
+      const long long x = first + d;
+      if (open_at >= 0) sum += fsm_episode_cost((long long)open_at + 1, x, p.num_docs);
+      else unpaired = (int32_t)x;                                      // (its open lies in an earlier tile, or it is the episode of doc 0)
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sum += (unsigned long long)__shfl_xor((long long)sum, off);
+      const int32_t other = __shfl_xor(unpaired, off);
+      unpaired = other > unpaired ? other : unpaired;
+    }
+    const int32_t last_open = __shfl(incl, 63);
+    if (lane == 0) {
+      if (sum != 0ull) atomicAdd(p.episode_entries, sum);
+      p.tile_first_close[tile] = unpaired;
+      p.tile_last_open[tile] = last_open;
+    }
+  }
+}
+
+// One workgroup: thread t takes a contiguous range of tiles.  The last open in front of every range (a prefix maximum), every tile's unpaired
+// close against the last open in front of it, the end of the docs.  *episode_entries += what is found here.
+static __global__ __launch_bounds__(1024) void fsm_episode_finish_kernel(const int32_t* __restrict__ tile_first_close, const int32_t* __restrict__ tile_last_open, int num_tiles,
+                                                                          int num_docs, const int32_t* __restrict__ final_pending, unsigned long long* __restrict__ episode_entries) {
+  __shared__ int32_t range_last[1024];
+  __shared__ int32_t all_last;
+  __shared__ unsigned long long total;
+  const int t = (int)threadIdx.x;
+  const int per = (num_tiles + 1023) / 1024;
+  const int lo = t * per < num_tiles ? t * per : num_tiles, hi = lo + per < num_tiles ? lo + per : num_tiles;
+  int32_t m = -1;
+  for (int i = lo; i < hi; ++i) { const int32_t o = tile_last_open[i]; m = o > m ? o : m; }
+  range_last[t] = m;
+  if (t == 0) total = 0ull;
+  __syncthreads();
+  if (t == 0) {
+    int32_t run = -1;
+    for (int i = 0; i < 1024; ++i) { const int32_t here = range_last[i]; range_last[i] = run; run = here > run ? here : run; }
+    all_last = run;
+  }
+  __syncthreads();
+  int32_t run = range_last[t];
+  unsigned long long sum = 0ull;
+  for (int i = lo; i < hi; ++i) {
+    const int32_t x = tile_first_close[i];
+    if (x >= 0) sum += fsm_episode_cost((long long)run + 1, (long long)x, (long long)num_docs);
+    const int32_t o = tile_last_open[i];
+    run = o > run ? o : run;
+  }
+  if (sum != 0ull) atomicAdd(&total, sum);
+  __syncthreads();
+  if (t == 0) {
+    unsigned long long all = total;
+    if (*final_pending != 0) all += fsm_episode_cost((long long)all_last + 1, (long long)num_docs, (long long)num_docs);
+    *episode_entries += all;
+  }
+}
+
 }  // namespace pg

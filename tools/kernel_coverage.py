@@ -186,6 +186,12 @@ def fsm_trees(Q, rng, n, count):
         lo = int(rng.integers(0, n)); return L(Q.Pred.doc_range(lo, min(n - 1, lo + int(rng.integers(0, n)))))
 
     out = []
+    # NOT children over scan leaves: the episode kernels (fsm_chunk_states / fsm_tile_states / fsm_episode_tiles / fsm_episode_finish), with a
+    # leaf that matches rarely (episodes of many batches), one that matches half the docs, an index-based leader, an OR beside the NOT
+    rare, half, some = L(Q.Pred.dict_range(A, 7, 8)), L(Q.Pred.dict_range(C2, 0, 1)), L(Q.Pred.dict_range(B, 2, 5))
+    posting = L(Q.Pred.dict_range(X, 0, 20, inverted=True))
+    out += [Q.and_(some, Q.not_(rare)), Q.and_(Q.not_(half), some), Q.and_(posting, Q.not_(rare)), Q.and_(some, Q.not_(half), Q.or_(rare, posting)),
+            Q.and_(posting, some, Q.not_(L(Q.Pred.dict_range(A, 0, 150)))), Q.and_(some, Q.not_(posting), Q.not_(rare))][:max(count, 0)]
     # machines of the rarer (states, inputs) classes, found by a search over shapes (tools/fstats/fstats_driver.cpp fstats_fsm_class): a child
     # is a pool index or an OR of pool indexes; nine to thirteen states over three inputs, four to fifteen over four
     frozen = [(3, [[2, 1, 0], 1, [2, 1, 0]]), (3, [[2, 0], [1, 2], 0, [2, 1]]), (3, [[0, 2, 1], [1, 1], [0, 2, 2], [0, 2]]), (3, [[1, 0], 2, 0, [0, 1, 2]]),
