@@ -396,7 +396,8 @@ def main():
         import re
         from tools import bench_variants
         match = re.compile(args.variants) if args.variants else None
-        result["variants"] = bench_variants.run(engine, gsegs[0], segs[0], n, args.rows_c5 or n, match, check=not args.no_cpu_baseline)
+        result["variants"] = bench_variants.run(engine, gsegs[0], segs[0], n, args.rows_c5 or n, match,
+                                                    check=(not args.no_cpu_baseline) or os.environ.get("PINOT_BENCH_CHECK_VARIANTS") == "1")
     gsegs[0].close()
     if world > 1:
         dist.barrier()

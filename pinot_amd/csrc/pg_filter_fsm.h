@@ -437,13 +437,37 @@ inline int64_t fsm_episode_entries_tiled(const Fsm& f, const std::vector<const u
     tile_last_open[(size_t)tile] = prev_open;
     state = cur;
   }
-  // across tiles
-  int32_t last_open = -1;
-  for (int64_t tile = 0; tile < num_tiles; ++tile) {
-    if (tile_first_close[(size_t)tile] >= 0) sum += episode_entries((int64_t)last_open + 1, tile_first_close[(size_t)tile], num_docs);
-    last_open = std::max(last_open, tile_last_open[(size_t)tile]);
+  // across tiles, the way fsm_episode_finish_kernel does it: sixteen wavefronts, each a contiguous range of tiles read 64 at a time (lane l: tile
+  // base + l); the last open in front of a tile = the maximum of the wavefronts in front, of the 64-tile groups in front (carry) and of the
+  // lanes in front (a prefix maximum over the wavefront)
+  const int64_t per_wave = (num_tiles + 15) / 16;
+  int32_t wave_last[16], wave_carry[16];
+  for (int wave = 0; wave < 16; ++wave) {
+    const int64_t lo = std::min<int64_t>(wave * per_wave, num_tiles), hi = std::min<int64_t>(lo + per_wave, num_tiles);
+    int32_t m = -1;
+    for (int64_t i = lo; i < hi; ++i) m = std::max(m, tile_last_open[(size_t)i]);
+    wave_last[wave] = m;
   }
-  if (final_pending) sum += episode_entries((int64_t)last_open + 1, num_docs, num_docs);
+  int32_t all_last = -1;
+  for (int wave = 0; wave < 16; ++wave) { wave_carry[wave] = all_last; all_last = std::max(all_last, wave_last[wave]); }
+  for (int wave = 0; wave < 16; ++wave) {
+    const int64_t lo = std::min<int64_t>(wave * per_wave, num_tiles), hi = std::min<int64_t>(lo + per_wave, num_tiles);
+    int32_t carry = wave_carry[wave];
+    for (int64_t base = lo; base < hi; base += 64) {
+      int32_t incl[64];
+      for (int lane = 0; lane < 64; ++lane) { const int64_t i = base + lane; incl[lane] = i < hi ? tile_last_open[(size_t)i] : -1; }
+      for (int off = 1; off < 64; off <<= 1)                        // (the device: __shfl_up rounds)
+        for (int lane = 63; lane >= off; --lane) incl[lane] = std::max(incl[lane], incl[lane - off]);
+      for (int lane = 0; lane < 64; ++lane) {
+        const int64_t i = base + lane;
+        const int32_t x = i < hi ? tile_first_close[(size_t)i] : -1;
+        const int32_t prev = std::max(carry, lane ? incl[lane - 1] : -1);
+        if (x >= 0) sum += episode_entries((int64_t)prev + 1, x, num_docs);
+      }
+      carry = std::max(carry, incl[63]);
+    }
+  }
+  if (final_pending) sum += episode_entries((int64_t)all_last + 1, num_docs, num_docs);
   return sum;
 }
 

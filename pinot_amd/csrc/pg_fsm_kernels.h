@@ -524,6 +524,7 @@ static __global__ __launch_bounds__(256) void fsm_episode_tiles_kernel(const Fsm
   const int L = p.num_inputs, S = p.num_states;
   for (int i = threadIdx.x; i < (S << L); i += blockDim.x) dm[i] = (uint8_t)((p.delta[i] & 15u) | ((uint32_t)p.marks[i] << 4));
   __syncthreads();
+  unsigned long long sum = 0ull;                                       // this lane's episodes over all of the wavefront's tiles: ONE atomic per wavefront at the end
   for (long long tile = (long long)blockIdx.x * 4 + wave; tile < p.num_tiles; tile += (long long)gridDim.x * 4) {
     const long long first = tile * 2048 + lane * 32;
     const long long rem = (long long)p.num_docs - first;
@@ -572,7 +573,6 @@ static __global__ __launch_bounds__(256) void fsm_episode_tiles_kernel(const Fsm
     }
     int32_t prev = __shfl_up(incl, 1);
     if (lane == 0) prev = -1;
-    unsigned long long sum = 0ull;
     int32_t unpaired = -1;
     for (uint32_t c = close_word; c != 0u; c &= c - 1u) {
       const int d = __builtin_ctz(c);
@@ -584,51 +584,71 @@ static __global__ __launch_bounds__(256) void fsm_episode_tiles_kernel(const Fsm
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      sum += (unsigned long long)__shfl_xor((long long)sum, off);
       const int32_t other = __shfl_xor(unpaired, off);
       unpaired = other > unpaired ? other : unpaired;
     }
     const int32_t last_open = __shfl(incl, 63);
     if (lane == 0) {
-      if (sum != 0ull) atomicAdd(p.episode_entries, sum);
       p.tile_first_close[tile] = unpaired;
       p.tile_last_open[tile] = last_open;
     }
   }
+  // (one atomic per TILE on the one counter -- 488 282 of them at 1 B docs -- was the first coding)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += (unsigned long long)__shfl_xor((long long)sum, off);
+  if (lane == 0 && sum != 0ull) atomicAdd(p.episode_entries, sum);
 }
 
-// One workgroup: thread t takes a contiguous range of tiles.  The last open in front of every range (a prefix maximum), every tile's unpaired
-// close against the last open in front of it, the end of the docs.  *episode_entries += what is found here.
+// One workgroup of sixteen wavefronts, each a contiguous range of tiles read 64 at a time (lane l: tile base + l -- the first coding gave every
+// THREAD a contiguous range: 1024 threads each pulling a 128-byte line for four bytes, through one compute unit).  The last open in front of
+// a tile = the maximum of the wavefronts in front, of the 64-tile groups in front (carry) and of the lanes in front (a prefix maximum over
+// the wavefront); every tile's unpaired close against it; the end of the docs closes what is open.  *episode_entries += what is found here.
+// (pg_filter_fsm.h fsm_episode_entries_tiled ends with the same structure.)
 static __global__ __launch_bounds__(1024) void fsm_episode_finish_kernel(const int32_t* __restrict__ tile_first_close, const int32_t* __restrict__ tile_last_open, int num_tiles,
                                                                           int num_docs, const int32_t* __restrict__ final_pending, unsigned long long* __restrict__ episode_entries) {
-  __shared__ int32_t range_last[1024];
+  __shared__ int32_t wave_last[16];
+  __shared__ int32_t wave_carry[16];
   __shared__ int32_t all_last;
   __shared__ unsigned long long total;
-  const int t = (int)threadIdx.x;
-  const int per = (num_tiles + 1023) / 1024;
-  const int lo = t * per < num_tiles ? t * per : num_tiles, hi = lo + per < num_tiles ? lo + per : num_tiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per_wave = (num_tiles + 15) / 16;
+  const int lo = wave * per_wave < num_tiles ? wave * per_wave : num_tiles, hi = lo + per_wave < num_tiles ? lo + per_wave : num_tiles;
   int32_t m = -1;
-  for (int i = lo; i < hi; ++i) { const int32_t o = tile_last_open[i]; m = o > m ? o : m; }
-  range_last[t] = m;
-  if (t == 0) total = 0ull;
+  for (int i = lo + lane; i < hi; i += 64) { const int32_t o = tile_last_open[i]; m = o > m ? o : m; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const int32_t other = __shfl_xor(m, off); m = other > m ? other : m; }
+  if (lane == 0) wave_last[wave] = m;
+  if (threadIdx.x == 0) total = 0ull;
   __syncthreads();
-  if (t == 0) {
+  if (threadIdx.x == 0) {
     int32_t run = -1;
-    for (int i = 0; i < 1024; ++i) { const int32_t here = range_last[i]; range_last[i] = run; run = here > run ? here : run; }
+    for (int v = 0; v < 16; ++v) { wave_carry[v] = run; run = wave_last[v] > run ? wave_last[v] : run; }
     all_last = run;
   }
   __syncthreads();
-  int32_t run = range_last[t];
+  int32_t carry = wave_carry[wave];
   unsigned long long sum = 0ull;
-  for (int i = lo; i < hi; ++i) {
-    const int32_t x = tile_first_close[i];
-    if (x >= 0) sum += fsm_episode_cost((long long)run + 1, (long long)x, (long long)num_docs);
-    const int32_t o = tile_last_open[i];
-    run = o > run ? o : run;
+  for (int base = lo; base < hi; base += 64) {                        // (wave-uniform trip count: the shuffles below see all 64 lanes)
+    const int i = base + lane;
+    int32_t incl = i < hi ? tile_last_open[i] : -1;
+    const int32_t x = i < hi ? tile_first_close[i] : -1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t other = __shfl_up(incl, off);
+      if (lane >= off) incl = other > incl ? other : incl;
+    }
+    int32_t excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = -1;
+    const int32_t prev = carry > excl ? carry : excl;
+    if (x >= 0) sum += fsm_episode_cost((long long)prev + 1, (long long)x, (long long)num_docs);
+    const int32_t group_last = __shfl(incl, 63);
+    carry = group_last > carry ? group_last : carry;
   }
-  if (sum != 0ull) atomicAdd(&total, sum);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += (unsigned long long)__shfl_xor((long long)sum, off);
+  if (lane == 0 && sum != 0ull) atomicAdd(&total, sum);
   __syncthreads();
-  if (t == 0) {
+  if (threadIdx.x == 0) {
     unsigned long long all = total;
     if (*final_pending != 0) all += fsm_episode_cost((long long)all_last + 1, (long long)num_docs, (long long)num_docs);
     *episode_entries += all;

@@ -360,6 +360,15 @@ def test_not_children_are_episodes_of_the_transducer(driver):
             tiled, _, _ = fsm(driver, seg, spec, 1)
             assert seq == tiled == want, (n, states, inputs, seq, tiled, want)
     assert compiled > 250 and with_not > 120 and len(shapes) > 20, (compiled, with_not, len(shapes))
+    # many tiles (the finish kernel's sixteen ranges of 64-tile groups): 3 M docs = 1 465 tiles, episodes from one batch to thousands of docs long
+    n = 3_000_017
+    seg = S.SegmentData("fsm_not_big", n, [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "f", n, 2000)[0], H.random_dict_column(rng, "d", n, 3)[0]])
+    a, d = Q.leaf(Q.Pred.dict_range(0, 3, 20)), Q.leaf(Q.Pred.dict_range(2, 1, 2))
+    for b in (Q.leaf(Q.Pred.dict_range(1, 100, 101)), Q.leaf(Q.Pred.dict_range(1, 100, 130)), Q.leaf(Q.Pred.dict_range(1, 0, 1500))):
+        for flt in (Q.and_(a, Q.not_(b)), Q.and_(Q.not_(b), d), Q.and_(d, Q.not_(b), a)):
+            spec = Q.QuerySpec([(Q.COUNT, -1)], filter=flt)
+            want = oracle.execute(seg, spec).stats[1]
+            assert fsm(driver, seg, spec, 0)[0] == want == fsm(driver, seg, spec, 1)[0]
     # two NOT children over scan leaves (two episode streams) and NOT over an OR stay with the replay
     n = 5000
     seg = S.SegmentData("fsm_not2", n, [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "d", n, 3)[0]])
