@@ -36,6 +36,8 @@ for r in rows:
     seen[key] = r
     unique.append(r)
 rows = unique
+# (rocPRIM's sort / select instantiations behind the rank image are the library's kernels, not this engine's: left out, as in tests/test_gpu_kernel_coverage.py)
+rows = [r for r in rows if "rocprim" not in r["name"]]
 names = [r["name"] for r in rows]
 dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
 with open(out, "w") as o:
