@@ -276,9 +276,10 @@ typedef struct pg_result {
   int32_t profile_waves;           /* number of wavefronts the sums cover */
   int32_t dominant_kernel;         /* pg_kernel_id of the kernel dominant_kernel_ms refers to */
   int32_t filter_entries_exact;    /* stats.num_entries_scanned_in_filter is the reference's count (AndDocIdSet / SVScanDocIdIterator accounting);
-                                    * 0: an upper bound (numDocs per scan leaf) -- filters whose iterators leap-frog (other than `a AND b` over
-                                    * two scan leaves, which the device counts), on segments above PINOT_GPU_EXACT_FILTER_STATS_DOCS docs,
-                                    * and enableNullHandling queries */
+                                    * 0: an upper bound (numDocs per scan leaf) -- filters whose iterators leap-frog in a shape the device does
+                                    * not count (it counts root ANDs of scan / index leaves, ORs of leaves and one NOT over a scan leaf, at any
+                                    * size: machines of at most 16 states over 8 leaves), on segments above PINOT_GPU_EXACT_FILTER_STATS_DOCS
+                                    * docs, and enableNullHandling queries */
   int32_t group_key_kind;          /* which of the reference's RawKeyHolders the key space calls for (DictionaryBasedGroupKeyGenerator.java:150-184):
                                     * 0 the raw key is an int (Array / IntMapBasedHolder): group_ids hold it;
                                     * 1 it is a long (LongMapBasedHolder, :628-700): group_ids64 hold it, group_ids are row numbers;
