@@ -65,6 +65,7 @@ def load():
         "po_result_free": (None, [P(_abi.pg_result)]),
         "po_filter_bitmap": (C.c_int, [P(_abi.pg_segment_desc), P(_abi.pg_query), P(C.c_uint64), C.c_int64, P(C.c_int64)]),
         "po_read_int_values": (C.c_int, [P(_abi.pg_segment_desc), C.c_int32, i32p, C.c_int32, i32p]),
+        "po_not_iterator_script": (C.c_int, [C.c_int, P(P(C.c_uint64)), C.c_int, C.c_int32, i32p, C.c_int, i32p, P(C.c_int64)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -112,6 +113,27 @@ def filter_bitmap(segment_data, spec):
     _check(lib.po_filter_bitmap(C.byref(segment_data.desc), C.byref(spec.c), words.ctypes.data_as(C.POINTER(C.c_uint64)),
                                 int(words.shape[0]), C.byref(card)))
     return words, int(card.value)
+
+
+def not_iterator_script(kind, members, num_docs, script):
+    """Test hook (pinot_oracle.c po_not_iterator_script): a NotDocIdIterator over a bitmap (kind 0), an OrDocIdIterator of bitmaps (1) or
+    a scan leaf (2) whose docId sets are `members` (lists of docIds), driven by `script` (-1: next(), t >= 0: advance(t)).
+    Returns (docIds returned, entries the scan leaf counted)."""
+    lib = load()
+    nw = max(1, (num_docs + 63) // 64)
+    keep = []
+    ptrs = (C.POINTER(C.c_uint64) * len(members))()
+    for i, docs in enumerate(members):
+        w = np.zeros(nw, dtype=np.uint64)
+        for d in docs:
+            w[d >> 6] |= np.uint64(1) << np.uint64(d & 63)
+        keep.append(w)
+        ptrs[i] = w.ctypes.data_as(C.POINTER(C.c_uint64))
+    script = np.ascontiguousarray(script, dtype=np.int32)
+    out = np.zeros(script.shape[0], dtype=np.int32)
+    entries = C.c_int64()
+    _check(lib.po_not_iterator_script(kind, ptrs, len(members), num_docs, _i32p(script), int(script.shape[0]), _i32p(out), C.byref(entries)))
+    return [int(x) for x in out], int(entries.value)
 
 
 def read_int_values(segment_data, column, doc_ids):

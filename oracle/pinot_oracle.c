@@ -18,7 +18,9 @@
  * writer restatement reproduces them byte for byte) plus known-answer bytes derived from
  * PinotDataBitSet.writeInt; the raw chunk layout by its header fields.  RoaringBitmap (third-party
  * org.roaringbitmap:RoaringBitmap:1.3.0, not under /root/reference) follows the public RoaringFormatSpec:
- * serialized-byte parity is "unpinned", set semantics are pinned through the golden queries.
+ * serialized-byte parity is "unpinned", set semantics are pinned through the golden queries.  The iterator objects behind
+ * numEntriesScannedInFilter are pinned by the golden 63 064 (AndDocIdSet / OrDocIdIterator / SVScanDocIdIterator) and, call by call, by
+ * the reference's NotDocIdIteratorTest.java:31-104 scripts (tests/test_oracle_not_iterator.py through po_not_iterator_script).
  *
  * The structure deliberately mirrors the JVM path so that timing it is a fair "port" CPU baseline:
  * 256-doc scan batches (BlockDocIdIterator.OPTIMAL_ITERATOR_BATCH_SIZE), 10 000-doc projection blocks
@@ -1205,6 +1207,40 @@ static int filter_entries_scanned(const po_column* cols, const pg_segment_desc* 
   }
   ds_free(root);
   return rc;
+}
+
+/* Test hook: the iterator objects above driven by a script of calls, the way the reference's own iterator tests drive theirs
+ * (dociditerators/NotDocIdIteratorTest.java:31-104: advance(1) = 2, next() = 3, ... over RangelessBitmapDocIdIterators and an
+ * OrDocIdIterator of three of them).  A NotDocIdIterator over: kind 0 the bitmap member[0]; kind 1 an OrDocIdIterator of the bitmap
+ * members; kind 2 a scan leaf whose matches are member[0] (SVScanDocIdIterator: *out_entries is what it counts).  script[i] >= 0:
+ * advance(script[i]); -1: next().  out[i] = the docId returned (PO_EOF = the reference's Constants.EOF). */
+int po_not_iterator_script(int kind, const uint64_t* const* member_words, int num_members, int32_t num_docs, const int32_t* script, int n, int32_t* out,
+                           int64_t* out_entries) {
+  if (num_members < 1 || (kind != 1 && num_members != 1)) return 1;
+  int64_t entries = 0;
+  po_ds* inner;
+  if (kind == 1) {
+    inner = ds_new(DS_OR, num_members);
+    for (int i = 0; i < num_members; i++) {
+      po_ds* m = ds_new(DS_BITMAP, 0);
+      int64_t nw = bitmap_words(num_docs);
+      m->words = (uint64_t*)malloc((size_t)(nw ? nw : 1) * 8);
+      memcpy(m->words, member_words[i], (size_t)nw * 8);
+      inner->child[inner->num_children++] = m;
+    }
+  } else {
+    inner = ds_new(kind == 2 ? DS_SCAN : DS_BITMAP, 0);
+    int64_t nw = bitmap_words(num_docs);
+    inner->words = (uint64_t*)malloc((size_t)(nw ? nw : 1) * 8);
+    memcpy(inner->words, member_words[0], (size_t)nw * 8);
+  }
+  po_ds* root = ds_not(inner);
+  po_it* it = ds_iterator(root, num_docs, &entries);
+  for (int i = 0; i < n; i++) out[i] = script[i] >= 0 ? it_advance(it, script[i]) : it_next(it);
+  it_free(it);
+  ds_free(root);
+  if (out_entries) *out_entries = entries;
+  return 0;
 }
 
 /* BlockDocIdIterator over either one streaming scan leaf (the C2 shape: ScanBasedFilterOperator directly
