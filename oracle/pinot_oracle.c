@@ -20,7 +20,7 @@
  * org.roaringbitmap:RoaringBitmap:1.3.0, not under /root/reference) follows the public RoaringFormatSpec:
  * serialized-byte parity is "unpinned", set semantics are pinned through the golden queries.  The iterator objects behind
  * numEntriesScannedInFilter are pinned by the golden 63 064 (AndDocIdSet / OrDocIdIterator / SVScanDocIdIterator) and, call by call, by
- * the reference's NotDocIdIteratorTest.java:31-104 scripts (tests/test_oracle_not_iterator.py through po_not_iterator_script).
+ * the reference's NotDocIdIteratorTest.java:31-104, AndDocIdIteratorTest.java:32-55 and OrDocIdIteratorTest.java:32-57 scripts (tests/test_oracle_iterator_scripts.py through po_not_iterator_script).
  *
  * The structure deliberately mirrors the JVM path so that timing it is a fair "port" CPU baseline:
  * 256-doc scan batches (BlockDocIdIterator.OPTIMAL_ITERATOR_BATCH_SIZE), 10 000-doc projection blocks
@@ -1212,14 +1212,31 @@ static int filter_entries_scanned(const po_column* cols, const pg_segment_desc* 
 /* Test hook: the iterator objects above driven by a script of calls, the way the reference's own iterator tests drive theirs
  * (dociditerators/NotDocIdIteratorTest.java:31-104: advance(1) = 2, next() = 3, ... over RangelessBitmapDocIdIterators and an
  * OrDocIdIterator of three of them).  A NotDocIdIterator over: kind 0 the bitmap member[0]; kind 1 an OrDocIdIterator of the bitmap
- * members; kind 2 a scan leaf whose matches are member[0] (SVScanDocIdIterator: *out_entries is what it counts).  script[i] >= 0:
- * advance(script[i]); -1: next().  out[i] = the docId returned (PO_EOF = the reference's Constants.EOF). */
+ * members; kind 2 a scan leaf whose matches are member[0] (SVScanDocIdIterator: *out_entries is what it counts).  Kinds 3 and 4: no NOT
+ * -- an AndDocIdIterator / an OrDocIdIterator of the bitmap members themselves (AndDocIdIteratorTest.java:32-55, OrDocIdIteratorTest.java:
+ * 32-57).  script[i] >= 0: advance(script[i]); -1: next().  out[i] = the docId returned (PO_EOF = the reference's Constants.EOF). */
 int po_not_iterator_script(int kind, const uint64_t* const* member_words, int num_members, int32_t num_docs, const int32_t* script, int n, int32_t* out,
                            int64_t* out_entries) {
-  if (num_members < 1 || (kind != 1 && num_members != 1)) return 1;
+  if (num_members < 1 || (kind != 1 && kind != 3 && kind != 4 && num_members != 1)) return 1;
   int64_t entries = 0;
   po_ds* inner;
-  if (kind == 1) {
+  if (kind == 3) {
+    /* (AndDocIdSet.iterator() would merge bitmap children into one bitmap: the test builds the AndDocIdIterator itself, so does this) */
+    po_it* it = it_new(IT_AND, num_docs);
+    it->child = (po_it**)calloc((size_t)num_members, sizeof(po_it*));
+    int64_t nw = bitmap_words(num_docs);
+    for (int i = 0; i < num_members; i++) {
+      po_it* m = it_new(IT_RANGELESS, num_docs);
+      m->words = (uint64_t*)malloc((size_t)(nw ? nw : 1) * 8); m->owns_words = 1;
+      memcpy(m->words, member_words[i], (size_t)nw * 8);
+      it->child[it->num_children++] = m;
+    }
+    for (int i = 0; i < n; i++) out[i] = script[i] >= 0 ? it_advance(it, script[i]) : it_next(it);
+    it_free(it);
+    if (out_entries) *out_entries = 0;
+    return 0;
+  }
+  if (kind == 1 || kind == 4) {
     inner = ds_new(DS_OR, num_members);
     for (int i = 0; i < num_members; i++) {
       po_ds* m = ds_new(DS_BITMAP, 0);
@@ -1234,7 +1251,7 @@ int po_not_iterator_script(int kind, const uint64_t* const* member_words, int nu
     inner->words = (uint64_t*)malloc((size_t)(nw ? nw : 1) * 8);
     memcpy(inner->words, member_words[0], (size_t)nw * 8);
   }
-  po_ds* root = ds_not(inner);
+  po_ds* root = kind == 4 ? inner : ds_not(inner);
   po_it* it = ds_iterator(root, num_docs, &entries);
   for (int i = 0; i < n; i++) out[i] = script[i] >= 0 ? it_advance(it, script[i]) : it_next(it);
   it_free(it);

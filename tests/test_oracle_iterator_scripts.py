@@ -57,3 +57,12 @@ def test_not_over_a_scan_leaf_counts_batches_and_advances():
     # the same leaf, asked beyond the known doc first: advance(300) drops the batch and walks 300 .. 590 (291), 590 is not asked about
     got, entries = oracle.not_iterator_script(2, [[10, 590]], 600, [300, 400])
     assert got == [300, 400] and entries == 256 + 291
+
+
+def test_and_and_or_iterators_call_by_call():
+    """AndDocIdIteratorTest.java:32-55 and OrDocIdIteratorTest.java:32-57: the leap-frogging AND and the OR the NOT's neighbours are."""
+    a1 = [0, 1, 2, 3, 5, 7, 10, 12, 13, 15, 16, 18, 20]
+    a2 = [1, 2, 4, 5, 6, 7, 9, 11, 12, 13, 15, 16, 17, 19, 20]
+    a3 = [0, 2, 3, 4, 7, 8, 10, 11, 13, 15, 16, 19, 20]
+    assert oracle.not_iterator_script(3, [a1, a2, a3], 21, [N, N, 10, 16, N, N])[0] == [2, 7, 13, 16, 20, EOF]
+    assert oracle.not_iterator_script(4, [DOCS1, DOCS2, DOCS3], 21, [1, N, N, 7, 13, N, 18, N, 21])[0] == [1, 2, 4, 8, 13, 15, 18, 19, EOF]
