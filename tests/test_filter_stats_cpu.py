@@ -26,7 +26,9 @@ def driver(tmp_path_factory):
         pytest.skip("needs g++")
     out = str(tmp_path_factory.mktemp("fstats") / "libfstats_driver.so")
     src = os.path.join(ROOT, "tools", "fstats", "fstats_driver.cpp")
-    base = ["g++", "-std=c++17", "-O1", "-g", "-shared", "-fPIC", "-pthread", "-Wall", "-Werror", "-o", out, src]
+    # (-Bsymbolic: the header's inline functions are weak symbols; libpinot_gpu.so, which another test of the process may have loaded, holds
+    #  copies of the same names -- this library must run ITS OWN build of the header)
+    base = ["g++", "-std=c++17", "-O1", "-g", "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", "-Wall", "-Werror", "-o", out, src]
     subprocess.run(base, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     lib = C.CDLL(out)
     lib.fstats_replay.restype = C.c_int64

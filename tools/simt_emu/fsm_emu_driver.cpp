@@ -1,0 +1,97 @@
+// tools/simt_emu/fsm_emu_driver.cpp -- TEST INFRASTRUCTURE: the transducer kernels of pinot_amd/csrc/pg_fsm_kernels.h compiled for the HOST and
+// run by the thread-per-lane emulator of tools/simt_emu/hip/hip_runtime.h, in the order pg_engine.hip's device_fsm_filter_stats launches them.
+// tests/test_fsm_kernels_emulated_cpu.py builds it (the kernel header is copied with `__shared__` rewritten to `static`) and holds the count
+// against the oracle's iterator objects: the kernels' own source on the CPU tier -- tails, chunk boundaries (more than 1024 tiles), the episode
+// kernels of a NOT child -- without a GPU.  Nothing under pinot_amd/ includes or links this file.
+#include "hip/hip_runtime.h"
+
+#include "pg_fsm_kernels_emu.h"                     // generated: pg_fsm_kernels.h with __shared__ -> static
+
+#include "../../pinot_amd/csrc/pg_filter_stats.h"
+#include "../../pinot_amd/csrc/pg_filter_fsm.h"
+
+namespace pg {
+uint32_t staged[16384];                             // `extern __shared__ uint32_t staged[]` of fsm_finish_kernel / fsm_chunk_states_kernel: 64 KB
+}
+
+namespace {
+
+template <int SM>
+bool launch_table_walk(unsigned blocks, const pg::FsmParams& fp, int L) {
+  using namespace pg;
+  // (pg_engine.hip PG_FSM_LAUNCH_L: the instantiations the library holds)
+  if (L <= 2 && SM <= 4) simt::launch(blocks, 256, [&] { fsm_tiles_kernel<(SM <= 4 ? SM : 4), 2>(fp); });
+  else if (L <= 3) simt::launch(blocks, 256, [&] { fsm_tiles_kernel<SM, 3>(fp); });
+  else if (L <= 4) simt::launch(blocks, 256, [&] { fsm_tiles_kernel<SM, 4>(fp); });
+  else if (L <= 6) simt::launch(blocks, 256, [&] { fsm_tiles_kernel<SM, 6>(fp); });
+  else simt::launch(blocks, 256, [&] { fsm_tiles_kernel<SM, 8>(fp); });
+  return true;
+}
+
+}  // namespace
+
+// walk: 0 the table walk (fsm_tiles_kernel), 1 the byte-function walk of <= 4 states (fsm_tiles_perm_kernel), 2 of <= 8 (fsm_tiles_perm8_kernel).
+// -1: the shape does not compile; -2: the walk does not take this machine.  `blocks`: workgroups of the tile kernels (4 wavefronts each).
+extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg_query* q, int32_t num_docs, const uint64_t* const* leaf_words, int32_t walk, int32_t blocks, int32_t* out_states, int32_t* out_inputs,
+                                 int32_t* out_episodes) {
+  using namespace pg;
+  fstats::Fsm fsm;
+  if (!fstats::compile_fsm(q, &fsm)) return -1;
+  const int L = fsm.num_inputs, S = fsm.num_states;
+  if (out_states) *out_states = S;
+  if (out_inputs) *out_inputs = L;
+  if (out_episodes) *out_episodes = fsm.has_episodes() ? 1 : 0;
+  int max_inc = 0;
+  for (uint8_t d : fsm.delta) max_inc = std::max(max_inc, (int)(d >> 4));
+  if (walk == 1 && !(S <= 4 && L <= 4 && max_inc <= 7)) return -2;
+  if (walk == 2 && !(S <= 8 && L <= 4 && max_inc <= 7)) return -2;
+  const long long tiles = std::max<long long>(1, ((long long)num_docs + 2047) / 2048);
+  const long long chunks = (tiles + kFsmChunk - 1) / kFsmChunk;
+  const size_t words64 = ((size_t)num_docs + 63) / 64;
+  // the leaves' doc-order bitmaps as the scan kernel leaves them: dword tile * 64 + lane, whole tiles
+  std::vector<std::vector<uint32_t>> bitmaps((size_t)L, std::vector<uint32_t>((size_t)tiles * 64, 0u));
+  for (int i = 0; i < L; ++i) {
+    const uint64_t* w = leaf_words[fsm.input_predicate[(size_t)i]];
+    for (size_t j = 0; j < (size_t)tiles * 64; ++j) bitmaps[(size_t)i][j] = j / 2 < words64 ? (uint32_t)(w[j / 2] >> (32 * (j & 1))) : 0u;
+  }
+  std::vector<uint32_t> tables((size_t)tiles * (size_t)S, 0xDEADBEEFu), chunk_tables((size_t)chunks * (size_t)S, 0xDEADBEEFu);
+  unsigned long long entries = 0xDEADBEEFull;
+  FsmParams fp;
+  memset(&fp, 0, sizeof(fp));
+  for (int i = 0; i < L; ++i) fp.leaf[i] = bitmaps[(size_t)i].data();
+  fp.delta = fsm.delta.data(); fp.tables = tables.data();
+  fp.num_inputs = L; fp.num_states = S; fp.num_docs = num_docs; fp.num_tiles = (int32_t)tiles;
+  const unsigned nb = (unsigned)std::max(1, blocks);
+  if (walk == 1) {
+    if (L <= 2) simt::launch(nb, 256, [&] { fsm_tiles_perm_kernel<2>(fp); });
+    else if (L <= 3) simt::launch(nb, 256, [&] { fsm_tiles_perm_kernel<3>(fp); });
+    else simt::launch(nb, 256, [&] { fsm_tiles_perm_kernel<4>(fp); });
+  } else if (walk == 2) {
+    if (L <= 3) simt::launch(nb, 256, [&] { fsm_tiles_perm8_kernel<3>(fp); });
+    else simt::launch(nb, 256, [&] { fsm_tiles_perm8_kernel<4>(fp); });
+  } else if (S <= 2) launch_table_walk<2>(nb, fp, L);
+  else if (S <= 4) launch_table_walk<4>(nb, fp, L);
+  else if (S <= 8) launch_table_walk<8>(nb, fp, L);
+  else launch_table_walk<16>(nb, fp, L);
+  simt::launch((unsigned)chunks, 1024, [&] { fsm_chain_kernel(tables.data(), tiles, S, chunk_tables.data()); });
+  simt::launch(1, 1024, [&] { fsm_finish_kernel(chunk_tables.data(), (int)chunks, S, &entries); });
+  unsigned long long episodes = 0;
+  if (fsm.has_episodes()) {
+    std::vector<uint8_t> chunk_state((size_t)chunks, 0xEE), tile_state((size_t)tiles, 0xEE);
+    std::vector<int32_t> first_close((size_t)tiles, 12345), last_open((size_t)tiles, 12345);
+    int32_t final_pending = 0;
+    simt::launch(1, 1024, [&] { fsm_chunk_states_kernel(chunk_tables.data(), (int)chunks, S, chunk_state.data()); });
+    simt::launch((unsigned)chunks, 1024, [&] { fsm_tile_states_kernel(tables.data(), tiles, S, chunk_state.data(), tile_state.data()); });
+    FsmEpisodeParams ep;
+    memset(&ep, 0, sizeof(ep));
+    for (int i = 0; i < L; ++i) ep.leaf[i] = fp.leaf[i];
+    ep.delta = fsm.delta.data(); ep.marks = fsm.marks.data(); ep.tile_state = tile_state.data();
+    ep.tile_first_close = first_close.data(); ep.tile_last_open = last_open.data();
+    ep.episode_entries = &episodes; ep.final_pending = &final_pending;
+    ep.pending_states = fsm.pending_states;
+    ep.num_inputs = L; ep.num_states = S; ep.num_docs = num_docs; ep.num_tiles = (int32_t)tiles;
+    simt::launch(nb, 256, [&] { fsm_episode_tiles_kernel(ep); });
+    simt::launch(1, 1024, [&] { fsm_episode_finish_kernel(first_close.data(), last_open.data(), (int)tiles, num_docs, &final_pending, &episodes); });
+  }
+  return (int64_t)(entries + episodes);
+}
