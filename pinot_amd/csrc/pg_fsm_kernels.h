@@ -539,7 +539,7 @@ static __global__ __launch_bounds__(256) void fsm_episode_tiles_kernel(const Fsm
     for (int d = 0; d < docs; ++d) {
       uint32_t in = 0u;
 #pragma unroll
-      for (int i = 0; i < kFsmInputs; ++i) in |= ((w[i] >> d) & 1u) << i;
+      for (int i = 0; i < kFsmInputs; ++i) if (i < L) in |= ((w[i] >> d) & 1u) << i;      // (L is uniform: a machine over two leaves assembles two bits, not eight)
 #pragma unroll
       for (int s = 0; s < kFsmStates; ++s) if (s < S) st[s] = dm[(st[s] << L) | in] & 15u;
     }
@@ -556,7 +556,7 @@ static __global__ __launch_bounds__(256) void fsm_episode_tiles_kernel(const Fsm
     for (int d = 0; d < docs; ++d) {
       uint32_t in = 0u;
 #pragma unroll
-      for (int i = 0; i < kFsmInputs; ++i) in |= ((w[i] >> d) & 1u) << i;
+      for (int i = 0; i < kFsmInputs; ++i) if (i < L) in |= ((w[i] >> d) & 1u) << i;      // (L is uniform: a machine over two leaves assembles two bits, not eight)
       const uint32_t t = dm[(cur << L) | in];
       open_word |= ((t >> 4) == kFsmMarkOpen ? 1u : 0u) << d;
       close_word |= ((t >> 4) == kFsmMarkClose ? 1u : 0u) << d;
