@@ -1579,7 +1579,7 @@ int po_execute(const pg_segment_desc* seg, const pg_query* q, pg_result* res) {
         if (v > hi) hi = v;
       }
       if (num_docs <= 0) { rc = 2; snprintf(po_error, sizeof(po_error), "group-by on a raw column of an empty segment"); goto done; }
-      if (integral && (uint64_t)(hi - lo) < 0x7FFFFFFEull) {
+      if (integral && (uint64_t)hi - (uint64_t)lo < 0x7FFFFFFEull) {      /* (unsigned: a LONG column may span more than 2^63) */
         key_base[g] = lo; key_raw[g] = 1; cards[g] = (int32_t)(hi - lo + 1); no_dict_keys = 1;
       } else {
         /* FLOAT / DOUBLE values, INT / LONG values over more than an int: NoDictionarySingleColumnGroupKeyGenerator.java:100-135 keys them by

@@ -2121,7 +2121,7 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
       }
       if (e != hipSuccess) { if (d_mm) (void)hipFree(d_mm); return bail(fail(PG_ERR_DEVICE, "column %s: value range: %s", col.name.c_str(), hipGetErrorString(e))); }
       col.raw_min = mm[0]; col.raw_max = mm[1];
-      if ((unsigned long long)(mm[1] - mm[0]) >= 0x7FFFFFFEull) { rank_placeholder(); continue; }      // max - min + 1 is not an int (with room for a null digit): a rank image instead
+      if ((unsigned long long)mm[1] - (unsigned long long)mm[0] >= 0x7FFFFFFEull) { rank_placeholder(); continue; }      // max - min + 1 is not an int (with room for a null digit): a rank image instead
       ColumnDev image;
       image.name = col.name + "$keyimage";
       image.stored_type = col.stored_type; image.encoding = PG_FWD_FIXED_BIT_DICT; image.vkind = kValI32;

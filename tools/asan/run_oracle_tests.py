@@ -3,8 +3,9 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import test_oracle_golden as A, test_oracle_nulls as B, test_oracle_group_map as Cm, test_oracle_typed as D, test_oracle_layouts as E
+import test_oracle_iterator_scripts as F, test_oracle_rank_keys as G
 ran=0
-for mod in (A,B,Cm,D,E):
+for mod in (A,B,Cm,D,E,F,G):
     for name, fn in inspect.getmembers(mod, inspect.isfunction):
         if not name.startswith("test_"): continue
         marks = getattr(fn, "pytestmark", [])
