@@ -28,6 +28,8 @@ Prints ONE JSON line on rank 0.  At N=1 the line also carries
   summary                 LAST key: {variant id: [frac on all kernels, all_kernels_ms, bit exact]} for the headline and every variant
 The printed line stays under 8 KB (tools/bench_line.py): the `variants` array goes to gpurun_out/bench_variants.json and the uncut
 result to gpurun_out/bench_full.json, both named in the line.
+Environment: PINOT_BENCH_CHECK_VARIANTS=1 keeps the variants' oracle check on under --no-cpu-baseline; PINOT_BENCH_CHECK_ENTRIES_1B=1 also replays
+numEntriesScannedInFilter of the AND-NOT-scan variant on the oracle at 1 B rows (~45 s of one host core); PINOT_BENCH_OUT names the side files' directory.
 `--single-process --gpus N`: ONE process drives N devices (segment s on device s mod N, one pg_execute_batch per step) -- the
 deployment shape of a Pinot server; the driver's torchrun launch stays one process per GPU.
 """
