@@ -339,7 +339,8 @@ def main():
                        "rows_per_segment": n, "segments": num_segments, "segments_per_gpu": len(mine), "algorithmic_bytes_per_row": algorithmic_bytes / n,
                        "dictionary": args.dictionary},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms": avg_kernel_ms,
+                         "traffic": traffic, "traffic_replayed": traffic is not None, "traffic_file": "profiles/traffic.json" if traffic is not None else None,
+                         "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms": avg_kernel_ms,
                          "all_kernels_ms": avg_query_ms, "frac_dominant_kernel": achieved_dominant / HBM_PEAK_GBPS,
                          "frac_note": "achieved / frac are algorithmic bytes over ALL kernels of the query (HIP events around every launch of a pg_execute); "
                                       "frac_dominant_kernel is the scan kernel alone",
@@ -400,6 +401,10 @@ def main():
         match = re.compile(args.variants) if args.variants else None
         result["variants"] = bench_variants.run(engine, gsegs[0], segs[0], n, args.rows_c5 or n, match,
                                                     check=(not args.no_cpu_baseline) or os.environ.get("PINOT_BENCH_CHECK_VARIANTS") == "1")
+        # BASELINE.json configs[0] IS a CPU configuration: its scan-forcing companion's 1-core port figure travels in the line (C3's and C5's: the variants file)
+        for v in result["variants"]:
+            if v.get("id") == "C1-sum" and v.get("cpu_baseline"):
+                result["cpu_baseline_c1"] = dict(v["cpu_baseline"], variant="C1-sum", gpu_rows_per_s_host_clock=v["rows"] / v["step_ms_host_clock"] * 1e3)
     gsegs[0].close()
     if world > 1:
         dist.barrier()

@@ -317,6 +317,25 @@ def execute_sliced(segment_data, spec, threads=None):
     return merged
 
 
+def execute_prefix(segment_data, spec, rows):
+    """The oracle on ONE host core over the first `rows` docs of a segment (rounded down to a multiple of 8 docs: whole bytes of every
+    bit width; the slice is a view of the same packed buffers) -- a bounded cpu_baseline sample of a 1 B-row workload.  Segments with
+    raw columns or inverted indexes are not cut: the whole segment runs.  Returns (Result, seconds, rows that ran)."""
+    import time
+    from pinot_amd import segment as S
+    n = segment_data.num_docs
+    rows = min(n, max(8, rows // 8 * 8))
+    cut = rows < n and all(c.encoding == _abi.PG_FWD_FIXED_BIT_DICT and c.inverted is None for c in segment_data.columns)
+    part = segment_data
+    if cut:
+        cols = [S.Column(c.name, c.encoding, c.bits, c.cardinality, c.fwd[:(rows * c.bits + 7) // 8], c.dictionary, None, c.dict_values, stored_type=c.stored_type)
+                for c in segment_data.columns]
+        part = S.SegmentData("prefix", rows, cols)
+    t0 = time.perf_counter()
+    res = execute(part, spec)
+    return res, time.perf_counter() - t0, part.num_docs
+
+
 def matches_sliced(got, want, functions):
     """A pinot_amd.query.Result against execute_sliced's merge: bit exact on what each function defines."""
     def same(a, w, f):

@@ -87,6 +87,7 @@ struct Engine {
   bool lean_batch = true;    // PINOT_GPU_LEAN_BATCH=0: items of scan_simple_kernel's shape share the general batch launch
   bool partition_two_level = true;   // PINOT_GPU_PARTITION_TWO_LEVEL=0: key spaces above one scatter pass keep the direct HBM atomics
   bool fsm_perm = true;      // PINOT_GPU_FSM_PERM=0: the transducer pass always walks tables (fsm_tiles_kernel), never byte functions
+  int index_and_waves = 0;    // PINOT_GPU_INDEX_AND_WAVES=n: index_and_kernel's persistent grid is n wavefronts per CU (0: what the registers and the LDS admit; -1: one wavefront per window, as before round 6)
   bool index_gather = true;  // PINOT_GPU_INDEX_GATHER=0: an index-led aggregation always runs scan_sparse_kernel behind index_and_kernel (never inside it)
   bool fsm_fused = true;     // PINOT_GPU_FSM_FUSED=0: the transducer always runs as a pass of its own behind the scan (leaf bitmaps through HBM)
   bool fsm_stats = true;     // PINOT_GPU_FSM_STATS=0: no transducer pass (host replay / upper bound)
@@ -939,6 +940,7 @@ struct Lowered {
   // an aggregation over a handful of survivors per window is done INSIDE it (gathered: no bitmap, no second kernel), everything else its
   // bitmap and window masks.  Lowering only prepares the kernel's arguments.
   bool and_pending = false, and_cardinality_only = false, gathered = false;
+  int and_num_cus = 256;                       // the segment's CUs (pg_segment.num_cus): index_and_kernel's persistent grid is sized by them
   IndexAndParams and_params;
   double and_expected_docs = 0;                // the planner's estimate of the AND's cardinality (independent postings)
   FsmSide* side = nullptr;                     // in: the transducer pass wants the leaves' bitmaps (ScanParams.leaf_out)
@@ -1131,7 +1133,11 @@ pg_status launch_index_and(Lowered* lw, ExecCtx* ctx, const ScanParams* gather_f
     lw->cardinality_atomic = true;
   }
   if (num_windows) {
-    index_and_kernel<<<dim3(num_windows), dim3(64), 0, ctx->stream>>>(ap);
+    // a persistent grid: what is resident (one wavefront per workgroup), each wave takes windows key, key + grid, ... with the next window's
+    // directory lookups in flight (pg_index_and.h).  PINOT_GPU_INDEX_AND_WAVES=n: n waves per CU; -1: one wave per window (rounds 2-5).
+    const int per_cu = g_engine.index_and_waves > 0 ? g_engine.index_and_waves : waves_index_and();
+    const unsigned grid = g_engine.index_and_waves < 0 ? num_windows : (unsigned)std::min<long long>(num_windows, (long long)lw->and_num_cus * per_cu);
+    launch_index_and_kernel((int)grid, ctx->stream, ap, num_windows);
     HIP_TRY(hipGetLastError());
     // (index_and_finalize_kernel: only when the tile list is read -- complete_index_list)
     lw->finalize_pending = !lw->and_cardinality_only && gather_from == nullptr;
@@ -1344,6 +1350,7 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
       HIP_TRY(mark_pre_work(ctx));
       // (the launch itself: launch_index_and, once the planner knows what reads the kernel's output)
       lw->and_params = ap;
+      lw->and_num_cus = seg->num_cus;
       lw->and_pending = true;
       lw->and_cardinality_only = cardinality_only;
       lw->finalize_windows = num_windows;
@@ -1752,6 +1759,7 @@ pg_status pg_init(const pg_config* config) {
   g_engine.fsm_fused = env_on("PINOT_GPU_FSM_FUSED");
   g_engine.fsm_episodes = env_on("PINOT_GPU_FSM_EPISODES");
   g_engine.index_gather = env_on("PINOT_GPU_INDEX_GATHER");
+  { const char* iaw = getenv("PINOT_GPU_INDEX_AND_WAVES"); g_engine.index_and_waves = iaw ? std::max(-1, std::min(32, atoi(iaw))) : 0; }
   g_engine.group_one_launch = env_on("PINOT_GPU_GROUP_ONE_LAUNCH");
   g_engine.plan_cache = env_on("PINOT_GPU_PLAN_CACHE");
   const char* bmo = getenv("PINOT_GPU_BATCH_MORE");

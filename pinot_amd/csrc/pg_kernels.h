@@ -2493,47 +2493,9 @@ static __global__ __launch_bounds__(kBlockThreads) void roaring_expand_kernel(co
 }
 
 // ------------------------------------------------------------------------------------------------
-// index_and_kernel: AND of inverted-index leaves at RoaringBitmap-container granularity -- AndDocIdSet.iterator's index-based
-// branch (core/operator/docidsets/AndDocIdSet.java:127-165: the bitmaps of all index-based children are and-ed, smallest first)
-// and BitmapCollection (core/operator/filter/BitmapCollection.java:58-128) for inverted (NOT_EQ / NOT_IN) members.
-//
-// ONE WAVEFRONT per 65 536-doc window (a workgroup is a single wave: its barriers cost nothing, nothing is shared with other
-// waves, and 8 KB of LDS per wave keeps ~18 windows in flight per CU -- the work per window is a handful of dependent loads, so
-// the kernel lives on how many windows are in flight, not on bandwidth).  The accumulator, 1024 words, stays in REGISTERS: lane l
-// owns the word pairs (2l + 128 i, 2l + 1 + 128 i), i = 0..7, so bitset containers, dense children and the result move as one
-// 16-byte access per lane and never touch LDS.  Array and run containers (and children that OR several postings: a child is the
-// OR of the postings of its matching dictIds, InvertedIndexFilterOperator.java:60-145) are scattered into the wave's 8 KB LDS
-// window with ds_or, read back by the owning lanes and re-zeroed in the same pass.  Serialized containers start at any byte
-// offset (odd array lengths, a run-flag bitset): they are read with aligned dword loads and re-aligned with v_alignbyte.
-// Every directory lookup of the window (one posting per lane, an interpolated guess confirmed by one load) is issued before any
-// container is touched, so a window costs two dependent loads plus one per child.  The window is finished as soon as the
-// accumulator is empty: later children's containers are never read.  Nothing dense is materialised per child.
-//
-// Per window it leaves {mask of its 32 2048-doc tiles that hold a match, cardinality}; index_and_finalize_kernel turns those into
-// the ascending list of matching tiles (the aggregating kernels visit only those) and the cardinality (COUNT(*) over an
-// index-only filter needs nothing else: FastFilteredCountOperator, core/operator/query/FastFilteredCountOperator.java:66-72) --
-// no same-address atomics, and the list order does not depend on scheduling.
+// index_and_kernel (the inverted-index children of a root AND, intersected container by container) lives in pg_index_and.h /
+// pg_unit_index_and.hip; its helpers and the kernels behind it follow.
 // ------------------------------------------------------------------------------------------------
-// Container of `key` inside one posting's sorted directory slice.  Postings of frequent values have a container in (nearly) every
-// window, so the slot is guessed by interpolation and confirmed with one load; a binary search over what is left otherwise.
-__device__ __forceinline__ bool find_container(const DevContainer* __restrict__ dir, int first, int count, uint32_t key, uint32_t num_windows, DevContainer* out) {
-  if (count <= 0) return false;
-  int lo = first, hi = first + count - 1;
-  int g = first + (int)(((unsigned long long)key * (unsigned long long)count) / (num_windows ? num_windows : 1u));
-  g = g > hi ? hi : g;
-  const DevContainer guess = dir[g];                    // the whole 24-byte entry: a right guess costs one round trip, not two
-  if (guess.key == key) { *out = guess; return true; }
-  // keys are distinct and ascending, so the slot is no further from the guess than the keys are apart
-  if (guess.key < key) { lo = g + 1; const long long far = (long long)g + (long long)(key - guess.key); hi = far < hi ? (int)far : hi; }
-  else { hi = g - 1; const long long far = (long long)g - (long long)(guess.key - key); lo = far > lo ? (int)far : lo; }
-  while (lo <= hi) {
-    const int mid = (lo + hi) >> 1;
-    const uint32_t k = dir[mid].key;
-    if (k < key) lo = mid + 1; else if (k > key) hi = mid - 1; else { *out = dir[mid]; return true; }
-  }
-  return false;
-}
-
 struct __attribute__((aligned(4))) Dwords4 { uint32_t x, y, z, w; };
 
 // 16 bytes at byte offset 16 * index of a stream that starts `lead` bytes into the 4-byte aligned `origin`.
@@ -2551,225 +2513,6 @@ __device__ __forceinline__ Dwords4 load16_stream(const uint32_t* __restrict__ or
 }
 
 __device__ __forceinline__ void or_doc(uint32_t* w32, uint32_t doc) { atomicOr(&w32[doc >> 5], 1u << (doc & 31u)); }
-
-// Round 4, what did NOT move this kernel (C5-sparse, 1 B rows, 15 259 windows, 66 us; rocprofv3 SQ counters in profiles/r4/pmc_c5s_sq*_summary.json:
-// ~1 660 instructions and ~11.6 us per window, 29 % of it issuing, 60 % waiting, ~2 850 of 4 096 possible windows in flight):
-//   five windows per SIMD (96 VGPRs, 7 spilled)                                        66.4 -> 63.7 us, the dense AND 55.1 -> 59.7
-//   touching every later child's array / run container right after the directory lookup   66.9 -> 71.9 us (twice, two codings)
-//   the lanes' arguments through scalar loads + selects instead of lane-indexed loads      66.2 -> 66.4 us
-#ifndef PG_INDEX_AND_WAVES
-#define PG_INDEX_AND_WAVES 4           // wavefronts (= windows) per SIMD the register allocation must allow
-#endif
-static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kernel(const IndexAndParams ap) {
-  __shared__ uint4 window[512];                         // 1024 64-bit words; all zero whenever no child is being expanded
-  uint32_t* w32 = reinterpret_cast<uint32_t*>(window);
-  const int lane = (int)threadIdx.x;
-  const uint32_t key = blockIdx.x;
-  const long long base = (long long)key * 1024;         // first word of the window
-  const long long words_here = ap.num_words - base < 1024 ? ap.num_words - base : 1024;   // a multiple of 32
-
-  // ---- every directory lookup of the window at once: lane t looks posting t up ----
-  int c_valid = 0;
-  uint32_t c_card = 0, c_type = 0, c_runs = 0, c_off_lo = 0, c_off_hi = 0;
-  if (lane < ap.num_postings) {
-    const AndChild& ch = ap.child[ap.posting_child[lane]];
-    DevContainer dc;
-    if (find_container(ch.dir, ap.first[lane], ap.count[lane], key, gridDim.x, &dc)) {
-      c_valid = 1; c_card = dc.cardinality; c_type = dc.type; c_runs = dc.num_runs;
-      c_off_lo = (uint32_t)dc.offset; c_off_hi = (uint32_t)(dc.offset >> 32);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) window[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
-  __syncthreads();
-
-  uint4 acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = make_uint4(0u, 0u, 0u, 0u);
-  bool alive = true;                                    // uniform
-  for (int c = 0; c < ap.num_children; ++c) {
-    const AndChild& ch = ap.child[c];
-    uint4 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (ch.dense != nullptr) {
-      const uint4* src = reinterpret_cast<const uint4*>(ch.dense + base);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) if (2 * (lane + 64 * i) < words_here) v[i] = src[lane + 64 * i];
-    } else {
-      int found = 0, last = -1;
-      for (int q = ch.posting_begin; q < ch.posting_end; ++q) if (__builtin_amdgcn_readlane(c_valid, q)) { found++; last = q; }
-      if (found == 0) {
-        if (!ch.exclusive) { alive = false; break; }    // this child has nothing in the window: neither has the AND
-      } else if (found == 1 && __builtin_amdgcn_readlane((int)c_type, last) == 1) {
-        // a single bitset container: straight from HBM into the owning lanes
-        const unsigned long long off = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)c_off_lo, last) |
-                                       ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)c_off_hi, last) << 32);
-        const uint32_t lead = (uint32_t)(off & 3ull);
-        const uint32_t* origin = reinterpret_cast<const uint32_t*>(ch.inv + (off - lead));
-        // Behind the smaller children only the pieces where something still stands are wanted (three postings of 1 / 256, 1 / 64 and
-        // 1 / 16 of the docs: ~4 docs of the window are left when the 8 KB bitset of the largest comes up -- AndDocIdSet.java:127-165
-        // and-s smallest first for the same reason).  A lane whose piece is not wanted reads piece 0 instead -- one line for the whole
-        // wave -- so that the eight loads stay unconditional (a load under an exec mask is waited for before the branch is left).
-        const bool probe = c > 0 && !ch.exclusive;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const bool wanted = !probe || (acc[i].x | acc[i].y | acc[i].z | acc[i].w) != 0u;
-          const Dwords4 d = load16_stream(origin, lead, wanted ? lane + 64 * i : 0);
-          v[i] = wanted ? make_uint4(d.x, d.y, d.z, d.w) : make_uint4(0u, 0u, 0u, 0u);
-        }
-      } else {
-        for (int q = ch.posting_begin; q < ch.posting_end; ++q) {
-          if (!__builtin_amdgcn_readlane(c_valid, q)) continue;
-          const uint32_t type = (uint32_t)__builtin_amdgcn_readlane((int)c_type, q);
-          const unsigned long long off = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)c_off_lo, q) |
-                                         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)c_off_hi, q) << 32);
-          if (type == 0u) {
-            // array container: sorted 16-bit docIds, eight per lane and step
-            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)c_card, q);
-            const uint32_t lead = (uint32_t)(off & 3ull);
-            const uint32_t* origin = reinterpret_cast<const uint32_t*>(ch.inv + (off - lead));
-            for (uint32_t e0 = 8u * (uint32_t)lane; e0 < n; e0 += 512u) {
-              const Dwords4 d = load16_stream(origin, lead, e0 >> 3);
-              const uint32_t left = n - e0;
-              or_doc(w32, d.x & 0xffffu);
-              if (left > 1u) or_doc(w32, d.x >> 16);
-              if (left > 2u) or_doc(w32, d.y & 0xffffu);
-              if (left > 3u) or_doc(w32, d.y >> 16);
-              if (left > 4u) or_doc(w32, d.z & 0xffffu);
-              if (left > 5u) or_doc(w32, d.z >> 16);
-              if (left > 6u) or_doc(w32, d.w & 0xffffu);
-              if (left > 7u) or_doc(w32, d.w >> 16);
-            }
-          } else if (type == 1u) {
-            const uint32_t lead = (uint32_t)(off & 3ull);
-            const uint32_t* origin = reinterpret_cast<const uint32_t*>(ch.inv + (off - lead));
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const Dwords4 d = load16_stream(origin, lead, lane + 64 * i);
-              uint4 o = window[lane + 64 * i];           // this lane's own words: no other lane writes them between the two accesses
-              o.x |= d.x; o.y |= d.y; o.z |= d.z; o.w |= d.w;
-              window[lane + 64 * i] = o;
-            }
-          } else {
-            // run container: u16 count, then (start, length - 1) pairs
-            const uint32_t runs = (uint32_t)__builtin_amdgcn_readlane((int)c_runs, q);
-            const unsigned long long first = off + 2ull;
-            const uint32_t lead = (uint32_t)(first & 3ull);
-            const uint32_t* origin = reinterpret_cast<const uint32_t*>(ch.inv + (first - lead));
-            for (uint32_t r = (uint32_t)lane; r < runs; r += 64u) {
-              uint32_t pair = origin[r];
-              if (lead != 0u) pair = __builtin_amdgcn_alignbyte(origin[r + 1], pair, lead);
-              const uint32_t start = pair & 0xffffu;
-              uint32_t end = start + (pair >> 16);                            // inclusive
-              end = end > 65535u ? 65535u : end;                              // a malformed run must not leave the window
-              for (uint32_t wi = start >> 5; wi <= (end >> 5); ++wi) {
-                const uint32_t lo = wi == (start >> 5) ? (start & 31u) : 0u;
-                const uint32_t hi = wi == (end >> 5) ? (end & 31u) : 31u;
-                atomicOr(&w32[wi], (hi - lo == 31u ? ~0u : ((1u << (hi - lo + 1u)) - 1u)) << lo);
-              }
-            }
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { v[i] = window[lane + 64 * i]; window[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u); }
-        __syncthreads();
-      }
-    }
-    uint32_t any = 0u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      uint4 x = v[i];
-      if (ch.exclusive) { x.x = ~x.x; x.y = ~x.y; x.z = ~x.z; x.w = ~x.w; }
-      if (c > 0) { x.x &= acc[i].x; x.y &= acc[i].y; x.z &= acc[i].z; x.w &= acc[i].w; }
-      acc[i] = x;
-      any |= x.x | x.y | x.z | x.w;
-    }
-    alive = __builtin_amdgcn_ballot_w64(any != 0u) != 0ull;
-    if (!alive) break;
-  }
-
-  // ---- the window's result: docs past numDocs cleared (an exclusive child sets them), words, tile mask, cardinality ----
-  uint32_t tiles = 0u;
-  uint32_t card = 0u;
-  unsigned long long gsum[kMaxAndGather] = {0ull, 0ull};       // gather mode: the survivors' values of this lane
-  uint32_t gmin[kMaxAndGather] = {0xFFFFFFFFu, 0xFFFFFFFFu}, gmax[kMaxAndGather] = {0u, 0u};
-  const long long docs_left = (long long)ap.num_docs - base * 64;      // docs of the segment from this window on
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint4 x = alive ? acc[i] : make_uint4(0u, 0u, 0u, 0u);
-    const long long bit0 = 128ll * (lane + 64 * i);                    // window-relative doc of this pair's first bit
-    if (bit0 + 128 > docs_left) {
-      uint32_t* xs = &x.x;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const long long rem = docs_left - (bit0 + 32 * k);
-        if (rem <= 0) xs[k] = 0u; else if (rem < 32) xs[k] &= (1u << (int)rem) - 1u;
-      }
-    }
-    card += (uint32_t)(__builtin_popcount(x.x) + __builtin_popcount(x.y) + __builtin_popcount(x.z) + __builtin_popcount(x.w));
-    if (ap.gather_cols != 0 && (x.x | x.y | x.z | x.w) != 0u) {
-      // the survivors' values, read here (a handful per window by the planner's estimate): doc -> (tile, lane, position) of the packed column
-      const uint32_t xs4[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        uint32_t w = xs4[k];
-        while (w != 0u) {
-          const uint32_t j = (uint32_t)__builtin_ctz(w);
-          w &= w - 1u;
-          const long long doc = base * 64 + bit0 + 32 * k + (long long)j;
-#pragma unroll
-          for (int a = 0; a < kMaxAndGather; ++a) {
-            if (a < ap.gather_cols) {
-              const DevAggCol& gc = ap.gather_col[a];
-              const uint32_t b = (uint32_t)gc.bits, bit = ((uint32_t)doc & 31u) * b;
-              const uint32_t* at = reinterpret_cast<const uint32_t*>(gc.fwd + (doc >> 11) * (256ll * (long long)b)) + (((uint32_t)doc >> 5) & 63u) * b + (bit >> 5);
-              const Dwords2 d = *reinterpret_cast<const Dwords2*>(at);
-              const unsigned long long x64 = ((unsigned long long)__builtin_bswap32(d.x) << 32) | (unsigned long long)__builtin_bswap32(d.y);
-              const uint32_t v = (uint32_t)(x64 >> (64u - (bit & 31u) - b)) & ((1u << b) - 1u);
-              gsum[a] += v;
-              gmin[a] = v < gmin[a] ? v : gmin[a];
-              gmax[a] = v > gmax[a] ? v : gmax[a];
-            }
-          }
-        }
-      }
-    }
-    // pair 2 (l + 64 i) lies in tile 4 i + (l >> 4)
-    const unsigned long long nz = __builtin_amdgcn_ballot_w64((x.x | x.y | x.z | x.w) != 0u);
-    // sparse output: only the tiles that hold a match are stored (the list-driven kernels read no others; anybody else calls
-    // index_and_zero_unlisted_kernel first)
-    const bool store = !ap.sparse_out || ((nz >> (16 * (lane >> 4))) & 0xffffull) != 0ull;
-    if (ap.out != nullptr && store && 2 * (lane + 64 * i) < words_here) reinterpret_cast<uint4*>(ap.out + base)[lane + 64 * i] = x;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) if ((nz >> (16 * g)) & 0xffffull) tiles |= 1u << (4 * i + g);
-  }
-  const uint32_t total = (uint32_t)wave_sum_i64((long long)card);
-  if (lane == 0) {
-    ap.window_info[key] = WindowInfo{tiles, total};
-    // (kAndCardinalityShards counters, one 128-byte line each: ONE counter made the kernel 58 -> 194 us on C5-sparse -- ~3 700 same-address
-    //  device-scope atomics at ~37 ns apiece, each holding its wave's slot until it retires)
-    if (ap.cardinality_out != nullptr && total != 0u)
-      __hip_atomic_fetch_add(ap.cardinality_out + (size_t)(key & (kAndCardinalityShards - 1)) * 16, (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (ap.gather_cols != 0 && total != 0u) {
-#pragma unroll
-    for (int a = 0; a < kMaxAndGather; ++a) {
-      if (a >= ap.gather_cols) continue;
-      const unsigned long long s = (unsigned long long)wave_sum_i64((long long)gsum[a]);
-      // (keys are below 2^31: dictIds / plane fields -- the signed wave reductions take them as they are)
-      const uint32_t kmin = (uint32_t)wave_min_i32((int32_t)(gmin[a] == 0xFFFFFFFFu ? 0x7FFFFFFF : gmin[a]));
-      const uint32_t kmax = (uint32_t)wave_max_i32((int32_t)gmax[a]);
-      if (lane == 0) {
-        unsigned long long* o = ap.gather_out + (size_t)(key & (kAndCardinalityShards - 1)) * 16 + 1 + 3 * a;      // (word 0 of the line: the cardinality)
-        __hip_atomic_fetch_add(o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_max(o + 1, (unsigned long long)(0xFFFFFFFFu - kmin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_max(o + 2, (unsigned long long)kmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-}
 
 // Completes a sparsely stored result (IndexAndParams.sparse_out) for a reader that does not go by the tile list: zeros in every
 // 2048-doc tile without a match.

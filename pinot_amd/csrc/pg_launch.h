@@ -64,6 +64,9 @@ int waves_scan_narrow_batch(bool single_leaf);
 // scan_typed_batch_kernel<slots>: the same for items of scan_private_typed_kernel's shape (agg_slots: the most any item needs -- 1, 2 or kMaxAggCols)
 void launch_scan_typed_batch(int agg_slots, int total_blocks, hipStream_t stream, const ScanParams* items, const uint32_t* block_first, int num_items);
 int waves_scan_typed_batch(int agg_slots);
+// index_and_kernel: the inverted-index children of a root AND, intersected window by window by a persistent grid of one-wave workgroups (pg_index_and.h)
+void launch_index_and_kernel(int blocks, hipStream_t stream, const IndexAndParams& ap, uint32_t num_windows);
+int waves_index_and();      // wavefronts (= windows in flight) per CU
 // scan_group_kernel<kDma, kLdsTable>: LDS-staged group-by
 void launch_scan_group(bool dma, bool lds_table, int blocks, int threads, size_t lds, hipStream_t stream, const GroupParams& gp);
 int waves_scan_group();

@@ -2,7 +2,9 @@
 // a binary search per doc for the image.  One-time work per column and segment, off the query path after the first GROUP BY on it.
 #include "pg_rank_image.h"
 
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -92,6 +94,11 @@ pg_status build_rank_image(const uint8_t* d_raw, int vkind, long long num_docs, 
     }                                                                                                                  \
   } while (0)
   const size_t n = (size_t)std::max<long long>(num_docs, 1);
+  // PINOT_GPU_RANK_TRACE=1: the phases on the host clock (a stream synchronisation behind each) and the transient allocations, on stderr
+  const bool trace = getenv("PINOT_GPU_RANK_TRACE") != nullptr && getenv("PINOT_GPU_RANK_TRACE")[0] == '1';
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+  const auto t_start = now();
   PG_RANK_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "stream");
   PG_RANK_TRY(hipMalloc((void**)&d_in, n * 8), "keys");
   PG_RANK_TRY(hipMalloc((void**)&d_out, n * 8), "sorted keys");
@@ -99,15 +106,22 @@ pg_status build_rank_image(const uint8_t* d_raw, int vkind, long long num_docs, 
   const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((num_docs + 255) / 256, (long long)num_cus * 16));
   rank_image_keys_kernel<<<dim3(grid), dim3(256), 0, stream>>>(d_raw, vkind, num_docs, d_in);
   PG_RANK_TRY(hipGetLastError(), "keys kernel");
+  double ms_alloc = 0, ms_keys = 0, ms_sort = 0, ms_unique = 0, ms_pack = 0;
+  if (trace) { ms_alloc = ms_since(t_start); const auto t = now(); PG_RANK_TRY(hipStreamSynchronize(stream), "keys"); ms_keys = ms_since(t); }
   size_t temp_sort = 0, temp_unique = 0;
   PG_RANK_TRY(rocprim::radix_sort_keys(nullptr, temp_sort, d_in, d_out, (size_t)num_docs, 0u, 64u, stream), "sort sizing");
   PG_RANK_TRY(rocprim::unique(nullptr, temp_unique, d_out, d_in, d_selected, (size_t)num_docs, rocprim::equal_to<unsigned long long>(), stream), "unique sizing");
   PG_RANK_TRY(hipMalloc(&d_temp, std::max<size_t>(std::max(temp_sort, temp_unique), 256)), "sort scratch");
+  const auto t_sort = now();
   PG_RANK_TRY(rocprim::radix_sort_keys(d_temp, temp_sort, d_in, d_out, (size_t)num_docs, 0u, 64u, stream), "sort");
+  if (trace) { PG_RANK_TRY(hipStreamSynchronize(stream), "sort"); ms_sort = ms_since(t_sort); }
+  const auto t_unique = now();
   PG_RANK_TRY(rocprim::unique(d_temp, temp_unique, d_out, d_in, d_selected, (size_t)num_docs, rocprim::equal_to<unsigned long long>(), stream), "unique");
   size_t selected_count = 0;
   PG_RANK_TRY(hipMemcpyAsync(&selected_count, d_selected, sizeof(size_t), hipMemcpyDeviceToHost, stream), "count copy");
   PG_RANK_TRY(hipStreamSynchronize(stream), "sort / unique");
+  ms_unique = ms_since(t_unique);
+  const auto t_pack = now();
   long long selected = num_docs <= 0 ? 0 : (long long)selected_count;
   if (selected >= 0x7FFFFFFEll) {
     snprintf(message, sizeof(message), "rank image: %lld distinct values do not fit the int dictId domain", selected);
@@ -129,6 +143,11 @@ pg_status build_rank_image(const uint8_t* d_raw, int vkind, long long num_docs, 
     PG_RANK_TRY(hipGetLastError(), "pack kernel");
   }
   PG_RANK_TRY(hipStreamSynchronize(stream), "pack");
+  ms_pack = ms_since(t_pack);
+  if (trace)
+    fprintf(stderr, "[rank image] docs %lld vkind %d cardinality %d bits %d | transient bytes: keys %zu + sorted %zu + sort scratch %zu = %zu | kept: dictionary %zu + image %zu | ms: alloc %.3f keys %.3f sort %.3f unique+copy %.3f pack (binary search per doc) %.3f total %.3f\n",
+            num_docs, vkind, cardinality, bits, n * 8, n * 8, std::max<size_t>(std::max(temp_sort, temp_unique), 256), n * 16 + std::max<size_t>(std::max(temp_sort, temp_unique), 256),
+            (size_t)std::max(cardinality, 1) * 8, image_bytes, ms_alloc, ms_keys, ms_sort, ms_unique, ms_pack, ms_since(t_start));
 #undef PG_RANK_TRY
   cleanup();
   *out_d_dict = d_dict; *out_image = d_image; *out_image_bytes = image_bytes; *out_bits = bits; *out_cardinality = cardinality;

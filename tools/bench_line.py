@@ -2,7 +2,9 @@
 
 Round 4's line was 20.9 KB (a 22-entry `variants` array) and the driver's parser saw only its 8 KB tail, so its record carried no
 roofline and no cpu_baseline.  The full result now goes to a side file and the printed line keeps the contract's keys, `config`,
-`roofline`, `cpu_baseline`, `cpu_baseline_all_cores`, `parity`, `cold_launch_ms`, `overlapped` and `summary`; free-text notes are
+`roofline` (with `traffic_replayed` / `traffic_file`: the traffic figure is a committed PMC pass replayed, never this run's), `cpu_baseline`,
+`cpu_baseline_all_cores`, `cpu_baseline_c1` (BASELINE.json configs[0] is a CPU configuration: its 1-core port figure), `parity`,
+`cold_launch_ms`, `overlapped` and `summary` ({id: [frac on all kernels, all_kernels_ms, bit exact, frac on the host clock]}); free-text notes are
 cut, floats are rounded to six significant digits, and keys are dropped in a fixed order if the line would still pass the limit.
 No torch / GPU imports here: tests/test_bench_line_cpu.py builds a synthetic result and checks the size.
 """
@@ -13,12 +15,12 @@ LIMIT_BYTES = 7600            # the driver keeps an 8 KB tail; stay well inside 
 
 # keys of the printed line, in print order (the contract's keys first; `summary` stays the LAST key)
 HEAD_KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-             "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_all_cores", "parity", "cold_launch_ms",
+             "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_all_cores", "cpu_baseline_c1", "parity", "cold_launch_ms",
              "hbm_GBps_whole_step", "clock_settle_launches", "overlapped", "aliased_devices", "ranks_share_gpus", "result", "setup", "process_model",
              "variants_file", "full_result_file"]
 # dropped first -> last when the line is still too long (the contract's keys and roofline / cpu_baseline are never dropped)
 DROP_ORDER = ["setup", "process_model", "result", "clock_settle_launches", "ranks_share_gpus", "aliased_devices", "overlapped", "hbm_GBps_whole_step",
-              "cpu_baseline_all_cores", "cold_launch_ms", "parity"]
+              "cpu_baseline_all_cores", "cold_launch_ms", "cpu_baseline_c1", "parity"]
 # free text that explains a number: kept in the side file, cut from the line
 NOTE_KEYS = {"note", "frac_note", "empirical_peak_note", "traffic_source", "reference_jvm", "host_cores_available", "check_s",
              "oracle_sum_segment0", "gpu_sum_segment0", "launches_timed"}
@@ -47,12 +49,15 @@ def _clip(s, n):
 
 
 def summary_of(result):
-    """{variant id: [frac of 8 TB/s on all kernels of the query, all_kernels_ms, bit exact vs oracle]} for the headline and every variant."""
+    """{variant id: [frac of 8 TB/s on all kernels of the query, all_kernels_ms, bit exact vs oracle, frac of 8 TB/s on the HOST clock around
+    the call]} for the headline and every variant (the headline's fourth entry: the whole step -- all its segments -- on the host clock)."""
     roof = result.get("roofline") or {}
-    out = {"headline(configs[1],[3])": [roof.get("frac"), roof.get("all_kernels_ms"), (result.get("parity") or {}).get("bit_exact_vs_oracle")]}
+    whole = result.get("hbm_GBps_whole_step")
+    out = {"headline(configs[1],[3])": [roof.get("frac"), roof.get("all_kernels_ms"), (result.get("parity") or {}).get("bit_exact_vs_oracle"),
+                                        None if whole is None or not roof.get("peak") else whole / roof["peak"]]}
     for v in result.get("variants") or []:
-        out[str(v.get("id"))] = [v.get("frac"), v.get("all_kernels_ms"), v.get("bit_exact_vs_oracle")]
-    return {k: [None if a is None else round(a, 4), None if b is None else round(b, 4), c] for k, (a, b, c) in out.items()}
+        out[str(v.get("id"))] = [v.get("frac"), v.get("all_kernels_ms"), v.get("bit_exact_vs_oracle"), v.get("frac_host_clock")]
+    return {k: [None if a is None else round(a, 4), None if b is None else round(b, 4), c, None if d is None else round(d, 4)] for k, (a, b, c, d) in out.items()}
 
 
 def compact(result, variants_file=None, full_file=None, limit=LIMIT_BYTES):
@@ -72,7 +77,7 @@ def compact(result, variants_file=None, full_file=None, limit=LIMIT_BYTES):
     cfg = line.get("config")
     if isinstance(cfg, dict) and isinstance(cfg.get("workload"), str):
         cfg["workload"] = _clip(cfg["workload"], 400)
-    for key in ("cpu_baseline", "cpu_baseline_all_cores"):
+    for key in ("cpu_baseline", "cpu_baseline_all_cores", "cpu_baseline_c1"):
         if isinstance(line.get(key), dict) and isinstance(line[key].get("sample"), str):
             line[key]["sample"] = _clip(line[key]["sample"], 240)
     summary = summary_of(result)

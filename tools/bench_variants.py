@@ -37,7 +37,13 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
     out = []
     want = lambda vid: match is None or match.search(vid) is not None
 
-    def report(vid, config, query, rows, nbytes, gseg, seg, spec, oracle_spec=None, extra=None):
+    def cpu_port(seg, spec, sample_rows):
+        """A 1-core cpu_baseline for a variant: the C oracle ("port": no JDK here) over a bounded prefix of the same workload."""
+        res, secs, ran = oracle.execute_prefix(seg, spec, sample_rows)
+        return {"value": ran / secs, "unit": "rows/s", "cores": 1, "kind": "port",
+                "sample": "the first %d of %d rows of the same segment and query through the C oracle on one host core; %.2f s" % (ran, seg.num_docs, secs)}
+
+    def report(vid, config, query, rows, nbytes, gseg, seg, spec, oracle_spec=None, extra=None, cpu_rows=0):
         t = timer.run(gseg, spec, steps, warmup)
         rec = {"id": vid, "config": config, "query": query, "rows": rows}
         rec.update(t)
@@ -55,6 +61,9 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
             wanted = oracle.execute_sliced(seg, oracle_spec or spec)
             rec["bit_exact_vs_oracle"] = bool(oracle.matches_sliced(got, wanted, [f for f, _ in spec.aggregations]) and got.stats[0] == wanted["docs_scanned"])
             rec["oracle_check_s"] = time.perf_counter() - t0
+            if cpu_rows:
+                rec["cpu_baseline"] = cpu_port(seg, spec, cpu_rows)          # (the query as the reference would run it: inverted leaves through the postings)
+        rec["frac_host_clock"] = (nbytes / t["step_ms_host_clock"] / 1e6 / HBM_PEAK_GBPS) if t["step_ms_host_clock"] > 0 else None
         if extra:
             rec.update(extra)
         out.append(rec)
@@ -96,7 +105,8 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                     report(vid, "BASELINE.md C2a (predicate on the summed column)", "SELECT SUM(%s) WHERE %s BETWEEN dict[45000] AND dict[54999] (10%%)" % (seg.columns[ci].name, seg.columns[ci].name),
                            n, B(v), g, seg, Q.QuerySpec([(Q.SUM, ci)], filter=Q.leaf(Q.Pred.dict_range(ci, 45000, 55000))), extra={"dictionary": "affine" if ci == 0 else "irregular"})
             if want("C3"):
-                report("C3", "BASELINE.json configs[2]", "SELECT SUM(a), MAX(b) GROUP BY k (1000 groups)", n, B(k) + B(a) + B(b), g, seg, Q.QuerySpec([(Q.SUM, 5), (Q.MAX, 6)], group_by=[4]))
+                report("C3", "BASELINE.json configs[2]", "SELECT SUM(a), MAX(b) GROUP BY k (1000 groups)", n, B(k) + B(a) + B(b), g, seg, Q.QuerySpec([(Q.SUM, 5), (Q.MAX, 6)], group_by=[4]),
+                       cpu_rows=200_000_000)
             if want("C3-filter"):
                 report("C3-filter", "BASELINE.json configs[2] + filter", "SELECT SUM(a), MAX(b) WHERE f < 100 GROUP BY k", n, B(k) + B(a) + B(b) + B(f), g, seg,
                        Q.QuerySpec([(Q.SUM, 5), (Q.MAX, 6)], filter=flt, group_by=[4]))
@@ -159,6 +169,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                 report(vid, "BASELINE.json configs[4]", "SELECT SUM(v) WHERE p=%d AND q=%d AND r=%d via inverted indexes (C = %d / %d / %d)" % (picks + cards), n_c5,
                        sum(post) + value_bytes, g, seg5, Q.QuerySpec([(Q.SUM, 3)], filter=Q.and_(inv(0, picks[0]), inv(1, picks[1]), inv(2, picks[2]))),
                        oracle_spec=Q.QuerySpec([(Q.SUM, 3)], filter=Q.and_(scan(0, picks[0]), scan(1, picks[1]), scan(2, picks[2]))),
+                       cpu_rows=n_c5,
                        extra={"posting_bytes_read": post, "value_bytes": value_bytes, "host_generate_s": gen_s,
                               "algorithmic_bytes_note": "the three serialized postings + min(B(v), survivors x 64 B); dense intermediates are not charged (BASELINE.md C5)"})
             if want(vid + "-count"):
@@ -179,8 +190,8 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
         seg1 = S.SegmentData("c1", n1, [raw])
         with engine.open(seg1) as g:
             report("C1-count-range", "BASELINE.json configs[0], scan-forcing companion", "SELECT COUNT(*) WHERE raw_i32 BETWEEN 1 AND 10 (10 M rows, raw)", n1, 4 * n1, g, seg1,
-                   Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.raw_range(0, 1, 10))))
-            report("C1-sum", "BASELINE.json configs[0], scan-forcing companion", "SELECT SUM(raw_i32) (10 M rows, raw)", n1, 4 * n1, g, seg1, Q.QuerySpec([(Q.SUM, 0)]))
+                   Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.raw_range(0, 1, 10))), cpu_rows=n1)
+            report("C1-sum", "BASELINE.json configs[0], scan-forcing companion", "SELECT SUM(raw_i32) (10 M rows, raw)", n1, 4 * n1, g, seg1, Q.QuerySpec([(Q.SUM, 0)]), cpu_rows=n1)
             report("C1-count", "BASELINE.json configs[0] literally: O(1) in the reference (NonScanBasedAggregationOperator) and here", "SELECT COUNT(*) (10 M rows)", n1, 0, g, seg1,
                    Q.QuerySpec([(Q.COUNT, -1)]))
         if want("C1-group-by"):
@@ -302,6 +313,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                             "rows": n1 * nseg, "algorithmic_bytes": int(nbytes), "modes": modes, "kernel": launch, "kernel_body": body, "kernel_ms": modes["batch"].get("kernel_ms"),
                             "all_kernels_ms": modes["batch"].get("kernel_ms"), "step_ms_host_clock": modes["batch"]["wall_ms"], "achieved_GBps": modes["batch"]["aggregate_GBps"],
                             "frac": modes["batch"]["frac_of_8TBps"], "frac_dominant_kernel": (modes["batch"]["kernel_GBps"] / HBM_PEAK_GBPS) if modes["batch"].get("kernel_GBps") else None,
+                            "frac_host_clock": modes["batch"]["frac_of_8TBps"],
                             "rows_per_s": n1 * nseg / modes["batch"]["wall_ms"] * 1e3, "bit_exact_vs_oracle": exact, "host_generate_s": gen_s,
                             "note": "frac / achieved_GBps are on the HOST clock around the whole call (lowering, launch, completion of all 64 segments)"})
         finally:

@@ -1,0 +1,44 @@
+#!/bin/bash
+# tools/gpu_r6.sh <tag> <step...>: round-6 GPU sessions in named steps; everything lands under gpurun_out/<tag>/
+#   ia_tests    the suites that reach index_and_kernel (its own tests, the tiny grid, the fuzz, the kernel-coverage gate, the goldens)
+#   c5_ab       C5 sparse / dense on resident 1 B-row segments: index_and_kernel's grid -- one wave per window, the persistent default, 8 / 12 / 20 waves per CU
+#   not_trace   rocprofv3 --kernel-trace --stats of AND-NOT-scan at 1 B rows: the episode pass per kernel
+#   c5_pmc      FETCH_SIZE of the C5 kernels (tools/profile_round.sh c5)
+#   rank        tools/rank_image_probe.py at 1 B rows (raw DOUBLE, 40-bit LONG)
+#   suite       the whole GPU suite
+#   bench       python bench.py (the driver's line)
+cd $GRAFT_REPO_ROOT; TAG=$1; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+for step in "$@"; do
+echo "=== $step"; t0=$(date +%s)
+case $step in
+ia_tests)
+  timeout 1500 python -m pytest tests/test_gpu_index_and.py tests/test_gpu_tiny_grid.py tests/test_gpu_fuzz.py tests/test_gpu_golden.py tests/test_gpu_kernel_coverage.py -m gpu -x -q 2>&1 | tail -15 | tee $OUT/ia_tests.txt ;;
+c5_ab)
+  timeout 1500 python tools/ab_r6.py c5 --steps 20 --out $OUT/c5_ab.jsonl --settings "PINOT_GPU_INDEX_AND_WAVES=-1;;PINOT_GPU_INDEX_AND_WAVES=8;PINOT_GPU_INDEX_AND_WAVES=12;PINOT_GPU_INDEX_AND_WAVES=20;PINOT_GPU_INDEX_AND_WAVES=-1;" 2> $OUT/c5_ab.err | python -c "
+import sys, json
+for l in sys.stdin:
+    r = json.loads(l); print('%-16s %-34s kernel %.4f all %.4f host %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r['frac_all_kernels'] or 0, r['exact']))" ;;
+c3_ab)
+  timeout 1500 python tools/ab_r6.py c3 --steps 20 --out $OUT/c3_ab.jsonl --settings "${C3_SETTINGS:-}" 2> $OUT/c3_ab.err | python -c "
+import sys, json
+for l in sys.stdin:
+    r = json.loads(l); print('%-16s %-34s kernel %.4f all %.4f host %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r['frac_all_kernels'] or 0, r['exact']))" ;;
+not_trace)
+  rm -rf $OUT/not_trace
+  (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/not_trace -o t -- python $GRAFT_REPO_ROOT/tools/ab_r6.py not --steps 10 --warmup 10 --match AND-NOT --no-check > $GRAFT_REPO_ROOT/$OUT/not_trace.jsonl 2> $GRAFT_REPO_ROOT/$OUT/not_trace.err)
+  find $OUT/not_trace -name "*kernel_stats*.csv" -exec cat {} \; | cut -c1-220 | head -24 | tee $OUT/not_trace_kernel_stats.csv
+  find $OUT/not_trace -name "*kernel_trace*.csv" -size +8M -delete
+  PINOT_GPU_FSM_TRACE=1 timeout 900 python tools/ab_r6.py not --steps 3 --warmup 2 --match AND-NOT --no-check 2>&1 | grep -i "fsm\|episode" | tail -8 | tee $OUT/not_fsm_trace.txt ;;
+c5_pmc)
+  bash tools/profile_round.sh $TAG c5 2>&1 | tail -12 ;;
+rank)
+  timeout 1500 python tools/rank_image_probe.py --rows ${RANK_ROWS:-1000000000} > $OUT/rank_image.jsonl 2> $OUT/rank_image.err; cat $OUT/rank_image.jsonl; grep "rank image" $OUT/rank_image.err ;;
+suite)
+  timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $OUT/gpu_suite.txt ;;
+bench)
+  timeout 1500 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err; tail -c 3600 $OUT/bench_line.json; cp gpurun_out/bench_variants.json $OUT/bench_variants.json 2>/dev/null; cp gpurun_out/bench_full.json $OUT/bench_full.json 2>/dev/null ;;
+*) echo "unknown step $step" ;;
+esac
+echo "--- $step took $(( $(date +%s) - t0 )) s"
+done
