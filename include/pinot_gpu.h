@@ -223,6 +223,15 @@ typedef struct pg_query {
  *    null docs of its own column per group (count == 0: the holder stays null).  numGroupsLimit binds at any key-space size, the
  *    first keys in docId order surviving.  Raw (no-dictionary) key columns: PG_ERR_UNSUPPORTED at plan time. */
 #define PG_QUERY_NULL_HANDLING 1
+/* The caller does not need ExecutionStatistics.numEntriesScannedInFilter (core/operator/ExecutionStatistics.java:25-64) to be the
+ * reference's exact count when that costs work beyond the query's own kernel.  For a filter whose iterators leap-frog (a root AND over
+ * scan-based leaves, OR / NOT children: AndDocIdIterator / OrDocIdIterator / NotDocIdIterator over SVScanDocIdIterator) the exact count
+ * is a walk of its own -- a transducer pass on the device, a chain kernel behind the scan, or a replay on the host (DESIGN.md section 5:
+ * up to several times the query for a NOT child).  With this flag such a filter runs nothing but the query: the statistic is the estimate
+ * numDocs x scan leaves (an upper bound for AND / OR trees; a NOT child, whose leaf is pulled in 256-doc batches, can pass it) and
+ * pg_result.filter_entries_exact = 0.  Everything else of the result is unchanged, and filters whose count
+ * is a closed form or falls out of the kernel (no scan leaf, no AND above one, scan leaves behind index-based children) stay exact. */
+#define PG_QUERY_STATS_UPPER_BOUND_OK 2
 
 /* Intermediate result of one aggregation function, in the reference's holder types:
  * SUM/MIN/MAX -> Double, COUNT -> Long, AVG -> AvgPair(sum, count). */

@@ -63,6 +63,14 @@ public class GpuPlanMaker extends InstancePlanMakerImplV2 {
   public static final String SKIP_STAR_TREE_SEGMENTS_KEY = "gpu.skip.startree";
 
   public static final String BATCH_KEY = "gpu.batch";
+  /**
+   * ExecutionStatistics.numEntriesScannedInFilter of a filter whose iterators leap-frog (a root AND over scan-based leaves, OR / NOT children)
+   * is a walk of its own behind the query on the device -- up to several times the query for a NOT child.  {@code false}: such filters run
+   * nothing but the query and report the upper bound numDocs x scan leaves (PG_QUERY_STATS_UPPER_BOUND_OK); everything else of the result is
+   * unchanged.  Default true (the reference's exact count).  Per query: the query option {@code gpuExactFilterStats=false}.
+   */
+  public static final String EXACT_FILTER_STATS_KEY = "gpu.exact.filter.stats";
+  public static final String EXACT_FILTER_STATS_QUERY_OPTION = "gpuExactFilterStats";
 
   private volatile GpuSegmentCache _segments;
   private boolean _skipStarTreeSegments;
@@ -78,6 +86,7 @@ public class GpuPlanMaker extends InstancePlanMakerImplV2 {
     int device = queryExecutorConfig.getProperty(DEVICE_KEY, 0);
     _skipStarTreeSegments = queryExecutorConfig.getProperty(SKIP_STAR_TREE_SEGMENTS_KEY, false);
     _batchEnabled = queryExecutorConfig.getProperty(BATCH_KEY, true);
+    GpuQueryLowering.setExactFilterStats(queryExecutorConfig.getProperty(EXACT_FILTER_STATS_KEY, true));
     try {
       // One process, every device of the node: pg_init once (its device is only the default for segments that name none), segments
       // placed over the devices by GpuSegmentCache, the library switching to a segment's device in every call.

@@ -17,6 +17,7 @@ package org.apache.pinot.gpu;
 import java.util.ArrayList;
 import java.util.Arrays;
 import java.util.List;
+import java.util.Map;
 import javax.annotation.Nullable;
 import org.apache.pinot.common.request.context.ExpressionContext;
 import org.apache.pinot.common.request.context.FilterContext;
@@ -106,6 +107,23 @@ final class GpuQueryLowering {
   private final List<int[]> _predInts = new ArrayList<>();
   private final List<long[]> _predLongs = new ArrayList<>();
   private final List<int[]> _predSets = new ArrayList<>();
+
+  // gpu.exact.filter.stats of the plan maker's configuration (GpuPlanMaker.init); a query turns it off for itself with the option gpuExactFilterStats=false
+  private static volatile boolean _exactFilterStats = true;
+
+  static void setExactFilterStats(boolean exact) {
+    _exactFilterStats = exact;
+  }
+
+  /** PG_QUERY_STATS_UPPER_BOUND_OK for this query: the server's setting, or the query's own option. */
+  static boolean statsUpperBoundOk(QueryContext queryContext) {
+    if (!_exactFilterStats) {
+      return true;
+    }
+    Map<String, String> options = queryContext.getQueryOptions();
+    String option = options == null ? null : options.get(GpuPlanMaker.EXACT_FILTER_STATS_QUERY_OPTION);
+    return option != null && "false".equalsIgnoreCase(option.trim());
+  }
 
   private GpuQueryLowering(GpuSegment segment, IndexSegment indexSegment, QueryContext queryContext) {
     _segment = segment;
@@ -240,7 +258,8 @@ final class GpuQueryLowering {
       out._setOffsets[i + 1] = at;
     }
     out._numGroupsLimit = _queryContext.getNumGroupsLimit();
-    out._flags = _queryContext.isNullHandlingEnabled() ? PinotGpuNative.PG_QUERY_NULL_HANDLING : 0;
+    out._flags = (_queryContext.isNullHandlingEnabled() ? PinotGpuNative.PG_QUERY_NULL_HANDLING : 0)
+        | (statsUpperBoundOk(_queryContext) ? PinotGpuNative.PG_QUERY_STATS_UPPER_BOUND_OK : 0);
     return out;
   }
 

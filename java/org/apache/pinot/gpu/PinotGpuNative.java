@@ -73,6 +73,8 @@ public final class PinotGpuNative {
 
   /** pg_query.flags */
   public static final int PG_QUERY_NULL_HANDLING = 1;
+  /** numEntriesScannedInFilter of a leap-frogging filter may be the upper bound (no pass behind the query): include/pinot_gpu.h. */
+  public static final int PG_QUERY_STATS_UPPER_BOUND_OK = 2;
 
   /** Record sizes of the flat arrays and slots of the result array (jni/pg_marshal.h). */
   public static final int PGM_FILTER_NODE_INTS = 3;

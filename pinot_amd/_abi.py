@@ -18,7 +18,7 @@ PG_TYPE_INT, PG_TYPE_LONG, PG_TYPE_FLOAT, PG_TYPE_DOUBLE = range(4)
 PG_FWD_FIXED_BIT_DICT, PG_FWD_RAW_FIXED_BYTE = 0, 1
 # pg_predicate_kind / pg_leaf_eval
 PG_PRED_MATCH_ALL, PG_PRED_MATCH_NONE, PG_PRED_DICT_RANGE, PG_PRED_DICT_SET, PG_PRED_RAW_RANGE, PG_PRED_DOC_RANGE, PG_PRED_IS_NULL = range(7)
-PG_QUERY_DEFAULT, PG_QUERY_NULL_HANDLING = 0, 1
+PG_QUERY_DEFAULT, PG_QUERY_NULL_HANDLING, PG_QUERY_STATS_UPPER_BOUND_OK = 0, 1, 2
 PG_EVAL_SCAN, PG_EVAL_INVERTED = 0, 1
 # pg_filter_op
 PG_FILTER_LEAF, PG_FILTER_AND, PG_FILTER_OR, PG_FILTER_NOT = range(4)

@@ -353,6 +353,8 @@ int32_t ph_plan_maker_init(int32_t device, int32_t time_kernels) {
     cfg[GpuPlanMaker::kConfigTimeKernels] = time_kernels ? "true" : "false";
     const char* batch = getenv("PINOT_GPU_HOST_BATCH");          // tests: "0" = every segment operator runs its own pg_execute
     cfg[GpuPlanMaker::kConfigBatch] = (batch && batch[0] == '0') ? "false" : "true";
+    const char* exact = getenv("PINOT_GPU_HOST_EXACT_FILTER_STATS");      // tests: "0" = gpu.exact.filter.stats=false
+    cfg[GpuPlanMaker::kConfigExactFilterStats] = (exact && exact[0] == '0') ? "false" : "true";
     g_planMaker.init(cfg);
   });
 }

@@ -232,6 +232,8 @@ struct QueryContext {
   int maxInitialResultHolderCapacity = 10000;        // InstancePlanMakerImplV2.java:69-91 defaults
   int numGroupsLimit = 100000;
   bool nullHandlingEnabled = false;                  // query option enableNullHandling (QueryContext.isNullHandlingEnabled)
+  bool gpuExactFilterStats = true;                   // query option gpuExactFilterStats (default true): false = numEntriesScannedInFilter of a leap-frogging
+                                                     //   filter may be the upper bound (PG_QUERY_STATS_UPPER_BOUND_OK) -- GpuQueryLowering.java reads the same option
   std::vector<OrderByExpressionContext> orderByExpressions;   // empty = no ORDER BY (getOrderByExpressions() == null)
   int limit = 10;                                    // LIMIT n; the parser's default of 10 rows without a LIMIT clause (CalciteSqlParser / PinotQuery.limit)
   int minSegmentGroupTrimSize = -1;                  // InstancePlanMakerImplV2.java:82-91 defaults; query options of the same names override
@@ -355,6 +357,10 @@ class GpuPlanMaker : public PlanMaker {
   ResultsBlock executeCombined(const std::vector<SegmentContext>& segments, const QueryContext& queryContext, int maxExecutionThreads);
   // pinot.server.query.executor.gpu.batch (default true): the segment operators of one executeCombined share ONE pg_execute_batch
   static constexpr const char* kConfigBatch = "pinot.server.query.executor.gpu.batch";
+  // pinot.server.query.executor.gpu.exact.filter.stats (default true): false = every query runs with PG_QUERY_STATS_UPPER_BOUND_OK (the exact
+  // numEntriesScannedInFilter of a leap-frogging filter is a pass of its own behind the query: DESIGN.md section 5); per query: SET gpuExactFilterStats = false
+  static constexpr const char* kConfigExactFilterStats = "pinot.server.query.executor.gpu.exact.filter.stats";
+  bool exactFilterStats() const { return _exactFilterStats; }
   static constexpr const char* kConfigDevice = "pinot.server.query.executor.gpu.device";
   static constexpr const char* kConfigTimeKernels = "pinot.server.query.executor.gpu.time.kernels";
   // pinot.server.query.executor.gpu.devices: "0-7", "0,2,4", "0-3,6" -- the devices ONE server process drives (a Pinot server is one JVM;
@@ -370,6 +376,7 @@ class GpuPlanMaker : public PlanMaker {
  private:
   int _device = 0;
   bool _batch = true;
+  bool _exactFilterStats = true;
   std::vector<int> _devices{0};
   std::vector<long long> _residentBytes{0};
   std::mutex _placementMu;

@@ -458,7 +458,7 @@ std::unique_ptr<LoweredQuery> lowerQuery(const ImmutableSegment& seg, const Quer
   q.group_by_columns = lq->groupBy.data();
   q.num_group_by = (int32_t)lq->groupBy.size();
   q.num_groups_limit = qc.numGroupsLimit;
-  q.flags = qc.nullHandlingEnabled ? PG_QUERY_NULL_HANDLING : PG_QUERY_DEFAULT;
+  q.flags = (qc.nullHandlingEnabled ? PG_QUERY_NULL_HANDLING : PG_QUERY_DEFAULT) | (qc.gpuExactFilterStats ? 0 : PG_QUERY_STATS_UPPER_BOUND_OK);
   return lq;
 }
 
@@ -681,6 +681,8 @@ void GpuPlanMaker::init(const std::map<std::string, std::string>& cfg) {
   if (it != cfg.end() && it->second == "true") c.flags |= PG_CFG_TIME_KERNELS;
   it = cfg.find(kConfigBatch);
   _batch = it == cfg.end() || it->second != "false";
+  it = cfg.find(kConfigExactFilterStats);
+  _exactFilterStats = it == cfg.end() || it->second != "false";
   checkStatus(gpuAbi().init(&c), "initialising the GPU plan maker");
 }
 
@@ -838,6 +840,11 @@ std::unique_ptr<PlanNode> GpuPlanMaker::makeSegmentPlanNode(const SegmentContext
   const ImmutableSegment* seg = sc.indexSegment;
   if (!seg || !seg->handle()) throw std::runtime_error("segment is not loaded on a device");
   if (qc.aggregations.empty()) throw UnsupportedOperationException("only aggregation / group-by queries are offloaded (selection stays on the CPU plan)");
+  if (!_exactFilterStats && qc.gpuExactFilterStats) {      // the server's setting: every lane of the query is lowered with PG_QUERY_STATS_UPPER_BOUND_OK
+    QueryContext relaxed = qc;
+    relaxed.gpuExactFilterStats = false;
+    return makeSegmentPlanNode(sc, relaxed);
+  }
   // Anything the device cannot run is rejected HERE, at plan time, never at run time.
   bool anyFiltered = false;
   for (const auto& a : qc.aggregations) anyFiltered |= a.hasFilter;

@@ -333,6 +333,7 @@ QueryContext getQueryContext(const std::string& sql) {
     for (auto& c : v) c = (char)tolower((unsigned char)c);
     if (k == "enablenullhandling") q.nullHandlingEnabled = v == "true";
     else if (k == "numgroupslimit") q.numGroupsLimit = atoi(v.c_str());
+    else if (k == "gpuexactfilterstats") q.gpuExactFilterStats = v != "false";
     // QueryOptionsUtils: minSegmentGroupTrimSize / minServerGroupTrimSize / groupTrimThreshold override the plan maker's defaults
     else if (k == "minsegmentgrouptrimsize") q.minSegmentGroupTrimSize = atoi(v.c_str());
     else if (k == "minservergrouptrimsize") q.minServerGroupTrimSize = atoi(v.c_str());

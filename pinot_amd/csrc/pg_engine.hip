@@ -87,7 +87,7 @@ struct Engine {
   bool lean_batch = true;    // PINOT_GPU_LEAN_BATCH=0: items of scan_simple_kernel's shape share the general batch launch
   bool partition_two_level = true;   // PINOT_GPU_PARTITION_TWO_LEVEL=0: key spaces above one scatter pass keep the direct HBM atomics
   bool fsm_perm = true;      // PINOT_GPU_FSM_PERM=0: the transducer pass always walks tables (fsm_tiles_kernel), never byte functions
-  int index_and_waves = 0;    // PINOT_GPU_INDEX_AND_WAVES=n: index_and_kernel's persistent grid is n wavefronts per CU (0: what the registers and the LDS admit; -1: one wavefront per window, as before round 6)
+  int index_and_waves = 0;    // PINOT_GPU_INDEX_AND_WAVES: -k = index_and_kernel's waves take k windows each (grid = windows / k); n > 0 = a persistent grid of n wavefronts per CU; 0 = of as many as are resident
   bool index_gather = true;  // PINOT_GPU_INDEX_GATHER=0: an index-led aggregation always runs scan_sparse_kernel behind index_and_kernel (never inside it)
   bool fsm_fused = true;     // PINOT_GPU_FSM_FUSED=0: the transducer always runs as a pass of its own behind the scan (leaf bitmaps through HBM)
   bool fsm_stats = true;     // PINOT_GPU_FSM_STATS=0: no transducer pass (host replay / upper bound)
@@ -1133,10 +1133,16 @@ pg_status launch_index_and(Lowered* lw, ExecCtx* ctx, const ScanParams* gather_f
     lw->cardinality_atomic = true;
   }
   if (num_windows) {
-    // a persistent grid: what is resident (one wavefront per workgroup), each wave takes windows key, key + grid, ... with the next window's
-    // directory lookups in flight (pg_index_and.h).  PINOT_GPU_INDEX_AND_WAVES=n: n waves per CU; -1: one wave per window (rounds 2-5).
+    // One wavefront per workgroup; a wave takes windows key, key + grid, ... with the next window's directory lookups in flight
+    // (pg_index_and.h).  PINOT_GPU_INDEX_AND_WAVES: 0 (default) = a persistent grid of as many waves as are resident; n > 0 = of n waves per
+    // CU; -k = k windows per wave (grid = windows / k workgroups handed out by the dispatcher as slots free up; -1: a wave per window, rounds
+    // 2-5).  Measured on C5 at 1 B rows (profiles/r6/c5_index_and_*.jsonl): the kernel is bound by instruction issue, not by waiting (SQ
+    // counters: the waves' active-instruction cycles per SIMD add up to the kernel's duration), so the grid's shape moves it by a few
+    // percent only -- after the scalar-instruction diet the resident grid is ahead (COUNT 39.5 vs 43.3 us, gathered SUM 58.1 vs 58.5-59.6);
+    // 8 or 12 waves per CU lose 20 - 40 %.
     const int per_cu = g_engine.index_and_waves > 0 ? g_engine.index_and_waves : waves_index_and();
-    const unsigned grid = g_engine.index_and_waves < 0 ? num_windows : (unsigned)std::min<long long>(num_windows, (long long)lw->and_num_cus * per_cu);
+    const unsigned grid = g_engine.index_and_waves < 0 ? (num_windows + (unsigned)(-g_engine.index_and_waves) - 1) / (unsigned)(-g_engine.index_and_waves)
+                                                        : (unsigned)std::min<long long>(num_windows, (long long)lw->and_num_cus * per_cu);
     launch_index_and_kernel((int)grid, ctx->stream, ap, num_windows);
     HIP_TRY(hipGetLastError());
     // (index_and_finalize_kernel: only when the tile list is read -- complete_index_list)
@@ -1759,7 +1765,7 @@ pg_status pg_init(const pg_config* config) {
   g_engine.fsm_fused = env_on("PINOT_GPU_FSM_FUSED");
   g_engine.fsm_episodes = env_on("PINOT_GPU_FSM_EPISODES");
   g_engine.index_gather = env_on("PINOT_GPU_INDEX_GATHER");
-  { const char* iaw = getenv("PINOT_GPU_INDEX_AND_WAVES"); g_engine.index_and_waves = iaw ? std::max(-1, std::min(32, atoi(iaw))) : 0; }
+  { const char* iaw = getenv("PINOT_GPU_INDEX_AND_WAVES"); g_engine.index_and_waves = iaw ? std::max(-64, std::min(32, atoi(iaw))) : 0; }
   g_engine.group_one_launch = env_on("PINOT_GPU_GROUP_ONE_LAUNCH");
   g_engine.plan_cache = env_on("PINOT_GPU_PLAN_CACHE");
   const char* bmo = getenv("PINOT_GPU_BATCH_MORE");
@@ -2671,7 +2677,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   ctx->pre_started = false;      // ev[0] is recorded by the first piece of work that precedes the scan kernel (mark_pre_work)
   ctx->ev_last = 3;
   if (out && !want_bitmap) lw.stats_plan = fstats::choose_plan(q, &lw.stats_scan_leaves);
-  if (lw.stats_plan == fstats::Plan::kLeap2 && !g_engine.leap2) lw.stats_plan = fstats::Plan::kReplay;
+  if (lw.stats_plan == fstats::Plan::kLeap2 && (!g_engine.leap2 || (q->flags & PG_QUERY_STATS_UPPER_BOUND_OK))) lw.stats_plan = fstats::Plan::kReplay;      // (kReplay with nobody replaying: the upper bound)
   lw.cardinality_only_hint = ng == 0 && out && !want_bitmap && na > 0;
   for (int a = 0; a < na; ++a) lw.cardinality_only_hint = lw.cardinality_only_hint && q->aggregations[a].function == PG_AGG_COUNT;
   lw.side = (out && !want_bitmap && lw.stats_plan == fstats::Plan::kReplay) ? side : nullptr;
@@ -4331,18 +4337,38 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
     HIP_TRY(hipGetLastError());
     fsm_tile_states_kernel<<<dim3((unsigned)chunks), dim3(1024), 0, 0>>>(d_tables, tiles, S, d_chunk_state, d_tile_state);
     HIP_TRY(hipGetLastError());
-    FsmEpisodeParams ep;
-    memset(&ep, 0, sizeof(ep));
-    for (int i = 0; i < L; ++i) ep.leaf[i] = fp.leaf[i];
-    ep.delta = d_delta; ep.marks = d_marks; ep.tile_state = d_tile_state;
-    ep.tile_first_close = d_first_close; ep.tile_last_open = d_last_open;
-    ep.episode_entries = d_episodes; ep.final_pending = d_final_pending;
-    ep.pending_states = fsm.pending_states;
-    ep.num_inputs = L; ep.num_states = S; ep.num_docs = seg->num_docs; ep.num_tiles = (int32_t)tiles;
-    fsm_episode_tiles_kernel<<<dim3(blocks), dim3(256), 0, 0>>>(ep);
-    HIP_TRY(hipGetLastError());
-    fsm_episode_finish_kernel<<<dim3(1), dim3(1024), 0, 0>>>(d_first_close, d_last_open, (int)tiles, seg->num_docs, d_final_pending, d_episodes);
-    HIP_TRY(hipGetLastError());
+    if (perm_walk && S <= 8 && L <= 4) {
+      // machines of at most eight states over at most four inputs: byte functions, a scan over the wavefront, a contiguous range of tiles per
+      // wavefront -- one record per RANGE for the finish kernel (pg_fsm_kernels.h "Round 6")
+      const long long num_ranges = std::min<long long>(tiles, (long long)blocks * 4);
+      FsmEpisodeRangeParams rp;
+      memset(&rp, 0, sizeof(rp));
+      for (int i = 0; i < L; ++i) rp.leaf[i] = fp.leaf[i];
+      rp.delta = d_delta; rp.marks = d_marks; rp.tile_state = d_tile_state;
+      rp.range_first_close = d_first_close; rp.range_last_open = d_last_open;
+      rp.episode_entries = d_episodes; rp.final_pending = d_final_pending;
+      rp.pending_states = fsm.pending_states;
+      rp.num_inputs = L; rp.num_states = S; rp.num_docs = seg->num_docs; rp.num_tiles = (int32_t)tiles; rp.num_ranges = (int32_t)num_ranges;
+      const dim3 rgrid((unsigned)((num_ranges + 3) / 4));
+      if (S <= 4) { if (L <= 2) fsm_episode_ranges_kernel<4, 2><<<rgrid, dim3(256), 0, 0>>>(rp); else fsm_episode_ranges_kernel<4, 4><<<rgrid, dim3(256), 0, 0>>>(rp); }
+      else { if (L <= 2) fsm_episode_ranges_kernel<8, 2><<<rgrid, dim3(256), 0, 0>>>(rp); else fsm_episode_ranges_kernel<8, 4><<<rgrid, dim3(256), 0, 0>>>(rp); }
+      HIP_TRY(hipGetLastError());
+      fsm_episode_finish_kernel<<<dim3(1), dim3(1024), 0, 0>>>(d_first_close, d_last_open, (int)num_ranges, seg->num_docs, d_final_pending, d_episodes);
+      HIP_TRY(hipGetLastError());
+    } else {
+      FsmEpisodeParams ep;
+      memset(&ep, 0, sizeof(ep));
+      for (int i = 0; i < L; ++i) ep.leaf[i] = fp.leaf[i];
+      ep.delta = d_delta; ep.marks = d_marks; ep.tile_state = d_tile_state;
+      ep.tile_first_close = d_first_close; ep.tile_last_open = d_last_open;
+      ep.episode_entries = d_episodes; ep.final_pending = d_final_pending;
+      ep.pending_states = fsm.pending_states;
+      ep.num_inputs = L; ep.num_states = S; ep.num_docs = seg->num_docs; ep.num_tiles = (int32_t)tiles;
+      fsm_episode_tiles_kernel<<<dim3(blocks), dim3(256), 0, 0>>>(ep);
+      HIP_TRY(hipGetLastError());
+      fsm_episode_finish_kernel<<<dim3(1), dim3(1024), 0, 0>>>(d_first_close, d_last_open, (int)tiles, seg->num_docs, d_final_pending, d_episodes);
+      HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipMemcpy(&episodes, d_episodes, 8, hipMemcpyDeviceToHost));
   }
   HIP_TRY(hipMemcpy(&entries, d_entries, 8, hipMemcpyDeviceToHost));
@@ -4363,7 +4389,8 @@ static pg_status execute_one(pg_segment* segment, const pg_query* query, pg_resu
   // (PINOT_GPU_FSM_STATS=0: never): the query's own kernel leaves the leaves' bitmaps in the segment's scratch (one such query at a
   // time per segment), the pass follows.  Other shapes: the host's replay of the iterator tree up to
   // PINOT_GPU_EXACT_FILTER_STATS_DOCS docs, else the upper bound stands.
-  const bool use_fsm = g_engine.fsm_stats;
+  const bool bound_ok = query && (query->flags & PG_QUERY_STATS_UPPER_BOUND_OK);      // the caller takes the upper bound: no pass, no replay
+  const bool use_fsm = g_engine.fsm_stats && !bound_ok;
   fstats::Fsm fsm;
   FsmSide side;
   std::unique_lock<std::mutex> fsm_lock;
@@ -4382,7 +4409,7 @@ static pg_status execute_one(pg_segment* segment, const pg_query* query, pg_resu
                                : execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr, true, defer, fsm_ready ? &side : nullptr);
   if (st == kDeferred) return st;
   // (enableNullHandling changes the iterator tree -- nulls are or-ed in, NOT takes the falses: the upper bound stands there)
-  if (st == PG_OK && !null_handling && !out_result->filter_entries_exact) {
+  if (st == PG_OK && !null_handling && !bound_ok && !out_result->filter_entries_exact) {
     if (fsm_ready) {
       const auto t0 = std::chrono::steady_clock::now();
       if (device_fsm_filter_stats(segment, query, fsm, side, out_result) != PG_OK) {

@@ -599,6 +599,207 @@ static __global__ __launch_bounds__(256) void fsm_episode_tiles_kernel(const Fsm
   if (lane == 0 && sum != 0ull) atomicAdd(p.episode_entries, sum);
 }
 
+// ---- Round 6: the episodes of machines of at most EIGHT states over at most four inputs, without a table walk per entry state ----------------
+// fsm_episode_tiles_kernel above is the general form (sixteen chains of byte reads per doc, lane 0 walking the 64 lane functions one after
+// the other, one record per TILE for a one-workgroup finish): 3.23 ms per 1 B docs behind a 1.07 ms scan (profiles/r6).  Here
+//   * a lane's function {entry state} -> {exit state} is the BYTES of one register (two for five to eight states) and a step over
+//     kDps = 8 / 4 / 2 docs (one / two / three-four inputs) is one LDS read of the step's function and one v_perm_b32 (two): 8 - 16 steps
+//     instead of 32 x S dependent byte reads;
+//   * the state every lane is entered in comes out of an inclusive SCAN of the lane functions over the wavefront (six rounds of one
+//     ds_bpermute + one v_perm_b32), not out of a 64-step walk by lane 0;
+//   * the second walk is ONE chain from that state: a 32-bit LDS read per step gives {next state, the step's opens, its closes};
+//   * a wavefront owns a CONTIGUOUS range of tiles and carries the last open across them, so what is left to pair across wavefronts is
+//     one {first unpaired close, last open} per wavefront (<= 2^14 records for fsm_episode_finish_kernel, which took 0.39 ms over one
+//     record per tile on its one compute unit) and no per-tile record is written at all.
+// The tiles' entry states still come from the count's tables walked downwards (fsm_chunk_states_kernel, fsm_tile_states_kernel).
+struct FsmEpisodeRangeParams {
+  const uint32_t* leaf[4];              // as FsmParams (at most four inputs)
+  const uint8_t* delta;                 // [S << L] next state | entries << 4
+  const uint8_t* marks;                 // [S << L]
+  const uint8_t* tile_state;            // [num_tiles] fsm_tile_states_kernel's output
+  int32_t* range_first_close;           // [num_ranges] the close of the range that has no open in front of it inside the range; -1
+  int32_t* range_last_open;             // [num_ranges] -1: none
+  unsigned long long* episode_entries;  // += the episodes paired inside ranges
+  int32_t* final_pending;               // = 1 when the state behind the last doc has an episode open
+  uint32_t pending_states;
+  int32_t num_inputs, num_states, num_docs, num_tiles, num_ranges;
+};
+
+template <int SMAX>
+struct FsmByteFn {                                                     // {entry state} -> {exit state}, a byte per entry state
+  uint32_t lo, hi;                                                     // (hi: states 4 .. 7, SMAX == 8 only)
+};
+template <int SMAX>
+__device__ __forceinline__ FsmByteFn<SMAX> fsm_fn_identity() { return FsmByteFn<SMAX>{0x03020100u, 0x07060504u}; }
+// `first`, then `then`:  out[s] = then[first[s]]
+template <int SMAX>
+__device__ __forceinline__ FsmByteFn<SMAX> fsm_fn_then(const FsmByteFn<SMAX>& first, const FsmByteFn<SMAX>& then) {
+  FsmByteFn<SMAX> out;
+  if constexpr (SMAX <= 4) { out.lo = __builtin_amdgcn_perm(then.lo, then.lo, first.lo); out.hi = 0u; }
+  else { out.lo = __builtin_amdgcn_perm(then.hi, then.lo, first.lo); out.hi = __builtin_amdgcn_perm(then.hi, then.lo, first.hi); }
+  return out;
+}
+template <int SMAX>
+__device__ __forceinline__ uint32_t fsm_fn_at(const FsmByteFn<SMAX>& f, uint32_t state) {
+  if constexpr (SMAX <= 4) return (f.lo >> (8u * state)) & 0xFFu;
+  else return ((state < 4u ? f.lo : f.hi) >> (8u * (state & 3u))) & 0xFFu;
+}
+
+template <int SMAX, int LMAX>
+__global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisodeRangeParams p) {
+  static_assert((SMAX == 4 || SMAX == 8) && LMAX >= 1 && LMAX <= 4, "byte functions of four or eight states over at most four inputs");
+  constexpr int kDps = LMAX == 1 ? 8 : (LMAX == 2 ? 4 : 2);           // docs per step
+  constexpr int kIndexBits = kDps * LMAX;                              // input i's bits of the step's docs at [i * kDps, (i + 1) * kDps)
+  constexpr int kWords = SMAX <= 4 ? 1 : 2;
+  __shared__ uint8_t dm[SMAX << LMAX];                                 // one doc: next state | mark << 4 (the last tile's partial lanes)
+  __shared__ uint32_t step_fn[kWords << kIndexBits];                   // a step's function: word 0 (and 1) of FsmByteFn, [idx * kWords + word]
+  __shared__ uint32_t step_mark[SMAX << kIndexBits];                   // [(state << kIndexBits) | idx]: next state | opens << 4 | closes << 12 (bit j: the step's doc j)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = p.num_inputs, S = p.num_states;
+  for (int i = threadIdx.x; i < (SMAX << LMAX); i += blockDim.x) {
+    const int st = i >> LMAX, in = i & ((1 << LMAX) - 1);
+    dm[i] = (st < S && in < (1 << L)) ? (uint8_t)((p.delta[(st << L) | in] & 15u) | ((uint32_t)p.marks[(st << L) | in] << 4)) : (uint8_t)0;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < (1 << kIndexBits); idx += blockDim.x) {
+    uint32_t fn[2] = {0u, 0u};
+    for (int st = 0; st < SMAX; ++st) {
+      uint32_t cur = (uint32_t)st, opens = 0u, closes = 0u;
+      for (int j = 0; j < kDps; ++j) {
+        uint32_t in = 0u;
+        for (int i = 0; i < LMAX; ++i) in |= (((uint32_t)idx >> (i * kDps + j)) & 1u) << i;
+        const uint32_t t = dm[(cur << LMAX) | in];
+        if ((t >> 4) == kFsmMarkOpen) opens |= 1u << j;
+        if ((t >> 4) == kFsmMarkClose) closes |= 1u << j;
+        cur = t & 15u;
+      }
+      step_mark[(st << kIndexBits) | idx] = cur | (opens << 4) | (closes << 12);
+      fn[st >> 2] |= cur << (8 * (st & 3));
+    }
+    step_fn[idx * kWords] = fn[0];
+    if constexpr (kWords == 2) step_fn[idx * kWords + 1] = fn[1];
+  }
+  __syncthreads();
+
+  const long long range = (long long)blockIdx.x * 4 + wave;
+  const long long per_range = ((long long)p.num_tiles + p.num_ranges - 1) / p.num_ranges;
+  const long long tile_begin = range * per_range < (long long)p.num_tiles ? range * per_range : (long long)p.num_tiles;
+  const long long tile_end = tile_begin + per_range < (long long)p.num_tiles ? tile_begin + per_range : (long long)p.num_tiles;
+  unsigned long long sum = 0ull;                                       // this lane's episodes over the range: ONE atomic per wavefront at the end
+  int32_t carry_open = -1;                                             // the last open of the range's tiles so far
+  int32_t first_close = -1;                                            // the range's close that has no open in front of it inside the range (at most one: opens and closes alternate)
+  for (long long tile = tile_begin; tile < tile_end; ++tile) {
+    const long long first = tile * 2048 + lane * 32;
+    const long long rem = (long long)p.num_docs - first;
+    const int docs = rem >= 32 ? 32 : (rem <= 0 ? 0 : (int)rem);
+    uint32_t w[LMAX];
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) w[i] = i < L ? p.leaf[i][tile * 64 + lane] : 0u;
+    const bool whole = __builtin_amdgcn_ballot_w64(docs != 32) == 0ull;      // every lane has its 32 docs (all tiles but the segment's last)
+    // ---- the lane's function: its docs from every entry state ----
+    FsmByteFn<SMAX> f = fsm_fn_identity<SMAX>();
+    if (whole) {
+#pragma unroll
+      for (int d = 0; d < 32; d += kDps) {
+        uint32_t idx = 0u;
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i) idx |= __builtin_amdgcn_ubfe(w[i], d, kDps) << (i * kDps);
+        FsmByteFn<SMAX> t;
+        t.lo = step_fn[idx * kWords];
+        t.hi = kWords == 2 ? step_fn[idx * kWords + (kWords - 1)] : 0u;
+        f = fsm_fn_then<SMAX>(f, t);
+      }
+    } else {
+      uint32_t st[SMAX];
+#pragma unroll
+      for (int s = 0; s < SMAX; ++s) st[s] = (uint32_t)s;
+      for (int d = 0; d < docs; ++d) {
+        uint32_t in = 0u;
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i) in |= __builtin_amdgcn_ubfe(w[i], d, 1) << i;
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) st[s] = dm[(st[s] << LMAX) | in] & 15u;
+      }
+      f.lo = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
+      if constexpr (SMAX > 4) f.hi = st[4] | (st[5] << 8) | (st[6] << 16) | (st[7] << 24);
+    }
+    // ---- the state this lane is entered in: the lanes in front composed (an inclusive scan, shifted by one lane), applied to the tile's ----
+    FsmByteFn<SMAX> incl = f;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      FsmByteFn<SMAX> before;
+      before.lo = (uint32_t)__shfl_up((int)incl.lo, (unsigned)off);
+      before.hi = SMAX > 4 ? (uint32_t)__shfl_up((int)incl.hi, (unsigned)off) : 0u;
+      if (lane >= off) incl = fsm_fn_then<SMAX>(before, incl);
+    }
+    FsmByteFn<SMAX> front;
+    front.lo = (uint32_t)__shfl_up((int)incl.lo, 1u);
+    front.hi = SMAX > 4 ? (uint32_t)__shfl_up((int)incl.hi, 1u) : 0u;
+    if (lane == 0) front = fsm_fn_identity<SMAX>();
+    uint32_t cur = fsm_fn_at<SMAX>(front, (uint32_t)p.tile_state[tile]);
+    // ---- the lane's docs again, one chain from that state: where episodes open and close ----
+    uint32_t open_word = 0u, close_word = 0u;
+    if (whole) {
+#pragma unroll
+      for (int d = 0; d < 32; d += kDps) {
+        uint32_t idx = 0u;
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i) idx |= __builtin_amdgcn_ubfe(w[i], d, kDps) << (i * kDps);
+        const uint32_t t = step_mark[(cur << kIndexBits) | idx];
+        open_word |= __builtin_amdgcn_ubfe(t, 4, kDps) << d;
+        close_word |= __builtin_amdgcn_ubfe(t, 12, kDps) << d;
+        cur = t & 15u;
+      }
+    } else {
+      for (int d = 0; d < docs; ++d) {
+        uint32_t in = 0u;
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i) in |= __builtin_amdgcn_ubfe(w[i], d, 1) << i;
+        const uint32_t t = dm[(cur << LMAX) | in];
+        open_word |= ((t >> 4) == kFsmMarkOpen ? 1u : 0u) << d;
+        close_word |= ((t >> 4) == kFsmMarkClose ? 1u : 0u) << d;
+        cur = t & 15u;
+      }
+    }
+    if (docs > 0 && first + docs == (long long)p.num_docs) *p.final_pending = (int32_t)((p.pending_states >> cur) & 1u);      // the lane that holds the last doc
+    // ---- the last open in front of every lane: an inclusive prefix maximum over the wavefront, shifted by one lane, and the range's carry ----
+    const int32_t mine = open_word ? (int32_t)(first + 31 - __builtin_clz(open_word)) : -1;
+    int32_t last = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t other = __shfl_up(last, (unsigned)off);
+      if (lane >= off) last = other > last ? other : last;
+    }
+    int32_t prev = __shfl_up(last, 1u);
+    if (lane == 0) prev = -1;
+    prev = prev > carry_open ? prev : carry_open;
+    int32_t unpaired = -1;
+    for (uint32_t c = close_word; c != 0u; c &= c - 1u) {
+      const int d = __builtin_ctz(c);
+      const uint32_t below = open_word & ((1u << d) - 1u);
+      const int32_t open_at = below ? (int32_t)(first + 31 - __builtin_clz(below)) : prev;
+      const long long x = first + d;
+      if (open_at >= 0) sum += fsm_episode_cost((long long)open_at + 1, x, p.num_docs);
+      else unpaired = (int32_t)x;                                      // (its open lies in front of the range, or it is the episode of doc 0)
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int32_t other = __shfl_xor(unpaired, off);
+      unpaired = other > unpaired ? other : unpaired;
+    }
+    if (first_close < 0) first_close = unpaired;
+    const int32_t tile_last = __shfl(last, 63);
+    carry_open = tile_last > carry_open ? tile_last : carry_open;
+  }
+  if (lane == 0 && range < (long long)p.num_ranges) {
+    p.range_first_close[range] = first_close;
+    p.range_last_open[range] = carry_open;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += (unsigned long long)__shfl_xor((long long)sum, off);
+  if (lane == 0 && sum != 0ull) atomicAdd(p.episode_entries, sum);
+}
+
 // One workgroup of sixteen wavefronts, each a contiguous range of tiles read 64 at a time (lane l: tile base + l -- the first coding gave every
 // THREAD a contiguous range: 1024 threads each pulling a 128-byte line for four bytes, through one compute unit).  The last open in front of
 // a tile = the maximum of the wavefronts in front, of the 64-tile groups in front (carry) and of the lanes in front (a prefix maximum over

@@ -128,15 +128,26 @@ __device__ __forceinline__ Dwords4 and_aligned16(Dwords4 a, uint32_t e, uint32_t
   return a;
 }
 
-__device__ __forceinline__ void and_scatter8(uint32_t* w32, const Dwords4& d, uint32_t left) {
-  or_doc(w32, d.x & 0xffffu);
-  if (left > 1u) or_doc(w32, d.x >> 16);
-  if (left > 2u) or_doc(w32, d.y & 0xffffu);
-  if (left > 3u) or_doc(w32, d.y >> 16);
-  if (left > 4u) or_doc(w32, d.z & 0xffffu);
-  if (left > 5u) or_doc(w32, d.z >> 16);
-  if (left > 6u) or_doc(w32, d.w & 0xffffu);
-  if (left > 7u) or_doc(w32, d.w >> 16);
+// Eight 16-bit docIds of an array container into the window.  and_scatter8_all: every one of them exists.  and_scatter8_some: only the
+// first `left` (1 .. 8) do -- the lane that holds the container's end; a doc past it is replaced by the lane's first (setting a bit twice
+// changes nothing), so nothing runs under a per-doc exec mask: round 6's SQ counters had 606 scalar instructions and 137 branches per
+// window, most of them the eight `left > k` guards of every scattered piece.
+__device__ __forceinline__ void and_scatter8_all(uint32_t* w32, const Dwords4& d) {
+  or_doc(w32, d.x & 0xffffu); or_doc(w32, d.x >> 16);
+  or_doc(w32, d.y & 0xffffu); or_doc(w32, d.y >> 16);
+  or_doc(w32, d.z & 0xffffu); or_doc(w32, d.z >> 16);
+  or_doc(w32, d.w & 0xffffu); or_doc(w32, d.w >> 16);
+}
+__device__ __forceinline__ void and_scatter8_some(uint32_t* w32, const Dwords4& d, uint32_t left) {
+  const uint32_t first = d.x & 0xffffu;
+  or_doc(w32, first);
+  or_doc(w32, left > 1u ? d.x >> 16 : first);
+  or_doc(w32, left > 2u ? d.y & 0xffffu : first);
+  or_doc(w32, left > 3u ? d.y >> 16 : first);
+  or_doc(w32, left > 4u ? d.z & 0xffffu : first);
+  or_doc(w32, left > 5u ? d.z >> 16 : first);
+  or_doc(w32, left > 6u ? d.w & 0xffffu : first);
+  or_doc(w32, left > 7u ? d.w >> 16 : first);
 }
 
 // A single bitset container, straight from HBM into the owning lanes.  Behind the smaller children only the pieces where something still
@@ -177,8 +188,13 @@ __device__ __forceinline__ void and_scatter_array(__amdgpu_buffer_rsrc_t rsrc, u
     for (int j = 0; j < kAndPiecesInFlight; ++j) and_request16<kLead>(rsrc, lane16, 1024u * (p0 + (uint32_t)j), &d[j], &e[j]);
 #pragma unroll
     for (int j = 0; j < kAndPiecesInFlight; ++j) {
-      const uint32_t e0 = 512u * (p0 + (uint32_t)j) + 8u * lane;
-      if (e0 < n) and_scatter8(w32, and_aligned16<kLead>(d[j], e[j], lead), n - e0);
+      const uint32_t piece_first = 512u * (p0 + (uint32_t)j);              // uniform
+      if (piece_first + 512u <= n) {
+        and_scatter8_all(w32, and_aligned16<kLead>(d[j], e[j], lead));      // a whole piece: every lane has eight docs
+      } else if (piece_first < n) {
+        const uint32_t e0 = piece_first + 8u * lane;                       // the container's last piece: the lanes past its end sit out
+        if (e0 < n) and_scatter8_some(w32, and_aligned16<kLead>(d[j], e[j], lead), n - e0);
+      }
     }
   }
 }
@@ -336,7 +352,7 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
     uint8_t* const out = ap.out != nullptr ? reinterpret_cast<uint8_t*>(ap.out + base) : nullptr;      // uniform
     if (!alive) {
       // nothing stands: no tile holds a match (a dense reader of the whole bitmap still gets its zeros)
-      if (lane == 0u) ap.window_info[key] = WindowInfo{0u, 0u};
+      if (lane == 0u && out != nullptr) ap.window_info[key] = WindowInfo{0u, 0u};
       if (out != nullptr && !ap.sparse_out) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -353,20 +369,22 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
     unsigned long long gsum[kMaxAndGather] = {0ull, 0ull};       // gather mode: the survivors' values of this lane
     uint32_t gmin[kMaxAndGather] = {0xFFFFFFFFu, 0xFFFFFFFFu}, gmax[kMaxAndGather] = {0u, 0u};
     const long long docs_left = (long long)ap.num_docs - base * 64;      // docs of the segment from this window on
-    const bool ragged = docs_left < 65536;                               // uniform: only the segment's last window
+    if (docs_left < 65536) {                                             // uniform: only the segment's last window
+      const uint32_t left = (uint32_t)docs_left;                         // 1 .. 65 535
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      uint4 x = acc[i];
-      const uint32_t bit0 = 128u * (lane + 64u * (uint32_t)i);           // window-relative doc of this pair's first bit
-      if (ragged) {
-        const uint32_t left = (uint32_t)docs_left;                        // 1 .. 65 535
-        uint32_t* xs = &x.x;
+      for (int i = 0; i < 8; ++i) {
+        uint32_t* xs = &acc[i].x;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const uint32_t first = bit0 + 32u * (uint32_t)k;
+          const uint32_t first = 128u * (lane + 64u * (uint32_t)i) + 32u * (uint32_t)k;
           if (first >= left) xs[k] = 0u; else if (left - first < 32u) xs[k] &= (1u << (left - first)) - 1u;
         }
       }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint4 x = acc[i];
+      const uint32_t bit0 = 128u * (lane + 64u * (uint32_t)i);           // window-relative doc of this pair's first bit
       card += (uint32_t)(__builtin_popcount(x.x) + __builtin_popcount(x.y) + __builtin_popcount(x.z) + __builtin_popcount(x.w));
       if (ap.gather_cols != 0 && (x.x | x.y | x.z | x.w) != 0u) {
         // the survivors' values, read here (a handful per window by the planner's estimate): doc -> (tile, lane, position) of the packed
@@ -397,19 +415,27 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
           }
         }
       }
-      // pair 2 (l + 64 i) lies in tile 4 i + (l >> 4)
-      const unsigned long long nz = __builtin_amdgcn_ballot_w64((x.x | x.y | x.z | x.w) != 0u);
-      // sparse output: only the tiles that hold a match are stored (the list-driven kernels read no others; anybody else calls
-      // index_and_zero_unlisted_kernel first)
-      const bool store = !ap.sparse_out || ((nz >> (16u * (lane >> 4))) & 0xffffull) != 0ull;
-      const uint32_t at = lane16 + 1024u * (uint32_t)i;
-      if (out != nullptr && store && at < 8u * words_here) *reinterpret_cast<uint4*>(out + at) = x;
+    }
+    if (out != nullptr) {
+      // (only a kernel that reads the bitmap wants the words and the window's tile mask: COUNT(*) and the gathered aggregation take
+      //  neither, and the ballots, the store decisions and the mask's scalar arithmetic were a fifth of their windows' instructions)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) if ((nz >> (16 * g)) & 0xffffull) tiles |= 1u << (4 * i + g);
+      for (int i = 0; i < 8; ++i) {
+        const uint4 x = acc[i];
+        // pair 2 (l + 64 i) lies in tile 4 i + (l >> 4)
+        const unsigned long long nz = __builtin_amdgcn_ballot_w64((x.x | x.y | x.z | x.w) != 0u);
+        // sparse output: only the tiles that hold a match are stored (the list-driven kernels read no others; anybody else calls
+        // index_and_zero_unlisted_kernel first)
+        const bool store = !ap.sparse_out || ((nz >> (16u * (lane >> 4))) & 0xffffull) != 0ull;
+        const uint32_t at = lane16 + 1024u * (uint32_t)i;
+        if (store && at < 8u * words_here) *reinterpret_cast<uint4*>(out + at) = x;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) if ((nz >> (16 * g)) & 0xffffull) tiles |= 1u << (4 * i + g);
+      }
     }
     const uint32_t total = (uint32_t)wave_sum_i64((long long)card);
     if (lane == 0u) {
-      ap.window_info[key] = WindowInfo{tiles, total};
+      if (out != nullptr) ap.window_info[key] = WindowInfo{tiles, total};
       // (kAndCardinalityShards counters, one 128-byte line each: ONE counter made the kernel 58 -> 194 us on C5-sparse -- ~3 700 same-address
       //  device-scope atomics at ~37 ns apiece, each holding its wave's slot until it retires)
       if (ap.cardinality_out != nullptr && total != 0u)

@@ -98,10 +98,12 @@ COUNT, SUM, MIN, MAX, AVG = _abi.PG_AGG_COUNT, _abi.PG_AGG_SUM, _abi.PG_AGG_MIN,
 
 
 class QuerySpec:
-    def __init__(self, aggregations, filter=None, group_by=(), null_handling=False, num_groups_limit=0):
+    def __init__(self, aggregations, filter=None, group_by=(), null_handling=False, num_groups_limit=0, stats_upper_bound_ok=False):
         """aggregations: list of (function, column_index) with column_index -1 for COUNT(*).
-        null_handling: the query option enableNullHandling=true (PG_QUERY_NULL_HANDLING)."""
+        null_handling: the query option enableNullHandling=true (PG_QUERY_NULL_HANDLING).
+        stats_upper_bound_ok: PG_QUERY_STATS_UPPER_BOUND_OK -- numEntriesScannedInFilter of a leap-frogging filter may be the upper bound."""
         self.null_handling = bool(null_handling)
+        self.stats_upper_bound_ok = bool(stats_upper_bound_ok)
         self.num_groups_limit = int(num_groups_limit)
         self.aggregations = [(int(f), int(c)) for f, c in aggregations]
         self.filter = filter
@@ -157,7 +159,7 @@ class QuerySpec:
         q.num_group_by = len(self.group_by)
         q.group_by_columns = self._groups
         q.num_groups_limit = self.num_groups_limit
-        q.flags = _abi.PG_QUERY_NULL_HANDLING if self.null_handling else _abi.PG_QUERY_DEFAULT
+        q.flags = (_abi.PG_QUERY_NULL_HANDLING if self.null_handling else _abi.PG_QUERY_DEFAULT) | (_abi.PG_QUERY_STATS_UPPER_BOUND_OK if self.stats_upper_bound_ok else 0)
         self.c = q
 
 

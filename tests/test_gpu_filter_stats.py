@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
+from pinot_amd import _abi
 from pinot_amd import query as Q
 from pinot_amd import segment as S
 import helpers as H
@@ -280,3 +281,83 @@ def test_a_and_not_b_above_the_replay_cap(engine):
             got, want = g.execute(spec), oracle.execute(seg, spec)
             H.assert_results_equal(got, want)
             assert got.filter_entries_exact and got.stats[1] == want.stats[1], (got.stats, want.stats)
+
+
+def test_the_caller_can_take_the_upper_bound(engine):
+    """PG_QUERY_STATS_UPPER_BOUND_OK (include/pinot_gpu.h): a leap-frogging filter runs nothing but the query -- same answer, same other
+    statistics, numEntriesScannedInFilter = numDocs x scan leaves with filter_entries_exact = 0; filters whose count costs nothing stay exact."""
+    n = 250_003
+    rng = np.random.default_rng(5)
+    ca, _, _ = H.random_dict_column(rng, "a", n, 100)
+    cb, _, _ = H.random_dict_column(rng, "b", n, 10)
+    cc, _, _ = H.random_dict_column(rng, "c", n, 40)
+    v = S.Column.synthetic_uniform("v", n, (np.arange(2000, dtype=np.int64) * 3 + 1).astype(np.int32), seed=7)
+    k = S.Column.synthetic_uniform("k", n, np.arange(50, dtype=np.int32), seed=8)
+    seg = S.SegmentData("bound_ok", n, [ca, cb, cc, v, k])
+    a, b, c = Q.leaf(Q.Pred.dict_range(0, 0, 30)), Q.leaf(Q.Pred.dict_range(1, 0, 5)), Q.leaf(Q.Pred.dict_range(2, 0, 20))
+    leapfrogging = [(Q.and_(a, b), 2), (Q.and_(a, b, c), 3), (Q.and_(a, Q.or_(b, c)), 3), (Q.and_(a, Q.not_(b)), 2), (Q.and_(Q.not_(a), Q.not_(b)), 2)]
+    with engine.open(seg) as g:
+        for flt, leaves in leapfrogging:
+            for aggs, group_by in (([(Q.COUNT, -1), (Q.SUM, 3)], []), ([(Q.SUM, 3), (Q.MAX, 3)], [4])):
+                exact = g.execute(Q.QuerySpec(aggs, filter=flt, group_by=group_by))
+                bound = g.execute(Q.QuerySpec(aggs, filter=flt, group_by=group_by, stats_upper_bound_ok=True))
+                want = oracle.execute(seg, Q.QuerySpec(aggs, filter=flt, group_by=group_by))
+                H.assert_results_equal(exact, want)
+                assert not bound.filter_entries_exact and bound.stats[1] == leaves * n
+                assert (bound.stats[0], bound.stats[2], bound.stats[3]) == (want.stats[0], want.stats[2], want.stats[3])
+                assert [(x.count, x.sum_i64, x.min, x.max) for x in bound.aggregations] == [(x.count, x.sum_i64, x.min, x.max) for x in exact.aggregations]
+                assert sorted(bound.groups) == sorted(exact.groups)
+                for gid in exact.groups:
+                    assert [(x.count, x.sum_i64, x.max) for x in bound.groups[gid]] == [(x.count, x.sum_i64, x.max) for x in exact.groups[gid]]
+                if exact.filter_entries_exact:
+                    assert exact.stats[1] == want.stats[1]
+                    # (numDocs x scan leaves bounds AND / OR trees; a NOT child re-scans 256-doc batches and can pass it: 21.8 G entries over
+                    #  1 G docs in bench.py's AND-NOT-scan)
+                    has_not = any(ch.op == _abi.PG_FILTER_NOT for ch in flt.children)
+                    assert has_not or want.stats[1] <= bound.stats[1]
+        # nothing to skip: one scan leaf (numDocs), an OR of scan leaves (numDocs each) -- exact with or without the flag
+        for flt in (a, Q.or_(a, b)):
+            r = g.execute(Q.QuerySpec([(Q.COUNT, -1)], filter=flt, stats_upper_bound_ok=True))
+            w = oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1)], filter=flt))
+            assert r.filter_entries_exact and r.stats[1] == w.stats[1]
+
+
+def test_the_upper_bound_flag_removes_every_statistics_kernel(tmp_path):
+    """The same four leap-frogging queries under rocprofv3 --kernel-trace with and without the flag: without it the trace holds the
+    transducer / chain kernels, with it none of them -- and the answers are the same."""
+    import csv
+    import glob
+    import json
+    import os
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    stats_kernels = ("fsm_", "leapfrog2_chain_kernel", "scan_private_fsm_kernel")
+    seen, answers = {}, {}
+    for mode in ("exact", "bound"):
+        out_dir = str(tmp_path / mode)
+        env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        for name in list(env):
+            if name.startswith("PINOT_GPU_") and name != "PINOT_GPU_LIB":
+                del env[name]
+        proc = subprocess.run([rocprof, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "t", "--", sys.executable, os.path.join(root, "tools", "stats_flag_probe.py"), mode],
+                              cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        lines = [ln for ln in proc.stdout.decode().splitlines() if ln.startswith("{")]
+        assert proc.returncode == 0 and lines, proc.stderr.decode()[-2000:]
+        answers[mode] = json.loads(lines[-1])
+        names = set()
+        for path in glob.glob(os.path.join(out_dir, "**", "*kernel_trace.csv"), recursive=True):
+            with open(path, newline="") as f:
+                names.update(row["Kernel_Name"] for row in csv.DictReader(f))
+        assert names, "rocprofv3 left no kernel trace"
+        seen[mode] = sorted(nm for nm in names if any(s in nm for s in stats_kernels))
+    assert seen["exact"], "without the flag the statistic's kernels run"
+    assert any("fsm_episode" in nm for nm in seen["exact"]) and any("leapfrog2_chain" in nm for nm in seen["exact"])
+    assert seen["bound"] == [], seen["bound"]
+    for name, e in answers["exact"].items():
+        bnd = answers["bound"][name]
+        assert e["exact"] and not bnd["exact"] and bnd["entries"] == bnd["scan_leaves_x_docs"]
+        assert "NOT" in name or bnd["entries"] >= e["entries"]
+        assert {k: e[k] for k in ("count", "sum", "docs_scanned", "post", "total")} == {k: bnd[k] for k in ("count", "sum", "docs_scanned", "post", "total")}

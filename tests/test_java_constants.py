@@ -22,7 +22,7 @@ JAVA_DIR = os.path.join(ROOT, "java", "org", "apache", "pinot", "gpu")
 ALIAS_PREFIXES = [("PRED_", "PG_PRED_"), ("EVAL_", "PG_EVAL_"), ("OP_", "PG_FILTER_"), ("AGG_", "PG_AGG_"), ("TYPE_", "PG_TYPE_"),
                   ("FWD_", "PG_FWD_"), ("H_", "PGM_H_"), ("R_", "PGM_R_")]
 # C names the Java side must mirror (prefix families); PG_KERNEL_* / PG_CFG_* are diagnostics Java never reads
-MIRRORED_FAMILIES = ("PG_OK", "PG_ERR_", "PG_TYPE_", "PG_FWD_", "PG_PRED_", "PG_EVAL_", "PG_FILTER_", "PG_AGG_", "PG_QUERY_NULL_HANDLING",
+MIRRORED_FAMILIES = ("PG_OK", "PG_ERR_", "PG_TYPE_", "PG_FWD_", "PG_PRED_", "PG_EVAL_", "PG_FILTER_", "PG_AGG_", "PG_QUERY_NULL_HANDLING", "PG_QUERY_STATS_UPPER_BOUND_OK",
                      "PG_ABI_VERSION", "PGM_")
 
 

@@ -19,6 +19,17 @@ c5_ab)
 import sys, json
 for l in sys.stdin:
     r = json.loads(l); print('%-16s %-34s kernel %.4f all %.4f host %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r['frac_all_kernels'] or 0, r['exact']))" ;;
+c5_ab2)
+  timeout 1500 python tools/ab_r6.py c5 --steps 20 --out $OUT/c5_ab2.jsonl --settings "${C5_SETTINGS:-PINOT_GPU_INDEX_AND_WAVES=-1;PINOT_GPU_INDEX_AND_WAVES=-2;PINOT_GPU_INDEX_AND_WAVES=-3;PINOT_GPU_INDEX_AND_WAVES=-4;PINOT_GPU_INDEX_AND_WAVES=0;PINOT_GPU_INDEX_AND_WAVES=-1;PINOT_GPU_INDEX_AND_WAVES=-2}" 2> $OUT/c5_ab2.err | python -c "
+import sys, json
+for l in sys.stdin:
+    r = json.loads(l); print('%-16s %-34s kernel %.4f all %.4f host %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r['frac_all_kernels'] or 0, r['exact']))" ;;
+c5s_sq)
+  bash tools/profile_round.sh $TAG c5s_sq 2>&1 | tail -12 ;;
+fsm_tests)
+  timeout 1800 python -m pytest tests/test_gpu_filter_stats.py tests/test_gpu_kernel_coverage.py -m gpu -x -q 2>&1 | tail -12 | tee $OUT/fsm_tests.txt ;;
+stats_flag)
+  timeout 900 python -m pytest tests/test_gpu_filter_stats.py -m gpu -x -q -k "upper_bound" 2>&1 | tail -8 | tee $OUT/stats_flag_tests.txt ;;
 c3_ab)
   timeout 1500 python tools/ab_r6.py c3 --steps 20 --out $OUT/c3_ab.jsonl --settings "${C3_SETTINGS:-}" 2> $OUT/c3_ab.err | python -c "
 import sys, json

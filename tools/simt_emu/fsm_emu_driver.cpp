@@ -90,8 +90,27 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
     ep.episode_entries = &episodes; ep.final_pending = &final_pending;
     ep.pending_states = fsm.pending_states;
     ep.num_inputs = L; ep.num_states = S; ep.num_docs = num_docs; ep.num_tiles = (int32_t)tiles;
-    simt::launch(nb, 256, [&] { fsm_episode_tiles_kernel(ep); });
-    simt::launch(1, 1024, [&] { fsm_episode_finish_kernel(first_close.data(), last_open.data(), (int)tiles, num_docs, &final_pending, &episodes); });
+    if (walk != 0 && S <= 8 && L <= 4) {
+      // the byte-function walks' episode kernel (pg_engine.hip: PINOT_GPU_FSM_PERM on, at most eight states over at most four inputs): a
+      // wavefront per contiguous RANGE of tiles, one record per range for the finish kernel
+      const long long num_ranges = std::min<long long>(tiles, (long long)nb * 4);
+      std::vector<int32_t> range_close((size_t)num_ranges, 12345), range_open((size_t)num_ranges, 12345);
+      FsmEpisodeRangeParams rp;
+      memset(&rp, 0, sizeof(rp));
+      for (int i = 0; i < L; ++i) rp.leaf[i] = fp.leaf[i];
+      rp.delta = fsm.delta.data(); rp.marks = fsm.marks.data(); rp.tile_state = tile_state.data();
+      rp.range_first_close = range_close.data(); rp.range_last_open = range_open.data();
+      rp.episode_entries = &episodes; rp.final_pending = &final_pending;
+      rp.pending_states = fsm.pending_states;
+      rp.num_inputs = L; rp.num_states = S; rp.num_docs = num_docs; rp.num_tiles = (int32_t)tiles; rp.num_ranges = (int32_t)num_ranges;
+      const unsigned rb = (unsigned)((num_ranges + 3) / 4);
+      if (S <= 4) { if (L <= 2) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 2>(rp); }); else simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 4>(rp); }); }
+      else { if (L <= 2) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<8, 2>(rp); }); else simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<8, 4>(rp); }); }
+      simt::launch(1, 1024, [&] { fsm_episode_finish_kernel(range_close.data(), range_open.data(), (int)num_ranges, num_docs, &final_pending, &episodes); });
+    } else {
+      simt::launch(nb, 256, [&] { fsm_episode_tiles_kernel(ep); });
+      simt::launch(1, 1024, [&] { fsm_episode_finish_kernel(first_close.data(), last_open.data(), (int)tiles, num_docs, &final_pending, &episodes); });
+    }
   }
   return (int64_t)(entries + episodes);
 }
