@@ -164,8 +164,10 @@ final class GpuAggregationOperator extends BaseOperator<BaseResultsBlock> {
       throw new UnsupportedOperationException("segment " + _segment.getSegmentName() + " is no longer resident on the device");
     }
     try {
-      return PinotGpuNative.execute(_segment.handle(), q._filterNodes, q._predInts, q._predLongs, q._setOffsets, q._setWords,
+      Object[] raw = PinotGpuNative.execute(_segment.handle(), q._filterNodes, q._predInts, q._predLongs, q._setOffsets, q._setWords,
           q._aggregations, q._groupBy, q._numGroupsLimit, q._flags);
+      _segment.refreshDeviceBytes();
+      return raw;
     } finally {
       _segment.unpin();
     }

@@ -110,6 +110,7 @@ final class GpuBatch {
     } finally {
       for (int i = 0; i < n; i++) {
         if (pinned[i]) {
+          _segments.get(i).refreshDeviceBytes();      // (what the copy holds may have grown: GpuSegmentCache.Account.update)
           _segments.get(i).unpin();
         }
       }

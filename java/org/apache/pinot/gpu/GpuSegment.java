@@ -117,6 +117,24 @@ final class GpuSegment implements Closeable {
     _account = account;
   }
 
+  /**
+   * After a query ran on this copy: what it holds on the device may have grown (a plane, a key image or a rank image built by the query, the
+   * scratch of a statistics pass) -- the cache's per-device byte count follows.  Called with the segment pinned (the handle is alive).
+   */
+  void refreshDeviceBytes() {
+    GpuSegmentCache.Account account = _account;
+    if (account == null) {
+      return;
+    }
+    try {
+      long now = PinotGpuNative.segmentDeviceBytes(handle());
+      _deviceBytes = now;
+      account.update(now);
+    } catch (RuntimeException e) {
+      // the byte count is bookkeeping: a failed read leaves it as it was
+    }
+  }
+
   long lastUsedNanos() {
     return _lastUsedNanos;
   }

@@ -30,7 +30,6 @@ import java.util.List;
 import java.util.Map;
 import java.util.Optional;
 import java.util.WeakHashMap;
-import java.util.concurrent.atomic.AtomicBoolean;
 import java.util.concurrent.atomic.AtomicLongArray;
 import org.apache.pinot.segment.spi.ImmutableSegment;
 import org.apache.pinot.segment.spi.IndexSegment;
@@ -114,8 +113,8 @@ final class GpuSegmentCache {
   static final class Account {
     private final AtomicLongArray _resident;
     private final int _slot;
-    private final long _bytes;
-    private final AtomicBoolean _returned = new AtomicBoolean();
+    private long _bytes;                                    // guarded by this
+    private boolean _returned;                              // guarded by this
 
     Account(AtomicLongArray resident, int slot, long bytes) {
       _resident = resident;
@@ -124,9 +123,23 @@ final class GpuSegmentCache {
       _resident.addAndGet(slot, _bytes);
     }
 
-    void giveBack() {
-      if (_returned.compareAndSet(false, true)) {
+    synchronized void giveBack() {
+      if (!_returned) {
+        _returned = true;
         _resident.addAndGet(_slot, -_bytes);
+      }
+    }
+
+    /**
+     * The copy's bytes as pg_segment_device_bytes reports them NOW: a copy grows after it was opened -- value planes, key images, the
+     * dictionary and rank image of a raw FLOAT / DOUBLE group-by key, the scratch of the numEntriesScannedInFilter passes -- and the
+     * per-device budget (makeRoom, leastLoadedSlot) has to see that memory.  No effect once the share was given back.
+     */
+    synchronized void update(long bytesNow) {
+      if (!_returned) {
+        long now = Math.max(0, bytesNow);
+        _resident.addAndGet(_slot, now - _bytes);
+        _bytes = now;
       }
     }
   }

@@ -165,7 +165,11 @@ public final class PinotGpuNative {
    */
   static native long[] groupKeyValues(long handle, int column);
 
-  /** pg_query_check: PG_OK or PG_ERR_UNSUPPORTED; nothing is launched. */
+  /**
+   * pg_query_check: PG_OK or PG_ERR_UNSUPPORTED.  Nothing is launched -- with one exception: the first check of a query that groups by a raw FLOAT /
+   * DOUBLE column (or a raw INT / LONG column spanning more than an int) builds that column's dictionary and rank image on the device, once per
+   * column and segment (its cardinality is what the plan is priced with); a build that fails answers PG_ERR_UNSUPPORTED: the CPU plan.
+   */
   static native int queryCheck(long handle, int[] filterNodes, int[] predInts, long[] predLongs, int[] setOffsets, int[] setWords,
       int[] aggregations, int[] groupBy, int numGroupsLimit, int flags);
 

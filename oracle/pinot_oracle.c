@@ -879,8 +879,11 @@ static int filter_to_bitmap(const po_column* cols, const pg_segment_desc* seg, c
  *   getTrues / getFalses          filter/AndFilterOperator.java:52-88, OrFilterOperator.java:51-87, NotFilterOperator.java:52-63,
  *                                 BaseFilterOperator.java:96-113
  * A scan leaf is represented by its match bitmap (the value matcher's answers): the count depends on nothing else.
- * (This fork's OrDocIdSet never fills its bitmapBasedDocIdIterators list, :80-82, so bitmap children of an OR always iterate
- * individually; followed here, it changes no docId set unless two sorted children meet a bitmap child.)
+ * (This fork's OrDocIdSet never fills its bitmapBasedDocIdIterators list, :80-82, so bitmap children of an OR iterate individually
+ * whenever nothing is merged -- followed here.  When two or more SORTED children are merged (:98-126) the fork builds the merged
+ * iterator from the sorted children alone and the bitmap children are in NO iterator: docs only a posting matches drop out of the OR.
+ * That is a bug of the fork, not a semantic: ds_iterator below KNOWINGLY deviates and ors the bitmap children into the merged iterator
+ * (what upstream Pinot's filled list does), so the oracle's docId sets are the query's.)
  * ------------------------------------------------------------------------------------------------------------------------------ */
 enum { IT_EMPTY = 0, IT_MATCH_ALL, IT_SCAN, IT_SORTED, IT_BITMAP, IT_RANGELESS, IT_AND, IT_OR, IT_NOT };
 

@@ -374,7 +374,6 @@ constexpr int kMaxAndPostings = 64;      // postings of all children together: o
 constexpr int kMaxChildPostings = 16;    // postings OR-ed into one child before it is expanded densely instead (EQ: 1; IN lists, short ranges)
 
 constexpr int kMaxAndGather = 2;              // IndexAndParams.gather_col
-constexpr int kAndCardinalityShards = 64;      // IndexAndParams.cardinality_out: this many counters, 16 words (128 bytes) apart
 struct WindowInfo { uint32_t tiles; uint32_t docs; };   // mask of the window's 32 2048-doc tiles that hold a match; matching docs
 
 struct AndChild {
@@ -394,16 +393,23 @@ struct IndexAndParams {
   long long num_words;                   // 64-bit words of the output bitmap (2048-doc tiles * 32)
   unsigned long long* out;               // doc-order result; nullptr = only the cardinality is wanted
   struct WindowInfo* window_info;        // [windows]
-  unsigned long long* cardinality_out;   // non-null: every window adds its matching docs to counter (window & 63) * 16 of these (the host keeps them at zero between queries): COUNT(*) over an
-                                         //   index-only filter is index_and_kernel and nothing else (FastFilteredCountOperator.java:66-72) -- no finalize launch
-  // The aggregation INSIDE this kernel (round 5): when the AND is expected to leave a handful of docs per window, the window's wave reads the
-  // survivors' values itself -- bit-packed fields of up to kMaxAndGather columns (dictIds for MIN / MAX, plane fields / arithmetic-progression
-  // dictIds for SUM: what scan_sparse_kernel reads) -- and adds them to gather_out: the cardinality counters' own lines, words 1 + 3 a ..: per column
-  // {sum, 2^32 - 1 - min, max} (all-zero identities), no bitmap is stored and no second kernel runs.  AndDocIdSet.java:127-172 + ProjectionOperator.
+  // The query's RECORD out of this kernel (round 6): COUNT(*) over an index-only filter (FastFilteredCountOperator.java:66-72) and the
+  // aggregation over a handful of survivors per window (AndDocIdSet.java:127-172 + ProjectionOperator) are index_and_kernel and nothing else.
+  // pub.partials != nullptr: every wavefront sums its windows' matching docs -- and, gather_cols > 0, reads the survivors' values itself:
+  // bit-packed fields of up to kMaxAndGather columns (dictIds for MIN / MAX, plane fields / arithmetic-progression dictIds for SUM: what
+  // scan_sparse_kernel reads) -- into ONE BlockPartial per wavefront, published like a scan kernel's (publish_block_partial: the wavefront
+  // whose arrival completes the count folds all of them into the pinned host record).  Rounds 4-5 added every window's figures to 64
+  // counter lines with device-scope atomics and copied the lines back: a copy, a memset and their latencies behind a 50 us kernel.
+  struct AndPublish {
+    uint32_t* done_counter;              // ExecCtx.d_done (zero between launches)
+    BlockPartial* partials;              // [grid + kFoldExtraRecords]; nullptr = no record (the kernel leaves a bitmap and window masks)
+    struct HostRecord* host_out;
+    unsigned long long host_seq;
+    int32_t fold_slots, fold_typed, profile, fold_one_counter;
+  } pub;
   int32_t gather_cols;
   int32_t reserved_gather;
   DevAggCol gather_col[2];
-  unsigned long long* gather_out;
   AndChild child[kMaxAndChildren];
   int32_t first[kMaxAndPostings];        // directory slice [first, first + count) of every posting
   int32_t count[kMaxAndPostings];

@@ -124,7 +124,15 @@ struct Engine {
 };
 Engine g_engine;
 // the HIP device behind a device id of the C ABI (pg_segment_desc.device_id, pg_config.device_id)
-inline int phys_device(int logical) { return g_engine.physical_devices > 0 ? logical % g_engine.physical_devices : logical; }
+// (ids alias only under PINOT_GPU_ALIAS_DEVICES, i.e. when more ids are accepted than devices exist; callers range-check with device_id_ok)
+inline int phys_device(int logical) { return (g_engine.logical_devices > g_engine.physical_devices && g_engine.physical_devices > 0) ? logical % g_engine.physical_devices : logical; }
+// a device id the C ABI accepts: 0 .. logical_devices - 1 once pg_init has counted them; before pg_init only what HIP itself has
+inline bool device_id_ok(int id) {
+  if (id < 0) return false;
+  if (g_engine.initialized) return id < g_engine.logical_devices;
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess && id < n;
+}
 
 inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
 inline uint32_t le16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
@@ -210,8 +218,13 @@ struct ExecCtx {
   unsigned long long seq = 0;                   // sequence number of the context's last launch (HostRecord.seq)
   bool pre_started = false;                     // timed runs: ev[0] has been recorded (some kernel runs before the scan)
   bool pre_enqueued = false;                    // something has been put on the stream ahead of the scan kernel (any run, timed or not)
-  bool and_counter_dirty = false;               // index_and_kernel's cardinality counters (d_and_counters[2 ...]) were added to and not yet zeroed again
-  unsigned long long* h_and_shards = nullptr;   // pinned: where the 64 counters land
+  // The transducer pass of numEntriesScannedInFilter (pg_filter_fsm.h): the leaves' bitmaps, the tiles' tables, the episode records.  Per
+  // CONTEXT since round 6 -- rounds 4-5 kept one scratch per segment under a mutex held across the whole query, so two leap-frogging
+  // queries on one segment ran back to back.  h_fsm_stage: pinned, the machine's tables on their way in and the two counts on their way out.
+  uint8_t* d_fsm_scratch = nullptr;
+  size_t fsm_scratch_bytes = 0;
+  uint8_t* h_fsm_stage = nullptr;
+  hipEvent_t ev_pass[2] = {nullptr, nullptr};
   int ev_last = 3;                              // timed runs: the event that closes the query's device work (2 when nothing follows the scan kernel)
   std::vector<unsigned long long*> d_bitmaps;   // each num_tiles*32 words
   std::vector<uint32_t*> d_sets;
@@ -247,7 +260,7 @@ struct pg_segment {
   int num_docs = 0;
   int num_tiles = 0;
   int num_cus = 256;
-  uint64_t device_bytes = 0;
+  std::atomic<uint64_t> device_bytes{0};      // (grows after open under three different mutexes -- key images, value planes, the transducer's scratch: atomic, so that no update is lost)
   std::string name;
   std::vector<ColumnDev> cols;          // the caller's columns, then hidden images: key images of raw columns (ColumnDev.keyimage_column), null-key images (nullkey_column)
   int num_user_cols = 0;
@@ -263,9 +276,6 @@ struct pg_segment {
   std::vector<ExecCtx*> free_ctx;
   std::vector<ExecCtx*> all_ctx;
   // the transducer pass of numEntriesScannedInFilter (device_fsm_filter_stats): leaf bitmaps + tables, one query at a time per segment
-  std::mutex fsm_mu;
-  uint8_t* d_fsm_scratch = nullptr;
-  size_t fsm_scratch_bytes = 0;
   // pg_execute_batch: the last few queries lowered for the shared launch (LoweredItem), so that a server that sends the same query to
   // its segments again and again -- one batch per broker request -- does not lower it again.  plane_epoch moves whenever a value plane of
   // this segment is built or dropped: an item lowered before that reads addresses that may be gone.
@@ -275,7 +285,6 @@ struct pg_segment {
 };
 
 // What a query's scan kernel leaves behind for the transducer pass: the bitmap of every input leaf it evaluated itself.
-constexpr size_t kAndShardBytes = (size_t)pg::kAndCardinalityShards * 128;
 
 struct FsmSide {
   const pg::fstats::Fsm* fsm = nullptr;
@@ -288,7 +297,9 @@ struct FsmSide {
   unsigned long long* entries = nullptr;        // fsm_finish_kernel's output
   long long num_tiles = 0, num_chunks = 0;
   bool fused = false;                           // out: the scan kernel walked the transducer itself; its count is in the context's pinned counter
+  bool prepared = false;                        // prepare_fsm_side gave it the context's scratch
 };
+constexpr size_t kFsmStageBytes = 64 + 2 * ((size_t)pg::kFsmStates << pg::kFsmInputs);      // ExecCtx.h_fsm_stage: the two counts | delta | marks
 
 namespace {
 
@@ -297,7 +308,9 @@ void destroy_ctx(ExecCtx* c) {
   // (round 5: a COUNT(*) over an index-only filter leaves a memset of its counters on the stream BEHIND the answer -- nothing of the context
   //  may be freed under it)
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  if (c->h_and_shards) (void)hipHostFree(c->h_and_shards);
+  if (c->h_fsm_stage) (void)hipHostFree(c->h_fsm_stage);
+  if (c->d_fsm_scratch) (void)hipFree(c->d_fsm_scratch);
+  for (hipEvent_t e : c->ev_pass) if (e) (void)hipEventDestroy(e);
   if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->h_record) (void)hipHostFree(c->h_record);
   if (c->d_done) (void)hipFree(c->d_done);
@@ -583,7 +596,6 @@ void free_segment(pg_segment* seg) {
   drop_planes_of(seg);
   if (seg->plane_stream) (void)hipStreamDestroy(seg->plane_stream);
   for (auto* c : seg->all_ctx) destroy_ctx(c);
-  if (seg->d_fsm_scratch) (void)hipFree(seg->d_fsm_scratch);
   for (auto& col : seg->cols) {
     if (col.d_fwd_alloc) (void)hipFree(col.d_fwd_alloc);
     if (col.d_dict && !col.borrows_dictionary) (void)hipFree(col.d_dict);
@@ -934,12 +946,12 @@ struct Lowered {
   // index_and_finalize_kernel (window masks -> the ascending tile list, its length, the cardinality) is launched only when somebody reads its
   // output: scan_sparse_kernel walks the window masks themselves and COUNT(*) takes the cardinality from index_and_kernel's own counter
   bool finalize_pending = false;
-  bool cardinality_atomic = false;             // d_cardinality is the kernel's atomic counter (kept at zero between queries by whoever reads it)
   unsigned finalize_windows = 0;
   // index_and_kernel itself is launched when the planner knows what follows it (launch_index_and): a COUNT(*) wants its cardinality counters,
   // an aggregation over a handful of survivors per window is done INSIDE it (gathered: no bitmap, no second kernel), everything else its
   // bitmap and window masks.  Lowering only prepares the kernel's arguments.
   bool and_pending = false, and_cardinality_only = false, gathered = false;
+  bool record_published = false;               // index_and_kernel folds the query's record into the context's pinned host record itself (launch_index_and)
   int and_num_cus = 256;                       // the segment's CUs (pg_segment.num_cus): index_and_kernel's persistent grid is sized by them
   IndexAndParams and_params;
   double and_expected_docs = 0;                // the planner's estimate of the AND's cardinality (independent postings)
@@ -1111,45 +1123,50 @@ pg_status launch_leap_chain(const pg_segment* seg, ExecCtx* ctx, unsigned long l
 }
 
 // index_and_kernel, launched when its consumer is known.  `gather_from`: the aggregation runs inside the kernel (ScanParams.agg_cols are the
-// columns it reads; no bitmap is stored); else the kernel leaves its bitmap / window masks (or, for COUNT(*), only its cardinality counters).
-pg_status launch_index_and(Lowered* lw, ExecCtx* ctx, const ScanParams* gather_from) {
+// columns it reads; no bitmap is stored); else the kernel leaves its bitmap / window masks.  COUNT(*) over the whole filter and the gathered
+// aggregation come back as the kernel's own folded RECORD in the context's pinned host record under sequence number `record_seq`
+// (IndexAndParams.pub, publish_block_partial): nothing follows the kernel on the stream.
+pg_status launch_index_and(Lowered* lw, ExecCtx* ctx, const ScanParams* gather_from, unsigned long long record_seq = 0) {
   if (!lw->and_pending) return PG_OK;
   lw->and_pending = false;
   IndexAndParams& ap = lw->and_params;
   const unsigned num_windows = lw->finalize_windows;
-  if (lw->and_cardinality_only || gather_from != nullptr) {
-    // the windows add their matching docs (and, gathered, the survivors' values) to counters the host keeps at zero between queries
-    if (ctx->and_counter_dirty) HIP_TRY(hipMemsetAsync(ctx->d_and_counters + 2, 0, kAndShardBytes, ctx->stream));      // (a query that failed before it read them)
-    ap.cardinality_out = ctx->d_and_counters + 2;
-    ctx->and_counter_dirty = true;
-  }
+  // One wavefront per workgroup; a wave takes windows key, key + grid, ... with the next window's directory lookups in flight
+  // (pg_index_and.h).  PINOT_GPU_INDEX_AND_WAVES: 0 (default) = a persistent grid of as many waves as are resident; n > 0 = of n waves per
+  // CU; -k = k windows per wave (grid = windows / k workgroups handed out by the dispatcher as slots free up; -1: a wave per window, rounds
+  // 2-5).  Measured on C5 at 1 B rows (profiles/r6/c5_index_and_*.jsonl): the kernel is bound by instruction issue, not by waiting (SQ
+  // counters: the waves' active-instruction cycles per SIMD add up to the kernel's duration), so the grid's shape moves it by a few
+  // percent only -- after the scalar-instruction diet the resident grid is ahead (COUNT 39.5 vs 43.3 us, gathered SUM 58.1 vs 58.5-59.6);
+  // 8 or 12 waves per CU lose 20 - 40 %.
+  const int per_cu = g_engine.index_and_waves > 0 ? g_engine.index_and_waves : waves_index_and();
+  const unsigned grid = std::max(1u, g_engine.index_and_waves < 0 ? (num_windows + (unsigned)(-g_engine.index_and_waves) - 1) / (unsigned)(-g_engine.index_and_waves)
+                                                                  : (unsigned)std::min<long long>(num_windows, (long long)lw->and_num_cus * per_cu));
+  memset(&ap.pub, 0, sizeof(ap.pub));
   if (gather_from != nullptr) {
     ap.gather_cols = gather_from->num_agg_cols;
     for (int a = 0; a < gather_from->num_agg_cols && a < kMaxAndGather; ++a) ap.gather_col[a] = gather_from->agg_cols[a];
-    ap.gather_out = ctx->d_and_counters + 2;       // (the cardinality counters' lines: words 1 ..)
     ap.out = nullptr;                              // nobody reads a bitmap
     lw->gathered = true;
-    lw->d_cardinality = ctx->d_and_counters + 2;
-    lw->cardinality_atomic = true;
   }
-  if (num_windows) {
-    // One wavefront per workgroup; a wave takes windows key, key + grid, ... with the next window's directory lookups in flight
-    // (pg_index_and.h).  PINOT_GPU_INDEX_AND_WAVES: 0 (default) = a persistent grid of as many waves as are resident; n > 0 = of n waves per
-    // CU; -k = k windows per wave (grid = windows / k workgroups handed out by the dispatcher as slots free up; -1: a wave per window, rounds
-    // 2-5).  Measured on C5 at 1 B rows (profiles/r6/c5_index_and_*.jsonl): the kernel is bound by instruction issue, not by waiting (SQ
-    // counters: the waves' active-instruction cycles per SIMD add up to the kernel's duration), so the grid's shape moves it by a few
-    // percent only -- after the scalar-instruction diet the resident grid is ahead (COUNT 39.5 vs 43.3 us, gathered SUM 58.1 vs 58.5-59.6);
-    // 8 or 12 waves per CU lose 20 - 40 %.
-    const int per_cu = g_engine.index_and_waves > 0 ? g_engine.index_and_waves : waves_index_and();
-    const unsigned grid = g_engine.index_and_waves < 0 ? (num_windows + (unsigned)(-g_engine.index_and_waves) - 1) / (unsigned)(-g_engine.index_and_waves)
-                                                        : (unsigned)std::min<long long>(num_windows, (long long)lw->and_num_cus * per_cu);
+  if (lw->and_cardinality_only || gather_from != nullptr) {
+    const pg_status ps = ensure_partials(ctx, (int)grid);
+    if (ps != PG_OK) return ps;
+    ap.pub.done_counter = ctx->d_done;
+    ap.pub.partials = ctx->d_partials;
+    ap.pub.host_out = ctx->h_record_dev;
+    ap.pub.host_seq = record_seq;
+    ap.pub.fold_slots = gather_from != nullptr ? gather_from->num_agg_cols : 0;
+    ap.pub.fold_one_counter = g_engine.fold_one_counter;
+    lw->record_published = true;
+  }
+  // (an empty segment has no window: one wavefront still runs, finds nothing and publishes the empty record)
+  if (num_windows || lw->record_published) {
     launch_index_and_kernel((int)grid, ctx->stream, ap, num_windows);
     HIP_TRY(hipGetLastError());
     // (index_and_finalize_kernel: only when the tile list is read -- complete_index_list)
-    lw->finalize_pending = !lw->and_cardinality_only && gather_from == nullptr;
-  } else if (!lw->and_cardinality_only && gather_from == nullptr) {
-    HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16, ctx->stream));
+    lw->finalize_pending = num_windows != 0 && !lw->and_cardinality_only && gather_from == nullptr;
   }
+  if (!num_windows && !lw->and_cardinality_only && gather_from == nullptr) HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16, ctx->stream));
   return PG_OK;
 }
 
@@ -1327,12 +1344,9 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
         HIP_TRY(hipMalloc((void**)&ctx->d_window_info, ctx->window_info_capacity * sizeof(WindowInfo)));
       }
       if (!ctx->d_and_counters) {
-        // [0] cardinality and [1] tile count (index_and_finalize_kernel's outputs), then index_and_kernel's own counters, zero between queries:
-        // 64 lines: word 0 the cardinality, words 1 .. 6 the gathered sums / extremes of up to two columns
-        HIP_TRY(hipMalloc((void**)&ctx->d_and_counters, 16 + kAndShardBytes));
-        HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16 + kAndShardBytes, ctx->stream));
-        HIP_TRY(hipHostMalloc((void**)&ctx->h_and_shards, kAndShardBytes, hipHostMallocDefault));
-        ctx->and_counter_dirty = false;
+        // [0] cardinality and [1] tile count: index_and_finalize_kernel's outputs
+        HIP_TRY(hipMalloc((void**)&ctx->d_and_counters, 16));
+        HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16, ctx->stream));
       }
       IndexAndParams ap;
       memset(&ap, 0, sizeof(ap));
@@ -1351,7 +1365,7 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
         }
         ap.child[c].posting_end = ap.num_postings;
       }
-      unsigned long long* d_cardinality = cardinality_only ? ctx->d_and_counters + 2 : ctx->d_and_counters;
+      unsigned long long* d_cardinality = ctx->d_and_counters;      // (index_and_finalize_kernel's; a cardinality-only or gathering launch publishes a record instead)
       uint32_t* d_tile_count = reinterpret_cast<uint32_t*>(ctx->d_and_counters + 1);
       HIP_TRY(mark_pre_work(ctx));
       // (the launch itself: launch_index_and, once the planner knows what reads the kernel's output)
@@ -1366,7 +1380,6 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
         lw->and_expected_docs = expected;
       }
       lw->d_cardinality = d_cardinality;
-      lw->cardinality_atomic = cardinality_only;
       lw->index_and_is_whole_filter = seq.size() == 1;
       if (cardinality_only) { L.kind = kLeafMatchAll; depth++; max_depth = std::max(max_depth, depth); continue; }   // never evaluated: execute_impl answers from the cardinality
       L.kind = kLeafBitmap;
@@ -1856,6 +1869,7 @@ pg_status pg_shutdown(void) {
 }
 
 pg_status pg_device_info(int32_t device_id, char* arch_name, int32_t arch_name_len, int32_t* num_cus, uint64_t* hbm_bytes) {
+  if (!device_id_ok(device_id)) return fail(PG_ERR_INVALID_ARGUMENT, "device id %d out of range", device_id);
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, phys_device(device_id)));
   if (arch_name && arch_name_len > 0) { strncpy(arch_name, prop.gcnArchName, (size_t)arch_name_len - 1); arch_name[arch_name_len - 1] = 0; }
@@ -1873,6 +1887,7 @@ pg_status pg_device_count(int32_t* out_devices, int32_t* out_physical) {
 
 pg_status pg_measure_stream_read(int32_t device_id, uint64_t bytes, int32_t launches, double* out_gbps) {
   if (!out_gbps || bytes < (1u << 20) || launches < 1) return fail(PG_ERR_INVALID_ARGUMENT, "bad stream probe arguments");
+  if (!device_id_ok(device_id)) return fail(PG_ERR_INVALID_ARGUMENT, "device id %d out of range", device_id);
   HIP_TRY(hipSetDevice(phys_device(device_id)));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, phys_device(device_id)));
@@ -2214,7 +2229,7 @@ pg_status pg_segment_num_docs(const pg_segment* segment, int32_t* out_num_docs) 
 
 pg_status pg_segment_device_bytes(const pg_segment* segment, uint64_t* out_bytes) {
   if (!segment || !out_bytes) return fail(PG_ERR_INVALID_ARGUMENT, "null argument");
-  *out_bytes = segment->device_bytes;
+  *out_bytes = segment->device_bytes.load(std::memory_order_relaxed);
   return PG_OK;
 }
 
@@ -2379,8 +2394,14 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
       if (seg->cols[(size_t)seg->cols[(size_t)c].keyimage_column].rank_image) {
         // a rank image's cardinality is what the plan is priced with: the column's dictionary is built here, the first time a query that
         // groups by it is checked (once per column and segment; the one thing pg_query_check ever launches)
+        // A build that fails -- no HBM for its transient keys, a device error -- is a reason to keep the CPU plan, not to fail a query at PLAN
+        // time: the JNI layer throws on every status but OK / UNSUPPORTED and GpuPlanMaker.makeSegmentPlanNode lets that through (advisor, round 5).
         const pg_status rst = ensure_key_image(const_cast<pg_segment*>(seg), c, nullptr);
-        if (rst != PG_OK) return rst;
+        if (rst != PG_OK) {
+          (void)hipGetLastError();
+          return fail(PG_ERR_UNSUPPORTED, "group-by on raw column %s: its dictionary and rank image could not be built (status %d: %s) -- CPU plan", seg->cols[(size_t)c].name.c_str(), (int)rst,
+                      pg_last_error());
+        }
       }
       c = seg->cols[(size_t)c].keyimage_column;
     }
@@ -2466,9 +2487,9 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
 
 // ExecutionStatistics.numEntriesScannedInFilter from the plan pg_filter_stats.h chose; `counted`: the kernel that ran carried the
 // kNodeCountEntries counter (its value has been copied to ctx->h_filter_entries and the stream is idle).
-static void finish_filter_stats(const Lowered& lw, const pg_segment* seg, int64_t counted_entries, bool counted, pg_result* out) {
-  const int64_t upper_bound = (int64_t)lw.stats_scan_leaves * seg->num_docs;      // every scan leaf looking at every doc
-  switch (lw.stats_plan) {
+static void finish_filter_stats(fstats::Plan stats_plan, int stats_scan_leaves, const pg_segment* seg, int64_t counted_entries, bool counted, pg_result* out) {
+  const int64_t upper_bound = (int64_t)stats_scan_leaves * seg->num_docs;      // every scan leaf looking at every doc
+  switch (stats_plan) {
     case fstats::Plan::kZero: out->stats.num_entries_scanned_in_filter = 0; out->filter_entries_exact = 1; break;
     case fstats::Plan::kPerLeaf: out->stats.num_entries_scanned_in_filter = upper_bound; out->filter_entries_exact = 1; break;
     case fstats::Plan::kLeap2:
@@ -2480,6 +2501,10 @@ static void finish_filter_stats(const Lowered& lw, const pg_segment* seg, int64_
       [[fallthrough]];                                                            // an LDS-staged kernel ran: replayed by pg_execute
     default: out->stats.num_entries_scanned_in_filter = upper_bound; out->filter_entries_exact = 0; break;
   }
+}
+
+static void finish_filter_stats(const Lowered& lw, const pg_segment* seg, int64_t counted_entries, bool counted, pg_result* out) {
+  finish_filter_stats(lw.stats_plan, lw.stats_scan_leaves, seg, counted_entries, counted, out);
 }
 
 // pg_execute_batch: a query whose whole device work is ONE launch of scan_private_kernel -- nothing ahead of it on the stream, no index
@@ -2564,6 +2589,8 @@ static std::shared_ptr<const OwnedQuery> own_query(const pg_query* q) {
   return o;
 }
 
+static pg_status prepare_fsm_side(pg_segment* seg, ExecCtx* ctx, const pg::fstats::Fsm& fsm, FsmSide* side);
+static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg_query* q, const FsmSide& side, pg_result* out);
 static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out, unsigned long long* d_out_bitmap_request,
                               uint64_t* host_bitmap, int64_t host_bitmap_words, int64_t* out_cardinality, bool allow_metadata_plan = true,
                               Deferred* defer = nullptr, FsmSide* side = nullptr) {
@@ -2680,7 +2707,13 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   if (lw.stats_plan == fstats::Plan::kLeap2 && (!g_engine.leap2 || (q->flags & PG_QUERY_STATS_UPPER_BOUND_OK))) lw.stats_plan = fstats::Plan::kReplay;      // (kReplay with nobody replaying: the upper bound)
   lw.cardinality_only_hint = ng == 0 && out && !want_bitmap && na > 0;
   for (int a = 0; a < na; ++a) lw.cardinality_only_hint = lw.cardinality_only_hint && q->aggregations[a].function == PG_AGG_COUNT;
-  lw.side = (out && !want_bitmap && lw.stats_plan == fstats::Plan::kReplay) ? side : nullptr;
+  lw.side = nullptr;
+  if (out && !want_bitmap && lw.stats_plan == fstats::Plan::kReplay && side != nullptr && side->fsm != nullptr) {
+    // numEntriesScannedInFilter is a statistic: a pass that cannot get its scratch leaves the query's answer standing with
+    // filter_entries_exact = 0 (pg_execute's host replay still applies at its sizes) -- it never fails the query
+    if (prepare_fsm_side(seg, ctx, *side->fsm, side) == PG_OK) lw.side = side;
+    else (void)hipGetLastError();
+  }
   st = lower_filter(seg, ctx, q, &lw);
   if (st != PG_OK) return st;
   ScanParams& sp = lw.sp;
@@ -2698,20 +2731,23 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     bool only_count = true;
     for (int a = 0; a < na; ++a) only_count &= q->aggregations[a].function == PG_AGG_COUNT;
     if (only_count) {
-      st = launch_index_and(&lw, ctx, nullptr);
+      const unsigned long long seq = ++ctx->seq;
+      st = launch_index_and(&lw, ctx, nullptr, seq);
       if (st != PG_OK) return st;
       unsigned long long* h_card = &ctx->h_partial->count;
-      if (lw.cardinality_atomic) HIP_TRY(hipMemcpyAsync(ctx->h_and_shards, lw.d_cardinality, kAndShardBytes, hipMemcpyDeviceToHost, ctx->stream));
-      else HIP_TRY(hipMemcpyAsync(h_card, lw.d_cardinality, 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (!lw.record_published) HIP_TRY(hipMemcpyAsync(h_card, lw.d_cardinality, 8, hipMemcpyDeviceToHost, ctx->stream));
       if (timed) { HIP_TRY(mark_pre_work(ctx)); HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      if (lw.cardinality_atomic) {
-        // the counters go back to zero behind the answer (nobody waits for this): the next COUNT(*) on this context starts from zero
-        HIP_TRY(hipMemsetAsync(ctx->d_and_counters + 2, 0, kAndShardBytes, ctx->stream));
-        ctx->and_counter_dirty = false;
-        unsigned long long total = 0ull;
-        for (int sh = 0; sh < kAndCardinalityShards; ++sh) total += ctx->h_and_shards[(size_t)sh * 16];
-        *h_card = total;
+      if (lw.record_published && g_engine.poll_result && g_engine.direct_result && !timed) {
+        // nothing follows the kernel on the stream: its folded record's sequence number is the completion signal
+        volatile unsigned long long* flag = &ctx->h_record->seq;
+        st = wait_polled(ctx->stream, (long long)seg->num_docs, [&] { return *flag == seq; });
+        if (st != PG_OK) return st;
+      } else {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+      }
+      if (lw.record_published) {
+        if (ctx->h_record->seq != seq) return fail(PG_ERR_INTERNAL, "index_and_kernel's record carries sequence %llu, expected %llu", ctx->h_record->seq, seq);
+        if (ctx->h_partial->flags & kPartialStale) return fail(PG_ERR_INTERNAL, "index_and_kernel's fold read a record that was not written by this launch (sequence %llu)", seq);
       }
       const int64_t card = (int64_t)*h_card;
       out->num_aggregations = na;
@@ -2913,13 +2949,14 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       sp.out_bitmap = ctx->d_bitmaps[0];
     }
     sp.sparse_windows = nullptr; sp.sparse_num_windows = 0;
+    const unsigned long long seq = ++ctx->seq;      // the sequence number the query's folded record is published under (a gathering index_and_kernel's, or the scan kernel's)
     if (use_sparse) {
       // A handful of survivors per window (the planner's estimate from the postings' sizes: independent predicates): index_and_kernel reads
       // their values itself -- ONE launch for `SUM(v) WHERE p = 3 AND q = 5 AND r = 7` (BASELINE.json configs[4]); else scan_sparse_kernel
       // walks the window masks behind it (no list, no index_and_finalize_kernel between the two kernels).  PINOT_GPU_INDEX_GATHER=0: never.
       const bool gather = g_engine.index_gather && lw.and_pending && lw.index_and_is_whole_filter && out && pl.num_agg_cols <= kMaxAndGather &&
                           lw.and_expected_docs <= 4.0 * (double)lw.finalize_windows;
-      st = launch_index_and(&lw, ctx, gather ? &sp : nullptr);
+      st = launch_index_and(&lw, ctx, gather ? &sp : nullptr, seq);
       if (st != PG_OK) return st;
       sp.tile_list = lw.tile_list; sp.tile_count = lw.tile_count;      // (not read by the kernel; "listed" is what the planner and the statistics go by)
       sp.sparse_windows = lw.and_info; sp.sparse_num_windows = (int32_t)lw.finalize_windows;
@@ -3037,7 +3074,6 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // were left with the separate launch so that the scan kernel's profiler duration was "the scan and nothing else"; the query paid
     // ~15 us for that, and its roofline fraction is a statement about the query, not about its largest kernel).
     const bool folded = g_engine.fold_finalize >= 0 ? g_engine.fold_finalize != 0 : true;
-    const unsigned long long seq = ++ctx->seq;
     sp.done_counter = folded ? ctx->d_done : nullptr;
     sp.host_out = g_engine.direct_result ? ctx->h_record_dev : nullptr;
     sp.host_seq = seq;
@@ -3087,29 +3123,17 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // (the chain kernel / copy commands behind the scan kernel; a kernel that leaves leaf bitmaps behind for the transducer pass must have
     //  RETIRED before that pass reads them -- its plain stores are only ordered by the end of the kernel, not by the pinned record's seq)
     if (lw.gathered) {
-      // index_and_kernel did the aggregation: its 64 + 64 lines of counters are the query's record
+      // index_and_kernel did the aggregation and folded its wavefronts' records into the pinned host record (launch_index_and: record_seq)
       if (timed) { HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream)); HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream)); }
-      HIP_TRY(hipMemcpyAsync(ctx->h_and_shards, ctx->d_and_counters + 2, kAndShardBytes, hipMemcpyDeviceToHost, ctx->stream));
-      if (timed) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-      ctx->ev_last = 3;
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      HIP_TRY(hipMemsetAsync(ctx->d_and_counters + 2, 0, kAndShardBytes, ctx->stream));      // zero again behind the answer: nobody waits for this
-      ctx->and_counter_dirty = false;
-      BlockPartial g;
-      memset(&g, 0, sizeof(g));
-      for (int a = 0; a < kMaxAggCols; ++a) { g.kmin[a] = 0x7FFFFFFF; g.kmax[a] = (int32_t)0x80000000; }
-      const unsigned long long* cards = ctx->h_and_shards;
-      for (int sh = 0; sh < kAndCardinalityShards; ++sh) {
-        if (cards[(size_t)sh * 16] == 0ull) continue;
-        g.count += cards[(size_t)sh * 16];
-        for (int a = 0; a < pl.num_agg_cols; ++a) {
-          const unsigned long long* o = cards + (size_t)sh * 16 + 1 + 3 * a;
-          g.sum[a] += (long long)o[0];
-          g.kmin[a] = std::min(g.kmin[a], (int32_t)(0xFFFFFFFFu - (uint32_t)o[1]));
-          g.kmax[a] = std::max(g.kmax[a], (int32_t)(uint32_t)o[2]);
-        }
+      ctx->ev_last = 2;
+      if (g_engine.poll_result && g_engine.direct_result && !timed) {
+        volatile unsigned long long* flag = &ctx->h_record->seq;
+        st = wait_polled(ctx->stream, (long long)seg->num_docs, [&] { return *flag == seq; });
+        if (st != PG_OK) return st;
+      } else {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
       }
-      *ctx->h_partial = g;
+      if (ctx->h_record->seq != seq) return fail(PG_ERR_INTERNAL, "index_and_kernel's record carries sequence %llu, expected %llu", ctx->h_record->seq, seq);
     } else {
     const bool post_work = !g_engine.direct_result || count_leap2 || want_bitmap || sp.leaf_out_enabled || fuse_fsm;
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -3400,7 +3424,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       std::array<int, kMaxGroupAggs> kinds{};
       for (int a = 0; a < NA; ++a) kinds[(size_t)a] = agg_kind[a];
       const size_t num_projected = projected.size();
-      item->convert_group = [q, seg, na, ng, cards, dev_agg_of, lw, G, NA, kinds, num_projected, no_dict_keys](const unsigned long long* table, pg_result* out) {
+      // (captured by value and kept with the cached item: what the conversion needs of the lowering -- the planes its aggregations read through
+      //  and the statistics plan -- not the whole Lowered with its index-AND parameter block: advisor, round 5)
+      const std::vector<char> plane_cols = lw.plane_cols;
+      const fstats::Plan stats_plan = lw.stats_plan;
+      const int stats_scan_leaves = lw.stats_scan_leaves;
+      item->convert_group = [q, seg, na, ng, cards, dev_agg_of, plane_cols, stats_plan, stats_scan_leaves, G, kinds, num_projected, no_dict_keys](const unsigned long long* table, pg_result* out) {
         int num_present = 0;
         for (int g = 0; g < G; ++g) num_present += table[g] != 0ull ? 1 : 0;
         out->num_aggregations = na;
@@ -3433,7 +3462,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
             if (kinds[(size_t)da] == kGroupMin) acc = 0x80000000ll - acc;
             else if (kinds[(size_t)da] == kGroupMax) acc = acc - 0x80000001ll;
             const ColumnDev& col = seg->cols[(size_t)ag.column];
-            const bool plane = lw.plane_cols[(size_t)ag.column] != 0;
+            const bool plane = plane_cols[(size_t)ag.column] != 0;
             if (ag.function == PG_AGG_SUM || ag.function == PG_AGG_AVG) set_integer_sum(&v, (__int128)acc * (__int128)sum_scale(col, plane) + (__int128)group_docs * (__int128)sum_base(col, plane));
             else if (ag.function == PG_AGG_MIN) v.min = agg_value_double(col, (int32_t)acc, plane);
             else v.max = agg_value_double(col, (int32_t)acc, plane);
@@ -3441,7 +3470,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
           ++k;
         }
         out->stats.num_docs_scanned = docs;
-        finish_filter_stats(lw, seg, 0, false, out);
+        finish_filter_stats(stats_plan, stats_scan_leaves, seg, 0, false, out);
         out->stats.num_entries_scanned_post_filter = docs * (int64_t)num_projected;
         out->stats.num_total_docs = seg->num_docs;
       };
@@ -3891,6 +3920,11 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if (ms_index > ms_scan) { out->dominant_kernel = PG_KERNEL_INDEX_AND; out->dominant_kernel_ms = ms_index; }
     }
   }
+  if (out && lw.side != nullptr && !lw.side->fused && !out->filter_entries_exact) {
+    // The transducer pass (pg_filter_fsm.h) behind the query's own kernels: they have retired (the result above was read), the leaves' bitmaps
+    // they left are in this context's scratch, the context is still ours.  A pass that fails leaves the answer standing, inexact.
+    if (device_fsm_filter_stats(seg, ctx, q, *lw.side, out) != PG_OK) { (void)hipGetLastError(); out->filter_entries_exact = 0; }
+  }
   return PG_OK;
 }
 
@@ -4198,7 +4232,7 @@ static pg_status replay_filter_stats(pg_segment* seg, const pg_query* q, pg_resu
 // The same count ON THE DEVICE, at any segment size, for the root ANDs pg_filter_fsm.h can compile (scan leaves, index-based leaves, ORs
 // of leaves -- `a AND b AND c`, `a AND (b OR c)`, the reference's golden filter): every leaf's docId set stays on the device as a
 // doc-order bitmap, the transducer's tables are built tile by tile and chained (pg_fsm_kernels.h).  Nothing but the count comes back.
-// Layout of the pass's scratch (pg_segment.d_fsm_scratch): L bitmaps of whole tiles | delta | tile tables | chunk tables | the count --
+// Layout of the pass's scratch (ExecCtx.d_fsm_scratch): L bitmaps of whole tiles | delta | tile tables | chunk tables | the count --
 // and, for a machine with a NOT child (Fsm::marks: the episodes of pg_fsm_kernels.h), from the next 256-byte boundary on:
 // episode count + final-pending flag | marks | chunk states | tile states | the tiles' unpaired closes | the tiles' last opens.
 struct FsmScratch {
@@ -4222,33 +4256,41 @@ struct FsmScratch {
     }
   }
 };
-// (under seg->fsm_mu) the scratch, grown when needed, and where every input's bitmap goes
-static pg_status prepare_fsm_side(pg_segment* seg, const fstats::Fsm& fsm, FsmSide* side) {
+// The context's scratch, grown when needed, and where every input's bitmap goes.  (execute_impl, with the context it runs on.)
+static pg_status prepare_fsm_side(pg_segment* seg, ExecCtx* ctx, const fstats::Fsm& fsm, FsmSide* side) {
   const FsmScratch lay(seg, fsm);
   // fsm_finish_kernel keeps one table per chunk in LDS (chunks * S * 4 bytes): 16 states near 2^31 docs pass 64 KB -- such a machine is not counted here
   if ((size_t)lay.chunks * (size_t)fsm.num_states * 4 > (60u << 10)) return fail(PG_ERR_UNSUPPORTED, "transducer pass: %lld chunks x %d states exceed the finish kernel's LDS", lay.chunks, fsm.num_states);
-  HIP_TRY(hipSetDevice(phys_device(seg->device)));
-  if (seg->fsm_scratch_bytes < lay.total) {
-    if (seg->d_fsm_scratch) (void)hipFree(seg->d_fsm_scratch);
-    seg->device_bytes -= seg->fsm_scratch_bytes;               // (the scratch is part of what pg_segment_device_bytes reports: the HBM budget of the caller sees it)
-    seg->d_fsm_scratch = nullptr; seg->fsm_scratch_bytes = 0;
-    HIP_TRY(hipMalloc((void**)&seg->d_fsm_scratch, lay.total));
-    seg->fsm_scratch_bytes = lay.total;
+  if (ctx->fsm_scratch_bytes < lay.total) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_fsm_scratch) (void)hipFree(ctx->d_fsm_scratch);
+    seg->device_bytes -= ctx->fsm_scratch_bytes;               // (the scratch is part of what pg_segment_device_bytes reports: the HBM budget of the caller sees it)
+    ctx->d_fsm_scratch = nullptr; ctx->fsm_scratch_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&ctx->d_fsm_scratch, lay.total));
+    ctx->fsm_scratch_bytes = lay.total;
     seg->device_bytes += lay.total;
   }
+  if (!ctx->h_fsm_stage) HIP_TRY(hipHostMalloc((void**)&ctx->h_fsm_stage, kFsmStageBytes, hipHostMallocDefault));
+  for (hipEvent_t& e : ctx->ev_pass) if (!e) HIP_TRY(hipEventCreate(&e));
+  const fstats::Fsm* keep = side->fsm;
   *side = FsmSide();
-  side->fsm = &fsm;
-  for (int i = 0; i < fsm.num_inputs; ++i) side->bitmap[i] = reinterpret_cast<uint32_t*>(seg->d_fsm_scratch + lay.bitmap_bytes * (size_t)i);
-  uint8_t* at = seg->d_fsm_scratch + lay.bitmap_bytes * (size_t)fsm.num_inputs + lay.delta_bytes;
+  side->fsm = keep ? keep : &fsm;
+  for (int i = 0; i < fsm.num_inputs; ++i) side->bitmap[i] = reinterpret_cast<uint32_t*>(ctx->d_fsm_scratch + lay.bitmap_bytes * (size_t)i);
+  uint8_t* at = ctx->d_fsm_scratch + lay.bitmap_bytes * (size_t)fsm.num_inputs + lay.delta_bytes;
   side->tables = reinterpret_cast<uint32_t*>(at); at += lay.tables_bytes;
   side->chunks = reinterpret_cast<uint32_t*>(at); at += lay.chunk_bytes;
   side->entries = reinterpret_cast<unsigned long long*>(at);
   side->num_tiles = lay.tiles; side->num_chunks = lay.chunks;
+  side->prepared = true;
   return PG_OK;
 }
 
-static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, const fstats::Fsm& fsm, const FsmSide& side, pg_result* out) {
-  HIP_TRY(hipSetDevice(phys_device(seg->device)));
+// Behind the query's own kernels, on the query's stream, with the context still held: kernels and copies are enqueued, ONE synchronisation
+// at the end (rounds 4-5: the NULL stream, four synchronous copies, under a segment-wide mutex).  For timed runs the pass is bracketed by
+// ctx->ev_pass and added to device_ms by the caller.
+static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg_query* q, const FsmSide& side, pg_result* out) {
+  const fstats::Fsm& fsm = *side.fsm;
+  hipStream_t stream = ctx->stream;
   const FsmScratch lay(seg, fsm);
   const long long tiles = lay.tiles, chunks = lay.chunks;
   const int L = fsm.num_inputs, S = fsm.num_states;
@@ -4256,7 +4298,8 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   const auto t_begin = now();
-  uint8_t* d_base = seg->d_fsm_scratch;
+  uint8_t* d_base = ctx->d_fsm_scratch;
+  if ((((size_t)fsm.num_states << fsm.num_inputs) * 2 + 64) > kFsmStageBytes) return fail(PG_ERR_INTERNAL, "transducer tables exceed the pinned staging area");
   FsmParams fp;
   memset(&fp, 0, sizeof(fp));
   int scanned_again = 0;
@@ -4278,16 +4321,21 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
     if (st != PG_OK) return st;
   }
   const auto t_leaves = now();
+  const bool timed_pass = (g_engine.flags & PG_CFG_TIME_KERNELS) != 0;
+  if (timed_pass) HIP_TRY(hipEventRecord(ctx->ev_pass[0], stream));
   uint8_t* at = d_base + lay.bitmap_bytes * (size_t)L;
   uint8_t* d_delta = at; at += lay.delta_bytes;
   uint32_t* d_tables = reinterpret_cast<uint32_t*>(at); at += lay.tables_bytes;
   uint32_t* d_chunks = reinterpret_cast<uint32_t*>(at); at += lay.chunk_bytes;
   unsigned long long* d_entries = reinterpret_cast<unsigned long long*>(at);
-  HIP_TRY(hipMemcpy(d_delta, fsm.delta.data(), (size_t)S << L, hipMemcpyHostToDevice));
+  uint8_t* const h_delta = ctx->h_fsm_stage + 64;
+  uint8_t* const h_marks = h_delta + ((size_t)S << L);
+  memcpy(h_delta, fsm.delta.data(), (size_t)S << L);
+  HIP_TRY(hipMemcpyAsync(d_delta, h_delta, (size_t)S << L, hipMemcpyHostToDevice, stream));
   fp.delta = d_delta; fp.tables = d_tables;
   fp.num_inputs = L; fp.num_states = S; fp.num_docs = seg->num_docs; fp.num_tiles = (int32_t)tiles;
   const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)seg->num_cus * 8));
-#define PG_FSM_LAUNCH(SM, LM) fsm_tiles_kernel<SM, LM><<<dim3(blocks), dim3(256), 0, 0>>>(fp)
+#define PG_FSM_LAUNCH(SM, LM) fsm_tiles_kernel<SM, LM><<<dim3(blocks), dim3(256), 0, stream>>>(fp)
 // (a machine over two inputs has at most three states -- 350 000 random root ANDs over two predicates, tools/kernel_coverage.py's search:
 //  the <8, 2>, <16, 2> table walks and the eight-state byte-function walk over two inputs were instantiations no query could reach;
 //  the coverage gate of round 5 found them, they are gone: such a machine, should one ever exist, walks the three-input form)
@@ -4298,13 +4346,13 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
   int max_inc = 0;
   for (uint8_t d : fsm.delta) max_inc = std::max(max_inc, (int)(d >> 4));
   if (S <= 4 && L <= 4 && max_inc <= 7 && perm_walk) {
-    if (L <= 2) fsm_tiles_perm_kernel<2><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
-    else if (L <= 3) fsm_tiles_perm_kernel<3><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
-    else fsm_tiles_perm_kernel<4><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
+    if (L <= 2) fsm_tiles_perm_kernel<2><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
+    else if (L <= 3) fsm_tiles_perm_kernel<3><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
+    else fsm_tiles_perm_kernel<4><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
   }
   else if (S <= 8 && L <= 4 && max_inc <= 7 && perm_walk) {
-    if (L <= 3) fsm_tiles_perm8_kernel<3><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
-    else fsm_tiles_perm8_kernel<4><<<dim3(blocks), dim3(256), 0, 0>>>(fp);
+    if (L <= 3) fsm_tiles_perm8_kernel<3><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
+    else fsm_tiles_perm8_kernel<4><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
   }
   else if (S <= 2) PG_FSM_LAUNCH_L(2);
   else if (S <= 4) PG_FSM_LAUNCH_L(4);
@@ -4315,9 +4363,9 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
   HIP_TRY(hipGetLastError());
   if (trace) HIP_TRY(hipDeviceSynchronize());
   const auto t_tiles = now();
-  fsm_chain_kernel<<<dim3((unsigned)chunks), dim3(1024), 0, 0>>>(d_tables, tiles, S, d_chunks);
+  fsm_chain_kernel<<<dim3((unsigned)chunks), dim3(1024), 0, stream>>>(d_tables, tiles, S, d_chunks);
   HIP_TRY(hipGetLastError());
-  fsm_finish_kernel<<<dim3(1), dim3(1024), (size_t)chunks * (size_t)S * 4, 0>>>(d_chunks, (int)chunks, S, d_entries);
+  fsm_finish_kernel<<<dim3(1), dim3(1024), (size_t)chunks * (size_t)S * 4, stream>>>(d_chunks, (int)chunks, S, d_entries);
   HIP_TRY(hipGetLastError());
   unsigned long long entries = 0, episodes = 0;
   if (fsm.has_episodes()) {
@@ -4331,11 +4379,12 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
     uint8_t* d_tile_state = d_chunk_state + lay.chunk_state_bytes;
     int32_t* d_first_close = reinterpret_cast<int32_t*>(d_tile_state + lay.tile_state_bytes);
     int32_t* d_last_open = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(d_first_close) + lay.tile_pos_bytes);
-    HIP_TRY(hipMemsetAsync(eb, 0, 16, 0));
-    HIP_TRY(hipMemcpy(d_marks, fsm.marks.data(), (size_t)S << L, hipMemcpyHostToDevice));
-    fsm_chunk_states_kernel<<<dim3(1), dim3(1024), (size_t)chunks * (size_t)S * 4, 0>>>(d_chunks, (int)chunks, S, d_chunk_state);
+    HIP_TRY(hipMemsetAsync(eb, 0, 16, stream));
+    memcpy(h_marks, fsm.marks.data(), (size_t)S << L);
+    HIP_TRY(hipMemcpyAsync(d_marks, h_marks, (size_t)S << L, hipMemcpyHostToDevice, stream));
+    fsm_chunk_states_kernel<<<dim3(1), dim3(1024), (size_t)chunks * (size_t)S * 4, stream>>>(d_chunks, (int)chunks, S, d_chunk_state);
     HIP_TRY(hipGetLastError());
-    fsm_tile_states_kernel<<<dim3((unsigned)chunks), dim3(1024), 0, 0>>>(d_tables, tiles, S, d_chunk_state, d_tile_state);
+    fsm_tile_states_kernel<<<dim3((unsigned)chunks), dim3(1024), 0, stream>>>(d_tables, tiles, S, d_chunk_state, d_tile_state);
     HIP_TRY(hipGetLastError());
     if (perm_walk && S <= 8 && L <= 4) {
       // machines of at most eight states over at most four inputs: byte functions, a scan over the wavefront, a contiguous range of tiles per
@@ -4350,10 +4399,10 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
       rp.pending_states = fsm.pending_states;
       rp.num_inputs = L; rp.num_states = S; rp.num_docs = seg->num_docs; rp.num_tiles = (int32_t)tiles; rp.num_ranges = (int32_t)num_ranges;
       const dim3 rgrid((unsigned)((num_ranges + 3) / 4));
-      if (S <= 4) { if (L <= 2) fsm_episode_ranges_kernel<4, 2><<<rgrid, dim3(256), 0, 0>>>(rp); else fsm_episode_ranges_kernel<4, 4><<<rgrid, dim3(256), 0, 0>>>(rp); }
-      else { if (L <= 2) fsm_episode_ranges_kernel<8, 2><<<rgrid, dim3(256), 0, 0>>>(rp); else fsm_episode_ranges_kernel<8, 4><<<rgrid, dim3(256), 0, 0>>>(rp); }
+      if (S <= 4) { if (L <= 2) fsm_episode_ranges_kernel<4, 2><<<rgrid, dim3(256), 0, stream>>>(rp); else fsm_episode_ranges_kernel<4, 4><<<rgrid, dim3(256), 0, stream>>>(rp); }
+      else { if (L <= 2) fsm_episode_ranges_kernel<8, 2><<<rgrid, dim3(256), 0, stream>>>(rp); else fsm_episode_ranges_kernel<8, 4><<<rgrid, dim3(256), 0, stream>>>(rp); }
       HIP_TRY(hipGetLastError());
-      fsm_episode_finish_kernel<<<dim3(1), dim3(1024), 0, 0>>>(d_first_close, d_last_open, (int)num_ranges, seg->num_docs, d_final_pending, d_episodes);
+      fsm_episode_finish_kernel<<<dim3(1), dim3(1024), 0, stream>>>(d_first_close, d_last_open, (int)num_ranges, seg->num_docs, d_final_pending, d_episodes);
       HIP_TRY(hipGetLastError());
     } else {
       FsmEpisodeParams ep;
@@ -4364,15 +4413,24 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, const pg_query* q, con
       ep.episode_entries = d_episodes; ep.final_pending = d_final_pending;
       ep.pending_states = fsm.pending_states;
       ep.num_inputs = L; ep.num_states = S; ep.num_docs = seg->num_docs; ep.num_tiles = (int32_t)tiles;
-      fsm_episode_tiles_kernel<<<dim3(blocks), dim3(256), 0, 0>>>(ep);
+      fsm_episode_tiles_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(ep);
       HIP_TRY(hipGetLastError());
-      fsm_episode_finish_kernel<<<dim3(1), dim3(1024), 0, 0>>>(d_first_close, d_last_open, (int)tiles, seg->num_docs, d_final_pending, d_episodes);
+      fsm_episode_finish_kernel<<<dim3(1), dim3(1024), 0, stream>>>(d_first_close, d_last_open, (int)tiles, seg->num_docs, d_final_pending, d_episodes);
       HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipMemcpy(&episodes, d_episodes, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(ctx->h_fsm_stage + 8, d_episodes, 8, hipMemcpyDeviceToHost, stream));
   }
-  HIP_TRY(hipMemcpy(&entries, d_entries, 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(ctx->h_fsm_stage, d_entries, 8, hipMemcpyDeviceToHost, stream));
+  if (timed_pass) HIP_TRY(hipEventRecord(ctx->ev_pass[1], stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  memcpy(&entries, ctx->h_fsm_stage, 8);
+  if (fsm.has_episodes()) memcpy(&episodes, ctx->h_fsm_stage + 8, 8);
   entries += episodes;
+  if (timed_pass) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_pass[0], ctx->ev_pass[1]));
+    out->device_ms += ms;
+  }
   if (trace) fprintf(stderr, "fsm stats: %d inputs %d states %lld tiles: %d leaf bitmaps scanned again %.1f us, tables kernel %.1f us, chain+finish+copy %.1f us%s\n", L, S, tiles,
                      scanned_again, us(t_begin, t_leaves), us(t_leaves, t_tiles), us(t_tiles, now()), fsm.has_episodes() ? " (with the episodes of a NOT child)" : "");
   out->stats.num_entries_scanned_in_filter = (int64_t)entries;
@@ -4393,37 +4451,18 @@ static pg_status execute_one(pg_segment* segment, const pg_query* query, pg_resu
   const bool use_fsm = g_engine.fsm_stats && !bound_ok;
   fstats::Fsm fsm;
   FsmSide side;
-  std::unique_lock<std::mutex> fsm_lock;
-  bool fsm_ready = false;
   if (use_fsm && !null_handling && segment && query && query->num_filter_nodes >= 3 && query->filter && query->predicates) {
     int scan_leaves = 0;
-    if (fstats::choose_plan(query, &scan_leaves) == fstats::Plan::kReplay && fstats::compile_fsm(query, &fsm) && (g_engine.fsm_episodes || !fsm.has_episodes())) {
-      fsm_lock = std::unique_lock<std::mutex>(segment->fsm_mu);
-      // numEntriesScannedInFilter is a statistic: a pass that cannot get its scratch (or fails later) leaves the query's answer standing
-      // with filter_entries_exact = 0 (the host replay below still applies at its sizes) -- it never fails the query
-      fsm_ready = prepare_fsm_side(segment, fsm, &side) == PG_OK;
-      if (!fsm_ready) { (void)hipGetLastError(); fsm_lock.unlock(); }
-    }
+    // (the machine only: execute_impl gives it the scratch of the context the query runs on and runs the pass behind the query's kernels, on
+    //  their stream -- two such queries on one segment overlap like any others; rounds 4-5 held a segment-wide mutex across query and pass)
+    if (fstats::choose_plan(query, &scan_leaves) == fstats::Plan::kReplay && fstats::compile_fsm(query, &fsm) && (g_engine.fsm_episodes || !fsm.has_episodes())) side.fsm = &fsm;
   }
   pg_status st = null_handling ? execute_null_handling(segment, query, out_result, nullptr, 0, nullptr)
-                               : execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr, true, defer, fsm_ready ? &side : nullptr);
+                               : execute_impl(segment, query, out_result, nullptr, nullptr, 0, nullptr, true, defer, side.fsm != nullptr ? &side : nullptr);
   if (st == kDeferred) return st;
   // (enableNullHandling changes the iterator tree -- nulls are or-ed in, NOT takes the falses: the upper bound stands there)
-  if (st == PG_OK && !null_handling && !bound_ok && !out_result->filter_entries_exact) {
-    if (fsm_ready) {
-      const auto t0 = std::chrono::steady_clock::now();
-      if (device_fsm_filter_stats(segment, query, fsm, side, out_result) != PG_OK) {
-        (void)hipGetLastError();
-        out_result->filter_entries_exact = 0;
-        if ((int64_t)segment->num_docs <= g_engine.exact_stats_docs) st = replay_filter_stats(segment, query, out_result);
-      }
-      // (timed runs: the pass is charged to the query on the host clock: it has no event bracket of its own, and a clock that includes
-      //  its copies overstates rather than hides it)
-      if (g_engine.flags & PG_CFG_TIME_KERNELS) out_result->device_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    } else if ((int64_t)segment->num_docs <= g_engine.exact_stats_docs) {
-      st = replay_filter_stats(segment, query, out_result);
-    }
-  }
+  if (st == PG_OK && !null_handling && !bound_ok && !out_result->filter_entries_exact && (int64_t)segment->num_docs <= g_engine.exact_stats_docs)
+    st = replay_filter_stats(segment, query, out_result);
   if (st != PG_OK) pg_result_free(out_result);
   return st;
 }
@@ -4925,8 +4964,10 @@ pg_status finish_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_res
 // all-zero table slice comes back whole and the host keeps the slots whose count is not zero (§4.1k).  Its lowering is remembered in the
 // segment's plan cache like a batch item's.  Everything else takes execute_one as before.  PINOT_GPU_GROUP_ONE_LAUNCH=0: never.
 pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_result) {
+  // (PG_CFG_PROFILE_WAVES: the per-wave phase counters live in the kernels execute_one launches itself, and its HIP events bracket ALL of a
+  //  query's launches -- the deferred form would leave profile_* empty and report the kernel bracket only)
   if (!(g_engine.group_one_launch && g_engine.batch_launch && g_engine.batch_group && segment && query && out_result && query->num_group_by > 0 &&
-        !(query->flags & PG_QUERY_NULL_HANDLING) && g_engine.initialized))
+        !(query->flags & PG_QUERY_NULL_HANDLING) && !(g_engine.flags & PG_CFG_PROFILE_WAVES) && g_engine.initialized))
     return execute_one(segment, query, out_result, nullptr);
   std::vector<Deferred> defs(1);
   defs[0].single = true;

@@ -199,9 +199,15 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
         num_sorted += classify(q->predicates[q->filter[g].predicate]) == LeafClass::kSorted ? 1 : 0;
       }
       if (num_members < 2) return false;
-      // (OrDocIdSet.java:62-126 merges two or more SORTED members -- and, in the oracle's reading of :80-110, the bitmap members beside them --
-      //  into one bitmap iterator; when no scan member remains the OR IS that iterator, an index-based child of the AND: a shape left to
-      //  the replay.  Round 4 bailed out only when EVERY member was sorted: `idx AND scan AND (bitmap OR sorted OR sorted)` was walked as a
+      // (OrDocIdSet.java:62-126 merges two or more SORTED members into one bitmap iterator; when no scan member remains the OR IS that
+      //  iterator, an index-based child of the AND: a shape left to the replay.
+      //  A KNOWING DEVIATION from the cited lines: this fork's OrDocIdSet.iterator() never fills `bitmapBasedDocIdIterators` (:80-82 count
+      //  the member's entries and add it to no list), so with two or more sorted members the reference DROPS the bitmap members of the OR --
+      //  docs that only a posting matches leave the result.  The oracle (ds_iterator, DS_OR), the host replay and this machine or the bitmap
+      //  members into the merged iterator, i.e. they compute the OR the query asks for; upstream Pinot fills the list.  With one sorted
+      //  member or none nothing is merged and the fork, the oracle and the machine agree line by line.  With a scan member present the
+      //  machine walks the unmerged members: the same docs and the same entries -- an index-based member costs no entries and a doc of the
+      //  OR is a doc of the OR -- held against the oracle by tests/test_filter_stats_cpu.py's random trees, which force this shape.  Round 4 bailed out only when EVERY member was sorted: `idx AND scan AND (bitmap OR sorted OR sorted)` was walked as a
       //  leap-frogging OR and counted 27 559 entries where the iterators count 15 468 -- found by the kernel-coverage table of round 5.)
       if (num_sorted > 1 && num_scans == 0) return false;
     } else if (q->filter[kid].op == PG_FILTER_NOT) {

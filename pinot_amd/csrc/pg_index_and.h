@@ -239,6 +239,11 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
   for (int i = 0; i < 8; ++i) window[lane0 + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
 
+  // record mode (ap.pub): what this lane found in all of the wave's windows -- reduced over the wave ONCE, behind the loop
+  uint32_t lane_card = 0u;
+  unsigned long long gsum[kMaxAndGather] = {0ull, 0ull};       // gather mode: the survivors' values of this lane
+  uint32_t gmin[kMaxAndGather] = {0xFFFFFFFFu, 0xFFFFFFFFu}, gmax[kMaxAndGather] = {0u, 0u};
+
   for (; key < num_windows; key += gridDim.x) {
     // (the lane number is made opaque once per window: left alone, LICM hoists every lane-dependent term of the window's code -- the
     //  pieces' offsets, the tail's doc numbers, the gathers' multiplies -- out of this loop, ~70 registers of them into scratch.  For
@@ -366,8 +371,6 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
     // ---- the window's result: docs past numDocs cleared (an exclusive child sets them), words, tile mask, cardinality ----
     uint32_t tiles = 0u;
     uint32_t card = 0u;
-    unsigned long long gsum[kMaxAndGather] = {0ull, 0ull};       // gather mode: the survivors' values of this lane
-    uint32_t gmin[kMaxAndGather] = {0xFFFFFFFFu, 0xFFFFFFFFu}, gmax[kMaxAndGather] = {0u, 0u};
     const long long docs_left = (long long)ap.num_docs - base * 64;      // docs of the segment from this window on
     if (docs_left < 65536) {                                             // uniform: only the segment's last window
       const uint32_t left = (uint32_t)docs_left;                         // 1 .. 65 535
@@ -433,30 +436,31 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
         for (int g = 0; g < 4; ++g) if ((nz >> (16 * g)) & 0xffffull) tiles |= 1u << (4 * i + g);
       }
     }
-    const uint32_t total = (uint32_t)wave_sum_i64((long long)card);
-    if (lane == 0u) {
-      if (out != nullptr) ap.window_info[key] = WindowInfo{tiles, total};
-      // (kAndCardinalityShards counters, one 128-byte line each: ONE counter made the kernel 58 -> 194 us on C5-sparse -- ~3 700 same-address
-      //  device-scope atomics at ~37 ns apiece, each holding its wave's slot until it retires)
-      if (ap.cardinality_out != nullptr && total != 0u)
-        __hip_atomic_fetch_add(ap.cardinality_out + (size_t)(key & (kAndCardinalityShards - 1)) * 16, (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lane_card += card;
+    if (out != nullptr) {
+      const uint32_t total = (uint32_t)wave_sum_i64((long long)card);
+      if (lane == 0u) ap.window_info[key] = WindowInfo{tiles, total};
     }
-    if (ap.gather_cols != 0 && total != 0u) {
+  }
+
+  if (ap.pub.partials != nullptr) {
+    // ---- the wavefront's record, published like a scan kernel's: the last wavefront to arrive folds them into the pinned host record ----
+    __shared__ BlockPartial red[1];
+    __shared__ uint32_t fold_flag;
+    BlockPartial mine;
+    partial_identity(mine);
+    mine.count = (unsigned long long)wave_sum_i64((long long)lane_card);
 #pragma unroll
-      for (int a = 0; a < kMaxAndGather; ++a) {
-        if (a >= ap.gather_cols) continue;
-        const unsigned long long s = (unsigned long long)wave_sum_i64((long long)gsum[a]);
-        // (keys are below 2^31: dictIds / plane fields -- the signed wave reductions take them as they are)
-        const uint32_t kmin = (uint32_t)wave_min_i32((int32_t)(gmin[a] == 0xFFFFFFFFu ? 0x7FFFFFFF : gmin[a]));
-        const uint32_t kmax = (uint32_t)wave_max_i32((int32_t)gmax[a]);
-        if (lane == 0u) {
-          unsigned long long* o = ap.gather_out + (size_t)(key & (kAndCardinalityShards - 1)) * 16 + 1 + 3 * a;      // (word 0 of the line: the cardinality)
-          __hip_atomic_fetch_add(o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_fetch_max(o + 1, (unsigned long long)(0xFFFFFFFFu - kmin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_fetch_max(o + 2, (unsigned long long)kmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
+    for (int a = 0; a < kMaxAndGather; ++a) {
+      if (a >= ap.gather_cols) continue;
+      // (keys are below 2^31: dictIds / plane fields -- the signed wave reductions take them as they are)
+      mine.sum[a] = wave_sum_i64((long long)gsum[a]);
+      mine.kmin[a] = wave_min_i32((int32_t)(gmin[a] == 0xFFFFFFFFu ? 0x7FFFFFFF : gmin[a]));
+      mine.kmax[a] = mine.count != 0ull ? wave_max_i32((int32_t)gmax[a]) : (int32_t)0x80000000;
     }
+    if (lane0 == 0) red[0] = mine;
+    __syncthreads();
+    publish_block_partial(ap.pub, red, 1, &fold_flag, blockIdx.x, gridDim.x);
   }
 }
 

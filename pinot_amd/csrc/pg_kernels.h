@@ -2126,97 +2126,6 @@ __host__ __device__ __forceinline__ uint32_t lds_group_table_bytes(const GroupPa
 #ifndef PG_GROUP_MINMAX_LOOK
 #define PG_GROUP_MINMAX_LOOK 0
 #endif
-// Sixteen of the lane's 32 docs (half H) of one 2048-doc tile: group ids from the key columns, then the count and every aggregation --
-// group_private_tile's direct-table forms, sixteen docs at a time (PG_GROUP_HALVES).
-#ifndef PG_GROUP_HALVES
-#define PG_GROUP_HALVES 1
-#endif
-template <bool kLds, bool kMasked, bool kWide, int H, typename GP>
-__device__ __forceinline__ void group_private_half(const GP& gp, long long tile, int lane, uint32_t m, unsigned long long* t_cnt, long long* t_acc, uint8_t* lds) {
-  const int G = gp.num_groups;
-  const int logR = kLds ? gp.lds_log_replicas : 0;
-  const uint32_t cls = (uint32_t)lane & ((1u << logR) - 1u);
-  const uint32_t mh = kMasked ? (m >> (16 * H)) & 0xFFFFu : 0xFFFFu;      // the half's match bits
-  if (kMasked && __builtin_amdgcn_ballot_w64(mh != 0u) == 0ull) return;    // nobody in the wave has a doc in this half
-  uint32_t lds_off = 0u;
-  const long long first_doc = tile * 2048 + lane * 32;
-  uint32_t g[16];
-  for (int c = 0; c < gp.num_group_cols; ++c) {
-    const auto& key = gp.group_keys[c];
-    const int b = key.bits;
-    const uint32_t mult = (uint32_t)key.mult;
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(key.fwd + tile * (256ll * b)) + lane * b;
-    uint32_t d[16];
-    decode16_private_dispatch<H>(b, words, d);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) g[j] = c == 0 ? d[j] : key_term<kWide>(d[j], mult) + g[j];
-  }
-  const bool packed = kLds && gp.packed_agg >= 0;
-  if (!packed) {
-    if constexpr (kLds) {
-      uint32_t* cnt_lane = reinterpret_cast<uint32_t*>(lds) + cls;
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (!kMasked || ((mh >> j) & 1u)) __hip_atomic_fetch_add(cnt_lane + (g[j] << logR), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      lds_off = lds_subtable_bytes(G, logR, 4);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) if (!kMasked || ((mh >> j) & 1u)) group_count<kLds>(t_cnt, g[j]);
-    }
-  }
-  for (int a = 0; a < gp.num_group_aggs; ++a) {
-    const auto& ga = gp.group_aggs[a];
-    long long* acc = kLds ? reinterpret_cast<long long*>(lds + lds_off) + cls : t_acc + (long long)a * G;      // kLds: this lane's copy of a SUM sub-table,
-    int32_t* acc32 = reinterpret_cast<int32_t*>(lds + lds_off) + cls;                                          //       or of a MIN / MAX one
-    if constexpr (kLds) lds_off += lds_subtable_bytes(G, logR, ga.kind == kGroupSum ? 8 : 4);
-    const int b = ga.bits;
-    const uint32_t* words = ga.is_raw ? reinterpret_cast<const uint32_t*>(ga.fwd) + first_doc
-                                      : reinterpret_cast<const uint32_t*>(ga.fwd + tile * (256ll * b)) + lane * b;
-    const bool is_unsigned = !ga.is_raw && ga.is_plane;
-    const uint32_t one_hi = (packed && a == gp.packed_agg) ? (1u << (gp.packed_shift - 32)) : 0u;
-    uint32_t d[16];
-    if (ga.is_raw) {
-      // raw INT column: the lane's 32 docs are 128 contiguous bytes
-#pragma unroll
-      for (int j = 0; j < 16; ++j) d[j] = __builtin_bswap32(words[16 * H + j]);      // raw buffers are padded to whole tiles
-    } else {
-      decode16_private_dispatch<H>(b, words, d);
-      if (ga.kind == kGroupSum && !ga.is_plane) {
-        // dictionary gather (small dictionaries / PINOT_GPU_VALUE_PLANE=0)
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ga.dict, 0, ga.dict_bytes, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) d[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, d[j] * 4u, 0, 0);
-      }
-    }
-    if (ga.kind == kGroupSum && is_unsigned) {
-      // plane field; the packed count lives entirely in the high dword: the operand is the register pair {field, one_hi}
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (!kMasked || ((mh >> j) & 1u)) group_sum<kLds>(acc + (g[j] << logR), (long long)(((unsigned long long)one_hi << 32) | (unsigned long long)d[j]));
-    } else if (ga.kind == kGroupSum) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (!kMasked || ((mh >> j) & 1u)) group_sum<kLds>(acc + (g[j] << logR), (long long)(int32_t)d[j]);
-    } else if (ga.kind == kGroupMin) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (!kMasked || ((mh >> j) & 1u)) {
-          if constexpr (kLds) __hip_atomic_fetch_min(acc32 + (g[j] << logR), (int32_t)d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          else group_min<false>(acc + g[j], (int32_t)d[j]);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (!kMasked || ((mh >> j) & 1u)) {
-          if constexpr (kLds) __hip_atomic_fetch_max(acc32 + (g[j] << logR), (int32_t)d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          else group_max<false>(acc + g[j], (int32_t)d[j]);
-        }
-      }
-    }
-  }
-}
-
 // One 2048-doc tile.  kMasked: only the docs whose bit is set in the lane's mask `m` reach the table (a filter's result, and /
 // or the docs that exist in the last, partial tile); otherwise every doc of the tile does, with no exec masking around the atomics.
 // GP: GroupParams, or its constant-address-space form in device memory (an item of group_lds_batch_kernel)
@@ -2272,14 +2181,12 @@ __device__ __forceinline__ void group_private_tile(const GP& gp, long long tile,
       return;
     }
   } else {
-#if PG_GROUP_HALVES
-  // Round 6: the lane's docs in two halves of sixteen -- keys, count and every aggregation of docs 0..15, then of 16..31.  The 32-entry
-  // group-id array was the kernel's largest live range (101 VGPRs: four waves per SIMD, ONE sixteen-wave workgroup per CU, 72 % of a
-  // wave's cycles waiting for one of a tile's three dependent column reads); sixteen ids at a time leave room for more waves per SIMD.
-  group_private_half<kLds, kMasked, kWide, 0>(gp, tile, lane, m, t_cnt, t_acc, lds);
-  group_private_half<kLds, kMasked, kWide, 1>(gp, tile, lane, m, t_cnt, t_acc, lds);
-  return;
-#else
+  // (Round 6, measured and not kept: the lane's docs in two halves of sixteen -- keys, count and every aggregation of docs 0..15, then of
+  //  16..31 -- to shorten the 32-entry group-id array's live range.  The registers it frees buy nothing (100 VGPRs instead of 101: the filter
+  //  program and the decoders set the allocation) and a tile becomes SIX dependent column reads instead of three: C3 0.950 -> 1.345 ms,
+  //  C3-filter 1.220 -> 1.533, C3-irregular 1.294 -> 1.913 (profiles/r6/c3_variants_ab.txt).  Bounding the kernels for five waves per SIMD
+  //  (two ten-wave workgroups per CU, 96 VGPRs, 2 spilled) on top of it: 1.406 ms.  The tile's three column reads are what a wave waits
+  //  for; more, shorter reads or more waves with fewer registers each make that worse, not better.)
   for (int c = 0; c < gp.num_group_cols; ++c) {
     const auto& key = gp.group_keys[c];
     const int b = key.bits;
@@ -2293,7 +2200,6 @@ __device__ __forceinline__ void group_private_tile(const GP& gp, long long tile,
       for (int j = 0; j < 16; ++j) g[16 * h + j] = c == 0 ? d[j] : key_term<kWide>(d[j], mult) + g[16 * h + j];
     }
   }
-#endif
   }
   const bool packed = kLds && gp.packed_agg >= 0;
   if (!packed) {
@@ -2477,8 +2383,14 @@ __device__ __forceinline__ void group_private_body(const GP& gp, uint32_t block_
 
 // (the forms without an LDS table are launched with kBlockThreads threads: at that bound the register allocation has the whole file --
 //  at the 1024-thread bound of the LDS-table form they spilled ~40 registers inside the tile loop)
+// (the LDS-table forms -- this kernel's and group_lds_batch_kernel's -- are bounded together: most threads of a workgroup, and the waves per
+//  SIMD the register allocation must allow; the engine sizes workgroups and their number per CU from the compiled kernels' registers)
+#ifndef PG_GROUP_LDS_THREADS
+#define PG_GROUP_LDS_THREADS kGroupBlockThreads
+#define PG_GROUP_LDS_WAVES 4
+#endif
 template <bool kLdsTable, bool kWide = false, bool kHash = false>
-__global__ __launch_bounds__(kLdsTable ? kGroupBlockThreads : kBlockThreads) void group_private_kernel(const GroupParams gp) {
+__global__ __launch_bounds__(kLdsTable ? PG_GROUP_LDS_THREADS : kBlockThreads, kLdsTable ? PG_GROUP_LDS_WAVES : 1) void group_private_kernel(const GroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   group_private_body<kLdsTable, kWide, kHash>(gp, blockIdx.x, gridDim.x, smem);
 }
@@ -2493,12 +2405,8 @@ struct GroupBatchParams {
   int32_t num_items;
   int32_t reserved;
 };
-#ifndef PG_GROUP_BATCH_THREADS
-#define PG_GROUP_BATCH_THREADS kGroupBlockThreads
-#define PG_GROUP_BATCH_WAVES 4
-#endif
 template <bool kWide = false>      // (a template so that only pg_unit_group_batch.hip instantiates it)
-__global__ __launch_bounds__(PG_GROUP_BATCH_THREADS, PG_GROUP_BATCH_WAVES) void group_lds_batch_kernel(const GroupBatchParams bp) {
+__global__ __launch_bounds__(PG_GROUP_LDS_THREADS, PG_GROUP_LDS_WAVES) void group_lds_batch_kernel(const GroupBatchParams bp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one
   while (lo < hi) {

@@ -123,7 +123,8 @@ class GpuSegment:
         return out.view(np.float64) if dtype is not None and np.issubdtype(np.dtype(dtype), np.floating) else out
 
     def check(self, spec):
-        """pg_query_check: the status pg_execute would return for eligibility reasons (0 = PG_OK, 2 = PG_ERR_UNSUPPORTED), nothing launched."""
+        """pg_query_check: the status pg_execute would return for eligibility reasons (0 = PG_OK, 2 = PG_ERR_UNSUPPORTED).  Nothing is launched, except
+        that the first check of a GROUP BY over a rank-keyed raw column builds its dictionary and rank image (a failed build: PG_ERR_UNSUPPORTED)."""
         return int(self.lib.pg_query_check(self.handle, C.byref(spec.c)))
 
     def execute_raw(self, spec, res):

@@ -204,6 +204,7 @@ def test_transducer_matches_the_iterator_replay_on_random_and_trees(driver):
     replay of the reference's iterator objects and against the oracle.  Sizes around the lane / tile boundaries."""
     rng = np.random.default_rng(4)
     shapes_seen, compiled, small, medium = set(), 0, 0, 0
+    or_of_sorted_and_scan = 0
     for n in (1, 31, 33, 2047, 2049, 4100, 20_011, 70_003):
         cols = [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "b", n, 7, with_inverted=True)[0],
                 H.random_dict_column(rng, "c", n, 300, with_inverted=True)[0], H.random_dict_column(rng, "d", n, 3)[0],
@@ -236,8 +237,17 @@ def test_transducer_matches_the_iterator_replay_on_random_and_trees(driver):
                     kids.append(scan_leaf())
                 elif r < 7:
                     kids.append(index_leaf())
-                else:
+                elif r < 9:
                     kids.append(Q.or_(*[scan_leaf() if rng.integers(0, 3) else index_leaf() for _m in range(int(rng.integers(2, 4)))]))
+                else:
+                    # two (or three) SORTED members beside a scan member, sometimes a posting too: OrDocIdSet.iterator() merges the sorted ones
+                    # into a bitmap iterator that leads the OrDocIdIterator (the advisor's shape, round 5)
+                    sorted_members = []
+                    for _m in range(int(rng.integers(2, 4))):
+                        lo = int(rng.integers(0, n)); sorted_members.append(Q.leaf(Q.Pred.doc_range(lo, min(n - 1, lo + int(rng.integers(0, max(1, n // 3)))))))
+                    extra = [Q.leaf(Q.Pred.dict_range(1, int(rng.integers(0, 5)), 7, inverted=True))] if rng.integers(0, 2) else []
+                    kids.append(Q.or_(*(sorted_members + [scan_leaf()] + extra)))
+                    or_of_sorted_and_scan += 1
             spec = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(*kids))
             if len(spec.predicates) > 8 or any(p.kind in (_abi.PG_PRED_MATCH_ALL, _abi.PG_PRED_MATCH_NONE) for p in spec.predicates):
                 continue
@@ -265,6 +275,7 @@ def test_transducer_matches_the_iterator_replay_on_random_and_trees(driver):
             else:
                 assert perm8 == -1
     assert compiled > 200 and len(shapes_seen) > 8 and small > 60 and medium > 20, (compiled, shapes_seen, small, medium)
+    assert or_of_sorted_and_scan > 30
 
 
 def test_an_or_of_index_based_members_only_is_not_a_leap_frogging_child(driver):

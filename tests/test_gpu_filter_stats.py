@@ -361,3 +361,53 @@ def test_the_upper_bound_flag_removes_every_statistics_kernel(tmp_path):
         assert e["exact"] and not bnd["exact"] and bnd["entries"] == bnd["scan_leaves_x_docs"]
         assert "NOT" in name or bnd["entries"] >= e["entries"]
         assert {k: e[k] for k in ("count", "sum", "docs_scanned", "post", "total")} == {k: bnd[k] for k in ("count", "sum", "docs_scanned", "post", "total")}
+
+
+def test_two_leapfrogging_queries_on_one_segment_overlap(engine):
+    """The transducer pass runs on the query's own context and stream (round 6): two threads with `a AND NOT b` on ONE segment are in
+    flight together.  Rounds 4-5 held a segment-wide mutex across the query and its pass: two threads took twice one thread's time.
+    The segment is small, so a query is launch and hand-off latency (a dozen kernels, three waits) -- what overlaps when nothing serialises."""
+    import threading
+    import time
+    n = 1_000_003
+    rng = np.random.default_rng(11)
+    ca, _, _ = H.random_dict_column(rng, "a", n, 100)
+    cb, _, _ = H.random_dict_column(rng, "b", n, 10)
+    v = S.Column.synthetic_uniform("v", n, (np.arange(2000, dtype=np.int64) * 3 + 1).astype(np.int32), seed=7)
+    seg = S.SegmentData("overlap", n, [ca, cb, v])
+    spec = Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 2)], filter=Q.and_(Q.leaf(Q.Pred.dict_range(0, 0, 30)), Q.not_(Q.leaf(Q.Pred.dict_range(1, 0, 5)))))
+    want = oracle.execute(seg, spec)
+    rounds = 40
+    with engine.open(seg) as g:
+        first = g.execute(spec)
+        H.assert_results_equal(first, want)
+        assert first.filter_entries_exact and first.stats[1] == want.stats[1]
+        res = _abi.pg_result()
+
+        def work(out):
+            import ctypes as C
+            r = _abi.pg_result()
+            entries = set()
+            for _ in range(rounds):
+                assert g.execute_raw(spec, r) == _abi.PG_OK      # (ctypes releases the GIL inside the call)
+                entries.add((int(r.stats.num_entries_scanned_in_filter), int(r.filter_entries_exact)))
+                engine.lib.pg_result_free(C.byref(r))
+            out.append(entries)
+
+        def timed(threads):
+            outs = []
+            ts = [threading.Thread(target=work, args=(outs,)) for _ in range(threads)]
+            t0 = time.perf_counter()
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            return time.perf_counter() - t0, outs
+
+        timed(1)                                                   # warm: contexts, scratch, clocks
+        timed(2)
+        one = min(timed(1)[0] for _ in range(3))
+        two, outs = min((timed(2) for _ in range(3)), key=lambda x: x[0])
+        for entries in outs:
+            assert entries == {(want.stats[1], 1)}                 # every concurrent query counted exactly, on its own scratch
+        # serialised, two threads take 2.0x one thread; in flight together they share the launch and hand-off latencies
+        assert two < 1.7 * one, (one, two)
+        del res

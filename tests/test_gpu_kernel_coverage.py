@@ -118,3 +118,51 @@ def test_every_kernel_is_dispatched_with_more_tiles_than_waves_and_equals_the_or
         assert any(family(k) == fam for k in kernels_in_the_library()), "EXEMPT names a kernel that no longer exists: " + fam
         if fam.startswith("fsm_"):
             assert any(family(k) == fam for k in ours), "not even a sample of %s ran" % fam
+
+
+# The environment switches of libpinot_gpu.so that change HOW a query is launched without changing which kernels exist: the
+# gate above runs the defaults, and the entries of its table set the switches that are needed to REACH a kernel.  These two runs put the whole
+# table through the other side of everything else, in two combinations, and hold every answer against the oracle -- a switch a deployment
+# can set is code a deployment can run.  (No dispatch-set requirement here: with the launch structure changed, other kernels answer.)
+FLIPPED = {
+    "launch-structure": "PINOT_GPU_GROUP_ONE_LAUNCH=0,PINOT_GPU_INDEX_GATHER=0,PINOT_GPU_FSM_EPISODES=0,PINOT_GPU_LEAN_BATCH=0,PINOT_GPU_BATCH_HIST=0,PINOT_GPU_BATCH_GROUP=0,"
+                        "PINOT_GPU_BATCH_MORE=0,PINOT_GPU_DIRECT_RESULT=0,PINOT_GPU_INDEX_AND_WAVES=-1,PINOT_GPU_PLAN_CACHE=0,PINOT_GPU_FOLD_ONE_COUNTER=0,PINOT_GPU_LEAP2=0,"
+                        "PINOT_GPU_LANE_SKIP=0,PINOT_GPU_SCAN_SPARSE=0,PINOT_GPU_SCAN_RAW=0,PINOT_GPU_SCAN_NARROW=0,PINOT_GPU_RAW64_COALESCED=0,PINOT_GPU_GROUP_PACK=0,"
+                        "PINOT_GPU_GROUP_REPLICAS=0,PINOT_GPU_PARTITION_STATS_CACHE=0,PINOT_GPU_PLANE_GCD=0,PINOT_GPU_STAGED_H2D=0,PINOT_GPU_SMALL_BLOCKS_PER_CU=0,"
+                        "PINOT_GPU_WIDE_BLOCKS=1,PINOT_GPU_GROUP_WAVES=4",
+    "geometry": "PINOT_GPU_POLL_RESULT=0,PINOT_GPU_SCAN_NARROW_SINGLE=0,PINOT_GPU_INDEX_AND_WAVES=3,PINOT_GPU_SPARSE_LANES=64,PINOT_GPU_BLOCKS_PER_CU=2,PINOT_GPU_BATCH_BLOCKS_PER_CU=2,"
+                "PINOT_GPU_DOUBLE_BUFFER=1,PINOT_GPU_TILE_STEPS=16,PINOT_GPU_GROUP_REPLICAS=1,PINOT_GPU_GROUP_WAVES=8,PINOT_GPU_FOLD_FINALIZE=0,PINOT_GPU_VALUE_PLANE=1,"
+                "PINOT_GPU_PLANE_BUDGET_BYTES=1000000",
+}
+
+
+@pytest.mark.parametrize("name", sorted(FLIPPED))
+def test_the_table_with_the_other_side_of_the_switches_equals_the_oracle(name):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in list(env):
+        if k.startswith("PINOT_GPU_") and k not in ("PINOT_GPU_LIB",):
+            del env[k]
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_coverage.py"), "--regime", "tiny", "--fsm-trees", "120", "--flip", FLIPPED[name]],
+                          cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    lines = [ln for ln in proc.stdout.decode().splitlines() if ln.startswith("{")]
+    assert lines, "no report from the table:\n" + proc.stderr.decode()[-3000:]
+    report = json.loads(lines[-1])
+    assert report["failed"] == [] and proc.returncode == 0, report["failed"][:10]
+    assert report["entries"] > 60
+
+
+def test_every_switch_of_the_library_has_a_test_on_its_other_side():
+    """Every PINOT_GPU_* name the library reads is set by some test or by the coverage table (or is a trace / test-harness switch): a switch
+    added without one fails here."""
+    import glob as _glob
+    import re as _re
+    names = set()
+    for path in _glob.glob(os.path.join(ROOT, "pinot_amd", "csrc", "*.h*")) + _glob.glob(os.path.join(ROOT, "pinot_amd", "csrc", "*.hip")):
+        names.update(_re.findall(r'"(PINOT_GPU_[A-Z0-9_]+)"', open(path).read()))
+    assert len(names) > 40
+    tested = ""
+    for path in _glob.glob(os.path.join(ROOT, "tests", "*.py")) + [os.path.join(ROOT, "tools", "kernel_coverage.py"), os.path.join(ROOT, "pinot_amd", "engine.py"), os.path.join(ROOT, "pinot_amd", "_abi.py")]:
+        tested += open(path).read()
+    diagnostics = {"PINOT_GPU_BATCH_TRACE", "PINOT_GPU_FSM_TRACE", "PINOT_GPU_PARTITION_TRACE", "PINOT_GPU_RANK_TRACE"}      # stderr only
+    missing = sorted(n for n in names if n not in tested and n not in diagnostics)
+    assert missing == [], missing

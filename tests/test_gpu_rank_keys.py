@@ -57,3 +57,33 @@ def test_rank_keyed_group_bys_in_a_batch_and_on_a_tiny_grid(engine, monkeypatch)
                 assert res.group_keys == want.group_keys
     finally:
         [g.close() for g in opened]
+
+
+@pytest.mark.parametrize("slots_log2", ["6", "12"])
+def test_the_dictionary_hash_table_is_rebuilt_larger_when_it_fills(engine, monkeypatch, slots_log2):
+    """The device builds a rank-keyed column's dictionary through an open-addressing table that starts at 2^20 slots and is rebuilt 16x
+    larger when probes grow long or more than half of it fills (pg_unit_rank_image.hip).  PINOT_GPU_RANK_SLOTS_LOG2 starts it at 64 / 4096
+    slots under 40 000 distinct doubles (and the specials, among them the image that equals the table's empty marker: none here has it --
+    the LONG case below does): two and one rebuilds, the same dictionary and ranks."""
+    monkeypatch.setenv("PINOT_GPU_RANK_SLOTS_LOG2", slots_log2)
+    case = [c for c in KC.cases() if c[0] == "many-doubles"][0]
+    seg, identities, specs = KC.build(case, seed=9)
+    with engine.open(seg) as g:
+        got, want = g.execute(specs[0]), oracle.execute(seg, specs[0])
+        H.assert_results_equal(got, want, check_stats=False)
+        assert got.group_keys == want.group_keys
+        assert np.array_equal(g.group_key_values(0), KC.rank_values(seg, 0))
+    # a LONG column that holds Long.MAX_VALUE: its order image is all ones -- the table's empty marker; it travels in a flag and ranks last
+    n = 20_011
+    rng = np.random.default_rng(3)
+    pool = np.unique(np.concatenate([np.array([np.iinfo(np.int64).max, np.iinfo(np.int64).min, -1, 0, 1], dtype=np.int64), rng.integers(-(2 ** 62), 2 ** 62, 300, dtype=np.int64)]))
+    key = S.Column.raw_typed("k", pool[rng.integers(0, len(pool), n)].astype(np.int64))
+    v = S.Column.synthetic_uniform("v", n, (np.arange(500, dtype=np.int64) * 7 + 3).astype(np.int32), seed=4)
+    seg2 = S.SegmentData("rank_max", n, [key, v])
+    spec = Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 1)], group_by=[0])
+    with engine.open(seg2) as g:
+        got, want = g.execute(spec), oracle.execute(seg2, spec)
+        H.assert_results_equal(got, want, check_stats=False)
+        assert got.group_keys == want.group_keys
+        vals = g.group_key_values(0)
+        assert vals[-1] == np.iinfo(np.int64).max and np.array_equal(vals, KC.rank_values(seg2, 0))

@@ -30,6 +30,17 @@ fsm_tests)
   timeout 1800 python -m pytest tests/test_gpu_filter_stats.py tests/test_gpu_kernel_coverage.py -m gpu -x -q 2>&1 | tail -12 | tee $OUT/fsm_tests.txt ;;
 stats_flag)
   timeout 900 python -m pytest tests/test_gpu_filter_stats.py -m gpu -x -q -k "upper_bound" 2>&1 | tail -8 | tee $OUT/stats_flag_tests.txt ;;
+c3_libs)
+  # C3 on resident 1 B-row columns: the default build, then A/B builds of the two LDS-table group-by units (tools/make_variant.sh)
+  for spec in ${C3_LIBS:-"default:;PINOT_GPU_GROUP_WAVES=8" "c3_old:" "c3_w5:PINOT_GPU_GROUP_WAVES=10;PINOT_GPU_GROUP_WAVES=5" "c3_w6:PINOT_GPU_GROUP_WAVES=8"}; do
+    lib=${spec%%:*}; settings=${spec#*:}
+    echo "-- build $lib"
+    if [ "$lib" = default ]; then unset PINOT_GPU_LIB; else export PINOT_GPU_LIB=$GRAFT_REPO_ROOT/tools/libpinot_gpu_$lib.so; fi
+    timeout 900 python tools/ab_r6.py c3 --steps 20 --out $OUT/c3_$lib.jsonl --settings "$settings" 2> $OUT/c3_$lib.err | python -c "
+import sys, json
+for l in sys.stdin:
+    r = json.loads(l); print('%-14s %-62s kernel %.4f all %.4f host %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r['frac_all_kernels'] or 0, r['exact']))"
+  done; unset PINOT_GPU_LIB ;;
 c3_ab)
   timeout 1500 python tools/ab_r6.py c3 --steps 20 --out $OUT/c3_ab.jsonl --settings "${C3_SETTINGS:-}" 2> $OUT/c3_ab.err | python -c "
 import sys, json

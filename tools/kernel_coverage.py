@@ -231,6 +231,8 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--fsm-trees", type=int, default=-1, help="random root ANDs for the transducer kernels (default: 400 tiny, 40 large)")
+    ap.add_argument("--flip", default="", help="NAME=value,...: switches set for the WHOLE table (an entry's own environment wins); the answers are what is "
+                                               "checked then, not which kernel gave them -- the non-default side of the launch-structure switches")
     args = ap.parse_args()
     t_begin = time.time()
     import helpers as H
@@ -242,6 +244,8 @@ def main():
 
     n = SIZES[args.regime]
     entries = table(Q, n)
+    flipped = dict(kv.split("=", 1) for kv in args.flip.split(",") if kv)
+    os.environ.update(flipped)
     if args.list:
         for e in entries:
             print(e[0], e[1], e[2])
@@ -263,7 +267,7 @@ def main():
     def check(eid, got, want, family):
         try:
             H.assert_results_equal(got, want)
-            if family is not None:
+            if family is not None and not flipped:
                 assert got.dominant_kernel == family, "dominant kernel %s, expected %s" % (got.dominant_kernel, family)
         except AssertionError as e:
             failed.append({"id": eid, "error": str(e)[:300]})
@@ -288,7 +292,7 @@ def main():
                     check(eid + "(again)", again, want_of(eid, spec), family)
                     ran += 1
         finally:
-            engine.reinit(**{k: None for k, _ in env})
+            engine.reinit(**{k: flipped.get(k) for k, _ in env})
     # ---- the SPI readers and the diagnostics ----
     if only is None or only.search("spi"):
         with engine.open(seg) as g:
@@ -335,7 +339,7 @@ def main():
                             failed.append({"id": "fsm%d" % t, "error": "numEntriesScannedInFilter %d, oracle %d" % (got.stats[1], want.stats[1])})
                         ran += 1
             finally:
-                engine.reinit(**{k: None for k in env})
+                engine.reinit(**{k: flipped.get(k) for k in env})
     # ---- pg_execute_batch: one launch per kind ----
     if only is None or "batch" in args.only:
         parts = 4 if args.regime == "tiny" else 3
