@@ -408,7 +408,7 @@ struct IndexAndParams {
     int32_t fold_slots, fold_typed, profile, fold_one_counter;
   } pub;
   int32_t gather_cols;
-  int32_t reserved_gather;
+  int32_t num_windows;                   // windows of the segment (index_and_batch_kernel reads it here; index_and_kernel takes it as an argument)
   DevAggCol gather_col[2];
   AndChild child[kMaxAndChildren];
   int32_t first[kMaxAndPostings];        // directory slice [first, first + count) of every posting

@@ -88,6 +88,7 @@ struct Engine {
   bool partition_two_level = true;   // PINOT_GPU_PARTITION_TWO_LEVEL=0: key spaces above one scatter pass keep the direct HBM atomics
   bool fsm_perm = true;      // PINOT_GPU_FSM_PERM=0: the transducer pass always walks tables (fsm_tiles_kernel), never byte functions
   int index_and_waves = 0;    // PINOT_GPU_INDEX_AND_WAVES: -k = index_and_kernel's waves take k windows each (grid = windows / k); n > 0 = a persistent grid of n wavefronts per CU; 0 = of as many as are resident
+  bool batch_index = true;   // PINOT_GPU_BATCH_INDEX=0: pg_execute_batch runs index-led items (COUNT(*) over an index-only filter, the gathered aggregation) as launches of their own instead of sharing index_and_batch_kernel's
   bool index_gather = true;  // PINOT_GPU_INDEX_GATHER=0: an index-led aggregation always runs scan_sparse_kernel behind index_and_kernel (never inside it)
   bool fsm_fused = true;     // PINOT_GPU_FSM_FUSED=0: the transducer always runs as a pass of its own behind the scan (leaf bitmaps through HBM)
   bool fsm_stats = true;     // PINOT_GPU_FSM_STATS=0: no transducer pass (host replay / upper bound)
@@ -1122,6 +1123,23 @@ pg_status launch_leap_chain(const pg_segment* seg, ExecCtx* ctx, unsigned long l
   return PG_OK;
 }
 
+// The aggregation INSIDE index_and_kernel: ScanParams.agg_cols are the columns it reads; no bitmap is stored.
+static void arm_index_gather(Lowered* lw, const ScanParams* gather_from) {
+  IndexAndParams& ap = lw->and_params;
+  ap.gather_cols = gather_from->num_agg_cols;
+  for (int a = 0; a < gather_from->num_agg_cols && a < kMaxAndGather; ++a) ap.gather_col[a] = gather_from->agg_cols[a];
+  ap.out = nullptr;                              // nobody reads a bitmap
+  lw->gathered = true;
+}
+// pg_execute_batch: an index-led item whose whole device work is index_and_kernel publishing the query's record -- COUNT(*) over the whole
+// filter, or the gathered aggregation -- can share index_and_batch_kernel's launch when nothing of it lives in the lowering context:
+// no child expanded densely ahead of the kernel (such a child is a bitmap of the context, and a launch of its own before this one).
+static bool index_and_shares_a_launch(const Lowered& lw) {
+  if (!lw.and_pending || lw.finalize_windows == 0) return false;
+  for (int c = 0; c < lw.and_params.num_children; ++c) if (lw.and_params.child[c].dense != nullptr) return false;
+  return true;
+}
+
 // index_and_kernel, launched when its consumer is known.  `gather_from`: the aggregation runs inside the kernel (ScanParams.agg_cols are the
 // columns it reads; no bitmap is stored); else the kernel leaves its bitmap / window masks.  COUNT(*) over the whole filter and the gathered
 // aggregation come back as the kernel's own folded RECORD in the context's pinned host record under sequence number `record_seq`
@@ -1138,16 +1156,15 @@ pg_status launch_index_and(Lowered* lw, ExecCtx* ctx, const ScanParams* gather_f
   // counters: the waves' active-instruction cycles per SIMD add up to the kernel's duration), so the grid's shape moves it by a few
   // percent only -- after the scalar-instruction diet the resident grid is ahead (COUNT 39.5 vs 43.3 us, gathered SUM 58.1 vs 58.5-59.6);
   // 8 or 12 waves per CU lose 20 - 40 %.
-  const int per_cu = g_engine.index_and_waves > 0 ? g_engine.index_and_waves : waves_index_and();
-  const unsigned grid = std::max(1u, g_engine.index_and_waves < 0 ? (num_windows + (unsigned)(-g_engine.index_and_waves) - 1) / (unsigned)(-g_engine.index_and_waves)
-                                                                  : (unsigned)std::min<long long>(num_windows, (long long)lw->and_num_cus * per_cu));
+  // (a workgroup is index_and_block_waves() independent wavefronts that publish one record together)
+  const unsigned wpb = (unsigned)index_and_block_waves();
+  const unsigned waves = g_engine.index_and_waves < 0 ? (num_windows + (unsigned)(-g_engine.index_and_waves) - 1) / (unsigned)(-g_engine.index_and_waves)
+                         : g_engine.index_and_waves > 0 ? (unsigned)std::min<long long>(num_windows, (long long)lw->and_num_cus * g_engine.index_and_waves)
+                                                        : (unsigned)std::min<long long>(num_windows, (long long)lw->and_num_cus * waves_index_and() * wpb);
+  const unsigned grid = std::max(1u, (waves + wpb - 1) / wpb);
   memset(&ap.pub, 0, sizeof(ap.pub));
-  if (gather_from != nullptr) {
-    ap.gather_cols = gather_from->num_agg_cols;
-    for (int a = 0; a < gather_from->num_agg_cols && a < kMaxAndGather; ++a) ap.gather_col[a] = gather_from->agg_cols[a];
-    ap.out = nullptr;                              // nobody reads a bitmap
-    lw->gathered = true;
-  }
+  ap.num_windows = (int32_t)num_windows;
+  if (gather_from != nullptr) arm_index_gather(lw, gather_from);
   if (lw->and_cardinality_only || gather_from != nullptr) {
     const pg_status ps = ensure_partials(ctx, (int)grid);
     if (ps != PG_OK) return ps;
@@ -1778,6 +1795,7 @@ pg_status pg_init(const pg_config* config) {
   g_engine.fsm_fused = env_on("PINOT_GPU_FSM_FUSED");
   g_engine.fsm_episodes = env_on("PINOT_GPU_FSM_EPISODES");
   g_engine.index_gather = env_on("PINOT_GPU_INDEX_GATHER");
+  g_engine.batch_index = env_on("PINOT_GPU_BATCH_INDEX");
   { const char* iaw = getenv("PINOT_GPU_INDEX_AND_WAVES"); g_engine.index_and_waves = iaw ? std::max(-64, std::min(32, atoi(iaw))) : 0; }
   g_engine.group_one_launch = env_on("PINOT_GPU_GROUP_ONE_LAUNCH");
   g_engine.plan_cache = env_on("PINOT_GPU_PLAN_CACHE");
@@ -2534,6 +2552,9 @@ struct LoweredItem {
   int group_threads = 0;
   size_t group_lds = 0, group_table_words = 0;
   std::function<void(const unsigned long long*, pg_result*)> convert_group;      // the item's slice (on the host) -> the result
+  // lean_kind 12 (index_and_batch_kernel): the item is an IndexAndParams whose kernel publishes the query's record (no ctx-owned memory in it)
+  std::shared_ptr<IndexAndParams> and_params;
+  uint32_t and_windows = 0;
   size_t hist_lds = 0;                            // lean_kind 3..5: the item's histogram (the launch's dynamic LDS is the largest item's)
   int hist_cw = 0, hist_col = -1;                 //   counter width; the summed column (a wrapped counter moves it to the guarded tier)
   // the cache's side (empty key: not cacheable)
@@ -2730,6 +2751,36 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // over a filter that the indexes answer alone is the cardinality of the and-ed bitmaps -- index_and_kernel counted it, nothing is scanned.
     bool only_count = true;
     for (int a = 0; a < na; ++a) only_count &= q->aggregations[a].function == PG_AGG_COUNT;
+    if (only_count && defer != nullptr && !defer->single && g_engine.batch_index && g_engine.direct_result && lw.and_cardinality_only && index_and_shares_a_launch(lw)) {
+      // pg_execute_batch: the item is index_and_kernel publishing the cardinality -- it shares index_and_batch_kernel's launch (lean_kind 12)
+      auto item = std::make_shared<LoweredItem>();
+      memset(&item->sp, 0, sizeof(item->sp));
+      item->sp.lean_kind = 12;
+      item->and_params = std::make_shared<IndexAndParams>(lw.and_params);
+      item->and_windows = lw.finalize_windows;
+      item->blocks = (int)std::min<long long>(((long long)lw.finalize_windows + index_and_block_waves() - 1) / index_and_block_waves(), (long long)lw.and_num_cus * waves_index_and());
+      const int total_docs = seg->num_docs;
+      item->convert = [na, total_docs](const BlockPartial& fp, pg_result* o) {
+        const int64_t card = (int64_t)fp.count;
+        o->num_aggregations = na;
+        o->aggregations = (pg_agg_value*)calloc((size_t)na, sizeof(pg_agg_value));
+        for (int a = 0; a < na; ++a) {
+          o->aggregations[a].count = card;
+          o->aggregations[a].min = std::numeric_limits<double>::infinity();
+          o->aggregations[a].max = -std::numeric_limits<double>::infinity();
+        }
+        o->dominant_kernel = PG_KERNEL_INDEX_AND;
+        o->stats.num_docs_scanned = card;
+        o->stats.num_entries_scanned_in_filter = 0;     // bitmaps only: nothing is scanned
+        o->filter_entries_exact = 1;
+        o->stats.num_entries_scanned_post_filter = 0;
+        o->stats.num_total_docs = total_docs;
+      };
+      defer->item = std::move(item);
+      defer->cacheable = !lw.plane_pending;
+      defer->planes.reset(new PlaneHold(std::move(planes)));
+      return kDeferred;
+    }
     if (only_count) {
       const unsigned long long seq = ++ctx->seq;
       st = launch_index_and(&lw, ctx, nullptr, seq);
@@ -2949,6 +3000,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       sp.out_bitmap = ctx->d_bitmaps[0];
     }
     sp.sparse_windows = nullptr; sp.sparse_num_windows = 0;
+    bool defer_index_and = false;
     const unsigned long long seq = ++ctx->seq;      // the sequence number the query's folded record is published under (a gathering index_and_kernel's, or the scan kernel's)
     if (use_sparse) {
       // A handful of survivors per window (the planner's estimate from the postings' sizes: independent predicates): index_and_kernel reads
@@ -2956,7 +3008,9 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       // walks the window masks behind it (no list, no index_and_finalize_kernel between the two kernels).  PINOT_GPU_INDEX_GATHER=0: never.
       const bool gather = g_engine.index_gather && lw.and_pending && lw.index_and_is_whole_filter && out && pl.num_agg_cols <= kMaxAndGather &&
                           lw.and_expected_docs <= 4.0 * (double)lw.finalize_windows;
-      st = launch_index_and(&lw, ctx, gather ? &sp : nullptr, seq);
+      defer_index_and = gather && defer != nullptr && !defer->single && g_engine.batch_index && g_engine.direct_result && !want_bitmap && index_and_shares_a_launch(lw);
+      if (defer_index_and) arm_index_gather(&lw, &sp);      // (launched by the batch: index_and_batch_kernel, lean_kind 12)
+      else st = launch_index_and(&lw, ctx, gather ? &sp : nullptr, seq);
       if (st != PG_OK) return st;
       sp.tile_list = lw.tile_list; sp.tile_count = lw.tile_count;      // (not read by the kernel; "listed" is what the planner and the statistics go by)
       sp.sparse_windows = lw.and_info; sp.sparse_num_windows = (int32_t)lw.finalize_windows;
@@ -3083,6 +3137,21 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     sp.lane_skip = g_engine.lane_skip ? 1 : 0;
     sp.sparse_lanes = g_engine.sparse_lanes;
     sp.fold_one_counter = g_engine.fold_one_counter;
+    if (defer_index_and) {
+      auto item = std::make_shared<LoweredItem>();
+      memset(&item->sp, 0, sizeof(item->sp));
+      item->sp.lean_kind = 12;
+      item->and_params = std::make_shared<IndexAndParams>(lw.and_params);
+      item->and_windows = lw.finalize_windows;
+      item->blocks = (int)std::min<long long>(((long long)lw.finalize_windows + index_and_block_waves() - 1) / index_and_block_waves(), (long long)lw.and_num_cus * waves_index_and());
+      item->one_slot = pl.num_agg_cols <= 1;
+      item->convert = convert;
+      item->plane_columns = planes.columns;
+      defer->item = std::move(item);
+      defer->cacheable = !lw.plane_pending;
+      defer->planes.reset(new PlaneHold(std::move(planes)));
+      return kDeferred;
+    }
     if (defer != nullptr) {
       // (the shared launch is for the many small segments of a server: a segment that fills the chip on its own -- more tiles than a few
       //  rounds of resident waves -- runs the kernel the planner picked for it, concurrently with the others, on a worker thread's stream:
@@ -4833,6 +4902,64 @@ pg_status finish_group_launch(DeferredLaunch* L, std::vector<Deferred>& defs, pg
   return PG_OK;
 }
 
+// The index-led items of one device (lean_kind 12): one launch of index_and_batch_kernel -- the items' workgroups
+// in proportion to their windows, about what is resident in total -- every item with its own records, arrival counters and pinned host record.
+static_assert(sizeof(IndexAndParams) <= kBatchItemSlot, "an index-AND item takes a slot of the batch's parameter blob");
+pg_status enqueue_index_and_launch(DeferredLaunch* L, BatchCtx* b, std::vector<Deferred>& defs, pg_segment* const* segments) {
+  const std::vector<int>& items = L->items;
+  const int n = L->n;
+  long long total_windows = 0;
+  for (int i : items) { total_windows += defs[(size_t)i].item->and_windows; L->docs += (long long)segments[i]->num_docs; }
+  const long long budget = (long long)segments[items[0]]->num_cus * waves_index_and();      // workgroups (of index_and_block_waves() wavefronts) resident at once
+  std::vector<int>& blocks = L->blocks;
+  blocks.assign((size_t)n, 0);
+  size_t partials = 0;
+  long long total_blocks = 0;
+  for (int k = 0; k < n; ++k) {
+    const LoweredItem& d = *defs[(size_t)items[(size_t)k]].item;
+    const long long share = total_windows > 0 ? ((long long)d.and_windows * budget + total_windows - 1) / total_windows : 1;
+    blocks[(size_t)k] = (int)std::max<long long>(1, std::min<long long>((long long)d.blocks, share));
+    partials += (size_t)blocks[(size_t)k] + (size_t)kFoldExtraRecords;
+    total_blocks += blocks[(size_t)k];
+  }
+  L->total_blocks = total_blocks;
+  pg_status st = ensure_batch_ctx(b, n, partials);
+  if (st != PG_OK) return st;
+  IndexAndParams* h_items = reinterpret_cast<IndexAndParams*>(b->h_blob + b->items_offset);
+  const IndexAndParams* d_items = reinterpret_cast<const IndexAndParams*>(b->d_blob + b->items_offset);
+  size_t off = 0;
+  uint32_t first = 0;
+  const unsigned long long seq = L->seq = ++b->seq;
+  for (int k = 0; k < n; ++k) {
+    const LoweredItem& d = *defs[(size_t)items[(size_t)k]].item;
+    IndexAndParams& ap = h_items[k];               // (the pinned copy the device reads: filled in place)
+    ap = *d.and_params;
+    ap.num_windows = (int32_t)d.and_windows;
+    ap.out = nullptr; ap.window_info = nullptr;     // record mode: neither a bitmap nor window masks
+    memset(&ap.pub, 0, sizeof(ap.pub));
+    ap.pub.done_counter = b->d_done + (size_t)k * (kFoldShards + 1) * kFoldStride;
+    ap.pub.partials = b->d_partials + off;
+    off += (size_t)blocks[(size_t)k] + (size_t)kFoldExtraRecords;
+    ap.pub.host_out = b->h_records_dev + k;
+    ap.pub.host_seq = seq;
+    ap.pub.fold_slots = ap.gather_cols;
+    ap.pub.fold_one_counter = g_engine.fold_one_counter;
+    b->h_first[k] = first;
+    first += (uint32_t)blocks[(size_t)k];
+  }
+  b->h_first[n] = first;
+  L->timed = (g_engine.flags & PG_CFG_TIME_KERNELS) != 0;
+  L->t0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipMemcpyAsync(b->d_blob, b->h_blob, b->items_offset + sizeof(IndexAndParams) * (size_t)n, hipMemcpyHostToDevice, b->stream));
+  if (L->timed) HIP_TRY(hipEventRecord(b->ev[0], b->stream));
+  launch_index_and_batch((int)total_blocks, b->stream, d_items, b->d_first, n);
+  HIP_TRY(hipGetLastError());
+  if (L->timed) HIP_TRY(hipEventRecord(b->ev[1], b->stream));
+  L->t1 = std::chrono::steady_clock::now();
+  L->launched = true;
+  return PG_OK;
+}
+
 pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_segment* const* segments) {
   const int device = L->device;
   const std::vector<int>& items = L->items;
@@ -4846,6 +4973,7 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
   L->b = b;
   const int n = L->n = (int)items.size();
   if (L->lean_kind == 6) return enqueue_group_launch(L, b, defs, segments);
+  if (L->lean_kind == 12) return enqueue_index_and_launch(L, b, defs, segments);
   // Workgroups per item in proportion to its tiles, about sixteen per CU in total (four waves each: ~4x what is resident, so that
   // the items' tails overlap other items' scans); never more than the item would get on its own.
   long long total_tiles = 0;

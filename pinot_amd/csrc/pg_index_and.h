@@ -93,6 +93,17 @@ __device__ __forceinline__ bool and_resolve(const AndLanePosting& lp, uint32_t k
   return false;
 }
 
+// A workgroup is kAndBlockWaves wavefronts that share NOTHING but the record they publish together at the very end (a quarter of the records
+// for the folding workgroup to read: 4 096 one-wave workgroups made the fold a 10 us tail -- two levels, eight dependent rounds of loads per
+// lane).  Inside the window loop a wave only ever reads LDS it wrote itself: LDS operations of one wave execute in order, so what separates
+// its scatter from its read-back is a compiler fence and the LDS counter, never a workgroup barrier (the waves run different numbers of
+// windows and children: an s_barrier there would deadlock).
+constexpr int kAndBlockWaves = 4;
+__device__ __forceinline__ void and_wave_sync() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // acc &= bits ^ flip; returns what is left of the four words, or-ed together
 __device__ __forceinline__ uint32_t and_take(uint4& acc, const uint4& bits, uint32_t flip) {
   acc.x &= bits.x ^ flip; acc.y &= bits.y ^ flip; acc.z &= bits.z ^ flip; acc.w &= bits.w ^ flip;
@@ -218,11 +229,18 @@ __device__ __forceinline__ void and_or_bitset(__amdgpu_buffer_rsrc_t rsrc, uint3
   }
 }
 
-static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kernel(const IndexAndParams ap, const uint32_t num_windows) {
-  __shared__ uint4 window[512];                         // 1024 64-bit words; all zero whenever no child is being expanded
-  __shared__ uint32_t guess[6 * 64];                    // the directory entries guessed for the wave's NEXT window (and_issue_guess)
+// The kernel's body over a parameter block P -- IndexAndParams out of the kernel arguments, or its constant-address-space form in device
+// memory (an item of index_and_batch_kernel: its wave-uniform fields are scalar loads either way).  Wavefront `first_wave` of the `num_waves`
+// that work on this block takes windows first_wave, first_wave + num_waves, ...; `window` / `guess` / `red` / `fold_flag`: the wave's LDS.
+template <typename P>
+__device__ __forceinline__ void index_and_body(const P& ap, const uint32_t num_windows, const uint32_t block_index, const uint32_t num_blocks, uint4* window, uint32_t* guess,
+                                               BlockPartial* red, uint32_t* fold_flag) {
+  const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (uniform: the wave's LDS bases are scalars)
+  const uint32_t first_wave = block_index * (uint32_t)kAndBlockWaves + wave_in_block, num_waves = num_blocks * (uint32_t)kAndBlockWaves;
+  window += 512u * wave_in_block;                       // this wave's 8 KB and its guesses
+  guess += 6u * 64u * wave_in_block;
   uint32_t* w32 = reinterpret_cast<uint32_t*>(window);
-  const int lane0 = (int)threadIdx.x;
+  const int lane0 = (int)(threadIdx.x & 63u);
 
   // ---- lane t looks posting t up, in every window of this wave ----
   AndLanePosting lp;
@@ -233,18 +251,18 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
     lp.count = ap.count[lane0];
     lp.per_window = (float)lp.count / (float)num_windows;
   }
-  uint32_t key = blockIdx.x;
+  uint32_t key = first_wave;
   if (key < num_windows) and_issue_guess(lp, key, guess);
 #pragma unroll
   for (int i = 0; i < 8; ++i) window[lane0 + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
-  __syncthreads();
+  and_wave_sync();
 
   // record mode (ap.pub): what this lane found in all of the wave's windows -- reduced over the wave ONCE, behind the loop
   uint32_t lane_card = 0u;
   unsigned long long gsum[kMaxAndGather] = {0ull, 0ull};       // gather mode: the survivors' values of this lane
   uint32_t gmin[kMaxAndGather] = {0xFFFFFFFFu, 0xFFFFFFFFu}, gmax[kMaxAndGather] = {0u, 0u};
 
-  for (; key < num_windows; key += gridDim.x) {
+  for (; key < num_windows; key += num_waves) {
     // (the lane number is made opaque once per window: left alone, LICM hoists every lane-dependent term of the window's code -- the
     //  pieces' offsets, the tail's doc numbers, the gathers' multiplies -- out of this loop, ~70 registers of them into scratch.  For
     //  the same reason everything a lane addresses is a uniform base plus ONE 32-bit offset: 64-bit per-lane indices of the eight
@@ -267,7 +285,7 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ... and have been read, before the next ones may land on them
-    if (key + gridDim.x < num_windows) and_issue_guess(lp, key + gridDim.x, guess);
+    if (key + num_waves < num_windows) and_issue_guess(lp, key + num_waves, guess);
 
     // the accumulator starts as the AND's identity; a child is taken in as (bits ^ flip) & acc, flip = all ones for NOT_EQ / NOT_IN members
     uint4 acc[8];
@@ -275,7 +293,7 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
     for (int i = 0; i < 8; ++i) acc[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     bool alive = true;                                    // uniform
     for (int c = 0; c < ap.num_children && alive; ++c) {
-      const AndChild& ch = ap.child[c];
+      const auto& ch = ap.child[c];
       const uint32_t flip = ch.exclusive ? ~0u : 0u;
       uint32_t any = 0u;
       if (ch.dense != nullptr) {
@@ -341,14 +359,14 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
               }
             }
           }
-          __syncthreads();
+          and_wave_sync();
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const uint4 x = window[lane + 64u * (uint32_t)i];
             window[lane + 64u * (uint32_t)i] = make_uint4(0u, 0u, 0u, 0u);
             any |= and_take(acc[i], x, flip);
           }
-          __syncthreads();
+          and_wave_sync();
         }
       }
       alive = __builtin_amdgcn_ballot_w64(any != 0u) != 0ull;
@@ -403,7 +421,7 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
 #pragma unroll
             for (int a = 0; a < kMaxAndGather; ++a) {
               if (a < ap.gather_cols) {
-                const DevAggCol& gc = ap.gather_col[a];
+                const auto& gc = ap.gather_col[a];
                 const uint32_t b = (uint32_t)gc.bits, bit = (doc & 31u) * b;
                 const uint8_t* tile0 = gc.fwd + (long long)key * (32ll * 256ll) * (long long)b;      // uniform
                 const uint32_t at = (doc >> 11) * (256u * b) + (((doc >> 5) & 63u) * b + (bit >> 5)) * 4u;
@@ -445,8 +463,6 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
 
   if (ap.pub.partials != nullptr) {
     // ---- the wavefront's record, published like a scan kernel's: the last wavefront to arrive folds them into the pinned host record ----
-    __shared__ BlockPartial red[1];
-    __shared__ uint32_t fold_flag;
     BlockPartial mine;
     partial_identity(mine);
     mine.count = (unsigned long long)wave_sum_i64((long long)lane_card);
@@ -458,10 +474,44 @@ static __global__ __launch_bounds__(64, PG_INDEX_AND_WAVES) void index_and_kerne
       mine.kmin[a] = wave_min_i32((int32_t)(gmin[a] == 0xFFFFFFFFu ? 0x7FFFFFFF : gmin[a]));
       mine.kmax[a] = mine.count != 0ull ? wave_max_i32((int32_t)gmax[a]) : (int32_t)0x80000000;
     }
-    if (lane0 == 0) red[0] = mine;
-    __syncthreads();
-    publish_block_partial(ap.pub, red, 1, &fold_flag, blockIdx.x, gridDim.x);
+    if (lane0 == 0) red[wave_in_block] = mine;
+    __syncthreads();                                     // (every wave of the workgroup gets here exactly once)
+    publish_block_partial(ap.pub, red, kAndBlockWaves, fold_flag, block_index, num_blocks);
   }
+}
+
+static __global__ __launch_bounds__(64 * kAndBlockWaves, PG_INDEX_AND_WAVES) void index_and_kernel(const IndexAndParams ap, const uint32_t num_windows) {
+  __shared__ uint4 window[512 * kAndBlockWaves];        // per wave: 1024 64-bit words; all zero whenever no child is being expanded
+  __shared__ uint32_t guess[6 * 64 * kAndBlockWaves];   // per wave: the directory entries guessed for its NEXT window (and_issue_guess)
+  __shared__ BlockPartial red[kAndBlockWaves];
+  __shared__ uint32_t fold_flag;
+  index_and_body(ap, num_windows, blockIdx.x, gridDim.x, window, guess, red, &fold_flag);
+}
+
+// Many index-led queries, one launch (pg_execute_batch): workgroups [block_first[i], block_first[i + 1]) -- kAndBlockWaves wavefronts each -- work on
+// items[i], every item with its own postings, gathered columns and record (IndexAndParams.pub: every item folds and publishes on its own
+// while the others still intersect).  What BaseCombineOperator (core/operator/combine/BaseCombineOperator.java:85-142) gets from a task per
+// segment when the filter is answered by the inverted indexes (InvertedIndexFilterOperator.java:60-145) over a server's many small segments.
+struct IndexAndBatchParams {
+  const IndexAndParams* items;       // device memory; items[i].num_windows windows each
+  const uint32_t* block_first;       // [num_items + 1] device memory
+  int32_t num_items;
+  int32_t reserved;
+};
+static __global__ __launch_bounds__(64 * kAndBlockWaves, PG_INDEX_AND_WAVES) void index_and_batch_kernel(const IndexAndBatchParams bp) {
+  __shared__ uint4 window[512 * kAndBlockWaves];
+  __shared__ uint32_t guess[6 * 64 * kAndBlockWaves];
+  __shared__ BlockPartial red[kAndBlockWaves];
+  __shared__ uint32_t fold_flag;
+  int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (bp.block_first[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const uint32_t first = bp.block_first[lo];
+  typedef const __attribute__((address_space(4))) IndexAndParams ConstantIndexAndParams;      // (scalar loads of the item's fields: see scan_private_batch_kernel)
+  const ConstantIndexAndParams& item = *(ConstantIndexAndParams*)(bp.items + lo);
+  index_and_body(item, (uint32_t)item.num_windows, blockIdx.x - first, bp.block_first[lo + 1] - first, window, guess, red, &fold_flag);
 }
 
 }  // namespace pg

@@ -1897,6 +1897,9 @@ __device__ __forceinline__ void agg_sparse_private(WP __restrict__ lane_words, W
 }
 
 #ifndef PG_PRIVATE_WAVES
+#ifndef PG_PRIVATE_FSM_WAVES
+#define PG_PRIVATE_FSM_WAVES 4  // scan_private_fsm_kernel (the transducer walked inside the scan): its own bound
+#endif
 #define PG_PRIVATE_WAVES 4      // wavefronts per SIMD the register allocation must allow; 5 and 6 spill in the hot path (measured)
 #endif
 // The kernel's body: workgroup `block_index` of the `num_blocks` that work on `p` (the whole grid in scan_private_kernel; one query's
@@ -2046,7 +2049,7 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
 
 // The same kernel with the transducer walk inside (kFsm): a leap-frogging root AND of at most four leaves-as-inputs and four states.
 template <int kAggSlots>
-__global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_fsm_kernel(const ScanParams p) {
+__global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_FSM_WAVES) void scan_private_fsm_kernel(const ScanParams p) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
   __shared__ PrivateAccLds<kAggSlots> acc;

@@ -169,6 +169,9 @@ __device__ __forceinline__ void agg_dict64_private(const AC& ac, long long tile,
 #ifndef PG_TYPED_WAVES
 #define PG_TYPED_WAVES 4
 #endif
+#ifndef PG_TYPED_WAVES_MANY
+#define PG_TYPED_WAVES_MANY 4
+#endif
 // `block_index` of `num_blocks`: the workgroup's place among those working on this parameter block (the whole grid, or an item's share of
 // scan_typed_batch_kernel's launch).  P: ScanParams, or its constant-address-space form in device memory.
 template <int kAggSlots, typename P>
@@ -242,7 +245,7 @@ __device__ __forceinline__ void scan_private_typed_body(const P& p, uint32_t blo
 }
 
 template <int kAggSlots>
-__global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : 4)) void scan_private_typed_kernel(const ScanParams p) {
+__global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : (kAggSlots == 2 ? 4 : PG_TYPED_WAVES_MANY))) void scan_private_typed_kernel(const ScanParams p) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
   scan_private_typed_body<kAggSlots>(p, blockIdx.x, gridDim.x, red, &fold_flag);
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : 4
 // dictionaries on a server's many small segments): workgroups [block_first[i], block_first[i + 1]) work on items[i], every item folds and
 // publishes its own record (see scan_private_batch_kernel).
 template <int kAggSlots>
-__global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : 4)) void scan_typed_batch_kernel(const BatchParams bp) {
+__global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : (kAggSlots == 2 ? 4 : PG_TYPED_WAVES_MANY))) void scan_typed_batch_kernel(const BatchParams bp) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
   int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one

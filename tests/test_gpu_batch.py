@@ -559,3 +559,50 @@ def test_narrow_and_typed_items_share_launches(engine, shapes):
                 assert res.stats == single.stats and res.dominant_kernel == single.dominant_kernel
     finally:
         [g.close() for g in opened]
+
+
+def _index_segments():
+    """Segments with three inverted-index columns (C = 8 / 16 / 40: array, bitset and run containers turn up) beside two value columns."""
+    segs = []
+    for s, n in enumerate([70_001, 1, 200_003, 65_536, 1_000_003, 131_073, 333_337, 2049]):
+        rng = np.random.default_rng(4000 + s)
+        cols = [H.random_dict_column(rng, "p", n, 8, with_inverted=True)[0], H.random_dict_column(rng, "q", n, 16, with_inverted=True)[0],
+                H.random_dict_column(rng, "r", n, 40, with_inverted=True)[0],
+                S.Column.synthetic_uniform("v", n, (np.arange(3000, dtype=np.int64) * 7 + 3 + s).astype(np.int32), seed=5 * s + 1),
+                S.Column.synthetic_uniform("f", n, np.arange(900, dtype=np.int32), seed=5 * s + 2)]
+        segs.append(S.SegmentData("ix%d" % s, n, cols))
+    return segs
+
+
+@pytest.mark.parametrize("shapes", [["count"], ["gather"], ["count", "gather", "gather2", "not-eq", "dense-beside", "scan-beside"]])
+def test_index_led_items_share_one_launch(engine, shapes):
+    """COUNT(*) over an index-only filter and the gathered aggregation are index_and_kernel publishing the query's record: in a batch they share
+    ONE launch of index_and_batch_kernel (lean_kind 12), every item with its own postings, records and pinned result -- same answers as
+    pg_execute and as the oracle, twice (the second call through the plan cache); shapes that keep a launch of their own ride along."""
+    inv = lambda c, d, **kw: Q.leaf(Q.Pred.dict_range(c, d, d + 1, inverted=True, **kw))
+
+    def spec(seg, s, shape):
+        if shape == "count":
+            return Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(inv(0, s % 8), inv(1, s % 16)))
+        if shape == "gather":
+            return Q.QuerySpec([(Q.SUM, 3)], filter=Q.and_(inv(0, 3), inv(1, 5), inv(2, 7)))
+        if shape == "gather2":
+            return Q.QuerySpec([(Q.SUM, 3), (Q.MAX, 4), (Q.MIN, 3), (Q.COUNT, -1)], filter=Q.and_(inv(0, 1), inv(1, 2), inv(2, s % 40)))
+        if shape == "not-eq":
+            return Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(inv(0, 2), inv(1, 3, exclusive=True)))
+        if shape == "dense-beside":                                   # denser than a handful per window: scan_sparse_kernel behind the AND, a launch of its own
+            return Q.QuerySpec([(Q.SUM, 3)], filter=Q.and_(inv(0, 3), inv(1, 5)))
+        return Q.QuerySpec([(Q.SUM, 3)], filter=Q.leaf(Q.Pred.dict_range(4, 0, 90)))
+    segs = _index_segments()
+    opened = [engine.open(seg) for seg in segs]
+    try:
+        specs = [spec(seg, s, shapes[s % len(shapes)]) for s, seg in enumerate(segs)]
+        for rep in range(2):
+            for s, (status, res) in enumerate(engine.execute_batch(opened, specs)):
+                assert status == _abi.PG_OK, (shapes[s % len(shapes)], s)
+                H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
+                single = opened[s].execute(specs[s])
+                assert res.stats == single.stats and res.filter_entries_exact == single.filter_entries_exact
+                assert [(a.count, a.sum_i64, a.min, a.max) for a in res.aggregations] == [(a.count, a.sum_i64, a.min, a.max) for a in single.aggregations]
+    finally:
+        [g.close() for g in opened]

@@ -126,7 +126,7 @@ def test_every_kernel_is_dispatched_with_more_tiles_than_waves_and_equals_the_or
 # can set is code a deployment can run.  (No dispatch-set requirement here: with the launch structure changed, other kernels answer.)
 FLIPPED = {
     "launch-structure": "PINOT_GPU_GROUP_ONE_LAUNCH=0,PINOT_GPU_INDEX_GATHER=0,PINOT_GPU_FSM_EPISODES=0,PINOT_GPU_LEAN_BATCH=0,PINOT_GPU_BATCH_HIST=0,PINOT_GPU_BATCH_GROUP=0,"
-                        "PINOT_GPU_BATCH_MORE=0,PINOT_GPU_DIRECT_RESULT=0,PINOT_GPU_INDEX_AND_WAVES=-1,PINOT_GPU_PLAN_CACHE=0,PINOT_GPU_FOLD_ONE_COUNTER=0,PINOT_GPU_LEAP2=0,"
+                        "PINOT_GPU_BATCH_MORE=0,PINOT_GPU_BATCH_INDEX=0,PINOT_GPU_DIRECT_RESULT=0,PINOT_GPU_INDEX_AND_WAVES=-1,PINOT_GPU_PLAN_CACHE=0,PINOT_GPU_FOLD_ONE_COUNTER=0,PINOT_GPU_LEAP2=0,"
                         "PINOT_GPU_LANE_SKIP=0,PINOT_GPU_SCAN_SPARSE=0,PINOT_GPU_SCAN_RAW=0,PINOT_GPU_SCAN_NARROW=0,PINOT_GPU_RAW64_COALESCED=0,PINOT_GPU_GROUP_PACK=0,"
                         "PINOT_GPU_GROUP_REPLICAS=0,PINOT_GPU_PARTITION_STATS_CACHE=0,PINOT_GPU_PLANE_GCD=0,PINOT_GPU_STAGED_H2D=0,PINOT_GPU_SMALL_BLOCKS_PER_CU=0,"
                         "PINOT_GPU_WIDE_BLOCKS=1,PINOT_GPU_GROUP_WAVES=4",

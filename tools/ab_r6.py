@@ -34,7 +34,7 @@ def parse_settings(text):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("shape", choices=["c5", "c3", "not"])
+    ap.add_argument("shape", choices=["c5", "c3", "not", "typed"])
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=40)
@@ -133,6 +133,19 @@ def main():
                    ("C3-irregular", Q.QuerySpec([(Q.SUM, 4), (Q.MAX, 3)], group_by=[1]), None, B(k) + B(a) + B(b))]
         with engine.open(seg) as g:
             sweep("C3", g, seg, queries)
+    elif args.shape == "typed":
+        # three and four aggregated raw / 8-byte columns: scan_private_typed_kernel<4> (and, in a batch of four segments, scan_typed_batch_kernel<4>)
+        rng = np.random.default_rng(3)
+        f = S.Column.synthetic_uniform("f", n, np.arange(1000, dtype=np.int32), seed=2)
+        rl = S.Column.raw_typed("rl", rng.integers(-(2 ** 40), 2 ** 40, n, dtype=np.int64))
+        rd = S.Column.raw_typed("rd", rng.normal(0, 1e6, n).astype(np.float64))
+        ri = S.Column.raw("ri", rng.integers(-1000000, 1000000, n).astype(np.int32))
+        seg = S.SegmentData("typed", n, [f, rl, rd, ri])
+        flt = Q.leaf(Q.Pred.dict_range(0, 0, 500))
+        queries = [("typed-4-slots", Q.QuerySpec([(Q.SUM, 1), (Q.MIN, 2), (Q.SUM, 3), (Q.AVG, 2)], filter=flt), None, B(f) + B(rl) + B(rd) + B(ri)),
+                   ("typed-3-slots-no-filter", Q.QuerySpec([(Q.SUM, 1), (Q.MAX, 2), (Q.MIN, 3)]), None, B(rl) + B(rd) + B(ri))]
+        with engine.open(seg) as g:
+            sweep("typed", g, seg, queries)
     else:
         v = S.Column.synthetic_uniform("v", n, v_dictionary("affine"), seed=1)
         f = S.Column.synthetic_uniform("f", n, np.arange(1000, dtype=np.int32), seed=2)

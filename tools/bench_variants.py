@@ -206,7 +206,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
     # ---- the small-segment regime: 64 segments of 10 M rows (BASELINE.json configs[0]'s size), one query over all of them ----
     # (a) pg_execute_batch: one launch, every segment folds its own result; (b) the way BaseCombineOperator would drive pg_execute: 16
     # host threads, each with the next segment, every pg_execute on a stream of its own; (c) one pg_execute after the other.
-    c1x64_ids = ("C1x64-count-range", "C1x64-dict-sum", "C1x64-dict-sum-irregular", "C1x64-group-by")
+    c1x64_ids = ("C1x64-count-range", "C1x64-dict-sum", "C1x64-dict-sum-irregular", "C1x64-group-by", "C5x64", "C5x64-count")
     if any(want(x) for x in c1x64_ids):
         import ctypes as C
         import threading
@@ -220,7 +220,12 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
             # (columns 3, 4: the same sum through a dictionary WITHOUT structure -- the normal case of a real Pinot dictionary -- and a 1000-value key)
             wcol = S.Column.synthetic_uniform("w", n1, v_dictionary("irregular", seed=9000 + s), seed=8500 + s)
             kcol = S.Column.synthetic_uniform("k", n1, np.arange(1000, dtype=np.int32), seed=9500 + s)
-            segs.append(S.SegmentData("c1_%d" % s, n1, [raw, fcol, vcol, wcol, kcol]))
+            cols = [raw, fcol, vcol, wcol, kcol]
+            if want("C5x64") or want("C5x64-count"):
+                # (columns 5, 6, 7: BASELINE.json configs[4]'s three inverted-index columns, C = 16 / 64 / 256, on every small segment)
+                for name, card, seed in (("p", 16, 11000 + s), ("q", 64, 12000 + s), ("r", 256, 13000 + s)):
+                    cols.append(S.Column.from_dict_ids(name, np.arange(card, dtype=np.int32), S.synthetic_dict_ids(seed, 0, n1, card), with_inverted=True))
+            segs.append(S.SegmentData("c1_%d" % s, n1, cols))
         gen_s = time.time() - t0
         opened = [engine.open(sd) for sd in segs]
         try:
@@ -230,6 +235,13 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                        lambda sd: Q.QuerySpec([(Q.SUM, 3)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), lambda sd: B(sd.columns[1]) + B(sd.columns[3])),
                       ("C1x64-group-by", "SELECT SUM(v), MAX(f) GROUP BY k (1000 groups)", lambda sd: Q.QuerySpec([(Q.SUM, 2), (Q.MAX, 1)], group_by=[4]),
                        lambda sd: B(sd.columns[1]) + B(sd.columns[2]) + B(sd.columns[4]))]
+            inv = lambda c, d: Q.leaf(Q.Pred.dict_range(c, d, d + 1, inverted=True))
+            posting = lambda sd, c: int(sd.columns[c].inverted.nbytes / sd.columns[c].cardinality)
+            shapes += [("C5x64", "SELECT SUM(v) WHERE p=3 AND q=5 AND r=7 via inverted indexes (C = 16 / 64 / 256)",
+                        lambda sd: Q.QuerySpec([(Q.SUM, 2)], filter=Q.and_(inv(5, 3), inv(6, 5), inv(7, 7))),
+                        lambda sd: posting(sd, 5) + posting(sd, 6) + posting(sd, 7) + int(sd.num_docs / (16 * 64 * 256)) * 64),
+                       ("C5x64-count", "SELECT COUNT(*) WHERE p=3 AND q=5 via inverted indexes", lambda sd: Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(inv(5, 3), inv(6, 5))),
+                        lambda sd: posting(sd, 5) + posting(sd, 6))]
             for vid, sql, mk, nb in shapes:
                 if not want(vid):
                     continue
@@ -302,12 +314,15 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                 # (the body that ran, as the library reports it per item; the shared launch is scan_lean_batch_kernel for the simple / raw shapes, scan_private_batch_kernel otherwise)
                 body = engine.execute_batch(opened[:1], specs[:1])[0][1].dominant_kernel
                 launch = {"scan_simple_kernel": "scan_lean_batch_kernel", "scan_raw_kernel": "scan_lean_batch_kernel", "scan_hist_kernel": "scan_hist_batch_kernel",
-                          "group_private_kernel": "group_lds_batch_kernel"}.get(body, "scan_private_batch_kernel")
+                          "group_private_kernel": "group_lds_batch_kernel", "index_and_kernel": "index_and_batch_kernel"}.get(body, "scan_private_batch_kernel")
                 if check:
                     got = engine.execute_batch(opened, specs)
                     exact = True
                     for sd, sp, (st, res) in zip(segs, specs, got):
-                        wanted = oracle.execute_sliced(sd, sp)
+                        wanted = oracle.execute(sd, sp) if vid.startswith("C5x64") else oracle.execute_sliced(sd, sp)
+                        if vid.startswith("C5x64"):
+                            exact = exact and st == _abi.PG_OK and [(a.count, a.sum_i64) for a in res.aggregations] == [(a.count, a.sum_i64) for a in wanted.aggregations] and res.stats[0] == wanted.stats[0]
+                            continue
                         exact = exact and st == _abi.PG_OK and bool(oracle.matches_sliced(res, wanted, [f for f, _ in sp.aggregations]) and res.stats[0] == wanted["docs_scanned"])
                 out.append({"id": vid, "config": "BASELINE.json configs[0] x 64 segments: the small-segment regime of a real server", "query": sql + " over 64 segments of 10 M rows",
                             "rows": n1 * nseg, "algorithmic_bytes": int(nbytes), "modes": modes, "kernel": launch, "kernel_body": body, "kernel_ms": modes["batch"].get("kernel_ms"),

@@ -41,6 +41,35 @@ import sys, json
 for l in sys.stdin:
     r = json.loads(l); print('%-14s %-62s kernel %.4f all %.4f host %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r['frac_all_kernels'] or 0, r['exact']))"
   done; unset PINOT_GPU_LIB ;;
+spill_ab)
+  # kernels that spill at four waves per SIMD against builds bounded at three (no spills): the four-slot typed scans, the scan with the transducer inside
+  for spec in "default" "typed3"; do
+    if [ "$spec" = default ]; then unset PINOT_GPU_LIB; else export PINOT_GPU_LIB=$GRAFT_REPO_ROOT/tools/libpinot_gpu_$spec.so; fi
+    echo "-- typed, build $spec"
+    timeout 900 python tools/ab_r6.py typed --rows 250000000 --steps 20 --no-check --out $OUT/spill_typed_$spec.jsonl --settings "" 2> $OUT/spill_typed_$spec.err | python -c "
+import sys, json
+for l in sys.stdin:
+    r = json.loads(l); print('%-26s kernel %-30s %.4f all %.4f frac %.3f' % (r['query'], r['kernel'], r['kernel_ms'], r['all_kernels_ms'], r['frac_all_kernels'] or 0))"
+  done
+  for spec in "default" "fsm3"; do
+    if [ "$spec" = default ]; then unset PINOT_GPU_LIB; else export PINOT_GPU_LIB=$GRAFT_REPO_ROOT/tools/libpinot_gpu_$spec.so; fi
+    echo "-- AND3-scan, build $spec"
+    timeout 900 python tools/ab_r6.py not --steps 20 --match AND3 --no-check --out $OUT/spill_and3_$spec.jsonl --settings "" 2> $OUT/spill_and3_$spec.err | python -c "
+import sys, json
+for l in sys.stdin:
+    r = json.loads(l); print('%-26s kernel %-30s %.4f all %.4f frac %.3f entries_exact %s' % (r['query'], r['kernel'], r['kernel_ms'], r['all_kernels_ms'], r['frac_all_kernels'] or 0, r['entries_exact']))"
+  done; unset PINOT_GPU_LIB ;;
+batch_tests)
+  timeout 1500 python -m pytest tests/test_gpu_batch.py tests/test_gpu_index_and.py tests/test_gpu_kernel_coverage.py -m gpu -x -q 2>&1 | tail -12 | tee $OUT/batch_tests.txt ;;
+c5x64)
+  timeout 1500 python bench.py --steps 3 --warmup 1 --segments 1 --rows 100000 --variants "^C5x64" > $OUT/c5x64_line.json 2> $OUT/c5x64.err; tail -3 $OUT/c5x64.err
+  python - <<'PY'
+import json
+for v in json.load(open("gpurun_out/bench_variants.json")):
+    if v["id"].startswith("C5x64"):
+        print(v["id"], "kernel", v.get("kernel"), "exact", v["bit_exact_vs_oracle"], {m: (round(x["wall_ms"], 4), round(x.get("kernel_ms", 0) or 0, 4)) for m, x in v["modes"].items()})
+PY
+  cp gpurun_out/bench_variants.json $OUT/c5x64_variants.json ;;
 c3_ab)
   timeout 1500 python tools/ab_r6.py c3 --steps 20 --out $OUT/c3_ab.jsonl --settings "${C3_SETTINGS:-}" 2> $OUT/c3_ab.err | python -c "
 import sys, json

@@ -363,6 +363,10 @@ def main():
             "batch-typed-2": Q.QuerySpec([(Q.SUM, RD), (Q.MAX, DL)], filter=f_lt(500)),
             "batch-typed-4": Q.QuerySpec([(Q.SUM, RL), (Q.MIN, RD), (Q.SUM, DL), (Q.AVG, RD)], filter=f_lt(500)),
             "batch-group": Q.QuerySpec([(Q.SUM, V), (Q.MAX, F)], filter=f_lt(700), group_by=[K]),
+            # index-led items whose whole device work is index_and_kernel publishing the record: one launch of index_and_batch_kernel
+            "batch-index-count": Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(L(Q.Pred.dict_range(X, 3, 4, inverted=True)), L(Q.Pred.dict_range(Y, 5, 6, inverted=True)))),
+            "batch-index-gather": Q.QuerySpec([(Q.SUM, V), (Q.MAX, F)], filter=Q.and_(L(Q.Pred.dict_range(X, 3, 4, inverted=True)), L(Q.Pred.dict_range(Y, 5, 6, inverted=True)),
+                                                                                     L(Q.Pred.dict_range(Z, 7, 8, inverted=True)))),
         }
         opened = [engine.open(s) for s in segs]
         try:
