@@ -374,6 +374,7 @@ constexpr int kMaxAndPostings = 64;      // postings of all children together: o
 constexpr int kMaxChildPostings = 16;    // postings OR-ed into one child before it is expanded densely instead (EQ: 1; IN lists, short ranges)
 
 constexpr int kMaxAndGather = 2;              // IndexAndParams.gather_col
+constexpr int kAndCardinalityShards = 64;      // IndexAndParams.shards: this many counter lines, 16 words (128 bytes) apart
 struct WindowInfo { uint32_t tiles; uint32_t docs; };   // mask of the window's 32 2048-doc tiles that hold a match; matching docs
 
 struct AndChild {
@@ -393,13 +394,18 @@ struct IndexAndParams {
   long long num_words;                   // 64-bit words of the output bitmap (2048-doc tiles * 32)
   unsigned long long* out;               // doc-order result; nullptr = only the cardinality is wanted
   struct WindowInfo* window_info;        // [windows]
-  // The query's RECORD out of this kernel (round 6): COUNT(*) over an index-only filter (FastFilteredCountOperator.java:66-72) and the
-  // aggregation over a handful of survivors per window (AndDocIdSet.java:127-172 + ProjectionOperator) are index_and_kernel and nothing else.
-  // pub.partials != nullptr: every wavefront sums its windows' matching docs -- and, gather_cols > 0, reads the survivors' values itself:
-  // bit-packed fields of up to kMaxAndGather columns (dictIds for MIN / MAX, plane fields / arithmetic-progression dictIds for SUM: what
-  // scan_sparse_kernel reads) -- into ONE BlockPartial per wavefront, published like a scan kernel's (publish_block_partial: the wavefront
-  // whose arrival completes the count folds all of them into the pinned host record).  Rounds 4-5 added every window's figures to 64
-  // counter lines with device-scope atomics and copied the lines back: a copy, a memset and their latencies behind a 50 us kernel.
+  // The query's figures out of this kernel: COUNT(*) over an index-only filter (FastFilteredCountOperator.java:66-72) and the aggregation over
+  // a handful of survivors per window (AndDocIdSet.java:127-172 + ProjectionOperator) are this kernel and nothing else.  Every wavefront sums
+  // its windows' matching docs and, gather_cols > 0, reads the survivors' values itself: bit-packed fields of up to kMaxAndGather columns
+  // (dictIds for MIN / MAX, plane fields / arithmetic-progression dictIds for SUM: what scan_sparse_kernel reads).  Two ways out:
+  //   shards != nullptr (index_and_kernel, one query): the wavefront adds its totals to counter line (wave & 63) of kAndCardinalityShards
+  //     128-byte lines with fire-and-forget device-scope atomics -- word 0 the cardinality, words 1 + 3 a .. per gathered column
+  //     {sum, 2^32 - 1 - min key, max key}, all-zero identities; the host copies the lines back and zeroes them behind the answer;
+  //   pub.partials != nullptr (index_and_batch_kernel, an item of a batch): ONE BlockPartial per wavefront, published like a scan kernel's
+  //     (publish_block_partial: the wavefront whose arrival completes the item's count folds them into the item's pinned host record) --
+  //     no copy and no memset per item.  For a single query the fold of ~4 000 records at the kernel's tail cost more than the copy
+  //     saves (C5-sparse 58.5 -> 62 us, COUNT 39.5 -> 50 us: profiles/r6/c5_index_and_records_vs_shards.jsonl).
+  unsigned long long* shards;
   struct AndPublish {
     uint32_t* done_counter;              // ExecCtx.d_done (zero between launches)
     BlockPartial* partials;              // [grid + kFoldExtraRecords]; nullptr = no record (the kernel leaves a bitmap and window masks)

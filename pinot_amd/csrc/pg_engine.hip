@@ -240,7 +240,9 @@ struct ExecCtx {
   uint8_t* d_partition = nullptr;               // partitioned group-by: counters, work list and the record buffers
   size_t partition_capacity = 0;
   uint32_t* d_tile_list = nullptr;              // index_and_kernel: surviving 2048-doc tiles (one entry per tile of the segment)
-  unsigned long long* d_and_counters = nullptr; // [0] cardinality (u64), [1] low dword: number of listed tiles
+  unsigned long long* d_and_counters = nullptr; // [0] cardinality (u64), [1] low dword: number of listed tiles; [2 ...] index_and_kernel's counter lines (IndexAndParams.shards)
+  bool and_counter_dirty = false;               // the counter lines were added to and not yet zeroed again
+  unsigned long long* h_and_shards = nullptr;   // pinned: where the lines land
   uint8_t* d_arena = nullptr;                   // DeviceScratch: per-query device scratch (compaction of group-by results)
   size_t arena_capacity = 0, arena_wanted = 0;
   uint8_t* h_groups = nullptr;                  // pinned staging of many-group results
@@ -300,6 +302,7 @@ struct FsmSide {
   bool fused = false;                           // out: the scan kernel walked the transducer itself; its count is in the context's pinned counter
   bool prepared = false;                        // prepare_fsm_side gave it the context's scratch
 };
+constexpr size_t kAndShardBytes = (size_t)pg::kAndCardinalityShards * 128;      // ExecCtx.d_and_counters + 2 / h_and_shards
 constexpr size_t kFsmStageBytes = 64 + 2 * ((size_t)pg::kFsmStates << pg::kFsmInputs);      // ExecCtx.h_fsm_stage: the two counts | delta | marks
 
 namespace {
@@ -324,6 +327,7 @@ void destroy_ctx(ExecCtx* c) {
   if (c->d_partition) (void)hipFree(c->d_partition);
   if (c->d_tile_list) (void)hipFree(c->d_tile_list);
   if (c->d_and_counters) (void)hipFree(c->d_and_counters);
+  if (c->h_and_shards) (void)hipHostFree(c->h_and_shards);
   if (c->d_window_info) (void)hipFree(c->d_window_info);
   if (c->d_arena) (void)hipFree(c->d_arena);
   if (c->h_groups) (void)hipHostFree(c->h_groups);
@@ -952,7 +956,7 @@ struct Lowered {
   // an aggregation over a handful of survivors per window is done INSIDE it (gathered: no bitmap, no second kernel), everything else its
   // bitmap and window masks.  Lowering only prepares the kernel's arguments.
   bool and_pending = false, and_cardinality_only = false, gathered = false;
-  bool record_published = false;               // index_and_kernel folds the query's record into the context's pinned host record itself (launch_index_and)
+  bool cardinality_atomic = false;             // index_and_kernel added its figures to the context's counter lines (launch_index_and; read_index_and_shards)
   int and_num_cus = 256;                       // the segment's CUs (pg_segment.num_cus): index_and_kernel's persistent grid is sized by them
   IndexAndParams and_params;
   double and_expected_docs = 0;                // the planner's estimate of the AND's cardinality (independent postings)
@@ -1142,9 +1146,9 @@ static bool index_and_shares_a_launch(const Lowered& lw) {
 
 // index_and_kernel, launched when its consumer is known.  `gather_from`: the aggregation runs inside the kernel (ScanParams.agg_cols are the
 // columns it reads; no bitmap is stored); else the kernel leaves its bitmap / window masks.  COUNT(*) over the whole filter and the gathered
-// aggregation come back as the kernel's own folded RECORD in the context's pinned host record under sequence number `record_seq`
-// (IndexAndParams.pub, publish_block_partial): nothing follows the kernel on the stream.
-pg_status launch_index_and(Lowered* lw, ExecCtx* ctx, const ScanParams* gather_from, unsigned long long record_seq = 0) {
+// aggregation come back on the context's counter lines (IndexAndParams.shards): the caller copies them to ctx->h_and_shards, reads them
+// with read_index_and_shards and zeroes them again behind the answer.
+pg_status launch_index_and(Lowered* lw, ExecCtx* ctx, const ScanParams* gather_from) {
   if (!lw->and_pending) return PG_OK;
   lw->and_pending = false;
   IndexAndParams& ap = lw->and_params;
@@ -1156,34 +1160,53 @@ pg_status launch_index_and(Lowered* lw, ExecCtx* ctx, const ScanParams* gather_f
   // counters: the waves' active-instruction cycles per SIMD add up to the kernel's duration), so the grid's shape moves it by a few
   // percent only -- after the scalar-instruction diet the resident grid is ahead (COUNT 39.5 vs 43.3 us, gathered SUM 58.1 vs 58.5-59.6);
   // 8 or 12 waves per CU lose 20 - 40 %.
-  // (a workgroup is index_and_block_waves() independent wavefronts that publish one record together)
-  const unsigned wpb = (unsigned)index_and_block_waves();
-  const unsigned waves = g_engine.index_and_waves < 0 ? (num_windows + (unsigned)(-g_engine.index_and_waves) - 1) / (unsigned)(-g_engine.index_and_waves)
-                         : g_engine.index_and_waves > 0 ? (unsigned)std::min<long long>(num_windows, (long long)lw->and_num_cus * g_engine.index_and_waves)
-                                                        : (unsigned)std::min<long long>(num_windows, (long long)lw->and_num_cus * waves_index_and() * wpb);
-  const unsigned grid = std::max(1u, (waves + wpb - 1) / wpb);
+  const int per_cu = g_engine.index_and_waves > 0 ? g_engine.index_and_waves : waves_index_and();
+  const unsigned grid = g_engine.index_and_waves < 0 ? (num_windows + (unsigned)(-g_engine.index_and_waves) - 1) / (unsigned)(-g_engine.index_and_waves)
+                                                      : (unsigned)std::min<long long>(num_windows, (long long)lw->and_num_cus * per_cu);
   memset(&ap.pub, 0, sizeof(ap.pub));
+  ap.shards = nullptr;
   ap.num_windows = (int32_t)num_windows;
   if (gather_from != nullptr) arm_index_gather(lw, gather_from);
   if (lw->and_cardinality_only || gather_from != nullptr) {
-    const pg_status ps = ensure_partials(ctx, (int)grid);
-    if (ps != PG_OK) return ps;
-    ap.pub.done_counter = ctx->d_done;
-    ap.pub.partials = ctx->d_partials;
-    ap.pub.host_out = ctx->h_record_dev;
-    ap.pub.host_seq = record_seq;
-    ap.pub.fold_slots = gather_from != nullptr ? gather_from->num_agg_cols : 0;
-    ap.pub.fold_one_counter = g_engine.fold_one_counter;
-    lw->record_published = true;
+    // the wavefronts add what they found to counter lines the host keeps at zero between queries
+    if (ctx->and_counter_dirty) HIP_TRY(hipMemsetAsync(ctx->d_and_counters + 2, 0, kAndShardBytes, ctx->stream));      // (a query that failed before it read them)
+    ap.shards = ctx->d_and_counters + 2;
+    ctx->and_counter_dirty = true;
+    lw->cardinality_atomic = true;
   }
-  // (an empty segment has no window: one wavefront still runs, finds nothing and publishes the empty record)
-  if (num_windows || lw->record_published) {
+  if (num_windows) {
     launch_index_and_kernel((int)grid, ctx->stream, ap, num_windows);
     HIP_TRY(hipGetLastError());
     // (index_and_finalize_kernel: only when the tile list is read -- complete_index_list)
-    lw->finalize_pending = num_windows != 0 && !lw->and_cardinality_only && gather_from == nullptr;
+    lw->finalize_pending = !lw->and_cardinality_only && gather_from == nullptr;
+  } else if (!lw->and_cardinality_only && gather_from == nullptr) {
+    HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16, ctx->stream));
   }
-  if (!num_windows && !lw->and_cardinality_only && gather_from == nullptr) HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16, ctx->stream));
+  return PG_OK;
+}
+// The counter lines of a COUNT(*) / gathering index_and_kernel, copied to ctx->h_and_shards and complete (the stream was waited for): zeroes
+// the device's lines again behind the answer (nobody waits for that) and folds the 64 lines into one record.
+pg_status read_index_and_shards(ExecCtx* ctx, int gather_cols, BlockPartial* g) {
+  HIP_TRY(hipMemsetAsync(ctx->d_and_counters + 2, 0, kAndShardBytes, ctx->stream));
+  ctx->and_counter_dirty = false;
+  memset(g, 0, sizeof(*g));
+  for (int a = 0; a < kMaxAggCols; ++a) { g->kmin[a] = 0x7FFFFFFF; g->kmax[a] = (int32_t)0x80000000; }
+  const unsigned long long* lines = ctx->h_and_shards;
+  unsigned long long kmin_inv[kMaxAndGather] = {0ull, 0ull}, kmax[kMaxAndGather] = {0ull, 0ull};
+  for (int sh = 0; sh < kAndCardinalityShards; ++sh) {
+    const unsigned long long* line = lines + (size_t)sh * 16;
+    g->count += line[0];
+    for (int a = 0; a < gather_cols && a < kMaxAndGather; ++a) {
+      g->sum[a] += (long long)line[1 + 3 * a];
+      kmin_inv[a] = std::max(kmin_inv[a], line[2 + 3 * a]);
+      kmax[a] = std::max(kmax[a], line[3 + 3 * a]);
+    }
+  }
+  for (int a = 0; a < gather_cols && a < kMaxAndGather; ++a) {
+    if (g->count == 0ull) continue;                 // (identities stay)
+    g->kmin[a] = (int32_t)(0xFFFFFFFFull - kmin_inv[a]);
+    g->kmax[a] = (int32_t)kmax[a];
+  }
   return PG_OK;
 }
 
@@ -1361,9 +1384,11 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
         HIP_TRY(hipMalloc((void**)&ctx->d_window_info, ctx->window_info_capacity * sizeof(WindowInfo)));
       }
       if (!ctx->d_and_counters) {
-        // [0] cardinality and [1] tile count: index_and_finalize_kernel's outputs
-        HIP_TRY(hipMalloc((void**)&ctx->d_and_counters, 16));
-        HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16, ctx->stream));
+        // [0] cardinality and [1] tile count: index_and_finalize_kernel's outputs; behind them index_and_kernel's counter lines
+        HIP_TRY(hipMalloc((void**)&ctx->d_and_counters, 16 + kAndShardBytes));
+        HIP_TRY(hipMemsetAsync(ctx->d_and_counters, 0, 16 + kAndShardBytes, ctx->stream));
+        HIP_TRY(hipHostMalloc((void**)&ctx->h_and_shards, kAndShardBytes, hipHostMallocDefault));
+        ctx->and_counter_dirty = false;
       }
       IndexAndParams ap;
       memset(&ap, 0, sizeof(ap));
@@ -2758,7 +2783,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       item->sp.lean_kind = 12;
       item->and_params = std::make_shared<IndexAndParams>(lw.and_params);
       item->and_windows = lw.finalize_windows;
-      item->blocks = (int)std::min<long long>(((long long)lw.finalize_windows + index_and_block_waves() - 1) / index_and_block_waves(), (long long)lw.and_num_cus * waves_index_and());
+      item->blocks = (int)std::min<long long>(((long long)lw.finalize_windows + index_and_batch_block_waves() - 1) / index_and_batch_block_waves(), (long long)lw.and_num_cus * index_and_batch_blocks_per_cu());
       const int total_docs = seg->num_docs;
       item->convert = [na, total_docs](const BlockPartial& fp, pg_result* o) {
         const int64_t card = (int64_t)fp.count;
@@ -2782,23 +2807,18 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       return kDeferred;
     }
     if (only_count) {
-      const unsigned long long seq = ++ctx->seq;
-      st = launch_index_and(&lw, ctx, nullptr, seq);
+      st = launch_index_and(&lw, ctx, nullptr);
       if (st != PG_OK) return st;
       unsigned long long* h_card = &ctx->h_partial->count;
-      if (!lw.record_published) HIP_TRY(hipMemcpyAsync(h_card, lw.d_cardinality, 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (lw.cardinality_atomic) HIP_TRY(hipMemcpyAsync(ctx->h_and_shards, ctx->d_and_counters + 2, kAndShardBytes, hipMemcpyDeviceToHost, ctx->stream));
+      else HIP_TRY(hipMemcpyAsync(h_card, lw.d_cardinality, 8, hipMemcpyDeviceToHost, ctx->stream));
       if (timed) { HIP_TRY(mark_pre_work(ctx)); HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
-      if (lw.record_published && g_engine.poll_result && g_engine.direct_result && !timed) {
-        // nothing follows the kernel on the stream: its folded record's sequence number is the completion signal
-        volatile unsigned long long* flag = &ctx->h_record->seq;
-        st = wait_polled(ctx->stream, (long long)seg->num_docs, [&] { return *flag == seq; });
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (lw.cardinality_atomic) {
+        BlockPartial g;
+        st = read_index_and_shards(ctx, 0, &g);
         if (st != PG_OK) return st;
-      } else {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-      }
-      if (lw.record_published) {
-        if (ctx->h_record->seq != seq) return fail(PG_ERR_INTERNAL, "index_and_kernel's record carries sequence %llu, expected %llu", ctx->h_record->seq, seq);
-        if (ctx->h_partial->flags & kPartialStale) return fail(PG_ERR_INTERNAL, "index_and_kernel's fold read a record that was not written by this launch (sequence %llu)", seq);
+        *h_card = g.count;
       }
       const int64_t card = (int64_t)*h_card;
       out->num_aggregations = na;
@@ -3010,7 +3030,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
                           lw.and_expected_docs <= 4.0 * (double)lw.finalize_windows;
       defer_index_and = gather && defer != nullptr && !defer->single && g_engine.batch_index && g_engine.direct_result && !want_bitmap && index_and_shares_a_launch(lw);
       if (defer_index_and) arm_index_gather(&lw, &sp);      // (launched by the batch: index_and_batch_kernel, lean_kind 12)
-      else st = launch_index_and(&lw, ctx, gather ? &sp : nullptr, seq);
+      else st = launch_index_and(&lw, ctx, gather ? &sp : nullptr);
       if (st != PG_OK) return st;
       sp.tile_list = lw.tile_list; sp.tile_count = lw.tile_count;      // (not read by the kernel; "listed" is what the planner and the statistics go by)
       sp.sparse_windows = lw.and_info; sp.sparse_num_windows = (int32_t)lw.finalize_windows;
@@ -3143,7 +3163,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       item->sp.lean_kind = 12;
       item->and_params = std::make_shared<IndexAndParams>(lw.and_params);
       item->and_windows = lw.finalize_windows;
-      item->blocks = (int)std::min<long long>(((long long)lw.finalize_windows + index_and_block_waves() - 1) / index_and_block_waves(), (long long)lw.and_num_cus * waves_index_and());
+      item->blocks = (int)std::min<long long>(((long long)lw.finalize_windows + index_and_batch_block_waves() - 1) / index_and_batch_block_waves(), (long long)lw.and_num_cus * index_and_batch_blocks_per_cu());
       item->one_slot = pl.num_agg_cols <= 1;
       item->convert = convert;
       item->plane_columns = planes.columns;
@@ -3192,17 +3212,16 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // (the chain kernel / copy commands behind the scan kernel; a kernel that leaves leaf bitmaps behind for the transducer pass must have
     //  RETIRED before that pass reads them -- its plain stores are only ordered by the end of the kernel, not by the pinned record's seq)
     if (lw.gathered) {
-      // index_and_kernel did the aggregation and folded its wavefronts' records into the pinned host record (launch_index_and: record_seq)
+      // index_and_kernel did the aggregation: its counter lines are the query's record
       if (timed) { HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream)); HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream)); }
-      ctx->ev_last = 2;
-      if (g_engine.poll_result && g_engine.direct_result && !timed) {
-        volatile unsigned long long* flag = &ctx->h_record->seq;
-        st = wait_polled(ctx->stream, (long long)seg->num_docs, [&] { return *flag == seq; });
-        if (st != PG_OK) return st;
-      } else {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-      }
-      if (ctx->h_record->seq != seq) return fail(PG_ERR_INTERNAL, "index_and_kernel's record carries sequence %llu, expected %llu", ctx->h_record->seq, seq);
+      HIP_TRY(hipMemcpyAsync(ctx->h_and_shards, ctx->d_and_counters + 2, kAndShardBytes, hipMemcpyDeviceToHost, ctx->stream));
+      if (timed) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+      ctx->ev_last = 3;
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      BlockPartial g;
+      st = read_index_and_shards(ctx, pl.num_agg_cols, &g);
+      if (st != PG_OK) return st;
+      *ctx->h_partial = g;
     } else {
     const bool post_work = !g_engine.direct_result || count_leap2 || want_bitmap || sp.leaf_out_enabled || fuse_fsm;
     if (timed) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -4910,7 +4929,7 @@ pg_status enqueue_index_and_launch(DeferredLaunch* L, BatchCtx* b, std::vector<D
   const int n = L->n;
   long long total_windows = 0;
   for (int i : items) { total_windows += defs[(size_t)i].item->and_windows; L->docs += (long long)segments[i]->num_docs; }
-  const long long budget = (long long)segments[items[0]]->num_cus * waves_index_and();      // workgroups (of index_and_block_waves() wavefronts) resident at once
+  const long long budget = (long long)segments[items[0]]->num_cus * index_and_batch_blocks_per_cu();      // workgroups (of index_and_batch_block_waves() wavefronts) resident at once
   std::vector<int>& blocks = L->blocks;
   blocks.assign((size_t)n, 0);
   size_t partials = 0;
@@ -4936,6 +4955,7 @@ pg_status enqueue_index_and_launch(DeferredLaunch* L, BatchCtx* b, std::vector<D
     ap = *d.and_params;
     ap.num_windows = (int32_t)d.and_windows;
     ap.out = nullptr; ap.window_info = nullptr;     // record mode: neither a bitmap nor window masks
+    ap.shards = nullptr;
     memset(&ap.pub, 0, sizeof(ap.pub));
     ap.pub.done_counter = b->d_done + (size_t)k * (kFoldShards + 1) * kFoldStride;
     ap.pub.partials = b->d_partials + off;

@@ -93,12 +93,20 @@ __device__ __forceinline__ bool and_resolve(const AndLanePosting& lp, uint32_t k
   return false;
 }
 
-// A workgroup is kAndBlockWaves wavefronts that share NOTHING but the record they publish together at the very end (a quarter of the records
-// for the folding workgroup to read: 4 096 one-wave workgroups made the fold a 10 us tail -- two levels, eight dependent rounds of loads per
-// lane).  Inside the window loop a wave only ever reads LDS it wrote itself: LDS operations of one wave execute in order, so what separates
-// its scatter from its read-back is a compiler fence and the LDS counter, never a workgroup barrier (the waves run different numbers of
-// windows and children: an s_barrier there would deadlock).
-constexpr int kAndBlockWaves = 4;
+// index_and_kernel (one query): one-wavefront workgroups.  index_and_batch_kernel: a workgroup is kAndBatchBlockWaves wavefronts that share
+// NOTHING but the record they publish together at the very end (a quarter of the records for the item's folding workgroup to read).  Inside
+// the window loop a wave only ever reads LDS it wrote itself: LDS operations of one wave execute in order, so what separates its scatter
+// from its read-back is a compiler fence and the LDS counter, never a workgroup barrier (the waves run different numbers of windows and
+// children: an s_barrier there would deadlock).  Measured on one query (C5 at 1 B rows, profiles/r6): four-wave workgroups lose 8 us of 62
+// to one-wave ones -- the dispatcher places a workgroup only where four wave slots and 38 KB of LDS are free at once.
+constexpr int kAndBlockWaves = 1;
+constexpr int kAndBatchBlockWaves = 4;
+// the sum of a 32-bit figure over the wavefront (a window holds at most 65 536 docs), the same in every lane
+__device__ __forceinline__ uint32_t and_wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+  return v;
+}
 __device__ __forceinline__ void and_wave_sync() {
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -232,11 +240,11 @@ __device__ __forceinline__ void and_or_bitset(__amdgpu_buffer_rsrc_t rsrc, uint3
 // The kernel's body over a parameter block P -- IndexAndParams out of the kernel arguments, or its constant-address-space form in device
 // memory (an item of index_and_batch_kernel: its wave-uniform fields are scalar loads either way).  Wavefront `first_wave` of the `num_waves`
 // that work on this block takes windows first_wave, first_wave + num_waves, ...; `window` / `guess` / `red` / `fold_flag`: the wave's LDS.
-template <typename P>
+template <bool kRecord, int kWaves, typename P>
 __device__ __forceinline__ void index_and_body(const P& ap, const uint32_t num_windows, const uint32_t block_index, const uint32_t num_blocks, uint4* window, uint32_t* guess,
                                                BlockPartial* red, uint32_t* fold_flag) {
   const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (uniform: the wave's LDS bases are scalars)
-  const uint32_t first_wave = block_index * (uint32_t)kAndBlockWaves + wave_in_block, num_waves = num_blocks * (uint32_t)kAndBlockWaves;
+  const uint32_t first_wave = block_index * (uint32_t)kWaves + wave_in_block, num_waves = num_blocks * (uint32_t)kWaves;
   window += 512u * wave_in_block;                       // this wave's 8 KB and its guesses
   guess += 6u * 64u * wave_in_block;
   uint32_t* w32 = reinterpret_cast<uint32_t*>(window);
@@ -257,10 +265,14 @@ __device__ __forceinline__ void index_and_body(const P& ap, const uint32_t num_w
   for (int i = 0; i < 8; ++i) window[lane0 + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
   and_wave_sync();
 
-  // record mode (ap.pub): what this lane found in all of the wave's windows -- reduced over the wave ONCE, behind the loop
-  uint32_t lane_card = 0u;
-  unsigned long long gsum[kMaxAndGather] = {0ull, 0ull};       // gather mode: the survivors' values of this lane
-  uint32_t gmin[kMaxAndGather] = {0xFFFFFFFFu, 0xFFFFFFFFu}, gmax[kMaxAndGather] = {0u, 0u};
+  // record mode (an item of a batch): what the wave found in all of its windows -- wave-UNIFORM totals (scalar registers: per-lane
+  // accumulators held across the window loop cost nine vector registers, 23 more of them in scratch inside the loop)
+  unsigned long long u_card = 0ull;
+  long long u_sum[kMaxAndGather] = {0ll, 0ll};
+  int32_t u_min[kMaxAndGather] = {0x7FFFFFFF, 0x7FFFFFFF}, u_max[kMaxAndGather] = {(int32_t)0x80000000, (int32_t)0x80000000};
+  // gather mode: the survivors' values of this lane in ONE window
+  unsigned long long gsum[kMaxAndGather];
+  uint32_t gmin[kMaxAndGather], gmax[kMaxAndGather];
 
   for (; key < num_windows; key += num_waves) {
     // (the lane number is made opaque once per window: left alone, LICM hoists every lane-dependent term of the window's code -- the
@@ -269,6 +281,8 @@ __device__ __forceinline__ void index_and_body(const P& ap, const uint32_t num_w
     //  pieces, hoisted out of the loop over the children, were another ~50.)
     uint32_t lane = (uint32_t)lane0;
     asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int a = 0; a < kMaxAndGather; ++a) { gsum[a] = 0ull; gmin[a] = 0xFFFFFFFFu; gmax[a] = 0u; }
     const uint32_t lane16 = lane * 16u;                   // this lane's 16 bytes of a 1 KB piece
     const long long base = (long long)key * 1024;         // first word of the window (uniform)
     const uint32_t words_here = (uint32_t)(ap.num_words - base < 1024 ? ap.num_words - base : 1024);   // a multiple of 32
@@ -454,41 +468,67 @@ __device__ __forceinline__ void index_and_body(const P& ap, const uint32_t num_w
         for (int g = 0; g < 4; ++g) if ((nz >> (16 * g)) & 0xffffull) tiles |= 1u << (4 * i + g);
       }
     }
-    lane_card += card;
-    if (out != nullptr) {
-      const uint32_t total = (uint32_t)wave_sum_i64((long long)card);
-      if (lane == 0u) ap.window_info[key] = WindowInfo{tiles, total};
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)and_wave_sum_u32(card));
+    if (lane == 0u && out != nullptr) ap.window_info[key] = WindowInfo{tiles, total};
+    if constexpr (kRecord) {
+      u_card += (unsigned long long)total;
+    } else {
+      // ---- one query: the window's figures onto counter line (window & 63), fire-and-forget ----
+      // (kAndCardinalityShards counters, one 128-byte line each: ONE counter made the kernel 58 -> 194 us on C5-sparse -- ~3 700 same-address
+      //  device-scope atomics at ~37 ns apiece, each holding its wave's slot until it retires)
+      if (lane == 0u && ap.shards != nullptr && total != 0u)
+        __hip_atomic_fetch_add(ap.shards + (size_t)(key & (uint32_t)(kAndCardinalityShards - 1)) * 16, (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (ap.gather_cols != 0 && total != 0u) {
+#pragma unroll
+      for (int a = 0; a < kMaxAndGather; ++a) {
+        if (a >= ap.gather_cols) continue;
+        const long long s = wave_sum_i64((long long)gsum[a]);
+        // (keys are below 2^31: dictIds / plane fields -- the signed wave reductions take them as they are)
+        const int32_t kmin = wave_min_i32((int32_t)(gmin[a] == 0xFFFFFFFFu ? 0x7FFFFFFF : gmin[a]));
+        const int32_t kmax = wave_max_i32((int32_t)gmax[a]);
+        if constexpr (kRecord) {
+          u_sum[a] += (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(s >> 32)) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)s));
+          const int32_t m0 = __builtin_amdgcn_readfirstlane(kmin), m1 = __builtin_amdgcn_readfirstlane(kmax);
+          u_min[a] = m0 < u_min[a] ? m0 : u_min[a];
+          u_max[a] = m1 > u_max[a] ? m1 : u_max[a];
+        } else if (lane == 0u) {
+          unsigned long long* o = ap.shards + (size_t)(key & (uint32_t)(kAndCardinalityShards - 1)) * 16 + 1 + 3 * a;      // (word 0 of the line: the cardinality)
+          __hip_atomic_fetch_add(o, (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_max(o + 1, (unsigned long long)(0xFFFFFFFFu - (uint32_t)kmin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_max(o + 2, (unsigned long long)(uint32_t)kmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     }
   }
 
-  if (ap.pub.partials != nullptr) {
-    // ---- the wavefront's record, published like a scan kernel's: the last wavefront to arrive folds them into the pinned host record ----
-    BlockPartial mine;
-    partial_identity(mine);
-    mine.count = (unsigned long long)wave_sum_i64((long long)lane_card);
+  if constexpr (kRecord) {
+    if (ap.pub.partials != nullptr) {
+      // ---- the wavefront's record, published like a scan kernel's: the last wavefront to arrive folds them into the pinned host record ----
+      BlockPartial mine;
+      partial_identity(mine);
+      mine.count = u_card;
 #pragma unroll
-    for (int a = 0; a < kMaxAndGather; ++a) {
-      if (a >= ap.gather_cols) continue;
-      // (keys are below 2^31: dictIds / plane fields -- the signed wave reductions take them as they are)
-      mine.sum[a] = wave_sum_i64((long long)gsum[a]);
-      mine.kmin[a] = wave_min_i32((int32_t)(gmin[a] == 0xFFFFFFFFu ? 0x7FFFFFFF : gmin[a]));
-      mine.kmax[a] = mine.count != 0ull ? wave_max_i32((int32_t)gmax[a]) : (int32_t)0x80000000;
+      for (int a = 0; a < kMaxAndGather; ++a) {
+        if (a >= ap.gather_cols) continue;
+        mine.sum[a] = u_sum[a];
+        mine.kmin[a] = u_min[a];
+        mine.kmax[a] = u_max[a];
+      }
+      if (lane0 == 0) red[wave_in_block] = mine;
+      __syncthreads();                                     // (every wave of the workgroup gets here exactly once)
+      publish_block_partial(ap.pub, red, kWaves, fold_flag, block_index, num_blocks);
     }
-    if (lane0 == 0) red[wave_in_block] = mine;
-    __syncthreads();                                     // (every wave of the workgroup gets here exactly once)
-    publish_block_partial(ap.pub, red, kAndBlockWaves, fold_flag, block_index, num_blocks);
   }
 }
 
 static __global__ __launch_bounds__(64 * kAndBlockWaves, PG_INDEX_AND_WAVES) void index_and_kernel(const IndexAndParams ap, const uint32_t num_windows) {
   __shared__ uint4 window[512 * kAndBlockWaves];        // per wave: 1024 64-bit words; all zero whenever no child is being expanded
   __shared__ uint32_t guess[6 * 64 * kAndBlockWaves];   // per wave: the directory entries guessed for its NEXT window (and_issue_guess)
-  __shared__ BlockPartial red[kAndBlockWaves];
-  __shared__ uint32_t fold_flag;
-  index_and_body(ap, num_windows, blockIdx.x, gridDim.x, window, guess, red, &fold_flag);
+  index_and_body<false, kAndBlockWaves>(ap, num_windows, blockIdx.x, gridDim.x, window, guess, nullptr, nullptr);
 }
 
-// Many index-led queries, one launch (pg_execute_batch): workgroups [block_first[i], block_first[i + 1]) -- kAndBlockWaves wavefronts each -- work on
+// Many index-led queries, one launch (pg_execute_batch): workgroups [block_first[i], block_first[i + 1]) -- kAndBatchBlockWaves wavefronts each -- work on
 // items[i], every item with its own postings, gathered columns and record (IndexAndParams.pub: every item folds and publishes on its own
 // while the others still intersect).  What BaseCombineOperator (core/operator/combine/BaseCombineOperator.java:85-142) gets from a task per
 // segment when the filter is answered by the inverted indexes (InvertedIndexFilterOperator.java:60-145) over a server's many small segments.
@@ -498,10 +538,10 @@ struct IndexAndBatchParams {
   int32_t num_items;
   int32_t reserved;
 };
-static __global__ __launch_bounds__(64 * kAndBlockWaves, PG_INDEX_AND_WAVES) void index_and_batch_kernel(const IndexAndBatchParams bp) {
-  __shared__ uint4 window[512 * kAndBlockWaves];
-  __shared__ uint32_t guess[6 * 64 * kAndBlockWaves];
-  __shared__ BlockPartial red[kAndBlockWaves];
+static __global__ __launch_bounds__(64 * kAndBatchBlockWaves, PG_INDEX_AND_WAVES) void index_and_batch_kernel(const IndexAndBatchParams bp) {
+  __shared__ uint4 window[512 * kAndBatchBlockWaves];
+  __shared__ uint32_t guess[6 * 64 * kAndBatchBlockWaves];
+  __shared__ BlockPartial red[kAndBatchBlockWaves];
   __shared__ uint32_t fold_flag;
   int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one
   while (lo < hi) {
@@ -511,7 +551,7 @@ static __global__ __launch_bounds__(64 * kAndBlockWaves, PG_INDEX_AND_WAVES) voi
   const uint32_t first = bp.block_first[lo];
   typedef const __attribute__((address_space(4))) IndexAndParams ConstantIndexAndParams;      // (scalar loads of the item's fields: see scan_private_batch_kernel)
   const ConstantIndexAndParams& item = *(ConstantIndexAndParams*)(bp.items + lo);
-  index_and_body(item, (uint32_t)item.num_windows, blockIdx.x - first, bp.block_first[lo + 1] - first, window, guess, red, &fold_flag);
+  index_and_body<true, kAndBatchBlockWaves>(item, (uint32_t)item.num_windows, blockIdx.x - first, bp.block_first[lo + 1] - first, window, guess, red, &fold_flag);
 }
 
 }  // namespace pg

@@ -66,8 +66,9 @@ void launch_scan_typed_batch(int agg_slots, int total_blocks, hipStream_t stream
 int waves_scan_typed_batch(int agg_slots);
 // index_and_kernel: the inverted-index children of a root AND, intersected window by window by a persistent grid of one-wave workgroups (pg_index_and.h)
 void launch_index_and_kernel(int blocks, hipStream_t stream, const IndexAndParams& ap, uint32_t num_windows);
-int waves_index_and();      // workgroups per CU ...
-int index_and_block_waves(); // ... of this many independent wavefronts (a window in flight each)
+int waves_index_and();                 // index_and_kernel: wavefronts (= one-wave workgroups, a window in flight each) per CU
+int index_and_batch_blocks_per_cu();   // index_and_batch_kernel: workgroups per CU ...
+int index_and_batch_block_waves();     // ... of this many independent wavefronts
 // index_and_batch_kernel: pg_execute_batch's shared launch for items whose whole device work is index_and_kernel (COUNT(*) over an index-only filter, the gathered aggregation)
 void launch_index_and_batch(int total_blocks, hipStream_t stream, const IndexAndParams* items, const uint32_t* block_first, int num_items);
 // scan_group_kernel<kDma, kLdsTable>: LDS-staged group-by

@@ -169,8 +169,10 @@ __device__ __forceinline__ void agg_dict64_private(const AC& ac, long long tile,
 #ifndef PG_TYPED_WAVES
 #define PG_TYPED_WAVES 4
 #endif
+// Three and four slots: 3 wavefronts per SIMD (168 registers, no scratch) instead of 4 (128 registers, 32 of them spilled inside the tile
+// loop) -- 1.280 -> 0.913 ms on four raw columns at 1 B rows (profiles/r6/spills_three_vs_four_waves_ab.txt).
 #ifndef PG_TYPED_WAVES_MANY
-#define PG_TYPED_WAVES_MANY 4
+#define PG_TYPED_WAVES_MANY 3
 #endif
 // `block_index` of `num_blocks`: the workgroup's place among those working on this parameter block (the whole grid, or an item's share of
 // scan_typed_batch_kernel's launch).  P: ScanParams, or its constant-address-space form in device memory.

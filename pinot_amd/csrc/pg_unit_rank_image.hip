@@ -79,8 +79,10 @@ static __global__ __launch_bounds__(256) void rank_hash_clear_kernel(RankSlot* s
 }
 
 static __global__ __launch_bounds__(256) void rank_hash_insert_kernel(const uint8_t* __restrict__ raw, int vkind, long long num_docs, RankTable t) {
-  for (long long doc = (long long)blockIdx.x * blockDim.x + threadIdx.x; doc < num_docs; doc += (long long)gridDim.x * blockDim.x) {
-    if (__hip_atomic_load(&t.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;      // somebody found the table too full: this attempt is over
+  int round = 0;
+  for (long long doc = (long long)blockIdx.x * blockDim.x + threadIdx.x; doc < num_docs; doc += (long long)gridDim.x * blockDim.x, ++round) {
+    // somebody found the table too full: this attempt is over (looked at every 32nd doc: the flag is one L2 line for the whole grid)
+    if ((round & 31) == 0 && __hip_atomic_load(&t.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const unsigned long long key = order_image(raw, vkind, doc);
     if (key == kRankEmpty) { if (t.flags[1] == 0u) __hip_atomic_store(&t.flags[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
     if (rank_hash_find<true>(t, key) == ~0ull) __hip_atomic_store(&t.flags[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -119,17 +121,22 @@ static __global__ __launch_bounds__(256) void rank_hash_assign_kernel(const unsi
 }
 
 // the rank of every doc's value in the sorted dictionary, packed MSB-first at `bits_out` bits per doc in the lane-private tile layout
-// (the same writer as build_raw_key_image_kernel: lane l of a tile owns docs [32 l, 32 l + 32), bits_out dwords)
+// (the same layout as build_raw_key_image_kernel: lane l of a tile owns docs [32 l, 32 l + 32), bits_out dwords).  A wavefront per tile:
+// the column is read COALESCED (round r: lane l takes doc 64 r + l of the tile -- a lane walking its own 32 docs made every load of the
+// wavefront 64 lines 256 bytes apart, and the pack was 46 ms of the 57 ms build at 1 B docs), probed right there, and the ranks change
+// hands through the wave's LDS (doc d at d + (d >> 5): the owners' read-back is conflict-free); the packed dwords go back through the same
+// LDS and leave as whole lines.
 static __global__ __launch_bounds__(256) void rank_image_pack_kernel(const uint8_t* __restrict__ raw, int vkind, RankTable t, int cardinality,
                                                               uint8_t* __restrict__ out, int bits_out, int num_tiles, long long num_docs) {
+  __shared__ uint32_t ids[4][2048 + 64];
   const int lane = threadIdx.x & 63;
+  uint32_t* mine = ids[threadIdx.x >> 6];
   for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < (long long)num_tiles; tile += (long long)gridDim.x * 4) {
-    const long long first = tile * 2048 + (long long)lane * 32;
-    uint32_t* dst = reinterpret_cast<uint32_t*>(out + tile * (256ll * bits_out)) + lane * bits_out;
-    unsigned long long acc = 0ull;
-    int have = 0, k = 0;
-    for (int j = 0; j < 32; ++j) {
-      const long long doc = first + j;
+    const long long first = tile * 2048;
+#pragma unroll 4
+    for (int r = 0; r < 32; ++r) {
+      const int d = r * 64 + lane;
+      const long long doc = first + d;
       uint32_t id = 0u;
       if (doc < num_docs) {
         const unsigned long long key = order_image(raw, vkind, doc);
@@ -139,10 +146,29 @@ static __global__ __launch_bounds__(256) void rank_image_pack_kernel(const uint8
           id = h != ~0ull ? (uint32_t)t.slots[h].rank : 0u;
         }
       }
-      acc = (acc << bits_out) | (unsigned long long)id;
-      have += bits_out;
-      if (have >= 32) { dst[k++] = __builtin_bswap32((uint32_t)(acc >> (have - 32))); have -= 32; }
+      mine[d + (d >> 5)] = id;
     }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) v[j] = mine[lane * 33 + j];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned long long acc = 0ull;
+    int have = 0, k = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      acc = (acc << bits_out) | (unsigned long long)v[j];
+      have += bits_out;
+      if (have >= 32) { mine[lane * bits_out + k++] = __builtin_bswap32((uint32_t)(acc >> (have - 32))); have -= 32; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + tile * (256ll * bits_out));
+    for (int i = lane; i < 64 * bits_out; i += 64) dst[i] = mine[i];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
 

@@ -16,8 +16,12 @@ class Engine:
         _abi.check(self.lib, self.lib.pg_init(C.byref(self._cfg)))
         self.device_id = device_id
 
-    def reinit(self, **env):
-        """pg_init again with environment switches changed (value None = unset): the library re-reads them; open segments stay open."""
+    def reinit(self, time_kernels=None, **env):
+        """pg_init again with environment switches changed (value None = unset): the library re-reads them; open segments stay open.
+        time_kernels: PG_CFG_TIME_KERNELS on / off from here on (None: as it was)."""
+        if time_kernels is not None:
+            flags = int(self._cfg.flags) & ~_abi.PG_CFG_TIME_KERNELS
+            self._cfg.flags = flags | (_abi.PG_CFG_TIME_KERNELS if time_kernels else 0)
         for k, v in env.items():
             if v is None:
                 os.environ.pop(k, None)

@@ -74,6 +74,10 @@ def main():
                 if want and not want.search(qid):
                     continue
                 t = timer.run(gseg, spec, args.steps, args.warmup)
+                # the same query without PG_CFG_TIME_KERNELS: no event records on the stream, the waits the product path uses
+                engine.reinit(time_kernels=False)
+                untimed = timer.run(gseg, spec, args.steps, args.warmup)["step_ms_host_clock"]
+                engine.reinit(time_kernels=True)
                 got = gseg.execute(spec)
                 if qid not in checked and not args.no_check:
                     w = oracle.execute_sliced(seg, ospec or spec)
@@ -86,7 +90,7 @@ def main():
                     first = checked.setdefault(qid + "/answer", answer)
                     exact_now = checked[qid] and first == answer
                 rec = {"shape": label, "query": qid, "setting": env, "rows": n, "kernel": t["kernel"], "kernel_ms": t["kernel_ms"], "all_kernels_ms": t["all_kernels_ms"],
-                       "host_clock_ms": t["step_ms_host_clock"], "bytes": nbytes, "frac_all_kernels": nbytes / t["all_kernels_ms"] / 1e6 / 8000.0 if t["all_kernels_ms"] > 0 else None,
+                       "host_clock_ms": t["step_ms_host_clock"], "host_clock_untimed_ms": untimed, "bytes": nbytes, "frac_all_kernels": nbytes / t["all_kernels_ms"] / 1e6 / 8000.0 if t["all_kernels_ms"] > 0 else None,
                        "frac_host_clock": nbytes / t["step_ms_host_clock"] / 1e6 / 8000.0, "docs": got.stats[0], "entries": got.stats[1], "entries_exact": bool(got.filter_entries_exact),
                        "exact": exact_now}
                 emit(rec)

@@ -18,12 +18,12 @@ c5_ab)
   timeout 1500 python tools/ab_r6.py c5 --steps 20 --out $OUT/c5_ab.jsonl --settings "PINOT_GPU_INDEX_AND_WAVES=-1;;PINOT_GPU_INDEX_AND_WAVES=8;PINOT_GPU_INDEX_AND_WAVES=12;PINOT_GPU_INDEX_AND_WAVES=20;PINOT_GPU_INDEX_AND_WAVES=-1;" 2> $OUT/c5_ab.err | python -c "
 import sys, json
 for l in sys.stdin:
-    r = json.loads(l); print('%-16s %-34s kernel %.4f all %.4f host %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r['frac_all_kernels'] or 0, r['exact']))" ;;
+    r = json.loads(l); print('%-16s %-34s kernel %.4f all %.4f host %.4f untimed %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r.get('host_clock_untimed_ms') or 0, r['frac_all_kernels'] or 0, r['exact']))" ;;
 c5_ab2)
   timeout 1500 python tools/ab_r6.py c5 --steps 20 --out $OUT/c5_ab2.jsonl --settings "${C5_SETTINGS:-PINOT_GPU_INDEX_AND_WAVES=-1;PINOT_GPU_INDEX_AND_WAVES=-2;PINOT_GPU_INDEX_AND_WAVES=-3;PINOT_GPU_INDEX_AND_WAVES=-4;PINOT_GPU_INDEX_AND_WAVES=0;PINOT_GPU_INDEX_AND_WAVES=-1;PINOT_GPU_INDEX_AND_WAVES=-2}" 2> $OUT/c5_ab2.err | python -c "
 import sys, json
 for l in sys.stdin:
-    r = json.loads(l); print('%-16s %-34s kernel %.4f all %.4f host %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r['frac_all_kernels'] or 0, r['exact']))" ;;
+    r = json.loads(l); print('%-16s %-34s kernel %.4f all %.4f host %.4f untimed %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r.get('host_clock_untimed_ms') or 0, r['frac_all_kernels'] or 0, r['exact']))" ;;
 c5s_sq)
   bash tools/profile_round.sh $TAG c5s_sq 2>&1 | tail -12 ;;
 fsm_tests)
@@ -39,7 +39,7 @@ c3_libs)
     timeout 900 python tools/ab_r6.py c3 --steps 20 --out $OUT/c3_$lib.jsonl --settings "$settings" 2> $OUT/c3_$lib.err | python -c "
 import sys, json
 for l in sys.stdin:
-    r = json.loads(l); print('%-14s %-62s kernel %.4f all %.4f host %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r['frac_all_kernels'] or 0, r['exact']))"
+    r = json.loads(l); print('%-14s %-62s kernel %.4f all %.4f host %.4f untimed %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r.get('host_clock_untimed_ms') or 0, r['frac_all_kernels'] or 0, r['exact']))"
   done; unset PINOT_GPU_LIB ;;
 spill_ab)
   # kernels that spill at four waves per SIMD against builds bounded at three (no spills): the four-slot typed scans, the scan with the transducer inside
@@ -74,7 +74,7 @@ c3_ab)
   timeout 1500 python tools/ab_r6.py c3 --steps 20 --out $OUT/c3_ab.jsonl --settings "${C3_SETTINGS:-}" 2> $OUT/c3_ab.err | python -c "
 import sys, json
 for l in sys.stdin:
-    r = json.loads(l); print('%-16s %-34s kernel %.4f all %.4f host %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r['frac_all_kernels'] or 0, r['exact']))" ;;
+    r = json.loads(l); print('%-16s %-34s kernel %.4f all %.4f host %.4f untimed %.4f frac %.3f exact %s' % (r['query'], r['setting'], r['kernel_ms'], r['all_kernels_ms'], r['host_clock_ms'], r.get('host_clock_untimed_ms') or 0, r['frac_all_kernels'] or 0, r['exact']))" ;;
 not_trace)
   rm -rf $OUT/not_trace
   (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/not_trace -o t -- python $GRAFT_REPO_ROOT/tools/ab_r6.py not --steps 10 --warmup 10 --match AND-NOT --no-check > $GRAFT_REPO_ROOT/$OUT/not_trace.jsonl 2> $GRAFT_REPO_ROOT/$OUT/not_trace.err)
