@@ -163,6 +163,7 @@ struct ColumnDev {
   DevContainer* d_dir = nullptr;
   std::vector<DevContainer> h_dir;
   std::vector<int64_t> posting_first;   // [cardinality + 1] index into the container directory
+  std::vector<int64_t> posting_docs;    // [cardinality] docs of every posting list (the planner's estimates: summing 15 259 containers per posting on every query was 8 us of host time each)
   unsigned long long* d_null_bitmap = nullptr;   // null value vector expanded to a doc-order bitmap (num_tiles * 32 words), or nullptr
   int nullkey_column = -1;              // nullable dictionary column: index of its hidden null-key image (dictId = cardinality where the doc is null)
   // Raw INT / LONG column as a group key: index of its hidden KEY IMAGE -- the fixed-bit stream of (value - raw_min), cardinality
@@ -1332,14 +1333,15 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
         mb.child.inv = col.d_inv; mb.child.dir = col.d_dir; mb.child.exclusive = pr.exclusive ? 1 : 0;
         double docs = 0;
         int postings = 0;
-        for (int d = 0; d < col.cardinality; ++d) {
-          bool in;
-          if (pr.kind == PG_PRED_DICT_RANGE) in = d >= pr.lo && d < pr.hi;
-          else in = (d >> 5) < pr.num_set_words && ((pr.set_words[d >> 5] >> (d & 31)) & 1u);
-          if (!in) continue;
+        // (a range walks its own dictIds only, a set the dictIds its words can name)
+        const bool is_range = pr.kind == PG_PRED_DICT_RANGE;
+        const int d_begin = is_range ? (int)std::max<int64_t>(pr.lo, 0) : 0;
+        const int d_end = is_range ? (int)std::min<int64_t>(pr.hi, col.cardinality) : (int)std::min<int64_t>((int64_t)pr.num_set_words * 32, col.cardinality);
+        for (int d = d_begin; d < d_end; ++d) {
+          if (!is_range && !((pr.set_words[d >> 5] >> (d & 31)) & 1u)) continue;
           const int64_t first = col.posting_first[d], cnt = col.posting_first[d + 1] - first;
           if (cnt <= 0) continue;
-          for (int64_t k = first; k < first + cnt; ++k) docs += col.h_dir[(size_t)k].cardinality;
+          docs += (double)col.posting_docs[(size_t)d];
           if (postings < kMaxChildPostings) mb.postings.emplace_back((int32_t)first, (int32_t)cnt);
           postings++;
         }
@@ -2119,6 +2121,9 @@ pg_status pg_segment_open(const pg_segment_desc* desc, pg_segment** out_segment)
         if (st != PG_OK) return bail(st);
       }
       col.posting_first[(size_t)cd.cardinality] = (int64_t)col.h_dir.size();
+      col.posting_docs.assign((size_t)cd.cardinality, 0);
+      for (int d = 0; d < cd.cardinality; ++d)
+        for (int64_t k = col.posting_first[(size_t)d]; k < col.posting_first[(size_t)d + 1]; ++k) col.posting_docs[(size_t)d] += (int64_t)col.h_dir[(size_t)k].cardinality;
       hipError_t e = hipMalloc((void**)&col.d_inv, (size_t)cd.inv_size + 64);
       if (e == hipSuccess) e = h2d_copy(col.d_inv, inv, (size_t)cd.inv_size, phys_device(seg->device));
       if (e == hipSuccess && !col.h_dir.empty()) {
@@ -2637,6 +2642,20 @@ static std::shared_ptr<const OwnedQuery> own_query(const pg_query* q) {
 
 static pg_status prepare_fsm_side(pg_segment* seg, ExecCtx* ctx, const pg::fstats::Fsm& fsm, FsmSide* side);
 static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg_query* q, const FsmSide& side, pg_result* out);
+// PINOT_GPU_EXEC_TRACE=1: the host phases of every pg_execute on stderr -- eligibility check | context + lowering | launches enqueued | wait |
+// result conversion (what a query's host clock is made of beside its kernels; execute_impl marks the boundaries it passes)
+struct ExecTrace {
+  std::chrono::steady_clock::time_point t[6];
+  bool seen[6];
+};
+static thread_local ExecTrace t_exec_trace;
+static bool exec_trace_on() { static const bool on = getenv("PINOT_GPU_EXEC_TRACE") != nullptr; return on; }
+static inline void exec_mark(int i) {
+  if (!exec_trace_on()) return;
+  t_exec_trace.t[i] = std::chrono::steady_clock::now();
+  t_exec_trace.seen[i] = true;
+}
+
 static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out, unsigned long long* d_out_bitmap_request,
                               uint64_t* host_bitmap, int64_t host_bitmap_words, int64_t* out_cardinality, bool allow_metadata_plan = true,
                               Deferred* defer = nullptr, FsmSide* side = nullptr) {
@@ -2650,6 +2669,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     const pg_status eligible = check_query_plan(seg, &shape, 0);
     if (eligible != PG_OK) return eligible;
   }
+  exec_mark(1);
   HIP_TRY(hipSetDevice(phys_device(seg->device)));
   ExecCtx* ctx = nullptr;
   pg_status st = acquire_ctx(seg, &ctx);
@@ -2762,6 +2782,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   }
   st = lower_filter(seg, ctx, q, &lw);
   if (st != PG_OK) return st;
+  exec_mark(2);
   ScanParams& sp = lw.sp;
   PlanParams& pl = lw.plan;
 
@@ -2813,7 +2834,9 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       if (lw.cardinality_atomic) HIP_TRY(hipMemcpyAsync(ctx->h_and_shards, ctx->d_and_counters + 2, kAndShardBytes, hipMemcpyDeviceToHost, ctx->stream));
       else HIP_TRY(hipMemcpyAsync(h_card, lw.d_cardinality, 8, hipMemcpyDeviceToHost, ctx->stream));
       if (timed) { HIP_TRY(mark_pre_work(ctx)); HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
+      exec_mark(3);
       HIP_TRY(hipStreamSynchronize(ctx->stream));
+      exec_mark(4);
       if (lw.cardinality_atomic) {
         BlockPartial g;
         st = read_index_and_shards(ctx, 0, &g);
@@ -3217,7 +3240,9 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       HIP_TRY(hipMemcpyAsync(ctx->h_and_shards, ctx->d_and_counters + 2, kAndShardBytes, hipMemcpyDeviceToHost, ctx->stream));
       if (timed) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
       ctx->ev_last = 3;
+      exec_mark(3);
       HIP_TRY(hipStreamSynchronize(ctx->stream));
+      exec_mark(4);
       BlockPartial g;
       st = read_index_and_shards(ctx, pl.num_agg_cols, &g);
       if (st != PG_OK) return st;
@@ -3265,6 +3290,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     }
     if (timed && (post_work || !folded)) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     ctx->ev_last = (post_work || !folded) ? 3 : 2;
+    exec_mark(3);
     if (g_engine.poll_result && !post_work && !timed) {
       // nothing follows the kernel on the stream: the record's sequence number is the completion signal
       volatile unsigned long long* flag = &ctx->h_record->seq;
@@ -3274,6 +3300,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     } else {
       HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    exec_mark(4);
     if (count_leap2 && ctx->h_record->leap_seq != seq) return fail(PG_ERR_INTERNAL, "the leap-frog chain kernel did not publish its result");
     if (g_engine.direct_result && ctx->h_record->seq != seq) return fail(PG_ERR_INTERNAL, "the scan kernel's record carries sequence %llu, expected %llu", ctx->h_record->seq, seq);
     }
@@ -5116,7 +5143,18 @@ pg_status pg_execute(pg_segment* segment, const pg_query* query, pg_result* out_
   //  query's launches -- the deferred form would leave profile_* empty and report the kernel bracket only)
   if (!(g_engine.group_one_launch && g_engine.batch_launch && g_engine.batch_group && segment && query && out_result && query->num_group_by > 0 &&
         !(query->flags & PG_QUERY_NULL_HANDLING) && !(g_engine.flags & PG_CFG_PROFILE_WAVES) && g_engine.initialized))
-    return execute_one(segment, query, out_result, nullptr);
+  {
+    if (exec_trace_on()) { memset(t_exec_trace.seen, 0, sizeof(t_exec_trace.seen)); exec_mark(0); }
+    const pg_status st = execute_one(segment, query, out_result, nullptr);
+    if (exec_trace_on()) {
+      exec_mark(5);
+      const ExecTrace& x = t_exec_trace;
+      auto us = [&](int a, int b) { return (x.seen[a] && x.seen[b]) ? std::chrono::duration<double, std::micro>(x.t[b] - x.t[a]).count() : -1.0; };
+      fprintf(stderr, "exec trace: status %d, check %.1f us, context + lowering %.1f us, launches %.1f us, wait %.1f us, after the wait %.1f us, total %.1f us (-1: phase not passed)\n",
+              (int)st, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(0, 5));
+    }
+    return st;
+  }
   std::vector<Deferred> defs(1);
   defs[0].single = true;
   std::string key;

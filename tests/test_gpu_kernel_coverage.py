@@ -163,6 +163,6 @@ def test_every_switch_of_the_library_has_a_test_on_its_other_side():
     tested = ""
     for path in _glob.glob(os.path.join(ROOT, "tests", "*.py")) + [os.path.join(ROOT, "tools", "kernel_coverage.py"), os.path.join(ROOT, "pinot_amd", "engine.py"), os.path.join(ROOT, "pinot_amd", "_abi.py")]:
         tested += open(path).read()
-    diagnostics = {"PINOT_GPU_BATCH_TRACE", "PINOT_GPU_FSM_TRACE", "PINOT_GPU_PARTITION_TRACE", "PINOT_GPU_RANK_TRACE"}      # stderr only
+    diagnostics = {"PINOT_GPU_BATCH_TRACE", "PINOT_GPU_EXEC_TRACE", "PINOT_GPU_FSM_TRACE", "PINOT_GPU_PARTITION_TRACE", "PINOT_GPU_RANK_TRACE"}      # stderr only
     missing = sorted(n for n in names if n not in tested and n not in diagnostics)
     assert missing == [], missing

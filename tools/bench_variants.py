@@ -184,7 +184,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
         del seg5, cols
 
     # ---- C1: 10 M rows, raw int32 forward index (BASELINE.json configs[0] is the reference's CPU case; COUNT(*) itself is O(1)) ----
-    if any(want(x) for x in ("C1-count-range", "C1-sum", "C1-count", "C1-group-by")):
+    if any(want(x) for x in ("C1-count-range", "C1-sum", "C1-count", "C1-group-by", "C1-group-by-raw-double")):
         n1 = 10_000_000
         raw = S.Column.raw("raw_i32", S.synthetic_dict_ids(42, 0, n1, 1_000_000))
         seg1 = S.SegmentData("c1", n1, [raw])
@@ -203,6 +203,19 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
             with engine.open(segg) as g:
                 report("C1-group-by", "BASELINE.json configs[2]'s query on one 10 M-row segment", "SELECT SUM(a), MAX(b) GROUP BY k (1000 groups, 10 M rows)", n1, B(kc) + B(ac) + B(bc), g, segg,
                        Q.QuerySpec([(Q.SUM, 1), (Q.MAX, 2)], group_by=[0]))
+        if want("C1-group-by-raw-double"):
+            # the same query keyed by a raw (no-dictionary) DOUBLE column: NoDictionarySingleColumnGroupKeyGenerator.java:100-135 keys it by value; here the
+            # first query builds the column's dictionary + rank image on the device (pg_unit_rank_image.hip), every later one reads the image
+            rng = np.random.default_rng(34)
+            values = np.sort(rng.normal(0.0, 1e6, 1000))
+            dc = S.Column.raw_typed("d", values[S.synthetic_dict_ids(35, 0, n1, 1000)].astype(np.float64))
+            ac = S.Column.synthetic_uniform("a", n1, (np.arange(100000, dtype=np.int64) * 5 + 1).astype(np.int32), seed=32)
+            bc = S.Column.synthetic_uniform("b", n1, np.arange(65536, dtype=np.int32) * 2, seed=33)
+            segd = S.SegmentData("c1gd", n1, [dc, ac, bc])
+            with engine.open(segd) as g:
+                report("C1-group-by-raw-double", "BASELINE.json configs[2]'s query on one 10 M-row segment, keyed by a raw DOUBLE column", "SELECT SUM(a), MAX(b) GROUP BY d (1000 distinct doubles, 10 M rows)",
+                       n1, B(dc) + B(ac) + B(bc), g, segd, Q.QuerySpec([(Q.SUM, 1), (Q.MAX, 2)], group_by=[0]),
+                       extra={"algorithmic_bytes_note": "charged with the raw column's 8 bytes per doc (what the reference reads); the kernel reads the 10-bit rank image built by the first query"})
     # ---- the small-segment regime: 64 segments of 10 M rows (BASELINE.json configs[0]'s size), one query over all of them ----
     # (a) pg_execute_batch: one launch, every segment folds its own result; (b) the way BaseCombineOperator would drive pg_execute: 16
     # host threads, each with the next segment, every pg_execute on a stream of its own; (c) one pg_execute after the other.
