@@ -1916,22 +1916,13 @@ struct PrivateAccLds {
 };
 template <>
 struct PrivateAccLds<1> { uint32_t unused; };          // the one-slot form keeps its accumulators in registers
-// ... except with the transducer walked inside (scan_private_fsm_kernel<1>): there the walk's byte functions want the registers
-struct PrivateAccLdsOne {
-  unsigned long long sum[1][kBlockThreads];
-  uint32_t umin[1][kBlockThreads], umax[1][kBlockThreads];
-  uint32_t count[kBlockThreads];               // matching docs of this thread (PG_FSM_COUNT_LDS)
-};
-#ifndef PG_FSM_COUNT_LDS
-#define PG_FSM_COUNT_LDS 0
-#endif
 // kFsm: numEntriesScannedInFilter of a leap-frogging root AND is walked here, tile by tile, on the leaves' masks while they are still in
 // registers (fsm_perm_tile, pg_fsm_kernels.h: machines of at most four states and four inputs) -- the separate pass wrote every leaf's
 // bitmap to HBM and read it back (AndDocIdIterator.java:40-73 is what is being counted).  fsm_delta / fsm_pair: the walk's LDS tables.
 struct FsmWalkLds { uint8_t delta[64]; uint2 pair_fn[256]; };
-template <int kAggSlots, typename P, bool kFsm = false, typename AccLds = PrivateAccLds<kAggSlots>>
+template <int kAggSlots, typename P, bool kFsm = false>
 __device__ __forceinline__ void scan_private_body(const P& p, const uint32_t block_index, const uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr,
-                                                  AccLds* acc_lds, FsmWalkLds* fsm_lds = nullptr) {
+                                                  PrivateAccLds<kAggSlots>* acc_lds, FsmWalkLds* fsm_lds = nullptr) {
   if constexpr (kFsm) fsm_perm_build_tables<4>(p.fsm_delta, 4, p.fsm_states, p.fsm_inputs, fsm_lds->delta, fsm_lds->pair_fn);
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
@@ -1940,7 +1931,7 @@ __device__ __forceinline__ void scan_private_body(const P& p, const uint32_t blo
   const long long num_tiles = ((long long)p.num_docs + 2047) / 2048;
 
   unsigned long long count = 0;
-  constexpr bool kAccInLds = sizeof(AccLds) > sizeof(uint32_t);
+  constexpr bool kAccInLds = kAggSlots > 1;
   unsigned long long sum[kAccInLds ? 1 : kAggSlots];
   uint32_t umin[kAccInLds ? 1 : kAggSlots], umax[kAccInLds ? 1 : kAggSlots];
 #pragma unroll
@@ -1948,7 +1939,6 @@ __device__ __forceinline__ void scan_private_body(const P& p, const uint32_t blo
   if constexpr (kAccInLds) {
 #pragma unroll
     for (int a = 0; a < kAggSlots; ++a) { acc_lds->sum[a][threadIdx.x] = 0ull; acc_lds->umin[a][threadIdx.x] = 0xFFFFFFFFu; acc_lds->umax[a][threadIdx.x] = 0u; }
-    if constexpr (kFsm && kAggSlots == 1 && PG_FSM_COUNT_LDS != 0) reinterpret_cast<PrivateAccLdsOne*>(acc_lds)->count[threadIdx.x] = 0u;
   }
 
   // (Early "touch" loads of the next column chunks were tried and lost 30 %: vmcnt retires in order, so a wave's own L2 hits
@@ -1994,8 +1984,7 @@ __device__ __forceinline__ void scan_private_body(const P& p, const uint32_t blo
     // docs past numDocs (last tile only)
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
     if (p.out_bitmap) ((GlobalWordsOut)reinterpret_cast<uint32_t*>(p.out_bitmap))[tile * 64 + lane] = m;
-    if constexpr (kFsm && kAggSlots == 1 && PG_FSM_COUNT_LDS != 0) reinterpret_cast<PrivateAccLdsOne*>(acc_lds)->count[threadIdx.x] += (unsigned)__builtin_popcount(m);
-    else count += (unsigned)__builtin_popcount(m);
+    count += (unsigned)__builtin_popcount(m);
     if (p.num_agg_cols == 0 || __builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
     // one instance of the width dispatch for all slots (a runtime loop: unrolling it four times quadruples the code and keeps
     // ~190 VGPRs live); the per-slot accumulators are selected with wave-uniform predicates
@@ -2030,7 +2019,6 @@ __device__ __forceinline__ void scan_private_body(const P& p, const uint32_t blo
   }
 
   flush_filter_entries(p, entries);
-  if constexpr (kFsm && kAggSlots == 1 && PG_FSM_COUNT_LDS != 0) count += reinterpret_cast<PrivateAccLdsOne*>(acc_lds)->count[threadIdx.x];
   BlockPartial mine;
   partial_identity(mine);
   mine.count = (unsigned long long)wave_sum_i64((long long)count);
@@ -2064,10 +2052,9 @@ template <int kAggSlots>
 __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_FSM_WAVES) void scan_private_fsm_kernel(const ScanParams p) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
-  typedef typename std::conditional<kAggSlots == 1, PrivateAccLdsOne, PrivateAccLds<kAggSlots>>::type AccLds;
-  __shared__ AccLds acc;
+  __shared__ PrivateAccLds<kAggSlots> acc;
   __shared__ FsmWalkLds fsm_lds;
-  scan_private_body<kAggSlots, ScanParams, true, AccLds>(p, blockIdx.x, gridDim.x, red, &fold_flag, &acc, &fsm_lds);
+  scan_private_body<kAggSlots, ScanParams, true>(p, blockIdx.x, gridDim.x, red, &fold_flag, &acc, &fsm_lds);
 }
 
 // Many queries, one launch (pg_execute_batch): workgroups [block_first[i], block_first[i + 1]) work on items[i] -- its own columns,
