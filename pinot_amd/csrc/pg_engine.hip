@@ -957,6 +957,10 @@ struct Lowered {
   // an aggregation over a handful of survivors per window is done INSIDE it (gathered: no bitmap, no second kernel), everything else its
   // bitmap and window masks.  Lowering only prepares the kernel's arguments.
   bool and_pending = false, and_cardinality_only = false, gathered = false;
+  // dictId-set leaves (IN lists): where the words were uploaded for THIS context, and the host's copy -- a batch's shared launch reads them
+  // from the batch's own blob instead (enqueue_deferred), so such an item is not tied to a context
+  struct SetLeaf { const uint32_t* ctx_words; const uint32_t* host_words; uint32_t bytes; };
+  std::vector<SetLeaf> set_leaves;
   bool cardinality_atomic = false;             // index_and_kernel added its figures to the context's counter lines (launch_index_and; read_index_and_shards)
   int and_num_cus = 256;                       // the segment's CUs (pg_segment.num_cus): index_and_kernel's persistent grid is sized by them
   IndexAndParams and_params;
@@ -1511,7 +1515,14 @@ pg_status lower_filter(pg_segment* seg, ExecCtx* ctx, const pg_query* q, Lowered
           size_t bytes = (size_t)pr.num_set_words * 4;
           pg_status st = ensure_set(ctx, set_idx, bytes);
           if (st != PG_OK) return st;
-          if (bytes) { HIP_TRY(mark_pre_work(ctx)); HIP_TRY(hipMemcpyAsync(ctx->d_sets[set_idx], pr.set_words, bytes, hipMemcpyHostToDevice, ctx->stream)); }
+          if (bytes) {
+            // (the upload alone does not tie the query to this context: pg_execute_batch's shared launch carries the words itself)
+            const bool tied = ctx->pre_enqueued;
+            HIP_TRY(mark_pre_work(ctx));
+            ctx->pre_enqueued = tied;
+            HIP_TRY(hipMemcpyAsync(ctx->d_sets[set_idx], pr.set_words, bytes, hipMemcpyHostToDevice, ctx->stream));
+            lw->set_leaves.push_back(Lowered::SetLeaf{ctx->d_sets[set_idx], pr.set_words, (uint32_t)bytes});
+          }
           // the host words may go out of scope as soon as pg_execute returns; the copy is ordered before the kernel
           // on the same stream and the caller's buffer is read synchronously for pageable memory.
           L.kind = kLeafDictSet; L.col = s; L.set_words = ctx->d_sets[set_idx]; L.set_bytes = (int32_t)bytes;
@@ -2577,6 +2588,7 @@ struct LoweredItem {
   bool one_slot = true;
   std::function<void(const BlockPartial&, pg_result*)> convert;
   std::vector<int> plane_columns;                 // value planes sp reads: held (PlaneHold) by every batch that launches this item
+  std::vector<Lowered::SetLeaf> sets;             // dictId-set leaves of sp: nodes whose set_words == ctx_words read the batch's copy of host_words (which the item's query owns)
   // lean_kind 6 (group_lds_batch_kernel): the item is a GroupParams; its table slice is count[G] | acc[NA][G], zero-identity keys
   std::shared_ptr<GroupParams> gp;
   int group_threads = 0;
@@ -3223,6 +3235,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         item->one_slot = pl.num_agg_cols <= 1;
         item->convert = convert;
         item->plane_columns = planes.columns;
+        item->sets = lw.set_leaves;
         if (hist_item) { item->hist_lds = hist_lds; item->hist_cw = hist_cw; item->hist_col = hist_col; }
         defer->item = std::move(item);
         defer->cacheable = !lw.plane_pending;
@@ -3534,6 +3547,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       item->group_lds = plds;
       item->group_table_words = ((size_t)gp.num_groups * (size_t)(1 + gp.num_group_aggs) + 31) & ~(size_t)31;      // (slices start on 256-byte boundaries)
       item->plane_columns = planes.columns;
+      item->sets = lw.set_leaves;
       const int G = gp.num_groups, NA = gp.num_group_aggs;
       int agg_kind[kMaxGroupAggs] = {};
       for (int a = 0; a < NA; ++a) agg_kind[a] = gp.group_aggs[a].kind;
@@ -4715,6 +4729,7 @@ struct BatchCtx {
   ScanParams* h_items = nullptr; ScanParams* d_items = nullptr;
   uint32_t* h_first = nullptr; uint32_t* d_first = nullptr;
   HostRecord* h_records = nullptr; HostRecord* h_records_dev = nullptr;  // pinned, device-mapped: one folded record per item
+  size_t sets_offset = 0, set_capacity = 0;    // the blob's last part: the items' dictId sets (IN lists), uploaded with the items
   uint32_t* d_done = nullptr;                                            // kFoldShards + 1 arrival counters per item
   BlockPartial* d_partials = nullptr;
   int item_capacity = 0;
@@ -4744,13 +4759,15 @@ void destroy_batch_ctx(BatchCtx* b) {
   delete b;
 }
 
-pg_status ensure_batch_ctx(BatchCtx* b, int items, size_t partials) {
+pg_status ensure_batch_ctx(BatchCtx* b, int items, size_t partials, size_t set_bytes = 0 /* the items' dictId sets, behind the item slots */) {
   if (!b->stream) {
     HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
   }
-  if (b->item_capacity < items) {
-    const int cap = std::max(items, 64);
+  if (b->item_capacity < items || b->set_capacity < set_bytes) {
+    const int cap = std::max({items, b->item_capacity, 64});
+    const size_t set_cap = set_bytes > b->set_capacity ? std::max<size_t>(set_bytes * 2, 64 * 1024) : b->set_capacity;
+    if (b->stream) HIP_TRY(hipStreamSynchronize(b->stream));      // (nothing of the last launch may still read the blob)
     if (b->h_blob) (void)hipHostFree(b->h_blob);
     if (b->d_blob) (void)hipFree(b->d_blob);
     if (b->h_records) (void)hipHostFree(b->h_records);
@@ -4758,7 +4775,9 @@ pg_status ensure_batch_ctx(BatchCtx* b, int items, size_t partials) {
     b->h_blob = nullptr; b->d_blob = nullptr; b->h_items = nullptr; b->d_items = nullptr; b->h_first = nullptr; b->d_first = nullptr; b->h_records = nullptr; b->d_done = nullptr;
     b->item_capacity = 0;
     b->items_offset = (4 * (size_t)(cap + 1) + 255) & ~(size_t)255;
-    const size_t blob_bytes = b->items_offset + kBatchItemSlot * (size_t)cap;
+    b->sets_offset = b->items_offset + kBatchItemSlot * (size_t)cap;
+    const size_t blob_bytes = b->sets_offset + set_cap;
+    b->set_capacity = set_cap;
     HIP_TRY(hipHostMalloc((void**)&b->h_blob, blob_bytes, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void**)&b->d_blob, blob_bytes));
     memset(b->h_blob, 0, blob_bytes);
@@ -4852,6 +4871,22 @@ struct DeferredLaunch {
 
 // The group-by items of one device (lean_kind 6): one launch of group_lds_batch_kernel over the items' GroupParams, each with a slice of the
 // context's table; then ONE copy of all slices to the pinned host image and a memset that leaves the table all-zero for the next launch.
+// The dictId sets (IN lists) of a deferred item ride in the batch's blob: copied behind the item slots, the item's leaves pointed at the copy
+// (they were lowered against the words of a context the item is no longer tied to).  *set_off: bytes of the set area used so far.
+static size_t item_set_bytes(const LoweredItem& d) {
+  size_t bytes = 0;
+  for (const auto& sl : d.sets) bytes += ((size_t)sl.bytes + 15) & ~(size_t)15;
+  return bytes;
+}
+static void place_item_sets(BatchCtx* b, const LoweredItem& d, ScanParams* sp, size_t* set_off) {
+  for (const auto& sl : d.sets) {
+    memcpy(b->h_blob + b->sets_offset + *set_off, sl.host_words, sl.bytes);
+    const uint32_t* d_words = reinterpret_cast<const uint32_t*>(b->d_blob + b->sets_offset + *set_off);
+    for (int nd = 0; nd < sp->num_nodes; ++nd)
+      if (sp->nodes[nd].op == PG_FILTER_LEAF && sp->nodes[nd].kind == kLeafDictSet && sp->nodes[nd].set_words == sl.ctx_words) sp->nodes[nd].set_words = d_words;
+    *set_off += ((size_t)sl.bytes + 15) & ~(size_t)15;
+  }
+}
 pg_status enqueue_group_launch(DeferredLaunch* L, BatchCtx* b, std::vector<Deferred>& defs, pg_segment* const* segments) {
   const std::vector<int>& items = L->items;
   const int n = L->n;
@@ -4882,7 +4917,9 @@ pg_status enqueue_group_launch(DeferredLaunch* L, BatchCtx* b, std::vector<Defer
     total_blocks += blocks[(size_t)k];
   }
   L->total_blocks = total_blocks;
-  pg_status st = ensure_batch_ctx(b, n, 0);
+  size_t set_bytes = 0, set_off = 0;
+  for (int i : items) set_bytes += item_set_bytes(*defs[(size_t)i].item);
+  pg_status st = ensure_batch_ctx(b, n, 0, set_bytes);
   if (st != PG_OK) return st;
   if (b->gtable_capacity < table_words) {
     if (b->d_gtable) (void)hipFree(b->d_gtable);
@@ -4906,6 +4943,7 @@ pg_status enqueue_group_launch(DeferredLaunch* L, BatchCtx* b, std::vector<Defer
     const LoweredItem& d = *defs[(size_t)items[(size_t)k]].item;
     GroupParams& gp = h_items[k];                 // (the pinned copy the device reads: filled in place)
     gp = *d.gp;
+    place_item_sets(b, d, &gp.scan, &set_off);
     gp.table_count = b->d_gtable + off;
     gp.table_acc = reinterpret_cast<long long*>(b->d_gtable + off + (size_t)gp.num_groups);
     L->table_offsets[(size_t)k] = off;
@@ -4917,6 +4955,7 @@ pg_status enqueue_group_launch(DeferredLaunch* L, BatchCtx* b, std::vector<Defer
   L->timed = (g_engine.flags & PG_CFG_TIME_KERNELS) != 0;
   L->t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipMemcpyAsync(b->d_blob, b->h_blob, b->items_offset + sizeof(GroupParams) * (size_t)n, hipMemcpyHostToDevice, b->stream));
+  if (set_off) HIP_TRY(hipMemcpyAsync(b->d_blob + b->sets_offset, b->h_blob + b->sets_offset, set_off, hipMemcpyHostToDevice, b->stream));
   if (L->timed) HIP_TRY(hipEventRecord(b->ev[0], b->stream));
   b->gtable_dirty = true;
   launch_group_lds_batch((int)total_blocks, threads, launch_lds, b->stream, d_items, b->d_first, n);
@@ -5064,14 +5103,17 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
     one_slot = one_slot && d.one_slot;
   }
   L->total_blocks = total_blocks;
-  pg_status st = ensure_batch_ctx(b, n, partials);
+  size_t set_bytes = 0;
+  for (int i : items) set_bytes += item_set_bytes(*defs[(size_t)i].item);
+  pg_status st = ensure_batch_ctx(b, n, partials, set_bytes);
   if (st != PG_OK) return st;
-  size_t off = 0;
+  size_t off = 0, set_off = 0;
   uint32_t first = 0;
   const unsigned long long seq = L->seq = ++b->seq;
   for (int k = 0; k < n; ++k) {
     ScanParams& sp = b->h_items[k];               // (the pinned copy the device reads: filled in place)
     sp = defs[(size_t)items[(size_t)k]].item->sp;
+    place_item_sets(b, *defs[(size_t)items[(size_t)k]].item, &sp, &set_off);
     sp.partials = b->d_partials + off;
     off += (size_t)blocks[(size_t)k] + (size_t)kFoldExtraRecords;
     sp.done_counter = b->d_done + (size_t)k * (kFoldShards + 1) * kFoldStride;
@@ -5084,6 +5126,7 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
   L->timed = (g_engine.flags & PG_CFG_TIME_KERNELS) != 0;
   L->t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipMemcpyAsync(b->d_blob, b->h_blob, b->items_offset + sizeof(ScanParams) * (size_t)n, hipMemcpyHostToDevice, b->stream));
+  if (set_off) HIP_TRY(hipMemcpyAsync(b->d_blob + b->sets_offset, b->h_blob + b->sets_offset, set_off, hipMemcpyHostToDevice, b->stream));
   if (L->timed) HIP_TRY(hipEventRecord(b->ev[0], b->stream));
   if (hist_kind) launch_scan_hist_batch(hist_cw, (int)total_blocks, launch_lds, b->stream, b->d_items, b->d_first, n);
   else if (narrow_kind) launch_scan_narrow_batch(L->lean_kind == 8, (int)total_blocks, b->stream, b->d_items, b->d_first, n);

@@ -606,3 +606,30 @@ def test_index_led_items_share_one_launch(engine, shapes):
                 assert [(a.count, a.sum_i64, a.min, a.max) for a in res.aggregations] == [(a.count, a.sum_i64, a.min, a.max) for a in single.aggregations]
     finally:
         [g.close() for g in opened]
+
+
+def test_items_with_dictid_sets_share_the_launch_of_their_kind():
+    """IN lists ride in the batch's blob (round 6): items whose filters carry dictId-set leaves share the launch of their kind instead of
+    each running on a context of its own.  tools/batch_set_probe.py holds every answer against the oracle and pg_execute (twice: the second
+    call through the plan cache); PINOT_GPU_BATCH_TRACE says how many items every shared launch carried."""
+    import json
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PINOT_GPU_BATCH_TRACE="1")
+    proc = subprocess.run([sys.executable, os.path.join(root, "tools", "batch_set_probe.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    report = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert report["failed"] == [], report["failed"][:10]
+    # per shape: the largest shared launch of each of the two calls carried (nearly) all of the items -- a 1-doc or 2049-doc segment may
+    # be answered by a plan of its own
+    shape, largest = None, {}
+    for line in proc.stderr.splitlines():
+        if line.startswith("== shape "):
+            shape = line[len("== shape "):]
+        m = re.search(r"deferred (?:group-by )?launch on device \d+: (\d+) items", line)
+        if m and shape:
+            largest[shape] = max(largest.get(shape, 0), int(m.group(1)))
+    for name, items in report["shapes"].items():
+        assert largest.get(name, 0) >= items - 2, (name, largest, proc.stderr[-1500:])

@@ -219,7 +219,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
     # ---- the small-segment regime: 64 segments of 10 M rows (BASELINE.json configs[0]'s size), one query over all of them ----
     # (a) pg_execute_batch: one launch, every segment folds its own result; (b) the way BaseCombineOperator would drive pg_execute: 16
     # host threads, each with the next segment, every pg_execute on a stream of its own; (c) one pg_execute after the other.
-    c1x64_ids = ("C1x64-count-range", "C1x64-dict-sum", "C1x64-dict-sum-irregular", "C1x64-group-by", "C5x64", "C5x64-count")
+    c1x64_ids = ("C1x64-count-range", "C1x64-dict-sum", "C1x64-dict-sum-irregular", "C1x64-dict-sum-in-list", "C1x64-group-by", "C5x64", "C5x64-count")
     if any(want(x) for x in c1x64_ids):
         import ctypes as C
         import threading
@@ -248,6 +248,9 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                        lambda sd: Q.QuerySpec([(Q.SUM, 3)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), lambda sd: B(sd.columns[1]) + B(sd.columns[3])),
                       ("C1x64-group-by", "SELECT SUM(v), MAX(f) GROUP BY k (1000 groups)", lambda sd: Q.QuerySpec([(Q.SUM, 2), (Q.MAX, 1)], group_by=[4]),
                        lambda sd: B(sd.columns[1]) + B(sd.columns[2]) + B(sd.columns[4]))]
+            # an IN list of 100 of f's 1000 values (every third of the first 300): a dictId-set leaf -- the words ride in the batch's blob (round 6)
+            shapes.append(("C1x64-dict-sum-in-list", "SELECT SUM(v) WHERE f IN (100 values)",
+                           lambda sd: Q.QuerySpec([(Q.SUM, 2)], filter=Q.leaf(Q.Pred.dict_set(1, list(range(0, 300, 3)), 1000))), lambda sd: B(sd.columns[1]) + B(sd.columns[2])))
             inv = lambda c, d: Q.leaf(Q.Pred.dict_range(c, d, d + 1, inverted=True))
             posting = lambda sd, c: int(sd.columns[c].inverted.nbytes / sd.columns[c].cardinality)
             shapes += [("C5x64", "SELECT SUM(v) WHERE p=3 AND q=5 AND r=7 via inverted indexes (C = 16 / 64 / 256)",
