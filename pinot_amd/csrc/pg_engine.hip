@@ -2783,6 +2783,9 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
   ctx->ev_last = 3;
   if (out && !want_bitmap) lw.stats_plan = fstats::choose_plan(q, &lw.stats_scan_leaves);
   if (lw.stats_plan == fstats::Plan::kLeap2 && (!g_engine.leap2 || (q->flags & PG_QUERY_STATS_UPPER_BOUND_OK))) lw.stats_plan = fstats::Plan::kReplay;      // (kReplay with nobody replaying: the upper bound)
+  // the caller takes the upper bound (PG_QUERY_STATS_UPPER_BOUND_OK): a leap-frogging filter has no pass behind its kernel, so in a batch it shares the launch like any other
+  const bool stats_is_final = lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf ||
+                              (lw.stats_plan == fstats::Plan::kReplay && (q->flags & PG_QUERY_STATS_UPPER_BOUND_OK) != 0);
   lw.cardinality_only_hint = ng == 0 && out && !want_bitmap && na > 0;
   for (int a = 0; a < na; ++a) lw.cardinality_only_hint = lw.cardinality_only_hint && q->aggregations[a].function == PG_AGG_COUNT;
   lw.side = nullptr;
@@ -3222,7 +3225,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       const bool typed_item = use_private_typed && !use_raw && !use_sparse && g_engine.batch_more;
       if (!defer->single && ((use_private && !use_hist && !use_narrow) || use_raw || hist_item || narrow_item || typed_item) && !use_sparse && !want_bitmap && out && sp.tile_list == nullptr && !count_entries && !ctx->pre_enqueued && g_engine.direct_result &&
           lw.side == nullptr && ((long long)seg->num_docs + 2047) / 2048 <= kBatchMaxTiles &&
-          (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf)) {
+          stats_is_final) {
         // items of scan_simple_kernel's / scan_raw_kernel's shape share a launch of their own kind (scan_lean_batch_kernel), the rest the general one
         const bool lean_batch = g_engine.lean_batch;
         sp.lean_kind = hist_item ? (hist_cw == 8 ? 3 : (hist_cw == 16 ? 4 : 5)) : narrow_item ? (narrow_single ? 8 : 7) : typed_item ? (pl.num_agg_cols <= 1 ? 9 : (pl.num_agg_cols == 2 ? 10 : 11))
@@ -3535,7 +3538,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // count is not zero.  What GroupByCombineOperator.java:102-165 gets from one task per segment.
     if (defer != nullptr && g_engine.batch_group && use_private && gp.use_lds_table && hash_plan.kind == 0 && !first_appearance && !typed_direct && !want_bitmap && out &&
         lw.tile_list == nullptr && lw.side == nullptr && !lw.stats_leap2_flagged && !lw.stats_chain_flagged && !ctx->pre_enqueued &&
-        (lw.stats_plan == fstats::Plan::kZero || lw.stats_plan == fstats::Plan::kPerLeaf) &&
+        stats_is_final &&
         (long long)(q->num_groups_limit > 0 ? q->num_groups_limit : 100000) >= product && (defer->single || ((long long)seg->num_docs + 2047) / 2048 <= kBatchMaxTiles)) {
       auto item = std::make_shared<LoweredItem>();
       item->gp = std::make_shared<GroupParams>(gp);

@@ -43,6 +43,8 @@ def main():
         "narrow": lambda s: Q.QuerySpec([(Q.COUNT, -1)], filter=in_list(2, 40, 40 + s, 11)),
         # a group-by of the LDS-table form under an IN list (group_lds_batch_kernel)
         "group-by": lambda s: Q.QuerySpec([(Q.SUM, 3), (Q.MAX, 1)], filter=in_list(0, 900, 60 + s, 400), group_by=[2]),
+        # a leap-frogging root AND whose caller takes the statistic's upper bound (PG_QUERY_STATS_UPPER_BOUND_OK): no pass behind the kernel, so it shares too
+        "flagged-and": lambda s: Q.QuerySpec([(Q.SUM, 3), (Q.MAX, 0)], filter=Q.and_(in_list(0, 900, 70 + s, 300), Q.leaf(Q.Pred.dict_range(1, 0, 150))), stats_upper_bound_ok=True),
         # SUM through the LDS histogram (a dictionary without structure) under an IN list
         "hist": lambda s: Q.QuerySpec([(Q.SUM, 4)], filter=in_list(0, 900, 50 + s, 450)),
     }
@@ -58,7 +60,15 @@ def main():
                     ok = status == _abi.PG_OK
                     if ok:
                         try:
-                            H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
+                            if name.startswith("flagged"):      # numEntriesScannedInFilter is the upper bound there, by request
+                                plain = Q.QuerySpec(specs[s].aggregations, filter=specs[s].filter, group_by=specs[s].group_by)
+                                exact = opened[s].execute(plain)
+                                H.assert_results_equal(exact, oracle.execute(segs[s], plain))
+                                assert not res.filter_entries_exact and res.stats[1] == 2 * segs[s].num_docs
+                                assert (res.stats[0], res.stats[2], res.stats[3]) == (exact.stats[0], exact.stats[2], exact.stats[3])
+                                assert [(a.count, a.sum_i64, a.min, a.max) for a in res.aggregations] == [(a.count, a.sum_i64, a.min, a.max) for a in exact.aggregations]
+                            else:
+                                H.assert_results_equal(res, oracle.execute(segs[s], specs[s]))
                             single = opened[s].execute(specs[s])
                             ok = res.stats == single.stats and [(a.count, a.sum_i64, a.min, a.max) for a in res.aggregations] == [(a.count, a.sum_i64, a.min, a.max) for a in single.aggregations]
                         except AssertionError:
