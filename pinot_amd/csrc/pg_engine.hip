@@ -304,7 +304,7 @@ struct FsmSide {
   bool prepared = false;                        // prepare_fsm_side gave it the context's scratch
 };
 constexpr size_t kAndShardBytes = (size_t)pg::kAndCardinalityShards * 128;      // ExecCtx.d_and_counters + 2 / h_and_shards
-constexpr size_t kFsmStageBytes = 64 + 2 * ((size_t)pg::kFsmStates << pg::kFsmInputs);      // ExecCtx.h_fsm_stage: the two counts | delta | marks
+constexpr size_t kFsmStageBytes = 64 + (1 + (size_t)fstats::kFsmMaxEpisodeStreams) * ((size_t)pg::kFsmStates << pg::kFsmInputs);      // ExecCtx.h_fsm_stage: the two counts | delta | marks of every episode stream
 
 namespace {
 
@@ -4373,7 +4373,7 @@ static pg_status replay_filter_stats(pg_segment* seg, const pg_query* q, pg_resu
 // doc-order bitmap, the transducer's tables are built tile by tile and chained (pg_fsm_kernels.h).  Nothing but the count comes back.
 // Layout of the pass's scratch (ExecCtx.d_fsm_scratch): L bitmaps of whole tiles | delta | tile tables | chunk tables | the count --
 // and, for a machine with a NOT child (Fsm::marks: the episodes of pg_fsm_kernels.h), from the next 256-byte boundary on:
-// episode count + final-pending flag | marks | chunk states | tile states | the tiles' unpaired closes | the tiles' last opens.
+// episode count + final-pending flags | marks of every episode stream | chunk states | tile states | the tiles' unpaired closes | the tiles' last opens.
 struct FsmScratch {
   size_t bitmap_bytes = 0, delta_bytes = 0, tables_bytes = 0, chunk_bytes = 0, total = 0;
   size_t episode_base = 0, chunk_state_bytes = 0, tile_state_bytes = 0, tile_pos_bytes = 0;
@@ -4391,7 +4391,7 @@ struct FsmScratch {
       chunk_state_bytes = ((size_t)chunks + 255) & ~(size_t)255;
       tile_state_bytes = ((size_t)tiles + 255) & ~(size_t)255;
       tile_pos_bytes = ((size_t)tiles * 4 + 255) & ~(size_t)255;
-      total = episode_base + 256 + delta_bytes + chunk_state_bytes + tile_state_bytes + 2 * tile_pos_bytes;
+      total = episode_base + 256 + delta_bytes * (size_t)fsm.num_episode_streams() + chunk_state_bytes + tile_state_bytes + 2 * tile_pos_bytes;
     }
   }
 };
@@ -4438,7 +4438,7 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
   auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   const auto t_begin = now();
   uint8_t* d_base = ctx->d_fsm_scratch;
-  if ((((size_t)fsm.num_states << fsm.num_inputs) * 2 + 64) > kFsmStageBytes) return fail(PG_ERR_INTERNAL, "transducer tables exceed the pinned staging area");
+  if ((((size_t)fsm.num_states << fsm.num_inputs) * (size_t)(1 + fsm.num_episode_streams()) + 64) > kFsmStageBytes) return fail(PG_ERR_INTERNAL, "transducer tables exceed the pinned staging area");
   FsmParams fp;
   memset(&fp, 0, sizeof(fp));
   int scanned_again = 0;
@@ -4512,19 +4512,26 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
     // tables of the count, walked downwards, give every tile its entry state; a second walk of the docs pairs the opens and the closes.
     uint8_t* eb = d_base + lay.episode_base;
     unsigned long long* d_episodes = reinterpret_cast<unsigned long long*>(eb);
-    int32_t* d_final_pending = reinterpret_cast<int32_t*>(eb + 8);
-    uint8_t* d_marks = eb + 256;
-    uint8_t* d_chunk_state = d_marks + lay.delta_bytes;
+    const int streams = fsm.num_episode_streams();
+    uint8_t* d_marks_base = eb + 256;
+    uint8_t* d_chunk_state = d_marks_base + lay.delta_bytes * (size_t)streams;
     uint8_t* d_tile_state = d_chunk_state + lay.chunk_state_bytes;
     int32_t* d_first_close = reinterpret_cast<int32_t*>(d_tile_state + lay.tile_state_bytes);
     int32_t* d_last_open = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(d_first_close) + lay.tile_pos_bytes);
-    HIP_TRY(hipMemsetAsync(eb, 0, 16, stream));
-    memcpy(h_marks, fsm.marks.data(), (size_t)S << L);
-    HIP_TRY(hipMemcpyAsync(d_marks, h_marks, (size_t)S << L, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(eb, 0, 64, stream));
     fsm_chunk_states_kernel<<<dim3(1), dim3(1024), (size_t)chunks * (size_t)S * 4, stream>>>(d_chunks, (int)chunks, S, d_chunk_state);
     HIP_TRY(hipGetLastError());
     fsm_tile_states_kernel<<<dim3((unsigned)chunks), dim3(1024), 0, stream>>>(d_tables, tiles, S, d_chunk_state, d_tile_state);
     HIP_TRY(hipGetLastError());
+    // every NOT child over a scan leaf has an episode stream of its own: the same machine and entry states, its own marks, its own
+    // final-pending flag; the streams' entries add up in *d_episodes (the kernels add into it)
+    for (int k = 0; k < streams; ++k) {
+    uint8_t* const d_marks = d_marks_base + lay.delta_bytes * (size_t)k;
+    uint8_t* const h_marks_k = h_marks + ((size_t)S << L) * (size_t)k;
+    int32_t* const d_final_pending = reinterpret_cast<int32_t*>(eb + 8) + k;
+    const uint32_t pending_states = fsm.stream_pending(k);
+    memcpy(h_marks_k, fsm.stream_marks(k).data(), (size_t)S << L);
+    HIP_TRY(hipMemcpyAsync(d_marks, h_marks_k, (size_t)S << L, hipMemcpyHostToDevice, stream));
     if (perm_walk && S <= 8 && L <= 4) {
       // machines of at most eight states over at most four inputs: byte functions, a scan over the wavefront, a contiguous range of tiles per
       // wavefront -- one record per RANGE for the finish kernel (pg_fsm_kernels.h "Round 6")
@@ -4535,7 +4542,7 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
       rp.delta = d_delta; rp.marks = d_marks; rp.tile_state = d_tile_state;
       rp.range_first_close = d_first_close; rp.range_last_open = d_last_open;
       rp.episode_entries = d_episodes; rp.final_pending = d_final_pending;
-      rp.pending_states = fsm.pending_states;
+      rp.pending_states = pending_states;
       rp.num_inputs = L; rp.num_states = S; rp.num_docs = seg->num_docs; rp.num_tiles = (int32_t)tiles; rp.num_ranges = (int32_t)num_ranges;
       const dim3 rgrid((unsigned)((num_ranges + 3) / 4));
       if (S <= 4) { if (L <= 2) fsm_episode_ranges_kernel<4, 2><<<rgrid, dim3(256), 0, stream>>>(rp); else fsm_episode_ranges_kernel<4, 4><<<rgrid, dim3(256), 0, stream>>>(rp); }
@@ -4550,12 +4557,13 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
       ep.delta = d_delta; ep.marks = d_marks; ep.tile_state = d_tile_state;
       ep.tile_first_close = d_first_close; ep.tile_last_open = d_last_open;
       ep.episode_entries = d_episodes; ep.final_pending = d_final_pending;
-      ep.pending_states = fsm.pending_states;
+      ep.pending_states = pending_states;
       ep.num_inputs = L; ep.num_states = S; ep.num_docs = seg->num_docs; ep.num_tiles = (int32_t)tiles;
       fsm_episode_tiles_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(ep);
       HIP_TRY(hipGetLastError());
       fsm_episode_finish_kernel<<<dim3(1), dim3(1024), 0, stream>>>(d_first_close, d_last_open, (int)tiles, seg->num_docs, d_final_pending, d_episodes);
       HIP_TRY(hipGetLastError());
+    }
     }
     HIP_TRY(hipMemcpyAsync(ctx->h_fsm_stage + 8, d_episodes, 8, hipMemcpyDeviceToHost, stream));
   }

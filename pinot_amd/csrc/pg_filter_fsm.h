@@ -45,8 +45,16 @@ struct Fsm {
   // A NOT child over a scan leaf (see "NOT children" below): the batches its leaf scans are charged per EPISODE, not per doc.
   std::vector<uint8_t> marks;          // [S << L] kMarkOpen / kMarkClose / 0; empty when the machine has no episodes
   uint32_t pending_states = 0;         // bit s: in state s an episode is open (the leaf's next() is scanning ahead) -- what the end of the docs closes
+  // Further NOT children over scan leaves (round 6b): every such child has an episode stream of its own -- the same machine (delta), its
+  // own marks and pending states; the episode pass runs once per stream.  `marks` / `pending_states` above are the first child's.
+  struct EpisodeStream { std::vector<uint8_t> marks; uint32_t pending_states = 0; };
+  std::vector<EpisodeStream> more_streams;
   bool has_episodes() const { return !marks.empty(); }
+  int num_episode_streams() const { return marks.empty() ? 0 : 1 + (int)more_streams.size(); }
+  const std::vector<uint8_t>& stream_marks(int k) const { return k == 0 ? marks : more_streams[(size_t)k - 1].marks; }
+  uint32_t stream_pending(int k) const { return k == 0 ? pending_states : more_streams[(size_t)k - 1].pending_states; }
 };
+constexpr int kFsmMaxEpisodeStreams = 3;
 constexpr uint8_t kMarkOpen = 1, kMarkClose = 2;
 
 // What an episode costs: the leaf's next() scans whole batches of kScanBatch = 256 docs (pg_filter_stats.h) from `origin` until the batch that holds the first match it
@@ -92,7 +100,9 @@ inline bool contains(const Child& c, unsigned input) {
 //                 (mark kMarkOpen: origin = that doc + 1) -> pending; if nobody asks, the child is stale again.
 // The constructor pulls next() once: doc 0 is entered pending, origin 0.  An episode's batches are a function of its origin and of the
 // doc that closes it (episode_entries above) -- the batch phase never becomes part of the state; the walk only has to say where episodes
-// open and close, and they alternate.  One such child per machine.
+// open and close, and they alternate.  Every such child keeps its own three states and its own episode stream (at most
+// kFsmMaxEpisodeStreams per machine): `not_state` holds one base-3 digit per NOT child over a scan leaf, in child order, and step()'s
+// `mark` two bits per stream.
 constexpr int kNotPending = 0, kNotStale = 1, kNotAdvancing = 2;
 
 struct State { int leader; int fresh; unsigned open; int not_state; };
@@ -130,24 +140,30 @@ inline State step(const Model& m, State s, unsigned input, int* entries, int* ma
       out.open = (out.open & ~(1u << bit)) | ((still_open ? 1u : 0u) << bit);
     }
   }
-  int mk = 0;
+  int mk = 0, stream = 0, digit_weight = 1;
   for (int c = 0; c < k; ++c) {
     const Child& ch = m.children[(size_t)c];
     if (ch.kind != Child::kNot || !ch.members[0].scan) continue;      // (NOT over an index-based leaf: a bitmap iterator underneath, nothing is counted)
     const bool is_asked = asked[(size_t)c] || s.leader == c;          // (a leading child is asked about every doc it leads over)
     const bool match = (input >> ch.members[0].input) & 1u;
-    switch (s.not_state) {
+    const int mine = (s.not_state / digit_weight) % 3;
+    int next_mine = mine, my_mark = 0;
+    switch (mine) {
       case kNotPending:
-        if (match && !is_asked) { mk = kMarkClose; out.not_state = kNotStale; }
+        if (match && !is_asked) { my_mark = kMarkClose; next_mine = kNotStale; }
         break;                                                        // (a match that is asked about is handed on: next() again, the episode goes on)
       case kNotStale:
-        if (is_asked) { inc += 1; if (match) { mk = kMarkOpen; out.not_state = kNotPending; } else out.not_state = kNotAdvancing; }
+        if (is_asked) { inc += 1; if (match) { my_mark = kMarkOpen; next_mine = kNotPending; } else next_mine = kNotAdvancing; }
         break;
       default:                                                        // kNotAdvancing
         inc += 1;
-        if (match) { if (is_asked) { mk = kMarkOpen; out.not_state = kNotPending; } else out.not_state = kNotStale; }
+        if (match) { if (is_asked) { my_mark = kMarkOpen; next_mine = kNotPending; } else next_mine = kNotStale; }
         break;
     }
+    out.not_state += (next_mine - mine) * digit_weight;
+    mk |= my_mark << (2 * stream);
+    digit_weight *= 3;
+    ++stream;
   }
   *entries = inc;
   if (mark) *mark = mk;
@@ -179,7 +195,7 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
   };
   struct Raw { Child child; bool index; };
   std::vector<Raw> raw;
-  bool has_not_scan = false;
+  int num_not_scan = 0;
   for (int kid : tb.children_of(root)) {
     Raw r;
     r.index = false;
@@ -217,7 +233,7 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
       if (under.size() != 1 || !leaf_of(under[0], &l)) return false;
       r.child.kind = Child::kNot;
       r.child.members.push_back(l);
-      if (l.scan) { if (has_not_scan) return false; has_not_scan = true; }      // one episode stream per machine
+      if (l.scan && ++num_not_scan > kFsmMaxEpisodeStreams) return false;      // an episode stream per such child
     } else {
       return false;                                             // nested AND under the root AND: the host replay's
     }
@@ -254,21 +270,26 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
   std::vector<State> states;
   id[State{0, 1, 0u, kNotPending}] = 0;                         // (NotDocIdIterator's constructor has pulled next(): an episode from doc 0)
   states.push_back(State{0, 1, 0u, kNotPending});
-  std::vector<std::vector<uint8_t>> rows, mark_rows;
+  // (ids of the REACHABLE states are 16 bits wide: a machine with two NOT children reaches 19-34 states that minimise to 15 -- the
+  //  kFsmMaxStates bound is applied to what the minimisation leaves)
+  constexpr int kFsmMaxReachable = 64;
+  std::vector<std::vector<uint16_t>> rows;                      // next state's id | entries << 12
+  std::vector<std::vector<uint8_t>> mark_rows;
   for (size_t at = 0; at < states.size(); ++at) {
-    std::vector<uint8_t> row((size_t)1 << L), mark_row((size_t)1 << L);
+    std::vector<uint16_t> row((size_t)1 << L);
+    std::vector<uint8_t> mark_row((size_t)1 << L);
     for (unsigned input = 0; input < (1u << L); ++input) {
       int inc = 0, mk = 0;
       const State nxt = step(m, states[at], input, &inc, &mk);
       mark_row[input] = (uint8_t)mk;
       auto it = id.find(nxt);
       if (it == id.end()) {
-        if ((int)states.size() >= kFsmMaxStates) return false;
+        if ((int)states.size() >= kFsmMaxReachable) return false;
         it = id.emplace(nxt, (int)states.size()).first;
         states.push_back(nxt);
       }
       if (inc > 15) return false;
-      row[input] = (uint8_t)(it->second | (inc << 4));
+      row[input] = (uint16_t)(it->second | (inc << 12));
     }
     rows.push_back(std::move(row));
     mark_rows.push_back(std::move(mark_row));
@@ -280,15 +301,23 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
   std::vector<int> cls((size_t)S0, 0);
   // (with a NOT child: the end of the docs closes an open episode -- an output of the STATE; pending and other states start in different classes)
   int num_start = 1;
-  if (has_not_scan) {
-    for (int st = 0; st < S0; ++st) { cls[(size_t)st] = states[(size_t)st].not_state == kNotPending ? 0 : 1; num_start = std::max(num_start, cls[(size_t)st] + 1); }
+  auto pending_mask = [&](int st) {                            // bit k: stream k's episode is open in this state
+    unsigned mask = 0;
+    int v = states[(size_t)st].not_state;
+    for (int k = 0; k < num_not_scan; ++k, v /= 3) mask |= (v % 3 == kNotPending ? 1u : 0u) << k;
+    return mask;
+  };
+  if (num_not_scan > 0) {
+    std::map<unsigned, int> start_id;                          // numbered by first appearance: state 0 (everything pending) is class 0
+    for (int st = 0; st < S0; ++st) cls[(size_t)st] = start_id.emplace(pending_mask(st), (int)start_id.size()).first->second;
+    num_start = (int)start_id.size();
   }
   for (int num_classes = num_start;;) {
     std::map<std::vector<int>, int> sig_id;
     std::vector<int> next_cls((size_t)S0, 0);
     for (int st = 0; st < S0; ++st) {
       std::vector<int> sig{cls[(size_t)st]};
-      for (unsigned input = 0; input < (1u << L); ++input) { const uint8_t d = rows[(size_t)st][input]; sig.push_back((d >> 4) | (mark_rows[(size_t)st][input] << 8)); sig.push_back(cls[(size_t)(d & 15)]); }
+      for (unsigned input = 0; input < (1u << L); ++input) { const uint16_t d = rows[(size_t)st][input]; sig.push_back((d >> 12) | (mark_rows[(size_t)st][input] << 8)); sig.push_back(cls[(size_t)(d & 0xFFF)]); }
       next_cls[(size_t)st] = sig_id.emplace(std::move(sig), (int)sig_id.size()).first->second;
     }
     cls = next_cls;
@@ -296,30 +325,36 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
     num_classes = (int)sig_id.size();
   }
   const int S = 1 + *std::max_element(cls.begin(), cls.end());
+  if (S > kFsmMaxStates) return false;
   out->num_inputs = L;
   out->input_predicate = input_predicate;
   out->num_states = S;
   out->delta.assign((size_t)S << L, 0);
   for (int st = 0; st < S0; ++st)
     for (unsigned input = 0; input < (1u << L); ++input) {
-      const uint8_t d = rows[(size_t)st][input];
-      out->delta[((size_t)cls[(size_t)st] << L) | input] = (uint8_t)(cls[(size_t)(d & 15)] | (d & 0xF0));
+      const uint16_t d = rows[(size_t)st][input];
+      out->delta[((size_t)cls[(size_t)st] << L) | input] = (uint8_t)(cls[(size_t)(d & 0xFFF)] | ((d >> 12) << 4));
     }
   out->marks.clear();
   out->pending_states = 0;
-  if (has_not_scan) {
-    out->marks.assign((size_t)S << L, 0);
+  out->more_streams.clear();
+  for (int k = 0; k < num_not_scan; ++k) {
+    std::vector<uint8_t> marks((size_t)S << L, 0);
+    uint32_t pending = 0;
     for (int st = 0; st < S0; ++st) {
-      for (unsigned input = 0; input < (1u << L); ++input) out->marks[((size_t)cls[(size_t)st] << L) | input] = mark_rows[(size_t)st][input];
-      if (states[(size_t)st].not_state == kNotPending) out->pending_states |= 1u << cls[(size_t)st];
+      for (unsigned input = 0; input < (1u << L); ++input) marks[((size_t)cls[(size_t)st] << L) | input] = (uint8_t)((mark_rows[(size_t)st][input] >> (2 * k)) & 3);
+      if ((pending_mask(st) >> k) & 1u) pending |= 1u << cls[(size_t)st];
     }
+    if (k == 0) { out->marks = std::move(marks); out->pending_states = pending; }
+    else { Fsm::EpisodeStream es; es.marks = std::move(marks); es.pending_states = pending; out->more_streams.push_back(std::move(es)); }
   }
   return true;
 }
 
 // The walk itself, doc by doc (reference for the tiled form below).
 inline int64_t fsm_count_sequential(const Fsm& f, const std::vector<const uint64_t*>& leaf_words, int32_t num_docs) {
-  int64_t entries = 0, origin = 0;                               // (origin: of the episode that is open, when the machine has episodes)
+  const int streams = f.num_episode_streams();
+  int64_t entries = 0, origin[kFsmMaxEpisodeStreams] = {0, 0, 0};      // (origin: of the episode that is open, per NOT child over a scan leaf)
   int state = 0;
   for (int32_t x = 0; x < num_docs; ++x) {
     unsigned input = 0;
@@ -328,12 +363,13 @@ inline int64_t fsm_count_sequential(const Fsm& f, const std::vector<const uint64
     const uint8_t d = f.delta[at];
     entries += d >> 4;
     state = d & 15;
-    if (f.has_episodes()) {
-      if (f.marks[at] == kMarkClose) entries += episode_entries(origin, x, num_docs);
-      else if (f.marks[at] == kMarkOpen) origin = (int64_t)x + 1;
+    for (int k = 0; k < streams; ++k) {
+      const uint8_t mk = f.stream_marks(k)[at];
+      if (mk == kMarkClose) entries += episode_entries(origin[k], x, num_docs);
+      else if (mk == kMarkOpen) origin[k] = (int64_t)x + 1;
     }
   }
-  if (f.has_episodes() && ((f.pending_states >> state) & 1u)) entries += episode_entries(origin, num_docs, num_docs);
+  for (int k = 0; k < streams; ++k) if ((f.stream_pending(k) >> state) & 1u) entries += episode_entries(origin[k], num_docs, num_docs);
   return entries;
 }
 
@@ -387,8 +423,15 @@ inline int64_t fsm_count_tiled(const Fsm& f, const std::vector<const uint64_t*>&
 // pairs every close with the last open in front of it inside the tile and keeps, per tile, the close that has none (there is at most one:
 // opens and closes alternate) and its last open; fsm_episode_finish_kernel pairs those across tiles and closes what the end of the docs
 // leaves open.  Returns the episodes' entries only (fsm_count_tiled counts the per-doc ones).
-inline int64_t fsm_episode_entries_tiled(const Fsm& f, const std::vector<const uint64_t*>& leaf_words, int32_t num_docs) {
+inline int64_t fsm_episode_entries_tiled(const Fsm& f, const std::vector<const uint64_t*>& leaf_words, int32_t num_docs, int stream = -1) {
   if (!f.has_episodes() || num_docs <= 0) return 0;
+  if (stream < 0) {                                             // every NOT child's stream: the pass once per stream, like the device
+    int64_t all = 0;
+    for (int k = 0; k < f.num_episode_streams(); ++k) all += fsm_episode_entries_tiled(f, leaf_words, num_docs, k);
+    return all;
+  }
+  const std::vector<uint8_t>& marks = f.stream_marks(stream);
+  const uint32_t pending_states = f.stream_pending(stream);
   const int S = f.num_states, L = f.num_inputs;
   const int64_t num_tiles = ((int64_t)num_docs + 2047) / 2048;
   auto lane_words = [&](int64_t first, int docs, uint32_t* w) { for (int i = 0; i < L; ++i) w[i] = docs > 0 ? (uint32_t)(leaf_words[(size_t)i][(size_t)first >> 6] >> (first & 63)) : 0u; };
@@ -424,11 +467,11 @@ inline int64_t fsm_episode_entries_tiled(const Fsm& f, const std::vector<const u
       int st = cur;
       for (int d = 0; d < docs; ++d) {
         const size_t at = ((size_t)st << L) | input_of(w, d);
-        open_word |= (f.marks[at] == kMarkOpen ? 1u : 0u) << d;
-        close_word |= (f.marks[at] == kMarkClose ? 1u : 0u) << d;
+        open_word |= (marks[at] == kMarkOpen ? 1u : 0u) << d;
+        close_word |= (marks[at] == kMarkClose ? 1u : 0u) << d;
         st = f.delta[at] & 15;
       }
-      if (docs > 0 && first + docs == (int64_t)num_docs) final_pending = (int)((f.pending_states >> st) & 1u);      // the lane that holds the last doc
+      if (docs > 0 && first + docs == (int64_t)num_docs) final_pending = (int)((pending_states >> st) & 1u);      // the lane that holds the last doc
       for (uint32_t cw = close_word; cw != 0; cw &= cw - 1) {
         const int d = __builtin_ctz(cw);
         const uint32_t below = open_word & ((1u << d) - 1u);

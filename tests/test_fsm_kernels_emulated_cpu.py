@@ -81,12 +81,14 @@ def leaves():
 @pytest.mark.parametrize("n", [1, 33, 2049, 5000, 70_003])
 def test_the_kernels_source_equals_the_oracle(emu, n):
     """Named shapes through every walk that takes them: three scan leaves, an OR beside a scan leaf, the merged-bitmap form, NOT over a dense
-    and over a rarely matching scan leaf (leading and not), NOT over an index-based leaf, five leaves."""
+    and over a rarely matching scan leaf (leading and not), NOT over an index-based leaf, five leaves, two NOT children over scan leaves (an episode stream each)."""
     rng = np.random.default_rng(100 + n)
     seg = segment(rng, n)
     a, d, rare, post, e = leaves()
     shapes = [Q.and_(a, d, rare), Q.and_(a, Q.or_(d, rare)), Q.and_(post, a, Q.or_(d, rare)), Q.and_(a, Q.not_(d)), Q.and_(a, Q.not_(rare)), Q.and_(Q.not_(rare), d, a),
-              Q.and_(post, Q.not_(rare)), Q.and_(a, Q.or_(d, rare), Q.not_(post)), Q.and_(a, d, e, rare, Q.leaf(Q.Pred.dict_range(0, 5, 40))), Q.and_(e, Q.not_(d), Q.or_(a, post))]
+              Q.and_(post, Q.not_(rare)), Q.and_(a, Q.or_(d, rare), Q.not_(post)), Q.and_(a, d, e, rare, Q.leaf(Q.Pred.dict_range(0, 5, 40))), Q.and_(e, Q.not_(d), Q.or_(a, post)),
+              # two NOT children over scan leaves: two episode streams of one machine (7 states: the range kernel; 15: the table walk)
+              Q.and_(Q.not_(a), Q.not_(rare)), Q.and_(a, Q.not_(d), Q.not_(rare)), Q.and_(post, Q.not_(rare), Q.not_(e))]
     ran = with_episodes = 0
     for flt in shapes:
         spec = Q.QuerySpec([(Q.COUNT, -1)], filter=flt)
@@ -99,7 +101,7 @@ def test_the_kernels_source_equals_the_oracle(emu, n):
             assert got == want, (n, walk, states, inputs, episodes, got, want)
             ran += 1
             with_episodes += 1 if episodes else 0
-    assert ran >= 20 and with_episodes >= 10
+    assert ran >= 24 and with_episodes >= 14
 
 
 def test_more_than_one_chunk_of_tiles(emu):

@@ -79,37 +79,44 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
   if (fsm.has_episodes()) {
     std::vector<uint8_t> chunk_state((size_t)chunks, 0xEE), tile_state((size_t)tiles, 0xEE);
     std::vector<int32_t> first_close((size_t)tiles, 12345), last_open((size_t)tiles, 12345);
-    int32_t final_pending = 0;
     simt::launch(1, 1024, [&] { fsm_chunk_states_kernel(chunk_tables.data(), (int)chunks, S, chunk_state.data()); });
     simt::launch((unsigned)chunks, 1024, [&] { fsm_tile_states_kernel(tables.data(), tiles, S, chunk_state.data(), tile_state.data()); });
-    FsmEpisodeParams ep;
-    memset(&ep, 0, sizeof(ep));
-    for (int i = 0; i < L; ++i) ep.leaf[i] = fp.leaf[i];
-    ep.delta = fsm.delta.data(); ep.marks = fsm.marks.data(); ep.tile_state = tile_state.data();
-    ep.tile_first_close = first_close.data(); ep.tile_last_open = last_open.data();
-    ep.episode_entries = &episodes; ep.final_pending = &final_pending;
-    ep.pending_states = fsm.pending_states;
-    ep.num_inputs = L; ep.num_states = S; ep.num_docs = num_docs; ep.num_tiles = (int32_t)tiles;
-    if (walk != 0 && S <= 8 && L <= 4) {
-      // the byte-function walks' episode kernel (pg_engine.hip: PINOT_GPU_FSM_PERM on, at most eight states over at most four inputs): a
-      // wavefront per contiguous RANGE of tiles, one record per range for the finish kernel
-      const long long num_ranges = std::min<long long>(tiles, (long long)nb * 4);
-      std::vector<int32_t> range_close((size_t)num_ranges, 12345), range_open((size_t)num_ranges, 12345);
-      FsmEpisodeRangeParams rp;
-      memset(&rp, 0, sizeof(rp));
-      for (int i = 0; i < L; ++i) rp.leaf[i] = fp.leaf[i];
-      rp.delta = fsm.delta.data(); rp.marks = fsm.marks.data(); rp.tile_state = tile_state.data();
-      rp.range_first_close = range_close.data(); rp.range_last_open = range_open.data();
-      rp.episode_entries = &episodes; rp.final_pending = &final_pending;
-      rp.pending_states = fsm.pending_states;
-      rp.num_inputs = L; rp.num_states = S; rp.num_docs = num_docs; rp.num_tiles = (int32_t)tiles; rp.num_ranges = (int32_t)num_ranges;
-      const unsigned rb = (unsigned)((num_ranges + 3) / 4);
-      if (S <= 4) { if (L <= 2) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 2>(rp); }); else simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 4>(rp); }); }
-      else { if (L <= 2) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<8, 2>(rp); }); else simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<8, 4>(rp); }); }
-      simt::launch(1, 1024, [&] { fsm_episode_finish_kernel(range_close.data(), range_open.data(), (int)num_ranges, num_docs, &final_pending, &episodes); });
-    } else {
-      simt::launch(nb, 256, [&] { fsm_episode_tiles_kernel(ep); });
-      simt::launch(1, 1024, [&] { fsm_episode_finish_kernel(first_close.data(), last_open.data(), (int)tiles, num_docs, &final_pending, &episodes); });
+    // one pass per NOT child over a scan leaf (pg_engine.hip device_fsm_filter_stats): its marks, its pending states, its final-pending flag
+    for (int k = 0; k < fsm.num_episode_streams(); ++k) {
+      int32_t final_pending = 0;
+      const uint8_t* const marks = fsm.stream_marks(k).data();
+      const uint32_t pending_states = fsm.stream_pending(k);
+      std::fill(first_close.begin(), first_close.end(), 12345);
+      std::fill(last_open.begin(), last_open.end(), 12345);
+      FsmEpisodeParams ep;
+      memset(&ep, 0, sizeof(ep));
+      for (int i = 0; i < L; ++i) ep.leaf[i] = fp.leaf[i];
+      ep.delta = fsm.delta.data(); ep.marks = marks; ep.tile_state = tile_state.data();
+      ep.tile_first_close = first_close.data(); ep.tile_last_open = last_open.data();
+      ep.episode_entries = &episodes; ep.final_pending = &final_pending;
+      ep.pending_states = pending_states;
+      ep.num_inputs = L; ep.num_states = S; ep.num_docs = num_docs; ep.num_tiles = (int32_t)tiles;
+      if (walk != 0 && S <= 8 && L <= 4) {
+        // the byte-function walks' episode kernel (pg_engine.hip: PINOT_GPU_FSM_PERM on, at most eight states over at most four inputs): a
+        // wavefront per contiguous RANGE of tiles, one record per range for the finish kernel
+        const long long num_ranges = std::min<long long>(tiles, (long long)nb * 4);
+        std::vector<int32_t> range_close((size_t)num_ranges, 12345), range_open((size_t)num_ranges, 12345);
+        FsmEpisodeRangeParams rp;
+        memset(&rp, 0, sizeof(rp));
+        for (int i = 0; i < L; ++i) rp.leaf[i] = fp.leaf[i];
+        rp.delta = fsm.delta.data(); rp.marks = marks; rp.tile_state = tile_state.data();
+        rp.range_first_close = range_close.data(); rp.range_last_open = range_open.data();
+        rp.episode_entries = &episodes; rp.final_pending = &final_pending;
+        rp.pending_states = pending_states;
+        rp.num_inputs = L; rp.num_states = S; rp.num_docs = num_docs; rp.num_tiles = (int32_t)tiles; rp.num_ranges = (int32_t)num_ranges;
+        const unsigned rb = (unsigned)((num_ranges + 3) / 4);
+        if (S <= 4) { if (L <= 2) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 2>(rp); }); else simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 4>(rp); }); }
+        else { if (L <= 2) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<8, 2>(rp); }); else simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<8, 4>(rp); }); }
+        simt::launch(1, 1024, [&] { fsm_episode_finish_kernel(range_close.data(), range_open.data(), (int)num_ranges, num_docs, &final_pending, &episodes); });
+      } else {
+        simt::launch(nb, 256, [&] { fsm_episode_tiles_kernel(ep); });
+        simt::launch(1, 1024, [&] { fsm_episode_finish_kernel(first_close.data(), last_open.data(), (int)tiles, num_docs, &final_pending, &episodes); });
+      }
     }
   }
   return (int64_t)(entries + episodes);
