@@ -316,6 +316,11 @@ struct GroupParams {
   unsigned long long* hash_keys_lvl[kMaxHashLevels];    // [hash_mask_lvl[l] + 1]
   unsigned long long key_mult[kMaxGroupCols];
   uint32_t* first_doc;              // non-null: the numGroupsLimit pass -- no aggregation, atomicMin of the docId into first_doc[slot]
+  // group_lds_batch_kernel's items (zero_identity): non-null = the workgroup whose arrival on scan.done_counter completes the item's share of
+  // the launch copies the item's table slice (count[G] | acc[NA][G], contiguous from table_count) to this pinned, device-mapped host image,
+  // leaves the slice all-zero again and stores scan.host_seq into scan.host_out->seq -- the host converts an item while the launch still
+  // works on the others; no copy command and no memset behind the launch.
+  unsigned long long* host_table;
 };
 constexpr unsigned long long kHashEmpty = ~0ull;
 

@@ -94,6 +94,7 @@ struct Engine {
   bool fsm_stats = true;     // PINOT_GPU_FSM_STATS=0: no transducer pass (host replay / upper bound)
   bool fsm_episodes = true;  // PINOT_GPU_FSM_EPISODES=0: a NOT child over a scan leaf stays with the host replay / upper bound (round 4's behaviour)
   bool plan_cache = true;    // PINOT_GPU_PLAN_CACHE=0: pg_execute_batch lowers every item of every call
+  bool group_publish = true; // PINOT_GPU_GROUP_PUBLISH=0: the group-by items of a shared launch come back through one copy of all slices and a memset behind the launch
   bool batch_more = true;    // PINOT_GPU_BATCH_MORE=0: items of scan_narrow_kernel's / scan_private_typed_kernel's shape run their own launches
   bool group_one_launch = true;   // PINOT_GPU_GROUP_ONE_LAUNCH=0: pg_execute runs a small group-by as init + kernel + count + scan + compact launches (rounds 1-4)
   bool batch_group = true;   // PINOT_GPU_BATCH_GROUP=0: group-by items run their own launches on a worker thread
@@ -1837,6 +1838,7 @@ pg_status pg_init(const pg_config* config) {
   { const char* iaw = getenv("PINOT_GPU_INDEX_AND_WAVES"); g_engine.index_and_waves = iaw ? std::max(-64, std::min(32, atoi(iaw))) : 0; }
   g_engine.group_one_launch = env_on("PINOT_GPU_GROUP_ONE_LAUNCH");
   g_engine.plan_cache = env_on("PINOT_GPU_PLAN_CACHE");
+  g_engine.group_publish = env_on("PINOT_GPU_GROUP_PUBLISH");
   const char* bmo = getenv("PINOT_GPU_BATCH_MORE");
   g_engine.batch_more = !(bmo && bmo[0] == '0');
   const char* bgr = getenv("PINOT_GPU_BATCH_GROUP");
@@ -4747,9 +4749,9 @@ struct BatchCtx {
   size_t partial_capacity = 0;
   unsigned long long seq = 0;
   // group-by launches (lean_kind 6): the items' table slices -- ONE device allocation, all-zero between launches, and its pinned host image
-  unsigned long long* d_gtable = nullptr; unsigned long long* h_gtable = nullptr;
+  unsigned long long* d_gtable = nullptr; unsigned long long* h_gtable = nullptr; unsigned long long* h_gtable_dev = nullptr;      // (the image is device-mapped: items publish their slices themselves)
   size_t gtable_capacity = 0;      // words
-  bool gtable_dirty = false;       // a launch was enqueued and the memset behind it was not: zero the whole table before the next launch
+  bool gtable_dirty = false;       // a launch did not publish every item (or the copy form's memset was not enqueued): zero the whole table and the arrival counters before the next launch
 };
 constexpr size_t kBatchItemSlot = sizeof(GroupParams) > sizeof(ScanParams) ? sizeof(GroupParams) : sizeof(ScanParams);      // a slot of the blob holds an item of either kind
 std::mutex g_batch_mu;
@@ -4875,7 +4877,7 @@ struct DeferredLaunch {
   long long total_blocks = 0, docs = 0;
   size_t lds = 0;
   unsigned long long seq = 0;
-  bool timed = false, launched = false;
+  bool timed = false, launched = false, publish = false;      // publish: the group-by items write their slices and sequence numbers themselves
   std::chrono::steady_clock::time_point t0, t1;
   ~DeferredLaunch() { if (b) { std::lock_guard<std::mutex> lk(g_batch_mu); g_batch_free.push_back(b); } }
 };
@@ -4938,12 +4940,21 @@ pg_status enqueue_group_launch(DeferredLaunch* L, BatchCtx* b, std::vector<Defer
     b->d_gtable = nullptr; b->h_gtable = nullptr; b->gtable_capacity = 0;
     const size_t cap = std::max(table_words, (size_t)1 << 18);
     HIP_TRY(hipMalloc((void**)&b->d_gtable, cap * 8));
-    HIP_TRY(hipHostMalloc((void**)&b->h_gtable, cap * 8, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&b->h_gtable, cap * 8, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&b->h_gtable_dev, b->h_gtable, 0));
     HIP_TRY(hipMemsetAsync(b->d_gtable, 0, cap * 8, b->stream));      // ordered before the launch below
     b->gtable_capacity = cap;
     b->gtable_dirty = false;
   }
-  if (b->gtable_dirty) { HIP_TRY(hipMemsetAsync(b->d_gtable, 0, b->gtable_capacity * 8, b->stream)); b->gtable_dirty = false; }
+  if (b->gtable_dirty) {
+    HIP_TRY(hipMemsetAsync(b->d_gtable, 0, b->gtable_capacity * 8, b->stream));
+    HIP_TRY(hipMemsetAsync(b->d_done, 0, (size_t)b->item_capacity * (kFoldShards + 1) * kFoldStride * 4, b->stream));
+    b->gtable_dirty = false;
+  }
+  // Items publish themselves (GroupParams.host_table; PINOT_GPU_GROUP_PUBLISH=0: one copy of all slices and a memset behind the launch,
+  // rounds 4-6a): the last workgroup of an item writes its slice to the pinned image and its sequence number to the item's record.
+  const bool publish = g_engine.group_publish;
+  L->publish = publish;
   GroupParams* h_items = reinterpret_cast<GroupParams*>(b->h_blob + b->items_offset);
   GroupParams* d_items = reinterpret_cast<GroupParams*>(b->d_blob + b->items_offset);
   size_t off = 0;
@@ -4957,6 +4968,12 @@ pg_status enqueue_group_launch(DeferredLaunch* L, BatchCtx* b, std::vector<Defer
     place_item_sets(b, d, &gp.scan, &set_off);
     gp.table_count = b->d_gtable + off;
     gp.table_acc = reinterpret_cast<long long*>(b->d_gtable + off + (size_t)gp.num_groups);
+    if (publish) {
+      gp.host_table = b->h_gtable_dev + off;
+      gp.scan.done_counter = b->d_done + (size_t)k * (kFoldShards + 1) * kFoldStride;
+      gp.scan.host_out = b->h_records_dev + k;
+      gp.scan.host_seq = L->seq;
+    }
     L->table_offsets[(size_t)k] = off;
     off += d.group_table_words;
     b->h_first[k] = first;
@@ -4972,10 +4989,14 @@ pg_status enqueue_group_launch(DeferredLaunch* L, BatchCtx* b, std::vector<Defer
   launch_group_lds_batch((int)total_blocks, threads, launch_lds, b->stream, d_items, b->d_first, n);
   HIP_TRY(hipGetLastError());
   if (L->timed) HIP_TRY(hipEventRecord(b->ev[1], b->stream));
-  HIP_TRY(hipMemcpyAsync(b->h_gtable, b->d_gtable, off * 8, hipMemcpyDeviceToHost, b->stream));
-  HIP_TRY(hipEventRecord(b->ev[2], b->stream));
-  HIP_TRY(hipMemsetAsync(b->d_gtable, 0, off * 8, b->stream));          // all-zero again: the next launch's precondition (nobody waits for it here)
-  b->gtable_dirty = false;
+  if (publish) b->gtable_dirty = false;          // (the launch leaves table and counters as it found them; finish_group_launch says otherwise when an item stays silent)
+  if (publish) (void)hipStreamQuery(b->stream);      // (nothing else of this call touches the stream before the items' numbers arrive: hand the commands to the device now)
+  if (!publish) {
+    HIP_TRY(hipMemcpyAsync(b->h_gtable, b->d_gtable, off * 8, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipEventRecord(b->ev[2], b->stream));
+    HIP_TRY(hipMemsetAsync(b->d_gtable, 0, off * 8, b->stream));          // all-zero again: the next launch's precondition (nobody waits for it here)
+    b->gtable_dirty = false;
+  }
   L->t1 = std::chrono::steady_clock::now();
   L->launched = true;
   return PG_OK;
@@ -4986,9 +5007,49 @@ pg_status finish_group_launch(DeferredLaunch* L, std::vector<Deferred>& defs, pg
   const int n = L->n;
   static const bool trace = getenv("PINOT_GPU_BATCH_TRACE") != nullptr;
   HIP_TRY(hipSetDevice(phys_device(L->device)));
+  float ms = 0.f;
+  if (L->publish) {
+    // Every item's last workgroup has written the item's slice to the pinned image and then the launch's sequence number to the item's
+    // record: an item is converted as soon as ITS number is there.  The items of a launch run side by side (every item has its share of the
+    // resident workgroups), so their numbers arrive together near the end of the kernel -- measured (profiles/r6/group_publish_trace.txt): what
+    // this form saves is the copy command and the memset behind the kernel (~70 us at 64 x 1 000 groups) and the helpers' wake-up (they are
+    // woken when the kernel starts, sleep through most of its expected duration and poll the rest: ~12 us of conversion per item then
+    // starts the moment the numbers are there).
+    const unsigned long long seq = L->seq;
+    const int conv_threads = n <= 1 ? 1 : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 2));      // (64 threads, one round of conversions, measured slower: 0.72-0.75 ms against 0.69-0.70)
+    // (a group-by streams at most ~1.1 G docs per ms: 60 % of that time is slept, not polled, when it is worth a sleep)
+    const auto sleep_until = L->t1 + std::chrono::nanoseconds((long long)((double)L->docs / 1100.0 * 0.6));
+    const bool sleep_first = n > 1 && (double)L->docs / 1100.0 * 0.6 > 200'000.0;      // (nanoseconds)
+    std::atomic<int> unpublished{0};
+    std::atomic<long long> convert_ns{0}, wait_ns{0};          // (PINOT_GPU_BATCH_TRACE: summed over the items)
+    run_items(n, conv_threads, 1, false, [&](int k) {
+      const int i = L->items[(size_t)k];
+      volatile unsigned long long* const flag = &b->h_records[k].seq;
+      if (sleep_first && *flag != seq && std::chrono::steady_clock::now() < sleep_until) std::this_thread::sleep_until(sleep_until);
+      const auto tw0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+      (void)wait_polled(b->stream, L->docs, [&] { return *flag == seq; });
+      const auto tw1 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+      if (*flag != seq) { unpublished.fetch_add(1); statuses[i] = fail(PG_ERR_INTERNAL, "batch item %d did not publish its group table", i); return; }
+      defs[(size_t)i].item->convert_group(b->h_gtable + L->table_offsets[(size_t)k], &results[i]);
+      statuses[i] = PG_OK;
+      if (trace) { wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(tw1 - tw0).count(); convert_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw1).count(); }
+    });
+    if (unpublished.load() != 0) b->gtable_dirty = true;
+    if (L->timed) { HIP_TRY(hipEventSynchronize(b->ev[1])); HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1])); }
+    for (int k = 0; k < n; ++k) {
+      const int i = L->items[(size_t)k];
+      if (statuses[i] != PG_OK) continue;
+      const float share = L->total_blocks > 0 ? ms * (float)L->blocks[(size_t)k] / (float)L->total_blocks : 0.f;
+      results[i].device_ms = share;
+      results[i].dominant_kernel_ms = share;
+    }
+    if (trace) fprintf(stderr, "  deferred group-by launch on device %d: %d items %lld workgroups, lds %zu, enqueue %.1f us, items published and converted %.1f us behind it (waits %.1f us, conversions %.1f us summed over the items), kernel %.1f us\n", L->device, n,
+                       L->total_blocks, L->lds, std::chrono::duration<double, std::micro>(L->t1 - L->t0).count(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - L->t1).count(),
+                       (double)wait_ns.load() * 1e-3, (double)convert_ns.load() * 1e-3, ms * 1e3);
+    return PG_OK;
+  }
   HIP_TRY(hipEventSynchronize(b->ev[2]));
   const auto t2 = std::chrono::steady_clock::now();
-  float ms = 0.f;
   if (L->timed) HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
   // the items' conversions (a thousand groups each: ~10 us) side by side on the library's worker threads
   run_items(n, (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 2)), 1, false, [&](int k) {

@@ -2381,6 +2381,32 @@ __device__ __forceinline__ void group_private_body(const GP& gp, uint32_t block_
         off += lds_subtable_bytes(G, logR, kind == kGroupSum ? 8 : 4);
       }
     }
+    if (gp.host_table != nullptr) {
+      // An item of the shared launch publishes ITSELF (round 6b): every workgroup arrives once its own atomics are acknowledged; the one
+      // whose arrival completes the item's share reads the slice back (agent-scope loads: where the atomics were performed), writes it
+      // through to the pinned host image (system-scope stores, acknowledged before the sequence number: store_host_record_by_wave0's
+      // reasoning), zeroes what it read and resets the counter -- the launch leaves table and counter as it found them.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                             // (the LDS table is dead from here: its first dword is the flag)
+      uint32_t* const flag = reinterpret_cast<uint32_t*>(smem);
+      if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(gp.scan.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == num_blocks ? 1u : 0u;
+      __syncthreads();
+      if (*flag != 0u) {
+        const int words = G * (1 + NA);
+        unsigned long long* const slice = gp.table_count;         // count[G] | acc[NA][G]: one allocation (enqueue_group_launch)
+        for (int i = threadIdx.x; i < words; i += blockDim.x) {
+          const unsigned long long v = __hip_atomic_load(&slice[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&gp.host_table[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (v != 0ull) __hip_atomic_store(&slice[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          __hip_atomic_store(gp.scan.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&gp.scan.host_out->seq, gp.scan.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
   }
 }
 

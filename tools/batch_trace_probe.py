@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--segments", type=int, default=64)
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--shapes", default="", help="comma-separated shape names (default: all)")
     args = ap.parse_args()
     import numpy as np
     from pinot_amd import _abi
@@ -35,12 +36,16 @@ def main():
         raw = S.Column.raw("raw_i32", S.synthetic_dict_ids(4200 + s, 0, n, 1_000_000))
         fcol = S.Column.synthetic_uniform("f", n, np.arange(1000, dtype=np.int32), seed=7000 + s)
         vcol = S.Column.synthetic_uniform("v", n, (np.arange(100000, dtype=np.int64) * 7 + 3 + s).astype(np.int32), seed=8000 + s)
-        segs.append(S.SegmentData("c1_%d" % s, n, [raw, fcol, vcol]))
+        kcol = S.Column.synthetic_uniform("k", n, np.arange(1000, dtype=np.int32) * 3, seed=9500 + s)
+        segs.append(S.SegmentData("c1_%d" % s, n, [raw, fcol, vcol, kcol]))
     opened = [engine.open(sd) for sd in segs]
     B = lambda c: int(np.asarray(c.fwd).nbytes)
     shapes = [("dict-sum", lambda: Q.QuerySpec([(Q.SUM, 2)], filter=Q.leaf(Q.Pred.dict_range(1, 0, 100))), lambda sd: B(sd.columns[1]) + B(sd.columns[2])),
+              ("group-by", lambda: Q.QuerySpec([(Q.SUM, 2), (Q.MAX, 1)], group_by=[3]), lambda sd: B(sd.columns[1]) + B(sd.columns[2]) + B(sd.columns[3])),
               ("raw-count-range", lambda: Q.QuerySpec([(Q.COUNT, -1)], filter=Q.leaf(Q.Pred.raw_range(0, 1, 10))), lambda sd: B(sd.columns[0]))]
     for name, mk, nb in shapes:
+        if args.shapes and name not in args.shapes.split(","):
+            continue
         specs = [mk() for _ in segs]
         nbytes = sum(nb(sd) for sd in segs)
         handles = (C.c_void_p * nseg)(*[g.handle for g in opened])
