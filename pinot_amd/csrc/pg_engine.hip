@@ -76,6 +76,7 @@ struct Engine {
                              // does in a launch of its own, -1 (default) = 1: at every size
   int fold_one_counter = 1;  // PINOT_GPU_FOLD_ONE_COUNTER=0: grids of at most 64 workgroups also arrive on eight shard counters + the top one
   bool poll_result = true;   // PINOT_GPU_POLL_RESULT=0: pg_execute always waits with hipStreamSynchronize instead of spinning on the pinned record's sequence number
+  bool set_lds = true;       // PINOT_GPU_SET_LDS=0: dictId-set leaves (IN lists) of the lane-private scan kernels read their words from memory per doc (rounds 2-6a)
   bool lane_skip = true;     // PINOT_GPU_LANE_SKIP=0: the aggregating kernels load a tile's value bytes for every lane, matches or not
   bool batch_blocks_per_cu_forced = false;
   int batch_blocks_per_cu = 4;    // PINOT_GPU_BATCH_BLOCKS_PER_CU: workgroups per CU a batch launch is cut into (all items together)
@@ -1828,6 +1829,7 @@ pg_status pg_init(const pg_config* config) {
   g_engine.batch_launch = !(bla && bla[0] == '0');
   auto env_on = [](const char* name) { const char* v = getenv(name); return !(v && v[0] == '0'); };
   g_engine.lean_batch = env_on("PINOT_GPU_LEAN_BATCH");
+  g_engine.set_lds = env_on("PINOT_GPU_SET_LDS");
   g_engine.partition_two_level = env_on("PINOT_GPU_PARTITION_TWO_LEVEL");
   g_engine.fsm_perm = env_on("PINOT_GPU_FSM_PERM");
   g_engine.fsm_stats = env_on("PINOT_GPU_FSM_STATS");
@@ -3195,6 +3197,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     sp.fold_slots = use_hist ? 2 : pl.num_agg_cols;
     sp.fold_typed = (!use_raw && (use_private_typed || (!use_hist && !use_narrow && !use_private && typed))) ? 1 : 0;
     sp.lane_skip = g_engine.lane_skip ? 1 : 0;
+    sp.set_leaves_in_lds = 0;
+    if (g_engine.set_lds) for (int nd = 0; nd < sp.num_nodes; ++nd) if (sp.nodes[nd].op == PG_FILTER_LEAF && sp.nodes[nd].kind == kLeafDictSet) sp.set_leaves_in_lds = 1;
     sp.sparse_lanes = g_engine.sparse_lanes;
     sp.fold_one_counter = g_engine.fold_one_counter;
     if (defer_index_and) {

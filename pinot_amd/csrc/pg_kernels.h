@@ -1563,8 +1563,29 @@ __device__ __forceinline__ uint32_t range_private_dispatch(int b, WP lane_words,
 }
 
 // (P / N: ScanParams / DevNode, or their constant-address-space forms in scan_private_batch_kernel)
+// The dictId sets of a filter in LDS (round 6b; scan_private_body stages them, kSetLdsWords per workgroup): a set leaf of a column of b bits
+// takes 2^b / 32 words there, zero beyond the set's own words, so a lookup needs no bound check -- `set_lds_fits` is the rule both the
+// staging and the evaluation follow, leaf after leaf in node order (`off`: words taken so far).  A lookup is then one conflict-light
+// ds_read_b32 (32 words: every bank holds one address) instead of a buffer load through the texture path per doc: measured on 64 x 10 M rows,
+// SUM(v) WHERE f IN (100 of 1000): profiles/r6/set_leaf_in_lds.txt.
+constexpr int kSetLdsWords = 2048;                        // 8 KB: one set over a 16-bit dictionary, or several over narrower ones
+__device__ __forceinline__ int set_lds_words(int bits) { return bits <= 5 ? 1 : 1 << (bits - 5); }
+__device__ __forceinline__ bool set_lds_fits(int bits, int off) { return bits <= 16 && off + set_lds_words(bits) <= kSetLdsWords; }
+template <typename P>
+__device__ __forceinline__ void stage_filter_sets(const P& p, uint32_t* set_lds) {
+  int off = 0;
+  for (int n = 0; n < p.num_nodes; ++n) {
+    const auto& nd = p.nodes[n];
+    if (nd.op != PG_FILTER_LEAF || nd.kind != kLeafDictSet || !set_lds_fits(nd.bits, off)) continue;
+    const int words = set_lds_words(nd.bits), have = nd.set_bytes >> 2;
+    for (int i = threadIdx.x; i < words; i += blockDim.x) set_lds[off + i] = i < have ? global_words(nd.set_words)[i] : 0u;
+    off += words;
+  }
+  __syncthreads();
+}
+
 template <typename P, typename N>
-__device__ __forceinline__ uint32_t eval_leaf_private(const P& p, const N& L, long long tile, int lane) {
+__device__ __forceinline__ uint32_t eval_leaf_private(const P& p, const N& L, long long tile, int lane, const uint32_t* set_lds = nullptr) {
   uint32_t m;
   switch (L.kind) {
     case kLeafMatchAll: m = 0xFFFFFFFFu; break;
@@ -1577,8 +1598,21 @@ __device__ __forceinline__ uint32_t eval_leaf_private(const P& p, const N& L, lo
     case kLeafDictSet: {
       // InPredicateEvaluator: bit dictId of the set (the words stay L1-resident)
       const GlobalWords words = global_words(L.fwd + tile * (256ll * L.bits)) + lane * L.bits;
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)L.set_words, 0, L.set_bytes, 0x00020000);
       m = 0;
+      if (set_lds != nullptr) {
+        // (the set's words are in LDS, zero-padded to the column's whole dictId range: pg_kernels.h "The dictId sets of a filter in LDS")
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          uint32_t d[16], w[16];
+          if (h == 0) decode16_private_dispatch<0>(L.bits, words, d); else decode16_private_dispatch<1>(L.bits, words, d);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) w[j] = set_lds[d[j] >> 5];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) m |= __builtin_amdgcn_ubfe(w[j], d[j] & 31u, 1) << (16 * h + j);
+        }
+        break;
+      }
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)L.set_words, 0, L.set_bytes, 0x00020000);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         uint32_t d[16], w[16];
@@ -1760,10 +1794,12 @@ static __global__ __launch_bounds__(1024) void leapfrog2_chain_kernel(const uint
 // SVScanDocIdIterator.java:115-145: one entry per doc of that bitmap).  On the AND chain the only mask on the stack is that bitmap.
 // kCollect: every leaf's own mask also goes to w[fsm_input_of_leaf[ordinal]] (the in-kernel transducer walk: scan_private_fsm_kernel) --
 // four registers picked with wave-uniform selects, no store to memory.
+// `set_lds`: the workgroup's staged dictId sets (stage_filter_sets), or nullptr: set leaves read their words from memory.
 template <bool kCollect = false, typename P>
-__device__ __forceinline__ uint32_t eval_filter_private(const P& p, long long tile, int lane, uint32_t& entries, uint32_t (*w)[4] = nullptr) {
+__device__ __forceinline__ uint32_t eval_filter_private(const P& p, long long tile, int lane, uint32_t& entries, uint32_t (*w)[4] = nullptr, const uint32_t* set_lds = nullptr) {
   if (p.num_nodes == 0) return 0xFFFFFFFFu;
-  if (p.num_nodes == 1) return eval_leaf_private(p, p.nodes[0], tile, lane);
+  if (p.num_nodes == 1) return eval_leaf_private(p, p.nodes[0], tile, lane, (set_lds != nullptr && p.nodes[0].kind == kLeafDictSet && set_lds_fits(p.nodes[0].bits, 0)) ? set_lds : nullptr);
+  int set_off = 0;                                                        // (uniform) words of the set area the leaves so far have taken
   MaskStack st;
 #pragma unroll
   for (int i = 0; i < kStackDepth; ++i) st.v[i] = 0;
@@ -1777,7 +1813,9 @@ __device__ __forceinline__ uint32_t eval_filter_private(const P& p, long long ti
         const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
         entries += (uint32_t)__builtin_popcount(st.v[0] & (rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u))));
       }
-      top = eval_leaf_private(p, nd, tile, lane);
+      const uint32_t* my_set = nullptr;
+      if (set_lds != nullptr && nd.kind == kLeafDictSet && set_lds_fits(nd.bits, set_off)) { my_set = set_lds + set_off; set_off += set_lds_words(nd.bits); }
+      top = eval_leaf_private(p, nd, tile, lane, my_set);
       if constexpr (kCollect) {
         const int in = p.fsm_input_of_leaf[leaf_ordinal];                  // (uniform)
 #pragma unroll
@@ -1922,8 +1960,10 @@ struct PrivateAccLds<1> { uint32_t unused; };          // the one-slot form keep
 struct FsmWalkLds { uint8_t delta[64]; uint2 pair_fn[256]; };
 template <int kAggSlots, typename P, bool kFsm = false>
 __device__ __forceinline__ void scan_private_body(const P& p, const uint32_t block_index, const uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr,
-                                                  PrivateAccLds<kAggSlots>* acc_lds, FsmWalkLds* fsm_lds = nullptr) {
+                                                  PrivateAccLds<kAggSlots>* acc_lds, FsmWalkLds* fsm_lds = nullptr, uint32_t* set_lds = nullptr) {
   if constexpr (kFsm) fsm_perm_build_tables<4>(p.fsm_delta, 4, p.fsm_states, p.fsm_inputs, fsm_lds->delta, fsm_lds->pair_fn);
+  if (p.set_leaves_in_lds == 0) set_lds = nullptr;                        // (uniform; PINOT_GPU_SET_LDS=0, or a filter without a set leaf)
+  if (set_lds != nullptr) stage_filter_sets(p, set_lds);
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
@@ -1976,10 +2016,10 @@ __device__ __forceinline__ void scan_private_body(const P& p, const uint32_t blo
     const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
     if constexpr (kFsm) {
       uint32_t fw[4] = {0u, 0u, 0u, 0u};
-      m = eval_filter_private<true>(p, tile, lane, entries, &fw);
+      m = eval_filter_private<true>(p, tile, lane, entries, &fw, set_lds);
       fsm_perm_tile<4>(fw, rem >= 32 ? 32 : (rem <= 0 ? 0 : (int)rem), fsm_lds->delta, fsm_lds->pair_fn, lane, p.fsm_states, p.fsm_tables + tile * p.fsm_states);
     } else {
-      m = eval_filter_private(p, tile, lane, entries);
+      m = eval_filter_private(p, tile, lane, entries, nullptr, set_lds);
     }
     // docs past numDocs (last tile only)
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
@@ -2044,7 +2084,8 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
   __shared__ PrivateAccLds<kAggSlots> acc;
-  scan_private_body<kAggSlots>(p, blockIdx.x, gridDim.x, red, &fold_flag, &acc);
+  __shared__ uint32_t set_lds[kSetLdsWords];
+  scan_private_body<kAggSlots>(p, blockIdx.x, gridDim.x, red, &fold_flag, &acc, nullptr, set_lds);
 }
 
 // The same kernel with the transducer walk inside (kFsm): a leap-frogging root AND of at most four leaves-as-inputs and four states.
@@ -2054,7 +2095,8 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_FSM_WAVES) void scan_priv
   __shared__ uint32_t fold_flag;
   __shared__ PrivateAccLds<kAggSlots> acc;
   __shared__ FsmWalkLds fsm_lds;
-  scan_private_body<kAggSlots, ScanParams, true>(p, blockIdx.x, gridDim.x, red, &fold_flag, &acc, &fsm_lds);
+  __shared__ uint32_t set_lds[kSetLdsWords];
+  scan_private_body<kAggSlots, ScanParams, true>(p, blockIdx.x, gridDim.x, red, &fold_flag, &acc, &fsm_lds, set_lds);
 }
 
 // Many queries, one launch (pg_execute_batch): workgroups [block_first[i], block_first[i + 1]) work on items[i] -- its own columns,
@@ -2073,6 +2115,7 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
   __shared__ PrivateAccLds<kAggSlots> acc;
+  __shared__ uint32_t set_lds[kSetLdsWords];
   int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -2086,7 +2129,7 @@ __global__ __launch_bounds__(kBlockThreads, PG_PRIVATE_WAVES) void scan_private_
   // Measured on one 1 B-row item: 0.91 ms against the single launch's 0.69.
   typedef const __attribute__((address_space(4))) ScanParams ConstantScanParams;
   const ConstantScanParams& item = *(ConstantScanParams*)(bp.items + lo);
-  scan_private_body<kAggSlots>(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag, &acc);
+  scan_private_body<kAggSlots>(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag, &acc, nullptr, set_lds);
 }
 
 // The slot of `key` in an open-addressing table of (mask + 1) slots, claiming a free one if the key is new (kHashEmpty = free).  The

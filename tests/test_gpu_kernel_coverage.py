@@ -130,7 +130,7 @@ FLIPPED = {
                         "PINOT_GPU_LANE_SKIP=0,PINOT_GPU_SCAN_SPARSE=0,PINOT_GPU_SCAN_RAW=0,PINOT_GPU_SCAN_NARROW=0,PINOT_GPU_RAW64_COALESCED=0,PINOT_GPU_GROUP_PACK=0,"
                         "PINOT_GPU_GROUP_REPLICAS=0,PINOT_GPU_PARTITION_STATS_CACHE=0,PINOT_GPU_PLANE_GCD=0,PINOT_GPU_STAGED_H2D=0,PINOT_GPU_SMALL_BLOCKS_PER_CU=0,"
                         "PINOT_GPU_WIDE_BLOCKS=1,PINOT_GPU_GROUP_WAVES=4",
-    "geometry": "PINOT_GPU_GROUP_PUBLISH=0,PINOT_GPU_POLL_RESULT=0,PINOT_GPU_SCAN_NARROW_SINGLE=0,PINOT_GPU_INDEX_AND_WAVES=3,PINOT_GPU_SPARSE_LANES=64,PINOT_GPU_BLOCKS_PER_CU=2,PINOT_GPU_BATCH_BLOCKS_PER_CU=2,"
+    "geometry": "PINOT_GPU_GROUP_PUBLISH=0,PINOT_GPU_SET_LDS=0,PINOT_GPU_POLL_RESULT=0,PINOT_GPU_SCAN_NARROW_SINGLE=0,PINOT_GPU_INDEX_AND_WAVES=3,PINOT_GPU_SPARSE_LANES=64,PINOT_GPU_BLOCKS_PER_CU=2,PINOT_GPU_BATCH_BLOCKS_PER_CU=2,"
                 "PINOT_GPU_DOUBLE_BUFFER=1,PINOT_GPU_TILE_STEPS=16,PINOT_GPU_GROUP_REPLICAS=1,PINOT_GPU_GROUP_WAVES=8,PINOT_GPU_FOLD_FINALIZE=0,PINOT_GPU_VALUE_PLANE=1,"
                 "PINOT_GPU_PLANE_BUDGET_BYTES=1000000",
 }

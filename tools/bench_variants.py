@@ -77,7 +77,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
         return lambda matched: B(col) if matched * 16 >= rows else min(B(col), matched * 64)
 
     # ---- C2 / C3 on 1 B rows: the headline's v and f, v under two dictionaries without structure, and the C3 columns ----
-    if any(want(x) for x in ("C2b-irregular", "C2b-window", "C2a-affine", "C2a-irregular", "C3", "C3-filter", "C3-irregular", "COUNT-filter", "C2b-1pct", "C2b-50pct", "AND3-scan", "AND-OR-scan", "AND-NOT-scan", "NOT-NOT-scan")):
+    if any(want(x) for x in ("C2b-irregular", "C2b-window", "C2a-affine", "C2a-irregular", "C3", "C3-filter", "C3-irregular", "COUNT-filter", "C2b-1pct", "C2b-50pct", "AND3-scan", "AND-OR-scan", "AND-NOT-scan", "NOT-NOT-scan", "C2b-in-list")):
         t0 = time.time()
         v_irr = _shared(S, v, "v_irr", v_dictionary("irregular"))
         v_win = _shared(S, v, "v_win", v_dictionary("window"))
@@ -100,6 +100,10 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                     report(vid, "BASELINE.json configs[1], other selectivities", "SELECT SUM(v) WHERE f < %d" % t, n, lambda m, charge=charge: B(f) + charge(m), g, seg,
                            Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_range(1, 0, t))),
                            extra={"dictionary": "affine", "algorithmic_bytes_note": "B(f) + (B(v) from 1/16 selectivity up, else min(B(v), matches x 64 B)): SURVEY.md 8(d)"})
+            if want("C2b-in-list"):
+                # InPredicateEvaluator over f's dictIds: a dictId-set leaf (the words staged in LDS once per workgroup: pg_kernels.h stage_filter_sets)
+                report("C2b-in-list", "BASELINE.json configs[1] with an IN list for a filter", "SELECT SUM(v) WHERE f IN (100 of f's 1000 values: every third of the first 300) (10%)", n, B(v) + B(f), g, seg,
+                       Q.QuerySpec([(Q.SUM, 0)], filter=Q.leaf(Q.Pred.dict_set(1, list(range(0, 300, 3)), 1000))), extra={"dictionary": "affine"})
             for vid, ci in (("C2a-affine", 0), ("C2a-irregular", 2)):
                 if want(vid):
                     report(vid, "BASELINE.md C2a (predicate on the summed column)", "SELECT SUM(%s) WHERE %s BETWEEN dict[45000] AND dict[54999] (10%%)" % (seg.columns[ci].name, seg.columns[ci].name),
