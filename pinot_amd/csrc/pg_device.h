@@ -21,6 +21,7 @@ constexpr int kMaxGroupCols = 10;               // group-by key columns (InnerSe
 constexpr int kMaxHashLevels = 8;               // chained first tables of a key beyond a long (GroupParams.hash_*): each takes >= 1 column, the first key >= 2
 constexpr int kMaxGroupAggs = 8;                // distinct (column, SUM|MIN|MAX) pairs of a group-by query
 constexpr int kStackDepth = 8;
+constexpr int kSetLdsWords = 2048;              // the dictId sets of a filter in LDS (pg_kernels.h stage_filter_sets): 8 KB per workgroup -- one set over a 16-bit dictionary, or several over narrower ones
 constexpr int kBlockThreads = 256;              // scan_agg_kernel: at most 4 wavefronts per workgroup
 constexpr int kWideBlockThreads = 640;          // scan_simple_kernel / scan_raw_kernel on a segment whose tiles all fit the chip at once: ten wavefronts per workgroup,
                                                 // two such workgroups per CU at five waves per SIMD -- 2.5x fewer records to hand to the fold, folded by 640 threads in one round
@@ -295,6 +296,7 @@ struct GroupParams {
   int32_t wide_keys;               // 1: num_groups > 2^24, so dictIds / multipliers may not fit the full-rate 24-bit multiply
   int32_t lds_log_replicas;        // group_private_kernel<true>: log2 of the copies of the LDS table a workgroup keeps (lane l uses copy l % R; pg_kernels.h)
   int32_t zero_identity;           // 1: the global table is all-zero before the launch and MIN / MAX reach it as keys whose identity is 0 (group_lds_batch_kernel)
+  int32_t set_lds_off;             // group_private_body: byte offset of the filter's dictId-set area (kSetLdsWords words) in the dynamic LDS, behind the table; -1 = none
   DevGroupKey group_keys[kMaxGroupCols];
   DevGroupAgg group_aggs[kMaxGroupAggs];
   unsigned long long* table_count; // [num_groups]

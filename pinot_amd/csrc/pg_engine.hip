@@ -3523,14 +3523,20 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // group_private_kernel's LDS table in as many bank-interleaved copies as the workgroup's share of the CU's LDS holds (pg_kernels.h,
     // lds_group_table_bytes): C3's 1000 groups x (SUM + MAX) are 12 KB a copy, eight copies for the one 16-wave workgroup of a CU.
     gp.lds_log_replicas = 0;
+    // (a filter with dictId-set leaves: kSetLdsWords words of the workgroup's LDS hold the sets, behind the table -- pg_kernels.h stage_filter_sets)
+    sp.set_leaves_in_lds = 0;
+    if (g_engine.set_lds) for (int nd = 0; nd < sp.num_nodes; ++nd) if (sp.nodes[nd].op == PG_FILTER_LEAF && sp.nodes[nd].kind == kLeafDictSet) sp.set_leaves_in_lds = 1;
+    const size_t set_area = (use_private && sp.set_leaves_in_lds != 0) ? (size_t)kSetLdsWords * 4 : 0;
     if (use_private && gp.use_lds_table) {
       const int resident = std::max(1, std::min(waves_group_private() / std::max(1, pthreads / 64), g_engine.blocks_per_cu > 0 ? g_engine.blocks_per_cu : 1 << 30));
-      const size_t budget = kLdsBudget / (size_t)resident;
+      const size_t budget = kLdsBudget / (size_t)resident - set_area;
       int log_r = 0;
       while (log_r < g_engine.group_log_replicas && (size_t)lds_group_table_bytes(gp, log_r + 1) <= budget) ++log_r;
       gp.lds_log_replicas = log_r;
       plds = lds_group_table_bytes(gp, log_r);
     }
+    gp.set_lds_off = -1;
+    if (set_area != 0 && plds + set_area <= kLdsBudget) { gp.set_lds_off = (int32_t)((plds + 15) & ~(size_t)15); plds = (size_t)gp.set_lds_off + set_area; }
     gp.scan = sp;
     gp.scan.partials = nullptr;
     gp.scan.out_bitmap = nullptr;
@@ -3873,7 +3879,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
           fg.first_doc = d_first_doc;
           fg.scan.filter_entries = nullptr; fg.scan.leap_tables = nullptr;
           for (int n = 0; n < fg.scan.num_nodes; ++n) fg.scan.nodes[n].flags &= ~(kNodeLeapfrog2 | kNodeCountEntries);
-          launch_group_private(false, pblocks, pthreads, 0, ctx->stream, fg);
+          launch_group_private(false, pblocks, pthreads, plds, ctx->stream, fg);      // (plds: the set area, when the filter has dictId sets)
           HIP_TRY(hipGetLastError());
           done_docs = seg->num_docs;
           max_first_doc = 0xFFFFFFFEu;

@@ -1568,7 +1568,6 @@ __device__ __forceinline__ uint32_t range_private_dispatch(int b, WP lane_words,
 // staging and the evaluation follow, leaf after leaf in node order (`off`: words taken so far).  A lookup is then one conflict-light
 // ds_read_b32 (32 words: every bank holds one address) instead of a buffer load through the texture path per doc: measured on 64 x 10 M rows,
 // SUM(v) WHERE f IN (100 of 1000): profiles/r6/set_leaf_in_lds.txt.
-constexpr int kSetLdsWords = 2048;                        // 8 KB: one set over a 16-bit dictionary, or several over narrower ones
 __device__ __forceinline__ int set_lds_words(int bits) { return bits <= 5 ? 1 : 1 << (bits - 5); }
 __device__ __forceinline__ bool set_lds_fits(int bits, int off) { return bits <= 16 && off + set_lds_words(bits) <= kSetLdsWords; }
 template <typename P>
@@ -2364,6 +2363,9 @@ __device__ __forceinline__ void group_private_body(const GP& gp, uint32_t block_
     t_cnt = gp.table_count;
     t_acc = gp.table_acc;
   }
+  // the filter's dictId sets (IN lists) behind the table in the dynamic LDS, when the host made room for them (GroupParams.set_lds_off)
+  uint32_t* set_lds = nullptr;
+  if (gp.scan.set_leaves_in_lds != 0 && gp.set_lds_off >= 0) { set_lds = reinterpret_cast<uint32_t*>(smem + gp.set_lds_off); stage_filter_sets(gp.scan, set_lds); }
   const long long num_tiles = ((long long)gp.scan.num_docs + 2047) / 2048;
   const long long wave = (long long)block_index * waves_per_block + wave_in_block;
   uint32_t entries = 0u;
@@ -2372,7 +2374,7 @@ __device__ __forceinline__ void group_private_body(const GP& gp, uint32_t block_
   for (long long tile_it = wave; tile_it < tile_limit; tile_it += total_waves) {
     const long long tile = listed ? (long long)gp.scan.tile_list[tile_it] : tile_it;
     // the filter (if any) in the same lane-private layout: bit j of the lane's mask = doc 32*lane + j of the tile
-    uint32_t m = eval_filter_private(gp.scan, tile, lane, entries);
+    uint32_t m = eval_filter_private(gp.scan, tile, lane, entries, nullptr, set_lds);
     const long long rem = (long long)gp.scan.num_docs - (tile * 2048 + lane * 32);
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
     if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;

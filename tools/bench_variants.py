@@ -77,7 +77,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
         return lambda matched: B(col) if matched * 16 >= rows else min(B(col), matched * 64)
 
     # ---- C2 / C3 on 1 B rows: the headline's v and f, v under two dictionaries without structure, and the C3 columns ----
-    if any(want(x) for x in ("C2b-irregular", "C2b-window", "C2a-affine", "C2a-irregular", "C3", "C3-filter", "C3-irregular", "COUNT-filter", "C2b-1pct", "C2b-50pct", "AND3-scan", "AND-OR-scan", "AND-NOT-scan", "NOT-NOT-scan", "C2b-in-list")):
+    if any(want(x) for x in ("C2b-irregular", "C2b-window", "C2a-affine", "C2a-irregular", "C3", "C3-filter", "C3-irregular", "COUNT-filter", "C2b-1pct", "C2b-50pct", "AND3-scan", "AND-OR-scan", "AND-NOT-scan", "NOT-NOT-scan", "C2b-in-list", "C3-in-list")):
         t0 = time.time()
         v_irr = _shared(S, v, "v_irr", v_dictionary("irregular"))
         v_win = _shared(S, v, "v_win", v_dictionary("window"))
@@ -114,6 +114,9 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
             if want("C3-filter"):
                 report("C3-filter", "BASELINE.json configs[2] + filter", "SELECT SUM(a), MAX(b) WHERE f < 100 GROUP BY k", n, B(k) + B(a) + B(b) + B(f), g, seg,
                        Q.QuerySpec([(Q.SUM, 5), (Q.MAX, 6)], filter=flt, group_by=[4]))
+            if want("C3-in-list"):
+                report("C3-in-list", "BASELINE.json configs[2] + an IN list for a filter", "SELECT SUM(a), MAX(b) WHERE f IN (100 of f's 1000 values) GROUP BY k", n, B(k) + B(a) + B(b) + B(f), g, seg,
+                       Q.QuerySpec([(Q.SUM, 5), (Q.MAX, 6)], filter=Q.leaf(Q.Pred.dict_set(1, list(range(0, 300, 3)), 1000)), group_by=[4]))
             if want("C3-irregular"):
                 report("C3-irregular", "BASELINE.json configs[2], summed column with a dictionary without structure", "SELECT SUM(a_irr), MAX(b) GROUP BY k", n, B(k) + B(a) + B(b), g, seg,
                        Q.QuerySpec([(Q.SUM, 7), (Q.MAX, 6)], group_by=[4]), extra={"dictionary": "irregular"})
