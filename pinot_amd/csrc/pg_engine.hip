@@ -2976,7 +2976,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       for (int n = 0; n < sp.num_nodes && use_narrow; ++n) {
         const DevNode& dn = sp.nodes[n];
         if (dn.op == PG_FILTER_LEAF) {
-          use_narrow = dn.kind == kLeafMatchAll || dn.kind == kLeafMatchNone || (dn.kind == kLeafDictRange && dn.bits >= 1 && dn.bits <= kNarrowMaxBits);
+          use_narrow = dn.kind == kLeafMatchAll || dn.kind == kLeafMatchNone || ((dn.kind == kLeafDictRange || (dn.kind == kLeafDictSet && g_engine.set_lds)) && dn.bits >= 1 && dn.bits <= kNarrowMaxBits);      // (a set of a narrow column: eight words in LDS, pg_scan_narrow.h)
           depth++;
         } else if (dn.op != PG_FILTER_NOT) depth -= dn.num_children - 1;
         max_depth = std::max(max_depth, depth);

@@ -9,7 +9,7 @@
 // aggregation state beyond a count.  Same lane-private layout as the other kernels (lane i owns docs 32 i .. 32 i + 31 of a tile, its
 // mask is dword 64 tile + i of the doc-order bitmap), so the bitmap it writes is the one every other kernel reads.
 // Leaves: dictId ranges (PredicateEvaluator lowering of EQ / NOT_EQ / RANGE: SVScanDocIdIterator's matcher, SVScanDocIdIterator.java:
-// 108-145, over FixedBitSVForwardIndexReaderV2's stream), match-all / match-none; any AND / OR / NOT tree whose evaluation needs at
+// 108-145, over FixedBitSVForwardIndexReaderV2's stream), dictId sets (IN / NOT IN: at most eight words, kept in LDS -- round 6b), match-all / match-none; any AND / OR / NOT tree whose evaluation needs at
 // most kNarrowStack masks.
 #pragma once
 #include "pg_kernels.h"
@@ -35,6 +35,57 @@ __device__ __forceinline__ void narrow_leaf_quad(const uint8_t* fwd, const long 
   }
 }
 
+// A dictId-SET leaf (InPredicateEvaluator / NotInPredicateEvaluator) over a narrow column (round 6b): the set of a column of at most 8 bits is
+// at most eight words -- leaf ordinal o keeps them in words [8 o, 8 o + 8) of the workgroup's LDS (stage_narrow_sets; zero beyond the set's own
+// words).  Up to five bits the whole set is ONE word held in a register: decode, bit-field extract, shift-or per doc -- a range compare's three
+// instructions; six to eight bits look the word up in LDS (eight words, one bank each).
+template <int B, int H>
+__device__ __forceinline__ void set16_narrow(const uint32_t (&w)[B], const uint32_t* set8, uint32_t& mm) {
+  uint32_t v[16];
+  decode16_private<B, H>(w, v);
+  if constexpr (B <= 5) {
+    const uint32_t mask = set8[0];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) mm = (mm << 1) | __builtin_amdgcn_ubfe(mask, v[j], 1);
+  } else {
+    uint32_t x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = set8[v[j] >> 5];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) mm = (mm << 1) | __builtin_amdgcn_ubfe(x[j], v[j] & 31u, 1);
+  }
+}
+template <int B>
+__device__ __forceinline__ void narrow_set_quad(const uint8_t* fwd, const long long (&tiles)[kNarrowTiles], int lane, const uint32_t* set8, uint32_t (&m)[kNarrowTiles]) {
+  uint32_t w[kNarrowTiles][B];
+#pragma unroll
+  for (int t = 0; t < kNarrowTiles; ++t) {
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(fwd + tiles[t] * (256ll * B)) + lane * B;
+#pragma unroll
+    for (int i = 0; i < B; ++i) w[t][i] = words[i];
+  }
+#pragma unroll
+  for (int t = 0; t < kNarrowTiles; ++t) {
+    uint32_t mm = 0;
+    set16_narrow<B, 0>(w[t], set8, mm);
+    set16_narrow<B, 1>(w[t], set8, mm);
+    m[t] = __builtin_bitreverse32(mm);          // value j -> bit j
+  }
+}
+constexpr int kNarrowSetWords = 8 * kMaxLeaves;
+template <typename P>
+__device__ __forceinline__ void stage_narrow_sets(const P& p, uint32_t* sets) {
+  if (p.set_leaves_in_lds == 0) return;            // (uniform: no set leaf in this filter)
+  int ordinal = 0;
+  for (int n = 0; n < p.num_nodes; ++n) {
+    const auto& nd = p.nodes[n];
+    if (nd.op != PG_FILTER_LEAF) continue;
+    if (nd.kind == kLeafDictSet && ordinal < kMaxLeaves && threadIdx.x < 8) sets[8 * ordinal + threadIdx.x] = (int)threadIdx.x < (nd.set_bytes >> 2) ? nd.set_words[threadIdx.x] : 0u;
+    ++ordinal;
+  }
+  __syncthreads();
+}
+
 struct NarrowStack {                              // kNarrowStack entries of four masks; selects instead of indexing keep it in registers
   uint32_t v[kNarrowStack][kNarrowTiles];
   int sp;
@@ -57,7 +108,8 @@ struct NarrowStack {                              // kNarrowStack entries of fou
 };
 
 template <typename P>
-__device__ __forceinline__ void scan_narrow_body(const P& p, uint32_t block_index, uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr) {
+__device__ __forceinline__ void scan_narrow_body(const P& p, uint32_t block_index, uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr, uint32_t* sets) {
+  stage_narrow_sets(p, sets);
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
@@ -86,6 +138,14 @@ __device__ __forceinline__ void scan_narrow_body(const P& p, uint32_t block_inde
           const uint32_t lo = (uint32_t)nd.lo, span = nd.span;
           switch (nd.bits) {
 #define PG_CASE(B) case B: narrow_leaf_quad<B>(nd.fwd, tiles, lane, lo, span, top); break;
+            PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8)
+#undef PG_CASE
+            default: break;
+          }
+        } else if (nd.kind == kLeafDictSet) {
+          const uint32_t* set8 = sets + 8 * leaf_ordinal;
+          switch (nd.bits) {
+#define PG_CASE(B) case B: narrow_set_quad<B>(nd.fwd, tiles, lane, set8, top); break;
             PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8)
 #undef PG_CASE
             default: break;
@@ -146,7 +206,8 @@ __device__ __forceinline__ void scan_narrow_body(const P& p, uint32_t block_inde
 static __global__ __launch_bounds__(kBlockThreads) void scan_narrow_kernel(const ScanParams p) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
-  scan_narrow_body(p, blockIdx.x, gridDim.x, red, &fold_flag);
+  __shared__ uint32_t sets[kNarrowSetWords];
+  scan_narrow_body(p, blockIdx.x, gridDim.x, red, &fold_flag, sets);
 }
 
 // A single dictId-range leaf (WHERE dim = x, the commonest narrow filter): no mask stack, so EIGHT tiles fit per wave and iteration
@@ -216,6 +277,7 @@ template <bool kSingle>
 __global__ __launch_bounds__(kBlockThreads) void scan_narrow_batch_kernel(const BatchParams bp) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
+  __shared__ uint32_t sets[kNarrowSetWords];
   int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -224,8 +286,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_narrow_batch_kernel(const 
   const uint32_t first = bp.block_first[lo];
   typedef const __attribute__((address_space(4))) ScanParams ConstantScanParams;
   const ConstantScanParams& item = *(ConstantScanParams*)(bp.items + lo);
-  if constexpr (kSingle) scan_narrow_single_body(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
-  else scan_narrow_body(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
+  if constexpr (kSingle) scan_narrow_single_body(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);      // (a single SET leaf takes the general body: the octet form with the lookups' registers on top drops to three waves)
+  else scan_narrow_body(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag, sets);
 }
 
 }  // namespace pg

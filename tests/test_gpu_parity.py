@@ -231,7 +231,7 @@ def test_group_by_whole_int_map_range(engine):
 @pytest.mark.parametrize("n", [1, 2047, 4 * 2048, 4 * 2048 + 5, 9 * 2048 + 77, 300_007])
 def test_narrow_column_filters_four_tiles_at_a_time(engine, n):
     """scan_narrow_kernel: COUNT(*) / the docId bitmap of filters over dictionary columns of 1..8 bits (any AND / OR / NOT tree of dictId
-    ranges), four tiles per wave and iteration.  Whole quads, ragged quads, a single doc."""
+    ranges and dictId sets), four tiles per wave and iteration.  Whole quads, ragged quads, a single doc."""
     rng = np.random.default_rng(77 + n)
     cols, ids = [], []
     for b in range(1, 9):
@@ -247,6 +247,11 @@ def test_narrow_column_filters_four_tiles_at_a_time(engine, n):
              Q.or_(R(1, 0, 2), Q.not_(R(4, 8, 20)), R(6, 100, 101)),
              Q.and_(Q.or_(R(2, 1, 3), R(3, 0, 9)), Q.not_(Q.and_(R(4, 0, 16), R(5, 10, 60, ex=True))), R(6, 0, 127)),
              Q.not_(Q.not_(Q.or_(Q.and_(R(0, 1, 2), R(1, 1, 3)), Q.and_(R(2, 2, 7), Q.leaf(Q.Pred.match_all())), Q.leaf(Q.Pred.match_none()))))]
+    # IN / NOT IN over narrow columns (round 6b): a set of at most eight words, one register up to five bits, looked up in LDS above
+    SET = lambda col, members, ex=False: Q.leaf(Q.Pred.dict_set(col, sorted(members), cols[col].cardinality, exclusive=ex))
+    trees += [SET(0, [1]), SET(2, [0, 3, 6]), SET(4, [0, 7, 19, 31], ex=True), SET(5, [1, 2, 33, 62]), SET(6, range(3, 120, 7)), SET(7, [0, 31, 32, 63, 64, 200, 255], ex=True),
+              Q.and_(SET(3, [1, 2, 9, 15]), R(5, 5, 40), SET(7, range(0, 256, 3))),
+              Q.or_(Q.not_(SET(6, [5, 50, 100])), Q.and_(SET(1, [0, 3]), SET(4, range(0, 32, 2))), R(2, 6, 7))]
     with engine.open(seg) as g:
         for tree in trees:
             spec = Q.QuerySpec([(Q.COUNT, -1)], filter=tree)

@@ -155,7 +155,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
 
     # ---- C5: inverted-index AND of 3 postings -> docIds -> SUM, sparse (C = 16 / 64 / 256) and dense (C = 2 / 4 / 8) ----
     for vid, cards, seeds, picks in (("C5-sparse", (16, 64, 256), (11, 12, 13), (3, 5, 7)), ("C5-dense", (2, 4, 8), (21, 22, 23), (1, 2, 5))):
-        if not (want(vid) or want(vid + "-count") or (vid == "C5-sparse" and want("C5-scan-count"))):
+        if not (want(vid) or want(vid + "-count") or (vid == "C5-sparse" and (want("C5-scan-count") or want("C5-scan-count-in-list")))):
             continue
         t0 = time.time()
         cols = []
@@ -191,6 +191,12 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                 sspec = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(scan(0, picks[0]), scan(1, picks[1]), scan(2, picks[2])))
                 report("C5-scan-count", "BASELINE.json configs[4] without the inverted indexes, COUNT", "SELECT COUNT(*) WHERE p=%d AND q=%d AND r=%d by scanning p, q, r (%d / %d / %d bits)"
                        % (picks + tuple(c.bits for c in cols)), n_c5, sum(B(c) for c in cols), g, seg5, sspec)
+            if vid == "C5-sparse" and want("C5-scan-count-in-list"):
+                # IN lists over the same narrow columns: dictId-set leaves in scan_narrow_kernel (one register up to five bits, eight words of LDS above)
+                inl = lambda c, members: Q.leaf(Q.Pred.dict_set(c, members, cols[c].cardinality))
+                ispec = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(inl(0, [1, 3, 6, 12]), inl(1, list(range(0, 64, 5))), inl(2, list(range(1, 256, 9)))))
+                report("C5-scan-count-in-list", "BASELINE.json configs[4] without the inverted indexes, IN lists, COUNT", "SELECT COUNT(*) WHERE p IN (4 values) AND q IN (13 values) AND r IN (29 values) by scanning p, q, r (%d / %d / %d bits)"
+                       % tuple(c.bits for c in cols), n_c5, sum(B(c) for c in cols), g, seg5, ispec)
         del seg5, cols
 
     # ---- C1: 10 M rows, raw int32 forward index (BASELINE.json configs[0] is the reference's CPU case; COUNT(*) itself is O(1)) ----
