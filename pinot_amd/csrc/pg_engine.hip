@@ -5142,7 +5142,11 @@ pg_status enqueue_deferred(DeferredLaunch* L, std::vector<Deferred>& defs, pg_se
   BatchCtx* b = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_batch_mu);
-    for (size_t i = 0; i < g_batch_free.size(); ++i) if (g_batch_free[i]->device == device) { b = g_batch_free[i]; g_batch_free.erase(g_batch_free.begin() + (long)i); break; }
+    // The context released LAST is taken first (round 6b).  Taken from the front, a caller rotated through every context the process had ever
+    // needed at once -- sixteen after sixteen threads had run group-bys side by side -- and each of them grew its blob, set area and group
+    // table on ITS first use by the new shape: the first dozen calls of a shape took twice their time (PINOT_GPU_BATCH_TRACE,
+    // profiles/r6/batch_ctx_pool_lifo.txt; DESIGN.md section 9's "C5x64 in a busy process").
+    for (size_t i = g_batch_free.size(); i-- > 0;) if (g_batch_free[i]->device == device) { b = g_batch_free[i]; g_batch_free.erase(g_batch_free.begin() + (long)i); break; }
   }
   if (!b) { b = new BatchCtx(); b->device = device; }
   L->b = b;
