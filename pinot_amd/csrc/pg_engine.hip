@@ -2506,8 +2506,9 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
             return fail(PG_ERR_UNSUPPORTED, "group-by aggregation of a raw 8-byte column under a raw 8-byte range predicate (plan-time fallback)");
         }
       }
-      if (hash_plan.kind != 0 && ((kind == 0 && col.vkind != kValI32) || (col.encoding == PG_FWD_RAW_FIXED_BYTE && col.vkind != kValI32)))
-        return fail(PG_ERR_UNSUPPORTED, "group-by with raw keys beyond an int aggregating the 8-byte column %s (plan-time fallback)", col.name.c_str());
+      // (a RAW 8-byte input takes group_typed_direct_kernel<.., kHash> since round 6b; the SUM of a dictionary column with 8-byte values has no kernel with a hashed table)
+      if (hash_plan.kind != 0 && kind == 0 && col.vkind != kValI32 && col.encoding != PG_FWD_RAW_FIXED_BYTE)
+        return fail(PG_ERR_UNSUPPORTED, "group-by with raw keys beyond an int summing the 8-byte dictionary column %s (plan-time fallback)", col.name.c_str());
       if (kind == 0 && col.vkind == kValI64 && !col.h_dict_i64.empty()) {
         const double max_abs = std::max(std::fabs((double)col.h_dict_i64.front()), std::fabs((double)col.h_dict_i64.back()));
         if ((double)seg->num_docs * max_abs >= 9.2e18) return fail(PG_ERR_UNSUPPORTED, "group-by SUM of LONG column %s could overflow int64", col.name.c_str());
@@ -3485,7 +3486,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     for (int l = 0; l < pl.num_leaves; ++l) private_leaves &= pl.leaves[l].kind <= kLeafBitmap || pl.leaves[l].kind == kLeafDocRange;
     if (typed_direct && !private_leaves) return fail(PG_ERR_UNSUPPORTED, "group-by aggregation of a raw 8-byte column under a raw 8-byte range predicate (plan-time fallback)");
     const bool use_private = (g_engine.group_private || hash_plan.kind != 0) && private_leaves && gp.dense_ok && !want_bitmap && !typed_direct;
-    if (hash_plan.kind != 0 && !use_private) return fail(PG_ERR_UNSUPPORTED, "group-by with raw keys beyond an int: only 32-bit-domain aggregations under lane-private filter leaves");
+    if (hash_plan.kind != 0 && !use_private && !typed_direct) return fail(PG_ERR_UNSUPPORTED, "group-by with raw keys beyond an int: only 32-bit-domain or raw 8-byte aggregations under lane-private filter leaves");
     int pblocks = blocks, pthreads = geo.threads;
     size_t plds = lds;
     if (use_private) {
@@ -3879,7 +3880,13 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
           fg.first_doc = d_first_doc;
           fg.scan.filter_entries = nullptr; fg.scan.leap_tables = nullptr;
           for (int n = 0; n < fg.scan.num_nodes; ++n) fg.scan.nodes[n].flags &= ~(kNodeLeapfrog2 | kNodeCountEntries);
-          launch_group_private(false, pblocks, pthreads, plds, ctx->stream, fg);      // (plds: the set area, when the filter has dictId sets)
+          // (plds: the set area, when the filter has dictId sets.  A query whose aggregation runs in group_typed_direct_kernel never sized a
+          //  group_private_kernel launch: the pass takes that kernel's own geometry then)
+          const long long fd_tiles = ((long long)seg->num_docs + 2047) / 2048;
+          const int fd_threads = use_private ? pthreads : kBlockThreads;
+          const int fd_blocks = use_private ? pblocks : (int)std::max<long long>(1, std::min<long long>((fd_tiles + 3) / 4, (long long)seg->num_cus * 8));
+          if (!use_private) fg.set_lds_off = -1;
+          launch_group_private(false, fd_blocks, fd_threads, use_private ? plds : 0, ctx->stream, fg);
           HIP_TRY(hipGetLastError());
           done_docs = seg->num_docs;
           max_first_doc = 0xFFFFFFFEu;

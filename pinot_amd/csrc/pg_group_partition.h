@@ -486,7 +486,9 @@ static __global__ __launch_bounds__(256) void group_repartition_scatter_kernel(c
 // Table slots: SUM of LONG / INT: int64 add; SUM of FLOAT / DOUBLE: the slot holds a double (global_atomic_add_f64); MIN / MAX of raw LONG:
 // the value; of raw FLOAT / DOUBLE: its order-preserving 64-bit key (f64_order_key); of dictionary columns: the dictId.
 // ------------------------------------------------------------------------------------------------
-template <bool kWide>
+// kHash (round 6b): the keys are beyond an int -- the slots come from the hashed table (hashed_group_slots, pg_kernels.h: the Long / ArrayMap
+// holders of DictionaryBasedGroupKeyGenerator.java:628-806), everything behind the slot number is the same.
+template <bool kWide, bool kHash = false>
 static __global__ __launch_bounds__(256) void group_typed_direct_kernel(const GroupParams gp) {
   const int lane = threadIdx.x & 63;
   const long long num_tiles = ((long long)gp.scan.num_docs + 2047) / 2048;
@@ -497,7 +499,8 @@ static __global__ __launch_bounds__(256) void group_typed_direct_kernel(const Gr
     const uint32_t m = eval_filter_private(gp.scan, tile, lane, entries) & tail_mask(gp, tile, lane);
     if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
     uint32_t g[32];
-    decode_group_keys<kWide>(gp, tile, lane, g);
+    if constexpr (kHash) hashed_group_slots<true>(gp, tile, lane, m, g);
+    else decode_group_keys<kWide>(gp, tile, lane, g);
     const long long first_doc = tile * 2048 + lane * 32;
 #pragma unroll
     for (int j = 0; j < 32; ++j) if ((m >> j) & 1u) __hip_atomic_fetch_add(&gp.table_count[g[j]], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -2165,30 +2165,10 @@ __host__ __device__ __forceinline__ uint32_t lds_group_table_bytes(const GroupPa
   return bytes;
 }
 
-// PG_GROUP_MINMAX_LOOK=1: an LDS MIN / MAX slot is READ first and the atomic issued only when the doc's value beats it (a slot's extreme
-// moves ~ln(n) times in n docs).  Measured on C3 (1 B rows, 1000 groups, SUM + MAX): 0.987 -> 1.028 ms -- the returning read and the
-// divergent branch cost more than the atomics they save (profiles/r5/c3_look_before_atomic_ab.txt).  Off.
-#ifndef PG_GROUP_MINMAX_LOOK
-#define PG_GROUP_MINMAX_LOOK 0
-#endif
-// One 2048-doc tile.  kMasked: only the docs whose bit is set in the lane's mask `m` reach the table (a filter's result, and /
-// or the docs that exist in the last, partial tile); otherwise every doc of the tile does, with no exec masking around the atomics.
-// GP: GroupParams, or its constant-address-space form in device memory (an item of group_lds_batch_kernel)
-template <bool kLds, bool kMasked, bool kWide = false, bool kHash = false, typename GP = GroupParams>
-__device__ __forceinline__ void group_private_tile(const GP& gp, long long tile, int lane, uint32_t m, unsigned long long* t_cnt, long long* t_acc, uint8_t* lds) {
-  const int G = gp.num_groups;
-  const int logR = kLds ? gp.lds_log_replicas : 0;                       // (see lds_group_table_bytes)
-  const uint32_t cls = (uint32_t)lane & ((1u << logR) - 1u);
-  uint32_t lds_off = 0u;                                                // uniform: where the next sub-table starts
-  const long long first_doc = tile * 2048 + lane * 32;
-  uint32_t g[32];
-  // (Round 5: the tile's columns are read one after the other -- three dependent HBM round trips per tile and wave, 72 % of a wave's cycles
-  //  are waits.  One "touch" load per later column ahead of the first decode, so that the later loads find their lines on the way or in
-  //  the L2, made C3 21 % SLOWER (0.985 -> 1.195 ms; profiles/r5/c3_touch_columns_ab.txt): loads return in order, the real loads queue
-  //  behind the touches, and the touches compete with the other fifteen waves' demand loads for the same queues.  Round 3 saw the same in
-  //  scan_private_kernel.  Latency is hidden by the resident waves, not inside a wave.)
-  if constexpr (kHash) {
-    // Long / ArrayMap holders: the 64-bit key of every (matching) doc, then its slot in the hashed table; sixteen docs at a time
+// Long / ArrayMap holders (GroupParams.hash_kind != 0): the 64-bit key of every (matching) doc, then its slot in the hashed table; sixteen docs
+// at a time.  (group_private_tile<.., kHash> and group_typed_direct_kernel<.., true>)
+template <bool kMasked, typename GP>
+__device__ __forceinline__ void hashed_group_slots(const GP& gp, long long tile, int lane, uint32_t m, uint32_t (&g)[32]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       unsigned long long k[16];
@@ -2219,6 +2199,32 @@ __device__ __forceinline__ void group_private_tile(const GP& gp, long long tile,
         if (!kMasked || ((m >> (16 * h + j)) & 1u)) g[16 * h + j] = hash_slot_of(gp.hash_keys, gp.hash_mask, k[j]);
       }
     }
+}
+
+// PG_GROUP_MINMAX_LOOK=1: an LDS MIN / MAX slot is READ first and the atomic issued only when the doc's value beats it (a slot's extreme
+// moves ~ln(n) times in n docs).  Measured on C3 (1 B rows, 1000 groups, SUM + MAX): 0.987 -> 1.028 ms -- the returning read and the
+// divergent branch cost more than the atomics they save (profiles/r5/c3_look_before_atomic_ab.txt).  Off.
+#ifndef PG_GROUP_MINMAX_LOOK
+#define PG_GROUP_MINMAX_LOOK 0
+#endif
+// One 2048-doc tile.  kMasked: only the docs whose bit is set in the lane's mask `m` reach the table (a filter's result, and /
+// or the docs that exist in the last, partial tile); otherwise every doc of the tile does, with no exec masking around the atomics.
+// GP: GroupParams, or its constant-address-space form in device memory (an item of group_lds_batch_kernel)
+template <bool kLds, bool kMasked, bool kWide = false, bool kHash = false, typename GP = GroupParams>
+__device__ __forceinline__ void group_private_tile(const GP& gp, long long tile, int lane, uint32_t m, unsigned long long* t_cnt, long long* t_acc, uint8_t* lds) {
+  const int G = gp.num_groups;
+  const int logR = kLds ? gp.lds_log_replicas : 0;                       // (see lds_group_table_bytes)
+  const uint32_t cls = (uint32_t)lane & ((1u << logR) - 1u);
+  uint32_t lds_off = 0u;                                                // uniform: where the next sub-table starts
+  const long long first_doc = tile * 2048 + lane * 32;
+  uint32_t g[32];
+  // (Round 5: the tile's columns are read one after the other -- three dependent HBM round trips per tile and wave, 72 % of a wave's cycles
+  //  are waits.  One "touch" load per later column ahead of the first decode, so that the later loads find their lines on the way or in
+  //  the L2, made C3 21 % SLOWER (0.985 -> 1.195 ms; profiles/r5/c3_touch_columns_ab.txt): loads return in order, the real loads queue
+  //  behind the touches, and the touches compete with the other fifteen waves' demand loads for the same queues.  Round 3 saw the same in
+  //  scan_private_kernel.  Latency is hidden by the resident waves, not inside a wave.)
+  if constexpr (kHash) {
+    hashed_group_slots<kMasked>(gp, tile, lane, m, g);
     if (gp.first_doc != nullptr) {
       // numGroupsLimit pass: which docId created every group (the reference admits keys in docId order until the limit is reached)
 #pragma unroll

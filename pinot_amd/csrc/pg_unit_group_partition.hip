@@ -42,7 +42,8 @@ void launch_group_repartition(int num_chunks, hipStream_t stream, const Repartit
 }
 
 void launch_group_typed_direct(int blocks, hipStream_t stream, const GroupParams& gp) {
-  if (gp.wide_keys) group_typed_direct_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(gp);
+  if (gp.hash_kind != 0) group_typed_direct_kernel<false, true><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(gp);      // Long / ArrayMap holders: hashed table
+  else if (gp.wide_keys) group_typed_direct_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(gp);
   else group_typed_direct_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(gp);
 }
 

@@ -53,8 +53,40 @@ def test_int_holders_also_return_the_dict_id_tuples(engine):
             assert raw == gid
 
 
+@pytest.mark.parametrize("case", [HC.cases()[0], HC.cases()[2], HC.cases()[3]], ids=["long-2cols", "array-3cols", "long-dense"])
+def test_hashed_holders_over_raw_eight_byte_inputs(engine, case):
+    """Round 6b: SUM / MIN / MAX / AVG of RAW LONG, DOUBLE and FLOAT columns under keys beyond an int -- group_typed_direct_kernel<.., kHash>:
+    the slots from the hashed table, the accumulators as in the direct-indexed form (SumAggregationFunction.aggregateGroupBySV over a
+    no-dictionary column, DictionaryBasedGroupKeyGenerator.java:628-806 for the keys).  With a filter, and with numGroupsLimit binding."""
+    from pinot_amd import segment as S
+    seg, ids, specs = HC.build(case)
+    n, nk = seg.num_docs, len(case[2])
+    rng = np.random.default_rng(11)
+    lv = rng.integers(-(1 << 40), 1 << 40, n).astype(np.int64)
+    dv = (rng.standard_normal(n) * 1e6).round(3)
+    fv = rng.integers(-5000, 5000, n).astype(np.float32)
+    first = len(seg.columns)
+    seg2 = S.SegmentData(seg.name + "_raw8", n, list(seg.columns) + [S.Column.raw_typed("l", lv), S.Column.raw_typed("d", dv), S.Column.raw_typed("f", fv)])
+    keys = list(range(nk))
+    flt = Q.leaf(Q.Pred.dict_range(nk + 2, 0, 37))
+    specs2 = [Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, first), (Q.MAX, first + 1), (Q.MIN, first)], group_by=keys),
+              Q.QuerySpec([(Q.SUM, first + 1), (Q.AVG, first), (Q.MIN, first + 2), (Q.SUM, nk)], filter=flt, group_by=keys),
+              Q.QuerySpec([(Q.MAX, first), (Q.SUM, first + 2)], group_by=keys, num_groups_limit=50),
+              Q.QuerySpec([(Q.AVG, first + 1)], filter=flt, group_by=keys, num_groups_limit=7)]
+    with engine.open(seg2) as g:
+        for spec in specs2:
+            assert g.check(spec) == _abi.PG_OK
+            got = g.execute(spec)
+            want = oracle.execute(seg2, spec)
+            H.assert_results_equal(got, want)
+            assert got.group_key_kind == want.group_key_kind == case[3]
+            assert got.group_keys == want.group_keys and got.group_ids64 == want.group_ids64
+            assert got.num_groups_limit_reached == want.num_groups_limit_reached
+
+
 def test_plan_time_limits_of_the_hashed_holders(engine):
-    """What pg_query_check declines: 8-byte aggregation inputs, and a table beyond PINOT_GPU_GROUP_TABLE_BYTES."""
+    """What pg_query_check declines: the SUM of a DICTIONARY column with 8-byte values (raw 8-byte inputs run: the test above), and a table
+    beyond PINOT_GPU_GROUP_TABLE_BYTES."""
     from pinot_amd import segment as S
     case = HC.cases()[0]
     seg, ids, specs = HC.build(case)

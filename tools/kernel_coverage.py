@@ -143,6 +143,7 @@ def table(Q, n):
     add("partition-two-level", force, "group_partition_scatter_kernel", Q.QuerySpec([(Q.SUM, V)], group_by=[K1, K2]))                  # 7.5 M raw keys
     add("group-typed", {}, None, Q.QuerySpec([(Q.SUM, RL), (Q.MAX, RD)], filter=f_lt(500), group_by=[K]))
     add("group-typed-wide", {}, None, Q.QuerySpec([(Q.SUM, RL)], filter=f_lt(10), group_by=[K1, K4]))
+    add("group-typed-hash", {}, None, Q.QuerySpec([(Q.SUM, RL), (Q.MIN, RD)], filter=f_lt(20), group_by=[K1, K2, K4]))                 # raw 8-byte inputs under a LongMap holder: group_typed_direct_kernel<false, true>
     add("group-double-key", {}, None, Q.QuerySpec([(Q.SUM, V), (Q.COUNT, -1)], filter=f_lt(500), group_by=[RD], num_groups_limit=1000))           # rank_image_keys / rank_image_pack kernels (+ rocPRIM)
     add("group-wide-long-key", {}, None, Q.QuerySpec([(Q.MAX, F)], filter=f_lt(50), group_by=[RL, B], num_groups_limit=500))
     add("group-raw-key", {}, None, Q.QuerySpec([(Q.SUM, V)], filter=L(Q.Pred.raw_range(RI, 0, 5000)), group_by=[RI]))                 # raw_min_max / build_raw_key_image
