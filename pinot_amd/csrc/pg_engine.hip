@@ -2945,12 +2945,17 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     finish_geometry(seg, &lw, 0, need_queue, kBlockThreads / 64, agg_wave_cap, &geo);
     int blocks = geo.blocks;
     const size_t lds = geo.lds;
-    size_t hist_lds = 0;
+    size_t hist_lds = 0, hist_set_off = 0;
     if (use_hist) {
       // one histogram per workgroup of 16 wavefronts; as many workgroups per CU as LDS and registers admit
       const int per_word = 32 / hist_cw;
       hist_lds = (((size_t)(seg->cols[(size_t)hist_col].cardinality + per_word - 1) / per_word * 4) + 15) & ~(size_t)15;
       hist_lds = std::max(hist_lds, sizeof(BlockPartial) * (kHistBlockThreads / 64) + 16);      // the reduction records (+ the fold flag) reuse the counters' LDS
+      // the filter's dictId sets (IN lists) behind the counters: ScanParams.set_leaves_in_lds = 1 + the area's byte offset (scan_hist_body)
+      hist_set_off = 0;
+      if (g_engine.set_lds && hist_lds + (size_t)kSetLdsWords * 4 <= 150 * 1024)
+        for (int nd = 0; nd < sp.num_nodes; ++nd) if (sp.nodes[nd].op == PG_FILTER_LEAF && sp.nodes[nd].kind == kLeafDictSet) hist_set_off = hist_lds;
+      if (hist_set_off != 0) hist_lds += (size_t)kSetLdsWords * 4;
       const size_t per_block = hist_lds + 256;
       int bpc = std::max(1, std::min(waves_scan_hist(hist_cw, hist_guarded) / (kHistBlockThreads / 64), (int)((160 * 1024 - 2048) / per_block)));
       if (g_engine.blocks_per_cu > 0) bpc = g_engine.blocks_per_cu;
@@ -3200,6 +3205,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     sp.lane_skip = g_engine.lane_skip ? 1 : 0;
     sp.set_leaves_in_lds = 0;
     if (g_engine.set_lds) for (int nd = 0; nd < sp.num_nodes; ++nd) if (sp.nodes[nd].op == PG_FILTER_LEAF && sp.nodes[nd].kind == kLeafDictSet) sp.set_leaves_in_lds = 1;
+    if (use_hist) sp.set_leaves_in_lds = hist_set_off != 0 ? 1 + (int32_t)hist_set_off : 0;      // (the histogram kernel keeps the area in its dynamic LDS, behind the counters)
     sp.sparse_lanes = g_engine.sparse_lanes;
     sp.fold_one_counter = g_engine.fold_one_counter;
     if (defer_index_and) {

@@ -166,6 +166,9 @@ __device__ __forceinline__ void scan_hist_body(const P& p, uint32_t block_index,
   constexpr int kPerWord = 32 / CW;
   const int hist_words = (C + kPerWord - 1) / kPerWord;
   for (int w = threadIdx.x; w < hist_words; w += blockDim.x) hist[w] = 0u;
+  // the filter's dictId sets behind the counters (the engine made room: set_leaves_in_lds = 1 + the area's byte offset), staged once per workgroup
+  uint32_t* set_lds = nullptr;
+  if (p.set_leaves_in_lds > 1) { set_lds = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(hist) + (p.set_leaves_in_lds - 1)); stage_filter_sets(p, set_lds); }
   __syncthreads();
 
   unsigned long long count = 0;
@@ -191,7 +194,7 @@ __device__ __forceinline__ void scan_hist_body(const P& p, uint32_t block_index,
         continue;
       }
     }
-    uint32_t m = eval_filter_private(p, tile, lane, entries);
+    uint32_t m = eval_filter_private(p, tile, lane, entries, nullptr, set_lds);
     const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
     count += (unsigned)__builtin_popcount(m);

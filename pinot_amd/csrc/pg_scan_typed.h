@@ -177,7 +177,10 @@ __device__ __forceinline__ void agg_dict64_private(const AC& ac, long long tile,
 // `block_index` of `num_blocks`: the workgroup's place among those working on this parameter block (the whole grid, or an item's share of
 // scan_typed_batch_kernel's launch).  P: ScanParams, or its constant-address-space form in device memory.
 template <int kAggSlots, typename P>
-__device__ __forceinline__ void scan_private_typed_body(const P& p, uint32_t block_index, uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr) {
+__device__ __forceinline__ void scan_private_typed_body(const P& p, uint32_t block_index, uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr, uint32_t* set_lds) {
+  // (the filter's dictId sets in LDS, once per workgroup: pg_kernels.h stage_filter_sets)
+  if (p.set_leaves_in_lds == 0) set_lds = nullptr;
+  if (set_lds != nullptr) stage_filter_sets(p, set_lds);
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
@@ -194,7 +197,7 @@ __device__ __forceinline__ void scan_private_typed_body(const P& p, uint32_t blo
   const long long tile_limit = listed ? (long long)*p.tile_count : num_tiles;
   for (long long tile_it = (long long)block_index * waves_per_block + wave_in_block; tile_it < tile_limit; tile_it += total_waves) {
     const long long tile = listed ? (long long)p.tile_list[tile_it] : tile_it;
-    uint32_t m = eval_filter_private(p, tile, lane, entries);
+    uint32_t m = eval_filter_private(p, tile, lane, entries, nullptr, set_lds);
     const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);
     m &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (int)rem) - 1u));
     if (p.out_bitmap) reinterpret_cast<uint32_t*>(p.out_bitmap)[tile * 64 + lane] = m;
@@ -250,7 +253,8 @@ template <int kAggSlots>
 __global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : (kAggSlots == 2 ? 4 : PG_TYPED_WAVES_MANY))) void scan_private_typed_kernel(const ScanParams p) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
-  scan_private_typed_body<kAggSlots>(p, blockIdx.x, gridDim.x, red, &fold_flag);
+  __shared__ uint32_t set_lds[kSetLdsWords];
+  scan_private_typed_body<kAggSlots>(p, blockIdx.x, gridDim.x, red, &fold_flag, set_lds);
 }
 
 // pg_execute_batch's shared launch for items of this kernel's shape (aggregations over raw INT / LONG / FLOAT / DOUBLE columns and 8-byte
@@ -260,6 +264,7 @@ template <int kAggSlots>
 __global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : (kAggSlots == 2 ? 4 : PG_TYPED_WAVES_MANY))) void scan_typed_batch_kernel(const BatchParams bp) {
   __shared__ BlockPartial red[kBlockThreads / 64];
   __shared__ uint32_t fold_flag;
+  __shared__ uint32_t set_lds[kSetLdsWords];
   int lo = 0, hi = bp.num_items - 1;                // the last item whose first workgroup is at or before this one
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(kBlockThreads, (kAggSlots == 1 ? PG_TYPED_WAVES : (
   const uint32_t first = bp.block_first[lo];
   typedef const __attribute__((address_space(4))) ScanParams ConstantScanParams;
   const ConstantScanParams& item = *(ConstantScanParams*)(bp.items + lo);
-  scan_private_typed_body<kAggSlots>(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
+  scan_private_typed_body<kAggSlots>(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag, set_lds);
 }
 
 }  // namespace pg
