@@ -507,6 +507,40 @@ def test_group_bys_beside_other_shapes_and_with_a_groups_limit(engine):
         [g.close() for g in opened]
 
 
+def test_group_bys_publish_themselves_under_concurrency(engine):
+    """Round 6b: the last workgroup of a group-by item writes the item's table slice to the pinned image, zeroes it and stores the item's
+    sequence number (GroupParams.host_table) -- no copy, no memset behind the launch.  Six threads, each with batches over all segments and
+    single pg_execute calls (the one-item form) in turn, every thread on batch contexts of its own: every answer against the oracle, and the
+    tables must come back zeroed for whoever takes the context next."""
+    import threading
+    segs = _segments()
+    opened = [engine.open(seg) for seg in segs]
+    try:
+        variants = ["sum-max", "filtered", "two-keys", "count-only"]
+        want = {v: [oracle.execute(seg, sp) for seg, sp in zip(segs, _group_specs(segs, v))] for v in variants}
+        errors = []
+
+        def work(t):
+            try:
+                for rep in range(6):
+                    v = variants[(t + rep) % len(variants)]
+                    specs = _group_specs(segs, v)
+                    for s, (status, res) in enumerate(engine.execute_batch(opened, specs)):
+                        assert status == _abi.PG_OK, (t, rep, v, s)
+                        H.assert_results_equal(res, want[v][s])
+                    s = (t * 7 + rep) % len(segs)
+                    H.assert_results_equal(opened[s].execute(specs[s]), want[v][s])
+            except Exception as e:          # noqa: BLE001 -- reported by the main thread
+                errors.append(repr(e))
+
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        assert errors == [], errors[:3]
+    finally:
+        [g.close() for g in opened]
+
+
 # ---- narrow-filter COUNTs and typed aggregations share launches as well (round 5) ----
 def _narrow_typed_segments(count=9):
     segs = []
