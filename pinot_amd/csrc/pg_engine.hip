@@ -3005,9 +3005,12 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     // (the one-stream shape `SUM(v) WHERE v in range` keeps scan_private_kernel's fused decode)
     bool use_simple = g_engine.scan_simple && use_private && !use_hist && !use_narrow && !use_sparse && !want_bitmap && lw.tile_list == nullptr && sp.num_nodes <= 1 &&
                       pl.num_agg_cols <= 1 && !(g_engine.flags & PG_CFG_PROFILE_WAVES) && !(out && (lw.stats_leap2_flagged || lw.stats_chain_flagged));
+    bool simple_set = false;
     if (use_simple && sp.num_nodes == 1) {
       const DevNode& dn = sp.nodes[0];
-      use_simple = dn.op == PG_FILTER_LEAF && dn.kind == kLeafDictRange && dn.bits >= 1 && dn.bits <= kSimpleMaxBits && (dn.flags & (kNodeCountEntries | kNodeLeapfrog2)) == 0;
+      // (a dictId SET over a column of at most 16 bits -- its words fit the LDS area -- takes scan_simple_set_kernel: round 6b)
+      simple_set = dn.op == PG_FILTER_LEAF && dn.kind == kLeafDictSet && g_engine.set_lds && dn.bits <= 16;
+      use_simple = dn.op == PG_FILTER_LEAF && (dn.kind == kLeafDictRange || simple_set) && dn.bits >= 1 && dn.bits <= kSimpleMaxBits && (dn.flags & (kNodeCountEntries | kNodeLeapfrog2)) == 0;
     }
     if (use_simple && pl.num_agg_cols == 1) {
       const DevAggCol& ac = sp.agg_cols[0];
@@ -3242,7 +3245,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         // items of scan_simple_kernel's / scan_raw_kernel's shape share a launch of their own kind (scan_lean_batch_kernel), the rest the general one
         const bool lean_batch = g_engine.lean_batch;
         sp.lean_kind = hist_item ? (hist_cw == 8 ? 3 : (hist_cw == 16 ? 4 : 5)) : narrow_item ? (narrow_single ? 8 : 7) : typed_item ? (pl.num_agg_cols <= 1 ? 9 : (pl.num_agg_cols == 2 ? 10 : 11))
-                       : use_simple ? 1 : (use_raw ? 2 : 0);
+                       : (use_simple && !simple_set) ? 1 : (use_raw ? 2 : 0);      // (a set leaf: the general body, which keeps the sets in LDS; the lean batch kernel has no set area)
         if (!lean_batch && sp.lean_kind == 1) sp.lean_kind = 0;      // (a raw-shaped item has no general form when its column is aggregated: it stays lean)
         if (sp.lean_kind == 2 && !lean_batch && use_private) sp.lean_kind = 0;
         auto item = std::make_shared<LoweredItem>();
@@ -3285,7 +3288,7 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
     if (use_hist) launch_scan_hist(hist_cw, hist_guarded, blocks, hist_lds, ctx->stream, sp);
     else if (use_narrow) launch_scan_narrow(narrow_single, blocks, ctx->stream, sp);
     else if (use_sparse) launch_scan_sparse(one, blocks, ctx->stream, sp);
-    else if (use_simple) launch_scan_simple(blocks, lean_threads, ctx->stream, sp);
+    else if (use_simple) launch_scan_simple(blocks, lean_threads, ctx->stream, sp, simple_set && use_simple);
     else if (use_raw) launch_scan_raw(blocks, lean_threads, ctx->stream, sp);
     else if (use_private && fuse_fsm) launch_scan_private_fsm(pl.num_agg_cols, blocks, ctx->stream, sp);
     else if (use_private) launch_scan_private(pl.num_agg_cols, blocks, ctx->stream, sp);

@@ -47,7 +47,7 @@ void launch_scan_private_batch(bool one_slot, int total_blocks, hipStream_t stre
 void launch_scan_sparse(bool one_slot, int blocks, hipStream_t stream, const ScanParams& p);      // one_slot: at most one aggregated column
 int waves_scan_sparse(bool one_slot);
 // scan_simple_kernel: one dictionary-range leaf (or none) + at most one aggregated packed column of <= 20 bits (pg_scan_simple.h)
-void launch_scan_simple(int blocks, int threads, hipStream_t stream, const ScanParams& p);      // threads: kBlockThreads or kWideBlockThreads
+void launch_scan_simple(int blocks, int threads, hipStream_t stream, const ScanParams& p, bool set_leaf = false);      // threads: kBlockThreads or kWideBlockThreads; set_leaf: scan_simple_set_kernel (the one leaf is a dictId set, looked up in LDS)
 int waves_scan_simple();
 // scan_raw_kernel: one raw INT range leaf (or no filter) + at most one aggregated raw INT column, five waves per SIMD, coalesced reads (pg_scan_raw.h)
 void launch_scan_raw(int blocks, int threads, hipStream_t stream, const ScanParams& p);

@@ -1,4 +1,4 @@
-// scan_simple_kernel: ONE dictionary-range leaf (or no filter at all) and at most ONE aggregated column read as bit-packed fields --
+// scan_simple_kernel: ONE dictionary-range leaf (or no filter at all; scan_simple_set_kernel: one dictId-SET leaf) and at most ONE aggregated column read as bit-packed fields --
 // `SELECT COUNT(*) / SUM(v) / MIN / MAX / AVG(v) ... WHERE f <op> x`: a single-predicate filter in front of a single aggregated column,
 // the shape of BASELINE.json configs[1] and the commonest shape of a segment query.
 //
@@ -37,6 +37,34 @@ __device__ __forceinline__ uint32_t simple_range_dispatch(int b, WP lane_words, 
   return __builtin_bitreverse32(m);      // value j -> bit j
 }
 
+// The leaf as a dictId SET (InPredicateEvaluator / NotInPredicateEvaluator; round 6b): the set's words are in LDS (stage_filter_sets, zero-padded
+// to the column's dictId range), a lookup is one ds_read_b32 -- eight at a time, so that the registers stay those of the range form.
+template <int B, int H, typename WP>
+__device__ __forceinline__ void set16_simple(WP __restrict__ lane_words, const uint32_t* set_lds, uint32_t& m) {
+  uint32_t v[16];
+  decode16_private<B, H>(lane_words, v);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    uint32_t x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = set_lds[v[8 * g + j] >> 5];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = (m << 1) | __builtin_amdgcn_ubfe(x[j], v[8 * g + j] & 31u, 1);
+  }
+}
+template <typename WP>
+__device__ __forceinline__ uint32_t simple_set_dispatch(int b, WP lane_words, const uint32_t* set_lds) {
+  uint32_t m = 0;
+  switch (b) {
+#define PG_CASE(B) case B: set16_simple<B, 0>(lane_words, set_lds, m); set16_simple<B, 1>(lane_words, set_lds, m); break;
+    PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10)
+    PG_CASE(11) PG_CASE(12) PG_CASE(13) PG_CASE(14) PG_CASE(15) PG_CASE(16)
+#undef PG_CASE
+    default: break;
+  }
+  return __builtin_bitreverse32(m);      // value j -> bit j
+}
+
 template <typename WP>
 __device__ __forceinline__ void simple_agg_dispatch(int b, WP lane_words, uint32_t m, bool need_sum, bool need_minmax,
                                                     uint32_t& psum, unsigned long long& wsum, uint32_t& umin, uint32_t& umax) {
@@ -52,8 +80,11 @@ __device__ __forceinline__ void simple_agg_dispatch(int b, WP lane_words, uint32
 
 // `block_index` of `num_blocks`: the workgroup's place among those that work on this query (the whole grid, or one item's share of a
 // batch launch: scan_lean_batch_kernel).  P: ScanParams, or its constant-address-space form there.
-template <typename P>
-__device__ __forceinline__ void scan_simple_body(const P& p, uint32_t block_index, uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr) {
+// kSet: the one leaf is a dictId set over a column of at most 16 bits (scan_simple_set_kernel: a kernel of its own, so that the range form's
+// code and registers -- the headline's -- stay what they were); `set_lds`: kSetLdsWords words of the workgroup's LDS.
+template <bool kSet = false, typename P>
+__device__ __forceinline__ void scan_simple_body(const P& p, uint32_t block_index, uint32_t num_blocks, BlockPartial* red, uint32_t* fold_flag_ptr, uint32_t* set_lds = nullptr) {
+  if constexpr (kSet) stage_filter_sets(p, set_lds);
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
@@ -73,7 +104,8 @@ __device__ __forceinline__ void scan_simple_body(const P& p, uint32_t block_inde
     uint32_t m = 0xFFFFFFFFu;
     if (has_filter) {
       const GlobalWords words = global_words(L.fwd + tile * (256ll * L.bits)) + lane * L.bits;
-      m = L.lo == 0 ? simple_range_dispatch<true>(L.bits, words, 0u, L.span) : simple_range_dispatch<false>(L.bits, words, (uint32_t)L.lo, L.span);
+      if constexpr (kSet) m = simple_set_dispatch(L.bits, words, set_lds);
+      else m = L.lo == 0 ? simple_range_dispatch<true>(L.bits, words, 0u, L.span) : simple_range_dispatch<false>(L.bits, words, (uint32_t)L.lo, L.span);
       if (L.exclusive) m = ~m;
     }
     const long long rem = (long long)p.num_docs - (tile * 2048 + lane * 32);        // docs past numDocs (last tile only)

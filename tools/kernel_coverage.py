@@ -83,6 +83,7 @@ def table(Q, n):
     add = lambda *e: T.append(e)
     # ---- the lane-private scan kernels ----
     add("simple", {}, "scan_simple_kernel", Q.QuerySpec([(Q.SUM, V)], filter=f_lt(100)))
+    add("simple-set", {}, "scan_simple_kernel", Q.QuerySpec([(Q.SUM, V), (Q.COUNT, -1)], filter=L(Q.Pred.dict_set(F, list(range(0, 300, 3)), 1000))))      # scan_simple_set_kernel: the one leaf an IN list, its words in LDS
     add("raw", {}, "scan_raw_kernel", Q.QuerySpec([(Q.COUNT, -1)], filter=L(Q.Pred.raw_range(RI, -1000, 250000))))
     add("raw-sum", {}, "scan_raw_kernel", Q.QuerySpec([(Q.SUM, RI), (Q.MAX, RI)], filter=L(Q.Pred.raw_range(RI, -1000, 250000))))
     add("private-1", {}, "scan_private_kernel", Q.QuerySpec([(Q.SUM, V), (Q.COUNT, -1)], filter=Q.and_(f_lt(300), L(Q.Pred.dict_range(K, 100, 900)))))
