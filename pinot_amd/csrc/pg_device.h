@@ -229,7 +229,7 @@ struct ScanParams {
   int32_t sparse_num_windows;
   int32_t set_leaves_in_lds;       // scan_private_*: 1 = the filter's dictId sets (IN lists) are staged in LDS once per workgroup (pg_kernels.h stage_filter_sets)
   uint8_t fsm_delta[64];                     // [state << 4 | input]: next state | entries << 4 (pg_filter_fsm.h's delta, four input bits wide)
-  int32_t lean_kind;               // pg_execute_batch: 0 the general lane-private body, 1 the item has scan_simple_kernel's shape, 2 scan_raw_kernel's
+  int32_t lean_kind;               // pg_execute_batch: 0 the general lane-private body, 1 the item has scan_simple_kernel's shape, 2 scan_raw_kernel's, 13 scan_simple_set_kernel's (3..12: pg_engine.hip "kinds of shared launch")
                                    // (scan_lean_batch_kernel runs those at five waves per SIMD)
 };
 

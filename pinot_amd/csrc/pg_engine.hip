@@ -3245,8 +3245,8 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
         // items of scan_simple_kernel's / scan_raw_kernel's shape share a launch of their own kind (scan_lean_batch_kernel), the rest the general one
         const bool lean_batch = g_engine.lean_batch;
         sp.lean_kind = hist_item ? (hist_cw == 8 ? 3 : (hist_cw == 16 ? 4 : 5)) : narrow_item ? (narrow_single ? 8 : 7) : typed_item ? (pl.num_agg_cols <= 1 ? 9 : (pl.num_agg_cols == 2 ? 10 : 11))
-                       : (use_simple && !simple_set) ? 1 : (use_raw ? 2 : 0);      // (a set leaf: the general body, which keeps the sets in LDS; the lean batch kernel has no set area)
-        if (!lean_batch && sp.lean_kind == 1) sp.lean_kind = 0;      // (a raw-shaped item has no general form when its column is aggregated: it stays lean)
+                       : use_simple ? (simple_set ? 13 : 1) : (use_raw ? 2 : 0);      // (13: scan_lean_batch_kernel<13>, the simple body with its one set leaf in LDS)
+        if (!lean_batch && (sp.lean_kind == 1 || sp.lean_kind == 13)) sp.lean_kind = 0;      // (a raw-shaped item has no general form when its column is aggregated: it stays lean)
         if (sp.lean_kind == 2 && !lean_batch && use_private) sp.lean_kind = 0;
         auto item = std::make_shared<LoweredItem>();
         item->sp = sp;

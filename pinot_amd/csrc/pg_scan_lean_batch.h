@@ -15,7 +15,7 @@ namespace pg {
 #define PG_LEAN_BATCH_WAVES 5
 #endif
 
-// kKind: ScanParams.lean_kind of EVERY item of the launch (one kernel with both bodies spilled 23 registers: the engine groups a batch's
+// kKind: ScanParams.lean_kind of EVERY item of the launch -- 1: scan_simple_body, 2: scan_raw_body, 13: scan_simple_body<kSet> -- (one kernel with both bodies spilled 23 registers: the engine groups a batch's
 // items by kind, a launch per kind)
 template <int kKind>
 // (the raw body keeps a whole 8 KB tile per wave in flight: with the item's fields in registers as well it wants 4 waves per SIMD -- as
@@ -33,7 +33,11 @@ __global__ __launch_bounds__(kBlockThreads, (kKind == 2 ? 4 : PG_LEAN_BATCH_WAVE
   typedef const __attribute__((address_space(4))) ScanParams ConstantScanParams;
   const ConstantScanParams& item = *(ConstantScanParams*)(bp.items + lo);
   if constexpr (kKind == 2) scan_raw_body(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
-  else scan_simple_body(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
+  else if constexpr (kKind == 13) {
+    // (scan_simple_set_kernel's body: the item's one leaf is a dictId set of at most 16 bits, staged in LDS from the batch's blob)
+    __shared__ uint32_t set_lds[kSetLdsWords];
+    scan_simple_body<true>(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag, set_lds);
+  } else scan_simple_body(item, blockIdx.x - first, bp.block_first[lo + 1] - first, red, &fold_flag);
 }
 
 }  // namespace pg

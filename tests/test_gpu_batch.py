@@ -667,3 +667,32 @@ def test_items_with_dictid_sets_share_the_launch_of_their_kind():
             largest[shape] = max(largest.get(shape, 0), int(m.group(1)))
     for name, items in report["shapes"].items():
         assert largest.get(name, 0) >= items - 2, (name, largest, proc.stderr[-1500:])
+
+
+@pytest.mark.parametrize("bits", [1, 2, 5, 6, 9, 10, 13, 16])
+def test_one_in_list_in_front_of_one_column_alone_and_in_a_batch(engine, bits):
+    """`SUM(v) ... WHERE f IN (...)` / `NOT IN (...)` has scan_simple_kernel's shape: alone it takes scan_simple_set_kernel, as items of a batch
+    scan_lean_batch_kernel<13> (ScanParams.lean_kind 13) -- the set's words in LDS, from the query's own buffer or from the batch's blob.
+    Filter columns of 1 .. 16 bits (InPredicateEvaluatorFactory.java:158-230, DictionaryBasedInPredicateEvaluator, is what the sets restate), ragged last tiles, IN and NOT IN."""
+    card = 2 if bits == 1 else (1 << bits) - (1 << (bits - 2)) + 1          # needs exactly `bits` bits
+    segs, specs = [], []
+    for s, n in enumerate([2047, 70001, 333337, 1000003, 4096, 1]):
+        rng = np.random.default_rng(7000 + 31 * bits + s)
+        v = S.Column.synthetic_uniform("v", n, (np.arange(900 + s, dtype=np.int64) * 11 - 4000).astype(np.int32), seed=5 * s + bits)
+        f = S.Column.synthetic_uniform("f", n, np.arange(card, dtype=np.int32) * 3, seed=77 * s + bits)
+        assert f.bits == bits
+        segs.append(S.SegmentData("in%d_%d" % (bits, s), n, [v, f]))
+        members = sorted(set(int(x) for x in rng.integers(0, card, max(1, card // 3))))
+        flt = Q.leaf(Q.Pred.dict_set(1, members, card, exclusive=(s % 2 == 1)))
+        specs.append(Q.QuerySpec([(Q.SUM, 0), (Q.COUNT, -1)] if s % 3 else [(Q.MIN, 0), (Q.MAX, 0), (Q.AVG, 0)], filter=flt))
+    opened = [engine.open(seg) for seg in segs]
+    try:
+        wants = [oracle.execute(seg, spec) for seg, spec in zip(segs, specs)]
+        for g, spec, want in zip(opened, specs, wants):
+            H.assert_results_equal(g.execute(spec), want)
+        for rep in range(2):
+            for s, (status, res) in enumerate(engine.execute_batch(opened, specs)):
+                assert status == _abi.PG_OK, (bits, s)
+                H.assert_results_equal(res, wants[s])
+    finally:
+        [g.close() for g in opened]

@@ -355,6 +355,7 @@ def main():
             # (dictId-range leaves only: a set leaf uploads its words ahead of the kernel, and an item with work of its own ahead of it is not shared)
             "batch-private-4": Q.QuerySpec([(Q.SUM, V), (Q.MAX, F), (Q.MIN, K)], filter=Q.or_(f_lt(100), L(Q.Pred.dict_range(K, 400, 460)))),
             "batch-simple": Q.QuerySpec([(Q.SUM, V)], filter=f_lt(100)),
+            "batch-simple-set": Q.QuerySpec([(Q.SUM, V), (Q.COUNT, -1)], filter=L(Q.Pred.dict_set(F, list(range(0, 300, 3)), 1000))),      # scan_lean_batch_kernel<13>
             "batch-raw": Q.QuerySpec([(Q.COUNT, -1)], filter=L(Q.Pred.raw_range(RI, -1000, 250000))),
             "batch-hist-8": Q.QuerySpec([(Q.SUM, W8)], filter=f_lt(100)),
             "batch-hist-16": Q.QuerySpec([(Q.SUM, W16)], filter=f_lt(100)),
