@@ -2506,9 +2506,7 @@ static pg_status check_query_plan(const pg_segment* seg, const pg_query* q, int 
             return fail(PG_ERR_UNSUPPORTED, "group-by aggregation of a raw 8-byte column under a raw 8-byte range predicate (plan-time fallback)");
         }
       }
-      // (a RAW 8-byte input takes group_typed_direct_kernel<.., kHash> since round 6b; the SUM of a dictionary column with 8-byte values has no kernel with a hashed table)
-      if (hash_plan.kind != 0 && kind == 0 && col.vkind != kValI32 && col.encoding != PG_FWD_RAW_FIXED_BYTE)
-        return fail(PG_ERR_UNSUPPORTED, "group-by with raw keys beyond an int summing the 8-byte dictionary column %s (plan-time fallback)", col.name.c_str());
+      // (an 8-byte input under a hashed holder -- RAW, or the SUM of a dictionary column with 8-byte values -- takes group_typed_direct_kernel<.., kHash>: round 6b)
       if (kind == 0 && col.vkind == kValI64 && !col.h_dict_i64.empty()) {
         const double max_abs = std::max(std::fabs((double)col.h_dict_i64.front()), std::fabs((double)col.h_dict_i64.back()));
         if ((double)seg->num_docs * max_abs >= 9.2e18) return fail(PG_ERR_UNSUPPORTED, "group-by SUM of LONG column %s could overflow int64", col.name.c_str());
@@ -3480,6 +3478,9 @@ static pg_status execute_impl(pg_segment* seg, const pg_query* q, pg_result* out
       // MIN / MAX run on dictIds whatever the value type; only a SUM reads 8-byte / floating-point dictionary entries
       ga.vkind = (ga.kind == kGroupSum) ? c.vkind : kValI32;
       if (c.is_raw && c.vkind != kValI32) { typed_direct = true; ga.vkind = c.vkind; }      // group_typed_direct_kernel: the value type decides the accumulator
+      // (the SUM of a dictionary column with 8-byte values under a Long / ArrayMap holder: the staged kernel that gathers such values has no
+      //  hashed table, group_typed_direct_kernel<.., kHash> gathers them too)
+      if (hash_plan.kind != 0 && ga.vkind != kValI32) typed_direct = true;
       if (ga.vkind != kValI32) gp.dense_ok = 0;
       if (ga.vkind == kValI64 && !c.is_raw) {
         // the table slot is one wrapping int64: refuse (plan-time fallback) when numDocs * max|value| could overflow it

@@ -77,7 +77,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
         return lambda matched: B(col) if matched * 16 >= rows else min(B(col), matched * 64)
 
     # ---- C2 / C3 on 1 B rows: the headline's v and f, v under two dictionaries without structure, and the C3 columns ----
-    if any(want(x) for x in ("C2b-irregular", "C2b-window", "C2a-affine", "C2a-irregular", "C3", "C3-filter", "C3-irregular", "COUNT-filter", "C2b-1pct", "C2b-50pct", "AND3-scan", "AND-OR-scan", "AND-NOT-scan", "NOT-NOT-scan", "C2b-in-list", "C2b-irregular-in-list", "C3-in-list")):
+    if any(want(x) for x in ("C2b-irregular", "C2b-window", "C2a-affine", "C2a-irregular", "C3", "C3-filter", "C3-irregular", "COUNT-filter", "C2b-1pct", "C2b-50pct", "AND3-scan", "AND-OR-scan", "AND-NOT-scan", "NOT-NOT-scan", "AND3-scan-bound", "AND-OR-scan-bound", "AND-NOT-scan-bound", "NOT-NOT-scan-bound", "C2b-in-list", "C2b-irregular-in-list", "C3-in-list")):
         t0 = time.time()
         v_irr = _shared(S, v, "v_irr", v_dictionary("irregular"))
         v_win = _shared(S, v, "v_win", v_dictionary("window"))
@@ -150,6 +150,12 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                             out[-1]["oracle_entries_s"] = time.perf_counter() - t_o
                         else:
                             out[-1]["entries_match_oracle"] = None
+                # the same query from a caller that does not read the exact statistic (PG_QUERY_STATS_UPPER_BOUND_OK: no transducer, no pass)
+                if want(vid + "-bound"):
+                    spb = Q.QuerySpec([(Q.SUM, 0)], filter=flt3, stats_upper_bound_ok=True)
+                    report(vid + "-bound", "a leap-frogging filter at 1 B rows, the statistic's upper bound accepted (PG_QUERY_STATS_UPPER_BOUND_OK)", sql, n,
+                           B(v) + B(f) + B(k) + (B(b) if vid not in ("AND-NOT-scan", "NOT-NOT-scan") else 0), g, seg, spb)
+                    out[-1]["filter_entries_exact"] = bool(g.execute(spb).filter_entries_exact)
             if want("COUNT-filter"):
                 report("COUNT-filter", "filter only", "SELECT COUNT(*) WHERE f < 100", n, B(f), g, seg, Q.QuerySpec([(Q.COUNT, -1)], filter=flt))
             if out:
