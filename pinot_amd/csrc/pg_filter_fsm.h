@@ -70,7 +70,7 @@ namespace fsm_detail {
 struct Leaf { int input; bool scan; };                       // a leaf as the walk sees it: which input bit, and whether looking at a doc costs an entry
 struct Child {
   enum Kind { kSet, kScan, kOr, kNot } kind = kSet;
-  std::vector<Leaf> members;                                  // kSet: the leaves and-ed into it (one, or the merged ones); kScan: one leaf; kOr: its members; kNot: the leaf under it
+  std::vector<Leaf> members;                                  // kSet: the leaves and-ed into it (one, or the merged ones); kScan: one leaf; kOr: its members; kNot: the leaf under it, or the members of the OR under it
   std::vector<int> open_bit;                                  // kOr: per member, its bit in the state's open mask (-1: an index-based member)
 };
 struct Model {
@@ -81,7 +81,7 @@ struct Model {
 };
 
 inline bool contains(const Child& c, unsigned input) {
-  if (c.kind == Child::kNot) return !((input >> c.members[0].input) & 1u);
+  if (c.kind == Child::kNot) { for (const Leaf& l : c.members) if ((input >> l.input) & 1u) return false; return true; }      // (one leaf, or the members of the OR under it)
   if (c.kind == Child::kOr) { for (const Leaf& l : c.members) if ((input >> l.input) & 1u) return true; return false; }
   for (const Leaf& l : c.members) if (!((input >> l.input) & 1u)) return false;
   return true;
@@ -143,9 +143,11 @@ inline State step(const Model& m, State s, unsigned input, int* entries, int* ma
   int mk = 0, stream = 0, digit_weight = 1;
   for (int c = 0; c < k; ++c) {
     const Child& ch = m.children[(size_t)c];
-    if (ch.kind != Child::kNot || !ch.members[0].scan) continue;      // (NOT over an index-based leaf: a bitmap iterator underneath, nothing is counted)
+    if (ch.kind != Child::kNot) continue;
     const bool is_asked = asked[(size_t)c] || s.leader == c;          // (a leading child is asked about every doc it leads over)
-    const bool match = (input >> ch.members[0].input) & 1u;
+    for (const Leaf& member : ch.members) {
+    if (!member.scan) continue;                                       // (an index-based leaf: a bitmap iterator underneath, nothing is counted)
+    const bool match = (input >> member.input) & 1u;
     const int mine = (s.not_state / digit_weight) % 3;
     int next_mine = mine, my_mark = 0;
     switch (mine) {
@@ -164,6 +166,7 @@ inline State step(const Model& m, State s, unsigned input, int* entries, int* ma
     mk |= my_mark << (2 * stream);
     digit_weight *= 3;
     ++stream;
+    }
   }
   *entries = inc;
   if (mark) *mark = mk;
@@ -228,12 +231,37 @@ inline bool compile_fsm(const pg_query* q, Fsm* out) {
       if (num_sorted > 1 && num_scans == 0) return false;
     } else if (q->filter[kid].op == PG_FILTER_NOT) {
       // NotFilterOperator.getTrues = the child's getFalses (NotFilterOperator.java:52-63); a leaf's getFalses is a NotDocIdSet over its
-      // docId set (BaseFilterOperator.java:96-113): a leap-frogging child.  NOT over anything but a leaf stays with the replay.
+      // docId set (BaseFilterOperator.java:96-113): a leap-frogging child.  NOT over anything but a leaf or an OR of leaves stays with the replay.
       const std::vector<int> under = tb.children_of(kid);
-      if (under.size() != 1 || !leaf_of(under[0], &l)) return false;
+      if (under.size() != 1) return false;
       r.child.kind = Child::kNot;
-      r.child.members.push_back(l);
-      if (l.scan && ++num_not_scan > kFsmMaxEpisodeStreams) return false;      // an episode stream per such child
+      if (leaf_of(under[0], &l)) {
+        r.child.members.push_back(l);
+        if (l.scan && ++num_not_scan > kFsmMaxEpisodeStreams) return false;      // an episode stream per such child
+      } else if (q->filter[under[0]].op == PG_FILTER_OR) {
+        // NOT over an OR of leaves (round 6c): OrFilterOperator.getFalses is a NotDocIdSet over the OrDocIdSet of the members' trues
+        // (OrFilterOperator.java:61-88).  The NotDocIdIterator knows one doc of the OR ahead -- the smallest of the members' look-aheads
+        // (OrDocIdIterator.java:52-108).  Asked about a doc beyond it, OrDocIdIterator.advance() advances exactly the members whose
+        // look-ahead lies behind the doc (doc by doc to their next match); handing the known doc on, OrDocIdIterator.next() pulls next()
+        // from exactly the members that stand AT it (whole 256-doc batches, from where each of them stands).  A member ahead of the doc is
+        // not touched either way.  So every scan member is the three-state machine of a NOT child over a scan leaf, driven by the NOT
+        // child's `asked` and by its OWN match bit: a stale member is advanced whenever the child is asked (the known doc lies behind with
+        // it), a member standing at the doc is handed on whenever the child is asked (nothing smaller is left once the stale ones have
+        // advanced), a match nobody asks about closes its episode.  One episode stream per scan member; the child contains a doc when no
+        // member matches it.  Index-based members cost no entries.
+        int num_sorted = 0, num_scans = 0;
+        for (int g : tb.children_of(under[0])) {
+          if (!leaf_of(g, &l)) return false;
+          r.child.members.push_back(l);
+          num_scans += l.scan ? 1 : 0;
+          num_sorted += classify(q->predicates[q->filter[g].predicate]) == LeafClass::kSorted ? 1 : 0;
+          if (l.scan && ++num_not_scan > kFsmMaxEpisodeStreams) return false;
+        }
+        if (r.child.members.size() < 2) return false;
+        if (num_sorted > 1 && num_scans == 0) return false;     // (see the OR child above: the fork's OrDocIdSet and two sorted members)
+      } else {
+        return false;                                           // NOT over an AND / a NOT: the host replay's
+      }
     } else {
       return false;                                             // nested AND under the root AND: the host replay's
     }

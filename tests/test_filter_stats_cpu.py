@@ -315,7 +315,7 @@ def test_not_children_are_episodes_of_the_transducer(driver):
     fsm_episode_finish_kernel) against the replay of the iterator objects and the oracle, sizes around the batch, lane and tile edges;
     leaves with rare matches (episodes of many batches) and with dense ones."""
     rng = np.random.default_rng(7)
-    compiled, with_not, shapes = 0, 0, set()
+    compiled, with_not, shapes, not_ors, not_ors_compiled = 0, 0, set(), 0, 0
     for n in (1, 31, 33, 255, 257, 513, 2047, 2049, 4100, 20_011, 70_003):
         cols = [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "b", n, 7, with_inverted=True)[0],
                 H.random_dict_column(rng, "c", n, 300, with_inverted=True)[0], H.random_dict_column(rng, "d", n, 3)[0],
@@ -346,6 +346,7 @@ def test_not_children_are_episodes_of_the_transducer(driver):
 
         for _ in range(40):
             kids, nots = [], 0
+            not_ors_before = not_ors
             for _c in range(int(rng.integers(2, 5))):
                 r = int(rng.integers(0, 12))
                 if r < 4:
@@ -354,8 +355,12 @@ def test_not_children_are_episodes_of_the_transducer(driver):
                     kids.append(index_leaf())
                 elif r < 8:
                     kids.append(Q.or_(*[scan_leaf() if rng.integers(0, 3) else index_leaf() for _m in range(int(rng.integers(2, 4)))]))
-                elif r < 11 and nots < 2:
+                elif r < 10 and nots < 2:
                     kids.append(Q.not_(scan_leaf())); nots += 1
+                elif r < 11 and nots < 2:
+                    # NOT over an OR of leaves: an episode stream per scan member (OrFilterOperator.getFalses)
+                    members = [scan_leaf() if rng.integers(0, 3) else index_leaf() for _m in range(int(rng.integers(2, 4)))]
+                    kids.append(Q.not_(Q.or_(*members))); nots += 1; not_ors += 1
                 else:
                     kids.append(Q.not_(index_leaf()))
             spec = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(*kids))
@@ -369,10 +374,11 @@ def test_not_children_are_episodes_of_the_transducer(driver):
                 continue
             compiled += 1
             with_not += nots
+            not_ors_compiled += not_ors - not_ors_before
             shapes.add((len(kids), nots, states))
             tiled, _, _ = fsm(driver, seg, spec, 1)
             assert seq == tiled == want, (n, states, inputs, seq, tiled, want)
-    assert compiled > 250 and with_not > 120 and len(shapes) > 20, (compiled, with_not, len(shapes))
+    assert compiled > 250 and with_not > 120 and len(shapes) > 20 and not_ors_compiled > 12, (compiled, with_not, len(shapes), not_ors, not_ors_compiled)
     # many tiles (the finish kernel's sixteen ranges of 64-tile groups): 3 M docs = 1 465 tiles, episodes from one batch to thousands of docs long
     n = 3_000_017
     seg = S.SegmentData("fsm_not_big", n, [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "f", n, 2000)[0], H.random_dict_column(rng, "d", n, 3)[0]])
@@ -383,11 +389,14 @@ def test_not_children_are_episodes_of_the_transducer(driver):
             want = oracle.execute(seg, spec).stats[1]
             assert fsm(driver, seg, spec, 0)[0] == want == fsm(driver, seg, spec, 1)[0]
     # two NOT children over scan leaves are two episode streams of one machine (7 states for the pair alone, 15 beside a third child);
-    # three of them beside a scan leaf (24-30 states after minimisation) and NOT over an OR stay with the replay
+    # three of them beside a scan leaf (24-30 states after minimisation) stay with the replay; NOT over an OR of leaves is an episode stream
+    # per scan member of the OR (round 6c); more than three streams and NOT over an AND stay with the replay
     n = 5000
     seg = S.SegmentData("fsm_not2", n, [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "d", n, 3)[0], H.random_dict_column(rng, "f", n, 2000)[0]])
     a, d, f = Q.leaf(Q.Pred.dict_range(0, 3, 20)), Q.leaf(Q.Pred.dict_range(1, 1, 2)), Q.leaf(Q.Pred.dict_range(2, 100, 130))
-    for flt, compiles in ((Q.and_(Q.not_(a), Q.not_(d)), 7), (Q.and_(a, Q.not_(d), Q.not_(f)), 15), (Q.and_(Q.not_(a), Q.not_(d), Q.not_(f)), 0), (Q.and_(a, Q.not_(Q.or_(a, d))), 0),
+    for flt, compiles in ((Q.and_(Q.not_(a), Q.not_(d)), 7), (Q.and_(a, Q.not_(d), Q.not_(f)), 15), (Q.and_(Q.not_(a), Q.not_(d), Q.not_(f)), 0), (Q.and_(a, Q.not_(Q.or_(a, d))), 16),
+                          (Q.and_(f, Q.not_(Q.or_(a, d))), 16), (Q.and_(Q.not_(Q.or_(f, d)), a), 16), (Q.and_(a, Q.not_(Q.or_(a, d, f))), 16), (Q.and_(a, Q.not_(Q.or_(a, d, f)), Q.not_(f)), 0),
+                          (Q.and_(a, Q.not_(Q.and_(f, d))), 0),
                           (Q.and_(a, Q.not_(d)), 8), (Q.and_(Q.not_(d), a), 8)):
         spec = Q.QuerySpec([(Q.COUNT, -1)], filter=flt)
         got, states, _ = fsm(driver, seg, spec, 0)
@@ -395,3 +404,59 @@ def test_not_children_are_episodes_of_the_transducer(driver):
         if compiles:
             assert states <= compiles, (states, compiles)
             assert got == oracle.execute(seg, spec).stats[1] == fsm(driver, seg, spec, 1)[0]
+
+
+def test_not_over_an_or_is_an_episode_stream_per_scan_member(driver):
+    """`a AND NOT (b OR c)`: OrFilterOperator.getFalses is a NotDocIdSet over the OrDocIdSet of the members' trues (OrFilterOperator.java:61-88);
+    the NotDocIdIterator knows the smallest of the members' look-aheads (NotDocIdIterator.java:35-76 over OrDocIdIterator.java:52-108).
+    OrDocIdIterator.advance() advances exactly the members behind the target, next() pulls exactly the members standing at the doc handed
+    on -- every scan member is the three-state machine of a NOT child over a scan leaf, with an episode stream of its own.  The machine
+    (doc by doc and in the device's tile structure) against the replay of the iterator objects and the oracle: members that match rarely
+    (episodes of many batches), densely, index-based members beside them, the NOT child leading and following, sizes around the batch,
+    lane and tile edges."""
+    rng = np.random.default_rng(61)
+    compiled = 0
+    for n in (1, 2, 255, 256, 257, 511, 2047, 2048, 2049, 4097, 30_011, 131_075):
+        cols = [H.random_dict_column(rng, "a", n, 50)[0], H.random_dict_column(rng, "b", n, 7, with_inverted=True)[0],
+                H.random_dict_column(rng, "d", n, 3)[0], H.random_dict_column(rng, "f", n, 2000)[0], H.random_dict_column(rng, "g", n, 400)[0]]
+        seg = S.SegmentData("fsm_not_or", n, cols)
+
+        def scan_leaf():
+            k = int(rng.integers(0, 5))
+            if k == 0:
+                lo = int(rng.integers(0, 40)); return Q.leaf(Q.Pred.dict_range(0, lo, lo + int(rng.integers(1, 25)), exclusive=bool(rng.integers(0, 2))))
+            if k == 1:
+                return Q.leaf(Q.Pred.dict_range(2, int(rng.integers(0, 2)), int(rng.integers(2, 4))))
+            if k == 2:
+                lo = int(rng.integers(0, 1990)); return Q.leaf(Q.Pred.dict_range(3, lo, lo + int(rng.integers(1, 8))))          # rare: episodes of many batches
+            if k == 3:
+                lo = int(rng.integers(0, 390)); return Q.leaf(Q.Pred.dict_range(4, lo, lo + int(rng.integers(1, 6))))
+            return Q.leaf(Q.Pred.dict_set(0, sorted(set(int(x) for x in rng.integers(0, 50, size=9))), 50, exclusive=bool(rng.integers(0, 2))))
+
+        def index_leaf():
+            if rng.integers(0, 2):
+                return Q.leaf(Q.Pred.dict_range(1, int(rng.integers(0, 5)), 7, inverted=True, exclusive=bool(rng.integers(0, 2))))
+            lo = int(rng.integers(0, n)); return Q.leaf(Q.Pred.doc_range(lo, min(n - 1, lo + int(rng.integers(0, n)))))
+
+        for _ in range(30):
+            members = [scan_leaf() for _m in range(int(rng.integers(1, 4)))] + [index_leaf() for _m in range(int(rng.integers(0, 2)))]
+            if len(members) < 2:
+                members.append(scan_leaf())
+            order = rng.permutation(len(members))
+            not_or = Q.not_(Q.or_(*[members[i] for i in order]))
+            others = [scan_leaf() if rng.integers(0, 4) else index_leaf() for _c in range(int(rng.integers(1, 3)))]
+            kids = others + [not_or]
+            kids = [kids[i] for i in rng.permutation(len(kids))]
+            spec = Q.QuerySpec([(Q.COUNT, -1)], filter=Q.and_(*kids))
+            if len(spec.predicates) > 8 or any(p.kind in (_abi.PG_PRED_MATCH_ALL, _abi.PG_PRED_MATCH_NONE) for p in spec.predicates):
+                continue
+            want = oracle.execute(seg, spec).stats[1]
+            keep, ptrs = leaf_bitmaps(seg, spec)
+            assert driver.fstats_replay_mode(C.byref(spec.c), n, ptrs, 0, 0, 0) == want
+            seq, states, inputs = fsm(driver, seg, spec, 0)
+            if seq < 0:
+                continue
+            compiled += 1
+            tiled, _, _ = fsm(driver, seg, spec, 1)
+            assert seq == tiled == want, (n, states, inputs, seq, tiled, want)
+    assert compiled > 120, compiled

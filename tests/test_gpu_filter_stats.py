@@ -223,8 +223,11 @@ def _random_and_tree_with_not(rng, n):
             kids.append(index_leaf())
         elif r < 8:
             kids.append(Q.or_(*[scan_leaf() if rng.integers(0, 3) else index_leaf() for _m in range(int(rng.integers(2, 4)))]))
-        elif r < 11 and nots < 2:
+        elif r < 10 and nots < 2:
             kids.append(Q.not_(scan_leaf())); nots += 1
+        elif r < 11 and nots < 2:
+            # NOT over an OR of leaves: an episode stream per scan member of the OR (OrFilterOperator.getFalses; round 6c)
+            kids.append(Q.not_(Q.or_(*[scan_leaf() if rng.integers(0, 3) else index_leaf() for _m in range(int(rng.integers(2, 4)))]))); nots += 1
         else:
             kids.append(Q.not_(index_leaf()))
     if nots == 0:
@@ -260,7 +263,11 @@ def test_not_children_are_counted_on_the_device(engine_without_replay, n):
                     Q.and_(posting, a, Q.not_(e)), Q.and_(a, Q.not_(posting)), Q.and_(Q.or_(a, d), Q.not_(rare)), Q.and_(a, Q.not_(rare), Q.not_(posting)),
                     # two NOT children over scan leaves: an episode stream each (7 states: fsm_episode_ranges_kernel twice; 15 states: fsm_episode_tiles_kernel twice)
                     Q.and_(Q.not_(a), Q.not_(rare)), Q.and_(Q.not_(d), Q.not_(e)), Q.and_(a, Q.not_(d), Q.not_(rare)), Q.and_(posting, Q.not_(rare), Q.not_(e)),
-                    Q.and_(posting, a, Q.not_(d), Q.not_(rare))):
+                    Q.and_(posting, a, Q.not_(d), Q.not_(rare)),
+                    # NOT over an OR of leaves (round 6c): every scan member of the OR is an episode stream of its own
+                    Q.and_(a, Q.not_(Q.or_(d, rare))), Q.and_(Q.not_(Q.or_(rare, e)), a), Q.and_(posting, Q.not_(Q.or_(d, rare))), Q.and_(a, Q.not_(Q.or_(posting, rare))),
+                    Q.and_(e, Q.not_(Q.or_(posting, d))), Q.and_(Q.not_(Q.or_(posting, rare)), Q.not_(e))):
+            # (three scan members under the NOT beside a scan leaf, or two beside another NOT child, reach more than 16 states: the upper bound here)
             for group_by in ([], [3]):
                 spec = Q.QuerySpec([(Q.COUNT, -1), (Q.SUM, 0)], filter=flt, group_by=group_by)
                 got, want = g.execute(spec), oracle.execute(seg, spec)

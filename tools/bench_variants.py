@@ -77,7 +77,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
         return lambda matched: B(col) if matched * 16 >= rows else min(B(col), matched * 64)
 
     # ---- C2 / C3 on 1 B rows: the headline's v and f, v under two dictionaries without structure, and the C3 columns ----
-    if any(want(x) for x in ("C2b-irregular", "C2b-window", "C2a-affine", "C2a-irregular", "C3", "C3-filter", "C3-irregular", "COUNT-filter", "C2b-1pct", "C2b-50pct", "AND3-scan", "AND-OR-scan", "AND-NOT-scan", "NOT-NOT-scan", "AND3-scan-bound", "AND-OR-scan-bound", "AND-NOT-scan-bound", "NOT-NOT-scan-bound", "C2b-in-list", "C2b-irregular-in-list", "C3-in-list")):
+    if any(want(x) for x in ("C2b-irregular", "C2b-window", "C2a-affine", "C2a-irregular", "C3", "C3-filter", "C3-irregular", "COUNT-filter", "C2b-1pct", "C2b-50pct", "AND3-scan", "AND-OR-scan", "AND-NOT-scan", "NOT-NOT-scan", "AND-NOT-OR-scan", "AND-NOT-OR-scan-bound", "AND3-scan-bound", "AND-OR-scan-bound", "AND-NOT-scan-bound", "NOT-NOT-scan-bound", "C2b-in-list", "C2b-irregular-in-list", "C3-in-list")):
         t0 = time.time()
         v_irr = _shared(S, v, "v_irr", v_dictionary("irregular"))
         v_win = _shared(S, v, "v_win", v_dictionary("window"))
@@ -134,7 +134,10 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                                     Q.and_(Q.leaf(Q.Pred.dict_range(1, 0, 300)), Q.not_(Q.leaf(Q.Pred.dict_range(4, 0, 500))))),
                                    # (two NOT children: two episode streams of one seven-state machine, the episode pass once per stream)
                                    ("NOT-NOT-scan", "SELECT SUM(v) WHERE NOT (f < 300) AND NOT (k < 1500) (two NOTs over scan leaves: two NotDocIdIterators leap-frogging)",
-                                    Q.and_(Q.not_(Q.leaf(Q.Pred.dict_range(1, 0, 300))), Q.not_(Q.leaf(Q.Pred.dict_range(4, 0, 500)))))):
+                                    Q.and_(Q.not_(Q.leaf(Q.Pred.dict_range(1, 0, 300))), Q.not_(Q.leaf(Q.Pred.dict_range(4, 0, 500))))),
+                                   # (NOT over an OR of two scan leaves: an episode stream per member of the OR -- OrFilterOperator.getFalses; round 6c)
+                                   ("AND-NOT-OR-scan", "SELECT SUM(v) WHERE f < 300 AND NOT (k < 300 OR b < 6000) (a scan leaf AND a NOT over an OR of two scan leaves)",
+                                    Q.and_(Q.leaf(Q.Pred.dict_range(1, 0, 300)), Q.not_(Q.or_(Q.leaf(Q.Pred.dict_range(4, 0, 100)), Q.leaf(Q.Pred.dict_range(6, 0, 3000))))))):
                 if want(vid):
                     sp3 = Q.QuerySpec([(Q.SUM, 0)], filter=flt3)
                     report(vid, "numEntriesScannedInFilter of a leap-frogging filter at 1 B rows", sql, n, B(v) + B(f) + B(k) + (B(b) if vid not in ("AND-NOT-scan", "NOT-NOT-scan") else 0), g, seg, sp3)
@@ -143,7 +146,7 @@ def run(engine, gseg0, seg0, n, n_c5, match, check=True, steps=10, warmup=40):
                     out[-1]["num_entries_scanned_in_filter"] = int(r3.stats[1])
                     if check:
                         # (the oracle replays the iterator objects doc by doc on one core: ~75 s per 1 B docs for the NOT filter, done for that variant only)
-                        if n <= 200_000_000 or (vid in ("AND-NOT-scan", "NOT-NOT-scan") and os.environ.get("PINOT_BENCH_CHECK_ENTRIES_1B") == "1"):
+                        if n <= 200_000_000 or (vid in ("AND-NOT-scan", "NOT-NOT-scan", "AND-NOT-OR-scan") and os.environ.get("PINOT_BENCH_CHECK_ENTRIES_1B") == "1"):
                             t_o = time.perf_counter()
                             out[-1]["oracle_num_entries_scanned_in_filter"] = int(oracle.execute(seg, Q.QuerySpec([(Q.COUNT, -1)], filter=flt3)).stats[1])
                             out[-1]["entries_match_oracle"] = bool(r3.stats[1] == out[-1]["oracle_num_entries_scanned_in_filter"])
