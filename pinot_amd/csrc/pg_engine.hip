@@ -4513,6 +4513,8 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
   //  costs more than 7 only when the tree names the same predicate in many leaves -- such machines walk tables)
   int max_inc = 0;
   for (uint8_t d : fsm.delta) max_inc = std::max(max_inc, (int)(d >> 4));
+  // (machines of 9 .. 16 states over three or four inputs whose episodes the range kernel takes: see fsm_tile_fns16_kernel)
+  const bool fns16 = perm_walk && S > 8 && S <= 16 && L >= 3 && L <= 4 && fsm.has_episodes();
   if (S <= 4 && L <= 4 && max_inc <= 7 && perm_walk) {
     if (L <= 2) fsm_tiles_perm_kernel<2><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
     else if (L <= 3) fsm_tiles_perm_kernel<3><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
@@ -4521,6 +4523,11 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
   else if (S <= 8 && L <= 4 && max_inc <= 7 && perm_walk) {
     if (L <= 3) fsm_tiles_perm8_kernel<3><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
     else fsm_tiles_perm8_kernel<4><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
+  }
+  else if (fns16) {
+    // nine to sixteen states with episodes: the tiles' functions only (four registers a function); the range kernel of the first stream counts the entries
+    if (L <= 3) fsm_tile_fns16_kernel<3><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
+    else fsm_tile_fns16_kernel<4><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
   }
   else if (S <= 2) PG_FSM_LAUNCH_L(2);
   else if (S <= 4) PG_FSM_LAUNCH_L(4);
@@ -4561,9 +4568,9 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
     const uint32_t pending_states = fsm.stream_pending(k);
     memcpy(h_marks_k, fsm.stream_marks(k).data(), (size_t)S << L);
     HIP_TRY(hipMemcpyAsync(d_marks, h_marks_k, (size_t)S << L, hipMemcpyHostToDevice, stream));
-    if (perm_walk && S <= 8 && L <= 4) {
-      // machines of at most eight states over at most four inputs: byte functions, a scan over the wavefront, a contiguous range of tiles per
-      // wavefront -- one record per RANGE for the finish kernel (pg_fsm_kernels.h "Round 6")
+    if (perm_walk && (S <= 8 || fns16) && L <= 4) {
+      // machines of at most eight (round 6c: sixteen) states over at most four inputs: byte functions, a scan over the wavefront, a contiguous
+      // range of tiles per wavefront -- one record per RANGE for the finish kernel (pg_fsm_kernels.h "Round 6")
       const long long num_ranges = std::min<long long>(tiles, (long long)blocks * 4);
       FsmEpisodeRangeParams rp;
       memset(&rp, 0, sizeof(rp));
@@ -4573,8 +4580,10 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
       rp.episode_entries = d_episodes; rp.final_pending = d_final_pending;
       rp.pending_states = pending_states;
       rp.num_inputs = L; rp.num_states = S; rp.num_docs = seg->num_docs; rp.num_tiles = (int32_t)tiles; rp.num_ranges = (int32_t)num_ranges;
+      rp.count_entries = (fns16 && k == 0) ? 1 : 0;      // (the tile pass built functions only: the first stream's walk counts what the docs cost)
       const dim3 rgrid((unsigned)((num_ranges + 3) / 4));
-      if (S <= 4) { if (L <= 2) fsm_episode_ranges_kernel<4, 2><<<rgrid, dim3(256), 0, stream>>>(rp); else fsm_episode_ranges_kernel<4, 4><<<rgrid, dim3(256), 0, stream>>>(rp); }
+      if (S > 8) fsm_episode_ranges_kernel<16, 4><<<rgrid, dim3(256), 0, stream>>>(rp);
+      else if (S <= 4) { if (L <= 2) fsm_episode_ranges_kernel<4, 2><<<rgrid, dim3(256), 0, stream>>>(rp); else fsm_episode_ranges_kernel<4, 4><<<rgrid, dim3(256), 0, stream>>>(rp); }
       else { if (L <= 2) fsm_episode_ranges_kernel<8, 2><<<rgrid, dim3(256), 0, stream>>>(rp); else fsm_episode_ranges_kernel<8, 4><<<rgrid, dim3(256), 0, stream>>>(rp); }
       HIP_TRY(hipGetLastError());
       fsm_episode_finish_kernel<<<dim3(1), dim3(1024), 0, stream>>>(d_first_close, d_last_open, (int)num_ranges, seg->num_docs, d_final_pending, d_episodes);

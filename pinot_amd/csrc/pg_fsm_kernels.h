@@ -623,61 +623,126 @@ struct FsmEpisodeRangeParams {
   int32_t* final_pending;               // = 1 when the state behind the last doc has an episode open
   uint32_t pending_states;
   int32_t num_inputs, num_states, num_docs, num_tiles, num_ranges;
+  int32_t count_entries;                // != 0: the per-doc entries of the walk are added too (machines of 9 .. 16 states: their tile kernel, fsm_tile_fns16_kernel, builds functions only)
 };
 
 template <int SMAX>
 struct FsmByteFn {                                                     // {entry state} -> {exit state}, a byte per entry state
-  uint32_t lo, hi;                                                     // (hi: states 4 .. 7, SMAX == 8 only)
+  uint32_t lo, hi;                                                     // (hi: states 4 .. 7, SMAX >= 8 only)
+  uint32_t w2, w3;                                                     // (states 8 .. 11, 12 .. 15: SMAX == 16 only -- round 6c)
 };
 template <int SMAX>
-__device__ __forceinline__ FsmByteFn<SMAX> fsm_fn_identity() { return FsmByteFn<SMAX>{0x03020100u, 0x07060504u}; }
+__device__ __forceinline__ FsmByteFn<SMAX> fsm_fn_identity() { return FsmByteFn<SMAX>{0x03020100u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu}; }
+// Four bytes of a sixteen-entry byte table {t0 .. t3} picked by the selector bytes of `sel` (values 0 .. 15): v_perm_b32 reaches eight bytes,
+// so both halves are looked up with the selectors' low three bits and bit 3 of every selector byte picks between them (v_bfi_b32).
+__device__ __forceinline__ uint32_t fsm_lookup16(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t sel) {
+  const uint32_t low = sel & 0x07070707u;
+  const uint32_t a = __builtin_amdgcn_perm(t1, t0, low), b = __builtin_amdgcn_perm(t3, t2, low);
+  const uint32_t upper = ((sel >> 3) & 0x01010101u) * 0xFFu;          // 0xFF in the bytes whose selector is 8 .. 15
+  return (b & upper) | (a & ~upper);
+}
 // `first`, then `then`:  out[s] = then[first[s]]
 template <int SMAX>
 __device__ __forceinline__ FsmByteFn<SMAX> fsm_fn_then(const FsmByteFn<SMAX>& first, const FsmByteFn<SMAX>& then) {
   FsmByteFn<SMAX> out;
+  out.w2 = 0u; out.w3 = 0u;
   if constexpr (SMAX <= 4) { out.lo = __builtin_amdgcn_perm(then.lo, then.lo, first.lo); out.hi = 0u; }
-  else { out.lo = __builtin_amdgcn_perm(then.hi, then.lo, first.lo); out.hi = __builtin_amdgcn_perm(then.hi, then.lo, first.hi); }
+  else if constexpr (SMAX <= 8) { out.lo = __builtin_amdgcn_perm(then.hi, then.lo, first.lo); out.hi = __builtin_amdgcn_perm(then.hi, then.lo, first.hi); }
+  else {
+    out.lo = fsm_lookup16(then.lo, then.hi, then.w2, then.w3, first.lo); out.hi = fsm_lookup16(then.lo, then.hi, then.w2, then.w3, first.hi);
+    out.w2 = fsm_lookup16(then.lo, then.hi, then.w2, then.w3, first.w2); out.w3 = fsm_lookup16(then.lo, then.hi, then.w2, then.w3, first.w3);
+  }
   return out;
 }
 template <int SMAX>
 __device__ __forceinline__ uint32_t fsm_fn_at(const FsmByteFn<SMAX>& f, uint32_t state) {
   if constexpr (SMAX <= 4) return (f.lo >> (8u * state)) & 0xFFu;
-  else return ((state < 4u ? f.lo : f.hi) >> (8u * (state & 3u))) & 0xFFu;
+  else if constexpr (SMAX <= 8) return ((state < 4u ? f.lo : f.hi) >> (8u * (state & 3u))) & 0xFFu;
+  else return ((state < 8u ? (state < 4u ? f.lo : f.hi) : (state < 12u ? f.w2 : f.w3)) >> (8u * (state & 3u))) & 0xFFu;
+}
+// A function handed to the lane `delta` lanes up the wavefront (every word of it).
+template <int SMAX>
+__device__ __forceinline__ FsmByteFn<SMAX> fsm_fn_shfl_up(const FsmByteFn<SMAX>& f, unsigned delta) {
+  FsmByteFn<SMAX> out;
+  out.lo = (uint32_t)__shfl_up((int)f.lo, delta);
+  out.hi = SMAX > 4 ? (uint32_t)__shfl_up((int)f.hi, delta) : 0u;
+  out.w2 = SMAX > 8 ? (uint32_t)__shfl_up((int)f.w2, delta) : 0u;
+  out.w3 = SMAX > 8 ? (uint32_t)__shfl_up((int)f.w3, delta) : 0u;
+  return out;
+}
+// The function of a lane's 32 docs: from the step table when the lane has all of them (whole), else doc by doc through `dm` (next state in
+// the low four bits).  step_fn: [idx * kWords + word]; idx: input i's bits of the step's kDps docs at [i * kDps, (i + 1) * kDps).
+template <int SMAX, int LMAX, int kDps, int kWords>
+__device__ __forceinline__ FsmByteFn<SMAX> fsm_lane_fn(const uint32_t (&w)[LMAX], int docs, bool whole, const uint32_t* step_fn, const uint8_t* dm) {
+  FsmByteFn<SMAX> f = fsm_fn_identity<SMAX>();
+  if (whole) {
+#pragma unroll
+    for (int d = 0; d < 32; d += kDps) {
+      uint32_t idx = 0u;
+#pragma unroll
+      for (int i = 0; i < LMAX; ++i) idx |= __builtin_amdgcn_ubfe(w[i], d, kDps) << (i * kDps);
+      FsmByteFn<SMAX> t;
+      t.lo = step_fn[idx * kWords];
+      t.hi = kWords >= 2 ? step_fn[idx * kWords + (kWords >= 2 ? 1 : 0)] : 0u;
+      t.w2 = kWords >= 4 ? step_fn[idx * kWords + (kWords >= 4 ? 2 : 0)] : 0u;
+      t.w3 = kWords >= 4 ? step_fn[idx * kWords + (kWords >= 4 ? 3 : 0)] : 0u;
+      f = fsm_fn_then<SMAX>(f, t);
+    }
+  } else {
+    uint32_t st[SMAX];
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) st[s] = (uint32_t)s;
+    for (int d = 0; d < docs; ++d) {
+      uint32_t in = 0u;
+#pragma unroll
+      for (int i = 0; i < LMAX; ++i) in |= __builtin_amdgcn_ubfe(w[i], d, 1) << i;
+#pragma unroll
+      for (int s = 0; s < SMAX; ++s) st[s] = dm[(st[s] << LMAX) | in] & 15u;
+    }
+    f.lo = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
+    if constexpr (SMAX > 4) f.hi = st[4] | (st[5] << 8) | (st[6] << 16) | (st[7] << 24);
+    if constexpr (SMAX > 8) { f.w2 = st[8] | (st[9] << 8) | (st[10] << 16) | (st[11] << 24); f.w3 = st[12] | (st[13] << 8) | (st[14] << 16) | (st[15] << 24); }
+  }
+  return f;
 }
 
 template <int SMAX, int LMAX>
 __global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisodeRangeParams p) {
-  static_assert((SMAX == 4 || SMAX == 8) && LMAX >= 1 && LMAX <= 4, "byte functions of four or eight states over at most four inputs");
+  static_assert((SMAX == 4 || SMAX == 8 || SMAX == 16) && LMAX >= 1 && LMAX <= 4, "byte functions of four, eight or sixteen states over at most four inputs");
   constexpr int kDps = LMAX == 1 ? 8 : (LMAX == 2 ? 4 : 2);           // docs per step
   constexpr int kIndexBits = kDps * LMAX;                              // input i's bits of the step's docs at [i * kDps, (i + 1) * kDps)
-  constexpr int kWords = SMAX <= 4 ? 1 : 2;
+  constexpr int kWords = SMAX / 4;
   __shared__ uint8_t dm[SMAX << LMAX];                                 // one doc: next state | mark << 4 (the last tile's partial lanes)
-  __shared__ uint32_t step_fn[kWords << kIndexBits];                   // a step's function: word 0 (and 1) of FsmByteFn, [idx * kWords + word]
-  __shared__ uint32_t step_mark[SMAX << kIndexBits];                   // [(state << kIndexBits) | idx]: next state | opens << 4 | closes << 12 (bit j: the step's doc j)
+  __shared__ uint8_t de[SMAX << LMAX];                                 // one doc: its entries (count_entries)
+  __shared__ uint32_t step_fn[kWords << kIndexBits];                   // a step's function: the words of FsmByteFn, [idx * kWords + word]
+  __shared__ uint32_t step_mark[SMAX << kIndexBits];                   // [(state << kIndexBits) | idx]: next state | opens << 4 | closes << 12 (bit j: the step's doc j) | the step's entries << 20
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int L = p.num_inputs, S = p.num_states;
   for (int i = threadIdx.x; i < (SMAX << LMAX); i += blockDim.x) {
     const int st = i >> LMAX, in = i & ((1 << LMAX) - 1);
-    dm[i] = (st < S && in < (1 << L)) ? (uint8_t)((p.delta[(st << L) | in] & 15u) | ((uint32_t)p.marks[(st << L) | in] << 4)) : (uint8_t)0;
+    const bool real = st < S && in < (1 << L);
+    dm[i] = real ? (uint8_t)((p.delta[(st << L) | in] & 15u) | ((uint32_t)p.marks[(st << L) | in] << 4)) : (uint8_t)0;
+    de[i] = real ? (uint8_t)(p.delta[(st << L) | in] >> 4) : (uint8_t)0;
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < (1 << kIndexBits); idx += blockDim.x) {
-    uint32_t fn[2] = {0u, 0u};
+    uint32_t fn[4] = {0u, 0u, 0u, 0u};
     for (int st = 0; st < SMAX; ++st) {
-      uint32_t cur = (uint32_t)st, opens = 0u, closes = 0u;
+      uint32_t cur = (uint32_t)st, opens = 0u, closes = 0u, ents = 0u;
       for (int j = 0; j < kDps; ++j) {
         uint32_t in = 0u;
         for (int i = 0; i < LMAX; ++i) in |= (((uint32_t)idx >> (i * kDps + j)) & 1u) << i;
         const uint32_t t = dm[(cur << LMAX) | in];
+        ents += de[(cur << LMAX) | in];
         if ((t >> 4) == kFsmMarkOpen) opens |= 1u << j;
         if ((t >> 4) == kFsmMarkClose) closes |= 1u << j;
         cur = t & 15u;
       }
-      step_mark[(st << kIndexBits) | idx] = cur | (opens << 4) | (closes << 12);
+      step_mark[(st << kIndexBits) | idx] = cur | (opens << 4) | (closes << 12) | (ents << 20);      // (eight docs x fifteen entries: seven bits)
       fn[st >> 2] |= cur << (8 * (st & 3));
     }
-    step_fn[idx * kWords] = fn[0];
-    if constexpr (kWords == 2) step_fn[idx * kWords + 1] = fn[1];
+#pragma unroll
+    for (int k = 0; k < kWords; ++k) step_fn[idx * kWords + k] = fn[k];
   }
   __syncthreads();
 
@@ -697,48 +762,19 @@ __global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisod
     for (int i = 0; i < LMAX; ++i) w[i] = i < L ? p.leaf[i][tile * 64 + lane] : 0u;
     const bool whole = __builtin_amdgcn_ballot_w64(docs != 32) == 0ull;      // every lane has its 32 docs (all tiles but the segment's last)
     // ---- the lane's function: its docs from every entry state ----
-    FsmByteFn<SMAX> f = fsm_fn_identity<SMAX>();
-    if (whole) {
-#pragma unroll
-      for (int d = 0; d < 32; d += kDps) {
-        uint32_t idx = 0u;
-#pragma unroll
-        for (int i = 0; i < LMAX; ++i) idx |= __builtin_amdgcn_ubfe(w[i], d, kDps) << (i * kDps);
-        FsmByteFn<SMAX> t;
-        t.lo = step_fn[idx * kWords];
-        t.hi = kWords == 2 ? step_fn[idx * kWords + (kWords - 1)] : 0u;
-        f = fsm_fn_then<SMAX>(f, t);
-      }
-    } else {
-      uint32_t st[SMAX];
-#pragma unroll
-      for (int s = 0; s < SMAX; ++s) st[s] = (uint32_t)s;
-      for (int d = 0; d < docs; ++d) {
-        uint32_t in = 0u;
-#pragma unroll
-        for (int i = 0; i < LMAX; ++i) in |= __builtin_amdgcn_ubfe(w[i], d, 1) << i;
-#pragma unroll
-        for (int s = 0; s < SMAX; ++s) st[s] = dm[(st[s] << LMAX) | in] & 15u;
-      }
-      f.lo = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
-      if constexpr (SMAX > 4) f.hi = st[4] | (st[5] << 8) | (st[6] << 16) | (st[7] << 24);
-    }
+    const FsmByteFn<SMAX> f = fsm_lane_fn<SMAX, LMAX, kDps, kWords>(w, docs, whole, step_fn, dm);
     // ---- the state this lane is entered in: the lanes in front composed (an inclusive scan, shifted by one lane), applied to the tile's ----
     FsmByteFn<SMAX> incl = f;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-      FsmByteFn<SMAX> before;
-      before.lo = (uint32_t)__shfl_up((int)incl.lo, (unsigned)off);
-      before.hi = SMAX > 4 ? (uint32_t)__shfl_up((int)incl.hi, (unsigned)off) : 0u;
+      const FsmByteFn<SMAX> before = fsm_fn_shfl_up<SMAX>(incl, (unsigned)off);
       if (lane >= off) incl = fsm_fn_then<SMAX>(before, incl);
     }
-    FsmByteFn<SMAX> front;
-    front.lo = (uint32_t)__shfl_up((int)incl.lo, 1u);
-    front.hi = SMAX > 4 ? (uint32_t)__shfl_up((int)incl.hi, 1u) : 0u;
+    FsmByteFn<SMAX> front = fsm_fn_shfl_up<SMAX>(incl, 1u);
     if (lane == 0) front = fsm_fn_identity<SMAX>();
     uint32_t cur = fsm_fn_at<SMAX>(front, (uint32_t)p.tile_state[tile]);
-    // ---- the lane's docs again, one chain from that state: where episodes open and close ----
-    uint32_t open_word = 0u, close_word = 0u;
+    // ---- the lane's docs again, one chain from that state: where episodes open and close (and what the docs cost: count_entries) ----
+    uint32_t open_word = 0u, close_word = 0u, ents = 0u;
     if (whole) {
 #pragma unroll
       for (int d = 0; d < 32; d += kDps) {
@@ -748,6 +784,7 @@ __global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisod
         const uint32_t t = step_mark[(cur << kIndexBits) | idx];
         open_word |= __builtin_amdgcn_ubfe(t, 4, kDps) << d;
         close_word |= __builtin_amdgcn_ubfe(t, 12, kDps) << d;
+        ents += t >> 20;
         cur = t & 15u;
       }
     } else {
@@ -756,11 +793,13 @@ __global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisod
 #pragma unroll
         for (int i = 0; i < LMAX; ++i) in |= __builtin_amdgcn_ubfe(w[i], d, 1) << i;
         const uint32_t t = dm[(cur << LMAX) | in];
+        ents += de[(cur << LMAX) | in];
         open_word |= ((t >> 4) == kFsmMarkOpen ? 1u : 0u) << d;
         close_word |= ((t >> 4) == kFsmMarkClose ? 1u : 0u) << d;
         cur = t & 15u;
       }
     }
+    if (p.count_entries != 0) sum += ents;
     if (docs > 0 && first + docs == (long long)p.num_docs) *p.final_pending = (int32_t)((p.pending_states >> cur) & 1u);      // the lane that holds the last doc
     // ---- the last open in front of every lane: an inclusive prefix maximum over the wavefront, shifted by one lane, and the range's carry ----
     const int32_t mine = open_word ? (int32_t)(first + 31 - __builtin_clz(open_word)) : -1;
@@ -798,6 +837,62 @@ __global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisod
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sum += (unsigned long long)__shfl_xor((long long)sum, off);
   if (lane == 0 && sum != 0ull) atomicAdd(p.episode_entries, sum);
+}
+
+// Machines of nine to sixteen states with episodes (two NOT children beside a third child, NOT over an OR of two scan leaves: round 6c).
+// Their tables came from fsm_tiles_kernel<16, L> -- sixteen chains of dependent LDS byte reads per doc, 3.16 ms per 1 B docs -- and their
+// episodes from fsm_episode_tiles_kernel, 4.06 ms per stream.  The range kernel above takes sixteen states (a function in four registers,
+// fsm_lookup16) and, since it walks every doc from the state the doc is really entered in, counts the per-doc entries on the way
+// (count_entries, the first stream's pass only).  What is left for the tile pass is the tiles' FUNCTIONS {entry state} -> {exit state}
+// alone: the lane functions as in the range kernel, the same inclusive scan, lane 63 holds the tile's.  Written in the tables' format
+// (next state | entries << 4, entries = 0) for fsm_chain_kernel / fsm_chunk_states_kernel / fsm_tile_states_kernel.
+template <int LMAX>
+__global__ __launch_bounds__(256) void fsm_tile_fns16_kernel(const FsmParams p) {
+  static_assert(LMAX >= 3 && LMAX <= 4, "a machine over two inputs has at most three states");
+  constexpr int SMAX = 16, kDps = 2, kIndexBits = kDps * LMAX, kWords = 4;
+  __shared__ uint8_t dm[SMAX << LMAX];
+  __shared__ uint32_t step_fn[kWords << kIndexBits];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = p.num_inputs, S = p.num_states;
+  for (int i = threadIdx.x; i < (SMAX << LMAX); i += blockDim.x) {
+    const int st = i >> LMAX, in = i & ((1 << LMAX) - 1);
+    dm[i] = (st < S && in < (1 << L)) ? (uint8_t)(p.delta[(st << L) | in] & 15u) : (uint8_t)0;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < (1 << kIndexBits); idx += blockDim.x) {
+    uint32_t fn[4] = {0u, 0u, 0u, 0u};
+    for (int st = 0; st < SMAX; ++st) {
+      uint32_t cur = (uint32_t)st;
+      for (int j = 0; j < kDps; ++j) {
+        uint32_t in = 0u;
+        for (int i = 0; i < LMAX; ++i) in |= (((uint32_t)idx >> (i * kDps + j)) & 1u) << i;
+        cur = dm[(cur << LMAX) | in] & 15u;
+      }
+      fn[st >> 2] |= cur << (8 * (st & 3));
+    }
+#pragma unroll
+    for (int k = 0; k < kWords; ++k) step_fn[idx * kWords + k] = fn[k];
+  }
+  __syncthreads();
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < p.num_tiles; tile += (long long)gridDim.x * 4) {
+    const long long first = tile * 2048 + lane * 32;
+    const long long rem = (long long)p.num_docs - first;
+    const int docs = rem >= 32 ? 32 : (rem <= 0 ? 0 : (int)rem);
+    uint32_t w[LMAX];
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) w[i] = i < L ? p.leaf[i][tile * 64 + lane] : 0u;
+    const bool whole = __builtin_amdgcn_ballot_w64(docs != 32) == 0ull;
+    FsmByteFn<SMAX> incl = fsm_lane_fn<SMAX, LMAX, kDps, kWords>(w, docs, whole, step_fn, dm);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const FsmByteFn<SMAX> before = fsm_fn_shfl_up<SMAX>(incl, (unsigned)off);
+      if (lane >= off) incl = fsm_fn_then<SMAX>(before, incl);
+    }
+    if (lane == 63) {
+      uint32_t* const out = p.tables + tile * S;
+      for (int c = 0; c < S; ++c) out[c] = fsm_fn_at<SMAX>(incl, (uint32_t)c);
+    }
+  }
 }
 
 // One workgroup of sixteen wavefronts, each a contiguous range of tiles read 64 at a time (lane l: tile base + l -- the first coding gave every

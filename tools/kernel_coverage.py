@@ -193,7 +193,11 @@ def fsm_trees(Q, rng, n, count):
     rare, half, some = L(Q.Pred.dict_range(A, 7, 8)), L(Q.Pred.dict_range(C2, 0, 1)), L(Q.Pred.dict_range(B, 2, 5))
     posting = L(Q.Pred.dict_range(X, 0, 20, inverted=True))
     out += [Q.and_(some, Q.not_(rare)), Q.and_(Q.not_(half), some), Q.and_(posting, Q.not_(rare)), Q.and_(some, Q.not_(half), Q.or_(rare, posting)),
-            Q.and_(posting, some, Q.not_(L(Q.Pred.dict_range(A, 0, 150)))), Q.and_(some, Q.not_(posting), Q.not_(rare))][:max(count, 0)]
+            Q.and_(posting, some, Q.not_(L(Q.Pred.dict_range(A, 0, 150)))), Q.and_(some, Q.not_(posting), Q.not_(rare)),
+            # NOT over an OR of leaves: an episode stream per scan member; nine to sixteen states over three / four inputs:
+            # fsm_tile_fns16_kernel<3 | 4> + fsm_episode_ranges_kernel<16, 4> (with PINOT_GPU_FSM_PERM=0: the table walks)
+            Q.and_(some, Q.not_(Q.or_(half, rare))), Q.and_(Q.not_(Q.or_(rare, some)), half), Q.and_(posting, some, Q.not_(Q.or_(half, rare))),
+            Q.and_(some, Q.not_(Q.or_(posting, rare)))][:max(count, 0)]
     # machines of the rarer (states, inputs) classes, found by a search over shapes (tools/fstats/fstats_driver.cpp fstats_fsm_class): a child
     # is a pool index or an OR of pool indexes; nine to thirteen states over three inputs, four to fifteen over four
     frozen = [(3, [[2, 1, 0], 1, [2, 1, 0]]), (3, [[2, 0], [1, 2], 0, [2, 1]]), (3, [[0, 2, 1], [1, 1], [0, 2, 2], [0, 2]]), (3, [[1, 0], 2, 0, [0, 1, 2]]),

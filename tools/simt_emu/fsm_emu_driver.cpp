@@ -30,7 +30,8 @@ bool launch_table_walk(unsigned blocks, const pg::FsmParams& fp, int L) {
 
 }  // namespace
 
-// walk: 0 the table walk (fsm_tiles_kernel), 1 the byte-function walk of <= 4 states (fsm_tiles_perm_kernel), 2 of <= 8 (fsm_tiles_perm8_kernel).
+// walk: 0 the table walk (fsm_tiles_kernel), 1 the byte-function walk of <= 4 states (fsm_tiles_perm_kernel), 2 of <= 8 (fsm_tiles_perm8_kernel),
+// 3 of 9 .. 16 states with episodes (fsm_tile_fns16_kernel + fsm_episode_ranges_kernel<16, 4>).
 // -1: the shape does not compile; -2: the walk does not take this machine.  `blocks`: workgroups of the tile kernels (4 wavefronts each).
 extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg_query* q, int32_t num_docs, const uint64_t* const* leaf_words, int32_t walk, int32_t blocks, int32_t* out_states, int32_t* out_inputs,
                                  int32_t* out_episodes) {
@@ -45,6 +46,9 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
   for (uint8_t d : fsm.delta) max_inc = std::max(max_inc, (int)(d >> 4));
   if (walk == 1 && !(S <= 4 && L <= 4 && max_inc <= 7)) return -2;
   if (walk == 2 && !(S <= 8 && L <= 4 && max_inc <= 7)) return -2;
+  // walk 3: machines of 9 .. 16 states with episodes -- fsm_tile_fns16_kernel (functions only) + fsm_episode_ranges_kernel<16, 4> counting the entries
+  const bool fns16 = walk == 3;
+  if (fns16 && !(S > 8 && S <= 16 && L >= 3 && L <= 4 && fsm.has_episodes())) return -2;
   const long long tiles = std::max<long long>(1, ((long long)num_docs + 2047) / 2048);
   const long long chunks = (tiles + kFsmChunk - 1) / kFsmChunk;
   const size_t words64 = ((size_t)num_docs + 63) / 64;
@@ -69,6 +73,9 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
   } else if (walk == 2) {
     if (L <= 3) simt::launch(nb, 256, [&] { fsm_tiles_perm8_kernel<3>(fp); });
     else simt::launch(nb, 256, [&] { fsm_tiles_perm8_kernel<4>(fp); });
+  } else if (fns16) {
+    if (L <= 3) simt::launch(nb, 256, [&] { fsm_tile_fns16_kernel<3>(fp); });
+    else simt::launch(nb, 256, [&] { fsm_tile_fns16_kernel<4>(fp); });
   } else if (S <= 2) launch_table_walk<2>(nb, fp, L);
   else if (S <= 4) launch_table_walk<4>(nb, fp, L);
   else if (S <= 8) launch_table_walk<8>(nb, fp, L);
@@ -96,7 +103,7 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
       ep.episode_entries = &episodes; ep.final_pending = &final_pending;
       ep.pending_states = pending_states;
       ep.num_inputs = L; ep.num_states = S; ep.num_docs = num_docs; ep.num_tiles = (int32_t)tiles;
-      if (walk != 0 && S <= 8 && L <= 4) {
+      if (walk != 0 && (S <= 8 || fns16) && L <= 4) {
         // the byte-function walks' episode kernel (pg_engine.hip: PINOT_GPU_FSM_PERM on, at most eight states over at most four inputs): a
         // wavefront per contiguous RANGE of tiles, one record per range for the finish kernel
         const long long num_ranges = std::min<long long>(tiles, (long long)nb * 4);
@@ -109,8 +116,10 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
         rp.episode_entries = &episodes; rp.final_pending = &final_pending;
         rp.pending_states = pending_states;
         rp.num_inputs = L; rp.num_states = S; rp.num_docs = num_docs; rp.num_tiles = (int32_t)tiles; rp.num_ranges = (int32_t)num_ranges;
+        rp.count_entries = (fns16 && k == 0) ? 1 : 0;
         const unsigned rb = (unsigned)((num_ranges + 3) / 4);
-        if (S <= 4) { if (L <= 2) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 2>(rp); }); else simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 4>(rp); }); }
+        if (S > 8) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<16, 4>(rp); });
+        else if (S <= 4) { if (L <= 2) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 2>(rp); }); else simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 4>(rp); }); }
         else { if (L <= 2) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<8, 2>(rp); }); else simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<8, 4>(rp); }); }
         simt::launch(1, 1024, [&] { fsm_episode_finish_kernel(range_close.data(), range_open.data(), (int)num_ranges, num_docs, &final_pending, &episodes); });
       } else {
