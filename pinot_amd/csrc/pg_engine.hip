@@ -4406,6 +4406,7 @@ static pg_status replay_filter_stats(pg_segment* seg, const pg_query* q, pg_resu
 struct FsmScratch {
   size_t bitmap_bytes = 0, delta_bytes = 0, tables_bytes = 0, chunk_bytes = 0, total = 0;
   size_t episode_base = 0, chunk_state_bytes = 0, tile_state_bytes = 0, tile_pos_bytes = 0;
+  size_t front_bytes = 0;            // machines of 9 .. 16 states with episodes: fsm_tile_fns16_kernel's lane fronts, sixteen bytes a lane, behind the last opens
   long long tiles = 0, chunks = 0;
   FsmScratch(const pg_segment* seg, const fstats::Fsm& fsm) {
     tiles = std::max<long long>(1, ((long long)seg->num_docs + 2047) / 2048);
@@ -4421,6 +4422,7 @@ struct FsmScratch {
       tile_state_bytes = ((size_t)tiles + 255) & ~(size_t)255;
       tile_pos_bytes = ((size_t)tiles * 4 + 255) & ~(size_t)255;
       total = episode_base + 256 + delta_bytes * (size_t)fsm.num_episode_streams() + chunk_state_bytes + tile_state_bytes + 2 * tile_pos_bytes;
+      if (fsm.num_states > 8) { front_bytes = (size_t)tiles * 64 * 16; total += front_bytes; }
     }
   }
 };
@@ -4526,6 +4528,7 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
   }
   else if (fns16) {
     // nine to sixteen states with episodes: the tiles' functions only (four registers a function); the range kernel of the first stream counts the entries
+    fp.lane_front = reinterpret_cast<uint4*>(d_base + lay.episode_base + 256 + lay.delta_bytes * (size_t)fsm.num_episode_streams() + lay.chunk_state_bytes + lay.tile_state_bytes + 2 * lay.tile_pos_bytes);
     if (L <= 3) fsm_tile_fns16_kernel<3><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
     else fsm_tile_fns16_kernel<4><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
   }
@@ -4581,6 +4584,7 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
       rp.pending_states = pending_states;
       rp.num_inputs = L; rp.num_states = S; rp.num_docs = seg->num_docs; rp.num_tiles = (int32_t)tiles; rp.num_ranges = (int32_t)num_ranges;
       rp.count_entries = (fns16 && k == 0) ? 1 : 0;      // (the tile pass built functions only: the first stream's walk counts what the docs cost)
+      rp.lane_front = fns16 ? fp.lane_front : nullptr;
       const dim3 rgrid((unsigned)((num_ranges + 3) / 4));
       if (S > 8) fsm_episode_ranges_kernel<16, 4><<<rgrid, dim3(256), 0, stream>>>(rp);
       else if (S <= 4) { if (L <= 2) fsm_episode_ranges_kernel<4, 2><<<rgrid, dim3(256), 0, stream>>>(rp); else fsm_episode_ranges_kernel<4, 4><<<rgrid, dim3(256), 0, stream>>>(rp); }

@@ -20,6 +20,7 @@ struct FsmParams {
   const uint8_t* delta;                 // [S << L] next state | entries << 4
   uint32_t* tables;                     // [num_tiles * S]
   int32_t num_inputs, num_states, num_docs, num_tiles;
+  uint4* lane_front;                    // fsm_tile_fns16_kernel: [num_tiles * 64] the function of the lanes IN FRONT of every lane within its tile (sixteen bytes: state -> state)
 };
 
 // Round 4b: the walk's table entry is 32 bits --  low half: the BYTE offset of the next state's row in the table, high half: the entries
@@ -623,6 +624,7 @@ struct FsmEpisodeRangeParams {
   int32_t* final_pending;               // = 1 when the state behind the last doc has an episode open
   uint32_t pending_states;
   int32_t num_inputs, num_states, num_docs, num_tiles, num_ranges;
+  const uint4* lane_front;              // SMAX == 16: fsm_tile_fns16_kernel's lane fronts (the lane functions are not built a second time)
   int32_t count_entries;                // != 0: the per-doc entries of the walk are added too (machines of 9 .. 16 states: their tile kernel, fsm_tile_fns16_kernel, builds functions only)
 };
 
@@ -761,6 +763,13 @@ __global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisod
 #pragma unroll
     for (int i = 0; i < LMAX; ++i) w[i] = i < L ? p.leaf[i][tile * 64 + lane] : 0u;
     const bool whole = __builtin_amdgcn_ballot_w64(docs != 32) == 0ull;      // every lane has its 32 docs (all tiles but the segment's last)
+    FsmByteFn<SMAX> front;
+    if constexpr (SMAX == 16) {
+      // (sixteen states: the tile pass -- fsm_tile_fns16_kernel -- has built every lane's function and scanned them already; it left the
+      //  function of the lanes in front of every lane, sixteen bytes a lane: building and scanning them again was 0.6 of this kernel's 0.99 ms)
+      const uint4 fr = p.lane_front[tile * 64 + lane];
+      front.lo = fr.x; front.hi = fr.y; front.w2 = fr.z; front.w3 = fr.w;
+    } else {
     // ---- the lane's function: its docs from every entry state ----
     const FsmByteFn<SMAX> f = fsm_lane_fn<SMAX, LMAX, kDps, kWords>(w, docs, whole, step_fn, dm);
     // ---- the state this lane is entered in: the lanes in front composed (an inclusive scan, shifted by one lane), applied to the tile's ----
@@ -770,8 +779,9 @@ __global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisod
       const FsmByteFn<SMAX> before = fsm_fn_shfl_up<SMAX>(incl, (unsigned)off);
       if (lane >= off) incl = fsm_fn_then<SMAX>(before, incl);
     }
-    FsmByteFn<SMAX> front = fsm_fn_shfl_up<SMAX>(incl, 1u);
+    front = fsm_fn_shfl_up<SMAX>(incl, 1u);
     if (lane == 0) front = fsm_fn_identity<SMAX>();
+    }
     uint32_t cur = fsm_fn_at<SMAX>(front, (uint32_t)p.tile_state[tile]);
     // ---- the lane's docs again, one chain from that state: where episodes open and close (and what the docs cost: count_entries) ----
     uint32_t open_word = 0u, close_word = 0u, ents = 0u;
@@ -892,6 +902,10 @@ __global__ __launch_bounds__(256) void fsm_tile_fns16_kernel(const FsmParams p) 
       uint32_t* const out = p.tables + tile * S;
       for (int c = 0; c < S; ++c) out[c] = fsm_fn_at<SMAX>(incl, (uint32_t)c);
     }
+    // the function of the lanes in front of this one (lane 0: none), for the range kernel's walk from the real entry state
+    FsmByteFn<SMAX> front = fsm_fn_shfl_up<SMAX>(incl, 1u);
+    if (lane == 0) front = fsm_fn_identity<SMAX>();
+    p.lane_front[tile * 64 + lane] = make_uint4(front.lo, front.hi, front.w2, front.w3);
   }
 }
 

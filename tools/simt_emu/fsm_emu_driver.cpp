@@ -66,6 +66,7 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
   fp.delta = fsm.delta.data(); fp.tables = tables.data();
   fp.num_inputs = L; fp.num_states = S; fp.num_docs = num_docs; fp.num_tiles = (int32_t)tiles;
   const unsigned nb = (unsigned)std::max(1, blocks);
+  std::vector<uint4> lane_fronts(fns16 ? (size_t)tiles * 64 : 0, uint4{0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu});
   if (walk == 1) {
     if (L <= 2) simt::launch(nb, 256, [&] { fsm_tiles_perm_kernel<2>(fp); });
     else if (L <= 3) simt::launch(nb, 256, [&] { fsm_tiles_perm_kernel<3>(fp); });
@@ -74,6 +75,7 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
     if (L <= 3) simt::launch(nb, 256, [&] { fsm_tiles_perm8_kernel<3>(fp); });
     else simt::launch(nb, 256, [&] { fsm_tiles_perm8_kernel<4>(fp); });
   } else if (fns16) {
+    fp.lane_front = lane_fronts.data();
     if (L <= 3) simt::launch(nb, 256, [&] { fsm_tile_fns16_kernel<3>(fp); });
     else simt::launch(nb, 256, [&] { fsm_tile_fns16_kernel<4>(fp); });
   } else if (S <= 2) launch_table_walk<2>(nb, fp, L);
@@ -117,6 +119,7 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
         rp.pending_states = pending_states;
         rp.num_inputs = L; rp.num_states = S; rp.num_docs = num_docs; rp.num_tiles = (int32_t)tiles; rp.num_ranges = (int32_t)num_ranges;
         rp.count_entries = (fns16 && k == 0) ? 1 : 0;
+        rp.lane_front = fns16 ? lane_fronts.data() : nullptr;
         const unsigned rb = (unsigned)((num_ranges + 3) / 4);
         if (S > 8) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<16, 4>(rp); });
         else if (S <= 4) { if (L <= 2) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 2>(rp); }); else simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 4>(rp); }); }
