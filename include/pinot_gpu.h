@@ -286,8 +286,9 @@ typedef struct pg_result {
   int32_t dominant_kernel;         /* pg_kernel_id of the kernel dominant_kernel_ms refers to */
   int32_t filter_entries_exact;    /* stats.num_entries_scanned_in_filter is the reference's count (AndDocIdSet / SVScanDocIdIterator accounting);
                                     * 0: an upper bound (numDocs per scan leaf) -- filters whose iterators leap-frog in a shape the device does
-                                    * not count (it counts root ANDs of scan / index leaves, ORs of leaves and up to three NOTs over scan leaves, at any
-                                    * size, while the machine minimises to at most 16 states over 8 leaves: two NOTs beside a third child do), on segments above PINOT_GPU_EXACT_FILTER_STATS_DOCS
+                                    * not count (it counts root ANDs of scan / index leaves, ORs of leaves, NOTs over a leaf or over an OR of leaves -- up to three scan leaves
+                                    * under NOTs in all -- at any size, while the machine minimises to at most 16 states over 8 leaves: two NOTs beside a third child and
+                                    * `a AND NOT (b OR c)` do), on segments above PINOT_GPU_EXACT_FILTER_STATS_DOCS
                                     * docs, and enableNullHandling queries */
   int32_t group_key_kind;          /* which of the reference's RawKeyHolders the key space calls for (DictionaryBasedGroupKeyGenerator.java:150-184):
                                     * 0 the raw key is an int (Array / IntMapBasedHolder): group_ids hold it;
