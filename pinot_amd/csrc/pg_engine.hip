@@ -4406,7 +4406,7 @@ static pg_status replay_filter_stats(pg_segment* seg, const pg_query* q, pg_resu
 struct FsmScratch {
   size_t bitmap_bytes = 0, delta_bytes = 0, tables_bytes = 0, chunk_bytes = 0, total = 0;
   size_t episode_base = 0, chunk_state_bytes = 0, tile_state_bytes = 0, tile_pos_bytes = 0;
-  size_t front_bytes = 0;            // machines of 9 .. 16 states with episodes: fsm_tile_fns16_kernel's lane fronts, sixteen bytes a lane, behind the last opens
+  size_t front_bytes = 0;            // machines with episodes: fsm_tile_fns_kernel's lane fronts (4 / 8 / 16 bytes a lane for <= 4 / 8 / 16 states), behind the last opens
   long long tiles = 0, chunks = 0;
   FsmScratch(const pg_segment* seg, const fstats::Fsm& fsm) {
     tiles = std::max<long long>(1, ((long long)seg->num_docs + 2047) / 2048);
@@ -4422,7 +4422,8 @@ struct FsmScratch {
       tile_state_bytes = ((size_t)tiles + 255) & ~(size_t)255;
       tile_pos_bytes = ((size_t)tiles * 4 + 255) & ~(size_t)255;
       total = episode_base + 256 + delta_bytes * (size_t)fsm.num_episode_streams() + chunk_state_bytes + tile_state_bytes + 2 * tile_pos_bytes;
-      if (fsm.num_states > 8) { front_bytes = (size_t)tiles * 64 * 16; total += front_bytes; }
+      front_bytes = (size_t)tiles * 64 * (fsm.num_states <= 4 ? 4 : (fsm.num_states <= 8 ? 8 : 16));
+      total += front_bytes;
     }
   }
 };
@@ -4515,9 +4516,17 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
   //  costs more than 7 only when the tree names the same predicate in many leaves -- such machines walk tables)
   int max_inc = 0;
   for (uint8_t d : fsm.delta) max_inc = std::max(max_inc, (int)(d >> 4));
-  // (machines of 9 .. 16 states over three or four inputs whose episodes the range kernel takes: see fsm_tile_fns16_kernel)
-  const bool fns16 = perm_walk && S > 8 && S <= 16 && L >= 3 && L <= 4 && fsm.has_episodes();
-  if (S <= 4 && L <= 4 && max_inc <= 7 && perm_walk) {
+  // (machines with episodes over at most four inputs: the tile pass builds the tiles' functions only and leaves every lane's front; the range
+  //  kernel of the first episode stream counts the per-doc entries -- see fsm_tile_fns_kernel)
+  const bool fns16 = perm_walk && S <= 16 && L <= 4 && fsm.has_episodes();
+  if (fns16) {
+    fp.lane_front = reinterpret_cast<uint32_t*>(d_base + lay.episode_base + 256 + lay.delta_bytes * (size_t)fsm.num_episode_streams() + lay.chunk_state_bytes + lay.tile_state_bytes + 2 * lay.tile_pos_bytes);
+    if (S <= 4) { if (L <= 2) fsm_tile_fns_kernel<4, 2><<<dim3(blocks), dim3(256), 0, stream>>>(fp); else fsm_tile_fns_kernel<4, 4><<<dim3(blocks), dim3(256), 0, stream>>>(fp); }
+    else if (S <= 8) { if (L <= 2) fsm_tile_fns_kernel<8, 2><<<dim3(blocks), dim3(256), 0, stream>>>(fp); else fsm_tile_fns_kernel<8, 4><<<dim3(blocks), dim3(256), 0, stream>>>(fp); }
+    else if (L <= 3) fsm_tile_fns_kernel<16, 3><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
+    else fsm_tile_fns_kernel<16, 4><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
+  }
+  else if (S <= 4 && L <= 4 && max_inc <= 7 && perm_walk) {
     if (L <= 2) fsm_tiles_perm_kernel<2><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
     else if (L <= 3) fsm_tiles_perm_kernel<3><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
     else fsm_tiles_perm_kernel<4><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
@@ -4525,12 +4534,6 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
   else if (S <= 8 && L <= 4 && max_inc <= 7 && perm_walk) {
     if (L <= 3) fsm_tiles_perm8_kernel<3><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
     else fsm_tiles_perm8_kernel<4><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
-  }
-  else if (fns16) {
-    // nine to sixteen states with episodes: the tiles' functions only (four registers a function); the range kernel of the first stream counts the entries
-    fp.lane_front = reinterpret_cast<uint4*>(d_base + lay.episode_base + 256 + lay.delta_bytes * (size_t)fsm.num_episode_streams() + lay.chunk_state_bytes + lay.tile_state_bytes + 2 * lay.tile_pos_bytes);
-    if (L <= 3) fsm_tile_fns16_kernel<3><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
-    else fsm_tile_fns16_kernel<4><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
   }
   else if (S <= 2) PG_FSM_LAUNCH_L(2);
   else if (S <= 4) PG_FSM_LAUNCH_L(4);
@@ -4571,7 +4574,7 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
     const uint32_t pending_states = fsm.stream_pending(k);
     memcpy(h_marks_k, fsm.stream_marks(k).data(), (size_t)S << L);
     HIP_TRY(hipMemcpyAsync(d_marks, h_marks_k, (size_t)S << L, hipMemcpyHostToDevice, stream));
-    if (perm_walk && (S <= 8 || fns16) && L <= 4) {
+    if (fns16) {
       // machines of at most eight (round 6c: sixteen) states over at most four inputs: byte functions, a scan over the wavefront, a contiguous
       // range of tiles per wavefront -- one record per RANGE for the finish kernel (pg_fsm_kernels.h "Round 6")
       const long long num_ranges = std::min<long long>(tiles, (long long)blocks * 4);

@@ -20,7 +20,7 @@ struct FsmParams {
   const uint8_t* delta;                 // [S << L] next state | entries << 4
   uint32_t* tables;                     // [num_tiles * S]
   int32_t num_inputs, num_states, num_docs, num_tiles;
-  uint4* lane_front;                    // fsm_tile_fns16_kernel: [num_tiles * 64] the function of the lanes IN FRONT of every lane within its tile (sixteen bytes: state -> state)
+  uint32_t* lane_front;                 // fsm_tile_fns_kernel: [num_tiles * 64 * SMAX / 4] the function of the lanes IN FRONT of every lane within its tile (a byte per entry state)
 };
 
 // Round 4b: the walk's table entry is 32 bits --  low half: the BYTE offset of the next state's row in the table, high half: the entries
@@ -613,6 +613,9 @@ static __global__ __launch_bounds__(256) void fsm_episode_tiles_kernel(const Fsm
 //     one {first unpaired close, last open} per wavefront (<= 2^14 records for fsm_episode_finish_kernel, which took 0.39 ms over one
 //     record per tile on its one compute unit) and no per-tile record is written at all.
 // The tiles' entry states still come from the count's tables walked downwards (fsm_chunk_states_kernel, fsm_tile_states_kernel).
+// Round 6c: the first two points -- the lane functions and their scan -- moved into the tile pass of these machines (fsm_tile_fns_kernel,
+// below: functions only, sixteen states too), which leaves every lane's front in memory; what remains here is the one chain from the real
+// entry state, which now also counts the per-doc entries (count_entries).
 struct FsmEpisodeRangeParams {
   const uint32_t* leaf[4];              // as FsmParams (at most four inputs)
   const uint8_t* delta;                 // [S << L] next state | entries << 4
@@ -624,8 +627,8 @@ struct FsmEpisodeRangeParams {
   int32_t* final_pending;               // = 1 when the state behind the last doc has an episode open
   uint32_t pending_states;
   int32_t num_inputs, num_states, num_docs, num_tiles, num_ranges;
-  const uint4* lane_front;              // SMAX == 16: fsm_tile_fns16_kernel's lane fronts (the lane functions are not built a second time)
-  int32_t count_entries;                // != 0: the per-doc entries of the walk are added too (machines of 9 .. 16 states: their tile kernel, fsm_tile_fns16_kernel, builds functions only)
+  const uint32_t* lane_front;           // fsm_tile_fns_kernel's lane fronts: [num_tiles * 64 * SMAX / 4] (the lane functions are not built a second time here)
+  int32_t count_entries;                // != 0: the per-doc entries of the walk are added too (the tile pass -- fsm_tile_fns_kernel -- built functions only)
 };
 
 template <int SMAX>
@@ -672,6 +675,22 @@ __device__ __forceinline__ FsmByteFn<SMAX> fsm_fn_shfl_up(const FsmByteFn<SMAX>&
   out.w3 = SMAX > 8 ? (uint32_t)__shfl_up((int)f.w3, delta) : 0u;
   return out;
 }
+// A function in memory: SMAX / 4 words a lane, one vector access.
+template <int SMAX>
+__device__ __forceinline__ void fsm_fn_store(uint32_t* base, long long index, const FsmByteFn<SMAX>& f) {
+  if constexpr (SMAX <= 4) base[index] = f.lo;
+  else if constexpr (SMAX <= 8) reinterpret_cast<uint2*>(base)[index] = make_uint2(f.lo, f.hi);
+  else reinterpret_cast<uint4*>(base)[index] = make_uint4(f.lo, f.hi, f.w2, f.w3);
+}
+template <int SMAX>
+__device__ __forceinline__ FsmByteFn<SMAX> fsm_fn_load(const uint32_t* base, long long index) {
+  FsmByteFn<SMAX> f;
+  f.hi = 0u; f.w2 = 0u; f.w3 = 0u;
+  if constexpr (SMAX <= 4) f.lo = base[index];
+  else if constexpr (SMAX <= 8) { const uint2 v = reinterpret_cast<const uint2*>(base)[index]; f.lo = v.x; f.hi = v.y; }
+  else { const uint4 v = reinterpret_cast<const uint4*>(base)[index]; f.lo = v.x; f.hi = v.y; f.w2 = v.z; f.w3 = v.w; }
+  return f;
+}
 // The function of a lane's 32 docs: from the step table when the lane has all of them (whole), else doc by doc through `dm` (next state in
 // the low four bits).  step_fn: [idx * kWords + word]; idx: input i's bits of the step's kDps docs at [i * kDps, (i + 1) * kDps).
 template <int SMAX, int LMAX, int kDps, int kWords>
@@ -713,10 +732,8 @@ __global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisod
   static_assert((SMAX == 4 || SMAX == 8 || SMAX == 16) && LMAX >= 1 && LMAX <= 4, "byte functions of four, eight or sixteen states over at most four inputs");
   constexpr int kDps = LMAX == 1 ? 8 : (LMAX == 2 ? 4 : 2);           // docs per step
   constexpr int kIndexBits = kDps * LMAX;                              // input i's bits of the step's docs at [i * kDps, (i + 1) * kDps)
-  constexpr int kWords = SMAX / 4;
   __shared__ uint8_t dm[SMAX << LMAX];                                 // one doc: next state | mark << 4 (the last tile's partial lanes)
   __shared__ uint8_t de[SMAX << LMAX];                                 // one doc: its entries (count_entries)
-  __shared__ uint32_t step_fn[kWords << kIndexBits];                   // a step's function: the words of FsmByteFn, [idx * kWords + word]
   __shared__ uint32_t step_mark[SMAX << kIndexBits];                   // [(state << kIndexBits) | idx]: next state | opens << 4 | closes << 12 (bit j: the step's doc j) | the step's entries << 20
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int L = p.num_inputs, S = p.num_states;
@@ -728,7 +745,6 @@ __global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisod
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < (1 << kIndexBits); idx += blockDim.x) {
-    uint32_t fn[4] = {0u, 0u, 0u, 0u};
     for (int st = 0; st < SMAX; ++st) {
       uint32_t cur = (uint32_t)st, opens = 0u, closes = 0u, ents = 0u;
       for (int j = 0; j < kDps; ++j) {
@@ -741,10 +757,7 @@ __global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisod
         cur = t & 15u;
       }
       step_mark[(st << kIndexBits) | idx] = cur | (opens << 4) | (closes << 12) | (ents << 20);      // (eight docs x fifteen entries: seven bits)
-      fn[st >> 2] |= cur << (8 * (st & 3));
     }
-#pragma unroll
-    for (int k = 0; k < kWords; ++k) step_fn[idx * kWords + k] = fn[k];
   }
   __syncthreads();
 
@@ -763,25 +776,10 @@ __global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisod
 #pragma unroll
     for (int i = 0; i < LMAX; ++i) w[i] = i < L ? p.leaf[i][tile * 64 + lane] : 0u;
     const bool whole = __builtin_amdgcn_ballot_w64(docs != 32) == 0ull;      // every lane has its 32 docs (all tiles but the segment's last)
-    FsmByteFn<SMAX> front;
-    if constexpr (SMAX == 16) {
-      // (sixteen states: the tile pass -- fsm_tile_fns16_kernel -- has built every lane's function and scanned them already; it left the
-      //  function of the lanes in front of every lane, sixteen bytes a lane: building and scanning them again was 0.6 of this kernel's 0.99 ms)
-      const uint4 fr = p.lane_front[tile * 64 + lane];
-      front.lo = fr.x; front.hi = fr.y; front.w2 = fr.z; front.w3 = fr.w;
-    } else {
-    // ---- the lane's function: its docs from every entry state ----
-    const FsmByteFn<SMAX> f = fsm_lane_fn<SMAX, LMAX, kDps, kWords>(w, docs, whole, step_fn, dm);
-    // ---- the state this lane is entered in: the lanes in front composed (an inclusive scan, shifted by one lane), applied to the tile's ----
-    FsmByteFn<SMAX> incl = f;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const FsmByteFn<SMAX> before = fsm_fn_shfl_up<SMAX>(incl, (unsigned)off);
-      if (lane >= off) incl = fsm_fn_then<SMAX>(before, incl);
-    }
-    front = fsm_fn_shfl_up<SMAX>(incl, 1u);
-    if (lane == 0) front = fsm_fn_identity<SMAX>();
-    }
+    // ---- the state this lane is entered in: the tile pass (fsm_tile_fns_kernel) has built every lane's function and scanned them over the
+    //      wavefront; it left the function of the lanes IN FRONT of every lane (SMAX bytes a lane), applied here to the tile's entry state.
+    //      (Rounds 6a-6b built and scanned the lane functions a second time in this kernel: 0.6 of its 0.99 ms at sixteen states.) ----
+    const FsmByteFn<SMAX> front = fsm_fn_load<SMAX>(p.lane_front, tile * 64 + lane);
     uint32_t cur = fsm_fn_at<SMAX>(front, (uint32_t)p.tile_state[tile]);
     // ---- the lane's docs again, one chain from that state: where episodes open and close (and what the docs cost: count_entries) ----
     uint32_t open_word = 0u, close_word = 0u, ents = 0u;
@@ -856,10 +854,12 @@ __global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisod
 // (count_entries, the first stream's pass only).  What is left for the tile pass is the tiles' FUNCTIONS {entry state} -> {exit state}
 // alone: the lane functions as in the range kernel, the same inclusive scan, lane 63 holds the tile's.  Written in the tables' format
 // (next state | entries << 4, entries = 0) for fsm_chain_kernel / fsm_chunk_states_kernel / fsm_tile_states_kernel.
-template <int LMAX>
-__global__ __launch_bounds__(256) void fsm_tile_fns16_kernel(const FsmParams p) {
-  static_assert(LMAX >= 3 && LMAX <= 4, "a machine over two inputs has at most three states");
-  constexpr int SMAX = 16, kDps = 2, kIndexBits = kDps * LMAX, kWords = 4;
+// Round 6c, last: the same split for every machine with episodes (SMAX 4 / 8 too): the byte-function tile kernels with entries
+// (fsm_tiles_perm_kernel, fsm_tiles_perm8_kernel) keep the machines WITHOUT episodes, whose count is all there is.
+template <int SMAX, int LMAX>
+__global__ __launch_bounds__(256) void fsm_tile_fns_kernel(const FsmParams p) {
+  static_assert((SMAX == 4 || SMAX == 8 || SMAX == 16) && LMAX >= 2 && LMAX <= 4, "as fsm_episode_ranges_kernel");
+  constexpr int kDps = LMAX == 2 ? 4 : 2, kIndexBits = kDps * LMAX, kWords = SMAX / 4;
   __shared__ uint8_t dm[SMAX << LMAX];
   __shared__ uint32_t step_fn[kWords << kIndexBits];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(256) void fsm_tile_fns16_kernel(const FsmParams p) 
     // the function of the lanes in front of this one (lane 0: none), for the range kernel's walk from the real entry state
     FsmByteFn<SMAX> front = fsm_fn_shfl_up<SMAX>(incl, 1u);
     if (lane == 0) front = fsm_fn_identity<SMAX>();
-    p.lane_front[tile * 64 + lane] = make_uint4(front.lo, front.hi, front.w2, front.w3);
+    fsm_fn_store<SMAX>(p.lane_front, tile * 64 + lane, front);
   }
 }
 

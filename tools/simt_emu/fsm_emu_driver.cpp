@@ -47,8 +47,9 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
   if (walk == 1 && !(S <= 4 && L <= 4 && max_inc <= 7)) return -2;
   if (walk == 2 && !(S <= 8 && L <= 4 && max_inc <= 7)) return -2;
   // walk 3: machines of 9 .. 16 states with episodes -- fsm_tile_fns16_kernel (functions only) + fsm_episode_ranges_kernel<16, 4> counting the entries
-  const bool fns16 = walk == 3;
-  if (fns16 && !(S > 8 && S <= 16 && L >= 3 && L <= 4 && fsm.has_episodes())) return -2;
+  if (walk == 3 && !(S > 8 && S <= 16 && L <= 4 && fsm.has_episodes())) return -2;
+  // (pg_engine.hip: every machine with episodes over at most four inputs takes the function-only tile pass when the byte-function walks are on)
+  const bool fns16 = walk != 0 && S <= 16 && L <= 4 && fsm.has_episodes();
   const long long tiles = std::max<long long>(1, ((long long)num_docs + 2047) / 2048);
   const long long chunks = (tiles + kFsmChunk - 1) / kFsmChunk;
   const size_t words64 = ((size_t)num_docs + 63) / 64;
@@ -67,17 +68,19 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
   fp.num_inputs = L; fp.num_states = S; fp.num_docs = num_docs; fp.num_tiles = (int32_t)tiles;
   const unsigned nb = (unsigned)std::max(1, blocks);
   std::vector<uint4> lane_fronts(fns16 ? (size_t)tiles * 64 : 0, uint4{0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu});
-  if (walk == 1) {
+  if (fns16) {
+    fp.lane_front = reinterpret_cast<uint32_t*>(lane_fronts.data());
+    if (S <= 4) { if (L <= 2) simt::launch(nb, 256, [&] { fsm_tile_fns_kernel<4, 2>(fp); }); else simt::launch(nb, 256, [&] { fsm_tile_fns_kernel<4, 4>(fp); }); }
+    else if (S <= 8) { if (L <= 2) simt::launch(nb, 256, [&] { fsm_tile_fns_kernel<8, 2>(fp); }); else simt::launch(nb, 256, [&] { fsm_tile_fns_kernel<8, 4>(fp); }); }
+    else if (L <= 3) simt::launch(nb, 256, [&] { fsm_tile_fns_kernel<16, 3>(fp); });
+    else simt::launch(nb, 256, [&] { fsm_tile_fns_kernel<16, 4>(fp); });
+  } else if (walk == 1) {
     if (L <= 2) simt::launch(nb, 256, [&] { fsm_tiles_perm_kernel<2>(fp); });
     else if (L <= 3) simt::launch(nb, 256, [&] { fsm_tiles_perm_kernel<3>(fp); });
     else simt::launch(nb, 256, [&] { fsm_tiles_perm_kernel<4>(fp); });
   } else if (walk == 2) {
     if (L <= 3) simt::launch(nb, 256, [&] { fsm_tiles_perm8_kernel<3>(fp); });
     else simt::launch(nb, 256, [&] { fsm_tiles_perm8_kernel<4>(fp); });
-  } else if (fns16) {
-    fp.lane_front = lane_fronts.data();
-    if (L <= 3) simt::launch(nb, 256, [&] { fsm_tile_fns16_kernel<3>(fp); });
-    else simt::launch(nb, 256, [&] { fsm_tile_fns16_kernel<4>(fp); });
   } else if (S <= 2) launch_table_walk<2>(nb, fp, L);
   else if (S <= 4) launch_table_walk<4>(nb, fp, L);
   else if (S <= 8) launch_table_walk<8>(nb, fp, L);
@@ -105,7 +108,7 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
       ep.episode_entries = &episodes; ep.final_pending = &final_pending;
       ep.pending_states = pending_states;
       ep.num_inputs = L; ep.num_states = S; ep.num_docs = num_docs; ep.num_tiles = (int32_t)tiles;
-      if (walk != 0 && (S <= 8 || fns16) && L <= 4) {
+      if (fns16) {
         // the byte-function walks' episode kernel (pg_engine.hip: PINOT_GPU_FSM_PERM on, at most eight states over at most four inputs): a
         // wavefront per contiguous RANGE of tiles, one record per range for the finish kernel
         const long long num_ranges = std::min<long long>(tiles, (long long)nb * 4);
@@ -118,8 +121,8 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
         rp.episode_entries = &episodes; rp.final_pending = &final_pending;
         rp.pending_states = pending_states;
         rp.num_inputs = L; rp.num_states = S; rp.num_docs = num_docs; rp.num_tiles = (int32_t)tiles; rp.num_ranges = (int32_t)num_ranges;
-        rp.count_entries = (fns16 && k == 0) ? 1 : 0;
-        rp.lane_front = fns16 ? lane_fronts.data() : nullptr;
+        rp.count_entries = k == 0 ? 1 : 0;
+        rp.lane_front = reinterpret_cast<const uint32_t*>(lane_fronts.data());
         const unsigned rb = (unsigned)((num_ranges + 3) / 4);
         if (S > 8) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<16, 4>(rp); });
         else if (S <= 4) { if (L <= 2) simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 2>(rp); }); else simt::launch(rb, 256, [&] { fsm_episode_ranges_kernel<4, 4>(rp); }); }
