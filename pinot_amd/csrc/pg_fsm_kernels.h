@@ -821,7 +821,18 @@ __global__ __launch_bounds__(256) void fsm_episode_ranges_kernel(const FsmEpisod
     if (lane == 0) prev = -1;
     prev = prev > carry_open ? prev : carry_open;
     int32_t unpaired = -1;
-    for (uint32_t c = close_word; c != 0u; c &= c - 1u) {
+    // A close whose open lies among the lane's own 32 docs ends an episode of ONE batch: (close - origin) / 256 = 0, and away from the end of
+    // the docs a whole batch is scanned -- kFsmScanBatch entries each, a population count.  (The loop below took every close: a dense leaf
+    // under the NOT closes an episode every few docs, eight or more iterations a lane with a 64-bit cost each -- more than the walk itself.)
+    // What is left for the loop: the closes in front of the lane's first open (opens and closes alternate: at most one), and the lanes
+    // within a batch of the end of the docs.
+    uint32_t loop_closes = close_word;
+    if (first + 32 + kFsmScanBatch <= (long long)p.num_docs) {
+      const uint32_t in_front = open_word ? ((open_word & (0u - open_word)) - 1u) : 0xFFFFFFFFu;      // the bits below the lane's first open
+      sum += (unsigned long long)kFsmScanBatch * (unsigned)__builtin_popcount(close_word & ~in_front);
+      loop_closes = close_word & in_front;
+    }
+    for (uint32_t c = loop_closes; c != 0u; c &= c - 1u) {
       const int d = __builtin_ctz(c);
       const uint32_t below = open_word & ((1u << d) - 1u);
       const int32_t open_at = below ? (int32_t)(first + 31 - __builtin_clz(below)) : prev;
