@@ -4518,8 +4518,8 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
   for (uint8_t d : fsm.delta) max_inc = std::max(max_inc, (int)(d >> 4));
   // (machines with episodes over at most four inputs: the tile pass builds the tiles' functions only and leaves every lane's front; the range
   //  kernel of the first episode stream counts the per-doc entries -- see fsm_tile_fns_kernel)
-  const bool fns16 = perm_walk && S <= 16 && L <= 4 && fsm.has_episodes();
-  if (fns16) {
+  const bool fns_pass = perm_walk && S <= 16 && L <= 4 && fsm.has_episodes();
+  if (fns_pass) {
     fp.lane_front = reinterpret_cast<uint32_t*>(d_base + lay.episode_base + 256 + lay.delta_bytes * (size_t)fsm.num_episode_streams() + lay.chunk_state_bytes + lay.tile_state_bytes + 2 * lay.tile_pos_bytes);
     if (S <= 4) { if (L <= 2) fsm_tile_fns_kernel<4, 2><<<dim3(blocks), dim3(256), 0, stream>>>(fp); else fsm_tile_fns_kernel<4, 4><<<dim3(blocks), dim3(256), 0, stream>>>(fp); }
     else if (S <= 8) { if (L <= 2) fsm_tile_fns_kernel<8, 2><<<dim3(blocks), dim3(256), 0, stream>>>(fp); else fsm_tile_fns_kernel<8, 4><<<dim3(blocks), dim3(256), 0, stream>>>(fp); }
@@ -4574,9 +4574,10 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
     const uint32_t pending_states = fsm.stream_pending(k);
     memcpy(h_marks_k, fsm.stream_marks(k).data(), (size_t)S << L);
     HIP_TRY(hipMemcpyAsync(d_marks, h_marks_k, (size_t)S << L, hipMemcpyHostToDevice, stream));
-    if (fns16) {
-      // machines of at most eight (round 6c: sixteen) states over at most four inputs: byte functions, a scan over the wavefront, a contiguous
-      // range of tiles per wavefront -- one record per RANGE for the finish kernel (pg_fsm_kernels.h "Round 6")
+    if (fns_pass) {
+      // machines of at most sixteen states over at most four inputs: the tile pass (fsm_tile_fns_kernel) left every lane's front; one chain per
+      // lane from the real entry state, a contiguous range of tiles per wavefront -- one record per RANGE for the finish kernel
+      // (pg_fsm_kernels.h "Round 6", "Round 6c")
       const long long num_ranges = std::min<long long>(tiles, (long long)blocks * 4);
       FsmEpisodeRangeParams rp;
       memset(&rp, 0, sizeof(rp));
@@ -4586,8 +4587,8 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
       rp.episode_entries = d_episodes; rp.final_pending = d_final_pending;
       rp.pending_states = pending_states;
       rp.num_inputs = L; rp.num_states = S; rp.num_docs = seg->num_docs; rp.num_tiles = (int32_t)tiles; rp.num_ranges = (int32_t)num_ranges;
-      rp.count_entries = (fns16 && k == 0) ? 1 : 0;      // (the tile pass built functions only: the first stream's walk counts what the docs cost)
-      rp.lane_front = fns16 ? fp.lane_front : nullptr;
+      rp.count_entries = k == 0 ? 1 : 0;      // (the tile pass built functions only: the first stream's walk counts what the docs cost)
+      rp.lane_front = fp.lane_front;
       const dim3 rgrid((unsigned)((num_ranges + 3) / 4));
       if (S > 8) fsm_episode_ranges_kernel<16, 4><<<rgrid, dim3(256), 0, stream>>>(rp);
       else if (S <= 4) { if (L <= 2) fsm_episode_ranges_kernel<4, 2><<<rgrid, dim3(256), 0, stream>>>(rp); else fsm_episode_ranges_kernel<4, 4><<<rgrid, dim3(256), 0, stream>>>(rp); }

@@ -49,7 +49,7 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
   // walk 3: machines of 9 .. 16 states with episodes -- fsm_tile_fns16_kernel (functions only) + fsm_episode_ranges_kernel<16, 4> counting the entries
   if (walk == 3 && !(S > 8 && S <= 16 && L <= 4 && fsm.has_episodes())) return -2;
   // (pg_engine.hip: every machine with episodes over at most four inputs takes the function-only tile pass when the byte-function walks are on)
-  const bool fns16 = walk != 0 && S <= 16 && L <= 4 && fsm.has_episodes();
+  const bool fns_pass = walk != 0 && S <= 16 && L <= 4 && fsm.has_episodes();
   const long long tiles = std::max<long long>(1, ((long long)num_docs + 2047) / 2048);
   const long long chunks = (tiles + kFsmChunk - 1) / kFsmChunk;
   const size_t words64 = ((size_t)num_docs + 63) / 64;
@@ -67,8 +67,8 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
   fp.delta = fsm.delta.data(); fp.tables = tables.data();
   fp.num_inputs = L; fp.num_states = S; fp.num_docs = num_docs; fp.num_tiles = (int32_t)tiles;
   const unsigned nb = (unsigned)std::max(1, blocks);
-  std::vector<uint4> lane_fronts(fns16 ? (size_t)tiles * 64 : 0, uint4{0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu});
-  if (fns16) {
+  std::vector<uint4> lane_fronts(fns_pass ? (size_t)tiles * 64 : 0, uint4{0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu});
+  if (fns_pass) {
     fp.lane_front = reinterpret_cast<uint32_t*>(lane_fronts.data());
     if (S <= 4) { if (L <= 2) simt::launch(nb, 256, [&] { fsm_tile_fns_kernel<4, 2>(fp); }); else simt::launch(nb, 256, [&] { fsm_tile_fns_kernel<4, 4>(fp); }); }
     else if (S <= 8) { if (L <= 2) simt::launch(nb, 256, [&] { fsm_tile_fns_kernel<8, 2>(fp); }); else simt::launch(nb, 256, [&] { fsm_tile_fns_kernel<8, 4>(fp); }); }
@@ -108,7 +108,7 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
       ep.episode_entries = &episodes; ep.final_pending = &final_pending;
       ep.pending_states = pending_states;
       ep.num_inputs = L; ep.num_states = S; ep.num_docs = num_docs; ep.num_tiles = (int32_t)tiles;
-      if (fns16) {
+      if (fns_pass) {
         // the byte-function walks' episode kernel (pg_engine.hip: PINOT_GPU_FSM_PERM on, at most eight states over at most four inputs): a
         // wavefront per contiguous RANGE of tiles, one record per range for the finish kernel
         const long long num_ranges = std::min<long long>(tiles, (long long)nb * 4);
