@@ -4403,6 +4403,11 @@ static pg_status replay_filter_stats(pg_segment* seg, const pg_query* q, pg_resu
 // Layout of the pass's scratch (ExecCtx.d_fsm_scratch): L bitmaps of whole tiles | delta | tile tables | chunk tables | the count --
 // and, for a machine with a NOT child (Fsm::marks: the episodes of pg_fsm_kernels.h), from the next 256-byte boundary on:
 // episode count + final-pending flags | marks of every episode stream | chunk states | tile states | the tiles' unpaired closes | the tiles' last opens.
+// A second walk of the docs behind the tile pass: the episodes of NOT children (one pass per episode stream), and -- round 6c -- the COUNT of
+// machines of 9 .. 16 states over at most four inputs without episodes (one pass, no marks): their tile pass builds functions only
+// (fsm_tile_fns_kernel) instead of walking sixteen chains of table reads per doc (fsm_tiles_kernel<16, L>).
+static inline bool needs_second_walk(const fstats::Fsm& fsm) { return fsm.has_episodes() || (fsm.num_states > 8 && fsm.num_inputs <= 4); }
+static inline int second_walk_passes(const fstats::Fsm& fsm) { return fsm.has_episodes() ? fsm.num_episode_streams() : 1; }
 struct FsmScratch {
   size_t bitmap_bytes = 0, delta_bytes = 0, tables_bytes = 0, chunk_bytes = 0, total = 0;
   size_t episode_base = 0, chunk_state_bytes = 0, tile_state_bytes = 0, tile_pos_bytes = 0;
@@ -4416,12 +4421,12 @@ struct FsmScratch {
     tables_bytes = (size_t)tiles * (size_t)fsm.num_states * 4;
     chunk_bytes = ((size_t)chunks * (size_t)fsm.num_states * 4 + 255) & ~(size_t)255;
     total = bitmap_bytes * (size_t)fsm.num_inputs + delta_bytes + tables_bytes + chunk_bytes + 256;
-    if (fsm.has_episodes()) {
+    if (needs_second_walk(fsm)) {
       episode_base = (total + 255) & ~(size_t)255;
       chunk_state_bytes = ((size_t)chunks + 255) & ~(size_t)255;
       tile_state_bytes = ((size_t)tiles + 255) & ~(size_t)255;
       tile_pos_bytes = ((size_t)tiles * 4 + 255) & ~(size_t)255;
-      total = episode_base + 256 + delta_bytes * (size_t)fsm.num_episode_streams() + chunk_state_bytes + tile_state_bytes + 2 * tile_pos_bytes;
+      total = episode_base + 256 + delta_bytes * (size_t)second_walk_passes(fsm) + chunk_state_bytes + tile_state_bytes + 2 * tile_pos_bytes;
       front_bytes = (size_t)tiles * 64 * (fsm.num_states <= 4 ? 4 : (fsm.num_states <= 8 ? 8 : 16));
       total += front_bytes;
     }
@@ -4470,7 +4475,7 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
   auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   const auto t_begin = now();
   uint8_t* d_base = ctx->d_fsm_scratch;
-  if ((((size_t)fsm.num_states << fsm.num_inputs) * (size_t)(1 + fsm.num_episode_streams()) + 64) > kFsmStageBytes) return fail(PG_ERR_INTERNAL, "transducer tables exceed the pinned staging area");
+  if ((((size_t)fsm.num_states << fsm.num_inputs) * (size_t)(1 + second_walk_passes(fsm)) + 64) > kFsmStageBytes) return fail(PG_ERR_INTERNAL, "transducer tables exceed the pinned staging area");
   FsmParams fp;
   memset(&fp, 0, sizeof(fp));
   int scanned_again = 0;
@@ -4518,9 +4523,11 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
   for (uint8_t d : fsm.delta) max_inc = std::max(max_inc, (int)(d >> 4));
   // (machines with episodes over at most four inputs: the tile pass builds the tiles' functions only and leaves every lane's front; the range
   //  kernel of the first episode stream counts the per-doc entries -- see fsm_tile_fns_kernel)
-  const bool fns_pass = perm_walk && S <= 16 && L <= 4 && fsm.has_episodes();
+  // (count_pass: nine to sixteen states WITHOUT episodes -- the same two kernels, the range kernel as the counter: one pass with no marks)
+  const bool count_pass = perm_walk && !fsm.has_episodes() && S > 8 && S <= 16 && L <= 4;
+  const bool fns_pass = perm_walk && S <= 16 && L <= 4 && (fsm.has_episodes() || count_pass);
   if (fns_pass) {
-    fp.lane_front = reinterpret_cast<uint32_t*>(d_base + lay.episode_base + 256 + lay.delta_bytes * (size_t)fsm.num_episode_streams() + lay.chunk_state_bytes + lay.tile_state_bytes + 2 * lay.tile_pos_bytes);
+    fp.lane_front = reinterpret_cast<uint32_t*>(d_base + lay.episode_base + 256 + lay.delta_bytes * (size_t)second_walk_passes(fsm) + lay.chunk_state_bytes + lay.tile_state_bytes + 2 * lay.tile_pos_bytes);
     if (S <= 4) { if (L <= 2) fsm_tile_fns_kernel<4, 2><<<dim3(blocks), dim3(256), 0, stream>>>(fp); else fsm_tile_fns_kernel<4, 4><<<dim3(blocks), dim3(256), 0, stream>>>(fp); }
     else if (S <= 8) { if (L <= 2) fsm_tile_fns_kernel<8, 2><<<dim3(blocks), dim3(256), 0, stream>>>(fp); else fsm_tile_fns_kernel<8, 4><<<dim3(blocks), dim3(256), 0, stream>>>(fp); }
     else if (L <= 3) fsm_tile_fns_kernel<16, 3><<<dim3(blocks), dim3(256), 0, stream>>>(fp);
@@ -4549,12 +4556,13 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
   fsm_finish_kernel<<<dim3(1), dim3(1024), (size_t)chunks * (size_t)S * 4, stream>>>(d_chunks, (int)chunks, S, d_entries);
   HIP_TRY(hipGetLastError());
   unsigned long long entries = 0, episodes = 0;
-  if (fsm.has_episodes()) {
+  if (fsm.has_episodes() || count_pass) {
     // A NOT child over a scan leaf: what its leaf scans in 256-doc batches is charged per episode (pg_fsm_kernels.h "NOT children").  The
     // tables of the count, walked downwards, give every tile its entry state; a second walk of the docs pairs the opens and the closes.
+    // (count_pass: no episodes -- one such walk with all-zero marks, for the per-doc entries alone)
     uint8_t* eb = d_base + lay.episode_base;
     unsigned long long* d_episodes = reinterpret_cast<unsigned long long*>(eb);
-    const int streams = fsm.num_episode_streams();
+    const int streams = second_walk_passes(fsm);
     uint8_t* d_marks_base = eb + 256;
     uint8_t* d_chunk_state = d_marks_base + lay.delta_bytes * (size_t)streams;
     uint8_t* d_tile_state = d_chunk_state + lay.chunk_state_bytes;
@@ -4571,8 +4579,9 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
     uint8_t* const d_marks = d_marks_base + lay.delta_bytes * (size_t)k;
     uint8_t* const h_marks_k = h_marks + ((size_t)S << L) * (size_t)k;
     int32_t* const d_final_pending = reinterpret_cast<int32_t*>(eb + 8) + k;
-    const uint32_t pending_states = fsm.stream_pending(k);
-    memcpy(h_marks_k, fsm.stream_marks(k).data(), (size_t)S << L);
+    const uint32_t pending_states = count_pass ? 0u : fsm.stream_pending(k);
+    if (count_pass) memset(h_marks_k, 0, (size_t)S << L);
+    else memcpy(h_marks_k, fsm.stream_marks(k).data(), (size_t)S << L);
     HIP_TRY(hipMemcpyAsync(d_marks, h_marks_k, (size_t)S << L, hipMemcpyHostToDevice, stream));
     if (fns_pass) {
       // machines of at most sixteen states over at most four inputs: the tile pass (fsm_tile_fns_kernel) left every lane's front; one chain per
@@ -4617,7 +4626,7 @@ static pg_status device_fsm_filter_stats(pg_segment* seg, ExecCtx* ctx, const pg
   if (timed_pass) HIP_TRY(hipEventRecord(ctx->ev_pass[1], stream));
   HIP_TRY(hipStreamSynchronize(stream));
   memcpy(&entries, ctx->h_fsm_stage, 8);
-  if (fsm.has_episodes()) memcpy(&episodes, ctx->h_fsm_stage + 8, 8);
+  if (fsm.has_episodes() || count_pass) memcpy(&episodes, ctx->h_fsm_stage + 8, 8);
   entries += episodes;
   if (timed_pass) {
     float ms = 0.f;

@@ -47,9 +47,11 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
   if (walk == 1 && !(S <= 4 && L <= 4 && max_inc <= 7)) return -2;
   if (walk == 2 && !(S <= 8 && L <= 4 && max_inc <= 7)) return -2;
   // walk 3: machines of 9 .. 16 states with episodes -- fsm_tile_fns16_kernel (functions only) + fsm_episode_ranges_kernel<16, 4> counting the entries
-  if (walk == 3 && !(S > 8 && S <= 16 && L <= 4 && fsm.has_episodes())) return -2;
-  // (pg_engine.hip: every machine with episodes over at most four inputs takes the function-only tile pass when the byte-function walks are on)
-  const bool fns_pass = walk != 0 && S <= 16 && L <= 4 && fsm.has_episodes();
+  if (walk == 3 && !(S > 8 && S <= 16 && L <= 4)) return -2;
+  // (pg_engine.hip: every machine with episodes over at most four inputs takes the function-only tile pass when the byte-function walks are on;
+  //  so do machines of 9 .. 16 states without episodes -- count_pass: the range kernel as the counter, one pass with no marks)
+  const bool count_pass = walk == 3 && !fsm.has_episodes();
+  const bool fns_pass = walk != 0 && S <= 16 && L <= 4 && (fsm.has_episodes() || count_pass);
   const long long tiles = std::max<long long>(1, ((long long)num_docs + 2047) / 2048);
   const long long chunks = (tiles + kFsmChunk - 1) / kFsmChunk;
   const size_t words64 = ((size_t)num_docs + 63) / 64;
@@ -88,16 +90,17 @@ extern "C" __attribute__((visibility("default"))) int64_t emu_fsm_count(const pg
   simt::launch((unsigned)chunks, 1024, [&] { fsm_chain_kernel(tables.data(), tiles, S, chunk_tables.data()); });
   simt::launch(1, 1024, [&] { fsm_finish_kernel(chunk_tables.data(), (int)chunks, S, &entries); });
   unsigned long long episodes = 0;
-  if (fsm.has_episodes()) {
+  if (fsm.has_episodes() || count_pass) {
     std::vector<uint8_t> chunk_state((size_t)chunks, 0xEE), tile_state((size_t)tiles, 0xEE);
     std::vector<int32_t> first_close((size_t)tiles, 12345), last_open((size_t)tiles, 12345);
     simt::launch(1, 1024, [&] { fsm_chunk_states_kernel(chunk_tables.data(), (int)chunks, S, chunk_state.data()); });
     simt::launch((unsigned)chunks, 1024, [&] { fsm_tile_states_kernel(tables.data(), tiles, S, chunk_state.data(), tile_state.data()); });
     // one pass per NOT child over a scan leaf (pg_engine.hip device_fsm_filter_stats): its marks, its pending states, its final-pending flag
-    for (int k = 0; k < fsm.num_episode_streams(); ++k) {
+    const std::vector<uint8_t> no_marks((size_t)S << L, 0);
+    for (int k = 0; k < (count_pass ? 1 : fsm.num_episode_streams()); ++k) {
       int32_t final_pending = 0;
-      const uint8_t* const marks = fsm.stream_marks(k).data();
-      const uint32_t pending_states = fsm.stream_pending(k);
+      const uint8_t* const marks = count_pass ? no_marks.data() : fsm.stream_marks(k).data();
+      const uint32_t pending_states = count_pass ? 0u : fsm.stream_pending(k);
       std::fill(first_close.begin(), first_close.end(), 12345);
       std::fill(last_open.begin(), last_open.end(), 12345);
       FsmEpisodeParams ep;
