@@ -1602,12 +1602,17 @@ __device__ __forceinline__ uint32_t eval_leaf_private(const P& p, const N& L, lo
         // (the set's words are in LDS, zero-padded to the column's whole dictId range: pg_kernels.h "The dictId sets of a filter in LDS")
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          uint32_t d[16], w[16];
+          uint32_t d[16];
           if (h == 0) decode16_private_dispatch<0>(L.bits, words, d); else decode16_private_dispatch<1>(L.bits, words, d);
+          // (eight lookups in flight at a time, as scan_simple_set_kernel: sixteen kept eight more registers live across the reads)
 #pragma unroll
-          for (int j = 0; j < 16; ++j) w[j] = set_lds[d[j] >> 5];
+          for (int g = 0; g < 2; ++g) {
+            uint32_t w[8];
 #pragma unroll
-          for (int j = 0; j < 16; ++j) m |= __builtin_amdgcn_ubfe(w[j], d[j] & 31u, 1) << (16 * h + j);
+            for (int j = 0; j < 8; ++j) w[j] = set_lds[d[8 * g + j] >> 5];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m |= __builtin_amdgcn_ubfe(w[j], d[8 * g + j] & 31u, 1) << (16 * h + 8 * g + j);
+          }
         }
         break;
       }
